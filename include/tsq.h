@@ -1,0 +1,368 @@
+/*
+ * tsq.h — C-ABI of libtsq: the MI355X (gfx950) hot path for TinySQL's chunked operators.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++/torch types.
+ * A cgo shim inside TinySQL's package `executor` binds exactly these symbols
+ * (see INTEGRATION.md).  Every entry point cites the reference interface it replaces
+ * (paths relative to the TinySQL tree).
+ *
+ * Conventions
+ *   - every function returns a tsq_status (int32_t); 0 == TSQ_OK.  Nothing aborts/exits.
+ *   - tsq_last_error(handle) returns a human readable message for the last failure on
+ *     that handle (or the last creation failure when handle == NULL).
+ *   - handles are NOT thread-affine (executor/join.go:207, aggregate.go:512 call Next from
+ *     background goroutines): every entry point sets its own device and uses the handle's
+ *     own HIP stream; one caller at a time per handle, except tsq_*_cancel which may be
+ *     called from any thread at any time.
+ *   - host pointers passed in are only read/written for the duration of the call
+ *     (cgo pointer rule); nothing is retained.
+ *   - a column (tsq_col) mirrors util/chunk/column.go:28-34: fixed-width little-endian
+ *     data, null bitmap with bit==1 meaning NOT NULL, LSB first (column.go:89-92);
+ *     null_bitmap == NULL means "no NULLs".
+ */
+#ifndef TSQ_H
+#define TSQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSQ_ABI_VERSION 1
+
+/* ---------------------------------------------------------------- status codes */
+typedef int32_t tsq_status;
+enum {
+    TSQ_OK = 0,
+    TSQ_ERR_INVALID = 1,          /* bad argument / bad state (maps to a Go errors.New)          */
+    TSQ_ERR_UNSUPPORTED = 2,      /* plan not eligible: caller must fall back to the Go operator */
+    TSQ_ERR_OOM_DEVICE = 3,
+    TSQ_ERR_HIP = 4,
+    TSQ_ERR_OVERFLOW_BIGINT = 5,  /* types.ErrOverflow "BIGINT"           (types/overflow.go:33-40) */
+    TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED = 6, /* types.ErrOverflow "BIGINT UNSIGNED"                  */
+    TSQ_ERR_OVERFLOW_DOUBLE = 7,  /* types.ErrOverflow "DOUBLE" (builtin_arithmetic_vec.go:51)     */
+    TSQ_ERR_CANCELLED = 8,        /* tsq_*_cancel was called (executor.go:158 kill flag)           */
+    TSQ_ERR_NO_DEVICE = 9,        /* no HIP device visible: the product path never falls back     */
+    TSQ_ERR_DIV_BY_ZERO = 10      /* only in strict INSERT/DELETE mode (expression/errors.go:65-77)*/
+};
+
+/* ---------------------------------------------------------------- column ABI */
+/* element types (types/eval_type.go:21-28 has only Int/Real/String eval types) */
+enum {
+    TSQ_I64 = 0,   /* bigint and narrower ints, stored as 8 bytes (util/chunk/codec.go:171-181) */
+    TSQ_U64 = 1,   /* same 8 bytes, UNSIGNED flag set in FieldType.Flag                         */
+    TSQ_F32 = 2,   /* float, 4 bytes                                                            */
+    TSQ_F64 = 3,   /* double, 8 bytes                                                           */
+    TSQ_BYTES = 4  /* var-len (offsets[n+1] + data); not accelerated -> TSQ_ERR_UNSUPPORTED     */
+};
+
+/* tsq_col.flags */
+#define TSQ_COL_DEVICE 1u /* data/null_bitmap/offsets are device (HBM) pointers */
+
+/* mirrors util/chunk/column.go:28-34 */
+typedef struct tsq_col {
+    void*    data;         /* fixed: length*elem_size bytes, native little endian                */
+    uint8_t* null_bitmap;  /* (length+7)/8 bytes, bit=1 => NOT NULL; NULL => column has no NULL */
+    int64_t* offsets;      /* var-len only (length+1 entries, first 0); NULL for fixed           */
+    int64_t  length;       /* rows                                                               */
+    int32_t  elem_size;    /* 4, 8, or -1 for var-len                                            */
+    int32_t  type;         /* TSQ_I64 ...                                                        */
+    uint32_t flags;        /* TSQ_COL_DEVICE                                                     */
+    uint32_t reserved;
+} tsq_col;
+
+/* ---------------------------------------------------------------- misc / context */
+typedef struct tsq_ctx tsq_ctx;
+
+int32_t     tsq_abi_version(void);
+int32_t     tsq_device_count(void);                 /* 0 when no GPU is visible */
+const char* tsq_last_error(const void* handle);     /* handle may be ctx/join/agg/expr or NULL */
+
+/* One context per (process, device).  All operators created from it share its stream. */
+tsq_status tsq_ctx_create(int32_t device, tsq_ctx** out);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
+tsq_status tsq_ctx_set_stream(tsq_ctx* ctx, void* hip_stream);
+tsq_status tsq_ctx_sync(tsq_ctx* ctx);
+void       tsq_ctx_destroy(tsq_ctx* ctx);
+
+/* Device memory + copies for harnesses that keep tables resident in HBM (bench, multi-GPU). */
+tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out);
+tsq_status tsq_dev_free(tsq_ctx* ctx, void* p);
+tsq_status tsq_dev_memset(tsq_ctx* ctx, void* p, int32_t byte, int64_t bytes);
+tsq_status tsq_copy_h2d(tsq_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+
+/* Timing helper: HIP events recorded on the ctx stream (bench.py's roofline leg). */
+tsq_status tsq_timer_start(tsq_ctx* ctx);
+tsq_status tsq_timer_stop_ms(tsq_ctx* ctx, double* ms_out); /* synchronises the stop event */
+
+/* ---------------------------------------------------------------- synthetic tables
+ * Counter-based generator, identical on host (oracle) and device:
+ *   r(i,c) = splitmix64(seed ^ (table<<56) ^ (c<<48) ^ i)
+ * Replaces the reference's mockDataSource generators (executor/benchmark_test.go:50-177). */
+enum {
+    TSQ_GEN_SEQ = 0,        /* v = start + i                                   (benchmark_test.go:396-407) */
+    TSQ_GEN_AFFINE = 1,     /* v = (a*i + b) mod m : bijection on [0,m) when gcd(a,m)=1, m < 2^31        */
+    TSQ_GEN_RAND_MOD = 2,   /* v = r(i,c) mod m                                                           */
+    TSQ_GEN_RAND_F64 = 3,   /* v = (r(i,c)>>11) * 2^-53 in [0,1)  (rand.Float64, benchmark_test.go:118)   */
+    TSQ_GEN_HASH_OF_COL = 4 /* v = splitmix64(src[i] ^ b): payload that is a function of another column  */
+};
+typedef struct tsq_gen_spec {
+    int32_t  kind;
+    int32_t  table;      /* t */
+    int32_t  col;        /* c */
+    int32_t  null_pct;   /* 0..100: row is NULL iff r(i,7) % 100 < null_pct */
+    uint64_t seed;
+    int64_t  start;      /* SEQ start / global row offset i0 for all kinds (row index = i0 + i) */
+    uint64_t a, b, m;    /* AFFINE / RAND_MOD parameters */
+} tsq_gen_spec;
+/* dst/null_bitmap/src are device pointers; null_bitmap may be NULL when null_pct == 0. */
+tsq_status tsq_gen_column(tsq_ctx* ctx, const tsq_gen_spec* spec, int64_t nrows,
+                          void* dst, uint8_t* null_bitmap, const void* src);
+
+/* ---------------------------------------------------------------- vectorized expressions
+ * Replaces expression.VecExpr / VecEval{Int,Real} (expression/expression.go:43-55,329-341),
+ * VectorizedFilter (chunk_executor.go:196-245) and EvaluatorSuite.Run (evaluator.go:121-133):
+ * the Go side flattens an expression tree to postfix bytecode; ONE fused kernel evaluates the
+ * whole tree per row instead of one pass per node.  Each opcode is one reference signature. */
+enum {
+    /* leaves */
+    TSQ_OP_COL_INT = 1,     /* arg = column index            (expression/column.go:56-75)          */
+    TSQ_OP_COL_REAL = 2,    /* arg = column index; F32 widened (column.go:81-104)                  */
+    TSQ_OP_CONST_INT = 3,   /* arg = const index             (constant.go:76-88, vectorized.go:23) */
+    TSQ_OP_CONST_REAL = 4,
+    TSQ_OP_CONST_NULL_INT = 5,
+    TSQ_OP_CONST_NULL_REAL = 6,
+    /* arithmetic (builtin_arithmetic_vec.go) */
+    TSQ_OP_PLUS_REAL = 10,  /* :275 */
+    TSQ_OP_MINUS_REAL = 11, /* :62  */
+    TSQ_OP_MUL_REAL = 12,   /* :29  */
+    TSQ_OP_DIV_REAL = 13,   /* :348 */
+    TSQ_OP_PLUS_INT = 14,   /* :389 (+plusUU/US/SU/SS :428-495), flags = unsigned bits           */
+    TSQ_OP_MINUS_INT = 15,  /* :95  (+minusFUU..SS :142-271), flags = unsigned bits|FORCE_SIGNED  */
+    TSQ_OP_MUL_INT = 16,    /* :308 */
+    TSQ_OP_MUL_INT_UNSIGNED = 17, /* :501 */
+    /* compare (builtin_compare_vec.go:26-292, builtin_compare_vec_generated.go) */
+    TSQ_OP_LT_INT = 20, TSQ_OP_LE_INT = 21, TSQ_OP_GT_INT = 22, TSQ_OP_GE_INT = 23,
+    TSQ_OP_EQ_INT = 24, TSQ_OP_NE_INT = 25,
+    TSQ_OP_LT_REAL = 26, TSQ_OP_LE_REAL = 27, TSQ_OP_GT_REAL = 28, TSQ_OP_GE_REAL = 29,
+    TSQ_OP_EQ_REAL = 30, TSQ_OP_NE_REAL = 31,
+    /* logic / unary (builtin_op_vec.go) */
+    TSQ_OP_LOGIC_AND = 40,  /* :173 */
+    TSQ_OP_LOGIC_OR = 41,   /* :29  */
+    TSQ_OP_NOT_INT = 42,    /* :249 */
+    TSQ_OP_NOT_REAL = 43,   /* :141 */
+    TSQ_OP_NEG_INT = 44,    /* :221, flags bit0 = arg unsigned */
+    TSQ_OP_NEG_REAL = 45,   /* :74  */
+    TSQ_OP_ISNULL_INT = 46, /* :92  */
+    TSQ_OP_ISNULL_REAL = 47,/* :113 */
+    /* control (builtin_control_vec_generated.go) */
+    TSQ_OP_IFNULL_INT = 50, /* :23  */
+    TSQ_OP_IFNULL_REAL = 51,/* :52  */
+    TSQ_OP_IF_INT = 52,     /* :117 (cond is Int; value args Int)  */
+    TSQ_OP_IF_REAL = 53,    /* :163 */
+    /* IN (builtin_other_vec_generated.go); arg = number of list items n (stack: x, v1..vn) */
+    TSQ_OP_IN_INT = 60,     /* :24, flags bit0 = x unsigned; unsigned-ness of item j in in_unsigned_mask bit j */
+    TSQ_OP_IN_REAL = 61     /* :151 */
+};
+/* tsq_expr_op.flags */
+#define TSQ_F_LHS_UNSIGNED 1u
+#define TSQ_F_RHS_UNSIGNED 2u
+#define TSQ_F_FORCE_SIGNED 4u /* SQLMode NO_UNSIGNED_SUBTRACTION (builtin_arithmetic_vec.go:119) */
+
+typedef struct tsq_expr_op {
+    uint8_t  opcode;
+    uint8_t  flags;
+    uint16_t arg;      /* column index / const index / IN item count */
+    uint32_t aux;      /* IN_INT: bitmask of unsigned list items (bit j-1 for item j) */
+} tsq_expr_op;
+
+#define TSQ_EXPR_MAX_OPS 64
+#define TSQ_EXPR_MAX_STACK 12
+#define TSQ_EXPR_MAX_CONSTS 32
+
+/* One expression tree in postfix form.  result_type: TSQ_I64 (Int, also used for U64) or TSQ_F64. */
+typedef struct tsq_expr_prog {
+    int32_t     n_ops;
+    int32_t     n_consts;
+    int32_t     result_type;
+    int32_t     result_unsigned; /* UNSIGNED flag of the result FieldType (informational) */
+    tsq_expr_op ops[TSQ_EXPR_MAX_OPS];
+    int64_t     consts[TSQ_EXPR_MAX_CONSTS]; /* int64 or the bit pattern of a double */
+} tsq_expr_prog;
+
+typedef struct tsq_expr tsq_expr;
+
+/* Compile = validate + upload.  n_progs > 1 is a CNF list (expression.CNFExprs) for filters. */
+tsq_status tsq_expr_compile(tsq_ctx* ctx, const tsq_expr_prog* progs, int32_t n_progs, tsq_expr** out);
+/* Projection form (evaluator.go:121 / expression.go:329 VecEval): evaluates progs[0] over
+ * nrows logical rows; `sel` (optional, int32[nrows]) is chunk.Chunk.sel (chunk.go:319-331).
+ * out->data/out->null_bitmap must be sized for nrows; out->type F64 or I64.
+ * div_by_zero_warnings (optional) receives the number of x/0 rows (errors.go:65-77). */
+tsq_status tsq_expr_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows,
+                         const int32_t* sel, tsq_col* out, int64_t* div_by_zero_warnings);
+/* Filter form (chunk_executor.go:196 VectorizedFilter / expression.go:205 VecEvalBool):
+ * selected_out[i] (one byte per row, Go []bool) = row passes every conjunct, non-NULL.
+ * isnull_out (optional) mirrors VecEvalBool's `nulls` for Int-typed conjuncts. */
+tsq_status tsq_filter_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows,
+                           const int32_t* sel, uint8_t* selected_out, uint8_t* isnull_out,
+                           int64_t* div_by_zero_warnings);
+void       tsq_expr_destroy(tsq_expr* e);
+
+/* ---------------------------------------------------------------- hash join
+ * Replaces HashJoinExec (executor/join.go:31-60): fetchAndBuildHashTable (:148-158, STUB in the
+ * reference), hashRowContainer.PutChunk/GetMatchedRows (hash_table.go:110-169), join2Chunk
+ * (join.go:325-362) and the joiners (joiner.go:220-410). */
+enum { TSQ_JOIN_INNER = 0, TSQ_JOIN_LEFT_OUTER = 1, TSQ_JOIN_RIGHT_OUTER = 2 }; /* joiner.go:105-116 */
+
+#define TSQ_MAX_KEYS 4
+#define TSQ_MAX_COLS 16
+
+typedef struct tsq_join_cfg {
+    int32_t join_type;
+    /* which child is the build (inner/hashed) side: 1 = right child (probe = left).
+     * Output column order is ALWAYS left-child cols || right-child cols (joiner.go:145-150). */
+    int32_t build_is_right;
+    int32_t n_keys;
+    int32_t build_key_idx[TSQ_MAX_KEYS];
+    int32_t probe_key_idx[TSQ_MAX_KEYS];
+    int32_t n_build_cols;
+    int32_t n_probe_cols;
+    int32_t build_types[TSQ_MAX_COLS];  /* TSQ_I64.. per build-side column */
+    int32_t probe_types[TSQ_MAX_COLS];
+    int64_t est_build_rows;             /* innerSideEstCount (hash_table.go:84-96); 0 = unknown */
+    int32_t max_chunk_size;             /* tidb_max_chunk_size (tidb_vars.go:242), default 1024 */
+    int32_t concurrency;                /* tidb_hash_join_concurrency; unused on the GPU (kept for parity of cfg) */
+    int64_t probe_batch_rows;           /* rows staged per device batch; 0 = default (4Mi) */
+    /* OtherConditions evaluated on the joined row (lhs||rhs) (joiner.go:155-167); may be NULL */
+    const tsq_expr_prog* other_conds;
+    int32_t n_other_conds;
+    /* outerSideFilter over the probe-side schema (join.go:328); may be NULL */
+    const tsq_expr_prog* outer_filters;
+    int32_t n_outer_filters;
+} tsq_join_cfg;
+
+typedef struct tsq_join tsq_join;
+
+tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_join** out);
+/* Build side: one call per inner-child chunk (hashRowContainer.PutChunk, hash_table.go:146).
+ * Rows whose key has a NULL are kept for outer-join output but never inserted (:161-163). */
+tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t n_cols, int64_t nrows);
+tsq_status tsq_join_build_finish(tsq_join* j);
+/* Probe side: one call per outer-child chunk (join2Chunk, join.go:325). `selected` (optional,
+ * one byte per row) is an externally evaluated outer-side filter; rows with selected==0 or a
+ * NULL key go to onMissMatch (join.go:344-345). */
+tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t n_cols, int64_t nrows,
+                               const uint8_t* selected);
+tsq_status tsq_join_probe_finish(tsq_join* j);
+/* HashJoinExec.Next (join.go:125-146): fills up to cap_rows joined rows into out_cols
+ * (n_cols == n_probe_cols + n_build_cols, left||right order, host or device buffers).
+ * *nrows_out == 0 && *eos == 0  -> needs more probe input;  *eos == 1 -> end of stream. */
+tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows,
+                         int64_t* nrows_out, int32_t* eos);
+/* COUNT(*) fast path (config C1: SELECT count(*) FROM t1 JOIN t2 ON t1.k=t2.k): number of
+ * joined rows produced so far by probe_push'd input, without materialising them.
+ * Valid instead of (not mixed with) tsq_join_pull. */
+tsq_status tsq_join_set_count_only(tsq_join* j, int32_t on);
+tsq_status tsq_join_count(tsq_join* j, int64_t* rows_out);
+/* Order-independent checksum of the joined rows seen so far in count-only mode:
+ * sum and xor over joined rows of rowhash(all output columns) — parity at full size. */
+tsq_status tsq_join_checksum(tsq_join* j, uint64_t* sum_out, uint64_t* xor_out);
+tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on);
+tsq_status tsq_join_cancel(tsq_join* j);
+void       tsq_join_destroy(tsq_join* j);
+
+/* ---------------------------------------------------------------- hash aggregation
+ * Replaces HashAggExec (executor/aggregate.go:134-155): partial workers' updatePartialResult
+ * (:332-350), getGroupKey (:359-394), shuffleIntermData (:354, STUB), consumeIntermData (:424,
+ * STUB), getFinalResult (:429-457) and the executor/aggfuncs package. */
+enum {
+    TSQ_AGG_COUNT = 0,      /* aggfuncs/func_count.go    */
+    TSQ_AGG_SUM = 1,        /* aggfuncs/func_sum.go      */
+    TSQ_AGG_AVG = 2,        /* aggfuncs/func_avg.go      */
+    TSQ_AGG_MAX = 3,        /* aggfuncs/func_max_min.go  */
+    TSQ_AGG_MIN = 4,
+    TSQ_AGG_FIRSTROW = 5    /* aggfuncs/func_first_row.go */
+};
+/* expression/aggregation/aggregation.go:82-97 */
+enum { TSQ_MODE_COMPLETE = 0, TSQ_MODE_FINAL = 1, TSQ_MODE_PARTIAL1 = 2, TSQ_MODE_PARTIAL2 = 3 };
+
+#define TSQ_MAX_AGGS 16
+#define TSQ_MAX_GROUP_KEYS 4
+
+typedef struct tsq_agg_func {
+    int32_t func;       /* TSQ_AGG_*                                                          */
+    int32_t mode;       /* TSQ_MODE_*; COMPLETE/PARTIAL1 read raw args, FINAL/PARTIAL2 merge   */
+    int32_t arg_col;    /* input column; -1 = constant non-NULL arg (COUNT(*) == count(1),
+                           parser/parser.y:3258-3262)                                         */
+    int32_t arg_col2;   /* AVG in FINAL/PARTIAL2 mode: arg_col = count column, arg_col2 = sum
+                           column (func_avg.go:86-113, descriptor.go:70-81)                    */
+    int32_t arg_type;   /* TSQ_I64/U64/F32/F64 of the value argument                           */
+    int32_t reserved;
+} tsq_agg_func;
+
+typedef struct tsq_agg_cfg {
+    int32_t n_group_keys;
+    int32_t group_key_col[TSQ_MAX_GROUP_KEYS];  /* bare input columns (group-by expressions are
+                                                   pre-evaluated with tsq_expr_eval)           */
+    int32_t group_key_type[TSQ_MAX_GROUP_KEYS];
+    int32_t n_aggs;
+    tsq_agg_func aggs[TSQ_MAX_AGGS];
+    int32_t n_input_cols;
+    int32_t input_types[TSQ_MAX_COLS];
+    int64_t est_groups;       /* 0 = unknown (table grows by rehash) */
+    int32_t max_chunk_size;
+    int32_t reserved;
+} tsq_agg_cfg;
+
+typedef struct tsq_agg tsq_agg;
+
+tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg** out);
+/* One call per child chunk (HashAggPartialWorker.updatePartialResult, aggregate.go:332). */
+tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols, int64_t nrows);
+/* End of child input: finalise groups (consumeIntermData + getFinalResult, aggregate.go:424-457).
+ * Returns TSQ_ERR_OVERFLOW_BIGINT if an int64 SUM/AVG left the BIGINT range (func_sum.go:133). */
+tsq_status tsq_agg_finish(tsq_agg* a);
+tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out);
+/* HashAggExec.Next (aggregate.go:559-588): output schema = one column per agg func, in cfg
+ * order.  COMPLETE/FINAL emit final values; PARTIAL1/PARTIAL2 emit partial columns (AVG emits
+ * two: count then sum).  Group order is unspecified (Go map order in the reference). */
+tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows,
+                        int64_t* nrows_out, int32_t* eos);
+tsq_status tsq_agg_cancel(tsq_agg* a);
+void       tsq_agg_destroy(tsq_agg* a);
+
+/* ---------------------------------------------------------------- multi-GPU radix redistribute
+ * Splits rows by rank(key) = ((mix64(key) & 0xffff) * n_parts) >> 16 into n_parts contiguous
+ * runs (CPU analogue: aggregate.go:352-356 shuffle / join.go:219 dispatch).  The exchange
+ * itself (RCCL all-to-all over xGMI) is done by the caller on the returned device buffers.
+ * key_mode 0 ranks by join-key equality (util/codec/codec.go:212-240), 1 by group-key equality
+ * (codec.go:713-746: -0.0 and +0.0 share a group).  Rows with a NULL key are routed to part 0.
+ * cols/out_cols are device resident; out_cols need capacity nrows; counts_out: int64[n_parts]
+ * on the host; run p of every output column is rows [sum(counts[0..p)), +counts[p]). */
+tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int32_t key_col,
+                           int32_t key_mode, int64_t nrows, int32_t n_parts, tsq_col* out_cols,
+                           int64_t* counts_out);
+
+/* ---------------------------------------------------------------- statistics (roofline reporting) */
+typedef struct tsq_stats {
+    int64_t build_rows;
+    int64_t build_rows_inserted;   /* non-NULL keys */
+    int64_t probe_rows;
+    int64_t out_rows;
+    int64_t table_bytes;
+    int64_t table_buckets;
+    double  build_kernel_ms;       /* HIP-event time of the last build / probe kernels */
+    double  probe_kernel_ms;
+    int64_t h2d_bytes;
+    int64_t d2h_bytes;
+    int64_t kernel_launches;
+} tsq_stats;
+tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out);
+tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSQ_H */

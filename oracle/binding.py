@@ -1,0 +1,242 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Allowed importers: tests/, bench.py's `cpu_baseline` leg, __graft_entry__.smoke().  The product
+package (tinysql_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tinysql_amd import _abi as abi
+from tinysql_amd.chunk import Chunk, Column, make_cols, np_dtype
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.orc_result_rows.restype = C.c_int64
+    lib.orc_result_rows.argtypes = [P]
+    lib.orc_result_cols.restype = C.c_int32
+    lib.orc_result_cols.argtypes = [P]
+    lib.orc_result_col_type.restype = C.c_int32
+    lib.orc_result_col_type.argtypes = [P, C.c_int32]
+    lib.orc_result_copy_col.restype = None
+    lib.orc_result_copy_col.argtypes = [P, C.c_int32, P, P]
+    lib.orc_result_free.restype = None
+    lib.orc_result_free.argtypes = [P]
+    lib.orc_last_error.restype = C.c_char_p
+    lib.orc_hash_keys.restype = None
+    lib.orc_hash_keys.argtypes = [C.POINTER(abi.Col), C.POINTER(C.c_int32), C.c_int32, C.c_int64, P, P, P]
+    lib.orc_fnv1_64.restype = C.c_uint64
+    lib.orc_fnv1_64.argtypes = [P, C.c_int64]
+    lib.orc_group_key_encode.restype = C.c_int32
+    lib.orc_group_key_encode.argtypes = [C.POINTER(abi.Col), C.c_int64, P]
+    lib.orc_gen_column.restype = None
+    lib.orc_gen_column.argtypes = [C.POINTER(abi.GenSpec), C.c_int64, P, P, P]
+    lib.orc_hash_join.restype = P
+    lib.orc_hash_join.argtypes = [C.POINTER(abi.JoinCfg), C.POINTER(abi.Col), C.c_int64, C.POINTER(abi.Col), C.c_int64, P,
+                                  C.POINTER(C.c_int32)]
+    lib.orc_hash_join_timed.restype = C.c_int64
+    lib.orc_hash_join_timed.argtypes = [C.POINTER(abi.JoinCfg), C.POINTER(abi.Col), C.c_int64, C.POINTER(abi.Col), C.c_int64,
+                                        C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64)]
+    lib.orc_rows_checksum.restype = None
+    lib.orc_rows_checksum.argtypes = [C.POINTER(abi.Col), C.c_int32, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.orc_hash_agg.restype = P
+    lib.orc_hash_agg.argtypes = [C.POINTER(abi.AggCfg), C.POINTER(abi.Col), C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    lib.orc_hash_agg_timed.restype = P
+    lib.orc_hash_agg_timed.argtypes = [C.POINTER(abi.AggCfg), C.POINTER(abi.Col), C.c_int64, C.c_int32, C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int32)]
+    lib.orc_expr_eval.restype = C.c_int32
+    lib.orc_expr_eval.argtypes = [C.POINTER(abi.ExprProg), C.POINTER(abi.Col), C.c_int32, C.c_int64, P, P, P, C.POINTER(C.c_int64)]
+    lib.orc_filter_eval.restype = C.c_int32
+    lib.orc_filter_eval.argtypes = [C.POINTER(abi.ExprProg), C.c_int32, C.POINTER(abi.Col), C.c_int32, C.c_int64, P, P, P,
+                                    C.POINTER(C.c_int64)]
+    lib.orc_rowhashmap_put_get.restype = C.c_int64
+    lib.orc_rowhashmap_put_get.argtypes = [P, P, C.c_int64, C.c_uint64, P, C.c_int64]
+    _lib = lib
+    return lib
+
+
+class OracleError(RuntimeError):
+    def __init__(self, status):
+        super().__init__("oracle status %d (%s)" % (status, abi.STATUS_NAMES.get(status, "?")))
+        self.status = status
+
+
+def _result_to_chunk(lib, res):
+    n = lib.orc_result_rows(res)
+    cols = []
+    for c in range(lib.orc_result_cols(res)):
+        tp = lib.orc_result_col_type(res, c)
+        data = np.zeros(max(n, 1), dtype=np_dtype(tp))
+        nn = np.zeros(max(n, 1), dtype=np.uint8)
+        lib.orc_result_copy_col(res, c, data.ctypes.data_as(C.c_void_p), nn.ctypes.data_as(C.c_void_p))
+        cols.append(Column(tp, data[:n], nn[:n].astype(bool)))
+    lib.orc_result_free(res)
+    return Chunk(cols)
+
+
+def hash_join(cfg, build_chunk, probe_chunk, selected=None):
+    lib = load()
+    keep = []
+    b = make_cols(build_chunk.columns, keep)
+    p = make_cols(probe_chunk.columns, keep)
+    st = C.c_int32(0)
+    sel = None
+    if selected is not None:
+        sel_np = np.ascontiguousarray(selected, dtype=np.uint8)
+        keep.append(sel_np)
+        sel = sel_np.ctypes.data_as(C.c_void_p)
+    res = lib.orc_hash_join(C.byref(cfg), b, build_chunk.NumRows(), p, probe_chunk.NumRows(), sel, C.byref(st))
+    if not res:
+        raise OracleError(st.value)
+    return _result_to_chunk(lib, res)
+
+
+def hash_join_timed(cfg, build_chunk, probe_chunk, threads):
+    lib = load()
+    keep = []
+    b = make_cols(build_chunk.columns, keep)
+    p = make_cols(probe_chunk.columns, keep)
+    bms, pms = C.c_double(0), C.c_double(0)
+    s, x = C.c_uint64(0), C.c_uint64(0)
+    n = lib.orc_hash_join_timed(C.byref(cfg), b, build_chunk.NumRows(), p, probe_chunk.NumRows(), threads, C.byref(bms), C.byref(pms),
+                                C.byref(s), C.byref(x))
+    return n, bms.value, pms.value, s.value, x.value
+
+
+def hash_agg(cfg, chunk, partial_workers=4, final_workers=4):
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    st = C.c_int32(0)
+    res = lib.orc_hash_agg(C.byref(cfg), cols, chunk.NumRows(), partial_workers, final_workers, C.byref(st))
+    if not res:
+        raise OracleError(st.value)
+    return _result_to_chunk(lib, res)
+
+
+def hash_agg_timed(cfg, chunk, threads):
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    st = C.c_int32(0)
+    ms = C.c_double(0)
+    res = lib.orc_hash_agg_timed(C.byref(cfg), cols, chunk.NumRows(), threads, C.byref(ms), C.byref(st))
+    if not res:
+        raise OracleError(st.value)
+    return _result_to_chunk(lib, res), ms.value
+
+
+def expr_eval(prog, chunk):
+    """returns (Column, warnings) or raises OracleError."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    n = chunk.NumRows()
+    real = prog.result_type == abi.F64
+    data = np.zeros(max(n, 1), dtype=np.float64 if real else np.int64)
+    nn = np.zeros(max(n, 1), dtype=np.uint8)
+    w = C.c_int64(0)
+    sel = chunk.sel.ctypes.data_as(C.c_void_p) if chunk.sel is not None else None
+    st = lib.orc_expr_eval(C.byref(prog), cols, len(chunk.columns), n, sel, data.ctypes.data_as(C.c_void_p),
+                           nn.ctypes.data_as(C.c_void_p), C.byref(w))
+    if st != abi.OK:
+        raise OracleError(st)
+    tp = abi.F64 if real else (abi.U64 if prog.result_unsigned else abi.I64)
+    arr = data[:n] if tp != abi.U64 else data[:n].view(np.uint64)
+    return Column(tp, arr, nn[:n].astype(bool)), w.value
+
+
+def filter_eval(progs, n_progs, chunk):
+    """returns (selected bool[], nulls bool[], warnings) or raises OracleError."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    n = chunk.NumRows()
+    sel_out = np.zeros(max(n, 1), dtype=np.uint8)
+    nul_out = np.zeros(max(n, 1), dtype=np.uint8)
+    w = C.c_int64(0)
+    sel = chunk.sel.ctypes.data_as(C.c_void_p) if chunk.sel is not None else None
+    st = lib.orc_filter_eval(progs, n_progs, cols, len(chunk.columns), n, sel, sel_out.ctypes.data_as(C.c_void_p),
+                             nul_out.ctypes.data_as(C.c_void_p), C.byref(w))
+    if st != abi.OK:
+        raise OracleError(st)
+    return sel_out[:n].astype(bool), nul_out[:n].astype(bool), w.value
+
+
+def gen_column(spec, nrows, src=None, want_nulls=False):
+    lib = load()
+    dst = np.zeros(max(nrows, 1), dtype=np.uint64)
+    bm = np.zeros((nrows + 7) // 8 + 8, dtype=np.uint8) if (want_nulls or spec.null_pct > 0) else None
+    lib.orc_gen_column(C.byref(spec), nrows, dst.ctypes.data_as(C.c_void_p),
+                       bm.ctypes.data_as(C.c_void_p) if bm is not None else None,
+                       src.ctypes.data_as(C.c_void_p) if src is not None else None)
+    return dst[:nrows], bm
+
+
+def rows_checksum(chunk):
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    s, x = C.c_uint64(0), C.c_uint64(0)
+    lib.orc_rows_checksum(cols, len(chunk.columns), chunk.NumRows(), C.byref(s), C.byref(x))
+    return s.value, x.value
+
+
+def hash_keys(chunk, key_idx, selected=None):
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    n = chunk.NumRows()
+    idx = (C.c_int32 * len(key_idx))(*key_idx)
+    h = np.zeros(max(n, 1), dtype=np.uint64)
+    hn = np.zeros(max(n, 1), dtype=np.uint8)
+    sel = None
+    if selected is not None:
+        s = np.ascontiguousarray(selected, dtype=np.uint8)
+        keep.append(s)
+        sel = s.ctypes.data_as(C.c_void_p)
+    lib.orc_hash_keys(cols, idx, len(key_idx), n, sel, h.ctypes.data_as(C.c_void_p), hn.ctypes.data_as(C.c_void_p))
+    return h[:n], hn[:n].astype(bool)
+
+
+def fnv1_64(b):
+    lib = load()
+    arr = np.frombuffer(bytes(b), dtype=np.uint8) if len(b) else np.zeros(1, np.uint8)
+    return lib.orc_fnv1_64(arr.ctypes.data_as(C.c_void_p), len(b))
+
+
+def group_key_encode(column, row):
+    lib = load()
+    keep = []
+    c = column.as_col(keep)
+    buf = np.zeros(32, dtype=np.uint8)
+    n = lib.orc_group_key_encode(C.byref(c), row, buf.ctypes.data_as(C.c_void_p))
+    return bytes(buf[:n])
+
+
+def rowhashmap_put_get(keys, ptrs, probe):
+    lib = load()
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    p = np.ascontiguousarray(ptrs, dtype=np.uint64)
+    out = np.zeros(max(len(k), 1), dtype=np.uint64)
+    n = lib.orc_rowhashmap_put_get(k.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(k), probe,
+                                   out.ctypes.data_as(C.c_void_p), len(out))
+    return out[:n]

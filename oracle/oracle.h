@@ -1,0 +1,102 @@
+/*
+ * oracle.h — CPU restatement of the TinySQL reference algorithms for the hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (tinysql_amd/, libtsq) may include,
+ * link, call or execute anything in this directory.  Allowed users: tests/, bench.py's
+ * `cpu_baseline` leg, __graft_entry__.smoke().
+ *
+ * The reference cannot be built here (no Go toolchain; HashJoinExec/HashAggExec bodies are
+ * course stubs), so this is a line-traceable restatement; every function cites
+ * the reference file:line it follows.  It is pinned against the reference's own golden
+ * vectors in tests/test_oracle_golden.py.  Parity status: pinned for all
+ * integer/COUNT paths; SUM/AVG(double) pinned on the reference's tiny exact cases;
+ * FIRST_ROW on non-key columns unpinned (nondeterministic in the reference itself).
+ *
+ * POD types (tsq_col, tsq_join_cfg, tsq_agg_cfg, tsq_expr_prog, opcodes) are shared with
+ * include/tsq.h so both sides are driven by byte-identical inputs.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include "../include/tsq.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_result orc_result; /* a materialised set of output columns */
+
+int64_t orc_result_rows(const orc_result* r);
+int32_t orc_result_cols(const orc_result* r);
+/* copies column c: data (rows*8 bytes; F32 columns are returned as 4-byte) and a per-row
+ * NOT-NULL byte array (1 = not null).  Either pointer may be NULL. */
+void    orc_result_copy_col(const orc_result* r, int32_t c, void* data, uint8_t* notnull);
+int32_t orc_result_col_type(const orc_result* r, int32_t c);
+void    orc_result_free(orc_result* r);
+const char* orc_last_error(void);
+
+/* hash/fnv New64 (FNV-1) over [flag][bytes] per key column — util/codec/codec.go:249-338,
+ * executor/hash_table.go:47-72.  out_hash[nrows], out_has_null[nrows]. */
+void orc_hash_keys(const tsq_col* cols, const int32_t* key_idx, int32_t n_keys, int64_t nrows,
+                   const uint8_t* selected, uint64_t* out_hash, uint8_t* out_has_null);
+/* FNV-1 64 of a raw byte string (KATs). */
+uint64_t orc_fnv1_64(const uint8_t* p, int64_t n);
+
+/* util/codec/codec.go:713-746 HashGroupKey for one row: appends the encoded key of column
+ * `col` row `row` to buf, returns bytes written. */
+int32_t orc_group_key_encode(const tsq_col* col, int64_t row, uint8_t* buf);
+
+/* synthetic tables — same generator as tsq_gen_column */
+void orc_gen_column(const tsq_gen_spec* spec, int64_t nrows, void* dst, uint8_t* null_bitmap,
+                    const void* src);
+
+/* HashJoinExec restated: executor/join.go:125-146,290-362, hash_table.go:110-169,181-276,
+ * joiner.go:145-167,220-410; stubs filled per courses/proj5-part2-README-zh_CN.md.
+ * Output: left-child cols || right-child cols.  Returns NULL on error (orc_last_error). */
+orc_result* orc_hash_join(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build,
+                          const tsq_col* probe_cols, int64_t n_probe, const uint8_t* selected,
+                          tsq_status* status);
+
+/* Timed CPU baseline: same algorithm, single-threaded build + `threads` probe workers,
+ * row-at-a-time append into per-worker 1024-row result chunks which are then dropped.
+ * Returns the number of joined rows; fills build_ms/probe_ms. */
+int64_t orc_hash_join_timed(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build,
+                            const tsq_col* probe_cols, int64_t n_probe, int32_t threads,
+                            double* build_ms, double* probe_ms,
+                            uint64_t* sum_out, uint64_t* xor_out);
+
+/* order-independent checksum of a result set: per row h = rowhash(values, null flags);
+ * returns sum and xor over rows — the same function the GPU fuses into its probe. */
+void orc_rows_checksum(const tsq_col* cols, int32_t n_cols, int64_t nrows,
+                       uint64_t* sum_out, uint64_t* xor_out);
+
+/* HashAggExec restated: executor/aggregate.go:307-350,359-410,429-457,559-588 with the two
+ * stubs (shuffleIntermData :354, consumeIntermData :424) filled per
+ * courses/proj5-part3-README-zh_CN.md; aggfuncs/func_{count,sum,avg,max_min,first_row}.go.
+ * partial_workers/final_workers emulate M partial + N final workers deterministically
+ * (chunk c goes to partial worker c % M; group goes to final worker fnv(groupkey) % N). */
+orc_result* orc_hash_agg(const tsq_agg_cfg* cfg, const tsq_col* cols, int64_t nrows,
+                         int32_t partial_workers, int32_t final_workers, tsq_status* status);
+/* timed multi-threaded variant (threads partial workers + threads final workers) */
+orc_result* orc_hash_agg_timed(const tsq_agg_cfg* cfg, const tsq_col* cols, int64_t nrows,
+                               int32_t threads, double* ms, tsq_status* status);
+
+/* expression.VecEval (expression.go:329) over builtin_*_vec.go signatures, node at a time.
+ * sel: optional chunk.sel.  Output: out_data (8 bytes/row), out_notnull (1 byte/row). */
+tsq_status orc_expr_eval(const tsq_expr_prog* prog, const tsq_col* cols, int32_t n_cols,
+                         int64_t nrows, const int32_t* sel, void* out_data, uint8_t* out_notnull,
+                         int64_t* div_by_zero_warnings);
+/* expression.VecEvalBool / VectorizedFilter (expression.go:205-279, chunk_executor.go:196) */
+tsq_status orc_filter_eval(const tsq_expr_prog* progs, int32_t n_progs, const tsq_col* cols,
+                           int32_t n_cols, int64_t nrows, const int32_t* sel,
+                           uint8_t* selected_out, uint8_t* isnull_out,
+                           int64_t* div_by_zero_warnings);
+
+/* rowHashMap unit (executor/hash_table.go:181-276): put n (key,ptr) pairs then Get(key):
+ * writes matching ptrs in the order Get returns them; returns the count. */
+int64_t orc_rowhashmap_put_get(const uint64_t* keys, const uint64_t* ptrs, int64_t n,
+                               uint64_t probe_key, uint64_t* out_ptrs, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """the CPU oracle (test infrastructure; built on demand with g++)."""
+    from oracle import binding
+    binding.load()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """one libtsq context on cuda:0 — GPU tests only.  No fallback: fails loudly without a GPU."""
+    from tinysql_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()

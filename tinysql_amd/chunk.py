@@ -1,0 +1,165 @@
+"""numpy-backed mirror of util/chunk (the Go caller's side of the column ABI).
+
+`Column` mirrors util/chunk/column.go:28-34 (fixed-width data + null bitmap with bit==1 meaning
+NOT NULL, LSB first); `Chunk` mirrors util/chunk/chunk.go:31-46 (columns + optional sel).
+Only the harness uses this module: tests, bench and the Python `Executor` mirrors.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+
+_NP = {abi.I64: np.int64, abi.U64: np.uint64, abi.F32: np.float32, abi.F64: np.float64}
+
+
+def np_dtype(tp):
+    return _NP[tp]
+
+
+def elem_size(tp):
+    return 4 if tp == abi.F32 else 8
+
+
+def pack_bitmap(notnull):
+    """bool/uint8 array (1 = NOT NULL) -> column.go bitmap bytes (LSB first)."""
+    return np.packbits(np.asarray(notnull, dtype=np.uint8), bitorder="little")
+
+
+def unpack_bitmap(bitmap, n):
+    return np.unpackbits(np.asarray(bitmap, dtype=np.uint8), bitorder="little")[:n].astype(bool)
+
+
+class Column:
+    """One column of a chunk.  `notnull` is None when the column has no NULLs."""
+
+    def __init__(self, tp, data, notnull=None):
+        self.tp = tp
+        self.data = np.ascontiguousarray(data, dtype=_NP[tp])
+        if notnull is not None:
+            notnull = np.asarray(notnull, dtype=bool)
+            if notnull.all():
+                notnull = None
+        self.notnull = notnull
+        if self.notnull is not None:
+            # NULL slots hold zero bytes (column.go:150-158 AppendNull)
+            self.data = self.data.copy()
+            self.data[~self.notnull] = 0
+        self._bitmap = None
+
+    def __len__(self):
+        return len(self.data)
+
+    def IsNull(self, i):
+        return self.notnull is not None and not self.notnull[i]
+
+    def bitmap(self):
+        if self.notnull is None:
+            return None
+        if self._bitmap is None:
+            bm = pack_bitmap(self.notnull)
+            self._bitmap = np.concatenate([bm, np.zeros(8, np.uint8)])  # slack for word reads
+        return self._bitmap
+
+    def as_col(self, keep):
+        """tsq_col view (host pointers).  `keep` collects references that must outlive the call."""
+        c = abi.Col()
+        c.data = self.data.ctypes.data_as(C.c_void_p)
+        bm = self.bitmap()
+        c.null_bitmap = bm.ctypes.data_as(C.c_void_p) if bm is not None else None
+        c.offsets = None
+        c.length = len(self.data)
+        c.elem_size = elem_size(self.tp)
+        c.type = self.tp
+        c.flags = 0
+        keep.append(self.data)
+        keep.append(bm)
+        return c
+
+    def slice(self, lo, hi):
+        return Column(self.tp, self.data[lo:hi], None if self.notnull is None else self.notnull[lo:hi])
+
+    def values(self):
+        """python list with None for NULL (tests)."""
+        out = self.data.tolist()
+        if self.notnull is not None:
+            for i in np.nonzero(~self.notnull)[0]:
+                out[i] = None
+        return out
+
+
+def make_cols(columns, keep):
+    arr = (abi.Col * len(columns))()
+    for i, c in enumerate(columns):
+        arr[i] = c.as_col(keep)
+    return arr
+
+
+class Chunk:
+    """util/chunk.Chunk: columns + optional selection vector."""
+
+    def __init__(self, columns, sel=None):
+        self.columns = list(columns)
+        self.sel = None if sel is None else np.ascontiguousarray(sel, dtype=np.int32)
+
+    def NumCols(self):
+        return len(self.columns)
+
+    def NumRows(self):  # chunk.go:308-316
+        if self.sel is not None:
+            return len(self.sel)
+        return len(self.columns[0]) if self.columns else 0
+
+    def types(self):
+        return [c.tp for c in self.columns]
+
+    def slice(self, lo, hi):
+        assert self.sel is None
+        return Chunk([c.slice(lo, hi) for c in self.columns])
+
+    def rows(self):
+        """list of row tuples honouring sel (tests; Result.Check-style comparisons)."""
+        cols = [c.values() for c in self.columns]
+        idx = range(len(self.columns[0])) if self.sel is None else self.sel.tolist()
+        return [tuple(col[i] for col in cols) for i in idx]
+
+
+def out_buffers(types, cap, keep):
+    """allocates output columns for a pull of up to `cap` rows; returns (tsq_col array, [(data, bitmap)])."""
+    arr = (abi.Col * len(types))()
+    bufs = []
+    for i, tp in enumerate(types):
+        data = np.zeros(cap, dtype=_NP[tp])
+        bm = np.zeros((cap + 7) // 8 + 8, dtype=np.uint8)
+        arr[i].data = data.ctypes.data_as(C.c_void_p)
+        arr[i].null_bitmap = bm.ctypes.data_as(C.c_void_p)
+        arr[i].length = cap
+        arr[i].elem_size = elem_size(tp)
+        arr[i].type = tp
+        arr[i].flags = 0
+        bufs.append((data, bm))
+    keep.append(bufs)
+    return arr, bufs
+
+
+def chunk_from_buffers(types, bufs, n):
+    cols = []
+    for tp, (data, bm) in zip(types, bufs):
+        cols.append(Column(tp, data[:n].copy(), unpack_bitmap(bm, n)))
+    return Chunk(cols)
+
+
+def concat(chunks, types):
+    if not chunks:
+        return Chunk([Column(tp, np.zeros(0, _NP[tp])) for tp in types])
+    cols = []
+    for i, tp in enumerate(types):
+        data = np.concatenate([c.columns[i].data for c in chunks])
+        if any(c.columns[i].notnull is not None for c in chunks):
+            nn = np.concatenate([
+                c.columns[i].notnull if c.columns[i].notnull is not None else np.ones(len(c.columns[i]), bool)
+                for c in chunks])
+        else:
+            nn = None
+        cols.append(Column(tp, data, nn))
+    return Chunk(cols)

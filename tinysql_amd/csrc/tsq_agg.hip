@@ -1,0 +1,857 @@
+// tsq_agg.hip — hash aggregation for gfx950 (MI355X).  Replaces executor/aggregate.go's partial
+// workers / shuffle / final workers and executor/aggfuncs/* (citations at each piece).
+//
+// Data layout in HBM: one open-addressed group table, structure of arrays, capacity `cap` slots
+// (+2 special slots: cap = the group whose key word equals the EMPTY sentinel, cap+1 = the NULL
+// group; NULL is a regular group in GROUP BY, util/codec/codec.go:718-719):
+//     tag[cap+2]            uint64   single key: the key word itself (exact);
+//                                    multi key : 64-bit mix of all (null,word) cells
+//     gkey[k][cap+2]        uint64   key words of the group (output of firstrow(key) / verification)
+//     gknull[cap+2]         uint8    bitmask of NULL key cells (multi key only)
+//     per aggregate i: acc[i], aux[i], cnt[i] (uint64) and seen[i] (uint8)
+// Group key words follow HashGroupKey (codec.go:713-746): ints by value (UNSIGNED ignored), reals by
+// their memcomparable image (float.go:22-30) so that -0.0 and +0.0 share a group.
+//
+// Update = one pass per pushed batch: find-or-claim the slot with a 64-bit CAS, then one or two
+// device-scope atomics per aggregate.  int64 SUM/AVG accumulate in 128 bits (lo += v with carry into
+// hi); overflow is reported iff the exact group sum leaves the BIGINT range (func_sum.go:133-137
+// reports it as soon as a running sum overflows, which depends on worker interleaving there).
+#include "tsq_stage.h"
+
+#include <memory>
+
+#define TSQ_EMPTY_TAG 0x8080808080808080ULL
+
+struct AggState {  // device pointers of one aggregate's state arrays
+    unsigned long long* acc;
+    unsigned long long* aux;
+    unsigned long long* cnt;
+    uint8_t* seen;
+};
+struct AggPlan {
+    int32_t n_keys;
+    int32_t key_col[TSQ_MAX_GROUP_KEYS];
+    int32_t n_aggs;
+    tsq_agg_func f[TSQ_MAX_AGGS];
+};
+struct AggTable {
+    unsigned long long* tag;
+    unsigned long long* gkey[TSQ_MAX_GROUP_KEYS];
+    uint8_t* gknull;
+    AggState st[TSQ_MAX_AGGS];
+    uint64_t cap;
+};
+struct AggArgs {
+    tsq_colset in;
+    AggPlan plan;
+    AggTable t;
+    int64_t nrows;
+    int64_t row_base;               // global row number of row 0 (diagnostics only)
+    const uint32_t* retry_in;       // optional: process only these rows
+    uint32_t* retry_out;            // rows that found no slot within the probe limit
+    unsigned long long* counters;   // [0]=new groups [1]=retry count [2]=hash collisions
+    int32_t phase;                  // multi key: 0 = claim slots, 1 = verify + update
+};
+
+// group key word of one cell (codec.go:713-746 semantics, see header)
+__device__ __forceinline__ uint64_t group_key_word(const tsq_colset& cs, int c, int64_t row) {
+    if (cs.type[c] == TSQ_F32 || cs.type[c] == TSQ_F64) {
+        double f = cs.type[c] == TSQ_F32 ? (double)((const float*)cs.data[c])[row] : ((const double*)cs.data[c])[row];
+        uint64_t u = tsq_f64_bits(f);
+        return f >= 0 ? (u | 0x8000000000000000ULL) : ~u;  // float.go:22-30 (−0.0 >= 0 is true)
+    }
+    return ((const uint64_t*)cs.data[c])[row];
+}
+// inverse of the float image, for firstrow(key)/output
+__device__ __forceinline__ uint64_t group_key_word_decode(uint64_t w, int32_t type) {
+    if (type == TSQ_F32 || type == TSQ_F64) {
+        uint64_t u = (w & 0x8000000000000000ULL) ? (w & ~0x8000000000000000ULL) : ~w;  // float.go:32-40
+        if (type == TSQ_F32) {
+            float f = (float)tsq_bits_f64(u);
+            uint32_t b;
+            memcpy(&b, &f, 4);
+            return b;
+        }
+        return u;
+    }
+    return w;
+}
+
+// order preserving images for atomicMax/atomicMin on uint64
+__device__ __forceinline__ uint64_t ord_image(const tsq_colset& cs, int c, int32_t type, int64_t row) {
+    switch (type) {
+        case TSQ_I64: return ((const uint64_t*)cs.data[c])[row] ^ 0x8000000000000000ULL;
+        case TSQ_U64: return ((const uint64_t*)cs.data[c])[row];
+        default: {
+            double f = cs.type[c] == TSQ_F32 ? (double)((const float*)cs.data[c])[row] : ((const double*)cs.data[c])[row];
+            uint64_t u = tsq_f64_bits(f);
+            return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+        }
+    }
+}
+__device__ __forceinline__ uint64_t ord_image_decode(uint64_t w, int32_t type) {
+    switch (type) {
+        case TSQ_I64: return w ^ 0x8000000000000000ULL;
+        case TSQ_U64: return w;
+        default: {
+            uint64_t u = (w >> 63) ? (w & ~0x8000000000000000ULL) : ~w;
+            if (type == TSQ_F32) {
+                float f = (float)tsq_bits_f64(u);
+                uint32_t b;
+                memcpy(&b, &f, 4);
+                return b;
+            }
+            return u;
+        }
+    }
+}
+
+__device__ __forceinline__ bool is_real_type(int32_t t) { return t == TSQ_F32 || t == TSQ_F64; }
+
+// 128-bit accumulate of a signed 64-bit addend: lo += v (returns carry), hi += sign(v) + carry
+__device__ __forceinline__ void add128(unsigned long long* lo, unsigned long long* hi, int64_t v) {
+    const unsigned long long uv = (unsigned long long)v;
+    const unsigned long long old = atomicAdd(lo, uv);
+    const long long carry = (old + uv < old) ? 1 : 0;
+    const long long d = carry + (v < 0 ? -1 : 0);
+    if (d) atomicAdd(hi, (unsigned long long)d);
+}
+
+// applies every aggregate of `plan` for input row `row` to slot `s`.
+// `winner` = this thread created the group (writes FIRST_ROW values, func_first_row.go:67-81:
+// any row of the group is a legitimate "first" row under parallel workers).
+__device__ __forceinline__ void agg_update_slot(const AggArgs& a, uint64_t s, int64_t row, bool winner) {
+    for (int i = 0; i < a.plan.n_aggs; i++) {
+        const tsq_agg_func f = a.plan.f[i];
+        const AggState st = a.t.st[i];
+        const bool merge = f.mode == TSQ_MODE_FINAL || f.mode == TSQ_MODE_PARTIAL2;
+        const bool arg_null = f.arg_col >= 0 ? tsq_is_null(a.in.nulls[f.arg_col], row) : false;
+        switch (f.func) {
+            case TSQ_AGG_COUNT:  // func_count.go:33-119
+                if (arg_null) break;
+                atomicAdd(&st.acc[s], merge ? ((const unsigned long long*)a.in.data[f.arg_col])[row] : 1ull);
+                break;
+            case TSQ_AGG_SUM:  // func_sum.go:60-154
+                if (arg_null) break;
+                if (is_real_type(f.arg_type)) {
+                    double v = a.in.type[f.arg_col] == TSQ_F32 ? (double)((const float*)a.in.data[f.arg_col])[row]
+                                                                : ((const double*)a.in.data[f.arg_col])[row];
+                    atomicAdd((double*)&st.acc[s], v);
+                } else {
+                    add128(&st.acc[s], &st.aux[s], ((const int64_t*)a.in.data[f.arg_col])[row]);
+                }
+                st.seen[s] = 1;
+                break;
+            case TSQ_AGG_AVG: {  // func_avg.go:62-128,164-216
+                int vc = merge ? f.arg_col2 : f.arg_col;
+                if (arg_null) break;
+                if (merge && tsq_is_null(a.in.nulls[vc], row)) break;
+                if (is_real_type(f.arg_type)) {
+                    double v = a.in.type[vc] == TSQ_F32 ? (double)((const float*)a.in.data[vc])[row] : ((const double*)a.in.data[vc])[row];
+                    atomicAdd((double*)&st.acc[s], v);
+                } else {
+                    add128(&st.acc[s], &st.aux[s], ((const int64_t*)a.in.data[vc])[row]);
+                }
+                atomicAdd(&st.cnt[s], merge ? ((const unsigned long long*)a.in.data[f.arg_col])[row] : 1ull);
+                break;
+            }
+            case TSQ_AGG_MAX:  // func_max_min.go:81-117 (+uint/float variants)
+                if (arg_null) break;
+                atomicMax(&st.acc[s], (unsigned long long)ord_image(a.in, f.arg_col, f.arg_type, row));
+                st.seen[s] = 1;
+                break;
+            case TSQ_AGG_MIN:
+                if (arg_null) break;
+                atomicMin(&st.acc[s], (unsigned long long)ord_image(a.in, f.arg_col, f.arg_type, row));
+                st.seen[s] = 1;
+                break;
+            case TSQ_AGG_FIRSTROW:
+                if (!winner) break;
+                st.acc[s] = arg_null ? 0ull : tsq_cell_raw(a.in, f.arg_col, row);
+                st.seen[s] = arg_null ? 0 : 1;
+                break;
+        }
+    }
+}
+
+#define TSQ_AGG_PROBE_LIMIT 4096
+
+// K7 — group-table upsert.  Replaces HashAggPartialWorker.updatePartialResult
+// (executor/aggregate.go:332-350): getGroupKey (:359-394) + getPartialResult (:396-410) + the per
+// row UpdatePartialResult calls.  SINGLE key: one fused pass.  MULTI key: phase 0 claims slots by
+// 64-bit tag and the claimer stores the key cells; phase 1 (a later launch, so the cells are
+// visible) verifies the cells and applies the aggregates — a tag collision between different keys
+// is counted and surfaces as an error instead of merging two groups.
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t new_groups = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
+        const int64_t row = a.retry_in ? (int64_t)a.retry_in[r] : r;
+        uint64_t tag, slot;
+        uint64_t kw[TSQ_MAX_GROUP_KEYS];
+        uint32_t nullmask = 0;
+        bool special = false;
+        if (a.plan.n_keys == 0) {  // no GROUP BY: one global group, kept in the NULL-group slot
+            slot = a.t.cap + 1;
+            special = true;
+            tag = 0;
+        } else if (!MULTI) {
+            const int c = a.plan.key_col[0];
+            if (tsq_is_null(a.in.nulls[c], row)) { slot = a.t.cap + 1; special = true; tag = 0; kw[0] = 0; nullmask = 1; }
+            else {
+                kw[0] = group_key_word(a.in, c, row);
+                tag = kw[0];
+                if (tag == TSQ_EMPTY_TAG) { slot = a.t.cap; special = true; }
+            }
+        } else {
+            uint64_t h = 0x6A09E667F3BCC908ULL;
+            for (int k = 0; k < a.plan.n_keys; k++) {
+                const int c = a.plan.key_col[k];
+                const bool isn = tsq_is_null(a.in.nulls[c], row);
+                kw[k] = isn ? 0 : group_key_word(a.in, c, row);
+                nullmask |= isn ? (1u << k) : 0u;
+                h = tsq_splitmix64(h ^ kw[k]) + (isn ? 0x9E3779B97F4A7C15ULL : 0);
+            }
+            tag = h == TSQ_EMPTY_TAG ? h ^ 1 : h;
+        }
+        bool winner = false;
+        if (special) {
+            // the two special slots are claimed through their tag word as well (EMPTY -> 1)
+            if (__hip_atomic_load(&a.t.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == TSQ_EMPTY_TAG)
+                winner = atomicCAS(&a.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, 1ull) == TSQ_EMPTY_TAG;
+        } else {
+            slot = tsq_mulhi64(tsq_mix64(tag), a.t.cap);
+            bool found = false;
+            for (int probe = 0; probe < TSQ_AGG_PROBE_LIMIT; probe++) {
+                unsigned long long cur = __hip_atomic_load(&a.t.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == TSQ_EMPTY_TAG) {
+                    if (MULTI && a.phase == 1) break;  // cannot happen after a complete phase 0
+                    cur = atomicCAS(&a.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, (unsigned long long)tag);
+                    if (cur == TSQ_EMPTY_TAG) { winner = true; found = true; break; }
+                }
+                if (cur == tag) { found = true; break; }
+                slot = slot + 1 == a.t.cap ? 0 : slot + 1;
+            }
+            if (!found) {  // table (nearly) full: hand the row back, the host grows the table
+                if (!MULTI || a.phase == 0) {  // (phase 1 fails for exactly the rows phase 0 handed back)
+                    uint32_t i = (uint32_t)atomicAdd(&a.counters[1], 1ull);
+                    a.retry_out[i] = (uint32_t)row;
+                }
+                continue;
+            }
+        }
+        if (winner) {
+            new_groups++;
+            for (int k = 0; k < a.plan.n_keys; k++) a.t.gkey[k][slot] = kw[k];
+            if (a.t.gknull) a.t.gknull[slot] = (uint8_t)nullmask;
+        }
+        if (!MULTI) {
+            agg_update_slot(a, slot, row, winner);
+        } else if (a.phase == 0) {
+            if (winner) {  // FIRST_ROW values come from the claimer
+                for (int i = 0; i < a.plan.n_aggs; i++) {
+                    const tsq_agg_func f = a.plan.f[i];
+                    if (f.func != TSQ_AGG_FIRSTROW) continue;
+                    const bool arg_null = tsq_is_null(a.in.nulls[f.arg_col], row);
+                    a.t.st[i].acc[slot] = arg_null ? 0ull : tsq_cell_raw(a.in, f.arg_col, row);
+                    a.t.st[i].seen[slot] = arg_null ? 0 : 1;
+                }
+            }
+        } else {
+            bool same = a.t.gknull[slot] == (uint8_t)nullmask;
+            for (int k = 0; k < a.plan.n_keys && same; k++) same = a.t.gkey[k][slot] == kw[k];
+            if (!same) { atomicAdd(&a.counters[2], 1ull); continue; }
+            agg_update_slot(a, slot, row, false);
+        }
+    }
+    if (new_groups) atomicAdd(&a.counters[0], (unsigned long long)new_groups);
+}
+
+// re-insert every occupied slot of an old table into a bigger one (table growth)
+struct RehashArgs {
+    AggTable from, to;
+    AggPlan plan;
+    int32_t multi;
+};
+__global__ void __launch_bounds__(256) k_agg_rehash(RehashArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.from.cap + 2; s += stride) {
+        const unsigned long long tag = a.from.tag[s];
+        if (tag == TSQ_EMPTY_TAG) continue;
+        uint64_t d;
+        if (s >= a.from.cap) d = a.to.cap + (s - a.from.cap);
+        else {
+            d = tsq_mulhi64(tsq_mix64(tag), a.to.cap);
+            for (;;) {  // distinct groups only: every tag is unique unless two keys collide (then both keep a slot)
+                if (atomicCAS(&a.to.tag[d], (unsigned long long)TSQ_EMPTY_TAG, tag) == TSQ_EMPTY_TAG) break;
+                d = d + 1 == a.to.cap ? 0 : d + 1;
+            }
+        }
+        if (s >= a.from.cap) a.to.tag[d] = tag;
+        for (int k = 0; k < a.plan.n_keys; k++) a.to.gkey[k][d] = a.from.gkey[k][s];
+        if (a.from.gknull) a.to.gknull[d] = a.from.gknull[s];
+        for (int i = 0; i < a.plan.n_aggs; i++) {
+            a.to.st[i].acc[d] = a.from.st[i].acc[s];
+            a.to.st[i].aux[d] = a.from.st[i].aux[s];
+            a.to.st[i].cnt[d] = a.from.st[i].cnt[s];
+            a.to.st[i].seen[d] = a.from.st[i].seen[s];
+        }
+    }
+}
+
+// initial values of the state arrays (MIN starts at all ones; everything else at zero)
+__global__ void __launch_bounds__(256) k_fill_u64(unsigned long long* p, unsigned long long v, uint64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// K8 — finalise: compacts occupied slots into output columns.  Replaces consumeIntermData /
+// getFinalResult (aggregate.go:424-457) and AggFunc.AppendFinalResult2Chunk of every function.
+struct FinalArgs {
+    AggTable t;
+    AggPlan plan;
+    int32_t key_type[TSQ_MAX_GROUP_KEYS];
+    void* out_data[2 * TSQ_MAX_AGGS];
+    uint8_t* out_notnull[2 * TSQ_MAX_AGGS];
+    unsigned long long* counters;  // [3] = output cursor, [4] = overflow flag (BIGINT)
+};
+__device__ __forceinline__ bool sum128_fits(unsigned long long lo, unsigned long long hi) {
+    return hi == ((lo >> 63) ? ~0ull : 0ull);  // hi must be the sign extension of lo
+}
+__global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint64_t nslots = a.t.cap + 2;
+    const uint64_t nround = (nslots + 63) & ~63ull;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nround; s += stride) {
+        const bool occ = s < nslots && a.t.tag[s] != TSQ_EMPTY_TAG;
+        const unsigned long long m = __ballot(occ);
+        if (!m) continue;
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&a.counters[3], (unsigned long long)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (!occ) continue;
+        const uint64_t pos = base + __popcll(m & ((1ull << lane) - 1));
+        int oc = 0;
+        for (int i = 0; i < a.plan.n_aggs; i++) {
+            const tsq_agg_func f = a.plan.f[i];
+            const AggState st = a.t.st[i];
+            const bool partial_out = f.mode == TSQ_MODE_PARTIAL1 || f.mode == TSQ_MODE_PARTIAL2;
+            const bool real = is_real_type(f.arg_type);
+            switch (f.func) {
+                case TSQ_AGG_COUNT:
+                    ((uint64_t*)a.out_data[oc])[pos] = st.acc[s];
+                    if (a.out_notnull[oc]) a.out_notnull[oc][pos] = 1;
+                    oc++;
+                    break;
+                case TSQ_AGG_SUM: {
+                    const bool nn = st.seen[s] != 0;
+                    if (!real && nn && !sum128_fits(st.acc[s], st.aux[s])) atomicOr(&a.counters[4], 1ull);
+                    ((uint64_t*)a.out_data[oc])[pos] = nn ? st.acc[s] : 0;
+                    a.out_notnull[oc][pos] = nn ? 1 : 0;
+                    oc++;
+                    break;
+                }
+                case TSQ_AGG_AVG: {
+                    const unsigned long long cnt = st.cnt[s];
+                    if (!real && cnt && !sum128_fits(st.acc[s], st.aux[s])) atomicOr(&a.counters[4], 1ull);
+                    if (partial_out) {  // (count, sum) columns (descriptor.go:70-81)
+                        ((uint64_t*)a.out_data[oc])[pos] = cnt;
+                        if (a.out_notnull[oc]) a.out_notnull[oc][pos] = 1;
+                        oc++;
+                        ((uint64_t*)a.out_data[oc])[pos] = st.acc[s];
+                        if (a.out_notnull[oc]) a.out_notnull[oc][pos] = 1;
+                        oc++;
+                    } else {
+                        uint64_t v = 0;
+                        if (cnt) {
+                            if (real) v = tsq_f64_bits(tsq_bits_f64(st.acc[s]) / (double)(long long)cnt);  // func_avg.go:154-162
+                            else v = (uint64_t)tsq_godiv((int64_t)st.acc[s], (int64_t)cnt);                 // func_avg.go:47-55
+                        }
+                        ((uint64_t*)a.out_data[oc])[pos] = v;
+                        a.out_notnull[oc][pos] = cnt ? 1 : 0;
+                        oc++;
+                    }
+                    break;
+                }
+                case TSQ_AGG_MAX:
+                case TSQ_AGG_MIN: {
+                    const bool nn = st.seen[s] != 0;
+                    const uint64_t v = nn ? ord_image_decode(st.acc[s], f.arg_type) : 0;
+                    if (f.arg_type == TSQ_F32) ((uint32_t*)a.out_data[oc])[pos] = (uint32_t)v;
+                    else ((uint64_t*)a.out_data[oc])[pos] = v;
+                    a.out_notnull[oc][pos] = nn ? 1 : 0;
+                    oc++;
+                    break;
+                }
+                case TSQ_AGG_FIRSTROW: {
+                    const bool nn = st.seen[s] != 0;
+                    if (f.arg_type == TSQ_F32) ((uint32_t*)a.out_data[oc])[pos] = nn ? (uint32_t)st.acc[s] : 0u;
+                    else ((uint64_t*)a.out_data[oc])[pos] = nn ? st.acc[s] : 0ull;
+                    a.out_notnull[oc][pos] = nn ? 1 : 0;
+                    oc++;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// ====================================================================== host side
+struct AggTableBufs {
+    DevBuf tag, gknull;
+    DevBuf gkey[TSQ_MAX_GROUP_KEYS];
+    DevBuf acc[TSQ_MAX_AGGS], aux[TSQ_MAX_AGGS], cnt[TSQ_MAX_AGGS], seen[TSQ_MAX_AGGS];
+    uint64_t cap = 0;
+    void release() {
+        tag.release();
+        gknull.release();
+        for (auto& b : gkey) b.release();
+        for (int i = 0; i < TSQ_MAX_AGGS; i++) { acc[i].release(); aux[i].release(); cnt[i].release(); seen[i].release(); }
+        cap = 0;
+    }
+};
+
+struct tsq_agg {
+    tsq_handle_hdr hdr;
+    tsq_ctx* ctx = nullptr;
+    tsq_agg_cfg cfg;
+    AggPlan plan{};
+    bool multi = false;
+    std::atomic<int> cancelled{0};
+    AggTableBufs tb;
+    int64_t groups = 0;
+    DevBuf counters, retry[2];
+    HostStage stage;
+    std::vector<ColStore> icols;  // device batch for host pushes
+    bool finished = false;
+    int64_t in_rows = 0;
+    // output
+    int n_out = 0;
+    std::vector<int32_t> out_types;
+    std::vector<DevBuf> odata, onn, obitmap;
+    std::vector<PinnedBuf> hdata, hbitmap;
+    int64_t out_rows = 0, out_cursor = 0;
+    bool out_on_host = false, host_mode = true;
+    tsq_stats st{};
+};
+
+namespace {
+
+tsq_status agg_cancelled(tsq_agg* a) {
+    if (a->cancelled.load()) return tsq_fail(&a->hdr, TSQ_ERR_CANCELLED, "aggregate cancelled");
+    return TSQ_OK;
+}
+
+void fill_agg_table(const tsq_agg* a, const AggTableBufs& b, AggTable& t) {
+    memset(&t, 0, sizeof t);
+    t.tag = b.tag.as<unsigned long long>();
+    for (int k = 0; k < a->plan.n_keys; k++) t.gkey[k] = b.gkey[k].as<unsigned long long>();
+    t.gknull = a->multi ? b.gknull.as<uint8_t>() : nullptr;
+    for (int i = 0; i < a->plan.n_aggs; i++) {
+        t.st[i].acc = b.acc[i].as<unsigned long long>();
+        t.st[i].aux = b.aux[i].as<unsigned long long>();
+        t.st[i].cnt = b.cnt[i].as<unsigned long long>();
+        t.st[i].seen = b.seen[i].as<uint8_t>();
+    }
+    t.cap = b.cap;
+}
+
+tsq_status alloc_table(tsq_agg* a, AggTableBufs& b, uint64_t cap) {
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const uint64_t n = cap + 2;
+    b.cap = cap;
+    TSQ_TRY(b.tag.reserve(ctx, h, n * 8));
+    TSQ_HIP(h, hipMemsetAsync(b.tag.p, 0x80, n * 8, ctx->stream));
+    for (int k = 0; k < a->plan.n_keys; k++) TSQ_TRY(b.gkey[k].reserve(ctx, h, n * 8));
+    if (a->multi) {
+        TSQ_TRY(b.gknull.reserve(ctx, h, n));
+        TSQ_HIP(h, hipMemsetAsync(b.gknull.p, 0, n, ctx->stream));
+    }
+    for (int i = 0; i < a->plan.n_aggs; i++) {
+        TSQ_TRY(b.acc[i].reserve(ctx, h, n * 8));
+        TSQ_TRY(b.aux[i].reserve(ctx, h, n * 8));
+        TSQ_TRY(b.cnt[i].reserve(ctx, h, n * 8));
+        TSQ_TRY(b.seen[i].reserve(ctx, h, n));
+        if (a->plan.f[i].func == TSQ_AGG_MIN) {
+            int grid = tsq_grid_for(ctx, (int64_t)n, 256);
+            hipLaunchKernelGGL(k_fill_u64, dim3(grid), dim3(256), 0, ctx->stream, b.acc[i].as<unsigned long long>(), ~0ull, n);
+            TSQ_HIP(h, hipGetLastError());
+        } else {
+            TSQ_HIP(h, hipMemsetAsync(b.acc[i].p, 0, n * 8, ctx->stream));
+        }
+        TSQ_HIP(h, hipMemsetAsync(b.aux[i].p, 0, n * 8, ctx->stream));
+        TSQ_HIP(h, hipMemsetAsync(b.cnt[i].p, 0, n * 8, ctx->stream));
+        TSQ_HIP(h, hipMemsetAsync(b.seen[i].p, 0, n, ctx->stream));
+    }
+    return TSQ_OK;
+}
+
+tsq_status grow_table(tsq_agg* a, uint64_t new_cap) {
+    tsq_ctx* ctx = a->ctx;
+    AggTableBufs nb;
+    tsq_status s = alloc_table(a, nb, new_cap);
+    if (s != TSQ_OK) { nb.release(); return s; }
+    RehashArgs ra;
+    memset(&ra, 0, sizeof ra);
+    fill_agg_table(a, a->tb, ra.from);
+    fill_agg_table(a, nb, ra.to);
+    ra.plan = a->plan;
+    ra.multi = a->multi;
+    int grid = tsq_grid_for(ctx, (int64_t)a->tb.cap + 2, 256);
+    hipLaunchKernelGGL(k_agg_rehash, dim3(grid), dim3(256), 0, ctx->stream, ra);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { nb.release(); return tsq_fail(&a->hdr, TSQ_ERR_HIP, std::string("rehash: ") + hipGetErrorString(e)); }
+    a->tb.release();
+    a->tb = nb;  // shallow move of the buffer handles
+    a->st.kernel_launches++;
+    return TSQ_OK;
+}
+
+tsq_status launch_update(tsq_agg* a, AggArgs& args) {
+    int grid = tsq_grid_for(a->ctx, args.nrows, 256);
+    if (a->multi) hipLaunchKernelGGL(k_agg_update<true>, dim3(grid), dim3(256), 0, a->ctx->stream, args);
+    else hipLaunchKernelGGL(k_agg_update<false>, dim3(grid), dim3(256), 0, a->ctx->stream, args);
+    TSQ_HIP(&a->hdr, hipGetLastError());
+    a->st.kernel_launches++;
+    return TSQ_OK;
+}
+
+// one device-resident batch through the update kernel(s), growing the table as needed
+tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    if (nrows == 0) return TSQ_OK;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    if (nrows >= 0xffffffffLL) return tsq_fail(h, TSQ_ERR_INVALID, "internal: batch too large");
+    // keep the load factor <= 0.5 for the groups known so far; rows that still find no slot are retried
+    if ((uint64_t)a->groups * 2 > a->tb.cap) TSQ_TRY(grow_table(a, a->tb.cap * 4));
+    TSQ_TRY(a->retry[0].reserve(ctx, h, (size_t)nrows * 4 + 16));
+    TSQ_TRY(a->retry[1].reserve(ctx, h, (size_t)nrows * 4 + 16));
+    AggArgs args;
+    memset(&args, 0, sizeof args);
+    args.in = in;
+    args.plan = a->plan;
+    args.nrows = nrows;
+    args.row_base = a->in_rows;
+    args.counters = a->counters.as<unsigned long long>();
+    const uint32_t* retry_in = nullptr;
+    int64_t n = nrows;
+    int which = 0;
+    for (int round = 0; round < 40; round++) {
+        TSQ_TRY(agg_cancelled(a));
+        fill_agg_table(a, a->tb, args.t);
+        args.nrows = n;
+        args.retry_in = retry_in;
+        args.retry_out = a->retry[which].as<uint32_t>();
+        TSQ_HIP(h, hipMemsetAsync(args.counters, 0, 3 * 8, ctx->stream));
+        args.phase = 0;
+        TSQ_TRY(launch_update(a, args));
+        if (a->multi) {
+            // phase 1 only for rows that found a slot; rows handed back are retried as a whole
+            args.phase = 1;
+            TSQ_TRY(launch_update(a, args));
+        }
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, args.counters, 3 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        a->groups += (int64_t)ctx->pinned[0];
+        const uint64_t n_retry = ctx->pinned[1];
+        if (ctx->pinned[2])
+            return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "64-bit group-key hash collision between distinct keys: fall back to the Go operator");
+        if (n_retry == 0) return TSQ_OK;
+        TSQ_TRY(grow_table(a, a->tb.cap * 4));
+        retry_in = a->retry[which].as<uint32_t>();
+        n = (int64_t)n_retry;
+        which ^= 1;
+    }
+    return tsq_fail(h, TSQ_ERR_HIP, "aggregate: table growth did not converge");
+}
+
+tsq_status agg_flush(tsq_agg* a) {
+    HostStage& sg = a->stage;
+    if (sg.staged == 0) return TSQ_OK;
+    DevBuf tmp;
+    for (size_t c = 0; c < a->icols.size(); c++) {
+        a->icols[c].rows = 0;
+        a->icols[c].has_nulls = false;
+        tsq_status s = tsq_col_append(a->ctx, &a->hdr, a->icols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
+        if (s != TSQ_OK) { tmp.release(); return s; }
+        a->st.h2d_bytes += sg.staged * a->icols[c].elem();
+    }
+    tsq_colset in;
+    tsq_fill_colset(in, a->icols);
+    tsq_status s = agg_batch(a, in, sg.staged);
+    hipError_t e = hipStreamSynchronize(a->ctx->stream);
+    tmp.release();
+    a->in_rows += sg.staged;
+    sg.reset();
+    if (s != TSQ_OK) return s;
+    if (e != hipSuccess) return tsq_fail(&a->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return TSQ_OK;
+}
+
+}  // namespace
+
+TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg** out) {
+    if (!ctx || !cfg || !out) return tsq_fail(nullptr, TSQ_ERR_INVALID, "tsq_agg_create: NULL argument");
+    *out = nullptr;
+    tsq_handle_hdr* ch = &ctx->hdr;
+    if (cfg->n_group_keys < 0 || cfg->n_group_keys > TSQ_MAX_GROUP_KEYS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "0..4 group keys supported");
+    if (cfg->n_aggs < 1 || cfg->n_aggs > TSQ_MAX_AGGS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 aggregate functions supported");
+    if (cfg->n_input_cols < 1 || cfg->n_input_cols > TSQ_MAX_COLS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 input columns supported");
+    for (int c = 0; c < cfg->n_input_cols; c++)
+        if (cfg->input_types[c] < TSQ_I64 || cfg->input_types[c] > TSQ_F64)
+            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len input column: fall back to the Go operator");
+    for (int k = 0; k < cfg->n_group_keys; k++) {
+        if (cfg->group_key_col[k] < 0 || cfg->group_key_col[k] >= cfg->n_input_cols) return tsq_fail(ch, TSQ_ERR_INVALID, "group key column out of range");
+        if (cfg->group_key_type[k] != cfg->input_types[cfg->group_key_col[k]]) return tsq_fail(ch, TSQ_ERR_INVALID, "group key type mismatch");
+    }
+    std::unique_ptr<tsq_agg> a(new tsq_agg());
+    a->hdr.magic = TSQ_MAGIC_AGG;
+    a->ctx = ctx;
+    a->cfg = *cfg;
+    if (a->cfg.max_chunk_size <= 0) a->cfg.max_chunk_size = 1024;
+    a->plan.n_keys = cfg->n_group_keys;
+    a->plan.n_aggs = cfg->n_aggs;
+    for (int k = 0; k < cfg->n_group_keys; k++) a->plan.key_col[k] = cfg->group_key_col[k];
+    a->multi = cfg->n_group_keys > 1;
+    for (int i = 0; i < cfg->n_aggs; i++) {
+        const tsq_agg_func& f = cfg->aggs[i];
+        if (f.func < TSQ_AGG_COUNT || f.func > TSQ_AGG_FIRSTROW) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "unknown aggregate function");
+        if (f.mode < TSQ_MODE_COMPLETE || f.mode > TSQ_MODE_PARTIAL2) return tsq_fail(ch, TSQ_ERR_INVALID, "bad aggregate mode");
+        const bool merge = f.mode == TSQ_MODE_FINAL || f.mode == TSQ_MODE_PARTIAL2;
+        if (f.arg_col >= cfg->n_input_cols || f.arg_col < -1) return tsq_fail(ch, TSQ_ERR_INVALID, "aggregate argument column out of range");
+        if (f.arg_col < 0 && !(f.func == TSQ_AGG_COUNT && !merge)) return tsq_fail(ch, TSQ_ERR_INVALID, "only COUNT may take a constant argument");
+        if (f.func == TSQ_AGG_AVG && merge && (f.arg_col2 < 0 || f.arg_col2 >= cfg->n_input_cols))
+            return tsq_fail(ch, TSQ_ERR_INVALID, "AVG in final mode needs (count, sum) columns");
+        if (f.arg_type < TSQ_I64 || f.arg_type > TSQ_F64) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len aggregate argument: fall back to the Go operator");
+        if (f.func != TSQ_AGG_COUNT) {
+            const int vc = (f.func == TSQ_AGG_AVG && merge) ? f.arg_col2 : f.arg_col;
+            if (cfg->input_types[vc] != f.arg_type) return tsq_fail(ch, TSQ_ERR_INVALID, "aggregate arg_type does not match its input column");
+        }
+        a->plan.f[i] = f;
+        // output schema
+        const bool partial_out = f.mode == TSQ_MODE_PARTIAL1 || f.mode == TSQ_MODE_PARTIAL2;
+        const bool real = f.arg_type == TSQ_F32 || f.arg_type == TSQ_F64;
+        switch (f.func) {
+            case TSQ_AGG_COUNT: a->out_types.push_back(TSQ_I64); break;
+            case TSQ_AGG_SUM: a->out_types.push_back(real ? TSQ_F64 : TSQ_I64); break;  // base_func.go:119-131
+            case TSQ_AGG_AVG:
+                if (partial_out) a->out_types.push_back(TSQ_I64);
+                a->out_types.push_back(real ? TSQ_F64 : TSQ_I64);
+                break;
+            default: a->out_types.push_back(f.arg_type); break;
+        }
+    }
+    a->n_out = (int)a->out_types.size();
+    TSQ_HIP(ch, hipSetDevice(ctx->device));
+    tsq_handle_hdr* h = &a->hdr;
+    a->icols.resize(cfg->n_input_cols);
+    for (int c = 0; c < cfg->n_input_cols; c++) a->icols[c].type = cfg->input_types[c];
+    tsq_status s = a->counters.reserve(ctx, h, 64);
+    if (s == TSQ_OK) {
+        hipError_t e = hipMemsetAsync(a->counters.p, 0, 64, ctx->stream);
+        if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e));
+    }
+    uint64_t cap = cfg->n_group_keys == 0 ? 16 : (cfg->est_groups > 0 ? (uint64_t)cfg->est_groups * 2 + 16 : (1u << 16));
+    if (s == TSQ_OK) s = alloc_table(a.get(), a->tb, cap);
+    if (s == TSQ_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e));
+    }
+    if (s != TSQ_OK) {
+        tsq_fail(ch, s, a->hdr.err);
+        tsq_agg_destroy(a.release());
+        return s;
+    }
+    *out = a.release();
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols, int64_t nrows) {
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
+    TSQ_TRY(agg_cancelled(a));
+    if (a->finished) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "push after finish");
+    if (nrows < 0 || (!cols && nrows > 0)) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "bad arguments");
+    if (nrows == 0) return TSQ_OK;
+    bool dev = false;
+    TSQ_TRY(tsq_validate_cols(&a->hdr, cols, n_cols, a->cfg.n_input_cols, a->cfg.input_types, nrows, &dev));
+    TSQ_HIP(&a->hdr, hipSetDevice(a->ctx->device));
+    if (a->in_rows == 0 && a->stage.staged == 0) a->host_mode = !dev;
+    if (dev) {
+        TSQ_TRY(agg_flush(a));
+        tsq_colset all;
+        tsq_colset_from_cols(all, cols, n_cols);
+        const int64_t slice = 64 << 20;
+        for (int64_t off = 0; off < nrows; off += slice) {
+            const int64_t n = std::min<int64_t>(slice, nrows - off);
+            tsq_colset s;
+            tsq_colset_slice(s, all, off);
+            TSQ_TRY(agg_batch(a, s, n));
+            a->in_rows += n;
+        }
+        return TSQ_OK;
+    }
+    if (a->stage.cap == 0) TSQ_TRY(a->stage.init(&a->hdr, n_cols, a->cfg.input_types, 4 << 20));
+    int64_t off = 0;
+    while (off < nrows) {
+        int64_t n = std::min<int64_t>(nrows - off, a->stage.room());
+        a->stage.add(cols, off, n, nullptr);
+        off += n;
+        if (a->stage.room() == 0) TSQ_TRY(agg_flush(a));
+    }
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
+    TSQ_TRY(agg_cancelled(a));
+    if (a->finished) return TSQ_OK;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    TSQ_TRY(agg_flush(a));
+    // empty input without GROUP BY: exactly one row of defaults (aggregate.go:572-574,
+    // builder.go:517-539): COUNT -> 0, everything else NULL.  The NULL-group slot (cap+1) is the
+    // single group of a key-less aggregate; claim it so that finalize emits it.
+    if (a->plan.n_keys == 0 && a->groups == 0) {
+        unsigned long long one = 1;
+        TSQ_HIP(h, hipMemcpy((char*)a->tb.tag.p + (a->tb.cap + 1) * 8, &one, 8, hipMemcpyHostToDevice));
+        a->groups = 1;
+    }
+    const int64_t g = a->groups;
+    a->odata.resize(a->n_out);
+    a->onn.resize(a->n_out);
+    a->obitmap.resize(a->n_out);
+    FinalArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fill_agg_table(a, a->tb, fa.t);
+    fa.plan = a->plan;
+    for (int k = 0; k < a->plan.n_keys; k++) fa.key_type[k] = a->cfg.group_key_type[k];
+    for (int oc = 0; oc < a->n_out; oc++) {
+        TSQ_TRY(a->odata[oc].reserve(ctx, h, (size_t)g * tsq_elem_size(a->out_types[oc]) + 16));
+        TSQ_TRY(a->onn[oc].reserve(ctx, h, (size_t)g + 16));
+        fa.out_data[oc] = a->odata[oc].p;
+        fa.out_notnull[oc] = a->onn[oc].as<uint8_t>();
+    }
+    fa.counters = a->counters.as<unsigned long long>();
+    TSQ_HIP(h, hipMemsetAsync((char*)a->counters.p + 3 * 8, 0, 16, ctx->stream));
+    int grid = tsq_grid_for(ctx, (int64_t)a->tb.cap + 2, 256);
+    hipLaunchKernelGGL(k_agg_finalize, dim3(grid), dim3(256), 0, ctx->stream, fa);
+    TSQ_HIP(h, hipGetLastError());
+    a->st.kernel_launches++;
+    for (int oc = 0; oc < a->n_out; oc++) {
+        TSQ_TRY(a->obitmap[oc].reserve(ctx, h, tsq_bitmap_bytes(g) + 16));
+        TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a->onn[oc].as<uint8_t>(), a->obitmap[oc].as<uint8_t>(), g));
+    }
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, (char*)a->counters.p + 3 * 8, 16, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const int64_t emitted = (int64_t)ctx->pinned[0];
+    const bool overflow = ctx->pinned[1] != 0;
+    if (overflow) return tsq_fail(h, TSQ_ERR_OVERFLOW_BIGINT, "BIGINT value is out of range in 'sum/avg' (func_sum.go:133-137)");
+    if (emitted != g) return tsq_fail(h, TSQ_ERR_HIP, "internal: finalize emitted " + std::to_string(emitted) + " groups, expected " + std::to_string(g));
+    a->out_rows = g;
+    a->out_cursor = 0;
+    a->st.out_rows = g;
+    if (a->host_mode) {
+        a->hdata.resize(a->n_out);
+        a->hbitmap.resize(a->n_out);
+        for (int oc = 0; oc < a->n_out; oc++) {
+            const size_t bytes = (size_t)g * tsq_elem_size(a->out_types[oc]);
+            TSQ_TRY(a->hdata[oc].reserve(h, bytes + 16));
+            TSQ_TRY(a->hbitmap[oc].reserve(h, tsq_bitmap_bytes(g) + 16));
+            TSQ_HIP(h, hipMemcpyAsync(a->hdata[oc].p, a->odata[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            TSQ_HIP(h, hipMemcpyAsync(a->hbitmap[oc].p, a->obitmap[oc].p, tsq_bitmap_bytes(g), hipMemcpyDeviceToHost, ctx->stream));
+            a->st.d2h_bytes += bytes;
+        }
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        a->out_on_host = true;
+    }
+    a->finished = true;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out) {
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG || !out) return TSQ_ERR_INVALID;
+    *out = a->finished ? a->out_rows : a->groups;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows, int64_t* nrows_out, int32_t* eos) {
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
+    if (!nrows_out || !eos) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "NULL out pointer");
+    *nrows_out = 0;
+    *eos = 0;
+    TSQ_TRY(agg_cancelled(a));
+    if (!a->finished) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "pull before finish");
+    if (n_cols != a->n_out) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "pull: wrong number of output columns");
+    const int64_t n = std::min<int64_t>(cap_rows, a->out_rows - a->out_cursor);
+    if (n <= 0) { *eos = 1; return TSQ_OK; }
+    TSQ_HIP(&a->hdr, hipSetDevice(a->ctx->device));
+    for (int oc = 0; oc < a->n_out; oc++) {
+        tsq_col& o = out_cols[oc];
+        const int es = tsq_elem_size(a->out_types[oc]);
+        const bool odev = o.flags & TSQ_COL_DEVICE;
+        if (!o.data || !o.null_bitmap) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "pull: out column needs data and null_bitmap buffers");
+        if (a->out_on_host && !odev) {
+            memcpy(o.data, (const char*)a->hdata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es);
+            const uint8_t* src = (const uint8_t*)a->hbitmap[oc].p;
+            if ((a->out_cursor & 7) == 0) memcpy(o.null_bitmap, src + (a->out_cursor >> 3), tsq_bitmap_bytes(n));
+            else {
+                memset(o.null_bitmap, 0, tsq_bitmap_bytes(n));
+                for (int64_t i = 0; i < n; i++) {
+                    const int64_t s = a->out_cursor + i;
+                    if ((src[s >> 3] >> (s & 7)) & 1) o.null_bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+                }
+            }
+        } else if (!a->out_on_host && odev) {
+            if (a->out_cursor & 7) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "device pull: cap_rows must keep the cursor a multiple of 8");
+            TSQ_HIP(&a->hdr, hipMemcpyAsync(o.data, (const char*)a->odata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es, hipMemcpyDeviceToDevice, a->ctx->stream));
+            TSQ_HIP(&a->hdr, hipMemcpyAsync(o.null_bitmap, a->obitmap[oc].as<uint8_t>() + (a->out_cursor >> 3), tsq_bitmap_bytes(n), hipMemcpyDeviceToDevice, a->ctx->stream));
+        } else {
+            return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "pull: output placement (host/device) must match the pushes");
+        }
+        o.length = n;
+        o.type = a->out_types[oc];
+        o.elem_size = es;
+    }
+    if (!a->out_on_host) TSQ_HIP(&a->hdr, hipStreamSynchronize(a->ctx->stream));
+    a->out_cursor += n;
+    *nrows_out = n;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_cancel(tsq_agg* a) {
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
+    a->cancelled.store(1);
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG || !out) return TSQ_ERR_INVALID;
+    a->st.probe_rows = a->in_rows;
+    a->st.table_buckets = (int64_t)a->tb.cap;
+    *out = a->st;
+    return TSQ_OK;
+}
+
+TSQ_API void tsq_agg_destroy(tsq_agg* a) {
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return;
+    (void)hipSetDevice(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    a->tb.release();
+    a->counters.release();
+    a->retry[0].release();
+    a->retry[1].release();
+    a->stage.release();
+    for (auto& c : a->icols) c.release();
+    for (auto& b : a->odata) b.release();
+    for (auto& b : a->onn) b.release();
+    for (auto& b : a->obitmap) b.release();
+    for (auto& b : a->hdata) b.release();
+    for (auto& b : a->hbitmap) b.release();
+    a->hdr.magic = 0;
+    delete a;
+}

@@ -1,0 +1,260 @@
+// tsq_ctx.hip — context, device memory, timers, synthetic-table generator (gfx950).
+#include "tsq_stage.h"
+
+static std::mutex g_err_mu;
+static std::string g_err;
+static thread_local std::string g_err_ret;
+
+void tsq_set_global_error(const std::string& s) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = s;
+}
+
+TSQ_API int32_t tsq_abi_version(void) { return TSQ_ABI_VERSION; }
+
+TSQ_API int32_t tsq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+TSQ_API const char* tsq_last_error(const void* handle) {
+    if (handle) {
+        const tsq_handle_hdr* h = (const tsq_handle_hdr*)handle;
+        if (h->magic == TSQ_MAGIC_CTX || h->magic == TSQ_MAGIC_JOIN || h->magic == TSQ_MAGIC_AGG ||
+            h->magic == TSQ_MAGIC_EXPR)
+            return h->err.c_str();
+    }
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err_ret = g_err;
+    return g_err_ret.c_str();
+}
+
+TSQ_API tsq_status tsq_ctx_create(int32_t device, tsq_ctx** out) {
+    if (!out) return tsq_fail(nullptr, TSQ_ERR_INVALID, "tsq_ctx_create: out == NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return tsq_fail(nullptr, TSQ_ERR_NO_DEVICE,
+                        "tsq_ctx_create: no HIP device visible; libtsq has no CPU fallback");
+    if (device < 0 || device >= n) return tsq_fail(nullptr, TSQ_ERR_INVALID, "tsq_ctx_create: bad device index");
+    tsq_ctx* c = new tsq_ctx();
+    c->hdr.magic = TSQ_MAGIC_CTX;
+    c->device = device;
+    tsq_handle_hdr* h = &c->hdr;
+    auto fail = [&](hipError_t e, const char* what) {
+        tsq_status s = tsq_fail(nullptr, e == hipErrorOutOfMemory ? TSQ_ERR_OOM_DEVICE : TSQ_ERR_HIP,
+                                std::string(what) + ": " + hipGetErrorString(e));
+        delete c;
+        return s;
+    };
+    (void)h;
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    if ((e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess) return fail(e, "hipGetDeviceProperties");
+    c->num_cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    c->own_stream = true;
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
+        return fail(e, "hipHostMalloc");
+    if ((e = hipMalloc((void**)&c->dscratch, 64 * sizeof(uint64_t))) != hipSuccess) return fail(e, "hipMalloc");
+    *out = c;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_ctx_set_stream(tsq_ctx* ctx, void* hip_stream) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_ctx_sync(tsq_ctx* ctx) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    TSQ_HIP(&ctx->hdr, hipStreamSynchronize(ctx->stream));
+    return TSQ_OK;
+}
+
+TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+    ctx->hdr.magic = 0;
+    delete ctx;
+}
+
+TSQ_API tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out) {
+    if (!ctx || !out || bytes < 0) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    *out = nullptr;
+    if (bytes == 0) bytes = 8;
+    TSQ_HIP(&ctx->hdr, hipMalloc(out, (size_t)bytes));
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_dev_free(tsq_ctx* ctx, void* p) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    if (p) TSQ_HIP(&ctx->hdr, hipFree(p));
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_dev_memset(tsq_ctx* ctx, void* p, int32_t byte, int64_t bytes) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    TSQ_HIP(&ctx->hdr, hipMemsetAsync(p, byte, (size_t)bytes, ctx->stream));
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_copy_h2d(tsq_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    TSQ_HIP(&ctx->hdr, hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    TSQ_HIP(&ctx->hdr, hipStreamSynchronize(ctx->stream));
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    TSQ_HIP(&ctx->hdr, hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(&ctx->hdr, hipStreamSynchronize(ctx->stream));
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_timer_start(tsq_ctx* ctx) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    TSQ_HIP(&ctx->hdr, hipEventRecord(ctx->ev0, ctx->stream));
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_timer_stop_ms(tsq_ctx* ctx, double* ms_out) {
+    if (!ctx || !ms_out) return TSQ_ERR_INVALID;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    TSQ_HIP(&ctx->hdr, hipEventRecord(ctx->ev1, ctx->stream));
+    TSQ_HIP(&ctx->hdr, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    TSQ_HIP(&ctx->hdr, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_out = (double)ms;
+    return TSQ_OK;
+}
+
+// ------------------------------------------------------------------ K11: synthetic columns
+// One row per lane, grid-stride; the null bitmap is produced with a wave ballot: one 64-bit word
+// per wave-iteration, stored by lane 0 (bitmap words are 8-byte aligned because rows advance in
+// multiples of 64 from a 64-aligned base).
+__global__ void __launch_bounds__(256) k_gen_column(tsq_gen_spec spec, int64_t nrows, uint64_t* __restrict__ dst,
+                                                    uint64_t* __restrict__ bm_words, const uint64_t* __restrict__ src) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nround = (nrows + 63) & ~(int64_t)63;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nround; k += stride) {
+        const bool in = k < nrows;
+        const uint64_t i = (uint64_t)(spec.start + k);
+        bool isnull = in ? tsq_gen_is_null(spec, i) : true;
+        if (in) {
+            uint64_t s = (spec.kind == TSQ_GEN_HASH_OF_COL) ? src[k] : 0;
+            dst[k] = isnull ? 0 : tsq_gen_value(spec, i, s);
+        }
+        if (bm_words) {
+            unsigned long long notnull = __ballot(!isnull);
+            if ((threadIdx.x & 63) == 0) {
+                // tail word: only write the bytes that belong to the bitmap
+                int64_t word = k >> 6;
+                int64_t bytes_left = (int64_t)((nrows + 7) / 8) - word * 8;
+                if (bytes_left >= 8) bm_words[word] = notnull;
+                else {
+                    uint8_t* b = (uint8_t*)(bm_words + word);
+                    for (int64_t j = 0; j < bytes_left; j++) b[j] = (uint8_t)(notnull >> (8 * j));
+                }
+            }
+        }
+    }
+}
+
+TSQ_API tsq_status tsq_gen_column(tsq_ctx* ctx, const tsq_gen_spec* spec, int64_t nrows, void* dst,
+                                  uint8_t* null_bitmap, const void* src) {
+    if (!ctx || !spec || !dst || nrows < 0) return tsq_fail(ctx ? &ctx->hdr : nullptr, TSQ_ERR_INVALID, "tsq_gen_column: bad args");
+    if ((spec->kind == TSQ_GEN_AFFINE || spec->kind == TSQ_GEN_RAND_MOD) && spec->m == 0)
+        return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_gen_column: m == 0");
+    if (spec->kind == TSQ_GEN_AFFINE && (spec->m >> 31))
+        return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_gen_column: AFFINE needs m < 2^31");
+    if (spec->kind == TSQ_GEN_HASH_OF_COL && !src)
+        return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_gen_column: HASH_OF_COL needs src");
+    if (spec->null_pct > 0 && !null_bitmap)
+        return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_gen_column: null_pct > 0 needs a null bitmap");
+    if (((uintptr_t)null_bitmap & 7) != 0)
+        return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_gen_column: null bitmap must be 8-byte aligned");
+    if (nrows == 0) return TSQ_OK;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    int grid = tsq_grid_for(ctx, nrows, 256);
+    hipLaunchKernelGGL(k_gen_column, dim3(grid), dim3(256), 0, ctx->stream, *spec, nrows, (uint64_t*)dst,
+                       (uint64_t*)null_bitmap, (const uint64_t*)src);
+    TSQ_HIP(&ctx->hdr, hipGetLastError());
+    return TSQ_OK;
+}
+
+// ------------------------------------------------------------------ byte flags -> null bitmap
+// notnull_bytes[i] != 0  ->  bit i set.  One 64-row word per wave-iteration (ballot).
+__global__ void __launch_bounds__(256) k_pack_bitmap(const uint8_t* __restrict__ flags, uint8_t* __restrict__ bitmap, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nround = (n + 63) & ~(int64_t)63;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nround; k += stride) {
+        bool nn = k < n ? flags[k] != 0 : false;
+        unsigned long long w = __ballot(nn);
+        if ((threadIdx.x & 63) == 0) {
+            int64_t byte0 = (k >> 6) * 8;
+            int64_t bytes_left = (n + 7) / 8 - byte0;
+            if (bytes_left > 8) bytes_left = 8;
+            for (int64_t j = 0; j < bytes_left; j++) bitmap[byte0 + j] = (uint8_t)(w >> (8 * j));
+        }
+    }
+}
+
+tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n) {
+    if (n <= 0) return TSQ_OK;
+    int grid = tsq_grid_for(ctx, n, 256);
+    hipLaunchKernelGGL(k_pack_bitmap, dim3(grid), dim3(256), 0, ctx->stream, notnull_bytes, bitmap, n);
+    TSQ_HIP(h, hipGetLastError());
+    return TSQ_OK;
+}
+
+// ------------------------------------------------------------------ bitmap append (device chunk.List growth)
+// dst bits [dst_off, dst_off+n) := src bits [0,n) (or all ones when src == nullptr).  One thread per
+// destination byte; edge bytes are read-modify-written by their single owner (appends are stream
+// ordered, so there is no concurrent writer).
+__global__ void __launch_bounds__(256) k_append_bits(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t n) {
+    const int64_t first_byte = dst_off >> 3, last_byte = (dst_off + n - 1) >> 3;
+    const int64_t nbytes = last_byte - first_byte + 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nbytes; j += stride) {
+        const int64_t B = first_byte + j;
+        uint8_t v = dst[B];
+        for (int bit = 0; bit < 8; bit++) {
+            const int64_t g = B * 8 + bit;
+            if (g < dst_off || g >= dst_off + n) continue;
+            const int64_t s = g - dst_off;
+            const bool one = src ? ((src[s >> 3] >> (s & 7)) & 1) : true;
+            v = one ? (uint8_t)(v | (1u << bit)) : (uint8_t)(v & ~(1u << bit));
+        }
+        dst[B] = v;
+    }
+}
+
+
+tsq_status tsq_launch_append_bits(tsq_ctx* ctx, tsq_handle_hdr* h, uint8_t* dst, int64_t dst_off, const uint8_t* src_dev, int64_t n) {
+    if (n <= 0) return TSQ_OK;
+    int64_t nbytes = ((dst_off + n - 1) >> 3) - (dst_off >> 3) + 1;
+    int grid = tsq_grid_for(ctx, nbytes, 256);
+    hipLaunchKernelGGL(k_append_bits, dim3(grid), dim3(256), 0, ctx->stream, dst, dst_off, src_dev, n);
+    TSQ_HIP(h, hipGetLastError());
+    return TSQ_OK;
+}

@@ -1,0 +1,528 @@
+// tsq_device.h — scalar building blocks shared by every HIP kernel of libtsq.
+//
+// Everything here is TSQ_HD (__host__ __device__) and free of HIP runtime calls so that the
+// exact same source can be compiled by g++ into tests/hostsim (a test-only shared object that
+// checks the per-row semantics against the oracle without a GPU).  The product never uses a
+// host build of these functions: libtsq's entry points launch HIP kernels or fail loudly.
+#ifndef TSQ_DEVICE_H
+#define TSQ_DEVICE_H
+
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/tsq.h"
+
+#if defined(__HIPCC__)
+#define TSQ_HD __host__ __device__ __forceinline__
+#else
+#define TSQ_HD inline
+#endif
+
+// ------------------------------------------------------------------ hashing
+// splitmix64 — the synthetic-table generator of SURVEY.md §8(d), also the row-checksum mixer.
+TSQ_HD uint64_t tsq_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+// Bucket hash of a 64-bit key word.  The reference hashes with FNV-1-64 (executor/hash_table.go:64)
+// but the hash value never reaches a result (equality is by bytes, util/codec/codec.go:377), so the
+// GPU is free to use a cheaper, better-mixing function.
+TSQ_HD uint64_t tsq_mix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xFF51AFD7ED558CCDULL;
+    k ^= k >> 33;
+    k *= 0xC4CEB9FE1A85EC53ULL;
+    k ^= k >> 33;
+    return k;
+}
+// high 64 bits of a 64x64 multiply: range reduction of a hash to [0, n) without a power-of-two n
+TSQ_HD uint64_t tsq_mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// order-independent row checksum: sum and xor over rows of this per-row hash
+#define TSQ_ROWHASH_SEED 0x243F6A8885A308D3ULL
+#define TSQ_ROWHASH_NULL 0xA5A5A5A55A5A5A5AULL
+TSQ_HD uint64_t tsq_rowhash_step(uint64_t h, uint64_t v, uint32_t c) {
+    return tsq_splitmix64(h ^ (v + (uint64_t)(c + 1) * 0x9E3779B97F4A7C15ULL));
+}
+
+// rank of a key for the multi-GPU radix redistribute (tsq_radix_split)
+TSQ_HD uint32_t tsq_key_rank(uint64_t kw, uint32_t n_parts) {
+    return (uint32_t)(((tsq_mix64(kw) & 0xffffu) * (uint64_t)n_parts) >> 16);
+}
+
+// ------------------------------------------------------------------ bit patterns
+TSQ_HD double tsq_bits_f64(uint64_t b) {
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+TSQ_HD uint64_t tsq_f64_bits(double d) {
+    uint64_t b;
+    memcpy(&b, &d, 8);
+    return b;
+}
+TSQ_HD float tsq_bits_f32(uint32_t b) {
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+// util/chunk/column.go:89-92: bit == 1 => NOT NULL, LSB first; bitmap == nullptr => no NULLs
+TSQ_HD bool tsq_is_null(const uint8_t* bm, int64_t i) {
+    if (!bm) return false;
+    return ((bm[i >> 3] >> (i & 7)) & 1) == 0;
+}
+
+// ------------------------------------------------------------------ synthetic tables
+TSQ_HD uint64_t tsq_gen_r(uint64_t seed, uint32_t table, uint64_t c, uint64_t i) {
+    return tsq_splitmix64(seed ^ ((uint64_t)table << 56) ^ (c << 48) ^ i);
+}
+TSQ_HD bool tsq_gen_is_null(const tsq_gen_spec& s, uint64_t i) {
+    return s.null_pct > 0 && (tsq_gen_r(s.seed, (uint32_t)s.table, 7, i) % 100) < (uint64_t)s.null_pct;
+}
+TSQ_HD uint64_t tsq_gen_value(const tsq_gen_spec& s, uint64_t i, uint64_t src) {
+    switch (s.kind) {
+        case TSQ_GEN_SEQ: return i;
+        case TSQ_GEN_AFFINE: return (s.a * (i % s.m) + s.b) % s.m;
+        case TSQ_GEN_RAND_MOD: return tsq_gen_r(s.seed, (uint32_t)s.table, (uint64_t)s.col, i) % s.m;
+        case TSQ_GEN_RAND_F64:
+            return tsq_f64_bits((double)(tsq_gen_r(s.seed, (uint32_t)s.table, (uint64_t)s.col, i) >> 11) *
+                                (1.0 / 9007199254740992.0));
+        case TSQ_GEN_HASH_OF_COL: return tsq_splitmix64(src ^ s.b);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ join key words
+// A join key cell becomes (class flag, 64-bit word) exactly like
+// util/codec/codec.go:212-240 encodeHashChunkRowIdx: ints -> raw 8 bytes with flag 8, or 9 when the
+// column is UNSIGNED and the value has its top bit set; float32 widened to float64, flag 5.
+// Two cells are equal iff flags and words are equal (codec.go:363-382).
+#define TSQ_FLAG_INT 8
+#define TSQ_FLAG_UINT 9
+#define TSQ_FLAG_FLOAT 5
+TSQ_HD uint64_t tsq_key_word(const void* data, int32_t type, int64_t row, uint32_t* flag) {
+    switch (type) {
+        case TSQ_I64: {
+            *flag = TSQ_FLAG_INT;
+            return ((const uint64_t*)data)[row];
+        }
+        case TSQ_U64: {
+            uint64_t v = ((const uint64_t*)data)[row];
+            *flag = (v >> 63) ? TSQ_FLAG_UINT : TSQ_FLAG_INT;
+            return v;
+        }
+        case TSQ_F32: {
+            *flag = TSQ_FLAG_FLOAT;
+            return tsq_f64_bits((double)((const float*)data)[row]);
+        }
+        default: {
+            *flag = TSQ_FLAG_FLOAT;
+            return ((const uint64_t*)data)[row];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ expression interpreter
+// One row through one postfix program.  Each opcode restates one builtin*Sig.vecEval* of the
+// reference for a single row; see include/tsq.h for the file:line of every opcode.
+struct tsq_val {
+    int64_t v;   // int64 or the bits of a double
+    bool null;
+};
+
+// Row sources for the interpreter: the caller decides how (column, logical row) maps to storage.
+// tsq_chunk_src  : one chunk, one physical row (chunk.sel already applied by the caller);
+// tsq_joined_src : a joined row lhs||rhs living in two chunks (joiner.go:145-150 column order).
+struct tsq_colset {  // kernel-argument friendly description of a chunk's columns
+    const void* data[TSQ_MAX_COLS];
+    const uint8_t* nulls[TSQ_MAX_COLS];
+    int32_t type[TSQ_MAX_COLS];
+    int32_t n;
+};
+TSQ_HD tsq_val tsq_cell_int(const tsq_colset& cs, int c, int64_t row) {
+    tsq_val r;
+    r.null = tsq_is_null(cs.nulls[c], row);
+    r.v = ((const int64_t*)cs.data[c])[row];
+    return r;
+}
+TSQ_HD tsq_val tsq_cell_real(const tsq_colset& cs, int c, int64_t row) {
+    tsq_val r;
+    r.null = tsq_is_null(cs.nulls[c], row);
+    if (cs.type[c] == TSQ_F32) r.v = (int64_t)tsq_f64_bits((double)((const float*)cs.data[c])[row]);
+    else r.v = ((const int64_t*)cs.data[c])[row];
+    return r;
+}
+// raw 64-bit image of a cell (F32 zero-extended) — what the row checksum and the gather use
+TSQ_HD uint64_t tsq_cell_raw(const tsq_colset& cs, int c, int64_t row) {
+    if (cs.type[c] == TSQ_F32) return ((const uint32_t*)cs.data[c])[row];
+    return ((const uint64_t*)cs.data[c])[row];
+}
+struct tsq_chunk_src {
+    const tsq_colset* cs;
+    int64_t row;
+    TSQ_HD tsq_val load_int(int c) const { return tsq_cell_int(*cs, c, row); }
+    TSQ_HD tsq_val load_real(int c) const { return tsq_cell_real(*cs, c, row); }
+};
+struct tsq_joined_src {
+    const tsq_colset* left;
+    const tsq_colset* right;
+    int64_t lrow, rrow;
+    TSQ_HD tsq_val load_int(int c) const {
+        return c < left->n ? tsq_cell_int(*left, c, lrow) : tsq_cell_int(*right, c - left->n, rrow);
+    }
+    TSQ_HD tsq_val load_real(int c) const {
+        return c < left->n ? tsq_cell_real(*left, c, lrow) : tsq_cell_real(*right, c - left->n, rrow);
+    }
+};
+
+#define TSQ_I64MAX 0x7fffffffffffffffLL
+#define TSQ_I64MIN (-TSQ_I64MAX - 1)
+#define TSQ_U64MAX 0xffffffffffffffffULL
+#define TSQ_F64MAX 1.7976931348623157e308
+
+TSQ_HD int64_t tsq_wneg(int64_t v) { return (int64_t)(0 - (uint64_t)v); }
+TSQ_HD int64_t tsq_godiv(int64_t a, int64_t b) { return b == -1 ? tsq_wneg(a) : a / b; }
+TSQ_HD bool tsq_isinf(double d) { return d > TSQ_F64MAX || d < -TSQ_F64MAX; }
+
+// types/compare.go:44-101
+TSQ_HD int tsq_cmp_int(int64_t x, int64_t y, bool ux, bool uy) {
+    if (ux && uy) {
+        uint64_t a = (uint64_t)x, b = (uint64_t)y;
+        return a < b ? -1 : (a == b ? 0 : 1);
+    }
+    if (ux && !uy) {
+        if (y < 0 || (uint64_t)x > (uint64_t)TSQ_I64MAX) return 1;
+        return x < y ? -1 : (x == y ? 0 : 1);
+    }
+    if (!ux && uy) {
+        if (x < 0 || (uint64_t)y > (uint64_t)TSQ_I64MAX) return -1;
+        return x < y ? -1 : (x == y ? 0 : 1);
+    }
+    return x < y ? -1 : (x == y ? 0 : 1);
+}
+TSQ_HD int tsq_cmp_real(double x, double y) { return x < y ? -1 : (x == y ? 0 : 1); }  // compare.go:104
+// types/helper.go:28 RoundFloat(f) == 0  <=>  |f| < 0.5 (and NaN is "non zero")
+TSQ_HD bool tsq_real_is_zero(double f) {
+    double a = f < 0 ? -f : f;
+    return a < 0.5;
+}
+
+// Evaluates `p` for one row.  Returns TSQ_OK or an overflow status; *err_node receives the
+// postfix index of the offending node.  *div0 is incremented per x/0 (errors.go:65-77 warning).
+template <class Src>
+TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* out, int* err_node, int* div0) {
+    tsq_val st[TSQ_EXPR_MAX_STACK];
+    int sp = 0;
+    for (int k = 0; k < p.n_ops; k++) {
+        const tsq_expr_op op = p.ops[k];
+        const bool ul = op.flags & TSQ_F_LHS_UNSIGNED, ur = op.flags & TSQ_F_RHS_UNSIGNED;
+        *err_node = k;
+        switch (op.opcode) {
+            case TSQ_OP_COL_INT: st[sp++] = src.load_int(op.arg); break;
+            case TSQ_OP_COL_REAL: st[sp++] = src.load_real(op.arg); break;
+            case TSQ_OP_CONST_INT:
+            case TSQ_OP_CONST_REAL: st[sp].v = p.consts[op.arg]; st[sp].null = false; sp++; break;
+            case TSQ_OP_CONST_NULL_INT:
+            case TSQ_OP_CONST_NULL_REAL: st[sp].v = 0; st[sp].null = true; sp++; break;
+            case TSQ_OP_PLUS_REAL:
+            case TSQ_OP_MINUS_REAL:
+            case TSQ_OP_MUL_REAL:
+            case TSQ_OP_DIV_REAL: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                a.null = a.null || b.null;
+                if (a.null) break;
+                double x = tsq_bits_f64((uint64_t)a.v), y = tsq_bits_f64((uint64_t)b.v), r;
+                if (op.opcode == TSQ_OP_PLUS_REAL) {
+                    if ((x > 0 && y > TSQ_F64MAX - x) || (x < 0 && y < -TSQ_F64MAX - x)) return TSQ_ERR_OVERFLOW_DOUBLE;
+                    r = x + y;
+                } else if (op.opcode == TSQ_OP_MINUS_REAL) {
+                    if ((x > 0 && -y > TSQ_F64MAX - x) || (x < 0 && -y < -TSQ_F64MAX - x)) return TSQ_ERR_OVERFLOW_DOUBLE;
+                    r = x - y;
+                } else if (op.opcode == TSQ_OP_MUL_REAL) {
+                    r = x * y;
+                    if (tsq_isinf(r)) return TSQ_ERR_OVERFLOW_DOUBLE;
+                } else {
+                    if (y == 0) {
+                        (*div0)++;
+                        a.null = true;
+                        break;
+                    }
+                    r = x / y;
+                    if (tsq_isinf(r)) return TSQ_ERR_OVERFLOW_DOUBLE;
+                }
+                a.v = (int64_t)tsq_f64_bits(r);
+                break;
+            }
+            case TSQ_OP_PLUS_INT: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                a.null = a.null || b.null;
+                if (a.null) break;
+                int64_t lh = a.v, rh = b.v;
+                if (ul && ur) {
+                    if ((uint64_t)lh > TSQ_U64MAX - (uint64_t)rh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                } else if (ul && !ur) {  // plusUS incl. the reference's lh-vs-lh check (:454)
+                    if (rh < 0 && (uint64_t)tsq_wneg(rh) > (uint64_t)lh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                    if (rh > 0 && (uint64_t)lh > TSQ_U64MAX - (uint64_t)lh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                } else if (!ul && ur) {
+                    if (lh < 0 && (uint64_t)tsq_wneg(lh) > (uint64_t)rh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                    if (lh > 0 && (uint64_t)rh > TSQ_U64MAX - (uint64_t)lh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                } else {
+                    if ((lh > 0 && rh > TSQ_I64MAX - lh) || (lh < 0 && rh < TSQ_I64MIN - lh)) return TSQ_ERR_OVERFLOW_BIGINT;
+                }
+                a.v = (int64_t)((uint64_t)lh + (uint64_t)rh);
+                break;
+            }
+            case TSQ_OP_MINUS_INT: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                a.null = a.null || b.null;
+                if (a.null) break;
+                const bool force = op.flags & TSQ_F_FORCE_SIGNED;
+                int64_t lh = a.v, rh = b.v;
+                const int64_t nrh = tsq_wneg(rh);
+                const bool ss_over = (lh > 0 && nrh > TSQ_I64MAX - lh) || (lh < 0 && nrh < TSQ_I64MIN - lh);
+                if (force && ul && ur) {
+                    if (lh < 0 || rh < 0) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                    if (ss_over) return TSQ_ERR_OVERFLOW_BIGINT;
+                } else if (force && ul && !ur) {
+                    if (lh < 0) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                    if (ss_over) return TSQ_ERR_OVERFLOW_BIGINT;
+                } else if (force && !ul && ur) {
+                    if (rh < 0) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                    if (ss_over) return TSQ_ERR_OVERFLOW_BIGINT;
+                } else if (!force && ul && ur) {
+                    if ((uint64_t)lh < (uint64_t)rh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                } else if (!force && ul && !ur) {
+                    if (rh >= 0 && (uint64_t)lh < (uint64_t)rh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                    if (rh < 0 && (uint64_t)lh > TSQ_U64MAX - (uint64_t)nrh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                } else if (!force && !ul && ur) {
+                    if (((uint64_t)lh - (uint64_t)TSQ_I64MIN) < (uint64_t)rh) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                } else {
+                    if (ss_over) return TSQ_ERR_OVERFLOW_BIGINT;
+                }
+                a.v = (int64_t)((uint64_t)lh - (uint64_t)rh);
+                break;
+            }
+            case TSQ_OP_MUL_INT: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                a.null = a.null || b.null;
+                if (a.null) break;
+                int64_t x = a.v, y = b.v;
+                int64_t tmp = (int64_t)((uint64_t)x * (uint64_t)y);
+                if (x != 0 && tsq_godiv(tmp, x) != y) return TSQ_ERR_OVERFLOW_BIGINT;
+                a.v = tmp;
+                break;
+            }
+            case TSQ_OP_MUL_INT_UNSIGNED: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                a.null = a.null || b.null;
+                if (a.null) break;
+                uint64_t x = (uint64_t)a.v, y = (uint64_t)b.v, res = x * y;
+                if (x != 0 && res / x != y) return TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED;
+                a.v = (int64_t)res;
+                break;
+            }
+            case TSQ_OP_LT_INT: case TSQ_OP_LE_INT: case TSQ_OP_GT_INT:
+            case TSQ_OP_GE_INT: case TSQ_OP_EQ_INT: case TSQ_OP_NE_INT:
+            case TSQ_OP_LT_REAL: case TSQ_OP_LE_REAL: case TSQ_OP_GT_REAL:
+            case TSQ_OP_GE_REAL: case TSQ_OP_EQ_REAL: case TSQ_OP_NE_REAL: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                a.null = a.null || b.null;
+                if (a.null) { a.v = 0; break; }
+                const bool isreal = op.opcode >= TSQ_OP_LT_REAL;
+                const int rel = isreal ? op.opcode - TSQ_OP_LT_REAL : op.opcode - TSQ_OP_LT_INT;
+                int c = isreal ? tsq_cmp_real(tsq_bits_f64((uint64_t)a.v), tsq_bits_f64((uint64_t)b.v))
+                               : tsq_cmp_int(a.v, b.v, ul, ur);
+                bool v = rel == 0 ? c < 0 : rel == 1 ? c <= 0 : rel == 2 ? c > 0 : rel == 3 ? c >= 0 : rel == 4 ? c == 0 : c != 0;
+                a.v = v ? 1 : 0;
+                break;
+            }
+            case TSQ_OP_LOGIC_AND: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                if (!a.null && a.v == 0) break;
+                if (!b.null && b.v == 0) { a.v = 0; a.null = false; break; }
+                if (a.null || b.null) { a.null = true; break; }
+                a.v = 1;
+                break;
+            }
+            case TSQ_OP_LOGIC_OR: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                if ((!a.null && a.v != 0) || (!b.null && b.v != 0)) { a.v = 1; a.null = false; }
+                else if (a.null || b.null) a.null = true;
+                else { a.v = 0; a.null = false; }
+                break;
+            }
+            case TSQ_OP_NOT_INT: {
+                tsq_val& a = st[sp - 1];
+                if (!a.null) a.v = a.v == 0 ? 1 : 0;
+                break;
+            }
+            case TSQ_OP_NOT_REAL: {
+                tsq_val& a = st[sp - 1];
+                if (!a.null) a.v = tsq_bits_f64((uint64_t)a.v) == 0 ? 1 : 0;
+                else a.v = 0;
+                break;
+            }
+            case TSQ_OP_NEG_INT: {
+                tsq_val& a = st[sp - 1];
+                if (a.null) break;
+                if (ul) {
+                    if ((uint64_t)a.v > ((uint64_t)1 << 63)) return TSQ_ERR_OVERFLOW_BIGINT;
+                } else if (a.v == TSQ_I64MIN) return TSQ_ERR_OVERFLOW_BIGINT;
+                a.v = tsq_wneg(a.v);
+                break;
+            }
+            case TSQ_OP_NEG_REAL: {
+                tsq_val& a = st[sp - 1];
+                a.v = (int64_t)tsq_f64_bits(-tsq_bits_f64((uint64_t)a.v));
+                break;
+            }
+            case TSQ_OP_ISNULL_INT:
+            case TSQ_OP_ISNULL_REAL: {
+                tsq_val& a = st[sp - 1];
+                a.v = a.null ? 1 : 0;
+                a.null = false;
+                break;
+            }
+            case TSQ_OP_IFNULL_INT:
+            case TSQ_OP_IFNULL_REAL: {
+                tsq_val b = st[--sp];
+                tsq_val& a = st[sp - 1];
+                if (a.null && !b.null) a = b;
+                break;
+            }
+            case TSQ_OP_IF_INT:
+            case TSQ_OP_IF_REAL: {
+                tsq_val c2 = st[--sp];
+                tsq_val c1 = st[--sp];
+                tsq_val& c0 = st[sp - 1];
+                if (c0.null || c0.v == 0) c0 = c2;
+                else c0 = c1;
+                break;
+            }
+            case TSQ_OP_IN_INT:
+            case TSQ_OP_IN_REAL: {
+                const int nitems = op.arg;
+                const tsq_val x = st[sp - nitems - 1];
+                bool hasNull = false, found = false;
+                for (int j = 0; j < nitems; j++) {
+                    const tsq_val it = st[sp - nitems + j];
+                    if (it.null || x.null) { hasNull = true; continue; }
+                    bool eq;
+                    if (op.opcode == TSQ_OP_IN_REAL) eq = tsq_cmp_real(tsq_bits_f64((uint64_t)x.v), tsq_bits_f64((uint64_t)it.v)) == 0;
+                    else {
+                        const bool uj = (op.aux >> j) & 1;
+                        if (ul == uj) eq = it.v == x.v;
+                        else if (!ul && uj) eq = x.v >= 0 && it.v == x.v;
+                        else eq = it.v >= 0 && it.v == x.v;
+                    }
+                    found = found || eq;
+                }
+                sp -= nitems;
+                st[sp - 1].v = found ? 1 : 0;
+                st[sp - 1].null = found ? false : hasNull;
+                break;
+            }
+            default: return TSQ_ERR_INVALID;
+        }
+    }
+    *out = st[0];
+    if (out->null) out->v = 0;
+    return TSQ_OK;
+}
+
+// expression.VecEvalBool for one row (expression/expression.go:205-279): conjuncts are evaluated in
+// order and only while the row is still alive; an Int-typed NULL keeps the row alive but marks it
+// (`nulls`), a Real-typed NULL drops it; truthiness per toBool (:281-326).
+template <class Src>
+TSQ_HD tsq_status tsq_filter_row(const tsq_expr_prog* progs, int n_progs, const Src& src, bool* selected,
+                                 bool* isnull, int* err_conj, int* err_node, int* div0) {
+    bool nulls = false, alive = true;
+    for (int e = 0; e < n_progs && alive; e++) {
+        tsq_val v;
+        *err_conj = e;
+        tsq_status s = tsq_eval_row(progs[e], src, &v, err_node, div0);
+        if (s != TSQ_OK) return s;
+        const bool isint = progs[e].result_type != TSQ_F64;
+        if (v.null) {
+            if (isint) nulls = true;
+            else alive = false;
+        } else if (isint ? (v.v == 0) : tsq_real_is_zero(tsq_bits_f64((uint64_t)v.v))) {
+            alive = false;
+        }
+    }
+    *selected = alive && !nulls;
+    *isnull = nulls;
+    return TSQ_OK;
+}
+
+// error word for "first offending node, then first offending row" semantics of the vectorized
+// evaluator: smaller == earlier in the reference's evaluation order.  atomicMin'ed by kernels.
+//   [63:58] conjunct  [57:52] node  [51:4] row  [3:0] status
+#define TSQ_ERRWORD_NONE 0xffffffffffffffffULL
+TSQ_HD uint64_t tsq_errword(int conj, int node, uint64_t row, tsq_status st) {
+    return ((uint64_t)conj << 58) | ((uint64_t)node << 52) | ((row & 0xffffffffffffULL) << 4) | (uint64_t)(st & 15);
+}
+
+// Static validation of a program (stack discipline, indices, result type): host side, at compile.
+inline tsq_status tsq_validate_prog(const tsq_expr_prog& p, int32_t n_cols, const char** why) {
+    if (p.n_ops <= 0 || p.n_ops > TSQ_EXPR_MAX_OPS) { *why = "n_ops out of range"; return TSQ_ERR_INVALID; }
+    if (p.n_consts < 0 || p.n_consts > TSQ_EXPR_MAX_CONSTS) { *why = "n_consts out of range"; return TSQ_ERR_INVALID; }
+    int sp = 0;
+    for (int k = 0; k < p.n_ops; k++) {
+        const tsq_expr_op& op = p.ops[k];
+        int pop = 0, push = 1;
+        switch (op.opcode) {
+            case TSQ_OP_COL_INT: case TSQ_OP_COL_REAL:
+                if (n_cols >= 0 && op.arg >= n_cols) { *why = "column index out of range"; return TSQ_ERR_INVALID; }
+                break;
+            case TSQ_OP_CONST_INT: case TSQ_OP_CONST_REAL:
+                if (op.arg >= p.n_consts) { *why = "const index out of range"; return TSQ_ERR_INVALID; }
+                break;
+            case TSQ_OP_CONST_NULL_INT: case TSQ_OP_CONST_NULL_REAL: break;
+            case TSQ_OP_PLUS_REAL: case TSQ_OP_MINUS_REAL: case TSQ_OP_MUL_REAL: case TSQ_OP_DIV_REAL:
+            case TSQ_OP_PLUS_INT: case TSQ_OP_MINUS_INT: case TSQ_OP_MUL_INT: case TSQ_OP_MUL_INT_UNSIGNED:
+            case TSQ_OP_LT_INT: case TSQ_OP_LE_INT: case TSQ_OP_GT_INT: case TSQ_OP_GE_INT:
+            case TSQ_OP_EQ_INT: case TSQ_OP_NE_INT: case TSQ_OP_LT_REAL: case TSQ_OP_LE_REAL:
+            case TSQ_OP_GT_REAL: case TSQ_OP_GE_REAL: case TSQ_OP_EQ_REAL: case TSQ_OP_NE_REAL:
+            case TSQ_OP_LOGIC_AND: case TSQ_OP_LOGIC_OR: case TSQ_OP_IFNULL_INT: case TSQ_OP_IFNULL_REAL:
+                pop = 2;
+                break;
+            case TSQ_OP_NOT_INT: case TSQ_OP_NOT_REAL: case TSQ_OP_NEG_INT: case TSQ_OP_NEG_REAL:
+            case TSQ_OP_ISNULL_INT: case TSQ_OP_ISNULL_REAL:
+                pop = 1;
+                break;
+            case TSQ_OP_IF_INT: case TSQ_OP_IF_REAL: pop = 3; break;
+            case TSQ_OP_IN_INT: case TSQ_OP_IN_REAL:
+                if (op.arg < 1 || op.arg > 31) { *why = "IN list size out of range"; return TSQ_ERR_INVALID; }
+                pop = op.arg + 1;
+                break;
+            default: *why = "unknown opcode"; return TSQ_ERR_UNSUPPORTED;
+        }
+        if (sp < pop) { *why = "stack underflow"; return TSQ_ERR_INVALID; }
+        sp = sp - pop + push;
+        if (sp > TSQ_EXPR_MAX_STACK) { *why = "expression too deep"; return TSQ_ERR_UNSUPPORTED; }
+    }
+    if (sp != 1) { *why = "program leaves stack depth != 1"; return TSQ_ERR_INVALID; }
+    if (p.result_type != TSQ_I64 && p.result_type != TSQ_F64) { *why = "result_type must be TSQ_I64 or TSQ_F64"; return TSQ_ERR_INVALID; }
+    return TSQ_OK;
+}
+
+#endif  // TSQ_DEVICE_H

@@ -1,0 +1,296 @@
+// tsq_expr.hip — fused vectorized expression evaluation for gfx950 (MI355X).
+//
+// The reference evaluates an expression tree node by node, materialising a 1024-row chunk.Column
+// per node (expression/scalar_function.go:43-80, builtin_*_vec.go).  Here the whole tree is ONE
+// kernel: each lane walks the postfix program for its row in registers (tsq_eval_row in
+// tsq_device.h restates every builtin*Sig.vecEval* per row), so an expression over `a` input
+// columns moves 8·a + 8 bytes per row instead of 16+ bytes per node.  Error semantics of the
+// vectorized evaluator ("the first offending node aborts the statement") are kept with an
+// atomicMin'ed error word ordered by (conjunct, node, row).
+#include "tsq_stage.h"
+
+#include <memory>
+
+struct ExprArgs {
+    tsq_colset in;
+    const tsq_expr_prog* progs;  // device
+    int32_t n_progs;
+    int64_t nrows;
+    const int32_t* sel;          // optional logical -> physical (chunk.go:319-331)
+    uint64_t* out_data;          // projection: 8 bytes per row
+    uint8_t* out_notnull;        // projection: 1 byte per row
+    uint8_t* out_selected;       // filter: 1 byte per row (Go []bool)
+    uint8_t* out_isnull;         // filter: optional
+    unsigned long long* counters;  // [0] = error word (min), [1] = division-by-zero warnings
+};
+
+// K9 — projection form: expression.VecEval (expression/expression.go:329-341)
+__global__ void __launch_bounds__(256) k_expr_eval(ExprArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint64_t errw = TSQ_ERRWORD_NONE;
+    uint32_t div0 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nrows; i += stride) {
+        tsq_chunk_src src{&a.in, a.sel ? (int64_t)a.sel[i] : i};
+        tsq_val v;
+        int node = 0, d0 = 0;
+        tsq_status s = tsq_eval_row(a.progs[0], src, &v, &node, &d0);
+        div0 += (uint32_t)d0;
+        if (s != TSQ_OK) {
+            uint64_t w = tsq_errword(0, node, (uint64_t)i, s);
+            errw = w < errw ? w : errw;
+            continue;
+        }
+        a.out_data[i] = (uint64_t)v.v;
+        a.out_notnull[i] = v.null ? 0 : 1;
+    }
+    if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[0], (unsigned long long)errw);
+    if (div0) atomicAdd(&a.counters[1], (unsigned long long)div0);
+}
+
+// K10 — filter form: expression.VecEvalBool / VectorizedFilter (expression.go:205-279,
+// chunk_executor.go:196-245): CNF list -> selected[] (+ nulls[]).
+__global__ void __launch_bounds__(256) k_filter_eval(ExprArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint64_t errw = TSQ_ERRWORD_NONE;
+    uint32_t div0 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nrows; i += stride) {
+        tsq_chunk_src src{&a.in, a.sel ? (int64_t)a.sel[i] : i};
+        bool selected = false, isnull = false;
+        int conj = 0, node = 0, d0 = 0;
+        tsq_status s = tsq_filter_row(a.progs, a.n_progs, src, &selected, &isnull, &conj, &node, &d0);
+        div0 += (uint32_t)d0;
+        if (s != TSQ_OK) {
+            uint64_t w = tsq_errword(conj, node, (uint64_t)i, s);
+            errw = w < errw ? w : errw;
+            continue;
+        }
+        a.out_selected[i] = selected ? 1 : 0;
+        if (a.out_isnull) a.out_isnull[i] = isnull ? 1 : 0;
+    }
+    if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[0], (unsigned long long)errw);
+    if (div0) atomicAdd(&a.counters[1], (unsigned long long)div0);
+}
+
+struct tsq_expr {
+    tsq_handle_hdr hdr;
+    tsq_ctx* ctx = nullptr;
+    std::vector<tsq_expr_prog> progs;
+    DevBuf progs_d, counters;
+    std::vector<ColStore> icols;  // device copies of host input chunks
+    DevBuf sel_d, out_data, out_nn, out_bitmap, out_sel, out_isnull;
+    PinnedBuf hout, hflags;
+    int64_t launches = 0;
+};
+
+namespace {
+
+// brings the input chunk to the device when it is host resident; fills `cs`
+tsq_status expr_inputs(tsq_expr* e, const tsq_col* cols, int32_t n_cols, int64_t phys_rows, tsq_colset& cs, bool* is_dev) {
+    tsq_ctx* ctx = e->ctx;
+    tsq_handle_hdr* h = &e->hdr;
+    if (n_cols < 0 || n_cols > TSQ_MAX_COLS) return tsq_fail(h, TSQ_ERR_INVALID, "too many input columns");
+    bool dev = false, host = false;
+    for (int c = 0; c < n_cols; c++) {
+        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "var-len column in a GPU expression");
+        if (!cols[c].data && cols[c].length > 0) return tsq_fail(h, TSQ_ERR_INVALID, "column data == NULL");
+        (cols[c].flags & TSQ_COL_DEVICE) ? dev = true : host = true;
+    }
+    if (dev && host) return tsq_fail(h, TSQ_ERR_INVALID, "mixing host and device columns");
+    *is_dev = dev;
+    if (dev) {
+        tsq_colset_from_cols(cs, cols, n_cols);
+        return TSQ_OK;
+    }
+    e->icols.resize(n_cols);
+    DevBuf tmp;
+    for (int c = 0; c < n_cols; c++) {
+        ColStore& st = e->icols[c];
+        st.type = cols[c].type;
+        st.rows = 0;
+        st.has_nulls = false;
+        const int64_t n = std::min<int64_t>(cols[c].length, phys_rows);
+        tsq_status s = tsq_col_append(ctx, h, st, cols[c].data, cols[c].null_bitmap, n, false, tmp);
+        if (s != TSQ_OK) { tmp.release(); return s; }
+    }
+    hipError_t err = hipStreamSynchronize(ctx->stream);
+    tmp.release();
+    if (err != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
+    tsq_fill_colset(cs, e->icols);
+    return TSQ_OK;
+}
+
+tsq_status expr_status(tsq_expr* e, uint64_t w) {
+    if (w == TSQ_ERRWORD_NONE) return TSQ_OK;
+    tsq_status s = (tsq_status)(w & 15);
+    const char* what = s == TSQ_ERR_OVERFLOW_BIGINT            ? "BIGINT value is out of range"
+                       : s == TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED ? "BIGINT UNSIGNED value is out of range"
+                       : s == TSQ_ERR_OVERFLOW_DOUBLE          ? "DOUBLE value is out of range"
+                                                               : "expression error";
+    char buf[160];
+    snprintf(buf, sizeof buf, "%s (conjunct %d, node %d, row %llu)", what, (int)(w >> 58), (int)((w >> 52) & 63),
+             (unsigned long long)((w >> 4) & 0xffffffffffffULL));
+    return tsq_fail(&e->hdr, s, buf);
+}
+
+}  // namespace
+
+TSQ_API tsq_status tsq_expr_compile(tsq_ctx* ctx, const tsq_expr_prog* progs, int32_t n_progs, tsq_expr** out) {
+    if (!ctx || !progs || !out || n_progs < 1 || n_progs > 16) return tsq_fail(ctx ? &ctx->hdr : nullptr, TSQ_ERR_INVALID, "tsq_expr_compile: bad arguments");
+    *out = nullptr;
+    for (int i = 0; i < n_progs; i++) {
+        const char* why = "";
+        tsq_status s = tsq_validate_prog(progs[i], -1, &why);
+        if (s != TSQ_OK) return tsq_fail(&ctx->hdr, s, std::string("tsq_expr_compile: ") + why);
+    }
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    std::unique_ptr<tsq_expr> e(new tsq_expr());
+    e->hdr.magic = TSQ_MAGIC_EXPR;
+    e->ctx = ctx;
+    e->progs.assign(progs, progs + n_progs);
+    tsq_status s = e->progs_d.reserve(ctx, &e->hdr, sizeof(tsq_expr_prog) * n_progs);
+    if (s == TSQ_OK) s = e->counters.reserve(ctx, &e->hdr, 64);
+    if (s == TSQ_OK) {
+        hipError_t err = hipMemcpy(e->progs_d.p, progs, sizeof(tsq_expr_prog) * n_progs, hipMemcpyHostToDevice);
+        if (err != hipSuccess) s = tsq_fail(&e->hdr, TSQ_ERR_HIP, hipGetErrorString(err));
+    }
+    if (s != TSQ_OK) {
+        tsq_fail(&ctx->hdr, s, e->hdr.err);
+        tsq_expr_destroy(e.release());
+        return s;
+    }
+    *out = e.release();
+    return TSQ_OK;
+}
+
+static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel,
+                           tsq_col* out, uint8_t* selected_out, uint8_t* isnull_out, int64_t* div0_out) {
+    tsq_ctx* ctx = e->ctx;
+    tsq_handle_hdr* h = &e->hdr;
+    if (nrows < 0 || (nrows > 0 && n_cols > 0 && !in_cols)) return tsq_fail(h, TSQ_ERR_INVALID, "bad arguments");
+    if (div0_out) *div0_out = 0;
+    if (nrows == 0) return TSQ_OK;
+    for (size_t p = 0; p < e->progs.size(); p++) {
+        const char* why = "";
+        tsq_status s = tsq_validate_prog(e->progs[p], n_cols, &why);
+        if (s != TSQ_OK) return tsq_fail(h, s, why);
+    }
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    // physical rows needed: with sel, rows up to max(sel)+1 are touched; the caller's columns say how long they are
+    int64_t phys = nrows;
+    for (int c = 0; c < n_cols; c++) phys = std::max<int64_t>(phys, in_cols[c].length);
+    ExprArgs a;
+    memset(&a, 0, sizeof a);
+    bool dev = false;
+    TSQ_TRY(expr_inputs(e, in_cols, n_cols, phys, a.in, &dev));
+    if (!sel)
+        for (int c = 0; c < n_cols; c++)
+            if (in_cols[c].length < nrows) return tsq_fail(h, TSQ_ERR_INVALID, "column shorter than nrows");
+    a.progs = e->progs_d.as<tsq_expr_prog>();
+    a.n_progs = (int32_t)e->progs.size();
+    a.nrows = nrows;
+    if (sel) {
+        if (dev) a.sel = sel;  // device-resident selection vector
+        else {
+            TSQ_TRY(e->sel_d.reserve(ctx, h, (size_t)nrows * 4 + 16));
+            TSQ_HIP(h, hipMemcpyAsync(e->sel_d.p, sel, (size_t)nrows * 4, hipMemcpyHostToDevice, ctx->stream));
+            a.sel = e->sel_d.as<int32_t>();
+        }
+    }
+    a.counters = e->counters.as<unsigned long long>();
+    ctx->pinned[0] = TSQ_ERRWORD_NONE;
+    ctx->pinned[1] = 0;
+    TSQ_HIP(h, hipMemcpyAsync(a.counters, ctx->pinned, 16, hipMemcpyHostToDevice, ctx->stream));
+    const int grid = tsq_grid_for(ctx, nrows, 256);
+    if (!filter) {
+        const bool odev = out->flags & TSQ_COL_DEVICE;
+        if (odev != dev) return tsq_fail(h, TSQ_ERR_INVALID, "output placement (host/device) must match the inputs");
+        if (!out->data || !out->null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "out needs data and null_bitmap buffers");
+        uint64_t* od = (uint64_t*)out->data;
+        if (!odev) {
+            TSQ_TRY(e->out_data.reserve(ctx, h, (size_t)nrows * 8 + 16));
+            od = e->out_data.as<uint64_t>();
+        }
+        TSQ_TRY(e->out_nn.reserve(ctx, h, (size_t)nrows + 16));
+        a.out_data = od;
+        a.out_notnull = e->out_nn.as<uint8_t>();
+        hipLaunchKernelGGL(k_expr_eval, dim3(grid), dim3(256), 0, ctx->stream, a);
+        TSQ_HIP(h, hipGetLastError());
+        uint8_t* ob = out->null_bitmap;
+        if (!odev) {
+            TSQ_TRY(e->out_bitmap.reserve(ctx, h, tsq_bitmap_bytes(nrows) + 16));
+            ob = e->out_bitmap.as<uint8_t>();
+        }
+        TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a.out_notnull, ob, nrows));
+        if (!odev) {
+            TSQ_TRY(e->hout.reserve(h, (size_t)nrows * 8 + tsq_bitmap_bytes(nrows) + 32));
+            TSQ_HIP(h, hipMemcpyAsync(e->hout.p, od, (size_t)nrows * 8, hipMemcpyDeviceToHost, ctx->stream));
+            TSQ_HIP(h, hipMemcpyAsync((char*)e->hout.p + (size_t)nrows * 8, ob, tsq_bitmap_bytes(nrows), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    } else {
+        TSQ_TRY(e->out_sel.reserve(ctx, h, (size_t)nrows + 16));
+        a.out_selected = dev ? selected_out : e->out_sel.as<uint8_t>();
+        if (isnull_out) {
+            TSQ_TRY(e->out_isnull.reserve(ctx, h, (size_t)nrows + 16));
+            a.out_isnull = dev ? isnull_out : e->out_isnull.as<uint8_t>();
+        }
+        hipLaunchKernelGGL(k_filter_eval, dim3(grid), dim3(256), 0, ctx->stream, a);
+        TSQ_HIP(h, hipGetLastError());
+        if (!dev) {
+            TSQ_TRY(e->hflags.reserve(h, (size_t)nrows * 2 + 32));
+            TSQ_HIP(h, hipMemcpyAsync(e->hflags.p, a.out_selected, (size_t)nrows, hipMemcpyDeviceToHost, ctx->stream));
+            if (isnull_out) TSQ_HIP(h, hipMemcpyAsync((char*)e->hflags.p + nrows, a.out_isnull, (size_t)nrows, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    e->launches++;
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, a.counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    if (div0_out) *div0_out = (int64_t)ctx->pinned[1];
+    TSQ_TRY(expr_status(e, ctx->pinned[0]));
+    if (!filter) {
+        if (!(out->flags & TSQ_COL_DEVICE)) {
+            memcpy(out->data, e->hout.p, (size_t)nrows * 8);
+            memcpy(out->null_bitmap, (char*)e->hout.p + (size_t)nrows * 8, tsq_bitmap_bytes(nrows));
+        }
+        out->length = nrows;
+        out->elem_size = 8;
+        out->type = e->progs[0].result_type == TSQ_F64 ? TSQ_F64 : (e->progs[0].result_unsigned ? TSQ_U64 : TSQ_I64);
+    } else if (!dev) {
+        memcpy(selected_out, e->hflags.p, (size_t)nrows);
+        if (isnull_out) memcpy(isnull_out, (char*)e->hflags.p + nrows, (size_t)nrows);
+    }
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_expr_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel, tsq_col* out,
+                                 int64_t* div_by_zero_warnings) {
+    if (!e || e->hdr.magic != TSQ_MAGIC_EXPR) return TSQ_ERR_INVALID;
+    if (!out) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "out == NULL");
+    if (e->progs.size() != 1) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "tsq_expr_eval needs a single program (use tsq_filter_eval for CNF lists)");
+    return expr_run(e, false, in_cols, n_cols, nrows, sel, out, nullptr, nullptr, div_by_zero_warnings);
+}
+
+TSQ_API tsq_status tsq_filter_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel,
+                                   uint8_t* selected_out, uint8_t* isnull_out, int64_t* div_by_zero_warnings) {
+    if (!e || e->hdr.magic != TSQ_MAGIC_EXPR) return TSQ_ERR_INVALID;
+    if (!selected_out) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "selected_out == NULL");
+    return expr_run(e, true, in_cols, n_cols, nrows, sel, nullptr, selected_out, isnull_out, div_by_zero_warnings);
+}
+
+TSQ_API void tsq_expr_destroy(tsq_expr* e) {
+    if (!e || e->hdr.magic != TSQ_MAGIC_EXPR) return;
+    (void)hipSetDevice(e->ctx->device);
+    (void)hipStreamSynchronize(e->ctx->stream);
+    e->progs_d.release();
+    e->counters.release();
+    for (auto& c : e->icols) c.release();
+    e->sel_d.release();
+    e->out_data.release();
+    e->out_nn.release();
+    e->out_bitmap.release();
+    e->out_sel.release();
+    e->out_isnull.release();
+    e->hout.release();
+    e->hflags.release();
+    e->hdr.magic = 0;
+    delete e;
+}

@@ -1,0 +1,130 @@
+// tsq_internal.h — host-side plumbing shared by the libtsq translation units (not part of the ABI).
+#ifndef TSQ_INTERNAL_H
+#define TSQ_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "tsq_device.h"
+
+#define TSQ_API extern "C" __attribute__((visibility("default")))
+
+// every handle starts with this header so tsq_last_error(handle) works on any of them
+struct tsq_handle_hdr {
+    uint32_t magic;
+    std::string err;
+};
+#define TSQ_MAGIC_CTX 0x74737143u   /* 'tsqC' */
+#define TSQ_MAGIC_JOIN 0x7473714au  /* 'tsqJ' */
+#define TSQ_MAGIC_AGG 0x74737141u   /* 'tsqA' */
+#define TSQ_MAGIC_EXPR 0x74737145u  /* 'tsqE' */
+
+void tsq_set_global_error(const std::string& s);
+
+struct tsq_ctx {
+    tsq_handle_hdr hdr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop;
+    int num_cus = 256;
+    // small pinned scratch for scalar results (counts, error words)
+    uint64_t* pinned = nullptr;      // host-mapped, 64 words
+    uint64_t* dscratch = nullptr;    // device, 64 words
+};
+
+inline tsq_status tsq_fail(tsq_handle_hdr* h, tsq_status s, const std::string& msg) {
+    if (h) h->err = msg;
+    tsq_set_global_error(msg);
+    return s;
+}
+
+#define TSQ_HIP(h, expr)                                                                               \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            tsq_status _s = (_e == hipErrorOutOfMemory) ? TSQ_ERR_OOM_DEVICE : TSQ_ERR_HIP;            \
+            return tsq_fail((h), _s, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+        }                                                                                              \
+    } while (0)
+
+#define TSQ_TRY(expr)                     \
+    do {                                  \
+        tsq_status _s = (expr);           \
+        if (_s != TSQ_OK) return _s;      \
+    } while (0)
+
+// growable device buffer (never shrinks); contents are NOT preserved on growth unless keep=true
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    tsq_status reserve(tsq_ctx* ctx, tsq_handle_hdr* h, size_t bytes, bool keep = false, size_t used = 0) {
+        if (bytes <= cap) return TSQ_OK;
+        size_t ncap = bytes;
+        if (keep && cap) ncap = std::max(bytes, cap + cap / 2);
+        void* np = nullptr;
+        TSQ_HIP(h, hipMalloc(&np, ncap));
+        if (keep && p && used) {
+            hipError_t e = hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) {
+                (void)hipFree(np);
+                return tsq_fail(h, TSQ_ERR_HIP, std::string("hipMemcpyAsync(grow): ") + hipGetErrorString(e));
+            }
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = ncap;
+        return TSQ_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    tsq_status reserve(tsq_handle_hdr* h, size_t bytes) {
+        if (bytes <= cap) return TSQ_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        TSQ_HIP(h, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+        return TSQ_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+inline int tsq_elem_size(int32_t type) { return type == TSQ_F32 ? 4 : 8; }
+inline size_t tsq_bitmap_bytes(int64_t rows) { return (size_t)((rows + 7) / 8); }
+
+// grid sizing for HBM-bound grid-stride kernels: enough waves to cover latency, ≤ 8 blocks/CU
+inline int tsq_grid_for(const tsq_ctx* ctx, int64_t work_items, int block, int items_per_thread = 1) {
+    int64_t blocks = (work_items + (int64_t)block * items_per_thread - 1) / ((int64_t)block * items_per_thread);
+    int64_t cap = (int64_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+// kernels defined in tsq_ctx.hip that other units launch through these wrappers
+tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n);
+
+#endif

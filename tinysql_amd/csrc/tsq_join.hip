@@ -1,0 +1,1081 @@
+// tsq_join.hip — hash join for gfx950 (MI355X).  Replaces executor/join.go + hash_table.go +
+// joiner.go of the reference (citations at each piece).
+//
+// Data layout in HBM
+//   build columns : one contiguous device array per column (+ optional null bitmap), appended
+//                   chunk by chunk — the device analogue of chunk.List (util/chunk/list.go:22-38).
+//   hash table    : bucketised open addressing, structure of arrays
+//                     keys[nbuckets][8]  uint64  key words, one 64-byte line per bucket
+//                     vals[nbuckets][8]  uint32  build row ids (RowPtr analogue, list.go:28-31)
+//                   A probe touches exactly one 64 B line of `keys` (plus the next bucket only if
+//                   that one is full); `vals` is touched only for matches that are materialised.
+//                   Duplicate keys simply occupy further slots: the table is a multimap like
+//                   rowHashMap (hash_table.go:181-276); insertion order inside a key is not kept
+//                   (row order is unspecified across join workers in the reference too).
+//   EMPTY sentinel: 0x8080808080808080 (memset-able).  Build rows whose key word equals the
+//                   sentinel go to a small side list so every int64 value remains a legal key.
+// Equality: a key cell is (flag, word) as in util/codec/codec.go:212-240; single-column keys store
+// the word itself (exact), multi-column keys store a 64-bit mix and verify against the build
+// columns through the row id.
+#include "tsq_stage.h"
+
+#include <deque>
+#include <memory>
+
+#define TSQ_EMPTY_KEY 0x8080808080808080ULL
+#define TSQ_BUCKET 8
+
+struct JoinTable {
+    uint64_t* keys;
+    uint32_t* vals;
+    uint64_t nbuckets;
+    const uint32_t* sent_rows;
+    uint32_t sent_count;
+};
+struct KeySpec {
+    int32_t n_keys;
+    int32_t bidx[TSQ_MAX_KEYS];
+    int32_t pidx[TSQ_MAX_KEYS];
+    int32_t skip_high;  // single int key with mixed signedness: cells with the top bit set never match
+};
+
+// ------------------------------------------------------------------ device helpers
+template <bool MULTI>
+__device__ __forceinline__ bool load_kw(const tsq_colset& cs, const int32_t* idx, int n_keys, bool skip_high,
+                                        int64_t row, uint64_t& kw) {
+    if (!MULTI) {
+        const int c = idx[0];
+        if (tsq_is_null(cs.nulls[c], row)) return false;
+        uint32_t flag;
+        kw = tsq_key_word(cs.data[c], cs.type[c], row, &flag);
+        if (skip_high && (kw >> 63)) return false;
+        return true;
+    } else {
+        uint64_t h = 0x6A09E667F3BCC908ULL;
+        for (int k = 0; k < n_keys; k++) {
+            const int c = idx[k];
+            if (tsq_is_null(cs.nulls[c], row)) return false;
+            uint32_t flag;
+            uint64_t w = tsq_key_word(cs.data[c], cs.type[c], row, &flag);
+            h = tsq_splitmix64(h ^ w) + flag;
+        }
+        kw = h;
+        return true;
+    }
+}
+// util/codec/codec.go:363-382 EqualChunkRow for multi-column keys
+__device__ __forceinline__ bool keys_equal(const tsq_colset& b, const tsq_colset& p, const KeySpec& ks, int64_t brow,
+                                           int64_t prow) {
+    for (int k = 0; k < ks.n_keys; k++) {
+        uint32_t f1, f2;
+        uint64_t w1 = tsq_key_word(b.data[ks.bidx[k]], b.type[ks.bidx[k]], brow, &f1);
+        uint64_t w2 = tsq_key_word(p.data[ks.pidx[k]], p.type[ks.pidx[k]], prow, &f2);
+        if (f1 != f2 || w1 != w2) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_xor_u64(uint64_t v) {
+    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
+    return v;
+}
+// exclusive prefix sum over the 64 lanes of a wave; *total = sum over all lanes
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t* total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+// Visits every slot of the multimap whose key word equals kw: f(slot) for each.
+// One 64-byte line (4 x dwordx4 loads, all issued before the first compare) per bucket; the walk
+// ends at the first bucket that still has an EMPTY slot (nothing was ever pushed past it).
+template <class F>
+__device__ __forceinline__ void for_each_slot(const JoinTable& t, uint64_t kw, F&& f) {
+    uint64_t bkt = tsq_mulhi64(tsq_mix64(kw), t.nbuckets);
+    for (;;) {
+        const ulonglong2* line = reinterpret_cast<const ulonglong2*>(t.keys + bkt * TSQ_BUCKET);
+        const ulonglong2 a = line[0], b = line[1], c = line[2], d = line[3];
+        const uint64_t k[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+        bool has_empty = false;
+#pragma unroll
+        for (int s = 0; s < TSQ_BUCKET; s++) {
+            if (k[s] == kw) f(bkt * TSQ_BUCKET + s);
+            has_empty |= (k[s] == TSQ_EMPTY_KEY);
+        }
+        if (has_empty) break;
+        bkt = (bkt + 1 == t.nbuckets) ? 0 : bkt + 1;
+    }
+}
+
+// ------------------------------------------------------------------ K2: build insert
+// Replaces hashRowContainer.PutChunk (executor/hash_table.go:146-169) + rowHashMap.Put (:247-256).
+// One build row per lane; claim the first EMPTY slot of the home bucket with a 64-bit CAS, spill to
+// the next bucket when full.  NULL keys are never inserted (:161-163).
+struct BuildArgs {
+    tsq_colset b;
+    KeySpec ks;
+    JoinTable t;
+    int64_t row0, nrows;
+    uint32_t* sent_rows;   // side list (capacity sent_cap)
+    uint32_t sent_cap;
+    uint32_t* sent_total;  // number of sentinel-key rows seen
+    unsigned long long* inserted;
+};
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_build_insert(BuildArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t ins = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
+        const int64_t row = a.row0 + r;
+        uint64_t kw;
+        if (!load_kw<MULTI>(a.b, a.ks.bidx, a.ks.n_keys, a.ks.skip_high, row, kw)) continue;
+        ins++;
+        if (kw == TSQ_EMPTY_KEY) {
+            uint32_t i = atomicAdd(a.sent_total, 1u);
+            if (i < a.sent_cap) a.sent_rows[i] = (uint32_t)row;
+            continue;
+        }
+        uint64_t bkt = tsq_mulhi64(tsq_mix64(kw), a.t.nbuckets);
+        bool done = false;
+        while (!done) {
+            unsigned long long* base = (unsigned long long*)(a.t.keys + bkt * TSQ_BUCKET);
+#pragma unroll 1
+            for (int s = 0; s < TSQ_BUCKET && !done; s++) {
+                // a stale EMPTY is harmless (the CAS decides); non-EMPTY never reverts
+                if (__hip_atomic_load(base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == TSQ_EMPTY_KEY) {
+                    unsigned long long old = atomicCAS(base + s, (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)kw);
+                    if (old == TSQ_EMPTY_KEY) {
+                        a.t.vals[bkt * TSQ_BUCKET + s] = (uint32_t)row;
+                        done = true;
+                    }
+                }
+            }
+            bkt = (bkt + 1 == a.t.nbuckets) ? 0 : bkt + 1;
+        }
+    }
+    uint64_t tot = wave_sum_u64(ins);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(a.inserted, (unsigned long long)tot);
+}
+// second chance for the sentinel side list when it overflowed its first capacity
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_collect_sentinel(BuildArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
+        uint64_t kw;
+        if (!load_kw<MULTI>(a.b, a.ks.bidx, a.ks.n_keys, a.ks.skip_high, a.row0 + r, kw)) continue;
+        if (kw != TSQ_EMPTY_KEY) continue;
+        uint32_t i = atomicAdd(a.sent_total, 1u);
+        if (i < a.sent_cap) a.sent_rows[i] = (uint32_t)(a.row0 + r);
+    }
+}
+
+// ------------------------------------------------------------------ K3/K4: probe
+struct ProbeArgs {
+    tsq_colset p;          // probe chunk(s), device resident
+    tsq_colset b;          // build columns
+    KeySpec ks;
+    JoinTable t;
+    int64_t nrows;
+    const uint8_t* selected;          // optional, one byte per probe row (join.go:328 result)
+    const tsq_expr_prog* filters;     // outerSideFilter over probe schema (device), may be null
+    int32_t n_filters;
+    const tsq_expr_prog* conds;       // OtherConditions over lhs||rhs (device), may be null
+    int32_t n_conds;
+    int32_t join_type;
+    int32_t probe_is_left;            // output order: left||right
+    unsigned long long* counters;     // [0]=joined rows [1]=checksum sum [2]=checksum xor [3]=err word [4]=div0 [5]=out cursor
+    // emit only
+    void* out_data[2 * TSQ_MAX_COLS];
+    uint8_t* out_notnull[2 * TSQ_MAX_COLS];  // one byte per output row, may be null per column
+};
+
+// probe-side eligibility of row k: selected && outer filter && non-NULL key (join.go:344)
+template <bool MULTI, bool GEN>
+__device__ __forceinline__ bool probe_row_valid(const ProbeArgs& a, int64_t k, uint64_t& kw, uint64_t& errw, uint32_t& div0) {
+    if (GEN) {
+        if (a.selected && !a.selected[k]) return false;
+        if (a.n_filters > 0) {
+            tsq_chunk_src src{&a.p, k};
+            bool sel = false, isnull = false;
+            int ec = 0, en = 0, d0 = 0;
+            tsq_status s = tsq_filter_row(a.filters, a.n_filters, src, &sel, &isnull, &ec, &en, &d0);
+            div0 += (uint32_t)d0;
+            if (s != TSQ_OK) {
+                uint64_t w = tsq_errword(ec, en, (uint64_t)k, s);
+                errw = w < errw ? w : errw;
+                return false;
+            }
+            if (!sel) return false;
+        }
+    }
+    return load_kw<MULTI>(a.p, a.ks.pidx, a.ks.n_keys, a.ks.skip_high, k, kw);
+}
+
+// is the (probe row k, build row brow) pair a joined row?  verify multi-column keys, then the
+// OtherConditions on the joined row (joiner.go:155-167).
+template <bool MULTI, bool GEN>
+__device__ __forceinline__ bool pair_matches(const ProbeArgs& a, int64_t k, uint32_t brow, uint64_t& errw, uint32_t& div0) {
+    if (MULTI && !keys_equal(a.b, a.p, a.ks, brow, k)) return false;
+    if (GEN && a.n_conds > 0) {
+        tsq_joined_src src;
+        if (a.probe_is_left) { src.left = &a.p; src.right = &a.b; src.lrow = k; src.rrow = brow; }
+        else { src.left = &a.b; src.right = &a.p; src.lrow = brow; src.rrow = k; }
+        bool sel = false, isnull = false;
+        int ec = 0, en = 0, d0 = 0;
+        tsq_status s = tsq_filter_row(a.conds, a.n_conds, src, &sel, &isnull, &ec, &en, &d0);
+        div0 += (uint32_t)d0;
+        if (s != TSQ_OK) {
+            // conditions are evaluated per probe row batch in the reference; order by probe row
+            uint64_t w = tsq_errword(ec, en, (uint64_t)k, s);
+            errw = w < errw ? w : errw;
+            return false;
+        }
+        return sel;
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint64_t joined_rowhash(const ProbeArgs& a, int64_t k, int64_t brow /* <0: NULL build side */) {
+    uint64_t h = TSQ_ROWHASH_SEED;
+    const tsq_colset& L = a.probe_is_left ? a.p : a.b;
+    const tsq_colset& R = a.probe_is_left ? a.b : a.p;
+    const int64_t lrow = a.probe_is_left ? k : brow, rrow = a.probe_is_left ? brow : k;
+    uint32_t c = 0;
+    for (int i = 0; i < L.n; i++, c++) {
+        uint64_t v = (lrow < 0 || tsq_is_null(L.nulls[i], lrow)) ? TSQ_ROWHASH_NULL : tsq_cell_raw(L, i, lrow);
+        h = tsq_rowhash_step(h, v, c);
+    }
+    for (int i = 0; i < R.n; i++, c++) {
+        uint64_t v = (rrow < 0 || tsq_is_null(R.nulls[i], rrow)) ? TSQ_ROWHASH_NULL : tsq_cell_raw(R, i, rrow);
+        h = tsq_rowhash_step(h, v, c);
+    }
+    return h;
+}
+
+// visits every build row joined with probe row k
+template <bool MULTI, bool GEN, class F>
+__device__ __forceinline__ void for_each_match(const ProbeArgs& a, int64_t k, uint64_t kw, uint64_t& errw, uint32_t& div0, F&& f) {
+    if (kw == TSQ_EMPTY_KEY) {
+        for (uint32_t j = 0; j < a.t.sent_count; j++) {
+            uint32_t brow = a.t.sent_rows[j];
+            if (pair_matches<MULTI, GEN>(a, k, brow, errw, div0)) f(brow);
+        }
+        return;
+    }
+    for_each_slot(a.t, kw, [&](uint64_t slot) {
+        if (!MULTI && !(GEN && a.n_conds > 0)) {
+            f(a.t.vals[slot]);  // the load is dead-code-eliminated when f ignores the row id
+        } else {
+            uint32_t brow = a.t.vals[slot];
+            if (pair_matches<MULTI, GEN>(a, k, brow, errw, div0)) f(brow);
+        }
+    });
+}
+
+// K3 — COUNT(*) probe (+ optional fused row checksum).  Replaces the per-row loop of join2Chunk
+// (executor/join.go:343-360) + GetMatchedRows (hash_table.go:110-134) when no row is materialised.
+// Fast path (inner join, single key, no filters): reads 8 B of probe key + one 64 B table line.
+template <bool MULTI, bool GEN, bool CHK>
+__global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint64_t cnt = 0, csum = 0, cxor = 0, errw = TSQ_ERRWORD_NONE;
+    uint32_t div0 = 0;
+    const bool outer = a.join_type != TSQ_JOIN_INNER;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nrows; k += stride) {
+        uint64_t kw = 0;
+        uint32_t c = 0;
+        if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0)) {
+            if (!MULTI && !GEN && !CHK) {
+                // leanest form: keys only, never touches vals
+                if (kw == TSQ_EMPTY_KEY) c = a.t.sent_count;
+                else for_each_slot(a.t, kw, [&](uint64_t) { c++; });
+            } else {
+                for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) {
+                    c++;
+                    if (CHK) {
+                        uint64_t h = joined_rowhash(a, k, (int64_t)brow);
+                        csum += h;
+                        cxor ^= h;
+                    }
+                });
+            }
+        }
+        if (GEN && outer && c == 0) {  // onMissMatch (joiner.go:274-277,337-340)
+            c = 1;
+            if (CHK) {
+                uint64_t h = joined_rowhash(a, k, -1);
+                csum += h;
+                cxor ^= h;
+            }
+        }
+        cnt += c;
+    }
+    cnt = wave_sum_u64(cnt);
+    if (CHK) { csum = wave_sum_u64(csum); cxor = wave_xor_u64(cxor); }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(&a.counters[0], (unsigned long long)cnt);
+        if (CHK) { atomicAdd(&a.counters[1], (unsigned long long)csum); atomicXor(&a.counters[2], (unsigned long long)cxor); }
+    }
+    if (GEN) {
+        if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[3], (unsigned long long)errw);
+        if (div0) atomicAdd(&a.counters[4], (unsigned long long)div0);
+    }
+}
+
+// K4 — materialising probe.  Replaces joiner.tryToMatchInners / makeJoinRowToChunk / onMissMatch
+// (executor/joiner.go:145-150,220-410) and Chunk.AppendRow (util/chunk/chunk.go:334-356).
+// Two sweeps over the (now cache resident) bucket per probe row: count, claim output rows with ONE
+// atomicAdd per wave (ballot-free wave prefix sum), then write lhs||rhs columns at the claimed rows.
+__device__ __forceinline__ void write_joined_row(const ProbeArgs& a, uint64_t pos, int64_t k, int64_t brow) {
+    const tsq_colset& L = a.probe_is_left ? a.p : a.b;
+    const tsq_colset& R = a.probe_is_left ? a.b : a.p;
+    const int64_t lrow = a.probe_is_left ? k : brow, rrow = a.probe_is_left ? brow : k;
+    int oc = 0;
+    for (int i = 0; i < L.n; i++, oc++) {
+        const bool nn = lrow >= 0 && !tsq_is_null(L.nulls[i], lrow);
+        if (L.type[i] == TSQ_F32) ((uint32_t*)a.out_data[oc])[pos] = nn ? ((const uint32_t*)L.data[i])[lrow] : 0u;
+        else ((uint64_t*)a.out_data[oc])[pos] = nn ? ((const uint64_t*)L.data[i])[lrow] : 0ull;
+        if (a.out_notnull[oc]) a.out_notnull[oc][pos] = nn ? 1 : 0;
+    }
+    for (int i = 0; i < R.n; i++, oc++) {
+        const bool nn = rrow >= 0 && !tsq_is_null(R.nulls[i], rrow);
+        if (R.type[i] == TSQ_F32) ((uint32_t*)a.out_data[oc])[pos] = nn ? ((const uint32_t*)R.data[i])[rrow] : 0u;
+        else ((uint64_t*)a.out_data[oc])[pos] = nn ? ((const uint64_t*)R.data[i])[rrow] : 0ull;
+        if (a.out_notnull[oc]) a.out_notnull[oc][pos] = nn ? 1 : 0;
+    }
+}
+
+template <bool MULTI, bool GEN>
+__global__ void __launch_bounds__(256) k_probe_emit(ProbeArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nround = (a.nrows + 63) & ~(int64_t)63;  // wave-uniform trip count for the collectives
+    const bool outer = a.join_type != TSQ_JOIN_INNER;
+    uint64_t errw = TSQ_ERRWORD_NONE;
+    uint32_t div0 = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nround; k += stride) {
+        const bool active = k < a.nrows;
+        uint64_t kw = 0;
+        bool valid = false;
+        uint32_t c = 0;
+        if (active) {
+            valid = probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0);
+            if (valid) for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t) { c++; });
+        }
+        const bool miss = active && outer && c == 0;
+        uint32_t n_out = c + (miss ? 1u : 0u), total;
+        uint32_t prefix = wave_excl_scan_u32(n_out, &total);
+        unsigned long long base = 0;
+        if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(&a.counters[5], (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+        uint64_t pos = base + prefix;
+        if (c) {
+            uint32_t dummy_d0 = 0;
+            uint64_t dummy_err = TSQ_ERRWORD_NONE;
+            for_each_match<MULTI, GEN>(a, k, kw, dummy_err, dummy_d0, [&](uint32_t brow) { write_joined_row(a, pos++, k, (int64_t)brow); });
+        } else if (miss) {
+            write_joined_row(a, pos, k, -1);
+        }
+    }
+    if (GEN) {
+        if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[3], (unsigned long long)errw);
+        if (div0) atomicAdd(&a.counters[4], (unsigned long long)div0);
+    }
+}
+
+// ====================================================================== host side
+namespace {
+
+struct ResultBatch {  // one probe batch worth of joined rows
+    int64_t rows = 0, cursor = 0;
+    std::vector<DevBuf> data;        // per output column, device
+    std::vector<DevBuf> notnull;     // per output column, device byte flags (cap 0 => column has no NULLs)
+    std::vector<DevBuf> bitmap;      // packed null bitmaps (device)
+    bool on_host = false;
+    std::vector<PinnedBuf> hdata, hbitmap;
+    void release() {
+        for (auto& b : data) b.release();
+        for (auto& b : notnull) b.release();
+        for (auto& b : bitmap) b.release();
+        for (auto& b : hdata) b.release();
+        for (auto& b : hbitmap) b.release();
+    }
+};
+
+}  // namespace
+
+struct tsq_join {
+    tsq_handle_hdr hdr;
+    tsq_ctx* ctx = nullptr;
+    tsq_join_cfg cfg;
+    std::vector<tsq_expr_prog> conds_h, filters_h;
+    DevBuf conds_d, filters_d;
+    std::atomic<int> cancelled{0};
+
+    // build side
+    std::vector<ColStore> bcols;
+    bool build_done = false;
+    bool never_match = false;  // key classes differ (int vs float): no row can ever match
+    bool multi = false;
+    KeySpec ks{};
+    DevBuf tkeys, tvals, sent;
+    uint64_t nbuckets = 0;
+    uint32_t sent_count = 0;
+    int64_t build_inserted = 0;
+
+    // host staging (shared by build and probe pushes; one side is active at a time)
+    HostStage stage;
+
+    // probe side device batch (for host pushes)
+    std::vector<ColStore> pcols;
+    DevBuf psel;
+    bool probe_done = false;
+    bool host_mode = true;  // result placement follows the first probe push
+    bool general = false;   // needs the GEN kernels (outer join / filters / conditions / selected)
+    bool count_only = false, checksum = false;
+    DevBuf counters;        // 8 x u64 on device
+    int64_t total_out = 0;  // emit mode: rows produced so far
+    std::deque<std::unique_ptr<ResultBatch>> results;
+
+    // stats
+    tsq_stats st{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_build_ev = false, have_probe_ev = false;
+    double probe_ms_acc = 0;
+};
+
+namespace {
+
+tsq_status check_cancel(tsq_join* j) {
+    if (j->cancelled.load()) return tsq_fail(&j->hdr, TSQ_ERR_CANCELLED, "join cancelled");
+    return TSQ_OK;
+}
+
+bool is_int_class(int32_t t) { return t == TSQ_I64 || t == TSQ_U64; }
+
+tsq_status build_flush(tsq_join* j) {
+    HostStage& sg = j->stage;
+    if (sg.staged == 0) return TSQ_OK;
+    DevBuf tmp;
+    for (size_t c = 0; c < j->bcols.size(); c++) {
+        tsq_status s = tsq_col_append(j->ctx, &j->hdr, j->bcols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
+        if (s != TSQ_OK) { tmp.release(); return s; }
+        j->st.h2d_bytes += sg.staged * j->bcols[c].elem();
+    }
+    hipError_t e = hipStreamSynchronize(j->ctx->stream);  // staging memory is reused
+    tmp.release();
+    sg.reset();
+    if (e != hipSuccess) return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return TSQ_OK;
+}
+
+template <bool MULTI>
+tsq_status launch_build(tsq_join* j, BuildArgs& a) {
+    int grid = tsq_grid_for(j->ctx, a.nrows, 256);
+    hipLaunchKernelGGL(k_build_insert<MULTI>, dim3(grid), dim3(256), 0, j->ctx->stream, a);
+    TSQ_HIP(&j->hdr, hipGetLastError());
+    j->st.kernel_launches++;
+    return TSQ_OK;
+}
+
+void fill_table(tsq_join* j, JoinTable& t) {
+    t.keys = j->tkeys.as<uint64_t>();
+    t.vals = j->tvals.as<uint32_t>();
+    t.nbuckets = j->nbuckets;
+    t.sent_rows = j->sent.as<uint32_t>();
+    t.sent_count = j->sent_count;
+}
+
+// decode the device error word into a status (first offending node, then row)
+tsq_status status_from_errword(tsq_join* j, uint64_t w) {
+    if (w == TSQ_ERRWORD_NONE) return TSQ_OK;
+    tsq_status s = (tsq_status)(w & 15);
+    char buf[160];
+    snprintf(buf, sizeof buf, "expression error %d in join condition/filter (conjunct %d, node %d, probe row %llu)", (int)s,
+             (int)(w >> 58), (int)((w >> 52) & 63), (unsigned long long)((w >> 4) & 0xffffffffffffULL));
+    return tsq_fail(&j->hdr, s, buf);
+}
+
+tsq_status reset_counters(tsq_join* j, bool only_batch) {
+    // counters[3] (err word) starts at all ones; [5] (emit cursor) is per batch
+    unsigned long long init[8] = {0, 0, 0, TSQ_ERRWORD_NONE, 0, 0, 0, 0};
+    if (only_batch) {
+        TSQ_HIP(&j->hdr, hipMemsetAsync((char*)j->counters.p + 5 * 8, 0, 8, j->ctx->stream));
+        return TSQ_OK;
+    }
+    memcpy(j->ctx->pinned, init, sizeof init);
+    TSQ_HIP(&j->hdr, hipMemcpyAsync(j->counters.p, j->ctx->pinned, sizeof init, hipMemcpyHostToDevice, j->ctx->stream));
+    TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
+    return TSQ_OK;
+}
+
+tsq_status read_counters(tsq_join* j, unsigned long long* out8) {
+    TSQ_HIP(&j->hdr, hipMemcpyAsync(j->ctx->pinned, j->counters.p, 8 * 8, hipMemcpyDeviceToHost, j->ctx->stream));
+    TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
+    memcpy(out8, j->ctx->pinned, 64);
+    return TSQ_OK;
+}
+
+template <bool MULTI, bool GEN>
+tsq_status launch_count(tsq_join* j, ProbeArgs& a, bool chk) {
+    int grid = tsq_grid_for(j->ctx, a.nrows, 256);
+    if (chk) hipLaunchKernelGGL((k_probe_count<MULTI, GEN, true>), dim3(grid), dim3(256), 0, j->ctx->stream, a);
+    else hipLaunchKernelGGL((k_probe_count<MULTI, GEN, false>), dim3(grid), dim3(256), 0, j->ctx->stream, a);
+    TSQ_HIP(&j->hdr, hipGetLastError());
+    j->st.kernel_launches++;
+    return TSQ_OK;
+}
+tsq_status dispatch_count(tsq_join* j, ProbeArgs& a, bool chk) {
+    if (j->multi) return j->general ? launch_count<true, true>(j, a, chk) : launch_count<true, false>(j, a, chk);
+    return j->general ? launch_count<false, true>(j, a, chk) : launch_count<false, false>(j, a, chk);
+}
+tsq_status dispatch_emit(tsq_join* j, ProbeArgs& a) {
+    int grid = tsq_grid_for(j->ctx, a.nrows, 256);
+    if (j->multi) {
+        if (j->general) hipLaunchKernelGGL((k_probe_emit<true, true>), dim3(grid), dim3(256), 0, j->ctx->stream, a);
+        else hipLaunchKernelGGL((k_probe_emit<true, false>), dim3(grid), dim3(256), 0, j->ctx->stream, a);
+    } else {
+        if (j->general) hipLaunchKernelGGL((k_probe_emit<false, true>), dim3(grid), dim3(256), 0, j->ctx->stream, a);
+        else hipLaunchKernelGGL((k_probe_emit<false, false>), dim3(grid), dim3(256), 0, j->ctx->stream, a);
+    }
+    TSQ_HIP(&j->hdr, hipGetLastError());
+    j->st.kernel_launches++;
+    return TSQ_OK;
+}
+
+// run the probe kernels over one device-resident batch described by pcs / selected
+tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
+    if (nrows == 0) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    ProbeArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = pcs;
+    tsq_fill_colset(a.b, j->bcols);
+    a.ks = j->ks;
+    fill_table(j, a.t);
+    a.nrows = nrows;
+    a.selected = selected_dev;
+    a.filters = j->filters_d.as<tsq_expr_prog>();
+    a.n_filters = (int32_t)j->filters_h.size();
+    a.conds = j->conds_d.as<tsq_expr_prog>();
+    a.n_conds = (int32_t)j->conds_h.size();
+    a.join_type = j->cfg.join_type;
+    a.probe_is_left = j->cfg.build_is_right ? 1 : 0;
+    a.counters = j->counters.as<unsigned long long>();
+    j->st.probe_rows += nrows;
+
+    TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
+    if (j->count_only) {
+        TSQ_TRY(dispatch_count(j, a, j->checksum));
+        TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    // emit mode: size the batch first (K3), then materialise (K4)
+    unsigned long long before[8], after[8];
+    TSQ_TRY(read_counters(j, before));
+    TSQ_TRY(dispatch_count(j, a, false));
+    TSQ_TRY(read_counters(j, after));
+    TSQ_TRY(status_from_errword(j, after[3]));
+    const int64_t out_rows = (int64_t)(after[0] - before[0]);
+    if (out_rows == 0) {
+        TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    const int nout = j->cfg.n_probe_cols + j->cfg.n_build_cols;
+    std::unique_ptr<ResultBatch> rb(new ResultBatch());
+    rb->rows = out_rows;
+    rb->data.resize(nout);
+    rb->notnull.resize(nout);
+    rb->bitmap.resize(nout);
+    const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
+    const int nl = a.probe_is_left ? j->cfg.n_probe_cols : j->cfg.n_build_cols;
+    for (int oc = 0; oc < nout; oc++) {
+        const bool from_probe = a.probe_is_left ? oc < nl : oc >= nl;
+        const int sc = oc < nl ? oc : oc - nl;
+        const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
+        const bool src_nulls = from_probe ? pcs.nulls[sc] != nullptr : j->bcols[sc].has_nulls;
+        const bool may_null = src_nulls || (outer && !from_probe);
+        tsq_status s = rb->data[oc].reserve(ctx, &j->hdr, (size_t)out_rows * tsq_elem_size(type) + 16);
+        if (s == TSQ_OK && may_null) s = rb->notnull[oc].reserve(ctx, &j->hdr, (size_t)out_rows + 16);
+        if (s != TSQ_OK) { rb->release(); return s; }
+        a.out_data[oc] = rb->data[oc].p;
+        a.out_notnull[oc] = may_null ? rb->notnull[oc].as<uint8_t>() : nullptr;
+    }
+    TSQ_TRY(reset_counters(j, true));
+    TSQ_TRY(dispatch_emit(j, a));
+    for (int oc = 0; oc < nout; oc++) {
+        if (!a.out_notnull[oc]) continue;
+        tsq_status s = rb->bitmap[oc].reserve(ctx, &j->hdr, tsq_bitmap_bytes(out_rows) + 16);
+        if (s == TSQ_OK) s = tsq_launch_pack_bitmap(ctx, &j->hdr, a.out_notnull[oc], rb->bitmap[oc].as<uint8_t>(), out_rows);
+        if (s != TSQ_OK) { rb->release(); return s; }
+    }
+    TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
+    j->have_probe_ev = true;
+    if (j->host_mode) {  // bring the batch to pinned host memory once; pulls are then plain memcpy
+        rb->hdata.resize(nout);
+        rb->hbitmap.resize(nout);
+        for (int oc = 0; oc < nout; oc++) {
+            const bool from_probe = a.probe_is_left ? oc < nl : oc >= nl;
+            const int sc = oc < nl ? oc : oc - nl;
+            const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
+            size_t bytes = (size_t)out_rows * tsq_elem_size(type);
+            tsq_status s = rb->hdata[oc].reserve(&j->hdr, bytes + 16);
+            if (s != TSQ_OK) { rb->release(); return s; }
+            TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            j->st.d2h_bytes += bytes;
+            if (a.out_notnull[oc]) {
+                s = rb->hbitmap[oc].reserve(&j->hdr, tsq_bitmap_bytes(out_rows) + 16);
+                if (s != TSQ_OK) { rb->release(); return s; }
+                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hbitmap[oc].p, rb->bitmap[oc].p, tsq_bitmap_bytes(out_rows), hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
+        TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
+        for (auto& b : rb->data) b.release();
+        for (auto& b : rb->notnull) b.release();
+        for (auto& b : rb->bitmap) b.release();
+        rb->on_host = true;
+    } else {
+        TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
+        for (auto& b : rb->notnull) b.release();
+    }
+    j->total_out += out_rows;
+    j->st.out_rows += out_rows;
+    j->results.push_back(std::move(rb));
+    return TSQ_OK;
+}
+
+tsq_status probe_flush(tsq_join* j) {
+    HostStage& sg = j->stage;
+    if (sg.staged == 0) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    DevBuf tmp;
+    for (size_t c = 0; c < j->pcols.size(); c++) {
+        j->pcols[c].rows = 0;
+        j->pcols[c].has_nulls = false;
+        tsq_status s = tsq_col_append(ctx, &j->hdr, j->pcols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
+        if (s != TSQ_OK) { tmp.release(); return s; }
+        j->st.h2d_bytes += sg.staged * j->pcols[c].elem();
+    }
+    const uint8_t* sel_dev = nullptr;
+    if (sg.sel_any) {
+        tsq_status s = j->psel.reserve(ctx, &j->hdr, (size_t)sg.staged + 16);
+        if (s != TSQ_OK) { tmp.release(); return s; }
+        hipError_t e = hipMemcpyAsync(j->psel.p, sg.sel.p, (size_t)sg.staged, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { tmp.release(); return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipMemcpyAsync(sel): ") + hipGetErrorString(e)); }
+        sel_dev = j->psel.as<uint8_t>();
+    }
+    tsq_colset pcs;
+    tsq_fill_colset(pcs, j->pcols);
+    tsq_status s = probe_batch(j, pcs, sg.staged, sel_dev);
+    // staging (pinned) memory is reused by the next pushes: wait for the H2D copies
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    tmp.release();
+    sg.reset();
+    if (s != TSQ_OK) return s;
+    if (e != hipSuccess) return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return TSQ_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C-ABI
+TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_join** out) {
+    if (!ctx || !cfg || !out) return tsq_fail(nullptr, TSQ_ERR_INVALID, "tsq_join_create: NULL argument");
+    *out = nullptr;
+    tsq_handle_hdr* ch = &ctx->hdr;
+    if (cfg->join_type < TSQ_JOIN_INNER || cfg->join_type > TSQ_JOIN_RIGHT_OUTER)
+        return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "only inner/left outer/right outer joins exist (joiner.go:105-116)");
+    // outer joins: the probe side is the outer side (join.go:31-60): left outer => build is right
+    if (cfg->join_type == TSQ_JOIN_LEFT_OUTER && !cfg->build_is_right)
+        return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "left outer join must build on the right child");
+    if (cfg->join_type == TSQ_JOIN_RIGHT_OUTER && cfg->build_is_right)
+        return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "right outer join must build on the left child");
+    if (cfg->n_keys < 1 || cfg->n_keys > TSQ_MAX_KEYS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..4 join key columns supported");
+    if (cfg->n_build_cols < 1 || cfg->n_build_cols > TSQ_MAX_COLS || cfg->n_probe_cols < 1 || cfg->n_probe_cols > TSQ_MAX_COLS)
+        return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 columns per side supported");
+    for (int c = 0; c < cfg->n_build_cols; c++)
+        if (cfg->build_types[c] < TSQ_I64 || cfg->build_types[c] > TSQ_F64)
+            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len build column: fall back to the Go operator");
+    for (int c = 0; c < cfg->n_probe_cols; c++)
+        if (cfg->probe_types[c] < TSQ_I64 || cfg->probe_types[c] > TSQ_F64)
+            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len probe column: fall back to the Go operator");
+    for (int k = 0; k < cfg->n_keys; k++) {
+        if (cfg->build_key_idx[k] < 0 || cfg->build_key_idx[k] >= cfg->n_build_cols || cfg->probe_key_idx[k] < 0 ||
+            cfg->probe_key_idx[k] >= cfg->n_probe_cols)
+            return tsq_fail(ch, TSQ_ERR_INVALID, "join key index out of range");
+    }
+    if ((cfg->n_other_conds > 0 && !cfg->other_conds) || (cfg->n_outer_filters > 0 && !cfg->outer_filters) ||
+        cfg->n_other_conds < 0 || cfg->n_outer_filters < 0 || cfg->n_other_conds > 16 || cfg->n_outer_filters > 16)
+        return tsq_fail(ch, TSQ_ERR_INVALID, "bad condition/filter list");
+    const int nleft = cfg->build_is_right ? cfg->n_probe_cols : cfg->n_build_cols;
+    (void)nleft;
+    for (int e = 0; e < cfg->n_other_conds; e++) {
+        const char* why = "";
+        tsq_status s = tsq_validate_prog(cfg->other_conds[e], cfg->n_probe_cols + cfg->n_build_cols, &why);
+        if (s != TSQ_OK) return tsq_fail(ch, s, std::string("other condition: ") + why);
+    }
+    for (int e = 0; e < cfg->n_outer_filters; e++) {
+        const char* why = "";
+        tsq_status s = tsq_validate_prog(cfg->outer_filters[e], cfg->n_probe_cols, &why);
+        if (s != TSQ_OK) return tsq_fail(ch, s, std::string("outer filter: ") + why);
+    }
+    TSQ_HIP(ch, hipSetDevice(ctx->device));
+    std::unique_ptr<tsq_join> j(new tsq_join());
+    j->hdr.magic = TSQ_MAGIC_JOIN;
+    j->ctx = ctx;
+    j->cfg = *cfg;
+    j->conds_h.assign(cfg->other_conds, cfg->other_conds + cfg->n_other_conds);
+    j->filters_h.assign(cfg->outer_filters, cfg->outer_filters + cfg->n_outer_filters);
+    j->cfg.other_conds = nullptr;
+    j->cfg.outer_filters = nullptr;
+    if (j->cfg.max_chunk_size <= 0) j->cfg.max_chunk_size = 1024;
+    if (j->cfg.probe_batch_rows <= 0) j->cfg.probe_batch_rows = 4 << 20;
+    j->cfg.probe_batch_rows = (j->cfg.probe_batch_rows + 63) & ~(int64_t)63;
+
+    j->bcols.resize(cfg->n_build_cols);
+    for (int c = 0; c < cfg->n_build_cols; c++) j->bcols[c].type = cfg->build_types[c];
+    j->pcols.resize(cfg->n_probe_cols);
+    for (int c = 0; c < cfg->n_probe_cols; c++) j->pcols[c].type = cfg->probe_types[c];
+
+    // key plan
+    KeySpec& ks = j->ks;
+    ks.n_keys = cfg->n_keys;
+    j->multi = cfg->n_keys > 1;
+    for (int k = 0; k < cfg->n_keys; k++) {
+        ks.bidx[k] = cfg->build_key_idx[k];
+        ks.pidx[k] = cfg->probe_key_idx[k];
+        const int32_t bt = cfg->build_types[ks.bidx[k]], pt = cfg->probe_types[ks.pidx[k]];
+        if (is_int_class(bt) != is_int_class(pt)) j->never_match = true;  // flag 8/9 vs 5 (codec.go:217-235)
+        if (!j->multi && is_int_class(bt) && bt != pt) ks.skip_high = 1;  // flag 8 vs 9 for cells >= 2^63
+    }
+    j->general = cfg->join_type != TSQ_JOIN_INNER || cfg->n_other_conds > 0 || cfg->n_outer_filters > 0;
+
+    tsq_handle_hdr* h = &j->hdr;
+    TSQ_TRY(j->counters.reserve(ctx, h, 64));
+    if (!j->conds_h.empty()) {
+        TSQ_TRY(j->conds_d.reserve(ctx, h, j->conds_h.size() * sizeof(tsq_expr_prog)));
+        TSQ_HIP(h, hipMemcpy(j->conds_d.p, j->conds_h.data(), j->conds_h.size() * sizeof(tsq_expr_prog), hipMemcpyHostToDevice));
+    }
+    if (!j->filters_h.empty()) {
+        TSQ_TRY(j->filters_d.reserve(ctx, h, j->filters_h.size() * sizeof(tsq_expr_prog)));
+        TSQ_HIP(h, hipMemcpy(j->filters_d.p, j->filters_h.data(), j->filters_h.size() * sizeof(tsq_expr_prog), hipMemcpyHostToDevice));
+    }
+    for (int i = 0; i < 4; i++) TSQ_HIP(h, hipEventCreate(&j->ev[i]));
+    {
+        tsq_status s = reset_counters(j.get(), false);
+        if (s != TSQ_OK) { tsq_fail(ch, s, j->hdr.err); return s; }
+    }
+    *out = j.release();
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t n_cols, int64_t nrows) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    TSQ_TRY(check_cancel(j));
+    if (j->build_done) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "build_push after build_finish");
+    if (nrows < 0 || (!cols && nrows > 0)) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "bad arguments");
+    if (nrows == 0) return TSQ_OK;
+    bool dev = false;
+    TSQ_TRY(tsq_validate_cols(&j->hdr, cols, n_cols, j->cfg.n_build_cols, j->cfg.build_types, nrows, &dev));
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    if (j->bcols[0].rows + j->stage.staged + nrows >= 0xfffffff0LL)
+        return tsq_fail(&j->hdr, TSQ_ERR_UNSUPPORTED, "build side exceeds 2^32 rows per GPU: partition across GPUs first");
+    if (dev) {
+        TSQ_TRY(build_flush(j));
+        DevBuf tmp;
+        for (int c = 0; c < n_cols; c++) {
+            tsq_status s = tsq_col_append(j->ctx, &j->hdr, j->bcols[c], cols[c].data, cols[c].null_bitmap, nrows, true, tmp);
+            if (s != TSQ_OK) { tmp.release(); return s; }
+        }
+        tmp.release();
+        return TSQ_OK;
+    }
+    if (j->stage.cap == 0) TSQ_TRY(j->stage.init(&j->hdr, n_cols, j->cfg.build_types, 1 << 20));
+    int64_t off = 0;
+    while (off < nrows) {
+        int64_t n = std::min<int64_t>(nrows - off, j->stage.room());
+        j->stage.add(cols, off, n, nullptr);
+        off += n;
+        if (j->stage.room() == 0) TSQ_TRY(build_flush(j));
+    }
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    TSQ_TRY(check_cancel(j));
+    if (j->build_done) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    TSQ_TRY(build_flush(j));
+    const int64_t nb = j->bcols[0].rows;
+    j->st.build_rows = nb;
+    // size: load factor <= 0.5 over 8-slot buckets (est_build_rows is only a hint, hash_table.go:84-96)
+    uint64_t nbuckets = (uint64_t)((nb + 3) / 4);
+    if (nbuckets < 16) nbuckets = 16;
+    j->nbuckets = nbuckets;
+    TSQ_TRY(j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8));
+    TSQ_TRY(j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4));
+    j->st.table_bytes = (int64_t)(nbuckets * TSQ_BUCKET * 12);
+    j->st.table_buckets = (int64_t)nbuckets;
+    TSQ_HIP(h, hipMemsetAsync(j->tkeys.p, 0x80, nbuckets * TSQ_BUCKET * 8, ctx->stream));
+    uint32_t sent_cap = 1024;
+    TSQ_TRY(j->sent.reserve(ctx, h, sent_cap * 4));
+    // dscratch[0] = inserted (u64), dscratch[1] low = sent_total (u32)
+    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch, 0, 16, ctx->stream));
+    j->sent_count = 0;
+    if (nb > 0 && !j->never_match) {
+        BuildArgs a;
+        memset(&a, 0, sizeof a);
+        tsq_fill_colset(a.b, j->bcols);
+        a.ks = j->ks;
+        fill_table(j, a.t);
+        a.row0 = 0;
+        a.nrows = nb;
+        a.sent_rows = j->sent.as<uint32_t>();
+        a.sent_cap = sent_cap;
+        a.sent_total = (uint32_t*)(ctx->dscratch + 1);
+        a.inserted = (unsigned long long*)ctx->dscratch;
+        TSQ_HIP(h, hipEventRecord(j->ev[0], ctx->stream));
+        if (j->multi) TSQ_TRY(launch_build<true>(j, a));
+        else TSQ_TRY(launch_build<false>(j, a));
+        TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
+        j->have_build_ev = true;
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, ctx->dscratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        j->build_inserted = (int64_t)ctx->pinned[0];
+        uint32_t sent_total = (uint32_t)ctx->pinned[1];
+        if (sent_total > sent_cap) {  // rare: many rows carry the sentinel key word — collect them all
+            TSQ_TRY(j->sent.reserve(ctx, h, (size_t)sent_total * 4));
+            TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 1, 0, 8, ctx->stream));
+            a.sent_rows = j->sent.as<uint32_t>();
+            a.sent_cap = sent_total;
+            int grid = tsq_grid_for(ctx, nb, 256);
+            if (j->multi) hipLaunchKernelGGL(k_collect_sentinel<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_collect_sentinel<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+            TSQ_HIP(h, hipGetLastError());
+            TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        }
+        j->sent_count = sent_total;
+    } else {
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    }
+    j->st.build_rows_inserted = j->build_inserted;
+    j->build_done = true;
+    j->stage.release();  // staging is re-initialised for the probe schema
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_set_count_only(tsq_join* j, int32_t on) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (j->st.probe_rows > 0 || j->stage.staged > 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "count-only must be chosen before the first probe row");
+    j->count_only = on != 0;
+    if (!j->count_only) j->checksum = false;
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (!j->count_only) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "checksum needs count-only mode");
+    j->checksum = on != 0;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t n_cols, int64_t nrows, const uint8_t* selected) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    TSQ_TRY(check_cancel(j));
+    if (!j->build_done) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "probe_push before build_finish");
+    if (j->probe_done) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "probe_push after probe_finish");
+    if (nrows < 0 || (!cols && nrows > 0)) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "bad arguments");
+    if (nrows == 0) return TSQ_OK;
+    bool dev = false;
+    TSQ_TRY(tsq_validate_cols(&j->hdr, cols, n_cols, j->cfg.n_probe_cols, j->cfg.probe_types, nrows, &dev));
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    if (j->st.probe_rows == 0 && j->stage.staged == 0) j->host_mode = !dev;
+    if (selected) j->general = true;
+    if (dev) {
+        TSQ_TRY(probe_flush(j));
+        tsq_colset pcs;
+        tsq_colset_from_cols(pcs, cols, n_cols);
+        // process in slices so an emit batch stays bounded
+        const int64_t slice = j->count_only ? nrows : j->cfg.probe_batch_rows;
+        for (int64_t off = 0; off < nrows; off += slice) {
+            const int64_t n = std::min<int64_t>(slice, nrows - off);
+            tsq_colset s;
+            tsq_colset_slice(s, pcs, off);  // slices are multiples of 64 rows
+            TSQ_TRY(check_cancel(j));
+            TSQ_TRY(probe_batch(j, s, n, selected ? selected + off : nullptr));
+        }
+        return TSQ_OK;
+    }
+    if (j->stage.cap == 0) TSQ_TRY(j->stage.init(&j->hdr, n_cols, j->cfg.probe_types, j->cfg.probe_batch_rows));
+    int64_t off = 0;
+    while (off < nrows) {
+        int64_t n = std::min<int64_t>(nrows - off, j->stage.room());
+        j->stage.add(cols, off, n, selected);
+        off += n;
+        if (j->stage.room() == 0) {
+            TSQ_TRY(check_cancel(j));
+            TSQ_TRY(probe_flush(j));
+        }
+    }
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_probe_finish(tsq_join* j) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    TSQ_TRY(check_cancel(j));
+    if (!j->build_done) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "probe_finish before build_finish");
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    TSQ_TRY(probe_flush(j));
+    j->probe_done = true;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows, int64_t* nrows_out, int32_t* eos) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (!nrows_out || !eos) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "NULL out pointer");
+    *nrows_out = 0;
+    *eos = 0;
+    TSQ_TRY(check_cancel(j));
+    if (j->count_only) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull in count-only mode");
+    const int nout = j->cfg.n_probe_cols + j->cfg.n_build_cols;
+    if (n_cols != nout) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: column count must be n_probe_cols + n_build_cols");
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    while (!j->results.empty() && j->results.front()->cursor >= j->results.front()->rows) {
+        j->results.front()->release();
+        j->results.pop_front();
+    }
+    if (j->results.empty()) {
+        if (j->probe_done) *eos = 1;
+        return TSQ_OK;
+    }
+    ResultBatch* rb = j->results.front().get();
+    const int64_t n = std::min<int64_t>(cap_rows, rb->rows - rb->cursor);
+    if (n <= 0) return TSQ_OK;
+    const bool probe_is_left = j->cfg.build_is_right != 0;
+    const int nl = probe_is_left ? j->cfg.n_probe_cols : j->cfg.n_build_cols;
+    for (int oc = 0; oc < nout; oc++) {
+        const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
+        const int sc = oc < nl ? oc : oc - nl;
+        const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
+        const int es = tsq_elem_size(type);
+        tsq_col& o = out_cols[oc];
+        const bool odev = o.flags & TSQ_COL_DEVICE;
+        if (!o.data) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: out column data == NULL");
+        const bool has_bm = rb->on_host ? rb->hbitmap[oc].p != nullptr : rb->bitmap[oc].p != nullptr;
+        if (rb->on_host && !odev) {
+            memcpy(o.data, (const char*)rb->hdata[oc].p + (size_t)rb->cursor * es, (size_t)n * es);
+            if (o.null_bitmap) {
+                if (!has_bm) memset(o.null_bitmap, 0xff, tsq_bitmap_bytes(n));
+                else if ((rb->cursor & 7) == 0) {
+                    memcpy(o.null_bitmap, (const uint8_t*)rb->hbitmap[oc].p + (rb->cursor >> 3), tsq_bitmap_bytes(n));
+                } else {
+                    const uint8_t* src = (const uint8_t*)rb->hbitmap[oc].p;
+                    memset(o.null_bitmap, 0, tsq_bitmap_bytes(n));
+                    for (int64_t i = 0; i < n; i++) {
+                        const int64_t s = rb->cursor + i;
+                        if ((src[s >> 3] >> (s & 7)) & 1) o.null_bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+                    }
+                }
+            } else if (has_bm) {
+                return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: column may contain NULLs but no null_bitmap buffer was given");
+            }
+        } else if (!rb->on_host && odev) {
+            TSQ_HIP(&j->hdr, hipMemcpyAsync(o.data, (const char*)rb->data[oc].p + (size_t)rb->cursor * es, (size_t)n * es, hipMemcpyDeviceToDevice, j->ctx->stream));
+            if (o.null_bitmap) {
+                if ((rb->cursor & 7) != 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "device pull: cap_rows must keep the cursor a multiple of 8");
+                if (!has_bm) TSQ_HIP(&j->hdr, hipMemsetAsync(o.null_bitmap, 0xff, tsq_bitmap_bytes(n), j->ctx->stream));
+                else TSQ_HIP(&j->hdr, hipMemcpyAsync(o.null_bitmap, rb->bitmap[oc].as<uint8_t>() + (rb->cursor >> 3), tsq_bitmap_bytes(n), hipMemcpyDeviceToDevice, j->ctx->stream));
+            } else if (has_bm) {
+                return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: column may contain NULLs but no null_bitmap buffer was given");
+            }
+        } else {
+            return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: output placement (host/device) must match the probe pushes");
+        }
+        o.length = n;
+        o.type = type;
+        o.elem_size = es;
+    }
+    if (!rb->on_host) TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
+    rb->cursor += n;
+    *nrows_out = n;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_count(tsq_join* j, int64_t* rows_out) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN || !rows_out) return TSQ_ERR_INVALID;
+    TSQ_TRY(check_cancel(j));
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    if (!j->count_only) {
+        *rows_out = j->total_out;
+        return TSQ_OK;
+    }
+    unsigned long long c[8];
+    TSQ_TRY(read_counters(j, c));
+    TSQ_TRY(status_from_errword(j, c[3]));
+    *rows_out = (int64_t)c[0];
+    j->st.out_rows = (int64_t)c[0];
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_checksum(tsq_join* j, uint64_t* sum_out, uint64_t* xor_out) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN || !sum_out || !xor_out) return TSQ_ERR_INVALID;
+    if (!j->count_only || !j->checksum) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "checksum mode is not enabled");
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    unsigned long long c[8];
+    TSQ_TRY(read_counters(j, c));
+    TSQ_TRY(status_from_errword(j, c[3]));
+    *sum_out = c[1];
+    *xor_out = c[2];
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_cancel(tsq_join* j) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    j->cancelled.store(1);
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN || !out) return TSQ_ERR_INVALID;
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
+    float ms = 0;
+    if (j->have_build_ev && hipEventElapsedTime(&ms, j->ev[0], j->ev[1]) == hipSuccess) j->st.build_kernel_ms = ms;
+    if (j->have_probe_ev && hipEventElapsedTime(&ms, j->ev[2], j->ev[3]) == hipSuccess) j->st.probe_kernel_ms = ms;
+    *out = j->st;
+    return TSQ_OK;
+}
+
+TSQ_API void tsq_join_destroy(tsq_join* j) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return;
+    (void)hipSetDevice(j->ctx->device);
+    (void)hipStreamSynchronize(j->ctx->stream);  // Close() drains in-flight work (join.go:81-107)
+    for (auto& c : j->bcols) c.release();
+    for (auto& c : j->pcols) c.release();
+    for (auto& r : j->results) r->release();
+    j->results.clear();
+    j->tkeys.release();
+    j->tvals.release();
+    j->sent.release();
+    j->psel.release();
+    j->counters.release();
+    j->conds_d.release();
+    j->filters_d.release();
+    j->stage.release();
+    for (int i = 0; i < 4; i++)
+        if (j->ev[i]) (void)hipEventDestroy(j->ev[i]);
+    j->hdr.magic = 0;
+    delete j;
+}
