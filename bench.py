@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py — probed rows/sec on an int64-key inner hash join (BASELINE.json metric).
+
+Workload (N = 1): `SELECT count(*) FROM probe JOIN build ON probe.k = build.k`, 1e8 ⋈ 1e8 rows of
+(k int64, v int64) per side, J-uniq-shuffled: build keys are a bijection of
+[0, N_b) in pseudo-random order, probe keys are uniform in [0, N_b) (hit ratio 1.0), generated on
+the device so the tables never cross PCIe.  The build side is built once and stays resident in
+HBM; one "step" = one probe pass of all N_p probe rows through libtsq (K3 k_probe_count).
+N > 1: weak scaling — every rank owns N_b build and N_p probe rows; rows are redistributed by
+hash-radix with an RCCL all-to-all (tinysql_amd/parallel.py); a step = split + exchange + local
+probe of the probe side; the build side is redistributed and built once (untimed, resident).
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of the probe kernel
+(24 B per probe row: 8 B key + one 16 B slot) / its average HIP-event duration.
+`cpu_baseline` = the oracle's C++ restatement of the reference algorithm (oracle/, test
+infrastructure — used here only as the reported baseline) timed on the host cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--build-rows", type=int, default=100_000_000)
+    ap.add_argument("--probe-rows", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-build-rows", type=int, default=10_000_000)
+    ap.add_argument("--cpu-probe-rows", type=int, default=20_000_000)
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even with one rank (validation)")
+    args = ap.parse_args()
+
+    n_gpus = args.gpus
+    distributed = n_gpus > 1 or args.force_dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch = dist = None
+    if distributed:
+        # torch FIRST: it bundles its own libamdhip64.so.7; loading it before libtsq makes both share
+        # one HIP runtime in this process (see DESIGN.md "Process model").
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        assert world == n_gpus or args.force_dist, "WORLD_SIZE must equal --gpus"
+
+    from tinysql_amd import _abi as abi
+    from tinysql_amd import _lib
+
+    ctx = _lib.Context(local_rank)
+    lib = ctx.lib
+    if distributed:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    nb, npr = args.build_rows, args.probe_rows  # per GPU
+    nb_global = nb * world
+    t_setup = time.time()
+
+    def spec(kind, **kw):
+        s = abi.GenSpec()
+        s.kind, s.seed = kind, 42
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+    def dev_col(ptr, n):
+        c = abi.Col()
+        c.data, c.length, c.elem_size, c.type, c.flags = ptr, n, 8, abi.I64, abi.COL_DEVICE
+        return c
+
+    # ---------------------------------------------------------------- tables on device
+    if distributed:
+        bk_t = torch.empty(nb, dtype=torch.int64, device="cuda")
+        bv_t = torch.empty(nb, dtype=torch.int64, device="cuda")
+        pk_t = torch.empty(npr, dtype=torch.int64, device="cuda")
+        bk, bv, pk = bk_t.data_ptr(), bv_t.data_ptr(), pk_t.data_ptr()
+        pv = None
+    else:
+        bk, bv, pk, pv = (ctx.alloc(nb * 8), ctx.alloc(nb * 8), ctx.alloc(npr * 8), ctx.alloc(npr * 8))
+    a_mult = 2654435761  # odd, not a multiple of 5: coprime with 10^k sizes -> bijection on [0, nb_global)
+    assert nb_global < (1 << 31)
+    ctx.gen_column(spec(abi.GEN_AFFINE, table=2, a=a_mult, b=12345, m=nb_global, start=rank * nb), nb, bk)
+    ctx.gen_column(spec(abi.GEN_HASH_OF_COL, table=2, b=0xABCDEF), nb, bv, src=bk)
+    ctx.gen_column(spec(abi.GEN_RAND_MOD, table=1, col=0, m=nb_global, start=rank * npr), npr, pk)
+    if pv:
+        ctx.gen_column(spec(abi.GEN_RAND_MOD, table=1, col=1, m=1 << 62, start=rank * npr), npr, pv)
+    ctx.sync()
+
+    # ---------------------------------------------------------------- build (resident in HBM)
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys = abi.JOIN_INNER, 1, 1
+    cfg.n_build_cols = 2
+    cfg.n_probe_cols = 1 if distributed else 2  # COUNT(*) needs only the key on the exchanged probe side
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    cfg.max_chunk_size, cfg.concurrency = 1024, 5
+    h = C.c_void_p()
+    _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    if distributed:
+        from tinysql_amd import parallel
+        (rbk, rbv), nb_local = parallel.redistribute(ctx, dist, torch, [bk_t, bv_t], [abi.I64, abi.I64], 0, 0, nb)
+        torch.cuda.synchronize()
+        bcols = (abi.Col * 2)(dev_col(rbk.data_ptr(), nb_local), dev_col(rbv.data_ptr(), nb_local))
+    else:
+        nb_local = nb
+        bcols = (abi.Col * 2)(dev_col(bk, nb), dev_col(bv, nb))
+    t0 = time.time()
+    _lib.check(lib.tsq_join_build_push(h, bcols, 2, nb_local), h)
+    _lib.check(lib.tsq_join_build_finish(h), h)
+    ctx.sync()
+    build_wall_ms = (time.time() - t0) * 1e3
+    _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+
+    if distributed:
+        from tinysql_amd import parallel
+
+        def step():
+            (rpk,), n_local = parallel.redistribute(ctx, dist, torch, [pk_t], [abi.I64], 0, 0, npr)
+            pc = (abi.Col * 1)(dev_col(rpk.data_ptr(), n_local))
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, n_local, None), h)
+            return rpk  # keep alive until the stream has consumed it
+
+        def full_sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        pcols = (abi.Col * 2)(dev_col(pk, npr), dev_col(pv, npr))
+
+        def step():
+            _lib.check(lib.tsq_join_probe_push(h, pcols, 2, npr, None), h)
+
+        def full_sync():
+            # single process, single stream: hipStreamSynchronize of the only stream with work
+            # (== torch.cuda.synchronize() for this process; torch is not loaded at N=1)
+            ctx.sync()
+
+    keep = []
+    for _ in range(args.warmup):
+        keep.append(step())
+    full_sync()
+    keep.clear()
+    setup_s = time.time() - t_setup
+
+    # ---------------------------------------------------------------- timed region: exactly K steps
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keep.append(step())
+    ev_ms = ctx.timer_stop_ms()  # HIP events on the stream the kernels were launched on
+    full_sync()
+    elapsed = time.perf_counter() - t0
+    keep.clear()
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------------------------------------------------------- verify (size-independent property)
+    cnt = C.c_int64(0)
+    _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+    total = cnt.value
+    if distributed:
+        t = torch.tensor([total], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        total = int(t.item())
+    # build keys are a bijection of [0, nb_global), every probe key lies in [0, nb_global): each probe row joins once
+    expect = (args.steps + args.warmup) * npr * world
+    ok = total == expect
+    st = abi.Stats()
+    _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+    lib.tsq_join_destroy(h)
+
+    rows_per_s = npr * world * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    kernel_ms = ev_ms / args.steps  # N=1: one K3 launch per step back-to-back on one stream
+    algo_bytes = 24.0 * npr
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if not distributed else None
+
+    out = {
+        "metric": "probed rows/sec on int64-key inner hash join",
+        "value": rows_per_s,
+        "unit": "rows/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {
+            "workload": "SELECT count(*) FROM probe JOIN build ON k: %.0e x %.0e int64-key inner hash join per GPU, "
+                        "J-uniq-shuffled, hit ratio 1.0, build side resident in HBM" % (npr, nb),
+            "probe_rows_per_gpu": npr, "build_rows_per_gpu": nb,
+            "parallelism": "hash-radix x%d, RCCL all-to-all" % world if distributed else "single GPU",
+        },
+        "verified": bool(ok),
+        "joined_rows": total,
+        "build_ms": build_wall_ms,
+        "build_kernel_ms": st.build_kernel_ms,
+        "table_bytes": st.table_bytes,
+        "setup_s": setup_s,
+    }
+    if not distributed:
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": None, "kernel": "k_probe_count<MULTI=0,GEN=0,CHK=0>", "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": algo_bytes,
+        }
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(abi, args.cpu_build_rows, args.cpu_probe_rows)
+        except Exception as e:  # the baseline is reporting only; never fail the bench for it
+            out["cpu_baseline"] = {"error": str(e)[:200]}
+
+    if not distributed:
+        for p in (bk, bv, pk, pv):
+            ctx.free(p)
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+    if not ok:
+        sys.exit("bench: join count mismatch: got %d expected %d" % (total, expect))
+
+
+def cpu_baseline(abi, nb, npr):
+    """oracle = C++ restatement of the reference Go algorithm (Go toolchain unavailable; the reference
+    operator bodies are course stubs): single-threaded build, `threads` probe workers, 1024-row chunks."""
+    import numpy as np
+
+    from oracle import binding as orc
+    from tinysql_amd.chunk import Chunk, Column
+
+    def spec(kind, **kw):
+        s = abi.GenSpec()
+        s.kind, s.seed = kind, 42
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+    bk, _ = orc.gen_column(spec(abi.GEN_AFFINE, table=2, a=2654435761, b=12345, m=nb), nb)
+    bv, _ = orc.gen_column(spec(abi.GEN_HASH_OF_COL, table=2, b=0xABCDEF), nb, src=bk)
+    pk, _ = orc.gen_column(spec(abi.GEN_RAND_MOD, table=1, col=0, m=nb), npr)
+    pv, _ = orc.gen_column(spec(abi.GEN_RAND_MOD, table=1, col=1, m=1 << 62), npr)
+    build = Chunk([Column(abi.I64, bk.view(np.int64)), Column(abi.I64, bv.view(np.int64))])
+    probe = Chunk([Column(abi.I64, pk.view(np.int64)), Column(abi.I64, pv.view(np.int64))])
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys = abi.JOIN_INNER, 1, 1
+    cfg.n_build_cols = cfg.n_probe_cols = 2
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    cfg.max_chunk_size = 1024
+    cfg.est_build_rows = nb
+    cores = os.cpu_count() or 1
+    threads = min(cores, 5)  # tidb_hash_join_concurrency default = 5 (sessionctx/variable/tidb_vars.go:249)
+    n, build_ms, probe_ms, _, _ = orc.hash_join_timed(cfg, build, probe, threads)
+    assert n == npr
+    return {
+        "value": npr / (probe_ms * 1e-3), "unit": "rows/s", "cores": threads, "kind": "port",
+        "sample": "C++ restatement of the reference HashJoinExec algorithm (FNV-1 + chained map, 1024-row chunks), "
+                  "%d probe worker threads of %d host cores, %.0e probe rows x %.0e build rows of the same generators; "
+                  "build %.0f ms single-threaded, probe %.0f ms" % (threads, cores, npr, nb, build_ms, probe_ms),
+        "build_rows_per_s": nb / (build_ms * 1e-3),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""GPU: hash-radix redistribute (tsq_radix_split) — every row lands in exactly the part its key
+ranks to, nothing is lost or duplicated, NULL keys go to part 0."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tinysql_amd import _abi as abi
+from tinysql_amd import _lib
+from tinysql_amd.chunk import Chunk, Column
+
+from . import gpu_helpers as G
+from . import helpers as H
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rank_fn():
+    subprocess.run(["make", "-C", os.path.join(HERE, "hostsim")], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(HERE, "hostsim", "hostsim.so"))
+    lib.sim_key_rank.restype = C.c_uint32
+    lib.sim_key_rank.argtypes = [C.c_uint64, C.c_uint32]
+    return lib.sim_key_rank
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 8])
+def test_radix_split_partitions_exactly(ctx, parts):
+    rank = _rank_fn()
+    rng = np.random.default_rng(40 + parts)
+    n = 50_001
+    key = Column(abi.I64, rng.integers(-1000, 1000, n), rng.random(n) > 0.03)
+    pay = H.random_column(rng, abi.F64, n, 0.2)
+    f32 = Column(abi.F32, rng.random(n).astype(np.float32))
+    src = [G.to_device(ctx, c) for c in (key, pay, f32)]
+    dst = [G.DevCol(ctx, c.tp, n, with_nulls=c.notnull is not None) for c in (key, pay, f32)]
+    try:
+        counts = (C.c_int64 * parts)()
+        _lib.check(ctx.lib.tsq_radix_split(ctx.h, G.dev_cols(src), 3, 0, 0, n, parts, G.dev_cols(dst), counts), ctx.h)
+        counts = list(counts)
+        assert sum(counts) == n
+        out = Chunk([d.to_host() for d in dst])
+        rows = out.rows()
+        off = 0
+        for p in range(parts):
+            for r in rows[off:off + counts[p]]:
+                want = 0 if r[0] is None else rank(r[0] & ((1 << 64) - 1), parts)
+                assert want == p
+            off += counts[p]
+        assert H.rows_equal_unordered(rows, Chunk([key, pay, f32]).rows())
+    finally:
+        for d in src + dst:
+            d.free()
