@@ -18,20 +18,11 @@
 // the word itself (exact), multi-column keys store a 64-bit mix and verify against the build
 // columns through the row id.
 #include "tsq_stage.h"
+#include "tsq_jointable.h"
 
 #include <deque>
 #include <memory>
 
-#define TSQ_EMPTY_KEY 0x8080808080808080ULL
-#define TSQ_BUCKET 8
-
-struct JoinTable {
-    uint64_t* keys;
-    uint32_t* vals;
-    uint64_t nbuckets;
-    const uint32_t* sent_rows;
-    uint32_t sent_count;
-};
 struct KeySpec {
     int32_t n_keys;
     int32_t bidx[TSQ_MAX_KEYS];
@@ -73,47 +64,6 @@ __device__ __forceinline__ bool keys_equal(const tsq_colset& b, const tsq_colset
         if (f1 != f2 || w1 != w2) return false;
     }
     return true;
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ uint64_t wave_xor_u64(uint64_t v) {
-    for (int o = 32; o > 0; o >>= 1) v ^= __shfl_xor(v, o, 64);
-    return v;
-}
-// exclusive prefix sum over the 64 lanes of a wave; *total = sum over all lanes
-__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t* total) {
-    const int lane = threadIdx.x & 63;
-    uint32_t x = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
-    }
-    *total = __shfl(x, 63, 64);
-    return x - v;
-}
-
-// Visits every slot of the multimap whose key word equals kw: f(slot) for each.
-// One 64-byte line (4 x dwordx4 loads, all issued before the first compare) per bucket; the walk
-// ends at the first bucket that still has an EMPTY slot (nothing was ever pushed past it).
-template <class F>
-__device__ __forceinline__ void for_each_slot(const JoinTable& t, uint64_t kw, F&& f) {
-    uint64_t bkt = tsq_mulhi64(tsq_mix64(kw), t.nbuckets);
-    for (;;) {
-        const ulonglong2* line = reinterpret_cast<const ulonglong2*>(t.keys + bkt * TSQ_BUCKET);
-        const ulonglong2 a = line[0], b = line[1], c = line[2], d = line[3];
-        const uint64_t k[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-        bool has_empty = false;
-#pragma unroll
-        for (int s = 0; s < TSQ_BUCKET; s++) {
-            if (k[s] == kw) f(bkt * TSQ_BUCKET + s);
-            has_empty |= (k[s] == TSQ_EMPTY_KEY);
-        }
-        if (has_empty) break;
-        bkt = (bkt + 1 == t.nbuckets) ? 0 : bkt + 1;
-    }
 }
 
 // ------------------------------------------------------------------ K2: build insert
