@@ -13,13 +13,13 @@
 // The set of joined rows is unchanged: a probe row meets exactly the build rows with an equal key
 // word (util/codec/codec.go:363-382) whichever partition it travels through.
 //
-// Layout of a partitioned store: P = 2^bits partitions x R regions x cap key slots.
-//   * shared regions  (R = 8)     : region r of partition p is appended to only by workgroups
-//     running on XCD r (HW_REG_XCC_ID), so the partially written line at each region's frontier
-//     stays in that XCD's L2 until it is complete (write combining in L2; 2^bits x 128 B per XCD).
-//     Space is claimed with one returning atomic per (tile, partition).
-//   * private regions (R = grid)  : region r belongs to workgroup r; the cursors live in LDS, no
-//     global atomics at all.
+// Layout of a partitioned store: P = 2^bits partitions x R = 8 regions x cap key slots.  Region r of
+// partition p is appended to only by workgroups running on XCD r (HW_REG_XCC_ID), so the partially
+// written line at each region's frontier stays in that XCD's L2 until it is complete (write combining
+// in L2; 2^bits x 128 B of frontier per XCD).  Space is claimed with one returning atomic per
+// (tile, partition): 27 G atomics/s measured, which is what bounds the fan-out (2^10: 6.3 M atomics per
+// 1e8 keys = 0.36 ms per pass; 2^11: 0.59 ms).  Block-private regions without atomics were measured
+// slower (0.54-0.65 ms): 8 MB of partially written lines per XCD do not survive in a 4 MiB L2.
 // A run that does not fit its region goes to the overflow list (skewed keys); the overflow list is
 // probed by a plain grid-stride kernel, so the result is exact for every key distribution.
 #ifndef TSQ_RADIX_H
@@ -40,6 +40,7 @@ struct RadixStore {
     uint64_t* ovf_keys;    // overflow list
     uint32_t* ovf_idx;
     uint32_t* ovf_count;
+    unsigned long long* queue;  // 8 chunk-queue heads, TSQ_RADIX_QSTRIDE words apart (probe side)
     uint32_t ovf_cap;
     uint32_t bits, R, cap;
 };
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wsum
 // with consecutive lanes on consecutive addresses.
 // Algorithmic bytes: 8 B read + 8 B written per key (+4 B with row ids).
 // MINW = waves per SIMD the register allocation must leave room for (blocks/CU * NT / 256).
-template <int NT, int K, int MINW, bool PRIVATE, bool WITH_IDX>
+template <int NT, int K, int MINW, bool WITH_IDX>
 __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, RadixStore st) {
     constexpr int T = NT * K;
     constexpr int MAXPER = (TSQ_RADIX_MAX_P + NT - 1) / NT;
@@ -91,15 +92,12 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
     __shared__ uint32_t s_idx[WITH_IDX ? T : 1];
     __shared__ uint32_t s_hist[TSQ_RADIX_MAX_P];   // per-partition count, then (overflow flag | exclusive offset)
     __shared__ uint32_t s_delta[TSQ_RADIX_MAX_P];  // global slot of the run minus its LDS offset
-    __shared__ uint32_t s_cur[PRIVATE ? TSQ_RADIX_MAX_P : 1];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_flag;
     const uint32_t tid = threadIdx.x;
     const uint32_t P = 1u << st.bits, shift = 64 - st.bits;
-    const uint32_t r = PRIVATE ? blockIdx.x : tsq_xcc_id();
+    const uint32_t r = tsq_xcc_id();
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
-    if (PRIVATE)
-        for (uint32_t p = tid; p < P; p += NT) s_cur[p] = 0;
     if (tid == 0) s_flag = 0;
     const int64_t ntiles = (src.nrows + T - 1) / T;
     const bool wide = src.nulls == nullptr && src.type != TSQ_F32 && !src.skip_high;
@@ -159,17 +157,10 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                 uint32_t flag = 0;
                 if (cnt) {
                     const uint32_t region = p * st.R + r;
-                    uint32_t g;
-                    if (PRIVATE) {
-                        g = s_cur[p];
-                        if (g + cnt <= st.cap) s_cur[p] = g + cnt;
-                        else flag = 1;
-                    } else {
-                        g = atomicAdd(&st.cursor[region], cnt);
-                        if (g + cnt > st.cap) {
-                            flag = 1;
-                            atomicMin(&st.valid_end[region], g);
-                        }
+                    const uint32_t g = atomicAdd(&st.cursor[region], cnt);
+                    if (g + cnt > st.cap) {
+                        flag = 1;
+                        atomicMin(&st.valid_end[region], g);
                     }
                     s_delta[p] = region * st.cap + g - offs;
                     if (flag) s_flag = 1;
@@ -208,8 +199,6 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
         }
         __syncthreads();
     }
-    if (PRIVATE)
-        for (uint32_t p = tid; p < P; p += NT) st.cursor[p * st.R + r] = s_cur[p];
 }
 
 // ------------------------------------------------------------------ partition-at-a-time probe
@@ -237,101 +226,161 @@ __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, uint64_t 
     }
 }
 
-// K3r — COUNT(*) probe over a partitioned key store.  Workgroup b serves virtual XCD b & 7 (the
-// dispatcher places workgroup b on XCD b % 8 — observed, used for speed only) and walks the
-// partitions p = 8*pi + (b & 7) in order, taking the same 1/J share of every partition, so all
-// workgroups of an XCD sweep the same table slice at the same time and the slice stays in that
-// XCD's L2.  U keys per lane are in flight, the next U are prefetched.
+// K3r — COUNT(*) probe over a partitioned key store.
+//
+// Ordering is what makes the L2 work: workgroup b serves virtual XCD vx = b & 7 (the dispatcher places
+// workgroup b on XCD b % 8 — observed on gfx950, used for speed only) and draws chunk tickets from
+// queue[vx].  Tickets enumerate the chunks (256*U keys) of partitions vx, vx+8, vx+16, ... in order, so
+// the keys in flight on one XCD always belong to a window of 2-3 consecutive partitions and their table
+// slices (contiguous, ~1.5 MB each) stay in that XCD's 4 MiB L2 (measured: TCC hit rate 25 % with a
+// static assignment that lets workgroups drift apart, 84 % with the ordered queue — profiles/).
+// Software pipeline: thread 0 (scout) has the ticket atomic of chunk i+2 in flight and decodes chunk
+// i+1's descriptor into LDS while chunk i's table lines are in flight; the key loads of chunk i+1 are
+// issued after the table loads of chunk i so waiting for the lines does not wait for them.
+// Quad probing: the 4 x 16-byte pieces of a 64-byte bucket are read by 4 adjacent lanes with ONE
+// dwordx4 load (16 distinct lines per wave instruction instead of 64: the texture-address unit is
+// charged per line — tools/ta_ubench.hip).  A streaming prefetch of the next slice was measured and
+// dropped (1.28 ms vs 1.04 ms without).  A key whose home bucket is full is parked in LDS and
+// resolved later by full waves (deferred spill) instead of stalling its wave on a dependent load.
 // Algorithmic bytes: 8 B key + one 16 B slot per probe row.
+#define TSQ_RADIX_QSTRIDE 64  // queue heads 512 B apart: each on its own L2 channel
 template <int U>
 __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
-    __shared__ uint32_t s_base[TSQ_RADIX_MAXSEG], s_n[TSQ_RADIX_MAXSEG];
+    constexpr uint32_t CH = 256 * U;
+    constexpr uint32_t END = 0xffffffffu;
+    constexpr uint32_t SPCAP = 2 * CH > 1024 ? 2 * CH : 1024;
+    __shared__ uint32_t s_len[TSQ_RADIX_MAXSEG];               // [pi * 8 + r] keys stored in region r of partition 8 pi + vx
+    __shared__ uint32_t s_cstart[TSQ_RADIX_MAX_P / 8 + 1];     // chunks before partition pi
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint64_t s_dsrc[2];
+    __shared__ uint32_t s_dn[2];
+    __shared__ uint64_t s_spk[SPCAP], s_spb[SPCAP];
+    __shared__ uint32_t s_spn;
     const uint32_t tid = threadIdx.x;
-    const uint32_t vx = blockIdx.x & 7u, j = blockIdx.x >> 3, J = gridDim.x >> 3;
-    const uint32_t P = 1u << a.st.bits, NP = P >> 3, R = a.st.R, cap = a.st.cap;
-    const uint32_t nseg_p = R >= J ? R / J : 1u;  // regions of one partition served by this workgroup
-    const uint32_t S = R >= J ? 1u : J / R;       // or: slices per region
-    const uint32_t nsegs = NP * nseg_p;
-    for (uint32_t sg = tid; sg < nsegs; sg += 256) {
-        const uint32_t pi = sg / nseg_p, m = sg % nseg_p, p = pi * 8 + vx;
-        const uint32_t r = R >= J ? j + m * J : j % R, s = R >= J ? 0u : j / R;
-        const uint32_t region = p * R + r;
+    const int lane = tid & 63;
+    const uint32_t vx = blockIdx.x & 7u;
+    const uint32_t P = 1u << a.st.bits, NP = P >> 3, cap = a.st.cap;
+    if (tid == 0) s_spn = 0;
+    for (uint32_t i = tid; i < NP * 8; i += 256) {
+        const uint32_t region = ((i >> 3) * 8 + vx) * 8 + (i & 7);
         uint32_t len = a.st.cursor[region];
         const uint32_t ve = a.st.valid_end[region];
         len = len < ve ? len : ve;
-        len = len < cap ? len : cap;
-        const uint32_t lo = (uint32_t)((uint64_t)len * s / S), hi = (uint32_t)((uint64_t)len * (s + 1) / S);
-        s_base[sg] = region * cap + lo;
-        s_n[sg] = hi - lo;
+        s_len[i] = len < cap ? len : cap;
     }
     __syncthreads();
-    uint32_t seg = 0, off = 0;
-    uint64_t cnt = 0;
-    bool alive = true;
-    auto fetch = [&](uint64_t& k) -> bool {
-        while (seg < nsegs && off >= s_n[seg]) {
-            seg++;
-            off = 0;
-        }
-        if (seg >= nsegs) {
-            alive = false;
-            return false;
-        }
-        const uint32_t i = off + tid;
-        off += 256;
-        if (i < s_n[seg]) {
-            k = a.st.keys[(size_t)s_base[seg] + i];
-            return true;
-        }
-        return false;
+    {
+        uint32_t nch = 0;
+        if (tid < NP)
+            for (int r = 0; r < 8; r++) nch += (s_len[tid * 8 + r] + CH - 1) / CH;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<256>(nch, s_wsum, &total);
+        if (tid < NP) s_cstart[tid] = ex;
+        if (tid == 0) s_cstart[NP] = total;
+    }
+    __syncthreads();
+    const uint32_t nchunks = s_cstart[NP];
+    auto take = [&]() -> uint32_t {
+        return (uint32_t)__hip_atomic_fetch_add(&a.st.queue[vx * TSQ_RADIX_QSTRIDE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    auto decode = [&](uint32_t t, int slot) {  // thread 0 only: ticket -> (partition, region, chunk)
+        if (t >= nchunks) {
+            s_dn[slot] = END;
+            return;
+        }
+        uint32_t lo = 0, hi = NP;  // s_cstart[lo] <= t < s_cstart[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_cstart[mid] <= t) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t pi = lo;
+        uint32_t c = t - s_cstart[pi], r = 0;
+        for (; r < 7; r++) {
+            const uint32_t cr = (s_len[pi * 8 + r] + CH - 1) / CH;
+            if (c < cr) break;
+            c -= cr;
+        }
+        const uint32_t p = pi * 8 + vx, len = s_len[pi * 8 + r];
+        s_dn[slot] = len - c * CH < CH ? len - c * CH : CH;
+        s_dsrc[slot] = (uint64_t)(a.st.keys + (size_t)(p * 8 + r) * cap + (size_t)c * CH);
+    };
+    uint64_t cnt = 0;
+    uint32_t tk_pending = 0;
+    if (tid == 0) {
+        const uint32_t tA = take(), tB = take();
+        tk_pending = take();
+        decode(tA, 0);
+        decode(tB, 1);
+    }
+    __syncthreads();
     uint64_t kn[U];
-    bool vn[U];
+    uint32_t nn = s_dn[0];
 #pragma unroll
-    for (int u = 0; u < U; u++) { kn[u] = 0; vn[u] = fetch(kn[u]); }
-    bool more = alive || vn[0];
-    while (more) {
-        uint64_t k[U];
-        bool v[U];
+    for (int u = 0; u < U; u++) {
+        kn[u] = 0;
+        const uint32_t i = u * 256 + tid;
+        if (nn != END && i < nn) kn[u] = __builtin_nontemporal_load((const uint64_t*)s_dsrc[0] + i);
+    }
+    for (uint32_t it = 0;; it++) {
+        const uint32_t n = nn;
+        if (n == END) break;
+        uint64_t k[U], bkt[U];
+        ulonglong2 L[U][4];  // L[u][g]: 16 bytes (lane & 3) of the bucket of the key held by lane 16 g + (lane >> 2)
 #pragma unroll
-        for (int u = 0; u < U; u++) { k[u] = kn[u]; v[u] = vn[u]; }
-        bool first_alive = false;
+        for (int u = 0; u < U; u++) {
+            k[u] = kn[u];
+            bkt[u] = (uint32_t)(u * 256) + tid < n ? tsq_mulhi64(tsq_mix64(k[u]), a.t.nbuckets) : 0;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint64_t bq = __shfl(bkt[u], g * 16 + (lane >> 2), 64);
+                L[u][g] = reinterpret_cast<const ulonglong2*>(a.t.keys + bq * TSQ_BUCKET)[lane & 3];
+            }
+        }
+        const int ns = (it + 1) & 1;
+        nn = s_dn[ns];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             kn[u] = 0;
-            vn[u] = fetch(kn[u]);
-            if (u == 0) first_alive = alive;
+            const uint32_t i = u * 256 + tid;
+            if (nn != END && i < nn) kn[u] = __builtin_nontemporal_load((const uint64_t*)s_dsrc[ns] + i);
         }
-        more = first_alive;
-        uint64_t bkt[U];
-        ulonglong2 L[U][4];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (v[u]) {
-                bkt[u] = tsq_mulhi64(tsq_mix64(k[u]), a.t.nbuckets);
-                const ulonglong2* line = reinterpret_cast<const ulonglong2*>(a.t.keys + bkt[u] * TSQ_BUCKET);
-                L[u][0] = line[0]; L[u][1] = line[1]; L[u][2] = line[2]; L[u][3] = line[3];
-            }
+        if (tid == 0) {  // chunk it+2 -> slot it & 1 (its readers finished before the previous barrier)
+            decode(tk_pending, it & 1);
+            tk_pending = take();
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (v[u]) {
-                const uint64_t kw = k[u];
-                if (kw == TSQ_EMPTY_KEY) {
-                    cnt += a.t.sent_count;
-                } else {
-                    const uint64_t w[8] = {L[u][0].x, L[u][0].y, L[u][1].x, L[u][1].y, L[u][2].x, L[u][2].y, L[u][3].x, L[u][3].y};
-                    uint32_t c = 0;
-                    bool has_empty = false;
 #pragma unroll
-                    for (int s = 0; s < TSQ_BUCKET; s++) {
-                        c += w[s] == kw ? 1u : 0u;
-                        has_empty |= w[s] == TSQ_EMPTY_KEY;
+            for (int g = 0; g < 4; g++) {
+                const int srcl = g * 16 + (lane >> 2);
+                const uint64_t kw = __shfl(k[u], srcl, 64);
+                const uint64_t bq = __shfl(bkt[u], srcl, 64);
+                const bool valid = (uint32_t)(u * 256) + (tid & ~63u) + (uint32_t)srcl < n;
+                const uint64_t x = L[u][g].x, y = L[u][g].y;
+                const uint64_t em = __ballot(x == TSQ_EMPTY_KEY || y == TSQ_EMPTY_KEY);
+                const bool quad_has_empty = ((em >> (lane & ~3)) & 0xfull) != 0;
+                if (valid) {
+                    if (kw == TSQ_EMPTY_KEY) {
+                        if ((lane & 3) == 0) cnt += a.t.sent_count;
+                    } else {
+                        cnt += (x == kw ? 1u : 0u) + (y == kw ? 1u : 0u);
+                        if ((lane & 3) == 0 && !quad_has_empty) {  // home bucket full: park (deferred spill)
+                            const uint32_t sl = atomicAdd(&s_spn, 1u);
+                            s_spk[sl] = kw;
+                            s_spb[sl] = bq;
+                        }
                     }
-                    if (!has_empty) c += radix_probe_spill(a.t, kw, bkt[u]);
-                    cnt += c;
                 }
             }
+        }
+        __syncthreads();
+        const uint32_t spn = s_spn;
+        if (nn == END || spn + CH > SPCAP) {  // drain the parked keys with full waves
+            for (uint32_t i = tid; i < spn; i += 256) cnt += radix_probe_spill(a.t, s_spk[i], s_spb[i]);
+            __syncthreads();
+            if (tid == 0) s_spn = 0;
+            __syncthreads();
         }
     }
     cnt = wave_sum_u64(cnt);
