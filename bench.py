@@ -5,13 +5,17 @@ Workload (N = 1): `SELECT count(*) FROM probe JOIN build ON probe.k = build.k`, 
 (k int64, v int64) per side, J-uniq-shuffled: build keys are a bijection of
 [0, N_b) in pseudo-random order, probe keys are uniform in [0, N_b) (hit ratio 1.0), generated on
 the device so the tables never cross PCIe.  The build side is built once and stays resident in
-HBM; one "step" = one probe pass of all N_p probe rows through libtsq (K3 k_probe_count).
+HBM; one "step" = one probe pass of all N_p probe rows through libtsq: radix partition of the probe
+keys (k_radix_partition) + partition-at-a-time probe (k_radix_probe_count), or the direct probe
+(k_probe_count) with --radix off.
 N > 1: weak scaling — every rank owns N_b build and N_p probe rows; rows are redistributed by
 hash-radix with an RCCL all-to-all (tinysql_amd/parallel.py); a step = split + exchange + local
 probe of the probe side; the build side is redistributed and built once (untimed, resident).
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes of the probe kernel
-(24 B per probe row: 8 B key + one 16 B slot) / its average HIP-event duration.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_radix_probe_count):
+algorithmic bytes (24 B per probe row: 8 B key + one 16 B slot) / its average
+HIP-event duration over the timed steps; `roofline.probe_phase` prices the whole step (partition +
+probe) against the same 24 B/row, `roofline.partition` the partition kernel at its own 16 B/key.
 `cpu_baseline` = the oracle's C++ restatement of the reference algorithm (oracle/, test
 infrastructure — used here only as the reported baseline) timed on the host cores on a bounded sample.
 """
@@ -37,6 +41,7 @@ def main():
     ap.add_argument("--cpu-build-rows", type=int, default=10_000_000)
     ap.add_argument("--cpu-probe-rows", type=int, default=20_000_000)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even with one rank (validation)")
+    ap.add_argument("--radix", choices=["auto", "off", "force"], default="auto", help="probe strategy (tsq_join_set_radix)")
     args = ap.parse_args()
 
     n_gpus = args.gpus
@@ -108,6 +113,7 @@ def main():
     cfg.max_chunk_size, cfg.concurrency = 1024, 5
     h = C.c_void_p()
     _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    _lib.check(lib.tsq_join_set_radix(h, {"auto": abi.RADIX_AUTO, "off": abi.RADIX_OFF, "force": abi.RADIX_FORCE}[args.radix]), h)
     if distributed:
         from tinysql_amd import parallel
         (rbk, rbv), nb_local = parallel.redistribute(ctx, dist, torch, [bk_t, bv_t], [abi.I64, abi.I64], 0, 0, nb)
@@ -185,9 +191,19 @@ def main():
 
     rows_per_s = npr * world * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    kernel_ms = ev_ms / args.steps  # N=1: one K3 launch per step back-to-back on one stream
+    step_ev_ms = ev_ms / args.steps  # HIP events around the K steps on the launch stream
     algo_bytes = 24.0 * npr
-    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if not distributed else None
+    radix = st.radix_batches > 0
+    if radix and st.radix_timed_batches > 0:
+        nt = min(st.radix_timed_batches, args.steps)  # the event ring keeps the most recent batches = the timed steps
+        kernel_name = "k_radix_probe_count<2>"
+        kernel_ms = st.radix_probe_kernel_ms_sum / st.radix_timed_batches
+        part_ms = st.partition_kernel_ms_sum / st.radix_timed_batches
+    else:
+        nt = args.steps
+        kernel_name = "k_probe_count<MULTI=0,GEN=0,CHK=0>"
+        kernel_ms, part_ms = step_ev_ms, 0.0
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
     out = {
         "metric": "probed rows/sec on int64-key inner hash join",
@@ -215,12 +231,35 @@ def main():
         "table_bytes": st.table_bytes,
         "setup_s": setup_s,
     }
+    out["probe_strategy"] = ("radix 2^%d partitions" % st.radix_bits) if radix else "direct"
+    traffic = traffic_part = None
+    try:  # PMC-derived HBM bytes per launch are measured offline (rocprofv3 --pmc passes) and committed under profiles/
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        w = tj["workload"]
+        if w["probe_rows"] == npr and w["build_rows"] == nb and world == 1:
+            if radix and w["radix_bits"] == st.radix_bits:
+                traffic = tj["k_radix_probe_count<2>"]["traffic_bytes"]
+                traffic_part = tj["k_radix_partition<1024,16,4,false>"]["traffic_bytes"]
+            elif not radix:
+                traffic = tj["k_probe_count<false,false,false> (direct probe, --radix off)"]["traffic_bytes"]
+    except Exception:
+        pass
     if not distributed:
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": None, "kernel": "k_probe_count<MULTI=0,GEN=0,CHK=0>", "kernel_ms": kernel_ms,
+            "traffic": traffic, "traffic_source": "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)" if traffic else None,
+            "kernel": kernel_name, "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": algo_bytes,
+            "probe_phase": {"ms": step_ev_ms, "achieved": algo_bytes / (step_ev_ms * 1e-3) / 1e9,
+                            "frac": algo_bytes / (step_ev_ms * 1e-3) / 1e9 / 8000.0,
+                            "note": "whole step (memsets + partition + probe + overflow kernels) priced at 24 B/probe row"},
         }
+        if radix:
+            pb = 16.0 * npr  # 8 B key read + 8 B key written per probe row (COUNT(*) carries no payload)
+            out["roofline"]["partition"] = {"kernel": "k_radix_partition<1024,16,4,false>", "kernel_ms": part_ms,
+                                            "algorithmic_bytes_per_launch": pb, "achieved": pb / (part_ms * 1e-3) / 1e9,
+                                            "frac": pb / (part_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic_part}
+            out["radix_overflow_rows"] = st.radix_overflow_rows
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     if rank == 0 and not distributed and not args.no_cpu_baseline:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSQ_ABI_VERSION 1
+#define TSQ_ABI_VERSION 2
 
 /* ---------------------------------------------------------------- status codes */
 typedef int32_t tsq_status;
@@ -270,6 +270,15 @@ tsq_status tsq_join_count(tsq_join* j, int64_t* rows_out);
  * sum and xor over joined rows of rowhash(all output columns) — parity at full size. */
 tsq_status tsq_join_checksum(tsq_join* j, uint64_t* sum_out, uint64_t* xor_out);
 tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on);
+/* Probe strategy of the COUNT(*) fast path.  TSQ_RADIX_AUTO (default): probe batches that are large
+ * enough are radix partitioned by the top bits of the key hash (LDS-staged, write combined) and probed
+ * partition by partition so that every XCD works inside a table slice that fits its L2; small batches
+ * and small tables take the direct probe.  OFF / FORCE exist for tests and measurements; the joined
+ * rows are identical either way.  Replaces the worker dispatch of executor/join.go:160-231. */
+#define TSQ_RADIX_AUTO  (-1)
+#define TSQ_RADIX_OFF     0
+#define TSQ_RADIX_FORCE   1
+tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode);
 tsq_status tsq_join_cancel(tsq_join* j);
 void       tsq_join_destroy(tsq_join* j);
 
@@ -358,6 +367,15 @@ typedef struct tsq_stats {
     int64_t h2d_bytes;
     int64_t d2h_bytes;
     int64_t kernel_launches;
+    double  partition_kernel_ms;   /* last radix batch: partition kernel (0 when the direct probe ran) */
+    double  radix_probe_kernel_ms; /* last radix batch: partition-at-a-time probe (+ overflow list) kernels */
+    double  partition_kernel_ms_sum;    /* HIP-event sums over the most recent radix_timed_batches (<= 32) batches */
+    double  radix_probe_kernel_ms_sum;
+    int64_t radix_timed_batches;
+    int64_t radix_batches;         /* probe batches that went through the radix path */
+    int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew) in the last batch */
+    int32_t radix_bits;            /* log2(partitions) of the last radix batch */
+    int32_t reserved;
 } tsq_stats;
 tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out);
 tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out);

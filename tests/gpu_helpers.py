@@ -23,12 +23,15 @@ def push_chunked(fn, handle, chunk, chunk_rows, selected=None, lib_handle_for_er
             _lib.check(fn(handle, cols, len(part.columns), hi - lo, s.ctypes.data_as(C.c_void_p)), handle)
 
 
-def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1024, count_only=False, checksum=False):
+def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1024, count_only=False, checksum=False, radix=None,
+             stats_out=None):
     """build_push* -> build_finish -> (probe_push, pull*)* -> probe_finish -> pull*; returns Chunk (or count[,sum,xor])."""
     lib = ctx.lib
     h = C.c_void_p()
     _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
     try:
+        if radix is not None:
+            _lib.check(lib.tsq_join_set_radix(h, radix), h)
         push_chunked(lib.tsq_join_build_push, h, build, chunk_rows)
         _lib.check(lib.tsq_join_build_finish(h), h)
         if count_only:
@@ -69,6 +72,10 @@ def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1
         if count_only:
             c = C.c_int64(0)
             _lib.check(lib.tsq_join_count(h, C.byref(c)), h)
+            if stats_out is not None:
+                st = abi.Stats()
+                _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+                stats_out.append(st)
             if checksum:
                 s, x = C.c_uint64(0), C.c_uint64(0)
                 _lib.check(lib.tsq_join_checksum(h, C.byref(s), C.byref(x)), h)

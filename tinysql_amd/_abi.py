@@ -5,7 +5,8 @@ Shared by the product binding (tinysql_amd._lib) and by the test-only oracle bin
 """
 import ctypes as C
 
-TSQ_ABI_VERSION = 1
+TSQ_ABI_VERSION = 2
+RADIX_AUTO, RADIX_OFF, RADIX_FORCE = -1, 0, 1
 
 # status codes
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
@@ -109,6 +110,9 @@ class Stats(C.Structure):
         ("out_rows", C.c_int64), ("table_bytes", C.c_int64), ("table_buckets", C.c_int64),
         ("build_kernel_ms", C.c_double), ("probe_kernel_ms", C.c_double), ("h2d_bytes", C.c_int64),
         ("d2h_bytes", C.c_int64), ("kernel_launches", C.c_int64),
+        ("partition_kernel_ms", C.c_double), ("radix_probe_kernel_ms", C.c_double), ("partition_kernel_ms_sum", C.c_double),
+        ("radix_probe_kernel_ms_sum", C.c_double), ("radix_timed_batches", C.c_int64), ("radix_batches", C.c_int64), ("radix_overflow_rows", C.c_int64),
+        ("radix_bits", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -145,6 +149,7 @@ SIGNATURES = {
     "tsq_join_count": (C.c_int32, [P, C.POINTER(C.c_int64)]),
     "tsq_join_checksum": (C.c_int32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tsq_join_set_checksum": (C.c_int32, [P, C.c_int32]),
+    "tsq_join_set_radix": (C.c_int32, [P, C.c_int32]),
     "tsq_join_cancel": (C.c_int32, [P]),
     "tsq_join_destroy": (None, [P]),
     "tsq_agg_create": (C.c_int32, [P, C.POINTER(AggCfg), PP]),

@@ -19,6 +19,7 @@
 // columns through the row id.
 #include "tsq_stage.h"
 #include "tsq_jointable.h"
+#include "tsq_radix.h"
 
 #include <deque>
 #include <memory>
@@ -395,6 +396,12 @@ struct tsq_join {
     int64_t total_out = 0;  // emit mode: rows produced so far
     std::deque<std::unique_ptr<ResultBatch>> results;
 
+    // radix probe path of the COUNT(*) fast path (tsq_radix.h)
+    int32_t radix_mode = TSQ_RADIX_AUTO;
+    DevBuf rkeys, rctl, rvend, rovf;  // partitioned keys | cursor + queue heads + overflow count | valid_end | overflow keys
+    static constexpr int RING = 32;   // HIP events of the most recent radix batches: [slot][0..2] = start, after partition, end
+    hipEvent_t rev[RING][3] = {};
+
     // stats
     tsq_stats st{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -501,6 +508,92 @@ tsq_status dispatch_emit(tsq_join* j, ProbeArgs& a) {
     return TSQ_OK;
 }
 
+
+// ---------------------------------------------------------------- radix probe path (host side)
+// Eligible: COUNT(*) without checksum, inner join, one key column, no filters / conditions / selected[].
+// AUTO takes it when both the table and the batch are big enough to pay for a partition pass.
+bool radix_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF) return false;
+    if (!j->count_only || j->checksum || j->multi || j->general || selected_dev || j->never_match) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE) return true;
+    // table slices of ~1.5 MB per partition need >= 8 partitions to be worth it; batch >= 4 Mi rows
+    return j->nbuckets * 64 >= ((uint64_t)12 << 20) && nrows >= (4 << 20);
+}
+
+uint32_t radix_bits_for(const tsq_join* j) {
+    const double slice_target = 1.5 * 1024 * 1024;  // two to three slices stay resident in a 4 MiB L2
+    const double parts = (double)j->nbuckets * 64.0 / slice_target;
+    uint32_t bits = TSQ_RADIX_MIN_BITS;
+    while (bits < 10 && (double)(1u << bits) < parts) bits++;  // 2^11 costs 0.59 ms per 1e8 keys (atomics), 2^10 0.36 ms
+    return bits;
+}
+
+tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    RadixStore st;
+    memset(&st, 0, sizeof st);
+    st.bits = radix_bits_for(j);
+    st.R = 8;
+    const uint32_t P = 1u << st.bits;
+    constexpr int NT = 1024, K = 16, T = NT * K;
+    const double lam = (double)nrows / ((double)P * 8.0);
+    st.cap = (uint32_t)(lam * 1.08 + 8.0 * sqrt(lam) + 2.0 * T / 64.0 + 64.0);
+    st.cap = (st.cap + 15u) & ~15u;  // regions start on 128-byte lines
+    const size_t nregions = (size_t)P * 8;
+    if (nregions * st.cap >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "radix probe batch too large");
+    const size_t ctl_words32 = nregions + 16;                       // cursors + overflow count (+pad)
+    const size_t ctl_bytes = ((ctl_words32 * 4 + 511) & ~(size_t)511) + 8 * TSQ_RADIX_QSTRIDE * 8;
+    TSQ_TRY(j->rkeys.reserve(ctx, h, nregions * st.cap * 8 + 256));
+    TSQ_TRY(j->rctl.reserve(ctx, h, ctl_bytes));
+    TSQ_TRY(j->rvend.reserve(ctx, h, nregions * 4));
+    TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 8 + 64));
+    st.keys = j->rkeys.as<uint64_t>();
+    st.cursor = j->rctl.as<uint32_t>();
+    st.ovf_count = st.cursor + nregions;
+    st.queue = (unsigned long long*)((char*)j->rctl.p + ((ctl_words32 * 4 + 511) & ~(size_t)511));
+    st.valid_end = j->rvend.as<uint32_t>();
+    st.ovf_keys = j->rovf.as<uint64_t>();
+    st.ovf_cap = (uint32_t)nrows;
+    TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, ctl_bytes, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, nregions * 4, ctx->stream));
+
+    RadixSrc src;
+    const int kc = j->ks.pidx[0];
+    src.data = pcs.data[kc];
+    src.nulls = pcs.nulls[kc];
+    src.type = pcs.type[kc];
+    src.skip_high = j->ks.skip_high;
+    src.nrows = nrows;
+    const int64_t ntiles = (nrows + T - 1) / T;
+    const int pgrid = (int)std::min<int64_t>(ntiles, ctx->num_cus);  // 148 KB of LDS: one workgroup per CU
+    hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
+    for (int e = 0; e < 3; e++)
+        if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    hipLaunchKernelGGL((k_radix_partition<NT, K, 4, false>), dim3(pgrid), dim3(NT), 0, ctx->stream, src, st);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
+    RadixProbeArgs pa;
+    pa.st = st;
+    fill_table(j, pa.t);
+    pa.counters = j->counters.as<unsigned long long>();
+    const int per_xcd = std::max(1, ctx->num_cus / 8) * 6;  // 6 workgroups per CU (measured optimum 5-6)
+    hipLaunchKernelGGL((k_radix_probe_count<2>), dim3(per_xcd * 8), dim3(256), 0, ctx->stream, pa);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_radix_probe_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+    j->have_probe_ev = true;
+    j->st.kernel_launches += 3;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)st.bits;
+    return TSQ_OK;
+}
+
 // run the probe kernels over one device-resident batch described by pcs / selected
 tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
     if (nrows == 0) return TSQ_OK;
@@ -522,6 +615,7 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     a.counters = j->counters.as<unsigned long long>();
     j->st.probe_rows += nrows;
 
+    if (radix_eligible(j, nrows, selected_dev)) return radix_probe(j, pcs, nrows);
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
     if (j->count_only) {
         TSQ_TRY(dispatch_count(j, a, j->checksum));
@@ -834,6 +928,12 @@ TSQ_API tsq_status tsq_join_set_count_only(tsq_join* j, int32_t on) {
     if (!j->count_only) j->checksum = false;
     return TSQ_OK;
 }
+TSQ_API tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (mode < TSQ_RADIX_AUTO || mode > TSQ_RADIX_FORCE) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "radix mode must be -1 (auto), 0 (off) or 1 (force)");
+    j->radix_mode = mode;
+    return TSQ_OK;
+}
 TSQ_API tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on) {
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     if (!j->count_only) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "checksum needs count-only mode");
@@ -1004,6 +1104,26 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
     float ms = 0;
     if (j->have_build_ev && hipEventElapsedTime(&ms, j->ev[0], j->ev[1]) == hipSuccess) j->st.build_kernel_ms = ms;
     if (j->have_probe_ev && hipEventElapsedTime(&ms, j->ev[2], j->ev[3]) == hipSuccess) j->st.probe_kernel_ms = ms;
+    j->st.partition_kernel_ms = 0;
+    j->st.radix_overflow_rows = 0;
+    j->st.radix_probe_kernel_ms = j->st.partition_kernel_ms_sum = j->st.radix_probe_kernel_ms_sum = 0;
+    j->st.radix_timed_batches = 0;
+    if (j->st.radix_batches > 0 && j->rctl.p) {
+        const int64_t nt = std::min<int64_t>(j->st.radix_batches, tsq_join::RING);
+        for (int64_t b = j->st.radix_batches - nt; b < j->st.radix_batches; b++) {
+            hipEvent_t* re = j->rev[b % tsq_join::RING];
+            float pm = 0, qm = 0;
+            if (hipEventElapsedTime(&pm, re[0], re[1]) != hipSuccess || hipEventElapsedTime(&qm, re[1], re[2]) != hipSuccess) continue;
+            j->st.partition_kernel_ms_sum += pm;
+            j->st.radix_probe_kernel_ms_sum += qm;
+            j->st.radix_timed_batches++;
+            j->st.partition_kernel_ms = pm;
+            j->st.radix_probe_kernel_ms = qm;
+        }
+        uint32_t ovf = 0;  // overflow count of the last radix batch sits behind the cursors
+        const size_t nregions = ((size_t)1 << j->st.radix_bits) * 8;
+        if (hipMemcpy(&ovf, j->rctl.as<uint32_t>() + nregions, 4, hipMemcpyDeviceToHost) == hipSuccess) j->st.radix_overflow_rows = ovf;
+    }
     *out = j->st;
     return TSQ_OK;
 }
@@ -1026,6 +1146,13 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->stage.release();
     for (int i = 0; i < 4; i++)
         if (j->ev[i]) (void)hipEventDestroy(j->ev[i]);
+    for (int i = 0; i < tsq_join::RING; i++)
+        for (int e = 0; e < 3; e++)
+            if (j->rev[i][e]) (void)hipEventDestroy(j->rev[i][e]);
+    j->rkeys.release();
+    j->rctl.release();
+    j->rvend.release();
+    j->rovf.release();
     j->hdr.magic = 0;
     delete j;
 }

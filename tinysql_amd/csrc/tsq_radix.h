@@ -189,11 +189,18 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                 const uint32_t d = s_delta[p] + i;
                 st.keys[d] = key;
                 if (WITH_IDX) st.idx[d] = s_idx[i];
-            } else {
-                const uint32_t o = atomicAdd(st.ovf_count, 1u);
-                if (o < st.ovf_cap) {
-                    st.ovf_keys[o] = key;
-                    if (WITH_IDX) st.ovf_idx[o] = s_idx[i];
+            }
+        }
+        if (any_ovf) {  // rare (skewed keys): runs that did not fit go to the overflow list, one slot at a time
+            for (uint32_t i = tid; i < total; i += NT) {
+                const uint64_t key = s_keys[i];
+                const uint32_t p = tsq_radix_part(key, shift);
+                if (s_hist[p] >> 31) {
+                    const uint32_t o = __hip_atomic_fetch_add(st.ovf_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (o < st.ovf_cap) {
+                        st.ovf_keys[o] = key;
+                        if (WITH_IDX) st.ovf_idx[o] = s_idx[i];
+                    }
                 }
             }
         }
