@@ -333,6 +333,16 @@ tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols, int64_t
 /* End of child input: finalise groups (consumeIntermData + getFinalResult, aggregate.go:424-457).
  * Returns TSQ_ERR_OVERFLOW_BIGINT if an int64 SUM/AVG left the BIGINT range (func_sum.go:133). */
 tsq_status tsq_agg_finish(tsq_agg* a);
+/* Update strategy.  TSQ_AGGFAST_AUTO (default): large batches of a single-key aggregate whose functions
+ * fit (COUNT/SUM/AVG/MIN/MAX over <= 2 argument columns, firstrow(group key)) are pre-aggregated in LDS
+ * — directly when few groups are expected, after a radix partition by group-key hash otherwise — and
+ * only the partial groups are merged into the table in HBM (the reference's partial -> shuffle -> final
+ * shape, executor/aggregate.go:96-133).  OFF / FORCE exist for tests and measurements; results are the
+ * same up to the documented floating-point reordering of SUM/AVG(double). */
+#define TSQ_AGGFAST_AUTO  (-1)
+#define TSQ_AGGFAST_OFF     0
+#define TSQ_AGGFAST_FORCE   1
+tsq_status tsq_agg_set_fast(tsq_agg* a, int32_t mode);
 tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out);
 /* HashAggExec.Next (aggregate.go:559-588): output schema = one column per agg func, in cfg
  * order.  COMPLETE/FINAL emit final values; PARTIAL1/PARTIAL2 emit partial columns (AVG emits
@@ -372,7 +382,7 @@ typedef struct tsq_stats {
     double  partition_kernel_ms_sum;    /* HIP-event sums over the most recent radix_timed_batches (<= 32) batches */
     double  radix_probe_kernel_ms_sum;
     int64_t radix_timed_batches;
-    int64_t radix_batches;         /* probe batches that went through the radix path */
+    int64_t radix_batches;         /* join: probe batches through the radix path; agg: batches pre-aggregated in LDS */
     int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew) in the last batch */
     int32_t radix_bits;            /* log2(partitions) of the last radix batch */
     int32_t reserved;

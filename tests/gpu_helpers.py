@@ -87,13 +87,19 @@ def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1
         lib.tsq_join_destroy(h)
 
 
-def run_agg(ctx, cfg, chunk, out_types, chunk_rows=1024, pull_rows=1024):
+def run_agg(ctx, cfg, chunk, out_types, chunk_rows=1024, pull_rows=1024, fast=None, stats_out=None):
     lib = ctx.lib
     h = C.c_void_p()
     _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
     try:
+        if fast is not None:
+            _lib.check(lib.tsq_agg_set_fast(h, fast), h)
         push_chunked(lib.tsq_agg_push, h, chunk, chunk_rows)
         _lib.check(lib.tsq_agg_finish(h), h)
+        if stats_out is not None:
+            st = abi.Stats()
+            _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
+            stats_out.append(st)
         got = []
         while True:
             keep = []

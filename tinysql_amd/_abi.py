@@ -7,6 +7,7 @@ import ctypes as C
 
 TSQ_ABI_VERSION = 2
 RADIX_AUTO, RADIX_OFF, RADIX_FORCE = -1, 0, 1
+AGGFAST_AUTO, AGGFAST_OFF, AGGFAST_FORCE = -1, 0, 1
 
 # status codes
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
@@ -155,6 +156,7 @@ SIGNATURES = {
     "tsq_agg_create": (C.c_int32, [P, C.POINTER(AggCfg), PP]),
     "tsq_agg_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),
     "tsq_agg_finish": (C.c_int32, [P]),
+    "tsq_agg_set_fast": (C.c_int32, [P, C.c_int32]),
     "tsq_agg_num_groups": (C.c_int32, [P, C.POINTER(C.c_int64)]),
     "tsq_agg_pull": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tsq_agg_cancel": (C.c_int32, [P]),

@@ -1,0 +1,302 @@
+// tsq_aggfast.h — LDS pre-aggregation for HashAggExec (device code, included by tsq_agg.hip).
+//
+// Why: the group-table upsert of tsq_agg.hip pays one CAS probe + one or two device-scope atomics per
+// input row in HBM; random device atomics run at ~20-27 G/s on MI355X (profiles/r01_probe_ubench.txt),
+// i.e. SELECT k, SUM(v), COUNT(*) GROUP BY k over 1e9 rows / 1e6 groups took 94 ms = 2 % of the HBM
+// roofline.  LDS atomics are two orders of magnitude faster, so rows are first aggregated inside LDS
+// and only the per-workgroup partial groups touch the table in HBM.  This is the reference's own
+// two-phase shape — partial workers -> shuffle by group key -> final workers
+// (executor/aggregate.go:96-133, 332-356, 424-457) — with LDS as the partial workers' map:
+//   L (few groups, <= S/2): every workgroup streams its share of the input columns into a private LDS
+//     table and emits its partial groups (PartialResult rows);
+//   H (up to ~2 M groups): rows are radix partitioned by the group-key hash (tsq_radix.h, payload =
+//     the argument cells), then ONE workgroup aggregates one partition whose groups fit its LDS table;
+//   the partial groups are merged into the HBM group table by k_agg_merge (= the final workers'
+//     consumeIntermData + MergePartialResult, aggfuncs/*.go).
+// Rows the LDS stage cannot take (NULL key or NULL argument cell, table full, sentinel key) are handed
+// to the row-at-a-time upsert, so every aggregate keeps its exact NULL protocol.
+#ifndef TSQ_AGGFAST_H
+#define TSQ_AGGFAST_H
+
+#include "tsq_radix.h"
+
+#define TSQ_AF_MAXW 5     /* 64-bit LDS words per group besides the key */
+#define TSQ_AF_NT 1024    /* one workgroup of 16 waves per CU */
+#define TSQ_AF_EMPTY 0x8080808080808080ULL
+
+struct AfAgg {
+    int32_t func, type;  // TSQ_AGG_*, argument type
+    int32_t v;           // payload cell index, -1 = no argument cell (COUNT(*), FIRSTROW(key))
+    int32_t w;           // first LDS word, -1 = none
+};
+struct AfPlan {
+    int32_t n_aggs;
+    AfAgg f[TSQ_MAX_AGGS];  // same order as the handle's aggregates
+    int32_t W, V;
+    int32_t key_col, key_type;
+    int32_t vcol[TSQ_RADIX_MAXV], vtype[TSQ_RADIX_MAXV];
+    unsigned long long init[TSQ_AF_MAXW];  // initial value of every word (MIN starts at all ones)
+};
+struct AfPartials {  // partial groups in HBM, structure of arrays
+    unsigned long long* key;
+    unsigned long long* w[TSQ_AF_MAXW];
+    uint32_t* count;  // records appended (may exceed cap: then the batch is redone row by row)
+    uint32_t cap;
+};
+
+__device__ __forceinline__ uint64_t af_ord_image(uint64_t cell, int32_t type) {  // order preserving image for min/max on uint64
+    switch (type) {
+        case TSQ_I64: return cell ^ 0x8000000000000000ULL;
+        case TSQ_U64: return cell;
+        default: {
+            const double f = type == TSQ_F32 ? (double)tsq_bits_f32((uint32_t)cell) : tsq_bits_f64(cell);
+            const uint64_t u = tsq_f64_bits(f);
+            return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+        }
+    }
+}
+__device__ __forceinline__ double af_real(uint64_t cell, int32_t type) {
+    return type == TSQ_F32 ? (double)tsq_bits_f32((uint32_t)cell) : tsq_bits_f64(cell);
+}
+__device__ __forceinline__ bool af_is_real(int32_t t) { return t == TSQ_F32 || t == TSQ_F64; }
+
+// the words of a partial group that consists of ONE row
+__device__ __forceinline__ void af_row_words(const AfPlan& pl, const uint64_t* cells, unsigned long long* w) {
+    for (int i = 0; i < pl.W; i++) w[i] = pl.init[i];
+    for (int i = 0; i < pl.n_aggs; i++) {
+        const AfAgg f = pl.f[i];
+        if (f.w < 0) continue;
+        switch (f.func) {
+            case TSQ_AGG_COUNT: w[f.w] = 1; break;
+            case TSQ_AGG_SUM:
+            case TSQ_AGG_AVG:
+                if (af_is_real(f.type)) {
+                    w[f.w] = tsq_f64_bits(af_real(cells[f.v], f.type));
+                    if (f.func == TSQ_AGG_AVG) w[f.w + 1] = 1;
+                } else {
+                    w[f.w] = cells[f.v];
+                    w[f.w + 1] = ((int64_t)cells[f.v] < 0) ? ~0ull : 0ull;
+                    if (f.func == TSQ_AGG_AVG) w[f.w + 2] = 1;
+                }
+                break;
+            case TSQ_AGG_MAX:
+            case TSQ_AGG_MIN: w[f.w] = af_ord_image(cells[f.v], f.type); break;
+        }
+    }
+}
+
+struct AfLdsArgs {
+    AfPlan plan;
+    AfPartials out;
+    // MODE 0: straight from the input columns
+    tsq_colset in;
+    int64_t nrows;
+    uint32_t* exc_rows;   // rows with a NULL key / NULL argument cell
+    uint32_t* exc_count;
+    // MODE 1: one workgroup per partition of a partitioned store; MODE 2: its overflow list
+    RadixStore st;
+};
+
+// K7a — LDS pre-aggregation (updatePartialResult of one partial worker, aggregate.go:332-350, into LDS).
+template <int MODE, int W>
+__global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
+    constexpr uint32_t S = W <= 3 ? 4096u : 2048u;
+    __shared__ unsigned long long s_key[S];
+    __shared__ unsigned long long s_w[W][S];
+    __shared__ uint32_t s_used;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < S; i += TSQ_AF_NT) {
+        s_key[i] = TSQ_AF_EMPTY;
+#pragma unroll
+        for (int k = 0; k < W; k++) s_w[k][i] = a.plan.init[k];
+    }
+    if (tid == 0) s_used = 0;
+    __syncthreads();
+
+    auto spill = [&](uint64_t tag, const uint64_t* cells) {  // a one-row partial group straight to HBM
+        unsigned long long w[TSQ_AF_MAXW];
+        af_row_words(a.plan, cells, w);
+        const uint32_t o = __hip_atomic_fetch_add(a.out.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o < a.out.cap) {
+            a.out.key[o] = tag;
+#pragma unroll
+            for (int k = 0; k < W; k++) a.out.w[k][o] = w[k];
+        }
+    };
+    auto apply = [&](uint64_t tag, uint64_t c0, uint64_t c1) {  // cells by value: a dynamically indexed local array would live in scratch
+        if (tag == TSQ_AF_EMPTY) {  // the sentinel key lives in a special slot of the HBM table
+            const uint64_t cells[TSQ_RADIX_MAXV] = {c0, c1};
+            spill(tag, cells);
+            return;
+        }
+        uint32_t slot = (uint32_t)tsq_mix64(tag) & (S - 1);
+        bool found = false;
+        for (int probe = 0; probe < 64 && !found; probe++) {
+            unsigned long long cur = s_key[slot];
+            if (cur == TSQ_AF_EMPTY) {
+                if (s_used >= S - S / 8) break;  // keep the table probe-able: the row is spilled instead
+                cur = atomicCAS(&s_key[slot], (unsigned long long)TSQ_AF_EMPTY, (unsigned long long)tag);
+                if (cur == TSQ_AF_EMPTY) {
+                    atomicAdd(&s_used, 1u);
+                    found = true;
+                    break;
+                }
+            }
+            if (cur == tag) found = true;
+            else slot = (slot + 1) & (S - 1);
+        }
+        if (!found) {
+            const uint64_t cells[TSQ_RADIX_MAXV] = {c0, c1};
+            spill(tag, cells);
+            return;
+        }
+        for (int i = 0; i < a.plan.n_aggs; i++) {
+            const AfAgg f = a.plan.f[i];
+            if (f.w < 0) continue;
+            const uint64_t cell = f.v == 1 ? c1 : c0;
+            switch (f.func) {
+                case TSQ_AGG_COUNT: atomicAdd(&s_w[f.w][slot], 1ull); break;
+                case TSQ_AGG_SUM:
+                case TSQ_AGG_AVG:
+                    if (af_is_real(f.type)) {
+                        atomicAdd(reinterpret_cast<double*>(&s_w[f.w][slot]), af_real(cell, f.type));
+                        if (f.func == TSQ_AGG_AVG) atomicAdd(&s_w[f.w + 1][slot], 1ull);
+                    } else {
+                        // exact sum without returning atomics: the low and the (signed) high 32-bit halves are summed
+                        // separately in 64 bits — neither can overflow in < 2^31 rows — and recombined into the
+                        // 128-bit (lo, hi) pair when the group is emitted (func_sum.go:133-137 is exact in 128 bits)
+                        const unsigned long long uv = cell;
+                        atomicAdd(&s_w[f.w][slot], uv & 0xffffffffull);
+                        atomicAdd(&s_w[f.w + 1][slot], (unsigned long long)((long long)uv >> 32));
+                        if (f.func == TSQ_AGG_AVG) atomicAdd(&s_w[f.w + 2][slot], 1ull);
+                    }
+                    break;
+                case TSQ_AGG_MAX: atomicMax(&s_w[f.w][slot], (unsigned long long)af_ord_image(cell, f.type)); break;
+                case TSQ_AGG_MIN: atomicMin(&s_w[f.w][slot], (unsigned long long)af_ord_image(cell, f.type)); break;
+            }
+        }
+    };
+
+    constexpr int U = 4;  // rows in flight per lane: the loop is bound by HBM latency at 16 waves per CU otherwise
+    if (MODE == 0) {
+        const int kc = a.plan.key_col;
+        RadixSrc ks;
+        ks.data = a.in.data[kc];
+        ks.type = a.in.type[kc];
+        ks.key_kind = 1;
+        const int64_t stride = (int64_t)gridDim.x * TSQ_AF_NT * U;
+        for (int64_t r0 = (int64_t)blockIdx.x * TSQ_AF_NT * U + tid; r0 < a.nrows; r0 += stride) {
+            uint64_t tag[U], cells[U][TSQ_RADIX_MAXV];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t r = r0 + (int64_t)u * TSQ_AF_NT;
+                ok[u] = false;
+                tag[u] = 0;
+                cells[u][0] = cells[u][1] = 0;
+                if (r < a.nrows) {
+                    bool isnull = tsq_is_null(a.in.nulls[kc], r);
+                    for (int v = 0; v < a.plan.V; v++) isnull |= tsq_is_null(a.in.nulls[a.plan.vcol[v]], r);
+                    if (isnull) {
+                        const uint32_t e = __hip_atomic_fetch_add(a.exc_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a.exc_rows[e] = (uint32_t)r;
+                    } else {
+                        ok[u] = true;
+                        tag[u] = radix_src_key(ks, r);
+#pragma unroll
+                        for (int v = 0; v < TSQ_RADIX_MAXV; v++) {
+                            if (v < a.plan.V) {
+                                const int c = a.plan.vcol[v];
+                                cells[u][v] = a.in.type[c] == TSQ_F32 ? (uint64_t)((const uint32_t*)a.in.data[c])[r] : ((const uint64_t*)a.in.data[c])[r];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (ok[u]) apply(tag[u], cells[u][0], cells[u][1]);
+        }
+    } else if (MODE == 1) {
+        const uint32_t p = blockIdx.x;
+        for (uint32_t r = 0; r < a.st.R; r++) {
+            const uint32_t region = p * a.st.R + r;
+            uint32_t len = a.st.cursor[region];
+            const uint32_t ve = a.st.valid_end[region];
+            len = len < ve ? len : ve;
+            len = len < a.st.cap ? len : a.st.cap;
+            const size_t base = (size_t)region * a.st.cap;
+            for (uint32_t i0 = tid; i0 < len; i0 += TSQ_AF_NT * U) {
+                uint64_t tag[U], cells[U][TSQ_RADIX_MAXV];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * TSQ_AF_NT;
+                    tag[u] = 0;
+                    cells[u][0] = cells[u][1] = 0;
+                    if (i < len) {
+                        tag[u] = a.st.keys[base + i];
+#pragma unroll
+                        for (int v = 0; v < TSQ_RADIX_MAXV; v++)
+                            if (v < a.plan.V) cells[u][v] = a.st.pay[v][base + i];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (i0 + (uint32_t)u * TSQ_AF_NT < len) apply(tag[u], cells[u][0], cells[u][1]);
+            }
+        }
+    } else {
+        uint32_t n = *a.st.ovf_count;
+        n = n < a.st.ovf_cap ? n : a.st.ovf_cap;
+        for (uint32_t i = blockIdx.x * TSQ_AF_NT + tid; i < n; i += gridDim.x * TSQ_AF_NT) {
+            uint64_t cells[TSQ_RADIX_MAXV] = {0, 0};
+#pragma unroll
+            for (int v = 0; v < TSQ_RADIX_MAXV; v++)
+                if (v < a.plan.V) cells[v] = a.st.ovf_pay[v][i];
+            apply(a.st.ovf_keys[i], cells[0], cells[1]);
+        }
+    }
+    __syncthreads();
+    // emit the partial groups of this workgroup: ONE returning atomic per workgroup claims s_used records (a
+    // same-address atomic per wave costs ~11 ns each chip-wide: 65 K of them were 0.6 ms of a 1 ms kernel),
+    // then a block scan per 1024-slot pass places every occupied slot
+    __shared__ uint32_t s_base, s_wsum[TSQ_AF_NT / 64];
+    if (tid == 0) s_base = s_used ? __hip_atomic_fetch_add(a.out.count, s_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    __syncthreads();
+    uint32_t running = s_base;
+    for (uint32_t i0 = 0; i0 < S; i0 += TSQ_AF_NT) {
+        const uint32_t i = i0 + tid;
+        const unsigned long long key = s_key[i];
+        const bool occ = key != TSQ_AF_EMPTY;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<TSQ_AF_NT>(occ ? 1u : 0u, s_wsum, &total);
+        const uint32_t o = running + ex;
+        running += total;
+        __syncthreads();  // s_wsum is reused by the next pass
+        if (occ) {
+            if (o < a.out.cap) {
+                a.out.key[o] = key;
+                unsigned long long w[W];
+#pragma unroll
+                for (int k = 0; k < W; k++) w[k] = s_w[k][i];
+                for (int q = 0; q < a.plan.n_aggs; q++) {  // split int64 sums -> (lo, hi) of the 128-bit value
+                    const AfAgg f = a.plan.f[q];
+                    if (f.w < 0 || (f.func != TSQ_AGG_SUM && f.func != TSQ_AGG_AVG) || af_is_real(f.type)) continue;
+#pragma unroll
+                    for (int k = 0; k + 1 < W; k++) {
+                        if (k == f.w) {
+                            const unsigned long long lo32 = w[k], hi32 = w[k + 1];
+                            const unsigned long long lo = (hi32 << 32) + lo32;
+                            w[k] = lo;
+                            w[k + 1] = (unsigned long long)((long long)hi32 >> 32) + (lo < lo32 ? 1ull : 0ull);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < W; k++) a.out.w[k][o] = w[k];
+            }
+        }
+    }
+}
+
+#endif

@@ -560,6 +560,7 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, nregions * 4, ctx->stream));
 
     RadixSrc src;
+    memset(&src, 0, sizeof src);
     const int kc = j->ks.pidx[0];
     src.data = pcs.data[kc];
     src.nulls = pcs.nulls[kc];
@@ -573,7 +574,7 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
         if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
-    hipLaunchKernelGGL((k_radix_partition<NT, K, 4, false>), dim3(pgrid), dim3(NT), 0, ctx->stream, src, st);
+    hipLaunchKernelGGL((k_radix_partition<NT, K, 4, 0, false>), dim3(pgrid), dim3(NT), 0, ctx->stream, src, st);
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     RadixProbeArgs pa;

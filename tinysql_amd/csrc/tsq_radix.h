@@ -32,8 +32,11 @@
 #define TSQ_RADIX_MAX_P (1 << TSQ_RADIX_MAX_BITS)
 #define TSQ_RADIX_MAXSEG 2048
 
+#define TSQ_RADIX_MAXV 2
 struct RadixStore {
     uint64_t* keys;        // [P * R * cap] key words
+    uint64_t* pay[TSQ_RADIX_MAXV];      // [P * R * cap] payload cells travelling with the key (optional)
+    uint64_t* ovf_pay[TSQ_RADIX_MAXV];  // payload of the overflow list
     uint32_t* idx;         // [P * R * cap] source row ids (optional)
     uint32_t* cursor;      // [P * R] slots claimed per region (may exceed cap after an overflow)
     uint32_t* valid_end;   // [P * R] first slot that was NOT written (0xffffffff: none)
@@ -44,13 +47,34 @@ struct RadixStore {
     uint32_t ovf_cap;
     uint32_t bits, R, cap;
 };
-struct RadixSrc {  // one key column of a device-resident chunk (util/chunk/column.go:28-34)
+struct RadixSrc {  // one key column (+ up to two payload columns) of a device-resident chunk (util/chunk/column.go:28-34)
     const void* data;
     const uint8_t* nulls;
     int32_t type;
     int32_t skip_high;
     int64_t nrows;
+    // key_kind 0: join key word (util/codec/codec.go:212-240); 1: GROUP BY key word (codec.go:713-746: reals by
+    // their memcomparable image).  Rows with a NULL key or a NULL payload cell are not partitioned: kind 0 drops
+    // them (inner join), kind 1 appends their row ids to exc_rows (the aggregate handles them row by row).
+    int32_t key_kind;
+    int32_t vtype[TSQ_RADIX_MAXV];
+    const void* vdata[TSQ_RADIX_MAXV];
+    const uint8_t* vnulls[TSQ_RADIX_MAXV];
+    uint32_t* exc_rows;
+    uint32_t* exc_count;
 };
+__device__ __forceinline__ uint64_t radix_src_key(const RadixSrc& src, int64_t row) {
+    if (src.key_kind == 0) {
+        uint32_t flag;
+        return tsq_key_word(src.data, src.type, row, &flag);
+    }
+    if (src.type == TSQ_F32 || src.type == TSQ_F64) {  // util/codec/float.go:22-30
+        const double f = src.type == TSQ_F32 ? (double)((const float*)src.data)[row] : ((const double*)src.data)[row];
+        const uint64_t u = tsq_f64_bits(f);
+        return f >= 0 ? (u | 0x8000000000000000ULL) : ~u;
+    }
+    return ((const uint64_t*)src.data)[row];
+}
 
 __device__ __forceinline__ uint32_t tsq_xcc_id() {
     uint32_t x;
@@ -81,11 +105,13 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wsum
 // K5a — radix partition.  One workgroup sorts a tile of NT*K key words by partition inside LDS
 // (LDS histogram with returning ds_add -> block scan -> LDS scatter) and writes each partition's run
 // with consecutive lanes on consecutive addresses.
-// Algorithmic bytes: 8 B read + 8 B written per key (+4 B with row ids).
+// Algorithmic bytes: 8 B read + 8 B written per key (+8 B each way per payload column, +4 B with row ids).
 // MINW = waves per SIMD the register allocation must leave room for (blocks/CU * NT / 256).
-template <int NT, int K, int MINW, bool WITH_IDX>
+template <int NT, int K, int MINW, int V, bool WITH_IDX>
 __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, RadixStore st) {
     constexpr int T = NT * K;
+    static_assert(V >= 0 && V <= TSQ_RADIX_MAXV, "payload columns");
+    __shared__ uint64_t s_pay[V ? V : 1][V ? T : 1];
     constexpr int MAXPER = (TSQ_RADIX_MAX_P + NT - 1) / NT;
     static_assert(T <= 65536 && (K % 2) == 0, "tile");
     __shared__ uint64_t s_keys[T];
@@ -100,12 +126,15 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
     if (tid == 0) s_flag = 0;
     const int64_t ntiles = (src.nrows + T - 1) / T;
-    const bool wide = src.nulls == nullptr && src.type != TSQ_F32 && !src.skip_high;
+    bool wide = src.nulls == nullptr && src.type != TSQ_F32 && !src.skip_high && !(src.key_kind == 1 && src.type == TSQ_F64);
+#pragma unroll
+    for (int v = 0; v < V; v++) wide = wide && src.vnulls[v] == nullptr && src.vtype[v] != TSQ_F32;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = tile * T;
         const int64_t rem = src.nrows - base;
         const uint32_t n = rem < T ? (uint32_t)rem : (uint32_t)T;
         uint64_t k[K];
+        uint64_t pay[V ? V : 1][K];
         uint32_t pr[K];  // (partition << 16) | rank inside the tile, 0xffffffff = no key
         for (uint32_t p = tid; p < P; p += NT) s_hist[p] = 0;
         const bool full = wide && n == (uint32_t)T;
@@ -117,16 +146,39 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                 k[2 * j] = v.x;
                 k[2 * j + 1] = v.y;
             }
+#pragma unroll
+            for (int vv = 0; vv < V; vv++) {
+                const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>((const uint64_t*)src.vdata[vv] + base);
+#pragma unroll
+                for (int j = 0; j < K / 2; j++) {
+                    const ulonglong2 v = p2[j * NT + tid];
+                    pay[vv][2 * j] = v.x;
+                    pay[vv][2 * j + 1] = v.y;
+                }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 const uint32_t pos = (uint32_t)j * NT + tid;
                 pr[j] = 0xffffffffu;
                 k[j] = 0;
-                if (pos < n && !tsq_is_null(src.nulls, base + pos)) {
-                    uint32_t flag;
-                    k[j] = tsq_key_word(src.data, src.type, base + pos, &flag);
-                    if (!(src.skip_high && (k[j] >> 63))) pr[j] = 0;
+#pragma unroll
+                for (int vv = 0; vv < V; vv++) pay[vv][j] = 0;
+                if (pos < n) {
+                    bool isnull = tsq_is_null(src.nulls, base + pos);
+#pragma unroll
+                    for (int vv = 0; vv < V; vv++) isnull |= tsq_is_null(src.vnulls[vv], base + pos);
+                    if (!isnull) {
+                        k[j] = radix_src_key(src, base + pos);
+                        if (!(src.skip_high && (k[j] >> 63))) pr[j] = 0;
+#pragma unroll
+                        for (int vv = 0; vv < V; vv++)
+                            pay[vv][j] = src.vtype[vv] == TSQ_F32 ? (uint64_t)((const uint32_t*)src.vdata[vv])[base + pos]
+                                                                 : ((const uint64_t*)src.vdata[vv])[base + pos];
+                    } else if (src.key_kind == 1) {
+                        const uint32_t e = __hip_atomic_fetch_add(src.exc_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        src.exc_rows[e] = (uint32_t)(base + pos);
+                    }
                 }
             }
         }
@@ -174,6 +226,8 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
             if (full || pr[j] != 0xffffffffu) {
                 const uint32_t d = (s_hist[pr[j] >> 16] & 0x7fffffffu) + (pr[j] & 0xffffu);
                 s_keys[d] = k[j];
+#pragma unroll
+                for (int vv = 0; vv < V; vv++) s_pay[vv][d] = pay[vv][j];
                 if (WITH_IDX) {
                     const uint32_t pos = full ? (((uint32_t)(j >> 1) * NT + tid) * 2 + (j & 1)) : ((uint32_t)j * NT + tid);
                     s_idx[d] = (uint32_t)base + pos;
@@ -188,6 +242,8 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
             if (!any_ovf || !(s_hist[p] >> 31)) {
                 const uint32_t d = s_delta[p] + i;
                 st.keys[d] = key;
+#pragma unroll
+                for (int vv = 0; vv < V; vv++) st.pay[vv][d] = s_pay[vv][i];
                 if (WITH_IDX) st.idx[d] = s_idx[i];
             }
         }
@@ -199,6 +255,8 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                     const uint32_t o = __hip_atomic_fetch_add(st.ovf_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (o < st.ovf_cap) {
                         st.ovf_keys[o] = key;
+#pragma unroll
+                        for (int vv = 0; vv < V; vv++) st.ovf_pay[vv][o] = s_pay[vv][i];
                         if (WITH_IDX) st.ovf_idx[o] = s_idx[i];
                     }
                 }
@@ -216,7 +274,7 @@ struct RadixProbeArgs {
 };
 
 // matches of kw in the buckets FOLLOWING bkt (the home bucket was full)
-__device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, uint64_t kw, uint64_t bkt) {
+static __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, uint64_t kw, uint64_t bkt) {
     uint32_t c = 0;
     for (;;) {
         bkt = (bkt + 1 == t.nbuckets) ? 0 : bkt + 1;
@@ -395,7 +453,7 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
 }
 
 // the overflow list (runs that did not fit their region): plain grid-stride probe
-__global__ void __launch_bounds__(256) k_radix_probe_ovf(RadixProbeArgs a) {
+static __global__ void __launch_bounds__(256) k_radix_probe_ovf(RadixProbeArgs a) {
     uint32_t n = *a.st.ovf_count;
     n = n < a.st.ovf_cap ? n : a.st.ovf_cap;
     uint64_t cnt = 0;

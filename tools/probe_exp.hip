@@ -954,8 +954,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&st.valid_end, P * 8 * 4)); CK(hipMemset(st.valid_end, 0xff, P * 8 * 4));
     CK(hipMalloc(&st.ovf_keys, (size_t)NP * 8)); CK(hipMalloc(&st.ovf_count, 4)); CK(hipMemset(st.ovf_count, 0, 4));
     st.ovf_cap = (uint32_t)NP;
-    RadixSrc src{pk, nullptr, TSQ_I64, 0, NP};
-    hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, false, false>), dim3(CUS), dim3(1024), 0, 0, src, st);
+    RadixSrc src{};
+    src.data = pk; src.type = TSQ_I64; src.nrows = NP;
+    hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, 0, false>), dim3(CUS), dim3(1024), 0, 0, src, st);
     CK(hipDeviceSynchronize());
     RadixProbeArgs pa{st, t, counters};
     const uint32_t J = (uint32_t)(CUS / 8 * Jc);

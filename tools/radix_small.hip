@@ -56,10 +56,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&st.ovf_keys, NP * 8 + 64)); CK(hipMalloc(&st.ovf_count, 4)); CK(hipMemset(st.ovf_count, 0, 4));
     CK(hipMalloc(&st.queue, 8 * TSQ_RADIX_QSTRIDE * 8)); CK(hipMemset(st.queue, 0, 8 * TSQ_RADIX_QSTRIDE * 8));
     st.ovf_cap = (uint32_t)NP;
-    RadixSrc src{pk, nullptr, TSQ_I64, 0, NP};
+    RadixSrc src{};
+    src.data = pk; src.type = TSQ_I64; src.nrows = NP;
     const int T = 16384;
     int grid = (int)((NP + T - 1) / T); if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, false>), dim3(grid), dim3(1024), 0, 0, src, st);
+    hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, 0, false>), dim3(grid), dim3(1024), 0, 0, src, st);
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     std::vector<uint32_t> cur(nreg), ve(nreg); uint32_t ovf;

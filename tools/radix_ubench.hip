@@ -128,7 +128,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&st.ovf_count, 4));
     st.ovf_cap = OVF_CAP;
     unsigned long long* d_sum; CK(hipMalloc(&d_sum, 16));
-    RadixSrc src{pk, nullptr, TSQ_I64, 0, NP};
+    RadixSrc src{};
+    src.data = pk; src.type = TSQ_I64; src.nrows = NP;
 
     CK(hipMalloc(&st.queue, 8 * TSQ_RADIX_QSTRIDE * 8));
     auto run_variant = [&](uint32_t bits, int NT, int K, int blocks_per_cu) {
@@ -150,7 +151,7 @@ int main(int argc, char** argv) {
         };
         auto launch_part = [&] {
 #define PART(NT_, K_, W_) \
-    if (NT == NT_ && K == K_) hipLaunchKernelGGL((k_radix_partition<NT_, K_, W_, false>), dim3(grid), dim3(NT_), 0, 0, src, st);
+    if (NT == NT_ && K == K_) hipLaunchKernelGGL((k_radix_partition<NT_, K_, W_, 0, false>), dim3(grid), dim3(NT_), 0, 0, src, st);
             PART(256, 16, 3) PART(512, 8, 6) PART(512, 14, 4) PART(1024, 16, 4)
         };
         float best = 1e30f;
