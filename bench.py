@@ -196,7 +196,7 @@ def main():
     radix = st.radix_batches > 0
     if radix and st.radix_timed_batches > 0:
         nt = min(st.radix_timed_batches, args.steps)  # the event ring keeps the most recent batches = the timed steps
-        kernel_name = "k_radix_probe_count<2>"
+        kernel_name = "k_radix_probe_count<2,0>"
         kernel_ms = st.radix_probe_kernel_ms_sum / st.radix_timed_batches
         part_ms = st.partition_kernel_ms_sum / st.radix_timed_batches
     else:
@@ -238,8 +238,8 @@ def main():
         w = tj["workload"]
         if w["probe_rows"] == npr and w["build_rows"] == nb and world == 1:
             if radix and w["radix_bits"] == st.radix_bits:
-                traffic = tj["k_radix_probe_count<2>"]["traffic_bytes"]
-                traffic_part = tj["k_radix_partition<1024,16,4,false>"]["traffic_bytes"]
+                traffic = tj["k_radix_probe_count<2,0>"]["traffic_bytes"]
+                traffic_part = tj["k_radix_partition<1024,16,4,0,false>"]["traffic_bytes"]
             elif not radix:
                 traffic = tj["k_probe_count<false,false,false> (direct probe, --radix off)"]["traffic_bytes"]
     except Exception:
@@ -256,7 +256,7 @@ def main():
         }
         if radix:
             pb = 16.0 * npr  # 8 B key read + 8 B key written per probe row (COUNT(*) carries no payload)
-            out["roofline"]["partition"] = {"kernel": "k_radix_partition<1024,16,4,false>", "kernel_ms": part_ms,
+            out["roofline"]["partition"] = {"kernel": "k_radix_partition<1024,16,4,0,false>", "kernel_ms": part_ms,
                                             "algorithmic_bytes_per_launch": pb, "achieved": pb / (part_ms * 1e-3) / 1e9,
                                             "frac": pb / (part_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic_part}
             out["radix_overflow_rows"] = st.radix_overflow_rows

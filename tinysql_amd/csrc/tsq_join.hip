@@ -578,11 +578,12 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     RadixProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
     pa.st = st;
     fill_table(j, pa.t);
     pa.counters = j->counters.as<unsigned long long>();
     const int per_xcd = std::max(1, ctx->num_cus / 8) * 6;  // 6 workgroups per CU (measured optimum 5-6)
-    hipLaunchKernelGGL((k_radix_probe_count<2>), dim3(per_xcd * 8), dim3(256), 0, ctx->stream, pa);
+    hipLaunchKernelGGL((k_radix_probe_count<2, 0>), dim3(per_xcd * 8), dim3(256), 0, ctx->stream, pa);
     TSQ_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(k_radix_probe_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
     TSQ_HIP(h, hipGetLastError());

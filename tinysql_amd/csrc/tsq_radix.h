@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
 struct RadixProbeArgs {
     RadixStore st;
     JoinTable t;
+    uint32_t pf_lead;
     unsigned long long* counters;  // [0] += joined rows
 };
 
@@ -309,7 +310,12 @@ static __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, ui
 // resolved later by full waves (deferred spill) instead of stalling its wave on a dependent load.
 // Algorithmic bytes: 8 B key + one 16 B slot per probe row.
 #define TSQ_RADIX_QSTRIDE 64  // queue heads 512 B apart: each on its own L2 channel
-template <int U>
+// PFB > 0: the first PFB workgroups of every virtual XCD are LOADERS: they never probe, they stream the
+// table slices of the partitions just ahead of the consumers' ticket head into the XCD's L2 (one 4-byte
+// touch per 128-byte line, many in flight) so that the consumers' bucket reads are L2 hits instead of
+// hits on a pending miss.  (The same touches issued by the consumer waves themselves made them slower:
+// vector-memory results return in order, so every bucket read then waited for a prefetch's HBM latency.)
+template <int U, int PFB>
 __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
     constexpr uint32_t CH = 256 * U;
     constexpr uint32_t END = 0xffffffffu;
@@ -321,11 +327,15 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
     __shared__ uint32_t s_dn[2];
     __shared__ uint64_t s_spk[SPCAP], s_spb[SPCAP];
     __shared__ uint32_t s_spn;
+    __shared__ unsigned long long s_total;
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t vx = blockIdx.x & 7u;
     const uint32_t P = 1u << a.st.bits, NP = P >> 3, cap = a.st.cap;
-    if (tid == 0) s_spn = 0;
+    if (tid == 0) {
+        s_spn = 0;
+        s_total = 0;
+    }
     for (uint32_t i = tid; i < NP * 8; i += 256) {
         const uint32_t region = ((i >> 3) * 8 + vx) * 8 + (i & 7);
         uint32_t len = a.st.cursor[region];
@@ -345,6 +355,41 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
     }
     __syncthreads();
     const uint32_t nchunks = s_cstart[NP];
+    if (PFB > 0 && (blockIdx.x >> 3) < (uint32_t)PFB) {
+        const uint32_t lj = blockIdx.x >> 3;      // loader index inside the XCD
+        const uint32_t shift = 64 - a.st.bits;
+        const uint32_t lead = a.pf_lead;          // partitions the loaders may run ahead of the ticket head
+        uint32_t next = 0, acc = 0, prev = 0;
+        for (int spin = 0; next < NP && spin < (1 << 22); spin++) {
+            // partition of the ticket head = where the consumers are
+            const uint32_t t = (uint32_t)__hip_atomic_load(&a.st.queue[vx * TSQ_RADIX_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t >= nchunks) break;
+            uint32_t lo = 0, hi = NP;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_cstart[mid] <= t) lo = mid;
+                else hi = mid;
+            }
+            if (next < lo) next = lo;             // never fetch what the consumers have already left behind
+            if (next > lo + lead) {
+                __builtin_amdgcn_s_sleep(16);
+                continue;
+            }
+            const uint64_t pp = (uint64_t)next * 8 + vx;
+            const uint64_t b0 = tsq_mulhi64(pp << shift, a.t.nbuckets);
+            const uint64_t b1 = pp + 1 == P ? a.t.nbuckets : tsq_mulhi64((pp + 1) << shift, a.t.nbuckets);
+            const uint64_t nlines = ((b1 - b0) * 64 + 127) / 128;
+            const uint64_t l0 = nlines * lj / PFB, l1 = nlines * (lj + 1) / PFB;
+            const char* pb = reinterpret_cast<const char*>(a.t.keys + b0 * TSQ_BUCKET);
+            for (uint64_t l = l0 + tid; l < l1; l += 256) {
+                acc ^= prev;
+                prev = *reinterpret_cast<const uint32_t*>(pb + l * 128);
+            }
+            next++;
+        }
+        if ((acc ^ prev) == 0x9e3779b9u) atomicAdd(&a.counters[7], 1ull);  // keeps the touches alive
+        return;
+    }
     auto take = [&]() -> uint32_t {
         return (uint32_t)__hip_atomic_fetch_add(&a.st.queue[vx * TSQ_RADIX_QSTRIDE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -370,7 +415,8 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
         s_dn[slot] = len - c * CH < CH ? len - c * CH : CH;
         s_dsrc[slot] = (uint64_t)(a.st.keys + (size_t)(p * 8 + r) * cap + (size_t)c * CH);
     };
-    uint64_t cnt = 0;
+    uint64_t cnt = 0;   // per lane (drain path)
+    uint64_t scnt = 0;  // per wave, lives in scalar registers
     uint32_t tk_pending = 0;
     if (tid == 0) {
         const uint32_t tA = take(), tB = take();
@@ -414,27 +460,36 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
             decode(tk_pending, it & 1);
             tk_pending = take();
         }
+        // Matches are counted on the scalar unit: the kernel is bound by vector-instruction issue (SQ counters:
+        // ACTIVE_INST_ANY x waves per SIMD > 1), so every compare writes a 64-bit lane mask and the validity /
+        // sentinel / "quad has an EMPTY slot" logic, the popcounts and the adds run as SALU on those masks.
+        const int n_u = (int)__builtin_amdgcn_readfirstlane(n), wave0 = (int)__builtin_amdgcn_readfirstlane(tid & ~63u);
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            int nv = n_u - (u * 256 + wave0);  // keys of this wave in this round: source lanes [0, nv)
+            nv = nv < 0 ? 0 : (nv > 64 ? 64 : nv);
 #pragma unroll
             for (int g = 0; g < 4; g++) {
+                int q = 4 * (nv - 16 * g);  // lane l reads the bucket of source lane 16 g + (l >> 2)
+                q = q < 0 ? 0 : (q > 64 ? 64 : q);
+                const uint64_t vmask = q >= 64 ? ~0ull : ((1ull << q) - 1ull);
+                if (vmask == 0) continue;
                 const int srcl = g * 16 + (lane >> 2);
                 const uint64_t kw = __shfl(k[u], srcl, 64);
-                const uint64_t bq = __shfl(bkt[u], srcl, 64);
-                const bool valid = (uint32_t)(u * 256) + (tid & ~63u) + (uint32_t)srcl < n;
                 const uint64_t x = L[u][g].x, y = L[u][g].y;
-                const uint64_t em = __ballot(x == TSQ_EMPTY_KEY || y == TSQ_EMPTY_KEY);
-                const bool quad_has_empty = ((em >> (lane & ~3)) & 0xfull) != 0;
-                if (valid) {
-                    if (kw == TSQ_EMPTY_KEY) {
-                        if ((lane & 3) == 0) cnt += a.t.sent_count;
-                    } else {
-                        cnt += (x == kw ? 1u : 0u) + (y == kw ? 1u : 0u);
-                        if ((lane & 3) == 0 && !quad_has_empty) {  // home bucket full: park (deferred spill)
-                            const uint32_t sl = atomicAdd(&s_spn, 1u);
-                            s_spk[sl] = kw;
-                            s_spb[sl] = bq;
-                        }
+                const uint64_t m_sent = __ballot(kw == TSQ_EMPTY_KEY) & vmask;  // probe key == the table's sentinel word
+                const uint64_t m_live = vmask & ~m_sent;
+                scnt += (uint64_t)__popcll(__ballot(x == kw) & m_live) + (uint64_t)__popcll(__ballot(y == kw) & m_live);
+                if (m_sent) scnt += (uint64_t)__popcll(m_sent & 0x1111111111111111ull) * a.t.sent_count;
+                const uint64_t m_e = __ballot(x == TSQ_EMPTY_KEY || y == TSQ_EMPTY_KEY);
+                const uint64_t quad_e = (m_e | (m_e >> 1) | (m_e >> 2) | (m_e >> 3)) & 0x1111111111111111ull;
+                const uint64_t park = m_live & 0x1111111111111111ull & ~quad_e;  // home bucket full: deferred spill
+                if (park) {
+                    const uint64_t bq = __shfl(bkt[u], srcl, 64);
+                    if ((park >> lane) & 1ull) {
+                        const uint32_t sl = atomicAdd(&s_spn, 1u);
+                        s_spk[sl] = kw;
+                        s_spb[sl] = bq;
                     }
                 }
             }
@@ -448,8 +503,10 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
             __syncthreads();
         }
     }
-    cnt = wave_sum_u64(cnt);
-    if ((tid & 63) == 0 && cnt) atomicAdd(&a.counters[0], (unsigned long long)cnt);
+    cnt = wave_sum_u64(cnt) + scnt;
+    if ((tid & 63) == 0 && cnt) atomicAdd(&s_total, (unsigned long long)cnt);
+    __syncthreads();
+    if (tid == 0 && s_total) atomicAdd(&a.counters[0], s_total);  // one device atomic per workgroup
 }
 
 // the overflow list (runs that did not fit their region): plain grid-stride probe

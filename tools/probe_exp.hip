@@ -958,7 +958,8 @@ int main(int argc, char** argv) {
     src.data = pk; src.type = TSQ_I64; src.nrows = NP;
     hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, 0, false>), dim3(CUS), dim3(1024), 0, 0, src, st);
     CK(hipDeviceSynchronize());
-    RadixProbeArgs pa{st, t, counters};
+    RadixProbeArgs pa{};
+    pa.st = st; pa.t = t; pa.counters = counters;
     const uint32_t J = (uint32_t)(CUS / 8 * Jc);
     auto report = [&](const char* name, float ms) {
         unsigned long long c[8];

@@ -69,8 +69,9 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < nreg; i++) { uint32_t c = cur[i] < ve[i] ? cur[i] : ve[i]; c = c < st.cap ? c : st.cap; stored += c; mx = c > mx ? c : mx; }
     printf("partition done: cap=%u stored=%llu ovf=%u maxfill=%u\n", st.cap, (unsigned long long)stored, ovf, mx); fflush(stdout);
     unsigned long long* counters; CK(hipMalloc(&counters, 64)); CK(hipMemset(counters, 0, 64));
-    RadixProbeArgs pa{st, t, counters};
-    hipLaunchKernelGGL((k_radix_probe_count<2>), dim3(8 * 32 * 6), dim3(256), 0, 0, pa);
+    RadixProbeArgs pa{};
+    pa.st = st; pa.t = t; pa.counters = counters;
+    hipLaunchKernelGGL((k_radix_probe_count<2, 0>), dim3(8 * 32 * 6), dim3(256), 0, 0, pa);
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     printf("probe done\n"); fflush(stdout);

@@ -168,19 +168,21 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(&ovf, st.ovf_count, 4, hipMemcpyDeviceToHost));
         printf("PART bits=%2u NT=%4d K=%2d grid=%4d cap=%6u : %.3f ms  %.1f Gkeys/s  %.0f GB/s(16B/key)  stored=%llu ovf=%u maxfill=%llu %s\n", bits, NT, K, grid,
                st.cap, best, NP / best / 1e6, NP * 16.0 / best / 1e6, hs[0], ovf, hs[1], hs[0] + ovf == (unsigned long long)NP ? "ok" : "BAD");
-        RadixProbeArgs pa{st, t, counters};
-        for (int Jc : {3, 4, 5, 6}) {  // workgroups per CU
+        RadixProbeArgs pa{};
+        pa.st = st; pa.t = t; pa.counters = counters;
+        for (int Jc : {5, 6}) {  // workgroups per CU
             const uint32_t J = (uint32_t)(CUS / 8 * Jc);
-            for (int U : {1, 2, 4}) {
+            for (int U : {2, 102, 202, 112, 212, 122, 222}) {  // U + 100*PFB + 10*(lead-1)
                 float bestp = 1e30f;
                 unsigned long long c = 0;
                 for (int rep = 0; rep < 3; rep++) {
                     CK(hipMemset(st.queue, 0, 8 * TSQ_RADIX_QSTRIDE * 8));
                     CK(hipMemset(counters, 0, 64));
                     float ms = time_ms([&] {
-                        if (U == 1) hipLaunchKernelGGL((k_radix_probe_count<1>), dim3(J * 8), dim3(256), 0, 0, pa);
-                        if (U == 2) hipLaunchKernelGGL((k_radix_probe_count<2>), dim3(J * 8), dim3(256), 0, 0, pa);
-                        if (U == 4) hipLaunchKernelGGL((k_radix_probe_count<4>), dim3(J * 8), dim3(256), 0, 0, pa);
+                        pa.pf_lead = (uint32_t)((U / 10) % 10) + 1;
+                        if (U / 100 == 0) hipLaunchKernelGGL((k_radix_probe_count<2, 0>), dim3(J * 8), dim3(256), 0, 0, pa);
+                        if (U / 100 == 1) hipLaunchKernelGGL((k_radix_probe_count<2, 1>), dim3((J + 1) * 8), dim3(256), 0, 0, pa);
+                        if (U / 100 == 2) hipLaunchKernelGGL((k_radix_probe_count<2, 2>), dim3((J + 2) * 8), dim3(256), 0, 0, pa);
                         hipLaunchKernelGGL(k_radix_probe_ovf, dim3(256), dim3(256), 0, 0, pa);
                     }, 1);
                     bestp = ms < bestp ? ms : bestp;
@@ -196,7 +198,6 @@ int main(int argc, char** argv) {
     int vi = 0;
 #define V(...) { if (only < 0 || only == vi) run_variant(__VA_ARGS__); vi++; }
     V(10, 1024, 16, 1)
-    V(9, 1024, 16, 1)
     V(11, 1024, 16, 1)
     return 0;
 }
