@@ -53,3 +53,33 @@ def test_radix_split_partitions_exactly(ctx, parts):
     finally:
         for d in src + dst:
             d.free()
+
+
+@pytest.mark.parametrize("parts,ncols", [(2, 1), (4, 2), (8, 3), (8, 1)])
+def test_radix_split_fast_path_tile_sort(ctx, parts, ncols):
+    # 8-byte columns without NULL bitmaps and >= 64 Ki rows take the LDS tile-sort path (k_rank_hist +
+    # k_radix_partition with exact region bases): same contract — contiguous runs, every row in the part its key ranks to,
+    # payload cells travel with their key.
+    rank = _rank_fn()
+    rng = np.random.default_rng(7 * parts + ncols)
+    n = 300_007
+    k = rng.integers(-10**12, 10**12, n)
+    cols = [Column(abi.I64, k)] + [Column(abi.I64, k * (j + 2) + j) for j in range(ncols - 1)]
+    src = [G.to_device(ctx, c) for c in cols]
+    dst = [G.DevCol(ctx, abi.I64, n) for _ in cols]
+    try:
+        counts = (C.c_int64 * parts)()
+        _lib.check(ctx.lib.tsq_radix_split(ctx.h, G.dev_cols(src), ncols, 0, 0, n, parts, G.dev_cols(dst), counts), ctx.h)
+        counts = list(counts)
+        assert sum(counts) == n
+        out = [d.to_host().data for d in dst]
+        want_rank = np.array([rank(int(x) & ((1 << 64) - 1), parts) for x in out[0][:: max(1, n // 5000)]])
+        bounds = np.cumsum([0] + counts)
+        got_part = np.searchsorted(bounds, np.arange(n)[:: max(1, n // 5000)], side="right") - 1
+        assert np.array_equal(want_rank, got_part)
+        for j in range(1, ncols):
+            assert np.array_equal(out[j], out[0] * (j + 1) + (j - 1))
+        assert np.array_equal(np.sort(out[0]), np.sort(k))
+    finally:
+        for d in src + dst:
+            d.free()

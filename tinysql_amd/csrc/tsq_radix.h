@@ -44,6 +44,10 @@ struct RadixStore {
     uint32_t* ovf_idx;
     uint32_t* ovf_count;
     unsigned long long* queue;  // 8 chunk-queue heads, TSQ_RADIX_QSTRIDE words apart (probe side)
+    // multi-GPU redistribute (tsq_radix_split): partition = tsq_key_rank(key, rank_parts) instead of the top hash bits,
+    // one exactly sized region per part starting at region_base[part] (cap is then unused: nothing can overflow)
+    const uint32_t* region_base;
+    uint32_t rank_parts;
     uint32_t ovf_cap;
     uint32_t bits, R, cap;
 };
@@ -121,11 +125,12 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_flag;
     const uint32_t tid = threadIdx.x;
-    const uint32_t P = 1u << st.bits, shift = 64 - st.bits;
-    const uint32_t r = tsq_xcc_id();
+    const uint32_t P = st.rank_parts ? st.rank_parts : 1u << st.bits, shift = 64 - st.bits;
+    const uint32_t r = st.rank_parts ? 0u : tsq_xcc_id();
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
     if (tid == 0) s_flag = 0;
     const int64_t ntiles = (src.nrows + T - 1) / T;
+    auto part_of = [&](uint64_t kw) -> uint32_t { return st.rank_parts ? tsq_key_rank(kw, st.rank_parts) : tsq_radix_part(kw, shift); };
     bool wide = src.nulls == nullptr && src.type != TSQ_F32 && !src.skip_high && !(src.key_kind == 1 && src.type == TSQ_F64);
 #pragma unroll
     for (int v = 0; v < V; v++) wide = wide && src.vnulls[v] == nullptr && src.vtype[v] != TSQ_F32;
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
 #pragma unroll
         for (int j = 0; j < K; j++) {
             if (full || pr[j] == 0) {
-                const uint32_t p = tsq_radix_part(k[j], shift);
+                const uint32_t p = part_of(k[j]);
                 pr[j] = (p << 16) | atomicAdd(&s_hist[p], 1u);
             }
         }
@@ -210,11 +215,11 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                 if (cnt) {
                     const uint32_t region = p * st.R + r;
                     const uint32_t g = atomicAdd(&st.cursor[region], cnt);
-                    if (g + cnt > st.cap) {
+                    if (!st.region_base && g + cnt > st.cap) {
                         flag = 1;
                         atomicMin(&st.valid_end[region], g);
                     }
-                    s_delta[p] = region * st.cap + g - offs;
+                    s_delta[p] = (st.region_base ? st.region_base[region] : region * st.cap) + g - offs;
                     if (flag) s_flag = 1;
                 }
                 s_hist[p] = offs | (flag << 31);
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
         const bool any_ovf = s_flag != 0;
         for (uint32_t i = tid; i < total; i += NT) {
             const uint64_t key = s_keys[i];
-            const uint32_t p = tsq_radix_part(key, shift);
+            const uint32_t p = part_of(key);
             if (!any_ovf || !(s_hist[p] >> 31)) {
                 const uint32_t d = s_delta[p] + i;
                 st.keys[d] = key;
@@ -250,7 +255,7 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
         if (any_ovf) {  // rare (skewed keys): runs that did not fit go to the overflow list, one slot at a time
             for (uint32_t i = tid; i < total; i += NT) {
                 const uint64_t key = s_keys[i];
-                const uint32_t p = tsq_radix_part(key, shift);
+                const uint32_t p = part_of(key);
                 if (s_hist[p] >> 31) {
                     const uint32_t o = __hip_atomic_fetch_add(st.ovf_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (o < st.ovf_cap) {
