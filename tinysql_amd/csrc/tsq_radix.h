@@ -279,6 +279,14 @@ struct RadixProbeArgs {
     unsigned long long* counters;  // [0] += joined rows
 };
 
+// mulhi64(h, nb) for nb < 2^32 in two multiplies: (h * nb) >> 64 == ((h >> 32) * nb + ((h & 0xffffffff) * nb >> 32)) >> 32
+__device__ __forceinline__ uint64_t radix_bucket(uint64_t h, uint64_t nb) {
+    if (nb >> 32) return tsq_mulhi64(h, nb);
+    const uint32_t n32 = (uint32_t)nb;
+    const uint64_t q = (uint64_t)__umulhi((uint32_t)h, n32);
+    return ((h >> 32) * (uint64_t)n32 + q) >> 32;
+}
+
 // matches of kw in the buckets FOLLOWING bkt (the home bucket was full)
 static __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, uint64_t kw, uint64_t bkt) {
     uint32_t c = 0;
@@ -320,8 +328,8 @@ static __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, ui
 // touch per 128-byte line, many in flight) so that the consumers' bucket reads are L2 hits instead of
 // hits on a pending miss.  (The same touches issued by the consumer waves themselves made them slower:
 // vector-memory results return in order, so every bucket read then waited for a prefetch's HBM latency.)
-template <int U, int PFB>
-__global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
+template <int U, int PFB, int MINW = 6>
+__global__ void __launch_bounds__(256, MINW) k_radix_probe_count(RadixProbeArgs a) {
     constexpr uint32_t CH = 256 * U;
     constexpr uint32_t END = 0xffffffffu;
     constexpr uint32_t SPCAP = 2 * CH > 1024 ? 2 * CH : 1024;
@@ -352,7 +360,7 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
     {
         uint32_t nch = 0;
         if (tid < NP)
-            for (int r = 0; r < 8; r++) nch += (s_len[tid * 8 + r] + CH - 1) / CH;
+            for (int r = 0; r < 8; r++) nch += ((uint32_t)s_len[tid * 8 + r] + CH - 1) / CH;
         uint32_t total;
         const uint32_t ex = block_excl_scan<256>(nch, s_wsum, &total);
         if (tid < NP) s_cstart[tid] = ex;
@@ -412,7 +420,7 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
         const uint32_t pi = lo;
         uint32_t c = t - s_cstart[pi], r = 0;
         for (; r < 7; r++) {
-            const uint32_t cr = (s_len[pi * 8 + r] + CH - 1) / CH;
+            const uint32_t cr = ((uint32_t)s_len[pi * 8 + r] + CH - 1) / CH;
             if (c < cr) break;
             c -= cr;
         }
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             k[u] = kn[u];
-            bkt[u] = (uint32_t)(u * 256) + tid < n ? tsq_mulhi64(tsq_mix64(k[u]), a.t.nbuckets) : 0;
+            bkt[u] = (uint32_t)(u * 256) + tid < n ? radix_bucket(tsq_mix64(k[u]), a.t.nbuckets) : 0;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const uint64_t bq = __shfl(bkt[u], g * 16 + (lane >> 2), 64);
@@ -473,6 +481,7 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
         for (int u = 0; u < U; u++) {
             int nv = n_u - (u * 256 + wave0);  // keys of this wave in this round: source lanes [0, nv)
             nv = nv < 0 ? 0 : (nv > 64 ? 64 : nv);
+            const uint64_t src_sent = __ballot(k[u] == TSQ_EMPTY_KEY);  // source lanes whose probe key is the sentinel word (rare)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 int q = 4 * (nv - 16 * g);  // lane l reads the bucket of source lane 16 g + (l >> 2)
@@ -482,12 +491,16 @@ __global__ void __launch_bounds__(256) k_radix_probe_count(RadixProbeArgs a) {
                 const int srcl = g * 16 + (lane >> 2);
                 const uint64_t kw = __shfl(k[u], srcl, 64);
                 const uint64_t x = L[u][g].x, y = L[u][g].y;
-                const uint64_t m_sent = __ballot(kw == TSQ_EMPTY_KEY) & vmask;  // probe key == the table's sentinel word
-                const uint64_t m_live = vmask & ~m_sent;
+                uint64_t m_live = vmask;
+                if ((src_sent >> (16 * g)) & 0xffffull) {  // a sentinel probe key in this group of 16: it matches the side list only
+                    const uint64_t m_sent = __ballot(kw == TSQ_EMPTY_KEY) & vmask;
+                    m_live = vmask & ~m_sent;
+                    scnt += (uint64_t)__popcll(m_sent & 0x1111111111111111ull) * a.t.sent_count;
+                }
                 scnt += (uint64_t)__popcll(__ballot(x == kw) & m_live) + (uint64_t)__popcll(__ballot(y == kw) & m_live);
-                if (m_sent) scnt += (uint64_t)__popcll(m_sent & 0x1111111111111111ull) * a.t.sent_count;
-                const uint64_t m_e = __ballot(x == TSQ_EMPTY_KEY || y == TSQ_EMPTY_KEY);
-                const uint64_t quad_e = (m_e | (m_e >> 1) | (m_e >> 2) | (m_e >> 3)) & 0x1111111111111111ull;
+                // slots are claimed in order (k_build_insert takes the first EMPTY one), so a bucket still has an EMPTY
+                // slot iff its LAST slot is EMPTY: only the y word of lane 4q+3 has to be looked at
+                const uint64_t quad_e = (__ballot(y == TSQ_EMPTY_KEY) >> 3) & 0x1111111111111111ull;
                 const uint64_t park = m_live & 0x1111111111111111ull & ~quad_e;  // home bucket full: deferred spill
                 if (park) {
                     const uint64_t bq = __shfl(bkt[u], srcl, 64);
