@@ -208,6 +208,15 @@ tsq_status tsq_expr_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, in
 tsq_status tsq_filter_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows,
                            const int32_t* sel, uint8_t* selected_out, uint8_t* isnull_out,
                            int64_t* div_by_zero_warnings);
+/* Kernel selection.  TSQ_JIT_AUTO (default): once a handle has seen >= 4 Mi rows its programs are compiled into
+ * specialised kernels with hiprtc (same source as the interpreter, programs as compile-time constants: the node loop
+ * unrolls and every opcode switch folds); smaller inputs and any hiprtc failure use the generic interpreter kernels
+ * (tsq_last_error(e) after tsq_expr_jit_launches tells why).  Results are identical by construction. */
+#define TSQ_JIT_AUTO  (-1)
+#define TSQ_JIT_OFF     0
+#define TSQ_JIT_FORCE   1
+tsq_status tsq_expr_set_jit(tsq_expr* e, int32_t mode);
+int64_t    tsq_expr_jit_launches(tsq_expr* e);   /* number of launches served by specialised kernels so far */
 void       tsq_expr_destroy(tsq_expr* e);
 
 /* ---------------------------------------------------------------- hash join

@@ -16,9 +16,9 @@ from .test_hostsim_vs_oracle import all_exprs, cols_for
 pytestmark = pytest.mark.gpu
 
 
-def check_same(ctx, orc, e, chk):
+def check_same(ctx, orc, e, chk, jit=None):
     prog = E.compile_expr(e)
-    ce = E.CompiledExpr(ctx, [e])
+    ce = E.CompiledExpr(ctx, [e], jit=jit)
     try:
         try:
             want, ow = orc.expr_eval(prog, chk)
@@ -33,6 +33,8 @@ def check_same(ctx, orc, e, chk):
         wn = want.notnull if want.notnull is not None else np.ones(len(want), bool)
         assert (gn == wn).all()
         assert (got.data.view(np.uint64)[gn] == want.data.view(np.uint64)[wn]).all()
+        if jit == abi.JIT_FORCE:
+            assert ce.jit_launches() >= 1  # the specialised kernel really served the call
     finally:
         ce.close()
 
@@ -100,3 +102,35 @@ def test_selection_and_projection_executors(ctx, orc):
     rev, _ = orc.expr_eval(E.compile_expr(proj[0]), chk)
     want = [(rev.values()[i], int(chk.columns[0].data[i])) for i in np.nonzero(sel)[0]]
     assert rows == want  # Projection/Selection preserve child order (projection.go:187-207)
+
+
+def test_jit_specialised_kernels_match_oracle(ctx, orc):
+    # every builtin signature once more, through hiprtc-specialised kernels (same tsq_eval_row source with the program
+    # as a compile-time constant): results, NULLs, warnings and the first-error semantics must not change
+    rng = np.random.default_rng(36)
+    small, full = cols_for(rng, 3000, True), cols_for(rng, 3000, False)
+    exprs = all_exprs()
+    for i, e in enumerate(exprs):
+        check_same(ctx, orc, e, small if i % 2 == 0 else full, jit=abi.JIT_FORCE)
+    i64max, u64max = (1 << 63) - 1, (1 << 64) - 1
+    chk = H.chunk_from_rows([[i64max, 1, 2], [1, u64max, 1]], [abi.I64, abi.U64, abi.U64])
+    F = E.ScalarFunction
+    e = F("mul", F("mul", E.Column(0, abi.I64), F("in", E.Column(0, abi.I64), E.Constant(i64max))),
+          F("isnull", F("plus", E.Column(1, abi.U64), E.Column(2, abi.U64))))
+    check_same(ctx, orc, e, chk, jit=abi.JIT_FORCE)
+    # CNF filters
+    chk = cols_for(rng, 5000, True)
+    I, R = abi.I64, abi.F64
+    c = {i: E.Column(i, t) for i, t in enumerate([I, I, abi.U64, abi.U64, R, R, abi.F32])}
+    lists = [[F("gt", c[0], E.Constant(0))], [c[0], c[4]],
+             [F("gt", c[0], E.Constant(-50000)), F("lt", F("plus", c[0], c[1]), E.Constant(1000)), c[5]],
+             [F("or", F("isnull", c[0]), F("gt", c[1], E.Constant(0))), F("div", c[4], F("minus", c[5], c[5]))]]
+    for lst in lists:
+        ce = E.CompiledExpr(ctx, lst, jit=abi.JIT_FORCE)
+        try:
+            sel, nulls = ce.VectorizedFilter(chk, want_nulls=True)
+            osel, onull, ow = orc.filter_eval(ce.progs, len(lst), chk)
+            assert (sel == osel).all() and (nulls == onull).all() and ce.warnings == ow
+            assert ce.jit_launches() >= 1
+        finally:
+            ce.close()

@@ -8,6 +8,7 @@ import ctypes as C
 TSQ_ABI_VERSION = 2
 RADIX_AUTO, RADIX_OFF, RADIX_FORCE = -1, 0, 1
 AGGFAST_AUTO, AGGFAST_OFF, AGGFAST_FORCE = -1, 0, 1
+JIT_AUTO, JIT_OFF, JIT_FORCE = -1, 0, 1
 
 # status codes
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM_DEVICE, ERR_HIP = 0, 1, 2, 3, 4
@@ -139,6 +140,8 @@ SIGNATURES = {
     "tsq_expr_compile": (C.c_int32, [P, C.POINTER(ExprProg), C.c_int32, PP]),
     "tsq_expr_eval": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_filter_eval": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, P, P, C.POINTER(C.c_int64)]),
+    "tsq_expr_set_jit": (C.c_int32, [P, C.c_int32]),
+    "tsq_expr_jit_launches": (C.c_int64, [P]),
     "tsq_expr_destroy": (None, [P]),
     "tsq_join_create": (C.c_int32, [P, C.POINTER(JoinCfg), PP]),
     "tsq_join_build_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),

@@ -92,6 +92,8 @@ TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+    (void)hipDeviceSynchronize();
+    for (hipModule_t m : ctx->retired_modules) (void)hipModuleUnload(m);
     ctx->hdr.magic = 0;
     delete ctx;
 }

@@ -17,6 +17,19 @@
 #else
 #define TSQ_HD inline
 #endif
+// A value every lane of the wave agrees on (the expression program is the same for all rows): telling the
+// compiler so turns the interpreter's switch into scalar branches instead of exec-masked regions for every case.
+#if defined(TSQ_JIT)
+// run-time specialisation (tsq_expr.hip): the program is a compile-time constant, the op loop unrolls and folds
+#define TSQ_UNIFORM(x) ((int)(x))
+#define TSQ_JIT_UNROLL _Pragma("unroll")
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define TSQ_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
+#define TSQ_JIT_UNROLL
+#else
+#define TSQ_UNIFORM(x) ((int)(x))
+#define TSQ_JIT_UNROLL
+#endif
 
 // ------------------------------------------------------------------ hashing
 // splitmix64 — the synthetic-table generator of SURVEY.md §8(d), also the row-checksum mixer.
@@ -221,25 +234,50 @@ TSQ_HD bool tsq_real_is_zero(double f) {
 // postfix index of the offending node.  *div0 is incremented per x/0 (errors.go:65-77 warning).
 template <class Src>
 TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* out, int* err_node, int* div0) {
-    tsq_val st[TSQ_EXPR_MAX_STACK];
+    // Evaluation stack with the top two entries cached in registers (r0 = top, r1 = below it); only deeper entries
+    // touch `mem`, a dynamically indexed array that the GPU compiler has to place in scratch memory.  With the whole
+    // stack in that array a 5-node expression ran at 7 % of the HBM roofline (profiles/r01_kernels.txt).
+    tsq_val mem[TSQ_EXPR_MAX_STACK];
+    tsq_val r0, r1;
+    r0.v = r1.v = 0;
+    r0.null = r1.null = true;
     int sp = 0;
-    for (int k = 0; k < p.n_ops; k++) {
-        const tsq_expr_op op = p.ops[k];
+    auto push = [&](const tsq_val& x) {
+        if (sp >= 2) mem[sp - 2] = r1;
+        r1 = r0;
+        r0 = x;
+        sp++;
+    };
+    auto pop = [&]() -> tsq_val {
+        const tsq_val x = r0;
+        r0 = r1;
+        if (sp >= 3) r1 = mem[sp - 3];
+        sp--;
+        return x;
+    };
+    const int n_ops = TSQ_UNIFORM(p.n_ops);
+    TSQ_JIT_UNROLL
+    for (int k = 0; k < n_ops; k++) {
+        tsq_expr_op op;
+        op.opcode = TSQ_UNIFORM(p.ops[k].opcode);
+        op.flags = TSQ_UNIFORM(p.ops[k].flags);
+        op.arg = TSQ_UNIFORM(p.ops[k].arg);
+        op.aux = (decltype(op.aux))TSQ_UNIFORM(p.ops[k].aux);
         const bool ul = op.flags & TSQ_F_LHS_UNSIGNED, ur = op.flags & TSQ_F_RHS_UNSIGNED;
         *err_node = k;
         switch (op.opcode) {
-            case TSQ_OP_COL_INT: st[sp++] = src.load_int(op.arg); break;
-            case TSQ_OP_COL_REAL: st[sp++] = src.load_real(op.arg); break;
+            case TSQ_OP_COL_INT: push(src.load_int(op.arg)); break;
+            case TSQ_OP_COL_REAL: push(src.load_real(op.arg)); break;
             case TSQ_OP_CONST_INT:
-            case TSQ_OP_CONST_REAL: st[sp].v = p.consts[op.arg]; st[sp].null = false; sp++; break;
+            case TSQ_OP_CONST_REAL: { tsq_val c; c.v = p.consts[op.arg]; c.null = false; push(c); break; }
             case TSQ_OP_CONST_NULL_INT:
-            case TSQ_OP_CONST_NULL_REAL: st[sp].v = 0; st[sp].null = true; sp++; break;
+            case TSQ_OP_CONST_NULL_REAL: { tsq_val c; c.v = 0; c.null = true; push(c); break; }
             case TSQ_OP_PLUS_REAL:
             case TSQ_OP_MINUS_REAL:
             case TSQ_OP_MUL_REAL:
             case TSQ_OP_DIV_REAL: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 a.null = a.null || b.null;
                 if (a.null) break;
                 double x = tsq_bits_f64((uint64_t)a.v), y = tsq_bits_f64((uint64_t)b.v), r;
@@ -265,8 +303,8 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 break;
             }
             case TSQ_OP_PLUS_INT: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 a.null = a.null || b.null;
                 if (a.null) break;
                 int64_t lh = a.v, rh = b.v;
@@ -285,8 +323,8 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 break;
             }
             case TSQ_OP_MINUS_INT: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 a.null = a.null || b.null;
                 if (a.null) break;
                 const bool force = op.flags & TSQ_F_FORCE_SIGNED;
@@ -316,8 +354,8 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 break;
             }
             case TSQ_OP_MUL_INT: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 a.null = a.null || b.null;
                 if (a.null) break;
                 int64_t x = a.v, y = b.v;
@@ -327,8 +365,8 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 break;
             }
             case TSQ_OP_MUL_INT_UNSIGNED: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 a.null = a.null || b.null;
                 if (a.null) break;
                 uint64_t x = (uint64_t)a.v, y = (uint64_t)b.v, res = x * y;
@@ -340,8 +378,8 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
             case TSQ_OP_GE_INT: case TSQ_OP_EQ_INT: case TSQ_OP_NE_INT:
             case TSQ_OP_LT_REAL: case TSQ_OP_LE_REAL: case TSQ_OP_GT_REAL:
             case TSQ_OP_GE_REAL: case TSQ_OP_EQ_REAL: case TSQ_OP_NE_REAL: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 a.null = a.null || b.null;
                 if (a.null) { a.v = 0; break; }
                 const bool isreal = op.opcode >= TSQ_OP_LT_REAL;
@@ -353,8 +391,8 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 break;
             }
             case TSQ_OP_LOGIC_AND: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 if (!a.null && a.v == 0) break;
                 if (!b.null && b.v == 0) { a.v = 0; a.null = false; break; }
                 if (a.null || b.null) { a.null = true; break; }
@@ -362,26 +400,26 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 break;
             }
             case TSQ_OP_LOGIC_OR: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 if ((!a.null && a.v != 0) || (!b.null && b.v != 0)) { a.v = 1; a.null = false; }
                 else if (a.null || b.null) a.null = true;
                 else { a.v = 0; a.null = false; }
                 break;
             }
             case TSQ_OP_NOT_INT: {
-                tsq_val& a = st[sp - 1];
+                tsq_val& a = r0;
                 if (!a.null) a.v = a.v == 0 ? 1 : 0;
                 break;
             }
             case TSQ_OP_NOT_REAL: {
-                tsq_val& a = st[sp - 1];
+                tsq_val& a = r0;
                 if (!a.null) a.v = tsq_bits_f64((uint64_t)a.v) == 0 ? 1 : 0;
                 else a.v = 0;
                 break;
             }
             case TSQ_OP_NEG_INT: {
-                tsq_val& a = st[sp - 1];
+                tsq_val& a = r0;
                 if (a.null) break;
                 if (ul) {
                     if ((uint64_t)a.v > ((uint64_t)1 << 63)) return TSQ_ERR_OVERFLOW_BIGINT;
@@ -390,29 +428,29 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 break;
             }
             case TSQ_OP_NEG_REAL: {
-                tsq_val& a = st[sp - 1];
+                tsq_val& a = r0;
                 a.v = (int64_t)tsq_f64_bits(-tsq_bits_f64((uint64_t)a.v));
                 break;
             }
             case TSQ_OP_ISNULL_INT:
             case TSQ_OP_ISNULL_REAL: {
-                tsq_val& a = st[sp - 1];
+                tsq_val& a = r0;
                 a.v = a.null ? 1 : 0;
                 a.null = false;
                 break;
             }
             case TSQ_OP_IFNULL_INT:
             case TSQ_OP_IFNULL_REAL: {
-                tsq_val b = st[--sp];
-                tsq_val& a = st[sp - 1];
+                tsq_val b = pop();
+                tsq_val& a = r0;
                 if (a.null && !b.null) a = b;
                 break;
             }
             case TSQ_OP_IF_INT:
             case TSQ_OP_IF_REAL: {
-                tsq_val c2 = st[--sp];
-                tsq_val c1 = st[--sp];
-                tsq_val& c0 = st[sp - 1];
+                tsq_val c2 = pop();
+                tsq_val c1 = pop();
+                tsq_val& c0 = r0;
                 if (c0.null || c0.v == 0) c0 = c2;
                 else c0 = c1;
                 break;
@@ -420,6 +458,10 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
             case TSQ_OP_IN_INT:
             case TSQ_OP_IN_REAL: {
                 const int nitems = op.arg;
+                // rare and wide: spill the cached entries so that the whole stack is addressable
+                if (sp >= 2) mem[sp - 2] = r1;
+                mem[sp - 1] = r0;
+                tsq_val* st = mem;
                 const tsq_val x = st[sp - nitems - 1];
                 bool hasNull = false, found = false;
                 for (int j = 0; j < nitems; j++) {
@@ -436,14 +478,15 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                     found = found || eq;
                 }
                 sp -= nitems;
-                st[sp - 1].v = found ? 1 : 0;
-                st[sp - 1].null = found ? false : hasNull;
+                r0.v = found ? 1 : 0;
+                r0.null = found ? false : hasNull;
+                if (sp >= 2) r1 = mem[sp - 2];
                 break;
             }
             default: return TSQ_ERR_INVALID;
         }
     }
-    *out = st[0];
+    *out = r0;
     if (out->null) out->v = 0;
     return TSQ_OK;
 }
@@ -455,6 +498,7 @@ template <class Src>
 TSQ_HD tsq_status tsq_filter_row(const tsq_expr_prog* progs, int n_progs, const Src& src, bool* selected,
                                  bool* isnull, int* err_conj, int* err_node, int* div0) {
     bool nulls = false, alive = true;
+    TSQ_JIT_UNROLL
     for (int e = 0; e < n_progs && alive; e++) {
         tsq_val v;
         *err_conj = e;

@@ -38,6 +38,11 @@ struct tsq_ctx {
     // small pinned scratch for scalar results (counts, error words)
     uint64_t* pinned = nullptr;      // host-mapped, 64 words
     uint64_t* dscratch = nullptr;    // device, 64 words
+    // hiprtc modules of destroyed expression handles: unloaded with the context.  (Unloading a module as soon as its
+    // handle is destroyed made LATER, unrelated kernels fault intermittently on ROCm 7.2 — 3 of 12 runs of
+    // tools/bench_kernels.py, address 0x100000 — although the stream had been synchronised before the unload.)
+    std::vector<hipModule_t> retired_modules;
+    std::mutex retired_mu;
 };
 
 inline tsq_status tsq_fail(tsq_handle_hdr* h, tsq_status s, const std::string& msg) {

@@ -206,7 +206,7 @@ def compile_list(exprs):
 class CompiledExpr:
     """tsq_expr handle: one projection expression or one CNF filter list."""
 
-    def __init__(self, ctx, exprs):
+    def __init__(self, ctx, exprs, jit=None):
         self.ctx = ctx
         self.lib = ctx.lib
         self.exprs = list(exprs)
@@ -214,7 +214,18 @@ class CompiledExpr:
         h = C.c_void_p()
         _lib.check(self.lib.tsq_expr_compile(ctx.h, self.progs, len(self.exprs), C.byref(h)), ctx.h)
         self.h = h
+        if jit is not None:
+            _lib.check(self.lib.tsq_expr_set_jit(h, jit), h)
         self.warnings = 0  # StmtCtx.AppendWarning(ErrDivisionByZero) count (errors.go:65-77)
+
+    def jit_launches(self):
+        """launches served by run-time specialised kernels; raises with the hiprtc log when the JIT is unavailable."""
+        n = self.lib.tsq_expr_jit_launches(self.h)
+        if n == 0:
+            msg = self.lib.tsq_last_error(self.h)
+            if msg and b"JIT unavailable" in msg:
+                raise RuntimeError(msg.decode(errors="replace"))
+        return n
 
     def close(self):
         if self.h:
