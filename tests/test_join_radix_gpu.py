@@ -167,3 +167,26 @@ def test_radix_full_size_1e8_by_1e8_property(ctx):
     n = 100_000_000  # BASELINE headline size: every probe key lies in [0, n) and joins exactly once
     got, st = _device_count(ctx, n, n, n, abi.RADIX_AUTO)
     assert got == n and st.radix_batches == 1 and st.radix_bits == 10 and st.radix_overflow_rows == 0
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+def test_radix_forced_leaves_every_other_probe_kernel_exact(ctx, orc, jt, inner):
+    # with the radix strategy forced, the materialising / outer-join / checksum probes (which are not eligible and keep
+    # the direct kernels) must still equal the oracle row for row on a table with full buckets and long spill chains.
+    rng = np.random.default_rng(17 + jt)
+    nb, npr = 40_000, 30_000
+    bk = rng.integers(0, 9000, nb)           # ~4.4 duplicates per key: full buckets, late list, spill chains
+    bk[:300] = 77                            # one key with 300 duplicates
+    bk[300:320] = SENT
+    pk = rng.integers(-100, 9500, npr)
+    pk[:50] = SENT
+    left = Chunk([Column(abi.I64, pk, rng.random(npr) > 0.05), Column(abi.I64, rng.integers(0, 99, npr))])
+    right = Chunk([Column(abi.I64, bk, rng.random(nb) > 0.05), Column(abi.I64, rng.integers(0, 99, nb))])
+    t = [abi.I64, abi.I64]
+    cfg = H.join_cfg(t, t, [0], [0], jt, inner)
+    build, probe = (right, left) if inner == 1 else (left, right)
+    want = orc.hash_join(cfg, build, probe)
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, radix=abi.RADIX_FORCE)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    c, s, x = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, checksum=True, radix=abi.RADIX_FORCE)
+    assert c == want.NumRows() and (s, x) == orc.rows_checksum(want)
