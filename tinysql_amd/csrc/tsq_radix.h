@@ -527,6 +527,7 @@ __global__ void __launch_bounds__(256, MINW) k_radix_probe_count(RadixProbeArgs 
     if (tid == 0 && s_total) atomicAdd(&a.counters[0], s_total);  // one device atomic per workgroup
 }
 
+
 // the overflow list (runs that did not fit their region): plain grid-stride probe
 static __global__ void __launch_bounds__(256) k_radix_probe_ovf(RadixProbeArgs a) {
     uint32_t n = *a.st.ovf_count;

@@ -181,8 +181,6 @@ int main(int argc, char** argv) {
                     float ms = time_ms([&] {
                         pa.pf_lead = (uint32_t)((U / 10) % 10) + 1;
                         if (U == 2) hipLaunchKernelGGL((k_radix_probe_count<2, 0>), dim3(J * 8), dim3(256), 0, 0, pa);
-                        if (U == 7) hipLaunchKernelGGL((k_radix_probe_count<2, 0, 7>), dim3(J * 8), dim3(256), 0, 0, pa);
-                        if (U == 8) hipLaunchKernelGGL((k_radix_probe_count<1, 0, 8>), dim3(J * 8), dim3(256), 0, 0, pa);
                         if (U == 102) hipLaunchKernelGGL((k_radix_probe_count<2, 1>), dim3((J + 1) * 8), dim3(256), 0, 0, pa);
                         if (U == 202) hipLaunchKernelGGL((k_radix_probe_count<2, 2>), dim3((J + 2) * 8), dim3(256), 0, 0, pa);
                         hipLaunchKernelGGL(k_radix_probe_ovf, dim3(256), dim3(256), 0, 0, pa);
