@@ -999,7 +999,7 @@ TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols,
         TSQ_TRY(agg_flush(a));
         tsq_colset all;
         tsq_colset_from_cols(all, cols, n_cols);
-        const int64_t slice = 64 << 20;
+        const int64_t slice = 256 << 20;  // device batches: every batch ends with a merge of its partial groups and two host syncs
         for (int64_t off = 0; off < nrows; off += slice) {
             const int64_t n = std::min<int64_t>(slice, nrows - off);
             tsq_colset s;

@@ -94,6 +94,7 @@ TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     (void)hipDeviceSynchronize();
     for (hipModule_t m : ctx->retired_modules) (void)hipModuleUnload(m);
+    for (auto& b : ctx->pool) (void)hipFree(b.first);
     ctx->hdr.magic = 0;
     delete ctx;
 }

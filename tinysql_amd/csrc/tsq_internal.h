@@ -43,7 +43,39 @@ struct tsq_ctx {
     // tools/bench_kernels.py, address 0x100000 — although the stream had been synchronised before the unload.)
     std::vector<hipModule_t> retired_modules;
     std::mutex retired_mu;
+    // device-memory pool: hipMalloc costs ~35 ms per GB, and one radix / pre-aggregation batch needs several GB of
+    // partition buffers — per handle that was 100+ ms of allocation for a 20 ms aggregate.  Buffers released by a handle
+    // are kept (up to pool_cap bytes) and handed to the next one; everything runs on ctx->stream, so stream order
+    // protects a buffer that is recycled while kernels of its previous owner are still queued.
+    std::mutex pool_mu;
+    std::vector<std::pair<void*, size_t>> pool;
+    size_t pool_bytes = 0, pool_cap = (size_t)48 << 30;
 };
+inline void* tsq_pool_get(tsq_ctx* ctx, size_t bytes, size_t* got) {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)ctx->pool.size(); i++) {
+        const size_t c = ctx->pool[i].second;
+        if (c >= bytes && c <= bytes + bytes / 2 + (1 << 20) && (best < 0 || c < ctx->pool[best].second)) best = i;
+    }
+    if (best < 0) return nullptr;
+    void* p = ctx->pool[best].first;
+    *got = ctx->pool[best].second;
+    ctx->pool_bytes -= *got;
+    ctx->pool.erase(ctx->pool.begin() + best);
+    return p;
+}
+inline void tsq_pool_put(tsq_ctx* ctx, void* p, size_t cap) {
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        if (cap >= (1 << 16) && ctx->pool_bytes + cap <= ctx->pool_cap && ctx->pool.size() < 256) {
+            ctx->pool.emplace_back(p, cap);
+            ctx->pool_bytes += cap;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
 
 inline tsq_status tsq_fail(tsq_handle_hdr* h, tsq_status s, const std::string& msg) {
     if (h) h->err = msg;
@@ -70,27 +102,34 @@ inline tsq_status tsq_fail(tsq_handle_hdr* h, tsq_status s, const std::string& m
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    tsq_ctx* owner = nullptr;
     tsq_status reserve(tsq_ctx* ctx, tsq_handle_hdr* h, size_t bytes, bool keep = false, size_t used = 0) {
         if (bytes <= cap) return TSQ_OK;
         size_t ncap = bytes;
         if (keep && cap) ncap = std::max(bytes, cap + cap / 2);
-        void* np = nullptr;
-        TSQ_HIP(h, hipMalloc(&np, ncap));
+        void* np = tsq_pool_get(ctx, ncap, &ncap);
+        if (!np) TSQ_HIP(h, hipMalloc(&np, ncap));
         if (keep && p && used) {
             hipError_t e = hipMemcpyAsync(np, p, used, hipMemcpyDeviceToDevice, ctx->stream);
             if (e != hipSuccess) {
-                (void)hipFree(np);
+                tsq_pool_put(ctx, np, ncap);
                 return tsq_fail(h, TSQ_ERR_HIP, std::string("hipMemcpyAsync(grow): ") + hipGetErrorString(e));
             }
             (void)hipStreamSynchronize(ctx->stream);
+        } else if (p) {
+            (void)hipStreamSynchronize(ctx->stream);  // queued kernels may still read the buffer that is handed back (hipFree used to wait too)
         }
-        if (p) (void)hipFree(p);
+        release();
         p = np;
         cap = ncap;
+        owner = ctx;
         return TSQ_OK;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (owner) tsq_pool_put(owner, p, cap);
+            else (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
     }
