@@ -144,6 +144,12 @@ struct ProbeArgs {
     int32_t join_type;
     int32_t probe_is_left;            // output order: left||right
     unsigned long long* counters;     // [0]=joined rows [1]=checksum sum [2]=checksum xor [3]=err word [4]=div0 [5]=out cursor
+    // materialising mode: contiguous rows per workgroup so that output positions need no device atomics.  The sizing
+    // pass (K3) leaves every workgroup's match count in block_base[], k_scan_blocks turns them into exclusive bases,
+    // the emit pass (K4) walks the same rows and hands out positions from an LDS cursor.  (One returning device atomic
+    // per wave on a single cursor was 4.4 ms of the 6 ms emit kernel for 25 M rows: ~11 ns each, chip-wide.)
+    unsigned long long* block_base;
+    int64_t rows_per_block;
     // emit only
     void* out_data[2 * TSQ_MAX_COLS];
     uint8_t* out_notnull[2 * TSQ_MAX_COLS];  // one byte per output row, may be null per column
@@ -241,7 +247,11 @@ __global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
     uint64_t cnt = 0, csum = 0, cxor = 0, errw = TSQ_ERRWORD_NONE;
     uint32_t div0 = 0;
     const bool outer = a.join_type != TSQ_JOIN_INNER;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nrows; k += stride) {
+    const bool chunked = a.block_base != nullptr;
+    const int64_t k_first = chunked ? (int64_t)blockIdx.x * a.rows_per_block + threadIdx.x : (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k_last = chunked ? (((int64_t)blockIdx.x + 1) * a.rows_per_block < a.nrows ? ((int64_t)blockIdx.x + 1) * a.rows_per_block : a.nrows) : a.nrows;
+    const int64_t k_step = chunked ? (int64_t)blockDim.x : stride;
+    for (int64_t k = k_first; k < k_last; k += k_step) {
         uint64_t kw = 0;
         uint32_t c = 0;
         if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0)) {
@@ -272,6 +282,14 @@ __global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
     }
     cnt = wave_sum_u64(cnt);
     if (CHK) { csum = wave_sum_u64(csum); cxor = wave_xor_u64(cxor); }
+    if (chunked) {  // this workgroup's output rows, for the emit pass
+        __shared__ unsigned long long s_block;
+        if (threadIdx.x == 0) s_block = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_block, (unsigned long long)cnt);
+        __syncthreads();
+        if (threadIdx.x == 0) a.block_base[blockIdx.x] = s_block;
+    }
     if ((threadIdx.x & 63) == 0) {
         if (cnt) atomicAdd(&a.counters[0], (unsigned long long)cnt);
         if (CHK) { atomicAdd(&a.counters[1], (unsigned long long)csum); atomicXor(&a.counters[2], (unsigned long long)cxor); }
@@ -307,38 +325,75 @@ __device__ __forceinline__ void write_joined_row(const ProbeArgs& a, uint64_t po
 
 template <bool MULTI, bool GEN>
 __global__ void __launch_bounds__(256) k_probe_emit(ProbeArgs a) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t nround = (a.nrows + 63) & ~(int64_t)63;  // wave-uniform trip count for the collectives
+    __shared__ unsigned long long s_cur;
     const bool outer = a.join_type != TSQ_JOIN_INNER;
     uint64_t errw = TSQ_ERRWORD_NONE;
     uint32_t div0 = 0;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nround; k += stride) {
-        const bool active = k < a.nrows;
+    const int64_t k_begin = (int64_t)blockIdx.x * a.rows_per_block;
+    int64_t k_last = k_begin + a.rows_per_block < a.nrows ? k_begin + a.rows_per_block : a.nrows;
+    if (k_last < k_begin) k_last = k_begin;  // workgroups past the end of the batch
+    const int64_t k_round = k_begin + ((k_last - k_begin + 63) & ~(int64_t)63);  // wave-uniform trip count for the collectives
+    if (threadIdx.x == 0) s_cur = a.block_base[blockIdx.x];
+    __syncthreads();
+    for (int64_t k = k_begin + threadIdx.x; k < k_round; k += blockDim.x) {
+        const bool active = k < k_last;
         uint64_t kw = 0;
         bool valid = false;
         uint32_t c = 0;
+        uint32_t first = 0;  // first matching build row: written by all lanes together, not inside the divergent slot walk
         if (active) {
             valid = probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0);
-            if (valid) for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t) { c++; });
+            if (valid) for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) {
+                if (c == 0) first = brow;
+                c++;
+            });
         }
         const bool miss = active && outer && c == 0;
         uint32_t n_out = c + (miss ? 1u : 0u), total;
         uint32_t prefix = wave_excl_scan_u32(n_out, &total);
         unsigned long long base = 0;
-        if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(&a.counters[5], (unsigned long long)total);
+        if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(&s_cur, (unsigned long long)total);  // LDS cursor of this workgroup
         base = __shfl(base, 0, 64);
         uint64_t pos = base + prefix;
-        if (c) {
-            uint32_t dummy_d0 = 0;
+        // The common case (one match per probe row, e.g. a foreign key probing a primary key) is ONE convergent
+        // gather/store sequence per wave.  Writing from inside the slot walk made every wave run the column copies
+        // up to 8 times with partial lane masks, each time waiting for its own gather latency (90 % of the wave cycles).
+        if (c) write_joined_row(a, pos, k, (int64_t)first);
+        else if (miss) write_joined_row(a, pos, k, -1);
+        if (c > 1) {  // duplicates: the remaining matches, in walk order
+            uint32_t dummy_d0 = 0, seen = 0;
             uint64_t dummy_err = TSQ_ERRWORD_NONE;
-            for_each_match<MULTI, GEN>(a, k, kw, dummy_err, dummy_d0, [&](uint32_t brow) { write_joined_row(a, pos++, k, (int64_t)brow); });
-        } else if (miss) {
-            write_joined_row(a, pos, k, -1);
+            for_each_match<MULTI, GEN>(a, k, kw, dummy_err, dummy_d0, [&](uint32_t brow) {
+                if (seen++) write_joined_row(a, pos + seen - 1, k, (int64_t)brow);
+            });
         }
     }
     if (GEN) {
         if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[3], (unsigned long long)errw);
         if (div0) atomicAdd(&a.counters[4], (unsigned long long)div0);
+    }
+}
+
+// exclusive scan of the per-workgroup match counts (n <= a few thousand): one workgroup
+__global__ void __launch_bounds__(1024) k_scan_blocks(unsigned long long* v, int n) {
+    __shared__ unsigned long long s_w[16];
+    const int per = (n + 1023) / 1024, lo = threadIdx.x * per;
+    unsigned long long sum = 0;
+    for (int i = lo; i < lo + per && i < n; i++) sum += v[i];
+    unsigned long long x = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(x, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned long long pre = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pre += s_w[w];
+    unsigned long long run = pre + x - sum;
+    for (int i = lo; i < lo + per && i < n; i++) {
+        const unsigned long long c = v[i];
+        v[i] = run;
+        run += c;
     }
 }
 
@@ -399,6 +454,7 @@ struct tsq_join {
     // radix probe path of the COUNT(*) fast path (tsq_radix.h)
     int32_t radix_mode = TSQ_RADIX_AUTO;
     DevBuf rkeys, rctl, rvend, rovf;  // partitioned keys | cursor + queue heads + overflow count | valid_end | overflow keys
+    DevBuf bbase;                     // per-workgroup output bases of the materialising probe
     static constexpr int RING = 32;   // HIP events of the most recent radix batches: [slot][0..2] = start, after partition, end
     hipEvent_t rev[RING][3] = {};
 
@@ -625,10 +681,16 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         j->have_probe_ev = true;
         return TSQ_OK;
     }
-    // emit mode: size the batch first (K3), then materialise (K4)
+    // emit mode: size the batch first (K3), then materialise (K4); both walk contiguous rows per workgroup
+    const int egrid = tsq_grid_for(ctx, nrows, 256);
+    TSQ_TRY(j->bbase.reserve(ctx, &j->hdr, (size_t)egrid * 8 + 64));
+    a.block_base = j->bbase.as<unsigned long long>();
+    a.rows_per_block = (((nrows + egrid - 1) / egrid) + 63) & ~(int64_t)63;
     unsigned long long before[8], after[8];
     TSQ_TRY(read_counters(j, before));
     TSQ_TRY(dispatch_count(j, a, false));
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, a.block_base, egrid);
+    TSQ_HIP(&j->hdr, hipGetLastError());
     TSQ_TRY(read_counters(j, after));
     TSQ_TRY(status_from_errword(j, after[3]));
     const int64_t out_rows = (int64_t)(after[0] - before[0]);
@@ -960,7 +1022,8 @@ TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t
         tsq_colset pcs;
         tsq_colset_from_cols(pcs, cols, n_cols);
         // process in slices so an emit batch stays bounded
-        const int64_t slice = j->count_only ? nrows : j->cfg.probe_batch_rows;
+        // device-resident input: larger emit batches (every batch costs a count pass, two host syncs and its output buffers)
+        const int64_t slice = j->count_only ? nrows : std::max<int64_t>(j->cfg.probe_batch_rows, 32 << 20);
         for (int64_t off = 0; off < nrows; off += slice) {
             const int64_t n = std::min<int64_t>(slice, nrows - off);
             tsq_colset s;
@@ -1151,6 +1214,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     for (int i = 0; i < tsq_join::RING; i++)
         for (int e = 0; e < 3; e++)
             if (j->rev[i][e]) (void)hipEventDestroy(j->rev[i][e]);
+    j->bbase.release();
     j->rkeys.release();
     j->rctl.release();
     j->rvend.release();
