@@ -361,6 +361,15 @@ tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, int64_t c
 tsq_status tsq_agg_cancel(tsq_agg* a);
 void       tsq_agg_destroy(tsq_agg* a);
 
+/* ---------------------------------------------------------------- device-chunk hand-off between GPU operators
+ * Dense copy of the selected rows of a DEVICE-resident chunk (selected[]: one byte per row, device memory, e.g. the
+ * output of tsq_filter_eval on device columns).  Replaces SelectionExec's copy of selected rows (executor/executor.go:
+ * 393-438) / Column.CopyReconstruct (util/chunk/column.go:504-552) when parent and child are both GPU operators, so a
+ * filtered chunk reaches the join / aggregate without leaving HBM.  out_cols must be sized for nrows rows; rows keep
+ * their order up to a permutation inside 256-row tiles (downstream hash operators are order-insensitive). */
+tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int64_t nrows, const uint8_t* selected,
+                             tsq_col* out_cols, int64_t* nrows_out);
+
 /* ---------------------------------------------------------------- multi-GPU radix redistribute
  * Splits rows by rank(key) = ((mix64(key) & 0xffff) * n_parts) >> 16 into n_parts contiguous
  * runs (CPU analogue: aggregate.go:352-356 shuffle / join.go:219 dispatch).  The exchange

@@ -1,0 +1,372 @@
+"""Device-resident volcano operators: the same Open / Next / Close contract as `executor.py`
+(executor/executor.go:146-162), but the chunks handed from child to parent stay in HBM.
+
+SURVEY.md §8(f) rank 1: when parent and child are both GPU operators the D2H -> H2D hop of a 1024-row
+host chunk is replaced by a pointer hand-off; `tidb_max_chunk_size` has no upper bound
+(sessionctx/variable/varsutil.go:251), so a "chunk" here is millions of rows.  Everything below is host
+plumbing around the C-ABI (`include/tsq.h`); all compute runs in libtsq:
+  GpuSelectionExec   = tsq_filter_eval (device flags) + tsq_chunk_compact  (executor.go:346-438, column.go:504-552)
+  GpuProjectionExec  = tsq_expr_eval per output column                     (projection.go:54-434, evaluator.go:121-133)
+  GpuHashJoinExec    = tsq_join_* with TSQ_COL_DEVICE columns              (join.go:31-146)
+  GpuHashAggExec     = tsq_agg_* with TSQ_COL_DEVICE columns               (aggregate.go:134-588)
+A chunk returned by Next is valid until the next call of Next on the same operator (the Go operators
+recycle their chunks the same way, join.go:62-78).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+from . import _lib
+from .chunk import Chunk, Column, np_dtype
+from .expression import ETReal, CompiledExpr
+
+
+def _es(tp):
+    return 4 if tp == abi.F32 else 8
+
+
+class DeviceColumn:
+    """one fixed-width column in HBM: data + optional null bitmap (bit 1 = NOT NULL, util/chunk/column.go:89-92)."""
+
+    def __init__(self, ctx, tp, cap_rows, with_bitmap=True, data=None, bitmap=None):
+        self.ctx, self.tp, self.cap = ctx, tp, cap_rows
+        self.owned = data is None
+        if self.owned:
+            self.data = ctx.alloc(max(cap_rows, 1) * _es(tp) + 64)
+            self.bitmap = ctx.alloc((cap_rows + 7) // 8 + 64) if with_bitmap else None
+        else:
+            self.data, self.bitmap = data, bitmap
+
+    def col(self, nrows):
+        c = abi.Col()
+        c.data, c.null_bitmap, c.length = self.data, self.bitmap, nrows
+        c.elem_size, c.type, c.flags = _es(self.tp), self.tp, abi.COL_DEVICE
+        return c
+
+    def view(self, lo):
+        """rows [lo, ...) — lo must be a multiple of 8 so that the bitmap stays byte aligned."""
+        assert lo % 8 == 0
+        return DeviceColumn(self.ctx, self.tp, self.cap - lo, data=self.data + lo * _es(self.tp),
+                            bitmap=None if self.bitmap is None else self.bitmap + lo // 8)
+
+    def to_host(self, nrows):
+        arr = np.zeros(max(nrows, 1), dtype=np_dtype(self.tp))
+        self.ctx.d2h(arr, self.data)
+        nn = None
+        if self.bitmap is not None:
+            bm = np.zeros((nrows + 7) // 8 + 1, np.uint8)
+            self.ctx.d2h(bm, self.bitmap)
+            nn = np.unpackbits(bm, bitorder="little")[:nrows].astype(bool)
+        return Column(self.tp, arr[:nrows].copy(), nn)
+
+    def free(self):
+        if self.owned:
+            self.ctx.free(self.data)
+            if self.bitmap is not None:
+                self.ctx.free(self.bitmap)
+        self.data = self.bitmap = None
+
+
+class DeviceChunk:
+    def __init__(self, columns, nrows):
+        self.columns, self.nrows = list(columns), nrows
+
+    def NumRows(self):
+        return self.nrows
+
+    def types(self):
+        return [c.tp for c in self.columns]
+
+    def cols(self):
+        return (abi.Col * len(self.columns))(*[c.col(self.nrows) for c in self.columns])
+
+    def to_host(self):
+        return Chunk([c.to_host(self.nrows) for c in self.columns])
+
+    def free(self):
+        for c in self.columns:
+            c.free()
+
+    @staticmethod
+    def from_host(ctx, chunk):
+        cols = []
+        for c in chunk.columns:
+            d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=True)
+            ctx.h2d(d.data, np.ascontiguousarray(c.data))
+            nn = np.ones(len(c), bool) if c.notnull is None else c.notnull
+            ctx.h2d(d.bitmap, np.packbits(nn, bitorder="little"))
+            cols.append(d)
+        return DeviceChunk(cols, chunk.NumRows())
+
+
+class GpuExecutor:
+    def __init__(self, ctx, types, children=()):
+        self.ctx, self.lib, self.types, self.children = ctx, ctx.lib, list(types), list(children)
+
+    def Schema(self):
+        return self.types
+
+    def Open(self):
+        for c in self.children:
+            c.Open()
+
+    def Close(self):
+        for c in self.children:
+            c.Close()
+
+    def _buffers(self, cap_rows):
+        return [DeviceColumn(self.ctx, t, cap_rows) for t in self.types]
+
+
+EOS = DeviceChunk([], 0)
+
+
+def drain_device(exe):
+    """Open / Next* / Close; returns host Chunks (the root of a plan copies its result out like writeChunks does)."""
+    exe.Open()
+    out = []
+    try:
+        while True:
+            chk = exe.Next()
+            if chk.NumRows() == 0:
+                break
+            out.append(chk.to_host())
+    finally:
+        exe.Close()
+    return out
+
+
+class DeviceTableScan(GpuExecutor):
+    """a table that already lives in HBM (what a GPU-side TableReader / cop-response decoder would produce), handed out in
+    batches of `batch_rows` rows as pointer views."""
+
+    def __init__(self, ctx, table, batch_rows=1 << 24):
+        super().__init__(ctx, table.types())
+        self.table, self.batch, self.pos = table, (batch_rows + 7) & ~7, 0
+
+    def Open(self):
+        self.pos = 0
+
+    def Next(self):
+        n = self.table.nrows
+        if self.pos >= n:
+            return EOS
+        hi = min(n, self.pos + self.batch)
+        out = DeviceChunk([c.view(self.pos) for c in self.table.columns], hi - self.pos)
+        self.pos = hi
+        return out
+
+
+class GpuSelectionExec(GpuExecutor):
+    def __init__(self, ctx, child, filters, jit=None):
+        super().__init__(ctx, child.Schema(), (child,))
+        self.child, self.filters, self.jit = child, list(filters), jit
+        self.expr, self.out, self.flags, self.cap = None, None, None, 0
+
+    def Open(self):
+        super().Open()
+        self.expr = CompiledExpr(self.ctx, self.filters, jit=self.jit)
+
+    def Next(self):
+        while True:
+            chk = self.child.Next()
+            n = chk.NumRows()
+            if n == 0:
+                return EOS
+            if n > self.cap:
+                self._release()
+                self.cap = n
+                self.out = self._buffers(n)
+                self.flags = self.ctx.alloc(n + 64)
+            w = C.c_int64(0)
+            _lib.check(self.lib.tsq_filter_eval(self.expr.h, chk.cols(), len(chk.columns), n, None, self.flags, None, C.byref(w)), self.expr.h)
+            self.expr.warnings += w.value
+            oc = (abi.Col * len(self.out))(*[c.col(n) for c in self.out])
+            m = C.c_int64(0)
+            _lib.check(self.lib.tsq_chunk_compact(self.ctx.h, chk.cols(), len(chk.columns), n, self.flags, oc, C.byref(m)), self.ctx.h)
+            if m.value:
+                return DeviceChunk(self.out, m.value)
+
+    def _release(self):
+        if self.out:
+            for c in self.out:
+                c.free()
+            self.ctx.free(self.flags)
+        self.out, self.flags, self.cap = None, None, 0
+
+    def Close(self):
+        self._release()
+        if self.expr:
+            self.expr.close()
+            self.expr = None
+        super().Close()
+
+
+class GpuProjectionExec(GpuExecutor):
+    def __init__(self, ctx, child, exprs, jit=None):
+        types = [abi.F64 if e.eval_type == ETReal else (abi.U64 if e.unsigned else abi.I64) for e in exprs]
+        super().__init__(ctx, types, (child,))
+        self.child, self.exprs, self.jit = child, list(exprs), jit
+        self.compiled, self.out, self.cap = [], None, 0
+
+    def Open(self):
+        super().Open()
+        self.compiled = [CompiledExpr(self.ctx, [e], jit=self.jit) for e in self.exprs]
+
+    def Next(self):
+        chk = self.child.Next()
+        n = chk.NumRows()
+        if n == 0:
+            return EOS
+        if n > self.cap:
+            self._release()
+            self.cap, self.out = n, self._buffers(n)
+        for ce, dst in zip(self.compiled, self.out):
+            oc = dst.col(n)
+            oc.type = abi.F64 if dst.tp == abi.F64 else abi.I64
+            w = C.c_int64(0)
+            _lib.check(self.lib.tsq_expr_eval(ce.h, chk.cols(), len(chk.columns), n, None, C.byref(oc), C.byref(w)), ce.h)
+            ce.warnings += w.value
+        return DeviceChunk(self.out, n)
+
+    def _release(self):
+        if self.out:
+            for c in self.out:
+                c.free()
+        self.out, self.cap = None, 0
+
+    def Close(self):
+        self._release()
+        for ce in self.compiled:
+            ce.close()
+        self.compiled = []
+        super().Close()
+
+
+class GpuHashJoinExec(GpuExecutor):
+    def __init__(self, ctx, left, right, left_keys, right_keys, join_type=abi.JOIN_INNER, inner_child_idx=1, pull_rows=1 << 24):
+        super().__init__(ctx, left.Schema() + right.Schema(), (left, right))
+        self.build_is_right = inner_child_idx == 1
+        self.build = right if self.build_is_right else left
+        self.probe = left if self.build_is_right else right
+        bkeys = right_keys if self.build_is_right else left_keys
+        pkeys = left_keys if self.build_is_right else right_keys
+        cfg = abi.JoinCfg()
+        cfg.join_type, cfg.build_is_right, cfg.n_keys = join_type, 1 if self.build_is_right else 0, len(bkeys)
+        for i, (b, p) in enumerate(zip(bkeys, pkeys)):
+            cfg.build_key_idx[i], cfg.probe_key_idx[i] = b, p
+        cfg.n_build_cols, cfg.n_probe_cols = len(self.build.Schema()), len(self.probe.Schema())
+        for i, t in enumerate(self.build.Schema()):
+            cfg.build_types[i] = t
+        for i, t in enumerate(self.probe.Schema()):
+            cfg.probe_types[i] = t
+        cfg.max_chunk_size = 1024
+        self.cfg, self.h, self.prepared = cfg, None, False
+        self.pull_rows = (pull_rows + 7) & ~7
+        self.out = None
+
+    def Open(self):
+        super().Open()
+        h = C.c_void_p()
+        _lib.check(self.lib.tsq_join_create(self.ctx.h, C.byref(self.cfg), C.byref(h)), self.ctx.h)
+        self.h, self.prepared = h, False
+        self.out = self._buffers(self.pull_rows)
+
+    def Next(self):
+        if not self.prepared:
+            while True:
+                chk = self.build.Next()
+                if chk.NumRows() == 0:
+                    break
+                _lib.check(self.lib.tsq_join_build_push(self.h, chk.cols(), len(chk.columns), chk.NumRows()), self.h)
+            _lib.check(self.lib.tsq_join_build_finish(self.h), self.h)
+            self.prepared = True
+        n, eos = C.c_int64(0), C.c_int32(0)
+        while True:
+            oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
+            _lib.check(self.lib.tsq_join_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
+            if n.value > 0:
+                return DeviceChunk(self.out, n.value)
+            if eos.value:
+                return EOS
+            chk = self.probe.Next()
+            if chk.NumRows() == 0:
+                _lib.check(self.lib.tsq_join_probe_finish(self.h), self.h)
+                continue
+            _lib.check(self.lib.tsq_join_probe_push(self.h, chk.cols(), len(chk.columns), chk.NumRows(), None), self.h)
+
+    def Close(self):
+        if self.h:
+            self.lib.tsq_join_cancel(self.h)
+            self.lib.tsq_join_destroy(self.h)
+            self.h = None
+        if self.out:
+            for c in self.out:
+                c.free()
+            self.out = None
+        super().Close()
+
+
+class GpuHashAggExec(GpuExecutor):
+    def __init__(self, ctx, child, group_by_cols, agg_funcs, est_groups=0, pull_rows=1 << 22):
+        types = []
+        for f in agg_funcs:
+            types += f.out_types()
+        super().__init__(ctx, types, (child,))
+        self.child = child
+        cfg = abi.AggCfg()
+        in_types = child.Schema()
+        cfg.n_group_keys = len(group_by_cols)
+        for i, c in enumerate(group_by_cols):
+            cfg.group_key_col[i], cfg.group_key_type[i] = c, in_types[c]
+        cfg.n_aggs = len(agg_funcs)
+        for i, f in enumerate(agg_funcs):
+            cfg.aggs[i].func, cfg.aggs[i].mode = f.func, f.mode
+            cfg.aggs[i].arg_col, cfg.aggs[i].arg_col2, cfg.aggs[i].arg_type = f.arg_col, f.arg_col2, f.arg_type
+        cfg.n_input_cols = len(in_types)
+        for i, t in enumerate(in_types):
+            cfg.input_types[i] = t
+        cfg.est_groups, cfg.max_chunk_size = est_groups, 1024
+        self.cfg, self.h, self.prepared, self.out = cfg, None, False, None
+        self.pull_rows = (pull_rows + 7) & ~7
+
+    def Open(self):
+        super().Open()
+        h = C.c_void_p()
+        _lib.check(self.lib.tsq_agg_create(self.ctx.h, C.byref(self.cfg), C.byref(h)), self.ctx.h)
+        self.h, self.prepared = h, False
+        self.out = self._buffers(self.pull_rows)
+
+    def Next(self):
+        if not self.prepared:
+            self.pushed = False
+            while True:
+                chk = self.child.Next()
+                if chk.NumRows() == 0:
+                    break
+                _lib.check(self.lib.tsq_agg_push(self.h, chk.cols(), len(chk.columns), chk.NumRows()), self.h)
+                self.pushed = True
+            _lib.check(self.lib.tsq_agg_finish(self.h), self.h)
+            self.prepared = True
+        if not self.pushed:
+            # no input chunk: GROUP BY yields no rows (aggregate_test.go:58-59).  The single default row of a key-less
+            # aggregate over empty input (aggregate.go:572-574) is served by the host-chunk HashAggExec.
+            return EOS
+        n, eos = C.c_int64(0), C.c_int32(0)
+        oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
+        _lib.check(self.lib.tsq_agg_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
+        if n.value == 0:
+            return EOS
+        return DeviceChunk(self.out, n.value)
+
+    def Close(self):
+        if self.h:
+            self.lib.tsq_agg_cancel(self.h)
+            self.lib.tsq_agg_destroy(self.h)
+            self.h = None
+        if self.out:
+            for c in self.out:
+                c.free()
+            self.out = None
+        super().Close()

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""TPC-H Q3-shaped query (BASELINE.json configs[4]) on device-resident operators:
+
+    SELECT l_orderkey, o_orderdate, o_shippriority, SUM(l_extendedprice * (1 - l_discount)) AS revenue
+    FROM customer, orders, lineitem
+    WHERE c_mktsegment = SEG AND c_custkey = o_custkey AND l_orderkey = o_orderkey AND o_orderdate < D AND l_shipdate > D
+    GROUP BY l_orderkey, o_orderdate, o_shippriority
+
+TinySQL has int / real / string types only (types/eval_type.go:21-28): dates are day numbers, the market segment an int code.
+Plan (what planner/core would produce with hash joins): Selection(customer) -> build;  Selection(orders) probes it;
+that result is the build side for Selection(lineitem);  Projection(revenue);  HashAgg.
+usage: q3.py [SF]   (customer 1.5e5*SF, orders 1.5e6*SF, lineitem 6e6*SF rows)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tinysql_amd import _abi as abi  # noqa: E402
+from tinysql_amd import _lib  # noqa: E402
+from tinysql_amd import expression as E  # noqa: E402
+from tinysql_amd import gpu_pipeline as G  # noqa: E402
+from tinysql_amd.chunk import Chunk, Column  # noqa: E402
+from tinysql_amd.executor import AggFuncDesc  # noqa: E402
+
+SEG, D = 1, 1200
+I, R = abi.I64, abi.F64
+
+
+def tables(sf, seed=7):
+    """host-side synthetic tables (numpy): deterministic, FK-consistent."""
+    rng = np.random.default_rng(seed)
+    nc, no, nl = int(150_000 * sf), int(1_500_000 * sf), int(6_000_000 * sf)
+    customer = Chunk([Column(I, np.arange(nc, dtype=np.int64)), Column(I, rng.integers(0, 5, nc))])                     # c_custkey, c_mktsegment
+    orders = Chunk([Column(I, rng.permutation(no).astype(np.int64)), Column(I, rng.integers(0, nc, no)),               # o_orderkey, o_custkey
+                    Column(I, rng.integers(0, 2400, no)), Column(I, rng.integers(0, 3, no))])                            # o_orderdate, o_shippriority
+    lineitem = Chunk([Column(I, rng.integers(0, no, nl)), Column(I, rng.integers(0, 2500, nl)),                         # l_orderkey, l_shipdate
+                      Column(R, rng.random(nl) * 1e5), Column(R, rng.integers(0, 11, nl) / 100.0)])                      # l_extendedprice, l_discount
+    return customer, orders, lineitem
+
+
+def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None):
+    F, Col, K = E.ScalarFunction, E.Column, E.Constant
+    cust = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, I), K(SEG))], jit=jit)
+    ords = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, orders_d, batch_rows), [F("lt", Col(2, I), K(D))], jit=jit)
+    # orders (probe, left) JOIN customer (build, right) ON o_custkey = c_custkey  ->  o_orderkey,o_custkey,o_orderdate,o_shippriority,c_custkey,c_mktsegment
+    j1 = G.GpuHashJoinExec(ctx, ords, cust, [1], [0], abi.JOIN_INNER, 1)
+    line = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, lineitem_d, batch_rows), [F("gt", Col(1, I), K(D))], jit=jit)
+    # lineitem (probe, left) JOIN j1 (build, right) ON l_orderkey = o_orderkey -> l_orderkey,l_shipdate,price,disc | o_orderkey,o_custkey,o_orderdate,o_shippriority,c_*,c_*
+    j2 = G.GpuHashJoinExec(ctx, line, j1, [0], [0], abi.JOIN_INNER, 1)
+    proj = G.GpuProjectionExec(ctx, j2, [Col(0, I), Col(6, I), Col(7, I), F("mul", Col(2, R), F("minus", K(1.0), Col(3, R)))], jit=jit)
+    aggs = [AggFuncDesc(abi.AGG_FIRSTROW, 0, I), AggFuncDesc(abi.AGG_FIRSTROW, 1, I), AggFuncDesc(abi.AGG_FIRSTROW, 2, I), AggFuncDesc(abi.AGG_SUM, 3, R)]
+    return G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs)
+
+
+def reference(customer, orders, lineitem):
+    """plain numpy restatement of the query (checker for the small test)."""
+    ck, cs = customer.columns[0].data, customer.columns[1].data
+    ok, oc, od, op = (c.data for c in orders.columns)
+    lk, ls, lp, ld = (c.data for c in lineitem.columns)
+    good_c = np.zeros(len(ck), bool)
+    good_c[ck[cs == SEG]] = True
+    o_sel = (od < D) & good_c[oc]
+    date_of = np.full(len(ok), -1, np.int64)
+    prio_of = np.zeros(len(ok), np.int64)
+    date_of[ok[o_sel]] = od[o_sel]
+    prio_of[ok[o_sel]] = op[o_sel]
+    l_sel = (ls > D) & (date_of[lk] >= 0)
+    keys = lk[l_sel]
+    rev = lp[l_sel] * (1.0 - ld[l_sel])
+    order = np.argsort(keys, kind="stable")
+    keys, rev = keys[order], rev[order]
+    uk, start = np.unique(keys, return_index=True)
+    sums = np.add.reduceat(rev, start) if len(keys) else np.zeros(0)
+    return uk, date_of[uk], prio_of[uk], sums
+
+
+def main():
+    sf = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+    t0 = time.time()
+    customer, orders, lineitem = tables(sf)
+    gen_s = time.time() - t0
+    with _lib.Context(0) as ctx:
+        dev = [G.DeviceChunk.from_host(ctx, t) for t in (customer, orders, lineitem)]
+        try:
+            best, groups = 1e30, 0
+            for rep in range(3):
+                exe = plan(ctx, *dev)
+                ctx.sync()
+                t1 = time.perf_counter()
+                out = G.drain_device(exe)
+                ctx.sync()
+                dt = time.perf_counter() - t1
+                best = min(best, dt)
+                groups = sum(c.NumRows() for c in out)
+            rows_in = customer.NumRows() + orders.NumRows() + lineitem.NumRows()
+            print(json.dumps({"query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg", "SF": sf, "input_rows": rows_in,
+                              "groups": groups, "best_s": best, "input_rows_per_s": rows_in / best, "host_table_gen_s": gen_s}))
+        finally:
+            for d in dev:
+                d.free()
+
+
+if __name__ == "__main__":
+    main()
