@@ -52,6 +52,8 @@ struct AggArgs {
     uint32_t* retry_out;            // rows that found no slot within the probe limit
     unsigned long long* counters;   // [0]=new groups [1]=retry count [2]=hash collisions
     int32_t phase;                  // multi key: 0 = claim slots, 1 = verify + update
+    uint32_t* slot_of;              // multi key: slot found by phase 0 for item r (0xffffffff = handed back), read by phase 1
+    uint64_t bail_after;            // once this many items were handed back the table is too small: the rest skip the walk
 };
 
 // group key word of one cell (codec.go:713-746 semantics, see header)
@@ -175,14 +177,17 @@ __device__ __forceinline__ void agg_update_slot(const AggArgs& a, uint64_t s, in
     }
 }
 
-#define TSQ_AGG_PROBE_LIMIT 4096
+// A walk longer than this means the table is over-full for this batch (the host keeps load <= 0.5 for the groups it
+// knows, where a 256-slot run is astronomically unlikely): the item is handed back and the host grows the table.
+#define TSQ_AGG_PROBE_LIMIT 256
 
 // K7 — group-table upsert.  Replaces HashAggPartialWorker.updatePartialResult
 // (executor/aggregate.go:332-350): getGroupKey (:359-394) + getPartialResult (:396-410) + the per
 // row UpdatePartialResult calls.  SINGLE key: one fused pass.  MULTI key: phase 0 claims slots by
 // 64-bit tag and the claimer stores the key cells; phase 1 (a later launch, so the cells are
 // visible) verifies the cells and applies the aggregates — a tag collision between different keys
-// is counted and surfaces as an error instead of merging two groups.
+// is counted and surfaces as an error instead of merging two groups.  Phase 0 leaves the slot of every item in
+// slot_of[], so phase 1 neither walks the table again nor depends on what other items did in between.
 template <bool MULTI>
 __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -217,17 +222,22 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
             tag = h == TSQ_EMPTY_TAG ? h ^ 1 : h;
         }
         bool winner = false;
-        if (special) {
+        if (MULTI && a.phase == 1) {
+            const uint32_t s32 = a.slot_of[r];
+            if (s32 == 0xffffffffu) continue;  // handed back by phase 0
+            slot = s32;
+        } else if (special) {
             // the two special slots are claimed through their tag word as well (EMPTY -> 1)
             if (__hip_atomic_load(&a.t.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == TSQ_EMPTY_TAG)
                 winner = atomicCAS(&a.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, 1ull) == TSQ_EMPTY_TAG;
         } else {
             slot = tsq_mulhi64(tsq_mix64(tag), a.t.cap);
             bool found = false;
-            for (int probe = 0; probe < TSQ_AGG_PROBE_LIMIT; probe++) {
+            // a batch with far more new groups than free slots: after bail_after failed walks nobody walks any more
+            const bool hopeless = __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.bail_after;
+            for (int probe = 0; probe < TSQ_AGG_PROBE_LIMIT && !hopeless; probe++) {
                 unsigned long long cur = __hip_atomic_load(&a.t.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == TSQ_EMPTY_TAG) {
-                    if (MULTI && a.phase == 1) break;  // cannot happen after a complete phase 0
                     cur = atomicCAS(&a.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, (unsigned long long)tag);
                     if (cur == TSQ_EMPTY_TAG) { winner = true; found = true; break; }
                 }
@@ -235,13 +245,13 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
                 slot = slot + 1 == a.t.cap ? 0 : slot + 1;
             }
             if (!found) {  // table (nearly) full: hand the row back, the host grows the table
-                if (!MULTI || a.phase == 0) {  // (phase 1 fails for exactly the rows phase 0 handed back)
-                    uint32_t i = (uint32_t)atomicAdd(&a.counters[1], 1ull);
-                    a.retry_out[i] = (uint32_t)row;
-                }
+                uint32_t i = (uint32_t)atomicAdd(&a.counters[1], 1ull);
+                a.retry_out[i] = (uint32_t)row;
+                if (MULTI) a.slot_of[r] = 0xffffffffu;
                 continue;
             }
         }
+        if (MULTI && a.phase == 0) a.slot_of[r] = (uint32_t)slot;
         if (winner) {
             new_groups++;
             for (int k = 0; k < a.plan.n_keys; k++) a.t.gkey[k][slot] = kw[k];
@@ -282,6 +292,7 @@ struct MergeArgs {
     const uint32_t* retry_in;
     uint32_t* retry_out;
     unsigned long long* counters;  // [0]=new groups [1]=retry count
+    uint64_t bail_after;           // as in AggArgs
 };
 __global__ void __launch_bounds__(256) k_agg_merge(MergeArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -298,7 +309,8 @@ __global__ void __launch_bounds__(256) k_agg_merge(MergeArgs a) {
         } else {
             slot = tsq_mulhi64(tsq_mix64(tag), a.t.cap);
             bool found = false;
-            for (int probe = 0; probe < TSQ_AGG_PROBE_LIMIT; probe++) {
+            const bool hopeless = __hip_atomic_load(&a.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.bail_after;
+            for (int probe = 0; probe < TSQ_AGG_PROBE_LIMIT && !hopeless; probe++) {
                 unsigned long long cur = __hip_atomic_load(&a.t.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == TSQ_EMPTY_TAG) {
                     cur = atomicCAS(&a.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, tag);
@@ -408,17 +420,34 @@ struct FinalArgs {
 __device__ __forceinline__ bool sum128_fits(unsigned long long lo, unsigned long long hi) {
     return hi == ((lo >> 63) ? ~0ull : 0ull);  // hi must be the sign extension of lo
 }
+// Output positions: a workgroup takes TSQ_FINAL_CHUNK consecutive slots, counts the occupied ones, reserves its output
+// range with ONE device atomic and hands positions out from an LDS cursor.  (One returning device atomic per wave on the
+// single cursor cost ~11 ns each, chip-wide: 1.3 ms for an 8 M-slot table.)
+#define TSQ_FINAL_CHUNK 4096
 __global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    __shared__ unsigned long long s_cnt, s_cur;
     const uint64_t nslots = a.t.cap + 2;
-    const uint64_t nround = (nslots + 63) & ~63ull;
-    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nround; s += stride) {
+    const uint64_t nchunks = (nslots + TSQ_FINAL_CHUNK - 1) / TSQ_FINAL_CHUNK;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const uint64_t lo = ch * TSQ_FINAL_CHUNK;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x; i < TSQ_FINAL_CHUNK; i += 256) mine += (lo + i < nslots && a.t.tag[lo + i] != TSQ_EMPTY_TAG) ? 1u : 0u;
+        for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o, 64);
+        if (lane == 0 && mine) atomicAdd(&s_cnt, (unsigned long long)mine);
+        __syncthreads();
+        if (threadIdx.x == 0) s_cur = s_cnt ? atomicAdd(&a.counters[3], s_cnt) : 0ull;
+        __syncthreads();
+        if (s_cnt == 0) continue;  // block-uniform
+      for (uint32_t i0 = 0; i0 < TSQ_FINAL_CHUNK; i0 += 256) {
+        const uint64_t s = lo + i0 + threadIdx.x;
         const bool occ = s < nslots && a.t.tag[s] != TSQ_EMPTY_TAG;
         const unsigned long long m = __ballot(occ);
         if (!m) continue;
-        const int lane = threadIdx.x & 63;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&a.counters[3], (unsigned long long)__popcll(m));
+        if (lane == 0) base = atomicAdd(&s_cur, (unsigned long long)__popcll(m));
         base = __shfl(base, 0, 64);
         if (!occ) continue;
         const uint64_t pos = base + __popcll(m & ((1ull << lane) - 1));
@@ -484,6 +513,7 @@ __global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
                 }
             }
         }
+      }
     }
 }
 
@@ -528,6 +558,7 @@ struct tsq_agg {
     int32_t fast_mode = TSQ_AGGFAST_AUTO;
     bool fast_ok = false;       // the plan is expressible in LDS words
     AfPlan fplan{};
+    DevBuf slot_of;             // multi key: phase 0 -> phase 1 slot numbers
     DevBuf fkey, fw[TSQ_AF_MAXW], fctl, fexc;      // partial groups | counters (partials, exceptions) | exception row ids
     DevBuf rkeys, rpay[TSQ_RADIX_MAXV], rctl, rvend, rokeys, ropay[TSQ_RADIX_MAXV];  // partitioned rows (H mode)
     int64_t fast_batches = 0, fast_fallbacks = 0;
@@ -644,7 +675,11 @@ tsq_status upsert_loop(tsq_agg* a, int64_t n0, const uint32_t* retry_in0, Launch
         if (ctx->pinned[2])
             return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "64-bit group-key hash collision between distinct keys: fall back to the Go operator");
         if (n_retry == 0) return TSQ_OK;
-        TSQ_TRY(grow_table(a, a->tb.cap * 4));
+        // every item handed back may be a new group: size for that, within x4 .. x64 of the current table
+        // (rounded to a power of two, so that a query that runs again finds its table arrays in the context pool)
+        uint64_t want = 1;
+        while (want < ((uint64_t)a->groups + n_retry) * 2) want <<= 1;
+        TSQ_TRY(grow_table(a, std::max<uint64_t>(a->tb.cap * 4, std::min<uint64_t>(a->tb.cap * 64, want))));
         retry_in = a->retry[which].as<uint32_t>();
         n = (int64_t)n_retry;
         which ^= 1;
@@ -662,8 +697,14 @@ tsq_status agg_rows(tsq_agg* a, const tsq_colset& in, int64_t nrows, const uint3
     args.plan = a->plan;
     args.row_base = a->in_rows;
     args.counters = a->counters.as<unsigned long long>();
+    if (a->multi) {
+        TSQ_TRY(a->slot_of.reserve(a->ctx, &a->hdr, (size_t)nrows * 4 + 16));
+        args.slot_of = a->slot_of.as<uint32_t>();
+    }
     return upsert_loop(a, nrows, rows_in, [&](const AggTable& t, int64_t n, const uint32_t* retry_in, uint32_t* retry_out) -> tsq_status {
+        if (a->multi && t.cap + 2 >= 0xffffffffULL) return tsq_fail(&a->hdr, TSQ_ERR_UNSUPPORTED, "multi-key aggregate: more than 2^32 group slots");
         args.t = t;
+        args.bail_after = std::max<uint64_t>(1024, t.cap / 16);
         args.nrows = n;
         args.retry_in = retry_in;
         args.retry_out = retry_out;
@@ -799,6 +840,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     ma.counters = a->counters.as<unsigned long long>();
     TSQ_TRY(upsert_loop(a, (int64_t)n_part, nullptr, [&](const AggTable& t, int64_t n, const uint32_t* retry_in, uint32_t* retry_out) -> tsq_status {
         ma.t = t;
+        ma.bail_after = std::max<uint64_t>(1024, t.cap / 16);
         ma.n = n;
         ma.retry_in = retry_in;
         ma.retry_out = retry_out;
@@ -1053,7 +1095,7 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     }
     fa.counters = a->counters.as<unsigned long long>();
     TSQ_HIP(h, hipMemsetAsync((char*)a->counters.p + 3 * 8, 0, 16, ctx->stream));
-    int grid = tsq_grid_for(ctx, (int64_t)a->tb.cap + 2, 256);
+    int grid = tsq_grid_for(ctx, (int64_t)a->tb.cap + 2, 256, TSQ_FINAL_CHUNK / 256);
     hipLaunchKernelGGL(k_agg_finalize, dim3(grid), dim3(256), 0, ctx->stream, fa);
     TSQ_HIP(h, hipGetLastError());
     a->st.kernel_launches++;
@@ -1169,6 +1211,7 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
     a->counters.release();
     a->retry[0].release();
     a->retry[1].release();
+    a->slot_of.release();
     a->stage.release();
     for (auto& c : a->icols) c.release();
     for (auto& b : a->odata) b.release();

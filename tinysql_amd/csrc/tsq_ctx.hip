@@ -94,23 +94,45 @@ TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     (void)hipDeviceSynchronize();
     for (hipModule_t m : ctx->retired_modules) (void)hipModuleUnload(m);
+    for (auto& kv : ctx->jit_cache)
+        if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
     for (auto& b : ctx->pool) (void)hipFree(b.first);
+    for (auto& b : ctx->user_allocs) (void)hipFree(b.first);  // blocks the caller never handed back
     ctx->hdr.magic = 0;
     delete ctx;
 }
 
+// tsq_dev_alloc / tsq_dev_free go through the context pool as well: a device-resident operator pipeline allocates its
+// output chunks (GBs) per query, and hipMalloc is ~35 ms per GB.  The size of every live allocation is remembered so that
+// tsq_dev_free can hand the block back; a recycled block is safe because every libtsq kernel and copy runs on ctx->stream.
 TSQ_API tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out) {
     if (!ctx || !out || bytes < 0) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     *out = nullptr;
     if (bytes == 0) bytes = 8;
-    TSQ_HIP(&ctx->hdr, hipMalloc(out, (size_t)bytes));
+    size_t cap = (size_t)bytes;
+    void* p = tsq_pool_get(ctx, cap, &cap);
+    if (!p) TSQ_HIP(&ctx->hdr, hipMalloc(&p, cap));
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        ctx->user_allocs[p] = cap;
+    }
+    *out = p;
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_dev_free(tsq_ctx* ctx, void* p) {
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
-    if (p) TSQ_HIP(&ctx->hdr, hipFree(p));
+    if (!p) return TSQ_OK;
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        auto it = ctx->user_allocs.find(p);
+        if (it == ctx->user_allocs.end()) return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_dev_free: pointer was not returned by tsq_dev_alloc on this context");
+        cap = it->second;
+        ctx->user_allocs.erase(it);
+    }
+    tsq_pool_put(ctx, p, cap);
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_dev_memset(tsq_ctx* ctx, void* p, int32_t byte, int64_t bytes) {

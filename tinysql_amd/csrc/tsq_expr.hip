@@ -265,22 +265,19 @@ extern "C" __global__ void __launch_bounds__(256) jit_filter(ExprArgs a) {
 }
 
 // compiles once per handle; on any failure the generic kernels keep serving (still the GPU, never a CPU path)
-static void jit_prepare(tsq_expr* e) {
-    if (e->jit_tried) return;
-    e->jit_tried = true;
-    const std::string src = jit_source(e->progs);
+static void jit_compile(tsq_ctx* ctx, const std::string& src, tsq_ctx::JitEntry& out) {
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "tsq_expr_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-        e->jit_log = "hiprtcCreateProgram failed";
+        out.log = "hiprtcCreateProgram failed";
         return;
     }
-    std::string arch = std::string("--offload-arch=") + e->ctx->prop.gcnArchName;
+    std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
     const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics"};
     const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
     size_t logsz = 0;
     if (hiprtcGetProgramLogSize(prog, &logsz) == HIPRTC_SUCCESS && logsz > 1) {
-        e->jit_log.resize(logsz);
-        (void)hiprtcGetProgramLog(prog, &e->jit_log[0]);
+        out.log.resize(logsz);
+        (void)hiprtcGetProgramLog(prog, &out.log[0]);
     }
     if (rc != HIPRTC_SUCCESS) {
         (void)hiprtcDestroyProgram(&prog);
@@ -294,13 +291,32 @@ static void jit_prepare(tsq_expr* e) {
     }
     (void)hiprtcDestroyProgram(&prog);
     if (code.empty()) return;
-    if (hipModuleLoadData(&e->jit_mod, code.data()) != hipSuccess) {
-        e->jit_mod = nullptr;
-        e->jit_log += "\nhipModuleLoadData failed";
+    if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) {
+        out.mod = nullptr;
+        out.log += "\nhipModuleLoadData failed";
         return;
     }
-    if (hipModuleGetFunction(&e->jit_expr, e->jit_mod, "jit_expr") != hipSuccess) e->jit_expr = nullptr;
-    if (hipModuleGetFunction(&e->jit_filter, e->jit_mod, "jit_filter") != hipSuccess) e->jit_filter = nullptr;
+    if (hipModuleGetFunction(&out.f_expr, out.mod, "jit_expr") != hipSuccess) out.f_expr = nullptr;
+    if (hipModuleGetFunction(&out.f_filter, out.mod, "jit_filter") != hipSuccess) out.f_filter = nullptr;
+}
+
+// The module belongs to the context's plan cache (tsq_internal.h) and lives until the context is destroyed.
+static void jit_prepare(tsq_expr* e) {
+    if (e->jit_tried) return;
+    e->jit_tried = true;
+    const std::string src = jit_source(e->progs);
+    tsq_ctx* ctx = e->ctx;
+    std::lock_guard<std::mutex> g(ctx->jit_mu);
+    auto it = ctx->jit_cache.find(src);
+    if (it == ctx->jit_cache.end()) {
+        tsq_ctx::JitEntry ent;
+        jit_compile(ctx, src, ent);
+        it = ctx->jit_cache.emplace(src, std::move(ent)).first;
+    }
+    e->jit_mod = it->second.mod;
+    e->jit_expr = it->second.f_expr;
+    e->jit_filter = it->second.f_filter;
+    e->jit_log = it->second.log;
 }
 
 // launches the specialised kernel when policy and availability allow it; returns false -> use the generic kernel
@@ -461,10 +477,8 @@ TSQ_API void tsq_expr_destroy(tsq_expr* e) {
     e->out_isnull.release();
     e->hout.release();
     e->hflags.release();
-    if (e->jit_mod) {
-        std::lock_guard<std::mutex> g(e->ctx->retired_mu);
-        e->ctx->retired_modules.push_back(e->jit_mod);
-    }
+    // e->jit_mod stays in the context's plan cache (unloading a module right after its handle died made later,
+    // unrelated kernels fault intermittently on ROCm 7.2 — see tsq_internal.h)
     e->hdr.magic = 0;
     delete e;
 }

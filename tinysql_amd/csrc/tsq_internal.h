@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "tsq_device.h"
@@ -43,6 +44,15 @@ struct tsq_ctx {
     // tools/bench_kernels.py, address 0x100000 — although the stream had been synchronised before the unload.)
     std::vector<hipModule_t> retired_modules;
     std::mutex retired_mu;
+    // plan cache of specialised expression kernels: generated source -> loaded module.  A query that runs again (or a
+    // second operator with the same expression list) skips the hiprtc compile; a failed compile is remembered too.
+    struct JitEntry {
+        hipModule_t mod = nullptr;
+        hipFunction_t f_expr = nullptr, f_filter = nullptr;
+        std::string log;
+    };
+    std::unordered_map<std::string, JitEntry> jit_cache;
+    std::mutex jit_mu;
     // device-memory pool: hipMalloc costs ~35 ms per GB, and one radix / pre-aggregation batch needs several GB of
     // partition buffers — per handle that was 100+ ms of allocation for a 20 ms aggregate.  Buffers released by a handle
     // are kept (up to pool_cap bytes) and handed to the next one; everything runs on ctx->stream, so stream order
@@ -50,6 +60,7 @@ struct tsq_ctx {
     std::mutex pool_mu;
     std::vector<std::pair<void*, size_t>> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)48 << 30;
+    std::unordered_map<void*, size_t> user_allocs;  // live tsq_dev_alloc blocks -> capacity (guarded by pool_mu)
 };
 inline void* tsq_pool_get(tsq_ctx* ctx, size_t bytes, size_t* got) {
     std::lock_guard<std::mutex> g(ctx->pool_mu);

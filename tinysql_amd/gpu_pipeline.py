@@ -19,6 +19,7 @@ import numpy as np
 from . import _abi as abi
 from . import _lib
 from .chunk import Chunk, Column, np_dtype
+from .expression import Column as Column_
 from .expression import ETReal, CompiledExpr
 
 
@@ -212,7 +213,10 @@ class GpuProjectionExec(GpuExecutor):
 
     def Open(self):
         super().Open()
-        self.compiled = [CompiledExpr(self.ctx, [e], jit=self.jit) for e in self.exprs]
+        # a bare 8-byte column needs no kernel: the child's column is handed on (the reference copies it, projection.go:54-62
+        # -> Column.CopyConstruct; a device pointer that stays valid until the child's next Next is equivalent here)
+        self.passthru = [e.index if isinstance(e, Column_) and e.tp != abi.F32 else None for e in self.exprs]
+        self.compiled = [None if p is not None else CompiledExpr(self.ctx, [e], jit=self.jit) for p, e in zip(self.passthru, self.exprs)]
 
     def Next(self):
         chk = self.child.Next()
@@ -221,25 +225,33 @@ class GpuProjectionExec(GpuExecutor):
             return EOS
         if n > self.cap:
             self._release()
-            self.cap, self.out = n, self._buffers(n)
-        for ce, dst in zip(self.compiled, self.out):
+            self.cap = n
+            self.out = [None if p is not None else DeviceColumn(self.ctx, t, n) for p, t in zip(self.passthru, self.types)]
+        cols = []
+        for p, ce, dst in zip(self.passthru, self.compiled, self.out):
+            if p is not None:
+                cols.append(chk.columns[p])
+                continue
             oc = dst.col(n)
             oc.type = abi.F64 if dst.tp == abi.F64 else abi.I64
             w = C.c_int64(0)
             _lib.check(self.lib.tsq_expr_eval(ce.h, chk.cols(), len(chk.columns), n, None, C.byref(oc), C.byref(w)), ce.h)
             ce.warnings += w.value
-        return DeviceChunk(self.out, n)
+            cols.append(dst)
+        return DeviceChunk(cols, n)
 
     def _release(self):
         if self.out:
             for c in self.out:
-                c.free()
+                if c is not None:
+                    c.free()
         self.out, self.cap = None, 0
 
     def Close(self):
         self._release()
         for ce in self.compiled:
-            ce.close()
+            if ce is not None:
+                ce.close()
         self.compiled = []
         super().Close()
 
