@@ -282,8 +282,11 @@ tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on);
 /* Probe strategy of the COUNT(*) fast path.  TSQ_RADIX_AUTO (default): probe batches that are large
  * enough are radix partitioned by the top bits of the key hash (LDS-staged, write combined) and probed
  * partition by partition so that every XCD works inside a table slice that fits its L2; small batches
- * and small tables take the direct probe.  OFF / FORCE exist for tests and measurements; the joined
- * rows are identical either way.  Replaces the worker dispatch of executor/join.go:160-231. */
+ * and small tables take the direct probe.  The same switch, when set before tsq_join_build_finish, selects
+ * the BUILD strategy: AUTO assembles the table slice by slice in LDS (two radix passes over key words +
+ * row ids, then one LDS image per slice) for single-key builds of >= 4 Mi rows and inserts row by row
+ * (64-bit CAS) otherwise.  OFF / FORCE exist for tests and measurements; the joined rows are identical
+ * either way.  Replaces the worker dispatch of executor/join.go:160-231 and PutChunk (hash_table.go:146-169). */
 #define TSQ_RADIX_AUTO  (-1)
 #define TSQ_RADIX_OFF     0
 #define TSQ_RADIX_FORCE   1
@@ -401,9 +404,9 @@ typedef struct tsq_stats {
     double  radix_probe_kernel_ms_sum;
     int64_t radix_timed_batches;
     int64_t radix_batches;         /* join: probe batches through the radix path; agg: batches pre-aggregated in LDS */
-    int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew) in the last batch */
+    int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew): last probe batch + the partitioned build */
     int32_t radix_bits;            /* log2(partitions) of the last radix batch */
-    int32_t reserved;
+    int32_t build_partitioned;     /* 1: the table was assembled slice by slice in LDS (tsq_buildpart.h), 0: row-at-a-time CAS build */
 } tsq_stats;
 tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out);
 tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out);

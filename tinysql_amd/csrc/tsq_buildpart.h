@@ -1,0 +1,204 @@
+// tsq_buildpart.h — partitioned build of the join hash table (device code; included by tsq_join.hip).
+//
+// Why: k_build_insert claims slots with one random 64-bit CAS per build row into a table of GBs: 9 ms per 1e8 rows,
+// 0.03 of the HBM roofline (random device atomics run at 20-27 G/s, and every row also scatters a 4-byte row id).
+// The table is range partitioned by construction — bucket(kw) = mulhi64(mix64(kw), nbuckets) is monotonic in the hash
+// (tsq_jointable.h) — so a slice of it can be ASSEMBLED IN LDS from the rows whose hash falls into that slice and then
+// written to HBM as whole lines:
+//   pass 1  k_radix_partition<.., WITH_IDX>   build key words + row ids by the top b1 hash bits (tsq_radix.h)
+//   pass 2  k_radix_subpartition              one workgroup per pass-1 partition splits it by the next b2 bits; the
+//                                             workgroup owns its 2^b2 outputs, so cursors live in LDS (no device atomics)
+//   pass 3  k_build_images                    one workgroup per sub-partition: LDS image of its nbuckets/2^(b1+b2)
+//                                             buckets (<= 768 buckets = 72 KB: two workgroups per CU), filled with LDS
+//                                             compare-and-swap, stored with 16-byte coalesced writes
+// nbuckets is rounded up to a multiple of 2^(b1+b2), so no bucket is shared by two sub-partitions.  Rows that do not fit
+// (a skewed partition overflowing its region, a bucket chain running past the end of its slice) are appended to a row
+// list and inserted afterwards by the ordinary k_build_insert: the linear-probing invariant holds because everything
+// between their home bucket and the end of the slice is full.  The resulting table is equivalent to the one
+// k_build_insert builds (same buckets, slots filled front to back, possibly another slot order inside a chain).
+//
+// Replaces (reference): hashRowContainer.PutChunk + rowHashMap.Put (executor/hash_table.go:146-169,247-256).
+#ifndef TSQ_BUILDPART_H
+#define TSQ_BUILDPART_H
+
+#include "tsq_radix.h"
+
+#define TSQ_BP_MAXP2 256
+#define TSQ_BP_MAX_SLICE 768  // buckets per LDS image (96 B each)
+
+struct SubStore {
+    uint64_t* keys;       // [Q * cap2] key words, Q = 2^(b1+b2)
+    uint32_t* idx;        // [Q * cap2] build row ids
+    uint32_t* count;      // [Q] rows stored per sub-partition
+    uint32_t* ovf_rows;   // build row ids that found no room (inserted later with k_build_insert)
+    uint32_t* ovf_count;
+    uint32_t ovf_cap;
+    uint32_t b1, b2, cap2;
+};
+
+// pass 2: partition p of a RadixStore (8 regions) -> 2^b2 sub-partitions
+template <int NT, int K>
+__global__ void __launch_bounds__(NT) k_radix_subpartition(RadixStore st, SubStore out) {
+    constexpr int T = NT * K;
+    __shared__ uint64_t s_keys[T];
+    __shared__ uint32_t s_idx[T];
+    __shared__ uint32_t s_hist[TSQ_BP_MAXP2];   // count, then (overflow flag | exclusive offset inside the tile)
+    __shared__ uint32_t s_delta[TSQ_BP_MAXP2];  // global slot of the run minus its LDS offset
+    __shared__ uint32_t s_cur[TSQ_BP_MAXP2];    // rows stored so far per sub-partition (this workgroup owns them)
+    __shared__ uint32_t s_wsum[NT / 64];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P1 = 1u << st.bits, P2 = 1u << out.b2;
+    const uint32_t shift = 64 - st.bits - out.b2, mask = P2 - 1;
+    for (uint32_t p = blockIdx.x; p < P1; p += gridDim.x) {
+        if (tid < P2) s_cur[tid] = 0;
+        __syncthreads();
+        for (uint32_t r = 0; r < st.R; r++) {
+            const uint32_t region = p * st.R + r;
+            uint32_t len = st.cursor[region];
+            const uint32_t ve = st.valid_end[region];
+            len = len < ve ? len : ve;
+            len = len < st.cap ? len : st.cap;
+            const size_t rbase = (size_t)region * st.cap;
+            for (uint32_t t0 = 0; t0 < len; t0 += T) {
+                const uint32_t n = len - t0 < (uint32_t)T ? len - t0 : (uint32_t)T;
+                uint64_t k[K];
+                uint32_t id[K], pr[K];
+                if (tid < P2) s_hist[tid] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const uint32_t pos = (uint32_t)j * NT + tid;
+                    pr[j] = 0xffffffffu;
+                    if (pos < n) {
+                        k[j] = st.keys[rbase + t0 + pos];
+                        id[j] = st.idx[rbase + t0 + pos];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const uint32_t pos = (uint32_t)j * NT + tid;
+                    if (pos < n) {
+                        const uint32_t s = (uint32_t)(tsq_mix64(k[j]) >> shift) & mask;
+                        pr[j] = (s << 16) | atomicAdd(&s_hist[s], 1u);
+                    }
+                }
+                __syncthreads();
+                const uint32_t cnt = tid < P2 ? s_hist[tid] : 0u;
+                uint32_t total;
+                const uint32_t offs = block_excl_scan<NT>(cnt, s_wsum, &total);
+                if (tid < P2) {
+                    uint32_t flag = 0;
+                    const uint32_t g = s_cur[tid];
+                    if (g + cnt > out.cap2) flag = 1;  // skew: the whole run goes to the row list
+                    else s_cur[tid] = g + cnt;
+                    s_delta[tid] = ((p << out.b2) + tid) * out.cap2 + g - offs;
+                    s_hist[tid] = offs | (flag << 31);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    if (pr[j] != 0xffffffffu) {
+                        const uint32_t d = (s_hist[pr[j] >> 16] & 0x7fffffffu) + (pr[j] & 0xffffu);
+                        s_keys[d] = k[j];
+                        s_idx[d] = id[j];
+                    }
+                }
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += NT) {
+                    const uint64_t key = s_keys[i];
+                    const uint32_t s = (uint32_t)(tsq_mix64(key) >> shift) & mask;
+                    if (!(s_hist[s] >> 31)) {
+                        const uint32_t d = s_delta[s] + i;  // 32-bit wrap-around: s_delta may be "negative"
+                        out.keys[d] = key;
+                        out.idx[d] = s_idx[i];
+                    } else {
+                        const uint32_t o = __hip_atomic_fetch_add(out.ovf_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (o < out.ovf_cap) out.ovf_rows[o] = s_idx[i];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid < P2) out.count[(p << out.b2) + tid] = s_cur[tid];
+        __syncthreads();
+    }
+}
+
+struct ImageArgs {
+    SubStore in;
+    JoinTable t;             // nbuckets is a multiple of Q
+    uint32_t m;              // buckets per sub-partition = nbuckets / Q
+    uint32_t* sent_rows;     // side list of the sentinel key word (capacity sent_cap)
+    uint32_t sent_cap;
+    uint32_t* sent_total;
+    unsigned long long* inserted;  // += rows placed here (image or side list)
+};
+
+// pass 3: LDS image of one table slice.  Dynamic LDS: m*8 key words, then m*8 row ids.
+template <int NT>
+__global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    unsigned long long* s_keys = (unsigned long long*)s_dyn;
+    uint32_t* s_vals = (uint32_t*)(s_dyn + (size_t)a.m * TSQ_BUCKET * 8);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Q = 1u << (a.in.b1 + a.in.b2);
+    const uint32_t nslots = a.m * TSQ_BUCKET;
+    __shared__ unsigned long long s_handled;
+    if (tid == 0) s_handled = 0;
+    uint32_t placed = 0;  // rows this thread put into an image or the side list (the row list is counted by k_build_insert)
+    for (uint32_t q = blockIdx.x; q < Q; q += gridDim.x) {
+        for (uint32_t i = tid; i < nslots; i += NT) s_keys[i] = TSQ_EMPTY_KEY;
+        __syncthreads();
+        const uint32_t cnt = a.in.count[q];
+        const size_t src = (size_t)q * a.in.cap2;
+        const uint64_t b0 = (uint64_t)q * a.m;
+        for (uint32_t i = tid; i < cnt; i += NT) {
+            const uint64_t kw = a.in.keys[src + i];
+            const uint32_t row = a.in.idx[src + i];
+            if (kw == TSQ_EMPTY_KEY) {
+                const uint32_t o = atomicAdd(a.sent_total, 1u);
+                if (o < a.sent_cap) a.sent_rows[o] = row;
+                placed++;
+                continue;
+            }
+            uint32_t lb = (uint32_t)(radix_bucket(tsq_mix64(kw), a.t.nbuckets) - b0);
+            bool done = false;
+            while (!done) {
+                if (lb >= a.m) {  // the chain runs past this slice: k_build_insert continues it in the next one
+                    const uint32_t o = __hip_atomic_fetch_add(a.in.ovf_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (o < a.in.ovf_cap) a.in.ovf_rows[o] = row;
+                    break;
+                }
+                unsigned long long* b = s_keys + lb * TSQ_BUCKET;
+#pragma unroll 1
+                for (int s = 0; s < TSQ_BUCKET && !done; s++) {
+                    // a stale EMPTY is harmless (the CAS decides); non-EMPTY never reverts
+                    if (__hip_atomic_load(&b[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == TSQ_EMPTY_KEY &&
+                        atomicCAS(&b[s], (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)kw) == TSQ_EMPTY_KEY) {
+                        s_vals[lb * TSQ_BUCKET + s] = row;
+                        done = true;
+                        placed++;
+                    }
+                }
+                lb++;
+            }
+        }
+        __syncthreads();
+        // slice image -> HBM, 16 bytes per lane (the slice starts on a 64-byte boundary: b0 * 64 B keys, b0 * 32 B row ids)
+        {
+            const ulonglong2* sk = (const ulonglong2*)s_keys;
+            ulonglong2* dk = (ulonglong2*)(a.t.keys + b0 * TSQ_BUCKET);
+            for (uint32_t i = tid; i < nslots / 2; i += NT) dk[i] = sk[i];
+            const uint4* sv = (const uint4*)s_vals;
+            uint4* dv = (uint4*)(a.t.vals + b0 * TSQ_BUCKET);
+            for (uint32_t i = tid; i < nslots / 4; i += NT) dv[i] = sv[i];
+        }
+        __syncthreads();
+    }
+    const uint64_t wsum = wave_sum_u64(placed);
+    if ((tid & 63) == 0 && wsum) atomicAdd(&s_handled, (unsigned long long)wsum);
+    __syncthreads();
+    if (tid == 0 && s_handled) atomicAdd(a.inserted, s_handled);
+}
+
+#endif

@@ -19,7 +19,7 @@
 // columns through the row id.
 #include "tsq_stage.h"
 #include "tsq_jointable.h"
-#include "tsq_radix.h"
+#include "tsq_buildpart.h"
 
 #include <deque>
 #include <memory>
@@ -80,13 +80,14 @@ struct BuildArgs {
     uint32_t sent_cap;
     uint32_t* sent_total;  // number of sentinel-key rows seen
     unsigned long long* inserted;
+    const uint32_t* row_list;  // optional: insert only these build rows (rows the partitioned build handed back)
 };
 template <bool MULTI>
 __global__ void __launch_bounds__(256) k_build_insert(BuildArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t ins = 0;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
-        const int64_t row = a.row0 + r;
+        const int64_t row = a.row_list ? (int64_t)a.row_list[r] : a.row0 + r;
         uint64_t kw;
         if (!load_kw<MULTI>(a.b, a.ks.bidx, a.ks.n_keys, a.ks.skip_high, row, kw)) continue;
         ins++;
@@ -494,6 +495,7 @@ struct tsq_join {
     uint64_t nbuckets = 0;
     uint32_t sent_count = 0;
     int64_t build_inserted = 0;
+    int64_t build_handed_back = 0;  // partitioned build: rows that went through the row list (skew, chains crossing a slice end)
 
     // host staging (shared by build and probe pushes; one side is active at a time)
     HostStage stage;
@@ -868,6 +870,149 @@ tsq_status probe_flush(tsq_join* j) {
     return TSQ_OK;
 }
 
+// ---------------------------------------------------------------- partitioned build (host side, tsq_buildpart.h)
+// Single key column, enough rows to pay for three passes.  Geometry: Q = 2^bits slices of m <= 768 buckets.
+bool build_partitioned_eligible(const tsq_join* j, int64_t nb) {
+    if (j->radix_mode == TSQ_RADIX_OFF || j->multi || j->never_match) return false;
+    if (nb >= 0xffffffffLL) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE) return nb >= (1 << 16);
+    return nb >= (4 << 20);
+}
+
+tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* done) {
+    *done = false;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const uint64_t nb0 = std::max<uint64_t>(16, (uint64_t)((nb + 3) / 4));
+    uint32_t bits = 4;
+    while (((nb0 + (1ull << bits) - 1) >> bits) > TSQ_BP_MAX_SLICE) bits++;
+    if (bits > 19) return TSQ_OK;
+    uint32_t b1, b2;
+    if (bits >= 16) { b2 = 8; b1 = bits - 8; }
+    else if (bits >= 9) { b1 = 8; b2 = bits - 8; }
+    else { b1 = bits - 1; b2 = 1; }
+    const uint32_t Q = 1u << bits, P1 = 1u << b1;
+    const uint32_t m = (uint32_t)((nb0 + Q - 1) >> bits);
+    const uint64_t nbuckets = (uint64_t)m * Q;
+    // pass-1 store (8 XCC regions per partition), as in radix_probe
+    RadixStore st;
+    memset(&st, 0, sizeof st);
+    st.bits = b1;
+    st.R = 8;
+    constexpr int NT = 1024, K1 = 8, T1 = NT * K1;
+    const double lam = (double)nb / ((double)P1 * 8.0);
+    st.cap = (uint32_t)(lam * 1.08 + 8.0 * sqrt(lam) + 2.0 * T1 / 64.0 + 64.0);
+    st.cap = (st.cap + 15u) & ~15u;
+    const size_t nregions = (size_t)P1 * 8, slots1 = nregions * st.cap;
+    const double lam2 = (double)nb / (double)Q;
+    uint32_t cap2 = (uint32_t)(lam2 * 1.08 + 8.0 * sqrt(lam2) + 64.0);
+    cap2 = (cap2 + 15u) & ~15u;
+    const size_t slots2 = (size_t)Q * cap2;
+    if (slots1 >= 0xffffffffULL || slots2 >= 0xffffffffULL) return TSQ_OK;
+    DevBuf k1, i1, ctl, vend, ok1, oi1, k2, i2, cnt2, orows;
+    auto release_all = [&]() {
+        for (DevBuf* b : {&k1, &i1, &ctl, &vend, &ok1, &oi1, &k2, &i2, &cnt2, &orows}) b->release();
+    };
+    tsq_status s = TSQ_OK;
+    const size_t ctl_bytes = nregions * 4 + 64;  // cursors | [nregions] pass-1 overflow count | [nregions+1] row-list count
+    if (s == TSQ_OK) s = k1.reserve(ctx, h, slots1 * 8 + 256);
+    if (s == TSQ_OK) s = i1.reserve(ctx, h, slots1 * 4 + 256);
+    if (s == TSQ_OK) s = ctl.reserve(ctx, h, ctl_bytes);
+    if (s == TSQ_OK) s = vend.reserve(ctx, h, nregions * 4);
+    if (s == TSQ_OK) s = ok1.reserve(ctx, h, (size_t)nb * 8 + 64);
+    if (s == TSQ_OK) s = oi1.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK) s = k2.reserve(ctx, h, slots2 * 8 + 256);
+    if (s == TSQ_OK) s = i2.reserve(ctx, h, slots2 * 4 + 256);
+    if (s == TSQ_OK) s = cnt2.reserve(ctx, h, (size_t)Q * 4);
+    if (s == TSQ_OK) s = orows.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK) s = j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8);
+    if (s == TSQ_OK) s = j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4);
+    if (s != TSQ_OK) { release_all(); return s; }
+    j->nbuckets = nbuckets;
+    st.keys = k1.as<uint64_t>();
+    st.idx = i1.as<uint32_t>();
+    st.cursor = ctl.as<uint32_t>();
+    st.ovf_count = st.cursor + nregions;
+    st.valid_end = vend.as<uint32_t>();
+    st.ovf_keys = ok1.as<uint64_t>();
+    st.ovf_idx = oi1.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nb;
+    SubStore sub;
+    memset(&sub, 0, sizeof sub);
+    sub.keys = k2.as<uint64_t>();
+    sub.idx = i2.as<uint32_t>();
+    sub.count = cnt2.as<uint32_t>();
+    sub.ovf_rows = orows.as<uint32_t>();
+    sub.ovf_count = st.cursor + nregions + 1;
+    sub.ovf_cap = (uint32_t)nb;
+    sub.b1 = b1;
+    sub.b2 = b2;
+    sub.cap2 = cap2;
+    hipError_t e = hipMemsetAsync(ctl.p, 0, ctl_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, nregions * 4, ctx->stream);
+    RadixSrc src;
+    memset(&src, 0, sizeof src);
+    const int kc = j->ks.bidx[0];
+    src.data = j->bcols[kc].data.p;
+    src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
+    src.type = j->cfg.build_types[kc];
+    src.skip_high = j->ks.skip_high;
+    src.nrows = nb;
+    ImageArgs ia;
+    memset(&ia, 0, sizeof ia);
+    ia.in = sub;
+    fill_table(j, ia.t);
+    ia.m = m;
+    ia.sent_rows = j->sent.as<uint32_t>();
+    ia.sent_cap = sent_cap;
+    ia.sent_total = (uint32_t*)(ctx->dscratch + 1);
+    ia.inserted = (unsigned long long*)ctx->dscratch;
+    const size_t img_bytes = (size_t)m * TSQ_BUCKET * 12;
+    if (e == hipSuccess && img_bytes > 48 * 1024)
+        e = hipFuncSetAttribute((const void*)k_build_images<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
+    if (e == hipSuccess) {
+        const int64_t ntiles = (nb + T1 - 1) / T1;
+        hipLaunchKernelGGL((k_radix_partition<NT, K1, 4, 0, true>), dim3((unsigned)std::min<int64_t>(ntiles, ctx->num_cus)), dim3(NT), 0, ctx->stream, src, st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_radix_subpartition<1024, 8>), dim3(P1), dim3(1024), 0, ctx->stream, st, sub);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_build_images<512>), dim3(Q), dim3(512), img_bytes, ctx->stream, ia);
+        e = hipGetLastError();
+    }
+    j->st.kernel_launches += 3;
+    // rows handed back: pass-1 overflow (st.ovf_idx) and the row list of passes 2 and 3
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 16, st.ovf_count, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { release_all(); return tsq_fail(h, TSQ_ERR_HIP, std::string("partitioned build: ") + hipGetErrorString(e)); }
+    const uint32_t n_ovf1 = ((const uint32_t*)(ctx->pinned + 16))[0], n_rows = ((const uint32_t*)(ctx->pinned + 16))[1];
+    BuildArgs a;
+    memset(&a, 0, sizeof a);
+    tsq_fill_colset(a.b, j->bcols);
+    a.ks = j->ks;
+    fill_table(j, a.t);
+    a.sent_rows = j->sent.as<uint32_t>();
+    a.sent_cap = sent_cap;
+    a.sent_total = (uint32_t*)(ctx->dscratch + 1);
+    a.inserted = (unsigned long long*)ctx->dscratch;
+    for (int pass = 0; pass < 2; pass++) {
+        a.nrows = pass == 0 ? n_ovf1 : n_rows;
+        a.row_list = pass == 0 ? st.ovf_idx : sub.ovf_rows;
+        if (a.nrows == 0) continue;
+        s = launch_build<false>(j, a);
+        if (s != TSQ_OK) { release_all(); return s; }
+    }
+    j->build_handed_back = (int64_t)n_ovf1 + n_rows;
+    e = hipStreamSynchronize(ctx->stream);  // the scratch buffers go back to the pool
+    release_all();
+    if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("partitioned build: ") + hipGetErrorString(e));
+    *done = true;
+    return TSQ_OK;
+}
+
 }  // namespace
 
 // ====================================================================== C-ABI
@@ -1006,17 +1151,30 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
     // size: load factor <= 0.5 over 8-slot buckets (est_build_rows is only a hint, hash_table.go:84-96)
     uint64_t nbuckets = (uint64_t)((nb + 3) / 4);
     if (nbuckets < 16) nbuckets = 16;
-    j->nbuckets = nbuckets;
-    TSQ_TRY(j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8));
-    TSQ_TRY(j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4));
-    j->st.table_bytes = (int64_t)(nbuckets * TSQ_BUCKET * 12);
-    j->st.table_buckets = (int64_t)nbuckets;
-    TSQ_HIP(h, hipMemsetAsync(j->tkeys.p, 0x80, nbuckets * TSQ_BUCKET * 8, ctx->stream));
     uint32_t sent_cap = 1024;
     TSQ_TRY(j->sent.reserve(ctx, h, sent_cap * 4));
     // dscratch[0] = inserted (u64), dscratch[1] low = sent_total (u32)
     TSQ_HIP(h, hipMemsetAsync(ctx->dscratch, 0, 16, ctx->stream));
     j->sent_count = 0;
+    bool part_done = false;
+    if (nb > 0 && build_partitioned_eligible(j, nb)) {
+        TSQ_HIP(h, hipEventRecord(j->ev[0], ctx->stream));
+        TSQ_TRY(build_partitioned(j, nb, sent_cap, &part_done));  // sets j->nbuckets (a multiple of the slice count)
+        if (part_done) {
+            TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
+            j->have_build_ev = true;
+            nbuckets = j->nbuckets;
+        }
+    }
+    if (!part_done) {
+        j->nbuckets = nbuckets;
+        TSQ_TRY(j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8));
+        TSQ_TRY(j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4));
+        TSQ_HIP(h, hipMemsetAsync(j->tkeys.p, 0x80, nbuckets * TSQ_BUCKET * 8, ctx->stream));
+    }
+    j->st.table_bytes = (int64_t)(nbuckets * TSQ_BUCKET * 12);
+    j->st.table_buckets = (int64_t)nbuckets;
+    j->st.build_partitioned = part_done ? 1 : 0;
     if (nb > 0 && !j->never_match) {
         BuildArgs a;
         memset(&a, 0, sizeof a);
@@ -1029,11 +1187,13 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
         a.sent_cap = sent_cap;
         a.sent_total = (uint32_t*)(ctx->dscratch + 1);
         a.inserted = (unsigned long long*)ctx->dscratch;
-        TSQ_HIP(h, hipEventRecord(j->ev[0], ctx->stream));
-        if (j->multi) TSQ_TRY(launch_build<true>(j, a));
-        else TSQ_TRY(launch_build<false>(j, a));
-        TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
-        j->have_build_ev = true;
+        if (!part_done) {
+            TSQ_HIP(h, hipEventRecord(j->ev[0], ctx->stream));
+            if (j->multi) TSQ_TRY(launch_build<true>(j, a));
+            else TSQ_TRY(launch_build<false>(j, a));
+            TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
+            j->have_build_ev = true;
+        }
         TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, ctx->dscratch, 16, hipMemcpyDeviceToHost, ctx->stream));
         TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
         j->build_inserted = (int64_t)ctx->pinned[0];
@@ -1244,7 +1404,7 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
     if (j->have_build_ev && hipEventElapsedTime(&ms, j->ev[0], j->ev[1]) == hipSuccess) j->st.build_kernel_ms = ms;
     if (j->have_probe_ev && hipEventElapsedTime(&ms, j->ev[2], j->ev[3]) == hipSuccess) j->st.probe_kernel_ms = ms;
     j->st.partition_kernel_ms = 0;
-    j->st.radix_overflow_rows = 0;
+    j->st.radix_overflow_rows = j->build_handed_back;
     j->st.radix_probe_kernel_ms = j->st.partition_kernel_ms_sum = j->st.radix_probe_kernel_ms_sum = 0;
     j->st.radix_timed_batches = 0;
     if (j->st.radix_batches > 0 && j->rctl.p) {
@@ -1261,7 +1421,7 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
         }
         uint32_t ovf = 0;  // overflow count of the last radix batch sits behind the cursors
         const size_t nregions = ((size_t)1 << j->st.radix_bits) * 8;
-        if (hipMemcpy(&ovf, j->rctl.as<uint32_t>() + nregions, 4, hipMemcpyDeviceToHost) == hipSuccess) j->st.radix_overflow_rows = ovf;
+        if (hipMemcpy(&ovf, j->rctl.as<uint32_t>() + nregions, 4, hipMemcpyDeviceToHost) == hipSuccess) j->st.radix_overflow_rows += ovf;
     }
     *out = j->st;
     return TSQ_OK;
