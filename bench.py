@@ -228,6 +228,7 @@ def main():
         "joined_rows": total,
         "build_ms": build_wall_ms,
         "build_kernel_ms": st.build_kernel_ms,
+        "build_strategy": "partitioned: 2 radix passes + LDS slice images" if st.build_partitioned else "row-at-a-time CAS",
         "table_bytes": st.table_bytes,
         "setup_s": setup_s,
     }

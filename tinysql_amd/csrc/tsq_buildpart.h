@@ -135,7 +135,13 @@ struct ImageArgs {
 };
 
 // pass 3: LDS image of one table slice.  Dynamic LDS: m*8 key words, then m*8 row ids.
-template <int NT>
+// Persistent workgroups (two per CU), slices q = blockIdx.x, + gridDim.x, ...: the rows of the NEXT slice are loaded
+// into registers before the current image is written out, so the only exposed latencies per slice are the LDS clear,
+// the inserts and two barriers.  (One workgroup per slice, launched 32 Ki times, ran at a third of the HBM rate: 21 us
+// per slice of launch -> count -> rows -> clear -> insert -> store, nothing overlapped; reading the bucket with wide LDS
+// loads instead of slot by slot changed nothing — the walk was never the bottleneck.)
+// Host guarantees cap2 <= NT * KPT.
+template <int NT, int KPT>
 __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     unsigned long long* s_keys = (unsigned long long*)s_dyn;
@@ -146,36 +152,57 @@ __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
     __shared__ unsigned long long s_handled;
     if (tid == 0) s_handled = 0;
     uint32_t placed = 0;  // rows this thread put into an image or the side list (the row list is counted by k_build_insert)
-    for (uint32_t q = blockIdx.x; q < Q; q += gridDim.x) {
-        for (uint32_t i = tid; i < nslots; i += NT) s_keys[i] = TSQ_EMPTY_KEY;
-        __syncthreads();
-        const uint32_t cnt = a.in.count[q];
+    uint64_t kw[KPT];
+    uint32_t row[KPT];
+    auto load_rows = [&](uint32_t q, uint32_t cnt) {
         const size_t src = (size_t)q * a.in.cap2;
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+            const uint32_t i = (uint32_t)j * NT + tid;
+            kw[j] = 0;
+            row[j] = 0xffffffffu;
+            if (i < cnt) {
+                kw[j] = a.in.keys[src + i];
+                row[j] = a.in.idx[src + i];
+            }
+        }
+    };
+    uint32_t q = blockIdx.x;
+    uint32_t cnt = q < Q ? a.in.count[q] : 0u;
+    if (q < Q) load_rows(q, cnt);
+    while (q < Q) {
+        const uint32_t qn = q + gridDim.x;
+        const uint32_t cnt_n = qn < Q ? a.in.count[qn] : 0u;
         const uint64_t b0 = (uint64_t)q * a.m;
-        for (uint32_t i = tid; i < cnt; i += NT) {
-            const uint64_t kw = a.in.keys[src + i];
-            const uint32_t row = a.in.idx[src + i];
-            if (kw == TSQ_EMPTY_KEY) {
+        {
+            ulonglong2* z = (ulonglong2*)s_keys;
+            for (uint32_t i = tid; i < nslots / 2; i += NT) z[i] = make_ulonglong2(TSQ_EMPTY_KEY, TSQ_EMPTY_KEY);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+            if (row[j] == 0xffffffffu) continue;
+            if (kw[j] == TSQ_EMPTY_KEY) {
                 const uint32_t o = atomicAdd(a.sent_total, 1u);
-                if (o < a.sent_cap) a.sent_rows[o] = row;
+                if (o < a.sent_cap) a.sent_rows[o] = row[j];
                 placed++;
                 continue;
             }
-            uint32_t lb = (uint32_t)(radix_bucket(tsq_mix64(kw), a.t.nbuckets) - b0);
+            uint32_t lb = (uint32_t)(radix_bucket(tsq_mix64(kw[j]), a.t.nbuckets) - b0);
             bool done = false;
             while (!done) {
                 if (lb >= a.m) {  // the chain runs past this slice: k_build_insert continues it in the next one
                     const uint32_t o = __hip_atomic_fetch_add(a.in.ovf_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (o < a.in.ovf_cap) a.in.ovf_rows[o] = row;
+                    if (o < a.in.ovf_cap) a.in.ovf_rows[o] = row[j];
                     break;
                 }
                 unsigned long long* b = s_keys + lb * TSQ_BUCKET;
 #pragma unroll 1
-                for (int s = 0; s < TSQ_BUCKET && !done; s++) {
+                for (int sl = 0; sl < TSQ_BUCKET && !done; sl++) {
                     // a stale EMPTY is harmless (the CAS decides); non-EMPTY never reverts
-                    if (__hip_atomic_load(&b[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == TSQ_EMPTY_KEY &&
-                        atomicCAS(&b[s], (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)kw) == TSQ_EMPTY_KEY) {
-                        s_vals[lb * TSQ_BUCKET + s] = row;
+                    if (__hip_atomic_load(&b[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == TSQ_EMPTY_KEY &&
+                        atomicCAS(&b[sl], (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)kw[j]) == TSQ_EMPTY_KEY) {
+                        s_vals[lb * TSQ_BUCKET + sl] = row[j];
                         done = true;
                         placed++;
                     }
@@ -184,6 +211,7 @@ __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
             }
         }
         __syncthreads();
+        if (qn < Q) load_rows(qn, cnt_n);  // in flight while the image is stored
         // slice image -> HBM, 16 bytes per lane (the slice starts on a 64-byte boundary: b0 * 64 B keys, b0 * 32 B row ids)
         {
             const ulonglong2* sk = (const ulonglong2*)s_keys;
@@ -194,6 +222,8 @@ __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
             for (uint32_t i = tid; i < nslots / 4; i += NT) dv[i] = sv[i];
         }
         __syncthreads();
+        q = qn;
+        cnt = cnt_n;
     }
     const uint64_t wsum = wave_sum_u64(placed);
     if ((tid & 63) == 0 && wsum) atomicAdd(&s_handled, (unsigned long long)wsum);

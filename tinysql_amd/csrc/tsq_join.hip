@@ -908,7 +908,7 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     uint32_t cap2 = (uint32_t)(lam2 * 1.08 + 8.0 * sqrt(lam2) + 64.0);
     cap2 = (cap2 + 15u) & ~15u;
     const size_t slots2 = (size_t)Q * cap2;
-    if (slots1 >= 0xffffffffULL || slots2 >= 0xffffffffULL) return TSQ_OK;
+    if (slots1 >= 0xffffffffULL || slots2 >= 0xffffffffULL || cap2 > 4096) return TSQ_OK;  // k_build_images<512, 8> holds a slice's rows in registers
     DevBuf k1, i1, ctl, vend, ok1, oi1, k2, i2, cnt2, orows;
     auto release_all = [&]() {
         for (DevBuf* b : {&k1, &i1, &ctl, &vend, &ok1, &oi1, &k2, &i2, &cnt2, &orows}) b->release();
@@ -969,7 +969,7 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     ia.inserted = (unsigned long long*)ctx->dscratch;
     const size_t img_bytes = (size_t)m * TSQ_BUCKET * 12;
     if (e == hipSuccess && img_bytes > 48 * 1024)
-        e = hipFuncSetAttribute((const void*)k_build_images<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
+        e = hipFuncSetAttribute((const void*)k_build_images<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
     if (e == hipSuccess) {
         const int64_t ntiles = (nb + T1 - 1) / T1;
         hipLaunchKernelGGL((k_radix_partition<NT, K1, 4, 0, true>), dim3((unsigned)std::min<int64_t>(ntiles, ctx->num_cus)), dim3(NT), 0, ctx->stream, src, st);
@@ -980,7 +980,7 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL((k_build_images<512>), dim3(Q), dim3(512), img_bytes, ctx->stream, ia);
+        hipLaunchKernelGGL((k_build_images<512, 8>), dim3(std::min<uint32_t>(Q, (uint32_t)ctx->num_cus * 2)), dim3(512), img_bytes, ctx->stream, ia);
         e = hipGetLastError();
     }
     j->st.kernel_launches += 3;
