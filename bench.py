@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--exchange-chunks", type=int, default=4, help="N>1: pieces of the probe-side exchange (probe of piece c overlaps the exchange of c+1..)")
     ap.add_argument("--build-rows", type=int, default=100_000_000)
     ap.add_argument("--probe-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,10 +134,14 @@ def main():
         from tinysql_amd import parallel
 
         def step():
-            (rpk,), n_local = parallel.redistribute(ctx, dist, torch, [pk_t], [abi.I64], 0, 0, npr)
-            pc = (abi.Col * 1)(dev_col(rpk.data_ptr(), n_local))
-            _lib.check(lib.tsq_join_probe_push(h, pc, 1, n_local, None), h)
-            return rpk  # keep alive until the stream has consumed it
+            # the probe of piece c runs while pieces c+1.. are still being exchanged (parallel.redistribute_pipelined)
+            # libtsq runs on torch's current stream, so a received tensor may be dropped as soon as its probe is queued:
+            # the caching allocator hands the block to later work of the same stream only (retaining every piece until the
+            # end of the timed region made each step allocate 1.6 GB of fresh device memory: 17 ms per step).
+            for (rpk,), n_local in parallel.redistribute_pipelined(ctx, dist, torch, [pk_t], [abi.I64], 0, 0, npr, args.exchange_chunks):
+                if n_local:
+                    pc = (abi.Col * 1)(dev_col(rpk.data_ptr(), n_local))
+                    _lib.check(lib.tsq_join_probe_push(h, pc, 1, n_local, None), h)
 
         def full_sync():
             torch.cuda.synchronize()

@@ -63,6 +63,30 @@ def main():
     dist.all_reduce(tot)
     assert tot.tolist() == [nb * world, npr * world]
 
+    # the pipelined exchange (bench.py's N>1 step) delivers the same multiset of rows in pieces; ranks own different row
+    # counts here (rank 1 holds 7 rows fewer)
+    def split_t(tensors, lo, hi, parts):
+        cols, counts = split([t[lo:hi].numpy() for t in tensors], 0, parts)
+        return [torch.from_numpy(np.ascontiguousarray(c)) for c in cols], counts
+
+    n_mine = npr - 7 * rank
+    got_k, got_v, pieces = [], [], 0
+    for (k, v), n in parallel.redistribute_pipelined(None, dist, torch, [torch.from_numpy(pk[:n_mine]), torch.from_numpy(pv[:n_mine])],
+                                                     [abi.I64, abi.I64], 0, 0, n_mine, 5, split=split_t):
+        assert len(k) == len(v) == n
+        got_k.append(k.numpy().copy())
+        got_v.append(v.numpy().copy())
+        pieces += 1
+    assert pieces == 5
+    gk, gv = np.concatenate(got_k), np.concatenate(got_v)
+    assert (np_rank(gk.view(np.uint64), world) == rank).all()
+    allp2 = [None] * world
+    dist.all_gather_object(allp2, (pk[:npr - 7 * rank], pv[:npr - 7 * rank]))
+    wk = np.concatenate([a[0] for a in allp2])
+    wv = np.concatenate([a[1] for a in allp2])
+    mine = np_rank(wk.view(np.uint64), world) == rank
+    assert sorted(zip(gk.tolist(), gv.tolist())) == sorted(zip(wk[mine].tolist(), wv[mine].tolist()))
+
     cfg = H.join_cfg([abi.I64] * 2, [abi.I64] * 2, [0], [0], abi.JOIN_INNER, 1)
     local = orc.hash_join(cfg, Chunk([Column(abi.I64, rbk), Column(abi.I64, rbv)]), Chunk([Column(abi.I64, rpk), Column(abi.I64, rpv)]))
     s, x = orc.rows_checksum(local)

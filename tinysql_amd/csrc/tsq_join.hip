@@ -948,7 +948,8 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     sub.b1 = b1;
     sub.b2 = b2;
     sub.cap2 = cap2;
-    hipError_t e = hipMemsetAsync(ctl.p, 0, ctl_bytes, ctx->stream);
+    hipError_t e = hipEventRecord(j->ev[0], ctx->stream);  // after the allocations: build_kernel_ms is kernel time
+    if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, ctl_bytes, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, nregions * 4, ctx->stream);
     RadixSrc src;
     memset(&src, 0, sizeof src);
@@ -1158,8 +1159,7 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
     j->sent_count = 0;
     bool part_done = false;
     if (nb > 0 && build_partitioned_eligible(j, nb)) {
-        TSQ_HIP(h, hipEventRecord(j->ev[0], ctx->stream));
-        TSQ_TRY(build_partitioned(j, nb, sent_cap, &part_done));  // sets j->nbuckets (a multiple of the slice count)
+        TSQ_TRY(build_partitioned(j, nb, sent_cap, &part_done));  // sets j->nbuckets (a multiple of the slice count); records ev[0]
         if (part_done) {
             TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
             j->have_build_ev = true;

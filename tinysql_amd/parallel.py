@@ -71,3 +71,50 @@ def redistribute(ctx, dist, torch, tensors, types, key_col, key_mode, nrows):
     recv_counts = exchange_counts(dist, torch, send_counts, tensors[0].device)
     got = exchange_runs(dist, torch, outs, send_counts, recv_counts)
     return got, sum(recv_counts)
+
+
+def redistribute_pipelined(ctx, dist, torch, tensors, types, key_col, key_mode, nrows, n_chunks=4, split=None):
+    """redistribute() in n_chunks pieces, as a generator of (received tensors, n_received): the rows are split chunk by
+    chunk, ONE count exchange covers all chunks, all data exchanges are issued asynchronously back to back, and piece c
+    is handed to the caller as soon as its exchange has completed — the single-GPU operator consumes piece c while pieces
+    c+1.. are still on the wire (xGMI moves 8 B/row at a fraction of what the probe kernel consumes, so the wire is the
+    longer leg; only the last piece's probe is exposed).  The union of the pieces is the same multiset of rows that
+    redistribute() returns.  `split(cols_as_tensors, lo, hi, n_parts) -> (out tensors, counts)` replaces the GPU split
+    in the CPU (gloo) test-suite."""
+    w = dist.get_world_size()
+    n_chunks = max(1, int(n_chunks))  # every rank must use the same value: the count exchange carries w * n_chunks words
+    bounds = [((nrows * c // n_chunks) + 7) & ~7 for c in range(n_chunks)] + [nrows]
+    bounds = [min(b, nrows) for b in bounds]
+    pieces, counts = [], []
+    for c in range(n_chunks):
+        lo, hi = bounds[c], bounds[c + 1]
+        if split is not None:
+            outs, cnt = split(tensors, lo, hi, w)
+        else:
+            outs = [torch.empty(max(hi - lo, 1), dtype=t.dtype, device=t.device)[: hi - lo] for t in tensors]
+            cols = [dev_col_from_tensor(t[lo:hi], tp, hi - lo) for t, tp in zip(tensors, types)]
+            ocols = [dev_col_from_tensor(t, tp, hi - lo) for t, tp in zip(outs, types)]
+            cnt = radix_split(ctx, cols, key_col, key_mode, hi - lo, w, ocols) if hi > lo else [0] * w
+        pieces.append(outs)
+        counts.append(cnt)
+    # one exchange for all counts: send[p * n_chunks + c] = rows of chunk c that go to rank p
+    dev = tensors[0].device
+    send = torch.tensor([counts[c][p] for p in range(w) for c in range(n_chunks)], dtype=torch.int64, device=dev)
+    recv = torch.empty(w * n_chunks, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, send)
+    recv = recv.tolist()
+    inflight = []
+    for c in range(n_chunks):
+        rc = [int(recv[s * n_chunks + c]) for s in range(w)]
+        total = sum(rc)
+        got, works = [], []
+        for t in pieces[c]:
+            r = torch.empty(max(total, 1), dtype=t.dtype, device=t.device)[:total]
+            works.append(dist.all_to_all_single(r, t[: sum(counts[c])], rc, list(counts[c]), async_op=True))
+            got.append(r)
+        inflight.append((got, total, works))
+    for got, total, works in inflight:
+        for wk in works:
+            wk.wait()  # nccl: the current stream waits for the exchange; gloo: the host does
+        yield got, total
+    del pieces  # send buffers stay alive until every exchange has been waited for
