@@ -404,9 +404,10 @@ typedef struct tsq_stats {
     double  radix_probe_kernel_ms_sum;
     int64_t radix_timed_batches;
     int64_t radix_batches;         /* join: probe batches through the radix path; agg: batches pre-aggregated in LDS */
-    int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew): last probe batch + the partitioned build */
+    int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew) in the last batch */
     int32_t radix_bits;            /* log2(partitions) of the last radix batch */
     int32_t build_partitioned;     /* 1: the table was assembled slice by slice in LDS (tsq_buildpart.h), 0: row-at-a-time CAS build */
+    int64_t build_handed_back_rows; /* partitioned build: rows inserted row by row afterwards (skewed regions, chains crossing a slice end) */
 } tsq_stats;
 tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out);
 tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out);

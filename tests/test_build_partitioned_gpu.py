@@ -99,7 +99,7 @@ def test_partitioned_build_skewed_keys_use_the_row_list(ctx):
     c, s, x = _join(ctx, cfg, build, probe, abi.RADIX_FORCE, stats=stats, count_only=True, checksum=True)
     n7 = nb - nb // 10
     assert c == 2 * n7 + 2
-    assert stats[0].build_partitioned == 1 and stats[0].radix_overflow_rows > 0 and stats[0].build_rows_inserted == nb
+    assert stats[0].build_partitioned == 1 and stats[0].build_handed_back_rows > 0 and stats[0].build_rows_inserted == nb
     assert _join(ctx, cfg, build, probe, abi.RADIX_OFF, count_only=True, checksum=True) == (c, s, x)
     got = _join(ctx, cfg, build, Chunk([Column(abi.I64, np.array([7], dtype=np.int64)), Column(abi.I64, np.zeros(1, np.int64))]), abi.RADIX_FORCE)
     assert got.NumRows() == n7 and sorted(got.columns[3].data.tolist()) == sorted(np.nonzero(bk == 7)[0].tolist())

@@ -114,7 +114,7 @@ class Stats(C.Structure):
         ("d2h_bytes", C.c_int64), ("kernel_launches", C.c_int64),
         ("partition_kernel_ms", C.c_double), ("radix_probe_kernel_ms", C.c_double), ("partition_kernel_ms_sum", C.c_double),
         ("radix_probe_kernel_ms_sum", C.c_double), ("radix_timed_batches", C.c_int64), ("radix_batches", C.c_int64), ("radix_overflow_rows", C.c_int64),
-        ("radix_bits", C.c_int32), ("build_partitioned", C.c_int32),
+        ("radix_bits", C.c_int32), ("build_partitioned", C.c_int32), ("build_handed_back_rows", C.c_int64),
     ]
 
 

@@ -1404,7 +1404,8 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
     if (j->have_build_ev && hipEventElapsedTime(&ms, j->ev[0], j->ev[1]) == hipSuccess) j->st.build_kernel_ms = ms;
     if (j->have_probe_ev && hipEventElapsedTime(&ms, j->ev[2], j->ev[3]) == hipSuccess) j->st.probe_kernel_ms = ms;
     j->st.partition_kernel_ms = 0;
-    j->st.radix_overflow_rows = j->build_handed_back;
+    j->st.radix_overflow_rows = 0;
+    j->st.build_handed_back_rows = j->build_handed_back;
     j->st.radix_probe_kernel_ms = j->st.partition_kernel_ms_sum = j->st.radix_probe_kernel_ms_sum = 0;
     j->st.radix_timed_batches = 0;
     if (j->st.radix_batches > 0 && j->rctl.p) {
@@ -1421,7 +1422,7 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
         }
         uint32_t ovf = 0;  // overflow count of the last radix batch sits behind the cursors
         const size_t nregions = ((size_t)1 << j->st.radix_bits) * 8;
-        if (hipMemcpy(&ovf, j->rctl.as<uint32_t>() + nregions, 4, hipMemcpyDeviceToHost) == hipSuccess) j->st.radix_overflow_rows += ovf;
+        if (hipMemcpy(&ovf, j->rctl.as<uint32_t>() + nregions, 4, hipMemcpyDeviceToHost) == hipSuccess) j->st.radix_overflow_rows = ovf;
     }
     *out = j->st;
     return TSQ_OK;

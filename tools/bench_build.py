@@ -41,7 +41,7 @@ def one(ctx, n, radix):
             finally:
                 lib.tsq_join_destroy(h)
         return {"rows": n, "partitioned": int(st.build_partitioned), "build_finish_ms": best_wall * 1e3, "build_kernels_ms": best_ev,
-                "rows_per_s": n / (best_ev * 1e-3), "table_bytes": int(st.table_bytes), "handed_back_rows": int(st.radix_overflow_rows),
+                "rows_per_s": n / (best_ev * 1e-3), "table_bytes": int(st.table_bytes), "handed_back_rows": int(st.build_handed_back_rows),
                 "roofline_frac_32B_per_row": 32.0 * n / (best_ev * 1e-3) / 8e12}
     finally:
         bk.free()
