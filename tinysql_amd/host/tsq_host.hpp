@@ -1,0 +1,611 @@
+// tsq_host.hpp — the host side ABOVE the C-ABI, in C++: what the cgo shim in package `executor` does in Go
+// (INTEGRATION.md), written against the same volcano contract so that tests read like the reference's own.
+//
+// The reference is Go and this image has no Go toolchain, so the host side that a TinySQL maintainer would write as
+//   type GPUHashJoinExec struct{ baseExecutor; ... }   (executor/join.go:31-60 shape)
+// is given here as header-only C++ over include/tsq.h.  Names, argument meaning and error behaviour follow the
+// reference:
+//   Column / Chunk      util/chunk/column.go:28-34, chunk.go:31-46   (fixed-width columns; bit 1 = NOT NULL)
+//   Executor            executor/executor.go:146-162                 (Open / Next(req) / Close; empty req = EOS)
+//   MockDataSource      executor/benchmark_test.go:50-177
+//   HashJoinExec        executor/join.go:110-146                     (left-child cols || right-child cols)
+//   HashAggExec         executor/aggregate.go:559-588
+//   SelectionExec       executor/executor.go:346-438
+//   ProjectionExec      executor/projection.go:54-90, expression/evaluator.go:121-133
+//   Expression          expression/{column,constant,scalar_function}.go, lowered to tsq_expr_prog postfix
+// All compute happens in libtsq (HIP); nothing here touches the oracle and there is no CPU fallback: without a
+// device tsq_ctx_create fails and every constructor throws.
+#ifndef TSQ_HOST_HPP
+#define TSQ_HOST_HPP
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tsq.h"
+
+namespace tsqhost {
+
+// ---------------------------------------------------------------- errors (terror values of the reference)
+struct Error : std::runtime_error {
+    tsq_status code;
+    Error(tsq_status c, const std::string& m) : std::runtime_error(m), code(c) {}
+    // types.ErrOverflow (types/overflow.go:33-40, builtin_arithmetic_vec.go:51)
+    bool IsOverflow() const { return code == TSQ_ERR_OVERFLOW_BIGINT || code == TSQ_ERR_OVERFLOW_BIGINT_UNSIGNED || code == TSQ_ERR_OVERFLOW_DOUBLE; }
+    bool IsUnsupported() const { return code == TSQ_ERR_UNSUPPORTED; }  // plan not eligible: run the Go operator
+};
+inline void check(tsq_status s, const void* handle) {
+    if (s == TSQ_OK) return;
+    const char* m = tsq_last_error(handle);
+    throw Error(s, std::string(m && *m ? m : "libtsq error") + " (status " + std::to_string((int)s) + ")");
+}
+
+// ---------------------------------------------------------------- util/chunk
+class Column {  // util/chunk/column.go:28-34, fixed-width element types only
+public:
+    int32_t type = TSQ_I64;
+    int64_t length = 0;
+    std::vector<uint8_t> nullBitmap;  // bit = 1 => NOT NULL, LSB first (column.go:89-92)
+    std::vector<uint8_t> data;
+
+    explicit Column(int32_t tp = TSQ_I64) : type(tp) {}
+    int elemSize() const { return type == TSQ_F32 ? 4 : 8; }
+    void Reset() { length = 0; nullBitmap.clear(); data.clear(); }
+    bool IsNull(int64_t i) const { return ((nullBitmap[i >> 3] >> (i & 7)) & 1) == 0; }
+    void appendNullBit(bool notNull) {  // column.go:113-127
+        if ((length & 7) == 0) nullBitmap.push_back(0);
+        if (notNull) nullBitmap[length >> 3] |= (uint8_t)(1u << (length & 7));
+    }
+    void appendRaw(const void* p, bool notNull) {
+        appendNullBit(notNull);
+        const size_t off = data.size();
+        data.resize(off + elemSize());
+        if (notNull) memcpy(&data[off], p, elemSize());  // a NULL slot holds zero bytes (column.go:150-158)
+        length++;
+    }
+    void AppendInt64(int64_t v) { appendRaw(&v, true); }
+    void AppendUint64(uint64_t v) { appendRaw(&v, true); }
+    void AppendFloat64(double v) { appendRaw(&v, true); }
+    void AppendFloat32(float v) { appendRaw(&v, true); }
+    void AppendNull() { uint64_t z = 0; appendRaw(&z, false); }
+    int64_t GetInt64(int64_t i) const { int64_t v; memcpy(&v, &data[i * 8], 8); return v; }
+    uint64_t GetUint64(int64_t i) const { uint64_t v; memcpy(&v, &data[i * 8], 8); return v; }
+    double GetFloat64(int64_t i) const { double v; memcpy(&v, &data[i * 8], 8); return v; }
+    float GetFloat32(int64_t i) const { float v; memcpy(&v, &data[i * 4], 4); return v; }
+    // prepare for being filled with up to n rows by libtsq
+    void resizeFor(int64_t n) {
+        data.assign((size_t)n * elemSize(), 0);
+        nullBitmap.assign((size_t)(n + 7) / 8, 0);
+        length = 0;
+    }
+    tsq_col View(int64_t rows) {
+        tsq_col c;
+        memset(&c, 0, sizeof c);
+        c.data = data.data();
+        c.null_bitmap = nullBitmap.data();
+        c.length = rows;
+        c.elem_size = elemSize();
+        c.type = type;
+        return c;
+    }
+    void truncate(int64_t n) {
+        length = n;
+        data.resize((size_t)n * elemSize());
+        nullBitmap.resize((size_t)(n + 7) / 8);
+    }
+};
+
+using Schema = std::vector<int32_t>;  // column types (expression.Schema carries more; only types matter on this path)
+
+class Chunk {  // util/chunk/chunk.go:31-46
+public:
+    std::vector<Column> columns;
+    int requiredRows = 1024;  // tidb_max_chunk_size (tidb_vars.go:242)
+    Chunk() {}
+    explicit Chunk(const Schema& s, int maxChunkSize = 1024) : requiredRows(maxChunkSize) {
+        for (int32_t t : s) columns.emplace_back(t);
+    }
+    int64_t NumRows() const { return columns.empty() ? 0 : columns[0].length; }  // chunk.go:308-316
+    int NumCols() const { return (int)columns.size(); }
+    void Reset() { for (auto& c : columns) c.Reset(); }                           // chunk.go:245-254
+    void SwapColumns(Chunk& other) { columns.swap(other.columns); }               // chunk.go:231-235
+    bool IsFull() const { return NumRows() >= requiredRows; }                     // chunk.go:165-167
+    Schema schema() const { Schema s; for (auto& c : columns) s.push_back(c.type); return s; }
+    std::vector<tsq_col> Views() {
+        std::vector<tsq_col> v;
+        for (auto& c : columns) v.push_back(c.View(c.length));
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------- context
+class Context {
+public:
+    tsq_ctx* h = nullptr;
+    explicit Context(int device = 0) { check(tsq_ctx_create(device, &h), nullptr); }
+    ~Context() { if (h) tsq_ctx_destroy(h); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+};
+
+// ---------------------------------------------------------------- package executor
+class Executor {  // executor/executor.go:146-152
+public:
+    virtual ~Executor() {}
+    virtual void Open() { for (auto* c : children_) c->Open(); }      // baseExecutor.Open (executor.go:71-79)
+    // Fills req with at most req->requiredRows rows; an EMPTY req means end of stream and Next stays idempotent
+    // after it (executor.go:145 NOTE, server/conn.go:955-957).
+    virtual void Next(Chunk* req) = 0;
+    virtual void Close() { for (auto* c : children_) c->Close(); }
+    const Schema& schema() const { return schema_; }
+    int maxChunkSize = 1024;
+protected:
+    Executor(Context* ctx, Schema s, std::vector<Executor*> children) : ctx_(ctx), schema_(std::move(s)), children_(std::move(children)) {}
+    Context* ctx_;
+    Schema schema_;
+    std::vector<Executor*> children_;
+};
+
+// recordSet + writeChunks (executor/adapter.go:93-119, server/conn.go:931-975)
+inline std::vector<Chunk> Drain(Executor* e) {
+    std::vector<Chunk> out;
+    e->Open();
+    try {
+        for (;;) {
+            Chunk req(e->schema(), e->maxChunkSize);
+            e->Next(&req);
+            if (req.NumRows() == 0) break;
+            out.push_back(std::move(req));
+        }
+    } catch (...) {
+        e->Close();
+        throw;
+    }
+    e->Close();
+    return out;
+}
+
+class MockDataSource : public Executor {  // executor/benchmark_test.go:50-144
+public:
+    MockDataSource(Context* ctx, Chunk table, int maxChunk = 1024) : Executor(ctx, table.schema(), {}), table_(std::move(table)) { maxChunkSize = maxChunk; }
+    void Open() override { pos_ = 0; }
+    void Next(Chunk* req) override {
+        req->Reset();
+        const int64_t n = table_.NumRows();
+        const int64_t hi = std::min<int64_t>(n, pos_ + std::min(req->requiredRows, maxChunkSize));
+        for (int64_t r = pos_; r < hi; r++)
+            for (int c = 0; c < table_.NumCols(); c++) {
+                const Column& src = table_.columns[c];
+                if (src.IsNull(r)) req->columns[c].AppendNull();
+                else req->columns[c].appendRaw(&src.data[(size_t)r * src.elemSize()], true);
+            }
+        pos_ = hi;
+    }
+private:
+    Chunk table_;
+    int64_t pos_ = 0;
+};
+
+// ---------------------------------------------------------------- package expression (tree -> postfix bytecode)
+enum EvalType { ETInt, ETReal };
+struct Expression {  // expression.Expression (expression.go:57-114), the vectorizable subset
+    enum Kind { COLUMN, CONSTANT, FUNC } kind = COLUMN;
+    EvalType evalType = ETInt;
+    bool isUnsigned = false;
+    int index = 0;             // COLUMN
+    bool isNull = false;       // CONSTANT NULL
+    int64_t bits = 0;          // CONSTANT: int64 or the bit pattern of a double
+    std::string name;          // FUNC (ast.* function names, lower case)
+    std::vector<Expression> args;
+};
+inline Expression Col(int index, int32_t type) {  // expression.Column (column.go:56-130)
+    Expression e;
+    e.kind = Expression::COLUMN;
+    e.index = index;
+    e.evalType = (type == TSQ_F32 || type == TSQ_F64) ? ETReal : ETInt;
+    e.isUnsigned = type == TSQ_U64;
+    return e;
+}
+inline Expression Int(int64_t v) { Expression e; e.kind = Expression::CONSTANT; e.bits = v; return e; }
+inline Expression Real(double v) { Expression e; e.kind = Expression::CONSTANT; e.evalType = ETReal; memcpy(&e.bits, &v, 8); return e; }
+inline Expression Null(EvalType t) { Expression e; e.kind = Expression::CONSTANT; e.evalType = t; e.isNull = true; return e; }
+// expression.NewFunction: result type inference of builtin_arithmetic.go:112-133,216-237,330-355,435-444,
+// builtin_compare.go:60-110 for same-class arguments (TinySQL has no CAST: mixed classes are not vectorizable here)
+inline Expression Func(const std::string& name, std::vector<Expression> args) {
+    Expression e;
+    e.kind = Expression::FUNC;
+    e.name = name;
+    e.args = std::move(args);
+    auto& a = e.args;
+    auto same = [&](size_t from) { for (size_t i = from + 1; i < a.size(); i++) if (a[i].evalType != a[from].evalType) return false; return true; };
+    static const char* cmp[] = {"lt", "le", "gt", "ge", "eq", "ne"};
+    bool isCmp = false;
+    for (auto* c : cmp) isCmp |= name == c;
+    if (name == "plus" || name == "minus" || name == "mul") {
+        if (a.size() != 2 || !same(0)) throw Error(TSQ_ERR_UNSUPPORTED, "mixed int/real arithmetic needs an implicit conversion");
+        e.evalType = a[0].evalType;
+        e.isUnsigned = e.evalType == ETInt && (a[0].isUnsigned || a[1].isUnsigned);
+    } else if (name == "div") {
+        if (a.size() != 2 || a[0].evalType != ETReal || a[1].evalType != ETReal) throw Error(TSQ_ERR_UNSUPPORTED, "DIV of non-real arguments");
+        e.evalType = ETReal;
+    } else if (isCmp) {
+        if (a.size() != 2 || !same(0)) throw Error(TSQ_ERR_UNSUPPORTED, "mixed int/real comparison needs an implicit conversion");
+    } else if (name == "and" || name == "or") {
+        if (a.size() != 2 || a[0].evalType != ETInt || a[1].evalType != ETInt) throw Error(TSQ_ERR_UNSUPPORTED, "logic operator over non-int arguments");
+    } else if (name == "not" || name == "isnull") {
+        if (a.size() != 1) throw Error(TSQ_ERR_INVALID, "arity");
+    } else if (name == "unaryminus") {
+        if (a.size() != 1) throw Error(TSQ_ERR_INVALID, "arity");
+        e.evalType = a[0].evalType;
+    } else if (name == "ifnull") {
+        if (a.size() != 2 || !same(0)) throw Error(TSQ_ERR_UNSUPPORTED, "IFNULL of mixed types");
+        e.evalType = a[0].evalType;
+        e.isUnsigned = a[0].isUnsigned && a[1].isUnsigned;
+    } else if (name == "if") {
+        if (a.size() != 3 || a[0].evalType != ETInt || a[1].evalType != a[2].evalType) throw Error(TSQ_ERR_UNSUPPORTED, "IF needs an int condition and same-typed branches");
+        e.evalType = a[1].evalType;
+        e.isUnsigned = a[1].isUnsigned && a[2].isUnsigned;
+    } else if (name == "in") {
+        if (a.size() < 2 || a.size() > 32 || !same(0)) throw Error(TSQ_ERR_UNSUPPORTED, "IN list");
+    } else {
+        throw Error(TSQ_ERR_UNSUPPORTED, "function " + name + " has no GPU signature");
+    }
+    return e;
+}
+inline void emit(const Expression& e, tsq_expr_prog& p) {
+    auto push = [&](int opcode, int flags, int arg, uint32_t aux) {
+        if (p.n_ops >= TSQ_EXPR_MAX_OPS) throw Error(TSQ_ERR_UNSUPPORTED, "expression too large for the GPU interpreter");
+        tsq_expr_op& o = p.ops[p.n_ops++];
+        o.opcode = (uint8_t)opcode;
+        o.flags = (uint8_t)flags;
+        o.arg = (uint16_t)arg;
+        o.aux = aux;
+    };
+    const bool real = e.evalType == ETReal;
+    if (e.kind == Expression::COLUMN) { push(real ? TSQ_OP_COL_REAL : TSQ_OP_COL_INT, 0, e.index, 0); return; }
+    if (e.kind == Expression::CONSTANT) {
+        if (e.isNull) { push(real ? TSQ_OP_CONST_NULL_REAL : TSQ_OP_CONST_NULL_INT, 0, 0, 0); return; }
+        if (p.n_consts >= TSQ_EXPR_MAX_CONSTS) throw Error(TSQ_ERR_UNSUPPORTED, "too many constants");
+        p.consts[p.n_consts] = e.bits;
+        push(real ? TSQ_OP_CONST_REAL : TSQ_OP_CONST_INT, 0, p.n_consts++, 0);
+        return;
+    }
+    for (auto& x : e.args) emit(x, p);
+    const auto& a = e.args;
+    const bool areal = a[0].evalType == ETReal;
+    int flags = 0;
+    if (a.size() >= 1 && a[0].isUnsigned) flags |= TSQ_F_LHS_UNSIGNED;
+    if (a.size() >= 2 && a[1].isUnsigned) flags |= TSQ_F_RHS_UNSIGNED;
+    const std::string& n = e.name;
+    static const char* cmp[] = {"lt", "le", "gt", "ge", "eq", "ne"};
+    for (int i = 0; i < 6; i++)
+        if (n == cmp[i]) { push((areal ? TSQ_OP_LT_REAL : TSQ_OP_LT_INT) + i, flags, 0, 0); return; }
+    if (n == "plus") push(areal ? TSQ_OP_PLUS_REAL : TSQ_OP_PLUS_INT, flags, 0, 0);
+    else if (n == "minus") push(areal ? TSQ_OP_MINUS_REAL : TSQ_OP_MINUS_INT, flags, 0, 0);
+    else if (n == "mul") push(areal ? TSQ_OP_MUL_REAL : ((a[0].isUnsigned || a[1].isUnsigned) ? TSQ_OP_MUL_INT_UNSIGNED : TSQ_OP_MUL_INT), areal ? 0 : flags, 0, 0);
+    else if (n == "div") push(TSQ_OP_DIV_REAL, 0, 0, 0);
+    else if (n == "and") push(TSQ_OP_LOGIC_AND, 0, 0, 0);
+    else if (n == "or") push(TSQ_OP_LOGIC_OR, 0, 0, 0);
+    else if (n == "not") push(areal ? TSQ_OP_NOT_REAL : TSQ_OP_NOT_INT, 0, 0, 0);
+    else if (n == "unaryminus") push(areal ? TSQ_OP_NEG_REAL : TSQ_OP_NEG_INT, flags, 0, 0);
+    else if (n == "isnull") push(areal ? TSQ_OP_ISNULL_REAL : TSQ_OP_ISNULL_INT, 0, 0, 0);
+    else if (n == "ifnull") push(areal ? TSQ_OP_IFNULL_REAL : TSQ_OP_IFNULL_INT, 0, 0, 0);
+    else if (n == "if") push(a[1].evalType == ETReal ? TSQ_OP_IF_REAL : TSQ_OP_IF_INT, 0, 0, 0);
+    else if (n == "in") {
+        uint32_t aux = 0;
+        for (size_t j = 1; j < a.size(); j++) if (a[j].isUnsigned) aux |= 1u << (j - 1);
+        push(areal ? TSQ_OP_IN_REAL : TSQ_OP_IN_INT, flags & TSQ_F_LHS_UNSIGNED, (int)a.size() - 1, aux);
+    }
+}
+inline tsq_expr_prog Lower(const Expression& e) {
+    tsq_expr_prog p;
+    memset(&p, 0, sizeof p);
+    emit(e, p);
+    p.result_type = e.evalType == ETReal ? TSQ_F64 : TSQ_I64;
+    p.result_unsigned = e.isUnsigned ? 1 : 0;
+    return p;
+}
+inline std::vector<tsq_expr_prog> LowerList(const std::vector<Expression>& es) {
+    std::vector<tsq_expr_prog> v;
+    for (auto& e : es) v.push_back(Lower(e));
+    return v;
+}
+
+class CompiledExpr {  // a tsq_expr handle: one projection expression or one CNF filter list
+public:
+    tsq_expr* h = nullptr;
+    int64_t divisionByZeroWarnings = 0;  // handleDivisionByZeroError (expression/errors.go:65-77)
+    CompiledExpr(Context* ctx, const std::vector<Expression>& es) {
+        auto progs = LowerList(es);
+        check(tsq_expr_compile(ctx->h, progs.data(), (int32_t)progs.size(), &h), ctx->h);
+    }
+    ~CompiledExpr() { if (h) tsq_expr_destroy(h); }
+    CompiledExpr(const CompiledExpr&) = delete;
+    CompiledExpr& operator=(const CompiledExpr&) = delete;
+};
+
+// ---------------------------------------------------------------- SelectionExec (executor/executor.go:346-438)
+class SelectionExec : public Executor {
+public:
+    SelectionExec(Context* ctx, Executor* child, std::vector<Expression> filters)
+        : Executor(ctx, child->schema(), {child}), filters_(std::move(filters)) {}
+    void Open() override {
+        Executor::Open();
+        expr_.reset(new CompiledExpr(ctx_, filters_));
+        child_.reset(new Chunk(schema_, maxChunkSize));
+        cursor_ = 0;
+        selected_.clear();
+    }
+    void Next(Chunk* req) override {  // executor.go:393-438: copy selected rows of the child chunk until req is full
+        req->Reset();
+        for (;;) {
+            for (; cursor_ < (int64_t)selected_.size(); cursor_++) {
+                if (!selected_[cursor_]) continue;
+                if (req->IsFull()) return;
+                for (int c = 0; c < req->NumCols(); c++) {
+                    const Column& src = child_->columns[c];
+                    if (src.IsNull(cursor_)) req->columns[c].AppendNull();
+                    else req->columns[c].appendRaw(&src.data[(size_t)cursor_ * src.elemSize()], true);
+                }
+            }
+            children_[0]->Next(child_.get());
+            const int64_t n = child_->NumRows();
+            if (n == 0) return;
+            selected_.assign((size_t)n, 0);
+            auto in = child_->Views();
+            int64_t w = 0;
+            check(tsq_filter_eval(expr_->h, in.data(), (int32_t)in.size(), n, nullptr, selected_.data(), nullptr, &w), expr_->h);
+            expr_->divisionByZeroWarnings += w;
+            cursor_ = 0;
+        }
+    }
+    void Close() override { expr_.reset(); Executor::Close(); }
+private:
+    std::vector<Expression> filters_;
+    std::unique_ptr<CompiledExpr> expr_;
+    std::unique_ptr<Chunk> child_;
+    std::vector<uint8_t> selected_;
+    int64_t cursor_ = 0;
+};
+
+// ---------------------------------------------------------------- ProjectionExec (executor/projection.go:54-90)
+class ProjectionExec : public Executor {
+public:
+    ProjectionExec(Context* ctx, Executor* child, std::vector<Expression> exprs) : Executor(ctx, types(exprs), {child}), exprs_(std::move(exprs)) {}
+    void Open() override {
+        Executor::Open();
+        compiled_.clear();
+        for (auto& e : exprs_) compiled_.emplace_back(new CompiledExpr(ctx_, {e}));
+        child_.reset(new Chunk(children_[0]->schema(), maxChunkSize));
+    }
+    void Next(Chunk* req) override {  // EvaluatorSuite.Run (evaluator.go:121-133): one VecEval per output column
+        req->Reset();
+        children_[0]->Next(child_.get());
+        const int64_t n = child_->NumRows();
+        if (n == 0) return;
+        auto in = child_->Views();
+        for (size_t i = 0; i < compiled_.size(); i++) {
+            Column& dst = req->columns[i];
+            dst.resizeFor(n);
+            tsq_col out = dst.View(n);
+            out.type = dst.type == TSQ_F64 ? TSQ_F64 : TSQ_I64;
+            int64_t w = 0;
+            check(tsq_expr_eval(compiled_[i]->h, in.data(), (int32_t)in.size(), n, nullptr, &out, &w), compiled_[i]->h);
+            compiled_[i]->divisionByZeroWarnings += w;
+            dst.length = n;
+        }
+    }
+    void Close() override { compiled_.clear(); Executor::Close(); }
+    int64_t DivisionByZeroWarnings() const { int64_t w = 0; for (auto& c : compiled_) w += c->divisionByZeroWarnings; return w; }
+private:
+    static Schema types(const std::vector<Expression>& es) {
+        Schema s;
+        for (auto& e : es) s.push_back(e.evalType == ETReal ? TSQ_F64 : (e.isUnsigned ? TSQ_U64 : TSQ_I64));
+        return s;
+    }
+    std::vector<Expression> exprs_;
+    std::vector<std::unique_ptr<CompiledExpr>> compiled_;
+    std::unique_ptr<Chunk> child_;
+};
+
+// ---------------------------------------------------------------- HashJoinExec (executor/join.go:31-146)
+enum JoinType { InnerJoin = TSQ_JOIN_INNER, LeftOuterJoin = TSQ_JOIN_LEFT_OUTER, RightOuterJoin = TSQ_JOIN_RIGHT_OUTER };
+class HashJoinExec : public Executor {
+public:
+    // children: left, right.  innerChildIdx picks the build side (planner/core/physical_plans.go:201-224).
+    HashJoinExec(Context* ctx, Executor* left, Executor* right, std::vector<int> leftKeys, std::vector<int> rightKeys, JoinType jt, int innerChildIdx,
+                 std::vector<Expression> otherConditions = {}, std::vector<Expression> outerFilter = {})
+        : Executor(ctx, concat(left->schema(), right->schema()), {left, right}), other_(LowerList(otherConditions)), filter_(LowerList(outerFilter)) {
+        memset(&cfg_, 0, sizeof cfg_);
+        buildIsRight_ = innerChildIdx == 1;
+        build_ = buildIsRight_ ? right : left;
+        probe_ = buildIsRight_ ? left : right;
+        const auto& bk = buildIsRight_ ? rightKeys : leftKeys;
+        const auto& pk = buildIsRight_ ? leftKeys : rightKeys;
+        if (bk.size() != pk.size() || bk.empty() || bk.size() > TSQ_MAX_KEYS) throw Error(TSQ_ERR_UNSUPPORTED, "1..4 join key columns supported");
+        cfg_.join_type = jt;
+        cfg_.build_is_right = buildIsRight_ ? 1 : 0;
+        cfg_.n_keys = (int32_t)bk.size();
+        for (size_t i = 0; i < bk.size(); i++) { cfg_.build_key_idx[i] = bk[i]; cfg_.probe_key_idx[i] = pk[i]; }
+        cfg_.n_build_cols = (int32_t)build_->schema().size();
+        cfg_.n_probe_cols = (int32_t)probe_->schema().size();
+        for (int i = 0; i < cfg_.n_build_cols; i++) cfg_.build_types[i] = build_->schema()[i];
+        for (int i = 0; i < cfg_.n_probe_cols; i++) cfg_.probe_types[i] = probe_->schema()[i];
+        cfg_.max_chunk_size = 1024;
+        cfg_.concurrency = 5;  // tidb_hash_join_concurrency default (tidb_vars.go:249); unused on the GPU
+    }
+    ~HashJoinExec() override { destroy(); }
+    void Open() override {
+        Executor::Open();
+        cfg_.other_conds = other_.empty() ? nullptr : other_.data();
+        cfg_.n_other_conds = (int32_t)other_.size();
+        cfg_.outer_filters = filter_.empty() ? nullptr : filter_.data();
+        cfg_.n_outer_filters = (int32_t)filter_.size();
+        check(tsq_join_create(ctx_->h, &cfg_, &h_), ctx_->h);
+        prepared_ = false;
+        probeDone_ = false;
+    }
+    void Next(Chunk* req) override {  // join.go:125-146
+        req->Reset();
+        if (!prepared_) {  // fetchAndBuildHashTable (join.go:148-158)
+            Chunk chk(build_->schema(), maxChunkSize);
+            for (;;) {
+                build_->Next(&chk);
+                if (chk.NumRows() == 0) break;
+                auto v = chk.Views();
+                check(tsq_join_build_push(h_, v.data(), (int32_t)v.size(), chk.NumRows()), h_);
+            }
+            check(tsq_join_build_finish(h_), h_);
+            prepared_ = true;
+        }
+        const int64_t cap = req->requiredRows;
+        Chunk probeChk(probe_->schema(), maxChunkSize);
+        for (;;) {
+            for (auto& c : req->columns) c.resizeFor(cap);
+            std::vector<tsq_col> out;
+            for (auto& c : req->columns) out.push_back(c.View(cap));
+            int64_t n = 0;
+            int32_t eos = 0;
+            check(tsq_join_pull(h_, out.data(), (int32_t)out.size(), cap, &n, &eos), h_);
+            if (n > 0) { for (auto& c : req->columns) c.truncate(n); return; }
+            if (eos) { for (auto& c : req->columns) c.truncate(0); return; }
+            if (probeDone_) continue;
+            probe_->Next(&probeChk);  // fetchOuterSideChunks (join.go:160-231)
+            if (probeChk.NumRows() == 0) {
+                check(tsq_join_probe_finish(h_), h_);
+                probeDone_ = true;
+                continue;
+            }
+            auto v = probeChk.Views();
+            check(tsq_join_probe_push(h_, v.data(), (int32_t)v.size(), probeChk.NumRows(), nullptr), h_);
+        }
+    }
+    // Close may race with Next on another thread (join_test.go:172-182, TestJoinLeak): cancel first.
+    void Close() override { destroy(); Executor::Close(); }
+    void Cancel() { if (h_) tsq_join_cancel(h_); }
+private:
+    static Schema concat(Schema a, const Schema& b) { a.insert(a.end(), b.begin(), b.end()); return a; }
+    void destroy() {
+        if (h_) { tsq_join_cancel(h_); tsq_join_destroy(h_); h_ = nullptr; }
+    }
+    tsq_join_cfg cfg_;
+    std::vector<tsq_expr_prog> other_, filter_;
+    Executor *build_, *probe_;
+    bool buildIsRight_ = true, prepared_ = false, probeDone_ = false;
+    tsq_join* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- HashAggExec (executor/aggregate.go:134-588)
+struct AggFuncDesc {  // expression/aggregation/descriptor.go:56-91
+    int32_t func;     // TSQ_AGG_*
+    int32_t argCol;   // -1: constant argument (COUNT(*) arrives as count(1), parser.y:3258-3262)
+    int32_t argType;  // TSQ_I64 ...
+    int32_t mode = TSQ_MODE_COMPLETE;
+    int32_t argCol2 = -1;  // AVG in Final/Partial2 mode: (count column, sum column)
+    Schema outTypes() const {
+        const bool partial = mode == TSQ_MODE_PARTIAL1 || mode == TSQ_MODE_PARTIAL2;
+        const bool real = argType == TSQ_F32 || argType == TSQ_F64;
+        switch (func) {
+            case TSQ_AGG_COUNT: return {TSQ_I64};
+            case TSQ_AGG_SUM: return {real ? TSQ_F64 : TSQ_I64};  // no DECIMAL in TinySQL: base_func.go:119-131
+            case TSQ_AGG_AVG: return partial ? Schema{TSQ_I64, real ? TSQ_F64 : TSQ_I64} : Schema{real ? TSQ_F64 : TSQ_I64};
+            default: return {argType};
+        }
+    }
+};
+class HashAggExec : public Executor {
+public:
+    HashAggExec(Context* ctx, Executor* child, std::vector<int> groupByCols, std::vector<AggFuncDesc> aggFuncs)
+        : Executor(ctx, types(aggFuncs), {child}) {
+        memset(&cfg_, 0, sizeof cfg_);
+        const Schema& in = child->schema();
+        if (groupByCols.size() > TSQ_MAX_GROUP_KEYS || aggFuncs.size() > TSQ_MAX_AGGS) throw Error(TSQ_ERR_UNSUPPORTED, "too many group keys / aggregates");
+        cfg_.n_group_keys = (int32_t)groupByCols.size();
+        for (size_t i = 0; i < groupByCols.size(); i++) { cfg_.group_key_col[i] = groupByCols[i]; cfg_.group_key_type[i] = in[groupByCols[i]]; }
+        cfg_.n_aggs = (int32_t)aggFuncs.size();
+        for (size_t i = 0; i < aggFuncs.size(); i++) {
+            cfg_.aggs[i].func = aggFuncs[i].func;
+            cfg_.aggs[i].mode = aggFuncs[i].mode;
+            cfg_.aggs[i].arg_col = aggFuncs[i].argCol;
+            cfg_.aggs[i].arg_col2 = aggFuncs[i].argCol2;
+            cfg_.aggs[i].arg_type = aggFuncs[i].argType;
+        }
+        cfg_.n_input_cols = (int32_t)in.size();
+        for (size_t i = 0; i < in.size(); i++) cfg_.input_types[i] = in[i];
+        cfg_.max_chunk_size = 1024;
+        // empty input without GROUP BY yields one row of defaults unless every function is FIRST_ROW
+        // (executor/builder.go:517-539, aggregate.go:572-574)
+        defaultRow_ = groupByCols.empty();
+        bool allFirstRow = true;
+        for (auto& f : aggFuncs) allFirstRow &= f.func == TSQ_AGG_FIRSTROW;
+        if (allFirstRow) defaultRow_ = false;
+        funcs_ = std::move(aggFuncs);
+    }
+    ~HashAggExec() override { destroy(); }
+    void Open() override {
+        Executor::Open();
+        check(tsq_agg_create(ctx_->h, &cfg_, &h_), ctx_->h);
+        prepared_ = false;
+        sawInput_ = false;
+        done_ = false;
+    }
+    void Next(Chunk* req) override {  // parallelExec (aggregate.go:559-588)
+        req->Reset();
+        if (done_) return;
+        if (!prepared_) {
+            Chunk chk(children_[0]->schema(), maxChunkSize);
+            for (;;) {
+                children_[0]->Next(&chk);
+                if (chk.NumRows() == 0) break;
+                sawInput_ = true;
+                auto v = chk.Views();
+                check(tsq_agg_push(h_, v.data(), (int32_t)v.size(), chk.NumRows()), h_);
+            }
+            check(tsq_agg_finish(h_), h_);
+            prepared_ = true;
+        }
+        if (!sawInput_) {
+            done_ = true;
+            if (!defaultRow_) return;
+            // COUNT -> 0, everything else NULL (expression/aggregation/base_func.go:176-185)
+            size_t c = 0;
+            for (auto& f : funcs_)
+                for (int32_t t : f.outTypes()) {
+                    (void)t;
+                    if (f.func == TSQ_AGG_COUNT) req->columns[c].AppendInt64(0);
+                    else req->columns[c].AppendNull();
+                    c++;
+                }
+            return;
+        }
+        const int64_t cap = req->requiredRows;
+        for (auto& c : req->columns) c.resizeFor(cap);
+        std::vector<tsq_col> out;
+        for (auto& c : req->columns) out.push_back(c.View(cap));
+        int64_t n = 0;
+        int32_t eos = 0;
+        check(tsq_agg_pull(h_, out.data(), (int32_t)out.size(), cap, &n, &eos), h_);
+        for (auto& c : req->columns) c.truncate(n);
+        if (n == 0) done_ = true;
+    }
+    void Close() override { destroy(); Executor::Close(); }
+private:
+    static Schema types(const std::vector<AggFuncDesc>& fs) {
+        Schema s;
+        for (auto& f : fs) for (int32_t t : f.outTypes()) s.push_back(t);
+        return s;
+    }
+    void destroy() {
+        if (h_) { tsq_agg_cancel(h_); tsq_agg_destroy(h_); h_ = nullptr; }
+    }
+    tsq_agg_cfg cfg_;
+    std::vector<AggFuncDesc> funcs_;
+    bool defaultRow_ = false, prepared_ = false, sawInput_ = false, done_ = false;
+    tsq_agg* h_ = nullptr;
+};
+
+}  // namespace tsqhost
+#endif
