@@ -69,6 +69,15 @@ def load():
                                     C.POINTER(C.c_int64)]
     lib.orc_rowhashmap_put_get.restype = C.c_int64
     lib.orc_rowhashmap_put_get.argtypes = [P, P, C.c_int64, C.c_uint64, P, C.c_int64]
+    lib.orc_value_size_signed.restype = C.c_int32
+    lib.orc_value_size_signed.argtypes = [C.c_int64]
+    lib.orc_value_size_unsigned.restype = C.c_int32
+    lib.orc_value_size_unsigned.argtypes = [C.c_uint64]
+    lib.orc_encode_rows.restype = C.c_int64
+    lib.orc_encode_rows.argtypes = [C.POINTER(abi.Col), C.c_int32, C.c_int64, C.c_int32, P, C.c_int64]
+    lib.orc_decode_rows.restype = C.c_int32
+    lib.orc_decode_rows.argtypes = [P, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 
@@ -240,3 +249,43 @@ def rowhashmap_put_get(keys, ptrs, probe):
     n = lib.orc_rowhashmap_put_get(k.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), len(k), probe,
                                    out.ctypes.data_as(C.c_void_p), len(out))
     return out[:n]
+
+
+# ---- coprocessor-response row codec (oracle/codec_rows.cpp)
+DECODE_STATUS = {0: "ok", 1: "invalid encoded key", 2: "insufficient bytes to decode value", 3: "value larger than 64 bits",
+                 4: "invalid encoded key flag", 5: "var-len flag"}
+
+
+def value_size_signed(v):
+    return load().orc_value_size_signed(v)
+
+
+def value_size_unsigned(v):
+    return load().orc_value_size_unsigned(v)
+
+
+def encode_rows(chunk, comparable=False):
+    """EncodeValue / EncodeKey (util/codec/codec.go:74-99,199-209) of every row of a fixed-width chunk -> np.uint8 array."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    n = chunk.NumRows()
+    out = np.zeros(max(1, n * len(chunk.columns) * 11 + 16), np.uint8)
+    got = lib.orc_encode_rows(cols, len(chunk.columns), n, 1 if comparable else 0, out.ctypes.data_as(C.c_void_p), out.size)
+    assert got >= 0
+    return out[:got].copy()
+
+
+def decode_rows(data, types, cap_rows):
+    """readRowsData + Decoder.DecodeOne (distsql/select_result.go:139-155, codec.go:623-690) -> (status, Chunk, consumed)."""
+    lib = load()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    bufs = [np.zeros(max(cap_rows, 1), dtype=np_dtype(t)) for t in types]
+    nns = [np.zeros(max(cap_rows, 1), dtype=np.uint8) for _ in types]
+    pd = (C.c_void_p * len(types))(*[b.ctypes.data for b in bufs])
+    pn = (C.c_void_p * len(types))(*[b.ctypes.data for b in nns])
+    tp = (C.c_int32 * len(types))(*types)
+    n, used = C.c_int64(0), C.c_int64(0)
+    st = lib.orc_decode_rows(data.ctypes.data_as(C.c_void_p), data.size, len(types), tp, cap_rows, pd, pn, C.byref(n), C.byref(used))
+    chk = Chunk([Column(t, b[:n.value], nn[:n.value].astype(bool)) for t, b, nn in zip(types, bufs, nns)])
+    return st, chk, used.value

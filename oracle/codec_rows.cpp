@@ -1,0 +1,216 @@
+/*
+ * codec_rows.cpp — CPU restatement of the coprocessor-response row codec (SURVEY.md §8 f, rank 2).
+ * TEST INFRASTRUCTURE ONLY (see oracle.h): the product never links or calls this file.
+ *
+ * Follows, line by line:
+ *   encode(..., comparable)            util/codec/codec.go:74-99      (EncodeValue :205-209 / EncodeKey :199-203)
+ *   encodeSignedInt / encodeUnsignedInt codec.go:145-154, 167-176
+ *   valueSizeOfSignedInt / Unsigned    codec.go:156-165, 178-187      (closed form pinned by codec_test.go:771-809)
+ *   EncodeInt/DecodeInt, EncodeUint/DecodeUint, EncodeVarint/DecodeVarint, EncodeUvarint/DecodeUvarint
+ *                                      util/codec/number.go:24-130 (+ Go's encoding/binary PutVarint/Varint/Uvarint)
+ *   EncodeFloat / DecodeFloat          util/codec/float.go:22-46
+ *   Decoder.DecodeOne                  util/codec/codec.go:623-690
+ *   appendFloatToChunk (TypeFloat -> float32)  codec.go:701-707
+ *   selectResult.readRowsData          distsql/select_result.go:139-155 (rows are decoded one after the other until the
+ *                                      chunk is full or the bytes are used up; the remainder is kept)
+ * encoding/binary is Go standard library (not in /root/reference): Uvarint = little-endian base-128, MSB = continuation,
+ * at most 10 bytes, the 10th byte at most 1 (else "overflow", n < 0); Varint = zig-zag over Uvarint.
+ */
+#include <cstdint>
+#include <cstring>
+
+#include "oracle.h"
+
+namespace {
+const uint8_t NilFlag = 0, bytesFlag = 1, compactBytesFlag = 2, intFlag = 3, uintFlag = 4, floatFlag = 5, varintFlag = 8, uvarintFlag = 9;
+const uint64_t signMask = 0x8000000000000000ULL;
+
+size_t put_uvarint(uint8_t* b, uint64_t x) {  // encoding/binary.PutUvarint
+    size_t i = 0;
+    while (x >= 0x80) {
+        b[i++] = (uint8_t)x | 0x80;
+        x >>= 7;
+    }
+    b[i] = (uint8_t)x;
+    return i + 1;
+}
+size_t put_varint(uint8_t* b, int64_t x) {  // encoding/binary.PutVarint: zig-zag
+    uint64_t ux = (uint64_t)x << 1;
+    if (x < 0) ux = ~ux;
+    return put_uvarint(b, ux);
+}
+// encoding/binary.Uvarint: returns n > 0 bytes read, 0 = buffer too small, < 0 = overflow
+int uvarint(const uint8_t* b, int64_t len, uint64_t* out) {
+    uint64_t x = 0;
+    unsigned s = 0;
+    for (int64_t i = 0; i < len; i++) {
+        if (i == 10) return -(int)(i + 1);  // MaxVarintLen64: overflow
+        const uint8_t c = b[i];
+        if (c < 0x80) {
+            if (i == 9 && c > 1) return -(int)(i + 1);  // overflow
+            *out = x | (uint64_t)c << s;
+            return (int)i + 1;
+        }
+        x |= (uint64_t)(c & 0x7f) << s;
+        s += 7;
+    }
+    *out = 0;
+    return 0;
+}
+void put_be64(uint8_t* b, uint64_t u) {
+    for (int i = 0; i < 8; i++) b[i] = (uint8_t)(u >> (56 - 8 * i));
+}
+uint64_t get_be64(const uint8_t* b) {
+    uint64_t u = 0;
+    for (int i = 0; i < 8; i++) u = (u << 8) | b[i];
+    return u;
+}
+uint64_t encodeFloatToCmpUint64(double f) {  // float.go:22-30
+    uint64_t u;
+    memcpy(&u, &f, 8);
+    if (f >= 0) u |= signMask; else u = ~u;
+    return u;
+}
+double decodeCmpUintToFloat(uint64_t u) {  // float.go:32-40
+    if (u & signMask) u &= ~signMask; else u = ~u;
+    double f;
+    memcpy(&f, &u, 8);
+    return f;
+}
+bool is_null(const tsq_col& c, int64_t r) { return c.null_bitmap && ((c.null_bitmap[r >> 3] >> (r & 7)) & 1) == 0; }
+}  // namespace
+
+extern "C" {
+
+/* valueSizeOfSignedInt (codec.go:156-165) / valueSizeOfUnsignedInt (:178-187) */
+int32_t orc_value_size_signed(int64_t v) {
+    if (v < 0) v = 0 - v - 1;
+    int32_t size = 2;
+    v = v >> 6;
+    while (v > 0) { size++; v = v >> 7; }
+    return size;
+}
+int32_t orc_value_size_unsigned(uint64_t v) {
+    int32_t size = 2;
+    v = v >> 7;
+    while (v > 0) { size++; v = v >> 7; }
+    return size;
+}
+
+/* encode (codec.go:74-99) of rows of fixed-width columns, row after row as the coprocessor writes them.
+ * I64 -> KindInt64, U64 -> KindUint64, F32/F64 -> floatFlag + EncodeFloat(float64(v)), NULL -> NilFlag.
+ * Returns the number of bytes written (the call fails with -1 if cap is too small: at most 11 bytes per value). */
+int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int32_t comparable, uint8_t* out, int64_t cap) {
+    int64_t n = 0;
+    for (int64_t r = 0; r < nrows; r++)
+        for (int c = 0; c < n_cols; c++) {
+            if (n + 11 > cap) return -1;
+            const tsq_col& col = cols[c];
+            if (is_null(col, r)) { out[n++] = NilFlag; continue; }
+            switch (col.type) {
+                case TSQ_I64: {
+                    const int64_t v = ((const int64_t*)col.data)[r];
+                    if (comparable) { out[n++] = intFlag; put_be64(out + n, (uint64_t)v ^ signMask); n += 8; }  // number.go:24-42
+                    else { out[n++] = varintFlag; n += (int64_t)put_varint(out + n, v); }                       // number.go:107-111
+                    break;
+                }
+                case TSQ_U64: {
+                    const uint64_t v = ((const uint64_t*)col.data)[r];
+                    if (comparable) { out[n++] = uintFlag; put_be64(out + n, v); n += 8; }
+                    else { out[n++] = uvarintFlag; n += (int64_t)put_uvarint(out + n, v); }
+                    break;
+                }
+                default: {
+                    const double f = col.type == TSQ_F32 ? (double)((const float*)col.data)[r] : ((const double*)col.data)[r];
+                    out[n++] = floatFlag;
+                    put_be64(out + n, encodeFloatToCmpUint64(f));
+                    n += 8;
+                }
+            }
+        }
+    return n;
+}
+
+/* readRowsData (select_result.go:139-155) over Decoder.DecodeOne (codec.go:623-690): decode rows until cap_rows rows are
+ * out or the bytes are used up.  out_data[c]: 8 bytes per row (4 for TSQ_F32 columns), out_notnull[c]: one byte per row.
+ * Status: 0 ok; 1 "invalid encoded key" (a row ends in the middle: DecodeOne called with no bytes left);
+ * 2 "insufficient bytes to decode value"; 3 "value larger than 64 bits"; 4 "invalid encoded key flag"; 5 var-len flag
+ * (bytes / compact bytes: not a fixed-width column).  On error *nrows_out holds the complete rows decoded before it. */
+int32_t orc_decode_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, const int32_t* types, int64_t cap_rows, void** out_data,
+                        uint8_t** out_notnull, int64_t* nrows_out, int64_t* consumed) {
+    int64_t pos = 0, rows = 0;
+    *nrows_out = 0;
+    *consumed = 0;
+    while (rows < cap_rows && pos < n_bytes) {
+        for (int c = 0; c < n_cols; c++) {
+            if (n_bytes - pos < 1) return 1;  // codec.go:624-626
+            const uint8_t flag = data[pos++];
+            const uint8_t* b = data + pos;
+            const int64_t left = n_bytes - pos;
+            uint64_t bits = 0;
+            bool isnull = false, real = false;
+            switch (flag) {
+                case intFlag:  // DecodeInt (number.go:44-53)
+                    if (left < 8) return 2;
+                    bits = get_be64(b) ^ signMask;
+                    pos += 8;
+                    break;
+                case uintFlag:  // DecodeUint (number.go:82-90)
+                    if (left < 8) return 2;
+                    bits = get_be64(b);
+                    pos += 8;
+                    break;
+                case varintFlag: {  // DecodeVarint (number.go:113-123) over binary.Varint
+                    uint64_t ux;
+                    const int k = uvarint(b, left, &ux);
+                    if (k < 0) return 3;
+                    if (k == 0) return 2;
+                    int64_t x = (int64_t)(ux >> 1);
+                    if (ux & 1) x = ~x;
+                    bits = (uint64_t)x;
+                    pos += k;
+                    break;
+                }
+                case uvarintFlag: {
+                    uint64_t ux;
+                    const int k = uvarint(b, left, &ux);
+                    if (k < 0) return 3;
+                    if (k == 0) return 2;
+                    bits = ux;
+                    pos += k;
+                    break;
+                }
+                case floatFlag: {  // DecodeFloat (float.go:42-46)
+                    if (left < 8) return 2;
+                    const double f = decodeCmpUintToFloat(get_be64(b));
+                    memcpy(&bits, &f, 8);
+                    real = true;
+                    pos += 8;
+                    break;
+                }
+                case NilFlag: isnull = true; break;
+                case bytesFlag:
+                case compactBytesFlag: return 5;
+                default: return 4;  // codec.go:683
+            }
+            // appendIntToChunk / appendUintToChunk / appendFloatToChunk (codec.go:692-707): the value goes into column c as
+            // decoded; only TypeFloat narrows to float32.  AppendNull writes a zero slot (column.go:150-158).
+            if (types[c] == TSQ_F32) {
+                float f32 = 0;
+                if (!isnull) {
+                    if (real) { double f; memcpy(&f, &bits, 8); f32 = (float)f; }
+                    else memcpy(&f32, &bits, 4);  // an int datum in a float column: the raw bytes (AppendInt64 on a 4-byte column is not meaningful)
+                }
+                ((float*)out_data[c])[rows] = f32;
+            } else {
+                ((uint64_t*)out_data[c])[rows] = isnull ? 0 : bits;
+            }
+            out_notnull[c][rows] = isnull ? 0 : 1;
+        }
+        rows++;
+        *nrows_out = rows;
+        *consumed = pos;
+    }
+    return 0;
+}
+}

@@ -96,6 +96,15 @@ tsq_status orc_filter_eval(const tsq_expr_prog* progs, int32_t n_progs, const ts
 int64_t orc_rowhashmap_put_get(const uint64_t* keys, const uint64_t* ptrs, int64_t n,
                                uint64_t probe_key, uint64_t* out_ptrs, int64_t cap);
 
+/* ---- coprocessor-response row codec (codec_rows.cpp; SURVEY.md §8 f rank 2) */
+int32_t orc_value_size_signed(int64_t v);    /* valueSizeOfSignedInt, util/codec/codec.go:156-165 */
+int32_t orc_value_size_unsigned(uint64_t v); /* valueSizeOfUnsignedInt, codec.go:178-187 */
+/* encode (codec.go:74-99): EncodeValue (comparable = 0) / EncodeKey (1) of rows of fixed-width columns */
+int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int32_t comparable, uint8_t* out, int64_t cap);
+/* readRowsData (distsql/select_result.go:139-155) + Decoder.DecodeOne (codec.go:623-690) */
+int32_t orc_decode_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, const int32_t* types, int64_t cap_rows, void** out_data,
+                        uint8_t** out_notnull, int64_t* nrows_out, int64_t* consumed);
+
 #ifdef __cplusplus
 }
 #endif

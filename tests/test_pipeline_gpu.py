@@ -66,3 +66,49 @@ def test_q3_shaped_plan_on_device_chunks(ctx, jit):
     finally:
         for d in dev:
             d.free()
+
+
+@pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
+def test_device_pipeline_equals_host_chunk_pipeline_with_nulls(ctx, jt):
+    # the same plan through device-resident chunks (gpu_pipeline.py) and through 1024-row host chunks (executor.py, itself
+    # pinned on the oracle): NULL join keys, NULL filter inputs (a NULL never passes a filter, expression.go:272-276),
+    # NULL aggregate arguments, NULL as a group (codec.go:718-719), outer-join NULL padding feeding the aggregate.
+    from tinysql_amd import executor as X
+    from tinysql_amd import expression as E
+    from tinysql_amd.executor import AggFuncDesc
+
+    rng = np.random.default_rng(100 + jt)
+    nf, nd = 120_000, 9_000
+    fact = Chunk([Column(abi.I64, rng.integers(0, 10_000, nf), rng.random(nf) > 0.05), Column(abi.I64, rng.integers(-50, 50, nf), rng.random(nf) > 0.1),
+                  Column(abi.F64, rng.integers(0, 1000, nf) / 8.0, rng.random(nf) > 0.1)])
+    dim = Chunk([Column(abi.I64, rng.permutation(12_000)[:nd].astype(np.int64), rng.random(nd) > 0.02), Column(abi.I64, rng.integers(0, 40, nd), rng.random(nd) > 0.2)])
+    F, Col, K = E.ScalarFunction, E.Column, E.Constant
+    filt = [F("gt", Col(1, abi.I64), K(-40)), F("lt", Col(2, abi.F64), K(120.0))]
+    proj = [Col(4, abi.I64), F("mul", Col(2, abi.F64), K(2.0)), Col(1, abi.I64)]           # d.grp, f.x * 2, f.v
+    aggs = [AggFuncDesc(abi.AGG_FIRSTROW, 0, abi.I64), AggFuncDesc(abi.AGG_COUNT, -1, abi.I64), AggFuncDesc(abi.AGG_SUM, 2, abi.I64),
+            AggFuncDesc(abi.AGG_AVG, 2, abi.I64), AggFuncDesc(abi.AGG_SUM, 1, abi.F64), AggFuncDesc(abi.AGG_MAX, 1, abi.F64)]
+
+    host = X.HashAggExec(ctx, X.ProjectionExec(ctx, X.HashJoinExec(ctx, X.SelectionExec(ctx, X.MockDataSource(ctx, fact), filt), X.MockDataSource(ctx, dim),
+                                                               [0], [0], jt, 1), proj), [0], aggs)
+    want = {}
+    for c in X.drain(host):
+        for r in c.rows():
+            want[r[0]] = r
+    dfact, ddim = GP.DeviceChunk.from_host(ctx, fact), GP.DeviceChunk.from_host(ctx, dim)
+    try:
+        dev = GP.GpuHashAggExec(ctx, GP.GpuProjectionExec(ctx, GP.GpuHashJoinExec(ctx, GP.GpuSelectionExec(ctx, GP.DeviceTableScan(ctx, dfact, 30_000), filt),
+                                                                               GP.DeviceTableScan(ctx, ddim, 4_000), [0], [0], jt, 1), proj), [0], aggs)
+        got = {}
+        for c in GP.drain_device(dev):
+            for r in c.rows():
+                assert r[0] not in got
+                got[r[0]] = r
+    finally:
+        dfact.free()
+        ddim.free()
+    assert set(got) == set(want) and len(got) > 30 and None in got
+    for k, w in want.items():
+        g = got[k]
+        assert g[:4] == w[:4], (k, g, w)                                  # firstrow(key), count, sum(int), avg(int): bit-exact
+        for a, b in zip(g[4:], w[4:]):                                    # sum / max of doubles that are multiples of 1/4: exact as well
+            assert a == b or (a is not None and b is not None and abs(a - b) <= 1e-9 * max(1.0, abs(b))), (k, g, w)
