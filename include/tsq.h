@@ -373,6 +373,22 @@ void       tsq_agg_destroy(tsq_agg* a);
 tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int64_t nrows, const uint8_t* selected,
                              tsq_col* out_cols, int64_t* nrows_out);
 
+/* ---------------------------------------------------------------- coprocessor response rows -> columns (SURVEY.md §8 f, rank 2)
+ * Replaces selectResult.readRowsData (distsql/select_result.go:139-155) + codec.Decoder.DecodeOne (util/codec/codec.go:
+ * 623-690) for fixed-width schemas: `rows_data` is the RowsData byte string of a coprocessor response chunk — rows one
+ * after the other, every value = flag byte + varint (8/9) | 8 big-endian bytes (3/4/5) | nothing (0 = NULL); both the
+ * EncodeValue and the EncodeKey forms are accepted, like DecodeOne.  Decodes at most cap_rows rows into out_cols (host
+ * or TSQ_COL_DEVICE buffers sized for cap_rows rows; data + null_bitmap), *bytes_consumed = length of the decoded
+ * prefix (the caller keeps the remainder, select_result.go:153).  data_flags: TSQ_COL_DEVICE when rows_data is in HBM.
+ * Errors are the reference's, decided by the FIRST offending value in stream order; *nrows_out then holds the complete
+ * rows before it (already in out_cols) and *bytes_consumed is 0: TSQ_ERR_INVALID with tsq_last_error =
+ * "invalid encoded key" (a row ends early, codec.go:625) | "insufficient bytes to decode value" (number.go:46,122) |
+ * "value larger than 64 bits" (number.go:120) | "invalid encoded key flag" (codec.go:683); a bytes / compact-bytes
+ * datum (var-len column) -> TSQ_ERR_UNSUPPORTED: decode that response with the Go decoder. */
+tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, uint32_t data_flags, int32_t n_cols,
+                           const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out,
+                           int64_t* bytes_consumed);
+
 /* ---------------------------------------------------------------- multi-GPU radix redistribute
  * Splits rows by rank(key) = ((mix64(key) & 0xffff) * n_parts) >> 16 into n_parts contiguous
  * runs (CPU analogue: aggregate.go:352-356 shuffle / join.go:219 dispatch).  The exchange

@@ -165,6 +165,8 @@ SIGNATURES = {
     "tsq_agg_cancel": (C.c_int32, [P]),
     "tsq_agg_destroy": (None, [P]),
     "tsq_chunk_compact": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.POINTER(Col), C.POINTER(C.c_int64)]),
+    "tsq_rows_decode": (C.c_int32, [P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(Col), C.c_int64, C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64)]),
     "tsq_radix_split": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                     C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_join_stats": (C.c_int32, [P, C.POINTER(Stats)]),

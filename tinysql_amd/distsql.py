@@ -1,0 +1,49 @@
+"""Mirror of distsql.selectResult's decode step (distsql/select_result.go:102-155) for the harness: the RowsData byte
+string of a coprocessor response -> chunk columns, decoded on the GPU by libtsq (`tsq_rows_decode`, SURVEY.md §8 f rank 2).
+
+`SelectResult.Next` keeps the reference's contract: it fills a chunk with at most `max_rows` rows and keeps the
+undecoded remainder of the response for the next call (select_result.go:153).  Errors are the reference's
+(`codec.Decoder.DecodeOne`, util/codec/codec.go:623-690) and surface as `_lib.TsqError` with the same message.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as abi
+from . import _lib
+from .chunk import Chunk, Column, chunk_from_buffers, concat, np_dtype, out_buffers
+
+
+def decode_rows(ctx, data, types, cap_rows):
+    """host bytes -> (host Chunk, bytes consumed).  data: bytes / np.uint8 array."""
+    raw = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data, dtype=np.uint8)
+    keep = []
+    out, bufs = out_buffers(types, max(cap_rows, 1), keep)
+    tp = (C.c_int32 * len(types))(*types)
+    n, used = C.c_int64(0), C.c_int64(0)
+    _lib.check(ctx.lib.tsq_rows_decode(ctx.h, raw.ctypes.data_as(C.c_void_p), raw.size, 0, len(types), tp, out, cap_rows, C.byref(n), C.byref(used)), ctx.h)
+    return chunk_from_buffers(types, bufs, n.value), used.value
+
+
+class SelectResult:
+    """distsql.selectResult over a list of response chunks (each a RowsData byte string)."""
+
+    def __init__(self, ctx, responses, types):
+        self.ctx, self.types = ctx, list(types)
+        self.responses = [np.frombuffer(r, dtype=np.uint8) if isinstance(r, (bytes, bytearray)) else np.asarray(r, dtype=np.uint8) for r in responses]
+        self.idx = 0
+
+    def Next(self, max_rows=1024):
+        """select_result.go:102-128: decode until the chunk is full or the responses are used up; empty chunk = EOS."""
+        got = []
+        want = max_rows
+        while want > 0 and self.idx < len(self.responses):
+            raw = self.responses[self.idx]
+            if raw.size == 0:
+                self.idx += 1
+                continue
+            chk, used = decode_rows(self.ctx, raw, self.types, want)
+            self.responses[self.idx] = raw[used:]
+            got.append(chk)
+            want -= chk.NumRows()
+        return concat(got, self.types) if got else Chunk([Column(t, np.zeros(0, np_dtype(t))) for t in self.types])
