@@ -8,25 +8,34 @@
 // value before it.
 //
 // Parallel formulation (speculative parsing): a value is at most 11 bytes long, so a block of bytes can be entered at
-// only 11 different offsets.  For every 64-byte sub-block and each of the 11 entry offsets we compute the exit offset
-// into the next sub-block and the number of values that start inside (an "exit map", 11 x 4 bits, and 11 counts).
-// Maps compose associatively, so
-//   K13a k_dec_map   : tile (16 KB in LDS): value length at every byte position (as if a value started there, all lanes
-//                      busy), 11 cheap pointer-chasing walks per sub-block, composition of the 256 sub-block maps ->
-//                      tile map + tile counts
-//   K13b k_dec_scan  : one workgroup composes the tile maps -> true entry offset and first value ordinal of every tile
-//   K13c k_dec_emit  : per tile again: lengths, sub-block maps, composition from the now known entry -> every sub-block
-//                      walks its true path, decodes its ~12 values and stores them at (row, column) = divmod(ordinal)
+// only 11 different offsets.  For every 32-byte sub-block and each of the 11 entry offsets we need the exit offset into
+// the next sub-block and the number of values that start inside (an "exit map", 11 x 4 bits, and 11 counts); maps compose
+// associatively.  Per sub-block this is ONE backward pass over its 32 positions — (exit, count)[p] = p + len[p] leaves the
+// sub-block ? (p + len[p] - 32, 1) : (exit, count + 1)[p + len[p]] — i.e. one step per byte, no divergence (walking the
+// 11 entry offsets forward costs 11 steps per VALUE and the slowest of 64 x 11 walks per wave: 5x more instructions,
+// measured).  Workgroup b owns the contiguous tiles [b*R, (b+1)*R):
+//   K13a k_dec_map   : per 8 KB tile in LDS: value length at every byte position (as if a value started there), the
+//                      backward pass, composition of the 256 sub-block maps (20 segments x 11 entry offsets in parallel,
+//                      then 20 sequential steps) -> tile map + counts; the workgroup composes its R tile maps
+//   K13b k_dec_scan  : one thread composes the <= 1024 workgroup maps -> entry offset and first value ordinal per workgroup
+//   K13c k_dec_emit  : workgroup b replays its tile maps from its entry; per tile: lengths, backward pass, composition
+//                      from the known entry -> every sub-block walks its TRUE path (about five values), decodes them
+//                      and stores them at (row, column) = divmod(ordinal, n_cols)
+// LDS rows are padded (36 bytes per 32-byte sub-block) so that 64 lanes working in 64 different sub-blocks fall into
+// different banks.
 // Errors follow the reference in stream order: the FIRST offending value decides (invalid flag, value cut by the end of
 // the buffer, varint longer than 64 bits, a row that ends early); atomicMin over (ordinal, code) finds it.
 // Algorithmic bytes: encoded bytes read once + 8 B written per value (the implementation reads the bytes twice).
 #include "tsq_stage.h"
 
-#define TSQ_DEC_TB 16384      // bytes per tile
-#define TSQ_DEC_SB 64         // bytes per sub-block
+#define TSQ_DEC_TB 8192       // bytes per tile
+#define TSQ_DEC_SB 32         // bytes per sub-block
 #define TSQ_DEC_NSB (TSQ_DEC_TB / TSQ_DEC_SB)
-#define TSQ_DEC_HALO 16
 #define TSQ_DEC_NT 256        // threads per workgroup = sub-blocks per tile
+#define TSQ_DEC_BSTR 36       // s_bytes: bytes per sub-block row (32 + 4 pad: 9 words, odd)
+#define TSQ_DEC_NSEG 20       // composition segments per tile
+#define TSQ_DEC_SEGLEN 13     // sub-blocks per segment (20 * 13 >= 256)
+#define TSQ_DEC_MAXWG 1024
 
 enum { DEC_OK = 0, DEC_ROW_CUT = 1, DEC_INSUFFICIENT = 2, DEC_OVERFLOW = 3, DEC_BAD_FLAG = 4, DEC_VARLEN = 5 };
 
@@ -34,10 +43,14 @@ struct DecArgs {
     const uint8_t* data;
     int64_t n_bytes;
     int64_t n_tiles;
+    int64_t tiles_per_wg;           // R
+    int32_t n_wg;                   // workgroups that own tiles (grid of map and emit)
     unsigned long long* tile_map;   // [n_tiles] 11 x 4-bit exit offsets
     uint16_t* tile_cnt;             // [n_tiles][12] values starting in the tile, per entry offset
-    uint8_t* tile_entry;            // [n_tiles] true entry offset (k_dec_scan)
-    unsigned long long* tile_base;  // [n_tiles + 1] ordinal of the first value starting in the tile; [n_tiles] = total
+    unsigned long long* wg_map;     // [n_wg]
+    uint32_t* wg_cnt;               // [n_wg][12]
+    uint32_t* wg_entry;             // [n_wg] true entry offset of the workgroup's first tile (k_dec_scan)
+    unsigned long long* wg_base;    // [n_wg + 1] ordinal of the first value of the workgroup's range; [n_wg] = total
     // emit
     int32_t n_cols;
     int32_t col_type[TSQ_MAX_COLS];
@@ -47,99 +60,136 @@ struct DecArgs {
     unsigned long long* result;  // [0] = min over errors of (ordinal << 4 | code), [1] = byte offset of value number cap_rows * n_cols
 };
 
-// length of the value that would start at LDS position p (flag + payload).  A varint has at most 10 bytes; one whose
-// 10th byte still has the continuation bit is an overflow (binary.Uvarint) and is given the maximal length 11 as well.
-__device__ __forceinline__ uint32_t dec_len_at(const uint8_t* s, uint32_t p) {
-    const uint8_t f = s[p];
-    if (f == 3 || f == 4 || f == 5) return 9;
-    if (f == 8 || f == 9) {
-        uint32_t k = 1;
-        while (k < 10 && (s[p + k] & 0x80)) k++;
-        return k + 1;
-    }
-    return 1;  // NULL, or a flag that is an error if this position is ever reached on the true path
-}
+// LDS state of one tile
+struct DecTile {
+    uint8_t bytes[(TSQ_DEC_NSB + 1) * TSQ_DEC_BSTR];  // stream bytes, padded rows (+ one halo row)
+    uint8_t len[TSQ_DEC_NSB * TSQ_DEC_BSTR];          // value length at every position (emit only), same row layout
+    unsigned long long map[TSQ_DEC_NSB];              // per sub-block: 11 x 4-bit exit offsets
+    uint32_t cnt[TSQ_DEC_NSB][3];                     // per sub-block: 11 counts, four per word
+    uint32_t seg_exit[TSQ_DEC_NSEG][12];              // per segment and entry offset
+    uint32_t seg_cnt[TSQ_DEC_NSEG][12];
+};
+__device__ __forceinline__ uint32_t dec_bidx(uint32_t p) { return (p >> 5) * TSQ_DEC_BSTR + (p & 31u); }
 
-// loads tile `t` (+halo, zero padded past n_bytes) into s_bytes and fills s_len; returns the number of valid bytes
-__device__ __forceinline__ uint32_t dec_load_tile(const DecArgs& a, int64_t t, uint8_t* s_bytes, uint8_t* s_len) {
-    const int64_t t0 = t * TSQ_DEC_TB;
-    const int64_t left = a.n_bytes - t0;
-    const uint32_t valid = left < TSQ_DEC_TB ? (uint32_t)left : (uint32_t)TSQ_DEC_TB;
-    const uint32_t avail = left < TSQ_DEC_TB + TSQ_DEC_HALO ? (uint32_t)left : (uint32_t)(TSQ_DEC_TB + TSQ_DEC_HALO);
-    // 16-byte loads where the source allows it (tiles start at multiples of 16 KB of a 16-byte aligned buffer)
-    const bool aligned = (((uintptr_t)a.data) & 15) == 0;
-    for (uint32_t i = threadIdx.x * 16; i < TSQ_DEC_TB + TSQ_DEC_HALO; i += TSQ_DEC_NT * 16) {
-        if (aligned && i + 16 <= avail) {
-            *(uint4*)(s_bytes + i) = *(const uint4*)(a.data + t0 + i);
-        } else {
-            for (uint32_t j = 0; j < 16; j++) s_bytes[i + j] = i + j < avail ? a.data[t0 + i + j] : (uint8_t)0;
-        }
-    }
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < TSQ_DEC_TB; p += TSQ_DEC_NT) s_len[p] = (uint8_t)dec_len_at(s_bytes, p);
-    __syncthreads();
-    return valid;
-}
-
-// exit map and counts of sub-block `sb` (one thread): 11 walks over the precomputed lengths, advanced in lockstep so that
-// the 11 dependent LDS reads of a round are in flight together.  Counts are packed four per word (cnt_out[3]).
-__device__ __forceinline__ void dec_subblock_map(const uint8_t* s_len, uint32_t sb, uint32_t valid, unsigned long long* map_out, uint32_t* cnt_out) {
-    const uint32_t lo = sb * TSQ_DEC_SB, end = lo + TSQ_DEC_SB;
-    const uint32_t lim = end < valid ? end : valid;
-    uint32_t pos[11], c[11];
-#pragma unroll
-    for (int e = 0; e < 11; e++) { pos[e] = lo + e; c[e] = 0; }
-    bool any = lo < lim;
-    while (any) {
-        any = false;
-#pragma unroll
-        for (int e = 0; e < 11; e++) {
-            if (pos[e] < lim) {
-                pos[e] += s_len[pos[e]];
-                c[e]++;
-                any |= pos[e] < lim;
-            }
-        }
-    }
-    unsigned long long m = 0;
-    uint32_t w[3] = {0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < 11; e++) {
-        const uint32_t ex = pos[e] >= end ? pos[e] - end : 0u;  // < 11
-        m |= (unsigned long long)ex << (4 * e);
-        w[e >> 2] |= c[e] << (8 * (e & 3));
-    }
-    *map_out = m;
-    cnt_out[0] = w[0];
-    cnt_out[1] = w[1];
-    cnt_out[2] = w[2];
-}
 // count of entry offset `state` out of the packed words (no data-dependent address: the loads do not wait for `state`)
 __device__ __forceinline__ uint32_t dec_cnt_of(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t state) {
     const uint32_t w = state < 4 ? w0 : (state < 8 ? w1 : w2);
     return (w >> (8 * (state & 3))) & 255u;
 }
+// the continuation bits (bit 7) of the four bytes of w as a 4-bit number, byte 0 first
+__device__ __forceinline__ uint32_t dec_msb4(uint32_t w) { return ((((w >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u; }
+
+// Loads tile `t` (+ 11 bytes of halo, zero padded past n_bytes) and computes the exit map and counts of every sub-block.
+// Thread sb owns sub-block sb: its 32 bytes + 11 halo bytes live in REGISTERS (11 conflict-free LDS words), the value
+// length at each position comes from the flag byte and a 43-bit mask of continuation bits (count-trailing-zeros instead
+// of a byte loop), and the backward pass keeps the last 11 results in registers (the successor p + len[p] is at most 11
+// positions ahead): fully unrolled, no LDS traffic, no divergence.  (Doing both with LDS byte reads and an LDS-resident
+// state array cost 56 % of k_dec_map.)  Returns the number of valid bytes of the tile.
+template <bool KEEP_LEN>
+__device__ __forceinline__ uint32_t dec_prepare_tile(const DecArgs& a, int64_t t, DecTile& T) {
+    const int64_t t0 = t * TSQ_DEC_TB;
+    const int64_t left = a.n_bytes - t0;
+    const uint32_t valid = left < TSQ_DEC_TB ? (uint32_t)left : (uint32_t)TSQ_DEC_TB;
+    const uint32_t avail = left < TSQ_DEC_TB + 12 ? (uint32_t)left : (uint32_t)(TSQ_DEC_TB + 12);
+    const bool aligned = (((uintptr_t)a.data) & 3) == 0;
+    // global -> LDS in 4-byte words (rows are 4-byte aligned; 64 lanes read 256 contiguous bytes)
+    for (uint32_t i = threadIdx.x * 4; i < TSQ_DEC_TB + 12; i += TSQ_DEC_NT * 4) {
+        uint32_t w = 0;
+        if (aligned && i + 4 <= avail) w = *(const uint32_t*)(a.data + t0 + i);
+        else
+            for (uint32_t j = 0; j < 4; j++) w |= (i + j < avail ? (uint32_t)a.data[t0 + i + j] : 0u) << (8 * j);
+        *(uint32_t*)(T.bytes + dec_bidx(i)) = w;
+    }
+    __syncthreads();
+    {
+        const uint32_t sb = threadIdx.x, lo = sb * TSQ_DEC_SB;
+        const uint32_t lim = lo + TSQ_DEC_SB <= valid ? (uint32_t)TSQ_DEC_SB : (valid > lo ? valid - lo : 0u);
+        const uint32_t* rw = (const uint32_t*)(T.bytes + sb * TSQ_DEC_BSTR);
+        uint32_t w[11];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = rw[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[8 + i] = rw[9 + i];  // first 12 bytes of the next row (word 8 of a row is padding)
+        unsigned long long msb = 0;
+#pragma unroll
+        for (int i = 0; i < 11; i++) msb |= (unsigned long long)dec_msb4(w[i]) << (4 * i);
+        // E[p] = exit << 4 | count << 8 of position p; positions 32..42 lie in the next sub-block: exit = p - 32, count 0
+        uint32_t E[43];
+#pragma unroll
+        for (int n = 32; n < 43; n++) E[n] = (uint32_t)(n - 32) << 4;
+        uint32_t lenw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int o = 31; o >= 0; o--) {
+            const uint32_t f = (w[o >> 2] >> (8 * (o & 3))) & 255u;
+            // a varint has at most 10 bytes; one whose 10th byte still has the continuation bit is an overflow
+            // (binary.Uvarint) and gets the maximal length 11 as well
+            uint32_t run = (uint32_t)__builtin_ctzll(~(msb >> (o + 1)) | (1ull << 9));  // continuation bytes after the flag, <= 9
+            uint32_t len = 1;  // NULL, or a flag that is an error if this position is ever reached on the true path
+            len = (f == 8 || f == 9) ? run + 2 : len;
+            len = (f == 3 || f == 4 || f == 5) ? 9u : len;
+            uint32_t nx = E[o + 1];
+#pragma unroll
+            for (int d = 2; d <= 11; d++) nx = len == (uint32_t)d ? E[o + d] : nx;
+            E[o] = (uint32_t)o < lim ? nx + (1u << 8) : 0u;  // past the end of the stream: not a value
+            lenw[o >> 2] |= len << (8 * (o & 3));
+        }
+        unsigned long long m = 0;
+        uint32_t cw[3] = {0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 11; e++) {
+            m |= (unsigned long long)((E[e] >> 4) & 15u) << (4 * e);
+            cw[e >> 2] |= (E[e] >> 8) << (8 * (e & 3));
+        }
+        T.map[sb] = m;
+        T.cnt[sb][0] = cw[0];
+        T.cnt[sb][1] = cw[1];
+        T.cnt[sb][2] = cw[2];
+        if (KEEP_LEN) {
+            uint32_t* lr = (uint32_t*)(T.len + sb * TSQ_DEC_BSTR);
+#pragma unroll
+            for (int i = 0; i < 8; i++) lr[i] = lenw[i];
+        }
+    }
+    __syncthreads();
+    // 20 segments x 11 entry offsets in parallel: exit offset and count of every (segment, entry)
+    if (threadIdx.x < TSQ_DEC_NSEG * 11) {
+        const uint32_t seg = threadIdx.x / 11, e = threadIdx.x - seg * 11;
+        uint32_t state = e, total = 0;
+        const uint32_t i1 = seg * TSQ_DEC_SEGLEN + TSQ_DEC_SEGLEN < TSQ_DEC_NSB ? seg * TSQ_DEC_SEGLEN + TSQ_DEC_SEGLEN : TSQ_DEC_NSB;
+        for (uint32_t i = seg * TSQ_DEC_SEGLEN; i < i1; i++) {
+            total += dec_cnt_of(T.cnt[i][0], T.cnt[i][1], T.cnt[i][2], state);
+            state = (uint32_t)(T.map[i] >> (4 * state)) & 15u;
+        }
+        T.seg_exit[seg][e] = state;
+        T.seg_cnt[seg][e] = total;
+    }
+    __syncthreads();
+    return valid;
+}
 
 __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_map(DecArgs a) {
-    __shared__ __align__(16) uint8_t s_bytes[TSQ_DEC_TB + TSQ_DEC_HALO];
-    __shared__ uint8_t s_len[TSQ_DEC_TB];
-    __shared__ unsigned long long s_map[TSQ_DEC_NSB];
-    __shared__ uint32_t s_cnt[TSQ_DEC_NSB][3];
-    __shared__ uint32_t s_exit[11];
-    for (int64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        const uint32_t valid = dec_load_tile(a, t, s_bytes, s_len);
-        dec_subblock_map(s_len, threadIdx.x, valid, &s_map[threadIdx.x], s_cnt[threadIdx.x]);
-        __syncthreads();
-        if (threadIdx.x < 11) {  // lane e follows entry offset e through the 256 sub-blocks (ALU-only dependency chain)
+    __shared__ __align__(16) DecTile T;
+    __shared__ uint32_t s_exit[11], s_tot[11];
+    const int64_t lo = (int64_t)blockIdx.x * a.tiles_per_wg;
+    const int64_t hi = lo + a.tiles_per_wg < a.n_tiles ? lo + a.tiles_per_wg : a.n_tiles;
+    uint32_t wstate = threadIdx.x, wtotal = 0;  // lanes 0..10: entry offset e of the workgroup's range, followed through its tiles
+    for (int64_t t = lo; t < hi; t++) {
+        dec_prepare_tile<false>(a, t, T);
+        if (threadIdx.x < 11) {  // entry offset e of the tile through the 20 segments
             uint32_t state = threadIdx.x, total = 0;
-            for (uint32_t i = 0; i < TSQ_DEC_NSB; i++) {
-                total += dec_cnt_of(s_cnt[i][0], s_cnt[i][1], s_cnt[i][2], state);
-                state = (uint32_t)(s_map[i] >> (4 * state)) & 15u;
+            for (int sg = 0; sg < TSQ_DEC_NSEG; sg++) {
+                total += T.seg_cnt[sg][state];
+                state = T.seg_exit[sg][state];
             }
             s_exit[threadIdx.x] = state;
+            s_tot[threadIdx.x] = total;
             a.tile_cnt[t * 12 + threadIdx.x] = (uint16_t)total;
         }
         __syncthreads();
+        if (threadIdx.x < 11) {  // workgroup-level composition: where does entry e of the RANGE stand after this tile
+            wtotal += s_tot[wstate];
+            wstate = s_exit[wstate];
+        }
         if (threadIdx.x == 0) {
             unsigned long long m = 0;
             for (int e = 0; e < 11; e++) m |= (unsigned long long)s_exit[e] << (4 * e);
@@ -147,58 +197,37 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_map(DecArgs a) {
         }
         __syncthreads();
     }
+    if (threadIdx.x < 11) {
+        s_exit[threadIdx.x] = wstate;
+        a.wg_cnt[blockIdx.x * 12 + threadIdx.x] = wtotal;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = 0;
+        for (int e = 0; e < 11; e++) m |= (unsigned long long)s_exit[e] << (4 * e);
+        a.wg_map[blockIdx.x] = m;
+    }
 }
 
-// one workgroup: thread i owns a contiguous run of tiles; run maps are composed through LDS
+// <= 1024 workgroup maps: one thread walks them (maps and counts staged in LDS)
 __global__ void __launch_bounds__(1024) k_dec_scan(DecArgs a) {
-    __shared__ unsigned long long s_map[1024];
-    __shared__ unsigned long long s_cnt[1024][11];
-    __shared__ uint8_t s_entry[1024];
-    __shared__ unsigned long long s_base[1025];
-    const int64_t per = (a.n_tiles + 1023) / 1024;
-    const int64_t lo = (int64_t)threadIdx.x * per;
-    const int64_t hi = lo + per < a.n_tiles ? lo + per : a.n_tiles;
-    {
-        uint32_t st[11];
-        unsigned long long cn[11];
-        for (int e = 0; e < 11; e++) { st[e] = e; cn[e] = 0; }
-        for (int64_t t = lo; t < hi; t++) {
-            const unsigned long long m = a.tile_map[t];
-            const uint16_t* c = a.tile_cnt + t * 12;
-#pragma unroll
-            for (int e = 0; e < 11; e++) {
-                uint32_t cc = 0;  // c[st[e]] without a data-dependent address
-#pragma unroll
-                for (int q = 0; q < 11; q++) cc = st[e] == (uint32_t)q ? c[q] : cc;
-                cn[e] += cc;
-                st[e] = (uint32_t)(m >> (4 * st[e])) & 15u;
-            }
-        }
-        unsigned long long m = 0;
-        for (int e = 0; e < 11; e++) { m |= (unsigned long long)st[e] << (4 * e); s_cnt[threadIdx.x][e] = cn[e]; }
-        s_map[threadIdx.x] = m;
+    __shared__ unsigned long long s_map[TSQ_DEC_MAXWG];
+    __shared__ uint32_t s_cnt[TSQ_DEC_MAXWG][12];
+    for (int i = threadIdx.x; i < a.n_wg; i += 1024) {
+        s_map[i] = a.wg_map[i];
+        for (int e = 0; e < 11; e++) s_cnt[i][e] = a.wg_cnt[i * 12 + e];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t state = 0;
         unsigned long long base = 0;
-        for (int i = 0; i < 1024; i++) {
-            s_entry[i] = (uint8_t)state;
-            s_base[i] = base;
+        for (int i = 0; i < a.n_wg; i++) {
+            a.wg_entry[i] = state;
+            a.wg_base[i] = base;
             base += s_cnt[i][state];
             state = (uint32_t)(s_map[i] >> (4 * state)) & 15u;
         }
-        s_base[1024] = base;
-        a.tile_base[a.n_tiles] = base;
-    }
-    __syncthreads();
-    uint32_t state = s_entry[threadIdx.x];
-    unsigned long long base = s_base[threadIdx.x];
-    for (int64_t t = lo; t < hi; t++) {
-        a.tile_entry[t] = (uint8_t)state;
-        a.tile_base[t] = base;
-        base += a.tile_cnt[t * 12 + state];
-        state = (uint32_t)(a.tile_map[t] >> (4 * state)) & 15u;
+        a.wg_base[a.n_wg] = base;
     }
 }
 
@@ -206,94 +235,114 @@ __device__ __forceinline__ void dec_error(const DecArgs& a, unsigned long long o
     atomicMin(&a.result[0], (ordinal << 4) | (unsigned long long)code);
 }
 
+// decodes the value at tile position pos (ordinal ord) and stores it; t0 = byte offset of the tile in the stream
+__device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes, uint32_t pos, uint32_t len, unsigned long long ord, int64_t t0, uint32_t ncols) {
+    const uint8_t f = bytes[dec_bidx(pos)];
+    uint64_t bits = 0;
+    bool isnull = false, real = false;
+    int err = DEC_OK;
+    if (t0 + pos + len > a.n_bytes) {
+        err = DEC_INSUFFICIENT;  // the value is cut by the end of the buffer (number.go:45,115-123)
+    } else if (f == 3 || f == 4 || f == 5) {
+        uint64_t u = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) u = (u << 8) | bytes[dec_bidx(pos + 1 + i)];
+        if (f == 3) bits = u ^ 0x8000000000000000ULL;  // DecodeCmpUintToInt (number.go:29-31)
+        else if (f == 4) bits = u;
+        else {  // decodeCmpUintToFloat (float.go:32-40)
+            bits = (u & 0x8000000000000000ULL) ? (u & ~0x8000000000000000ULL) : ~u;
+            real = true;
+        }
+    } else if (f == 8 || f == 9) {
+        // binary.Uvarint: a 10th byte with the continuation bit (an 11th byte would be needed) or above 1 is an overflow
+        // ("value larger than 64 bits", number.go:119-121)
+        if (len == 11 && bytes[dec_bidx(pos + 10)] > 1) err = DEC_OVERFLOW;
+        else {
+            uint64_t x = 0;
+            for (uint32_t i = 0; i + 1 < len; i++) x |= (uint64_t)(bytes[dec_bidx(pos + 1 + i)] & 0x7f) << (7 * i);
+            bits = f == 8 ? ((x >> 1) ^ (0 - (x & 1))) : x;  // zig-zag (binary.Varint)
+        }
+    } else if (f == 0) {
+        isnull = true;
+    } else {
+        err = (f == 1 || f == 2) ? DEC_VARLEN : DEC_BAD_FLAG;
+    }
+    if (err != DEC_OK) {
+        dec_error(a, ord, err);
+        return;
+    }
+    const unsigned long long row = ord / ncols;
+    const uint32_t col = (uint32_t)(ord - row * ncols);
+    if (a.col_type[col] == TSQ_F32) {
+        uint32_t w = 0;
+        if (!isnull) {
+            if (real) { const float f32 = (float)tsq_bits_f64(bits); memcpy(&w, &f32, 4); }
+            else w = (uint32_t)bits;
+        }
+        ((uint32_t*)a.out_data[col])[row] = w;
+    } else {
+        ((uint64_t*)a.out_data[col])[row] = isnull ? 0ull : bits;
+    }
+    a.out_notnull[col][row] = isnull ? 0 : 1;
+}
+
 __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
-    __shared__ __align__(16) uint8_t s_bytes[TSQ_DEC_TB + TSQ_DEC_HALO];
-    __shared__ uint8_t s_len[TSQ_DEC_TB];
-    __shared__ unsigned long long s_map[TSQ_DEC_NSB];
-    __shared__ uint32_t s_cnt[TSQ_DEC_NSB][3];
+    __shared__ __align__(16) DecTile T;
+    __shared__ uint32_t s_seg_entry[TSQ_DEC_NSEG], s_seg_base[TSQ_DEC_NSEG];
     __shared__ uint8_t s_entry[TSQ_DEC_NSB];
     __shared__ uint32_t s_base[TSQ_DEC_NSB];
     const unsigned long long limit = (unsigned long long)a.cap_rows * (unsigned long long)a.n_cols;  // values wanted
     const uint32_t ncols = (uint32_t)a.n_cols;
-    for (int64_t t = blockIdx.x; t < a.n_tiles; t += gridDim.x) {
-        const unsigned long long tile_base = a.tile_base[t];
-        if (tile_base > limit) continue;  // block-uniform: everything in this tile lies beyond cap_rows
-        const uint32_t valid = dec_load_tile(a, t, s_bytes, s_len);
-        dec_subblock_map(s_len, threadIdx.x, valid, &s_map[threadIdx.x], s_cnt[threadIdx.x]);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t state = a.tile_entry[t], base = 0;
-            for (uint32_t i = 0; i < TSQ_DEC_NSB; i++) {
-                s_entry[i] = (uint8_t)state;
-                s_base[i] = base;
-                base += dec_cnt_of(s_cnt[i][0], s_cnt[i][1], s_cnt[i][2], state);
-                state = (uint32_t)(s_map[i] >> (4 * state)) & 15u;
-            }
-        }
-        __syncthreads();
-        {
-            const uint32_t lo = threadIdx.x * TSQ_DEC_SB, end = lo + TSQ_DEC_SB;
-            const uint32_t lim = end < valid ? end : valid;
-            uint32_t pos = lo + s_entry[threadIdx.x];
-            unsigned long long ord = tile_base + s_base[threadIdx.x];
+    const int64_t lo = (int64_t)blockIdx.x * a.tiles_per_wg;
+    const int64_t hi = lo + a.tiles_per_wg < a.n_tiles ? lo + a.tiles_per_wg : a.n_tiles;
+    uint32_t tile_entry = a.wg_entry[blockIdx.x];
+    unsigned long long tile_base = a.wg_base[blockIdx.x];
+    for (int64_t t = lo; t < hi; t++) {
+        const unsigned long long tmap = a.tile_map[t];
+        const uint32_t tcnt = a.tile_cnt[t * 12 + tile_entry];
+        if (tile_base <= limit) {  // block-uniform; a tile beyond cap_rows is only accounted for
             const int64_t t0 = t * TSQ_DEC_TB;
-            while (pos < lim) {
-                const uint32_t len = s_len[pos];
-                if (ord == limit) a.result[1] = (unsigned long long)(t0 + pos);  // first byte that is not consumed
-                if (ord < limit) {
-                    const uint8_t f = s_bytes[pos];
-                    uint64_t bits = 0;
-                    bool isnull = false, real = false;
-                    int err = DEC_OK;
-                    if (t0 + pos + len > a.n_bytes) {
-                        err = DEC_INSUFFICIENT;  // the value is cut by the end of the buffer (number.go:45,115-123)
-                    } else if (f == 3 || f == 4 || f == 5) {
-                        uint64_t u = 0;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) u = (u << 8) | s_bytes[pos + 1 + i];
-                        if (f == 3) bits = u ^ 0x8000000000000000ULL;  // DecodeCmpUintToInt (number.go:29-31)
-                        else if (f == 4) bits = u;
-                        else {  // decodeCmpUintToFloat (float.go:32-40)
-                            bits = (u & 0x8000000000000000ULL) ? (u & ~0x8000000000000000ULL) : ~u;
-                            real = true;
-                        }
-                    } else if (f == 8 || f == 9) {
-                        // binary.Uvarint: a 10th byte with the continuation bit (an 11th byte would be needed) or above 1 is
-                        // an overflow ("value larger than 64 bits", number.go:119-121)
-                        if (len == 11 && s_bytes[pos + 10] > 1) err = DEC_OVERFLOW;
-                        else {
-                            uint64_t x = 0;
-                            for (uint32_t i = 0; i + 1 < len; i++) x |= (uint64_t)(s_bytes[pos + 1 + i] & 0x7f) << (7 * i);
-                            bits = f == 8 ? ((x >> 1) ^ (0 - (x & 1))) : x;  // zig-zag (binary.Varint)
-                        }
-                    } else if (f == 0) {
-                        isnull = true;
-                    } else {
-                        err = (f == 1 || f == 2) ? DEC_VARLEN : DEC_BAD_FLAG;
-                    }
-                    if (err != DEC_OK) {
-                        dec_error(a, ord, err);
-                    } else {
-                        const unsigned long long row = ord / ncols;
-                        const uint32_t col = (uint32_t)(ord - row * ncols);
-                        if (a.col_type[col] == TSQ_F32) {
-                            uint32_t w = 0;
-                            if (!isnull) {
-                                if (real) { const float f32 = (float)tsq_bits_f64(bits); memcpy(&w, &f32, 4); }
-                                else w = (uint32_t)bits;
-                            }
-                            ((uint32_t*)a.out_data[col])[row] = w;
-                        } else {
-                            ((uint64_t*)a.out_data[col])[row] = isnull ? 0ull : bits;
-                        }
-                        a.out_notnull[col][row] = isnull ? 0 : 1;
-                    }
+            const uint32_t valid = dec_prepare_tile<true>(a, t, T);
+            if (threadIdx.x == 0) {  // the true path through the 20 segments ...
+                uint32_t state = tile_entry, base = 0;
+                for (int sg = 0; sg < TSQ_DEC_NSEG; sg++) {
+                    s_seg_entry[sg] = state;
+                    s_seg_base[sg] = base;
+                    base += T.seg_cnt[sg][state];
+                    state = T.seg_exit[sg][state];
                 }
-                pos += len;
-                ord++;
             }
+            __syncthreads();
+            if (threadIdx.x < TSQ_DEC_NSEG) {  // ... and through the sub-blocks of every segment
+                const uint32_t seg = threadIdx.x;
+                uint32_t state = s_seg_entry[seg], base = s_seg_base[seg];
+                const uint32_t i1 = seg * TSQ_DEC_SEGLEN + TSQ_DEC_SEGLEN < TSQ_DEC_NSB ? seg * TSQ_DEC_SEGLEN + TSQ_DEC_SEGLEN : TSQ_DEC_NSB;
+                for (uint32_t i = seg * TSQ_DEC_SEGLEN; i < i1; i++) {
+                    s_entry[i] = (uint8_t)state;
+                    s_base[i] = base;
+                    base += dec_cnt_of(T.cnt[i][0], T.cnt[i][1], T.cnt[i][2], state);
+                    state = (uint32_t)(T.map[i] >> (4 * state)) & 15u;
+                }
+            }
+            __syncthreads();
+            {
+                const uint32_t sblo = threadIdx.x * TSQ_DEC_SB;
+                const uint32_t lim = sblo + TSQ_DEC_SB <= valid ? (uint32_t)TSQ_DEC_SB : (valid > sblo ? valid - sblo : 0u);
+                const uint8_t* row = T.len + threadIdx.x * TSQ_DEC_BSTR;
+                uint32_t pos = s_entry[threadIdx.x];
+                unsigned long long ord = tile_base + s_base[threadIdx.x];
+                while (pos < lim) {
+                    const uint32_t len = row[pos];
+                    if (ord == limit) a.result[1] = (unsigned long long)(t0 + sblo + pos);  // first byte that is not consumed
+                    if (ord < limit) dec_value(a, T.bytes, sblo + pos, len, ord, t0, ncols);
+                    pos += len;
+                    ord++;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        tile_base += tcnt;
+        tile_entry = (uint32_t)(tmap >> (4 * tile_entry)) & 15u;
     }
 }
 
@@ -321,11 +370,16 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     memset(&a, 0, sizeof a);
     a.n_bytes = n_bytes;
     a.n_tiles = (n_bytes + TSQ_DEC_TB - 1) / TSQ_DEC_TB;
+    {   // workgroup b owns tiles [b*R, (b+1)*R): <= 1024 workgroups, 4 per CU
+        const int64_t want = std::min<int64_t>(std::min<int64_t>(a.n_tiles, (int64_t)ctx->num_cus * 4), TSQ_DEC_MAXWG);
+        a.tiles_per_wg = (a.n_tiles + want - 1) / want;
+        a.n_wg = (int32_t)((a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg);
+    }
     a.n_cols = n_cols;
     a.cap_rows = cap_rows;
-    DevBuf dbytes, dmap, dcnt, dentry, dbase, dres, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
+    DevBuf dbytes, dmap, dcnt, dwmap, dwcnt, dentry, dbase, dres, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
     auto release_all = [&]() {
-        for (DevBuf* b : {&dbytes, &dmap, &dcnt, &dentry, &dbase, &dres}) b->release();
+        for (DevBuf* b : {&dbytes, &dmap, &dcnt, &dwmap, &dwcnt, &dentry, &dbase, &dres}) b->release();
         for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dnn[c].release(); dbm[c].release(); }
     };
     tsq_status s = TSQ_OK;
@@ -341,8 +395,10 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     }
     if (s == TSQ_OK) s = dmap.reserve(ctx, h, (size_t)a.n_tiles * 8 + 64);
     if (s == TSQ_OK) s = dcnt.reserve(ctx, h, (size_t)a.n_tiles * 24 + 64);
-    if (s == TSQ_OK) s = dentry.reserve(ctx, h, (size_t)a.n_tiles + 64);
-    if (s == TSQ_OK) s = dbase.reserve(ctx, h, ((size_t)a.n_tiles + 1) * 8 + 64);
+    if (s == TSQ_OK) s = dwmap.reserve(ctx, h, (size_t)a.n_wg * 8 + 64);
+    if (s == TSQ_OK) s = dwcnt.reserve(ctx, h, (size_t)a.n_wg * 48 + 64);
+    if (s == TSQ_OK) s = dentry.reserve(ctx, h, (size_t)a.n_wg * 4 + 64);
+    if (s == TSQ_OK) s = dbase.reserve(ctx, h, ((size_t)a.n_wg + 1) * 8 + 64);
     if (s == TSQ_OK) s = dres.reserve(ctx, h, 64);
     for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
         a.col_type[c] = col_types[c];
@@ -355,13 +411,15 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     if (s != TSQ_OK) return fail(s);
     a.tile_map = dmap.as<unsigned long long>();
     a.tile_cnt = dcnt.as<uint16_t>();
-    a.tile_entry = dentry.as<uint8_t>();
-    a.tile_base = dbase.as<unsigned long long>();
+    a.wg_map = dwmap.as<unsigned long long>();
+    a.wg_cnt = dwcnt.as<uint32_t>();
+    a.wg_entry = dentry.as<uint32_t>();
+    a.wg_base = dbase.as<unsigned long long>();
     a.result = dres.as<unsigned long long>();
     ctx->pinned[0] = ~0ull;             // no error
     ctx->pinned[1] = (uint64_t)n_bytes; // everything consumed unless value number cap_rows * n_cols exists
     hipError_t e = hipMemcpyAsync(a.result, ctx->pinned, 16, hipMemcpyHostToDevice, ctx->stream);
-    const int grid = (int)std::min<int64_t>(a.n_tiles, (int64_t)ctx->num_cus * 4);
+    const int grid = a.n_wg;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_dec_map, dim3(grid), dim3(TSQ_DEC_NT), 0, ctx->stream, a);
         hipLaunchKernelGGL(k_dec_scan, dim3(1), dim3(1024), 0, ctx->stream, a);
@@ -369,7 +427,7 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 2, a.result, 16, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 4, a.tile_base + a.n_tiles, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 4, a.wg_base + a.n_wg, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode: ") + hipGetErrorString(e)));
     const uint64_t errw = ctx->pinned[2], cut = ctx->pinned[3], total = ctx->pinned[4];
