@@ -45,8 +45,6 @@ struct DecArgs {
     int64_t n_tiles;
     int64_t tiles_per_wg;           // R
     int32_t n_wg;                   // workgroups that own tiles (grid of map and emit)
-    unsigned long long* tile_map;   // [n_tiles] 11 x 4-bit exit offsets
-    uint16_t* tile_cnt;             // [n_tiles][12] values starting in the tile, per entry offset
     unsigned long long* wg_map;     // [n_wg]
     uint32_t* wg_cnt;               // [n_wg][12]
     uint32_t* wg_entry;             // [n_wg] true entry offset of the workgroup's first tile (k_dec_scan)
@@ -90,15 +88,21 @@ __device__ __forceinline__ uint32_t dec_prepare_tile(const DecArgs& a, int64_t t
     const int64_t t0 = t * TSQ_DEC_TB;
     const int64_t left = a.n_bytes - t0;
     const uint32_t valid = left < TSQ_DEC_TB ? (uint32_t)left : (uint32_t)TSQ_DEC_TB;
-    const uint32_t avail = left < TSQ_DEC_TB + 12 ? (uint32_t)left : (uint32_t)(TSQ_DEC_TB + 12);
-    const bool aligned = (((uintptr_t)a.data) & 3) == 0;
-    // global -> LDS in 4-byte words (rows are 4-byte aligned; 64 lanes read 256 contiguous bytes)
-    for (uint32_t i = threadIdx.x * 4; i < TSQ_DEC_TB + 12; i += TSQ_DEC_NT * 4) {
-        uint32_t w = 0;
-        if (aligned && i + 4 <= avail) w = *(const uint32_t*)(a.data + t0 + i);
-        else
-            for (uint32_t j = 0; j < 4; j++) w |= (i + j < avail ? (uint32_t)a.data[t0 + i + j] : 0u) << (8 * j);
-        *(uint32_t*)(T.bytes + dec_bidx(i)) = w;
+    const uint32_t avail = left < TSQ_DEC_TB + 16 ? (uint32_t)left : (uint32_t)(TSQ_DEC_TB + 16);
+    const bool aligned = (((uintptr_t)a.data) & 15) == 0;
+    // global -> LDS: 16-byte global loads (a tile starts at a multiple of 8 KB), 4-byte LDS stores into the padded rows.
+    // (Prefetching the next tile into registers while this one is processed was measured and dropped: 12 more live VGPRs
+    // cost more than the hidden latency, k_dec_emit 1.74 -> 2.09 ms.)
+    for (uint32_t i = threadIdx.x * 16; i < TSQ_DEC_TB + 16; i += TSQ_DEC_NT * 16) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (aligned && i + 16 <= avail) {
+            const uint4 v = *(const uint4*)(a.data + t0 + i);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (uint32_t j = 0; j < 16; j++) w[j >> 2] |= (i + j < avail ? (uint32_t)a.data[t0 + i + j] : 0u) << (8 * (j & 3));
+        }
+        uint32_t* d = (uint32_t*)(T.bytes + dec_bidx(i));  // 16 bytes never straddle a 32-byte row
+        d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
     }
     __syncthreads();
     {
@@ -169,33 +173,20 @@ __device__ __forceinline__ uint32_t dec_prepare_tile(const DecArgs& a, int64_t t
 
 __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_map(DecArgs a) {
     __shared__ __align__(16) DecTile T;
-    __shared__ uint32_t s_exit[11], s_tot[11];
+    __shared__ uint32_t s_exit[11];
     const int64_t lo = (int64_t)blockIdx.x * a.tiles_per_wg;
     const int64_t hi = lo + a.tiles_per_wg < a.n_tiles ? lo + a.tiles_per_wg : a.n_tiles;
-    uint32_t wstate = threadIdx.x, wtotal = 0;  // lanes 0..10: entry offset e of the workgroup's range, followed through its tiles
+    // lanes 0..10 follow entry offset e of the workgroup's RANGE through the segments of all its tiles
+    uint32_t wstate = threadIdx.x, wtotal = 0;
     for (int64_t t = lo; t < hi; t++) {
         dec_prepare_tile<false>(a, t, T);
-        if (threadIdx.x < 11) {  // entry offset e of the tile through the 20 segments
-            uint32_t state = threadIdx.x, total = 0;
+        if (threadIdx.x < 11) {
             for (int sg = 0; sg < TSQ_DEC_NSEG; sg++) {
-                total += T.seg_cnt[sg][state];
-                state = T.seg_exit[sg][state];
+                wtotal += T.seg_cnt[sg][wstate];
+                wstate = T.seg_exit[sg][wstate];
             }
-            s_exit[threadIdx.x] = state;
-            s_tot[threadIdx.x] = total;
-            a.tile_cnt[t * 12 + threadIdx.x] = (uint16_t)total;
         }
-        __syncthreads();
-        if (threadIdx.x < 11) {  // workgroup-level composition: where does entry e of the RANGE stand after this tile
-            wtotal += s_tot[wstate];
-            wstate = s_exit[wstate];
-        }
-        if (threadIdx.x == 0) {
-            unsigned long long m = 0;
-            for (int e = 0; e < 11; e++) m |= (unsigned long long)s_exit[e] << (4 * e);
-            a.tile_map[t] = m;
-        }
-        __syncthreads();
+        // the next tile's prepare overwrites T.seg_* only after two barriers that lanes 0..10 take part in
     }
     if (threadIdx.x < 11) {
         s_exit[threadIdx.x] = wstate;
@@ -235,18 +226,26 @@ __device__ __forceinline__ void dec_error(const DecArgs& a, unsigned long long o
     atomicMin(&a.result[0], (ordinal << 4) | (unsigned long long)code);
 }
 
-// decodes the value at tile position pos (ordinal ord) and stores it; t0 = byte offset of the tile in the stream
+// decodes the value at tile position pos (ordinal ord) and stores it; t0 = byte offset of the tile in the stream.
+// The 12 bytes starting at pos are fetched as four aligned LDS words + a byte funnel shift; big-endian payloads are two
+// byte swaps, a varint is eight shift-and-mask terms cut to its length — no per-byte loop.
 __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes, uint32_t pos, uint32_t len, unsigned long long ord, int64_t t0, uint32_t ncols) {
-    const uint8_t f = bytes[dec_bidx(pos)];
+    const uint32_t* W = (const uint32_t*)bytes;
+    const uint32_t q = pos >> 2, sh = pos & 3u;
+    uint32_t w[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) w[k] = W[((q + k) >> 3) * (TSQ_DEC_BSTR / 4) + ((q + k) & 7u)];  // word 8 of a row is padding
+    const uint32_t b0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh), b1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh),
+                   b2 = __builtin_amdgcn_alignbyte(w[3], w[2], sh);
+    const uint32_t f = b0 & 255u;
+    const uint32_t p_lo = (b0 >> 8) | (b1 << 24), p_hi = (b1 >> 8) | (b2 << 24);  // payload bytes 1..8, little endian
     uint64_t bits = 0;
     bool isnull = false, real = false;
     int err = DEC_OK;
     if (t0 + pos + len > a.n_bytes) {
         err = DEC_INSUFFICIENT;  // the value is cut by the end of the buffer (number.go:45,115-123)
     } else if (f == 3 || f == 4 || f == 5) {
-        uint64_t u = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 8; i++) u = (u << 8) | bytes[dec_bidx(pos + 1 + i)];
+        const uint64_t u = ((uint64_t)__builtin_bswap32(p_lo) << 32) | __builtin_bswap32(p_hi);  // binary.BigEndian.Uint64
         if (f == 3) bits = u ^ 0x8000000000000000ULL;  // DecodeCmpUintToInt (number.go:29-31)
         else if (f == 4) bits = u;
         else {  // decodeCmpUintToFloat (float.go:32-40)
@@ -254,12 +253,17 @@ __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes
             real = true;
         }
     } else if (f == 8 || f == 9) {
+        const uint32_t byte9 = (b2 >> 8) & 255u, byte10 = (b2 >> 16) & 255u;
         // binary.Uvarint: a 10th byte with the continuation bit (an 11th byte would be needed) or above 1 is an overflow
         // ("value larger than 64 bits", number.go:119-121)
-        if (len == 11 && bytes[dec_bidx(pos + 10)] > 1) err = DEC_OVERFLOW;
+        if (len == 11 && byte10 > 1) err = DEC_OVERFLOW;
         else {
-            uint64_t x = 0;
-            for (uint32_t i = 0; i + 1 < len; i++) x |= (uint64_t)(bytes[dec_bidx(pos + 1 + i)] & 0x7f) << (7 * i);
+            const uint64_t P = (uint64_t)p_lo | ((uint64_t)p_hi << 32);
+            uint64_t x = (P & 0x7full) | ((P >> 1) & (0x7full << 7)) | ((P >> 2) & (0x7full << 14)) | ((P >> 3) & (0x7full << 21)) |
+                         ((P >> 4) & (0x7full << 28)) | ((P >> 5) & (0x7full << 35)) | ((P >> 6) & (0x7full << 42)) | ((P >> 7) & (0x7full << 49)) |
+                         ((uint64_t)(byte9 & 0x7fu) << 56) | ((uint64_t)(byte10 & 1u) << 63);
+            const uint32_t nb = len - 1;  // bytes of the varint, 1..10
+            if (nb < 10) x &= (1ull << (7 * nb)) - 1;
             bits = f == 8 ? ((x >> 1) ^ (0 - (x & 1))) : x;  // zig-zag (binary.Varint)
         }
     } else if (f == 0) {
@@ -274,12 +278,12 @@ __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes
     const unsigned long long row = ord / ncols;
     const uint32_t col = (uint32_t)(ord - row * ncols);
     if (a.col_type[col] == TSQ_F32) {
-        uint32_t w = 0;
+        uint32_t w32 = 0;
         if (!isnull) {
-            if (real) { const float f32 = (float)tsq_bits_f64(bits); memcpy(&w, &f32, 4); }
-            else w = (uint32_t)bits;
+            if (real) { const float f32 = (float)tsq_bits_f64(bits); memcpy(&w32, &f32, 4); }
+            else w32 = (uint32_t)bits;
         }
-        ((uint32_t*)a.out_data[col])[row] = w;
+        ((uint32_t*)a.out_data[col])[row] = w32;
     } else {
         ((uint64_t*)a.out_data[col])[row] = isnull ? 0ull : bits;
     }
@@ -288,7 +292,7 @@ __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes
 
 __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
     __shared__ __align__(16) DecTile T;
-    __shared__ uint32_t s_seg_entry[TSQ_DEC_NSEG], s_seg_base[TSQ_DEC_NSEG];
+    __shared__ uint32_t s_seg_entry[TSQ_DEC_NSEG], s_seg_base[TSQ_DEC_NSEG], s_next[2];
     __shared__ uint8_t s_entry[TSQ_DEC_NSB];
     __shared__ uint32_t s_base[TSQ_DEC_NSB];
     const unsigned long long limit = (unsigned long long)a.cap_rows * (unsigned long long)a.n_cols;  // values wanted
@@ -297,10 +301,8 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
     const int64_t hi = lo + a.tiles_per_wg < a.n_tiles ? lo + a.tiles_per_wg : a.n_tiles;
     uint32_t tile_entry = a.wg_entry[blockIdx.x];
     unsigned long long tile_base = a.wg_base[blockIdx.x];
-    for (int64_t t = lo; t < hi; t++) {
-        const unsigned long long tmap = a.tile_map[t];
-        const uint32_t tcnt = a.tile_cnt[t * 12 + tile_entry];
-        if (tile_base <= limit) {  // block-uniform; a tile beyond cap_rows is only accounted for
+    for (int64_t t = lo; t < hi && tile_base <= limit; t++) {  // block-uniform: tiles beyond cap_rows are not needed at all
+        {
             const int64_t t0 = t * TSQ_DEC_TB;
             const uint32_t valid = dec_prepare_tile<true>(a, t, T);
             if (threadIdx.x == 0) {  // the true path through the 20 segments ...
@@ -311,6 +313,8 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
                     base += T.seg_cnt[sg][state];
                     state = T.seg_exit[sg][state];
                 }
+                s_next[0] = state;  // ... leaves the tile here, after `base` values
+                s_next[1] = base;
             }
             __syncthreads();
             if (threadIdx.x < TSQ_DEC_NSEG) {  // ... and through the sub-blocks of every segment
@@ -339,10 +343,10 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
                     ord++;
                 }
             }
+            tile_entry = s_next[0];
+            tile_base += s_next[1];
             __syncthreads();
         }
-        tile_base += tcnt;
-        tile_entry = (uint32_t)(tmap >> (4 * tile_entry)) & 15u;
     }
 }
 
@@ -377,9 +381,9 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     }
     a.n_cols = n_cols;
     a.cap_rows = cap_rows;
-    DevBuf dbytes, dmap, dcnt, dwmap, dwcnt, dentry, dbase, dres, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
+    DevBuf dbytes, dwmap, dwcnt, dentry, dbase, dres, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
     auto release_all = [&]() {
-        for (DevBuf* b : {&dbytes, &dmap, &dcnt, &dwmap, &dwcnt, &dentry, &dbase, &dres}) b->release();
+        for (DevBuf* b : {&dbytes, &dwmap, &dwcnt, &dentry, &dbase, &dres}) b->release();
         for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dnn[c].release(); dbm[c].release(); }
     };
     tsq_status s = TSQ_OK;
@@ -393,8 +397,6 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     } else {
         a.data = rows_data;
     }
-    if (s == TSQ_OK) s = dmap.reserve(ctx, h, (size_t)a.n_tiles * 8 + 64);
-    if (s == TSQ_OK) s = dcnt.reserve(ctx, h, (size_t)a.n_tiles * 24 + 64);
     if (s == TSQ_OK) s = dwmap.reserve(ctx, h, (size_t)a.n_wg * 8 + 64);
     if (s == TSQ_OK) s = dwcnt.reserve(ctx, h, (size_t)a.n_wg * 48 + 64);
     if (s == TSQ_OK) s = dentry.reserve(ctx, h, (size_t)a.n_wg * 4 + 64);
@@ -409,8 +411,6 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
         a.out_notnull[c] = dnn[c].as<uint8_t>();
     }
     if (s != TSQ_OK) return fail(s);
-    a.tile_map = dmap.as<unsigned long long>();
-    a.tile_cnt = dcnt.as<uint16_t>();
     a.wg_map = dwmap.as<unsigned long long>();
     a.wg_cnt = dwcnt.as<uint32_t>();
     a.wg_entry = dentry.as<uint32_t>();
