@@ -908,6 +908,7 @@ tsq_status agg_flush(tsq_agg* a) {
 }  // namespace
 
 TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg** out) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx || !cfg || !out) return tsq_fail(nullptr, TSQ_ERR_INVALID, "tsq_agg_create: NULL argument");
     *out = nullptr;
     tsq_handle_hdr* ch = &ctx->hdr;
@@ -1028,6 +1029,7 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
 }
 
 TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols, int64_t nrows) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
     TSQ_TRY(agg_cancelled(a));
     if (a->finished) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "push after finish");
@@ -1063,6 +1065,7 @@ TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols,
 }
 
 TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
     TSQ_TRY(agg_cancelled(a));
     if (a->finished) return TSQ_OK;
@@ -1138,12 +1141,14 @@ TSQ_API tsq_status tsq_agg_set_fast(tsq_agg* a, int32_t mode) {
 }
 
 TSQ_API tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG || !out) return TSQ_ERR_INVALID;
     *out = a->finished ? a->out_rows : a->groups;
     return TSQ_OK;
 }
 
 TSQ_API tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows, int64_t* nrows_out, int32_t* eos) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
     if (!nrows_out || !eos) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "NULL out pointer");
     *nrows_out = 0;
@@ -1194,6 +1199,7 @@ TSQ_API tsq_status tsq_agg_cancel(tsq_agg* a) {
 }
 
 TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG || !out) return TSQ_ERR_INVALID;
     a->st.probe_rows = a->in_rows;
     a->st.table_buckets = (int64_t)a->tb.cap;
@@ -1204,6 +1210,7 @@ TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
 }
 
 TSQ_API void tsq_agg_destroy(tsq_agg* a) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return;
     (void)hipSetDevice(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->stream);

@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) k_compact_scatter(CompactArgs a) {
 
 TSQ_API tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int64_t nrows, const uint8_t* selected,
                                      tsq_col* out_cols, int64_t* nrows_out) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     tsq_handle_hdr* h = &ctx->hdr;
     if (!cols || !out_cols || !nrows_out || !selected || n_cols < 1 || n_cols > TSQ_MAX_COLS || nrows < 0)

@@ -65,6 +65,7 @@ TSQ_API tsq_status tsq_ctx_create(int32_t device, tsq_ctx** out) {
 }
 
 TSQ_API tsq_status tsq_ctx_set_stream(tsq_ctx* ctx, void* hip_stream) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     if (ctx->own_stream && ctx->stream) {
@@ -77,6 +78,7 @@ TSQ_API tsq_status tsq_ctx_set_stream(tsq_ctx* ctx, void* hip_stream) {
 }
 
 TSQ_API tsq_status tsq_ctx_sync(tsq_ctx* ctx) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     TSQ_HIP(&ctx->hdr, hipStreamSynchronize(ctx->stream));
@@ -106,6 +108,7 @@ TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
 // output chunks (GBs) per query, and hipMalloc is ~35 ms per GB.  The size of every live allocation is remembered so that
 // tsq_dev_free can hand the block back; a recycled block is safe because every libtsq kernel and copy runs on ctx->stream.
 TSQ_API tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx || !out || bytes < 0) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     *out = nullptr;
@@ -121,6 +124,7 @@ TSQ_API tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out) {
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_dev_free(tsq_ctx* ctx, void* p) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     if (!p) return TSQ_OK;
@@ -136,12 +140,14 @@ TSQ_API tsq_status tsq_dev_free(tsq_ctx* ctx, void* p) {
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_dev_memset(tsq_ctx* ctx, void* p, int32_t byte, int64_t bytes) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     TSQ_HIP(&ctx->hdr, hipMemsetAsync(p, byte, (size_t)bytes, ctx->stream));
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_copy_h2d(tsq_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     TSQ_HIP(&ctx->hdr, hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -149,6 +155,7 @@ TSQ_API tsq_status tsq_copy_h2d(tsq_ctx* ctx, void* dst_dev, const void* src_hos
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     TSQ_HIP(&ctx->hdr, hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -157,12 +164,14 @@ TSQ_API tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_de
 }
 
 TSQ_API tsq_status tsq_timer_start(tsq_ctx* ctx) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     TSQ_HIP(&ctx->hdr, hipEventRecord(ctx->ev0, ctx->stream));
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_timer_stop_ms(tsq_ctx* ctx, double* ms_out) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx || !ms_out) return TSQ_ERR_INVALID;
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     TSQ_HIP(&ctx->hdr, hipEventRecord(ctx->ev1, ctx->stream));
@@ -207,6 +216,7 @@ __global__ void __launch_bounds__(256) k_gen_column(tsq_gen_spec spec, int64_t n
 
 TSQ_API tsq_status tsq_gen_column(tsq_ctx* ctx, const tsq_gen_spec* spec, int64_t nrows, void* dst,
                                   uint8_t* null_bitmap, const void* src) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx || !spec || !dst || nrows < 0) return tsq_fail(ctx ? &ctx->hdr : nullptr, TSQ_ERR_INVALID, "tsq_gen_column: bad args");
     if ((spec->kind == TSQ_GEN_AFFINE || spec->kind == TSQ_GEN_RAND_MOD) && spec->m == 0)
         return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_gen_column: m == 0");

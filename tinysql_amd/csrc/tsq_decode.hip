@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
 // ====================================================================== host side
 TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, uint32_t data_flags, int32_t n_cols,
                                    const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_consumed) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     tsq_handle_hdr* h = &ctx->hdr;
     if (nrows_out) *nrows_out = 0;

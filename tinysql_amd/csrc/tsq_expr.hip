@@ -162,6 +162,7 @@ tsq_status expr_status(tsq_expr* e, uint64_t w) {
 }  // namespace
 
 TSQ_API tsq_status tsq_expr_compile(tsq_ctx* ctx, const tsq_expr_prog* progs, int32_t n_progs, tsq_expr** out) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx || !progs || !out || n_progs < 1 || n_progs > 16) return tsq_fail(ctx ? &ctx->hdr : nullptr, TSQ_ERR_INVALID, "tsq_expr_compile: bad arguments");
     *out = nullptr;
     for (int i = 0; i < n_progs; i++) {
@@ -437,6 +438,7 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
 
 TSQ_API tsq_status tsq_expr_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel, tsq_col* out,
                                  int64_t* div_by_zero_warnings) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(e, TSQ_MAGIC_EXPR));
     if (!e || e->hdr.magic != TSQ_MAGIC_EXPR) return TSQ_ERR_INVALID;
     if (!out) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "out == NULL");
     if (e->progs.size() != 1) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "tsq_expr_eval needs a single program (use tsq_filter_eval for CNF lists)");
@@ -445,6 +447,7 @@ TSQ_API tsq_status tsq_expr_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_
 
 TSQ_API tsq_status tsq_filter_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel,
                                    uint8_t* selected_out, uint8_t* isnull_out, int64_t* div_by_zero_warnings) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(e, TSQ_MAGIC_EXPR));
     if (!e || e->hdr.magic != TSQ_MAGIC_EXPR) return TSQ_ERR_INVALID;
     if (!selected_out) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "selected_out == NULL");
     return expr_run(e, true, in_cols, n_cols, nrows, sel, nullptr, selected_out, isnull_out, div_by_zero_warnings);
@@ -463,6 +466,7 @@ TSQ_API int64_t tsq_expr_jit_launches(tsq_expr* e) {
 }
 
 TSQ_API void tsq_expr_destroy(tsq_expr* e) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(e, TSQ_MAGIC_EXPR));
     if (!e || e->hdr.magic != TSQ_MAGIC_EXPR) return;
     (void)hipSetDevice(e->ctx->device);
     (void)hipStreamSynchronize(e->ctx->stream);

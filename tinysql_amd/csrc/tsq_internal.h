@@ -53,6 +53,12 @@ struct tsq_ctx {
     };
     std::unordered_map<std::string, JitEntry> jit_cache;
     std::mutex jit_mu;
+    // One context = one stream + one block of pinned scratch words shared by all of its handles.  The Go callers run
+    // operators of one plan on several goroutines (executor/join.go:207, aggregate.go:512, projection.go:312-347), so two
+    // handles of the same context may be entered at the same time: every entry point that touches the stream or the
+    // scratch holds this lock for its duration (the GPU work is serialised by the stream anyway).  tsq_*_cancel does not
+    // take it: it only sets an atomic flag.  Recursive: entry points call each other's helpers.
+    std::recursive_mutex api_mu;
     // device-memory pool: hipMalloc costs ~35 ms per GB, and one radix / pre-aggregation batch needs several GB of
     // partition buffers — per handle that was 100+ ms of allocation for a 20 ms aggregate.  Buffers released by a handle
     // are kept (up to pool_cap bytes) and handed to the next one; everything runs on ctx->stream, so stream order
@@ -87,6 +93,13 @@ inline void tsq_pool_put(tsq_ctx* ctx, void* p, size_t cap) {
     }
     (void)hipFree(p);
 }
+
+struct tsq_ctx_lock {
+    std::unique_lock<std::recursive_mutex> g;
+    explicit tsq_ctx_lock(tsq_ctx* c) { if (c) g = std::unique_lock<std::recursive_mutex>(c->api_mu); }
+};
+template <class H>
+inline tsq_ctx* tsq_ctx_of(H* h, uint32_t magic) { return h && h->hdr.magic == magic ? h->ctx : nullptr; }
 
 inline tsq_status tsq_fail(tsq_handle_hdr* h, tsq_status s, const std::string& msg) {
     if (h) h->err = msg;

@@ -1018,6 +1018,7 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
 
 // ====================================================================== C-ABI
 TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_join** out) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx || !cfg || !out) return tsq_fail(nullptr, TSQ_ERR_INVALID, "tsq_join_create: NULL argument");
     *out = nullptr;
     tsq_handle_hdr* ch = &ctx->hdr;
@@ -1108,6 +1109,7 @@ TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_jo
 }
 
 TSQ_API tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t n_cols, int64_t nrows) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     TSQ_TRY(check_cancel(j));
     if (j->build_done) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "build_push after build_finish");
@@ -1140,6 +1142,7 @@ TSQ_API tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t
 }
 
 TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     TSQ_TRY(check_cancel(j));
     if (j->build_done) return TSQ_OK;
@@ -1240,6 +1243,7 @@ TSQ_API tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on) {
 }
 
 TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t n_cols, int64_t nrows, const uint8_t* selected) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     TSQ_TRY(check_cancel(j));
     if (!j->build_done) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "probe_push before build_finish");
@@ -1282,6 +1286,7 @@ TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t
 }
 
 TSQ_API tsq_status tsq_join_probe_finish(tsq_join* j) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     TSQ_TRY(check_cancel(j));
     if (!j->build_done) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "probe_finish before build_finish");
@@ -1292,6 +1297,7 @@ TSQ_API tsq_status tsq_join_probe_finish(tsq_join* j) {
 }
 
 TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows, int64_t* nrows_out, int32_t* eos) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     if (!nrows_out || !eos) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "NULL out pointer");
     *nrows_out = 0;
@@ -1363,6 +1369,7 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
 }
 
 TSQ_API tsq_status tsq_join_count(tsq_join* j, int64_t* rows_out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN || !rows_out) return TSQ_ERR_INVALID;
     TSQ_TRY(check_cancel(j));
     TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
@@ -1379,6 +1386,7 @@ TSQ_API tsq_status tsq_join_count(tsq_join* j, int64_t* rows_out) {
 }
 
 TSQ_API tsq_status tsq_join_checksum(tsq_join* j, uint64_t* sum_out, uint64_t* xor_out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN || !sum_out || !xor_out) return TSQ_ERR_INVALID;
     if (!j->count_only || !j->checksum) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "checksum mode is not enabled");
     TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
@@ -1397,6 +1405,7 @@ TSQ_API tsq_status tsq_join_cancel(tsq_join* j) {
 }
 
 TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN || !out) return TSQ_ERR_INVALID;
     TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
     TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
@@ -1429,6 +1438,7 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
 }
 
 TSQ_API void tsq_join_destroy(tsq_join* j) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return;
     (void)hipSetDevice(j->ctx->device);
     (void)hipStreamSynchronize(j->ctx->stream);  // Close() drains in-flight work (join.go:81-107)

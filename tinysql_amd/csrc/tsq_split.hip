@@ -193,6 +193,7 @@ static tsq_status split_fast(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, 
 
 TSQ_API tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode, int64_t nrows,
                                    int32_t n_parts, tsq_col* out_cols, int64_t* counts_out) {
+    tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     tsq_handle_hdr* h = &ctx->hdr;
     if (!cols || !out_cols || !counts_out || n_cols < 1 || n_cols > TSQ_MAX_COLS || key_col < 0 || key_col >= n_cols || nrows < 0)
