@@ -78,6 +78,10 @@ def load():
     lib.orc_decode_rows.restype = C.c_int32
     lib.orc_decode_rows.argtypes = [P, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.orc_row_compare.restype = C.c_int32
+    lib.orc_row_compare.argtypes = [C.POINTER(abi.Col), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64]
+    lib.orc_sort_rows.restype = None
+    lib.orc_sort_rows.argtypes = [C.POINTER(abi.Col), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, P]
     _lib = lib
     return lib
 
@@ -289,3 +293,30 @@ def decode_rows(data, types, cap_rows):
     st = lib.orc_decode_rows(data.ctypes.data_as(C.c_void_p), data.size, len(types), tp, cap_rows, pd, pn, C.byref(n), C.byref(used))
     chk = Chunk([Column(t, b[:n.value], nn[:n.value].astype(bool)) for t, b, nn in zip(types, bufs, nns)])
     return st, chk, used.value
+
+
+# ---- SortExec / TopNExec row order (oracle/sort_rows.cpp)
+def sort_perm(chunk, key_cols, key_desc):
+    """SortExec (executor/sort.go:58-131): row indices in ORDER BY order (stable: one legal outcome of sort.Slice)."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    kc = (C.c_int32 * len(key_cols))(*key_cols)
+    kd = (C.c_int32 * len(key_cols))(*[1 if d else 0 for d in key_desc])
+    perm = np.zeros(max(chunk.NumRows(), 1), np.int64)
+    lib.orc_sort_rows(cols, chunk.NumRows(), kc, kd, len(key_cols), perm.ctypes.data_as(C.c_void_p))
+    return perm[:chunk.NumRows()]
+
+
+def sort_rows(chunk, key_cols, key_desc):
+    perm = sort_perm(chunk, key_cols, key_desc)
+    return Chunk([Column(c.tp, c.data[perm], None if c.notnull is None else c.notnull[perm]) for c in chunk.columns])
+
+
+def row_compare(chunk, key_cols, key_desc, i, j):
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    kc = (C.c_int32 * len(key_cols))(*key_cols)
+    kd = (C.c_int32 * len(key_cols))(*[1 if d else 0 for d in key_desc])
+    return lib.orc_row_compare(cols, kc, kd, len(key_cols), i, j)

@@ -105,6 +105,10 @@ int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int3
 int32_t orc_decode_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, const int32_t* types, int64_t cap_rows, void** out_data,
                         uint8_t** out_notnull, int64_t* nrows_out, int64_t* consumed);
 
+/* ---- SortExec / TopNExec row order (sort_rows.cpp; SURVEY.md §8 f rank 3) */
+int32_t orc_row_compare(const tsq_col* cols, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t i, int64_t j);
+void    orc_sort_rows(const tsq_col* cols, int64_t nrows, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t* perm_out);
+
 #ifdef __cplusplus
 }
 #endif
