@@ -389,6 +389,34 @@ tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_byt
                            const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out,
                            int64_t* bytes_consumed);
 
+/* ---------------------------------------------------------------- ORDER BY / TopN (SURVEY.md §8 f, rank 3)
+ * Replaces SortExec (executor/sort.go:27-144) and TopNExec (sort.go:146-318): all child rows are pushed, tsq_sort_finish
+ * orders them by the ByItems — bare columns (sort.go:107-113), each ascending or descending, compared like
+ * chunk.GetCompareFunc's comparators (util/chunk/compare.go:27-103: NULL smaller than every value, unsigned / signed /
+ * float32-widened / float64 order) — and tsq_sort_pull hands them out in that order.  limit_count >= 0 makes it a
+ * TopN: only rows [limit_offset, limit_offset + limit_count) of the order are returned (sort.go:213-238).  Rows whose
+ * keys all compare equal come out in input order (the reference's sort.Slice / heap leave that order unspecified). */
+typedef struct tsq_sort_cfg {
+    int32_t n_cols;
+    int32_t col_types[TSQ_MAX_COLS];
+    int32_t n_keys;                       /* ByItems */
+    int32_t key_col[TSQ_MAX_KEYS];
+    int32_t key_desc[TSQ_MAX_KEYS];       /* ByItems[i].Desc */
+    int64_t limit_offset;                 /* PhysicalLimit.Offset (0 for a plain sort) */
+    int64_t limit_count;                  /* PhysicalLimit.Count; < 0 = no limit (SortExec) */
+    int32_t max_chunk_size;
+    int32_t reserved;
+} tsq_sort_cfg;
+typedef struct tsq_sort tsq_sort;
+tsq_status tsq_sort_create(tsq_ctx* ctx, const tsq_sort_cfg* cfg, tsq_sort** out);
+tsq_status tsq_sort_push(tsq_sort* s, const tsq_col* cols, int32_t n_cols, int64_t nrows);   /* fetchRowChunks, sort.go:80-97 */
+tsq_status tsq_sort_finish(tsq_sort* s);
+/* out_cols: the input schema; host or TSQ_COL_DEVICE buffers (data + null_bitmap) for cap_rows rows */
+tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows, int64_t* nrows_out, int32_t* eos);
+tsq_status tsq_sort_stats(tsq_sort* s, int64_t* rows, int32_t* passes, int32_t* passes_skipped, double* sort_kernel_ms);
+tsq_status tsq_sort_cancel(tsq_sort* s);
+void       tsq_sort_destroy(tsq_sort* s);
+
 /* ---------------------------------------------------------------- multi-GPU radix redistribute
  * Splits rows by rank(key) = ((mix64(key) & 0xffff) * n_parts) >> 16 into n_parts contiguous
  * runs (CPU analogue: aggregate.go:352-356 shuffle / join.go:219 dispatch).  The exchange

@@ -115,6 +115,42 @@ def run_agg(ctx, cfg, chunk, out_types, chunk_rows=1024, pull_rows=1024, fast=No
         lib.tsq_agg_destroy(h)
 
 
+def run_sort(ctx, chunk, key_cols, key_desc, chunk_rows=1024, pull_rows=1024, offset=0, count=-1, stats_out=None):
+    """push* -> finish -> pull* through the C-ABI; returns the ordered Chunk."""
+    lib = ctx.lib
+    types = chunk.types()
+    cfg = abi.SortCfg()
+    cfg.n_cols = len(types)
+    for i, t in enumerate(types):
+        cfg.col_types[i] = t
+    cfg.n_keys = len(key_cols)
+    for i, (c, d) in enumerate(zip(key_cols, key_desc)):
+        cfg.key_col[i], cfg.key_desc[i] = c, 1 if d else 0
+    cfg.limit_offset, cfg.limit_count, cfg.max_chunk_size = offset, count, 1024
+    h = C.c_void_p()
+    _lib.check(lib.tsq_sort_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        push_chunked(lib.tsq_sort_push, h, chunk, chunk_rows)
+        _lib.check(lib.tsq_sort_finish(h), h)
+        if stats_out is not None:
+            rows, p, sk, ms = C.c_int64(0), C.c_int32(0), C.c_int32(0), C.c_double(0)
+            _lib.check(lib.tsq_sort_stats(h, C.byref(rows), C.byref(p), C.byref(sk), C.byref(ms)), h)
+            stats_out.append({"rows": rows.value, "passes": p.value, "passes_skipped": sk.value, "sort_kernel_ms": ms.value})
+        got = []
+        while True:
+            keep = []
+            out, bufs = out_buffers(types, pull_rows, keep)
+            n, eos = C.c_int64(0), C.c_int32(0)
+            _lib.check(lib.tsq_sort_pull(h, out, len(types), pull_rows, C.byref(n), C.byref(eos)), h)
+            if n.value == 0:
+                assert eos.value == 1
+                break
+            got.append(chunk_from_buffers(types, bufs, n.value))
+        return concat(got, types)
+    finally:
+        lib.tsq_sort_destroy(h)
+
+
 class DevCol:
     """a device-resident column allocated through the C-ABI (tsq_dev_alloc)."""
 

@@ -1,0 +1,184 @@
+"""GPU parity of tsq_sort_* (ORDER BY / TopN, SURVEY.md §8 f rank 3) against the oracle's restatement of SortExec /
+TopNExec (executor/sort.go:27-318 over util/chunk/compare.go:27-103).  Both are stable, so on inputs without NaN the
+ordered rows must be identical row for row; the reference's own ORDER BY results (union_scan_test.go:33-36) go through the
+executor mirror."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from tinysql_amd import _abi as abi
+from tinysql_amd import _lib
+from tinysql_amd import executor as X
+from tinysql_amd.chunk import Chunk, Column
+
+from . import gpu_helpers as G
+from . import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(rows):
+    cols = list(zip(*rows))
+    return Chunk([Column(abi.I64, np.array(c, dtype=np.int64)) for c in cols])
+
+
+def _rows(chunks):
+    out = []
+    for c in chunks:
+        out += c.rows()
+    return out
+
+
+def test_reference_order_by_rows_through_the_executors(ctx):
+    t = _t([(1, 5), (2, 3), (3, 4), (4, 8), (6, 8), (7, 6)])  # union_scan_test.go:31
+    q = lambda by, desc: _rows(X.drain(X.SortExec(ctx, X.MockDataSource(ctx, t), by, desc)))
+    assert q([0], [True]) == [(7, 6), (6, 8), (4, 8), (3, 4), (2, 3), (1, 5)]                   # :33
+    assert q([1, 0], [False, False]) == [(2, 3), (3, 4), (1, 5), (7, 6), (4, 8), (6, 8)]        # :34
+    assert q([1, 0], [True, True]) == [(6, 8), (4, 8), (7, 6), (1, 5), (3, 4), (2, 3)]          # :35
+    # distsql_test.go:158 shape: order by b desc limit 2,1 -> the third row of the descending order
+    top = X.TopNExec(ctx, X.MockDataSource(ctx, t), [1, 0], [True, True], offset=2, count=1)
+    assert _rows(X.drain(top)) == [(7, 6)]
+    assert _rows(X.drain(X.TopNExec(ctx, X.MockDataSource(ctx, t), [0], [False], offset=4, count=100))) == [(6, 8), (7, 6)]
+    assert _rows(X.drain(X.TopNExec(ctx, X.MockDataSource(ctx, t), [0], [False], offset=9, count=5))) == []
+    empty = Chunk([Column(abi.I64, np.zeros(0, np.int64))] * 2)
+    assert _rows(X.drain(X.SortExec(ctx, X.MockDataSource(ctx, empty), [0], [False]))) == []
+
+
+def _rand(rng, n, tp, null_p, small):
+    if tp == abi.I64:
+        v = rng.integers(-50, 50, n) if small else rng.integers(-(1 << 63), (1 << 63) - 1, n, dtype=np.int64)
+    elif tp == abi.U64:
+        v = rng.integers(0, 100, n).astype(np.uint64) if small else rng.integers(0, (1 << 64) - 1, n, dtype=np.uint64)
+        if small:
+            v[::7] |= np.uint64(1 << 63)
+    elif tp == abi.F64:
+        v = rng.integers(-40, 40, n) / 4.0 if small else np.ldexp(rng.random(n) - 0.5, rng.integers(-300, 300, n))
+        v[::11] = -0.0
+        v[::13] = 0.0
+        v[1::97] = math.inf
+        v[2::97] = -math.inf
+    else:
+        v = (rng.integers(-40, 40, n) / 4.0).astype(np.float32)
+    return Column(tp, v, rng.random(n) >= null_p if null_p else None)
+
+
+def _same_rows(a, b):
+    assert a.NumRows() == b.NumRows()
+    if a.NumRows() == 0:
+        return
+    for ca, cb in zip(a.columns, b.columns):
+        na = np.ones(len(ca), bool) if ca.notnull is None else ca.notnull
+        nb = np.ones(len(cb), bool) if cb.notnull is None else cb.notnull
+        assert (na == nb).all()
+        assert (ca.data.view(np.uint8).reshape(len(ca), -1)[na] == cb.data.view(np.uint8).reshape(len(cb), -1)[nb]).all()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 4095, 4096, 4097, 30_011])
+@pytest.mark.parametrize("keys", [([0], [False]), ([1], [True]), ([2, 0], [False, True]), ([3, 1, 0], [True, False, False]), ([1, 2, 3, 0], [False] * 4)])
+def test_random_tables_equal_the_stable_oracle_row_for_row(ctx, orc, n, keys):
+    rng = np.random.default_rng(n * 31 + len(keys[0]))
+    chk = Chunk([_rand(rng, n, abi.I64, 0.1, True), _rand(rng, n, abi.F64, 0.1, True), _rand(rng, n, abi.U64, 0.0, True),
+                 _rand(rng, n, abi.F32, 0.2, True), Column(abi.I64, np.arange(n))])
+    want = orc.sort_rows(chk, *keys)
+    _same_rows(G.run_sort(ctx, chk, *keys, chunk_rows=1024, pull_rows=1000), want)
+
+
+@pytest.mark.parametrize("tp", [abi.I64, abi.U64, abi.F64])
+@pytest.mark.parametrize("desc", [False, True])
+def test_full_range_keys_all_eight_digit_passes(ctx, orc, tp, desc):
+    rng = np.random.default_rng(tp * 2 + desc)
+    n = 50_000
+    chk = Chunk([_rand(rng, n, tp, 0.05, False), Column(abi.I64, np.arange(n))])
+    stats = []
+    got = G.run_sort(ctx, chk, [0], [desc], chunk_rows=1 << 20, pull_rows=1 << 20, stats_out=stats)
+    _same_rows(got, orc.sort_rows(chk, [0], [desc]))
+    assert stats[0]["passes"] == 9 and stats[0]["rows"] == n   # 8 digits + the NULL flag
+
+
+def test_small_range_keys_skip_the_constant_digits(ctx, orc):
+    rng = np.random.default_rng(4)
+    n = 100_000
+    chk = Chunk([Column(abi.I64, rng.integers(0, 2500, n)), Column(abi.I64, np.arange(n))])  # day numbers: two non-trivial bytes
+    stats = []
+    got = G.run_sort(ctx, chk, [0], [False], chunk_rows=1 << 20, pull_rows=1 << 20, stats_out=stats)
+    _same_rows(got, orc.sort_rows(chk, [0], [False]))
+    assert stats[0]["passes"] == 2 and stats[0]["passes_skipped"] == 6
+
+
+def test_topn_offsets_and_limits(ctx, orc):
+    rng = np.random.default_rng(6)
+    n = 20_000
+    chk = Chunk([_rand(rng, n, abi.I64, 0.1, True), _rand(rng, n, abi.F64, 0.0, True), Column(abi.I64, np.arange(n))])
+    full = orc.sort_rows(chk, [0, 1], [True, False])
+    for off, cnt in [(0, 1), (0, 10), (5, 1000), (19_990, 100), (20_000, 5), (0, 0), (123, 4096)]:
+        got = G.run_sort(ctx, chk, [0, 1], [True, False], offset=off, count=cnt, pull_rows=512)
+        _same_rows(got, full.slice(min(off, n), min(n, off + cnt)))
+
+
+def test_nan_keys_sort_after_every_number(ctx):
+    # CompareFloat64 answers "greater" whenever a NaN is involved (types/compare.go:104-112): no total order in the
+    # reference; here NaNs form one run after +inf (ASC) / before everything (DESC), NULLs stay outside as usual
+    v = np.array([1.0, math.nan, -math.inf, 3.0, math.nan, math.inf, 0.0])
+    chk = Chunk([Column(abi.F64, v, np.array([1, 1, 1, 0, 1, 1, 1], bool)), Column(abi.I64, np.arange(7))])
+    asc = G.run_sort(ctx, chk, [0], [False]).columns[1].data.tolist()
+    assert asc == [3, 2, 6, 0, 5, 1, 4]
+    assert G.run_sort(ctx, chk, [0], [True]).columns[1].data.tolist() == [1, 4, 5, 0, 6, 2, 3]
+
+
+def test_device_resident_input_and_output(ctx, orc):
+    rng = np.random.default_rng(9)
+    n = 300_000
+    chk = Chunk([_rand(rng, n, abi.I64, 0.05, False), _rand(rng, n, abi.F64, 0.05, False), Column(abi.I64, np.arange(n))])
+    ins = [G.to_device(ctx, c) for c in chk.columns]
+    outs = [G.DevCol(ctx, c.tp, n, with_nulls=True) for c in chk.columns]
+    cfg = abi.SortCfg()
+    cfg.n_cols, cfg.n_keys, cfg.limit_offset, cfg.limit_count = 3, 2, 0, -1
+    for i, t in enumerate(chk.types()):
+        cfg.col_types[i] = t
+    cfg.key_col[0], cfg.key_desc[0], cfg.key_col[1], cfg.key_desc[1] = 1, 1, 0, 0
+    h = C.c_void_p()
+    _lib.check(ctx.lib.tsq_sort_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        _lib.check(ctx.lib.tsq_sort_push(h, G.dev_cols(ins), 3, n), h)
+        _lib.check(ctx.lib.tsq_sort_finish(h), h)
+        m, eos = C.c_int64(0), C.c_int32(0)
+        _lib.check(ctx.lib.tsq_sort_pull(h, G.dev_cols(outs), 3, n, C.byref(m), C.byref(eos)), h)
+        assert m.value == n
+        _same_rows(Chunk([o.to_host() for o in outs]), orc.sort_rows(chk, [1, 0], [True, False]))
+    finally:
+        ctx.lib.tsq_sort_destroy(h)
+        for d in ins + outs:
+            d.free()
+
+
+def test_full_size_sortedness_and_permutation_property(ctx):
+    # 5e7 rows: the output keys are non-decreasing, the payload is a permutation of the row ids, and every row still carries
+    # its own key (payload = f(key) checked through the generator)
+    n = 50_000_000
+    k, v = G.DevCol(ctx, abi.I64, n), G.DevCol(ctx, abi.I64, n)
+    ok_, ov = G.DevCol(ctx, abi.I64, n, with_nulls=True), G.DevCol(ctx, abi.I64, n, with_nulls=True)
+    try:
+        ctx.gen_column(G.gen_spec(abi.GEN_RAND_MOD, table=5, col=0, m=1 << 40), n, k.data)
+        ctx.gen_column(G.gen_spec(abi.GEN_SEQ), n, v.data)
+        cfg = abi.SortCfg()
+        cfg.n_cols, cfg.n_keys, cfg.limit_offset, cfg.limit_count = 2, 1, 0, -1
+        cfg.col_types[0] = cfg.col_types[1] = abi.I64
+        h = C.c_void_p()
+        _lib.check(ctx.lib.tsq_sort_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            _lib.check(ctx.lib.tsq_sort_push(h, G.dev_cols([k, v]), 2, n), h)
+            _lib.check(ctx.lib.tsq_sort_finish(h), h)
+            m, eos = C.c_int64(0), C.c_int32(0)
+            _lib.check(ctx.lib.tsq_sort_pull(h, G.dev_cols([ok_, ov]), 2, n, C.byref(m), C.byref(eos)), h)
+            assert m.value == n
+        finally:
+            ctx.lib.tsq_sort_destroy(h)
+        keys, ids = ok_.to_host().data, ov.to_host().data
+        assert (np.diff(keys) >= 0).all()
+        assert (np.sort(ids) == np.arange(n)).all()
+        assert (keys == (G.np_gen_r(42, 5, 0, ids.astype(np.uint64)) % np.uint64(1 << 40)).astype(np.int64)).all()
+    finally:
+        for d in (k, v, ok_, ov):
+            d.free()

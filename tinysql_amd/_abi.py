@@ -106,6 +106,14 @@ class AggCfg(C.Structure):
     ]
 
 
+class SortCfg(C.Structure):
+    _fields_ = [
+        ("n_cols", C.c_int32), ("col_types", C.c_int32 * MAX_COLS), ("n_keys", C.c_int32), ("key_col", C.c_int32 * MAX_KEYS),
+        ("key_desc", C.c_int32 * MAX_KEYS), ("limit_offset", C.c_int64), ("limit_count", C.c_int64), ("max_chunk_size", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("build_rows", C.c_int64), ("build_rows_inserted", C.c_int64), ("probe_rows", C.c_int64),
@@ -164,6 +172,13 @@ SIGNATURES = {
     "tsq_agg_pull": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tsq_agg_cancel": (C.c_int32, [P]),
     "tsq_agg_destroy": (None, [P]),
+    "tsq_sort_create": (C.c_int32, [P, C.POINTER(SortCfg), PP]),
+    "tsq_sort_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),
+    "tsq_sort_finish": (C.c_int32, [P]),
+    "tsq_sort_pull": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "tsq_sort_stats": (C.c_int32, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "tsq_sort_cancel": (C.c_int32, [P]),
+    "tsq_sort_destroy": (None, [P]),
     "tsq_chunk_compact": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_rows_decode": (C.c_int32, [P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(Col), C.c_int64, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64)]),

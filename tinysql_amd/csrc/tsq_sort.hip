@@ -1,0 +1,546 @@
+// tsq_sort.hip — ORDER BY / TopN on the GPU (gfx950).  SURVEY.md §8 (f) rank 3.
+//
+// Replaces SortExec (executor/sort.go:27-144: fetchRowChunks + sort.Slice(rowPtrs, keyColumnsLess) over
+// chunk.GetCompareFunc comparators, util/chunk/compare.go:27-103) and TopNExec (sort.go:146-318: rows
+// [Offset, Offset + Count) of that order, kept in a heap there).
+//
+// The row order of `ORDER BY k1 [DESC], k2 [DESC], ...` is a lexicographic order, so it is produced by stable
+// least-significant-digit radix passes over (key image, row id) pairs: key columns from the LAST to the first, and
+// inside a column the 8 bytes of an order-preserving 64-bit image of the value (ints: sign bit flipped; unsigned:
+// as is; reals: the memcomparable image of the double, float32 widened like cmpFloat32; DESC: image inverted), then
+// one pass on the NULL flag (NULL is smaller than every value, cmpNull compare.go:48-56; DESC puts it last).
+//   K14a k_sort_image    : image[i] = f(column[row_id[i]]) for the key column being processed
+//   K14b k_sort_count8   : all eight digit histograms of the images in one read -> passes whose digit is the same for
+//                          every row are skipped (day numbers, small ints: 2-3 passes instead of 8)
+//   K14c k_sort_tilehist : per 4096-row tile digit histogram            (one pass = K14c + K14d + K14e)
+//   K14d k_sort_scan     : digit-major exclusive scan (one workgroup per digit, then the 256 digit totals)
+//   K14e k_sort_scatter  : stable ranks without atomics — every wave owns a contiguous quarter of the tile, matches equal
+//                          digits with 8 ballots, and keeps its running digit counts in LDS; the tile is laid out sorted in
+//                          LDS and every digit run is written with consecutive lanes on consecutive addresses
+//   K14f k_gather_rows   : output columns = input columns gathered through the final row ids (data + packed null bitmap)
+// Equal keys keep their input order (stable), one of the orders sort.Slice may produce (it is not stable; the TopN heap
+// is not either): parity is checked on key columns position by position and on rows as multisets within equal-key runs.
+// Algorithmic bytes per pass: 12 B read + 12 B written per row (the implementation reads the images twice: 32 B).
+#include "tsq_radix.h"
+#include "tsq_stage.h"
+
+#include <memory>
+
+#define TSQ_SORT_NT 256
+#define TSQ_SORT_K 16
+#define TSQ_SORT_T (TSQ_SORT_NT * TSQ_SORT_K)  // rows per tile
+#define TSQ_SORT_NW (TSQ_SORT_NT / 64)
+
+struct SortKeySrc {
+    const void* data;
+    const uint8_t* nulls;  // bit 1 = NOT NULL, or null
+    int32_t type;
+    int32_t desc;
+};
+
+// order-preserving 64-bit image (ascending); NaN sorts after +inf (CompareFloat64 answers "greater" for it, compare.go:104-112)
+__device__ __forceinline__ uint64_t sort_image(const SortKeySrc& k, uint32_t row) {
+    uint64_t u;
+    if (k.type == TSQ_I64) u = ((const uint64_t*)k.data)[row] ^ 0x8000000000000000ULL;
+    else if (k.type == TSQ_U64) u = ((const uint64_t*)k.data)[row];
+    else {
+        const double f = k.type == TSQ_F32 ? (double)((const float*)k.data)[row] : ((const double*)k.data)[row];
+        const uint64_t b = tsq_f64_bits(f);
+        // -0.0 == +0.0 for CompareFloat64: one image, so that such rows stay in input order like every other tie
+        u = f != f ? ~0ull : (f == 0.0 ? 0x8000000000000000ULL : ((b >> 63) ? ~b : (b | 0x8000000000000000ULL)));
+    }
+    return k.desc ? ~u : u;
+}
+
+struct SortArgs {
+    SortKeySrc key;
+    int64_t n;
+    const uint64_t* img_in;
+    const uint32_t* idx_in;  // null: identity
+    uint64_t* img_out;
+    uint32_t* idx_out;
+    int32_t digit;           // 0..7: byte of the image; 8: the NULL flag of key.nulls (through idx_in)
+    int64_t ntiles;
+    uint32_t* hist;          // [256][ntiles]
+    uint32_t* totals;        // [256] row totals, then exclusive bases
+    unsigned long long* count8;  // [8][256]
+};
+
+__device__ __forceinline__ uint32_t sort_digit(const SortArgs& a, uint64_t img, uint32_t row) {
+    if (a.digit < 8) return (uint32_t)(img >> (8 * a.digit)) & 255u;
+    const uint32_t notnull = (a.key.nulls[row >> 3] >> (row & 7)) & 1u;
+    return a.key.desc ? 1u - notnull : notnull;  // ASC: NULL first; DESC: NULL last (sort.go:121-123 negates cmpNull)
+}
+
+__global__ void __launch_bounds__(256) k_sort_image(SortArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const uint32_t row = a.idx_in ? a.idx_in[i] : (uint32_t)i;
+        a.img_out[i] = sort_image(a.key, row);
+        if (!a.idx_in) a.idx_out[i] = (uint32_t)i;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sort_count8(SortArgs a) {
+    __shared__ uint32_t s_h[8][256];
+    for (int i = threadIdx.x; i < 8 * 256; i += 256) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const uint64_t v = a.img_in[i];
+#pragma unroll
+        for (int d = 0; d < 8; d++) atomicAdd(&s_h[d][(v >> (8 * d)) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 256; i += 256) {
+        const uint32_t c = (&s_h[0][0])[i];
+        if (c) atomicAdd(&a.count8[i], (unsigned long long)c);
+    }
+}
+
+__global__ void __launch_bounds__(TSQ_SORT_NT) k_sort_tilehist(SortArgs a) {
+    __shared__ uint32_t s_h[256];
+    for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        s_h[threadIdx.x] = 0;
+        __syncthreads();
+        const int64_t base = t * TSQ_SORT_T;
+#pragma unroll 4
+        for (int j = 0; j < TSQ_SORT_K; j++) {
+            const int64_t i = base + (int64_t)j * TSQ_SORT_NT + threadIdx.x;
+            if (i < a.n) atomicAdd(&s_h[sort_digit(a, a.digit < 8 ? a.img_in[i] : 0ull, a.digit < 8 ? 0u : a.idx_in[i])], 1u);
+        }
+        __syncthreads();
+        a.hist[(int64_t)threadIdx.x * a.ntiles + t] = s_h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// workgroup d: exclusive scan of hist[d][0..ntiles) in place, totals[d] = row sum
+__global__ void __launch_bounds__(1024) k_sort_scan_rows(SortArgs a) {
+    __shared__ uint32_t s_wsum[16];
+    uint32_t* row = a.hist + (int64_t)blockIdx.x * a.ntiles;
+    uint32_t carry = 0;
+    for (int64_t c0 = 0; c0 < a.ntiles; c0 += 1024) {
+        const int64_t i = c0 + threadIdx.x;
+        const uint32_t v = i < a.ntiles ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<1024>(v, s_wsum, &total);
+        if (i < a.ntiles) row[i] = carry + ex;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.totals[blockIdx.x] = carry;
+}
+__global__ void __launch_bounds__(256) k_sort_scan_totals(SortArgs a) {
+    __shared__ uint32_t s_wsum[4];
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<256>(a.totals[threadIdx.x], s_wsum, &total);
+    a.totals[threadIdx.x] = ex;
+}
+
+__global__ void __launch_bounds__(TSQ_SORT_NT) k_sort_scatter(SortArgs a) {
+    __shared__ uint64_t s_img[TSQ_SORT_T];
+    __shared__ uint32_t s_idx[TSQ_SORT_T];
+    __shared__ uint32_t s_whist[TSQ_SORT_NW][256];  // running digit counts of each wave, then its exclusive base
+    __shared__ uint32_t s_start[256];               // first position of digit d in the sorted tile
+    __shared__ uint32_t s_gbase[256];               // global position of that first element
+    __shared__ uint32_t s_wsum[TSQ_SORT_NT / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        const int64_t base = t * TSQ_SORT_T;
+#pragma unroll
+        for (int q = 0; q < TSQ_SORT_NW; q++) s_whist[q][tid] = 0;
+        s_gbase[tid] = a.totals[tid] + a.hist[(int64_t)tid * a.ntiles + t];
+        __syncthreads();
+        uint64_t img[TSQ_SORT_K];
+        uint32_t idx[TSQ_SORT_K], rk[TSQ_SORT_K];  // rk = digit << 16 | rank inside the wave's quarter
+        // wave w owns rows [w*1024, (w+1)*1024) of the tile, 64 consecutive rows per step: memory order = rank order
+#pragma unroll
+        for (int j = 0; j < TSQ_SORT_K; j++) {
+            const int64_t i = base + (int64_t)w * (64 * TSQ_SORT_K) + j * 64 + lane;
+            const bool ok = i < a.n;
+            img[j] = ok ? a.img_in[i] : 0ull;
+            idx[j] = ok ? a.idx_in[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < TSQ_SORT_K; j++) {
+            const int64_t i = base + (int64_t)w * (64 * TSQ_SORT_K) + j * 64 + lane;
+            const bool ok = i < a.n;
+            const uint32_t d = ok ? sort_digit(a, img[j], idx[j]) : 0u;
+            unsigned long long peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            const uint32_t before = (uint32_t)__popcll(peers & lt);
+            const uint32_t prev = s_whist[w][d];  // every lane of the match group reads before its first lane adds
+            if (ok && before == 0) s_whist[w][d] = prev + (uint32_t)__popcll(peers);
+            rk[j] = ok ? ((d << 16) | (prev + before)) : 0xffffffffu;
+        }
+        __syncthreads();
+        {   // digit totals of the tile -> exclusive start of every digit; per-wave exclusive bases
+            uint32_t run = 0;
+#pragma unroll
+            for (int q = 0; q < TSQ_SORT_NW; q++) {
+                const uint32_t c = s_whist[q][tid];
+                s_whist[q][tid] = run;
+                run += c;
+            }
+            uint32_t total;
+            s_start[tid] = block_excl_scan<TSQ_SORT_NT>(run, s_wsum, &total);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TSQ_SORT_K; j++) {
+            if (rk[j] != 0xffffffffu) {
+                const uint32_t d = rk[j] >> 16;
+                const uint32_t pos = s_start[d] + s_whist[w][d] + (rk[j] & 0xffffu);
+                s_img[pos] = img[j];
+                s_idx[pos] = idx[j];
+            }
+        }
+        __syncthreads();
+        const int64_t left = a.n - base;
+        const uint32_t nt = left < TSQ_SORT_T ? (uint32_t)left : (uint32_t)TSQ_SORT_T;
+        for (uint32_t i = tid; i < nt; i += TSQ_SORT_NT) {
+            const uint64_t v = s_img[i];
+            const uint32_t r = s_idx[i];
+            const uint32_t d = sort_digit(a, v, r);
+            const uint32_t dst = s_gbase[d] + (i - s_start[d]);
+            a.img_out[dst] = v;
+            a.idx_out[dst] = r;
+        }
+        __syncthreads();
+    }
+}
+
+struct GatherRowsArgs {
+    const uint32_t* idx;  // row ids, already offset to the first wanted row
+    int64_t rows;
+    const void* src[TSQ_MAX_COLS];
+    const uint8_t* src_nulls[TSQ_MAX_COLS];
+    void* dst[TSQ_MAX_COLS];
+    uint8_t* dst_bitmap[TSQ_MAX_COLS];
+    int32_t es[TSQ_MAX_COLS];
+};
+// blockIdx.y = column; eight consecutive output rows per thread (independent gathers, one bitmap byte)
+__global__ void __launch_bounds__(256) k_gather_rows(GatherRowsArgs a) {
+    const int c = blockIdx.y;
+    const int64_t groups = (a.rows + 7) >> 3;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r0 = g << 3;
+        const int n = a.rows - r0 < 8 ? (int)(a.rows - r0) : 8;
+        uint32_t id[8], nn = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) id[i] = i < n ? a.idx[r0 + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            bool ok = i < n;
+            if (ok && a.src_nulls[c]) ok = (a.src_nulls[c][id[i] >> 3] >> (id[i] & 7)) & 1;
+            nn |= ok ? (1u << i) : 0u;
+        }
+        if (a.es[c] == 8) {
+            uint64_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (nn >> i) & 1 ? ((const uint64_t*)a.src[c])[id[i]] : 0ull;
+            for (int i = 0; i < n; i++) ((uint64_t*)a.dst[c])[r0 + i] = v[i];
+        } else {
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (nn >> i) & 1 ? ((const uint32_t*)a.src[c])[id[i]] : 0u;
+            for (int i = 0; i < n; i++) ((uint32_t*)a.dst[c])[r0 + i] = v[i];
+        }
+        a.dst_bitmap[c][g] = (uint8_t)nn;
+    }
+}
+
+// ====================================================================== host side
+#define TSQ_MAGIC_SORT 0x74737153u /* 'tsqS' */
+
+struct tsq_sort {
+    tsq_handle_hdr hdr;
+    tsq_ctx* ctx = nullptr;
+    tsq_sort_cfg cfg;
+    std::atomic<int> cancelled{0};
+    std::vector<ColStore> cols;
+    HostStage stage;
+    bool finished = false;
+    int64_t n = 0, first = 0, last = 0, cursor = 0;  // output rows [first, last) of the sorted order
+    DevBuf img[2], idx[2], hist, totals, count8;
+    int cur = 0;                                       // which of idx[] holds the final row ids
+    std::vector<DevBuf> odata, obm;                    // gather targets for host pulls
+    int32_t passes = 0, passes_skipped = 0;
+    double sort_ms = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+namespace {
+tsq_status sort_cancelled(tsq_sort* s) {
+    if (s->cancelled.load()) return tsq_fail(&s->hdr, TSQ_ERR_CANCELLED, "sort cancelled");
+    return TSQ_OK;
+}
+tsq_status sort_flush(tsq_sort* s) {
+    HostStage& sg = s->stage;
+    if (sg.staged == 0) return TSQ_OK;
+    DevBuf tmp;
+    for (size_t c = 0; c < s->cols.size(); c++) {
+        tsq_status st = tsq_col_append(s->ctx, &s->hdr, s->cols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
+        if (st != TSQ_OK) { tmp.release(); return st; }
+    }
+    hipError_t e = hipStreamSynchronize(s->ctx->stream);  // staging memory is reused
+    tmp.release();
+    sg.reset();
+    if (e != hipSuccess) return tsq_fail(&s->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return TSQ_OK;
+}
+
+// one stable pass on `digit` of the current images / row ids
+tsq_status sort_pass(tsq_sort* s, SortArgs& a, int digit) {
+    tsq_ctx* ctx = s->ctx;
+    a.digit = digit;
+    a.img_in = s->img[s->cur].as<uint64_t>();
+    a.idx_in = s->idx[s->cur].as<uint32_t>();
+    a.img_out = s->img[s->cur ^ 1].as<uint64_t>();
+    a.idx_out = s->idx[s->cur ^ 1].as<uint32_t>();
+    const int grid = (int)std::min<int64_t>(a.ntiles, (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_sort_tilehist, dim3(grid), dim3(TSQ_SORT_NT), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_sort_scan_rows, dim3(256), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_sort_scan_totals, dim3(1), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(TSQ_SORT_NT), 0, ctx->stream, a);
+    TSQ_HIP(&s->hdr, hipGetLastError());
+    s->cur ^= 1;
+    s->passes++;
+    return TSQ_OK;
+}
+}  // namespace
+
+TSQ_API tsq_status tsq_sort_create(tsq_ctx* ctx, const tsq_sort_cfg* cfg, tsq_sort** out) {
+    tsq_ctx_lock _api_lock(ctx);
+    if (!ctx || !cfg || !out) return tsq_fail(nullptr, TSQ_ERR_INVALID, "tsq_sort_create: NULL argument");
+    *out = nullptr;
+    tsq_handle_hdr* ch = &ctx->hdr;
+    if (cfg->n_cols < 1 || cfg->n_cols > TSQ_MAX_COLS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 columns supported");
+    if (cfg->n_keys < 1 || cfg->n_keys > TSQ_MAX_KEYS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..4 ORDER BY items supported");
+    for (int c = 0; c < cfg->n_cols; c++)
+        if (cfg->col_types[c] < TSQ_I64 || cfg->col_types[c] > TSQ_F64) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len column: fall back to the Go operator");
+    for (int k = 0; k < cfg->n_keys; k++)
+        if (cfg->key_col[k] < 0 || cfg->key_col[k] >= cfg->n_cols) return tsq_fail(ch, TSQ_ERR_INVALID, "ORDER BY column index out of range");
+    if (cfg->limit_offset < 0) return tsq_fail(ch, TSQ_ERR_INVALID, "negative offset");
+    std::unique_ptr<tsq_sort> s(new tsq_sort());
+    s->hdr.magic = TSQ_MAGIC_SORT;
+    s->ctx = ctx;
+    s->cfg = *cfg;
+    s->cols.resize(cfg->n_cols);
+    for (int c = 0; c < cfg->n_cols; c++) s->cols[c].type = cfg->col_types[c];
+    TSQ_HIP(ch, hipSetDevice(ctx->device));
+    for (int i = 0; i < 2; i++) TSQ_HIP(ch, hipEventCreate(&s->ev[i]));
+    *out = s.release();
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_sort_push(tsq_sort* s, const tsq_col* cols, int32_t n_cols, int64_t nrows) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(s, TSQ_MAGIC_SORT));
+    if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return TSQ_ERR_INVALID;
+    TSQ_TRY(sort_cancelled(s));
+    if (s->finished) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "push after finish");
+    if (nrows < 0 || (!cols && nrows > 0)) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "bad arguments");
+    if (nrows == 0) return TSQ_OK;
+    bool dev = false;
+    TSQ_TRY(tsq_validate_cols(&s->hdr, cols, n_cols, s->cfg.n_cols, s->cfg.col_types, nrows, &dev));
+    TSQ_HIP(&s->hdr, hipSetDevice(s->ctx->device));
+    if (s->cols[0].rows + s->stage.staged + nrows >= 0xfffffff0LL) return tsq_fail(&s->hdr, TSQ_ERR_UNSUPPORTED, "more than 2^32 rows per GPU");
+    if (dev) {
+        TSQ_TRY(sort_flush(s));
+        DevBuf tmp;
+        for (int c = 0; c < n_cols; c++) {
+            tsq_status st = tsq_col_append(s->ctx, &s->hdr, s->cols[c], cols[c].data, cols[c].null_bitmap, nrows, true, tmp);
+            if (st != TSQ_OK) { tmp.release(); return st; }
+        }
+        tmp.release();
+        return TSQ_OK;
+    }
+    if (s->stage.cap == 0) TSQ_TRY(s->stage.init(&s->hdr, n_cols, s->cfg.col_types, 1 << 20));
+    int64_t off = 0;
+    while (off < nrows) {
+        const int64_t n = std::min<int64_t>(nrows - off, s->stage.room());
+        s->stage.add(cols, off, n, nullptr);
+        off += n;
+        if (s->stage.room() == 0) TSQ_TRY(sort_flush(s));
+    }
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(s, TSQ_MAGIC_SORT));
+    if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return TSQ_ERR_INVALID;
+    TSQ_TRY(sort_cancelled(s));
+    if (s->finished) return TSQ_OK;
+    tsq_ctx* ctx = s->ctx;
+    tsq_handle_hdr* h = &s->hdr;
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    TSQ_TRY(sort_flush(s));
+    s->stage.release();
+    const int64_t n = s->cols[0].rows;
+    s->n = n;
+    s->first = std::min<int64_t>(n, s->cfg.limit_offset);
+    s->last = s->cfg.limit_count < 0 ? n : std::min<int64_t>(n, s->cfg.limit_offset + s->cfg.limit_count);  // TopNExec: Offset + Count (sort.go:215)
+    if (s->last < s->first) s->last = s->first;
+    s->cursor = s->first;
+    s->finished = true;
+    if (n == 0 || s->first == s->last) return TSQ_OK;
+    SortArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = n;
+    a.ntiles = (n + TSQ_SORT_T - 1) / TSQ_SORT_T;
+    for (int i = 0; i < 2; i++) {
+        TSQ_TRY(s->img[i].reserve(ctx, h, (size_t)n * 8 + 64));
+        TSQ_TRY(s->idx[i].reserve(ctx, h, (size_t)n * 4 + 64));
+    }
+    TSQ_TRY(s->hist.reserve(ctx, h, (size_t)a.ntiles * 256 * 4 + 64));
+    TSQ_TRY(s->totals.reserve(ctx, h, 256 * 4));
+    TSQ_TRY(s->count8.reserve(ctx, h, 8 * 256 * 8));
+    a.hist = s->hist.as<uint32_t>();
+    a.totals = s->totals.as<uint32_t>();
+    a.count8 = s->count8.as<unsigned long long>();
+    TSQ_HIP(h, hipEventRecord(s->ev[0], ctx->stream));
+    s->cur = 0;
+    bool have_idx = false;
+    PinnedBuf hcount;
+    TSQ_TRY(hcount.reserve(h, 8 * 256 * 8));
+    const int egrid = tsq_grid_for(ctx, n, 256, 4);
+    for (int k = s->cfg.n_keys - 1; k >= 0; k--) {  // least significant ORDER BY item first
+        tsq_status st = sort_cancelled(s);
+        if (st != TSQ_OK) { hcount.release(); return st; }
+        const int kc = s->cfg.key_col[k];
+        a.key.data = s->cols[kc].data.p;
+        a.key.nulls = s->cols[kc].has_nulls ? s->cols[kc].nulls.as<uint8_t>() : nullptr;
+        a.key.type = s->cfg.col_types[kc];
+        a.key.desc = s->cfg.key_desc[k] ? 1 : 0;
+        // images of this key column in the current row order (first key: identity order, row ids are initialised here)
+        a.idx_in = have_idx ? s->idx[s->cur].as<uint32_t>() : nullptr;
+        a.img_out = s->img[s->cur].as<uint64_t>();
+        a.idx_out = s->idx[s->cur].as<uint32_t>();
+        hipLaunchKernelGGL(k_sort_image, dim3(egrid), dim3(256), 0, ctx->stream, a);
+        have_idx = true;
+        a.img_in = s->img[s->cur].as<uint64_t>();
+        hipError_t e = hipMemsetAsync(s->count8.p, 0, 8 * 256 * 8, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_sort_count8, dim3(std::min(egrid, ctx->num_cus * 4)), dim3(256), 0, ctx->stream, a);
+            e = hipMemcpyAsync(hcount.p, s->count8.p, 8 * 256 * 8, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { hcount.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("sort: ") + hipGetErrorString(e)); }
+        const unsigned long long* c8 = (const unsigned long long*)hcount.p;
+        for (int d = 0; d < 8; d++) {
+            bool trivial = false;  // every row has the same digit: the pass would not move anything
+            for (int b = 0; b < 256; b++) trivial |= c8[d * 256 + b] == (unsigned long long)n;
+            if (trivial) { s->passes_skipped++; continue; }
+            st = sort_pass(s, a, d);
+            if (st != TSQ_OK) { hcount.release(); return st; }
+        }
+        if (a.key.nulls) {
+            st = sort_pass(s, a, 8);
+            if (st != TSQ_OK) { hcount.release(); return st; }
+        }
+    }
+    TSQ_HIP(h, hipEventRecord(s->ev[1], ctx->stream));
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hcount.release();
+    if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("sort: ") + hipGetErrorString(e));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) s->sort_ms = ms;
+    for (int i = 0; i < 2; i++) s->img[i].release();
+    s->idx[s->cur ^ 1].release();
+    s->hist.release();
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows, int64_t* nrows_out, int32_t* eos) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(s, TSQ_MAGIC_SORT));
+    if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return TSQ_ERR_INVALID;
+    if (!nrows_out || !eos) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "NULL out pointer");
+    *nrows_out = 0;
+    *eos = 0;
+    TSQ_TRY(sort_cancelled(s));
+    if (!s->finished) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "pull before finish");
+    if (n_cols != s->cfg.n_cols) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "pull: column count must equal the input schema");
+    tsq_ctx* ctx = s->ctx;
+    tsq_handle_hdr* h = &s->hdr;
+    const int64_t n = std::min<int64_t>(cap_rows, s->last - s->cursor);
+    if (n <= 0) { *eos = 1; return TSQ_OK; }
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    const bool odev = out_cols[0].flags & TSQ_COL_DEVICE;
+    GatherRowsArgs g;
+    memset(&g, 0, sizeof g);
+    g.idx = s->idx[s->cur].as<uint32_t>() + s->cursor;
+    g.rows = n;
+    if (!odev) { s->odata.resize(n_cols); s->obm.resize(n_cols); }
+    for (int c = 0; c < n_cols; c++) {
+        if (!out_cols[c].data || !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "pull: out columns need data and null_bitmap buffers");
+        if (((out_cols[c].flags & TSQ_COL_DEVICE) != 0) != odev) return tsq_fail(h, TSQ_ERR_INVALID, "pull: mixed host/device outputs");
+        g.es[c] = tsq_elem_size(s->cfg.col_types[c]);
+        g.src[c] = s->cols[c].data.p;
+        g.src_nulls[c] = s->cols[c].has_nulls ? s->cols[c].nulls.as<uint8_t>() : nullptr;
+        if (odev) {
+            g.dst[c] = out_cols[c].data;
+            g.dst_bitmap[c] = out_cols[c].null_bitmap;
+        } else {
+            TSQ_TRY(s->odata[c].reserve(ctx, h, (size_t)n * g.es[c] + 64));
+            TSQ_TRY(s->obm[c].reserve(ctx, h, tsq_bitmap_bytes(n) + 64));
+            g.dst[c] = s->odata[c].p;
+            g.dst_bitmap[c] = s->obm[c].as<uint8_t>();
+        }
+    }
+    const int64_t groups = (n + 7) / 8;
+    const int gx = (int)std::min<int64_t>((groups + 255) / 256, (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_gather_rows, dim3(gx, n_cols), dim3(256), 0, ctx->stream, g);
+    TSQ_HIP(h, hipGetLastError());
+    if (!odev)
+        for (int c = 0; c < n_cols; c++) {
+            TSQ_HIP(h, hipMemcpyAsync(out_cols[c].data, g.dst[c], (size_t)n * g.es[c], hipMemcpyDeviceToHost, ctx->stream));
+            TSQ_HIP(h, hipMemcpyAsync(out_cols[c].null_bitmap, g.dst_bitmap[c], tsq_bitmap_bytes(n), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < n_cols; c++) {
+        out_cols[c].length = n;
+        out_cols[c].type = s->cfg.col_types[c];
+        out_cols[c].elem_size = g.es[c];
+    }
+    s->cursor += n;
+    *nrows_out = n;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_sort_stats(tsq_sort* s, int64_t* rows, int32_t* passes, int32_t* passes_skipped, double* sort_kernel_ms) {
+    if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return TSQ_ERR_INVALID;
+    if (rows) *rows = s->n;
+    if (passes) *passes = s->passes;
+    if (passes_skipped) *passes_skipped = s->passes_skipped;
+    if (sort_kernel_ms) *sort_kernel_ms = s->sort_ms;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_sort_cancel(tsq_sort* s) {
+    if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return TSQ_ERR_INVALID;
+    s->cancelled.store(1);
+    return TSQ_OK;
+}
+
+TSQ_API void tsq_sort_destroy(tsq_sort* s) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(s, TSQ_MAGIC_SORT));
+    if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    for (auto& c : s->cols) c.release();
+    s->stage.release();
+    for (int i = 0; i < 2; i++) { s->img[i].release(); s->idx[i].release(); if (s->ev[i]) (void)hipEventDestroy(s->ev[i]); }
+    s->hist.release();
+    s->totals.release();
+    s->count8.release();
+    for (auto& b : s->odata) b.release();
+    for (auto& b : s->obm) b.release();
+    s->hdr.magic = 0;
+    delete s;
+}

@@ -323,3 +323,57 @@ class ProjectionExec(Executor):
             ce.close()
         self.compiled = []
         super().Close()
+
+
+class SortExec(Executor):
+    """GPU SortExec (replaces executor/sort.go:27-144): ORDER BY over bare columns, each ascending or descending."""
+
+    def __init__(self, ctx, child, by_cols, by_desc, max_chunk_size=1024, offset=0, count=-1):
+        super().__init__(ctx, child.Schema(), (child,), max_chunk_size)
+        self.lib = ctx.lib
+        cfg = abi.SortCfg()
+        cfg.n_cols = len(self.types)
+        for i, t in enumerate(self.types):
+            cfg.col_types[i] = t
+        cfg.n_keys = len(by_cols)
+        for i, (c, d) in enumerate(zip(by_cols, by_desc)):
+            cfg.key_col[i], cfg.key_desc[i] = c, 1 if d else 0
+        cfg.limit_offset, cfg.limit_count, cfg.max_chunk_size = offset, count, max_chunk_size
+        self.cfg, self.h, self.fetched = cfg, None, False
+
+    def Open(self):
+        super().Open()
+        h = C.c_void_p()
+        _lib.check(self.lib.tsq_sort_create(self.ctx.h, C.byref(self.cfg), C.byref(h)), self.ctx.h)
+        self.h, self.fetched = h, False
+
+    def Next(self):
+        if not self.fetched:  # fetchRowChunks (sort.go:80-97), then the sort
+            while True:
+                chk = self.children[0].Next()
+                if chk.NumRows() == 0:
+                    break
+                keep = []
+                cols = make_cols(chk.columns, keep)
+                _lib.check(self.lib.tsq_sort_push(self.h, cols, len(chk.columns), chk.NumRows()), self.h)
+            _lib.check(self.lib.tsq_sort_finish(self.h), self.h)
+            self.fetched = True
+        keep = []
+        out, bufs = out_buffers(self.types, self.max_chunk_size, keep)
+        n, eos = C.c_int64(0), C.c_int32(0)
+        _lib.check(self.lib.tsq_sort_pull(self.h, out, len(self.types), self.max_chunk_size, C.byref(n), C.byref(eos)), self.h)
+        return chunk_from_buffers(self.types, bufs, n.value) if n.value else self.empty()
+
+    def Close(self):
+        if self.h:
+            self.lib.tsq_sort_cancel(self.h)
+            self.lib.tsq_sort_destroy(self.h)
+            self.h = None
+        super().Close()
+
+
+class TopNExec(SortExec):
+    """GPU TopNExec (replaces executor/sort.go:146-318): rows [offset, offset + count) of the ORDER BY order."""
+
+    def __init__(self, ctx, child, by_cols, by_desc, offset, count, max_chunk_size=1024):
+        super().__init__(ctx, child, by_cols, by_desc, max_chunk_size, offset=offset, count=count)
