@@ -10,8 +10,8 @@
 // as is; reals: the memcomparable image of the double, float32 widened like cmpFloat32; DESC: image inverted), then
 // one pass on the NULL flag (NULL is smaller than every value, cmpNull compare.go:48-56; DESC puts it last).
 //   K14a k_sort_image    : image[i] = f(column[row_id[i]]) for the key column being processed
-//   K14b k_sort_count8   : all eight digit histograms of the images in one read -> passes whose digit is the same for
-//                          every row are skipped (day numbers, small ints: 2-3 passes instead of 8)
+//                          + the OR and the AND of all images -> passes whose digit is the same for every row are
+//                          skipped (day numbers, small ints: 2-3 passes instead of 8)
 //   K14c k_sort_tilehist : per 4096-row tile digit histogram            (one pass = K14c + K14d + K14e)
 //   K14d k_sort_scan     : digit-major exclusive scan (one workgroup per digit, then the 256 digit totals)
 //   K14e k_sort_scatter  : stable ranks without atomics — every wave owns a contiguous quarter of the tile, matches equal
@@ -63,7 +63,7 @@ struct SortArgs {
     int64_t ntiles;
     uint32_t* hist;          // [256][ntiles]
     uint32_t* totals;        // [256] row totals, then exclusive bases
-    unsigned long long* count8;  // [8][256]
+    unsigned long long* orand;   // [0] = OR of all images, [1] = AND
 };
 
 __device__ __forceinline__ uint32_t sort_digit(const SortArgs& a, uint64_t img, uint32_t row) {
@@ -72,29 +72,27 @@ __device__ __forceinline__ uint32_t sort_digit(const SortArgs& a, uint64_t img, 
     return a.key.desc ? 1u - notnull : notnull;  // ASC: NULL first; DESC: NULL last (sort.go:121-123 negates cmpNull)
 }
 
+// Also reduces the bitwise OR and AND of all images (orand[0], orand[1]): byte d is the same in every row exactly when
+// the two agree on it, and then the pass on digit d would not move anything.  (Eight digit histograms for the same
+// decision cost 2 ms per 1e8 rows in LDS atomics.)
 __global__ void __launch_bounds__(256) k_sort_image(SortArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long vor = 0, vand = ~0ull;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
         const uint32_t row = a.idx_in ? a.idx_in[i] : (uint32_t)i;
-        a.img_out[i] = sort_image(a.key, row);
+        const uint64_t v = sort_image(a.key, row);
+        a.img_out[i] = v;
+        vor |= v;
+        vand &= v;
         if (!a.idx_in) a.idx_out[i] = (uint32_t)i;
     }
-}
-
-__global__ void __launch_bounds__(256) k_sort_count8(SortArgs a) {
-    __shared__ uint32_t s_h[8][256];
-    for (int i = threadIdx.x; i < 8 * 256; i += 256) (&s_h[0][0])[i] = 0;
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-        const uint64_t v = a.img_in[i];
-#pragma unroll
-        for (int d = 0; d < 8; d++) atomicAdd(&s_h[d][(v >> (8 * d)) & 255u], 1u);
+    for (int o = 32; o; o >>= 1) {
+        vor |= __shfl_xor(vor, o, 64);
+        vand &= __shfl_xor(vand, o, 64);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 8 * 256; i += 256) {
-        const uint32_t c = (&s_h[0][0])[i];
-        if (c) atomicAdd(&a.count8[i], (unsigned long long)c);
+    if ((threadIdx.x & 63) == 0) {
+        atomicOr(&a.orand[0], vor);
+        atomicAnd(&a.orand[1], vand);
     }
 }
 
@@ -400,15 +398,15 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
     }
     TSQ_TRY(s->hist.reserve(ctx, h, (size_t)a.ntiles * 256 * 4 + 64));
     TSQ_TRY(s->totals.reserve(ctx, h, 256 * 4));
-    TSQ_TRY(s->count8.reserve(ctx, h, 8 * 256 * 8));
+    TSQ_TRY(s->count8.reserve(ctx, h, 64));
     a.hist = s->hist.as<uint32_t>();
     a.totals = s->totals.as<uint32_t>();
-    a.count8 = s->count8.as<unsigned long long>();
+    a.orand = s->count8.as<unsigned long long>();
     TSQ_HIP(h, hipEventRecord(s->ev[0], ctx->stream));
     s->cur = 0;
     bool have_idx = false;
     PinnedBuf hcount;
-    TSQ_TRY(hcount.reserve(h, 8 * 256 * 8));
+    TSQ_TRY(hcount.reserve(h, 64));
     const int egrid = tsq_grid_for(ctx, n, 256, 4);
     for (int k = s->cfg.n_keys - 1; k >= 0; k--) {  // least significant ORDER BY item first
         tsq_status st = sort_cancelled(s);
@@ -422,21 +420,20 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
         a.idx_in = have_idx ? s->idx[s->cur].as<uint32_t>() : nullptr;
         a.img_out = s->img[s->cur].as<uint64_t>();
         a.idx_out = s->idx[s->cur].as<uint32_t>();
-        hipLaunchKernelGGL(k_sort_image, dim3(egrid), dim3(256), 0, ctx->stream, a);
+        ((unsigned long long*)hcount.p)[0] = 0;
+        ((unsigned long long*)hcount.p)[1] = ~0ull;
+        hipError_t e = hipMemcpyAsync(s->count8.p, hcount.p, 16, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_sort_image, dim3(egrid), dim3(256), 0, ctx->stream, a);
+            e = hipMemcpyAsync((char*)hcount.p + 16, s->count8.p, 16, hipMemcpyDeviceToHost, ctx->stream);
+        }
         have_idx = true;
         a.img_in = s->img[s->cur].as<uint64_t>();
-        hipError_t e = hipMemsetAsync(s->count8.p, 0, 8 * 256 * 8, ctx->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_sort_count8, dim3(std::min(egrid, ctx->num_cus * 4)), dim3(256), 0, ctx->stream, a);
-            e = hipMemcpyAsync(hcount.p, s->count8.p, 8 * 256 * 8, hipMemcpyDeviceToHost, ctx->stream);
-        }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { hcount.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("sort: ") + hipGetErrorString(e)); }
-        const unsigned long long* c8 = (const unsigned long long*)hcount.p;
+        const unsigned long long differ = ((const unsigned long long*)hcount.p)[2] ^ ((const unsigned long long*)hcount.p)[3];  // OR ^ AND
         for (int d = 0; d < 8; d++) {
-            bool trivial = false;  // every row has the same digit: the pass would not move anything
-            for (int b = 0; b < 256; b++) trivial |= c8[d * 256 + b] == (unsigned long long)n;
-            if (trivial) { s->passes_skipped++; continue; }
+            if (((differ >> (8 * d)) & 255ull) == 0) { s->passes_skipped++; continue; }  // every row has the same digit
             st = sort_pass(s, a, d);
             if (st != TSQ_OK) { hcount.release(); return st; }
         }

@@ -12,12 +12,14 @@
 //   HashAggExec         executor/aggregate.go:559-588
 //   SelectionExec       executor/executor.go:346-438
 //   ProjectionExec      executor/projection.go:54-90, expression/evaluator.go:121-133
+//   SortExec / TopNExec executor/sort.go:27-318
 //   Expression          expression/{column,constant,scalar_function}.go, lowered to tsq_expr_prog postfix
 // All compute happens in libtsq (HIP); nothing here touches the oracle and there is no CPU fallback: without a
 // device tsq_ctx_create fails and every constructor throws.
 #ifndef TSQ_HOST_HPP
 #define TSQ_HOST_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -605,6 +607,69 @@ private:
     std::vector<AggFuncDesc> funcs_;
     bool defaultRow_ = false, prepared_ = false, sawInput_ = false, done_ = false;
     tsq_agg* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- SortExec / TopNExec (executor/sort.go:27-318)
+struct ByItem {  // plannercore.ByItems: a bare column and its direction (sort.go:107-113)
+    int col;
+    bool desc;
+};
+class SortExec : public Executor {
+public:
+    SortExec(Context* ctx, Executor* child, std::vector<ByItem> byItems) : SortExec(ctx, child, std::move(byItems), 0, -1) {}
+    ~SortExec() override { destroy(); }
+    void Open() override {
+        Executor::Open();
+        check(tsq_sort_create(ctx_->h, &cfg_, &h_), ctx_->h);
+        fetched_ = false;
+    }
+    void Next(Chunk* req) override {  // sort.go:58-78
+        req->Reset();
+        if (!fetched_) {  // fetchRowChunks (sort.go:80-97), then the sort
+            Chunk chk(children_[0]->schema(), maxChunkSize);
+            for (;;) {
+                children_[0]->Next(&chk);
+                if (chk.NumRows() == 0) break;
+                auto v = chk.Views();
+                check(tsq_sort_push(h_, v.data(), (int32_t)v.size(), chk.NumRows()), h_);
+            }
+            check(tsq_sort_finish(h_), h_);
+            fetched_ = true;
+        }
+        const int64_t cap = req->requiredRows;
+        for (auto& c : req->columns) c.resizeFor(cap);
+        std::vector<tsq_col> out;
+        for (auto& c : req->columns) out.push_back(c.View(cap));
+        int64_t n = 0;
+        int32_t eos = 0;
+        check(tsq_sort_pull(h_, out.data(), (int32_t)out.size(), cap, &n, &eos), h_);
+        for (auto& c : req->columns) c.truncate(n);
+    }
+    void Close() override { destroy(); Executor::Close(); }
+protected:
+    SortExec(Context* ctx, Executor* child, std::vector<ByItem> byItems, int64_t offset, int64_t count) : Executor(ctx, child->schema(), {child}) {
+        memset(&cfg_, 0, sizeof cfg_);
+        if (byItems.empty() || byItems.size() > TSQ_MAX_KEYS) throw Error(TSQ_ERR_UNSUPPORTED, "1..4 ORDER BY items supported");
+        cfg_.n_cols = (int32_t)schema_.size();
+        for (size_t i = 0; i < schema_.size(); i++) cfg_.col_types[i] = schema_[i];
+        cfg_.n_keys = (int32_t)byItems.size();
+        for (size_t i = 0; i < byItems.size(); i++) { cfg_.key_col[i] = byItems[i].col; cfg_.key_desc[i] = byItems[i].desc ? 1 : 0; }
+        cfg_.limit_offset = offset;
+        cfg_.limit_count = count;
+        cfg_.max_chunk_size = 1024;
+    }
+private:
+    void destroy() {
+        if (h_) { tsq_sort_cancel(h_); tsq_sort_destroy(h_); h_ = nullptr; }
+    }
+    tsq_sort_cfg cfg_;
+    tsq_sort* h_ = nullptr;
+    bool fetched_ = false;
+};
+class TopNExec : public SortExec {  // rows [Offset, Offset + Count) of the order (sort.go:213-238)
+public:
+    TopNExec(Context* ctx, Executor* child, std::vector<ByItem> byItems, uint64_t offset, uint64_t count)
+        : SortExec(ctx, child, std::move(byItems), (int64_t)offset, (int64_t)std::min<uint64_t>(count, (uint64_t)INT64_MAX)) {}
 };
 
 }  // namespace tsqhost

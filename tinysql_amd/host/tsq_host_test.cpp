@@ -220,6 +220,46 @@ int main() {
         HashAggExec agg(&ctx, &j, {2}, {{TSQ_AGG_FIRSTROW, 2, TSQ_I64}, {TSQ_AGG_COUNT, -1, TSQ_I64}, {TSQ_AGG_SUM, 1, TSQ_I64}});
         expect_true("Selection -> HashJoin -> HashAgg over 49 + 3 chunks equals a std::map restatement", render(Drain(&agg)) == [&] { std::sort(wr.begin(), wr.end()); return wr; }());
     }
+    // ---- executor/union_scan_test.go:31-35: ORDER BY rows (ordered comparison: no sorting of the rendered rows here)
+    {
+        auto ordered = [](const std::vector<Chunk>& chunks) {
+            Rows out;
+            for (auto& chk : chunks)
+                for (int64_t r = 0; r < chk.NumRows(); r++) {
+                    std::string s;
+                    for (int c = 0; c < chk.NumCols(); c++) s += (c ? " " : "") + cell(chk.columns[c], r);
+                    out.push_back(s);
+                }
+            return out;
+        };
+        Chunk t = table_i64(2, {1, 5, 2, 3, 3, 4, 4, 8, 6, 8, 7, 6});
+        {
+            MockDataSource src(&ctx, t);
+            SortExec so(&ctx, &src, {{0, true}});
+            expect_true("union_scan_test.go:33 order by a desc", ordered(Drain(&so)) == Rows{"7 6", "6 8", "4 8", "3 4", "2 3", "1 5"});
+        }
+        {
+            MockDataSource src(&ctx, t);
+            SortExec so(&ctx, &src, {{1, false}, {0, false}});
+            expect_true("union_scan_test.go:34 order by b, a", ordered(Drain(&so)) == Rows{"2 3", "3 4", "1 5", "7 6", "4 8", "6 8"});
+        }
+        {
+            MockDataSource src(&ctx, t);
+            SortExec so(&ctx, &src, {{1, true}, {0, true}});
+            expect_true("union_scan_test.go:35 order by b desc, a desc", ordered(Drain(&so)) == Rows{"6 8", "4 8", "7 6", "1 5", "3 4", "2 3"});
+        }
+        {
+            MockDataSource src(&ctx, t);
+            TopNExec top(&ctx, &src, {{1, true}, {0, true}}, 2, 1);
+            expect_true("distsql_test.go:158 shape: order by b desc limit 2,1", ordered(Drain(&top)) == Rows{"7 6"});
+        }
+        {   // NULL is the smallest value (compare.go:48-56); executor_test.go:504: limit 18446744073709551615 = no limit
+            Chunk n = table_i64(1, {3, NIL, -7, NIL, 0});
+            MockDataSource src(&ctx, n);
+            TopNExec top(&ctx, &src, {{0, false}}, 0, UINT64_MAX);
+            expect_true("compare.go:48-56 NULLs first; executor_test.go:504 max limit", ordered(Drain(&top)) == Rows{"<nil>", "<nil>", "-7", "0", "3"});
+        }
+    }
     printf("%d passed, %d failed\n", g_pass, g_fail);
     return g_fail ? 1 : 0;
 }
