@@ -153,6 +153,9 @@ struct ProbeArgs {
     int64_t rows_per_block;
     // emit only: joined rows as (probe row | build row << 32) pairs, build row 0xffffffff = no match (outer join)
     unsigned long long* pairs;
+    // sizing pass -> emit pass: per probe row (first joined build row | output rows << 32).  A probe row with one output
+    // row (the common case) is emitted from this word alone; only rows with several matches walk the table again.
+    unsigned long long* first_cnt;
 };
 
 // probe-side eligibility of row k: selected && outer filter && non-NULL key (join.go:344)
@@ -238,6 +241,8 @@ __device__ __forceinline__ void for_each_match(const ProbeArgs& a, int64_t k, ui
     });
 }
 
+#define TSQ_PAIR_MISS 0xffffffffu
+
 // K3 — COUNT(*) probe (+ optional fused row checksum).  Replaces the per-row loop of join2Chunk
 // (executor/join.go:343-360) + GetMatchedRows (hash_table.go:110-134) when no row is materialised.
 // Fast path (inner join, single key, no filters): reads 8 B of probe key + one 64 B table line.
@@ -253,14 +258,15 @@ __global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
     const int64_t k_step = chunked ? (int64_t)blockDim.x : stride;
     for (int64_t k = k_first; k < k_last; k += k_step) {
         uint64_t kw = 0;
-        uint32_t c = 0;
+        uint32_t c = 0, first = TSQ_PAIR_MISS;
         if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0)) {
-            if (!MULTI && !GEN && !CHK) {
+            if (!MULTI && !GEN && !CHK && !a.first_cnt) {
                 // leanest form: keys only, never touches vals
                 if (kw == TSQ_EMPTY_KEY) c = a.t.sent_count;
                 else for_each_slot(a.t, kw, [&](uint64_t) { c++; });
             } else {
                 for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) {
+                    if (c == 0) first = brow;
                     c++;
                     if (CHK) {
                         uint64_t h = joined_rowhash(a, k, (int64_t)brow);
@@ -278,6 +284,7 @@ __global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
                 cxor ^= h;
             }
         }
+        if (a.first_cnt) a.first_cnt[k] = (unsigned long long)first | ((unsigned long long)c << 32);  // coalesced
         cnt += c;
     }
     cnt = wave_sum_u64(cnt);
@@ -309,7 +316,6 @@ __global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
 // loads per column one after the other (1.4 ms for 8 M probe rows -> 0.8 M x 10 columns).  In K4b every lane is
 // active, the eight gathers of a thread are independent, the stores are 64 contiguous bytes per thread, and the
 // null bitmap byte of the eight rows is written directly (no byte flags + pack pass).
-#define TSQ_PAIR_MISS 0xffffffffu
 __device__ __forceinline__ void write_pair(const ProbeArgs& a, uint64_t pos, int64_t k, uint32_t brow) {
     a.pairs[pos] = (unsigned long long)(uint32_t)k | ((unsigned long long)brow << 32);
 }
@@ -386,7 +392,6 @@ __global__ void __launch_bounds__(256) k_gather_cols(GatherArgs a) {
 template <bool MULTI, bool GEN>
 __global__ void __launch_bounds__(256) k_probe_emit(ProbeArgs a) {
     __shared__ unsigned long long s_cur;
-    const bool outer = a.join_type != TSQ_JOIN_INNER;
     uint64_t errw = TSQ_ERRWORD_NONE;
     uint32_t div0 = 0;
     const int64_t k_begin = (int64_t)blockIdx.x * a.rows_per_block;
@@ -397,39 +402,25 @@ __global__ void __launch_bounds__(256) k_probe_emit(ProbeArgs a) {
     __syncthreads();
     for (int64_t k = k_begin + threadIdx.x; k < k_round; k += blockDim.x) {
         const bool active = k < k_last;
-        uint64_t kw = 0;
-        bool valid = false;
-        uint32_t c = 0;
-        uint32_t first = 0;  // first matching build row: written by all lanes together, not inside the divergent slot walk
-        if (active) {
-            valid = probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0);
-            if (valid) for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) {
-                if (c == 0) first = brow;
-                c++;
-            });
-        }
-        const bool miss = active && outer && c == 0;
-        uint32_t n_out = c + (miss ? 1u : 0u), total;
+        // what the sizing pass found for this probe row: no second walk of the table for rows with one output row
+        const unsigned long long fc = active ? a.first_cnt[k] : 0ull;
+        const uint32_t first = (uint32_t)fc, n_out = (uint32_t)(fc >> 32);
+        uint32_t total;
         uint32_t prefix = wave_excl_scan_u32(n_out, &total);
         unsigned long long base = 0;
         if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(&s_cur, (unsigned long long)total);  // LDS cursor of this workgroup
         base = __shfl(base, 0, 64);
         uint64_t pos = base + prefix;
-        // The common case (one match per probe row, e.g. a foreign key probing a primary key) is ONE convergent store
-        // per wave, outside the divergent slot walk.
-        if (c) write_pair(a, pos, k, first);
-        else if (miss) write_pair(a, pos, k, TSQ_PAIR_MISS);
-        if (c > 1) {  // duplicates: the remaining matches, in walk order
-            uint32_t dummy_d0 = 0, seen = 0;
-            uint64_t dummy_err = TSQ_ERRWORD_NONE;
-            for_each_match<MULTI, GEN>(a, k, kw, dummy_err, dummy_d0, [&](uint32_t brow) {
-                if (seen++) write_pair(a, pos + seen - 1, k, brow);
-            });
+        if (n_out) write_pair(a, pos, k, first);  // the first match, or the NULL-padded row of an outer join (first = MISS)
+        if (n_out > 1) {  // duplicates: the remaining matches, in walk order (same filters / conditions as the sizing pass,
+                          // whose errors and warnings were reported there)
+            uint64_t kw = 0;
+            uint32_t seen = 0;
+            if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0))
+                for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) {
+                    if (seen++) write_pair(a, pos + seen - 1, k, brow);
+                });
         }
-    }
-    if (GEN) {
-        if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[3], (unsigned long long)errw);
-        if (div0) atomicAdd(&a.counters[4], (unsigned long long)div0);
     }
 }
 
@@ -516,6 +507,7 @@ struct tsq_join {
     DevBuf rkeys, rctl, rvend, rovf;  // partitioned keys | cursor + queue heads + overflow count | valid_end | overflow keys
     DevBuf bbase;                     // per-workgroup output bases of the materialising probe
     DevBuf pairs;                     // (probe row, build row) of every joined row of the current slice
+    DevBuf firstcnt;                  // per probe row of the slice: first joined build row | output rows << 32
     static constexpr int RING = 32;   // HIP events of the most recent radix batches: [slot][0..2] = start, after partition, end
     hipEvent_t rev[RING][3] = {};
 
@@ -745,7 +737,9 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     // emit mode: size the batch first (K3), then materialise (K4); both walk contiguous rows per workgroup
     const int egrid = tsq_grid_for(ctx, nrows, 256);
     TSQ_TRY(j->bbase.reserve(ctx, &j->hdr, (size_t)egrid * 8 + 64));
+    TSQ_TRY(j->firstcnt.reserve(ctx, &j->hdr, (size_t)nrows * 8 + 64));
     a.block_base = j->bbase.as<unsigned long long>();
+    a.first_cnt = j->firstcnt.as<unsigned long long>();
     a.rows_per_block = (((nrows + egrid - 1) / egrid) + 63) & ~(int64_t)63;
     unsigned long long before[8], after[8];
     TSQ_TRY(read_counters(j, before));
@@ -793,6 +787,17 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         gc.dst_bitmap = may_null ? rb->bitmap[oc].as<uint8_t>() : nullptr;
         gc.es = tsq_elem_size(type);
         gc.from_probe = from_probe ? 1 : 0;
+        // The build-side key of an inner join on one integer column of the same type IS the probe key (same flag, same 8
+        // bytes: codec.go:212-240): copy it from the probe column — consecutive rows — instead of gathering it through the
+        // build row id (a random 8-byte read per joined row, 42 G/s).
+        if (!from_probe && !outer && !j->multi && sc == j->ks.bidx[0]) {
+            const int pkc = j->ks.pidx[0];
+            if (j->cfg.probe_types[pkc] == type && (type == TSQ_I64 || type == TSQ_U64)) {
+                gc.src = a.p.data[pkc];
+                gc.src_nulls = a.p.nulls[pkc];
+                gc.from_probe = 1;
+            }
+        }
     }
     TSQ_TRY(reset_counters(j, true));
     TSQ_TRY(dispatch_emit(j, a));
@@ -1461,6 +1466,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
             if (j->rev[i][e]) (void)hipEventDestroy(j->rev[i][e]);
     j->bbase.release();
     j->pairs.release();
+    j->firstcnt.release();
     j->rkeys.release();
     j->rctl.release();
     j->rvend.release();
