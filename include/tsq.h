@@ -413,6 +413,8 @@ tsq_status tsq_sort_push(tsq_sort* s, const tsq_col* cols, int32_t n_cols, int64
 tsq_status tsq_sort_finish(tsq_sort* s);
 /* out_cols: the input schema; host or TSQ_COL_DEVICE buffers (data + null_bitmap) for cap_rows rows */
 tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows, int64_t* nrows_out, int32_t* eos);
+/* rows = rows that went through the radix passes: all of them for a sort; for a TopN whose Offset + Count is small, only the
+ * candidates kept by the radix select on the first ORDER BY item (ties at the threshold included) */
 tsq_status tsq_sort_stats(tsq_sort* s, int64_t* rows, int32_t* passes, int32_t* passes_skipped, double* sort_kernel_ms);
 tsq_status tsq_sort_cancel(tsq_sort* s);
 void       tsq_sort_destroy(tsq_sort* s);

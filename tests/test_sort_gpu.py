@@ -182,3 +182,25 @@ def test_full_size_sortedness_and_permutation_property(ctx):
     finally:
         for d in (k, v, ok_, ov):
             d.free()
+
+
+@pytest.mark.parametrize("case", ["asc_wide", "desc_nulls", "ties_two_keys", "nulls_cover_the_limit"])
+def test_topn_radix_select_on_large_inputs(ctx, orc, case):
+    # n >= 1 Mi rows and Offset + Count <= n / 16: the K-th key of the first ORDER BY item is found by radix select and only
+    # the candidates (ties at the threshold included, in input order) are sorted; the rows must equal the stable oracle's
+    rng = np.random.default_rng(len(case))
+    n = 1_500_000
+    if case == "asc_wide":
+        chk, keys, off, cnt = Chunk([_rand(rng, n, abi.I64, 0.0, False), Column(abi.I64, np.arange(n))]), ([0], [False]), 10, 1000
+    elif case == "desc_nulls":
+        chk, keys, off, cnt = Chunk([_rand(rng, n, abi.F64, 0.05, False), Column(abi.I64, np.arange(n))]), ([0], [True]), 0, 5000
+    elif case == "ties_two_keys":   # 40 distinct first keys: the threshold bucket holds ~37 K rows, the second key decides
+        chk = Chunk([Column(abi.I64, rng.integers(0, 40, n)), Column(abi.F64, rng.integers(0, 1000, n) / 8.0), Column(abi.I64, np.arange(n))])
+        keys, off, cnt = ([0, 1], [False, True]), 100, 2000
+    else:                           # ASC with 20 % NULLs: the first 30 000 rows of the order are all NULL keys (ties, input order)
+        chk, keys, off, cnt = Chunk([_rand(rng, n, abi.I64, 0.2, False), Column(abi.I64, np.arange(n))]), ([0], [False]), 0, 30_000
+    stats = []
+    got = G.run_sort(ctx, chk, *keys, chunk_rows=1 << 20, pull_rows=1 << 16, offset=off, count=cnt, stats_out=stats)
+    want = orc.sort_rows(chk, *keys).slice(off, off + cnt)
+    _same_rows(got, want)
+    assert got.NumRows() == cnt and stats[0]["rows"] < n // 2

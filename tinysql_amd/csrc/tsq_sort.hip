@@ -214,6 +214,98 @@ __global__ void __launch_bounds__(TSQ_SORT_NT) k_sort_scatter(SortArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- TopN: radix select before the sort
+// TopNExec needs rows [Offset, Offset + Count) of the order only (sort.go:213-238; a heap there).  With K = Offset + Count
+// much smaller than the input, the K-th smallest key of the FIRST ORDER BY item is found by a most-significant-digit radix
+// select on (NULL flag, image) — one 256-bin histogram pass per digit over the rows that still match the decided prefix,
+// no data movement — until the bucket that holds rank K is small; the rows whose key is <= that bucket (a superset of
+// the answer, ties included) are compacted IN INPUT ORDER (so that ties stay stable) and only they are sorted.
+struct SelArgs {
+    SortKeySrc key;
+    int64_t n;
+    const uint64_t* img;        // images of the first ORDER BY item, identity order
+    uint64_t mask, val;         // decided high digits of the threshold: candidates match (img & mask) == val at this level
+    int32_t digit;              // 8: histogram of the NULL-flag level (2 bins); 0..7: histogram of that byte
+    int32_t null_level;         // level of the threshold on the NULL flag (0 or 1), -1: the column has no NULLs
+    unsigned long long* hist;   // [256]
+    unsigned long long* block_cnt;  // per-workgroup candidate counts -> exclusive bases (compaction)
+    int64_t rows_per_block;
+    uint32_t* idx_out;
+};
+__device__ __forceinline__ uint32_t sel_null_level(const SelArgs& a, int64_t i) {
+    const uint32_t notnull = (a.key.nulls[i >> 3] >> (i & 7)) & 1u;
+    return a.key.desc ? 1u - notnull : notnull;
+}
+__global__ void __launch_bounds__(256) k_select_hist(SelArgs a) {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        if (a.digit == 8) {
+            atomicAdd(&s_h[sel_null_level(a, i)], 1u);
+        } else {
+            if (a.null_level >= 0 && sel_null_level(a, i) != (uint32_t)a.null_level) continue;
+            const uint64_t v = a.img[i];
+            if ((v & a.mask) != a.val) continue;
+            atomicAdd(&s_h[(v >> (8 * a.digit)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&a.hist[threadIdx.x], (unsigned long long)s_h[threadIdx.x]);
+}
+// candidate: key <= threshold bucket, i.e. NULL level below the threshold's, or the same level and decided digits <= val
+__device__ __forceinline__ bool sel_is_candidate(const SelArgs& a, int64_t i) {
+    if (a.null_level >= 0) {
+        const uint32_t lv = sel_null_level(a, i);
+        if (lv != (uint32_t)a.null_level) return lv < (uint32_t)a.null_level;
+    }
+    return (a.img[i] & a.mask) <= a.val;
+}
+__global__ void __launch_bounds__(256) k_select_count(SelArgs a) {
+    __shared__ unsigned int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * a.rows_per_block;
+    const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+    unsigned int c = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) c += sel_is_candidate(a, i) ? 1u : 0u;
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_n, c);
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_cnt[blockIdx.x] = s_n;
+}
+__global__ void __launch_bounds__(1024) k_select_scan(unsigned long long* v, int n, unsigned long long* total) {
+    __shared__ uint32_t s_wsum[16];
+    const int per = (n + 1023) / 1024, lo = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (int i = lo; i < lo + per && i < n; i++) sum += (uint32_t)v[i];
+    uint32_t tot;
+    uint32_t run = block_excl_scan<1024>(sum, s_wsum, &tot);
+    for (int i = lo; i < lo + per && i < n; i++) {
+        const uint32_t c = (uint32_t)v[i];
+        v[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) *total = tot;
+}
+// order-preserving: a workgroup walks its contiguous rows 256 at a time, positions by block scan of the flags
+__global__ void __launch_bounds__(256) k_select_scatter(SelArgs a) {
+    __shared__ uint32_t s_wsum[4];
+    const int64_t lo = (int64_t)blockIdx.x * a.rows_per_block;
+    const int64_t hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+    uint32_t base = (uint32_t)a.block_cnt[blockIdx.x];
+    for (int64_t i0 = lo; i0 < hi; i0 += 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const uint32_t f = (i < hi && sel_is_candidate(a, i)) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan<256>(f, s_wsum, &tot);
+        if (f) a.idx_out[base + ex] = (uint32_t)i;
+        base += tot;
+        __syncthreads();
+    }
+}
+
 struct GatherRowsArgs {
     const uint32_t* idx;  // row ids, already offset to the first wanted row
     int64_t rows;
@@ -270,6 +362,7 @@ struct tsq_sort {
     int cur = 0;                                       // which of idx[] holds the final row ids
     std::vector<DevBuf> odata, obm;                    // gather targets for host pulls
     int32_t passes = 0, passes_skipped = 0;
+    int64_t rows_sorted = 0;                           // rows that went through the radix passes (TopN: the selected candidates)
     double sort_ms = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
@@ -396,7 +489,7 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
         TSQ_TRY(s->img[i].reserve(ctx, h, (size_t)n * 8 + 64));
         TSQ_TRY(s->idx[i].reserve(ctx, h, (size_t)n * 4 + 64));
     }
-    TSQ_TRY(s->hist.reserve(ctx, h, (size_t)a.ntiles * 256 * 4 + 64));
+    TSQ_TRY(s->hist.reserve(ctx, h, std::max<size_t>((size_t)a.ntiles * 256 * 4, 4096 + (size_t)ctx->num_cus * 8 * 8) + 64));
     TSQ_TRY(s->totals.reserve(ctx, h, 256 * 4));
     TSQ_TRY(s->count8.reserve(ctx, h, 64));
     a.hist = s->hist.as<uint32_t>();
@@ -406,8 +499,81 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
     s->cur = 0;
     bool have_idx = false;
     PinnedBuf hcount;
-    TSQ_TRY(hcount.reserve(h, 64));
-    const int egrid = tsq_grid_for(ctx, n, 256, 4);
+    TSQ_TRY(hcount.reserve(h, 4096));
+    int egrid = tsq_grid_for(ctx, n, 256, 4);
+    s->rows_sorted = n;
+    const int64_t K = s->last;  // rows of the order that are needed at all
+    if (s->cfg.limit_count >= 0 && n >= (1 << 20) && K * 16 <= n) {
+        // ---- TopN: radix select on the first ORDER BY item, then sort only the candidates (see k_select_hist)
+        const int kc = s->cfg.key_col[0];
+        a.key.data = s->cols[kc].data.p;
+        a.key.nulls = s->cols[kc].has_nulls ? s->cols[kc].nulls.as<uint8_t>() : nullptr;
+        a.key.type = s->cfg.col_types[kc];
+        a.key.desc = s->cfg.key_desc[0] ? 1 : 0;
+        a.idx_in = nullptr;
+        a.img_out = s->img[0].as<uint64_t>();
+        a.idx_out = s->idx[1].as<uint32_t>();  // identity row ids: not needed here
+        hipLaunchKernelGGL(k_sort_image, dim3(egrid), dim3(256), 0, ctx->stream, a);
+        SelArgs sa;
+        memset(&sa, 0, sizeof sa);
+        sa.key = a.key;
+        sa.n = n;
+        sa.img = s->img[0].as<uint64_t>();
+        sa.hist = (unsigned long long*)s->hist.p;
+        sa.null_level = -1;
+        const int sgrid = std::min(egrid, ctx->num_cus * 8);
+        unsigned long long* hh = (unsigned long long*)hcount.p;
+        auto hist_pass = [&](int digit) -> hipError_t {
+            sa.digit = digit;
+            hipError_t e = hipMemsetAsync(sa.hist, 0, 256 * 8, ctx->stream);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_select_hist, dim3(sgrid), dim3(256), 0, ctx->stream, sa);
+            e = hipMemcpyAsync(hh, sa.hist, 256 * 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) return e;
+            return hipStreamSynchronize(ctx->stream);
+        };
+        hipError_t e = hipSuccess;
+        uint64_t rank = (uint64_t)K, bucket = (uint64_t)n;
+        if (sa.key.nulls) {
+            e = hist_pass(8);
+            if (e == hipSuccess) {
+                if (rank <= hh[0]) { sa.null_level = 0; bucket = hh[0]; }
+                else { sa.null_level = 1; rank -= hh[0]; bucket = hh[1]; }
+            }
+        }
+        const uint64_t small = std::max<uint64_t>((uint64_t)K * 4, 1u << 16);
+        for (int d = 7; d >= 0 && e == hipSuccess && bucket > small; d--) {
+            e = hist_pass(d);
+            if (e != hipSuccess) break;
+            uint64_t cum = 0;
+            int b = 0;
+            while (b < 255 && cum + hh[b] < rank) cum += hh[b++];
+            rank -= cum;
+            bucket = hh[b];
+            sa.val |= (uint64_t)b << (8 * d);
+            sa.mask |= 0xffull << (8 * d);
+        }
+        if (e == hipSuccess) {  // order-preserving compaction of the candidates into idx[0]
+            const int cgrid = std::min<int>(ctx->num_cus * 8, (int)((n + 255) / 256));
+            sa.rows_per_block = (((n + cgrid - 1) / cgrid) + 255) & ~(int64_t)255;
+            sa.block_cnt = (unsigned long long*)((char*)s->hist.p + 4096);
+            sa.idx_out = s->idx[0].as<uint32_t>();
+            hipLaunchKernelGGL(k_select_count, dim3(cgrid), dim3(256), 0, ctx->stream, sa);
+            hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, ctx->stream, sa.block_cnt, cgrid, sa.hist);
+            hipLaunchKernelGGL(k_select_scatter, dim3(cgrid), dim3(256), 0, ctx->stream, sa);
+            e = hipMemcpyAsync(hh, sa.hist, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e != hipSuccess) { hcount.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("TopN select: ") + hipGetErrorString(e)); }
+        const int64_t n_cand = (int64_t)hh[0];
+        if (n_cand < K) { hcount.release(); return tsq_fail(h, TSQ_ERR_HIP, "internal: TopN select lost rows"); }
+        a.n = n_cand;
+        a.ntiles = (n_cand + TSQ_SORT_T - 1) / TSQ_SORT_T;
+        egrid = tsq_grid_for(ctx, n_cand, 256, 4);
+        s->rows_sorted = n_cand;
+        s->cur = 0;
+        have_idx = true;
+    }
     for (int k = s->cfg.n_keys - 1; k >= 0; k--) {  // least significant ORDER BY item first
         tsq_status st = sort_cancelled(s);
         if (st != TSQ_OK) { hcount.release(); return st; }
@@ -512,7 +678,7 @@ TSQ_API tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols,
 
 TSQ_API tsq_status tsq_sort_stats(tsq_sort* s, int64_t* rows, int32_t* passes, int32_t* passes_skipped, double* sort_kernel_ms) {
     if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return TSQ_ERR_INVALID;
-    if (rows) *rows = s->n;
+    if (rows) *rows = s->rows_sorted;
     if (passes) *passes = s->passes;
     if (passes_skipped) *passes_skipped = s->passes_skipped;
     if (sort_kernel_ms) *sort_kernel_ms = s->sort_ms;
