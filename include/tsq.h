@@ -291,6 +291,12 @@ tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on);
 #define TSQ_RADIX_OFF     0
 #define TSQ_RADIX_FORCE   1
 tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode);
+/* Ordered output: joined rows come out in probe-row order (the order of the probe pushes and of the rows inside them), the
+ * matches of one probe row in build-row order (the order of the build pushes).  With both children sorted on the join keys
+ * and the OUTER child as probe side this is exactly MergeJoinExec's output order (executor/merge_join.go:257-310: outer
+ * rows in order, each with its inner group in order, NULL-key inner rows skipped :148-156, unmatched outer rows padded for
+ * outer joins) — the GPU operator does not need the inputs to be sorted to produce it.  Pulls then also preserve it. */
+tsq_status tsq_join_set_ordered(tsq_join* j, int32_t on);
 tsq_status tsq_join_cancel(tsq_join* j);
 void       tsq_join_destroy(tsq_join* j);
 

@@ -69,6 +69,8 @@ def load():
                                     C.POINTER(C.c_int64)]
     lib.orc_rowhashmap_put_get.restype = C.c_int64
     lib.orc_rowhashmap_put_get.argtypes = [P, P, C.c_int64, C.c_uint64, P, C.c_int64]
+    lib.orc_merge_join.restype = P
+    lib.orc_merge_join.argtypes = [C.POINTER(abi.JoinCfg), C.POINTER(abi.Col), C.c_int64, C.POINTER(abi.Col), C.c_int64, C.POINTER(C.c_int32)]
     lib.orc_value_size_signed.restype = C.c_int32
     lib.orc_value_size_signed.argtypes = [C.c_int64]
     lib.orc_value_size_unsigned.restype = C.c_int32
@@ -320,3 +322,16 @@ def row_compare(chunk, key_cols, key_desc, i, j):
     kc = (C.c_int32 * len(key_cols))(*key_cols)
     kd = (C.c_int32 * len(key_cols))(*[1 if d else 0 for d in key_desc])
     return lib.orc_row_compare(cols, kc, kd, len(key_cols), i, j)
+
+
+def merge_join(cfg, inner_chunk, outer_chunk):
+    """MergeJoinExec (executor/merge_join.go) over sorted children: rows in outer order, each with its inner group in order."""
+    lib = load()
+    keep = []
+    b = make_cols(inner_chunk.columns, keep)
+    p = make_cols(outer_chunk.columns, keep)
+    st = C.c_int32(0)
+    res = lib.orc_merge_join(C.byref(cfg), b, inner_chunk.NumRows(), p, outer_chunk.NumRows(), C.byref(st))
+    if not res:
+        raise OracleError(st.value)
+    return _result_to_chunk(lib, res)

@@ -940,6 +940,97 @@ orc_result* orc_hash_join(const tsq_join_cfg* cfg, const tsq_col* build_cols, in
     return res;
 }
 
+// MergeJoinExec (executor/merge_join.go:31-373): both children arrive sorted on the join keys; the outer rows are taken in
+// order, the inner table is consumed group by group ("rows with the same key", :93-127, rows with a NULL key skipped
+// :148-156), joinToChunk (:257-310) compares the outer row with the current inner group: greater -> next group, smaller
+// (or filtered out, or no group left) -> onMissMatch, equal -> the outer row joined with every row of the group in order.
+// `build` plays the inner table, `probe` the outer one (cfg->build_is_right tells which child is which; output is
+// left-child columns || right-child columns, joiner.go:145-150).  OtherConditions are not restated here.
+orc_result* orc_merge_join(const tsq_join_cfg* cfg, const tsq_col* inner_cols, int64_t n_inner, const tsq_col* outer_cols,
+                           int64_t n_outer, tsq_status* status) {
+    *status = TSQ_OK;
+    if (cfg->n_other_conds > 0) { *status = TSQ_ERR_UNSUPPORTED; return nullptr; }
+    const int32_t nb = cfg->n_build_cols, np = cfg->n_probe_cols;
+    const bool outerIsRight = !cfg->build_is_right;
+    const int32_t probe_off = outerIsRight ? nb : 0, build_off = outerIsRight ? 0 : np;
+    orc_result* res = new orc_result();
+    res->cols.resize(nb + np);
+    for (int32_t c = 0; c < np; c++) res->cols[probe_off + c].type = cfg->probe_types[c];
+    for (int32_t c = 0; c < nb; c++) res->cols[build_off + c].type = cfg->build_types[c];
+    std::vector<uint8_t> selected(n_outer, 1), nulls;  // mergeJoinOuterTable.filter (:356-372)
+    if (cfg->n_outer_filters > 0) {
+        int64_t w = 0;
+        tsq_status st = vec_eval_bool(cfg->outer_filters, cfg->n_outer_filters, outer_cols, np, n_outer, nullptr, selected, nulls, &w);
+        if (st != TSQ_OK) { *status = st; delete res; return nullptr; }
+    }
+    // chunk.CompareFunc per key (compare.go:27-103) through expression.GetCmpFunction: NULL smallest, then by value
+    auto cmp_cell = [&](const tsq_col& a, int64_t i, const tsq_col& b, int64_t j) -> int {
+        const bool an = col_is_null(a, i), bn = col_is_null(b, j);
+        if (an || bn) return (an && bn) ? 0 : (an ? -1 : 1);
+        const bool areal = a.type == TSQ_F32 || a.type == TSQ_F64, breal = b.type == TSQ_F32 || b.type == TSQ_F64;
+        if (areal || breal) {
+            const double x = a.type == TSQ_F32 ? (double)((const float*)a.data)[i] : (a.type == TSQ_F64 ? ((const double*)a.data)[i] : (double)((const int64_t*)a.data)[i]);
+            const double y = b.type == TSQ_F32 ? (double)((const float*)b.data)[j] : (b.type == TSQ_F64 ? ((const double*)b.data)[j] : (double)((const int64_t*)b.data)[j]);
+            return x < y ? -1 : (x == y ? 0 : 1);
+        }
+        const uint64_t x = ((const uint64_t*)a.data)[i], y = ((const uint64_t*)b.data)[j];
+        const bool au = a.type == TSQ_U64, bu = b.type == TSQ_U64;
+        if (au == bu) return au ? (x < y ? -1 : x > y) : ((int64_t)x < (int64_t)y ? -1 : (int64_t)x > (int64_t)y);
+        if (!au) return (int64_t)x < 0 ? -1 : (x < y ? -1 : x > y);   // signed vs unsigned (types.CompareInt)
+        return (int64_t)y < 0 ? 1 : (x < y ? -1 : x > y);
+    };
+    auto cmp_keys = [&](int64_t orow, int64_t irow) {
+        for (int k = 0; k < cfg->n_keys; k++) {
+            const int c = cmp_cell(outer_cols[cfg->probe_key_idx[k]], orow, inner_cols[cfg->build_key_idx[k]], irow);
+            if (c) return c;
+        }
+        return 0;
+    };
+    auto inner_has_null = [&](int64_t r) {
+        for (int k = 0; k < cfg->n_keys; k++)
+            if (col_is_null(inner_cols[cfg->build_key_idx[k]], r)) return true;
+        return false;
+    };
+    auto emit = [&](int64_t prow, int64_t brow) {
+        for (int32_t c = 0; c < np; c++) append_cell(res->cols[probe_off + c], outer_cols[c], prow);
+        for (int32_t c = 0; c < nb; c++) append_cell(res->cols[build_off + c], inner_cols[c], brow);
+        res->rows++;
+    };
+    auto on_miss = [&](int64_t prow) {
+        if (cfg->join_type == TSQ_JOIN_INNER) return;
+        for (int32_t c = 0; c < np; c++) append_cell(res->cols[probe_off + c], outer_cols[c], prow);
+        for (int32_t c = 0; c < nb; c++) res->cols[build_off + c].append_raw(0, false);
+        res->rows++;
+    };
+    // rowsWithSameKey (:93-127): [g0, g1) = the current inner group among the rows without a NULL key
+    std::vector<int64_t> inner;
+    for (int64_t r = 0; r < n_inner; r++)
+        if (!inner_has_null(r)) inner.push_back(r);
+    size_t g0 = 0, g1 = 0;
+    auto next_group = [&]() {
+        g0 = g1;
+        if (g0 >= inner.size()) return;
+        g1 = g0 + 1;
+        while (g1 < inner.size()) {
+            bool same = true;
+            for (int k = 0; k < cfg->n_keys && same; k++)
+                same = cmp_cell(inner_cols[cfg->build_key_idx[k]], inner[g1], inner_cols[cfg->build_key_idx[k]], inner[g0]) == 0;
+            if (!same) break;
+            g1++;
+        }
+    };
+    next_group();
+    for (int64_t o = 0; o < n_outer;) {  // joinToChunk (:257-310)
+        int c = -1;
+        if (selected[o] && g0 < inner.size()) c = cmp_keys(o, inner[g0]);
+        if (c > 0) { next_group(); continue; }
+        if (c < 0) { on_miss(o); o++; continue; }
+        for (size_t g = g0; g < g1; g++) emit(o, inner[g]);
+        o++;
+    }
+    return res;
+}
+
 int64_t orc_hash_join_timed(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build,
                             const tsq_col* probe_cols, int64_t n_probe, int32_t threads, double* build_ms,
                             double* probe_ms, uint64_t* sum_out, uint64_t* xor_out) {

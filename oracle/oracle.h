@@ -96,6 +96,11 @@ tsq_status orc_filter_eval(const tsq_expr_prog* progs, int32_t n_progs, const ts
 int64_t orc_rowhashmap_put_get(const uint64_t* keys, const uint64_t* ptrs, int64_t n,
                                uint64_t probe_key, uint64_t* out_ptrs, int64_t cap);
 
+/* MergeJoinExec (executor/merge_join.go:31-373) over sorted children: outer rows in order, each with its inner group in
+ * order; `build` = inner table, `probe` = outer table of cfg.  OtherConditions -> TSQ_ERR_UNSUPPORTED. */
+orc_result* orc_merge_join(const tsq_join_cfg* cfg, const tsq_col* inner_cols, int64_t n_inner, const tsq_col* outer_cols,
+                           int64_t n_outer, tsq_status* status);
+
 /* ---- coprocessor-response row codec (codec_rows.cpp; SURVEY.md §8 f rank 2) */
 int32_t orc_value_size_signed(int64_t v);    /* valueSizeOfSignedInt, util/codec/codec.go:156-165 */
 int32_t orc_value_size_unsigned(uint64_t v); /* valueSizeOfUnsignedInt, codec.go:178-187 */

@@ -161,6 +161,7 @@ SIGNATURES = {
     "tsq_join_count": (C.c_int32, [P, C.POINTER(C.c_int64)]),
     "tsq_join_checksum": (C.c_int32, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "tsq_join_set_checksum": (C.c_int32, [P, C.c_int32]),
+    "tsq_join_set_ordered": (C.c_int32, [P, C.c_int32]),
     "tsq_join_set_radix": (C.c_int32, [P, C.c_int32]),
     "tsq_join_cancel": (C.c_int32, [P]),
     "tsq_join_destroy": (None, [P]),

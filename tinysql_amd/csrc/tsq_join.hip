@@ -156,6 +156,9 @@ struct ProbeArgs {
     // sizing pass -> emit pass: per probe row (first joined build row | output rows << 32).  A probe row with one output
     // row (the common case) is emitted from this word alone; only rows with several matches walk the table again.
     unsigned long long* first_cnt;
+    // ordered mode (tsq_join_set_ordered): joined rows come out in probe-row order, the matches of one probe row in
+    // build-row order — MergeJoinExec's output order (executor/merge_join.go:257-310) when its inputs are sorted
+    int32_t ordered;
 };
 
 // probe-side eligibility of row k: selected && outer filter && non-NULL key (join.go:344)
@@ -403,6 +406,41 @@ __global__ void __launch_bounds__(256) k_probe_emit(ProbeArgs a) {
     const int64_t k_round = k_begin + ((k_last - k_begin + 63) & ~(int64_t)63);  // wave-uniform trip count for the collectives
     if (threadIdx.x == 0) s_cur = a.block_base[blockIdx.x];
     __syncthreads();
+    if (a.ordered) {
+        // positions in probe-row order: block-wide exclusive scan of the per-row output counts, 256 consecutive rows per
+        // step, on top of the workgroup's base (the workgroups own consecutive row ranges, k_scan_blocks ordered them)
+        __shared__ uint32_t s_wsum[4];
+        unsigned long long run = a.block_base[blockIdx.x];
+        const int64_t k_round256 = k_begin + ((k_last - k_begin + 255) & ~(int64_t)255);
+        for (int64_t k = k_begin + threadIdx.x; k < k_round256; k += 256) {
+            const unsigned long long fc = k < k_last ? a.first_cnt[k] : 0ull;
+            const uint32_t first = (uint32_t)fc, n_out = (uint32_t)(fc >> 32);
+            uint32_t total;
+            const uint32_t ex = block_excl_scan<256>(n_out, s_wsum, &total);
+            const uint64_t pos = run + ex;
+            run += total;
+            if (n_out) write_pair(a, pos, k, first);
+            if (n_out > 1) {
+                uint64_t kw = 0;
+                uint32_t seen = 0;
+                if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0))
+                    for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) { write_pair(a, pos + seen++, k, brow); });
+                // the slots of a chain are filled in whatever order the build's CAS won: put this row's matches into
+                // build-row (= insertion) order (insertion sort: match lists are short unless the key is heavily duplicated)
+                for (uint32_t i = 1; i < n_out; i++) {
+                    const unsigned long long v = a.pairs[pos + i];
+                    uint32_t q = i;
+                    while (q > 0 && (a.pairs[pos + q - 1] >> 32) > (v >> 32)) {
+                        a.pairs[pos + q] = a.pairs[pos + q - 1];
+                        q--;
+                    }
+                    a.pairs[pos + q] = v;
+                }
+            }
+            __syncthreads();  // s_wsum is reused by the next step
+        }
+        return;
+    }
     for (int64_t k = k_begin + threadIdx.x; k < k_round; k += blockDim.x) {
         const bool active = k < k_last;
         // what the sizing pass found for this probe row: no second walk of the table for rows with one output row
@@ -500,7 +538,7 @@ struct tsq_join {
     bool probe_done = false;
     bool host_mode = true;  // result placement follows the first probe push
     bool general = false;   // needs the GEN kernels (outer join / filters / conditions / selected)
-    bool count_only = false, checksum = false;
+    bool count_only = false, checksum = false, ordered = false;
     DevBuf counters;        // 8 x u64 on device
     int64_t total_out = 0;  // emit mode: rows produced so far
     std::deque<std::unique_ptr<ResultBatch>> results;
@@ -743,6 +781,7 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     TSQ_TRY(j->firstcnt.reserve(ctx, &j->hdr, (size_t)nrows * 8 + 64));
     a.block_base = j->bbase.as<unsigned long long>();
     a.first_cnt = j->firstcnt.as<unsigned long long>();
+    a.ordered = j->ordered ? 1 : 0;
     a.rows_per_block = (((nrows + egrid - 1) / egrid) + 63) & ~(int64_t)63;
     unsigned long long before[8], after[8];
     TSQ_TRY(read_counters(j, before));
@@ -1235,6 +1274,12 @@ TSQ_API tsq_status tsq_join_set_count_only(tsq_join* j, int32_t on) {
     if (j->st.probe_rows > 0 || j->stage.staged > 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "count-only must be chosen before the first probe row");
     j->count_only = on != 0;
     if (!j->count_only) j->checksum = false;
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_join_set_ordered(tsq_join* j, int32_t on) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (j->st.probe_rows > 0 || j->stage.staged > 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "ordered output must be chosen before the first probe row");
+    j->ordered = on != 0;
     return TSQ_OK;
 }
 TSQ_API tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode) {

@@ -135,6 +135,8 @@ class HashJoinExec(Executor):
         self.h = h
         self.prepared = False
         self.probe_eos = False
+        if getattr(self, "ordered", False):
+            _lib.check(self.lib.tsq_join_set_ordered(h, 1), h)
 
     def _build(self):  # fetchAndBuildHashTable (join.go:148-158)
         while True:
@@ -180,6 +182,18 @@ class HashJoinExec(Executor):
             self.lib.tsq_join_destroy(self.h)
             self.h = None
         super().Close()
+
+
+class MergeJoinExec(HashJoinExec):
+    """GPU MergeJoinExec (replaces executor/merge_join.go:31-373).  The reference walks two SORTED children with two cursors;
+    its result is the outer rows in order, each joined with its inner group in order (NULL-key inner rows skipped, unmatched
+    outer rows padded for outer joins).  That is the hash join with ordered output (tsq_join_set_ordered): the outer child is
+    the probe side, the inner child the build side — and the inputs need not even be sorted for the order to hold."""
+
+    def __init__(self, ctx, left, right, left_keys, right_keys, join_type=abi.JOIN_INNER, inner_child_idx=1, other_conditions=(),
+                 outer_filter=(), max_chunk_size=1024):
+        super().__init__(ctx, left, right, left_keys, right_keys, join_type, inner_child_idx, other_conditions, outer_filter, max_chunk_size)
+        self.ordered = True
 
 
 class AggFuncDesc:

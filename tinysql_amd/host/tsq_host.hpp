@@ -13,6 +13,7 @@
 //   SelectionExec       executor/executor.go:346-438
 //   ProjectionExec      executor/projection.go:54-90, expression/evaluator.go:121-133
 //   SortExec / TopNExec executor/sort.go:27-318
+//   MergeJoinExec       executor/merge_join.go:31-373 (= HashJoinExec with ordered output)
 //   Expression          expression/{column,constant,scalar_function}.go, lowered to tsq_expr_prog postfix
 // All compute happens in libtsq (HIP); nothing here touches the oracle and there is no CPU fallback: without a
 // device tsq_ctx_create fails and every constructor throws.
@@ -447,6 +448,7 @@ public:
         cfg_.outer_filters = filter_.empty() ? nullptr : filter_.data();
         cfg_.n_outer_filters = (int32_t)filter_.size();
         check(tsq_join_create(ctx_->h, &cfg_, &h_), ctx_->h);
+        if (ordered_) check(tsq_join_set_ordered(h_, 1), h_);
         prepared_ = false;
         probeDone_ = false;
     }
@@ -488,6 +490,8 @@ public:
     // Close may race with Next on another thread (join_test.go:172-182, TestJoinLeak): cancel first.
     void Close() override { destroy(); Executor::Close(); }
     void Cancel() { if (h_) tsq_join_cancel(h_); }
+protected:
+    bool ordered_ = false;  // MergeJoinExec: outer rows in order, each with its inner matches in order
 private:
     static Schema concat(Schema a, const Schema& b) { a.insert(a.end(), b.begin(), b.end()); return a; }
     void destroy() {
@@ -498,6 +502,19 @@ private:
     Executor *build_, *probe_;
     bool buildIsRight_ = true, prepared_ = false, probeDone_ = false;
     tsq_join* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- MergeJoinExec (executor/merge_join.go:31-373)
+// Two sorted children walked with two cursors in the reference; its output — outer rows in order, each with its inner
+// group in order, NULL-key inner rows skipped, unmatched outer rows padded for outer joins — is the hash join with ordered
+// output (tsq_join_set_ordered): outer child = probe side, inner child = build side.
+class MergeJoinExec : public HashJoinExec {
+public:
+    MergeJoinExec(Context* ctx, Executor* left, Executor* right, std::vector<int> leftKeys, std::vector<int> rightKeys, JoinType jt, int innerChildIdx,
+                  std::vector<Expression> otherConditions = {}, std::vector<Expression> outerFilter = {})
+        : HashJoinExec(ctx, left, right, std::move(leftKeys), std::move(rightKeys), jt, innerChildIdx, std::move(otherConditions), std::move(outerFilter)) {
+        ordered_ = true;
+    }
 };
 
 // ---------------------------------------------------------------- HashAggExec (executor/aggregate.go:134-588)

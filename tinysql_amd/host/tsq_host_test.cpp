@@ -253,6 +253,25 @@ int main() {
             TopNExec top(&ctx, &src, {{1, true}, {0, true}}, 2, 1);
             expect_true("distsql_test.go:158 shape: order by b desc limit 2,1", ordered(Drain(&top)) == Rows{"7 6"});
         }
+        // ---- executor/merge_join_test.go:245-258, 276-279, 316-321: rows IN ORDER through MergeJoinExec
+        {
+            Chunk mt = table_i64(2, {1, 1, 2, 2}), mt1 = table_i64(2, {2, 3, 4, 4});
+            MockDataSource l(&ctx, mt), r(&ctx, mt1);
+            MergeJoinExec mj(&ctx, &l, &r, {0}, {0}, LeftOuterJoin, 1, {}, {Func("ne", {Col(0, TSQ_I64), Int(1)})});
+            expect_true("merge_join_test.go:257-258 left outer join on t.c1 = t1.c1 and t.c1 != 1", ordered(Drain(&mj)) == Rows{"1 1 <nil> <nil>", "2 2 2 3"});
+            MockDataSource l2(&ctx, mt1), r2(&ctx, mt);
+            MergeJoinExec mj2(&ctx, &l2, &r2, {0}, {0}, RightOuterJoin, 0);
+            expect_true("merge_join_test.go:251 t1 right outer join t", ordered(Drain(&mj2)) == Rows{"<nil> <nil> 1 1", "2 3 2 2"});
+            Chunk tt = table_i64(2, {1, 1, 1, 2, 1, 3, 1, 4}), ss = table_i64(1, {1});
+            MockDataSource l3(&ctx, tt), r3(&ctx, ss);
+            MergeJoinExec mj3(&ctx, &l3, &r3, {0}, {0}, InnerJoin, 1);
+            expect_true("merge_join_test.go:316-321 t join s: four rows in t order", ordered(Drain(&mj3)) == Rows{"1 1 1", "1 2 1", "1 3 1", "1 4 1"});
+            Chunk o = table_i64(2, {NIL, 0, 1, 1, 1, 2, 3, 3, 5, 4, 5, 5, 9, 6}), in = table_i64(2, {NIL, 10, NIL, 11, 1, 12, 2, 13, 5, 14, 5, 15, 7, 16});
+            MockDataSource l4(&ctx, o), r4(&ctx, in);
+            MergeJoinExec mj4(&ctx, &l4, &r4, {0}, {0}, LeftOuterJoin, 1);
+            expect_true("merge_join.go:148-156,257-310 NULL keys, group walk, outer rows in order",
+                        ordered(Drain(&mj4)) == Rows{"<nil> 0 <nil> <nil>", "1 1 1 12", "1 2 1 12", "3 3 <nil> <nil>", "5 4 5 14", "5 4 5 15", "5 5 5 14", "5 5 5 15", "9 6 <nil> <nil>"});
+        }
         {   // NULL is the smallest value (compare.go:48-56); executor_test.go:504: limit 18446744073709551615 = no limit
             Chunk n = table_i64(1, {3, NIL, -7, NIL, 0});
             MockDataSource src(&ctx, n);
