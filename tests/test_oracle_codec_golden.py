@@ -118,3 +118,22 @@ def test_decode_errors_of_the_reference():
     assert orc.decode_rows(np.frombuffer(b"\x02\x02ab", np.uint8), [abi.I64], 9)[0] == 5                      # compact bytes: var-len
     st, chk, used = orc.decode_rows(np.concatenate([ok, ok[:1]]), t2, 9)                                       # complete row, then garbage
     assert st == 2 and chk.NumRows() == 1 and used == ok.size
+
+
+def test_the_bench_tool_numpy_encoder_writes_the_same_bytes():
+    # tools/bench_decode.py generates its input without the oracle; its vectorised EncodeValue must be the reference format
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_decode", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_decode.py"))
+    bd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bd)
+    rng = np.random.default_rng(0)
+    m = 20_000
+    a = rng.integers(-(1 << 62), 1 << 62, m)
+    a[:10] = [0, -1, 1, 63, -64, 64, -65, (1 << 63) - 1, -(1 << 63), 300]
+    b = rng.integers(0, 2500, m)
+    c = rng.random(m) * 1e5 - 5e4
+    d = rng.integers(0, 11, m) / 100.0
+    want = orc.encode_rows(Chunk([Column(abi.I64, a), Column(abi.I64, b), Column(abi.F64, c), Column(abi.F64, d)]))
+    got = bd.encode_value_rows([a, b, c, d])
+    assert got.size == want.size and (got == want).all()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tsq_rows_decode timing: a lineitem-shaped response (int64 key, int64 day number, double, double) encoded with EncodeValue by the
-oracle (test infrastructure: generator + CPU baseline only), resident in HBM, decoded into device columns.
+"""tsq_rows_decode timing: a lineitem-shaped response (int64 key, int64 day number, double, double) in the EncodeValue format
+(generated here with numpy), resident in HBM, decoded into device columns; the oracle appears only in the cpu_baseline leg.
 usage: bench_decode.py [rows]"""
 import ctypes as C
 import json
@@ -13,11 +13,51 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from oracle import binding as orc  # noqa: E402  (generator + cpu baseline leg)
 from tinysql_amd import _abi as abi  # noqa: E402
 from tinysql_amd import _lib  # noqa: E402
-from tinysql_amd.chunk import Chunk, Column  # noqa: E402
 import gpu_helpers as G  # noqa: E402
+
+
+def encode_value_rows(cols):
+    """EncodeValue (util/codec/codec.go:74-99,205-209) of rows of int64 / float64 columns, vectorised in numpy: the INPUT
+    generator of this bench (flag 8 + zig-zag varint for ints, flag 5 + 8 big-endian memcomparable bytes for doubles)."""
+    n = len(cols[0])
+    parts, lens = [], []
+    for c in cols:
+        if c.dtype == np.float64:
+            u = c.view(np.uint64)
+            u = np.where(c >= 0, u | np.uint64(1 << 63), ~u)
+            b = np.zeros((n, 11), np.uint8)
+            b[:, 0] = 5
+            b[:, 1:9] = u.astype(">u8").view(np.uint8).reshape(n, 8)
+            ln = np.full(n, 9, np.int64)
+        else:
+            v = c.astype(np.int64)
+            z = ((v << 1) ^ (v >> 63)).view(np.uint64)          # zig-zag (encoding/binary.PutVarint)
+            nb = np.ones(n, np.int64)                             # bytes of the varint: one per started 7-bit group
+            for k in range(1, 10):
+                nb += ((z >> np.uint64(7 * k)) != 0).astype(np.int64)
+            b = np.zeros((n, 11), np.uint8)
+            b[:, 0] = 8
+            for k in range(10):
+                b[:, 1 + k] = ((z >> np.uint64(7 * k)) & np.uint64(0x7F)).astype(np.uint8) | ((nb > k + 1).astype(np.uint8) << 7)
+            ln = nb + 1                                           # + flag byte
+        parts.append(b)
+        lens.append(ln)
+    # interleave column-wise per row, dropping the unused tail bytes of every value
+    allb = np.stack(parts, axis=1).reshape(n * len(cols), 11)
+    alll = np.stack(lens, axis=1).reshape(n * len(cols))
+    mask = np.arange(11)[None, :] < alll[:, None]
+    return allb[mask]
+
+
+def cpu_baseline_leg(raw, types, rows):
+    """cpu_baseline: the oracle's restatement of readRowsData + DecodeOne (test infrastructure), timed on one host core."""
+    from oracle import binding as orc
+    t = time.perf_counter()
+    st, _, _ = orc.decode_rows(raw, types, rows)
+    assert st == 0
+    return time.perf_counter() - t
 
 
 def main():
@@ -28,15 +68,10 @@ def main():
     raws = []
     for lo in range(0, n, piece):
         m = min(piece, n - lo)
-        chk = Chunk([Column(abi.I64, rng.integers(0, 1 << 28, m)), Column(abi.I64, rng.integers(0, 2500, m)), Column(abi.F64, rng.random(m) * 1e5),
-                     Column(abi.F64, rng.integers(0, 11, m) / 100.0)])
-        raws.append(orc.encode_rows(chk))
+        raws.append(encode_value_rows([rng.integers(0, 1 << 28, m), rng.integers(0, 2500, m), rng.random(m) * 1e5, rng.integers(0, 11, m) / 100.0]))
         if lo == 0:
-            t = time.perf_counter()
-            st, _, _ = orc.decode_rows(raws[0], types, m)
-            cpu_s = time.perf_counter() - t
+            cpu_s = cpu_baseline_leg(raws[0], types, m)
             cpu_vals = m * 4
-            assert st == 0
     raw = np.concatenate(raws)
     del raws
     with _lib.Context(0) as ctx:
