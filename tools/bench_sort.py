@@ -13,7 +13,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from oracle import binding as orc  # noqa: E402  (cpu baseline leg)
 from tinysql_amd import _abi as abi  # noqa: E402
 from tinysql_amd import _lib  # noqa: E402
 from tinysql_amd.chunk import Chunk, Column  # noqa: E402
@@ -65,6 +64,7 @@ def main():
     rng = np.random.default_rng(1)
     m = 5_000_000
     chk = Chunk([Column(abi.I64, rng.integers(0, 1 << 40, m)), Column(abi.I64, np.arange(m))])
+    from oracle import binding as orc  # cpu_baseline leg only: the oracle's SortExec restatement (test infrastructure)
     t = time.perf_counter()
     orc.sort_perm(chk, [0], [False])
     cpu_s = time.perf_counter() - t
