@@ -14,6 +14,7 @@ timeout 300 python tools/bench_build.py > $O/build.json 2>&1
 timeout 600 python tools/bench_configs.py > $O/configs.json 2> $O/configs.err
 timeout 600 python tools/bench_decode.py > $O/decode.json 2> $O/decode.err; cut -c1-300 $O/decode.json
 timeout 600 python tools/bench_sort.py > $O/sort.json 2> $O/sort.err; cut -c1-200 $O/sort.json
+timeout 600 python tools/bench_emit.py > $O/emit.json 2> $O/emit.err; cut -c1-300 $O/emit.json
 export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_v4 -o v4 --output-format csv -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_v4_bench.txt 2>&1
