@@ -28,7 +28,7 @@
 
 #define TSQ_SORT_NT 256
 #define TSQ_SORT_K 16
-#define TSQ_SORT_T (TSQ_SORT_NT * TSQ_SORT_K)  // rows per tile
+#define TSQ_SORT_T (TSQ_SORT_NT * TSQ_SORT_K)  // rows per tile (measured: 2048 -> 13.4 ms, 4096 -> 8.5 ms, 6144 -> 9.6 ms per 1e8 x 8 passes)
 #define TSQ_SORT_NW (TSQ_SORT_NT / 64)
 
 struct SortKeySrc {
