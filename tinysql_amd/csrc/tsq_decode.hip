@@ -45,6 +45,8 @@ struct DecArgs {
     int64_t n_tiles;
     int64_t tiles_per_wg;           // R
     int32_t n_wg;                   // workgroups that own tiles (grid of map and emit)
+    unsigned long long* sb_map;     // [n_tiles * 256] exit map of every sub-block (written by K13a, read by K13c)
+    uint32_t* sb_cnt;               // [n_tiles * 256][3] packed counts of every sub-block
     unsigned long long* wg_map;     // [n_wg]
     uint32_t* wg_cnt;               // [n_wg][12]
     uint32_t* wg_entry;             // [n_wg] true entry offset of the workgroup's first tile (k_dec_scan)
@@ -61,7 +63,6 @@ struct DecArgs {
 // LDS state of one tile
 struct DecTile {
     uint8_t bytes[(TSQ_DEC_NSB + 1) * TSQ_DEC_BSTR];  // stream bytes, padded rows (+ one halo row)
-    uint8_t len[TSQ_DEC_NSB * TSQ_DEC_BSTR];          // value length at every position (emit only), same row layout
     unsigned long long map[TSQ_DEC_NSB];              // per sub-block: 11 x 4-bit exit offsets
     uint32_t cnt[TSQ_DEC_NSB][3];                     // per sub-block: 11 counts, four per word
     uint32_t seg_exit[TSQ_DEC_NSEG][12];              // per segment and entry offset
@@ -80,10 +81,10 @@ __device__ __forceinline__ uint32_t dec_msb4(uint32_t w) { return ((((w >> 7) & 
 // Loads tile `t` (+ 11 bytes of halo, zero padded past n_bytes) and computes the exit map and counts of every sub-block.
 // Thread sb owns sub-block sb: its 32 bytes + 11 halo bytes live in REGISTERS (11 conflict-free LDS words), the value
 // length at each position comes from the flag byte and a 43-bit mask of continuation bits (count-trailing-zeros instead
-// of a byte loop), and the backward pass keeps the last 11 results in registers (the successor p + len[p] is at most 11
-// positions ahead): fully unrolled, no LDS traffic, no divergence.  (Doing both with LDS byte reads and an LDS-resident
+// of a byte loop), and the backward pass keeps the last 11 results packed in a 128-bit register window (the successor
+// p + len[p] is at most 11 positions ahead): fully unrolled, no LDS traffic, no divergence.  (Doing both with LDS byte reads and an LDS-resident
 // state array cost 56 % of k_dec_map.)  Returns the number of valid bytes of the tile.
-template <bool KEEP_LEN>
+template <bool FROM_MAPS>
 __device__ __forceinline__ uint32_t dec_prepare_tile(const DecArgs& a, int64_t t, DecTile& T) {
     const int64_t t0 = t * TSQ_DEC_TB;
     const int64_t left = a.n_bytes - t0;
@@ -105,7 +106,13 @@ __device__ __forceinline__ uint32_t dec_prepare_tile(const DecArgs& a, int64_t t
         d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
     }
     __syncthreads();
-    {
+    if (FROM_MAPS) {  // K13c: the maps were computed by K13a — 20 bytes per sub-block read back instead of a second backward pass
+        const size_t g = (size_t)t * TSQ_DEC_NSB + threadIdx.x;
+        T.map[threadIdx.x] = a.sb_map[g];
+        T.cnt[threadIdx.x][0] = a.sb_cnt[g * 3 + 0];
+        T.cnt[threadIdx.x][1] = a.sb_cnt[g * 3 + 1];
+        T.cnt[threadIdx.x][2] = a.sb_cnt[g * 3 + 2];
+    } else {
         const uint32_t sb = threadIdx.x, lo = sb * TSQ_DEC_SB;
         const uint32_t lim = lo + TSQ_DEC_SB <= valid ? (uint32_t)TSQ_DEC_SB : (valid > lo ? valid - lo : 0u);
         const uint32_t* rw = (const uint32_t*)(T.bytes + sb * TSQ_DEC_BSTR);
@@ -114,45 +121,55 @@ __device__ __forceinline__ uint32_t dec_prepare_tile(const DecArgs& a, int64_t t
         for (int i = 0; i < 8; i++) w[i] = rw[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) w[8 + i] = rw[9 + i];  // first 12 bytes of the next row (word 8 of a row is padding)
-        unsigned long long msb = 0;
+        uint32_t m_lo = 0, m_hi = 0;  // continuation bits of bytes 0..31 / 32..43
 #pragma unroll
-        for (int i = 0; i < 11; i++) msb |= (unsigned long long)dec_msb4(w[i]) << (4 * i);
-        // E[p] = exit << 4 | count << 8 of position p; positions 32..42 lie in the next sub-block: exit = p - 32, count 0
-        uint32_t E[43];
+        for (int i = 0; i < 8; i++) m_lo |= dec_msb4(w[i]) << (4 * i);
 #pragma unroll
-        for (int n = 32; n < 43; n++) E[n] = (uint32_t)(n - 32) << 4;
-        uint32_t lenw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; i++) m_hi |= dec_msb4(w[8 + i]) << (4 * i);
+        // (exit | count << 4) of the 11 positions after the current one, 10 bits each, position o + j in field j - 1 of a
+        // 128-bit window: the successor o + len is picked with one variable shift instead of ten compare-selects.
+        // Positions 32..42 lie in the next sub-block: exit = p - 32, count 0.
+        unsigned long long w_lo = 0, w_hi = 0;
+#pragma unroll
+        for (int j = 1; j <= 11; j++) {
+            const unsigned long long f = (unsigned long long)(j - 1);
+            if (10 * (j - 1) < 64) w_lo |= f << (10 * (j - 1));
+            if (10 * (j - 1) + 10 > 64) w_hi |= 10 * (j - 1) >= 64 ? f << (10 * (j - 1) - 64) : f >> (64 - 10 * (j - 1));
+        }
 #pragma unroll
         for (int o = 31; o >= 0; o--) {
             const uint32_t f = (w[o >> 2] >> (8 * (o & 3))) & 255u;
             // a varint has at most 10 bytes; one whose 10th byte still has the continuation bit is an overflow
             // (binary.Uvarint) and gets the maximal length 11 as well
-            uint32_t run = (uint32_t)__builtin_ctzll(~(msb >> (o + 1)) | (1ull << 9));  // continuation bytes after the flag, <= 9
+            const uint32_t after = o + 1 < 32 ? __funnelshift_r(m_lo, m_hi, o + 1) : m_hi >> (o + 1 - 32);  // continuation bits from o + 1 on
+            const uint32_t run = (uint32_t)__builtin_ctz(~after | (1u << 9));  // continuation bytes after the flag, <= 9
             uint32_t len = 1;  // NULL, or a flag that is an error if this position is ever reached on the true path
             len = (f == 8 || f == 9) ? run + 2 : len;
             len = (f == 3 || f == 4 || f == 5) ? 9u : len;
-            uint32_t nx = E[o + 1];
-#pragma unroll
-            for (int d = 2; d <= 11; d++) nx = len == (uint32_t)d ? E[o + d] : nx;
-            E[o] = (uint32_t)o < lim ? nx + (1u << 8) : 0u;  // past the end of the stream: not a value
-            lenw[o >> 2] |= len << (8 * (o & 3));
+            const uint32_t sh = 10u * (len - 1);
+            const unsigned long long pick = sh < 64 ? ((w_lo >> sh) | (sh ? w_hi << (64 - sh) : 0ull)) : (w_hi >> (sh - 64));
+            const uint32_t e = (uint32_t)o < lim ? ((uint32_t)pick & 0x3ffu) + (1u << 4) : 0u;  // past the end of the stream: not a value
+            w_hi = (w_hi << 10) | (w_lo >> 54);
+            w_lo = (w_lo << 10) | e;
         }
+        // the window now holds positions 0..10 in fields 0..10
         unsigned long long m = 0;
         uint32_t cw[3] = {0, 0, 0};
 #pragma unroll
         for (int e = 0; e < 11; e++) {
-            m |= (unsigned long long)((E[e] >> 4) & 15u) << (4 * e);
-            cw[e >> 2] |= (E[e] >> 8) << (8 * (e & 3));
+            const uint32_t v = (uint32_t)(10 * e < 64 ? ((w_lo >> (10 * e)) | (10 * e + 10 > 64 ? w_hi << (64 - 10 * e) : 0ull)) : (w_hi >> (10 * e - 64))) & 0x3ffu;
+            m |= (unsigned long long)(v & 15u) << (4 * e);
+            cw[e >> 2] |= (v >> 4) << (8 * (e & 3));
         }
         T.map[sb] = m;
         T.cnt[sb][0] = cw[0];
         T.cnt[sb][1] = cw[1];
         T.cnt[sb][2] = cw[2];
-        if (KEEP_LEN) {
-            uint32_t* lr = (uint32_t*)(T.len + sb * TSQ_DEC_BSTR);
-#pragma unroll
-            for (int i = 0; i < 8; i++) lr[i] = lenw[i];
-        }
+        const size_t g = (size_t)t * TSQ_DEC_NSB + sb;
+        a.sb_map[g] = m;
+        a.sb_cnt[g * 3 + 0] = cw[0];
+        a.sb_cnt[g * 3 + 1] = cw[1];
+        a.sb_cnt[g * 3 + 2] = cw[2];
     }
     __syncthreads();
     // 20 segments x 11 entry offsets in parallel: exit offset and count of every (segment, entry)
@@ -220,6 +237,19 @@ __global__ void __launch_bounds__(1024) k_dec_scan(DecArgs a) {
         }
         a.wg_base[a.n_wg] = base;
     }
+}
+
+// length of the value that starts at tile position p (flag + payload), from the LDS bytes: used on the true path only
+// (~5 values per sub-block).  Same rule as in dec_prepare_tile: a varint has at most 10 bytes, overflow gets length 11.
+__device__ __forceinline__ uint32_t dec_len_at(const uint8_t* bytes, uint32_t p) {
+    const uint8_t f = bytes[dec_bidx(p)];
+    if (f == 3 || f == 4 || f == 5) return 9;
+    if (f == 8 || f == 9) {
+        uint32_t k = 1;
+        while (k < 10 && (bytes[dec_bidx(p + k)] & 0x80)) k++;
+        return k + 1;
+    }
+    return 1;
 }
 
 __device__ __forceinline__ void dec_error(const DecArgs& a, unsigned long long ordinal, int code) {
@@ -332,11 +362,10 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
             {
                 const uint32_t sblo = threadIdx.x * TSQ_DEC_SB;
                 const uint32_t lim = sblo + TSQ_DEC_SB <= valid ? (uint32_t)TSQ_DEC_SB : (valid > sblo ? valid - sblo : 0u);
-                const uint8_t* row = T.len + threadIdx.x * TSQ_DEC_BSTR;
                 uint32_t pos = s_entry[threadIdx.x];
                 unsigned long long ord = tile_base + s_base[threadIdx.x];
                 while (pos < lim) {
-                    const uint32_t len = row[pos];
+                    const uint32_t len = dec_len_at(T.bytes, sblo + pos);
                     if (ord == limit) a.result[1] = (unsigned long long)(t0 + sblo + pos);  // first byte that is not consumed
                     if (ord < limit) dec_value(a, T.bytes, sblo + pos, len, ord, t0, ncols);
                     pos += len;
@@ -382,9 +411,9 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     }
     a.n_cols = n_cols;
     a.cap_rows = cap_rows;
-    DevBuf dbytes, dwmap, dwcnt, dentry, dbase, dres, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
+    DevBuf dbytes, dsbmap, dsbcnt, dwmap, dwcnt, dentry, dbase, dres, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
     auto release_all = [&]() {
-        for (DevBuf* b : {&dbytes, &dwmap, &dwcnt, &dentry, &dbase, &dres}) b->release();
+        for (DevBuf* b : {&dbytes, &dsbmap, &dsbcnt, &dwmap, &dwcnt, &dentry, &dbase, &dres}) b->release();
         for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dnn[c].release(); dbm[c].release(); }
     };
     tsq_status s = TSQ_OK;
@@ -398,6 +427,8 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     } else {
         a.data = rows_data;
     }
+    if (s == TSQ_OK) s = dsbmap.reserve(ctx, h, (size_t)a.n_tiles * TSQ_DEC_NSB * 8 + 64);
+    if (s == TSQ_OK) s = dsbcnt.reserve(ctx, h, (size_t)a.n_tiles * TSQ_DEC_NSB * 12 + 64);
     if (s == TSQ_OK) s = dwmap.reserve(ctx, h, (size_t)a.n_wg * 8 + 64);
     if (s == TSQ_OK) s = dwcnt.reserve(ctx, h, (size_t)a.n_wg * 48 + 64);
     if (s == TSQ_OK) s = dentry.reserve(ctx, h, (size_t)a.n_wg * 4 + 64);
@@ -412,6 +443,8 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
         a.out_notnull[c] = dnn[c].as<uint8_t>();
     }
     if (s != TSQ_OK) return fail(s);
+    a.sb_map = dsbmap.as<unsigned long long>();
+    a.sb_cnt = dsbcnt.as<uint32_t>();
     a.wg_map = dwmap.as<unsigned long long>();
     a.wg_cnt = dwcnt.as<uint32_t>();
     a.wg_entry = dentry.as<uint32_t>();
