@@ -55,7 +55,8 @@ struct DecArgs {
     int32_t n_cols;
     int32_t col_type[TSQ_MAX_COLS];
     void* out_data[TSQ_MAX_COLS];
-    uint8_t* out_notnull[TSQ_MAX_COLS];  // one byte per row
+    uint8_t* out_notnull[TSQ_MAX_COLS];  // one byte per row (packed afterwards), or
+    uint32_t* out_bm32[TSQ_MAX_COLS];    // the packed bitmap itself, preset to all ones: a NULL clears its bit (atomicAnd)
     int64_t cap_rows;
     unsigned long long* result;  // [0] = min over errors of (ordinal << 4 | code), [1] = byte offset of value number cap_rows * n_cols
 };
@@ -317,7 +318,11 @@ __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes
     } else {
         ((uint64_t*)a.out_data[col])[row] = isnull ? 0ull : bits;
     }
-    a.out_notnull[col][row] = isnull ? 0 : 1;
+    if (a.out_bm32[col]) {
+        if (isnull) atomicAnd(&a.out_bm32[col][row >> 5], ~(1u << (row & 31)));  // NULLs are the rare case: no flag byte per value, no pack pass
+    } else {
+        a.out_notnull[col][row] = isnull ? 0 : 1;
+    }
 }
 
 __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
@@ -434,13 +439,29 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     if (s == TSQ_OK) s = dentry.reserve(ctx, h, (size_t)a.n_wg * 4 + 64);
     if (s == TSQ_OK) s = dbase.reserve(ctx, h, ((size_t)a.n_wg + 1) * 8 + 64);
     if (s == TSQ_OK) s = dres.reserve(ctx, h, 64);
+    // null bitmaps: written in place (preset to ones, NULLs clear their bit) when the destination is 4-byte aligned,
+    // otherwise through one flag byte per value + a pack pass
+    bool direct_bm = true;
+    for (int c = 0; c < n_cols; c++) direct_bm = direct_bm && (!out_dev || (((uintptr_t)out_cols[c].null_bitmap) & 3) == 0);
+    const size_t bm_bytes = (tsq_bitmap_bytes(max_rows) + 3) & ~(size_t)3;
+    // the NULL-clearing atomics work on whole 32-bit words: a device destination (sized for cap_rows rows by contract) must
+    // consist of whole words
+    if (out_dev) direct_bm = direct_bm && (tsq_bitmap_bytes(cap_rows) & 3) == 0;
     for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
         a.col_type[c] = col_types[c];
-        s = dnn[c].reserve(ctx, h, (size_t)max_rows + 64);
+        if (!direct_bm) s = dnn[c].reserve(ctx, h, (size_t)max_rows + 64);
         if (s == TSQ_OK && !out_dev) s = ddata[c].reserve(ctx, h, (size_t)max_rows * tsq_elem_size(col_types[c]) + 64);
-        if (s == TSQ_OK && !out_dev) s = dbm[c].reserve(ctx, h, tsq_bitmap_bytes(max_rows) + 64);
+        if (s == TSQ_OK && !out_dev) s = dbm[c].reserve(ctx, h, bm_bytes + 64);
         a.out_data[c] = out_dev ? out_cols[c].data : ddata[c].p;
-        a.out_notnull[c] = dnn[c].as<uint8_t>();
+        a.out_notnull[c] = direct_bm ? nullptr : dnn[c].as<uint8_t>();
+        a.out_bm32[c] = direct_bm ? (uint32_t*)(out_dev ? out_cols[c].null_bitmap : dbm[c].as<uint8_t>()) : nullptr;
+        if (s == TSQ_OK && direct_bm) {
+            // bytes of rows the caller asked for: a device destination holds cap_rows rows, so (cap_rows + 7) / 8 bytes exist;
+            // the word-wise atomics may touch up to 3 bytes beyond the last row's byte only inside this rounded size
+            const size_t dst_bytes = out_dev ? std::min<size_t>(tsq_bitmap_bytes(cap_rows), bm_bytes) : bm_bytes;
+            hipError_t e0 = hipMemsetAsync(a.out_bm32[c], 0xff, dst_bytes, ctx->stream);
+            if (e0 != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, std::string("hipMemsetAsync(bitmap): ") + hipGetErrorString(e0));
+        }
     }
     if (s != TSQ_OK) return fail(s);
     a.sb_map = dsbmap.as<unsigned long long>();
@@ -478,7 +499,7 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     if (rows > 0) {
         for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
             uint8_t* bm = out_dev ? out_cols[c].null_bitmap : dbm[c].as<uint8_t>();
-            s = tsq_launch_pack_bitmap(ctx, h, a.out_notnull[c], bm, rows);
+            if (!direct_bm) s = tsq_launch_pack_bitmap(ctx, h, a.out_notnull[c], bm, rows);
             if (s == TSQ_OK && !out_dev) {
                 hipError_t e2 = hipMemcpyAsync(out_cols[c].data, ddata[c].p, (size_t)rows * tsq_elem_size(col_types[c]), hipMemcpyDeviceToHost, ctx->stream);
                 if (e2 == hipSuccess) e2 = hipMemcpyAsync(out_cols[c].null_bitmap, bm, tsq_bitmap_bytes(rows), hipMemcpyDeviceToHost, ctx->stream);
