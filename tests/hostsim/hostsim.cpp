@@ -91,3 +91,36 @@ uint32_t sim_key_rank(uint64_t kw, uint32_t n_parts) { return tsq_key_rank(kw, n
 uint64_t sim_mix64(uint64_t k) { return tsq_mix64(k); }
 uint64_t sim_mulhi64(uint64_t a, uint64_t b) { return tsq_mulhi64(a, b); }
 }
+
+// ---- tsq_rows_decode's scalar core (tsq_decode_dp.h), driven over a whole byte stream the way the kernels do it
+#include "../../tinysql_amd/csrc/tsq_decode_dp.h"
+
+extern "C" {
+
+// exit map + packed counts of every 32-byte sub-block of `bytes` (k_dec_map's per-thread work)
+void sim_dec_maps(const uint8_t* bytes, int64_t n, unsigned long long* maps, uint32_t* cnts) {
+    const int64_t nsb = (n + 31) / 32;
+    for (int64_t sb = 0; sb < nsb; sb++) {
+        uint8_t buf[44];
+        for (int i = 0; i < 44; i++) buf[i] = sb * 32 + i < n ? bytes[sb * 32 + i] : 0;  // zero padded past the end, like the LDS tile
+        uint32_t w[11];
+        memcpy(w, buf, 44);
+        const uint32_t lim = n - sb * 32 >= 32 ? 32u : (uint32_t)(n - sb * 32);
+        tsq_dec_subblock(w, lim, &maps[sb], &cnts[sb * 3]);
+    }
+}
+
+// the value at byte position pos with length len (k_dec_emit's dec_value without the store): returns the status code
+int32_t sim_dec_value(const uint8_t* bytes, int64_t n, int64_t pos, uint32_t len, uint64_t* bits, uint8_t* isnull, uint8_t* real) {
+    uint8_t buf[12];
+    for (int i = 0; i < 12; i++) buf[i] = pos + i < n ? bytes[pos + i] : 0;
+    uint32_t b[3];
+    memcpy(b, buf, 12);
+    bool nl = false, re = false;
+    if (pos + len > n) return DEC_INSUFFICIENT;
+    const int e = tsq_dec_value(b[0], b[1], b[2], len, bits, &nl, &re);
+    *isnull = nl;
+    *real = re;
+    return e;
+}
+}

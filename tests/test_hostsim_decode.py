@@ -1,0 +1,128 @@
+"""CPU: the scalar core of tsq_rows_decode (tinysql_amd/csrc/tsq_decode_dp.h: the backward pass that yields a sub-block's exit
+map / counts, and the word-based value decode) compiled with g++ through tests/hostsim and driven over whole byte streams
+like the kernels do — against a brute-force walk of every entry offset and against the oracle's sequential decoder.  This
+is the part of the GPU algorithm where an off-by-one would silently mis-parse, checked here without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from tinysql_amd import _abi as abi
+from tinysql_amd.chunk import Chunk, Column
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def sim():
+    subprocess.run(["make", "-C", os.path.join(HERE, "hostsim")], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(HERE, "hostsim", "hostsim.so"))
+    P = C.c_void_p
+    lib.sim_dec_maps.restype = None
+    lib.sim_dec_maps.argtypes = [P, C.c_int64, P, P]
+    lib.sim_dec_value.restype = C.c_int32
+    lib.sim_dec_value.argtypes = [P, C.c_int64, C.c_int64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    return lib
+
+
+def _len_at(b, p):
+    """length rule of the format (flag byte + payload), as the reference's decoder consumes bytes"""
+    f = b[p] if p < len(b) else 0
+    if f in (3, 4, 5):
+        return 9
+    if f in (8, 9):
+        k = 1
+        while k < 10 and p + k < len(b) and b[p + k] & 0x80:
+            k += 1
+        return k + 1
+    return 1
+
+
+def _maps(sim, raw):
+    nsb = (raw.size + 31) // 32
+    maps = np.zeros(nsb, np.uint64)
+    cnts = np.zeros(nsb * 3, np.uint32)
+    sim.sim_dec_maps(raw.ctypes.data_as(C.c_void_p), raw.size, maps.ctypes.data_as(C.c_void_p), cnts.ctypes.data_as(C.c_void_p))
+    return maps, cnts.reshape(nsb, 3)
+
+
+def _streams():
+    rng = np.random.default_rng(12)
+    n = 3000
+    wide = (rng.integers(-(1 << 63), (1 << 63) - 1, n, dtype=np.int64) >> rng.integers(0, 63, n)).astype(np.int64)
+    chk = Chunk([Column(abi.I64, wide, rng.random(n) > 0.2), Column(abi.F64, np.ldexp(rng.random(n) - 0.5, rng.integers(-40, 40, n))),
+                 Column(abi.U64, (rng.integers(0, (1 << 64) - 1, n, dtype=np.uint64) >> rng.integers(0, 64, n).astype(np.uint64)).astype(np.uint64))])
+    yield "EncodeValue", orc.encode_rows(chk), chk
+    yield "EncodeKey", orc.encode_rows(chk, True), chk
+    alphabet = np.array([0x00, 0x03, 0x05, 0x08, 0x09, 0x80, 0xFF, 0x01], dtype=np.uint8)   # payloads that look like flags
+    u = alphabet[rng.integers(0, 8, (n, 8))].copy().view(np.uint64).reshape(n)
+    tricky = Chunk([Column(abi.U64, u), Column(abi.I64, u.view(np.int64), rng.random(n) > 0.3)])
+    yield "flag-like payloads", orc.encode_rows(tricky, True), tricky
+    small = Chunk([Column(abi.I64, rng.integers(-60, 60, 5000), rng.random(5000) > 0.5)])      # 1-2 byte values: up to 32 per sub-block
+    yield "tiny values", orc.encode_rows(small), small
+
+
+def test_subblock_maps_equal_a_brute_force_walk_of_every_entry_offset(sim):
+    for name, raw, _ in _streams():
+        b = raw.tolist()
+        maps, cnts = _maps(sim, raw)
+        for sb in range(len(maps)):
+            lo = sb * 32
+            lim = min(32, len(b) - lo)
+            for e in range(11):
+                pos, c = e, 0
+                while pos < lim:
+                    pos += _len_at(b, lo + pos)
+                    c += 1
+                want_exit = pos - 32 if pos >= 32 else 0
+                got_exit = (int(maps[sb]) >> (4 * e)) & 15
+                got_cnt = (int(cnts[sb][e >> 2]) >> (8 * (e & 3))) & 255
+                assert (got_exit, got_cnt) == (want_exit, c), (name, sb, e)
+
+
+def test_composed_maps_and_value_decode_equal_the_sequential_decoder(sim):
+    for name, raw, chk in _streams():
+        b = raw.tolist()
+        maps, cnts = _maps(sim, raw)
+        types = chk.types()
+        st, want, _ = orc.decode_rows(raw, types, chk.NumRows())
+        assert st == 0
+        # follow entry offset 0 through the sub-blocks (what K13a/K13b/K13c compose), decoding every value on the path
+        state, vals = 0, []
+        for sb in range(len(maps)):
+            lo = sb * 32
+            lim = min(32, len(b) - lo)
+            pos, c = state, 0
+            while pos < lim:
+                ln = _len_at(b, lo + pos)
+                bits, isnull, real = C.c_uint64(0), C.c_uint8(0), C.c_uint8(0)
+                err = sim.sim_dec_value(raw.ctypes.data_as(C.c_void_p), raw.size, lo + pos, ln, C.byref(bits), C.byref(isnull), C.byref(real))
+                assert err == 0, (name, lo + pos)
+                vals.append(None if isnull.value else bits.value)
+                pos += ln
+                c += 1
+            assert c == (int(cnts[sb][state >> 2]) >> (8 * (state & 3))) & 255
+            state = (int(maps[sb]) >> (4 * state)) & 15
+        ncols = len(types)
+        assert len(vals) == chk.NumRows() * ncols
+        for col in range(ncols):
+            wc = want.columns[col]
+            nn = np.ones(len(wc), bool) if wc.notnull is None else wc.notnull
+            got = vals[col::ncols]
+            assert [v is not None for v in got] == nn.tolist()
+            assert [v for v in got if v is not None] == wc.data.view(np.uint64)[nn].tolist()
+
+
+def test_value_decode_errors(sim):
+    def dec(raw, ln):
+        a = np.frombuffer(raw, np.uint8)
+        bits, isnull, real = C.c_uint64(0), C.c_uint8(0), C.c_uint8(0)
+        return sim.sim_dec_value(a.ctypes.data_as(C.c_void_p), a.size, 0, ln, C.byref(bits), C.byref(isnull), C.byref(real)), bits.value
+    assert dec(b"\x08" + b"\xff" * 9 + b"\x01", 11) == (0, (1 << 64) - 1 >> 1 ^ ((1 << 64) - 1))          # MinInt64: ff*9 01
+    assert dec(b"\x08" + b"\xff" * 9 + b"\x02", 11)[0] == 3                                                  # 10th byte > 1
+    assert dec(b"\x08" + b"\xff" * 10 + b"\x01", 11)[0] == 3                                                 # continuation in the 10th byte
+    assert dec(b"\x07\x00", 1)[0] == 4 and dec(b"\x02\x02ab", 1)[0] == 5
+    assert dec(b"\x03\x80\x00", 9)[0] == 2                                                                   # cut by the end of the buffer

@@ -27,6 +27,7 @@
 // the buffer, varint longer than 64 bits, a row that ends early); atomicMin over (ordinal, code) finds it.
 // Algorithmic bytes: encoded bytes read once + 8 B written per value (the implementation reads the bytes twice).
 #include "tsq_stage.h"
+#include "tsq_decode_dp.h"
 
 #define TSQ_DEC_TB 8192       // bytes per tile
 #define TSQ_DEC_SB 32         // bytes per sub-block
@@ -37,7 +38,6 @@
 #define TSQ_DEC_SEGLEN 13     // sub-blocks per segment (20 * 13 >= 256)
 #define TSQ_DEC_MAXWG 1024
 
-enum { DEC_OK = 0, DEC_ROW_CUT = 1, DEC_INSUFFICIENT = 2, DEC_OVERFLOW = 3, DEC_BAD_FLAG = 4, DEC_VARLEN = 5 };
 
 struct DecArgs {
     const uint8_t* data;
@@ -76,8 +76,6 @@ __device__ __forceinline__ uint32_t dec_cnt_of(uint32_t w0, uint32_t w1, uint32_
     const uint32_t w = state < 4 ? w0 : (state < 8 ? w1 : w2);
     return (w >> (8 * (state & 3))) & 255u;
 }
-// the continuation bits (bit 7) of the four bytes of w as a 4-bit number, byte 0 first
-__device__ __forceinline__ uint32_t dec_msb4(uint32_t w) { return ((((w >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u; }
 
 // Loads tile `t` (+ 11 bytes of halo, zero padded past n_bytes) and computes the exit map and counts of every sub-block.
 // Thread sb owns sub-block sb: its 32 bytes + 11 halo bytes live in REGISTERS (11 conflict-free LDS words), the value
@@ -122,46 +120,9 @@ __device__ __forceinline__ uint32_t dec_prepare_tile(const DecArgs& a, int64_t t
         for (int i = 0; i < 8; i++) w[i] = rw[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) w[8 + i] = rw[9 + i];  // first 12 bytes of the next row (word 8 of a row is padding)
-        uint32_t m_lo = 0, m_hi = 0;  // continuation bits of bytes 0..31 / 32..43
-#pragma unroll
-        for (int i = 0; i < 8; i++) m_lo |= dec_msb4(w[i]) << (4 * i);
-#pragma unroll
-        for (int i = 0; i < 3; i++) m_hi |= dec_msb4(w[8 + i]) << (4 * i);
-        // (exit | count << 4) of the 11 positions after the current one, 10 bits each, position o + j in field j - 1 of a
-        // 128-bit window: the successor o + len is picked with one variable shift instead of ten compare-selects.
-        // Positions 32..42 lie in the next sub-block: exit = p - 32, count 0.
-        unsigned long long w_lo = 0, w_hi = 0;
-#pragma unroll
-        for (int j = 1; j <= 11; j++) {
-            const unsigned long long f = (unsigned long long)(j - 1);
-            if (10 * (j - 1) < 64) w_lo |= f << (10 * (j - 1));
-            if (10 * (j - 1) + 10 > 64) w_hi |= 10 * (j - 1) >= 64 ? f << (10 * (j - 1) - 64) : f >> (64 - 10 * (j - 1));
-        }
-#pragma unroll
-        for (int o = 31; o >= 0; o--) {
-            const uint32_t f = (w[o >> 2] >> (8 * (o & 3))) & 255u;
-            // a varint has at most 10 bytes; one whose 10th byte still has the continuation bit is an overflow
-            // (binary.Uvarint) and gets the maximal length 11 as well
-            const uint32_t after = o + 1 < 32 ? __funnelshift_r(m_lo, m_hi, o + 1) : m_hi >> (o + 1 - 32);  // continuation bits from o + 1 on
-            const uint32_t run = (uint32_t)__builtin_ctz(~after | (1u << 9));  // continuation bytes after the flag, <= 9
-            uint32_t len = 1;  // NULL, or a flag that is an error if this position is ever reached on the true path
-            len = (f == 8 || f == 9) ? run + 2 : len;
-            len = (f == 3 || f == 4 || f == 5) ? 9u : len;
-            const uint32_t sh = 10u * (len - 1);
-            const unsigned long long pick = sh < 64 ? ((w_lo >> sh) | (sh ? w_hi << (64 - sh) : 0ull)) : (w_hi >> (sh - 64));
-            const uint32_t e = (uint32_t)o < lim ? ((uint32_t)pick & 0x3ffu) + (1u << 4) : 0u;  // past the end of the stream: not a value
-            w_hi = (w_hi << 10) | (w_lo >> 54);
-            w_lo = (w_lo << 10) | e;
-        }
-        // the window now holds positions 0..10 in fields 0..10
-        unsigned long long m = 0;
-        uint32_t cw[3] = {0, 0, 0};
-#pragma unroll
-        for (int e = 0; e < 11; e++) {
-            const uint32_t v = (uint32_t)(10 * e < 64 ? ((w_lo >> (10 * e)) | (10 * e + 10 > 64 ? w_hi << (64 - 10 * e) : 0ull)) : (w_hi >> (10 * e - 64))) & 0x3ffu;
-            m |= (unsigned long long)(v & 15u) << (4 * e);
-            cw[e >> 2] |= (v >> 4) << (8 * (e & 3));
-        }
+        unsigned long long m;
+        uint32_t cw[3];
+        tsq_dec_subblock(w, lim, &m, cw);
         T.map[sb] = m;
         T.cnt[sb][0] = cw[0];
         T.cnt[sb][1] = cw[1];
@@ -268,40 +229,10 @@ __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes
     for (uint32_t k = 0; k < 4; k++) w[k] = W[((q + k) >> 3) * (TSQ_DEC_BSTR / 4) + ((q + k) & 7u)];  // word 8 of a row is padding
     const uint32_t b0 = __builtin_amdgcn_alignbyte(w[1], w[0], sh), b1 = __builtin_amdgcn_alignbyte(w[2], w[1], sh),
                    b2 = __builtin_amdgcn_alignbyte(w[3], w[2], sh);
-    const uint32_t f = b0 & 255u;
-    const uint32_t p_lo = (b0 >> 8) | (b1 << 24), p_hi = (b1 >> 8) | (b2 << 24);  // payload bytes 1..8, little endian
     uint64_t bits = 0;
     bool isnull = false, real = false;
-    int err = DEC_OK;
-    if (t0 + pos + len > a.n_bytes) {
-        err = DEC_INSUFFICIENT;  // the value is cut by the end of the buffer (number.go:45,115-123)
-    } else if (f == 3 || f == 4 || f == 5) {
-        const uint64_t u = ((uint64_t)__builtin_bswap32(p_lo) << 32) | __builtin_bswap32(p_hi);  // binary.BigEndian.Uint64
-        if (f == 3) bits = u ^ 0x8000000000000000ULL;  // DecodeCmpUintToInt (number.go:29-31)
-        else if (f == 4) bits = u;
-        else {  // decodeCmpUintToFloat (float.go:32-40)
-            bits = (u & 0x8000000000000000ULL) ? (u & ~0x8000000000000000ULL) : ~u;
-            real = true;
-        }
-    } else if (f == 8 || f == 9) {
-        const uint32_t byte9 = (b2 >> 8) & 255u, byte10 = (b2 >> 16) & 255u;
-        // binary.Uvarint: a 10th byte with the continuation bit (an 11th byte would be needed) or above 1 is an overflow
-        // ("value larger than 64 bits", number.go:119-121)
-        if (len == 11 && byte10 > 1) err = DEC_OVERFLOW;
-        else {
-            const uint64_t P = (uint64_t)p_lo | ((uint64_t)p_hi << 32);
-            uint64_t x = (P & 0x7full) | ((P >> 1) & (0x7full << 7)) | ((P >> 2) & (0x7full << 14)) | ((P >> 3) & (0x7full << 21)) |
-                         ((P >> 4) & (0x7full << 28)) | ((P >> 5) & (0x7full << 35)) | ((P >> 6) & (0x7full << 42)) | ((P >> 7) & (0x7full << 49)) |
-                         ((uint64_t)(byte9 & 0x7fu) << 56) | ((uint64_t)(byte10 & 1u) << 63);
-            const uint32_t nb = len - 1;  // bytes of the varint, 1..10
-            if (nb < 10) x &= (1ull << (7 * nb)) - 1;
-            bits = f == 8 ? ((x >> 1) ^ (0 - (x & 1))) : x;  // zig-zag (binary.Varint)
-        }
-    } else if (f == 0) {
-        isnull = true;
-    } else {
-        err = (f == 1 || f == 2) ? DEC_VARLEN : DEC_BAD_FLAG;
-    }
+    int err = t0 + pos + len > a.n_bytes ? DEC_INSUFFICIENT  // the value is cut by the end of the buffer (number.go:45,115-123)
+                                         : tsq_dec_value(b0, b1, b2, len, &bits, &isnull, &real);
     if (err != DEC_OK) {
         dec_error(a, ord, err);
         return;
