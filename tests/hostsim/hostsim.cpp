@@ -124,3 +124,9 @@ int32_t sim_dec_value(const uint8_t* bytes, int64_t n, int64_t pos, uint32_t len
     return e;
 }
 }
+
+// ---- ORDER BY key images (tsq_sort_image.h)
+#include "../../tinysql_amd/csrc/tsq_sort_image.h"
+extern "C" void sim_sort_images(const void* data, int32_t type, int32_t desc, int64_t n, uint64_t* out) {
+    for (int64_t i = 0; i < n; i++) out[i] = tsq_sort_image(data, type, desc, (uint64_t)i);
+}

@@ -126,3 +126,31 @@ def test_value_decode_errors(sim):
     assert dec(b"\x08" + b"\xff" * 10 + b"\x01", 11)[0] == 3                                                 # continuation in the 10th byte
     assert dec(b"\x07\x00", 1)[0] == 4 and dec(b"\x02\x02ab", 1)[0] == 5
     assert dec(b"\x03\x80\x00", 9)[0] == 2                                                                   # cut by the end of the buffer
+
+
+@pytest.mark.parametrize("tp", [abi.I64, abi.U64, abi.F64, abi.F32])
+@pytest.mark.parametrize("desc", [False, True])
+def test_sort_key_images_order_like_the_reference_comparators(sim, tp, desc):
+    # tsq_sort_image.h: image(a) < image(b) <=> cmp(a, b) < 0 and equal images <=> cmp == 0, for the oracle's restatement of
+    # util/chunk/compare.go — checked on all pairs of a value set with the extremes, +-0, +-inf and denormals
+    sim.sim_sort_images.restype = None
+    sim.sim_sort_images.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
+    rng = np.random.default_rng(tp)
+    if tp == abi.I64:
+        v = np.concatenate([np.array([-(1 << 63), (1 << 63) - 1, 0, -1, 1], dtype=np.int64), rng.integers(-(1 << 63), (1 << 63) - 1, 60, dtype=np.int64), rng.integers(-5, 5, 20)])
+    elif tp == abi.U64:
+        v = np.concatenate([np.array([0, 1, (1 << 63) - 1, 1 << 63, (1 << 64) - 1], dtype=np.uint64), rng.integers(0, (1 << 64) - 1, 60, dtype=np.uint64)])
+    else:
+        big = 3.4028234663852886e38 if tp == abi.F32 else 1.7976931348623157e308
+        v = np.concatenate([[0.0, -0.0, np.inf, -np.inf, 5e-324, -5e-324, 1.0, -1.0, big, -big], np.ldexp(rng.random(60) - 0.5, rng.integers(-100, 100, 60)),
+                            rng.integers(-3, 3, 20) / 2.0])
+        v = v.astype(np.float32) if tp == abi.F32 else v.astype(np.float64)
+    v = np.ascontiguousarray(v)
+    img = np.zeros(len(v), np.uint64)
+    sim.sim_sort_images(v.ctypes.data_as(C.c_void_p), tp, 1 if desc else 0, len(v), img.ctypes.data_as(C.c_void_p))
+    chk = Chunk([Column(tp, v)])
+    for i in range(len(v)):
+        for j in range(len(v)):
+            c = orc.row_compare(chk, [0], [desc], i, j)
+            got = -1 if img[i] < img[j] else (1 if img[i] > img[j] else 0)
+            assert got == c, (v[i], v[j], desc)

@@ -23,6 +23,7 @@
 // Algorithmic bytes per pass: 12 B read + 12 B written per row (the implementation reads the images twice: 32 B).
 #include "tsq_radix.h"
 #include "tsq_stage.h"
+#include "tsq_sort_image.h"
 
 #include <memory>
 
@@ -38,19 +39,7 @@ struct SortKeySrc {
     int32_t desc;
 };
 
-// order-preserving 64-bit image (ascending); NaN sorts after +inf (CompareFloat64 answers "greater" for it, compare.go:104-112)
-__device__ __forceinline__ uint64_t sort_image(const SortKeySrc& k, uint32_t row) {
-    uint64_t u;
-    if (k.type == TSQ_I64) u = ((const uint64_t*)k.data)[row] ^ 0x8000000000000000ULL;
-    else if (k.type == TSQ_U64) u = ((const uint64_t*)k.data)[row];
-    else {
-        const double f = k.type == TSQ_F32 ? (double)((const float*)k.data)[row] : ((const double*)k.data)[row];
-        const uint64_t b = tsq_f64_bits(f);
-        // -0.0 == +0.0 for CompareFloat64: one image, so that such rows stay in input order like every other tie
-        u = f != f ? ~0ull : (f == 0.0 ? 0x8000000000000000ULL : ((b >> 63) ? ~b : (b | 0x8000000000000000ULL)));
-    }
-    return k.desc ? ~u : u;
-}
+__device__ __forceinline__ uint64_t sort_image(const SortKeySrc& k, uint32_t row) { return tsq_sort_image(k.data, k.type, k.desc, row); }
 
 struct SortArgs {
     SortKeySrc key;
