@@ -112,3 +112,21 @@ def test_device_pipeline_equals_host_chunk_pipeline_with_nulls(ctx, jt):
         assert g[:4] == w[:4], (k, g, w)                                  # firstrow(key), count, sum(int), avg(int): bit-exact
         for a, b in zip(g[4:], w[4:]):                                    # sum / max of doubles that are multiples of 1/4: exact as well
             assert a == b or (a is not None and b is not None and abs(a - b) <= 1e-9 * max(1.0, abs(b))), (k, g, w)
+
+
+def test_q3_shaped_plan_with_order_by_revenue_limit_10(ctx):
+    # the full Q3 shape: ... GROUP BY ... ORDER BY revenue DESC, o_orderdate LIMIT 10 — the TopN runs on the device chunk of groups
+    customer, orders, lineitem = q3.tables(0.05)
+    dev = [GP.DeviceChunk.from_host(ctx, t) for t in (customer, orders, lineitem)]
+    try:
+        out = GP.drain_device(q3.plan(ctx, *dev, batch_rows=50_000, topn=10))
+        rows = [r for c in out for r in c.rows()]
+        uk, dates, prios, sums = q3.reference(customer, orders, lineitem)
+        order = np.lexsort((dates, -sums))[:10]
+        assert len(rows) == 10
+        for r, i in zip(rows, order.tolist()):
+            assert r[0] == uk[i] and r[1] == dates[i] and r[2] == prios[i] and abs(r[3] - sums[i]) <= 1e-9 * abs(sums[i])
+        assert all(rows[i][3] >= rows[i + 1][3] for i in range(9))
+    finally:
+        for d in dev:
+            d.free()

@@ -9,6 +9,7 @@ plumbing around the C-ABI (`include/tsq.h`); all compute runs in libtsq:
   GpuProjectionExec  = tsq_expr_eval per output column                     (projection.go:54-434, evaluator.go:121-133)
   GpuHashJoinExec    = tsq_join_* with TSQ_COL_DEVICE columns              (join.go:31-146)
   GpuHashAggExec     = tsq_agg_* with TSQ_COL_DEVICE columns               (aggregate.go:134-588)
+  GpuSortExec        = tsq_sort_* (ORDER BY / TopN) with TSQ_COL_DEVICE columns (sort.go:27-318)
 A chunk returned by Next is valid until the next call of Next on the same operator (the Go operators
 recycle their chunks the same way, join.go:62-78).
 """
@@ -376,6 +377,56 @@ class GpuHashAggExec(GpuExecutor):
         if self.h:
             self.lib.tsq_agg_cancel(self.h)
             self.lib.tsq_agg_destroy(self.h)
+            self.h = None
+        if self.out:
+            for c in self.out:
+                c.free()
+            self.out = None
+        super().Close()
+
+
+class GpuSortExec(GpuExecutor):
+    """SortExec / TopNExec on device-resident chunks: tsq_sort_* with TSQ_COL_DEVICE columns (executor/sort.go:27-318)."""
+
+    def __init__(self, ctx, child, by_cols, by_desc, offset=0, count=-1, pull_rows=1 << 22):
+        super().__init__(ctx, child.Schema(), (child,))
+        self.child = child
+        cfg = abi.SortCfg()
+        cfg.n_cols = len(self.types)
+        for i, t in enumerate(self.types):
+            cfg.col_types[i] = t
+        cfg.n_keys = len(by_cols)
+        for i, (c, d) in enumerate(zip(by_cols, by_desc)):
+            cfg.key_col[i], cfg.key_desc[i] = c, 1 if d else 0
+        cfg.limit_offset, cfg.limit_count, cfg.max_chunk_size = offset, count, 1024
+        self.cfg, self.h, self.fetched, self.out = cfg, None, False, None
+        self.pull_rows = (pull_rows + 7) & ~7
+
+    def Open(self):
+        super().Open()
+        h = C.c_void_p()
+        _lib.check(self.lib.tsq_sort_create(self.ctx.h, C.byref(self.cfg), C.byref(h)), self.ctx.h)
+        self.h, self.fetched = h, False
+        self.out = self._buffers(self.pull_rows)
+
+    def Next(self):
+        if not self.fetched:
+            while True:
+                chk = self.child.Next()
+                if chk.NumRows() == 0:
+                    break
+                _lib.check(self.lib.tsq_sort_push(self.h, chk.cols(), len(chk.columns), chk.NumRows()), self.h)
+            _lib.check(self.lib.tsq_sort_finish(self.h), self.h)
+            self.fetched = True
+        n, eos = C.c_int64(0), C.c_int32(0)
+        oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
+        _lib.check(self.lib.tsq_sort_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
+        return DeviceChunk(self.out, n.value) if n.value else EOS
+
+    def Close(self):
+        if self.h:
+            self.lib.tsq_sort_cancel(self.h)
+            self.lib.tsq_sort_destroy(self.h)
             self.h = None
         if self.out:
             for c in self.out:

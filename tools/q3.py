@@ -4,7 +4,7 @@
     SELECT l_orderkey, o_orderdate, o_shippriority, SUM(l_extendedprice * (1 - l_discount)) AS revenue
     FROM customer, orders, lineitem
     WHERE c_mktsegment = SEG AND c_custkey = o_custkey AND l_orderkey = o_orderkey AND o_orderdate < D AND l_shipdate > D
-    GROUP BY l_orderkey, o_orderdate, o_shippriority
+    GROUP BY l_orderkey, o_orderdate, o_shippriority   [ORDER BY revenue DESC, o_orderdate LIMIT 10 with --topn]
 
 TinySQL has int / real / string types only (types/eval_type.go:21-28): dates are day numbers, the market segment an int code.
 Plan (what planner/core would produce with hash joins): Selection(customer) -> build;  Selection(orders) probes it;
@@ -72,7 +72,7 @@ def tables_device(ctx, sf, seed=7):
     return customer, orders, lineitem
 
 
-def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None):
+def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None, topn=0):
     F, Col, K = E.ScalarFunction, E.Column, E.Constant
     cust = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, I), K(SEG))], jit=jit)
     ords = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, orders_d, batch_rows), [F("lt", Col(2, I), K(D))], jit=jit)
@@ -83,7 +83,11 @@ def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None):
     j2 = G.GpuHashJoinExec(ctx, line, j1, [0], [0], abi.JOIN_INNER, 1)
     proj = G.GpuProjectionExec(ctx, j2, [Col(0, I), Col(6, I), Col(7, I), F("mul", Col(2, R), F("minus", K(1.0), Col(3, R)))], jit=jit)
     aggs = [AggFuncDesc(abi.AGG_FIRSTROW, 0, I), AggFuncDesc(abi.AGG_FIRSTROW, 1, I), AggFuncDesc(abi.AGG_FIRSTROW, 2, I), AggFuncDesc(abi.AGG_SUM, 3, R)]
-    return G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs)
+    agg = G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs)
+    if not topn:
+        return agg
+    # ... ORDER BY revenue DESC, o_orderdate LIMIT topn (TopNExec, executor/sort.go:146-318); agg output: orderkey, date, prio, revenue
+    return G.GpuSortExec(ctx, agg, [3, 1], [True, False], offset=0, count=topn, pull_rows=max(8, topn))
 
 
 def reference(customer, orders, lineitem):
@@ -131,6 +135,9 @@ def main():
     trace = "--trace" in sys.argv
     if trace:
         sys.argv.remove("--trace")
+    topn = 10 if "--topn" in sys.argv else 0
+    if topn:
+        sys.argv.remove("--topn")
     on_device = "--device-gen" in sys.argv
     if on_device:
         sys.argv.remove("--device-gen")
@@ -152,7 +159,7 @@ def main():
             for rep in range(4):
                 if trace and rep == 3:
                     ctx.lib = TimedLib(ctx.lib)
-                exe = plan(ctx, *dev)
+                exe = plan(ctx, *dev, topn=topn)
                 ctx.sync()
                 t1 = time.perf_counter()
                 exe.Open()
@@ -178,7 +185,7 @@ def main():
                     print("%-28s %5d calls %9.3f ms" % (k, n, t * 1e3), file=sys.stderr)
                 print("last rep: total %.3f ms, in Next %.3f ms" % (dt * 1e3, t_exec * 1e3), file=sys.stderr)
             rows_in = customer.NumRows() + orders.NumRows() + lineitem.NumRows()
-            print(json.dumps({"query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg", "SF": sf, "input_rows": rows_in,
+            print(json.dumps({"query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg" + ("->TopN(10)" if topn else ""), "SF": sf, "input_rows": rows_in,
                               "tables": "generated in HBM (tsq_gen_column)" if on_device else "numpy, copied to HBM once",
                               "groups": groups, "best_s": best, "exec_s_result_in_hbm": best_exec, "input_rows_per_s": rows_in / best,
                               "input_rows_per_s_result_in_hbm": rows_in / best_exec, "host_table_gen_s": gen_s}))
