@@ -221,7 +221,8 @@ __device__ __forceinline__ void dec_error(const DecArgs& a, unsigned long long o
 // decodes the value at tile position pos (ordinal ord) and stores it; t0 = byte offset of the tile in the stream.
 // The 12 bytes starting at pos are fetched as four aligned LDS words + a byte funnel shift; big-endian payloads are two
 // byte swaps, a varint is eight shift-and-mask terms cut to its length — no per-byte loop.
-__device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes, uint32_t pos, uint32_t len, unsigned long long ord, int64_t t0, uint32_t ncols) {
+__device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes, uint32_t pos, uint32_t len, unsigned long long ord, unsigned long long row, uint32_t col,
+                                          int64_t t0) {
     const uint32_t* W = (const uint32_t*)bytes;
     const uint32_t q = pos >> 2, sh = pos & 3u;
     uint32_t w[4];
@@ -237,8 +238,6 @@ __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes
         dec_error(a, ord, err);
         return;
     }
-    const unsigned long long row = ord / ncols;
-    const uint32_t col = (uint32_t)(ord - row * ncols);
     if (a.col_type[col] == TSQ_F32) {
         uint32_t w32 = 0;
         if (!isnull) {
@@ -258,7 +257,7 @@ __device__ __forceinline__ void dec_value(const DecArgs& a, const uint8_t* bytes
 
 __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
     __shared__ __align__(16) DecTile T;
-    __shared__ uint32_t s_seg_entry[TSQ_DEC_NSEG], s_seg_base[TSQ_DEC_NSEG], s_next[2];
+    __shared__ uint32_t s_next[2];
     __shared__ uint8_t s_entry[TSQ_DEC_NSB];
     __shared__ uint32_t s_base[TSQ_DEC_NSB];
     const unsigned long long limit = (unsigned long long)a.cap_rows * (unsigned long long)a.n_cols;  // values wanted
@@ -271,27 +270,25 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
         {
             const int64_t t0 = t * TSQ_DEC_TB;
             const uint32_t valid = dec_prepare_tile<true>(a, t, T);
-            if (threadIdx.x == 0) {  // the true path through the 20 segments ...
+            if (threadIdx.x < TSQ_DEC_NSEG) {
+                // segment `seg` finds its own entry on the true path (the segments before it, <= 19 steps) and then walks its
+                // 13 sub-blocks; the last segment also knows where the path leaves the tile
+                const uint32_t seg = threadIdx.x;
                 uint32_t state = tile_entry, base = 0;
-                for (int sg = 0; sg < TSQ_DEC_NSEG; sg++) {
-                    s_seg_entry[sg] = state;
-                    s_seg_base[sg] = base;
+                for (uint32_t sg = 0; sg < seg; sg++) {
                     base += T.seg_cnt[sg][state];
                     state = T.seg_exit[sg][state];
                 }
-                s_next[0] = state;  // ... leaves the tile here, after `base` values
-                s_next[1] = base;
-            }
-            __syncthreads();
-            if (threadIdx.x < TSQ_DEC_NSEG) {  // ... and through the sub-blocks of every segment
-                const uint32_t seg = threadIdx.x;
-                uint32_t state = s_seg_entry[seg], base = s_seg_base[seg];
                 const uint32_t i1 = seg * TSQ_DEC_SEGLEN + TSQ_DEC_SEGLEN < TSQ_DEC_NSB ? seg * TSQ_DEC_SEGLEN + TSQ_DEC_SEGLEN : TSQ_DEC_NSB;
                 for (uint32_t i = seg * TSQ_DEC_SEGLEN; i < i1; i++) {
                     s_entry[i] = (uint8_t)state;
                     s_base[i] = base;
                     base += dec_cnt_of(T.cnt[i][0], T.cnt[i][1], T.cnt[i][2], state);
                     state = (uint32_t)(T.map[i] >> (4 * state)) & 15u;
+                }
+                if (seg == TSQ_DEC_NSEG - 1) {
+                    s_next[0] = state;  // the true path leaves the tile here, after `base` values
+                    s_next[1] = base;
                 }
             }
             __syncthreads();
@@ -300,12 +297,16 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
                 const uint32_t lim = sblo + TSQ_DEC_SB <= valid ? (uint32_t)TSQ_DEC_SB : (valid > sblo ? valid - sblo : 0u);
                 uint32_t pos = s_entry[threadIdx.x];
                 unsigned long long ord = tile_base + s_base[threadIdx.x];
+                // (row, column) of the first value by one division, of the following ones by counting
+                unsigned long long row = ord / ncols;
+                uint32_t col = (uint32_t)(ord - row * ncols);
                 while (pos < lim) {
                     const uint32_t len = dec_len_at(T.bytes, sblo + pos);
                     if (ord == limit) a.result[1] = (unsigned long long)(t0 + sblo + pos);  // first byte that is not consumed
-                    if (ord < limit) dec_value(a, T.bytes, sblo + pos, len, ord, t0, ncols);
+                    if (ord < limit) dec_value(a, T.bytes, sblo + pos, len, ord, row, col, t0);
                     pos += len;
                     ord++;
+                    if (++col == ncols) { col = 0; row++; }
                 }
             }
             tile_entry = s_next[0];
