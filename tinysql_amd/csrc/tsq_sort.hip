@@ -303,6 +303,12 @@ struct GatherRowsArgs {
     void* dst[TSQ_MAX_COLS];
     uint8_t* dst_bitmap[TSQ_MAX_COLS];
     int32_t es[TSQ_MAX_COLS];
+    // The first ORDER BY column, when it is an integer column, is not gathered at all: its sorted images are still there
+    // (consecutive reads) and the value is the inverse of the image.  (Reals are gathered: -0.0 and NaN payloads are not
+    // recoverable from the image.)
+    const uint64_t* key_img;  // images in output order, already offset; null: gather every column
+    int32_t key_col, key_desc;
+    uint64_t key_flip;        // 0x8000... for a signed column, 0 for an unsigned one
 };
 // blockIdx.y = column; eight consecutive output rows per thread (independent gathers, one bitmap byte)
 __global__ void __launch_bounds__(256) k_gather_rows(GatherRowsArgs a) {
@@ -320,7 +326,10 @@ __global__ void __launch_bounds__(256) k_gather_rows(GatherRowsArgs a) {
             if (ok && a.src_nulls[c]) ok = (a.src_nulls[c][id[i] >> 3] >> (id[i] & 7)) & 1;
             nn |= ok ? (1u << i) : 0u;
         }
-        if (a.es[c] == 8) {
+        if (a.key_img && c == a.key_col) {  // I64: image ^ sign bit, U64: the image itself (tsq_sort_image.h), DESC inverted
+            const uint64_t flip = (a.key_desc ? ~0ull : 0ull) ^ a.key_flip;
+            for (int i = 0; i < n; i++) ((uint64_t*)a.dst[c])[r0 + i] = (nn >> i) & 1 ? (a.key_img[r0 + i] ^ flip) : 0ull;
+        } else if (a.es[c] == 8) {
             uint64_t v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = (nn >> i) & 1 ? ((const uint64_t*)a.src[c])[id[i]] : 0ull;
@@ -351,6 +360,7 @@ struct tsq_sort {
     int cur = 0;                                       // which of idx[] holds the final row ids
     std::vector<DevBuf> odata, obm;                    // gather targets for host pulls
     int32_t passes = 0, passes_skipped = 0;
+    bool key_img_kept = false;
     int64_t rows_sorted = 0;                           // rows that went through the radix passes (TopN: the selected candidates)
     double sort_ms = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -603,7 +613,12 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
     if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("sort: ") + hipGetErrorString(e));
     float ms = 0;
     if (hipEventElapsedTime(&ms, s->ev[0], s->ev[1]) == hipSuccess) s->sort_ms = ms;
-    for (int i = 0; i < 2; i++) s->img[i].release();
+    {   // the sorted images of the first ORDER BY column stay for the pulls when it is an integer column (see k_gather_rows)
+        const int32_t t0 = s->cfg.col_types[s->cfg.key_col[0]];
+        s->key_img_kept = t0 == TSQ_I64 || t0 == TSQ_U64;
+        s->img[s->cur ^ 1].release();
+        if (!s->key_img_kept) s->img[s->cur].release();
+    }
     s->idx[s->cur ^ 1].release();
     s->hist.release();
     return TSQ_OK;
@@ -628,6 +643,12 @@ TSQ_API tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols,
     memset(&g, 0, sizeof g);
     g.idx = s->idx[s->cur].as<uint32_t>() + s->cursor;
     g.rows = n;
+    if (s->key_img_kept) {
+        g.key_img = s->img[s->cur].as<uint64_t>() + s->cursor;
+        g.key_col = s->cfg.key_col[0];
+        g.key_desc = s->cfg.key_desc[0] ? 1 : 0;
+        g.key_flip = s->cfg.col_types[g.key_col] == TSQ_I64 ? 0x8000000000000000ULL : 0ull;
+    }
     if (!odev) { s->odata.resize(n_cols); s->obm.resize(n_cols); }
     for (int c = 0; c < n_cols; c++) {
         if (!out_cols[c].data || !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "pull: out columns need data and null_bitmap buffers");
