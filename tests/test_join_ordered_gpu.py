@@ -84,3 +84,16 @@ def test_ordered_large_device_join_keeps_probe_order(ctx):
     assert (np.diff(b)[same] > 0).all()
     cnt = np.bincount(build.columns[0].data, minlength=500_000)
     assert got.NumRows() == int(cnt[probe.columns[0].data].sum())
+
+
+def test_ordered_with_heavily_duplicated_keys(ctx, orc):
+    # 3000 inner rows of one key x 40 outer rows of it (match lists far beyond the insertion-sort range) next to ordinary keys
+    rng = np.random.default_rng(13)
+    ik = np.concatenate([np.full(3000, 7), rng.integers(100, 2000, 5000)])
+    rng.shuffle(ik)
+    ok = np.concatenate([np.full(40, 7), rng.integers(100, 2000, 3000)])
+    rng.shuffle(ok)
+    innr = Chunk([Column(abi.I64, ik), Column(abi.I64, np.arange(len(ik)))])
+    outer = Chunk([Column(abi.I64, ok), Column(abi.I64, np.arange(len(ok)))])
+    cfg = H.join_cfg([abi.I64, abi.I64], [abi.I64, abi.I64], [0], [0], abi.JOIN_INNER, 1)
+    assert G.run_join(ctx, cfg, innr, outer, chunk_rows=1 << 20, pull_rows=1 << 20, ordered=True).rows() == orc.hash_join(cfg, innr, outer).rows()

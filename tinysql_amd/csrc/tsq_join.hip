@@ -395,6 +395,42 @@ __global__ void __launch_bounds__(256) k_gather_cols(GatherArgs a) {
     }
 }
 
+// in-place sort of one probe row's pairs by build row id (the high word): insertion sort for the usual short match lists,
+// heapsort beyond 32 so that a heavily duplicated key costs n log n, not n^2, per probe row
+__device__ __noinline__ void sort_pairs_by_build_row(unsigned long long* p, uint32_t n) {
+    if (n <= 32) {
+        for (uint32_t i = 1; i < n; i++) {
+            const unsigned long long v = p[i];
+            uint32_t q = i;
+            while (q > 0 && (p[q - 1] >> 32) > (v >> 32)) {
+                p[q] = p[q - 1];
+                q--;
+            }
+            p[q] = v;
+        }
+        return;
+    }
+    auto sift = [&](uint32_t root, uint32_t end) {  // max-heap on the build row id over p[0, end)
+        const unsigned long long v = p[root];
+        for (;;) {
+            uint32_t child = 2 * root + 1;
+            if (child >= end) break;
+            if (child + 1 < end && (p[child + 1] >> 32) > (p[child] >> 32)) child++;
+            if ((p[child] >> 32) <= (v >> 32)) break;
+            p[root] = p[child];
+            root = child;
+        }
+        p[root] = v;
+    };
+    for (uint32_t i = n / 2; i-- > 0;) sift(i, n);
+    for (uint32_t end = n - 1; end > 0; end--) {
+        const unsigned long long t = p[0];
+        p[0] = p[end];
+        p[end] = t;
+        sift(0, end);
+    }
+}
+
 template <bool MULTI, bool GEN>
 __global__ void __launch_bounds__(256) k_probe_emit(ProbeArgs a) {
     __shared__ unsigned long long s_cur;
@@ -426,16 +462,8 @@ __global__ void __launch_bounds__(256) k_probe_emit(ProbeArgs a) {
                 if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0))
                     for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) { write_pair(a, pos + seen++, k, brow); });
                 // the slots of a chain are filled in whatever order the build's CAS won: put this row's matches into
-                // build-row (= insertion) order (insertion sort: match lists are short unless the key is heavily duplicated)
-                for (uint32_t i = 1; i < n_out; i++) {
-                    const unsigned long long v = a.pairs[pos + i];
-                    uint32_t q = i;
-                    while (q > 0 && (a.pairs[pos + q - 1] >> 32) > (v >> 32)) {
-                        a.pairs[pos + q] = a.pairs[pos + q - 1];
-                        q--;
-                    }
-                    a.pairs[pos + q] = v;
-                }
+                // build-row (= insertion) order
+                sort_pairs_by_build_row(a.pairs + pos, n_out);
             }
             __syncthreads();  // s_wsum is reused by the next step
         }
