@@ -204,3 +204,39 @@ def test_topn_radix_select_on_large_inputs(ctx, orc, case):
     want = orc.sort_rows(chk, *keys).slice(off, off + cnt)
     _same_rows(got, want)
     assert got.NumRows() == cnt and stats[0]["rows"] < n // 2
+
+
+def test_sort_call_sequence_and_cancel_contract(ctx):
+    # create -> push* -> finish -> pull* -> destroy; cancel from anywhere; misuse is an error, not a crash
+    lib = ctx.lib
+    cfg = abi.SortCfg()
+    cfg.n_cols, cfg.n_keys, cfg.limit_offset, cfg.limit_count = 1, 1, 0, -1
+    cfg.col_types[0] = abi.I64
+    bad = abi.SortCfg()
+    bad.n_cols, bad.n_keys, bad.limit_count = 1, 1, -1
+    bad.col_types[0] = 4  # TSQ_BYTES: var-len columns keep the Go operator
+    h = C.c_void_p()
+    assert lib.tsq_sort_create(ctx.h, C.byref(bad), C.byref(h)) == abi.ERR_UNSUPPORTED
+    bad.col_types[0], bad.key_col[0] = abi.I64, 3
+    assert lib.tsq_sort_create(ctx.h, C.byref(bad), C.byref(h)) == abi.ERR_INVALID
+    _lib.check(lib.tsq_sort_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        chk = Chunk([Column(abi.I64, np.array([3, 1, 2]))])
+        keep = []
+        from tinysql_amd.chunk import make_cols, out_buffers
+        cols = make_cols(chk.columns, keep)
+        out, bufs = out_buffers([abi.I64], 8, keep)
+        n, eos = C.c_int64(0), C.c_int32(0)
+        assert lib.tsq_sort_pull(h, out, 1, 8, C.byref(n), C.byref(eos)) == abi.ERR_INVALID           # pull before finish
+        _lib.check(lib.tsq_sort_push(h, cols, 1, 3), h)
+        assert lib.tsq_sort_push(h, cols, 2, 3) == abi.ERR_INVALID                                    # wrong column count
+        _lib.check(lib.tsq_sort_finish(h), h)
+        assert lib.tsq_sort_push(h, cols, 1, 3) == abi.ERR_INVALID                                    # push after finish
+        _lib.check(lib.tsq_sort_pull(h, out, 1, 8, C.byref(n), C.byref(eos)), h)
+        assert n.value == 3 and bufs[0][0][:3].tolist() == [1, 2, 3]
+        _lib.check(lib.tsq_sort_pull(h, out, 1, 8, C.byref(n), C.byref(eos)), h)
+        assert n.value == 0 and eos.value == 1                                                         # idempotent end of stream
+        _lib.check(lib.tsq_sort_cancel(h), h)
+        assert lib.tsq_sort_pull(h, out, 1, 8, C.byref(n), C.byref(eos)) == abi.ERR_CANCELLED
+    finally:
+        lib.tsq_sort_destroy(h)
