@@ -209,3 +209,25 @@ def test_full_size_round_trip_property(ctx, orc):
     for a, b in zip(got.columns, chk.columns):
         assert a.notnull is None or a.notnull.all()
         assert (a.data.view(np.uint64) == b.data.view(np.uint64)).all()
+
+
+def test_decode_argument_contract(ctx, orc):
+    lib = ctx.lib
+    from tinysql_amd.chunk import out_buffers
+    keep = []
+    out, bufs = out_buffers([abi.I64], 8, keep)
+    n, used = C.c_int64(-1), C.c_int64(-1)
+    tp = (C.c_int32 * 1)(abi.I64)
+    raw = orc.encode_rows(Chunk([Column(abi.I64, np.array([5, 6, 7]))]))
+    p = raw.ctypes.data_as(C.c_void_p)
+    # nothing to do is not an error: empty response, or a chunk that wants no rows (select_result.go:139-142)
+    assert lib.tsq_rows_decode(ctx.h, p, 0, 0, 1, tp, out, 8, C.byref(n), C.byref(used)) == abi.OK and (n.value, used.value) == (0, 0)
+    assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, tp, out, 0, C.byref(n), C.byref(used)) == abi.OK and (n.value, used.value) == (0, 0)
+    # misuse: NULL outputs, negative sizes, too many columns, var-len column type
+    assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, tp, out, 8, None, C.byref(used)) == abi.ERR_INVALID
+    assert lib.tsq_rows_decode(ctx.h, p, -1, 0, 1, tp, out, 8, C.byref(n), C.byref(used)) == abi.ERR_INVALID
+    assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 17, tp, out, 8, C.byref(n), C.byref(used)) == abi.ERR_UNSUPPORTED
+    assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, (C.c_int32 * 1)(4), out, 8, C.byref(n), C.byref(used)) == abi.ERR_UNSUPPORTED
+    # and the normal call still works on the same context afterwards
+    _lib.check(lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, tp, out, 8, C.byref(n), C.byref(used)), ctx.h)
+    assert n.value == 3 and used.value == raw.size and bufs[0][0][:3].tolist() == [5, 6, 7]
