@@ -142,6 +142,8 @@ def main():
                 if n_local:
                     pc = (abi.Col * 1)(dev_col(rpk.data_ptr(), n_local))
                     _lib.check(lib.tsq_join_probe_push(h, pc, 1, n_local, None), h)
+                    local_probe[0] += n_local
+                    local_probe[1] += 1
 
         def full_sync():
             torch.cuda.synchronize()
@@ -158,11 +160,13 @@ def main():
             # (== torch.cuda.synchronize() for this process; torch is not loaded at N=1)
             ctx.sync()
 
+    local_probe = [0, 0]  # N>1: rows this rank probed / probe batches it pushed (for the per-launch roofline figure)
     keep = []
     for _ in range(args.warmup):
         keep.append(step())
     full_sync()
     keep.clear()
+    local_probe[0] = local_probe[1] = 0
     setup_s = time.time() - t_setup
 
     # ---------------------------------------------------------------- timed region: exactly K steps
@@ -266,6 +270,21 @@ def main():
                                             "algorithmic_bytes_per_launch": pb, "achieved": pb / (part_ms * 1e-3) / 1e9,
                                             "frac": pb / (part_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic_part}
             out["radix_overflow_rows"] = st.radix_overflow_rows
+    elif radix and local_probe[1] > 0 and kernel_ms > 0:
+        # N>1: the local probe runs once per received piece; price the same kernel per launch on rank 0's own pieces
+        rows_per_launch = local_probe[0] / local_probe[1]
+        ab = 24.0 * rows_per_launch
+        out["roofline"] = {
+            "bound": "hbm", "achieved": ab / (kernel_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+            "frac": ab / (kernel_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+            "kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": ab,
+            "note": "rank 0, per probe launch (one launch per received piece of %.3g rows on average, %d pieces per step); "
+                    "the step also contains tsq_radix_split and the RCCL all-to-all, which this figure does not price"
+                    % (rows_per_launch, args.exchange_chunks),
+            "partition": {"kernel": "k_radix_partition<1024,16,4,0,false>", "kernel_ms": part_ms,
+                          "algorithmic_bytes_per_launch": 16.0 * rows_per_launch,
+                          "achieved": 16.0 * rows_per_launch / (part_ms * 1e-3) / 1e9 if part_ms > 0 else None},
+        }
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     if rank == 0 and not distributed and not args.no_cpu_baseline:
