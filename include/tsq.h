@@ -395,6 +395,34 @@ tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_byt
                            const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out,
                            int64_t* bytes_consumed);
 
+/* ---------------------------------------------------------------- stored rows (rowcodec v2) -> columns (SURVEY.md §8 f, rank 4)
+ * Replaces the per-row loop around rowcodec.ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238; row.fromBytes /
+ * findColID / getData, util/rowcodec/row.go:37-150) — equivalently the storage-side chain BytesDecoder.DecodeToBytes
+ * (decoder.go:252-322, mocktikv tableScanExec, store/mockstore/mocktikv/executor.go:124-196) + readRowsData + DecodeOne —
+ * for fixed-width schemas: a table scan's KV values, each one row in the new row format
+ *     [128][flag: bit0 = large][numNotNull u16][numNull u16][colIDs: u8 | u32 each, not-null ids sorted then null ids sorted]
+ *     [end offsets of the not-null values: u16 | u32 each][values: ints 1/2/4/8 little-endian bytes, reals 8 bytes memcomparable]
+ * become chunk columns.  `values` (n_bytes bytes) holds the rows back to back, row r = bytes [offsets[r], offsets[r+1])
+ * (offsets: nrows+1 non-decreasing entries, the last one <= n_bytes), handles[r] = the row's int64 handle from its key (may be NULL when no column is the handle).  data_flags:
+ * TSQ_COL_DEVICE when values / offsets / handles are in HBM.  cols[c] describes output column c. */
+#define TSQ_RC_HANDLE      1u /* the column is the handle column (col.ID == handleColID, decoder.go:165-168): value = handles[r]   */
+#define TSQ_RC_HAS_DEFAULT 2u /* column absent from the row: def_bits instead of NULL (defDatum, decoder.go:186-194)              */
+typedef struct tsq_rowcodec_col {
+    int64_t  col_id;    /* ColInfo.ID                                                                                          */
+    int32_t  type;      /* TSQ_I64 (signed int types, year), TSQ_U64 (UnsignedFlag), TSQ_F32 (TypeFloat), TSQ_F64 (TypeDouble)  */
+    uint32_t flags;     /* TSQ_RC_*                                                                                             */
+    uint64_t def_bits;  /* default value as it is stored in the column (a float32 default in the low 4 bytes)                  */
+} tsq_rowcodec_col;
+/* out_cols: host or TSQ_COL_DEVICE buffers for nrows rows (data + null_bitmap).  Errors are decided by the FIRST offending
+ * row in scan order; *nrows_out then holds the rows before it (already in out_cols): TSQ_ERR_INVALID with tsq_last_error =
+ * "invalid codec version" (row.go:54-56) | "insufficient bytes to decode value" (a real shorter than 8 bytes, codec
+ * number.go:84-86) | "malformed row" (header / id / offset arrays or a value running past the row, an int value that is not
+ * 1, 2, 4 or >= 8 bytes long: the reference panics with an index out of range there).  A var-len column type ->
+ * TSQ_ERR_UNSUPPORTED at call time: that scan keeps the Go decoder. */
+tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_bytes, const int64_t* offsets,
+                               const int64_t* handles, int64_t nrows, uint32_t data_flags, int32_t n_cols,
+                               const tsq_rowcodec_col* cols, tsq_col* out_cols, int64_t* nrows_out);
+
 /* ---------------------------------------------------------------- ORDER BY / TopN (SURVEY.md §8 f, rank 3)
  * Replaces SortExec (executor/sort.go:27-144) and TopNExec (sort.go:146-318): all child rows are pushed, tsq_sort_finish
  * orders them by the ByItems — bare columns (sort.go:107-113), each ascending or descending, compared like

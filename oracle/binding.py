@@ -84,6 +84,15 @@ def load():
     lib.orc_row_compare.argtypes = [C.POINTER(abi.Col), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64]
     lib.orc_sort_rows.restype = None
     lib.orc_sort_rows.argtypes = [C.POINTER(abi.Col), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, P]
+    lib.orc_rowcodec_encode.restype = C.c_int64
+    lib.orc_rowcodec_encode.argtypes = [C.POINTER(abi.Col), C.POINTER(C.c_int64), C.c_int32, C.c_int64, C.c_int64, P, P, C.c_int64, P]
+    lib.orc_rowcodec_decode.restype = C.c_int32
+    lib.orc_rowcodec_decode.argtypes = [P, P, P, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_int64)]
+    lib.orc_rowcodec_to_old_bytes.restype = C.c_int64
+    lib.orc_rowcodec_to_old_bytes.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, P, C.c_int64]
+    lib.orc_rowcodec_column_is_null.restype = C.c_int32
+    lib.orc_rowcodec_column_is_null.argtypes = [P, C.c_int64, C.c_int64, C.c_int32]
     _lib = lib
     return lib
 
@@ -335,3 +344,75 @@ def merge_join(cfg, inner_chunk, outer_chunk):
     if not res:
         raise OracleError(st.value)
     return _result_to_chunk(lib, res)
+
+
+# ---- stored rows, rowcodec v2 (oracle/rowcodec.cpp)
+ROWCODEC_STATUS = {0: "ok", 1: "invalid codec version", 2: "malformed row", 3: "insufficient bytes to decode value"}
+
+
+def rowcodec_cols(specs):
+    """specs: [(col_id, type, flags, def_bits)] -> tsq_rowcodec_col array."""
+    arr = (abi.RowcodecCol * len(specs))()
+    for i, sp in enumerate(specs):
+        arr[i].col_id, arr[i].type = sp[0], sp[1]
+        arr[i].flags = sp[2] if len(sp) > 2 else 0
+        arr[i].def_bits = sp[3] if len(sp) > 3 else 0
+    return arr
+
+
+def rowcodec_encode(chunk, col_ids, pad_col_id=-1, pad_len=None):
+    """Encoder.Encode (util/rowcodec/encoder.go:34-194) of every row -> (bytes np.uint8, offsets np.int64[n+1])."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    n = chunk.NumRows()
+    ids = (C.c_int64 * len(col_ids))(*col_ids)
+    pl = None
+    extra = 0
+    if pad_col_id >= 0:
+        pl = np.ascontiguousarray(pad_len, dtype=np.int64)
+        extra = int(pl.sum()) + 8 * n
+    cap = n * (6 + 16 * (len(col_ids) + 1)) + extra + 64
+    out = np.zeros(cap, np.uint8)
+    offs = np.zeros(n + 1, np.int64)
+    got = lib.orc_rowcodec_encode(cols, ids, len(col_ids), n, pad_col_id, pl.ctypes.data_as(C.c_void_p) if pl is not None else None,
+                                  out.ctypes.data_as(C.c_void_p), out.size, offs.ctypes.data_as(C.c_void_p))
+    assert got >= 0
+    return out[:got].copy(), offs
+
+
+def rowcodec_decode(values, offsets, handles, specs):
+    """the scan loop around ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238) -> (status, Chunk of the rows before an error)."""
+    lib = load()
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    types = [sp[1] for sp in specs]
+    bufs = [np.zeros(max(n, 1), dtype=np_dtype(t)) for t in types]
+    nns = [np.zeros(max(n, 1), dtype=np.uint8) for _ in types]
+    pd = (C.c_void_p * len(types))(*[b.ctypes.data for b in bufs])
+    pn = (C.c_void_p * len(types))(*[b.ctypes.data for b in nns])
+    h = np.ascontiguousarray(handles, dtype=np.int64) if handles is not None else np.zeros(max(n, 1), np.int64)
+    got = C.c_int64(0)
+    st = lib.orc_rowcodec_decode(values.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), n,
+                                 rowcodec_cols(specs), len(specs), pd, pn, C.byref(got))
+    chk = Chunk([Column(t, b[:got.value], nn[:got.value].astype(bool)) for t, b, nn in zip(types, bufs, nns)])
+    return st, chk
+
+
+def rowcodec_to_old_bytes(row, handle, specs):
+    """BytesDecoder.DecodeToBytes (decoder.go:252-322) of one row: old datum bytes of the requested columns, concatenated."""
+    lib = load()
+    row = np.ascontiguousarray(row, dtype=np.uint8)
+    out = np.zeros(12 * len(specs) + row.size + 16, np.uint8)
+    got = lib.orc_rowcodec_to_old_bytes(row.ctypes.data_as(C.c_void_p), row.size, handle, rowcodec_cols(specs), len(specs),
+                                        out.ctypes.data_as(C.c_void_p), out.size)
+    if got < 0:
+        raise OracleError(int(-got))
+    return out[:got].copy()
+
+
+def rowcodec_column_is_null(row, col_id, has_default=False):
+    lib = load()
+    row = np.ascontiguousarray(row, dtype=np.uint8)
+    return lib.orc_rowcodec_column_is_null(row.ctypes.data_as(C.c_void_p), row.size, col_id, 1 if has_default else 0)

@@ -110,6 +110,19 @@ int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int3
 int32_t orc_decode_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, const int32_t* types, int64_t cap_rows, void** out_data,
                         uint8_t** out_notnull, int64_t* nrows_out, int64_t* consumed);
 
+/* ---- stored rows, rowcodec v2 (rowcodec.cpp; SURVEY.md §8 f rank 4) */
+/* Encoder.Encode (util/rowcodec/encoder.go:34-194) of every row of a fixed-width chunk (+ an optional KindBytes pad column) */
+int64_t orc_rowcodec_encode(const tsq_col* cols, const int64_t* col_ids, int32_t n_cols, int64_t nrows, int64_t pad_col_id, const int64_t* pad_len,
+                            uint8_t* out, int64_t cap, int64_t* offsets_out);
+/* the scan loop around ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238) */
+int32_t orc_rowcodec_decode(const uint8_t* values, const int64_t* offsets, const int64_t* handles, int64_t nrows, const tsq_rowcodec_col* cols,
+                            int32_t n_cols, void** out_data, uint8_t** out_notnull, int64_t* nrows_out);
+/* BytesDecoder.DecodeToBytes (decoder.go:252-322) of one row, values concatenated in column order */
+int64_t orc_rowcodec_to_old_bytes(const uint8_t* row_data, int64_t len, int64_t handle, const tsq_rowcodec_col* cols, int32_t n_cols, uint8_t* out,
+                                  int64_t cap);
+/* row.ColumnIsNull (util/rowcodec/row.go:152-165) */
+int32_t orc_rowcodec_column_is_null(const uint8_t* row_data, int64_t len, int64_t col_id, int32_t has_default);
+
 /* ---- SortExec / TopNExec row order (sort_rows.cpp; SURVEY.md §8 f rank 3) */
 int32_t orc_row_compare(const tsq_col* cols, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t i, int64_t j);
 void    orc_sort_rows(const tsq_col* cols, int64_t nrows, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t* perm_out);

@@ -130,3 +130,76 @@ int32_t sim_dec_value(const uint8_t* bytes, int64_t n, int64_t pos, uint32_t len
 extern "C" void sim_sort_images(const void* data, int32_t type, int32_t desc, int64_t n, uint64_t* out) {
     for (int64_t i = 0; i < n; i++) out[i] = tsq_sort_image(data, type, desc, (uint64_t)i);
 }
+
+#include <stdlib.h>
+// ---- stored rows -> columns (tsq_rowcodec_dp.h): a CPU walk-through of k_rowcodec_decode (tsq_rowcodec.hip) with the same tile
+// plan, the same staged copy (aligned 16-byte vectors into a 48 KB tile; bytes outside `values` read as zero here), the same
+// per-lane row code and the same bitmap bytes (one ballot per 64 rows, lanes 0..7 store one byte each when it exists).
+#include "../../tinysql_amd/csrc/tsq_rowcodec_dp.h"
+namespace {
+struct SimBytes {
+    const uint8_t* p;
+    uint32_t operator()(uint32_t i) const { return p[i]; }
+};
+}  // namespace
+extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, uint64_t base_addr, const int64_t* offsets, const int64_t* handles,
+                                        int64_t nrows, const tsq_rowcodec_col* cols, int32_t n_cols, void** out, uint8_t** out_bm, uint32_t lds_bytes,
+                                        int64_t* staged_tiles) {
+    const int NT = 256;
+    uint64_t err = ~0ull;
+    const int64_t n_tiles = (nrows + NT - 1) / NT, bm_bytes = (nrows + 7) / 8;
+    uint8_t* tile = (uint8_t*)malloc(lds_bytes + 16);
+    *staged_tiles = 0;
+    for (int64_t t = 0; t < n_tiles; t++) {
+        const int64_t r0 = t * NT, r1 = r0 + NT < nrows ? r0 + NT : nrows;
+        const int64_t tile_lo = offsets[r0], tile_hi = offsets[r1];
+        const tsq_rc_plan plan = tsq_rc_tile_plan(base_addr, tile_lo, tile_hi, n_bytes, lds_bytes);
+        if (plan.staged) {
+            (*staged_tiles)++;
+            for (uint32_t i = 0; i < plan.n_vec * 16u; i++) {
+                const int64_t at = plan.copy_from + (int64_t)i;
+                tile[i] = (at >= 0 && at < n_bytes) ? values[at] : 0;
+            }
+        }
+        for (int c = 0; c < n_cols; c++)
+            for (int w = 0; w < NT / 64; w++) {  // one wave
+                uint64_t ballot = 0;
+                for (int lane = 0; lane < 64; lane++) {
+                    const int tid = w * 64 + lane;
+                    const int64_t r = r0 + tid;
+                    const bool live = r < r1;
+                    if (!live) continue;
+                    const int64_t lo = offsets[r], hi = offsets[r + 1];
+                    const bool bad_offsets = lo < tile_lo || hi < lo || hi > tile_hi || tile_hi > n_bytes || hi - lo > 0x7fffffffLL;
+                    const uint32_t len = bad_offsets ? 0u : (uint32_t)(hi - lo);
+                    SimBytes rd;
+                    rd.p = plan.staged ? tile + (bad_offsets ? 0u : plan.skew + (uint32_t)(lo - tile_lo)) : values + (bad_offsets ? 0 : lo);
+                    // the kernel carries `code` across the column loop; replaying columns 0..c gives the same state
+                    int code = RC_OK;
+                    tsq_rc_row row = {0, 0, 0, 0, 0, 0, 0};
+                    code = bad_offsets ? RC_MALFORMED : tsq_rc_parse(rd, len, &row);
+                    uint64_t bits = 0;
+                    bool notnull = false;
+                    for (int k = 0; k <= c; k++) {
+                        bits = 0;
+                        notnull = false;
+                        if (code == RC_OK)
+                            code = tsq_rc_column(rd, row, cols[k].col_id, cols[k].type, cols[k].flags, cols[k].def_bits, handles ? handles[r] : 0, &bits, &notnull);
+                    }
+                    if (cols[c].type == TSQ_F32) ((uint32_t*)out[c])[r] = (uint32_t)bits;
+                    else ((uint64_t*)out[c])[r] = bits;
+                    if (notnull) ballot |= 1ull << lane;
+                    if (c == n_cols - 1 && code != RC_OK) {
+                        const uint64_t e = ((uint64_t)r << 4) | (uint64_t)code;
+                        if (e < err) err = e;
+                    }
+                }
+                for (int lane = 0; lane < 8; lane++) {
+                    const int64_t byte_at = ((r0 + w * 64) >> 3) + lane;
+                    if (byte_at < bm_bytes) out_bm[c][byte_at] = (uint8_t)(ballot >> (8 * lane));
+                }
+            }
+    }
+    free(tile);
+    return err;
+}

@@ -41,13 +41,13 @@ def test_struct_sizes_equal_what_gcc_computes_for_the_header(tmp_path):
     # every struct that crosses the boundary by pointer: compile include/tsq.h with gcc and compare sizeof with ctypes
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(tsq_col), sizeof(tsq_expr_prog), '
-                   'sizeof(tsq_gen_spec), sizeof(tsq_join_cfg), sizeof(tsq_agg_cfg), sizeof(tsq_sort_cfg), sizeof(tsq_stats));return 0;}\n'
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(tsq_col), sizeof(tsq_expr_prog), '
+                   'sizeof(tsq_gen_spec), sizeof(tsq_join_cfg), sizeof(tsq_agg_cfg), sizeof(tsq_sort_cfg), sizeof(tsq_stats), sizeof(tsq_rowcodec_col));return 0;}\n'
                    % os.path.join(ROOT, "include", "tsq.h"))
     exe = tmp_path / "sz"
     subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
-    assert got == [C.sizeof(t) for t in (abi.Col, abi.ExprProg, abi.GenSpec, abi.JoinCfg, abi.AggCfg, abi.SortCfg, abi.Stats)]
+    assert got == [C.sizeof(t) for t in (abi.Col, abi.ExprProg, abi.GenSpec, abi.JoinCfg, abi.AggCfg, abi.SortCfg, abi.Stats, abi.RowcodecCol)]
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -1,0 +1,173 @@
+"""CPU: the code k_rowcodec_decode runs per tile and per row (tinysql_amd/csrc/tsq_rowcodec_dp.h: tile plan, header parse, column
+id search, value decode) compiled with g++ through tests/hostsim and walked tile by tile like the kernel does — staged copy at
+every 16-byte phase of the `values` address, 256-row tiles, ballot-shaped bitmap bytes — against the oracle's restatement of
+ChunkDecoder.DecodeToChunk.  The index arithmetic of the staging is where an off-by-one would hide; it is checked here without
+a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from tinysql_amd import _abi as abi
+from tinysql_amd.chunk import Chunk, Column, unpack_bitmap
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NP = {abi.I64: np.int64, abi.U64: np.uint64, abi.F64: np.float64, abi.F32: np.float32}
+
+
+@pytest.fixture(scope="module")
+def sim():
+    subprocess.run(["make", "-C", os.path.join(HERE, "hostsim")], check=True, stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(HERE, "hostsim", "hostsim.so"))
+    P = C.c_void_p
+    lib.sim_rowcodec_decode.restype = C.c_uint64
+    lib.sim_rowcodec_decode.argtypes = [P, C.c_int64, C.c_uint64, P, P, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_int64)]
+    return lib
+
+
+def run_sim(sim, values, offsets, handles, specs, base_addr=0, lds_bytes=48 * 1024):
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    types = [sp[1] for sp in specs]
+    bufs = [np.full(max(n, 1), 0x55, dtype=NP[t]) if NP[t] in (np.int64, np.uint64) else np.zeros(max(n, 1), dtype=NP[t]) for t in types]
+    bms = [np.full((n + 7) // 8 + 8, 0xEE, dtype=np.uint8) for _ in types]
+    pd = (C.c_void_p * len(types))(*[b.ctypes.data for b in bufs])
+    pb = (C.c_void_p * len(types))(*[b.ctypes.data for b in bms])
+    h = np.ascontiguousarray(handles, dtype=np.int64) if handles is not None else None
+    staged = C.c_int64(0)
+    err = sim.sim_rowcodec_decode(values.ctypes.data_as(C.c_void_p), values.size, base_addr, offsets.ctypes.data_as(C.c_void_p),
+                                  h.ctypes.data_as(C.c_void_p) if h is not None else None, n, orc.rowcodec_cols(specs), len(specs), pd, pb, lds_bytes,
+                                  C.byref(staged))
+    rows = n if err == (1 << 64) - 1 else err >> 4
+    code = 0 if err == (1 << 64) - 1 else err & 15
+    for bm in bms:  # nothing is written past the bitmap's last byte
+        assert (bm[(n + 7) // 8:] == 0xEE).all()
+    chk = Chunk([Column(t, b[:rows].copy(), unpack_bitmap(bm, rows)) for t, b, bm in zip(types, bufs, bms)])
+    return code, chk, staged.value
+
+
+def random_scan(rng, n, null_frac=0.2):
+    edge = np.array([0, 1, -1, 127, -128, 128, -129, 32767, -32768, 32768, (1 << 31) - 1, -(1 << 31), 1 << 31, (1 << 63) - 1, -(1 << 63)])
+    return Chunk([
+        Column(abi.I64, np.where(rng.random(n) < 0.5, rng.choice(edge, n), rng.integers(-(1 << 62), 1 << 62, n)), rng.random(n) >= null_frac),
+        Column(abi.U64, (rng.integers(0, 1 << 62, n) >> rng.integers(0, 62, n)).astype(np.uint64), rng.random(n) >= null_frac),
+        Column(abi.F64, rng.standard_normal(n) * 1e6, rng.random(n) >= null_frac),
+        Column(abi.F32, rng.standard_normal(n).astype(np.float32), rng.random(n) >= null_frac),
+    ])
+
+
+SPECS = [(200, abi.F64), (-1, abi.I64, abi.RC_HANDLE), (7, abi.I64), (31, abi.F32), (2, abi.U64), (99, abi.I64), (98, abi.I64, abi.RC_HAS_DEFAULT, 5)]
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 1000, 5000])
+def test_tiles_and_bitmap_tail(sim, n):
+    rng = np.random.default_rng(n)
+    chk = random_scan(rng, n)
+    handles = rng.integers(-(1 << 62), 1 << 62, n)
+    b, o = orc.rowcodec_encode(chk, [7, 2, 200, 31])
+    st, want = orc.rowcodec_decode(b, o, handles, SPECS)
+    code, got, staged = run_sim(sim, b, o, handles, SPECS)
+    assert st == 0 and code == 0 and got.rows() == want.rows()
+    assert staged == (n + 255) // 256
+
+
+@pytest.mark.parametrize("phase", range(16))
+def test_every_alignment_phase_of_the_values_pointer(sim, phase):
+    # the staged copy starts at the 16-byte boundary below the tile's first byte: every phase of (address + tile_lo) & 15
+    rng = np.random.default_rng(100 + phase)
+    chk = random_scan(rng, 700)
+    b, o = orc.rowcodec_encode(chk, [7, 2, 200, 31])
+    st, want = orc.rowcodec_decode(b, o, None, SPECS[:1] + SPECS[2:])
+    code, got, _ = run_sim(sim, b, o, None, SPECS[:1] + SPECS[2:], base_addr=0x7f0000001000 + phase)
+    assert st == 0 and code == 0 and got.rows() == want.rows()
+
+
+def test_large_ids_and_wide_rows_fall_back_to_global_reads(sim):
+    # ids above 255 -> 4-byte ids and offsets; a 70000-byte string next to the requested columns -> large offsets, and a tile
+    # that no longer fits the LDS budget is parsed straight from `values` (staged == 0 for it)
+    rng = np.random.default_rng(3)
+    n = 600
+    chk = random_scan(rng, n)
+    pad = np.where(np.arange(n) % 97 == 5, 70000, rng.integers(0, 40, n))
+    b, o = orc.rowcodec_encode(chk, [7, 300, 200, 31], 24, pad)
+    specs = [(300, abi.U64), (7, abi.I64), (200, abi.F64), (31, abi.F32), (24, abi.I64)]
+    st, want = orc.rowcodec_decode(b, o, None, specs[:4])
+    code, got, staged = run_sim(sim, b, o, None, specs[:4])
+    assert st == 0 and code == 0 and got.rows() == want.rows() and staged == 0
+    code, got, staged = run_sim(sim, b, o, None, specs[:4], lds_bytes=1 << 30)  # the same rows through the staged path
+    assert code == 0 and got.rows() == want.rows() and staged == 3
+
+
+def test_empty_rows_and_schema_without_columns(sim):
+    # a row with no columns at all (6-byte header) and columns that are all absent / NULL
+    chk = Chunk([Column(abi.I64, np.zeros(300, np.int64), np.zeros(300, bool))])
+    b, o = orc.rowcodec_encode(chk, [4])
+    specs = [(4, abi.I64), (5, abi.F64), (6, abi.U64, abi.RC_HAS_DEFAULT, 77)]
+    st, want = orc.rowcodec_decode(b, o, None, specs)
+    code, got, _ = run_sim(sim, b, o, None, specs)
+    assert st == 0 and code == 0 and got.rows() == want.rows() == [(None, None, 77)] * 300
+
+
+@pytest.mark.parametrize("case", ["version", "short_float", "cut_header", "cut_value", "odd_int", "offsets_backwards", "empty_value"])
+def test_first_error_in_scan_order(sim, case):
+    rng = np.random.default_rng(9)
+    n = 900
+    chk = random_scan(rng, n, null_frac=0.0)
+    b, o = orc.rowcodec_encode(chk, [7, 2, 200, 31])
+    specs = [(7, abi.I64), (2, abi.U64), (200, abi.F64), (31, abi.F32)]
+    b, o = b.copy(), o.copy()
+    at = 517
+    if case == "version":
+        b[o[at]] = 1
+        b[o[at + 100]] = 1  # a later one does not matter
+        want_code = 1
+    elif case == "short_float":
+        specs = [(7, abi.F64)] + specs[1:]  # an int column read as a real: rows whose int is narrower than 8 bytes fail
+        want_code = 3
+        at = None
+    elif case == "cut_header":
+        o[at + 1:] -= 0  # keep the bytes, shrink the row: its offsets array now runs past its end
+        rows = [b[o[r]:o[r + 1]] for r in range(n)]
+        rows[at] = rows[at][:9]
+        b = np.concatenate(rows)
+        o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        want_code = 2
+    elif case == "cut_value":
+        rows = [b[o[r]:o[r + 1]] for r in range(n)]
+        rows[at] = rows[at][:-3]  # the last value (the double, id 200) runs past the end of the row
+        b = np.concatenate(rows)
+        o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        want_code = 2
+    elif case == "odd_int":
+        # a 3-byte int value: hand-made row, id 7 -> 3 bytes (LittleEndian.Uint64 on 3 bytes panics in the reference)
+        rows = [b[o[r]:o[r + 1]] for r in range(n)]
+        rows[at] = np.array([128, 0, 1, 0, 0, 0, 7, 3, 0, 1, 2, 3], dtype=np.uint8)
+        b = np.concatenate(rows)
+        o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        specs = specs[:1]
+        want_code = 2
+    elif case == "offsets_backwards":
+        o[at + 1] = o[at] - 1
+        want_code = 2
+    else:
+        rows = [b[o[r]:o[r + 1]] for r in range(n)]
+        rows[at] = rows[at][:0]
+        b = np.concatenate(rows)
+        o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        want_code = 2
+    if case == "offsets_backwards":
+        # the oracle walks rows one by one and would read a negative length: compare with the rows before the damaged one
+        st, want = orc.rowcodec_decode(b, o[:at + 1], None, specs)
+        st = 2
+    else:
+        st, want = orc.rowcodec_decode(b, o, None, specs)
+    code, got, _ = run_sim(sim, b, o, None, specs)
+    assert st == want_code and code == want_code
+    if at is not None:
+        assert want.NumRows() == at
+    assert got.rows() == want.rows()

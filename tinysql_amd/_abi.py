@@ -47,6 +47,19 @@ OP_IN_INT, OP_IN_REAL = 60, 61
 F_LHS_UNSIGNED, F_RHS_UNSIGNED, F_FORCE_SIGNED = 1, 2, 4
 
 
+RC_HANDLE, RC_HAS_DEFAULT = 1, 2  # tsq_rowcodec_col.flags
+
+
+class RowcodecCol(C.Structure):
+    """tsq_rowcodec_col — one requested column of a stored-row scan (rowcodec.ColInfo, util/rowcodec/decoder.go:45-55)."""
+    _fields_ = [
+        ("col_id", C.c_int64),
+        ("type", C.c_int32),
+        ("flags", C.c_uint32),
+        ("def_bits", C.c_uint64),
+    ]
+
+
 class Col(C.Structure):
     """tsq_col — mirrors util/chunk/column.go:28-34."""
     _fields_ = [
@@ -183,6 +196,8 @@ SIGNATURES = {
     "tsq_chunk_compact": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_rows_decode": (C.c_int32, [P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(Col), C.c_int64, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64)]),
+    "tsq_rowcodec_decode": (C.c_int32, [P, P, C.c_int64, P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(RowcodecCol), C.POINTER(Col),
+                                        C.POINTER(C.c_int64)]),
     "tsq_radix_split": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                     C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_join_stats": (C.c_int32, [P, C.POINTER(Stats)]),

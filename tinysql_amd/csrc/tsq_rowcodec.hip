@@ -1,0 +1,213 @@
+// tsq_rowcodec.hip — stored rows (rowcodec v2, one KV value per row) -> chunk columns on the GPU (SURVEY.md §8 f, rank 4).
+//
+// Replaces the per-row loop around rowcodec.ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238) that a table scan
+// runs over its KV values (storage side: BytesDecoder.DecodeToBytes, decoder.go:252-322, called from mocktikv's tableScanExec,
+// store/mockstore/mocktikv/executor.go:124-196, followed on the SQL side by readRowsData + DecodeOne).
+//
+// Unlike the coprocessor response (tsq_decode.hip) the row boundaries are known here (one KV value per row), so rows are
+// independent: K15 `k_rowcodec_decode` gives every lane one row.  HBM-bound byte work, no MFMA:
+//   * a workgroup takes 256 consecutive rows; their bytes are ONE contiguous span of `values`, copied into LDS with 16-byte
+//     loads (consecutive lanes, consecutive addresses) — the per-row parse (header, binary search of the column id, 1/2/4/8-byte
+//     value) then reads LDS bytes instead of issuing 64 scattered global loads per wave instruction;
+//   * column c of row r is stored at out[c][r]: consecutive lanes write consecutive 8-byte slots;
+//   * the null bitmap of 64 rows is one wave ballot, written as 8 bytes by lanes 0..7 (bit 1 = NOT NULL, column.go:89-92);
+//   * a tile wider than the LDS budget (rows with long strings next to the requested columns) is parsed from global memory.
+// Algorithmic bytes per row: its stored bytes + 8 B per output value (+ 1/8 B bitmap).
+#include "tsq_internal.h"
+#include "tsq_rowcodec_dp.h"
+
+#define RC_NT 256
+#define RC_LDS_BYTES (48 * 1024)
+
+struct RcArgs {
+    const uint8_t* bytes;
+    const int64_t* offsets;
+    const int64_t* handles;
+    int64_t nrows, n_bytes;
+    int32_t n_cols;
+    tsq_rowcodec_col cols[TSQ_MAX_COLS];
+    void* out[TSQ_MAX_COLS];
+    uint8_t* out_bm[TSQ_MAX_COLS];
+    unsigned long long* err;  // min over (row << 4 | code); ~0 = no error
+};
+
+namespace {
+
+struct RcBytes {
+    const uint8_t* p;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return p[i]; }
+};
+
+// the rows of one tile, one per lane: parse, decode every requested column, store value + bitmap bits, report the first error
+__device__ __forceinline__ void rc_rows(const RcArgs& a, const RcBytes& rd, uint32_t len, bool live, bool bad_offsets, int64_t handle,
+                                        int64_t r, int64_t r0, int64_t bm_bytes, uint32_t tid) {
+    int code = RC_OK;
+    tsq_rc_row row = {0, 0, 0, 0, 0, 0, 0};
+    if (live) code = bad_offsets ? RC_MALFORMED /* offsets not non-decreasing inside [0, n_bytes] */ : tsq_rc_parse(rd, len, &row);
+    for (int c = 0; c < a.n_cols; c++) {
+        uint64_t bits = 0;
+        bool notnull = false;
+        if (live && code == RC_OK)
+            code = tsq_rc_column(rd, row, a.cols[c].col_id, a.cols[c].type, a.cols[c].flags, a.cols[c].def_bits, handle, &bits, &notnull);
+        if (live) {
+            if (a.cols[c].type == TSQ_F32) ((uint32_t*)a.out[c])[r] = (uint32_t)bits;
+            else ((uint64_t*)a.out[c])[r] = bits;
+        }
+        // 64 rows = one ballot = 8 bitmap bytes, written by lanes 0..7 (bit 1 = NOT NULL; rows past the end contribute zeros)
+        const unsigned long long m = __ballot(notnull);
+        const uint32_t lane = tid & 63u;
+        const int64_t byte_at = ((r0 + (int64_t)(tid & ~63u)) >> 3) + lane;
+        if (lane < 8 && byte_at < bm_bytes) a.out_bm[c][byte_at] = (uint8_t)(m >> (8 * lane));
+    }
+    if (live && code != RC_OK) atomicMin(a.err, ((unsigned long long)r << 4) | (unsigned long long)code);
+}
+
+__global__ void __launch_bounds__(RC_NT) k_rowcodec_decode(RcArgs a) {
+    __shared__ uint4 s_tile[RC_LDS_BYTES / 16];
+    const uint32_t tid = threadIdx.x;
+    const int64_t n_tiles = (a.nrows + RC_NT - 1) / RC_NT;
+    const int64_t bm_bytes = (a.nrows + 7) / 8;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int64_t r0 = t * RC_NT, r1 = r0 + RC_NT < a.nrows ? r0 + RC_NT : a.nrows;
+        const int64_t r = r0 + tid;
+        const bool live = r < r1;
+        const int64_t tile_lo = a.offsets[r0], tile_hi = a.offsets[r1];
+        int64_t lo = 0, hi = 0;
+        if (live) {
+            lo = a.offsets[r];
+            hi = a.offsets[r + 1];
+        }
+        const tsq_rc_plan plan = tsq_rc_tile_plan((uint64_t)(uintptr_t)a.bytes, tile_lo, tile_hi, a.n_bytes, RC_LDS_BYTES);
+        if (plan.staged) {
+            const uint4* src = (const uint4*)(a.bytes + plan.copy_from);  // 16-byte aligned by construction
+            for (uint32_t i = tid; i < plan.n_vec; i += RC_NT) s_tile[i] = src[i];
+        }
+        __syncthreads();
+        const bool bad_offsets = live && (lo < tile_lo || hi < lo || hi > tile_hi || tile_hi > a.n_bytes || hi - lo > 0x7fffffffLL);
+        const bool ok_row = live && !bad_offsets;
+        const uint32_t len = ok_row ? (uint32_t)(hi - lo) : 0u;
+        const int64_t handle = (live && a.handles) ? a.handles[r] : 0;
+        // plan.staged is the same for the whole workgroup: each branch is entered by complete waves (the ballots inside need
+        // that), and each instantiation reads through a pointer of one address space (LDS reads, not flat ones)
+        if (plan.staged) {
+            RcBytes rd;
+            rd.p = (const uint8_t*)s_tile + (ok_row ? plan.skew + (uint32_t)(lo - tile_lo) : 0u);
+            rc_rows(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
+        } else {
+            RcBytes rd;
+            rd.p = a.bytes + (ok_row ? lo : 0);
+            rc_rows(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
+        }
+        __syncthreads();  // the tile is overwritten by the next iteration
+    }
+}
+
+}  // namespace
+
+// ====================================================================== host side
+TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_bytes, const int64_t* offsets, const int64_t* handles,
+                                       int64_t nrows, uint32_t data_flags, int32_t n_cols, const tsq_rowcodec_col* cols, tsq_col* out_cols,
+                                       int64_t* nrows_out) {
+    tsq_ctx_lock _api_lock(ctx);
+    if (!ctx) return TSQ_ERR_INVALID;
+    tsq_handle_hdr* h = &ctx->hdr;
+    if (nrows_out) *nrows_out = 0;
+    if (!nrows_out || !cols || !out_cols || nrows < 0 || n_bytes < 0 || (nrows > 0 && (!offsets || (n_bytes > 0 && !values))))
+        return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: bad arguments");
+    if (n_cols < 1 || n_cols > TSQ_MAX_COLS) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "1..16 columns supported");
+    if (nrows >= (1LL << 40)) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "more than 2^40 rows per call");
+    bool any_handle = false;
+    for (int c = 0; c < n_cols; c++) {
+        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "var-len column: decode this scan with the Go decoder");
+        if ((cols[c].flags & TSQ_RC_HANDLE) && cols[c].type != TSQ_I64 && cols[c].type != TSQ_U64)
+            return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: the handle column is an integer column");
+        any_handle = any_handle || (cols[c].flags & TSQ_RC_HANDLE);
+        if (!out_cols[c].data || !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: out columns need data and null_bitmap buffers");
+        if (((out_cols[c].flags ^ out_cols[0].flags) & TSQ_COL_DEVICE) != 0) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: mixed host/device outputs");
+    }
+    if (nrows == 0) return TSQ_OK;
+    if (any_handle && !handles) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: a handle column needs handles[]");
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    const bool in_dev = data_flags & TSQ_COL_DEVICE, out_dev = out_cols[0].flags & TSQ_COL_DEVICE;
+    RcArgs a;
+    memset(&a, 0, sizeof a);
+    a.nrows = nrows;
+    a.n_bytes = n_bytes;
+    a.n_cols = n_cols;
+    DevBuf dbytes, doffs, dhandles, derr, ddata[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
+    auto release_all = [&]() {
+        for (DevBuf* b : {&dbytes, &doffs, &dhandles, &derr}) b->release();
+        for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dbm[c].release(); }
+    };
+    auto fail = [&](tsq_status st) { release_all(); return st; };
+    tsq_status s = derr.reserve(ctx, h, 64);
+    hipError_t e = hipSuccess;
+    if (s == TSQ_OK && !in_dev) {
+        // host rows: one H2D copy per array (the caller has gathered the KV values of a scan batch into one buffer)
+        s = dbytes.reserve(ctx, h, (size_t)n_bytes + 64);
+        if (s == TSQ_OK) s = doffs.reserve(ctx, h, ((size_t)nrows + 1) * 8 + 64);
+        if (s == TSQ_OK && any_handle) s = dhandles.reserve(ctx, h, (size_t)nrows * 8 + 64);
+        if (s == TSQ_OK && n_bytes > 0) e = hipMemcpyAsync(dbytes.p, values, (size_t)n_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (s == TSQ_OK && e == hipSuccess) e = hipMemcpyAsync(doffs.p, offsets, ((size_t)nrows + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (s == TSQ_OK && e == hipSuccess && any_handle) e = hipMemcpyAsync(dhandles.p, handles, (size_t)nrows * 8, hipMemcpyHostToDevice, ctx->stream);
+        a.bytes = dbytes.as<uint8_t>();
+        a.offsets = doffs.as<int64_t>();
+        a.handles = any_handle ? dhandles.as<int64_t>() : nullptr;
+    } else {
+        a.bytes = values;
+        a.offsets = offsets;
+        a.handles = any_handle ? handles : nullptr;
+    }
+    if (s != TSQ_OK) return fail(s);
+    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(H2D): ") + hipGetErrorString(e)));
+    for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
+        a.cols[c] = cols[c];
+        if (!out_dev) {
+            s = ddata[c].reserve(ctx, h, (size_t)nrows * tsq_elem_size(cols[c].type) + 64);
+            if (s == TSQ_OK) s = dbm[c].reserve(ctx, h, tsq_bitmap_bytes(nrows) + 64);
+        }
+        a.out[c] = out_dev ? out_cols[c].data : ddata[c].p;
+        a.out_bm[c] = out_dev ? out_cols[c].null_bitmap : dbm[c].as<uint8_t>();
+    }
+    if (s != TSQ_OK) return fail(s);
+    a.err = derr.as<unsigned long long>();
+    e = hipMemsetAsync(a.err, 0xff, 8, ctx->stream);
+    if (e == hipSuccess) {
+        const int64_t n_tiles = (nrows + RC_NT - 1) / RC_NT;
+        const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * 3);  // 48 KB of LDS per workgroup: three per CU
+        hipLaunchKernelGGL(k_rowcodec_decode, dim3(grid), dim3(RC_NT), 0, ctx->stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, a.err, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode: ") + hipGetErrorString(e)));
+    const uint64_t errw = ctx->pinned[0];
+    int code = RC_OK;
+    int64_t rows = nrows;
+    if (errw != ~0ull) {
+        code = (int)(errw & 15);
+        rows = (int64_t)(errw >> 4);
+    }
+    // hand the rows before the first offending one over (the reference has appended them to the chunk by then)
+    if (!out_dev && rows > 0) {
+        for (int c = 0; c < n_cols && e == hipSuccess; c++) {
+            e = hipMemcpyAsync(out_cols[c].data, ddata[c].p, (size_t)rows * tsq_elem_size(cols[c].type), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(out_cols[c].null_bitmap, dbm[c].p, tsq_bitmap_bytes(rows), hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(D2H): ") + hipGetErrorString(e)));
+    }
+    for (int c = 0; c < n_cols; c++) {
+        out_cols[c].length = rows;
+        out_cols[c].type = cols[c].type;
+        out_cols[c].elem_size = tsq_elem_size(cols[c].type);
+    }
+    release_all();
+    *nrows_out = rows;
+    switch (code) {
+        case RC_OK: return TSQ_OK;
+        case RC_BAD_VERSION: return tsq_fail(h, TSQ_ERR_INVALID, "invalid codec version");                 // row.go:54-56
+        case RC_SHORT_FLOAT: return tsq_fail(h, TSQ_ERR_INVALID, "insufficient bytes to decode value");  // number.go:84-86 via float.go:42-46
+        default: return tsq_fail(h, TSQ_ERR_INVALID, "malformed row");  // the reference panics (index / slice bounds out of range)
+    }
+}

@@ -1,0 +1,162 @@
+// tsq_rowcodec_dp.h — the scalar core of tsq_rowcodec_decode (tsq_rowcodec.hip): one stored row (rowcodec v2) -> the values of
+// the requested columns.  TSQ_HD and templated on the byte reader, so the kernel runs it on a tile staged in LDS (or on global
+// memory for very wide rows) and the CPU test-suite runs the very same code through tests/hostsim against the oracle.
+// Reference: util/rowcodec/row.go:37-78 (fromBytes), :101-150 (findColID), :37-52 (getData); util/rowcodec/decoder.go:158-238
+// (ChunkDecoder.DecodeToChunk / decodeColToChunk); util/rowcodec/common.go:103-114,199-210 (decodeInt / decodeUint);
+// util/codec/float.go:32-46 (DecodeFloat).
+#ifndef TSQ_ROWCODEC_DP_H
+#define TSQ_ROWCODEC_DP_H
+
+#include "tsq_device.h"
+
+enum { RC_OK = 0, RC_BAD_VERSION = 1, RC_MALFORMED = 2, RC_SHORT_FLOAT = 3 };
+#define TSQ_RC_CODEC_VER 128u
+
+// How a workgroup brings the bytes [tile_lo, tile_hi) of `values` (device address base_addr) into LDS: whole 16-byte vectors
+// starting at the 16-byte boundary at or below the first byte, so that every lane issues aligned 16-byte loads.  `skew` = where
+// byte tile_lo lands in the staged copy.  Not staged: the offsets are inconsistent, or the span exceeds the LDS budget (the rows
+// are then parsed from global memory).
+struct tsq_rc_plan {
+    uint32_t staged;
+    uint32_t skew;
+    uint32_t n_vec;     // 16-byte vectors to copy
+    int64_t copy_from;  // byte offset into `values` of the first vector (down to -15 when `values` itself is not 16-byte aligned)
+};
+TSQ_HD tsq_rc_plan tsq_rc_tile_plan(uint64_t base_addr, int64_t tile_lo, int64_t tile_hi, int64_t n_bytes, uint32_t lds_bytes) {
+    tsq_rc_plan p;
+    p.staged = 0;
+    p.skew = 0;
+    p.n_vec = 0;
+    p.copy_from = 0;
+    if (tile_lo < 0 || tile_hi < tile_lo || tile_hi > n_bytes) return p;
+    const uint32_t skew = (uint32_t)((base_addr + (uint64_t)tile_lo) & 15u);
+    const int64_t span = tile_hi - tile_lo;
+    if (span + skew > (int64_t)lds_bytes) return p;
+    p.staged = 1;
+    p.skew = skew;
+    p.n_vec = (uint32_t)((span + skew + 15) >> 4);
+    p.copy_from = tile_lo - (int64_t)skew;
+    return p;
+}
+
+// little-endian reads of 2 / 4 / 8 bytes at byte position p through the reader (R::operator()(uint32_t) -> byte)
+template <class R>
+TSQ_HD uint32_t rc_u16(const R& b, uint32_t p) { return (uint32_t)b(p) | ((uint32_t)b(p + 1) << 8); }
+template <class R>
+TSQ_HD uint32_t rc_u32(const R& b, uint32_t p) { return rc_u16(b, p) | (rc_u16(b, p + 2) << 16); }
+template <class R>
+TSQ_HD uint64_t rc_u64(const R& b, uint32_t p) { return (uint64_t)rc_u32(b, p) | ((uint64_t)rc_u32(b, p + 4) << 32); }
+template <class R>
+TSQ_HD uint64_t rc_be64(const R& b, uint32_t p) {
+    return ((uint64_t)__builtin_bswap32(rc_u32(b, p)) << 32) | (uint64_t)__builtin_bswap32(rc_u32(b, p + 4));
+}
+
+// the parsed header of one row (row.fromBytes): where the id / offset / value arrays start
+struct tsq_rc_row {
+    uint32_t len;       // bytes of the row
+    uint32_t large;     // ids and offsets are 4 bytes wide instead of 1 / 2
+    uint32_t n_notnull, n_null;
+    uint32_t ids_at, offs_at, data_at;
+};
+
+template <class R>
+TSQ_HD int tsq_rc_parse(const R& b, uint32_t len, tsq_rc_row* r) {
+    r->len = len;
+    if (len < 1) return RC_MALFORMED;                   // rowData[0] on an empty value: index out of range in the reference
+    if (b(0) != TSQ_RC_CODEC_VER) return RC_BAD_VERSION;  // row.go:54-56
+    if (len < 6) return RC_MALFORMED;
+    r->large = b(1) & 1u;
+    r->n_notnull = rc_u16(b, 2);
+    r->n_null = rc_u16(b, 4);
+    r->ids_at = 6;
+    r->offs_at = 6 + (r->n_notnull + r->n_null) * (r->large ? 4u : 1u);
+    r->data_at = r->offs_at + r->n_notnull * (r->large ? 4u : 2u);
+    return r->data_at <= len ? RC_OK : RC_MALFORMED;  // the reference slices rowData[cursor : cursor+len]: out of range panics
+}
+
+template <class R>
+TSQ_HD int64_t tsq_rc_id(const R& b, const tsq_rc_row& r, uint32_t i) {
+    return r.large ? (int64_t)rc_u32(b, r.ids_at + 4 * i) : (int64_t)b(r.ids_at + i);
+}
+
+// row.findColID (row.go:101-150): binary search in the not-null ids, then in the null ids.
+// returns 0 = found (idx_out), 1 = the column is NULL in this row, 2 = not in the row
+template <class R>
+TSQ_HD int tsq_rc_find(const R& b, const tsq_rc_row& r, int64_t col_id, uint32_t* idx_out) {
+    uint32_t i = 0, j = r.n_notnull;
+    while (i < j) {
+        const uint32_t h = (i + j) >> 1;
+        const int64_t v = tsq_rc_id(b, r, h);
+        if (v < col_id) i = h + 1;
+        else if (v > col_id) j = h;
+        else { *idx_out = h; return 0; }
+    }
+    i = r.n_notnull;
+    j = r.n_notnull + r.n_null;
+    while (i < j) {
+        const uint32_t h = (i + j) >> 1;
+        const int64_t v = tsq_rc_id(b, r, h);
+        if (v < col_id) i = h + 1;
+        else if (v > col_id) j = h;
+        else return 1;
+    }
+    return 2;
+}
+
+// one output column of one row (DecodeToChunk's loop body, decoder.go:164-196): *bits_out is what the column stores (a float32
+// in the low 4 bytes), *notnull_out its bitmap bit.  type = TSQ_I64 / TSQ_U64 / TSQ_F32 / TSQ_F64.
+template <class R>
+TSQ_HD int tsq_rc_column(const R& b, const tsq_rc_row& r, int64_t col_id, int32_t type, uint32_t flags, uint64_t def_bits, int64_t handle,
+                         uint64_t* bits_out, bool* notnull_out) {
+    *bits_out = 0;  // a NULL slot holds zero bytes (column.go:150-158)
+    *notnull_out = false;
+    if (flags & TSQ_RC_HANDLE) {  // chk.AppendInt64(colIdx, handle)
+        *bits_out = (uint64_t)handle;
+        *notnull_out = true;
+        return RC_OK;
+    }
+    uint32_t idx = 0;
+    const int f = tsq_rc_find(b, r, col_id, &idx);
+    if (f == 1) return RC_OK;  // AppendNull
+    if (f == 2) {              // not in the row: the default, if there is one (decoder.go:186-194)
+        if (flags & TSQ_RC_HAS_DEFAULT) { *bits_out = def_bits; *notnull_out = true; }
+        return RC_OK;
+    }
+    // getData (row.go:37-52): data[offsets[idx-1] : offsets[idx]]
+    uint32_t start = 0, end;
+    if (r.large) {
+        if (idx > 0) start = rc_u32(b, r.offs_at + 4 * (idx - 1));
+        end = rc_u32(b, r.offs_at + 4 * idx);
+    } else {
+        if (idx > 0) start = rc_u16(b, r.offs_at + 2 * (idx - 1));
+        end = rc_u16(b, r.offs_at + 2 * idx);
+    }
+    if (start > end || end > r.len - r.data_at) return RC_MALFORMED;  // slice bounds out of range in the reference
+    const uint32_t n = end - start, p = r.data_at + start;
+    uint64_t bits;
+    if (type == TSQ_I64 || type == TSQ_U64) {
+        // decodeInt / decodeUint (common.go:103-114,199-210): 1, 2, 4 bytes or LittleEndian.Uint64 (which needs 8)
+        if (n == 1) bits = type == TSQ_I64 ? (uint64_t)(int64_t)(int8_t)b(p) : (uint64_t)b(p);
+        else if (n == 2) bits = type == TSQ_I64 ? (uint64_t)(int64_t)(int16_t)rc_u16(b, p) : (uint64_t)rc_u16(b, p);
+        else if (n == 4) bits = type == TSQ_I64 ? (uint64_t)(int64_t)(int32_t)rc_u32(b, p) : (uint64_t)rc_u32(b, p);
+        else if (n >= 8) bits = rc_u64(b, p);
+        else return RC_MALFORMED;
+    } else {
+        if (n < 8) return RC_SHORT_FLOAT;  // DecodeFloat -> DecodeUint: "insufficient bytes to decode value"
+        const uint64_t u = rc_be64(b, p);
+        bits = (u & 0x8000000000000000ULL) ? (u & ~0x8000000000000000ULL) : ~u;  // decodeCmpUintToFloat (float.go:32-40)
+        if (type == TSQ_F32) {  // chk.AppendFloat32(colIdx, float32(fVal))
+            double d;
+            memcpy(&d, &bits, 8);
+            const float f32 = (float)d;
+            uint32_t w;
+            memcpy(&w, &f32, 4);
+            bits = w;
+        }
+    }
+    *bits_out = bits;
+    *notnull_out = true;
+    return RC_OK;
+}
+
+#endif

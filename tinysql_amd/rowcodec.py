@@ -1,0 +1,86 @@
+"""Mirror of util/rowcodec's chunk decoder for the harness: the KV values of a table scan (rowcodec v2 rows) -> chunk columns,
+decoded on the GPU by libtsq (`tsq_rowcodec_decode`, SURVEY.md §8 f rank 4).
+
+`ColInfo` / `NewChunkDecoder(columns, handleColID, defDatum)` keep the reference's shape (util/rowcodec/decoder.go:45-55,
+:146-156).  The reference decodes ONE row per `DecodeToChunk(rowData, handle, chk)` call; a GPU wants the whole scan batch, so
+`DecodeToChunk` here takes the rows of a batch (`values` back to back + `offsets`, `handles`) and returns the chunk — row for
+row what the loop over the reference's method appends.  Errors are the reference's ("invalid codec version", "insufficient
+bytes to decode value"; rows on which the reference would panic give "malformed row") and surface as `_lib.TsqError`; a
+var-len column type raises with TSQ_ERR_UNSUPPORTED (that scan keeps the Go decoder).  No CPU fallback.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import _abi as abi
+from . import _lib
+from .chunk import chunk_from_buffers, out_buffers
+
+# mysql type codes the decoder switches on (parser/mysql/type.go; decoder.go:201-236)
+TypeTiny, TypeShort, TypeLong, TypeFloat, TypeDouble, TypeLonglong, TypeInt24, TypeYear = 1, 2, 3, 4, 5, 8, 9, 13
+TypeVarchar, TypeBit, TypeBlob, TypeVarString, TypeString = 15, 16, 252, 253, 254
+UnsignedFlag = 32  # parser/mysql/const.go
+_INT_TYPES = (TypeLonglong, TypeLong, TypeInt24, TypeShort, TypeTiny, TypeYear)
+
+
+class ColInfo:
+    """rowcodec.ColInfo (decoder.go:45-55)."""
+
+    def __init__(self, ID, Tp, Flag=0, IsPKHandle=False):
+        self.ID, self.Tp, self.Flag, self.IsPKHandle = ID, Tp, Flag, IsPKHandle
+
+    def tsq_type(self):
+        if self.Tp in _INT_TYPES:
+            return abi.U64 if self.Flag & UnsignedFlag else abi.I64
+        if self.Tp == TypeFloat:
+            return abi.F32
+        if self.Tp == TypeDouble:
+            return abi.F64
+        return abi.BYTES  # strings, blobs, bit: not accelerated
+
+
+def _def_bits(tp, v):
+    if tp == abi.F64:
+        return struct.unpack("<Q", struct.pack("<d", float(v)))[0]
+    if tp == abi.F32:
+        return struct.unpack("<I", struct.pack("<f", float(v)))[0]
+    return int(v) & ((1 << 64) - 1)
+
+
+class ChunkDecoder:
+    """rowcodec.ChunkDecoder (decoder.go:140-156) over libtsq."""
+
+    def __init__(self, ctx, columns, handleColID=-1, defDatum=None):
+        self.ctx, self.columns, self.handleColID, self.defDatum = ctx, list(columns), handleColID, defDatum
+        self.types = [c.tsq_type() for c in self.columns]
+        self.cols = (abi.RowcodecCol * len(self.columns))()
+        for i, c in enumerate(self.columns):
+            self.cols[i].col_id, self.cols[i].type, self.cols[i].flags, self.cols[i].def_bits = c.ID, self.types[i], 0, 0
+            if c.ID == handleColID:  # decoder.go:165
+                self.cols[i].flags = abi.RC_HANDLE
+            elif defDatum is not None:
+                d = defDatum(i)  # a NULL default datum is the same as no default (AppendDatum of a NULL datum appends NULL)
+                if d is not None:
+                    self.cols[i].flags = abi.RC_HAS_DEFAULT
+                    self.cols[i].def_bits = _def_bits(self.types[i], d)
+
+    def DecodeToChunk(self, values, offsets, handles=None):
+        """values: bytes / np.uint8 (the rows back to back); offsets: n+1 row boundaries; handles: n int64 or None."""
+        raw = np.frombuffer(values, dtype=np.uint8) if isinstance(values, (bytes, bytearray)) else np.ascontiguousarray(values, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offs) - 1
+        hd = np.ascontiguousarray(handles, dtype=np.int64) if handles is not None else None
+        keep = []
+        out_types = [t if t != abi.BYTES else abi.I64 for t in self.types]  # a var-len type is refused by the library before any buffer is used
+        out, bufs = out_buffers(out_types, max(n, 1), keep)
+        got = C.c_int64(0)
+        _lib.check(self.ctx.lib.tsq_rowcodec_decode(self.ctx.h, raw.ctypes.data_as(C.c_void_p), raw.size, offs.ctypes.data_as(C.c_void_p),
+                                                    hd.ctypes.data_as(C.c_void_p) if hd is not None else None, n, 0, len(self.columns), self.cols, out,
+                                                    C.byref(got)), self.ctx.h)
+        return chunk_from_buffers(self.types, bufs, got.value)
+
+
+def NewChunkDecoder(ctx, columns, handleColID=-1, defDatum=None):
+    """rowcodec.NewChunkDecoder(columns, handleColID, defDatum, loc) (decoder.go:146-156); loc is unused without time types."""
+    return ChunkDecoder(ctx, columns, handleColID, defDatum)
