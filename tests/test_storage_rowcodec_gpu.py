@@ -261,12 +261,12 @@ def test_table_scan_feeds_selection_and_partial_aggregate(ctx, orc):
 
 
 def test_full_size_round_trip_property(ctx):
-    # 2e7 stored rows x 5 columns (numpy encoder pinned on the oracle's in tests/test_oracle_rowcodec_golden.py):
+    # 1e7 stored rows x 5 columns (numpy encoder pinned on the oracle's in tests/test_oracle_rowcodec_golden.py):
     # decode(encode(table)) == table, column by column
     spec = importlib.util.spec_from_file_location("bench_rowcodec", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_rowcodec.py"))
     br = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(br)
-    n, piece = 20_000_000, 5_000_000
+    n, piece = 10_000_000, 2_500_000
     rng = np.random.default_rng(99)
     cols = [RC.ColInfo(i, RC.TypeDouble if t == abi.F64 else RC.TypeLonglong) for i, t in zip(br.IDS, br.TYPES)]
     dec = RC.NewChunkDecoder(ctx, cols)

@@ -28,22 +28,21 @@ def encode_rows_v2(cols, ids):
     cols = [cols[i] for i in order]
     assert max(ids) <= 255
     n, k = len(cols[0]), len(cols)
-    vals = np.zeros((n, k, 8), np.uint8)
-    lens = np.zeros((n, k), np.int64)
+    vals, lens = [], np.zeros((n, k), np.int64)
     for j, c in enumerate(cols):
         if c.dtype == np.float64:
             u = c.view(np.uint64)
             u = np.where(c >= 0, u | np.uint64(1 << 63), ~u)
-            vals[:, j, :] = u.astype(">u8").view(np.uint8).reshape(n, 8)
+            vals.append(u.byteswap().view(np.uint8).reshape(n, 8))  # 8 big-endian bytes
             lens[:, j] = 8
         elif c.dtype == np.uint64:
-            vals[:, j, :] = c.astype("<u8").view(np.uint8).reshape(n, 8)
-            lens[:, j] = np.where(c < (1 << 8), 1, np.where(c < (1 << 16), 2, np.where(c < (1 << 32), 4, 8)))
+            vals.append(np.ascontiguousarray(c).view(np.uint8).reshape(n, 8))
+            lens[:, j] = 1 + (c >= (1 << 8)) + 2 * (c >= (1 << 16)) + 4 * (c >= (1 << 32))
         else:
-            v = c.astype(np.int64)
-            vals[:, j, :] = v.astype("<i8").view(np.uint8).reshape(n, 8)
-            lens[:, j] = np.where((v >= -(1 << 7)) & (v < (1 << 7)), 1, np.where((v >= -(1 << 15)) & (v < (1 << 15)), 2,
-                                                                                  np.where((v >= -(1 << 31)) & (v < (1 << 31)), 4, 8)))
+            v = np.ascontiguousarray(c, dtype=np.int64)
+            vals.append(v.view(np.uint8).reshape(n, 8))
+            m = v ^ (v >> 63)  # non-negative image: the value fits w bytes iff m < 2^(8w-1)
+            lens[:, j] = 1 + (m >= (1 << 7)) + 2 * (m >= (1 << 15)) + 4 * (m >= (1 << 31))
     ends = np.cumsum(lens, axis=1)
     assert int(ends[:, -1].max()) < 65535
     head = np.zeros((n, 6 + 3 * k), np.uint8)
@@ -52,10 +51,8 @@ def encode_rows_v2(cols, ids):
     head[:, 3] = k >> 8
     head[:, 6:6 + k] = np.array(ids, np.uint8)[None, :]
     head[:, 6 + k:] = ends.astype("<u2").view(np.uint8).reshape(n, 2 * k)
-    body = vals.reshape(n, 8 * k)
-    mask = (np.arange(8)[None, None, :] < lens[:, :, None]).reshape(n, 8 * k)
-    full = np.concatenate([head, body], axis=1)
-    fmask = np.concatenate([np.ones((n, 6 + 3 * k), bool), mask], axis=1)
+    full = np.concatenate([head] + vals, axis=1)
+    fmask = np.concatenate([np.ones((n, 6 + 3 * k), bool), (np.arange(8)[None, None, :] < lens[:, :, None]).reshape(n, 8 * k)], axis=1)
     offsets = np.zeros(n + 1, np.int64)
     np.cumsum(6 + 3 * k + ends[:, -1], out=offsets[1:])
     return full[fmask], offsets
