@@ -133,14 +133,38 @@ extern "C" void sim_sort_images(const void* data, int32_t type, int32_t desc, in
 
 #include <stdlib.h>
 // ---- stored rows -> columns (tsq_rowcodec_dp.h): a CPU walk-through of k_rowcodec_decode (tsq_rowcodec.hip) with the same tile
-// plan, the same staged copy (aligned 16-byte vectors into a 48 KB tile; bytes outside `values` read as zero here), the same
+// plan, the same staged copy (aligned 16-byte vectors into the tile; bytes outside `values` and stale tile bytes are garbage here), the same
 // per-lane row code and the same bitmap bytes (one ballot per 64 rows, lanes 0..7 store one byte each when it exists).
 #include "../../tinysql_amd/csrc/tsq_rowcodec_dp.h"
 namespace {
-struct SimBytes {
+struct SimBytes {  // RcGlobal of the kernel
     const uint8_t* p;
     uint32_t operator()(uint32_t i) const { return p[i]; }
+    uint64_t le(uint32_t q, uint32_t n) const { return tsq_rc_le_bytes(*this, q, n); }
 };
+struct SimWords {  // RcLds of the kernel: aligned 32-bit words of the staged tile + funnel shift
+    const uint32_t* w;
+    uint32_t base;
+    uint32_t operator()(uint32_t i) const { return ((const uint8_t*)w)[base + i]; }
+    uint64_t le(uint32_t p, uint32_t) const {
+        const uint32_t q = base + p, i = q >> 2;
+        return tsq_rc_funnel(w[i], w[i + 1], w[i + 2], q);
+    }
+};
+template <class R>
+int sim_row(const R& rd, uint32_t len, bool bad_offsets, const tsq_rowcodec_col* cols, int c, int64_t handle, uint64_t* bits, bool* notnull) {
+    // the kernel carries `code` across the column loop; replaying columns 0..c gives the same state
+    tsq_rc_row row = {0, 0, 0, 0, 0, 0, 0};
+    int code = bad_offsets ? RC_MALFORMED : tsq_rc_parse(rd, len, &row);
+    *bits = 0;
+    *notnull = false;
+    for (int k = 0; k <= c; k++) {
+        *bits = 0;
+        *notnull = false;
+        if (code == RC_OK) code = tsq_rc_column(rd, row, cols[k].col_id, cols[k].type, cols[k].flags, cols[k].def_bits, handle, bits, notnull);
+    }
+    return code;
+}
 }  // namespace
 extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, uint64_t base_addr, const int64_t* offsets, const int64_t* handles,
                                         int64_t nrows, const tsq_rowcodec_col* cols, int32_t n_cols, void** out, uint8_t** out_bm, uint32_t lds_bytes,
@@ -148,7 +172,7 @@ extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, 
     const int NT = 256;
     uint64_t err = ~0ull;
     const int64_t n_tiles = (nrows + NT - 1) / NT, bm_bytes = (nrows + 7) / 8;
-    uint8_t* tile = (uint8_t*)malloc(lds_bytes + 16);
+    uint8_t* tile = (uint8_t*)calloc((size_t)lds_bytes + 32, 1);  // + the slack the word reads may touch
     *staged_tiles = 0;
     for (int64_t t = 0; t < n_tiles; t++) {
         const int64_t r0 = t * NT, r1 = r0 + NT < nrows ? r0 + NT : nrows;
@@ -156,9 +180,11 @@ extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, 
         const tsq_rc_plan plan = tsq_rc_tile_plan(base_addr, tile_lo, tile_hi, n_bytes, lds_bytes);
         if (plan.staged) {
             (*staged_tiles)++;
+            // whatever the previous tile left behind (and whatever surrounds `values` in memory) must not matter: garbage
+            memset(tile, 0xA5, (size_t)lds_bytes + 32);
             for (uint32_t i = 0; i < plan.n_vec * 16u; i++) {
                 const int64_t at = plan.copy_from + (int64_t)i;
-                tile[i] = (at >= 0 && at < n_bytes) ? values[at] : 0;
+                tile[i] = (at >= 0 && at < n_bytes) ? values[at] : (uint8_t)0x5A;
             }
         }
         for (int c = 0; c < n_cols; c++)
@@ -172,19 +198,18 @@ extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, 
                     const int64_t lo = offsets[r], hi = offsets[r + 1];
                     const bool bad_offsets = lo < tile_lo || hi < lo || hi > tile_hi || tile_hi > n_bytes || hi - lo > 0x7fffffffLL;
                     const uint32_t len = bad_offsets ? 0u : (uint32_t)(hi - lo);
-                    SimBytes rd;
-                    rd.p = plan.staged ? tile + (bad_offsets ? 0u : plan.skew + (uint32_t)(lo - tile_lo)) : values + (bad_offsets ? 0 : lo);
-                    // the kernel carries `code` across the column loop; replaying columns 0..c gives the same state
-                    int code = RC_OK;
-                    tsq_rc_row row = {0, 0, 0, 0, 0, 0, 0};
-                    code = bad_offsets ? RC_MALFORMED : tsq_rc_parse(rd, len, &row);
                     uint64_t bits = 0;
                     bool notnull = false;
-                    for (int k = 0; k <= c; k++) {
-                        bits = 0;
-                        notnull = false;
-                        if (code == RC_OK)
-                            code = tsq_rc_column(rd, row, cols[k].col_id, cols[k].type, cols[k].flags, cols[k].def_bits, handles ? handles[r] : 0, &bits, &notnull);
+                    int code;
+                    if (plan.staged) {
+                        SimWords rd;
+                        rd.w = (const uint32_t*)tile;
+                        rd.base = bad_offsets ? 0u : plan.skew + (uint32_t)(lo - tile_lo);
+                        code = sim_row(rd, len, bad_offsets, cols, c, handles ? handles[r] : 0, &bits, &notnull);
+                    } else {
+                        SimBytes rd;
+                        rd.p = values + (bad_offsets ? 0 : lo);
+                        code = sim_row(rd, len, bad_offsets, cols, c, handles ? handles[r] : 0, &bits, &notnull);
                     }
                     if (cols[c].type == TSQ_F32) ((uint32_t*)out[c])[r] = (uint32_t)bits;
                     else ((uint64_t*)out[c])[r] = bits;

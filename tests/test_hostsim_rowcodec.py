@@ -99,7 +99,7 @@ def test_large_ids_and_wide_rows_fall_back_to_global_reads(sim):
     st, want = orc.rowcodec_decode(b, o, None, specs[:4])
     code, got, staged = run_sim(sim, b, o, None, specs[:4])
     assert st == 0 and code == 0 and got.rows() == want.rows() and staged == 0
-    code, got, staged = run_sim(sim, b, o, None, specs[:4], lds_bytes=1 << 30)  # the same rows through the staged path
+    code, got, staged = run_sim(sim, b, o, None, specs[:4], lds_bytes=1 << 20)  # the same rows through the staged path
     assert code == 0 and got.rows() == want.rows() and staged == 3
 
 
@@ -131,7 +131,6 @@ def test_first_error_in_scan_order(sim, case):
         want_code = 3
         at = None
     elif case == "cut_header":
-        o[at + 1:] -= 0  # keep the bytes, shrink the row: its offsets array now runs past its end
         rows = [b[o[r]:o[r + 1]] for r in range(n)]
         rows[at] = rows[at][:9]
         b = np.concatenate(rows)

@@ -17,7 +17,10 @@
 #include "tsq_rowcodec_dp.h"
 
 #define RC_NT 256
-#define RC_LDS_BYTES (48 * 1024)
+// LDS tile of one workgroup: sized per call from the average row length (dynamic shared memory) — a fixed 48 KB tile allowed
+// only three workgroups (12 waves) per CU, and between its two barriers a workgroup either loads or parses
+#define RC_LDS_MIN (8 * 1024)
+#define RC_LDS_MAX (64 * 1024)
 
 struct RcArgs {
     const uint8_t* bytes;
@@ -29,17 +32,31 @@ struct RcArgs {
     void* out[TSQ_MAX_COLS];
     uint8_t* out_bm[TSQ_MAX_COLS];
     unsigned long long* err;  // min over (row << 4 | code); ~0 = no error
+    uint32_t lds_bytes;       // dynamic shared memory of the launch
 };
 
 namespace {
 
-struct RcBytes {
+// the row's bytes inside the staged tile: single bytes as LDS byte reads, anything wider as three aligned words + a funnel shift
+struct RcLds {
+    const uint32_t* w;  // the tile
+    uint32_t base;      // where the row starts in it
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return ((const uint8_t*)w)[base + i]; }
+    __device__ __forceinline__ uint64_t le(uint32_t p, uint32_t) const {
+        const uint32_t q = base + p, i = q >> 2;
+        return tsq_rc_funnel(w[i], w[i + 1], w[i + 2], q);  // up to 11 bytes past q: the tile has 16 bytes of slack
+    }
+};
+// the row's bytes in global memory (tiles that do not fit the LDS budget): exactly the bytes asked for
+struct RcGlobal {
     const uint8_t* p;
     __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return p[i]; }
+    __device__ __forceinline__ uint64_t le(uint32_t q, uint32_t n) const { return tsq_rc_le_bytes(*this, q, n); }
 };
 
 // the rows of one tile, one per lane: parse, decode every requested column, store value + bitmap bits, report the first error
-__device__ __forceinline__ void rc_rows(const RcArgs& a, const RcBytes& rd, uint32_t len, bool live, bool bad_offsets, int64_t handle,
+template <class R>
+__device__ __forceinline__ void rc_rows(const RcArgs& a, const R& rd, uint32_t len, bool live, bool bad_offsets, int64_t handle,
                                         int64_t r, int64_t r0, int64_t bm_bytes, uint32_t tid) {
     int code = RC_OK;
     tsq_rc_row row = {0, 0, 0, 0, 0, 0, 0};
@@ -63,7 +80,7 @@ __device__ __forceinline__ void rc_rows(const RcArgs& a, const RcBytes& rd, uint
 }
 
 __global__ void __launch_bounds__(RC_NT) k_rowcodec_decode(RcArgs a) {
-    __shared__ uint4 s_tile[RC_LDS_BYTES / 16];
+    extern __shared__ uint4 s_tile[];
     const uint32_t tid = threadIdx.x;
     const int64_t n_tiles = (a.nrows + RC_NT - 1) / RC_NT;
     const int64_t bm_bytes = (a.nrows + 7) / 8;
@@ -77,7 +94,7 @@ __global__ void __launch_bounds__(RC_NT) k_rowcodec_decode(RcArgs a) {
             lo = a.offsets[r];
             hi = a.offsets[r + 1];
         }
-        const tsq_rc_plan plan = tsq_rc_tile_plan((uint64_t)(uintptr_t)a.bytes, tile_lo, tile_hi, a.n_bytes, RC_LDS_BYTES);
+        const tsq_rc_plan plan = tsq_rc_tile_plan((uint64_t)(uintptr_t)a.bytes, tile_lo, tile_hi, a.n_bytes, a.lds_bytes);
         if (plan.staged) {
             const uint4* src = (const uint4*)(a.bytes + plan.copy_from);  // 16-byte aligned by construction
             for (uint32_t i = tid; i < plan.n_vec; i += RC_NT) s_tile[i] = src[i];
@@ -90,11 +107,12 @@ __global__ void __launch_bounds__(RC_NT) k_rowcodec_decode(RcArgs a) {
         // plan.staged is the same for the whole workgroup: each branch is entered by complete waves (the ballots inside need
         // that), and each instantiation reads through a pointer of one address space (LDS reads, not flat ones)
         if (plan.staged) {
-            RcBytes rd;
-            rd.p = (const uint8_t*)s_tile + (ok_row ? plan.skew + (uint32_t)(lo - tile_lo) : 0u);
+            RcLds rd;
+            rd.w = (const uint32_t*)s_tile;
+            rd.base = ok_row ? plan.skew + (uint32_t)(lo - tile_lo) : 0u;
             rc_rows(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
         } else {
-            RcBytes rd;
+            RcGlobal rd;
             rd.p = a.bytes + (ok_row ? lo : 0);
             rc_rows(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
         }
@@ -174,8 +192,15 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     e = hipMemsetAsync(a.err, 0xff, 8, ctx->stream);
     if (e == hipSuccess) {
         const int64_t n_tiles = (nrows + RC_NT - 1) / RC_NT;
-        const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * 3);  // 48 KB of LDS per workgroup: three per CU
-        hipLaunchKernelGGL(k_rowcodec_decode, dim3(grid), dim3(RC_NT), 0, ctx->stream, a);
+        // tile = 256 average rows + 25 % + the alignment skew, in 4 KB steps; a tile that does not fit (rows far above the
+        // average) is parsed from global memory by its workgroup
+        int64_t want = (n_bytes / nrows) * RC_NT;
+        want = ((want + want / 4 + 512 + 4095) / 4096) * 4096;
+        if (const char* kb = getenv("TSQ_ROWCODEC_LDS_KB")) want = (int64_t)atoi(kb) * 1024;  // tuning knob for tools/bench_rowcodec.py
+        a.lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(want, RC_LDS_MIN), RC_LDS_MAX);
+        const int64_t wg_per_cu = std::min<int64_t>(8, (160 * 1024) / a.lds_bytes);  // 160 KB of LDS and 32 waves per CU
+        const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * wg_per_cu);
+        hipLaunchKernelGGL(k_rowcodec_decode, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);  // + slack for the word reads
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, a.err, 8, hipMemcpyDeviceToHost, ctx->stream);

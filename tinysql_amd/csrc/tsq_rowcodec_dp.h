@@ -39,17 +39,27 @@ TSQ_HD tsq_rc_plan tsq_rc_tile_plan(uint64_t base_addr, int64_t tile_lo, int64_t
     return p;
 }
 
-// little-endian reads of 2 / 4 / 8 bytes at byte position p through the reader (R::operator()(uint32_t) -> byte)
-template <class R>
-TSQ_HD uint32_t rc_u16(const R& b, uint32_t p) { return (uint32_t)b(p) | ((uint32_t)b(p + 1) << 8); }
-template <class R>
-TSQ_HD uint32_t rc_u32(const R& b, uint32_t p) { return rc_u16(b, p) | (rc_u16(b, p + 2) << 16); }
-template <class R>
-TSQ_HD uint64_t rc_u64(const R& b, uint32_t p) { return (uint64_t)rc_u32(b, p) | ((uint64_t)rc_u32(b, p + 4) << 32); }
-template <class R>
-TSQ_HD uint64_t rc_be64(const R& b, uint32_t p) {
-    return ((uint64_t)__builtin_bswap32(rc_u32(b, p)) << 32) | (uint64_t)__builtin_bswap32(rc_u32(b, p + 4));
+// A byte reader R gives the row's bytes: R::operator()(p) = byte p, R::le(p, n) = the n <= 8 bytes at p as a little-endian
+// number whose bytes ABOVE n are unspecified (a reader over a staged tile returns whatever follows: it always fetches 8 bytes
+// from aligned words; a reader over plain memory touches exactly n bytes).  Callers mask or shift the excess away.
+// low 64 bits of the 96-bit little-endian number w2:w1:w0 shifted right by 8 * (byte offset 0..3): how the staged-tile reader
+// turns three aligned 32-bit words into the 8 bytes that start at an arbitrary byte
+TSQ_HD uint64_t tsq_rc_funnel(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t byte_off) {
+    const uint32_t sh = 8u * (byte_off & 3u);
+    const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    return sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;
 }
+// exact n-byte little-endian read through byte accesses only (the reader over plain memory, and the host-side readers)
+template <class R>
+TSQ_HD uint64_t tsq_rc_le_bytes(const R& b, uint32_t p, uint32_t n) {
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < n; i++) v |= (uint64_t)b(p + i) << (8 * i);
+    return v;
+}
+template <class R>
+TSQ_HD uint32_t rc_u16(const R& b, uint32_t p) { return (uint32_t)b.le(p, 2) & 0xffffu; }
+template <class R>
+TSQ_HD uint32_t rc_u32(const R& b, uint32_t p) { return (uint32_t)b.le(p, 4); }
 
 // the parsed header of one row (row.fromBytes): where the id / offset / value arrays start
 struct tsq_rc_row {
@@ -65,9 +75,10 @@ TSQ_HD int tsq_rc_parse(const R& b, uint32_t len, tsq_rc_row* r) {
     if (len < 1) return RC_MALFORMED;                   // rowData[0] on an empty value: index out of range in the reference
     if (b(0) != TSQ_RC_CODEC_VER) return RC_BAD_VERSION;  // row.go:54-56
     if (len < 6) return RC_MALFORMED;
-    r->large = b(1) & 1u;
-    r->n_notnull = rc_u16(b, 2);
-    r->n_null = rc_u16(b, 4);
+    const uint64_t hdr = b.le(0, 6);  // [ver][flag][numNotNull u16][numNull u16]
+    r->large = (uint32_t)(hdr >> 8) & 1u;
+    r->n_notnull = (uint32_t)(hdr >> 16) & 0xffffu;
+    r->n_null = (uint32_t)(hdr >> 32) & 0xffffu;
     r->ids_at = 6;
     r->offs_at = 6 + (r->n_notnull + r->n_null) * (r->large ? 4u : 1u);
     r->data_at = r->offs_at + r->n_notnull * (r->large ? 4u : 2u);
@@ -75,18 +86,22 @@ TSQ_HD int tsq_rc_parse(const R& b, uint32_t len, tsq_rc_row* r) {
 }
 
 template <class R>
-TSQ_HD int64_t tsq_rc_id(const R& b, const tsq_rc_row& r, uint32_t i) {
-    return r.large ? (int64_t)rc_u32(b, r.ids_at + 4 * i) : (int64_t)b(r.ids_at + i);
+TSQ_HD uint32_t tsq_rc_id(const R& b, const tsq_rc_row& r, uint32_t i) {
+    return r.large ? rc_u32(b, r.ids_at + 4 * i) : b(r.ids_at + i);
 }
 
 // row.findColID (row.go:101-150): binary search in the not-null ids, then in the null ids.
 // returns 0 = found (idx_out), 1 = the column is NULL in this row, 2 = not in the row
 template <class R>
-TSQ_HD int tsq_rc_find(const R& b, const tsq_rc_row& r, int64_t col_id, uint32_t* idx_out) {
+TSQ_HD int tsq_rc_find(const R& b, const tsq_rc_row& r, int64_t col_id64, uint32_t* idx_out) {
+    // stored ids are uint8 / uint32: an id outside [0, 2^32) compares the same way against every stored id, both searches
+    // run off one end and the column is not in the row; inside that range the comparisons are the reference's, in 32 bits
+    if (col_id64 < 0 || col_id64 > 0xffffffffLL) return 2;
+    const uint32_t col_id = (uint32_t)col_id64;
     uint32_t i = 0, j = r.n_notnull;
     while (i < j) {
         const uint32_t h = (i + j) >> 1;
-        const int64_t v = tsq_rc_id(b, r, h);
+        const uint32_t v = tsq_rc_id(b, r, h);
         if (v < col_id) i = h + 1;
         else if (v > col_id) j = h;
         else { *idx_out = h; return 0; }
@@ -95,7 +110,7 @@ TSQ_HD int tsq_rc_find(const R& b, const tsq_rc_row& r, int64_t col_id, uint32_t
     j = r.n_notnull + r.n_null;
     while (i < j) {
         const uint32_t h = (i + j) >> 1;
-        const int64_t v = tsq_rc_id(b, r, h);
+        const uint32_t v = tsq_rc_id(b, r, h);
         if (v < col_id) i = h + 1;
         else if (v > col_id) j = h;
         else return 1;
@@ -122,36 +137,35 @@ TSQ_HD int tsq_rc_column(const R& b, const tsq_rc_row& r, int64_t col_id, int32_
         if (flags & TSQ_RC_HAS_DEFAULT) { *bits_out = def_bits; *notnull_out = true; }
         return RC_OK;
     }
-    // getData (row.go:37-52): data[offsets[idx-1] : offsets[idx]]
-    uint32_t start = 0, end;
-    if (r.large) {
-        if (idx > 0) start = rc_u32(b, r.offs_at + 4 * (idx - 1));
-        end = rc_u32(b, r.offs_at + 4 * idx);
-    } else {
-        if (idx > 0) start = rc_u16(b, r.offs_at + 2 * (idx - 1));
-        end = rc_u16(b, r.offs_at + 2 * idx);
-    }
+    // getData (row.go:37-52): data[offsets[idx-1] : offsets[idx]] — both offsets with one read: the w bytes before entry idx
+    // are entry idx-1, or (idx = 0) the tail of the id array, which is inside the row and ignored
+    const uint32_t w = r.large ? 4u : 2u;
+    const uint64_t oo = b.le(r.offs_at + w * idx - w, 2 * w);
+    const uint32_t start = idx > 0 ? (uint32_t)(r.large ? oo : (oo & 0xffffu)) : 0u;
+    const uint32_t end = r.large ? (uint32_t)(oo >> 32) : (uint32_t)(oo >> 16) & 0xffffu;
     if (start > end || end > r.len - r.data_at) return RC_MALFORMED;  // slice bounds out of range in the reference
     const uint32_t n = end - start, p = r.data_at + start;
     uint64_t bits;
     if (type == TSQ_I64 || type == TSQ_U64) {
-        // decodeInt / decodeUint (common.go:103-114,199-210): 1, 2, 4 bytes or LittleEndian.Uint64 (which needs 8)
-        if (n == 1) bits = type == TSQ_I64 ? (uint64_t)(int64_t)(int8_t)b(p) : (uint64_t)b(p);
-        else if (n == 2) bits = type == TSQ_I64 ? (uint64_t)(int64_t)(int16_t)rc_u16(b, p) : (uint64_t)rc_u16(b, p);
-        else if (n == 4) bits = type == TSQ_I64 ? (uint64_t)(int64_t)(int32_t)rc_u32(b, p) : (uint64_t)rc_u32(b, p);
-        else if (n >= 8) bits = rc_u64(b, p);
-        else return RC_MALFORMED;
+        // decodeInt / decodeUint (common.go:103-114,199-210): 1, 2, 4 bytes, or LittleEndian.Uint64 of the first 8 (which needs
+        // 8): read min(n, 8) bytes, then sign- / zero-extend from n bytes with one pair of shifts
+        if (!(n == 1 || n == 2 || n == 4 || n >= 8)) return RC_MALFORMED;
+        const uint32_t nb = n < 8 ? n : 8u;
+        const uint64_t raw = b.le(p, nb);
+        const uint32_t sh = 64u - 8u * nb;
+        bits = type == TSQ_I64 ? (uint64_t)((int64_t)(raw << sh) >> sh) : ((raw << sh) >> sh);
     } else {
         if (n < 8) return RC_SHORT_FLOAT;  // DecodeFloat -> DecodeUint: "insufficient bytes to decode value"
-        const uint64_t u = rc_be64(b, p);
+        const uint64_t le8 = b.le(p, 8);
+        const uint64_t u = ((uint64_t)__builtin_bswap32((uint32_t)le8) << 32) | (uint64_t)__builtin_bswap32((uint32_t)(le8 >> 32));  // big endian
         bits = (u & 0x8000000000000000ULL) ? (u & ~0x8000000000000000ULL) : ~u;  // decodeCmpUintToFloat (float.go:32-40)
         if (type == TSQ_F32) {  // chk.AppendFloat32(colIdx, float32(fVal))
             double d;
             memcpy(&d, &bits, 8);
             const float f32 = (float)d;
-            uint32_t w;
-            memcpy(&w, &f32, 4);
-            bits = w;
+            uint32_t w32;
+            memcpy(&w32, &f32, 4);
+            bits = w32;
         }
     }
     *bits_out = bits;

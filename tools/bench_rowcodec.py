@@ -118,12 +118,26 @@ def main():
                 ctx.sync()
                 best = min(best, time.perf_counter() - t)
             assert m.value == n
+            sweep = {}
+            if os.environ.get("TSQ_RC_SWEEP"):  # LDS tile size of the kernel (tuning knob of libtsq), best of 3 each
+                for kb in (8, 12, 16, 20, 24, 32, 48, 64):
+                    os.environ["TSQ_ROWCODEC_LDS_KB"] = str(kb)
+                    b3 = 1e30
+                    for rep in range(3):
+                        ctx.sync()
+                        t = time.perf_counter()
+                        _lib.check(ctx.lib.tsq_rowcodec_decode(ctx.h, C.c_void_p(dbytes), raw.size, C.c_void_p(doffs), None, n, abi.COL_DEVICE, len(IDS), specs(),
+                                                               oc, C.byref(m)), ctx.h)
+                        ctx.sync()
+                        b3 = min(b3, time.perf_counter() - t)
+                    sweep["%dKB" % kb] = round(b3 * 1e3, 4)
+                del os.environ["TSQ_ROWCODEC_LDS_KB"]
             key = outs[0].to_host().data
             algo = raw.size + 8.0 * n + 8.0 * len(IDS) * n  # row bytes + one 8-byte row boundary + 8 B per decoded value
             print(json.dumps({"workload": "decode %d stored rows (rowcodec v2, %d fixed-width columns), bytes and columns resident in HBM" % (n, len(IDS)),
                               "encoded_bytes": int(raw.size), "bytes_per_row": raw.size / float(n), "ms": best * 1e3, "rows_per_s": n / best,
                               "values_per_s": len(IDS) * n / best, "algorithmic_GBs": algo / best / 1e9, "frac_of_8TBs": algo / best / 8e12,
-                              "key_checksum_ok": bool(int(key.astype(np.int64).sum()) == key_sum),
+                              "key_checksum_ok": bool(int(key.astype(np.int64).sum()) == key_sum), "lds_tile_sweep_ms": sweep,
                               "cpu_baseline": {"kind": "port", "cores": 1, "rows_per_s": cpu_rows / cpu_s,
                                                "sample": "oracle restatement of the ChunkDecoder.DecodeToChunk loop, %d rows x %d columns, single thread" % (cpu_rows, len(IDS))}}))
         finally:
