@@ -20,6 +20,7 @@
 // LDS tile of one workgroup: sized per call from the average row length (dynamic shared memory) — a fixed 48 KB tile allowed
 // only three workgroups (12 waves) per CU, and between its two barriers a workgroup either loads or parses
 #define RC_LDS_MIN (8 * 1024)
+#define RC_LDS_DEFAULT_MIN (24 * 1024)  // six workgroups per CU: measured best (0.77 ms per 2.5e7 rows; eight: 0.81, four: 1.18, three: 1.11)
 #define RC_LDS_MAX (64 * 1024)
 
 struct RcArgs {
@@ -195,7 +196,7 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         // tile = 256 average rows + 25 % + the alignment skew, in 4 KB steps; a tile that does not fit (rows far above the
         // average) is parsed from global memory by its workgroup
         int64_t want = (n_bytes / nrows) * RC_NT;
-        want = ((want + want / 4 + 512 + 4095) / 4096) * 4096;
+        want = std::max<int64_t>(((want + want / 4 + 512 + 4095) / 4096) * 4096, RC_LDS_DEFAULT_MIN);
         if (const char* kb = getenv("TSQ_ROWCODEC_LDS_KB")) want = (int64_t)atoi(kb) * 1024;  // tuning knob for tools/bench_rowcodec.py
         a.lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(want, RC_LDS_MIN), RC_LDS_MAX);
         const int64_t wg_per_cu = std::min<int64_t>(8, (160 * 1024) / a.lds_bytes);  // 160 KB of LDS and 32 waves per CU
