@@ -168,12 +168,13 @@ int sim_row(const R& rd, uint32_t len, bool bad_offsets, const tsq_rowcodec_col*
 }  // namespace
 extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, uint64_t base_addr, const int64_t* offsets, const int64_t* handles,
                                         int64_t nrows, const tsq_rowcodec_col* cols, int32_t n_cols, void** out, uint8_t** out_bm, uint32_t lds_bytes,
-                                        int64_t* staged_tiles) {
+                                        int32_t fast_layout, int64_t* staged_tiles, int64_t* fast_waves) {
     const int NT = 256;
     uint64_t err = ~0ull;
     const int64_t n_tiles = (nrows + NT - 1) / NT, bm_bytes = (nrows + 7) / 8;
     uint8_t* tile = (uint8_t*)calloc((size_t)lds_bytes + 32, 1);  // + the slack the word reads may touch
     *staged_tiles = 0;
+    *fast_waves = 0;
     for (int64_t t = 0; t < n_tiles; t++) {
         const int64_t r0 = t * NT, r1 = r0 + NT < nrows ? r0 + NT : nrows;
         const int64_t tile_lo = offsets[r0], tile_hi = offsets[r1];
@@ -190,6 +191,28 @@ extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, 
         for (int c = 0; c < n_cols; c++)
             for (int w = 0; w < NT / 64; w++) {  // one wave
                 uint64_t ballot = 0;
+                // the vote of rc_rows_lds: every live row of the wave has the signature of the wave's first lane
+                bool fast = false;
+                uint64_t hdr0 = 0, ids0 = 0;
+                if (plan.staged && fast_layout) {
+                    int n_live = 0, n_same = 0;
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int64_t r = r0 + w * 64 + lane;
+                        if (r >= r1) continue;
+                        n_live++;
+                        const int64_t lo = offsets[r], hi = offsets[r + 1];
+                        const bool bad_offsets = lo < tile_lo || hi < lo || hi > tile_hi || tile_hi > n_bytes || hi - lo > 0x7fffffffLL;
+                        SimWords rd;
+                        rd.w = (const uint32_t*)tile;
+                        rd.base = bad_offsets ? 0u : plan.skew + (uint32_t)(lo - tile_lo);
+                        uint64_t hdr = 0, ids8 = 0;
+                        const bool cand = !bad_offsets && tsq_rc_signature(rd, (uint32_t)(hi - lo), &hdr, &ids8);
+                        if (lane == 0) { hdr0 = cand ? hdr : 0; ids0 = cand ? ids8 : 0; }
+                        if (cand && hdr == hdr0 && ids8 == ids0) n_same++;
+                    }
+                    fast = (hdr0 & 0xffu) == TSQ_RC_CODEC_VER && n_same == n_live;
+                    if (fast && c == 0) (*fast_waves)++;
+                }
                 for (int lane = 0; lane < 64; lane++) {
                     const int tid = w * 64 + lane;
                     const int64_t r = r0 + tid;
@@ -201,7 +224,22 @@ extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, 
                     uint64_t bits = 0;
                     bool notnull = false;
                     int code;
-                    if (plan.staged) {
+                    if (plan.staged && fast) {
+                        SimWords rd;
+                        rd.w = (const uint32_t*)tile;
+                        rd.base = plan.skew + (uint32_t)(lo - tile_lo);
+                        const uint32_t nn = (uint32_t)(hdr0 >> 16) & 0xffffu, nl = (uint32_t)(hdr0 >> 32) & 0xffffu;
+                        uint64_t o_lo = 0, o_hi = 0;
+                        tsq_rc_fast_offsets(rd, nn, 6 + nn + nl, &o_lo, &o_hi);
+                        code = RC_OK;
+                        for (int k = 0; k <= c; k++) {
+                            bits = 0;
+                            notnull = false;
+                            if (code == RC_OK)
+                                code = tsq_rc_fast_column(rd, len, hdr0, ids0, o_lo, o_hi, cols[k].col_id, cols[k].type, cols[k].flags, cols[k].def_bits,
+                                                          handles ? handles[r] : 0, &bits, &notnull);
+                        }
+                    } else if (plan.staged) {
                         SimWords rd;
                         rd.w = (const uint32_t*)tile;
                         rd.base = bad_offsets ? 0u : plan.skew + (uint32_t)(lo - tile_lo);

@@ -25,11 +25,11 @@ def sim():
     P = C.c_void_p
     lib.sim_rowcodec_decode.restype = C.c_uint64
     lib.sim_rowcodec_decode.argtypes = [P, C.c_int64, C.c_uint64, P, P, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, C.POINTER(C.c_void_p),
-                                        C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_int64)]
+                                        C.POINTER(C.c_void_p), C.c_uint32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     return lib
 
 
-def run_sim(sim, values, offsets, handles, specs, base_addr=0, lds_bytes=48 * 1024):
+def run_sim(sim, values, offsets, handles, specs, base_addr=0, lds_bytes=48 * 1024, fast_layout=1, stats=None):
     values = np.ascontiguousarray(values, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     n = len(offsets) - 1
@@ -39,10 +39,12 @@ def run_sim(sim, values, offsets, handles, specs, base_addr=0, lds_bytes=48 * 10
     pd = (C.c_void_p * len(types))(*[b.ctypes.data for b in bufs])
     pb = (C.c_void_p * len(types))(*[b.ctypes.data for b in bms])
     h = np.ascontiguousarray(handles, dtype=np.int64) if handles is not None else None
-    staged = C.c_int64(0)
+    staged, fastw = C.c_int64(0), C.c_int64(0)
     err = sim.sim_rowcodec_decode(values.ctypes.data_as(C.c_void_p), values.size, base_addr, offsets.ctypes.data_as(C.c_void_p),
                                   h.ctypes.data_as(C.c_void_p) if h is not None else None, n, orc.rowcodec_cols(specs), len(specs), pd, pb, lds_bytes,
-                                  C.byref(staged))
+                                  fast_layout, C.byref(staged), C.byref(fastw))
+    if stats is not None:
+        stats.append(fastw.value)
     rows = n if err == (1 << 64) - 1 else err >> 4
     code = 0 if err == (1 << 64) - 1 else err & 15
     for bm in bms:  # nothing is written past the bitmap's last byte
@@ -170,3 +172,104 @@ def test_first_error_in_scan_order(sim, case):
     if at is not None:
         assert want.NumRows() == at
     assert got.rows() == want.rows()
+
+
+# ---- waves whose rows share one layout (rc_rows_lds: the column search runs once per wave on the shared signature)
+def _uniform_scan(rng, n, n_int=3, null_cols=()):
+    """no NULLs except whole columns listed in null_cols (NULL in every row: the layout stays the same)"""
+    cols = []
+    for j in range(n_int):
+        v = np.where(rng.random(n) < 0.5, rng.choice(np.array([0, 1, -1, 127, -128, 128, 32767, -32769, (1 << 31) - 1, 1 << 31, -(1 << 63)]), n),
+                     rng.integers(-(1 << 62), 1 << 62, n))
+        cols.append(Column(abi.I64, v, np.zeros(n, bool) if j in null_cols else None))
+    cols.append(Column(abi.U64, (rng.integers(0, 1 << 62, n) >> rng.integers(0, 62, n)).astype(np.uint64)))
+    cols.append(Column(abi.F64, rng.standard_normal(n) * 1e6))
+    cols.append(Column(abi.F32, rng.standard_normal(n).astype(np.float32)))
+    return Chunk(cols)
+
+
+def _both_paths(sim, b, o, handles, specs, want_fast=None, **kw):
+    st, want = orc.rowcodec_decode(b, o, handles, specs)
+    stats = []
+    code1, got1, _ = run_sim(sim, b, o, handles, specs, fast_layout=1, stats=stats, **kw)
+    code0, got0, _ = run_sim(sim, b, o, handles, specs, fast_layout=0, **kw)
+    assert code1 == code0 == st and got1.rows() == want.rows() and got0.rows() == want.rows()
+    if want_fast is not None:
+        assert stats[0] == want_fast
+    return stats[0]
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 300, 2000])
+def test_shared_layout_waves_take_the_fast_path_and_agree(sim, n):
+    rng = np.random.default_rng(500 + n)
+    chk = _uniform_scan(rng, n, null_cols=(1,))
+    ids = [9, 3, 17, 4, 200, 31]
+    b, o = orc.rowcodec_encode(chk, ids)
+    handles = rng.integers(-(1 << 62), 1 << 62, n)
+    specs = [(200, abi.F64), (-1, abi.I64, abi.RC_HANDLE), (9, abi.I64), (3, abi.I64), (31, abi.F32), (4, abi.U64), (17, abi.I64), (99, abi.I64),
+             (98, abi.I64, abi.RC_HAS_DEFAULT, 5), (1 << 40, abi.I64), (-7, abi.I64)]
+    _both_paths(sim, b, o, handles, specs, want_fast=(n + 63) // 64)
+
+
+def test_eight_ids_are_a_signature_nine_are_not(sim):
+    rng = np.random.default_rng(8)
+    n = 500
+    for k, fast in ((8, (n + 63) // 64), (9, 0)):
+        chk = Chunk([Column(abi.I64, rng.integers(-300, 300, n)) for _ in range(k)])
+        ids = list(range(10, 10 + k))
+        b, o = orc.rowcodec_encode(chk, ids)
+        _both_paths(sim, b, o, None, [(i, abi.I64) for i in reversed(ids)] + [(5, abi.I64)], want_fast=fast)
+
+
+def test_mixed_layouts_vote_wave_by_wave(sim):
+    # rows 0..639 share a layout except row 200 (one NULL) and rows 320..383 (a different table shape); large ids never qualify
+    rng = np.random.default_rng(77)
+    n = 640
+    nn = np.ones(n, bool)
+    nn[200] = False
+    chk = Chunk([Column(abi.I64, rng.integers(-9999, 9999, n), nn), Column(abi.F64, rng.random(n)), Column(abi.I64, rng.integers(0, 9, n))])
+    b1, o1 = orc.rowcodec_encode(chk, [1, 2, 3])
+    other = Chunk([Column(abi.I64, rng.integers(-9999, 9999, 64)), Column(abi.F64, rng.random(64))])
+    b2, o2 = orc.rowcodec_encode(other, [1, 2])
+    rows = [b1[o1[r]:o1[r + 1]] for r in range(n)]
+    rows[320:384] = [b2[o2[r]:o2[r + 1]] for r in range(64)]
+    b = np.concatenate(rows)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    fast = _both_paths(sim, b, o, None, [(3, abi.I64), (1, abi.I64), (2, abi.F64)])
+    assert fast == 9  # 10 waves, the one holding row 200 is mixed; rows 320..383 are uniform among themselves
+    big, ob = orc.rowcodec_encode(chk, [1, 2, 300])
+    assert _both_paths(sim, big, ob, None, [(300, abi.I64), (1, abi.I64), (2, abi.F64)]) == 0
+
+
+@pytest.mark.parametrize("case", ["cut_value", "odd_int", "short_float", "version_first_lane", "version_other_lane"])
+def test_errors_inside_shared_layout_waves(sim, case):
+    rng = np.random.default_rng(31)
+    n = 700
+    chk = _uniform_scan(rng, n)
+    ids = [9, 3, 17, 4, 200, 31]
+    b, o = orc.rowcodec_encode(chk, ids)
+    specs = [(9, abi.I64), (3, abi.I64), (17, abi.I64), (4, abi.U64), (200, abi.F64), (31, abi.F32)]
+    rows = [b[o[r]:o[r + 1]].copy() for r in range(n)]
+    at = 453
+    if case == "cut_value":
+        rows[at] = rows[at][:-5]          # header and ids intact (the wave still votes "same layout"), the last value runs past the row
+    elif case == "odd_int":
+        r = rows[at]
+        nnc = int(r[2])
+        offs_at = 6 + nnc
+        ends = r[offs_at:offs_at + 2 * nnc].view("<u2").astype(np.int64)
+        w0 = int(ends[0])                 # first value (id 3) gets 3 bytes: shift the later offsets, keep the layout
+        ends = (ends + (3 - w0)).astype("<u2")
+        rows[at] = np.concatenate([r[:offs_at], ends.view(np.uint8), np.array([1, 2, 3], np.uint8), r[offs_at + 2 * nnc + w0:]])
+    elif case == "short_float":
+        specs = [(9, abi.F64)] + specs[1:]
+    elif case == "version_first_lane":
+        at = 448                          # lane 0 of its wave: the wave has no valid signature and takes the general path
+        rows[at][0] = 7
+    else:
+        rows[at][0] = 7
+    b = np.concatenate(rows)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    st, want = orc.rowcodec_decode(b, o, None, specs)
+    assert st != 0 and (case == "short_float" or want.NumRows() == at)
+    _both_paths(sim, b, o, None, specs)

@@ -278,3 +278,96 @@ def test_full_size_round_trip_property(ctx):
         for a, t in zip(got.columns, table):
             assert a.notnull is None or a.notnull.all()
             assert (a.data.view(np.uint64) == np.ascontiguousarray(t).view(np.uint64)).all()
+
+
+# ---- waves whose rows share one layout resolve the column positions once (rc_rows_lds); TSQ_ROWCODEC_FAST_LAYOUT=0 switches the
+# vote off, so both paths of the kernel are compared with the oracle on the same scans
+def _uniform_scan(rng, n, null_col=None):
+    cols = []
+    for j in range(3):
+        v = np.where(rng.random(n) < 0.5, rng.choice(EDGE, n), rng.integers(-(1 << 62), 1 << 62, n))
+        cols.append(Column(abi.I64, v, np.zeros(n, bool) if j == null_col else None))
+    cols.append(Column(abi.U64, (rng.integers(0, 1 << 62, n) >> rng.integers(0, 62, n)).astype(np.uint64)))
+    cols.append(Column(abi.F64, rng.standard_normal(n) * 1e6))
+    cols.append(Column(abi.F32, rng.standard_normal(n).astype(np.float32)))
+    return Chunk(cols)
+
+
+U_IDS = [9, 3, 17, 4, 200, 31]
+U_SPECS = [(200, abi.F64), (-1, abi.I64, abi.RC_HANDLE), (9, abi.I64), (3, abi.I64), (31, abi.F32), (4, abi.U64), (17, abi.I64), (99, abi.I64),
+           (98, abi.I64, abi.RC_HAS_DEFAULT, 5), (1 << 40, abi.I64), (-7, abi.I64)]
+
+
+def _both_kernel_paths(ctx, b, o, handles, specs, want_st, want):
+    n = len(o) - 1
+    for knob in ("1", "0"):
+        os.environ["TSQ_ROWCODEC_FAST_LAYOUT"] = knob
+        try:
+            gst, m, got = _decode_device(ctx, b, o, handles, specs, n)
+        finally:
+            del os.environ["TSQ_ROWCODEC_FAST_LAYOUT"]
+        assert (gst == abi.OK) == (want_st == 0) and m == want.NumRows(), knob
+        if want_st:
+            assert _lib.last_error(ctx.h) == MSG[want_st]
+        _same(got, want)
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 1000, 100_000])
+def test_shared_layout_scans(ctx, orc, n):
+    rng = np.random.default_rng(500 + n)
+    chk = _uniform_scan(rng, n, null_col=1)
+    handles = rng.integers(-(1 << 62), 1 << 62, n)
+    b, o = orc.rowcodec_encode(chk, U_IDS)
+    st, want = orc.rowcodec_decode(b, o, handles, U_SPECS)
+    assert st == 0
+    _both_kernel_paths(ctx, b, o, handles, U_SPECS, st, want)
+
+
+def test_mixed_layouts_and_signature_limits(ctx, orc):
+    rng = np.random.default_rng(77)
+    n = 6400
+    nn = np.ones(n, bool)
+    nn[rng.integers(0, n, 20)] = False  # a few rows with one NULL: their waves take the general path
+    chk = Chunk([Column(abi.I64, rng.integers(-9999, 9999, n), nn), Column(abi.F64, rng.random(n)), Column(abi.I64, rng.integers(0, 9, n))])
+    b1, o1 = orc.rowcodec_encode(chk, [1, 2, 3])
+    other = Chunk([Column(abi.I64, rng.integers(-9999, 9999, 640)), Column(abi.F64, rng.random(640))])
+    b2, o2 = orc.rowcodec_encode(other, [1, 2])
+    rows = [b1[o1[r]:o1[r + 1]] for r in range(n)]
+    rows[3200:3840] = [b2[o2[r]:o2[r + 1]] for r in range(640)]  # another table shape in the middle of the scan
+    b = np.concatenate(rows)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    specs = [(3, abi.I64), (1, abi.I64), (2, abi.F64)]
+    st, want = orc.rowcodec_decode(b, o, None, specs)
+    _both_kernel_paths(ctx, b, o, None, specs, st, want)
+    for k in (8, 9):  # eight ids fit the signature, nine do not
+        wide = Chunk([Column(abi.I64, rng.integers(-300, 300, 3000)) for _ in range(k)])
+        ids = list(range(10, 10 + k))
+        b, o = orc.rowcodec_encode(wide, ids)
+        specs = [(i, abi.I64) for i in reversed(ids)] + [(5, abi.I64)]
+        st, want = orc.rowcodec_decode(b, o, None, specs)
+        _both_kernel_paths(ctx, b, o, None, specs, st, want)
+
+
+@pytest.mark.parametrize("case", ["cut_value", "short_float", "version_first_lane", "version_other_lane"])
+def test_errors_inside_shared_layout_waves(ctx, orc, case):
+    rng = np.random.default_rng(31)
+    n = 7000
+    chk = _uniform_scan(rng, n)
+    b, o = orc.rowcodec_encode(chk, U_IDS)
+    specs = [(9, abi.I64), (3, abi.I64), (17, abi.I64), (4, abi.U64), (200, abi.F64), (31, abi.F32)]
+    rows = [b[o[r]:o[r + 1]].copy() for r in range(n)]
+    at = 4549
+    if case == "cut_value":
+        rows[at] = rows[at][:-5]
+    elif case == "short_float":
+        specs = [(9, abi.F64)] + specs[1:]
+    elif case == "version_first_lane":
+        at = 4544  # lane 0 of its wave
+        rows[at][0] = 7
+    else:
+        rows[at][0] = 7
+    b = np.concatenate(rows)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    st, want = orc.rowcodec_decode(b, o, None, specs)
+    assert st != 0 and (case == "short_float" or want.NumRows() == at)
+    _both_kernel_paths(ctx, b, o, None, specs, st, want)

@@ -34,6 +34,7 @@ struct RcArgs {
     uint8_t* out_bm[TSQ_MAX_COLS];
     unsigned long long* err;  // min over (row << 4 | code); ~0 = no error
     uint32_t lds_bytes;       // dynamic shared memory of the launch
+    uint32_t fast_layout;     // 1: waves whose rows share one layout resolve the columns once (0 only through the tuning knob)
 };
 
 namespace {
@@ -80,6 +81,47 @@ __device__ __forceinline__ void rc_rows(const RcArgs& a, const R& rd, uint32_t l
     if (live && code != RC_OK) atomicMin(a.err, ((unsigned long long)r << 4) | (unsigned long long)code);
 }
 
+__device__ __forceinline__ uint64_t rc_first_lane(uint64_t v) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+
+// the staged tile: when every row of the wave has the layout of the wave's first row (same header, same ids — the usual case
+// inside one table) the column search runs once on that shared signature (uniform values: scalar unit) and a lane only reads its
+// offsets and values; otherwise the wave takes the general path above.  Both give the reference's result for every row.
+__device__ __forceinline__ void rc_rows_lds(const RcArgs& a, const RcLds& rd, uint32_t len, bool live, bool bad_offsets, int64_t handle, int64_t r,
+                                            int64_t r0, int64_t bm_bytes, uint32_t tid) {
+    uint64_t hdr = 0, ids8 = 0;
+    const bool cand = live && !bad_offsets && tsq_rc_signature(rd, len, &hdr, &ids8);
+    const uint64_t hdr0 = rc_first_lane(cand ? hdr : 0), ids0 = rc_first_lane(cand ? ids8 : 0);
+    const bool same = cand && hdr == hdr0 && ids8 == ids0;
+    const bool fast = a.fast_layout && (hdr0 & 0xffu) == TSQ_RC_CODEC_VER && __ballot(same) == __ballot(live);
+    if (!fast) {
+        rc_rows(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
+        return;
+    }
+    const uint32_t nn = (uint32_t)(hdr0 >> 16) & 0xffffu, nl = (uint32_t)(hdr0 >> 32) & 0xffffu;
+    uint64_t o_lo = 0, o_hi = 0;
+    if (live) tsq_rc_fast_offsets(rd, nn, 6 + nn + nl, &o_lo, &o_hi);
+    int code = RC_OK;
+    for (int c = 0; c < a.n_cols; c++) {
+        uint64_t bits = 0;
+        bool notnull = false;
+        if (live && code == RC_OK)
+            code = tsq_rc_fast_column(rd, len, hdr0, ids0, o_lo, o_hi, a.cols[c].col_id, a.cols[c].type, a.cols[c].flags, a.cols[c].def_bits, handle, &bits,
+                                      &notnull);
+        if (live) {
+            if (a.cols[c].type == TSQ_F32) ((uint32_t*)a.out[c])[r] = (uint32_t)bits;
+            else ((uint64_t*)a.out[c])[r] = bits;
+        }
+        const unsigned long long m = __ballot(notnull);
+        const uint32_t lane = tid & 63u;
+        const int64_t byte_at = ((r0 + (int64_t)(tid & ~63u)) >> 3) + lane;
+        if (lane < 8 && byte_at < bm_bytes) a.out_bm[c][byte_at] = (uint8_t)(m >> (8 * lane));
+    }
+    if (live && code != RC_OK) atomicMin(a.err, ((unsigned long long)r << 4) | (unsigned long long)code);
+}
+
 __global__ void __launch_bounds__(RC_NT) k_rowcodec_decode(RcArgs a) {
     extern __shared__ uint4 s_tile[];
     const uint32_t tid = threadIdx.x;
@@ -111,7 +153,7 @@ __global__ void __launch_bounds__(RC_NT) k_rowcodec_decode(RcArgs a) {
             RcLds rd;
             rd.w = (const uint32_t*)s_tile;
             rd.base = ok_row ? plan.skew + (uint32_t)(lo - tile_lo) : 0u;
-            rc_rows(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
+            rc_rows_lds(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
         } else {
             RcGlobal rd;
             rd.p = a.bytes + (ok_row ? lo : 0);
@@ -197,7 +239,9 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         // average) is parsed from global memory by its workgroup
         int64_t want = (n_bytes / nrows) * RC_NT;
         want = std::max<int64_t>(((want + want / 4 + 512 + 4095) / 4096) * 4096, RC_LDS_DEFAULT_MIN);
-        if (const char* kb = getenv("TSQ_ROWCODEC_LDS_KB")) want = (int64_t)atoi(kb) * 1024;  // tuning knob for tools/bench_rowcodec.py
+        if (const char* kb = getenv("TSQ_ROWCODEC_LDS_KB")) want = (int64_t)atoi(kb) * 1024;  // tuning knobs for tools/bench_rowcodec.py
+        const char* fl = getenv("TSQ_ROWCODEC_FAST_LAYOUT");
+        a.fast_layout = (fl && fl[0] == '0') ? 0u : 1u;
         a.lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(want, RC_LDS_MIN), RC_LDS_MAX);
         const int64_t wg_per_cu = std::min<int64_t>(8, (160 * 1024) / a.lds_bytes);  // 160 KB of LDS and 32 waves per CU
         const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * wg_per_cu);

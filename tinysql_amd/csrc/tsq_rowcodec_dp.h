@@ -118,6 +118,36 @@ TSQ_HD int tsq_rc_find(const R& b, const tsq_rc_row& r, int64_t col_id64, uint32
     return 2;
 }
 
+// the n bytes at p as the column stores them (decodeColToChunk, decoder.go:200-238)
+template <class R>
+TSQ_HD int tsq_rc_value(const R& b, uint32_t p, uint32_t n, int32_t type, uint64_t* bits_out) {
+    uint64_t bits;
+    if (type == TSQ_I64 || type == TSQ_U64) {
+        // decodeInt / decodeUint (common.go:103-114,199-210): 1, 2, 4 bytes, or LittleEndian.Uint64 of the first 8 (which needs
+        // 8): read min(n, 8) bytes, then sign- / zero-extend from n bytes with one pair of shifts
+        if (!(n == 1 || n == 2 || n == 4 || n >= 8)) return RC_MALFORMED;
+        const uint32_t nb = n < 8 ? n : 8u;
+        const uint64_t raw = b.le(p, nb);
+        const uint32_t sh = 64u - 8u * nb;
+        bits = type == TSQ_I64 ? (uint64_t)((int64_t)(raw << sh) >> sh) : ((raw << sh) >> sh);
+    } else {
+        if (n < 8) return RC_SHORT_FLOAT;  // DecodeFloat -> DecodeUint: "insufficient bytes to decode value"
+        const uint64_t le8 = b.le(p, 8);
+        const uint64_t u = ((uint64_t)__builtin_bswap32((uint32_t)le8) << 32) | (uint64_t)__builtin_bswap32((uint32_t)(le8 >> 32));  // big endian
+        bits = (u & 0x8000000000000000ULL) ? (u & ~0x8000000000000000ULL) : ~u;  // decodeCmpUintToFloat (float.go:32-40)
+        if (type == TSQ_F32) {  // chk.AppendFloat32(colIdx, float32(fVal))
+            double d;
+            memcpy(&d, &bits, 8);
+            const float f32 = (float)d;
+            uint32_t w32;
+            memcpy(&w32, &f32, 4);
+            bits = w32;
+        }
+    }
+    *bits_out = bits;
+    return RC_OK;
+}
+
 // one output column of one row (DecodeToChunk's loop body, decoder.go:164-196): *bits_out is what the column stores (a float32
 // in the low 4 bytes), *notnull_out its bitmap bit.  type = TSQ_I64 / TSQ_U64 / TSQ_F32 / TSQ_F64.
 template <class R>
@@ -144,31 +174,91 @@ TSQ_HD int tsq_rc_column(const R& b, const tsq_rc_row& r, int64_t col_id, int32_
     const uint32_t start = idx > 0 ? (uint32_t)(r.large ? oo : (oo & 0xffffu)) : 0u;
     const uint32_t end = r.large ? (uint32_t)(oo >> 32) : (uint32_t)(oo >> 16) & 0xffffu;
     if (start > end || end > r.len - r.data_at) return RC_MALFORMED;  // slice bounds out of range in the reference
-    const uint32_t n = end - start, p = r.data_at + start;
-    uint64_t bits;
-    if (type == TSQ_I64 || type == TSQ_U64) {
-        // decodeInt / decodeUint (common.go:103-114,199-210): 1, 2, 4 bytes, or LittleEndian.Uint64 of the first 8 (which needs
-        // 8): read min(n, 8) bytes, then sign- / zero-extend from n bytes with one pair of shifts
-        if (!(n == 1 || n == 2 || n == 4 || n >= 8)) return RC_MALFORMED;
-        const uint32_t nb = n < 8 ? n : 8u;
-        const uint64_t raw = b.le(p, nb);
-        const uint32_t sh = 64u - 8u * nb;
-        bits = type == TSQ_I64 ? (uint64_t)((int64_t)(raw << sh) >> sh) : ((raw << sh) >> sh);
-    } else {
-        if (n < 8) return RC_SHORT_FLOAT;  // DecodeFloat -> DecodeUint: "insufficient bytes to decode value"
-        const uint64_t le8 = b.le(p, 8);
-        const uint64_t u = ((uint64_t)__builtin_bswap32((uint32_t)le8) << 32) | (uint64_t)__builtin_bswap32((uint32_t)(le8 >> 32));  // big endian
-        bits = (u & 0x8000000000000000ULL) ? (u & ~0x8000000000000000ULL) : ~u;  // decodeCmpUintToFloat (float.go:32-40)
-        if (type == TSQ_F32) {  // chk.AppendFloat32(colIdx, float32(fVal))
-            double d;
-            memcpy(&d, &bits, 8);
-            const float f32 = (float)d;
-            uint32_t w32;
-            memcpy(&w32, &f32, 4);
-            bits = w32;
-        }
+    const int vc = tsq_rc_value(b, r.data_at + start, end - start, type, bits_out);
+    if (vc != RC_OK) return vc;
+    *notnull_out = true;
+    return RC_OK;
+}
+
+// ---------------------------------------------------------------- rows that share their layout (the fast path of a wave)
+// The rows of one table usually carry the same columns: same header and same id array, only the values differ.  When the 64
+// rows of a wave agree on (header, ids) — small rows with at most 8 ids — the column -> value-index search is the same for all
+// of them: it is done once on the shared signature (uniform values, scalar unit) and every lane only reads its offsets and value.
+// The functions below are what a lane runs on that path; which path a wave takes is a vote (ballot) in the kernel.
+
+// signature of a small row: hdr = its 6 header bytes, ids8 = its <= 8 id bytes (zero padded).  false: not a candidate
+// (not the new format, large, more than 8 ids, or the header arrays do not fit the row) — such rows take the general path
+template <class R>
+TSQ_HD bool tsq_rc_signature(const R& b, uint32_t len, uint64_t* hdr_out, uint64_t* ids8_out) {
+    *hdr_out = 0;
+    *ids8_out = 0;
+    if (len < 6) return false;
+    const uint64_t hdr = b.le(0, 6) & 0xffffffffffffULL;
+    const uint32_t nn = (uint32_t)(hdr >> 16) & 0xffffu, nl = (uint32_t)(hdr >> 32) & 0xffffu;
+    if ((hdr & 0xffu) != TSQ_RC_CODEC_VER || ((hdr >> 8) & 1u) || nn + nl > 8 || 6 + nn + nl + 2 * nn > len) return false;
+    const uint32_t k = nn + nl;
+    const uint64_t ids = k ? b.le(6, k) : 0;
+    *hdr_out = hdr;
+    *ids8_out = k >= 8 ? ids : ids & ((1ULL << (8 * k)) - 1);
+    return true;
+}
+
+// row.findColID over the ids of a signature (one byte each): the same two binary searches as tsq_rc_find
+TSQ_HD int tsq_rc_find_small(uint64_t ids8, uint32_t nn, uint32_t nl, int64_t col_id64, uint32_t* idx_out) {
+    if (col_id64 < 0 || col_id64 > 0xffffffffLL) return 2;
+    const uint32_t col_id = (uint32_t)col_id64;
+    uint32_t i = 0, j = nn;
+    while (i < j) {
+        const uint32_t h = (i + j) >> 1;
+        const uint32_t v = (uint32_t)(ids8 >> (8 * h)) & 255u;
+        if (v < col_id) i = h + 1;
+        else if (v > col_id) j = h;
+        else { *idx_out = h; return 0; }
     }
-    *bits_out = bits;
+    i = nn;
+    j = nn + nl;
+    while (i < j) {
+        const uint32_t h = (i + j) >> 1;
+        const uint32_t v = (uint32_t)(ids8 >> (8 * h)) & 255u;
+        if (v < col_id) i = h + 1;
+        else if (v > col_id) j = h;
+        else return 1;
+    }
+    return 2;
+}
+
+// the row's <= 8 end offsets (2 bytes each) in two words
+template <class R>
+TSQ_HD void tsq_rc_fast_offsets(const R& b, uint32_t nn, uint32_t offs_at, uint64_t* o_lo, uint64_t* o_hi) {
+    *o_lo = nn ? b.le(offs_at, nn >= 4 ? 8 : 2 * nn) : 0;
+    *o_hi = nn > 4 ? b.le(offs_at + 8, 2 * (nn - 4)) : 0;
+}
+
+// one output column of a row on the shared-layout path: hdr0 / ids0 = the signature every row of the wave has
+template <class R>
+TSQ_HD int tsq_rc_fast_column(const R& b, uint32_t len, uint64_t hdr0, uint64_t ids0, uint64_t o_lo, uint64_t o_hi, int64_t col_id, int32_t type,
+                              uint32_t flags, uint64_t def_bits, int64_t handle, uint64_t* bits_out, bool* notnull_out) {
+    *bits_out = 0;
+    *notnull_out = false;
+    if (flags & TSQ_RC_HANDLE) {
+        *bits_out = (uint64_t)handle;
+        *notnull_out = true;
+        return RC_OK;
+    }
+    const uint32_t nn = (uint32_t)(hdr0 >> 16) & 0xffffu, nl = (uint32_t)(hdr0 >> 32) & 0xffffu;
+    uint32_t idx = 0;
+    const int f = tsq_rc_find_small(ids0, nn, nl, col_id, &idx);  // the same for every row of the wave
+    if (f == 1) return RC_OK;
+    if (f == 2) {
+        if (flags & TSQ_RC_HAS_DEFAULT) { *bits_out = def_bits; *notnull_out = true; }
+        return RC_OK;
+    }
+    const uint32_t data_at = 6 + nn + nl + 2 * nn;
+    const uint32_t end = (uint32_t)((idx < 4 ? o_lo : o_hi) >> (16 * (idx & 3))) & 0xffffu;
+    const uint32_t start = idx > 0 ? (uint32_t)((idx - 1 < 4 ? o_lo : o_hi) >> (16 * ((idx - 1) & 3))) & 0xffffu : 0u;
+    if (start > end || end > len - data_at) return RC_MALFORMED;
+    const int vc = tsq_rc_value(b, data_at + start, end - start, type, bits_out);
+    if (vc != RC_OK) return vc;
     *notnull_out = true;
     return RC_OK;
 }
