@@ -83,7 +83,7 @@ def test_reference_rows_of_rowcodec_test(ctx, orc):
     assert RC.NewChunkDecoder(ctx, cols, -1, lambda i: 9 if i == 1 else None).DecodeToChunk(b, o).rows() == [(1, None)]
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 1000, 4097, 100_000])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 1000, 4097, 100_000, 1_000_000])
 def test_random_scans_against_the_oracle(ctx, orc, n):
     rng = np.random.default_rng(n)
     chk = _scan(rng, n)
@@ -92,6 +92,12 @@ def test_random_scans_against_the_oracle(ctx, orc, n):
     st, want = orc.rowcodec_decode(b, o, handles, SPECS)
     assert st == 0
     _same(_decoder(ctx).DecodeToChunk(b, o, handles), want)
+    if n in (257, 100_000):  # the plain kernel as well
+        os.environ["TSQ_ROWCODEC_PIPELINE"] = "0"
+        try:
+            _same(_decoder(ctx).DecodeToChunk(b, o, handles), want)
+        finally:
+            del os.environ["TSQ_ROWCODEC_PIPELINE"]
 
 
 def test_large_ids_and_rows_wider_than_the_lds_tile(ctx, orc):
@@ -300,13 +306,13 @@ U_SPECS = [(200, abi.F64), (-1, abi.I64, abi.RC_HANDLE), (9, abi.I64), (3, abi.I
 
 def _both_kernel_paths(ctx, b, o, handles, specs, want_st, want):
     n = len(o) - 1
-    for knob in ("1", "0"):
-        os.environ["TSQ_ROWCODEC_FAST_LAYOUT"] = knob
+    for knob, pipe in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):  # TSQ_ROWCODEC_PIPELINE=0: the plain (not software-pipelined) kernel
+        os.environ["TSQ_ROWCODEC_FAST_LAYOUT"], os.environ["TSQ_ROWCODEC_PIPELINE"] = knob, pipe
         try:
             gst, m, got = _decode_device(ctx, b, o, handles, specs, n)
         finally:
-            del os.environ["TSQ_ROWCODEC_FAST_LAYOUT"]
-        assert (gst == abi.OK) == (want_st == 0) and m == want.NumRows(), knob
+            del os.environ["TSQ_ROWCODEC_FAST_LAYOUT"], os.environ["TSQ_ROWCODEC_PIPELINE"]
+        assert (gst == abi.OK) == (want_st == 0) and m == want.NumRows(), (knob, pipe)
         if want_st:
             assert _lib.last_error(ctx.h) == MSG[want_st]
         _same(got, want)

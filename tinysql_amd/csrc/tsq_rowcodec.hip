@@ -163,6 +163,88 @@ __global__ void __launch_bounds__(RC_NT) k_rowcodec_decode(RcArgs a) {
     }
 }
 
+// The software-pipelined form (the default): a workgroup walks its tiles t, t + G, t + 2G, ... and keeps TWO things in flight
+// while it parses tile t out of LDS: the bytes of tile t + G (in registers: KV 16-byte vectors per lane, written to LDS at the
+// top of the next iteration) and the row boundaries of tile t + 2G (which the loads of the iteration after need).  The plain
+// kernel above pays offsets -> bytes -> parse as three dependent latencies per tile.
+struct RcMeta {
+    int64_t tile_lo, tile_hi, lo, hi;
+};
+__device__ __forceinline__ RcMeta rc_load_meta(const RcArgs& a, int64_t t, int64_t n_tiles, uint32_t tid) {
+    RcMeta m = {0, 0, 0, 0};
+    if (t < n_tiles) {
+        const int64_t r0 = t * RC_NT, r1 = r0 + RC_NT < a.nrows ? r0 + RC_NT : a.nrows;
+        m.tile_lo = a.offsets[r0];
+        m.tile_hi = a.offsets[r1];
+        if (r0 + tid < r1) {
+            m.lo = a.offsets[r0 + tid];
+            m.hi = a.offsets[r0 + tid + 1];
+        }
+    }
+    return m;
+}
+
+template <int KV>
+__global__ void __launch_bounds__(RC_NT, KV <= 6 ? 6 : 1) k_rowcodec_decode_pipe(RcArgs a) {
+    extern __shared__ uint4 s_tile[];
+    const uint32_t tid = threadIdx.x;
+    const int64_t n_tiles = (a.nrows + RC_NT - 1) / RC_NT, G = gridDim.x;
+    const int64_t bm_bytes = (a.nrows + 7) / 8;
+    const tsq_rc_plan none = {0, 0, 0, 0};
+    uint4 regs[KV];
+    int64_t t = blockIdx.x;
+    RcMeta m0 = rc_load_meta(a, t, n_tiles, tid), m1 = rc_load_meta(a, t + G, n_tiles, tid);
+    tsq_rc_plan p0 = t < n_tiles ? tsq_rc_tile_plan((uint64_t)(uintptr_t)a.bytes, m0.tile_lo, m0.tile_hi, a.n_bytes, a.lds_bytes) : none;
+#pragma unroll
+    for (int i = 0; i < KV; i++) regs[i] = make_uint4(0, 0, 0, 0);
+    if (p0.staged) {
+        const uint4* src = (const uint4*)(a.bytes + p0.copy_from);
+        const uint32_t last = p0.n_vec ? p0.n_vec - 1 : 0u;  // lanes past the end re-read the last vector (never stored)
+#pragma unroll
+        for (int i = 0; i < KV; i++) regs[i] = src[min((uint32_t)i * RC_NT + tid, last)];
+    }
+    while (t < n_tiles) {
+        if (p0.staged) {
+#pragma unroll
+            for (int i = 0; i < KV; i++)
+                if ((uint32_t)i * RC_NT + tid < p0.n_vec) s_tile[(uint32_t)i * RC_NT + tid] = regs[i];
+        }
+        __syncthreads();
+        // in flight during the parse: boundaries of tile t + 2G, bytes of tile t + G
+        const RcMeta m2 = rc_load_meta(a, t + 2 * G, n_tiles, tid);
+        const tsq_rc_plan p1 = t + G < n_tiles ? tsq_rc_tile_plan((uint64_t)(uintptr_t)a.bytes, m1.tile_lo, m1.tile_hi, a.n_bytes, a.lds_bytes) : none;
+        if (p1.staged) {
+            const uint4* src = (const uint4*)(a.bytes + p1.copy_from);
+            const uint32_t last = p1.n_vec ? p1.n_vec - 1 : 0u;
+#pragma unroll
+            for (int i = 0; i < KV; i++) regs[i] = src[min((uint32_t)i * RC_NT + tid, last)];
+        }
+        const int64_t r0 = t * RC_NT, r1 = r0 + RC_NT < a.nrows ? r0 + RC_NT : a.nrows;
+        const int64_t r = r0 + tid;
+        const bool live = r < r1;
+        const int64_t lo = m0.lo, hi = m0.hi, tile_lo = m0.tile_lo, tile_hi = m0.tile_hi;
+        const bool bad_offsets = live && (lo < tile_lo || hi < lo || hi > tile_hi || tile_hi > a.n_bytes || hi - lo > 0x7fffffffLL);
+        const bool ok_row = live && !bad_offsets;
+        const uint32_t len = ok_row ? (uint32_t)(hi - lo) : 0u;
+        const int64_t handle = (live && a.handles) ? a.handles[r] : 0;
+        if (p0.staged) {
+            RcLds rd;
+            rd.w = (const uint32_t*)s_tile;
+            rd.base = ok_row ? p0.skew + (uint32_t)(lo - tile_lo) : 0u;
+            rc_rows_lds(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
+        } else {
+            RcGlobal rd;
+            rd.p = a.bytes + (ok_row ? lo : 0);
+            rc_rows(a, rd, len, live, bad_offsets, handle, r, r0, bm_bytes, tid);
+        }
+        __syncthreads();  // every wave is done with the tile before the next one is written over it
+        m0 = m1;
+        m1 = m2;
+        p0 = p1;
+        t += G;
+    }
+}
+
 }  // namespace
 
 // ====================================================================== host side
@@ -245,7 +327,16 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         a.lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(want, RC_LDS_MIN), RC_LDS_MAX);
         const int64_t wg_per_cu = std::min<int64_t>(8, (160 * 1024) / a.lds_bytes);  // 160 KB of LDS and 32 waves per CU
         const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * wg_per_cu);
-        hipLaunchKernelGGL(k_rowcodec_decode, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);  // + slack for the word reads
+        const char* pl = getenv("TSQ_ROWCODEC_PIPELINE");
+        if (pl && pl[0] == '0') {
+            hipLaunchKernelGGL(k_rowcodec_decode, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);  // + slack for the word reads
+        } else if (a.lds_bytes <= 24 * 1024) {  // KV = 16-byte vectors a lane may hold for the next tile = tile bytes / (16 * 256)
+            hipLaunchKernelGGL(k_rowcodec_decode_pipe<6>, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);
+        } else if (a.lds_bytes <= 32 * 1024) {
+            hipLaunchKernelGGL(k_rowcodec_decode_pipe<8>, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL(k_rowcodec_decode_pipe<16>, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, a.err, 8, hipMemcpyDeviceToHost, ctx->stream);

@@ -143,6 +143,17 @@ def main():
                     b3 = min(b3, time.perf_counter() - t)
                 sweep["general_path_only"] = round(b3 * 1e3, 4)
                 del os.environ["TSQ_ROWCODEC_FAST_LAYOUT"]
+                os.environ["TSQ_ROWCODEC_PIPELINE"] = "0"  # the plain kernel: offsets -> bytes -> parse per tile, nothing prefetched
+                b3 = 1e30
+                for rep in range(3):
+                    ctx.sync()
+                    t = time.perf_counter()
+                    _lib.check(ctx.lib.tsq_rowcodec_decode(ctx.h, C.c_void_p(dbytes), raw.size, C.c_void_p(doffs), None, n, abi.COL_DEVICE, len(IDS), specs(), oc,
+                                                           C.byref(m)), ctx.h)
+                    ctx.sync()
+                    b3 = min(b3, time.perf_counter() - t)
+                sweep["not_pipelined"] = round(b3 * 1e3, 4)
+                del os.environ["TSQ_ROWCODEC_PIPELINE"]
             key = outs[0].to_host().data
             algo = raw.size + 8.0 * n + 8.0 * len(IDS) * n  # row bytes + one 8-byte row boundary + 8 B per decoded value
             print(json.dumps({"workload": "decode %d stored rows (rowcodec v2, %d fixed-width columns), bytes and columns resident in HBM" % (n, len(IDS)),
