@@ -132,6 +132,7 @@ extern "C" void sim_sort_images(const void* data, int32_t type, int32_t desc, in
 }
 
 #include <stdlib.h>
+#include <vector>
 // ---- stored rows -> columns (tsq_rowcodec_dp.h): a CPU walk-through of k_rowcodec_decode (tsq_rowcodec.hip) with the same tile
 // plan, the same staged copy (aligned 16-byte vectors into the tile; bytes outside `values` and stale tile bytes are garbage here), the same
 // per-lane row code and the same bitmap bytes (one ballot per 64 rows, lanes 0..7 store one byte each when it exists).
@@ -265,4 +266,103 @@ extern "C" uint64_t sim_rowcodec_decode(const uint8_t* values, int64_t n_bytes, 
     }
     free(tile);
     return err;
+}
+
+// ---- chunk rows -> response bytes (tsq_encode_dp.h): a CPU walk-through of k_enc_size / k_enc_scan / k_enc_emit (tsq_encode.hip):
+// the same value lengths and datum bytes, the same ownership of contiguous tile ranges by workgroups, the per-tile LDS image at
+// the same skew, and the same copy-out plan (head bytes by lanes 0..15, whole vectors, tail bytes by lanes 16..31) into an output
+// whose address alignment is `out_phase` — bytes outside [0, total) must stay untouched.
+#include "../../tinysql_amd/csrc/tsq_encode_dp.h"
+namespace {
+uint64_t sim_enc_load(const tsq_col& col, int64_t r, bool* notnull) {
+    const uint8_t* bm = col.null_bitmap;
+    *notnull = bm ? ((bm[r >> 3] >> (r & 7)) & 1) != 0 : true;
+    if (col.type == TSQ_F32) {
+        const double d = (double)((const float*)col.data)[r];
+        uint64_t b;
+        memcpy(&b, &d, 8);
+        return b;
+    }
+    return ((const uint64_t*)col.data)[r];
+}
+uint32_t sim_enc_row_len(const tsq_col* cols, int n_cols, uint32_t comparable, int64_t r) {
+    uint32_t len = 0;
+    for (int c = 0; c < n_cols; c++) {
+        bool nn;
+        const uint64_t bits = sim_enc_load(cols[c], r, &nn);
+        len += tsq_enc_len(cols[c].type, (comparable >> c) & 1u, bits, nn);
+    }
+    return len;
+}
+}  // namespace
+// out: a buffer with 64 guard bytes on both sides of the region the caller checks; out_phase = (address of out[0]) & 15 to simulate.
+// Returns the total; row_offsets gets nrows + 1 entries.
+extern "C" int64_t sim_rows_encode(const tsq_col* cols, int32_t n_cols, uint32_t comparable, int64_t nrows, int32_t n_wg_want, uint8_t* out, int64_t cap,
+                                   uint32_t out_phase, int64_t* row_offsets) {
+    const int NT = 256;
+    const int64_t n_tiles = (nrows + NT - 1) / NT;
+    if (n_tiles == 0) { row_offsets[0] = 0; return 0; }
+    const int64_t want = n_wg_want < n_tiles ? n_wg_want : n_tiles;
+    const int64_t tiles_per_wg = (n_tiles + want - 1) / want;
+    const int n_wg = (int)((n_tiles + tiles_per_wg - 1) / tiles_per_wg);
+    std::vector<unsigned long long> wg(n_wg + 1, 0);
+    for (int b = 0; b < n_wg; b++) {  // k_enc_size
+        const int64_t t0 = b * tiles_per_wg, t1 = t0 + tiles_per_wg < n_tiles ? t0 + tiles_per_wg : n_tiles;
+        for (int64_t t = t0; t < t1; t++)
+            for (int tid = 0; tid < NT; tid++) {
+                const int64_t r = t * NT + tid;
+                if (r < nrows) wg[b] += sim_enc_row_len(cols, n_cols, comparable, r);
+            }
+    }
+    unsigned long long run = 0;  // k_enc_scan
+    for (int b = 0; b < n_wg; b++) { const unsigned long long v = wg[b]; wg[b] = run; run += v; }
+    wg[n_wg] = run;
+    if ((int64_t)run > cap) return (int64_t)run;
+    uint32_t row_max = 0;
+    for (int c = 0; c < n_cols; c++) row_max += (cols[c].type == TSQ_F32 || cols[c].type == TSQ_F64 || ((comparable >> c) & 1u)) ? 9u : TSQ_ENC_MAX_VALUE;
+    const size_t lds = (((size_t)NT * row_max + 15 + 16 + 15) / 16) * 16;
+    std::vector<uint8_t> img(lds);
+    const uint64_t out_addr = 0x7f0000002000ULL + out_phase;  // only its low bits matter
+    for (int b = 0; b < n_wg; b++) {  // k_enc_emit
+        const int64_t t0 = b * tiles_per_wg, t1 = t0 + tiles_per_wg < n_tiles ? t0 + tiles_per_wg : n_tiles;
+        int64_t base = (int64_t)wg[b];
+        for (int64_t t = t0; t < t1; t++) {
+            uint32_t len[NT], ex[NT], T = 0;
+            for (int tid = 0; tid < NT; tid++) {
+                const int64_t r = t * NT + tid;
+                len[tid] = r < nrows ? sim_enc_row_len(cols, n_cols, comparable, r) : 0u;
+                ex[tid] = T;  // block_excl_scan
+                T += len[tid];
+            }
+            const tsq_enc_copy plan = tsq_enc_copy_plan(out_addr, base, T);
+            if (plan.skew + T > lds) return -1;  // the LDS budget of the launch would be exceeded
+            memset(img.data(), 0xA5, lds);  // stale bytes of the previous tile must not leak
+            for (int tid = 0; tid < NT; tid++) {
+                const int64_t r = t * NT + tid;
+                if (r >= nrows) continue;
+                row_offsets[r] = base + (int64_t)ex[tid];
+                uint32_t pos = plan.skew + ex[tid];
+                for (int c = 0; c < n_cols; c++) {
+                    bool nn;
+                    const uint64_t bits = sim_enc_load(cols[c], r, &nn);
+                    uint64_t lo;
+                    uint32_t hi;
+                    const uint32_t n = tsq_enc_bytes(cols[c].type, (comparable >> c) & 1u, bits, nn, &lo, &hi);
+                    for (uint32_t i = 0; i < n; i++) img[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
+                    pos += n;
+                }
+            }
+            // copy-out: global byte (base - skew) + i <-> image byte i.  `out` here is indexed from the region start.
+            uint8_t* g = out + base - plan.skew;
+            for (uint32_t tid = 0; tid < 16; tid++)
+                if (plan.skew + tid < plan.head_end) g[plan.skew + tid] = img[plan.skew + tid];
+            for (uint32_t tid = 16; tid < 32; tid++)
+                if (plan.tail_lo + (tid - 16) < plan.tail_end) g[plan.tail_lo + (tid - 16)] = img[plan.tail_lo + (tid - 16)];
+            if (((out_addr + (uint64_t)base - plan.skew) & 15u) != 0) return -2;  // the vector stores would be misaligned
+            for (uint32_t i = plan.body_lo; i < plan.body_hi; i++) memcpy(g + 16 * (size_t)i, img.data() + 16 * (size_t)i, 16);
+            base += T;
+        }
+        if (t1 == n_tiles && t1 > t0) row_offsets[nrows] = base;
+    }
+    return (int64_t)run;
 }

@@ -48,6 +48,7 @@ F_LHS_UNSIGNED, F_RHS_UNSIGNED, F_FORCE_SIGNED = 1, 2, 4
 
 
 RC_HANDLE, RC_HAS_DEFAULT = 1, 2  # tsq_rowcodec_col.flags
+ENC_COMPARABLE = 1  # tsq_rows_encode col_flags
 
 
 class RowcodecCol(C.Structure):
@@ -198,6 +199,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_int64)]),
     "tsq_rowcodec_decode": (C.c_int32, [P, P, C.c_int64, P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(RowcodecCol), C.POINTER(Col),
                                         C.POINTER(C.c_int64)]),
+    "tsq_rows_encode": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.POINTER(C.c_uint32), C.c_int64, P, C.c_int64, C.c_uint32, P, C.POINTER(C.c_int64)]),
     "tsq_radix_split": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                     C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_join_stats": (C.c_int32, [P, C.POINTER(Stats)]),

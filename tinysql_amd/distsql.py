@@ -47,3 +47,31 @@ class SelectResult:
             got.append(chk)
             want -= chk.NumRows()
         return concat(got, self.types) if got else Chunk([Column(t, np.zeros(0, np_dtype(t))) for t in self.types])
+
+
+def encode_rows(ctx, chunk, comparable_cols=()):
+    """The storage side's inverse of decode_rows: the rows of a fixed-width chunk -> (RowsData bytes, row offsets[n + 1]), encoded
+    on the GPU by libtsq (`tsq_rows_encode`; codec.EncodeValue per value, util/codec/codec.go:74-99,205-209).  Columns listed in
+    `comparable_cols` use the EncodeKey form (the handle column of a table scan, util/rowcodec/decoder.go:263-273)."""
+    from .chunk import make_cols
+    n = chunk.NumRows()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    flags = (C.c_uint32 * len(chunk.columns))(*[abi.ENC_COMPARABLE if i in comparable_cols else 0 for i in range(len(chunk.columns))])
+    cap = n * len(chunk.columns) * 11 + 16
+    out = np.zeros(cap, np.uint8)
+    offs = np.zeros(n + 1, np.int64)
+    got = C.c_int64(0)
+    _lib.check(ctx.lib.tsq_rows_encode(ctx.h, cols, len(chunk.columns), flags, n, out.ctypes.data_as(C.c_void_p), cap, 0, offs.ctypes.data_as(C.c_void_p),
+                                       C.byref(got)), ctx.h)
+    return out[:got.value].copy(), offs
+
+
+ROWS_PER_CHUNK = 64  # store/mockstore/mocktikv/cop_handler_dag.go:510
+
+
+def response_chunks(raw, offsets):
+    """fillUpData4SelectResponse / appendRow (cop_handler_dag.go:414-425, :512-519): the byte string cut into tipb.Chunk.RowsData
+    pieces of 64 rows."""
+    n = len(offsets) - 1
+    return [bytes(raw[offsets[lo]:offsets[min(lo + ROWS_PER_CHUNK, n)]]) for lo in range(0, n, ROWS_PER_CHUNK)]
