@@ -1,6 +1,6 @@
 // tsq_encode_dp.h — the scalar core of tsq_rows_encode (tsq_encode.hip): one value -> its datum bytes, and how a workgroup copies
 // the bytes of a tile from LDS to their (arbitrarily aligned) place in the output.  TSQ_HD so that the CPU test-suite runs the
-// very same code through tests/hostsim against the oracle (oracle/codec_rows.cpp, pinned on codec_test.go).
+// very same code through tests/hostsim against the CPU restatement that is pinned on codec_test.go.
 // Reference: codec.encode (util/codec/codec.go:74-99) with comparable = false (EncodeValue, :205-209: varint forms) or true
 // (EncodeKey, :199-203: the handle column of a table scan, util/rowcodec/decoder.go:263-273); encodeSignedInt / encodeUnsignedInt
 // (codec.go:145-154, 167-176); EncodeInt / EncodeUint / EncodeVarint / EncodeUvarint (util/codec/number.go:24-111);
