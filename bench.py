@@ -183,6 +183,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N>1: one extra, untimed pass of the split + all-to-all alone (no probe), for SURVEY.md §8(d)'s t_exchange
+    exchange_ms = None
+    if distributed:
+        try:
+            full_sync()
+            te = time.perf_counter()
+            for _pieces, _n in parallel.redistribute_pipelined(ctx, dist, torch, [pk_t], [abi.I64], 0, 0, npr, args.exchange_chunks):
+                pass
+            full_sync()
+            tx = torch.tensor([time.perf_counter() - te], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+            exchange_ms = float(tx.item()) * 1e3
+        except Exception:  # reporting only
+            exchange_ms = None
+
     # ---------------------------------------------------------------- verify (size-independent property)
     cnt = C.c_int64(0)
     _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
@@ -241,6 +256,8 @@ def main():
         "table_bytes": st.table_bytes,
         "setup_s": setup_s,
     }
+    if exchange_ms is not None:
+        out["split_and_exchange_ms"] = exchange_ms  # tsq_radix_split + RCCL all-to-all of one step's probe keys, without the probes
     out["probe_strategy"] = ("radix 2^%d partitions" % st.radix_bits) if radix else "direct"
     traffic = traffic_part = None
     try:  # PMC-derived HBM bytes per launch are measured offline (rocprofv3 --pmc passes) and committed under profiles/
