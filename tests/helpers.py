@@ -161,3 +161,30 @@ def approx_equal(a, b, tol):
             return True
         return abs(a - b) <= tol
     return a == b
+
+
+_M64 = (1 << 64) - 1
+
+
+def mix64(k):
+    """tsq_mix64 (murmur3 finaliser) — the join table stores mix64(key word) (tinysql_amd/csrc/tsq_jointable.h)."""
+    k &= _M64
+    k ^= k >> 33
+    k = (k * 0xFF51AFD7ED558CCD) & _M64
+    k ^= k >> 33
+    k = (k * 0xC4CEB9FE1A85EC53) & _M64
+    k ^= k >> 33
+    return k
+
+
+def unmix64(w):
+    """inverse of mix64 (it is a bijection on 64-bit words): the int64 key whose table word is w."""
+    inv1, inv2 = pow(0xFF51AFD7ED558CCD, -1, 1 << 64), pow(0xC4CEB9FE1A85EC53, -1, 1 << 64)
+    w &= _M64
+    w ^= w >> 33
+    w = (w * inv2) & _M64
+    w ^= w >> 33
+    w = (w * inv1) & _M64
+    w ^= w >> 33
+    assert mix64(w) == (mix64(w) & _M64)
+    return int(np.uint64(w).astype(np.int64))

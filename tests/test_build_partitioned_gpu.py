@@ -86,23 +86,38 @@ def test_partitioned_build_key_types(ctx, orc, bt, pt):
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
 
 
-def test_partitioned_build_skewed_keys_use_the_row_list(ctx):
-    # 90 % of the build rows share one key: its pass-1 region and its sub-partition overflow, the slice image fills up and
-    # the chain runs on through the following slices — all of that through the row list + k_build_insert.
+def test_partitioned_build_skewed_keys_rebuild_unsliced(ctx):
+    # 2.5 % of the build rows share one key: its table slice (~4000 slots) cannot hold 5 000 duplicates, the slice image
+    # raises the fail flag and the table is rebuilt as ONE slice by k_build_insert — same rows, same checksum.
     nb = 200_000
-    bk = np.full(nb, 7, dtype=np.int64)
-    bk[::10] = np.arange(nb // 10) + 100
+    bk = np.arange(nb, dtype=np.int64) + 100
+    bk[::40] = 7
     build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(nb))])
     probe = Chunk([Column(abi.I64, np.array([7, 100, 101, 5, 7], dtype=np.int64)), Column(abi.I64, np.arange(5))])
     cfg = H.join_cfg([abi.I64, abi.I64], [abi.I64, abi.I64], [0], [0], abi.JOIN_INNER, 1)
     stats = []
     c, s, x = _join(ctx, cfg, build, probe, abi.RADIX_FORCE, stats=stats, count_only=True, checksum=True)
-    n7 = nb - nb // 10
-    assert c == 2 * n7 + 2
-    assert stats[0].build_partitioned == 1 and stats[0].build_handed_back_rows > 0 and stats[0].build_rows_inserted == nb
+    n7 = nb // 40
+    assert c == 2 * n7 + 1
+    assert stats[0].build_slice_retries == 1 and stats[0].table_slice_bits == 0 and stats[0].build_rows_inserted == nb
     assert _join(ctx, cfg, build, probe, abi.RADIX_OFF, count_only=True, checksum=True) == (c, s, x)
     got = _join(ctx, cfg, build, Chunk([Column(abi.I64, np.array([7], dtype=np.int64)), Column(abi.I64, np.zeros(1, np.int64))]), abi.RADIX_FORCE)
     assert got.NumRows() == n7 and sorted(got.columns[3].data.tolist()) == sorted(np.nonzero(bk == 7)[0].tolist())
+
+
+def test_build_with_one_key_on_most_rows_is_handed_back_to_go(ctx):
+    # 90 % of the build rows share one key: every insert would scan the key's whole run (O(d^2 / 8) bucket reads); rowHashMap.Put
+    # is O(1) (hash_table.go:247-256), so the build refuses and the Go operator runs instead (INTEGRATION.md eligibility)
+    nb = 200_000
+    bk = np.full(nb, 7, dtype=np.int64)
+    bk[::10] = np.arange(nb // 10) + 100
+    build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, np.array([7], dtype=np.int64)), Column(abi.I64, np.arange(1))])
+    cfg = H.join_cfg([abi.I64, abi.I64], [abi.I64, abi.I64], [0], [0], abi.JOIN_INNER, 1)
+    for radix in (abi.RADIX_FORCE, abi.RADIX_OFF):
+        with pytest.raises(_lib.TsqError) as ei:
+            _join(ctx, cfg, build, probe, radix, count_only=True)
+        assert ei.value.status == abi.ERR_UNSUPPORTED
 
 
 def _device_join_checksum(ctx, n_build, n_probe, radix):

@@ -20,6 +20,7 @@ from . import helpers as H
 pytestmark = pytest.mark.gpu
 
 SENT = np.uint64(0x8080808080808080).astype(np.int64)  # the table's EMPTY sentinel is a legal key
+SENT_PRE = H.unmix64(0x8080808080808080)               # ... and so is the key whose TABLE WORD mix64(key) is the sentinel
 
 
 def _cfg(bt=abi.I64, pt=abi.I64):
@@ -57,16 +58,17 @@ def test_radix_ragged_sizes_dups_nulls_vs_oracle(ctx, orc, n_probe):
 
 def test_radix_sentinel_key_and_long_chains(ctx, orc):
     rng = np.random.default_rng(5)
-    bk = np.concatenate([np.full(7, SENT), np.full(40, 12345), rng.integers(0, 50, 500)]).astype(np.int64)
-    pk = np.concatenate([np.full(11, SENT), np.full(9, 12345), rng.integers(0, 60, 3000)]).astype(np.int64)
+    bk = np.concatenate([np.full(7, SENT), np.full(5, SENT_PRE), np.full(40, 12345), rng.integers(0, 50, 500)]).astype(np.int64)
+    pk = np.concatenate([np.full(11, SENT), np.full(13, SENT_PRE), np.full(9, 12345), rng.integers(0, 60, 3000)]).astype(np.int64)
     rng.shuffle(bk)
     rng.shuffle(pk)
     build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(len(bk)))])
     probe = Chunk([Column(abi.I64, pk), Column(abi.I64, np.arange(len(pk)))])
     cfg = _cfg()
     want = orc.hash_join(cfg, build, probe).NumRows()
-    assert want >= 7 * 11 + 40 * 9
+    assert want >= 7 * 11 + 5 * 13 + 40 * 9
     assert _count(ctx, cfg, build, probe, abi.RADIX_FORCE) == want
+    assert _count(ctx, cfg, build, probe, abi.RADIX_OFF) == want
 
 
 @pytest.mark.parametrize("bt,pt", [(abi.F64, abi.F64), (abi.F32, abi.F64), (abi.U64, abi.I64), (abi.I64, abi.U64), (abi.U64, abi.U64)])
@@ -166,7 +168,8 @@ def test_radix_auto_engages_on_large_batches_and_matches_direct_probe(ctx):
 def test_radix_full_size_1e8_by_1e8_property(ctx):
     n = 100_000_000  # BASELINE headline size: every probe key lies in [0, n) and joins exactly once
     got, st = _device_count(ctx, n, n, n, abi.RADIX_AUTO)
-    assert got == n and st.radix_batches == 1 and st.radix_bits == 10 and st.radix_overflow_rows == 0
+    assert got == n and st.radix_batches == 1 and st.radix_bits >= 10 and st.radix_overflow_rows == 0
+    assert st.table_slice_bits >= 13 and st.build_slice_retries == 0
 
 
 @pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
@@ -178,8 +181,10 @@ def test_radix_forced_leaves_every_other_probe_kernel_exact(ctx, orc, jt, inner)
     bk = rng.integers(0, 9000, nb)           # ~4.4 duplicates per key: full buckets, late list, spill chains
     bk[:300] = 77                            # one key with 300 duplicates
     bk[300:320] = SENT
+    bk[320:330] = SENT_PRE
     pk = rng.integers(-100, 9500, npr)
     pk[:50] = SENT
+    pk[50:80] = SENT_PRE
     left = Chunk([Column(abi.I64, pk, rng.random(npr) > 0.05), Column(abi.I64, rng.integers(0, 99, npr))])
     right = Chunk([Column(abi.I64, bk, rng.random(nb) > 0.05), Column(abi.I64, rng.integers(0, 99, nb))])
     t = [abi.I64, abi.I64]
@@ -190,3 +195,101 @@ def test_radix_forced_leaves_every_other_probe_kernel_exact(ctx, orc, jt, inner)
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
     c, s, x = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, checksum=True, radix=abi.RADIX_FORCE)
     assert c == want.NumRows() and (s, x) == orc.rows_checksum(want)
+
+
+# ---------------------------------------------------------------- LDS probe (tsq_ldsprobe.h) on sliced tables
+def _env(**kw):
+    import contextlib
+    import os
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: os.environ.get(k) for k in kw}
+        try:
+            for k, v in kw.items():
+                os.environ[k] = str(v)
+            yield
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return cm()
+
+
+def _sliced_inputs(seed, nb, npr):
+    rng = np.random.default_rng(seed)
+    bk = rng.integers(-(1 << 62), 1 << 62, nb)          # full-width keys: every table slice gets rows
+    bk[: nb // 4] = rng.integers(0, nb // 16, nb // 4)  # ... and a quarter of the rows carries ~4 duplicates per key
+    bk[:700] = 4242                                     # one key with 700 duplicates: a chain of ~90 full buckets that wraps
+    bk[700:712] = SENT_PRE
+    bk[712:720] = SENT
+    pk = np.concatenate([rng.choice(bk, npr // 2), rng.integers(-(1 << 62), 1 << 62, npr - npr // 2)])
+    pk[:40] = SENT_PRE
+    pk[40:60] = 4242
+    rng.shuffle(pk)
+    build = Chunk([Column(abi.I64, bk, rng.random(nb) > 0.03), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, pk, rng.random(npr) > 0.03), Column(abi.I64, np.arange(npr))])
+    return build, probe
+
+
+@pytest.mark.parametrize("knobs", [{}, {"TSQ_LDS_NF_MAX": 1}, {"TSQ_LDS_NF_MAX": 3, "TSQ_RADIX_PB_MAX": 4}, {"TSQ_LDS_NF_MAX": 2, "TSQ_RADIX_PB_MAX": 3},
+                                   {"TSQ_RADIX_KERNEL": "l2"}, {"TSQ_TABLE_LF": 0.5}, {"TSQ_TABLE_LF": 0.65}],
+                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()) or "default")
+def test_lds_probe_on_a_sliced_table_vs_oracle(ctx, orc, knobs):
+    # 300 K build rows -> partitioned build, ~100 table slices; the knobs force several images per partition (S > 1, a last
+    # image with fewer slices), the L2 route over the same sliced table, and other load factors
+    build, probe = _sliced_inputs(23, 300_000, 1_200_000)
+    cfg = _cfg()
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    with _env(**knobs):
+        stats = []
+        assert _count(ctx, cfg, build, probe, abi.RADIX_FORCE, stats=stats) == want
+        st = stats[0]
+        assert st.radix_batches == 1 and st.build_partitioned == 1 and st.table_slice_bits >= 5 and st.build_slice_retries == 0
+    assert _count(ctx, cfg, build, probe, abi.RADIX_OFF) == want
+
+
+def test_sliced_table_serves_the_materialising_and_outer_probes(ctx, orc):
+    build, probe = _sliced_inputs(29, 120_000, 90_000)
+    t = [abi.I64, abi.I64]
+    for jt in (abi.JOIN_INNER, abi.JOIN_LEFT_OUTER):
+        cfg = H.join_cfg(t, t, [0], [0], jt, 1)
+        want = orc.hash_join(cfg, build, probe)
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, radix=abi.RADIX_FORCE)
+        assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+        c, s, x = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, checksum=True)
+        assert c == want.NumRows() and (s, x) == orc.rows_checksum(want)
+
+
+def test_overfull_slice_rebuilds_the_table_as_one_slice(ctx, orc):
+    # 6000 duplicates of one key cannot live in one table slice (~4000 slots): the build notices, rebuilds unsliced, stays exact
+    rng = np.random.default_rng(31)
+    nb, npr = 200_000, 400_000
+    bk = rng.integers(0, 1 << 40, nb)
+    bk[:6000] = 99
+    pk = rng.choice(bk, npr)
+    build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, pk), Column(abi.I64, np.arange(npr))])
+    cfg = _cfg()
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    for radix in (abi.RADIX_FORCE, abi.RADIX_AUTO):
+        stats = []
+        assert _count(ctx, cfg, build, probe, radix, stats=stats) == want
+        assert stats[0].build_slice_retries == 1 and stats[0].table_slice_bits == 0
+
+
+def test_heavily_duplicated_build_key_is_refused_quickly(ctx):
+    # d duplicates of one key cost O(d^2 / 8) bucket reads in an open-addressing multimap; rowHashMap.Put is O(1)
+    # (hash_table.go:247-256).  Beyond ~16 K duplicates the build gives the operator back to Go instead of running for minutes.
+    import time
+    nb = 1_500_000
+    bk = np.zeros(nb, dtype=np.int64)
+    bk[: nb // 3] = np.arange(nb // 3)
+    build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, np.arange(10, dtype=np.int64)), Column(abi.I64, np.arange(10))])
+    t0 = time.time()
+    with pytest.raises(_lib.TsqError) as ei:
+        _count(ctx, _cfg(), build, probe, abi.RADIX_AUTO)
+    assert ei.value.status == abi.ERR_UNSUPPORTED and time.time() - t0 < 20

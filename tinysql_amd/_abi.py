@@ -137,6 +137,7 @@ class Stats(C.Structure):
         ("partition_kernel_ms", C.c_double), ("radix_probe_kernel_ms", C.c_double), ("partition_kernel_ms_sum", C.c_double),
         ("radix_probe_kernel_ms_sum", C.c_double), ("radix_timed_batches", C.c_int64), ("radix_batches", C.c_int64), ("radix_overflow_rows", C.c_int64),
         ("radix_bits", C.c_int32), ("build_partitioned", C.c_int32), ("build_handed_back_rows", C.c_int64),
+        ("table_slice_bits", C.c_int32), ("build_slice_retries", C.c_int32),
     ]
 
 

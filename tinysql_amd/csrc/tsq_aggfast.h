@@ -221,10 +221,7 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
         const uint32_t p = blockIdx.x;
         for (uint32_t r = 0; r < a.st.R; r++) {
             const uint32_t region = p * a.st.R + r;
-            uint32_t len = a.st.cursor[region];
-            const uint32_t ve = a.st.valid_end[region];
-            len = len < ve ? len : ve;
-            len = len < a.st.cap ? len : a.st.cap;
+            const uint32_t len = radix_region_len(a.st, 1u << a.st.bits, p, r);
             const size_t base = (size_t)region * a.st.cap;
             for (uint32_t i0 = tid; i0 < len; i0 += TSQ_AF_NT * U) {
                 uint64_t tag[U], cells[U][TSQ_RADIX_MAXV];

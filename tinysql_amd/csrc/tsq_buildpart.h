@@ -2,20 +2,21 @@
 //
 // Why: k_build_insert claims slots with one random 64-bit CAS per build row into a table of GBs: 9 ms per 1e8 rows,
 // 0.03 of the HBM roofline (random device atomics run at 20-27 G/s, and every row also scatters a 4-byte row id).
-// The table is range partitioned by construction — bucket(kw) = mulhi64(mix64(kw), nbuckets) is monotonic in the hash
-// (tsq_jointable.h) — so a slice of it can be ASSEMBLED IN LDS from the rows whose hash falls into that slice and then
-// written to HBM as whole lines:
-//   pass 1  k_radix_partition<.., WITH_IDX>   build key words + row ids by the top b1 hash bits (tsq_radix.h)
+// The table is 2^tb self-contained slices selected by the top tb bits of the table word w = mix64(key word)
+// (tsq_jointable.h), so a slice can be ASSEMBLED IN LDS from the rows whose word falls into it and then written to HBM
+// as whole lines:
+//   pass 1  k_radix_partition<.., WITH_IDX, HASHED>  table words + row ids by the top b1 bits of w (tsq_radix.h)
 //   pass 2  k_radix_subpartition              one workgroup per pass-1 partition splits it by the next b2 bits; the
 //                                             workgroup owns its 2^b2 outputs, so cursors live in LDS (no device atomics)
 //   pass 3  k_build_images                    one workgroup per sub-partition: LDS image of its nbuckets/2^(b1+b2)
 //                                             buckets (<= 768 buckets = 72 KB: two workgroups per CU), filled with LDS
 //                                             compare-and-swap, stored with 16-byte coalesced writes
-// nbuckets is rounded up to a multiple of 2^(b1+b2), so no bucket is shared by two sub-partitions.  Rows that do not fit
-// (a skewed partition overflowing its region, a bucket chain running past the end of its slice) are appended to a row
-// list and inserted afterwards by the ordinary k_build_insert: the linear-probing invariant holds because everything
-// between their home bucket and the end of the slice is full.  The resulting table is equivalent to the one
-// k_build_insert builds (same buckets, slots filled front to back, possibly another slot order inside a chain).
+// b1 + b2 = tb: a sub-partition IS a table slice; a chain that reaches the end of the slice wraps to its first bucket,
+// exactly as k_build_insert and every probe walk do.  Rows of a skewed partition that overflow their pass-1 / pass-2
+// region are appended to a row list and inserted afterwards by k_build_insert; a slice that cannot take all of its rows
+// (heavily duplicated keys) raises the fail flag and the host rebuilds the table unsliced.  The resulting table is
+// equivalent to the one k_build_insert builds (same buckets, slots filled front to back, possibly another slot order
+// inside a chain).
 //
 // Replaces (reference): hashRowContainer.PutChunk + rowHashMap.Put (executor/hash_table.go:146-169,247-256).
 #ifndef TSQ_BUILDPART_H
@@ -25,6 +26,7 @@
 
 #define TSQ_BP_MAXP2 256
 #define TSQ_BP_MAX_SLICE 768  // buckets per LDS image (96 B each)
+#define TSQ_BP_MAX_SLICE_ROWS 3200  // mean rows of a slice: k_build_images<512, 8> holds <= 4096 rows of a slice in registers
 
 struct SubStore {
     uint64_t* keys;       // [Q * cap2] key words, Q = 2^(b1+b2)
@@ -54,10 +56,7 @@ __global__ void __launch_bounds__(NT) k_radix_subpartition(RadixStore st, SubSto
         __syncthreads();
         for (uint32_t r = 0; r < st.R; r++) {
             const uint32_t region = p * st.R + r;
-            uint32_t len = st.cursor[region];
-            const uint32_t ve = st.valid_end[region];
-            len = len < ve ? len : ve;
-            len = len < st.cap ? len : st.cap;
+            const uint32_t len = radix_region_len(st, P1, p, r);
             const size_t rbase = (size_t)region * st.cap;
             for (uint32_t t0 = 0; t0 < len; t0 += T) {
                 const uint32_t n = len - t0 < (uint32_t)T ? len - t0 : (uint32_t)T;
@@ -78,7 +77,7 @@ __global__ void __launch_bounds__(NT) k_radix_subpartition(RadixStore st, SubSto
                 for (int j = 0; j < K; j++) {
                     const uint32_t pos = (uint32_t)j * NT + tid;
                     if (pos < n) {
-                        const uint32_t s = (uint32_t)(tsq_mix64(k[j]) >> shift) & mask;
+                        const uint32_t s = (uint32_t)(k[j] >> shift) & mask;  // k[] are table words
                         pr[j] = (s << 16) | atomicAdd(&s_hist[s], 1u);
                     }
                 }
@@ -106,7 +105,7 @@ __global__ void __launch_bounds__(NT) k_radix_subpartition(RadixStore st, SubSto
                 __syncthreads();
                 for (uint32_t i = tid; i < n; i += NT) {
                     const uint64_t key = s_keys[i];
-                    const uint32_t s = (uint32_t)(tsq_mix64(key) >> shift) & mask;
+                    const uint32_t s = (uint32_t)(key >> shift) & mask;
                     if (!(s_hist[s] >> 31)) {
                         const uint32_t d = s_delta[s] + i;  // 32-bit wrap-around: s_delta may be "negative"
                         out.keys[d] = key;
@@ -126,8 +125,9 @@ __global__ void __launch_bounds__(NT) k_radix_subpartition(RadixStore st, SubSto
 
 struct ImageArgs {
     SubStore in;
-    JoinTable t;             // nbuckets is a multiple of Q
-    uint32_t m;              // buckets per sub-partition = nbuckets / Q
+    JoinTable t;             // t.tb == b1 + b2
+    uint32_t m;              // buckets per sub-partition = t.bs
+    uint32_t* fail;          // [0] set when a slice cannot take all of its rows, [1] when two rows carry the same table word
     uint32_t* sent_rows;     // side list of the sentinel key word (capacity sent_cap)
     uint32_t sent_cap;
     uint32_t* sent_total;
@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
     __shared__ unsigned long long s_handled;
     if (tid == 0) s_handled = 0;
     uint32_t placed = 0;  // rows this thread put into an image or the side list (the row list is counted by k_build_insert)
+    bool dup = false;
     uint64_t kw[KPT];
     uint32_t row[KPT];
     auto load_rows = [&](uint32_t q, uint32_t cnt) {
@@ -188,26 +189,29 @@ __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
                 placed++;
                 continue;
             }
-            uint32_t lb = (uint32_t)(radix_bucket(tsq_mix64(kw[j]), a.t.nbuckets) - b0);
+            uint32_t lb = jt_local(a.t.tb, a.m, kw[j]);  // kw[] are table words; the slice is q by construction
             bool done = false;
-            while (!done) {
-                if (lb >= a.m) {  // the chain runs past this slice: k_build_insert continues it in the next one
-                    const uint32_t o = __hip_atomic_fetch_add(a.in.ovf_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (o < a.in.ovf_cap) a.in.ovf_rows[o] = row[j];
+            for (uint32_t steps = 0; !done; steps++) {
+                if (steps >= a.m) {  // the slice is full (heavily duplicated keys): the host rebuilds the table unsliced
+                    __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
                 unsigned long long* b = s_keys + lb * TSQ_BUCKET;
 #pragma unroll 1
                 for (int sl = 0; sl < TSQ_BUCKET && !done; sl++) {
                     // a stale EMPTY is harmless (the CAS decides); non-EMPTY never reverts
-                    if (__hip_atomic_load(&b[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == TSQ_EMPTY_KEY &&
-                        atomicCAS(&b[sl], (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)kw[j]) == TSQ_EMPTY_KEY) {
-                        s_vals[lb * TSQ_BUCKET + sl] = row[j];
-                        done = true;
-                        placed++;
+                    unsigned long long cur = __hip_atomic_load(&b[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cur == TSQ_EMPTY_KEY) {
+                        cur = atomicCAS(&b[sl], (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)kw[j]);
+                        if (cur == TSQ_EMPTY_KEY) {
+                            s_vals[lb * TSQ_BUCKET + sl] = row[j];
+                            done = true;
+                            placed++;
+                        }
                     }
+                    if (!done && cur == kw[j]) dup = true;  // equal words walk the same buckets: the later one sees the earlier one's slot
                 }
-                lb++;
+                lb = (lb + 1 == a.m) ? 0 : lb + 1;
             }
         }
         __syncthreads();
@@ -225,6 +229,7 @@ __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
         q = qn;
         cnt = cnt_n;
     }
+    if (dup) __hip_atomic_store(a.fail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t wsum = wave_sum_u64(placed);
     if ((tid & 63) == 0 && wsum) atomicAdd(&s_handled, (unsigned long long)wsum);
     __syncthreads();

@@ -4,15 +4,16 @@
 // Data layout in HBM
 //   build columns : one contiguous device array per column (+ optional null bitmap), appended
 //                   chunk by chunk — the device analogue of chunk.List (util/chunk/list.go:22-38).
-//   hash table    : bucketised open addressing, structure of arrays
-//                     keys[nbuckets][8]  uint64  key words, one 64-byte line per bucket
+//   hash table    : bucketised open addressing, structure of arrays (tsq_jointable.h)
+//                     keys[nbuckets][8]  uint64  table words w = mix64(key word), one 64-byte line per bucket
 //                     vals[nbuckets][8]  uint32  build row ids (RowPtr analogue, list.go:28-31)
+//                   2^tb self-contained slices of bs buckets (chains wrap inside their slice).
 //                   A probe touches exactly one 64 B line of `keys` (plus the next bucket only if
 //                   that one is full); `vals` is touched only for matches that are materialised.
 //                   Duplicate keys simply occupy further slots: the table is a multimap like
 //                   rowHashMap (hash_table.go:181-276); insertion order inside a key is not kept
 //                   (row order is unspecified across join workers in the reference too).
-//   EMPTY sentinel: 0x8080808080808080 (memset-able).  Build rows whose key word equals the
+//   EMPTY sentinel: 0x8080808080808080 (memset-able).  Build rows whose TABLE word equals the
 //                   sentinel go to a small side list so every int64 value remains a legal key.
 // Equality: a key cell is (flag, word) as in util/codec/codec.go:212-240; single-column keys store
 // the word itself (exact), multi-column keys store a 64-bit mix and verify against the build
@@ -20,6 +21,7 @@
 #include "tsq_stage.h"
 #include "tsq_jointable.h"
 #include "tsq_buildpart.h"
+#include "tsq_ldsprobe.h"
 
 #include <deque>
 #include <memory>
@@ -81,7 +83,10 @@ struct BuildArgs {
     uint32_t* sent_total;  // number of sentinel-key rows seen
     unsigned long long* inserted;
     const uint32_t* row_list;  // optional: insert only these build rows (rows the partitioned build handed back)
+    uint32_t* fail;            // [0] set when a row found no slot within TSQ_MAX_WALK buckets (slice full / key duplicated too often)
+                               // [1] set when a row walked past a slot holding its own table word (the build side has duplicate keys)
 };
+#define TSQ_MAX_WALK 2048u
 template <bool MULTI>
 __global__ void __launch_bounds__(256) k_build_insert(BuildArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -91,28 +96,41 @@ __global__ void __launch_bounds__(256) k_build_insert(BuildArgs a) {
         uint64_t kw;
         if (!load_kw<MULTI>(a.b, a.ks.bidx, a.ks.n_keys, a.ks.skip_high, row, kw)) continue;
         ins++;
-        if (kw == TSQ_EMPTY_KEY) {
+        const uint64_t w = tsq_table_word(kw);
+        if (w == TSQ_EMPTY_KEY) {
             uint32_t i = atomicAdd(a.sent_total, 1u);
             if (i < a.sent_cap) a.sent_rows[i] = (uint32_t)row;
             continue;
         }
-        uint64_t bkt = tsq_mulhi64(tsq_mix64(kw), a.t.nbuckets);
-        bool done = false;
-        while (!done) {
+        const uint64_t base_b = (uint64_t)jt_slice(a.t.tb, w) * a.t.bs;
+        uint32_t lb = jt_local(a.t.tb, a.t.bs, w);
+        const uint32_t max_steps = a.t.bs < TSQ_MAX_WALK ? a.t.bs : TSQ_MAX_WALK;
+        bool done = false, dup = false;
+        for (uint32_t steps = 0; !done; steps++) {
+            if (steps >= max_steps) {  // a full slice (skewed keys) or one key duplicated beyond reason: the host decides
+                __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            const uint64_t bkt = base_b + lb;
             unsigned long long* base = (unsigned long long*)(a.t.keys + bkt * TSQ_BUCKET);
 #pragma unroll 1
             for (int s = 0; s < TSQ_BUCKET && !done; s++) {
                 // a stale EMPTY is harmless (the CAS decides); non-EMPTY never reverts
-                if (__hip_atomic_load(base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == TSQ_EMPTY_KEY) {
-                    unsigned long long old = atomicCAS(base + s, (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)kw);
-                    if (old == TSQ_EMPTY_KEY) {
+                unsigned long long cur = __hip_atomic_load(base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == TSQ_EMPTY_KEY) {
+                    cur = atomicCAS(base + s, (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)w);
+                    if (cur == TSQ_EMPTY_KEY) {
                         a.t.vals[bkt * TSQ_BUCKET + s] = (uint32_t)row;
                         done = true;
                     }
                 }
+                // equal words walk the same buckets in the same order, so the later of two always sees the earlier one's slot
+                if (!done && cur == w) dup = true;
             }
-            bkt = (bkt + 1 == a.t.nbuckets) ? 0 : bkt + 1;
+            lb = (lb + 1 == a.t.bs) ? 0 : lb + 1;
         }
+        if (dup) __hip_atomic_store(a.fail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!done && __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // the build is void: stop early
     }
     uint64_t tot = wave_sum_u64(ins);
     if ((threadIdx.x & 63) == 0 && tot) atomicAdd(a.inserted, (unsigned long long)tot);
@@ -124,7 +142,7 @@ __global__ void __launch_bounds__(256) k_collect_sentinel(BuildArgs a) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
         uint64_t kw;
         if (!load_kw<MULTI>(a.b, a.ks.bidx, a.ks.n_keys, a.ks.skip_high, a.row0 + r, kw)) continue;
-        if (kw != TSQ_EMPTY_KEY) continue;
+        if (tsq_table_word(kw) != TSQ_EMPTY_KEY) continue;
         uint32_t i = atomicAdd(a.sent_total, 1u);
         if (i < a.sent_cap) a.sent_rows[i] = (uint32_t)(a.row0 + r);
     }
@@ -227,14 +245,15 @@ __device__ __forceinline__ uint64_t joined_rowhash(const ProbeArgs& a, int64_t k
 // visits every build row joined with probe row k
 template <bool MULTI, bool GEN, class F>
 __device__ __forceinline__ void for_each_match(const ProbeArgs& a, int64_t k, uint64_t kw, uint64_t& errw, uint32_t& div0, F&& f) {
-    if (kw == TSQ_EMPTY_KEY) {
+    const uint64_t w = tsq_table_word(kw);
+    if (w == TSQ_EMPTY_KEY) {
         for (uint32_t j = 0; j < a.t.sent_count; j++) {
             uint32_t brow = a.t.sent_rows[j];
             if (pair_matches<MULTI, GEN>(a, k, brow, errw, div0)) f(brow);
         }
         return;
     }
-    for_each_slot(a.t, kw, [&](uint64_t slot) {
+    for_each_slot_w(a.t, w, [&](uint64_t slot) {
         if (!MULTI && !(GEN && a.n_conds > 0)) {
             f(a.t.vals[slot]);  // the load is dead-code-eliminated when f ignores the row id
         } else {
@@ -265,8 +284,9 @@ __global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
         if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0)) {
             if (!MULTI && !GEN && !CHK && !a.first_cnt) {
                 // leanest form: keys only, never touches vals
-                if (kw == TSQ_EMPTY_KEY) c = a.t.sent_count;
-                else for_each_slot(a.t, kw, [&](uint64_t) { c++; });
+                const uint64_t w = tsq_table_word(kw);
+                if (w == TSQ_EMPTY_KEY) c = a.t.sent_count;
+                else for_each_slot_w(a.t, w, [&](uint64_t) { c++; });
             } else {
                 for_each_match<MULTI, GEN>(a, k, kw, errw, div0, [&](uint32_t brow) {
                     if (c == 0) first = brow;
@@ -552,7 +572,9 @@ struct tsq_join {
     bool multi = false;
     KeySpec ks{};
     DevBuf tkeys, tvals, sent;
-    uint64_t nbuckets = 0;
+    uint64_t nbuckets = 0;  // bs << tb
+    uint32_t tb = 0, bs = 0;  // slice geometry (tsq_jointable.h)
+    bool unique = false;      // no two table slots hold the same word (the build compares every slot it walks past)
     uint32_t sent_count = 0;
     int64_t build_inserted = 0;
     int64_t build_handed_back = 0;  // partitioned build: rows that went through the row list (skew, chains crossing a slice end)
@@ -625,6 +647,8 @@ void fill_table(tsq_join* j, JoinTable& t) {
     t.keys = j->tkeys.as<uint64_t>();
     t.vals = j->tvals.as<uint32_t>();
     t.nbuckets = j->nbuckets;
+    t.tb = j->tb;
+    t.bs = j->bs;
     t.sent_rows = j->sent.as<uint32_t>();
     t.sent_count = j->sent_count;
 }
@@ -699,12 +723,43 @@ bool radix_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_de
     return j->nbuckets * 64 >= ((uint64_t)12 << 20) && nrows >= (4 << 20);
 }
 
-uint32_t radix_bits_for(const tsq_join* j) {
+// Geometry of a radix probe batch.  LDS route (sliced table): P = 2^pb partitions of 2^(tb - pb) table slices each, read as S
+// images of nf slices (<= 128 KB); L2 route (plain table, or TSQ_RADIX_KERNEL=l2): table slices of ~1.5 MB per partition.
+struct RadixPlan {
+    bool lds;
+    uint32_t bits, S, nf;
+};
+RadixPlan radix_plan_for(const tsq_join* j) {
+    RadixPlan pl{false, TSQ_RADIX_MIN_BITS, 1, 1};
+    // test / experiment knobs: TSQ_RADIX_KERNEL=l2 keeps the L2 route, TSQ_LDS_NF_MAX caps the slices per image (forces S > 1 on
+    // small tables), TSQ_RADIX_PB_MAX caps log2(partitions)
+    const char* force = getenv("TSQ_RADIX_KERNEL");
+    const char* nf_env = getenv("TSQ_LDS_NF_MAX");
+    const char* pb_env = getenv("TSQ_RADIX_PB_MAX");
+    const bool want_lds = !(force && force[0] == 'l' && force[1] == '2');
+    if (want_lds && j->tb >= TSQ_RADIX_MIN_BITS && (uint64_t)j->bs * 64 <= TSQ_LDS_IMAGE_MAX) {
+        uint32_t nf_max = (uint32_t)(TSQ_LDS_IMAGE_MAX / ((uint64_t)j->bs * 64));
+        if (nf_env && atoi(nf_env) >= 1 && (uint32_t)atoi(nf_env) < nf_max) nf_max = (uint32_t)atoi(nf_env);
+        uint32_t k = 0;
+        while ((2u << k) <= nf_max) k++;  // largest power of two <= nf_max
+        int pb = (int)j->tb - (int)k;
+        if (pb < TSQ_RADIX_MIN_BITS) pb = TSQ_RADIX_MIN_BITS;
+        if (pb > TSQ_RADIX_MAX_BITS) pb = TSQ_RADIX_MAX_BITS;
+        if (pb_env && atoi(pb_env) >= TSQ_RADIX_MIN_BITS && atoi(pb_env) < pb) pb = atoi(pb_env);
+        const uint32_t fpp = 1u << (j->tb - (uint32_t)pb);
+        pl.lds = true;
+        pl.bits = (uint32_t)pb;
+        pl.nf = fpp < nf_max ? fpp : nf_max;
+        pl.S = (fpp + pl.nf - 1) / pl.nf;
+        return pl;
+    }
     const double slice_target = 1.5 * 1024 * 1024;  // two to three slices stay resident in a 4 MiB L2
     const double parts = (double)j->nbuckets * 64.0 / slice_target;
     uint32_t bits = TSQ_RADIX_MIN_BITS;
-    while (bits < 10 && (double)(1u << bits) < parts) bits++;  // 2^11 costs 0.59 ms per 1e8 keys (atomics), 2^10 0.36 ms
-    return bits;
+    while (bits < 10 && (double)(1u << bits) < parts) bits++;
+    if (j->tb && bits > j->tb) bits = j->tb;  // a partition is a whole number of slices
+    pl.bits = bits;
+    return pl;
 }
 
 tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
@@ -712,7 +767,8 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     tsq_handle_hdr* h = &j->hdr;
     RadixStore st;
     memset(&st, 0, sizeof st);
-    st.bits = radix_bits_for(j);
+    const RadixPlan pl = radix_plan_for(j);
+    st.bits = pl.bits;
     st.R = 8;
     const uint32_t P = 1u << st.bits;
     constexpr int NT = 1024, K = 16, T = NT * K;
@@ -752,7 +808,7 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
         if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
-    hipLaunchKernelGGL((k_radix_partition<NT, K, 4, 0, false>), dim3(pgrid), dim3(NT), 0, ctx->stream, src, st);
+    hipLaunchKernelGGL((k_radix_partition<NT, K, 4, 0, false, true>), dim3(pgrid), dim3(NT), 0, ctx->stream, src, st);
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     RadixProbeArgs pa;
@@ -760,8 +816,41 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     pa.st = st;
     fill_table(j, pa.t);
     pa.counters = j->counters.as<unsigned long long>();
-    const int per_xcd = std::max(1, ctx->num_cus / 8) * 6;  // 6 workgroups per CU (measured optimum 5-6)
-    hipLaunchKernelGGL((k_radix_probe_count<2, 0>), dim3(per_xcd * 8), dim3(256), 0, ctx->stream, pa);
+    if (pl.lds) {
+        constexpr int LNT = 1024;
+        LdsProbeArgs la;
+        memset(&la, 0, sizeof la);
+        la.st = st;
+        la.t = pa.t;
+        la.S = pl.S;
+        la.nf = pl.nf;
+        la.unique = j->unique ? 1u : 0u;
+        la.counters = pa.counters;
+        const size_t lds = (size_t)pl.nf * j->bs * 64 + (size_t)(LNT / 64) * TSQ_LDS_RING_BYTES;
+        const int lgrid = std::max(1, ctx->num_cus / 8) * 8;
+        if (getenv("TSQ_LDS_PROF")) {  // experiment: per-phase shader cycles of the LDS probe, printed per batch (synchronises)
+            DevBuf pb;
+            TSQ_TRY(pb.reserve(ctx, h, 64));
+            la.prof = pb.as<unsigned long long>();
+            TSQ_HIP(h, hipMemsetAsync(pb.p, 0, 64, ctx->stream));
+            TSQ_HIP(h, hipFuncSetAttribute((const void*)k_lds_probe_count<LNT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_lds_probe_count<LNT, true>), dim3(lgrid), dim3(LNT), lds, ctx->stream, la);
+            unsigned long long pf[8];
+            TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 24, pb.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+            TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+            memcpy(pf, ctx->pinned + 24, 64);
+            pb.release();
+            const double nw = (double)lgrid * (LNT / 64);
+            fprintf(stderr, "[lds-prof] P=2^%u S=%u nf=%u bs=%u waves=%.0f | per wave kcycles: imageA %.1f loadwait %.1f step %.1f probe %.1f drainB %.1f total %.1f | probes/wave %.0f\n",
+                    st.bits, pl.S, pl.nf, j->bs, nw, pf[0] / nw / 1e3, pf[1] / nw / 1e3, pf[2] / nw / 1e3, pf[3] / nw / 1e3, pf[4] / nw / 1e3, pf[5] / nw / 1e3, pf[6] / nw);
+        } else {
+            TSQ_HIP(h, hipFuncSetAttribute((const void*)k_lds_probe_count<LNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_lds_probe_count<LNT>), dim3(lgrid), dim3(LNT), lds, ctx->stream, la);
+        }
+    } else {
+        const int per_xcd = std::max(1, ctx->num_cus / 8) * 6;  // 6 workgroups per CU (measured optimum 5-6)
+        hipLaunchKernelGGL((k_radix_probe_count<2>), dim3(per_xcd * 8), dim3(256), 0, ctx->stream, pa);
+    }
     TSQ_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(k_radix_probe_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
     TSQ_HIP(h, hipGetLastError());
@@ -945,10 +1034,33 @@ tsq_status probe_flush(tsq_join* j) {
     return TSQ_OK;
 }
 
-// ---------------------------------------------------------------- partitioned build (host side, tsq_buildpart.h)
-// Single key column, enough rows to pay for three passes.  Geometry: Q = 2^bits slices of m <= 768 buckets.
+// ---------------------------------------------------------------- table geometry + partitioned build (host side)
+// Sliced tables (tsq_jointable.h): load factor ~0.75 over 8-slot buckets, 2^tb slices of bs buckets with at most
+// TSQ_BP_MAX_SLICE_ROWS rows each on average (a slice is one LDS image of the partitioned build; four of them are one
+// image of the LDS probe).  Small or skew-rebuilt tables are one slice at load factor <= 0.5 (est_build_rows is only a
+// hint in the reference too, hash_table.go:84-96).
+void table_geometry(tsq_join* j, int64_t nb, bool sliced) {
+    j->tb = 0;
+    j->bs = (uint32_t)std::max<uint64_t>(16, (uint64_t)((nb + 3) / 4));
+    if (sliced) {
+        const char* lf_env = getenv("TSQ_TABLE_LF");
+        double lf = lf_env ? atof(lf_env) : 0.75;
+        if (!(lf >= 0.3 && lf <= 0.9)) lf = 0.75;
+        const uint64_t nbk = std::max<uint64_t>(64, (uint64_t)ceil((double)nb / (8.0 * lf)));
+        const uint64_t bs_max = std::min<uint64_t>(TSQ_BP_MAX_SLICE, (uint64_t)(TSQ_BP_MAX_SLICE_ROWS / (8.0 * lf)));
+        uint32_t bits = 0;
+        while (((nbk + (1ull << bits) - 1) >> bits) > bs_max) bits++;
+        if (bits >= TSQ_RADIX_MIN_BITS && bits <= 19) {
+            j->tb = bits;
+            j->bs = (uint32_t)((nbk + (1ull << bits) - 1) >> bits);
+        }
+    }
+    j->nbuckets = (uint64_t)j->bs << j->tb;
+}
+
+// Single key column, enough rows to pay for three passes, sliced geometry chosen by the caller (Q = 2^tb slices of m = bs buckets).
 bool build_partitioned_eligible(const tsq_join* j, int64_t nb) {
-    if (j->radix_mode == TSQ_RADIX_OFF || j->multi || j->never_match) return false;
+    if (j->radix_mode == TSQ_RADIX_OFF || j->multi || j->never_match || j->tb < 2) return false;
     if (nb >= 0xffffffffLL) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE) return nb >= (1 << 16);
     return nb >= (4 << 20);
@@ -958,17 +1070,14 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     *done = false;
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
-    const uint64_t nb0 = std::max<uint64_t>(16, (uint64_t)((nb + 3) / 4));
-    uint32_t bits = 4;
-    while (((nb0 + (1ull << bits) - 1) >> bits) > TSQ_BP_MAX_SLICE) bits++;
-    if (bits > 19) return TSQ_OK;
+    const uint32_t bits = j->tb;
     uint32_t b1, b2;
     if (bits >= 16) { b2 = 8; b1 = bits - 8; }
     else if (bits >= 9) { b1 = 8; b2 = bits - 8; }
     else { b1 = bits - 1; b2 = 1; }
     const uint32_t Q = 1u << bits, P1 = 1u << b1;
-    const uint32_t m = (uint32_t)((nb0 + Q - 1) >> bits);
-    const uint64_t nbuckets = (uint64_t)m * Q;
+    const uint32_t m = j->bs;
+    const uint64_t nbuckets = j->nbuckets;
     // pass-1 store (8 XCC regions per partition), as in radix_probe
     RadixStore st;
     memset(&st, 0, sizeof st);
@@ -1003,7 +1112,6 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     if (s == TSQ_OK) s = j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8);
     if (s == TSQ_OK) s = j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4);
     if (s != TSQ_OK) { release_all(); return s; }
-    j->nbuckets = nbuckets;
     st.keys = k1.as<uint64_t>();
     st.idx = i1.as<uint32_t>();
     st.cursor = ctl.as<uint32_t>();
@@ -1043,12 +1151,13 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     ia.sent_cap = sent_cap;
     ia.sent_total = (uint32_t*)(ctx->dscratch + 1);
     ia.inserted = (unsigned long long*)ctx->dscratch;
+    ia.fail = (uint32_t*)(ctx->dscratch + 2);
     const size_t img_bytes = (size_t)m * TSQ_BUCKET * 12;
     if (e == hipSuccess && img_bytes > 48 * 1024)
         e = hipFuncSetAttribute((const void*)k_build_images<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
     if (e == hipSuccess) {
         const int64_t ntiles = (nb + T1 - 1) / T1;
-        hipLaunchKernelGGL((k_radix_partition<NT, K1, 4, 0, true>), dim3((unsigned)std::min<int64_t>(ntiles, ctx->num_cus)), dim3(NT), 0, ctx->stream, src, st);
+        hipLaunchKernelGGL((k_radix_partition<NT, K1, 4, 0, true, true>), dim3((unsigned)std::min<int64_t>(ntiles, ctx->num_cus)), dim3(NT), 0, ctx->stream, src, st);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
@@ -1074,6 +1183,7 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     a.sent_cap = sent_cap;
     a.sent_total = (uint32_t*)(ctx->dscratch + 1);
     a.inserted = (unsigned long long*)ctx->dscratch;
+    a.fail = (uint32_t*)(ctx->dscratch + 2);
     for (int pass = 0; pass < 2; pass++) {
         a.nrows = pass == 0 ? n_ovf1 : n_rows;
         a.row_list = pass == 0 ? st.ovf_idx : sub.ovf_rows;
@@ -1227,33 +1337,35 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
     TSQ_TRY(build_flush(j));
     const int64_t nb = j->bcols[0].rows;
     j->st.build_rows = nb;
-    // size: load factor <= 0.5 over 8-slot buckets (est_build_rows is only a hint, hash_table.go:84-96)
-    uint64_t nbuckets = (uint64_t)((nb + 3) / 4);
-    if (nbuckets < 16) nbuckets = 16;
     uint32_t sent_cap = 1024;
     TSQ_TRY(j->sent.reserve(ctx, h, sent_cap * 4));
-    // dscratch[0] = inserted (u64), dscratch[1] low = sent_total (u32)
-    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch, 0, 16, ctx->stream));
     j->sent_count = 0;
+    j->build_inserted = 0;
+    bool sliced = nb >= 32768 && !j->never_match && j->radix_mode != TSQ_RADIX_OFF;
     bool part_done = false;
-    if (nb > 0 && build_partitioned_eligible(j, nb)) {
-        TSQ_TRY(build_partitioned(j, nb, sent_cap, &part_done));  // sets j->nbuckets (a multiple of the slice count); records ev[0]
-        if (part_done) {
-            TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
-            j->have_build_ev = true;
-            nbuckets = j->nbuckets;
+    for (int attempt = 0;; attempt++) {
+        table_geometry(j, nb, sliced);
+        const uint64_t nbuckets = j->nbuckets;
+        if (nbuckets >> 32) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "build side too large for one table: partition across GPUs first");
+        // dscratch[0] = inserted (u64), dscratch[1] low = sent_total (u32), dscratch[2] low = fail flag (u32)
+        TSQ_HIP(h, hipMemsetAsync(ctx->dscratch, 0, 24, ctx->stream));
+        part_done = false;
+        if (nb > 0 && build_partitioned_eligible(j, nb)) {
+            TSQ_TRY(build_partitioned(j, nb, sent_cap, &part_done));  // records ev[0]
+            if (part_done) {
+                TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
+                j->have_build_ev = true;
+            }
         }
-    }
-    if (!part_done) {
-        j->nbuckets = nbuckets;
-        TSQ_TRY(j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8));
-        TSQ_TRY(j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4));
-        TSQ_HIP(h, hipMemsetAsync(j->tkeys.p, 0x80, nbuckets * TSQ_BUCKET * 8, ctx->stream));
-    }
-    j->st.table_bytes = (int64_t)(nbuckets * TSQ_BUCKET * 12);
-    j->st.table_buckets = (int64_t)nbuckets;
-    j->st.build_partitioned = part_done ? 1 : 0;
-    if (nb > 0 && !j->never_match) {
+        if (!part_done) {
+            TSQ_TRY(j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8));
+            TSQ_TRY(j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4));
+            TSQ_HIP(h, hipMemsetAsync(j->tkeys.p, 0x80, nbuckets * TSQ_BUCKET * 8, ctx->stream));
+        }
+        if (nb == 0 || j->never_match) {
+            TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+            break;
+        }
         BuildArgs a;
         memset(&a, 0, sizeof a);
         tsq_fill_colset(a.b, j->bcols);
@@ -1265,6 +1377,7 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
         a.sent_cap = sent_cap;
         a.sent_total = (uint32_t*)(ctx->dscratch + 1);
         a.inserted = (unsigned long long*)ctx->dscratch;
+        a.fail = (uint32_t*)(ctx->dscratch + 2);
         if (!part_done) {
             TSQ_HIP(h, hipEventRecord(j->ev[0], ctx->stream));
             if (j->multi) TSQ_TRY(launch_build<true>(j, a));
@@ -1272,11 +1385,24 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
             TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
             j->have_build_ev = true;
         }
-        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, ctx->dscratch, 16, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, ctx->dscratch, 24, hipMemcpyDeviceToHost, ctx->stream));
         TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        j->unique = (ctx->pinned[2] >> 32) == 0;
+        if ((uint32_t)ctx->pinned[2]) {
+            // A slice could not take all of its rows (skewed / heavily duplicated keys): once more as one slice at load
+            // factor 0.5.  If even that walks more than TSQ_MAX_WALK buckets for one row, a key has tens of thousands of
+            // duplicates and every insert would scan its whole run: the Go operator (O(1) per row, hash_table.go:247-256)
+            // is the better executor for that input.
+            if (sliced && attempt == 0) {
+                sliced = false;
+                j->st.build_slice_retries++;
+                continue;
+            }
+            return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "build key duplicated too heavily for the open-addressing table: fall back to the Go operator");
+        }
         j->build_inserted = (int64_t)ctx->pinned[0];
         uint32_t sent_total = (uint32_t)ctx->pinned[1];
-        if (sent_total > sent_cap) {  // rare: many rows carry the sentinel key word — collect them all
+        if (sent_total > sent_cap) {  // rare: many rows carry the sentinel table word — collect them all
             TSQ_TRY(j->sent.reserve(ctx, h, (size_t)sent_total * 4));
             TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 1, 0, 8, ctx->stream));
             a.sent_rows = j->sent.as<uint32_t>();
@@ -1288,9 +1414,12 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
             TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
         }
         j->sent_count = sent_total;
-    } else {
-        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        break;
     }
+    j->st.table_bytes = (int64_t)(j->nbuckets * TSQ_BUCKET * 12);
+    j->st.table_buckets = (int64_t)j->nbuckets;
+    j->st.table_slice_bits = (int32_t)j->tb;
+    j->st.build_partitioned = part_done ? 1 : 0;
     j->st.build_rows_inserted = j->build_inserted;
     j->build_done = true;
     j->stage.release();  // staging is re-initialised for the probe schema

@@ -1,0 +1,261 @@
+// tsq_ldsprobe.h — probe of a partitioned key store against LDS COPIES of the join table's slices
+// (device code; included by tsq_join.hip).
+//
+// Why: a probe that reads the table through the L2 — even partition by partition, with the slice resident in
+// one XCD's L2 (k_radix_probe_count, tsq_radix.h) — pays one 64-byte L2 request per probe key: 1e8 requests at
+// the 210-260 G/s an L2-resident table delivers are 0.4 ms before anything else happens, and the misses that
+// bring the slice in arrive as random 64-byte lines at 55 G/s instead of as a stream.  Here the table is read
+// from HBM exactly once, with 16-byte coalesced loads, into LDS, and every compare runs against LDS:
+//
+//   ticket (XCD vx)  ->  (partition p = 8 pi + vx, sub-slice s)      ordered queue per XCD, as in tsq_radix.h
+//   image            =   nf consecutive table slices (tsq_jointable.h: self-contained linear-probing tables of
+//                        bs buckets) = nf * bs * 64 bytes <= 128 KB, copied verbatim
+//   keys             =   ALL table words of partition p (8 XCC regions of the HASHED store); a word whose slice
+//                        lies outside the image belongs to one of the S - 1 sibling tickets and is dropped
+//
+// The S workgroups that hold the sub-slices of one partition draw consecutive tickets of the same XCD, so the
+// partition's keys come from HBM once and from that XCD's L2 S - 1 times.  The kernel is bound by vector-instruction
+// issue, not by memory (SQ counters: VALU busy 67 %, LDS 32 %), so the work per key is organised around that:
+//   * words that pass the slice test are compacted through a per-wave LDS ring and probed 64 at a time;
+//   * a probe round looks at ONE bucket per lane; a lane whose bucket is full (the chain may go on) puts its word back
+//     into the ring with a hop count instead of walking on while 63 lanes wait — rounds = bucket visits / 64, not the
+//     longest chain of every 64 keys (~10 buckets at load factor 0.75: 2.2 ms per 1e8 keys, 2/3 of it in that loop);
+//   * matches are counted per lane on the vector unit (the CU's ONE scalar unit, shared by its 16 waves, was as busy as
+//     the four SIMDs when the eight compare masks were popcounted and added there);
+//   * the four 16-byte pieces of a bucket are read in an order rotated by the lane number: with the same piece order in
+//     every lane the 16 lanes of an LDS access group would only ever hit 4 of the 16 four-bank columns.
+// The image of the NEXT ticket is in flight (16-byte registers) while the keys of the current one are probed.
+//
+// Replaces (reference): join2Chunk + hashRowContainer.GetMatchedRows (executor/join.go:343-360,
+// hash_table.go:110-134) for the COUNT(*) shape; same joined-row count whichever route a key takes (a probe row
+// meets exactly the build rows with an equal key word, util/codec/codec.go:363-382).
+// Algorithmic bytes: 8 B key + one 16 B slot per probe row; real traffic per probe row:
+// 8 B (partitioned word) + table bytes / probe rows.
+#ifndef TSQ_LDSPROBE_H
+#define TSQ_LDSPROBE_H
+
+#include "tsq_radix.h"
+
+#define TSQ_LDS_IMAGE_MAX (128 * 1024)
+#define TSQ_LDS_RING 128  // entries per wave ring: <= 63 left over + <= 64 new per step / continuations per round
+#define TSQ_LDS_RING_BYTES (TSQ_LDS_RING * 10)  // 8-byte word + 2-byte hop count
+
+typedef unsigned long long tsq_u64x2 __attribute__((ext_vector_type(2)));
+// 16-byte streaming load (read once: do not keep the line in L1 / prefer eviction in L2)
+__device__ __forceinline__ ulonglong2 nt_load16(const void* p) {
+    const tsq_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const tsq_u64x2*>(p));
+    return make_ulonglong2(v.x, v.y);
+}
+
+// Software-pipelined streaming loads.  The compiler's s_waitcnt insertion gives up on a rotating set of in-flight loads
+// inside a loop with inner loops (it waits for vmcnt(0) at the loop header: every load then pays its full latency), so
+// the chunk loads are issued and waited for by hand: results return in order, `younger` loads may stay in flight.
+// The wait takes the destination as an in/out operand so that no use of it can be scheduled above the wait.  Waits the
+// compiler inserts for ITS loads stay correct: it can only under-count what is in flight, i.e. wait for longer.
+__device__ __forceinline__ void async_nt_load16(tsq_u64x2& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int YOUNGER>
+__device__ __forceinline__ void async_wait(tsq_u64x2& dst) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dst) : "n"(YOUNGER) : "memory");
+}
+
+struct LdsProbeArgs {
+    RadixStore st;   // HASHED store, P = 2^st.bits >= 8 partitions
+    JoinTable t;     // t.tb >= st.bits
+    uint32_t S;      // sub-slices (tickets) per partition
+    uint32_t nf;     // table slices per image (the last sub-slice of a partition may hold fewer)
+    uint32_t unique; // the build saw no two equal table words: a probe word that has found its slot is done
+    unsigned long long* counters;  // [0] += joined rows
+    unsigned long long* prof;      // PROF kernels: [0..7] += shader cycles per phase, summed over waves (see k_lds_probe_count)
+};
+
+// Vector-memory results return in order and s_waitcnt counts them, so every wave issues a FIXED sequence of loads: a load
+// that has nothing to fetch (past the end of a region, past the last chunk) is still issued, on a clamped address, and its
+// result is ignored.  With loads under a branch the compiler can only wait for "everything" (vmcnt(0)), which serialises
+// the prefetch distance away: 2.2 ms per 1e8 keys instead of 0.4.
+// PROF: per-wave shader-cycle sums (s_memtime) -> a.prof: [0] image store + barrier A, [1] waits for chunk loads, [2] slice
+// test + ring, [3] bucket compares, [4] drain + barrier B, [5] whole ticket loop, [6] probe calls, [7] bucket reads.
+template <int NT, bool PROF = false>
+__global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
+    constexpr int NW = NT / 64;
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> unsigned long long { return PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
+    const unsigned long long t_begin = now();
+    constexpr int IMG_R = TSQ_LDS_IMAGE_MAX / 16 / NT;  // 16-byte units of an image per thread
+    constexpr int D = 4;                                // chunk loads in flight per wave
+    static_assert(NW % 8 == 0, "NW / 8 waves per XCC region");
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ uint32_t s_len[8];
+    __shared__ uint32_t s_tk[2];
+    __shared__ unsigned long long s_total;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t vx = blockIdx.x & 7u;
+    const uint32_t P = 1u << a.st.bits, NP = P >> 3;
+    const uint32_t tb = a.t.tb, bs = a.t.bs, sh = 64u - tb;
+    const uint32_t fpp = 1u << (tb - a.st.bits);
+    const uint32_t ntk = NP * a.S;
+    const uint32_t img_words = a.nf * bs * TSQ_BUCKET;
+    uint64_t* s_img = reinterpret_cast<uint64_t*>(s_dyn);
+    uint64_t* s_ring = s_img + img_words + (size_t)wave * TSQ_LDS_RING;                                      // words waiting for a probe round
+    uint16_t* s_hop = reinterpret_cast<uint16_t*>(s_img + img_words + (size_t)NW * TSQ_LDS_RING) + (size_t)wave * TSQ_LDS_RING;  // ... and how far along their chain
+    auto take = [&]() -> uint32_t {
+        return (uint32_t)__hip_atomic_fetch_add(&a.st.queue[vx * TSQ_RADIX_QSTRIDE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    uint32_t pend = 0;
+    if (tid == 0) {
+        s_total = 0;
+        s_tk[0] = take();
+        s_tk[1] = take();
+        pend = take();
+    }
+    __syncthreads();
+    // ticket -> first table slice, slices in the image
+    auto first_slice = [&](uint32_t tk, uint32_t& nfi) -> uint32_t {
+        const uint32_t pi = tk / a.S, sub = tk - pi * a.S;
+        const uint32_t rest = fpp - sub * a.nf;
+        nfi = rest < a.nf ? rest : a.nf;
+        return (pi * 8u + vx) * fpp + sub * a.nf;
+    };
+    ulonglong2 pre[IMG_R];
+    auto image_load = [&](uint32_t tk) {  // a ticket past the end loads the first image again (ignored)
+        uint32_t nfi;
+        const uint32_t f0 = first_slice(tk < ntk ? tk : 0u, nfi);
+        const uint32_t n16 = nfi * bs * (TSQ_BUCKET / 2);
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a.t.keys + (size_t)f0 * bs * TSQ_BUCKET);
+#pragma unroll
+        for (int j = 0; j < IMG_R; j++) {
+            const uint32_t i = (uint32_t)j * NT + tid;
+            pre[j] = nt_load16(src + (i < n16 ? i : 0u));
+        }
+    };
+    uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane(s_tk[0]);
+    image_load(tk);
+    uint32_t cnt = 0;  // joined rows seen by this lane (< 2^32: a lane probes a few thousand words, a word has < 2^14 matches)
+    for (uint32_t it = 0; tk < ntk; it++) {
+        const unsigned long long t0 = now();
+        uint32_t nfi;
+        const uint32_t f0 = first_slice(tk, nfi);
+        const uint32_t p = (tk / a.S) * 8u + vx;
+        {
+            const uint32_t n16 = nfi * bs * (TSQ_BUCKET / 2);
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(s_img);
+#pragma unroll
+            for (int j = 0; j < IMG_R; j++) {
+                const uint32_t i = (uint32_t)j * NT + tid;
+                if (i < n16) dst[i] = pre[j];
+            }
+        }
+        if (tid < 8) s_len[tid] = radix_region_len(a.st, P, p, tid);
+        __syncthreads();  // A: image and region lengths are in LDS
+        if (PROF) pf[0] += now() - t0;
+        const uint32_t tkn = (uint32_t)__builtin_amdgcn_readfirstlane(s_tk[(it + 1) & 1u]);
+        // Every wave streams ONE region: wave w reads chunks (128 words, two per lane) w / 8, w / 8 + NW / 8, ... of region w % 8.
+        // (Enumerating the chunks of all eight regions in one sequence balances skewed regions better, but cost ~35 scalar
+        // instructions per chunk for the region lookup; the scalar unit is shared by all waves of the CU.)
+        const uint32_t rg = wave & 7u, rlen = (uint32_t)__builtin_amdgcn_readfirstlane(s_len[rg]);
+        const uint32_t nck = (rlen + 127u) / 128u;
+        const uint64_t* rbase = a.st.keys + ((size_t)p * 8u + rg) * a.st.cap;
+        auto chunk_load = [&](uint32_t k, tsq_u64x2& v, uint32_t& nv) {
+            const uint32_t off = k * 128u + lane * 2u;
+            nv = off + 1u < rlen ? 2u : (off < rlen ? 1u : 0u);  // a chunk past the end loads the region's first line (ignored)
+            async_nt_load16(v, rbase + (off < rlen ? off : 0u));
+        };
+        tsq_u64x2 v[D];
+        uint32_t nv[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) chunk_load(wave / 8u + (uint32_t)d * (NW / 8), v[d], nv[d]);
+        image_load(tkn);          // in flight while this ticket's keys are probed
+        uint32_t qh = 0, qt = 0;  // ring head / tail (wave uniform)
+        // compaction append of (word, hop) for the lanes in `on`
+        auto push = [&](bool on, uint64_t w, uint32_t hop) {
+            const uint64_t m = __ballot(on);
+            if (m) {
+                if (on) {
+                    const uint32_t pos = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (TSQ_LDS_RING - 1);
+                    s_ring[pos] = w;
+                    s_hop[pos] = (uint16_t)hop;
+                }
+                qt += (uint32_t)__popcll(m);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        };
+        // one bucket per lane for the n (<= 64) oldest ring entries
+        auto probe_round = [&](uint32_t n) {
+            const unsigned long long tp = now();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t pos = (qh + lane) & (TSQ_LDS_RING - 1);
+            qh += n;
+            bool go_on = false;
+            uint64_t x = 0;
+            uint32_t hop = 0;
+            if (lane < n) {  // (the compares below then leave the bits of idle lanes clear: no mask arithmetic)
+                x = s_ring[pos];
+                hop = s_hop[pos];
+                if (x == TSQ_EMPTY_KEY) {
+                    cnt += a.t.sent_count;  // the sentinel word matches the side list only
+                } else {
+                    uint32_t lb = jt_local(tb, bs, x) + hop;
+                    lb = lb >= bs ? lb - bs : lb;
+                    const uint64_t* bk = s_img + ((size_t)((uint32_t)(x >> sh) - f0) * bs + lb) * TSQ_BUCKET;
+                    const ulonglong2* b = reinterpret_cast<const ulonglong2*>(bk);
+                    const ulonglong2 q0 = b[lane & 3u], q1 = b[(lane + 1u) & 3u], q2 = b[(lane + 2u) & 3u], q3 = b[(lane + 3u) & 3u];
+                    const uint64_t last = bk[TSQ_BUCKET - 1];  // slots are claimed front to back: the bucket is full iff its LAST slot is taken
+                    const uint32_t c = (uint32_t)(q0.x == x) + (uint32_t)(q0.y == x) + (uint32_t)(q1.x == x) + (uint32_t)(q1.y == x) +
+                                       (uint32_t)(q2.x == x) + (uint32_t)(q2.y == x) + (uint32_t)(q3.x == x) + (uint32_t)(q3.y == x);
+                    cnt += c;
+                    go_on = last != TSQ_EMPTY_KEY && !(a.unique && c) && hop + 1u < bs;
+                }
+            }
+            push(go_on, x, hop + 1u);
+            if (PROF) {
+                pf[3] += now() - tp;
+                pf[6]++;
+            }
+        };
+        auto step = [&](uint64_t w, bool valid) {
+            push(valid && ((uint32_t)(w >> sh) - f0) < nfi, w, 0u);
+            while (qt - qh >= 64u) probe_round(64u);
+        };
+        for (uint32_t k = wave / 8u; k < nck; k += D * (NW / 8)) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const unsigned long long tw = now();
+                async_wait<D - 1>(v[d]);
+                const unsigned long long ts = now();
+                step(v[d].x, nv[d] >= 1);
+                step(v[d].y, nv[d] >= 2);
+                if (PROF) {
+                    pf[1] += ts - tw;
+                    pf[2] += now() - ts;
+                }
+                chunk_load(k + (uint32_t)(d + D) * (NW / 8), v[d], nv[d]);  // reload only after use: no register copy, D - 1 chunks ahead
+            }
+        }
+        const unsigned long long td = now();
+        // D clamped loads of the last round are still in flight: their registers must stay allocated until they have landed
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+        static_assert(D == 4, "drain lists v[0..3]");
+        while (qt != qh) probe_round(qt - qh < 64u ? qt - qh : 64u);  // the last, partial rounds (and their continuations)
+        __syncthreads();  // B: nobody reads the image or s_tk[(it + 1) & 1] any more
+        if (PROF) pf[4] += now() - td;
+        if (tid == 0) {   // ticket of iteration it + 2 (its atomic has been in flight since the previous iteration)
+            s_tk[it & 1u] = pend;
+            pend = take();
+        }
+        tk = tkn;
+    }
+    if (PROF && lane == 0) {
+        pf[5] = now() - t_begin;
+        pf[2] -= pf[3];
+#pragma unroll
+        for (int i = 0; i < 8; i++) atomicAdd(&a.prof[i], pf[i]);
+    }
+    const uint64_t ws = wave_sum_u64(cnt);
+    if (lane == 0 && ws) atomicAdd(&s_total, (unsigned long long)ws);
+    __syncthreads();
+    if (tid == 0 && s_total) atomicAdd(&a.counters[0], s_total);  // one device atomic per workgroup
+}
+
+#endif

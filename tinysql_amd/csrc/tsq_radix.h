@@ -17,8 +17,10 @@
 // partition p is appended to only by workgroups running on XCD r (HW_REG_XCC_ID), so the partially
 // written line at each region's frontier stays in that XCD's L2 until it is complete (write combining
 // in L2; 2^bits x 128 B of frontier per XCD).  Space is claimed with one returning atomic per
-// (tile, partition): 27 G atomics/s measured, which is what bounds the fan-out (2^10: 6.3 M atomics per
-// 1e8 keys = 0.36 ms per pass; 2^11: 0.59 ms).  Block-private regions without atomics were measured
+// (tile, PAIR of partitions): the cursors of region r are one row cursor[r * P + p], so two neighbouring
+// partitions are one 64-bit word and one 64-bit atomic add claims both runs (a cursor never reaches 2^32,
+// so the low half cannot carry into the high half).  The atomic rate (27 G/s measured) is what bounds the
+// fan-out: with one 32-bit atomic per (tile, partition) 2^10 cost 0.36 ms per 1e8 keys and 2^11 0.59 ms.  Block-private regions without atomics were measured
 // slower (0.54-0.65 ms): 8 MB of partially written lines per XCD do not survive in a 4 MiB L2.
 // A run that does not fit its region goes to the overflow list (skewed keys); the overflow list is
 // probed by a plain grid-stride kernel, so the result is exact for every key distribution.
@@ -38,8 +40,8 @@ struct RadixStore {
     uint64_t* pay[TSQ_RADIX_MAXV];      // [P * R * cap] payload cells travelling with the key (optional)
     uint64_t* ovf_pay[TSQ_RADIX_MAXV];  // payload of the overflow list
     uint32_t* idx;         // [P * R * cap] source row ids (optional)
-    uint32_t* cursor;      // [P * R] slots claimed per region (may exceed cap after an overflow)
-    uint32_t* valid_end;   // [P * R] first slot that was NOT written (0xffffffff: none)
+    uint32_t* cursor;      // [R][P] slots claimed per region (may exceed cap after an overflow); 8-byte aligned
+    uint32_t* valid_end;   // [R][P] first slot that was NOT written (0xffffffff: none)
     uint64_t* ovf_keys;    // overflow list
     uint32_t* ovf_idx;
     uint32_t* ovf_count;
@@ -86,6 +88,15 @@ __device__ __forceinline__ uint32_t tsq_xcc_id() {
     return x & 7u;
 }
 __device__ __forceinline__ uint32_t tsq_radix_part(uint64_t kw, uint32_t shift) { return (uint32_t)(tsq_mix64(kw) >> shift); }
+// index of (partition p, region r) in cursor[] / valid_end[]; the DATA of the region sits at (p * R + r) * cap
+__device__ __forceinline__ uint32_t radix_ctl(const RadixStore& st, uint32_t P, uint32_t p, uint32_t r) { return r * P + p; }
+__device__ __forceinline__ uint32_t radix_region_len(const RadixStore& st, uint32_t P, uint32_t p, uint32_t r) {
+    const uint32_t c = radix_ctl(st, P, p, r);
+    uint32_t len = st.cursor[c];
+    const uint32_t ve = st.valid_end[c];
+    len = len < ve ? len : ve;
+    return len < st.cap ? len : st.cap;
+}
 
 // exclusive prefix sum over the NT threads of a workgroup (contains one __syncthreads)
 template <int NT>
@@ -111,7 +122,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wsum
 // with consecutive lanes on consecutive addresses.
 // Algorithmic bytes: 8 B read + 8 B written per key (+8 B each way per payload column, +4 B with row ids).
 // MINW = waves per SIMD the register allocation must leave room for (blocks/CU * NT / 256).
-template <int NT, int K, int MINW, int V, bool WITH_IDX>
+// HASHED: the store receives TABLE WORDS w = mix64(key word) (tsq_jointable.h) instead of key words, and the
+// partition is the top bits of w — what the join paths use (the consumer never hashes again).
+template <int NT, int K, int MINW, int V, bool WITH_IDX, bool HASHED = false>
 __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, RadixStore st) {
     constexpr int T = NT * K;
     static_assert(V >= 0 && V <= TSQ_RADIX_MAXV, "payload columns");
@@ -130,7 +143,10 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
     if (tid == 0) s_flag = 0;
     const int64_t ntiles = (src.nrows + T - 1) / T;
-    auto part_of = [&](uint64_t kw) -> uint32_t { return st.rank_parts ? tsq_key_rank(kw, st.rank_parts) : tsq_radix_part(kw, shift); };
+    auto part_of = [&](uint64_t kw) -> uint32_t {
+        if (HASHED) return (uint32_t)(kw >> shift);
+        return st.rank_parts ? tsq_key_rank(kw, st.rank_parts) : tsq_radix_part(kw, shift);
+    };
     bool wide = src.nulls == nullptr && src.type != TSQ_F32 && !src.skip_high && !(src.key_kind == 1 && src.type == TSQ_F64);
 #pragma unroll
     for (int v = 0; v < V; v++) wide = wide && src.vnulls[v] == nullptr && src.vtype[v] != TSQ_F32;
@@ -148,8 +164,8 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
 #pragma unroll
             for (int j = 0; j < K / 2; j++) {
                 const ulonglong2 v = s2[j * NT + tid];
-                k[2 * j] = v.x;
-                k[2 * j + 1] = v.y;
+                k[2 * j] = HASHED ? tsq_table_word(v.x) : v.x;
+                k[2 * j + 1] = HASHED ? tsq_table_word(v.y) : v.y;
             }
 #pragma unroll
             for (int vv = 0; vv < V; vv++) {
@@ -176,6 +192,7 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                     if (!isnull) {
                         k[j] = radix_src_key(src, base + pos);
                         if (!(src.skip_high && (k[j] >> 63))) pr[j] = 0;
+                        if (HASHED) k[j] = tsq_table_word(k[j]);
 #pragma unroll
                         for (int vv = 0; vv < V; vv++)
                             pay[vv][j] = src.vtype[vv] == TSQ_F32 ? (uint64_t)((const uint32_t*)src.vdata[vv])[base + pos]
@@ -206,6 +223,28 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
         }
         uint32_t total;
         uint32_t run = block_excl_scan<NT>(sum, s_wsum, &total);
+        // claim the runs: one 64-bit atomic per pair of neighbouring partitions (per is 1 or even)
+        uint32_t g[MAXPER];
+        if (per >= 2 && !st.rank_parts) {
+#pragma unroll
+            for (int q = 0; q < MAXPER; q += 2) {
+                g[q] = 0;
+                if (q + 1 < MAXPER) g[q + 1] = 0;
+                if ((uint32_t)q < per && p0 + q < P && (c[q] | c[q + 1 < MAXPER ? q + 1 : q])) {
+                    const uint32_t c1 = q + 1 < MAXPER ? c[q + 1] : 0u;
+                    unsigned long long* cw = reinterpret_cast<unsigned long long*>(st.cursor + radix_ctl(st, P, p0 + q, r));
+                    const unsigned long long old = atomicAdd(cw, (unsigned long long)c[q] | ((unsigned long long)c1 << 32));
+                    g[q] = (uint32_t)old;
+                    if (q + 1 < MAXPER) g[q + 1] = (uint32_t)(old >> 32);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXPER; q++) {
+                g[q] = 0;
+                if ((uint32_t)q < per && p0 + q < P && c[q]) g[q] = atomicAdd(&st.cursor[radix_ctl(st, P, p0 + q, r)], c[q]);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < MAXPER; q++) {
             if ((uint32_t)q < per && p0 + q < P) {
@@ -214,12 +253,11 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                 uint32_t flag = 0;
                 if (cnt) {
                     const uint32_t region = p * st.R + r;
-                    const uint32_t g = atomicAdd(&st.cursor[region], cnt);
-                    if (!st.region_base && g + cnt > st.cap) {
+                    if (!st.region_base && g[q] + cnt > st.cap) {
                         flag = 1;
-                        atomicMin(&st.valid_end[region], g);
+                        atomicMin(&st.valid_end[radix_ctl(st, P, p, r)], g[q]);
                     }
-                    s_delta[p] = (st.region_base ? st.region_base[region] : region * st.cap) + g - offs;
+                    s_delta[p] = (st.region_base ? st.region_base[region] : region * st.cap) + g[q] - offs;
                     if (flag) s_flag = 1;
                 }
                 s_hist[p] = offs | (flag << 31);
@@ -273,36 +311,30 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
 
 // ------------------------------------------------------------------ partition-at-a-time probe
 struct RadixProbeArgs {
-    RadixStore st;
+    RadixStore st;  // HASHED store: keys[] holds table words
     JoinTable t;
-    uint32_t pf_lead;
     unsigned long long* counters;  // [0] += joined rows
 };
 
-// mulhi64(h, nb) for nb < 2^32 in two multiplies: (h * nb) >> 64 == ((h >> 32) * nb + ((h & 0xffffffff) * nb >> 32)) >> 32
-__device__ __forceinline__ uint64_t radix_bucket(uint64_t h, uint64_t nb) {
-    if (nb >> 32) return tsq_mulhi64(h, nb);
-    const uint32_t n32 = (uint32_t)nb;
-    const uint64_t q = (uint64_t)__umulhi((uint32_t)h, n32);
-    return ((h >> 32) * (uint64_t)n32 + q) >> 32;
-}
-
-// matches of kw in the buckets FOLLOWING bkt (the home bucket was full)
-static __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, uint64_t kw, uint64_t bkt) {
+// matches of table word w in the buckets FOLLOWING global bucket bkt (the home bucket was full); the walk wraps inside the slice
+static __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, uint64_t w, uint64_t bkt) {
     uint32_t c = 0;
-    for (;;) {
-        bkt = (bkt + 1 == t.nbuckets) ? 0 : bkt + 1;
-        const ulonglong2* line = reinterpret_cast<const ulonglong2*>(t.keys + bkt * TSQ_BUCKET);
+    const uint64_t base = (uint64_t)jt_slice(t.tb, w) * t.bs;
+    uint32_t lb = (uint32_t)(bkt - base);
+    for (uint32_t steps = 1; steps < t.bs; steps++) {
+        lb = (lb + 1 == t.bs) ? 0 : lb + 1;
+        const ulonglong2* line = reinterpret_cast<const ulonglong2*>(t.keys + (base + lb) * TSQ_BUCKET);
         const ulonglong2 a = line[0], b = line[1], cc = line[2], d = line[3];
         const uint64_t k[8] = {a.x, a.y, b.x, b.y, cc.x, cc.y, d.x, d.y};
         bool has_empty = false;
 #pragma unroll
         for (int s = 0; s < TSQ_BUCKET; s++) {
-            c += k[s] == kw ? 1u : 0u;
+            c += k[s] == w ? 1u : 0u;
             has_empty |= k[s] == TSQ_EMPTY_KEY;
         }
         if (has_empty) return c;
     }
+    return c;
 }
 
 // K3r — COUNT(*) probe over a partitioned key store.
@@ -323,12 +355,7 @@ static __device__ __noinline__ uint32_t radix_probe_spill(const JoinTable& t, ui
 // resolved later by full waves (deferred spill) instead of stalling its wave on a dependent load.
 // Algorithmic bytes: 8 B key + one 16 B slot per probe row.
 #define TSQ_RADIX_QSTRIDE 64  // queue heads 512 B apart: each on its own L2 channel
-// PFB > 0: the first PFB workgroups of every virtual XCD are LOADERS: they never probe, they stream the
-// table slices of the partitions just ahead of the consumers' ticket head into the XCD's L2 (one 4-byte
-// touch per 128-byte line, many in flight) so that the consumers' bucket reads are L2 hits instead of
-// hits on a pending miss.  (The same touches issued by the consumer waves themselves made them slower:
-// vector-memory results return in order, so every bucket read then waited for a prefetch's HBM latency.)
-template <int U, int PFB, int MINW = 6>
+template <int U, int MINW = 6>
 __global__ void __launch_bounds__(256, MINW) k_radix_probe_count(RadixProbeArgs a) {
     constexpr uint32_t CH = 256 * U;
     constexpr uint32_t END = 0xffffffffu;
@@ -349,13 +376,7 @@ __global__ void __launch_bounds__(256, MINW) k_radix_probe_count(RadixProbeArgs 
         s_spn = 0;
         s_total = 0;
     }
-    for (uint32_t i = tid; i < NP * 8; i += 256) {
-        const uint32_t region = ((i >> 3) * 8 + vx) * 8 + (i & 7);
-        uint32_t len = a.st.cursor[region];
-        const uint32_t ve = a.st.valid_end[region];
-        len = len < ve ? len : ve;
-        s_len[i] = len < cap ? len : cap;
-    }
+    for (uint32_t i = tid; i < NP * 8; i += 256) s_len[i] = radix_region_len(a.st, P, (i >> 3) * 8 + vx, i & 7);
     __syncthreads();
     {
         uint32_t nch = 0;
@@ -368,41 +389,6 @@ __global__ void __launch_bounds__(256, MINW) k_radix_probe_count(RadixProbeArgs 
     }
     __syncthreads();
     const uint32_t nchunks = s_cstart[NP];
-    if (PFB > 0 && (blockIdx.x >> 3) < (uint32_t)PFB) {
-        const uint32_t lj = blockIdx.x >> 3;      // loader index inside the XCD
-        const uint32_t shift = 64 - a.st.bits;
-        const uint32_t lead = a.pf_lead;          // partitions the loaders may run ahead of the ticket head
-        uint32_t next = 0, acc = 0, prev = 0;
-        for (int spin = 0; next < NP && spin < (1 << 22); spin++) {
-            // partition of the ticket head = where the consumers are
-            const uint32_t t = (uint32_t)__hip_atomic_load(&a.st.queue[vx * TSQ_RADIX_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t >= nchunks) break;
-            uint32_t lo = 0, hi = NP;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_cstart[mid] <= t) lo = mid;
-                else hi = mid;
-            }
-            if (next < lo) next = lo;             // never fetch what the consumers have already left behind
-            if (next > lo + lead) {
-                __builtin_amdgcn_s_sleep(16);
-                continue;
-            }
-            const uint64_t pp = (uint64_t)next * 8 + vx;
-            const uint64_t b0 = tsq_mulhi64(pp << shift, a.t.nbuckets);
-            const uint64_t b1 = pp + 1 == P ? a.t.nbuckets : tsq_mulhi64((pp + 1) << shift, a.t.nbuckets);
-            const uint64_t nlines = ((b1 - b0) * 64 + 127) / 128;
-            const uint64_t l0 = nlines * lj / PFB, l1 = nlines * (lj + 1) / PFB;
-            const char* pb = reinterpret_cast<const char*>(a.t.keys + b0 * TSQ_BUCKET);
-            for (uint64_t l = l0 + tid; l < l1; l += 256) {
-                acc ^= prev;
-                prev = *reinterpret_cast<const uint32_t*>(pb + l * 128);
-            }
-            next++;
-        }
-        if ((acc ^ prev) == 0x9e3779b9u) atomicAdd(&a.counters[7], 1ull);  // keeps the touches alive
-        return;
-    }
     auto take = [&]() -> uint32_t {
         return (uint32_t)__hip_atomic_fetch_add(&a.st.queue[vx * TSQ_RADIX_QSTRIDE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -454,7 +440,7 @@ __global__ void __launch_bounds__(256, MINW) k_radix_probe_count(RadixProbeArgs 
 #pragma unroll
         for (int u = 0; u < U; u++) {
             k[u] = kn[u];
-            bkt[u] = (uint32_t)(u * 256) + tid < n ? radix_bucket(tsq_mix64(k[u]), a.t.nbuckets) : 0;
+            bkt[u] = (uint32_t)(u * 256) + tid < n ? (uint64_t)jt_slice(a.t.tb, k[u]) * a.t.bs + jt_local(a.t.tb, a.t.bs, k[u]) : 0;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const uint64_t bq = __shfl(bkt[u], g * 16 + (lane >> 2), 64);
@@ -534,9 +520,9 @@ static __global__ void __launch_bounds__(256) k_radix_probe_ovf(RadixProbeArgs a
     n = n < a.st.ovf_cap ? n : a.st.ovf_cap;
     uint64_t cnt = 0;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint64_t kw = a.st.ovf_keys[i];
-        if (kw == TSQ_EMPTY_KEY) cnt += a.t.sent_count;
-        else for_each_slot(a.t, kw, [&](uint64_t) { cnt++; });
+        const uint64_t w = a.st.ovf_keys[i];  // table words (HASHED store)
+        if (w == TSQ_EMPTY_KEY) cnt += a.t.sent_count;
+        else for_each_slot_w(a.t, w, [&](uint64_t) { cnt++; });
     }
     cnt = wave_sum_u64(cnt);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&a.counters[0], (unsigned long long)cnt);
