@@ -25,6 +25,11 @@
 //   * the four 16-byte pieces of a bucket are read in an order rotated by the lane number: with the same piece order in
 //     every lane the 16 lanes of an LDS access group would only ever hit 4 of the 16 four-bank columns.
 // The image of the NEXT ticket is in flight (16-byte registers) while the keys of the current one are probed.
+// Measured and dropped (profiles/r02_lds_probe_experiments.txt): drawing chunk numbers from an LDS counter instead of the
+// static chunk -> wave assignment (the waves wait 20-27 % of their time at the end of a ticket for the slowest one, but
+// every draw is an LDS round trip on the load-issue path: 0.80 vs 0.73 ms); software-pipelining the rounds (ring fetch of
+// the next round behind the bucket reads of this one: 0.77 ms) — the kernel is not waiting for LDS latency, its SIMDs
+// (50 %), LDS (42 %) and scalar unit (24 %) are all busy.
 //
 // Replaces (reference): join2Chunk + hashRowContainer.GetMatchedRows (executor/join.go:343-360,
 // hash_table.go:110-134) for the COUNT(*) shape; same joined-row count whichever route a key takes (a probe row
