@@ -6,18 +6,23 @@ Workload (N = 1): `SELECT count(*) FROM probe JOIN build ON probe.k = build.k`, 
 [0, N_b) in pseudo-random order, probe keys are uniform in [0, N_b) (hit ratio 1.0), generated on
 the device so the tables never cross PCIe.  The build side is built once and stays resident in
 HBM; one "step" = one probe pass of all N_p probe rows through libtsq: radix partition of the probe
-keys (k_radix_partition) + partition-at-a-time probe (k_radix_probe_count), or the direct probe
-(k_probe_count) with --radix off.
+keys into table words (k_radix_partition) + the probe of every partition against LDS copies of its
+table slices (k_lds_probe_count), or the direct probe (k_probe_count) with --radix off.
 N > 1: weak scaling — every rank owns N_b build and N_p probe rows; rows are redistributed by
-hash-radix with an RCCL all-to-all (tinysql_amd/parallel.py); a step = split + exchange + local
-probe of the probe side; the build side is redistributed and built once (untimed, resident).
+hash-radix through libtsq's own communicator (tsq_redistribute: tsq_radix_split + RCCL send/recv,
+csrc/tsq_comm.hip — no torch in the process); a step = split + exchange + local probe of the probe
+side, in pieces so that the wire time of piece c + 1 hides behind the probe of piece c; the build
+side is redistributed and built once (untimed, resident).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_radix_probe_count):
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_lds_probe_count):
 algorithmic bytes (24 B per probe row: 8 B key + one 16 B slot) / its average
 HIP-event duration over the timed steps; `roofline.probe_phase` prices the whole step (partition +
 probe) against the same 24 B/row, `roofline.partition` the partition kernel at its own 16 B/key.
 `cpu_baseline` = the oracle's C++ restatement of the reference algorithm (oracle/, test
 infrastructure — used here only as the reported baseline) timed on the host cores on a bounded sample.
+N = 1 also reports, as extra keys measured after the timed region (each verified by a closed form):
+`c2_1e8x1e7` (BASELINE configs[1]), `c3_agg_1e9_1e6` (configs[2]) and `materialising` (the same
+1e8 x 1e8 join with its four output columns written to HBM — what HashJoinExec.Next does).
 """
 import argparse
 import ctypes as C
@@ -43,6 +48,7 @@ def main():
     ap.add_argument("--cpu-probe-rows", type=int, default=20_000_000)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even with one rank (validation)")
     ap.add_argument("--radix", choices=["auto", "off", "force"], default="auto", help="probe strategy (tsq_join_set_radix)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c2 / c3 / materialising side measurements (N = 1)")
     args = ap.parse_args()
 
     n_gpus = args.gpus
@@ -50,25 +56,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch = dist = None
-    if distributed:
-        # torch FIRST: it bundles its own libamdhip64.so.7; loading it before libtsq makes both share
-        # one HIP runtime in this process (see DESIGN.md "Process model").
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        assert world == n_gpus or args.force_dist, "WORLD_SIZE must equal --gpus"
+    assert world == n_gpus or args.force_dist or not distributed, "WORLD_SIZE must equal --gpus"
 
     from tinysql_amd import _abi as abi
     from tinysql_amd import _lib
 
+    # One process per GPU.  N > 1: the ranks meet through libtsq's own communicator (RCCL inside the library, tsq_comm_*):
+    # no torch in this process, every call in the timed region is a C-ABI call a Go host could make.
     ctx = _lib.Context(local_rank)
     lib = ctx.lib
+    comm = None
     if distributed:
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        from tinysql_amd import parallel
+        comm = parallel.Comm(ctx, rank, world)
 
     nb, npr = args.build_rows, args.probe_rows  # per GPU
     nb_global = nb * world
@@ -87,14 +87,8 @@ def main():
         return c
 
     # ---------------------------------------------------------------- tables on device
-    if distributed:
-        bk_t = torch.empty(nb, dtype=torch.int64, device="cuda")
-        bv_t = torch.empty(nb, dtype=torch.int64, device="cuda")
-        pk_t = torch.empty(npr, dtype=torch.int64, device="cuda")
-        bk, bv, pk = bk_t.data_ptr(), bv_t.data_ptr(), pk_t.data_ptr()
-        pv = None
-    else:
-        bk, bv, pk, pv = (ctx.alloc(nb * 8), ctx.alloc(nb * 8), ctx.alloc(npr * 8), ctx.alloc(npr * 8))
+    bk, bv, pk = ctx.alloc(nb * 8), ctx.alloc(nb * 8), ctx.alloc(npr * 8)
+    pv = None if distributed else ctx.alloc(npr * 8)
     a_mult = 2654435761  # odd, not a multiple of 5: coprime with 10^k sizes -> bijection on [0, nb_global)
     assert nb_global < (1 << 31)
     ctx.gen_column(spec(abi.GEN_AFFINE, table=2, a=a_mult, b=12345, m=nb_global, start=rank * nb), nb, bk)
@@ -112,44 +106,39 @@ def main():
     for i in range(2):
         cfg.build_types[i] = cfg.probe_types[i] = abi.I64
     cfg.max_chunk_size, cfg.concurrency = 1024, 5
-    h = C.c_void_p()
-    _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
-    _lib.check(lib.tsq_join_set_radix(h, {"auto": abi.RADIX_AUTO, "off": abi.RADIX_OFF, "force": abi.RADIX_FORCE}[args.radix]), h)
+    radix_mode = {"auto": abi.RADIX_AUTO, "off": abi.RADIX_OFF, "force": abi.RADIX_FORCE}[args.radix]
+    dj = None
     if distributed:
-        from tinysql_amd import parallel
-        (rbk, rbv), nb_local = parallel.redistribute(ctx, dist, torch, [bk_t, bv_t], [abi.I64, abi.I64], 0, 0, nb)
-        torch.cuda.synchronize()
-        bcols = (abi.Col * 2)(dev_col(rbk.data_ptr(), nb_local), dev_col(rbv.data_ptr(), nb_local))
-    else:
-        nb_local = nb
-        bcols = (abi.Col * 2)(dev_col(bk, nb), dev_col(bv, nb))
-    t0 = time.time()
-    _lib.check(lib.tsq_join_build_push(h, bcols, 2, nb_local), h)
-    _lib.check(lib.tsq_join_build_finish(h), h)
-    ctx.sync()
-    build_wall_ms = (time.time() - t0) * 1e3
-    _lib.check(lib.tsq_join_set_count_only(h, 1), h)
-
-    if distributed:
-        from tinysql_amd import parallel
+        dj = parallel.DistHashJoinCount(comm, cfg)
+        h = dj.h
+        _lib.check(lib.tsq_join_set_radix(h, radix_mode), h)
+        t0 = time.time()
+        nb_local = dj.build([dev_col(bk, nb), dev_col(bv, nb)], 0, nb)  # redistribute by rank(key), then the local build
+        ctx.sync()
+        build_wall_ms = (time.time() - t0) * 1e3
+        pcols1 = [dev_col(pk, npr)]
 
         def step():
-            # the probe of piece c runs while pieces c+1.. are still being exchanged (parallel.redistribute_pipelined)
-            # libtsq runs on torch's current stream, so a received tensor may be dropped as soon as its probe is queued:
-            # the caching allocator hands the block to later work of the same stream only (retaining every piece until the
-            # end of the timed region made each step allocate 1.6 GB of fresh device memory: 17 ms per step).
-            for (rpk,), n_local in parallel.redistribute_pipelined(ctx, dist, torch, [pk_t], [abi.I64], 0, 0, npr, args.exchange_chunks):
-                if n_local:
-                    pc = (abi.Col * 1)(dev_col(rpk.data_ptr(), n_local))
-                    _lib.check(lib.tsq_join_probe_push(h, pc, 1, n_local, None), h)
-                    local_probe[0] += n_local
-                    local_probe[1] += 1
+            # piece c + 1 is split and on the wire (RCCL, the communicator's stream) while piece c is probed (tsq_redistribute /
+            # tsq_redistribute_wait / tsq_join_probe_push, tinysql_amd/parallel.py: redistribute_pieces)
+            dj.probe(pcols1, 0, npr, args.exchange_chunks)
 
         def full_sync():
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            ctx.sync()
+            comm.barrier()
+            ctx.sync()
     else:
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        _lib.check(lib.tsq_join_set_radix(h, radix_mode), h)
+        nb_local = nb
+        bcols = (abi.Col * 2)(dev_col(bk, nb), dev_col(bv, nb))
+        t0 = time.time()
+        _lib.check(lib.tsq_join_build_push(h, bcols, 2, nb_local), h)
+        _lib.check(lib.tsq_join_build_finish(h), h)
+        ctx.sync()
+        build_wall_ms = (time.time() - t0) * 1e3
+        _lib.check(lib.tsq_join_set_count_only(h, 1), h)
         pcols = (abi.Col * 2)(dev_col(pk, npr), dev_col(pv, npr))
 
         def step():
@@ -157,61 +146,55 @@ def main():
 
         def full_sync():
             # single process, single stream: hipStreamSynchronize of the only stream with work
-            # (== torch.cuda.synchronize() for this process; torch is not loaded at N=1)
             ctx.sync()
 
-    local_probe = [0, 0]  # N>1: rows this rank probed / probe batches it pushed (for the per-launch roofline figure)
-    keep = []
     for _ in range(args.warmup):
-        keep.append(step())
+        step()
     full_sync()
-    keep.clear()
-    local_probe[0] = local_probe[1] = 0
+    if dj:
+        dj.probed_local = dj.probe_batches = 0
     setup_s = time.time() - t_setup
 
     # ---------------------------------------------------------------- timed region: exactly K steps
     ctx.timer_start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        keep.append(step())
+        step()
     ev_ms = ctx.timer_stop_ms()  # HIP events on the stream the kernels were launched on
     full_sync()
     elapsed = time.perf_counter() - t0
-    keep.clear()
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = comm.allreduce_f64([elapsed], parallel.Comm.MAX)[0]
+    local_probe = [dj.probed_local, dj.probe_batches] if dj else [0, 0]  # rows this rank probed / probe batches (per-launch roofline)
 
-    # N>1: one extra, untimed pass of the split + all-to-all alone (no probe), for SURVEY.md §8(d)'s t_exchange
+    # N>1: one extra, untimed pass of the split + exchange alone (no probe), for SURVEY.md §8(d)'s t_exchange
     exchange_ms = None
     if distributed:
         try:
             full_sync()
             te = time.perf_counter()
-            for _pieces, _n in parallel.redistribute_pipelined(ctx, dist, torch, [pk_t], [abi.I64], 0, 0, npr, args.exchange_chunks):
-                pass
+            parallel.redistribute_pieces(comm, pcols1, 0, 0, npr, args.exchange_chunks, lambda got, n: None)
             full_sync()
-            tx = torch.tensor([time.perf_counter() - te], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tx, op=dist.ReduceOp.MAX)
-            exchange_ms = float(tx.item()) * 1e3
+            exchange_ms = comm.allreduce_f64([time.perf_counter() - te], parallel.Comm.MAX)[0] * 1e3
         except Exception:  # reporting only
             exchange_ms = None
 
     # ---------------------------------------------------------------- verify (size-independent property)
-    cnt = C.c_int64(0)
-    _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
-    total = cnt.value
     if distributed:
-        t = torch.tensor([total], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t)
-        total = int(t.item())
+        total = dj.count()  # local counts, summed with one 8-byte all-reduce
+    else:
+        cnt = C.c_int64(0)
+        _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+        total = cnt.value
     # build keys are a bijection of [0, nb_global), every probe key lies in [0, nb_global): each probe row joins once
     expect = (args.steps + args.warmup) * npr * world
     ok = total == expect
     st = abi.Stats()
     _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
-    lib.tsq_join_destroy(h)
+    if dj:
+        dj.close()
+    else:
+        lib.tsq_join_destroy(h)
 
     rows_per_s = npr * world * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -220,7 +203,7 @@ def main():
     radix = st.radix_batches > 0
     if radix and st.radix_timed_batches > 0:
         nt = min(st.radix_timed_batches, args.steps)  # the event ring keeps the most recent batches = the timed steps
-        kernel_name = "k_radix_probe_count<2,0>"
+        kernel_name = "k_lds_probe_count<1024>" if st.table_slice_bits >= 3 and os.environ.get("TSQ_RADIX_KERNEL", "") != "l2" else "k_radix_probe_count<2>"
         kernel_ms = st.radix_probe_kernel_ms_sum / st.radix_timed_batches
         part_ms = st.partition_kernel_ms_sum / st.radix_timed_batches
     else:
@@ -246,7 +229,7 @@ def main():
             "workload": "SELECT count(*) FROM probe JOIN build ON k: %.0e x %.0e int64-key inner hash join per GPU, "
                         "J-uniq-shuffled, hit ratio 1.0, build side resident in HBM" % (npr, nb),
             "probe_rows_per_gpu": npr, "build_rows_per_gpu": nb,
-            "parallelism": "hash-radix x%d, RCCL all-to-all" % world if distributed else "single GPU",
+            "parallelism": "hash-radix x%d, RCCL send/recv all-to-all inside libtsq (tsq_redistribute)" % world if distributed else "single GPU",
         },
         "verified": bool(ok),
         "joined_rows": total,
@@ -257,24 +240,22 @@ def main():
         "setup_s": setup_s,
     }
     if exchange_ms is not None:
-        out["split_and_exchange_ms"] = exchange_ms  # tsq_radix_split + RCCL all-to-all of one step's probe keys, without the probes
-    out["probe_strategy"] = ("radix 2^%d partitions" % st.radix_bits) if radix else "direct"
+        out["split_and_exchange_ms"] = exchange_ms  # tsq_redistribute of one step's probe keys (split + RCCL exchange), without the probes
+    out["probe_strategy"] = ("radix 2^%d partitions, table of 2^%d LDS-sized slices" % (st.radix_bits, st.table_slice_bits)) if radix else "direct"
     traffic = traffic_part = None
     try:  # PMC-derived HBM bytes per launch are measured offline (rocprofv3 --pmc passes) and committed under profiles/
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
         w = tj["workload"]
         if w["probe_rows"] == npr and w["build_rows"] == nb and world == 1:
-            if radix and w["radix_bits"] == st.radix_bits:
-                traffic = tj["k_radix_probe_count<2,0>"]["traffic_bytes"]
-                traffic_part = tj["k_radix_partition<1024,16,4,0,false>"]["traffic_bytes"]
-            elif not radix:
-                traffic = tj["k_probe_count<false,false,false> (direct probe, --radix off)"]["traffic_bytes"]
+            if radix and w["radix_bits"] == st.radix_bits and kernel_name in tj:
+                traffic = tj[kernel_name]["traffic_bytes"]
+                traffic_part = tj["k_radix_partition<1024,16,4,0,false,true>"]["traffic_bytes"]
     except Exception:
         pass
     if not distributed:
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": traffic, "traffic_source": "profiles/traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)" if traffic else None,
+            "traffic": traffic, "traffic_source": "profiles/traffic_r02.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected)" if traffic else None,
             "kernel": kernel_name, "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": algo_bytes,
             "probe_phase": {"ms": step_ev_ms, "achieved": algo_bytes / (step_ev_ms * 1e-3) / 1e9,
@@ -283,7 +264,7 @@ def main():
         }
         if radix:
             pb = 16.0 * npr  # 8 B key read + 8 B key written per probe row (COUNT(*) carries no payload)
-            out["roofline"]["partition"] = {"kernel": "k_radix_partition<1024,16,4,0,false>", "kernel_ms": part_ms,
+            out["roofline"]["partition"] = {"kernel": "k_radix_partition<1024,16,4,0,false,true>", "kernel_ms": part_ms,
                                             "algorithmic_bytes_per_launch": pb, "achieved": pb / (part_ms * 1e-3) / 1e9,
                                             "frac": pb / (part_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic_part}
             out["radix_overflow_rows"] = st.radix_overflow_rows
@@ -298,10 +279,20 @@ def main():
             "note": "rank 0, per probe launch (one launch per received piece of %.3g rows on average, %d pieces per step); "
                     "the step also contains tsq_radix_split and the RCCL all-to-all, which this figure does not price"
                     % (rows_per_launch, args.exchange_chunks),
-            "partition": {"kernel": "k_radix_partition<1024,16,4,0,false>", "kernel_ms": part_ms,
+            "partition": {"kernel": "k_radix_partition<1024,16,4,0,false,true>", "kernel_ms": part_ms,
                           "algorithmic_bytes_per_launch": 16.0 * rows_per_launch,
                           "achieved": 16.0 * rows_per_launch / (part_ms * 1e-3) / 1e9 if part_ms > 0 else None},
         }
+
+    # ---------------------------------------------------------------- BASELINE configs[1], configs[2] and the materialising join (N = 1)
+    if not distributed and not args.no_extras and nb == 100_000_000 and npr == 100_000_000:
+        for key, fn in (("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
+                        ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
+                        ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib))):
+            try:
+                out[key] = fn()
+            except Exception as e:  # reporting only
+                out[key] = {"error": str(e)[:200]}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     if rank == 0 and not distributed and not args.no_cpu_baseline:
@@ -310,17 +301,142 @@ def main():
         except Exception as e:  # the baseline is reporting only; never fail the bench for it
             out["cpu_baseline"] = {"error": str(e)[:200]}
 
-    if not distributed:
-        for p in (bk, bv, pk, pv):
-            ctx.free(p)
+    for p in (bk, bv, pk, pv):
+        ctx.free(p)
+    if comm:
+        comm.close()
     ctx.close()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
     if not ok:
         sys.exit("bench: join count mismatch: got %d expected %d" % (total, expect))
+
+
+def _dev_col(abi, ptr, n, tp=None):
+    c = abi.Col()
+    c.data, c.length, c.elem_size, c.type, c.flags = ptr, n, 8, abi.I64 if tp is None else tp, abi.COL_DEVICE
+    return c
+
+
+def _spec(abi, kind, **kw):
+    s = abi.GenSpec()
+    s.kind, s.seed = kind, 42
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def extra_c2(ctx, abi, _lib, pk, npr, nb=10_000_000, steps=10):
+    """BASELINE configs[1]: 1e8 probe rows x 1e7 build rows, count(*); probe keys = the bench's keys mod nb (hit ratio 1.0)."""
+    lib = ctx.lib
+    bk, pk2 = ctx.alloc(nb * 8), ctx.alloc(npr * 8)
+    try:
+        ctx.gen_column(_spec(abi, abi.GEN_AFFINE, table=2, a=2654435761, b=12345, m=nb), nb, bk)
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=1, col=0, m=nb), npr, pk2)
+        cfg = abi.JoinCfg()
+        cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 1, 1
+        cfg.build_types[0] = cfg.probe_types[0] = abi.I64
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            _lib.check(lib.tsq_join_build_push(h, (abi.Col * 1)(_dev_col(abi, bk, nb)), 1, nb), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+            pc = (abi.Col * 1)(_dev_col(abi, pk2, npr))
+            for _ in range(2):
+                _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(steps):
+                _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+            ms = ctx.timer_stop_ms() / steps
+            cnt = C.c_int64(0)
+            _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+        finally:
+            lib.tsq_join_destroy(h)
+    finally:
+        ctx.free(bk)
+        ctx.free(pk2)
+    return {"workload": "1e8 x 1e7 int64-key inner hash join, count(*), build side resident", "ms_per_probe_pass": ms, "rows_per_s": npr / ms * 1e3,
+            "frac": 24.0 * npr / ms / 1e6 / 8000.0, "verified": cnt.value == (steps + 2) * npr, "probe_kernel_ms": st.radix_probe_kernel_ms,
+            "partition_kernel_ms": st.partition_kernel_ms, "build_kernel_ms": st.build_kernel_ms, "steps": steps}
+
+
+def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3):
+    """The bench's join with its four output columns (probe k, v | build k, v) materialised in HBM: HashJoinExec.Next
+    (executor/join.go:125-146, joiner.go:351-378).  Algorithmic bytes: 32 B per probe row + 24 B per joined row."""
+    lib = ctx.lib
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 2, 2
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    best = 1e30
+    rows = 0
+    for _ in range(reps):
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            _lib.check(lib.tsq_join_build_push(h, (abi.Col * 2)(_dev_col(abi, bk, nb), _dev_col(abi, bv, nb)), 2, nb), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            ctx.sync()
+            t = time.perf_counter()
+            _lib.check(lib.tsq_join_probe_push(h, (abi.Col * 2)(_dev_col(abi, pk, npr), _dev_col(abi, pv, npr)), 2, npr, None), h)
+            _lib.check(lib.tsq_join_probe_finish(h), h)
+            ctx.sync()
+            best = min(best, time.perf_counter() - t)
+            c = C.c_int64(0)
+            _lib.check(lib.tsq_join_count(h, C.byref(c)), h)
+            rows = c.value
+        finally:
+            lib.tsq_join_destroy(h)
+    algo = 32.0 * npr + 24.0 * rows
+    return {"workload": "1e8 x 1e8 (k, v) x (k, v) inner join, 4 output columns written to HBM", "ms": best * 1e3, "joined_rows": rows,
+            "joined_rows_per_s": rows / best, "frac": algo / best / 8e12, "verified": rows == npr, "timing": "host clock around probe_push + probe_finish + stream sync, best of %d" % reps}
+
+
+def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=100_000_000):
+    """BASELINE configs[2]: SELECT k, SUM(v), COUNT(*) GROUP BY k, 1e9 rows / 1e6 int64 groups; the rows are generated batch by
+    batch on the device (untimed) and pushed device resident, like the chunks of a GPU child operator."""
+    lib = ctx.lib
+    k, v = ctx.alloc(batch * 8), ctx.alloc(batch * 8)
+    try:
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 1
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
+        cfg.n_input_cols = 2
+        cfg.input_types[0], cfg.input_types[1] = abi.I64, abi.I64
+        cfg.n_aggs = 3
+        for i, (f, col) in enumerate([(abi.AGG_FIRSTROW, 0), (abi.AGG_SUM, 1), (abi.AGG_COUNT, -1)]):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
+        cfg.est_groups = groups
+        h = C.c_void_p()
+        _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            ms, done = 0.0, 0
+            while done < n:
+                m = min(batch, n - done)
+                ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=0, m=groups, start=done), m, k)
+                ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=1, m=1000, start=done), m, v)
+                ctx.sync()
+                ctx.timer_start()
+                _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m)), 2, m), h)
+                ms += ctx.timer_stop_ms()
+                done += m
+            ctx.timer_start()
+            _lib.check(lib.tsq_agg_finish(h), h)
+            ms += ctx.timer_stop_ms()
+            ng = C.c_int64(0)
+            _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+        finally:
+            lib.tsq_agg_destroy(h)
+    finally:
+        ctx.free(k)
+        ctx.free(v)
+    algo = 16.0 * n + 24.0 * ng.value
+    return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows / 1e6 int64 groups, HashAggExec", "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value,
+            "frac": algo / ms / 1e6 / 8000.0, "verified": ng.value == groups}
 
 
 def cpu_baseline(abi, nb, npr):

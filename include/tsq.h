@@ -482,6 +482,33 @@ tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, in
                            int32_t key_mode, int64_t nrows, int32_t n_parts, tsq_col* out_cols,
                            int64_t* counts_out);
 
+/* ---------------------------------------------------------------- multi-GPU exchange (RCCL over xGMI), one process per GPU
+ * What the reference does with goroutines and channels inside one process — HashJoinExec handing outer chunks to its join
+ * workers (executor/join.go:160-231), HashAggExec shuffling partial results to its final workers by group key
+ * (executor/aggregate.go:352-356) — across the GPUs of a node: the rank of a key (((mix64(key word) & 0xffff) * world) >> 16, as in tsq_radix_split) owns it.
+ * Every rank runs the same call sequence.  Bootstrap: rank 0 calls tsq_comm_unique_id and hands the 128 bytes to the other
+ * ranks by any side channel (the Go host: the coordinator's RPC; the harness: a file), then every rank calls tsq_comm_create.
+ *
+ * tsq_redistribute splits `cols` (device resident, no NULLs) by rank(key) on the context's stream (tsq_radix_split), exchanges
+ * the run sizes, and queues ONE group of RCCL sends / receives on the communicator's own stream.  out_cols describe device
+ * buffers owned by `slot` (0..7) of the communicator: they hold the received rows once tsq_redistribute_wait(comm, slot) has
+ * made the context's stream wait for the exchange, and stay valid until the next tsq_redistribute on the same slot.  Queue
+ * piece c + 1's redistribute before piece c's consumer (wait; tsq_join_probe_push / tsq_agg_push) and the wire time of
+ * c + 1 hides behind the operator kernels of c.
+ * The all-reduces take up to 8 host words (op 0 sum, 1 max, 2 min) and synchronise both streams: they are the barrier + the
+ * COUNT(*) / timing reductions a distributed plan needs. */
+typedef struct tsq_comm tsq_comm;
+#define TSQ_COMM_ID_BYTES 128
+tsq_status tsq_comm_unique_id(uint8_t* id_out /* [TSQ_COMM_ID_BYTES] */);
+tsq_status tsq_comm_create(tsq_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id, tsq_comm** out);
+void       tsq_comm_destroy(tsq_comm* c);
+tsq_status tsq_comm_allreduce_i64(tsq_comm* c, int64_t* inout, int32_t n, int32_t op);
+tsq_status tsq_comm_allreduce_f64(tsq_comm* c, double* inout, int32_t n, int32_t op);
+tsq_status tsq_comm_barrier(tsq_comm* c);
+tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode,
+                            int64_t nrows, int32_t slot, tsq_col* out_cols, int64_t* nrows_out);
+tsq_status tsq_redistribute_wait(tsq_comm* c, int32_t slot);
+
 /* ---------------------------------------------------------------- statistics (roofline reporting) */
 typedef struct tsq_stats {
     int64_t build_rows;

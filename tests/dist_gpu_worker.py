@@ -1,0 +1,139 @@
+"""One rank of the multi-GPU parity run (tests/test_comm_gpu.py): the REAL path — tsq_radix_split + RCCL send/recv inside
+libtsq (tsq_redistribute) + the HIP join / aggregate — against the oracle's whole-table result.
+Every rank generates ALL ranks' rows from per-rank seeds (so it can run the oracle on the union), feeds its own rows to the
+distributed plan, and checks: the all-reduced join count equals the oracle's; every received key ranks to this rank; the
+final groups this rank owns equal the oracle's groups with those keys; the group counts of all ranks add up.
+usage: dist_gpu_worker.py  (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT in the environment)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import binding as orc  # noqa: E402
+from tests import gpu_helpers as G  # noqa: E402
+from tests import helpers as H  # noqa: E402
+from tinysql_amd import _abi as abi  # noqa: E402
+from tinysql_amd import _lib  # noqa: E402
+from tinysql_amd import parallel  # noqa: E402
+from tinysql_amd.chunk import Chunk, Column  # noqa: E402
+
+
+def np_rank(keys, parts):
+    k = keys.view(np.uint64).copy()
+    with np.errstate(over="ignore"):
+        k ^= k >> np.uint64(33)
+        k *= np.uint64(0xFF51AFD7ED558CCD)
+        k ^= k >> np.uint64(33)
+        k *= np.uint64(0xC4CEB9FE1A85EC53)
+        k ^= k >> np.uint64(33)
+    return (((k & np.uint64(0xFFFF)) * np.uint64(parts)) >> np.uint64(16)).astype(np.int64)
+
+
+def rows_of(rank, nb, npr):
+    rng = np.random.default_rng(7000 + rank)
+    return (rng.integers(0, 60_000, nb).astype(np.int64), rng.integers(-99, 99, nb).astype(np.int64),
+            rng.integers(0, 70_000, npr).astype(np.int64), rng.integers(-99, 99, npr).astype(np.int64))
+
+
+def dev(ctx, arr, keep):
+    p = ctx.alloc(max(arr.nbytes, 8))
+    ctx.h2d(p, np.ascontiguousarray(arr))
+    keep.append(p)
+    c = abi.Col()
+    c.data, c.length, c.elem_size, c.type, c.flags = p, len(arr), 8, abi.I64, abi.COL_DEVICE
+    return c
+
+
+def main():
+    import time
+    t_start = time.time()
+
+    def lap(what):
+        if os.environ.get("TSQ_TEST_TIMING"):
+            print("[rank %s] %-28s %.2f s" % (os.environ.get("RANK", "0"), what, time.time() - t_start), flush=True)
+
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    nb, npr = 150_000, 400_000  # per rank: above the fast-split threshold (2^16 rows), ragged pieces
+    allrows = [rows_of(r, nb, npr + 1000 * r) for r in range(world)]
+    bk, bv, pk, pv = allrows[rank]
+    keep = []
+    with _lib.Context(local) as ctx:
+        lap("context")
+        comm = parallel.Comm(ctx, rank, world)
+        lap("communicator")
+        try:
+            assert comm.allreduce_i64([rank + 1, 10])[0] == world * (world + 1) // 2
+            assert comm.allreduce_i64([rank], parallel.Comm.MAX)[0] == world - 1
+            assert abs(comm.allreduce_f64([0.5 * (rank + 1)])[0] - 0.25 * world * (world + 1)) < 1e-12
+            # ---- redistribute alone: every received key ranks here, nothing lost
+            got, n = comm.redistribute([dev(ctx, bk, keep), dev(ctx, bv, keep)], 0, 0, nb, slot=3)
+            comm.wait(3)
+            ctx.sync()
+            rk, rv = np.empty(n, np.int64), np.empty(n, np.int64)
+            if n:
+                ctx.d2h(rk, got[0].data)
+                ctx.d2h(rv, got[1].data)
+            assert (np_rank(rk, world) == rank).all()
+            uk = np.concatenate([a[0] for a in allrows])
+            uv = np.concatenate([a[1] for a in allrows])
+            own = np_rank(uk, world) == rank
+            assert sorted(zip(rk.tolist(), rv.tolist())) == sorted(zip(uk[own].tolist(), uv[own].tolist()))
+            assert comm.allreduce_i64([n])[0] == nb * world
+            lap("redistribute checked")
+            # ---- distributed COUNT(*) join vs the oracle on the union of all ranks' rows
+            t = [abi.I64, abi.I64]
+            cfg = H.join_cfg(t, t, [0], [0], abi.JOIN_INNER, 1)
+            j = parallel.DistHashJoinCount(comm, cfg)
+            try:
+                j.build([dev(ctx, bk, keep), dev(ctx, bv, keep)], 0, nb)
+                j.probe([dev(ctx, pk, keep), dev(ctx, pv, keep)], 0, len(pk), n_pieces=3)
+                j.probe([dev(ctx, pk, keep), dev(ctx, pv, keep)], 0, len(pk), n_pieces=1)
+                total = j.count()
+            finally:
+                j.close()
+            lap("distributed join")
+            ubk = np.concatenate([a[0] for a in allrows])
+            ubv = np.concatenate([a[1] for a in allrows])
+            upk = np.concatenate([a[2] for a in allrows])
+            upv = np.concatenate([a[3] for a in allrows])
+            want = orc.hash_join(cfg, Chunk([Column(abi.I64, ubk), Column(abi.I64, ubv)]), Chunk([Column(abi.I64, upk), Column(abi.I64, upv)])).NumRows()
+            assert total == 2 * want, (total, want)
+            lap("oracle join")
+            # ---- distributed GROUP BY k: SUM(v), COUNT(*), MIN(v) vs the oracle
+            paggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_SUM, 1, abi.I64, abi.MODE_PARTIAL1),
+                     (abi.AGG_COUNT, -1, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_MIN, 1, abi.I64, abi.MODE_PARTIAL1)]
+            ptypes = [abi.I64, abi.I64, abi.I64, abi.I64]
+            faggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_FINAL), (abi.AGG_SUM, 1, abi.I64, abi.MODE_FINAL),
+                     (abi.AGG_COUNT, 2, abi.I64, abi.MODE_FINAL), (abi.AGG_MIN, 3, abi.I64, abi.MODE_FINAL)]
+            out, ng = parallel.dist_hash_agg(comm, H.agg_cfg(t, [0], paggs), H.agg_cfg(ptypes, [0], faggs), [dev(ctx, pk, keep), dev(ctx, pv, keep)],
+                                             len(pk), ptypes)
+            lap("distributed aggregate")
+            cols = []
+            for p, q in out:
+                a = np.empty(ng, np.int64)
+                if ng:
+                    ctx.d2h(a, p)
+                cols.append(a)
+                ctx.free(p)
+                ctx.free(q)
+            caggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_MIN, 1, abi.I64)]
+            whole = orc.hash_agg(H.agg_cfg(t, [0], caggs), Chunk([Column(abi.I64, upk), Column(abi.I64, upv)]), 4, 4)
+            wk = np.array(whole.columns[0].data)
+            mine = np_rank(wk, world) == rank
+            want_rows = sorted(zip(*[np.array(c.data)[mine].tolist() for c in whole.columns]))
+            assert sorted(zip(*[c.tolist() for c in cols])) == want_rows
+            assert comm.allreduce_i64([ng])[0] == whole.NumRows()
+            lap("oracle aggregate")
+            print("rank %d/%d OK: join %d rows, %d of %d groups" % (rank, world, total, ng, whole.NumRows()), flush=True)
+        finally:
+            for p in keep:
+                ctx.free(p)
+            comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,10 +4,7 @@ tile-boundary sizes, both value forms and a per-column mix, host and device plac
 the row boundaries (64-row response chunks), the too-small-buffer contract, the argument contract, the round trip through
 tsq_rows_decode, and the coprocessor chain scan -> selection -> partial aggregate -> response bytes.
 
-NOT YET RUN ON HARDWARE: the kernels were written after this round's GPU budget was spent.  They are cross-compiled for gfx950,
-and their per-tile code is walked on the CPU against the oracle (tests/test_hostsim_encode.py) — the same preparation the
-stored-row decoder had before its first (green) GPU run.  Until the first hardware run (round 2) these tests only run with
-TSQ_RUN_UNVERIFIED=1."""
+First hardware run: round 2 (gpurun_out/r2i, 22 tests green on the first run; profiles/r02_pytest_gpu.txt)."""
 import ctypes as C
 import os
 
@@ -22,8 +19,7 @@ from tinysql_amd.chunk import Chunk, Column, make_cols
 from . import gpu_helpers as G
 from . import helpers as H
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("TSQ_RUN_UNVERIFIED") != "1", reason="tsq_rows_encode: first hardware run pending (set TSQ_RUN_UNVERIFIED=1)")]
+pytestmark = pytest.mark.gpu
 
 
 def rand_chunk(rng, n, null_p=0.2):

@@ -141,6 +141,9 @@ class Stats(C.Structure):
     ]
 
 
+COMM_ID_BYTES = 128
+
+
 # every symbol include/tsq.h declares: name -> (restype, argtypes)
 P = C.c_void_p
 PP = C.POINTER(C.c_void_p)
@@ -203,6 +206,14 @@ SIGNATURES = {
     "tsq_rows_encode": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.POINTER(C.c_uint32), C.c_int64, P, C.c_int64, C.c_uint32, P, C.POINTER(C.c_int64)]),
     "tsq_radix_split": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                     C.POINTER(Col), C.POINTER(C.c_int64)]),
+    "tsq_comm_unique_id": (C.c_int32, [P]),
+    "tsq_comm_create": (C.c_int32, [P, C.c_int32, C.c_int32, P, PP]),
+    "tsq_comm_destroy": (None, [P]),
+    "tsq_comm_allreduce_i64": (C.c_int32, [P, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
+    "tsq_comm_allreduce_f64": (C.c_int32, [P, C.POINTER(C.c_double), C.c_int32, C.c_int32]),
+    "tsq_comm_barrier": (C.c_int32, [P]),
+    "tsq_redistribute": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(Col), C.POINTER(C.c_int64)]),
+    "tsq_redistribute_wait": (C.c_int32, [P, C.c_int32]),
     "tsq_join_stats": (C.c_int32, [P, C.POINTER(Stats)]),
     "tsq_agg_stats": (C.c_int32, [P, C.POINTER(Stats)]),
 }

@@ -146,11 +146,14 @@ TSQ_API tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
         (cols[c].flags & TSQ_COL_DEVICE) ? in_dev = true : in_host = true;
     }
     if (in_dev && in_host) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: mixed host/device columns");
-    if (nrows == 0) {
-        if (row_offsets && !(out_flags & TSQ_COL_DEVICE)) row_offsets[0] = 0;
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    if (nrows == 0) {  // an empty response still has its first row boundary
+        if (row_offsets) {
+            if (out_flags & TSQ_COL_DEVICE) TSQ_HIP(h, hipMemsetAsync(row_offsets, 0, sizeof(row_offsets[0]), ctx->stream));
+            else row_offsets[0] = 0;
+        }
         return TSQ_OK;
     }
-    TSQ_HIP(h, hipSetDevice(ctx->device));
     const bool out_dev = out_flags & TSQ_COL_DEVICE;
     EncArgs a;
     memset(&a, 0, sizeof a);

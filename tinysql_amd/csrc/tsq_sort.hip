@@ -475,7 +475,8 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
     const int64_t n = s->cols[0].rows;
     s->n = n;
     s->first = std::min<int64_t>(n, s->cfg.limit_offset);
-    s->last = s->cfg.limit_count < 0 ? n : std::min<int64_t>(n, s->cfg.limit_offset + s->cfg.limit_count);  // TopNExec: Offset + Count (sort.go:215)
+    // TopNExec: rows [Offset, Offset + Count) (sort.go:215; uint64 there).  "LIMIT off, 9223372036854775807" must not overflow the sum.
+    s->last = (s->cfg.limit_count < 0 || s->cfg.limit_count >= n - s->first) ? n : s->first + s->cfg.limit_count;
     if (s->last < s->first) s->last = s->first;
     s->cursor = s->first;
     s->finished = true;

@@ -1,5 +1,10 @@
-"""Multi-GPU hash-radix redistribute: one process per GPU, torch.distributed (backend "nccl" == RCCL
-on ROCm) all-to-all(v) over xGMI.
+"""Multi-GPU hash-radix redistribute: one process per GPU.
+
+The product path is `Comm` below: a thin caller of libtsq's tsq_comm_* / tsq_redistribute (RCCL send/recv over xGMI inside
+the library, csrc/tsq_comm.hip) — nothing but plain pointers and sizes crosses the C-ABI, a Go host calls the same sequence
+(INTEGRATION.md §6).  `DistHashJoinCount` and `dist_hash_agg` are the two distributed plans built from it.
+The torch.distributed functions further down move torch tensors with the same bookkeeping (run sizes, pieces, ragged counts);
+they are what the CPU test-suite runs at world size 2 over gloo, where no GPU and therefore no RCCL exists.
 
 CPU analogue in the reference: HashAggExec's partial->final shuffle (executor/aggregate.go:352-356)
 and the probe-chunk dispatch of HashJoinExec (executor/join.go:219).  Equi-join and GROUP BY are
@@ -118,3 +123,231 @@ def redistribute_pipelined(ctx, dist, torch, tensors, types, key_col, key_mode, 
             wk.wait()  # nccl: the current stream waits for the exchange; gloo: the host does
         yield got, total
     del pieces  # send buffers stay alive until every exchange has been waited for
+
+
+# ====================================================================== the C-ABI path (RCCL inside libtsq)
+import os
+import time
+
+
+def rendezvous_unique_id(lib, rank, world, timeout_s=180.0):
+    """rank 0 creates the RCCL unique id, the other ranks of this launch read it from a file.  The launcher (torchrun) is the
+    parent of every rank: its pid + MASTER_PORT name the launch, so concurrent or earlier runs cannot be confused."""
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tsq_rdzv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
+    if world == 1:
+        _lib.check(lib.tsq_comm_unique_id(buf))
+        return bytes(buf), None
+    if rank == 0:
+        _lib.check(lib.tsq_comm_unique_id(buf))
+        with open(path + ".tmp", "wb") as f:
+            f.write(bytes(buf))
+        os.replace(path + ".tmp", path)
+        return bytes(buf), path
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                b = f.read()
+            if len(b) == abi.COMM_ID_BYTES:
+                return b, None
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise RuntimeError("rendezvous: no unique id at %s after %.0f s" % (path, timeout_s))
+        time.sleep(0.01)
+
+
+class Comm:
+    """tsq_comm handle: one per process / GPU."""
+
+    SUM, MAX, MIN = 0, 1, 2
+
+    def __init__(self, ctx, rank=None, world=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        uid, self._rdzv = rendezvous_unique_id(self.lib, self.rank, self.world)
+        idbuf = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(uid)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.tsq_comm_create(ctx.h, self.rank, self.world, idbuf, C.byref(self.h)), ctx.h)
+
+    def close(self):
+        if self.h:
+            self.barrier()
+            self.lib.tsq_comm_destroy(self.h)
+            self.h = None
+            if self._rdzv:
+                try:
+                    os.remove(self._rdzv)
+                except OSError:
+                    pass
+
+    def allreduce_i64(self, values, op=0):
+        a = (C.c_int64 * len(values))(*values)
+        _lib.check(self.lib.tsq_comm_allreduce_i64(self.h, a, len(values), op), self.h)
+        return list(a)
+
+    def allreduce_f64(self, values, op=0):
+        a = (C.c_double * len(values))(*values)
+        _lib.check(self.lib.tsq_comm_allreduce_f64(self.h, a, len(values), op), self.h)
+        return list(a)
+
+    def barrier(self):
+        _lib.check(self.lib.tsq_comm_barrier(self.h), self.h)
+
+    def redistribute(self, cols, key_col, key_mode, nrows, slot=0):
+        """cols: list of abi.Col (device resident).  Returns (received abi.Col array, n_received); call wait(slot) before the
+        consumer of the received columns is queued."""
+        arr = (abi.Col * len(cols))(*cols)
+        out = (abi.Col * len(cols))()
+        n = C.c_int64(0)
+        _lib.check(self.lib.tsq_redistribute(self.h, arr, len(cols), key_col, key_mode, nrows, slot, out, C.byref(n)), self.h)
+        return out, n.value
+
+    def wait(self, slot=0):
+        _lib.check(self.lib.tsq_redistribute_wait(self.h, slot), self.h)
+
+
+def col_slice(col, lo, hi):
+    """rows [lo, hi) of a device-resident fixed-width column without NULLs"""
+    c = abi.Col()
+    c.data = (col.data or 0) + lo * col.elem_size
+    c.null_bitmap, c.offsets = None, None
+    c.length, c.elem_size, c.type, c.flags = hi - lo, col.elem_size, col.type, col.flags
+    return c
+
+
+def redistribute_pieces(comm, cols, key_col, key_mode, nrows, n_pieces, consume):
+    """The rows in n_pieces pieces: piece c + 1 is split and put on the wire BEFORE piece c's consumer is queued, so the
+    exchange of c + 1 overlaps the operator kernels of c (consume(received cols, n) queues work on the context's stream)."""
+    n_pieces = max(1, min(int(n_pieces), 8))
+    bounds = [min(nrows, ((nrows * c // n_pieces) + 63) & ~63) for c in range(n_pieces)] + [nrows]
+    pending = None
+    for c in range(n_pieces):
+        lo, hi = bounds[c], bounds[c + 1]
+        got = comm.redistribute([col_slice(x, lo, hi) for x in cols], key_col, key_mode, hi - lo, slot=c % 8)
+        if pending is not None:
+            comm.wait(pending[0])
+            consume(pending[1], pending[2])
+        pending = (c % 8, got[0], got[1])
+    comm.wait(pending[0])
+    consume(pending[1], pending[2])
+
+
+class DistHashJoinCount:
+    """SELECT count(*) FROM probe JOIN build ON k across the ranks of `comm`: both sides are redistributed by rank(key), every
+    rank builds and probes what it owns with the single-GPU operator, the counts are summed (one 8-byte all-reduce)."""
+
+    def __init__(self, comm, cfg):
+        self.comm, self.lib, self.ctx = comm, comm.lib, comm.ctx
+        self.h = C.c_void_p()
+        _lib.check(self.lib.tsq_join_create(self.ctx.h, C.byref(cfg), C.byref(self.h)), self.ctx.h)
+        self.probed_local = 0
+        self.probe_batches = 0
+
+    def build(self, cols, key_col, nrows):
+        got, n = self.comm.redistribute(cols, key_col, 0, nrows, slot=0)
+        self.comm.wait(0)
+        if n:
+            _lib.check(self.lib.tsq_join_build_push(self.h, got, len(cols), n), self.h)
+        _lib.check(self.lib.tsq_join_build_finish(self.h), self.h)
+        _lib.check(self.lib.tsq_join_set_count_only(self.h, 1), self.h)
+        return n
+
+    def probe(self, cols, key_col, nrows, n_pieces=4):
+        def consume(got, n):
+            if n:
+                _lib.check(self.lib.tsq_join_probe_push(self.h, got, len(cols), n, None), self.h)
+                self.probed_local += n
+                self.probe_batches += 1
+        redistribute_pieces(self.comm, cols, key_col, 0, nrows, n_pieces, consume)
+
+    def count(self):
+        c = C.c_int64(0)
+        _lib.check(self.lib.tsq_join_count(self.h, C.byref(c)), self.h)
+        return self.comm.allreduce_i64([c.value])[0]
+
+    def stats(self):
+        st = abi.Stats()
+        _lib.check(self.lib.tsq_join_stats(self.h, C.byref(st)), self.h)
+        return st
+
+    def close(self):
+        if self.h:
+            self.lib.tsq_join_destroy(self.h)
+            self.h = None
+
+
+def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_col_partial=0, cap=None):
+    """HashAggExec across the ranks of `comm`, the reference's own three stages (executor/aggregate.go:96-133):
+      1. every rank pre-aggregates ITS rows (partial workers, Partial1Mode): one row per local group;
+      2. the partial rows are redistributed by rank(group key) — shuffleIntermData (aggregate.go:352-356) over xGMI;
+      3. every rank merges the partial rows of the groups it owns (final workers, FinalMode) and returns them.
+    partial_cfg / final_cfg: abi.AggCfg of the two stages; partial_types: column types of the partial rows (the input schema of
+    final_cfg); key_col_partial: the group key's column in the partial rows.  Returns (device column buffers, n_groups_local):
+    the caller owns the buffers (ctx.free)."""
+    lib, ctx = comm.lib, comm.ctx
+    hp = C.c_void_p()
+    _lib.check(lib.tsq_agg_create(ctx.h, C.byref(partial_cfg), C.byref(hp)), ctx.h)
+    bufs = []
+    try:
+        arr = (abi.Col * len(cols))(*cols)
+        if nrows:
+            _lib.check(lib.tsq_agg_push(hp, arr, len(cols), nrows), hp)
+        _lib.check(lib.tsq_agg_finish(hp), hp)
+        ng = C.c_int64(0)
+        _lib.check(lib.tsq_agg_num_groups(hp, C.byref(ng)), hp)
+        n_part = ng.value
+        pcols = (abi.Col * len(partial_types))()
+        bm_bytes = (max(n_part, 1) + 7) // 8 + 8
+        for i, tp in enumerate(partial_types):
+            es = 4 if tp == abi.F32 else 8
+            p, q = ctx.alloc(max(n_part, 1) * es), ctx.alloc(bm_bytes)
+            bufs += [p, q]
+            pcols[i].data, pcols[i].null_bitmap, pcols[i].length, pcols[i].elem_size, pcols[i].type, pcols[i].flags = p, q, n_part, es, tp, abi.COL_DEVICE
+        if n_part:
+            n, eos = C.c_int64(0), C.c_int32(0)
+            _lib.check(lib.tsq_agg_pull(hp, pcols, len(partial_types), (n_part + 7) & ~7, C.byref(n), C.byref(eos)), hp)
+            assert n.value == n_part
+            # the exchange carries no null bitmaps yet (tsq_redistribute): a partial row with a NULL cell (a group whose every
+            # argument was NULL) cannot travel — refuse loudly instead of dropping the flag
+            import numpy as np
+            for i in range(len(partial_types)):
+                bm = np.empty((n_part + 7) // 8, dtype=np.uint8)
+                ctx.d2h(bm, pcols[i].null_bitmap)
+                bits = np.unpackbits(bm, bitorder="little")[:n_part]
+                if not bits.all():
+                    raise _lib.TsqError(abi.ERR_UNSUPPORTED, "dist_hash_agg: partial column %d holds NULLs; NULL partial results are not exchanged yet" % i)
+        for i in range(len(partial_types)):
+            pcols[i].null_bitmap = None
+    finally:
+        lib.tsq_agg_destroy(hp)
+    hf = C.c_void_p()
+    _lib.check(lib.tsq_agg_create(ctx.h, C.byref(final_cfg), C.byref(hf)), ctx.h)
+    try:
+        got, n = comm.redistribute(list(pcols), key_col_partial, 1, n_part, slot=0)
+        comm.wait(0)
+        if n:
+            _lib.check(lib.tsq_agg_push(hf, got, len(partial_types), n), hf)
+        _lib.check(lib.tsq_agg_finish(hf), hf)
+        ng = C.c_int64(0)
+        _lib.check(lib.tsq_agg_num_groups(hf, C.byref(ng)), hf)
+        n_out = ng.value
+        n_out_cols = final_cfg.n_aggs
+        out_bufs, ocols = [], (abi.Col * n_out_cols)()
+        for i in range(n_out_cols):
+            p = ctx.alloc(max(n_out, 1) * 8)
+            q = ctx.alloc(max(n_out, 8) // 8 + 8)
+            out_bufs.append((p, q))
+            ocols[i].data, ocols[i].null_bitmap, ocols[i].length, ocols[i].elem_size, ocols[i].flags = p, q, n_out, 8, abi.COL_DEVICE
+        if n_out:
+            m, eos = C.c_int64(0), C.c_int32(0)
+            _lib.check(lib.tsq_agg_pull(hf, ocols, n_out_cols, (n_out + 7) & ~7, C.byref(m), C.byref(eos)), hf)
+            assert m.value == n_out
+        ctx.sync()
+    finally:
+        lib.tsq_agg_destroy(hf)
+        for p in bufs:
+            ctx.free(p)
+    return out_bufs, n_out
