@@ -293,3 +293,108 @@ def test_heavily_duplicated_build_key_is_refused_quickly(ctx):
     with pytest.raises(_lib.TsqError) as ei:
         _count(ctx, _cfg(), build, probe, abi.RADIX_AUTO)
     assert ei.value.status == abi.ERR_UNSUPPORTED and time.time() - t0 < 20
+
+
+# ---------------------------------------------------------------- materialising radix path (k_lds_probe_count MODE 1 / 2)
+def _emit_inputs(seed, nb, npr, kt=abi.I64, n_pay_b=1, n_pay_p=1, pay_t=abi.I64, key_pos=0):
+    rng = np.random.default_rng(seed)
+    bk = rng.integers(-(1 << 62), 1 << 62, nb)
+    bk[: nb // 4] = rng.integers(0, nb // 16, nb // 4)  # ~4 duplicates per key on a quarter of the rows
+    bk[:300] = 4242
+    bk[300:305] = SENT_PRE
+    pk = np.concatenate([rng.choice(bk, npr // 2), rng.integers(-(1 << 62), 1 << 62, npr - npr // 2)])
+    pk[:7] = SENT_PRE
+    rng.shuffle(pk)
+    if kt == abi.U64:
+        bk, pk = bk.astype(np.uint64), pk.astype(np.uint64)
+
+    def pay(n):
+        return Column(pay_t, rng.random(n) if pay_t == abi.F64 else rng.integers(-(1 << 40), 1 << 40, n))
+
+    bcols = [pay(nb) for _ in range(n_pay_b)]
+    pcols = [pay(npr) for _ in range(n_pay_p)]
+    bcols.insert(min(key_pos, len(bcols)), Column(kt, bk))
+    pcols.insert(min(key_pos, len(pcols)), Column(kt, pk))
+    return Chunk(bcols), Chunk(pcols), min(key_pos, n_pay_b), min(key_pos, n_pay_p)
+
+
+@pytest.mark.parametrize("shape", [dict(), dict(n_pay_b=2, n_pay_p=2, key_pos=1), dict(n_pay_b=0, n_pay_p=1), dict(n_pay_b=1, n_pay_p=0), dict(kt=abi.U64, pay_t=abi.F64, key_pos=2),
+                                   dict(knobs={"TSQ_LDS_NF_MAX": 1}), dict(knobs={"TSQ_LDS_NF_MAX": 3, "TSQ_RADIX_PB_MAX": 4}, n_pay_b=2)],
+                         ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()) or "k,v x k,v")
+def test_materialising_radix_join_vs_oracle(ctx, orc, shape):
+    shape = dict(shape)
+    knobs = shape.pop("knobs", {})
+    build, probe, bkc, pkc = _emit_inputs(41, 250_000, 900_000, **shape)
+    cfg = H.join_cfg(probe.types(), build.types(), [pkc], [bkc], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe)
+    with _env(**knobs):
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, radix=abi.RADIX_FORCE)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    off = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, radix=abi.RADIX_OFF)
+    assert H.rows_equal_unordered(off, want)
+
+
+def test_materialising_radix_join_skewed_probe_keys_use_the_overflow_list(ctx, orc):
+    n = 600_000
+    rng = np.random.default_rng(43)
+    bk = rng.permutation(200_000).astype(np.int64)
+    bk[:3] = 7  # three build rows with the hot key
+    pk = np.full(n, 7, dtype=np.int64)
+    pk[::1000] = 8
+    build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(len(bk)))])
+    probe = Chunk([Column(abi.I64, pk), Column(abi.I64, np.arange(n))])
+    t = [abi.I64, abi.I64]
+    cfg = H.join_cfg(t, t, [0], [0], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe)
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, radix=abi.RADIX_FORCE)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+def test_materialising_radix_join_full_size_property(ctx):
+    # 1e8 x 1e8 (k, v) x (k, v), every probe row joins exactly once: row count, the key columns agree, and the order-independent
+    # checksum of the four output columns equals the direct path's (GPU vs GPU at full size; both are pinned on the oracle above)
+    n = 50_000_000
+    lib = ctx.lib
+    cols = [G.DevCol(ctx, abi.I64, n) for _ in range(4)]
+    outs = [G.DevCol(ctx, abi.I64, n, with_nulls=True) for _ in range(4)]
+    try:
+        ctx.gen_column(G.gen_spec(abi.GEN_AFFINE, table=2, a=2654435761, b=12345, m=n), n, cols[0].data)
+        ctx.gen_column(G.gen_spec(abi.GEN_RAND_MOD, table=2, col=1, m=1 << 30), n, cols[1].data)
+        ctx.gen_column(G.gen_spec(abi.GEN_RAND_MOD, table=1, col=0, m=n), n, cols[2].data)
+        ctx.gen_column(G.gen_spec(abi.GEN_RAND_MOD, table=1, col=1, m=1 << 30), n, cols[3].data)
+        cfg = H.join_cfg([abi.I64, abi.I64], [abi.I64, abi.I64], [0], [0], abi.JOIN_INNER, 1)
+        sums = {}
+        for radix in (abi.RADIX_AUTO, abi.RADIX_OFF):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                _lib.check(lib.tsq_join_set_radix(h, radix), h)
+                _lib.check(lib.tsq_join_build_push(h, G.dev_cols(cols[:2]), 2, n), h)
+                _lib.check(lib.tsq_join_build_finish(h), h)
+                _lib.check(lib.tsq_join_probe_push(h, G.dev_cols(cols[2:]), 2, n, None), h)
+                _lib.check(lib.tsq_join_probe_finish(h), h)
+                total, acc = 0, [0, 0, 0, 0]
+                while True:
+                    m, eos = C.c_int64(0), C.c_int32(0)
+                    _lib.check(lib.tsq_join_pull(h, G.dev_cols(outs), 4, n, C.byref(m), C.byref(eos)), h)
+                    if m.value == 0:
+                        break
+                    got = [np.empty(m.value, np.int64) for _ in range(4)]
+                    for g, o in zip(got, outs):
+                        ctx.d2h(g, o.data)
+                    assert (got[0] == got[2]).all()  # probe key == build key on every joined row
+                    with np.errstate(over="ignore"):
+                        mix = (got[0].view(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (got[1].view(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) ^ got[3].view(np.uint64)
+                        acc[0] += int(mix.sum(dtype=np.uint64))
+                        acc[1] ^= int(np.bitwise_xor.reduce(mix))
+                    total += m.value
+                st = abi.Stats()
+                _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+                sums[radix] = (total, acc[0] & ((1 << 64) - 1), acc[1], st.radix_batches)
+            finally:
+                lib.tsq_join_destroy(h)
+        assert sums[abi.RADIX_AUTO][0] == n and sums[abi.RADIX_AUTO][:3] == sums[abi.RADIX_OFF][:3]
+        assert sums[abi.RADIX_AUTO][3] >= 1 and sums[abi.RADIX_OFF][3] == 0
+    finally:
+        for d in cols + outs:
+            d.free()

@@ -596,6 +596,10 @@ struct tsq_join {
     // radix probe path of the COUNT(*) fast path (tsq_radix.h)
     int32_t radix_mode = TSQ_RADIX_AUTO;
     DevBuf rkeys, rctl, rvend, rovf;  // partitioned keys | cursor + queue heads + overflow count | valid_end | overflow keys
+    DevBuf rpay[TSQ_LDS_MAXPAY], rovfpay[TSQ_LDS_MAXPAY];  // materialising radix path: probe payload columns travelling with the key
+    DevBuf tkcnt;                                          // ... joined rows per ticket, then their exclusive scan
+    DevBuf tpay[TSQ_LDS_MAXPAY];                           // ... build payload columns in table-slot order (k_table_payload)
+    bool tpay_ready = false;
     DevBuf bbase;                     // per-workgroup output bases of the materialising probe
     DevBuf pairs;                     // (probe row, build row) of every joined row of the current slice
     DevBuf firstcnt;                  // per probe row of the slice: first joined build row | output rows << 32
@@ -710,6 +714,46 @@ tsq_status dispatch_emit(tsq_join* j, ProbeArgs& a) {
     return TSQ_OK;
 }
 
+
+// hand a materialised batch (device columns) to tsq_join_pull: host pushes get it in pinned host memory (pulls are then plain memcpy)
+tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std::vector<bool>& may_null_v) {
+    tsq_ctx* ctx = j->ctx;
+    const int nout = j->cfg.n_probe_cols + j->cfg.n_build_cols;
+    const bool probe_is_left = j->cfg.build_is_right != 0;
+    const int nl = probe_is_left ? j->cfg.n_probe_cols : j->cfg.n_build_cols;
+    const int64_t out_rows = rb->rows;
+    if (j->host_mode) {
+        rb->hdata.resize(nout);
+        rb->hbitmap.resize(nout);
+        for (int oc = 0; oc < nout; oc++) {
+            const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
+            const int sc = oc < nl ? oc : oc - nl;
+            const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
+            size_t bytes = (size_t)out_rows * tsq_elem_size(type);
+            tsq_status s = rb->hdata[oc].reserve(&j->hdr, bytes + 16);
+            if (s != TSQ_OK) { rb->release(); return s; }
+            TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            j->st.d2h_bytes += bytes;
+            if (may_null_v[oc]) {
+                s = rb->hbitmap[oc].reserve(&j->hdr, tsq_bitmap_bytes(out_rows) + 16);
+                if (s != TSQ_OK) { rb->release(); return s; }
+                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hbitmap[oc].p, rb->bitmap[oc].p, tsq_bitmap_bytes(out_rows), hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
+        TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
+        for (auto& b : rb->data) b.release();
+        for (auto& b : rb->notnull) b.release();
+        for (auto& b : rb->bitmap) b.release();
+        rb->on_host = true;
+    } else {
+        TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
+        for (auto& b : rb->notnull) b.release();
+    }
+    j->total_out += out_rows;
+    j->st.out_rows += out_rows;
+    j->results.push_back(std::move(rb));
+    return TSQ_OK;
+}
 
 // ---------------------------------------------------------------- radix probe path (host side)
 // Eligible: COUNT(*) without checksum, inner join, one key column, no filters / conditions / selected[].
@@ -863,6 +907,212 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     return TSQ_OK;
 }
 
+// ---------------------------------------------------------------- materialising radix path (host side)
+// HashJoinExec.Next materialises every joined row (executor/join.go:125-146, joiner.go:351-378, chunk.go:334-356).  The direct
+// route sizes the batch with an unpartitioned probe (two random lines per probe row) and then gathers every output cell through
+// a row id (one random 8-byte read per cell: 42 G/s).  Here nothing is gathered from all over HBM:
+//   probe side : the payload columns travel with the key through the radix partition (tsq_radix.h, <= 2 columns)
+//   build side : the payload columns are kept a second time in TABLE-SLOT order (k_table_payload, once per build), so the emit
+//                pass reads them next to the slices it is probing
+//   keys       : both key columns are recovered from the table word (mix64 is a bijection)
+//   rows       : k_lds_probe_count<MODE 1> sizes every ticket, an exclusive scan turns that into output bases, <MODE 2> probes
+//                again and writes the joined rows column by column (unspecified row order, as in the reference).
+// Eligible: inner join on one BIGINT key of the same signedness, no conditions / filters / selected[] / ordered output,
+// <= 3 eight-byte columns per side without NULLs, a sliced table.  Everything else keeps the direct route.
+bool radix_emit_eligible(const tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->general || selected_dev || j->never_match || j->ordered) return false;
+    if (j->tb < TSQ_RADIX_MIN_BITS || nrows <= 0 || nrows > 0x7fffffffLL) return false;
+    if (j->cfg.n_probe_cols > 1 + TSQ_LDS_MAXPAY || j->cfg.n_build_cols > 1 + TSQ_LDS_MAXPAY) return false;
+    const int32_t kt = j->cfg.build_types[j->ks.bidx[0]];
+    if ((kt != TSQ_I64 && kt != TSQ_U64) || j->cfg.probe_types[j->ks.pidx[0]] != kt) return false;
+    for (int c = 0; c < j->cfg.n_probe_cols; c++)
+        if (tsq_elem_size(j->cfg.probe_types[c]) != 8 || pcs.nulls[c]) return false;
+    for (int c = 0; c < j->cfg.n_build_cols; c++)
+        if (tsq_elem_size(j->cfg.build_types[c]) != 8 || j->bcols[c].has_nulls) return false;
+    if (!radix_plan_for(j).lds) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (4 << 20);
+}
+
+tsq_status ensure_table_payload(tsq_join* j) {
+    if (j->tpay_ready) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    const uint64_t nslots = j->nbuckets * TSQ_BUCKET;
+    int v = 0;
+    for (int c = 0; c < j->cfg.n_build_cols; c++) {
+        if (c == j->ks.bidx[0]) continue;
+        TSQ_TRY(j->tpay[v].reserve(ctx, &j->hdr, nslots * 8 + 64));
+        hipLaunchKernelGGL(k_table_payload, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, j->tkeys.as<uint64_t>(), j->tvals.as<uint32_t>(),
+                           j->bcols[c].data.as<uint64_t>(), j->tpay[v].as<uint64_t>(), nslots);
+        TSQ_HIP(&j->hdr, hipGetLastError());
+        j->st.kernel_launches++;
+        v++;
+    }
+    j->tpay_ready = true;
+    return TSQ_OK;
+}
+
+tsq_status radix_emit(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    TSQ_TRY(ensure_table_payload(j));
+    const RadixPlan pl = radix_plan_for(j);
+    RadixStore st;
+    memset(&st, 0, sizeof st);
+    st.bits = pl.bits;
+    st.R = 8;
+    const uint32_t P = 1u << st.bits;
+    const int V = j->cfg.n_probe_cols - 1;
+    const int K = V == 0 ? 16 : (V == 1 ? 8 : 4), T = 1024 * K;
+    const double lam = (double)nrows / ((double)P * 8.0);
+    st.cap = (uint32_t)(lam * 1.08 + 8.0 * sqrt(lam) + 2.0 * T / 64.0 + 64.0);
+    st.cap = (st.cap + 15u) & ~15u;
+    const size_t nregions = (size_t)P * 8;
+    if (nregions * st.cap >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "radix probe batch too large");
+    const size_t ctl_words32 = nregions + 16;
+    const size_t q_off = (ctl_words32 * 4 + 511) & ~(size_t)511, q_bytes = 8 * TSQ_RADIX_QSTRIDE * 8, ctl_bytes = q_off + q_bytes;
+    TSQ_TRY(j->rkeys.reserve(ctx, h, nregions * st.cap * 8 + 256));
+    TSQ_TRY(j->rctl.reserve(ctx, h, ctl_bytes));
+    TSQ_TRY(j->rvend.reserve(ctx, h, nregions * 4));
+    TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 8 + 64));
+    for (int v = 0; v < V; v++) {
+        TSQ_TRY(j->rpay[v].reserve(ctx, h, nregions * st.cap * 8 + 256));
+        TSQ_TRY(j->rovfpay[v].reserve(ctx, h, (size_t)nrows * 8 + 64));
+        st.pay[v] = j->rpay[v].as<uint64_t>();
+        st.ovf_pay[v] = j->rovfpay[v].as<uint64_t>();
+    }
+    st.keys = j->rkeys.as<uint64_t>();
+    st.cursor = j->rctl.as<uint32_t>();
+    st.ovf_count = st.cursor + nregions;
+    st.queue = (unsigned long long*)((char*)j->rctl.p + q_off);
+    st.valid_end = j->rvend.as<uint32_t>();
+    st.ovf_keys = j->rovf.as<uint64_t>();
+    st.ovf_cap = (uint32_t)nrows;
+    const uint32_t ntk = (P >> 3) * pl.S;
+    const size_t n_tk = (size_t)8 * ntk + 1;  // [xcd][ticket], then one more word: the exclusive scan leaves the total there
+    TSQ_TRY(j->tkcnt.reserve(ctx, h, n_tk * 8 + 64));
+    TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, ctl_bytes, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, nregions * 4, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->tkcnt.p, 0, n_tk * 8, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 4, 0, 16, ctx->stream));  // [4] joined rows of the overflow list, [5] its output cursor
+
+    RadixSrc src;
+    memset(&src, 0, sizeof src);
+    const int kc = j->ks.pidx[0];
+    src.data = pcs.data[kc];
+    src.type = pcs.type[kc];
+    src.nrows = nrows;
+    {
+        int v = 0;
+        for (int c = 0; c < j->cfg.n_probe_cols; c++) {
+            if (c == kc) continue;
+            src.vdata[v] = pcs.data[c];
+            src.vtype[v] = pcs.type[c];
+            v++;
+        }
+    }
+    const int64_t ntiles = (nrows + T - 1) / T;
+    const int pgrid = (int)std::min<int64_t>(ntiles, ctx->num_cus);
+    hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
+    for (int e = 0; e < 3; e++)
+        if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    if (V == 0) hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, 0, false, true>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
+    else if (V == 1) hipLaunchKernelGGL((k_radix_partition<1024, 8, 4, 1, false, true>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
+    else hipLaunchKernelGGL((k_radix_partition<1024, 4, 4, 2, false, true>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
+    constexpr int LNT = 1024;
+    LdsProbeArgs la;
+    memset(&la, 0, sizeof la);
+    la.st = st;
+    fill_table(j, la.t);
+    la.S = pl.S;
+    la.nf = pl.nf;
+    la.unique = j->unique ? 1u : 0u;
+    la.counters = j->counters.as<unsigned long long>();
+    la.tk_cnt = j->tkcnt.as<unsigned long long>();
+    const int lgrid = std::max(1, ctx->num_cus / 8) * 8;
+    const size_t img = (size_t)pl.nf * j->bs * 64;
+    const size_t lds1 = img + (size_t)(LNT / 64) * TSQ_LDS_RING_BYTES, lds2 = img + (size_t)(LNT / 64) * TSQ_LDS_RING_BYTES_EMIT;
+    if (lds2 + 256 > 160 * 1024) return tsq_fail(h, TSQ_ERR_INVALID, "internal: LDS image + rings exceed 160 KB");
+    // ---- sizing pass
+    TSQ_HIP(h, hipFuncSetAttribute((const void*)k_lds_probe_count<LNT, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    hipLaunchKernelGGL((k_lds_probe_count<LNT, false, 1>), dim3(lgrid), dim3(LNT), lds1, ctx->stream, la);
+    TSQ_HIP(h, hipGetLastError());
+    RadixProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.st = st;
+    pa.t = la.t;
+    pa.counters = (unsigned long long*)(ctx->dscratch + 4);
+    hipLaunchKernelGGL(k_radix_probe_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, la.tk_cnt, (int)n_tk);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 32, la.tk_cnt + (n_tk - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 33, ctx->dscratch + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const int64_t tk_rows = (int64_t)ctx->pinned[32], ovf_rows = (int64_t)ctx->pinned[33], out_rows = tk_rows + ovf_rows;
+    j->st.kernel_launches += 4;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)st.bits;
+    if (out_rows == 0) {
+        TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+        TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    // ---- output batch
+    const int nout = j->cfg.n_probe_cols + j->cfg.n_build_cols;
+    const bool probe_is_left = j->cfg.build_is_right != 0;
+    const int nl = probe_is_left ? j->cfg.n_probe_cols : j->cfg.n_build_cols;
+    std::unique_ptr<ResultBatch> rb(new ResultBatch());
+    rb->rows = out_rows;
+    rb->data.resize(nout);
+    rb->notnull.resize(nout);
+    rb->bitmap.resize(nout);
+    std::vector<bool> may_null_v(nout, false);
+    for (int oc = 0; oc < nout; oc++) {
+        tsq_status s = rb->data[oc].reserve(ctx, h, ((size_t)out_rows + 8) * 8 + 16);
+        if (s != TSQ_OK) { rb->release(); return s; }
+    }
+    {
+        int pv = 0, bv = 0;
+        la.n_out_probe = j->cfg.n_probe_cols;
+        la.n_out_build = j->cfg.n_build_cols;
+        for (int c = 0; c < j->cfg.n_probe_cols; c++) {
+            la.out_probe[c] = rb->data[probe_is_left ? c : nl + c].as<uint64_t>();
+            la.probe_src[c] = c == kc ? -1 : pv++;
+        }
+        for (int c = 0; c < j->cfg.n_build_cols; c++) {
+            la.out_build[c] = rb->data[probe_is_left ? nl + c : c].as<uint64_t>();
+            if (c == j->ks.bidx[0]) {
+                la.build_src[c] = -1;
+            } else {
+                la.bpay[bv] = j->tpay[bv].as<uint64_t>();
+                la.bcol[bv] = j->bcols[c].data.as<uint64_t>();
+                la.build_src[c] = bv++;
+            }
+        }
+    }
+    // ---- emit pass: the same tickets again (queue heads back to zero), then the overflow list behind the tickets' rows
+    TSQ_HIP(h, hipMemsetAsync(st.queue, 0, q_bytes, ctx->stream));
+    ctx->pinned[34] = (uint64_t)tk_rows;
+    TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 5, ctx->pinned + 34, 8, hipMemcpyHostToDevice, ctx->stream));
+    la.ovf_cursor = (unsigned long long*)(ctx->dscratch + 5);
+    TSQ_HIP(h, hipFuncSetAttribute((const void*)k_lds_probe_count<LNT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    hipLaunchKernelGGL((k_lds_probe_count<LNT, false, 2>), dim3(lgrid), dim3(LNT), lds2, ctx->stream, la);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_lds_emit_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, la);
+    TSQ_HIP(h, hipGetLastError());
+    j->st.kernel_launches += 2;
+    TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+    j->have_probe_ev = true;
+    return deliver_batch(j, std::move(rb), may_null_v);
+}
+
 // run the probe kernels over one device-resident batch described by pcs / selected
 tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
     if (nrows == 0) return TSQ_OK;
@@ -885,6 +1135,7 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     j->st.probe_rows += nrows;
 
     if (radix_eligible(j, nrows, selected_dev)) return radix_probe(j, pcs, nrows);
+    if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
     if (j->count_only) {
         TSQ_TRY(dispatch_count(j, a, j->checksum));
@@ -969,37 +1220,7 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     }
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
     j->have_probe_ev = true;
-    if (j->host_mode) {  // bring the batch to pinned host memory once; pulls are then plain memcpy
-        rb->hdata.resize(nout);
-        rb->hbitmap.resize(nout);
-        for (int oc = 0; oc < nout; oc++) {
-            const bool from_probe = a.probe_is_left ? oc < nl : oc >= nl;
-            const int sc = oc < nl ? oc : oc - nl;
-            const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
-            size_t bytes = (size_t)out_rows * tsq_elem_size(type);
-            tsq_status s = rb->hdata[oc].reserve(&j->hdr, bytes + 16);
-            if (s != TSQ_OK) { rb->release(); return s; }
-            TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-            j->st.d2h_bytes += bytes;
-            if (may_null_v[oc]) {
-                s = rb->hbitmap[oc].reserve(&j->hdr, tsq_bitmap_bytes(out_rows) + 16);
-                if (s != TSQ_OK) { rb->release(); return s; }
-                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hbitmap[oc].p, rb->bitmap[oc].p, tsq_bitmap_bytes(out_rows), hipMemcpyDeviceToHost, ctx->stream));
-            }
-        }
-        TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
-        for (auto& b : rb->data) b.release();
-        for (auto& b : rb->notnull) b.release();
-        for (auto& b : rb->bitmap) b.release();
-        rb->on_host = true;
-    } else {
-        TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
-        for (auto& b : rb->notnull) b.release();
-    }
-    j->total_out += out_rows;
-    j->st.out_rows += out_rows;
-    j->results.push_back(std::move(rb));
-    return TSQ_OK;
+    return deliver_batch(j, std::move(rb), may_null_v);
 }
 
 tsq_status probe_flush(tsq_join* j) {
@@ -1471,7 +1692,8 @@ TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t
         tsq_colset_from_cols(pcs, cols, n_cols);
         // process in slices so an emit batch stays bounded
         // device-resident input: larger emit batches (every batch costs a count pass, two host syncs and its output buffers)
-        const int64_t slice = j->count_only ? nrows : std::max<int64_t>(j->cfg.probe_batch_rows, 32 << 20);
+        // (the materialising radix path partitions the whole push at once: its passes are the better the longer the partitions)
+        const int64_t slice = (j->count_only || radix_emit_eligible(j, pcs, nrows, selected)) ? nrows : std::max<int64_t>(j->cfg.probe_batch_rows, 32 << 20);
         for (int64_t off = 0; off < nrows; off += slice) {
             const int64_t n = std::min<int64_t>(slice, nrows - off);
             tsq_colset s;
@@ -1632,6 +1854,7 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
         for (int64_t b = j->st.radix_batches - nt; b < j->st.radix_batches; b++) {
             hipEvent_t* re = j->rev[b % tsq_join::RING];
             float pm = 0, qm = 0;
+            if (!re[0] || !re[1] || !re[2]) continue;
             if (hipEventElapsedTime(&pm, re[0], re[1]) != hipSuccess || hipEventElapsedTime(&qm, re[1], re[2]) != hipSuccess) continue;
             j->st.partition_kernel_ms_sum += pm;
             j->st.radix_probe_kernel_ms_sum += qm;
@@ -1676,6 +1899,12 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->rctl.release();
     j->rvend.release();
     j->rovf.release();
+    j->tkcnt.release();
+    for (int v = 0; v < TSQ_LDS_MAXPAY; v++) {
+        j->rpay[v].release();
+        j->rovfpay[v].release();
+        j->tpay[v].release();
+    }
     j->hdr.magic = 0;
     delete j;
 }

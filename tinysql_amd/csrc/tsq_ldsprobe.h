@@ -44,6 +44,8 @@
 #define TSQ_LDS_IMAGE_MAX (128 * 1024)
 #define TSQ_LDS_RING 128  // entries per wave ring: <= 63 left over + <= 64 new per step / continuations per round
 #define TSQ_LDS_RING_BYTES (TSQ_LDS_RING * 10)  // 8-byte word + 2-byte hop count
+#define TSQ_LDS_RING_BYTES_EMIT (TSQ_LDS_RING * 14)  // ... + 4-byte position in the partitioned store
+#define TSQ_LDS_MAXPAY 2
 
 typedef unsigned long long tsq_u64x2 __attribute__((ext_vector_type(2)));
 // 16-byte streaming load (read once: do not keep the line in L1 / prefer eviction in L2)
@@ -73,7 +75,30 @@ struct LdsProbeArgs {
     uint32_t unique; // the build saw no two equal table words: a probe word that has found its slot is done
     unsigned long long* counters;  // [0] += joined rows
     unsigned long long* prof;      // PROF kernels: [0..7] += shader cycles per phase, summed over waves (see k_lds_probe_count)
+    // MODE 1 (sizing pass of the materialising join): joined rows per ticket -> tk_cnt[xcd * ntk + ticket]; MODE 2 (emit pass): the
+    // exclusive scan of those counts = first output row of every ticket
+    unsigned long long* tk_cnt;
+    // MODE 2: joined rows are written column by column.  A probe / build output column is the key (src -1: recovered from the
+    // table word, mix64 is a bijection) or payload column src (probe: st.pay[src] travels with the key through the partition;
+    // build: bpay[src][slot] = the payload cell of the build row in table slot `slot`, see k_table_payload)
+    uint64_t* out_probe[1 + TSQ_LDS_MAXPAY];
+    uint64_t* out_build[1 + TSQ_LDS_MAXPAY];
+    int32_t probe_src[1 + TSQ_LDS_MAXPAY], build_src[1 + TSQ_LDS_MAXPAY];
+    int32_t n_out_probe, n_out_build;
+    const uint64_t* bpay[TSQ_LDS_MAXPAY];
+    const uint64_t* bcol[TSQ_LDS_MAXPAY];  // the same payload columns by build ROW (the side list of the sentinel word holds row ids)
+    unsigned long long* ovf_cursor;        // k_lds_emit_ovf: next output row of the overflow list's joined rows
 };
+
+// inverse of tsq_mix64 (murmur3 finaliser): the key word of a table word
+__device__ __forceinline__ uint64_t tsq_unmix64(uint64_t w) {
+    w ^= w >> 33;
+    w *= 0x9CB4B2F8129337DBULL;  // inverse of 0xC4CEB9FE1A85EC53 mod 2^64
+    w ^= w >> 33;
+    w *= 0x4F74430C22A54005ULL;  // inverse of 0xFF51AFD7ED558CCD mod 2^64
+    w ^= w >> 33;
+    return w;
+}
 
 // Vector-memory results return in order and s_waitcnt counts them, so every wave issues a FIXED sequence of loads: a load
 // that has nothing to fetch (past the end of a region, past the last chunk) is still issued, on a clamped address, and its
@@ -81,7 +106,8 @@ struct LdsProbeArgs {
 // the prefetch distance away: 2.2 ms per 1e8 keys instead of 0.4.
 // PROF: per-wave shader-cycle sums (s_memtime) -> a.prof: [0] image store + barrier A, [1] waits for chunk loads, [2] slice
 // test + ring, [3] bucket compares, [4] drain + barrier B, [5] whole ticket loop, [6] probe calls, [7] bucket reads.
-template <int NT, bool PROF = false>
+// MODE 0: COUNT(*) (one total); 1: joined rows per ticket (sizing pass of the materialising join); 2: emit the joined rows.
+template <int NT, bool PROF = false, int MODE = 0>
 __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
     constexpr int NW = NT / 64;
     unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -105,6 +131,9 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
     uint64_t* s_img = reinterpret_cast<uint64_t*>(s_dyn);
     uint64_t* s_ring = s_img + img_words + (size_t)wave * TSQ_LDS_RING;                                      // words waiting for a probe round
     uint16_t* s_hop = reinterpret_cast<uint16_t*>(s_img + img_words + (size_t)NW * TSQ_LDS_RING) + (size_t)wave * TSQ_LDS_RING;  // ... and how far along their chain
+    uint32_t* s_gix = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(s_img + img_words) + (size_t)NW * TSQ_LDS_RING * 10) + (size_t)wave * TSQ_LDS_RING;  // MODE 2: where the word sits in the store
+    __shared__ unsigned long long s_tkcnt;  // MODE 1: joined rows of the current ticket; MODE 2: first output row of the ticket
+    __shared__ uint32_t s_out;              // MODE 2: output rows handed out inside the ticket
     auto take = [&]() -> uint32_t {
         return (uint32_t)__hip_atomic_fetch_add(&a.st.queue[vx * TSQ_RADIX_QSTRIDE], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -153,6 +182,12 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
             }
         }
         if (tid < 8) s_len[tid] = radix_region_len(a.st, P, p, tid);
+        if (MODE == 1 && tid == 8) s_tkcnt = 0;
+        if (MODE == 2 && tid == 8) {
+            s_tkcnt = a.tk_cnt[(size_t)vx * ntk + tk];
+            s_out = 0;
+        }
+        const uint32_t cnt0 = cnt;
         __syncthreads();  // A: image and region lengths are in LDS
         if (PROF) pf[0] += now() - t0;
         const uint32_t tkn = (uint32_t)__builtin_amdgcn_readfirstlane(s_tk[(it + 1) & 1u]);
@@ -162,25 +197,28 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
         const uint32_t rg = wave & 7u, rlen = (uint32_t)__builtin_amdgcn_readfirstlane(s_len[rg]);
         const uint32_t nck = (rlen + 127u) / 128u;
         const uint64_t* rbase = a.st.keys + ((size_t)p * 8u + rg) * a.st.cap;
-        auto chunk_load = [&](uint32_t k, tsq_u64x2& v, uint32_t& nv) {
+        const uint32_t gbase = (uint32_t)(((size_t)p * 8u + rg) * a.st.cap);  // the store has < 2^32 slots (host check)
+        auto chunk_load = [&](uint32_t k, tsq_u64x2& v, uint32_t& nv, uint32_t& gi) {
             const uint32_t off = k * 128u + lane * 2u;
             nv = off + 1u < rlen ? 2u : (off < rlen ? 1u : 0u);  // a chunk past the end loads the region's first line (ignored)
+            gi = gbase + off;
             async_nt_load16(v, rbase + (off < rlen ? off : 0u));
         };
         tsq_u64x2 v[D];
-        uint32_t nv[D];
+        uint32_t nv[D], gi[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) chunk_load(wave / 8u + (uint32_t)d * (NW / 8), v[d], nv[d]);
+        for (int d = 0; d < D; d++) chunk_load(wave / 8u + (uint32_t)d * (NW / 8), v[d], nv[d], gi[d]);
         image_load(tkn);          // in flight while this ticket's keys are probed
         uint32_t qh = 0, qt = 0;  // ring head / tail (wave uniform)
         // compaction append of (word, hop) for the lanes in `on`
-        auto push = [&](bool on, uint64_t w, uint32_t hop) {
+        auto push = [&](bool on, uint64_t w, uint32_t hop, uint32_t gx) {
             const uint64_t m = __ballot(on);
             if (m) {
                 if (on) {
                     const uint32_t pos = (qt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (TSQ_LDS_RING - 1);
                     s_ring[pos] = w;
                     s_hop[pos] = (uint16_t)hop;
+                    if (MODE == 2) s_gix[pos] = gx;
                 }
                 qt += (uint32_t)__popcll(m);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -193,17 +231,34 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
             const uint32_t pos = (qh + lane) & (TSQ_LDS_RING - 1);
             qh += n;
             bool go_on = false;
-            uint64_t x = 0;
-            uint32_t hop = 0;
+            uint64_t x = 0, gbkt = 0;
+            uint32_t hop = 0, gx = 0, mm = 0;  // mm: which of the eight slots of this lane's bucket hold its word (MODE 2)
+            uint64_t ppay[TSQ_LDS_MAXPAY] = {0, 0};
             if (lane < n) {  // (the compares below then leave the bits of idle lanes clear: no mask arithmetic)
                 x = s_ring[pos];
                 hop = s_hop[pos];
+                if (MODE == 2) {
+                    gx = s_gix[pos];
+#pragma unroll
+                    for (int vv = 0; vv < TSQ_LDS_MAXPAY; vv++)
+                        if (a.st.pay[vv]) ppay[vv] = a.st.pay[vv][gx];  // the probe row's payload: in flight while the bucket is compared
+                }
                 if (x == TSQ_EMPTY_KEY) {
                     cnt += a.t.sent_count;  // the sentinel word matches the side list only
+                    if (MODE == 2 && a.t.sent_count) {
+                        const uint64_t key = tsq_unmix64(x);
+                        const uint64_t row0 = s_tkcnt + atomicAdd(&s_out, a.t.sent_count);
+                        for (uint32_t i = 0; i < a.t.sent_count; i++) {
+                            const uint32_t brow = a.t.sent_rows[i];
+                            for (int oc = 0; oc < a.n_out_probe; oc++) a.out_probe[oc][row0 + i] = a.probe_src[oc] < 0 ? key : ppay[a.probe_src[oc]];
+                            for (int oc = 0; oc < a.n_out_build; oc++) a.out_build[oc][row0 + i] = a.build_src[oc] < 0 ? key : a.bcol[a.build_src[oc]][brow];
+                        }
+                    }
                 } else {
                     uint32_t lb = jt_local(tb, bs, x) + hop;
                     lb = lb >= bs ? lb - bs : lb;
-                    const uint64_t* bk = s_img + ((size_t)((uint32_t)(x >> sh) - f0) * bs + lb) * TSQ_BUCKET;
+                    const uint32_t lbkt = ((uint32_t)(x >> sh) - f0) * bs + lb;  // bucket inside the image
+                    const uint64_t* bk = s_img + (size_t)lbkt * TSQ_BUCKET;
                     const ulonglong2* b = reinterpret_cast<const ulonglong2*>(bk);
                     const ulonglong2 q0 = b[lane & 3u], q1 = b[(lane + 1u) & 3u], q2 = b[(lane + 2u) & 3u], q3 = b[(lane + 3u) & 3u];
                     const uint64_t last = bk[TSQ_BUCKET - 1];  // slots are claimed front to back: the bucket is full iff its LAST slot is taken
@@ -211,16 +266,48 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
                                        (uint32_t)(q2.x == x) + (uint32_t)(q2.y == x) + (uint32_t)(q3.x == x) + (uint32_t)(q3.y == x);
                     cnt += c;
                     go_on = last != TSQ_EMPTY_KEY && !(a.unique && c) && hop + 1u < bs;
+                    if (MODE == 2 && c) {
+                        // one output row per matching slot.  The lanes of the round share ONE block of output rows (LDS cursor +
+                        // prefix sum of the per-lane match counts); a lane writes the cells of its rows column by column.  The loop
+                        // runs over a lane's k-th match, so a unique table takes ONE pass: one payload load in flight per lane, the
+                        // rows of neighbouring lanes next to each other.  (A loop over the eight slots instead put eight dependent
+                        // global loads one after the other into every round: 5.4 ms per 1e8 rows.)
+                        mm = (uint32_t)(q0.x == x) | ((uint32_t)(q0.y == x) << 1) | ((uint32_t)(q1.x == x) << 2) | ((uint32_t)(q1.y == x) << 3) |
+                             ((uint32_t)(q2.x == x) << 4) | ((uint32_t)(q2.y == x) << 5) | ((uint32_t)(q3.x == x) << 6) | ((uint32_t)(q3.y == x) << 7);
+                        gbkt = (uint64_t)f0 * bs + lbkt;  // bucket in the whole table
+                    }
                 }
             }
-            push(go_on, x, hop + 1u);
+            if (MODE == 2) {
+                const uint64_t any = __ballot(mm != 0);
+                if (any) {  // wave uniform
+                    const uint32_t c = (uint32_t)__popc(mm);
+                    uint32_t tot;
+                    const uint32_t pre = wave_excl_scan_u32(c, &tot);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_out, tot);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane(base);
+                    const uint64_t key = tsq_unmix64(x);
+                    uint64_t row = s_tkcnt + base + pre;
+                    while (mm) {
+                        const uint32_t i = (uint32_t)__builtin_ctz(mm);
+                        mm &= mm - 1u;
+                        const uint32_t slot = 2u * ((lane + (i >> 1)) & 3u) + (i & 1u);  // bit i = piece (lane + i / 2) & 3, word i & 1
+                        for (int oc = 0; oc < a.n_out_probe; oc++) a.out_probe[oc][row] = a.probe_src[oc] < 0 ? key : ppay[a.probe_src[oc]];
+                        for (int oc = 0; oc < a.n_out_build; oc++)
+                            a.out_build[oc][row] = a.build_src[oc] < 0 ? key : a.bpay[a.build_src[oc]][gbkt * TSQ_BUCKET + slot];
+                        row++;
+                    }
+                }
+            }
+            push(go_on, x, hop + 1u, gx);
             if (PROF) {
                 pf[3] += now() - tp;
                 pf[6]++;
             }
         };
-        auto step = [&](uint64_t w, bool valid) {
-            push(valid && ((uint32_t)(w >> sh) - f0) < nfi, w, 0u);
+        auto step = [&](uint64_t w, bool valid, uint32_t gx) {
+            push(valid && ((uint32_t)(w >> sh) - f0) < nfi, w, 0u, gx);
             while (qt - qh >= 64u) probe_round(64u);
         };
         for (uint32_t k = wave / 8u; k < nck; k += D * (NW / 8)) {
@@ -229,13 +316,13 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
                 const unsigned long long tw = now();
                 async_wait<D - 1>(v[d]);
                 const unsigned long long ts = now();
-                step(v[d].x, nv[d] >= 1);
-                step(v[d].y, nv[d] >= 2);
+                step(v[d].x, nv[d] >= 1, gi[d]);
+                step(v[d].y, nv[d] >= 2, gi[d] + 1u);
                 if (PROF) {
                     pf[1] += ts - tw;
                     pf[2] += now() - ts;
                 }
-                chunk_load(k + (uint32_t)(d + D) * (NW / 8), v[d], nv[d]);  // reload only after use: no register copy, D - 1 chunks ahead
+                chunk_load(k + (uint32_t)(d + D) * (NW / 8), v[d], nv[d], gi[d]);  // reload only after use: no register copy, D - 1 chunks ahead
             }
         }
         const unsigned long long td = now();
@@ -243,7 +330,12 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
         static_assert(D == 4, "drain lists v[0..3]");
         while (qt != qh) probe_round(qt - qh < 64u ? qt - qh : 64u);  // the last, partial rounds (and their continuations)
+        if (MODE == 1) {  // joined rows of this ticket
+            const uint64_t wsum = wave_sum_u64((uint64_t)(cnt - cnt0));
+            if (lane == 0 && wsum) atomicAdd(&s_tkcnt, (unsigned long long)wsum);
+        }
         __syncthreads();  // B: nobody reads the image or s_tk[(it + 1) & 1] any more
+        if (MODE == 1 && tid == 8) a.tk_cnt[(size_t)vx * ntk + tk] = s_tkcnt;  // (thread 8 also clears it for the next ticket)
         if (PROF) pf[4] += now() - td;
         if (tid == 0) {   // ticket of iteration it + 2 (its atomic has been in flight since the previous iteration)
             s_tk[it & 1u] = pend;
@@ -260,7 +352,40 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
     const uint64_t ws = wave_sum_u64(cnt);
     if (lane == 0 && ws) atomicAdd(&s_total, (unsigned long long)ws);
     __syncthreads();
-    if (tid == 0 && s_total) atomicAdd(&a.counters[0], s_total);  // one device atomic per workgroup
+    if (MODE == 0 && tid == 0 && s_total) atomicAdd(&a.counters[0], s_total);  // one device atomic per workgroup
+}
+
+// the joined rows of the store's overflow list (skewed partitions): plain grid-stride probe of the table in HBM, output
+// rows from one device cursor (the list is short or empty)
+static __global__ void __launch_bounds__(256) k_lds_emit_ovf(LdsProbeArgs a) {
+    uint32_t n = *a.st.ovf_count;
+    n = n < a.st.ovf_cap ? n : a.st.ovf_cap;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint64_t w = a.st.ovf_keys[i], key = tsq_unmix64(w);
+        uint64_t ppay[TSQ_LDS_MAXPAY] = {0, 0};
+#pragma unroll
+        for (int vv = 0; vv < TSQ_LDS_MAXPAY; vv++)
+            if (a.st.ovf_pay[vv]) ppay[vv] = a.st.ovf_pay[vv][i];
+        auto emit = [&](uint64_t bval_idx, bool by_row) {
+            const unsigned long long row = atomicAdd(a.ovf_cursor, 1ull);
+            for (int oc = 0; oc < a.n_out_probe; oc++) a.out_probe[oc][row] = a.probe_src[oc] < 0 ? key : ppay[a.probe_src[oc]];
+            for (int oc = 0; oc < a.n_out_build; oc++)
+                a.out_build[oc][row] = a.build_src[oc] < 0 ? key : (by_row ? a.bcol[a.build_src[oc]][bval_idx] : a.bpay[a.build_src[oc]][bval_idx]);
+        };
+        if (w == TSQ_EMPTY_KEY) {
+            for (uint32_t q = 0; q < a.t.sent_count; q++) emit(a.t.sent_rows[q], true);
+        } else {
+            for_each_slot_w(a.t, w, [&](uint64_t slot) { emit(slot, false); });
+        }
+    }
+}
+
+// bpay[slot] = payload cell of the build row that sits in table slot `slot` (0 for an empty slot): the build side's payload
+// column in TABLE order, so that the emit pass reads it next to the slice it is probing instead of gathering it by row id
+// from all over HBM (one random 8-byte read per joined row: 42 G/s, 2.4 ms per 1e8 rows and column)
+static __global__ void __launch_bounds__(256) k_table_payload(const uint64_t* keys, const uint32_t* vals, const uint64_t* col, uint64_t* out, uint64_t nslots) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nslots; i += (uint64_t)gridDim.x * 256)
+        out[i] = keys[i] != TSQ_EMPTY_KEY ? col[vals[i]] : 0ull;
 }
 
 #endif
