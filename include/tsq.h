@@ -54,7 +54,8 @@ enum {
     TSQ_U64 = 1,   /* same 8 bytes, UNSIGNED flag set in FieldType.Flag                         */
     TSQ_F32 = 2,   /* float, 4 bytes                                                            */
     TSQ_F64 = 3,   /* double, 8 bytes                                                           */
-    TSQ_BYTES = 4  /* var-len (offsets[n+1] + data); not accelerated -> TSQ_ERR_UNSUPPORTED     */
+    TSQ_BYTES = 4  /* var-len (offsets[n+1] + data), binary collation: expression inputs (string builtins);
+                      the join / aggregate operators still answer TSQ_ERR_UNSUPPORTED for such a column      */
 };
 
 /* tsq_col.flags */
@@ -164,7 +165,20 @@ enum {
     TSQ_OP_IF_REAL = 53,    /* :163 */
     /* IN (builtin_other_vec_generated.go); arg = number of list items n (stack: x, v1..vn) */
     TSQ_OP_IN_INT = 60,     /* :24, flags bit0 = x unsigned; unsigned-ness of item j in in_unsigned_mask bit j */
-    TSQ_OP_IN_REAL = 61     /* :151 */
+    TSQ_OP_IN_REAL = 61,    /* :151 */
+    /* strings (types.EvalType ETString), binary collation: types.CompareString = bytes.Compare.  A string VALUE on the evaluation
+     * stack is a reference (source column or the program's constant pool, byte offset, length): no bytes are copied. */
+    TSQ_OP_COL_STR = 70,        /* arg = column index (TSQ_BYTES)        (expression/column.go:106-129)              */
+    TSQ_OP_CONST_STR = 71,      /* arg = const index: consts[arg] = (offset into str_pool << 32) | length            */
+    TSQ_OP_CONST_NULL_STR = 72,
+    TSQ_OP_LT_STR = 73, TSQ_OP_LE_STR = 74, TSQ_OP_GT_STR = 75, TSQ_OP_GE_STR = 76,  /* builtin_compare_vec_generated.go:65,147,229,311 */
+    TSQ_OP_EQ_STR = 77, TSQ_OP_NE_STR = 78,                                          /* :393, :475                                      */
+    TSQ_OP_STRCMP = 79,         /* builtin_string_vec.go:52  -> -1 / 0 / 1                                          */
+    TSQ_OP_LENGTH = 80,         /* builtin_string_vec.go:89  -> bytes                                               */
+    TSQ_OP_ISNULL_STR = 81,     /* builtin_string_vec.go:21 (builtinStringIsNullSig)                                */
+    TSQ_OP_IFNULL_STR = 82,     /* builtin_control_vec_generated.go:81                                              */
+    TSQ_OP_IF_STR = 83,         /* builtin_control_vec_generated.go:209 (cond is Int; value args String)            */
+    TSQ_OP_IN_STR = 84          /* builtin_other_vec_generated.go:97; arg = number of list items                    */
 };
 /* tsq_expr_op.flags */
 #define TSQ_F_LHS_UNSIGNED 1u
@@ -181,15 +195,21 @@ typedef struct tsq_expr_op {
 #define TSQ_EXPR_MAX_OPS 64
 #define TSQ_EXPR_MAX_STACK 12
 #define TSQ_EXPR_MAX_CONSTS 32
+#define TSQ_EXPR_STR_POOL 256
 
-/* One expression tree in postfix form.  result_type: TSQ_I64 (Int, also used for U64) or TSQ_F64. */
+/* One expression tree in postfix form.  result_type: TSQ_I64 (Int, also used for U64) or TSQ_F64: the ROOT of a program is
+ * Int or Real (a projection that is a bare string column is a column swap in the reference too, chunk.go:231-235; a string-valued
+ * root such as IF(c, s1, s2) keeps the Go evaluator).  String-valued nodes below the root are evaluated here. */
 typedef struct tsq_expr_prog {
     int32_t     n_ops;
     int32_t     n_consts;
     int32_t     result_type;
     int32_t     result_unsigned; /* UNSIGNED flag of the result FieldType (informational) */
     tsq_expr_op ops[TSQ_EXPR_MAX_OPS];
-    int64_t     consts[TSQ_EXPR_MAX_CONSTS]; /* int64 or the bit pattern of a double */
+    int64_t     consts[TSQ_EXPR_MAX_CONSTS]; /* int64, the bit pattern of a double, or (offset << 32 | length) of a string constant */
+    int32_t     n_str_bytes;                 /* bytes used in str_pool */
+    int32_t     reserved;
+    uint8_t     str_pool[TSQ_EXPR_STR_POOL]; /* the bytes of the string constants */
 } tsq_expr_prog;
 
 typedef struct tsq_expr tsq_expr;

@@ -202,17 +202,30 @@ namespace {
 // ------------------------------------------------------------------ expressions
 // A materialised intermediate column (what every builtin*Sig.vecEval* produces).
 struct ECol {
-    bool real = false;
+    bool real = false, str = false;
     std::vector<int64_t> i;
     std::vector<double> f;
+    std::vector<std::string> s;  // ETString results: the evaluator copies the bytes, like Column.AppendString
     std::vector<uint8_t> null;  // 1 = NULL
     void resize(int64_t n, bool r) {
         real = r;
+        str = false;
         null.assign(n, 0);
         if (r) f.assign(n, 0.0);
         else i.assign(n, 0);
     }
+    void resize_str(int64_t n) {
+        real = false;
+        str = true;
+        null.assign(n, 0);
+        s.assign(n, std::string());
+    }
 };
+// types/compare.go:115-123 CompareString: Go's string order is byte-wise lexicographic
+inline int cmp_string(const std::string& x, const std::string& y) {
+    const int c = x.compare(y);  // char_traits<char>::compare = memcmp, then the lengths
+    return c < 0 ? -1 : (c == 0 ? 0 : 1);
+}
 
 inline int64_t wrap_neg(int64_t v) { return (int64_t)(0 - (uint64_t)v); }          // Go -v wraps
 inline int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
@@ -610,12 +623,130 @@ tsq_status eval_prog(const tsq_expr_prog& p, EvalCtx& cx, ECol& out) {
                 st.push_back(std::move(r));
                 break;
             }
+            // ---------------- strings (ETString), binary collation
+            case TSQ_OP_COL_STR: {  // expression/column.go:106-129 VecEvalString -> CopyReconstruct(sel)
+                if (op.arg >= cx.n_cols) { g_err = "column index out of range"; return TSQ_ERR_INVALID; }
+                const tsq_col& c = cx.cols[op.arg];
+                if (c.type != TSQ_BYTES || !c.offsets) { g_err = "COL_STR on a fixed-width column"; return TSQ_ERR_INVALID; }
+                ECol r;
+                r.resize_str(n);
+                for (int64_t i = 0; i < n; i++) {
+                    const int64_t ph = cx.phys(i);
+                    r.null[i] = col_is_null(c, ph);
+                    if (!r.null[i]) r.s[i].assign((const char*)c.data + c.offsets[ph], (size_t)(c.offsets[ph + 1] - c.offsets[ph]));
+                }
+                st.push_back(std::move(r));
+                break;
+            }
+            case TSQ_OP_CONST_STR:
+            case TSQ_OP_CONST_NULL_STR: {  // expression/vectorized.go:23-80 broadcast
+                ECol r;
+                r.resize_str(n);
+                const bool isnull = op.opcode == TSQ_OP_CONST_NULL_STR;
+                std::string v;
+                if (!isnull) {
+                    const uint64_t ol = (uint64_t)p.consts[op.arg];
+                    v.assign((const char*)p.str_pool + (ol >> 32), (size_t)(ol & 0xffffffffu));
+                }
+                for (int64_t i = 0; i < n; i++) {
+                    r.null[i] = isnull;
+                    r.s[i] = v;
+                }
+                st.push_back(std::move(r));
+                break;
+            }
+            case TSQ_OP_LT_STR: case TSQ_OP_LE_STR: case TSQ_OP_GT_STR:
+            case TSQ_OP_GE_STR: case TSQ_OP_EQ_STR: case TSQ_OP_NE_STR:  // builtin_compare_vec_generated.go:65-555
+            case TSQ_OP_STRCMP: {                                        // builtin_string_vec.go:52-83
+                ECol b = std::move(st.back()); st.pop_back();
+                ECol a = std::move(st.back()); st.pop_back();
+                ECol r;
+                r.resize(n, false);
+                for (int64_t i = 0; i < n; i++) {
+                    r.null[i] = a.null[i] || b.null[i];  // result.MergeNulls(buf0, buf1)
+                    if (r.null[i]) continue;
+                    const int c = cmp_string(a.s[i], b.s[i]);
+                    if (op.opcode == TSQ_OP_STRCMP) { r.i[i] = c; continue; }
+                    const int rel = op.opcode - TSQ_OP_LT_STR;
+                    const bool v = rel == 0 ? c < 0 : rel == 1 ? c <= 0 : rel == 2 ? c > 0 : rel == 3 ? c >= 0 : rel == 4 ? c == 0 : c != 0;
+                    r.i[i] = v ? 1 : 0;
+                }
+                st.push_back(std::move(r));
+                break;
+            }
+            case TSQ_OP_LENGTH: {  // builtin_string_vec.go:89-92 is a course stub ("Your code here"): MySQL LENGTH() = bytes, NULL in -> NULL out
+                ECol a = std::move(st.back()); st.pop_back();
+                ECol r;
+                r.resize(n, false);
+                for (int64_t i = 0; i < n; i++) {
+                    r.null[i] = a.null[i];
+                    r.i[i] = a.null[i] ? 0 : (int64_t)a.s[i].size();
+                }
+                st.push_back(std::move(r));
+                break;
+            }
+            case TSQ_OP_ISNULL_STR: {  // builtin_string_vec.go:21-42
+                ECol a = std::move(st.back()); st.pop_back();
+                ECol r;
+                r.resize(n, false);
+                for (int64_t i = 0; i < n; i++) r.i[i] = a.null[i] ? 1 : 0;
+                st.push_back(std::move(r));
+                break;
+            }
+            case TSQ_OP_IFNULL_STR: {  // builtin_control_vec_generated.go:81-111
+                ECol b = std::move(st.back()); st.pop_back();
+                ECol a = std::move(st.back()); st.pop_back();
+                for (int64_t i = 0; i < n; i++) {
+                    if (a.null[i] && !b.null[i]) {
+                        a.null[i] = 0;
+                        a.s[i] = b.s[i];
+                    }
+                }
+                st.push_back(std::move(a));
+                break;
+            }
+            case TSQ_OP_IF_STR: {  // builtin_control_vec_generated.go:209-253
+                ECol c2 = std::move(st.back()); st.pop_back();
+                ECol c1 = std::move(st.back()); st.pop_back();
+                ECol c0 = std::move(st.back()); st.pop_back();
+                for (int64_t i = 0; i < n; i++) {
+                    if (c0.null[i] || c0.i[i] == 0) {
+                        c1.null[i] = c2.null[i];
+                        c1.s[i] = c2.s[i];
+                    }
+                }
+                st.push_back(std::move(c1));
+                break;
+            }
+            case TSQ_OP_IN_STR: {  // builtin_other_vec_generated.go:97-145
+                const int nitems = op.arg;
+                if ((int)st.size() < nitems + 1) { g_err = "IN: stack underflow"; return TSQ_ERR_INVALID; }
+                std::vector<ECol> items(nitems);
+                for (int j = nitems - 1; j >= 0; j--) { items[j] = std::move(st.back()); st.pop_back(); }
+                ECol x = std::move(st.back()); st.pop_back();
+                ECol r;
+                r.resize(n, false);
+                std::vector<uint8_t> hasNull(n, 0), found(n, 0);
+                for (int j = 0; j < nitems; j++) {
+                    for (int64_t i = 0; i < n; i++) {
+                        if (items[j].null[i] || x.null[i]) { hasNull[i] = 1; continue; }
+                        if (cmp_string(x.s[i], items[j].s[i]) == 0) found[i] = 1;
+                    }
+                }
+                for (int64_t i = 0; i < n; i++) {
+                    if (found[i]) { r.i[i] = 1; r.null[i] = 0; }
+                    else { r.i[i] = 0; r.null[i] = hasNull[i]; }
+                }
+                st.push_back(std::move(r));
+                break;
+            }
             default:
                 g_err = "unknown opcode " + std::to_string(op.opcode);
                 return TSQ_ERR_INVALID;
         }
     }
     if (st.size() != 1) { g_err = "malformed program: stack depth != 1"; return TSQ_ERR_INVALID; }
+    if (st.back().str) { g_err = "string-valued root"; return TSQ_ERR_UNSUPPORTED; }
     out = std::move(st.back());
     return TSQ_OK;
 }

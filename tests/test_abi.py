@@ -32,7 +32,7 @@ def test_struct_layouts_match_the_header():
     # sizes the C compiler produces for include/tsq.h (asserted again on the C side by the build)
     assert C.sizeof(abi.Col) == 48
     assert C.sizeof(abi.ExprOp) == 8
-    assert C.sizeof(abi.ExprProg) == 16 + 8 * abi.EXPR_MAX_OPS + 8 * abi.EXPR_MAX_CONSTS
+    assert C.sizeof(abi.ExprProg) == 16 + 8 * abi.EXPR_MAX_OPS + 8 * abi.EXPR_MAX_CONSTS + 8 + abi.EXPR_STR_POOL
     assert C.sizeof(abi.GenSpec) == 56
     assert C.sizeof(abi.AggFunc) == 24
 

@@ -32,7 +32,7 @@ AGG_COUNT, AGG_SUM, AGG_AVG, AGG_MAX, AGG_MIN, AGG_FIRSTROW = 0, 1, 2, 3, 4, 5
 MODE_COMPLETE, MODE_FINAL, MODE_PARTIAL1, MODE_PARTIAL2 = 0, 1, 2, 3
 
 MAX_KEYS, MAX_COLS, MAX_AGGS, MAX_GROUP_KEYS = 4, 16, 16, 4
-EXPR_MAX_OPS, EXPR_MAX_STACK, EXPR_MAX_CONSTS = 64, 12, 32
+EXPR_MAX_OPS, EXPR_MAX_STACK, EXPR_MAX_CONSTS, EXPR_STR_POOL = 64, 12, 32, 256
 
 # opcodes
 OP_COL_INT, OP_COL_REAL, OP_CONST_INT, OP_CONST_REAL, OP_CONST_NULL_INT, OP_CONST_NULL_REAL = 1, 2, 3, 4, 5, 6
@@ -44,6 +44,9 @@ OP_LOGIC_AND, OP_LOGIC_OR, OP_NOT_INT, OP_NOT_REAL, OP_NEG_INT, OP_NEG_REAL = 40
 OP_ISNULL_INT, OP_ISNULL_REAL = 46, 47
 OP_IFNULL_INT, OP_IFNULL_REAL, OP_IF_INT, OP_IF_REAL = 50, 51, 52, 53
 OP_IN_INT, OP_IN_REAL = 60, 61
+OP_COL_STR, OP_CONST_STR, OP_CONST_NULL_STR = 70, 71, 72
+OP_LT_STR, OP_LE_STR, OP_GT_STR, OP_GE_STR, OP_EQ_STR, OP_NE_STR = 73, 74, 75, 76, 77, 78
+OP_STRCMP, OP_LENGTH, OP_ISNULL_STR, OP_IFNULL_STR, OP_IF_STR, OP_IN_STR = 79, 80, 81, 82, 83, 84
 F_LHS_UNSIGNED, F_RHS_UNSIGNED, F_FORCE_SIGNED = 1, 2, 4
 
 
@@ -90,6 +93,7 @@ class ExprProg(C.Structure):
     _fields_ = [
         ("n_ops", C.c_int32), ("n_consts", C.c_int32), ("result_type", C.c_int32), ("result_unsigned", C.c_int32),
         ("ops", ExprOp * EXPR_MAX_OPS), ("consts", C.c_int64 * EXPR_MAX_CONSTS),
+        ("n_str_bytes", C.c_int32), ("reserved", C.c_int32), ("str_pool", C.c_uint8 * EXPR_STR_POOL),
     ]
 
 

@@ -88,6 +88,55 @@ class Column:
         return out
 
 
+class StrColumn:
+    """A var-len column (util/chunk/column.go:28-34: offsets[n + 1] + concatenated data bytes, binary strings).
+    `values`: list of bytes / str (utf-8 encoded) / None (NULL)."""
+
+    tp = abi.BYTES
+
+    def __init__(self, values):
+        vals = [None if v is None else (v.encode() if isinstance(v, str) else bytes(v)) for v in values]
+        self._vals = vals
+        self.notnull = None if all(v is not None for v in vals) else np.array([v is not None for v in vals], dtype=bool)
+        lens = np.array([0 if v is None else len(v) for v in vals], dtype=np.int64)  # a NULL cell has no bytes (AppendNull)
+        self.offsets = np.zeros(len(vals) + 1, dtype=np.int64)
+        np.cumsum(lens, out=self.offsets[1:])
+        self.data = np.frombuffer(b"".join(v for v in vals if v is not None) + b"\0" * 8, dtype=np.uint8).copy()
+        self._bitmap = None
+
+    def __len__(self):
+        return len(self._vals)
+
+    def IsNull(self, i):
+        return self._vals[i] is None
+
+    def bitmap(self):
+        if self.notnull is None:
+            return None
+        if self._bitmap is None:
+            self._bitmap = np.concatenate([pack_bitmap(self.notnull), np.zeros(8, np.uint8)])
+        return self._bitmap
+
+    def as_col(self, keep):
+        c = abi.Col()
+        c.data = self.data.ctypes.data_as(C.c_void_p)
+        bm = self.bitmap()
+        c.null_bitmap = bm.ctypes.data_as(C.c_void_p) if bm is not None else None
+        c.offsets = self.offsets.ctypes.data_as(C.c_void_p)
+        c.length = len(self._vals)
+        c.elem_size = -1
+        c.type = abi.BYTES
+        c.flags = 0
+        keep += [self.data, bm, self.offsets]
+        return c
+
+    def slice(self, lo, hi):
+        return StrColumn(self._vals[lo:hi])
+
+    def values(self):
+        return list(self._vals)
+
+
 def make_cols(columns, keep):
     arr = (abi.Col * len(columns))()
     for i, c in enumerate(columns):

@@ -159,9 +159,31 @@ struct tsq_val {
 struct tsq_colset {  // kernel-argument friendly description of a chunk's columns
     const void* data[TSQ_MAX_COLS];
     const uint8_t* nulls[TSQ_MAX_COLS];
+    const int64_t* offs[TSQ_MAX_COLS];  // TSQ_BYTES columns: offsets[n + 1] into data (util/chunk/column.go:28-34)
     int32_t type[TSQ_MAX_COLS];
     int32_t n;
 };
+// A string VALUE on the evaluation stack is a reference, no bytes move: [63:56] source (column index, or TSQ_STR_POOL = the
+// program's constant pool), [55:32] length (< 2^24), [31:0] byte offset into the source's data (< 2^32).
+#define TSQ_STR_POOL 0xffu
+#define TSQ_STR_MAXLEN 0xffffffu
+TSQ_HD uint64_t tsq_str_ref(uint32_t src, uint64_t off, uint64_t len) { return ((uint64_t)src << 56) | (len << 32) | off; }
+TSQ_HD uint32_t tsq_str_len(uint64_t h) { return (uint32_t)(h >> 32) & TSQ_STR_MAXLEN; }
+// types.CompareString with the binary collation = bytes.Compare (types/compare.go:136-139): -1 / 0 / 1
+TSQ_HD int tsq_cmp_bytes(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb) {
+    const uint32_t n = la < lb ? la : lb;
+    for (uint32_t i = 0; i < n; i++) {
+        if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+    }
+    return la < lb ? -1 : (la == lb ? 0 : 1);
+}
+// a TSQ_BYTES cell as a string reference; *bad is set when the cell does not fit the reference (TSQ_ERR_UNSUPPORTED)
+TSQ_HD uint64_t tsq_cell_str(const tsq_colset& cs, int c, int gc, int64_t row, bool* isnull, bool* bad) {
+    *isnull = tsq_is_null(cs.nulls[c], row);
+    const int64_t o0 = cs.offs[c][row], o1 = cs.offs[c][row + 1];
+    if ((uint64_t)o0 >> 32 || (uint64_t)(o1 - o0) > TSQ_STR_MAXLEN) *bad = true;
+    return tsq_str_ref((uint32_t)gc, (uint64_t)o0 & 0xffffffffu, (uint64_t)(o1 - o0) & TSQ_STR_MAXLEN);
+}
 TSQ_HD tsq_val tsq_cell_int(const tsq_colset& cs, int c, int64_t row) {
     tsq_val r;
     r.null = tsq_is_null(cs.nulls[c], row);
@@ -185,6 +207,12 @@ struct tsq_chunk_src {
     int64_t row;
     TSQ_HD tsq_val load_int(int c) const { return tsq_cell_int(*cs, c, row); }
     TSQ_HD tsq_val load_real(int c) const { return tsq_cell_real(*cs, c, row); }
+    TSQ_HD tsq_val load_str(int c, bool* bad) const {
+        tsq_val r;
+        r.v = (int64_t)tsq_cell_str(*cs, c, c, row, &r.null, bad);
+        return r;
+    }
+    TSQ_HD const uint8_t* str_base(uint32_t src) const { return (const uint8_t*)cs->data[src]; }
 };
 struct tsq_joined_src {
     const tsq_colset* left;
@@ -195,6 +223,14 @@ struct tsq_joined_src {
     }
     TSQ_HD tsq_val load_real(int c) const {
         return c < left->n ? tsq_cell_real(*left, c, lrow) : tsq_cell_real(*right, c - left->n, rrow);
+    }
+    TSQ_HD tsq_val load_str(int c, bool* bad) const {
+        tsq_val r;
+        r.v = (int64_t)(c < left->n ? tsq_cell_str(*left, c, c, lrow, &r.null, bad) : tsq_cell_str(*right, c - left->n, c, rrow, &r.null, bad));
+        return r;
+    }
+    TSQ_HD const uint8_t* str_base(uint32_t src) const {
+        return (const uint8_t*)((int)src < left->n ? left->data[src] : right->data[src - left->n]);
     }
 };
 
@@ -483,6 +519,87 @@ TSQ_HD tsq_status tsq_eval_row(const tsq_expr_prog& p, const Src& src, tsq_val* 
                 if (sp >= 2) r1 = mem[sp - 2];
                 break;
             }
+            case TSQ_OP_COL_STR: {
+                bool bad = false;
+                const tsq_val x = src.load_str(op.arg, &bad);
+                if (bad) return TSQ_ERR_UNSUPPORTED;  // a cell beyond 4 GB of column data or longer than 16 MB
+                push(x);
+                break;
+            }
+            case TSQ_OP_CONST_STR: {
+                tsq_val c;
+                const uint64_t ol = (uint64_t)p.consts[op.arg];
+                c.v = (int64_t)tsq_str_ref(TSQ_STR_POOL, ol >> 32, ol & TSQ_STR_MAXLEN);
+                c.null = false;
+                push(c);
+                break;
+            }
+            case TSQ_OP_CONST_NULL_STR: { tsq_val c; c.v = 0; c.null = true; push(c); break; }
+            case TSQ_OP_LT_STR: case TSQ_OP_LE_STR: case TSQ_OP_GT_STR:
+            case TSQ_OP_GE_STR: case TSQ_OP_EQ_STR: case TSQ_OP_NE_STR:
+            case TSQ_OP_STRCMP: {
+                tsq_val b = pop();
+                tsq_val& a = r0;
+                a.null = a.null || b.null;
+                if (a.null) { a.v = 0; break; }
+                const uint64_t ha = (uint64_t)a.v, hb = (uint64_t)b.v;
+                const uint32_t sa = (uint32_t)(ha >> 56), sb = (uint32_t)(hb >> 56);
+                const uint8_t* pa = (sa == TSQ_STR_POOL ? (const uint8_t*)p.str_pool : src.str_base(sa)) + (uint32_t)ha;
+                const uint8_t* pb = (sb == TSQ_STR_POOL ? (const uint8_t*)p.str_pool : src.str_base(sb)) + (uint32_t)hb;
+                const int c = tsq_cmp_bytes(pa, tsq_str_len(ha), pb, tsq_str_len(hb));
+                if (op.opcode == TSQ_OP_STRCMP) { a.v = c; break; }
+                const int rel = op.opcode - TSQ_OP_LT_STR;
+                const bool v = rel == 0 ? c < 0 : rel == 1 ? c <= 0 : rel == 2 ? c > 0 : rel == 3 ? c >= 0 : rel == 4 ? c == 0 : c != 0;
+                a.v = v ? 1 : 0;
+                break;
+            }
+            case TSQ_OP_LENGTH: {
+                tsq_val& a = r0;
+                a.v = a.null ? 0 : (int64_t)tsq_str_len((uint64_t)a.v);
+                break;
+            }
+            case TSQ_OP_ISNULL_STR: {
+                tsq_val& a = r0;
+                a.v = a.null ? 1 : 0;
+                a.null = false;
+                break;
+            }
+            case TSQ_OP_IFNULL_STR: {
+                tsq_val b = pop();
+                tsq_val& a = r0;
+                if (a.null && !b.null) a = b;
+                break;
+            }
+            case TSQ_OP_IF_STR: {
+                tsq_val c2 = pop();
+                tsq_val c1 = pop();
+                tsq_val& c0 = r0;
+                if (c0.null || c0.v == 0) c0 = c2;
+                else c0 = c1;
+                break;
+            }
+            case TSQ_OP_IN_STR: {
+                const int nitems = op.arg;
+                if (sp >= 2) mem[sp - 2] = r1;
+                mem[sp - 1] = r0;
+                tsq_val* st = mem;
+                const tsq_val x = st[sp - nitems - 1];
+                bool hasNull = false, found = false;
+                for (int j = 0; j < nitems; j++) {
+                    const tsq_val it = st[sp - nitems + j];
+                    if (it.null || x.null) { hasNull = true; continue; }
+                    const uint64_t ha = (uint64_t)x.v, hb = (uint64_t)it.v;
+                    const uint32_t sa = (uint32_t)(ha >> 56), sb = (uint32_t)(hb >> 56);
+                    const uint8_t* pa = (sa == TSQ_STR_POOL ? (const uint8_t*)p.str_pool : src.str_base(sa)) + (uint32_t)ha;
+                    const uint8_t* pb = (sb == TSQ_STR_POOL ? (const uint8_t*)p.str_pool : src.str_base(sb)) + (uint32_t)hb;
+                    found = found || tsq_cmp_bytes(pa, tsq_str_len(ha), pb, tsq_str_len(hb)) == 0;
+                }
+                sp -= nitems;
+                r0.v = found ? 1 : 0;
+                r0.null = found ? false : hasNull;
+                if (sp >= 2) r1 = mem[sp - 2];
+                break;
+            }
             default: return TSQ_ERR_INVALID;
         }
     }
@@ -525,22 +642,37 @@ TSQ_HD uint64_t tsq_errword(int conj, int node, uint64_t row, tsq_status st) {
     return ((uint64_t)conj << 58) | ((uint64_t)node << 52) | ((row & 0xffffffffffffULL) << 4) | (uint64_t)(st & 15);
 }
 
-// Static validation of a program (stack discipline, indices, result type): host side, at compile.
-inline tsq_status tsq_validate_prog(const tsq_expr_prog& p, int32_t n_cols, const char** why) {
+// Static validation of a program (stack discipline, value kinds, indices, result type): host side, at compile.
+// col_types (optional, n_cols entries) lets the column leaves be checked against the schema.
+inline tsq_status tsq_validate_prog(const tsq_expr_prog& p, int32_t n_cols, const char** why, const int32_t* col_types = nullptr) {
     if (p.n_ops <= 0 || p.n_ops > TSQ_EXPR_MAX_OPS) { *why = "n_ops out of range"; return TSQ_ERR_INVALID; }
     if (p.n_consts < 0 || p.n_consts > TSQ_EXPR_MAX_CONSTS) { *why = "n_consts out of range"; return TSQ_ERR_INVALID; }
+    if (p.n_str_bytes < 0 || p.n_str_bytes > TSQ_EXPR_STR_POOL) { *why = "string pool size out of range"; return TSQ_ERR_INVALID; }
+    bool is_str[TSQ_EXPR_MAX_STACK + 1];  // kind of every stack entry: string reference or number
     int sp = 0;
     for (int k = 0; k < p.n_ops; k++) {
         const tsq_expr_op& op = p.ops[k];
-        int pop = 0, push = 1;
+        int pop = 0;
+        bool res_str = false;
+        int str_args = -1;  // -1: all popped values must be numbers; otherwise a bit mask of the popped entries (bit 0 = deepest) that must be strings
         switch (op.opcode) {
-            case TSQ_OP_COL_INT: case TSQ_OP_COL_REAL:
+            case TSQ_OP_COL_INT: case TSQ_OP_COL_REAL: case TSQ_OP_COL_STR:
                 if (n_cols >= 0 && op.arg >= n_cols) { *why = "column index out of range"; return TSQ_ERR_INVALID; }
+                if (col_types && ((col_types[op.arg] == TSQ_BYTES) != (op.opcode == TSQ_OP_COL_STR))) { *why = "column leaf does not match the column type"; return TSQ_ERR_INVALID; }
+                res_str = op.opcode == TSQ_OP_COL_STR;
                 break;
             case TSQ_OP_CONST_INT: case TSQ_OP_CONST_REAL:
                 if (op.arg >= p.n_consts) { *why = "const index out of range"; return TSQ_ERR_INVALID; }
                 break;
+            case TSQ_OP_CONST_STR: {
+                if (op.arg >= p.n_consts) { *why = "const index out of range"; return TSQ_ERR_INVALID; }
+                const uint64_t ol = (uint64_t)p.consts[op.arg];
+                if ((ol >> 32) + (ol & 0xffffffffu) > (uint64_t)p.n_str_bytes) { *why = "string constant outside the pool"; return TSQ_ERR_INVALID; }
+                res_str = true;
+                break;
+            }
             case TSQ_OP_CONST_NULL_INT: case TSQ_OP_CONST_NULL_REAL: break;
+            case TSQ_OP_CONST_NULL_STR: res_str = true; break;
             case TSQ_OP_PLUS_REAL: case TSQ_OP_MINUS_REAL: case TSQ_OP_MUL_REAL: case TSQ_OP_DIV_REAL:
             case TSQ_OP_PLUS_INT: case TSQ_OP_MINUS_INT: case TSQ_OP_MUL_INT: case TSQ_OP_MUL_INT_UNSIGNED:
             case TSQ_OP_LT_INT: case TSQ_OP_LE_INT: case TSQ_OP_GT_INT: case TSQ_OP_GE_INT:
@@ -549,22 +681,48 @@ inline tsq_status tsq_validate_prog(const tsq_expr_prog& p, int32_t n_cols, cons
             case TSQ_OP_LOGIC_AND: case TSQ_OP_LOGIC_OR: case TSQ_OP_IFNULL_INT: case TSQ_OP_IFNULL_REAL:
                 pop = 2;
                 break;
+            case TSQ_OP_LT_STR: case TSQ_OP_LE_STR: case TSQ_OP_GT_STR: case TSQ_OP_GE_STR:
+            case TSQ_OP_EQ_STR: case TSQ_OP_NE_STR: case TSQ_OP_STRCMP:
+                pop = 2;
+                str_args = 3;
+                break;
+            case TSQ_OP_IFNULL_STR:
+                pop = 2;
+                str_args = 3;
+                res_str = true;
+                break;
             case TSQ_OP_NOT_INT: case TSQ_OP_NOT_REAL: case TSQ_OP_NEG_INT: case TSQ_OP_NEG_REAL:
             case TSQ_OP_ISNULL_INT: case TSQ_OP_ISNULL_REAL:
                 pop = 1;
                 break;
+            case TSQ_OP_LENGTH: case TSQ_OP_ISNULL_STR:
+                pop = 1;
+                str_args = 1;
+                break;
             case TSQ_OP_IF_INT: case TSQ_OP_IF_REAL: pop = 3; break;
-            case TSQ_OP_IN_INT: case TSQ_OP_IN_REAL:
+            case TSQ_OP_IF_STR:
+                pop = 3;
+                str_args = 6;  // cond is a number, both values are strings
+                res_str = true;
+                break;
+            case TSQ_OP_IN_INT: case TSQ_OP_IN_REAL: case TSQ_OP_IN_STR:
                 if (op.arg < 1 || op.arg > 31) { *why = "IN list size out of range"; return TSQ_ERR_INVALID; }
                 pop = op.arg + 1;
+                if (op.opcode == TSQ_OP_IN_STR) str_args = -2;  // every popped value is a string
                 break;
             default: *why = "unknown opcode"; return TSQ_ERR_UNSUPPORTED;
         }
         if (sp < pop) { *why = "stack underflow"; return TSQ_ERR_INVALID; }
-        sp = sp - pop + push;
+        for (int q = 0; q < pop; q++) {
+            const bool want = str_args == -2 ? true : (str_args < 0 ? false : ((str_args >> q) & 1) != 0);
+            if (is_str[sp - pop + q] != want) { *why = "operand kind (string / number) does not match the opcode"; return TSQ_ERR_INVALID; }
+        }
+        sp = sp - pop + 1;
         if (sp > TSQ_EXPR_MAX_STACK) { *why = "expression too deep"; return TSQ_ERR_UNSUPPORTED; }
+        is_str[sp - 1] = res_str;
     }
     if (sp != 1) { *why = "program leaves stack depth != 1"; return TSQ_ERR_INVALID; }
+    if (is_str[0]) { *why = "string-valued root: not evaluated on the GPU"; return TSQ_ERR_UNSUPPORTED; }
     if (p.result_type != TSQ_I64 && p.result_type != TSQ_F64) { *why = "result_type must be TSQ_I64 or TSQ_F64"; return TSQ_ERR_INVALID; }
     return TSQ_OK;
 }

@@ -118,8 +118,9 @@ tsq_status expr_inputs(tsq_expr* e, const tsq_col* cols, int32_t n_cols, int64_t
     if (n_cols < 0 || n_cols > TSQ_MAX_COLS) return tsq_fail(h, TSQ_ERR_INVALID, "too many input columns");
     bool dev = false, host = false;
     for (int c = 0; c < n_cols; c++) {
-        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "var-len column in a GPU expression");
-        if (!cols[c].data && cols[c].length > 0) return tsq_fail(h, TSQ_ERR_INVALID, "column data == NULL");
+        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "unknown column type");
+        if (cols[c].type == TSQ_BYTES && !cols[c].offsets) return tsq_fail(h, TSQ_ERR_INVALID, "var-len column without offsets");
+        if (!cols[c].data && cols[c].length > 0 && cols[c].type != TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "column data == NULL");
         (cols[c].flags & TSQ_COL_DEVICE) ? dev = true : host = true;
     }
     if (dev && host) return tsq_fail(h, TSQ_ERR_INVALID, "mixing host and device columns");
@@ -136,7 +137,30 @@ tsq_status expr_inputs(tsq_expr* e, const tsq_col* cols, int32_t n_cols, int64_t
         st.rows = 0;
         st.has_nulls = false;
         const int64_t n = std::min<int64_t>(cols[c].length, phys_rows);
-        tsq_status s = tsq_col_append(ctx, h, st, cols[c].data, cols[c].null_bitmap, n, false, tmp);
+        tsq_status s = TSQ_OK;
+        if (cols[c].type == TSQ_BYTES) {
+            // var-len column (util/chunk/column.go:28-34): the n + 1 offsets and the offsets[n] data bytes, as they are
+            const int64_t nbytes = n > 0 ? cols[c].offsets[n] : 0;
+            if (nbytes < 0 || (n > 0 && cols[c].offsets[0] != 0)) { tmp.release(); return tsq_fail(h, TSQ_ERR_INVALID, "var-len column: offsets must start at 0 and grow"); }
+            if ((uint64_t)nbytes >> 32) { tmp.release(); return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "var-len column beyond 4 GB of data in one batch"); }
+            s = st.offs.reserve(ctx, h, (size_t)(n + 1) * 8 + 64);
+            if (s == TSQ_OK) s = st.data.reserve(ctx, h, (size_t)nbytes + 64);
+            if (s != TSQ_OK) { tmp.release(); return s; }
+            static const int64_t zero = 0;
+            hipError_t e1 = hipMemcpyAsync(st.offs.p, n > 0 ? cols[c].offsets : &zero, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+            if (e1 == hipSuccess && nbytes) e1 = hipMemcpyAsync(st.data.p, cols[c].data, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream);
+            if (e1 != hipSuccess) { tmp.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("hipMemcpyAsync(var-len column): ") + hipGetErrorString(e1)); }
+            if (cols[c].null_bitmap && n > 0) {  // the store starts at row 0: the host bitmap is copied as it is
+                s = st.nulls.reserve(ctx, h, tsq_bitmap_bytes(n) + 64);
+                if (s != TSQ_OK) { tmp.release(); return s; }
+                e1 = hipMemcpyAsync(st.nulls.p, cols[c].null_bitmap, tsq_bitmap_bytes(n), hipMemcpyHostToDevice, ctx->stream);
+                if (e1 != hipSuccess) { tmp.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("hipMemcpyAsync(bitmap): ") + hipGetErrorString(e1)); }
+                st.has_nulls = true;
+            }
+            st.rows = n;
+        } else {
+            s = tsq_col_append(ctx, h, st, cols[c].data, cols[c].null_bitmap, n, false, tmp);
+        }
         if (s != TSQ_OK) { tmp.release(); return s; }
     }
     hipError_t err = hipStreamSynchronize(ctx->stream);
@@ -214,6 +238,8 @@ static std::string jit_source(const std::vector<tsq_expr_prog>& progs) {
         }
         o << "}, {";
         for (int c = 0; c < TSQ_EXPR_MAX_CONSTS; c++) o << "(int64_t)0x" << std::hex << (unsigned long long)(c < p.n_consts ? p.consts[c] : 0) << std::dec << "ULL,";
+        o << "}, " << p.n_str_bytes << ", 0, {";
+        for (int b = 0; b < TSQ_EXPR_STR_POOL; b++) o << (b < p.n_str_bytes ? (int)p.str_pool[b] : 0) << ",";
         o << "} },\n";
     }
     o << "};\n";
@@ -345,7 +371,9 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
     if (nrows == 0) return TSQ_OK;
     for (size_t p = 0; p < e->progs.size(); p++) {
         const char* why = "";
-        tsq_status s = tsq_validate_prog(e->progs[p], n_cols, &why);
+        int32_t ctypes[TSQ_MAX_COLS];
+        for (int c = 0; c < n_cols && c < TSQ_MAX_COLS; c++) ctypes[c] = in_cols[c].type;
+        tsq_status s = tsq_validate_prog(e->progs[p], n_cols, &why, n_cols <= TSQ_MAX_COLS ? ctypes : nullptr);
         if (s != TSQ_OK) return tsq_fail(h, s, why);
     }
     TSQ_HIP(h, hipSetDevice(ctx->device));

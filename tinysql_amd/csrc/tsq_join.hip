@@ -1456,12 +1456,17 @@ TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_jo
     (void)nleft;
     for (int e = 0; e < cfg->n_other_conds; e++) {
         const char* why = "";
-        tsq_status s = tsq_validate_prog(cfg->other_conds[e], cfg->n_probe_cols + cfg->n_build_cols, &why);
+        int32_t jt[2 * TSQ_MAX_COLS];  // the joined row lhs || rhs (joiner.go:145-150)
+        for (int c = 0; c < cfg->n_probe_cols + cfg->n_build_cols; c++) {
+            const bool from_probe = cfg->build_is_right ? c < cfg->n_probe_cols : c >= cfg->n_build_cols;
+            jt[c] = from_probe ? cfg->probe_types[cfg->build_is_right ? c : c - cfg->n_build_cols] : cfg->build_types[cfg->build_is_right ? c - cfg->n_probe_cols : c];
+        }
+        tsq_status s = tsq_validate_prog(cfg->other_conds[e], cfg->n_probe_cols + cfg->n_build_cols, &why, jt);
         if (s != TSQ_OK) return tsq_fail(ch, s, std::string("other condition: ") + why);
     }
     for (int e = 0; e < cfg->n_outer_filters; e++) {
         const char* why = "";
-        tsq_status s = tsq_validate_prog(cfg->outer_filters[e], cfg->n_probe_cols, &why);
+        tsq_status s = tsq_validate_prog(cfg->outer_filters[e], cfg->n_probe_cols, &why, cfg->probe_types);
         if (s != TSQ_OK) return tsq_fail(ch, s, std::string("outer filter: ") + why);
     }
     TSQ_HIP(ch, hipSetDevice(ctx->device));

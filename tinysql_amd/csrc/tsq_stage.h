@@ -13,6 +13,7 @@
 
 struct ColStore {  // one device-resident column that grows by appends
     DevBuf data, nulls;
+    DevBuf offs;  // TSQ_BYTES: offsets[rows + 1] (only the expression inputs keep var-len columns so far)
     bool has_nulls = false;
     int64_t rows = 0;
     int32_t type = TSQ_I64;
@@ -20,6 +21,7 @@ struct ColStore {  // one device-resident column that grows by appends
     void release() {
         data.release();
         nulls.release();
+        offs.release();
         rows = 0;
         has_nulls = false;
     }
@@ -60,6 +62,7 @@ inline void tsq_fill_colset(tsq_colset& cs, const std::vector<ColStore>& cols) {
     for (int c = 0; c < cs.n; c++) {
         cs.data[c] = cols[c].data.p;
         cs.nulls[c] = cols[c].has_nulls ? cols[c].nulls.as<uint8_t>() : nullptr;
+        cs.offs[c] = cols[c].type == TSQ_BYTES ? cols[c].offs.as<int64_t>() : nullptr;
         cs.type[c] = cols[c].type;
     }
 }
@@ -69,6 +72,7 @@ inline void tsq_colset_from_cols(tsq_colset& cs, const tsq_col* cols, int32_t n_
     for (int c = 0; c < n_cols; c++) {
         cs.data[c] = cols[c].data;
         cs.nulls[c] = cols[c].null_bitmap;
+        cs.offs[c] = cols[c].type == TSQ_BYTES ? cols[c].offsets : nullptr;
         cs.type[c] = cols[c].type;
     }
 }

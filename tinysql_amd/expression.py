@@ -15,7 +15,7 @@ from . import _abi as abi
 from . import _lib
 from .chunk import Column as ChunkColumn, make_cols, pack_bitmap, unpack_bitmap  # noqa: F401
 
-ETInt, ETReal = "int", "real"
+ETInt, ETReal, ETString = "int", "real", "string"
 
 
 class Unsupported(Exception):
@@ -36,7 +36,7 @@ class Column(Expression):
     def __init__(self, index, tp):
         self.index = index
         self.tp = tp
-        self.eval_type = ETReal if tp in (abi.F32, abi.F64) else ETInt
+        self.eval_type = ETString if tp == abi.BYTES else (ETReal if tp in (abi.F32, abi.F64) else ETInt)
         self.unsigned = tp == abi.U64
 
 
@@ -45,7 +45,7 @@ class Constant(Expression):
 
     def __init__(self, value, eval_type=None, unsigned=False):
         if eval_type is None:
-            eval_type = ETReal if isinstance(value, float) else ETInt
+            eval_type = ETString if isinstance(value, (str, bytes)) else (ETReal if isinstance(value, float) else ETInt)
         self.value = value
         self.eval_type = eval_type
         self.unsigned = unsigned
@@ -67,8 +67,8 @@ class ScalarFunction(Expression):
         n, a = self.name, self.args
         ets = [x.eval_type for x in a]
         if n in ("plus", "minus", "mul"):
-            if len(set(ets)) != 1:
-                raise Unsupported("mixed int/real arithmetic needs an implicit conversion")
+            if len(set(ets)) != 1 or ets[0] == ETString:
+                raise Unsupported("mixed int/real/string arithmetic needs an implicit conversion")
             self.eval_type = ets[0]
             # builtin_arithmetic.go:112-133,216-237,330-355: int result is UNSIGNED if either side is
             self.unsigned = self.eval_type == ETInt and (a[0].unsigned or a[1].unsigned)
@@ -87,8 +87,18 @@ class ScalarFunction(Expression):
                 raise Unsupported("logic operators over non-int arguments")
             self.eval_type = ETInt
         elif n in ("not", "unaryminus"):
+            if ets[0] == ETString:
+                raise Unsupported("NOT / unary minus of a string needs an implicit conversion")
             self.eval_type = ETInt if n == "not" else ets[0]
             self.unsigned = False
+        elif n == "strcmp":  # builtin_string.go strcmpFunctionClass -> builtinStrcmpSig
+            if ets != [ETString, ETString]:
+                raise Unsupported("STRCMP of non-string arguments needs an implicit conversion")
+            self.eval_type = ETInt
+        elif n == "length":  # builtinLengthSig
+            if ets != [ETString]:
+                raise Unsupported("LENGTH of a non-string argument needs an implicit conversion")
+            self.eval_type = ETInt
         elif n == "isnull":
             self.eval_type = ETInt
         elif n == "ifnull":
@@ -113,11 +123,22 @@ class ScalarFunction(Expression):
 
 def _emit(e, ops, consts):
     if isinstance(e, Column):
-        ops.append((abi.OP_COL_REAL if e.eval_type == ETReal else abi.OP_COL_INT, 0, e.index, 0))
+        op = abi.OP_COL_STR if e.eval_type == ETString else (abi.OP_COL_REAL if e.eval_type == ETReal else abi.OP_COL_INT)
+        ops.append((op, 0, e.index, 0))
         return
     if isinstance(e, Constant):
         if e.value is None:
-            ops.append((abi.OP_CONST_NULL_REAL if e.eval_type == ETReal else abi.OP_CONST_NULL_INT, 0, 0, 0))
+            op = abi.OP_CONST_NULL_STR if e.eval_type == ETString else (abi.OP_CONST_NULL_REAL if e.eval_type == ETReal else abi.OP_CONST_NULL_INT)
+            ops.append((op, 0, 0, 0))
+            return
+        if e.eval_type == ETString:
+            b = e.value.encode() if isinstance(e.value, str) else bytes(e.value)
+            pool = consts.pool
+            if len(pool) + len(b) > abi.EXPR_STR_POOL:
+                raise Unsupported("string constants exceed the program's %d-byte pool" % abi.EXPR_STR_POOL)
+            consts.append((len(pool) << 32) | len(b))
+            pool.extend(b)
+            ops.append((abi.OP_CONST_STR, 0, len(consts) - 1, 0))
             return
         if e.eval_type == ETReal:
             bits = struct.unpack("<q", struct.pack("<d", float(e.value)))[0]
@@ -133,6 +154,7 @@ def _emit(e, ops, consts):
     for x in a:
         _emit(x, ops, consts)
     real = a[0].eval_type == ETReal
+    isstr = a[0].eval_type == ETString
     flags = 0
     if len(a) >= 1 and a[0].unsigned:
         flags |= abi.F_LHS_UNSIGNED
@@ -154,8 +176,12 @@ def _emit(e, ops, consts):
     elif n == "div":
         ops.append((abi.OP_DIV_REAL, 0, 0, 0))
     elif n in _CMP:
-        base = abi.OP_LT_REAL if real else abi.OP_LT_INT
-        ops.append((base + _CMP[n], flags, 0, 0))
+        base = abi.OP_LT_STR if isstr else (abi.OP_LT_REAL if real else abi.OP_LT_INT)
+        ops.append((base + _CMP[n], 0 if isstr else flags, 0, 0))
+    elif n == "strcmp":
+        ops.append((abi.OP_STRCMP, 0, 0, 0))
+    elif n == "length":
+        ops.append((abi.OP_LENGTH, 0, 0, 0))
     elif n == "and":
         ops.append((abi.OP_LOGIC_AND, 0, 0, 0))
     elif n == "or":
@@ -165,25 +191,34 @@ def _emit(e, ops, consts):
     elif n == "unaryminus":
         ops.append((abi.OP_NEG_REAL if real else abi.OP_NEG_INT, flags, 0, 0))
     elif n == "isnull":
-        ops.append((abi.OP_ISNULL_REAL if real else abi.OP_ISNULL_INT, 0, 0, 0))
+        ops.append((abi.OP_ISNULL_STR if isstr else (abi.OP_ISNULL_REAL if real else abi.OP_ISNULL_INT), 0, 0, 0))
     elif n == "ifnull":
-        ops.append((abi.OP_IFNULL_REAL if real else abi.OP_IFNULL_INT, 0, 0, 0))
+        ops.append((abi.OP_IFNULL_STR if isstr else (abi.OP_IFNULL_REAL if real else abi.OP_IFNULL_INT), 0, 0, 0))
     elif n == "if":
-        ops.append((abi.OP_IF_REAL if a[1].eval_type == ETReal else abi.OP_IF_INT, 0, 0, 0))
+        ops.append((abi.OP_IF_STR if a[1].eval_type == ETString else (abi.OP_IF_REAL if a[1].eval_type == ETReal else abi.OP_IF_INT), 0, 0, 0))
     elif n == "in":
         aux = 0
         for j, item in enumerate(a[1:]):
             if item.unsigned:
                 aux |= 1 << j
-        ops.append((abi.OP_IN_REAL if real else abi.OP_IN_INT, flags & abi.F_LHS_UNSIGNED, len(a) - 1, aux))
+        if isstr:
+            ops.append((abi.OP_IN_STR, 0, len(a) - 1, 0))
+        else:
+            ops.append((abi.OP_IN_REAL if real else abi.OP_IN_INT, flags & abi.F_LHS_UNSIGNED, len(a) - 1, aux))
 
 
 def compile_expr(e):
     """Expression tree -> abi.ExprProg (postfix)."""
-    ops, consts = [], []
+    class _Consts(list):
+        pass
+
+    ops, consts = [], _Consts()
+    consts.pool = bytearray()
     _emit(e, ops, consts)
     if len(ops) > abi.EXPR_MAX_OPS or len(consts) > abi.EXPR_MAX_CONSTS:
         raise Unsupported("expression too large for the GPU interpreter")
+    if e.eval_type == ETString:
+        raise Unsupported("string-valued root: the Go evaluator keeps it (a bare string column is a column swap)")
     p = abi.ExprProg()
     p.n_ops = len(ops)
     p.n_consts = len(consts)
@@ -193,6 +228,9 @@ def compile_expr(e):
         p.ops[i].opcode, p.ops[i].flags, p.ops[i].arg, p.ops[i].aux = opc, fl, arg, aux
     for i, c in enumerate(consts):
         p.consts[i] = c
+    p.n_str_bytes = len(consts.pool)
+    for i, b in enumerate(consts.pool):
+        p.str_pool[i] = b
     return p
 
 
