@@ -418,32 +418,37 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=100_000_00
         for i, (f, col) in enumerate([(abi.AGG_FIRSTROW, 0), (abi.AGG_SUM, 1), (abi.AGG_COUNT, -1)]):
             cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
         cfg.est_groups = groups
-        h = C.c_void_p()
-        _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
-        try:
-            ms, done = 0.0, 0
-            while done < n:
-                m = min(batch, n - done)
-                ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=0, m=groups, start=done), m, k)
-                ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=1, m=1000, start=done), m, v)
-                ctx.sync()
+        runs = []
+        for _ in range(2):  # the second run finds its partition / group buffers in the context's pool (hipMalloc costs ~35 ms per GB)
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ms, done = 0.0, 0
+                while done < n:
+                    m = min(batch, n - done)
+                    ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=0, m=groups, start=done), m, k)
+                    ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=1, m=1000, start=done), m, v)
+                    ctx.sync()
+                    ctx.timer_start()
+                    _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m)), 2, m), h)
+                    ms += ctx.timer_stop_ms()
+                    done += m
                 ctx.timer_start()
-                _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m)), 2, m), h)
+                _lib.check(lib.tsq_agg_finish(h), h)
                 ms += ctx.timer_stop_ms()
-                done += m
-            ctx.timer_start()
-            _lib.check(lib.tsq_agg_finish(h), h)
-            ms += ctx.timer_stop_ms()
-            ng = C.c_int64(0)
-            _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
-        finally:
-            lib.tsq_agg_destroy(h)
+                ng = C.c_int64(0)
+                _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                runs.append(ms)
+            finally:
+                lib.tsq_agg_destroy(h)
+        ms = runs[-1]
     finally:
         ctx.free(k)
         ctx.free(v)
     algo = 16.0 * n + 24.0 * ng.value
     return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows / 1e6 int64 groups, HashAggExec", "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value,
-            "frac": algo / ms / 1e6 / 8000.0, "verified": ng.value == groups}
+            "frac": algo / ms / 1e6 / 8000.0, "verified": ng.value == groups, "first_run_ms": runs[0],
+            "timing": "HIP events around every tsq_agg_push (10 device-resident batches of 1e8 rows) + tsq_agg_finish; second of two runs"}
 
 
 def cpu_baseline(abi, nb, npr):
