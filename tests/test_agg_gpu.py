@@ -218,3 +218,27 @@ def test_agg_config3_shape_device_resident_property(ctx):
     order = np.argsort(keys)
     assert (keys[order] == np.arange(g)).all()
     assert (cnts[order] == exp_cnt).all() and (sums[order] == exp_sum).all()
+
+
+def test_sum_int64_running_overflow_divergence_is_pinned(ctx, orc):
+    # DESIGN.md "Known divergences": the reference adds row by row and reports ErrOverflow as soon as a RUNNING sum leaves BIGINT
+    # (aggfuncs/func_sum.go:133-137, types/overflow.go:33-40) — with one partial worker that is deterministic, and the oracle
+    # reproduces it.  The GPU sums exactly in 128 bits and reports overflow iff the FINAL sum of a group leaves BIGINT, so a
+    # transient excursion that comes back into range is a value here and an error there.  INTEGRATION.md lists it.
+    from oracle.binding import OracleError
+    i64max = (1 << 63) - 1
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, abi.I64)]
+    cfg = H.agg_cfg([abi.I64, abi.I64], [0], aggs)
+    transient = Chunk([Column(abi.I64, np.array([1, 1, 1, 2])), Column(abi.I64, np.array([i64max, 1, -5, 7]))])
+    with pytest.raises(OracleError) as ei:
+        orc.hash_agg(cfg, transient, 1, 1)
+    assert ei.value.status == abi.ERR_OVERFLOW_BIGINT
+    got = G.run_agg(ctx, cfg, transient, [abi.I64, abi.I64])
+    assert sorted(got.rows()) == [(1, i64max - 4), (2, 7)]
+    # a final sum outside BIGINT is an error on both sides
+    final = Chunk([Column(abi.I64, np.array([1, 1, 2])), Column(abi.I64, np.array([i64max, 5, 7]))])
+    with pytest.raises(OracleError):
+        orc.hash_agg(cfg, final, 1, 1)
+    with pytest.raises(_lib.TsqError) as e2:
+        G.run_agg(ctx, cfg, final, [abi.I64, abi.I64])
+    assert e2.value.status == abi.ERR_OVERFLOW_BIGINT

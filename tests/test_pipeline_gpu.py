@@ -1,6 +1,7 @@
 """GPU: device-resident operator pipeline (tinysql_amd/gpu_pipeline.py) on a Q3-shaped plan —
-Selection -> HashJoin -> HashJoin -> Projection -> HashAgg with chunks that never leave HBM — against a plain numpy
-restatement of the query, plus tsq_chunk_compact on its own against numpy boolean indexing."""
+Selection -> HashJoin -> HashJoin -> Projection -> HashAgg with chunks that never leave HBM — against the ORACLE's operators
+chained the same way (orc.filter_eval -> orc.hash_join -> orc.hash_join -> orc.expr_eval -> orc.hash_agg; the numpy restatement
+of the query in tools/q3.py is checked against that chain too), plus tsq_chunk_compact on its own against numpy boolean indexing."""
 import ctypes as C
 import os
 import sys
@@ -19,6 +20,43 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import q3  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+
+
+def q3_by_the_oracle(orc, customer, orders, lineitem):
+    """tools/q3.py's plan, operator by operator, through the oracle (the CPU restatement of the reference executors).
+    Returns {orderkey: (orderdate, shippriority, revenue, rows in the group, sum of |price * (1 - discount)|)}."""
+    from tinysql_amd import expression as E
+    F, Col, K, I, R = E.ScalarFunction, E.Column, E.Constant, abi.I64, abi.F64
+
+    def select(chk, conj):  # SelectionExec: VectorizedFilter, then the selected rows (executor.go:401-438)
+        sel, _, _ = orc.filter_eval(E.compile_list(conj), len(conj), chk)
+        return Chunk([Column(c.tp, c.data[sel], None if c.notnull is None else c.notnull[sel]) for c in chk.columns])
+
+    cust = select(customer, [F("eq", Col(1, I), K(q3.SEG))])
+    ords = select(orders, [F("lt", Col(2, I), K(q3.D))])
+    line = select(lineitem, [F("gt", Col(1, I), K(q3.D))])
+    j1 = orc.hash_join(H.join_cfg(ords.types(), cust.types(), [1], [0], abi.JOIN_INNER, 1), cust, ords)     # orders probe (left), customer build
+    j2 = orc.hash_join(H.join_cfg(line.types(), j1.types(), [0], [0], abi.JOIN_INNER, 1), j1, line)         # lineitem probe (left), j1 build
+    rev, _ = orc.expr_eval(E.compile_expr(F("mul", Col(2, R), F("minus", K(1.0), Col(3, R)))), j2)
+    proj = Chunk([j2.columns[0], j2.columns[6], j2.columns[7], rev])
+    aggs = [(abi.AGG_FIRSTROW, 0, I), (abi.AGG_FIRSTROW, 1, I), (abi.AGG_FIRSTROW, 2, I), (abi.AGG_SUM, 3, R)]
+    out = orc.hash_agg(H.agg_cfg(proj.types(), [0, 1, 2], aggs), proj, 4, 4)
+    keys = proj.columns[0].data
+    order = np.argsort(keys, kind="stable")
+    uk, start, cnt = np.unique(keys[order], return_index=True, return_counts=True)
+    sabs = np.add.reduceat(np.abs(rev.data[order]), start) if len(keys) else np.zeros(0)
+    n_of, abs_of = dict(zip(uk.tolist(), cnt.tolist())), dict(zip(uk.tolist(), sabs.tolist()))
+    res = {}
+    for k, d, p, s in out.rows():
+        assert k not in res
+        res[k] = (d, p, s, n_of[k], abs_of[k])
+    return res
+
+
+def sum_tol(n_rows, sum_abs):
+    """SUM(double) of a group is order dependent (partial -> final workers); any two orders differ by at most
+    2 * n_g * 2^-53 * sum(|v|)."""
+    return 2.0 * n_rows * 2.0 ** -53 * sum_abs
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 1000, 70001])
@@ -47,22 +85,27 @@ def test_chunk_compact_matches_boolean_indexing(ctx, n):
 
 
 @pytest.mark.parametrize("jit", [abi.JIT_OFF, abi.JIT_FORCE])
-def test_q3_shaped_plan_on_device_chunks(ctx, jit):
+def test_q3_shaped_plan_on_device_chunks(ctx, orc, jit):
     customer, orders, lineitem = q3.tables(0.05)  # 7.5e3 / 7.5e4 / 3e5 rows
+    want = q3_by_the_oracle(orc, customer, orders, lineitem)
     dev = [GP.DeviceChunk.from_host(ctx, t) for t in (customer, orders, lineitem)]
     try:
         out = GP.drain_device(q3.plan(ctx, *dev, batch_rows=50_000, jit=jit))  # several batches per table
-        uk, dates, prios, sums = q3.reference(customer, orders, lineitem)
         got = {}
         for c in out:
             for k, d, p, s in c.rows():
                 assert k not in got
                 got[k] = (d, p, s)
-        assert len(got) == len(uk) > 1000
-        for k, d, p, s in zip(uk.tolist(), dates.tolist(), prios.tolist(), sums.tolist()):
+        assert set(got) == set(want) and len(got) > 1000
+        for k, (d, p, s, n_g, s_abs) in want.items():
             g = got[k]
             assert g[0] == d and g[1] == p
-            assert abs(g[2] - s) <= 1e-9 * max(1.0, abs(s))  # double SUM re-ordering bound, a handful of rows per group
+            assert abs(g[2] - s) <= sum_tol(n_g, s_abs), (k, g[2], s, n_g)
+        # tools/q3.py's numpy restatement (the checker of the SF 10 / SF 100 runs) against the same chain
+        uk, dates, prios, sums = q3.reference(customer, orders, lineitem)
+        assert set(uk.tolist()) == set(want)
+        for k, d, p, s in zip(uk.tolist(), dates.tolist(), prios.tolist(), sums.tolist()):
+            assert want[k][0] == d and want[k][1] == p and abs(want[k][2] - s) <= sum_tol(want[k][3], want[k][4])
     finally:
         for d in dev:
             d.free()
@@ -114,18 +157,23 @@ def test_device_pipeline_equals_host_chunk_pipeline_with_nulls(ctx, jt):
             assert a == b or (a is not None and b is not None and abs(a - b) <= 1e-9 * max(1.0, abs(b))), (k, g, w)
 
 
-def test_q3_shaped_plan_with_order_by_revenue_limit_10(ctx):
+def test_q3_shaped_plan_with_order_by_revenue_limit_10(ctx, orc):
     # the full Q3 shape: ... GROUP BY ... ORDER BY revenue DESC, o_orderdate LIMIT 10 — the TopN runs on the device chunk of groups
     customer, orders, lineitem = q3.tables(0.05)
+    want = q3_by_the_oracle(orc, customer, orders, lineitem)
     dev = [GP.DeviceChunk.from_host(ctx, t) for t in (customer, orders, lineitem)]
     try:
         out = GP.drain_device(q3.plan(ctx, *dev, batch_rows=50_000, topn=10))
         rows = [r for c in out for r in c.rows()]
-        uk, dates, prios, sums = q3.reference(customer, orders, lineitem)
-        order = np.lexsort((dates, -sums))[:10]
+        # the oracle's groups in the query's order (orc.sort_rows: SortExec restated, stable): revenue DESC, o_orderdate
+        ks = sorted(want)
+        groups = Chunk([Column(abi.I64, np.array(ks)), Column(abi.I64, np.array([want[k][0] for k in ks])), Column(abi.I64, np.array([want[k][1] for k in ks])),
+                        Column(abi.F64, np.array([want[k][2] for k in ks]))])
+        top = orc.sort_rows(groups, [3, 1], [True, False]).rows()[:10]
         assert len(rows) == 10
-        for r, i in zip(rows, order.tolist()):
-            assert r[0] == uk[i] and r[1] == dates[i] and r[2] == prios[i] and abs(r[3] - sums[i]) <= 1e-9 * abs(sums[i])
+        for r, w in zip(rows, top):
+            # the ten largest revenues are far apart compared with the SUM tolerance, so the order itself is pinned
+            assert r[0] == w[0] and r[1] == w[1] and r[2] == w[2] and abs(r[3] - w[3]) <= sum_tol(want[w[0]][3], want[w[0]][4])
         assert all(rows[i][3] >= rows[i + 1][3] for i in range(9))
     finally:
         for d in dev:
