@@ -290,6 +290,11 @@ tsq_status tsq_join_probe_finish(tsq_join* j);
  * *nrows_out == 0 && *eos == 0  -> needs more probe input;  *eos == 1 -> end of stream. */
 tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows,
                          int64_t* nrows_out, int32_t* eos);
+/* Var-len (TSQ_BYTES) columns travel through the join as payload (util/chunk/column.go:28-34: offsets + data; Chunk.AppendRow,
+ * chunk.go:334-356); join KEYS are fixed width.  A pull fills out_cols[c].offsets (cap_rows + 1 entries) and .data of such a
+ * column; tsq_join_peek tells, for the next pull of up to cap_rows rows, how many rows it will deliver and how many data bytes
+ * each var-len output column needs (bytes_out[c]; 0 for fixed-width columns), so the caller can size .data first. */
+tsq_status tsq_join_peek(tsq_join* j, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_out, int32_t n_cols);
 /* COUNT(*) fast path (config C1: SELECT count(*) FROM t1 JOIN t2 ON t1.k=t2.k): number of
  * joined rows produced so far by probe_push'd input, without materialising them.
  * Valid instead of (not mixed with) tsq_join_pull. */

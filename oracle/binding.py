@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from tinysql_amd import _abi as abi
-from tinysql_amd.chunk import Chunk, Column, make_cols, np_dtype
+from tinysql_amd.chunk import Chunk, Column, StrColumn, make_cols, np_dtype
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
@@ -37,6 +37,10 @@ def load():
     lib.orc_result_col_type.argtypes = [P, C.c_int32]
     lib.orc_result_copy_col.restype = None
     lib.orc_result_copy_col.argtypes = [P, C.c_int32, P, P]
+    lib.orc_result_col_bytes.restype = C.c_int64
+    lib.orc_result_col_bytes.argtypes = [P, C.c_int32]
+    lib.orc_result_copy_varlen.restype = None
+    lib.orc_result_copy_varlen.argtypes = [P, C.c_int32, P, P, P]
     lib.orc_result_free.restype = None
     lib.orc_result_free.argtypes = [P]
     lib.orc_last_error.restype = C.c_char_p
@@ -108,6 +112,15 @@ def _result_to_chunk(lib, res):
     cols = []
     for c in range(lib.orc_result_cols(res)):
         tp = lib.orc_result_col_type(res, c)
+        if tp == abi.BYTES:
+            nbytes = lib.orc_result_col_bytes(res, c)
+            offs = np.zeros(n + 1, dtype=np.int64)
+            raw = np.zeros(max(nbytes, 1), dtype=np.uint8)
+            nn = np.zeros(max(n, 1), dtype=np.uint8)
+            lib.orc_result_copy_varlen(res, c, offs.ctypes.data_as(C.c_void_p), raw.ctypes.data_as(C.c_void_p), nn.ctypes.data_as(C.c_void_p))
+            b = raw.tobytes()
+            cols.append(StrColumn([b[offs[i]:offs[i + 1]] if nn[i] else None for i in range(n)]))
+            continue
         data = np.zeros(max(n, 1), dtype=np_dtype(tp))
         nn = np.zeros(max(n, 1), dtype=np.uint8)
         lib.orc_result_copy_col(res, c, data.ctypes.data_as(C.c_void_p), nn.ctypes.data_as(C.c_void_p))

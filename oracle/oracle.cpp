@@ -182,11 +182,18 @@ struct RowHashMap {
 // ------------------------------------------------------------------ result set
 struct OutCol {
     int32_t type = TSQ_I64;
-    std::vector<uint64_t> v;  // raw 64-bit (F32 stored in low 32 bits)
+    std::vector<uint64_t> v;  // raw 64-bit (F32 stored in low 32 bits); TSQ_BYTES: the END offset of the cell in `bytes`
     std::vector<uint8_t> notnull;
+    std::string bytes;        // TSQ_BYTES: concatenated data (util/chunk/column.go:28-34: a NULL cell has no bytes)
     void append_raw(uint64_t bits, bool nn) {
-        v.push_back(nn ? bits : 0);
+        if (type == TSQ_BYTES) bits = bytes.size();  // AppendNull on a var-len column repeats the last offset
+        v.push_back(nn || type == TSQ_BYTES ? bits : 0);
         notnull.push_back(nn ? 1 : 0);
+    }
+    void append_bytes(const void* p, size_t n) {  // Column.AppendBytes (column.go:207-211)
+        bytes.append((const char*)p, n);
+        v.push_back(bytes.size());
+        notnull.push_back(1);
     }
 };
 
@@ -852,6 +859,11 @@ void build_table(JoinState& js) {
 
 void append_cell(OutCol& oc, const tsq_col& c, int64_t row) {
     bool isnull = col_is_null(c, row);
+    if (c.type == TSQ_BYTES) {  // Chunk.AppendRow of a var-len cell (chunk.go:334-356, appendCellByCell)
+        if (isnull) oc.append_raw(0, false);
+        else oc.append_bytes((const char*)c.data + c.offsets[row], (size_t)(c.offsets[row + 1] - c.offsets[row]));
+        return;
+    }
     oc.append_raw(isnull ? 0 : col_raw64(c, row), !isnull);
 }
 
@@ -872,6 +884,15 @@ void orc_result_copy_col(const orc_result* r, int32_t c, void* data, uint8_t* no
             memcpy(data, oc.v.data(), r->rows * 8);
         }
     }
+    if (notnull) memcpy(notnull, oc.notnull.data(), r->rows);
+}
+/* var-len result column: total data bytes; then offsets (rows + 1 entries, first 0) and the bytes */
+int64_t orc_result_col_bytes(const orc_result* r, int32_t c) { return (int64_t)r->cols[c].bytes.size(); }
+void orc_result_copy_varlen(const orc_result* r, int32_t c, int64_t* offsets, void* data, uint8_t* notnull) {
+    const OutCol& oc = r->cols[c];
+    offsets[0] = 0;
+    for (int64_t i = 0; i < r->rows; i++) offsets[i + 1] = (int64_t)oc.v[i];
+    if (!oc.bytes.empty()) memcpy(data, oc.bytes.data(), oc.bytes.size());
     if (notnull) memcpy(notnull, oc.notnull.data(), r->rows);
 }
 void orc_result_free(orc_result* r) { delete r; }

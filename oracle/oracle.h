@@ -31,6 +31,8 @@ int32_t orc_result_cols(const orc_result* r);
  * NOT-NULL byte array (1 = not null).  Either pointer may be NULL. */
 void    orc_result_copy_col(const orc_result* r, int32_t c, void* data, uint8_t* notnull);
 int32_t orc_result_col_type(const orc_result* r, int32_t c);
+int64_t orc_result_col_bytes(const orc_result* r, int32_t c);   /* TSQ_BYTES column: data bytes */
+void    orc_result_copy_varlen(const orc_result* r, int32_t c, int64_t* offsets, void* data, uint8_t* notnull);
 void    orc_result_free(orc_result* r);
 const char* orc_last_error(void);
 

@@ -46,10 +46,17 @@ def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1
         out_types = ptypes + btypes if probe_is_left else btypes + ptypes
         got = []
 
+        has_var = abi.BYTES in out_types
+
         def pull_all():
             while True:
                 keep = []
-                out, bufs = out_buffers(out_types, pull_rows, keep)
+                var_bytes = None
+                if has_var:  # size the data arrays of the var-len columns for this pull (tsq_join_peek)
+                    pn, pb = C.c_int64(0), (C.c_int64 * len(out_types))()
+                    _lib.check(lib.tsq_join_peek(h, pull_rows, C.byref(pn), pb, len(out_types)), h)
+                    var_bytes = list(pb)
+                out, bufs = out_buffers(out_types, pull_rows, keep, var_bytes)
                 n, eos = C.c_int64(0), C.c_int32(0)
                 _lib.check(lib.tsq_join_pull(h, out, len(out_types), pull_rows, C.byref(n), C.byref(eos)), h)
                 if n.value == 0:

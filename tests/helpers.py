@@ -41,6 +41,8 @@ def canon(v):
         return None
     if isinstance(v, float):
         return ("f", np.float64(v).view(np.uint64).item())
+    if isinstance(v, (bytes, bytearray)):
+        return ("b", bytes(v))
     return int(v)
 
 

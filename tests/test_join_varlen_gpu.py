@@ -1,0 +1,74 @@
+"""GPU: var-len (TSQ_BYTES, string) PAYLOAD columns through tsq_join_* — the reference's own join benchmark schema is
+(bigint key, ..., varstring payload) (executor/benchmark_test.go:328-407) — against the oracle's join (Chunk.AppendRow of var-len
+cells, util/chunk/chunk.go:334-356): host chunks of tidb_max_chunk_size rows through pinned staging, big pushes, inner and outer
+joins (NULL padding of a var-len column), NULL and empty strings, long payloads (one wave per cell), duplicates on the build side."""
+import numpy as np
+import pytest
+
+from tinysql_amd import _abi as abi
+from tinysql_amd import _lib
+from tinysql_amd.chunk import Chunk, Column, StrColumn
+
+from . import gpu_helpers as G
+from . import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def strs(rng, n, maxlen, null_p=0.1):
+    out = []
+    for _ in range(n):
+        if rng.random() < null_p:
+            out.append(None)
+        else:
+            out.append(bytes(rng.integers(0, 256, int(rng.integers(0, maxlen + 1)), dtype=np.uint8)))
+    return out
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("chunk_rows", [1024, 1 << 22])
+def test_join_with_string_payloads_vs_oracle(ctx, orc, jt, inner, chunk_rows):
+    rng = np.random.default_rng(300 + jt + chunk_rows % 7)
+    nl, nr = 9000, 6000
+    left = Chunk([Column(abi.I64, rng.integers(0, 4000, nl), rng.random(nl) > 0.05), StrColumn(strs(rng, nl, 24)), Column(abi.F64, rng.random(nl))])
+    right = Chunk([StrColumn(strs(rng, nr, 12)), Column(abi.I64, rng.integers(0, 4000, nr), rng.random(nr) > 0.05), StrColumn(strs(rng, nr, 40, 0.3))])
+    cfg = H.join_cfg(left.types(), right.types(), [0], [1], jt, inner)
+    build, probe = (right, left) if inner == 1 else (left, right)
+    want = orc.hash_join(cfg, build, probe)
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=chunk_rows, pull_rows=777)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+def test_benchmark_schema_bigint_key_and_5k_payload(ctx, orc):
+    # executor/benchmark_test.go:328: columns (bigint, ..., varstring of 5 KiB); one wave copies one cell
+    rng = np.random.default_rng(11)
+    n = 3000
+    pay = [bytes(rng.integers(0, 256, 5 << 10, dtype=np.uint8)) for _ in range(40)]
+    build = Chunk([Column(abi.I64, rng.permutation(n).astype(np.int64)), StrColumn([pay[i % 40] + bytes([i % 251]) for i in range(n)])])
+    probe = Chunk([Column(abi.I64, rng.integers(0, n + 500, 2 * n)), StrColumn([pay[(7 * i) % 40][: 100 + i % 900] for i in range(2 * n)])])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe)
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1024, pull_rows=500)
+    assert got.NumRows() == want.NumRows() > n and H.rows_equal_unordered(got, want)
+
+
+def test_string_join_key_is_handed_back_to_go(ctx):
+    t = [abi.BYTES, abi.I64]
+    cfg = H.join_cfg(t, t, [0], [0], abi.JOIN_INNER, 1)
+    h = None
+    import ctypes as C
+    hh = C.c_void_p()
+    st = ctx.lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(hh))
+    assert st == abi.ERR_UNSUPPORTED
+
+
+def test_count_and_empty_inputs_with_string_columns(ctx, orc):
+    rng = np.random.default_rng(5)
+    build = Chunk([Column(abi.I64, np.arange(100)), StrColumn(strs(rng, 100, 8))])
+    probe = Chunk([Column(abi.I64, rng.integers(0, 150, 1000)), StrColumn(strs(rng, 1000, 8))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe)
+    assert G.run_join(ctx, cfg, build, probe, count_only=True) == want.NumRows()
+    empty = Chunk([Column(abi.I64, np.zeros(0, np.int64)), StrColumn([])])
+    assert G.run_join(ctx, cfg, empty, probe).NumRows() == 0
+    assert G.run_join(ctx, cfg, build, empty).NumRows() == 0

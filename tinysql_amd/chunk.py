@@ -173,36 +173,53 @@ class Chunk:
         return [tuple(col[i] for col in cols) for i in idx]
 
 
-def out_buffers(types, cap, keep):
-    """allocates output columns for a pull of up to `cap` rows; returns (tsq_col array, [(data, bitmap)])."""
+def out_buffers(types, cap, keep, var_bytes=None):
+    """allocates output columns for a pull of up to `cap` rows; returns (tsq_col array, [(data, bitmap[, offsets])]).
+    var_bytes[i] = data bytes of var-len column i for this pull (tsq_join_peek)."""
     arr = (abi.Col * len(types))()
     bufs = []
     for i, tp in enumerate(types):
-        data = np.zeros(cap, dtype=_NP[tp])
         bm = np.zeros((cap + 7) // 8 + 8, dtype=np.uint8)
+        if tp == abi.BYTES:
+            data = np.zeros((var_bytes[i] if var_bytes is not None else 0) + 8, dtype=np.uint8)
+            offs = np.zeros(cap + 1, dtype=np.int64)
+            arr[i].offsets = offs.ctypes.data_as(C.c_void_p)
+            arr[i].elem_size = -1
+            bufs.append((data, bm, offs))
+        else:
+            data = np.zeros(cap, dtype=_NP[tp])
+            arr[i].elem_size = elem_size(tp)
+            bufs.append((data, bm))
         arr[i].data = data.ctypes.data_as(C.c_void_p)
         arr[i].null_bitmap = bm.ctypes.data_as(C.c_void_p)
         arr[i].length = cap
-        arr[i].elem_size = elem_size(tp)
         arr[i].type = tp
         arr[i].flags = 0
-        bufs.append((data, bm))
     keep.append(bufs)
     return arr, bufs
 
 
 def chunk_from_buffers(types, bufs, n):
     cols = []
-    for tp, (data, bm) in zip(types, bufs):
-        cols.append(Column(tp, data[:n].copy(), unpack_bitmap(bm, n)))
+    for tp, b in zip(types, bufs):
+        if tp == abi.BYTES:
+            data, bm, offs = b
+            nn = unpack_bitmap(bm, n)
+            raw = data.tobytes()
+            cols.append(StrColumn([raw[offs[i]:offs[i + 1]] if nn[i] else None for i in range(n)]))
+        else:
+            cols.append(Column(tp, b[0][:n].copy(), unpack_bitmap(b[1], n)))
     return Chunk(cols)
 
 
 def concat(chunks, types):
     if not chunks:
-        return Chunk([Column(tp, np.zeros(0, _NP[tp])) for tp in types])
+        return Chunk([StrColumn([]) if tp == abi.BYTES else Column(tp, np.zeros(0, _NP[tp])) for tp in types])
     cols = []
     for i, tp in enumerate(types):
+        if tp == abi.BYTES:
+            cols.append(StrColumn([v for c in chunks for v in c.columns[i].values()]))
+            continue
         data = np.concatenate([c.columns[i].data for c in chunks])
         if any(c.columns[i].notnull is not None for c in chunks):
             nn = np.concatenate([

@@ -293,3 +293,97 @@ tsq_status tsq_launch_append_bits(tsq_ctx* ctx, tsq_handle_hdr* h, uint8_t* dst,
     TSQ_HIP(h, hipGetLastError());
     return TSQ_OK;
 }
+
+// ---------------------------------------------------------------- var-len columns (util/chunk/column.go:28-34: offsets[n + 1] + data)
+// dst[i] = src[i] + delta: the offsets of an appended chunk, or of a pulled slice, moved to their new base
+__global__ void __launch_bounds__(256) k_offsets_rebase(int64_t* dst, const int64_t* src, int64_t n, int64_t delta) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i] + delta;
+}
+tsq_status tsq_launch_offsets_rebase(tsq_ctx* ctx, tsq_handle_hdr* h, int64_t* dst, const int64_t* src_dev, int64_t n, int64_t delta) {
+    if (n <= 0) return TSQ_OK;
+    hipLaunchKernelGGL(k_offsets_rebase, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, dst, src_dev, n, delta);
+    TSQ_HIP(h, hipGetLastError());
+    return TSQ_OK;
+}
+
+// exclusive prefix sum of n int64 lengths in place; v[n] receives the total.  Three launches: sums of 2048-element blocks, a
+// one-workgroup scan of those, the blocks again with their bases.
+#define TSQ_SCAN_BLK 2048
+__global__ void __launch_bounds__(256) k_scan64_sums(const int64_t* v, int64_t n, unsigned long long* sums) {
+    __shared__ unsigned long long s_w[4];
+    const int64_t b0 = (int64_t)blockIdx.x * TSQ_SCAN_BLK;
+    unsigned long long acc = 0;
+    for (int k = 0; k < TSQ_SCAN_BLK / 256; k++) {
+        const int64_t i = b0 + k * 256 + threadIdx.x;
+        if (i < n) acc += (unsigned long long)v[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(1024) k_scan64_top(unsigned long long* sums, int n) {  // exclusive, in place; sums[n] = total
+    __shared__ unsigned long long s_w[16];
+    const int per = (n + 1023) / 1024, lo = threadIdx.x * per;
+    unsigned long long sum = 0;
+    for (int i = lo; i < lo + per && i < n; i++) sum += sums[i];
+    unsigned long long x = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long y = __shfl_up(x, o, 64);
+        if ((int)(threadIdx.x & 63) >= o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < (int)(threadIdx.x >> 6)) pre += s_w[w];
+        tot += s_w[w];
+    }
+    unsigned long long run = pre + x - sum;
+    for (int i = lo; i < lo + per && i < n; i++) {
+        const unsigned long long c = sums[i];
+        sums[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0) sums[n] = tot;
+}
+__global__ void __launch_bounds__(256) k_scan64_apply(int64_t* v, int64_t n, const unsigned long long* sums) {
+    __shared__ unsigned long long s_w[4];
+    __shared__ unsigned long long s_run;
+    const int64_t b0 = (int64_t)blockIdx.x * TSQ_SCAN_BLK;
+    if (threadIdx.x == 0) s_run = sums[blockIdx.x];
+    __syncthreads();
+    for (int k = 0; k < TSQ_SCAN_BLK / 256; k++) {
+        const int64_t i = b0 + k * 256 + threadIdx.x;
+        const unsigned long long c = i < n ? (unsigned long long)v[i] : 0ull;
+        unsigned long long x = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long y = __shfl_up(x, o, 64);
+            if ((int)(threadIdx.x & 63) >= o) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = x;
+        __syncthreads();
+        unsigned long long pre = s_run;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) pre += s_w[w];
+        if (i < n) v[i] = (int64_t)(pre + x - c);
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) v[n] = (int64_t)sums[gridDim.x];
+}
+// v: n + 1 entries; scratch: (blocks + 1) words
+tsq_status tsq_launch_scan64(tsq_ctx* ctx, tsq_handle_hdr* h, int64_t* v, int64_t n, DevBuf& scratch) {
+    if (n <= 0) {
+        TSQ_HIP(h, hipMemsetAsync(v, 0, 8, ctx->stream));
+        return TSQ_OK;
+    }
+    const int64_t blocks = (n + TSQ_SCAN_BLK - 1) / TSQ_SCAN_BLK;
+    if (blocks > 0x7ffffff0LL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "scan: too many rows");
+    TSQ_TRY(scratch.reserve(ctx, h, (size_t)(blocks + 1) * 8 + 64));
+    hipLaunchKernelGGL(k_scan64_sums, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, v, n, scratch.as<unsigned long long>());
+    hipLaunchKernelGGL(k_scan64_top, dim3(1), dim3(1024), 0, ctx->stream, scratch.as<unsigned long long>(), (int)blocks);
+    hipLaunchKernelGGL(k_scan64_apply, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, v, n, scratch.as<unsigned long long>());
+    TSQ_HIP(h, hipGetLastError());
+    return TSQ_OK;
+}

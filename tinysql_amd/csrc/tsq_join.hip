@@ -361,6 +361,7 @@ struct GatherArgs {
 };
 __global__ void __launch_bounds__(256) k_gather_cols(GatherArgs a) {
     const GatherCol c = a.col[blockIdx.y];
+    if (c.es == 0) return;  // a var-len column: k_varlen_* handle it
     const int64_t groups = (a.rows + 7) >> 3;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r0 = g << 3;
@@ -412,6 +413,80 @@ __global__ void __launch_bounds__(256) k_gather_cols(GatherArgs a) {
             }
         }
         if (c.dst_bitmap) c.dst_bitmap[g] = (uint8_t)nn;
+    }
+}
+
+// K4c — var-len output columns (util/chunk/column.go:28-34; Chunk.AppendRow of a var-len cell, chunk.go:334-356): the lengths of
+// the gathered cells (k_varlen_len), their exclusive scan = the output offsets (tsq_launch_scan64), then the bytes.
+struct VarGatherArgs {
+    const unsigned long long* pairs;
+    int64_t rows;
+    const int64_t* src_offs;
+    const uint8_t* src_data;
+    const uint8_t* src_nulls;
+    int32_t from_probe;
+    int64_t* out_offs;    // [rows + 1]: k_varlen_len leaves the lengths, the scan turns them into offsets
+    uint8_t* out_data;
+    uint8_t* out_bitmap;  // packed, or null when the column cannot hold NULLs
+};
+__device__ __forceinline__ uint32_t var_src_row(const VarGatherArgs& a, int64_t r, bool* valid) {
+    const unsigned long long v = a.pairs[r];
+    const uint32_t idx = a.from_probe ? (uint32_t)v : (uint32_t)(v >> 32);
+    bool ok = a.from_probe || idx != TSQ_PAIR_MISS;
+    if (ok && a.src_nulls) ok = (a.src_nulls[idx >> 3] >> (idx & 7)) & 1;
+    *valid = ok;
+    return idx;
+}
+__global__ void __launch_bounds__(256) k_varlen_len(VarGatherArgs a) {
+    const int64_t groups = (a.rows + 7) >> 3;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r0 = g << 3;
+        uint32_t nn = 0;
+        for (int i = 0; i < 8 && r0 + i < a.rows; i++) {
+            bool ok;
+            const uint32_t idx = var_src_row(a, r0 + i, &ok);
+            a.out_offs[r0 + i] = ok ? a.src_offs[idx + 1] - a.src_offs[idx] : 0;  // a NULL cell has no bytes
+            nn |= ok ? (1u << i) : 0u;
+        }
+        if (a.out_bitmap) a.out_bitmap[g] = (uint8_t)nn;
+    }
+}
+// short cells: one row per lane
+__global__ void __launch_bounds__(256) k_varlen_copy_rows(VarGatherArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x) {
+        bool ok;
+        const uint32_t idx = var_src_row(a, r, &ok);
+        if (!ok) continue;
+        const uint8_t* s = a.src_data + a.src_offs[idx];
+        uint8_t* d = a.out_data + a.out_offs[r];
+        const int64_t n = a.out_offs[r + 1] - a.out_offs[r];
+        for (int64_t i = 0; i < n; i++) d[i] = s[i];
+    }
+}
+// long cells (the reference's join benchmark carries a 5 KiB payload, executor/benchmark_test.go:328): one row per wave, 64 lanes on
+// consecutive bytes
+__global__ void __launch_bounds__(256) k_varlen_copy_wave(VarGatherArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < a.rows; r += nwaves) {
+        bool ok;
+        const uint32_t idx = var_src_row(a, r, &ok);
+        if (!ok) continue;
+        const uint8_t* s = a.src_data + a.src_offs[idx];
+        uint8_t* d = a.out_data + a.out_offs[r];
+        const int64_t n = a.out_offs[r + 1] - a.out_offs[r];
+        // head up to an 8-byte boundary of the destination, then 8 bytes per lane, then the tail
+        int64_t head = (8 - ((uintptr_t)d & 7)) & 7;
+        head = head < n ? head : n;
+        if (lane < head) d[lane] = s[lane];
+        const int64_t words = (n - head) >> 3;
+        for (int64_t w = lane; w < words; w += 64) {
+            uint64_t x;
+            memcpy(&x, s + head + w * 8, 8);  // the source is not aligned with the destination
+            *reinterpret_cast<uint64_t*>(d + head + w * 8) = x;
+        }
+        const int64_t done = head + words * 8;
+        if (done + lane < n) d[done + lane] = s[done + lane];
     }
 }
 
@@ -544,14 +619,18 @@ struct ResultBatch {  // one probe batch worth of joined rows
     std::vector<DevBuf> data;        // per output column, device
     std::vector<DevBuf> notnull;     // per output column, device byte flags (cap 0 => column has no NULLs)
     std::vector<DevBuf> bitmap;      // packed null bitmaps (device)
+    std::vector<DevBuf> offs;        // var-len output columns: offsets[rows + 1] (device)
+    std::vector<int64_t> nbytes;     // ... and their data bytes
     bool on_host = false;
-    std::vector<PinnedBuf> hdata, hbitmap;
+    std::vector<PinnedBuf> hdata, hbitmap, hoffs;
     void release() {
         for (auto& b : data) b.release();
         for (auto& b : notnull) b.release();
         for (auto& b : bitmap) b.release();
+        for (auto& b : offs) b.release();
         for (auto& b : hdata) b.release();
         for (auto& b : hbitmap) b.release();
+        for (auto& b : hoffs) b.release();
     }
 };
 
@@ -625,14 +704,15 @@ bool is_int_class(int32_t t) { return t == TSQ_I64 || t == TSQ_U64; }
 tsq_status build_flush(tsq_join* j) {
     HostStage& sg = j->stage;
     if (sg.staged == 0) return TSQ_OK;
-    DevBuf tmp;
+    DevBuf tmp, tmp2;
     for (size_t c = 0; c < j->bcols.size(); c++) {
-        tsq_status s = tsq_col_append(j->ctx, &j->hdr, j->bcols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
-        if (s != TSQ_OK) { tmp.release(); return s; }
-        j->st.h2d_bytes += sg.staged * j->bcols[c].elem();
+        tsq_status s = sg.append_to(j->ctx, &j->hdr, (int)c, j->bcols[c], tmp, tmp2);
+        if (s != TSQ_OK) { tmp.release(); tmp2.release(); return s; }
+        j->st.h2d_bytes += j->bcols[c].type == TSQ_BYTES ? sg.nbytes[c] + sg.staged * 8 : sg.staged * j->bcols[c].elem();
     }
     hipError_t e = hipStreamSynchronize(j->ctx->stream);  // staging memory is reused
     tmp.release();
+    tmp2.release();
     sg.reset();
     if (e != hipSuccess) return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return TSQ_OK;
@@ -725,14 +805,20 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
     if (j->host_mode) {
         rb->hdata.resize(nout);
         rb->hbitmap.resize(nout);
+        rb->hoffs.resize(nout);
         for (int oc = 0; oc < nout; oc++) {
             const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
             const int sc = oc < nl ? oc : oc - nl;
             const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
-            size_t bytes = (size_t)out_rows * tsq_elem_size(type);
+            size_t bytes = type == TSQ_BYTES ? (size_t)rb->nbytes[oc] : (size_t)out_rows * tsq_elem_size(type);
             tsq_status s = rb->hdata[oc].reserve(&j->hdr, bytes + 16);
+            if (s == TSQ_OK && type == TSQ_BYTES) s = rb->hoffs[oc].reserve(&j->hdr, ((size_t)out_rows + 1) * 8 + 16);
             if (s != TSQ_OK) { rb->release(); return s; }
-            TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (bytes) TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (type == TSQ_BYTES) {
+                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hoffs[oc].p, rb->offs[oc].p, ((size_t)out_rows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                bytes += ((size_t)out_rows + 1) * 8;
+            }
             j->st.d2h_bytes += bytes;
             if (may_null_v[oc]) {
                 s = rb->hbitmap[oc].reserve(&j->hdr, tsq_bitmap_bytes(out_rows) + 16);
@@ -744,6 +830,7 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
         for (auto& b : rb->data) b.release();
         for (auto& b : rb->notnull) b.release();
         for (auto& b : rb->bitmap) b.release();
+        for (auto& b : rb->offs) b.release();
         rb->on_host = true;
     } else {
         TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
@@ -926,9 +1013,9 @@ bool radix_emit_eligible(const tsq_join* j, const tsq_colset& pcs, int64_t nrows
     const int32_t kt = j->cfg.build_types[j->ks.bidx[0]];
     if ((kt != TSQ_I64 && kt != TSQ_U64) || j->cfg.probe_types[j->ks.pidx[0]] != kt) return false;
     for (int c = 0; c < j->cfg.n_probe_cols; c++)
-        if (tsq_elem_size(j->cfg.probe_types[c]) != 8 || pcs.nulls[c]) return false;
+        if (j->cfg.probe_types[c] == TSQ_F32 || j->cfg.probe_types[c] == TSQ_BYTES || pcs.nulls[c]) return false;
     for (int c = 0; c < j->cfg.n_build_cols; c++)
-        if (tsq_elem_size(j->cfg.build_types[c]) != 8 || j->bcols[c].has_nulls) return false;
+        if (j->cfg.build_types[c] == TSQ_F32 || j->cfg.build_types[c] == TSQ_BYTES || j->bcols[c].has_nulls) return false;
     if (!radix_plan_for(j).lds) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE) return true;
     return nrows >= (4 << 20);
@@ -1072,6 +1159,8 @@ tsq_status radix_emit(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     rb->data.resize(nout);
     rb->notnull.resize(nout);
     rb->bitmap.resize(nout);
+    rb->offs.resize(nout);
+    rb->nbytes.assign(nout, 0);
     std::vector<bool> may_null_v(nout, false);
     for (int oc = 0; oc < nout; oc++) {
         tsq_status s = rb->data[oc].reserve(ctx, h, ((size_t)out_rows + 8) * 8 + 16);
@@ -1170,6 +1259,8 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     rb->data.resize(nout);
     rb->notnull.resize(nout);
     rb->bitmap.resize(nout);
+    rb->offs.resize(nout);
+    rb->nbytes.assign(nout, 0);
     const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
     const int nl = a.probe_is_left ? j->cfg.n_probe_cols : j->cfg.n_build_cols;
     if (nrows > 0xffffffffLL) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "internal: probe slice too large");
@@ -1187,10 +1278,16 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         const bool src_nulls = from_probe ? pcs.nulls[sc] != nullptr : j->bcols[sc].has_nulls;
         const bool may_null = src_nulls || (outer && !from_probe);
         may_null_v[oc] = may_null;
-        tsq_status s = rb->data[oc].reserve(ctx, &j->hdr, ((size_t)out_rows + 8) * tsq_elem_size(type) + 16);
+        tsq_status s = type == TSQ_BYTES ? rb->offs[oc].reserve(ctx, &j->hdr, ((size_t)out_rows + 2) * 8 + 16)
+                                         : rb->data[oc].reserve(ctx, &j->hdr, ((size_t)out_rows + 8) * tsq_elem_size(type) + 16);
         if (s == TSQ_OK && may_null) s = rb->bitmap[oc].reserve(ctx, &j->hdr, tsq_bitmap_bytes(out_rows) + 16);
         if (s != TSQ_OK) { rb->release(); return s; }
         GatherCol& gc = ga.col[oc];
+        if (type == TSQ_BYTES) {  // es == 0: skipped by k_gather_cols, gathered below
+            gc.es = 0;
+            gc.from_probe = from_probe ? 1 : 0;
+            continue;
+        }
         gc.src = from_probe ? a.p.data[sc] : a.b.data[sc];
         gc.src_nulls = src_nulls ? (from_probe ? a.p.nulls[sc] : a.b.nulls[sc]) : nullptr;
         gc.dst = rb->data[oc].p;
@@ -1218,6 +1315,46 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         TSQ_HIP(&j->hdr, hipGetLastError());
         j->st.kernel_launches++;
     }
+    // var-len output columns: lengths -> offsets (exclusive scan) -> bytes
+    for (int oc = 0; oc < nout; oc++) {
+        const bool from_probe = a.probe_is_left ? oc < nl : oc >= nl;
+        const int sc = oc < nl ? oc : oc - nl;
+        const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
+        if (type != TSQ_BYTES) continue;
+        VarGatherArgs va;
+        memset(&va, 0, sizeof va);
+        va.pairs = a.pairs;
+        va.rows = out_rows;
+        va.from_probe = from_probe ? 1 : 0;
+        va.src_offs = from_probe ? pcs.offs[sc] : j->bcols[sc].offs.as<int64_t>();
+        va.src_data = (const uint8_t*)(from_probe ? pcs.data[sc] : j->bcols[sc].data.p);
+        va.src_nulls = from_probe ? pcs.nulls[sc] : (j->bcols[sc].has_nulls ? j->bcols[sc].nulls.as<uint8_t>() : nullptr);
+        va.out_offs = rb->offs[oc].as<int64_t>();
+        va.out_bitmap = may_null_v[oc] ? rb->bitmap[oc].as<uint8_t>() : nullptr;
+        const int gl = tsq_grid_for(ctx, (out_rows + 7) / 8, 256);
+        hipLaunchKernelGGL(k_varlen_len, dim3(gl), dim3(256), 0, ctx->stream, va);
+        TSQ_HIP(&j->hdr, hipGetLastError());
+        DevBuf scratch;
+        tsq_status s = tsq_launch_scan64(ctx, &j->hdr, va.out_offs, out_rows, scratch);
+        if (s == TSQ_OK) {
+            hipError_t e = hipMemcpyAsync(ctx->pinned + 42, va.out_offs + out_rows, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) s = tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("var-len gather: ") + hipGetErrorString(e));
+        }
+        scratch.release();
+        if (s != TSQ_OK) { rb->release(); return s; }
+        const int64_t nbytes = (int64_t)ctx->pinned[42];
+        rb->nbytes[oc] = nbytes;
+        s = rb->data[oc].reserve(ctx, &j->hdr, (size_t)nbytes + 64);
+        if (s != TSQ_OK) { rb->release(); return s; }
+        va.out_data = rb->data[oc].as<uint8_t>();
+        if (nbytes > 0) {
+            if (nbytes / out_rows > 32) hipLaunchKernelGGL(k_varlen_copy_wave, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, va);
+            else hipLaunchKernelGGL(k_varlen_copy_rows, dim3(tsq_grid_for(ctx, out_rows, 256)), dim3(256), 0, ctx->stream, va);
+            TSQ_HIP(&j->hdr, hipGetLastError());
+        }
+        j->st.kernel_launches += 5;
+    }
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
     j->have_probe_ev = true;
     return deliver_batch(j, std::move(rb), may_null_v);
@@ -1227,20 +1364,19 @@ tsq_status probe_flush(tsq_join* j) {
     HostStage& sg = j->stage;
     if (sg.staged == 0) return TSQ_OK;
     tsq_ctx* ctx = j->ctx;
-    DevBuf tmp;
+    DevBuf tmp, tmp2;
     for (size_t c = 0; c < j->pcols.size(); c++) {
-        j->pcols[c].rows = 0;
-        j->pcols[c].has_nulls = false;
-        tsq_status s = tsq_col_append(ctx, &j->hdr, j->pcols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
-        if (s != TSQ_OK) { tmp.release(); return s; }
-        j->st.h2d_bytes += sg.staged * j->pcols[c].elem();
+        j->pcols[c].clear();
+        tsq_status s = sg.append_to(ctx, &j->hdr, (int)c, j->pcols[c], tmp, tmp2);
+        if (s != TSQ_OK) { tmp.release(); tmp2.release(); return s; }
+        j->st.h2d_bytes += j->pcols[c].type == TSQ_BYTES ? sg.nbytes[c] + sg.staged * 8 : sg.staged * j->pcols[c].elem();
     }
     const uint8_t* sel_dev = nullptr;
     if (sg.sel_any) {
         tsq_status s = j->psel.reserve(ctx, &j->hdr, (size_t)sg.staged + 16);
-        if (s != TSQ_OK) { tmp.release(); return s; }
+        if (s != TSQ_OK) { tmp.release(); tmp2.release(); return s; }
         hipError_t e = hipMemcpyAsync(j->psel.p, sg.sel.p, (size_t)sg.staged, hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) { tmp.release(); return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipMemcpyAsync(sel): ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { tmp.release(); tmp2.release(); return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipMemcpyAsync(sel): ") + hipGetErrorString(e)); }
         sel_dev = j->psel.as<uint8_t>();
     }
     tsq_colset pcs;
@@ -1249,6 +1385,7 @@ tsq_status probe_flush(tsq_join* j) {
     // staging (pinned) memory is reused by the next pushes: wait for the H2D copies
     hipError_t e = hipStreamSynchronize(ctx->stream);
     tmp.release();
+    tmp2.release();
     sg.reset();
     if (s != TSQ_OK) return s;
     if (e != hipSuccess) return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
@@ -1439,15 +1576,17 @@ TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_jo
     if (cfg->n_build_cols < 1 || cfg->n_build_cols > TSQ_MAX_COLS || cfg->n_probe_cols < 1 || cfg->n_probe_cols > TSQ_MAX_COLS)
         return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 columns per side supported");
     for (int c = 0; c < cfg->n_build_cols; c++)
-        if (cfg->build_types[c] < TSQ_I64 || cfg->build_types[c] > TSQ_F64)
-            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len build column: fall back to the Go operator");
+        if (cfg->build_types[c] < TSQ_I64 || cfg->build_types[c] > TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_INVALID, "unknown build column type");
     for (int c = 0; c < cfg->n_probe_cols; c++)
-        if (cfg->probe_types[c] < TSQ_I64 || cfg->probe_types[c] > TSQ_F64)
-            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len probe column: fall back to the Go operator");
+        if (cfg->probe_types[c] < TSQ_I64 || cfg->probe_types[c] > TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_INVALID, "unknown probe column type");
     for (int k = 0; k < cfg->n_keys; k++) {
         if (cfg->build_key_idx[k] < 0 || cfg->build_key_idx[k] >= cfg->n_build_cols || cfg->probe_key_idx[k] < 0 ||
             cfg->probe_key_idx[k] >= cfg->n_probe_cols)
             return tsq_fail(ch, TSQ_ERR_INVALID, "join key index out of range");
+        // var-len (string) columns travel through the join as payload; a string JOIN KEY (codec.go:233-235: compactBytesFlag + bytes)
+        // is not hashed on the GPU yet
+        if (cfg->build_types[cfg->build_key_idx[k]] == TSQ_BYTES || cfg->probe_types[cfg->probe_key_idx[k]] == TSQ_BYTES)
+            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len join key: fall back to the Go operator");
     }
     if ((cfg->n_other_conds > 0 && !cfg->other_conds) || (cfg->n_outer_filters > 0 && !cfg->outer_filters) ||
         cfg->n_other_conds < 0 || cfg->n_outer_filters < 0 || cfg->n_other_conds > 16 || cfg->n_outer_filters > 16)
@@ -1533,12 +1672,15 @@ TSQ_API tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t
         return tsq_fail(&j->hdr, TSQ_ERR_UNSUPPORTED, "build side exceeds 2^32 rows per GPU: partition across GPUs first");
     if (dev) {
         TSQ_TRY(build_flush(j));
-        DevBuf tmp;
+        DevBuf tmp, tmp2;
         for (int c = 0; c < n_cols; c++) {
-            tsq_status s = tsq_col_append(j->ctx, &j->hdr, j->bcols[c], cols[c].data, cols[c].null_bitmap, nrows, true, tmp);
-            if (s != TSQ_OK) { tmp.release(); return s; }
+            tsq_status s = cols[c].type == TSQ_BYTES
+                               ? tsq_col_append_varlen(j->ctx, &j->hdr, j->bcols[c], cols[c].data, cols[c].offsets, cols[c].null_bitmap, nrows, true, tmp, tmp2)
+                               : tsq_col_append(j->ctx, &j->hdr, j->bcols[c], cols[c].data, cols[c].null_bitmap, nrows, true, tmp);
+            if (s != TSQ_OK) { tmp.release(); tmp2.release(); return s; }
         }
         tmp.release();
+        tmp2.release();
         return TSQ_OK;
     }
     if (j->stage.cap == 0) TSQ_TRY(j->stage.init(&j->hdr, n_cols, j->cfg.build_types, 1 << 20));
@@ -1674,6 +1816,9 @@ TSQ_API tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode) {
 TSQ_API tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on) {
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     if (!j->count_only) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "checksum needs count-only mode");
+    for (int c = 0; on && c < j->cfg.n_build_cols + j->cfg.n_probe_cols; c++)
+        if ((c < j->cfg.n_build_cols ? j->cfg.build_types[c] : j->cfg.probe_types[c - j->cfg.n_build_cols]) == TSQ_BYTES)
+            return tsq_fail(&j->hdr, TSQ_ERR_UNSUPPORTED, "the row checksum does not cover var-len columns");
     j->checksum = on != 0;
     return TSQ_OK;
 }
@@ -1766,7 +1911,13 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
         const bool odev = o.flags & TSQ_COL_DEVICE;
         if (!o.data) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: out column data == NULL");
         const bool has_bm = rb->on_host ? rb->hbitmap[oc].p != nullptr : rb->bitmap[oc].p != nullptr;
+        if (type == TSQ_BYTES && !o.offsets) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: var-len out column needs an offsets buffer (tsq_join_peek tells the data bytes)");
         if (rb->on_host && !odev) {
+            if (type == TSQ_BYTES) {  // cells [cursor, cursor + n): their bytes, and the offsets moved to start at 0
+                const int64_t* so = (const int64_t*)rb->hoffs[oc].p + rb->cursor;
+                memcpy(o.data, (const char*)rb->hdata[oc].p + so[0], (size_t)(so[n] - so[0]));
+                for (int64_t i = 0; i <= n; i++) o.offsets[i] = so[i] - so[0];
+            } else
             memcpy(o.data, (const char*)rb->hdata[oc].p + (size_t)rb->cursor * es, (size_t)n * es);
             if (o.null_bitmap) {
                 if (!has_bm) memset(o.null_bitmap, 0xff, tsq_bitmap_bytes(n));
@@ -1784,6 +1935,15 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
                 return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: column may contain NULLs but no null_bitmap buffer was given");
             }
         } else if (!rb->on_host && odev) {
+            if (type == TSQ_BYTES) {
+                const int64_t* so = rb->offs[oc].as<int64_t>() + rb->cursor;
+                TSQ_HIP(&j->hdr, hipMemcpyAsync(j->ctx->pinned + 44, so, 8, hipMemcpyDeviceToHost, j->ctx->stream));
+                TSQ_HIP(&j->hdr, hipMemcpyAsync(j->ctx->pinned + 45, so + n, 8, hipMemcpyDeviceToHost, j->ctx->stream));
+                TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
+                const int64_t b0 = (int64_t)j->ctx->pinned[44], b1 = (int64_t)j->ctx->pinned[45];
+                if (b1 > b0) TSQ_HIP(&j->hdr, hipMemcpyAsync(o.data, (const char*)rb->data[oc].p + b0, (size_t)(b1 - b0), hipMemcpyDeviceToDevice, j->ctx->stream));
+                TSQ_TRY(tsq_launch_offsets_rebase(j->ctx, &j->hdr, o.offsets, so, n + 1, -b0));
+            } else
             TSQ_HIP(&j->hdr, hipMemcpyAsync(o.data, (const char*)rb->data[oc].p + (size_t)rb->cursor * es, (size_t)n * es, hipMemcpyDeviceToDevice, j->ctx->stream));
             if (o.null_bitmap) {
                 if ((rb->cursor & 7) != 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "device pull: cap_rows must keep the cursor a multiple of 8");
@@ -1797,11 +1957,48 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
         }
         o.length = n;
         o.type = type;
-        o.elem_size = es;
+        o.elem_size = type == TSQ_BYTES ? -1 : es;
     }
     if (!rb->on_host) TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
     rb->cursor += n;
     *nrows_out = n;
+    return TSQ_OK;
+}
+
+// What the next tsq_join_pull of up to cap_rows rows will deliver: the row count and, per output column, the data bytes of a
+// var-len column (0 for fixed-width columns) — a Go caller sizes its chunk.Column.data with it (column.go:207-211 grows by append).
+TSQ_API tsq_status tsq_join_peek(tsq_join* j, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_out, int32_t n_cols) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (!nrows_out || !bytes_out) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "NULL out pointer");
+    const int nout = j->cfg.n_probe_cols + j->cfg.n_build_cols;
+    if (n_cols != nout) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "peek: column count must be n_probe_cols + n_build_cols");
+    *nrows_out = 0;
+    for (int oc = 0; oc < nout; oc++) bytes_out[oc] = 0;
+    TSQ_TRY(check_cancel(j));
+    TSQ_HIP(&j->hdr, hipSetDevice(j->ctx->device));
+    while (!j->results.empty() && j->results.front()->cursor >= j->results.front()->rows) {
+        j->results.front()->release();
+        j->results.pop_front();
+    }
+    if (j->results.empty()) return TSQ_OK;
+    ResultBatch* rb = j->results.front().get();
+    const int64_t n = std::min<int64_t>(cap_rows, rb->rows - rb->cursor);
+    if (n <= 0) return TSQ_OK;
+    *nrows_out = n;
+    for (int oc = 0; oc < nout; oc++) {
+        if (rb->on_host ? !(oc < (int)rb->hoffs.size() && rb->hoffs[oc].p) : !rb->offs[oc].p) continue;
+        if (rb->on_host) {
+            const int64_t* so = (const int64_t*)rb->hoffs[oc].p + rb->cursor;
+            bytes_out[oc] = so[n] - so[0];
+        } else {
+            const int64_t* so = rb->offs[oc].as<int64_t>() + rb->cursor;
+            TSQ_HIP(&j->hdr, hipMemcpyAsync(j->ctx->pinned + 44, so, 8, hipMemcpyDeviceToHost, j->ctx->stream));
+            TSQ_HIP(&j->hdr, hipMemcpyAsync(j->ctx->pinned + 45, so + n, 8, hipMemcpyDeviceToHost, j->ctx->stream));
+            TSQ_HIP(&j->hdr, hipStreamSynchronize(j->ctx->stream));
+            bytes_out[oc] = (int64_t)j->ctx->pinned[45] - (int64_t)j->ctx->pinned[44];
+        }
+    }
     return TSQ_OK;
 }
 
