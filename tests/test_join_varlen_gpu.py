@@ -72,3 +72,57 @@ def test_count_and_empty_inputs_with_string_columns(ctx, orc):
     empty = Chunk([Column(abi.I64, np.zeros(0, np.int64)), StrColumn([])])
     assert G.run_join(ctx, cfg, empty, probe).NumRows() == 0
     assert G.run_join(ctx, cfg, build, empty).NumRows() == 0
+
+
+@pytest.mark.parametrize("n,maxlen", [(1, 5), (64, 9), (70001, 12), (3000, 700)])
+def test_chunk_compact_with_a_string_column(ctx, n, maxlen):
+    # SelectionExec's copy of the selected rows / Column.CopyReconstruct of a var-len column (executor.go:401-438, column.go:504-552)
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    vals = strs(rng, n, maxlen, 0.2)
+    sc = StrColumn(vals)
+    ints = Column(abi.I64, rng.integers(-9, 9, n), rng.random(n) > 0.3)
+    sel = rng.random(n) > 0.45
+    bufs = []
+
+    def dev(arr):
+        arr = np.ascontiguousarray(arr)
+        p = ctx.alloc(max(arr.nbytes, 8) + 64)
+        ctx.h2d(p, arr)
+        bufs.append(p)
+        return p
+
+    try:
+        cin = (abi.Col * 2)()
+        cin[0].data, cin[0].offsets, cin[0].null_bitmap = dev(sc.data), dev(sc.offsets), dev(sc.bitmap())
+        cin[0].length, cin[0].elem_size, cin[0].type, cin[0].flags = n, -1, abi.BYTES, abi.COL_DEVICE
+        cin[1].data, cin[1].null_bitmap = dev(ints.data), dev(ints.bitmap())
+        cin[1].length, cin[1].elem_size, cin[1].type, cin[1].flags = n, 8, abi.I64, abi.COL_DEVICE
+        cout = (abi.Col * 2)()
+        cout[0].data, cout[0].offsets, cout[0].null_bitmap = dev(np.zeros(len(sc.data) + 8, np.uint8)), dev(np.zeros(n + 1, np.int64)), dev(np.zeros(n // 8 + 8, np.uint8))
+        cout[0].length, cout[0].elem_size, cout[0].type, cout[0].flags = n, -1, abi.BYTES, abi.COL_DEVICE
+        cout[1].data, cout[1].null_bitmap = dev(np.zeros(n, np.int64)), dev(np.zeros(n // 8 + 8, np.uint8))
+        cout[1].length, cout[1].elem_size, cout[1].type, cout[1].flags = n, 8, abi.I64, abi.COL_DEVICE
+        flags = dev(sel.astype(np.uint8))
+        m = C.c_int64(0)
+        _lib.check(ctx.lib.tsq_chunk_compact(ctx.h, cin, 2, n, flags, cout, C.byref(m)), ctx.h)
+        k = m.value
+        assert k == int(sel.sum())
+        offs, data, bm = np.zeros(k + 1, np.int64), np.zeros(len(sc.data) + 8, np.uint8), np.zeros(k // 8 + 8, np.uint8)
+        iv, ibm = np.zeros(max(k, 1), np.int64), np.zeros(k // 8 + 8, np.uint8)
+        ctx.d2h(offs, cout[0].offsets)
+        ctx.d2h(data, cout[0].data)
+        ctx.d2h(bm, cout[0].null_bitmap)
+        ctx.d2h(iv, cout[1].data)
+        ctx.d2h(ibm, cout[1].null_bitmap)
+        nn = np.unpackbits(bm, bitorder="little")[:k].astype(bool)
+        inn = np.unpackbits(ibm, bitorder="little")[:k].astype(bool)
+        raw = data.tobytes()
+        import collections
+        got = collections.Counter((H.canon(raw[offs[i]:offs[i + 1]] if nn[i] else None), H.canon(int(iv[i]) if inn[i] else None)) for i in range(k))
+        iw = ints.values()
+        want = collections.Counter((H.canon(vals[i]), H.canon(iw[i])) for i in range(n) if sel[i])
+        assert got == want  # (the dense rows keep the input order up to a permutation inside 256-row tiles)
+    finally:
+        for p in bufs:
+            ctx.free(p)

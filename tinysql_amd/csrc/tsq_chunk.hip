@@ -21,6 +21,8 @@ struct CompactArgs {
     unsigned long long* block_base;  // in: per-workgroup counts -> exclusive bases
     void* out_data[TSQ_MAX_COLS];
     uint8_t* out_notnull[TSQ_MAX_COLS];
+    int64_t* out_offs[TSQ_MAX_COLS];  // var-len columns: the scatter leaves the cell lengths here, a scan makes them offsets
+    uint32_t* src_row;                // var-len columns: source row of every dense row (for the byte copy)
     unsigned long long* total;
 };
 
@@ -83,10 +85,31 @@ __global__ void __launch_bounds__(256) k_compact_scatter(CompactArgs a) {
         base = __shfl(base, 0, 64);
         if (!sel) continue;
         const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (a.src_row) a.src_row[pos] = (uint32_t)r;
         for (int c = 0; c < a.in.n; c++) {
-            if (a.in.type[c] == TSQ_F32) ((uint32_t*)a.out_data[c])[pos] = ((const uint32_t*)a.in.data[c])[r];
+            if (a.in.type[c] == TSQ_BYTES) a.out_offs[c][pos] = a.in.offs[c][r + 1] - a.in.offs[c][r];
+            else if (a.in.type[c] == TSQ_F32) ((uint32_t*)a.out_data[c])[pos] = ((const uint32_t*)a.in.data[c])[r];
             else ((uint64_t*)a.out_data[c])[pos] = ((const uint64_t*)a.in.data[c])[r];
             if (a.out_notnull[c]) a.out_notnull[c][pos] = tsq_is_null(a.in.nulls[c], r) ? 0 : 1;
+        }
+    }
+}
+// the bytes of the selected cells of one var-len column (Column.CopyReconstruct of a var-len column, column.go:504-552): one cell per
+// lane for short cells, one per wave (64 lanes on consecutive bytes) for long ones
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_compact_varlen(const uint8_t* src, const int64_t* src_offs, const uint32_t* src_row, const int64_t* out_offs,
+                                                        uint8_t* dst, int64_t n_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t me = WAVE ? ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6 : (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = WAVE ? ((int64_t)gridDim.x * blockDim.x) >> 6 : (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = me; p < n_out; p += step) {
+        const uint8_t* s = src + src_offs[src_row[p]];
+        uint8_t* d = dst + out_offs[p];
+        const int64_t n = out_offs[p + 1] - out_offs[p];
+        if (WAVE) {
+            for (int64_t i = lane; i < n; i += 64) d[i] = s[i];
+        } else {
+            for (int64_t i = 0; i < n; i++) d[i] = s[i];
         }
     }
 }
@@ -102,11 +125,21 @@ TSQ_API tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t 
     for (int c = 0; c < n_cols; c++) {
         if (!(cols[c].flags & TSQ_COL_DEVICE) || !(out_cols[c].flags & TSQ_COL_DEVICE))
             return tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_compact: columns (and the selected[] flags) must be device resident");
-        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_chunk_compact: var-len column");
+        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_compact: unknown column type");
         if (cols[c].null_bitmap && !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_compact: nullable column needs an output bitmap");
-        if (nrows > 0 && (!cols[c].data || !out_cols[c].data)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_compact: NULL data pointer");
+        if (cols[c].type == TSQ_BYTES) {
+            // a var-len output column needs offsets[nrows + 1] and a data array as large as the input's (a selection never grows)
+            if (nrows > 0 && (!cols[c].offsets || !out_cols[c].offsets)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_compact: var-len column needs offsets on both sides");
+            if (nrows >= 0xffffffffLL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_chunk_compact: var-len chunk beyond 2^32 rows");
+        } else if (nrows > 0 && (!cols[c].data || !out_cols[c].data)) {
+            return tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_compact: NULL data pointer");
+        }
     }
-    if (nrows == 0) return TSQ_OK;
+    if (nrows == 0) {
+        for (int c = 0; c < n_cols; c++)
+            if (cols[c].type == TSQ_BYTES && out_cols[c].offsets) TSQ_HIP(h, hipMemsetAsync(out_cols[c].offsets, 0, 8, ctx->stream));
+        return TSQ_OK;
+    }
     TSQ_HIP(h, hipSetDevice(ctx->device));
     CompactArgs a;
     memset(&a, 0, sizeof a);
@@ -115,15 +148,24 @@ TSQ_API tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t 
     a.nrows = nrows;
     const int grid = tsq_grid_for(ctx, nrows, 256);
     a.rows_per_block = (((nrows + grid - 1) / grid) + 63) & ~(int64_t)63;
-    DevBuf base;
+    DevBuf base, srow, scratch;
     std::vector<DevBuf> nn(n_cols);
     auto cleanup = [&]() {
         base.release();
+        srow.release();
+        scratch.release();
         for (auto& b : nn) b.release();
     };
     tsq_status s = base.reserve(ctx, h, (size_t)grid * 8 + 64);
+    bool any_var = false;
+    for (int c = 0; c < n_cols; c++) any_var = any_var || cols[c].type == TSQ_BYTES;
+    if (s == TSQ_OK && any_var) {
+        s = srow.reserve(ctx, h, (size_t)nrows * 4 + 64);
+        a.src_row = srow.as<uint32_t>();
+    }
     for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
         a.out_data[c] = out_cols[c].data;
+        a.out_offs[c] = cols[c].type == TSQ_BYTES ? out_cols[c].offsets : nullptr;
         if (cols[c].null_bitmap) {
             s = nn[c].reserve(ctx, h, (size_t)nrows + 64);
             a.out_notnull[c] = nn[c].as<uint8_t>();
@@ -148,7 +190,26 @@ TSQ_API tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t 
         }
         out_cols[c].length = n_out;
         out_cols[c].type = cols[c].type;
-        out_cols[c].elem_size = tsq_elem_size(cols[c].type);
+        out_cols[c].elem_size = cols[c].type == TSQ_BYTES ? -1 : tsq_elem_size(cols[c].type);
+        if (cols[c].type == TSQ_BYTES && s == TSQ_OK) {  // lengths -> offsets, then the bytes
+            s = tsq_launch_scan64(ctx, h, out_cols[c].offsets, n_out, scratch);
+            if (s == TSQ_OK && n_out > 0) {
+                e = hipMemcpyAsync(ctx->pinned + 17, out_cols[c].offsets + n_out, 8, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e));
+                const int64_t nbytes = (int64_t)ctx->pinned[17];
+                if (s == TSQ_OK && nbytes > 0) {
+                    if (nbytes / n_out > 32)
+                        hipLaunchKernelGGL(k_compact_varlen<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, (const uint8_t*)cols[c].data, cols[c].offsets,
+                                           a.src_row, out_cols[c].offsets, (uint8_t*)out_cols[c].data, n_out);
+                    else
+                        hipLaunchKernelGGL(k_compact_varlen<false>, dim3(tsq_grid_for(ctx, n_out, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)cols[c].data,
+                                           cols[c].offsets, a.src_row, out_cols[c].offsets, (uint8_t*)out_cols[c].data, n_out);
+                    e = hipGetLastError();
+                    if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e));
+                }
+            }
+        }
     }
     if (s == TSQ_OK) {
         e = hipStreamSynchronize(ctx->stream);
