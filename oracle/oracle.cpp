@@ -815,7 +815,16 @@ inline uint64_t hash_row_keys(const JoinSide& s, int32_t n_keys, int64_t row, bo
         uint8_t flag;
         uint64_t bits;
         bool isnull;
-        encode_hash_cell(s.cols[s.key_idx[k]], row, flag, bits, isnull);
+        const tsq_col& c = s.cols[s.key_idx[k]];
+        if (c.type == TSQ_BYTES) {  // codec.go:233-235: flag = compactBytesFlag, b = row.GetBytes(idx)
+            isnull = col_is_null(c, row);
+            flag = isnull ? NilFlag : compactBytesFlag;
+            h = fnv1_write(h, &flag, 1);
+            if (isnull) hasNull = true;
+            else h = fnv1_write(h, (const uint8_t*)c.data + c.offsets[row], c.offsets[row + 1] - c.offsets[row]);
+            continue;
+        }
+        encode_hash_cell(c, row, flag, bits, isnull);
         h = fnv1_write(h, &flag, 1);
         if (isnull) hasNull = true;  // codec.go:261-263: flag only, no bytes
         else h = fnv1_write(h, (const uint8_t*)&bits, 8);
@@ -828,8 +837,20 @@ inline bool equal_row_keys(const JoinSide& a, int64_t ra, const JoinSide& b, int
         uint8_t f1, f2;
         uint64_t b1, b2;
         bool n1, n2;
-        encode_hash_cell(a.cols[a.key_idx[k]], ra, f1, b1, n1);
-        encode_hash_cell(b.cols[b.key_idx[k]], rb, f2, b2, n2);
+        const tsq_col &ca = a.cols[a.key_idx[k]], &cb = b.cols[b.key_idx[k]];
+        if (ca.type == TSQ_BYTES || cb.type == TSQ_BYTES) {  // flag1 == flag2 && bytes.Equal(b1, b2)
+            if (ca.type != cb.type) return false;
+            const bool na = col_is_null(ca, ra), nb = col_is_null(cb, rb);
+            if (na || nb) {
+                if (na != nb) return false;
+                continue;
+            }
+            const int64_t la = ca.offsets[ra + 1] - ca.offsets[ra], lb = cb.offsets[rb + 1] - cb.offsets[rb];
+            if (la != lb || memcmp((const char*)ca.data + ca.offsets[ra], (const char*)cb.data + cb.offsets[rb], (size_t)la) != 0) return false;
+            continue;
+        }
+        encode_hash_cell(ca, ra, f1, b1, n1);
+        encode_hash_cell(cb, rb, f2, b2, n2);
         if (!(f1 == f2 && b1 == b2)) return false;
     }
     return true;

@@ -203,9 +203,9 @@ def test_join_config1_count_star_1e5(ctx, orc):
 
 def test_join_errors_are_loud(ctx):
     lib = ctx.lib
-    cfg = H.join_cfg([abi.I64], [abi.BYTES], [0], [0], abi.JOIN_INNER, 1)
+    cfg = H.join_cfg([abi.I64], [7], [0], [0], abi.JOIN_INNER, 1)
     h = C.c_void_p()
-    assert lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)) == abi.ERR_UNSUPPORTED  # var-len -> Go operator
+    assert lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)) == abi.ERR_INVALID  # no such column type (var-len columns are accepted since round 2)
     cfg = H.join_cfg([abi.I64], [abi.I64], [0], [0], abi.JOIN_LEFT_OUTER, 0)
     assert lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)) == abi.ERR_UNSUPPORTED
     # overflow inside an OtherCondition surfaces as types.ErrOverflow

@@ -52,14 +52,32 @@ def test_benchmark_schema_bigint_key_and_5k_payload(ctx, orc):
     assert got.NumRows() == want.NumRows() > n and H.rows_equal_unordered(got, want)
 
 
-def test_string_join_key_is_handed_back_to_go(ctx):
-    t = [abi.BYTES, abi.I64]
-    cfg = H.join_cfg(t, t, [0], [0], abi.JOIN_INNER, 1)
-    h = None
-    import ctypes as C
-    hh = C.c_void_p()
-    st = ctx.lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(hh))
-    assert st == abi.ERR_UNSUPPORTED
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1)])
+def test_string_join_keys_vs_oracle(ctx, orc, jt, inner):
+    # a string key cell is (compactBytesFlag, bytes) (util/codec/codec.go:233-235); equality = bytes.Equal (:363-382).  Single string key,
+    # and (string, bigint) composite key; NULL keys never join; keys that differ only in length / in a late byte / that share 8-byte prefixes
+    rng = np.random.default_rng(21 + jt)
+    words = [b"", b"a", b"ab", b"abcdefgh", b"abcdefghi", b"abcdefgh\x00", b"abcdefgX", b"zz" * 20, b"zz" * 20 + b"!", None]
+    nl, nr = 5000, 3000
+    lk = [words[i] for i in rng.integers(0, len(words), nl)]
+    rk = [words[i] for i in rng.integers(0, len(words) - 3, nr)] + []
+    left = Chunk([StrColumn(lk), Column(abi.I64, rng.integers(0, 4, nl)), Column(abi.I64, np.arange(nl))])
+    right = Chunk([StrColumn(rk), Column(abi.I64, rng.integers(0, 4, nr)), StrColumn(strs(rng, nr, 6))])
+    for lkeys, rkeys in (([0], [0]), ([0, 1], [0, 1])):
+        cfg = H.join_cfg(left.types(), right.types(), lkeys, rkeys, jt, inner)
+        want = orc.hash_join(cfg, right, left)
+        got = G.run_join(ctx, cfg, right, left, chunk_rows=1024, pull_rows=4096)
+        assert got.NumRows() == want.NumRows() > nl and H.rows_equal_unordered(got, want)
+        assert G.run_join(ctx, cfg, right, left, chunk_rows=1 << 20, count_only=True) == want.NumRows()
+
+
+def test_string_key_against_number_key_never_matches(ctx, orc):
+    left = Chunk([StrColumn(["1", "2", None]), Column(abi.I64, np.arange(3))])
+    right = Chunk([Column(abi.I64, np.array([1, 2, 3])), Column(abi.I64, np.arange(3))])
+    cfg = H.join_cfg(left.types(), right.types(), [0], [0], abi.JOIN_LEFT_OUTER, 1)
+    want = orc.hash_join(cfg, right, left)
+    got = G.run_join(ctx, cfg, right, left)
+    assert got.NumRows() == want.NumRows() == 3 and H.rows_equal_unordered(got, want)
 
 
 def test_count_and_empty_inputs_with_string_columns(ctx, orc):

@@ -50,7 +50,25 @@ __device__ __forceinline__ bool load_kw(const tsq_colset& cs, const int32_t* idx
             const int c = idx[k];
             if (tsq_is_null(cs.nulls[c], row)) return false;
             uint32_t flag;
-            uint64_t w = tsq_key_word(cs.data[c], cs.type[c], row, &flag);
+            uint64_t w;
+            if (cs.type[c] == TSQ_BYTES) {  // a string key cell is (compactBytesFlag, its bytes) (codec.go:233-235): any hash of the bytes will do,
+                                            // keys_equal compares the bytes themselves
+                const int64_t o0 = cs.offs[c][row], n = cs.offs[c][row + 1] - o0;
+                const uint8_t* p = (const uint8_t*)cs.data[c] + o0;
+                w = 0x9E3779B97F4A7C15ULL ^ (uint64_t)n;
+                int64_t i = 0;
+                for (; i + 8 <= n; i += 8) {
+                    uint64_t x;
+                    memcpy(&x, p + i, 8);
+                    w = tsq_splitmix64(w ^ x);
+                }
+                uint64_t tail = 0;
+                for (int64_t q = i; q < n; q++) tail = (tail << 8) | p[q];
+                w = tsq_splitmix64(w ^ tail);
+                flag = 2;
+            } else {
+                w = tsq_key_word(cs.data[c], cs.type[c], row, &flag);
+            }
             h = tsq_splitmix64(h ^ w) + flag;
         }
         kw = h;
@@ -61,9 +79,19 @@ __device__ __forceinline__ bool load_kw(const tsq_colset& cs, const int32_t* idx
 __device__ __forceinline__ bool keys_equal(const tsq_colset& b, const tsq_colset& p, const KeySpec& ks, int64_t brow,
                                            int64_t prow) {
     for (int k = 0; k < ks.n_keys; k++) {
+        const int cb = ks.bidx[k], cp = ks.pidx[k];
+        if (b.type[cb] == TSQ_BYTES) {  // bytes.Equal(b1, b2) (codec.go:377); a string and a number never share a flag (the host sets never_match)
+            const int64_t ob = b.offs[cb][brow], nb = b.offs[cb][brow + 1] - ob, op = p.offs[cp][prow], np = p.offs[cp][prow + 1] - op;
+            if (nb != np) return false;
+            const uint8_t* x = (const uint8_t*)b.data[cb] + ob;
+            const uint8_t* y = (const uint8_t*)p.data[cp] + op;
+            for (int64_t i = 0; i < nb; i++)
+                if (x[i] != y[i]) return false;
+            continue;
+        }
         uint32_t f1, f2;
-        uint64_t w1 = tsq_key_word(b.data[ks.bidx[k]], b.type[ks.bidx[k]], brow, &f1);
-        uint64_t w2 = tsq_key_word(p.data[ks.pidx[k]], p.type[ks.pidx[k]], prow, &f2);
+        uint64_t w1 = tsq_key_word(b.data[cb], b.type[cb], brow, &f1);
+        uint64_t w2 = tsq_key_word(p.data[cp], p.type[cp], prow, &f2);
         if (f1 != f2 || w1 != w2) return false;
     }
     return true;
@@ -1583,10 +1611,6 @@ TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_jo
         if (cfg->build_key_idx[k] < 0 || cfg->build_key_idx[k] >= cfg->n_build_cols || cfg->probe_key_idx[k] < 0 ||
             cfg->probe_key_idx[k] >= cfg->n_probe_cols)
             return tsq_fail(ch, TSQ_ERR_INVALID, "join key index out of range");
-        // var-len (string) columns travel through the join as payload; a string JOIN KEY (codec.go:233-235: compactBytesFlag + bytes)
-        // is not hashed on the GPU yet
-        if (cfg->build_types[cfg->build_key_idx[k]] == TSQ_BYTES || cfg->probe_types[cfg->probe_key_idx[k]] == TSQ_BYTES)
-            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len join key: fall back to the Go operator");
     }
     if ((cfg->n_other_conds > 0 && !cfg->other_conds) || (cfg->n_outer_filters > 0 && !cfg->outer_filters) ||
         cfg->n_other_conds < 0 || cfg->n_outer_filters < 0 || cfg->n_other_conds > 16 || cfg->n_outer_filters > 16)
@@ -1634,6 +1658,11 @@ TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_jo
         ks.bidx[k] = cfg->build_key_idx[k];
         ks.pidx[k] = cfg->probe_key_idx[k];
         const int32_t bt = cfg->build_types[ks.bidx[k]], pt = cfg->probe_types[ks.pidx[k]];
+        // a string key cell is (compactBytesFlag, bytes) (codec.go:233-235): the table stores a hash of the bytes and every match is
+        // verified against the build row's bytes — the multi-column route, also for a single string key
+        if (bt == TSQ_BYTES || pt == TSQ_BYTES) j->multi = true;
+        if ((bt == TSQ_BYTES) != (pt == TSQ_BYTES)) j->never_match = true;  // flag 2 vs 5 / 8 / 9
+        else if (bt == TSQ_BYTES) continue;
         if (is_int_class(bt) != is_int_class(pt)) j->never_match = true;  // flag 8/9 vs 5 (codec.go:217-235)
         if (!j->multi && is_int_class(bt) && bt != pt) ks.skip_high = 1;  // flag 8 vs 9 for cells >= 2^63
     }
