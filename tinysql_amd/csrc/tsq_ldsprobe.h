@@ -25,11 +25,11 @@
 //   * the four 16-byte pieces of a bucket are read in an order rotated by the lane number: with the same piece order in
 //     every lane the 16 lanes of an LDS access group would only ever hit 4 of the 16 four-bank columns.
 // The image of the NEXT ticket is in flight (16-byte registers) while the keys of the current one are probed.
-// Measured and dropped (profiles/r02_lds_probe_experiments.txt): drawing chunk numbers from an LDS counter instead of the
-// static chunk -> wave assignment (the waves wait 20-27 % of their time at the end of a ticket for the slowest one, but
-// every draw is an LDS round trip on the load-issue path: 0.80 vs 0.73 ms); software-pipelining the rounds (ring fetch of
-// the next round behind the bucket reads of this one: 0.77 ms) — the kernel is not waiting for LDS latency, its SIMDs
-// (50 %), LDS (42 %) and scalar unit (24 %) are all busy.
+// Measured and dropped (profiles/r02_lds_probe_experiments.txt): drawing a number per 128-word CHUNK from an LDS counter (every
+// draw is an LDS round trip on the load-issue path: 0.80 vs 0.73 ms with the static assignment — the shipped kernel draws per
+// 512-word super-chunk, two draws ahead); software-pipelining the rounds (ring fetch of the next round behind the bucket reads
+// of this one: 0.77 ms) — the kernel is not waiting for LDS latency, its SIMDs (50 %), LDS (42 %) and scalar unit (24 %) are
+// all busy.
 //
 // Replaces (reference): join2Chunk + hashRowContainer.GetMatchedRows (executor/join.go:343-360,
 // hash_table.go:110-134) for the COUNT(*) shape; same joined-row count whichever route a key takes (a probe row
@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ uint32_t s_len[8];
     __shared__ uint32_t s_tk[2];
+    __shared__ uint32_t s_next;  // next super-chunk of the current ticket
     __shared__ unsigned long long s_total;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
@@ -188,6 +189,7 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
             }
         }
         if (tid < 8) s_len[tid] = radix_region_len(a.st, P, p, tid);
+        if (tid == 9) s_next = 0;
         if (MODE == 1 && tid == 8) s_tkcnt = 0;
         if (MODE == 2 && tid == 8) {
             s_tkcnt = a.tk_cnt[(size_t)vx * ntk + tk];
@@ -197,23 +199,53 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
         __syncthreads();  // A: image and region lengths are in LDS
         if (PROF) pf[0] += now() - t0;
         const uint32_t tkn = (uint32_t)__builtin_amdgcn_readfirstlane(s_tk[(it + 1) & 1u]);
-        // Every wave streams ONE region: wave w reads chunks (128 words, two per lane) w / 8, w / 8 + NW / 8, ... of region w % 8.
-        // (Enumerating the chunks of all eight regions in one sequence balances skewed regions better, but cost ~35 scalar
-        // instructions per chunk for the region lookup; the scalar unit is shared by all waves of the CU.)
-        const uint32_t rg = wave & 7u, rlen = (uint32_t)__builtin_amdgcn_readfirstlane(s_len[rg]);
-        const uint32_t nck = (rlen + 127u) / 128u;
-        const uint64_t* rbase = a.st.keys + ((size_t)p * 8u + rg) * a.st.cap;
-        const uint32_t gbase = (uint32_t)(((size_t)p * 8u + rg) * a.st.cap);  // the store has < 2^32 slots (host check)
-        auto chunk_load = [&](uint32_t k, tsq_u64x2& v, uint32_t& nv, uint32_t& gi) {
-            const uint32_t off = k * 128u + lane * 2u;
-            nv = off + 1u < rlen ? 2u : (off < rlen ? 1u : 0u);  // a chunk past the end loads the region's first line (ignored)
-            gi = gbase + off;
-            async_nt_load16(v, rbase + (off < rlen ? off : 0u));
+        // The words of the partition in SUPER-CHUNKS of 512 (4 chunks of 128 = the D loads a wave keeps in flight): super-chunk i =
+        // region i / spr, words [(i % spr) * 512, +512) of it, spr = super-chunks of the longest region (a super-chunk past the end of
+        // a shorter region is empty).  Waves DRAW super-chunk numbers from an LDS counter, so that all waves of the workgroup run dry
+        // together whatever their luck with candidates and chains (with a static chunk -> wave assignment the waves spent 27 % of
+        // their time waiting for the slowest one at the end of a ticket).  The draw for super-chunk n + 2 is issued when n starts
+        // and picked up when n + 1 starts: an LDS round trip on the load-issue path of every CHUNK cost more than the balance bought.
+        uint32_t maxlen = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane(s_len[r]);
+            maxlen = l > maxlen ? l : maxlen;
+        }
+        const uint32_t spr = (maxlen + 511u) / 512u, nsc = spr * 8u;
+        const uint64_t* pbase = a.st.keys + (size_t)p * 8u * a.st.cap;
+        const uint32_t pgbase = (uint32_t)((size_t)p * 8u * a.st.cap);  // the store has < 2^32 slots (host check)
+        struct Sc {  // where a super-chunk lives (wave uniform)
+            uint32_t rbase, rlen, off0;
         };
+        auto locate = [&](uint32_t id) -> Sc {
+            uint32_t r = 0;
+#pragma unroll
+            for (uint32_t q = 1; q < 8; q++) r += id >= q * spr ? 1u : 0u;  // (id >= nsc lands in region 7 with off0 >= its length: empty)
+            Sc x;
+            x.rlen = (uint32_t)__builtin_amdgcn_readfirstlane(s_len[r]);
+            x.rbase = r * a.st.cap;
+            x.off0 = (id - r * spr) * 512u;
+            return x;
+        };
+        auto chunk_load = [&](const Sc& sc, uint32_t d, tsq_u64x2& v, uint32_t& nv, uint32_t& gi) {
+            const uint32_t off = sc.off0 + d * 128u + lane * 2u;
+            nv = off + 1u < sc.rlen ? 2u : (off < sc.rlen ? 1u : 0u);  // nothing to fetch: the region's first line (ignored)
+            gi = pgbase + sc.rbase + off;
+            async_nt_load16(v, pbase + (sc.rbase + (off < sc.rlen ? off : 0u)));
+        };
+        auto draw = [&]() -> uint32_t {  // issue only: the answer is read later
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(&s_next, 1u);
+            return g;
+        };
+        uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane(draw());
+        uint32_t nxt = (uint32_t)__builtin_amdgcn_readfirstlane(draw());
+        uint32_t gpend = draw();
+        Sc sc_cur = locate(cur), sc_nxt = locate(nxt);
         tsq_u64x2 v[D];
         uint32_t nv[D], gi[D];
 #pragma unroll
-        for (int d = 0; d < D; d++) chunk_load(wave / 8u + (uint32_t)d * (NW / 8), v[d], nv[d], gi[d]);
+        for (int d = 0; d < D; d++) chunk_load(sc_cur, (uint32_t)d, v[d], nv[d], gi[d]);
         image_load(tkn);          // in flight while this ticket's keys are probed
         uint32_t qh = 0, qt = 0;  // ring head / tail (wave uniform)
         // compaction append of (word, hop) for the lanes in `on`
@@ -316,7 +348,7 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
             push(valid && ((uint32_t)(w >> sh) - f0) < nfi, w, 0u, gx);
             while (qt - qh >= 64u) probe_round(64u);
         };
-        for (uint32_t k = wave / 8u; k < nck; k += D * (NW / 8)) {
+        while (cur < nsc) {  // the numbers a wave draws grow: cur is its oldest
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 const unsigned long long tw = now();
@@ -328,8 +360,13 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
                     pf[1] += ts - tw;
                     pf[2] += now() - ts;
                 }
-                chunk_load(k + (uint32_t)(d + D) * (NW / 8), v[d], nv[d], gi[d]);  // reload only after use: no register copy, D - 1 chunks ahead
+                chunk_load(sc_nxt, (uint32_t)d, v[d], nv[d], gi[d]);  // reload only after use: no register copy, D - 1 chunks ahead
             }
+            cur = nxt;
+            sc_cur = sc_nxt;
+            nxt = (uint32_t)__builtin_amdgcn_readfirstlane(gpend);
+            gpend = draw();
+            sc_nxt = locate(nxt);
         }
         const unsigned long long td = now();
         // D clamped loads of the last round are still in flight: their registers must stay allocated until they have landed

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-O=gpurun_out/${1:-r2l}
+O=gpurun_out/${1:-r2m}
 mkdir -p $O
 export TMPDIR=/tmp
 R=$(pwd)
