@@ -12,6 +12,7 @@ static void fill(tsq_colset& cs, const tsq_col* cols, int n) {
     for (int c = 0; c < n; c++) {
         cs.data[c] = cols[c].data;
         cs.nulls[c] = cols[c].null_bitmap;
+        cs.offs[c] = cols[c].type == TSQ_BYTES ? cols[c].offsets : nullptr;
         cs.type[c] = cols[c].type;
     }
 }
@@ -79,6 +80,10 @@ void sim_gen_column(const tsq_gen_spec* spec, int64_t nrows, uint64_t* dst, uint
 int32_t sim_validate(const tsq_expr_prog* p, int32_t n_cols) {
     const char* why = "";
     return tsq_validate_prog(*p, n_cols, &why);
+}
+int32_t sim_validate_typed(const tsq_expr_prog* p, int32_t n_cols, const int32_t* col_types) {
+    const char* why = "";
+    return tsq_validate_prog(*p, n_cols, &why, col_types);
 }
 
 uint64_t sim_rowhash(const uint64_t* vals, const uint8_t* notnull, int32_t n) {

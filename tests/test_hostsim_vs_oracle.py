@@ -233,3 +233,40 @@ def test_rowhash_matches_oracle_checksum(sim, orc):
         s = (s + h) & ((1 << 64) - 1)
         x ^= h
     assert (s, x) == orc.rows_checksum(chk)
+
+
+# ---------------------------------------------------------------- strings: the device interpreter's ETString opcodes on the CPU
+def test_string_signatures_device_interpreter_vs_oracle(sim, orc):
+    """the same expression set as tests/test_expr_string_gpu.py, evaluated by tsq_eval_row compiled for the host: the per-row string
+    semantics of the kernels (references on the stack, byte-wise compares, NULL protocols) against the node-at-a-time oracle"""
+    from tinysql_amd.chunk import StrColumn
+    from .test_oracle_string_golden import rand_strs
+    rng = np.random.default_rng(77)
+    n = 4000
+    chk = Chunk([StrColumn([None if v is None else v * int(rng.integers(1, 6)) for v in rand_strs(rng, n)]), StrColumn(rand_strs(rng, n)),
+                 StrColumn(rand_strs(rng, n, 0.4)), Column(abi.I64, rng.integers(-2, 3, n), rng.random(n) > 0.2)])
+    S0, S1, S2, I3 = E.Column(0, abi.BYTES), E.Column(1, abi.BYTES), E.Column(2, abi.BYTES), E.Column(3, abi.I64)
+    F, K = E.ScalarFunction, E.Constant
+    exprs = [F(op, S0, S1) for op in ("lt", "le", "gt", "ge", "eq", "ne")] + [
+        F("lt", S1, K(b"ab\x80")), F("eq", K(""), S2), F("strcmp", S0, S1), F("strcmp", S0, K(None, E.ETString)), F("length", S0), F("isnull", S2),
+        F("length", F("ifnull", S2, S0)), F("strcmp", F("if", I3, S0, S1), F("ifnull", S2, K("abc"))),
+        F("in", S1, K("a"), K("ab"), K(b"\xff"), K("")), F("in", S1, S2, K(None, E.ETString), S0),
+        F("plus", F("length", S0), F("mul", I3, F("strcmp", S1, S2)))]
+    sel = np.sort(rng.permutation(n)[: n // 3]).astype(np.int32)
+    for e in exprs:
+        check_same(sim, orc, e, chk)
+        check_same(sim, orc, e, Chunk(chk.columns, sel=sel))
+
+
+def test_string_program_validation(sim):
+    S0 = E.Column(0, abi.BYTES)
+    prog = E.compile_expr(E.ScalarFunction("length", S0))
+    sim.sim_validate_typed.restype = C.c_int32
+    sim.sim_validate_typed.argtypes = [C.POINTER(abi.ExprProg), C.c_int32, C.POINTER(C.c_int32)]
+    assert sim.sim_validate_typed(C.byref(prog), 1, (C.c_int32 * 1)(abi.BYTES)) == abi.OK
+    assert sim.sim_validate_typed(C.byref(prog), 1, (C.c_int32 * 1)(abi.I64)) == abi.ERR_INVALID       # COL_STR on a BIGINT column
+    prog.ops[1].opcode = abi.OP_NEG_INT                                                                 # a number operator on a string value
+    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_INVALID
+    prog = E.compile_expr(E.ScalarFunction("length", S0))
+    prog.n_ops = 1                                                                                      # string-valued root
+    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_UNSUPPORTED
