@@ -236,4 +236,120 @@ __global__ void __launch_bounds__(NT) k_build_images(ImageArgs a) {
     if (tid == 0 && s_handled) atomicAdd(a.inserted, s_handled);
 }
 
+// pass 3, counting variant: a bucket's slots are handed out by an LDS counter per bucket instead of a CAS walk over its
+// slots.  A row takes ticket r = atomicAdd(count[home]); r < 8 is its slot, no compare, no retry (at load factor 0.75
+// that is ~96 % of the rows); a row that finds its bucket sold out moves to the next bucket's counter, which preserves
+// the probe's invariant (a row homed at b that lives in b+k implies b .. b+k-1 are full: a counter that reached 8 has
+// handed out 8 slots and all of them are written before the image is stored).  Equal table words are found afterwards
+// by re-reading the buckets home .. placed with wide LDS loads (the `unique` flag of the probe depends on it).
+// Dynamic LDS: m*8 key words | m*8 row ids | m counters.
+template <int NT, int KPT>
+__global__ void __launch_bounds__(NT) k_build_images_cnt(ImageArgs a) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    unsigned long long* s_keys = (unsigned long long*)s_dyn;
+    uint32_t* s_vals = (uint32_t*)(s_dyn + (size_t)a.m * TSQ_BUCKET * 8);
+    uint32_t* s_cnt = (uint32_t*)(s_dyn + (size_t)a.m * TSQ_BUCKET * 12);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t Q = 1u << (a.in.b1 + a.in.b2);
+    const uint32_t nslots = a.m * TSQ_BUCKET;
+    __shared__ unsigned long long s_handled;
+    if (tid == 0) s_handled = 0;
+    uint32_t placed = 0;
+    bool dup = false;
+    uint64_t kw[KPT];
+    uint32_t row[KPT];
+    uint32_t where[KPT];  // (home bucket << 16) | buckets walked past it; 0xffffffff = not in the image
+    auto load_rows = [&](uint32_t q, uint32_t cnt) {
+        const size_t src = (size_t)q * a.in.cap2;
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+            const uint32_t i = (uint32_t)j * NT + tid;
+            kw[j] = 0;
+            row[j] = 0xffffffffu;
+            if (i < cnt) {
+                kw[j] = a.in.keys[src + i];
+                row[j] = a.in.idx[src + i];
+            }
+        }
+    };
+    uint32_t q = blockIdx.x;
+    uint32_t cnt = q < Q ? a.in.count[q] : 0u;
+    if (q < Q) load_rows(q, cnt);
+    while (q < Q) {
+        const uint32_t qn = q + gridDim.x;
+        const uint32_t cnt_n = qn < Q ? a.in.count[qn] : 0u;
+        const uint64_t b0 = (uint64_t)q * a.m;
+        {
+            ulonglong2* z = (ulonglong2*)s_keys;
+            for (uint32_t i = tid; i < nslots / 2; i += NT) z[i] = make_ulonglong2(TSQ_EMPTY_KEY, TSQ_EMPTY_KEY);
+            uint4* zv = (uint4*)s_vals;
+            for (uint32_t i = tid; i < nslots / 4; i += NT) zv[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = tid; i < a.m; i += NT) s_cnt[i] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+            where[j] = 0xffffffffu;
+            if (row[j] == 0xffffffffu) continue;
+            if (kw[j] == TSQ_EMPTY_KEY) {
+                const uint32_t o = atomicAdd(a.sent_total, 1u);
+                if (o < a.sent_cap) a.sent_rows[o] = row[j];
+                placed++;
+                continue;
+            }
+            const uint32_t home = jt_local(a.t.tb, a.m, kw[j]);
+            uint32_t lb = home, steps = 0;
+            for (;;) {
+                const uint32_t r = atomicAdd(&s_cnt[lb], 1u);
+                if (r < TSQ_BUCKET) {
+                    s_keys[lb * TSQ_BUCKET + r] = kw[j];
+                    s_vals[lb * TSQ_BUCKET + r] = row[j];
+                    where[j] = (home << 16) | steps;
+                    placed++;
+                    break;
+                }
+                if (++steps >= a.m) {  // the slice is full (heavily duplicated keys): the host rebuilds the table unsliced
+                    __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                lb = (lb + 1 == a.m) ? 0 : lb + 1;
+            }
+        }
+        __syncthreads();
+        // equal words share their home bucket and sit between it and the bucket the later one reached
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+            if (where[j] == 0xffffffffu) continue;
+            uint32_t lb = where[j] >> 16, eq = 0;
+            for (uint32_t s = 0; s <= (where[j] & 0xffffu); s++) {
+                const ulonglong2* b = (const ulonglong2*)(s_keys + lb * TSQ_BUCKET);
+#pragma unroll
+                for (int h = 0; h < TSQ_BUCKET / 2; h++) {
+                    const ulonglong2 v = b[h];
+                    eq += (v.x == kw[j]) + (v.y == kw[j]);
+                }
+                lb = (lb + 1 == a.m) ? 0 : lb + 1;
+            }
+            if (eq > 1) dup = true;
+        }
+        if (qn < Q) load_rows(qn, cnt_n);  // in flight while the image is stored
+        {
+            const ulonglong2* sk = (const ulonglong2*)s_keys;
+            ulonglong2* dk = (ulonglong2*)(a.t.keys + b0 * TSQ_BUCKET);
+            for (uint32_t i = tid; i < nslots / 2; i += NT) dk[i] = sk[i];
+            const uint4* sv = (const uint4*)s_vals;
+            uint4* dv = (uint4*)(a.t.vals + b0 * TSQ_BUCKET);
+            for (uint32_t i = tid; i < nslots / 4; i += NT) dv[i] = sv[i];
+        }
+        __syncthreads();
+        q = qn;
+        cnt = cnt_n;
+    }
+    if (dup) __hip_atomic_store(a.fail + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t wsum = wave_sum_u64(placed);
+    if ((tid & 63) == 0 && wsum) atomicAdd(&s_handled, (unsigned long long)wsum);
+    __syncthreads();
+    if (tid == 0 && s_handled) atomicAdd(a.inserted, s_handled);
+}
+
 #endif

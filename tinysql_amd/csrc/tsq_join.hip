@@ -1538,9 +1538,11 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     ia.sent_total = (uint32_t*)(ctx->dscratch + 1);
     ia.inserted = (unsigned long long*)ctx->dscratch;
     ia.fail = (uint32_t*)(ctx->dscratch + 2);
-    const size_t img_bytes = (size_t)m * TSQ_BUCKET * 12;
+    static const bool cas_images = [] { const char* v = getenv("TSQ_BUILD_IMAGES"); return v && !strcmp(v, "cas"); }();
+    const size_t img_bytes = (size_t)m * TSQ_BUCKET * 12 + (cas_images ? 0 : (size_t)m * 4);
     if (e == hipSuccess && img_bytes > 48 * 1024)
-        e = hipFuncSetAttribute((const void*)k_build_images<512, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
+        e = hipFuncSetAttribute(cas_images ? (const void*)k_build_images<512, 8> : (const void*)k_build_images_cnt<512, 8>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_bytes);
     if (e == hipSuccess) {
         const int64_t ntiles = (nb + T1 - 1) / T1;
         hipLaunchKernelGGL((k_radix_partition<NT, K1, 4, 0, true, true>), dim3((unsigned)std::min<int64_t>(ntiles, ctx->num_cus)), dim3(NT), 0, ctx->stream, src, st);
@@ -1551,7 +1553,9 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL((k_build_images<512, 8>), dim3(std::min<uint32_t>(Q, (uint32_t)ctx->num_cus * 2)), dim3(512), img_bytes, ctx->stream, ia);
+        const dim3 igrid(std::min<uint32_t>(Q, (uint32_t)ctx->num_cus * 2));
+        if (cas_images) hipLaunchKernelGGL((k_build_images<512, 8>), igrid, dim3(512), img_bytes, ctx->stream, ia);
+        else hipLaunchKernelGGL((k_build_images_cnt<512, 8>), igrid, dim3(512), img_bytes, ctx->stream, ia);
         e = hipGetLastError();
     }
     j->st.kernel_launches += 3;

@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
     auto now = [&]() -> unsigned long long { return PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull; };
     const unsigned long long t_begin = now();
     constexpr int IMG_R = TSQ_LDS_IMAGE_MAX / 16 / NT;  // 16-byte units of an image per thread
+    // ... of which PRE_R are prefetched into registers during the previous ticket.  The emit pass has no registers left for the
+    // whole image: with all 8 prefetched it spilled one (i.e. waited for every load in flight right after issuing them).
+    constexpr int PRE_R = MODE == 2 ? IMG_R - 2 : IMG_R;
     constexpr int D = 4;                                // chunk loads in flight per wave
     static_assert(NW % 8 == 0, "NW / 8 waves per XCC region");
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -159,14 +162,14 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
         nfi = rest < a.nf ? rest : a.nf;
         return (pi * 8u + vx) * fpp + sub * a.nf;
     };
-    ulonglong2 pre[IMG_R];
+    ulonglong2 pre[PRE_R];
     auto image_load = [&](uint32_t tk) {  // a ticket past the end loads the first image again (ignored)
         uint32_t nfi;
         const uint32_t f0 = first_slice(tk < ntk ? tk : 0u, nfi);
         const uint32_t n16 = nfi * bs * (TSQ_BUCKET / 2);
         const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a.t.keys + (size_t)f0 * bs * TSQ_BUCKET);
 #pragma unroll
-        for (int j = 0; j < IMG_R; j++) {
+        for (int j = 0; j < PRE_R; j++) {
             const uint32_t i = (uint32_t)j * NT + tid;
             pre[j] = nt_load16(src + (i < n16 ? i : 0u));
         }
@@ -182,10 +185,22 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
         {
             const uint32_t n16 = nfi * bs * (TSQ_BUCKET / 2);
             ulonglong2* dst = reinterpret_cast<ulonglong2*>(s_img);
+            ulonglong2 late[IMG_R - PRE_R + 1];
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a.t.keys + (size_t)f0 * bs * TSQ_BUCKET);
 #pragma unroll
-            for (int j = 0; j < IMG_R; j++) {
+            for (int j = PRE_R; j < IMG_R; j++) {
+                const uint32_t i = (uint32_t)j * NT + tid;
+                late[j - PRE_R] = nt_load16(src + (i < n16 ? i : 0u));
+            }
+#pragma unroll
+            for (int j = 0; j < PRE_R; j++) {
                 const uint32_t i = (uint32_t)j * NT + tid;
                 if (i < n16) dst[i] = pre[j];
+            }
+#pragma unroll
+            for (int j = PRE_R; j < IMG_R; j++) {
+                const uint32_t i = (uint32_t)j * NT + tid;
+                if (i < n16) dst[i] = late[j - PRE_R];
             }
         }
         if (tid < 8) s_len[tid] = radix_region_len(a.st, P, p, tid);
