@@ -54,8 +54,8 @@ enum {
     TSQ_U64 = 1,   /* same 8 bytes, UNSIGNED flag set in FieldType.Flag                         */
     TSQ_F32 = 2,   /* float, 4 bytes                                                            */
     TSQ_F64 = 3,   /* double, 8 bytes                                                           */
-    TSQ_BYTES = 4  /* var-len (offsets[n+1] + data), binary collation: expression inputs (string builtins);
-                      the join / aggregate operators still answer TSQ_ERR_UNSUPPORTED for such a column      */
+    TSQ_BYTES = 4  /* var-len (offsets[n+1] + data), binary collation: expression inputs (string builtins), join payload
+                      and join keys, group keys and FIRST_ROW / MAX / MIN / COUNT arguments of the aggregate */
 };
 
 /* tsq_col.flags */
@@ -350,7 +350,8 @@ typedef struct tsq_agg_func {
                            parser/parser.y:3258-3262)                                         */
     int32_t arg_col2;   /* AVG in FINAL/PARTIAL2 mode: arg_col = count column, arg_col2 = sum
                            column (func_avg.go:86-113, descriptor.go:70-81)                    */
-    int32_t arg_type;   /* TSQ_I64/U64/F32/F64 of the value argument                           */
+    int32_t arg_type;   /* TSQ_I64/U64/F32/F64 of the value argument; TSQ_BYTES for COUNT / MAX / MIN /
+                           FIRST_ROW of a string (func_max_min.go:312-378, func_first_row.go:193-230)  */
     int32_t reserved;
 } tsq_agg_func;
 
@@ -392,6 +393,13 @@ tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out);
  * two: count then sum).  Group order is unspecified (Go map order in the reference). */
 tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, int64_t cap_rows,
                         int64_t* nrows_out, int32_t* eos);
+/* Strings in the aggregate: a group key may be TSQ_BYTES (getGroupKey: compactBytesFlag + bytes, util/codec/codec.go:738-744;
+ * NULL is its own group) and FIRST_ROW / MAX / MIN (binary collation, types.CompareString) / COUNT take a TSQ_BYTES argument;
+ * SUM / AVG of a string answer TSQ_ERR_UNSUPPORTED (the planner casts to double first).  The operator keeps the bytes of the
+ * var-len input columns it was pushed until it is destroyed.  A pull fills out_cols[c].offsets (cap_rows + 1 entries) and .data
+ * of a var-len output column; tsq_agg_peek (after tsq_agg_finish) tells how many rows the next pull of up to cap_rows rows
+ * delivers and how many data bytes each var-len output column needs (bytes_out[c]; 0 for fixed-width columns). */
+tsq_status tsq_agg_peek(tsq_agg* a, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_out, int32_t n_cols);
 tsq_status tsq_agg_cancel(tsq_agg* a);
 void       tsq_agg_destroy(tsq_agg* a);
 

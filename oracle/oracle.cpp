@@ -1317,12 +1317,18 @@ struct Partial {
     int64_t count = 0;   // AVG count
     bool isNull = true;  // SUM/MAX/MIN: no non-NULL input yet;  FIRST_ROW: value is NULL
     bool got = false;    // FIRST_ROW gotFirstRow
+    std::string s;       // partialResult4MaxMinString.val / partialResult4FirstRowString.val (deep copies: stringutil.Copy)
 };
 
 struct AggDesc {
     tsq_agg_func f;
     bool is_real;  // value domain real (F32/F64) vs int
+    bool is_str;   // ... or string (maxMin4String, firstRow4String, countOriginal4String)
 };
+
+inline std::string col_string(const tsq_col& c, int64_t i) {  // Column.GetString (util/chunk/column.go)
+    return std::string((const char*)c.data + c.offsets[i], (size_t)(c.offsets[i + 1] - c.offsets[i]));
+}
 
 inline bool add_int64_overflow(int64_t a, int64_t b) {  // types/overflow.go:33-40 AddInt64
     return (a > 0 && b > 0 && I64MAX - a < b) || (a < 0 && b < 0 && I64MIN - a > b);
@@ -1385,7 +1391,14 @@ tsq_status agg_update(const AggDesc& d, const tsq_col* cols, int64_t row, Partia
         case TSQ_AGG_MIN: {  // func_max_min.go:81-103 (+uint/float variants)
             if (arg_null) return TSQ_OK;
             const bool isMax = f.func == TSQ_AGG_MAX;
-            if (d.is_real) {
+            if (d.is_str) {  // maxMin4String.UpdatePartialResult (func_max_min.go:337-362)
+                std::string v = col_string(cols[f.arg_col], row);
+                if (p.isNull) { p.s = v; p.isNull = false; }
+                else {
+                    const int c = cmp_string(v, p.s);
+                    if ((isMax && c == 1) || (!isMax && c == -1)) p.s = v;
+                }
+            } else if (d.is_real) {
                 double v = col_f64(cols[f.arg_col], row);
                 if (p.isNull) { p.f = v; p.isNull = false; }
                 else if ((isMax && v > p.f) || (!isMax && v < p.f)) p.f = v;
@@ -1404,7 +1417,8 @@ tsq_status agg_update(const AggDesc& d, const tsq_col* cols, int64_t row, Partia
             if (p.got) return TSQ_OK;
             p.got = true;
             p.isNull = arg_null;
-            if (d.is_real) p.f = arg_null ? 0 : col_f64(cols[f.arg_col], row);
+            if (d.is_str) { if (!arg_null) p.s = col_string(cols[f.arg_col], row); }  // firstRow4String (func_first_row.go:206-220)
+            else if (d.is_real) p.f = arg_null ? 0 : col_f64(cols[f.arg_col], row);
             else p.i = arg_null ? 0 : col_i64(cols[f.arg_col], row);
             return TSQ_OK;
     }
@@ -1437,7 +1451,10 @@ tsq_status agg_merge(const AggDesc& d, const Partial& src, Partial& dst) {
             if (src.isNull) return TSQ_OK;
             if (dst.isNull) { dst = src; return TSQ_OK; }
             const bool isMax = f.func == TSQ_AGG_MAX;
-            if (d.is_real) { if ((isMax && src.f > dst.f) || (!isMax && src.f < dst.f)) dst.f = src.f; }
+            if (d.is_str) {  // maxMin4String.MergePartialResult (func_max_min.go:364-378)
+                const int c = cmp_string(src.s, dst.s);
+                if ((isMax && c > 0) || (!isMax && c < 0)) dst.s = src.s;
+            } else if (d.is_real) { if ((isMax && src.f > dst.f) || (!isMax && src.f < dst.f)) dst.f = src.f; }
             else if (f.arg_type == TSQ_U64) {
                 if ((isMax && (uint64_t)src.i > (uint64_t)dst.i) || (!isMax && (uint64_t)src.i < (uint64_t)dst.i)) dst.i = src.i;
             } else if ((isMax && src.i > dst.i) || (!isMax && src.i < dst.i)) dst.i = src.i;
@@ -1457,6 +1474,7 @@ std::vector<AggDesc> make_descs(const tsq_agg_cfg* cfg) {
     for (int32_t a = 0; a < cfg->n_aggs; a++) {
         ds[a].f = cfg->aggs[a];
         ds[a].is_real = cfg->aggs[a].arg_type == TSQ_F32 || cfg->aggs[a].arg_type == TSQ_F64;
+        ds[a].is_str = cfg->aggs[a].arg_type == TSQ_BYTES;
     }
     return ds;
 }
@@ -1474,11 +1492,27 @@ std::vector<Partial> alloc_partials(const std::vector<AggDesc>& ds) {
 // partial worker: updatePartialResult over rows [lo,hi) (aggregate.go:332-350)
 tsq_status partial_update(const tsq_agg_cfg* cfg, const std::vector<AggDesc>& ds, const tsq_col* cols, int64_t lo,
                           int64_t hi, GroupMap& m) {
-    uint8_t kb[16 * TSQ_MAX_GROUP_KEYS];
+    uint8_t kb[16];
+    std::string key;
     for (int64_t r = lo; r < hi; r++) {
-        int32_t kl = 0;  // getGroupKey (aggregate.go:359-394)
-        for (int32_t g = 0; g < cfg->n_group_keys; g++) kl += orc_group_key_encode(&cols[cfg->group_key_col[g]], r, kb + kl);
-        std::string key((const char*)kb, kl);
+        key.clear();  // getGroupKey (aggregate.go:359-394)
+        for (int32_t g = 0; g < cfg->n_group_keys; g++) {
+            const tsq_col& kc = cols[cfg->group_key_col[g]];
+            if (kc.type == TSQ_BYTES && !col_is_null(kc, r)) {  // encodeBytes(.., comparable=false): compactBytesFlag + varint(len) + bytes
+                                                              // (codec.go:738-744, bytes.go:144-148)
+                const int64_t n = kc.offsets[r + 1] - kc.offsets[r];
+                uint64_t ux = ((uint64_t)n << 1) ^ (uint64_t)(n >> 63);
+                key.push_back((char)compactBytesFlag);
+                while (ux >= 0x80) {
+                    key.push_back((char)((uint8_t)ux | 0x80));
+                    ux >>= 7;
+                }
+                key.push_back((char)(uint8_t)ux);
+                key.append((const char*)kc.data + kc.offsets[r], (size_t)n);
+            } else {
+                key.append((const char*)kb, (size_t)orc_group_key_encode(&kc, r, kb));
+            }
+        }
         auto it = m.find(key);  // getPartialResult (aggregate.go:396-410)
         if (it == m.end()) it = m.emplace(key, alloc_partials(ds)).first;
         for (size_t a = 0; a < ds.size(); a++) {
@@ -1508,6 +1542,11 @@ void append_final(const tsq_agg_cfg* cfg, const std::vector<AggDesc>& ds, const 
                 res->cols[oc].type = t;
                 res->cols[oc++].append_raw((uint64_t)v, nn);
             };
+            auto put_str = [&](const std::string& v, bool nn) {  // chk.AppendString / AppendNull (func_max_min.go:327-335)
+                res->cols[oc].type = TSQ_BYTES;
+                if (nn) res->cols[oc++].append_bytes(v.data(), v.size());
+                else res->cols[oc++].append_raw(0, false);
+            };
             switch (f.func) {
                 case TSQ_AGG_COUNT: put_int(p.i, true, TSQ_I64); break;  // func_count.go:22-26
                 case TSQ_AGG_SUM:                                        // func_sum.go:50-58,107-115
@@ -1527,11 +1566,13 @@ void append_final(const tsq_agg_cfg* cfg, const std::vector<AggDesc>& ds, const 
                     break;
                 case TSQ_AGG_MAX:
                 case TSQ_AGG_MIN:
-                    if (ds[a].is_real) put_real(p.f, !p.isNull, f.arg_type);
+                    if (ds[a].is_str) put_str(p.s, !p.isNull);
+                    else if (ds[a].is_real) put_real(p.f, !p.isNull, f.arg_type);
                     else put_int(p.i, !p.isNull, f.arg_type);
                     break;
                 case TSQ_AGG_FIRSTROW:  // func_first_row.go:91-99
-                    if (ds[a].is_real) put_real(p.f, !(p.isNull || !p.got), f.arg_type);
+                    if (ds[a].is_str) put_str(p.s, !(p.isNull || !p.got));
+                    else if (ds[a].is_real) put_real(p.f, !(p.isNull || !p.got), f.arg_type);
                     else put_int(p.i, !(p.isNull || !p.got), f.arg_type);
                     break;
             }

@@ -110,9 +110,15 @@ def run_agg(ctx, cfg, chunk, out_types, chunk_rows=1024, pull_rows=1024, fast=No
             _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
             stats_out.append(st)
         got = []
+        has_var = abi.BYTES in out_types
         while True:
             keep = []
-            out, bufs = out_buffers(out_types, pull_rows, keep)
+            var_bytes = None
+            if has_var:  # size the data arrays of the var-len columns for this pull (tsq_agg_peek)
+                pn, pb = C.c_int64(0), (C.c_int64 * len(out_types))()
+                _lib.check(lib.tsq_agg_peek(h, pull_rows, C.byref(pn), pb, len(out_types)), h)
+                var_bytes = list(pb)
+            out, bufs = out_buffers(out_types, pull_rows, keep, var_bytes)
             n, eos = C.c_int64(0), C.c_int32(0)
             _lib.check(lib.tsq_agg_pull(h, out, len(out_types), pull_rows, C.byref(n), C.byref(eos)), h)
             if n.value == 0:
@@ -194,6 +200,55 @@ class DevCol:
         if self.bitmap:
             self.ctx.free(self.bitmap)
         self.data = self.bitmap = None
+
+
+class DevStrCol:
+    """a device-resident var-len column (offsets[n + 1] + data [+ bitmap]) holding the cells of a StrColumn, or an empty
+    output column with room for `nrows` cells and `nbytes` data bytes."""
+
+    tp = abi.BYTES
+
+    def __init__(self, ctx, column=None, nrows=0, nbytes=0):
+        self.ctx = ctx
+        if column is not None:
+            self.n = len(column)
+            self.data = ctx.alloc(len(column.data) + 64)
+            self.offsets = ctx.alloc((self.n + 1) * 8 + 64)
+            ctx.h2d(self.data, column.data)
+            ctx.h2d(self.offsets, column.offsets)
+            self.bitmap = None
+            if column.notnull is not None:
+                self.bitmap = ctx.alloc((self.n + 7) // 8 + 64)
+                ctx.h2d(self.bitmap, column.bitmap())
+        else:
+            self.n = nrows
+            self.data = ctx.alloc(nbytes + 64)
+            self.offsets = ctx.alloc((nrows + 1) * 8 + 64)
+            self.bitmap = ctx.alloc((nrows + 7) // 8 + 64)
+
+    def col(self):
+        c = abi.Col()
+        c.data, c.null_bitmap, c.offsets = self.data, self.bitmap, self.offsets
+        c.length, c.elem_size, c.type, c.flags = self.n, -1, abi.BYTES, abi.COL_DEVICE
+        return c
+
+    def to_host(self, n, nbytes):
+        from tinysql_amd.chunk import StrColumn, unpack_bitmap
+
+        offs = np.zeros(n + 1, np.int64)
+        self.ctx.d2h(offs, self.offsets)
+        data = np.zeros(nbytes + 8, np.uint8)
+        self.ctx.d2h(data, self.data)
+        bm = np.zeros((n + 7) // 8 + 1, np.uint8)
+        self.ctx.d2h(bm, self.bitmap)
+        nn = unpack_bitmap(bm, n)
+        raw = data.tobytes()
+        return StrColumn([raw[offs[i]:offs[i + 1]] if nn[i] else None for i in range(n)])
+
+    def free(self):
+        for p in (self.data, self.offsets, self.bitmap):
+            if p:
+                self.ctx.free(p)
 
 
 def dev_cols(cols):

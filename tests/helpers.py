@@ -7,10 +7,10 @@ import numpy as np
 
 from tinysql_amd import _abi as abi
 from tinysql_amd import expression as E
-from tinysql_amd.chunk import Chunk, Column, np_dtype
+from tinysql_amd.chunk import Chunk, Column, StrColumn, np_dtype
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TYPES = {"i64": abi.I64, "u64": abi.U64, "f32": abi.F32, "f64": abi.F64}
+TYPES = {"i64": abi.I64, "u64": abi.U64, "f32": abi.F32, "f64": abi.F64, "str": abi.BYTES}
 JOIN_TYPES = {"inner": abi.JOIN_INNER, "left": abi.JOIN_LEFT_OUTER, "right": abi.JOIN_RIGHT_OUTER}
 AGG_FUNCS = {"count": abi.AGG_COUNT, "sum": abi.AGG_SUM, "avg": abi.AGG_AVG, "max": abi.AGG_MAX, "min": abi.AGG_MIN,
              "firstrow": abi.AGG_FIRSTROW}
@@ -26,6 +26,9 @@ def chunk_from_rows(rows, types):
     cols = []
     for c, tp in enumerate(types):
         vals = [r[c] for r in rows]
+        if tp == abi.BYTES:
+            cols.append(StrColumn(vals))
+            continue
         nn = np.array([v is not None for v in vals], dtype=bool)
         if tp == abi.U64:
             data = np.array([0 if v is None else int(v) for v in vals], dtype=np.uint64)
@@ -158,6 +161,10 @@ def random_column(rng, tp, n, null_frac=0.2, lo=None, hi=None):
 def approx_equal(a, b, tol):
     if a is None or b is None:
         return a is None and b is None
+    if isinstance(a, str):  # golden strings vs the bytes of a var-len cell
+        a = a.encode()
+    if isinstance(b, str):
+        b = b.encode()
     if isinstance(a, float) or isinstance(b, float):
         if math.isnan(a) and math.isnan(b):
             return True

@@ -1,0 +1,185 @@
+"""GPU parity of strings in HashAggExec, through the C-ABI, against the oracle: string group keys (getGroupKey:
+compactBytesFlag + bytes, util/codec/codec.go:738-744; NULL and '' are different groups), firstRow4String
+(aggfuncs/func_first_row.go:193-230), maxMin4String (func_max_min.go:312-378, binary collation) and COUNT of a string.
+All results are bit-exact (bytes and integers); FIRST_ROW is compared only where it is functionally dependent on the key."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tinysql_amd import _abi as abi
+from tinysql_amd import _lib
+from tinysql_amd.chunk import Chunk, Column, StrColumn, concat
+
+from . import gpu_helpers as G
+from . import helpers as H
+from .test_agg_gpu import out_types_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _words(rng, n, distinct, lo=0, hi=24, null_frac=0.05, alphabet=b"abcXYZ019 _"):
+    """n cells drawn from `distinct` random byte strings of length lo..hi (shared prefixes on purpose), some NULL."""
+    pool = []
+    for i in range(distinct):
+        ln = int(rng.integers(lo, hi + 1))
+        body = bytes(rng.choice(list(alphabet), size=ln).astype(np.uint8))
+        pool.append((b"pre" + body) if i % 3 == 0 else body)
+    pool[0] = b""  # the empty string is a value, not NULL
+    pick = rng.integers(0, distinct, n)
+    isnull = rng.random(n) < null_frac
+    return StrColumn([None if isnull[i] else pool[pick[i]] for i in range(n)])
+
+
+def _run(ctx, cfg, chk, aggs, **kw):
+    return G.run_agg(ctx, cfg, chk, out_types_for(aggs), **kw)
+
+
+@pytest.mark.parametrize("n,distinct", [(1, 1), (37, 5), (5000, 300), (200001, 20000)])
+def test_string_group_key_vs_oracle(ctx, orc, n, distinct):
+    rng = np.random.default_rng(n)
+    k = _words(rng, n, distinct)
+    v = H.random_column(rng, abi.I64, n, 0.1, lo=-1000, hi=1000)
+    s = _words(rng, n, max(2, distinct // 3), null_frac=0.2)
+    chk = Chunk([k, v, s])
+    types = [abi.BYTES, abi.I64, abi.BYTES]
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_MAX, 2, abi.BYTES),
+            (abi.AGG_MIN, 2, abi.BYTES), (abi.AGG_COUNT, 2, abi.BYTES), (abi.AGG_MIN, 1, abi.I64)]
+    cfg = H.agg_cfg(types, [0], aggs)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    got = _run(ctx, cfg, chk, aggs)
+    assert got.NumRows() == want.NumRows()
+    assert H.rows_equal_unordered(got, want)
+    # chunk-sized pushes reach the same groups
+    assert H.rows_equal_unordered(_run(ctx, cfg, chk, aggs, chunk_rows=1000, pull_rows=333), want)
+
+
+def test_null_and_empty_string_keys_are_different_groups(ctx, orc):
+    k = StrColumn([None, b"", b"", None, b"a", b"a\0", b"a", None])  # a trailing NUL byte is part of the value
+    chk = Chunk([k, Column(abi.I64, np.arange(8))])
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 1, abi.I64)]
+    cfg = H.agg_cfg([abi.BYTES, abi.I64], [0], aggs)
+    got = _run(ctx, cfg, chk, aggs)
+    assert H.rows_equal_unordered(got, [(None, 3, 0 + 3 + 7), (b"", 2, 3), (b"a", 2, 10), (b"a\0", 1, 5)])
+    assert H.rows_equal_unordered(got, orc.hash_agg(cfg, chk, 2, 2))
+
+
+@pytest.mark.parametrize("keys", [[0, 1], [1, 0], [0, 1, 2], [0, 2]])
+def test_multi_key_with_strings_vs_oracle(ctx, orc, keys):
+    rng = np.random.default_rng(len(keys) * 7 + keys[0])
+    n = 60000
+    a = _words(rng, n, 40)
+    b = Column(abi.I64, rng.integers(0, 25, n), rng.random(n) > 0.05)
+    c = _words(rng, n, 6, lo=30, hi=60)
+    v = H.random_column(rng, abi.I64, n, 0.1, lo=-50, hi=50)
+    chk = Chunk([a, b, c, v])
+    types = [abi.BYTES, abi.I64, abi.BYTES, abi.I64]
+    aggs = [(abi.AGG_FIRSTROW, kc, types[kc]) for kc in keys] + [(abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 3, abi.I64), (abi.AGG_MAX, 2, abi.BYTES)]
+    cfg = H.agg_cfg(types, keys, aggs)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    got = _run(ctx, cfg, chk, aggs)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+def test_global_max_min_of_strings_and_empty_input(ctx, orc):
+    rng = np.random.default_rng(3)
+    s = _words(rng, 100000, 5000, lo=1, hi=12, null_frac=0.3)
+    chk = Chunk([s])
+    aggs = [(abi.AGG_MAX, 0, abi.BYTES), (abi.AGG_MIN, 0, abi.BYTES), (abi.AGG_COUNT, 0, abi.BYTES)]
+    cfg = H.agg_cfg([abi.BYTES], [], aggs)
+    vals = [x for x in s.values() if x is not None]
+    got = _run(ctx, cfg, chk, aggs)
+    assert got.rows() == [(max(vals), min(vals), len(vals))]
+    assert got.rows() == orc.hash_agg(cfg, chk, 4, 4).rows()
+    # every cell NULL, and no rows at all: MAX/MIN are NULL, COUNT is 0 (aggregate.go:572-574)
+    nulls = Chunk([StrColumn([None] * 9)])
+    assert _run(ctx, cfg, nulls, aggs).rows() == [(None, None, 0)]
+    assert _run(ctx, cfg, H.chunk_from_rows([], [abi.BYTES]), aggs).rows() == [(None, None, 0)]
+
+
+def test_partial_final_split_with_strings_equals_complete(ctx, orc):
+    # descriptor.go:56-91 Split: Complete == Final(Partial1); the partial rows carry string columns
+    rng = np.random.default_rng(21)
+    n = 30000
+    k = _words(rng, n, 200)
+    s = _words(rng, n, 900, null_frac=0.25)
+    chk = Chunk([k, s])
+    types = [abi.BYTES, abi.BYTES]
+    complete = [(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_MAX, 1, abi.BYTES), (abi.AGG_MIN, 1, abi.BYTES), (abi.AGG_COUNT, 1, abi.BYTES)]
+    want = orc.hash_agg(H.agg_cfg(types, [0], complete), chk, 1, 1)
+    paggs = [(f, c, t, abi.MODE_PARTIAL1) for f, c, t in complete]
+    pt = out_types_for(paggs)
+    parts = [_run(ctx, H.agg_cfg(types, [0], paggs), chk.slice(lo, hi), paggs) for lo, hi in [(0, 9000), (9000, 9001), (9001, n)]]
+    both = concat(parts, pt)
+    faggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES, abi.MODE_FINAL), (abi.AGG_MAX, 1, abi.BYTES, abi.MODE_FINAL),
+             (abi.AGG_MIN, 2, abi.BYTES, abi.MODE_FINAL), (abi.AGG_COUNT, 3, abi.BYTES, abi.MODE_FINAL)]
+    got = G.run_agg(ctx, H.agg_cfg(pt, [0], faggs), both, out_types_for(complete))
+    assert H.rows_equal_unordered(got, want)
+
+
+def test_long_cells_take_the_wave_copy(ctx, orc):
+    rng = np.random.default_rng(8)
+    n = 4000
+    k = Column(abi.I64, rng.integers(0, 50, n))
+    s = _words(rng, n, 300, lo=100, hi=700, null_frac=0.1)  # the join benchmark's payload is 5 KiB (executor/benchmark_test.go:328)
+    chk = Chunk([k, s])
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_MAX, 1, abi.BYTES), (abi.AGG_MIN, 1, abi.BYTES)]
+    cfg = H.agg_cfg([abi.I64, abi.BYTES], [0], aggs)
+    assert H.rows_equal_unordered(_run(ctx, cfg, chk, aggs), orc.hash_agg(cfg, chk, 4, 4))
+
+
+def test_device_resident_batches_of_odd_sizes(ctx, orc):
+    # every push is one batch: the operator copies the cells into its own heap (the caller may free its columns right after
+    # the push) and pads the heap to 8 rows between batches; pull on the device
+    rng = np.random.default_rng(5)
+    sizes = [1, 7, 1000, 13, 4097, 250]
+    n = sum(sizes)
+    k = _words(rng, n, 60)
+    s = _words(rng, n, 500, null_frac=0.2)
+    v = H.random_column(rng, abi.I64, n, 0.1, lo=0, hi=99)
+    chk = Chunk([k, s, v])
+    types = [abi.BYTES, abi.BYTES, abi.I64]
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_MAX, 1, abi.BYTES), (abi.AGG_SUM, 2, abi.I64), (abi.AGG_COUNT, -1, abi.I64)]
+    cfg = H.agg_cfg(types, [0], aggs)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    lib = ctx.lib
+    h = C.c_void_p()
+    _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        lo = 0
+        for sz in sizes:
+            part = chk.slice(lo, lo + sz)
+            lo += sz
+            dcols = [G.DevStrCol(ctx, part.columns[0]), G.DevStrCol(ctx, part.columns[1]), G.to_device(ctx, part.columns[2])]
+            _lib.check(lib.tsq_agg_push(h, G.dev_cols(dcols), 3, sz), h)
+            ctx.sync()
+            for d in dcols[:2]:  # the pushed columns are gone before the next batch arrives
+                ctx.memset(d.data, 0x5A, 8)
+                d.free()
+        _lib.check(lib.tsq_agg_finish(h), h)
+        g = C.c_int64(0)
+        _lib.check(lib.tsq_agg_num_groups(h, C.byref(g)), h)
+        cap = (g.value + 7) & ~7
+        pn, pb = C.c_int64(0), (C.c_int64 * 4)()
+        _lib.check(lib.tsq_agg_peek(h, cap, C.byref(pn), pb, 4), h)
+        assert pn.value == g.value and pb[2] == 0 and pb[3] == 0
+        outs = [G.DevStrCol(ctx, nrows=cap, nbytes=pb[0]), G.DevStrCol(ctx, nrows=cap, nbytes=pb[1]), G.DevCol(ctx, abi.I64, cap, True),
+                G.DevCol(ctx, abi.I64, cap, True)]
+        nr, eos = C.c_int64(0), C.c_int32(0)
+        _lib.check(lib.tsq_agg_pull(h, G.dev_cols(outs), 4, cap, C.byref(nr), C.byref(eos)), h)
+        assert nr.value == g.value
+        got = Chunk([outs[0].to_host(nr.value, pb[0]), outs[1].to_host(nr.value, pb[1])] + [Column(*_fixed(o, nr.value)) for o in outs[2:]])
+        assert H.rows_equal_unordered(got, want)
+    finally:
+        lib.tsq_agg_destroy(h)
+
+
+def _fixed(dev, n):
+    col = dev.to_host()
+    return abi.I64, col.data[:n], None if col.notnull is None else col.notnull[:n]
+
+
+def test_unsupported_string_plans_are_refused(ctx):
+    cfg = H.agg_cfg([abi.BYTES], [], [(abi.AGG_SUM, 0, abi.BYTES)])
+    h = C.c_void_p()
+    assert ctx.lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)) == abi.ERR_UNSUPPORTED

@@ -117,7 +117,10 @@ def test_join_int_vs_varlen_class_never_equal(orc):
 # ------------------------------------------------------------------ aggregate functions
 def _agg_input(tp_name, n, trailing_null=False):
     tp = H.TYPES[tp_name]
-    rows = [[i] for i in range(n)] if tp in (abi.I64, abi.U64) else [[float(i)] for i in range(n)]
+    if tp == abi.BYTES:  # aggfunc_test.go:157-158: the decimal digits of the row number
+        rows = [[str(i)] for i in range(n)]
+    else:
+        rows = [[i] for i in range(n)] if tp in (abi.I64, abi.U64) else [[float(i)] for i in range(n)]
     if trailing_null:
         rows.append([None])
     return H.chunk_from_rows(rows, [tp]), tp

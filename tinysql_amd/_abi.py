@@ -219,6 +219,7 @@ SIGNATURES = {
     "tsq_redistribute": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_redistribute_wait": (C.c_int32, [P, C.c_int32]),
     "tsq_join_peek": (C.c_int32, [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
+    "tsq_agg_peek": (C.c_int32, [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     "tsq_join_stats": (C.c_int32, [P, C.POINTER(Stats)]),
     "tsq_agg_stats": (C.c_int32, [P, C.POINTER(Stats)]),
 }

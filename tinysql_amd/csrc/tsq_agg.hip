@@ -16,6 +16,14 @@
 // device-scope atomics per aggregate.  int64 SUM/AVG accumulate in 128 bits (lo += v with carry into
 // hi); overflow is reported iff the exact group sum leaves the BIGINT range (func_sum.go:133-137
 // reports it as soon as a running sum overflows, which depends on worker interleaving there).
+//
+// Var-len cells (string group keys: codec.go:738-744; firstRow4String, func_first_row.go:193-230; maxMin4String,
+// func_max_min.go:312-378).  The reference deep-copies the string a partial result keeps (stringutil.Copy); here the
+// operator keeps the bytes of every var-len input column it was pushed — one growing heap per column in HBM — and a cell
+// is a 64-bit REFERENCE into that heap, byte offset << 24 | length.  A reference fits the 8-byte words of gkey[] / acc[],
+// so claiming a group, FIRST_ROW and table growth move strings as words; only the equality check of a string key and the
+// MAX/MIN comparison (a CAS loop on the reference) touch the bytes.  A string key makes the aggregate take the multi-key
+// path (tag = hash of the bytes, the bytes themselves verified in phase 1).
 #include "tsq_stage.h"
 #include "tsq_aggfast.h"
 
@@ -111,6 +119,35 @@ __device__ __forceinline__ uint64_t ord_image_decode(uint64_t w, int32_t type) {
 
 __device__ __forceinline__ bool is_real_type(int32_t t) { return t == TSQ_F32 || t == TSQ_F64; }
 
+// ---- references to var-len cells (see the file header)
+#define TSQ_REF_LEN_BITS 24
+#define TSQ_REF_MAXLEN ((1ull << TSQ_REF_LEN_BITS) - 2)  /* a longer cell raises counters[5]: UNSUPPORTED */
+#define TSQ_REF_NONE (~0ull)                             /* MAX/MIN of strings: no value yet */
+__device__ __forceinline__ uint64_t ref_len(uint64_t ref) { return ref & ((1ull << TSQ_REF_LEN_BITS) - 1); }
+__device__ __forceinline__ uint64_t ref_off(uint64_t ref) { return ref >> TSQ_REF_LEN_BITS; }
+// the cell (c, row) of a batch whose var-len columns ARE the heap (data = heap base, offsets absolute)
+__device__ __forceinline__ uint64_t str_ref(const tsq_colset& cs, int c, int64_t row, unsigned long long* too_long) {
+    const int64_t o = cs.offs[c][row], n = cs.offs[c][row + 1] - o;
+    if ((uint64_t)n > TSQ_REF_MAXLEN) {
+        __hip_atomic_store(too_long, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (uint64_t)o << TSQ_REF_LEN_BITS;
+    }
+    return ((uint64_t)o << TSQ_REF_LEN_BITS) | (uint64_t)n;
+}
+__device__ __forceinline__ int ref_cmp(const void* heap, uint64_t x, uint64_t y) {  // types.CompareString: binary collation
+    const uint8_t* h = (const uint8_t*)heap;
+    return tsq_cmp_bytes(h + ref_off(x), (uint32_t)ref_len(x), h + ref_off(y), (uint32_t)ref_len(y));
+}
+__device__ __forceinline__ bool ref_equal(const void* heap, uint64_t x, uint64_t y) {
+    if (x == y) return true;
+    if (ref_len(x) != ref_len(y)) return false;
+    return ref_cmp(heap, x, y) == 0;
+}
+// the 8-byte image of a cell as FIRST_ROW keeps it
+__device__ __forceinline__ uint64_t agg_cell(const tsq_colset& cs, int c, int64_t row, unsigned long long* too_long) {
+    return cs.type[c] == TSQ_BYTES ? str_ref(cs, c, row, too_long) : tsq_cell_raw(cs, c, row);
+}
+
 // 128-bit accumulate of a signed 64-bit addend: lo += v (returns carry), hi += sign(v) + carry
 __device__ __forceinline__ void add128(unsigned long long* lo, unsigned long long* hi, int64_t v) {
     const unsigned long long uv = (unsigned long long)v;
@@ -159,18 +196,30 @@ __device__ __forceinline__ void agg_update_slot(const AggArgs& a, uint64_t s, in
                 break;
             }
             case TSQ_AGG_MAX:  // func_max_min.go:81-117 (+uint/float variants)
-                if (arg_null) break;
-                atomicMax(&st.acc[s], (unsigned long long)ord_image(a.in, f.arg_col, f.arg_type, row));
-                st.seen[s] = 1;
-                break;
             case TSQ_AGG_MIN:
                 if (arg_null) break;
-                atomicMin(&st.acc[s], (unsigned long long)ord_image(a.in, f.arg_col, f.arg_type, row));
+                if (f.arg_type == TSQ_BYTES) {  // maxMin4String (func_max_min.go:337-362): the reference of the best string so far
+                    const unsigned long long mine = str_ref(a.in, f.arg_col, row, &a.counters[5]);
+                    unsigned long long cur = __hip_atomic_load(&st.acc[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        if (cur != TSQ_REF_NONE) {
+                            const int c = ref_cmp(a.in.data[f.arg_col], mine, cur);
+                            if (f.func == TSQ_AGG_MAX ? c <= 0 : c >= 0) break;
+                        }
+                        const unsigned long long prev = atomicCAS(&st.acc[s], cur, mine);
+                        if (prev == cur) break;
+                        cur = prev;
+                    }
+                } else if (f.func == TSQ_AGG_MAX) {
+                    atomicMax(&st.acc[s], (unsigned long long)ord_image(a.in, f.arg_col, f.arg_type, row));
+                } else {
+                    atomicMin(&st.acc[s], (unsigned long long)ord_image(a.in, f.arg_col, f.arg_type, row));
+                }
                 st.seen[s] = 1;
                 break;
             case TSQ_AGG_FIRSTROW:
                 if (!winner) break;
-                st.acc[s] = arg_null ? 0ull : tsq_cell_raw(a.in, f.arg_col, row);
+                st.acc[s] = arg_null ? 0ull : agg_cell(a.in, f.arg_col, row, &a.counters[5]);
                 st.seen[s] = arg_null ? 0 : 1;
                 break;
         }
@@ -226,9 +275,16 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
             for (int k = 0; k < a.plan.n_keys; k++) {
                 const int c = a.plan.key_col[k];
                 const bool isn = tsq_is_null(a.in.nulls[c], row);
-                kw[k] = isn ? 0 : group_key_word(a.in, c, row);
+                uint64_t hw;
+                if (a.in.type[c] == TSQ_BYTES) {  // the group keeps a reference; the tag (phase 0 only) hashes the bytes
+                    kw[k] = isn ? 0 : str_ref(a.in, c, row, &a.counters[5]);
+                    hw = (isn || a.phase != 0) ? 0 : tsq_hash_bytes((const uint8_t*)a.in.data[c] + ref_off(kw[k]), (int64_t)ref_len(kw[k]));
+                } else {
+                    kw[k] = isn ? 0 : group_key_word(a.in, c, row);
+                    hw = kw[k];
+                }
                 nullmask |= isn ? (1u << k) : 0u;
-                h = tsq_splitmix64(h ^ kw[k]) + (isn ? 0x9E3779B97F4A7C15ULL : 0);
+                h = tsq_splitmix64(h ^ hw) + (isn ? 0x9E3779B97F4A7C15ULL : 0);
             }
             tag = h == TSQ_EMPTY_TAG ? h ^ 1 : h;
         }
@@ -276,13 +332,17 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
                     const tsq_agg_func f = a.plan.f[i];
                     if (f.func != TSQ_AGG_FIRSTROW) continue;
                     const bool arg_null = tsq_is_null(a.in.nulls[f.arg_col], row);
-                    a.t.st[i].acc[slot] = arg_null ? 0ull : tsq_cell_raw(a.in, f.arg_col, row);
+                    a.t.st[i].acc[slot] = arg_null ? 0ull : agg_cell(a.in, f.arg_col, row, &a.counters[5]);
                     a.t.st[i].seen[slot] = arg_null ? 0 : 1;
                 }
             }
         } else {
             bool same = a.t.gknull[slot] == (uint8_t)nullmask;
-            for (int k = 0; k < a.plan.n_keys && same; k++) same = a.t.gkey[k][slot] == kw[k];
+            for (int k = 0; k < a.plan.n_keys && same; k++) {
+                const int c = a.plan.key_col[k];
+                if (a.in.type[c] == TSQ_BYTES) same = ((nullmask >> k) & 1u) || ref_equal(a.in.data[c], a.t.gkey[k][slot], kw[k]);
+                else same = a.t.gkey[k][slot] == kw[k];
+            }
             if (!same) { atomicAdd(&a.counters[2], 1ull); continue; }
             agg_update_slot(a, slot, row, false);
         }
@@ -511,7 +571,7 @@ __global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
                 case TSQ_AGG_MAX:
                 case TSQ_AGG_MIN: {
                     const bool nn = st.seen[s] != 0;
-                    const uint64_t v = nn ? ord_image_decode(st.acc[s], f.arg_type) : 0;
+                    const uint64_t v = !nn ? 0 : (f.arg_type == TSQ_BYTES ? st.acc[s] : ord_image_decode(st.acc[s], f.arg_type));
                     if (f.arg_type == TSQ_F32) ((uint32_t*)a.out_data[oc])[pos] = (uint32_t)v;
                     else ((uint64_t*)a.out_data[oc])[pos] = v;
                     a.out_notnull[oc][pos] = nn ? 1 : 0;
@@ -529,6 +589,34 @@ __global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
             }
         }
       }
+    }
+}
+
+// K8b — var-len output columns (AppendFinalResult2Chunk of firstRow4String / maxMin4String: chk.AppendString): the
+// finalize pass left references; their lengths (k_ref_len), the exclusive scan of the lengths = the column's offsets
+// (tsq_launch_scan64), then the bytes out of the heap (k_ref_copy: one row per lane, or per wave for long cells).
+struct RefOutArgs {
+    const unsigned long long* refs;
+    const uint8_t* notnull;  // one byte per row
+    int64_t rows;
+    const uint8_t* heap;
+    int64_t* out_offs;       // [rows + 1]
+    uint8_t* out_data;
+};
+__global__ void __launch_bounds__(256) k_ref_len(RefOutArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x)
+        a.out_offs[r] = a.notnull[r] ? (int64_t)ref_len(a.refs[r]) : 0;  // a NULL cell has no bytes
+}
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_ref_copy(RefOutArgs a) {
+    const int lane = WAVE ? (threadIdx.x & 63) : 0, step = WAVE ? 64 : 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = WAVE ? (t >> 6) : t; r < a.rows; r += WAVE ? (nt >> 6) : nt) {
+        if (!a.notnull[r]) continue;
+        const uint8_t* s = a.heap + ref_off(a.refs[r]);
+        uint8_t* d = a.out_data + a.out_offs[r];
+        const int64_t n = a.out_offs[r + 1] - a.out_offs[r];
+        for (int64_t i = lane; i < n; i += step) d[i] = s[i];
     }
 }
 
@@ -559,6 +647,10 @@ struct tsq_agg {
     DevBuf counters, retry[2];
     HostStage stage;
     std::vector<ColStore> icols;  // device batch for host pushes
+    // var-len input columns: the bytes of every pushed cell stay here until the operator is destroyed (file header); a batch
+    // starts at a heap row that is a multiple of 8, so its null bitmap starts on a byte
+    std::vector<ColStore> heap;
+    bool has_str = false;
     bool finished = false;
     int64_t in_rows = 0;
     // output
@@ -566,6 +658,10 @@ struct tsq_agg {
     std::vector<int32_t> out_types;
     std::vector<DevBuf> odata, onn, obitmap;
     std::vector<PinnedBuf> hdata, hbitmap;
+    std::vector<int32_t> out_arg_col;   // var-len output column -> the input column whose heap its references point into
+    std::vector<DevBuf> ooffs, obytes;  // var-len output columns: offsets[out_rows + 1] and the bytes (odata holds the references)
+    std::vector<int64_t> onbytes;
+    std::vector<PinnedBuf> hoffs;
     int64_t out_rows = 0, out_cursor = 0;
     bool out_on_host = false, host_mode = true;
     tsq_stats st{};
@@ -617,7 +713,7 @@ tsq_status alloc_table(tsq_agg* a, AggTableBufs& b, uint64_t cap) {
         TSQ_TRY(b.aux[i].reserve(ctx, h, n * 8));
         TSQ_TRY(b.cnt[i].reserve(ctx, h, n * 8));
         TSQ_TRY(b.seen[i].reserve(ctx, h, n));
-        if (a->plan.f[i].func == TSQ_AGG_MIN) {
+        if (a->plan.f[i].func == TSQ_AGG_MIN || (a->plan.f[i].func == TSQ_AGG_MAX && a->plan.f[i].arg_type == TSQ_BYTES)) {
             int grid = tsq_grid_for(ctx, (int64_t)n, 256);
             hipLaunchKernelGGL(k_fill_u64, dim3(grid), dim3(256), 0, ctx->stream, b.acc[i].as<unsigned long long>(), ~0ull, n);
             TSQ_HIP(h, hipGetLastError());
@@ -904,22 +1000,57 @@ tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     return TSQ_OK;
 }
 
+// appends n rows of var-len input column c (pinned staging or the caller's device column) to its heap and pads the heap to
+// a multiple of 8 rows; *row0 = heap row of the first appended row
+tsq_status heap_append(tsq_agg* a, int c, const void* data, const int64_t* offsets, const uint8_t* bitmap, int64_t n, bool src_dev, DevBuf& t1,
+                       DevBuf& t2, int64_t* row0) {
+    ColStore& hs = a->heap[c];
+    *row0 = hs.rows;
+    TSQ_TRY(tsq_col_append_varlen(a->ctx, &a->hdr, hs, data, offsets, bitmap, n, src_dev, t1, t2));
+    if (hs.nbytes >= (1ll << 40)) return tsq_fail(&a->hdr, TSQ_ERR_UNSUPPORTED, "aggregate: more than 1 TiB of string cells in one column");
+    const int64_t pad = (8 - (hs.rows & 7)) & 7;
+    if (pad) {
+        static const int64_t zeros[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        TSQ_TRY(tsq_col_append_varlen(a->ctx, &a->hdr, hs, zeros, zeros, nullptr, pad, false, t1, t2));
+    }
+    return TSQ_OK;
+}
+// points the var-len columns of a batch at their heaps (data = heap base, offsets absolute, bitmap from the batch's first row)
+void colset_use_heap(const tsq_agg* a, tsq_colset& in, int c, int64_t row0) {
+    const ColStore& hs = a->heap[c];
+    in.data[c] = hs.data.p;
+    in.offs[c] = hs.offs.as<int64_t>() + row0;
+    in.nulls[c] = hs.has_nulls ? hs.nulls.as<uint8_t>() + (row0 >> 3) : nullptr;
+    in.type[c] = TSQ_BYTES;
+}
+
 tsq_status agg_flush(tsq_agg* a) {
     HostStage& sg = a->stage;
     if (sg.staged == 0) return TSQ_OK;
-    DevBuf tmp;
+    if (sg.failed) return tsq_fail(&a->hdr, TSQ_ERR_OOM_DEVICE, "pinned staging for a var-len column could not grow");
+    DevBuf tmp, tmp2;
+    std::vector<int64_t> row0(a->icols.size(), 0);
     for (size_t c = 0; c < a->icols.size(); c++) {
-        a->icols[c].rows = 0;
-        a->icols[c].has_nulls = false;
-        tsq_status s = tsq_col_append(a->ctx, &a->hdr, a->icols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
-        if (s != TSQ_OK) { tmp.release(); return s; }
-        a->st.h2d_bytes += sg.staged * a->icols[c].elem();
+        tsq_status s;
+        if (a->icols[c].type == TSQ_BYTES) {
+            s = heap_append(a, (int)c, sg.data[c].p, (const int64_t*)sg.offs[c].p, sg.bitmap((int)c), sg.staged, false, tmp, tmp2, &row0[c]);
+            a->st.h2d_bytes += sg.nbytes[c] + sg.staged * 8;
+        } else {
+            a->icols[c].rows = 0;
+            a->icols[c].has_nulls = false;
+            s = tsq_col_append(a->ctx, &a->hdr, a->icols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
+            a->st.h2d_bytes += sg.staged * a->icols[c].elem();
+        }
+        if (s != TSQ_OK) { tmp.release(); tmp2.release(); return s; }
     }
     tsq_colset in;
     tsq_fill_colset(in, a->icols);
+    for (size_t c = 0; c < a->icols.size(); c++)
+        if (a->icols[c].type == TSQ_BYTES) colset_use_heap(a, in, (int)c, row0[c]);
     tsq_status s = agg_batch(a, in, sg.staged);
     hipError_t e = hipStreamSynchronize(a->ctx->stream);
     tmp.release();
+    tmp2.release();
     a->in_rows += sg.staged;
     sg.reset();
     if (s != TSQ_OK) return s;
@@ -937,9 +1068,11 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
     if (cfg->n_group_keys < 0 || cfg->n_group_keys > TSQ_MAX_GROUP_KEYS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "0..4 group keys supported");
     if (cfg->n_aggs < 1 || cfg->n_aggs > TSQ_MAX_AGGS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 aggregate functions supported");
     if (cfg->n_input_cols < 1 || cfg->n_input_cols > TSQ_MAX_COLS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 input columns supported");
-    for (int c = 0; c < cfg->n_input_cols; c++)
-        if (cfg->input_types[c] < TSQ_I64 || cfg->input_types[c] > TSQ_F64)
-            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len input column: fall back to the Go operator");
+    bool has_str = false;
+    for (int c = 0; c < cfg->n_input_cols; c++) {
+        if (cfg->input_types[c] < TSQ_I64 || cfg->input_types[c] > TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_INVALID, "unknown input column type");
+        has_str |= cfg->input_types[c] == TSQ_BYTES;
+    }
     for (int k = 0; k < cfg->n_group_keys; k++) {
         if (cfg->group_key_col[k] < 0 || cfg->group_key_col[k] >= cfg->n_input_cols) return tsq_fail(ch, TSQ_ERR_INVALID, "group key column out of range");
         if (cfg->group_key_type[k] != cfg->input_types[cfg->group_key_col[k]]) return tsq_fail(ch, TSQ_ERR_INVALID, "group key type mismatch");
@@ -953,6 +1086,8 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
     a->plan.n_aggs = cfg->n_aggs;
     for (int k = 0; k < cfg->n_group_keys; k++) a->plan.key_col[k] = cfg->group_key_col[k];
     a->multi = cfg->n_group_keys > 1;
+    for (int k = 0; k < cfg->n_group_keys; k++) a->multi |= cfg->group_key_type[k] == TSQ_BYTES;  // a string key is verified by its bytes
+    a->has_str = has_str;
     for (int i = 0; i < cfg->n_aggs; i++) {
         const tsq_agg_func& f = cfg->aggs[i];
         if (f.func < TSQ_AGG_COUNT || f.func > TSQ_AGG_FIRSTROW) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "unknown aggregate function");
@@ -962,7 +1097,9 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
         if (f.arg_col < 0 && !(f.func == TSQ_AGG_COUNT && !merge)) return tsq_fail(ch, TSQ_ERR_INVALID, "only COUNT may take a constant argument");
         if (f.func == TSQ_AGG_AVG && merge && (f.arg_col2 < 0 || f.arg_col2 >= cfg->n_input_cols))
             return tsq_fail(ch, TSQ_ERR_INVALID, "AVG in final mode needs (count, sum) columns");
-        if (f.arg_type < TSQ_I64 || f.arg_type > TSQ_F64) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len aggregate argument: fall back to the Go operator");
+        if (f.arg_type < TSQ_I64 || f.arg_type > TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_INVALID, "unknown aggregate argument type");
+        if (f.arg_type == TSQ_BYTES && (f.func == TSQ_AGG_SUM || f.func == TSQ_AGG_AVG))
+            return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "SUM/AVG of a string argument (the planner casts it to double first): fall back to the Go operator");
         if (f.func != TSQ_AGG_COUNT) {
             const int vc = (f.func == TSQ_AGG_AVG && merge) ? f.arg_col2 : f.arg_col;
             if (cfg->input_types[vc] != f.arg_type) return tsq_fail(ch, TSQ_ERR_INVALID, "aggregate arg_type does not match its input column");
@@ -980,12 +1117,14 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
                 break;
             default: a->out_types.push_back(f.arg_type); break;
         }
+        a->out_arg_col.resize(a->out_types.size(), -1);
+        if (f.func != TSQ_AGG_COUNT && f.func != TSQ_AGG_SUM && f.func != TSQ_AGG_AVG && f.arg_type == TSQ_BYTES) a->out_arg_col.back() = f.arg_col;
     }
     a->n_out = (int)a->out_types.size();
     {   // LDS pre-aggregation plan: one group key, raw-argument modes, every aggregate expressible in <= 5 LDS words
         AfPlan& fp = a->fplan;
         memset(&fp, 0, sizeof fp);
-        bool ok = cfg->n_group_keys == 1;
+        bool ok = cfg->n_group_keys == 1 && !has_str;  // LDS words are fixed width
         fp.n_aggs = cfg->n_aggs;
         if (ok) {
             fp.key_col = cfg->group_key_col[0];
@@ -1029,7 +1168,8 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
     TSQ_HIP(ch, hipSetDevice(ctx->device));
     tsq_handle_hdr* h = &a->hdr;
     a->icols.resize(cfg->n_input_cols);
-    for (int c = 0; c < cfg->n_input_cols; c++) a->icols[c].type = cfg->input_types[c];
+    a->heap.resize(cfg->n_input_cols);
+    for (int c = 0; c < cfg->n_input_cols; c++) a->icols[c].type = a->heap[c].type = cfg->input_types[c];
     tsq_status s = a->counters.reserve(ctx, h, 64);
     if (s == TSQ_OK) {
         hipError_t e = hipMemsetAsync(a->counters.p, 0, 64, ctx->stream);
@@ -1065,6 +1205,19 @@ TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols,
         TSQ_TRY(agg_flush(a));
         tsq_colset all;
         tsq_colset_from_cols(all, cols, n_cols);
+        if (a->has_str) {  // the operator keeps the var-len cells (device to device) and works on its own copy
+            DevBuf t1, t2;
+            tsq_status hs = TSQ_OK;
+            for (int c = 0; c < n_cols && hs == TSQ_OK; c++) {
+                if (cols[c].type != TSQ_BYTES) continue;
+                int64_t row0 = 0;
+                hs = heap_append(a, c, cols[c].data, cols[c].offsets, cols[c].null_bitmap, nrows, true, t1, t2, &row0);
+                if (hs == TSQ_OK) colset_use_heap(a, all, c, row0);
+            }
+            t1.release();
+            t2.release();
+            TSQ_TRY(hs);
+        }
         const int64_t slice = 256 << 20;  // device batches: every batch ends with a merge of its partial groups and two host syncs
         for (int64_t off = 0; off < nrows; off += slice) {
             const int64_t n = std::min<int64_t>(slice, nrows - off);
@@ -1128,23 +1281,69 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
         TSQ_TRY(a->obitmap[oc].reserve(ctx, h, tsq_bitmap_bytes(g) + 16));
         TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a->onn[oc].as<uint8_t>(), a->obitmap[oc].as<uint8_t>(), g));
     }
-    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, (char*)a->counters.p + 3 * 8, 16, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, (char*)a->counters.p + 3 * 8, 24, hipMemcpyDeviceToHost, ctx->stream));
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
     const int64_t emitted = (int64_t)ctx->pinned[0];
     const bool overflow = ctx->pinned[1] != 0;
+    if (ctx->pinned[2]) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "aggregate: a string cell longer than 16 MiB - 2 bytes: fall back to the Go operator");
     if (overflow) return tsq_fail(h, TSQ_ERR_OVERFLOW_BIGINT, "BIGINT value is out of range in 'sum/avg' (func_sum.go:133-137)");
     if (emitted != g) return tsq_fail(h, TSQ_ERR_HIP, "internal: finalize emitted " + std::to_string(emitted) + " groups, expected " + std::to_string(g));
+    // var-len output columns: references -> offsets + bytes
+    a->ooffs.resize(a->n_out);
+    a->obytes.resize(a->n_out);
+    a->onbytes.assign(a->n_out, 0);
+    for (int oc = 0; oc < a->n_out; oc++) {
+        if (a->out_types[oc] != TSQ_BYTES) continue;
+        TSQ_TRY(a->ooffs[oc].reserve(ctx, h, (size_t)(g + 1) * 8 + 64));
+        TSQ_HIP(h, hipMemsetAsync(a->ooffs[oc].p, 0, 8, ctx->stream));
+        if (g == 0) continue;
+        RefOutArgs ra;
+        memset(&ra, 0, sizeof ra);
+        ra.refs = a->odata[oc].as<unsigned long long>();
+        ra.notnull = a->onn[oc].as<uint8_t>();
+        ra.rows = g;
+        ra.heap = (const uint8_t*)a->heap[a->out_arg_col[oc]].data.p;
+        ra.out_offs = a->ooffs[oc].as<int64_t>();
+        hipLaunchKernelGGL(k_ref_len, dim3(tsq_grid_for(ctx, g, 256)), dim3(256), 0, ctx->stream, ra);
+        TSQ_HIP(h, hipGetLastError());
+        DevBuf scratch;
+        tsq_status s = tsq_launch_scan64(ctx, h, ra.out_offs, g, scratch);
+        if (s == TSQ_OK) {
+            hipError_t e = hipMemcpyAsync(ctx->pinned + 8, ra.out_offs + g, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, std::string("var-len output: ") + hipGetErrorString(e));
+        }
+        scratch.release();
+        TSQ_TRY(s);
+        const int64_t nbytes = (int64_t)ctx->pinned[8];
+        a->onbytes[oc] = nbytes;
+        TSQ_TRY(a->obytes[oc].reserve(ctx, h, (size_t)nbytes + 64));
+        ra.out_data = a->obytes[oc].as<uint8_t>();
+        if (nbytes > 0) {
+            if (nbytes / g > 32) hipLaunchKernelGGL(k_ref_copy<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, ra);
+            else hipLaunchKernelGGL(k_ref_copy<false>, dim3(tsq_grid_for(ctx, g, 256)), dim3(256), 0, ctx->stream, ra);
+            TSQ_HIP(h, hipGetLastError());
+        }
+        a->st.kernel_launches += 5;
+    }
     a->out_rows = g;
     a->out_cursor = 0;
     a->st.out_rows = g;
     if (a->host_mode) {
         a->hdata.resize(a->n_out);
         a->hbitmap.resize(a->n_out);
+        a->hoffs.resize(a->n_out);
         for (int oc = 0; oc < a->n_out; oc++) {
-            const size_t bytes = (size_t)g * tsq_elem_size(a->out_types[oc]);
+            const bool var = a->out_types[oc] == TSQ_BYTES;
+            const size_t bytes = var ? (size_t)a->onbytes[oc] : (size_t)g * tsq_elem_size(a->out_types[oc]);
             TSQ_TRY(a->hdata[oc].reserve(h, bytes + 16));
             TSQ_TRY(a->hbitmap[oc].reserve(h, tsq_bitmap_bytes(g) + 16));
-            TSQ_HIP(h, hipMemcpyAsync(a->hdata[oc].p, a->odata[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (var) {
+                TSQ_TRY(a->hoffs[oc].reserve(h, (size_t)(g + 1) * 8 + 16));
+                TSQ_HIP(h, hipMemcpyAsync(a->hoffs[oc].p, a->ooffs[oc].p, (size_t)(g + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                a->st.d2h_bytes += (g + 1) * 8;
+            }
+            if (bytes) TSQ_HIP(h, hipMemcpyAsync(a->hdata[oc].p, var ? a->obytes[oc].p : a->odata[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
             TSQ_HIP(h, hipMemcpyAsync(a->hbitmap[oc].p, a->obitmap[oc].p, tsq_bitmap_bytes(g), hipMemcpyDeviceToHost, ctx->stream));
             a->st.d2h_bytes += bytes;
         }
@@ -1184,10 +1383,18 @@ TSQ_API tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, i
     for (int oc = 0; oc < a->n_out; oc++) {
         tsq_col& o = out_cols[oc];
         const int es = tsq_elem_size(a->out_types[oc]);
+        const bool var = a->out_types[oc] == TSQ_BYTES;
         const bool odev = o.flags & TSQ_COL_DEVICE;
         if (!o.data || !o.null_bitmap) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "pull: out column needs data and null_bitmap buffers");
+        if (var && !o.offsets) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "pull: var-len out column needs an offsets buffer (tsq_agg_peek tells the data bytes)");
         if (a->out_on_host && !odev) {
-            memcpy(o.data, (const char*)a->hdata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es);
+            if (var) {  // cells [cursor, cursor + n): their bytes, and the offsets moved to start at 0
+                const int64_t* so = (const int64_t*)a->hoffs[oc].p + a->out_cursor;
+                memcpy(o.data, (const char*)a->hdata[oc].p + so[0], (size_t)(so[n] - so[0]));
+                for (int64_t i = 0; i <= n; i++) o.offsets[i] = so[i] - so[0];
+            } else {
+                memcpy(o.data, (const char*)a->hdata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es);
+            }
             const uint8_t* src = (const uint8_t*)a->hbitmap[oc].p;
             if ((a->out_cursor & 7) == 0) memcpy(o.null_bitmap, src + (a->out_cursor >> 3), tsq_bitmap_bytes(n));
             else {
@@ -1199,18 +1406,57 @@ TSQ_API tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, i
             }
         } else if (!a->out_on_host && odev) {
             if (a->out_cursor & 7) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "device pull: cap_rows must keep the cursor a multiple of 8");
-            TSQ_HIP(&a->hdr, hipMemcpyAsync(o.data, (const char*)a->odata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es, hipMemcpyDeviceToDevice, a->ctx->stream));
+            if (var) {
+                const int64_t* so = a->ooffs[oc].as<int64_t>() + a->out_cursor;
+                TSQ_HIP(&a->hdr, hipMemcpyAsync(a->ctx->pinned + 44, so, 8, hipMemcpyDeviceToHost, a->ctx->stream));
+                TSQ_HIP(&a->hdr, hipMemcpyAsync(a->ctx->pinned + 45, so + n, 8, hipMemcpyDeviceToHost, a->ctx->stream));
+                TSQ_HIP(&a->hdr, hipStreamSynchronize(a->ctx->stream));
+                const int64_t b0 = (int64_t)a->ctx->pinned[44], b1 = (int64_t)a->ctx->pinned[45];
+                if (b1 > b0) TSQ_HIP(&a->hdr, hipMemcpyAsync(o.data, (const char*)a->obytes[oc].p + b0, (size_t)(b1 - b0), hipMemcpyDeviceToDevice, a->ctx->stream));
+                TSQ_TRY(tsq_launch_offsets_rebase(a->ctx, &a->hdr, o.offsets, so, n + 1, -b0));
+            } else {
+                TSQ_HIP(&a->hdr, hipMemcpyAsync(o.data, (const char*)a->odata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es, hipMemcpyDeviceToDevice, a->ctx->stream));
+            }
             TSQ_HIP(&a->hdr, hipMemcpyAsync(o.null_bitmap, a->obitmap[oc].as<uint8_t>() + (a->out_cursor >> 3), tsq_bitmap_bytes(n), hipMemcpyDeviceToDevice, a->ctx->stream));
         } else {
             return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "pull: output placement (host/device) must match the pushes");
         }
         o.length = n;
         o.type = a->out_types[oc];
-        o.elem_size = es;
+        o.elem_size = var ? -1 : es;
     }
     if (!a->out_on_host) TSQ_HIP(&a->hdr, hipStreamSynchronize(a->ctx->stream));
     a->out_cursor += n;
     *nrows_out = n;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_peek(tsq_agg* a, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_out, int32_t n_cols) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
+    if (!nrows_out || !bytes_out) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "NULL out pointer");
+    if (!a->finished) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "peek before finish");
+    if (n_cols != a->n_out) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "peek: wrong number of output columns");
+    *nrows_out = 0;
+    for (int oc = 0; oc < n_cols; oc++) bytes_out[oc] = 0;
+    TSQ_TRY(agg_cancelled(a));
+    const int64_t n = std::min<int64_t>(cap_rows, a->out_rows - a->out_cursor);
+    if (n <= 0) return TSQ_OK;
+    *nrows_out = n;
+    TSQ_HIP(&a->hdr, hipSetDevice(a->ctx->device));
+    for (int oc = 0; oc < n_cols; oc++) {
+        if (a->out_types[oc] != TSQ_BYTES) continue;
+        if (a->out_on_host) {
+            const int64_t* so = (const int64_t*)a->hoffs[oc].p + a->out_cursor;
+            bytes_out[oc] = so[n] - so[0];
+        } else {
+            const int64_t* so = a->ooffs[oc].as<int64_t>() + a->out_cursor;
+            TSQ_HIP(&a->hdr, hipMemcpyAsync(a->ctx->pinned + 44, so, 8, hipMemcpyDeviceToHost, a->ctx->stream));
+            TSQ_HIP(&a->hdr, hipMemcpyAsync(a->ctx->pinned + 45, so + n, 8, hipMemcpyDeviceToHost, a->ctx->stream));
+            TSQ_HIP(&a->hdr, hipStreamSynchronize(a->ctx->stream));
+            bytes_out[oc] = (int64_t)a->ctx->pinned[45] - (int64_t)a->ctx->pinned[44];
+        }
+    }
     return TSQ_OK;
 }
 
@@ -1243,6 +1489,10 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
     a->slot_of.release();
     a->stage.release();
     for (auto& c : a->icols) c.release();
+    for (auto& c : a->heap) c.release();
+    for (auto& b : a->ooffs) b.release();
+    for (auto& b : a->obytes) b.release();
+    for (auto& b : a->hoffs) b.release();
     for (auto& b : a->odata) b.release();
     for (auto& b : a->onn) b.release();
     for (auto& b : a->obitmap) b.release();

@@ -67,6 +67,20 @@ TSQ_HD uint64_t tsq_rowhash_step(uint64_t h, uint64_t v, uint32_t c) {
     return tsq_splitmix64(h ^ (v + (uint64_t)(c + 1) * 0x9E3779B97F4A7C15ULL));
 }
 
+// hash of a var-len cell (string join keys and string group keys: equality is decided by the bytes, so any hash will do)
+TSQ_HD uint64_t tsq_hash_bytes(const uint8_t* p, int64_t n) {
+    uint64_t w = 0x9E3779B97F4A7C15ULL ^ (uint64_t)n;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, p + i, 8);
+        w = tsq_splitmix64(w ^ x);
+    }
+    uint64_t tail = 0;
+    for (int64_t q = i; q < n; q++) tail = (tail << 8) | p[q];
+    return tsq_splitmix64(w ^ tail);
+}
+
 // rank of a key for the multi-GPU radix redistribute (tsq_radix_split)
 TSQ_HD uint32_t tsq_key_rank(uint64_t kw, uint32_t n_parts) {
     return (uint32_t)(((tsq_mix64(kw) & 0xffffu) * (uint64_t)n_parts) >> 16);

@@ -54,17 +54,7 @@ __device__ __forceinline__ bool load_kw(const tsq_colset& cs, const int32_t* idx
             if (cs.type[c] == TSQ_BYTES) {  // a string key cell is (compactBytesFlag, its bytes) (codec.go:233-235): any hash of the bytes will do,
                                             // keys_equal compares the bytes themselves
                 const int64_t o0 = cs.offs[c][row], n = cs.offs[c][row + 1] - o0;
-                const uint8_t* p = (const uint8_t*)cs.data[c] + o0;
-                w = 0x9E3779B97F4A7C15ULL ^ (uint64_t)n;
-                int64_t i = 0;
-                for (; i + 8 <= n; i += 8) {
-                    uint64_t x;
-                    memcpy(&x, p + i, 8);
-                    w = tsq_splitmix64(w ^ x);
-                }
-                uint64_t tail = 0;
-                for (int64_t q = i; q < n; q++) tail = (tail << 8) | p[q];
-                w = tsq_splitmix64(w ^ tail);
+                w = tsq_hash_bytes((const uint8_t*)cs.data[c] + o0, n);
                 flag = 2;
             } else {
                 w = tsq_key_word(cs.data[c], cs.type[c], row, &flag);

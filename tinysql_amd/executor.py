@@ -263,7 +263,12 @@ class HashAggExec(Executor):
             _lib.check(self.lib.tsq_agg_finish(self.h), self.h)
             self.prepared = True
         keep = []
-        out, bufs = out_buffers(self.types, self.max_chunk_size, keep)
+        var_bytes = None
+        if abi.BYTES in self.types:  # string outputs (firstRow4String / maxMin4String): size their data arrays for this pull
+            pn, pb = C.c_int64(0), (C.c_int64 * len(self.types))()
+            _lib.check(self.lib.tsq_agg_peek(self.h, self.max_chunk_size, C.byref(pn), pb, len(self.types)), self.h)
+            var_bytes = list(pb)
+        out, bufs = out_buffers(self.types, self.max_chunk_size, keep, var_bytes)
         n = C.c_int64(0)
         eos = C.c_int32(0)
         _lib.check(self.lib.tsq_agg_pull(self.h, out, len(self.types), self.max_chunk_size, C.byref(n), C.byref(eos)), self.h)
