@@ -522,8 +522,10 @@ tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, in
  * Every rank runs the same call sequence.  Bootstrap: rank 0 calls tsq_comm_unique_id and hands the 128 bytes to the other
  * ranks by any side channel (the Go host: the coordinator's RPC; the harness: a file), then every rank calls tsq_comm_create.
  *
- * tsq_redistribute splits `cols` (device resident, no NULLs) by rank(key) on the context's stream (tsq_radix_split), exchanges
- * the run sizes, and queues ONE group of RCCL sends / receives on the communicator's own stream.  out_cols describe device
+ * tsq_redistribute splits `cols` (device resident, fixed width) by rank(key) on the context's stream (tsq_radix_split), exchanges
+ * the run sizes, and queues ONE group of RCCL sends / receives on the communicator's own stream.  A column with a null bitmap
+ * on ANY rank travels with one NOT-NULL byte per row and arrives with a packed bitmap (out_cols[c].null_bitmap, owned by the
+ * slot); rows with a NULL key go to rank 0 (they never join; GROUP BY makes them one group).  out_cols describe device
  * buffers owned by `slot` (0..7) of the communicator: they hold the received rows once tsq_redistribute_wait(comm, slot) has
  * made the context's stream wait for the exchange, and stay valid until the next tsq_redistribute on the same slot.  Queue
  * piece c + 1's redistribute before piece c's consumer (wait; tsq_join_probe_push / tsq_agg_push) and the wire time of

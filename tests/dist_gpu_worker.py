@@ -48,6 +48,27 @@ def dev(ctx, arr, keep):
     return c
 
 
+def devn(ctx, arr, notnull, keep):
+    """device column with a null bitmap (bit = 1: NOT NULL)"""
+    c = dev(ctx, arr, keep)
+    bm = np.concatenate([np.packbits(notnull.astype(np.uint8), bitorder="little"), np.zeros(8, np.uint8)])
+    q = ctx.alloc(bm.nbytes)
+    ctx.h2d(q, bm)
+    keep.append(q)
+    c.null_bitmap = q
+    return c
+
+
+def null_rows_of(rank, n):
+    rng = np.random.default_rng(9100 + rank)
+    k = rng.integers(0, 5000, n).astype(np.int64)
+    v = rng.integers(-99, 99, n).astype(np.int64)
+    kn = rng.random(n) > 0.03
+    vn = rng.random(n) > 0.10
+    vn[k % 17 == 0] = False  # whole groups without a single non-NULL value: SUM / MIN are NULL, also as partial results
+    return k, kn, v, vn
+
+
 def main():
     import time
     t_start = time.time()
@@ -128,7 +149,55 @@ def main():
             assert sorted(zip(*[c.tolist() for c in cols])) == want_rows
             assert comm.allreduce_i64([ng])[0] == whole.NumRows()
             lap("oracle aggregate")
-            print("rank %d/%d OK: join %d rows, %d of %d groups" % (rank, world, total, ng, whole.NumRows()), flush=True)
+            # ---- NULLs travel with the rows: NULL keys form one group (owned by rank 0), NULL values and NULL partial results
+            nn_rows = [null_rows_of(r, 90_000 + 500 * r) for r in range(world)]
+            k, kn, v, vn = nn_rows[rank]
+            got, n = comm.redistribute([devn(ctx, k, kn, keep), devn(ctx, v, vn, keep)], 0, 1, len(k), slot=5)
+            comm.wait(5)
+            ctx.sync()
+            rk, rv = np.empty(n, np.int64), np.empty(n, np.int64)
+            bk2, bv2 = np.zeros((n + 7) // 8 + 1, np.uint8), np.zeros((n + 7) // 8 + 1, np.uint8)
+            if n:
+                ctx.d2h(rk, got[0].data)
+                ctx.d2h(rv, got[1].data)
+                ctx.d2h(bk2[:(n + 7) // 8], got[0].null_bitmap)
+                ctx.d2h(bv2[:(n + 7) // 8], got[1].null_bitmap)
+            rkn = np.unpackbits(bk2, bitorder="little")[:n].astype(bool)
+            rvn = np.unpackbits(bv2, bitorder="little")[:n].astype(bool)
+            uk2 = np.concatenate([a[0] for a in nn_rows])
+            ukn = np.concatenate([a[1] for a in nn_rows])
+            uv2 = np.concatenate([a[2] for a in nn_rows])
+            uvn = np.concatenate([a[3] for a in nn_rows])
+            owner = np.where(ukn, np_rank(uk2, world), 0)
+            cell = lambda x, ok: [a if b else None for a, b in zip(x.tolist(), ok.tolist())]  # noqa: E731
+            key_of = lambda r: tuple((x is None, x or 0) for x in r)  # noqa: E731
+            mine = owner == rank
+            assert sorted(zip(cell(rk, rkn), cell(rv, rvn)), key=key_of) == sorted(zip(cell(uk2[mine], ukn[mine]), cell(uv2[mine], uvn[mine])), key=key_of)
+            paggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_SUM, 1, abi.I64, abi.MODE_PARTIAL1),
+                     (abi.AGG_COUNT, 1, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_MIN, 1, abi.I64, abi.MODE_PARTIAL1)]
+            faggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_FINAL), (abi.AGG_SUM, 1, abi.I64, abi.MODE_FINAL),
+                     (abi.AGG_COUNT, 2, abi.I64, abi.MODE_FINAL), (abi.AGG_MIN, 3, abi.I64, abi.MODE_FINAL)]
+            out, ng2 = parallel.dist_hash_agg(comm, H.agg_cfg(t, [0], paggs), H.agg_cfg(ptypes, [0], faggs),
+                                              [devn(ctx, k, kn, keep), devn(ctx, v, vn, keep)], len(k), ptypes)
+            got_cols = []
+            for p, q in out:
+                a, bm = np.empty(ng2, np.int64), np.zeros((ng2 + 7) // 8 + 1, np.uint8)
+                if ng2:
+                    ctx.d2h(a, p)
+                    ctx.d2h(bm[:(ng2 + 7) // 8], q)
+                got_cols.append(cell(a, np.unpackbits(bm, bitorder="little")[:ng2].astype(bool)))
+                ctx.free(p)
+                ctx.free(q)
+            caggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, 1, abi.I64), (abi.AGG_MIN, 1, abi.I64)]
+            whole2 = orc.hash_agg(H.agg_cfg(t, [0], caggs), Chunk([Column(abi.I64, uk2, ukn), Column(abi.I64, uv2, uvn)]), 4, 4)
+            wrows = whole2.rows()
+            wown = [0 if r[0] is None else int(np_rank(np.array([r[0]], np.int64), world)[0]) for r in wrows]
+            assert sorted(zip(*got_cols), key=key_of) == sorted([r for r, o in zip(wrows, wown) if o == rank], key=key_of)
+            assert comm.allreduce_i64([ng2])[0] == whole2.NumRows()
+            assert any(r[1] is None for r in wrows) and any(r[0] is None for r in wrows)  # the case really holds NULL sums and the NULL group
+            lap("NULLs through the exchange")
+            print("rank %d/%d OK: join %d rows, %d of %d groups, %d of %d groups with NULLs" % (rank, world, total, ng, whole.NumRows(), ng2, whole2.NumRows()),
+                  flush=True)
         finally:
             for p in keep:
                 ctx.free(p)

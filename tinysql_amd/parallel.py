@@ -210,10 +210,11 @@ class Comm:
 
 
 def col_slice(col, lo, hi):
-    """rows [lo, hi) of a device-resident fixed-width column without NULLs"""
+    """rows [lo, hi) of a device-resident fixed-width column (lo a multiple of 8 when the column has a null bitmap)"""
     c = abi.Col()
     c.data = (col.data or 0) + lo * col.elem_size
-    c.null_bitmap, c.offsets = None, None
+    assert not col.null_bitmap or lo % 8 == 0
+    c.null_bitmap, c.offsets = (col.null_bitmap + lo // 8) if col.null_bitmap else None, None
     c.length, c.elem_size, c.type, c.flags = hi - lo, col.elem_size, col.type, col.flags
     return c
 
@@ -310,17 +311,6 @@ def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_
             n, eos = C.c_int64(0), C.c_int32(0)
             _lib.check(lib.tsq_agg_pull(hp, pcols, len(partial_types), (n_part + 7) & ~7, C.byref(n), C.byref(eos)), hp)
             assert n.value == n_part
-            # the exchange carries no null bitmaps yet (tsq_redistribute): a partial row with a NULL cell (a group whose every
-            # argument was NULL) cannot travel — refuse loudly instead of dropping the flag
-            import numpy as np
-            for i in range(len(partial_types)):
-                bm = np.empty((n_part + 7) // 8, dtype=np.uint8)
-                ctx.d2h(bm, pcols[i].null_bitmap)
-                bits = np.unpackbits(bm, bitorder="little")[:n_part]
-                if not bits.all():
-                    raise _lib.TsqError(abi.ERR_UNSUPPORTED, "dist_hash_agg: partial column %d holds NULLs; NULL partial results are not exchanged yet" % i)
-        for i in range(len(partial_types)):
-            pcols[i].null_bitmap = None
     finally:
         lib.tsq_agg_destroy(hp)
     hf = C.c_void_p()
