@@ -566,7 +566,8 @@ typedef struct tsq_stats {
     int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew) in the last batch */
     int32_t radix_bits;            /* log2(partitions) of the last radix batch */
     int32_t build_partitioned;     /* 1: the table was assembled slice by slice in LDS (tsq_buildpart.h), 0: row-at-a-time CAS build */
-    int64_t build_handed_back_rows; /* partitioned build: rows inserted row by row afterwards (skewed pass-1 / pass-2 regions) */
+    int64_t build_handed_back_rows; /* partitioned build: rows inserted row by row afterwards (skewed pass-1 / pass-2 regions);
+                                       aggregate: rows of a multi-key GROUP BY whose 64-bit tag belonged to another key (resolved) */
     int32_t table_slice_bits;      /* log2(slices) of the join table (0: one slice) */
     int32_t build_slice_retries;   /* 1: a slice overflowed (skewed keys) and the table was rebuilt as one slice */
 } tsq_stats;

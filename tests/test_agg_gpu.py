@@ -245,3 +245,36 @@ def test_sum_int64_running_overflow_divergence_is_pinned(ctx, orc):
     with pytest.raises(_lib.TsqError) as e2:
         G.run_agg(ctx, cfg, final, [abi.I64, abi.I64])
     assert e2.value.status == abi.ERR_OVERFLOW_BIGINT
+
+
+@pytest.mark.parametrize("bits", [7, 10])
+def test_multi_key_tag_collisions_are_resolved_not_reported(ctx, orc, bits):
+    # TSQ_AGG_TAG_BITS truncates the 64-bit tag of the multi-key path: with 2^bits tags for ~7 K groups, 7 to 55 different keys
+    # share every tag (a run of that many slots; the walk limit is 256), which is what a real 64-bit collision looks like to the
+    # table.  Every group must still come out once, with its own rows.
+    import os
+
+    rng = np.random.default_rng(bits)
+    n = 120_000
+    a = Column(abi.I64, rng.integers(0, 90, n), rng.random(n) > 0.03)
+    b = Column(abi.I64, rng.integers(-40, 40, n), rng.random(n) > 0.03)
+    v = H.random_column(rng, abi.I64, n, 0.1, lo=-1000, hi=1000)
+    chk = Chunk([a, b, v])
+    types = [abi.I64, abi.I64, abi.I64]
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_FIRSTROW, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 2, abi.I64), (abi.AGG_MAX, 2, abi.I64)]
+    cfg = H.agg_cfg(types, [0, 1], aggs)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    old = os.environ.get("TSQ_AGG_TAG_BITS")
+    os.environ["TSQ_AGG_TAG_BITS"] = str(bits)
+    try:
+        stats = []
+        got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 22, stats_out=stats)
+        got2 = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=7000)  # many batches: later rows meet earlier groups
+    finally:
+        if old is None:
+            os.environ.pop("TSQ_AGG_TAG_BITS", None)
+        else:
+            os.environ["TSQ_AGG_TAG_BITS"] = old
+    assert stats[0].build_handed_back_rows > n // 2  # most rows really went the long way
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    assert H.rows_equal_unordered(got2, want)

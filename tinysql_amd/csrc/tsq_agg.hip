@@ -30,6 +30,7 @@
 #include <memory>
 
 #define TSQ_EMPTY_TAG 0x8080808080808080ULL
+#define TSQ_BUSY_TAG 0x8080808080808082ULL  /* multi key, phase 1: slot claimed, its key cells not yet published */
 
 struct AggState {  // device pointers of one aggregate's state arrays
     unsigned long long* acc;
@@ -58,9 +59,10 @@ struct AggArgs {
     int64_t row_base;               // global row number of row 0 (diagnostics only)
     const uint32_t* retry_in;       // optional: process only these rows
     uint32_t* retry_out;            // rows that found no slot within the probe limit
-    unsigned long long* counters;   // [0]=new groups [1]=retry count [2]=hash collisions
+    unsigned long long* counters;   // [0]=new groups [1]=retry count [2]=rows whose tag was another key's (resolved) [5]=a string cell too long for a reference
     int32_t phase;                  // multi key: 0 = claim slots, 1 = verify + update
     uint32_t* slot_of;              // multi key: slot found by phase 0 for item r (0xffffffff = handed back), read by phase 1
+    uint32_t tag_bits;              // 0, or (tests) keep only this many bits of the multi-key tag so that distinct keys collide
     uint64_t bail_after;            // once this many items were handed back the table is too small: the rest skip the walk
 };
 
@@ -245,9 +247,10 @@ __device__ __forceinline__ void block_add_u32(unsigned long long* dst, uint32_t 
 // (executor/aggregate.go:332-350): getGroupKey (:359-394) + getPartialResult (:396-410) + the per
 // row UpdatePartialResult calls.  SINGLE key: one fused pass.  MULTI key: phase 0 claims slots by
 // 64-bit tag and the claimer stores the key cells; phase 1 (a later launch, so the cells are
-// visible) verifies the cells and applies the aggregates — a tag collision between different keys
-// is counted and surfaces as an error instead of merging two groups.  Phase 0 leaves the slot of every item in
-// slot_of[], so phase 1 neither walks the table again nor depends on what other items did in between.
+// visible) verifies the cells and applies the aggregates.  Phase 0 leaves the slot of every item in slot_of[], so phase 1
+// does not walk the table again — unless the slot belongs to ANOTHER key with the same 64-bit tag: then the row walks on
+// from there, comparing cells, and finds or claims its own group (see the BUSY protocol below).  Two keys never merge
+// and the stream never has to be abandoned for a collision.
 template <bool MULTI>
 __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -286,7 +289,8 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
                 nullmask |= isn ? (1u << k) : 0u;
                 h = tsq_splitmix64(h ^ hw) + (isn ? 0x9E3779B97F4A7C15ULL : 0);
             }
-            tag = h == TSQ_EMPTY_TAG ? h ^ 1 : h;
+            if (a.tag_bits) h &= (1ull << a.tag_bits) - 1;
+            tag = (h == TSQ_EMPTY_TAG || h == TSQ_BUSY_TAG) ? h ^ 1 : h;
         }
         bool winner = false;
         if (MULTI && a.phase == 1) {
@@ -337,14 +341,53 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
                 }
             }
         } else {
-            bool same = a.t.gknull[slot] == (uint8_t)nullmask;
-            for (int k = 0; k < a.plan.n_keys && same; k++) {
-                const int c = a.plan.key_col[k];
-                if (a.in.type[c] == TSQ_BYTES) same = ((nullmask >> k) & 1u) || ref_equal(a.in.data[c], a.t.gkey[k][slot], kw[k]);
-                else same = a.t.gkey[k][slot] == kw[k];
+            auto keys_at = [&](uint64_t sl) -> bool {
+                bool same = a.t.gknull[sl] == (uint8_t)nullmask;
+                for (int k = 0; k < a.plan.n_keys && same; k++) {
+                    const int c = a.plan.key_col[k];
+                    if (a.in.type[c] == TSQ_BYTES) same = ((nullmask >> k) & 1u) || ref_equal(a.in.data[c], a.t.gkey[k][sl], kw[k]);
+                    else same = a.t.gkey[k][sl] == kw[k];
+                }
+                return same;
+            };
+            bool claimed = false;
+            if (!keys_at(slot)) {
+                // Two different keys share a 64-bit tag: this row's group lives further along the probe sequence, or nowhere yet.
+                // Everything phase 0 wrote is visible now, so tags AND cells are compared; a new group is claimed as BUSY, its
+                // cells written, then its tag published — a lane that meets BUSY looks at the slot again (the claimer never
+                // waits for anybody, so the wave makes progress whatever its lanes do).
+                atomicAdd(&a.counters[2], 1ull);  // statistic: rows that went the long way
+                bool found = false;
+                int probe = 0;
+                slot = slot + 1 == a.t.cap ? 0 : slot + 1;
+                while (probe < TSQ_AGG_PROBE_LIMIT && !found) {
+                    unsigned long long cur = __hip_atomic_load(&a.t.tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == TSQ_EMPTY_TAG) {
+                        cur = atomicCAS(&a.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, (unsigned long long)TSQ_BUSY_TAG);
+                        if (cur == TSQ_EMPTY_TAG) {
+                            for (int k = 0; k < a.plan.n_keys; k++) a.t.gkey[k][slot] = kw[k];
+                            a.t.gknull[slot] = (uint8_t)nullmask;
+                            __hip_atomic_store(&a.t.tag[slot], (unsigned long long)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            claimed = found = true;
+                            new_groups++;
+                        }
+                        continue;  // lost the race: the slot is BUSY or published now, look again
+                    }
+                    if (cur == TSQ_BUSY_TAG) continue;
+                    if (cur == tag && keys_at(slot)) {
+                        found = true;
+                        break;
+                    }
+                    slot = slot + 1 == a.t.cap ? 0 : slot + 1;
+                    probe++;
+                }
+                if (!found) {  // the run is too long for this table: the host grows it and runs the row again
+                    const uint32_t i = (uint32_t)atomicAdd(&a.counters[1], 1ull);
+                    a.retry_out[i] = (uint32_t)row;
+                    continue;
+                }
             }
-            if (!same) { atomicAdd(&a.counters[2], 1ull); continue; }
-            agg_update_slot(a, slot, row, false);
+            agg_update_slot(a, slot, row, claimed);
         }
     }
     // one device atomic per workgroup: a same-address atomic per THREAD costs ~11 ns each, chip-wide (3e5 of them were
@@ -651,6 +694,7 @@ struct tsq_agg {
     // starts at a heap row that is a multiple of 8, so its null bitmap starts on a byte
     std::vector<ColStore> heap;
     bool has_str = false;
+    uint32_t test_tag_bits = 0;  // TSQ_AGG_TAG_BITS (tests): truncated multi-key tags, so that distinct keys share a tag
     bool finished = false;
     int64_t in_rows = 0;
     // output
@@ -790,8 +834,7 @@ tsq_status upsert_loop(tsq_agg* a, int64_t n0, const uint32_t* retry_in0, Launch
         TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
         a->groups += (int64_t)ctx->pinned[0];
         const uint64_t n_retry = ctx->pinned[1];
-        if (ctx->pinned[2])
-            return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "64-bit group-key hash collision between distinct keys: fall back to the Go operator");
+        a->st.build_handed_back_rows += (int64_t)ctx->pinned[2];  // rows whose 64-bit tag was shared by another key (resolved in phase 1)
         if (n_retry == 0) return TSQ_OK;
         // every item handed back may be a new group: size for that, within x4 .. x64 of the current table
         // (rounded to a power of two, so that a query that runs again finds its table arrays in the context pool)
@@ -815,6 +858,7 @@ tsq_status agg_rows(tsq_agg* a, const tsq_colset& in, int64_t nrows, const uint3
     args.plan = a->plan;
     args.row_base = a->in_rows;
     args.counters = a->counters.as<unsigned long long>();
+    args.tag_bits = a->test_tag_bits;
     if (a->multi) {
         TSQ_TRY(a->slot_of.reserve(a->ctx, &a->hdr, (size_t)nrows * 4 + 16));
         args.slot_of = a->slot_of.as<uint32_t>();
@@ -1088,6 +1132,7 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
     a->multi = cfg->n_group_keys > 1;
     for (int k = 0; k < cfg->n_group_keys; k++) a->multi |= cfg->group_key_type[k] == TSQ_BYTES;  // a string key is verified by its bytes
     a->has_str = has_str;
+    if (const char* v = getenv("TSQ_AGG_TAG_BITS")) a->test_tag_bits = (uint32_t)atoi(v) < 64 ? (uint32_t)atoi(v) : 0;
     for (int i = 0; i < cfg->n_aggs; i++) {
         const tsq_agg_func& f = cfg->aggs[i];
         if (f.func < TSQ_AGG_COUNT || f.func > TSQ_AGG_FIRSTROW) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "unknown aggregate function");
