@@ -47,16 +47,18 @@ inline void check(tsq_status s, const void* handle) {
 }
 
 // ---------------------------------------------------------------- util/chunk
-class Column {  // util/chunk/column.go:28-34, fixed-width element types only
+class Column {  // util/chunk/column.go:28-34: fixed-width cells, or offsets[n + 1] + data for var-len (TSQ_BYTES) columns
 public:
     int32_t type = TSQ_I64;
     int64_t length = 0;
     std::vector<uint8_t> nullBitmap;  // bit = 1 => NOT NULL, LSB first (column.go:89-92)
+    std::vector<int64_t> offsets;     // var-len only: length + 1 entries, first 0
     std::vector<uint8_t> data;
 
-    explicit Column(int32_t tp = TSQ_I64) : type(tp) {}
+    explicit Column(int32_t tp = TSQ_I64) : type(tp) { if (isVar()) offsets.assign(1, 0); }
+    bool isVar() const { return type == TSQ_BYTES; }
     int elemSize() const { return type == TSQ_F32 ? 4 : 8; }
-    void Reset() { length = 0; nullBitmap.clear(); data.clear(); }
+    void Reset() { length = 0; nullBitmap.clear(); data.clear(); if (isVar()) offsets.assign(1, 0); }
     bool IsNull(int64_t i) const { return ((nullBitmap[i >> 3] >> (i & 7)) & 1) == 0; }
     void appendNullBit(bool notNull) {  // column.go:113-127
         if ((length & 7) == 0) nullBitmap.push_back(0);
@@ -73,30 +75,65 @@ public:
     void AppendUint64(uint64_t v) { appendRaw(&v, true); }
     void AppendFloat64(double v) { appendRaw(&v, true); }
     void AppendFloat32(float v) { appendRaw(&v, true); }
-    void AppendNull() { uint64_t z = 0; appendRaw(&z, false); }
+    void AppendBytes(const void* p, size_t n) {  // column.go:207-211
+        appendNullBit(true);
+        data.insert(data.end(), (const uint8_t*)p, (const uint8_t*)p + n);
+        offsets.push_back((int64_t)data.size());
+        length++;
+    }
+    void AppendString(const std::string& v) { AppendBytes(v.data(), v.size()); }
+    void AppendNull() {
+        if (isVar()) {  // a NULL var-len cell has no bytes: the offset repeats (column.go:150-158)
+            appendNullBit(false);
+            offsets.push_back((int64_t)data.size());
+            length++;
+            return;
+        }
+        uint64_t z = 0;
+        appendRaw(&z, false);
+    }
+    // copies cell r of `src` (same type)
+    void AppendCell(const Column& src, int64_t r) {
+        if (src.IsNull(r)) AppendNull();
+        else if (isVar()) AppendBytes(src.data.data() + src.offsets[r], (size_t)(src.offsets[r + 1] - src.offsets[r]));
+        else appendRaw(&src.data[(size_t)r * src.elemSize()], true);
+    }
     int64_t GetInt64(int64_t i) const { int64_t v; memcpy(&v, &data[i * 8], 8); return v; }
     uint64_t GetUint64(int64_t i) const { uint64_t v; memcpy(&v, &data[i * 8], 8); return v; }
     double GetFloat64(int64_t i) const { double v; memcpy(&v, &data[i * 8], 8); return v; }
     float GetFloat32(int64_t i) const { float v; memcpy(&v, &data[i * 4], 4); return v; }
-    // prepare for being filled with up to n rows by libtsq
-    void resizeFor(int64_t n) {
-        data.assign((size_t)n * elemSize(), 0);
+    std::string GetString(int64_t i) const { return std::string((const char*)data.data() + offsets[i], (size_t)(offsets[i + 1] - offsets[i])); }
+    // prepare for being filled with up to n rows by libtsq (var-len: `bytes` data bytes, from tsq_join_peek / tsq_agg_peek)
+    void resizeFor(int64_t n, int64_t bytes = 0) {
+        if (isVar()) {
+            data.assign((size_t)bytes + 8, 0);
+            offsets.assign((size_t)n + 1, 0);
+        } else {
+            data.assign((size_t)n * elemSize(), 0);
+        }
         nullBitmap.assign((size_t)(n + 7) / 8, 0);
         length = 0;
     }
     tsq_col View(int64_t rows) {
         tsq_col c;
         memset(&c, 0, sizeof c);
+        if (isVar() && data.empty()) data.assign(8, 0);  // libtsq wants a data pointer even when every cell is empty
         c.data = data.data();
         c.null_bitmap = nullBitmap.data();
+        c.offsets = isVar() ? offsets.data() : nullptr;
         c.length = rows;
-        c.elem_size = elemSize();
+        c.elem_size = isVar() ? -1 : elemSize();
         c.type = type;
         return c;
     }
     void truncate(int64_t n) {
         length = n;
-        data.resize((size_t)n * elemSize());
+        if (isVar()) {
+            offsets.resize((size_t)n + 1);
+            data.resize((size_t)offsets[n]);
+        } else {
+            data.resize((size_t)n * elemSize());
+        }
         nullBitmap.resize((size_t)(n + 7) / 8);
     }
 };
@@ -181,9 +218,7 @@ public:
         const int64_t hi = std::min<int64_t>(n, pos_ + std::min(req->requiredRows, maxChunkSize));
         for (int64_t r = pos_; r < hi; r++)
             for (int c = 0; c < table_.NumCols(); c++) {
-                const Column& src = table_.columns[c];
-                if (src.IsNull(r)) req->columns[c].AppendNull();
-                else req->columns[c].appendRaw(&src.data[(size_t)r * src.elemSize()], true);
+                req->columns[c].AppendCell(table_.columns[c], r);
             }
         pos_ = hi;
     }
@@ -193,7 +228,7 @@ private:
 };
 
 // ---------------------------------------------------------------- package expression (tree -> postfix bytecode)
-enum EvalType { ETInt, ETReal };
+enum EvalType { ETInt, ETReal, ETString };  // types/eval_type.go:21-28
 struct Expression {  // expression.Expression (expression.go:57-114), the vectorizable subset
     enum Kind { COLUMN, CONSTANT, FUNC } kind = COLUMN;
     EvalType evalType = ETInt;
@@ -201,6 +236,7 @@ struct Expression {  // expression.Expression (expression.go:57-114), the vector
     int index = 0;             // COLUMN
     bool isNull = false;       // CONSTANT NULL
     int64_t bits = 0;          // CONSTANT: int64 or the bit pattern of a double
+    std::string str;           // CONSTANT of ETString
     std::string name;          // FUNC (ast.* function names, lower case)
     std::vector<Expression> args;
 };
@@ -208,10 +244,11 @@ inline Expression Col(int index, int32_t type) {  // expression.Column (column.g
     Expression e;
     e.kind = Expression::COLUMN;
     e.index = index;
-    e.evalType = (type == TSQ_F32 || type == TSQ_F64) ? ETReal : ETInt;
+    e.evalType = type == TSQ_BYTES ? ETString : ((type == TSQ_F32 || type == TSQ_F64) ? ETReal : ETInt);
     e.isUnsigned = type == TSQ_U64;
     return e;
 }
+inline Expression Str(const std::string& v) { Expression e; e.kind = Expression::CONSTANT; e.evalType = ETString; e.str = v; return e; }
 inline Expression Int(int64_t v) { Expression e; e.kind = Expression::CONSTANT; e.bits = v; return e; }
 inline Expression Real(double v) { Expression e; e.kind = Expression::CONSTANT; e.evalType = ETReal; memcpy(&e.bits, &v, 8); return e; }
 inline Expression Null(EvalType t) { Expression e; e.kind = Expression::CONSTANT; e.evalType = t; e.isNull = true; return e; }
@@ -228,7 +265,7 @@ inline Expression Func(const std::string& name, std::vector<Expression> args) {
     bool isCmp = false;
     for (auto* c : cmp) isCmp |= name == c;
     if (name == "plus" || name == "minus" || name == "mul") {
-        if (a.size() != 2 || !same(0)) throw Error(TSQ_ERR_UNSUPPORTED, "mixed int/real arithmetic needs an implicit conversion");
+        if (a.size() != 2 || !same(0) || a[0].evalType == ETString) throw Error(TSQ_ERR_UNSUPPORTED, "arithmetic over mixed or string arguments needs an implicit conversion");
         e.evalType = a[0].evalType;
         e.isUnsigned = e.evalType == ETInt && (a[0].isUnsigned || a[1].isUnsigned);
     } else if (name == "div") {
@@ -239,9 +276,13 @@ inline Expression Func(const std::string& name, std::vector<Expression> args) {
     } else if (name == "and" || name == "or") {
         if (a.size() != 2 || a[0].evalType != ETInt || a[1].evalType != ETInt) throw Error(TSQ_ERR_UNSUPPORTED, "logic operator over non-int arguments");
     } else if (name == "not" || name == "isnull") {
-        if (a.size() != 1) throw Error(TSQ_ERR_INVALID, "arity");
+        if (a.size() != 1 || (name == "not" && a[0].evalType == ETString)) throw Error(TSQ_ERR_INVALID, "arity / type");
+    } else if (name == "strcmp") {  // builtin_string_vec.go:52
+        if (a.size() != 2 || a[0].evalType != ETString || a[1].evalType != ETString) throw Error(TSQ_ERR_UNSUPPORTED, "STRCMP of non-string arguments");
+    } else if (name == "length") {  // builtin_string_vec.go:89
+        if (a.size() != 1 || a[0].evalType != ETString) throw Error(TSQ_ERR_UNSUPPORTED, "LENGTH of a non-string argument");
     } else if (name == "unaryminus") {
-        if (a.size() != 1) throw Error(TSQ_ERR_INVALID, "arity");
+        if (a.size() != 1 || a[0].evalType == ETString) throw Error(TSQ_ERR_INVALID, "arity / type");
         e.evalType = a[0].evalType;
     } else if (name == "ifnull") {
         if (a.size() != 2 || !same(0)) throw Error(TSQ_ERR_UNSUPPORTED, "IFNULL of mixed types");
@@ -267,25 +308,35 @@ inline void emit(const Expression& e, tsq_expr_prog& p) {
         o.arg = (uint16_t)arg;
         o.aux = aux;
     };
-    const bool real = e.evalType == ETReal;
-    if (e.kind == Expression::COLUMN) { push(real ? TSQ_OP_COL_REAL : TSQ_OP_COL_INT, 0, e.index, 0); return; }
+    const bool real = e.evalType == ETReal, str = e.evalType == ETString;
+    if (e.kind == Expression::COLUMN) { push(str ? TSQ_OP_COL_STR : (real ? TSQ_OP_COL_REAL : TSQ_OP_COL_INT), 0, e.index, 0); return; }
     if (e.kind == Expression::CONSTANT) {
-        if (e.isNull) { push(real ? TSQ_OP_CONST_NULL_REAL : TSQ_OP_CONST_NULL_INT, 0, 0, 0); return; }
+        if (e.isNull) { push(str ? TSQ_OP_CONST_NULL_STR : (real ? TSQ_OP_CONST_NULL_REAL : TSQ_OP_CONST_NULL_INT), 0, 0, 0); return; }
         if (p.n_consts >= TSQ_EXPR_MAX_CONSTS) throw Error(TSQ_ERR_UNSUPPORTED, "too many constants");
+        if (str) {  // the bytes go into the program's pool, the constant is (offset << 32) | length
+            if ((size_t)p.n_str_bytes + e.str.size() > TSQ_EXPR_STR_POOL) throw Error(TSQ_ERR_UNSUPPORTED, "string constants exceed the program's pool");
+            p.consts[p.n_consts] = ((int64_t)p.n_str_bytes << 32) | (int64_t)e.str.size();
+            memcpy(p.str_pool + p.n_str_bytes, e.str.data(), e.str.size());
+            p.n_str_bytes += (int32_t)e.str.size();
+            push(TSQ_OP_CONST_STR, 0, p.n_consts++, 0);
+            return;
+        }
         p.consts[p.n_consts] = e.bits;
         push(real ? TSQ_OP_CONST_REAL : TSQ_OP_CONST_INT, 0, p.n_consts++, 0);
         return;
     }
     for (auto& x : e.args) emit(x, p);
     const auto& a = e.args;
-    const bool areal = a[0].evalType == ETReal;
+    const bool areal = a[0].evalType == ETReal, astr = a[0].evalType == ETString;
     int flags = 0;
     if (a.size() >= 1 && a[0].isUnsigned) flags |= TSQ_F_LHS_UNSIGNED;
     if (a.size() >= 2 && a[1].isUnsigned) flags |= TSQ_F_RHS_UNSIGNED;
     const std::string& n = e.name;
     static const char* cmp[] = {"lt", "le", "gt", "ge", "eq", "ne"};
     for (int i = 0; i < 6; i++)
-        if (n == cmp[i]) { push((areal ? TSQ_OP_LT_REAL : TSQ_OP_LT_INT) + i, flags, 0, 0); return; }
+        if (n == cmp[i]) { push((astr ? TSQ_OP_LT_STR : (areal ? TSQ_OP_LT_REAL : TSQ_OP_LT_INT)) + i, astr ? 0 : flags, 0, 0); return; }
+    if (n == "strcmp") { push(TSQ_OP_STRCMP, 0, 0, 0); return; }
+    if (n == "length") { push(TSQ_OP_LENGTH, 0, 0, 0); return; }
     if (n == "plus") push(areal ? TSQ_OP_PLUS_REAL : TSQ_OP_PLUS_INT, flags, 0, 0);
     else if (n == "minus") push(areal ? TSQ_OP_MINUS_REAL : TSQ_OP_MINUS_INT, flags, 0, 0);
     else if (n == "mul") push(areal ? TSQ_OP_MUL_REAL : ((a[0].isUnsigned || a[1].isUnsigned) ? TSQ_OP_MUL_INT_UNSIGNED : TSQ_OP_MUL_INT), areal ? 0 : flags, 0, 0);
@@ -294,19 +345,21 @@ inline void emit(const Expression& e, tsq_expr_prog& p) {
     else if (n == "or") push(TSQ_OP_LOGIC_OR, 0, 0, 0);
     else if (n == "not") push(areal ? TSQ_OP_NOT_REAL : TSQ_OP_NOT_INT, 0, 0, 0);
     else if (n == "unaryminus") push(areal ? TSQ_OP_NEG_REAL : TSQ_OP_NEG_INT, flags, 0, 0);
-    else if (n == "isnull") push(areal ? TSQ_OP_ISNULL_REAL : TSQ_OP_ISNULL_INT, 0, 0, 0);
-    else if (n == "ifnull") push(areal ? TSQ_OP_IFNULL_REAL : TSQ_OP_IFNULL_INT, 0, 0, 0);
-    else if (n == "if") push(a[1].evalType == ETReal ? TSQ_OP_IF_REAL : TSQ_OP_IF_INT, 0, 0, 0);
+    else if (n == "isnull") push(astr ? TSQ_OP_ISNULL_STR : (areal ? TSQ_OP_ISNULL_REAL : TSQ_OP_ISNULL_INT), 0, 0, 0);
+    else if (n == "ifnull") push(astr ? TSQ_OP_IFNULL_STR : (areal ? TSQ_OP_IFNULL_REAL : TSQ_OP_IFNULL_INT), 0, 0, 0);
+    else if (n == "if") push(a[1].evalType == ETString ? TSQ_OP_IF_STR : (a[1].evalType == ETReal ? TSQ_OP_IF_REAL : TSQ_OP_IF_INT), 0, 0, 0);
     else if (n == "in") {
         uint32_t aux = 0;
         for (size_t j = 1; j < a.size(); j++) if (a[j].isUnsigned) aux |= 1u << (j - 1);
-        push(areal ? TSQ_OP_IN_REAL : TSQ_OP_IN_INT, flags & TSQ_F_LHS_UNSIGNED, (int)a.size() - 1, aux);
+        if (astr) push(TSQ_OP_IN_STR, 0, (int)a.size() - 1, 0);
+        else push(areal ? TSQ_OP_IN_REAL : TSQ_OP_IN_INT, flags & TSQ_F_LHS_UNSIGNED, (int)a.size() - 1, aux);
     }
 }
 inline tsq_expr_prog Lower(const Expression& e) {
     tsq_expr_prog p;
     memset(&p, 0, sizeof p);
     emit(e, p);
+    if (e.evalType == ETString) throw Error(TSQ_ERR_UNSUPPORTED, "a string-valued root (VecEvalString) has no GPU signature: strings feed comparisons");
     p.result_type = e.evalType == ETReal ? TSQ_F64 : TSQ_I64;
     p.result_unsigned = e.isUnsigned ? 1 : 0;
     return p;
@@ -348,11 +401,7 @@ public:
             for (; cursor_ < (int64_t)selected_.size(); cursor_++) {
                 if (!selected_[cursor_]) continue;
                 if (req->IsFull()) return;
-                for (int c = 0; c < req->NumCols(); c++) {
-                    const Column& src = child_->columns[c];
-                    if (src.IsNull(cursor_)) req->columns[c].AppendNull();
-                    else req->columns[c].appendRaw(&src.data[(size_t)cursor_ * src.elemSize()], true);
-                }
+                for (int c = 0; c < req->NumCols(); c++) req->columns[c].AppendCell(child_->columns[c], cursor_);
             }
             children_[0]->Next(child_.get());
             const int64_t n = child_->NumRows();
@@ -467,8 +516,15 @@ public:
         }
         const int64_t cap = req->requiredRows;
         Chunk probeChk(probe_->schema(), maxChunkSize);
+        bool anyVar = false;
+        for (auto& c : req->columns) anyVar |= c.isVar();
         for (;;) {
-            for (auto& c : req->columns) c.resizeFor(cap);
+            std::vector<int64_t> bytes(req->columns.size(), 0);
+            if (anyVar) {  // data bytes of the var-len columns of the next pull
+                int64_t pn = 0;
+                check(tsq_join_peek(h_, cap, &pn, bytes.data(), (int32_t)bytes.size()), h_);
+            }
+            for (size_t c = 0; c < req->columns.size(); c++) req->columns[c].resizeFor(cap, bytes[c]);
             std::vector<tsq_col> out;
             for (auto& c : req->columns) out.push_back(c.View(cap));
             int64_t n = 0;
@@ -601,7 +657,14 @@ public:
             return;
         }
         const int64_t cap = req->requiredRows;
-        for (auto& c : req->columns) c.resizeFor(cap);
+        std::vector<int64_t> bytes(req->columns.size(), 0);
+        bool anyVar = false;
+        for (auto& c : req->columns) anyVar |= c.isVar();
+        if (anyVar) {  // firstRow4String / maxMin4String outputs: their data bytes for this pull
+            int64_t pn = 0;
+            check(tsq_agg_peek(h_, cap, &pn, bytes.data(), (int32_t)bytes.size()), h_);
+        }
+        for (size_t c = 0; c < req->columns.size(); c++) req->columns[c].resizeFor(cap, bytes[c]);
         std::vector<tsq_col> out;
         for (auto& c : req->columns) out.push_back(c.View(cap));
         int64_t n = 0;

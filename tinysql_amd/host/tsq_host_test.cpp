@@ -20,6 +20,7 @@ typedef std::vector<std::string> Rows;
 static std::string cell(const Column& c, int64_t r) {
     if (c.IsNull(r)) return "<nil>";
     char buf[64];
+    if (c.type == TSQ_BYTES) return c.GetString(r);
     switch (c.type) {
         case TSQ_I64: snprintf(buf, sizeof buf, "%lld", (long long)c.GetInt64(r)); break;
         case TSQ_U64: snprintf(buf, sizeof buf, "%llu", (unsigned long long)c.GetUint64(r)); break;
@@ -61,6 +62,22 @@ static Chunk table_i64(int ncols, std::initializer_list<int64_t> cells) {
     for (int64_t v : cells) {
         if (v == NIL) t.columns[c].AppendNull(); else t.columns[c].AppendInt64(v);
         c = (c + 1) % ncols;
+    }
+    return t;
+}
+
+// a table with mixed column types: cells are strings, "NULL" marks a NULL cell; ints / floats are parsed
+static Chunk table_mixed(const Schema& types, std::initializer_list<const char*> cells) {
+    Chunk t(types);
+    size_t c = 0;
+    for (const char* v : cells) {
+        Column& col = t.columns[c];
+        if (!strcmp(v, "NULL")) col.AppendNull();
+        else if (col.type == TSQ_BYTES) col.AppendString(v);
+        else if (col.type == TSQ_F32) col.AppendFloat32((float)atof(v));
+        else if (col.type == TSQ_F64) col.AppendFloat64(atof(v));
+        else col.AppendInt64(atoll(v));
+        c = (c + 1) % types.size();
     }
     return t;
 }
@@ -277,6 +294,61 @@ int main() {
             MockDataSource src(&ctx, n);
             TopNExec top(&ctx, &src, {{0, false}}, 0, UINT64_MAX);
             expect_true("compare.go:48-56 NULLs first; executor_test.go:504 max limit", ordered(Drain(&top)) == Rows{"<nil>", "<nil>", "-7", "0", "3"});
+        }
+    }
+    // ---- strings (varchar columns travel as TSQ_BYTES: offsets + data, util/chunk/column.go:28-34)
+    {
+        {   // join_test.go:184-191: user(id, name) left join aa left join bb where bb.id < 10 -> "1 a"
+            Chunk user = table_mixed({TSQ_I64, TSQ_BYTES}, {"1", "a", "2", "b"}), aa = table_i64(1, {1}), bb = table_i64(1, {1});
+            MockDataSource u(&ctx, user), a(&ctx, aa), b(&ctx, bb);
+            HashJoinExec j1(&ctx, &u, &a, {0}, {0}, LeftOuterJoin, 1);
+            HashJoinExec j2(&ctx, &j1, &b, {2}, {0}, LeftOuterJoin, 1);
+            SelectionExec sel(&ctx, &j2, {Func("lt", {Col(3, TSQ_I64), Int(10)})});
+            expect("join_test.go:184-191 string payload through two outer joins and a filter", render(Drain(&sel)), {"1 a 1 1"});
+        }
+        {   // join_test.go:336-341 TestIssue5255: t1(a int, b varchar, c float) join t2(a) -> "1 2017-11-29 2.2 1"
+            Chunk t1 = table_mixed({TSQ_I64, TSQ_BYTES, TSQ_F32}, {"1", "2017-11-29", "2.2"}), t2 = table_i64(1, {1});
+            for (int inner = 0; inner < 2; inner++) {
+                MockDataSource l(&ctx, t1), r(&ctx, t2);
+                HashJoinExec j(&ctx, &l, &r, {0}, {0}, InnerJoin, inner);
+                expect("join_test.go:336-341 varchar + float payload", render(Drain(&j)), {"1 2017-11-29 2.2 1"});
+            }
+        }
+        {   // join_test.go:325-329: ... where t2.name = 'xxx' (builtinEQStringSig, builtin_compare_vec_generated.go:393)
+            Chunk t2 = table_mixed({TSQ_I64, TSQ_BYTES, TSQ_BYTES}, {"1", "xxx", "2003-06-09 10:51:26", "2", "xxy", "never", "3", "NULL", "never"});
+            MockDataSource src(&ctx, t2);
+            SelectionExec sel(&ctx, &src, {Func("eq", {Col(1, TSQ_BYTES), Str("xxx")})});
+            expect("join_test.go:325-329 filter name = 'xxx'", render(Drain(&sel)), {"1 xxx 2003-06-09 10:51:26"});
+        }
+        {   // string join keys: equal bytes join, NULL never joins, '' is a value (codec.go:233-235, 363-382)
+            Chunk l = table_mixed({TSQ_BYTES, TSQ_I64}, {"ab", "1", "", "2", "NULL", "3", "abc", "4", "ab", "5"});
+            Chunk r = table_mixed({TSQ_BYTES, TSQ_I64}, {"ab", "10", "", "20", "NULL", "30", "b", "40"});
+            MockDataSource ls(&ctx, l), rs(&ctx, r);
+            HashJoinExec j(&ctx, &ls, &rs, {0}, {0}, LeftOuterJoin, 1);
+            expect("string join key, left outer", render(Drain(&j)),
+                   {"ab 1 ab 10", "ab 5 ab 10", " 2  20", "<nil> 3 <nil> <nil>", "abc 4 <nil> <nil>"});
+        }
+        {   // GROUP BY a varchar: firstrow(name), count(*), max / min of a varchar (func_first_row.go:193-230, func_max_min.go:312-378)
+            Chunk t = table_mixed({TSQ_BYTES, TSQ_BYTES, TSQ_I64},
+                                  {"x", "pear", "1", "y", "fig", "2", "x", "apple", "3", "NULL", "kiwi", "4", "x", "NULL", "5", "", "plum", "6", "NULL", "NULL", "7"});
+            MockDataSource src(&ctx, t);
+            HashAggExec agg(&ctx, &src, {0},
+                            {{TSQ_AGG_FIRSTROW, 0, TSQ_BYTES}, {TSQ_AGG_COUNT, -1, TSQ_I64},
+                             {TSQ_AGG_MAX, 1, TSQ_BYTES}, {TSQ_AGG_MIN, 1, TSQ_BYTES},
+                             {TSQ_AGG_SUM, 2, TSQ_I64}});
+            expect("group by varchar: firstrow / count / max / min of strings", render(Drain(&agg)),
+                   {"x 3 pear apple 9", "y 1 fig fig 2", "<nil> 2 kiwi kiwi 11", " 1 plum plum 6"});
+        }
+        {   // func_max_min_test.go:31,37,50,56: max / min of "0".."4" without GROUP BY; empty input -> NULL (aggregate.go:572-574)
+            Chunk t = table_mixed({TSQ_BYTES}, {"0", "1", "2", "3", "4", "NULL"});
+            MockDataSource src(&ctx, t);
+            HashAggExec agg(&ctx, &src, {}, {{TSQ_AGG_MAX, 0, TSQ_BYTES}, {TSQ_AGG_MIN, 0, TSQ_BYTES},
+                                             {TSQ_AGG_COUNT, 0, TSQ_BYTES}});
+            expect("func_max_min_test.go:31,37 max/min of strings", render(Drain(&agg)), {"4 0 5"});
+            Chunk none(Schema{TSQ_BYTES});
+            MockDataSource empty(&ctx, none);
+            HashAggExec agg0(&ctx, &empty, {}, {{TSQ_AGG_MAX, 0, TSQ_BYTES}, {TSQ_AGG_COUNT, 0, TSQ_BYTES}});
+            expect("aggregate.go:572-574 empty input: max(string) NULL, count 0", render(Drain(&agg0)), {"<nil> 0"});
         }
     }
     printf("%d passed, %d failed\n", g_pass, g_fail);
