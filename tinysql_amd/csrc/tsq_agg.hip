@@ -979,9 +979,10 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         src.exc_rows = la.exc_rows;
         src.exc_count = la.exc_count;
         const int pgrid = (int)std::min<int64_t>((nrows + T - 1) / T, ctx->num_cus);
-        if (pl.V == 0) hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, 0, false>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
-        else if (pl.V == 1) hipLaunchKernelGGL((k_radix_partition<1024, 8, 4, 1, false>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
-        else hipLaunchKernelGGL((k_radix_partition<1024, 4, 4, 2, false>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
+        // HASHED: the store receives table words mix64(group key word) — see tsq_aggfast.h
+        if (pl.V == 0) hipLaunchKernelGGL((k_radix_partition<1024, 16, 4, 0, false, true>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
+        else if (pl.V == 1) hipLaunchKernelGGL((k_radix_partition<1024, 8, 4, 1, false, true>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
+        else hipLaunchKernelGGL((k_radix_partition<1024, 4, 4, 2, false, true>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, st);
         TSQ_HIP(h, hipGetLastError());
         a->st.kernel_launches++;
         la.st = st;
@@ -1208,6 +1209,7 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
             fp.W += words;
         }
         if (fp.W == 0) ok = false;
+        if (ok) af_fill_wdesc(fp);
         a->fast_ok = ok;
     }
     TSQ_HIP(ch, hipSetDevice(ctx->device));

@@ -11,6 +11,10 @@
 //     table and emits its partial groups (PartialResult rows);
 //   H (up to ~2 M groups): rows are radix partitioned by the group-key hash (tsq_radix.h, payload =
 //     the argument cells), then ONE workgroup aggregates one partition whose groups fit its LDS table;
+//     the partitioned store holds TABLE WORDS w = mix64(key word) (the HASHED store of the join): the one
+//     hash a row pays selects its partition (top bits) and its LDS slot (low bits), and w identifies the
+//     group as well as the key does (mix64 is a bijection; the key comes back with tsq_unmix64 when a
+//     partial group is emitted);
 //   the partial groups are merged into the HBM group table by k_agg_merge (= the final workers'
 //     consumeIntermData + MergePartialResult, aggfuncs/*.go).
 // Rows the LDS stage cannot take (NULL key or NULL argument cell, table full, sentinel key) are handed
@@ -36,7 +40,44 @@ struct AfPlan {
     int32_t key_col, key_type;
     int32_t vcol[TSQ_RADIX_MAXV], vtype[TSQ_RADIX_MAXV];
     unsigned long long init[TSQ_AF_MAXW];  // initial value of every word (MIN starts at all ones)
+    // what a row does to LDS word k, decoded once per kernel instead of walking f[] for every row: bits 0-2 = AF_W_* kind,
+    // bit 3 = which argument cell, bits 4-5 = the cell's TSQ_* type (tsq_agg_create fills it from f[])
+    uint32_t wdesc[TSQ_AF_MAXW];
 };
+enum { AF_W_ADD1 = 0, AF_W_ADD_REAL = 1, AF_W_ADD_LO32 = 2, AF_W_ADD_HI32 = 3, AF_W_MAX = 4, AF_W_MIN = 5 };
+inline uint32_t af_wdesc(int kind, int v, int type) { return (uint32_t)kind | ((uint32_t)(v > 0 ? 1 : 0) << 3) | ((uint32_t)type << 4); }
+// fills wdesc[] from f[] (host side, after W / V / f[].w / f[].v are known)
+inline void af_fill_wdesc(AfPlan& p) {
+    for (int k = 0; k < TSQ_AF_MAXW; k++) p.wdesc[k] = 0;
+    for (int i = 0; i < p.n_aggs; i++) {
+        const AfAgg& f = p.f[i];
+        if (f.w < 0) continue;
+        const bool real = f.type == TSQ_F32 || f.type == TSQ_F64;
+        switch (f.func) {
+            case TSQ_AGG_COUNT: p.wdesc[f.w] = af_wdesc(AF_W_ADD1, 0, 0); break;
+            case TSQ_AGG_SUM:
+            case TSQ_AGG_AVG: {
+                int w = f.w;
+                if (real) p.wdesc[w++] = af_wdesc(AF_W_ADD_REAL, f.v, f.type);
+                else {
+                    p.wdesc[w++] = af_wdesc(AF_W_ADD_LO32, f.v, f.type);
+                    p.wdesc[w++] = af_wdesc(AF_W_ADD_HI32, f.v, f.type);
+                }
+                if (f.func == TSQ_AGG_AVG) p.wdesc[w] = af_wdesc(AF_W_ADD1, 0, 0);
+                break;
+            }
+            case TSQ_AGG_MAX: p.wdesc[f.w] = af_wdesc(AF_W_MAX, f.v, f.type); break;
+            case TSQ_AGG_MIN: p.wdesc[f.w] = af_wdesc(AF_W_MIN, f.v, f.type); break;
+        }
+    }
+}
+// slot of a key word inside an LDS table of 2^log2s slots (L mode: the rows come straight from the input columns).  Not mix64:
+// its two 64-bit multiplies are eight quarter-rate v_mul_lo/hi_u32; a 32-bit multiplicative hash (top bits) is enough for a table
+// that is at most half full.
+__device__ __forceinline__ uint32_t af_slot_hash(uint64_t tag, uint32_t log2s) {
+    const uint32_t lo = (uint32_t)tag, hi = (uint32_t)(tag >> 32);
+    return ((lo ^ (hi * 0x85EBCA6Bu)) * 0x9E3779B1u) >> (32u - log2s);
+}
 struct AfPartials {  // partial groups in HBM, structure of arrays
     unsigned long long* key;
     unsigned long long* w[TSQ_AF_MAXW];
@@ -100,7 +141,11 @@ struct AfLdsArgs {
 // K7a — LDS pre-aggregation (updatePartialResult of one partial worker, aggregate.go:332-350, into LDS).
 template <int MODE, int W>
 __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
-    constexpr uint32_t S = W <= 3 ? 4096u : 2048u;
+    constexpr uint32_t S = W <= 3 ? 4096u : 2048u, LOG2S = W <= 3 ? 12u : 11u;
+    constexpr bool HASHED_TAGS = MODE != 0;  // MODE 1 / 2 read a HASHED store: tags are table words
+    uint32_t wd[W];  // wave uniform: what a row adds to each word
+#pragma unroll
+    for (int k = 0; k < W; k++) wd[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.plan.wdesc[k]);
     __shared__ unsigned long long s_key[S];
     __shared__ unsigned long long s_w[W][S];
     __shared__ uint32_t s_used;
@@ -118,7 +163,7 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
         af_row_words(a.plan, cells, w);
         const uint32_t o = __hip_atomic_fetch_add(a.out.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (o < a.out.cap) {
-            a.out.key[o] = tag;
+            a.out.key[o] = HASHED_TAGS ? tsq_unmix64(tag) : tag;
 #pragma unroll
             for (int k = 0; k < W; k++) a.out.w[k][o] = w[k];
         }
@@ -129,7 +174,7 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
             spill(tag, cells);
             return;
         }
-        uint32_t slot = (uint32_t)tsq_mix64(tag) & (S - 1);
+        uint32_t slot = HASHED_TAGS ? ((uint32_t)tag & (S - 1)) : af_slot_hash(tag, LOG2S);
         bool found = false;
         for (int probe = 0; probe < 64 && !found; probe++) {
             unsigned long long cur = s_key[slot];
@@ -150,29 +195,21 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
             spill(tag, cells);
             return;
         }
-        for (int i = 0; i < a.plan.n_aggs; i++) {
-            const AfAgg f = a.plan.f[i];
-            if (f.w < 0) continue;
-            const uint64_t cell = f.v == 1 ? c1 : c0;
-            switch (f.func) {
-                case TSQ_AGG_COUNT: atomicAdd(&s_w[f.w][slot], 1ull); break;
-                case TSQ_AGG_SUM:
-                case TSQ_AGG_AVG:
-                    if (af_is_real(f.type)) {
-                        atomicAdd(reinterpret_cast<double*>(&s_w[f.w][slot]), af_real(cell, f.type));
-                        if (f.func == TSQ_AGG_AVG) atomicAdd(&s_w[f.w + 1][slot], 1ull);
-                    } else {
-                        // exact sum without returning atomics: the low and the (signed) high 32-bit halves are summed
-                        // separately in 64 bits — neither can overflow in < 2^31 rows — and recombined into the
-                        // 128-bit (lo, hi) pair when the group is emitted (func_sum.go:133-137 is exact in 128 bits)
-                        const unsigned long long uv = cell;
-                        atomicAdd(&s_w[f.w][slot], uv & 0xffffffffull);
-                        atomicAdd(&s_w[f.w + 1][slot], (unsigned long long)((long long)uv >> 32));
-                        if (f.func == TSQ_AGG_AVG) atomicAdd(&s_w[f.w + 2][slot], 1ull);
-                    }
-                    break;
-                case TSQ_AGG_MAX: atomicMax(&s_w[f.w][slot], (unsigned long long)af_ord_image(cell, f.type)); break;
-                case TSQ_AGG_MIN: atomicMin(&s_w[f.w][slot], (unsigned long long)af_ord_image(cell, f.type)); break;
+        // one non-returning LDS atomic per word.  int64 sums: the low and the (signed) high 32-bit halves are summed separately in
+        // 64 bits — neither can overflow in < 2^31 rows — and recombined into the 128-bit (lo, hi) pair when the group is emitted
+        // (func_sum.go:133-137 is exact in 128 bits)
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const uint32_t d = wd[k];
+            const uint64_t cell = (d & 8u) ? c1 : c0;
+            const int32_t type = (int32_t)(d >> 4);
+            switch (d & 7u) {
+                case AF_W_ADD1: atomicAdd(&s_w[k][slot], 1ull); break;
+                case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(&s_w[k][slot]), af_real(cell, type)); break;
+                case AF_W_ADD_LO32: atomicAdd(&s_w[k][slot], (unsigned long long)(cell & 0xffffffffull)); break;
+                case AF_W_ADD_HI32: atomicAdd(&s_w[k][slot], (unsigned long long)((long long)cell >> 32)); break;
+                case AF_W_MAX: atomicMax(&s_w[k][slot], (unsigned long long)af_ord_image(cell, type)); break;
+                default: atomicMin(&s_w[k][slot], (unsigned long long)af_ord_image(cell, type)); break;
             }
         }
     };
@@ -272,7 +309,7 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
         __syncthreads();  // s_wsum is reused by the next pass
         if (occ) {
             if (o < a.out.cap) {
-                a.out.key[o] = key;
+                a.out.key[o] = HASHED_TAGS ? tsq_unmix64(key) : key;
                 unsigned long long w[W];
 #pragma unroll
                 for (int k = 0; k < W; k++) w[k] = s_w[k][i];

@@ -35,6 +35,15 @@ struct JoinTable {
 
 // the word a key word is stored and compared as
 TSQ_HD uint64_t tsq_table_word(uint64_t kw) { return tsq_mix64(kw); }
+// inverse of tsq_mix64 (murmur3 finaliser): the key word of a table word
+TSQ_HD uint64_t tsq_unmix64(uint64_t w) {
+    w ^= w >> 33;
+    w *= 0x9CB4B2F8129337DBULL;  // inverse of 0xC4CEB9FE1A85EC53 mod 2^64
+    w ^= w >> 33;
+    w *= 0x4F74430C22A54005ULL;  // inverse of 0xFF51AFD7ED558CCD mod 2^64
+    w ^= w >> 33;
+    return w;
+}
 TSQ_HD uint32_t jt_slice(uint32_t tb, uint64_t w) { return tb ? (uint32_t)(w >> (64 - tb)) : 0u; }
 TSQ_HD uint32_t jt_local(uint32_t tb, uint32_t bs, uint64_t w) {
     const uint32_t x = (uint32_t)((w << tb) >> 32);

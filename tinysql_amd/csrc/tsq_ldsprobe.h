@@ -96,16 +96,6 @@ struct LdsProbeArgs {
     unsigned long long* ovf_cursor;        // k_lds_emit_ovf: next output row of the overflow list's joined rows
 };
 
-// inverse of tsq_mix64 (murmur3 finaliser): the key word of a table word
-__device__ __forceinline__ uint64_t tsq_unmix64(uint64_t w) {
-    w ^= w >> 33;
-    w *= 0x9CB4B2F8129337DBULL;  // inverse of 0xC4CEB9FE1A85EC53 mod 2^64
-    w ^= w >> 33;
-    w *= 0x4F74430C22A54005ULL;  // inverse of 0xFF51AFD7ED558CCD mod 2^64
-    w ^= w >> 33;
-    return w;
-}
-
 // Vector-memory results return in order and s_waitcnt counts them, so every wave issues a FIXED sequence of loads: a load
 // that has nothing to fetch (past the end of a region, past the last chunk) is still issued, on a clamped address, and its
 // result is ignored.  With loads under a branch the compiler can only wait for "everything" (vmcnt(0)), which serialises

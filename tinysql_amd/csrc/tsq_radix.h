@@ -160,12 +160,14 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
         for (uint32_t p = tid; p < P; p += NT) s_hist[p] = 0;
         const bool full = wide && n == (uint32_t)T;
         if (full) {
+            // every load of the tile first, the hashing afterwards: with tsq_table_word() written next to its load the compiler
+            // waited for each 16-byte load before it issued the next one (K / 2 serial HBM round trips per tile)
             const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>((const uint64_t*)src.data + base);
 #pragma unroll
             for (int j = 0; j < K / 2; j++) {
                 const ulonglong2 v = s2[j * NT + tid];
-                k[2 * j] = HASHED ? tsq_table_word(v.x) : v.x;
-                k[2 * j + 1] = HASHED ? tsq_table_word(v.y) : v.y;
+                k[2 * j] = v.x;
+                k[2 * j + 1] = v.y;
             }
 #pragma unroll
             for (int vv = 0; vv < V; vv++) {
@@ -176,6 +178,11 @@ __global__ void __launch_bounds__(NT, MINW) k_radix_partition(RadixSrc src, Radi
                     pay[vv][2 * j] = v.x;
                     pay[vv][2 * j + 1] = v.y;
                 }
+            }
+            if (HASHED) {
+                __builtin_amdgcn_sched_barrier(0);  // nothing moves across: the loads above stay ahead of the multiplies below
+#pragma unroll
+                for (int j = 0; j < K; j++) k[j] = tsq_table_word(k[j]);
             }
         } else {
 #pragma unroll
