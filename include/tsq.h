@@ -473,6 +473,22 @@ tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_by
 tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, const uint32_t* col_flags, int64_t nrows,
                            uint8_t* out, int64_t cap_bytes, uint32_t out_flags, int64_t* row_offsets, int64_t* bytes_out);
 
+/* ---------------------------------------------------------------- record keys of a table scan <-> handles (SURVEY.md §8 f, rank 4)
+ * Replaces tablecodec.DecodeRowKey (tablecodec/tablecodec.go:235-242; DecodeRecordKey :73-77 hands the table id back as well),
+ * called once per scanned KV pair by mocktikv's tableScanExec (store/mockstore/mocktikv/executor.go:124-196) before
+ * rd.DecodeToBytes — handles_out[] is the `handles` argument of tsq_rowcodec_decode — and EncodeRowKeyWithHandle (:65-70).
+ *     record key = 't' | EncodeInt(tableID) | "_r" | EncodeInt(handle)           RecordRowKeyLen = 19 bytes
+ * `keys` holds the keys back to back: key r = bytes [key_offsets[r], key_offsets[r+1]) (n_keys+1 non-decreasing entries), or
+ * bytes [19 r, 19 r + 19) when key_offsets is NULL (then n_bytes = 19 * n_keys).  data_flags: TSQ_COL_DEVICE when keys /
+ * key_offsets / the outputs are in HBM.  table_ids_out may be NULL.  The FIRST key in scan order that is not a record key
+ * (length != 19, no 't' prefix, no "_r" separator) decides: TSQ_ERR_INVALID with tsq_last_error = "invalid key"
+ * (errInvalidKey, tablecodec.go:237), *nkeys_out = the keys before it (their handles are out). */
+tsq_status tsq_rowkeys_decode(tsq_ctx* ctx, const uint8_t* keys, int64_t n_bytes, const int64_t* key_offsets, int64_t n_keys,
+                              uint32_t data_flags, int64_t* handles_out, int64_t* table_ids_out, int64_t* nkeys_out);
+/* keys_out: 19 * n_keys bytes, key r = EncodeRowKeyWithHandle(table_id, handles[r]) */
+tsq_status tsq_rowkeys_encode(tsq_ctx* ctx, int64_t table_id, const int64_t* handles, int64_t n_keys, uint32_t data_flags,
+                              uint8_t* keys_out);
+
 /* ---------------------------------------------------------------- ORDER BY / TopN (SURVEY.md §8 f, rank 3)
  * Replaces SortExec (executor/sort.go:27-144) and TopNExec (sort.go:146-318): all child rows are pushed, tsq_sort_finish
  * orders them by the ByItems — bare columns (sort.go:107-113), each ascending or descending, compared like

@@ -97,6 +97,16 @@ def load():
     lib.orc_rowcodec_to_old_bytes.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, P, C.c_int64]
     lib.orc_rowcodec_column_is_null.restype = C.c_int32
     lib.orc_rowcodec_column_is_null.argtypes = [P, C.c_int64, C.c_int64, C.c_int32]
+    lib.orc_encode_row_key.restype = None
+    lib.orc_encode_row_key.argtypes = [C.c_int64, C.c_int64, P]
+    lib.orc_decode_row_key.restype = C.c_int32
+    lib.orc_decode_row_key.argtypes = [P, C.c_int64, C.POINTER(C.c_int64)]
+    lib.orc_decode_key_head.restype = C.c_int32
+    lib.orc_decode_key_head.argtypes = [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.orc_decode_record_key.restype = C.c_int32
+    lib.orc_decode_record_key.argtypes = [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.orc_cop_hash_agg.restype = P
+    lib.orc_cop_hash_agg.argtypes = [C.POINTER(abi.AggCfg), C.POINTER(abi.Col), C.c_int64, C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 
@@ -429,3 +439,52 @@ def rowcodec_column_is_null(row, col_id, has_default=False):
     lib = load()
     row = np.ascontiguousarray(row, dtype=np.uint8)
     return lib.orc_rowcodec_column_is_null(row.ctypes.data_as(C.c_void_p), row.size, col_id, 1 if has_default else 0)
+
+
+# ---- tablecodec record keys + the storage side's datum-level aggregate (mocktikv.cpp)
+def encode_row_key(table_id, handle):
+    """tablecodec.EncodeRowKeyWithHandle"""
+    out = (C.c_uint8 * 19)()
+    load().orc_encode_row_key(table_id, handle, out)
+    return bytes(out)
+
+
+def decode_row_key(key):
+    """tablecodec.DecodeRowKey -> handle, or raises ValueError('invalid key')"""
+    h = C.c_int64(0)
+    buf = (C.c_uint8 * max(len(key), 1)).from_buffer_copy(bytes(key) or b"\0")
+    if load().orc_decode_row_key(buf, len(key), C.byref(h)) != 0:
+        raise ValueError("invalid key")
+    return h.value
+
+
+def decode_key_head(key):
+    """tablecodec.DecodeKeyHead -> (tableID, indexID, isRecordKey) or raises ValueError"""
+    t, i, r = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    buf = (C.c_uint8 * max(len(key), 1)).from_buffer_copy(bytes(key) or b"\0")
+    st = load().orc_decode_key_head(buf, len(key), C.byref(t), C.byref(i), C.byref(r))
+    if st != 0:
+        raise ValueError("invalid key" if st == 1 else "insufficient bytes to decode value")
+    return t.value, i.value, bool(r.value)
+
+
+def decode_record_key(key):
+    """tablecodec.DecodeRecordKey -> (tableID, handle) or raises ValueError"""
+    t, h = C.c_int64(0), C.c_int64(0)
+    buf = (C.c_uint8 * max(len(key), 1)).from_buffer_copy(bytes(key) or b"\0")
+    st = load().orc_decode_record_key(buf, len(key), C.byref(t), C.byref(h))
+    if st != 0:
+        raise ValueError("invalid key" if st == 1 else "insufficient bytes to decode value")
+    return t.value, h.value
+
+
+def cop_hash_agg(cfg, chunk):
+    """mocktikv hashAggExec over the rows of `chunk` in scan order: partial results + group-by values, first-seen group order."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    st = C.c_int32(0)
+    res = lib.orc_cop_hash_agg(C.byref(cfg), cols, chunk.NumRows(), C.byref(st))
+    if not res:
+        raise OracleError(st.value)
+    return _result_to_chunk(lib, res)

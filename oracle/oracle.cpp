@@ -179,30 +179,9 @@ struct RowHashMap {
     }
 };
 
-// ------------------------------------------------------------------ result set
-struct OutCol {
-    int32_t type = TSQ_I64;
-    std::vector<uint64_t> v;  // raw 64-bit (F32 stored in low 32 bits); TSQ_BYTES: the END offset of the cell in `bytes`
-    std::vector<uint8_t> notnull;
-    std::string bytes;        // TSQ_BYTES: concatenated data (util/chunk/column.go:28-34: a NULL cell has no bytes)
-    void append_raw(uint64_t bits, bool nn) {
-        if (type == TSQ_BYTES) bits = bytes.size();  // AppendNull on a var-len column repeats the last offset
-        v.push_back(nn || type == TSQ_BYTES ? bits : 0);
-        notnull.push_back(nn ? 1 : 0);
-    }
-    void append_bytes(const void* p, size_t n) {  // Column.AppendBytes (column.go:207-211)
-        bytes.append((const char*)p, n);
-        v.push_back(bytes.size());
-        notnull.push_back(1);
-    }
-};
-
 }  // namespace
 
-struct orc_result {
-    std::vector<OutCol> cols;
-    int64_t rows = 0;
-};
+#include "orc_result_internal.h"  // OutCol, orc_result (shared with mocktikv.cpp)
 
 namespace {
 
@@ -889,6 +868,8 @@ void append_cell(OutCol& oc, const tsq_col& c, int64_t row) {
 }
 
 }  // namespace
+
+void orc_set_error(const std::string& msg) { g_err = msg; }
 
 extern "C" {
 

@@ -129,6 +129,14 @@ int32_t orc_rowcodec_column_is_null(const uint8_t* row_data, int64_t len, int64_
 int32_t orc_row_compare(const tsq_col* cols, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t i, int64_t j);
 void    orc_sort_rows(const tsq_col* cols, int64_t nrows, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t* perm_out);
 
+/* ---- tablecodec record keys + the storage side's datum-level aggregate (mocktikv.cpp; SURVEY.md §8 f rank 4) */
+void    orc_encode_row_key(int64_t table_id, int64_t handle, uint8_t* out19);                       /* EncodeRowKeyWithHandle, tablecodec.go:65-70 */
+int32_t orc_decode_row_key(const uint8_t* key, int64_t len, int64_t* handle);                       /* DecodeRowKey, :235-242 */
+int32_t orc_decode_key_head(const uint8_t* key, int64_t len, int64_t* table_id, int64_t* index_id, int32_t* is_record);  /* DecodeKeyHead, :188-220 */
+int32_t orc_decode_record_key(const uint8_t* key, int64_t len, int64_t* table_id, int64_t* handle); /* DecodeRecordKey, :73-77 (stub filled) */
+/* hashAggExec (store/mockstore/mocktikv/aggregate.go:78-182) with expression/aggregation's functions, row at a time in scan order */
+orc_result* orc_cop_hash_agg(const tsq_agg_cfg* cfg, const tsq_col* cols, int64_t nrows, tsq_status* status);
+
 #ifdef __cplusplus
 }
 #endif

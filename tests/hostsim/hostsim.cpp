@@ -371,3 +371,94 @@ extern "C" int64_t sim_rows_encode(const tsq_col* cols, int32_t n_cols, uint32_t
     }
     return (int64_t)run;
 }
+
+// ---- record keys <-> handles (tsq_tablecodec_dp.h): a CPU walk-through of k_rowkeys_decode / k_rowkeys_encode (tsq_tablecodec.hip) with the
+// same tile plans: the staged copy of 1024 keys as aligned 16-byte vectors (bytes outside `keys` and stale tile bytes are garbage), the word +
+// funnel reader, and the encoder's LDS image at the skew of its destination with head / body / tail copy-out.
+#include "../../tinysql_amd/csrc/tsq_tablecodec_dp.h"
+extern "C" uint64_t sim_rowkeys_decode(const uint8_t* keys, int64_t n_bytes, uint64_t base_addr, const int64_t* offsets, int64_t n, int64_t* handles,
+                                       int64_t* table_ids, int64_t* staged_tiles) {
+    const int NT = 256, KPL = 4, TILE = NT * KPL;
+    const uint32_t LDS = TILE * 19 + 64;
+    uint64_t err = ~0ull;
+    std::vector<uint8_t> tile((LDS / 16 + 1) * 16);
+    *staged_tiles = 0;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t t = 0; t < n_tiles; t++) {
+        const int64_t r0 = t * TILE, r1 = r0 + TILE < n ? r0 + TILE : n;
+        const int64_t tile_lo = offsets ? offsets[r0] : r0 * 19, tile_hi = offsets ? offsets[r1] : r1 * 19;
+        const tsq_rc_plan plan = tsq_rc_tile_plan(base_addr, tile_lo, tile_hi, n_bytes, LDS - 32);
+        memset(tile.data(), 0xA5, tile.size());
+        if (plan.staged) {
+            (*staged_tiles)++;
+            if ((size_t)plan.n_vec * 16 > tile.size()) return 0xBAD0;  // the kernel's LDS array would be overrun
+            for (uint32_t i = 0; i < plan.n_vec * 16u; i++) {
+                const int64_t at = plan.copy_from + (int64_t)i;
+                tile[i] = (at >= 0 && at < n_bytes) ? keys[at] : (uint8_t)0x5A;
+            }
+        }
+        for (int k = 0; k < KPL; k++)
+            for (int tid = 0; tid < NT; tid++) {
+                const int64_t r = r0 + (int64_t)k * NT + tid;
+                if (r >= r1) continue;
+                const int64_t lo = offsets ? offsets[r] : r * 19, hi = offsets ? offsets[r + 1] : lo + 19;
+                int code;
+                int64_t table_id = 0, handle = 0;
+                if (lo < tile_lo || hi < lo || hi > tile_hi || lo < 0 || hi > n_bytes) {
+                    code = TC_INVALID_KEY;
+                } else if (plan.staged) {
+                    SimWords rd;
+                    rd.w = (const uint32_t*)tile.data();
+                    rd.base = plan.skew + (uint32_t)(lo - tile_lo);
+                    if ((size_t)rd.base + 19 + 12 > tile.size()) return 0xBAD1;  // a word read past the LDS array
+                    code = tsq_tc_decode_row_key(rd, (uint32_t)(hi - lo > 0xffff ? 0xffff : hi - lo), &table_id, &handle);
+                } else {
+                    SimBytes rd;
+                    rd.p = keys + lo;
+                    code = tsq_tc_decode_row_key(rd, (uint32_t)(hi - lo > 0xffff ? 0xffff : hi - lo), &table_id, &handle);
+                }
+                handles[r] = handle;
+                if (table_ids) table_ids[r] = table_id;
+                if (code != TC_OK) {
+                    const uint64_t e = ((uint64_t)r << 4) | (uint64_t)code;
+                    if (e < err) err = e;
+                }
+            }
+    }
+    return err;
+}
+// `out` is indexed from the start of the key array; out_phase = the low bits of its device address
+extern "C" int32_t sim_rowkeys_encode(int64_t table_id, const int64_t* handles, int64_t n, uint8_t* out, uint32_t out_phase) {
+    const int NT = 256, KPL = 4, TILE = NT * KPL;
+    const uint32_t LDS = TILE * 19 + 64;
+    std::vector<uint8_t> img((LDS / 16 + 1) * 16);
+    const uint64_t out_addr = 0x7f0000004000ULL + out_phase;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t t = 0; t < n_tiles; t++) {
+        const int64_t r0 = t * TILE, r1 = r0 + TILE < n ? r0 + TILE : n;
+        const int64_t base = r0 * 19;
+        const uint32_t T = (uint32_t)(r1 - r0) * 19u;
+        const tsq_enc_copy plan = tsq_enc_copy_plan(out_addr, base, T);
+        if ((size_t)plan.skew + T > img.size()) return -1;
+        memset(img.data(), 0xA5, img.size());
+        for (int k = 0; k < KPL; k++)
+            for (int tid = 0; tid < NT; tid++) {
+                const int64_t r = r0 + (int64_t)k * NT + tid;
+                if (r >= r1) continue;
+                uint64_t p0, p1;
+                uint32_t p2;
+                tsq_tc_encode_row_key(table_id, handles[r], &p0, &p1, &p2);
+                const uint32_t pos = plan.skew + (uint32_t)(r - r0) * 19u;
+                for (uint32_t i = 0; i < 8; i++) img[pos + i] = (uint8_t)(p0 >> (8 * i));
+                for (uint32_t i = 0; i < 8; i++) img[pos + 8 + i] = (uint8_t)(p1 >> (8 * i));
+                for (uint32_t i = 0; i < 3; i++) img[pos + 16 + i] = (uint8_t)(p2 >> (8 * i));
+            }
+        uint8_t* g = out + base - plan.skew;
+        for (uint32_t tid = 0; tid < 16; tid++)
+            if (plan.skew + tid < plan.head_end) g[plan.skew + tid] = img[plan.skew + tid];
+        for (uint32_t tid = 16; tid < 32; tid++)
+            if (plan.tail_lo + (tid - 16) < plan.tail_end) g[plan.tail_lo + (tid - 16)] = img[plan.tail_lo + (tid - 16)];
+        for (uint32_t i = plan.body_lo; i < plan.body_hi; i++) memcpy(g + 16 * (size_t)i, img.data() + 16 * (size_t)i, 16);
+    }
+    return 0;
+}

@@ -1,0 +1,103 @@
+"""CPU: pins oracle/mocktikv.cpp — the restatement of tablecodec's record keys and of the storage side's datum-level aggregate —
+on the reference's own tests: tablecodec/tablecodec_test.go (TestTableCodec :42-53, TestRecordKey :111-135, TestPrefix :138-160,
+TestReplaceRecordKeyTableID :163-188) and expression/aggregation/aggregation_test.go (TestAvg :60-84, TestSum :114-140, TestCount
+:142-168, TestFirstRow :170-195, TestMaxMin :197-259), plus the executor's own contract (mocktikv/aggregate.go:78-182: partial
+results then group-by values, groups in first-seen order, the first row of the scan for FIRST_ROW)."""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from tests import helpers as H
+from tinysql_amd import _abi as abi
+from tinysql_amd.chunk import Chunk, Column
+
+MAX_U32 = (1 << 32) - 1
+
+
+def test_table_codec_round_trip_of_the_reference():
+    # TestTableCodec: EncodeRowKey(1, EncodeInt(nil, 2)) == EncodeRowKeyWithHandle(1, 2); DecodeRowKey gives 2 back
+    key = orc.encode_row_key(1, 2)
+    assert key == b"t" + bytes([0x80, 0, 0, 0, 0, 0, 0, 1]) + b"_r" + bytes([0x80, 0, 0, 0, 0, 0, 0, 2])  # EncodeInt = big-endian v ^ signMask
+    assert len(key) == 19  # RecordRowKeyLen
+    assert orc.decode_row_key(key) == 2
+
+
+def test_record_key_of_the_reference():
+    # TestRecordKey: table 55, handle math.MaxUint32
+    key = orc.encode_row_key(55, MAX_U32)
+    assert orc.decode_key_head(key) == (55, 0, True)
+    assert orc.decode_record_key(key) == (55, MAX_U32)
+    with pytest.raises(ValueError):
+        orc.decode_record_key(b"")
+    with pytest.raises(ValueError):
+        orc.decode_record_key(b"abcdefghijklmnopqrstuvwxyz")
+    with pytest.raises(ValueError):
+        orc.decode_row_key(b"abcdefghijklmnopqrs")  # 19 bytes, no 't' prefix
+
+
+def test_key_heads_and_replaced_table_ids():
+    # TestPrefix: an index prefix is not a record key; TestReplaceRecordKeyTableID: ids 1, 2, 3 and -1 read back
+    index_prefix = b"t" + orc.encode_row_key(66, 0)[1:9] + b"_i" + orc.encode_row_key(MAX_U32, 0)[1:9]
+    assert orc.decode_key_head(index_prefix) == (66, MAX_U32, False)
+    for tid in (1, 2, 3, -1, (1 << 63) - 1, -(1 << 63)):
+        assert orc.decode_key_head(orc.encode_row_key(tid, 1)) == (tid, 0, True)
+    with pytest.raises(ValueError):
+        orc.decode_key_head(b"t" + bytes(8) + b"_x")
+    # keys order like their (table, handle) pairs: EncodeInt is memcomparable (TestRange's premise)
+    pairs = [(22, -5), (22, 0), (22, 7), (23, -(1 << 63)), (23, (1 << 63) - 1)]
+    keys = [orc.encode_row_key(t, h) for t, h in pairs]
+    assert keys == sorted(keys)
+    for (t, h), k in zip(pairs, keys):
+        assert orc.decode_record_key(k) == (t, h)
+
+
+def _one_col(vals):
+    return H.chunk_from_rows([[v] for v in vals], [abi.I64])
+
+
+def _agg(chunk, funcs, group=()):
+    aggs = [(f, c, chunk.columns[c].tp if c >= 0 else abi.I64) for f, c in funcs]
+    cfg = H.agg_cfg(chunk.types(), list(group), aggs)
+    return [list(r) for r in orc.cop_hash_agg(cfg, chunk).rows()]
+
+
+def test_aggregation_functions_of_the_reference():
+    rows = [i for i in range(1, 101) for _ in range(i)]  # generateRowData: i repeated i times, 5050 rows
+    chunk = _one_col(rows + [None])                       # ... then s.nullRow
+    out = _agg(chunk, [(abi.AGG_AVG, 0), (abi.AGG_SUM, 0), (abi.AGG_COUNT, 0), (abi.AGG_FIRSTROW, 0), (abi.AGG_MAX, 0), (abi.AGG_MIN, 0)])
+    # TestAvg: 338350 / 5050 = 67 (integer division, from the partial [count, sum]); TestSum 338350; TestCount 5050
+    assert out == [[5050, 338350, 338350, 5050, 1, 100, 1]]
+    assert out[0][1] // out[0][0] == 67
+    # TestFirstRow: rows 1 then 2 -> 1; TestMaxMin: 2, 3, 1, NULL -> max 3, min 1
+    assert _agg(_one_col([1, 2]), [(abi.AGG_FIRSTROW, 0)]) == [[1]]
+    assert _agg(_one_col([2, 3, 1, None]), [(abi.AGG_MAX, 0), (abi.AGG_MIN, 0)]) == [[3, 1]]
+    # before any row: no group, no output (hashAggExec.Next returns nil for an empty scan, aggregate.go:96-98)
+    assert _agg(_one_col([]), [(abi.AGG_COUNT, 0)]) == []
+    # only NULLs: SUM / MAX / MIN stay NULL, COUNT 0 (GetResult of a fresh context, TestSum / TestMaxMin / TestCount)
+    assert _agg(_one_col([None, None]), [(abi.AGG_SUM, 0), (abi.AGG_MAX, 0), (abi.AGG_COUNT, 0), (abi.AGG_AVG, 0)]) == [[None, None, 0, 0, None]]
+
+
+def test_groups_in_first_seen_order_with_the_first_row_of_the_scan():
+    chunk = H.chunk_from_rows([[7, 1.5, 10], [3, 2.5, 20], [7, -1.0, 30], [None, 4.0, 40], [3, None, 50], [None, 1.0, 60]], [abi.I64, abi.F64, abi.I64])
+    out = _agg(chunk, [(abi.AGG_COUNT, -1), (abi.AGG_SUM, 1), (abi.AGG_FIRSTROW, 2), (abi.AGG_AVG, 2)], group=[0])
+    # [count(*), sum(f), first_row(c2), avg: count, sum, group key]
+    assert out == [[2, 0.5, 10, 2, 40, 7], [2, 2.5, 20, 2, 70, 3], [2, 5.0, 40, 2, 100, None]]
+
+
+def test_unsigned_and_float32_arguments_become_int64_and_float64_datums():
+    big = np.array([5, 9], dtype=np.uint64)
+    chunk = Chunk([Column(abi.U64, big, None), Column(abi.F32, np.array([0.5, 0.25], dtype=np.float32), None)])
+    assert _agg(chunk, [(abi.AGG_SUM, 0), (abi.AGG_MAX, 0), (abi.AGG_SUM, 1), (abi.AGG_MIN, 1)]) == [[14, 9, 0.75, 0.25]]
+
+
+def test_running_sum_overflow_is_an_error():
+    # calculateSum -> ComputePlus -> AddInt64 (types/overflow.go:33-40): the RUNNING sum decides, the row order matters
+    m = (1 << 63) - 1
+    with pytest.raises(orc.OracleError) as e:
+        _agg(_one_col([m, 1, -5]), [(abi.AGG_SUM, 0)])
+    assert e.value.status == abi.ERR_OVERFLOW_BIGINT
+    assert _agg(_one_col([m, -5, 1]), [(abi.AGG_SUM, 0)]) == [[m - 4]]
+    # an unsigned argument above MaxInt64 cannot become the int64 datum calculateSum adds (ConvertUintToInt, convert.go:122-128)
+    chunk = Chunk([Column(abi.U64, np.array([1 << 63], dtype=np.uint64), None)])
+    with pytest.raises(orc.OracleError):
+        _agg(chunk, [(abi.AGG_SUM, 0)])

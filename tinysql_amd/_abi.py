@@ -208,6 +208,8 @@ SIGNATURES = {
     "tsq_rowcodec_decode": (C.c_int32, [P, P, C.c_int64, P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(RowcodecCol), C.POINTER(Col),
                                         C.POINTER(C.c_int64)]),
     "tsq_rows_encode": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.POINTER(C.c_uint32), C.c_int64, P, C.c_int64, C.c_uint32, P, C.POINTER(C.c_int64)]),
+    "tsq_rowkeys_decode": (C.c_int32, [P, P, C.c_int64, P, C.c_int64, C.c_uint32, P, P, C.POINTER(C.c_int64)]),
+    "tsq_rowkeys_encode": (C.c_int32, [P, C.c_int64, P, C.c_int64, C.c_uint32, P]),
     "tsq_radix_split": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                     C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_comm_unique_id": (C.c_int32, [P]),
