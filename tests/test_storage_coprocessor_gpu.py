@@ -278,6 +278,20 @@ def test_the_cut_does_not_depend_on_the_batches_rows_arrive_in(ctx, orc):
     assert chunks == chunks_of(orc, select(scanned, keep))
 
 
+def test_limit_above_a_selection_takes_the_first_rows_in_scan_order(ctx, orc):
+    # selectionExec hands rows on in the order it got them (executor.go:360-390), limitExec keeps the first `limit` (:472-507):
+    # tsq_chunk_compact must preserve the row order across waves and workgroups
+    rng = np.random.default_rng(17)
+    pairs, scanned = make_table(orc, rng, 200_000)
+    conds = [E.ScalarFunction("ge", E.Column(1, abi.I64), E.Constant(0))]
+    keep, _, _ = orc.filter_eval(E.compile_list(conds), 1, scanned)
+    sel = select(scanned, keep)
+    for limit in (100, 70_001):
+        resp = cop.handleCopDAGRequest(ctx, [("TableScan", COLS), ("Selection", conds), ("Limit", limit)], [3, 1], pairs)
+        want = select(Chunk([sel.columns[3], sel.columns[1]]), slice(0, limit))
+        assert resp.Error is None and resp.Chunks == chunks_of(orc, want)
+
+
 def test_errors_become_the_response_error(ctx, orc):
     rng = np.random.default_rng(16)
     (keys, vals, offs), _ = make_table(orc, rng, 2000)

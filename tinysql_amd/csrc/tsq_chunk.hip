@@ -4,21 +4,23 @@
 // selected rows into the output chunk (executor/executor.go:393-438) / Column.CopyReconstruct gathers by the selection
 // vector (util/chunk/column.go:504-552).  With device-resident chunks this is the hand-off between a GPU Selection and a
 // GPU join / aggregate: no D2H, the dense chunk never leaves HBM.
-//   K12a k_compact_count  : selected rows per workgroup (contiguous rows per workgroup)
-//   K12b k_compact_scatter: exclusive bases by k_scan (one workgroup) -> LDS cursor per workgroup, wave ballot + popcount
-//                           prefix, every column's cell copied to its dense position; NULL flags as bytes -> k_pack_bitmap
-// Algorithmic bytes: 1 B flag + (8 B read + 8 B written per SELECTED cell).  Row order is preserved inside a wave and a
-// workgroup's rows stay together, i.e. the output is the input order up to a permutation inside 256-row tiles — operators
-// downstream (join probe, aggregate) are order-insensitive; Projection/Selection order guarantees of the reference
-// (executor/projection.go:187-207) are kept by the host-chunk path, which does not use this entry point.
+//   K12a k_compact_count  : selected rows per WAVE (every wave owns a contiguous run of rows)
+//   K12b k_compact_scatter: exclusive bases by k_compact_scan (one workgroup) -> a running cursor per wave in a register, wave
+//                           ballot + popcount prefix, every column's cell copied to its dense position; NULL flags as bytes ->
+//                           k_pack_bitmap
+// Algorithmic bytes: 1 B flag + (8 B read + 8 B written per SELECTED cell).  ROW ORDER IS PRESERVED: a wave walks its rows in
+// order and the waves' output ranges follow each other — what SelectionExec / CopyReconstruct guarantee (a Limit above a
+// Selection, a keep-order table scan: store/mockstore/mocktikv/executor.go:360-390, :472-507).  (The first version handed out
+// positions from one LDS cursor per workgroup: the four waves raced for it and the output was the input order only up to a
+// permutation inside 256-row tiles.)
 #include "tsq_stage.h"
 
 struct CompactArgs {
     tsq_colset in;
     const uint8_t* selected;  // one byte per row (Go []bool)
     int64_t nrows;
-    int64_t rows_per_block;
-    unsigned long long* block_base;  // in: per-workgroup counts -> exclusive bases
+    int64_t rows_per_wave;           // rows of one wave's contiguous run (a multiple of 64)
+    unsigned long long* block_base;  // per-wave counts -> exclusive bases (4 per workgroup)
     void* out_data[TSQ_MAX_COLS];
     uint8_t* out_notnull[TSQ_MAX_COLS];
     int64_t* out_offs[TSQ_MAX_COLS];  // var-len columns: the scatter leaves the cell lengths here, a scan makes them offsets
@@ -27,18 +29,15 @@ struct CompactArgs {
 };
 
 __global__ void __launch_bounds__(256) k_compact_count(CompactArgs a) {
-    __shared__ unsigned int s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * a.rows_per_block;
-    int64_t hi = lo + a.rows_per_block;
+    const int lane = threadIdx.x & 63;
+    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // this wave's run of rows
+    const int64_t lo = u * a.rows_per_wave;
+    int64_t hi = lo + a.rows_per_wave;
     hi = hi < a.nrows ? hi : a.nrows;
     unsigned int c = 0;
-    for (int64_t r = lo + threadIdx.x; r < hi; r += 256) c += a.selected[r] ? 1u : 0u;
+    for (int64_t r = lo + lane; r < hi; r += 64) c += a.selected[r] ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_n, c);
-    __syncthreads();
-    if (threadIdx.x == 0) a.block_base[blockIdx.x] = s_n;
+    if (lane == 0) a.block_base[u] = c;
 }
 // exclusive scan of n per-workgroup counts; *total = sum
 __global__ void __launch_bounds__(1024) k_compact_scan(unsigned long long* v, int n, unsigned long long* total) {
@@ -67,24 +66,18 @@ __global__ void __launch_bounds__(1024) k_compact_scan(unsigned long long* v, in
     if (threadIdx.x == 0) *total = all;
 }
 __global__ void __launch_bounds__(256) k_compact_scatter(CompactArgs a) {
-    __shared__ unsigned long long s_cur;
-    if (threadIdx.x == 0) s_cur = a.block_base[blockIdx.x];
-    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t lo = (int64_t)blockIdx.x * a.rows_per_block;
-    int64_t hi = lo + a.rows_per_block;
+    const int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t lo = u * a.rows_per_wave;  // a multiple of 64
+    int64_t hi = lo + a.rows_per_wave;
     hi = hi < a.nrows ? hi : a.nrows;
-    if (hi < lo) hi = lo;
-    const int64_t round = lo + ((hi - lo + 63) & ~(int64_t)63);
-    for (int64_t r = lo + threadIdx.x; r < round; r += 256) {
+    unsigned long long cur = a.block_base[u];  // first output row of this wave's run (wave uniform)
+    for (int64_t r = lo + lane; r - lane < hi; r += 64) {
         const bool sel = r < hi && a.selected[r];
         const unsigned long long m = __ballot(sel);
-        if (!m) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&s_cur, (unsigned long long)__popcll(m));
-        base = __shfl(base, 0, 64);
+        const unsigned long long pos = cur + __popcll(m & ((1ull << lane) - 1ull));
+        cur += (unsigned long long)__popcll(m);
         if (!sel) continue;
-        const unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
         if (a.src_row) a.src_row[pos] = (uint32_t)r;
         for (int c = 0; c < a.in.n; c++) {
             if (a.in.type[c] == TSQ_BYTES) a.out_offs[c][pos] = a.in.offs[c][r + 1] - a.in.offs[c][r];
@@ -147,7 +140,8 @@ TSQ_API tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t 
     a.selected = selected;
     a.nrows = nrows;
     const int grid = tsq_grid_for(ctx, nrows, 256);
-    a.rows_per_block = (((nrows + grid - 1) / grid) + 63) & ~(int64_t)63;
+    const int n_runs = grid * 4;
+    a.rows_per_wave = (((nrows + n_runs - 1) / n_runs) + 63) & ~(int64_t)63;
     DevBuf base, srow, scratch;
     std::vector<DevBuf> nn(n_cols);
     auto cleanup = [&]() {
@@ -156,7 +150,7 @@ TSQ_API tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t 
         scratch.release();
         for (auto& b : nn) b.release();
     };
-    tsq_status s = base.reserve(ctx, h, (size_t)grid * 8 + 64);
+    tsq_status s = base.reserve(ctx, h, (size_t)n_runs * 8 + 64);
     bool any_var = false;
     for (int c = 0; c < n_cols; c++) any_var = any_var || cols[c].type == TSQ_BYTES;
     if (s == TSQ_OK && any_var) {
@@ -173,9 +167,9 @@ TSQ_API tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t 
     }
     if (s != TSQ_OK) { cleanup(); return s; }
     a.block_base = base.as<unsigned long long>();
-    a.total = a.block_base + grid;
+    a.total = a.block_base + n_runs;
     hipLaunchKernelGGL(k_compact_count, dim3(grid), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, ctx->stream, a.block_base, grid, a.total);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, ctx->stream, a.block_base, n_runs, a.total);
     hipLaunchKernelGGL(k_compact_scatter, dim3(grid), dim3(256), 0, ctx->stream, a);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 16, a.total, 8, hipMemcpyDeviceToHost, ctx->stream);

@@ -298,9 +298,11 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
                         }
                     }
                 } else {
-                    uint32_t lb = jt_local(tb, bs, x) + hop;
+                    // local bucket = mulhi(the 32 bits below the slice bits, bs): one funnel shift of (hi, lo) instead of 64-bit shifts
+                    const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x;
+                    uint32_t lb = __umulhi(__builtin_amdgcn_alignbit(xh, xl, 32u - tb), bs) + hop;  // 1 <= tb <= 31 on this route
                     lb = lb >= bs ? lb - bs : lb;
-                    const uint32_t lbkt = ((uint32_t)(x >> sh) - f0) * bs + lb;  // bucket inside the image
+                    const uint32_t lbkt = __umul24((xh >> (sh - 32u)) - f0, bs) + lb;  // bucket inside the image (a few slices of < 2^10 buckets)
                     const uint64_t* bk = s_img + (size_t)lbkt * TSQ_BUCKET;
                     const ulonglong2* b = reinterpret_cast<const ulonglong2*>(bk);
                     const ulonglong2 q0 = b[lane & 3u], q1 = b[(lane + 1u) & 3u], q2 = b[(lane + 2u) & 3u], q3 = b[(lane + 3u) & 3u];
@@ -350,7 +352,8 @@ __global__ void __launch_bounds__(NT) k_lds_probe_count(LdsProbeArgs a) {
             }
         };
         auto step = [&](uint64_t w, bool valid, uint32_t gx) {
-            push(valid && ((uint32_t)(w >> sh) - f0) < nfi, w, 0u, gx);
+            // slice of w = its top tb <= 32 bits: a 32-bit shift of the high dword (sh >= 32)
+            push(valid && (((uint32_t)(w >> 32) >> (sh - 32u)) - f0) < nfi, w, 0u, gx);
             while (qt - qh >= 64u) probe_round(64u);
         };
         while (cur < nsc) {  // the numbers a wave draws grow: cur is its oldest
