@@ -432,7 +432,7 @@ tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_byt
  * Replaces the per-row loop around rowcodec.ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238; row.fromBytes /
  * findColID / getData, util/rowcodec/row.go:37-150) — equivalently the storage-side chain BytesDecoder.DecodeToBytes
  * (decoder.go:252-322, mocktikv tableScanExec, store/mockstore/mocktikv/executor.go:124-196) + readRowsData + DecodeOne —
- * for fixed-width schemas: a table scan's KV values, each one row in the new row format
+ * a table scan's KV values, each one row in the new row format
  *     [128][flag: bit0 = large][numNotNull u16][numNull u16][colIDs: u8 | u32 each, not-null ids sorted then null ids sorted]
  *     [end offsets of the not-null values: u16 | u32 each][values: ints 1/2/4/8 little-endian bytes, reals 8 bytes memcomparable]
  * become chunk columns.  `values` (n_bytes bytes) holds the rows back to back, row r = bytes [offsets[r], offsets[r+1])
@@ -442,16 +442,18 @@ tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_byt
 #define TSQ_RC_HAS_DEFAULT 2u /* column absent from the row: def_bits instead of NULL (defDatum, decoder.go:186-194)              */
 typedef struct tsq_rowcodec_col {
     int64_t  col_id;    /* ColInfo.ID                                                                                          */
-    int32_t  type;      /* TSQ_I64 (signed int types, year), TSQ_U64 (UnsignedFlag), TSQ_F32 (TypeFloat), TSQ_F64 (TypeDouble)  */
+    int32_t  type;      /* TSQ_I64 (signed int types, year), TSQ_U64 (UnsignedFlag), TSQ_F32 (TypeFloat), TSQ_F64 (TypeDouble),
+                           TSQ_BYTES (varchar / varstring / string / blobs: chk.AppendBytes of the value, decoder.go:226-228)     */
     uint32_t flags;     /* TSQ_RC_*                                                                                             */
     uint64_t def_bits;  /* default value as it is stored in the column (a float32 default in the low 4 bytes)                  */
 } tsq_rowcodec_col;
-/* out_cols: host or TSQ_COL_DEVICE buffers for nrows rows (data + null_bitmap).  Errors are decided by the FIRST offending
+/* out_cols: host or TSQ_COL_DEVICE buffers for nrows rows (data + null_bitmap); a TSQ_BYTES column: offsets[nrows + 1] and a data
+ * buffer of n_bytes bytes (a cell is a piece of its row, so the column cannot be larger than `values`).  Errors are decided by the FIRST offending
  * row in scan order; *nrows_out then holds the rows before it (already in out_cols): TSQ_ERR_INVALID with tsq_last_error =
  * "invalid codec version" (row.go:54-56) | "insufficient bytes to decode value" (a real shorter than 8 bytes, codec
  * number.go:84-86) | "malformed row" (header / id / offset arrays or a value running past the row, an int value that is not
- * 1, 2, 4 or >= 8 bytes long: the reference panics with an index out of range there).  A var-len column type ->
- * TSQ_ERR_UNSUPPORTED at call time: that scan keeps the Go decoder. */
+ * 1, 2, 4 or >= 8 bytes long: the reference panics with an index out of range there).  TSQ_ERR_UNSUPPORTED at call time (that scan
+ * keeps the Go decoder): a TSQ_BYTES column with TSQ_RC_HAS_DEFAULT (def_bits cannot carry bytes), TypeBit columns. */
 tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_bytes, const int64_t* offsets,
                                const int64_t* handles, int64_t nrows, uint32_t data_flags, int32_t n_cols,
                                const tsq_rowcodec_col* cols, tsq_col* out_cols, int64_t* nrows_out);

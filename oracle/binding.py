@@ -93,6 +93,8 @@ def load():
     lib.orc_rowcodec_decode.restype = C.c_int32
     lib.orc_rowcodec_decode.argtypes = [P, P, P, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_int64)]
+    lib.orc_rowcodec_decode_chunk.restype = P
+    lib.orc_rowcodec_decode_chunk.argtypes = [P, P, P, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, C.POINTER(C.c_int32)]
     lib.orc_rowcodec_to_old_bytes.restype = C.c_int64
     lib.orc_rowcodec_to_old_bytes.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(abi.RowcodecCol), C.c_int32, P, C.c_int64]
     lib.orc_rowcodec_column_is_null.restype = C.c_int32
@@ -395,6 +397,7 @@ def rowcodec_encode(chunk, col_ids, pad_col_id=-1, pad_len=None):
     if pad_col_id >= 0:
         pl = np.ascontiguousarray(pad_len, dtype=np.int64)
         extra = int(pl.sum()) + 8 * n
+    extra += sum(int(c.offsets[-1]) if getattr(c, 'offsets', None) is not None and len(c.offsets) else 0 for c in chunk.columns if c.tp == abi.BYTES)
     cap = n * (6 + 16 * (len(col_ids) + 1)) + extra + 64
     out = np.zeros(cap, np.uint8)
     offs = np.zeros(n + 1, np.int64)
@@ -421,6 +424,20 @@ def rowcodec_decode(values, offsets, handles, specs):
                                  rowcodec_cols(specs), len(specs), pd, pn, C.byref(got))
     chk = Chunk([Column(t, b[:got.value], nn[:got.value].astype(bool)) for t, b, nn in zip(types, bufs, nns)])
     return st, chk
+
+
+def rowcodec_decode_chunk(values, offsets, handles, specs):
+    """the same loop with var-len (abi.BYTES) columns -> (status, Chunk of the rows before an error)"""
+    lib = load()
+    values = np.ascontiguousarray(values, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    h = np.ascontiguousarray(handles, dtype=np.int64) if handles is not None else np.zeros(max(n, 1), np.int64)
+    st = C.c_int32(0)
+    buf = values if values.size else np.zeros(1, np.uint8)
+    res = lib.orc_rowcodec_decode_chunk(buf.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), n,
+                                        rowcodec_cols(specs), len(specs), C.byref(st))
+    return st.value, _result_to_chunk(lib, res)
 
 
 def rowcodec_to_old_bytes(row, handle, specs):

@@ -119,6 +119,9 @@ int64_t orc_rowcodec_encode(const tsq_col* cols, const int64_t* col_ids, int32_t
 /* the scan loop around ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238) */
 int32_t orc_rowcodec_decode(const uint8_t* values, const int64_t* offsets, const int64_t* handles, int64_t nrows, const tsq_rowcodec_col* cols,
                             int32_t n_cols, void** out_data, uint8_t** out_notnull, int64_t* nrows_out);
+/* the same loop with var-len (TSQ_BYTES) columns, into a materialised result: the rows before the offending one */
+orc_result* orc_rowcodec_decode_chunk(const uint8_t* values, const int64_t* offsets, const int64_t* handles, int64_t nrows, const tsq_rowcodec_col* cols,
+                                      int32_t n_cols, int32_t* status);
 /* BytesDecoder.DecodeToBytes (decoder.go:252-322) of one row, values concatenated in column order */
 int64_t orc_rowcodec_to_old_bytes(const uint8_t* row_data, int64_t len, int64_t handle, const tsq_rowcodec_col* cols, int32_t n_cols, uint8_t* out,
                                   int64_t cap);

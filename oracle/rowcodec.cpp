@@ -23,7 +23,7 @@
 #include <cstring>
 #include <vector>
 
-#include "oracle.h"
+#include "orc_result_internal.h"
 
 namespace {
 const uint8_t CodecVer = 128;
@@ -185,7 +185,7 @@ extern "C" {
  * offsets_out[r] .. offsets_out[r+1] bound row r.  Returns the bytes written, -1 when cap is too small. */
 int64_t orc_rowcodec_encode(const tsq_col* cols, const int64_t* col_ids, int32_t n_cols, int64_t nrows, int64_t pad_col_id, const int64_t* pad_len,
                             uint8_t* out, int64_t cap, int64_t* offsets_out) {
-    struct Val { int64_t id; int kind; /* 0 null 1 int 2 uint 3 float 4 bytes */ uint64_t bits; double f; int64_t blen; };
+    struct Val { int64_t id; int kind; /* 0 null 1 int 2 uint 3 float 4 bytes */ uint64_t bits; double f; int64_t blen; const uint8_t* bptr; };
     int64_t n = 0;
     offsets_out[0] = 0;
     for (int64_t r = 0; r < nrows; r++) {
@@ -200,19 +200,24 @@ int64_t orc_rowcodec_encode(const tsq_col* cols, const int64_t* col_ids, int32_t
             vals.push_back(v);
         };
         for (int c = 0; c < n_cols; c++) {
-            Val v{0, 0, 0, 0.0, 0};
+            Val v{0, 0, 0, 0.0, 0, nullptr};
             if (!is_null(cols[c], r)) {
                 switch (cols[c].type) {
                     case TSQ_I64: v.kind = 1; v.bits = ((const uint64_t*)cols[c].data)[r]; break;
                     case TSQ_U64: v.kind = 2; v.bits = ((const uint64_t*)cols[c].data)[r]; break;
                     case TSQ_F32: v.kind = 3; v.f = (double)((const float*)cols[c].data)[r]; break;  // SetFloat32 keeps float64(f)
+                    case TSQ_BYTES:  // KindString / KindBytes: the bytes as they are (EncodeValueDatum, encoder.go:180-181)
+                        v.kind = 4;
+                        v.blen = cols[c].offsets[r + 1] - cols[c].offsets[r];
+                        v.bptr = (const uint8_t*)cols[c].data + cols[c].offsets[r];
+                        break;
                     default: v.kind = 3; v.f = ((const double*)cols[c].data)[r];
                 }
             }
             append(col_ids[c], v);
         }
         if (pad_col_id >= 0) {
-            Val v{0, 4, 0, 0.0, pad_len[r]};
+            Val v{0, 4, 0, 0.0, pad_len[r], nullptr};
             append(pad_col_id, v);
         }
         // reformatCols (encoder.go:73-119): not-null columns first, each part sorted by id
@@ -232,7 +237,9 @@ int64_t orc_rowcodec_encode(const tsq_col* cols, const int64_t* col_ids, int32_t
                 case 1: encodeInt(data, (int64_t)v.bits); break;
                 case 2: encodeUint(data, v.bits); break;
                 case 3: encodeFloat(data, v.f); break;
-                default: data.insert(data.end(), (size_t)v.blen, (uint8_t)'a');
+                default:
+                    if (v.bptr) data.insert(data.end(), v.bptr, v.bptr + v.blen);
+                    else data.insert(data.end(), (size_t)v.blen, (uint8_t)'a');
             }
             if (data.size() > 65535 && !large) large = true;  // "handle convert to large" (ids and the offsets so far are widened)
             offsets[i] = (uint32_t)data.size();
@@ -316,6 +323,57 @@ int32_t orc_rowcodec_decode(const uint8_t* values, const int64_t* offsets, const
         *nrows_out = r + 1;
     }
     return 0;
+}
+
+/* The same scan loop with var-len columns (TSQ_BYTES: chk.AppendBytes(colIdx, colData), decoder.go:226-228; a NULL or absent
+ * cell: AppendNull) into a materialised result.  *status as above; the result holds the rows decoded before the offending one. */
+orc_result* orc_rowcodec_decode_chunk(const uint8_t* values, const int64_t* offsets, const int64_t* handles, int64_t nrows, const tsq_rowcodec_col* cols,
+                                      int32_t n_cols, int32_t* status) {
+    orc_result* res = new orc_result();
+    res->cols.resize((size_t)n_cols);
+    for (int c = 0; c < n_cols; c++) res->cols[c].type = cols[c].type;
+    *status = 0;
+    for (int64_t r = 0; r < nrows; r++) {
+        Row row;
+        int st = fromBytes(row, values + offsets[r], offsets[r + 1] - offsets[r]);
+        // a row is appended column by column in the reference; this restatement appends it whole or not at all (the rows BEFORE the
+        // offending one are what the callers compare)
+        std::vector<uint64_t> bits((size_t)n_cols, 0);
+        std::vector<uint8_t> nn((size_t)n_cols, 0);
+        std::vector<std::pair<const uint8_t*, int64_t>> cell((size_t)n_cols, {nullptr, 0});
+        for (int c = 0; c < n_cols && !st; c++) {
+            const tsq_rowcodec_col& col = cols[c];
+            if (col.flags & TSQ_RC_HANDLE) { bits[c] = (uint64_t)handles[r]; nn[c] = 1; continue; }
+            int idx;
+            bool isNil, notFound;
+            findColID(row, col.col_id, &idx, &isNil, &notFound);
+            if (!notFound && !isNil) {
+                const uint8_t* val;
+                int64_t n;
+                if (!getData(row, idx, &val, &n)) { st = 2; break; }
+                if (col.type == TSQ_BYTES) cell[c] = {val, n};
+                else if (col.type == TSQ_I64) { int64_t v; if (!decodeInt(val, n, &v)) { st = 2; break; } bits[c] = (uint64_t)v; }
+                else if (col.type == TSQ_U64) { if (!decodeUint(val, n, &bits[c])) { st = 2; break; } }
+                else {
+                    double f;
+                    if (!decodeFloat(val, n, &f)) { st = 3; break; }
+                    if (col.type == TSQ_F32) { const float f32 = (float)f; uint32_t w; memcpy(&w, &f32, 4); bits[c] = w; }
+                    else memcpy(&bits[c], &f, 8);
+                }
+                nn[c] = 1;
+            } else if (!isNil && (col.flags & TSQ_RC_HAS_DEFAULT) && col.type != TSQ_BYTES) {
+                bits[c] = col.def_bits;
+                nn[c] = 1;
+            }
+        }
+        if (st) { *status = st; break; }
+        for (int c = 0; c < n_cols; c++) {
+            if (cols[c].type == TSQ_BYTES && nn[c]) res->cols[c].append_bytes(cell[c].first, (size_t)cell[c].second);
+            else res->cols[c].append_raw(bits[c], nn[c] != 0);
+        }
+        res->rows = r + 1;
+    }
+    return res;
 }
 
 /* BytesDecoder.DecodeToBytes (decoder.go:252-302) for ONE row with outputOffset = column order and no default bytes: the old

@@ -273,3 +273,45 @@ def test_errors_inside_shared_layout_waves(sim, case):
     st, want = orc.rowcodec_decode(b, o, None, specs)
     assert st != 0 and (case == "short_float" or want.NumRows() == at)
     _both_paths(sim, b, o, None, specs)
+
+
+def test_string_columns_become_references_into_the_row(sim):
+    # a TSQ_BYTES column: the per-row code leaves (start inside the row) << 32 | length — what k_rowcodec_var_len / _copy turn into
+    # offsets and bytes — checked here against the cells of the oracle's DecodeToChunk restatement, on both wave paths and for rows
+    # parsed from global memory
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(77)
+    n = 3000
+    words = [None if rng.random() < 0.15 else bytes(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8)) for _ in range(n)]
+    wide = [None if rng.random() < 0.1 else b"w" * int(rng.integers(0, 3) * 120) for _ in range(n)]
+    chk = Chunk([Column(abi.I64, rng.integers(-1000, 1000, n), rng.random(n) >= 0.2), StrColumn(words), StrColumn(wide)])
+    b, o = orc.rowcodec_encode(chk, [3, 1, 8])
+    specs = [(1, abi.BYTES), (3, abi.I64), (8, abi.BYTES), (4, abi.BYTES)]
+    st, want = orc.rowcodec_decode_chunk(b, o, None, specs)
+    assert st == 0
+    for lds, fast in ((48 * 1024, 1), (48 * 1024, 0), (8 * 1024, 1)):  # 8 KB: the wide tiles fall back to global reads
+        isim = [(sp[0], abi.I64 if sp[1] == abi.BYTES else sp[1]) + tuple(sp[2:]) for sp in specs]  # buffers: 8 bytes per row
+        isim_specs = [(sp[0], sp[1]) for sp in specs]
+        values = np.ascontiguousarray(b, dtype=np.uint8)
+        offsets = np.ascontiguousarray(o, dtype=np.int64)
+        bufs = [np.zeros(n, np.uint64) for _ in specs]
+        bms = [np.zeros((n + 7) // 8 + 8, np.uint8) for _ in specs]
+        pd = (C.c_void_p * len(specs))(*[x.ctypes.data for x in bufs])
+        pb = (C.c_void_p * len(specs))(*[x.ctypes.data for x in bms])
+        staged, fastw = C.c_int64(0), C.c_int64(0)
+        err = sim.sim_rowcodec_decode(values.ctypes.data_as(C.c_void_p), values.size, 5, offsets.ctypes.data_as(C.c_void_p), None, n, orc.rowcodec_cols(isim_specs),
+                                      len(specs), pd, pb, lds, fast, C.byref(staged), C.byref(fastw))
+        assert err == (1 << 64) - 1 and isim
+        for c, sp in enumerate(specs):
+            nn = unpack_bitmap(bms[c], n)
+            col = want.columns[c]
+            if sp[1] != abi.BYTES:
+                assert [None if not nn[r] else int(bufs[c][r].astype(np.int64)) for r in range(n)] == col.values()
+                continue
+            for r in range(n):
+                ref = int(bufs[c][r])
+                if col.IsNull(r):
+                    assert not nn[r] and ref == 0  # a NULL cell has no bytes
+                else:
+                    start, ln = ref >> 32, ref & 0xffffffff
+                    assert nn[r] and bytes(values[o[r] + start:o[r] + start + ln]) == col.values()[r]

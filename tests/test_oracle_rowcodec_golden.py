@@ -193,3 +193,27 @@ def test_the_bench_tool_numpy_encoder_writes_the_same_bytes():
     want_b, want_o = orc.rowcodec_encode(Chunk([Column(abi.I64, a), Column(abi.I64, b), Column(abi.F64, c), Column(abi.U64, u)]), [9, 3, 200, 4])
     got_b, got_o = br.encode_rows_v2([a, b, c, u], [9, 3, 200, 4])
     assert (got_o == want_o).all() and got_b.size == want_b.size and (got_b == want_b).all()
+
+
+def test_string_columns_round_trip_and_layout():
+    # rowcodec_test.go:165-328 (TestTypesNewRowCodec) carries a varchar next to the numbers: EncodeValueDatum writes the bytes as
+    # they are (encoder.go:180-181), decodeColToChunk hands them to chk.AppendBytes (decoder.go:226-228); a NULL string is a NULL id
+    from tinysql_amd.chunk import StrColumn
+    chk = Chunk([Column(abi.I64, np.array([7, -300, 0]), np.array([True, True, False])), StrColumn([b"abc", None, b""]),
+                 StrColumn([b"\x00\xff", b"x" * 300, b"tail"])])
+    b, o = orc.rowcodec_encode(chk, [1, 2, 9])
+    # row 0 by hand (row.toBytes, row.go:80-99): 3 not-null ids 1, 2, 9; end offsets 1, 4, 6; data = 07 | "abc" | 00 ff
+    assert bytes(b[o[0]:o[1]]) == bytes([128, 0, 3, 0, 0, 0, 1, 2, 9, 1, 0, 4, 0, 6, 0, 7]) + b"abc" + b"\x00\xff"
+    # row 1: the string under id 2 is NULL -> ids 1, 9 then the null id 2; -300 takes two bytes
+    assert bytes(b[o[1]:o[1] + 13]) == bytes([128, 0, 2, 0, 1, 0, 1, 9, 2, 2, 0, 46, 1])
+    specs = [(9, abi.BYTES), (1, abi.I64), (2, abi.BYTES), (5, abi.BYTES)]
+    st, got = orc.rowcodec_decode_chunk(b, o, None, specs)
+    assert st == 0
+    assert got.rows() == [(b"\x00\xff", 7, b"abc", None), (b"x" * 300, -300, None, None), (b"tail", None, b"", None)]
+    # an empty string is not NULL: it is a not-null id whose value has no bytes
+    assert got.columns[2].values()[2] == b"" and not got.columns[2].IsNull(2)
+    # the fixed-width decoder and the chunk decoder agree where both apply; a damaged row stops both at the same row
+    cut = b.copy()
+    cut[o[2]] = 127
+    st, got = orc.rowcodec_decode_chunk(cut, o, None, specs)
+    assert st == 1 and got.NumRows() == 2

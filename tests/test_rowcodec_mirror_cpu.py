@@ -14,8 +14,9 @@ def test_colinfo_type_mapping():
     for tp in (RC.TypeTiny, RC.TypeShort, RC.TypeInt24, RC.TypeLong, RC.TypeLonglong, RC.TypeYear):
         assert RC.ColInfo(1, tp).tsq_type() == abi.I64 and RC.ColInfo(1, tp, RC.UnsignedFlag).tsq_type() == abi.U64
     assert RC.ColInfo(1, RC.TypeFloat).tsq_type() == abi.F32 and RC.ColInfo(1, RC.TypeDouble).tsq_type() == abi.F64
-    for tp in (RC.TypeVarchar, RC.TypeVarString, RC.TypeString, RC.TypeBlob, RC.TypeBit):
-        assert RC.ColInfo(1, tp).tsq_type() == abi.BYTES  # the library refuses these: that scan keeps the Go decoder
+    for tp in (RC.TypeVarchar, RC.TypeVarString, RC.TypeString, RC.TypeBlob, RC.TypeTinyBlob, RC.TypeMediumBlob, RC.TypeLongBlob):
+        assert RC.ColInfo(1, tp).tsq_type() == abi.BYTES  # chk.AppendBytes of the value (decoder.go:226-228)
+    assert RC.ColInfo(1, RC.TypeBit).tsq_type() is None   # a binary literal built from Flen (decoder.go:229-231): that scan keeps the Go decoder
 
 
 def test_decoder_descriptor_flags_and_default_bits():

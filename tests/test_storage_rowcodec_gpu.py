@@ -221,16 +221,18 @@ def test_argument_contract(ctx, orc):
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, None, None, 3, 0, 1, one, out, C.byref(n)) == abi.ERR_INVALID
     assert lib.tsq_rowcodec_decode(ctx.h, pb, -1, po, None, 3, 0, 1, one, out, C.byref(n)) == abi.ERR_INVALID
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 17, one, out, C.byref(n)) == abi.ERR_UNSUPPORTED
-    assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.BYTES)]), out, C.byref(n)) == abi.ERR_UNSUPPORTED
+    assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.BYTES)]), out, C.byref(n)) == abi.ERR_INVALID  # a var-len column without offsets[]
+    assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.BYTES, abi.RC_HAS_DEFAULT)]), out, C.byref(n)) == abi.ERR_UNSUPPORTED
+    assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, 9)]), out, C.byref(n)) == abi.ERR_INVALID  # no such column type
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.I64, abi.RC_HANDLE)]), out, C.byref(n)) == abi.ERR_INVALID
     # offsets that run past n_bytes are caught per row, not read
     bad = o.copy()
     bad[3] = b.size + 100
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, bad.ctypes.data_as(C.c_void_p), None, 3, 0, 1, one, out, C.byref(n)) == abi.ERR_INVALID
     assert _lib.last_error(ctx.h) == "malformed row"
-    # the mirror refuses a string column the same way (that scan keeps the Go decoder)
+    # the mirror refuses a bit column (decodeColToChunk builds a binary literal from Flen, decoder.go:229-231): that scan keeps the Go decoder
     with pytest.raises(_lib.TsqError) as ei:
-        RC.NewChunkDecoder(ctx, [RC.ColInfo(1, RC.TypeVarchar)]).DecodeToChunk(b, o)
+        RC.NewChunkDecoder(ctx, [RC.ColInfo(1, RC.TypeBit)]).DecodeToChunk(b, o)
     assert ei.value.status == abi.ERR_UNSUPPORTED
     # and the normal call still works on the same context afterwards
     _lib.check(lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, one, out, C.byref(n)), ctx.h)
@@ -377,3 +379,84 @@ def test_errors_inside_shared_layout_waves(ctx, orc, case):
     st, want = orc.rowcodec_decode(b, o, None, specs)
     assert st != 0 and (case == "short_float" or want.NumRows() == at)
     _both_kernel_paths(ctx, b, o, None, specs, st, want)
+
+
+# ------------------------------------------------------------------------------------------------ string columns (round 2)
+def _string_scan(rng, n, long_cells=False):
+    from tinysql_amd.chunk import StrColumn
+    words = [None if rng.random() < 0.15 else bytes(rng.integers(0, 256, int(rng.integers(0, 24)), dtype=np.uint8)) for _ in range(n)]
+    if long_cells:  # the reference's benchmark payload is 5 KiB (executor/benchmark_test.go:328): one cell per wave in the copy kernel
+        notes = [None if rng.random() < 0.1 else bytes([65 + i % 26]) * int(rng.integers(0, 3) * 2600) for i in range(n)]
+    else:
+        notes = [None if rng.random() < 0.1 else (b"" if rng.random() < 0.2 else b"n%05d" % i) for i in range(n)]
+    return Chunk([Column(abi.I64, rng.integers(-(1 << 40), 1 << 40, n), rng.random(n) >= 0.2), StrColumn(words),
+                  Column(abi.F64, rng.standard_normal(n), rng.random(n) >= 0.2), StrColumn(notes)])
+
+
+STR_COLS = [RC.ColInfo(4, RC.TypeVarchar), RC.ColInfo(1, RC.TypeLonglong), RC.ColInfo(-1, RC.TypeLonglong, 0, True), RC.ColInfo(2, RC.TypeBlob),
+            RC.ColInfo(3, RC.TypeDouble), RC.ColInfo(50, RC.TypeVarString)]
+STR_SPECS = [(4, abi.BYTES), (1, abi.I64), (-1, abi.I64, abi.RC_HANDLE), (2, abi.BYTES), (3, abi.F64), (50, abi.BYTES)]
+
+
+@pytest.mark.parametrize("n,long_cells", [(1, False), (64, False), (257, False), (5000, False), (100_000, False), (700, True)])
+def test_string_columns_against_the_oracle(ctx, orc, n, long_cells):
+    # varchar / blob cells are the value's bytes as they are (chk.AppendBytes, decoder.go:226-228); a NULL id or an absent column
+    # is a NULL cell, an empty value an empty string
+    rng = np.random.default_rng(n + 5)
+    chk = _string_scan(rng, n, long_cells)
+    handles = rng.integers(-(1 << 62), 1 << 62, n)
+    b, o = orc.rowcodec_encode(chk, [1, 2, 3, 4])
+    st, want = orc.rowcodec_decode_chunk(b, o, handles, STR_SPECS)
+    got = RC.NewChunkDecoder(ctx, STR_COLS, -1).DecodeToChunk(b, o, handles)
+    assert st == 0 and got.NumRows() == n and got.rows() == want.rows()
+    assert all(v is None for v in got.columns[5].values())  # id 50 is in no row
+
+
+def test_string_columns_device_resident_and_rows_before_an_error(ctx, orc):
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(31)
+    n = 20_000
+    chk = _string_scan(rng, n)
+    b, o = orc.rowcodec_encode(chk, [1, 2, 3, 4])
+    specs = [(2, abi.BYTES), (1, abi.I64), (4, abi.BYTES)]
+    for damage in (None, 12_345):
+        raw = b.copy()
+        if damage is not None:
+            raw[o[damage]] = 127  # "invalid codec version" at that row: the rows before it are handed over, strings included
+        st, want = orc.rowcodec_decode_chunk(raw, o, None, specs)
+        dbytes, doffs = ctx.alloc(raw.size + 64 + 7), ctx.alloc(o.nbytes + 64)
+        d1, o1, b1 = ctx.alloc(raw.size + 64), ctx.alloc(8 * (n + 1) + 64), ctx.alloc(n // 8 + 64)
+        d2, b2 = ctx.alloc(8 * n + 64), ctx.alloc(n // 8 + 64)
+        d3, o3, b3 = ctx.alloc(raw.size + 64), ctx.alloc(8 * (n + 1) + 64), ctx.alloc(n // 8 + 64)
+        try:
+            ctx.h2d(dbytes + 7, raw)  # the values start 7 bytes into their buffer
+            ctx.h2d(doffs, o)
+            out = (abi.Col * 3)()
+            for i, (d, of, bm, tp) in enumerate(((d1, o1, b1, abi.BYTES), (d2, None, b2, abi.I64), (d3, o3, b3, abi.BYTES))):
+                out[i].data, out[i].offsets, out[i].null_bitmap, out[i].length, out[i].type, out[i].flags = d, of, bm, n, tp, abi.COL_DEVICE
+                out[i].elem_size = -1 if tp == abi.BYTES else 8
+            m = C.c_int64(0)
+            gst = ctx.lib.tsq_rowcodec_decode(ctx.h, C.c_void_p(dbytes + 7), raw.size, C.c_void_p(doffs), None, n, abi.COL_DEVICE, 3, orc_cols(specs), out, C.byref(m))
+            rows = m.value
+            assert rows == want.NumRows() == (n if damage is None else damage)
+            assert (gst == abi.OK) == (damage is None) and (damage is None or _lib.last_error(ctx.h) == "invalid codec version")
+            cols = []
+            for d, of, bm, tp in ((d1, o1, b1, abi.BYTES), (d2, None, b2, abi.I64), (d3, o3, b3, abi.BYTES)):
+                bits = np.zeros(n // 8 + 8, np.uint8)
+                ctx.d2h(bits, bm)
+                nn = np.unpackbits(bits, bitorder="little")[:rows].astype(bool)
+                if tp == abi.BYTES:
+                    offs = np.zeros(rows + 1, np.int64)
+                    ctx.d2h(offs, of)
+                    data = np.zeros(max(int(offs[rows]), 1), np.uint8)
+                    ctx.d2h(data, d)
+                    assert offs[0] == 0 and (np.diff(offs) >= 0).all()
+                    cols.append(StrColumn([bytes(data[offs[r]:offs[r + 1]]) if nn[r] else None for r in range(rows)]))
+                else:
+                    v = np.zeros(max(rows, 1), np.int64)
+                    ctx.d2h(v, d)
+                    cols.append(Column(tp, v[:rows], nn))
+            assert Chunk(cols).rows() == want.rows()
+        finally:
+            for p in (dbytes, doffs, d1, o1, b1, d2, b2, d3, o3, b3):
+                ctx.free(p)

@@ -53,6 +53,10 @@ class tableScanExec(GpuExecutor):
     def __init__(self, ctx, columns, keys, values, value_offsets, batch_rows=1 << 22):
         self.columns = list(columns)
         types = [c.tsq_type() for c in self.columns]
+        if any(t is None or t == abi.BYTES for t in types):
+            # the device-resident chunks of this chain are fixed-width (gpu_pipeline.DeviceColumn); a scan with string columns decodes
+            # them through rowcodec.ChunkDecoder into host chunks and keeps the Go executors above it
+            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "var-len column in a device-resident coprocessor chain")
         super().__init__(ctx, types)
         self.raw_keys = np.frombuffer(keys, dtype=np.uint8) if isinstance(keys, (bytes, bytearray)) else np.ascontiguousarray(keys, dtype=np.uint8)
         self.raw_vals = np.frombuffer(values, dtype=np.uint8) if isinstance(values, (bytes, bytearray)) else np.ascontiguousarray(values, dtype=np.uint8)

@@ -13,7 +13,7 @@
 //   * the null bitmap of 64 rows is one wave ballot, written as 8 bytes by lanes 0..7 (bit 1 = NOT NULL, column.go:89-92);
 //   * a tile wider than the LDS budget (rows with long strings next to the requested columns) is parsed from global memory.
 // Algorithmic bytes per row: its stored bytes + 8 B per output value (+ 1/8 B bitmap).
-#include "tsq_internal.h"
+#include "tsq_stage.h"
 #include "tsq_rowcodec_dp.h"
 
 #define RC_NT 256
@@ -245,6 +245,51 @@ __global__ void __launch_bounds__(RC_NT, KV <= 6 ? 6 : 1) k_rowcodec_decode_pipe
     }
 }
 
+// ---- var-len (string / blob) columns: chk.AppendBytes(colIdx, colData) (decoder.go:226-228).  The decode kernels leave a
+// REFERENCE per row in place of the cell — (start inside the row) << 32 | length, 0 for a NULL — because where a cell's bytes go
+// depends on the lengths of all the cells before it.  K15b turns the references into lengths, tsq_launch_scan64 into the column's
+// offsets, K15c copies the bytes out of `values` (one row per lane for short cells, one per wave for long ones).
+struct RcVarArgs {
+    const uint8_t* bytes;     // values
+    const int64_t* offsets;   // row boundaries in values
+    const uint64_t* ref;      // [rows]
+    int64_t rows;
+    int64_t* out_offs;        // [rows + 1]: lengths, then (after the scan) the offsets of the column
+    uint8_t* out_data;
+};
+__global__ void __launch_bounds__(256) k_rowcodec_var_len(RcVarArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x)
+        a.out_offs[r] = (int64_t)(uint32_t)a.ref[r];
+}
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_rowcodec_var_copy(RcVarArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    const int64_t first = WAVE ? gtid >> 6 : gtid, step = WAVE ? nthr >> 6 : nthr;
+    for (int64_t r = first; r < a.rows; r += step) {
+        const uint64_t ref = a.ref[r];
+        const int64_t n = (int64_t)(uint32_t)ref;
+        if (n == 0) continue;
+        const uint8_t* s = a.bytes + a.offsets[r] + (int64_t)(ref >> 32);
+        uint8_t* d = a.out_data + a.out_offs[r];
+        if (!WAVE) {
+            for (int64_t i = 0; i < n; i++) d[i] = s[i];
+        } else {  // head up to an 8-byte boundary of the destination, then 8 bytes per lane, then the tail
+            int64_t head = (8 - ((uintptr_t)d & 7)) & 7;
+            head = head < n ? head : n;
+            if (lane < head) d[lane] = s[lane];
+            const int64_t words = (n - head) >> 3;
+            for (int64_t w = lane; w < words; w += 64) {
+                uint64_t x;
+                memcpy(&x, s + head + w * 8, 8);  // the source is not aligned with the destination
+                *reinterpret_cast<uint64_t*>(d + head + w * 8) = x;
+            }
+            const int64_t done = head + words * 8;
+            if (done + lane < n) d[done + lane] = s[done + lane];
+        }
+    }
+}
+
 }  // namespace
 
 // ====================================================================== host side
@@ -259,16 +304,29 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: bad arguments");
     if (n_cols < 1 || n_cols > TSQ_MAX_COLS) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "1..16 columns supported");
     if (nrows >= (1LL << 40)) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "more than 2^40 rows per call");
-    bool any_handle = false;
+    bool any_handle = false, any_var = false;
     for (int c = 0; c < n_cols; c++) {
-        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "var-len column: decode this scan with the Go decoder");
+        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: unknown column type");
         if ((cols[c].flags & TSQ_RC_HANDLE) && cols[c].type != TSQ_I64 && cols[c].type != TSQ_U64)
             return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: the handle column is an integer column");
+        if (cols[c].type == TSQ_BYTES && (cols[c].flags & TSQ_RC_HAS_DEFAULT))
+            return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "a default value of a var-len column: decode this scan with the Go decoder");
         any_handle = any_handle || (cols[c].flags & TSQ_RC_HANDLE);
-        if (!out_cols[c].data || !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: out columns need data and null_bitmap buffers");
+        any_var = any_var || cols[c].type == TSQ_BYTES;
+        // a var-len output column: offsets[nrows + 1] and room for n_bytes data bytes (a cell is a piece of its row)
+        const bool var = cols[c].type == TSQ_BYTES;
+        if (!out_cols[c].null_bitmap || (var ? (!out_cols[c].offsets || (n_bytes > 0 && !out_cols[c].data)) : !out_cols[c].data))
+            return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: out columns need data and null_bitmap buffers (a var-len column: offsets too)");
         if (((out_cols[c].flags ^ out_cols[0].flags) & TSQ_COL_DEVICE) != 0) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: mixed host/device outputs");
     }
-    if (nrows == 0) return TSQ_OK;
+    if (nrows == 0) {  // an empty scan: a var-len column still has its first offset
+        for (int c = 0; c < n_cols; c++) {
+            if (cols[c].type != TSQ_BYTES) continue;
+            if (out_cols[c].flags & TSQ_COL_DEVICE) TSQ_HIP(h, hipMemsetAsync(out_cols[c].offsets, 0, 8, ctx->stream));
+            else out_cols[c].offsets[0] = 0;
+        }
+        return TSQ_OK;
+    }
     if (any_handle && !handles) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: a handle column needs handles[]");
     TSQ_HIP(h, hipSetDevice(ctx->device));
     const bool in_dev = data_flags & TSQ_COL_DEVICE, out_dev = out_cols[0].flags & TSQ_COL_DEVICE;
@@ -277,10 +335,10 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     a.nrows = nrows;
     a.n_bytes = n_bytes;
     a.n_cols = n_cols;
-    DevBuf dbytes, doffs, dhandles, derr, ddata[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
+    DevBuf dbytes, doffs, dhandles, derr, scratch, ddata[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS], dref[TSQ_MAX_COLS], dvoffs[TSQ_MAX_COLS];
     auto release_all = [&]() {
-        for (DevBuf* b : {&dbytes, &doffs, &dhandles, &derr}) b->release();
-        for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dbm[c].release(); }
+        for (DevBuf* b : {&dbytes, &doffs, &dhandles, &derr, &scratch}) b->release();
+        for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dbm[c].release(); dref[c].release(); dvoffs[c].release(); }
     };
     auto fail = [&](tsq_status st) { release_all(); return st; };
     tsq_status s = derr.reserve(ctx, h, 64);
@@ -305,11 +363,14 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(H2D): ") + hipGetErrorString(e)));
     for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
         a.cols[c] = cols[c];
-        if (!out_dev) {
-            s = ddata[c].reserve(ctx, h, (size_t)nrows * tsq_elem_size(cols[c].type) + 64);
+        const bool var = cols[c].type == TSQ_BYTES;
+        if (var) s = dref[c].reserve(ctx, h, (size_t)nrows * 8 + 64);  // the kernel leaves (start, length) references here
+        if (s == TSQ_OK && !out_dev) {
+            s = ddata[c].reserve(ctx, h, (var ? (size_t)n_bytes : (size_t)nrows * tsq_elem_size(cols[c].type)) + 64);
             if (s == TSQ_OK) s = dbm[c].reserve(ctx, h, tsq_bitmap_bytes(nrows) + 64);
+            if (s == TSQ_OK && var) s = dvoffs[c].reserve(ctx, h, ((size_t)nrows + 1) * 8 + 64);
         }
-        a.out[c] = out_dev ? out_cols[c].data : ddata[c].p;
+        a.out[c] = var ? dref[c].p : (out_dev ? out_cols[c].data : ddata[c].p);
         a.out_bm[c] = out_dev ? out_cols[c].null_bitmap : dbm[c].as<uint8_t>();
     }
     if (s != TSQ_OK) return fail(s);
@@ -349,11 +410,49 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         code = (int)(errw & 15);
         rows = (int64_t)(errw >> 4);
     }
+    // var-len columns of the rows before the first offending one: references -> lengths -> offsets (scan) -> bytes
+    int64_t var_bytes[TSQ_MAX_COLS] = {0};
+    for (int c = 0; c < n_cols && any_var; c++) {
+        if (cols[c].type != TSQ_BYTES) continue;
+        RcVarArgs va;
+        va.bytes = a.bytes;
+        va.offsets = a.offsets;
+        va.ref = dref[c].as<uint64_t>();
+        va.rows = rows;
+        va.out_offs = out_dev ? out_cols[c].offsets : dvoffs[c].as<int64_t>();
+        va.out_data = out_dev ? (uint8_t*)out_cols[c].data : ddata[c].as<uint8_t>();
+        if (rows > 0) {
+            hipLaunchKernelGGL(k_rowcodec_var_len, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, va);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(var len): ") + hipGetErrorString(e)));
+        }
+        const tsq_status vs = tsq_launch_scan64(ctx, h, va.out_offs, rows, scratch);
+        if (vs != TSQ_OK) return fail(vs);
+        e = hipMemcpyAsync(ctx->pinned + 1, va.out_offs + rows, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(var scan): ") + hipGetErrorString(e)));
+        var_bytes[c] = (int64_t)ctx->pinned[1];
+        if (var_bytes[c] > 0) {
+            if (var_bytes[c] / rows > 32) hipLaunchKernelGGL(k_rowcodec_var_copy<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, va);
+            else hipLaunchKernelGGL(k_rowcodec_var_copy<false>, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, va);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(var copy): ") + hipGetErrorString(e)));
+        }
+    }
+    if (any_var) {
+        e = hipStreamSynchronize(ctx->stream);  // the references and `values` staging are released below
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(var): ") + hipGetErrorString(e)));
+    }
     // hand the rows before the first offending one over (the reference has appended them to the chunk by then)
-    if (!out_dev && rows > 0) {
+    if (!out_dev && (rows > 0 || any_var)) {
         for (int c = 0; c < n_cols && e == hipSuccess; c++) {
-            e = hipMemcpyAsync(out_cols[c].data, ddata[c].p, (size_t)rows * tsq_elem_size(cols[c].type), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(out_cols[c].null_bitmap, dbm[c].p, tsq_bitmap_bytes(rows), hipMemcpyDeviceToHost, ctx->stream);
+            if (cols[c].type == TSQ_BYTES) {
+                e = hipMemcpyAsync(out_cols[c].offsets, dvoffs[c].p, ((size_t)rows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess && var_bytes[c] > 0) e = hipMemcpyAsync(out_cols[c].data, ddata[c].p, (size_t)var_bytes[c], hipMemcpyDeviceToHost, ctx->stream);
+            } else if (rows > 0) {
+                e = hipMemcpyAsync(out_cols[c].data, ddata[c].p, (size_t)rows * tsq_elem_size(cols[c].type), hipMemcpyDeviceToHost, ctx->stream);
+            }
+            if (e == hipSuccess && rows > 0) e = hipMemcpyAsync(out_cols[c].null_bitmap, dbm[c].p, tsq_bitmap_bytes(rows), hipMemcpyDeviceToHost, ctx->stream);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(D2H): ") + hipGetErrorString(e)));
@@ -361,7 +460,7 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     for (int c = 0; c < n_cols; c++) {
         out_cols[c].length = rows;
         out_cols[c].type = cols[c].type;
-        out_cols[c].elem_size = tsq_elem_size(cols[c].type);
+        out_cols[c].elem_size = cols[c].type == TSQ_BYTES ? -1 : tsq_elem_size(cols[c].type);
     }
     release_all();
     *nrows_out = rows;

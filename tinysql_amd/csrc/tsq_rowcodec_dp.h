@@ -122,7 +122,12 @@ TSQ_HD int tsq_rc_find(const R& b, const tsq_rc_row& r, int64_t col_id64, uint32
 template <class R>
 TSQ_HD int tsq_rc_value(const R& b, uint32_t p, uint32_t n, int32_t type, uint64_t* bits_out) {
     uint64_t bits;
-    if (type == TSQ_I64 || type == TSQ_U64) {
+    if (type == TSQ_BYTES) {
+        // chk.AppendBytes(colIdx, colData) (decoder.go:226-228): the cell is the value's bytes as they are.  What the column stores
+        // for now is a REFERENCE — where the bytes start inside the row (high dword) and how many there are (low dword); the
+        // bytes are copied once every row's length is known (tsq_rowcodec.hip: lengths -> scan -> copy)
+        bits = ((uint64_t)p << 32) | (uint64_t)n;
+    } else if (type == TSQ_I64 || type == TSQ_U64) {
         // decodeInt / decodeUint (common.go:103-114,199-210): 1, 2, 4 bytes, or LittleEndian.Uint64 of the first 8 (which needs
         // 8): read min(n, 8) bytes, then sign- / zero-extend from n bytes with one pair of shifts
         if (!(n == 1 || n == 2 || n == 4 || n >= 8)) return RC_MALFORMED;
@@ -149,7 +154,7 @@ TSQ_HD int tsq_rc_value(const R& b, uint32_t p, uint32_t n, int32_t type, uint64
 }
 
 // one output column of one row (DecodeToChunk's loop body, decoder.go:164-196): *bits_out is what the column stores (a float32
-// in the low 4 bytes), *notnull_out its bitmap bit.  type = TSQ_I64 / TSQ_U64 / TSQ_F32 / TSQ_F64.
+// in the low 4 bytes; a TSQ_BYTES cell as a (start in the row, length) reference), *notnull_out its bitmap bit.
 template <class R>
 TSQ_HD int tsq_rc_column(const R& b, const tsq_rc_row& r, int64_t col_id, int32_t type, uint32_t flags, uint64_t def_bits, int64_t handle,
                          uint64_t* bits_out, bool* notnull_out) {

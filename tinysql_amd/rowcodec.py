@@ -22,6 +22,8 @@ TypeTiny, TypeShort, TypeLong, TypeFloat, TypeDouble, TypeLonglong, TypeInt24, T
 TypeVarchar, TypeBit, TypeBlob, TypeVarString, TypeString = 15, 16, 252, 253, 254
 UnsignedFlag = 32  # parser/mysql/const.go
 _INT_TYPES = (TypeLonglong, TypeLong, TypeInt24, TypeShort, TypeTiny, TypeYear)
+TypeTinyBlob, TypeMediumBlob, TypeLongBlob = 249, 250, 251
+_STRING_TYPES = (TypeVarString, TypeVarchar, TypeString, TypeBlob, TypeTinyBlob, TypeMediumBlob, TypeLongBlob)
 
 
 class ColInfo:
@@ -37,7 +39,9 @@ class ColInfo:
             return abi.F32
         if self.Tp == TypeDouble:
             return abi.F64
-        return abi.BYTES  # strings, blobs, bit: not accelerated
+        if self.Tp in _STRING_TYPES:
+            return abi.BYTES  # chk.AppendBytes of the value (decoder.go:226-228)
+        return None  # TypeBit and the types TinySQL does not have: the Go decoder
 
 
 def _def_bits(tp, v):
@@ -54,6 +58,8 @@ class ChunkDecoder:
     def __init__(self, ctx, columns, handleColID=-1, defDatum=None):
         self.ctx, self.columns, self.handleColID, self.defDatum = ctx, list(columns), handleColID, defDatum
         self.types = [c.tsq_type() for c in self.columns]
+        if any(t is None for t in self.types):
+            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "unknown type")  # decodeColToChunk's default branch / TypeBit: the Go decoder
         self.cols = (abi.RowcodecCol * len(self.columns))()
         for i, c in enumerate(self.columns):
             self.cols[i].col_id, self.cols[i].type, self.cols[i].flags, self.cols[i].def_bits = c.ID, self.types[i], 0, 0
@@ -72,8 +78,8 @@ class ChunkDecoder:
         n = len(offs) - 1
         hd = np.ascontiguousarray(handles, dtype=np.int64) if handles is not None else None
         keep = []
-        out_types = [t if t != abi.BYTES else abi.I64 for t in self.types]  # a var-len type is refused by the library before any buffer is used
-        out, bufs = out_buffers(out_types, max(n, 1), keep)
+        # a var-len cell is a piece of its row: the column's data cannot exceed the rows' bytes
+        out, bufs = out_buffers(self.types, max(n, 1), keep, var_bytes=[raw.size if t == abi.BYTES else 0 for t in self.types])
         got = C.c_int64(0)
         _lib.check(self.ctx.lib.tsq_rowcodec_decode(self.ctx.h, raw.ctypes.data_as(C.c_void_p), raw.size, offs.ctypes.data_as(C.c_void_p),
                                                     hd.ctypes.data_as(C.c_void_p) if hd is not None else None, n, 0, len(self.columns), self.cols, out,
