@@ -346,7 +346,14 @@ def sort_perm(chunk, key_cols, key_desc):
 
 def sort_rows(chunk, key_cols, key_desc):
     perm = sort_perm(chunk, key_cols, key_desc)
-    return Chunk([Column(c.tp, c.data[perm], None if c.notnull is None else c.notnull[perm]) for c in chunk.columns])
+    cols = []
+    for c in chunk.columns:
+        if c.tp == abi.BYTES:
+            vals = c.values()
+            cols.append(StrColumn([vals[i] for i in perm]))
+        else:
+            cols.append(Column(c.tp, c.data[perm], None if c.notnull is None else c.notnull[perm]))
+    return Chunk(cols)
 
 
 def row_compare(chunk, key_cols, key_desc, i, j):

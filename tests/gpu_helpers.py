@@ -154,9 +154,16 @@ def run_sort(ctx, chunk, key_cols, key_desc, chunk_rows=1024, pull_rows=1024, of
         got = []
         while True:
             keep = []
-            out, bufs = out_buffers(types, pull_rows, keep)
+            var_bytes = None
+            if abi.BYTES in types:
+                vb, nr = (C.c_int64 * len(types))(), C.c_int64(0)
+                _lib.check(lib.tsq_sort_peek(h, pull_rows, C.byref(nr), vb, len(types)), h)
+                var_bytes = list(vb)
+            out, bufs = out_buffers(types, pull_rows, keep, var_bytes=var_bytes)
             n, eos = C.c_int64(0), C.c_int32(0)
             _lib.check(lib.tsq_sort_pull(h, out, len(types), pull_rows, C.byref(n), C.byref(eos)), h)
+            if var_bytes is not None:
+                assert n.value == nr.value
             if n.value == 0:
                 assert eos.value == 1
                 break

@@ -214,7 +214,7 @@ def test_sort_call_sequence_and_cancel_contract(ctx):
     cfg.col_types[0] = abi.I64
     bad = abi.SortCfg()
     bad.n_cols, bad.n_keys, bad.limit_count = 1, 1, -1
-    bad.col_types[0] = 4  # TSQ_BYTES: var-len columns keep the Go operator
+    bad.col_types[0] = 4  # TSQ_BYTES as an ORDER BY item: the string comparator keeps the Go operator (payload columns may be var-len)
     h = C.c_void_p()
     assert lib.tsq_sort_create(ctx.h, C.byref(bad), C.byref(h)) == abi.ERR_UNSUPPORTED
     bad.col_types[0], bad.key_col[0] = abi.I64, 3
@@ -240,3 +240,88 @@ def test_sort_call_sequence_and_cancel_contract(ctx):
         assert lib.tsq_sort_pull(h, out, 1, 8, C.byref(n), C.byref(eos)) == abi.ERR_CANCELLED
     finally:
         lib.tsq_sort_destroy(h)
+
+
+# ------------------------------------------------------------------------------------------------ var-len payload columns (round 2)
+def _string_table(rng, n, long_cells=False):
+    from tinysql_amd.chunk import StrColumn
+    names = [None if rng.random() < 0.1 else (b"" if rng.random() < 0.1 else b"name-%06d" % i) for i in range(n)]
+    if long_cells:  # a 5 KiB payload like the reference's join benchmark: one cell per wave in the copy kernel
+        notes = [None if rng.random() < 0.2 else bytes([97 + i % 26]) * int(rng.integers(1, 3) * 2500) for i in range(n)]
+    else:
+        notes = [bytes(rng.integers(0, 256, int(rng.integers(0, 20)), dtype=np.uint8)) for _ in range(n)]
+    return Chunk([StrColumn(names), Column(abi.I64, rng.integers(0, max(n // 7, 2), n), rng.random(n) >= 0.1), StrColumn(notes),
+                  Column(abi.F64, np.round(rng.standard_normal(n), 1), rng.random(n) >= 0.1)])
+
+
+@pytest.mark.parametrize("n,long_cells", [(1, False), (1000, False), (70_000, False), (900, True)])
+def test_string_payload_columns_follow_their_rows(ctx, orc, n, long_cells):
+    # ORDER BY k, f DESC over (name varchar, k, note blob, f): the var-len cells travel with their rows (Chunk.AppendRow), NULL and
+    # empty strings stay what they are; equal keys keep input order (the stable oracle), so the rows are identical one by one
+    rng = np.random.default_rng(n)
+    t = _string_table(rng, n, long_cells)
+    want = orc.sort_rows(t, [1, 3], [False, True])
+    got = G.run_sort(ctx, t, [1, 3], [False, True], chunk_rows=1024, pull_rows=1000)
+    assert got.rows() == want.rows()
+
+
+def test_string_payload_topn_window_and_the_executor_mirror(ctx, orc):
+    from tinysql_amd import executor as X
+    rng = np.random.default_rng(4)
+    t = _string_table(rng, 30_000)
+    want = orc.sort_rows(t, [3, 1], [False, False]).rows()
+    got = G.run_sort(ctx, t, [3, 1], [False, False], chunk_rows=4096, pull_rows=333, offset=1234, count=5000)
+    assert got.rows() == want[1234:6234]
+    chunks = X.drain(X.TopNExec(ctx, X.MockDataSource(ctx, t), [3, 1], [False, False], 10, 2000))
+    assert [r for c in chunks for r in c.rows()] == want[10:2010] and all(c.NumRows() <= 1024 for c in chunks)
+
+
+def test_string_payload_device_resident(ctx, orc):
+    # device-resident push of a var-len column (offsets + data in HBM) and device-resident pull sized by tsq_sort_peek
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(8)
+    n = 50_000
+    t = _string_table(rng, n)
+    want = orc.sort_rows(t, [1], [True])
+    lib = ctx.lib
+    cfg = abi.SortCfg()
+    cfg.n_cols, cfg.n_keys, cfg.limit_offset, cfg.limit_count, cfg.max_chunk_size = 2, 1, 0, -1, 1024
+    cfg.col_types[0], cfg.col_types[1], cfg.key_col[0], cfg.key_desc[0] = abi.I64, abi.BYTES, 0, 1
+    names, keys = t.columns[0], t.columns[1]
+    nbytes = int(names.offsets[-1])
+    dk, dkb = ctx.alloc(8 * n + 64), ctx.alloc(n // 8 + 64)
+    dd, do, db = ctx.alloc(nbytes + 64), ctx.alloc(8 * (n + 1) + 64), ctx.alloc(n // 8 + 64)
+    od, oo, ob, okd, okb = ctx.alloc(nbytes + 64), ctx.alloc(8 * (n + 1) + 64), ctx.alloc(n // 8 + 64), ctx.alloc(8 * n + 64), ctx.alloc(n // 8 + 64)
+    h = C.c_void_p()
+    _lib.check(lib.tsq_sort_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        ctx.h2d(dk, np.ascontiguousarray(keys.data))
+        ctx.h2d(dkb, np.packbits(keys.notnull, bitorder="little"))
+        ctx.h2d(dd, names.data[:max(nbytes, 1)].copy())
+        ctx.h2d(do, names.offsets)
+        ctx.h2d(db, np.packbits(names.notnull, bitorder="little"))
+        cols = (abi.Col * 2)()
+        cols[0].data, cols[0].null_bitmap, cols[0].length, cols[0].elem_size, cols[0].type, cols[0].flags = dk, dkb, n, 8, abi.I64, abi.COL_DEVICE
+        cols[1].data, cols[1].offsets, cols[1].null_bitmap, cols[1].length, cols[1].elem_size, cols[1].type, cols[1].flags = dd, do, db, n, -1, abi.BYTES, abi.COL_DEVICE
+        _lib.check(lib.tsq_sort_push(h, cols, 2, n), h)
+        _lib.check(lib.tsq_sort_finish(h), h)
+        vb, nr = (C.c_int64 * 2)(), C.c_int64(0)
+        _lib.check(lib.tsq_sort_peek(h, n, C.byref(nr), vb, 2), h)
+        assert nr.value == n and vb[0] == 0 and vb[1] == nbytes
+        out = (abi.Col * 2)()
+        out[0].data, out[0].null_bitmap, out[0].length, out[0].elem_size, out[0].type, out[0].flags = okd, okb, n, 8, abi.I64, abi.COL_DEVICE
+        out[1].data, out[1].offsets, out[1].null_bitmap, out[1].length, out[1].elem_size, out[1].type, out[1].flags = od, oo, ob, n, -1, abi.BYTES, abi.COL_DEVICE
+        m, eos = C.c_int64(0), C.c_int32(0)
+        _lib.check(lib.tsq_sort_pull(h, out, 2, n, C.byref(m), C.byref(eos)), h)
+        assert m.value == n
+        offs, data, bits = np.zeros(n + 1, np.int64), np.zeros(max(nbytes, 1), np.uint8), np.zeros(n // 8 + 8, np.uint8)
+        ctx.d2h(offs, oo)
+        ctx.d2h(data, od)
+        ctx.d2h(bits, ob)
+        nn = np.unpackbits(bits, bitorder="little")[:n].astype(bool)
+        got = [bytes(data[offs[r]:offs[r + 1]]) if nn[r] else None for r in range(n)]
+        assert offs[0] == 0 and offs[n] == nbytes and got == want.columns[0].values()
+    finally:
+        lib.tsq_sort_destroy(h)
+        for p in (dk, dkb, dd, do, db, od, oo, ob, okd, okb):
+            ctx.free(p)

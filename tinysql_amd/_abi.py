@@ -199,6 +199,7 @@ SIGNATURES = {
     "tsq_sort_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),
     "tsq_sort_finish": (C.c_int32, [P]),
     "tsq_sort_pull": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "tsq_sort_peek": (C.c_int32, [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     "tsq_sort_stats": (C.c_int32, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "tsq_sort_cancel": (C.c_int32, [P]),
     "tsq_sort_destroy": (None, [P]),

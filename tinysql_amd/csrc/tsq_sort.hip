@@ -329,6 +329,8 @@ __global__ void __launch_bounds__(256) k_gather_rows(GatherRowsArgs a) {
         if (a.key_img && c == a.key_col) {  // I64: image ^ sign bit, U64: the image itself (tsq_sort_image.h), DESC inverted
             const uint64_t flip = (a.key_desc ? ~0ull : 0ull) ^ a.key_flip;
             for (int i = 0; i < n; i++) ((uint64_t*)a.dst[c])[r0 + i] = (nn >> i) & 1 ? (a.key_img[r0 + i] ^ flip) : 0ull;
+        } else if (a.es[c] == 0) {
+            // a var-len column: its bytes are gathered by k_sort_var_* (lengths -> scan -> copy); only the NULL flags here
         } else if (a.es[c] == 8) {
             uint64_t v[8];
 #pragma unroll
@@ -341,6 +343,53 @@ __global__ void __launch_bounds__(256) k_gather_rows(GatherRowsArgs a) {
             for (int i = 0; i < n; i++) ((uint32_t*)a.dst[c])[r0 + i] = v[i];
         }
         a.dst_bitmap[c][g] = (uint8_t)nn;
+    }
+}
+
+// K14g — var-len (string) PAYLOAD columns of the ordered rows (Chunk.AppendRow of a var-len cell, util/chunk/chunk.go:334-356;
+// ORDER BY keys are fixed width): the lengths of the cells in output order, their exclusive scan = the output offsets
+// (tsq_launch_scan64), then the bytes — one cell per lane, or one per wave when the cells are long.
+struct SortVarArgs {
+    const uint32_t* idx;
+    int64_t rows;
+    const int64_t* src_offs;
+    const uint8_t* src_data;
+    const uint8_t* src_nulls;
+    int64_t* out_offs;  // [rows + 1]
+    uint8_t* out_data;
+};
+__global__ void __launch_bounds__(256) k_sort_var_len(SortVarArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t id = a.idx[r];
+        const bool ok = !a.src_nulls || ((a.src_nulls[id >> 3] >> (id & 7)) & 1);
+        a.out_offs[r] = ok ? a.src_offs[id + 1] - a.src_offs[id] : 0;  // a NULL cell has no bytes
+    }
+}
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_sort_var_copy(SortVarArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    const int64_t first = WAVE ? gtid >> 6 : gtid, step = WAVE ? nthr >> 6 : nthr;
+    for (int64_t r = first; r < a.rows; r += step) {
+        const int64_t n = a.out_offs[r + 1] - a.out_offs[r];
+        if (n == 0) continue;
+        const uint8_t* s = a.src_data + a.src_offs[a.idx[r]];
+        uint8_t* d = a.out_data + a.out_offs[r];
+        if (!WAVE) {
+            for (int64_t i = 0; i < n; i++) d[i] = s[i];
+        } else {  // head up to an 8-byte boundary of the destination, then 8 bytes per lane, then the tail
+            int64_t head = (8 - ((uintptr_t)d & 7)) & 7;
+            head = head < n ? head : n;
+            if (lane < head) d[lane] = s[lane];
+            const int64_t words = (n - head) >> 3;
+            for (int64_t w = lane; w < words; w += 64) {
+                uint64_t x;
+                memcpy(&x, s + head + w * 8, 8);  // the source is not aligned with the destination
+                *reinterpret_cast<uint64_t*>(d + head + w * 8) = x;
+            }
+            const int64_t done = head + words * 8;
+            if (done + lane < n) d[done + lane] = s[done + lane];
+        }
     }
 }
 
@@ -358,7 +407,11 @@ struct tsq_sort {
     int64_t n = 0, first = 0, last = 0, cursor = 0;  // output rows [first, last) of the sorted order
     DevBuf img[2], idx[2], hist, totals, count8;
     int cur = 0;                                       // which of idx[] holds the final row ids
-    std::vector<DevBuf> odata, obm;                    // gather targets for host pulls
+    std::vector<DevBuf> odata, obm, ooffs;             // gather targets for host pulls (ooffs: offsets of var-len columns)
+    std::vector<DevBuf> voffs;                         // var-len columns: the offsets tsq_sort_peek computed for the next pull
+    std::vector<int64_t> vbytes;                       // ... and their data bytes
+    int64_t peek_cursor = -1, peek_rows = 0;
+    DevBuf scratch;
     int32_t passes = 0, passes_skipped = 0;
     bool key_img_kept = false;
     int64_t rows_sorted = 0;                           // rows that went through the radix passes (TopN: the selected candidates)
@@ -374,13 +427,14 @@ tsq_status sort_cancelled(tsq_sort* s) {
 tsq_status sort_flush(tsq_sort* s) {
     HostStage& sg = s->stage;
     if (sg.staged == 0) return TSQ_OK;
-    DevBuf tmp;
+    DevBuf tmp, tmp_offs;
     for (size_t c = 0; c < s->cols.size(); c++) {
-        tsq_status st = tsq_col_append(s->ctx, &s->hdr, s->cols[c], sg.data[c].p, sg.bitmap((int)c), sg.staged, false, tmp);
-        if (st != TSQ_OK) { tmp.release(); return st; }
+        tsq_status st = sg.append_to(s->ctx, &s->hdr, (int)c, s->cols[c], tmp, tmp_offs);
+        if (st != TSQ_OK) { tmp.release(); tmp_offs.release(); return st; }
     }
     hipError_t e = hipStreamSynchronize(s->ctx->stream);  // staging memory is reused
     tmp.release();
+    tmp_offs.release();
     sg.reset();
     if (e != hipSuccess) return tsq_fail(&s->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return TSQ_OK;
@@ -404,6 +458,40 @@ tsq_status sort_pass(tsq_sort* s, SortArgs& a, int digit) {
     s->passes++;
     return TSQ_OK;
 }
+// offsets (and data bytes) of the var-len columns for the next n output rows, cached for the pull that follows a peek
+tsq_status sort_var_offsets(tsq_sort* s, int64_t n) {
+    if (s->peek_cursor == s->cursor && s->peek_rows == n) return TSQ_OK;
+    tsq_ctx* ctx = s->ctx;
+    tsq_handle_hdr* h = &s->hdr;
+    const int n_cols = s->cfg.n_cols;
+    s->voffs.resize(n_cols);
+    s->vbytes.assign(n_cols, 0);
+    int slot = 0;
+    for (int c = 0; c < n_cols; c++) {
+        if (s->cfg.col_types[c] != TSQ_BYTES) continue;
+        TSQ_TRY(s->voffs[c].reserve(ctx, h, ((size_t)n + 1) * 8 + 64));
+        SortVarArgs va;
+        memset(&va, 0, sizeof va);
+        va.idx = s->idx[s->cur].as<uint32_t>() + s->cursor;
+        va.rows = n;
+        va.src_offs = s->cols[c].offs.as<int64_t>();
+        va.src_nulls = s->cols[c].has_nulls ? s->cols[c].nulls.as<uint8_t>() : nullptr;
+        va.out_offs = s->voffs[c].as<int64_t>();
+        hipLaunchKernelGGL(k_sort_var_len, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, va);
+        TSQ_HIP(h, hipGetLastError());
+        TSQ_TRY(tsq_launch_scan64(ctx, h, va.out_offs, n, s->scratch));
+        if (slot >= 8) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "more than 8 var-len columns in one sort");
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48 + slot, va.out_offs + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        slot++;
+    }
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    slot = 0;
+    for (int c = 0; c < n_cols; c++)
+        if (s->cfg.col_types[c] == TSQ_BYTES) s->vbytes[c] = (int64_t)ctx->pinned[48 + slot++];
+    s->peek_cursor = s->cursor;
+    s->peek_rows = n;
+    return TSQ_OK;
+}
 }  // namespace
 
 TSQ_API tsq_status tsq_sort_create(tsq_ctx* ctx, const tsq_sort_cfg* cfg, tsq_sort** out) {
@@ -414,9 +502,11 @@ TSQ_API tsq_status tsq_sort_create(tsq_ctx* ctx, const tsq_sort_cfg* cfg, tsq_so
     if (cfg->n_cols < 1 || cfg->n_cols > TSQ_MAX_COLS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..16 columns supported");
     if (cfg->n_keys < 1 || cfg->n_keys > TSQ_MAX_KEYS) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "1..4 ORDER BY items supported");
     for (int c = 0; c < cfg->n_cols; c++)
-        if (cfg->col_types[c] < TSQ_I64 || cfg->col_types[c] > TSQ_F64) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "var-len column: fall back to the Go operator");
-    for (int k = 0; k < cfg->n_keys; k++)
+        if (cfg->col_types[c] < TSQ_I64 || cfg->col_types[c] > TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_INVALID, "unknown column type");
+    for (int k = 0; k < cfg->n_keys; k++) {
         if (cfg->key_col[k] < 0 || cfg->key_col[k] >= cfg->n_cols) return tsq_fail(ch, TSQ_ERR_INVALID, "ORDER BY column index out of range");
+        if (cfg->col_types[cfg->key_col[k]] == TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "ORDER BY a var-len column: fall back to the Go operator");
+    }
     if (cfg->limit_offset < 0) return tsq_fail(ch, TSQ_ERR_INVALID, "negative offset");
     std::unique_ptr<tsq_sort> s(new tsq_sort());
     s->hdr.magic = TSQ_MAGIC_SORT;
@@ -443,12 +533,15 @@ TSQ_API tsq_status tsq_sort_push(tsq_sort* s, const tsq_col* cols, int32_t n_col
     if (s->cols[0].rows + s->stage.staged + nrows >= 0xfffffff0LL) return tsq_fail(&s->hdr, TSQ_ERR_UNSUPPORTED, "more than 2^32 rows per GPU");
     if (dev) {
         TSQ_TRY(sort_flush(s));
-        DevBuf tmp;
+        DevBuf tmp, tmp_offs;
         for (int c = 0; c < n_cols; c++) {
-            tsq_status st = tsq_col_append(s->ctx, &s->hdr, s->cols[c], cols[c].data, cols[c].null_bitmap, nrows, true, tmp);
-            if (st != TSQ_OK) { tmp.release(); return st; }
+            tsq_status st = cols[c].type == TSQ_BYTES
+                                ? tsq_col_append_varlen(s->ctx, &s->hdr, s->cols[c], cols[c].data, cols[c].offsets, cols[c].null_bitmap, nrows, true, tmp, tmp_offs)
+                                : tsq_col_append(s->ctx, &s->hdr, s->cols[c], cols[c].data, cols[c].null_bitmap, nrows, true, tmp);
+            if (st != TSQ_OK) { tmp.release(); tmp_offs.release(); return st; }
         }
         tmp.release();
+        tmp_offs.release();
         return TSQ_OK;
     }
     if (s->stage.cap == 0) TSQ_TRY(s->stage.init(&s->hdr, n_cols, s->cfg.col_types, 1 << 20));
@@ -650,20 +743,24 @@ TSQ_API tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols,
         g.key_desc = s->cfg.key_desc[0] ? 1 : 0;
         g.key_flip = s->cfg.col_types[g.key_col] == TSQ_I64 ? 0x8000000000000000ULL : 0ull;
     }
-    if (!odev) { s->odata.resize(n_cols); s->obm.resize(n_cols); }
+    if (!odev) { s->odata.resize(n_cols); s->obm.resize(n_cols); s->ooffs.resize(n_cols); }
+    bool any_var = false;
     for (int c = 0; c < n_cols; c++) {
-        if (!out_cols[c].data || !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "pull: out columns need data and null_bitmap buffers");
+        const bool var = s->cfg.col_types[c] == TSQ_BYTES;
+        any_var = any_var || var;
+        if (!out_cols[c].null_bitmap || (var ? !out_cols[c].offsets : !out_cols[c].data))
+            return tsq_fail(h, TSQ_ERR_INVALID, "pull: out columns need data and null_bitmap buffers (a var-len column: offsets, and data for the bytes tsq_sort_peek announced)");
         if (((out_cols[c].flags & TSQ_COL_DEVICE) != 0) != odev) return tsq_fail(h, TSQ_ERR_INVALID, "pull: mixed host/device outputs");
-        g.es[c] = tsq_elem_size(s->cfg.col_types[c]);
+        g.es[c] = var ? 0 : tsq_elem_size(s->cfg.col_types[c]);
         g.src[c] = s->cols[c].data.p;
         g.src_nulls[c] = s->cols[c].has_nulls ? s->cols[c].nulls.as<uint8_t>() : nullptr;
         if (odev) {
             g.dst[c] = out_cols[c].data;
             g.dst_bitmap[c] = out_cols[c].null_bitmap;
         } else {
-            TSQ_TRY(s->odata[c].reserve(ctx, h, (size_t)n * g.es[c] + 64));
+            if (!var) TSQ_TRY(s->odata[c].reserve(ctx, h, (size_t)n * g.es[c] + 64));
             TSQ_TRY(s->obm[c].reserve(ctx, h, tsq_bitmap_bytes(n) + 64));
-            g.dst[c] = s->odata[c].p;
+            g.dst[c] = var ? nullptr : s->odata[c].p;
             g.dst_bitmap[c] = s->obm[c].as<uint8_t>();
         }
     }
@@ -671,18 +768,71 @@ TSQ_API tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols,
     const int gx = (int)std::min<int64_t>((groups + 255) / 256, (int64_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(k_gather_rows, dim3(gx, n_cols), dim3(256), 0, ctx->stream, g);
     TSQ_HIP(h, hipGetLastError());
+    // var-len payload columns: the offsets of these n rows (computed now, or by the tsq_sort_peek that sized the caller's buffers)
+    if (any_var) TSQ_TRY(sort_var_offsets(s, n));
+    for (int c = 0; c < n_cols && any_var; c++) {
+        if (s->cfg.col_types[c] != TSQ_BYTES) continue;
+        SortVarArgs va;
+        va.idx = g.idx;
+        va.rows = n;
+        va.src_offs = s->cols[c].offs.as<int64_t>();
+        va.src_data = s->cols[c].data.as<uint8_t>();
+        va.src_nulls = g.src_nulls[c];
+        va.out_offs = s->voffs[c].as<int64_t>();
+        const int64_t nbytes = s->vbytes[c];
+        if (nbytes > 0 && !out_cols[c].data) return tsq_fail(h, TSQ_ERR_INVALID, "pull: a var-len column needs a data buffer (tsq_sort_peek tells its size)");
+        if (odev) {
+            va.out_data = (uint8_t*)out_cols[c].data;
+            TSQ_HIP(h, hipMemcpyAsync(out_cols[c].offsets, va.out_offs, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            TSQ_TRY(s->odata[c].reserve(ctx, h, (size_t)nbytes + 64));
+            va.out_data = s->odata[c].as<uint8_t>();
+        }
+        if (nbytes > 0) {
+            if (nbytes / n > 32) hipLaunchKernelGGL(k_sort_var_copy<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, va);
+            else hipLaunchKernelGGL(k_sort_var_copy<false>, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, va);
+            TSQ_HIP(h, hipGetLastError());
+        }
+        if (!odev) {
+            TSQ_HIP(h, hipMemcpyAsync(out_cols[c].offsets, va.out_offs, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (nbytes > 0) TSQ_HIP(h, hipMemcpyAsync(out_cols[c].data, va.out_data, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
     if (!odev)
         for (int c = 0; c < n_cols; c++) {
-            TSQ_HIP(h, hipMemcpyAsync(out_cols[c].data, g.dst[c], (size_t)n * g.es[c], hipMemcpyDeviceToHost, ctx->stream));
+            if (g.es[c]) TSQ_HIP(h, hipMemcpyAsync(out_cols[c].data, g.dst[c], (size_t)n * g.es[c], hipMemcpyDeviceToHost, ctx->stream));
             TSQ_HIP(h, hipMemcpyAsync(out_cols[c].null_bitmap, g.dst_bitmap[c], tsq_bitmap_bytes(n), hipMemcpyDeviceToHost, ctx->stream));
         }
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    s->peek_cursor = -1;
     for (int c = 0; c < n_cols; c++) {
         out_cols[c].length = n;
         out_cols[c].type = s->cfg.col_types[c];
-        out_cols[c].elem_size = g.es[c];
+        out_cols[c].elem_size = g.es[c] ? g.es[c] : -1;
     }
     s->cursor += n;
+    *nrows_out = n;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_sort_peek(tsq_sort* s, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_out, int32_t n_cols) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(s, TSQ_MAGIC_SORT));
+    if (!s || s->hdr.magic != TSQ_MAGIC_SORT) return TSQ_ERR_INVALID;
+    if (!nrows_out || !bytes_out) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "NULL out pointer");
+    *nrows_out = 0;
+    TSQ_TRY(sort_cancelled(s));
+    if (!s->finished) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "peek before finish");
+    if (n_cols != s->cfg.n_cols) return tsq_fail(&s->hdr, TSQ_ERR_INVALID, "peek: column count must equal the input schema");
+    for (int c = 0; c < n_cols; c++) bytes_out[c] = 0;
+    const int64_t n = std::min<int64_t>(cap_rows, s->last - s->cursor);
+    if (n <= 0) return TSQ_OK;
+    bool any_var = false;
+    for (int c = 0; c < n_cols; c++) any_var = any_var || s->cfg.col_types[c] == TSQ_BYTES;
+    if (any_var) {
+        TSQ_HIP(&s->hdr, hipSetDevice(s->ctx->device));
+        TSQ_TRY(sort_var_offsets(s, n));
+        for (int c = 0; c < n_cols; c++) bytes_out[c] = s->vbytes[c];
+    }
     *nrows_out = n;
     return TSQ_OK;
 }
@@ -715,6 +865,9 @@ TSQ_API void tsq_sort_destroy(tsq_sort* s) {
     s->count8.release();
     for (auto& b : s->odata) b.release();
     for (auto& b : s->obm) b.release();
+    for (auto& b : s->ooffs) b.release();
+    for (auto& b : s->voffs) b.release();
+    s->scratch.release();
     s->hdr.magic = 0;
     delete s;
 }

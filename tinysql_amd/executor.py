@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _abi as abi
 from . import _lib
-from .chunk import Chunk, Column, chunk_from_buffers, make_cols, np_dtype, out_buffers
+from .chunk import Chunk, Column, StrColumn, chunk_from_buffers, make_cols, np_dtype, out_buffers
 from .expression import CompiledExpr
 
 
@@ -39,7 +39,7 @@ class Executor:
             c.Close()
 
     def empty(self):
-        return Chunk([Column(tp, np.zeros(0, np_dtype(tp))) for tp in self.types])
+        return Chunk([StrColumn([]) if tp == abi.BYTES else Column(tp, np.zeros(0, np_dtype(tp))) for tp in self.types])
 
 
 def drain(exe):
@@ -378,7 +378,12 @@ class SortExec(Executor):
             _lib.check(self.lib.tsq_sort_finish(self.h), self.h)
             self.fetched = True
         keep = []
-        out, bufs = out_buffers(self.types, self.max_chunk_size, keep)
+        var_bytes = None
+        if abi.BYTES in self.types:  # how many data bytes the var-len columns of the next chunk need
+            vb, nr = (C.c_int64 * len(self.types))(), C.c_int64(0)
+            _lib.check(self.lib.tsq_sort_peek(self.h, self.max_chunk_size, C.byref(nr), vb, len(self.types)), self.h)
+            var_bytes = list(vb)
+        out, bufs = out_buffers(self.types, self.max_chunk_size, keep, var_bytes=var_bytes)
         n, eos = C.c_int64(0), C.c_int32(0)
         _lib.check(self.lib.tsq_sort_pull(self.h, out, len(self.types), self.max_chunk_size, C.byref(n), C.byref(eos)), self.h)
         return chunk_from_buffers(self.types, bufs, n.value) if n.value else self.empty()
