@@ -909,6 +909,8 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     uint32_t bits = 0;
     if (!low) {
         // H: partitions small enough that their groups half-fill one LDS table, at least 256 of them (parallelism)
+        // (2^11 partitions — tables 1/8 full, shorter walks — were measured: k_agg_lds 0.66 -> 0.64 ms per 1e8 rows, but the partition
+        // kernel with a payload column writes 32-byte runs then and goes from 0.76 to 0.83 ms: kept at 2^10)
         bits = 8;
         while (bits < 10 && ((double)groups_est * 2.2 / (double)S) > (double)(1u << bits)) bits++;
         if (((double)groups_est * 1.3 / (double)S) > (double)(1u << bits)) return TSQ_OK;  // too many groups for LDS tables

@@ -175,6 +175,8 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
             return;
         }
         uint32_t slot = HASHED_TAGS ? ((uint32_t)tag & (S - 1)) : af_slot_hash(tag, LOG2S);
+        // (testing the home slot once before the loop — "the group is usually already there" — was measured and dropped: 0.66 ->
+        // 0.71 ms per 1e8 rows; nearly every wave has a lane that needs the loop anyway, and the extra LDS read is not free)
         bool found = false;
         for (int probe = 0; probe < 64 && !found; probe++) {
             unsigned long long cur = s_key[slot];
