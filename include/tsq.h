@@ -428,6 +428,20 @@ tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_byt
                            const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out,
                            int64_t* bytes_consumed);
 
+/* The same for a response whose CHUNKS are known, var-len columns included.  The storage side cuts the rows of a response into
+ * tipb.Chunks of 64 rows (cop_handler_dag.go:510-519) — selectResult walks them one after the other (select_result.go:102-155).
+ * Chunk k = bytes [chunk_offsets[k], chunk_offsets[k+1]) of rows_data (n_chunks + 1 non-decreasing entries); every chunk holds whole
+ * rows.  col_types may contain TSQ_BYTES: a compact-bytes datum (flag 2: varint length + bytes, util/codec/bytes.go:141-160 — what
+ * a varchar / blob column arrives as) becomes a var-len cell; such an output column needs offsets[cap_rows + 1] and a data buffer of
+ * n_bytes bytes (a cell is a piece of the response).  All rows of all chunks are decoded: if they exceed cap_rows nothing is written
+ * and the call returns TSQ_ERR_INVALID with *nrows_out = the rows needed.  Errors as for tsq_rows_decode, decided by the first
+ * offending value in stream order (*nrows_out = the complete rows before it, already in out_cols); additionally TSQ_ERR_INVALID
+ * "datum kind does not match the column type" (a bytes datum for a number column or the reverse) and TSQ_ERR_UNSUPPORTED for a
+ * memcomparable bytes datum (flag 1: index keys). */
+tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks,
+                                  uint32_t data_flags, int32_t n_cols, const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows,
+                                  int64_t* nrows_out);
+
 /* ---------------------------------------------------------------- stored rows (rowcodec v2) -> columns (SURVEY.md §8 f, rank 4)
  * Replaces the per-row loop around rowcodec.ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238; row.fromBytes /
  * findColID / getData, util/rowcodec/row.go:37-150) — equivalently the storage-side chain BytesDecoder.DecodeToBytes

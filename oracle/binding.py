@@ -84,6 +84,8 @@ def load():
     lib.orc_decode_rows.restype = C.c_int32
     lib.orc_decode_rows.argtypes = [P, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.orc_decode_rows_chunks.restype = P
+    lib.orc_decode_rows_chunks.argtypes = [P, C.c_int64, P, C.c_int64, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.orc_row_compare.restype = C.c_int32
     lib.orc_row_compare.argtypes = [C.POINTER(abi.Col), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64]
     lib.orc_sort_rows.restype = None
@@ -310,7 +312,8 @@ def encode_rows(chunk, comparable=False):
     keep = []
     cols = make_cols(chunk.columns, keep)
     n = chunk.NumRows()
-    out = np.zeros(max(1, n * len(chunk.columns) * 11 + 16), np.uint8)
+    var = sum(int(c.offsets[-1]) for c in chunk.columns if c.tp == abi.BYTES and len(c.offsets))
+    out = np.zeros(max(1, n * len(chunk.columns) * 11 + 16 + var), np.uint8)
     got = lib.orc_encode_rows(cols, len(chunk.columns), n, 1 if comparable else 0, out.ctypes.data_as(C.c_void_p), out.size)
     assert got >= 0
     return out[:got].copy()
@@ -332,6 +335,18 @@ def decode_rows(data, types, cap_rows):
 
 
 # ---- SortExec / TopNExec row order (oracle/sort_rows.cpp)
+def decode_rows_chunks(data, chunk_offsets, types):
+    """the chunks of a response one after the other (var-len columns included) -> (status, Chunk of the complete rows before an error)"""
+    lib = load()
+    raw = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data, dtype=np.uint8)
+    offs = np.ascontiguousarray(chunk_offsets, dtype=np.int64)
+    tp = (C.c_int32 * len(types))(*types)
+    st = C.c_int32(0)
+    buf = raw if raw.size else np.zeros(1, np.uint8)
+    res = lib.orc_decode_rows_chunks(buf.ctypes.data_as(C.c_void_p), raw.size, offs.ctypes.data_as(C.c_void_p), len(offs) - 1, len(types), tp, C.byref(st))
+    return st.value, _result_to_chunk(lib, res)
+
+
 def sort_perm(chunk, key_cols, key_desc):
     """SortExec (executor/sort.go:58-131): row indices in ORDER BY order (stable: one legal outcome of sort.Slice)."""
     lib = load()

@@ -19,7 +19,10 @@
 #include <cstdint>
 #include <cstring>
 
-#include "oracle.h"
+#include <string>
+#include <vector>
+
+#include "orc_result_internal.h"
 
 namespace {
 const uint8_t NilFlag = 0, bytesFlag = 1, compactBytesFlag = 2, intFlag = 3, uintFlag = 4, floatFlag = 5, varintFlag = 8, uvarintFlag = 9;
@@ -107,6 +110,17 @@ int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int3
             if (n + 11 > cap) return -1;
             const tsq_col& col = cols[c];
             if (is_null(col, r)) { out[n++] = NilFlag; continue; }
+            if (col.type == TSQ_BYTES) {  // encodeBytes (codec.go:101-109): comparable -> bytesFlag + EncodeBytes (not built here);
+                                          // otherwise compactBytesFlag + EncodeCompactBytes = varint(len) + the bytes (bytes.go:141-148)
+                if (comparable) return -1;
+                const int64_t lo = col.offsets[r], len = col.offsets[r + 1] - lo;
+                if (n + 11 + len > cap) return -1;
+                out[n++] = compactBytesFlag;
+                n += (int64_t)put_varint(out + n, len);
+                memcpy(out + n, (const uint8_t*)col.data + lo, (size_t)len);
+                n += len;
+                continue;
+            }
             switch (col.type) {
                 case TSQ_I64: {
                     const int64_t v = ((const int64_t*)col.data)[r];
@@ -212,5 +226,85 @@ int32_t orc_decode_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, co
         *consumed = pos;
     }
     return 0;
+}
+
+/* selectResult over the chunks of a response (select_result.go:102-155): every chunk is decoded to its end with DecodeOne
+ * (codec.go:623-690), bytes datums included (compactBytesFlag -> DecodeCompactBytes, bytes.go:150-160 -> chk.AppendBytes).  Status as
+ * orc_decode_rows, plus 6 = a datum whose kind cannot go into the column (a string for a number column or the reverse), 5 = a
+ * memcomparable bytes datum (bytesFlag).  The result holds the complete rows before the first offending value. */
+orc_result* orc_decode_rows_chunks(const uint8_t* data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks, int32_t n_cols,
+                                   const int32_t* types, int32_t* status) {
+    orc_result* res = new orc_result();
+    res->cols.resize((size_t)n_cols);
+    for (int c = 0; c < n_cols; c++) res->cols[c].type = types[c];
+    *status = 0;
+    for (int64_t k = 0; k < n_chunks; k++) {
+        int64_t pos = chunk_offsets[k];
+        const int64_t end = chunk_offsets[k + 1];
+        if (pos < 0 || end < pos || end > n_bytes) { *status = 1; return res; }
+        while (pos < end) {
+            std::vector<uint64_t> bits((size_t)n_cols, 0);
+            std::vector<uint8_t> nn((size_t)n_cols, 0);
+            std::vector<std::pair<const uint8_t*, int64_t>> cell((size_t)n_cols, {nullptr, 0});
+            for (int c = 0; c < n_cols; c++) {
+                if (end - pos < 1) { *status = 1; return res; }  // codec.go:624-626
+                const uint8_t flag = data[pos++];
+                const uint8_t* b = data + pos;
+                const int64_t left = end - pos;
+                int kind = 0;  // 0 null 1 int 2 uint 3 real 4 bytes
+                switch (flag) {
+                    case intFlag: if (left < 8) { *status = 2; return res; } bits[c] = get_be64(b) ^ signMask; pos += 8; kind = 1; break;
+                    case uintFlag: if (left < 8) { *status = 2; return res; } bits[c] = get_be64(b); pos += 8; kind = 2; break;
+                    case floatFlag: {
+                        if (left < 8) { *status = 2; return res; }
+                        const double f = decodeCmpUintToFloat(get_be64(b));
+                        memcpy(&bits[c], &f, 8);
+                        pos += 8;
+                        kind = 3;
+                        break;
+                    }
+                    case varintFlag:
+                    case uvarintFlag:
+                    case compactBytesFlag: {
+                        uint64_t ux;
+                        const int kb = uvarint(b, left, &ux);
+                        if (kb < 0) { *status = 3; return res; }
+                        if (kb == 0) { *status = 2; return res; }
+                        pos += kb;
+                        int64_t x = (int64_t)(ux >> 1);
+                        if (ux & 1) x = ~x;
+                        if (flag == uvarintFlag) { bits[c] = ux; kind = 2; }
+                        else if (flag == varintFlag) { bits[c] = (uint64_t)x; kind = 1; }
+                        else {
+                            if (x < 0 || end - pos < x) { *status = 2; return res; }  // "insufficient bytes to decode value, expected length"
+                            cell[c] = {data + pos, x};
+                            pos += x;
+                            kind = 4;
+                        }
+                        break;
+                    }
+                    case NilFlag: break;
+                    case bytesFlag: *status = 5; return res;
+                    default: *status = 4; return res;
+                }
+                if (kind != 0 && (types[c] == TSQ_BYTES) != (kind == 4)) { *status = 6; return res; }
+                nn[c] = kind != 0;
+                if (kind != 0 && types[c] == TSQ_F32) {
+                    float f32;
+                    if (kind == 3) { double f; memcpy(&f, &bits[c], 8); f32 = (float)f; }
+                    else memcpy(&f32, &bits[c], 4);
+                    uint32_t w;
+                    memcpy(&w, &f32, 4);
+                    bits[c] = w;
+                }
+            }
+            for (int c = 0; c < n_cols; c++) {
+                if (types[c] == TSQ_BYTES && nn[c]) res->cols[c].append_bytes(cell[c].first, (size_t)cell[c].second);
+                else res->cols[c].append_raw(bits[c], nn[c] != 0);
+            }
+            res->rows++;
+        }
+    }
+    return res;
 }
 }

@@ -112,6 +112,10 @@ int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int3
 int32_t orc_decode_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, const int32_t* types, int64_t cap_rows, void** out_data,
                         uint8_t** out_notnull, int64_t* nrows_out, int64_t* consumed);
 
+/* the chunks of a response one after the other, bytes datums included (var-len columns) */
+orc_result* orc_decode_rows_chunks(const uint8_t* data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks, int32_t n_cols,
+                                   const int32_t* types, int32_t* status);
+
 /* ---- stored rows, rowcodec v2 (rowcodec.cpp; SURVEY.md §8 f rank 4) */
 /* Encoder.Encode (util/rowcodec/encoder.go:34-194) of every row of a fixed-width chunk (+ an optional KindBytes pad column) */
 int64_t orc_rowcodec_encode(const tsq_col* cols, const int64_t* col_ids, int32_t n_cols, int64_t nrows, int64_t pad_col_id, const int64_t* pad_len,

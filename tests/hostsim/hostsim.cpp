@@ -462,3 +462,115 @@ extern "C" int32_t sim_rowkeys_encode(int64_t table_id, const int64_t* handles, 
     }
     return 0;
 }
+
+// ---- response chunks -> columns, var-len included (tsq_decode_dp.h: tsq_decc_*): a CPU walk-through of k_decc_count / k_decc_emit
+// (tsq_decodec.hip): one "lane" per chunk, the 12-byte fetch built from aligned 8-byte words of a buffer whose surroundings are
+// garbage (bytes at or past the chunk end must read as zero, words that hold no byte of the response are never touched), the error
+// word, the rows-per-chunk scan, and the (position, length) references of string cells.
+namespace {
+struct SimFetch {
+    const uint8_t* buf;   // the response at buf[guard + phase ...], garbage around it
+    int64_t guard, phase, n_bytes;
+    int64_t bad_touch = 0;
+    uint64_t word(int64_t abs_at) {  // aligned 8-byte word at absolute buffer offset abs_at
+        const int64_t lo = guard + phase, hi = lo + n_bytes;
+        if (abs_at + 8 <= lo || abs_at >= hi) bad_touch++;  // a word without any response byte
+        uint64_t w;
+        memcpy(&w, buf + abs_at, 8);
+        return w;
+    }
+    void fetch12(int64_t p, int64_t end, uint32_t* b0, uint32_t* b1, uint32_t* b2) {
+        const int64_t addr = guard + phase + p, a = addr & ~(int64_t)7, lim = guard + phase + n_bytes;
+        const uint32_t sh = (uint32_t)(addr & 7) * 8u;
+        const uint64_t w0 = word(a);
+        const uint64_t w1 = a + 8 < lim ? word(a + 8) : 0ull;
+        const uint64_t w2 = a + 16 < lim ? word(a + 16) : 0ull;
+        uint64_t lo = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
+        uint64_t hi = sh ? (w1 >> sh) | (w2 << (64u - sh)) : w1;
+        const int64_t valid = end - p;
+        if (valid < 8) { lo &= (1ull << (8 * valid)) - 1; hi = 0; }
+        else if (valid < 12) hi &= (1ull << (8 * (valid - 8))) - 1;
+        *b0 = (uint32_t)lo;
+        *b1 = (uint32_t)(lo >> 32);
+        *b2 = (uint32_t)hi;
+    }
+};
+}  // namespace
+// buf: `guard` garbage bytes, `phase` more (the alignment of the response pointer: guard is a multiple of 8), the response, garbage.
+// out_bits[c][row] (8 bytes per row: the stored value, or for a TSQ_BYTES column the cell's absolute position in the response),
+// out_len[c][row] (TSQ_BYTES: the cell's length), out_nn[c][row].  Returns the error word (~0: none); *rows_out = rows handed over.
+extern "C" uint64_t sim_rows_decode_chunks(const uint8_t* buf, int64_t guard, int64_t phase, int64_t n_bytes, const int64_t* chunk_offs, int64_t n_chunks,
+                                           int32_t n_cols, const int32_t* types, uint64_t** out_bits, int64_t** out_len, uint8_t** out_nn, int64_t cap_rows,
+                                           int64_t* rows_out, int64_t* bad_touch_out) {
+    SimFetch F{buf, guard, phase, n_bytes};
+    std::vector<int64_t> rows((size_t)n_chunks + 1, 0);
+    uint64_t err = ~0ull;
+    auto range_ok = [&](int64_t k, int64_t* lo, int64_t* hi) { *lo = chunk_offs[k]; *hi = chunk_offs[k + 1]; return *lo >= 0 && *hi >= *lo && *hi <= n_bytes; };
+    for (int64_t k = 0; k < n_chunks; k++) {  // k_decc_count
+        int64_t lo, hi, vals = 0;
+        int code = DEC_OK;
+        if (!range_ok(k, &lo, &hi)) code = DEC_ROW_CUT;
+        else {
+            int32_t col = 0;
+            for (int64_t p = lo; p < hi;) {
+                uint32_t b0, b1, b2;
+                F.fetch12(p, hi, &b0, &b1, &b2);
+                tsq_decc_val v;
+                code = tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v);
+                uint64_t bits;
+                if (code == DEC_OK && !tsq_decc_store(types[col], v, &bits)) code = DEC_KIND_MISMATCH;
+                if (code != DEC_OK) break;
+                p += (int64_t)v.len;
+                vals++;
+                col = col + 1 == n_cols ? 0 : col + 1;
+            }
+            if (code == DEC_OK && vals % n_cols != 0) code = DEC_ROW_CUT;
+        }
+        rows[(size_t)k] = vals / n_cols;
+        if (code != DEC_OK) {
+            const uint64_t ord = (uint64_t)(vals < (1 << 28) - 1 ? vals : (1 << 28) - 1);
+            const uint64_t e = ((uint64_t)k << 32) | (ord << 4) | (uint64_t)code;
+            if (e < err) err = e;
+        }
+    }
+    int64_t run = 0;  // tsq_launch_scan64
+    for (int64_t k = 0; k < n_chunks; k++) { const int64_t c = rows[(size_t)k]; rows[(size_t)k] = run; run += c; }
+    rows[(size_t)n_chunks] = run;
+    int64_t total = run, err_chunk = n_chunks, err_rows = 0;
+    if (err != ~0ull) {
+        err_chunk = (int64_t)(err >> 32);
+        err_rows = rows[(size_t)err_chunk + 1] - rows[(size_t)err_chunk];
+        total = rows[(size_t)err_chunk] + err_rows;
+    }
+    *rows_out = total;
+    *bad_touch_out = F.bad_touch;
+    if (total > cap_rows) return err;
+    for (int64_t k = 0; k < n_chunks && k <= err_chunk; k++) {  // k_decc_emit
+        int64_t lo, hi;
+        if (!range_ok(k, &lo, &hi)) continue;
+        const int64_t base = rows[(size_t)k], want = k == err_chunk ? err_rows : rows[(size_t)k + 1] - base;
+        int64_t r = 0;
+        int32_t col = 0;
+        for (int64_t p = lo; p < hi && r < want;) {
+            uint32_t b0, b1, b2;
+            F.fetch12(p, hi, &b0, &b1, &b2);
+            tsq_decc_val v;
+            if (tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v) != DEC_OK) break;
+            uint64_t bits;
+            (void)tsq_decc_store(types[col], v, &bits);
+            const int64_t row = base + r;
+            if (types[col] == TSQ_BYTES) {
+                out_bits[col][row] = (uint64_t)(p + (int64_t)v.data_at);
+                out_len[col][row] = v.kind == DECV_BYTES ? (int64_t)v.bits : 0;
+            } else {
+                out_bits[col][row] = bits;
+            }
+            out_nn[col][row] = v.kind != DECV_NULL ? 1 : 0;
+            p += (int64_t)v.len;
+            col++;
+            if (col == n_cols) { col = 0; r++; }
+        }
+    }
+    *bad_touch_out = F.bad_touch;
+    return err;
+}

@@ -206,6 +206,8 @@ SIGNATURES = {
     "tsq_chunk_compact": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_rows_decode": (C.c_int32, [P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(Col), C.c_int64, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64)]),
+    "tsq_rows_decode_chunks": (C.c_int32, [P, P, C.c_int64, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(Col), C.c_int64,
+                                           C.POINTER(C.c_int64)]),
     "tsq_rowcodec_decode": (C.c_int32, [P, P, C.c_int64, P, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(RowcodecCol), C.POINTER(Col),
                                         C.POINTER(C.c_int64)]),
     "tsq_rows_encode": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.POINTER(C.c_uint32), C.c_int64, P, C.c_int64, C.c_uint32, P, C.POINTER(C.c_int64)]),

@@ -114,4 +114,99 @@ TSQ_HD int tsq_dec_value(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t len, ui
     return err;
 }
 
+// ---------------------------------------------------------------- a response CHUNK walked value by value (tsq_rows_decode_chunks)
+// tipb.SelectResponse.Chunks cut the response every 64 rows (cop_handler_dag.go:510-519): the chunks are independent byte strings,
+// so one lane walks one chunk, and a value may be of any length — a compact-bytes datum (flag 2: varint length + the bytes,
+// util/codec/bytes.go:141-160) is what a varchar / blob column arrives as.
+enum { DEC_KIND_MISMATCH = 6 };
+enum { DECV_NULL = 0, DECV_INT = 1, DECV_UINT = 2, DECV_REAL = 3, DECV_BYTES = 4 };
+
+TSQ_HD uint32_t dec_byte12(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t k) {  // byte k (0..11) of b0 | b1 << 32 | b2 << 64
+    const uint32_t w = k < 4 ? b0 : (k < 8 ? b1 : b2);
+    return (w >> (8 * (k & 3))) & 255u;
+}
+// binary.Uvarint (Go) over the bytes that follow the flag byte; `avail` of them exist.  n == 0 (the bytes run out) is
+// "insufficient bytes to decode value", n < 0 "value larger than 64 bits" (number.go:113-123)
+TSQ_HD int tsq_decc_uvarint(uint32_t b0, uint32_t b1, uint32_t b2, uint64_t avail, uint64_t* x_out, uint32_t* nb_out) {
+    uint64_t x = 0;
+    for (uint32_t i = 0;; i++) {
+        if ((uint64_t)i >= avail) return DEC_INSUFFICIENT;  // `for i, b := range buf` ends: return 0, 0
+        if (i == 10) return DEC_OVERFLOW;                   // i == MaxVarintLen64
+        const uint32_t c = dec_byte12(b0, b1, b2, 1 + i);
+        if (c < 0x80) {
+            if (i == 9 && c > 1) return DEC_OVERFLOW;
+            *x_out = x | ((uint64_t)c << (7 * i));
+            *nb_out = i + 1;
+            return DEC_OK;
+        }
+        x |= (uint64_t)(c & 0x7fu) << (7 * i);
+    }
+}
+struct tsq_decc_val {
+    uint64_t len;       // bytes of the whole value (flag included)
+    uint32_t kind;      // DECV_*
+    uint32_t data_at;   // DECV_BYTES: where the string's bytes start inside the value
+    uint64_t bits;      // the decoded number (a real: its double image); DECV_BYTES: the string's length
+};
+// Decoder.DecodeOne (util/codec/codec.go:623-690) of the value whose first 12 bytes are b0 | b1 << 32 | b2 << 64 (zero past the
+// chunk); avail = bytes from its first byte to the end of the chunk (>= 1)
+TSQ_HD int tsq_decc_value(uint32_t b0, uint32_t b1, uint32_t b2, uint64_t avail, tsq_decc_val* v) {
+    const uint32_t f = b0 & 255u;
+    v->len = 1;
+    v->kind = DECV_NULL;
+    v->data_at = 0;
+    v->bits = 0;
+    if (f == 0) return DEC_OK;  // NilFlag
+    if (f == 3 || f == 4 || f == 5) {
+        if (avail < 9) return DEC_INSUFFICIENT;  // DecodeInt / DecodeUint / DecodeFloat need 8 bytes (number.go:44-53,82-90)
+        bool isnull, real;
+        (void)tsq_dec_value(b0, b1, b2, 9, &v->bits, &isnull, &real);
+        v->len = 9;
+        v->kind = f == 3 ? DECV_INT : (f == 4 ? DECV_UINT : DECV_REAL);
+        return DEC_OK;
+    }
+    if (f == 8 || f == 9 || f == 2) {
+        uint64_t x = 0;
+        uint32_t nb = 0;
+        const int st = tsq_decc_uvarint(b0, b1, b2, avail - 1, &x, &nb);
+        if (st != DEC_OK) return st;
+        const uint64_t zz = (x >> 1) ^ (0 - (x & 1));  // binary.Varint: zig-zag
+        if (f == 9) { v->bits = x; v->kind = DECV_UINT; v->len = 1 + nb; return DEC_OK; }
+        if (f == 8) { v->bits = zz; v->kind = DECV_INT; v->len = 1 + nb; return DEC_OK; }
+        // compactBytesFlag: DecodeCompactBytes (bytes.go:150-160): `if int64(len(b)) < n` -> insufficient bytes; a negative length
+        // makes the reference slice out of range (panic): reported the same way
+        const int64_t n = (int64_t)zz;
+        if (n < 0 || (uint64_t)n > avail - 1 - nb) return DEC_INSUFFICIENT;
+        v->kind = DECV_BYTES;
+        v->data_at = 1 + nb;
+        v->bits = (uint64_t)n;
+        v->len = 1 + (uint64_t)nb + (uint64_t)n;
+        return DEC_OK;
+    }
+    return f == 1 ? DEC_VARLEN : DEC_BAD_FLAG;  // bytesFlag (memcomparable groups: index keys) keeps the Go decoder
+}
+// what column type `type` stores for a datum (appendIntToChunk / appendUintToChunk / appendFloatToChunk / AppendBytes,
+// codec.go:692-707): false = the datum's kind cannot go into that column (a string into a number column or the reverse)
+TSQ_HD bool tsq_decc_store(int32_t type, const tsq_decc_val& v, uint64_t* bits_out) {
+    *bits_out = 0;
+    if (v.kind == DECV_NULL) return true;
+    if ((type == TSQ_BYTES) != (v.kind == DECV_BYTES)) return false;
+    if (type == TSQ_BYTES) return true;
+    if (type == TSQ_F32) {
+        if (v.kind == DECV_REAL) {  // appendFloatToChunk narrows for TypeFloat
+            double d;
+            memcpy(&d, &v.bits, 8);
+            const float f32 = (float)d;
+            uint32_t w;
+            memcpy(&w, &f32, 4);
+            *bits_out = w;
+        } else {
+            *bits_out = (uint32_t)v.bits;  // an integer datum in a float column: the raw low bytes (not meaningful in the reference either)
+        }
+        return true;
+    }
+    *bits_out = v.bits;
+    return true;
+}
+
 #endif

@@ -13,6 +13,8 @@ from . import _abi as abi
 from . import _lib
 from .chunk import Chunk, Column, chunk_from_buffers, concat, np_dtype, out_buffers
 
+ROWS_PER_CHUNK = 64  # store/mockstore/mocktikv/cop_handler_dag.go:510
+
 
 def decode_rows(ctx, data, types, cap_rows):
     """host bytes -> (host Chunk, bytes consumed).  data: bytes / np.uint8 array."""
@@ -25,6 +27,30 @@ def decode_rows(ctx, data, types, cap_rows):
     return chunk_from_buffers(types, bufs, n.value), used.value
 
 
+def decode_chunks(ctx, chunks, types, cap_rows=None):
+    """the RowsData byte strings of a response's tipb.Chunks -> host Chunk, decoded on the GPU by `tsq_rows_decode_chunks` (one lane
+    per chunk; bytes datums become var-len cells).  cap_rows: rows the output buffers hold (default: 64 per chunk, the storage side's
+    cut, cop_handler_dag.go:510; the call is repeated with the reported size if a chunk holds more)."""
+    parts = [np.frombuffer(c, dtype=np.uint8) if isinstance(c, (bytes, bytearray)) else np.asarray(c, dtype=np.uint8) for c in chunks]
+    raw = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    offs = np.zeros(len(parts) + 1, np.int64)
+    np.cumsum([p.size for p in parts], out=offs[1:])
+    cap = ROWS_PER_CHUNK * max(len(parts), 1) if cap_rows is None else cap_rows
+    tp = (C.c_int32 * len(types))(*types)
+    buf = raw if raw.size else np.zeros(1, np.uint8)
+    while True:
+        keep = []
+        out, bufs = out_buffers(types, max(cap, 1), keep, var_bytes=[raw.size if t == abi.BYTES else 0 for t in types])
+        n = C.c_int64(0)
+        st = ctx.lib.tsq_rows_decode_chunks(ctx.h, buf.ctypes.data_as(C.c_void_p), raw.size, offs.ctypes.data_as(C.c_void_p), len(parts), 0, len(types), tp, out, cap,
+                                            C.byref(n))
+        if st == abi.ERR_INVALID and n.value > cap:
+            cap = n.value  # a chunk with more than 64 rows: size the buffers from the count the library reported
+            continue
+        _lib.check(st, ctx.h)
+        return chunk_from_buffers(types, bufs, n.value)
+
+
 class SelectResult:
     """distsql.selectResult over a list of response chunks (each a RowsData byte string)."""
 
@@ -35,6 +61,8 @@ class SelectResult:
 
     def Next(self, max_rows=1024):
         """select_result.go:102-128: decode until the chunk is full or the responses are used up; empty chunk = EOS."""
+        if abi.BYTES in self.types:
+            return self._next_varlen(max_rows)
         got = []
         want = max_rows
         while want > 0 and self.idx < len(self.responses):
@@ -47,6 +75,20 @@ class SelectResult:
             got.append(chk)
             want -= chk.NumRows()
         return concat(got, self.types) if got else Chunk([Column(t, np.zeros(0, np_dtype(t))) for t in self.types])
+
+
+def _next_varlen(self, max_rows):
+    """schemas with var-len columns: all chunks are decoded at once (tsq_rows_decode_chunks) the first time, then handed out in
+    pieces of max_rows rows — the reference's contract (a chunk is filled up to its capacity, the rest waits) without re-parsing."""
+    if getattr(self, "_all", None) is None:
+        self._all, self._pos = decode_chunks(self.ctx, self.responses, self.types), 0
+        self.idx = len(self.responses)
+    lo, hi = self._pos, min(self._all.NumRows(), self._pos + max_rows)
+    self._pos = hi
+    return self._all.slice(lo, hi)
+
+
+SelectResult._next_varlen = _next_varlen
 
 
 def encode_rows(ctx, chunk, comparable_cols=()):
@@ -67,7 +109,6 @@ def encode_rows(ctx, chunk, comparable_cols=()):
     return out[:got.value].copy(), offs
 
 
-ROWS_PER_CHUNK = 64  # store/mockstore/mocktikv/cop_handler_dag.go:510
 
 
 def response_chunks(raw, offsets):
