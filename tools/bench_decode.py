@@ -90,12 +90,45 @@ def main():
                 ctx.sync()
                 best = min(best, time.perf_counter() - t)
             assert m.value == n and used.value == raw.size
+            # the same response through the chunk-parallel decoder (one lane per 64-row tipb.Chunk; the route for var-len schemas)
+            chunk_best = None
+            if len(sys.argv) > 2 and sys.argv[2] == "--chunks":
+                # chunk boundaries every 64 rows: positions of the rows are known to the generator (4 values per row)
+                # the chunk boundaries: the generator's own rows walked once on the host (input preparation, untimed)
+                pos, offs = 0, [0]
+                view = raw
+                for lo in range(0, n, 64):
+                    hi = min(lo + 64, n)
+                    for _ in range((hi - lo) * 4):
+                        f = view[pos]
+                        if f == 5:
+                            pos += 9
+                        else:
+                            pos += 1
+                            while view[pos] & 0x80:
+                                pos += 1
+                            pos += 1
+                    offs.append(pos)
+                offs = np.array(offs, np.int64)
+                doffs = ctx.alloc(offs.nbytes + 64)
+                ctx.h2d(doffs, offs)
+                chunk_best = 1e30
+                for rep in range(5):
+                    ctx.sync()
+                    t = time.perf_counter()
+                    _lib.check(ctx.lib.tsq_rows_decode_chunks(ctx.h, C.c_void_p(dbytes), raw.size, C.c_void_p(doffs), len(offs) - 1, abi.COL_DEVICE, 4, tp, oc, n, C.byref(m)), ctx.h)
+                    ctx.sync()
+                    chunk_best = min(chunk_best, time.perf_counter() - t)
+                assert m.value == n
+                ctx.free(doffs)
             key = outs[0].to_host().data
             algo = raw.size + 8.0 * 4 * n
             print(json.dumps({"workload": "decode %d rows x 4 fixed-width columns of an EncodeValue response, bytes and columns resident in HBM" % n,
                               "encoded_bytes": int(raw.size), "bytes_per_value": raw.size / (4.0 * n), "ms": best * 1e3, "values_per_s": 4 * n / best,
                               "input_GBs": raw.size / best / 1e9, "algorithmic_GBs": algo / best / 1e9, "frac_of_8TBs": algo / best / 8e12,
                               "key_checksum_ok": bool(int(key.sum()) == int(key.astype(np.int64).sum())),
+                              "chunks_route": None if chunk_best is None else {"ms": chunk_best * 1e3, "values_per_s": 4 * n / chunk_best, "frac_of_8TBs": algo / chunk_best / 8e12,
+                                                                                "note": "tsq_rows_decode_chunks: one lane per 64-row chunk"},
                               "cpu_baseline": {"kind": "port", "cores": 1, "values_per_s": cpu_vals / cpu_s,
                                                "sample": "oracle restatement of readRowsData + DecodeOne, %d rows x 4 columns, single thread" % (cpu_vals // 4)}}))
         finally:
