@@ -476,15 +476,17 @@ tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_by
  * The inverse of tsq_rows_decode, for the storage side of a pushed-down plan: replaces the per-datum codec.EncodeValue loop
  * that turns the output rows of the coprocessor's executors into RowsData (store/mockstore/mocktikv/aggregate.go:96-113 for
  * partial aggregates, util/rowcodec/decoder.go:252-322 for scanned rows; cop_handler_dag.go:414-425 concatenates the values of a
- * row).  Row r of the fixed-width columns `cols` becomes its values' datums back to back — int64 -> varintFlag + zig-zag varint,
- * uint64 -> uvarintFlag + varint, float / double -> floatFlag + 8 memcomparable bytes of the double, NULL -> NilFlag
+ * row).  Row r of the columns `cols` becomes its values' datums back to back — int64 -> varintFlag + zig-zag varint,
+ * uint64 -> uvarintFlag + varint, float / double -> floatFlag + 8 memcomparable bytes of the double, a var-len (TSQ_BYTES) cell ->
+ * compactBytesFlag + varint(length) + the bytes (codec.go:101-109, bytes.go:141-148), NULL -> NilFlag
  * (util/codec/codec.go:74-99 with comparable = false) — and rows follow each other in `out` (host, or TSQ_COL_DEVICE in
  * out_flags).  col_flags[c] & TSQ_ENC_COMPARABLE selects the EncodeKey form of an integer column (intFlag / uintFlag + 8
  * big-endian bytes): what BytesDecoder.DecodeToBytes emits for the handle column (decoder.go:263-273).  col_flags may be NULL.
  * row_offsets (NULL or nrows + 1 entries, same residency as out): row r = out[row_offsets[r], row_offsets[r + 1]) — the response
  * is cut into tipb.Chunks of 64 rows (cop_handler_dag.go:510-519).  *bytes_out = length of the byte string; when it exceeds
- * cap_bytes nothing is written and the call returns TSQ_ERR_INVALID with *bytes_out = the bytes needed.  A var-len column ->
- * TSQ_ERR_UNSUPPORTED: that response keeps the Go encoder. */
+ * cap_bytes nothing is written and the call returns TSQ_ERR_INVALID with *bytes_out = the bytes needed (a caller that cannot bound
+ * the size — string columns — asks with cap_bytes = 0 first).  TSQ_ENC_COMPARABLE on a var-len column (memcomparable bytes, the
+ * EncodeKey form) -> TSQ_ERR_UNSUPPORTED: that response keeps the Go encoder.  256 consecutive rows must encode to < 4 GiB. */
 #define TSQ_ENC_COMPARABLE 1u
 tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, const uint32_t* col_flags, int64_t nrows,
                            uint8_t* out, int64_t cap_bytes, uint32_t out_flags, int64_t* row_offsets, int64_t* bytes_out);

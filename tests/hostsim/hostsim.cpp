@@ -293,6 +293,13 @@ uint64_t sim_enc_load(const tsq_col& col, int64_t r, bool* notnull) {
 uint32_t sim_enc_row_len(const tsq_col* cols, int n_cols, uint32_t comparable, int64_t r) {
     uint32_t len = 0;
     for (int c = 0; c < n_cols; c++) {
+        if (cols[c].type == TSQ_BYTES) {
+            const uint8_t* bm = cols[c].null_bitmap;
+            const bool nn = bm ? ((bm[r >> 3] >> (r & 7)) & 1) != 0 : true;
+            const uint64_t n = (uint64_t)(cols[c].offsets[r + 1] - cols[c].offsets[r]);
+            len += nn ? tsq_enc_str_hdr_len(n) + (uint32_t)n : 1u;
+            continue;
+        }
         bool nn;
         const uint64_t bits = sim_enc_load(cols[c], r, &nn);
         len += tsq_enc_len(cols[c].type, (comparable >> c) & 1u, bits, nn);
@@ -324,8 +331,13 @@ extern "C" int64_t sim_rows_encode(const tsq_col* cols, int32_t n_cols, uint32_t
     wg[n_wg] = run;
     if ((int64_t)run > cap) return (int64_t)run;
     uint32_t row_max = 0;
-    for (int c = 0; c < n_cols; c++) row_max += (cols[c].type == TSQ_F32 || cols[c].type == TSQ_F64 || ((comparable >> c) & 1u)) ? 9u : TSQ_ENC_MAX_VALUE;
-    const size_t lds = (((size_t)NT * row_max + 15 + 16 + 15) / 16) * 16;
+    bool any_var = false;
+    for (int c = 0; c < n_cols; c++) {
+        any_var = any_var || cols[c].type == TSQ_BYTES;
+        row_max += cols[c].type == TSQ_BYTES ? 32u : ((cols[c].type == TSQ_F32 || cols[c].type == TSQ_F64 || ((comparable >> c) & 1u)) ? 9u : TSQ_ENC_MAX_VALUE);
+    }
+    size_t lds = (((size_t)NT * row_max + 15 + 16 + 15) / 16) * 16;
+    if (any_var) lds = lds < 32 * 1024 ? 32 * 1024 : (lds > 64 * 1024 ? 64 * 1024 : lds);
     std::vector<uint8_t> img(lds);
     const uint64_t out_addr = 0x7f0000002000ULL + out_phase;  // only its low bits matter
     for (int b = 0; b < n_wg; b++) {  // k_enc_emit
@@ -340,23 +352,38 @@ extern "C" int64_t sim_rows_encode(const tsq_col* cols, int32_t n_cols, uint32_t
                 T += len[tid];
             }
             const tsq_enc_copy plan = tsq_enc_copy_plan(out_addr, base, T);
-            if (plan.skew + T > lds) return -1;  // the LDS budget of the launch would be exceeded
+            const bool staged = (size_t)plan.skew + T + 16 <= lds;  // otherwise the rows go to their place directly
             memset(img.data(), 0xA5, lds);  // stale bytes of the previous tile must not leak
             for (int tid = 0; tid < NT; tid++) {
                 const int64_t r = t * NT + tid;
                 if (r >= nrows) continue;
                 row_offsets[r] = base + (int64_t)ex[tid];
-                uint32_t pos = plan.skew + ex[tid];
+                uint8_t* dst = staged ? img.data() + plan.skew + ex[tid] : out + base + ex[tid];
+                uint32_t pos = 0;
                 for (int c = 0; c < n_cols; c++) {
-                    bool nn;
-                    const uint64_t bits = sim_enc_load(cols[c], r, &nn);
                     uint64_t lo;
                     uint32_t hi;
+                    if (cols[c].type == TSQ_BYTES) {
+                        const uint8_t* bm = cols[c].null_bitmap;
+                        const bool nn = bm ? ((bm[r >> 3] >> (r & 7)) & 1) != 0 : true;
+                        if (!nn) { dst[pos++] = 0; continue; }
+                        const int64_t s0 = cols[c].offsets[r];
+                        const uint64_t n = (uint64_t)(cols[c].offsets[r + 1] - s0);
+                        const uint32_t hn = tsq_enc_str_hdr(n, &lo, &hi);
+                        for (uint32_t i = 0; i < hn; i++) dst[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
+                        pos += hn;
+                        memcpy(dst + pos, (const uint8_t*)cols[c].data + s0, (size_t)n);
+                        pos += (uint32_t)n;
+                        continue;
+                    }
+                    bool nn;
+                    const uint64_t bits = sim_enc_load(cols[c], r, &nn);
                     const uint32_t n = tsq_enc_bytes(cols[c].type, (comparable >> c) & 1u, bits, nn, &lo, &hi);
-                    for (uint32_t i = 0; i < n; i++) img[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
+                    for (uint32_t i = 0; i < n; i++) dst[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
                     pos += n;
                 }
             }
+            if (!staged) { base += T; continue; }
             // copy-out: global byte (base - skew) + i <-> image byte i.  `out` here is indexed from the region start.
             uint8_t* g = out + base - plan.skew;
             for (uint32_t tid = 0; tid < 16; tid++)

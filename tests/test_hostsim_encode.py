@@ -113,3 +113,27 @@ def test_output_too_small_writes_nothing(sim):
     want = orc.encode_rows(chk, False)
     total, got, _ = run_sim(sim, chk, 0, cap=want.size - 1)
     assert total == want.size  # the size is reported; run_sim saw that no byte of the buffer was touched
+
+
+def string_chunk(rng, n, long_every=0):
+    from tinysql_amd.chunk import StrColumn
+    words = [None if rng.random() < 0.15 else bytes(rng.integers(0, 256, int(rng.integers(0, 30)), dtype=np.uint8)) for _ in range(n)]
+    notes = [(b"L" * 70_000 if long_every and i % long_every == 3 else (None if rng.random() < 0.1 else (b"" if rng.random() < 0.2 else b"note-%d" % i))) for i in range(n)]
+    iv = rng.integers(-(1 << 40), 1 << 40, n)
+    return Chunk([StrColumn(words), Column(abi.I64, iv, rng.random(n) >= 0.2), StrColumn(notes), Column(abi.F64, rng.standard_normal(n), None)])
+
+
+@pytest.mark.parametrize("n,long_every", [(1, 0), (255, 0), (256, 0), (257, 0), (3000, 0), (700, 50)])
+@pytest.mark.parametrize("phase", [0, 5, 15])
+def test_string_columns_as_compact_bytes(sim, n, long_every, phase):
+    # a var-len cell = compactBytesFlag + varint(len) + the bytes (codec.go:101-109, bytes.go:141-148); a tile whose rows do not fit
+    # the LDS image (70 000-byte cells) is written directly — same bytes either way
+    rng = np.random.default_rng(n + phase)
+    chk = string_chunk(rng, n, long_every)
+    want = orc.encode_rows(chk)
+    cap = len(want) + 64
+    total, got, offs = run_sim(sim, chk, 0, n_wg=7, phase=phase, cap=cap)
+    assert total == len(want) and bytes(got) == bytes(want)
+    # the row boundaries cut the byte string into the rows the oracle encodes one by one
+    for r in (0, n // 2, n - 1):
+        assert bytes(got[offs[r]:offs[r + 1]]) == bytes(orc.encode_rows(chk.slice(r, r + 1)))

@@ -99,7 +99,9 @@ def test_contracts(ctx, orc):
     assert lib.tsq_rows_encode(ctx.h, cols, 17, None, 3, po, 64, 0, None, C.byref(m)) == abi.ERR_UNSUPPORTED
     assert lib.tsq_rows_encode(ctx.h, cols, 1, None, 4, po, 64, 0, None, C.byref(m)) == abi.ERR_INVALID  # column shorter than nrows
     cols[0].type = abi.BYTES
-    assert lib.tsq_rows_encode(ctx.h, cols, 1, None, 3, po, 64, 0, None, C.byref(m)) == abi.ERR_UNSUPPORTED
+    assert lib.tsq_rows_encode(ctx.h, cols, 1, None, 3, po, 64, 0, None, C.byref(m)) == abi.ERR_INVALID  # a var-len column without offsets
+    cmpf = (C.c_uint32 * 1)(abi.ENC_COMPARABLE)
+    assert lib.tsq_rows_encode(ctx.h, cols, 1, cmpf, 3, po, 64, 0, None, C.byref(m)) == abi.ERR_UNSUPPORTED  # memcomparable bytes (EncodeKey form)
     cols[0].type = abi.I64
     _lib.check(lib.tsq_rows_encode(ctx.h, cols, 1, None, 3, po, 64, 0, None, C.byref(m)), ctx.h)
     assert m.value == 6 and bytes(out[:6]) == b"\x08\x0a\x08\x0c\x08\x0e" and (out[6:] == 0xEE).all()
@@ -140,3 +142,35 @@ def test_coprocessor_chain_scan_selection_partial_aggregate_response(ctx, orc):
     want_in = Chunk([Column(c.tp, c.data[want_keep], None if c.notnull is None else c.notnull[want_keep]) for c in table.columns])
     assert H.rows_equal_unordered(rows, orc.hash_agg(acfg, want_in, 4, 4))
     assert bytes(raw) == bytes(orc.encode_rows(partial))
+
+
+# ------------------------------------------------------------------------------------------------ string columns (round 2)
+@pytest.mark.parametrize("n,long_every", [(1, 0), (257, 0), (5000, 0), (100_000, 0), (700, 50)])
+def test_string_columns_as_compact_bytes(ctx, orc, n, long_every):
+    # a var-len cell = compactBytesFlag + varint(len) + the bytes (codec.go:101-109, bytes.go:141-148); tiles with 70 000-byte cells
+    # bypass the LDS image; the response decodes back to the rows (tsq_rows_decode_chunks) and equals the oracle byte for byte
+    from .test_hostsim_encode import string_chunk
+    rng = np.random.default_rng(n)
+    chk = string_chunk(rng, n, long_every)
+    want = orc.encode_rows(chk)
+    raw, offs = distsql.encode_rows(ctx, chk)
+    assert bytes(raw) == bytes(want) and offs[0] == 0 and offs[-1] == len(want)
+    chunks = distsql.response_chunks(raw, offs)
+    assert len(chunks) == (n + 63) // 64
+    back = distsql.decode_chunks(ctx, chunks, chk.types())
+    assert back.rows() == chk.rows()
+
+
+def test_string_response_size_can_be_asked_first(ctx, orc):
+    from .test_hostsim_encode import string_chunk
+    from tinysql_amd.chunk import make_cols
+    rng = np.random.default_rng(3)
+    chk = string_chunk(rng, 1000)
+    want = orc.encode_rows(chk)
+    keep = []
+    cols = make_cols(chk.columns, keep)
+    m = C.c_int64(0)
+    assert ctx.lib.tsq_rows_encode(ctx.h, cols, 4, None, 1000, None, 0, 0, None, C.byref(m)) == abi.ERR_INVALID and m.value == len(want)
+    out = np.full(m.value + 8, 0xEE, np.uint8)
+    _lib.check(ctx.lib.tsq_rows_encode(ctx.h, cols, 4, None, 1000, out.ctypes.data_as(C.c_void_p), m.value, 0, None, C.byref(m)), ctx.h)
+    assert bytes(out[:m.value]) == bytes(want) and (out[m.value:] == 0xEE).all()

@@ -22,6 +22,8 @@
 struct EncArgs {
     const void* data[TSQ_MAX_COLS];
     const uint8_t* nulls[TSQ_MAX_COLS];  // nullptr: no NULLs
+    const int64_t* offs[TSQ_MAX_COLS];   // var-len columns: offsets[nrows + 1] into data
+    uint32_t lds_bytes;                  // LDS image of the launch: a tile that does not fit is written to the output directly
     int32_t type[TSQ_MAX_COLS];
     uint32_t comparable;                 // bit c: column c in the EncodeKey form
     int32_t n_cols;
@@ -50,6 +52,13 @@ __device__ __forceinline__ uint64_t enc_load(const EncArgs& a, int c, int64_t r,
 __device__ __forceinline__ uint32_t enc_row_len(const EncArgs& a, int64_t r) {
     uint32_t len = 0;
     for (int c = 0; c < a.n_cols; c++) {
+        if (a.type[c] == TSQ_BYTES) {  // NilFlag, or compactBytesFlag + varint(n) + the n bytes
+            const uint8_t* bm = a.nulls[c];
+            const bool nn = bm ? ((bm[r >> 3] >> (r & 7)) & 1) != 0 : true;
+            const uint64_t n = (uint64_t)(a.offs[c][r + 1] - a.offs[c][r]);
+            len += nn ? tsq_enc_str_hdr_len(n) + (uint32_t)n : 1u;
+            continue;
+        }
         bool nn;
         const uint64_t bits = enc_load(a, c, r, &nn);
         len += tsq_enc_len(a.type[c], (a.comparable >> c) & 1u, bits, nn);
@@ -103,24 +112,43 @@ __global__ void __launch_bounds__(ENC_NT) k_enc_emit(EncArgs a) {
         uint32_t T;
         const uint32_t ex = block_excl_scan<ENC_NT>(len, s_wsum, &T);
         const tsq_enc_copy plan = tsq_enc_copy_plan((uint64_t)(uintptr_t)a.out, base, T);
+        // a tile whose bytes do not fit the LDS image (rows with long strings) is written to its place directly, row by row
+        const bool staged = (size_t)plan.skew + T + 16 <= a.lds_bytes;  // workgroup uniform
+        uint8_t* dst = staged ? img + plan.skew + ex : a.out + base + ex;
         if (live) {
             if (a.row_offsets) a.row_offsets[r] = base + (int64_t)ex;
-            uint32_t pos = plan.skew + ex;
+            uint32_t pos = 0;
             for (int c = 0; c < a.n_cols; c++) {
-                bool nn;
-                const uint64_t bits = enc_load(a, c, r, &nn);
                 uint64_t lo;
                 uint32_t hi;
+                if (a.type[c] == TSQ_BYTES) {
+                    const uint8_t* bm = a.nulls[c];
+                    const bool nn = bm ? ((bm[r >> 3] >> (r & 7)) & 1) != 0 : true;
+                    if (!nn) { dst[pos++] = 0; continue; }  // NilFlag
+                    const int64_t s0 = a.offs[c][r];
+                    const uint64_t n = (uint64_t)(a.offs[c][r + 1] - s0);
+                    const uint32_t hn = tsq_enc_str_hdr(n, &lo, &hi);
+                    for (uint32_t i = 0; i < hn; i++) dst[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
+                    pos += hn;
+                    const uint8_t* src = (const uint8_t*)a.data[c] + s0;
+                    for (uint64_t i = 0; i < n; i++) dst[pos + i] = src[i];
+                    pos += (uint32_t)n;
+                    continue;
+                }
+                bool nn;
+                const uint64_t bits = enc_load(a, c, r, &nn);
                 const uint32_t n = tsq_enc_bytes(a.type[c], (a.comparable >> c) & 1u, bits, nn, &lo, &hi);
-                for (uint32_t i = 0; i < n; i++) img[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
+                for (uint32_t i = 0; i < n; i++) dst[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
                 pos += n;
             }
         }
         __syncthreads();
-        uint8_t* g = a.out + base - plan.skew;  // 16-byte aligned by construction
-        if (tid < 16 && plan.skew + tid < plan.head_end) g[plan.skew + tid] = img[plan.skew + tid];
-        if (tid >= 16 && tid < 32 && plan.tail_lo + (tid - 16) < plan.tail_end) g[plan.tail_lo + (tid - 16)] = img[plan.tail_lo + (tid - 16)];
-        for (uint32_t i = plan.body_lo + tid; i < plan.body_hi; i += ENC_NT) ((uint4*)g)[i] = s_img[i];
+        if (staged) {
+            uint8_t* g = a.out + base - plan.skew;  // 16-byte aligned by construction
+            if (tid < 16 && plan.skew + tid < plan.head_end) g[plan.skew + tid] = img[plan.skew + tid];
+            if (tid >= 16 && tid < 32 && plan.tail_lo + (tid - 16) < plan.tail_end) g[plan.tail_lo + (tid - 16)] = img[plan.tail_lo + (tid - 16)];
+            for (uint32_t i = plan.body_lo + tid; i < plan.body_hi; i += ENC_NT) ((uint4*)g)[i] = s_img[i];
+        }
         __syncthreads();  // the image (and s_wsum) are reused by the next tile
         base += T;
     }
@@ -138,11 +166,18 @@ TSQ_API tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
     if (bytes_out) *bytes_out = 0;
     if (!bytes_out || !cols || nrows < 0 || cap_bytes < 0 || (cap_bytes > 0 && !out)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: bad arguments");
     if (n_cols < 1 || n_cols > TSQ_MAX_COLS) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "1..16 columns supported");
-    bool in_dev = false, in_host = false;
+    bool in_dev = false, in_host = false, any_host_var = false;
     for (int c = 0; c < n_cols; c++) {
-        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "var-len column: encode this response with the Go encoder");
+        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: unknown column type");
         if (cols[c].length < nrows) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: column shorter than nrows");
-        if (nrows > 0 && !cols[c].data) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: column data == NULL");
+        if (cols[c].type == TSQ_BYTES) {
+            if (col_flags && (col_flags[c] & TSQ_ENC_COMPARABLE))
+                return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "EncodeKey form of a var-len column (memcomparable bytes): encode it with the Go encoder");
+            if (nrows > 0 && !cols[c].offsets) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: var-len column without offsets");
+            if (!(cols[c].flags & TSQ_COL_DEVICE)) any_host_var = true;
+        } else if (nrows > 0 && !cols[c].data) {
+            return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: column data == NULL");
+        }
         (cols[c].flags & TSQ_COL_DEVICE) ? in_dev = true : in_host = true;
     }
     if (in_dev && in_host) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: mixed host/device columns");
@@ -165,23 +200,43 @@ TSQ_API tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
         a.tiles_per_wg = (a.n_tiles + want - 1) / want;
         a.n_wg = (int32_t)((a.n_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg);
     }
-    DevBuf dwg, dout, doffs, ddata[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS];
+    DevBuf dwg, dout, doffs, ddata[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS], dco[TSQ_MAX_COLS];
     auto release_all = [&]() {
         for (DevBuf* b : {&dwg, &dout, &doffs}) b->release();
-        for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dbm[c].release(); }
+        for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dbm[c].release(); dco[c].release(); }
     };
+    (void)any_host_var;
     auto fail = [&](tsq_status st) { release_all(); return st; };
     tsq_status s = dwg.reserve(ctx, h, ((size_t)a.n_wg + 1) * 8 + 64);
     hipError_t e = hipSuccess;
     uint32_t row_max = 0;
+    bool any_var = false;
     for (int c = 0; c < n_cols && s == TSQ_OK && e == hipSuccess; c++) {
         a.type[c] = cols[c].type;
         const bool cmp = col_flags && (col_flags[c] & TSQ_ENC_COMPARABLE);
         if (cmp) a.comparable |= 1u << c;
-        row_max += (cols[c].type == TSQ_F32 || cols[c].type == TSQ_F64 || cmp) ? 9u : TSQ_ENC_MAX_VALUE;
+        const bool var = cols[c].type == TSQ_BYTES;
+        any_var = any_var || var;
+        row_max += var ? 32u : ((cols[c].type == TSQ_F32 || cols[c].type == TSQ_F64 || cmp) ? 9u : TSQ_ENC_MAX_VALUE);  // (strings: a guess; tiles that do not fit go direct)
         if (in_dev) {
             a.data[c] = cols[c].data;
             a.nulls[c] = cols[c].null_bitmap;
+            a.offs[c] = var ? cols[c].offsets : nullptr;
+        } else if (var) {
+            // a host var-len column: its offsets and the bytes they span (the offsets may start anywhere: the kernel indexes data with them)
+            const int64_t b0 = cols[c].offsets[0], b1 = cols[c].offsets[nrows];
+            if (b1 < b0) { s = tsq_fail(h, TSQ_ERR_INVALID, "var-len column: offsets must not decrease"); break; }
+            s = dco[c].reserve(ctx, h, ((size_t)nrows + 1) * 8 + 64);
+            if (s == TSQ_OK) s = ddata[c].reserve(ctx, h, (size_t)(b1 - b0) + 64);
+            if (s == TSQ_OK) e = hipMemcpyAsync(dco[c].p, cols[c].offsets, ((size_t)nrows + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+            if (s == TSQ_OK && e == hipSuccess && b1 > b0) e = hipMemcpyAsync(ddata[c].p, (const uint8_t*)cols[c].data + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, ctx->stream);
+            a.data[c] = (const uint8_t*)ddata[c].p - b0;  // data[offsets[r]] addresses the staged copy
+            a.offs[c] = dco[c].as<int64_t>();
+            if (s == TSQ_OK && e == hipSuccess && cols[c].null_bitmap) {
+                s = dbm[c].reserve(ctx, h, tsq_bitmap_bytes(nrows) + 64);
+                if (s == TSQ_OK) e = hipMemcpyAsync(dbm[c].p, cols[c].null_bitmap, tsq_bitmap_bytes(nrows), hipMemcpyHostToDevice, ctx->stream);
+                a.nulls[c] = dbm[c].as<uint8_t>();
+            }
         } else {
             const size_t es = (size_t)tsq_elem_size(cols[c].type);
             s = ddata[c].reserve(ctx, h, (size_t)nrows * es + 64);
@@ -217,8 +272,10 @@ TSQ_API tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
         a.out = dout.as<uint8_t>();
         a.row_offsets = row_offsets ? doffs.as<int64_t>() : nullptr;
     }
-    const size_t lds = (((size_t)ENC_NT * row_max + 15 + 16 + 15) / 16) * 16;  // the tile at any skew, whole vectors
+    size_t lds = (((size_t)ENC_NT * row_max + 15 + 16 + 15) / 16) * 16;  // the tile at any skew, whole vectors
+    if (any_var) lds = std::min<size_t>(std::max<size_t>(lds, 32 * 1024), 64 * 1024);  // tiles with longer strings are written directly
     if (lds > 64 * 1024) return fail(tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_rows_encode: row too wide for the LDS tile"));
+    a.lds_bytes = (uint32_t)lds;
     hipLaunchKernelGGL(k_enc_emit, dim3(a.n_wg), dim3(ENC_NT), lds, ctx->stream, a);
     e = hipGetLastError();
     if (e == hipSuccess && !out_dev) {

@@ -68,6 +68,15 @@ TSQ_HD uint32_t tsq_enc_bytes(int32_t type, bool comparable, uint64_t bits, bool
     return 1u + nb;
 }
 
+// a var-len cell of `n` bytes: compactBytesFlag + EncodeCompactBytes = [2][varint(n)][the bytes] (codec.go:101-109, bytes.go:141-148).
+// The header (flag + varint, <= 11 bytes) is the varint form of the int64 n with the flag byte replaced
+TSQ_HD uint32_t tsq_enc_str_hdr(uint64_t n, uint64_t* lo, uint32_t* hi) {
+    const uint32_t h = tsq_enc_bytes(TSQ_I64, false, n, true, lo, hi);
+    *lo = (*lo & ~0xffull) | 2ull;  // compactBytesFlag
+    return h;
+}
+TSQ_HD uint32_t tsq_enc_str_hdr_len(uint64_t n) { return tsq_enc_len(TSQ_I64, false, n, true); }
+
 // How the T bytes of a tile, assembled in LDS at [skew, skew + T), reach out[base, base + T): LDS byte i <-> global byte
 // (out + base - skew) + i with skew = (address of out[base]) & 15, so whole 16-byte vectors are stored aligned; the bytes before the
 // first / after the last whole vector are shared with the neighbouring tiles' vectors and are stored one by one.

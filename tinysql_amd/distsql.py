@@ -92,7 +92,7 @@ SelectResult._next_varlen = _next_varlen
 
 
 def encode_rows(ctx, chunk, comparable_cols=()):
-    """The storage side's inverse of decode_rows: the rows of a fixed-width chunk -> (RowsData bytes, row offsets[n + 1]), encoded
+    """The storage side's inverse of decode_rows: the rows of a chunk (var-len columns as compact-bytes datums) -> (RowsData bytes, row offsets[n + 1]), encoded
     on the GPU by libtsq (`tsq_rows_encode`; codec.EncodeValue per value, util/codec/codec.go:74-99,205-209).  Columns listed in
     `comparable_cols` use the EncodeKey form (the handle column of a table scan, util/rowcodec/decoder.go:263-273)."""
     from .chunk import make_cols
@@ -100,7 +100,8 @@ def encode_rows(ctx, chunk, comparable_cols=()):
     keep = []
     cols = make_cols(chunk.columns, keep)
     flags = (C.c_uint32 * len(chunk.columns))(*[abi.ENC_COMPARABLE if i in comparable_cols else 0 for i in range(len(chunk.columns))])
-    cap = n * len(chunk.columns) * 11 + 16
+    # 11 bytes bound every fixed-width datum; a string cell adds its bytes to its (<= 11-byte) header
+    cap = n * len(chunk.columns) * 11 + 16 + sum(int(c.offsets[-1] - c.offsets[0]) for c in chunk.columns if c.tp == abi.BYTES and len(c.offsets))
     out = np.zeros(cap, np.uint8)
     offs = np.zeros(n + 1, np.int64)
     got = C.c_int64(0)
