@@ -717,7 +717,14 @@ public:
             fetched_ = true;
         }
         const int64_t cap = req->requiredRows;
-        for (auto& c : req->columns) c.resizeFor(cap);
+        std::vector<int64_t> bytes(req->columns.size(), 0);
+        bool anyVar = false;
+        for (auto& c : req->columns) anyVar |= c.isVar();
+        if (anyVar) {  // string payload columns: their data bytes for this pull
+            int64_t pn = 0;
+            check(tsq_sort_peek(h_, cap, &pn, bytes.data(), (int32_t)bytes.size()), h_);
+        }
+        for (size_t c = 0; c < req->columns.size(); c++) req->columns[c].resizeFor(cap, bytes[c]);
         std::vector<tsq_col> out;
         for (auto& c : req->columns) out.push_back(c.View(cap));
         int64_t n = 0;
@@ -751,6 +758,164 @@ public:
     TopNExec(Context* ctx, Executor* child, std::vector<ByItem> byItems, uint64_t offset, uint64_t count)
         : SortExec(ctx, child, std::move(byItems), (int64_t)offset, (int64_t)std::min<uint64_t>(count, (uint64_t)INT64_MAX)) {}
 };
+
+
+// ---------------------------------------------------------------- the storage side: package tablecodec + mocktikv's executors
+// tablecodec.EncodeRowKeyWithHandle / DecodeRowKey for a batch (tablecodec/tablecodec.go:65-70, 235-242) through libtsq
+inline std::vector<uint8_t> EncodeRowKeysWithHandles(Context* ctx, int64_t tableID, const std::vector<int64_t>& handles) {
+    std::vector<uint8_t> keys(handles.size() * 19 + 1);
+    check(tsq_rowkeys_encode(ctx->h, tableID, handles.data(), (int64_t)handles.size(), 0, keys.data()), ctx->h);
+    keys.resize(handles.size() * 19);
+    return keys;
+}
+inline std::vector<int64_t> DecodeRowKeys(Context* ctx, const std::vector<uint8_t>& keys) {
+    if (keys.size() % 19) throw Error(TSQ_ERR_INVALID, "invalid key");
+    std::vector<int64_t> handles(keys.size() / 19 + 1);
+    int64_t n = 0;
+    check(tsq_rowkeys_decode(ctx->h, keys.data(), (int64_t)keys.size(), nullptr, (int64_t)(keys.size() / 19), 0, handles.data(), nullptr, &n), ctx->h);
+    handles.resize((size_t)n);
+    return handles;
+}
+
+namespace mocktikv {
+// rowcodec.ColInfo (util/rowcodec/decoder.go:45-55) as far as this path reads it
+struct ColInfo {
+    int64_t ID;
+    int32_t type;     // TSQ_I64 / TSQ_U64 / TSQ_F32 / TSQ_F64 / TSQ_BYTES (the mysql type + UnsignedFlag folded)
+    bool IsPKHandle;
+};
+// the KV pairs of the scanned ranges, in scan order: record keys back to back (19 bytes each) and the stored rows (rowcodec v2)
+struct Pairs {
+    std::vector<uint8_t> keys, values;
+    std::vector<int64_t> valueOffsets;  // n + 1
+};
+
+// tableScanExec (store/mockstore/mocktikv/executor.go:48-196): DecodeRowKey + the row decode of every pair, a chunk at a time
+class tableScanExec : public Executor {
+public:
+    tableScanExec(Context* ctx, std::vector<ColInfo> columns, const Pairs* pairs) : Executor(ctx, types(columns), {}), cols_(std::move(columns)), p_(pairs) {
+        n_ = (int64_t)p_->valueOffsets.size() - 1;
+        if ((int64_t)p_->keys.size() != 19 * n_) throw Error(TSQ_ERR_INVALID, "invalid key");
+        for (auto& c : cols_) {
+            tsq_rowcodec_col rc;
+            memset(&rc, 0, sizeof rc);
+            rc.col_id = c.ID;
+            rc.type = c.type;
+            rc.flags = c.IsPKHandle ? TSQ_RC_HANDLE : 0;
+            rc_.push_back(rc);
+        }
+    }
+    void Open() override {
+        pos_ = 0;
+        handles_.assign((size_t)n_ + 1, 0);
+        int64_t got = 0;
+        if (n_) check(tsq_rowkeys_decode(ctx_->h, p_->keys.data(), (int64_t)p_->keys.size(), nullptr, n_, 0, handles_.data(), nullptr, &got), ctx_->h);
+    }
+    void Next(Chunk* req) override {
+        req->Reset();
+        if (pos_ >= n_) return;
+        const int64_t lo = pos_, hi = std::min<int64_t>(n_, pos_ + std::min(req->requiredRows, maxChunkSize));
+        const int64_t b0 = p_->valueOffsets[lo], b1 = p_->valueOffsets[hi];
+        std::vector<int64_t> offs((size_t)(hi - lo) + 1);  // the batch's rows, rebased onto its first byte
+        for (int64_t r = lo; r <= hi; r++) offs[(size_t)(r - lo)] = p_->valueOffsets[r] - b0;
+        for (auto& c : req->columns) c.resizeFor(hi - lo, b1 - b0);
+        std::vector<tsq_col> out;
+        for (auto& c : req->columns) out.push_back(c.View(hi - lo));
+        int64_t n = 0;
+        check(tsq_rowcodec_decode(ctx_->h, p_->values.data() + b0, b1 - b0, offs.data(), handles_.data() + lo, hi - lo, 0, (int32_t)rc_.size(), rc_.data(), out.data(), &n),
+              ctx_->h);
+        for (auto& c : req->columns) c.truncate(n);
+        pos_ = hi;
+        count_ += n;
+    }
+    int64_t Count() const { return count_; }  // Counts() of the one range (executor.go:76-85)
+private:
+    static Schema types(const std::vector<ColInfo>& cs) { Schema s; for (auto& c : cs) s.push_back(c.type); return s; }
+    std::vector<ColInfo> cols_;
+    const Pairs* p_;
+    std::vector<tsq_rowcodec_col> rc_;
+    std::vector<int64_t> handles_;
+    int64_t n_ = 0, pos_ = 0, count_ = 0;
+};
+
+// selectionExec (executor.go:322-390) = SelectionExec; topNExec (:392-470, topn.go) = TopNExec with offset 0
+using selectionExec = SelectionExec;
+class topNExec : public TopNExec {
+public:
+    topNExec(Context* ctx, Executor* src, std::vector<ByItem> orderBy, uint64_t limit) : TopNExec(ctx, src, std::move(orderBy), 0, limit) {}
+};
+// hashAggExec (aggregate.go:30-182): per function its partial results (AVG: count, sum — avg.go:78-81), then the group-by values
+class hashAggExec : public HashAggExec {
+public:
+    hashAggExec(Context* ctx, Executor* src, const std::vector<std::pair<int32_t, int>>& aggFuncs, const std::vector<int>& groupByCols)
+        : HashAggExec(ctx, src, groupByCols, descs(src->schema(), aggFuncs, groupByCols)) {}
+private:
+    static std::vector<AggFuncDesc> descs(const Schema& in, const std::vector<std::pair<int32_t, int>>& fs, const std::vector<int>& gby) {
+        std::vector<AggFuncDesc> d;
+        for (auto& f : fs) {
+            AggFuncDesc a;
+            a.func = f.first;
+            a.argCol = f.second;
+            a.argType = f.second >= 0 ? in[(size_t)f.second] : TSQ_I64;
+            a.mode = f.first == TSQ_AGG_AVG ? TSQ_MODE_PARTIAL1 : TSQ_MODE_COMPLETE;
+            d.push_back(a);
+        }
+        for (int g : gby) {
+            AggFuncDesc a;
+            a.func = TSQ_AGG_FIRSTROW;
+            a.argCol = g;
+            a.argType = in[(size_t)g];
+            d.push_back(a);
+        }
+        return d;
+    }
+};
+// limitExec (executor.go:472-507)
+class limitExec : public Executor {
+public:
+    limitExec(Context* ctx, Executor* src, uint64_t limit) : Executor(ctx, src->schema(), {src}), limit_(limit) {}
+    void Open() override { Executor::Open(); cursor_ = 0; }
+    void Next(Chunk* req) override {
+        req->Reset();
+        if (cursor_ >= limit_) return;
+        Chunk chk(schema_, maxChunkSize);
+        chk.requiredRows = (int)std::min<uint64_t>((uint64_t)req->requiredRows, limit_ - cursor_);
+        children_[0]->Next(&chk);
+        const int64_t n = std::min<int64_t>(chk.NumRows(), (int64_t)(limit_ - cursor_));
+        for (int64_t r = 0; r < n; r++)
+            for (int c = 0; c < chk.NumCols(); c++) req->columns[c].AppendCell(chk.columns[c], r);
+        cursor_ += (uint64_t)n;
+    }
+private:
+    uint64_t limit_, cursor_ = 0;
+};
+
+// handleCopDAGRequest's tail (cop_handler_dag.go:58-83, 414-425, 510-519): run the executor to its end, encode the requested columns of
+// every row (codec.EncodeValue on the GPU), cut the rows into RowsData pieces of 64
+inline std::vector<std::string> fillUpData4SelectResponse(Context* ctx, Executor* e, const std::vector<int>& outputOffsets) {
+    std::vector<std::string> chunks;
+    int64_t rowCnt = 0;
+    for (Chunk& chk : Drain(e)) {
+        const int64_t n = chk.NumRows();
+        std::vector<tsq_col> cols;
+        for (int o : outputOffsets) cols.push_back(chk.columns[(size_t)o].View(n));
+        int64_t need = 0;
+        const tsq_status st = tsq_rows_encode(ctx->h, cols.data(), (int32_t)cols.size(), nullptr, n, nullptr, 0, 0, nullptr, &need);  // the size first
+        if (st != TSQ_ERR_INVALID && st != TSQ_OK) check(st, ctx->h);
+        std::vector<uint8_t> raw((size_t)need + 8);
+        std::vector<int64_t> offs((size_t)n + 1);
+        check(tsq_rows_encode(ctx->h, cols.data(), (int32_t)cols.size(), nullptr, n, raw.data(), need, 0, offs.data(), &need), ctx->h);
+        for (int64_t lo = 0; lo < n;) {
+            const int64_t room = 64 - rowCnt % 64, hi = std::min<int64_t>(n, lo + room);
+            if (rowCnt % 64 == 0) chunks.emplace_back();
+            chunks.back().append((const char*)raw.data() + offs[(size_t)lo], (size_t)(offs[(size_t)hi] - offs[(size_t)lo]));
+            rowCnt += hi - lo;
+            lo = hi;
+        }
+    }
+    return chunks;
+}
+}  // namespace mocktikv
 
 }  // namespace tsqhost
 #endif

@@ -351,6 +351,69 @@ int main() {
             expect("aggregate.go:572-574 empty input: max(string) NULL, count 0", render(Drain(&agg0)), {"<nil> 0"});
         }
     }
+    // ---- the storage side (round 2): tablecodec's record keys, string payload through TopNExec, mocktikv's executor chain
+    {
+        // tablecodec_test.go:42-53, 111-135: EncodeRowKeyWithHandle / DecodeRowKey; RecordRowKeyLen = 19
+        const std::vector<uint8_t> key = EncodeRowKeysWithHandles(&ctx, 1, {2});
+        const uint8_t want[19] = {'t', 0x80, 0, 0, 0, 0, 0, 0, 1, '_', 'r', 0x80, 0, 0, 0, 0, 0, 0, 2};
+        expect_true("tablecodec_test.go:42-53 EncodeRowKeyWithHandle(1, 2)", key.size() == 19 && !memcmp(key.data(), want, 19));
+        const std::vector<int64_t> hs = {0, -1, 4294967295LL, INT64_MAX, INT64_MIN};
+        expect_true("tablecodec_test.go:111-135 DecodeRowKey of encoded handles", DecodeRowKeys(&ctx, EncodeRowKeysWithHandles(&ctx, 55, hs)) == hs);
+        bool threw = false;
+        try { DecodeRowKeys(&ctx, std::vector<uint8_t>(19, 'x')); } catch (const Error& e) { threw = std::string(e.what()).find("invalid key") != std::string::npos; }
+        expect_true("tablecodec.go:235-242 DecodeRowKey: invalid key", threw);
+    }
+    {   // ORDER BY v LIMIT with a varchar payload column (sort.go:146-318; the string cells travel with their rows)
+        Chunk t = table_mixed({TSQ_BYTES, TSQ_I64}, {"pear", "3", "NULL", "1", "", "2", "fig", "5", "apple", "4"});
+        MockDataSource src(&ctx, t);
+        TopNExec top(&ctx, &src, {{1, true}}, 1, 3);
+        std::vector<Chunk> got = Drain(&top);
+        Rows ordered;
+        for (auto& chk : got) for (int64_t r = 0; r < chk.NumRows(); r++) ordered.push_back(cell(chk.columns[0], r) + " " + cell(chk.columns[1], r));
+        expect_true("TopN with a string payload: rows 1..3 of ORDER BY v DESC", ordered == Rows{"apple 4", "pear 3", " 2"});
+    }
+    {
+        // a table (k, v, name) with an int handle; stored rows assembled like row.toBytes (util/rowcodec/row.go:80-99): small ids, one-byte ints
+        struct R { int64_t h; int k, v; const char* name; };
+        const R rows[] = {{1, 1, 10, "a"}, {2, 2, 20, "bb"}, {3, 1, 30, nullptr}, {4, 2, 5, ""}};
+        mocktikv::Pairs pairs;
+        std::vector<int64_t> handles;
+        pairs.valueOffsets.push_back(0);
+        for (const R& r : rows) {
+            handles.push_back(r.h);
+            std::vector<uint8_t>& b = pairs.values;
+            const size_t nameLen = r.name ? strlen(r.name) : 0;
+            const int notNull = r.name ? 3 : 2;
+            b.insert(b.end(), {128, 0, (uint8_t)notNull, 0, (uint8_t)(3 - notNull), 0});
+            b.insert(b.end(), {1, 2, 3});  // the not-null ids sorted, then the null ids: id 3 comes last either way
+            const uint16_t ends[3] = {1, 2, (uint16_t)(2 + nameLen)};
+            for (int i = 0; i < notNull; i++) { b.push_back((uint8_t)ends[i]); b.push_back((uint8_t)(ends[i] >> 8)); }
+            b.push_back((uint8_t)r.k);
+            b.push_back((uint8_t)r.v);
+            if (r.name) b.insert(b.end(), r.name, r.name + nameLen);
+            pairs.valueOffsets.push_back((int64_t)b.size());
+        }
+        pairs.keys = EncodeRowKeysWithHandles(&ctx, 41, handles);
+        const std::vector<mocktikv::ColInfo> cols = {{1, TSQ_I64, false}, {2, TSQ_I64, false}, {3, TSQ_BYTES, false}, {-1, TSQ_I64, true}};
+        {   // tableScanExec -> limitExec -> response: the handle from the key, the string as a compact-bytes datum, 64 rows per chunk
+            mocktikv::tableScanExec scan(&ctx, cols, &pairs);
+            mocktikv::limitExec lim(&ctx, &scan, 3);
+            const std::vector<std::string> chunks = mocktikv::fillUpData4SelectResponse(&ctx, &lim, {3, 0, 2});
+            const std::string want = std::string("\x08\x02\x08\x02\x02\x02" "a", 7) + std::string("\x08\x04\x08\x04\x02\x04" "bb", 8) + std::string("\x08\x06\x08\x02\x00", 5);
+            expect_true("executor.go:48-196,472-507 + cop_handler_dag.go:414-425: scan -> limit 3 -> RowsData", chunks.size() == 1 && chunks[0] == want);
+        }
+        {   // tableScanExec -> selectionExec (v > 7) -> hashAggExec (count(*), sum(v), avg(v) group by k): partial results, then the group-by value
+            mocktikv::tableScanExec scan(&ctx, cols, &pairs);
+            mocktikv::selectionExec sel(&ctx, &scan, {Func("gt", {Col(1, TSQ_I64), Int(7)})});
+            mocktikv::hashAggExec agg(&ctx, &sel, {{TSQ_AGG_COUNT, -1}, {TSQ_AGG_SUM, 1}, {TSQ_AGG_AVG, 1}}, {0});
+            expect("aggregate.go:78-116 scan -> selection -> hashAgg: [count, sum, avg.count, avg.sum, k]", render(Drain(&agg)), {"2 40 2 40 1", "1 20 1 20 2"});
+        }
+        {   // topNExec above the scan: ORDER BY v DESC LIMIT 2, the varchar column travels along
+            mocktikv::tableScanExec scan(&ctx, cols, &pairs);
+            mocktikv::topNExec top(&ctx, &scan, {{1, true}}, 2);
+            expect("executor.go:392-470 scan -> topN", render(Drain(&top)), {"1 30 <nil> 3", "2 20 bb 2"});
+        }
+    }
     printf("%d passed, %d failed\n", g_pass, g_fail);
     return g_fail ? 1 : 0;
 }
