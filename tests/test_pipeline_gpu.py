@@ -178,3 +178,44 @@ def test_q3_shaped_plan_with_order_by_revenue_limit_10(ctx, orc):
     finally:
         for d in dev:
             d.free()
+
+
+def test_string_columns_stay_in_hbm_through_the_pipeline(ctx, orc):
+    # the Q3 shape with its REAL predicate — c_mktsegment = 'BUILDING' is a string compare — and string columns travelling along:
+    # Selection(customer: segment = 'BUILDING') -> HashJoin(orders) with the customer's name as payload -> HashAgg GROUP BY name
+    # (MAX of a string, COUNT) -> ORDER BY count DESC, key with the name as payload; var-len columns never leave HBM between the
+    # operators (tsq_chunk_compact, tsq_join_peek / tsq_agg_peek / tsq_sort_peek size the device buffers)
+    from tinysql_amd import expression as E
+    from tinysql_amd.chunk import StrColumn
+    from tinysql_amd.executor import AggFuncDesc
+    rng = np.random.default_rng(12)
+    nc, no = 5000, 60_000
+    segs = [b"BUILDING", b"AUTOMOBILE", b"MACHINERY", b"FURNITURE", b"HOUSEHOLD"]
+    customer = Chunk([Column(abi.I64, np.arange(nc, dtype=np.int64), None), StrColumn([None if i % 97 == 0 else segs[int(rng.integers(0, 5))] for i in range(nc)]),
+                      StrColumn([b"Customer#%09d" % (i % 700) for i in range(nc)])])
+    orders = Chunk([Column(abi.I64, np.arange(no, dtype=np.int64), None), Column(abi.I64, rng.integers(0, nc, no), rng.random(no) >= 0.02),
+                    StrColumn([None if rng.random() < 0.1 else b"P%d" % int(rng.integers(0, 9)) + b"-" * int(rng.integers(0, 6)) for _ in range(no)])])
+    cond = [E.ScalarFunction("eq", E.Column(1, abi.BYTES), E.Constant("BUILDING"))]
+    # oracle chain
+    keep, _, _ = orc.filter_eval(E.compile_list(cond), 1, customer)
+    idx = np.flatnonzero(keep)
+    cust = Chunk([Column(abi.I64, customer.columns[0].data[idx], None), StrColumn([customer.columns[1].values()[i] for i in idx]),
+                  StrColumn([customer.columns[2].values()[i] for i in idx])])
+    j = orc.hash_join(H.join_cfg(orders.types(), cust.types(), [1], [0], abi.JOIN_INNER, 1), cust, orders)  # orders probe (left), customer build
+    aggs = [(abi.AGG_FIRSTROW, 5, abi.BYTES), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_MAX, 2, abi.BYTES), (abi.AGG_MIN, 0, abi.I64)]
+    want = orc.hash_agg(H.agg_cfg(j.types(), [5], aggs), j, 4, 4)
+    want_sorted = orc.sort_rows(want, [1, 3], [True, False])
+    # device pipeline
+    dcust, dord = GP.DeviceChunk.from_host(ctx, customer), GP.DeviceChunk.from_host(ctx, orders)
+    try:
+        sel = GP.GpuSelectionExec(ctx, GP.DeviceTableScan(ctx, dcust, batch_rows=2048), cond)
+        join = GP.GpuHashJoinExec(ctx, GP.DeviceTableScan(ctx, dord, batch_rows=16384), sel, [1], [0], abi.JOIN_INNER, 1, pull_rows=1 << 15)
+        descs = [AggFuncDesc(f, c, t) for f, c, t in aggs]
+        agg = GP.GpuHashAggExec(ctx, join, [5], descs, pull_rows=1 << 12)
+        top = GP.GpuSortExec(ctx, agg, [1, 3], [True, False], pull_rows=1 << 12)
+        got = [r for chk in GP.drain_device(top) for r in chk.rows()]
+    finally:
+        dcust.free()
+        dord.free()
+    assert len(got) == want.NumRows() and len(got) > 100
+    assert got == want_sorted.rows()  # (count DESC, min orderkey): a total order — names included, row for row

@@ -170,7 +170,16 @@ def make_table(orc, rng, n, groups=500, null_frac=0.05, unique_v=False):
 
 
 def select(chunk, keep):
-    return Chunk([Column(c.tp, c.data[keep], None if c.notnull is None else c.notnull[keep]) for c in chunk.columns])
+    from tinysql_amd.chunk import StrColumn
+    cols = []
+    for c in chunk.columns:
+        if c.tp == abi.BYTES:
+            vals = c.values()
+            idx = range(len(vals))[keep] if isinstance(keep, slice) else np.flatnonzero(keep)
+            cols.append(StrColumn([vals[i] for i in idx]))
+        else:
+            cols.append(Column(c.tp, c.data[keep], None if c.notnull is None else c.notnull[keep]))
+    return Chunk(cols)
 
 
 def read_back(ctx, resp, types):
@@ -328,3 +337,48 @@ def test_running_sum_overflow_divergence_is_pinned(ctx, orc):
             assert resp.Error is not None and resp.Chunks == []
         else:
             assert read_back(ctx, resp, [abi.I64]) == [(m - 4,)]
+
+
+# ------------------------------------------------------------------------------------------------ string columns through the chain
+def make_string_table(orc, rng, n):
+    from tinysql_amd.chunk import StrColumn
+    handles = np.arange(n, dtype=np.int64) * 3 - n
+    seg = [None if rng.random() < 0.05 else [b"BUILDING", b"AUTOMOBILE", b"MACHINERY", b"", b"HOUSEHOLD"][int(rng.integers(0, 5))] for _ in range(n)]
+    note = [None if rng.random() < 0.1 else b"note-%d-" % i + b"x" * int(rng.integers(0, 30)) for i in range(n)]
+    table = Chunk([Column(abi.I64, rng.integers(0, 50, n), rng.random(n) >= 0.05), StrColumn(seg), StrColumn(note)])
+    vals, offs = orc.rowcodec_encode(table, [1, 2, 3])
+    return (oracle_keys(orc, 7, handles), vals, offs), Chunk(table.columns + [Column(abi.I64, handles, None)])
+
+
+SCOLS = [RC.ColInfo(1, RC.TypeLonglong), RC.ColInfo(2, RC.TypeVarchar), RC.ColInfo(3, RC.TypeBlob), RC.ColInfo(-1, RC.TypeLonglong, 0, True)]
+STYPES = [abi.I64, abi.BYTES, abi.BYTES, abi.I64]
+
+
+def test_string_columns_scan_selection_limit_response(ctx, orc):
+    # WHERE seg = 'BUILDING' AND k < 40 over a table with varchar / blob columns, LIMIT 500: string cells stay in HBM from the stored
+    # rows to the response bytes (compact-bytes datums); the rows come back in scan order
+    rng = np.random.default_rng(21)
+    pairs, scanned = make_string_table(orc, rng, 30_000)
+    conds = [E.ScalarFunction("eq", E.Column(1, abi.BYTES), E.Constant("BUILDING")), E.ScalarFunction("lt", E.Column(0, abi.I64), E.Constant(40))]
+    resp = cop.handleCopDAGRequest(ctx, [("TableScan", SCOLS), ("Selection", conds), ("Limit", 500)], [3, 1, 2, 0], pairs)
+    keep, _, _ = orc.filter_eval(E.compile_list(conds), 2, scanned)
+    sel = select(scanned, keep)
+    want = select(Chunk([sel.columns[i] for i in (3, 1, 2, 0)]), slice(0, 500))
+    assert resp.Error is None and resp.Chunks == chunks_of(orc, want)
+    back = distsql.decode_chunks(ctx, resp.Chunks, [abi.I64, abi.BYTES, abi.BYTES, abi.I64])
+    assert back.rows() == want.rows()
+
+
+def test_string_group_keys_and_topn_payload_through_the_chain(ctx, orc):
+    rng = np.random.default_rng(22)
+    pairs, scanned = make_string_table(orc, rng, 20_000)
+    # GROUP BY seg: count(*), max(note), sum(k) — the group-by value (a string) follows the partial results
+    funcs = [(abi.AGG_COUNT, -1), (abi.AGG_MAX, 2), (abi.AGG_SUM, 0)]
+    resp = cop.handleCopDAGRequest(ctx, [("TableScan", SCOLS), ("Aggregation", funcs, [1])], [0, 1, 2, 3], pairs)
+    got = distsql.decode_chunks(ctx, resp.Chunks, [abi.I64, abi.BYTES, abi.I64, abi.BYTES])
+    cfg = H.agg_cfg(STYPES, [1], [(f, c, STYPES[c] if c >= 0 else abi.I64) for f, c in funcs])
+    assert resp.Error is None and H.rows_equal_unordered(got, orc.cop_hash_agg(cfg, scanned))
+    # ORDER BY handle DESC LIMIT 100 with both string columns as payload
+    resp = cop.handleCopDAGRequest(ctx, [("TableScan", SCOLS), ("TopN", [3], [True], 100)], [3, 2, 1], pairs)
+    want = select(orc.sort_rows(scanned, [3], [True]), slice(0, 100))
+    assert resp.Error is None and resp.Chunks == chunks_of(orc, Chunk([want.columns[i] for i in (3, 2, 1)]))

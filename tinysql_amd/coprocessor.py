@@ -1,5 +1,5 @@
 """The storage side's coprocessor executors over libtsq — the harness mirror of store/mockstore/mocktikv's DAG handler
-(cop_handler_dag.go:49-83 handleCopDAGRequest, :149-160 buildDAG) for fixed-width schemas (SURVEY.md §8 f rank 4).
+(cop_handler_dag.go:49-83 handleCopDAGRequest, :149-160 buildDAG), string columns included (SURVEY.md §8 f rank 4).
 
 The reference runs the pushed-down plan row at a time over `[][]byte` datums: tableScanExec (executor.go:48-196: DecodeRowKey +
 rowcodec.BytesDecoder.DecodeToBytes per KV pair) -> selectionExec (:322-390: decode the related columns, evalBool) -> hashAggExec
@@ -53,10 +53,8 @@ class tableScanExec(GpuExecutor):
     def __init__(self, ctx, columns, keys, values, value_offsets, batch_rows=1 << 22):
         self.columns = list(columns)
         types = [c.tsq_type() for c in self.columns]
-        if any(t is None or t == abi.BYTES for t in types):
-            # the device-resident chunks of this chain are fixed-width (gpu_pipeline.DeviceColumn); a scan with string columns decodes
-            # them through rowcodec.ChunkDecoder into host chunks and keeps the Go executors above it
-            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "var-len column in a device-resident coprocessor chain")
+        if any(t is None for t in types):
+            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "unknown type")  # TypeBit and friends: the Go executors
         super().__init__(ctx, types)
         self.raw_keys = np.frombuffer(keys, dtype=np.uint8) if isinstance(keys, (bytes, bytearray)) else np.ascontiguousarray(keys, dtype=np.uint8)
         self.raw_vals = np.frombuffer(values, dtype=np.uint8) if isinstance(values, (bytes, bytearray)) else np.ascontiguousarray(values, dtype=np.uint8)
@@ -76,7 +74,8 @@ class tableScanExec(GpuExecutor):
         ctx = self.ctx
         self.dk, self.dv, self.do = _DevBytes(ctx, self.raw_keys), _DevBytes(ctx, self.raw_vals), _DevBytes(ctx, self.offs)
         self.dh = ctx.alloc(max(self.n, 1) * 8 + 64)
-        self.out = self._buffers(min(self.batch, max(self.n, 8)))
+        # a string cell is a piece of its row: a var-len column of a batch cannot hold more bytes than the scanned values
+        self.out = self._buffers(min(self.batch, max(self.n, 8)), var_bytes=[self.raw_vals.size] * len(self.types))
         self.pos = self.count = 0
         # DecodeRowKey of every pair (one launch for the whole scan: 27 bytes of traffic per row)
         got = C.c_int64(0)
@@ -173,6 +172,12 @@ def fillUpData4SelectResponse(ctx, chunk, outputOffsets, chunks=None, rowCnt=0):
         return chunks, rowCnt
     cols = (abi.Col * len(outputOffsets))(*[chunk.columns[o].col(n) for o in outputOffsets])
     cap = n * len(outputOffsets) * 11 + 16
+    got = C.c_int64(0)
+    if any(chunk.columns[o].tp == abi.BYTES for o in outputOffsets):  # string cells: the size of the response is asked first
+        st = ctx.lib.tsq_rows_encode(ctx.h, cols, len(outputOffsets), None, n, None, 0, abi.COL_DEVICE, None, C.byref(got))
+        if st not in (abi.OK, abi.ERR_INVALID):
+            _lib.check(st, ctx.h)
+        cap = got.value + 16
     dout = ctx.alloc(cap + 64)
     doffs = ctx.alloc((n + 1) * 8 + 64)
     try:

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _abi as abi
 from . import _lib
-from .chunk import Chunk, Column, np_dtype
+from .chunk import Chunk, Column, StrColumn, np_dtype
 from .expression import Column as Column_
 from .expression import ETReal, CompiledExpr
 
@@ -29,37 +29,72 @@ def _es(tp):
 
 
 class DeviceColumn:
-    """one fixed-width column in HBM: data + optional null bitmap (bit 1 = NOT NULL, util/chunk/column.go:89-92)."""
+    """one column in HBM: data + optional null bitmap (bit 1 = NOT NULL, util/chunk/column.go:89-92); a var-len (abi.BYTES)
+    column also has offsets[cap + 1] and its data buffer holds `cap_bytes` bytes (column.go:28-34)."""
 
-    def __init__(self, ctx, tp, cap_rows, with_bitmap=True, data=None, bitmap=None):
+    def __init__(self, ctx, tp, cap_rows, with_bitmap=True, data=None, bitmap=None, offsets=None, cap_bytes=0):
         self.ctx, self.tp, self.cap = ctx, tp, cap_rows
+        self.var = tp == abi.BYTES
+        self.cap_bytes = cap_bytes
         self.owned = data is None
         if self.owned:
-            self.data = ctx.alloc(max(cap_rows, 1) * _es(tp) + 64)
+            self.data = ctx.alloc((max(cap_bytes, 1) if self.var else max(cap_rows, 1) * _es(tp)) + 64)
             self.bitmap = ctx.alloc((cap_rows + 7) // 8 + 64) if with_bitmap else None
+            self.offsets = ctx.alloc((cap_rows + 1) * 8 + 64) if self.var else None
         else:
-            self.data, self.bitmap = data, bitmap
+            self.data, self.bitmap, self.offsets = data, bitmap, offsets
 
     def col(self, nrows):
         c = abi.Col()
         c.data, c.null_bitmap, c.length = self.data, self.bitmap, nrows
-        c.elem_size, c.type, c.flags = _es(self.tp), self.tp, abi.COL_DEVICE
+        c.offsets = self.offsets if self.var else None
+        c.elem_size, c.type, c.flags = (-1 if self.var else _es(self.tp)), self.tp, abi.COL_DEVICE
         return c
 
     def view(self, lo):
-        """rows [lo, ...) — lo must be a multiple of 8 so that the bitmap stays byte aligned."""
+        """rows [lo, ...) — lo must be a multiple of 8 so that the bitmap stays byte aligned.  A var-len view keeps the data
+        base: the offsets index it (the rows' offsets need not start at 0, tsq_colset_slice)."""
         assert lo % 8 == 0
+        if self.var:
+            return DeviceColumn(self.ctx, self.tp, self.cap - lo, data=self.data, offsets=self.offsets + 8 * lo, cap_bytes=self.cap_bytes,
+                                bitmap=None if self.bitmap is None else self.bitmap + lo // 8)
         return DeviceColumn(self.ctx, self.tp, self.cap - lo, data=self.data + lo * _es(self.tp),
                             bitmap=None if self.bitmap is None else self.bitmap + lo // 8)
 
+    def nbytes(self, nrows):
+        """data bytes spanned by the first nrows cells of a var-len column (one 16-byte read-back)"""
+        if not self.var or nrows == 0:
+            return 0
+        o = np.zeros(1, np.int64)
+        e = np.zeros(1, np.int64)
+        self.ctx.d2h(o, self.offsets)
+        self.ctx.d2h(e, self.offsets + 8 * nrows)
+        return int(e[0] - o[0])
+
+    def ensure_bytes(self, nbytes):
+        """grow the data buffer of an owned var-len column (contents are not kept: called before a pull fills it)"""
+        if self.var and nbytes > self.cap_bytes:
+            assert self.owned
+            self.ctx.free(self.data)
+            self.cap_bytes = int(nbytes * 1.25) + 64
+            self.data = self.ctx.alloc(self.cap_bytes + 64)
+
     def to_host(self, nrows):
-        arr = np.zeros(max(nrows, 1), dtype=np_dtype(self.tp))
-        self.ctx.d2h(arr, self.data)
         nn = None
         if self.bitmap is not None:
             bm = np.zeros((nrows + 7) // 8 + 1, np.uint8)
             self.ctx.d2h(bm, self.bitmap)
             nn = np.unpackbits(bm, bitorder="little")[:nrows].astype(bool)
+        if self.var:
+            offs = np.zeros(nrows + 1, np.int64)
+            self.ctx.d2h(offs, self.offsets)
+            lo, hi = int(offs[0]), int(offs[nrows])
+            raw = np.zeros(max(hi - lo, 1), np.uint8)
+            if hi > lo:
+                self.ctx.d2h(raw, self.data + lo)
+            return StrColumn([bytes(raw[offs[r] - lo:offs[r + 1] - lo]) if (nn is None or nn[r]) else None for r in range(nrows)])
+        arr = np.zeros(max(nrows, 1), dtype=np_dtype(self.tp))
+        self.ctx.d2h(arr, self.data)
         return Column(self.tp, arr[:nrows].copy(), nn)
 
     def free(self):
@@ -67,7 +102,9 @@ class DeviceColumn:
             self.ctx.free(self.data)
             if self.bitmap is not None:
                 self.ctx.free(self.bitmap)
-        self.data = self.bitmap = None
+            if self.offsets is not None:
+                self.ctx.free(self.offsets)
+        self.data = self.bitmap = self.offsets = None
 
 
 class DeviceChunk:
@@ -94,10 +131,18 @@ class DeviceChunk:
     def from_host(ctx, chunk):
         cols = []
         for c in chunk.columns:
-            d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=True)
-            ctx.h2d(d.data, np.ascontiguousarray(c.data))
             nn = np.ones(len(c), bool) if c.notnull is None else c.notnull
-            ctx.h2d(d.bitmap, np.packbits(nn, bitorder="little"))
+            if c.tp == abi.BYTES:
+                nb = int(c.offsets[-1]) if len(c.offsets) else 0
+                d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=True, cap_bytes=nb)
+                if nb:
+                    ctx.h2d(d.data, np.ascontiguousarray(c.data[:nb]))
+                ctx.h2d(d.offsets, np.ascontiguousarray(c.offsets))
+            else:
+                d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=True)
+                ctx.h2d(d.data, np.ascontiguousarray(c.data))
+            if len(c):
+                ctx.h2d(d.bitmap, np.packbits(nn, bitorder="little"))
             cols.append(d)
         return DeviceChunk(cols, chunk.NumRows())
 
@@ -117,8 +162,18 @@ class GpuExecutor:
         for c in self.children:
             c.Close()
 
-    def _buffers(self, cap_rows):
-        return [DeviceColumn(self.ctx, t, cap_rows) for t in self.types]
+    def _buffers(self, cap_rows, var_bytes=None):
+        """output columns for up to cap_rows rows; var_bytes[i]: data bytes of var-len column i (grown later by ensure_bytes)"""
+        return [DeviceColumn(self.ctx, t, cap_rows, cap_bytes=(var_bytes[i] if var_bytes else 0) if t == abi.BYTES else 0) for i, t in enumerate(self.types)]
+
+    def _size_varlen(self, peek, handle, out, cap_rows):
+        """before a pull: ask how many data bytes the var-len output columns of the next pull need and grow their buffers"""
+        if abi.BYTES not in self.types:
+            return
+        vb, nr = (C.c_int64 * len(self.types))(), C.c_int64(0)
+        _lib.check(peek(handle, cap_rows, C.byref(nr), vb, len(self.types)), handle)
+        for c, b in zip(out, vb):
+            c.ensure_bytes(b)
 
 
 EOS = DeviceChunk([], 0)
@@ -181,6 +236,8 @@ class GpuSelectionExec(GpuExecutor):
                 self.cap = n
                 self.out = self._buffers(n)
                 self.flags = self.ctx.alloc(n + 64)
+            for src, dst in zip(chk.columns, self.out):  # a selection never grows a var-len column
+                dst.ensure_bytes(src.nbytes(n))
             w = C.c_int64(0)
             _lib.check(self.lib.tsq_filter_eval(self.expr.h, chk.cols(), len(chk.columns), n, None, self.flags, None, C.byref(w)), self.expr.h)
             self.expr.warnings += w.value
@@ -297,6 +354,7 @@ class GpuHashJoinExec(GpuExecutor):
             self.prepared = True
         n, eos = C.c_int64(0), C.c_int32(0)
         while True:
+            self._size_varlen(self.lib.tsq_join_peek, self.h, self.out, self.pull_rows)
             oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
             _lib.check(self.lib.tsq_join_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
             if n.value > 0:
@@ -367,6 +425,7 @@ class GpuHashAggExec(GpuExecutor):
             # aggregate over empty input (aggregate.go:572-574) is served by the host-chunk HashAggExec.
             return EOS
         n, eos = C.c_int64(0), C.c_int32(0)
+        self._size_varlen(self.lib.tsq_agg_peek, self.h, self.out, self.pull_rows)
         oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
         _lib.check(self.lib.tsq_agg_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
         if n.value == 0:
@@ -419,6 +478,7 @@ class GpuSortExec(GpuExecutor):
             _lib.check(self.lib.tsq_sort_finish(self.h), self.h)
             self.fetched = True
         n, eos = C.c_int64(0), C.c_int32(0)
+        self._size_varlen(self.lib.tsq_sort_peek, self.h, self.out, self.pull_rows)
         oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
         _lib.check(self.lib.tsq_sort_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
         return DeviceChunk(self.out, n.value) if n.value else EOS
