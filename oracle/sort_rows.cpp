@@ -3,8 +3,8 @@
  * TEST INFRASTRUCTURE ONLY (see oracle.h): the product never links or calls this file.
  *
  * Follows:
- *   chunk.GetCompareFunc / cmpNull / cmpInt64 / cmpUint64 / cmpFloat32 / cmpFloat64   util/chunk/compare.go:27-103
- *   types.CompareInt64 / CompareUint64 / CompareFloat64                              types/compare.go:22-43,103-112
+ *   chunk.GetCompareFunc / cmpNull / cmpInt64 / cmpUint64 / cmpString / cmpFloat32 / cmpFloat64   util/chunk/compare.go:27-103
+ *   types.CompareInt64 / CompareUint64 / CompareFloat64 / CompareString              types/compare.go:22-43,103-123
  *   SortExec.lessRow (ByItems, Desc negates the comparison)                           executor/sort.go:116-131
  *   SortExec.Next: sort.Slice(rowPtrs, keyColumnsLess)                                executor/sort.go:58-78
  *   TopNExec: rows [Offset, Offset+Count) of the sorted order                          executor/sort.go:213-238
@@ -31,6 +31,11 @@ int cmp_cell(const tsq_col& c, int64_t i, int64_t j) {
     switch (c.type) {
         case TSQ_I64: return cmp3(((const int64_t*)c.data)[i], ((const int64_t*)c.data)[j]);
         case TSQ_U64: return cmp3(((const uint64_t*)c.data)[i], ((const uint64_t*)c.data)[j]);
+        case TSQ_BYTES: {  // cmpString (compare.go:71-77): Go's string order = bytes, then the shorter first
+            const int64_t li = c.offsets[i + 1] - c.offsets[i], lj = c.offsets[j + 1] - c.offsets[j];
+            const int m = memcmp((const uint8_t*)c.data + c.offsets[i], (const uint8_t*)c.data + c.offsets[j], (size_t)std::min(li, lj));
+            return m ? (m < 0 ? -1 : 1) : cmp3(li, lj);
+        }
         case TSQ_F32: return cmp3((double)((const float*)c.data)[i], (double)((const float*)c.data)[j]);  // compare.go:86-92
         default: return cmp3(((const double*)c.data)[i], ((const double*)c.data)[j]);
     }

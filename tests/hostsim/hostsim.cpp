@@ -136,8 +136,28 @@ extern "C" void sim_sort_images(const void* data, int32_t type, int32_t desc, in
     for (int64_t i = 0; i < n; i++) out[i] = tsq_sort_image(data, type, desc, (uint64_t)i);
 }
 
-#include <stdlib.h>
+#include <algorithm>
 #include <vector>
+// ORDER BY a string column the way tsq_sort_finish walks it (tsq_sort.hip): one stable sort per image, least significant first —
+// the length, then the 8-byte chunks from the last to the first — and a last stable pass that puts the NULL rows first
+// (ascending) or last (descending).  perm_io holds the current row order (identity, or the order of the less significant keys).
+extern "C" void sim_sort_str_key(const uint8_t* data, const int64_t* offs, const uint8_t* notnull, int32_t desc, int64_t n, int64_t* perm_io) {
+    int64_t maxlen = 0;
+    for (int64_t i = 0; i < n; i++) maxlen = std::max(maxlen, offs[i + 1] - offs[i]);
+    const int n_sub = 1 + (int)((maxlen + 7) / 8);
+    std::vector<uint64_t> img((size_t)n);
+    for (int sub = 0; sub < n_sub; sub++) {
+        const int32_t chunk = sub == 0 ? -1 : n_sub - 1 - sub;
+        for (int64_t i = 0; i < n; i++) img[(size_t)i] = tsq_sort_image_str(data, offs, chunk, desc, (uint64_t)i);
+        std::stable_sort(perm_io, perm_io + n, [&](int64_t a, int64_t b) { return img[(size_t)a] < img[(size_t)b]; });
+    }
+    if (notnull) {
+        auto level = [&](int64_t r) { const int nn = (notnull[r >> 3] >> (r & 7)) & 1; return desc ? !nn : nn; };  // NULL first asc, last desc
+        std::stable_sort(perm_io, perm_io + n, [&](int64_t a, int64_t b) { return level(a) < level(b); });
+    }
+}
+
+#include <stdlib.h>
 // ---- stored rows -> columns (tsq_rowcodec_dp.h): a CPU walk-through of k_rowcodec_decode (tsq_rowcodec.hip) with the same tile
 // plan, the same staged copy (aligned 16-byte vectors into the tile; bytes outside `values` and stale tile bytes are garbage here), the same
 // per-lane row code and the same bitmap bytes (one ballot per 64 rows, lanes 0..7 store one byte each when it exists).

@@ -154,3 +154,41 @@ def test_sort_key_images_order_like_the_reference_comparators(sim, tp, desc):
             c = orc.row_compare(chk, [0], [desc], i, j)
             got = -1 if img[i] < img[j] else (1 if img[i] > img[j] else 0)
             assert got == c, (v[i], v[j], desc)
+
+
+def _string_key_cases():
+    rng = np.random.default_rng(77)
+    alphabet = [b"", b"\x00", b"\x00\x00", b"a", b"a\x00", b"ab", b"abc", b"abcdefgh", b"abcdefgh\x00", b"abcdefghi", b"abcdefgi", b"\xff", b"\xff\xff" * 5,
+                b"abcdefghijklmnop", b"abcdefghijklmnopq", b"abcdefghijklmnoq", b"b", b"B", b"\x80", b"\x7f"]
+    vals = list(alphabet) + [bytes(rng.integers(0, 256, int(rng.integers(0, 21)), dtype=np.uint8)) for _ in range(120)]
+    vals += [bytes(rng.integers(97, 100, int(rng.integers(0, 5)), dtype=np.uint8)) for _ in range(160)]  # many ties and shared prefixes
+    order = rng.permutation(len(vals))
+    return [vals[i] for i in order]
+
+
+@pytest.mark.parametrize("desc", [False, True])
+@pytest.mark.parametrize("with_nulls", [False, True])
+def test_string_sort_key_walk_orders_like_the_reference_comparator(sim, desc, with_nulls):
+    # tsq_sort_image_str + the sub-key sequence of tsq_sort_finish (length, then chunks last to first, then the NULL pass), each a
+    # stable sort, against the oracle's stable sort with cmpString (compare.go:71-77): the permutations are the same one
+    from tinysql_amd.chunk import StrColumn
+    sim.sim_sort_str_key.restype = None
+    sim.sim_sort_str_key.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+    vals = _string_key_cases()
+    if with_nulls:
+        vals = [None if i % 7 == 3 else v for i, v in enumerate(vals)]
+    col = StrColumn(vals)
+    n = len(vals)
+    perm = np.arange(n, dtype=np.int64)
+    bm = col.bitmap()
+    sim.sim_sort_str_key(col.data.ctypes.data_as(C.c_void_p), col.offsets.ctypes.data_as(C.c_void_p), None if bm is None else bm.ctypes.data_as(C.c_void_p),
+                         1 if desc else 0, n, perm.ctypes.data_as(C.c_void_p))
+    want = orc.sort_perm(Chunk([col]), [0], [desc])
+    assert perm.tolist() == want.tolist()
+    # and the oracle's order is Go's string order: bytes compare, NULL before everything (ascending)
+    ref = sorted(range(n), key=lambda i: (vals[i] is not None, vals[i] or b""), reverse=False)
+    if not desc:
+        assert want.tolist() == ref
+    else:
+        keys = [(vals[i] is not None, vals[i] or b"") for i in want]
+        assert all(keys[i] >= keys[i + 1] for i in range(n - 1))

@@ -214,9 +214,9 @@ def test_sort_call_sequence_and_cancel_contract(ctx):
     cfg.col_types[0] = abi.I64
     bad = abi.SortCfg()
     bad.n_cols, bad.n_keys, bad.limit_count = 1, 1, -1
-    bad.col_types[0] = 4  # TSQ_BYTES as an ORDER BY item: the string comparator keeps the Go operator (payload columns may be var-len)
+    bad.col_types[0] = 9  # not a column type
     h = C.c_void_p()
-    assert lib.tsq_sort_create(ctx.h, C.byref(bad), C.byref(h)) == abi.ERR_UNSUPPORTED
+    assert lib.tsq_sort_create(ctx.h, C.byref(bad), C.byref(h)) != abi.OK
     bad.col_types[0], bad.key_col[0] = abi.I64, 3
     assert lib.tsq_sort_create(ctx.h, C.byref(bad), C.byref(h)) == abi.ERR_INVALID
     _lib.check(lib.tsq_sort_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
@@ -325,3 +325,63 @@ def test_string_payload_device_resident(ctx, orc):
         lib.tsq_sort_destroy(h)
         for p in (dk, dkb, dd, do, db, od, oo, ob, okd, okb):
             ctx.free(p)
+
+
+# ------------------------------------------------------------------------------------------------ string ORDER BY items (round 2)
+def _string_keys(rng, n, kind):
+    if kind == "short":      # many ties, shared prefixes, the empty string
+        return [None if rng.random() < 0.08 else bytes(rng.integers(97, 100, int(rng.integers(0, 5)), dtype=np.uint8)) for _ in range(n)]
+    if kind == "binary":     # every byte value, zero bytes at the end (a string and the same string + "\0" differ)
+        return [None if rng.random() < 0.05 else bytes(rng.integers(0, 256, int(rng.integers(0, 12)), dtype=np.uint8)) + b"\0" * int(rng.integers(0, 3)) for _ in range(n)]
+    if kind == "long":       # three 8-byte chunks and more, differences late in the string
+        return [b"customer#%09d-%s" % (int(rng.integers(0, 50)), bytes(rng.integers(97, 123, int(rng.integers(0, 9)), dtype=np.uint8))) for _ in range(n)]
+    return [b"" for _ in range(n)]  # "empty": only the length image, and it is constant
+
+
+@pytest.mark.parametrize("n", [1, 64, 4097, 30_011])
+@pytest.mark.parametrize("kind", ["short", "binary", "long", "empty"])
+@pytest.mark.parametrize("desc", [False, True])
+def test_order_by_a_string_column_equals_the_stable_oracle(ctx, orc, n, kind, desc):
+    # cmpString (compare.go:71-77): bytes, then the shorter first; NULL before every string; Desc negates.  The string key runs as
+    # a sequence of stable radix sorts (length, then 8-byte chunks last to first), so equal strings keep input order like the oracle.
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(n * 7 + len(kind) + desc)
+    t = Chunk([StrColumn(_string_keys(rng, n, kind)), Column(abi.I64, np.arange(n, dtype=np.int64))])
+    want = orc.sort_rows(t, [0], [desc])
+    got = G.run_sort(ctx, t, [0], [desc], chunk_rows=1024, pull_rows=1000)
+    assert got.rows() == want.rows()
+
+
+@pytest.mark.parametrize("keys", [([1, 0], [False, False]), ([0, 1], [True, False]), ([2, 0, 3], [False, True, True]), ([0, 2], [False, False])])
+def test_string_and_number_order_by_items_mixed(ctx, orc, keys):
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(len(keys[0]) + keys[0][0])
+    n = 20_000
+    t = Chunk([StrColumn(_string_keys(rng, n, "short")), Column(abi.I64, rng.integers(0, 40, n), rng.random(n) >= 0.1), StrColumn(_string_keys(rng, n, "long")),
+               Column(abi.F64, np.round(rng.standard_normal(n), 1), rng.random(n) >= 0.1)])
+    want = orc.sort_rows(t, keys[0], keys[1])
+    got = G.run_sort(ctx, t, keys[0], keys[1], chunk_rows=4096, pull_rows=777)
+    assert got.rows() == want.rows()
+
+
+def test_string_key_topn_and_the_executor_mirror(ctx, orc):
+    # TopN on a string first key takes the full sort (no radix select: a string has no single image) and returns the window; a
+    # string SECOND key behind a selected first key sorts only the candidates (n >= 2^20 rows so that the select runs)
+    from tinysql_amd import executor as X
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(12)
+    n = 40_000
+    t = Chunk([StrColumn(_string_keys(rng, n, "long")), Column(abi.I64, rng.integers(0, 1000, n))])
+    want = orc.sort_rows(t, [0, 1], [True, False]).rows()
+    got = G.run_sort(ctx, t, [0, 1], [True, False], chunk_rows=4096, pull_rows=500, offset=100, count=3000)
+    assert got.rows() == want[100:3100]
+    chunks = X.drain(X.TopNExec(ctx, X.MockDataSource(ctx, t), [0, 1], [True, False], 5, 700))
+    assert [r for c in chunks for r in c.rows()] == want[5:705]
+    n = (1 << 20) + 17
+    k = rng.integers(0, 1 << 40, n)
+    k[rng.integers(0, n, 5000)] = 3  # ties on the first key inside the window: the string key orders them
+    t = Chunk([Column(abi.I64, k), StrColumn([b"s%03d" % int(x) for x in rng.integers(0, 300, n)])])
+    stats = []
+    got = G.run_sort(ctx, t, [0, 1], [False, False], chunk_rows=1 << 18, pull_rows=4096, offset=0, count=3000, stats_out=stats)
+    assert got.rows() == orc.sort_rows(t, [0, 1], [False, False]).rows()[:3000]
+    assert stats[0]["rows"] < n // 2

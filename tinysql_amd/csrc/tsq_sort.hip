@@ -37,9 +37,28 @@ struct SortKeySrc {
     const uint8_t* nulls;  // bit 1 = NOT NULL, or null
     int32_t type;
     int32_t desc;
+    const int64_t* offs;   // a var-len (string) key: its offsets; the image is then chunk `chunk` of the cell (tsq_sort_image.h)
+    int32_t chunk;         // >= 0: bytes [8 chunk, 8 chunk + 8); -1: the length
 };
 
-__device__ __forceinline__ uint64_t sort_image(const SortKeySrc& k, uint32_t row) { return tsq_sort_image(k.data, k.type, k.desc, row); }
+__device__ __forceinline__ uint64_t sort_image(const SortKeySrc& k, uint32_t row) {
+    if (k.type == TSQ_BYTES) return tsq_sort_image_str((const uint8_t*)k.data, k.offs, k.chunk, k.desc, row);
+    return tsq_sort_image(k.data, k.type, k.desc, row);
+}
+
+// longest cell of a var-len key column (the number of 8-byte chunks its images need)
+__global__ void __launch_bounds__(256) k_sort_str_maxlen(const int64_t* offs, int64_t n, unsigned long long* out) {
+    unsigned long long m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long l = (unsigned long long)(offs[i + 1] - offs[i]);
+        m = l > m ? l : m;
+    }
+    for (int o = 32; o; o >>= 1) {
+        const unsigned long long y = __shfl_xor(m, o, 64);
+        m = y > m ? y : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 
 struct SortArgs {
     SortKeySrc key;
@@ -505,7 +524,6 @@ TSQ_API tsq_status tsq_sort_create(tsq_ctx* ctx, const tsq_sort_cfg* cfg, tsq_so
         if (cfg->col_types[c] < TSQ_I64 || cfg->col_types[c] > TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_INVALID, "unknown column type");
     for (int k = 0; k < cfg->n_keys; k++) {
         if (cfg->key_col[k] < 0 || cfg->key_col[k] >= cfg->n_cols) return tsq_fail(ch, TSQ_ERR_INVALID, "ORDER BY column index out of range");
-        if (cfg->col_types[cfg->key_col[k]] == TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "ORDER BY a var-len column: fall back to the Go operator");
     }
     if (cfg->limit_offset < 0) return tsq_fail(ch, TSQ_ERR_INVALID, "negative offset");
     std::unique_ptr<tsq_sort> s(new tsq_sort());
@@ -596,7 +614,7 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
     int egrid = tsq_grid_for(ctx, n, 256, 4);
     s->rows_sorted = n;
     const int64_t K = s->last;  // rows of the order that are needed at all
-    if (s->cfg.limit_count >= 0 && n >= (1 << 20) && K * 16 <= n) {
+    if (s->cfg.limit_count >= 0 && n >= (1 << 20) && K * 16 <= n && s->cfg.col_types[s->cfg.key_col[0]] != TSQ_BYTES) {  // (a string has no single image to select on)
         // ---- TopN: radix select on the first ORDER BY item, then sort only the candidates (see k_select_hist)
         const int kc = s->cfg.key_col[0];
         a.key.data = s->cols[kc].data.p;
@@ -675,6 +693,26 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
         a.key.nulls = s->cols[kc].has_nulls ? s->cols[kc].nulls.as<uint8_t>() : nullptr;
         a.key.type = s->cfg.col_types[kc];
         a.key.desc = s->cfg.key_desc[k] ? 1 : 0;
+        a.key.offs = nullptr;
+        a.key.chunk = 0;
+        // a string key is a sequence of images, least significant first: its length, then its 8-byte chunks from the last to the
+        // first (tsq_sort_image.h); a fixed-width key is one image
+        int n_sub = 1;
+        if (a.key.type == TSQ_BYTES) {
+            a.key.offs = s->cols[kc].offs.as<int64_t>();
+            ((unsigned long long*)hcount.p)[0] = 0;
+            hipError_t e0 = hipMemcpyAsync(s->count8.p, hcount.p, 8, hipMemcpyHostToDevice, ctx->stream);
+            if (e0 == hipSuccess) {
+                hipLaunchKernelGGL(k_sort_str_maxlen, dim3(egrid), dim3(256), 0, ctx->stream, a.key.offs, n, (unsigned long long*)s->count8.p);
+                e0 = hipMemcpyAsync((char*)hcount.p + 32, s->count8.p, 8, hipMemcpyDeviceToHost, ctx->stream);
+            }
+            if (e0 == hipSuccess) e0 = hipStreamSynchronize(ctx->stream);
+            if (e0 != hipSuccess) { hcount.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("sort: ") + hipGetErrorString(e0)); }
+            const unsigned long long maxlen = ((const unsigned long long*)hcount.p)[4];
+            n_sub = 1 + (int)((maxlen + 7) / 8);
+        }
+        for (int sub = 0; sub < n_sub; sub++) {
+        if (a.key.type == TSQ_BYTES) a.key.chunk = sub == 0 ? -1 : n_sub - 1 - sub;  // length, then chunk m - 1 .. 0
         // images of this key column in the current row order (first key: identity order, row ids are initialised here)
         a.idx_in = have_idx ? s->idx[s->cur].as<uint32_t>() : nullptr;
         a.img_out = s->img[s->cur].as<uint64_t>();
@@ -696,6 +734,7 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
             st = sort_pass(s, a, d);
             if (st != TSQ_OK) { hcount.release(); return st; }
         }
+        }  // sub-keys
         if (a.key.nulls) {
             st = sort_pass(s, a, 8);
             if (st != TSQ_OK) { hcount.release(); return st; }

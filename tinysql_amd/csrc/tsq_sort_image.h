@@ -23,4 +23,22 @@ TSQ_HD uint64_t tsq_sort_image(const void* data, int32_t type, int32_t desc, uin
     return desc ? ~u : u;
 }
 
+// A STRING key (chunk.GetCompareFunc's cmpString: byte-wise, a prefix sorts before the longer string — Go's string order,
+// util/chunk/compare.go:71-77, types.CompareString types/compare.go:115-123) has no 64-bit image; it is a SEQUENCE of images, most significant first:
+//     chunk 0 = bytes [0, 8) big endian, zero padded;  chunk 1 = bytes [8, 16);  ...  chunk m - 1;  then the length
+// Zero padding makes a string and the same string followed by zero bytes look alike chunk by chunk — they differ exactly in their
+// lengths, and the shorter one is the smaller: the length is the last (least significant) image.  The stable least-significant-digit
+// sort processes the sequence backwards (length first, chunk 0 last).  chunk < 0 selects the length image.
+TSQ_HD uint64_t tsq_sort_image_str(const uint8_t* data, const int64_t* offs, int32_t chunk, int32_t desc, uint64_t row) {
+    const int64_t lo = offs[row], len = offs[row + 1] - lo;
+    uint64_t u = 0;
+    if (chunk < 0) {
+        u = (uint64_t)len;
+    } else {
+        const int64_t at = (int64_t)chunk * 8;
+        for (int i = 0; i < 8; i++) u = (u << 8) | (at + i < len ? (uint64_t)data[lo + at + i] : 0ull);
+    }
+    return desc ? ~u : u;
+}
+
 #endif
