@@ -442,6 +442,37 @@ tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data, int64_
                                   uint32_t data_flags, int32_t n_cols, const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows,
                                   int64_t* nrows_out);
 
+/* ---------------------------------------------------------------- the chunk wire format (SURVEY.md §8 a/A "wire Codec", f rank 2)
+ * Replaces chunk.Codec (util/chunk/codec.go:28-143) and chunk.Decoder (codec.go:233-353) on device chunks.  A wire chunk is its
+ * columns one after the other, each  u32 length | u32 nullCount | [(length + 7) / 8 bitmap bytes, only when nullCount > 0] |
+ * [(length + 1) int64 offsets, var-len only] | data  — little endian, no padding (codec.go:50-76).  This is the column-major response
+ * format a coprocessor can answer with instead of datum rows (tsq_rows_decode*): decoding it is a copy.
+ *
+ * tsq_chunk_encode = Codec.Encode (codec.go:42-48): cols (host, or TSQ_COL_DEVICE) -> out (host, or device with out_flags =
+ * TSQ_COL_DEVICE).  *bytes_out = the encoded length; cap_bytes = 0 only asks for it; a too small buffer -> TSQ_ERR_INVALID with
+ * *bytes_out set.  A column whose bitmap has no zero bit in its first nrows bits travels without it (nullCount = 0).
+ *
+ * tsq_chunk_decode = Codec.DecodeToChunk (codec.go:88-93) followed by Decoder.Decode (codec.go:257-269, 298-353): rows
+ * [first_row, first_row + max_rows) of the wire chunk (cut at its end) are APPENDED to out_cols behind the out_cols[c].length rows
+ * they already hold — data copied, var-len offsets rebased onto offsets[length] (an empty destination gets offsets[0] = 0), bitmap
+ * bits shifted to the destination's bit position with the bits beyond the last row cleared; a column without a wire bitmap appends
+ * set bits.  first_row must be a multiple of 8 (the Decoder consumes its intermediate chunk in multiples of 8 rows, codec.go:259);
+ * the buffers of out_cols must hold length + max_rows rows (tsq_chunk_decode_peek tells the data bytes of the var-len columns).
+ * out_cols[c].length is updated, *nrows_out = rows appended, *bytes_consumed = the length of the wire chunk (n_cols columns; the
+ * caller keeps the remainder, codec.go:93).  first_row = 0, max_rows >= length on empty out_cols is DecodeToChunk / ReuseIntermChk.
+ * Errors: TSQ_ERR_INVALID when the buffer ends inside a column, the offsets of a var-len column are damaged, or the columns have
+ * different lengths (the reference slices out of range and panics). */
+tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int64_t nrows, uint8_t* out, int64_t cap_bytes,
+                            uint32_t out_flags, int64_t* bytes_out);
+/* rows_total_out: Column.length of the wire chunk; nrows_out: rows the window holds; bytes_out[c]: data bytes of var-len column c in
+ * that window (0 for fixed-width columns); any out pointer may be NULL */
+tsq_status tsq_chunk_decode_peek(tsq_ctx* ctx, const uint8_t* buf, int64_t n_bytes, uint32_t data_flags, const int32_t* col_types,
+                                 int32_t n_cols, int64_t first_row, int64_t max_rows, int64_t* rows_total_out, int64_t* nrows_out,
+                                 int64_t* bytes_out, int64_t* bytes_consumed);
+tsq_status tsq_chunk_decode(tsq_ctx* ctx, const uint8_t* buf, int64_t n_bytes, uint32_t data_flags, const int32_t* col_types,
+                            int32_t n_cols, int64_t first_row, int64_t max_rows, tsq_col* out_cols, int64_t* nrows_out,
+                            int64_t* bytes_consumed);
+
 /* ---------------------------------------------------------------- stored rows (rowcodec v2) -> columns (SURVEY.md §8 f, rank 4)
  * Replaces the per-row loop around rowcodec.ChunkDecoder.DecodeToChunk (util/rowcodec/decoder.go:158-238; row.fromBytes /
  * findColID / getData, util/rowcodec/row.go:37-150) — equivalently the storage-side chain BytesDecoder.DecodeToBytes

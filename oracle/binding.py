@@ -111,6 +111,15 @@ def load():
     lib.orc_decode_record_key.argtypes = [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.orc_cop_hash_agg.restype = P
     lib.orc_cop_hash_agg.argtypes = [C.POINTER(abi.AggCfg), C.POINTER(abi.Col), C.c_int64, C.POINTER(C.c_int32)]
+    for name, res, args in [("orc_wire_new", P, [C.POINTER(C.c_int32), C.c_int32]), ("orc_wire_from_cols", P, [C.POINTER(abi.Col), C.c_int32, C.c_int64]),
+                            ("orc_wire_free", None, [P]), ("orc_wire_encode", C.c_int64, [P, P, C.c_int64]),
+                            ("orc_wire_decode_to_chunk", C.c_int64, [P, P, C.c_int64]), ("orc_wire_decoder_reset", C.c_int64, [P, P, C.c_int64]),
+                            ("orc_wire_decoder_remained", C.c_int64, [P]), ("orc_wire_decoder_decode", C.c_int64, [P, P, C.c_int64]),
+                            ("orc_wire_decoder_reuse", None, [P, P]), ("orc_wire_col_length", C.c_int64, [P, C.c_int32]),
+                            ("orc_wire_col_bitmap", C.c_int64, [P, C.c_int32, P, C.c_int64]), ("orc_wire_col_offsets", C.c_int64, [P, C.c_int32, P, C.c_int64]),
+                            ("orc_wire_col_data", C.c_int64, [P, C.c_int32, P, C.c_int64])]:
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = args
     _lib = lib
     return lib
 
@@ -527,3 +536,64 @@ def cop_hash_agg(cfg, chunk):
     if not res:
         raise OracleError(st.value)
     return _result_to_chunk(lib, res)
+
+
+# ---- the chunk wire format: chunk.Codec / chunk.Decoder (oracle/chunk_wire.cpp)
+class WireChunk:
+    """A chunk as the reference holds it: per column (length, nullBitmap bytes, offsets, data bytes)."""
+
+    def __init__(self, elem=None, handle=None):
+        self.lib = load()
+        if handle is None:
+            arr = (C.c_int32 * len(elem))(*elem)
+            handle = self.lib.orc_wire_new(arr, len(elem))
+        self.h = handle
+
+    @classmethod
+    def from_chunk(cls, chunk):
+        lib = load()
+        keep = []
+        cols = make_cols(chunk.columns, keep)
+        return cls(handle=lib.orc_wire_from_cols(cols, len(chunk.columns), chunk.NumRows()))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_wire_free(self.h)
+            self.h = None
+
+    def encode(self):  # Codec.Encode
+        n = self.lib.orc_wire_encode(self.h, None, 0)
+        out = np.zeros(n + 8, np.uint8)
+        self.lib.orc_wire_encode(self.h, out.ctypes.data_as(C.c_void_p), n)
+        return out[:n].tobytes()
+
+    def decode_to_chunk(self, buffer):  # Codec.DecodeToChunk: bytes consumed, or -1 (the reference panics)
+        raw = np.frombuffer(bytes(buffer) + b"\0" * 8, np.uint8)
+        return self.lib.orc_wire_decode_to_chunk(self.h, raw.ctypes.data_as(C.c_void_p), len(buffer))
+
+    def decoder_reset(self, data):
+        raw = np.frombuffer(bytes(data) + b"\0" * 8, np.uint8)
+        return self.lib.orc_wire_decoder_reset(self.h, raw.ctypes.data_as(C.c_void_p), len(data))
+
+    def decoder_remained(self):
+        return self.lib.orc_wire_decoder_remained(self.h)
+
+    def decoder_decode(self, chk, required):
+        return self.lib.orc_wire_decoder_decode(self.h, chk.h, required)
+
+    def decoder_reuse(self, chk):
+        self.lib.orc_wire_decoder_reuse(self.h, chk.h)
+
+    def column(self, c):
+        """(length, nullBitmap bytes, offsets or None, data bytes)"""
+        lib = self.lib
+        nb = lib.orc_wire_col_bitmap(self.h, c, None, 0)
+        bm = np.zeros(nb + 1, np.uint8)
+        lib.orc_wire_col_bitmap(self.h, c, bm.ctypes.data_as(C.c_void_p), nb)
+        no = lib.orc_wire_col_offsets(self.h, c, None, 0)
+        offs = np.zeros(no + 1, np.int64)
+        lib.orc_wire_col_offsets(self.h, c, offs.ctypes.data_as(C.c_void_p), no)
+        nd = lib.orc_wire_col_data(self.h, c, None, 0)
+        data = np.zeros(nd + 1, np.uint8)
+        lib.orc_wire_col_data(self.h, c, data.ctypes.data_as(C.c_void_p), nd)
+        return lib.orc_wire_col_length(self.h, c), bm[:nb].tobytes(), (offs[:no].tolist() if no else None), data[:nd].tobytes()

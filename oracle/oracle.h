@@ -132,6 +132,23 @@ int64_t orc_rowcodec_to_old_bytes(const uint8_t* row_data, int64_t len, int64_t 
 /* row.ColumnIsNull (util/rowcodec/row.go:152-165) */
 int32_t orc_rowcodec_column_is_null(const uint8_t* row_data, int64_t len, int64_t col_id, int32_t has_default);
 
+/* ---- the chunk wire format: chunk.Codec / chunk.Decoder (chunk_wire.cpp; SURVEY.md §8 a/A) — a chunk object holds every Column
+ * as the reference does (length, nullBitmap, offsets, data as byte slices) */
+typedef struct orc_wire_chunk orc_wire_chunk;
+orc_wire_chunk* orc_wire_new(const int32_t* elem, int32_t n_cols);                                  /* chunk.New; elem = getFixedLen: 4, 8, -1 */
+orc_wire_chunk* orc_wire_from_cols(const tsq_col* cols, int32_t n_cols, int64_t nrows);
+void    orc_wire_free(orc_wire_chunk* k);
+int64_t orc_wire_encode(const orc_wire_chunk* k, uint8_t* out, int64_t cap);                       /* Codec.Encode, codec.go:42-76 */
+int64_t orc_wire_decode_to_chunk(orc_wire_chunk* k, const uint8_t* buffer, int64_t n);            /* Codec.DecodeToChunk, codec.go:88-143; -1: out of range */
+int64_t orc_wire_decoder_reset(orc_wire_chunk* interm, const uint8_t* data, int64_t n);           /* Decoder.Reset, codec.go:272-275 */
+int64_t orc_wire_decoder_remained(const orc_wire_chunk* interm);
+int64_t orc_wire_decoder_decode(orc_wire_chunk* interm, orc_wire_chunk* chk, int64_t required);   /* Decoder.Decode, codec.go:257-269, 298-353 */
+void    orc_wire_decoder_reuse(orc_wire_chunk* interm, orc_wire_chunk* chk);                      /* Decoder.ReuseIntermChk, codec.go:291-308 */
+int64_t orc_wire_col_length(const orc_wire_chunk* k, int32_t c);
+int64_t orc_wire_col_bitmap(const orc_wire_chunk* k, int32_t c, uint8_t* out, int64_t cap);
+int64_t orc_wire_col_offsets(const orc_wire_chunk* k, int32_t c, int64_t* out, int64_t cap);
+int64_t orc_wire_col_data(const orc_wire_chunk* k, int32_t c, uint8_t* out, int64_t cap);
+
 /* ---- SortExec / TopNExec row order (sort_rows.cpp; SURVEY.md §8 f rank 3) */
 int32_t orc_row_compare(const tsq_col* cols, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t i, int64_t j);
 void    orc_sort_rows(const tsq_col* cols, int64_t nrows, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t* perm_out);

@@ -621,3 +621,19 @@ extern "C" uint64_t sim_rows_decode_chunks(const uint8_t* buf, int64_t guard, in
     *bad_touch_out = F.bad_touch;
     return err;
 }
+
+// ---- the chunk wire format (tsq_wire_dp.h): the header walk, and every lane of every workgroup of one piece of k_wire_move
+#include "../../tinysql_amd/csrc/tsq_wire_dp.h"
+extern "C" void sim_wire_walk(const uint8_t* buf, int64_t n_bytes, const int32_t* elem, int32_t n_cols, int64_t first, int64_t max_rows, uint64_t* out) {
+    tsq_wire_walk(buf, n_bytes, elem, n_cols, first, max_rows, out);
+}
+extern "C" void sim_wire_move(int32_t mode, const uint8_t* src, uint8_t* dst, int64_t n, int64_t imm) {
+    int64_t blocks = 1;  // MovePlan::add (tsq_wire.hip)
+    if (mode == WM_COPY) blocks = std::max<int64_t>(1, (n + TSQ_WIRE_BLOCK_BYTES - 1) / TSQ_WIRE_BLOCK_BYTES);
+    else if (mode == WM_BITS) blocks = std::max<int64_t>(1, (((imm + n + 7) >> 3) - (imm >> 3) + 4095) / 4096);
+    else if (mode == WM_OFFS) blocks = std::max<int64_t>(1, (n + 2047) / 2048);
+    if (mode != WM_HDR && n <= 0) return;
+    // WM_BITS reads the destination's first byte (the rows already there) in lane 0 of workgroup 0 only, before it writes it
+    for (int64_t b = 0; b < blocks; b++)
+        for (int t = 0; t < 256; t++) tsq_wire_move_lane(mode, src, dst, n, imm, b, t);
+}

@@ -171,6 +171,95 @@ public:
     Context& operator=(const Context&) = delete;
 };
 
+// ---------------------------------------------------------------- chunk.Codec / chunk.Decoder (util/chunk/codec.go:28-143, 233-353)
+// colTypes are the schema's column types; getFixedLen (codec.go:169-181) is their element size
+class Codec {
+public:
+    Context* ctx;
+    Schema colTypes;
+    Codec(Context* c, const Schema& t) : ctx(c), colTypes(t) {}
+    std::vector<uint8_t> Encode(Chunk& chk) {  // codec.go:42-48
+        std::vector<tsq_col> v = chk.Views();
+        int64_t need = 0;
+        check(tsq_chunk_encode(ctx->h, v.data(), (int32_t)v.size(), chk.NumRows(), nullptr, 0, 0, &need), ctx->h);
+        std::vector<uint8_t> buffer((size_t)need);
+        uint8_t dummy = 0;
+        check(tsq_chunk_encode(ctx->h, v.data(), (int32_t)v.size(), chk.NumRows(), need ? buffer.data() : &dummy, need, 0, &need), ctx->h);
+        return buffer;
+    }
+    // appends rows [first, first + maxRows) of the wire chunk to chk (Decoder.decodeColumn, codec.go:298-353); returns the rows
+    // appended, *used = the length of the wire chunk
+    int64_t decodeWindow(const uint8_t* buffer, int64_t n, int64_t first, int64_t maxRows, Chunk& chk, int64_t* used) {
+        const int nc = (int)colTypes.size();
+        std::vector<int64_t> bytes((size_t)nc);
+        int64_t total = 0, take = 0;
+        check(tsq_chunk_decode_peek(ctx->h, buffer, n, 0, colTypes.data(), nc, first, maxRows, &total, &take, bytes.data(), used), ctx->h);
+        std::vector<tsq_col> out;
+        for (int c = 0; c < nc; c++) {  // room for the appended rows behind the ones the destination holds
+            Column& col = chk.columns[(size_t)c];
+            const int64_t rows = col.length + take;
+            col.nullBitmap.resize((size_t)(rows + 7) / 8 + 1);
+            if (col.isVar()) {
+                col.offsets.resize((size_t)rows + 1);
+                col.data.resize((size_t)(col.offsets[(size_t)col.length] + bytes[(size_t)c]) + 8);
+            } else {
+                col.data.resize((size_t)rows * col.elemSize());
+            }
+            out.push_back(col.View(col.length));
+        }
+        int64_t got = 0;
+        check(tsq_chunk_decode(ctx->h, buffer, n, 0, colTypes.data(), nc, first, maxRows, out.data(), &got, used), ctx->h);
+        for (int c = 0; c < nc; c++) {
+            Column& col = chk.columns[(size_t)c];
+            col.length = out[(size_t)c].length;
+            col.nullBitmap.resize((size_t)(col.length + 7) / 8);
+            if (col.isVar()) col.data.resize((size_t)col.offsets[(size_t)col.length]);
+        }
+        return got;
+    }
+    // DecodeToChunk (codec.go:88-93): returns the remained bytes
+    std::vector<uint8_t> DecodeToChunk(const std::vector<uint8_t>& buffer, Chunk& chk) {
+        chk.Reset();
+        int64_t used = 0;
+        decodeWindow(buffer.data(), (int64_t)buffer.size(), 0, (int64_t)1 << 40, chk, &used);
+        return std::vector<uint8_t>(buffer.begin() + used, buffer.end());
+    }
+};
+
+class Decoder {  // codec.go:233-353; the intermediate chunk is the wire buffer itself, decoded window by window
+public:
+    Codec codec;
+    Chunk* intermChk;
+    int64_t remainedRows = 0, next = 0;
+    std::vector<uint8_t> data;
+    Decoder(Context* ctx, Chunk* chk, const Schema& colTypes) : codec(ctx, colTypes), intermChk(chk) {}
+    void Reset(const std::vector<uint8_t>& d) {  // codec.go:272-275
+        data = d;
+        next = 0;
+        check(tsq_chunk_decode_peek(codec.ctx->h, data.data(), (int64_t)data.size(), 0, codec.colTypes.data(), (int32_t)codec.colTypes.size(), 0, 0, &remainedRows,
+                                    nullptr, nullptr, nullptr), codec.ctx->h);
+    }
+    void Decode(Chunk& chk) {  // codec.go:257-269
+        int64_t requiredRows = chk.requiredRows - chk.NumRows();
+        requiredRows = (requiredRows + 7) >> 3 << 3;
+        if (requiredRows > remainedRows) requiredRows = remainedRows;
+        int64_t used = 0;
+        codec.decodeWindow(data.data(), (int64_t)data.size(), next, requiredRows, chk, &used);
+        next += requiredRows;
+        remainedRows -= requiredRows;
+    }
+    bool IsFinished() const { return remainedRows == 0; }
+    int64_t RemainedRows() const { return remainedRows; }
+    void ReuseIntermChk(Chunk& chk) {  // codec.go:291-308: the rest of the rows without a second copy
+        intermChk->Reset();
+        int64_t used = 0;
+        codec.decodeWindow(data.data(), (int64_t)data.size(), next, remainedRows, *intermChk, &used);
+        chk.SwapColumns(*intermChk);
+        next += remainedRows;
+        remainedRows = 0;
+    }
+};
+
 // ---------------------------------------------------------------- package executor
 class Executor {  // executor/executor.go:146-152
 public:

@@ -414,6 +414,36 @@ int main() {
             expect("executor.go:392-470 scan -> topN", render(Drain(&top)), {"1 30 <nil> 3", "2 20 bb 2"});
         }
     }
+    // ---- util/chunk/codec_test.go:29-71 TestCodec: (NULL, i, "<i>.12345", "<i>.12345") x 10 through Encode / DecodeToChunk
+    {
+        const Schema colTypes = {TSQ_I64, TSQ_I64, TSQ_BYTES, TSQ_BYTES};
+        Chunk oldChk(colTypes, 10);
+        for (int i = 0; i < 10; i++) {
+            const std::string str = std::to_string(i) + ".12345";
+            oldChk.columns[0].AppendNull();
+            oldChk.columns[1].AppendInt64(i);
+            oldChk.columns[2].AppendString(str);
+            oldChk.columns[3].AppendString(str);
+        }
+        Codec codec(&ctx, colTypes);
+        const std::vector<uint8_t> buffer = codec.Encode(oldChk);
+        expect_true("codec.go:50-76: 8+2+80 | 8+80 | 8+88+70 | 8+88+70 wire bytes", buffer.size() == 510 && buffer[0] == 10 && buffer[4] == 10 && buffer[94] == 0);
+        Chunk newChk(colTypes, 10);
+        const std::vector<uint8_t> remained = codec.DecodeToChunk(buffer, newChk);
+        expect_true("codec_test.go:52-55 remained / NumCols / NumRows", remained.empty() && newChk.NumCols() == 4 && newChk.NumRows() == 10);
+        Rows want;
+        for (int i = 0; i < 10; i++) want.push_back("<nil> " + std::to_string(i) + " " + std::to_string(i) + ".12345 " + std::to_string(i) + ".12345");
+        expect("codec_test.go:56-69 TestCodec rows", render({newChk}), want);
+        // Decoder: 10 rows into chunks that ask for 3 rows -> 8 + 2 (multiples of 8, codec.go:259), then the rest by ReuseIntermChk
+        Chunk interm(colTypes), part(colTypes, 3), rest(colTypes);
+        Decoder dec(&ctx, &interm, colTypes);
+        dec.Reset(buffer);
+        dec.Decode(part);
+        expect_true("codec.go:257-269 Decode takes a multiple of 8 rows", part.NumRows() == 8 && dec.RemainedRows() == 2 && !dec.IsFinished());
+        dec.ReuseIntermChk(rest);
+        expect_true("codec.go:291-308 ReuseIntermChk", dec.IsFinished() && rest.NumRows() == 2 && rest.columns[2].offsets[0] == 0);
+        expect("Decoder: the two parts are the rows", render({part, rest}), want);
+    }
     printf("%d passed, %d failed\n", g_pass, g_fail);
     return g_fail ? 1 : 0;
 }
