@@ -436,11 +436,30 @@ tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_byt
  * n_bytes bytes (a cell is a piece of the response).  All rows of all chunks are decoded: if they exceed cap_rows nothing is written
  * and the call returns TSQ_ERR_INVALID with *nrows_out = the rows needed.  Errors as for tsq_rows_decode, decided by the first
  * offending value in stream order (*nrows_out = the complete rows before it, already in out_cols); additionally TSQ_ERR_INVALID
- * "datum kind does not match the column type" (a bytes datum for a number column or the reverse) and TSQ_ERR_UNSUPPORTED for a
- * memcomparable bytes datum (flag 1: index keys). */
+ * "datum kind does not match the column type" (a bytes datum for a number column or the reverse).  A memcomparable bytes datum
+ * (flag 1: groups of 8 bytes + a marker, util/codec/bytes.go:35-118 — the EncodeKey form index keys hold) becomes a var-len cell too;
+ * its errors are DecodeBytes': "insufficient bytes to decode value" | "invalid marker byte" | "invalid padding byte". */
 tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks,
                                   uint32_t data_flags, int32_t n_cols, const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows,
                                   int64_t* nrows_out);
+
+/* ---------------------------------------------------------------- index scans: the pairs of an index range -> columns (SURVEY.md §8 f, rank 4)
+ * Replaces mocktikv's indexScanExec loop (store/mockstore/mocktikv/executor.go:191-320) = tablecodec.DecodeIndexKV
+ * (tablecodec/tablecodec.go:376-434) per pair + the DecodeOne of every cut value by the executors above it.  Key k = bytes
+ * [key_offsets[k], key_offsets[k+1]) of `keys`:  't' | EncodeInt(tableID) | "_i" | EncodeInt(indexID)  (19 bytes, skipped like
+ * CutIndexKeyNew does)  | n_index_cols datums in EncodeKey form (ints flag 3, uints 4, reals 5, strings flag 1 + memcomparable
+ * groups, NULL 0; the value forms are accepted too, like DecodeOne)  | [the handle as an int datum — a non-unique index].
+ * pk_status (tablecodec.PrimaryKeyStatus): 0 = no handle column; 1 / 2 = out column n_index_cols is the handle (TSQ_I64 / TSQ_U64):
+ * taken from the key when bytes remain behind the index columns, otherwise from the pair's value (bytes [value_offsets[k],
+ * value_offsets[k+1]) of `values`, 8 bytes big endian: DecodeIndexValueAsHandle, tablecodec.go:456-465).
+ * col_types / out_cols: n_index_cols (+ 1) entries; out_cols sized for n_keys rows, a TSQ_BYTES column with offsets[n_keys + 1] and
+ * a data buffer of n_bytes bytes.  data_flags: TSQ_COL_DEVICE when keys / key_offsets / values / value_offsets are in HBM.
+ * Errors are decided by the first offending pair in key order (*nkeys_out = the pairs before it, already in out_cols):
+ * TSQ_ERR_INVALID "invalid encoded key" (a key shorter than its prefix + columns) | the DecodeOne errors of tsq_rows_decode_chunks |
+ * "no handle in index key or value". */
+tsq_status tsq_indexkeys_decode(tsq_ctx* ctx, const uint8_t* keys, int64_t n_bytes, const int64_t* key_offsets, int64_t n_keys,
+                                const uint8_t* values, int64_t n_value_bytes, const int64_t* value_offsets, uint32_t data_flags,
+                                int32_t n_index_cols, const int32_t* col_types, int32_t pk_status, tsq_col* out_cols, int64_t* nkeys_out);
 
 /* ---------------------------------------------------------------- the chunk wire format (SURVEY.md §8 a/A "wire Codec", f rank 2)
  * Replaces chunk.Codec (util/chunk/codec.go:28-143) and chunk.Decoder (codec.go:233-353) on device chunks.  A wire chunk is its

@@ -120,6 +120,10 @@ def load():
                             ("orc_wire_col_data", C.c_int64, [P, C.c_int32, P, C.c_int64])]:
         getattr(lib, name).restype = res
         getattr(lib, name).argtypes = args
+    lib.orc_encode_index_keys.restype = C.c_int64
+    lib.orc_encode_index_keys.argtypes = [C.POINTER(abi.Col), C.c_int32, C.c_int64, C.c_int64, C.c_int64, P, P, P, C.c_int64, P]
+    lib.orc_decode_index_kv.restype = P
+    lib.orc_decode_index_kv.argtypes = [P, C.c_int64, P, C.c_int64, P, P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 
@@ -322,7 +326,7 @@ def encode_rows(chunk, comparable=False):
     cols = make_cols(chunk.columns, keep)
     n = chunk.NumRows()
     var = sum(int(c.offsets[-1]) for c in chunk.columns if c.tp == abi.BYTES and len(c.offsets))
-    out = np.zeros(max(1, n * len(chunk.columns) * 11 + 16 + var), np.uint8)
+    out = np.zeros(max(1, n * len(chunk.columns) * 11 + 16 + var + (var // 8 + n * len(chunk.columns) + 1) * 2), np.uint8)  # (grouped strings: 9 bytes per 8)
     got = lib.orc_encode_rows(cols, len(chunk.columns), n, 1 if comparable else 0, out.ctypes.data_as(C.c_void_p), out.size)
     assert got >= 0
     return out[:got].copy()
@@ -597,3 +601,36 @@ class WireChunk:
         data = np.zeros(nd + 1, np.uint8)
         lib.orc_wire_col_data(self.h, c, data.ctypes.data_as(C.c_void_p), nd)
         return lib.orc_wire_col_length(self.h, c), bm[:nb].tobytes(), (offs[:no].tolist() if no else None), data[:nd].tobytes()
+
+
+# ---- index keys (oracle/codec_rows.cpp)
+def encode_index_keys(chunk, table_id, index_id, handles=None, handle_in_key=None):
+    """EncodeIndexSeekKey(tableID, idxID, EncodeKey(values...[, handle])) of every row -> (keys np.uint8, key_offsets np.int64)."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    n = chunk.NumRows()
+    var = sum(int(c.offsets[-1]) for c in chunk.columns if c.tp == abi.BYTES and len(c.offsets))
+    cap = n * (19 + 9 + 11 * len(chunk.columns)) + (var // 8 + n * len(chunk.columns) + 1) * 9 + var + 64
+    out = np.zeros(cap, np.uint8)
+    offs = np.zeros(n + 1, np.int64)
+    h = None if handles is None else np.ascontiguousarray(handles, dtype=np.int64)
+    f = None if handle_in_key is None else np.ascontiguousarray(handle_in_key, dtype=np.uint8)
+    got = lib.orc_encode_index_keys(cols, len(chunk.columns), n, table_id, index_id, None if h is None else h.ctypes.data_as(C.c_void_p),
+                                    None if f is None else f.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), cap, offs.ctypes.data_as(C.c_void_p))
+    assert got >= 0
+    return out[:got].copy(), offs
+
+
+def decode_index_kv(keys, key_offsets, values, value_offsets, n_index_cols, types, pk_status):
+    """indexScanExec: tablecodec.DecodeIndexKV of every pair -> (status, Chunk of the pairs before the first offending one)."""
+    lib = load()
+    raw = np.frombuffer(bytes(keys) + b"\0" * 8, np.uint8)
+    ko = np.ascontiguousarray(key_offsets, dtype=np.int64)
+    v = None if values is None else np.frombuffer(bytes(values) + b"\0" * 8, np.uint8)
+    vo = None if value_offsets is None else np.ascontiguousarray(value_offsets, dtype=np.int64)
+    tp = (C.c_int32 * len(types))(*types)
+    st = C.c_int32(0)
+    res = lib.orc_decode_index_kv(raw.ctypes.data_as(C.c_void_p), len(keys), ko.ctypes.data_as(C.c_void_p), len(ko) - 1, None if v is None else v.ctypes.data_as(C.c_void_p),
+                                  None if vo is None else vo.ctypes.data_as(C.c_void_p), n_index_cols, tp, pk_status, C.byref(st))
+    return st.value, _result_to_chunk(lib, res)

@@ -103,17 +103,40 @@ int32_t orc_value_size_unsigned(uint64_t v) {
 /* encode (codec.go:74-99) of rows of fixed-width columns, row after row as the coprocessor writes them.
  * I64 -> KindInt64, U64 -> KindUint64, F32/F64 -> floatFlag + EncodeFloat(float64(v)), NULL -> NilFlag.
  * Returns the number of bytes written (the call fails with -1 if cap is too small: at most 11 bytes per value). */
+static int64_t encode_rows_impl(const tsq_col* cols, int32_t n_cols, int64_t nrows, int32_t comparable, uint8_t* out, int64_t cap, int64_t* row_ends);
 int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int32_t comparable, uint8_t* out, int64_t cap) {
+    return encode_rows_impl(cols, n_cols, nrows, comparable, out, cap, nullptr);
+}
+static int64_t encode_rows_impl(const tsq_col* cols, int32_t n_cols, int64_t nrows, int32_t comparable, uint8_t* out, int64_t cap, int64_t* row_ends) {
     int64_t n = 0;
-    for (int64_t r = 0; r < nrows; r++)
+    for (int64_t r = 0; r < nrows; r++) {
+        if (row_ends && r > 0) row_ends[r - 1] = n;
         for (int c = 0; c < n_cols; c++) {
             if (n + 11 > cap) return -1;
             const tsq_col& col = cols[c];
             if (is_null(col, r)) { out[n++] = NilFlag; continue; }
-            if (col.type == TSQ_BYTES) {  // encodeBytes (codec.go:101-109): comparable -> bytesFlag + EncodeBytes (not built here);
+            if (col.type == TSQ_BYTES) {  // encodeBytes (codec.go:101-109): comparable -> bytesFlag + EncodeBytes (bytes.go:35-67);
                                           // otherwise compactBytesFlag + EncodeCompactBytes = varint(len) + the bytes (bytes.go:141-148)
-                if (comparable) return -1;
                 const int64_t lo = col.offsets[r], len = col.offsets[r + 1] - lo;
+                if (comparable) {
+                    if (n + 1 + (len / 8 + 1) * 9 > cap) return -1;
+                    out[n++] = bytesFlag;
+                    const uint8_t* d = (const uint8_t*)col.data + lo;
+                    for (int64_t idx = 0; idx <= len; idx += 8) {  // [group1][marker1]...[groupN][markerN]
+                        const int64_t remain = len - idx;
+                        int pad = 0;
+                        if (remain >= 8) { memcpy(out + n, d + idx, 8); n += 8; }
+                        else {
+                            pad = (int)(8 - remain);
+                            memcpy(out + n, d + idx, (size_t)remain);
+                            n += remain;
+                            memset(out + n, 0, (size_t)pad);
+                            n += pad;
+                        }
+                        out[n++] = (uint8_t)(0xFF - pad);
+                    }
+                    continue;
+                }
                 if (n + 11 + len > cap) return -1;
                 out[n++] = compactBytesFlag;
                 n += (int64_t)put_varint(out + n, len);
@@ -142,6 +165,8 @@ int64_t orc_encode_rows(const tsq_col* cols, int32_t n_cols, int64_t nrows, int3
                 }
             }
         }
+    }
+    if (row_ends && nrows > 0) row_ends[nrows - 1] = n;
     return n;
 }
 
@@ -228,10 +253,88 @@ int32_t orc_decode_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, co
     return 0;
 }
 
+namespace {
+// Decoder.DecodeOne (codec.go:623-690) of the value at data[pos ..end) for a column of type `type`: 0, or the status of
+// orc_decode_rows_chunks.  A string cell is (pointer, length); a memcomparable one is decoded into `owned` first.
+int decode_one(const uint8_t* data, int64_t& pos, int64_t end, int32_t type, uint64_t& bits, uint8_t& nn, std::pair<const uint8_t*, int64_t>& cell,
+               std::string& owned) {
+    if (end - pos < 1) return 1;  // codec.go:624-626
+    const uint8_t flag = data[pos++];
+    const uint8_t* b = data + pos;
+    const int64_t left = end - pos;
+    int kind = 0;  // 0 null 1 int 2 uint 3 real 4 bytes
+    switch (flag) {
+        case intFlag: if (left < 8) return 2; bits = get_be64(b) ^ signMask; pos += 8; kind = 1; break;
+        case uintFlag: if (left < 8) return 2; bits = get_be64(b); pos += 8; kind = 2; break;
+        case floatFlag: {
+            if (left < 8) return 2;
+            const double f = decodeCmpUintToFloat(get_be64(b));
+            memcpy(&bits, &f, 8);
+            pos += 8;
+            kind = 3;
+            break;
+        }
+        case varintFlag:
+        case uvarintFlag:
+        case compactBytesFlag: {
+            uint64_t ux;
+            const int kb = uvarint(b, left, &ux);
+            if (kb < 0) return 3;
+            if (kb == 0) return 2;
+            pos += kb;
+            int64_t x = (int64_t)(ux >> 1);
+            if (ux & 1) x = ~x;
+            if (flag == uvarintFlag) { bits = ux; kind = 2; }
+            else if (flag == varintFlag) { bits = (uint64_t)x; kind = 1; }
+            else {
+                if (x < 0 || end - pos < x) return 2;  // "insufficient bytes to decode value, expected length"
+                cell = {data + pos, x};
+                pos += x;
+                kind = 4;
+            }
+            break;
+        }
+        case NilFlag: break;
+        case bytesFlag: {  // decodeBytes (bytes.go:69-112)
+            std::string& buf = owned;
+            for (;;) {
+                if (end - pos < 9) return 2;
+                const uint8_t* group = data + pos;
+                const unsigned pad = 0xFFu - group[8];
+                if (pad > 8) return 7;  // "invalid marker byte"
+                buf.append((const char*)group, 8 - pad);
+                pos += 9;
+                if (pad != 0) {
+                    for (unsigned q = 8 - pad; q < 8; q++)
+                        if (group[q] != 0) return 8;  // "invalid padding byte"
+                    break;
+                }
+            }
+            cell = {(const uint8_t*)buf.data(), (int64_t)buf.size()};
+            kind = 4;
+            break;
+        }
+        default: return 4;
+    }
+    if (kind != 0 && (type == TSQ_BYTES) != (kind == 4)) return 6;
+    nn = kind != 0;
+    if (kind != 0 && type == TSQ_F32) {
+        float f32;
+        if (kind == 3) { double f; memcpy(&f, &bits, 8); f32 = (float)f; }
+        else memcpy(&f32, &bits, 4);
+        uint32_t w;
+        memcpy(&w, &f32, 4);
+        bits = w;
+    }
+    return 0;
+}
+}  // namespace
+
 /* selectResult over the chunks of a response (select_result.go:102-155): every chunk is decoded to its end with DecodeOne
  * (codec.go:623-690), bytes datums included (compactBytesFlag -> DecodeCompactBytes, bytes.go:150-160 -> chk.AppendBytes).  Status as
- * orc_decode_rows, plus 6 = a datum whose kind cannot go into the column (a string for a number column or the reverse), 5 = a
- * memcomparable bytes datum (bytesFlag).  The result holds the complete rows before the first offending value. */
+ * orc_decode_rows, plus 6 = a datum whose kind cannot go into the column (a string for a number column or the reverse); a
+ * memcomparable bytes datum (bytesFlag -> DecodeBytes, bytes.go:69-118): 7 = "invalid marker byte", 8 = "invalid padding byte".
+ * The result holds the complete rows before the first offending value. */
 orc_result* orc_decode_rows_chunks(const uint8_t* data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks, int32_t n_cols,
                                    const int32_t* types, int32_t* status) {
     orc_result* res = new orc_result();
@@ -246,57 +349,10 @@ orc_result* orc_decode_rows_chunks(const uint8_t* data, int64_t n_bytes, const i
             std::vector<uint64_t> bits((size_t)n_cols, 0);
             std::vector<uint8_t> nn((size_t)n_cols, 0);
             std::vector<std::pair<const uint8_t*, int64_t>> cell((size_t)n_cols, {nullptr, 0});
+            std::vector<std::string> owned((size_t)n_cols);  // DecodeBytes output (a memcomparable cell is not contiguous in the response)
             for (int c = 0; c < n_cols; c++) {
-                if (end - pos < 1) { *status = 1; return res; }  // codec.go:624-626
-                const uint8_t flag = data[pos++];
-                const uint8_t* b = data + pos;
-                const int64_t left = end - pos;
-                int kind = 0;  // 0 null 1 int 2 uint 3 real 4 bytes
-                switch (flag) {
-                    case intFlag: if (left < 8) { *status = 2; return res; } bits[c] = get_be64(b) ^ signMask; pos += 8; kind = 1; break;
-                    case uintFlag: if (left < 8) { *status = 2; return res; } bits[c] = get_be64(b); pos += 8; kind = 2; break;
-                    case floatFlag: {
-                        if (left < 8) { *status = 2; return res; }
-                        const double f = decodeCmpUintToFloat(get_be64(b));
-                        memcpy(&bits[c], &f, 8);
-                        pos += 8;
-                        kind = 3;
-                        break;
-                    }
-                    case varintFlag:
-                    case uvarintFlag:
-                    case compactBytesFlag: {
-                        uint64_t ux;
-                        const int kb = uvarint(b, left, &ux);
-                        if (kb < 0) { *status = 3; return res; }
-                        if (kb == 0) { *status = 2; return res; }
-                        pos += kb;
-                        int64_t x = (int64_t)(ux >> 1);
-                        if (ux & 1) x = ~x;
-                        if (flag == uvarintFlag) { bits[c] = ux; kind = 2; }
-                        else if (flag == varintFlag) { bits[c] = (uint64_t)x; kind = 1; }
-                        else {
-                            if (x < 0 || end - pos < x) { *status = 2; return res; }  // "insufficient bytes to decode value, expected length"
-                            cell[c] = {data + pos, x};
-                            pos += x;
-                            kind = 4;
-                        }
-                        break;
-                    }
-                    case NilFlag: break;
-                    case bytesFlag: *status = 5; return res;
-                    default: *status = 4; return res;
-                }
-                if (kind != 0 && (types[c] == TSQ_BYTES) != (kind == 4)) { *status = 6; return res; }
-                nn[c] = kind != 0;
-                if (kind != 0 && types[c] == TSQ_F32) {
-                    float f32;
-                    if (kind == 3) { double f; memcpy(&f, &bits[c], 8); f32 = (float)f; }
-                    else memcpy(&f32, &bits[c], 4);
-                    uint32_t w;
-                    memcpy(&w, &f32, 4);
-                    bits[c] = w;
-                }
+                const int st = decode_one(data, pos, end, types[c], bits[(size_t)c], nn[(size_t)c], cell[(size_t)c], owned[(size_t)c]);
+                if (st != 0) { *status = st; return res; }
             }
             for (int c = 0; c < n_cols; c++) {
                 if (types[c] == TSQ_BYTES && nn[c]) res->cols[c].append_bytes(cell[c].first, (size_t)cell[c].second);
@@ -304,6 +360,80 @@ orc_result* orc_decode_rows_chunks(const uint8_t* data, int64_t n_bytes, const i
             }
             res->rows++;
         }
+    }
+    return res;
+}
+
+/* Index keys of the rows of a chunk: EncodeIndexSeekKey (tablecodec.go:87-93) = 't' | EncodeInt(tableID) | "_i" | EncodeInt(indexID) |
+ * EncodeKey(values...) (codec.go:199-203), and behind it the handle as an int datum where handle_in_key[r] != 0 (a non-unique index:
+ * `EncodeKey(.., append(values, handle))`).  key_offsets_out: nrows + 1 entries.  Returns the bytes written, -1 when cap is too small. */
+int64_t orc_encode_index_keys(const tsq_col* cols, int32_t n_cols, int64_t nrows, int64_t table_id, int64_t index_id, const int64_t* handles,
+                              const uint8_t* handle_in_key, uint8_t* out, int64_t cap, int64_t* key_offsets_out) {
+    std::vector<uint8_t> vals((size_t)cap + 64);
+    std::vector<int64_t> ends((size_t)nrows + 1, 0);
+    const int64_t got = encode_rows_impl(cols, n_cols, nrows, 1, vals.data(), cap, ends.data());
+    if (got < 0) return -1;
+    int64_t n = 0, prev = 0;
+    for (int64_t r = 0; r < nrows; r++) {
+        key_offsets_out[r] = n;
+        const int64_t len = ends[(size_t)r] - prev;
+        if (n + 19 + len + 9 > cap) return -1;
+        out[n++] = 't';
+        put_be64(out + n, (uint64_t)table_id ^ signMask); n += 8;  // codec.EncodeInt = EncodeIntToCmpUint, big endian (number.go:24-42)
+        out[n++] = '_'; out[n++] = 'i';
+        put_be64(out + n, (uint64_t)index_id ^ signMask); n += 8;
+        memcpy(out + n, vals.data() + prev, (size_t)len); n += len;
+        prev = ends[(size_t)r];
+        if (handle_in_key && handle_in_key[r]) { out[n++] = intFlag; put_be64(out + n, (uint64_t)handles[r] ^ signMask); n += 8; }
+    }
+    key_offsets_out[nrows] = n;
+    return n;
+}
+
+/* indexScanExec (mocktikv/executor.go:191-320) over all pairs of a range: tablecodec.DecodeIndexKV (tablecodec.go:376-434) —
+ * CutIndexKeyNew cuts n_index_cols values behind the 19-byte prefix, what remains is the handle datum (kept when pk_status != 0),
+ * otherwise the pair's value holds the handle (DecodeIndexValueAsHandle, :456-465: 8 bytes big endian) — and every cut value through
+ * DecodeOne into its column (what the executors above the scan do with it).  types: n_index_cols (+ 1: the handle column when
+ * pk_status != 0; 1 = signed, 2 = unsigned).  Status as orc_decode_rows_chunks, plus 9 = no handle in key or value; the result holds
+ * the pairs before the first offending one. */
+orc_result* orc_decode_index_kv(const uint8_t* keys, int64_t n_bytes, const int64_t* key_offsets, int64_t n_keys, const uint8_t* values,
+                                const int64_t* value_offsets, int32_t n_index_cols, const int32_t* types, int32_t pk_status, int32_t* status) {
+    const int n_cols = n_index_cols + (pk_status != 0 ? 1 : 0);
+    orc_result* res = new orc_result();
+    res->cols.resize((size_t)n_cols);
+    for (int c = 0; c < n_cols; c++) res->cols[(size_t)c].type = types[c];
+    *status = 0;
+    for (int64_t k = 0; k < n_keys; k++) {
+        int64_t pos = key_offsets[k];
+        const int64_t end = key_offsets[k + 1];
+        if (pos < 0 || end < pos || end > n_bytes || end - pos < 19) { *status = 1; return res; }
+        pos += 19;  // key[prefixLen+idLen:]
+        std::vector<uint64_t> bits((size_t)n_cols, 0);
+        std::vector<uint8_t> nn((size_t)n_cols, 0);
+        std::vector<std::pair<const uint8_t*, int64_t>> cell((size_t)n_cols, {nullptr, 0});
+        std::vector<std::string> owned((size_t)n_cols);
+        for (int c = 0; c < n_index_cols; c++) {
+            const int st = decode_one(keys, pos, end, types[c], bits[(size_t)c], nn[(size_t)c], cell[(size_t)c], owned[(size_t)c]);
+            if (st != 0) { *status = st; return res; }
+        }
+        if (pk_status != 0) {
+            const size_t hc = (size_t)n_index_cols;
+            if (pos < end) {  // len(b) > 0: values = append(values, b)
+                const int st = decode_one(keys, pos, end, TSQ_I64, bits[hc], nn[hc], cell[hc], owned[hc]);
+                if (st != 0) { *status = st; return res; }
+                if (!nn[hc]) { *status = 6; return res; }  // a NULL handle datum
+            } else {
+                const int64_t vlo = value_offsets ? value_offsets[k] : 0, vhi = value_offsets ? value_offsets[k + 1] : -1;
+                if (!values || vhi - vlo < 8) { *status = 9; return res; }
+                bits[hc] = get_be64(values + vlo);
+                nn[hc] = 1;
+            }
+        }
+        for (int c = 0; c < n_cols; c++) {
+            if (types[c] == TSQ_BYTES && nn[(size_t)c]) res->cols[(size_t)c].append_bytes(cell[(size_t)c].first, (size_t)cell[(size_t)c].second);
+            else res->cols[(size_t)c].append_raw(bits[(size_t)c], nn[(size_t)c] != 0);
+        }
+        res->rows++;
     }
     return res;
 }

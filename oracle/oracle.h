@@ -149,6 +149,12 @@ int64_t orc_wire_col_bitmap(const orc_wire_chunk* k, int32_t c, uint8_t* out, in
 int64_t orc_wire_col_offsets(const orc_wire_chunk* k, int32_t c, int64_t* out, int64_t cap);
 int64_t orc_wire_col_data(const orc_wire_chunk* k, int32_t c, uint8_t* out, int64_t cap);
 
+/* ---- index keys: EncodeIndexSeekKey + EncodeKey, and indexScanExec's DecodeIndexKV (codec_rows.cpp; SURVEY.md §8 f rank 4) */
+int64_t orc_encode_index_keys(const tsq_col* cols, int32_t n_cols, int64_t nrows, int64_t table_id, int64_t index_id, const int64_t* handles,
+                              const uint8_t* handle_in_key, uint8_t* out, int64_t cap, int64_t* key_offsets_out);
+orc_result* orc_decode_index_kv(const uint8_t* keys, int64_t n_bytes, const int64_t* key_offsets, int64_t n_keys, const uint8_t* values,
+                                const int64_t* value_offsets, int32_t n_index_cols, const int32_t* types, int32_t pk_status, int32_t* status);
+
 /* ---- SortExec / TopNExec row order (sort_rows.cpp; SURVEY.md §8 f rank 3) */
 int32_t orc_row_compare(const tsq_col* cols, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t i, int64_t j);
 void    orc_sort_rows(const tsq_col* cols, int64_t nrows, const int32_t* key_col, const int32_t* key_desc, int32_t n_keys, int64_t* perm_out);

@@ -564,6 +564,7 @@ extern "C" uint64_t sim_rows_decode_chunks(const uint8_t* buf, int64_t guard, in
                 F.fetch12(p, hi, &b0, &b1, &b2);
                 tsq_decc_val v;
                 code = tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v);
+                if (code == DEC_VARLEN) code = tsq_decc_membytes(buf + guard + phase + p, (uint64_t)(hi - p), &v);
                 uint64_t bits;
                 if (code == DEC_OK && !tsq_decc_store(types[col], v, &bits)) code = DEC_KIND_MISMATCH;
                 if (code != DEC_OK) break;
@@ -602,12 +603,15 @@ extern "C" uint64_t sim_rows_decode_chunks(const uint8_t* buf, int64_t guard, in
             uint32_t b0, b1, b2;
             F.fetch12(p, hi, &b0, &b1, &b2);
             tsq_decc_val v;
-            if (tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v) != DEC_OK) break;
+            int code = tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v);
+            const bool grouped = code == DEC_VARLEN;
+            if (grouped) code = tsq_decc_membytes(buf + guard + phase + p, (uint64_t)(hi - p), &v);
+            if (code != DEC_OK) break;
             uint64_t bits;
             (void)tsq_decc_store(types[col], v, &bits);
             const int64_t row = base + r;
             if (types[col] == TSQ_BYTES) {
-                out_bits[col][row] = (uint64_t)(p + (int64_t)v.data_at);
+                out_bits[col][row] = (uint64_t)((p + (int64_t)v.data_at) | (grouped ? TSQ_DECC_GROUPED : 0));
                 out_len[col][row] = v.kind == DECV_BYTES ? (int64_t)v.bits : 0;
             } else {
                 out_bits[col][row] = bits;

@@ -17,7 +17,7 @@ from .test_hostsim_decode_chunks import response, table
 
 pytestmark = pytest.mark.gpu
 MSG = {1: "invalid encoded key", 2: "insufficient bytes to decode value", 3: "value larger than 64 bits", 4: "invalid encoded key flag",
-       6: "datum kind does not match the column type"}
+       6: "datum kind does not match the column type", 7: "invalid marker byte", 8: "invalid padding byte"}
 
 
 def chunks_of(data, offs):
@@ -32,6 +32,34 @@ def test_responses_against_the_oracle(ctx, orc, n, per):
     st, want = orc.decode_rows_chunks(data, offs, t.types())
     got = distsql.decode_chunks(ctx, chunks_of(data, offs), t.types(), cap_rows=n)
     assert st == 0 and got.NumRows() == n and got.rows() == want.rows()
+
+
+@pytest.mark.parametrize("n,per,long_strings", [(1, 64, False), (5000, 64, False), (5000, 7, False), (400, 1, True), (600, 64, True)])
+def test_comparable_responses_memcomparable_strings(ctx, orc, n, per, long_strings):
+    # every value in its EncodeKey form (what an index scan answers with): ints flag 3, uints flag 4, strings bytesFlag + groups of
+    # 8 bytes + marker (util/codec/bytes.go:35-67) -> DecodeOne's DecodeBytes (codec.go:662-668, bytes.go:69-118)
+    rng = np.random.default_rng(n * 3 + per)
+    t = table(rng, n, long_strings=long_strings)
+    if n == 600:  # long cells: the byte copy runs one cell per wave
+        t = Chunk([t.columns[0], StrColumn([None if i % 11 == 0 else bytes([65 + i % 26]) * (700 + i % 9) for i in range(n)])])
+    parts = [bytes(orc.encode_rows(t.slice(lo, min(lo + per, n)), comparable=True)) for lo in range(0, n, per)]
+    data, offs = b"".join(parts), np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    st, want = orc.decode_rows_chunks(data, offs, t.types())
+    got = distsql.decode_chunks(ctx, chunks_of(data, offs), t.types(), cap_rows=n)
+    assert st == 0 and got.NumRows() == n and got.rows() == want.rows() == t.rows()
+
+
+def test_reference_bytes_codec_vectors_on_the_gpu(ctx, orc):
+    # util/codec/bytes_test.go:33-47, 68-78
+    from . import test_hostsim_decode_chunks as T
+    for dec, enc in T.BYTES_CODEC:
+        assert distsql.decode_chunks(ctx, [bytes([1] + enc)], [abi.BYTES]).rows() == [(bytes(dec),)]
+    for enc in T.BYTES_CODEC_ERR:
+        data = bytes([1] + enc)
+        st, _ = orc.decode_rows_chunks(data, [0, len(data)], [abi.BYTES])
+        with pytest.raises(_lib.TsqError) as e:
+            distsql.decode_chunks(ctx, [data], [abi.BYTES])
+        assert e.value.status == abi.ERR_INVALID and MSG[st] in str(e.value)
 
 
 def test_long_cells_one_per_wave(ctx, orc):
@@ -144,9 +172,7 @@ def test_first_error_in_stream_order(ctx, orc, case):
     tpa = (C.c_int32 * 3)(*types)
     m = C.c_int64(0)
     gst = ctx.lib.tsq_rows_decode_chunks(ctx.h, raw.ctypes.data_as(C.c_void_p), raw.size, offs.ctypes.data_as(C.c_void_p), len(offs) - 1, 0, 3, tpa, out, 256, C.byref(m))
-    assert gst == (abi.ERR_UNSUPPORTED if st == 5 else abi.ERR_INVALID)
-    if st != 5:
-        assert _lib.last_error(ctx.h) == MSG[st]
+    assert gst == abi.ERR_INVALID and _lib.last_error(ctx.h) == MSG[st]
     assert m.value == want.NumRows() and chunk_from_buffers(types, bufs, m.value).rows() == want.rows()  # the rows before the error were handed over
 
 

@@ -15,7 +15,7 @@ from tinysql_amd.chunk import Chunk, Column, StrColumn
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GUARD = 64
-STATUS = {0: "ok", 1: "row cut", 2: "insufficient", 3: "overflow", 4: "bad flag", 5: "bytesFlag", 6: "kind mismatch"}
+STATUS = {0: "ok", 1: "row cut", 2: "insufficient", 3: "overflow", 4: "bad flag", 5: "bytesFlag", 6: "kind mismatch", 7: "bad marker", 8: "bad padding"}
 
 
 @pytest.fixture(scope="module")
@@ -55,7 +55,13 @@ def run_sim(sim, data, chunk_offs, types, phase=0, cap_rows=None):
         nn = nns[c][:n].astype(bool)
         assert (nns[c][n:] == 7).all()  # nothing past the rows handed over
         if t == abi.BYTES:
-            cols.append(StrColumn([bytes(raw[int(bits[c][r]):int(bits[c][r]) + int(lens[c][r])]) if nn[r] else None for r in range(n)]))
+            def cell(r):  # K13f's copy: a grouped (memcomparable) cell skips one marker byte after every 8 data bytes
+                pos, ln = int(bits[c][r]), int(lens[c][r])
+                if pos >> 62 & 1:
+                    pos &= (1 << 62) - 1
+                    return bytes(raw[pos + i + i // 8] for i in range(ln))
+                return bytes(raw[pos:pos + ln])
+            cols.append(StrColumn([cell(r) if nn[r] else None for r in range(n)]))
         elif t == abi.F32:
             cols.append(Column(t, bits[c][:n].astype(np.uint32).view(np.float32).copy(), nn))
         elif t == abi.F64:
@@ -163,3 +169,41 @@ def test_first_error_in_stream_order(sim, case):
         code, rows, got = run_sim(sim, data, offs, types, phase)
         assert st != 0 and code == st, (STATUS[st], STATUS[code])
         assert rows == want.NumRows() == want_rows and got.rows() == want.rows()
+
+
+# ---- memcomparable (bytesFlag) datums: the EncodeKey form of strings, what index keys hold (round 2)
+BYTES_CODEC = [  # util/codec/bytes_test.go:33-47 (the ascending form)
+    ([], [0, 0, 0, 0, 0, 0, 0, 0, 247]), ([0], [0, 0, 0, 0, 0, 0, 0, 0, 248]), ([1, 2, 3], [1, 2, 3, 0, 0, 0, 0, 0, 250]), ([1, 2, 3, 0], [1, 2, 3, 0, 0, 0, 0, 0, 251]),
+    ([1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6, 7, 0, 254]), ([0] * 8, [0] * 8 + [255] + [0] * 8 + [247]), ([1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 3, 4, 5, 6, 7, 8, 255, 0, 0, 0, 0, 0, 0, 0, 0, 247]),
+    ([1, 2, 3, 4, 5, 6, 7, 8, 9], [1, 2, 3, 4, 5, 6, 7, 8, 255, 9, 0, 0, 0, 0, 0, 0, 0, 248])]
+BYTES_CODEC_ERR = [  # bytes_test.go:68-78: DecodeBytes must fail
+    [1, 2, 3, 4], [0, 0, 0, 0, 0, 0, 0, 247], [0, 0, 0, 0, 0, 0, 0, 0, 246], [0, 0, 0, 0, 0, 0, 0, 1, 247], [1, 2, 3, 4, 5, 6, 7, 8, 0], [1, 2, 3, 4, 5, 6, 7, 8, 255, 1],
+    [1, 2, 3, 4, 5, 6, 7, 8, 255, 1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 3, 4, 5, 6, 7, 8, 255, 1, 2, 3, 4, 5, 6, 7, 8, 255], [1, 2, 3, 4, 5, 6, 7, 8, 255, 1, 2, 3, 4, 5, 6, 7, 8, 0]]
+
+
+def test_reference_bytes_codec_vectors(sim):
+    for dec, enc in BYTES_CODEC:
+        assert orc.encode_rows(Chunk([StrColumn([bytes(dec)])]), comparable=True).tolist() == [1] + enc  # EncodeBytes behind the bytesFlag
+        data = bytes([1] + enc)
+        st, want = orc.decode_rows_chunks(data, [0, len(data)], [abi.BYTES])
+        code, rows, got = run_sim(sim, data, [0, len(data)], [abi.BYTES], phase=3)
+        assert st == code == 0 and want.rows() == got.rows() == [(bytes(dec),)]
+    for enc in BYTES_CODEC_ERR:
+        data = bytes([1] + enc)
+        st, want = orc.decode_rows_chunks(data, [0, len(data)], [abi.BYTES])
+        code, rows, got = run_sim(sim, data, [0, len(data)], [abi.BYTES])
+        assert st in (2, 7, 8) and code == st and rows == 0, (enc, STATUS[st], STATUS[code])
+
+
+@pytest.mark.parametrize("n,per", [(1, 64), (65, 64), (1000, 7), (300, 1)])
+@pytest.mark.parametrize("phase", [0, 5])
+def test_comparable_responses_walk_like_the_oracle(sim, n, per, phase):
+    # every value in its EncodeKey form: ints flag 3, uints flag 4, reals flag 5, strings flag 1 + groups (codec.go:74-109)
+    rng = np.random.default_rng(n + per + phase)
+    t = table(rng, n, long_strings=(n == 300))
+    parts = [bytes(orc.encode_rows(t.slice(lo, min(lo + per, n)), comparable=True)) for lo in range(0, n, per)]
+    data, offs = b"".join(parts), np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    st, want = orc.decode_rows_chunks(data, offs, t.types())
+    code, rows, got = run_sim(sim, data, offs, t.types(), phase)
+    assert st == 0 and code == 0 and rows == n
+    assert got.rows() == want.rows() == t.rows()

@@ -101,3 +101,27 @@ def test_running_sum_overflow_is_an_error():
     chunk = Chunk([Column(abi.U64, np.array([1 << 63], dtype=np.uint64), None)])
     with pytest.raises(orc.OracleError):
         _agg(chunk, [(abi.AGG_SUM, 0)])
+
+
+def test_cut_index_key_new_of_the_reference(orc):
+    # tablecodec_test.go:55-75 TestCutKeyNew: values (1, "abc", 5.5) + handle 100 under table 4 / index 5 -> CutIndexKeyNew(indexKey, 3)
+    # gives the three values and the handle bytes, each decoding (DecodeOne) to its datum
+    import numpy as np
+    from tinysql_amd import _abi as abi
+    from tinysql_amd.chunk import Chunk, Column, StrColumn
+    t = Chunk([Column(abi.I64, np.array([1])), StrColumn([b"abc"]), Column(abi.F64, np.array([5.5]))])
+    keys, offs = orc.encode_index_keys(t, 4, 5, np.array([100]), np.array([1], np.uint8))
+    want_key = (b"t" + bytes([0x80, 0, 0, 0, 0, 0, 0, 4]) + b"_i" + bytes([0x80, 0, 0, 0, 0, 0, 0, 5])          # EncodeIndexSeekKey, tablecodec.go:87-93
+                + bytes([3, 0x80, 0, 0, 0, 0, 0, 0, 1]) + bytes([1]) + b"abc" + bytes(5) + bytes([250])          # intFlag + EncodeInt; bytesFlag + EncodeBytes
+                + bytes([5]) + bytes([0xC0, 0x16, 0, 0, 0, 0, 0, 0]) + bytes([3, 0x80, 0, 0, 0, 0, 0, 0, 100]))  # floatFlag + EncodeFloat(5.5) (float.go:22-46)
+    assert keys.tobytes() == want_key and offs.tolist() == [0, len(want_key)]
+    st, rows = orc.decode_index_kv(keys.tobytes(), offs, None, None, 3, [abi.I64, abi.BYTES, abi.F64, abi.I64], 1)
+    assert st == 0 and rows.rows() == [(1, b"abc", 5.5, 100)]
+    # a unique index: no handle in the key, the pair's value holds it (DecodeIndexValueAsHandle, tablecodec.go:456-465)
+    keys, offs = orc.encode_index_keys(t, 4, 5)
+    st, rows = orc.decode_index_kv(keys.tobytes(), offs, (100).to_bytes(8, "big"), [0, 8], 3, [abi.I64, abi.BYTES, abi.F64, abi.I64], 1)
+    assert st == 0 and rows.rows() == [(1, b"abc", 5.5, 100)]
+    # PrimaryKeyNotExists: the remainder is dropped (tablecodec.go:411-414)
+    keys, offs = orc.encode_index_keys(t, 4, 5, np.array([100]), np.array([1], np.uint8))
+    st, rows = orc.decode_index_kv(keys.tobytes(), offs, None, None, 3, [abi.I64, abi.BYTES, abi.F64], 0)
+    assert st == 0 and rows.rows() == [(1, b"abc", 5.5)]

@@ -208,6 +208,8 @@ SIGNATURES = {
                                     C.POINTER(C.c_int64)]),
     "tsq_rows_decode_chunks": (C.c_int32, [P, P, C.c_int64, P, C.c_int64, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(Col), C.c_int64,
                                            C.POINTER(C.c_int64)]),
+    "tsq_indexkeys_decode": (C.c_int32, [P, P, C.c_int64, P, C.c_int64, P, C.c_int64, P, C.c_uint32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(Col),
+                                         C.POINTER(C.c_int64)]),
     "tsq_chunk_encode": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.c_int64, C.c_uint32, C.POINTER(C.c_int64)]),
     "tsq_chunk_decode_peek": (C.c_int32, [P, P, C.c_int64, C.c_uint32, C.POINTER(C.c_int32), C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64),
                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -8,6 +8,7 @@ topn.go: a heap of `limit` rows) | limitExec (:472-507), then fillUpData4SelectR
 rows (cop_handler_dag.go:414-425, :510-519).  Here every executor is batch at a time and its chunks stay in HBM (gpu_pipeline.py's
 device chunks); all compute runs in libtsq:
     tableScanExec  = tsq_rowkeys_decode (record keys -> handles) + tsq_rowcodec_decode (stored rows -> columns)
+    indexScanExec  = tsq_indexkeys_decode (index keys [+ values] -> the index columns and the handle; memcomparable strings)
     selectionExec  = tsq_filter_eval + tsq_chunk_compact
     hashAggExec    = tsq_agg_* in the partial layout of the reference: per function its partial results (AVG: count, sum —
                      avg.go:78-81), then the group-by values (aggregate.go:96-113)
@@ -109,6 +110,64 @@ class tableScanExec(GpuExecutor):
             for c in self.out:
                 c.free()
         self.dk = self.dv = self.do = self.dh = self.out = None
+
+
+class indexScanExec(GpuExecutor):
+    """mocktikv.indexScanExec (executor.go:191-320) over the KV pairs of its ranges, in scan order: every pair through
+    tablecodec.DecodeIndexKV (tablecodec.go:376-434).  `keys` / `key_offsets` = the index keys back to back; `values` /
+    `value_offsets` = the pairs' values (the handle of a unique index, 8 bytes big endian); `types` = the index columns' types
+    (+ the handle column, I64 or U64, when pkStatus != PrimaryKeyNotExists); colsLen = len(IndexScan.Columns) without the handle."""
+
+    PrimaryKeyNotExists, PrimaryKeyIsSigned, PrimaryKeyIsUnsigned = 0, 1, 2  # tablecodec.go:394-403
+
+    def __init__(self, ctx, types, colsLen, pkStatus, keys, key_offsets, values=b"", value_offsets=None, batch_rows=1 << 22):
+        super().__init__(ctx, list(types))
+        assert len(self.types) == colsLen + (1 if pkStatus else 0)
+        self.colsLen, self.pkStatus = colsLen, pkStatus
+        self.raw_keys = np.frombuffer(bytes(keys), dtype=np.uint8) if isinstance(keys, (bytes, bytearray)) else np.ascontiguousarray(keys, dtype=np.uint8)
+        self.koffs = np.ascontiguousarray(key_offsets, dtype=np.int64)
+        self.n = len(self.koffs) - 1
+        self.raw_vals = np.frombuffer(bytes(values), dtype=np.uint8) if isinstance(values, (bytes, bytearray)) else np.ascontiguousarray(values, dtype=np.uint8)
+        self.voffs = None if value_offsets is None else np.ascontiguousarray(value_offsets, dtype=np.int64)
+        self.batch = batch_rows
+        self.dk = self.dko = self.dv = self.dvo = None
+        self.out, self.pos, self.count = None, 0, 0
+
+    def Open(self):
+        ctx = self.ctx
+        self.dk, self.dko = _DevBytes(ctx, self.raw_keys), _DevBytes(ctx, self.koffs)
+        if self.voffs is not None:
+            self.dv, self.dvo = _DevBytes(ctx, self.raw_vals), _DevBytes(ctx, self.voffs)
+        self.out = self._buffers(min(self.batch, max(self.n, 8)), var_bytes=[self.raw_keys.size] * len(self.types))  # a string cell is a piece of its key
+        self.pos = self.count = 0
+
+    def Next(self):
+        if self.pos >= self.n:
+            return EOS
+        lo, hi = self.pos, min(self.n, self.pos + self.batch)
+        oc = (abi.Col * len(self.out))(*[c.col(hi - lo) for c in self.out])
+        tp = (C.c_int32 * len(self.types))(*self.types)
+        got = C.c_int64(0)
+        # pairs [lo, hi): their boundaries are key_offsets[lo .. hi] / value_offsets[lo .. hi] (absolute byte positions)
+        _lib.check(self.lib.tsq_indexkeys_decode(self.ctx.h, C.c_void_p(self.dk.p), self.raw_keys.size, C.c_void_p(self.dko.p + 8 * lo), hi - lo,
+                                                 C.c_void_p(self.dv.p) if self.dv else None, self.raw_vals.size if self.dv else 0,
+                                                 C.c_void_p(self.dvo.p + 8 * lo) if self.dvo else None, abi.COL_DEVICE, self.colsLen, tp, self.pkStatus, oc,
+                                                 C.byref(got)), self.ctx.h)
+        self.pos = hi
+        self.count += got.value
+        return DeviceChunk(self.out, got.value)
+
+    def Counts(self):
+        return [self.count]
+
+    def Close(self):
+        for b in (self.dk, self.dko, self.dv, self.dvo):
+            if b:
+                b.free()
+        if self.out:
+            for c in self.out:
+                c.free()
+        self.dk = self.dko = self.dv = self.dvo = self.out = None
 
 
 class selectionExec(GpuSelectionExec):

@@ -118,7 +118,7 @@ TSQ_HD int tsq_dec_value(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t len, ui
 // tipb.SelectResponse.Chunks cut the response every 64 rows (cop_handler_dag.go:510-519): the chunks are independent byte strings,
 // so one lane walks one chunk, and a value may be of any length — a compact-bytes datum (flag 2: varint length + the bytes,
 // util/codec/bytes.go:141-160) is what a varchar / blob column arrives as.
-enum { DEC_KIND_MISMATCH = 6 };
+enum { DEC_KIND_MISMATCH = 6, DEC_BAD_MARKER = 7, DEC_BAD_PADDING = 8, DEC_NO_HANDLE = 9 };
 enum { DECV_NULL = 0, DECV_INT = 1, DECV_UINT = 2, DECV_REAL = 3, DECV_BYTES = 4 };
 
 TSQ_HD uint32_t dec_byte12(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t k) {  // byte k (0..11) of b0 | b1 << 32 | b2 << 64
@@ -183,8 +183,35 @@ TSQ_HD int tsq_decc_value(uint32_t b0, uint32_t b1, uint32_t b2, uint64_t avail,
         v->len = 1 + (uint64_t)nb + (uint64_t)n;
         return DEC_OK;
     }
-    return f == 1 ? DEC_VARLEN : DEC_BAD_FLAG;  // bytesFlag (memcomparable groups: index keys) keeps the Go decoder
+    return f == 1 ? DEC_VARLEN : DEC_BAD_FLAG;  // bytesFlag: the caller walks the groups in memory (tsq_decc_membytes)
 }
+// A bytesFlag datum — the memcomparable form an index key holds (EncodeBytes, util/codec/bytes.go:35-67): after the flag, groups
+// of 8 data bytes + 1 marker byte; marker 0xFF = a full group, another follows; marker 0xFF - pad = the last group, whose final
+// `pad` bytes are zero padding.  decodeBytes (bytes.go:69-112) step by step, over the value's bytes in memory (p = its flag byte,
+// avail = bytes from there to the end of the chunk / key): v->bits = the string's length, v->len = 1 + 9 x groups; the string's
+// byte i sits at p[1 + i + i / 8] (tsq_decc_grouped_at).
+TSQ_HD int tsq_decc_membytes(const uint8_t* p, uint64_t avail, tsq_decc_val* v) {
+    uint64_t at = 1, n = 0;
+    for (;;) {
+        if (avail < at + 9) return DEC_INSUFFICIENT;       // len(b) < encGroupSize + 1
+        const uint32_t pad = 0xffu - (uint32_t)p[at + 8];  // encMarker - marker
+        if (pad > 8) return DEC_BAD_MARKER;
+        n += 8 - pad;
+        if (pad != 0) {
+            for (uint32_t k = 8 - pad; k < 8; k++)
+                if (p[at + k] != 0) return DEC_BAD_PADDING;
+            at += 9;
+            break;
+        }
+        at += 9;
+    }
+    v->kind = DECV_BYTES;
+    v->data_at = 1;
+    v->bits = n;
+    v->len = at;
+    return DEC_OK;
+}
+#define TSQ_DECC_GROUPED (1ll << 62)  // flag in a cell reference: the bytes are grouped (skip one marker byte after every 8)
 // what column type `type` stores for a datum (appendIntToChunk / appendUintToChunk / appendFloatToChunk / AppendBytes,
 // codec.go:692-707): false = the datum's kind cannot go into that column (a string into a number column or the reverse)
 TSQ_HD bool tsq_decc_store(int32_t type, const tsq_decc_val& v, uint64_t* bits_out) {

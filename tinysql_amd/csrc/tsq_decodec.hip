@@ -33,6 +33,11 @@ struct DeccArgs {
     uint8_t* out_notnull[TSQ_MAX_COLS]; // one byte per row
     int64_t* ref_pos[TSQ_MAX_COLS];     // var-len columns: where the cell's bytes start in `data`
     int64_t* out_offs[TSQ_MAX_COLS];    // var-len columns: the cell's length (the scan makes offsets of them)
+    // index keys (tsq_indexkeys_decode): every "chunk" is one key = `prefix` bytes, n_key_cols datums, then the handle datum or nothing
+    int32_t prefix, n_key_cols, pk_status;
+    const uint8_t* vals;        // the pairs' values: the handle of a key that does not carry it (8 bytes big endian)
+    const int64_t* val_offs;    // [n_chunks + 1]
+    int64_t n_val_bytes;
 };
 
 namespace {
@@ -75,6 +80,7 @@ __global__ void __launch_bounds__(256) k_decc_count(DeccArgs a) {
                 decc_fetch12(a.data, a.n_bytes, p, hi, &b0, &b1, &b2);
                 tsq_decc_val v;
                 code = tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v);
+                if (code == DEC_VARLEN) code = tsq_decc_membytes(a.data + p, (uint64_t)(hi - p), &v);
                 uint64_t bits;
                 if (code == DEC_OK && !tsq_decc_store(a.col_type[col], v, &bits)) code = DEC_KIND_MISMATCH;
                 if (code != DEC_OK) break;
@@ -105,13 +111,16 @@ __global__ void __launch_bounds__(256) k_decc_emit(DeccArgs a) {
             uint32_t b0, b1, b2;
             decc_fetch12(a.data, a.n_bytes, p, hi, &b0, &b1, &b2);
             tsq_decc_val v;
-            if (tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v) != DEC_OK) break;  // (K13d has seen it: rows before it only)
+            int code = tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), &v);
+            const bool grouped = code == DEC_VARLEN;
+            if (grouped) code = tsq_decc_membytes(a.data + p, (uint64_t)(hi - p), &v);
+            if (code != DEC_OK) break;  // (K13d has seen it: rows before it only)
             uint64_t bits;
             (void)tsq_decc_store(a.col_type[col], v, &bits);
             const int64_t row = base + r;
             const int32_t t = a.col_type[col];
             if (t == TSQ_BYTES) {
-                a.ref_pos[col][row] = p + (int64_t)v.data_at;
+                a.ref_pos[col][row] = (p + (int64_t)v.data_at) | (grouped ? TSQ_DECC_GROUPED : 0);
                 a.out_offs[col][row] = v.kind == DECV_BYTES ? (int64_t)v.bits : 0;  // a NULL cell has no bytes
             } else if (t == TSQ_F32) {
                 ((uint32_t*)a.out_data[col])[row] = (uint32_t)bits;
@@ -122,6 +131,79 @@ __global__ void __launch_bounds__(256) k_decc_emit(DeccArgs a) {
             p += (int64_t)v.len;
             col++;
             if (col == a.n_cols) { col = 0; r++; }
+        }
+    }
+}
+
+// one datum at p (DecodeOne, codec.go:623-690); *grouped: a memcomparable string
+__device__ __forceinline__ int decc_one(const DeccArgs& a, int64_t p, int64_t hi, tsq_decc_val* v, bool* grouped) {
+    uint32_t b0, b1, b2;
+    decc_fetch12(a.data, a.n_bytes, p, hi, &b0, &b1, &b2);
+    int code = tsq_decc_value(b0, b1, b2, (uint64_t)(hi - p), v);
+    *grouped = code == DEC_VARLEN;
+    if (*grouped) code = tsq_decc_membytes(a.data + p, (uint64_t)(hi - p), v);
+    return code;
+}
+
+// K13g: index keys.  tablecodec.DecodeIndexKV (tablecodec.go:376-434) of pair k: CutIndexKeyNew skips the 19-byte prefix
+// ('t' tableID "_i" indexID) and cuts n_key_cols datums; if bytes remain they are the handle datum (a non-unique index, or a unique
+// one whose key holds a NULL), otherwise the pair's VALUE is the handle (DecodeIndexValueAsHandle, tablecodec.go:456-465: 8 bytes
+// big endian).  EMIT = false: validate only (rows[k] = 1 for a good key, the first offending key in order goes to a.err).
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_idx_walk(DeccArgs a) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.n_chunks && (!EMIT || k < a.err_chunk); k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo, hi;
+        int code = DEC_OK;
+        int32_t col = 0;
+        if (!decc_chunk_range(a, k, &lo, &hi) || hi - lo < a.prefix) {
+            code = DEC_ROW_CUT;
+        } else {
+            int64_t p = lo + a.prefix;
+            for (; col < a.n_key_cols; col++) {
+                if (p >= hi) { code = DEC_ROW_CUT; break; }  // peek / DecodeOne on an empty slice: "invalid encoded key"
+                tsq_decc_val v;
+                bool grouped;
+                code = decc_one(a, p, hi, &v, &grouped);
+                uint64_t bits = 0;
+                if (code == DEC_OK && !tsq_decc_store(a.col_type[col], v, &bits)) code = DEC_KIND_MISMATCH;
+                if (code != DEC_OK) break;
+                if (EMIT) {
+                    const int32_t t = a.col_type[col];
+                    if (t == TSQ_BYTES) {
+                        a.ref_pos[col][k] = (p + (int64_t)v.data_at) | (grouped ? TSQ_DECC_GROUPED : 0);
+                        a.out_offs[col][k] = v.kind == DECV_BYTES ? (int64_t)v.bits : 0;
+                    } else if (t == TSQ_F32) {
+                        ((uint32_t*)a.out_data[col])[k] = (uint32_t)bits;
+                    } else {
+                        ((uint64_t*)a.out_data[col])[k] = bits;
+                    }
+                    a.out_notnull[col][k] = v.kind != DECV_NULL ? 1 : 0;
+                }
+                p += (int64_t)v.len;
+            }
+            if (code == DEC_OK && a.pk_status != 0) {
+                uint64_t handle = 0;
+                if (p < hi) {  // the handle travels in the key (values = append(values, b), tablecodec.go:411-414)
+                    tsq_decc_val v;
+                    bool grouped;
+                    code = decc_one(a, p, hi, &v, &grouped);
+                    if (code == DEC_OK && (v.kind == DECV_NULL || v.kind == DECV_BYTES)) code = DEC_KIND_MISMATCH;  // (an int datum in every key the reference writes)
+                    handle = v.bits;
+                } else {
+                    const int64_t vlo = a.val_offs ? a.val_offs[k] : 0, vhi = a.val_offs ? a.val_offs[k + 1] : -1;
+                    if (!a.vals || vlo < 0 || vhi - vlo < 8 || vhi > a.n_val_bytes) code = DEC_NO_HANDLE;
+                    else
+                        for (int i = 0; i < 8; i++) handle = (handle << 8) | a.vals[vlo + i];  // binary.Read(buf, binary.BigEndian, &h)
+                }
+                if (EMIT && code == DEC_OK) {
+                    ((uint64_t*)a.out_data[col])[k] = handle;
+                    a.out_notnull[col][k] = 1;
+                }
+            }
+        }
+        if (!EMIT) {
+            a.rows[k] = code == DEC_OK ? 1 : 0;
+            if (code != DEC_OK) atomicMin(a.err, ((unsigned long long)k << 32) | ((unsigned long long)col << 4) | (unsigned long long)code);
         }
     }
 }
@@ -141,9 +223,12 @@ __global__ void __launch_bounds__(256) k_decc_var_copy(DeccVarArgs a) {
     for (int64_t r = first; r < a.rows; r += step) {
         const int64_t n = a.offs[r + 1] - a.offs[r];
         if (n == 0) continue;
-        const uint8_t* s = a.data + a.pos[r];
+        const bool grouped = (a.pos[r] & TSQ_DECC_GROUPED) != 0;
+        const uint8_t* s = a.data + (a.pos[r] & ~TSQ_DECC_GROUPED);
         uint8_t* d = a.out + a.offs[r];
-        if (!WAVE) {
+        if (grouped) {  // a memcomparable cell: one marker byte follows every 8 data bytes
+            for (int64_t i = WAVE ? lane : 0; i < n; i += WAVE ? 64 : 1) d[i] = s[i + (i >> 3)];
+        } else if (!WAVE) {
             for (int64_t i = 0; i < n; i++) d[i] = s[i];
         } else {  // head up to an 8-byte boundary of the destination, then 8 bytes per lane, then the tail
             int64_t head = (8 - ((uintptr_t)d & 7)) & 7;
@@ -164,25 +249,34 @@ __global__ void __launch_bounds__(256) k_decc_var_copy(DeccVarArgs a) {
 }  // namespace
 
 // ====================================================================== host side
-TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks,
-                                          uint32_t data_flags, int32_t n_cols, const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows,
-                                          int64_t* nrows_out) {
+namespace {
+struct IdxMode {  // tsq_indexkeys_decode: the extra inputs of the key walk
+    int32_t n_key_cols, pk_status;
+    const uint8_t* vals;
+    int64_t n_val_bytes;
+    const int64_t* val_offs;
+};
+}  // namespace
+
+static tsq_status decc_decode(tsq_ctx* ctx, const std::string& who, const uint8_t* rows_data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks,
+                              uint32_t data_flags, int32_t n_cols, const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out,
+                              const IdxMode* idx) {
     tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;
     tsq_handle_hdr* h = &ctx->hdr;
     if (nrows_out) *nrows_out = 0;
     if (!nrows_out || !col_types || !out_cols || n_bytes < 0 || n_chunks < 0 || cap_rows < 0 || (n_bytes > 0 && !rows_data) || (n_chunks > 0 && !chunk_offsets))
-        return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode_chunks: bad arguments");
+        return tsq_fail(h, TSQ_ERR_INVALID, who + ": bad arguments");
     if (n_cols < 1 || n_cols > TSQ_MAX_COLS) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "1..16 columns supported");
     if (n_chunks >= (1LL << 31)) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "more than 2^31 response chunks per call");
     bool any_var = false;
     for (int c = 0; c < n_cols; c++) {
-        if (col_types[c] < TSQ_I64 || col_types[c] > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode_chunks: unknown column type");
+        if (col_types[c] < TSQ_I64 || col_types[c] > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, who + ": unknown column type");
         const bool var = col_types[c] == TSQ_BYTES;
         any_var = any_var || var;
         if (!out_cols[c].null_bitmap || (var ? (!out_cols[c].offsets || (n_bytes > 0 && !out_cols[c].data)) : !out_cols[c].data))
-            return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode_chunks: out columns need data and null_bitmap buffers (a var-len column: offsets too)");
-        if (((out_cols[c].flags ^ out_cols[0].flags) & TSQ_COL_DEVICE) != 0) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode_chunks: mixed host/device outputs");
+            return tsq_fail(h, TSQ_ERR_INVALID, who + ": out columns need data and null_bitmap buffers (a var-len column: offsets too)");
+        if (((out_cols[c].flags ^ out_cols[0].flags) & TSQ_COL_DEVICE) != 0) return tsq_fail(h, TSQ_ERR_INVALID, who + ": mixed host/device outputs");
     }
     TSQ_HIP(h, hipSetDevice(ctx->device));
     const bool in_dev = data_flags & TSQ_COL_DEVICE, out_dev = out_cols[0].flags & TSQ_COL_DEVICE;
@@ -202,9 +296,9 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
     a.n_chunks = n_chunks;
     a.n_cols = n_cols;
     for (int c = 0; c < n_cols; c++) a.col_type[c] = col_types[c];
-    DevBuf dbytes, dco, drows, derr, scratch, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS], dpos[TSQ_MAX_COLS], dvoffs[TSQ_MAX_COLS];
+    DevBuf dbytes, dco, drows, derr, scratch, dvals, dvo, ddata[TSQ_MAX_COLS], dnn[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS], dpos[TSQ_MAX_COLS], dvoffs[TSQ_MAX_COLS];
     auto release_all = [&]() {
-        for (DevBuf* b : {&dbytes, &dco, &drows, &derr, &scratch}) b->release();
+        for (DevBuf* b : {&dbytes, &dco, &drows, &derr, &scratch, &dvals, &dvo}) b->release();
         for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dnn[c].release(); dbm[c].release(); dpos[c].release(); dvoffs[c].release(); }
     };
     auto fail = [&](tsq_status st) { release_all(); return st; };
@@ -222,23 +316,40 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
         a.data = rows_data;
         a.chunk_offs = chunk_offsets;
     }
+    if (idx) {
+        a.prefix = 19;  // prefixLen + idLen: 't' | tableID | "_i" | indexID (tablecodec.go:372-374)
+        a.n_key_cols = idx->n_key_cols;
+        a.pk_status = idx->pk_status;
+        a.vals = idx->vals;
+        a.val_offs = idx->val_offs;
+        a.n_val_bytes = idx->n_val_bytes;
+        if (s == TSQ_OK && e == hipSuccess && !in_dev && idx->vals && idx->val_offs) {
+            s = dvals.reserve(ctx, h, (size_t)idx->n_val_bytes + 64);
+            if (s == TSQ_OK) s = dvo.reserve(ctx, h, ((size_t)n_chunks + 1) * 8 + 64);
+            if (s == TSQ_OK && idx->n_val_bytes > 0) e = hipMemcpyAsync(dvals.p, idx->vals, (size_t)idx->n_val_bytes, hipMemcpyHostToDevice, ctx->stream);
+            if (s == TSQ_OK && e == hipSuccess) e = hipMemcpyAsync(dvo.p, idx->val_offs, ((size_t)n_chunks + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+            a.vals = dvals.as<uint8_t>();
+            a.val_offs = dvo.as<int64_t>();
+        }
+    }
     if (s != TSQ_OK) return fail(s);
-    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks(H2D): ") + hipGetErrorString(e)));
+    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(H2D): ") + hipGetErrorString(e)));
     a.rows = drows.as<int64_t>();
     a.err = derr.as<unsigned long long>();
     e = hipMemsetAsync(a.err, 0xff, 8, ctx->stream);
     const int grid = tsq_grid_for(ctx, n_chunks, 256);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_decc_count, dim3(grid), dim3(256), 0, ctx->stream, a);
+        if (idx) hipLaunchKernelGGL(k_idx_walk<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_decc_count, dim3(grid), dim3(256), 0, ctx->stream, a);
         e = hipGetLastError();
     }
-    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks(count): ") + hipGetErrorString(e)));
+    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(count): ") + hipGetErrorString(e)));
     s = tsq_launch_scan64(ctx, h, a.rows, n_chunks, scratch);  // rows[k] = first output row of chunk k, rows[n_chunks] = all rows
     if (s != TSQ_OK) return fail(s);
     e = hipMemcpyAsync(ctx->pinned, a.err, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 1, a.rows + n_chunks, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks: ") + hipGetErrorString(e)));
+    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + ": ") + hipGetErrorString(e)));
     const uint64_t errw = ctx->pinned[0];
     int64_t rows = (int64_t)ctx->pinned[1];
     int code = DEC_OK;
@@ -250,14 +361,14 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
         e = hipMemcpyAsync(ctx->pinned + 2, a.rows + a.err_chunk, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 3, a.rows + a.err_chunk + 1, 8, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks: ") + hipGetErrorString(e)));
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + ": ") + hipGetErrorString(e)));
         a.err_rows = (int64_t)ctx->pinned[3] - (int64_t)ctx->pinned[2];  // K13d counted the complete rows before the error
         rows = (int64_t)ctx->pinned[2] + a.err_rows;
     }
     if (rows > cap_rows) {
         release_all();
         *nrows_out = rows;
-        return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode_chunks: output columns too small (*nrows_out = rows needed)");
+        return tsq_fail(h, TSQ_ERR_INVALID, who + ": output columns too small (*nrows_out = rows needed)");
     }
     if (rows > 0) {
         for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
@@ -275,9 +386,10 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
             a.out_offs[c] = var ? (out_dev ? out_cols[c].offsets : dvoffs[c].as<int64_t>()) : nullptr;
         }
         if (s != TSQ_OK) return fail(s);
-        hipLaunchKernelGGL(k_decc_emit, dim3(grid), dim3(256), 0, ctx->stream, a);
+        if (idx) hipLaunchKernelGGL(k_idx_walk<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_decc_emit, dim3(grid), dim3(256), 0, ctx->stream, a);
         e = hipGetLastError();
-        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks(emit): ") + hipGetErrorString(e)));
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(emit): ") + hipGetErrorString(e)));
         int64_t var_bytes[TSQ_MAX_COLS] = {0};
         for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
             uint8_t* bm = out_dev ? out_cols[c].null_bitmap : dbm[c].as<uint8_t>();
@@ -287,7 +399,7 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
             if (s != TSQ_OK) break;
             e = hipMemcpyAsync(ctx->pinned + 4, a.out_offs[c] + rows, 8, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) { s = tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks(var scan): ") + hipGetErrorString(e)); break; }
+            if (e != hipSuccess) { s = tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(var scan): ") + hipGetErrorString(e)); break; }
             var_bytes[c] = (int64_t)ctx->pinned[4];
             if (var_bytes[c] > 0) {
                 DeccVarArgs va;
@@ -299,7 +411,7 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
                 if (var_bytes[c] / rows > 32) hipLaunchKernelGGL(k_decc_var_copy<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, va);
                 else hipLaunchKernelGGL(k_decc_var_copy<false>, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, va);
                 e = hipGetLastError();
-                if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks(var copy): ") + hipGetErrorString(e));
+                if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(var copy): ") + hipGetErrorString(e));
             }
         }
         if (s != TSQ_OK) return fail(s);
@@ -315,7 +427,7 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
             }
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode_chunks(D2H): ") + hipGetErrorString(e)));
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(D2H): ") + hipGetErrorString(e)));
     } else {
         s = empty_result();
         if (s != TSQ_OK) return fail(s);
@@ -332,8 +444,36 @@ TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data
         case DEC_ROW_CUT: return tsq_fail(h, TSQ_ERR_INVALID, "invalid encoded key");                        // codec.go:625
         case DEC_INSUFFICIENT: return tsq_fail(h, TSQ_ERR_INVALID, "insufficient bytes to decode value");   // number.go:46,122; bytes.go:156-158
         case DEC_OVERFLOW: return tsq_fail(h, TSQ_ERR_INVALID, "value larger than 64 bits");                // number.go:120
-        case DEC_VARLEN: return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "memcomparable bytes datum (bytesFlag): decode this response with the Go decoder");
+        case DEC_BAD_MARKER: return tsq_fail(h, TSQ_ERR_INVALID, "invalid marker byte");                    // bytes.go:89-91
+        case DEC_BAD_PADDING: return tsq_fail(h, TSQ_ERR_INVALID, "invalid padding byte");                  // bytes.go:103-107
         case DEC_KIND_MISMATCH: return tsq_fail(h, TSQ_ERR_INVALID, "datum kind does not match the column type");
+        case DEC_NO_HANDLE: return tsq_fail(h, TSQ_ERR_INVALID, "no handle in index key or value");                // tablecodec.go:449-453, 456-465
         default: return tsq_fail(h, TSQ_ERR_INVALID, "invalid encoded key flag");                           // codec.go:683
     }
+}
+
+TSQ_API tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks,
+                                          uint32_t data_flags, int32_t n_cols, const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows,
+                                          int64_t* nrows_out) {
+    return decc_decode(ctx, "tsq_rows_decode_chunks", rows_data, n_bytes, chunk_offsets, n_chunks, data_flags, n_cols, col_types, out_cols, cap_rows, nrows_out,
+                       nullptr);
+}
+
+// mocktikv's indexScanExec (executor.go:191-320): tablecodec.DecodeIndexKV of every pair of an index range
+TSQ_API tsq_status tsq_indexkeys_decode(tsq_ctx* ctx, const uint8_t* keys, int64_t n_bytes, const int64_t* key_offsets, int64_t n_keys, const uint8_t* values,
+                                        int64_t n_value_bytes, const int64_t* value_offsets, uint32_t data_flags, int32_t n_index_cols, const int32_t* col_types,
+                                        int32_t pk_status, tsq_col* out_cols, int64_t* nkeys_out) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    if (n_index_cols < 0 || pk_status < 0 || pk_status > 2 || n_value_bytes < 0 || (n_value_bytes > 0 && !values))
+        return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_indexkeys_decode: bad arguments");
+    const int32_t n_cols = n_index_cols + (pk_status != 0 ? 1 : 0);
+    if (col_types && pk_status != 0 && n_cols >= 1 && n_cols <= TSQ_MAX_COLS && col_types[n_cols - 1] != (pk_status == 2 ? TSQ_U64 : TSQ_I64))
+        return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_indexkeys_decode: the handle column is TSQ_I64 (PrimaryKeyIsSigned) or TSQ_U64 (PrimaryKeyIsUnsigned)");
+    IdxMode im;
+    im.n_key_cols = n_index_cols;
+    im.pk_status = pk_status;
+    im.vals = values;
+    im.n_val_bytes = n_value_bytes;
+    im.val_offs = value_offsets;
+    return decc_decode(ctx, "tsq_indexkeys_decode", keys, n_bytes, key_offsets, n_keys, data_flags, n_cols, col_types, out_cols, n_keys, nkeys_out, &im);
 }
