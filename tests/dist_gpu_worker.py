@@ -196,6 +196,49 @@ def main():
             assert comm.allreduce_i64([ng2])[0] == whole2.NumRows()
             assert any(r[1] is None for r in wrows) and any(r[0] is None for r in wrows)  # the case really holds NULL sums and the NULL group
             lap("NULLs through the exchange")
+            # ---- var-len payload columns travel with their rows (offsets slices + bytes per run, rebased on arrival)
+            from tinysql_amd.chunk import StrColumn
+            def str_rows_of(r, n):
+                g = np.random.default_rng(9900 + r)
+                keys = g.integers(0, 1 << 40, n).astype(np.int64)
+                names = [None if g.random() < 0.1 else (b"" if g.random() < 0.1 else b"r%d-%d-" % (r, i) + bytes([97 + i % 26]) * int(g.integers(0, 40))) for i in range(n)]
+                notes = [bytes(g.integers(0, 256, int(g.integers(0, 9)), dtype=np.uint8)) for _ in range(n)]
+                return keys, names, notes
+            srows = [str_rows_of(r, 30_000 + 700 * r) for r in range(world)]
+            sk, snames, snotes = srows[rank]
+            cn, cm = G.DevStrCol(ctx, StrColumn(snames)), G.DevStrCol(ctx, StrColumn(snotes))
+            got, n = comm.redistribute([dev(ctx, sk, keep), cn.col(), cm.col(), dev(ctx, sk * 3, keep)], 0, 0, len(sk), slot=6)
+            comm.wait(6)
+            ctx.sync()
+            def pull_str(col, n):
+                offs = np.zeros(n + 1, np.int64)
+                ctx.d2h(offs, col.offsets)
+                data = np.zeros(int(offs[n]) + 8, np.uint8)
+                if offs[n]:
+                    ctx.d2h(data[:int(offs[n])], col.data)
+                nn = np.ones(n, bool)
+                if col.null_bitmap:
+                    bm = np.zeros((n + 7) // 8 + 1, np.uint8)
+                    ctx.d2h(bm[:(n + 7) // 8], col.null_bitmap)
+                    nn = np.unpackbits(bm, bitorder="little")[:n].astype(bool)
+                raw = data.tobytes()
+                assert offs[0] == 0 and (np.diff(offs) >= 0).all()
+                return [raw[int(offs[i]):int(offs[i + 1])] if nn[i] else None for i in range(n)]
+            rk, r3 = np.empty(n, np.int64), np.empty(n, np.int64)
+            if n:
+                ctx.d2h(rk, got[0].data)
+                ctx.d2h(r3, got[3].data)
+            gn, gm = pull_str(got[1], n), pull_str(got[2], n)
+            want = []
+            for r in range(world):
+                k, a, b = srows[r]
+                mine = np_rank(k, world) == rank
+                want += [(int(k[i]), a[i], b[i], int(k[i]) * 3) for i in np.nonzero(mine)[0]]
+            skey = lambda t: (t[0], t[1] is None, t[1] or b"", t[2])  # noqa: E731
+            assert n == len(want) and sorted(zip(rk.tolist(), gn, gm, r3.tolist()), key=skey) == sorted(want, key=skey)
+            cn.free()
+            cm.free()
+            lap("strings through the exchange")
             print("rank %d/%d OK: join %d rows, %d of %d groups, %d of %d groups with NULLs" % (rank, world, total, ng, whole.NumRows(), ng2, whole2.NumRows()),
                   flush=True)
         finally:

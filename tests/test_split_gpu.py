@@ -83,3 +83,40 @@ def test_radix_split_fast_path_tile_sort(ctx, parts, ncols):
     finally:
         for d in src + dst:
             d.free()
+
+
+@pytest.mark.parametrize("parts,long_cells", [(1, False), (3, False), (8, False), (4, True)])
+def test_radix_split_carries_var_len_payload_columns(ctx, parts, long_cells):
+    # a var-len column is payload of the split: its cells follow their rows (lengths -> scan = the offsets of the split order, then
+    # the bytes), NULL cells have no bytes; rows inside a part keep no particular order, so the parts are compared as multisets
+    from tinysql_amd.chunk import StrColumn
+    rank = _rank_fn()
+    rng = np.random.default_rng(70 + parts)
+    n = 2000 if long_cells else 40_003
+    key = Column(abi.I64, rng.integers(-500, 500, n), rng.random(n) > 0.03)
+    width = 3000 if long_cells else 24
+    names = StrColumn([None if rng.random() < 0.1 else (b"" if rng.random() < 0.1 else bytes(rng.integers(65, 91, int(rng.integers(1, width)), dtype=np.uint8))) for _ in range(n)])
+    tags = StrColumn([b"t%d" % (i % 97) for i in range(n)])
+    pay = H.random_column(rng, abi.F64, n, 0.2)
+    src = [G.to_device(ctx, key), G.DevStrCol(ctx, names), G.to_device(ctx, pay), G.DevStrCol(ctx, tags)]
+    dst = [G.DevCol(ctx, abi.I64, n, True), G.DevStrCol(ctx, nrows=n, nbytes=len(names.data)), G.DevCol(ctx, abi.F64, n, True),
+           G.DevStrCol(ctx, nrows=n, nbytes=len(tags.data))]
+    try:
+        counts = (C.c_int64 * parts)()
+        _lib.check(ctx.lib.tsq_radix_split(ctx.h, G.dev_cols(src), 4, 0, 0, n, parts, G.dev_cols(dst), counts), ctx.h)
+        counts = list(counts)
+        assert sum(counts) == n
+        out = Chunk([dst[0].to_host(), dst[1].to_host(n, len(names.data)), dst[2].to_host(), dst[3].to_host(n, len(tags.data))])
+        rows, want = out.rows(), Chunk([key, names, pay, tags]).rows()
+        off = 0
+        for p in range(parts):
+            for r in rows[off:off + counts[p]]:
+                assert (0 if r[0] is None else rank(r[0] & ((1 << 64) - 1), parts)) == p
+            off += counts[p]
+        assert H.rows_equal_unordered(rows, want)
+        # a var-len KEY column is refused (the rank of a string key is not built)
+        bad = ctx.lib.tsq_radix_split(ctx.h, G.dev_cols(src), 4, 1, 0, n, parts, G.dev_cols(dst), (C.c_int64 * parts)())
+        assert bad == abi.ERR_UNSUPPORTED
+    finally:
+        for d in src + dst:
+            d.free()

@@ -83,6 +83,10 @@ RcclApi* rccl() {
 
 }  // namespace
 
+// words one rank contributes to the count exchange at most: its row counts per destination, its null-bitmap mask, and for every
+// var-len column its BYTE counts per destination
+static inline size_t comm_lmax(int world) { return (size_t)world + 1 + (size_t)TSQ_MAX_COLS * world; }
+
 struct tsq_comm {
     tsq_handle_hdr hdr;
     tsq_ctx* ctx = nullptr;
@@ -98,6 +102,9 @@ struct tsq_comm {
         // bitmap and lands at an arbitrary bit of the receiver's): sendbm = the split's packed bitmap, sendnn / recvnn =
         // the byte flags on the wire, recvbm = the received column's packed bitmap
         std::vector<DevBuf> sendbm, sendnn, recvnn, recvbm;
+        // a var-len column: send = the split's data bytes, sendoffs = the split's offsets[nrows + 1]; every run travels as its slice
+        // of the offsets (rows + 1 entries, landing in recvtmp) and its bytes; recvoffs = the received column's offsets, rebased
+        std::vector<DevBuf> sendoffs, recvtmp, recvoffs;
         hipEvent_t split_done = nullptr, xchg_done = nullptr;
         bool pending = false;
     } slot[TSQ_COMM_SLOTS];
@@ -139,7 +146,7 @@ TSQ_API tsq_status tsq_comm_create(tsq_ctx* ctx, int32_t rank, int32_t world, co
     memcpy(&uid, id, sizeof uid);
     TSQ_NCCL(ch, r->CommInitRank(&c->nccl, world, uid, rank));
     TSQ_HIP(ch, hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
-    const size_t words = (size_t)(world + 1) * (world + 1) + 8;
+    const size_t words = (size_t)(world + 1) * comm_lmax(world) + 8;
     TSQ_TRY(c->cnt_dev.reserve(ctx, ch, words * 8));
     TSQ_HIP(ch, hipHostMalloc((void**)&c->cnt_host, words * 8, hipHostMallocDefault));
     for (auto& s : c->slot) {
@@ -157,7 +164,7 @@ TSQ_API void tsq_comm_destroy(tsq_comm* c) {
     if (c->xs) (void)hipStreamSynchronize(c->xs);
     (void)hipStreamSynchronize(c->ctx->stream);
     for (auto& s : c->slot) {
-        for (auto* v : {&s.send, &s.recv, &s.sendbm, &s.sendnn, &s.recvnn, &s.recvbm})
+        for (auto* v : {&s.send, &s.recv, &s.sendbm, &s.sendnn, &s.recvnn, &s.recvbm, &s.sendoffs, &s.recvtmp, &s.recvoffs})
             for (auto& b : *v) b.release();
         if (s.split_done) (void)hipEventDestroy(s.split_done);
         if (s.xchg_done) (void)hipEventDestroy(s.xchg_done);
@@ -173,6 +180,9 @@ TSQ_API void tsq_comm_destroy(tsq_comm* c) {
 namespace {
 
 // packed bitmap (bit = 1: NOT NULL, util/chunk/column.go:89-92) <-> one byte per row, on the exchange stream
+__global__ void __launch_bounds__(256) k_offsets_shift(const int64_t* src, int64_t* dst, int64_t n, int64_t delta) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i] + delta;
+}
 __global__ void __launch_bounds__(256) k_bits_to_bytes(const uint8_t* bits, uint8_t* bytes, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bytes[i] = (bits[i >> 3] >> (i & 7)) & 1;
 }
@@ -190,7 +200,7 @@ tsq_status allreduce8(tsq_comm* c, void* inout, int32_t n, ncclDataType_t dt, in
     tsq_handle_hdr* h = &c->hdr;
     if (!inout || n < 1 || n > 8 || op < 0 || op > 2) return tsq_fail(h, TSQ_ERR_INVALID, "all-reduce: 1..8 words, op 0 (sum) / 1 (max) / 2 (min)");
     TSQ_HIP(h, hipSetDevice(c->ctx->device));
-    const size_t off = (size_t)(c->world + 1) * (c->world + 1);
+    const size_t off = (size_t)(c->world + 1) * comm_lmax(c->world);
     uint64_t* dev = c->cnt_dev.as<uint64_t>() + off;
     uint64_t* host = c->cnt_host + off;
     TSQ_HIP(h, hipStreamSynchronize(c->ctx->stream));  // a barrier-like call: everything this rank queued is done
@@ -232,26 +242,44 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
     if (!cols || !out_cols || !nrows_out || n_cols < 1 || n_cols > TSQ_MAX_COLS || key_col < 0 || key_col >= n_cols || nrows < 0 || slot < 0 || slot >= TSQ_COMM_SLOTS)
         return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: bad arguments");
     uint64_t my_mask = 0;
+    int var_of[TSQ_MAX_COLS], n_var = 0;  // column -> its index among the var-len columns
     for (int i = 0; i < n_cols; i++) {
         if (!(cols[i].flags & TSQ_COL_DEVICE)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: columns must be device resident");
-        if (cols[i].type < TSQ_I64 || cols[i].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_redistribute: fixed-width columns only");
+        if (cols[i].type < TSQ_I64 || cols[i].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: unknown column type");
+        if (cols[i].type == TSQ_BYTES && i == key_col) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_redistribute: the key column must be fixed width (var-len columns travel as payload)");
+        if (cols[i].type == TSQ_BYTES && !cols[i].offsets) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: a var-len column needs offsets");
         if (cols[i].null_bitmap) my_mask |= 1ull << i;
+        var_of[i] = cols[i].type == TSQ_BYTES ? n_var++ : -1;
     }
     TSQ_HIP(h, hipSetDevice(ctx->device));
     tsq_comm::Slot& s = c->slot[slot];
-    const int W = c->world, L = W + 1;
+    const int W = c->world, L = W + 1 + n_var * W;
     if (s.pending) TSQ_HIP(h, hipStreamSynchronize(c->xs));  // the previous exchange of this slot (its buffers are rewritten below)
     s.pending = false;
-    for (auto* v : {&s.send, &s.recv, &s.sendbm, &s.sendnn, &s.recvnn, &s.recvbm}) v->resize(n_cols);
+    for (auto* v : {&s.send, &s.recv, &s.sendbm, &s.sendnn, &s.recvnn, &s.recvbm, &s.sendoffs, &s.recvtmp, &s.recvoffs}) v->resize(n_cols);
+    // ---- the data bytes of the var-len columns (the split writes as many as it reads)
+    int64_t in_bytes[TSQ_MAX_COLS] = {0};
+    if (n_var && nrows > 0) {
+        for (int i = 0; i < n_cols; i++)
+            if (var_of[i] >= 0) TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + i, cols[i].offsets + nrows, 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n_cols; i++)
+            if (var_of[i] >= 0) in_bytes[i] = (int64_t)ctx->pinned[i];
+    }
     // ---- split on the operator stream (ends with the host counts: tsq_radix_split synchronises).  Rows with a NULL key go
     // to rank 0 (they never join; GROUP BY makes them one group)
     std::vector<tsq_col> sc(n_cols);
     for (int i = 0; i < n_cols; i++) {
-        const size_t es = tsq_elem_size(cols[i].type);
-        TSQ_TRY(s.send[i].reserve(ctx, h, (size_t)std::max<int64_t>(nrows, 1) * es + 64));
+        const bool var = var_of[i] >= 0;
+        const size_t es = var ? 0 : tsq_elem_size(cols[i].type);
+        TSQ_TRY(s.send[i].reserve(ctx, h, (var ? (size_t)in_bytes[i] : (size_t)std::max<int64_t>(nrows, 1) * es) + 64));
         sc[i] = cols[i];
         sc[i].data = s.send[i].p;
         sc[i].null_bitmap = nullptr;
+        if (var) {
+            TSQ_TRY(s.sendoffs[i].reserve(ctx, h, ((size_t)nrows + 1) * 8 + 64));
+            sc[i].offsets = s.sendoffs[i].as<int64_t>();
+        }
         if (cols[i].null_bitmap) {
             TSQ_TRY(s.sendbm[i].reserve(ctx, h, tsq_bitmap_bytes(nrows) + 64));
             sc[i].null_bitmap = s.sendbm[i].as<uint8_t>();
@@ -262,23 +290,47 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
         tsq_status st = tsq_radix_split(ctx, cols, n_cols, key_col, key_mode, nrows, W, sc.data(), sendc);
         if (st != TSQ_OK) return tsq_fail(h, st, ctx->hdr.err);
     }
-    // ---- counts and nullable-column masks: every rank learns the whole world x (world + 1) matrix
+    // ---- counts, nullable-column masks and the var-len columns' byte counts: every rank learns the whole world x L matrix
     uint64_t* cd = c->cnt_dev.as<uint64_t>();
     for (int p = 0; p < W; p++) c->cnt_host[p] = (uint64_t)sendc[p];
     c->cnt_host[W] = my_mask;
+    for (int k = 0; k < n_var * W; k++) c->cnt_host[W + 1 + k] = 0;
+    if (n_var && nrows > 0) {  // byte boundaries of the runs: offsets[first row of run p]
+        std::vector<int64_t> bounds((size_t)n_var * (W + 1));
+        for (int i = 0; i < n_cols; i++) {
+            if (var_of[i] < 0) continue;
+            int64_t row = 0;
+            for (int p = 0; p <= W; p++) {
+                TSQ_HIP(h, hipMemcpyAsync(&bounds[(size_t)var_of[i] * (W + 1) + p], s.sendoffs[i].as<int64_t>() + row, 8, hipMemcpyDeviceToHost, ctx->stream));
+                if (p < W) row += sendc[p];
+            }
+        }
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        for (int v = 0; v < n_var; v++)
+            for (int p = 0; p < W; p++) c->cnt_host[W + 1 + v * W + p] = (uint64_t)(bounds[(size_t)v * (W + 1) + p + 1] - bounds[(size_t)v * (W + 1) + p]);
+    }
     TSQ_HIP(h, hipMemcpyAsync(cd, c->cnt_host, (size_t)L * 8, hipMemcpyHostToDevice, c->xs));
     TSQ_NCCL(h, rccl()->AllGather(cd, cd + L, (size_t)L, ncclInt64, c->nccl, c->xs));
     TSQ_HIP(h, hipMemcpyAsync(c->cnt_host + L, cd + L, (size_t)W * L * 8, hipMemcpyDeviceToHost, c->xs));
     TSQ_HIP(h, hipStreamSynchronize(c->xs));
+    const uint64_t* M = c->cnt_host + L;  // M[q * L + ...]: rank q's vector
     int64_t recvc[TSQ_SPLIT_MAX_PARTS], total = 0;
     uint64_t mask = 0;  // a column is nullable for everybody as soon as one rank holds NULLs in it
     for (int p = 0; p < W; p++) {
-        recvc[p] = (int64_t)c->cnt_host[L + (size_t)p * L + c->rank];  // what rank p sends to this rank
+        recvc[p] = (int64_t)M[(size_t)p * L + c->rank];  // what rank p sends to this rank
         total += recvc[p];
-        mask |= c->cnt_host[L + (size_t)p * L + W];
+        mask |= M[(size_t)p * L + W];
     }
+    int64_t recv_bytes[TSQ_MAX_COLS] = {0};  // var-len columns: data bytes this rank receives
     for (int i = 0; i < n_cols; i++) {
-        TSQ_TRY(s.recv[i].reserve(ctx, h, (size_t)std::max<int64_t>(total, 1) * tsq_elem_size(cols[i].type) + 64));
+        const bool var = var_of[i] >= 0;
+        if (var)
+            for (int q = 0; q < W; q++) recv_bytes[i] += (int64_t)M[(size_t)q * L + W + 1 + var_of[i] * W + c->rank];
+        TSQ_TRY(s.recv[i].reserve(ctx, h, (var ? (size_t)recv_bytes[i] : (size_t)std::max<int64_t>(total, 1) * tsq_elem_size(cols[i].type)) + 64));
+        if (var) {
+            TSQ_TRY(s.recvtmp[i].reserve(ctx, h, ((size_t)total + W + 1) * 8 + 64));
+            TSQ_TRY(s.recvoffs[i].reserve(ctx, h, ((size_t)total + 1) * 8 + 64));
+        }
         if ((mask >> i) & 1) {
             TSQ_TRY(s.sendnn[i].reserve(ctx, h, (size_t)std::max<int64_t>(nrows, 1) + 64));
             TSQ_TRY(s.recvnn[i].reserve(ctx, h, (size_t)std::max<int64_t>(total, 1) + 64));
@@ -301,26 +353,69 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
     }
     TSQ_NCCL(h, rccl()->GroupStart());
     for (int i = 0; i < n_cols; i++) {
-        const size_t es = tsq_elem_size(cols[i].type);
+        const bool var = var_of[i] >= 0;
+        const size_t es = var ? 0 : tsq_elem_size(cols[i].type);
         const bool nn = (mask >> i) & 1;
         size_t so = 0, ro = 0;  // in rows
+        size_t sb = 0, rb = 0;  // var-len: in bytes
         for (int p = 0; p < W; p++) {
             const size_t sr = (size_t)sendc[p], rr = (size_t)recvc[p];
-            if (p == c->rank) {
+            if (var) {
+                // run p of this rank: offsets[so .. so + sr] and the bytes between its first and its last offset; run from rank p:
+                // rr + 1 offsets into recvtmp at ro + p (one extra entry per source), its bytes behind the bytes of the sources before it
+                const size_t sby = (size_t)M[(size_t)c->rank * L + W + 1 + var_of[i] * W + p], rby = (size_t)M[(size_t)p * L + W + 1 + var_of[i] * W + c->rank];
+                const int64_t* so_p = s.sendoffs[i].as<int64_t>() + so;
+                int64_t* rt_p = s.recvtmp[i].as<int64_t>() + ro + p;
+                if (p == c->rank) {
+                    if (sr) TSQ_HIP(h, hipMemcpyAsync(rt_p, so_p, (sr + 1) * 8, hipMemcpyDeviceToDevice, c->xs));
+                    if (sby) TSQ_HIP(h, hipMemcpyAsync((char*)s.recv[i].p + rb, (const char*)s.send[i].p + sb, sby, hipMemcpyDeviceToDevice, c->xs));
+                } else {
+                    if (sr) TSQ_NCCL(h, rccl()->Send(so_p, (sr + 1) * 8, ncclChar, p, c->nccl, c->xs));
+                    if (rr) TSQ_NCCL(h, rccl()->Recv(rt_p, (rr + 1) * 8, ncclChar, p, c->nccl, c->xs));
+                    if (sby) TSQ_NCCL(h, rccl()->Send((const char*)s.send[i].p + sb, sby, ncclChar, p, c->nccl, c->xs));
+                    if (rby) TSQ_NCCL(h, rccl()->Recv((char*)s.recv[i].p + rb, rby, ncclChar, p, c->nccl, c->xs));
+                }
+                sb += sby;
+                rb += rby;
+            } else if (p == c->rank) {
                 if (sr) TSQ_HIP(h, hipMemcpyAsync((char*)s.recv[i].p + ro * es, (const char*)s.send[i].p + so * es, sr * es, hipMemcpyDeviceToDevice, c->xs));
-                if (sr && nn) TSQ_HIP(h, hipMemcpyAsync((char*)s.recvnn[i].p + ro, (const char*)s.sendnn[i].p + so, sr, hipMemcpyDeviceToDevice, c->xs));
             } else {
                 if (sr) TSQ_NCCL(h, rccl()->Send((const char*)s.send[i].p + so * es, sr * es, ncclChar, p, c->nccl, c->xs));
                 if (rr) TSQ_NCCL(h, rccl()->Recv((char*)s.recv[i].p + ro * es, rr * es, ncclChar, p, c->nccl, c->xs));
-                if (sr && nn) TSQ_NCCL(h, rccl()->Send((const char*)s.sendnn[i].p + so, sr, ncclChar, p, c->nccl, c->xs));
-                if (rr && nn) TSQ_NCCL(h, rccl()->Recv((char*)s.recvnn[i].p + ro, rr, ncclChar, p, c->nccl, c->xs));
+            }
+            if (nn && p == c->rank) {
+                if (sr) TSQ_HIP(h, hipMemcpyAsync((char*)s.recvnn[i].p + ro, (const char*)s.sendnn[i].p + so, sr, hipMemcpyDeviceToDevice, c->xs));
+            } else if (nn) {
+                if (sr) TSQ_NCCL(h, rccl()->Send((const char*)s.sendnn[i].p + so, sr, ncclChar, p, c->nccl, c->xs));
+                if (rr) TSQ_NCCL(h, rccl()->Recv((char*)s.recvnn[i].p + ro, rr, ncclChar, p, c->nccl, c->xs));
             }
             so += sr;
             ro += rr;
         }
     }
     TSQ_NCCL(h, rccl()->GroupEnd());
-    for (int i = 0; i < n_cols; i++) {  // received bytes -> the packed bitmap of the received column
+    for (int i = 0; i < n_cols; i++) {
+        if (var_of[i] >= 0) {
+            // received offsets -> the column's offsets: the run from rank q starts at row ro and at byte rb of this rank; on the wire its
+            // offsets count from the bytes rank q sent to the ranks before this one
+            TSQ_HIP(h, hipMemsetAsync(s.recvoffs[i].p, 0, 8, c->xs));
+            size_t ro = 0;
+            int64_t rb = 0;
+            for (int q = 0; q < W; q++) {
+                const int64_t rr = recvc[q];
+                int64_t first = 0;  // the run's first offset on rank q
+                for (int p = 0; p < c->rank; p++) first += (int64_t)M[(size_t)q * L + W + 1 + var_of[i] * W + p];
+                if (rr > 0) {
+                    const int grid = (int)std::min<int64_t>((rr + 255) / 256, (int64_t)ctx->num_cus * 8);
+                    hipLaunchKernelGGL(k_offsets_shift, dim3(grid), dim3(256), 0, c->xs, s.recvtmp[i].as<int64_t>() + ro + q + 1, s.recvoffs[i].as<int64_t>() + ro + 1, rr,
+                                       rb - first);
+                    TSQ_HIP(h, hipGetLastError());
+                }
+                ro += (size_t)rr;
+                rb += (int64_t)M[(size_t)q * L + W + 1 + var_of[i] * W + c->rank];
+            }
+        }
+        // received bytes -> the packed bitmap of the received column
         if (!((mask >> i) & 1) || total == 0) continue;
         const int grid = (int)std::min<int64_t>(((total + 7) / 8 + 255) / 256, (int64_t)ctx->num_cus * 8);
         hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid), dim3(256), 0, c->xs, s.recvnn[i].as<uint8_t>(), s.recvbm[i].as<uint8_t>(), total);
@@ -332,7 +427,7 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
         out_cols[i] = cols[i];
         out_cols[i].data = s.recv[i].p;
         out_cols[i].null_bitmap = ((mask >> i) & 1) ? s.recvbm[i].as<uint8_t>() : nullptr;
-        out_cols[i].offsets = nullptr;
+        out_cols[i].offsets = var_of[i] >= 0 ? s.recvoffs[i].as<int64_t>() : nullptr;
         out_cols[i].length = total;
         out_cols[i].flags = TSQ_COL_DEVICE;
     }

@@ -248,6 +248,23 @@ __global__ void __launch_bounds__(256) k_decc_var_copy(DeccVarArgs a) {
 
 }  // namespace
 
+// cells (pos[r], offs[r + 1] - offs[r]) of `data` -> out + offs[r]: shared with the var-len columns of tsq_radix_split (tsq_stage.h)
+tsq_status tsq_launch_var_copy(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* data, const int64_t* pos, const int64_t* offs, int64_t rows, int64_t total_bytes,
+                               uint8_t* out) {
+    if (rows <= 0 || total_bytes <= 0) return TSQ_OK;
+    DeccVarArgs va;
+    va.data = data;
+    va.pos = pos;
+    va.offs = offs;
+    va.rows = rows;
+    va.out = out;
+    if (total_bytes / rows > 32) hipLaunchKernelGGL(k_decc_var_copy<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, va);
+    else hipLaunchKernelGGL(k_decc_var_copy<false>, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, va);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("var copy: ") + hipGetErrorString(e));
+    return TSQ_OK;
+}
+
 // ====================================================================== host side
 namespace {
 struct IdxMode {  // tsq_indexkeys_decode: the extra inputs of the key walk
@@ -401,18 +418,7 @@ static tsq_status decc_decode(tsq_ctx* ctx, const std::string& who, const uint8_
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) { s = tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(var scan): ") + hipGetErrorString(e)); break; }
             var_bytes[c] = (int64_t)ctx->pinned[4];
-            if (var_bytes[c] > 0) {
-                DeccVarArgs va;
-                va.data = a.data;
-                va.pos = a.ref_pos[c];
-                va.offs = a.out_offs[c];
-                va.rows = rows;
-                va.out = out_dev ? (uint8_t*)out_cols[c].data : ddata[c].as<uint8_t>();
-                if (var_bytes[c] / rows > 32) hipLaunchKernelGGL(k_decc_var_copy<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, va);
-                else hipLaunchKernelGGL(k_decc_var_copy<false>, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, va);
-                e = hipGetLastError();
-                if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(var copy): ") + hipGetErrorString(e));
-            }
+            s = tsq_launch_var_copy(ctx, h, a.data, a.ref_pos[c], a.out_offs[c], rows, var_bytes[c], out_dev ? (uint8_t*)out_cols[c].data : ddata[c].as<uint8_t>());
         }
         if (s != TSQ_OK) return fail(s);
         if (!out_dev) {

@@ -22,6 +22,10 @@ struct SplitArgs {
     unsigned long long* cursors;  // [n_parts] running output positions (pre-loaded with run offsets)
     void* out_data[TSQ_MAX_COLS];
     uint8_t* out_notnull[TSQ_MAX_COLS];
+    // var-len (payload) columns: the cell's length goes to out_len[c][pos] (its scan = the output offsets), its source position to
+    // out_pos[c][pos]; the bytes follow in a second kernel (tsq_launch_var_copy)
+    int64_t* out_len[TSQ_MAX_COLS];
+    int64_t* out_pos[TSQ_MAX_COLS];
 };
 
 __device__ __forceinline__ uint32_t split_rank(const SplitArgs& a, int64_t row) {
@@ -69,7 +73,11 @@ __global__ void __launch_bounds__(256) k_split_scatter(SplitArgs a) {
         if (!active) continue;
         for (int c = 0; c < a.in.n; c++) {
             const bool nn = !tsq_is_null(a.in.nulls[c], r);
-            if (a.in.type[c] == TSQ_F32) ((uint32_t*)a.out_data[c])[pos] = ((const uint32_t*)a.in.data[c])[r];
+            if (a.in.type[c] == TSQ_BYTES) {
+                const int64_t lo = a.in.offs[c][r];
+                a.out_pos[c][pos] = lo;
+                a.out_len[c][pos] = nn ? a.in.offs[c][r + 1] - lo : 0;  // a NULL cell has no bytes
+            } else if (a.in.type[c] == TSQ_F32) ((uint32_t*)a.out_data[c])[pos] = ((const uint32_t*)a.in.data[c])[r];
             else ((uint64_t*)a.out_data[c])[pos] = ((const uint64_t*)a.in.data[c])[r];
             if (a.out_notnull[c]) a.out_notnull[c][pos] = nn ? 1 : 0;
         }
@@ -125,7 +133,7 @@ static tsq_status split_fast(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, 
     tsq_handle_hdr* h = &ctx->hdr;
     if (n_parts > 8 || n_cols > 1 + TSQ_RADIX_MAXV || nrows >= 0xffffffffLL || nrows < (1 << 16)) return TSQ_OK;
     for (int c = 0; c < n_cols; c++)
-        if (cols[c].null_bitmap || out_cols[c].null_bitmap || cols[c].type == TSQ_F32) return TSQ_OK;
+        if (cols[c].null_bitmap || out_cols[c].null_bitmap || cols[c].type == TSQ_F32 || cols[c].type == TSQ_BYTES) return TSQ_OK;
     if (key_mode == 0 && cols[key_col].type == TSQ_F64) {}  // join-key word of a double is its bits: fine
     const bool f64_image = key_mode == 1 && cols[key_col].type == TSQ_F64;
     if (f64_image) return TSQ_OK;  // the partition kernel's wide path reads raw key words; group-key float images take the general path
@@ -203,9 +211,11 @@ TSQ_API tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
     for (int c = 0; c < n_cols; c++) {
         if (!(cols[c].flags & TSQ_COL_DEVICE) || !(out_cols[c].flags & TSQ_COL_DEVICE))
             return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: columns must be device resident");
-        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_radix_split: var-len column");
+        if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: unknown column type");
+        if (cols[c].type == TSQ_BYTES && c == key_col) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_radix_split: the key column must be fixed width (var-len columns travel as payload)");
+        if (cols[c].type == TSQ_BYTES && (!cols[c].offsets || !out_cols[c].offsets)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: a var-len column needs offsets");
         if (cols[c].null_bitmap && !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: nullable column needs an output bitmap");
-        if (nrows > 0 && (!cols[c].data || !out_cols[c].data)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: NULL data pointer");
+        if (nrows > 0 && cols[c].type != TSQ_BYTES && (!cols[c].data || !out_cols[c].data)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: NULL data pointer");
     }
     for (int p = 0; p < n_parts; p++) counts_out[p] = 0;
     if (nrows == 0) return TSQ_OK;
@@ -222,11 +232,13 @@ TSQ_API tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
     a.key_mode = key_mode;
     a.n_parts = n_parts;
     a.nrows = nrows;
-    DevBuf cur;
-    std::vector<DevBuf> nn(n_cols);
+    DevBuf cur, scan_scratch;
+    std::vector<DevBuf> nn(n_cols), vpos(n_cols);
     auto cleanup = [&]() {
         cur.release();
+        scan_scratch.release();
         for (auto& b : nn) b.release();
+        for (auto& b : vpos) b.release();
     };
     tsq_status s = cur.reserve(ctx, h, 2 * TSQ_SPLIT_MAX_PARTS * 8);
     if (s != TSQ_OK) { cleanup(); return s; }
@@ -248,6 +260,12 @@ TSQ_API tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
     if (e != hipSuccess) { cleanup(); return tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_radix_split: ") + hipGetErrorString(e)); }
     for (int c = 0; c < n_cols; c++) {
         a.out_data[c] = out_cols[c].data;
+        if (cols[c].type == TSQ_BYTES) {
+            s = vpos[c].reserve(ctx, h, (size_t)nrows * 8 + 64);
+            if (s != TSQ_OK) { cleanup(); return s; }
+            a.out_pos[c] = vpos[c].as<int64_t>();
+            a.out_len[c] = out_cols[c].offsets;  // lengths first, their scan in place
+        }
         if (cols[c].null_bitmap) {
             s = nn[c].reserve(ctx, h, (size_t)nrows + 16);
             if (s != TSQ_OK) { cleanup(); return s; }
@@ -266,7 +284,19 @@ TSQ_API tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
         if (s != TSQ_OK) { cleanup(); return s; }
         out_cols[c].length = nrows;
         out_cols[c].type = cols[c].type;
-        out_cols[c].elem_size = tsq_elem_size(cols[c].type);
+        out_cols[c].elem_size = cols[c].type == TSQ_BYTES ? -1 : tsq_elem_size(cols[c].type);
+        if (cols[c].type == TSQ_BYTES) {  // lengths -> offsets[nrows + 1], then the bytes of every cell to its new place
+            s = tsq_launch_scan64(ctx, h, out_cols[c].offsets, nrows, scan_scratch);
+            if (s == TSQ_OK) {
+                e = hipMemcpyAsync(ctx->pinned, out_cols[c].offsets + nrows, 8, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_radix_split: ") + hipGetErrorString(e));
+            }
+            const int64_t total = (int64_t)ctx->pinned[0];
+            if (s == TSQ_OK && total > 0 && !out_cols[c].data) s = tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: NULL data pointer");
+            if (s == TSQ_OK) s = tsq_launch_var_copy(ctx, h, (const uint8_t*)cols[c].data, a.out_pos[c], out_cols[c].offsets, nrows, total, (uint8_t*)out_cols[c].data);
+            if (s != TSQ_OK) { cleanup(); return s; }
+        }
     }
     e = hipStreamSynchronize(ctx->stream);
     cleanup();

@@ -36,6 +36,9 @@ struct ColStore {  // one device-resident column that grows by appends
 tsq_status tsq_launch_append_bits(tsq_ctx* ctx, tsq_handle_hdr* h, uint8_t* dst, int64_t dst_off, const uint8_t* src_dev, int64_t n);
 tsq_status tsq_launch_offsets_rebase(tsq_ctx* ctx, tsq_handle_hdr* h, int64_t* dst, const int64_t* src_dev, int64_t n, int64_t delta);
 tsq_status tsq_launch_scan64(tsq_ctx* ctx, tsq_handle_hdr* h, int64_t* v, int64_t n, DevBuf& scratch);
+// cell r = bytes [pos[r], pos[r] + offs[r + 1] - offs[r]) of `data` -> out + offs[r] (tsq_decodec.hip; one cell per lane, or per wave when cells are long)
+tsq_status tsq_launch_var_copy(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* data, const int64_t* pos, const int64_t* offs, int64_t rows, int64_t total_bytes,
+                               uint8_t* out);
 
 inline tsq_status tsq_col_append_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, ColStore& cs, const uint8_t* bitmap, int64_t n, bool src_dev, DevBuf& tmp_bits) {
     if (bitmap && !cs.has_nulls) {
