@@ -602,8 +602,9 @@ void       tsq_sort_destroy(tsq_sort* s);
  * (codec.go:713-746: -0.0 and +0.0 share a group).  Rows with a NULL key are routed to part 0.
  * cols/out_cols are device resident; out_cols need capacity nrows; counts_out: int64[n_parts]
  * on the host; run p of every output column is rows [sum(counts[0..p)), +counts[p]).
- * Var-len (TSQ_BYTES) columns travel as payload (the key column is fixed width): their out column needs offsets[nrows + 1] and as
- * many data bytes as the input column holds; the cells are laid out in the order of the split rows. */
+ * Var-len (TSQ_BYTES) columns travel with their rows — as payload, or as the key (equal strings rank alike: a hash of the bytes):
+ * their out column needs offsets[nrows + 1] and as many data bytes as the input column holds; the cells are laid out in the order
+ * of the split rows. */
 tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int32_t key_col,
                            int32_t key_mode, int64_t nrows, int32_t n_parts, tsq_col* out_cols,
                            int64_t* counts_out);
@@ -615,7 +616,7 @@ tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, in
  * Every rank runs the same call sequence.  Bootstrap: rank 0 calls tsq_comm_unique_id and hands the 128 bytes to the other
  * ranks by any side channel (the Go host: the coordinator's RPC; the harness: a file), then every rank calls tsq_comm_create.
  *
- * tsq_redistribute splits `cols` (device resident; the key column fixed width, var-len columns as payload) by rank(key) on the
+ * tsq_redistribute splits `cols` (device resident; var-len columns included, also as the key) by rank(key) on the
  * context's stream (tsq_radix_split), exchanges the run sizes (rows, and bytes of every var-len column), and queues ONE group of RCCL
  * sends / receives on the communicator's own stream.  A var-len column's run travels as its slice of the offsets plus its bytes; the
  * received column gets offsets[n + 1] rebased onto its own data (out_cols[c].offsets, owned by the slot).  A column with a null bitmap

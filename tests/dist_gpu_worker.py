@@ -236,6 +236,26 @@ def main():
                 want += [(int(k[i]), a[i], b[i], int(k[i]) * 3) for i in np.nonzero(mine)[0]]
             skey = lambda t: (t[0], t[1] is None, t[1] or b"", t[2])  # noqa: E731
             assert n == len(want) and sorted(zip(rk.tolist(), gn, gm, r3.tolist()), key=skey) == sorted(want, key=skey)
+            # a string KEY: rows with equal names meet on one rank (whichever), every row arrives exactly once
+            got, n = comm.redistribute([cn.col(), dev(ctx, sk, keep)], 0, 1, len(sk), slot=7)
+            comm.wait(7)
+            ctx.sync()
+            gn2 = pull_str(got[0], n)
+            rk2 = np.empty(n, np.int64)
+            if n:
+                ctx.d2h(rk2, got[1].data)
+            mine_names = set(gn2)
+            counts = comm.allreduce_i64([n, len(mine_names)])
+            all_names = set()
+            for r in range(world):
+                all_names |= set(srows[r][1])
+            assert counts[0] == sum(len(srows[r][0]) for r in range(world)) and counts[1] == len(all_names)  # no name on two ranks
+            union = {}
+            for r in range(world):
+                for k, a in zip(srows[r][0].tolist(), srows[r][1]):
+                    union.setdefault(a, []).append(k)
+            for name in list(mine_names)[:200]:
+                assert sorted(k for k, a in zip(rk2.tolist(), gn2) if a == name) == sorted(union[name])
             cn.free()
             cm.free()
             lap("strings through the exchange")

@@ -114,9 +114,20 @@ def test_radix_split_carries_var_len_payload_columns(ctx, parts, long_cells):
                 assert (0 if r[0] is None else rank(r[0] & ((1 << 64) - 1), parts)) == p
             off += counts[p]
         assert H.rows_equal_unordered(rows, want)
-        # a var-len KEY column is refused (the rank of a string key is not built)
-        bad = ctx.lib.tsq_radix_split(ctx.h, G.dev_cols(src), 4, 1, 0, n, parts, G.dev_cols(dst), (C.c_int64 * parts)())
-        assert bad == abi.ERR_UNSUPPORTED
+        # a var-len KEY column: equal strings land in the same part, NULL strings in part 0
+        counts2 = (C.c_int64 * parts)()
+        _lib.check(ctx.lib.tsq_radix_split(ctx.h, G.dev_cols(src), 4, 3, 0, n, parts, G.dev_cols(dst), counts2), ctx.h)
+        counts2 = list(counts2)
+        out = Chunk([dst[0].to_host(), dst[1].to_host(n, len(names.data)), dst[2].to_host(), dst[3].to_host(n, len(tags.data))])
+        rows = out.rows()
+        assert sum(counts2) == n and H.rows_equal_unordered(rows, want)
+        part_of, off = {}, 0
+        for p in range(parts):
+            for r in rows[off:off + counts2[p]]:
+                assert part_of.setdefault(r[3], p) == p
+            off += counts2[p]
+        if parts > 1:
+            assert len(set(part_of.values())) > 1  # 97 distinct tags do not all rank to one part
     finally:
         for d in src + dst:
             d.free()

@@ -246,7 +246,6 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
     for (int i = 0; i < n_cols; i++) {
         if (!(cols[i].flags & TSQ_COL_DEVICE)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: columns must be device resident");
         if (cols[i].type < TSQ_I64 || cols[i].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: unknown column type");
-        if (cols[i].type == TSQ_BYTES && i == key_col) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_redistribute: the key column must be fixed width (var-len columns travel as payload)");
         if (cols[i].type == TSQ_BYTES && !cols[i].offsets) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: a var-len column needs offsets");
         if (cols[i].null_bitmap) my_mask |= 1ull << i;
         var_of[i] = cols[i].type == TSQ_BYTES ? n_var++ : -1;

@@ -32,6 +32,10 @@ __device__ __forceinline__ uint32_t split_rank(const SplitArgs& a, int64_t row) 
     const int c = a.key_col;
     if (tsq_is_null(a.in.nulls[c], row)) return 0;
     uint64_t w;
+    if (a.in.type[c] == TSQ_BYTES) {  // a string key: equal bytes rank alike (string join keys: codec.go:233-235; group keys: :739-742)
+        const int64_t lo = a.in.offs[c][row];
+        return tsq_key_rank(tsq_hash_bytes((const uint8_t*)a.in.data[c] + lo, a.in.offs[c][row + 1] - lo), (uint32_t)a.n_parts);
+    }
     if (a.key_mode == 1 && (a.in.type[c] == TSQ_F32 || a.in.type[c] == TSQ_F64)) {
         double f = a.in.type[c] == TSQ_F32 ? (double)((const float*)a.in.data[c])[row] : ((const double*)a.in.data[c])[row];
         uint64_t u = tsq_f64_bits(f);
@@ -212,7 +216,6 @@ TSQ_API tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
         if (!(cols[c].flags & TSQ_COL_DEVICE) || !(out_cols[c].flags & TSQ_COL_DEVICE))
             return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: columns must be device resident");
         if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: unknown column type");
-        if (cols[c].type == TSQ_BYTES && c == key_col) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_radix_split: the key column must be fixed width (var-len columns travel as payload)");
         if (cols[c].type == TSQ_BYTES && (!cols[c].offsets || !out_cols[c].offsets)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: a var-len column needs offsets");
         if (cols[c].null_bitmap && !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: nullable column needs an output bitmap");
         if (nrows > 0 && cols[c].type != TSQ_BYTES && (!cols[c].data || !out_cols[c].data)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_radix_split: NULL data pointer");
