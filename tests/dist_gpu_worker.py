@@ -256,6 +256,41 @@ def main():
                     union.setdefault(a, []).append(k)
             for name in list(mine_names)[:200]:
                 assert sorted(k for k, a in zip(rk2.tolist(), gn2) if a == name) == sorted(union[name])
+            # ---- GROUP BY a string across the ranks: partial rows (name, sum, count) shuffled by rank(name), merged by their owner
+            def grows_of(r):
+                n_r = len(srows[r][0])
+                return [None if (i + r) % 41 == 0 else b"g%03d" % ((i * 7 + r) % 613) for i in range(n_r)], (srows[r][0] % 1000).astype(np.int64)
+            gnames, gv = grows_of(rank)
+            cg = G.DevStrCol(ctx, StrColumn(gnames))
+            st = [abi.BYTES, abi.I64]
+            spt = [abi.BYTES, abi.I64, abi.I64]
+            spaggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES, abi.MODE_PARTIAL1), (abi.AGG_SUM, 1, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_COUNT, 1, abi.I64, abi.MODE_PARTIAL1)]
+            sfaggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES, abi.MODE_FINAL), (abi.AGG_SUM, 1, abi.I64, abi.MODE_FINAL), (abi.AGG_COUNT, 2, abi.I64, abi.MODE_FINAL)]
+            sout, sng = parallel.dist_hash_agg(comm, H.agg_cfg(st, [0], spaggs), H.agg_cfg(spt, [0], sfaggs), [cg.col(), dev(ctx, gv, keep)], len(gv), spt,
+                                               out_types=[abi.BYTES, abi.I64, abi.I64])
+            class _V:  # a view of a returned var-len column for pull_str
+                pass
+            v0 = _V()
+            v0.data, v0.null_bitmap, v0.offsets = sout[0][0], sout[0][1], sout[0][2]
+            names_out = pull_str(v0, sng)
+            sums, cnts = np.empty(sng, np.int64), np.empty(sng, np.int64)
+            if sng:
+                ctx.d2h(sums, sout[1][0])
+                ctx.d2h(cnts, sout[2][0])
+            wantg = {}
+            for r in range(world):
+                a, b = grows_of(r)
+                for nm, x in zip(a, b.tolist()):
+                    e = wantg.setdefault(nm, [0, 0])
+                    e[0] += x
+                    e[1] += 1
+            mine_g = dict(zip(names_out, zip(sums.tolist(), cnts.tolist())))
+            assert len(mine_g) == sng and all(tuple(wantg[k]) == v for k, v in mine_g.items())
+            assert comm.allreduce_i64([sng])[0] == len(wantg) and (None in wantg)
+            for b in sout:
+                for q in b[:3]:
+                    ctx.free(q)
+            cg.free()
             cn.free()
             cm.free()
             lap("strings through the exchange")

@@ -280,18 +280,45 @@ class DistHashJoinCount:
             self.h = None
 
 
-def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_col_partial=0, cap=None):
+def _pull_buffers(ctx, lib, handle, peek, types, n):
+    """device buffers for a pull of n rows with the given column types (var-len columns sized by the operator's peek):
+    returns (abi.Col array, [(data, bitmap[, offsets, data bytes])])"""
+    cols = (abi.Col * len(types))()
+    var_bytes = [0] * len(types)
+    if n and abi.BYTES in types:
+        vb, nr = (C.c_int64 * len(types))(), C.c_int64(0)
+        _lib.check(peek(handle, (n + 7) & ~7, C.byref(nr), vb, len(types)), handle)
+        var_bytes = list(vb)
+    bufs = []
+    for i, tp in enumerate(types):
+        q = ctx.alloc((max(n, 1) + 7) // 8 + 8)
+        if tp == abi.BYTES:
+            p, o = ctx.alloc(var_bytes[i] + 64), ctx.alloc((max(n, 1) + 1) * 8 + 64)
+            cols[i].offsets, cols[i].elem_size = o, -1
+            bufs.append((p, q, o, var_bytes[i]))
+        else:
+            es = 4 if tp == abi.F32 else 8
+            p = ctx.alloc(max(n, 1) * es)
+            cols[i].elem_size = es
+            bufs.append((p, q))
+        cols[i].data, cols[i].null_bitmap, cols[i].length, cols[i].type, cols[i].flags = p, q, n, tp, abi.COL_DEVICE
+    return cols, bufs
+
+
+def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_col_partial=0, cap=None, out_types=None):
     """HashAggExec across the ranks of `comm`, the reference's own three stages (executor/aggregate.go:96-133):
       1. every rank pre-aggregates ITS rows (partial workers, Partial1Mode): one row per local group;
       2. the partial rows are redistributed by rank(group key) — shuffleIntermData (aggregate.go:352-356) over xGMI;
       3. every rank merges the partial rows of the groups it owns (final workers, FinalMode) and returns them.
     partial_cfg / final_cfg: abi.AggCfg of the two stages; partial_types: column types of the partial rows (the input schema of
-    final_cfg); key_col_partial: the group key's column in the partial rows.  Returns (device column buffers, n_groups_local):
-    the caller owns the buffers (ctx.free)."""
+    final_cfg); key_col_partial: the group key's column in the partial rows (a string group key travels like any other: the rank
+    of its bytes' hash); out_types: types of the final columns (default: 8-byte columns).  Returns (device column buffers —
+    (data, bitmap) or (data, bitmap, offsets, data bytes) for a var-len column —, n_groups_local): the caller owns the buffers
+    (ctx.free)."""
     lib, ctx = comm.lib, comm.ctx
     hp = C.c_void_p()
     _lib.check(lib.tsq_agg_create(ctx.h, C.byref(partial_cfg), C.byref(hp)), ctx.h)
-    bufs = []
+    pbufs = []
     try:
         arr = (abi.Col * len(cols))(*cols)
         if nrows:
@@ -300,13 +327,7 @@ def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_
         ng = C.c_int64(0)
         _lib.check(lib.tsq_agg_num_groups(hp, C.byref(ng)), hp)
         n_part = ng.value
-        pcols = (abi.Col * len(partial_types))()
-        bm_bytes = (max(n_part, 1) + 7) // 8 + 8
-        for i, tp in enumerate(partial_types):
-            es = 4 if tp == abi.F32 else 8
-            p, q = ctx.alloc(max(n_part, 1) * es), ctx.alloc(bm_bytes)
-            bufs += [p, q]
-            pcols[i].data, pcols[i].null_bitmap, pcols[i].length, pcols[i].elem_size, pcols[i].type, pcols[i].flags = p, q, n_part, es, tp, abi.COL_DEVICE
+        pcols, pbufs = _pull_buffers(ctx, lib, hp, lib.tsq_agg_peek, list(partial_types), n_part)
         if n_part:
             n, eos = C.c_int64(0), C.c_int32(0)
             _lib.check(lib.tsq_agg_pull(hp, pcols, len(partial_types), (n_part + 7) & ~7, C.byref(n), C.byref(eos)), hp)
@@ -325,12 +346,8 @@ def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_
         _lib.check(lib.tsq_agg_num_groups(hf, C.byref(ng)), hf)
         n_out = ng.value
         n_out_cols = final_cfg.n_aggs
-        out_bufs, ocols = [], (abi.Col * n_out_cols)()
-        for i in range(n_out_cols):
-            p = ctx.alloc(max(n_out, 1) * 8)
-            q = ctx.alloc(max(n_out, 8) // 8 + 8)
-            out_bufs.append((p, q))
-            ocols[i].data, ocols[i].null_bitmap, ocols[i].length, ocols[i].elem_size, ocols[i].flags = p, q, n_out, 8, abi.COL_DEVICE
+        otypes = list(out_types) if out_types is not None else [abi.I64] * n_out_cols
+        ocols, out_bufs = _pull_buffers(ctx, lib, hf, lib.tsq_agg_peek, otypes, n_out)
         if n_out:
             m, eos = C.c_int64(0), C.c_int32(0)
             _lib.check(lib.tsq_agg_pull(hf, ocols, n_out_cols, (n_out + 7) & ~7, C.byref(m), C.byref(eos)), hf)
@@ -338,6 +355,7 @@ def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_
         ctx.sync()
     finally:
         lib.tsq_agg_destroy(hf)
-        for p in bufs:
-            ctx.free(p)
+        for b in pbufs:
+            for p in b[:3]:
+                ctx.free(p)
     return out_bufs, n_out
