@@ -403,7 +403,7 @@ def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3):
                       "(it also lays the build payload out in table-slot order, once per build)" % reps}
 
 
-def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=100_000_000):
+def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_000):
     """BASELINE configs[2]: SELECT k, SUM(v), COUNT(*) GROUP BY k, 1e9 rows / 1e6 int64 groups; the rows are generated batch by
     batch on the device (untimed) and pushed device resident, like the chunks of a GPU child operator."""
     lib = ctx.lib
@@ -448,7 +448,7 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=100_000_00
     algo = 16.0 * n + 24.0 * ng.value
     return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows / 1e6 int64 groups, HashAggExec", "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value,
             "frac": algo / ms / 1e6 / 8000.0, "verified": ng.value == groups, "first_run_ms": runs[0],
-            "timing": "HIP events around every tsq_agg_push (10 device-resident batches of 1e8 rows) + tsq_agg_finish; second of two runs"}
+            "timing": "HIP events around every tsq_agg_push (%d device-resident batches of %.3g rows) + tsq_agg_finish; second of two runs" % ((n + batch - 1) // batch, batch)}
 
 
 def cpu_baseline(abi, nb, npr):
