@@ -927,6 +927,48 @@ private:
     int64_t n_ = 0, pos_ = 0, count_ = 0;
 };
 
+// the KV pairs of an index range, in scan order: index keys back to back + offsets, the pairs' values (the handle of a unique index)
+struct IndexPairs {
+    std::vector<uint8_t> keys, values;
+    std::vector<int64_t> keyOffsets, valueOffsets;  // n + 1 each (valueOffsets may stay empty when every key carries its handle)
+};
+enum PrimaryKeyStatus { PrimaryKeyNotExists = 0, PrimaryKeyIsSigned = 1, PrimaryKeyIsUnsigned = 2 };  // tablecodec.go:394-403
+
+// indexScanExec (store/mockstore/mocktikv/executor.go:191-320): tablecodec.DecodeIndexKV (tablecodec.go:376-434) of every pair, a chunk
+// at a time.  types: the index columns (+ the handle column when pkStatus != PrimaryKeyNotExists); colsLen = the index columns
+class indexScanExec : public Executor {
+public:
+    indexScanExec(Context* ctx, Schema types, int colsLen, PrimaryKeyStatus pkStatus, const IndexPairs* pairs)
+        : Executor(ctx, std::move(types), {}), colsLen_(colsLen), pk_(pkStatus), p_(pairs) {
+        n_ = (int64_t)p_->keyOffsets.size() - 1;
+    }
+    void Open() override { pos_ = count_ = 0; }
+    void Next(Chunk* req) override {
+        req->Reset();
+        if (pos_ >= n_) return;
+        const int64_t lo = pos_, hi = std::min<int64_t>(n_, pos_ + std::min(req->requiredRows, maxChunkSize));
+        const int64_t keyBytes = p_->keyOffsets[(size_t)hi] - p_->keyOffsets[(size_t)lo];
+        for (auto& c : req->columns) c.resizeFor(hi - lo, keyBytes);  // a string cell is a piece of its key
+        std::vector<tsq_col> out;
+        for (auto& c : req->columns) out.push_back(c.View(hi - lo));
+        const Schema tp = req->schema();
+        const bool vals = !p_->valueOffsets.empty();
+        int64_t n = 0;
+        check(tsq_indexkeys_decode(ctx_->h, p_->keys.data(), (int64_t)p_->keys.size(), p_->keyOffsets.data() + lo, hi - lo, vals ? p_->values.data() : nullptr,
+                                   vals ? (int64_t)p_->values.size() : 0, vals ? p_->valueOffsets.data() + lo : nullptr, 0, colsLen_, tp.data(), (int32_t)pk_, out.data(), &n),
+              ctx_->h);
+        for (auto& c : req->columns) c.truncate(n);
+        pos_ = hi;
+        count_ += n;
+    }
+    int64_t Count() const { return count_; }
+private:
+    int colsLen_;
+    PrimaryKeyStatus pk_;
+    const IndexPairs* p_;
+    int64_t n_ = 0, pos_ = 0, count_ = 0;
+};
+
 // selectionExec (executor.go:322-390) = SelectionExec; topNExec (:392-470, topn.go) = TopNExec with offset 0
 using selectionExec = SelectionExec;
 class topNExec : public TopNExec {

@@ -414,6 +414,31 @@ int main() {
             expect("executor.go:392-470 scan -> topN", render(Drain(&top)), {"1 30 <nil> 3", "2 20 bb 2"});
         }
     }
+    // ---- tablecodec_test.go:55-75 TestCutKeyNew: (1, "abc", 5.5) + handle 100 under table 4 / index 5, as an index scan's pair;
+    //      the same row from a unique index (no handle in the key: the pair's value holds it)
+    {
+        auto be = [](std::vector<uint8_t>& b, uint64_t v) { for (int i = 7; i >= 0; i--) b.push_back((uint8_t)(v >> (8 * i))); };
+        const uint64_t sign = 0x8000000000000000ull;
+        mocktikv::IndexPairs ip;
+        for (int withHandle = 1; withHandle >= 0; withHandle--) {
+            ip.keyOffsets.push_back((int64_t)ip.keys.size());
+            ip.valueOffsets.push_back((int64_t)ip.values.size());
+            ip.keys.push_back('t'); be(ip.keys, 4 ^ sign); ip.keys.push_back('_'); ip.keys.push_back('i'); be(ip.keys, 5 ^ sign);  // EncodeIndexSeekKey
+            ip.keys.push_back(3); be(ip.keys, 1 ^ sign);                                                                           // intFlag + EncodeInt(1)
+            ip.keys.push_back(1); for (char ch : std::string("abc")) ip.keys.push_back((uint8_t)ch);                               // bytesFlag + EncodeBytes("abc")
+            for (int i = 0; i < 5; i++) ip.keys.push_back(0);
+            ip.keys.push_back(250);
+            ip.keys.push_back(5); be(ip.keys, 0xC016000000000000ull);                                                              // floatFlag + EncodeFloat(5.5)
+            if (withHandle) { ip.keys.push_back(3); be(ip.keys, 100 ^ sign); ip.values.push_back('0'); }
+            else be(ip.values, 100);                                                                                                // the handle as the value
+        }
+        ip.keyOffsets.push_back((int64_t)ip.keys.size());
+        ip.valueOffsets.push_back((int64_t)ip.values.size());
+        mocktikv::indexScanExec scan(&ctx, {TSQ_I64, TSQ_BYTES, TSQ_F64, TSQ_I64}, 3, mocktikv::PrimaryKeyIsSigned, &ip);
+        expect("tablecodec_test.go:55-75 + tablecodec.go:406-434: index pairs -> (1, abc, 5.5, handle 100)", render(Drain(&scan)), {"1 abc 5.5 100", "1 abc 5.5 100"});
+        mocktikv::indexScanExec noPk(&ctx, {TSQ_I64, TSQ_BYTES, TSQ_F64}, 3, mocktikv::PrimaryKeyNotExists, &ip);
+        expect("tablecodec.go:411-414 PrimaryKeyNotExists drops the handle", render(Drain(&noPk)), {"1 abc 5.5", "1 abc 5.5"});
+    }
     // ---- util/chunk/codec_test.go:29-71 TestCodec: (NULL, i, "<i>.12345", "<i>.12345") x 10 through Encode / DecodeToChunk
     {
         const Schema colTypes = {TSQ_I64, TSQ_I64, TSQ_BYTES, TSQ_BYTES};
