@@ -584,7 +584,7 @@ tsq_status tsq_sort_pull(tsq_sort* s, tsq_col* out_cols, int32_t n_cols, int64_t
 /* Var-len (TSQ_BYTES) columns travel through the sort as payload (Chunk.AppendRow of a var-len cell, util/chunk/chunk.go:334-356)
  * and may be ORDER BY items: chunk.GetCompareFunc's cmpString (util/chunk/compare.go:71-77: bytes, then the shorter string first;
  * binary collation, the only one TinySQL has).  A string item costs one radix pass per byte position that differs between rows
- * (plus the length); the TopN radix select needs a fixed-width FIRST item, otherwise the whole input is sorted.  A pull fills out_cols[c].offsets (cap_rows + 1 entries) and .data of a var-len column; tsq_sort_peek (after
+ * (plus the length); the TopN radix select takes a string first item by its first eight bytes.  A pull fills out_cols[c].offsets (cap_rows + 1 entries) and .data of a var-len column; tsq_sort_peek (after
  * tsq_sort_finish) tells how many rows the next pull of up to cap_rows rows delivers and how many data bytes each var-len column
  * needs (bytes_out[c]; 0 for fixed-width columns). */
 tsq_status tsq_sort_peek(tsq_sort* s, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_out, int32_t n_cols);

@@ -365,7 +365,7 @@ def test_string_and_number_order_by_items_mixed(ctx, orc, keys):
 
 
 def test_string_key_topn_and_the_executor_mirror(ctx, orc):
-    # TopN on a string first key takes the full sort (no radix select: a string has no single image) and returns the window; a
+    # TopN on a string first key (small inputs take the full sort, large ones select on the first image: next test); a
     # string SECOND key behind a selected first key sorts only the candidates (n >= 2^20 rows so that the select runs)
     from tinysql_amd import executor as X
     from tinysql_amd.chunk import StrColumn
@@ -385,3 +385,20 @@ def test_string_key_topn_and_the_executor_mirror(ctx, orc):
     got = G.run_sort(ctx, t, [0, 1], [False, False], chunk_rows=1 << 18, pull_rows=4096, offset=0, count=3000, stats_out=stats)
     assert got.rows() == orc.sort_rows(t, [0, 1], [False, False]).rows()[:3000]
     assert stats[0]["rows"] < n // 2
+
+
+@pytest.mark.parametrize("desc", [False, True])
+def test_topn_radix_select_on_a_string_first_key(ctx, orc, desc):
+    # n >= 2^20 and a small window: the candidates are selected on the string's first eight bytes (ties on that image included),
+    # then sorted on the whole string; long shared prefixes make the first image a weak filter, short ones a sharp one
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(31 + desc)
+    n = (1 << 20) + 333
+    vals = rng.integers(0, 1 << 40, n)
+    names = [None if v % 1013 == 0 else b"%010x-%d" % (int(v), i % 7) for i, v in enumerate(vals.tolist())]
+    t = Chunk([StrColumn(names), Column(abi.I64, np.arange(n, dtype=np.int64))])
+    stats = []
+    got = G.run_sort(ctx, t, [0, 1], [desc, False], chunk_rows=1 << 18, pull_rows=4096, offset=17, count=2000, stats_out=stats)
+    want = orc.sort_rows(t, [0, 1], [desc, False]).rows()[17:2017]
+    assert got.rows() == want
+    assert stats[0]["rows"] < n // 4  # only the candidates went through the radix passes

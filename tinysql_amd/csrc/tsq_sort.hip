@@ -614,13 +614,17 @@ TSQ_API tsq_status tsq_sort_finish(tsq_sort* s) {
     int egrid = tsq_grid_for(ctx, n, 256, 4);
     s->rows_sorted = n;
     const int64_t K = s->last;  // rows of the order that are needed at all
-    if (s->cfg.limit_count >= 0 && n >= (1 << 20) && K * 16 <= n && s->cfg.col_types[s->cfg.key_col[0]] != TSQ_BYTES) {  // (a string has no single image to select on)
+    if (s->cfg.limit_count >= 0 && n >= (1 << 20) && K * 16 <= n) {
         // ---- TopN: radix select on the first ORDER BY item, then sort only the candidates (see k_select_hist)
         const int kc = s->cfg.key_col[0];
         a.key.data = s->cols[kc].data.p;
         a.key.nulls = s->cols[kc].has_nulls ? s->cols[kc].nulls.as<uint8_t>() : nullptr;
         a.key.type = s->cfg.col_types[kc];
         a.key.desc = s->cfg.key_desc[0] ? 1 : 0;
+        // a string item is selected on its FIRST image (bytes [0, 8), the most significant one): a row whose first eight bytes are
+        // beyond those of the K-th row cannot be among the first K; ties on the image stay candidates and the sort decides
+        a.key.offs = a.key.type == TSQ_BYTES ? s->cols[kc].offs.as<int64_t>() : nullptr;
+        a.key.chunk = 0;
         a.idx_in = nullptr;
         a.img_out = s->img[0].as<uint64_t>();
         a.idx_out = s->idx[1].as<uint32_t>();  // identity row ids: not needed here
