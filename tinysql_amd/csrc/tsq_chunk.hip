@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) k_compact_varlen(const uint8_t* src, cons
         if (WAVE) {
             for (int64_t i = lane; i < n; i += 64) d[i] = s[i];
         } else {
-            for (int64_t i = 0; i < n; i++) d[i] = s[i];
+            tsq_copy_cell(d, s, n);
         }
     }
 }

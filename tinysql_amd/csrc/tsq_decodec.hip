@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_decc_var_copy(DeccVarArgs a) {
         if (grouped) {  // a memcomparable cell: one marker byte follows every 8 data bytes
             for (int64_t i = WAVE ? lane : 0; i < n; i += WAVE ? 64 : 1) d[i] = s[i + (i >> 3)];
         } else if (!WAVE) {
-            for (int64_t i = 0; i < n; i++) d[i] = s[i];
+            tsq_copy_cell(d, s, n);
         } else {  // head up to an 8-byte boundary of the destination, then 8 bytes per lane, then the tail
             int64_t head = (8 - ((uintptr_t)d & 7)) & 7;
             head = head < n ? head : n;

@@ -81,6 +81,17 @@ TSQ_HD uint64_t tsq_hash_bytes(const uint8_t* p, int64_t n) {
     return tsq_splitmix64(w ^ tail);
 }
 
+// one var-len cell copied by ONE lane: eight bytes at a time (global loads and stores take any byte address), then the tail
+TSQ_HD void tsq_copy_cell(uint8_t* d, const uint8_t* s, int64_t n) {
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, s + i, 8);
+        memcpy(d + i, &x, 8);
+    }
+    for (; i < n; i++) d[i] = s[i];
+}
+
 // rank of a key for the multi-GPU radix redistribute (tsq_radix_split)
 TSQ_HD uint32_t tsq_key_rank(uint64_t kw, uint32_t n_parts) {
     return (uint32_t)(((tsq_mix64(kw) & 0xffffu) * (uint64_t)n_parts) >> 16);

@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(256) k_varlen_copy_rows(VarGatherArgs a) {
         const uint8_t* s = a.src_data + a.src_offs[idx];
         uint8_t* d = a.out_data + a.out_offs[r];
         const int64_t n = a.out_offs[r + 1] - a.out_offs[r];
-        for (int64_t i = 0; i < n; i++) d[i] = s[i];
+        tsq_copy_cell(d, s, n);
     }
 }
 // long cells (the reference's join benchmark carries a 5 KiB payload, executor/benchmark_test.go:328): one row per wave, 64 lanes on

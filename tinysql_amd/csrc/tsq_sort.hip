@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) k_sort_var_copy(SortVarArgs a) {
         const uint8_t* s = a.src_data + a.src_offs[a.idx[r]];
         uint8_t* d = a.out_data + a.out_offs[r];
         if (!WAVE) {
-            for (int64_t i = 0; i < n; i++) d[i] = s[i];
+            tsq_copy_cell(d, s, n);
         } else {  // head up to an 8-byte boundary of the destination, then 8 bytes per lane, then the tail
             int64_t head = (8 - ((uintptr_t)d & 7)) & 7;
             head = head < n ? head : n;
