@@ -111,6 +111,25 @@ def test_q3_shaped_plan_on_device_chunks(ctx, orc, jit):
             d.free()
 
 
+def test_q3_with_the_market_segment_as_a_varchar_column(ctx, orc):
+    # tools/q3.py --string-segment: WHERE c_mktsegment = 'BUILDING' as EQString on a device-resident var-len column; the same seed gives
+    # the same segment per customer as the int-coded tables, so the groups must be those of the oracle's chain over the int codes
+    customer, orders, lineitem = q3.tables(0.05)
+    want = q3_by_the_oracle(orc, customer, orders, lineitem)
+    scust = q3.tables(0.05, string_segment=True)[0]
+    assert [q3.SEGMENTS.index(v) for v in scust.columns[1].values()] == customer.columns[1].data.tolist()
+    dev = [GP.DeviceChunk.from_host(ctx, t) for t in (scust, orders, lineitem)]
+    try:
+        out = GP.drain_device(q3.plan(ctx, *dev, batch_rows=50_000, string_segment=True))
+        got = {k: (d, p, s) for c in out for k, d, p, s in c.rows()}
+        assert set(got) == set(want)
+        for k, (d, p, s, n_g, s_abs) in want.items():
+            assert got[k][0] == d and got[k][1] == p and abs(got[k][2] - s) <= sum_tol(n_g, s_abs)
+    finally:
+        for d in dev:
+            d.free()
+
+
 @pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
 def test_device_pipeline_equals_host_chunk_pipeline_with_nulls(ctx, jt):
     # the same plan through device-resident chunks (gpu_pipeline.py) and through 1024-row host chunks (executor.py, itself

@@ -23,18 +23,23 @@ from tinysql_amd import _abi as abi  # noqa: E402
 from tinysql_amd import _lib  # noqa: E402
 from tinysql_amd import expression as E  # noqa: E402
 from tinysql_amd import gpu_pipeline as G  # noqa: E402
-from tinysql_amd.chunk import Chunk, Column  # noqa: E402
+from tinysql_amd.chunk import Chunk, Column, StrColumn  # noqa: E402
 from tinysql_amd.executor import AggFuncDesc  # noqa: E402
 
 SEG, D = 1, 1200
 I, R = abi.I64, abi.F64
 
 
-def tables(sf, seed=7):
-    """host-side synthetic tables (numpy): deterministic, FK-consistent."""
+SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD"]  # TPC-H c_mktsegment; SEGMENTS[SEG] = the query's
+
+
+def tables(sf, seed=7, string_segment=False):
+    """host-side synthetic tables (numpy): deterministic, FK-consistent.  string_segment: c_mktsegment as the varchar it is in
+    TPC-H (the filter is then EQString, builtin_compare_vec_generated.go:393) instead of an int code."""
     rng = np.random.default_rng(seed)
     nc, no, nl = int(150_000 * sf), int(1_500_000 * sf), int(6_000_000 * sf)
-    customer = Chunk([Column(I, np.arange(nc, dtype=np.int64)), Column(I, rng.integers(0, 5, nc))])                     # c_custkey, c_mktsegment
+    seg = rng.integers(0, 5, nc)
+    customer = Chunk([Column(I, np.arange(nc, dtype=np.int64)), StrColumn([SEGMENTS[i] for i in seg.tolist()]) if string_segment else Column(I, seg)])  # c_custkey, c_mktsegment
     orders = Chunk([Column(I, rng.permutation(no).astype(np.int64)), Column(I, rng.integers(0, nc, no)),               # o_orderkey, o_custkey
                     Column(I, rng.integers(0, 2400, no)), Column(I, rng.integers(0, 3, no))])                            # o_orderdate, o_shippriority
     lineitem = Chunk([Column(I, rng.integers(0, no, nl)), Column(I, rng.integers(0, 2500, nl)),                         # l_orderkey, l_shipdate
@@ -72,9 +77,13 @@ def tables_device(ctx, sf, seed=7):
     return customer, orders, lineitem
 
 
-def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None, topn=0):
+def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None, topn=0, string_segment=False):
     F, Col, K = E.ScalarFunction, E.Column, E.Constant
-    cust = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, I), K(SEG))], jit=jit)
+    if string_segment:  # WHERE c_mktsegment = 'BUILDING' on the varchar column; the join below only needs c_custkey (column pruning)
+        sel = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, abi.BYTES), K(SEGMENTS[SEG]))], jit=jit)
+        cust = G.GpuProjectionExec(ctx, sel, [Col(0, I), Col(0, I)], jit=jit)  # (two columns so that the join's output keeps its column numbers)
+    else:
+        cust = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, I), K(SEG))], jit=jit)
     ords = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, orders_d, batch_rows), [F("lt", Col(2, I), K(D))], jit=jit)
     # orders (probe, left) JOIN customer (build, right) ON o_custkey = c_custkey  ->  o_orderkey,o_custkey,o_orderdate,o_shippriority,c_custkey,c_mktsegment
     j1 = G.GpuHashJoinExec(ctx, ords, cust, [1], [0], abi.JOIN_INNER, 1)
@@ -92,7 +101,8 @@ def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None, to
 
 def reference(customer, orders, lineitem):
     """plain numpy restatement of the query (checker for the small test)."""
-    ck, cs = customer.columns[0].data, customer.columns[1].data
+    ck = customer.columns[0].data
+    cs = customer.columns[1].data if customer.columns[1].tp != abi.BYTES else np.array([SEGMENTS.index(v) for v in customer.columns[1].values()])
     ok, oc, od, op = (c.data for c in orders.columns)
     lk, ls, lp, ld = (c.data for c in lineitem.columns)
     good_c = np.zeros(len(ck), bool)
@@ -141,10 +151,14 @@ def main():
     on_device = "--device-gen" in sys.argv
     if on_device:
         sys.argv.remove("--device-gen")
+    strseg = "--string-segment" in sys.argv
+    if strseg:
+        sys.argv.remove("--string-segment")
+        assert not on_device, "--string-segment builds the customer table on the host"
     sf = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
     t0 = time.time()
     if not on_device:
-        customer, orders, lineitem = tables(sf)
+        customer, orders, lineitem = tables(sf, string_segment=strseg)
     gen_s = time.time() - t0
     with _lib.Context(0) as ctx:
         if on_device:
@@ -159,7 +173,7 @@ def main():
             for rep in range(4):
                 if trace and rep == 3:
                     ctx.lib = TimedLib(ctx.lib)
-                exe = plan(ctx, *dev, topn=topn)
+                exe = plan(ctx, *dev, topn=topn, string_segment=strseg)
                 ctx.sync()
                 t1 = time.perf_counter()
                 exe.Open()
@@ -185,7 +199,7 @@ def main():
                     print("%-28s %5d calls %9.3f ms" % (k, n, t * 1e3), file=sys.stderr)
                 print("last rep: total %.3f ms, in Next %.3f ms" % (dt * 1e3, t_exec * 1e3), file=sys.stderr)
             rows_in = customer.NumRows() + orders.NumRows() + lineitem.NumRows()
-            print(json.dumps({"query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg" + ("->TopN(10)" if topn else ""), "SF": sf, "input_rows": rows_in,
+            print(json.dumps({"query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg" + ("->TopN(10)" if topn else "") + (", c_mktsegment = 'BUILDING' on a varchar column" if strseg else ""), "SF": sf, "input_rows": rows_in,
                               "tables": "generated in HBM (tsq_gen_column)" if on_device else "numpy, copied to HBM once",
                               "groups": groups, "best_s": best, "exec_s_result_in_hbm": best_exec, "input_rows_per_s": rows_in / best,
                               "input_rows_per_s_result_in_hbm": rows_in / best_exec, "host_table_gen_s": gen_s}))
