@@ -137,3 +137,38 @@ def test_the_bench_tool_numpy_encoder_writes_the_same_bytes():
     want = orc.encode_rows(Chunk([Column(abi.I64, a), Column(abi.I64, b), Column(abi.F64, c), Column(abi.F64, d)]))
     got = bd.encode_value_rows([a, b, c, d])
     assert got.size == want.size and (got == want).all()
+
+
+def test_storage_boundary_codecs_against_the_transcribed_vectors(orc):
+    # tests/golden/codec_cases.json (bytes_test.go:33-78, tablecodec_test.go:55-75, chunk/codec_test.go:29-71)
+    import json
+    import os
+
+    import numpy as np
+
+    from tinysql_amd import _abi as abi
+    from tinysql_amd.chunk import Chunk, Column, StrColumn
+
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "codec_cases.json")))
+    for c in g["bytes_codec"]:
+        enc = bytes([1] + c["enc"])  # the bytesFlag datum around EncodeBytes
+        assert orc.encode_rows(Chunk([StrColumn([bytes(c["dec"])])]), comparable=True).tobytes() == enc
+        st, rows = orc.decode_rows_chunks(enc, [0, len(enc)], [abi.BYTES])
+        assert st == 0 and rows.rows() == [(bytes(c["dec"]),)]
+    for e in g["bytes_codec_errors"]:
+        enc = bytes([1] + e)
+        assert orc.decode_rows_chunks(enc, [0, len(enc)], [abi.BYTES])[0] != 0
+    k = g["cut_index_key"]
+    t = Chunk([Column(abi.I64, np.array([k["values"][0]])), StrColumn([k["values"][1].encode()]), Column(abi.F64, np.array([k["values"][2]]))])
+    keys, offs = orc.encode_index_keys(t, k["table_id"], k["index_id"], np.array([k["handle"]]), np.array([1], np.uint8))
+    st, rows = orc.decode_index_kv(keys.tobytes(), offs, None, None, k["cols_len"], [abi.I64, abi.BYTES, abi.F64, abi.I64], 1)
+    assert st == 0 and rows.rows() == [(k["values"][0], k["values"][1].encode(), k["values"][2], k["handle"])]
+    w = g["chunk_codec"]
+    n = w["rows"]
+    chk = Chunk([Column(abi.I64, np.zeros(n, np.int64), np.zeros(n, bool)), Column(abi.I64, np.arange(n)), StrColumn([b"%d.12345" % i for i in range(n)]),
+                 StrColumn([b"%d.12345" % i for i in range(n)])])
+    buf = orc.WireChunk.from_chunk(chk).encode()
+    assert len(buf) == w["wire_bytes"] == sum(w["column_bytes"])
+    assert list(buf[:8]) == w["first_column_header"] and list(buf[w["column_bytes"][0]:w["column_bytes"][0] + 8]) == w["second_column_header"]
+    back = orc.WireChunk([8, 8, -1, -1])
+    assert back.decode_to_chunk(buf) == len(buf) and np.frombuffer(back.column(1)[3], np.int64).tolist() == list(range(n))
