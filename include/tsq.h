@@ -510,14 +510,17 @@ typedef struct tsq_rowcodec_col {
                            TSQ_BYTES (varchar / varstring / string / blobs: chk.AppendBytes of the value, decoder.go:226-228)     */
     uint32_t flags;     /* TSQ_RC_*                                                                                             */
     uint64_t def_bits;  /* default value as it is stored in the column (a float32 default in the low 4 bytes)                  */
+    const uint8_t* def_bytes; /* TSQ_BYTES column with TSQ_RC_HAS_DEFAULT: the default string (host memory), def_len bytes       */
+    int64_t  def_len;
 } tsq_rowcodec_col;
 /* out_cols: host or TSQ_COL_DEVICE buffers for nrows rows (data + null_bitmap); a TSQ_BYTES column: offsets[nrows + 1] and a data
- * buffer of n_bytes bytes (a cell is a piece of its row, so the column cannot be larger than `values`).  Errors are decided by the FIRST offending
+ * buffer of n_bytes bytes (a cell is a piece of its row, so the column cannot be larger than `values`) — plus nrows * def_len bytes for
+ * a column with a default string (every row may lack the column).  Errors are decided by the FIRST offending
  * row in scan order; *nrows_out then holds the rows before it (already in out_cols): TSQ_ERR_INVALID with tsq_last_error =
  * "invalid codec version" (row.go:54-56) | "insufficient bytes to decode value" (a real shorter than 8 bytes, codec
  * number.go:84-86) | "malformed row" (header / id / offset arrays or a value running past the row, an int value that is not
- * 1, 2, 4 or >= 8 bytes long: the reference panics with an index out of range there).  TSQ_ERR_UNSUPPORTED at call time (that scan
- * keeps the Go decoder): a TSQ_BYTES column with TSQ_RC_HAS_DEFAULT (def_bits cannot carry bytes), TypeBit columns. */
+ * 1, 2, 4 or >= 8 bytes long: the reference panics with an index out of range there).  TypeBit columns keep the Go decoder (the
+ * shim does not offer such a scan). */
 tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_bytes, const int64_t* offsets,
                                const int64_t* handles, int64_t nrows, uint32_t data_flags, int32_t n_cols,
                                const tsq_rowcodec_col* cols, tsq_col* out_cols, int64_t* nrows_out);

@@ -413,10 +413,18 @@ ROWCODEC_STATUS = {0: "ok", 1: "invalid codec version", 2: "malformed row", 3: "
 def rowcodec_cols(specs):
     """specs: [(col_id, type, flags, def_bits)] -> tsq_rowcodec_col array."""
     arr = (abi.RowcodecCol * len(specs))()
+    keep = []
     for i, sp in enumerate(specs):
         arr[i].col_id, arr[i].type = sp[0], sp[1]
         arr[i].flags = sp[2] if len(sp) > 2 else 0
-        arr[i].def_bits = sp[3] if len(sp) > 3 else 0
+        d = sp[3] if len(sp) > 3 else 0
+        if isinstance(d, (bytes, bytearray)):  # the default string of a TSQ_BYTES column
+            buf = (C.c_uint8 * max(len(d), 1)).from_buffer_copy(bytes(d) or b"\0")
+            keep.append(buf)
+            arr[i].def_bytes, arr[i].def_len = C.cast(buf, C.c_void_p), len(d)
+        else:
+            arr[i].def_bits = d
+    arr._keep = keep
     return arr
 
 

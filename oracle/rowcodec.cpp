@@ -361,8 +361,9 @@ orc_result* orc_rowcodec_decode_chunk(const uint8_t* values, const int64_t* offs
                     else memcpy(&bits[c], &f, 8);
                 }
                 nn[c] = 1;
-            } else if (!isNil && (col.flags & TSQ_RC_HAS_DEFAULT) && col.type != TSQ_BYTES) {
-                bits[c] = col.def_bits;
+            } else if (!isNil && (col.flags & TSQ_RC_HAS_DEFAULT)) {  // defDatum(colIdx) -> chk.AppendDatum (decoder.go:186-194)
+                if (col.type == TSQ_BYTES) cell[c] = {col.def_bytes, col.def_len};
+                else bits[c] = col.def_bits;
                 nn[c] = 1;
             }
         }

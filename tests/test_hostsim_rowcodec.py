@@ -315,3 +315,39 @@ def test_string_columns_become_references_into_the_row(sim):
                 else:
                     start, ln = ref >> 32, ref & 0xffffffff
                     assert nn[r] and bytes(values[o[r] + start:o[r] + start + ln]) == col.values()[r]
+
+
+def test_default_string_reference_is_handed_out_for_an_absent_column(sim):
+    # a TSQ_BYTES column with TSQ_RC_HAS_DEFAULT: the host puts the cell reference of the default string — (1 << 63) | where << 32 |
+    # length, into the pool of default strings — into def_bits, and the per-row code hands it out wherever the row lacks the column
+    # (defDatum, decoder.go:186-194); a column that is present (or NULL in the row) is untouched by the default
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(5)
+    n = 500
+    words = [None if rng.random() < 0.3 else b"w%d" % i for i in range(n)]
+    chk = Chunk([Column(abi.I64, rng.integers(0, 9, n)), StrColumn(words)])
+    b, o = orc.rowcodec_encode(chk, [1, 2])
+    default = b"the default"
+    specs = [(2, abi.BYTES, abi.RC_HAS_DEFAULT, default), (7, abi.BYTES, abi.RC_HAS_DEFAULT, default), (1, abi.I64)]
+    st, want = orc.rowcodec_decode_chunk(b, o, None, specs)
+    assert st == 0 and want.columns[0].values() == words and want.columns[1].values() == [default] * n
+    ref = (1 << 63) | (4 << 32) | len(default)  # the pool holds 4 bytes of another column's default first
+    isim = [(2, abi.BYTES, abi.RC_HAS_DEFAULT, ref), (7, abi.BYTES, abi.RC_HAS_DEFAULT, ref), (1, abi.I64)]
+    values, offsets = np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(o, dtype=np.int64)
+    for fast in (1, 0):
+        bufs = [np.zeros(n, np.uint64) for _ in isim]
+        bms = [np.zeros((n + 7) // 8 + 8, np.uint8) for _ in isim]
+        pd = (C.c_void_p * 3)(*[x.ctypes.data for x in bufs])
+        pb = (C.c_void_p * 3)(*[x.ctypes.data for x in bms])
+        staged, fastw = C.c_int64(0), C.c_int64(0)
+        err = sim.sim_rowcodec_decode(values.ctypes.data_as(C.c_void_p), values.size, 3, offsets.ctypes.data_as(C.c_void_p), None, n, orc.rowcodec_cols(isim), 3, pd, pb,
+                                      48 * 1024, fast, C.byref(staged), C.byref(fastw))
+        assert err == (1 << 64) - 1
+        assert (bufs[1] == np.uint64(ref)).all() and unpack_bitmap(bms[1], n).all()  # column 7 is in no row
+        nn = unpack_bitmap(bms[0], n)
+        for r in range(n):  # column 2 is in every row (NULL or not): never the default
+            if words[r] is None:
+                assert not nn[r]
+            else:
+                v = int(bufs[0][r])
+                assert nn[r] and v >> 63 == 0 and bytes(values[o[r] + (v >> 32):o[r] + (v >> 32) + (v & 0xffffffff)]) == words[r]

@@ -39,3 +39,11 @@ def test_response_chunks_of_64_rows():
     chunks = distsql.response_chunks(raw, offs)
     assert [len(c) for c in chunks] == [192, 192, 6] and b"".join(chunks) == bytes(raw)
     assert distsql.response_chunks(raw[:0], offs[:1]) == []
+
+
+def test_string_default_goes_into_the_descriptor_as_bytes():
+    d = RC.ChunkDecoder(None, [RC.ColInfo(3, RC.TypeVarchar), RC.ColInfo(4, RC.TypeBlob), RC.ColInfo(5, RC.TypeVarchar)], -1, lambda i: {0: "n/a", 1: b"\x00\x01"}.get(i))
+    assert [d.cols[i].flags for i in range(3)] == [abi.RC_HAS_DEFAULT, abi.RC_HAS_DEFAULT, 0]
+    assert [d.cols[i].def_len for i in range(3)] == [3, 2, 0] and d.def_len == [3, 2, 0]
+    import ctypes as C
+    assert C.string_at(d.cols[0].def_bytes, 3) == b"n/a" and C.string_at(d.cols[1].def_bytes, 2) == b"\x00\x01" and not d.cols[2].def_bytes

@@ -222,7 +222,7 @@ def test_argument_contract(ctx, orc):
     assert lib.tsq_rowcodec_decode(ctx.h, pb, -1, po, None, 3, 0, 1, one, out, C.byref(n)) == abi.ERR_INVALID
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 17, one, out, C.byref(n)) == abi.ERR_UNSUPPORTED
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.BYTES)]), out, C.byref(n)) == abi.ERR_INVALID  # a var-len column without offsets[]
-    assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.BYTES, abi.RC_HAS_DEFAULT)]), out, C.byref(n)) == abi.ERR_UNSUPPORTED
+    assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.BYTES, abi.RC_HAS_DEFAULT)]), out, C.byref(n)) == abi.ERR_INVALID
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, 9)]), out, C.byref(n)) == abi.ERR_INVALID  # no such column type
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, orc_cols([(1, abi.I64, abi.RC_HANDLE)]), out, C.byref(n)) == abi.ERR_INVALID
     # offsets that run past n_bytes are caught per row, not read
@@ -460,3 +460,22 @@ def test_string_columns_device_resident_and_rows_before_an_error(ctx, orc):
         finally:
             for p in (dbytes, doffs, d1, o1, b1, d2, b2, d3, o3, b3):
                 ctx.free(p)
+
+
+@pytest.mark.parametrize("n", [1, 700, 30_000])
+def test_default_strings_for_columns_the_rows_lack(ctx, orc, n):
+    # ALTER TABLE ... ADD COLUMN note varchar DEFAULT 'n/a' after the rows were written: the rows lack the column and the scan hands
+    # out the default (defDatum -> chk.AppendDatum, decoder.go:186-194); a column that IS in the row (NULL or not) ignores its default
+    from tinysql_amd.chunk import StrColumn
+    rng = np.random.default_rng(n)
+    words = [None if rng.random() < 0.3 else bytes(rng.integers(97, 123, int(rng.integers(0, 12)), dtype=np.uint8)) for _ in range(n)]
+    chk = Chunk([Column(abi.I64, rng.integers(0, 9, n)), StrColumn(words)])
+    b, o = orc.rowcodec_encode(chk, [1, 2])
+    defaults = {0: b"present-so-unused", 1: b"n/a", 2: b"", 3: b"x" * 100}
+    cols = [RC.ColInfo(2, RC.TypeVarchar), RC.ColInfo(7, RC.TypeVarchar), RC.ColInfo(8, RC.TypeBlob), RC.ColInfo(9, RC.TypeVarString), RC.ColInfo(1, RC.TypeLonglong), RC.ColInfo(10, RC.TypeVarchar)]
+    got = RC.NewChunkDecoder(ctx, cols, defDatum=lambda i: defaults.get(i)).DecodeToChunk(b, o)
+    specs = [(2, abi.BYTES, abi.RC_HAS_DEFAULT, defaults[0]), (7, abi.BYTES, abi.RC_HAS_DEFAULT, defaults[1]), (8, abi.BYTES, abi.RC_HAS_DEFAULT, defaults[2]),
+             (9, abi.BYTES, abi.RC_HAS_DEFAULT, defaults[3]), (1, abi.I64), (10, abi.BYTES)]
+    st, want = orc.rowcodec_decode_chunk(b, o, None, specs)
+    assert st == 0 and got.rows() == want.rows()
+    assert got.columns[0].values() == words and got.columns[1].values() == [b"n/a"] * n and got.columns[2].values() == [b""] * n and got.columns[5].values() == [None] * n

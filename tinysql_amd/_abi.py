@@ -61,6 +61,8 @@ class RowcodecCol(C.Structure):
         ("type", C.c_int32),
         ("flags", C.c_uint32),
         ("def_bits", C.c_uint64),
+        ("def_bytes", C.c_void_p),
+        ("def_len", C.c_int64),
     ]
 
 

@@ -256,6 +256,7 @@ struct RcVarArgs {
     int64_t rows;
     int64_t* out_offs;        // [rows + 1]: lengths, then (after the scan) the offsets of the column
     uint8_t* out_data;
+    const uint8_t* def_pool;  // default strings of the scan's columns: a reference with bit 63 set points here (bits 62..32: where)
 };
 __global__ void __launch_bounds__(256) k_rowcodec_var_len(RcVarArgs a) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x)
@@ -270,7 +271,7 @@ __global__ void __launch_bounds__(256) k_rowcodec_var_copy(RcVarArgs a) {
         const uint64_t ref = a.ref[r];
         const int64_t n = (int64_t)(uint32_t)ref;
         if (n == 0) continue;
-        const uint8_t* s = a.bytes + a.offsets[r] + (int64_t)(ref >> 32);
+        const uint8_t* s = (ref >> 63) ? a.def_pool + (int64_t)((ref >> 32) & 0x7fffffffu) : a.bytes + a.offsets[r] + (int64_t)(ref >> 32);
         uint8_t* d = a.out_data + a.out_offs[r];
         if (!WAVE) {
             tsq_copy_cell(d, s, n);
@@ -309,8 +310,8 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: unknown column type");
         if ((cols[c].flags & TSQ_RC_HANDLE) && cols[c].type != TSQ_I64 && cols[c].type != TSQ_U64)
             return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: the handle column is an integer column");
-        if (cols[c].type == TSQ_BYTES && (cols[c].flags & TSQ_RC_HAS_DEFAULT))
-            return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "a default value of a var-len column: decode this scan with the Go decoder");
+        if (cols[c].type == TSQ_BYTES && (cols[c].flags & TSQ_RC_HAS_DEFAULT) && (cols[c].def_len < 0 || cols[c].def_len > 0x7fffffffLL || (cols[c].def_len > 0 && !cols[c].def_bytes)))
+            return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: a var-len column with a default needs def_bytes / def_len");
         any_handle = any_handle || (cols[c].flags & TSQ_RC_HANDLE);
         any_var = any_var || cols[c].type == TSQ_BYTES;
         // a var-len output column: offsets[nrows + 1] and room for n_bytes data bytes (a cell is a piece of its row)
@@ -335,9 +336,9 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     a.nrows = nrows;
     a.n_bytes = n_bytes;
     a.n_cols = n_cols;
-    DevBuf dbytes, doffs, dhandles, derr, scratch, ddata[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS], dref[TSQ_MAX_COLS], dvoffs[TSQ_MAX_COLS];
+    DevBuf dbytes, doffs, dhandles, derr, scratch, ddef, ddata[TSQ_MAX_COLS], dbm[TSQ_MAX_COLS], dref[TSQ_MAX_COLS], dvoffs[TSQ_MAX_COLS];
     auto release_all = [&]() {
-        for (DevBuf* b : {&dbytes, &doffs, &dhandles, &derr, &scratch}) b->release();
+        for (DevBuf* b : {&dbytes, &doffs, &dhandles, &derr, &scratch, &ddef}) b->release();
         for (int c = 0; c < TSQ_MAX_COLS; c++) { ddata[c].release(); dbm[c].release(); dref[c].release(); dvoffs[c].release(); }
     };
     auto fail = [&](tsq_status st) { release_all(); return st; };
@@ -361,12 +362,31 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     }
     if (s != TSQ_OK) return fail(s);
     if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(H2D): ") + hipGetErrorString(e)));
-    for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
+    // default strings (defDatum of a var-len column, decoder.go:186-194): one small pool in HBM; the column's def_bits becomes a cell
+    // reference into it — (1 << 63) | where << 32 | length — which the kernel hands out like any default (tsq_rc_column)
+    std::string pool;
+    int64_t def_len[TSQ_MAX_COLS] = {0};
+    for (int c = 0; c < n_cols; c++) {
         a.cols[c] = cols[c];
+        a.cols[c].def_bytes = nullptr;
+        if (cols[c].type != TSQ_BYTES || !(cols[c].flags & TSQ_RC_HAS_DEFAULT)) continue;
+        a.cols[c].def_bits = (1ull << 63) | ((uint64_t)pool.size() << 32) | (uint64_t)cols[c].def_len;
+        def_len[c] = cols[c].def_len;
+        pool.append((const char*)cols[c].def_bytes, (size_t)cols[c].def_len);
+    }
+    if (pool.size() >= (1ull << 31)) return fail(tsq_fail(h, TSQ_ERR_UNSUPPORTED, "tsq_rowcodec_decode: default strings of 2 GB"));
+    if (!pool.empty()) {
+        s = ddef.reserve(ctx, h, pool.size() + 64);
+        if (s != TSQ_OK) return fail(s);
+        e = hipMemcpyAsync(ddef.p, pool.data(), pool.size(), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (pool is a local)
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(H2D): ") + hipGetErrorString(e)));
+    }
+    for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
         const bool var = cols[c].type == TSQ_BYTES;
         if (var) s = dref[c].reserve(ctx, h, (size_t)nrows * 8 + 64);  // the kernel leaves (start, length) references here
         if (s == TSQ_OK && !out_dev) {
-            s = ddata[c].reserve(ctx, h, (var ? (size_t)n_bytes : (size_t)nrows * tsq_elem_size(cols[c].type)) + 64);
+            s = ddata[c].reserve(ctx, h, (var ? (size_t)n_bytes + (size_t)nrows * (size_t)def_len[c] : (size_t)nrows * tsq_elem_size(cols[c].type)) + 64);
             if (s == TSQ_OK) s = dbm[c].reserve(ctx, h, tsq_bitmap_bytes(nrows) + 64);
             if (s == TSQ_OK && var) s = dvoffs[c].reserve(ctx, h, ((size_t)nrows + 1) * 8 + 64);
         }
@@ -421,6 +441,7 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         va.rows = rows;
         va.out_offs = out_dev ? out_cols[c].offsets : dvoffs[c].as<int64_t>();
         va.out_data = out_dev ? (uint8_t*)out_cols[c].data : ddata[c].as<uint8_t>();
+        va.def_pool = ddef.as<uint8_t>();
         if (rows > 0) {
             hipLaunchKernelGGL(k_rowcodec_var_len, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, va);
             e = hipGetLastError();

@@ -61,6 +61,7 @@ class ChunkDecoder:
         if any(t is None for t in self.types):
             raise _lib.TsqError(abi.ERR_UNSUPPORTED, "unknown type")  # decodeColToChunk's default branch / TypeBit: the Go decoder
         self.cols = (abi.RowcodecCol * len(self.columns))()
+        self._keep, self.def_len = [], [0] * len(self.columns)
         for i, c in enumerate(self.columns):
             self.cols[i].col_id, self.cols[i].type, self.cols[i].flags, self.cols[i].def_bits = c.ID, self.types[i], 0, 0
             if c.ID == handleColID:  # decoder.go:165
@@ -69,7 +70,14 @@ class ChunkDecoder:
                 d = defDatum(i)  # a NULL default datum is the same as no default (AppendDatum of a NULL datum appends NULL)
                 if d is not None:
                     self.cols[i].flags = abi.RC_HAS_DEFAULT
-                    self.cols[i].def_bits = _def_bits(self.types[i], d)
+                    if self.types[i] == abi.BYTES:  # a string default: its bytes (chk.AppendDatum -> AppendBytes)
+                        b = d.encode() if isinstance(d, str) else bytes(d)
+                        buf = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
+                        self._keep.append(buf)
+                        self.cols[i].def_bytes, self.cols[i].def_len = C.cast(buf, C.c_void_p), len(b)
+                        self.def_len[i] = len(b)
+                    else:
+                        self.cols[i].def_bits = _def_bits(self.types[i], d)
 
     def DecodeToChunk(self, values, offsets, handles=None):
         """values: bytes / np.uint8 (the rows back to back); offsets: n+1 row boundaries; handles: n int64 or None."""
@@ -78,8 +86,8 @@ class ChunkDecoder:
         n = len(offs) - 1
         hd = np.ascontiguousarray(handles, dtype=np.int64) if handles is not None else None
         keep = []
-        # a var-len cell is a piece of its row: the column's data cannot exceed the rows' bytes
-        out, bufs = out_buffers(self.types, max(n, 1), keep, var_bytes=[raw.size if t == abi.BYTES else 0 for t in self.types])
+        # a var-len cell is a piece of its row (or the column's default string): the column's data cannot exceed the rows' bytes + n defaults
+        out, bufs = out_buffers(self.types, max(n, 1), keep, var_bytes=[raw.size + n * self.def_len[i] if t == abi.BYTES else 0 for i, t in enumerate(self.types)])
         got = C.c_int64(0)
         _lib.check(self.ctx.lib.tsq_rowcodec_decode(self.ctx.h, raw.ctypes.data_as(C.c_void_p), raw.size, offs.ctypes.data_as(C.c_void_p),
                                                     hd.ctypes.data_as(C.c_void_p) if hd is not None else None, n, 0, len(self.columns), self.cols, out,
