@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSQ_ABI_VERSION 2
+#define TSQ_ABI_VERSION 3
 
 /* ---------------------------------------------------------------- status codes */
 typedef int32_t tsq_status;

@@ -5,7 +5,7 @@ Shared by the product binding (tinysql_amd._lib) and by the test-only oracle bin
 """
 import ctypes as C
 
-TSQ_ABI_VERSION = 2
+TSQ_ABI_VERSION = 3
 RADIX_AUTO, RADIX_OFF, RADIX_FORCE = -1, 0, 1
 AGGFAST_AUTO, AGGFAST_OFF, AGGFAST_FORCE = -1, 0, 1
 JIT_AUTO, JIT_OFF, JIT_FORCE = -1, 0, 1
