@@ -44,8 +44,8 @@ def main():
     ap.add_argument("--build-rows", type=int, default=100_000_000)
     ap.add_argument("--probe-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-build-rows", type=int, default=10_000_000)
-    ap.add_argument("--cpu-probe-rows", type=int, default=20_000_000)
+    ap.add_argument("--cpu-build-rows", type=int, default=20_000_000)
+    ap.add_argument("--cpu-probe-rows", type=int, default=40_000_000)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even with one rank (validation)")
     ap.add_argument("--radix", choices=["auto", "off", "force"], default="auto", help="probe strategy (tsq_join_set_radix)")
     ap.add_argument("--no-extras", action="store_true", help="skip the c2 / c3 / materialising side measurements (N = 1)")
