@@ -504,6 +504,9 @@ tsq_status tsq_chunk_decode(tsq_ctx* ctx, const uint8_t* buf, int64_t n_bytes, u
  * TSQ_COL_DEVICE when values / offsets / handles are in HBM.  cols[c] describes output column c. */
 #define TSQ_RC_HANDLE      1u /* the column is the handle column (col.ID == handleColID, decoder.go:165-168): value = handles[r]   */
 #define TSQ_RC_HAS_DEFAULT 2u /* column absent from the row: def_bits instead of NULL (defDatum, decoder.go:186-194)              */
+#define TSQ_RC_BIT         4u /* a TypeBit column (type TSQ_BYTES): stored as an unsigned int, the cell is its last byteSize bytes in
+                                 big endian (decoder.go:229-231, types.NewBinaryLiteralFromUint); byteSize = (Flen + 7) / 8 in flags bits 8..11 */
+#define TSQ_RC_BIT_SIZE(flags) (((flags) >> 8) & 15u)
 typedef struct tsq_rowcodec_col {
     int64_t  col_id;    /* ColInfo.ID                                                                                          */
     int32_t  type;      /* TSQ_I64 (signed int types, year), TSQ_U64 (UnsignedFlag), TSQ_F32 (TypeFloat), TSQ_F64 (TypeDouble),
@@ -519,8 +522,7 @@ typedef struct tsq_rowcodec_col {
  * row in scan order; *nrows_out then holds the rows before it (already in out_cols): TSQ_ERR_INVALID with tsq_last_error =
  * "invalid codec version" (row.go:54-56) | "insufficient bytes to decode value" (a real shorter than 8 bytes, codec
  * number.go:84-86) | "malformed row" (header / id / offset arrays or a value running past the row, an int value that is not
- * 1, 2, 4 or >= 8 bytes long: the reference panics with an index out of range there).  TypeBit columns keep the Go decoder (the
- * shim does not offer such a scan). */
+ * 1, 2, 4 or >= 8 bytes long: the reference panics with an index out of range there). */
 tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_bytes, const int64_t* offsets,
                                const int64_t* handles, int64_t nrows, uint32_t data_flags, int32_t n_cols,
                                const tsq_rowcodec_col* cols, tsq_col* out_cols, int64_t* nrows_out);

@@ -341,6 +341,7 @@ orc_result* orc_rowcodec_decode_chunk(const uint8_t* values, const int64_t* offs
         std::vector<uint64_t> bits((size_t)n_cols, 0);
         std::vector<uint8_t> nn((size_t)n_cols, 0);
         std::vector<std::pair<const uint8_t*, int64_t>> cell((size_t)n_cols, {nullptr, 0});
+        std::vector<std::string> bitcell((size_t)n_cols);
         for (int c = 0; c < n_cols && !st; c++) {
             const tsq_rowcodec_col& col = cols[c];
             if (col.flags & TSQ_RC_HANDLE) { bits[c] = (uint64_t)handles[r]; nn[c] = 1; continue; }
@@ -351,7 +352,16 @@ orc_result* orc_rowcodec_decode_chunk(const uint8_t* values, const int64_t* offs
                 const uint8_t* val;
                 int64_t n;
                 if (!getData(row, idx, &val, &n)) { st = 2; break; }
-                if (col.type == TSQ_BYTES) cell[c] = {val, n};
+                if (col.type == TSQ_BYTES && (col.flags & TSQ_RC_BIT)) {
+                    // byteSize := (Flen + 7) >> 3; NewBinaryLiteralFromUint(decodeUint(colData), byteSize): buf[8 - byteSize:] of
+                    // BigEndian.PutUint64 (decoder.go:229-231, types/binary_literal.go:57-69)
+                    uint64_t u;
+                    if (!decodeUint(val, n, &u)) { st = 2; break; }
+                    const int bsz = (int)TSQ_RC_BIT_SIZE(col.flags);
+                    bitcell[c].resize((size_t)bsz);
+                    for (int q = 0; q < bsz; q++) bitcell[c][(size_t)q] = (char)(uint8_t)(u >> (8 * (bsz - 1 - q)));
+                    cell[c] = {(const uint8_t*)bitcell[c].data(), bsz};
+                } else if (col.type == TSQ_BYTES) cell[c] = {val, n};
                 else if (col.type == TSQ_I64) { int64_t v; if (!decodeInt(val, n, &v)) { st = 2; break; } bits[c] = (uint64_t)v; }
                 else if (col.type == TSQ_U64) { if (!decodeUint(val, n, &bits[c])) { st = 2; break; } }
                 else {

@@ -16,7 +16,8 @@ def test_colinfo_type_mapping():
     assert RC.ColInfo(1, RC.TypeFloat).tsq_type() == abi.F32 and RC.ColInfo(1, RC.TypeDouble).tsq_type() == abi.F64
     for tp in (RC.TypeVarchar, RC.TypeVarString, RC.TypeString, RC.TypeBlob, RC.TypeTinyBlob, RC.TypeMediumBlob, RC.TypeLongBlob):
         assert RC.ColInfo(1, tp).tsq_type() == abi.BYTES  # chk.AppendBytes of the value (decoder.go:226-228)
-    assert RC.ColInfo(1, RC.TypeBit).tsq_type() is None   # a binary literal built from Flen (decoder.go:229-231): that scan keeps the Go decoder
+    assert RC.ColInfo(1, RC.TypeBit).tsq_type() is None and RC.ColInfo(1, RC.TypeBit, Flen=10).tsq_type() == abi.BYTES  # a binary literal of (Flen + 7) / 8 bytes (decoder.go:229-231)
+    assert RC.ChunkDecoder(None, [RC.ColInfo(1, RC.TypeBit, Flen=10)]).cols[0].flags == abi.RC_BIT | (2 << 8)
 
 
 def test_decoder_descriptor_flags_and_default_bits():

@@ -230,9 +230,9 @@ def test_argument_contract(ctx, orc):
     bad[3] = b.size + 100
     assert lib.tsq_rowcodec_decode(ctx.h, pb, b.size, bad.ctypes.data_as(C.c_void_p), None, 3, 0, 1, one, out, C.byref(n)) == abi.ERR_INVALID
     assert _lib.last_error(ctx.h) == "malformed row"
-    # the mirror refuses a bit column (decodeColToChunk builds a binary literal from Flen, decoder.go:229-231): that scan keeps the Go decoder
+    # the mirror refuses a column type the decoder does not know (decodeColToChunk's default branch, decoder.go:232-233)
     with pytest.raises(_lib.TsqError) as ei:
-        RC.NewChunkDecoder(ctx, [RC.ColInfo(1, RC.TypeBit)]).DecodeToChunk(b, o)
+        RC.NewChunkDecoder(ctx, [RC.ColInfo(1, 246)]).DecodeToChunk(b, o)
     assert ei.value.status == abi.ERR_UNSUPPORTED
     # and the normal call still works on the same context afterwards
     _lib.check(lib.tsq_rowcodec_decode(ctx.h, pb, b.size, po, None, 3, 0, 1, one, out, C.byref(n)), ctx.h)
@@ -479,3 +479,26 @@ def test_default_strings_for_columns_the_rows_lack(ctx, orc, n):
     st, want = orc.rowcodec_decode_chunk(b, o, None, specs)
     assert st == 0 and got.rows() == want.rows()
     assert got.columns[0].values() == words and got.columns[1].values() == [b"n/a"] * n and got.columns[2].values() == [b""] * n and got.columns[5].values() == [None] * n
+
+
+@pytest.mark.parametrize("flen", [1, 8, 9, 24, 40, 64])
+def test_bit_columns_become_binary_literals(ctx, orc, flen):
+    # TypeBit (decoder.go:229-231): the stored unsigned int becomes a literal of (Flen + 7) / 8 big-endian bytes
+    # (types.NewBinaryLiteralFromUint, binary_literal.go:57-69); NULLs, rows that lack the column (a default literal / NULL)
+    rng = np.random.default_rng(flen)
+    n = 5000
+    vals = rng.integers(0, 1 << min(flen, 62), n).astype(np.uint64)
+    if flen == 64:
+        vals = vals * np.uint64(4) + np.uint64(3)
+    chk = Chunk([Column(abi.U64, vals, rng.random(n) >= 0.2), Column(abi.I64, np.arange(n))])
+    b, o = orc.rowcodec_encode(chk, [3, 1])
+    bsz = (flen + 7) >> 3
+    lit = bytes(range(1, bsz + 1))
+    cols = [RC.ColInfo(3, RC.TypeBit, Flen=flen), RC.ColInfo(1, RC.TypeLonglong), RC.ColInfo(9, RC.TypeBit, Flen=flen), RC.ColInfo(10, RC.TypeBit, Flen=flen)]
+    got = RC.NewChunkDecoder(ctx, cols, defDatum=lambda i: lit if i == 2 else None).DecodeToChunk(b, o)
+    bit = abi.RC_BIT | (bsz << 8)
+    st, want = orc.rowcodec_decode_chunk(b, o, None, [(3, abi.BYTES, bit), (1, abi.I64), (9, abi.BYTES, bit | abi.RC_HAS_DEFAULT, lit), (10, abi.BYTES, bit)])
+    assert st == 0 and got.rows() == want.rows()
+    nn = chk.columns[0].notnull
+    assert got.columns[0].values() == [int(v).to_bytes(8, "big")[8 - bsz:] if ok else None for v, ok in zip(vals.tolist(), nn.tolist())]
+    assert got.columns[2].values() == [lit] * n and got.columns[3].values() == [None] * n

@@ -50,7 +50,7 @@ OP_STRCMP, OP_LENGTH, OP_ISNULL_STR, OP_IFNULL_STR, OP_IF_STR, OP_IN_STR = 79, 8
 F_LHS_UNSIGNED, F_RHS_UNSIGNED, F_FORCE_SIGNED = 1, 2, 4
 
 
-RC_HANDLE, RC_HAS_DEFAULT = 1, 2  # tsq_rowcodec_col.flags
+RC_HANDLE, RC_HAS_DEFAULT, RC_BIT = 1, 2, 4  # tsq_rowcodec_col.flags (a bit column: its byte size in bits 8..11)
 ENC_COMPARABLE = 1  # tsq_rows_encode col_flags
 
 

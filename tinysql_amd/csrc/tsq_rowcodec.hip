@@ -262,6 +262,30 @@ __global__ void __launch_bounds__(256) k_rowcodec_var_len(RcVarArgs a) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x)
         a.out_offs[r] = (int64_t)(uint32_t)a.ref[r];
 }
+// A TypeBit column (decoder.go:229-231): the value is stored as an unsigned int; its cell is the last byteSize = (Flen + 7) / 8 bytes
+// of the value in BIG endian (types.NewBinaryLiteralFromUint, types/binary_literal.go:57-69).  The row kernel decodes such a column
+// as a TSQ_U64 column into a scratch array; here the cells' lengths (byteSize, 0 for NULL) and, after the scan, their bytes.
+struct RcBitArgs {
+    const uint64_t* vals;    // [rows] the decoded unsigned values
+    const uint8_t* bitmap;   // packed NOT NULL bits of the column
+    int64_t rows;
+    int32_t byte_size;       // 1..8
+    int64_t* out_offs;       // [rows + 1]
+    uint8_t* out_data;
+};
+__global__ void __launch_bounds__(256) k_rowcodec_bit_len(RcBitArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x)
+        a.out_offs[r] = ((a.bitmap[r >> 3] >> (r & 7)) & 1) ? a.byte_size : 0;
+}
+__global__ void __launch_bounds__(256) k_rowcodec_bit_cells(RcBitArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x) {
+        if (a.out_offs[r + 1] == a.out_offs[r]) continue;
+        const uint64_t v = a.vals[r];
+        uint8_t* d = a.out_data + a.out_offs[r];
+        for (int i = 0; i < a.byte_size; i++) d[i] = (uint8_t)(v >> (8 * (a.byte_size - 1 - i)));  // buf[8 - byteSize:] of BigEndian.PutUint64
+    }
+}
+
 template <bool WAVE>
 __global__ void __launch_bounds__(256) k_rowcodec_var_copy(RcVarArgs a) {
     const int lane = threadIdx.x & 63;
@@ -312,6 +336,9 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
             return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: the handle column is an integer column");
         if (cols[c].type == TSQ_BYTES && (cols[c].flags & TSQ_RC_HAS_DEFAULT) && (cols[c].def_len < 0 || cols[c].def_len > 0x7fffffffLL || (cols[c].def_len > 0 && !cols[c].def_bytes)))
             return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: a var-len column with a default needs def_bytes / def_len");
+        if ((cols[c].flags & TSQ_RC_BIT) && (cols[c].type != TSQ_BYTES || TSQ_RC_BIT_SIZE(cols[c].flags) < 1 || TSQ_RC_BIT_SIZE(cols[c].flags) > 8 ||
+                                             ((cols[c].flags & TSQ_RC_HAS_DEFAULT) && cols[c].def_len != (int64_t)TSQ_RC_BIT_SIZE(cols[c].flags))))
+            return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rowcodec_decode: a bit column is a TSQ_BYTES column of 1..8 bytes (its default: a literal of that size)");
         any_handle = any_handle || (cols[c].flags & TSQ_RC_HANDLE);
         any_var = any_var || cols[c].type == TSQ_BYTES;
         // a var-len output column: offsets[nrows + 1] and room for n_bytes data bytes (a cell is a piece of its row)
@@ -369,6 +396,14 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     for (int c = 0; c < n_cols; c++) {
         a.cols[c] = cols[c];
         a.cols[c].def_bytes = nullptr;
+        if (cols[c].flags & TSQ_RC_BIT) {  // decoded as the unsigned int it is stored as; its cells are made afterwards (k_rowcodec_bit_*)
+            a.cols[c].type = TSQ_U64;
+            uint64_t v = 0;
+            if (cols[c].flags & TSQ_RC_HAS_DEFAULT)
+                for (int64_t i = 0; i < cols[c].def_len; i++) v = (v << 8) | cols[c].def_bytes[i];  // the literal is big endian
+            a.cols[c].def_bits = v;
+            continue;
+        }
         if (cols[c].type != TSQ_BYTES || !(cols[c].flags & TSQ_RC_HAS_DEFAULT)) continue;
         a.cols[c].def_bits = (1ull << 63) | ((uint64_t)pool.size() << 32) | (uint64_t)cols[c].def_len;
         def_len[c] = cols[c].def_len;
@@ -384,7 +419,7 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
     }
     for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
         const bool var = cols[c].type == TSQ_BYTES;
-        if (var) s = dref[c].reserve(ctx, h, (size_t)nrows * 8 + 64);  // the kernel leaves (start, length) references here
+        if (var) s = dref[c].reserve(ctx, h, (size_t)nrows * 8 + 64);  // the kernel leaves (start, length) references here (a bit column: its values)
         if (s == TSQ_OK && !out_dev) {
             s = ddata[c].reserve(ctx, h, (var ? (size_t)n_bytes + (size_t)nrows * (size_t)def_len[c] : (size_t)nrows * tsq_elem_size(cols[c].type)) + 64);
             if (s == TSQ_OK) s = dbm[c].reserve(ctx, h, tsq_bitmap_bytes(nrows) + 64);
@@ -442,6 +477,24 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         va.out_offs = out_dev ? out_cols[c].offsets : dvoffs[c].as<int64_t>();
         va.out_data = out_dev ? (uint8_t*)out_cols[c].data : ddata[c].as<uint8_t>();
         va.def_pool = ddef.as<uint8_t>();
+        if (cols[c].flags & TSQ_RC_BIT) {
+            RcBitArgs ba;
+            ba.vals = dref[c].as<uint64_t>();
+            ba.bitmap = a.out_bm[c];
+            ba.rows = rows;
+            ba.byte_size = (int32_t)TSQ_RC_BIT_SIZE(cols[c].flags);
+            ba.out_offs = va.out_offs;
+            ba.out_data = va.out_data;
+            if (rows > 0) hipLaunchKernelGGL(k_rowcodec_bit_len, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, ba);
+            tsq_status bs = tsq_launch_scan64(ctx, h, ba.out_offs, rows, scratch);
+            if (bs != TSQ_OK) return fail(bs);
+            if (rows > 0) hipLaunchKernelGGL(k_rowcodec_bit_cells, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, ba);
+            e = hipMemcpyAsync(ctx->pinned + 1, ba.out_offs + rows, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rowcodec_decode(bit cells): ") + hipGetErrorString(e)));
+            var_bytes[c] = (int64_t)ctx->pinned[1];
+            continue;
+        }
         if (rows > 0) {
             hipLaunchKernelGGL(k_rowcodec_var_len, dim3(tsq_grid_for(ctx, rows, 256)), dim3(256), 0, ctx->stream, va);
             e = hipGetLastError();

@@ -29,8 +29,8 @@ _STRING_TYPES = (TypeVarString, TypeVarchar, TypeString, TypeBlob, TypeTinyBlob,
 class ColInfo:
     """rowcodec.ColInfo (decoder.go:45-55)."""
 
-    def __init__(self, ID, Tp, Flag=0, IsPKHandle=False):
-        self.ID, self.Tp, self.Flag, self.IsPKHandle = ID, Tp, Flag, IsPKHandle
+    def __init__(self, ID, Tp, Flag=0, IsPKHandle=False, Flen=0):
+        self.ID, self.Tp, self.Flag, self.IsPKHandle, self.Flen = ID, Tp, Flag, IsPKHandle, Flen
 
     def tsq_type(self):
         if self.Tp in _INT_TYPES:
@@ -41,7 +41,9 @@ class ColInfo:
             return abi.F64
         if self.Tp in _STRING_TYPES:
             return abi.BYTES  # chk.AppendBytes of the value (decoder.go:226-228)
-        return None  # TypeBit and the types TinySQL does not have: the Go decoder
+        if self.Tp == TypeBit and 1 <= self.Flen <= 64:
+            return abi.BYTES  # a binary literal of (Flen + 7) / 8 bytes built from the stored uint (decoder.go:229-231)
+        return None  # the types TinySQL does not have: the Go decoder
 
 
 def _def_bits(tp, v):
@@ -59,17 +61,21 @@ class ChunkDecoder:
         self.ctx, self.columns, self.handleColID, self.defDatum = ctx, list(columns), handleColID, defDatum
         self.types = [c.tsq_type() for c in self.columns]
         if any(t is None for t in self.types):
-            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "unknown type")  # decodeColToChunk's default branch / TypeBit: the Go decoder
+            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "unknown type")  # decodeColToChunk's default branch: the Go decoder
         self.cols = (abi.RowcodecCol * len(self.columns))()
         self._keep, self.def_len = [], [0] * len(self.columns)
         for i, c in enumerate(self.columns):
             self.cols[i].col_id, self.cols[i].type, self.cols[i].flags, self.cols[i].def_bits = c.ID, self.types[i], 0, 0
+            bit = 0
+            if c.Tp == TypeBit:
+                bit = abi.RC_BIT | (((c.Flen + 7) >> 3) << 8)
+                self.cols[i].flags = bit
             if c.ID == handleColID:  # decoder.go:165
                 self.cols[i].flags = abi.RC_HANDLE
             elif defDatum is not None:
                 d = defDatum(i)  # a NULL default datum is the same as no default (AppendDatum of a NULL datum appends NULL)
                 if d is not None:
-                    self.cols[i].flags = abi.RC_HAS_DEFAULT
+                    self.cols[i].flags = abi.RC_HAS_DEFAULT | bit
                     if self.types[i] == abi.BYTES:  # a string default: its bytes (chk.AppendDatum -> AppendBytes)
                         b = d.encode() if isinstance(d, str) else bytes(d)
                         buf = (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
