@@ -55,7 +55,7 @@ class tableScanExec(GpuExecutor):
         self.columns = list(columns)
         types = [c.tsq_type() for c in self.columns]
         if any(t is None for t in types):
-            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "unknown type")  # TypeBit and friends: the Go executors
+            raise _lib.TsqError(abi.ERR_UNSUPPORTED, "unknown type")  # a type the decoder does not know: the Go executors
         super().__init__(ctx, types)
         self.raw_keys = np.frombuffer(keys, dtype=np.uint8) if isinstance(keys, (bytes, bytearray)) else np.ascontiguousarray(keys, dtype=np.uint8)
         self.raw_vals = np.frombuffer(values, dtype=np.uint8) if isinstance(values, (bytes, bytearray)) else np.ascontiguousarray(values, dtype=np.uint8)
@@ -68,6 +68,8 @@ class tableScanExec(GpuExecutor):
         for i, c in enumerate(self.columns):
             self.rc[i].col_id, self.rc[i].type, self.rc[i].def_bits = c.ID, types[i], 0
             self.rc[i].flags = abi.RC_HANDLE if c.IsPKHandle else 0
+            if c.Tp == RC.TypeBit:  # the stored uint as a binary literal of (Flen + 7) / 8 bytes (decoder.go:229-231)
+                self.rc[i].flags |= abi.RC_BIT | (((c.Flen + 7) >> 3) << 8)
         self.dk = self.dv = self.do = self.dh = None
         self.out, self.pos, self.count = None, 0, 0
 
