@@ -201,10 +201,9 @@ __global__ void __launch_bounds__(256) k_idx_walk(DeccArgs a) {
                 }
             }
         }
-        if (!EMIT) {
-            a.rows[k] = code == DEC_OK ? 1 : 0;
-            if (code != DEC_OK) atomicMin(a.err, ((unsigned long long)k << 32) | ((unsigned long long)col << 4) | (unsigned long long)code);
-        }
+        if (!EMIT) a.rows[k] = code == DEC_OK ? 1 : 0;
+        // the first offending pair in key order decides (row k = pair k: the emitting walk needs no validating pass before it)
+        if (code != DEC_OK) atomicMin(a.err, ((unsigned long long)k << 32) | ((unsigned long long)col << 4) | (unsigned long long)code);
     }
 }
 
@@ -355,20 +354,22 @@ static tsq_status decc_decode(tsq_ctx* ctx, const std::string& who, const uint8_
     a.err = derr.as<unsigned long long>();
     e = hipMemsetAsync(a.err, 0xff, 8, ctx->stream);
     const int grid = tsq_grid_for(ctx, n_chunks, 256);
-    if (e == hipSuccess) {
-        if (idx) hipLaunchKernelGGL(k_idx_walk<false>, dim3(grid), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(k_decc_count, dim3(grid), dim3(256), 0, ctx->stream, a);
-        e = hipGetLastError();
-    }
-    if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(count): ") + hipGetErrorString(e)));
-    s = tsq_launch_scan64(ctx, h, a.rows, n_chunks, scratch);  // rows[k] = first output row of chunk k, rows[n_chunks] = all rows
-    if (s != TSQ_OK) return fail(s);
-    e = hipMemcpyAsync(ctx->pinned, a.err, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 1, a.rows + n_chunks, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + ": ") + hipGetErrorString(e)));
-    const uint64_t errw = ctx->pinned[0];
-    int64_t rows = (int64_t)ctx->pinned[1];
+    uint64_t errw = ~0ull;
+    int64_t rows = n_chunks;  // index keys: row k = pair k, one walk (k_idx_walk<true>) writes the rows and finds the first offending pair
+    if (!idx) {
+        hipLaunchKernelGGL(k_decc_count, dim3(grid), dim3(256), 0, ctx->stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(count): ") + hipGetErrorString(e)));
+        s = tsq_launch_scan64(ctx, h, a.rows, n_chunks, scratch);  // rows[k] = first output row of chunk k, rows[n_chunks] = all rows
+        if (s != TSQ_OK) return fail(s);
+        e = hipMemcpyAsync(ctx->pinned, a.err, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 1, a.rows + n_chunks, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + ": ") + hipGetErrorString(e)));
+        errw = ctx->pinned[0];
+        rows = (int64_t)ctx->pinned[1];
+    }
     int code = DEC_OK;
     a.err_chunk = n_chunks;
     a.err_rows = 0;
@@ -406,6 +407,14 @@ static tsq_status decc_decode(tsq_ctx* ctx, const std::string& who, const uint8_
         if (idx) hipLaunchKernelGGL(k_idx_walk<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(k_decc_emit, dim3(grid), dim3(256), 0, ctx->stream, a);
         e = hipGetLastError();
+        if (idx && e == hipSuccess) {  // the pairs before the first offending one
+            e = hipMemcpyAsync(ctx->pinned, a.err, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess && ctx->pinned[0] != ~0ull) {
+                code = (int)(ctx->pinned[0] & 15);
+                rows = (int64_t)(ctx->pinned[0] >> 32);
+            }
+        }
         if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + "(emit): ") + hipGetErrorString(e)));
         int64_t var_bytes[TSQ_MAX_COLS] = {0};
         for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
