@@ -148,10 +148,10 @@ __device__ __forceinline__ int decc_one(const DeccArgs& a, int64_t p, int64_t hi
 // K13g: index keys.  tablecodec.DecodeIndexKV (tablecodec.go:376-434) of pair k: CutIndexKeyNew skips the 19-byte prefix
 // ('t' tableID "_i" indexID) and cuts n_key_cols datums; if bytes remain they are the handle datum (a non-unique index, or a unique
 // one whose key holds a NULL), otherwise the pair's VALUE is the handle (DecodeIndexValueAsHandle, tablecodec.go:456-465: 8 bytes
-// big endian).  EMIT = false: validate only (rows[k] = 1 for a good key, the first offending key in order goes to a.err).
-template <bool EMIT>
+// big endian).  Row k = pair k; the first offending pair in key order goes to a.err (the pairs before it are the result).
 __global__ void __launch_bounds__(256) k_idx_walk(DeccArgs a) {
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.n_chunks && (!EMIT || k < a.err_chunk); k += (int64_t)gridDim.x * blockDim.x) {
+    constexpr bool EMIT = true;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.n_chunks; k += (int64_t)gridDim.x * blockDim.x) {
         int64_t lo, hi;
         int code = DEC_OK;
         int32_t col = 0;
@@ -201,7 +201,6 @@ __global__ void __launch_bounds__(256) k_idx_walk(DeccArgs a) {
                 }
             }
         }
-        if (!EMIT) a.rows[k] = code == DEC_OK ? 1 : 0;
         // the first offending pair in key order decides (row k = pair k: the emitting walk needs no validating pass before it)
         if (code != DEC_OK) atomicMin(a.err, ((unsigned long long)k << 32) | ((unsigned long long)col << 4) | (unsigned long long)code);
     }
@@ -356,7 +355,7 @@ static tsq_status decc_decode(tsq_ctx* ctx, const std::string& who, const uint8_
     const int grid = tsq_grid_for(ctx, n_chunks, 256);
     if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string(who + ": ") + hipGetErrorString(e)));
     uint64_t errw = ~0ull;
-    int64_t rows = n_chunks;  // index keys: row k = pair k, one walk (k_idx_walk<true>) writes the rows and finds the first offending pair
+    int64_t rows = n_chunks;  // index keys: row k = pair k, one walk (k_idx_walk) writes the rows and finds the first offending pair
     if (!idx) {
         hipLaunchKernelGGL(k_decc_count, dim3(grid), dim3(256), 0, ctx->stream, a);
         e = hipGetLastError();
@@ -404,7 +403,7 @@ static tsq_status decc_decode(tsq_ctx* ctx, const std::string& who, const uint8_
             a.out_offs[c] = var ? (out_dev ? out_cols[c].offsets : dvoffs[c].as<int64_t>()) : nullptr;
         }
         if (s != TSQ_OK) return fail(s);
-        if (idx) hipLaunchKernelGGL(k_idx_walk<true>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        if (idx) hipLaunchKernelGGL(k_idx_walk, dim3(grid), dim3(256), 0, ctx->stream, a);
         else hipLaunchKernelGGL(k_decc_emit, dim3(grid), dim3(256), 0, ctx->stream, a);
         e = hipGetLastError();
         if (idx && e == hipSuccess) {  // the pairs before the first offending one
