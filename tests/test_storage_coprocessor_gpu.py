@@ -382,3 +382,20 @@ def test_string_group_keys_and_topn_payload_through_the_chain(ctx, orc):
     resp = cop.handleCopDAGRequest(ctx, [("TableScan", SCOLS), ("TopN", [3], [True], 100)], [3, 2, 1], pairs)
     want = select(orc.sort_rows(scanned, [3], [True]), slice(0, 100))
     assert resp.Error is None and resp.Chunks == chunks_of(orc, Chunk([want.columns[i] for i in (3, 2, 1)]))
+
+
+def test_table_scan_with_a_bit_column(ctx, orc):
+    # a BIT(12) column comes out of tableScanExec as its two-byte binary literal (decoder.go:229-231) and travels like any string column
+    rng = np.random.default_rng(21)
+    n = 3000
+    handles = np.arange(n, dtype=np.int64) * 2 - 100
+    flags = rng.integers(0, 1 << 12, n).astype(np.uint64)
+    table = Chunk([Column(abi.U64, flags, rng.random(n) >= 0.1), Column(abi.I64, rng.integers(-9, 9, n))])
+    vals, offs = orc.rowcodec_encode(table, [1, 2])
+    cols = [RC.ColInfo(1, RC.TypeBit, Flen=12), RC.ColInfo(2, RC.TypeLonglong), RC.ColInfo(-1, RC.TypeLonglong, 0, True)]
+    scan = cop.tableScanExec(ctx, cols, oracle_keys(orc, 41, handles), vals, offs, batch_rows=1024)
+    from tinysql_amd.gpu_pipeline import drain_device
+    got = [r for c in drain_device(scan) for r in c.rows()]
+    nn = table.columns[0].notnull
+    want = [(int(f).to_bytes(2, "big") if ok else None, v, h) for f, ok, v, h in zip(flags.tolist(), nn.tolist(), table.columns[1].values(), handles.tolist())]
+    assert got == want
