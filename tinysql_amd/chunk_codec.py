@@ -129,25 +129,48 @@ class Codec:
         return chk, self.DecodeToChunk(buffer, chk)
 
 
-def _peek(ctx, raw, colTypes, first, max_rows):
+class _WireBuf:
+    """the wire bytes as the C-ABI takes them: host memory, or (dev=True) uploaded to HBM once — what a Decoder does with a response
+    it decodes window by window (a host buffer would be staged again for every window)"""
+
+    def __init__(self, ctx, buffer, dev=False):
+        self.ctx, self.n = ctx, len(buffer)
+        self.raw = np.frombuffer(bytes(buffer) + b"\0" * 8, np.uint8)
+        self.dptr, self.flags = None, 0
+        if dev and self.n:
+            self.dptr = ctx.alloc(self.n + 64)
+            ctx.h2d(self.dptr, self.raw[:self.n])
+            self.flags = abi.COL_DEVICE
+
+    def ptr(self):
+        return C.c_void_p(self.dptr) if self.dptr else self.raw.ctypes.data_as(C.c_void_p)
+
+    def free(self):
+        if self.dptr:
+            self.ctx.free(self.dptr)
+            self.dptr = None
+
+
+def _peek(ctx, wb, colTypes, first, max_rows):
     tp = _types_arr(colTypes)
     total, take, used = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     nbytes = (C.c_int64 * len(colTypes))()
-    _lib.check(ctx.lib.tsq_chunk_decode_peek(ctx.h, raw.ctypes.data_as(C.c_void_p), raw.size - 8, 0, tp, len(colTypes), first, max_rows, C.byref(total),
+    _lib.check(ctx.lib.tsq_chunk_decode_peek(ctx.h, wb.ptr(), wb.n, wb.flags, tp, len(colTypes), first, max_rows, C.byref(total),
                                              C.byref(take), nbytes, C.byref(used)), ctx.h)
     return total.value, take.value, list(nbytes), used.value
 
 
 def _decode_window(ctx, buffer, colTypes, first, max_rows, chk):
-    """appends rows [first, first + max_rows) of the wire chunk in `buffer` to chk; returns (rows appended, bytes of the wire chunk)."""
-    raw = np.frombuffer(bytes(buffer) + b"\0" * 8, np.uint8)
-    total, take, nbytes, used = _peek(ctx, raw, colTypes, first, max_rows)
+    """appends rows [first, first + max_rows) of the wire chunk in `buffer` (bytes, or a _WireBuf) to chk; returns (rows appended,
+    bytes of the wire chunk)."""
+    wb = buffer if isinstance(buffer, _WireBuf) else _WireBuf(ctx, buffer)
+    total, take, nbytes, used = _peek(ctx, wb, colTypes, first, max_rows)
     for c, nb in zip(chk.columns, nbytes):
         c.reserve(c.length + take, c.data_bytes() + (nb if c.tp == abi.BYTES else take * elem_size(c.tp)))
     keep = []
     out = chk._out_cols(keep)
     n, u = C.c_int64(0), C.c_int64(0)
-    _lib.check(ctx.lib.tsq_chunk_decode(ctx.h, raw.ctypes.data_as(C.c_void_p), raw.size - 8, 0, _types_arr(colTypes), len(colTypes), first, max_rows, out,
+    _lib.check(ctx.lib.tsq_chunk_decode(ctx.h, wb.ptr(), wb.n, wb.flags, _types_arr(colTypes), len(colTypes), first, max_rows, out,
                                         C.byref(n), C.byref(u)), ctx.h)
     for i, c in enumerate(chk.columns):
         c.length = out[i].length
@@ -163,14 +186,26 @@ class Decoder:
         self.intermChk = chk
         self.colTypes = list(colTypes)
         self.remainedRows = 0
-        self._data = b""
+        self._data = None
         self._next = 0
 
     def Reset(self, data):
-        self._data = bytes(data)
-        raw = np.frombuffer(self._data + b"\0" * 8, np.uint8)
-        self.remainedRows = _peek(self.ctx, raw, self.colTypes, 0, 0)[0]
+        """the response's bytes go to HBM once; every Decode / ReuseIntermChk then copies a window of them (codec.go:272-275)"""
+        self.Close()
+        self._data = _WireBuf(self.ctx, data, dev=True)
+        self.remainedRows = _peek(self.ctx, self._data, self.colTypes, 0, 0)[0]
         self._next = 0
+
+    def Close(self):
+        if self._data is not None:
+            self._data.free()
+            self._data = None
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass
 
     def Decode(self, chk):
         requiredRows = chk.RequiredRows() - chk.NumRows()

@@ -189,11 +189,11 @@ public:
     }
     // appends rows [first, first + maxRows) of the wire chunk to chk (Decoder.decodeColumn, codec.go:298-353); returns the rows
     // appended, *used = the length of the wire chunk
-    int64_t decodeWindow(const uint8_t* buffer, int64_t n, int64_t first, int64_t maxRows, Chunk& chk, int64_t* used) {
+    int64_t decodeWindow(const uint8_t* buffer, int64_t n, int64_t first, int64_t maxRows, Chunk& chk, int64_t* used, uint32_t dataFlags = 0) {
         const int nc = (int)colTypes.size();
         std::vector<int64_t> bytes((size_t)nc);
         int64_t total = 0, take = 0;
-        check(tsq_chunk_decode_peek(ctx->h, buffer, n, 0, colTypes.data(), nc, first, maxRows, &total, &take, bytes.data(), used), ctx->h);
+        check(tsq_chunk_decode_peek(ctx->h, buffer, n, dataFlags, colTypes.data(), nc, first, maxRows, &total, &take, bytes.data(), used), ctx->h);
         std::vector<tsq_col> out;
         for (int c = 0; c < nc; c++) {  // room for the appended rows behind the ones the destination holds
             Column& col = chk.columns[(size_t)c];
@@ -208,7 +208,7 @@ public:
             out.push_back(col.View(col.length));
         }
         int64_t got = 0;
-        check(tsq_chunk_decode(ctx->h, buffer, n, 0, colTypes.data(), nc, first, maxRows, out.data(), &got, used), ctx->h);
+        check(tsq_chunk_decode(ctx->h, buffer, n, dataFlags, colTypes.data(), nc, first, maxRows, out.data(), &got, used), ctx->h);
         for (int c = 0; c < nc; c++) {
             Column& col = chk.columns[(size_t)c];
             col.length = out[(size_t)c].length;
@@ -226,17 +226,29 @@ public:
     }
 };
 
-class Decoder {  // codec.go:233-353; the intermediate chunk is the wire buffer itself, decoded window by window
+class Decoder {  // codec.go:233-353; the intermediate chunk is the wire buffer itself — in HBM since Reset — decoded window by window
 public:
     Codec codec;
     Chunk* intermChk;
-    int64_t remainedRows = 0, next = 0;
-    std::vector<uint8_t> data;
+    int64_t remainedRows = 0, next = 0, nBytes = 0;
+    void* dev = nullptr;  // the response's bytes in HBM (one H2D copy per response; a host buffer would be staged again for every window)
     Decoder(Context* ctx, Chunk* chk, const Schema& colTypes) : codec(ctx, colTypes), intermChk(chk) {}
+    Decoder(const Decoder&) = delete;
+    Decoder& operator=(const Decoder&) = delete;
+    ~Decoder() { release(); }
+    void release() {
+        if (dev) (void)tsq_dev_free(codec.ctx->h, dev);
+        dev = nullptr;
+    }
     void Reset(const std::vector<uint8_t>& d) {  // codec.go:272-275
-        data = d;
+        release();
+        nBytes = (int64_t)d.size();
         next = 0;
-        check(tsq_chunk_decode_peek(codec.ctx->h, data.data(), (int64_t)data.size(), 0, codec.colTypes.data(), (int32_t)codec.colTypes.size(), 0, 0, &remainedRows,
+        remainedRows = 0;
+        if (nBytes == 0) return;
+        check(tsq_dev_alloc(codec.ctx->h, nBytes + 64, &dev), codec.ctx->h);
+        check(tsq_copy_h2d(codec.ctx->h, dev, d.data(), nBytes), codec.ctx->h);
+        check(tsq_chunk_decode_peek(codec.ctx->h, (const uint8_t*)dev, nBytes, TSQ_COL_DEVICE, codec.colTypes.data(), (int32_t)codec.colTypes.size(), 0, 0, &remainedRows,
                                     nullptr, nullptr, nullptr), codec.ctx->h);
     }
     void Decode(Chunk& chk) {  // codec.go:257-269
@@ -244,7 +256,7 @@ public:
         requiredRows = (requiredRows + 7) >> 3 << 3;
         if (requiredRows > remainedRows) requiredRows = remainedRows;
         int64_t used = 0;
-        codec.decodeWindow(data.data(), (int64_t)data.size(), next, requiredRows, chk, &used);
+        codec.decodeWindow((const uint8_t*)dev, nBytes, next, requiredRows, chk, &used, TSQ_COL_DEVICE);
         next += requiredRows;
         remainedRows -= requiredRows;
     }
@@ -253,7 +265,7 @@ public:
     void ReuseIntermChk(Chunk& chk) {  // codec.go:291-308: the rest of the rows without a second copy
         intermChk->Reset();
         int64_t used = 0;
-        codec.decodeWindow(data.data(), (int64_t)data.size(), next, remainedRows, *intermChk, &used);
+        codec.decodeWindow((const uint8_t*)dev, nBytes, next, remainedRows, *intermChk, &used, TSQ_COL_DEVICE);
         chk.SwapColumns(*intermChk);
         next += remainedRows;
         remainedRows = 0;
