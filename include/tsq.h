@@ -479,6 +479,8 @@ tsq_status tsq_indexkeys_decode(tsq_ctx* ctx, const uint8_t* keys, int64_t n_byt
  * the buffers of out_cols must hold length + max_rows rows (tsq_chunk_decode_peek tells the data bytes of the var-len columns).
  * out_cols[c].length is updated, *nrows_out = rows appended, *bytes_consumed = the length of the wire chunk (n_cols columns; the
  * caller keeps the remainder, codec.go:93).  first_row = 0, max_rows >= length on empty out_cols is DecodeToChunk / ReuseIntermChk.
+ * A HOST buffer is staged into HBM by every call (the whole wire chunk): a Decoder that takes its response window by window uploads it
+ * once (tsq_dev_alloc + tsq_copy_h2d) and passes data_flags = TSQ_COL_DEVICE.
  * Errors: TSQ_ERR_INVALID when the buffer ends inside a column, the offsets of a var-len column are damaged, or the columns have
  * different lengths (the reference slices out of range and panics). */
 tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, int64_t nrows, uint8_t* out, int64_t cap_bytes,
