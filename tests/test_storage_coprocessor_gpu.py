@@ -399,3 +399,33 @@ def test_table_scan_with_a_bit_column(ctx, orc):
     nn = table.columns[0].notnull
     want = [(int(f).to_bytes(2, "big") if ok else None, v, h) for f, ok, v, h in zip(flags.tolist(), nn.tolist(), table.columns[1].values(), handles.tolist())]
     assert got == want
+
+
+def test_chunk_encoded_response_of_the_same_plan(ctx, orc):
+    # the plan of test_string_columns_scan_selection_limit_response answering in the chunk wire format (one chunk.Codec buffer per
+    # batch of the DAG's output): every buffer equals chunk.Codec.Encode of those rows (the oracle's restatement) and chunk.Decoder
+    # gives the rows back — the same rows the datum-row response carries
+    from tinysql_amd import chunk_codec as CC
+    rng = np.random.default_rng(21)
+    pairs, scanned = make_string_table(orc, rng, 30_000)
+    conds = [E.ScalarFunction("eq", E.Column(1, abi.BYTES), E.Constant("BUILDING")), E.ScalarFunction("lt", E.Column(0, abi.I64), E.Constant(40))]
+    plan = [("TableScan", SCOLS), ("Selection", conds)]
+    resp = cop.handleCopDAGRequest(ctx, plan, [3, 1, 2, 0], pairs, encodeType="chunk")
+    keep, _, _ = orc.filter_eval(E.compile_list(conds), 2, scanned)
+    sel = select(scanned, keep)
+    want = Chunk([sel.columns[i] for i in (3, 1, 2, 0)])
+    types = [abi.I64, abi.BYTES, abi.BYTES, abi.I64]
+    assert resp.Error is None and len(resp.Chunks) >= 1
+    dec = CC.Decoder(ctx, CC.WireChunk(types), types)
+    rows, at = [], 0
+    for buf in resp.Chunks:
+        dec.Reset(buf)
+        n = dec.RemainedRows()
+        assert buf == orc.WireChunk.from_chunk(select(want, slice(at, at + n))).encode()  # byte for byte Codec.Encode of these rows
+        while not dec.IsFinished():
+            chk = CC.WireChunk(types, 1024)
+            dec.Decode(chk)
+            rows += chk.to_chunk().rows()
+        at += n
+    dec.Close()
+    assert rows == want.rows() and at == want.NumRows()

@@ -14,7 +14,8 @@ device chunks); all compute runs in libtsq:
                      avg.go:78-81), then the group-by values (aggregate.go:96-113)
     topNExec       = tsq_sort_* with a row limit (radix select + sort of the candidates)
     limitExec      = the first `limit` rows
-    response       = tsq_rows_encode of the requested output offsets + the 64-row cut
+    response       = tsq_rows_encode of the requested output offsets + the 64-row cut, or (encodeType "chunk") one wire chunk per
+                     batch (tsq_chunk_encode), read back by chunk.Decoder
 Same names and argument meaning as the reference's executors; differences that follow from running in parallel are the ones
 DESIGN.md lists (group order, FIRST_ROW of a column that is not functionally dependent on the group key, the running-sum overflow).
 """
@@ -265,6 +266,28 @@ def fillUpData4SelectResponse(ctx, chunk, outputOffsets, chunks=None, rowCnt=0):
     return chunks, rowCnt
 
 
+def fillUpChunkResponse(ctx, chunk, outputOffsets, chunks=None):
+    """The column-major answer (upstream's tipb.EncodeType_TypeChunk; TinySQL ships the codec, util/chunk/codec.go:28-143, and answers
+    with datum rows): every batch of the DAG's output becomes ONE wire chunk — chunk.Codec.Encode of the requested columns on the GPU
+    (tsq_chunk_encode).  The SQL side reads it back with chunk.Decoder (tinysql_amd/chunk_codec.py): a copy instead of a parse."""
+    chunks = [] if chunks is None else chunks
+    n = chunk.NumRows()
+    if n == 0:
+        return chunks
+    cols = (abi.Col * len(outputOffsets))(*[chunk.columns[o].col(n) for o in outputOffsets])
+    need = C.c_int64(0)
+    _lib.check(ctx.lib.tsq_chunk_encode(ctx.h, cols, len(outputOffsets), n, None, 0, abi.COL_DEVICE, C.byref(need)), ctx.h)
+    dout = ctx.alloc(need.value + 64)
+    try:
+        _lib.check(ctx.lib.tsq_chunk_encode(ctx.h, cols, len(outputOffsets), n, C.c_void_p(dout), need.value, abi.COL_DEVICE, C.byref(need)), ctx.h)
+        raw = np.zeros(need.value, np.uint8)
+        ctx.d2h(raw, dout)
+    finally:
+        ctx.free(dout)
+    chunks.append(raw.tobytes())
+    return chunks
+
+
 class SelectResponse:
     """tipb.SelectResponse as far as this path fills it: Chunks (RowsData byte strings), OutputCounts, Error."""
 
@@ -295,10 +318,12 @@ def buildDAG(ctx, executors, pairs):
     return src
 
 
-def handleCopDAGRequest(ctx, executors, outputOffsets, pairs):
+def handleCopDAGRequest(ctx, executors, outputOffsets, pairs, encodeType="default"):
     """cop_handler_dag.go:49-83: run the DAG to its end, encode the rows, cut them into chunks.  An executor error becomes
-    SelectResponse.Error (toPBError) and no chunks, like the reference."""
+    SelectResponse.Error (toPBError) and no chunks, like the reference.  encodeType "chunk": the response's Chunks are wire chunks
+    (fillUpChunkResponse) instead of 64-row pieces of datum rows."""
     resp = SelectResponse()
+    resp.EncodeType = encodeType
     e = buildDAG(ctx, executors, pairs)
     scan = e
     while scan.children:
@@ -310,7 +335,10 @@ def handleCopDAGRequest(ctx, executors, outputOffsets, pairs):
             chk = e.Next()
             if chk.NumRows() == 0:
                 break
-            resp.Chunks, rows = fillUpData4SelectResponse(ctx, chk, outputOffsets, resp.Chunks, rows)
+            if encodeType == "chunk":
+                resp.Chunks = fillUpChunkResponse(ctx, chk, outputOffsets, resp.Chunks)
+            else:
+                resp.Chunks, rows = fillUpData4SelectResponse(ctx, chk, outputOffsets, resp.Chunks, rows)
         resp.OutputCounts = scan.Counts() if hasattr(scan, "Counts") else None
     except _lib.TsqError as err:
         resp.Chunks, resp.Error = [], err.message
