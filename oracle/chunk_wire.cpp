@@ -120,8 +120,10 @@ orc_wire_chunk* orc_wire_from_cols(const tsq_col* cols, int32_t n_cols, int64_t 
         w.length = nrows;
         w.elem = s.type == TSQ_BYTES ? -1 : (s.type == TSQ_F32 ? 4 : 8);
         const size_t nbm = (size_t)((nrows + 7) / 8);
-        if (s.null_bitmap) w.null_bitmap.assign(s.null_bitmap, s.null_bitmap + nbm);
-        else {
+        if (s.null_bitmap) {
+            w.null_bitmap.assign(s.null_bitmap, s.null_bitmap + nbm);
+            if (nrows & 7) w.null_bitmap[nbm - 1] &= (uint8_t)((1u << (nrows & 7)) - 1u);  // appendNullBitmap never sets a bit beyond the last row
+        } else {
             w.null_bitmap.assign(nbm, 0xFF);
             if (nrows & 7) w.null_bitmap[nbm - 1] = (uint8_t)((1u << (nrows & 7)) - 1u);
         }

@@ -276,3 +276,23 @@ def test_full_size_round_trip_on_device(ctx):
         c.free()
     ctx.free(w1)
     ctx.free(w2)
+
+
+def test_bits_beyond_the_last_row_do_not_travel(ctx, orc):
+    # a device column whose bitmap was preset to all ones (only NULLs cleared, like tsq_rows_decode leaves it) has set bits beyond its
+    # last row; a Go Column never has (column.go:113-125), so the encoder clears them: the wire bytes are those of the clean column
+    rng = np.random.default_rng(7)
+    n = 1003
+    nn = rng.random(n) >= 0.3
+    clean = Chunk([Column(abi.I64, rng.integers(0, 99, n), nn)])
+    want = orc.WireChunk.from_chunk(clean).encode()
+    d = G.DevCol(ctx, abi.I64, n, True)
+    ctx.h2d(d.data, np.ascontiguousarray(clean.columns[0].data))
+    bm = clean.columns[0].bitmap().copy()
+    bm[n // 8] |= 0xFF ^ ((1 << (n % 8)) - 1)  # garbage in the unused bits of the last byte
+    ctx.h2d(d.bitmap, bm)
+    need = C.c_int64(0)
+    out = np.zeros(len(want) + 8, np.uint8)
+    _lib.check(ctx.lib.tsq_chunk_encode(ctx.h, G.dev_cols([d]), 1, n, out.ctypes.data_as(C.c_void_p), len(want), 0, C.byref(need)), ctx.h)
+    assert need.value == len(want) and out[:len(want)].tobytes() == want
+    d.free()

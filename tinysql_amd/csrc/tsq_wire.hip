@@ -200,7 +200,9 @@ TSQ_API tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n
     for (int c = 0; c < n_cols; c++) {
         mp.add(WM_HDR, nullptr, w + pos, 8, (int64_t)((uint64_t)nrows | ((uint64_t)nulls[c] << 32)));
         pos += 8;
-        if (nulls[c] > 0) { mp.add(WM_COPY, bm[c], w + pos, (int64_t)nbm, 0); pos += (int64_t)nbm; }
+        // the bitmap through the bit mover (no shift): the bits beyond the last row are cleared — a Go Column never has them set
+        // (appendNullBitmap, column.go:113-125), a device column of this library may (bitmaps preset to all ones)
+        if (nulls[c] > 0) { mp.add(WM_BITS, bm[c], w + pos, nrows, 0); pos += (int64_t)nbm; }
         if (cols[c].type == TSQ_BYTES) { mp.add(WM_COPY, offs[c], w + pos, (nrows + 1) * 8, 0); pos += (nrows + 1) * 8; }
         mp.add(WM_COPY, data[c], w + pos, data_bytes[c], 0);
         pos += data_bytes[c];
