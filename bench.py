@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--cpu-probe-rows", type=int, default=40_000_000)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even with one rank (validation)")
     ap.add_argument("--radix", choices=["auto", "off", "force"], default="auto", help="probe strategy (tsq_join_set_radix)")
+    ap.add_argument("--packing", choices=["auto", "off"], default="auto", help="key packing of the radix probe (tsq_join_set_key_packing)")
     ap.add_argument("--no-extras", action="store_true", help="skip the c2 / c3 / materialising side measurements (N = 1)")
     args = ap.parse_args()
 
@@ -131,6 +132,8 @@ def main():
         h = C.c_void_p()
         _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
         _lib.check(lib.tsq_join_set_radix(h, radix_mode), h)
+        if args.packing == "off":
+            _lib.check(lib.tsq_join_set_key_packing(h, abi.RADIX_OFF), h)
         nb_local = nb
         bcols = (abi.Col * 2)(dev_col(bk, nb), dev_col(bv, nb))
         t0 = time.time()
@@ -191,6 +194,34 @@ def main():
     ok = total == expect
     st = abi.Stats()
     _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+    # ... which a kernel that merely counted its rows would pass too.  N = 1: one more, untimed probe pass with keys uniform in
+    # [0, 2 nb) (hit ratio 0.5, SURVEY.md §8d's rho variants) through the same handle; the expected count comes from numpy
+    # on a host copy of that key column (nothing of libtsq's join code computes it).
+    rho_check = None
+    if not distributed:
+        import numpy as np
+        pk2 = ctx.alloc(npr * 8)
+        try:
+            ctx.gen_column(spec(abi.GEN_RAND_MOD, table=1, col=5, m=2 * nb), npr, pk2)
+            ctx.sync()
+            host = np.empty(npr, dtype=np.int64)
+            ctx.d2h(host, pk2)
+            want_half = int(np.count_nonzero((host >= 0) & (host < nb)))
+            del host
+            pc2 = (abi.Col * 2)(dev_col(pk2, npr), dev_col(pv, npr))
+            _lib.check(lib.tsq_join_probe_push(h, pc2, 2, npr, None), h)  # warm
+            ctx.timer_start()
+            _lib.check(lib.tsq_join_probe_push(h, pc2, 2, npr, None), h)
+            half_ms = ctx.timer_stop_ms()
+            c2 = C.c_int64(0)
+            _lib.check(lib.tsq_join_count(h, C.byref(c2)), h)
+            got_half = (c2.value - total) // 2
+            rho_check = {"workload": "the same join, probe keys uniform in [0, 2 N_b): hit ratio 0.5", "joined_rows": got_half, "expected_by_numpy": want_half,
+                         "ms_per_probe_pass": half_ms, "rows_per_s": npr / half_ms * 1e3, "frac": 24.0 * npr / half_ms / 1e6 / 8000.0,
+                         "verified": got_half == want_half and (c2.value - total) == 2 * want_half}
+            ok = ok and rho_check["verified"]
+        finally:
+            ctx.free(pk2)
     if dj:
         dj.close()
     else:
@@ -201,9 +232,18 @@ def main():
     step_ev_ms = ev_ms / args.steps  # HIP events around the K steps on the launch stream
     algo_bytes = 24.0 * npr
     radix = st.radix_batches > 0
+    packed = st.probe_route == abi.ROUTE_PACKED
+    part_name = "k_radix_partition<1024,16,4,0,false,true>"
+    part_bytes_per_key = 16.0  # 8 B key read + 8 B table word written (COUNT(*) carries no payload)
     if radix and st.radix_timed_batches > 0:
         nt = min(st.radix_timed_batches, args.steps)  # the event ring keeps the most recent batches = the timed steps
-        kernel_name = "k_lds_probe_count<1024>" if st.table_slice_bits >= 3 and os.environ.get("TSQ_RADIX_KERNEL", "") != "l2" else "k_radix_probe_count<2>"
+        if packed:
+            wide = st.packed_key_bits - st.radix_bits > 16
+            kernel_name = "k_da_probe_count<1024,uint32_t>" if wide else "k_da_probe_count<512,uint16_t>"
+            part_name = "k_da_partition<1024,16,%s>" % ("uint32_t" if wide else "uint16_t")
+            part_bytes_per_key = 8.0 + (4.0 if wide else 2.0)  # 8 B key read + one packed entry written
+        else:
+            kernel_name = "k_lds_probe_count<1024>" if st.table_slice_bits >= 3 and os.environ.get("TSQ_RADIX_KERNEL", "") != "l2" else "k_radix_probe_count<2>"
         kernel_ms = st.radix_probe_kernel_ms_sum / st.radix_timed_batches
         part_ms = st.partition_kernel_ms_sum / st.radix_timed_batches
     else:
@@ -241,32 +281,52 @@ def main():
     }
     if exchange_ms is not None:
         out["split_and_exchange_ms"] = exchange_ms  # tsq_redistribute of one step's probe keys (split + RCCL exchange), without the probes
-    out["probe_strategy"] = ("radix 2^%d partitions, table of 2^%d LDS-sized slices" % (st.radix_bits, st.table_slice_bits)) if radix else "direct"
-    traffic = traffic_part = None
+    if packed:
+        out["probe_strategy"] = ("packed keys: build-side key range of %d bits, 2^%d partitions of %d-byte entries against one-byte "
+                                 "direct-address images of 2^%d cells in LDS" % (st.packed_key_bits, st.radix_bits, 4 if st.packed_key_bits - st.radix_bits > 16 else 2,
+                                                                                   st.packed_key_bits - st.radix_bits))
+        out["packed_images_ms"] = st.packed_build_ms
+    else:
+        out["probe_strategy"] = ("radix 2^%d partitions, table of 2^%d LDS-sized slices" % (st.radix_bits, st.table_slice_bits)) if radix else "direct"
+    if rho_check is not None:
+        out["rho_0.5"] = rho_check
+    traffic = traffic_part = traffic_src = None
     try:  # PMC-derived HBM bytes per launch are measured offline (rocprofv3 --pmc passes) and committed under profiles/
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))
         w = tj["workload"]
         if w["probe_rows"] == npr and w["build_rows"] == nb and world == 1:
-            if radix and w["radix_bits"] == st.radix_bits and kernel_name in tj:
+            if radix and w["radix_bits"] == st.radix_bits and kernel_name in tj and part_name in tj:
                 traffic = tj[kernel_name]["traffic_bytes"]
-                traffic_part = tj["k_radix_partition<1024,16,4,0,false,true>"]["traffic_bytes"]
+                traffic_part = tj[part_name]["traffic_bytes"]
+                traffic_src = "profiles/traffic_r03.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected)"
     except Exception:
         pass
     if not distributed:
-        out["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": traffic, "traffic_source": "profiles/traffic_r02.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected)" if traffic else None,
-            "kernel": kernel_name, "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_launch": algo_bytes,
-            "probe_phase": {"ms": step_ev_ms, "achieved": algo_bytes / (step_ev_ms * 1e-3) / 1e9,
-                            "frac": algo_bytes / (step_ev_ms * 1e-3) / 1e9 / 8000.0,
-                            "note": "whole step (memsets + partition + probe + overflow kernels) priced at 24 B/probe row"},
-        }
+        # `roofline` prices the DOMINANT kernel of the step.  Packed route: the partition kernel (its own algorithmic bytes: the
+        # key read + the entry written); 64-bit route: the LDS probe kernel at SURVEY.md §8(d)'s 24 B per probe row.  The north
+        # star's yardstick is `probe_phase`: the WHOLE step at 24 B per probe row.
+        phase = {"ms": step_ev_ms, "achieved": algo_bytes / (step_ev_ms * 1e-3) / 1e9,
+                 "frac": algo_bytes / (step_ev_ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": algo_bytes,
+                 "traffic": (traffic + traffic_part) if traffic and traffic_part else None,
+                 "note": "whole step (memsets + partition + probe + overflow kernels) priced at 24 B/probe row (SURVEY.md 8d)"}
+        pb = part_bytes_per_key * npr
+        part = {"kernel": part_name, "kernel_ms": part_ms, "algorithmic_bytes_per_launch": pb,
+                "achieved": pb / (part_ms * 1e-3) / 1e9 if part_ms > 0 else None,
+                "frac": pb / (part_ms * 1e-3) / 1e9 / 8000.0 if part_ms > 0 else None, "traffic": traffic_part}
+        probe_k = {"kernel": kernel_name, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes, "achieved": achieved,
+                   "frac": achieved / 8000.0, "traffic": traffic,
+                   "note": "priced at the whole 24 B/probe row although the partition kernel has already read the 8-byte keys"}
+        if radix and part_ms > kernel_ms:
+            out["roofline"] = {"bound": "hbm", "achieved": part["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": part["frac"],
+                               "traffic": traffic_part, "traffic_source": traffic_src, "kernel": part_name, "kernel_ms": part_ms,
+                               "algorithmic_bytes_per_launch": pb, "probe_phase": phase, "probe_kernel": probe_k}
+        else:
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "kernel_ms": kernel_ms,
+                               "algorithmic_bytes_per_launch": algo_bytes, "probe_phase": phase}
+            if radix:
+                out["roofline"]["partition"] = part
         if radix:
-            pb = 16.0 * npr  # 8 B key read + 8 B key written per probe row (COUNT(*) carries no payload)
-            out["roofline"]["partition"] = {"kernel": "k_radix_partition<1024,16,4,0,false,true>", "kernel_ms": part_ms,
-                                            "algorithmic_bytes_per_launch": pb, "achieved": pb / (part_ms * 1e-3) / 1e9,
-                                            "frac": pb / (part_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic_part}
             out["radix_overflow_rows"] = st.radix_overflow_rows
     elif radix and local_probe[1] > 0 and kernel_ms > 0:
         # N>1: the local probe runs once per received piece; price the same kernel per launch on rank 0's own pieces
@@ -279,14 +339,15 @@ def main():
             "note": "rank 0, per probe launch (one launch per received piece of %.3g rows on average, %d pieces per step); "
                     "the step also contains tsq_radix_split and the RCCL all-to-all, which this figure does not price"
                     % (rows_per_launch, args.exchange_chunks),
-            "partition": {"kernel": "k_radix_partition<1024,16,4,0,false,true>", "kernel_ms": part_ms,
-                          "algorithmic_bytes_per_launch": 16.0 * rows_per_launch,
-                          "achieved": 16.0 * rows_per_launch / (part_ms * 1e-3) / 1e9 if part_ms > 0 else None},
+            "partition": {"kernel": part_name, "kernel_ms": part_ms,
+                          "algorithmic_bytes_per_launch": part_bytes_per_key * rows_per_launch,
+                          "achieved": part_bytes_per_key * rows_per_launch / (part_ms * 1e-3) / 1e9 if part_ms > 0 else None},
         }
 
     # ---------------------------------------------------------------- BASELINE configs[1], configs[2] and the materialising join (N = 1)
     if not distributed and not args.no_extras and nb == 100_000_000 and npr == 100_000_000:
-        for key, fn in (("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
+        for key, fn in (("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
+                        ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
                         ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr))):
             try:
@@ -361,7 +422,41 @@ def extra_c2(ctx, abi, _lib, pk, npr, nb=10_000_000, steps=10):
         ctx.free(pk2)
     return {"workload": "1e8 x 1e7 int64-key inner hash join, count(*), build side resident", "ms_per_probe_pass": ms, "rows_per_s": npr / ms * 1e3,
             "frac": 24.0 * npr / ms / 1e6 / 8000.0, "verified": cnt.value == (steps + 2) * npr, "probe_kernel_ms": st.radix_probe_kernel_ms,
-            "partition_kernel_ms": st.partition_kernel_ms, "build_kernel_ms": st.build_kernel_ms, "steps": steps}
+            "partition_kernel_ms": st.partition_kernel_ms, "build_kernel_ms": st.build_kernel_ms, "steps": steps, "route": st.probe_route,
+            "packed_key_bits": st.packed_key_bits}
+
+
+def extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
+    """The headline join with key packing switched off: every key travels as a 64-bit table word (round 2's route, the one a build
+    side takes whose keys do not fit 28 bits)."""
+    lib = ctx.lib
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 1, 1
+    cfg.build_types[0] = cfg.probe_types[0] = abi.I64
+    h = C.c_void_p()
+    _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        _lib.check(lib.tsq_join_set_key_packing(h, abi.RADIX_OFF), h)
+        _lib.check(lib.tsq_join_build_push(h, (abi.Col * 1)(_dev_col(abi, bk, nb)), 1, nb), h)
+        _lib.check(lib.tsq_join_build_finish(h), h)
+        _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+        pc = (abi.Col * 1)(_dev_col(abi, pk, npr))
+        for _ in range(2):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(steps):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ms = ctx.timer_stop_ms() / steps
+        cnt = C.c_int64(0)
+        _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+        st = abi.Stats()
+        _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+    finally:
+        lib.tsq_join_destroy(h)
+    return {"workload": "1e8 x 1e8 count(*), key packing off: 64-bit table words (k_radix_partition + k_lds_probe_count)", "ms_per_probe_pass": ms,
+            "rows_per_s": npr / ms * 1e3, "frac": 24.0 * npr / ms / 1e6 / 8000.0, "verified": cnt.value == (steps + 2) * npr,
+            "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "steps": steps}
 
 
 def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSQ_ABI_VERSION 3
+#define TSQ_ABI_VERSION 4
 
 /* ---------------------------------------------------------------- status codes */
 typedef int32_t tsq_status;
@@ -316,6 +316,15 @@ tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on);
 #define TSQ_RADIX_OFF     0
 #define TSQ_RADIX_FORCE   1
 tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode);
+/* Key packing of the radix probe (round 3; csrc/tsq_dajoin.h).  The build side is complete before the first probe row, so the
+ * range [kmin, kmax] of its key column is known.  TSQ_RADIX_AUTO (default): when the key is ONE integer column on both sides,
+ * the range fits 28 bits, holds >= 1 build row per 32 values and no key has more than 255 build rows, a COUNT(*) probe batch
+ * travels as 2-byte entries (bijective mix of key - kmin; partition = its top bits) and meets a direct-address table of one
+ * byte per value of the range, one 64 KB image per partition in LDS — equality of entries IS equality of keys
+ * (util/codec/codec.go:363-382), a probe key outside the range joins nothing.  OFF keeps 64-bit table words; FORCE drops the
+ * size and density conditions (tests).  Must be chosen before the first probe batch.  The joined rows are identical either way.
+ * Replaces join2Chunk + GetMatchedRows (executor/join.go:343-360, hash_table.go:110-134) for that shape. */
+tsq_status tsq_join_set_key_packing(tsq_join* j, int32_t mode);
 /* Ordered output: joined rows come out in probe-row order (the order of the probe pushes and of the rows inside them), the
  * matches of one probe row in build-row order (the order of the build pushes).  With both children sorted on the join keys
  * and the OUTER child as probe side this is exactly MergeJoinExec's output order (executor/merge_join.go:257-310: outer
@@ -673,7 +682,14 @@ typedef struct tsq_stats {
                                        aggregate: rows of a multi-key GROUP BY whose 64-bit tag belonged to another key (resolved) */
     int32_t table_slice_bits;      /* log2(slices) of the join table (0: one slice) */
     int32_t build_slice_retries;   /* 1: a slice overflowed (skewed keys) and the table was rebuilt as one slice */
+    int32_t probe_route;           /* route of the last probe batch: TSQ_ROUTE_* */
+    int32_t packed_key_bits;       /* TSQ_ROUTE_PACKED: bits of the build side's key range (0 otherwise) */
+    double  packed_build_ms;       /* kernels that made the packed-key images (once per build side) */
 } tsq_stats;
+#define TSQ_ROUTE_DIRECT     0   /* k_probe_count / k_probe_emit on the table in HBM */
+#define TSQ_ROUTE_RADIX_L2   1   /* radix partition, table slices through the XCD's L2 */
+#define TSQ_ROUTE_RADIX_LDS  2   /* radix partition, LDS copies of the table slices (64-bit table words) */
+#define TSQ_ROUTE_PACKED     3   /* packed keys: 2-byte entries against direct-address images in LDS */
 tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out);
 tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out);
 

@@ -24,7 +24,7 @@ def push_chunked(fn, handle, chunk, chunk_rows, selected=None, lib_handle_for_er
 
 
 def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1024, count_only=False, checksum=False, radix=None,
-             stats_out=None, ordered=None):
+             stats_out=None, ordered=None, packing=None):
     """build_push* -> build_finish -> (probe_push, pull*)* -> probe_finish -> pull*; returns Chunk (or count[,sum,xor])."""
     lib = ctx.lib
     h = C.c_void_p()
@@ -34,6 +34,8 @@ def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1
             _lib.check(lib.tsq_join_set_radix(h, radix), h)
         if ordered is not None:
             _lib.check(lib.tsq_join_set_ordered(h, 1 if ordered else 0), h)
+        if packing is not None:
+            _lib.check(lib.tsq_join_set_key_packing(h, packing), h)
         push_chunked(lib.tsq_join_build_push, h, build, chunk_rows)
         _lib.check(lib.tsq_join_build_finish(h), h)
         if count_only:

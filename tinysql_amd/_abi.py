@@ -5,7 +5,7 @@ Shared by the product binding (tinysql_amd._lib) and by the test-only oracle bin
 """
 import ctypes as C
 
-TSQ_ABI_VERSION = 3
+TSQ_ABI_VERSION = 4
 RADIX_AUTO, RADIX_OFF, RADIX_FORCE = -1, 0, 1
 AGGFAST_AUTO, AGGFAST_OFF, AGGFAST_FORCE = -1, 0, 1
 JIT_AUTO, JIT_OFF, JIT_FORCE = -1, 0, 1
@@ -144,7 +144,11 @@ class Stats(C.Structure):
         ("radix_probe_kernel_ms_sum", C.c_double), ("radix_timed_batches", C.c_int64), ("radix_batches", C.c_int64), ("radix_overflow_rows", C.c_int64),
         ("radix_bits", C.c_int32), ("build_partitioned", C.c_int32), ("build_handed_back_rows", C.c_int64),
         ("table_slice_bits", C.c_int32), ("build_slice_retries", C.c_int32),
+        ("probe_route", C.c_int32), ("packed_key_bits", C.c_int32), ("packed_build_ms", C.c_double),
     ]
+
+
+ROUTE_DIRECT, ROUTE_RADIX_L2, ROUTE_RADIX_LDS, ROUTE_PACKED = 0, 1, 2, 3
 
 
 COMM_ID_BYTES = 128
@@ -187,6 +191,7 @@ SIGNATURES = {
     "tsq_join_set_checksum": (C.c_int32, [P, C.c_int32]),
     "tsq_join_set_ordered": (C.c_int32, [P, C.c_int32]),
     "tsq_join_set_radix": (C.c_int32, [P, C.c_int32]),
+    "tsq_join_set_key_packing": (C.c_int32, [P, C.c_int32]),
     "tsq_join_cancel": (C.c_int32, [P]),
     "tsq_join_destroy": (None, [P]),
     "tsq_agg_create": (C.c_int32, [P, C.POINTER(AggCfg), PP]),

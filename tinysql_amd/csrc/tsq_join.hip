@@ -22,6 +22,7 @@
 #include "tsq_jointable.h"
 #include "tsq_buildpart.h"
 #include "tsq_ldsprobe.h"
+#include "tsq_dajoin.h"
 
 #include <deque>
 #include <memory>
@@ -700,6 +701,14 @@ struct tsq_join {
     DevBuf bbase;                     // per-workgroup output bases of the materialising probe
     DevBuf pairs;                     // (probe row, build row) of every joined row of the current slice
     DevBuf firstcnt;                  // per probe row of the slice: first joined build row | output rows << 32
+    // packed-key route (tsq_dajoin.h): key range of the build side + direct-address images, made by the first eligible probe batch
+    int32_t packing_mode = TSQ_RADIX_AUTO;
+    int da_state = 0;                 // 0: not tried yet, 1: usable, -1: not usable for this build side
+    DaDomain da_dm{};
+    uint32_t da_pbits = 0, da_ebits = 0;
+    bool da_unique = false;
+    DevBuf da_img;                    // 2^b one-byte cells
+    double da_build_ms = 0;
     static constexpr int RING = 32;   // HIP events of the most recent radix batches: [slot][0..2] = start, after partition, end
     hipEvent_t rev[RING][3] = {};
 
@@ -1009,6 +1018,224 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     j->st.kernel_launches += 3;
     j->st.radix_batches++;
     j->st.radix_bits = (int32_t)st.bits;
+    j->st.probe_route = pl.lds ? TSQ_ROUTE_RADIX_LDS : TSQ_ROUTE_RADIX_L2;
+    return TSQ_OK;
+}
+
+// ---------------------------------------------------------------- packed-key route (host side; tsq_dajoin.h)
+// Eligible (on top of radix_eligible): ONE integer key column on both sides whose build-side range fits TSQ_DA_MAX_BITS bits and is
+// dense enough (>= 1 build row per 32 cells), no build key with more than 255 duplicates.  The range and the images are made by
+// the first probe batch that asks for them (the build side does not know yet whether the probe will only count).
+struct DaGeom {
+    uint32_t P, cap;
+    size_t nregions, ent_bytes, ctl_bytes;
+};
+DaGeom da_geometry(uint32_t pbits, uint32_t ebits, int64_t nrows, int T) {
+    DaGeom g;
+    g.P = 1u << pbits;
+    const double lam = (double)nrows / ((double)g.P * 8.0);
+    g.cap = (uint32_t)(lam * 1.08 + 8.0 * sqrt(lam) + 2.0 * T / 64.0 + 64.0);
+    g.cap = (g.cap + 63u) & ~63u;  // regions start on 128-byte lines also with 2-byte entries
+    g.nregions = (size_t)g.P * 8;
+    g.ent_bytes = g.nregions * g.cap * (ebits > 16 ? 4 : 2) + 256;
+    g.ctl_bytes = ((g.nregions + 16) * 4 + 511) & ~(size_t)511;
+    return g;
+}
+tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st) {
+    constexpr int NT = 1024, K = 16, T = NT * K;
+    const int64_t ntiles = (src.nrows + T - 1) / T;
+    const dim3 grid((unsigned)std::min<int64_t>(ntiles, j->ctx->num_cus));
+    if (st.ebits > 16) hipLaunchKernelGGL((k_da_partition<NT, K, uint32_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    TSQ_HIP(&j->hdr, hipGetLastError());
+    j->st.kernel_launches++;
+    return TSQ_OK;
+}
+
+tsq_status da_prepare(tsq_join* j) {
+    if (j->da_state) return TSQ_OK;
+    j->da_state = -1;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    static const bool env_off = [] { const char* v = getenv("TSQ_PACKED_KEYS"); return v && v[0] == '0'; }();
+    if (env_off || j->packing_mode == TSQ_RADIX_OFF || j->multi || j->never_match) return TSQ_OK;
+    const int kc = j->ks.bidx[0];
+    const int32_t bt = j->cfg.build_types[kc], pt = j->cfg.probe_types[j->ks.pidx[0]];
+    if (!is_int_class(bt) || !is_int_class(pt)) return TSQ_OK;
+    const int64_t nb = j->bcols[kc].rows;
+    if (nb <= 0 || nb >= 0xffffffffLL) return TSQ_OK;
+    const bool force = j->packing_mode == TSQ_RADIX_FORCE;
+    if (!force && nb < (4 << 20)) return TSQ_OK;
+    // ---- key range of the build side
+    DaMinMaxArgs ma;
+    memset(&ma, 0, sizeof ma);
+    ma.src.data = j->bcols[kc].data.as<uint64_t>();
+    ma.src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
+    ma.src.nrows = nb;
+    ma.flip = (bt == TSQ_I64 && pt == TSQ_I64) ? 0x8000000000000000ULL : 0ULL;  // mixed signedness: only cells < 2^63 are usable, both orders agree
+    ma.skip_high = j->ks.skip_high;
+    ma.out = (unsigned long long*)(ctx->dscratch + 48);
+    ctx->pinned[48] = ~0ULL;
+    ctx->pinned[49] = 0;
+    ctx->pinned[50] = 0;
+    ctx->pinned[51] = 0;  // [51]: the two flag words of the images kernel
+    TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nb, 256)), dim3(256), 0, ctx->stream, ma);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    j->st.kernel_launches++;
+    const uint64_t usable = ctx->pinned[50];
+    if (usable == 0) return TSQ_OK;
+    const uint64_t kmin = ctx->pinned[48] ^ ma.flip, kmax = ctx->pinned[49] ^ ma.flip, range = kmax - kmin;
+    if (range >> TSQ_DA_MAX_BITS) return TSQ_OK;
+    uint32_t b = TSQ_DA_MIN_BITS;
+    while ((range >> b) != 0) b++;
+    if (!force && (1ULL << b) > 32ULL * usable) return TSQ_OK;  // a sparse domain: the images would be mostly zeros
+    int pb = std::min<int>(TSQ_RADIX_MAX_BITS, (int)b - 10);
+    if (const char* e = getenv("TSQ_DA_PB")) pb = atoi(e);
+    pb = std::max<int>(pb, (int)b - TSQ_DA_MAX_EBITS);
+    pb = std::min<int>(std::max<int>(pb, TSQ_RADIX_MIN_BITS), TSQ_RADIX_MAX_BITS);
+    if ((int)b - pb > TSQ_DA_MAX_EBITS || (int)b - pb < 4) return TSQ_OK;
+    j->da_pbits = (uint32_t)pb;
+    j->da_ebits = b - (uint32_t)pb;
+    j->da_dm.kmin = kmin;
+    j->da_dm.range = range;
+    j->da_dm.b = b;
+    j->da_dm.s = (b + 1) / 2;
+    j->da_dm.mask = (uint32_t)((1ULL << b) - 1);
+    j->da_dm.skip_high = j->ks.skip_high;
+    // ---- partition the build keys, assemble the images
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nb, 1024 * 16);
+    if (g.nregions * g.cap >= 0xffffffffULL) return TSQ_OK;
+    DevBuf ent, ctl, vend, ovf;
+    auto release_all = [&]() {
+        for (DevBuf* x : {&ent, &ctl, &vend, &ovf}) x->release();
+    };
+    tsq_status s = ent.reserve(ctx, h, g.ent_bytes);
+    if (s == TSQ_OK) s = ctl.reserve(ctx, h, g.ctl_bytes);
+    if (s == TSQ_OK) s = vend.reserve(ctx, h, g.nregions * 4);
+    if (s == TSQ_OK) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK) s = j->da_img.reserve(ctx, h, ((size_t)1 << b) + 64);
+    if (s != TSQ_OK) { release_all(); j->da_img.release(); return s; }
+    DaStore st;
+    memset(&st, 0, sizeof st);
+    st.ent = ent.p;
+    st.cursor = ctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.valid_end = vend.as<uint32_t>();
+    st.ovf = ovf.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nb;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
+    if (e == hipSuccess) s = da_launch_partition(j, ma.src, st);
+    DaImageArgs ia;
+    memset(&ia, 0, sizeof ia);
+    ia.st = st;
+    ia.img = j->da_img.as<uint8_t>();
+    ia.flags = (uint32_t*)(ctx->dscratch + 51);
+    const size_t img_lds = (size_t)1 << j->da_ebits;
+    if (e == hipSuccess && s == TSQ_OK) {
+        if (j->da_ebits > 16) {
+            e = hipFuncSetAttribute((const void*)k_da_build_images<1024, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_images<1024, uint32_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, ia);
+        } else {
+            e = hipFuncSetAttribute((const void*)k_da_build_images<512, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_images<512, uint16_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(512), img_lds, ctx->stream, ia);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e == hipSuccess && s == TSQ_OK) {
+        hipLaunchKernelGGL(k_da_build_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 51, ctx->dscratch + 51, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0;
+    if (e == hipSuccess && e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms = ms;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    release_all();
+    j->st.kernel_launches += 2;
+    if (s != TSQ_OK) { j->da_img.release(); return s; }
+    if (e != hipSuccess) { j->da_img.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key images: ") + hipGetErrorString(e)); }
+    const uint32_t f_over = ((const uint32_t*)(ctx->pinned + 51))[0], f_dup = ((const uint32_t*)(ctx->pinned + 51))[1];
+    if (f_over) {  // a key with more than 255 build rows: the 64-bit route keeps this join
+        j->da_img.release();
+        return TSQ_OK;
+    }
+    j->da_unique = f_dup == 0;
+    j->da_state = 1;
+    return TSQ_OK;
+}
+
+tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nrows, 1024 * 16);
+    if (g.nregions * g.cap >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "radix probe batch too large");
+    TSQ_TRY(j->rkeys.reserve(ctx, h, g.ent_bytes));
+    TSQ_TRY(j->rctl.reserve(ctx, h, g.ctl_bytes));
+    TSQ_TRY(j->rvend.reserve(ctx, h, g.nregions * 4));
+    TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    DaStore st;
+    memset(&st, 0, sizeof st);
+    st.ent = j->rkeys.p;
+    st.cursor = j->rctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.valid_end = j->rvend.as<uint32_t>();
+    st.ovf = j->rovf.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nrows;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
+    DaSrc src;
+    memset(&src, 0, sizeof src);
+    const int kc = j->ks.pidx[0];
+    src.data = (const uint64_t*)pcs.data[kc];
+    src.nulls = pcs.nulls[kc];
+    src.nrows = nrows;
+    hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
+    for (int e = 0; e < 3; e++)
+        if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    TSQ_TRY(da_launch_partition(j, src, st));
+    TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
+    DaProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.st = st;
+    pa.img = j->da_img.as<uint8_t>();
+    pa.counters = j->counters.as<unsigned long long>();
+    const size_t img_lds = (size_t)1 << j->da_ebits;
+    if (j->da_ebits > 16) {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<1024, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds));
+        hipLaunchKernelGGL((k_da_probe_count<1024, uint32_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, pa);
+    } else {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<512, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds));
+        hipLaunchKernelGGL((k_da_probe_count<512, uint16_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(512), img_lds, ctx->stream, pa);
+    }
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_da_probe_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+    j->have_probe_ev = true;
+    j->st.kernel_launches += 2;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)st.bits;
+    j->st.probe_route = TSQ_ROUTE_PACKED;
+    j->st.packed_key_bits = (int32_t)j->da_dm.b;
     return TSQ_OK;
 }
 
@@ -1162,6 +1389,7 @@ tsq_status radix_emit(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     j->st.kernel_launches += 4;
     j->st.radix_batches++;
     j->st.radix_bits = (int32_t)st.bits;
+    j->st.probe_route = TSQ_ROUTE_RADIX_LDS;
     if (out_rows == 0) {
         TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
         TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
@@ -1241,9 +1469,14 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     a.counters = j->counters.as<unsigned long long>();
     j->st.probe_rows += nrows;
 
-    if (radix_eligible(j, nrows, selected_dev)) return radix_probe(j, pcs, nrows);
+    if (radix_eligible(j, nrows, selected_dev)) {
+        TSQ_TRY(da_prepare(j));
+        if (j->da_state == 1) return da_probe(j, pcs, nrows);
+        return radix_probe(j, pcs, nrows);
+    }
     if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
+    j->st.probe_route = TSQ_ROUTE_DIRECT;
     if (j->count_only) {
         TSQ_TRY(dispatch_count(j, a, j->checksum));
         TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
@@ -1836,6 +2069,13 @@ TSQ_API tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode) {
     j->radix_mode = mode;
     return TSQ_OK;
 }
+TSQ_API tsq_status tsq_join_set_key_packing(tsq_join* j, int32_t mode) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (mode < TSQ_RADIX_AUTO || mode > TSQ_RADIX_FORCE) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "key packing mode must be -1 (auto), 0 (off) or 1 (force)");
+    if (j->da_state != 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "key packing must be chosen before the first probe batch");
+    j->packing_mode = mode;
+    return TSQ_OK;
+}
 TSQ_API tsq_status tsq_join_set_checksum(tsq_join* j, int32_t on) {
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     if (!j->count_only) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "checksum needs count-only mode");
@@ -2072,6 +2312,7 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
     j->st.partition_kernel_ms = 0;
     j->st.radix_overflow_rows = 0;
     j->st.build_handed_back_rows = j->build_handed_back;
+    j->st.packed_build_ms = j->da_build_ms;
     j->st.radix_probe_kernel_ms = j->st.partition_kernel_ms_sum = j->st.radix_probe_kernel_ms_sum = 0;
     j->st.radix_timed_batches = 0;
     if (j->st.radix_batches > 0 && j->rctl.p) {
@@ -2125,6 +2366,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->rvend.release();
     j->rovf.release();
     j->tkcnt.release();
+    j->da_img.release();
     for (int v = 0; v < TSQ_LDS_MAXPAY; v++) {
         j->rpay[v].release();
         j->rovfpay[v].release();
