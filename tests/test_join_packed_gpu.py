@@ -104,16 +104,17 @@ def test_packed_signedness(ctx, orc, bt, pt):
 def test_packed_duplicates_255_stay_256_fall_back(ctx):
     rng = np.random.default_rng(2)
     pk = rng.integers(0, 1200, 100_000)
-    for dups, route in ((255, abi.ROUTE_PACKED), (256, None), (3000, None)):
-        bk = np.concatenate([np.full(dups, 77), np.arange(1000)]).astype(np.int64)
+    for dups in (255, 256, 3000):
+        bk = np.concatenate([np.full(dups, 2077), np.arange(1000)]).astype(np.int64)  # key 2077: `dups` build rows
         rng.shuffle(bk)
+        pk[::7] = 2077
         build, probe = _tables(bk, pk)
-        want = int((pk < 1000).sum()) + dups * int((pk == 77).sum())
+        want = int((pk < 1000).sum()) + dups * int((pk == 2077).sum())
         stats = []
         got = G.run_join(ctx, _cfg(), build, probe, chunk_rows=1 << 22, count_only=True, radix=FORCE, packing=FORCE, stats_out=stats)
         assert got == want
-        if route == abi.ROUTE_PACKED:
-            assert stats[0].probe_route == route
+        if dups == 255:
+            assert stats[0].probe_route == abi.ROUTE_PACKED
         else:
             assert stats[0].probe_route != abi.ROUTE_PACKED  # a cell cannot hold the multiplicity: 64-bit table words keep the join
 
