@@ -93,6 +93,10 @@ def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1
                 return c.value, s.value, x.value
             return c.value
         assert pull_all() is True
+        if stats_out is not None:
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+            stats_out.append(st)
         return concat(got, out_types)
     finally:
         lib.tsq_join_destroy(h)

@@ -152,3 +152,74 @@ def test_packed_auto_at_1e7_hit_ratio_half(ctx):
     got = G.run_join(ctx, _cfg(), Chunk([Column(abi.I64, bk2), build.columns[1]]), Chunk([Column(abi.I64, pk * 100_003), probe.columns[1]]),
                      chunk_rows=1 << 24, count_only=True, stats_out=stats)
     assert got == want and stats[0].probe_route == abi.ROUTE_RADIX_LDS
+
+
+# ------------------------------------------------------------------ materialising packed route (K4d: pairs through the CSR images)
+from tinysql_amd.chunk import StrColumn  # noqa: E402
+
+
+def _strs(rng, n, maxlen, null_p=0.1):
+    return [None if rng.random() < null_p else bytes(rng.integers(97, 123, int(rng.integers(0, maxlen + 1)), dtype=np.uint8)) for _ in range(n)]
+
+
+def _rows(ctx, cfg, build, probe, chunk_rows=1 << 22, want_route=abi.ROUTE_PACKED, radix=FORCE, packing=FORCE):
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=chunk_rows, pull_rows=4096, radix=radix, packing=packing, stats_out=stats)
+    if want_route is not None:
+        assert stats[0].probe_route == want_route, (stats[0].probe_route, stats[0].radix_batches)
+    return got
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_INNER, 0), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("n_probe", [1, 64, 4097, 60_001])
+def test_packed_rows_wide_nullable_vs_oracle(ctx, orc, jt, inner, n_probe):
+    # 6-column build side and 4-column probe side with NULLs in keys and payloads, float / double / string payloads, ~3 build rows per
+    # key, probe keys on both sides of the build range: none of this fits the 64-bit LDS route's shape, all of it joins on the packed route
+    rng = np.random.default_rng(7 * n_probe + jt + inner)
+    nb = 5000
+    bside = Chunk([Column(abi.F64, rng.random(nb), rng.random(nb) > 0.1), Column(abi.I64, rng.integers(-800, 900, nb), rng.random(nb) > 0.03),
+                   Column(abi.I64, rng.integers(-9, 9, nb), rng.random(nb) > 0.2), Column(abi.F32, rng.random(nb).astype(np.float32)),
+                   StrColumn(_strs(rng, nb, 12)), Column(abi.U64, rng.integers(0, 1 << 62, nb).astype(np.uint64))])
+    pside = Chunk([Column(abi.I64, rng.integers(-1000, 1100, n_probe), rng.random(n_probe) > 0.03), Column(abi.F64, rng.random(n_probe), rng.random(n_probe) > 0.3),
+                   StrColumn(_strs(rng, n_probe, 20, 0.2)), Column(abi.I64, np.arange(n_probe))])
+    left, right = (pside, bside) if inner == 1 else (bside, pside)
+    cfg = H.join_cfg(left.types(), right.types(), [0] if inner == 1 else [1], [1] if inner == 1 else [0], jt, inner)
+    want = orc.hash_join(cfg, bside, pside)
+    got = _rows(ctx, cfg, bside, pside)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    got = _rows(ctx, cfg, bside, pside, chunk_rows=1024)  # host chunks of tidb_max_chunk_size rows reach the same batch
+    assert H.rows_equal_unordered(got, want)
+
+
+@pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
+def test_packed_rows_duplicates_overflow_and_misses(ctx, orc, jt):
+    # every probe row carries one of three keys (its partition's region overflows: the overflow list's rows come out through
+    # k_da_emit_ovf), a key has 200 build rows, and an outer join pads the probe rows whose key is NULL or outside the build range
+    rng = np.random.default_rng(31 + jt)
+    bk = np.concatenate([np.full(200, 5), np.arange(100, 1100), np.full(3, 40_000)]).astype(np.int64)
+    rng.shuffle(bk)
+    build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(len(bk)))])
+    n = 70_000
+    pk = rng.choice(np.array([5, 5, 5, 101, 40_000, 77, -3, 50_000], dtype=np.int64), n)
+    probe = Chunk([Column(abi.I64, pk, rng.random(n) > 0.02), Column(abi.I64, np.arange(n))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], jt, 1)
+    want = orc.hash_join(cfg, build, probe)
+    got = _rows(ctx, cfg, build, probe)
+    assert got.NumRows() == want.NumRows() > 200 * n // 4 and H.rows_equal_unordered(got, want)
+
+
+def test_packed_rows_auto_1e7_checksum_vs_count_route(ctx):
+    # AUTO at scale: 2^23 build rows (a bijection of the key range), 3 x 2^22 probe rows with hit ratio 0.5, a nullable payload (the
+    # 64-bit LDS route refuses it): the joined rows' order-independent checksum must equal the direct route's (tsq_join_set_checksum)
+    rng = np.random.default_rng(13)
+    nb, n = 1 << 23, 3 * (4 << 20)
+    build = Chunk([Column(abi.I64, rng.permutation(nb).astype(np.int64)), Column(abi.I64, rng.integers(0, 1 << 40, nb), rng.random(nb) > 0.03)])
+    probe = Chunk([Column(abi.I64, rng.integers(0, 2 * nb, n)), Column(abi.I64, np.arange(n))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], abi.JOIN_INNER, 1)
+    c, s, x = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, count_only=True, checksum=True, radix=OFF)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, pull_rows=1 << 20, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_PACKED and stats[0].radix_batches == 3
+    assert got.NumRows() == c == int((probe.columns[0].data < nb).sum())
+    from oracle import binding as orc_b
+    assert orc_b.rows_checksum(got) == (s, x)

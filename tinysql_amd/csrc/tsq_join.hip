@@ -709,6 +709,9 @@ struct tsq_join {
     bool da_unique = false;
     DevBuf da_img;                    // 2^b one-byte cells
     double da_build_ms = 0;
+    int da_rows_state = 0;            // materialising packed route: build rows sorted by word (CSR over the images)
+    DevBuf da_coarse, da_pstart, da_brows;
+    DevBuf ridx, rovfidx, rmiss;      // ... probe rows travelling with the entries | of the overflow list | that cannot match (outer joins)
     static constexpr int RING = 32;   // HIP events of the most recent radix batches: [slot][0..2] = start, after partition, end
     hipEvent_t rev[RING][3] = {};
 
@@ -1033,7 +1036,10 @@ struct DaGeom {
 DaGeom da_geometry(uint32_t pbits, uint32_t ebits, int64_t nrows, int T) {
     DaGeom g;
     g.P = 1u << pbits;
-    const double lam = (double)nrows / ((double)g.P * 8.0);
+    // region (p, r) takes the tiles that ran on XCD r: ceil(tiles / 8) of them — for a batch of a few tiles that is far more than
+    // rows / (8 P), and a region sized by the average would send most of a small batch to the overflow list
+    const double tiles = ceil((double)nrows / T);
+    const double lam = std::max((double)nrows / ((double)g.P * 8.0), ceil(tiles / 8.0) * std::min<double>((double)T, (double)nrows) / (double)g.P);
     g.cap = (uint32_t)(lam * 1.08 + 8.0 * sqrt(lam) + 2.0 * T / 64.0 + 64.0);
     g.cap = (g.cap + 63u) & ~63u;  // regions start on 128-byte lines also with 2-byte entries
     g.nregions = (size_t)g.P * 8;
@@ -1041,11 +1047,13 @@ DaGeom da_geometry(uint32_t pbits, uint32_t ebits, int64_t nrows, int T) {
     g.ctl_bytes = ((g.nregions + 16) * 4 + 511) & ~(size_t)511;
     return g;
 }
-tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st) {
+tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st, bool with_idx = false, bool miss = false) {
     constexpr int NT = 1024, K = 16, T = NT * K;
     const int64_t ntiles = (src.nrows + T - 1) / T;
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, j->ctx->num_cus));
-    if (st.ebits > 16) hipLaunchKernelGGL((k_da_partition<NT, K, uint32_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    if (with_idx && miss) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    else if (with_idx) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, false>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    else if (st.ebits > 16) hipLaunchKernelGGL((k_da_partition<NT, K, uint32_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     TSQ_HIP(&j->hdr, hipGetLastError());
     j->st.kernel_launches++;
@@ -1226,7 +1234,7 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
         hipLaunchKernelGGL((k_da_probe_count<512, uint16_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(512), img_lds, ctx->stream, pa);
     }
     TSQ_HIP(h, hipGetLastError());
-    hipLaunchKernelGGL(k_da_probe_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    hipLaunchKernelGGL(k_da_probe_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
@@ -1237,6 +1245,232 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     j->st.probe_route = TSQ_ROUTE_PACKED;
     j->st.packed_key_bits = (int32_t)j->da_dm.b;
     return TSQ_OK;
+}
+
+// ---- materialising packed route (K4d): which rows join, as (probe row, build row) pairs; the columns follow through the pairs
+// Eligible: inner / left outer / right outer join on ONE integer key with a packable build side (da_prepare), no outer filter,
+// no OtherConditions, no selected[], not ordered; any number and type of payload columns, NULLs anywhere.
+bool da_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->never_match || j->ordered) return false;
+    if (selected_dev || !j->conds_h.empty() || !j->filters_h.empty()) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (4 << 20);
+}
+
+// the build rows sorted by word + the coarse ranks (once per build side)
+tsq_status da_prepare_rows(tsq_join* j) {
+    if (j->da_rows_state) return TSQ_OK;
+    j->da_rows_state = -1;
+    if (j->da_state != 1 || j->da_ebits > 16 || j->da_ebits < 5) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const int kc = j->ks.bidx[0];
+    const int64_t nb = j->bcols[kc].rows;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nb, 1024 * 16);
+    if (g.nregions * g.cap >= 0xffffffffULL) return TSQ_OK;
+    DevBuf ent, idx, ctl, vend, ovf, ovfi;
+    auto release_all = [&]() {
+        for (DevBuf* x : {&ent, &idx, &ctl, &vend, &ovf, &ovfi}) x->release();
+    };
+    tsq_status s = ent.reserve(ctx, h, g.ent_bytes);
+    if (s == TSQ_OK) s = idx.reserve(ctx, h, g.nregions * g.cap * 4 + 256);
+    if (s == TSQ_OK) s = ctl.reserve(ctx, h, g.ctl_bytes);
+    if (s == TSQ_OK) s = vend.reserve(ctx, h, g.nregions * 4);
+    if (s == TSQ_OK) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK) s = ovfi.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK) s = j->da_coarse.reserve(ctx, h, (((size_t)1 << j->da_dm.b) >> 5) * 4 + 64);
+    if (s == TSQ_OK) s = j->da_pstart.reserve(ctx, h, ((size_t)g.P + 1) * 4 + 64);
+    if (s == TSQ_OK) s = j->da_brows.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s != TSQ_OK) { release_all(); return s; }
+    DaStore st;
+    memset(&st, 0, sizeof st);
+    st.ent = ent.p;
+    st.idx = idx.as<uint32_t>();
+    st.cursor = ctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.valid_end = vend.as<uint32_t>();
+    st.ovf = ovf.as<uint32_t>();
+    st.ovf_idx = ovfi.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nb;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    DaSrc src;
+    memset(&src, 0, sizeof src);
+    src.data = j->bcols[kc].data.as<uint64_t>();
+    src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
+    src.nrows = nb;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
+    if (e == hipSuccess) s = da_launch_partition(j, src, st, true, false);
+    if (e == hipSuccess && s == TSQ_OK) {
+        hipLaunchKernelGGL(k_da_part_starts, dim3(1), dim3(1024), 0, ctx->stream, st, j->da_pstart.as<uint32_t>());
+        e = hipGetLastError();
+    }
+    DaRowsArgs ra;
+    memset(&ra, 0, sizeof ra);
+    ra.st = st;
+    ra.img = j->da_img.as<uint8_t>();
+    ra.coarse = j->da_coarse.as<uint32_t>();
+    ra.pstart = j->da_pstart.as<uint32_t>();
+    ra.brows = j->da_brows.as<uint32_t>();
+    const size_t cells = (size_t)1 << j->da_ebits, lds = 2 * cells + (cells >> 5) * 4;
+    if (e == hipSuccess && s == TSQ_OK) e = hipFuncSetAttribute((const void*)k_da_build_rows<1024, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && s == TSQ_OK) {
+        hipLaunchKernelGGL((k_da_build_rows<1024, uint16_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), lds, ctx->stream, ra);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 52, st.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0;
+    if (e == hipSuccess && e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms += ms;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    release_all();
+    j->st.kernel_launches += 3;
+    if (s != TSQ_OK) return s;
+    if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key build rows: ") + hipGetErrorString(e));
+    if (((const uint32_t*)(ctx->pinned + 52))[0] != 0) {  // skewed build keys: some rows missed their region — keep the other routes
+        for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_brows}) b->release();
+        return TSQ_OK;
+    }
+    j->da_rows_state = 1;
+    return TSQ_OK;
+}
+
+template <class F>
+tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows, int64_t out_rows, F&& produce_pairs);
+
+tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nrows, 1024 * 16);
+    if (g.nregions * g.cap >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "radix probe batch too large");
+    TSQ_TRY(j->rkeys.reserve(ctx, h, g.ent_bytes));
+    TSQ_TRY(j->ridx.reserve(ctx, h, g.nregions * g.cap * 4 + 256));
+    TSQ_TRY(j->rctl.reserve(ctx, h, g.ctl_bytes));
+    TSQ_TRY(j->rvend.reserve(ctx, h, g.nregions * 4));
+    TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(j->rovfidx.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    if (outer) TSQ_TRY(j->rmiss.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    const size_t n_pc = (size_t)g.P + 1;  // [partition], then one more word: the exclusive scan leaves the total there
+    TSQ_TRY(j->tkcnt.reserve(ctx, h, n_pc * 8 + 64));
+    DaStore st;
+    memset(&st, 0, sizeof st);
+    st.ent = j->rkeys.p;
+    st.idx = j->ridx.as<uint32_t>();
+    st.cursor = j->rctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.miss_count = st.cursor + g.nregions + 1;
+    st.miss = j->rmiss.as<uint32_t>();
+    st.valid_end = j->rvend.as<uint32_t>();
+    st.ovf = j->rovf.as<uint32_t>();
+    st.ovf_idx = j->rovfidx.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nrows;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->tkcnt.p, 0, n_pc * 8, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));  // [52] joined rows of the overflow list, [53] its output cursor
+    DaSrc src;
+    memset(&src, 0, sizeof src);
+    const int kc = j->ks.pidx[0];
+    src.data = (const uint64_t*)pcs.data[kc];
+    src.nulls = pcs.nulls[kc];
+    src.nrows = nrows;
+    hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
+    for (int e = 0; e < 3; e++)
+        if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    TSQ_TRY(da_launch_partition(j, src, st, true, outer));
+    TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
+    // ---- sizing pass: output rows per partition, their exclusive scan
+    DaProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.st = st;
+    pa.img = j->da_img.as<uint8_t>();
+    pa.counters = (unsigned long long*)(ctx->dscratch + 52);
+    pa.pcount = j->tkcnt.as<unsigned long long>();
+    const size_t cells = (size_t)1 << j->da_ebits;
+    const dim3 pgrid(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2));
+    if (outer) {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<512, uint16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells));
+        hipLaunchKernelGGL((k_da_probe_count<512, uint16_t, true, true>), pgrid, dim3(512), cells, ctx->stream, pa);
+        TSQ_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(k_da_probe_ovf<true>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    } else {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<512, uint16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells));
+        hipLaunchKernelGGL((k_da_probe_count<512, uint16_t, true, false>), pgrid, dim3(512), cells, ctx->stream, pa);
+        TSQ_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(k_da_probe_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    }
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, pa.pcount, (int)n_pc);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 52, pa.pcount + g.P, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 53, ctx->dscratch + 52, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 54, st.miss_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const int64_t part_rows = (int64_t)ctx->pinned[52], ovf_rows = (int64_t)ctx->pinned[53];
+    const int64_t miss_rows = outer ? (int64_t)((const uint32_t*)(ctx->pinned + 54))[0] : 0;
+    const int64_t out_rows = part_rows + ovf_rows + miss_rows;
+    j->st.kernel_launches += 3;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)st.bits;
+    j->st.probe_route = TSQ_ROUTE_PACKED;
+    j->st.packed_key_bits = (int32_t)j->da_dm.b;
+    if (out_rows == 0) {
+        TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+        TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    return materialise_pairs(j, pcs, a, nrows, out_rows, [&]() -> tsq_status {
+        DaEmitArgs ea;
+        memset(&ea, 0, sizeof ea);
+        ea.st = st;
+        ea.img = pa.img;
+        ea.coarse = j->da_coarse.as<uint32_t>();
+        ea.pstart = j->da_pstart.as<uint32_t>();
+        ea.brows = j->da_brows.as<uint32_t>();
+        ea.pbase = pa.pcount;
+        ea.pairs = a.pairs;
+        ea.ovf_cursor = (unsigned long long*)(ctx->dscratch + 53);
+        ctx->pinned[55] = (uint64_t)part_rows;
+        TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 53, ctx->pinned + 55, 8, hipMemcpyHostToDevice, ctx->stream));
+        const size_t lds = cells + (cells >> 5) * 4;
+        if (outer) {
+            TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_pairs<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_da_emit_pairs<512, true>), pgrid, dim3(512), lds, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+            hipLaunchKernelGGL(k_da_emit_ovf<true>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+            if (miss_rows) {
+                hipLaunchKernelGGL(k_da_emit_miss, dim3(tsq_grid_for(ctx, miss_rows, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)st.miss, (uint32_t)miss_rows,
+                                   a.pairs + part_rows + ovf_rows);
+                TSQ_HIP(h, hipGetLastError());
+            }
+        } else {
+            TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_pairs<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_da_emit_pairs<512, false>), pgrid, dim3(512), lds, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+            hipLaunchKernelGGL(k_da_emit_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+        }
+        TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+        j->st.kernel_launches += 3;
+        return TSQ_OK;
+    });
 }
 
 // ---------------------------------------------------------------- materialising radix path (host side)
@@ -1448,62 +1682,12 @@ tsq_status radix_emit(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     return deliver_batch(j, std::move(rb), may_null_v);
 }
 
-// run the probe kernels over one device-resident batch described by pcs / selected
-tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
-    if (nrows == 0) return TSQ_OK;
+// The joined rows of a batch are known as (probe row, build row) pairs (build row TSQ_PAIR_MISS = the NULL-padded row of an outer
+// join): allocate the output batch, let `produce_pairs` fill a.pairs[0, out_rows), copy the columns through the pairs (K4b / K4c)
+// and hand the batch to tsq_join_pull.  Shared by the direct route (K3 + K4a) and the packed-key route (tsq_dajoin.h).
+template <class F>
+tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows, int64_t out_rows, F&& produce_pairs) {
     tsq_ctx* ctx = j->ctx;
-    ProbeArgs a;
-    memset(&a, 0, sizeof a);
-    a.p = pcs;
-    tsq_fill_colset(a.b, j->bcols);
-    a.ks = j->ks;
-    fill_table(j, a.t);
-    a.nrows = nrows;
-    a.selected = selected_dev;
-    a.filters = j->filters_d.as<tsq_expr_prog>();
-    a.n_filters = (int32_t)j->filters_h.size();
-    a.conds = j->conds_d.as<tsq_expr_prog>();
-    a.n_conds = (int32_t)j->conds_h.size();
-    a.join_type = j->cfg.join_type;
-    a.probe_is_left = j->cfg.build_is_right ? 1 : 0;
-    a.counters = j->counters.as<unsigned long long>();
-    j->st.probe_rows += nrows;
-
-    if (radix_eligible(j, nrows, selected_dev)) {
-        TSQ_TRY(da_prepare(j));
-        if (j->da_state == 1) return da_probe(j, pcs, nrows);
-        return radix_probe(j, pcs, nrows);
-    }
-    if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
-    TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
-    j->st.probe_route = TSQ_ROUTE_DIRECT;
-    if (j->count_only) {
-        TSQ_TRY(dispatch_count(j, a, j->checksum));
-        TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
-        j->have_probe_ev = true;
-        return TSQ_OK;
-    }
-    // emit mode: size the batch first (K3), then materialise (K4); both walk contiguous rows per workgroup
-    const int egrid = tsq_grid_for(ctx, nrows, 256);
-    TSQ_TRY(j->bbase.reserve(ctx, &j->hdr, (size_t)egrid * 8 + 64));
-    TSQ_TRY(j->firstcnt.reserve(ctx, &j->hdr, (size_t)nrows * 8 + 64));
-    a.block_base = j->bbase.as<unsigned long long>();
-    a.first_cnt = j->firstcnt.as<unsigned long long>();
-    a.ordered = j->ordered ? 1 : 0;
-    a.rows_per_block = (((nrows + egrid - 1) / egrid) + 63) & ~(int64_t)63;
-    unsigned long long before[8], after[8];
-    TSQ_TRY(read_counters(j, before));
-    TSQ_TRY(dispatch_count(j, a, false));
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, a.block_base, egrid);
-    TSQ_HIP(&j->hdr, hipGetLastError());
-    TSQ_TRY(read_counters(j, after));
-    TSQ_TRY(status_from_errword(j, after[3]));
-    const int64_t out_rows = (int64_t)(after[0] - before[0]);
-    if (out_rows == 0) {
-        TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
-        j->have_probe_ev = true;
-        return TSQ_OK;
-    }
     const int nout = j->cfg.n_probe_cols + j->cfg.n_build_cols;
     std::unique_ptr<ResultBatch> rb(new ResultBatch());
     rb->rows = out_rows;
@@ -1557,8 +1741,7 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
             }
         }
     }
-    TSQ_TRY(reset_counters(j, true));
-    TSQ_TRY(dispatch_emit(j, a));
+    TSQ_TRY(produce_pairs());
     {
         const int64_t groups = (out_rows + 7) / 8;
         const int gx = (int)std::min<int64_t>((groups + 255) / 256, (int64_t)ctx->num_cus * 8);
@@ -1609,6 +1792,73 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
     j->have_probe_ev = true;
     return deliver_batch(j, std::move(rb), may_null_v);
+}
+
+// run the probe kernels over one device-resident batch described by pcs / selected
+tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
+    if (nrows == 0) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    ProbeArgs a;
+    memset(&a, 0, sizeof a);
+    a.p = pcs;
+    tsq_fill_colset(a.b, j->bcols);
+    a.ks = j->ks;
+    fill_table(j, a.t);
+    a.nrows = nrows;
+    a.selected = selected_dev;
+    a.filters = j->filters_d.as<tsq_expr_prog>();
+    a.n_filters = (int32_t)j->filters_h.size();
+    a.conds = j->conds_d.as<tsq_expr_prog>();
+    a.n_conds = (int32_t)j->conds_h.size();
+    a.join_type = j->cfg.join_type;
+    a.probe_is_left = j->cfg.build_is_right ? 1 : 0;
+    a.counters = j->counters.as<unsigned long long>();
+    j->st.probe_rows += nrows;
+
+    if (radix_eligible(j, nrows, selected_dev)) {
+        TSQ_TRY(da_prepare(j));
+        if (j->da_state == 1) return da_probe(j, pcs, nrows);
+        return radix_probe(j, pcs, nrows);
+    }
+    if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
+    if (da_emit_eligible(j, nrows, selected_dev)) {
+        TSQ_TRY(da_prepare(j));
+        TSQ_TRY(da_prepare_rows(j));
+        if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows);
+    }
+    TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
+    j->st.probe_route = TSQ_ROUTE_DIRECT;
+    if (j->count_only) {
+        TSQ_TRY(dispatch_count(j, a, j->checksum));
+        TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    // emit mode: size the batch first (K3), then materialise (K4); both walk contiguous rows per workgroup
+    const int egrid = tsq_grid_for(ctx, nrows, 256);
+    TSQ_TRY(j->bbase.reserve(ctx, &j->hdr, (size_t)egrid * 8 + 64));
+    TSQ_TRY(j->firstcnt.reserve(ctx, &j->hdr, (size_t)nrows * 8 + 64));
+    a.block_base = j->bbase.as<unsigned long long>();
+    a.first_cnt = j->firstcnt.as<unsigned long long>();
+    a.ordered = j->ordered ? 1 : 0;
+    a.rows_per_block = (((nrows + egrid - 1) / egrid) + 63) & ~(int64_t)63;
+    unsigned long long before[8], after[8];
+    TSQ_TRY(read_counters(j, before));
+    TSQ_TRY(dispatch_count(j, a, false));
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, a.block_base, egrid);
+    TSQ_HIP(&j->hdr, hipGetLastError());
+    TSQ_TRY(read_counters(j, after));
+    TSQ_TRY(status_from_errword(j, after[3]));
+    const int64_t out_rows = (int64_t)(after[0] - before[0]);
+    if (out_rows == 0) {
+        TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    return materialise_pairs(j, pcs, a, nrows, out_rows, [&]() -> tsq_status {
+        TSQ_TRY(reset_counters(j, true));
+        return dispatch_emit(j, a);
+    });
 }
 
 tsq_status probe_flush(tsq_join* j) {
@@ -2367,6 +2617,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->rovf.release();
     j->tkcnt.release();
     j->da_img.release();
+    for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss}) b->release();
     for (int v = 0; v < TSQ_LDS_MAXPAY; v++) {
         j->rpay[v].release();
         j->rovfpay[v].release();
