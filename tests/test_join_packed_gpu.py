@@ -208,8 +208,8 @@ def test_packed_rows_duplicates_overflow_and_misses(ctx, orc, jt):
     assert got.NumRows() == want.NumRows() > 200 * n // 4 and H.rows_equal_unordered(got, want)
 
 
-def test_packed_rows_auto_1e7_checksum_vs_count_route(ctx):
-    # AUTO at scale: 2^23 build rows (a bijection of the key range), 3 x 2^22 probe rows with hit ratio 0.5, a nullable payload (the
+def test_packed_rows_1e7_checksum_vs_count_route(ctx):
+    # at scale: 2^23 build rows (a bijection of the key range), 3 x 2^22 probe rows with hit ratio 0.5, a nullable payload (the
     # 64-bit LDS route refuses it): the joined rows' order-independent checksum must equal the direct route's (tsq_join_set_checksum)
     rng = np.random.default_rng(13)
     nb, n = 1 << 23, 3 * (4 << 20)
@@ -218,7 +218,7 @@ def test_packed_rows_auto_1e7_checksum_vs_count_route(ctx):
     cfg = H.join_cfg(probe.types(), build.types(), [0], [0], abi.JOIN_INNER, 1)
     c, s, x = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, count_only=True, checksum=True, radix=OFF)
     stats = []
-    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, pull_rows=1 << 20, stats_out=stats)
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, pull_rows=1 << 20, stats_out=stats, packing=FORCE)
     assert stats[0].probe_route == abi.ROUTE_PACKED and stats[0].radix_batches == 3
     assert got.NumRows() == c == int((probe.columns[0].data < nb).sum())
     from oracle import binding as orc_b
