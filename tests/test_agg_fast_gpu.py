@@ -2,7 +2,7 @@
 that the LDS tables, the radix partition with payload cells, the spill / exception / fallback routes and
 the partial-group merge are all compared with the oracle; AUTO is checked at C3 scale through
 size-independent properties.  Integer aggregates are bit-exact; SUM/AVG(double) within the re-ordering
-bound 2*n*2^-53*sum|v|."""
+bound 2*n_g*2^-53*sum_g|v| of every GROUP."""
 import ctypes as C
 
 import numpy as np
@@ -14,7 +14,7 @@ from tinysql_amd.chunk import Chunk, Column
 
 from . import gpu_helpers as G
 from . import helpers as H
-from .test_agg_gpu import _match_by_key, out_types_for
+from .test_agg_gpu import _match_by_key, group_tols, out_types_for
 
 pytestmark = pytest.mark.gpu
 SENT = np.uint64(0x8080808080808080).astype(np.int64)
@@ -60,8 +60,8 @@ def test_fast_random_vs_oracle(ctx, orc, aggset, n, groups, est):
     stats = []
     got = _run(ctx, cfg, chk, aggs, abi.AGGFAST_FORCE, stats=stats)
     assert stats[0].radix_batches >= 1  # the LDS path really ran
-    tol = 2 * n * 2.0 ** -53 * float(np.abs(d.data).sum() + 50.0 * n)
     real_cols = [i for i, a in enumerate(aggs) if a[0] in (abi.AGG_SUM, abi.AGG_AVG) and a[2] in (abi.F64, abi.F32)]
+    tol = group_tols(chk, 0, aggs, real_cols)  # per group: 2 n_g 2^-53 sum_g|v|
     exact_cols = [i for i in range(len(aggs)) if i not in real_cols]
     key_out = [i for i, a in enumerate(aggs) if a[0] == abi.AGG_FIRSTROW][0]
     _match_by_key(got, want, [key_out], exact_cols, real_cols, tol)

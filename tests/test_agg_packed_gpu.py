@@ -1,0 +1,103 @@
+"""GPU parity of the PACKED-KEY pre-aggregation of HashAggExec (csrc/tsq_daagg.h): an integer group key whose values span
+few bits travels as a 2-byte entry next to its argument cells and is aggregated in a direct-addressed LDS table.  Forced on
+small inputs (every aggregate function, NULL keys and arguments, negative and unsigned keys, a hot key that overflows its
+partition's region, later batches with keys outside the range the first batch showed) against the oracle; integer results
+are bit-exact, SUM/AVG(double) within 2 n_g 2^-53 sum_g|v| per group."""
+import numpy as np
+import pytest
+
+from tinysql_amd import _abi as abi
+from tinysql_amd.chunk import Chunk, Column
+
+from . import gpu_helpers as G
+from . import helpers as H
+from .test_agg_gpu import _match_by_key, group_tols, out_types_for
+
+pytestmark = pytest.mark.gpu
+
+AGG_SETS = {
+    "c3": [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64)],
+    "c3_double": [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 2, abi.F64), (abi.AGG_COUNT, -1, abi.I64)],
+    "ints": [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_COUNT, 1, abi.I64), (abi.AGG_AVG, 1, abi.I64), (abi.AGG_MAX, 1, abi.I64)],
+    "minmax2": [(abi.AGG_MIN, 1, abi.I64), (abi.AGG_MAX, 4, abi.U64), (abi.AGG_MIN, 4, abi.U64), (abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_COUNT, -1, abi.I64)],
+    "reals": [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 2, abi.F64), (abi.AGG_AVG, 2, abi.F64), (abi.AGG_MAX, 2, abi.F64)],
+    "f32": [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 3, abi.F32), (abi.AGG_MIN, 3, abi.F32), (abi.AGG_COUNT, 3, abi.F32)],
+    "count_only": [(abi.AGG_COUNT, -1, abi.I64), (abi.AGG_FIRSTROW, 0, abi.I64)],
+}
+
+
+def _chunk(rng, n, lo, hi, kt=abi.I64, key_nulls=0.03):
+    kv = rng.integers(lo, hi, n)
+    k = Column(kt, kv.astype(np.uint64) if kt == abi.U64 else kv, rng.random(n) > key_nulls)
+    v = H.random_column(rng, abi.I64, n, 0.1, lo=-10**6, hi=10**6)
+    d = H.random_column(rng, abi.F64, n, 0.1)
+    f = Column(abi.F32, rng.integers(-50, 50, n).astype(np.float32), rng.random(n) > 0.1)
+    u = H.random_column(rng, abi.U64, n, 0.1)
+    return Chunk([k, v, d, f, u]), [kt, abi.I64, abi.F64, abi.F32, abi.U64]
+
+
+def _check(ctx, orc, chk, types, aggs, est, chunk_rows=1 << 22, want_packed=True):
+    cfg = H.agg_cfg(types, [0], aggs, est_groups=est)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    stats = []
+    got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=chunk_rows, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].radix_batches >= 1
+    if want_packed is not None:
+        assert (stats[0].packed_key_bits > 0) == want_packed, stats[0].packed_key_bits
+    real_cols = [i for i, a in enumerate(aggs) if a[0] in (abi.AGG_SUM, abi.AGG_AVG) and a[2] in (abi.F64, abi.F32)]
+    exact_cols = [i for i in range(len(aggs)) if i not in real_cols]
+    key_out = [i for i, a in enumerate(aggs) if a[0] == abi.AGG_FIRSTROW][0]
+    _match_by_key(got, want, [key_out], exact_cols, real_cols, group_tols(chk, 0, aggs, real_cols))
+    return stats[0]
+
+
+@pytest.mark.parametrize("aggset", sorted(AGG_SETS))
+@pytest.mark.parametrize("n,lo,hi", [(5000, -3000, 3000), (70_001, 10**12, 10**12 + 50_000), (300_001, -(1 << 21), 1 << 21)])
+def test_packed_agg_random_vs_oracle(ctx, orc, aggset, n, lo, hi):
+    rng = np.random.default_rng(n + len(aggset))
+    chk, types = _chunk(rng, n, lo, hi)
+    st = _check(ctx, orc, chk, types, AGG_SETS[aggset], est=max(4096, (hi - lo) // 2))
+    assert st.packed_key_bits >= 15
+
+
+def test_packed_agg_unsigned_keys_above_2_63(ctx, orc):
+    rng = np.random.default_rng(3)
+    n = 60_000
+    kv = (np.uint64(1 << 63) + rng.integers(0, 20_000, n).astype(np.uint64))
+    chk = Chunk([Column(abi.U64, kv, rng.random(n) > 0.02), H.random_column(rng, abi.I64, n, 0.1, lo=-99, hi=99)])
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.U64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64)]
+    cfg = H.agg_cfg([abi.U64, abi.I64], [0], aggs, est_groups=20_000)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    stats = []
+    got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 22, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].packed_key_bits > 0 and H.rows_equal_unordered(got, want)
+
+
+def test_packed_agg_hot_key_and_later_batches_outside_the_range(ctx, orc, monkeypatch):
+    monkeypatch.setenv("TSQ_AGG_BATCH_ROWS", str(1 << 17))
+    # batch 1 (device batches of 2^17 rows): keys in [0, 30000) with one key carrying 40 % of
+    # the rows (its partition's region overflows: those rows take the row-at-a-time upsert); batch 2 brings keys far outside the range
+    # the first batch showed (exception rows); batch 3 is mostly outside (the operator leaves the packed route)
+    rng = np.random.default_rng(8)
+    n1 = 1 << 17
+    k1 = rng.integers(0, 30_000, n1)
+    k1[rng.random(n1) < 0.4] = 777
+    k2 = np.concatenate([rng.integers(0, 30_000, n1 - 5000), rng.integers(10**9, 10**9 + 50, 5000)])
+    k3 = rng.integers(-10**15, -10**15 + 40_000, n1)
+    keys = np.concatenate([k1, k2, k3])
+    n = len(keys)
+    chk = Chunk([Column(abi.I64, keys, rng.random(n) > 0.01), H.random_column(rng, abi.I64, n, 0.05, lo=-1000, hi=1000), H.random_column(rng, abi.F64, n, 0.05)])
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 2, abi.F64), (abi.AGG_MIN, 1, abi.I64)]
+    cfg = H.agg_cfg([abi.I64, abi.I64, abi.F64], [0], aggs, est_groups=30_000)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    stats = []
+    got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=n1, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].packed_key_bits > 0 and stats[0].radix_batches >= 3
+    _match_by_key(got, want, [0], [1, 2, 4], [3], group_tols(chk, 0, aggs, [3]))
+
+
+def test_packed_agg_wide_keys_keep_the_64_bit_route(ctx, orc):
+    rng = np.random.default_rng(5)
+    chk, types = _chunk(rng, 80_000, -(1 << 40), 1 << 40)
+    chk.columns[0] = Column(abi.I64, rng.integers(0, 30_000, 80_000) * (1 << 30))  # 30 K groups spread over 2^45
+    _check(ctx, orc, chk, types, AGG_SETS["c3"], est=30_000, want_packed=False)

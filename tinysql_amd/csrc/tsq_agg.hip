@@ -26,6 +26,7 @@
 // path (tag = hash of the bytes, the bytes themselves verified in phase 1).
 #include "tsq_stage.h"
 #include "tsq_aggfast.h"
+#include "tsq_daagg.h"
 
 #include <memory>
 
@@ -717,6 +718,11 @@ struct tsq_agg {
     DevBuf fkey, fw[TSQ_AF_MAXW], fctl, fexc;      // partial groups | counters (partials, exceptions) | exception row ids
     DevBuf rkeys, rpay[TSQ_RADIX_MAXV], rctl, rvend, rokeys, ropay[TSQ_RADIX_MAXV];  // partitioned rows (H mode)
     int64_t fast_batches = 0, fast_fallbacks = 0;
+    // packed-key pre-aggregation (tsq_daagg.h): the key range the first large batch showed
+    int da_state = 0;  // 0: not tried, 1: in use, -1: not usable (range too wide, float key, too many rows outside the range)
+    DaDomain da_dm{};
+    uint32_t da_pbits = 0, da_ebits = 0;
+    int64_t packed_batches = 0;
 };
 
 namespace {
@@ -898,6 +904,64 @@ tsq_status launch_lds(tsq_agg* a, AfLdsArgs& la, int grid) {
     return TSQ_OK;
 }
 
+// ---- packed-key H mode (tsq_daagg.h)
+tsq_status launch_agg_da(tsq_agg* a, DaAggLdsArgs& la, int grid) {
+    hipStream_t st = a->ctx->stream;
+    switch (la.plan.W) {  // W <= 3: 4096 cells per partition (96 KB of LDS words), else 2048
+        case 1: hipLaunchKernelGGL((k_agg_da<1, 4096>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+        case 2: hipLaunchKernelGGL((k_agg_da<2, 4096>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+        case 3: hipLaunchKernelGGL((k_agg_da<3, 4096>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+        case 4: hipLaunchKernelGGL((k_agg_da<4, 2048>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+        default: hipLaunchKernelGGL((k_agg_da<5, 2048>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+    }
+    TSQ_HIP(&a->hdr, hipGetLastError());
+    a->st.kernel_launches++;
+    return TSQ_OK;
+}
+// the key range of the first large batch decides: [kmin, kmin + 2^b) with b <= TSQ_DAAGG_MAX_BITS, or the 64-bit H mode
+tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    if (a->da_state) return TSQ_OK;
+    a->da_state = -1;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    static const bool env_off = [] { const char* v = getenv("TSQ_PACKED_KEYS"); return v && v[0] == '0'; }();
+    const AfPlan& pl = a->fplan;
+    if (env_off || (pl.key_type != TSQ_I64 && pl.key_type != TSQ_U64)) return TSQ_OK;
+    DaMinMaxArgs ma;
+    memset(&ma, 0, sizeof ma);
+    ma.src.data = (const uint64_t*)in.data[pl.key_col];
+    ma.src.nulls = in.nulls[pl.key_col];
+    ma.src.nrows = nrows;
+    ma.flip = pl.key_type == TSQ_I64 ? 0x8000000000000000ULL : 0ULL;
+    ma.out = (unsigned long long*)(ctx->dscratch + 48);
+    ctx->pinned[48] = ~0ULL;
+    ctx->pinned[49] = 0;
+    ctx->pinned[50] = 0;
+    TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 24, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, ma);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    a->st.kernel_launches++;
+    if (ctx->pinned[50] == 0) return TSQ_OK;
+    const uint64_t kmin = ctx->pinned[48] ^ ma.flip, kmax = ctx->pinned[49] ^ ma.flip, range = kmax - kmin;
+    const uint32_t log2c = pl.W <= 3 ? 12u : 11u;
+    if (range >> TSQ_DAAGG_MAX_BITS) return TSQ_OK;
+    uint32_t b = log2c + TSQ_RADIX_MIN_BITS;
+    while ((range >> b) != 0) b++;
+    if (b - log2c > TSQ_RADIX_MAX_BITS) return TSQ_OK;
+    a->da_pbits = b - log2c;
+    a->da_ebits = log2c;
+    a->da_dm.kmin = kmin;
+    a->da_dm.range = ((uint64_t)1 << b) - 1;  // the whole 2^b window above kmin: later batches may bring somewhat larger keys
+    a->da_dm.b = b;
+    a->da_dm.s = (b + 1) / 2;
+    a->da_dm.mask = (uint32_t)(((uint64_t)1 << b) - 1);
+    a->da_dm.skip_high = 0;
+    a->da_state = 1;
+    return TSQ_OK;
+}
+
 // one batch through LDS pre-aggregation.  *done = false: nothing was merged, the caller runs the row path.
 tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64_t groups_est, bool* done) {
     *done = false;
@@ -907,7 +971,9 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     const uint32_t S = af_slots(pl);
     const bool low = groups_est <= (int64_t)(S / 2);
     uint32_t bits = 0;
-    if (!low) {
+    if (!low) TSQ_TRY(da_agg_setup(a, in, nrows));
+    const bool packed = !low && a->da_state == 1;
+    if (!low && !packed) {
         // H: partitions small enough that their groups half-fill one LDS table, at least 256 of them (parallelism)
         // (2^11 partitions — tables 1/8 full, shorter walks — were measured: k_agg_lds 0.66 -> 0.64 ms per 1e8 rows, but the partition
         // kernel with a payload column writes 32-byte runs then and goes from 0.76 to 0.83 ms: kept at 2^10)
@@ -916,7 +982,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         if (((double)groups_est * 1.3 / (double)S) > (double)(1u << bits)) return TSQ_OK;  // too many groups for LDS tables
     }
     // partial-group buffer: every workgroup may emit a table, plus spilled rows; beyond cap the batch is redone row by row
-    const size_t nblocks = low ? (size_t)ctx->num_cus : ((size_t)1 << bits);
+    const size_t nblocks = low ? (size_t)ctx->num_cus : ((size_t)1 << (packed ? a->da_pbits : bits));
     const size_t pcap = std::min<size_t>(nblocks * S + (size_t)nrows / 8 + 4096, 0x7fffffffULL);
     TSQ_TRY(a->fkey.reserve(ctx, h, pcap * 8));
     for (int k = 0; k < pl.W; k++) TSQ_TRY(a->fw[k].reserve(ctx, h, pcap * 8));
@@ -936,6 +1002,56 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     la.exc_count = a->fctl.as<uint32_t>() + 1;
     if (low) {
         TSQ_TRY(launch_lds<0>(a, la, (int)std::min<int64_t>(ctx->num_cus, (nrows + TSQ_AF_NT - 1) / TSQ_AF_NT)));
+    } else if (packed) {
+        DaAggStore st;
+        memset(&st, 0, sizeof st);
+        st.bits = a->da_pbits;
+        st.ebits = a->da_ebits;
+        const uint32_t P = 1u << st.bits;
+        const int K = pl.V == 0 ? 16 : (pl.V == 1 ? 8 : 4), T = 1024 * K;
+        const double tiles = ceil((double)nrows / T);
+        const double lam = std::max((double)nrows / ((double)P * 8.0), ceil(tiles / 8.0) * std::min<double>((double)T, (double)nrows) / (double)P);
+        st.cap = (uint32_t)(lam * 1.08 + 8.0 * sqrt(lam) + 2.0 * T / 64.0 + 64.0);
+        st.cap = (st.cap + 63u) & ~63u;
+        const size_t nregions = (size_t)P * 8, slots = nregions * st.cap;
+        if (slots >= 0xffffffffULL) return TSQ_OK;
+        TSQ_TRY(a->rkeys.reserve(ctx, h, slots * 2 + 256));
+        for (int v = 0; v < pl.V; v++) TSQ_TRY(a->rpay[v].reserve(ctx, h, slots * 8 + 256));
+        TSQ_TRY(a->rctl.reserve(ctx, h, nregions * 4 + 64));
+        TSQ_TRY(a->rvend.reserve(ctx, h, nregions * 4));
+        st.ent = a->rkeys.as<uint16_t>();
+        st.cursor = a->rctl.as<uint32_t>();
+        st.valid_end = a->rvend.as<uint32_t>();
+        for (int v = 0; v < pl.V; v++) st.pay[v] = a->rpay[v].as<uint64_t>();
+        TSQ_HIP(h, hipMemsetAsync(a->rctl.p, 0, nregions * 4 + 64, ctx->stream));
+        TSQ_HIP(h, hipMemsetAsync(a->rvend.p, 0xff, nregions * 4, ctx->stream));
+        DaAggSrc src;
+        memset(&src, 0, sizeof src);
+        src.kdata = in.data[pl.key_col];
+        src.knulls = in.nulls[pl.key_col];
+        src.nrows = nrows;
+        for (int v = 0; v < pl.V; v++) {
+            src.vdata[v] = in.data[pl.vcol[v]];
+            src.vnulls[v] = in.nulls[pl.vcol[v]];
+            src.vtype[v] = in.type[pl.vcol[v]];
+        }
+        src.exc_rows = la.exc_rows;
+        src.exc_count = la.exc_count;
+        const int pgrid = (int)std::min<int64_t>((nrows + T - 1) / T, ctx->num_cus);
+        if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st);
+        else if (pl.V == 1) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st);
+        else hipLaunchKernelGGL((k_daagg_partition<1024, 4, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st);
+        TSQ_HIP(h, hipGetLastError());
+        a->st.kernel_launches++;
+        DaAggLdsArgs da;
+        memset(&da, 0, sizeof da);
+        da.plan = pl;
+        da.out = la.out;
+        da.st = st;
+        da.dm = a->da_dm;
+        const int agrid = (int)std::min<uint32_t>(P, (uint32_t)ctx->num_cus);
+        TSQ_TRY(launch_agg_da(a, da, agrid));
+        a->packed_batches++;
     } else {
         RadixStore st;
         memset(&st, 0, sizeof st);
@@ -1015,6 +1131,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         return TSQ_OK;
     }));
     if (n_exc) TSQ_TRY(agg_rows(a, in, (int64_t)n_exc, a->fexc.as<uint32_t>()));
+    if (packed && (int64_t)n_exc > nrows / 4) a->da_state = -1;  // the range of the first batch does not describe the input: 64-bit H mode from here on
     a->fast_batches++;
     *done = true;
     return TSQ_OK;
@@ -1277,7 +1394,11 @@ TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols,
         }
         return TSQ_OK;
     }
-    if (a->stage.cap == 0) TSQ_TRY(a->stage.init(&a->hdr, n_cols, a->cfg.input_types, 4 << 20));
+    if (a->stage.cap == 0) {
+        int64_t batch = 4 << 20;  // host chunks are aggregated in device batches of this many rows (test knob: TSQ_AGG_BATCH_ROWS)
+        if (const char* e = getenv("TSQ_AGG_BATCH_ROWS")) batch = std::max<int64_t>(1024, (atoll(e) + 63) & ~63LL);
+        TSQ_TRY(a->stage.init(&a->hdr, n_cols, a->cfg.input_types, batch));
+    }
     int64_t off = 0;
     while (off < nrows) {
         int64_t n = std::min<int64_t>(nrows - off, a->stage.room());
@@ -1522,6 +1643,7 @@ TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
     a->st.table_buckets = (int64_t)a->tb.cap;
     a->st.radix_batches = a->fast_batches;
     a->st.radix_overflow_rows = a->fast_fallbacks;
+    a->st.packed_key_bits = a->packed_batches > 0 ? (int32_t)a->da_dm.b : 0;
     *out = a->st;
     return TSQ_OK;
 }
