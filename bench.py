@@ -349,6 +349,7 @@ def main():
         for key, fn in (("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
+                        ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
                         ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr))):
             try:
                 out[key] = fn()
@@ -498,23 +499,31 @@ def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3):
                       "(it also lays the build payload out in table-slot order, once per build)" % reps}
 
 
-def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_000):
+def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_000, double=False):
     """BASELINE configs[2]: SELECT k, SUM(v), COUNT(*) GROUP BY k, 1e9 rows / 1e6 int64 groups; the rows are generated batch by
-    batch on the device (untimed) and pushed device resident, like the chunks of a GPU child operator."""
+    batch on the device (untimed) and pushed device resident, like the chunks of a GPU child operator.  v = r mod 1000 (BIGINT:
+    bit-exact SUM) or, double=True, a double in [0, 1) (BASELINE.md C3's primary shape).  Verified against numpy on host copies of the
+    value batches: sum of the groups' counts = rows, sum of the groups' sums = sum of all values (exact for BIGINT, within the
+    re-ordering bound 2 n 2^-53 sum|v| for doubles), every key in [0, groups) exactly once."""
+    import numpy as np
+
     lib = ctx.lib
+    vt = abi.F64 if double else abi.I64
     k, v = ctx.alloc(batch * 8), ctx.alloc(batch * 8)
     try:
         cfg = abi.AggCfg()
         cfg.n_group_keys = 1
         cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
         cfg.n_input_cols = 2
-        cfg.input_types[0], cfg.input_types[1] = abi.I64, abi.I64
+        cfg.input_types[0], cfg.input_types[1] = abi.I64, vt
         cfg.n_aggs = 3
-        for i, (f, col) in enumerate([(abi.AGG_FIRSTROW, 0), (abi.AGG_SUM, 1), (abi.AGG_COUNT, -1)]):
-            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
+        for i, (f, col, t) in enumerate([(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, vt), (abi.AGG_COUNT, -1, abi.I64)]):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, t
         cfg.est_groups = groups
         runs = []
-        for _ in range(2):  # the second run finds its partition / group buffers in the context's pool (hipMalloc costs ~35 ms per GB)
+        want_sum, want_abs = 0, 0.0
+        check = {}
+        for run in range(2):  # the second run finds its partition / group buffers in the context's pool (hipMalloc costs ~35 ms per GB)
             h = C.c_void_p()
             _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
             try:
@@ -522,10 +531,22 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
                 while done < n:
                     m = min(batch, n - done)
                     ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=0, m=groups, start=done), m, k)
-                    ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=1, m=1000, start=done), m, v)
+                    if double:
+                        ctx.gen_column(_spec(abi, abi.GEN_RAND_F64, table=3, col=1, start=done), m, v)
+                    else:
+                        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=1, m=1000, start=done), m, v)
                     ctx.sync()
+                    if run == 1:  # the independent total of the values (numpy on a host copy)
+                        host = np.empty(m, dtype=np.float64 if double else np.int64)
+                        ctx.d2h(host, v)
+                        if double:
+                            want_sum += float(host.sum(dtype=np.float64))
+                            want_abs += float(np.abs(host).sum())
+                        else:
+                            want_sum += int(host.sum(dtype=np.int64))
+                        del host
                     ctx.timer_start()
-                    _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m)), 2, m), h)
+                    _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m, vt)), 2, m), h)
                     ms += ctx.timer_stop_ms()
                     done += m
                 ctx.timer_start()
@@ -533,7 +554,33 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
                 ms += ctx.timer_stop_ms()
                 ng = C.c_int64(0)
                 _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
                 runs.append(ms)
+                if run == 1:  # pull the groups: (firstrow k, sum, count)
+                    cap = 1 << 20
+                    bufs = [np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float64 if double else np.int64), np.empty(cap, dtype=np.int64)]
+                    keys_seen = np.zeros(groups, dtype=np.uint8)
+                    got_rows, got_cnt, got_sum, bad_keys = 0, 0, 0, 0
+                    while True:
+                        out = (abi.Col * 3)()
+                        for i, b in enumerate(bufs):
+                            out[i].data, out[i].length, out[i].elem_size, out[i].type = b.ctypes.data_as(C.c_void_p), cap, 8, (abi.I64, vt, abi.I64)[i]
+                        nn, eos = C.c_int64(0), C.c_int32(0)
+                        _lib.check(lib.tsq_agg_pull(h, out, 3, cap, C.byref(nn), C.byref(eos)), h)
+                        if nn.value == 0:
+                            break
+                        kk = bufs[0][:nn.value]
+                        ok = (kk >= 0) & (kk < groups)
+                        bad_keys += int((~ok).sum())
+                        np.add.at(keys_seen, kk[ok], 1)
+                        got_rows += nn.value
+                        got_cnt += int(bufs[2][:nn.value].sum())
+                        got_sum += float(bufs[1][:nn.value].sum()) if double else int(bufs[1][:nn.value].sum())
+                    tol = 2.0 * n * 2.0 ** -53 * want_abs * 2 if double else 0
+                    check = {"groups_pulled": got_rows, "sum_of_counts": got_cnt, "sum_of_sums": got_sum, "sum_of_values_numpy": want_sum,
+                             "every_key_once": bool(bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1),
+                             "ok": bool(got_cnt == n and abs(got_sum - want_sum) <= tol and bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1)}
             finally:
                 lib.tsq_agg_destroy(h)
         ms = runs[-1]
@@ -541,8 +588,10 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
         ctx.free(k)
         ctx.free(v)
     algo = 16.0 * n + 24.0 * ng.value
-    return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows / 1e6 int64 groups, HashAggExec", "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value,
-            "frac": algo / ms / 1e6 / 8000.0, "verified": ng.value == groups, "first_run_ms": runs[0],
+    return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows / 1e6 int64 groups, v %s, HashAggExec" % ("double in [0, 1)" if double else "BIGINT r mod 1000"),
+            "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value,
+            "frac": algo / ms / 1e6 / 8000.0, "verified": bool(ng.value == groups and check.get("ok")), "check": check, "first_run_ms": runs[0],
+            "route": "packed keys: %d-bit key range, 2-byte entries + argument cells, direct-addressed LDS accumulators" % st.packed_key_bits if st.packed_key_bits else "64-bit table words, LDS hash tables",
             "timing": "HIP events around every tsq_agg_push (%d device-resident batches of %.3g rows) + tsq_agg_finish; second of two runs" % ((n + batch - 1) // batch, batch)}
 
 
