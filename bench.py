@@ -560,12 +560,14 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
                 if run == 1:  # pull the groups: (firstrow k, sum, count)
                     cap = 1 << 20
                     bufs = [np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float64 if double else np.int64), np.empty(cap, dtype=np.int64)]
+                    bms = [np.zeros(cap // 8 + 16, dtype=np.uint8) for _ in range(3)]
                     keys_seen = np.zeros(groups, dtype=np.uint8)
                     got_rows, got_cnt, got_sum, bad_keys = 0, 0, 0, 0
                     while True:
                         out = (abi.Col * 3)()
                         for i, b in enumerate(bufs):
                             out[i].data, out[i].length, out[i].elem_size, out[i].type = b.ctypes.data_as(C.c_void_p), cap, 8, (abi.I64, vt, abi.I64)[i]
+                            out[i].null_bitmap = bms[i].ctypes.data_as(C.c_void_p)
                         nn, eos = C.c_int64(0), C.c_int32(0)
                         _lib.check(lib.tsq_agg_pull(h, out, 3, cap, C.byref(nn), C.byref(eos)), h)
                         if nn.value == 0:
