@@ -197,9 +197,10 @@ typedef struct tsq_expr_op {
 #define TSQ_EXPR_MAX_CONSTS 32
 #define TSQ_EXPR_STR_POOL 256
 
-/* One expression tree in postfix form.  result_type: TSQ_I64 (Int, also used for U64) or TSQ_F64: the ROOT of a program is
- * Int or Real (a projection that is a bare string column is a column swap in the reference too, chunk.go:231-235; a string-valued
- * root such as IF(c, s1, s2) keeps the Go evaluator).  String-valued nodes below the root are evaluated here. */
+/* One expression tree in postfix form.  result_type: TSQ_I64 (Int, also used for U64), TSQ_F64, or TSQ_BYTES for a STRING-valued
+ * root — builtinIfStringSig / builtinIfNullStringSig.vecEvalString (builtin_control_vec_generated.go:209, :81), a string column
+ * (Column.VecEvalString, column.go:111) or constant (constant.go:86) — which tsq_expr_eval_str evaluates into a var-len column;
+ * tsq_expr_eval, tsq_filter_eval and the join's conditions / filters take Int and Real roots only. */
 typedef struct tsq_expr_prog {
     int32_t     n_ops;
     int32_t     n_consts;
@@ -222,6 +223,16 @@ tsq_status tsq_expr_compile(tsq_ctx* ctx, const tsq_expr_prog* progs, int32_t n_
  * div_by_zero_warnings (optional) receives the number of x/0 rows (errors.go:65-77). */
 tsq_status tsq_expr_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows,
                          const int32_t* sel, tsq_col* out, int64_t* div_by_zero_warnings);
+/* String-valued root (prog.result_type TSQ_BYTES): the result is a var-len column — ProjectionExec's evaluatorSuite on an ETString
+ * expression (executor/projection.go:160, expression/evaluator.go:54-133 -> VecEvalString, expression.go:329-341).  Replaces
+ * builtinIfStringSig / builtinIfNullStringSig.vecEvalString (expression/builtin_control_vec_generated.go:209, :81: per row
+ * AppendNull or AppendString of the chosen argument), Column.VecEvalString (column.go:111: CopyReconstruct through sel) and
+ * Constant.VecEvalString (constant.go:86: the value n times).  out->offsets holds nrows + 1 entries, out->data cap_bytes bytes,
+ * out->null_bitmap (nrows + 7) / 8 bytes; same placement (host / TSQ_COL_DEVICE) as the inputs.  *bytes_out = the data bytes of
+ * the result; cap_bytes < that (0: only ask) -> nothing but *bytes_out is written and the call returns TSQ_ERR_INVALID.  A NULL row
+ * has no bytes (offsets repeat) and a clear bitmap bit, as AppendNull leaves it (util/chunk/column.go:150-158). */
+tsq_status tsq_expr_eval_str(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel, tsq_col* out,
+                             int64_t cap_bytes, int64_t* bytes_out, int64_t* div_by_zero_warnings);
 /* Filter form (chunk_executor.go:196 VectorizedFilter / expression.go:205 VecEvalBool):
  * selected_out[i] (one byte per row, Go []bool) = row passes every conjunct, non-NULL.
  * isnull_out (optional) mirrors VecEvalBool's `nulls` for Int-typed conjuncts. */

@@ -228,6 +228,30 @@ def expr_eval(prog, chunk):
     return Column(tp, arr, nn[:n].astype(bool)), w.value
 
 
+def expr_eval_str(prog, chunk):
+    """string-valued root: returns (offsets[n + 1], data bytes, notnull bool[n], warnings) — the state of the result column."""
+    lib = load()
+    keep = []
+    cols = make_cols(chunk.columns, keep)
+    n = chunk.NumRows()
+    offs = np.zeros(n + 1, dtype=np.int64)
+    nn = np.zeros(max(n, 1), dtype=np.uint8)
+    w, need = C.c_int64(0), C.c_int64(0)
+    sel = chunk.sel.ctypes.data_as(C.c_void_p) if chunk.sel is not None else None
+    lib.orc_expr_eval_str.restype = C.c_int32
+    args = lambda data, cap: (C.byref(prog), cols, C.c_int32(len(chunk.columns)), C.c_int64(n), sel, offs.ctypes.data_as(C.c_void_p),
+                              data.ctypes.data_as(C.c_void_p), C.c_int64(cap), nn.ctypes.data_as(C.c_void_p), C.byref(need), C.byref(w))
+    data = np.zeros(8, dtype=np.uint8)
+    st = lib.orc_expr_eval_str(*args(data, 0))
+    if st != abi.OK:
+        raise OracleError(st)
+    data = np.zeros(need.value + 8, dtype=np.uint8)
+    st = lib.orc_expr_eval_str(*args(data, need.value))
+    if st != abi.OK:
+        raise OracleError(st)
+    return offs, data[:need.value], nn[:n].astype(bool), w.value
+
+
 def filter_eval(progs, n_progs, chunk):
     """returns (selected bool[], nulls bool[], warnings) or raises OracleError."""
     lib = load()

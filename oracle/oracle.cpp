@@ -732,7 +732,9 @@ tsq_status eval_prog(const tsq_expr_prog& p, EvalCtx& cx, ECol& out) {
         }
     }
     if (st.size() != 1) { g_err = "malformed program: stack depth != 1"; return TSQ_ERR_INVALID; }
-    if (st.back().str) { g_err = "string-valued root"; return TSQ_ERR_UNSUPPORTED; }
+    // a string-valued root is a VecEvalString call (orc_expr_eval_str); VecEvalInt / VecEvalReal / VecEvalBool callers declare an
+    // Int or Real result
+    if (st.back().str != (p.result_type == TSQ_BYTES)) { g_err = "string-valued root <=> result_type TSQ_BYTES"; return TSQ_ERR_UNSUPPORTED; }
     out = std::move(st.back());
     return TSQ_OK;
 }
@@ -1270,6 +1272,33 @@ tsq_status orc_expr_eval(const tsq_expr_prog* prog, const tsq_col* cols, int32_t
         if (r.real) ((double*)out_data)[i] = r.null[i] ? 0.0 : r.f[i];
         else ((int64_t*)out_data)[i] = r.null[i] ? 0 : r.i[i];
     }
+    return TSQ_OK;
+}
+
+tsq_status orc_expr_eval_str(const tsq_expr_prog* prog, const tsq_col* cols, int32_t n_cols, int64_t nrows, const int32_t* sel,
+                             int64_t* out_offsets, uint8_t* out_data, int64_t cap_bytes, uint8_t* out_notnull, int64_t* bytes_out,
+                             int64_t* div_by_zero_warnings) {
+    EvalCtx cx{cols, n_cols, nrows, sel};
+    ECol r;
+    tsq_status s = eval_prog(*prog, cx, r);
+    if (div_by_zero_warnings) *div_by_zero_warnings = cx.warnings;
+    if (s != TSQ_OK) return s;
+    if (!r.str) { g_err = "the root of the program is not string-valued"; return TSQ_ERR_INVALID; }
+    // Column.AppendNull of a var-len column repeats the last offset (no bytes), AppendString appends the bytes
+    // (util/chunk/column.go:150-158, 220-226)
+    int64_t pos = 0;
+    out_offsets[0] = 0;
+    for (int64_t i = 0; i < nrows; i++) {
+        if (out_notnull) out_notnull[i] = r.null[i] ? 0 : 1;
+        if (!r.null[i]) {
+            const std::string& v = r.s[i];
+            for (size_t b = 0; b < v.size(); b++)
+                if (pos + (int64_t)b < cap_bytes) out_data[pos + b] = (uint8_t)v[b];
+            pos += (int64_t)v.size();
+        }
+        out_offsets[i + 1] = pos;
+    }
+    if (bytes_out) *bytes_out = pos;
     return TSQ_OK;
 }
 

@@ -87,6 +87,14 @@ orc_result* orc_hash_agg_timed(const tsq_agg_cfg* cfg, const tsq_col* cols, int6
 tsq_status orc_expr_eval(const tsq_expr_prog* prog, const tsq_col* cols, int32_t n_cols,
                          int64_t nrows, const int32_t* sel, void* out_data, uint8_t* out_notnull,
                          int64_t* div_by_zero_warnings);
+/* expression.VecEvalString (expression.go:329-341) for a STRING-valued root: builtinIfStringSig / builtinIfNullStringSig
+ * .vecEvalString (builtin_control_vec_generated.go:209, :81: result.ReserveString(n), then AppendNull or AppendString per row),
+ * Column.VecEvalString (column.go:111-130: CopyReconstruct through sel), Constant.VecEvalString (constant.go:86).  Output = the
+ * state of the result column: out_offsets[nrows + 1], its data bytes (at most cap_bytes are written; *bytes_out = all of them),
+ * out_notnull (1 byte/row). */
+tsq_status orc_expr_eval_str(const tsq_expr_prog* prog, const tsq_col* cols, int32_t n_cols, int64_t nrows, const int32_t* sel,
+                             int64_t* out_offsets, uint8_t* out_data, int64_t cap_bytes, uint8_t* out_notnull, int64_t* bytes_out,
+                             int64_t* div_by_zero_warnings);
 /* expression.VecEvalBool / VectorizedFilter (expression.go:205-279, chunk_executor.go:196) */
 tsq_status orc_filter_eval(const tsq_expr_prog* progs, int32_t n_progs, const tsq_col* cols,
                            int32_t n_cols, int64_t nrows, const int32_t* sel,

@@ -96,3 +96,81 @@ def test_string_leaf_on_a_fixed_width_column_is_rejected(ctx):
         assert ei.value.status == abi.ERR_INVALID
     finally:
         ce.close()
+
+
+# ------------------------------------------------------------------ string-valued ROOTS (tsq_expr_eval_str)
+# builtinIfStringSig / builtinIfNullStringSig.vecEvalString (builtin_control_vec_generated.go:209, :81), Column.VecEvalString with a
+# selection vector (column.go:111), Constant.VecEvalString (constant.go:86): the result is a var-len COLUMN; its offsets, its data
+# bytes and its NULL flags are compared with the oracle's.
+STR_ROOTS = {
+    "if(int,col,col)": E.ScalarFunction("if", I3, S0, S1),
+    "if(cmp,col,const)": E.ScalarFunction("if", E.ScalarFunction("lt", S0, S1), S2, E.Constant("otherwise")),
+    "if(isnull,const,col)": E.ScalarFunction("if", E.ScalarFunction("isnull", S2), E.Constant(""), S2),
+    "ifnull(col,col)": E.ScalarFunction("ifnull", S2, S0),
+    "ifnull(col,const)": E.ScalarFunction("ifnull", S2, E.Constant(b"\x00nul\xff")),
+    "ifnull(ifnull)": E.ScalarFunction("ifnull", S2, E.ScalarFunction("ifnull", S1, E.Constant(None, E.ETString))),
+    "if(nested)": E.ScalarFunction("if", I3, E.ScalarFunction("ifnull", S2, S1), E.ScalarFunction("if", E.ScalarFunction("eq", S1, S2), S0, E.Constant("x" * 40))),
+    "column": S1,
+    "constant": E.Constant("a constant"),
+    "null constant": E.Constant(None, E.ETString),
+}
+
+
+def _same_column(got, want):
+    go, gd, gn = got
+    wo, wd, wn = want[0], want[1], want[2]
+    assert (gn == wn).all()
+    assert (go == wo).all()
+    assert bytes(gd) == bytes(wd)
+
+
+@pytest.mark.parametrize("name", sorted(STR_ROOTS))
+@pytest.mark.parametrize("jit", [abi.JIT_OFF, abi.JIT_FORCE])
+def test_string_valued_root_column_bytes_vs_oracle(ctx, orc, name, jit):
+    chk = inputs(13, 20_000)
+    e = STR_ROOTS[name]
+    prog = E.compile_expr(e)
+    assert prog.result_type == abi.BYTES
+    ce = E.CompiledExpr(ctx, [e], jit=jit)
+    try:
+        _same_column(ce.VecEvalString(chk), orc.expr_eval_str(prog, chk))
+        sel = np.random.default_rng(5).permutation(20_000)[:6001].astype(np.int32)  # an UNSORTED selection vector: rows are gathered in its order
+        chk_sel = Chunk(chk.columns, sel=sel)
+        _same_column(ce.VecEvalString(chk_sel), orc.expr_eval_str(prog, chk_sel))
+    finally:
+        ce.close()
+
+
+def test_string_valued_root_long_cells_and_edges(ctx, orc):
+    # cells of a few KB (one wave copies one cell), an empty chunk, one row, all-NULL results
+    rng = np.random.default_rng(3)
+    big = [None if rng.random() < 0.1 else bytes(rng.integers(0, 256, int(rng.integers(0, 5000)), dtype=np.uint8)) for _ in range(300)]
+    chk = Chunk([StrColumn(big), StrColumn(big[::-1]), StrColumn([None] * 300), Column(abi.I64, rng.integers(0, 2, 300), rng.random(300) > 0.3)])
+    for e in (E.ScalarFunction("if", I3, S0, S1), E.ScalarFunction("ifnull", S2, S0), S2):
+        ce = E.CompiledExpr(ctx, [e])
+        try:
+            _same_column(ce.VecEvalString(chk), orc.expr_eval_str(E.compile_expr(e), chk))
+            for m in (0, 1):
+                part = chk.slice(0, m)
+                _same_column(ce.VecEvalString(part), orc.expr_eval_str(E.compile_expr(e), part))
+        finally:
+            ce.close()
+
+
+def test_string_root_and_numeric_entry_points_do_not_mix(ctx):
+    from tinysql_amd import _lib
+    chk = inputs(1, 100)
+    ce = E.CompiledExpr(ctx, [E.ScalarFunction("ifnull", S2, S0)])
+    try:
+        with pytest.raises(_lib.TsqError) as ei:
+            ce.VecEval(chk)  # tsq_expr_eval: Int / Real roots only
+        assert ei.value.status == abi.ERR_UNSUPPORTED
+    finally:
+        ce.close()
+    ce = E.CompiledExpr(ctx, [E.ScalarFunction("length", S0)])
+    try:
+        with pytest.raises(_lib.TsqError) as ei:
+            ce.VecEvalString(chk)
+        assert ei.value.status == abi.ERR_INVALID
+    finally:
+        ce.close()

@@ -268,5 +268,11 @@ def test_string_program_validation(sim):
     prog.ops[1].opcode = abi.OP_NEG_INT                                                                 # a number operator on a string value
     assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_INVALID
     prog = E.compile_expr(E.ScalarFunction("length", S0))
-    prog.n_ops = 1                                                                                      # string-valued root
-    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_UNSUPPORTED
+    prog.n_ops = 1                                                                                      # a string-valued root ...
+    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_INVALID                                        # ... declared as an Int result
+    prog.result_type = abi.BYTES                                                                        # ... declared as such: tsq_expr_eval_str
+    assert sim.sim_validate(C.byref(prog), 1) == abi.OK
+    prog = E.compile_expr(E.ScalarFunction("ifnull", S0, E.Constant("x")))
+    assert prog.result_type == abi.BYTES and sim.sim_validate(C.byref(prog), 1) == abi.OK
+    prog.result_type = abi.I64
+    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_INVALID

@@ -67,6 +67,37 @@ def test_in_ifnull_if_isnull_protocols():
     assert ev(E.ScalarFunction("isnull", E.ScalarFunction("if", E.Column(2, abi.I64), S0, S1)), chk) == [0, 0, 0, 1, 1]
 
 
-def test_string_valued_root_is_refused():
-    with pytest.raises(E.Unsupported):
-        E.compile_expr(E.ScalarFunction("ifnull", S0, S1))
+def test_string_valued_root_is_declared_as_such():
+    # round 3: a string-valued root compiles to result_type TSQ_BYTES (tsq_expr_eval_str evaluates it into a var-len column)
+    assert E.compile_expr(E.ScalarFunction("ifnull", S0, S1)).result_type == abi.BYTES
+    assert E.compile_expr(E.ScalarFunction("length", E.ScalarFunction("ifnull", S0, S1))).result_type == abi.I64
+
+
+def test_oracle_string_valued_roots_vs_python(orc):
+    """builtinIfStringSig / builtinIfNullStringSig.vecEvalString (builtin_control_vec_generated.go:209-255, :81-115): per row
+    AppendNull or AppendString of the chosen argument; Column.VecEvalString through a selection vector (column.go:111-130);
+    Constant.VecEvalString (constant.go:86).  The reference holds no golden bytes for them (its tests are vec == row on random data),
+    so the restatement is pinned on a row-at-a-time Python statement of the same rules, on the column STATE (offsets, bytes, NULLs)."""
+    rng = np.random.default_rng(77)
+    n = 3000
+    a, b, c = rand_strs(rng, n), rand_strs(rng, n, 0.4), rand_strs(rng, n)
+    cond = rng.integers(-1, 2, n)
+    cnn = rng.random(n) > 0.2
+    chk = Chunk([StrColumn(a), StrColumn(b), StrColumn(c), Column(abi.I64, cond, cnn)])
+    S0, S1, S2, I3 = E.Column(0, abi.BYTES), E.Column(1, abi.BYTES), E.Column(2, abi.BYTES), E.Column(3, abi.I64)
+    sel = rng.permutation(n)[:1111].astype(np.int32)
+    cases = [
+        (E.ScalarFunction("if", I3, S0, S1), lambda i: a[i] if (cnn[i] and cond[i] != 0) else b[i]),   # :237-249: NULL or 0 condition -> third argument
+        (E.ScalarFunction("ifnull", S1, S2), lambda i: b[i] if b[i] is not None else c[i]),            # :100-110
+        (E.ScalarFunction("ifnull", S1, E.Constant("dflt")), lambda i: b[i] if b[i] is not None else b"dflt"),
+        (S2, lambda i: c[i]),
+        (E.Constant("k"), lambda i: b"k"),
+        (E.Constant(None, E.ETString), lambda i: None),
+    ]
+    for e, rule in cases:
+        for ch, idx in ((chk, range(n)), (Chunk(chk.columns, sel=sel), sel.tolist())):
+            offs, data, nn, _ = orc.expr_eval_str(E.compile_expr(e), ch)
+            want = [rule(i) for i in idx]
+            assert nn.tolist() == [v is not None for v in want]
+            assert bytes(data) == b"".join(v for v in want if v is not None)
+            assert offs.tolist() == [0] + np.cumsum([0 if v is None else len(v) for v in want]).tolist()

@@ -175,6 +175,7 @@ SIGNATURES = {
     "tsq_gen_column": (C.c_int32, [P, C.POINTER(GenSpec), C.c_int64, P, P, P]),
     "tsq_expr_compile": (C.c_int32, [P, C.POINTER(ExprProg), C.c_int32, PP]),
     "tsq_expr_eval": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.POINTER(Col), C.POINTER(C.c_int64)]),
+    "tsq_expr_eval_str": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, C.POINTER(Col), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tsq_filter_eval": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, P, P, C.POINTER(C.c_int64)]),
     "tsq_expr_set_jit": (C.c_int32, [P, C.c_int32]),
     "tsq_expr_jit_launches": (C.c_int64, [P]),

@@ -747,8 +747,10 @@ inline tsq_status tsq_validate_prog(const tsq_expr_prog& p, int32_t n_cols, cons
         is_str[sp - 1] = res_str;
     }
     if (sp != 1) { *why = "program leaves stack depth != 1"; return TSQ_ERR_INVALID; }
-    if (is_str[0]) { *why = "string-valued root: not evaluated on the GPU"; return TSQ_ERR_UNSUPPORTED; }
-    if (p.result_type != TSQ_I64 && p.result_type != TSQ_F64) { *why = "result_type must be TSQ_I64 or TSQ_F64"; return TSQ_ERR_INVALID; }
+    // a string-valued root (IF / IFNULL of strings, a string column, a string constant) is declared by result_type TSQ_BYTES and
+    // evaluated by tsq_expr_eval_str only; conditions and filters need an Int or Real root
+    if (is_str[0] != (p.result_type == TSQ_BYTES)) { *why = "result_type does not match the root (TSQ_BYTES <=> a string-valued root)"; return TSQ_ERR_INVALID; }
+    if (p.result_type != TSQ_I64 && p.result_type != TSQ_F64 && p.result_type != TSQ_BYTES) { *why = "result_type must be TSQ_I64, TSQ_F64 or TSQ_BYTES"; return TSQ_ERR_INVALID; }
     return TSQ_OK;
 }
 

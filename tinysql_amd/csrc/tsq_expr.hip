@@ -90,13 +90,54 @@ __global__ void __launch_bounds__(256) k_filter_eval(ExprArgs a) {
     if (div0) atomicAdd(&a.counters[1], (unsigned long long)div0);
 }
 
+// K9s — a string-valued root: the evaluation kernels leave a REFERENCE per row (source column or the program's constant pool,
+// offset, length: tsq_device.h); the lengths of the non-NULL rows, their exclusive scan (= offsets[nrows + 1]) and one copy pass
+// make the var-len column AppendNull / AppendString would have built (builtin_control_vec_generated.go:81-115, 209-255).
+struct StrRootArgs {
+    const uint64_t* refs;
+    const uint8_t* notnull;
+    int64_t nrows;
+    tsq_colset in;
+    const tsq_expr_prog* prog;  // device: the constant pool
+    int64_t* offs;
+    uint8_t* data;
+};
+__global__ void __launch_bounds__(256) k_expr_str_len(StrRootArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nrows; i += (int64_t)gridDim.x * 256)
+        a.offs[i] = a.notnull[i] ? (int64_t)tsq_str_len(a.refs[i]) : 0;
+}
+__device__ __forceinline__ const uint8_t* str_root_src(const StrRootArgs& a, uint64_t ref) {
+    const uint32_t src = (uint32_t)(ref >> 56);
+    const uint32_t off = (uint32_t)ref;
+    return src == TSQ_STR_POOL ? a.prog->str_pool + off : (const uint8_t*)a.in.data[src] + off;
+}
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_expr_str_copy(StrRootArgs a) {
+    if (!WAVE) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nrows; i += (int64_t)gridDim.x * 256) {
+            const int64_t n = a.offs[i + 1] - a.offs[i];
+            if (n > 0) tsq_copy_cell(a.data + a.offs[i], str_root_src(a, a.refs[i]), n);
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63;  // long cells: one row per wave, 64 lanes on consecutive bytes
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t i = wave; i < a.nrows; i += nwaves) {
+        const int64_t n = a.offs[i + 1] - a.offs[i];
+        if (n <= 0) continue;
+        const uint8_t* s = str_root_src(a, a.refs[i]);
+        uint8_t* d = a.data + a.offs[i];
+        for (int64_t b = lane; b < n; b += 64) d[b] = s[b];
+    }
+}
+
 struct tsq_expr {
     tsq_handle_hdr hdr;
     tsq_ctx* ctx = nullptr;
     std::vector<tsq_expr_prog> progs;
     DevBuf progs_d, counters;
     std::vector<ColStore> icols;  // device copies of host input chunks
-    DevBuf sel_d, out_data, out_nn, out_bitmap, out_sel, out_isnull;
+    DevBuf sel_d, out_data, out_nn, out_bitmap, out_sel, out_isnull, str_offs, str_data, scan_tmp;
     PinnedBuf hout, hflags;
     int64_t launches = 0;
     // run-time specialised kernels (hiprtc): the postfix programs become compile-time constants, the interpreter
@@ -363,13 +404,22 @@ static bool jit_launch(tsq_expr* e, bool filter, ExprArgs& a, int grid) {
 }
 
 static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel,
-                           tsq_col* out, uint8_t* selected_out, uint8_t* isnull_out, int64_t* div0_out) {
+                           tsq_col* out, uint8_t* selected_out, uint8_t* isnull_out, int64_t* div0_out, bool str_root = false,
+                           int64_t cap_bytes = 0, int64_t* bytes_out = nullptr) {
     tsq_ctx* ctx = e->ctx;
     tsq_handle_hdr* h = &e->hdr;
     if (nrows < 0 || (nrows > 0 && n_cols > 0 && !in_cols)) return tsq_fail(h, TSQ_ERR_INVALID, "bad arguments");
     if (div0_out) *div0_out = 0;
-    if (nrows == 0) return TSQ_OK;
+    if (bytes_out) *bytes_out = 0;
+    if (nrows == 0) {
+        if (str_root && out && out->offsets && !(out->flags & TSQ_COL_DEVICE)) out->offsets[0] = 0;
+        if (str_root && out) { out->length = 0; out->type = TSQ_BYTES; }
+        return TSQ_OK;
+    }
     for (size_t p = 0; p < e->progs.size(); p++) {
+        if ((e->progs[p].result_type == TSQ_BYTES) != str_root)
+            return tsq_fail(h, str_root ? TSQ_ERR_INVALID : TSQ_ERR_UNSUPPORTED,
+                            str_root ? "tsq_expr_eval_str needs a string-valued root (result_type TSQ_BYTES)" : "a string-valued root is evaluated by tsq_expr_eval_str");
         const char* why = "";
         int32_t ctypes[TSQ_MAX_COLS];
         for (int c = 0; c < n_cols && c < TSQ_MAX_COLS; c++) ctypes[c] = in_cols[c].type;
@@ -406,9 +456,10 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
     if (!filter) {
         const bool odev = out->flags & TSQ_COL_DEVICE;
         if (odev != dev) return tsq_fail(h, TSQ_ERR_INVALID, "output placement (host/device) must match the inputs");
-        if (!out->data || !out->null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "out needs data and null_bitmap buffers");
+        if (!out->null_bitmap || (!str_root && !out->data) || (str_root && (!out->offsets || (!out->data && cap_bytes > 0))))
+            return tsq_fail(h, TSQ_ERR_INVALID, "out needs data and null_bitmap buffers (and offsets for a string-valued root)");
         uint64_t* od = (uint64_t*)out->data;
-        if (!odev) {
+        if (!odev || str_root) {
             TSQ_TRY(e->out_data.reserve(ctx, h, (size_t)nrows * 8 + 16));
             od = e->out_data.as<uint64_t>();
         }
@@ -421,6 +472,60 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
         if (!odev) {
             TSQ_TRY(e->out_bitmap.reserve(ctx, h, tsq_bitmap_bytes(nrows) + 16));
             ob = e->out_bitmap.as<uint8_t>();
+        }
+        if (str_root) {
+            // references -> lengths -> offsets (exclusive scan) -> bytes; the caller's buffers are written only when the bytes fit
+            StrRootArgs sa;
+            memset(&sa, 0, sizeof sa);
+            sa.refs = od;
+            sa.notnull = a.out_notnull;
+            sa.nrows = nrows;
+            sa.in = a.in;
+            sa.prog = e->progs_d.as<tsq_expr_prog>();
+            TSQ_TRY(e->str_offs.reserve(ctx, h, ((size_t)nrows + 2) * 8));
+            sa.offs = e->str_offs.as<int64_t>();
+            hipLaunchKernelGGL(k_expr_str_len, dim3(grid), dim3(256), 0, ctx->stream, sa);
+            TSQ_HIP(h, hipGetLastError());
+            TSQ_TRY(tsq_launch_scan64(ctx, h, sa.offs, nrows, e->scan_tmp));
+            TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 2, sa.offs + nrows, 8, hipMemcpyDeviceToHost, ctx->stream));
+            TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, a.counters, 16, hipMemcpyDeviceToHost, ctx->stream));
+            TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+            e->launches++;
+            e->rows_seen += nrows;
+            if (div0_out) *div0_out = (int64_t)ctx->pinned[1];
+            TSQ_TRY(expr_status(e, ctx->pinned[0]));
+            const int64_t nbytes = (int64_t)ctx->pinned[2];
+            if (bytes_out) *bytes_out = nbytes;
+            if (nbytes > cap_bytes) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_expr_eval_str: the result needs " + std::to_string(nbytes) + " data bytes");
+            uint8_t* dd = (uint8_t*)out->data;
+            if (!odev) {
+                TSQ_TRY(e->str_data.reserve(ctx, h, (size_t)nbytes + 64));
+                dd = e->str_data.as<uint8_t>();
+            }
+            sa.data = dd;
+            if (nbytes > 0) {
+                if (nbytes / nrows > 32) hipLaunchKernelGGL(k_expr_str_copy<true>, dim3(ctx->num_cus * 8), dim3(256), 0, ctx->stream, sa);
+                else hipLaunchKernelGGL(k_expr_str_copy<false>, dim3(grid), dim3(256), 0, ctx->stream, sa);
+                TSQ_HIP(h, hipGetLastError());
+            }
+            uint8_t* sb = out->null_bitmap;
+            if (!odev) {
+                TSQ_TRY(e->out_bitmap.reserve(ctx, h, tsq_bitmap_bytes(nrows) + 16));
+                sb = e->out_bitmap.as<uint8_t>();
+            }
+            TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a.out_notnull, sb, nrows));
+            if (odev) {
+                TSQ_HIP(h, hipMemcpyAsync(out->offsets, sa.offs, ((size_t)nrows + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            } else {
+                TSQ_HIP(h, hipMemcpyAsync(out->offsets, sa.offs, ((size_t)nrows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                if (nbytes > 0) TSQ_HIP(h, hipMemcpyAsync(out->data, dd, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+                TSQ_HIP(h, hipMemcpyAsync(out->null_bitmap, sb, tsq_bitmap_bytes(nrows), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+            out->length = nrows;
+            out->elem_size = -1;
+            out->type = TSQ_BYTES;
+            return TSQ_OK;
         }
         TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a.out_notnull, ob, nrows));
         if (!odev) {
@@ -473,6 +578,15 @@ TSQ_API tsq_status tsq_expr_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_
     return expr_run(e, false, in_cols, n_cols, nrows, sel, out, nullptr, nullptr, div_by_zero_warnings);
 }
 
+TSQ_API tsq_status tsq_expr_eval_str(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel, tsq_col* out,
+                                     int64_t cap_bytes, int64_t* bytes_out, int64_t* div_by_zero_warnings) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(e, TSQ_MAGIC_EXPR));
+    if (!e || e->hdr.magic != TSQ_MAGIC_EXPR) return TSQ_ERR_INVALID;
+    if (!out || cap_bytes < 0) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "out == NULL or cap_bytes < 0");
+    if (e->progs.size() != 1) return tsq_fail(&e->hdr, TSQ_ERR_INVALID, "tsq_expr_eval_str needs a single program");
+    return expr_run(e, false, in_cols, n_cols, nrows, sel, out, nullptr, nullptr, div_by_zero_warnings, true, cap_bytes, bytes_out);
+}
+
 TSQ_API tsq_status tsq_filter_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows, const int32_t* sel,
                                    uint8_t* selected_out, uint8_t* isnull_out, int64_t* div_by_zero_warnings) {
     tsq_ctx_lock _api_lock(tsq_ctx_of(e, TSQ_MAGIC_EXPR));
@@ -499,6 +613,9 @@ TSQ_API void tsq_expr_destroy(tsq_expr* e) {
     (void)hipSetDevice(e->ctx->device);
     (void)hipStreamSynchronize(e->ctx->stream);
     e->progs_d.release();
+    e->str_offs.release();
+    e->str_data.release();
+    e->scan_tmp.release();
     e->counters.release();
     for (auto& c : e->icols) c.release();
     e->sel_d.release();

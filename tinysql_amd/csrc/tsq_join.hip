@@ -2107,11 +2107,13 @@ TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_jo
         }
         tsq_status s = tsq_validate_prog(cfg->other_conds[e], cfg->n_probe_cols + cfg->n_build_cols, &why, jt);
         if (s != TSQ_OK) return tsq_fail(ch, s, std::string("other condition: ") + why);
+        if (cfg->other_conds[e].result_type == TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "other condition: a string-valued condition keeps the Go evaluator");
     }
     for (int e = 0; e < cfg->n_outer_filters; e++) {
         const char* why = "";
         tsq_status s = tsq_validate_prog(cfg->outer_filters[e], cfg->n_probe_cols, &why, cfg->probe_types);
         if (s != TSQ_OK) return tsq_fail(ch, s, std::string("outer filter: ") + why);
+        if (cfg->outer_filters[e].result_type == TSQ_BYTES) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "outer filter: a string-valued filter keeps the Go evaluator");
     }
     TSQ_HIP(ch, hipSetDevice(ctx->device));
     std::unique_ptr<tsq_join> j(new tsq_join());

@@ -217,12 +217,11 @@ def compile_expr(e):
     _emit(e, ops, consts)
     if len(ops) > abi.EXPR_MAX_OPS or len(consts) > abi.EXPR_MAX_CONSTS:
         raise Unsupported("expression too large for the GPU interpreter")
-    if e.eval_type == ETString:
-        raise Unsupported("string-valued root: the Go evaluator keeps it (a bare string column is a column swap)")
     p = abi.ExprProg()
     p.n_ops = len(ops)
     p.n_consts = len(consts)
-    p.result_type = abi.F64 if e.eval_type == ETReal else abi.I64
+    # a string-valued root (IF / IFNULL of strings, a string column or constant) is evaluated by tsq_expr_eval_str
+    p.result_type = abi.BYTES if e.eval_type == ETString else (abi.F64 if e.eval_type == ETReal else abi.I64)
     p.result_unsigned = 1 if e.unsigned else 0
     for i, (opc, fl, arg, aux) in enumerate(ops):
         p.ops[i].opcode, p.ops[i].flags, p.ops[i].arg, p.ops[i].aux = opc, fl, arg, aux
@@ -294,6 +293,33 @@ class CompiledExpr:
         if tp == abi.U64:
             arr = arr.view(np.uint64)
         return ChunkColumn(tp, arr.copy(), unpack_bitmap(bm, n))
+
+    def VecEvalString(self, chk):
+        """expression.VecEvalString (expression.go:329-341 -> builtinIfStringSig / builtinIfNullStringSig.vecEvalString,
+        Column.VecEvalString, Constant.VecEvalString): returns (offsets[n + 1], data bytes, notnull bool[n]) — the state of the
+        var-len result column (util/chunk/column.go:28-34).  First call asks for the size, second one fills the buffers."""
+        n = chk.NumRows()
+        keep = []
+        cols = make_cols(chk.columns, keep)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        bm = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+        sel = chk.sel.ctypes.data_as(C.c_void_p) if chk.sel is not None else None
+        out = abi.Col()
+        out.offsets = offs.ctypes.data_as(C.c_void_p)
+        out.null_bitmap = bm.ctypes.data_as(C.c_void_p)
+        out.length, out.elem_size, out.type = n, -1, abi.BYTES
+        w, need = C.c_int64(0), C.c_int64(0)
+        st = self.lib.tsq_expr_eval_str(self.h, cols, len(chk.columns), n, sel, C.byref(out), 0, C.byref(need), C.byref(w))
+        if st != abi.OK and not (st == abi.ERR_INVALID and need.value > 0):
+            self.warnings += w.value
+            _lib.check(st, self.h)
+        data = np.zeros(need.value + 8, dtype=np.uint8)
+        if need.value > 0 or st != abi.OK:
+            out.data = data.ctypes.data_as(C.c_void_p)
+            st = self.lib.tsq_expr_eval_str(self.h, cols, len(chk.columns), n, sel, C.byref(out), need.value, C.byref(need), C.byref(w))
+        self.warnings += w.value
+        _lib.check(st, self.h)
+        return offs, data[:need.value], unpack_bitmap(bm, n)
 
     def VectorizedFilter(self, chk, want_nulls=False):
         """expression.VectorizedFilter (chunk_executor.go:196): returns selected[] (and nulls[])."""

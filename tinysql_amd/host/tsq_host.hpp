@@ -460,8 +460,9 @@ inline tsq_expr_prog Lower(const Expression& e) {
     tsq_expr_prog p;
     memset(&p, 0, sizeof p);
     emit(e, p);
-    if (e.evalType == ETString) throw Error(TSQ_ERR_UNSUPPORTED, "a string-valued root (VecEvalString) has no GPU signature: strings feed comparisons");
-    p.result_type = e.evalType == ETReal ? TSQ_F64 : TSQ_I64;
+    // a string-valued root (builtinIfStringSig / builtinIfNullStringSig.vecEvalString, a string column or constant) is declared as
+    // TSQ_BYTES and evaluated by tsq_expr_eval_str
+    p.result_type = e.evalType == ETString ? TSQ_BYTES : (e.evalType == ETReal ? TSQ_F64 : TSQ_I64);
     p.result_unsigned = e.isUnsigned ? 1 : 0;
     return p;
 }
@@ -542,6 +543,22 @@ public:
         auto in = child_->Views();
         for (size_t i = 0; i < compiled_.size(); i++) {
             Column& dst = req->columns[i];
+            if (dst.type == TSQ_BYTES) {  // VecEvalString (expression.go:329-341): ask for the bytes of the result, then fill the column
+                int64_t w = 0, need = 0;
+                dst.resizeFor(n, 0);
+                tsq_col ask = dst.View(n);
+                tsq_status s0 = tsq_expr_eval_str(compiled_[i]->h, in.data(), (int32_t)in.size(), n, nullptr, &ask, 0, &need, &w);
+                if (s0 != TSQ_OK && !(s0 == TSQ_ERR_INVALID && need > 0)) check(s0, compiled_[i]->h);
+                if (need > 0) {
+                    dst.resizeFor(n, need);
+                    tsq_col out = dst.View(n);
+                    check(tsq_expr_eval_str(compiled_[i]->h, in.data(), (int32_t)in.size(), n, nullptr, &out, need, &need, &w), compiled_[i]->h);
+                }
+                compiled_[i]->divisionByZeroWarnings += w;
+                dst.length = n;
+                dst.data.resize((size_t)need);
+                continue;
+            }
             dst.resizeFor(n);
             tsq_col out = dst.View(n);
             out.type = dst.type == TSQ_F64 ? TSQ_F64 : TSQ_I64;
@@ -556,7 +573,7 @@ public:
 private:
     static Schema types(const std::vector<Expression>& es) {
         Schema s;
-        for (auto& e : es) s.push_back(e.evalType == ETReal ? TSQ_F64 : (e.isUnsigned ? TSQ_U64 : TSQ_I64));
+        for (auto& e : es) s.push_back(e.evalType == ETString ? TSQ_BYTES : (e.evalType == ETReal ? TSQ_F64 : (e.isUnsigned ? TSQ_U64 : TSQ_I64)));
         return s;
     }
     std::vector<Expression> exprs_;

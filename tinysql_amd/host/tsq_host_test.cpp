@@ -197,6 +197,22 @@ int main() {
         expect("selection c1>1 and c1<>4; projection c1+1, c2/0, c2*2", render(one), {"3 <nil> 2", "4 <nil> 3", "6 <nil> 5"});
         expect_true("errors.go:65-77 division by zero -> NULL + one warning per row", warns == 3);
     }
+    // ---- a projection that computes STRINGS: select if(c > 2, s, 'small'), ifnull(s, 'none') — builtinIfStringSig /
+    //      builtinIfNullStringSig.vecEvalString (builtin_control_vec_generated.go:209, :81) through tsq_expr_eval_str
+    {
+        Chunk t(Schema{TSQ_I64, TSQ_BYTES});
+        const char* names[5] = {"one", "two", nullptr, "four", ""};
+        for (int i = 1; i <= 5; i++) {
+            t.columns[0].AppendInt64(i);
+            if (names[i - 1]) t.columns[1].AppendString(names[i - 1]);
+            else t.columns[1].AppendNull();
+        }
+        MockDataSource src(&ctx, t);
+        ProjectionExec proj(&ctx, &src, {Col(0, TSQ_I64), Func("if", {Func("gt", {Col(0, TSQ_I64), Int(2)}), Col(1, TSQ_BYTES), Str("small")}),
+                                         Func("ifnull", {Col(1, TSQ_BYTES), Str("none")})});
+        expect("projection c, if(c > 2, s, 'small'), ifnull(s, 'none')", render(Drain(&proj)),
+               {"1 small one", "2 small two", "3 <nil> none", "4 four four", "5  "});
+    }
     // ---- arithmetic overflow aborts the statement (builtin_arithmetic_vec.go:481-495 plusSS)
     {
         Chunk t = table_i64(1, {1, INT64_MAX});
