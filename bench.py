@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--exchange-chunks", type=int, default=4, help="N>1: pieces of the probe-side exchange (probe of piece c overlaps the exchange of c+1..)")
     ap.add_argument("--build-rows", type=int, default=100_000_000)
     ap.add_argument("--probe-rows", type=int, default=100_000_000)
+    ap.add_argument("--rows-global", type=int, default=0, help="TOTAL rows per side over all ranks (strong scaling; BASELINE configs[3] = "
+                    "--gpus 8 --rows-global 1000000000); default: --build-rows / --probe-rows PER rank (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-build-rows", type=int, default=20_000_000)
     ap.add_argument("--cpu-probe-rows", type=int, default=40_000_000)
@@ -72,6 +74,8 @@ def main():
         comm = parallel.Comm(ctx, rank, world)
 
     nb, npr = args.build_rows, args.probe_rows  # per GPU
+    if args.rows_global > 0:  # the whole join is fixed, every rank starts with 1 / world of both sides (rows are multiples of 64)
+        nb = npr = max(64, (args.rows_global // world) & ~63)
     nb_global = nb * world
     t_setup = time.time()
 
@@ -261,7 +265,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.rows_global > 0 else "weak",
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
@@ -560,18 +564,21 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
                 if run == 1:  # pull the groups: (firstrow k, sum, count)
                     cap = 1 << 20
                     bufs = [np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float64 if double else np.int64), np.empty(cap, dtype=np.int64)]
-                    bms = [np.zeros(cap // 8 + 16, dtype=np.uint8) for _ in range(3)]
+                    dbufs = [ctx.alloc(cap * 8) for _ in range(3)]  # device-resident pushes -> device-resident pulls, then a copy to the host
+                    dbms = [ctx.alloc(cap // 8 + 64) for _ in range(3)]
                     keys_seen = np.zeros(groups, dtype=np.uint8)
                     got_rows, got_cnt, got_sum, bad_keys = 0, 0, 0, 0
                     while True:
                         out = (abi.Col * 3)()
                         for i, b in enumerate(bufs):
-                            out[i].data, out[i].length, out[i].elem_size, out[i].type = b.ctypes.data_as(C.c_void_p), cap, 8, (abi.I64, vt, abi.I64)[i]
-                            out[i].null_bitmap = bms[i].ctypes.data_as(C.c_void_p)
+                            out[i].data, out[i].length, out[i].elem_size, out[i].type, out[i].flags = dbufs[i], cap, 8, (abi.I64, vt, abi.I64)[i], abi.COL_DEVICE
+                            out[i].null_bitmap = dbms[i]
                         nn, eos = C.c_int64(0), C.c_int32(0)
                         _lib.check(lib.tsq_agg_pull(h, out, 3, cap, C.byref(nn), C.byref(eos)), h)
                         if nn.value == 0:
                             break
+                        for i, b in enumerate(bufs):
+                            ctx.d2h(b[:nn.value], dbufs[i])
                         kk = bufs[0][:nn.value]
                         ok = (kk >= 0) & (kk < groups)
                         bad_keys += int((~ok).sum())
@@ -579,6 +586,8 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
                         got_rows += nn.value
                         got_cnt += int(bufs[2][:nn.value].sum())
                         got_sum += float(bufs[1][:nn.value].sum()) if double else int(bufs[1][:nn.value].sum())
+                    for pbuf in dbufs + dbms:
+                        ctx.free(pbuf)
                     tol = 2.0 * n * 2.0 ** -53 * want_abs * 2 if double else 0
                     check = {"groups_pulled": got_rows, "sum_of_counts": got_cnt, "sum_of_sums": got_sum, "sum_of_values_numpy": want_sum,
                              "every_key_once": bool(bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1),

@@ -1,6 +1,12 @@
-"""Worker for tests/test_dist_cpu.py: world_size-2 gloo run of the N>1 redistribute logic
-(tinysql_amd/parallel.py) with CPU stand-ins for the two GPU pieces (numpy split in place of
-tsq_radix_split, the oracle join in place of the HIP join)."""
+"""Worker for tests/test_dist_cpu.py: a world-size-2 (or more) gloo run of the SHIPPED exchange bookkeeping.
+
+tsq_redistribute (csrc/tsq_comm.hip) = split on the GPU + count all-gather + the transfers and offset shifts that
+csrc/tsq_comm_plan.h computes from the gathered matrix.  Here two real processes run that plan: the count vectors are
+all-gathered over gloo, every process gets ITS plan from the same header (tests/hostsim: sim_comm_plan), and the transfers are
+executed with torch.distributed send / recv on CPU byte tensors in the plan's issue order (a fixed-width nullable key, a double,
+a var-len column).  The split kernel is replaced by a stable numpy partition by tsq_key_rank, the wire by gloo — nothing else.
+Then the local join of what every rank received equals the whole join (the oracle, on rank 0)."""
+import ctypes as C
 import os
 import sys
 
@@ -12,106 +18,155 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import binding as orc  # noqa: E402
-from tests import gpu_helpers as G  # noqa: E402
 from tests import helpers as H  # noqa: E402
 from tinysql_amd import _abi as abi  # noqa: E402
-from tinysql_amd import parallel  # noqa: E402
-from tinysql_amd.chunk import Chunk, Column  # noqa: E402
+from tinysql_amd.chunk import Chunk, Column, StrColumn  # noqa: E402
+
+SIM = C.CDLL(os.path.join(ROOT, "tests", "hostsim", "hostsim.so"))
+SIM.sim_key_rank.restype = C.c_uint32
+SIM.sim_key_rank.argtypes = [C.c_uint64, C.c_uint32]
+DATA, OFFS, NOTNULL = 0, 1, 2
 
 
-def np_mix64(k):
-    with np.errstate(over="ignore"):
-        k = k ^ (k >> np.uint64(33))
-        k = k * np.uint64(0xFF51AFD7ED558CCD)
-        k = k ^ (k >> np.uint64(33))
-        k = k * np.uint64(0xC4CEB9FE1A85EC53)
-        return k ^ (k >> np.uint64(33))
+def key_ranks(keys, notnull, world):
+    return np.array([SIM.sim_key_rank(int(k) & ((1 << 64) - 1), world) if nn else 0 for k, nn in zip(keys.tolist(), notnull.tolist())], dtype=np.int64)
 
 
-def np_rank(keys_u64, parts):
-    return (((np_mix64(keys_u64) & np.uint64(0xFFFF)) * np.uint64(parts)) >> np.uint64(16)).astype(np.int64)
-
-
-def split(cols, key, parts):
-    r = np_rank(cols[key].view(np.uint64), parts)
-    order = np.argsort(r, kind="stable")
-    counts = np.bincount(r, minlength=parts).tolist()
-    return [c[order] for c in cols], counts
+def redistribute(rank, world, cols):
+    """cols: list of ('fixed', np array of 8-byte cells, notnull bool[] or None) / ('var', list of bytes-or-None).  Column 0 is the key.
+    Returns the received columns in the same form."""
+    n = len(cols[0][1])
+    knn = cols[0][2] if cols[0][2] is not None else np.ones(n, bool)
+    dest = key_ranks(cols[0][1].view(np.int64), knn, world)
+    order = np.argsort(dest, kind="stable")
+    sendc = np.bincount(dest, minlength=world).tolist()
+    es = [8 if c[0] == "fixed" else 0 for c in cols]
+    var_cols = [i for i, c in enumerate(cols) if c[0] == "var"]
+    L = world + 1 + len(var_cols) * world
+    # ---- the split: send buffers per (column, kind) as byte arrays
+    send = {}
+    mask = 0
+    for i, c in enumerate(cols):
+        if c[0] == "fixed":
+            send[(i, DATA)] = np.ascontiguousarray(c[1][order]).view(np.uint8)
+            nn = c[2][order] if c[2] is not None else np.ones(n, bool)
+            if c[2] is not None:
+                mask |= 1 << i
+        else:
+            vals = [c[1][j] for j in order.tolist()]
+            offs = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum([0 if v is None else len(v) for v in vals], out=offs[1:])
+            send[(i, OFFS)] = offs.view(np.uint8)
+            send[(i, DATA)] = np.frombuffer(b"".join(v for v in vals if v is not None), dtype=np.uint8).copy()
+            nn = np.array([v is not None for v in vals], dtype=bool)
+            if not nn.all():
+                mask |= 1 << i
+        send[(i, NOTNULL)] = nn.astype(np.uint8)
+    vec = np.zeros(L, dtype=np.int64)
+    vec[:world] = sendc
+    vec[world] = mask
+    for v, i in enumerate(var_cols):
+        offs = send[(i, OFFS)].view(np.int64)
+        row = 0
+        for p in range(world):
+            vec[world + 1 + v * world + p] = offs[row + sendc[p]] - offs[row]
+            row += sendc[p]
+    gathered = [torch.zeros(L, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(vec))  # = the ncclAllGather of the count vectors
+    M = np.concatenate([g.numpy() for g in gathered]).astype(np.uint64)
+    # ---- this rank's plan, from the header tsq_comm.hip executes
+    cap = 16 * len(cols) * world + 64
+    xf, sh = np.zeros(7 * cap, dtype=np.int64), np.zeros(5 * cap, dtype=np.int64)
+    total, pmask, nx, ns = C.c_int64(0), C.c_uint64(0), C.c_int32(0), C.c_int32(0)
+    rbytes = np.zeros(len(cols), dtype=np.int64)
+    rc = SIM.sim_comm_plan(rank, world, len(cols), (C.c_int32 * len(cols))(*es), M.ctypes.data_as(C.c_void_p), C.byref(total), C.byref(pmask),
+                           rbytes.ctypes.data_as(C.c_void_p), xf.ctypes.data_as(C.c_void_p), cap, C.byref(nx), sh.ctypes.data_as(C.c_void_p), cap, C.byref(ns))
+    assert rc == 0
+    total = total.value
+    recv = {}
+    for i, c in enumerate(cols):
+        recv[(i, DATA)] = np.full(total * 8 if c[0] == "fixed" else int(rbytes[i]), 0xEE, dtype=np.uint8)
+        recv[(i, OFFS)] = np.full((total + world + 1) * 8, 0xEE, dtype=np.uint8)
+        recv[(i, NOTNULL)] = np.full(total, 0xEE, dtype=np.uint8)
+    # ---- the group of sends and receives, in the plan's order (isend / irecv = inside ncclGroupStart / End)
+    works, keep = [], []
+    for k in range(nx.value):
+        col, kind, peer, so, sl, ro, rl = xf[7 * k: 7 * k + 7].tolist()
+        if peer == rank:
+            assert sl == rl
+            recv[(col, kind)][ro:ro + rl] = send[(col, kind)][so:so + sl]
+            continue
+        if sl:
+            t = torch.from_numpy(np.ascontiguousarray(send[(col, kind)][so:so + sl]))
+            keep.append(t)
+            works.append(dist.isend(t, peer))
+        if rl:
+            t = torch.from_numpy(recv[(col, kind)][ro:ro + rl])  # a view: the bytes land in place
+            works.append(dist.irecv(t, peer))
+    for w in works:
+        w.wait()
+    out = []
+    for i, c in enumerate(cols):
+        nn = recv[(i, NOTNULL)].astype(bool) if (pmask.value >> i) & 1 else np.ones(total, bool)
+        if c[0] == "fixed":
+            out.append(("fixed", recv[(i, DATA)].view(np.int64).copy(), nn))
+        else:
+            tmp = recv[(i, OFFS)].view(np.int64)
+            offs = np.full(total + 1, -1, dtype=np.int64)
+            offs[0] = 0
+            for k in range(ns.value):
+                scol, src, dst, rows, delta = sh[5 * k: 5 * k + 5].tolist()
+                if scol == i:
+                    offs[dst:dst + rows] = tmp[src:src + rows] + delta
+            assert (np.diff(offs) >= 0).all() and offs[total] == len(recv[(i, DATA)])
+            data = recv[(i, DATA)].tobytes()
+            out.append(("var", [data[offs[j]:offs[j + 1]] if nn[j] else None for j in range(total)]))
+    return out
 
 
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    nb, npr = 20000, 30000
+    nb, npr = 20000 - 13 * rank, 30000 + 7 * rank  # ragged: the ranks own different row counts
     rng = np.random.default_rng(1000 + rank)
-    bk = rng.integers(0, 5000, nb).astype(np.int64)
-    bv = rng.integers(-99, 99, nb).astype(np.int64)
-    pk = rng.integers(0, 6000, npr).astype(np.int64)
-    pv = rng.integers(-99, 99, npr).astype(np.int64)
 
-    def redistribute(cols):
-        parts, counts = split(cols, 0, world)
-        rc = parallel.exchange_counts(dist, torch, counts, "cpu")
-        got = parallel.exchange_runs(dist, torch, [torch.from_numpy(np.ascontiguousarray(c)) for c in parts], counts, rc)
-        return [g.numpy() for g in got], counts, rc
+    def table(n, keys_hi, null_keys):
+        k = rng.integers(0, keys_hi, n).astype(np.int64)
+        knn = rng.random(n) > 0.03 if null_keys else None
+        v = rng.random(n).view(np.int64)
+        s = [None if rng.random() < 0.1 else bytes(rng.integers(97, 123, int(rng.integers(0, 12)), dtype=np.uint8)) for _ in range(n)]
+        return [("fixed", k, knn), ("fixed", v, None), ("var", s)]
 
-    (rbk, rbv), sc, rc = redistribute([bk, bv])
-    (rpk, rpv), _, _ = redistribute([pk, pv])
-    # every received key ranks to this rank; nothing lost
-    assert (np_rank(rbk.view(np.uint64), world) == rank).all() and (np_rank(rpk.view(np.uint64), world) == rank).all()
-    tot = torch.tensor([len(rbk), len(rpk)], dtype=torch.int64)
+    # rank 1's build keys carry NULLs, rank 0's do not: the column must travel as nullable on BOTH
+    build, probe = table(nb, 5000, rank == 1), table(npr, 6000, True)
+    rb, rp = redistribute(rank, world, build), redistribute(rank, world, probe)
+    for got in (rb, rp):  # every received key ranks to this rank (NULL keys to rank 0); nothing lost
+        assert (key_ranks(got[0][1], got[0][2], world) == rank).all()
+    tot = torch.tensor([len(rb[0][1]), len(rp[0][1])], dtype=torch.int64)
     dist.all_reduce(tot)
-    assert tot.tolist() == [nb * world, npr * world]
+    nbs, nps = torch.tensor([nb]), torch.tensor([npr])
+    dist.all_reduce(nbs)
+    dist.all_reduce(nps)
+    assert tot.tolist() == [int(nbs), int(nps)]
 
-    # the pipelined exchange (bench.py's N>1 step) delivers the same multiset of rows in pieces; ranks own different row
-    # counts here (rank 1 holds 7 rows fewer)
-    def split_t(tensors, lo, hi, parts):
-        cols, counts = split([t[lo:hi].numpy() for t in tensors], 0, parts)
-        return [torch.from_numpy(np.ascontiguousarray(c)) for c in cols], counts
+    def chunk(t):
+        return Chunk([Column(abi.I64, t[0][1], t[0][2]), Column(abi.F64, t[1][1].view(np.float64)), StrColumn(t[2][1])])
 
-    n_mine = npr - 7 * rank
-    got_k, got_v, pieces = [], [], 0
-    for (k, v), n in parallel.redistribute_pipelined(None, dist, torch, [torch.from_numpy(pk[:n_mine]), torch.from_numpy(pv[:n_mine])],
-                                                     [abi.I64, abi.I64], 0, 0, n_mine, 5, split=split_t):
-        assert len(k) == len(v) == n
-        got_k.append(k.numpy().copy())
-        got_v.append(v.numpy().copy())
-        pieces += 1
-    assert pieces == 5
-    gk, gv = np.concatenate(got_k), np.concatenate(got_v)
-    assert (np_rank(gk.view(np.uint64), world) == rank).all()
-    allp2 = [None] * world
-    dist.all_gather_object(allp2, (pk[:npr - 7 * rank], pv[:npr - 7 * rank]))
-    wk = np.concatenate([a[0] for a in allp2])
-    wv = np.concatenate([a[1] for a in allp2])
-    mine = np_rank(wk.view(np.uint64), world) == rank
-    assert sorted(zip(gk.tolist(), gv.tolist())) == sorted(zip(wk[mine].tolist(), wv[mine].tolist()))
-
-    cfg = H.join_cfg([abi.I64] * 2, [abi.I64] * 2, [0], [0], abi.JOIN_INNER, 1)
-    local = orc.hash_join(cfg, Chunk([Column(abi.I64, rbk), Column(abi.I64, rbv)]), Chunk([Column(abi.I64, rpk), Column(abi.I64, rpv)]))
-    s, x = orc.rows_checksum(local)
-    agg = torch.tensor([local.NumRows(), s & 0x7FFFFFFFFFFFFFFF, s >> 63], dtype=torch.int64)
-    dist.all_reduce(agg)
-    xs = [None] * world
-    dist.all_gather_object(xs, x)
-
-    # reference: the whole (unpartitioned) join on rank 0
-    allb = [None] * world
-    allp = [None] * world
-    dist.all_gather_object(allb, (bk, bv))
-    dist.all_gather_object(allp, (pk, pv))
-    if rank == 0:
-        B = Chunk([Column(abi.I64, np.concatenate([b[0] for b in allb])), Column(abi.I64, np.concatenate([b[1] for b in allb]))])
-        P = Chunk([Column(abi.I64, np.concatenate([p[0] for p in allp])), Column(abi.I64, np.concatenate([p[1] for p in allp]))])
-        whole = orc.hash_join(cfg, B, P)
-        ws, wx = orc.rows_checksum(whole)
-        assert whole.NumRows() == int(agg[0]), (whole.NumRows(), int(agg[0]))
-        gx = 0
-        for v in xs:
-            gx ^= v
-        assert gx == wx
-        gs = (int(agg[1]) + (int(agg[2]) << 63)) & ((1 << 64) - 1)
-        assert gs == ws
+    types = [abi.I64, abi.F64, abi.BYTES]
+    cfg = H.join_cfg(types, types, [0], [0], abi.JOIN_INNER, 1)
+    local = orc.hash_join(cfg, chunk(rb), chunk(rp))
+    mine = sorted(H.multiset(local))
+    allrows, allb, allp = [None] * world, [None] * world, [None] * world
+    dist.all_gather_object(allrows, mine)
+    dist.all_gather_object(allb, build)
+    dist.all_gather_object(allp, probe)
+    if rank == 0:  # reference: the whole (unpartitioned) join
+        def cat(parts):
+            return [("fixed", np.concatenate([p[0][1] for p in parts]), np.concatenate([p[0][2] if p[0][2] is not None else np.ones(len(p[0][1]), bool) for p in parts])),
+                    ("fixed", np.concatenate([p[1][1] for p in parts]), None), ("var", sum((p[2][1] for p in parts), []))]
+        whole = orc.hash_join(cfg, chunk(cat(allb)), chunk(cat(allp)))
+        got = sorted(sum(allrows, []), key=lambda t: tuple((x is None, str(x)) for x in t))
+        assert got == H.multiset(whole), (len(got), whole.NumRows())
         print("DIST_OK rows=%d" % whole.NumRows())
     dist.barrier()
     dist.destroy_process_group()

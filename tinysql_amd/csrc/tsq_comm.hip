@@ -16,6 +16,7 @@
 //     on the wire while piece c is probed.
 // RCCL is loaded with dlopen at the first tsq_comm_* call: single-GPU users (and the CPU-only symbol check) never need it.
 #include "tsq_internal.h"
+#include "tsq_comm_plan.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -145,13 +146,25 @@ TSQ_API tsq_status tsq_comm_create(tsq_ctx* ctx, int32_t rank, int32_t world, co
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     TSQ_NCCL(ch, r->CommInitRank(&c->nccl, world, uid, rank));
-    TSQ_HIP(ch, hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    // from here on a failure must give back what exists already (the communicator, the stream, the events): tsq_comm_destroy does
+    auto fail = [&](tsq_status st) {
+        const std::string msg = ch->err;
+        tsq_comm_destroy(c.release());
+        ch->err = msg;
+        return st;
+    };
     const size_t words = (size_t)(world + 1) * comm_lmax(world) + 8;
-    TSQ_TRY(c->cnt_dev.reserve(ctx, ch, words * 8));
-    TSQ_HIP(ch, hipHostMalloc((void**)&c->cnt_host, words * 8, hipHostMallocDefault));
-    for (auto& s : c->slot) {
-        TSQ_HIP(ch, hipEventCreateWithFlags(&s.split_done, hipEventDisableTiming));
-        TSQ_HIP(ch, hipEventCreateWithFlags(&s.xchg_done, hipEventDisableTiming));
+    {
+        tsq_status st = TSQ_OK;
+        hipError_t e = hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking);
+        if (e == hipSuccess) st = c->cnt_dev.reserve(ctx, ch, words * 8);
+        if (e == hipSuccess && st == TSQ_OK) e = hipHostMalloc((void**)&c->cnt_host, words * 8, hipHostMallocDefault);
+        for (auto& s : c->slot) {
+            if (e == hipSuccess && st == TSQ_OK) e = hipEventCreateWithFlags(&s.split_done, hipEventDisableTiming);
+            if (e == hipSuccess && st == TSQ_OK) e = hipEventCreateWithFlags(&s.xchg_done, hipEventDisableTiming);
+        }
+        if (st != TSQ_OK) return fail(st);
+        if (e != hipSuccess) return fail(tsq_fail(ch, TSQ_ERR_HIP, std::string("tsq_comm_create: ") + hipGetErrorString(e)));
     }
     *out = c.release();
     return TSQ_OK;
@@ -313,19 +326,16 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
     TSQ_HIP(h, hipMemcpyAsync(c->cnt_host + L, cd + L, (size_t)W * L * 8, hipMemcpyDeviceToHost, c->xs));
     TSQ_HIP(h, hipStreamSynchronize(c->xs));
     const uint64_t* M = c->cnt_host + L;  // M[q * L + ...]: rank q's vector
-    int64_t recvc[TSQ_SPLIT_MAX_PARTS], total = 0;
-    uint64_t mask = 0;  // a column is nullable for everybody as soon as one rank holds NULLs in it
-    for (int p = 0; p < W; p++) {
-        recvc[p] = (int64_t)M[(size_t)p * L + c->rank];  // what rank p sends to this rank
-        total += recvc[p];
-        mask |= M[(size_t)p * L + W];
-    }
-    int64_t recv_bytes[TSQ_MAX_COLS] = {0};  // var-len columns: data bytes this rank receives
+    // ---- who sends what to whom, where it lands, how received offsets are rebased: tsq_comm_plan.h (walked on the CPU for world
+    // sizes 2, 4 and 8 by tests/hostsim)
+    int32_t es_of[TSQ_MAX_COLS];
+    for (int i = 0; i < n_cols; i++) es_of[i] = var_of[i] >= 0 ? 0 : (int32_t)tsq_elem_size(cols[i].type);
+    const tsq_comm_plan pl = tsq_comm_make_plan(c->rank, W, n_cols, es_of, M);
+    const int64_t total = pl.total_rows;
+    const uint64_t mask = pl.mask;  // a column is nullable for everybody as soon as one rank holds NULLs in it
     for (int i = 0; i < n_cols; i++) {
         const bool var = var_of[i] >= 0;
-        if (var)
-            for (int q = 0; q < W; q++) recv_bytes[i] += (int64_t)M[(size_t)q * L + W + 1 + var_of[i] * W + c->rank];
-        TSQ_TRY(s.recv[i].reserve(ctx, h, (var ? (size_t)recv_bytes[i] : (size_t)std::max<int64_t>(total, 1) * tsq_elem_size(cols[i].type)) + 64));
+        TSQ_TRY(s.recv[i].reserve(ctx, h, (var ? (size_t)pl.recv_bytes[(size_t)i] : (size_t)std::max<int64_t>(total, 1) * tsq_elem_size(cols[i].type)) + 64));
         if (var) {
             TSQ_TRY(s.recvtmp[i].reserve(ctx, h, ((size_t)total + W + 1) * 8 + 64));
             TSQ_TRY(s.recvoffs[i].reserve(ctx, h, ((size_t)total + 1) * 8 + 64));
@@ -351,70 +361,37 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
         }
     }
     TSQ_NCCL(h, rccl()->GroupStart());
-    for (int i = 0; i < n_cols; i++) {
-        const bool var = var_of[i] >= 0;
-        const size_t es = var ? 0 : tsq_elem_size(cols[i].type);
-        const bool nn = (mask >> i) & 1;
-        size_t so = 0, ro = 0;  // in rows
-        size_t sb = 0, rb = 0;  // var-len: in bytes
-        for (int p = 0; p < W; p++) {
-            const size_t sr = (size_t)sendc[p], rr = (size_t)recvc[p];
-            if (var) {
-                // run p of this rank: offsets[so .. so + sr] and the bytes between its first and its last offset; run from rank p:
-                // rr + 1 offsets into recvtmp at ro + p (one extra entry per source), its bytes behind the bytes of the sources before it
-                const size_t sby = (size_t)M[(size_t)c->rank * L + W + 1 + var_of[i] * W + p], rby = (size_t)M[(size_t)p * L + W + 1 + var_of[i] * W + c->rank];
-                const int64_t* so_p = s.sendoffs[i].as<int64_t>() + so;
-                int64_t* rt_p = s.recvtmp[i].as<int64_t>() + ro + p;
-                if (p == c->rank) {
-                    if (sr) TSQ_HIP(h, hipMemcpyAsync(rt_p, so_p, (sr + 1) * 8, hipMemcpyDeviceToDevice, c->xs));
-                    if (sby) TSQ_HIP(h, hipMemcpyAsync((char*)s.recv[i].p + rb, (const char*)s.send[i].p + sb, sby, hipMemcpyDeviceToDevice, c->xs));
-                } else {
-                    if (sr) TSQ_NCCL(h, rccl()->Send(so_p, (sr + 1) * 8, ncclChar, p, c->nccl, c->xs));
-                    if (rr) TSQ_NCCL(h, rccl()->Recv(rt_p, (rr + 1) * 8, ncclChar, p, c->nccl, c->xs));
-                    if (sby) TSQ_NCCL(h, rccl()->Send((const char*)s.send[i].p + sb, sby, ncclChar, p, c->nccl, c->xs));
-                    if (rby) TSQ_NCCL(h, rccl()->Recv((char*)s.recv[i].p + rb, rby, ncclChar, p, c->nccl, c->xs));
+    {
+        // an error inside the group must still close it (an open group swallows every later RCCL call of this process)
+        tsq_status gs = TSQ_OK;
+        for (const tsq_comm_xfer& x : pl.xfers) {
+            const char* sbase = (const char*)(x.kind == TSQ_XFER_DATA ? s.send[x.col].p : (x.kind == TSQ_XFER_OFFS ? s.sendoffs[x.col].p : s.sendnn[x.col].p));
+            char* rbase = (char*)(x.kind == TSQ_XFER_DATA ? s.recv[x.col].p : (x.kind == TSQ_XFER_OFFS ? s.recvtmp[x.col].p : s.recvnn[x.col].p));
+            if (x.peer == c->rank) {
+                if (x.send_len) {
+                    hipError_t e = hipMemcpyAsync(rbase + x.recv_off, sbase + x.send_off, x.send_len, hipMemcpyDeviceToDevice, c->xs);
+                    if (e != hipSuccess) { gs = tsq_fail(h, TSQ_ERR_HIP, std::string("hipMemcpyAsync(own run): ") + hipGetErrorString(e)); break; }
                 }
-                sb += sby;
-                rb += rby;
-            } else if (p == c->rank) {
-                if (sr) TSQ_HIP(h, hipMemcpyAsync((char*)s.recv[i].p + ro * es, (const char*)s.send[i].p + so * es, sr * es, hipMemcpyDeviceToDevice, c->xs));
-            } else {
-                if (sr) TSQ_NCCL(h, rccl()->Send((const char*)s.send[i].p + so * es, sr * es, ncclChar, p, c->nccl, c->xs));
-                if (rr) TSQ_NCCL(h, rccl()->Recv((char*)s.recv[i].p + ro * es, rr * es, ncclChar, p, c->nccl, c->xs));
+                continue;
             }
-            if (nn && p == c->rank) {
-                if (sr) TSQ_HIP(h, hipMemcpyAsync((char*)s.recvnn[i].p + ro, (const char*)s.sendnn[i].p + so, sr, hipMemcpyDeviceToDevice, c->xs));
-            } else if (nn) {
-                if (sr) TSQ_NCCL(h, rccl()->Send((const char*)s.sendnn[i].p + so, sr, ncclChar, p, c->nccl, c->xs));
-                if (rr) TSQ_NCCL(h, rccl()->Recv((char*)s.recvnn[i].p + ro, rr, ncclChar, p, c->nccl, c->xs));
-            }
-            so += sr;
-            ro += rr;
+            ncclResult_t r1 = ncclSuccess;
+            if (x.send_len) r1 = rccl()->Send(sbase + x.send_off, x.send_len, ncclChar, x.peer, c->nccl, c->xs);
+            if (r1 == ncclSuccess && x.recv_len) r1 = rccl()->Recv(rbase + x.recv_off, x.recv_len, ncclChar, x.peer, c->nccl, c->xs);
+            if (r1 != ncclSuccess) { gs = tsq_fail(h, TSQ_ERR_HIP, std::string("ncclSend / ncclRecv: ") + rccl()->GetErrorString(r1)); break; }
         }
+        const ncclResult_t ge = rccl()->GroupEnd();
+        if (gs != TSQ_OK) return gs;
+        if (ge != ncclSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("ncclGroupEnd: ") + rccl()->GetErrorString(ge));
     }
-    TSQ_NCCL(h, rccl()->GroupEnd());
-    for (int i = 0; i < n_cols; i++) {
-        if (var_of[i] >= 0) {
-            // received offsets -> the column's offsets: the run from rank q starts at row ro and at byte rb of this rank; on the wire its
-            // offsets count from the bytes rank q sent to the ranks before this one
-            TSQ_HIP(h, hipMemsetAsync(s.recvoffs[i].p, 0, 8, c->xs));
-            size_t ro = 0;
-            int64_t rb = 0;
-            for (int q = 0; q < W; q++) {
-                const int64_t rr = recvc[q];
-                int64_t first = 0;  // the run's first offset on rank q
-                for (int p = 0; p < c->rank; p++) first += (int64_t)M[(size_t)q * L + W + 1 + var_of[i] * W + p];
-                if (rr > 0) {
-                    const int grid = (int)std::min<int64_t>((rr + 255) / 256, (int64_t)ctx->num_cus * 8);
-                    hipLaunchKernelGGL(k_offsets_shift, dim3(grid), dim3(256), 0, c->xs, s.recvtmp[i].as<int64_t>() + ro + q + 1, s.recvoffs[i].as<int64_t>() + ro + 1, rr,
-                                       rb - first);
-                    TSQ_HIP(h, hipGetLastError());
-                }
-                ro += (size_t)rr;
-                rb += (int64_t)M[(size_t)q * L + W + 1 + var_of[i] * W + c->rank];
-            }
-        }
-        // received bytes -> the packed bitmap of the received column
+    for (int i = 0; i < n_cols; i++)
+        if (var_of[i] >= 0) TSQ_HIP(h, hipMemsetAsync(s.recvoffs[i].p, 0, 8, c->xs));
+    for (const tsq_comm_shift& sh : pl.shifts) {  // received offsets -> the column's offsets
+        const int grid = (int)std::min<int64_t>(((int64_t)sh.rows + 255) / 256, (int64_t)ctx->num_cus * 8);
+        hipLaunchKernelGGL(k_offsets_shift, dim3(grid), dim3(256), 0, c->xs, s.recvtmp[sh.col].as<int64_t>() + sh.src_entry, s.recvoffs[sh.col].as<int64_t>() + sh.dst_entry,
+                           (int64_t)sh.rows, sh.delta);
+        TSQ_HIP(h, hipGetLastError());
+    }
+    for (int i = 0; i < n_cols; i++) {  // received bytes -> the packed bitmap of the received column
         if (!((mask >> i) & 1) || total == 0) continue;
         const int grid = (int)std::min<int64_t>(((total + 7) / 8 + 255) / 256, (int64_t)ctx->num_cus * 8);
         hipLaunchKernelGGL(k_bytes_to_bits, dim3(grid), dim3(256), 0, c->xs, s.recvnn[i].as<uint8_t>(), s.recvbm[i].as<uint8_t>(), total);

@@ -1,20 +1,18 @@
 """Multi-GPU hash-radix redistribute: one process per GPU.
 
-The product path is `Comm` below: a thin caller of libtsq's tsq_comm_* / tsq_redistribute (RCCL send/recv over xGMI inside
-the library, csrc/tsq_comm.hip) — nothing but plain pointers and sizes crosses the C-ABI, a Go host calls the same sequence
+`Comm` is a thin caller of libtsq's tsq_comm_* / tsq_redistribute (RCCL send/recv over xGMI inside the library,
+csrc/tsq_comm.hip) — nothing but plain pointers and sizes crosses the C-ABI, a Go host calls the same sequence
 (INTEGRATION.md §6).  `DistHashJoinCount` and `dist_hash_agg` are the two distributed plans built from it.
-The torch.distributed functions further down move torch tensors with the same bookkeeping (run sizes, pieces, ragged counts);
-they are what the CPU test-suite runs at world size 2 over gloo, where no GPU and therefore no RCCL exists.
 
-CPU analogue in the reference: HashAggExec's partial->final shuffle (executor/aggregate.go:352-356)
-and the probe-chunk dispatch of HashJoinExec (executor/join.go:219).  Equi-join and GROUP BY are
-partitionable by any function of the key, so the ONLY data-path collective is this exchange:
-rank r keeps/receives every row whose key ranks to r (tsq_key_rank), then runs the single-GPU
-operator locally.  xGMI is point-to-point (7 links per GPU), so an all-to-all drives all links at
-once; ring-style collectives would be bound by one link.
+CPU analogue in the reference: HashAggExec's partial->final shuffle (executor/aggregate.go:352-356) and the probe-chunk
+dispatch of HashJoinExec (executor/join.go:219).  Equi-join and GROUP BY are partitionable by any function of the key, so the
+ONLY data-path collective is this exchange: rank r keeps / receives every row whose key ranks to r (tsq_key_rank), then runs
+the single-GPU operator locally.  xGMI is point-to-point (7 links per GPU), so an all-to-all drives all links at once;
+ring-style collectives would be bound by one link.
 
-The functions below only move torch tensors (device tensors with nccl, CPU tensors with gloo in the
-CPU test-suite); the split itself is libtsq's tsq_radix_split on the GPU.
+The exchange's bookkeeping (who sends which bytes to whom, where they land, how received var-len offsets are rebased) lives in
+csrc/tsq_comm_plan.h and is walked without a GPU by tests/test_dist_cpu.py (world sizes 1-8 in one process, and two processes
+over gloo).  Round 2's torch.distributed copy of that bookkeeping is gone: nothing in the product called it.
 """
 import ctypes as C
 
@@ -22,136 +20,59 @@ from . import _abi as abi
 from . import _lib
 
 
-def exchange_counts(dist, torch, send_counts, device):
-    """all-to-all of the per-destination row counts; returns the per-source counts this rank receives."""
-    w = dist.get_world_size()
-    send = torch.tensor(list(send_counts), dtype=torch.int64, device=device)
-    recv = torch.empty(w, dtype=torch.int64, device=device)
-    dist.all_to_all_single(recv, send)
-    return [int(x) for x in recv.tolist()]
-
-
-def exchange_runs(dist, torch, tensors, send_counts, recv_counts):
-    """all-to-all(v) of contiguous runs.  tensors[i] holds this rank's rows already grouped by
-    destination (run p = rows for rank p, send_counts[p] rows); returns the received tensors."""
-    out = []
-    total = sum(recv_counts)
-    for t in tensors:
-        r = torch.empty(max(total, 1), dtype=t.dtype, device=t.device)[:total]
-        dist.all_to_all_single(r, t[: sum(send_counts)], list(recv_counts), list(send_counts))
-        out.append(r)
-    return out
-
-
-def dev_col_from_tensor(t, tp, nrows, bitmap=None):
-    """tsq_col view of a device torch tensor (plain pointer + size: no torch types cross the C-ABI)."""
-    c = abi.Col()
-    c.data = t.data_ptr()
-    c.null_bitmap = bitmap.data_ptr() if bitmap is not None else None
-    c.offsets = None
-    c.length = nrows
-    c.elem_size = 4 if tp == abi.F32 else 8
-    c.type = tp
-    c.flags = abi.COL_DEVICE
-    return c
-
-
-def radix_split(ctx, cols, key_col, key_mode, nrows, n_parts, out_cols):
-    """tsq_radix_split wrapper: returns the per-part row counts (host ints)."""
-    counts = (C.c_int64 * n_parts)()
-    arr_in = (abi.Col * len(cols))(*cols)
-    arr_out = (abi.Col * len(out_cols))(*out_cols)
-    _lib.check(ctx.lib.tsq_radix_split(ctx.h, arr_in, len(cols), key_col, key_mode, nrows, n_parts, arr_out, counts), ctx.h)
-    return list(counts)
-
-
-def redistribute(ctx, dist, torch, tensors, types, key_col, key_mode, nrows):
-    """split by rank(key) on the GPU, exchange counts, all-to-all the runs.
-    tensors: device torch tensors (one per column, no NULLs).  Returns (received tensors, n_received)."""
-    w = dist.get_world_size()
-    outs = [torch.empty_like(t) for t in tensors]
-    cols = [dev_col_from_tensor(t, tp, nrows) for t, tp in zip(tensors, types)]
-    ocols = [dev_col_from_tensor(t, tp, nrows) for t, tp in zip(outs, types)]
-    send_counts = radix_split(ctx, cols, key_col, key_mode, nrows, w, ocols)
-    recv_counts = exchange_counts(dist, torch, send_counts, tensors[0].device)
-    got = exchange_runs(dist, torch, outs, send_counts, recv_counts)
-    return got, sum(recv_counts)
-
-
-def redistribute_pipelined(ctx, dist, torch, tensors, types, key_col, key_mode, nrows, n_chunks=4, split=None):
-    """redistribute() in n_chunks pieces, as a generator of (received tensors, n_received): the rows are split chunk by
-    chunk, ONE count exchange covers all chunks, all data exchanges are issued asynchronously back to back, and piece c
-    is handed to the caller as soon as its exchange has completed — the single-GPU operator consumes piece c while pieces
-    c+1.. are still on the wire (xGMI moves 8 B/row at a fraction of what the probe kernel consumes, so the wire is the
-    longer leg; only the last piece's probe is exposed).  The union of the pieces is the same multiset of rows that
-    redistribute() returns.  `split(cols_as_tensors, lo, hi, n_parts) -> (out tensors, counts)` replaces the GPU split
-    in the CPU (gloo) test-suite."""
-    w = dist.get_world_size()
-    n_chunks = max(1, int(n_chunks))  # every rank must use the same value: the count exchange carries w * n_chunks words
-    bounds = [((nrows * c // n_chunks) + 7) & ~7 for c in range(n_chunks)] + [nrows]
-    bounds = [min(b, nrows) for b in bounds]
-    pieces, counts = [], []
-    for c in range(n_chunks):
-        lo, hi = bounds[c], bounds[c + 1]
-        if split is not None:
-            outs, cnt = split(tensors, lo, hi, w)
-        else:
-            outs = [torch.empty(max(hi - lo, 1), dtype=t.dtype, device=t.device)[: hi - lo] for t in tensors]
-            cols = [dev_col_from_tensor(t[lo:hi], tp, hi - lo) for t, tp in zip(tensors, types)]
-            ocols = [dev_col_from_tensor(t, tp, hi - lo) for t, tp in zip(outs, types)]
-            cnt = radix_split(ctx, cols, key_col, key_mode, hi - lo, w, ocols) if hi > lo else [0] * w
-        pieces.append(outs)
-        counts.append(cnt)
-    # one exchange for all counts: send[p * n_chunks + c] = rows of chunk c that go to rank p
-    dev = tensors[0].device
-    send = torch.tensor([counts[c][p] for p in range(w) for c in range(n_chunks)], dtype=torch.int64, device=dev)
-    recv = torch.empty(w * n_chunks, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv, send)
-    recv = recv.tolist()
-    inflight = []
-    for c in range(n_chunks):
-        rc = [int(recv[s * n_chunks + c]) for s in range(w)]
-        total = sum(rc)
-        got, works = [], []
-        for t in pieces[c]:
-            r = torch.empty(max(total, 1), dtype=t.dtype, device=t.device)[:total]
-            works.append(dist.all_to_all_single(r, t[: sum(counts[c])], rc, list(counts[c]), async_op=True))
-            got.append(r)
-        inflight.append((got, total, works))
-    for got, total, works in inflight:
-        for wk in works:
-            wk.wait()  # nccl: the current stream waits for the exchange; gloo: the host does
-        yield got, total
-    del pieces  # send buffers stay alive until every exchange has been waited for
-
-
 # ====================================================================== the C-ABI path (RCCL inside libtsq)
 import os
 import time
 
 
+_generation = [0]  # communicators created by this process so far: every rank creates them in the same order
+
+
+def _launch_start_time():
+    """start time of the launcher (the parent of every rank); an id file older than that belongs to an earlier, crashed launch"""
+    try:
+        import psutil
+        return psutil.Process(os.getppid()).create_time()
+    except Exception:
+        return 0.0
+
+
 def rendezvous_unique_id(lib, rank, world, timeout_s=180.0):
-    """rank 0 creates the RCCL unique id, the other ranks of this launch read it from a file.  The launcher (torchrun) is the
-    parent of every rank: its pid + MASTER_PORT name the launch, so concurrent or earlier runs cannot be confused."""
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tsq_rdzv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    """rank 0 creates the RCCL unique id, the other ranks of this launch read it from a file named after the launch (the launcher's
+    pid, MASTER_PORT / TORCHELASTIC_RUN_ID) AND the number of the communicator inside the process (a second Comm of the same launch
+    cannot read the first one's id).  Rank 0 removes what may lie at that path before it writes; a reader ignores a file older than
+    the launcher (a crashed earlier launch with a recycled pid); every reader leaves an acknowledgement that rank 0 waits for
+    before it unlinks the id in Comm.close()."""
+    gen = _generation[0]
+    _generation[0] += 1
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tsq_rdzv_%d_%s_%s_%d" % (os.getppid(), os.environ.get("MASTER_PORT", "0"),
+                                                                                   os.environ.get("TORCHELASTIC_RUN_ID", "0"), gen))
     buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
     if world == 1:
         _lib.check(lib.tsq_comm_unique_id(buf))
         return bytes(buf), None
     if rank == 0:
+        for stale in [path] + [path + ".ack%d" % r for r in range(1, world)]:
+            try:
+                os.remove(stale)
+            except OSError:
+                pass
         _lib.check(lib.tsq_comm_unique_id(buf))
         with open(path + ".tmp", "wb") as f:
             f.write(bytes(buf))
         os.replace(path + ".tmp", path)
         return bytes(buf), path
-    t0 = time.time()
+    t0, born = time.time(), _launch_start_time()
     while True:
         try:
-            with open(path, "rb") as f:
-                b = f.read()
-            if len(b) == abi.COMM_ID_BYTES:
-                return b, None
-        except FileNotFoundError:
+            if os.path.getmtime(path) + 1.0 >= born:
+                with open(path, "rb") as f:
+                    b = f.read()
+                if len(b) == abi.COMM_ID_BYTES:
+                    with open(path + ".ack%d" % rank, "wb") as f:
+                        f.write(b"1")
+                    return b, None
+        except (FileNotFoundError, OSError):
             pass
         if time.time() - t0 > timeout_s:
             raise RuntimeError("rendezvous: no unique id at %s after %.0f s" % (path, timeout_s))
@@ -177,11 +98,12 @@ class Comm:
             self.barrier()
             self.lib.tsq_comm_destroy(self.h)
             self.h = None
-            if self._rdzv:
-                try:
-                    os.remove(self._rdzv)
-                except OSError:
-                    pass
+            if self._rdzv:  # rank 0: every reader has acknowledged the id (they all passed the barrier above, after reading it)
+                for f in [self._rdzv] + [self._rdzv + ".ack%d" % r for r in range(1, self.world)]:
+                    try:
+                        os.remove(f)
+                    except OSError:
+                        pass
 
     def allreduce_i64(self, values, op=0):
         a = (C.c_int64 * len(values))(*values)
