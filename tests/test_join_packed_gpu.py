@@ -223,3 +223,67 @@ def test_packed_rows_1e7_checksum_vs_count_route(ctx):
     assert got.NumRows() == c == int((probe.columns[0].data < nb).sum())
     from oracle import binding as orc_b
     assert orc_b.rows_checksum(got) == (s, x)
+
+
+# ------------------------------------------------------------------ travelling columns (K5f + K4e): 8-byte columns on both sides
+def _wide8(rng, n, key_lo, key_hi, ncols, null_key=0.03, null_pay=0.1):
+    cols = [Column(abi.I64, rng.integers(key_lo, key_hi, n), rng.random(n) > null_key)]
+    for c in range(1, ncols):
+        tp = (abi.I64, abi.F64, abi.U64)[c % 3]
+        if tp == abi.F64:
+            data = rng.random(n)
+        elif tp == abi.U64:
+            data = rng.integers(0, 1 << 63, n).astype(np.uint64)
+        else:
+            data = rng.integers(-(1 << 40), 1 << 40, n)
+        cols.append(Column(tp, data, (rng.random(n) > null_pay) if c % 2 else None))
+    return Chunk(cols)
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_INNER, 0), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("n_probe,np_cols,nb_cols", [(1, 1, 1), (64, 2, 2), (4097, 4, 6), (60_001, 8, 8), (150_003, 3, 2)])
+def test_packed_travelling_columns_vs_oracle(ctx, orc, jt, inner, n_probe, np_cols, nb_cols):
+    rng = np.random.default_rng(11 * n_probe + jt + inner)
+    bside = _wide8(rng, 6000, -900, 1000, nb_cols)      # ~3 build rows per key, NULL keys and NULL payload cells
+    pside = _wide8(rng, n_probe, -1100, 1200, np_cols)  # probe keys on both sides of the build range
+    left, right = (pside, bside) if inner == 1 else (bside, pside)
+    cfg = H.join_cfg(left.types(), right.types(), [0], [0], jt, inner)
+    want = orc.hash_join(cfg, bside, pside)
+    got = _rows(ctx, cfg, bside, pside)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    got = _rows(ctx, cfg, bside, pside, chunk_rows=1024)
+    assert H.rows_equal_unordered(got, want)
+
+
+@pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
+def test_packed_travelling_columns_overflow_list_and_misses(ctx, orc, jt):
+    # a hot probe key overflows its partition's region: those rows, and the NULL / out-of-range probe rows of an outer join, are the
+    # batch's exception rows (pairs + one lane per row); a key with 200 build rows multiplies its probe rows
+    rng = np.random.default_rng(41 + jt)
+    bk = np.concatenate([np.full(200, 5), np.arange(100, 1100), np.full(3, 40_000)]).astype(np.int64)
+    rng.shuffle(bk)
+    build = Chunk([Column(abi.I64, bk), Column(abi.F64, rng.random(len(bk)), rng.random(len(bk)) > 0.2)])
+    n = 70_000
+    pk = rng.choice(np.array([5, 5, 5, 101, 40_000, 77, -3, 50_000], dtype=np.int64), n)
+    probe = Chunk([Column(abi.I64, pk, rng.random(n) > 0.02), Column(abi.I64, np.arange(n)), Column(abi.U64, rng.integers(0, 99, n).astype(np.uint64), rng.random(n) > 0.5)])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], jt, 1)
+    want = orc.hash_join(cfg, build, probe)
+    got = _rows(ctx, cfg, build, probe)
+    assert got.NumRows() == want.NumRows() > 200 * n // 4 and H.rows_equal_unordered(got, want)
+
+
+def test_packed_travelling_columns_auto_1e7_checksum(ctx):
+    # AUTO at scale: 2^23 build rows, 3 x 2^22 probe rows (hit ratio 0.5), nullable payloads on both sides, a left outer join:
+    # the order-independent checksum of the joined rows equals the direct route's (tsq_join_set_checksum, GEN kernels)
+    rng = np.random.default_rng(15)
+    nb, n = 1 << 23, 3 * (4 << 20)
+    build = Chunk([Column(abi.I64, rng.permutation(nb).astype(np.int64)), Column(abi.I64, rng.integers(0, 1 << 40, nb), rng.random(nb) > 0.03)])
+    probe = Chunk([Column(abi.I64, rng.integers(0, 2 * nb, n), rng.random(n) > 0.03), Column(abi.F64, rng.random(n), rng.random(n) > 0.03)])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], abi.JOIN_LEFT_OUTER, 1)
+    c, s, x = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, count_only=True, checksum=True, radix=OFF)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, pull_rows=1 << 20, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_PACKED and stats[0].radix_batches == 3
+    assert got.NumRows() == c == n
+    from oracle import binding as orc_b
+    assert orc_b.rows_checksum(got) == (s, x)

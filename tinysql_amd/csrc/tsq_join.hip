@@ -712,6 +712,9 @@ struct tsq_join {
     int da_rows_state = 0;            // materialising packed route: build rows sorted by word (CSR over the images)
     DevBuf da_coarse, da_pstart, da_brows;
     DevBuf ridx, rovfidx, rmiss;      // ... probe rows travelling with the entries | of the overflow list | that cannot match (outer joins)
+    int da_cols_state = 0;            // travelling-columns route: the build columns sorted by word (+ NOT-NULL bytes)
+    DevBuf da_bsorted[TSQ_DA_MAXCOLS], da_bsorted_nn[TSQ_DA_MAXCOLS];
+    DevBuf rcols[TSQ_DA_MAXCOLS], rnnmask;  // ... the probe columns travelling with the entries, their NOT-NULL bits
     static constexpr int RING = 32;   // HIP events of the most recent radix batches: [slot][0..2] = start, after partition, end
     hipEvent_t rev[RING][3] = {};
 
@@ -1477,6 +1480,272 @@ tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nro
     });
 }
 
+// ---- materialising packed route with travelling columns (K5f + K4e, tsq_dajoin.h): nothing is gathered from all over HBM
+// Eligible: what da_emit takes, with every column on both sides an 8-byte type (BIGINT, BIGINT UNSIGNED, DOUBLE) and at most
+// TSQ_DA_MAXCOLS columns per side.  NULLs anywhere, inner and outer joins.
+bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->never_match || j->ordered) return false;
+    if (selected_dev || !j->conds_h.empty() || !j->filters_h.empty()) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0 || j->da_cols_state < 0) return false;
+    if (j->cfg.n_probe_cols > TSQ_DA_MAXCOLS || j->cfg.n_build_cols > TSQ_DA_MAXCOLS) return false;
+    for (int c = 0; c < j->cfg.n_probe_cols; c++)
+        if (j->cfg.probe_types[c] == TSQ_F32 || j->cfg.probe_types[c] == TSQ_BYTES) return false;
+    for (int c = 0; c < j->cfg.n_build_cols; c++)
+        if (j->cfg.build_types[c] == TSQ_F32 || j->cfg.build_types[c] == TSQ_BYTES) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (4 << 20);
+}
+
+tsq_status da_prepare_cols(tsq_join* j) {
+    if (j->da_cols_state) return TSQ_OK;
+    j->da_cols_state = -1;
+    if (j->da_rows_state != 1) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const int64_t nb = j->bcols[0].rows;
+    DaSortColsArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.brows = j->da_brows.as<uint32_t>();
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 56, j->da_pstart.as<uint32_t>() + ((size_t)1 << j->da_pbits), 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    sa.n = (int64_t)((const uint32_t*)(ctx->pinned + 56))[0];  // the build rows that have a usable key
+    if (sa.n > nb) return TSQ_OK;
+    for (int c = 0; c < j->cfg.n_build_cols; c++) {
+        TSQ_TRY(j->da_bsorted[c].reserve(ctx, h, (size_t)sa.n * 8 + 64));
+        sa.col[c] = j->bcols[c].data.as<uint64_t>();
+        sa.sorted[c] = j->da_bsorted[c].as<uint64_t>();
+        if (j->bcols[c].has_nulls) {
+            TSQ_TRY(j->da_bsorted_nn[c].reserve(ctx, h, (size_t)sa.n + 64));
+            sa.nulls[c] = j->bcols[c].nulls.as<uint8_t>();
+            sa.sorted_nn[c] = j->da_bsorted_nn[c].as<uint8_t>();
+        }
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    TSQ_HIP(h, hipEventCreate(&e0));
+    TSQ_HIP(h, hipEventCreate(&e1));
+    TSQ_HIP(h, hipEventRecord(e0, ctx->stream));
+    if (sa.n > 0) {
+        hipLaunchKernelGGL(k_da_sort_cols, dim3(tsq_grid_for(ctx, sa.n, 256), j->cfg.n_build_cols), dim3(256), 0, ctx->stream, sa);
+        TSQ_HIP(h, hipGetLastError());
+    }
+    TSQ_HIP(h, hipEventRecord(e1, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms += ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    j->st.kernel_launches++;
+    j->da_cols_state = 1;
+    return TSQ_OK;
+}
+
+tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
+    const int np = j->cfg.n_probe_cols, nbc = j->cfg.n_build_cols;
+    constexpr int T = 1024 * 8;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nrows, T);
+    if (g.nregions * g.cap >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "radix probe batch too large");
+    const size_t slots = g.nregions * g.cap;
+    TSQ_TRY(j->rkeys.reserve(ctx, h, g.ent_bytes));
+    TSQ_TRY(j->rctl.reserve(ctx, h, g.ctl_bytes));
+    TSQ_TRY(j->rvend.reserve(ctx, h, g.nregions * 4));
+    TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(j->rovfidx.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    if (outer) TSQ_TRY(j->rmiss.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    bool any_nulls = false;
+    for (int c = 0; c < np; c++) {
+        TSQ_TRY(j->rcols[c].reserve(ctx, h, slots * 8 + 256));
+        any_nulls = any_nulls || pcs.nulls[c] != nullptr;
+    }
+    if (any_nulls) TSQ_TRY(j->rnnmask.reserve(ctx, h, slots + 256));
+    const size_t n_pc = (size_t)g.P + 1;
+    TSQ_TRY(j->tkcnt.reserve(ctx, h, n_pc * 8 + 64));
+    DaColStore cs;
+    memset(&cs, 0, sizeof cs);
+    DaStore& st = cs.st;
+    st.ent = j->rkeys.p;
+    st.cursor = j->rctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.miss_count = st.cursor + g.nregions + 1;
+    st.miss = j->rmiss.as<uint32_t>();
+    st.valid_end = j->rvend.as<uint32_t>();
+    st.ovf = j->rovf.as<uint32_t>();
+    st.ovf_idx = j->rovfidx.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nrows;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    for (int c = 0; c < np; c++) cs.pay[c] = j->rcols[c].as<uint64_t>();
+    cs.nnmask = any_nulls ? j->rnnmask.as<uint8_t>() : nullptr;
+    TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->tkcnt.p, 0, n_pc * 8, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));
+    DaColSrc src;
+    memset(&src, 0, sizeof src);
+    const int kc = j->ks.pidx[0];
+    src.key.data = (const uint64_t*)pcs.data[kc];
+    src.key.nulls = pcs.nulls[kc];
+    src.key.nrows = nrows;
+    src.n_cols = np;
+    src.any_nulls = any_nulls ? 1 : 0;
+    for (int c = 0; c < np; c++) {
+        src.col[c] = (const uint64_t*)pcs.data[c];
+        src.nulls[c] = pcs.nulls[c];
+    }
+    hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
+    for (int e = 0; e < 3; e++)
+        if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    {
+        const dim3 grid((unsigned)std::min<int64_t>((nrows + T - 1) / T, ctx->num_cus));
+        if (outer) hipLaunchKernelGGL((k_da_partition_cols<1024, 8, true>), grid, dim3(1024), 0, ctx->stream, src, j->da_dm, cs);
+        else hipLaunchKernelGGL((k_da_partition_cols<1024, 8, false>), grid, dim3(1024), 0, ctx->stream, src, j->da_dm, cs);
+        TSQ_HIP(h, hipGetLastError());
+    }
+    TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
+    // ---- sizing pass
+    DaProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.st = st;
+    pa.img = j->da_img.as<uint8_t>();
+    pa.counters = (unsigned long long*)(ctx->dscratch + 52);
+    pa.pcount = j->tkcnt.as<unsigned long long>();
+    const size_t cells = (size_t)1 << j->da_ebits;
+    const dim3 pgrid(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2));
+    if (outer) {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<512, uint16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells));
+        hipLaunchKernelGGL((k_da_probe_count<512, uint16_t, true, true>), pgrid, dim3(512), cells, ctx->stream, pa);
+        TSQ_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(k_da_probe_ovf<true>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    } else {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<512, uint16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells));
+        hipLaunchKernelGGL((k_da_probe_count<512, uint16_t, true, false>), pgrid, dim3(512), cells, ctx->stream, pa);
+        TSQ_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL(k_da_probe_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    }
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, pa.pcount, (int)n_pc);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 52, pa.pcount + g.P, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 53, ctx->dscratch + 52, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 54, st.miss_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const int64_t part_rows = (int64_t)ctx->pinned[52], ovf_rows = (int64_t)ctx->pinned[53];
+    const int64_t miss_rows = outer ? (int64_t)((const uint32_t*)(ctx->pinned + 54))[0] : 0;
+    const int64_t exc_rows = ovf_rows + miss_rows, out_rows = exc_rows + part_rows;
+    j->st.kernel_launches += 4;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)st.bits;
+    j->st.probe_route = TSQ_ROUTE_PACKED;
+    j->st.packed_key_bits = (int32_t)j->da_dm.b;
+    if (out_rows == 0) {
+        TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+        TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    // ---- the output batch: [exception rows | rows of the partitions]; NULLs as one byte per row, packed at the end
+    const int nout = np + nbc;
+    const bool probe_is_left = j->cfg.build_is_right != 0;
+    const int nl = probe_is_left ? np : nbc;
+    std::unique_ptr<ResultBatch> rb(new ResultBatch());
+    rb->rows = out_rows;
+    rb->data.resize(nout);
+    rb->notnull.resize(nout);
+    rb->bitmap.resize(nout);
+    rb->offs.resize(nout);
+    rb->nbytes.assign(nout, 0);
+    std::vector<bool> may_null_v(nout, false);
+    DaEmitColsArgs ea;
+    memset(&ea, 0, sizeof ea);
+    DaExcArgs xa;
+    memset(&xa, 0, sizeof xa);
+    for (int oc = 0; oc < nout; oc++) {
+        const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
+        const int sc = oc < nl ? oc : oc - nl;
+        const bool may_null = from_probe ? pcs.nulls[sc] != nullptr : (j->bcols[sc].has_nulls || outer);
+        may_null_v[oc] = may_null;
+        tsq_status s = rb->data[oc].reserve(ctx, h, ((size_t)out_rows + 8) * 8 + 16);
+        if (s == TSQ_OK && may_null) s = rb->notnull[oc].reserve(ctx, h, (size_t)out_rows + 64);
+        if (s == TSQ_OK && may_null) s = rb->bitmap[oc].reserve(ctx, h, tsq_bitmap_bytes(out_rows) + 16);
+        if (s != TSQ_OK) { rb->release(); return s; }
+        uint64_t* od = rb->data[oc].as<uint64_t>();
+        uint8_t* of = may_null ? rb->notnull[oc].as<uint8_t>() : nullptr;
+        if (from_probe) {
+            ea.out_probe[sc] = od;
+            ea.out_probe_nn[sc] = of;
+            xa.pcol[sc] = (const uint64_t*)pcs.data[sc];
+            xa.pnull[sc] = pcs.nulls[sc];
+            xa.out_probe[sc] = od;
+            xa.out_probe_nn[sc] = of;
+        } else {
+            ea.out_build[sc] = od;
+            ea.out_build_nn[sc] = of;
+            ea.bsorted[sc] = j->da_bsorted[sc].as<uint64_t>();
+            ea.bsorted_nn[sc] = j->bcols[sc].has_nulls ? j->da_bsorted_nn[sc].as<uint8_t>() : nullptr;
+            xa.bcol[sc] = j->bcols[sc].data.as<uint64_t>();
+            xa.bnull[sc] = j->bcols[sc].has_nulls ? j->bcols[sc].nulls.as<uint8_t>() : nullptr;
+            xa.out_build[sc] = od;
+            xa.out_build_nn[sc] = of;
+        }
+    }
+    if (exc_rows > 0) {  // overflow-list rows, then the NULL-padded rows of the miss list, as pairs; their cells through the pairs
+        TSQ_TRY(j->pairs.reserve(ctx, h, (size_t)exc_rows * 8 + 64));
+        DaEmitArgs pe;
+        memset(&pe, 0, sizeof pe);
+        pe.st = st;
+        pe.img = pa.img;
+        pe.coarse = j->da_coarse.as<uint32_t>();
+        pe.pstart = j->da_pstart.as<uint32_t>();
+        pe.brows = j->da_brows.as<uint32_t>();
+        pe.pairs = j->pairs.as<unsigned long long>();
+        pe.ovf_cursor = (unsigned long long*)(ctx->dscratch + 53);  // starts at 0 (cleared above)
+        if (outer) hipLaunchKernelGGL(k_da_emit_ovf<true>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pe);
+        else hipLaunchKernelGGL(k_da_emit_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pe);
+        TSQ_HIP(h, hipGetLastError());
+        if (miss_rows) {
+            hipLaunchKernelGGL(k_da_emit_miss, dim3(tsq_grid_for(ctx, miss_rows, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)st.miss, (uint32_t)miss_rows,
+                               pe.pairs + ovf_rows);
+            TSQ_HIP(h, hipGetLastError());
+        }
+        xa.pairs = pe.pairs;
+        xa.n = exc_rows;
+        xa.n_probe = np;
+        xa.n_build = nbc;
+        hipLaunchKernelGGL(k_da_gather_exc, dim3(tsq_grid_for(ctx, exc_rows, 256)), dim3(256), 0, ctx->stream, xa);
+        TSQ_HIP(h, hipGetLastError());
+        j->st.kernel_launches += 3;
+    }
+    ea.cs = cs;
+    ea.img = pa.img;
+    ea.coarse = j->da_coarse.as<uint32_t>();
+    ea.pstart = j->da_pstart.as<uint32_t>();
+    ea.pbase = pa.pcount;
+    ea.row0 = (unsigned long long)exc_rows;
+    ea.n_probe = np;
+    ea.n_build = nbc;
+    const size_t lds = cells + (cells >> 5) * 4;
+    if (outer) {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_cols<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_da_emit_cols<512, true>), pgrid, dim3(512), lds, ctx->stream, ea);
+    } else {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_cols<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_da_emit_cols<512, false>), pgrid, dim3(512), lds, ctx->stream, ea);
+    }
+    TSQ_HIP(h, hipGetLastError());
+    j->st.kernel_launches++;
+    for (int oc = 0; oc < nout; oc++)
+        if (may_null_v[oc]) TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, rb->notnull[oc].as<uint8_t>(), rb->bitmap[oc].as<uint8_t>(), out_rows));
+    TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+    j->have_probe_ev = true;
+    return deliver_batch(j, std::move(rb), may_null_v);
+}
+
 // ---------------------------------------------------------------- materialising radix path (host side)
 // HashJoinExec.Next materialises every joined row (executor/join.go:125-146, joiner.go:351-378, chunk.go:334-356).  The direct
 // route sizes the batch with an unpartitioned probe (two random lines per probe row) and then gathers every output cell through
@@ -1823,6 +2092,12 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         TSQ_TRY(da_prepare(j));
         if (j->da_state == 1) return da_probe(j, pcs, nrows);
         return radix_probe(j, pcs, nrows);
+    }
+    if (da_cols_eligible(j, nrows, selected_dev)) {
+        TSQ_TRY(da_prepare(j));
+        TSQ_TRY(da_prepare_rows(j));
+        TSQ_TRY(da_prepare_cols(j));
+        if (j->da_cols_state == 1) return da_emit_cols(j, pcs, nrows);
     }
     if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
     if (da_emit_eligible(j, nrows, selected_dev)) {
@@ -2362,7 +2637,8 @@ TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t
         // process in slices so an emit batch stays bounded
         // device-resident input: larger emit batches (every batch costs a count pass, two host syncs and its output buffers)
         // (the materialising radix path partitions the whole push at once: its passes are the better the longer the partitions)
-        const int64_t slice = (j->count_only || radix_emit_eligible(j, pcs, nrows, selected)) ? nrows : std::max<int64_t>(j->cfg.probe_batch_rows, 32 << 20);
+        const int64_t slice = (j->count_only || radix_emit_eligible(j, pcs, nrows, selected) || (da_cols_eligible(j, nrows, selected) && j->da_cols_state >= 0))
+                                  ? nrows : std::max<int64_t>(j->cfg.probe_batch_rows, 32 << 20);
         for (int64_t off = 0; off < nrows; off += slice) {
             const int64_t n = std::min<int64_t>(slice, nrows - off);
             tsq_colset s;
@@ -2623,7 +2899,12 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->rovf.release();
     j->tkcnt.release();
     j->da_img.release();
-    for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss}) b->release();
+    for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
+    for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
+        j->da_bsorted[c].release();
+        j->da_bsorted_nn[c].release();
+        j->rcols[c].release();
+    }
     for (int v = 0; v < TSQ_LDS_MAXPAY; v++) {
         j->rpay[v].release();
         j->rovfpay[v].release();
