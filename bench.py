@@ -354,7 +354,8 @@ def main():
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
                         ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
-                        ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr))):
+                        ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
+                        ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True))):
             try:
                 out[key] = fn()
             except Exception as e:  # reporting only
@@ -464,43 +465,76 @@ def extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
             "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "steps": steps}
 
 
-def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3):
+def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3, nullable_left_outer=False):
     """The bench's join with its four output columns (probe k, v | build k, v) materialised in HBM: HashJoinExec.Next
-    (executor/join.go:125-146, joiner.go:351-378).  Algorithmic bytes: 32 B per probe row + 24 B per joined row."""
+    (executor/join.go:125-146, joiner.go:351-378).  Algorithmic bytes: 32 B per probe row + 24 B per joined row.
+    nullable_left_outer: 3 % NULL probe keys, 3 % NULL payload cells on both sides, LEFT OUTER JOIN (joiner.go:220-281: a probe row
+    without a match is padded with NULLs) — every probe row makes exactly one output row (unique build keys, hit ratio 1.0)."""
     lib = ctx.lib
     cfg = abi.JoinCfg()
-    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 2, 2
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_LEFT_OUTER if nullable_left_outer else abi.JOIN_INNER, 1, 1, 2, 2
     for i in range(2):
         cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    bms = []
+
+    def col(ptr, n, bm=None):
+        c = _dev_col(abi, ptr, n)
+        if bm:
+            c.null_bitmap = bm
+        return c
+
+    if nullable_left_outer:
+        tmp = ctx.alloc(max(nb, npr) * 8)
+        for n, colid in ((npr, 11), (npr, 12), (nb, 13)):  # bitmaps of: probe key, probe payload, build payload (3 % NULL each)
+            bm = ctx.alloc(n // 8 + 64)
+            ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=4, col=colid, m=7, null_pct=3), n, tmp, null_bitmap=bm)
+            bms.append(bm)
+        ctx.sync()
+        ctx.free(tmp)
+        bcols = (abi.Col * 2)(col(bk, nb), col(bv, nb, bms[2]))
+        pcols = (abi.Col * 2)(col(pk, npr, bms[0]), col(pv, npr, bms[1]))
+    else:
+        bcols = (abi.Col * 2)(col(bk, nb), col(bv, nb))
+        pcols = (abi.Col * 2)(col(pk, npr), col(pv, npr))
     best, first = 1e30, 1e30
     rows = 0
-    for _ in range(reps):
-        h = C.c_void_p()
-        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
-        try:
-            _lib.check(lib.tsq_join_build_push(h, (abi.Col * 2)(_dev_col(abi, bk, nb), _dev_col(abi, bv, nb)), 2, nb), h)
-            _lib.check(lib.tsq_join_build_finish(h), h)
-            ctx.sync()
-            for pass_no in range(2):  # HashJoinExec probes many chunks per build: pass 0 also lays the build payload out in table order
-                t = time.perf_counter()
-                _lib.check(lib.tsq_join_probe_push(h, (abi.Col * 2)(_dev_col(abi, pk, npr), _dev_col(abi, pv, npr)), 2, npr, None), h)
+    st = abi.Stats()
+    try:
+        for _ in range(reps):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                _lib.check(lib.tsq_join_build_push(h, bcols, 2, nb), h)
+                _lib.check(lib.tsq_join_build_finish(h), h)
                 ctx.sync()
-                dt = time.perf_counter() - t
-                if pass_no == 0:
-                    first = min(first, dt)
-                else:
-                    best = min(best, dt)
-            _lib.check(lib.tsq_join_probe_finish(h), h)
-            c = C.c_int64(0)
-            _lib.check(lib.tsq_join_count(h, C.byref(c)), h)
-            rows = c.value // 2
-        finally:
-            lib.tsq_join_destroy(h)
+                for pass_no in range(2):  # HashJoinExec probes many chunks per build: pass 0 also prepares the build side for the route taken
+                    t = time.perf_counter()
+                    _lib.check(lib.tsq_join_probe_push(h, pcols, 2, npr, None), h)
+                    ctx.sync()
+                    dt = time.perf_counter() - t
+                    if pass_no == 0:
+                        first = min(first, dt)
+                    else:
+                        best = min(best, dt)
+                _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+                _lib.check(lib.tsq_join_probe_finish(h), h)
+                c = C.c_int64(0)
+                _lib.check(lib.tsq_join_count(h, C.byref(c)), h)
+                rows = c.value // 2
+            finally:
+                lib.tsq_join_destroy(h)
+    finally:
+        for bm in bms:
+            ctx.free(bm)
     algo = 32.0 * npr + 24.0 * rows
-    return {"workload": "1e8 x 1e8 (k, v) x (k, v) inner join, 4 output columns written to HBM", "ms": best * 1e3, "joined_rows": rows,
-            "joined_rows_per_s": rows / best, "frac": algo / best / 8e12, "verified": rows == npr, "first_pass_ms": first * 1e3,
+    return {"workload": "1e8 x 1e8 (k, v) x (k, v) %s, 4 output columns written to HBM" % ("LEFT OUTER JOIN with 3 % NULL probe keys and 3 % NULL payload cells on both sides"
+                                                                                            if nullable_left_outer else "inner join"),
+            "ms": best * 1e3, "joined_rows": rows, "joined_rows_per_s": rows / best, "frac": algo / best / 8e12, "verified": rows == npr, "first_pass_ms": first * 1e3,
+            "route": {0: "direct (K3 + K4a + gather)", 2: "64-bit LDS route (partition with payload, sizing pass, emit)",
+                      3: "packed keys: probe columns travel with 2-byte entries, build columns sorted by word, K4e writes the rows"}.get(st.probe_route, str(st.probe_route)),
+            "packed_prepare_ms": st.packed_build_ms,
             "timing": "host clock around one probe_push of all rows + stream sync, best of %d; first_pass_ms = the first push after the build "
-                      "(it also lays the build payload out in table-slot order, once per build)" % reps}
+                      "(it also prepares the build side for the route: images, sorted rows and columns — packed_prepare_ms of kernels — once per build)" % reps}
 
 
 def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_000, double=False):
