@@ -296,3 +296,76 @@ def test_bits_beyond_the_last_row_do_not_travel(ctx, orc):
     _lib.check(ctx.lib.tsq_chunk_encode(ctx.h, G.dev_cols([d]), 1, n, out.ctypes.data_as(C.c_void_p), len(want), 0, C.byref(need)), ctx.h)
     assert need.value == len(want) and out[:len(want)].tobytes() == want
     d.free()
+
+
+def test_offsets_that_decrease_in_the_middle_are_refused_before_anything_is_written(ctx, orc):
+    # offsets[0] == 0 and a plausible offsets[rows] are not enough — an offset in between that runs backwards (or far
+    # beyond the data) would put negative lengths / out-of-buffer cells into the decoded column.  The window's offsets are checked on
+    # the device (k_wire_check_offs) before a byte of the destination changes.
+    rng = np.random.default_rng(16)
+    chk = _chunk(rng, 40)
+    buf = orc.WireChunk.from_chunk(chk).encode()
+    codec = CC.Codec(ctx, TYPES)
+    pos = 8 + 5 + 320 + 8 + 5 + 160 + 8 + 5  # the offsets of column 2 (see test_damaged_buffers_and_bad_arguments)
+    for row, val in ((17, 1 << 40), (17, -5), (3, 10**6), (39, 0)):
+        bad = bytearray(buf)
+        end = int.from_bytes(buf[pos + 8 * 40:pos + 8 * 41], "little")
+        if val == 0 and end == 0:
+            continue
+        bad[pos + 8 * row:pos + 8 * row + 8] = int(val).to_bytes(8, "little", signed=True)
+        with pytest.raises(_lib.TsqError) as e:
+            codec.Decode(bytes(bad))
+        assert e.value.status == abi.ERR_INVALID and "damaged" in str(e.value), (row, val, str(e.value))
+    assert codec.Decode(buf).rows() == chk.rows()  # the undamaged chunk still decodes
+
+
+def test_encode_of_a_var_len_view_whose_offsets_start_anywhere(ctx, orc):
+    # DeviceColumn.view / tsq_colset_slice hand out var-len columns whose offsets do not start at 0.  The wire chunk carries
+    # offsets from 0 and only the view's bytes — byte-identical to encoding the sliced column (Codec.Encode of chk.Slice, codec.go:42-76)
+    rng = np.random.default_rng(18)
+    n = 5000
+    chk = Chunk(_chunk(rng, n).columns[:3])
+    lo, hi = 1000, 4200  # a multiple of 8: the bitmap of the view starts on a byte
+    want = orc.WireChunk.from_chunk(Chunk([c.slice(lo, hi) for c in chk.columns])).encode()
+    lib = ctx.lib
+    # host columns: pointers into the middle of the arrays
+    from tinysql_amd.chunk import make_cols
+    keep = []
+    cols = make_cols(chk.columns, keep)
+    for c in range(3):
+        es = ELEM[c] if ELEM[c] > 0 else 0
+        if es:
+            cols[c].data = cols[c].data + lo * es
+        else:
+            cols[c].offsets = cols[c].offsets + lo * 8
+        if cols[c].null_bitmap:
+            cols[c].null_bitmap = cols[c].null_bitmap + lo // 8
+        cols[c].length = hi - lo
+    need = C.c_int64(0)
+    _lib.check(lib.tsq_chunk_encode(ctx.h, cols, 3, hi - lo, None, 0, 0, C.byref(need)), ctx.h)
+    assert need.value == len(want)
+    out = np.zeros(need.value, np.uint8)
+    _lib.check(lib.tsq_chunk_encode(ctx.h, cols, 3, hi - lo, out.ctypes.data_as(C.c_void_p), need.value, 0, C.byref(need)), ctx.h)
+    assert out.tobytes() == want
+    # device columns: the same view of device-resident columns
+    d0, d1 = G.DevCol(ctx, abi.I64, n, True), G.DevCol(ctx, abi.F32, n, True)
+    ctx.h2d(d0.data, np.ascontiguousarray(chk.columns[0].data)); ctx.h2d(d0.bitmap, chk.columns[0].bitmap())
+    ctx.h2d(d1.data, np.ascontiguousarray(chk.columns[1].data)); ctx.h2d(d1.bitmap, chk.columns[1].bitmap())
+    d2 = G.DevStrCol(ctx, chk.columns[2])
+    dcols = G.dev_cols([d0, d1, d2])
+    for c in range(3):
+        if ELEM[c] > 0:
+            dcols[c].data = dcols[c].data + lo * ELEM[c]
+        else:
+            dcols[c].offsets = dcols[c].offsets + lo * 8
+        if dcols[c].null_bitmap:
+            dcols[c].null_bitmap = dcols[c].null_bitmap + lo // 8
+        dcols[c].length = hi - lo
+    dbuf = ctx.alloc(len(want) + 64)
+    _lib.check(lib.tsq_chunk_encode(ctx.h, dcols, 3, hi - lo, C.c_void_p(dbuf + 5), len(want), abi.COL_DEVICE, C.byref(need)), ctx.h)
+    back = np.zeros(len(want), np.uint8)
+    ctx.d2h(back, dbuf + 5)
+    assert back.tobytes() == want
+    for d in (d0, d1, d2):
+        d.free()
+    ctx.free(dbuf)

@@ -280,19 +280,36 @@ def test_overfull_slice_rebuilds_the_table_as_one_slice(ctx, orc):
         assert stats[0].build_slice_retries == 1 and stats[0].table_slice_bits == 0
 
 
-def test_heavily_duplicated_build_key_is_refused_quickly(ctx):
-    # d duplicates of one key cost O(d^2 / 8) bucket reads in an open-addressing multimap; rowHashMap.Put is O(1)
-    # (hash_table.go:247-256).  Beyond ~16 K duplicates the build gives the operator back to Go instead of running for minutes.
+def test_heavily_duplicated_build_key_takes_the_chained_table(ctx, orc):
+    # d duplicates of one key cost O(d^2 / 8) bucket reads in an open-addressing multimap; rowHashMap.Put is O(1) (hash_table.go:247-256).
+    # Round 3: when the multimap's bounded walks give up, the table is rebuilt with ONE slot per distinct key + a chain of its rows
+    # (rowHashMap's entry list) — any multiplicity, quickly, the same joined rows.
     import time
     nb = 1_500_000
-    bk = np.zeros(nb, dtype=np.int64)
+    bk = np.zeros(nb, dtype=np.int64)  # key 0: a million build rows
     bk[: nb // 3] = np.arange(nb // 3)
     build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(nb))])
-    probe = Chunk([Column(abi.I64, np.arange(10, dtype=np.int64)), Column(abi.I64, np.arange(10))])
+    pk = np.array([0, 1, 2, 0, 499_999, 500_000, 7, -1, 0], dtype=np.int64)
+    probe = Chunk([Column(abi.I64, pk, np.array([1, 1, 1, 1, 1, 1, 1, 1, 0], dtype=bool)), Column(abi.I64, np.arange(len(pk)))])
     t0 = time.time()
-    with pytest.raises(_lib.TsqError) as ei:
-        _count(ctx, _cfg(), build, probe, abi.RADIX_AUTO)
-    assert ei.value.status == abi.ERR_UNSUPPORTED and time.time() - t0 < 20
+    stats = []
+    got = _count(ctx, _cfg(), build, probe, abi.RADIX_AUTO, stats=stats)
+    zeros = nb - nb // 3 + 1
+    assert got == 2 * zeros + 4 and time.time() - t0 < 30
+    assert stats[0].build_slice_retries >= 1
+    # the joined rows themselves, inner and left outer, against the oracle on a smaller heavy key (40 K duplicates)
+    rng = np.random.default_rng(4)
+    bk2 = np.concatenate([np.full(40_000, 77), np.arange(5000)]).astype(np.int64)
+    rng.shuffle(bk2)
+    build2 = Chunk([Column(abi.I64, bk2), Column(abi.F64, rng.random(len(bk2)), rng.random(len(bk2)) > 0.1)])
+    probe2 = Chunk([Column(abi.I64, np.array([77, 3, 77, 9999, 4999], dtype=np.int64), np.array([1, 1, 0, 1, 1], dtype=bool)), Column(abi.I64, np.arange(5))])
+    for jt in (abi.JOIN_INNER, abi.JOIN_LEFT_OUTER):
+        cfg = H.join_cfg(probe2.types(), build2.types(), [0], [0], jt, 1)
+        want = orc.hash_join(cfg, build2, probe2)
+        got2 = G.run_join(ctx, cfg, build2, probe2, chunk_rows=1 << 22, pull_rows=8192)
+        assert got2.NumRows() == want.NumRows() and H.rows_equal_unordered(got2, want)
+        c, s, x = G.run_join(ctx, cfg, build2, probe2, chunk_rows=1 << 22, count_only=True, checksum=True)
+        assert c == want.NumRows() and (s, x) == orc.rows_checksum(want)
 
 
 # ---------------------------------------------------------------- materialising radix path (k_lds_probe_count MODE 1 / 2)

@@ -154,6 +154,56 @@ __global__ void __launch_bounds__(256) k_build_insert(BuildArgs a) {
     uint64_t tot = wave_sum_u64(ins);
     if ((threadIdx.x & 63) == 0 && tot) atomicAdd(a.inserted, (unsigned long long)tot);
 }
+// K2c — chained insert (JoinTable.next): find-or-claim the word's ONE slot, then push the row at the head of its chain
+// (rowHashMap.Put, hash_table.go:247-256).  Walks depend on the number of DISTINCT words only.
+struct ChainArgs {
+    BuildArgs b;
+    uint32_t* next;  // [build rows]
+};
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_build_insert_chained(ChainArgs ca) {
+    const BuildArgs& a = ca.b;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t ins = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.nrows; r += stride) {
+        const int64_t row = a.row0 + r;
+        uint64_t kw;
+        if (!load_kw<MULTI>(a.b, a.ks.bidx, a.ks.n_keys, a.ks.skip_high, row, kw)) continue;
+        ins++;
+        const uint64_t w = tsq_table_word(kw);
+        if (w == TSQ_EMPTY_KEY) {
+            uint32_t i = atomicAdd(a.sent_total, 1u);
+            if (i < a.sent_cap) a.sent_rows[i] = (uint32_t)row;
+            continue;
+        }
+        const uint64_t base_b = (uint64_t)jt_slice(a.t.tb, w) * a.t.bs;
+        uint32_t lb = jt_local(a.t.tb, a.t.bs, w);
+        const uint32_t max_steps = a.t.bs < TSQ_MAX_WALK ? a.t.bs : TSQ_MAX_WALK;
+        uint64_t slot = ~0ull;
+        for (uint32_t steps = 0; slot == ~0ull; steps++) {
+            if (steps >= max_steps) {
+                __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            const uint64_t bkt = base_b + lb;
+            unsigned long long* base = (unsigned long long*)(a.t.keys + bkt * TSQ_BUCKET);
+#pragma unroll 1
+            for (int s = 0; s < TSQ_BUCKET && slot == ~0ull; s++) {
+                unsigned long long cur = __hip_atomic_load(base + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == TSQ_EMPTY_KEY) cur = atomicCAS(base + s, (unsigned long long)TSQ_EMPTY_KEY, (unsigned long long)w);
+                if (cur == TSQ_EMPTY_KEY || cur == w) slot = bkt * TSQ_BUCKET + (uint64_t)s;  // claimed it, or the word lives here
+            }
+            lb = (lb + 1 == a.t.bs) ? 0 : lb + 1;
+        }
+        if (slot == ~0ull) {
+            if (__hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            continue;
+        }
+        ca.next[row] = atomicExch(&a.t.vals[slot], (uint32_t)row);  // vals start at TSQ_CHAIN_END
+    }
+    uint64_t tot = wave_sum_u64(ins);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(a.inserted, (unsigned long long)tot);
+}
 // second chance for the sentinel side list when it overflowed its first capacity
 template <bool MULTI>
 __global__ void __launch_bounds__(256) k_collect_sentinel(BuildArgs a) {
@@ -272,6 +322,15 @@ __device__ __forceinline__ void for_each_match(const ProbeArgs& a, int64_t k, ui
         }
         return;
     }
+    if (a.t.next) {  // chained table: one slot per word, then the word's rows
+        const uint64_t slot = jt_find_slot(a.t, w);
+        if (slot == ~0ull) return;
+        for (uint32_t brow = a.t.vals[slot]; brow != TSQ_CHAIN_END; brow = a.t.next[brow]) {
+            if (!MULTI && !(GEN && a.n_conds > 0)) f(brow);
+            else if (pair_matches<MULTI, GEN>(a, k, brow, errw, div0)) f(brow);
+        }
+        return;
+    }
     for_each_slot_w(a.t, w, [&](uint64_t slot) {
         if (!MULTI && !(GEN && a.n_conds > 0)) {
             f(a.t.vals[slot]);  // the load is dead-code-eliminated when f ignores the row id
@@ -301,7 +360,7 @@ __global__ void __launch_bounds__(256) k_probe_count(ProbeArgs a) {
         uint64_t kw = 0;
         uint32_t c = 0, first = TSQ_PAIR_MISS;
         if (probe_row_valid<MULTI, GEN>(a, k, kw, errw, div0)) {
-            if (!MULTI && !GEN && !CHK && !a.first_cnt) {
+            if (!MULTI && !GEN && !CHK && !a.first_cnt && !a.t.next) {
                 // leanest form: keys only, never touches vals
                 const uint64_t w = tsq_table_word(kw);
                 if (w == TSQ_EMPTY_KEY) c = a.t.sent_count;
@@ -669,7 +728,8 @@ struct tsq_join {
     bool never_match = false;  // key classes differ (int vs float): no row can ever match
     bool multi = false;
     KeySpec ks{};
-    DevBuf tkeys, tvals, sent;
+    DevBuf tkeys, tvals, sent, tnext;
+    bool chained = false;     // the table holds one slot per distinct word + row chains (JoinTable.next)
     uint64_t nbuckets = 0;  // bs << tb
     uint32_t tb = 0, bs = 0;  // slice geometry (tsq_jointable.h)
     bool unique = false;      // no two table slots hold the same word (the build compares every slot it walks past)
@@ -768,6 +828,7 @@ void fill_table(tsq_join* j, JoinTable& t) {
     t.bs = j->bs;
     t.sent_rows = j->sent.as<uint32_t>();
     t.sent_count = j->sent_count;
+    t.next = j->chained ? j->tnext.as<uint32_t>() : nullptr;
 }
 
 // decode the device error word into a status (first offending node, then row)
@@ -880,7 +941,7 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
 // AUTO takes it when both the table and the batch are big enough to pay for a partition pass.
 bool radix_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF) return false;
-    if (!j->count_only || j->checksum || j->multi || j->general || selected_dev || j->never_match) return false;
+    if (!j->count_only || j->checksum || j->multi || j->general || selected_dev || j->never_match || j->chained) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE) return true;
     // table slices of ~1.5 MB per partition need >= 8 partitions to be worth it; batch >= 4 Mi rows
@@ -1759,7 +1820,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
 // Eligible: inner join on one BIGINT key of the same signedness, no conditions / filters / selected[] / ordered output,
 // <= 3 eight-byte columns per side without NULLs, a sliced table.  Everything else keeps the direct route.
 bool radix_emit_eligible(const tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
-    if (j->radix_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->general || selected_dev || j->never_match || j->ordered) return false;
+    if (j->radix_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->general || selected_dev || j->never_match || j->ordered || j->chained) return false;
     if (j->tb < TSQ_RADIX_MIN_BITS || nrows <= 0 || nrows > 0x7fffffffLL) return false;
     if (j->cfg.n_probe_cols > 1 + TSQ_LDS_MAXPAY || j->cfg.n_build_cols > 1 + TSQ_LDS_MAXPAY) return false;
     const int32_t kt = j->cfg.build_types[j->ks.bidx[0]];
@@ -2516,6 +2577,10 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
             TSQ_TRY(j->tkeys.reserve(ctx, h, nbuckets * TSQ_BUCKET * 8));
             TSQ_TRY(j->tvals.reserve(ctx, h, nbuckets * TSQ_BUCKET * 4));
             TSQ_HIP(h, hipMemsetAsync(j->tkeys.p, 0x80, nbuckets * TSQ_BUCKET * 8, ctx->stream));
+            if (j->chained) {
+                TSQ_TRY(j->tnext.reserve(ctx, h, (size_t)nb * 4 + 64));
+                TSQ_HIP(h, hipMemsetAsync(j->tvals.p, 0xff, nbuckets * TSQ_BUCKET * 4, ctx->stream));
+            }
         }
         if (nb == 0 || j->never_match) {
             TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
@@ -2535,14 +2600,23 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
         a.fail = (uint32_t*)(ctx->dscratch + 2);
         if (!part_done) {
             TSQ_HIP(h, hipEventRecord(j->ev[0], ctx->stream));
-            if (j->multi) TSQ_TRY(launch_build<true>(j, a));
+            if (j->chained) {
+                ChainArgs ca;
+                ca.b = a;
+                ca.next = j->tnext.as<uint32_t>();
+                const int grid = tsq_grid_for(ctx, a.nrows, 256);
+                if (j->multi) hipLaunchKernelGGL(k_build_insert_chained<true>, dim3(grid), dim3(256), 0, ctx->stream, ca);
+                else hipLaunchKernelGGL(k_build_insert_chained<false>, dim3(grid), dim3(256), 0, ctx->stream, ca);
+                TSQ_HIP(h, hipGetLastError());
+                j->st.kernel_launches++;
+            } else if (j->multi) TSQ_TRY(launch_build<true>(j, a));
             else TSQ_TRY(launch_build<false>(j, a));
             TSQ_HIP(h, hipEventRecord(j->ev[1], ctx->stream));
             j->have_build_ev = true;
         }
         TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, ctx->dscratch, 24, hipMemcpyDeviceToHost, ctx->stream));
         TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
-        j->unique = (ctx->pinned[2] >> 32) == 0;
+        j->unique = !j->chained && (ctx->pinned[2] >> 32) == 0;
         if ((uint32_t)ctx->pinned[2]) {
             // A slice could not take all of its rows (skewed / heavily duplicated keys): once more as one slice at load
             // factor 0.5.  If even that walks more than TSQ_MAX_WALK buckets for one row, a key has tens of thousands of
@@ -2553,7 +2627,13 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
                 j->st.build_slice_retries++;
                 continue;
             }
-            return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "build key duplicated too heavily for the open-addressing table: fall back to the Go operator");
+            if (!j->chained) {  // a key with tens of thousands of build rows: one slot per distinct word + row chains (rowHashMap's layout)
+                j->chained = true;
+                sliced = false;
+                j->st.build_slice_retries++;
+                continue;
+            }
+            return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "the build side does not fit one open-addressing table: partition across GPUs first");
         }
         j->build_inserted = (int64_t)ctx->pinned[0];
         uint32_t sent_total = (uint32_t)ctx->pinned[1];
@@ -2879,6 +2959,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->results.clear();
     j->tkeys.release();
     j->tvals.release();
+    j->tnext.release();
     j->sent.release();
     j->psel.release();
     j->counters.release();

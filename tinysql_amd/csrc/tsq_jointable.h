@@ -31,7 +31,15 @@ struct JoinTable {
     uint32_t bs;        // buckets per slice (< 2^32)
     const uint32_t* sent_rows;
     uint32_t sent_count;
+    // CHAINED mode (a build key with tens of thousands of duplicates made the multimap's walks explode): ONE slot per distinct
+    // table word, vals[slot] = the word's most recently inserted build row, next[row] = the next build row with the same word
+    // (0xffffffff ends the chain) — rowHashMap's entry list (executor/hash_table.go:181-276): O(1) per inserted row whatever the
+    // multiplicity.  nullptr: the multimap described above.
+    const uint32_t* next;
 };
+#define TSQ_CHAIN_END 0xffffffffu
+
+
 
 // the word a key word is stored and compared as
 TSQ_HD uint64_t tsq_table_word(uint64_t kw) { return tsq_mix64(kw); }
@@ -48,6 +56,27 @@ TSQ_HD uint32_t jt_slice(uint32_t tb, uint64_t w) { return tb ? (uint32_t)(w >> 
 TSQ_HD uint32_t jt_local(uint32_t tb, uint32_t bs, uint64_t w) {
     const uint32_t x = (uint32_t)((w << tb) >> 32);
     return (uint32_t)(((uint64_t)x * bs) >> 32);
+}
+
+// chained mode: the slot that holds table word w, or ~0 when no build row has it
+__device__ __forceinline__ uint64_t jt_find_slot(const JoinTable& t, uint64_t w) {
+    const uint64_t base = (uint64_t)jt_slice(t.tb, w) * t.bs;
+    uint32_t lb = jt_local(t.tb, t.bs, w);
+    for (uint32_t steps = 0; steps < t.bs; steps++) {
+        const uint64_t bkt = base + lb;
+        const ulonglong2* line = reinterpret_cast<const ulonglong2*>(t.keys + bkt * 8);
+        const ulonglong2 a = line[0], b = line[1], c = line[2], d = line[3];
+        const uint64_t k[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+        bool has_empty = false;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            if (k[s] == w) return bkt * 8 + (uint64_t)s;
+            has_empty |= (k[s] == 0x8080808080808080ULL);
+        }
+        if (has_empty) break;
+        lb = (lb + 1 == t.bs) ? 0 : lb + 1;
+    }
+    return ~0ull;
 }
 
 // Visits every slot of the multimap whose table word equals w: f(slot) for each.

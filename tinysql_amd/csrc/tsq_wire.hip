@@ -117,9 +117,9 @@ TSQ_API tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n
     }
     TSQ_HIP(h, hipSetDevice(ctx->device));
     const bool in_dev = cols[0].flags & TSQ_COL_DEVICE, out_dev = out_flags & TSQ_COL_DEVICE;
-    DevBuf sdata[TSQ_MAX_COLS], sbm[TSQ_MAX_COLS], soffs[TSQ_MAX_COLS], dout, dcnt;
+    DevBuf sdata[TSQ_MAX_COLS], sbm[TSQ_MAX_COLS], soffs[TSQ_MAX_COLS], srebase[TSQ_MAX_COLS], dout, dcnt;
     auto fail = [&](tsq_status st) {
-        for (int c = 0; c < TSQ_MAX_COLS; c++) { sdata[c].release(); sbm[c].release(); soffs[c].release(); }
+        for (int c = 0; c < TSQ_MAX_COLS; c++) { sdata[c].release(); sbm[c].release(); soffs[c].release(); srebase[c].release(); }
         dout.release();
         dcnt.release();
         return st;
@@ -129,6 +129,7 @@ TSQ_API tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n
     const uint8_t* bm[TSQ_MAX_COLS];
     const int64_t* offs[TSQ_MAX_COLS];
     int64_t data_bytes[TSQ_MAX_COLS];
+    int64_t off0[TSQ_MAX_COLS] = {0};  // a var-len VIEW (DeviceColumn.view, tsq_colset_slice) has offsets that start anywhere: the wire's start at 0
     tsq_status s = dcnt.reserve(ctx, h, TSQ_MAX_COLS * 8 + 64);
     if (s != TSQ_OK) return fail(s);
     hipError_t e = hipMemsetAsync(dcnt.p, 0, TSQ_MAX_COLS * 8, ctx->stream);
@@ -141,17 +142,20 @@ TSQ_API tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n
             bm[c] = cols[c].null_bitmap;
             offs[c] = var ? cols[c].offsets : nullptr;
             if (var) e = hipMemcpyAsync(ctx->pinned + c, cols[c].offsets + nrows, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (var && e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 2 * TSQ_MAX_COLS + c, cols[c].offsets, 8, hipMemcpyDeviceToHost, ctx->stream);
             continue;
         }
         if (var) {
-            data_bytes[c] = cols[c].offsets[nrows];
-            if (data_bytes[c] < 0 || (data_bytes[c] > 0 && !cols[c].data)) return fail(tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_encode: bad offsets"));
+            off0[c] = cols[c].offsets[0];
+            data_bytes[c] = cols[c].offsets[nrows] - off0[c];
+            if (off0[c] < 0 || data_bytes[c] < 0 || (data_bytes[c] > 0 && !cols[c].data)) return fail(tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_encode: bad offsets"));
             s = soffs[c].reserve(ctx, h, ((size_t)nrows + 1) * 8 + 64);
             if (s == TSQ_OK) e = hipMemcpyAsync(soffs[c].p, cols[c].offsets, ((size_t)nrows + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
         }
         offs[c] = var ? soffs[c].as<int64_t>() : nullptr;
         if (s == TSQ_OK) s = sdata[c].reserve(ctx, h, (size_t)data_bytes[c] + 64);
-        if (s == TSQ_OK && e == hipSuccess && data_bytes[c] > 0) e = hipMemcpyAsync(sdata[c].p, cols[c].data, (size_t)data_bytes[c], hipMemcpyHostToDevice, ctx->stream);
+        if (s == TSQ_OK && e == hipSuccess && data_bytes[c] > 0)
+            e = hipMemcpyAsync(sdata[c].p, (const uint8_t*)cols[c].data + off0[c], (size_t)data_bytes[c], hipMemcpyHostToDevice, ctx->stream);
         data[c] = sdata[c].p;
         bm[c] = nullptr;
         if (cols[c].null_bitmap && nrows > 0) {
@@ -179,8 +183,10 @@ TSQ_API tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n
     int64_t nulls[TSQ_MAX_COLS], total = 0;
     for (int c = 0; c < n_cols; c++) {
         if (in_dev && cols[c].type == TSQ_BYTES) {
-            data_bytes[c] = (int64_t)ctx->pinned[c];
-            if (data_bytes[c] < 0) return fail(tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_encode: bad offsets"));
+            off0[c] = (int64_t)ctx->pinned[2 * TSQ_MAX_COLS + c];
+            data_bytes[c] = (int64_t)ctx->pinned[c] - off0[c];
+            if (off0[c] < 0 || data_bytes[c] < 0) return fail(tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_encode: bad offsets"));
+            data[c] = (const uint8_t*)data[c] + off0[c];  // the bytes of rows [0, nrows) of the view
         }
         nulls[c] = ca.bm[c] ? nrows - (int64_t)ctx->pinned[TSQ_MAX_COLS + c] : 0;
         total += 8 + (nulls[c] > 0 ? (int64_t)nbm : 0) + (cols[c].type == TSQ_BYTES ? (nrows + 1) * 8 : 0) + data_bytes[c];
@@ -193,6 +199,24 @@ TSQ_API tsq_status tsq_chunk_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n
         s = dout.reserve(ctx, h, (size_t)total + 64);
         if (s != TSQ_OK) return fail(s);
         w = dout.as<uint8_t>();
+    }
+    {   // offsets that do not start at 0 are rebased into an aligned scratch first (WM_OFFS wants an aligned destination; the wire
+        // position of the offsets is arbitrary): the wire chunk then carries offsets from 0 and only the view's bytes
+        MovePlan pre;
+        memset(&pre.a, 0, sizeof pre.a);
+        for (int c = 0; c < n_cols && s == TSQ_OK; c++) {
+            if (cols[c].type != TSQ_BYTES || off0[c] == 0) continue;
+            s = srebase[c].reserve(ctx, h, ((size_t)nrows + 1) * 8 + 64);
+            if (s != TSQ_OK) break;
+            pre.add(WM_OFFS, (const uint8_t*)offs[c], (uint8_t*)srebase[c].p, nrows + 1, -off0[c]);
+            offs[c] = srebase[c].as<int64_t>();
+        }
+        if (s != TSQ_OK) return fail(s);
+        if (pre.grid > 0) {
+            hipLaunchKernelGGL(k_wire_move, dim3(pre.grid), dim3(256), 0, ctx->stream, pre.a);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_chunk_encode(rebase): ") + hipGetErrorString(e)));
+        }
     }
     MovePlan mp;
     memset(&mp.a, 0, sizeof mp.a);
@@ -287,6 +311,23 @@ tsq_status wire_check(tsq_ctx* ctx, const char* who, const uint8_t* buf, int64_t
 }
 }  // namespace
 
+// the offsets of the window [first, first + take] of every var-len column must not decrease: its endpoints lie inside the data
+// (wire_view), so every cell then does — a damaged or hostile chunk is refused before a byte of the destination changes (the
+// reference slices out of range and panics, codec.go:314-320)
+struct WireOffsCheckArgs {
+    const uint8_t* offs[TSQ_MAX_COLS];  // at any byte position
+    int64_t n;                          // pairs to compare
+    uint32_t* bad;                      // bit c: column c
+};
+__global__ void __launch_bounds__(256) k_wire_check_offs(WireOffsCheckArgs a) {
+    const uint8_t* p = a.offs[blockIdx.y];
+    if (!p) return;
+    bool bad = false;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.n; k += (int64_t)gridDim.x * 256)
+        bad |= ((const tsq_wire_i64u*)(p + (k + 1) * 8))->v < ((const tsq_wire_i64u*)(p + k * 8))->v;
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(a.bad, 1u << blockIdx.y);
+}
+
 TSQ_API tsq_status tsq_chunk_decode_peek(tsq_ctx* ctx, const uint8_t* buf, int64_t n_bytes, uint32_t data_flags, const int32_t* col_types, int32_t n_cols,
                                          int64_t first_row, int64_t max_rows, int64_t* rows_total_out, int64_t* nrows_out, int64_t* bytes_out,
                                          int64_t* bytes_consumed) {
@@ -357,6 +398,32 @@ TSQ_API tsq_status tsq_chunk_decode(tsq_ctx* ctx, const uint8_t* buf, int64_t n_
                 if (col_types[c] == TSQ_BYTES) base[c] = (int64_t)ctx->pinned[c];
     }
     if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_chunk_decode: ") + hipGetErrorString(e)));
+    {
+        WireOffsCheckArgs oc;
+        memset(&oc, 0, sizeof oc);
+        bool any = false;
+        for (int c = 0; c < n_cols; c++)
+            if (col_types[c] == TSQ_BYTES && take > 0) { oc.offs[c] = w + v.offs_pos[c] + first * 8; any = true; }
+        if (any) {
+            oc.n = take;
+            oc.bad = (uint32_t*)(ctx->dscratch + 40);
+            e = hipMemsetAsync(oc.bad, 0, 8, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_wire_check_offs, dim3((unsigned)std::min<int64_t>(ctx->num_cus * 4, (take + 255) / 256), n_cols), dim3(256), 0, ctx->stream, oc);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 40, oc.bad, 8, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return fail(tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_chunk_decode(check): ") + hipGetErrorString(e)));
+            const uint32_t bad = (uint32_t)ctx->pinned[40];
+            if (bad) {
+                int c = 0;
+                while (!((bad >> c) & 1)) c++;
+                *nrows_out = 0;
+                return fail(tsq_fail(h, TSQ_ERR_INVALID, "tsq_chunk_decode: offsets of column " + std::to_string(c) + " are damaged (they decrease)"));
+            }
+        }
+    }
     const int b = (int)(dst_rows & 7);
     const int64_t bm_first = dst_rows >> 3, bm_bytes = ((dst_rows + take + 7) >> 3) - bm_first;
     MovePlan mp;

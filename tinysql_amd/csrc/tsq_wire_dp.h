@@ -32,8 +32,10 @@ TSQ_HD uint32_t tsq_wire_u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint3
 TSQ_HD int64_t tsq_wire_i64(const uint8_t* p) { return (int64_t)((uint64_t)tsq_wire_u32(p) | ((uint64_t)tsq_wire_u32(p + 4) << 32)); }
 
 // One column starting at `pos`.  elem: 4 / 8, or -1 for a var-len column (getFixedLen, codec.go:169-181).  Returns 0, or 1 when the
-// buffer ends inside the column or its offsets are not a non-decreasing sequence from 0 that stays inside the buffer (the
-// reference slices out of range and panics there; a malformed chunk is an error here).
+// buffer ends inside the column, its offsets do not start at 0 or its last offset is negative / beyond the buffer.  The offsets IN
+// BETWEEN are checked where they are used: tsq_chunk_decode verifies that the offsets of the window it appends do not decrease
+// (k_wire_check_offs, before anything is written) and that the window's endpoints lie inside the data (wire_view) — a damaged chunk
+// is an error (TSQ_ERR_INVALID) where the reference slices out of range and panics.
 TSQ_HD int32_t tsq_wire_parse_col(const uint8_t* buf, int64_t n_bytes, int64_t pos, int32_t elem, tsq_wire_col* d) {
     if (pos < 0 || n_bytes - pos < 8) return 1;
     d->rows = (int64_t)tsq_wire_u32(buf + pos);
