@@ -316,7 +316,7 @@ def test_offsets_that_decrease_in_the_middle_are_refused_before_anything_is_writ
         with pytest.raises(_lib.TsqError) as e:
             codec.Decode(bytes(bad))
         assert e.value.status == abi.ERR_INVALID and "damaged" in str(e.value), (row, val, str(e.value))
-    assert codec.Decode(buf).rows() == chk.rows()  # the undamaged chunk still decodes
+    assert codec.Decode(buf)[0].to_chunk().rows() == chk.rows()  # the undamaged chunk still decodes
 
 
 def test_encode_of_a_var_len_view_whose_offsets_start_anywhere(ctx, orc):

@@ -1118,7 +1118,11 @@ tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st,
     if (with_idx && miss) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     else if (with_idx) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, false>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     else if (st.ebits > 16) hipLaunchKernelGGL((k_da_partition<NT, K, uint32_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
-    else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    else {
+        static const bool pf = [] { const char* v = getenv("TSQ_DA_PREFETCH"); return v && v[0] == '1'; }();
+        if (pf) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, false, false, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+        else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    }
     TSQ_HIP(&j->hdr, hipGetLastError());
     j->st.kernel_launches++;
     return TSQ_OK;
