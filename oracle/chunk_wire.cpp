@@ -10,7 +10,11 @@
  *   Codec.DecodeToChunk / decodeColumn / setAllNotNull                       util/chunk/codec.go:88-155
  *   Decoder.{Reset, Decode, IsFinished, RemainedRows, ReuseIntermChk, decodeColumn}   util/chunk/codec.go:246-353
  * The reference slices out of range (and panics) on a damaged buffer; here those accesses return -1.
- * Pinned on the reference's own TestCodec (util/chunk/codec_test.go:29-71) through tests/test_oracle_chunk_wire.py.
+ * Pinned on the reference's own TestCodec (util/chunk/codec_test.go:29-71) in
+ * tests/test_oracle_codec_golden.py::test_storage_boundary_codecs_against_the_transcribed_vectors (the "chunk_codec" vector of
+ * tests/golden/codec_cases.json: the wire length the reference asserts, the per-column lengths and headers, the rows after
+ * DecodeToChunk).  The reference's test holds no golden BYTES beyond those sizes and headers; the byte layout itself is pinned by
+ * the statement-level restatement of codec.go:50-76 below and by tests/test_hostsim_wire.py (walks every alignment).
  */
 #include <cstdint>
 #include <cstring>
