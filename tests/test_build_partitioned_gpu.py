@@ -105,19 +105,18 @@ def test_partitioned_build_skewed_keys_rebuild_unsliced(ctx):
     assert got.NumRows() == n7 and sorted(got.columns[3].data.tolist()) == sorted(np.nonzero(bk == 7)[0].tolist())
 
 
-def test_build_with_one_key_on_most_rows_is_handed_back_to_go(ctx):
-    # 90 % of the build rows share one key: every insert would scan the key's whole run (O(d^2 / 8) bucket reads); rowHashMap.Put
-    # is O(1) (hash_table.go:247-256), so the build refuses and the Go operator runs instead (INTEGRATION.md eligibility)
+def test_build_with_one_key_on_most_rows_takes_the_chained_table(ctx):
+    # 90 % of the build rows share one key: in the open-addressing multimap every insert would scan the key's whole run (O(d^2 / 8)
+    # bucket reads).  rowHashMap.Put is O(1) (hash_table.go:247-256) — and since round 3 so is the build here: when the bounded walks
+    # give up (sliced, then one slice) the table is rebuilt with one slot per distinct key + row chains, with either build strategy
     nb = 200_000
     bk = np.full(nb, 7, dtype=np.int64)
     bk[::10] = np.arange(nb // 10) + 100
     build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(nb))])
-    probe = Chunk([Column(abi.I64, np.array([7], dtype=np.int64)), Column(abi.I64, np.arange(1))])
+    probe = Chunk([Column(abi.I64, np.array([7, 100, 99, 7], dtype=np.int64)), Column(abi.I64, np.arange(4))])
     cfg = H.join_cfg([abi.I64, abi.I64], [abi.I64, abi.I64], [0], [0], abi.JOIN_INNER, 1)
     for radix in (abi.RADIX_FORCE, abi.RADIX_OFF):
-        with pytest.raises(_lib.TsqError) as ei:
-            _join(ctx, cfg, build, probe, radix, count_only=True)
-        assert ei.value.status == abi.ERR_UNSUPPORTED
+        assert _join(ctx, cfg, build, probe, radix, count_only=True) == 2 * (nb - nb // 10) + 1
 
 
 def _device_join_checksum(ctx, n_build, n_probe, radix):

@@ -369,6 +369,9 @@ class GpuHashJoinExec(GpuExecutor):
 
     def Close(self):
         if self.h:
+            st = abi.Stats()
+            if self.lib.tsq_join_stats(self.h, C.byref(st)) == abi.OK:
+                self.last_stats = st  # which route the probe batches took (tools/q3.py reports it)
             self.lib.tsq_join_cancel(self.h)
             self.lib.tsq_join_destroy(self.h)
             self.h = None

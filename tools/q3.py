@@ -77,6 +77,10 @@ def tables_device(ctx, sf, seed=7):
     return customer, orders, lineitem
 
 
+JOINS = []  # the two join operators of the last plan (their route statistics are reported)
+ROUTES = {0: "direct", 1: "radix, slices through L2", 2: "radix, 64-bit LDS images", 3: "packed keys"}
+
+
 def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None, topn=0, string_segment=False):
     F, Col, K = E.ScalarFunction, E.Column, E.Constant
     if string_segment:  # WHERE c_mktsegment = 'BUILDING' on the varchar column; the join below only needs c_custkey (column pruning)
@@ -87,9 +91,11 @@ def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None, to
     ords = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, orders_d, batch_rows), [F("lt", Col(2, I), K(D))], jit=jit)
     # orders (probe, left) JOIN customer (build, right) ON o_custkey = c_custkey  ->  o_orderkey,o_custkey,o_orderdate,o_shippriority,c_custkey,c_mktsegment
     j1 = G.GpuHashJoinExec(ctx, ords, cust, [1], [0], abi.JOIN_INNER, 1)
+    JOINS[:] = [j1]
     line = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, lineitem_d, batch_rows), [F("gt", Col(1, I), K(D))], jit=jit)
     # lineitem (probe, left) JOIN j1 (build, right) ON l_orderkey = o_orderkey -> l_orderkey,l_shipdate,price,disc | o_orderkey,o_custkey,o_orderdate,o_shippriority,c_*,c_*
     j2 = G.GpuHashJoinExec(ctx, line, j1, [0], [0], abi.JOIN_INNER, 1)
+    JOINS.append(j2)
     proj = G.GpuProjectionExec(ctx, j2, [Col(0, I), Col(6, I), Col(7, I), F("mul", Col(2, R), F("minus", K(1.0), Col(3, R)))], jit=jit)
     aggs = [AggFuncDesc(abi.AGG_FIRSTROW, 0, I), AggFuncDesc(abi.AGG_FIRSTROW, 1, I), AggFuncDesc(abi.AGG_FIRSTROW, 2, I), AggFuncDesc(abi.AGG_SUM, 3, R)]
     agg = G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs)
@@ -202,7 +208,10 @@ def main():
             print(json.dumps({"query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg" + ("->TopN(10)" if topn else "") + (", c_mktsegment = 'BUILDING' on a varchar column" if strseg else ""), "SF": sf, "input_rows": rows_in,
                               "tables": "generated in HBM (tsq_gen_column)" if on_device else "numpy, copied to HBM once",
                               "groups": groups, "best_s": best, "exec_s_result_in_hbm": best_exec, "input_rows_per_s": rows_in / best,
-                              "input_rows_per_s_result_in_hbm": rows_in / best_exec, "host_table_gen_s": gen_s}))
+                              "input_rows_per_s_result_in_hbm": rows_in / best_exec, "host_table_gen_s": gen_s,
+                              "joins": [{"build_rows": int(j.last_stats.build_rows), "probe_rows": int(j.last_stats.probe_rows), "out_rows": int(j.last_stats.out_rows),
+                                         "route_of_last_batch": ROUTES.get(j.last_stats.probe_route, "?"), "radix_batches": int(j.last_stats.radix_batches),
+                                         "packed_key_bits": int(j.last_stats.packed_key_bits)} for j in JOINS if getattr(j, "last_stats", None) is not None]}))
         finally:
             for d in dev:
                 d.free()
