@@ -1582,22 +1582,25 @@ tsq_status da_prepare_cols(tsq_join* j) {
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
     sa.n = (int64_t)((const uint32_t*)(ctx->pinned + 56))[0];  // the build rows that have a usable key
     if (sa.n > nb) return TSQ_OK;
+    int nsort = 0;  // every build column but the key (the emit kernel recovers the key from the word)
     for (int c = 0; c < j->cfg.n_build_cols; c++) {
+        if (c == j->ks.bidx[0]) continue;
         TSQ_TRY(j->da_bsorted[c].reserve(ctx, h, (size_t)sa.n * 8 + 64));
-        sa.col[c] = j->bcols[c].data.as<uint64_t>();
-        sa.sorted[c] = j->da_bsorted[c].as<uint64_t>();
+        sa.col[nsort] = j->bcols[c].data.as<uint64_t>();
+        sa.sorted[nsort] = j->da_bsorted[c].as<uint64_t>();
         if (j->bcols[c].has_nulls) {
             TSQ_TRY(j->da_bsorted_nn[c].reserve(ctx, h, (size_t)sa.n + 64));
-            sa.nulls[c] = j->bcols[c].nulls.as<uint8_t>();
-            sa.sorted_nn[c] = j->da_bsorted_nn[c].as<uint8_t>();
+            sa.nulls[nsort] = j->bcols[c].nulls.as<uint8_t>();
+            sa.sorted_nn[nsort] = j->da_bsorted_nn[c].as<uint8_t>();
         }
+        nsort++;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     TSQ_HIP(h, hipEventCreate(&e0));
     TSQ_HIP(h, hipEventCreate(&e1));
     TSQ_HIP(h, hipEventRecord(e0, ctx->stream));
-    if (sa.n > 0) {
-        hipLaunchKernelGGL(k_da_sort_cols, dim3(tsq_grid_for(ctx, sa.n, 256), j->cfg.n_build_cols), dim3(256), 0, ctx->stream, sa);
+    if (sa.n > 0 && nsort > 0) {
+        hipLaunchKernelGGL(k_da_sort_cols, dim3(tsq_grid_for(ctx, sa.n, 256), nsort), dim3(256), 0, ctx->stream, sa);
         TSQ_HIP(h, hipGetLastError());
     }
     TSQ_HIP(h, hipEventRecord(e1, ctx->stream));
@@ -1626,10 +1629,14 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 4 + 64));
     TSQ_TRY(j->rovfidx.reserve(ctx, h, (size_t)nrows * 4 + 64));
     if (outer) TSQ_TRY(j->rmiss.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    const int kc = j->ks.pidx[0], kb = j->ks.bidx[0];
+    int trav[TSQ_DA_MAXCOLS], ntrav = 0;  // the probe columns that travel: all but the key
+    for (int c = 0; c < np; c++)
+        if (c != kc) trav[ntrav++] = c;
     bool any_nulls = false;
-    for (int c = 0; c < np; c++) {
-        TSQ_TRY(j->rcols[c].reserve(ctx, h, slots * 8 + 256));
-        any_nulls = any_nulls || pcs.nulls[c] != nullptr;
+    for (int v = 0; v < ntrav; v++) {
+        TSQ_TRY(j->rcols[v].reserve(ctx, h, slots * 8 + 256));
+        any_nulls = any_nulls || pcs.nulls[trav[v]] != nullptr;
     }
     if (any_nulls) TSQ_TRY(j->rnnmask.reserve(ctx, h, slots + 256));
     const size_t n_pc = (size_t)g.P + 1;
@@ -1649,7 +1656,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     st.bits = j->da_pbits;
     st.ebits = j->da_ebits;
     st.cap = g.cap;
-    for (int c = 0; c < np; c++) cs.pay[c] = j->rcols[c].as<uint64_t>();
+    for (int v = 0; v < ntrav; v++) cs.pay[v] = j->rcols[v].as<uint64_t>();
     cs.nnmask = any_nulls ? j->rnnmask.as<uint8_t>() : nullptr;
     TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
     TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
@@ -1657,15 +1664,14 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));
     DaColSrc src;
     memset(&src, 0, sizeof src);
-    const int kc = j->ks.pidx[0];
     src.key.data = (const uint64_t*)pcs.data[kc];
     src.key.nulls = pcs.nulls[kc];
     src.key.nrows = nrows;
-    src.n_cols = np;
+    src.n_cols = ntrav;
     src.any_nulls = any_nulls ? 1 : 0;
-    for (int c = 0; c < np; c++) {
-        src.col[c] = (const uint64_t*)pcs.data[c];
-        src.nulls[c] = pcs.nulls[c];
+    for (int v = 0; v < ntrav; v++) {
+        src.col[v] = (const uint64_t*)pcs.data[trav[v]];
+        src.nulls[v] = pcs.nulls[trav[v]];
     }
     hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
     for (int e = 0; e < 3; e++)
@@ -1748,17 +1754,29 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
         uint64_t* od = rb->data[oc].as<uint64_t>();
         uint8_t* of = may_null ? rb->notnull[oc].as<uint8_t>() : nullptr;
         if (from_probe) {
-            ea.out_probe[sc] = od;
-            ea.out_probe_nn[sc] = of;
+            if (sc == kc) {
+                ea.out_pkey = od;
+                ea.out_pkey_nn = of;
+            } else {
+                const int v = sc < kc ? sc : sc - 1;
+                ea.out_probe[v] = od;
+                ea.out_probe_nn[v] = of;
+            }
             xa.pcol[sc] = (const uint64_t*)pcs.data[sc];
             xa.pnull[sc] = pcs.nulls[sc];
             xa.out_probe[sc] = od;
             xa.out_probe_nn[sc] = of;
         } else {
-            ea.out_build[sc] = od;
-            ea.out_build_nn[sc] = of;
-            ea.bsorted[sc] = j->da_bsorted[sc].as<uint64_t>();
-            ea.bsorted_nn[sc] = j->bcols[sc].has_nulls ? j->da_bsorted_nn[sc].as<uint8_t>() : nullptr;
+            if (sc == kb) {
+                ea.out_bkey = od;
+                ea.out_bkey_nn = of;
+            } else {
+                const int v = sc < kb ? sc : sc - 1;
+                ea.out_build[v] = od;
+                ea.out_build_nn[v] = of;
+                ea.bsorted[v] = j->da_bsorted[sc].as<uint64_t>();
+                ea.bsorted_nn[v] = j->bcols[sc].has_nulls ? j->da_bsorted_nn[sc].as<uint8_t>() : nullptr;
+            }
             xa.bcol[sc] = j->bcols[sc].data.as<uint64_t>();
             xa.bnull[sc] = j->bcols[sc].has_nulls ? j->bcols[sc].nulls.as<uint8_t>() : nullptr;
             xa.out_build[sc] = od;
@@ -1798,8 +1816,9 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     ea.pstart = j->da_pstart.as<uint32_t>();
     ea.pbase = pa.pcount;
     ea.row0 = (unsigned long long)exc_rows;
-    ea.n_probe = np;
-    ea.n_build = nbc;
+    ea.dm = j->da_dm;
+    ea.n_probe = ntrav;
+    ea.n_build = nbc - 1;
     const size_t lds = cells + (cells >> 5) * 4;
     if (outer) {
         TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_cols<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
