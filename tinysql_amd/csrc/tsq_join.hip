@@ -1751,6 +1751,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
         if (s == TSQ_OK && may_null) s = rb->notnull[oc].reserve(ctx, h, (size_t)out_rows + 64);
         if (s == TSQ_OK && may_null) s = rb->bitmap[oc].reserve(ctx, h, tsq_bitmap_bytes(out_rows) + 16);
         if (s != TSQ_OK) { rb->release(); return s; }
+        if (may_null) TSQ_HIP(h, hipMemsetAsync(rb->notnull[oc].p, 1, (size_t)out_rows, ctx->stream));  // K4e stores the NULL cells' flags only
         uint64_t* od = rb->data[oc].as<uint64_t>();
         uint8_t* of = may_null ? rb->notnull[oc].as<uint8_t>() : nullptr;
         if (from_probe) {
@@ -1820,12 +1821,14 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     ea.n_probe = ntrav;
     ea.n_build = nbc - 1;
     const size_t lds = cells + (cells >> 5) * 4;
-    if (outer) {
-        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_cols<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_da_emit_cols<512, true>), pgrid, dim3(512), lds, ctx->stream, ea);
-    } else {
-        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_cols<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_da_emit_cols<512, false>), pgrid, dim3(512), lds, ctx->stream, ea);
+    {
+        const void* fn = outer ? (j->da_unique ? (const void*)k_da_emit_cols<512, true, true> : (const void*)k_da_emit_cols<512, true, false>)
+                               : (j->da_unique ? (const void*)k_da_emit_cols<512, false, true> : (const void*)k_da_emit_cols<512, false, false>);
+        TSQ_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (outer && j->da_unique) hipLaunchKernelGGL((k_da_emit_cols<512, true, true>), pgrid, dim3(512), lds, ctx->stream, ea);
+        else if (outer) hipLaunchKernelGGL((k_da_emit_cols<512, true, false>), pgrid, dim3(512), lds, ctx->stream, ea);
+        else if (j->da_unique) hipLaunchKernelGGL((k_da_emit_cols<512, false, true>), pgrid, dim3(512), lds, ctx->stream, ea);
+        else hipLaunchKernelGGL((k_da_emit_cols<512, false, false>), pgrid, dim3(512), lds, ctx->stream, ea);
     }
     TSQ_HIP(h, hipGetLastError());
     j->st.kernel_launches++;
