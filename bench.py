@@ -350,7 +350,9 @@ def main():
 
     # ---------------------------------------------------------------- BASELINE configs[1], configs[2] and the materialising join (N = 1)
     if not distributed and not args.no_extras and nb == 100_000_000 and npr == 100_000_000:
-        for key, fn in (("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
+        for key, fn in (("build_warm", lambda: extra_build_warm(ctx, abi, _lib, bk, bv, nb)),
+                        ("pcie_inclusive_1e7", lambda: extra_pcie(ctx, abi, _lib)),
+                        ("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
                         ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
@@ -430,6 +432,93 @@ def extra_c2(ctx, abi, _lib, pk, npr, nb=10_000_000, steps=10):
             "frac": 24.0 * npr / ms / 1e6 / 8000.0, "verified": cnt.value == (steps + 2) * npr, "probe_kernel_ms": st.radix_probe_kernel_ms,
             "partition_kernel_ms": st.partition_kernel_ms, "build_kernel_ms": st.build_kernel_ms, "steps": steps, "route": st.probe_route,
             "packed_key_bits": st.packed_key_bits}
+
+
+def extra_build_warm(ctx, abi, _lib, bk, bv, nb):
+    """`build_ms` of the headline is a COLD build: ~6 GB of first-touch hipMalloc (35 ms per GB).  A second build on the same context
+    finds its buffers in the context's pool — what every join after the first one of a session sees."""
+    lib = ctx.lib
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 2, 2
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    out = []
+    for _ in range(2):
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            t0 = time.perf_counter()
+            _lib.check(lib.tsq_join_build_push(h, (abi.Col * 2)(_dev_col(abi, bk, nb), _dev_col(abi, bv, nb)), 2, nb), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            ctx.sync()
+            out.append((time.perf_counter() - t0) * 1e3)
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+        finally:
+            lib.tsq_join_destroy(h)
+    return {"workload": "tsq_join_build_push + tsq_join_build_finish of 1e8 (k, v) rows, buffers from the context's pool", "build_ms_warm": min(out),
+            "build_kernel_ms": st.build_kernel_ms, "algorithmic_frac_of_kernels": 32.0 * nb / st.build_kernel_ms / 1e6 / 8000.0 if st.build_kernel_ms > 0 else None}
+
+
+def extra_pcie(ctx, abi, _lib, n=10_000_000):
+    """SURVEY.md §8(d) "end-to-end incl. H2D / D2H": a 1e7 x 1e7 (k, v) x (k, v) inner join with HOST chunks in and HOST chunks out, the
+    way the cgo shim drives it: pushes of tidb_max_chunk_size = 1024 rows (copied into pinned staging, flushed in 4 Mi-row batches) and
+    pulls of 1024 rows, against pushes / pulls of 1 Mi rows.  Never `value`: the link (63 GB/s) bounds a 16-byte row at 4e9 rows/s."""
+    import numpy as np
+    lib = ctx.lib
+    rng = np.random.default_rng(1)
+    bk, bv = rng.permutation(n).astype(np.int64), rng.integers(0, 1 << 40, n)
+    pk, pv = rng.integers(0, n, n), np.arange(n, dtype=np.int64)
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 2, 2
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    res = {}
+    for chunk in (1024, 1 << 20):
+        def cols(a, b, lo, hi):
+            arr = (abi.Col * 2)()
+            for i, x in enumerate((a, b)):
+                arr[i].data, arr[i].length, arr[i].elem_size, arr[i].type = x[lo:hi].ctypes.data_as(C.c_void_p), hi - lo, 8, abi.I64
+            return arr
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            t0 = time.perf_counter()
+            for lo in range(0, n, chunk):
+                _lib.check(lib.tsq_join_build_push(h, cols(bk, bv, lo, min(n, lo + chunk)), 2, min(n, lo + chunk) - lo), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            t_build = time.perf_counter() - t0
+            outb = [np.empty(chunk, dtype=np.int64) for _ in range(4)]
+            bms = [np.zeros(chunk // 8 + 16, dtype=np.uint8) for _ in range(4)]
+            oc = (abi.Col * 4)()
+            for i in range(4):
+                oc[i].data, oc[i].null_bitmap, oc[i].length, oc[i].elem_size, oc[i].type = outb[i].ctypes.data_as(C.c_void_p), bms[i].ctypes.data_as(C.c_void_p), chunk, 8, abi.I64
+            rows, t_pull = 0, 0.0
+            nn, eos = C.c_int64(0), C.c_int32(0)
+
+            def drain():
+                nonlocal rows, t_pull
+                while True:
+                    t = time.perf_counter()
+                    _lib.check(lib.tsq_join_pull(h, oc, 4, chunk, C.byref(nn), C.byref(eos)), h)
+                    t_pull += time.perf_counter() - t
+                    if nn.value == 0:
+                        return
+                    rows += nn.value
+            t0 = time.perf_counter()
+            for lo in range(0, n, chunk):
+                _lib.check(lib.tsq_join_probe_push(h, cols(pk, pv, lo, min(n, lo + chunk)), 2, min(n, lo + chunk) - lo, None), h)
+                if (lo // chunk) % 64 == 63 or chunk > 1024:
+                    drain()
+            _lib.check(lib.tsq_join_probe_finish(h), h)
+            drain()
+            t_probe = time.perf_counter() - t0
+        finally:
+            lib.tsq_join_destroy(h)
+        res["chunks_of_%d_rows" % chunk] = {"build_s": t_build, "probe_and_pull_s": t_probe, "of_which_pull_s": t_pull, "joined_rows": rows,
+                                             "probe_rows_per_s_end_to_end": n / t_probe, "verified": rows == n}
+    res["workload"] = "1e7 x 1e7 (k, v) x (k, v) inner join, host chunks in (pinned staging -> HBM) and host chunks out (D2H per result batch, then memcpy per pull)"
+    return res
 
 
 def extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
