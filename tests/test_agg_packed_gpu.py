@@ -101,3 +101,137 @@ def test_packed_agg_wide_keys_keep_the_64_bit_route(ctx, orc):
     chk, types = _chunk(rng, 80_000, -(1 << 40), 1 << 40)
     chk.columns[0] = Column(abi.I64, rng.integers(0, 30_000, 80_000) * (1 << 30))  # 30 K groups spread over 2^45
     _check(ctx, orc, chk, types, AGG_SETS["c3"], est=30_000, want_packed=False)
+
+
+# ---------------------------------------------------------------- several integer key columns as the fields of one packed word
+def _group_tols_multi(chk, key_idxs, aggs, real_cols):
+    """group_tols() for a several-column key: {tuple of canonical key cells: {output column: 2 n_g 2^-53 sum_g|v|}}"""
+    rows = chk.rows()
+    out = {}
+    for c in real_cols:
+        func, arg = aggs[c][0], aggs[c][1]
+        acc = {}
+        for r in rows:
+            if r[arg] is None:
+                continue
+            k = tuple(H.canon(r[i]) for i in key_idxs)
+            n, s = acc.get(k, (0, 0.0))
+            acc[k] = (n + 1, s + abs(float(r[arg])))
+        for k, (n, sa) in acc.items():
+            t = 2.0 * n * 2.0 ** -53 * sa
+            if func == abi.AGG_AVG:
+                t = t / n + (sa / n) * 2.0 ** -52
+            out.setdefault(k, {})[c] = t
+    return out
+
+
+def _mk_chunk(rng, n, specs):
+    """specs: per key column (type, lo, hi, null fraction or None for a column without a bitmap); then v I64, d F64, f F32, u U64"""
+    cols, types = [], []
+    for tp, lo, hi, nf in specs:
+        kv = rng.integers(lo, hi, n)
+        cols.append(Column(tp, kv.astype(np.uint64) if tp == abi.U64 else kv, None if nf is None else rng.random(n) >= nf))
+        types.append(tp)
+    nk = len(specs)
+    cols += [H.random_column(rng, abi.I64, n, 0.1, lo=-10**6, hi=10**6), H.random_column(rng, abi.F64, n, 0.1),
+             Column(abi.F32, rng.integers(-50, 50, n).astype(np.float32), rng.random(n) > 0.1), H.random_column(rng, abi.U64, n, 0.1)]
+    types += [abi.I64, abi.F64, abi.F32, abi.U64]
+    return Chunk(cols), types, nk
+
+
+def _mk_aggs(nk, types, which):
+    v, d, f, u = nk, nk + 1, nk + 2, nk + 3
+    first = [(abi.AGG_FIRSTROW, k, types[k]) for k in range(nk)]
+    sets = {
+        "sum_count": [(abi.AGG_SUM, v, abi.I64), (abi.AGG_COUNT, -1, abi.I64)],
+        "ints": [(abi.AGG_COUNT, v, abi.I64), (abi.AGG_AVG, v, abi.I64), (abi.AGG_MAX, v, abi.I64)],
+        "minmax2": [(abi.AGG_MIN, v, abi.I64), (abi.AGG_MAX, u, abi.U64), (abi.AGG_MIN, u, abi.U64), (abi.AGG_COUNT, -1, abi.I64)],
+        "reals": [(abi.AGG_SUM, d, abi.F64), (abi.AGG_AVG, d, abi.F64), (abi.AGG_MAX, d, abi.F64)],
+        "f32": [(abi.AGG_SUM, f, abi.F32), (abi.AGG_MIN, f, abi.F32), (abi.AGG_COUNT, f, abi.F32)],
+    }
+    return first + sets[which]
+
+
+def _mk_check(ctx, orc, chk, types, nk, aggs, chunk_rows=1 << 22, want_packed=True, min_batches=1):
+    cfg = H.agg_cfg(types, list(range(nk)), aggs, est_groups=5000)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    stats = []
+    got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=chunk_rows, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    if want_packed is not None:
+        assert (stats[0].packed_key_bits > 0) == want_packed, stats[0].packed_key_bits
+    if want_packed:
+        assert stats[0].radix_batches >= min_batches
+    real_cols = [i for i, a in enumerate(aggs) if a[0] in (abi.AGG_SUM, abi.AGG_AVG) and a[2] in (abi.F64, abi.F32)]
+    exact_cols = [i for i in range(nk, len(aggs)) if i not in real_cols]
+    _match_by_key(got, want, list(range(nk)), exact_cols, real_cols, _group_tols_multi(chk, list(range(nk)), aggs, real_cols))
+    return stats[0]
+
+
+MK_SPECS = {
+    # 7 + 5 + 2 bits: partitioned route (more than one LDS table of cells)
+    "partitioned": [(abi.I64, -50, 50, 0.03), (abi.I64, 10**12, 10**12 + 20, None), (abi.U64, 0, 3, 0.05)],
+    # 5 + 3 bits: the word fits one LDS table, no partition pass
+    "one_table": [(abi.I64, 0, 30, 0.04), (abi.I64, -3, 3, None)],
+    # four columns, one of them constant (a field of width 0)
+    "four": [(abi.I64, -5, 5, 0.1), (abi.U64, (1 << 63) + 5, (1 << 63) + 9, None), (abi.I64, 7, 8, None), (abi.I64, 0, 40, 0.02)],
+}
+
+
+@pytest.mark.parametrize("which", ["sum_count", "ints", "minmax2", "reals", "f32"])
+@pytest.mark.parametrize("spec", sorted(MK_SPECS))
+def test_packed_agg_several_key_columns_vs_oracle(ctx, orc, spec, which):
+    rng = np.random.default_rng(len(spec) * 7 + len(which))
+    specs = MK_SPECS[spec]
+    if spec == "four":  # rng.integers cannot draw above 2^63: the unsigned column is built by hand
+        specs = [specs[0], (abi.I64, 5, 9, None), specs[2], specs[3]]
+    chk, types, nk = _mk_chunk(rng, 120_001, specs)
+    if spec == "four":
+        chk.columns[1] = Column(abi.U64, chk.columns[1].data.astype(np.uint64) + np.uint64(1 << 63))
+        types[1] = abi.U64
+    st = _mk_check(ctx, orc, chk, types, nk, _mk_aggs(nk, types, which))
+    assert st.packed_key_bits >= 14
+
+
+def test_packed_agg_several_key_columns_later_batches_outside_the_fields(ctx, orc, monkeypatch):
+    monkeypatch.setenv("TSQ_AGG_BATCH_ROWS", str(1 << 16))
+    # batch 1 shows (a in [0, 100), b in [0, 8)) without NULLs in b; batch 2 brings b = NULL (no code: exception rows), a few a
+    # outside its field and a = NULL; batch 3 is mostly outside (the operator leaves the packed route for the row upsert)
+    rng = np.random.default_rng(12)
+    n1 = 1 << 16
+    a1, b1 = rng.integers(0, 100, n1), rng.integers(0, 8, n1)
+    a2 = np.concatenate([rng.integers(0, 100, n1 - 3000), rng.integers(5000, 5050, 3000)])
+    b2 = rng.integers(0, 8, n1)
+    a3, b3 = rng.integers(-10**9, -10**9 + 300, n1), rng.integers(0, 8, n1)
+    a = np.concatenate([a1, a2, a3])
+    b = np.concatenate([b1, b2, b3])
+    n = len(a)
+    ann = rng.random(n) > 0.02
+    bnn = np.ones(n, bool)
+    bnn[n1:] = rng.random(n - n1) > 0.05
+    chk = Chunk([Column(abi.I64, a, ann), Column(abi.I64, b, bnn), H.random_column(rng, abi.I64, n, 0.05, lo=-1000, hi=1000), H.random_column(rng, abi.F64, n, 0.05)])
+    types = [abi.I64, abi.I64, abi.I64, abi.F64]
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_FIRSTROW, 1, abi.I64), (abi.AGG_SUM, 2, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 3, abi.F64),
+            (abi.AGG_MIN, 2, abi.I64)]
+    cfg = H.agg_cfg(types, [0, 1], aggs, est_groups=1000)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    stats = []
+    got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=n1, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].packed_key_bits > 0 and stats[0].radix_batches >= 2
+    _match_by_key(got, want, [0, 1], [2, 3, 5], [4], _group_tols_multi(chk, [0, 1], aggs, [4]))
+
+
+def test_packed_agg_several_key_columns_with_shared_tags(ctx, orc, monkeypatch):
+    # TSQ_AGG_TAG_BITS (tests): 2^9 tags for ~3000 groups — distinct keys share a tag, the merge of the packed partial groups
+    # compares cells and walks on (k_agg_merge_multi phase 1), as the row upsert does
+    monkeypatch.setenv("TSQ_AGG_TAG_BITS", "9")
+    rng = np.random.default_rng(13)
+    chk, types, nk = _mk_chunk(rng, 90_000, [(abi.I64, 0, 400, 0.02), (abi.I64, -4, 4, 0.02)])
+    st = _mk_check(ctx, orc, chk, types, nk, _mk_aggs(nk, types, "sum_count"))
+    assert st.build_handed_back_rows > 0
+
+
+def test_packed_agg_several_key_columns_too_wide_keeps_the_row_upsert(ctx, orc):
+    rng = np.random.default_rng(14)
+    chk, types, nk = _mk_chunk(rng, 50_000, [(abi.I64, 0, 1 << 20, None), (abi.I64, 0, 1 << 10, None)])
+    chk.columns[0] = Column(abi.I64, rng.integers(0, 50, 50_000) * (1 << 14))
+    _mk_check(ctx, orc, chk, types, nk, _mk_aggs(nk, types, "sum_count"), want_packed=False)

@@ -229,6 +229,17 @@ __device__ __forceinline__ void agg_update_slot(const AggArgs& a, uint64_t s, in
     }
 }
 
+// the 64-bit tag of a several-column group key: a chain over the key words (shared by the row upsert and the merge of packed
+// partial groups — the same key must reach the same tag whichever way its rows came)
+#define TSQ_AGG_TAG_SEED 0x6A09E667F3BCC908ULL
+__device__ __forceinline__ uint64_t agg_tag_step(uint64_t h, uint64_t hw, bool isnull) {
+    return tsq_splitmix64(h ^ hw) + (isnull ? 0x9E3779B97F4A7C15ULL : 0);
+}
+__device__ __forceinline__ uint64_t agg_tag_finish(uint64_t h, uint32_t tag_bits) {
+    if (tag_bits) h &= (1ull << tag_bits) - 1;
+    return (h == TSQ_EMPTY_TAG || h == TSQ_BUSY_TAG) ? h ^ 1 : h;
+}
+
 // A walk longer than this means the table is over-full for this batch (the host keeps load <= 0.5 for the groups it
 // knows, where a 256-slot run is astronomically unlikely): the item is handed back and the host grows the table.
 #define TSQ_AGG_PROBE_LIMIT 256
@@ -275,7 +286,7 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
                 if (tag == TSQ_EMPTY_TAG) { slot = a.t.cap; special = true; }
             }
         } else {
-            uint64_t h = 0x6A09E667F3BCC908ULL;
+            uint64_t h = TSQ_AGG_TAG_SEED;
             for (int k = 0; k < a.plan.n_keys; k++) {
                 const int c = a.plan.key_col[k];
                 const bool isn = tsq_is_null(a.in.nulls[c], row);
@@ -288,10 +299,9 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
                     hw = kw[k];
                 }
                 nullmask |= isn ? (1u << k) : 0u;
-                h = tsq_splitmix64(h ^ hw) + (isn ? 0x9E3779B97F4A7C15ULL : 0);
+                h = agg_tag_step(h, hw, isn);
             }
-            if (a.tag_bits) h &= (1ull << a.tag_bits) - 1;
-            tag = (h == TSQ_EMPTY_TAG || h == TSQ_BUSY_TAG) ? h ^ 1 : h;
+            tag = agg_tag_finish(h, a.tag_bits);
         }
         bool winner = false;
         if (MULTI && a.phase == 1) {
@@ -411,6 +421,39 @@ struct MergeArgs {
     unsigned long long* counters;  // [0]=new groups [1]=retry count
     uint64_t bail_after;           // as in AggArgs
 };
+// the words of partial group `rec` into the aggregates of slot `slot` (FIRSTROW is the caller's: it needs the key)
+__device__ __forceinline__ void merge_apply(const AfPlan& plan, const AfPartials& in, const AggTable& t, uint64_t slot, uint32_t rec) {
+    for (int i = 0; i < plan.n_aggs; i++) {
+        const AfAgg f = plan.f[i];
+        const AggState st = t.st[i];
+        if (f.func == TSQ_AGG_FIRSTROW) continue;
+        const unsigned long long w0 = in.w[f.w][rec];
+        switch (f.func) {
+            case TSQ_AGG_COUNT: atomicAdd(&st.acc[slot], w0); break;
+            case TSQ_AGG_SUM:
+            case TSQ_AGG_AVG:
+                if (af_is_real(f.type)) {
+                    atomicAdd((double*)&st.acc[slot], tsq_bits_f64(w0));
+                    if (f.func == TSQ_AGG_AVG) atomicAdd(&st.cnt[slot], in.w[f.w + 1][rec]);
+                } else {  // 128-bit add of (lo, hi)
+                    const unsigned long long old = atomicAdd(&st.acc[slot], w0);
+                    const unsigned long long hi = in.w[f.w + 1][rec] + ((old + w0 < old) ? 1ull : 0ull);
+                    if (hi) atomicAdd(&st.aux[slot], hi);
+                    if (f.func == TSQ_AGG_AVG) atomicAdd(&st.cnt[slot], in.w[f.w + 2][rec]);
+                }
+                if (f.func == TSQ_AGG_SUM) st.seen[slot] = 1;
+                break;
+            case TSQ_AGG_MAX:
+                atomicMax(&st.acc[slot], w0);
+                st.seen[slot] = 1;
+                break;
+            case TSQ_AGG_MIN:
+                atomicMin(&st.acc[slot], w0);
+                st.seen[slot] = 1;
+                break;
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_agg_merge(MergeArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t new_groups = 0;
@@ -446,46 +489,128 @@ __global__ void __launch_bounds__(256) k_agg_merge(MergeArgs a) {
             new_groups++;
             a.t.gkey[0][slot] = tag;
         }
-        for (int i = 0; i < a.plan.n_aggs; i++) {
-            const AfAgg f = a.plan.f[i];
-            const AggState st = a.t.st[i];
-            if (f.func == TSQ_AGG_FIRSTROW) {  // firstrow(group key): any row of the group (func_first_row.go:67-81)
-                if (winner) {
-                    st.acc[slot] = group_key_word_decode(tag, a.plan.key_type);
-                    st.seen[slot] = 1;
+        if (winner) {  // firstrow(group key): any row of the group (func_first_row.go:67-81)
+            for (int i = 0; i < a.plan.n_aggs; i++)
+                if (a.plan.f[i].func == TSQ_AGG_FIRSTROW) {
+                    a.t.st[i].acc[slot] = group_key_word_decode(tag, a.plan.key_type);
+                    a.t.st[i].seen[slot] = 1;
                 }
-                continue;
-            }
-            const unsigned long long w0 = a.in.w[f.w][rec];
-            switch (f.func) {
-                case TSQ_AGG_COUNT: atomicAdd(&st.acc[slot], w0); break;
-                case TSQ_AGG_SUM:
-                case TSQ_AGG_AVG:
-                    if (af_is_real(f.type)) {
-                        atomicAdd((double*)&st.acc[slot], tsq_bits_f64(w0));
-                        if (f.func == TSQ_AGG_AVG) atomicAdd(&st.cnt[slot], a.in.w[f.w + 1][rec]);
-                    } else {  // 128-bit add of (lo, hi)
-                        const unsigned long long old = atomicAdd(&st.acc[slot], w0);
-                        const unsigned long long hi = a.in.w[f.w + 1][rec] + ((old + w0 < old) ? 1ull : 0ull);
-                        if (hi) atomicAdd(&st.aux[slot], hi);
-                        if (f.func == TSQ_AGG_AVG) atomicAdd(&st.cnt[slot], a.in.w[f.w + 2][rec]);
-                    }
-                    if (f.func == TSQ_AGG_SUM) st.seen[slot] = 1;
-                    break;
-                case TSQ_AGG_MAX:
-                    atomicMax(&st.acc[slot], w0);
-                    st.seen[slot] = 1;
-                    break;
-                case TSQ_AGG_MIN:
-                    atomicMin(&st.acc[slot], w0);
-                    st.seen[slot] = 1;
-                    break;
-            }
         }
+        merge_apply(a.plan, a.in, a.t, slot, rec);
     }
     // one device atomic per workgroup: a same-address atomic per THREAD costs ~11 ns each, chip-wide (3e5 of them were
     // most of a 0.25 ms launch over 8e5 rows)
     block_add_u32(&a.counters[0], new_groups);
+}
+
+// K7c — merge of packed partial groups whose key is SEVERAL columns (tsq_daagg.h: key word = the fields d).  Same protocol as the
+// several-column row upsert (k_agg_update<true>): phase 0 claims a slot by the 64-bit tag of the decoded cells and the claimer
+// stores them, phase 1 (a later launch) compares the cells and merges the words — or walks on when another key owns the tag.
+struct MergeMultiArgs {
+    MergeArgs m;
+    DaAggKeys ks;
+    int32_t phase;
+    uint32_t* slot_of;
+    uint32_t tag_bits;
+};
+__global__ void __launch_bounds__(256) k_agg_merge_multi(MergeMultiArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t new_groups = 0;
+    const int nk = a.ks.n;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.m.n; r += stride) {
+        const uint32_t rec = a.m.retry_in ? a.m.retry_in[r] : (uint32_t)r;
+        const uint32_t d = (uint32_t)a.m.in.key[rec];
+        uint64_t kw[TSQ_DAAGG_MAXK];
+        uint32_t nullmask = 0;
+        uint64_t h = TSQ_AGG_TAG_SEED;
+        for (int k = 0; k < nk; k++) {
+            bool isn;
+            kw[k] = daagg_field_cell(a.ks, d, k, &isn);
+            nullmask |= isn ? (1u << k) : 0u;
+            h = agg_tag_step(h, kw[k], isn);
+        }
+        const unsigned long long tag = agg_tag_finish(h, a.tag_bits);
+        auto first_rows = [&](uint64_t sl) {  // firstrow(key column): the cell itself
+            for (int i = 0; i < a.m.plan.n_aggs; i++) {
+                const int fk = a.ks.fr_key[i];
+                if (fk < 0) continue;
+                a.m.t.st[i].acc[sl] = kw[fk];
+                a.m.t.st[i].seen[sl] = ((nullmask >> fk) & 1u) ? 0 : 1;
+            }
+        };
+        uint64_t slot;
+        if (a.phase == 0) {
+            slot = tsq_mulhi64(tsq_mix64(tag), a.m.t.cap);
+            bool found = false, winner = false;
+            const bool hopeless = __hip_atomic_load(&a.m.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > a.m.bail_after;
+            for (int probe = 0; probe < TSQ_AGG_PROBE_LIMIT && !hopeless; probe++) {
+                unsigned long long cur = __hip_atomic_load(&a.m.t.tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == TSQ_EMPTY_TAG) {
+                    cur = atomicCAS(&a.m.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, tag);
+                    if (cur == TSQ_EMPTY_TAG) { winner = true; found = true; break; }
+                }
+                if (cur == tag) { found = true; break; }
+                slot = slot + 1 == a.m.t.cap ? 0 : slot + 1;
+            }
+            if (!found) {
+                const uint32_t i = (uint32_t)atomicAdd(&a.m.counters[1], 1ull);
+                a.m.retry_out[i] = rec;
+                a.slot_of[r] = 0xffffffffu;
+                continue;
+            }
+            a.slot_of[r] = (uint32_t)slot;
+            if (winner) {
+                new_groups++;
+                for (int k = 0; k < nk; k++) a.m.t.gkey[k][slot] = kw[k];
+                a.m.t.gknull[slot] = (uint8_t)nullmask;
+                first_rows(slot);
+            }
+            continue;
+        }
+        const uint32_t s32 = a.slot_of[r];
+        if (s32 == 0xffffffffu) continue;  // handed back by phase 0
+        slot = s32;
+        auto keys_at = [&](uint64_t sl) -> bool {
+            bool same = a.m.t.gknull[sl] == (uint8_t)nullmask;
+            for (int k = 0; k < nk && same; k++) same = a.m.t.gkey[k][sl] == kw[k];
+            return same;
+        };
+        if (!keys_at(slot)) {  // another key owns this tag: the BUSY protocol of k_agg_update<true>, phase 1
+            atomicAdd(&a.m.counters[2], 1ull);
+            bool found = false;
+            int probe = 0;
+            slot = slot + 1 == a.m.t.cap ? 0 : slot + 1;
+            while (probe < TSQ_AGG_PROBE_LIMIT && !found) {
+                unsigned long long cur = __hip_atomic_load(&a.m.t.tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == TSQ_EMPTY_TAG) {
+                    cur = atomicCAS(&a.m.t.tag[slot], (unsigned long long)TSQ_EMPTY_TAG, (unsigned long long)TSQ_BUSY_TAG);
+                    if (cur == TSQ_EMPTY_TAG) {
+                        for (int k = 0; k < nk; k++) a.m.t.gkey[k][slot] = kw[k];
+                        a.m.t.gknull[slot] = (uint8_t)nullmask;
+                        first_rows(slot);
+                        __hip_atomic_store(&a.m.t.tag[slot], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        found = true;
+                        new_groups++;
+                    }
+                    continue;  // lost the race: the slot is BUSY or published now, look again
+                }
+                if (cur == TSQ_BUSY_TAG) continue;
+                if (cur == tag && keys_at(slot)) {
+                    found = true;
+                    break;
+                }
+                slot = slot + 1 == a.m.t.cap ? 0 : slot + 1;
+                probe++;
+            }
+            if (!found) {
+                const uint32_t i = (uint32_t)atomicAdd(&a.m.counters[1], 1ull);
+                a.m.retry_out[i] = rec;
+                continue;
+            }
+        }
+        merge_apply(a.m.plan, a.m.in, a.m.t, slot, rec);
+    }
+    block_add_u32(&a.m.counters[0], new_groups);
 }
 
 // re-insert every occupied slot of an old table into a bigger one (table growth)
@@ -723,6 +848,11 @@ struct tsq_agg {
     DaDomain da_dm{};
     uint32_t da_pbits = 0, da_ebits = 0;
     int64_t packed_batches = 0;
+    // several integer key columns as the fields of one packed word (tsq_daagg.h): mk_n > 1.  da_low: the word fits one LDS table
+    int mk_n = 0;
+    int32_t mk_col[TSQ_DAAGG_MAXK] = {0, 0, 0, 0};
+    DaAggKeys da_keys{};
+    bool da_low = false;
 };
 
 namespace {
@@ -918,6 +1048,68 @@ tsq_status launch_agg_da(tsq_agg* a, DaAggLdsArgs& la, int grid) {
     a->st.kernel_launches++;
     return TSQ_OK;
 }
+// several key columns: the range of every column in the first large batch gives its field (a nullable column gets one more code
+// for NULL); the fields must fit TSQ_DAAGG_MAX_BITS together
+tsq_status da_agg_setup_multi(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const AfPlan& pl = a->fplan;
+    DaAggKeys& ks = a->da_keys;
+    ks.n = a->mk_n;
+    uint32_t total = 0;
+    for (int k = 0; k < a->mk_n; k++) {
+        const int c = a->mk_col[k];
+        DaMinMaxArgs ma;
+        memset(&ma, 0, sizeof ma);
+        ma.src.data = (const uint64_t*)in.data[c];
+        ma.src.nulls = in.nulls[c];
+        ma.src.nrows = nrows;
+        ma.flip = a->cfg.group_key_type[k] == TSQ_I64 ? 0x8000000000000000ULL : 0ULL;
+        ma.out = (unsigned long long*)(ctx->dscratch + 48);
+        ctx->pinned[48] = ~0ULL;
+        ctx->pinned[49] = 0;
+        ctx->pinned[50] = 0;
+        TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 24, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, ma);
+        TSQ_HIP(h, hipGetLastError());
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        a->st.kernel_launches++;
+        const bool nullable = in.nulls[c] != nullptr;
+        uint64_t kmin = 0, range = 0;
+        if (ctx->pinned[50] != 0) {
+            kmin = ctx->pinned[48] ^ ma.flip;
+            range = (ctx->pinned[49] ^ ma.flip) - kmin;
+        }
+        if (range >> TSQ_DAAGG_MAX_BITS) return TSQ_OK;
+        const uint64_t codes = range + 1 + (nullable ? 1 : 0);
+        uint32_t w = 0;
+        while (((uint64_t)1 << w) < codes) w++;
+        ks.kmin[k] = kmin;
+        ks.width[k] = w;
+        ks.shift[k] = total;
+        ks.nullcode[k] = nullable ? (uint32_t)(((uint64_t)1 << w) - 1) : TSQ_DAAGG_NO_NULL;
+        ks.maxd[k] = (uint32_t)(((uint64_t)1 << w) - 1) - (nullable ? 1u : 0u);
+        if (w == 0) ks.maxd[k] = 0;
+        total += w;
+        if (total > TSQ_DAAGG_MAX_BITS) return TSQ_OK;
+    }
+    const uint32_t log2c = pl.W <= 3 ? 12u : 11u;
+    a->da_low = total <= log2c;  // the word fits one LDS table: no partition pass (k_agg_da_low)
+    uint32_t b = std::max(total, log2c + TSQ_RADIX_MIN_BITS);
+    if (b - log2c > TSQ_RADIX_MAX_BITS) return TSQ_OK;
+    a->da_pbits = b - log2c;
+    a->da_ebits = log2c;
+    a->da_dm.kmin = 0;  // the partial group's key word is the field word d itself
+    a->da_dm.range = ((uint64_t)1 << b) - 1;
+    a->da_dm.b = b;
+    a->da_dm.s = (b + 1) / 2;
+    a->da_dm.mask = (uint32_t)(((uint64_t)1 << b) - 1);
+    a->da_dm.skip_high = 0;
+    a->da_state = 1;
+    return TSQ_OK;
+}
+
 // the key range of the first large batch decides: [kmin, kmin + 2^b) with b <= TSQ_DAAGG_MAX_BITS, or the 64-bit H mode
 tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     if (a->da_state) return TSQ_OK;
@@ -927,6 +1119,7 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     static const bool env_off = [] { const char* v = getenv("TSQ_PACKED_KEYS"); return v && v[0] == '0'; }();
     const AfPlan& pl = a->fplan;
     if (env_off || (pl.key_type != TSQ_I64 && pl.key_type != TSQ_U64)) return TSQ_OK;
+    if (a->mk_n > 1) return da_agg_setup_multi(a, in, nrows);
     DaMinMaxArgs ma;
     memset(&ma, 0, sizeof ma);
     ma.src.data = (const uint64_t*)in.data[pl.key_col];
@@ -969,10 +1162,13 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     tsq_handle_hdr* h = &a->hdr;
     const AfPlan& pl = a->fplan;
     const uint32_t S = af_slots(pl);
-    const bool low = groups_est <= (int64_t)(S / 2);
+    const bool mk = a->mk_n > 1;  // several key columns: the packed route or nothing
+    const bool low = !mk && groups_est <= (int64_t)(S / 2);
     uint32_t bits = 0;
     if (!low) TSQ_TRY(da_agg_setup(a, in, nrows));
     const bool packed = !low && a->da_state == 1;
+    if (mk && !packed) return TSQ_OK;
+    const bool packed_low = packed && mk && a->da_low;
     if (!low && !packed) {
         // H: partitions small enough that their groups half-fill one LDS table, at least 256 of them (parallelism)
         // (2^11 partitions — tables 1/8 full, shorter walks — were measured: k_agg_lds 0.66 -> 0.64 ms per 1e8 rows, but the partition
@@ -982,7 +1178,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         if (((double)groups_est * 1.3 / (double)S) > (double)(1u << bits)) return TSQ_OK;  // too many groups for LDS tables
     }
     // partial-group buffer: every workgroup may emit a table, plus spilled rows; beyond cap the batch is redone row by row
-    const size_t nblocks = low ? (size_t)ctx->num_cus : ((size_t)1 << (packed ? a->da_pbits : bits));
+    const size_t nblocks = (low || packed_low) ? (size_t)ctx->num_cus : ((size_t)1 << (packed ? a->da_pbits : bits));
     const size_t pcap = std::min<size_t>(nblocks * S + (size_t)nrows / 8 + 4096, 0x7fffffffULL);
     TSQ_TRY(a->fkey.reserve(ctx, h, pcap * 8));
     for (int k = 0; k < pl.W; k++) TSQ_TRY(a->fw[k].reserve(ctx, h, pcap * 8));
@@ -1002,6 +1198,35 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     la.exc_count = a->fctl.as<uint32_t>() + 1;
     if (low) {
         TSQ_TRY(launch_lds<0>(a, la, (int)std::min<int64_t>(ctx->num_cus, (nrows + TSQ_AF_NT - 1) / TSQ_AF_NT)));
+    } else if (packed_low) {
+        DaAggLowArgs lo;
+        memset(&lo, 0, sizeof lo);
+        lo.plan = pl;
+        lo.out = la.out;
+        lo.ks = a->da_keys;
+        lo.src.nrows = nrows;
+        for (int k = 0; k < a->mk_n; k++) {
+            lo.src.mkdata[k] = in.data[a->mk_col[k]];
+            lo.src.mknulls[k] = in.nulls[a->mk_col[k]];
+        }
+        for (int v = 0; v < pl.V; v++) {
+            lo.src.vdata[v] = in.data[pl.vcol[v]];
+            lo.src.vnulls[v] = in.nulls[pl.vcol[v]];
+            lo.src.vtype[v] = in.type[pl.vcol[v]];
+        }
+        lo.src.exc_rows = la.exc_rows;
+        lo.src.exc_count = la.exc_count;
+        const dim3 lgrid((unsigned)std::min<int64_t>(ctx->num_cus, (nrows + TSQ_AF_NT - 1) / TSQ_AF_NT));
+        switch (pl.W) {
+            case 1: hipLaunchKernelGGL((k_agg_da_low<1, 4096>), lgrid, dim3(TSQ_AF_NT), 0, ctx->stream, lo); break;
+            case 2: hipLaunchKernelGGL((k_agg_da_low<2, 4096>), lgrid, dim3(TSQ_AF_NT), 0, ctx->stream, lo); break;
+            case 3: hipLaunchKernelGGL((k_agg_da_low<3, 4096>), lgrid, dim3(TSQ_AF_NT), 0, ctx->stream, lo); break;
+            case 4: hipLaunchKernelGGL((k_agg_da_low<4, 2048>), lgrid, dim3(TSQ_AF_NT), 0, ctx->stream, lo); break;
+            default: hipLaunchKernelGGL((k_agg_da_low<5, 2048>), lgrid, dim3(TSQ_AF_NT), 0, ctx->stream, lo); break;
+        }
+        TSQ_HIP(h, hipGetLastError());
+        a->st.kernel_launches++;
+        a->packed_batches++;
     } else if (packed) {
         DaAggStore st;
         memset(&st, 0, sizeof st);
@@ -1030,6 +1255,10 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         src.kdata = in.data[pl.key_col];
         src.knulls = in.nulls[pl.key_col];
         src.nrows = nrows;
+        for (int k = 0; k < a->mk_n; k++) {
+            src.mkdata[k] = in.data[a->mk_col[k]];
+            src.mknulls[k] = in.nulls[a->mk_col[k]];
+        }
         for (int v = 0; v < pl.V; v++) {
             src.vdata[v] = in.data[pl.vcol[v]];
             src.vnulls[v] = in.nulls[pl.vcol[v]];
@@ -1037,10 +1266,12 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         }
         src.exc_rows = la.exc_rows;
         src.exc_count = la.exc_count;
+        DaAggKeys ks = a->da_keys;
+        if (!mk) ks.n = 1;
         const int pgrid = (int)std::min<int64_t>((nrows + T - 1) / T, ctx->num_cus);
-        if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st);
-        else if (pl.V == 1) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st);
-        else hipLaunchKernelGGL((k_daagg_partition<1024, 4, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st);
+        if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
+        else if (pl.V == 1) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
+        else hipLaunchKernelGGL((k_daagg_partition<1024, 4, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
         TSQ_HIP(h, hipGetLastError());
         a->st.kernel_launches++;
         DaAggLdsArgs da;
@@ -1119,12 +1350,29 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     ma.plan = pl;
     ma.in = la.out;
     ma.counters = a->counters.as<unsigned long long>();
+    if (mk) TSQ_TRY(a->slot_of.reserve(ctx, h, (size_t)n_part * 4 + 16));
     TSQ_TRY(upsert_loop(a, (int64_t)n_part, nullptr, [&](const AggTable& t, int64_t n, const uint32_t* retry_in, uint32_t* retry_out) -> tsq_status {
         ma.t = t;
         ma.bail_after = std::max<uint64_t>(1024, t.cap / 16);
         ma.n = n;
         ma.retry_in = retry_in;
         ma.retry_out = retry_out;
+        if (mk) {  // several key columns: claim by tag, then compare the cells (two launches, as the row upsert does)
+            if (t.cap + 2 >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "multi-key aggregate: more than 2^32 group slots");
+            MergeMultiArgs mm;
+            memset(&mm, 0, sizeof mm);
+            mm.m = ma;
+            mm.ks = a->da_keys;
+            mm.slot_of = a->slot_of.as<uint32_t>();
+            mm.tag_bits = a->test_tag_bits;
+            for (int phase = 0; phase < 2; phase++) {
+                mm.phase = phase;
+                hipLaunchKernelGGL(k_agg_merge_multi, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, mm);
+                TSQ_HIP(h, hipGetLastError());
+                a->st.kernel_launches++;
+            }
+            return TSQ_OK;
+        }
         hipLaunchKernelGGL(k_agg_merge, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, ma);
         TSQ_HIP(h, hipGetLastError());
         a->st.kernel_launches++;
@@ -1289,12 +1537,19 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
     {   // LDS pre-aggregation plan: one group key, raw-argument modes, every aggregate expressible in <= 5 LDS words
         AfPlan& fp = a->fplan;
         memset(&fp, 0, sizeof fp);
-        bool ok = cfg->n_group_keys == 1 && !has_str;  // LDS words are fixed width
+        bool ok = cfg->n_group_keys >= 1 && cfg->n_group_keys <= TSQ_DAAGG_MAXK && !has_str;  // LDS words are fixed width
         fp.n_aggs = cfg->n_aggs;
         if (ok) {
             fp.key_col = cfg->group_key_col[0];
             fp.key_type = cfg->group_key_type[0];
         }
+        // several key columns: integers only, and only through the packed route (their cells become the fields of one word)
+        a->mk_n = ok && cfg->n_group_keys > 1 ? cfg->n_group_keys : 0;
+        for (int k = 0; k < a->mk_n && ok; k++) {
+            a->mk_col[k] = cfg->group_key_col[k];
+            if (cfg->group_key_type[k] != TSQ_I64 && cfg->group_key_type[k] != TSQ_U64) ok = false;
+        }
+        memset(a->da_keys.fr_key, 0xff, sizeof a->da_keys.fr_key);
         for (int i = 0; i < cfg->n_aggs && ok; i++) {
             const tsq_agg_func& f = cfg->aggs[i];
             AfAgg& g = fp.f[i];
@@ -1303,7 +1558,16 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
             g.v = g.w = -1;
             if (f.mode != TSQ_MODE_COMPLETE && f.mode != TSQ_MODE_PARTIAL1) { ok = false; break; }
             if (f.func == TSQ_AGG_FIRSTROW) {  // only firstrow(group key): its value is the key itself
-                ok = f.arg_col == fp.key_col;
+                if (a->mk_n) {
+                    ok = false;
+                    for (int k = 0; k < a->mk_n; k++)
+                        if (f.arg_col == a->mk_col[k]) {
+                            a->da_keys.fr_key[i] = (int8_t)k;
+                            ok = true;
+                        }
+                } else {
+                    ok = f.arg_col == fp.key_col;
+                }
                 continue;
             }
             if (f.arg_col >= 0) {
@@ -1329,6 +1593,7 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
         }
         if (fp.W == 0) ok = false;
         if (ok) af_fill_wdesc(fp);
+        if (!ok) a->mk_n = 0;
         a->fast_ok = ok;
     }
     TSQ_HIP(ch, hipSetDevice(ctx->device));

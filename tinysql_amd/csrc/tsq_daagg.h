@@ -32,9 +32,25 @@ struct DaAggStore {
     uint32_t ovf_cap;
     uint32_t bits, ebits, cap;
 };
+// A group key of SEVERAL integer columns as one word: field i holds key_i - kmin_i (or the NULL code of a nullable column) at bit
+// shift[i]; a cell outside its field's window makes the row an exception, like a key outside [kmin, kmin + 2^b) of the one-column
+// route.  Equal words <=> equal cells in every column, NULL = NULL (the group key of getGroupKey, aggregate.go:359-394, is the
+// concatenation of the encoded cells: util/codec/codec.go:713-746).  n == 1: the DaDomain alone describes the key.
+#define TSQ_DAAGG_MAXK 4
+#define TSQ_DAAGG_NO_NULL 0xffffffffu
+struct DaAggKeys {
+    int32_t n;
+    uint64_t kmin[TSQ_DAAGG_MAXK];
+    uint32_t maxd[TSQ_DAAGG_MAXK];      // largest key - kmin the field holds
+    uint32_t nullcode[TSQ_DAAGG_MAXK];  // field value of a NULL cell; TSQ_DAAGG_NO_NULL: a NULL cell is an exception
+    uint32_t shift[TSQ_DAAGG_MAXK], width[TSQ_DAAGG_MAXK];
+    int8_t fr_key[TSQ_MAX_AGGS];        // aggregate i is FIRSTROW(key column fr_key[i]) (-1: it is not)
+};
 struct DaAggSrc {
     const void* kdata;
     const uint8_t* knulls;
+    const void* mkdata[TSQ_DAAGG_MAXK];   // several key columns (DaAggKeys.n > 1)
+    const uint8_t* mknulls[TSQ_DAAGG_MAXK];
     const void* vdata[TSQ_RADIX_MAXV];
     const uint8_t* vnulls[TSQ_RADIX_MAXV];
     int32_t vtype[TSQ_RADIX_MAXV];
@@ -42,6 +58,33 @@ struct DaAggSrc {
     uint32_t* exc_rows;   // rows the LDS stage cannot take (NULL key / NULL argument / key outside the packed range)
     uint32_t* exc_count;
 };
+// the fields of row `row` as one number d, or TSQ_DA_NONE (a cell outside its window, a NULL without a code)
+__device__ __forceinline__ uint32_t daagg_fields(const DaAggKeys& ks, const DaAggSrc& src, int64_t row) {
+    uint32_t d = 0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < TSQ_DAAGG_MAXK; k++) {
+        if (k < ks.n) {
+            uint32_t f;
+            if (tsq_is_null(src.mknulls[k], row)) {
+                f = ks.nullcode[k];
+                ok = ok && f != TSQ_DAAGG_NO_NULL;
+            } else {
+                const uint64_t diff = ((const uint64_t*)src.mkdata[k])[row] - ks.kmin[k];
+                ok = ok && diff <= (uint64_t)ks.maxd[k];
+                f = (uint32_t)diff;
+            }
+            d |= f << ks.shift[k];
+        }
+    }
+    return ok ? d : TSQ_DA_NONE;
+}
+// field k of d back into (cell, is NULL)
+__device__ __forceinline__ uint64_t daagg_field_cell(const DaAggKeys& ks, uint32_t d, int k, bool* isnull) {
+    const uint32_t f = (d >> ks.shift[k]) & (ks.width[k] >= 32 ? 0xffffffffu : ((1u << ks.width[k]) - 1u));
+    *isnull = ks.nullcode[k] != TSQ_DAAGG_NO_NULL && f == ks.nullcode[k];
+    return *isnull ? 0ull : ks.kmin[k] + (uint64_t)f;
+}
 __device__ __forceinline__ uint32_t daagg_region_len(const DaAggStore& st, uint32_t P, uint32_t p, uint32_t r) {
     const uint32_t c = r * P + p;
     uint32_t len = st.cursor[c];
@@ -54,7 +97,7 @@ __device__ __forceinline__ uint32_t daagg_region_len(const DaAggStore& st, uint3
 // staged through LDS next to the words; a run that does not fit its region sends its ROWS to the exception list (they are
 // aggregated row by row: exact under any skew).
 template <int NT, int K, int V>
-__global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain dm, DaAggStore st) {
+__global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain dm, DaAggStore st, DaAggKeys ks) {
     constexpr int T = NT * K;
     constexpr int MAXPER = (TSQ_RADIX_MAX_P + NT - 1) / NT;
     static_assert(T <= 65536 && (K % 2) == 0 && V >= 0 && V <= TSQ_RADIX_MAXV, "tile");
@@ -71,7 +114,8 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
     if (tid == 0) s_flag = 0;
     const int64_t ntiles = (src.nrows + T - 1) / T;
-    bool wide = src.knulls == nullptr;
+    const bool mk = ks.n > 1;  // several key columns: the per-row path
+    bool wide = src.knulls == nullptr && !mk;
 #pragma unroll
     for (int v = 0; v < V; v++) wide = wide && src.vnulls[v] == nullptr && src.vtype[v] != TSQ_F32;
     auto except = [&](uint32_t row) {
@@ -119,10 +163,17 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
 #pragma unroll
                 for (int v = 0; v < V; v++) pay[v][j] = 0;
                 if (pos < n) {
-                    bool isnull = tsq_is_null(src.knulls, base + pos);
+                    bool isnull = !mk && tsq_is_null(src.knulls, base + pos);
 #pragma unroll
                     for (int v = 0; v < V; v++) isnull |= tsq_is_null(src.vnulls[v], base + pos);
-                    if (!isnull) u[j] = da_word(dm, ((const uint64_t*)src.kdata)[base + pos]);
+                    if (!isnull) {
+                        if (mk) {
+                            const uint32_t d = daagg_fields(ks, src, base + pos);
+                            if (d != TSQ_DA_NONE) u[j] = tsq_da_mix(d, dm.s, dm.mask);
+                        } else {
+                            u[j] = da_word(dm, ((const uint64_t*)src.kdata)[base + pos]);
+                        }
+                    }
                     if (u[j] == TSQ_DA_NONE) except((uint32_t)base + pos);
                     else {
 #pragma unroll
@@ -214,14 +265,77 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
 }
 
 // K7d — direct-addressed LDS pre-aggregation of one partition: words [k][e], one non-returning LDS atomic per word and row.
-// A cell that received a row is marked in a bitmap; the partial groups (key = kmin + unmix(p : e)) leave through ONE returning
-// device atomic per workgroup and a block scan, as in k_agg_lds.
+// A cell that received a row is marked in a bitmap; the partial groups (key = kmin + unmix(p : e), or the field word d of a
+// several-column key) leave through ONE returning device atomic per workgroup and a block scan, as in k_agg_lds.
 struct DaAggLdsArgs {
     AfPlan plan;
     AfPartials out;
     DaAggStore st;
     DaDomain dm;
 };
+// what one row does to the accumulators of cell e
+template <int W, int CELLS>
+__device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1) {
+    atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const uint32_t d = wd[k];
+        const uint64_t cell = (d & 8u) ? c1 : c0;
+        const int32_t type = (int32_t)(d >> 4);
+        switch (d & 7u) {
+            case AF_W_ADD1: atomicAdd(&s_w[k][e], 1ull); break;
+            case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(&s_w[k][e]), af_real(cell, type)); break;
+            case AF_W_ADD_LO32: atomicAdd(&s_w[k][e], (unsigned long long)(cell & 0xffffffffull)); break;
+            case AF_W_ADD_HI32: atomicAdd(&s_w[k][e], (unsigned long long)((long long)cell >> 32)); break;
+            case AF_W_MAX: atomicMax(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
+            default: atomicMin(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
+        }
+    }
+}
+// the touched cells of the workgroup's table -> partial groups; key_of(cell) = the 64-bit key word of the record
+template <int W, int CELLS, class KeyOf>
+__device__ __forceinline__ void daagg_emit_cells(const AfPlan& plan, const AfPartials& out, unsigned long long (*s_w)[CELLS], const uint32_t* s_touch,
+                                                 uint32_t* s_base, uint32_t* s_wsum, KeyOf key_of) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < (uint32_t)CELLS / 32; i += TSQ_AF_NT) mine += (uint32_t)__popc(s_touch[i]);
+    uint32_t used;
+    (void)block_excl_scan<TSQ_AF_NT>(mine, s_wsum, &used);
+    __syncthreads();
+    if (tid == 0) *s_base = used ? __hip_atomic_fetch_add(out.count, used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    __syncthreads();
+    uint32_t running = *s_base;
+    for (uint32_t i0 = 0; i0 < (uint32_t)CELLS; i0 += TSQ_AF_NT) {
+        const uint32_t i = i0 + tid;
+        const bool occ = (s_touch[i >> 5] >> (i & 31u)) & 1u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<TSQ_AF_NT>(occ ? 1u : 0u, s_wsum, &total);
+        const uint32_t o = running + ex;
+        running += total;
+        __syncthreads();  // s_wsum is reused by the next pass
+        if (occ && o < out.cap) {
+            out.key[o] = key_of(i);
+            unsigned long long w[W];
+#pragma unroll
+            for (int k = 0; k < W; k++) w[k] = s_w[k][i];
+            for (int q = 0; q < plan.n_aggs; q++) {  // split int64 sums -> (lo, hi) of the 128-bit value
+                const AfAgg f = plan.f[q];
+                if (f.w < 0 || (f.func != TSQ_AGG_SUM && f.func != TSQ_AGG_AVG) || af_is_real(f.type)) continue;
+#pragma unroll
+                for (int k = 0; k + 1 < W; k++) {
+                    if (k == f.w) {
+                        const unsigned long long lo32 = w[k], hi32 = w[k + 1];
+                        const unsigned long long lo = (hi32 << 32) + lo32;
+                        w[k] = lo;
+                        w[k + 1] = (unsigned long long)((long long)hi32 >> 32) + (lo < lo32 ? 1ull : 0ull);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < W; k++) out.w[k][o] = w[k];
+        }
+    }
+}
 template <int W, int CELLS>
 __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
     constexpr int U = 4;
@@ -241,23 +355,6 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
         }
         for (uint32_t i = tid; i < (uint32_t)CELLS / 32; i += TSQ_AF_NT) s_touch[i] = 0;
         __syncthreads();
-        auto apply = [&](uint32_t e, uint64_t c0, uint64_t c1) {
-            atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
-#pragma unroll
-            for (int k = 0; k < W; k++) {
-                const uint32_t d = wd[k];
-                const uint64_t cell = (d & 8u) ? c1 : c0;
-                const int32_t type = (int32_t)(d >> 4);
-                switch (d & 7u) {
-                    case AF_W_ADD1: atomicAdd(&s_w[k][e], 1ull); break;
-                    case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(&s_w[k][e]), af_real(cell, type)); break;
-                    case AF_W_ADD_LO32: atomicAdd(&s_w[k][e], (unsigned long long)(cell & 0xffffffffull)); break;
-                    case AF_W_ADD_HI32: atomicAdd(&s_w[k][e], (unsigned long long)((long long)cell >> 32)); break;
-                    case AF_W_MAX: atomicMax(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
-                    default: atomicMin(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
-                }
-            }
-        };
         for (uint32_t r = 0; r < 8; r++) {
             const uint32_t len = daagg_region_len(a.st, P, p, r);
             const size_t base = (size_t)(p * 8u + r) * a.st.cap;
@@ -274,51 +371,65 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
                 }
 #pragma unroll
                 for (int x = 0; x < U; x++)
-                    if (i0 + (uint32_t)x * TSQ_AF_NT < len) apply(e[x], cells[x][0], cells[x][1]);
+                    if (i0 + (uint32_t)x * TSQ_AF_NT < len) daagg_apply<W, CELLS>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
             }
         }
         __syncthreads();
-        // ---- emit the touched cells
-        uint32_t mine = 0;
-        for (uint32_t i = tid; i < (uint32_t)CELLS / 32; i += TSQ_AF_NT) mine += (uint32_t)__popc(s_touch[i]);
-        uint32_t used;
-        (void)block_excl_scan<TSQ_AF_NT>(mine, s_wsum, &used);
-        __syncthreads();
-        if (tid == 0) s_base = used ? __hip_atomic_fetch_add(a.out.count, used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        __syncthreads();
-        uint32_t running = s_base;
-        for (uint32_t i0 = 0; i0 < (uint32_t)CELLS; i0 += TSQ_AF_NT) {
-            const uint32_t i = i0 + tid;
-            const bool occ = (s_touch[i >> 5] >> (i & 31u)) & 1u;
-            uint32_t total;
-            const uint32_t ex = block_excl_scan<TSQ_AF_NT>(occ ? 1u : 0u, s_wsum, &total);
-            const uint32_t o = running + ex;
-            running += total;
-            __syncthreads();  // s_wsum is reused by the next pass
-            if (occ && o < a.out.cap) {
-                const uint32_t uu = (p << a.st.ebits) | i;
-                a.out.key[o] = a.dm.kmin + (uint64_t)tsq_da_unmix(uu, a.dm.s, a.dm.mask);
-                unsigned long long w[W];
-#pragma unroll
-                for (int k = 0; k < W; k++) w[k] = s_w[k][i];
-                for (int q = 0; q < a.plan.n_aggs; q++) {  // split int64 sums -> (lo, hi) of the 128-bit value
-                    const AfAgg f = a.plan.f[q];
-                    if (f.w < 0 || (f.func != TSQ_AGG_SUM && f.func != TSQ_AGG_AVG) || af_is_real(f.type)) continue;
-#pragma unroll
-                    for (int k = 0; k + 1 < W; k++) {
-                        if (k == f.w) {
-                            const unsigned long long lo32 = w[k], hi32 = w[k + 1];
-                            const unsigned long long lo = (hi32 << 32) + lo32;
-                            w[k] = lo;
-                            w[k + 1] = (unsigned long long)((long long)hi32 >> 32) + (lo < lo32 ? 1ull : 0ull);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < W; k++) a.out.w[k][o] = w[k];
-            }
-        }
+        daagg_emit_cells<W, CELLS>(a.plan, a.out, s_w, s_touch, &s_base, s_wsum, [&](uint32_t i) -> unsigned long long {
+            return a.dm.kmin + (uint64_t)tsq_da_unmix((p << a.st.ebits) | i, a.dm.s, a.dm.mask);
+        });
     }
+}
+
+// K7e — the same accumulators WITHOUT a partition pass, for a several-column key whose field word fits one LDS table (d < CELLS):
+// every workgroup takes a stripe of the input columns, cell d of its table is the group.  Rows with a NULL argument, a cell outside
+// its field's window or a NULL key cell without a code go to the exception list.  16 B per row read once and
+// nothing written but the partial groups.
+struct DaAggLowArgs {
+    AfPlan plan;
+    AfPartials out;
+    DaAggSrc src;
+    DaAggKeys ks;
+};
+template <int W, int CELLS>
+__global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da_low(DaAggLowArgs a) {
+    uint32_t wd[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) wd[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.plan.wdesc[k]);
+    __shared__ unsigned long long s_w[W][CELLS];
+    __shared__ uint32_t s_touch[CELLS / 32];
+    __shared__ uint32_t s_base, s_wsum[TSQ_AF_NT / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < (uint32_t)CELLS; i += TSQ_AF_NT) {
+#pragma unroll
+        for (int k = 0; k < W; k++) s_w[k][i] = a.plan.init[k];
+    }
+    for (uint32_t i = tid; i < (uint32_t)CELLS / 32; i += TSQ_AF_NT) s_touch[i] = 0;
+    __syncthreads();
+    // a contiguous stripe of rows per workgroup (the tail of a 64-row bitmap word belongs to one workgroup)
+    const int64_t per = ((a.src.nrows + gridDim.x - 1) / gridDim.x + 63) & ~(int64_t)63;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < a.src.nrows ? lo + per : a.src.nrows;
+    for (int64_t row = lo + tid; row < hi; row += TSQ_AF_NT) {
+        bool isnull = false;
+#pragma unroll
+        for (int v = 0; v < TSQ_RADIX_MAXV; v++)
+            if (v < a.plan.V) isnull |= tsq_is_null(a.src.vnulls[v], row);
+        const uint32_t d = isnull ? TSQ_DA_NONE : daagg_fields(a.ks, a.src, row);
+        if (d == TSQ_DA_NONE || d >= (uint32_t)CELLS) {
+            const uint32_t x = __hip_atomic_fetch_add(a.src.exc_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.src.exc_rows[x] = (uint32_t)row;
+            continue;
+        }
+        uint64_t c[TSQ_RADIX_MAXV];
+#pragma unroll
+        for (int v = 0; v < TSQ_RADIX_MAXV; v++) {
+            c[v] = 0;
+            if (v < a.plan.V) c[v] = a.src.vtype[v] == TSQ_F32 ? (uint64_t)((const uint32_t*)a.src.vdata[v])[row] : ((const uint64_t*)a.src.vdata[v])[row];
+        }
+        daagg_apply<W, CELLS>(wd, s_w, s_touch, d, c[0], c[1]);
+    }
+    __syncthreads();
+    daagg_emit_cells<W, CELLS>(a.plan, a.out, s_w, s_touch, &s_base, s_wsum, [&](uint32_t i) -> unsigned long long { return (unsigned long long)i; });
 }
 
 #endif
