@@ -356,6 +356,8 @@ def main():
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
                         ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
+                        ("agg_two_keys_1000x100", lambda: extra_two_keys(ctx, abi, _lib)),
+                        ("agg_two_keys_50x20", lambda: extra_two_keys(ctx, abi, _lib, ma=50, mb=20)),
                         ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
                         ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True))):
             try:
@@ -727,6 +729,80 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
             "frac": algo / ms / 1e6 / 8000.0, "verified": bool(ng.value == groups and check.get("ok")), "check": check, "first_run_ms": runs[0],
             "route": "packed keys: %d-bit key range, 2-byte entries + argument cells, direct-addressed LDS accumulators" % st.packed_key_bits if st.packed_key_bits else "64-bit table words, LDS hash tables",
             "timing": "HIP events around every tsq_agg_push (%d device-resident batches of %.3g rows) + tsq_agg_finish; second of two runs" % ((n + batch - 1) // batch, batch)}
+
+
+def extra_two_keys(ctx, abi, _lib, n=250_000_000, ma=1000, mb=100):
+    """SELECT a, b, SUM(v), COUNT(*) GROUP BY a, b — two BIGINT key columns (a = r mod ma, b = r' mod mb), v = r'' mod 1000, one
+    device-resident batch: the key cells travel as the fields of one packed word (tsq_daagg.h).  Verified: every (a, b) pair once,
+    sum of counts = rows, sum of sums = numpy's sum of the value column."""
+    import numpy as np
+
+    lib = ctx.lib
+    bufs = [ctx.alloc(n * 8) for _ in range(3)]
+    try:
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 2
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
+        cfg.group_key_col[1], cfg.group_key_type[1] = 1, abi.I64
+        cfg.n_input_cols = 3
+        for c in range(3):
+            cfg.input_types[c] = abi.I64
+        aggs = [(abi.AGG_FIRSTROW, 0), (abi.AGG_FIRSTROW, 1), (abi.AGG_SUM, 2), (abi.AGG_COUNT, -1)]
+        cfg.n_aggs = len(aggs)
+        for i, (f, col) in enumerate(aggs):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
+        cfg.est_groups = ma * mb
+        for c, m in enumerate((ma, mb, 1000)):
+            ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=5, col=c, m=m), n, bufs[c])
+        ctx.sync()
+        host = np.empty(n, dtype=np.int64)
+        ctx.d2h(host, bufs[2])
+        want_sum = int(host.sum(dtype=np.int64))
+        del host
+        runs = []
+        for run in range(2):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ctx.timer_start()
+                _lib.check(lib.tsq_agg_push(h, (abi.Col * 3)(*[_dev_col(abi, b, n) for b in bufs]), 3, n), h)
+                _lib.check(lib.tsq_agg_finish(h), h)
+                runs.append(ctx.timer_stop_ms())
+                ng = C.c_int64(0)
+                _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
+                if run == 1:
+                    cap = ma * mb + 8
+                    dbufs = [ctx.alloc(cap * 8) for _ in range(4)]
+                    dbms = [ctx.alloc(cap // 8 + 64) for _ in range(4)]
+                    out = (abi.Col * 4)()
+                    for i in range(4):
+                        out[i].data, out[i].length, out[i].elem_size, out[i].type, out[i].flags = dbufs[i], cap, 8, abi.I64, abi.COL_DEVICE
+                        out[i].null_bitmap = dbms[i]
+                    nn, eos = C.c_int64(0), C.c_int32(0)
+                    _lib.check(lib.tsq_agg_pull(h, out, 4, cap, C.byref(nn), C.byref(eos)), h)
+                    got = [np.empty(nn.value, dtype=np.int64) for _ in range(4)]
+                    for i in range(4):
+                        ctx.d2h(got[i], dbufs[i])
+                    for pbuf in dbufs + dbms:
+                        ctx.free(pbuf)
+                    pair = got[0] * mb + got[1]
+                    in_range = bool(((got[0] >= 0) & (got[0] < ma) & (got[1] >= 0) & (got[1] < mb)).all())
+                    check = {"groups_pulled": int(nn.value), "every_pair_once": bool(in_range and len(np.unique(pair)) == ma * mb and nn.value == ma * mb),
+                             "sum_of_counts": int(got[3].sum()), "sum_of_sums": int(got[2].sum()), "sum_of_values_numpy": want_sum}
+                    check["ok"] = bool(check["every_pair_once"] and check["sum_of_counts"] == n and check["sum_of_sums"] == want_sum)
+            finally:
+                lib.tsq_agg_destroy(h)
+    finally:
+        for b in bufs:
+            ctx.free(b)
+    ms = runs[-1]
+    return {"workload": "SELECT a, b, SUM(v), COUNT(*) GROUP BY a, b: %.3g rows, %d x %d BIGINT key pairs, HashAggExec" % (n, ma, mb), "ms": ms,
+            "rows_per_s": n / ms * 1e3, "groups": ng.value, "frac": 24.0 * n / ms / 1e6 / 8000.0, "verified": bool(check.get("ok")), "check": check,
+            "first_run_ms": runs[0], "packed_key_bits": int(st.packed_key_bits),
+            "route": ("packed keys: the two key cells are the fields of one %d-bit word" % st.packed_key_bits) if st.packed_key_bits else "row-at-a-time upsert (two-phase tag table)",
+            "timing": "HIP events around tsq_agg_push of one device-resident batch + tsq_agg_finish; second of two runs; frac prices 24 B per row"}
 
 
 def cpu_baseline(abi, nb, npr):

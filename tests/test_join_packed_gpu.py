@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 
 from tinysql_amd import _abi as abi
+from tinysql_amd import _lib
+from tinysql_amd import expression as E
 from tinysql_amd.chunk import Chunk, Column
 
 from . import gpu_helpers as G
@@ -287,3 +289,49 @@ def test_packed_travelling_columns_auto_1e7_checksum(ctx):
     assert got.NumRows() == c == n
     from oracle import binding as orc_b
     assert orc_b.rows_checksum(got) == (s, x)
+
+
+# ------------------------------------------------------------------ OtherConditions of an inner join on the travelling-columns route
+@pytest.mark.parametrize("inner", [1, 0])
+@pytest.mark.parametrize("n_probe", [64, 4097, 90_001])
+def test_packed_travelling_columns_other_conditions_vs_oracle(ctx, orc, inner, n_probe):
+    # innerJoiner.tryToMatch filters the joined chunk by OtherConditions (joiner.go:351-378): here the batch is materialised first, the
+    # conditions run over its rows (NULL cells: an Int-typed NULL drops the row, expression.go:205-279) and the survivors are compacted
+    rng = np.random.default_rng(5 * n_probe + inner)
+    bside = _wide8(rng, 6000, -900, 1000, 3)   # (k, F64 nullable, U64)
+    pside = _wide8(rng, n_probe, -1100, 1200, 4)  # (k, F64 nullable, U64, I64 nullable)
+    left, right = (pside, bside) if inner == 1 else (bside, pside)
+    nl = len(left.types())
+    lf, rf = E.Column(1, abi.F64), E.Column(nl + 1, abi.F64)
+    i3 = E.Column(3 if inner == 1 else nl + 3, abi.I64)
+    conds = [E.ScalarFunction("lt", lf, rf), E.ScalarFunction("gt", i3, E.Constant(-(1 << 39)))]
+    keep = []
+    cfg = H.join_cfg(left.types(), right.types(), [0], [0], abi.JOIN_INNER, inner, conds, (), keep)
+    want = orc.hash_join(cfg, bside, pside)
+    got = _rows(ctx, cfg, bside, pside)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    if n_probe > 4000:
+        assert 0 < want.NumRows()
+    # a condition nothing passes: an empty result, not an empty batch
+    cfg0 = H.join_cfg(left.types(), right.types(), [0], [0], abi.JOIN_INNER, inner, [E.ScalarFunction("lt", lf, E.Constant(-1.0))], (), keep)
+    assert _rows(ctx, cfg0, bside, pside).NumRows() == 0
+
+
+def test_packed_travelling_columns_condition_error_is_the_direct_routes(ctx):
+    # an overflow inside a condition: the batch is dropped and goes through the direct route, which reports the error of the
+    # first probe row in order (types.ErrOverflow), exactly as without the packed route
+    rng = np.random.default_rng(3)
+    n = 20_000
+    build = Chunk([Column(abi.I64, np.arange(5000)), Column(abi.I64, rng.integers(1, 100, 5000))])
+    pv = rng.integers(0, 100, n)
+    pv[12_345] = (1 << 63) - 1
+    probe = Chunk([Column(abi.I64, rng.integers(0, 5000, n)), Column(abi.I64, pv)])
+    cond = [E.ScalarFunction("gt", E.ScalarFunction("plus", E.Column(1, abi.I64), E.Column(3, abi.I64)), E.Constant(-1))]
+    keep = []
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], abi.JOIN_INNER, 1, cond, (), keep)
+    with pytest.raises(_lib.TsqError) as ei:
+        _rows(ctx, cfg, build, probe, want_route=None)
+    assert ei.value.status == abi.ERR_OVERFLOW_BIGINT
+    pv[12_345] = 5  # without the poisoned cell the same join runs on the packed route
+    probe = Chunk([Column(abi.I64, probe.columns[0].data), Column(abi.I64, pv)])
+    assert _rows(ctx, cfg, build, probe).NumRows() == n

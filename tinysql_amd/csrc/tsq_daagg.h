@@ -114,8 +114,11 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
     if (tid == 0) s_flag = 0;
     const int64_t ntiles = (src.nrows + T - 1) / T;
-    const bool mk = ks.n > 1;  // several key columns: the per-row path
-    bool wide = src.knulls == nullptr && !mk;
+    const bool mk = ks.n > 1;  // several key columns
+    bool wide = mk || src.knulls == nullptr;
+#pragma unroll
+    for (int k = 0; k < TSQ_DAAGG_MAXK; k++)
+        if (mk && k < ks.n) wide = wide && src.mknulls[k] == nullptr;
 #pragma unroll
     for (int v = 0; v < V; v++) wide = wide && src.vnulls[v] == nullptr && src.vtype[v] != TSQ_F32;
     auto except = [&](uint32_t row) {
@@ -132,12 +135,34 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
         const bool full = wide && n == (uint32_t)T;
         if (full) {
             uint64_t k[K];
-            const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>((const uint64_t*)src.kdata + base);
+            uint32_t dsum[K];  // several key columns: the fields so far, TSQ_DA_NONE once a cell fell outside its window
+            if (mk) {
 #pragma unroll
-            for (int j = 0; j < K / 2; j++) {
-                const ulonglong2 x = s2[j * NT + tid];
-                k[2 * j] = x.x;
-                k[2 * j + 1] = x.y;
+                for (int j = 0; j < K; j++) dsum[j] = 0;
+                for (int kk = 0; kk < ks.n; kk++) {  // one key column at a time (its 16-byte loads in flight together)
+                    const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>((const uint64_t*)src.mkdata[kk] + base);
+#pragma unroll
+                    for (int j = 0; j < K / 2; j++) {
+                        const ulonglong2 x = c2[j * NT + tid];
+                        k[2 * j] = x.x;
+                        k[2 * j + 1] = x.y;
+                    }
+                    const uint64_t kmin = ks.kmin[kk], maxd = ks.maxd[kk];
+                    const uint32_t sh = ks.shift[kk];
+#pragma unroll
+                    for (int j = 0; j < K; j++) {
+                        const uint64_t diff = k[j] - kmin;
+                        dsum[j] = (diff <= maxd && dsum[j] != TSQ_DA_NONE) ? (dsum[j] | ((uint32_t)diff << sh)) : TSQ_DA_NONE;
+                    }
+                }
+            } else {
+                const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>((const uint64_t*)src.kdata + base);
+#pragma unroll
+                for (int j = 0; j < K / 2; j++) {
+                    const ulonglong2 x = s2[j * NT + tid];
+                    k[2 * j] = x.x;
+                    k[2 * j + 1] = x.y;
+                }
             }
 #pragma unroll
             for (int v = 0; v < V; v++) {
@@ -152,7 +177,8 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < K; j++) {
-                u[j] = da_word(dm, k[j]);
+                if (mk) u[j] = dsum[j] == TSQ_DA_NONE ? TSQ_DA_NONE : tsq_da_mix(dsum[j], dm.s, dm.mask);
+                else u[j] = da_word(dm, k[j]);
                 if (u[j] == TSQ_DA_NONE) except((uint32_t)base + ((uint32_t)(j >> 1) * NT + tid) * 2 + (j & 1));
             }
         } else {
@@ -276,7 +302,8 @@ struct DaAggLdsArgs {
 // what one row does to the accumulators of cell e
 template <int W, int CELLS>
 __device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1) {
-    atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
+    // (a plain LDS read first: after its first row a cell's bit is set, and a returning-or-not LDS atomic costs more than a read)
+    if (!((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
 #pragma unroll
     for (int k = 0; k < W; k++) {
         const uint32_t d = wd[k];
@@ -286,7 +313,9 @@ __device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned lo
             case AF_W_ADD1: atomicAdd(&s_w[k][e], 1ull); break;
             case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(&s_w[k][e]), af_real(cell, type)); break;
             case AF_W_ADD_LO32: atomicAdd(&s_w[k][e], (unsigned long long)(cell & 0xffffffffull)); break;
-            case AF_W_ADD_HI32: atomicAdd(&s_w[k][e], (unsigned long long)((long long)cell >> 32)); break;
+            case AF_W_ADD_HI32:  // adding zero changes nothing: a non-negative value below 2^32 (most counters, prices, ids) skips the atomic
+                if ((long long)cell >> 32) atomicAdd(&s_w[k][e], (unsigned long long)((long long)cell >> 32));
+                break;
             case AF_W_MAX: atomicMax(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
             default: atomicMin(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
         }
@@ -409,24 +438,38 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da_low(DaAggLowArgs a) {
     // a contiguous stripe of rows per workgroup (the tail of a 64-row bitmap word belongs to one workgroup)
     const int64_t per = ((a.src.nrows + gridDim.x - 1) / gridDim.x + 63) & ~(int64_t)63;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < a.src.nrows ? lo + per : a.src.nrows;
-    for (int64_t row = lo + tid; row < hi; row += TSQ_AF_NT) {
-        bool isnull = false;
+    constexpr int U = 4;  // rows per thread in flight
+    constexpr uint32_t SKIP = 0xfffffffeu;
+    for (int64_t r0 = lo + tid; r0 < hi; r0 += (int64_t)TSQ_AF_NT * U) {
+        uint32_t d[U];
+        uint64_t c[U][TSQ_RADIX_MAXV];
 #pragma unroll
-        for (int v = 0; v < TSQ_RADIX_MAXV; v++)
-            if (v < a.plan.V) isnull |= tsq_is_null(a.src.vnulls[v], row);
-        const uint32_t d = isnull ? TSQ_DA_NONE : daagg_fields(a.ks, a.src, row);
-        if (d == TSQ_DA_NONE || d >= (uint32_t)CELLS) {
-            const uint32_t x = __hip_atomic_fetch_add(a.src.exc_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.src.exc_rows[x] = (uint32_t)row;
-            continue;
-        }
-        uint64_t c[TSQ_RADIX_MAXV];
+        for (int x = 0; x < U; x++) {
+            const int64_t row = r0 + (int64_t)x * TSQ_AF_NT;
+            d[x] = SKIP;
 #pragma unroll
-        for (int v = 0; v < TSQ_RADIX_MAXV; v++) {
-            c[v] = 0;
-            if (v < a.plan.V) c[v] = a.src.vtype[v] == TSQ_F32 ? (uint64_t)((const uint32_t*)a.src.vdata[v])[row] : ((const uint64_t*)a.src.vdata[v])[row];
+            for (int v = 0; v < TSQ_RADIX_MAXV; v++) c[x][v] = 0;
+            if (row < hi) {
+                bool isnull = false;
+#pragma unroll
+                for (int v = 0; v < TSQ_RADIX_MAXV; v++)
+                    if (v < a.plan.V) isnull |= tsq_is_null(a.src.vnulls[v], row);
+                d[x] = isnull ? TSQ_DA_NONE : daagg_fields(a.ks, a.src, row);
+#pragma unroll
+                for (int v = 0; v < TSQ_RADIX_MAXV; v++)
+                    if (v < a.plan.V) c[x][v] = a.src.vtype[v] == TSQ_F32 ? (uint64_t)((const uint32_t*)a.src.vdata[v])[row] : ((const uint64_t*)a.src.vdata[v])[row];
+            }
         }
-        daagg_apply<W, CELLS>(wd, s_w, s_touch, d, c[0], c[1]);
+#pragma unroll
+        for (int x = 0; x < U; x++) {
+            if (d[x] == SKIP) continue;
+            if (d[x] == TSQ_DA_NONE || d[x] >= (uint32_t)CELLS) {
+                const uint32_t i = __hip_atomic_fetch_add(a.src.exc_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.src.exc_rows[i] = (uint32_t)(r0 + (int64_t)x * TSQ_AF_NT);
+                continue;
+            }
+            daagg_apply<W, CELLS>(wd, s_w, s_touch, d[x], c[x][0], c[x][1]);
+        }
     }
     __syncthreads();
     daagg_emit_cells<W, CELLS>(a.plan, a.out, s_w, s_touch, &s_base, s_wsum, [&](uint32_t i) -> unsigned long long { return (unsigned long long)i; });

@@ -1126,7 +1126,9 @@ tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st,
         if (pf) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, false, false, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
         else if (two) {
             const dim3 grid2((unsigned)std::min<int64_t>(ntiles, (int64_t)j->ctx->num_cus * 2));
-            hipLaunchKernelGGL((k_da_partition2<512, 8, 4>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
+            static const bool ntl = [] { const char* v = getenv("TSQ_DA_NT"); return v && v[0] == '1'; }();
+            if (ntl) hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
+            else hipLaunchKernelGGL((k_da_partition2<512, 8, 4>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
         } else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     }
     TSQ_HIP(&j->hdr, hipGetLastError());
@@ -1557,7 +1559,10 @@ tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nro
 // TSQ_DA_MAXCOLS columns per side.  NULLs anywhere, inner and outer joins.
 bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->never_match || j->ordered) return false;
-    if (selected_dev || !j->conds_h.empty() || !j->filters_h.empty()) return false;
+    // OtherConditions of an INNER join are a filter over the joined rows (joiner.go:351-378: innerJoiner.tryToMatch filters the
+    // joined chunk): evaluated on the output batch and compacted (da_post_conditions).  An outer join needs "did ANY match of this
+    // outer row pass" — the direct route
+    if (selected_dev || !j->filters_h.empty() || (!j->conds_h.empty() && j->cfg.join_type != TSQ_JOIN_INNER)) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0 || j->da_cols_state < 0) return false;
     if (j->cfg.n_probe_cols > TSQ_DA_MAXCOLS || j->cfg.n_build_cols > TSQ_DA_MAXCOLS) return false;
     for (int c = 0; c < j->cfg.n_probe_cols; c++)
@@ -1614,7 +1619,126 @@ tsq_status da_prepare_cols(tsq_join* j) {
     return TSQ_OK;
 }
 
-tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+// OtherConditions over a materialised batch of joined rows: row i of the output columns is (left row, right row) at once.
+struct PostCondArgs {
+    tsq_colset L, R;
+    const tsq_expr_prog* conds;
+    int32_t n_conds;
+    int64_t n;
+    uint8_t* keep;
+    unsigned long long* err;  // err word (preset TSQ_ERRWORD_NONE): an evaluation error sends the whole batch to the direct route
+};
+__global__ void __launch_bounds__(256) k_post_conds(PostCondArgs a) {
+    uint64_t errw = TSQ_ERRWORD_NONE;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        tsq_joined_src src;
+        src.left = &a.L;
+        src.right = &a.R;
+        src.lrow = src.rrow = i;
+        bool sel = false, isnull = false;
+        int ec = 0, en = 0, d0 = 0;
+        const tsq_status s = tsq_filter_row(a.conds, a.n_conds, src, &sel, &isnull, &ec, &en, &d0);
+        if (s != TSQ_OK) {
+            const uint64_t w = tsq_errword(ec, en, (uint64_t)i, s);
+            errw = w < errw ? w : errw;
+            sel = false;
+        }
+        a.keep[i] = sel ? 1 : 0;
+    }
+    if (errw != TSQ_ERRWORD_NONE) atomicMin(a.err, (unsigned long long)errw);
+}
+// filters the batch in place (new, dense column buffers).  *redo: a condition raised an error — which error the reference reports
+// depends on the probe row order, so the batch is dropped and the caller runs it through the direct route.
+tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bool>& may_null_v, bool* redo) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const int np = j->cfg.n_probe_cols, nbc = j->cfg.n_build_cols, nout = np + nbc;
+    const bool probe_is_left = j->cfg.build_is_right != 0;
+    const int nl = probe_is_left ? np : nbc;
+    const int64_t n = rb.rows;
+    PostCondArgs pa;
+    memset(&pa, 0, sizeof pa);
+    std::vector<tsq_col> in((size_t)nout), out((size_t)nout);
+    for (int oc = 0; oc < nout; oc++) {
+        const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
+        const int sc = oc < nl ? oc : oc - nl;
+        const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
+        tsq_colset& cs = oc < nl ? pa.L : pa.R;
+        cs.data[sc] = rb.data[oc].p;
+        cs.nulls[sc] = may_null_v[oc] ? rb.bitmap[oc].as<uint8_t>() : nullptr;
+        cs.type[sc] = type;
+        memset(&in[(size_t)oc], 0, sizeof(tsq_col));
+        in[(size_t)oc].data = rb.data[oc].p;
+        in[(size_t)oc].null_bitmap = may_null_v[oc] ? rb.bitmap[oc].as<uint8_t>() : nullptr;
+        in[(size_t)oc].length = n;
+        in[(size_t)oc].elem_size = 8;
+        in[(size_t)oc].type = type;
+        in[(size_t)oc].flags = TSQ_COL_DEVICE;
+    }
+    pa.L.n = nl;
+    pa.R.n = nout - nl;
+    pa.conds = j->conds_d.as<tsq_expr_prog>();
+    pa.n_conds = (int32_t)j->conds_h.size();
+    pa.n = n;
+    DevBuf keep;
+    TSQ_TRY(keep.reserve(ctx, h, (size_t)n + 64));
+    pa.keep = keep.as<uint8_t>();
+    pa.err = (unsigned long long*)(ctx->dscratch + 56);
+    ctx->pinned[56] = TSQ_ERRWORD_NONE;
+    hipError_t e = hipMemcpyAsync(ctx->dscratch + 56, ctx->pinned + 56, 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_post_conds, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, pa);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 56, ctx->dscratch + 56, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        keep.release();
+        return tsq_fail(h, TSQ_ERR_HIP, std::string("conditions over the joined batch: ") + hipGetErrorString(e));
+    }
+    j->st.kernel_launches++;
+    if (ctx->pinned[56] != TSQ_ERRWORD_NONE) {
+        keep.release();
+        *redo = true;
+        return TSQ_OK;
+    }
+    std::vector<DevBuf> nd((size_t)nout), nbm((size_t)nout);
+    tsq_status s = TSQ_OK;
+    for (int oc = 0; oc < nout && s == TSQ_OK; oc++) {
+        s = nd[(size_t)oc].reserve(ctx, h, ((size_t)n + 8) * 8 + 16);
+        if (s == TSQ_OK && may_null_v[oc]) s = nbm[(size_t)oc].reserve(ctx, h, tsq_bitmap_bytes(n) + 16);
+        out[(size_t)oc] = in[(size_t)oc];
+        out[(size_t)oc].data = nd[(size_t)oc].p;
+        out[(size_t)oc].null_bitmap = may_null_v[oc] ? nbm[(size_t)oc].as<uint8_t>() : nullptr;
+    }
+    int64_t kept = 0;
+    if (s == TSQ_OK) {
+        s = tsq_chunk_compact(ctx, in.data(), nout, n, keep.as<uint8_t>(), out.data(), &kept);
+        if (s != TSQ_OK) tsq_fail(h, s, ctx->hdr.err);
+    }
+    if (s == TSQ_OK) {
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        if (e2 != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e2));
+    }
+    keep.release();
+    if (s != TSQ_OK) {
+        for (auto& b : nd) b.release();
+        for (auto& b : nbm) b.release();
+        return s;
+    }
+    for (int oc = 0; oc < nout; oc++) {
+        rb.data[oc].release();
+        rb.data[oc] = nd[(size_t)oc];  // shallow move of the buffer handle
+        if (may_null_v[oc]) {
+            rb.bitmap[oc].release();
+            rb.bitmap[oc] = nbm[(size_t)oc];
+        }
+    }
+    rb.rows = kept;
+    return TSQ_OK;
+}
+
+tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool* redo) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
@@ -1834,9 +1958,24 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     j->st.kernel_launches++;
     for (int oc = 0; oc < nout; oc++)
         if (may_null_v[oc]) TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, rb->notnull[oc].as<uint8_t>(), rb->bitmap[oc].as<uint8_t>(), out_rows));
+    if (!j->conds_h.empty()) {
+        tsq_status ps = da_post_conditions(j, *rb, may_null_v, redo);
+        if (ps != TSQ_OK || *redo) {
+            rb->release();
+            if (*redo) {  // as if this route had not been tried
+                j->st.radix_batches--;
+                j->st.probe_route = TSQ_ROUTE_DIRECT;
+            }
+            return ps;
+        }
+    }
     TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
     j->have_probe_ev = true;
+    if (rb->rows == 0) {
+        rb->release();
+        return TSQ_OK;
+    }
     return deliver_batch(j, std::move(rb), may_null_v);
 }
 
@@ -2191,7 +2330,11 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         TSQ_TRY(da_prepare(j));
         TSQ_TRY(da_prepare_rows(j));
         TSQ_TRY(da_prepare_cols(j));
-        if (j->da_cols_state == 1) return da_emit_cols(j, pcs, nrows);
+        if (j->da_cols_state == 1) {
+            bool redo = false;
+            TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo));
+            if (!redo) return TSQ_OK;
+        }
     }
     if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
     if (da_emit_eligible(j, nrows, selected_dev)) {
