@@ -666,6 +666,15 @@ tsq_status tsq_comm_barrier(tsq_comm* c);
 tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode,
                             int64_t nrows, int32_t slot, tsq_col* out_cols, int64_t* nrows_out);
 tsq_status tsq_redistribute_wait(tsq_comm* c, int32_t slot);
+/* tsq_redistribute in three calls, for a plan that redistributes its input in PIECES (piece c -> slot c): prepare every piece
+ * (the split, on the context's stream), exchange the run sizes of ALL prepared slots with one all-gather (the only call of the
+ * three that waits for the other ranks on the host), then issue the pieces one after the other — each issue only queues the
+ * sends / receives of its slot behind the previous one.  tsq_redistribute(slot) = prepare(slot) + counts({slot}) + issue(slot).
+ * Every rank lists the same slots in the same order. */
+tsq_status tsq_redistribute_prepare(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode,
+                                    int64_t nrows, int32_t slot);
+tsq_status tsq_redistribute_counts(tsq_comm* c, const int32_t* slots, int32_t n_slots);
+tsq_status tsq_redistribute_issue(tsq_comm* c, int32_t slot, tsq_col* out_cols, int32_t n_cols, int64_t* nrows_out);
 
 /* ---------------------------------------------------------------- statistics (roofline reporting) */
 typedef struct tsq_stats {

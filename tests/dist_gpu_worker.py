@@ -113,6 +113,7 @@ def main():
                 j.build([dev(ctx, bk, keep), dev(ctx, bv, keep)], 0, nb)
                 j.probe([dev(ctx, pk, keep), dev(ctx, pv, keep)], 0, len(pk), n_pieces=3)
                 j.probe([dev(ctx, pk, keep), dev(ctx, pv, keep)], 0, len(pk), n_pieces=1)
+                j.probe([dev(ctx, pk, keep), dev(ctx, pv, keep)], 0, len(pk), n_pieces=3, batched_counts=True)  # one count exchange for the pieces
                 total = j.count()
             finally:
                 j.close()
@@ -122,7 +123,7 @@ def main():
             upk = np.concatenate([a[2] for a in allrows])
             upv = np.concatenate([a[3] for a in allrows])
             want = orc.hash_join(cfg, Chunk([Column(abi.I64, ubk), Column(abi.I64, ubv)]), Chunk([Column(abi.I64, upk), Column(abi.I64, upv)])).NumRows()
-            assert total == 2 * want, (total, want)
+            assert total == 3 * want, (total, want)
             lap("oracle join")
             # ---- distributed GROUP BY k: SUM(v), COUNT(*), MIN(v) vs the oracle
             paggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_SUM, 1, abi.I64, abi.MODE_PARTIAL1),

@@ -240,4 +240,31 @@ int32_t sim_comm_plan(int32_t rank, int32_t world, int32_t n_cols, const int32_t
     return 0;
 }
 
+// the count exchange of several pieces at once: every rank packs its pieces' vectors, the all-gather concatenates the ranks'
+// contributions, every piece's matrix must come back as if it had been exchanged alone.  Ls[k]: words of piece k's vector.
+int32_t sim_comm_counts(int32_t world, int32_t n_pieces, const int32_t* Ls, uint64_t seed) {
+    uint64_t s = seed;
+    std::vector<size_t> L((size_t)n_pieces);
+    size_t Lsum = 0;
+    for (int k = 0; k < n_pieces; k++) Lsum += (L[(size_t)k] = (size_t)Ls[k]);
+    std::vector<std::vector<std::vector<uint64_t>>> vec((size_t)world, std::vector<std::vector<uint64_t>>((size_t)n_pieces));  // [rank][piece]
+    std::vector<uint64_t> G((size_t)world * Lsum);
+    for (int r = 0; r < world; r++) {
+        std::vector<const std::vector<uint64_t>*> mine;
+        for (int k = 0; k < n_pieces; k++) {
+            for (size_t w = 0; w < L[(size_t)k]; w++) vec[(size_t)r][(size_t)k].push_back(rnd(s));
+            mine.push_back(&vec[(size_t)r][(size_t)k]);
+        }
+        if (tsq_comm_pack_counts(mine, G.data() + (size_t)r * Lsum) != Lsum) return 1;  // (the all-gather: rank r's words land at r * Lsum)
+    }
+    for (int k = 0; k < n_pieces; k++) {
+        const std::vector<uint64_t> M = tsq_comm_unpack_counts(G.data(), world, L, (size_t)k);
+        if (M.size() != (size_t)world * L[(size_t)k]) return 2;
+        for (int r = 0; r < world; r++)
+            for (size_t w = 0; w < L[(size_t)k]; w++)
+                if (M[(size_t)r * L[(size_t)k] + w] != vec[(size_t)r][(size_t)k][w]) return 3;
+    }
+    return 0;
+}
+
 }  // extern "C"

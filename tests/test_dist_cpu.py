@@ -48,6 +48,15 @@ def test_exchange_plan_ragged_and_empty_ranks(sim, world):
     _run(sim, world, kinds, 0, [1] * world, 8)                            # one row each: most runs are empty
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_count_exchange_of_several_pieces_at_once(sim, world):
+    # tsq_redistribute_counts: pieces with different vector lengths (a piece with var-len columns carries their byte counts too)
+    sim.sim_comm_counts.restype = C.c_int32
+    sim.sim_comm_counts.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_uint64]
+    for ls in ([world + 1], [world + 1] * 4, [world + 1, 3 * world + 1, world + 1, 2 * world + 1, world + 1, world + 1, world + 1, 5 * world + 1]):
+        assert sim.sim_comm_counts(world, len(ls), (C.c_int32 * len(ls))(*ls), 99 + world) == 0
+
+
 def test_world_size_2_two_processes_run_the_shipped_plan_over_gloo():
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"

@@ -238,6 +238,9 @@ SIGNATURES = {
     "tsq_comm_barrier": (C.c_int32, [P]),
     "tsq_redistribute": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_redistribute_wait": (C.c_int32, [P, C.c_int32]),
+    "tsq_redistribute_prepare": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
+    "tsq_redistribute_counts": (C.c_int32, [P, C.POINTER(C.c_int32), C.c_int32]),
+    "tsq_redistribute_issue": (C.c_int32, [P, C.c_int32, C.POINTER(Col), C.c_int32, C.POINTER(C.c_int64)]),
     "tsq_join_peek": (C.c_int32, [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     "tsq_agg_peek": (C.c_int32, [P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]),
     "tsq_join_stats": (C.c_int32, [P, C.POINTER(Stats)]),

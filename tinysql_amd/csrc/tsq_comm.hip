@@ -87,6 +87,8 @@ RcclApi* rccl() {
 // words one rank contributes to the count exchange at most: its row counts per destination, its null-bitmap mask, and for every
 // var-len column its BYTE counts per destination
 static inline size_t comm_lmax(int world) { return (size_t)world + 1 + (size_t)TSQ_MAX_COLS * world; }
+// ... and the count exchange of up to TSQ_COMM_SLOTS prepared pieces at once: [own vectors | world x gathered vectors]
+static inline size_t comm_words(int world) { return (size_t)(world + 1) * comm_lmax(world) * TSQ_COMM_SLOTS; }
 
 struct tsq_comm {
     tsq_handle_hdr hdr;
@@ -108,6 +110,14 @@ struct tsq_comm {
         std::vector<DevBuf> sendoffs, recvtmp, recvoffs;
         hipEvent_t split_done = nullptr, xchg_done = nullptr;
         bool pending = false;
+        // a piece between tsq_redistribute_prepare and tsq_redistribute_issue: its columns (split into `send`), its count vector
+        // (tsq_comm_plan.h: L words) and, after tsq_redistribute_counts, every rank's vector
+        int state = 0;  // 0: idle, 1: prepared, 2: counted
+        std::vector<tsq_col> cols;
+        int64_t nrows = 0;
+        int n_var = 0;
+        int var_of[TSQ_MAX_COLS];
+        std::vector<uint64_t> vec, M;
     } slot[TSQ_COMM_SLOTS];
 };
 
@@ -153,7 +163,7 @@ TSQ_API tsq_status tsq_comm_create(tsq_ctx* ctx, int32_t rank, int32_t world, co
         ch->err = msg;
         return st;
     };
-    const size_t words = (size_t)(world + 1) * comm_lmax(world) + 8;
+    const size_t words = comm_words(world) + 8;
     {
         tsq_status st = TSQ_OK;
         hipError_t e = hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking);
@@ -213,7 +223,7 @@ tsq_status allreduce8(tsq_comm* c, void* inout, int32_t n, ncclDataType_t dt, in
     tsq_handle_hdr* h = &c->hdr;
     if (!inout || n < 1 || n > 8 || op < 0 || op > 2) return tsq_fail(h, TSQ_ERR_INVALID, "all-reduce: 1..8 words, op 0 (sum) / 1 (max) / 2 (min)");
     TSQ_HIP(h, hipSetDevice(c->ctx->device));
-    const size_t off = (size_t)(c->world + 1) * comm_lmax(c->world);
+    const size_t off = comm_words(c->world);
     uint64_t* dev = c->cnt_dev.as<uint64_t>() + off;
     uint64_t* host = c->cnt_host + off;
     TSQ_HIP(h, hipStreamSynchronize(c->ctx->stream));  // a barrier-like call: everything this rank queued is done
@@ -246,28 +256,30 @@ TSQ_API tsq_status tsq_comm_barrier(tsq_comm* c) {
     return allreduce8(c, &one, 1, ncclInt64, 0);
 }
 
-TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode, int64_t nrows,
-                                    int32_t slot, tsq_col* out_cols, int64_t* nrows_out) {
-    tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));
-    if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
+namespace {
+
+// ---- stage 1: the piece is split on the operator stream into the slot's send buffers; its count vector is known on the host
+tsq_status comm_prepare(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode, int64_t nrows, int32_t slot) {
     tsq_handle_hdr* h = &c->hdr;
     tsq_ctx* ctx = c->ctx;
-    if (!cols || !out_cols || !nrows_out || n_cols < 1 || n_cols > TSQ_MAX_COLS || key_col < 0 || key_col >= n_cols || nrows < 0 || slot < 0 || slot >= TSQ_COMM_SLOTS)
+    if (!cols || n_cols < 1 || n_cols > TSQ_MAX_COLS || key_col < 0 || key_col >= n_cols || nrows < 0 || slot < 0 || slot >= TSQ_COMM_SLOTS)
         return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: bad arguments");
+    tsq_comm::Slot& s = c->slot[slot];
     uint64_t my_mask = 0;
-    int var_of[TSQ_MAX_COLS], n_var = 0;  // column -> its index among the var-len columns
+    int n_var = 0;  // column -> its index among the var-len columns
     for (int i = 0; i < n_cols; i++) {
         if (!(cols[i].flags & TSQ_COL_DEVICE)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: columns must be device resident");
         if (cols[i].type < TSQ_I64 || cols[i].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: unknown column type");
         if (cols[i].type == TSQ_BYTES && !cols[i].offsets) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute: a var-len column needs offsets");
         if (cols[i].null_bitmap) my_mask |= 1ull << i;
-        var_of[i] = cols[i].type == TSQ_BYTES ? n_var++ : -1;
+        s.var_of[i] = cols[i].type == TSQ_BYTES ? n_var++ : -1;
     }
+    const int* var_of = s.var_of;
     TSQ_HIP(h, hipSetDevice(ctx->device));
-    tsq_comm::Slot& s = c->slot[slot];
     const int W = c->world, L = W + 1 + n_var * W;
     if (s.pending) TSQ_HIP(h, hipStreamSynchronize(c->xs));  // the previous exchange of this slot (its buffers are rewritten below)
     s.pending = false;
+    s.state = 0;
     for (auto* v : {&s.send, &s.recv, &s.sendbm, &s.sendnn, &s.recvnn, &s.recvbm, &s.sendoffs, &s.recvtmp, &s.recvoffs}) v->resize(n_cols);
     // ---- the data bytes of the var-len columns (the split writes as many as it reads)
     int64_t in_bytes[TSQ_MAX_COLS] = {0};
@@ -302,11 +314,10 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
         tsq_status st = tsq_radix_split(ctx, cols, n_cols, key_col, key_mode, nrows, W, sc.data(), sendc);
         if (st != TSQ_OK) return tsq_fail(h, st, ctx->hdr.err);
     }
-    // ---- counts, nullable-column masks and the var-len columns' byte counts: every rank learns the whole world x L matrix
-    uint64_t* cd = c->cnt_dev.as<uint64_t>();
-    for (int p = 0; p < W; p++) c->cnt_host[p] = (uint64_t)sendc[p];
-    c->cnt_host[W] = my_mask;
-    for (int k = 0; k < n_var * W; k++) c->cnt_host[W + 1 + k] = 0;
+    // ---- counts, nullable-column mask and the var-len columns' byte counts: this rank's vector (tsq_comm_plan.h)
+    s.vec.assign((size_t)L, 0);
+    for (int p = 0; p < W; p++) s.vec[(size_t)p] = (uint64_t)sendc[p];
+    s.vec[(size_t)W] = my_mask;
     if (n_var && nrows > 0) {  // byte boundaries of the runs: offsets[first row of run p]
         std::vector<int64_t> bounds((size_t)n_var * (W + 1));
         for (int i = 0; i < n_cols; i++) {
@@ -319,13 +330,65 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
         }
         TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
         for (int v = 0; v < n_var; v++)
-            for (int p = 0; p < W; p++) c->cnt_host[W + 1 + v * W + p] = (uint64_t)(bounds[(size_t)v * (W + 1) + p + 1] - bounds[(size_t)v * (W + 1) + p]);
+            for (int p = 0; p < W; p++) s.vec[(size_t)W + 1 + (size_t)v * W + p] = (uint64_t)(bounds[(size_t)v * (W + 1) + p + 1] - bounds[(size_t)v * (W + 1) + p]);
     }
-    TSQ_HIP(h, hipMemcpyAsync(cd, c->cnt_host, (size_t)L * 8, hipMemcpyHostToDevice, c->xs));
-    TSQ_NCCL(h, rccl()->AllGather(cd, cd + L, (size_t)L, ncclInt64, c->nccl, c->xs));
-    TSQ_HIP(h, hipMemcpyAsync(c->cnt_host + L, cd + L, (size_t)W * L * 8, hipMemcpyDeviceToHost, c->xs));
+    s.cols.assign(cols, cols + n_cols);
+    s.nrows = nrows;
+    s.n_var = n_var;
+    s.state = 1;
+    return TSQ_OK;
+}
+
+// ---- stage 2: ONE all-gather for the count vectors of every listed (prepared) piece: each rank learns every piece's world x L matrix
+tsq_status comm_counts(tsq_comm* c, const int32_t* slots, int32_t n_slots) {
+    tsq_handle_hdr* h = &c->hdr;
+    if (!slots || n_slots < 1 || n_slots > TSQ_COMM_SLOTS) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute_counts: 1..8 slots");
+    const int W = c->world;
+    size_t Lsum = 0;
+    for (int k = 0; k < n_slots; k++) {
+        if (slots[k] < 0 || slots[k] >= TSQ_COMM_SLOTS || c->slot[slots[k]].state != 1) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute_counts: a slot that was not prepared");
+        for (int q = 0; q < k; q++)
+            if (slots[q] == slots[k]) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute_counts: a slot listed twice");
+        Lsum += c->slot[slots[k]].vec.size();
+    }
+    if ((size_t)(W + 1) * Lsum > comm_words(W)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute_counts: count vectors too long");
+    TSQ_HIP(h, hipSetDevice(c->ctx->device));
+    uint64_t* cd = c->cnt_dev.as<uint64_t>();
+    std::vector<const std::vector<uint64_t>*> vecs;
+    std::vector<size_t> Ls;
+    for (int k = 0; k < n_slots; k++) {
+        vecs.push_back(&c->slot[slots[k]].vec);
+        Ls.push_back(c->slot[slots[k]].vec.size());
+    }
+    (void)tsq_comm_pack_counts(vecs, c->cnt_host);
+    TSQ_HIP(h, hipMemcpyAsync(cd, c->cnt_host, Lsum * 8, hipMemcpyHostToDevice, c->xs));
+    TSQ_NCCL(h, rccl()->AllGather(cd, cd + Lsum, Lsum, ncclInt64, c->nccl, c->xs));
+    TSQ_HIP(h, hipMemcpyAsync(c->cnt_host + Lsum, cd + Lsum, (size_t)W * Lsum * 8, hipMemcpyDeviceToHost, c->xs));
     TSQ_HIP(h, hipStreamSynchronize(c->xs));
-    const uint64_t* M = c->cnt_host + L;  // M[q * L + ...]: rank q's vector
+    const uint64_t* G = c->cnt_host + Lsum;  // rank q's vectors, piece after piece, at G + q * Lsum (tsq_comm_plan.h)
+    for (int k = 0; k < n_slots; k++) {
+        tsq_comm::Slot& s = c->slot[slots[k]];
+        s.M = tsq_comm_unpack_counts(G, W, Ls, (size_t)k);
+        s.state = 2;
+    }
+    return TSQ_OK;
+}
+
+// ---- stage 3: the exchange of one counted piece, queued on the communicator's stream (no host synchronisation)
+tsq_status comm_issue(tsq_comm* c, int32_t slot, tsq_col* out_cols, int32_t n_out, int64_t* nrows_out) {
+    tsq_handle_hdr* h = &c->hdr;
+    tsq_ctx* ctx = c->ctx;
+    if (slot < 0 || slot >= TSQ_COMM_SLOTS || !out_cols || !nrows_out) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute_issue: bad arguments");
+    tsq_comm::Slot& s = c->slot[slot];
+    if (s.state != 2) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute_issue: the slot's counts were not exchanged");
+    const int n_cols = (int)s.cols.size();
+    if (n_out != n_cols) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_redistribute_issue: as many output columns as the piece has");
+    const tsq_col* cols = s.cols.data();
+    const int* var_of = s.var_of;
+    const int64_t nrows = s.nrows;
+    const int W = c->world;
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    const uint64_t* M = s.M.data();  // M[q * L + ...]: rank q's vector
     // ---- who sends what to whom, where it lands, how received offsets are rebased: tsq_comm_plan.h (walked on the CPU for world
     // sizes 2, 4 and 8 by tests/hostsim)
     int32_t es_of[TSQ_MAX_COLS];
@@ -408,8 +471,41 @@ TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_
         out_cols[i].flags = TSQ_COL_DEVICE;
     }
     *nrows_out = total;
+    s.state = 0;
     return TSQ_OK;
 }
+
+}  // namespace
+
+TSQ_API tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode, int64_t nrows,
+                                    int32_t slot, tsq_col* out_cols, int64_t* nrows_out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));
+    if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
+    if (!out_cols || !nrows_out) return tsq_fail(&c->hdr, TSQ_ERR_INVALID, "tsq_redistribute: bad arguments");
+    TSQ_TRY(comm_prepare(c, cols, n_cols, key_col, key_mode, nrows, slot));
+    TSQ_TRY(comm_counts(c, &slot, 1));
+    return comm_issue(c, slot, out_cols, n_cols, nrows_out);
+}
+
+// The same exchange in three calls, so that a plan that redistributes its input in PIECES pays ONE count exchange (one blocking
+// all-gather + host synchronisation) for all of them: prepare every piece (slot c = piece c), exchange the counts of all slots,
+// then issue piece after piece — nothing between two issues waits for the host.
+TSQ_API tsq_status tsq_redistribute_prepare(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode, int64_t nrows, int32_t slot) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));
+    if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
+    return comm_prepare(c, cols, n_cols, key_col, key_mode, nrows, slot);
+}
+TSQ_API tsq_status tsq_redistribute_counts(tsq_comm* c, const int32_t* slots, int32_t n_slots) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));
+    if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
+    return comm_counts(c, slots, n_slots);
+}
+TSQ_API tsq_status tsq_redistribute_issue(tsq_comm* c, int32_t slot, tsq_col* out_cols, int32_t n_cols, int64_t* nrows_out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));
+    if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
+    return comm_issue(c, slot, out_cols, n_cols, nrows_out);
+}
+
 
 TSQ_API tsq_status tsq_redistribute_wait(tsq_comm* c, int32_t slot) {
     tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));

@@ -21,6 +21,28 @@
 //   [world + 1 + v * world + p]     data BYTES of var-len column v (the v-th var-len column) it sends to rank p
 inline size_t tsq_comm_lwords(int world, int n_var) { return (size_t)world + 1 + (size_t)n_var * world; }
 
+// The count exchange of SEVERAL pieces at once (tsq_redistribute_counts): every rank contributes the vectors of its pieces one
+// after the other (Lsum words), ONE all-gather returns G[q * Lsum + ...] (rank q's contribution); piece k's world x L_k matrix is
+// the k-th slice of every rank's contribution.
+inline size_t tsq_comm_pack_counts(const std::vector<const std::vector<uint64_t>*>& vecs, uint64_t* out) {
+    size_t o = 0;
+    for (const std::vector<uint64_t>* v : vecs) {
+        for (uint64_t w : *v) out[o++] = w;
+    }
+    return o;
+}
+inline std::vector<uint64_t> tsq_comm_unpack_counts(const uint64_t* G, int world, const std::vector<size_t>& Ls, size_t k) {
+    size_t Lsum = 0, off = 0;
+    for (size_t i = 0; i < Ls.size(); i++) {
+        if (i < k) off += Ls[i];
+        Lsum += Ls[i];
+    }
+    std::vector<uint64_t> M((size_t)world * Ls[k]);
+    for (int q = 0; q < world; q++)
+        for (size_t w = 0; w < Ls[k]; w++) M[(size_t)q * Ls[k] + w] = G[(size_t)q * Lsum + off + w];
+    return M;
+}
+
 enum { TSQ_XFER_DATA = 0, TSQ_XFER_OFFS = 1, TSQ_XFER_NOTNULL = 2 };
 struct tsq_comm_xfer {  // one piece: send_len bytes at send_off of the (column, kind) send buffer go to `peer`, recv_len bytes from `peer`
     int32_t col, kind, peer;  // land at recv_off of the (column, kind) receive buffer.  peer == own rank: a local copy (send_len == recv_len)

@@ -141,21 +141,43 @@ def col_slice(col, lo, hi):
     return c
 
 
-def redistribute_pieces(comm, cols, key_col, key_mode, nrows, n_pieces, consume):
-    """The rows in n_pieces pieces: piece c + 1 is split and put on the wire BEFORE piece c's consumer is queued, so the
-    exchange of c + 1 overlaps the operator kernels of c (consume(received cols, n) queues work on the context's stream)."""
+def redistribute_pieces(comm, cols, key_col, key_mode, nrows, n_pieces, consume, batched_counts=False):
+    """The rows in n_pieces pieces (piece c -> slot c); consume(received cols, n) queues the operator's work on the context's stream.
+
+    Default: piece c + 1 is split and put on the wire BEFORE piece c's consumer is queued, so the exchange of c + 1 overlaps the
+    operator kernels of c and the split of c + 1 overlaps the wire time of c — one count all-gather (a host-side wait) per piece.
+    batched_counts: every piece is split first, ONE all-gather carries the run sizes of all pieces (tsq_redistribute_prepare /
+    _counts / _issue), then the exchanges are queued one behind the other with no host-side wait in between; the splits are not
+    hidden behind the wire then (the 8-byte split moves 16 B per row: DESIGN.md §6 has the arithmetic of which one wins where)."""
     n_pieces = max(1, min(int(n_pieces), 8))
     bounds = [min(nrows, ((nrows * c // n_pieces) + 63) & ~63) for c in range(n_pieces)] + [nrows]
-    pending = None
+    if not batched_counts:
+        pending = None
+        for c in range(n_pieces):
+            lo, hi = bounds[c], bounds[c + 1]
+            got = comm.redistribute([col_slice(x, lo, hi) for x in cols], key_col, key_mode, hi - lo, slot=c % 8)
+            if pending is not None:
+                comm.wait(pending[0])
+                consume(pending[1], pending[2])
+            pending = (c % 8, got[0], got[1])
+        comm.wait(pending[0])
+        consume(pending[1], pending[2])
+        return
+    lib, n_cols = comm.lib, len(cols)
     for c in range(n_pieces):
         lo, hi = bounds[c], bounds[c + 1]
-        got = comm.redistribute([col_slice(x, lo, hi) for x in cols], key_col, key_mode, hi - lo, slot=c % 8)
-        if pending is not None:
-            comm.wait(pending[0])
-            consume(pending[1], pending[2])
-        pending = (c % 8, got[0], got[1])
-    comm.wait(pending[0])
-    consume(pending[1], pending[2])
+        arr = (abi.Col * n_cols)(*[col_slice(x, lo, hi) for x in cols])
+        _lib.check(lib.tsq_redistribute_prepare(comm.h, arr, n_cols, key_col, key_mode, hi - lo, c), comm.h)
+    slots = (C.c_int32 * n_pieces)(*range(n_pieces))
+    _lib.check(lib.tsq_redistribute_counts(comm.h, slots, n_pieces), comm.h)
+    got = []
+    for c in range(n_pieces):
+        out, n = (abi.Col * n_cols)(), C.c_int64(0)
+        _lib.check(lib.tsq_redistribute_issue(comm.h, c, out, n_cols, C.byref(n)), comm.h)
+        got.append((out, n.value))
+    for c in range(n_pieces):
+        comm.wait(c)
+        consume(got[c][0], got[c][1])
 
 
 class DistHashJoinCount:
@@ -178,13 +200,13 @@ class DistHashJoinCount:
         _lib.check(self.lib.tsq_join_set_count_only(self.h, 1), self.h)
         return n
 
-    def probe(self, cols, key_col, nrows, n_pieces=4):
+    def probe(self, cols, key_col, nrows, n_pieces=4, batched_counts=False):
         def consume(got, n):
             if n:
                 _lib.check(self.lib.tsq_join_probe_push(self.h, got, len(cols), n, None), self.h)
                 self.probed_local += n
                 self.probe_batches += 1
-        redistribute_pieces(self.comm, cols, key_col, 0, nrows, n_pieces, consume)
+        redistribute_pieces(self.comm, cols, key_col, 0, nrows, n_pieces, consume, batched_counts)
 
     def count(self):
         c = C.c_int64(0)
