@@ -244,7 +244,7 @@ def main():
         if packed:
             wide = st.packed_key_bits - st.radix_bits > 16
             kernel_name = "k_da_probe_count<1024,uint32_t>" if wide else "k_da_probe_count<512,uint16_t>"
-            part_name = "k_da_partition<1024,16,uint32_t>" if wide else ("k_da_partition<1024,16,uint16_t>" if os.environ.get("TSQ_DA_PART2", "1") == "0" else "k_da_partition2<512,8,4>")
+            part_name = "k_da_partition<1024,16,uint32_t>" if wide else ("k_da_partition<1024,16,uint16_t>" if os.environ.get("TSQ_DA_PART2", "1") == "0" else ("k_da_partition2<512,8,4>" if os.environ.get("TSQ_DA_NT", "1") == "0" else "k_da_partition2<512,8,4,true>"))
             part_bytes_per_key = 8.0 + (4.0 if wide else 2.0)  # 8 B key read + one packed entry written
         else:
             kernel_name = "k_lds_probe_count<1024>" if st.table_slice_bits >= 3 and os.environ.get("TSQ_RADIX_KERNEL", "") != "l2" else "k_radix_probe_count<2>"

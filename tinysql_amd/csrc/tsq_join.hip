@@ -1126,7 +1126,9 @@ tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st,
         if (pf) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, false, false, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
         else if (two) {
             const dim3 grid2((unsigned)std::min<int64_t>(ntiles, (int64_t)j->ctx->num_cus * 2));
-            static const bool ntl = [] { const char* v = getenv("TSQ_DA_NT"); return v && v[0] == '1'; }();
+            // non-temporal key loads: measured 3 x A/B in one session (profiles/r03_partition_nt_ab.txt): step 0.362 vs 0.373 ms, and
+            // the probe kernel that follows finds more of the entries in cache (0.074 vs 0.079 ms).  TSQ_DA_NT=0: plain loads
+            static const bool ntl = [] { const char* v = getenv("TSQ_DA_NT"); return !(v && v[0] == '0'); }();
             if (ntl) hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
             else hipLaunchKernelGGL((k_da_partition2<512, 8, 4>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
         } else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
