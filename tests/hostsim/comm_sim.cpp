@@ -11,6 +11,7 @@
 
 #include "../../tinysql_amd/csrc/tsq_device.h"
 #include "../../tinysql_amd/csrc/tsq_comm_plan.h"
+#include "../../tinysql_amd/csrc/tsq_arena.h"
 
 namespace {
 
@@ -264,6 +265,45 @@ int32_t sim_comm_counts(int32_t world, int32_t n_pieces, const int32_t* Ls, uint
             for (size_t w = 0; w < L[(size_t)k]; w++)
                 if (M[(size_t)r * L[(size_t)k] + w] != vec[(size_t)r][(size_t)k][w]) return 3;
     }
+    return 0;
+}
+
+// the context arena's range bookkeeping (tsq_arena.h) under a random allocate / release sequence: live blocks never overlap, stay
+// inside the slab, `used` is their sum, and once everything is released the slab is ONE free range again.  0 = all of that held.
+int32_t sim_arena(uint64_t slab, int32_t steps, uint64_t seed) {
+    tsq_arena_ranges a;
+    a.reset((size_t)slab);
+    uint64_t s = seed;
+    std::vector<std::pair<size_t, size_t>> live;  // (offset, length)
+    size_t sum = 0;
+    for (int i = 0; i < steps; i++) {
+        if (live.empty() || rnd(s) % 3) {
+            const size_t want = (size_t)(rnd(s) % (slab / 8 + 1)) + 1;
+            size_t off = 0, got = 0;
+            if (a.get(want, &off, &got)) {
+                if (got < want || (got & 255) || off + got > slab) return 1;
+                for (const auto& b : live)
+                    if (off < b.first + b.second && b.first < off + got) return 2;  // overlap
+                live.emplace_back(off, got);
+                sum += got;
+            }
+        } else {
+            const size_t k = (size_t)(rnd(s) % live.size());
+            a.put(live[k].first, live[k].second);
+            sum -= live[k].second;
+            live.erase(live.begin() + (long)k);
+        }
+        if (a.used != sum || a.peak < a.used) return 3;
+        size_t free_sum = 0, prev_end = (size_t)-1;
+        for (const auto& f : a.free_) {
+            if (prev_end != (size_t)-1 && f.first <= prev_end) return 4;  // two free ranges touch or overlap: not merged
+            prev_end = f.first + f.second;
+            free_sum += f.second;
+        }
+        if (free_sum + sum != slab) return 5;
+    }
+    for (const auto& b : live) a.put(b.first, b.second);
+    if (a.used != 0 || a.free_.size() != 1 || a.free_.begin()->first != 0 || a.free_.begin()->second != slab) return 6;
     return 0;
 }
 

@@ -165,6 +165,8 @@ SIGNATURES = {
     "tsq_ctx_set_stream": (C.c_int32, [P, P]),
     "tsq_ctx_sync": (C.c_int32, [P]),
     "tsq_ctx_destroy": (None, [P]),
+    "tsq_ctx_reserve": (C.c_int32, [P, C.c_int64]),
+    "tsq_ctx_arena_stats": (C.c_int32, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tsq_dev_alloc": (C.c_int32, [P, C.c_int64, PP]),
     "tsq_dev_free": (C.c_int32, [P, P]),
     "tsq_dev_memset": (C.c_int32, [P, P, C.c_int32, C.c_int64]),

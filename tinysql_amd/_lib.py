@@ -69,6 +69,15 @@ class Context:
     def sync(self):
         check(self.lib.tsq_ctx_sync(self.h), self.h)
 
+    def reserve(self, nbytes):
+        """tsq_ctx_reserve: one slab of HBM that every operator buffer of this context is carved from (0 gives it back)"""
+        check(self.lib.tsq_ctx_reserve(self.h, nbytes), self.h)
+
+    def arena_stats(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.tsq_ctx_arena_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)
+        return {"size": a.value, "used": b.value, "peak": c.value}
+
     def alloc(self, nbytes):
         p = C.c_void_p()
         check(self.lib.tsq_dev_alloc(self.h, nbytes, C.byref(p)), self.h)

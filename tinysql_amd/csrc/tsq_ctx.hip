@@ -99,9 +99,49 @@ TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
     for (auto& kv : ctx->jit_cache)
         if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
     for (auto& b : ctx->pool) (void)hipFree(b.first);
-    for (auto& b : ctx->user_allocs) (void)hipFree(b.first);  // blocks the caller never handed back
+    for (auto& b : ctx->user_allocs)  // blocks the caller never handed back (the arena's go with the slab)
+        if (!ctx->arena_base || (char*)b.first < ctx->arena_base || (char*)b.first >= ctx->arena_base + ctx->arena.size) (void)hipFree(b.first);
+    if (ctx->arena_base) (void)hipFree(ctx->arena_base);
     ctx->hdr.magic = 0;
     delete ctx;
+}
+
+// The arena (tsq_internal.h): one slab for the buffers of every operator of this context, allocated here — when the host process
+// sets the context up — instead of piece by piece inside the first query.
+TSQ_API tsq_status tsq_ctx_reserve(tsq_ctx* ctx, int64_t bytes) {
+    tsq_ctx_lock _api_lock(ctx);
+    if (!ctx || bytes < 0) return TSQ_ERR_INVALID;
+    tsq_handle_hdr* h = &ctx->hdr;
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    if (ctx->arena_base) {
+        if (ctx->arena.used) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_ctx_reserve: the arena holds live buffers (reserve before the first operator, or after the last one is destroyed)");
+        (void)hipFree(ctx->arena_base);
+        ctx->arena_base = nullptr;
+        ctx->arena.reset(0);
+    }
+    if (bytes == 0) return TSQ_OK;
+    const size_t sz = ((size_t)bytes + 255) & ~(size_t)255;
+    void* p = nullptr;
+    TSQ_HIP(h, hipMalloc(&p, sz));
+    hipError_t e = hipMemsetAsync(p, 0, sz, ctx->stream);  // every page is mapped before the first operator runs
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_ctx_reserve: ") + hipGetErrorString(e));
+    }
+    ctx->arena_base = (char*)p;
+    ctx->arena.reset(sz);
+    return TSQ_OK;
+}
+TSQ_API tsq_status tsq_ctx_arena_stats(tsq_ctx* ctx, int64_t* size_out, int64_t* used_out, int64_t* peak_out) {
+    if (!ctx) return TSQ_ERR_INVALID;
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    if (size_out) *size_out = (int64_t)ctx->arena.size;
+    if (used_out) *used_out = (int64_t)ctx->arena.used;
+    if (peak_out) *peak_out = (int64_t)ctx->arena.peak;
+    return TSQ_OK;
 }
 
 // tsq_dev_alloc / tsq_dev_free go through the context pool as well: a device-resident operator pipeline allocates its

@@ -24,6 +24,7 @@
 #include "tsq_ldsprobe.h"
 #include "tsq_dajoin.h"
 
+#include <chrono>
 #include <deque>
 #include <memory>
 
@@ -1745,6 +1746,12 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     tsq_handle_hdr* h = &j->hdr;
     const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
     const int np = j->cfg.n_probe_cols, nbc = j->cfg.n_build_cols;
+    // TSQ_DA_TRACE=1: host-side time points of one batch on stderr (where the wall time between the kernels goes)
+    static const bool trace = [] { const char* v = getenv("TSQ_DA_TRACE"); return v && v[0] == '1'; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    auto tp = [&](const char* what) {
+        if (trace) fprintf(stderr, "[da_emit_cols] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    };
     constexpr int T = 1024 * 8;
     const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nrows, T);
     if (g.nregions * g.cap >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "radix probe batch too large");
@@ -1802,6 +1809,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
     for (int e = 0; e < 3; e++)
         if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    tp("buffers + memsets queued");
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
     {
@@ -1837,7 +1845,9 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 52, pa.pcount + g.P, 8, hipMemcpyDeviceToHost, ctx->stream));
     TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 53, ctx->dscratch + 52, 8, hipMemcpyDeviceToHost, ctx->stream));
     TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 54, st.miss_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    tp("partition + sizing queued");
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    tp("sizing pass done");
     const int64_t part_rows = (int64_t)ctx->pinned[52], ovf_rows = (int64_t)ctx->pinned[53];
     const int64_t miss_rows = outer ? (int64_t)((const uint32_t*)(ctx->pinned + 54))[0] : 0;
     const int64_t exc_rows = ovf_rows + miss_rows, out_rows = exc_rows + part_rows;
@@ -1910,6 +1920,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
             xa.out_build_nn[sc] = of;
         }
     }
+    tp("output buffers");
     if (exc_rows > 0) {  // overflow-list rows, then the NULL-padded rows of the miss list, as pairs; their cells through the pairs
         TSQ_TRY(j->pairs.reserve(ctx, h, (size_t)exc_rows * 8 + 64));
         DaEmitArgs pe;
@@ -1974,11 +1985,14 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
     j->have_probe_ev = true;
+    tp("emit queued");
     if (rb->rows == 0) {
         rb->release();
         return TSQ_OK;
     }
-    return deliver_batch(j, std::move(rb), may_null_v);
+    const tsq_status ds = deliver_batch(j, std::move(rb), may_null_v);
+    tp("delivered (stream idle)");
+    return ds;
 }
 
 // ---------------------------------------------------------------- materialising radix path (host side)
