@@ -362,6 +362,7 @@ def main():
         for key, fn in (("build_warm", lambda: extra_build_warm(ctx, abi, _lib, bk, bv, nb)),
                         ("pcie_inclusive_1e7", lambda: extra_pcie(ctx, abi, _lib)),
                         ("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
+                        ("wide_keys_31bit_unique_bit_cells", lambda: extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
                         ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
@@ -581,6 +582,54 @@ def extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
     return {"workload": "1e8 x 1e8 count(*), key packing off: 64-bit table words (k_radix_partition + k_lds_probe_count)", "ms_per_probe_pass": ms,
             "rows_per_s": npr / ms * 1e3, "frac": 24.0 * npr / ms / 1e6 / 8000.0, "verified": cnt.value == (steps + 2) * npr,
             "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "steps": steps}
+
+
+def extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
+    """The headline join with its keys SPREAD over 31 bits (key' = 16 key + 3, build side still unique): one byte per cell does not
+    fit (2^31 cells), one BIT per cell does (k_da_build_bits: 256 MB of images, 4-byte entries).  Every second probe key is moved off
+    the grid (+ 1: a miss), so the count is checked against numpy's count of the keys that stayed on it."""
+    import numpy as np
+
+    lib = ctx.lib
+    hb, hp = np.empty(nb, dtype=np.int64), np.empty(npr, dtype=np.int64)
+    ctx.d2h(hb, bk)
+    ctx.d2h(hp, pk)
+    hb = hb * 16 + 3
+    hp = hp * 16 + 3 + (np.arange(npr, dtype=np.int64) & 1)
+    want = int(npr - (npr // 2))  # rows with an even index keep their key
+    bk2, pk2 = ctx.alloc(nb * 8), ctx.alloc(npr * 8)
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 1, 1
+    cfg.build_types[0] = cfg.probe_types[0] = abi.I64
+    h = C.c_void_p()
+    try:
+        ctx.h2d(bk2, hb)
+        ctx.h2d(pk2, hp)
+        del hb, hp
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        _lib.check(lib.tsq_join_build_push(h, (abi.Col * 1)(_dev_col(abi, bk2, nb)), 1, nb), h)
+        _lib.check(lib.tsq_join_build_finish(h), h)
+        _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+        pc = (abi.Col * 1)(_dev_col(abi, pk2, npr))
+        for _ in range(2):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(steps):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ms = ctx.timer_stop_ms() / steps
+        cnt = C.c_int64(0)
+        _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+        st = abi.Stats()
+        _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+    finally:
+        if h:
+            lib.tsq_join_destroy(h)
+        ctx.free(bk2)
+        ctx.free(pk2)
+    return {"workload": "1e8 x 1e8 count(*), keys spread over 31 bits (16 k + 3), hit ratio 0.5: 4-byte entries against one-BIT cells in LDS", "ms_per_probe_pass": ms,
+            "rows_per_s": npr / ms * 1e3, "frac": 24.0 * npr / ms / 1e6 / 8000.0, "verified": cnt.value == (steps + 2) * want, "packed_key_bits": int(st.packed_key_bits),
+            "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "packed_images_ms": st.packed_build_ms, "steps": steps}
 
 
 def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3, nullable_left_outer=False):

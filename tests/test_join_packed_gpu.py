@@ -335,3 +335,45 @@ def test_packed_travelling_columns_condition_error_is_the_direct_routes(ctx):
     pv[12_345] = 5  # without the poisoned cell the same join runs on the packed route
     probe = Chunk([Column(abi.I64, probe.columns[0].data), Column(abi.I64, pv)])
     assert _rows(ctx, cfg, build, probe).NumRows() == n
+
+
+# ------------------------------------------------------------------ bit cells: unique build keys spanning 29..31 bits (COUNT(*) route)
+@pytest.mark.parametrize("span_bits,n_build", [(29, 120_000), (30, 50_000), (31, 300_000)])
+def test_packed_bit_cells_unique_build_side(ctx, span_bits, n_build):
+    # one BIT per cell (k_da_build_bits): 2^b / 8 bytes of images, 4-byte entries.  Probe keys: hits, misses inside the range, keys
+    # outside it on both sides, NULLs; a hot probe key overflows its partition's region (the overflow list tests bits in HBM)
+    rng = np.random.default_rng(span_bits)
+    span = (1 << span_bits) - 5
+    base = -(1 << 50) + 99
+    bk = base + np.unique(np.concatenate([rng.integers(0, span, n_build), np.array([0, span - 1])]))
+    rng.shuffle(bk)
+    n = 400_000
+    pk = np.where(rng.random(n) < 0.5, bk[rng.integers(0, len(bk), n)], base + rng.integers(-span // 8, span + span // 8, n))
+    pk[::5] = bk[3]  # the hot key
+    pnn = rng.random(n) > 0.03
+    build, probe = _tables(bk, pk, None, pnn)
+    want = int(np.isin(pk[pnn], bk).sum())
+    stats = []
+    got = G.run_join(ctx, _cfg(), build, probe, chunk_rows=1 << 22, count_only=True, radix=FORCE, packing=FORCE, stats_out=stats)
+    assert got == want
+    assert stats[0].probe_route == abi.ROUTE_PACKED and stats[0].packed_key_bits == span_bits and stats[0].radix_overflow_rows > 0
+    assert _count(ctx, _cfg(), build, probe, chunk_rows=4096) == want
+
+
+def test_packed_bit_cells_need_a_unique_build_side(ctx):
+    # one duplicate among keys that span 30 bits: a bit cannot hold a multiplicity, the join keeps 64-bit table words (a materialising
+    # join over such a range never takes the packed route: bit cells carry no ranks)
+    rng = np.random.default_rng(31)
+    bk = np.unique(rng.integers(0, 1 << 30, 60_000))
+    bk = np.concatenate([bk, bk[:1]])
+    pk = np.concatenate([bk[rng.integers(0, len(bk), 100_000)], rng.integers(0, 1 << 30, 100_000)])
+    build, probe = _tables(bk, pk)
+    keys, cnts = np.unique(bk, return_counts=True)
+    pos = np.searchsorted(keys, pk)
+    pos[pos == len(keys)] = 0
+    want = int(cnts[pos][keys[pos] == pk].sum())
+    stats = []
+    got = G.run_join(ctx, _cfg(), build, probe, chunk_rows=1 << 22, count_only=True, radix=FORCE, packing=FORCE, stats_out=stats)
+    assert got == want and stats[0].probe_route != abi.ROUTE_PACKED
+    rows = G.run_join(ctx, _cfg(), build, probe.slice(0, 5000), chunk_rows=1 << 22, radix=FORCE, packing=FORCE)
+    assert rows.NumRows() == int(cnts[pos[:5000]][keys[pos[:5000]] == pk[:5000]].sum())

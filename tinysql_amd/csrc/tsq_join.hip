@@ -768,7 +768,8 @@ struct tsq_join {
     DaDomain da_dm{};
     uint32_t da_pbits = 0, da_ebits = 0;
     bool da_unique = false;
-    DevBuf da_img;                    // 2^b one-byte cells
+    bool da_bits = false;             // bit cells: a unique build side whose keys span 29..31 bits (COUNT(*) route)
+    DevBuf da_img;                    // 2^b one-byte cells (bit cells: 2^b / 8 bytes)
     double da_build_ms = 0;
     int da_rows_state = 0;            // materialising packed route: build rows sorted by word (CSR over the images)
     DevBuf da_coarse, da_pstart, da_brows;
@@ -1176,15 +1177,20 @@ tsq_status da_prepare(tsq_join* j) {
     const uint64_t usable = ctx->pinned[50];
     if (usable == 0) return TSQ_OK;
     const uint64_t kmin = ctx->pinned[48] ^ ma.flip, kmax = ctx->pinned[49] ^ ma.flip, range = kmax - kmin;
-    if (range >> TSQ_DA_MAX_BITS) return TSQ_OK;
+    // 29..31 bits: one BIT per cell instead of one byte (k_da_build_bits) — only a build side WITHOUT duplicate keys fits that
+    // (the images kernel finds out); COUNT(*) route only
+    const bool bits_mode = (range >> TSQ_DA_MAX_BITS) != 0;
+    if (bits_mode && ((range >> TSQ_DA_MAX_BITS_UNIQ) != 0 || !j->count_only)) return TSQ_OK;
     uint32_t b = TSQ_DA_MIN_BITS;
     while ((range >> b) != 0) b++;
     if (!force && (1ULL << b) > 32ULL * usable) return TSQ_OK;  // a sparse domain: the images would be mostly zeros
     int pb = std::min<int>(TSQ_RADIX_MAX_BITS, (int)b - 10);
     if (const char* e = getenv("TSQ_DA_PB")) pb = atoi(e);
-    pb = std::max<int>(pb, (int)b - TSQ_DA_MAX_EBITS);
+    const int max_ebits = bits_mode ? TSQ_DA_MAX_EBITS_UNIQ : TSQ_DA_MAX_EBITS;
+    pb = std::max<int>(pb, (int)b - max_ebits);
     pb = std::min<int>(std::max<int>(pb, TSQ_RADIX_MIN_BITS), TSQ_RADIX_MAX_BITS);
-    if ((int)b - pb > TSQ_DA_MAX_EBITS || (int)b - pb < 4) return TSQ_OK;
+    if ((int)b - pb > max_ebits || (int)b - pb < 4) return TSQ_OK;
+    j->da_bits = bits_mode;
     j->da_pbits = (uint32_t)pb;
     j->da_ebits = b - (uint32_t)pb;
     j->da_dm.kmin = kmin;
@@ -1204,7 +1210,7 @@ tsq_status da_prepare(tsq_join* j) {
     if (s == TSQ_OK) s = ctl.reserve(ctx, h, g.ctl_bytes);
     if (s == TSQ_OK) s = vend.reserve(ctx, h, g.nregions * 4);
     if (s == TSQ_OK) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
-    if (s == TSQ_OK) s = j->da_img.reserve(ctx, h, ((size_t)1 << b) + 64);
+    if (s == TSQ_OK) s = j->da_img.reserve(ctx, h, (bits_mode ? ((size_t)1 << b) / 8 : ((size_t)1 << b)) + 64);
     if (s != TSQ_OK) { release_all(); j->da_img.release(); return s; }
     DaStore st;
     memset(&st, 0, sizeof st);
@@ -1229,9 +1235,12 @@ tsq_status da_prepare(tsq_join* j) {
     ia.st = st;
     ia.img = j->da_img.as<uint8_t>();
     ia.flags = (uint32_t*)(ctx->dscratch + 51);
-    const size_t img_lds = (size_t)1 << j->da_ebits;
+    const size_t img_lds = bits_mode ? ((size_t)1 << j->da_ebits) / 8 : ((size_t)1 << j->da_ebits);
     if (e == hipSuccess && s == TSQ_OK) {
-        if (j->da_ebits > 16) {
+        if (bits_mode) {
+            e = hipFuncSetAttribute((const void*)k_da_build_bits<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_bits<1024>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, ia);
+        } else if (j->da_ebits > 16) {
             e = hipFuncSetAttribute((const void*)k_da_build_images<1024, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
             if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_images<1024, uint32_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, ia);
         } else {
@@ -1241,7 +1250,8 @@ tsq_status da_prepare(tsq_join* j) {
         if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess && s == TSQ_OK) {
-        hipLaunchKernelGGL(k_da_build_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
+        if (bits_mode) hipLaunchKernelGGL(k_da_build_bits_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
+        else hipLaunchKernelGGL(k_da_build_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
@@ -1256,7 +1266,7 @@ tsq_status da_prepare(tsq_join* j) {
     if (s != TSQ_OK) { j->da_img.release(); return s; }
     if (e != hipSuccess) { j->da_img.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key images: ") + hipGetErrorString(e)); }
     const uint32_t f_over = ((const uint32_t*)(ctx->pinned + 51))[0], f_dup = ((const uint32_t*)(ctx->pinned + 51))[1];
-    if (f_over) {  // a key with more than 255 build rows: the 64-bit route keeps this join
+    if (f_over || (bits_mode && f_dup)) {  // a key with more than 255 build rows (bit cells: with more than one): the 64-bit route keeps this join
         j->da_img.release();
         return TSQ_OK;
     }
@@ -1305,8 +1315,12 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     pa.st = st;
     pa.img = j->da_img.as<uint8_t>();
     pa.counters = j->counters.as<unsigned long long>();
-    const size_t img_lds = (size_t)1 << j->da_ebits;
-    if (j->da_ebits > 16) {
+    const size_t img_lds = j->da_bits ? ((size_t)1 << j->da_ebits) / 8 : ((size_t)1 << j->da_ebits);
+    if (j->da_bits) {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<1024, uint32_t, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds));
+        const uint32_t per_cu = img_lds <= (64u << 10) ? 2u : 1u;
+        hipLaunchKernelGGL((k_da_probe_count<1024, uint32_t, false, false, true>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * per_cu)), dim3(1024), img_lds, ctx->stream, pa);
+    } else if (j->da_ebits > 16) {
         TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<1024, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds));
         hipLaunchKernelGGL((k_da_probe_count<1024, uint32_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, pa);
     } else {
@@ -1314,7 +1328,8 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
         hipLaunchKernelGGL((k_da_probe_count<512, uint16_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(512), img_lds, ctx->stream, pa);
     }
     TSQ_HIP(h, hipGetLastError());
-    hipLaunchKernelGGL(k_da_probe_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    if (j->da_bits) hipLaunchKernelGGL((k_da_probe_ovf<false, true>), dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    else hipLaunchKernelGGL(k_da_probe_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
