@@ -341,7 +341,10 @@ tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode);
  * the range fits 28 bits, holds >= 1 build row per 32 values and no key has more than 255 build rows, a COUNT(*) probe batch
  * travels as 2-byte entries (bijective mix of key - kmin; partition = its top bits) and meets a direct-address table of one
  * byte per value of the range, one 64 KB image per partition in LDS — equality of entries IS equality of keys
- * (util/codec/codec.go:363-382), a probe key outside the range joins nothing.  OFF keeps 64-bit table words; FORCE drops the
+ * (util/codec/codec.go:363-382), a probe key outside the range joins nothing.  A build side WITHOUT duplicate keys may span up to
+ * 31 bits for a COUNT(*) probe: one BIT per value (4-byte entries).  Materialising probes of inner / outer joins (8-byte columns,
+ * OtherConditions of inner joins included) take the same entries with the probe columns travelling next to them (<= 27 bits).
+ * OFF keeps 64-bit table words; FORCE drops the
  * size and density conditions (tests).  Must be chosen before the first probe batch.  The joined rows are identical either way.
  * Replaces join2Chunk + GetMatchedRows (executor/join.go:343-360, hash_table.go:110-134) for that shape. */
 tsq_status tsq_join_set_key_packing(tsq_join* j, int32_t mode);
