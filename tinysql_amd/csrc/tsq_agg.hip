@@ -1098,8 +1098,8 @@ tsq_status da_agg_setup_multi(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     a->da_low = total <= log2c;  // the word fits one LDS table: no partition pass (k_agg_da_low)
     uint32_t b = std::max(total, log2c + TSQ_RADIX_MIN_BITS);
     if (b - log2c > TSQ_RADIX_MAX_BITS) return TSQ_OK;
-    a->da_pbits = b - log2c;
-    a->da_ebits = log2c;
+    a->da_pbits = std::max<uint32_t>(b - log2c, 5);  // >= 32 partitions x 8 region shares: a workgroup for every CU (k_agg_da)
+    a->da_ebits = b - a->da_pbits;
     a->da_dm.kmin = 0;  // the partial group's key word is the field word d itself
     a->da_dm.range = ((uint64_t)1 << b) - 1;
     a->da_dm.b = b;
@@ -1143,8 +1143,8 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     uint32_t b = log2c + TSQ_RADIX_MIN_BITS;
     while ((range >> b) != 0) b++;
     if (b - log2c > TSQ_RADIX_MAX_BITS) return TSQ_OK;
-    a->da_pbits = b - log2c;
-    a->da_ebits = log2c;
+    a->da_pbits = std::max<uint32_t>(b - log2c, 5);  // >= 32 partitions x 8 region shares: a workgroup for every CU (k_agg_da)
+    a->da_ebits = b - a->da_pbits;
     a->da_dm.kmin = kmin;
     a->da_dm.range = ((uint64_t)1 << b) - 1;  // the whole 2^b window above kmin: later batches may bring somewhat larger keys
     a->da_dm.b = b;
@@ -1178,7 +1178,11 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         if (((double)groups_est * 1.3 / (double)S) > (double)(1u << bits)) return TSQ_OK;  // too many groups for LDS tables
     }
     // partial-group buffer: every workgroup may emit a table, plus spilled rows; beyond cap the batch is redone row by row
-    const size_t nblocks = (low || packed_low) ? (size_t)ctx->num_cus : ((size_t)1 << (packed ? a->da_pbits : bits));
+    // a packed batch with few partitions splits each of them over up to 8 workgroups (k_agg_da: one share of the XCC regions each)
+    uint32_t da_nsplit = 1;
+    if (packed && !packed_low)
+        while (da_nsplit < 8 && ((uint32_t)1 << a->da_pbits) * da_nsplit < (uint32_t)ctx->num_cus) da_nsplit *= 2;
+    const size_t nblocks = (low || packed_low) ? (size_t)ctx->num_cus : (((size_t)1 << (packed ? a->da_pbits : bits)) * da_nsplit);
     const size_t pcap = std::min<size_t>(nblocks * S + (size_t)nrows / 8 + 4096, 0x7fffffffULL);
     TSQ_TRY(a->fkey.reserve(ctx, h, pcap * 8));
     for (int k = 0; k < pl.W; k++) TSQ_TRY(a->fw[k].reserve(ctx, h, pcap * 8));
@@ -1280,7 +1284,8 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         da.out = la.out;
         da.st = st;
         da.dm = a->da_dm;
-        const int agrid = (int)std::min<uint32_t>(P, (uint32_t)ctx->num_cus);
+        da.nsplit = da_nsplit;
+        const int agrid = (int)std::min<uint32_t>(P * da.nsplit, (uint32_t)ctx->num_cus);
         TSQ_TRY(launch_agg_da(a, da, agrid));
         a->packed_batches++;
     } else {

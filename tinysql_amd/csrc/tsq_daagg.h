@@ -298,6 +298,7 @@ struct DaAggLdsArgs {
     AfPartials out;
     DaAggStore st;
     DaDomain dm;
+    uint32_t nsplit;  // workgroups per partition (1, 2, 4 or 8: each takes every nsplit-th XCC region)
 };
 // what one row does to the accumulators of cell e
 template <int W, int CELLS>
@@ -376,7 +377,12 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
     __shared__ uint32_t s_base, s_wsum[TSQ_AF_NT / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t P = 1u << a.st.bits;
-    for (uint32_t p = blockIdx.x; p < P; p += gridDim.x) {
+    // a work item = (partition, share of its 8 XCC regions): a narrow key range has few partitions (2^5 for 17 bits) — with one
+    // workgroup per partition 32 of 256 CUs worked (3.5 ms per 2.5e8 rows); nsplit workgroups per partition each take every
+    // nsplit-th region and emit their own partial groups (the merge adds them up)
+    const uint32_t nsplit = a.nsplit;
+    for (uint32_t item = blockIdx.x; item < P * nsplit; item += gridDim.x) {
+        const uint32_t p = item / nsplit, r0 = item % nsplit;
         __syncthreads();
         for (uint32_t i = tid; i < (uint32_t)CELLS; i += TSQ_AF_NT) {
 #pragma unroll
@@ -384,7 +390,7 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
         }
         for (uint32_t i = tid; i < (uint32_t)CELLS / 32; i += TSQ_AF_NT) s_touch[i] = 0;
         __syncthreads();
-        for (uint32_t r = 0; r < 8; r++) {
+        for (uint32_t r = r0; r < 8; r += nsplit) {
             const uint32_t len = daagg_region_len(a.st, P, p, r);
             const size_t base = (size_t)(p * 8u + r) * a.st.cap;
             for (uint32_t i0 = tid; i0 < len; i0 += TSQ_AF_NT * U) {
