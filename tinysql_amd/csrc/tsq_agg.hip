@@ -1037,6 +1037,16 @@ tsq_status launch_lds(tsq_agg* a, AfLdsArgs& la, int grid) {
 // ---- packed-key H mode (tsq_daagg.h)
 tsq_status launch_agg_da(tsq_agg* a, DaAggLdsArgs& la, int grid) {
     hipStream_t st = a->ctx->stream;
+    if (la.plan.W <= 3 && la.st.ebits <= 11) {  // half-size tables: two workgroups per CU
+        switch (la.plan.W) {
+            case 1: hipLaunchKernelGGL((k_agg_da<1, 2048>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+            case 2: hipLaunchKernelGGL((k_agg_da<2, 2048>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+            default: hipLaunchKernelGGL((k_agg_da<3, 2048>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
+        }
+        TSQ_HIP(&a->hdr, hipGetLastError());
+        a->st.kernel_launches++;
+        return TSQ_OK;
+    }
     switch (la.plan.W) {  // W <= 3: 4096 cells per partition (96 KB of LDS words), else 2048
         case 1: hipLaunchKernelGGL((k_agg_da<1, 4096>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
         case 2: hipLaunchKernelGGL((k_agg_da<2, 4096>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
@@ -1094,7 +1104,8 @@ tsq_status da_agg_setup_multi(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
         total += w;
         if (total > TSQ_DAAGG_MAX_BITS) return TSQ_OK;
     }
-    const uint32_t log2c = pl.W <= 3 ? 12u : 11u;
+    static const int log2c_env = [] { const char* v = getenv("TSQ_DAAGG_LOG2C"); return v ? atoi(v) : 0; }();  // (experiment knob: 11 = half-size tables)
+    const uint32_t log2c = (log2c_env >= 9 && log2c_env <= 12 && pl.W <= 3) ? (uint32_t)log2c_env : (pl.W <= 3 ? 12u : 11u);
     a->da_low = total <= log2c;  // the word fits one LDS table: no partition pass (k_agg_da_low)
     uint32_t b = std::max(total, log2c + TSQ_RADIX_MIN_BITS);
     if (b - log2c > TSQ_RADIX_MAX_BITS) return TSQ_OK;
@@ -1138,7 +1149,8 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     a->st.kernel_launches++;
     if (ctx->pinned[50] == 0) return TSQ_OK;
     const uint64_t kmin = ctx->pinned[48] ^ ma.flip, kmax = ctx->pinned[49] ^ ma.flip, range = kmax - kmin;
-    const uint32_t log2c = pl.W <= 3 ? 12u : 11u;
+    static const int log2c_env = [] { const char* v = getenv("TSQ_DAAGG_LOG2C"); return v ? atoi(v) : 0; }();  // (experiment knob: 11 = half-size tables)
+    const uint32_t log2c = (log2c_env >= 9 && log2c_env <= 12 && pl.W <= 3) ? (uint32_t)log2c_env : (pl.W <= 3 ? 12u : 11u);
     if (range >> TSQ_DAAGG_MAX_BITS) return TSQ_OK;
     uint32_t b = log2c + TSQ_RADIX_MIN_BITS;
     while ((range >> b) != 0) b++;
@@ -1285,7 +1297,8 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         da.st = st;
         da.dm = a->da_dm;
         da.nsplit = da_nsplit;
-        const int agrid = (int)std::min<uint32_t>(P * da.nsplit, (uint32_t)ctx->num_cus);
+        const uint32_t wg_per_cu = (pl.W <= 3 && st.ebits <= 11) ? 2u : 1u;
+        const int agrid = (int)std::min<uint32_t>(P * da.nsplit, (uint32_t)ctx->num_cus * wg_per_cu);
         TSQ_TRY(launch_agg_da(a, da, agrid));
         a->packed_batches++;
     } else {
