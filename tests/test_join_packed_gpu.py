@@ -377,3 +377,71 @@ def test_packed_bit_cells_need_a_unique_build_side(ctx):
     assert got == want and stats[0].probe_route != abi.ROUTE_PACKED
     rows = G.run_join(ctx, _cfg(), build, probe.slice(0, 5000), chunk_rows=1 << 22, radix=FORCE, packing=FORCE)
     assert rows.NumRows() == int(cnts[pos[:5000]][keys[pos[:5000]] == pk[:5000]].sum())
+
+
+# ------------------------------------------------------------------ several integer key columns: one composite key column (k_da_compose)
+def _mk_side(rng, n, fields, n_pay, null_key=0.03):
+    """fields: per key column (type, lo, hi); then n_pay 8-byte payload columns (alternating nullable)"""
+    cols = []
+    for tp, lo, hi in fields:
+        v = rng.integers(lo, hi, n)
+        cols.append(Column(tp, v.astype(np.uint64) if tp == abi.U64 else v, rng.random(n) > null_key if null_key else None))
+    for c in range(n_pay):
+        tp = (abi.F64, abi.I64, abi.U64)[c % 3]
+        data = rng.random(n) if tp == abi.F64 else (rng.integers(0, 1 << 40, n).astype(np.uint64) if tp == abi.U64 else rng.integers(-(1 << 40), 1 << 40, n))
+        cols.append(Column(tp, data, (rng.random(n) > 0.1) if c % 2 == 0 else None))
+    return Chunk(cols)
+
+
+@pytest.mark.parametrize("nk", [2, 3, 4])
+@pytest.mark.parametrize("n_probe", [1, 4097, 120_001])
+def test_packed_several_key_columns_count_vs_oracle(ctx, orc, nk, n_probe):
+    # COUNT(*) over a join on (k1, .., kn): NULL cells, probe cells outside the build side's fields, duplicates of whole key tuples
+    rng = np.random.default_rng(nk * 1000 + n_probe)
+    fields = [(abi.I64, -40, 41), (abi.I64, 10**12, 10**12 + 9), (abi.U64, 0, 5), (abi.I64, -3, 4)][:nk]
+    wider = [(tp, lo - 3, hi + 3) for tp, lo, hi in fields]
+    build = _mk_side(rng, 5000, fields, 1)
+    probe = _mk_side(rng, n_probe, wider, 1)
+    keys = list(range(nk))
+    cfg = H.join_cfg(probe.types(), build.types(), keys, keys, abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    assert _count(ctx, cfg, build, probe, want_route=abi.ROUTE_PACKED) == want
+    assert _count(ctx, cfg, build, probe, packing=OFF) == want
+    assert _count(ctx, cfg, build, probe, chunk_rows=1024) == want
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_INNER, 0), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("n_probe", [64, 60_001])
+def test_packed_several_key_columns_rows_vs_oracle(ctx, orc, jt, inner, n_probe):
+    # the same on the travelling-columns route: the key columns are ordinary payload there (they travel / are sorted by word)
+    rng = np.random.default_rng(17 * n_probe + jt + inner)
+    fields = [(abi.I64, -30, 31), (abi.U64, 5, 14), (abi.I64, 0, 3)]
+    build = _mk_side(rng, 4000, fields, 2)
+    probe = _mk_side(rng, n_probe, [(tp, lo - 2, hi + 2) for tp, lo, hi in fields], 3)
+    left, right = (probe, build) if inner == 1 else (build, probe)
+    cfg = H.join_cfg(left.types(), right.types(), [0, 1, 2], [0, 1, 2], jt, inner)
+    want = orc.hash_join(cfg, build, probe)
+    got = _rows(ctx, cfg, build, probe)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+def test_packed_several_key_columns_mixed_signedness_and_too_wide(ctx, orc):
+    rng = np.random.default_rng(77)
+    # BIGINT against BIGINT UNSIGNED in the second key column: cells >= 2^63 never match (codec.go:219-224)
+    n = 6000
+    b2 = rng.integers(0, 50, n).astype(np.uint64)
+    b2[::9] += np.uint64(1 << 63)
+    build = Chunk([Column(abi.I64, rng.integers(0, 60, n)), Column(abi.U64, b2), Column(abi.I64, np.arange(n))])
+    p2 = rng.integers(0, 50, 50_000)
+    p2[::11] = -5  # the same bits as a huge unsigned cell would need: still no match
+    probe = Chunk([Column(abi.I64, rng.integers(0, 60, 50_000)), Column(abi.I64, p2), Column(abi.I64, np.arange(50_000))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    assert _count(ctx, cfg, build, probe, want_route=abi.ROUTE_PACKED) == want
+    # fields that add up to more than 28 bits: the direct route keeps the join
+    build = Chunk([Column(abi.I64, rng.integers(0, 1 << 20, n)), Column(abi.I64, rng.integers(0, 1 << 12, n))])
+    probe = Chunk([Column(abi.I64, build.columns[0].data[rng.integers(0, n, 30_000)]), Column(abi.I64, rng.integers(0, 1 << 12, 30_000))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_INNER, 1)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, radix=FORCE, packing=FORCE, stats_out=stats)
+    assert got == orc.hash_join(cfg, build, probe).NumRows() and stats[0].probe_route == abi.ROUTE_DIRECT

@@ -769,6 +769,9 @@ struct tsq_join {
     uint32_t da_pbits = 0, da_ebits = 0;
     bool da_unique = false;
     bool da_bits = false;             // bit cells: a unique build side whose keys span 29..31 bits (COUNT(*) route)
+    bool da_multi = false;            // several integer key columns composed into one key column (k_da_compose)
+    DaFields da_fields{};
+    DevBuf da_ckey, rckey;            // composite key column of the build side | of the probe batch in flight
     DevBuf da_img;                    // 2^b one-byte cells (bit cells: 2^b / 8 bytes)
     double da_build_ms = 0;
     int da_rows_state = 0;            // materialising packed route: build rows sorted by word (CSR over the images)
@@ -948,6 +951,17 @@ bool radix_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_de
     if (j->radix_mode == TSQ_RADIX_FORCE) return true;
     // table slices of ~1.5 MB per partition need >= 8 partitions to be worth it; batch >= 4 Mi rows
     return j->nbuckets * 64 >= ((uint64_t)12 << 20) && nrows >= (4 << 20);
+}
+
+// COUNT(*) over a join on several integer key columns: no 64-bit radix route exists for it, only the packed one (da_multi_ok is
+// defined with the packed route below)
+bool da_multi_ok(const tsq_join* j);
+bool da_multi_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || !j->multi || !da_multi_ok(j) || j->da_state < 0) return false;
+    if (!j->count_only || j->checksum || j->general || selected_dev || j->never_match || j->chained) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (4 << 20);
 }
 
 // Geometry of a radix probe batch.  LDS route (sliced table): P = 2^pb partitions of 2^(tb - pb) table slices each, read as S
@@ -1140,13 +1154,118 @@ tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st,
     return TSQ_OK;
 }
 
+// several key columns ride the packed routes as ONE composite column (tsq_dajoin.h, k_da_compose) when all of them are integers
+bool da_multi_ok(const tsq_join* j) {
+    if (!j->multi || j->ks.n_keys > TSQ_DA_MAXKEYS) return false;
+    for (int k = 0; k < j->ks.n_keys; k++)
+        if (!is_int_class(j->cfg.build_types[j->ks.bidx[k]]) || !is_int_class(j->cfg.probe_types[j->ks.pidx[k]])) return false;
+    return true;
+}
+// the key column the packed kernels partition: the build side's ...
+void da_build_key(const tsq_join* j, DaSrc& src) {
+    memset(&src, 0, sizeof src);
+    const int kc = j->ks.bidx[0];
+    src.nrows = j->bcols[kc].rows;
+    if (j->da_multi) {
+        src.data = j->da_ckey.as<uint64_t>();
+        return;
+    }
+    src.data = j->bcols[kc].data.as<uint64_t>();
+    src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
+}
+// ... and a probe batch's (composed into j->rckey first when the key has several columns)
+tsq_status da_probe_key(tsq_join* j, const tsq_colset& pcs, int64_t nrows, DaSrc& src) {
+    memset(&src, 0, sizeof src);
+    src.nrows = nrows;
+    if (!j->da_multi) {
+        const int kc = j->ks.pidx[0];
+        src.data = (const uint64_t*)pcs.data[kc];
+        src.nulls = pcs.nulls[kc];
+        return TSQ_OK;
+    }
+    TSQ_TRY(j->rckey.reserve(j->ctx, &j->hdr, (size_t)nrows * 8 + 64));
+    DaComposeArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.f = j->da_fields;
+    for (int k = 0; k < j->ks.n_keys; k++) {
+        ca.col[k] = (const uint64_t*)pcs.data[j->ks.pidx[k]];
+        ca.nulls[k] = pcs.nulls[j->ks.pidx[k]];
+    }
+    ca.nrows = nrows;
+    ca.out = j->rckey.as<uint64_t>();
+    hipLaunchKernelGGL(k_da_compose, dim3(tsq_grid_for(j->ctx, nrows, 256)), dim3(256), 0, j->ctx->stream, ca);
+    TSQ_HIP(&j->hdr, hipGetLastError());
+    j->st.kernel_launches++;
+    src.data = j->rckey.as<uint64_t>();
+    return TSQ_OK;
+}
+// the fields of a several-column key from the build side's columns, and the build side's composite column
+tsq_status da_compose_build(tsq_join* j, bool* ok) {
+    *ok = false;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const int nk = j->ks.n_keys;
+    const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
+    DaFields& f = j->da_fields;
+    memset(&f, 0, sizeof f);
+    f.n = nk;
+    uint32_t total = 0;
+    for (int k = 0; k < nk; k++) {
+        const int c = j->ks.bidx[k];
+        const int32_t bt = j->cfg.build_types[c], pt = j->cfg.probe_types[j->ks.pidx[k]];
+        DaMinMaxArgs ma;
+        memset(&ma, 0, sizeof ma);
+        ma.src.data = j->bcols[c].data.as<uint64_t>();
+        ma.src.nulls = j->bcols[c].has_nulls ? j->bcols[c].nulls.as<uint8_t>() : nullptr;
+        ma.src.nrows = nb;
+        ma.flip = (bt == TSQ_I64 && pt == TSQ_I64) ? 0x8000000000000000ULL : 0ULL;
+        ma.skip_high = bt != pt ? 1 : 0;  // BIGINT against BIGINT UNSIGNED: cells >= 2^63 never match (codec.go:219-224)
+        ma.out = (unsigned long long*)(ctx->dscratch + 48);
+        ctx->pinned[48] = ~0ULL;
+        ctx->pinned[49] = 0;
+        ctx->pinned[50] = 0;
+        TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 24, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nb, 256)), dim3(256), 0, ctx->stream, ma);
+        TSQ_HIP(h, hipGetLastError());
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        j->st.kernel_launches++;
+        if (ctx->pinned[50] == 0) return TSQ_OK;  // no usable cell in this column: nothing can match, the direct route says so
+        const uint64_t kmin = ctx->pinned[48] ^ ma.flip, range = (ctx->pinned[49] ^ ma.flip) - kmin;
+        if (range >> TSQ_DA_MAX_BITS) return TSQ_OK;
+        uint32_t w = 0;
+        while ((range >> w) != 0) w++;
+        f.kmin[k] = kmin;
+        f.maxd[k] = range;
+        f.shift[k] = total;
+        f.skip_high[k] = ma.skip_high;
+        total += w;
+        if (total > TSQ_DA_MAX_BITS) return TSQ_OK;
+    }
+    TSQ_TRY(j->da_ckey.reserve(ctx, h, (size_t)nb * 8 + 64));
+    DaComposeArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.f = f;
+    for (int k = 0; k < nk; k++) {
+        ca.col[k] = j->bcols[j->ks.bidx[k]].data.as<uint64_t>();
+        ca.nulls[k] = j->bcols[j->ks.bidx[k]].has_nulls ? j->bcols[j->ks.bidx[k]].nulls.as<uint8_t>() : nullptr;
+    }
+    ca.nrows = nb;
+    ca.out = j->da_ckey.as<uint64_t>();
+    hipLaunchKernelGGL(k_da_compose, dim3(tsq_grid_for(ctx, nb, 256)), dim3(256), 0, ctx->stream, ca);
+    TSQ_HIP(h, hipGetLastError());
+    j->st.kernel_launches++;
+    *ok = true;
+    return TSQ_OK;
+}
+
 tsq_status da_prepare(tsq_join* j) {
     if (j->da_state) return TSQ_OK;
     j->da_state = -1;
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     static const bool env_off = [] { const char* v = getenv("TSQ_PACKED_KEYS"); return v && v[0] == '0'; }();
-    if (env_off || j->packing_mode == TSQ_RADIX_OFF || j->multi || j->never_match) return TSQ_OK;
+    if (env_off || j->packing_mode == TSQ_RADIX_OFF || (j->multi && !da_multi_ok(j)) || j->never_match) return TSQ_OK;
     const int kc = j->ks.bidx[0];
     const int32_t bt = j->cfg.build_types[kc], pt = j->cfg.probe_types[j->ks.pidx[0]];
     if (!is_int_class(bt) || !is_int_class(pt)) return TSQ_OK;
@@ -1155,14 +1274,18 @@ tsq_status da_prepare(tsq_join* j) {
     const bool force = j->packing_mode == TSQ_RADIX_FORCE;
     static const int64_t min_build = [] { const char* v = getenv("TSQ_DA_MIN_BUILD_ROWS"); return v ? atoll(v) : (int64_t)(4 << 20); }();  // (experiment knob)
     if (!force && nb < min_build) return TSQ_OK;
+    if (j->multi) {  // several key columns: one composite column, unsigned, ~0 = cannot match
+        bool ok = false;
+        TSQ_TRY(da_compose_build(j, &ok));
+        if (!ok) { j->da_ckey.release(); return TSQ_OK; }
+        j->da_multi = true;
+    }
     // ---- key range of the build side
     DaMinMaxArgs ma;
     memset(&ma, 0, sizeof ma);
-    ma.src.data = j->bcols[kc].data.as<uint64_t>();
-    ma.src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
-    ma.src.nrows = nb;
-    ma.flip = (bt == TSQ_I64 && pt == TSQ_I64) ? 0x8000000000000000ULL : 0ULL;  // mixed signedness: only cells < 2^63 are usable, both orders agree
-    ma.skip_high = j->ks.skip_high;
+    da_build_key(j, ma.src);
+    ma.flip = (!j->da_multi && bt == TSQ_I64 && pt == TSQ_I64) ? 0x8000000000000000ULL : 0ULL;  // mixed signedness: only cells < 2^63 are usable, both orders agree
+    ma.skip_high = j->da_multi ? 1 : j->ks.skip_high;
     ma.out = (unsigned long long*)(ctx->dscratch + 48);
     ctx->pinned[48] = ~0ULL;
     ctx->pinned[49] = 0;
@@ -1198,7 +1321,7 @@ tsq_status da_prepare(tsq_join* j) {
     j->da_dm.b = b;
     j->da_dm.s = (b + 1) / 2;
     j->da_dm.mask = (uint32_t)((1ULL << b) - 1);
-    j->da_dm.skip_high = j->ks.skip_high;
+    j->da_dm.skip_high = ma.skip_high;
     // ---- partition the build keys, assemble the images
     const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nb, 1024 * 16);
     if (g.nregions * g.cap >= 0xffffffffULL) return TSQ_OK;
@@ -1297,17 +1420,13 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     st.cap = g.cap;
     TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
     TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
-    DaSrc src;
-    memset(&src, 0, sizeof src);
-    const int kc = j->ks.pidx[0];
-    src.data = (const uint64_t*)pcs.data[kc];
-    src.nulls = pcs.nulls[kc];
-    src.nrows = nrows;
     hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
     for (int e = 0; e < 3; e++)
         if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    DaSrc src;
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src));
     TSQ_TRY(da_launch_partition(j, src, st));
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     DaProbeArgs pa;
@@ -1346,7 +1465,7 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
 // Eligible: inner / left outer / right outer join on ONE integer key with a packable build side (da_prepare), no outer filter,
 // no OtherConditions, no selected[], not ordered; any number and type of payload columns, NULLs anywhere.
 bool da_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
-    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->never_match || j->ordered) return false;
+    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || (j->multi && !da_multi_ok(j)) || j->never_match || j->ordered) return false;
     if (selected_dev || !j->conds_h.empty() || !j->filters_h.empty()) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
@@ -1396,10 +1515,7 @@ tsq_status da_prepare_rows(tsq_join* j) {
     st.ebits = j->da_ebits;
     st.cap = g.cap;
     DaSrc src;
-    memset(&src, 0, sizeof src);
-    src.data = j->bcols[kc].data.as<uint64_t>();
-    src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
-    src.nrows = nb;
+    da_build_key(j, src);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
@@ -1480,17 +1596,13 @@ tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nro
     TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
     TSQ_HIP(h, hipMemsetAsync(j->tkcnt.p, 0, n_pc * 8, ctx->stream));
     TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));  // [52] joined rows of the overflow list, [53] its output cursor
-    DaSrc src;
-    memset(&src, 0, sizeof src);
-    const int kc = j->ks.pidx[0];
-    src.data = (const uint64_t*)pcs.data[kc];
-    src.nulls = pcs.nulls[kc];
-    src.nrows = nrows;
     hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
     for (int e = 0; e < 3; e++)
         if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    DaSrc src;
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src));
     TSQ_TRY(da_launch_partition(j, src, st, true, outer));
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     // ---- sizing pass: output rows per partition, their exclusive scan
@@ -1576,7 +1688,7 @@ tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nro
 // Eligible: what da_emit takes, with every column on both sides an 8-byte type (BIGINT, BIGINT UNSIGNED, DOUBLE) and at most
 // TSQ_DA_MAXCOLS columns per side.  NULLs anywhere, inner and outer joins.
 bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
-    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->never_match || j->ordered) return false;
+    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || (j->multi && !da_multi_ok(j)) || j->never_match || j->ordered) return false;
     // OtherConditions of an INNER join are a filter over the joined rows (joiner.go:351-378: innerJoiner.tryToMatch filters the
     // joined chunk): evaluated on the output batch and compacted (da_post_conditions).  An outer join needs "did ANY match of this
     // outer row pass" — the direct route
@@ -1605,9 +1717,9 @@ tsq_status da_prepare_cols(tsq_join* j) {
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
     sa.n = (int64_t)((const uint32_t*)(ctx->pinned + 56))[0];  // the build rows that have a usable key
     if (sa.n > nb) return TSQ_OK;
-    int nsort = 0;  // every build column but the key (the emit kernel recovers the key from the word)
+    int nsort = 0;  // every build column but the key (the emit kernel recovers the key from the word; a composite key's columns travel)
     for (int c = 0; c < j->cfg.n_build_cols; c++) {
-        if (c == j->ks.bidx[0]) continue;
+        if (!j->da_multi && c == j->ks.bidx[0]) continue;
         TSQ_TRY(j->da_bsorted[c].reserve(ctx, h, (size_t)sa.n * 8 + 64));
         sa.col[nsort] = j->bcols[c].data.as<uint64_t>();
         sa.sorted[nsort] = j->da_bsorted[c].as<uint64_t>();
@@ -1777,7 +1889,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 4 + 64));
     TSQ_TRY(j->rovfidx.reserve(ctx, h, (size_t)nrows * 4 + 64));
     if (outer) TSQ_TRY(j->rmiss.reserve(ctx, h, (size_t)nrows * 4 + 64));
-    const int kc = j->ks.pidx[0], kb = j->ks.bidx[0];
+    const int kc = j->da_multi ? -1 : j->ks.pidx[0], kb = j->da_multi ? -1 : j->ks.bidx[0];  // (-1: a composite key, its columns are payload)
     int trav[TSQ_DA_MAXCOLS], ntrav = 0;  // the probe columns that travel: all but the key
     for (int c = 0; c < np; c++)
         if (c != kc) trav[ntrav++] = c;
@@ -1812,9 +1924,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));
     DaColSrc src;
     memset(&src, 0, sizeof src);
-    src.key.data = (const uint64_t*)pcs.data[kc];
-    src.key.nulls = pcs.nulls[kc];
-    src.key.nrows = nrows;
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src.key));
     src.n_cols = ntrav;
     src.any_nulls = any_nulls ? 1 : 0;
     for (int v = 0; v < ntrav; v++) {
@@ -1910,7 +2020,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
                 ea.out_pkey = od;
                 ea.out_pkey_nn = of;
             } else {
-                const int v = sc < kc ? sc : sc - 1;
+                const int v = (kc < 0 || sc < kc) ? sc : sc - 1;
                 ea.out_probe[v] = od;
                 ea.out_probe_nn[v] = of;
             }
@@ -1923,7 +2033,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
                 ea.out_bkey = od;
                 ea.out_bkey_nn = of;
             } else {
-                const int v = sc < kb ? sc : sc - 1;
+                const int v = (kb < 0 || sc < kb) ? sc : sc - 1;
                 ea.out_build[v] = od;
                 ea.out_build_nn[v] = of;
                 ea.bsorted[v] = j->da_bsorted[sc].as<uint64_t>();
@@ -1971,7 +2081,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     ea.row0 = (unsigned long long)exc_rows;
     ea.dm = j->da_dm;
     ea.n_probe = ntrav;
-    ea.n_build = nbc - 1;
+    ea.n_build = kb < 0 ? nbc : nbc - 1;
     const size_t lds = cells + (cells >> 5) * 4;
     {
         const void* fn = outer ? (j->da_unique ? (const void*)k_da_emit_cols<512, true, true> : (const void*)k_da_emit_cols<512, true, false>)
@@ -2356,6 +2466,10 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         TSQ_TRY(da_prepare(j));
         if (j->da_state == 1) return da_probe(j, pcs, nrows);
         return radix_probe(j, pcs, nrows);
+    }
+    if (da_multi_count_eligible(j, nrows, selected_dev)) {  // several integer key columns: the packed route or the direct one
+        TSQ_TRY(da_prepare(j));
+        if (j->da_state == 1) return da_probe(j, pcs, nrows);
     }
     if (da_cols_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
@@ -3187,6 +3301,8 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->rovf.release();
     j->tkcnt.release();
     j->da_img.release();
+    j->da_ckey.release();
+    j->rckey.release();
     for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
         j->da_bsorted[c].release();
