@@ -363,6 +363,7 @@ def main():
                         ("pcie_inclusive_1e7", lambda: extra_pcie(ctx, abi, _lib)),
                         ("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("wide_keys_31bit_unique_bit_cells", lambda: extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr)),
+                        ("two_key_columns_count", lambda: extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
                         ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
@@ -630,6 +631,63 @@ def extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
     return {"workload": "1e8 x 1e8 count(*), keys spread over 31 bits (16 k + 3), hit ratio 0.5: 4-byte entries against one-BIT cells in LDS", "ms_per_probe_pass": ms,
             "rows_per_s": npr / ms * 1e3, "frac": 24.0 * npr / ms / 1e6 / 8000.0, "verified": cnt.value == (steps + 2) * want, "packed_key_bits": int(st.packed_key_bits),
             "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "packed_images_ms": st.packed_build_ms, "steps": steps}
+
+
+def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3):
+    """The headline join on TWO key columns: (k div 10000, k mod 10000) on both sides — the same pairs match as in the one-column
+    join, every second probe row's second cell is pushed out of its field (a miss).  Packed route (the cells composed into one key
+    column per batch) against the direct route (64-bit tag of both cells, cells compared)."""
+    import numpy as np
+
+    lib = ctx.lib
+    hb, hp = np.empty(nb, dtype=np.int64), np.empty(npr, dtype=np.int64)
+    ctx.d2h(hb, bk)
+    ctx.d2h(hp, pk)
+    cols_h = [hb // 10000, hb % 10000, hp // 10000, hp % 10000 + 20000 * (np.arange(npr, dtype=np.int64) & 1)]
+    del hb, hp
+    want = int(npr - npr // 2)
+    dev = [ctx.alloc(len(c) * 8) for c in cols_h]
+    res = {}
+    try:
+        for d, c in zip(dev, cols_h):
+            ctx.h2d(d, np.ascontiguousarray(c))
+        del cols_h
+        for name, mode in (("packed", abi.RADIX_AUTO), ("direct", abi.RADIX_OFF)):
+            cfg = abi.JoinCfg()
+            cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 2, 2, 2
+            for i in range(2):
+                cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+                cfg.build_key_idx[i] = cfg.probe_key_idx[i] = i
+            h = C.c_void_p()
+            _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                _lib.check(lib.tsq_join_set_key_packing(h, mode), h)
+                t0 = time.perf_counter()
+                _lib.check(lib.tsq_join_build_push(h, (abi.Col * 2)(_dev_col(abi, dev[0], nb), _dev_col(abi, dev[1], nb)), 2, nb), h)
+                _lib.check(lib.tsq_join_build_finish(h), h)
+                ctx.sync()
+                build_ms = (time.perf_counter() - t0) * 1e3
+                _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+                pc = (abi.Col * 2)(_dev_col(abi, dev[2], npr), _dev_col(abi, dev[3], npr))
+                _lib.check(lib.tsq_join_probe_push(h, pc, 2, npr, None), h)
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(steps):
+                    _lib.check(lib.tsq_join_probe_push(h, pc, 2, npr, None), h)
+                ms = ctx.timer_stop_ms() / steps
+                cnt = C.c_int64(0)
+                _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+                res[name] = {"ms_per_probe_pass": ms, "rows_per_s": npr / ms * 1e3, "frac": 32.0 * npr / ms / 1e6 / 8000.0, "build_ms": build_ms,
+                             "verified": cnt.value == (steps + 1) * want, "route": st.probe_route, "packed_key_bits": int(st.packed_key_bits)}
+            finally:
+                lib.tsq_join_destroy(h)
+    finally:
+        for d in dev:
+            ctx.free(d)
+    res["workload"] = "1e8 x 1e8 count(*) on TWO BIGINT key columns (k div 10000, k mod 10000), hit ratio 0.5; frac prices 32 B per probe row (two key cells + one 16 B slot)"
+    return res
 
 
 def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3, nullable_left_outer=False):
