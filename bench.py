@@ -384,7 +384,9 @@ def main():
                      "agg_two_keys_50x20": ["k_agg_da_low<3,4096>"], "materialising": ["k_da_partition_cols<1024,8,false>", "k_da_emit_cols<512,false,true>"],
                      "materialising_nullable_left_outer": ["k_da_partition_cols<1024,8,true>", "k_da_emit_cols<512,true,true>"],
                      "build_warm": ["k_radix_partition<1024,8,4,0,true,true>", "k_radix_subpartition<1024,8>", "k_build_images_cnt<512,8>"],
-                     "wide_keys_64bit_route": ["k_lds_probe_count<1024,false,0>"]}
+                     "wide_keys_64bit_route": ["k_lds_probe_count<1024,false,0>"],
+                     "wide_keys_31bit_unique_bit_cells": ["k_da_build_bits<1024>", "k_da_probe_count<1024,uint32_t,BITS>"],
+                     "two_key_columns_count": ["k_da_compose", "k_probe_count<MULTI>"]}
             for key, names in which.items():
                 if key in out and "error" not in out[key]:
                     out[key]["traffic_KiB_per_launch"] = {n: tk[n] for n in names if n in tk}
