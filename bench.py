@@ -377,7 +377,7 @@ def main():
                 out[key] = {"error": str(e)[:200]}
 
         # PMC-derived HBM traffic of the extras' kernels (measured offline, committed under profiles/: per launch, KiB; FETCH_SIZE
-        # needs x2 for wide streaming reads on gfx950, WRITE_SIZE is uncalibrated — profiles/r03_bench_pmc.txt)
+        # needs x2 for wide streaming reads on gfx950, per-launch averages mix the shapes a kernel serves — profiles/r03_bench_pmc.txt)
         try:
             tk = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))["other_kernels_of_the_line_KiB"]
             which = {"c3_agg_1e9_1e6": ["k_daagg_partition<1024,8,1>", "k_agg_da<3,4096>"], "c3_agg_1e9_1e6_double": ["k_daagg_partition<1024,8,1>", "k_agg_da<3,4096>"],
