@@ -1306,7 +1306,8 @@ tsq_status da_prepare(tsq_join* j) {
     if (bits_mode && ((range >> TSQ_DA_MAX_BITS_UNIQ) != 0 || !j->count_only)) return TSQ_OK;
     uint32_t b = TSQ_DA_MIN_BITS;
     while ((range >> b) != 0) b++;
-    if (!force && (1ULL << b) > 32ULL * usable) return TSQ_OK;  // a sparse domain: the images would be mostly zeros
+    // a sparse domain: the images would be mostly zeros (byte cells: at most 32 B of image per build row; bit cells: the same 32 B)
+    if (!force && (1ULL << b) > (bits_mode ? 256ULL : 32ULL) * usable) return TSQ_OK;
     int pb = std::min<int>(TSQ_RADIX_MAX_BITS, (int)b - 10);
     if (const char* e = getenv("TSQ_DA_PB")) pb = atoi(e);
     const int max_ebits = bits_mode ? TSQ_DA_MAX_EBITS_UNIQ : TSQ_DA_MAX_EBITS;
