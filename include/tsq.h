@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSQ_ABI_VERSION 4
+#define TSQ_ABI_VERSION 5
 
 /* ---------------------------------------------------------------- status codes */
 typedef int32_t tsq_status;
@@ -718,6 +718,8 @@ typedef struct tsq_stats {
     int32_t probe_route;           /* route of the last probe batch: TSQ_ROUTE_* */
     int32_t packed_key_bits;       /* TSQ_ROUTE_PACKED: bits of the build side's key range (0 otherwise) */
     double  packed_build_ms;       /* kernels that made the packed-key images (once per build side) */
+    int64_t heap_bytes;            /* aggregate: bytes of var-len input cells the operator holds (largest column heap) */
+    int64_t heap_compactions;      /* aggregate: times a string heap was compacted to the strings the groups refer to */
 } tsq_stats;
 #define TSQ_ROUTE_DIRECT     0   /* k_probe_count / k_probe_emit on the table in HBM */
 #define TSQ_ROUTE_RADIX_L2   1   /* radix partition, table slices through the XCD's L2 */

@@ -128,7 +128,10 @@ def test_long_cells_take_the_wave_copy(ctx, orc):
     assert H.rows_equal_unordered(_run(ctx, cfg, chk, aggs), orc.hash_agg(cfg, chk, 4, 4))
 
 
-def test_device_resident_batches_of_odd_sizes(ctx, orc):
+@pytest.mark.parametrize("compact", [False, True])
+def test_device_resident_batches_of_odd_sizes(ctx, orc, compact, monkeypatch):
+    if compact:  # the string heaps are compacted after every push (test_string_heaps_are_compacted_between_batches)
+        monkeypatch.setenv("TSQ_AGG_HEAP_GC_BYTES", "1")
     # every push is one batch: the operator copies the cells into its own heap (the caller may free its columns right after
     # the push) and pads the heap to 8 rows between batches; pull on the device
     rng = np.random.default_rng(5)
@@ -183,3 +186,31 @@ def test_unsupported_string_plans_are_refused(ctx):
     cfg = H.agg_cfg([abi.BYTES], [], [(abi.AGG_SUM, 0, abi.BYTES)])
     h = C.c_void_p()
     assert ctx.lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)) == abi.ERR_UNSUPPORTED
+
+
+def test_string_heaps_are_compacted_between_batches(ctx, orc, monkeypatch):
+    """the operator keeps every pushed var-len cell until it is destroyed — unless the heap is compacted to the strings
+    the groups still refer to (group keys, FIRST_ROW / MAX / MIN values).  TSQ_AGG_HEAP_GC_BYTES (test knob) makes every batch
+    trigger it: the results must not change and the heap must stay as small as the groups' strings."""
+    rng = np.random.default_rng(77)
+    n = 120_000
+    k = _words(rng, n, 400)
+    v = H.random_column(rng, abi.I64, n, 0.1, lo=-1000, hi=1000)
+    s = _words(rng, n, 5000, lo=8, hi=40, null_frac=0.2)
+    k2 = Column(abi.I64, rng.integers(0, 3, n))
+    chk = Chunk([k, v, s, k2])
+    types = [abi.BYTES, abi.I64, abi.BYTES, abi.I64]
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_FIRSTROW, 3, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 1, abi.I64),
+            (abi.AGG_MAX, 2, abi.BYTES), (abi.AGG_MIN, 2, abi.BYTES), (abi.AGG_COUNT, 2, abi.BYTES)]
+    cfg = H.agg_cfg(types, [0, 3], aggs)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    plain_stats = []
+    assert H.rows_equal_unordered(_run(ctx, cfg, chk, aggs, chunk_rows=1 << 20, stats_out=plain_stats), want)
+    monkeypatch.setenv("TSQ_AGG_HEAP_GC_BYTES", "1")
+    monkeypatch.setenv("TSQ_AGG_BATCH_ROWS", "8192")  # 15 device batches, a compaction of both heaps after each
+    stats = []
+    got = _run(ctx, cfg, chk, aggs, chunk_rows=1000, pull_rows=777, stats_out=stats)
+    assert H.rows_equal_unordered(got, want)
+    assert stats[0].heap_compactions >= 20
+    # ~1200 groups x (a key of <= 27 bytes | two values of <= 40 bytes): far below the 2.5 MB / 2.4 MB the input columns hold
+    assert stats[0].heap_bytes < 200_000 < plain_stats[0].heap_bytes, (stats[0].heap_bytes, plain_stats[0].heap_bytes)

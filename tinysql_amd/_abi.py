@@ -5,7 +5,7 @@ Shared by the product binding (tinysql_amd._lib) and by the test-only oracle bin
 """
 import ctypes as C
 
-TSQ_ABI_VERSION = 4
+TSQ_ABI_VERSION = 5
 RADIX_AUTO, RADIX_OFF, RADIX_FORCE = -1, 0, 1
 AGGFAST_AUTO, AGGFAST_OFF, AGGFAST_FORCE = -1, 0, 1
 JIT_AUTO, JIT_OFF, JIT_FORCE = -1, 0, 1
@@ -145,6 +145,7 @@ class Stats(C.Structure):
         ("radix_bits", C.c_int32), ("build_partitioned", C.c_int32), ("build_handed_back_rows", C.c_int64),
         ("table_slice_bits", C.c_int32), ("build_slice_retries", C.c_int32),
         ("probe_route", C.c_int32), ("packed_key_bits", C.c_int32), ("packed_build_ms", C.c_double),
+        ("heap_bytes", C.c_int64), ("heap_compactions", C.c_int64),
     ]
 
 

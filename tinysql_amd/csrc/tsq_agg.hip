@@ -789,6 +789,51 @@ __global__ void __launch_bounds__(256) k_ref_copy(RefOutArgs a) {
     }
 }
 
+// ---- compaction of a string heap: the operator appends every pushed var-len cell to the column's heap, but only the
+// cells the group table REFERS to are needed afterwards — group keys, FIRST_ROW / MAX / MIN values.  Between two batches the
+// referenced strings are copied into a fresh heap and the references rewritten, so the heap grows with the groups, not with the
+// input (the reference keeps one copy per group: stringutil.Copy in its partial results).
+#define TSQ_HEAP_GC_MAXF 20
+struct HeapGcArgs {
+    const unsigned long long* tag;
+    uint64_t nslots;                          // cap + 2
+    int32_t n_fields;
+    unsigned long long* ref[TSQ_HEAP_GC_MAXF];  // the field's reference array (gkey[k] or acc[i]), rewritten in place
+    const uint8_t* seen[TSQ_HEAP_GC_MAXF];      // aggregate value: its seen[] flags; group key: nullptr
+    int32_t nullbit[TSQ_HEAP_GC_MAXF];          // group key k: bit k of gknull[s] says NULL; aggregate value: -1
+    const uint8_t* gknull;
+    const uint8_t* heap;
+    uint8_t* new_heap;
+    int64_t* offs;                            // [n_fields * nslots + 1]: lengths, then (scanned) new offsets
+};
+__device__ __forceinline__ bool heap_gc_live(const HeapGcArgs& a, int f, uint64_t s) {
+    if (a.tag[s] == TSQ_EMPTY_TAG) return false;
+    if (a.nullbit[f] >= 0) return !a.gknull || !((a.gknull[s] >> a.nullbit[f]) & 1u);
+    return a.seen[f][s] != 0 && a.ref[f][s] != TSQ_REF_NONE;
+}
+__global__ void __launch_bounds__(256) k_heap_gc_len(HeapGcArgs a) {
+    const uint64_t n = a.nslots * (uint64_t)a.n_fields;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const int f = (int)(i / a.nslots);
+        const uint64_t s = i % a.nslots;
+        a.offs[i] = heap_gc_live(a, f, s) ? (int64_t)ref_len(a.ref[f][s]) : 0;
+    }
+}
+__global__ void __launch_bounds__(256) k_heap_gc_move(HeapGcArgs a) {
+    const uint64_t n = a.nslots * (uint64_t)a.n_fields;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const int f = (int)(i / a.nslots);
+        const uint64_t s = i % a.nslots;
+        if (!heap_gc_live(a, f, s)) continue;
+        const unsigned long long r = a.ref[f][s];
+        const uint64_t len = ref_len(r), to = (uint64_t)a.offs[i];
+        const uint8_t* src = a.heap + ref_off(r);
+        uint8_t* dst = a.new_heap + to;
+        for (uint64_t b = 0; b < len; b++) dst[b] = src[b];
+        a.ref[f][s] = (to << TSQ_REF_LEN_BITS) | len;
+    }
+}
+
 // ====================================================================== host side
 struct AggTableBufs {
     DevBuf tag, gknull;
@@ -820,6 +865,8 @@ struct tsq_agg {
     // starts at a heap row that is a multiple of 8, so its null bitmap starts on a byte
     std::vector<ColStore> heap;
     bool has_str = false;
+    std::vector<int64_t> heap_gc_at;  // per var-len input column: compact its heap when it holds more bytes than this
+    int64_t heap_gcs = 0;
     uint32_t test_tag_bits = 0;  // TSQ_AGG_TAG_BITS (tests): truncated multi-key tags, so that distinct keys share a tag
     bool finished = false;
     int64_t in_rows = 0;
@@ -1454,6 +1501,88 @@ void colset_use_heap(const tsq_agg* a, tsq_colset& in, int c, int64_t row0) {
     in.type[c] = TSQ_BYTES;
 }
 
+// between two batches: a heap that has outgrown its mark keeps only the strings the group table refers to
+tsq_status agg_heap_gc(tsq_agg* a) {
+    if (!a->has_str) return TSQ_OK;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const char* gc_env = getenv("TSQ_AGG_HEAP_GC_BYTES");  // (test knob, read per call: a compaction after every batch)
+    const int64_t gc_min = gc_env ? atoll(gc_env) : (int64_t)(256 << 20);
+    if (a->heap_gc_at.empty()) a->heap_gc_at.assign(a->heap.size(), gc_min);
+    if (gc_env)
+        for (auto& m : a->heap_gc_at) m = std::min<int64_t>(m, gc_min);
+    for (size_t c = 0; c < a->heap.size(); c++) {
+        ColStore& hs = a->heap[c];
+        if (hs.type != TSQ_BYTES || hs.nbytes <= a->heap_gc_at[c]) continue;
+        HeapGcArgs ga;
+        memset(&ga, 0, sizeof ga);
+        AggTable t;
+        fill_agg_table(a, a->tb, t);
+        ga.tag = t.tag;
+        ga.nslots = t.cap + 2;
+        ga.gknull = t.gknull;
+        ga.heap = (const uint8_t*)hs.data.p;
+        for (int k = 0; k < a->plan.n_keys; k++)
+            if (a->cfg.group_key_type[k] == TSQ_BYTES && a->plan.key_col[k] == (int)c) {
+                ga.ref[ga.n_fields] = t.gkey[k];
+                ga.nullbit[ga.n_fields] = k;
+                ga.n_fields++;
+            }
+        for (int i = 0; i < a->plan.n_aggs; i++) {
+            const tsq_agg_func& f = a->plan.f[i];
+            if (f.arg_type != TSQ_BYTES || f.arg_col != (int)c) continue;
+            if (f.func != TSQ_AGG_FIRSTROW && f.func != TSQ_AGG_MAX && f.func != TSQ_AGG_MIN) continue;
+            ga.ref[ga.n_fields] = t.st[i].acc;
+            ga.seen[ga.n_fields] = t.st[i].seen;
+            ga.nullbit[ga.n_fields] = -1;
+            ga.n_fields++;
+        }
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        int64_t live = 0;
+        DevBuf nd, offs, scratch;
+        if (ga.n_fields > 0) {
+            const uint64_t n = ga.nslots * (uint64_t)ga.n_fields;
+            tsq_status s = offs.reserve(ctx, h, (n + 1) * 8 + 64);
+            if (s != TSQ_OK) return s;
+            ga.offs = offs.as<int64_t>();
+            hipLaunchKernelGGL(k_heap_gc_len, dim3(tsq_grid_for(ctx, (int64_t)n, 256)), dim3(256), 0, ctx->stream, ga);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { offs.release(); return tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e)); }
+            s = tsq_launch_scan64(ctx, h, ga.offs, (int64_t)n, scratch);  // exclusive, and offs[n] = the live bytes
+            if (s == TSQ_OK) {
+                e = hipMemcpyAsync(ctx->pinned + 43, ga.offs + n, 8, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e));
+            }
+            if (s == TSQ_OK) {
+                live = (int64_t)ctx->pinned[43];
+                s = nd.reserve(ctx, h, (size_t)live + 64);
+            }
+            if (s == TSQ_OK) {
+                ga.new_heap = nd.as<uint8_t>();
+                hipLaunchKernelGGL(k_heap_gc_move, dim3(tsq_grid_for(ctx, (int64_t)n, 256)), dim3(256), 0, ctx->stream, ga);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e));
+            }
+            offs.release();
+            scratch.release();
+            if (s != TSQ_OK) { nd.release(); return s; }
+            a->st.kernel_launches += 3;
+        }
+        // the compacted heap: the live strings, no rows (the next batch appends behind them, tsq_col_append_varlen)
+        if (ga.n_fields > 0) {
+            hs.data.release();
+            hs.data = nd;  // shallow move of the buffer handle
+        }
+        hs.nbytes = live;
+        hs.rows = 0;
+        a->heap_gc_at[c] = std::max<int64_t>(gc_min, 2 * live);
+        a->heap_gcs++;
+    }
+    return TSQ_OK;
+}
+
 tsq_status agg_flush(tsq_agg* a) {
     HostStage& sg = a->stage;
     if (sg.staged == 0) return TSQ_OK;
@@ -1485,7 +1614,7 @@ tsq_status agg_flush(tsq_agg* a) {
     sg.reset();
     if (s != TSQ_OK) return s;
     if (e != hipSuccess) return tsq_fail(&a->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-    return TSQ_OK;
+    return agg_heap_gc(a);
 }
 
 }  // namespace
@@ -1675,7 +1804,7 @@ TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols,
             TSQ_TRY(agg_batch(a, s, n));
             a->in_rows += n;
         }
-        return TSQ_OK;
+        return agg_heap_gc(a);
     }
     if (a->stage.cap == 0) {
         int64_t batch = 4 << 20;  // host chunks are aggregated in device batches of this many rows (test knob: TSQ_AGG_BATCH_ROWS)
@@ -1927,6 +2056,10 @@ TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
     a->st.radix_batches = a->fast_batches;
     a->st.radix_overflow_rows = a->fast_fallbacks;
     a->st.packed_key_bits = a->packed_batches > 0 ? (int32_t)a->da_dm.b : 0;
+    a->st.heap_bytes = 0;
+    for (const ColStore& hs : a->heap)
+        if (hs.type == TSQ_BYTES) a->st.heap_bytes = std::max<int64_t>(a->st.heap_bytes, hs.nbytes);
+    a->st.heap_compactions = a->heap_gcs;
     *out = a->st;
     return TSQ_OK;
 }

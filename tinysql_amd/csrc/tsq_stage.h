@@ -79,7 +79,14 @@ inline tsq_status tsq_col_append_varlen(tsq_ctx* ctx, tsq_handle_hdr* h, ColStor
     TSQ_TRY(cs.data.reserve(ctx, h, (size_t)(cs.nbytes + bytes) + 64, true, (size_t)cs.nbytes));
     if (bytes) TSQ_HIP(h, hipMemcpyAsync((char*)cs.data.p + cs.nbytes, (const char*)data + o0, (size_t)bytes, src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     TSQ_TRY(cs.offs.reserve(ctx, h, (size_t)(cs.rows + n + 1) * 8 + 64, true, (size_t)(cs.rows + 1) * 8));
-    if (cs.rows == 0) TSQ_HIP(h, hipMemsetAsync(cs.offs.p, 0, 8, ctx->stream));
+    if (cs.rows == 0) {  // offsets[0] = the bytes already there (0 for a fresh column; the live strings of a compacted aggregate heap)
+        if (cs.nbytes == 0) TSQ_HIP(h, hipMemsetAsync(cs.offs.p, 0, 8, ctx->stream));
+        else {
+            ctx->pinned[42] = (uint64_t)cs.nbytes;
+            TSQ_HIP(h, hipMemcpyAsync(cs.offs.p, ctx->pinned + 42, 8, hipMemcpyHostToDevice, ctx->stream));
+            TSQ_HIP(h, hipStreamSynchronize(ctx->stream));  // (the pinned word is reused)
+        }
+    }
     const int64_t* src = offsets;
     if (!src_dev) {
         TSQ_TRY(tmp_offs.reserve(ctx, h, (size_t)(n + 1) * 8 + 64));
