@@ -343,7 +343,7 @@ tsq_status tsq_join_set_radix(tsq_join* j, int32_t mode);
  * byte per value of the range, one 64 KB image per partition in LDS — equality of entries IS equality of keys
  * (util/codec/codec.go:363-382), a probe key outside the range joins nothing.  A build side WITHOUT duplicate keys may span up to
  * 31 bits for a COUNT(*) probe: one BIT per value (4-byte entries).  Materialising probes of inner / outer joins (8-byte columns,
- * OtherConditions of inner joins included) take the same entries with the probe columns travelling next to them (<= 27 bits).
+ * OtherConditions of inner joins — and of outer joins over a build side without duplicate keys — included) take the same entries with the probe columns travelling next to them (<= 27 bits).
  * Several integer key columns (<= 4, fields adding up to <= 28 bits) are composed into one key column first and take the same routes.
  * OFF keeps 64-bit table words; FORCE drops the
  * size and density conditions (tests).  Must be chosen before the first probe batch.  The joined rows are identical either way.

@@ -445,3 +445,29 @@ def test_packed_several_key_columns_mixed_signedness_and_too_wide(ctx, orc):
     stats = []
     got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, radix=FORCE, packing=FORCE, stats_out=stats)
     assert got == orc.hash_join(cfg, build, probe).NumRows() and stats[0].probe_route == abi.ROUTE_DIRECT
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("unique", [True, False])
+def test_packed_travelling_columns_outer_join_conditions(ctx, orc, jt, inner, unique):
+    # leftOuterJoiner / rightOuterJoiner with OtherConditions (joiner.go:220-344): an outer row whose candidates all fail the
+    # conditions is padded with NULLs.  With a UNIQUE build side there is one candidate at most: the packed route materialises the
+    # batch and un-matches the failed rows (k_outer_unmatch); with duplicates the direct route keeps the join
+    rng = np.random.default_rng(23 + jt + unique)
+    nb = 4000
+    bk = rng.permutation(6000)[:nb] - 1000 if unique else rng.integers(-900, 1000, nb)
+    bside = Chunk([Column(abi.I64, bk, None if unique else rng.random(nb) > 0.03), Column(abi.F64, rng.random(nb), rng.random(nb) > 0.1),
+                   Column(abi.I64, rng.integers(0, 100, nb))])
+    n = 50_001
+    pside = Chunk([Column(abi.I64, rng.integers(-1200, 5200, n), rng.random(n) > 0.03), Column(abi.F64, rng.random(n), rng.random(n) > 0.2),
+                   Column(abi.I64, rng.integers(0, 100, n))])
+    left, right = (pside, bside) if inner == 1 else (bside, pside)
+    nl = 3
+    conds = [E.ScalarFunction("lt", E.Column(1, abi.F64), E.Column(nl + 1, abi.F64)), E.ScalarFunction("ne", E.Column(2, abi.I64), E.Column(nl + 2, abi.I64))]
+    keep = []
+    cfg = H.join_cfg(left.types(), right.types(), [0], [0], jt, inner, conds, (), keep)
+    want = orc.hash_join(cfg, bside, pside)
+    got = _rows(ctx, cfg, bside, pside, want_route=abi.ROUTE_PACKED if unique else abi.ROUTE_DIRECT)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    if unique:
+        assert got.NumRows() == n

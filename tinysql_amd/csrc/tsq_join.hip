@@ -1692,8 +1692,9 @@ bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || (j->multi && !da_multi_ok(j)) || j->never_match || j->ordered) return false;
     // OtherConditions of an INNER join are a filter over the joined rows (joiner.go:351-378: innerJoiner.tryToMatch filters the
     // joined chunk): evaluated on the output batch and compacted (da_post_conditions).  An outer join needs "did ANY match of this
-    // outer row pass" — the direct route
-    if (selected_dev || !j->filters_h.empty() || (!j->conds_h.empty() && j->cfg.join_type != TSQ_JOIN_INNER)) return false;
+    // outer row pass" — taken here only when no build key repeats (da_unique, known once the images exist: probe_batch checks): an outer row then has
+    // at most one candidate, and a candidate that fails the conditions turns into the NULL-padded row (onMissMatch, joiner.go:274-281)
+    if (selected_dev || !j->filters_h.empty()) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0 || j->da_cols_state < 0) return false;
     if (j->cfg.n_probe_cols > TSQ_DA_MAXCOLS || j->cfg.n_build_cols > TSQ_DA_MAXCOLS) return false;
     for (int c = 0; c < j->cfg.n_probe_cols; c++)
@@ -1778,6 +1779,22 @@ __global__ void __launch_bounds__(256) k_post_conds(PostCondArgs a) {
     }
     if (errw != TSQ_ERRWORD_NONE) atomicMin(a.err, (unsigned long long)errw);
 }
+// outer join, unique build side: a joined row whose conditions failed becomes the NULL-padded row — the build side's cells go NULL
+struct OuterUnmatchArgs {
+    const uint8_t* keep;
+    int64_t n;
+    int32_t n_cols;
+    uint8_t* bitmap[TSQ_MAX_COLS];  // the build side's output columns
+};
+__global__ void __launch_bounds__(256) k_outer_unmatch(OuterUnmatchArgs a) {
+    const int64_t nbytes = (a.n + 7) >> 3;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nbytes; b += (int64_t)gridDim.x * 256) {
+        uint32_t m = 0;
+        for (int k = 0; k < 8 && b * 8 + k < a.n; k++) m |= a.keep[b * 8 + k] ? (1u << k) : 0u;
+        if (m == 0xffu) continue;
+        for (int c = 0; c < a.n_cols; c++) a.bitmap[c][b] &= (uint8_t)m;
+    }
+}
 // filters the batch in place (new, dense column buffers).  *redo: a condition raised an error — which error the reference reports
 // depends on the probe row order, so the batch is dropped and the caller runs it through the direct route.
 tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bool>& may_null_v, bool* redo) {
@@ -1831,6 +1848,25 @@ tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bo
     if (ctx->pinned[56] != TSQ_ERRWORD_NONE) {
         keep.release();
         *redo = true;
+        return TSQ_OK;
+    }
+    if (j->cfg.join_type != TSQ_JOIN_INNER) {  // every outer row keeps its one output row; a failed candidate is un-matched
+        OuterUnmatchArgs ua;
+        memset(&ua, 0, sizeof ua);
+        ua.keep = keep.as<uint8_t>();
+        ua.n = n;
+        for (int oc = 0; oc < nout; oc++) {
+            const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
+            if (from_probe) continue;
+            if (!may_null_v[oc]) { keep.release(); return tsq_fail(h, TSQ_ERR_HIP, "internal: outer join output column without a bitmap"); }
+            ua.bitmap[ua.n_cols++] = rb.bitmap[oc].as<uint8_t>();
+        }
+        hipLaunchKernelGGL(k_outer_unmatch, dim3(tsq_grid_for(ctx, (n + 7) / 8, 256)), dim3(256), 0, ctx->stream, ua);
+        hipError_t e3 = hipGetLastError();
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
+        keep.release();
+        if (e3 != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("outer join conditions: ") + hipGetErrorString(e3));
+        j->st.kernel_launches++;
         return TSQ_OK;
     }
     std::vector<DevBuf> nd((size_t)nout), nbm((size_t)nout);
@@ -2474,9 +2510,13 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     }
     if (da_cols_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
-        TSQ_TRY(da_prepare_rows(j));
-        TSQ_TRY(da_prepare_cols(j));
-        if (j->da_cols_state == 1) {
+        // conditions of an OUTER join: only with a unique build side (one candidate per outer row, see da_cols_eligible)
+        const bool usable = j->conds_h.empty() || j->cfg.join_type == TSQ_JOIN_INNER || j->da_unique;
+        if (usable) {
+            TSQ_TRY(da_prepare_rows(j));
+            TSQ_TRY(da_prepare_cols(j));
+        }
+        if (usable && j->da_cols_state == 1) {
             bool redo = false;
             TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo));
             if (!redo) return TSQ_OK;
