@@ -12,6 +12,7 @@
 #include "../../tinysql_amd/csrc/tsq_device.h"
 #include "../../tinysql_amd/csrc/tsq_comm_plan.h"
 #include "../../tinysql_amd/csrc/tsq_arena.h"
+#include "../../tinysql_amd/csrc/tsq_dapack.h"
 
 namespace {
 
@@ -304,6 +305,70 @@ int32_t sim_arena(uint64_t slab, int32_t steps, uint64_t seed) {
     }
     for (const auto& b : live) a.put(b.first, b.second);
     if (a.used != 0 || a.free_.size() != 1 || a.free_.begin()->first != 0 || a.free_.begin()->second != slab) return 6;
+    return 0;
+}
+
+// the arithmetic of packed keys (tsq_dapack.h).  b <= exhaustive_bits: every d in [0, 2^b) — mix stays inside the range, unmix
+// inverts it (so mix is a bijection); larger b: `samples` random d.  0 = held for every b in [13, 31].
+int32_t sim_da_mix(int32_t exhaustive_bits, int64_t samples, uint64_t seed) {
+    uint64_t s = seed;
+    for (uint32_t b = 13; b <= 31; b++) {
+        const uint32_t mask = (uint32_t)((1ull << b) - 1), sh = (b + 1) / 2;
+        if ((int32_t)b <= exhaustive_bits) {
+            for (uint32_t d = 0; d <= mask; d++) {
+                const uint32_t u = tsq_da_mix(d, sh, mask);
+                if (u > mask) return (int32_t)b;
+                if (tsq_da_unmix(u, sh, mask) != d) return 100 + (int32_t)b;
+            }
+        } else {
+            for (int64_t i = 0; i < samples; i++) {
+                const uint32_t d = (uint32_t)rnd(s) & mask;
+                const uint32_t u = tsq_da_mix(d, sh, mask);
+                if (u > mask) return (int32_t)b;
+                if (tsq_da_unmix(u, sh, mask) != d) return 100 + (int32_t)b;
+                if (tsq_da_mix(tsq_da_unmix(d, sh, mask), sh, mask) != d) return 200 + (int32_t)b;  // (and the other way round: onto)
+            }
+        }
+    }
+    return 0;
+}
+// composite keys: n_keys columns with random fields; rows drawn inside and slightly outside the fields.  Two rows must get the same
+// composite exactly when every cell is inside its field and all cells are equal; a row with a cell outside gets ~0.
+int32_t sim_da_compose(int32_t n_keys, int32_t rows, uint64_t seed) {
+    uint64_t s = seed;
+    DaFields f;
+    memset(&f, 0, sizeof f);
+    f.n = n_keys;
+    uint32_t total = 0;
+    for (int k = 0; k < n_keys; k++) {
+        const uint32_t w = 1 + (uint32_t)(rnd(s) % 6);
+        f.kmin[k] = rnd(s) % 3 == 0 ? (uint64_t)(-(int64_t)(rnd(s) % 1000)) : rnd(s) % 100000;  // (a negative BIGINT minimum wraps: exact)
+        f.maxd[k] = (1ull << w) - 1 - rnd(s) % 2;
+        f.shift[k] = total;
+        f.skip_high[k] = 0;
+        total += w;
+    }
+    std::vector<std::vector<uint64_t>> cells((size_t)rows, std::vector<uint64_t>((size_t)n_keys));
+    std::vector<uint64_t> comp((size_t)rows);
+    std::vector<char> inside((size_t)rows);
+    for (int r = 0; r < rows; r++) {
+        bool in = true;
+        for (int k = 0; k < n_keys; k++) {
+            const int64_t off = (int64_t)(rnd(s) % (f.maxd[k] + 4)) - 1;  // -1 .. maxd + 2
+            cells[(size_t)r][(size_t)k] = f.kmin[k] + (uint64_t)off;
+            in = in && off >= 0 && (uint64_t)off <= f.maxd[k];
+        }
+        inside[(size_t)r] = in;
+        comp[(size_t)r] = tsq_da_compose_cells(f, cells[(size_t)r].data());
+        if (in == (comp[(size_t)r] == ~0ull)) return 1;
+        if (in && (comp[(size_t)r] >> total)) return 2;  // the composite fits the fields' bits
+    }
+    for (int a = 0; a < rows; a++)
+        for (int b = a + 1; b < rows; b++) {
+            if (!inside[(size_t)a] || !inside[(size_t)b]) continue;
+            const bool same_cells = cells[(size_t)a] == cells[(size_t)b];
+            if (same_cells != (comp[(size_t)a] == comp[(size_t)b])) return 3;
+        }
     return 0;
 }
 
