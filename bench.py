@@ -290,7 +290,7 @@ def main():
         "build_ms": build_wall_ms,
         "arena": {"reserved_gb": args.arena_gb, "reserve_s": t_arena,
                   "note": "build_ms is the FIRST build of the process; its buffers come out of the arena reserved at start-up "
-                          "(tsq_ctx_reserve) — with --arena-gb 0 the same build pays ~35 ms per GB of first hipMalloc (310 ms, profiles/r03_bench.json)"},
+                          "(tsq_ctx_reserve) — with --arena-gb 0 the same build pays ~35 ms per GB of first hipMalloc (310 ms before the arena existed, DESIGN.md §5)"},
         "build_kernel_ms": st.build_kernel_ms,
         "build_strategy": "partitioned: 2 radix passes + LDS slice images" if st.build_partitioned else "row-at-a-time CAS",
         "table_bytes": st.table_bytes,
