@@ -1094,6 +1094,20 @@ tsq_status launch_agg_da(tsq_agg* a, DaAggLdsArgs& la, int grid) {
         a->st.kernel_launches++;
         return TSQ_OK;
     }
+    {   // the two commonest plans: update descriptors as compile-time constants (tsq_daagg.h, SIG)
+        const uint32_t* wd = la.plan.wdesc;
+        static const bool sig_on = [] { const char* v = getenv("TSQ_DAAGG_SIG"); return !(v && v[0] == '0'); }();
+        int sig = 0;
+        if (sig_on && la.plan.W == 3 && wd[0] == af_wdesc(AF_W_ADD_LO32, 0, TSQ_I64) && wd[1] == af_wdesc(AF_W_ADD_HI32, 0, TSQ_I64) && wd[2] == af_wdesc(AF_W_ADD1, 0, 0)) sig = 1;
+        if (sig_on && la.plan.W == 2 && wd[0] == af_wdesc(AF_W_ADD_REAL, 0, TSQ_F64) && wd[1] == af_wdesc(AF_W_ADD1, 0, 0)) sig = 2;
+        if (sig) {
+            if (sig == 1) hipLaunchKernelGGL((k_agg_da<3, 4096, 1>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la);
+            else hipLaunchKernelGGL((k_agg_da<2, 4096, 2>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la);
+            TSQ_HIP(&a->hdr, hipGetLastError());
+            a->st.kernel_launches++;
+            return TSQ_OK;
+        }
+    }
     switch (la.plan.W) {  // W <= 3: 4096 cells per partition (96 KB of LDS words), else 2048
         case 1: hipLaunchKernelGGL((k_agg_da<1, 4096>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;
         case 2: hipLaunchKernelGGL((k_agg_da<2, 4096>), dim3(grid), dim3(TSQ_AF_NT), 0, st, la); break;

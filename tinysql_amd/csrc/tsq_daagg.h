@@ -301,10 +301,24 @@ struct DaAggLdsArgs {
     uint32_t nsplit;  // workgroups per partition (1, 2, 4 or 8: each takes every nsplit-th XCC region)
 };
 // what one row does to the accumulators of cell e
-template <int W, int CELLS>
+// SIG: the two commonest plans with their update descriptors known at compile time — 1: SUM(BIGINT cell 0) + COUNT(*) (words lo32,
+// hi32, count), 2: SUM(DOUBLE cell 0) + COUNT(*) — instead of a wave-uniform switch per word and row (scalar compares and
+// branches: k_agg_da<3,4096> issued as many scalar as vector instructions, profiles/r03_bench_sq.txt); 0: any plan.
+template <int W, int CELLS, int SIG = 0>
 __device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1) {
     // (a plain LDS read first: after its first row a cell's bit is set, and a returning-or-not LDS atomic costs more than a read)
     if (!((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
+    if (SIG == 1 && W == 3) {
+        atomicAdd(&s_w[0][e], (unsigned long long)(c0 & 0xffffffffull));
+        if ((long long)c0 >> 32) atomicAdd(&s_w[1][e], (unsigned long long)((long long)c0 >> 32));
+        atomicAdd(&s_w[W - 1][e], 1ull);
+        return;
+    }
+    if (SIG == 2 && W == 2) {
+        atomicAdd(reinterpret_cast<double*>(&s_w[0][e]), tsq_bits_f64(c0));
+        atomicAdd(&s_w[W - 1][e], 1ull);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < W; k++) {
         const uint32_t d = wd[k];
@@ -366,7 +380,7 @@ __device__ __forceinline__ void daagg_emit_cells(const AfPlan& plan, const AfPar
         }
     }
 }
-template <int W, int CELLS>
+template <int W, int CELLS, int SIG = 0>
 __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
     constexpr int U = 4;
     uint32_t wd[W];
@@ -406,7 +420,7 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
                 }
 #pragma unroll
                 for (int x = 0; x < U; x++)
-                    if (i0 + (uint32_t)x * TSQ_AF_NT < len) daagg_apply<W, CELLS>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
+                    if (i0 + (uint32_t)x * TSQ_AF_NT < len) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
             }
         }
         __syncthreads();
