@@ -167,6 +167,15 @@ public:
     tsq_ctx* h = nullptr;
     explicit Context(int device = 0) { check(tsq_ctx_create(device, &h), nullptr); }
     ~Context() { if (h) tsq_ctx_destroy(h); }
+    // one slab of HBM for the buffers of every operator of this context, reserved when the process starts (tsq_ctx_reserve):
+    // the first query does not pay hipMalloc (the Go process keeps its heap across queries the same way)
+    void Reserve(int64_t bytes) { check(tsq_ctx_reserve(h, bytes), h); }
+    struct Arena { int64_t size, used, peak; };
+    Arena ArenaStats() const {
+        Arena a{0, 0, 0};
+        check(tsq_ctx_arena_stats(h, &a.size, &a.used, &a.peak), h);
+        return a;
+    }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
 };

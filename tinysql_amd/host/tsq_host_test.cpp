@@ -85,6 +85,7 @@ static Chunk table_mixed(const Schema& types, std::initializer_list<const char*>
 int main() {
     if (tsq_device_count() <= 0) { printf("no HIP device: the host executors have no CPU fallback\n"); return 2; }
     Context ctx(0);
+    ctx.Reserve(512ll << 20);  // what the host process does once at start-up: every operator below works out of this slab
 
     // ---- executor/join_test.go:134-160: t = (1,1),(2,2),(3,3); t1 = (1,2),(1,3),(1,4),(3,4),(4,5)
     {
@@ -484,6 +485,10 @@ int main() {
         dec.ReuseIntermChk(rest);
         expect_true("codec.go:291-308 ReuseIntermChk", dec.IsFinished() && rest.NumRows() == 2 && rest.columns[2].offsets[0] == 0);
         expect("Decoder: the two parts are the rows", render({part, rest}), want);
+    }
+    {   // every executor above is closed: its buffers went back to the slab they came from
+        const Context::Arena a = ctx.ArenaStats();
+        expect_true("tsq_ctx_reserve: the operators worked out of the arena and gave everything back", a.size == (512ll << 20) && a.peak > 0 && a.used == 0);
     }
     printf("%d passed, %d failed\n", g_pass, g_fail);
     return g_fail ? 1 : 0;
