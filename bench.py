@@ -49,10 +49,16 @@ def main():
     ap.add_argument("--cpu-build-rows", type=int, default=20_000_000)
     ap.add_argument("--cpu-probe-rows", type=int, default=40_000_000)
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path even with one rank (validation)")
+    ap.add_argument("--emulate-world", type=int, default=0, help="with --force-dist on ONE GPU: generate rank 0's share of a W-rank weak-scaling job "
+                    "(keys drawn from the W x build-rows global domain), so the per-rank probe step of an N = W run is measured without W GPUs")
+    ap.add_argument("--dist-plan", choices=["auto", "exchange"], default="auto", help="N>1: auto = shared packed images when the build side is packable "
+                    "(no probe row crosses xGMI), else the hash-radix exchange; exchange = always redistribute both sides by rank(key)")
     ap.add_argument("--radix", choices=["auto", "off", "force"], default="auto", help="probe strategy (tsq_join_set_radix)")
     ap.add_argument("--packing", choices=["auto", "off"], default="auto", help="key packing of the radix probe (tsq_join_set_key_packing)")
     ap.add_argument("--arena-gb", type=float, default=64.0, help="tsq_ctx_reserve: HBM reserved for the context's operators at start-up, before any "
                     "query runs (0: none — every first allocation of a size is a hipMalloc, ~35 ms per GB)")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="tsq_ctx_set_knob before anything runs (A/B measurements), e.g. DA_PARTITION=2")
+    ap.add_argument("--only-extras", default="", help="comma-separated keys of the side measurements to run (default: all)")
     ap.add_argument("--no-extras", action="store_true", help="skip the c2 / c3 / materialising side measurements (N = 1)")
     args = ap.parse_args()
 
@@ -70,6 +76,9 @@ def main():
     # no torch in this process, every call in the timed region is a C-ABI call a Go host could make.
     ctx = _lib.Context(local_rank)
     lib = ctx.lib
+    for kv in args.knob:
+        name, val = kv.split("=")
+        ctx.set_knob(getattr(abi, "KNOB_" + name), int(val))
     t_arena = time.time()
     if args.arena_gb > 0:  # what a host process does once, when it creates its context (untimed set-up, like the table generation)
         try:
@@ -87,6 +96,9 @@ def main():
     if args.rows_global > 0:  # the whole join is fixed, every rank starts with 1 / world of both sides (rows are multiples of 64)
         nb = npr = max(64, (args.rows_global // world) & ~63)
     nb_global = nb * world
+    emu = args.emulate_world if (args.emulate_world > 1 and world == 1 and distributed) else 0
+    if emu:  # rank 0 of an emu-rank job: its 1 / emu of the build side (keys all over the GLOBAL domain), its own probe rows
+        nb_global = nb * emu
     t_setup = time.time()
 
     def spec(kind, **kw):
@@ -124,13 +136,15 @@ def main():
     radix_mode = {"auto": abi.RADIX_AUTO, "off": abi.RADIX_OFF, "force": abi.RADIX_FORCE}[args.radix]
     dj = None
     if distributed:
-        dj = parallel.DistHashJoinCount(comm, cfg)
-        h = dj.h
-        _lib.check(lib.tsq_join_set_radix(h, radix_mode), h)
+        dj = parallel.DistHashJoinCount(comm, cfg, radix_mode=radix_mode, packing_mode=abi.RADIX_OFF if args.packing == "off" else None,
+                                        shared=args.dist_plan == "auto" and args.packing != "off")
         t0 = time.time()
-        nb_local = dj.build([dev_col(bk, nb), dev_col(bv, nb)], 0, nb)  # redistribute by rank(key), then the local build
+        # shared images: local rows pushed, the packed images summed across the ranks (ONE all-reduce per build side);
+        # exchange plan: redistribute by rank(key), then the local build
+        nb_local = dj.build([dev_col(bk, nb), dev_col(bv, nb)], 0, nb)
         ctx.sync()
         build_wall_ms = (time.time() - t0) * 1e3
+        h = dj.h
         pcols1 = [dev_col(pk, npr)]
 
         def step():
@@ -186,7 +200,7 @@ def main():
 
     # N>1: one extra, untimed pass of the split + exchange alone (no probe), for SURVEY.md §8(d)'s t_exchange
     exchange_ms = None
-    if distributed:
+    if distributed and not dj.shared:
         try:
             full_sync()
             te = time.perf_counter()
@@ -205,6 +219,16 @@ def main():
         total = cnt.value
     # build keys are a bijection of [0, nb_global), every probe key lies in [0, nb_global): each probe row joins once
     expect = (args.steps + args.warmup) * npr * world
+    if emu:
+        # rank 0 alone holds build keys {(a i + b) mod M : i < nb}; a probe key k joins iff ((k - b) a^-1 mod M) < nb — numpy, on a host
+        # copy of the probe keys (nothing of libtsq's join code computes it)
+        import numpy as np
+        host = np.empty(npr, dtype=np.int64)
+        ctx.d2h(host, pk)
+        ainv = pow(a_mult, -1, nb_global)
+        idx = ((host - 12345) % nb_global).astype(np.uint64) * np.uint64(ainv) % np.uint64(nb_global)
+        expect = (args.steps + args.warmup) * int(np.count_nonzero(idx < np.uint64(nb)))
+        del host, idx
     ok = total == expect
     st = abi.Stats()
     _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
@@ -254,10 +278,10 @@ def main():
         if packed:
             wide = st.packed_key_bits - st.radix_bits > 16
             kernel_name = "k_da_probe_count<1024,uint32_t>" if wide else "k_da_probe_count<512,uint16_t>"
-            part_name = "k_da_partition<1024,16,uint32_t>" if wide else ("k_da_partition<1024,16,uint16_t>" if os.environ.get("TSQ_DA_PART2", "1") == "0" else ("k_da_partition2<512,8,4>" if os.environ.get("TSQ_DA_NT", "1") == "0" else "k_da_partition2<512,8,4,true>"))
+            part_name = "k_da_partition<1024,16,uint32_t>" if wide else "k_da_partition2<512,8,4,true>"
             part_bytes_per_key = 8.0 + (4.0 if wide else 2.0)  # 8 B key read + one packed entry written
         else:
-            kernel_name = "k_lds_probe_count<1024>" if st.table_slice_bits >= 3 and os.environ.get("TSQ_RADIX_KERNEL", "") != "l2" else "k_radix_probe_count<2>"
+            kernel_name = "k_lds_probe_count<1024>" if st.table_slice_bits >= 3 else "k_radix_probe_count<2>"
         kernel_ms = st.radix_probe_kernel_ms_sum / st.radix_timed_batches
         part_ms = st.partition_kernel_ms_sum / st.radix_timed_batches
     else:
@@ -267,6 +291,7 @@ def main():
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
     out = {
+        "knobs": args.knob or None,
         "metric": "probed rows/sec on int64-key inner hash join",
         "value": rows_per_s,
         "unit": "rows/s",
@@ -283,7 +308,9 @@ def main():
             "workload": "SELECT count(*) FROM probe JOIN build ON k: %.0e x %.0e int64-key inner hash join per GPU, "
                         "J-uniq-shuffled, hit ratio 1.0, build side resident in HBM" % (npr, nb),
             "probe_rows_per_gpu": npr, "build_rows_per_gpu": nb,
-            "parallelism": "hash-radix x%d, RCCL send/recv all-to-all inside libtsq (tsq_redistribute)" % world if distributed else "single GPU",
+            "parallelism": ("single GPU" if not distributed else
+                            ("shared packed images x%d: every rank probes its own rows, the images are all-reduced once per build side (tsq_join_build_finish_shared)" % world
+                             if dj.shared else "hash-radix x%d, RCCL send/recv all-to-all inside libtsq (tsq_redistribute)" % world)),
         },
         "verified": bool(ok),
         "joined_rows": total,
@@ -296,6 +323,20 @@ def main():
         "table_bytes": st.table_bytes,
         "setup_s": setup_s,
     }
+    if distributed:
+        # what the plan puts on xGMI: per probe row in the timed step, and once per build side
+        out["dist_plan"] = "shared_images" if dj.shared else "hash_radix_exchange"
+        if emu:
+            out["emulated_world"] = emu
+            out["emulation_note"] = ("ONE GPU playing rank 0 of a %d-rank weak-scaling job: %d of the %d global build keys, images over the global %d-bit range; "
+                                     "ms_per_step is the per-rank step of that job (the shared-images plan has no wire traffic in the step), so the "
+                                     "projected aggregate is %d x value" % (emu, nb, nb_global, st.packed_key_bits, emu))
+            out["projected_aggregate_rows_per_s"] = emu * rows_per_s if dj.shared else None
+        out["wire_bytes_per_probe_row"] = 0.0 if dj.shared else 8.0 * (world - 1) / world
+        if dj.shared:
+            out["shared_images"] = {"image_bytes": st.shared_image_bytes, "allreduce_ms": st.shared_allreduce_ms,
+                                    "wire_bytes_per_rank_once_per_build": 2.0 * st.shared_image_bytes * (world - 1) / world,
+                                    "cells": "bit" if st.packed_key_bits > 28 else "byte", "key_range_bits": st.packed_key_bits}
     if exchange_ms is not None:
         out["split_and_exchange_ms"] = exchange_ms  # tsq_redistribute of one step's probe keys (split + RCCL exchange), without the probes
     if packed:
@@ -375,6 +416,8 @@ def main():
                         ("agg_two_keys_50x20", lambda: extra_two_keys(ctx, abi, _lib, ma=50, mb=20)),
                         ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
                         ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True))):
+            if args.only_extras and key not in args.only_extras.split(","):
+                continue
             try:
                 out[key] = fn()
             except Exception as e:  # reporting only

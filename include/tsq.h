@@ -94,6 +94,37 @@ void       tsq_ctx_destroy(tsq_ctx* ctx);
  * falls through to hipMalloc.  bytes = 0 gives the arena back; not allowed
  * while operators hold buffers of it.  tsq_ctx_arena_stats: slab size, bytes in use, high-water mark. */
 tsq_status tsq_ctx_reserve(tsq_ctx* ctx, int64_t bytes);
+/* TEST AND MEASUREMENT KNOBS.  A host never calls this: every knob defaults to what the library was measured and tested
+ * with.  The parity tests use them to force the rarely taken variants (a heap compaction after every batch, truncated group
+ * tags, the un-pipelined row decoder ...), tools/ and bench.py to A/B kernel variants on one box.  They replace the
+ * environment variables earlier rounds read inside the product code.  value = TSQ_KNOB_DEFAULT restores the default.
+ * A knob is read when the operator takes the decision it steers (usually at its first batch). */
+#define TSQ_KNOB_DEFAULT INT64_MIN
+enum {
+    TSQ_KNOB_PACKED_KEYS = 0,        /* 0: no packed-key routes (join and aggregate) */
+    TSQ_KNOB_DA_MIN_BUILD_ROWS = 1,  /* build rows from which AUTO tries the packed routes (default 4 Mi) */
+    TSQ_KNOB_DA_PBITS = 2,           /* log2(partitions) of the packed routes (default: min(11, b - 10)) */
+    TSQ_KNOB_PACKED_EMIT_PAIRS = 3,  /* 1: AUTO may take the pairs variant of the materialising packed route (K4d) */
+    TSQ_KNOB_RADIX_KERNEL_L2 = 4,    /* 1: the 64-bit radix probe keeps round 1's L2 route */
+    TSQ_KNOB_LDS_NF_MAX = 5,         /* cap on the table slices per LDS image (forces S > 1 on small tables) */
+    TSQ_KNOB_RADIX_PB_MAX = 6,       /* cap on log2(partitions) of the 64-bit radix probe */
+    TSQ_KNOB_TABLE_LF_PERMILLE = 7,  /* load factor of a sliced join table, in 1/1000 (default 750) */
+    TSQ_KNOB_LDS_PROF = 8,           /* 1: per-phase shader cycles of the LDS probe on stderr (synchronises) */
+    TSQ_KNOB_DA_TRACE = 9,           /* 1: host time points of the travelling-columns route on stderr */
+    TSQ_KNOB_BUILD_IMAGES_CAS = 10,  /* 1: the first (compare-and-swap) slice-image kernel of the partitioned build */
+    TSQ_KNOB_DAAGG_SIG = 11,         /* 0: no plan-specialised instantiations of k_agg_da */
+    TSQ_KNOB_DAAGG_LOG2C = 12,       /* log2(cells per LDS table) of the packed aggregate, 9..12 */
+    TSQ_KNOB_AGG_HEAP_GC_BYTES = 13, /* string-heap size from which the aggregate compacts between batches (default 256 MiB) */
+    TSQ_KNOB_AGG_TAG_BITS = 14,      /* truncate the 64-bit group tag of a several-column GROUP BY (collision tests) */
+    TSQ_KNOB_AGG_BATCH_ROWS = 15,    /* device batch of host-pushed aggregate input (default 4 Mi rows) */
+    TSQ_KNOB_ROWCODEC_LDS_KB = 16,   /* LDS tile of the stored-row decoder */
+    TSQ_KNOB_ROWCODEC_FAST_LAYOUT = 17, /* 0: every wave takes the per-row column search */
+    TSQ_KNOB_ROWCODEC_PIPELINE = 18, /* 0: the un-pipelined decoder kernel */
+    TSQ_KNOB_DA_PARTITION = 19,      /* packed partition kernel: 0 = default per entry width, 1 = one 1024-thread workgroup per CU, 2 = two of 512 */
+    TSQ_KNOB_DA_NT_LOADS = 20,       /* 0: plain instead of non-temporal key loads in k_da_partition2 */
+    TSQ_KNOB_COUNT = 48
+};
+tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
 tsq_status tsq_ctx_arena_stats(tsq_ctx* ctx, int64_t* size_out, int64_t* used_out, int64_t* peak_out);
 
 /* Device memory + copies for harnesses that keep tables resident in HBM (bench, multi-GPU). */
@@ -299,6 +330,22 @@ tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_join** out
  * Rows whose key has a NULL are kept for outer-join output but never inserted (:161-163). */
 tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t n_cols, int64_t nrows);
 tsq_status tsq_join_build_finish(tsq_join* j);
+/* The build side of a COUNT(*) join SHARDED over the GPUs of a node, without moving a single probe row.
+ * COLLECTIVE: every rank of `comm` pushes ITS build rows (tsq_join_build_push) and then calls this instead of
+ * tsq_join_build_finish.  The ranks agree on the key range of the whole build side (two 8-byte all-reduces), every rank
+ * assembles the packed direct-address images (csrc/tsq_dajoin.h) of its rows over that range, and the images are summed across
+ * the ranks with ONE all-reduce (2^b bytes, or 2^b / 8 for a build side without duplicate keys: 128 MiB for 8e8 keys).  Every
+ * rank then holds the images of the WHOLE build side: tsq_join_probe_push takes the rank's OWN probe rows, tsq_join_count the
+ * rank's joined rows (the plan adds them up, tsq_comm_allreduce_i64) — the probe phase puts nothing on xGMI and scales with the
+ * number of GPUs.  Replaces the N join workers probing ONE shared, read-only hashRowContainer (executor/join.go:233-239,
+ * hash_table.go:110-134): the images are that container, replicated because HBM is not shared between GPUs.
+ * *shared_out = 1: done — the handle is count-only.  *shared_out = 0 (the same on every rank): the build side is not packable
+ * (outer join / conditions / several or non-integer key columns, a key range beyond 31 bits or too sparse, more than 255 build
+ * rows per key, duplicate keys in a range beyond 28 bits) — nothing was built, the handle still holds the pushed rows
+ * (tsq_join_build_finish makes it a LOCAL join); a distributed plan destroys it and redistributes both sides by rank(key)
+ * (tsq_redistribute), as tinysql_amd/parallel.py does. */
+typedef struct tsq_comm tsq_comm;
+tsq_status tsq_join_build_finish_shared(tsq_join* j, tsq_comm* comm, int32_t* shared_out);
 /* Probe side: one call per outer-child chunk (join2Chunk, join.go:325). `selected` (optional,
  * one byte per row) is an externally evaluated outer-side filter; rows with selected==0 or a
  * NULL key go to onMissMatch (join.go:344-345). */
@@ -668,7 +715,6 @@ tsq_status tsq_radix_split(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, in
  * c + 1 hides behind the operator kernels of c.
  * The all-reduces take up to 8 host words (op 0 sum, 1 max, 2 min) and synchronise both streams: they are the barrier + the
  * COUNT(*) / timing reductions a distributed plan needs. */
-typedef struct tsq_comm tsq_comm;
 #define TSQ_COMM_ID_BYTES 128
 tsq_status tsq_comm_unique_id(uint8_t* id_out /* [TSQ_COMM_ID_BYTES] */);
 tsq_status tsq_comm_create(tsq_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id, tsq_comm** out);
@@ -720,6 +766,13 @@ typedef struct tsq_stats {
     double  packed_build_ms;       /* kernels that made the packed-key images (once per build side) */
     int64_t heap_bytes;            /* aggregate: bytes of var-len input cells the operator holds (largest column heap) */
     int64_t heap_compactions;      /* aggregate: times a string heap was compacted to the strings the groups refer to */
+    int32_t shared_build;          /* join: 1 = tsq_join_build_finish_shared replicated the packed images (probe rows never cross xGMI) */
+    int32_t reserved0;
+    int64_t shared_image_bytes;    /* ... bytes of the images every rank all-reduced, once per build side */
+    double  shared_allreduce_ms;   /* ... wall time of that all-reduce on this rank */
+    int64_t div_by_zero_warnings;  /* join: division-by-zero warnings the OtherConditions / outer filters raised so far (NULL result + warning,
+                                      expression/errors.go:65-77): the shim appends that many ErrDivisionByZero warnings to the statement context
+                                      (handleDivisionByZeroError via executor/joiner.go:155-167) */
 } tsq_stats;
 #define TSQ_ROUTE_DIRECT     0   /* k_probe_count / k_probe_emit on the table in HBM */
 #define TSQ_ROUTE_RADIX_L2   1   /* radix partition, table slices through the XCD's L2 */

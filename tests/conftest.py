@@ -27,3 +27,11 @@ def ctx():
     c = _lib.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _knobs_back_to_default(request):
+    """a test may turn the context's test knobs (tsq_ctx_set_knob); the session-wide context gets its defaults back afterwards"""
+    yield
+    if "ctx" in request.fixturenames:
+        request.getfixturevalue("ctx").reset_knobs()

@@ -125,6 +125,56 @@ def main():
             want = orc.hash_join(cfg, Chunk([Column(abi.I64, ubk), Column(abi.I64, ubv)]), Chunk([Column(abi.I64, upk), Column(abi.I64, upv)])).NumRows()
             assert total == 3 * want, (total, want)
             lap("oracle join")
+            # ---- the SHARED-IMAGES plan (tsq_join_build_finish_shared): the packed images of the whole build side are summed across the
+            # ranks once, every rank probes its OWN rows — no probe row is exchanged.  Route asserted, count vs the oracle's whole join.
+            def shared_case(bkeys_of, pkeys_of, expect_shared, what, expect_bits=None):
+                allb = [bkeys_of(r) for r in range(world)]
+                allp = [pkeys_of(r) for r in range(world)]
+                js = parallel.DistHashJoinCount(comm, cfg, packing_mode=abi.RADIX_FORCE)
+                try:
+                    mb, mp = allb[rank], allp[rank]
+                    js.build([dev(ctx, mb, keep), dev(ctx, mb * 2, keep)], 0, len(mb))
+                    assert js.shared == expect_shared, (what, js.shared)
+                    js.probe([dev(ctx, mp, keep), dev(ctx, mp + 1, keep)], 0, len(mp), n_pieces=2)
+                    js.probe([dev(ctx, mp, keep), dev(ctx, mp + 1, keep)], 0, len(mp), n_pieces=1)
+                    tot = js.count()
+                    stt = js.stats()
+                finally:
+                    js.close()
+                ub, up = np.concatenate(allb), np.concatenate(allp)
+                want_s = orc.hash_join(cfg, Chunk([Column(abi.I64, ub), Column(abi.I64, ub * 2)]), Chunk([Column(abi.I64, up), Column(abi.I64, up + 1)])).NumRows()
+                assert tot == 2 * want_s, (what, tot, want_s)
+                if expect_shared:
+                    assert stt.shared_build == 1 and stt.probe_route == abi.ROUTE_PACKED and stt.shared_image_bytes > 0, (what, stt.shared_build, stt.probe_route)
+                    assert js.wire_bytes_probe == 0
+                    if expect_bits is not None:
+                        assert (stt.packed_key_bits > 28) == expect_bits, (what, stt.packed_key_bits)
+                else:
+                    assert stt.shared_build == 0
+                return want_s
+            g = lambda seed: np.random.default_rng(seed)  # noqa: E731
+            # byte cells: duplicate keys inside a rank and across ranks (cells add up), negative keys, probe keys outside the range
+            w1 = shared_case(lambda r: g(8100 + r).integers(-30_000, 40_000, 120_000 + 999 * r).astype(np.int64),
+                             lambda r: g(8200 + r).integers(-50_000, 60_000, 300_000 + 77 * r).astype(np.int64), True, "byte cells", expect_bits=False)
+            assert w1 > 0
+            # bit cells: a UNIQUE build side over the ranks whose keys span 30 bits (rank r owns the keys = r mod world)
+            uniq = lambda r: (g(8300).permutation(1 << 20)[:200_000].astype(np.int64) * world + r) * (1 << 9) + 5  # noqa: E731
+            w2 = shared_case(uniq, lambda r: np.concatenate([uniq((r + 1) % world)[:150_000], g(8400 + r).integers(0, 1 << 30, 100_000).astype(np.int64)]), True,
+                             "bit cells", expect_bits=True)
+            assert w2 >= 150_000 * world
+            # a key with more than 255 build rows over the ranks TOGETHER (each rank alone stays below): the summed byte wraps, every rank
+            # notices in the population of the sum and all of them take the exchange plan
+            hot = 300 // world + 1
+            shared_case(lambda r: np.concatenate([np.full(hot, 777, np.int64), g(8500 + r).integers(0, 50_000, 100_000).astype(np.int64)]),
+                        lambda r: g(8600 + r).integers(0, 50_000, 200_000).astype(np.int64), False, "a cell beyond 255")
+            if world > 1:
+                # a key present on two ranks of a wide (bit-cell) range: a carry in the summed words -> the exchange plan, on every rank
+                shared_case(lambda r: uniq(r) if r == 0 else np.concatenate([uniq(r), uniq(0)[:1]]),
+                            lambda r: uniq(r)[:1000], False, "a key on two ranks, bit cells")
+                # a rank without build rows takes part in every collective
+                shared_case(lambda r: g(8700 + r).integers(0, 40_000, 0 if r == 0 else 90_000).astype(np.int64),
+                            lambda r: g(8800 + r).integers(0, 40_000, 100_000).astype(np.int64), True, "a rank without build rows")
+            lap("shared images")
             # ---- distributed GROUP BY k: SUM(v), COUNT(*), MIN(v) vs the oracle
             paggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_SUM, 1, abi.I64, abi.MODE_PARTIAL1),
                      (abi.AGG_COUNT, -1, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_MIN, 1, abi.I64, abi.MODE_PARTIAL1)]

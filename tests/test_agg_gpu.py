@@ -294,17 +294,10 @@ def test_multi_key_tag_collisions_are_resolved_not_reported(ctx, orc, bits):
     aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_FIRSTROW, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 2, abi.I64), (abi.AGG_MAX, 2, abi.I64)]
     cfg = H.agg_cfg(types, [0, 1], aggs)
     want = orc.hash_agg(cfg, chk, 4, 4)
-    old = os.environ.get("TSQ_AGG_TAG_BITS")
-    os.environ["TSQ_AGG_TAG_BITS"] = str(bits)
-    try:
+    with ctx.knobs(AGG_TAG_BITS=bits):
         stats = []
         got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 22, stats_out=stats)
         got2 = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=7000)  # many batches: later rows meet earlier groups
-    finally:
-        if old is None:
-            os.environ.pop("TSQ_AGG_TAG_BITS", None)
-        else:
-            os.environ["TSQ_AGG_TAG_BITS"] = old
     assert stats[0].build_handed_back_rows > n // 2  # most rows really went the long way
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
     assert H.rows_equal_unordered(got2, want)

@@ -74,7 +74,7 @@ def test_packed_agg_unsigned_keys_above_2_63(ctx, orc):
 
 
 def test_packed_agg_hot_key_and_later_batches_outside_the_range(ctx, orc, monkeypatch):
-    monkeypatch.setenv("TSQ_AGG_BATCH_ROWS", str(1 << 17))
+    ctx.set_knob(abi.KNOB_AGG_BATCH_ROWS, 1 << 17)
     # batch 1 (device batches of 2^17 rows): keys in [0, 30000) with one key carrying 40 % of
     # the rows (its partition's region overflows: those rows take the row-at-a-time upsert); batch 2 brings keys far outside the range
     # the first batch showed (exception rows); batch 3 is mostly outside (the operator leaves the packed route)
@@ -193,7 +193,7 @@ def test_packed_agg_several_key_columns_vs_oracle(ctx, orc, spec, which):
 
 
 def test_packed_agg_several_key_columns_later_batches_outside_the_fields(ctx, orc, monkeypatch):
-    monkeypatch.setenv("TSQ_AGG_BATCH_ROWS", str(1 << 16))
+    ctx.set_knob(abi.KNOB_AGG_BATCH_ROWS, 1 << 16)
     # batch 1 shows (a in [0, 100), b in [0, 8)) without NULLs in b; batch 2 brings b = NULL (no code: exception rows), a few a
     # outside its field and a = NULL; batch 3 is mostly outside (the operator leaves the packed route for the row upsert)
     rng = np.random.default_rng(12)
@@ -223,7 +223,7 @@ def test_packed_agg_several_key_columns_later_batches_outside_the_fields(ctx, or
 def test_packed_agg_several_key_columns_with_shared_tags(ctx, orc, monkeypatch):
     # TSQ_AGG_TAG_BITS (tests): 2^9 tags for ~3000 groups — distinct keys share a tag, the merge of the packed partial groups
     # compares cells and walks on (k_agg_merge_multi phase 1), as the row upsert does
-    monkeypatch.setenv("TSQ_AGG_TAG_BITS", "9")
+    ctx.set_knob(abi.KNOB_AGG_TAG_BITS, 9)
     rng = np.random.default_rng(13)
     chk, types, nk = _mk_chunk(rng, 90_000, [(abi.I64, 0, 400, 0.02), (abi.I64, -4, 4, 0.02)])
     st = _mk_check(ctx, orc, chk, types, nk, _mk_aggs(nk, types, "sum_count"))

@@ -131,7 +131,7 @@ def test_long_cells_take_the_wave_copy(ctx, orc):
 @pytest.mark.parametrize("compact", [False, True])
 def test_device_resident_batches_of_odd_sizes(ctx, orc, compact, monkeypatch):
     if compact:  # the string heaps are compacted after every push (test_string_heaps_are_compacted_between_batches)
-        monkeypatch.setenv("TSQ_AGG_HEAP_GC_BYTES", "1")
+        ctx.set_knob(abi.KNOB_AGG_HEAP_GC_BYTES, 1)
     # every push is one batch: the operator copies the cells into its own heap (the caller may free its columns right after
     # the push) and pads the heap to 8 rows between batches; pull on the device
     rng = np.random.default_rng(5)
@@ -190,7 +190,7 @@ def test_unsupported_string_plans_are_refused(ctx):
 
 def test_string_heaps_are_compacted_between_batches(ctx, orc, monkeypatch):
     """the operator keeps every pushed var-len cell until it is destroyed — unless the heap is compacted to the strings
-    the groups still refer to (group keys, FIRST_ROW / MAX / MIN values).  TSQ_AGG_HEAP_GC_BYTES (test knob) makes every batch
+    the groups still refer to (group keys, FIRST_ROW / MAX / MIN values).  KNOB_AGG_HEAP_GC_BYTES (tsq_ctx_set_knob) makes every batch
     trigger it: the results must not change and the heap must stay as small as the groups' strings."""
     rng = np.random.default_rng(77)
     n = 120_000
@@ -206,8 +206,8 @@ def test_string_heaps_are_compacted_between_batches(ctx, orc, monkeypatch):
     want = orc.hash_agg(cfg, chk, 4, 4)
     plain_stats = []
     assert H.rows_equal_unordered(_run(ctx, cfg, chk, aggs, chunk_rows=1 << 20, stats_out=plain_stats), want)
-    monkeypatch.setenv("TSQ_AGG_HEAP_GC_BYTES", "1")
-    monkeypatch.setenv("TSQ_AGG_BATCH_ROWS", "8192")  # 15 device batches, a compaction of both heaps after each
+    ctx.set_knob(abi.KNOB_AGG_HEAP_GC_BYTES, 1)
+    ctx.set_knob(abi.KNOB_AGG_BATCH_ROWS, 8192)  # 15 device batches, a compaction of both heaps after each
     stats = []
     got = _run(ctx, cfg, chk, aggs, chunk_rows=1000, pull_rows=777, stats_out=stats)
     assert H.rows_equal_unordered(got, want)

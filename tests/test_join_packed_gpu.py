@@ -471,3 +471,45 @@ def test_packed_travelling_columns_outer_join_conditions(ctx, orc, jt, inner, un
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
     if unique:
         assert got.NumRows() == n
+
+
+# ------------------------------------------------------------------ hot probe keys through BOTH partition kernels, at the tile shapes that differ
+# k_da_partition2 instantiated for 4-byte entries failed the bit-cell test with a hot probe key at the end of round 3 and was
+# reverted without an explanation.  These cases run both kernels (TSQ_KNOB_DA_PARTITION: 1 = one 1024-thread workgroup per CU, 2 = two of 512)
+# over every entry width (2-byte entries; 4-byte entries of a 28-bit byte-cell range; 4-byte entries of bit cells) at the tile shapes whose code
+# paths differ: exactly one full tile, a partial last tile, a NULL bitmap (no tile takes the 16-byte-load path), and more tiles than workgroups
+# with the hot key in the FIRST tiles only (the workgroup's overflow flag is sticky across its tiles).
+T_TILE = 16384
+
+
+def _hot_case(rng, span_bits, n, nulls, hot_first_only):
+    span = (1 << span_bits) - 3
+    bk = np.unique(np.concatenate([rng.integers(0, span, 50_000), np.array([0, span - 1])])) + 1000
+    rng.shuffle(bk)
+    pk = np.where(rng.random(n) < 0.5, bk[rng.integers(0, len(bk), n)], 1000 + rng.integers(-span // 8, span + span // 8, n))
+    hot = slice(0, min(n, 40 * T_TILE)) if hot_first_only else slice(0, n)
+    sel = np.zeros(n, bool)
+    sel[hot] = rng.random(len(pk[hot])) < 0.6
+    pk[sel] = bk[7]
+    pnn = rng.random(n) > 0.02 if nulls else None
+    want = int(np.isin(pk if pnn is None else pk[pnn], bk).sum())
+    return bk, pk, pnn, want
+
+
+@pytest.mark.parametrize("variant", [1, 2], ids=["one_wg_per_cu", "two_wg_per_cu"])
+@pytest.mark.parametrize("span_bits", [20, 28, 30], ids=["u16_entries", "u32_byte_cells", "u32_bit_cells"])
+@pytest.mark.parametrize("shape", ["one_full_tile", "partial_last_tile", "null_bitmap", "sticky_overflow_flag"])
+def test_packed_hot_probe_key_both_partition_kernels(ctx, variant, span_bits, shape):
+    rng = np.random.default_rng(span_bits * 10 + variant)
+    n = {"one_full_tile": T_TILE, "partial_last_tile": 3 * T_TILE + 1, "null_bitmap": 5 * T_TILE + 100, "sticky_overflow_flag": 600 * T_TILE + 77}[shape]
+    bk, pk, pnn, want = _hot_case(rng, span_bits, n, shape == "null_bitmap", shape == "sticky_overflow_flag")
+    build, probe = _tables(bk, pk, None, pnn)
+    cfg = _cfg()
+    cfg.probe_batch_rows = 1 << 24  # ONE device batch: 600 tiles for at most 512 workgroups in the last shape
+    with ctx.knobs(DA_PARTITION=variant):
+        stats = []
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 24, count_only=True, radix=FORCE, packing=FORCE, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_PACKED and stats[0].packed_key_bits == span_bits
+    assert got == want, (got, want, stats[0].radix_overflow_rows)
+    if shape != "one_full_tile":
+        assert stats[0].radix_overflow_rows > 0

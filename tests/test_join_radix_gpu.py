@@ -198,24 +198,9 @@ def test_radix_forced_leaves_every_other_probe_kernel_exact(ctx, orc, jt, inner)
 
 
 # ---------------------------------------------------------------- LDS probe (tsq_ldsprobe.h) on sliced tables
-def _env(**kw):
-    import contextlib
-    import os
-
-    @contextlib.contextmanager
-    def cm():
-        old = {k: os.environ.get(k) for k in kw}
-        try:
-            for k, v in kw.items():
-                os.environ[k] = str(v)
-            yield
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
-    return cm()
+def _env(ctx, **kw):
+    """the knobs of tsq_ctx_set_knob (include/tsq.h) for the duration of a with-block"""
+    return ctx.knobs(**kw)
 
 
 def _sliced_inputs(seed, nb, npr):
@@ -234,8 +219,8 @@ def _sliced_inputs(seed, nb, npr):
     return build, probe
 
 
-@pytest.mark.parametrize("knobs", [{}, {"TSQ_LDS_NF_MAX": 1}, {"TSQ_LDS_NF_MAX": 3, "TSQ_RADIX_PB_MAX": 4}, {"TSQ_LDS_NF_MAX": 2, "TSQ_RADIX_PB_MAX": 3},
-                                   {"TSQ_RADIX_KERNEL": "l2"}, {"TSQ_TABLE_LF": 0.5}, {"TSQ_TABLE_LF": 0.65}],
+@pytest.mark.parametrize("knobs", [{}, {"LDS_NF_MAX": 1}, {"LDS_NF_MAX": 3, "RADIX_PB_MAX": 4}, {"LDS_NF_MAX": 2, "RADIX_PB_MAX": 3},
+                                   {"RADIX_KERNEL_L2": 1}, {"TABLE_LF_PERMILLE": 500}, {"TABLE_LF_PERMILLE": 650}],
                          ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()) or "default")
 def test_lds_probe_on_a_sliced_table_vs_oracle(ctx, orc, knobs):
     # 300 K build rows -> partitioned build, ~100 table slices; the knobs force several images per partition (S > 1, a last
@@ -243,7 +228,7 @@ def test_lds_probe_on_a_sliced_table_vs_oracle(ctx, orc, knobs):
     build, probe = _sliced_inputs(23, 300_000, 1_200_000)
     cfg = _cfg()
     want = orc.hash_join(cfg, build, probe).NumRows()
-    with _env(**knobs):
+    with _env(ctx, **knobs):
         stats = []
         assert _count(ctx, cfg, build, probe, abi.RADIX_FORCE, stats=stats) == want
         st = stats[0]
@@ -336,7 +321,7 @@ def _emit_inputs(seed, nb, npr, kt=abi.I64, n_pay_b=1, n_pay_p=1, pay_t=abi.I64,
 
 
 @pytest.mark.parametrize("shape", [dict(), dict(n_pay_b=2, n_pay_p=2, key_pos=1), dict(n_pay_b=0, n_pay_p=1), dict(n_pay_b=1, n_pay_p=0), dict(kt=abi.U64, pay_t=abi.F64, key_pos=2),
-                                   dict(knobs={"TSQ_LDS_NF_MAX": 1}), dict(knobs={"TSQ_LDS_NF_MAX": 3, "TSQ_RADIX_PB_MAX": 4}, n_pay_b=2)],
+                                   dict(knobs={"LDS_NF_MAX": 1}), dict(knobs={"LDS_NF_MAX": 3, "RADIX_PB_MAX": 4}, n_pay_b=2)],
                          ids=lambda s: ",".join("%s=%s" % kv for kv in s.items()) or "k,v x k,v")
 def test_materialising_radix_join_vs_oracle(ctx, orc, shape):
     shape = dict(shape)
@@ -344,7 +329,7 @@ def test_materialising_radix_join_vs_oracle(ctx, orc, shape):
     build, probe, bkc, pkc = _emit_inputs(41, 250_000, 900_000, **shape)
     cfg = H.join_cfg(probe.types(), build.types(), [pkc], [bkc], abi.JOIN_INNER, 1)
     want = orc.hash_join(cfg, build, probe)
-    with _env(**knobs):
+    with _env(ctx, **knobs):
         got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, radix=abi.RADIX_FORCE)
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
     off = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, radix=abi.RADIX_OFF)

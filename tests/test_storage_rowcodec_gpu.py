@@ -93,11 +93,8 @@ def test_random_scans_against_the_oracle(ctx, orc, n):
     assert st == 0
     _same(_decoder(ctx).DecodeToChunk(b, o, handles), want)
     if n in (257, 100_000):  # the plain kernel as well
-        os.environ["TSQ_ROWCODEC_PIPELINE"] = "0"
-        try:
+        with ctx.knobs(ROWCODEC_PIPELINE=0):
             _same(_decoder(ctx).DecodeToChunk(b, o, handles), want)
-        finally:
-            del os.environ["TSQ_ROWCODEC_PIPELINE"]
 
 
 def test_large_ids_and_rows_wider_than_the_lds_tile(ctx, orc):
@@ -308,12 +305,9 @@ U_SPECS = [(200, abi.F64), (-1, abi.I64, abi.RC_HANDLE), (9, abi.I64), (3, abi.I
 
 def _both_kernel_paths(ctx, b, o, handles, specs, want_st, want):
     n = len(o) - 1
-    for knob, pipe in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):  # TSQ_ROWCODEC_PIPELINE=0: the plain (not software-pipelined) kernel
-        os.environ["TSQ_ROWCODEC_FAST_LAYOUT"], os.environ["TSQ_ROWCODEC_PIPELINE"] = knob, pipe
-        try:
+    for knob, pipe in ((1, 1), (0, 1), (1, 0), (0, 0)):  # ROWCODEC_PIPELINE = 0: the plain (not software-pipelined) kernel
+        with ctx.knobs(ROWCODEC_FAST_LAYOUT=knob, ROWCODEC_PIPELINE=pipe):
             gst, m, got = _decode_device(ctx, b, o, handles, specs, n)
-        finally:
-            del os.environ["TSQ_ROWCODEC_FAST_LAYOUT"], os.environ["TSQ_ROWCODEC_PIPELINE"]
         assert (gst == abi.OK) == (want_st == 0) and m == want.NumRows(), (knob, pipe)
         if want_st:
             assert _lib.last_error(ctx.h) == MSG[want_st]

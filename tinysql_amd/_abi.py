@@ -146,6 +146,8 @@ class Stats(C.Structure):
         ("table_slice_bits", C.c_int32), ("build_slice_retries", C.c_int32),
         ("probe_route", C.c_int32), ("packed_key_bits", C.c_int32), ("packed_build_ms", C.c_double),
         ("heap_bytes", C.c_int64), ("heap_compactions", C.c_int64),
+        ("shared_build", C.c_int32), ("reserved0", C.c_int32), ("shared_image_bytes", C.c_int64), ("shared_allreduce_ms", C.c_double),
+        ("div_by_zero_warnings", C.c_int64),
     ]
 
 
@@ -153,6 +155,13 @@ ROUTE_DIRECT, ROUTE_RADIX_L2, ROUTE_RADIX_LDS, ROUTE_PACKED = 0, 1, 2, 3
 
 
 COMM_ID_BYTES = 128
+
+# tsq_ctx_set_knob (test / measurement knobs, include/tsq.h)
+KNOB_DEFAULT = -(1 << 63)
+(KNOB_PACKED_KEYS, KNOB_DA_MIN_BUILD_ROWS, KNOB_DA_PBITS, KNOB_PACKED_EMIT_PAIRS, KNOB_RADIX_KERNEL_L2, KNOB_LDS_NF_MAX, KNOB_RADIX_PB_MAX,
+ KNOB_TABLE_LF_PERMILLE, KNOB_LDS_PROF, KNOB_DA_TRACE, KNOB_BUILD_IMAGES_CAS, KNOB_DAAGG_SIG, KNOB_DAAGG_LOG2C, KNOB_AGG_HEAP_GC_BYTES,
+ KNOB_AGG_TAG_BITS, KNOB_AGG_BATCH_ROWS, KNOB_ROWCODEC_LDS_KB, KNOB_ROWCODEC_FAST_LAYOUT, KNOB_ROWCODEC_PIPELINE, KNOB_DA_PARTITION,
+ KNOB_DA_NT_LOADS) = range(21)
 
 
 # every symbol include/tsq.h declares: name -> (restype, argtypes)
@@ -167,6 +176,7 @@ SIGNATURES = {
     "tsq_ctx_sync": (C.c_int32, [P]),
     "tsq_ctx_destroy": (None, [P]),
     "tsq_ctx_reserve": (C.c_int32, [P, C.c_int64]),
+    "tsq_ctx_set_knob": (C.c_int32, [P, C.c_int32, C.c_int64]),
     "tsq_ctx_arena_stats": (C.c_int32, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tsq_dev_alloc": (C.c_int32, [P, C.c_int64, PP]),
     "tsq_dev_free": (C.c_int32, [P, P]),
@@ -185,6 +195,7 @@ SIGNATURES = {
     "tsq_expr_destroy": (None, [P]),
     "tsq_join_create": (C.c_int32, [P, C.POINTER(JoinCfg), PP]),
     "tsq_join_build_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),
+    "tsq_join_build_finish_shared": (C.c_int32, [P, P, C.POINTER(C.c_int32)]),
     "tsq_join_build_finish": (C.c_int32, [P]),
     "tsq_join_probe_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P]),
     "tsq_join_probe_finish": (C.c_int32, [P]),

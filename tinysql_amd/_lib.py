@@ -73,6 +73,28 @@ class Context:
         """tsq_ctx_reserve: one slab of HBM that every operator buffer of this context is carved from (0 gives it back)"""
         check(self.lib.tsq_ctx_reserve(self.h, nbytes), self.h)
 
+    def set_knob(self, knob, value=abi.KNOB_DEFAULT):
+        """tsq_ctx_set_knob: a test / measurement knob (abi.KNOB_*); no value = back to the default"""
+        check(self.lib.tsq_ctx_set_knob(self.h, knob, value), self.h)
+
+    def reset_knobs(self):
+        for k in range(48):
+            self.set_knob(k)
+
+    def knobs(self, **kv):
+        """context manager: `with ctx.knobs(AGG_TAG_BITS=7): ...` sets the knobs and restores the defaults afterwards"""
+        ctx = self
+
+        class _K:
+            def __enter__(self_inner):
+                for k, v in kv.items():
+                    ctx.set_knob(getattr(abi, "KNOB_" + k), int(v))
+
+            def __exit__(self_inner, *a):
+                for k in kv:
+                    ctx.set_knob(getattr(abi, "KNOB_" + k))
+        return _K()
+
     def arena_stats(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(self.lib.tsq_ctx_arena_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), self.h)

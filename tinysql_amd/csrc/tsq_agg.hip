@@ -1096,7 +1096,7 @@ tsq_status launch_agg_da(tsq_agg* a, DaAggLdsArgs& la, int grid) {
     }
     {   // the two commonest plans: update descriptors as compile-time constants (tsq_daagg.h, SIG)
         const uint32_t* wd = la.plan.wdesc;
-        static const bool sig_on = [] { const char* v = getenv("TSQ_DAAGG_SIG"); return !(v && v[0] == '0'); }();
+        const bool sig_on = tsq_knob(a->ctx, TSQ_KNOB_DAAGG_SIG, 1) != 0;
         int sig = 0;
         if (sig_on && la.plan.W == 3 && wd[0] == af_wdesc(AF_W_ADD_LO32, 0, TSQ_I64) && wd[1] == af_wdesc(AF_W_ADD_HI32, 0, TSQ_I64) && wd[2] == af_wdesc(AF_W_ADD1, 0, 0)) sig = 1;
         if (sig_on && la.plan.W == 2 && wd[0] == af_wdesc(AF_W_ADD_REAL, 0, TSQ_F64) && wd[1] == af_wdesc(AF_W_ADD1, 0, 0)) sig = 2;
@@ -1165,7 +1165,7 @@ tsq_status da_agg_setup_multi(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
         total += w;
         if (total > TSQ_DAAGG_MAX_BITS) return TSQ_OK;
     }
-    static const int log2c_env = [] { const char* v = getenv("TSQ_DAAGG_LOG2C"); return v ? atoi(v) : 0; }();  // (experiment knob: 11 = half-size tables)
+    const int log2c_env = (int)tsq_knob(a->ctx, TSQ_KNOB_DAAGG_LOG2C, 0);  // (experiment knob: 11 = half-size tables)
     const uint32_t log2c = (log2c_env >= 9 && log2c_env <= 12 && pl.W <= 3) ? (uint32_t)log2c_env : (pl.W <= 3 ? 12u : 11u);
     a->da_low = total <= log2c;  // the word fits one LDS table: no partition pass (k_agg_da_low)
     uint32_t b = std::max(total, log2c + TSQ_RADIX_MIN_BITS);
@@ -1188,7 +1188,7 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     a->da_state = -1;
     tsq_ctx* ctx = a->ctx;
     tsq_handle_hdr* h = &a->hdr;
-    static const bool env_off = [] { const char* v = getenv("TSQ_PACKED_KEYS"); return v && v[0] == '0'; }();
+    const bool env_off = tsq_knob(a->ctx, TSQ_KNOB_PACKED_KEYS, 1) == 0;
     const AfPlan& pl = a->fplan;
     if (env_off || (pl.key_type != TSQ_I64 && pl.key_type != TSQ_U64)) return TSQ_OK;
     if (a->mk_n > 1) return da_agg_setup_multi(a, in, nrows);
@@ -1210,7 +1210,7 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     a->st.kernel_launches++;
     if (ctx->pinned[50] == 0) return TSQ_OK;
     const uint64_t kmin = ctx->pinned[48] ^ ma.flip, kmax = ctx->pinned[49] ^ ma.flip, range = kmax - kmin;
-    static const int log2c_env = [] { const char* v = getenv("TSQ_DAAGG_LOG2C"); return v ? atoi(v) : 0; }();  // (experiment knob: 11 = half-size tables)
+    const int log2c_env = (int)tsq_knob(a->ctx, TSQ_KNOB_DAAGG_LOG2C, 0);  // (experiment knob: 11 = half-size tables)
     const uint32_t log2c = (log2c_env >= 9 && log2c_env <= 12 && pl.W <= 3) ? (uint32_t)log2c_env : (pl.W <= 3 ? 12u : 11u);
     if (range >> TSQ_DAAGG_MAX_BITS) return TSQ_OK;
     uint32_t b = log2c + TSQ_RADIX_MIN_BITS;
@@ -1520,8 +1520,8 @@ tsq_status agg_heap_gc(tsq_agg* a) {
     if (!a->has_str) return TSQ_OK;
     tsq_ctx* ctx = a->ctx;
     tsq_handle_hdr* h = &a->hdr;
-    const char* gc_env = getenv("TSQ_AGG_HEAP_GC_BYTES");  // (test knob, read per call: a compaction after every batch)
-    const int64_t gc_min = gc_env ? atoll(gc_env) : (int64_t)(256 << 20);
+    const bool gc_env = ctx->knob[TSQ_KNOB_AGG_HEAP_GC_BYTES] != TSQ_KNOB_DEFAULT;  // (test knob, read per call: a compaction after every batch)
+    const int64_t gc_min = tsq_knob(ctx, TSQ_KNOB_AGG_HEAP_GC_BYTES, (int64_t)(256 << 20));
     if (a->heap_gc_at.empty()) a->heap_gc_at.assign(a->heap.size(), gc_min);
     if (gc_env)
         for (auto& m : a->heap_gc_at) m = std::min<int64_t>(m, gc_min);
@@ -1661,7 +1661,10 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
     a->multi = cfg->n_group_keys > 1;
     for (int k = 0; k < cfg->n_group_keys; k++) a->multi |= cfg->group_key_type[k] == TSQ_BYTES;  // a string key is verified by its bytes
     a->has_str = has_str;
-    if (const char* v = getenv("TSQ_AGG_TAG_BITS")) a->test_tag_bits = (uint32_t)atoi(v) < 64 ? (uint32_t)atoi(v) : 0;
+    {
+        const int64_t tb = tsq_knob(ctx, TSQ_KNOB_AGG_TAG_BITS, 0);
+        a->test_tag_bits = (tb > 0 && tb < 64) ? (uint32_t)tb : 0;
+    }
     for (int i = 0; i < cfg->n_aggs; i++) {
         const tsq_agg_func& f = cfg->aggs[i];
         if (f.func < TSQ_AGG_COUNT || f.func > TSQ_AGG_FIRSTROW) return tsq_fail(ch, TSQ_ERR_UNSUPPORTED, "unknown aggregate function");
@@ -1822,7 +1825,7 @@ TSQ_API tsq_status tsq_agg_push(tsq_agg* a, const tsq_col* cols, int32_t n_cols,
     }
     if (a->stage.cap == 0) {
         int64_t batch = 4 << 20;  // host chunks are aggregated in device batches of this many rows (test knob: TSQ_AGG_BATCH_ROWS)
-        if (const char* e = getenv("TSQ_AGG_BATCH_ROWS")) batch = std::max<int64_t>(1024, (atoll(e) + 63) & ~63LL);
+        if (a->ctx->knob[TSQ_KNOB_AGG_BATCH_ROWS] != TSQ_KNOB_DEFAULT) batch = std::max<int64_t>(1024, (a->ctx->knob[TSQ_KNOB_AGG_BATCH_ROWS] + 63) & ~63LL);
         TSQ_TRY(a->stage.init(&a->hdr, n_cols, a->cfg.input_types, batch));
     }
     int64_t off = 0;

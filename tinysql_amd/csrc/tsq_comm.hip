@@ -249,6 +249,20 @@ TSQ_API tsq_status tsq_comm_allreduce_f64(tsq_comm* c, double* inout, int32_t n,
     if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
     return allreduce8(c, inout, n, ncclDouble, op);
 }
+// ---- collective steps of an operator (declared in tsq_internal.h)
+bool tsq_comm_usable(const tsq_comm* c, const tsq_ctx* ctx) { return c && c->hdr.magic == TSQ_MAGIC_COMM && c->ctx == ctx && c->nccl; }
+int32_t tsq_comm_world_size(const tsq_comm* c) { return c->world; }
+tsq_status tsq_comm_allreduce_host_i64(tsq_comm* c, int64_t* inout, int32_t n, int32_t op) { return allreduce8(c, inout, n, ncclInt64, op); }
+tsq_status tsq_comm_allreduce_dev_sum(tsq_comm* c, void* buf, size_t count, int elem_bytes) {
+    tsq_handle_hdr* h = &c->hdr;
+    if (!buf || (elem_bytes != 1 && elem_bytes != 4)) return tsq_fail(h, TSQ_ERR_INVALID, "device all-reduce: 1- or 4-byte elements");
+    TSQ_HIP(h, hipSetDevice(c->ctx->device));
+    TSQ_HIP(h, hipStreamSynchronize(c->ctx->stream));  // the buffer's producer kernels ran on the context's stream
+    if (count) TSQ_NCCL(h, rccl()->AllReduce(buf, buf, count, elem_bytes == 1 ? ncclUint8 : ncclUint32, ncclSum, c->nccl, c->xs));
+    TSQ_HIP(h, hipStreamSynchronize(c->xs));
+    return TSQ_OK;
+}
+
 TSQ_API tsq_status tsq_comm_barrier(tsq_comm* c) {
     tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));
     if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;

@@ -43,6 +43,13 @@ inline std::vector<uint64_t> tsq_comm_unpack_counts(const uint64_t* G, int world
     return M;
 }
 
+// ---- wire arithmetic of the two distributed join plans, per rank
+// shared images (tsq_join_build_finish_shared): ONE all-reduce of the images per build side — a ring moves 2 (W - 1) / W of the
+// buffer through every rank — and nothing per probe row.
+inline uint64_t tsq_shared_plan_wire_bytes(int world, uint64_t image_bytes) { return world <= 1 ? 0 : 2 * image_bytes * (uint64_t)(world - 1) / (uint64_t)world; }
+// hash-radix exchange (tsq_redistribute): every row leaves its rank unless it is owned by it — (W - 1) / W of the rows, row_bytes each, per step
+inline uint64_t tsq_exchange_plan_wire_bytes(int world, uint64_t rows, uint64_t row_bytes) { return world <= 1 ? 0 : rows * row_bytes * (uint64_t)(world - 1) / (uint64_t)world; }
+
 enum { TSQ_XFER_DATA = 0, TSQ_XFER_OFFS = 1, TSQ_XFER_NOTNULL = 2 };
 struct tsq_comm_xfer {  // one piece: send_len bytes at send_off of the (column, kind) send buffer go to `peer`, recv_len bytes from `peer`
     int32_t col, kind, peer;  // land at recv_off of the (column, kind) receive buffer.  peer == own rank: a local copy (send_len == recv_len)

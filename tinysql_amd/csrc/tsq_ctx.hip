@@ -41,6 +41,7 @@ TSQ_API tsq_status tsq_ctx_create(int32_t device, tsq_ctx** out) {
     tsq_ctx* c = new tsq_ctx();
     c->hdr.magic = TSQ_MAGIC_CTX;
     c->device = device;
+    for (int64_t& k : c->knob) k = TSQ_KNOB_DEFAULT;
     tsq_handle_hdr* h = &c->hdr;
     auto fail = [&](hipError_t e, const char* what) {
         tsq_status s = tsq_fail(nullptr, e == hipErrorOutOfMemory ? TSQ_ERR_OOM_DEVICE : TSQ_ERR_HIP,
@@ -104,6 +105,14 @@ TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
     if (ctx->arena_base) (void)hipFree(ctx->arena_base);
     ctx->hdr.magic = 0;
     delete ctx;
+}
+
+TSQ_API tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value) {
+    tsq_ctx_lock _api_lock(ctx);
+    if (!ctx || ctx->hdr.magic != TSQ_MAGIC_CTX) return TSQ_ERR_INVALID;
+    if (knob < 0 || knob >= TSQ_KNOB_COUNT) return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_ctx_set_knob: unknown knob");
+    ctx->knob[knob] = value;
+    return TSQ_OK;
 }
 
 // The arena (tsq_internal.h): one slab for the buffers of every operator of this context, allocated here — when the host process

@@ -61,6 +61,8 @@ struct tsq_ctx {
     // scratch holds this lock for its duration (the GPU work is serialised by the stream anyway).  tsq_*_cancel does not
     // take it: it only sets an atomic flag.  Recursive: entry points call each other's helpers.
     std::recursive_mutex api_mu;
+    // test / measurement knobs (tsq_ctx_set_knob, include/tsq.h): TSQ_KNOB_DEFAULT = not set
+    int64_t knob[TSQ_KNOB_COUNT];
     // device-memory pool: hipMalloc costs ~35 ms per GB, and one radix / pre-aggregation batch needs several GB of
     // partition buffers — per handle that was 100+ ms of allocation for a 20 ms aggregate.  Buffers released by a handle
     // are kept (up to pool_cap bytes) and handed to the next one; everything runs on ctx->stream, so stream order
@@ -114,6 +116,8 @@ inline void tsq_pool_put(tsq_ctx* ctx, void* p, size_t cap) {
     }
     (void)hipFree(p);
 }
+
+inline int64_t tsq_knob(const tsq_ctx* ctx, int k, int64_t dflt) { return ctx->knob[k] == TSQ_KNOB_DEFAULT ? dflt : ctx->knob[k]; }
 
 struct tsq_ctx_lock {
     std::unique_lock<std::recursive_mutex> g;
@@ -215,5 +219,14 @@ inline int tsq_grid_for(const tsq_ctx* ctx, int64_t work_items, int block, int i
 
 // kernels defined in tsq_ctx.hip that other units launch through these wrappers
 tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n);
+
+// tsq_comm.hip, for the COLLECTIVE steps of an operator (tsq_join_build_finish_shared): every rank of the communicator calls them
+// in the same order.  The device all-reduce sums `count` elements of 1 or 4 bytes in place: it waits for the context's stream,
+// runs on the communicator's exchange stream and returns when the result is in `buf`.
+struct tsq_comm;
+bool tsq_comm_usable(const tsq_comm* c, const tsq_ctx* ctx);
+int32_t tsq_comm_world_size(const tsq_comm* c);
+tsq_status tsq_comm_allreduce_dev_sum(tsq_comm* c, void* buf, size_t count, int elem_bytes);
+tsq_status tsq_comm_allreduce_host_i64(tsq_comm* c, int64_t* inout, int32_t n, int32_t op);  // op: 0 sum, 1 max, 2 min; n <= 8
 
 #endif

@@ -774,6 +774,11 @@ struct tsq_join {
     DevBuf da_ckey, rckey;            // composite key column of the build side | of the probe batch in flight
     DevBuf da_img;                    // 2^b one-byte cells (bit cells: 2^b / 8 bytes)
     double da_build_ms = 0;
+    // a build side SHARDED over the ranks of a communicator whose packed images were summed across the ranks
+    // (tsq_join_build_finish_shared): the handle answers COUNT(*) for LOCAL probe rows, no 64-bit table exists
+    bool shared = false;
+    int64_t shared_image_bytes = 0, shared_usable_local = 0;
+    double shared_allreduce_ms = 0;
     int da_rows_state = 0;            // materialising packed route: build rows sorted by word (CSR over the images)
     DevBuf da_coarse, da_pstart, da_brows;
     DevBuf ridx, rovfidx, rmiss;      // ... probe rows travelling with the entries | of the overflow list | that cannot match (outer joins)
@@ -974,19 +979,17 @@ RadixPlan radix_plan_for(const tsq_join* j) {
     RadixPlan pl{false, TSQ_RADIX_MIN_BITS, 1, 1};
     // test / experiment knobs: TSQ_RADIX_KERNEL=l2 keeps the L2 route, TSQ_LDS_NF_MAX caps the slices per image (forces S > 1 on
     // small tables), TSQ_RADIX_PB_MAX caps log2(partitions)
-    const char* force = getenv("TSQ_RADIX_KERNEL");
-    const char* nf_env = getenv("TSQ_LDS_NF_MAX");
-    const char* pb_env = getenv("TSQ_RADIX_PB_MAX");
-    const bool want_lds = !(force && force[0] == 'l' && force[1] == '2');
+    const int64_t nf_env = tsq_knob(j->ctx, TSQ_KNOB_LDS_NF_MAX, 0), pb_env = tsq_knob(j->ctx, TSQ_KNOB_RADIX_PB_MAX, 0);
+    const bool want_lds = tsq_knob(j->ctx, TSQ_KNOB_RADIX_KERNEL_L2, 0) == 0;
     if (want_lds && j->tb >= TSQ_RADIX_MIN_BITS && (uint64_t)j->bs * 64 <= TSQ_LDS_IMAGE_MAX) {
         uint32_t nf_max = (uint32_t)(TSQ_LDS_IMAGE_MAX / ((uint64_t)j->bs * 64));
-        if (nf_env && atoi(nf_env) >= 1 && (uint32_t)atoi(nf_env) < nf_max) nf_max = (uint32_t)atoi(nf_env);
+        if (nf_env >= 1 && (uint32_t)nf_env < nf_max) nf_max = (uint32_t)nf_env;
         uint32_t k = 0;
         while ((2u << k) <= nf_max) k++;  // largest power of two <= nf_max
         int pb = (int)j->tb - (int)k;
         if (pb < TSQ_RADIX_MIN_BITS) pb = TSQ_RADIX_MIN_BITS;
         if (pb > TSQ_RADIX_MAX_BITS) pb = TSQ_RADIX_MAX_BITS;
-        if (pb_env && atoi(pb_env) >= TSQ_RADIX_MIN_BITS && atoi(pb_env) < pb) pb = atoi(pb_env);
+        if (pb_env >= TSQ_RADIX_MIN_BITS && pb_env < pb) pb = (int)pb_env;
         const uint32_t fpp = 1u << (j->tb - (uint32_t)pb);
         pl.lds = true;
         pl.bits = (uint32_t)pb;
@@ -1069,7 +1072,7 @@ tsq_status radix_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
         la.counters = pa.counters;
         const size_t lds = (size_t)pl.nf * j->bs * 64 + (size_t)(LNT / 64) * TSQ_LDS_RING_BYTES;
         const int lgrid = std::max(1, ctx->num_cus / 8) * 8;
-        if (getenv("TSQ_LDS_PROF")) {  // experiment: per-phase shader cycles of the LDS probe, printed per batch (synchronises)
+        if (tsq_knob(ctx, TSQ_KNOB_LDS_PROF, 0) != 0) {  // experiment: per-phase shader cycles of the LDS probe, printed per batch (synchronises)
             DevBuf pb;
             TSQ_TRY(pb.reserve(ctx, h, 64));
             la.prof = pb.as<unsigned long long>();
@@ -1133,21 +1136,24 @@ tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st,
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, j->ctx->num_cus));
     if (with_idx && miss) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     else if (with_idx) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, false>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
-    else if (st.ebits > 16) hipLaunchKernelGGL((k_da_partition<NT, K, uint32_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     else {
-        // experiment knobs: TSQ_DA_PREFETCH=1 (next tile's keys prefetched into registers: measured slower, 0.36 vs 0.30 ms per 1e8
-        // keys — it spills), TSQ_DA_PART2=0 (one 1024-thread workgroup per CU instead of two of 512 threads)
-        static const bool pf = [] { const char* v = getenv("TSQ_DA_PREFETCH"); return v && v[0] == '1'; }();
-        static const bool two = [] { const char* v = getenv("TSQ_DA_PART2"); return !(v && v[0] == '0'); }();
-        if (pf) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, false, false, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
-        else if (two) {
-            const dim3 grid2((unsigned)std::min<int64_t>(ntiles, (int64_t)j->ctx->num_cus * 2));
-            // non-temporal key loads: measured 3 x A/B in one session (profiles/r03_partition_nt_ab.txt): step 0.362 vs 0.373 ms, and
-            // the probe kernel that follows finds more of the entries in cache (0.074 vs 0.079 ms).  TSQ_DA_NT=0: plain loads
-            static const bool ntl = [] { const char* v = getenv("TSQ_DA_NT"); return !(v && v[0] == '0'); }();
+        // COUNT(*) routes: two 512-thread workgroups per CU (k_da_partition2: one loads while the other scatters) with non-temporal key
+        // loads (3 x A/B in one session, profiles/r03_partition_nt_ab.txt: step 0.362 vs 0.373 ms, and the probe kernel that follows
+        // finds more of the entries in cache).  TSQ_KNOB_DA_PARTITION = 1 keeps one 1024-thread workgroup per CU, TSQ_KNOB_DA_NT_LOADS = 0
+        // plain loads (A/B measurements).
+        const bool wide = st.ebits > 16;
+        const int64_t variant = tsq_knob(j->ctx, TSQ_KNOB_DA_PARTITION, 0);
+        const bool two = variant == 0 ? !wide : variant == 2;  // (4-byte entries: the default stays the 1024-thread kernel until the A/B below is in)
+        const bool ntl = tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) != 0;
+        const dim3 grid2((unsigned)std::min<int64_t>(ntiles, (int64_t)j->ctx->num_cus * 2));
+        if (two && wide) {
+            if (ntl) hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true, uint32_t>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
+            else hipLaunchKernelGGL((k_da_partition2<512, 8, 4, false, uint32_t>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
+        } else if (two) {
             if (ntl) hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
             else hipLaunchKernelGGL((k_da_partition2<512, 8, 4>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
-        } else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+        } else if (wide) hipLaunchKernelGGL((k_da_partition<NT, K, uint32_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+        else hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     }
     TSQ_HIP(&j->hdr, hipGetLastError());
     j->st.kernel_launches++;
@@ -1259,21 +1265,25 @@ tsq_status da_compose_build(tsq_join* j, bool* ok) {
     return TSQ_OK;
 }
 
-tsq_status da_prepare(tsq_join* j) {
+// sc != nullptr: the build side is SHARDED over the ranks of a communicator (tsq_join_build_finish_shared) — the key range is the
+// range over all ranks, every rank assembles the images of ITS rows over that range, and the images are summed across the ranks
+// (one all-reduce, once per build side): afterwards every rank holds the images of the WHOLE build side and probes its own probe
+// rows locally.  Every rank takes the same decisions: they depend on the configuration and on all-reduced values only.
+tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr) {
     if (j->da_state) return TSQ_OK;
     j->da_state = -1;
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
-    static const bool env_off = [] { const char* v = getenv("TSQ_PACKED_KEYS"); return v && v[0] == '0'; }();
-    if (env_off || j->packing_mode == TSQ_RADIX_OFF || (j->multi && !da_multi_ok(j)) || j->never_match) return TSQ_OK;
+    const bool env_off = tsq_knob(ctx, TSQ_KNOB_PACKED_KEYS, 1) == 0;
+    if (env_off || j->packing_mode == TSQ_RADIX_OFF || (j->multi && (sc || !da_multi_ok(j))) || j->never_match) return TSQ_OK;
     const int kc = j->ks.bidx[0];
     const int32_t bt = j->cfg.build_types[kc], pt = j->cfg.probe_types[j->ks.pidx[0]];
     if (!is_int_class(bt) || !is_int_class(pt)) return TSQ_OK;
     const int64_t nb = j->bcols[kc].rows;
-    if (nb <= 0 || nb >= 0xffffffffLL) return TSQ_OK;
+    if (!sc && (nb <= 0 || nb >= 0xffffffffLL)) return TSQ_OK;
     const bool force = j->packing_mode == TSQ_RADIX_FORCE;
-    static const int64_t min_build = [] { const char* v = getenv("TSQ_DA_MIN_BUILD_ROWS"); return v ? atoll(v) : (int64_t)(4 << 20); }();  // (experiment knob)
-    if (!force && nb < min_build) return TSQ_OK;
+    const int64_t min_build = tsq_knob(ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(4 << 20));  // (experiment knob)
+    if (!sc && !force && nb < min_build) return TSQ_OK;
     if (j->multi) {  // several key columns: one composite column, unsigned, ~0 = cannot match
         bool ok = false;
         TSQ_TRY(da_compose_build(j, &ok));
@@ -1291,105 +1301,172 @@ tsq_status da_prepare(tsq_join* j) {
     ctx->pinned[49] = 0;
     ctx->pinned[50] = 0;
     ctx->pinned[51] = 0;  // [51]: the two flag words of the images kernel
-    TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 32, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nb, 256)), dim3(256), 0, ctx->stream, ma);
-    TSQ_HIP(h, hipGetLastError());
-    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
-    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
-    j->st.kernel_launches++;
-    const uint64_t usable = ctx->pinned[50];
+    bool local_fail = sc && nb >= 0xffffffffLL;  // (a shared build: a rank that cannot take part still joins every collective)
+    if (nb > 0 && !local_fail) {
+        TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 32, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nb, 256)), dim3(256), 0, ctx->stream, ma);
+        TSQ_HIP(h, hipGetLastError());
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        j->st.kernel_launches++;
+    }
+    uint64_t lo_img = ctx->pinned[48], hi_img = ctx->pinned[49], usable = ctx->pinned[50];
+    const uint64_t usable_local = usable;
+    if (sc) {  // the range and the usable rows over all ranks (images compare unsigned: through int64 with the top bit flipped)
+        int64_t mm[2] = {(int64_t)(lo_img ^ 0x8000000000000000ULL), ~(int64_t)(hi_img ^ 0x8000000000000000ULL)};
+        TSQ_TRY(tsq_comm_allreduce_host_i64(sc, mm, 2, 2));
+        int64_t su[1] = {(int64_t)usable};
+        TSQ_TRY(tsq_comm_allreduce_host_i64(sc, su, 1, 0));
+        lo_img = (uint64_t)mm[0] ^ 0x8000000000000000ULL;
+        hi_img = (uint64_t)(~mm[1]) ^ 0x8000000000000000ULL;
+        usable = (uint64_t)su[0];
+        if (!force && (int64_t)usable < min_build) return TSQ_OK;
+    }
     if (usable == 0) return TSQ_OK;
-    const uint64_t kmin = ctx->pinned[48] ^ ma.flip, kmax = ctx->pinned[49] ^ ma.flip, range = kmax - kmin;
+    const int pb_env = (int)tsq_knob(ctx, TSQ_KNOB_DA_PBITS, -1);  // (experiment knob)
     // 29..31 bits: one BIT per cell instead of one byte (k_da_build_bits) — only a build side WITHOUT duplicate keys fits that
-    // (the images kernel finds out); COUNT(*) route only
-    const bool bits_mode = (range >> TSQ_DA_MAX_BITS) != 0;
-    if (bits_mode && ((range >> TSQ_DA_MAX_BITS_UNIQ) != 0 || !j->count_only)) return TSQ_OK;
-    uint32_t b = TSQ_DA_MIN_BITS;
-    while ((range >> b) != 0) b++;
-    // a sparse domain: the images would be mostly zeros (byte cells: at most 32 B of image per build row; bit cells: the same 32 B)
-    if (!force && (1ULL << b) > (bits_mode ? 256ULL : 32ULL) * usable) return TSQ_OK;
-    int pb = std::min<int>(TSQ_RADIX_MAX_BITS, (int)b - 10);
-    if (const char* e = getenv("TSQ_DA_PB")) pb = atoi(e);
-    const int max_ebits = bits_mode ? TSQ_DA_MAX_EBITS_UNIQ : TSQ_DA_MAX_EBITS;
-    pb = std::max<int>(pb, (int)b - max_ebits);
-    pb = std::min<int>(std::max<int>(pb, TSQ_RADIX_MIN_BITS), TSQ_RADIX_MAX_BITS);
-    if ((int)b - pb > max_ebits || (int)b - pb < 4) return TSQ_OK;
+    // (the images kernel finds out); COUNT(*) route only.  The arithmetic is host-only: tsq_da_plan (tsq_dapack.h)
+    const DaPlan pl = tsq_da_plan(lo_img ^ ma.flip, hi_img ^ ma.flip, usable, ma.skip_high, j->count_only, force, pb_env);
+    if (!pl.ok) return TSQ_OK;
+    const bool bits_mode = pl.bit_cells != 0;
     j->da_bits = bits_mode;
-    j->da_pbits = (uint32_t)pb;
-    j->da_ebits = b - (uint32_t)pb;
-    j->da_dm.kmin = kmin;
-    j->da_dm.range = range;
-    j->da_dm.b = b;
-    j->da_dm.s = (b + 1) / 2;
-    j->da_dm.mask = (uint32_t)((1ULL << b) - 1);
-    j->da_dm.skip_high = ma.skip_high;
+    j->da_pbits = pl.pbits;
+    j->da_ebits = pl.ebits;
+    j->da_dm = pl.dm;
     // ---- partition the build keys, assemble the images
+    const size_t img_bytes = (size_t)tsq_da_image_bytes(pl);
     const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nb, 1024 * 16);
-    if (g.nregions * g.cap >= 0xffffffffULL) return TSQ_OK;
+    if (g.nregions * g.cap >= 0xffffffffULL) {
+        if (!sc) return TSQ_OK;
+        local_fail = true;
+    }
     DevBuf ent, ctl, vend, ovf;
     auto release_all = [&]() {
         for (DevBuf* x : {&ent, &ctl, &vend, &ovf}) x->release();
     };
-    tsq_status s = ent.reserve(ctx, h, g.ent_bytes);
-    if (s == TSQ_OK) s = ctl.reserve(ctx, h, g.ctl_bytes);
-    if (s == TSQ_OK) s = vend.reserve(ctx, h, g.nregions * 4);
-    if (s == TSQ_OK) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
-    if (s == TSQ_OK) s = j->da_img.reserve(ctx, h, (bits_mode ? ((size_t)1 << b) / 8 : ((size_t)1 << b)) + 64);
-    if (s != TSQ_OK) { release_all(); j->da_img.release(); return s; }
-    DaStore st;
-    memset(&st, 0, sizeof st);
-    st.ent = ent.p;
-    st.cursor = ctl.as<uint32_t>();
-    st.ovf_count = st.cursor + g.nregions;
-    st.valid_end = vend.as<uint32_t>();
-    st.ovf = ovf.as<uint32_t>();
-    st.ovf_cap = (uint32_t)nb;
-    st.bits = j->da_pbits;
-    st.ebits = j->da_ebits;
-    st.cap = g.cap;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
-    if (e == hipSuccess) s = da_launch_partition(j, ma.src, st);
-    DaImageArgs ia;
-    memset(&ia, 0, sizeof ia);
-    ia.st = st;
-    ia.img = j->da_img.as<uint8_t>();
-    ia.flags = (uint32_t*)(ctx->dscratch + 51);
-    const size_t img_lds = bits_mode ? ((size_t)1 << j->da_ebits) / 8 : ((size_t)1 << j->da_ebits);
-    if (e == hipSuccess && s == TSQ_OK) {
-        if (bits_mode) {
-            e = hipFuncSetAttribute((const void*)k_da_build_bits<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
-            if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_bits<1024>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, ia);
-        } else if (j->da_ebits > 16) {
-            e = hipFuncSetAttribute((const void*)k_da_build_images<1024, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
-            if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_images<1024, uint32_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, ia);
-        } else {
-            e = hipFuncSetAttribute((const void*)k_da_build_images<512, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
-            if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_images<512, uint16_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(512), img_lds, ctx->stream, ia);
+    tsq_status s = TSQ_OK;
+    hipError_t e = hipSuccess;
+    if (!local_fail) {
+        s = j->da_img.reserve(ctx, h, img_bytes + 64);
+        if (s == TSQ_OK && nb > 0) s = ent.reserve(ctx, h, g.ent_bytes);
+        if (s == TSQ_OK && nb > 0) s = ctl.reserve(ctx, h, g.ctl_bytes);
+        if (s == TSQ_OK && nb > 0) s = vend.reserve(ctx, h, g.nregions * 4);
+        if (s == TSQ_OK && nb > 0) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
+        if (s != TSQ_OK && !sc) { release_all(); j->da_img.release(); return s; }
+    }
+    if (!local_fail && s == TSQ_OK && nb == 0) {  // (a rank of a shared build side without rows: its images are zeros)
+        e = hipMemsetAsync(j->da_img.p, 0, img_bytes, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    } else if (!local_fail && s == TSQ_OK) {
+        DaStore st;
+        memset(&st, 0, sizeof st);
+        st.ent = ent.p;
+        st.cursor = ctl.as<uint32_t>();
+        st.ovf_count = st.cursor + g.nregions;
+        st.valid_end = vend.as<uint32_t>();
+        st.ovf = ovf.as<uint32_t>();
+        st.ovf_cap = (uint32_t)nb;
+        st.bits = j->da_pbits;
+        st.ebits = j->da_ebits;
+        st.cap = g.cap;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
+        if (e == hipSuccess) s = da_launch_partition(j, ma.src, st);
+        DaImageArgs ia;
+        memset(&ia, 0, sizeof ia);
+        ia.st = st;
+        ia.img = j->da_img.as<uint8_t>();
+        ia.flags = (uint32_t*)(ctx->dscratch + 51);
+        const size_t img_lds = bits_mode ? ((size_t)1 << j->da_ebits) / 8 : ((size_t)1 << j->da_ebits);
+        if (e == hipSuccess && s == TSQ_OK) {
+            if (bits_mode) {
+                e = hipFuncSetAttribute((const void*)k_da_build_bits<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
+                if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_bits<1024>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, ia);
+            } else if (j->da_ebits > 16) {
+                e = hipFuncSetAttribute((const void*)k_da_build_images<1024, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
+                if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_images<1024, uint32_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), img_lds, ctx->stream, ia);
+            } else {
+                e = hipFuncSetAttribute((const void*)k_da_build_images<512, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds);
+                if (e == hipSuccess) hipLaunchKernelGGL((k_da_build_images<512, uint16_t>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(512), img_lds, ctx->stream, ia);
+            }
+            if (e == hipSuccess) e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess && s == TSQ_OK) {
+            if (bits_mode) hipLaunchKernelGGL(k_da_build_bits_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
+            else hipLaunchKernelGGL(k_da_build_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 51, ctx->dscratch + 51, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        float ms = 0;
+        if (e == hipSuccess && e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms = ms;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        j->st.kernel_launches += 2;
     }
-    if (e == hipSuccess && s == TSQ_OK) {
-        if (bits_mode) hipLaunchKernelGGL(k_da_build_bits_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
-        else hipLaunchKernelGGL(k_da_build_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ia);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 51, ctx->dscratch + 51, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    float ms = 0;
-    if (e == hipSuccess && e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms = ms;
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     release_all();
-    j->st.kernel_launches += 2;
+    uint32_t f_over = ((const uint32_t*)(ctx->pinned + 51))[0], f_dup = ((const uint32_t*)(ctx->pinned + 51))[1];
+    if (sc) {  // one more agreement: did every rank get its images, did any rank's cell overflow / hold a duplicate (bit cells)
+        int64_t fl[3] = {(local_fail || s != TSQ_OK || e != hipSuccess) ? 1 : 0, (int64_t)(f_over != 0), (int64_t)(bits_mode && f_dup != 0)};
+        const tsq_status cs = tsq_comm_allreduce_host_i64(sc, fl, 3, 1);
+        if (s == TSQ_OK && e == hipSuccess && cs != TSQ_OK) s = cs;
+        if (fl[0] || fl[1] || fl[2]) {
+            j->da_img.release();
+            if (s != TSQ_OK) return s;
+            if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key images: ") + hipGetErrorString(e));
+            return TSQ_OK;
+        }
+        // ---- the images of all ranks, summed: byte cells as bytes, bit cells as 32-bit words (tsq_dapack.h: what the sum can do wrong
+        // shows in its population)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        const auto t0 = std::chrono::steady_clock::now();
+        tsq_status as = tsq_comm_allreduce_dev_sum(sc, j->da_img.p, bits_mode ? img_bytes / 4 : img_bytes, bits_mode ? 4 : 1);
+        j->shared_allreduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (as != TSQ_OK) {
+            tsq_fail(h, as, "shared build side: all-reduce of the images failed");
+            j->da_img.release();
+            return as;
+        }
+        DaImageCheckArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.img = (const uint4*)j->da_img.p;
+        ca.n16 = img_bytes / 16;
+        ca.bits = bits_mode ? 1 : 0;
+        ca.out = (unsigned long long*)(ctx->dscratch + 52);
+        e = hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream);
+        if (e == hipSuccess && e0) e = hipEventRecord(e0, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_da_image_check, dim3(tsq_grid_for(ctx, (int64_t)ca.n16, 256)), dim3(256), 0, ctx->stream, ca);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && e1) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 52, ctx->dscratch + 52, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        float ms = 0;
+        if (e == hipSuccess && e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms += ms;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        j->st.kernel_launches++;
+        if (e != hipSuccess) { j->da_img.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("shared build side, image check: ") + hipGetErrorString(e)); }
+        if (!tsq_da_shared_images_ok(ctx->pinned[52], usable)) {  // a cell passed 255 / a key lives on two ranks (bit cells): identical on every rank
+            j->da_img.release();
+            return TSQ_OK;
+        }
+        j->da_unique = ctx->pinned[53] == 0;
+        j->shared_image_bytes = (int64_t)img_bytes;
+        j->shared_usable_local = (int64_t)usable_local;
+        j->da_state = 1;
+        return TSQ_OK;
+    }
     if (s != TSQ_OK) { j->da_img.release(); return s; }
     if (e != hipSuccess) { j->da_img.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key images: ") + hipGetErrorString(e)); }
-    const uint32_t f_over = ((const uint32_t*)(ctx->pinned + 51))[0], f_dup = ((const uint32_t*)(ctx->pinned + 51))[1];
     if (f_over || (bits_mode && f_dup)) {  // a key with more than 255 build rows (bit cells: with more than one): the 64-bit route keeps this join
         j->da_img.release();
         return TSQ_OK;
@@ -1473,7 +1550,7 @@ bool da_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_
     // AUTO: the pairs come out in PARTITION order, so the gather of the probe-side columns is as random as the build side's (the
     // direct route emits in probe order: 9 ms vs 16 ms per 1e8 x 1e8 (k, v) rows) — until the payload columns travel with the
     // entries this route is taken on request only
-    static const bool env_on = [] { const char* v = getenv("TSQ_PACKED_EMIT"); return v && v[0] == '1'; }();
+    const bool env_on = tsq_knob(j->ctx, TSQ_KNOB_PACKED_EMIT_PAIRS, 0) != 0;
     return env_on && nrows >= (4 << 20);
 }
 
@@ -1911,7 +1988,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
     const int np = j->cfg.n_probe_cols, nbc = j->cfg.n_build_cols;
     // TSQ_DA_TRACE=1: host-side time points of one batch on stderr (where the wall time between the kernels goes)
-    static const bool trace = [] { const char* v = getenv("TSQ_DA_TRACE"); return v && v[0] == '1'; }();
+    const bool trace = tsq_knob(ctx, TSQ_KNOB_DA_TRACE, 0) != 0;
     const auto t0 = std::chrono::steady_clock::now();
     auto tp = [&](const char* what) {
         if (trace) fprintf(stderr, "[da_emit_cols] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
@@ -2499,6 +2576,11 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     a.counters = j->counters.as<unsigned long long>();
     j->st.probe_rows += nrows;
 
+    if (j->shared) {  // the images of a build side sharded over several GPUs: there is no other table to fall back to
+        if (!j->count_only || j->checksum || j->general || selected_dev || nrows > 0x7fffffffLL)
+            return tsq_fail(&j->hdr, TSQ_ERR_UNSUPPORTED, "a shared build side (tsq_join_build_finish_shared) answers COUNT(*) of an inner join without conditions");
+        return da_probe(j, pcs, nrows);
+    }
     if (radix_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
         if (j->da_state == 1) return da_probe(j, pcs, nrows);
@@ -2604,8 +2686,7 @@ void table_geometry(tsq_join* j, int64_t nb, bool sliced) {
     j->tb = 0;
     j->bs = (uint32_t)std::max<uint64_t>(16, (uint64_t)((nb + 3) / 4));
     if (sliced) {
-        const char* lf_env = getenv("TSQ_TABLE_LF");
-        double lf = lf_env ? atof(lf_env) : 0.75;
+        double lf = (double)tsq_knob(j->ctx, TSQ_KNOB_TABLE_LF_PERMILLE, 750) / 1000.0;
         if (!(lf >= 0.3 && lf <= 0.9)) lf = 0.75;
         const uint64_t nbk = std::max<uint64_t>(64, (uint64_t)ceil((double)nb / (8.0 * lf)));
         const uint64_t bs_max = std::min<uint64_t>(TSQ_BP_MAX_SLICE, (uint64_t)(TSQ_BP_MAX_SLICE_ROWS / (8.0 * lf)));
@@ -2713,7 +2794,7 @@ tsq_status build_partitioned(tsq_join* j, int64_t nb, uint32_t sent_cap, bool* d
     ia.sent_total = (uint32_t*)(ctx->dscratch + 1);
     ia.inserted = (unsigned long long*)ctx->dscratch;
     ia.fail = (uint32_t*)(ctx->dscratch + 2);
-    static const bool cas_images = [] { const char* v = getenv("TSQ_BUILD_IMAGES"); return v && !strcmp(v, "cas"); }();
+    const bool cas_images = tsq_knob(ctx, TSQ_KNOB_BUILD_IMAGES_CAS, 0) != 0;
     const size_t img_bytes = (size_t)m * TSQ_BUCKET * 12 + (cas_images ? 0 : (size_t)m * 4);
     if (e == hipSuccess && img_bytes > 48 * 1024)
         e = hipFuncSetAttribute(cas_images ? (const void*)k_build_images<512, 8> : (const void*)k_build_images_cnt<512, 8>,
@@ -3023,6 +3104,39 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
     return TSQ_OK;
 }
 
+// The build side of a COUNT(*) join SHARDED over the ranks of a communicator, without moving a probe row: every rank pushes ITS
+// build rows, then all ranks call this instead of tsq_join_build_finish.  See da_prepare(j, comm) and DESIGN.md §6.
+TSQ_API tsq_status tsq_join_build_finish_shared(tsq_join* j, tsq_comm* c, int32_t* shared_out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    TSQ_TRY(check_cancel(j));
+    tsq_handle_hdr* h = &j->hdr;
+    if (!shared_out) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_join_build_finish_shared: NULL argument");
+    *shared_out = 0;
+    if (!tsq_comm_usable(c, j->ctx)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_join_build_finish_shared: the communicator does not belong to the join's context");
+    if (j->build_done) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_join_build_finish_shared after build_finish");
+    TSQ_HIP(h, hipSetDevice(j->ctx->device));
+    TSQ_TRY(build_flush(j));
+    // what the images can answer (the same on every rank: it is the plan): COUNT(*) of an inner equi-join on one integer column
+    if (j->general || j->multi || j->never_match || j->ordered || j->radix_mode == TSQ_RADIX_OFF) return TSQ_OK;
+    const bool was_count_only = j->count_only;
+    j->count_only = true;
+    j->da_state = 0;
+    const tsq_status s = da_prepare(j, c);
+    if (s != TSQ_OK || j->da_state != 1) {  // not packable (or this rank failed): the handle still holds its rows, nothing else
+        j->count_only = was_count_only;
+        j->da_state = 0;
+        return s;
+    }
+    j->shared = true;
+    j->st.build_rows = j->bcols[0].rows;
+    j->st.build_rows_inserted = j->shared_usable_local;
+    j->build_done = true;
+    j->stage.release();
+    *shared_out = 1;
+    return TSQ_OK;
+}
+
 TSQ_API tsq_status tsq_join_set_count_only(tsq_join* j, int32_t on) {
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     if (j->st.probe_rows > 0 || j->stage.staged > 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "count-only must be chosen before the first probe row");
@@ -3287,6 +3401,9 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
     j->st.radix_overflow_rows = 0;
     j->st.build_handed_back_rows = j->build_handed_back;
     j->st.packed_build_ms = j->da_build_ms;
+    j->st.shared_build = j->shared ? 1 : 0;
+    j->st.shared_image_bytes = j->shared_image_bytes;
+    j->st.shared_allreduce_ms = j->shared_allreduce_ms;
     j->st.radix_probe_kernel_ms = j->st.partition_kernel_ms_sum = j->st.radix_probe_kernel_ms_sum = 0;
     j->st.radix_timed_batches = 0;
     if (j->st.radix_batches > 0 && j->rctl.p) {

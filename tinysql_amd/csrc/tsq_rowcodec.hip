@@ -437,14 +437,12 @@ TSQ_API tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int6
         // average) is parsed from global memory by its workgroup
         int64_t want = (n_bytes / nrows) * RC_NT;
         want = std::max<int64_t>(((want + want / 4 + 512 + 4095) / 4096) * 4096, RC_LDS_DEFAULT_MIN);
-        if (const char* kb = getenv("TSQ_ROWCODEC_LDS_KB")) want = (int64_t)atoi(kb) * 1024;  // tuning knobs for tools/bench_rowcodec.py
-        const char* fl = getenv("TSQ_ROWCODEC_FAST_LAYOUT");
-        a.fast_layout = (fl && fl[0] == '0') ? 0u : 1u;
+        if (ctx->knob[TSQ_KNOB_ROWCODEC_LDS_KB] != TSQ_KNOB_DEFAULT) want = ctx->knob[TSQ_KNOB_ROWCODEC_LDS_KB] * 1024;  // tuning knobs for tools/bench_rowcodec.py
+        a.fast_layout = tsq_knob(ctx, TSQ_KNOB_ROWCODEC_FAST_LAYOUT, 1) == 0 ? 0u : 1u;
         a.lds_bytes = (uint32_t)std::min<int64_t>(std::max<int64_t>(want, RC_LDS_MIN), RC_LDS_MAX);
         const int64_t wg_per_cu = std::min<int64_t>(8, (160 * 1024) / a.lds_bytes);  // 160 KB of LDS and 32 waves per CU
         const int grid = (int)std::min<int64_t>(n_tiles, (int64_t)ctx->num_cus * wg_per_cu);
-        const char* pl = getenv("TSQ_ROWCODEC_PIPELINE");
-        if (pl && pl[0] == '0') {
+        if (tsq_knob(ctx, TSQ_KNOB_ROWCODEC_PIPELINE, 1) == 0) {
             hipLaunchKernelGGL(k_rowcodec_decode, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);  // + slack for the word reads
         } else if (a.lds_bytes <= 24 * 1024) {  // KV = 16-byte vectors a lane may hold for the next tile = tile bytes / (16 * 256)
             hipLaunchKernelGGL(k_rowcodec_decode_pipe<6>, dim3(grid), dim3(RC_NT), a.lds_bytes + 16, ctx->stream, a);

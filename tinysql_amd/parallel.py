@@ -181,17 +181,47 @@ def redistribute_pieces(comm, cols, key_col, key_mode, nrows, n_pieces, consume,
 
 
 class DistHashJoinCount:
-    """SELECT count(*) FROM probe JOIN build ON k across the ranks of `comm`: both sides are redistributed by rank(key), every
-    rank builds and probes what it owns with the single-GPU operator, the counts are summed (one 8-byte all-reduce)."""
+    """SELECT count(*) FROM probe JOIN build ON k across the ranks of `comm`.
 
-    def __init__(self, comm, cfg):
+    Two plans, chosen by the build side (the same choice on every rank):
+    * SHARED IMAGES (tsq_join_build_finish_shared): every rank pushes its own build rows, the packed direct-address images of
+      the whole build side are summed across the ranks once, and every rank probes its OWN probe rows — no probe row ever
+      crosses xGMI, the probe phase scales with the number of GPUs.  The reference's shape: N join workers probing one shared,
+      read-only hash table (executor/join.go:233-239).
+    * HASH-RADIX EXCHANGE (the fallback for build sides the images cannot hold: key ranges beyond 31 bits, ...): both sides are
+      redistributed by rank(key) (tsq_redistribute), every rank builds and probes what it owns.
+    The counts are summed with one 8-byte all-reduce either way."""
+
+    def __init__(self, comm, cfg, radix_mode=None, packing_mode=None, shared=True):
         self.comm, self.lib, self.ctx = comm, comm.lib, comm.ctx
-        self.h = C.c_void_p()
-        _lib.check(self.lib.tsq_join_create(self.ctx.h, C.byref(cfg), C.byref(self.h)), self.ctx.h)
+        self.cfg, self.radix_mode, self.packing_mode, self.want_shared = cfg, radix_mode, packing_mode, shared
+        self.h = None
+        self.shared = False
+        self._create()
         self.probed_local = 0
         self.probe_batches = 0
+        self.wire_bytes_probe = 0  # bytes of probe rows this rank put on the wire (0 on the shared-images plan)
+
+    def _create(self):
+        self.h = C.c_void_p()
+        _lib.check(self.lib.tsq_join_create(self.ctx.h, C.byref(self.cfg), C.byref(self.h)), self.ctx.h)
+        if self.radix_mode is not None:
+            _lib.check(self.lib.tsq_join_set_radix(self.h, self.radix_mode), self.h)
+        if self.packing_mode is not None:
+            _lib.check(self.lib.tsq_join_set_key_packing(self.h, self.packing_mode), self.h)
 
     def build(self, cols, key_col, nrows):
+        if self.want_shared:
+            arr = (abi.Col * len(cols))(*cols)
+            if nrows:
+                _lib.check(self.lib.tsq_join_build_push(self.h, arr, len(cols), nrows), self.h)
+            ok = C.c_int32(0)
+            _lib.check(self.lib.tsq_join_build_finish_shared(self.h, self.comm.h, C.byref(ok)), self.h)
+            if ok.value:
+                self.shared = True
+                return nrows
+            self.lib.tsq_join_destroy(self.h)  # not packable (every rank got the same answer): the exchange plan, from scratch
+            self._create()
         got, n = self.comm.redistribute(cols, key_col, 0, nrows, slot=0)
         self.comm.wait(0)
         if n:
@@ -201,12 +231,21 @@ class DistHashJoinCount:
         return n
 
     def probe(self, cols, key_col, nrows, n_pieces=4, batched_counts=False):
+        if self.shared:  # this rank's own rows against the images of the whole build side
+            if nrows:
+                arr = (abi.Col * len(cols))(*cols)
+                _lib.check(self.lib.tsq_join_probe_push(self.h, arr, len(cols), nrows, None), self.h)
+                self.probed_local += nrows
+                self.probe_batches += 1
+            return
+
         def consume(got, n):
             if n:
                 _lib.check(self.lib.tsq_join_probe_push(self.h, got, len(cols), n, None), self.h)
                 self.probed_local += n
                 self.probe_batches += 1
         redistribute_pieces(self.comm, cols, key_col, 0, nrows, n_pieces, consume, batched_counts)
+        self.wire_bytes_probe += nrows * 8 * len(cols) * (self.comm.world - 1) // self.comm.world
 
     def count(self):
         c = C.c_int64(0)

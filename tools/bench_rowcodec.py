@@ -121,7 +121,7 @@ def main():
             sweep = {}
             if os.environ.get("TSQ_RC_SWEEP"):  # LDS tile size of the kernel (tuning knob of libtsq), best of 3 each
                 for kb in (8, 12, 16, 20, 24, 32, 48, 64):
-                    os.environ["TSQ_ROWCODEC_LDS_KB"] = str(kb)
+                    ctx.set_knob(abi.KNOB_ROWCODEC_LDS_KB, kb)
                     b3 = 1e30
                     for rep in range(3):
                         ctx.sync()
@@ -131,8 +131,8 @@ def main():
                         ctx.sync()
                         b3 = min(b3, time.perf_counter() - t)
                     sweep["%dKB" % kb] = round(b3 * 1e3, 4)
-                del os.environ["TSQ_ROWCODEC_LDS_KB"]
-                os.environ["TSQ_ROWCODEC_FAST_LAYOUT"] = "0"  # every wave through the general per-row column search
+                ctx.set_knob(abi.KNOB_ROWCODEC_LDS_KB)
+                ctx.set_knob(abi.KNOB_ROWCODEC_FAST_LAYOUT, 0)  # every wave through the general per-row column search
                 b3 = 1e30
                 for rep in range(3):
                     ctx.sync()
@@ -142,8 +142,8 @@ def main():
                     ctx.sync()
                     b3 = min(b3, time.perf_counter() - t)
                 sweep["general_path_only"] = round(b3 * 1e3, 4)
-                del os.environ["TSQ_ROWCODEC_FAST_LAYOUT"]
-                os.environ["TSQ_ROWCODEC_PIPELINE"] = "0"  # the plain kernel: offsets -> bytes -> parse per tile, nothing prefetched
+                ctx.set_knob(abi.KNOB_ROWCODEC_FAST_LAYOUT)
+                ctx.set_knob(abi.KNOB_ROWCODEC_PIPELINE, 0)  # the plain kernel: offsets -> bytes -> parse per tile, nothing prefetched
                 b3 = 1e30
                 for rep in range(3):
                     ctx.sync()
@@ -153,7 +153,7 @@ def main():
                     ctx.sync()
                     b3 = min(b3, time.perf_counter() - t)
                 sweep["not_pipelined"] = round(b3 * 1e3, 4)
-                del os.environ["TSQ_ROWCODEC_PIPELINE"]
+                ctx.set_knob(abi.KNOB_ROWCODEC_PIPELINE)
             key = outs[0].to_host().data
             algo = raw.size + 8.0 * n + 8.0 * len(IDS) * n  # row bytes + one 8-byte row boundary + 8 B per decoded value
             print(json.dumps({"workload": "decode %d stored rows (rowcodec v2, %d fixed-width columns), bytes and columns resident in HBM" % (n, len(IDS)),
