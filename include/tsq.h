@@ -122,6 +122,8 @@ enum {
     TSQ_KNOB_ROWCODEC_PIPELINE = 18, /* 0: the un-pipelined decoder kernel */
     TSQ_KNOB_DA_PARTITION = 19,      /* packed partition kernel: 0 = default per entry width, 1 = one 1024-thread workgroup per CU, 2 = two of 512 */
     TSQ_KNOB_DA_NT_LOADS = 20,       /* 0: plain instead of non-temporal key loads in k_da_partition2 */
+    TSQ_KNOB_LAZY_TABLE = 21,        /* 0: tsq_join_build_finish always builds the 64-bit table (default: a build side the packed routes are likely to
+                                        serve leaves it to the first probe batch that needs it) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);

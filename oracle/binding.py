@@ -185,6 +185,20 @@ def hash_join_timed(cfg, build_chunk, probe_chunk, threads):
     return n, bms.value, pms.value, s.value, x.value
 
 
+def hash_join_timed_multi(cfg, build_chunk, probe_chunk, thread_counts):
+    """one single-threaded build, then one timed probe pass per thread count: returns (rows, build ms, [probe ms per count])"""
+    lib = load()
+    keep = []
+    b = make_cols(build_chunk.columns, keep)
+    p = make_cols(probe_chunk.columns, keep)
+    bms = C.c_double(0)
+    pms = (C.c_double * len(thread_counts))()
+    tc = (C.c_int32 * len(thread_counts))(*thread_counts)
+    lib.orc_hash_join_timed_multi.restype = C.c_int64
+    n = lib.orc_hash_join_timed_multi(C.byref(cfg), b, C.c_int64(build_chunk.NumRows()), p, C.c_int64(probe_chunk.NumRows()), tc, len(thread_counts), C.byref(bms), pms, None, None)
+    return n, bms.value, list(pms)
+
+
 def hash_agg(cfg, chunk, partial_workers=4, final_workers=4):
     lib = load()
     keep = []

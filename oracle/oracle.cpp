@@ -1187,9 +1187,10 @@ orc_result* orc_merge_join(const tsq_join_cfg* cfg, const tsq_col* inner_cols, i
     return res;
 }
 
-int64_t orc_hash_join_timed(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build,
-                            const tsq_col* probe_cols, int64_t n_probe, int32_t threads, double* build_ms,
-                            double* probe_ms, uint64_t* sum_out, uint64_t* xor_out) {
+// build once (single build thread), then one timed probe pass per entry of threads[]: the CPU baseline of bench.py at the reference's
+// concurrencies (executor/benchmark_test.go:357 runs 4 workers, tidb_hash_join_concurrency defaults to 5, sessionctx/variable/tidb_vars.go:249)
+int64_t orc_hash_join_timed_multi(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build, const tsq_col* probe_cols, int64_t n_probe,
+                                  const int32_t* thread_counts, int32_t n_runs, double* build_ms, double* probe_ms, uint64_t* sum_out, uint64_t* xor_out) {
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     RowHashMap map((size_t)std::max<int64_t>(0, cfg->est_build_rows / 8));
@@ -1202,62 +1203,76 @@ int64_t orc_hash_join_timed(const tsq_join_cfg* cfg, const tsq_col* build_cols, 
     const int32_t nb = cfg->n_build_cols, np = cfg->n_probe_cols;
     const int32_t chunk = cfg->max_chunk_size > 0 ? cfg->max_chunk_size : 1024;
     const int64_t n_chunks = (n_probe + chunk - 1) / chunk;
-    std::atomic<int64_t> next_chunk{0};
-    std::vector<int64_t> counts(threads, 0);
-    std::vector<uint64_t> sums(threads, 0), xors(threads, 0);
-    auto worker = [&](int32_t id) {  // runJoinWorker (join.go:243 STUB; intended loop per README)
-        std::vector<uint64_t> ptrs;
-        // per-worker result chunk, rows appended one at a time then handed over (dropped) when full
-        std::vector<std::vector<uint64_t>> rchk(nb + np, std::vector<uint64_t>(chunk));
-        int64_t fill = 0, cnt = 0;
-        uint64_t s = 0, x = 0;
-        for (;;) {
-            int64_t c = next_chunk.fetch_add(1);  // fetchOuterSideChunks hands out chunks (join.go:194-221)
-            if (c >= n_chunks) break;
-            int64_t lo = c * chunk, hi = std::min<int64_t>(n_probe, lo + chunk);
-            for (int64_t i = lo; i < hi; i++) {
-                bool hasNull;
-                uint64_t h = hash_row_keys(js.probe, cfg->n_keys, i, hasNull);
-                if (hasNull) continue;
-                map.Get(h, ptrs);
-                for (uint64_t p : ptrs) {
-                    if (!equal_row_keys(js.build, (int64_t)p, js.probe, i, cfg->n_keys)) continue;
-                    uint64_t rh = ROWHASH_SEED;
-                    for (int32_t cc = 0; cc < np; cc++) {  // AppendRow / AppendPartialRow (chunk.go:334-356)
-                        bool isnull = col_is_null(probe_cols[cc], i);
-                        uint64_t v = isnull ? 0 : col_raw64(probe_cols[cc], i);
-                        rchk[cc][fill] = v;
-                        rh = rowhash_step(rh, isnull ? ROWHASH_NULL : v, (uint32_t)cc);
+    int64_t total = 0;
+    for (int32_t run = 0; run < n_runs; run++) {
+        const int32_t threads = thread_counts[run] > 0 ? thread_counts[run] : 1;
+        auto tp0 = clk::now();
+        std::atomic<int64_t> next_chunk{0};
+        std::vector<int64_t> counts(threads, 0);
+        std::vector<uint64_t> sums(threads, 0), xors(threads, 0);
+        auto worker = [&](int32_t id) {  // runJoinWorker (join.go:243 STUB; intended loop per README)
+            std::vector<uint64_t> ptrs;
+            // per-worker result chunk, rows appended one at a time then handed over (dropped) when full
+            std::vector<std::vector<uint64_t>> rchk(nb + np, std::vector<uint64_t>(chunk));
+            int64_t fill = 0, cnt = 0;
+            uint64_t s = 0, x = 0;
+            for (;;) {
+                int64_t c = next_chunk.fetch_add(1);  // fetchOuterSideChunks hands out chunks (join.go:194-221)
+                if (c >= n_chunks) break;
+                int64_t lo = c * chunk, hi = std::min<int64_t>(n_probe, lo + chunk);
+                for (int64_t i = lo; i < hi; i++) {
+                    bool hasNull;
+                    uint64_t h = hash_row_keys(js.probe, cfg->n_keys, i, hasNull);
+                    if (hasNull) continue;
+                    map.Get(h, ptrs);
+                    for (uint64_t p : ptrs) {
+                        if (!equal_row_keys(js.build, (int64_t)p, js.probe, i, cfg->n_keys)) continue;
+                        uint64_t rh = ROWHASH_SEED;
+                        for (int32_t cc = 0; cc < np; cc++) {  // AppendRow / AppendPartialRow (chunk.go:334-356)
+                            bool isnull = col_is_null(probe_cols[cc], i);
+                            uint64_t v = isnull ? 0 : col_raw64(probe_cols[cc], i);
+                            rchk[cc][fill] = v;
+                            rh = rowhash_step(rh, isnull ? ROWHASH_NULL : v, (uint32_t)cc);
+                        }
+                        for (int32_t cc = 0; cc < nb; cc++) {
+                            bool isnull = col_is_null(build_cols[cc], (int64_t)p);
+                            uint64_t v = isnull ? 0 : col_raw64(build_cols[cc], (int64_t)p);
+                            rchk[np + cc][fill] = v;
+                            rh = rowhash_step(rh, isnull ? ROWHASH_NULL : v, (uint32_t)(np + cc));
+                        }
+                        s += rh;
+                        x ^= rh;
+                        cnt++;
+                        if (++fill == chunk) fill = 0;  // IsFull -> joinResultCh <- chk (join.go:311-318)
                     }
-                    for (int32_t cc = 0; cc < nb; cc++) {
-                        bool isnull = col_is_null(build_cols[cc], (int64_t)p);
-                        uint64_t v = isnull ? 0 : col_raw64(build_cols[cc], (int64_t)p);
-                        rchk[np + cc][fill] = v;
-                        rh = rowhash_step(rh, isnull ? ROWHASH_NULL : v, (uint32_t)(np + cc));
-                    }
-                    s += rh;
-                    x ^= rh;
-                    cnt++;
-                    if (++fill == chunk) fill = 0;  // IsFull -> joinResultCh <- chk (join.go:311-318)
                 }
             }
+            counts[id] = cnt;
+            sums[id] = s;
+            xors[id] = x;
+        };
+        std::vector<std::thread> th;
+        for (int32_t t = 0; t < threads; t++) th.emplace_back(worker, t);
+        for (auto& t : th) t.join();
+        auto tp1 = clk::now();
+        if (probe_ms) probe_ms[run] = std::chrono::duration<double, std::milli>(tp1 - tp0).count();
+        total = 0;
+        uint64_t s = 0, x = 0;
+        for (int32_t t = 0; t < threads; t++) {
+            total += counts[t];
+            s += sums[t];
+            x ^= xors[t];
         }
-        counts[id] = cnt;
-        sums[id] = s;
-        xors[id] = x;
-    };
-    std::vector<std::thread> th;
-    for (int32_t t = 0; t < threads; t++) th.emplace_back(worker, t);
-    for (auto& t : th) t.join();
-    auto t2 = clk::now();
-    if (probe_ms) *probe_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
-    int64_t total = 0;
-    uint64_t s = 0, x = 0;
-    for (int32_t t = 0; t < threads; t++) { total += counts[t]; s += sums[t]; x ^= xors[t]; }
-    // NOTE: the timed variant assumes left = probe (build_is_right = 1) for the checksum column order.
-    if (sum_out) *sum_out = s;
-    if (xor_out) *xor_out = x;
+        if (sum_out) *sum_out = s;
+        if (xor_out) *xor_out = x;
+    }
     return total;
+}
+
+int64_t orc_hash_join_timed(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build,
+                            const tsq_col* probe_cols, int64_t n_probe, int32_t threads, double* build_ms,
+                            double* probe_ms, uint64_t* sum_out, uint64_t* xor_out) {
+    return orc_hash_join_timed_multi(cfg, build_cols, n_build, probe_cols, n_probe, &threads, 1, build_ms, probe_ms, sum_out, xor_out);
 }
 
 tsq_status orc_expr_eval(const tsq_expr_prog* prog, const tsq_col* cols, int32_t n_cols, int64_t nrows,

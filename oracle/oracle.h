@@ -61,6 +61,9 @@ orc_result* orc_hash_join(const tsq_join_cfg* cfg, const tsq_col* build_cols, in
 /* Timed CPU baseline: same algorithm, single-threaded build + `threads` probe workers,
  * row-at-a-time append into per-worker 1024-row result chunks which are then dropped.
  * Returns the number of joined rows; fills build_ms/probe_ms. */
+int64_t orc_hash_join_timed_multi(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build, const tsq_col* probe_cols, int64_t n_probe,
+                                  const int32_t* thread_counts, int32_t n_runs, double* build_ms, double* probe_ms /* [n_runs] */, uint64_t* sum_out,
+                                  uint64_t* xor_out);
 int64_t orc_hash_join_timed(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build,
                             const tsq_col* probe_cols, int64_t n_probe, int32_t threads,
                             double* build_ms, double* probe_ms,

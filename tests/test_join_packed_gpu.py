@@ -513,3 +513,37 @@ def test_packed_hot_probe_key_both_partition_kernels(ctx, variant, span_bits, sh
     assert got == want, (got, want, stats[0].radix_overflow_rows)
     if shape != "one_full_tile":
         assert stats[0].radix_overflow_rows > 0
+
+
+# ------------------------------------------------------------------ division-by-zero WARNINGS of join conditions reach the host (tsq_stats)
+# The reference evaluates OtherConditions over the joined chunk (joiner.go:351-378 -> VecEvalBool) and every division by zero appends a
+# warning to the statement context (expression/errors.go:65-77: NULL result + ErrDivisionByZero warning).  The shim needs the COUNT
+# (tsq_stats.div_by_zero_warnings) to call handleDivisionByZeroError that many times.  Expected value: the oracle's VecEvalBool over the
+# oracle's condition-less join of the same tables — one evaluation per candidate pair, as in the reference.
+@pytest.mark.parametrize("route", ["direct", "packed"])
+@pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
+def test_division_by_zero_warnings_of_join_conditions_are_counted(ctx, orc, route, jt):
+    rng = np.random.default_rng(77)
+    nb, npr = 40_000, 90_000
+    bk = rng.permutation(nb).astype(np.int64)  # unique build keys: the packed route takes outer-join conditions too
+    bv = rng.integers(0, 4, nb).astype(np.float64)  # a quarter of the divisors is zero (DIV is real-only, builtin_arithmetic.go:435-444)
+    pk = rng.integers(-5000, nb + 5000, npr).astype(np.int64)
+    pv = rng.integers(-50, 50, npr).astype(np.float64)
+    build = Chunk([Column(abi.I64, bk), Column(abi.F64, bv, rng.random(nb) > 0.05)])
+    probe = Chunk([Column(abi.I64, pk, rng.random(npr) > 0.03), Column(abi.F64, pv, rng.random(npr) > 0.05)])
+    t = [abi.I64, abi.F64]
+    keep = []
+    # probe.v / build.v > 1  (joined row = probe columns 0..1, build columns 2..3)
+    conds = [E.ScalarFunction("gt", E.ScalarFunction("div", E.Column(1, abi.F64), E.Column(3, abi.F64)), E.Constant(1.0))]
+    cfg = H.join_cfg(t, t, [0], [0], jt, 1, conds, (), keep)
+    plain = H.join_cfg(t, t, [0], [0], abi.JOIN_INNER, 1)
+    candidates = orc.hash_join(plain, build, probe)  # every (probe row, build row) pair the conditions are evaluated on
+    _, _, want_w = orc.filter_eval(E.compile_list(conds), 1, candidates)
+    assert want_w > 1000
+    want = orc.hash_join(cfg, build, probe)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, stats_out=stats,
+                     radix=FORCE if route == "packed" else abi.RADIX_OFF, packing=FORCE if route == "packed" else abi.RADIX_OFF)
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    assert stats[0].probe_route == (abi.ROUTE_PACKED if route == "packed" else abi.ROUTE_DIRECT)
+    assert stats[0].div_by_zero_warnings == want_w, (stats[0].div_by_zero_warnings, want_w)

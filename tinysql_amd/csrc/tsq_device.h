@@ -749,7 +749,10 @@ inline tsq_status tsq_validate_prog(const tsq_expr_prog& p, int32_t n_cols, cons
     if (sp != 1) { *why = "program leaves stack depth != 1"; return TSQ_ERR_INVALID; }
     // a string-valued root (IF / IFNULL of strings, a string column, a string constant) is declared by result_type TSQ_BYTES and
     // evaluated by tsq_expr_eval_str only; conditions and filters need an Int or Real root
-    if (is_str[0] != (p.result_type == TSQ_BYTES)) { *why = "result_type does not match the root (TSQ_BYTES <=> a string-valued root)"; return TSQ_ERR_INVALID; }
+    // A string-valued root declared as a number is a plan the numeric evaluators cannot take — UNSUPPORTED, the fallback signal of
+    // every other string-valued root a host may hand in (it keeps its Go evaluator); a numeric root declared TSQ_BYTES is malformed.
+    if (is_str[0] && p.result_type != TSQ_BYTES) { *why = "a string-valued root: declare result_type TSQ_BYTES and evaluate it with tsq_expr_eval_str"; return TSQ_ERR_UNSUPPORTED; }
+    if (!is_str[0] && p.result_type == TSQ_BYTES) { *why = "result_type TSQ_BYTES needs a string-valued root"; return TSQ_ERR_INVALID; }
     if (p.result_type != TSQ_I64 && p.result_type != TSQ_F64 && p.result_type != TSQ_BYTES) { *why = "result_type must be TSQ_I64, TSQ_F64 or TSQ_BYTES"; return TSQ_ERR_INVALID; }
     return TSQ_OK;
 }

@@ -726,6 +726,7 @@ struct tsq_join {
     // build side
     std::vector<ColStore> bcols;
     bool build_done = false;
+    bool table_ready = false;  // the 64-bit table exists (tsq_join_build_finish, or the first probe batch that needed it)
     bool never_match = false;  // key classes differ (int vs float): no row can ever match
     bool multi = false;
     KeySpec ks{};
@@ -776,6 +777,7 @@ struct tsq_join {
     double da_build_ms = 0;
     // a build side SHARDED over the ranks of a communicator whose packed images were summed across the ranks
     // (tsq_join_build_finish_shared): the handle answers COUNT(*) for LOCAL probe rows, no 64-bit table exists
+    int64_t div0_packed = 0;          // division-by-zero warnings of conditions evaluated over materialised batches (da_post_conditions)
     bool shared = false;
     int64_t shared_image_bytes = 0, shared_usable_local = 0;
     double shared_allreduce_ms = 0;
@@ -794,6 +796,8 @@ struct tsq_join {
     bool have_build_ev = false, have_probe_ev = false;
     double probe_ms_acc = 0;
 };
+
+static tsq_status build_table(tsq_join* j);  // (defined with tsq_join_build_finish)
 
 namespace {
 
@@ -1772,58 +1776,183 @@ bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_
     // outer row pass" — taken here only when no build key repeats (da_unique, known once the images exist: probe_batch checks): an outer row then has
     // at most one candidate, and a candidate that fails the conditions turns into the NULL-padded row (onMissMatch, joiner.go:274-281)
     if (selected_dev || !j->filters_h.empty()) return false;
-    if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0 || j->da_cols_state < 0) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_cols_state < 0) return false;
     if (j->cfg.n_probe_cols > TSQ_DA_MAXCOLS || j->cfg.n_build_cols > TSQ_DA_MAXCOLS) return false;
     for (int c = 0; c < j->cfg.n_probe_cols; c++)
         if (j->cfg.probe_types[c] == TSQ_F32 || j->cfg.probe_types[c] == TSQ_BYTES) return false;
     for (int c = 0; c < j->cfg.n_build_cols; c++)
         if (j->cfg.build_types[c] == TSQ_F32 || j->cfg.build_types[c] == TSQ_BYTES) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
-    return nrows >= (4 << 20);
+    // AUTO: a batch big enough to pay for a partition pass — and, until the build side is prepared (once per build: ~1.5 ms per 1e8
+    // rows and column), big enough next to the build side for that preparation to amortise: a 4 Mi-row probe against 1e8 build rows
+    // is better served by the routes that only read the table (the gate used to look at the batch alone)
+    if (nrows < (4 << 20)) return false;
+    return j->da_cols_state == 1 || nrows * 4 >= j->bcols[j->ks.bidx[0]].rows;
 }
 
-tsq_status da_prepare_cols(tsq_join* j) {
+// Round 4: the build side of the travelling-columns route in one partition pass + one sort pass (tsq_dajoin.h: k_da_coarse,
+// k_da_sort_partition) — replaces da_prepare_rows + da_prepare_cols for this route (5.0 -> ~1.5 ms per 1e8 (k, v) rows; the pairs
+// route K4d keeps the row-id CSR of da_prepare_rows).
+tsq_status da_prepare_cols_direct(tsq_join* j) {
     if (j->da_cols_state) return TSQ_OK;
     j->da_cols_state = -1;
-    if (j->da_rows_state != 1) return TSQ_OK;
+    if (j->da_state != 1 || j->da_bits || j->da_ebits > 16 || j->da_ebits < 5) return TSQ_OK;
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
-    const int64_t nb = j->bcols[0].rows;
-    DaSortColsArgs sa;
-    memset(&sa, 0, sizeof sa);
-    sa.brows = j->da_brows.as<uint32_t>();
-    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 56, j->da_pstart.as<uint32_t>() + ((size_t)1 << j->da_pbits), 4, hipMemcpyDeviceToHost, ctx->stream));
-    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
-    sa.n = (int64_t)((const uint32_t*)(ctx->pinned + 56))[0];  // the build rows that have a usable key
-    if (sa.n > nb) return TSQ_OK;
-    int nsort = 0;  // every build column but the key (the emit kernel recovers the key from the word; a composite key's columns travel)
+    const int kb = j->da_multi ? -1 : j->ks.bidx[0];
+    const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
+    constexpr int T = 1024 * 8;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nb, T);
+    if (g.nregions * g.cap >= 0xffffffffULL) return TSQ_OK;
+    const size_t slots = g.nregions * g.cap;
+    int cols_of[TSQ_DA_MAXCOLS], ncols = 0;  // every build column but the key (the emit kernel recovers the key from the word; a composite key's columns travel)
+    bool any_nulls = false;
     for (int c = 0; c < j->cfg.n_build_cols; c++) {
-        if (!j->da_multi && c == j->ks.bidx[0]) continue;
-        TSQ_TRY(j->da_bsorted[c].reserve(ctx, h, (size_t)sa.n * 8 + 64));
-        sa.col[nsort] = j->bcols[c].data.as<uint64_t>();
-        sa.sorted[nsort] = j->da_bsorted[c].as<uint64_t>();
-        if (j->bcols[c].has_nulls) {
-            TSQ_TRY(j->da_bsorted_nn[c].reserve(ctx, h, (size_t)sa.n + 64));
-            sa.nulls[nsort] = j->bcols[c].nulls.as<uint8_t>();
-            sa.sorted_nn[nsort] = j->da_bsorted_nn[c].as<uint8_t>();
+        if (c == kb) continue;
+        if (ncols == TSQ_DA_MAXCOLS) return TSQ_OK;
+        cols_of[ncols++] = c;
+        any_nulls = any_nulls || j->bcols[c].has_nulls;
+    }
+    DevBuf ent, ctl, vend, ovf, ovfi, nnm, bdup, pay[TSQ_DA_MAXCOLS];
+    auto release_all = [&]() {
+        for (DevBuf* x : {&ent, &ctl, &vend, &ovf, &ovfi, &nnm, &bdup}) x->release();
+        for (auto& b : pay) b.release();
+    };
+    auto give_up = [&](tsq_status st) {
+        release_all();
+        for (DevBuf* b : {&j->da_coarse, &j->da_pstart}) b->release();
+        for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
+            j->da_bsorted[c].release();
+            j->da_bsorted_nn[c].release();
         }
-        nsort++;
+        return st;
+    };
+    tsq_status s = ent.reserve(ctx, h, g.ent_bytes);
+    if (s == TSQ_OK) s = ctl.reserve(ctx, h, g.ctl_bytes);
+    if (s == TSQ_OK) s = vend.reserve(ctx, h, g.nregions * 4);
+    if (s == TSQ_OK) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK) s = ovfi.reserve(ctx, h, (size_t)nb * 4 + 64);
+    for (int v = 0; v < ncols && s == TSQ_OK; v++) s = pay[v].reserve(ctx, h, slots * 8 + 256);
+    if (s == TSQ_OK && any_nulls) s = nnm.reserve(ctx, h, slots + 256);
+    if (s == TSQ_OK && !j->da_unique) s = bdup.reserve(ctx, h, slots + 256);
+    if (s == TSQ_OK) s = j->da_pstart.reserve(ctx, h, ((size_t)g.P + 1) * 4 + 64);
+    if (s == TSQ_OK) s = j->da_coarse.reserve(ctx, h, (((size_t)1 << j->da_dm.b) >> 5) * 4 + 64);
+    if (s != TSQ_OK) return give_up(s);
+    DaColStore cs;
+    memset(&cs, 0, sizeof cs);
+    DaStore& st = cs.st;
+    st.ent = ent.p;
+    st.cursor = ctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.miss_count = st.cursor + g.nregions + 1;
+    st.valid_end = vend.as<uint32_t>();
+    st.ovf = ovf.as<uint32_t>();
+    st.ovf_idx = ovfi.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nb;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    for (int v = 0; v < ncols; v++) cs.pay[v] = pay[v].as<uint64_t>();
+    cs.nnmask = any_nulls ? nnm.as<uint8_t>() : nullptr;
+    DaColSrc src;
+    memset(&src, 0, sizeof src);
+    da_build_key(j, src.key);
+    src.n_cols = ncols;
+    src.any_nulls = any_nulls ? 1 : 0;
+    for (int v = 0; v < ncols; v++) {
+        src.col[v] = j->bcols[cols_of[v]].data.as<uint64_t>();
+        src.nulls[v] = j->bcols[cols_of[v]].has_nulls ? j->bcols[cols_of[v]].nulls.as<uint8_t>() : nullptr;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    TSQ_HIP(h, hipEventCreate(&e0));
-    TSQ_HIP(h, hipEventCreate(&e1));
-    TSQ_HIP(h, hipEventRecord(e0, ctx->stream));
-    if (sa.n > 0 && nsort > 0) {
-        hipLaunchKernelGGL(k_da_sort_cols, dim3(tsq_grid_for(ctx, sa.n, 256), nsort), dim3(256), 0, ctx->stream, sa);
-        TSQ_HIP(h, hipGetLastError());
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
+    if (e == hipSuccess) {
+        const dim3 grid((unsigned)std::min<int64_t>((nb + T - 1) / T, ctx->num_cus));
+        hipLaunchKernelGGL((k_da_partition_cols<1024, 8, false>), grid, dim3(1024), 0, ctx->stream, src, j->da_dm, cs);
+        e = hipGetLastError();
     }
-    TSQ_HIP(h, hipEventRecord(e1, ctx->stream));
-    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms += ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    j->st.kernel_launches++;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_da_part_starts, dim3(1), dim3(1024), 0, ctx->stream, st, j->da_pstart.as<uint32_t>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 52, st.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 56, j->da_pstart.as<uint32_t>() + g.P, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    j->st.kernel_launches += 2;
+    auto finish_events = [&]() {
+        float ms = 0;
+        if (e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms += ms;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    if (e != hipSuccess) {
+        finish_events();
+        return give_up(tsq_fail(h, TSQ_ERR_HIP, std::string("packed build columns: ") + hipGetErrorString(e)));
+    }
+    const int64_t n = (int64_t)((const uint32_t*)(ctx->pinned + 56))[0];  // the build rows that have a usable key
+    if (((const uint32_t*)(ctx->pinned + 52))[0] != 0 || n > nb) {  // skewed build keys: some rows missed their region — the other routes keep this join
+        (void)hipEventRecord(e1, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        finish_events();
+        return give_up(TSQ_OK);
+    }
+    DaSortPartArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.cs = cs;
+    sa.img = j->da_img.as<uint8_t>();
+    sa.coarse = j->da_coarse.as<uint32_t>();
+    sa.pstart = j->da_pstart.as<uint32_t>();
+    sa.bdup = j->da_unique ? nullptr : bdup.as<uint8_t>();
+    sa.n_cols = ncols;
+    for (int v = 0; v < ncols && s == TSQ_OK; v++) {
+        const int c = cols_of[v];
+        s = j->da_bsorted[c].reserve(ctx, h, (size_t)n * 8 + 64);
+        sa.sorted[v] = j->da_bsorted[c].as<uint64_t>();
+        if (s == TSQ_OK && j->bcols[c].has_nulls) {
+            s = j->da_bsorted_nn[c].reserve(ctx, h, (size_t)n + 64);
+            sa.sorted_nn[v] = j->da_bsorted_nn[c].as<uint8_t>();
+        }
+    }
+    if (s != TSQ_OK) {
+        finish_events();
+        return give_up(s);
+    }
+    const uint32_t cells = 1u << j->da_ebits;
+    sa.sub_bits = j->da_ebits > 13 ? std::min<uint32_t>(3u, j->da_ebits - 13u) : 0u;
+    const uint32_t scells = cells >> sa.sub_bits;
+    // the staging buffer: twice the expected rows of a sub-bucket (denser sub-buckets take several windows), at most ~100 KB
+    const uint64_t expect = (uint64_t)(n / std::max<int64_t>(1, (int64_t)g.P << sa.sub_bits)) * 2 + 1024;
+    sa.stage_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(expect, 2048), 12288);
+    {
+        DaCoarseArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.st = st;
+        ca.img = sa.img;
+        ca.coarse = j->da_coarse.as<uint32_t>();
+        e = hipFuncSetAttribute((const void*)k_da_coarse<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((k_da_coarse<1024>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(1024), cells, ctx->stream, ca);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess && ncols > 0 && n > 0) {
+        const size_t lds = (size_t)2 * scells + (size_t)(scells >> 5) * 4 + (size_t)sa.stage_cap * 9 + 16;
+        e = hipFuncSetAttribute((const void*)k_da_sort_partition<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            const uint32_t grid = (uint32_t)std::max(8, (ctx->num_cus / 8) * 8);
+            hipLaunchKernelGGL((k_da_sort_partition<1024>), dim3(grid), dim3(1024), lds, ctx->stream, sa);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    finish_events();
+    j->st.kernel_launches += 2;
+    if (e != hipSuccess) return give_up(tsq_fail(h, TSQ_ERR_HIP, std::string("packed build columns (sort): ") + hipGetErrorString(e)));
+    release_all();
     j->da_cols_state = 1;
     return TSQ_OK;
 }
@@ -1836,10 +1965,20 @@ struct PostCondArgs {
     int64_t n;
     uint8_t* keep;
     unsigned long long* err;  // err word (preset TSQ_ERRWORD_NONE): an evaluation error sends the whole batch to the direct route
+    unsigned long long* div0; // += division-by-zero warnings of the conditions (NULL result + warning, expression/errors.go:65-77)
+    // outer joins: the packed NOT-NULL bitmap of the build side's KEY output column — a joined row holds a build key (NULL keys are
+    // never inserted, hash_table.go:161-163), a NULL-padded row of an unmatched outer row does not.  The reference never evaluates
+    // the conditions on a padded row (joiner.go onMissMatch): neither does this kernel (nullptr: inner join, every row is a match)
+    const uint8_t* matched;
 };
 __global__ void __launch_bounds__(256) k_post_conds(PostCondArgs a) {
     uint64_t errw = TSQ_ERRWORD_NONE;
+    uint32_t div0 = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        if (a.matched && tsq_is_null(a.matched, i)) {  // the padded row of an unmatched outer row: it stays what it is
+            a.keep[i] = 1;
+            continue;
+        }
         tsq_joined_src src;
         src.left = &a.L;
         src.right = &a.R;
@@ -1847,6 +1986,7 @@ __global__ void __launch_bounds__(256) k_post_conds(PostCondArgs a) {
         bool sel = false, isnull = false;
         int ec = 0, en = 0, d0 = 0;
         const tsq_status s = tsq_filter_row(a.conds, a.n_conds, src, &sel, &isnull, &ec, &en, &d0);
+        div0 += (uint32_t)d0;
         if (s != TSQ_OK) {
             const uint64_t w = tsq_errword(ec, en, (uint64_t)i, s);
             errw = w < errw ? w : errw;
@@ -1855,6 +1995,8 @@ __global__ void __launch_bounds__(256) k_post_conds(PostCondArgs a) {
         a.keep[i] = sel ? 1 : 0;
     }
     if (errw != TSQ_ERRWORD_NONE) atomicMin(a.err, (unsigned long long)errw);
+    const uint64_t d = wave_sum_u64(div0);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(a.div0, (unsigned long long)d);
 }
 // outer join, unique build side: a joined row whose conditions failed becomes the NULL-padded row — the build side's cells go NULL
 struct OuterUnmatchArgs {
@@ -1909,24 +2051,32 @@ tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bo
     TSQ_TRY(keep.reserve(ctx, h, (size_t)n + 64));
     pa.keep = keep.as<uint8_t>();
     pa.err = (unsigned long long*)(ctx->dscratch + 56);
+    pa.div0 = (unsigned long long*)(ctx->dscratch + 57);
+    if (j->cfg.join_type != TSQ_JOIN_INNER) {  // which output rows are matches: the build side's key column is NOT NULL there
+        const int kb = j->ks.bidx[0], okb = probe_is_left ? nl + kb : kb;
+        if (!may_null_v[okb]) return tsq_fail(h, TSQ_ERR_HIP, "internal: outer join output column without a bitmap");
+        pa.matched = rb.bitmap[okb].as<uint8_t>();
+    }
     ctx->pinned[56] = TSQ_ERRWORD_NONE;
-    hipError_t e = hipMemcpyAsync(ctx->dscratch + 56, ctx->pinned + 56, 8, hipMemcpyHostToDevice, ctx->stream);
+    ctx->pinned[57] = 0;
+    hipError_t e = hipMemcpyAsync(ctx->dscratch + 56, ctx->pinned + 56, 16, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_post_conds, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, pa);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 56, ctx->dscratch + 56, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 56, ctx->dscratch + 56, 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         keep.release();
         return tsq_fail(h, TSQ_ERR_HIP, std::string("conditions over the joined batch: ") + hipGetErrorString(e));
     }
     j->st.kernel_launches++;
-    if (ctx->pinned[56] != TSQ_ERRWORD_NONE) {
+    if (ctx->pinned[56] != TSQ_ERRWORD_NONE) {  // (the direct route evaluates the batch again and counts its warnings itself)
         keep.release();
         *redo = true;
         return TSQ_OK;
     }
+    j->div0_packed += (int64_t)ctx->pinned[57];
     if (j->cfg.join_type != TSQ_JOIN_INNER) {  // every outer row keeps its one output row; a failed candidate is un-matched
         OuterUnmatchArgs ua;
         memset(&ua, 0, sizeof ua);
@@ -2153,8 +2303,10 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
                 ea.bsorted[v] = j->da_bsorted[sc].as<uint64_t>();
                 ea.bsorted_nn[v] = j->bcols[sc].has_nulls ? j->da_bsorted_nn[sc].as<uint8_t>() : nullptr;
             }
-            xa.bcol[sc] = j->bcols[sc].data.as<uint64_t>();
-            xa.bnull[sc] = j->bcols[sc].has_nulls ? j->bcols[sc].nulls.as<uint8_t>() : nullptr;
+            // exception rows read the build side where the emit kernel reads it: the sorted columns (the key cell of a joined row is the
+            // probe row's key cell: same flag, same 8 bytes, codec.go:212-240)
+            xa.bcol[sc] = sc == kb ? nullptr : j->da_bsorted[sc].as<uint64_t>();
+            xa.bnn[sc] = (sc != kb && j->bcols[sc].has_nulls) ? j->da_bsorted_nn[sc].as<uint8_t>() : nullptr;
             xa.out_build[sc] = od;
             xa.out_build_nn[sc] = of;
         }
@@ -2168,7 +2320,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
         pe.img = pa.img;
         pe.coarse = j->da_coarse.as<uint32_t>();
         pe.pstart = j->da_pstart.as<uint32_t>();
-        pe.brows = j->da_brows.as<uint32_t>();
+        pe.brows = nullptr;  // the pairs name PLACES of the sorted build columns (pstart + rank + k), not build rows
         pe.pairs = j->pairs.as<unsigned long long>();
         pe.ovf_cursor = (unsigned long long*)(ctx->dscratch + 53);  // starts at 0 (cleared above)
         if (outer) hipLaunchKernelGGL(k_da_emit_ovf<true>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pe);
@@ -2180,6 +2332,8 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
             TSQ_HIP(h, hipGetLastError());
         }
         xa.pairs = pe.pairs;
+        xa.bkey_col = kb;
+        xa.pkey_col = kc;
         xa.n = exc_rows;
         xa.n_probe = np;
         xa.n_build = nbc;
@@ -2581,10 +2735,18 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
             return tsq_fail(&j->hdr, TSQ_ERR_UNSUPPORTED, "a shared build side (tsq_join_build_finish_shared) answers COUNT(*) of an inner join without conditions");
         return da_probe(j, pcs, nrows);
     }
+    // the 64-bit table may have been left for the first batch that needs it (tsq_join_build_finish: table_can_wait)
+    auto need_table = [&]() -> tsq_status {
+        if (j->table_ready) return TSQ_OK;
+        TSQ_TRY(build_table(j));
+        fill_table(j, a.t);
+        return TSQ_OK;
+    };
     if (radix_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
         if (j->da_state == 1) return da_probe(j, pcs, nrows);
-        return radix_probe(j, pcs, nrows);
+        TSQ_TRY(need_table());
+        if (radix_eligible(j, nrows, selected_dev)) return radix_probe(j, pcs, nrows);  // (the real table may be chained / too small)
     }
     if (da_multi_count_eligible(j, nrows, selected_dev)) {  // several integer key columns: the packed route or the direct one
         TSQ_TRY(da_prepare(j));
@@ -2594,22 +2756,23 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         TSQ_TRY(da_prepare(j));
         // conditions of an OUTER join: only with a unique build side (one candidate per outer row, see da_cols_eligible)
         const bool usable = j->conds_h.empty() || j->cfg.join_type == TSQ_JOIN_INNER || j->da_unique;
-        if (usable) {
-            TSQ_TRY(da_prepare_rows(j));
-            TSQ_TRY(da_prepare_cols(j));
-        }
+        if (usable) TSQ_TRY(da_prepare_cols_direct(j));
         if (usable && j->da_cols_state == 1) {
             bool redo = false;
             TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo));
             if (!redo) return TSQ_OK;
         }
     }
-    if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
+    if (radix_emit_eligible(j, pcs, nrows, selected_dev)) {
+        TSQ_TRY(need_table());
+        if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
+    }
     if (da_emit_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
         TSQ_TRY(da_prepare_rows(j));
         if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows);
     }
+    TSQ_TRY(need_table());
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
     j->st.probe_route = TSQ_ROUTE_DIRECT;
     if (j->count_only) {
@@ -2985,17 +3148,14 @@ TSQ_API tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t
     return TSQ_OK;
 }
 
-TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
-    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
-    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
-    TSQ_TRY(check_cancel(j));
-    if (j->build_done) return TSQ_OK;
+// the 64-bit hash table of the build side (tsq_jointable.h).  Built by tsq_join_build_finish — or, when the build side looks packable
+// (below), by the first probe batch that needs it: the packed routes never read it, and 2.6 ms per 1e8 build rows
+// is more than the packed images cost.
+static tsq_status build_table(tsq_join* j) {
+    if (j->table_ready) return TSQ_OK;
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
-    TSQ_HIP(h, hipSetDevice(ctx->device));
-    TSQ_TRY(build_flush(j));
     const int64_t nb = j->bcols[0].rows;
-    j->st.build_rows = nb;
     uint32_t sent_cap = 1024;
     TSQ_TRY(j->sent.reserve(ctx, h, sent_cap * 4));
     j->sent_count = 0;
@@ -3099,6 +3259,38 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
     j->st.table_slice_bits = (int32_t)j->tb;
     j->st.build_partitioned = part_done ? 1 : 0;
     j->st.build_rows_inserted = j->build_inserted;
+    j->table_ready = true;
+    return TSQ_OK;
+}
+
+// May the 64-bit table wait for a probe batch that needs it?  Yes when the packed routes are likely to serve every batch: one integer
+// key column (or several that compose), nothing switched off, and a build side of the size AUTO packs (or packing FORCEd).  The
+// decision only moves WORK: a batch that takes another route builds the table first (probe_batch: need_table).
+static bool table_can_wait(const tsq_join* j, int64_t nb) {
+    if (j->never_match || j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || nb <= 0 || nb >= 0xffffffffLL) return false;
+    if (tsq_knob(j->ctx, TSQ_KNOB_PACKED_KEYS, 1) == 0 || tsq_knob(j->ctx, TSQ_KNOB_LAZY_TABLE, 1) == 0) return false;
+    if (j->multi ? !da_multi_ok(j) : !(is_int_class(j->cfg.build_types[j->ks.bidx[0]]) && is_int_class(j->cfg.probe_types[j->ks.pidx[0]]))) return false;
+    if (!j->filters_h.empty() || j->ordered) return false;
+    return j->packing_mode == TSQ_RADIX_FORCE || nb >= tsq_knob(j->ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(4 << 20));
+}
+
+TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    TSQ_TRY(check_cancel(j));
+    if (j->build_done) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    TSQ_HIP(h, hipSetDevice(ctx->device));
+    TSQ_TRY(build_flush(j));
+    const int64_t nb = j->bcols[0].rows;
+    j->st.build_rows = nb;
+    if (table_can_wait(j, nb)) {
+        // the geometry is host arithmetic: the route choices that ask for it (radix_eligible: table bytes, slices) get the planned one
+        table_geometry(j, nb, nb >= 32768);
+    } else {
+        TSQ_TRY(build_table(j));
+    }
     j->build_done = true;
     j->stage.release();  // staging is re-initialised for the probe schema
     return TSQ_OK;
@@ -3401,6 +3593,10 @@ TSQ_API tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out) {
     j->st.radix_overflow_rows = 0;
     j->st.build_handed_back_rows = j->build_handed_back;
     j->st.packed_build_ms = j->da_build_ms;
+    {   // warnings of OtherConditions / outer filters so far: counters[4] of the direct kernels + the packed route's own count
+        unsigned long long d0 = 0;
+        if (hipMemcpy(&d0, j->counters.as<unsigned long long>() + 4, 8, hipMemcpyDeviceToHost) == hipSuccess) j->st.div_by_zero_warnings = (int64_t)d0 + j->div0_packed;
+    }
     j->st.shared_build = j->shared ? 1 : 0;
     j->st.shared_image_bytes = j->shared_image_bytes;
     j->st.shared_allreduce_ms = j->shared_allreduce_ms;

@@ -21,7 +21,7 @@ from . import _abi as abi
 from . import _lib
 from .chunk import Chunk, Column, StrColumn, np_dtype
 from .expression import Column as Column_
-from .expression import ETReal, CompiledExpr
+from .expression import ETReal, ETString, CompiledExpr, Unsupported
 
 
 def _es(tp):
@@ -264,6 +264,11 @@ class GpuSelectionExec(GpuExecutor):
 
 class GpuProjectionExec(GpuExecutor):
     def __init__(self, ctx, child, exprs, jit=None):
+        # a string-valued expression has no fixed-width output column here: the planner must learn that when it BUILDS the plan
+        # (Unsupported = keep the Go ProjectionExec), not from a failing Next
+        for e in exprs:
+            if e.eval_type == ETString:
+                raise Unsupported("GpuProjectionExec: a string-valued projection expression keeps the Go operator (VecEvalString exists on chunk level only)")
         types = [abi.F64 if e.eval_type == ETReal else (abi.U64 if e.unsigned else abi.I64) for e in exprs]
         super().__init__(ctx, types, (child,))
         self.child, self.exprs, self.jit = child, list(exprs), jit
