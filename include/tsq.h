@@ -60,6 +60,11 @@ enum {
 
 /* tsq_col.flags */
 #define TSQ_COL_DEVICE 1u /* data/null_bitmap/offsets are device (HBM) pointers */
+#define TSQ_COL_BORROW 2u /* an OUTPUT column of a device-resident pull (tsq_join_pull): instead of copying into the caller's buffers the
+                             operator hands out pointers into its own result batch — data / null_bitmap are SET by the call (null_bitmap =
+                             NULL when the column holds no NULL) and stay valid until the next pull, finish or destroy on the handle.
+                             The device-chunk hand-off between GPU operators (Chunk.SwapColumns, util/chunk/chunk.go:231-235, is the
+                             same idea: ownership of the buffers moves, no row is copied).  Fixed-width columns only. */
 
 /* mirrors util/chunk/column.go:28-34 */
 typedef struct tsq_col {
@@ -124,6 +129,8 @@ enum {
     TSQ_KNOB_DA_NT_LOADS = 20,       /* 0: plain instead of non-temporal key loads in k_da_partition2 */
     TSQ_KNOB_LAZY_TABLE = 21,        /* 0: tsq_join_build_finish always builds the 64-bit table (default: a build side the packed routes are likely to
                                         serve leaves it to the first probe batch that needs it) */
+    TSQ_KNOB_DA_PAIRS_BELOW_PERMILLE = 22, /* AUTO: a probe batch whose sampled hit ratio lies below this (in 1/1000, default 350) takes the pairs
+                                        variant of the materialising packed route (K4d) instead of the travelling columns (K5f + K4e) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -135,6 +142,8 @@ tsq_status tsq_dev_free(tsq_ctx* ctx, void* p);
 tsq_status tsq_dev_memset(tsq_ctx* ctx, void* p, int32_t byte, int64_t bytes);
 tsq_status tsq_copy_h2d(tsq_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
 tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+/* device to device, queued on the context's stream (not synchronised): an operator's output batch kept beyond its next Next() */
+tsq_status tsq_copy_d2d(tsq_ctx* ctx, void* dst_dev, const void* src_dev, int64_t bytes);
 
 /* Timing helper: HIP events recorded on the ctx stream (bench.py's roofline leg). */
 tsq_status tsq_timer_start(tsq_ctx* ctx);
@@ -367,6 +376,11 @@ tsq_status tsq_join_peek(tsq_join* j, int64_t cap_rows, int64_t* nrows_out, int6
 /* COUNT(*) fast path (config C1: SELECT count(*) FROM t1 JOIN t2 ON t1.k=t2.k): number of
  * joined rows produced so far by probe_push'd input, without materialising them.
  * Valid instead of (not mixed with) tsq_join_pull. */
+/* Inline projection (column pruning, planner/core/rule_column_pruning.go): used[c] = 0 tells the operator that the parent never
+ * reads output column c (left child's columns, then right child's): routes that gather their output through (probe row,
+ * build row) pairs do not materialise it, tsq_join_pull does not touch its buffer (TSQ_COL_BORROW: data = NULL).  A route that
+ * writes whole rows anyway may still fill it.  used = NULL: every column is used (default).  Before the first probe row. */
+tsq_status tsq_join_set_used_columns(tsq_join* j, const uint8_t* used, int32_t n_cols);
 tsq_status tsq_join_set_count_only(tsq_join* j, int32_t on);
 tsq_status tsq_join_count(tsq_join* j, int64_t* rows_out);
 /* Order-independent checksum of the joined rows seen so far in count-only mode:
@@ -724,6 +738,12 @@ void       tsq_comm_destroy(tsq_comm* c);
 tsq_status tsq_comm_allreduce_i64(tsq_comm* c, int64_t* inout, int32_t n, int32_t op);
 tsq_status tsq_comm_allreduce_f64(tsq_comm* c, double* inout, int32_t n, int32_t op);
 tsq_status tsq_comm_barrier(tsq_comm* c);
+/* key_mode of tsq_redistribute: 0 / 1 as for tsq_radix_split; TSQ_KEYMODE_BROADCAST = an ALL-GATHER of the columns — every rank
+ * receives every rank's rows, in rank order (key_col is ignored): the small side of a broadcast join (a filtered dimension table,
+ * the result of an earlier join) goes to every GPU once, and the big side is never moved (tinysql_amd/parallel.py: dist_q3). */
+#define TSQ_KEYMODE_JOIN      0
+#define TSQ_KEYMODE_GROUP     1
+#define TSQ_KEYMODE_BROADCAST 2
 tsq_status tsq_redistribute(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_t key_col, int32_t key_mode,
                             int64_t nrows, int32_t slot, tsq_col* out_cols, int64_t* nrows_out);
 tsq_status tsq_redistribute_wait(tsq_comm* c, int32_t slot);

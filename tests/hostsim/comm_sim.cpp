@@ -64,6 +64,8 @@ int32_t sim_comm_exchange(int32_t world, int32_t n_cols, const int32_t* col_kind
     for (int i = 0; i < n_cols; i++)
         if (col_kinds[i] == 0) var_of[(size_t)i] = n_var++;
     const size_t L = tsq_comm_lwords(world, n_var);
+    const bool broadcast = skew == 2;  // key_mode 2 of tsq_redistribute: an all-gather of the columns
+    if (broadcast) skew = 0;
     // ---- the tables: column 0 is the BIGINT key (NULL keys go to rank 0, tsq_comm.hip)
     std::vector<SimRank> in((size_t)world);
     uint64_t s = seed;
@@ -100,6 +102,10 @@ int32_t sim_comm_exchange(int32_t world, int32_t n_cols, const int32_t* col_kind
         for (int64_t k = 0; k < in[(size_t)r].rows; k++) {
             uint64_t kw = 0;
             memcpy(&kw, key.data.data() + k * key.es, (size_t)key.es);
+            if (broadcast) {  // key_mode 2: every row goes to every rank
+                for (int d = 0; d < world; d++) dest_rows[(size_t)r][(size_t)d].push_back(k);
+                continue;
+            }
             const uint32_t d = key.notnull[(size_t)k] ? tsq_key_rank(kw, (uint32_t)world) : 0u;
             if (d >= (uint32_t)world) return fail(10, "tsq_key_rank out of range");
             dest_rows[(size_t)r][d].push_back(k);
@@ -107,7 +113,7 @@ int32_t sim_comm_exchange(int32_t world, int32_t n_cols, const int32_t* col_kind
         std::vector<int64_t> order;
         for (int p = 0; p < world; p++) {
             M[(size_t)r * L + (size_t)p] = (uint64_t)dest_rows[(size_t)r][(size_t)p].size();
-            order.insert(order.end(), dest_rows[(size_t)r][(size_t)p].begin(), dest_rows[(size_t)r][(size_t)p].end());
+            if (!broadcast || p == 0) order.insert(order.end(), dest_rows[(size_t)r][(size_t)p].begin(), dest_rows[(size_t)r][(size_t)p].end());  // broadcast: the columns once
         }
         uint64_t mask = 0;
         for (int i = 0; i < n_cols; i++) {
@@ -119,7 +125,7 @@ int32_t sim_comm_exchange(int32_t world, int32_t n_cols, const int32_t* col_kind
                 for (int p = 0; p < world; p++) {
                     const size_t n = dest_rows[(size_t)r][(size_t)p].size();
                     M[(size_t)r * L + (size_t)world + 1 + (size_t)var_of[(size_t)i] * world + (size_t)p] = (uint64_t)(sc.offs[row + n] - sc.offs[row]);
-                    row += n;
+                    if (!broadcast) row += n;
                 }
             }
         }
@@ -130,7 +136,7 @@ int32_t sim_comm_exchange(int32_t world, int32_t n_cols, const int32_t* col_kind
     struct Recv { std::vector<uint8_t> data, nn; std::vector<int64_t> tmp, offs; };
     std::vector<std::vector<Recv>> recv((size_t)world, std::vector<Recv>((size_t)n_cols));
     for (int r = 0; r < world; r++) {
-        plan.push_back(tsq_comm_make_plan(r, world, n_cols, col_kinds, M.data()));
+        plan.push_back(tsq_comm_make_plan(r, world, n_cols, col_kinds, M.data(), broadcast));
         const tsq_comm_plan& pl = plan.back();
         for (int i = 0; i < n_cols; i++) {
             Recv& rc = recv[(size_t)r][(size_t)i];

@@ -49,6 +49,16 @@ def test_exchange_plan_ragged_and_empty_ranks(sim, world):
 
 
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_broadcast_mode_is_an_all_gather_of_the_columns(sim, world):
+    # key_mode 2 of tsq_redistribute (the small sides of a broadcast join: tinysql_amd/parallel.py, dist_q3): every rank receives every
+    # rank's rows in rank order; fixed-width, nullable and var-len columns, ragged and empty ranks
+    kinds = [8, 0, 4, 8]
+    _run(sim, world, kinds, 0, [700 + 13 * r for r in range(world)], 11, skew=2)
+    _run(sim, world, kinds, (1 << (len(kinds) * world)) - 1, [0 if r % 2 else 900 for r in range(world)], 12, skew=2)
+    _run(sim, world, kinds, 0b0110, [1] * world, 13, skew=2)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_count_exchange_of_several_pieces_at_once(sim, world):
     # tsq_redistribute_counts: pieces with different vector lengths (a piece with var-len columns carries their byte counts too)
     sim.sim_comm_counts.restype = C.c_int32

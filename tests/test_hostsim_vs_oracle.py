@@ -269,10 +269,13 @@ def test_string_program_validation(sim):
     assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_INVALID
     prog = E.compile_expr(E.ScalarFunction("length", S0))
     prog.n_ops = 1                                                                                      # a string-valued root ...
-    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_INVALID                                        # ... declared as an Int result
+    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_UNSUPPORTED                                    # ... declared as an Int result: the fallback signal
     prog.result_type = abi.BYTES                                                                        # ... declared as such: tsq_expr_eval_str
     assert sim.sim_validate(C.byref(prog), 1) == abi.OK
     prog = E.compile_expr(E.ScalarFunction("ifnull", S0, E.Constant("x")))
     assert prog.result_type == abi.BYTES and sim.sim_validate(C.byref(prog), 1) == abi.OK
     prog.result_type = abi.I64
+    assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_UNSUPPORTED
+    prog = E.compile_expr(E.ScalarFunction("length", S0))
+    prog.result_type = abi.BYTES                                                                        # a numeric root declared TSQ_BYTES is malformed
     assert sim.sim_validate(C.byref(prog), 1) == abi.ERR_INVALID

@@ -547,3 +547,30 @@ def test_division_by_zero_warnings_of_join_conditions_are_counted(ctx, orc, rout
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
     assert stats[0].probe_route == (abi.ROUTE_PACKED if route == "packed" else abi.ROUTE_DIRECT)
     assert stats[0].div_by_zero_warnings == want_w, (stats[0].div_by_zero_warnings, want_w)
+
+
+# ------------------------------------------------------------------ selected[] on the packed routes (round 4)
+# tsq_join_probe_push(selected): an externally evaluated outer-side filter — a row with selected == 0 goes to onMissMatch (join.go:344-345):
+# dropped by an inner join, NULL-padded by an outer join.  The packed kernels treat such a row like a row with a NULL key; the device
+# pipeline uses it to hand a Selection's flags to the join without compacting the chunk (gpu_pipeline.GpuSelectionExec(compact=False)).
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("route", ["travelling_columns", "pairs"])
+def test_packed_routes_take_a_selected_vector(ctx, orc, jt, inner, route):
+    rng = np.random.default_rng(91 + jt)
+    nb, npr = 30_000, 70_001
+    bk = rng.integers(0, 25_000, nb).astype(np.int64)  # duplicates
+    pk = rng.integers(-3000, 28_000, npr).astype(np.int64)
+    build = Chunk([Column(abi.I64, bk, rng.random(nb) > 0.03), Column(abi.I64, rng.integers(-9, 9, nb), rng.random(nb) > 0.1)])
+    probe = Chunk([Column(abi.I64, pk, rng.random(npr) > 0.03), Column(abi.F64, rng.random(npr)), Column(abi.I64, np.arange(npr))])
+    sel = (rng.random(npr) > 0.4).astype(np.uint8)
+    left, right = (probe, build) if inner == 1 else (build, probe)
+    cfg = H.join_cfg(left.types(), right.types(), [0], [0], jt, inner)
+    want = orc.hash_join(cfg, build, probe, selected=sel)
+    with ctx.knobs(PACKED_EMIT_PAIRS=1, DA_PAIRS_BELOW_PERMILLE=(1001 if route == "pairs" else 0)):
+        stats = []
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, selected=sel, stats_out=stats, radix=FORCE, packing=FORCE)
+    assert stats[0].probe_route == abi.ROUTE_PACKED
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    if jt == abi.JOIN_INNER:
+        c = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, selected=sel, count_only=True, radix=FORCE, packing=FORCE)
+        assert c == want.NumRows()

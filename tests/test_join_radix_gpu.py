@@ -169,7 +169,12 @@ def test_radix_full_size_1e8_by_1e8_property(ctx):
     n = 100_000_000  # BASELINE headline size: every probe key lies in [0, n) and joins exactly once
     got, st = _device_count(ctx, n, n, n, abi.RADIX_AUTO)
     assert got == n and st.radix_batches == 1 and st.radix_bits >= 10 and st.radix_overflow_rows == 0
-    assert st.table_slice_bits >= 13 and st.build_slice_retries == 0
+    # round 4: a build side the packed routes serve never builds its 64-bit table (tsq_join_build_finish leaves it to the first batch
+    # that needs it); with the knob off the table is built as before: 2^13+ LDS-sized slices, no retry
+    assert st.probe_route == abi.ROUTE_PACKED and st.table_buckets == 0
+    with ctx.knobs(LAZY_TABLE=0):
+        got, st = _device_count(ctx, n, n, n, abi.RADIX_AUTO)
+    assert got == n and st.table_slice_bits >= 13 and st.build_slice_retries == 0 and st.table_buckets > 0
 
 
 @pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])

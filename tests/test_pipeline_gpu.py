@@ -84,13 +84,14 @@ def test_chunk_compact_matches_boolean_indexing(ctx, n):
         ctx.free(flags)
 
 
+@pytest.mark.parametrize("classic", [False, True], ids=["flags_into_joins_used_columns", "compacting_selections_all_columns"])
 @pytest.mark.parametrize("jit", [abi.JIT_OFF, abi.JIT_FORCE])
-def test_q3_shaped_plan_on_device_chunks(ctx, orc, jit):
+def test_q3_shaped_plan_on_device_chunks(ctx, orc, jit, classic):
     customer, orders, lineitem = q3.tables(0.05)  # 7.5e3 / 7.5e4 / 3e5 rows
     want = q3_by_the_oracle(orc, customer, orders, lineitem)
     dev = [GP.DeviceChunk.from_host(ctx, t) for t in (customer, orders, lineitem)]
     try:
-        out = GP.drain_device(q3.plan(ctx, *dev, batch_rows=50_000, jit=jit))  # several batches per table
+        out = GP.drain_device(q3.plan(ctx, *dev, batch_rows=50_000, jit=jit, classic=classic))  # several batches per table
         got = {}
         for c in out:
             for k, d, p, s in c.rows():

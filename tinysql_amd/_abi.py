@@ -22,6 +22,7 @@ STATUS_NAMES = {
 # column types
 I64, U64, F32, F64, BYTES = 0, 1, 2, 3, 4
 COL_DEVICE = 1
+COL_BORROW = 2
 
 # generator kinds
 GEN_SEQ, GEN_AFFINE, GEN_RAND_MOD, GEN_RAND_F64, GEN_HASH_OF_COL = 0, 1, 2, 3, 4
@@ -155,13 +156,14 @@ ROUTE_DIRECT, ROUTE_RADIX_L2, ROUTE_RADIX_LDS, ROUTE_PACKED = 0, 1, 2, 3
 
 
 COMM_ID_BYTES = 128
+KEYMODE_JOIN, KEYMODE_GROUP, KEYMODE_BROADCAST = 0, 1, 2
 
 # tsq_ctx_set_knob (test / measurement knobs, include/tsq.h)
 KNOB_DEFAULT = -(1 << 63)
 (KNOB_PACKED_KEYS, KNOB_DA_MIN_BUILD_ROWS, KNOB_DA_PBITS, KNOB_PACKED_EMIT_PAIRS, KNOB_RADIX_KERNEL_L2, KNOB_LDS_NF_MAX, KNOB_RADIX_PB_MAX,
  KNOB_TABLE_LF_PERMILLE, KNOB_LDS_PROF, KNOB_DA_TRACE, KNOB_BUILD_IMAGES_CAS, KNOB_DAAGG_SIG, KNOB_DAAGG_LOG2C, KNOB_AGG_HEAP_GC_BYTES,
  KNOB_AGG_TAG_BITS, KNOB_AGG_BATCH_ROWS, KNOB_ROWCODEC_LDS_KB, KNOB_ROWCODEC_FAST_LAYOUT, KNOB_ROWCODEC_PIPELINE, KNOB_DA_PARTITION,
- KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE) = range(22)
+ KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE, KNOB_DA_PAIRS_BELOW_PERMILLE) = range(23)
 
 
 # every symbol include/tsq.h declares: name -> (restype, argtypes)
@@ -183,6 +185,7 @@ SIGNATURES = {
     "tsq_dev_memset": (C.c_int32, [P, P, C.c_int32, C.c_int64]),
     "tsq_copy_h2d": (C.c_int32, [P, P, P, C.c_int64]),
     "tsq_copy_d2h": (C.c_int32, [P, P, P, C.c_int64]),
+    "tsq_copy_d2d": (C.c_int32, [P, P, P, C.c_int64]),
     "tsq_timer_start": (C.c_int32, [P]),
     "tsq_timer_stop_ms": (C.c_int32, [P, C.POINTER(C.c_double)]),
     "tsq_gen_column": (C.c_int32, [P, C.POINTER(GenSpec), C.c_int64, P, P, P]),
@@ -196,6 +199,7 @@ SIGNATURES = {
     "tsq_join_create": (C.c_int32, [P, C.POINTER(JoinCfg), PP]),
     "tsq_join_build_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),
     "tsq_join_build_finish_shared": (C.c_int32, [P, P, C.POINTER(C.c_int32)]),
+    "tsq_join_set_used_columns": (C.c_int32, [P, P, C.c_int32]),
     "tsq_join_build_finish": (C.c_int32, [P]),
     "tsq_join_probe_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P]),
     "tsq_join_probe_finish": (C.c_int32, [P]),

@@ -110,6 +110,7 @@ struct tsq_comm {
         std::vector<DevBuf> sendoffs, recvtmp, recvoffs;
         hipEvent_t split_done = nullptr, xchg_done = nullptr;
         bool pending = false;
+        bool broadcast = false;  // key_mode 2: the piece is all-gathered (every rank receives every rank's rows)
         // a piece between tsq_redistribute_prepare and tsq_redistribute_issue: its columns (split into `send`), its count vector
         // (tsq_comm_plan.h: L words) and, after tsq_redistribute_counts, every rank's vector
         int state = 0;  // 0: idle, 1: prepared, 2: counted
@@ -324,7 +325,18 @@ tsq_status comm_prepare(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_
         }
     }
     int64_t sendc[TSQ_SPLIT_MAX_PARTS] = {0};
-    if (nrows > 0) {
+    s.broadcast = key_mode == TSQ_KEYMODE_BROADCAST;
+    if (s.broadcast) {
+        // an all-gather of the columns: no split — the send buffers hold the columns once, every rank gets all rows (tsq_comm_plan.h)
+        for (int i = 0; i < n_cols && nrows > 0; i++) {
+            const bool var = var_of[i] >= 0;
+            const size_t bytes = var ? (size_t)in_bytes[i] : (size_t)nrows * tsq_elem_size(cols[i].type);
+            if (bytes) TSQ_HIP(h, hipMemcpyAsync(s.send[i].p, cols[i].data, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            if (var) TSQ_HIP(h, hipMemcpyAsync(s.sendoffs[i].p, cols[i].offsets, ((size_t)nrows + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            if (cols[i].null_bitmap) TSQ_HIP(h, hipMemcpyAsync(s.sendbm[i].p, cols[i].null_bitmap, tsq_bitmap_bytes(nrows), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        for (int p = 0; p < W; p++) sendc[p] = nrows;
+    } else if (nrows > 0) {
         tsq_status st = tsq_radix_split(ctx, cols, n_cols, key_col, key_mode, nrows, W, sc.data(), sendc);
         if (st != TSQ_OK) return tsq_fail(h, st, ctx->hdr.err);
     }
@@ -338,6 +350,10 @@ tsq_status comm_prepare(tsq_comm* c, const tsq_col* cols, int32_t n_cols, int32_
             if (var_of[i] < 0) continue;
             int64_t row = 0;
             for (int p = 0; p <= W; p++) {
+                if (s.broadcast) {  // every run is the whole column
+                    bounds[(size_t)var_of[i] * (W + 1) + p] = (int64_t)p * in_bytes[i];
+                    continue;
+                }
                 TSQ_HIP(h, hipMemcpyAsync(&bounds[(size_t)var_of[i] * (W + 1) + p], s.sendoffs[i].as<int64_t>() + row, 8, hipMemcpyDeviceToHost, ctx->stream));
                 if (p < W) row += sendc[p];
             }
@@ -407,7 +423,7 @@ tsq_status comm_issue(tsq_comm* c, int32_t slot, tsq_col* out_cols, int32_t n_ou
     // sizes 2, 4 and 8 by tests/hostsim)
     int32_t es_of[TSQ_MAX_COLS];
     for (int i = 0; i < n_cols; i++) es_of[i] = var_of[i] >= 0 ? 0 : (int32_t)tsq_elem_size(cols[i].type);
-    const tsq_comm_plan pl = tsq_comm_make_plan(c->rank, W, n_cols, es_of, M);
+    const tsq_comm_plan pl = tsq_comm_make_plan(c->rank, W, n_cols, es_of, M, s.broadcast);
     const int64_t total = pl.total_rows;
     const uint64_t mask = pl.mask;  // a column is nullable for everybody as soon as one rank holds NULLs in it
     for (int i = 0; i < n_cols; i++) {

@@ -75,7 +75,9 @@ struct tsq_comm_plan {
 //   OFFS     send: the split's offsets[nrows + 1] (8 B each)  recv: a scratch of (total rows + world) entries — the run from rank q lands
 //            at entry (rows before it) + q and brings rows + 1 entries; the shifts rebase it into the column's offsets[total + 1]
 //   NOTNULL  send / recv: one byte per row, run after run
-inline tsq_comm_plan tsq_comm_make_plan(int rank, int world, int n_cols, const int32_t* elem_size, const uint64_t* M) {
+// broadcast (key_mode 2 of tsq_redistribute = an all-gather of the columns): every rank sends ALL its rows to every rank, the send
+// buffers hold the columns once (no runs): every send starts at offset 0 and a received var-len run's offsets count from 0.
+inline tsq_comm_plan tsq_comm_make_plan(int rank, int world, int n_cols, const int32_t* elem_size, const uint64_t* M, bool broadcast = false) {
     tsq_comm_plan pl;
     int n_var = 0;
     std::vector<int> var_of((size_t)n_cols, -1);
@@ -106,16 +108,16 @@ inline tsq_comm_plan tsq_comm_make_plan(int rank, int world, int n_cols, const i
                 pl.xfers.push_back({i, TSQ_XFER_DATA, p, sb, sby, rb, rby});
                 // on the wire the run's offsets count from the bytes rank p sent to the ranks before this one
                 int64_t first = 0;
-                for (int q = 0; q < rank; q++) first += (int64_t)var_bytes(p, v, q);
+                for (int q = 0; q < rank && !broadcast; q++) first += (int64_t)var_bytes(p, v, q);
                 if (rr) pl.shifts.push_back({i, ro + (uint64_t)p + 1, ro + 1, rr, (int64_t)rb - first});
-                sb += sby;
+                if (!broadcast) sb += sby;
                 rb += rby;
             } else {
                 const uint64_t es = (uint64_t)elem_size[i];
                 pl.xfers.push_back({i, TSQ_XFER_DATA, p, so * es, sr * es, ro * es, rr * es});
             }
             if (nn) pl.xfers.push_back({i, TSQ_XFER_NOTNULL, p, so, sr, ro, rr});
-            so += sr;
+            if (!broadcast) so += sr;
             ro += rr;
         }
         if (v >= 0) pl.recv_bytes[(size_t)i] = (int64_t)rb;

@@ -212,6 +212,15 @@ TSQ_API tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_de
     return TSQ_OK;
 }
 
+TSQ_API tsq_status tsq_copy_d2d(tsq_ctx* ctx, void* dst_dev, const void* src_dev, int64_t bytes) {
+    tsq_ctx_lock _api_lock(ctx);
+    if (!ctx || bytes < 0) return TSQ_ERR_INVALID;
+    if (bytes == 0) return TSQ_OK;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    TSQ_HIP(&ctx->hdr, hipMemcpyAsync(dst_dev, src_dev, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));  // stream ordered, not synchronised
+    return TSQ_OK;
+}
+
 TSQ_API tsq_status tsq_timer_start(tsq_ctx* ctx) {
     tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;

@@ -748,6 +748,7 @@ struct tsq_join {
     bool probe_done = false;
     bool host_mode = true;  // result placement follows the first probe push
     bool general = false;   // needs the GEN kernels (outer join / filters / conditions / selected)
+    bool general_cfg = false;  // ... by its configuration alone (outer join / filters / conditions): what the packed routes ask
     bool count_only = false, checksum = false, ordered = false;
     DevBuf counters;        // 8 x u64 on device
     int64_t total_out = 0;  // emit mode: rows produced so far
@@ -777,6 +778,8 @@ struct tsq_join {
     double da_build_ms = 0;
     // a build side SHARDED over the ranks of a communicator whose packed images were summed across the ranks
     // (tsq_join_build_finish_shared): the handle answers COUNT(*) for LOCAL probe rows, no 64-bit table exists
+    std::vector<uint8_t> used_out;    // per output column: 0 = the parent never reads it (tsq_join_set_used_columns); empty: all are used
+    double last_sampled_hit_ratio = -1.0;  // of the last probe batch whose materialising route was chosen by a sample (k_da_sample)
     int64_t div0_packed = 0;          // division-by-zero warnings of conditions evaluated over materialised batches (da_post_conditions)
     bool shared = false;
     int64_t shared_image_bytes = 0, shared_usable_local = 0;
@@ -918,6 +921,7 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
             const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
             const int sc = oc < nl ? oc : oc - nl;
             const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
+            if (!rb->data[oc].p && !(type == TSQ_BYTES && rb->offs[oc].p)) continue;  // a column the parent does not use: never materialised
             size_t bytes = type == TSQ_BYTES ? (size_t)rb->nbytes[oc] : (size_t)out_rows * tsq_elem_size(type);
             tsq_status s = rb->hdata[oc].reserve(&j->hdr, bytes + 16);
             if (s == TSQ_OK && type == TSQ_BYTES) s = rb->hoffs[oc].reserve(&j->hdr, ((size_t)out_rows + 1) * 8 + 16);
@@ -955,7 +959,7 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
 // AUTO takes it when both the table and the batch are big enough to pay for a partition pass.
 bool radix_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF) return false;
-    if (!j->count_only || j->checksum || j->multi || j->general || selected_dev || j->never_match || j->chained) return false;
+    if (!j->count_only || j->checksum || j->multi || j->general_cfg || j->never_match || j->chained) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE) return true;
     // table slices of ~1.5 MB per partition need >= 8 partitions to be worth it; batch >= 4 Mi rows
@@ -967,7 +971,7 @@ bool radix_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_de
 bool da_multi_ok(const tsq_join* j);
 bool da_multi_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || !j->multi || !da_multi_ok(j) || j->da_state < 0) return false;
-    if (!j->count_only || j->checksum || j->general || selected_dev || j->never_match || j->chained) return false;
+    if (!j->count_only || j->checksum || j->general_cfg || j->never_match || j->chained) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
     return nrows >= (4 << 20);
@@ -1184,9 +1188,10 @@ void da_build_key(const tsq_join* j, DaSrc& src) {
     src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
 }
 // ... and a probe batch's (composed into j->rckey first when the key has several columns)
-tsq_status da_probe_key(tsq_join* j, const tsq_colset& pcs, int64_t nrows, DaSrc& src) {
+tsq_status da_probe_key(tsq_join* j, const tsq_colset& pcs, int64_t nrows, DaSrc& src, const uint8_t* sel = nullptr) {
     memset(&src, 0, sizeof src);
     src.nrows = nrows;
+    src.sel = sel;
     if (!j->da_multi) {
         const int kc = j->ks.pidx[0];
         src.data = (const uint64_t*)pcs.data[kc];
@@ -1480,7 +1485,7 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr) {
     return TSQ_OK;
 }
 
-tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* sel = nullptr) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nrows, 1024 * 16);
@@ -1508,7 +1513,7 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
     DaSrc src;
-    TSQ_TRY(da_probe_key(j, pcs, nrows, src));
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src, sel));
     TSQ_TRY(da_launch_partition(j, src, st));
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     DaProbeArgs pa;
@@ -1548,7 +1553,7 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
 // no OtherConditions, no selected[], not ordered; any number and type of payload columns, NULLs anywhere.
 bool da_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || (j->multi && !da_multi_ok(j)) || j->never_match || j->ordered) return false;
-    if (selected_dev || !j->conds_h.empty() || !j->filters_h.empty()) return false;
+    if (!j->conds_h.empty() || !j->filters_h.empty()) return false;  // (selected[]: the packed kernels treat a row with selected == 0 like a NULL key)
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
     // AUTO: the pairs come out in PARTITION order, so the gather of the probe-side columns is as random as the build side's (the
@@ -1644,7 +1649,7 @@ tsq_status da_prepare_rows(tsq_join* j) {
 template <class F>
 tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows, int64_t out_rows, F&& produce_pairs);
 
-tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows) {
+tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows, const uint8_t* sel = nullptr) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
@@ -1684,7 +1689,7 @@ tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nro
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
     DaSrc src;
-    TSQ_TRY(da_probe_key(j, pcs, nrows, src));
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src, sel));
     TSQ_TRY(da_launch_partition(j, src, st, true, outer));
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     // ---- sizing pass: output rows per partition, their exclusive scan
@@ -1775,7 +1780,7 @@ bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_
     // joined chunk): evaluated on the output batch and compacted (da_post_conditions).  An outer join needs "did ANY match of this
     // outer row pass" — taken here only when no build key repeats (da_unique, known once the images exist: probe_batch checks): an outer row then has
     // at most one candidate, and a candidate that fails the conditions turns into the NULL-padded row (onMissMatch, joiner.go:274-281)
-    if (selected_dev || !j->filters_h.empty()) return false;
+    if (!j->filters_h.empty()) return false;  // (selected[]: the packed kernels treat a row with selected == 0 like a NULL key)
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_cols_state < 0) return false;
     if (j->cfg.n_probe_cols > TSQ_DA_MAXCOLS || j->cfg.n_build_cols > TSQ_DA_MAXCOLS) return false;
     for (int c = 0; c < j->cfg.n_probe_cols; c++)
@@ -2132,7 +2137,7 @@ tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bo
     return TSQ_OK;
 }
 
-tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool* redo) {
+tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool* redo, const uint8_t* sel = nullptr) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
@@ -2188,7 +2193,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));
     DaColSrc src;
     memset(&src, 0, sizeof src);
-    TSQ_TRY(da_probe_key(j, pcs, nrows, src.key));
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src.key, sel));
     src.n_cols = ntrav;
     src.any_nulls = any_nulls ? 1 : 0;
     for (int v = 0; v < ntrav; v++) {
@@ -2628,6 +2633,13 @@ tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, i
         const bool src_nulls = from_probe ? pcs.nulls[sc] != nullptr : j->bcols[sc].has_nulls;
         const bool may_null = src_nulls || (outer && !from_probe);
         may_null_v[oc] = may_null;
+        GatherCol& gc0 = ga.col[oc];
+        if (!j->used_out.empty() && !j->used_out[(size_t)oc]) {  // the parent never reads this column: it is not gathered at all
+            gc0.es = 0;
+            gc0.from_probe = from_probe ? 1 : 0;
+            may_null_v[oc] = false;
+            continue;
+        }
         tsq_status s = type == TSQ_BYTES ? rb->offs[oc].reserve(ctx, &j->hdr, ((size_t)out_rows + 2) * 8 + 16)
                                          : rb->data[oc].reserve(ctx, &j->hdr, ((size_t)out_rows + 8) * tsq_elem_size(type) + 16);
         if (s == TSQ_OK && may_null) s = rb->bitmap[oc].reserve(ctx, &j->hdr, tsq_bitmap_bytes(out_rows) + 16);
@@ -2669,7 +2681,7 @@ tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, i
         const bool from_probe = a.probe_is_left ? oc < nl : oc >= nl;
         const int sc = oc < nl ? oc : oc - nl;
         const int32_t type = from_probe ? j->cfg.probe_types[sc] : j->cfg.build_types[sc];
-        if (type != TSQ_BYTES) continue;
+        if (type != TSQ_BYTES || (!j->used_out.empty() && !j->used_out[(size_t)oc])) continue;
         VarGatherArgs va;
         memset(&va, 0, sizeof va);
         va.pairs = a.pairs;
@@ -2709,6 +2721,32 @@ tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, i
     return deliver_batch(j, std::move(rb), may_null_v);
 }
 
+// hit ratio of a probe batch against the packed images, from a strided sample of its keys (k_da_sample): one small kernel + one sync
+tsq_status da_sample_hit_ratio(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* sel, double* rho) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    DaSampleArgs sa;
+    memset(&sa, 0, sizeof sa);
+    const int kc = j->ks.pidx[0];
+    sa.src.data = (const uint64_t*)pcs.data[kc];
+    sa.src.nulls = pcs.nulls[kc];
+    sa.src.nrows = nrows;
+    sa.src.sel = sel;
+    sa.dm = j->da_dm;
+    sa.img = j->da_img.as<uint8_t>();
+    sa.n_samples = std::min<int64_t>(nrows, 1 << 16);
+    sa.stride = std::max<int64_t>(1, nrows / sa.n_samples);
+    sa.out = (unsigned long long*)(ctx->dscratch + 58);
+    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 58, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_da_sample, dim3((unsigned)((sa.n_samples + 255) / 256)), dim3(256), 0, ctx->stream, sa);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 58, ctx->dscratch + 58, 16, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    j->st.kernel_launches++;
+    *rho = ctx->pinned[59] ? (double)ctx->pinned[58] / (double)ctx->pinned[59] : 0.0;
+    return TSQ_OK;
+}
+
 // run the probe kernels over one device-resident batch described by pcs / selected
 tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
     if (nrows == 0) return TSQ_OK;
@@ -2731,9 +2769,9 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     j->st.probe_rows += nrows;
 
     if (j->shared) {  // the images of a build side sharded over several GPUs: there is no other table to fall back to
-        if (!j->count_only || j->checksum || j->general || selected_dev || nrows > 0x7fffffffLL)
+        if (!j->count_only || j->checksum || j->general_cfg || nrows > 0x7fffffffLL)
             return tsq_fail(&j->hdr, TSQ_ERR_UNSUPPORTED, "a shared build side (tsq_join_build_finish_shared) answers COUNT(*) of an inner join without conditions");
-        return da_probe(j, pcs, nrows);
+        return da_probe(j, pcs, nrows, selected_dev);
     }
     // the 64-bit table may have been left for the first batch that needs it (tsq_join_build_finish: table_can_wait)
     auto need_table = [&]() -> tsq_status {
@@ -2744,13 +2782,34 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     };
     if (radix_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
-        if (j->da_state == 1) return da_probe(j, pcs, nrows);
-        TSQ_TRY(need_table());
-        if (radix_eligible(j, nrows, selected_dev)) return radix_probe(j, pcs, nrows);  // (the real table may be chained / too small)
+        if (j->da_state == 1) return da_probe(j, pcs, nrows, selected_dev);
+        if (!selected_dev) {  // (the 64-bit radix route knows no selected[])
+            TSQ_TRY(need_table());
+            if (radix_eligible(j, nrows, selected_dev)) return radix_probe(j, pcs, nrows);  // (the real table may be chained / too small)
+        }
     }
     if (da_multi_count_eligible(j, nrows, selected_dev)) {  // several integer key columns: the packed route or the direct one
         TSQ_TRY(da_prepare(j));
-        if (j->da_state == 1) return da_probe(j, pcs, nrows);
+        if (j->da_state == 1) return da_probe(j, pcs, nrows, selected_dev);
+    }
+    // ---- materialising packed routes.  Which one: when most probe rows join, the probe columns travel with the entries (K5f + K4e);
+    // a SELECTIVE batch (few rows join: a sample of its keys against the images tells, k_da_sample) is better served by (probe row,
+    // build row) pairs + a gather of the few joined rows (K4d) — moving every column of every row through the partition is waste.
+    const bool forced = j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE;
+    bool prefer_pairs = false;
+    const bool pairs_knob_set = ctx->knob[TSQ_KNOB_DA_PAIRS_BELOW_PERMILLE] != TSQ_KNOB_DEFAULT;  // (tests force either variant with it)
+    if ((!forced || pairs_knob_set) && !j->count_only && !j->da_multi && da_cols_eligible(j, nrows, selected_dev) && j->conds_h.empty()) {
+        TSQ_TRY(da_prepare(j));
+        if (j->da_state == 1 && !j->da_bits) {
+            double rho = 1.0;
+            TSQ_TRY(da_sample_hit_ratio(j, pcs, nrows, selected_dev, &rho));
+            prefer_pairs = rho * 1000.0 < (double)tsq_knob(ctx, TSQ_KNOB_DA_PAIRS_BELOW_PERMILLE, 350);
+            j->last_sampled_hit_ratio = rho;
+        }
+    }
+    if (prefer_pairs) {
+        TSQ_TRY(da_prepare_rows(j));
+        if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows, selected_dev);
     }
     if (da_cols_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
@@ -2759,18 +2818,18 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         if (usable) TSQ_TRY(da_prepare_cols_direct(j));
         if (usable && j->da_cols_state == 1) {
             bool redo = false;
-            TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo));
+            TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo, selected_dev));
             if (!redo) return TSQ_OK;
         }
     }
-    if (radix_emit_eligible(j, pcs, nrows, selected_dev)) {
+    if (!selected_dev && radix_emit_eligible(j, pcs, nrows, selected_dev)) {
         TSQ_TRY(need_table());
         if (radix_emit_eligible(j, pcs, nrows, selected_dev)) return radix_emit(j, pcs, nrows);
     }
     if (da_emit_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
         TSQ_TRY(da_prepare_rows(j));
-        if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows);
+        if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows, selected_dev);
     }
     TSQ_TRY(need_table());
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
@@ -3092,6 +3151,7 @@ TSQ_API tsq_status tsq_join_create(tsq_ctx* ctx, const tsq_join_cfg* cfg, tsq_jo
         if (!j->multi && is_int_class(bt) && bt != pt) ks.skip_high = 1;  // flag 8 vs 9 for cells >= 2^63
     }
     j->general = cfg->join_type != TSQ_JOIN_INNER || cfg->n_other_conds > 0 || cfg->n_outer_filters > 0;
+    j->general_cfg = j->general;
 
     tsq_handle_hdr* h = &j->hdr;
     TSQ_TRY(j->counters.reserve(ctx, h, 64));
@@ -3336,6 +3396,16 @@ TSQ_API tsq_status tsq_join_set_count_only(tsq_join* j, int32_t on) {
     if (!j->count_only) j->checksum = false;
     return TSQ_OK;
 }
+// Inline projection of the join's output (the planner's column pruning: a parent that reads 5 of 10 joined columns): the routes that
+// gather the output through (probe row, build row) pairs skip the unused columns entirely; tsq_join_pull leaves them untouched.
+TSQ_API tsq_status tsq_join_set_used_columns(tsq_join* j, const uint8_t* used, int32_t n_cols) {
+    if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
+    if (j->st.probe_rows > 0 || j->stage.staged > 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "the used columns must be chosen before the first probe row");
+    if (!used) { j->used_out.clear(); return TSQ_OK; }
+    if (n_cols != j->cfg.n_probe_cols + j->cfg.n_build_cols) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "tsq_join_set_used_columns: one flag per output column (left child's, then right child's)");
+    j->used_out.assign(used, used + n_cols);
+    return TSQ_OK;
+}
 TSQ_API tsq_status tsq_join_set_ordered(tsq_join* j, int32_t on) {
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
     if (j->st.probe_rows > 0 || j->stage.staged > 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "ordered output must be chosen before the first probe row");
@@ -3452,8 +3522,21 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
         const int es = tsq_elem_size(type);
         tsq_col& o = out_cols[oc];
         const bool odev = o.flags & TSQ_COL_DEVICE;
-        if (!o.data) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: out column data == NULL");
         const bool has_bm = rb->on_host ? rb->hbitmap[oc].p != nullptr : rb->bitmap[oc].p != nullptr;
+        if ((o.flags & TSQ_COL_BORROW) && odev && !rb->on_host && type != TSQ_BYTES) {  // pointers into the result batch: no copy
+            if ((rb->cursor & 7) != 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "device pull: cap_rows must keep the cursor a multiple of 8");
+            o.data = rb->data[oc].p ? (char*)rb->data[oc].p + (size_t)rb->cursor * es : nullptr;  // (nullptr: a column the parent does not use)
+            o.null_bitmap = has_bm ? rb->bitmap[oc].as<uint8_t>() + (rb->cursor >> 3) : nullptr;
+            o.length = n;
+            o.type = type;
+            o.elem_size = es;
+            continue;
+        }
+        if (!j->used_out.empty() && !j->used_out[(size_t)oc]) {  // not materialised (tsq_join_set_used_columns): nothing to copy
+            o.length = n;
+            continue;
+        }
+        if (!o.data) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: out column data == NULL");
         if (type == TSQ_BYTES && !o.offsets) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "pull: var-len out column needs an offsets buffer (tsq_join_peek tells the data bytes)");
         if (rb->on_host && !odev) {
             if (type == TSQ_BYTES) {  // cells [cursor, cursor + n): their bytes, and the offsets moved to start at 0

@@ -108,8 +108,10 @@ class DeviceColumn:
 
 
 class DeviceChunk:
-    def __init__(self, columns, nrows):
-        self.columns, self.nrows = list(columns), nrows
+    def __init__(self, columns, nrows, sel=None):
+        # sel: device pointer to one byte per row, 0 = the row was filtered out (Chunk.sel of the reference is a selection VECTOR,
+        # util/chunk/chunk.go:31-46; a flag per row is its device form).  Only operators that say so accept a chunk with sel.
+        self.columns, self.nrows, self.sel = list(columns), nrows, sel
 
     def NumRows(self):
         return self.nrows
@@ -129,20 +131,21 @@ class DeviceChunk:
 
     @staticmethod
     def from_host(ctx, chunk):
+        """a host chunk copied to HBM; a column without a NOT-NULL array (a NOT NULL column) gets no null bitmap"""
         cols = []
         for c in chunk.columns:
-            nn = np.ones(len(c), bool) if c.notnull is None else c.notnull
+            has_nulls = c.notnull is not None
             if c.tp == abi.BYTES:
                 nb = int(c.offsets[-1]) if len(c.offsets) else 0
-                d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=True, cap_bytes=nb)
+                d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=has_nulls, cap_bytes=nb)
                 if nb:
                     ctx.h2d(d.data, np.ascontiguousarray(c.data[:nb]))
                 ctx.h2d(d.offsets, np.ascontiguousarray(c.offsets))
             else:
-                d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=True)
+                d = DeviceColumn(ctx, c.tp, len(c), with_bitmap=has_nulls)
                 ctx.h2d(d.data, np.ascontiguousarray(c.data))
-            if len(c):
-                ctx.h2d(d.bitmap, np.packbits(nn, bitorder="little"))
+            if len(c) and has_nulls:
+                ctx.h2d(d.bitmap, np.packbits(c.notnull, bitorder="little"))
             cols.append(d)
         return DeviceChunk(cols, chunk.NumRows())
 
@@ -216,9 +219,11 @@ class DeviceTableScan(GpuExecutor):
 
 
 class GpuSelectionExec(GpuExecutor):
-    def __init__(self, ctx, child, filters, jit=None):
+    def __init__(self, ctx, child, filters, jit=None, compact=True):
+        """compact=False: the chunk is handed on UNCOMPACTED with its selection flags (DeviceChunk.sel) — for a parent that takes them
+        (GpuHashJoinExec's probe side: tsq_join_probe_push(selected)): the filtered rows are never copied."""
         super().__init__(ctx, child.Schema(), (child,))
-        self.child, self.filters, self.jit = child, list(filters), jit
+        self.child, self.filters, self.jit, self.compact = child, list(filters), jit, compact
         self.expr, self.out, self.flags, self.cap = None, None, None, 0
 
     def Open(self):
@@ -234,13 +239,15 @@ class GpuSelectionExec(GpuExecutor):
             if n > self.cap:
                 self._release()
                 self.cap = n
-                self.out = self._buffers(n)
+                self.out = self._buffers(n) if self.compact else []
                 self.flags = self.ctx.alloc(n + 64)
-            for src, dst in zip(chk.columns, self.out):  # a selection never grows a var-len column
-                dst.ensure_bytes(src.nbytes(n))
             w = C.c_int64(0)
             _lib.check(self.lib.tsq_filter_eval(self.expr.h, chk.cols(), len(chk.columns), n, None, self.flags, None, C.byref(w)), self.expr.h)
             self.expr.warnings += w.value
+            if not self.compact:
+                return DeviceChunk(chk.columns, n, sel=self.flags)
+            for src, dst in zip(chk.columns, self.out):  # a selection never grows a var-len column
+                dst.ensure_bytes(src.nbytes(n))
             oc = (abi.Col * len(self.out))(*[c.col(n) for c in self.out])
             m = C.c_int64(0)
             _lib.check(self.lib.tsq_chunk_compact(self.ctx.h, chk.cols(), len(chk.columns), n, self.flags, oc, C.byref(m)), self.ctx.h)
@@ -251,6 +258,7 @@ class GpuSelectionExec(GpuExecutor):
         if self.out:
             for c in self.out:
                 c.free()
+        if self.flags:
             self.ctx.free(self.flags)
         self.out, self.flags, self.cap = None, None, 0
 
@@ -320,8 +328,11 @@ class GpuProjectionExec(GpuExecutor):
 
 
 class GpuHashJoinExec(GpuExecutor):
-    def __init__(self, ctx, left, right, left_keys, right_keys, join_type=abi.JOIN_INNER, inner_child_idx=1, pull_rows=1 << 24):
+    def __init__(self, ctx, left, right, left_keys, right_keys, join_type=abi.JOIN_INNER, inner_child_idx=1, pull_rows=1 << 24, used=None):
+        """used: the output columns (indices into left's + right's columns) the parent reads — the planner's column pruning
+        (tsq_join_set_used_columns); the others are not materialised and come out as columns without data."""
         super().__init__(ctx, left.Schema() + right.Schema(), (left, right))
+        self.used = None if used is None else sorted(set(used))
         self.build_is_right = inner_child_idx == 1
         self.build = right if self.build_is_right else left
         self.probe = left if self.build_is_right else right
@@ -346,7 +357,13 @@ class GpuHashJoinExec(GpuExecutor):
         h = C.c_void_p()
         _lib.check(self.lib.tsq_join_create(self.ctx.h, C.byref(self.cfg), C.byref(h)), self.ctx.h)
         self.h, self.prepared = h, False
-        self.out = self._buffers(self.pull_rows)
+        if self.used is not None:
+            flags = (C.c_uint8 * len(self.types))(*[1 if i in self.used else 0 for i in range(len(self.types))])
+            _lib.check(self.lib.tsq_join_set_used_columns(h, flags, len(self.types)), h)
+        # fixed-width outputs are BORROWED from the operator's result batch (TSQ_COL_BORROW: pointers valid until the next pull) — the
+        # device form of Chunk.SwapColumns; a var-len output column keeps the copying pull
+        self.borrow = abi.BYTES not in self.types
+        self.out = None if self.borrow else self._buffers(self.pull_rows)
 
     def Next(self):
         if not self.prepared:
@@ -359,18 +376,31 @@ class GpuHashJoinExec(GpuExecutor):
             self.prepared = True
         n, eos = C.c_int64(0), C.c_int32(0)
         while True:
-            self._size_varlen(self.lib.tsq_join_peek, self.h, self.out, self.pull_rows)
-            oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
-            _lib.check(self.lib.tsq_join_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
-            if n.value > 0:
-                return DeviceChunk(self.out, n.value)
+            if self.borrow:
+                oc = (abi.Col * len(self.types))()
+                for i, t in enumerate(self.types):
+                    oc[i].type, oc[i].elem_size, oc[i].flags = t, _es(t), abi.COL_DEVICE | abi.COL_BORROW
+                _lib.check(self.lib.tsq_join_pull(self.h, oc, len(self.types), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
+                if n.value > 0:
+                    # a column the parent does not use has no data: it aliases a materialised column's buffer so that a consumer which
+                    # passes whole chunks on (it never reads the cells) still hands out valid pointers
+                    alias = next(oc[i].data for i in range(len(self.types)) if oc[i].data)
+                    cols = [DeviceColumn(self.ctx, t, n.value, data=oc[i].data or alias, bitmap=oc[i].null_bitmap if oc[i].data else None) for i, t in enumerate(self.types)]
+                    return DeviceChunk(cols, n.value)
+            else:
+                self._size_varlen(self.lib.tsq_join_peek, self.h, self.out, self.pull_rows)
+                oc = (abi.Col * len(self.out))(*[c.col(self.pull_rows) for c in self.out])
+                _lib.check(self.lib.tsq_join_pull(self.h, oc, len(self.out), self.pull_rows, C.byref(n), C.byref(eos)), self.h)
+                if n.value > 0:
+                    return DeviceChunk(self.out, n.value)
             if eos.value:
                 return EOS
             chk = self.probe.Next()
             if chk.NumRows() == 0:
                 _lib.check(self.lib.tsq_join_probe_finish(self.h), self.h)
                 continue
-            _lib.check(self.lib.tsq_join_probe_push(self.h, chk.cols(), len(chk.columns), chk.NumRows(), None), self.h)
+            # a probe-side chunk may carry selection flags (GpuSelectionExec(compact=False)): the join takes them as `selected`
+            _lib.check(self.lib.tsq_join_probe_push(self.h, chk.cols(), len(chk.columns), chk.NumRows(), C.c_void_p(chk.sel) if chk.sel else None), self.h)
 
     def Close(self):
         if self.h:

@@ -130,6 +130,11 @@ class Comm:
     def wait(self, slot=0):
         _lib.check(self.lib.tsq_redistribute_wait(self.h, slot), self.h)
 
+    def allgather(self, cols, nrows, slot=0):
+        """every rank receives every rank's rows, in rank order (tsq_redistribute with TSQ_KEYMODE_BROADCAST): the small side of a
+        broadcast join.  Returns (received abi.Col array, total rows); wait(slot) before the consumer is queued."""
+        return self.redistribute(cols, 0, abi.KEYMODE_BROADCAST, nrows, slot)
+
 
 def col_slice(col, lo, hi):
     """rows [lo, hi) of a device-resident fixed-width column (lo a multiple of 8 when the column has a null bitmap)"""
@@ -342,3 +347,151 @@ def dist_hash_agg(comm, partial_cfg, final_cfg, cols, nrows, partial_types, key_
             for p in b[:3]:
                 ctx.free(p)
     return out_bufs, n_out
+
+
+# ====================================================================== distributed operator plans on device-resident executors
+from . import gpu_pipeline as G  # noqa: E402
+
+
+class _Collected(G.GpuExecutor):
+    """helper: drains a child into ONE device chunk (owned buffers); the exchange executors hand that chunk to the communicator"""
+
+    def __init__(self, ctx, child):
+        super().__init__(ctx, child.Schema(), (child,))
+        self.child, self.buf, self.n, self.cap = child, None, 0, 0
+
+    def collect(self):
+        parts, total = [], 0
+        while True:
+            chk = self.child.Next()
+            if chk.NumRows() == 0:
+                break
+            # the child's buffers are reused by its next Next(): copy the batch (device to device, on the context's stream)
+            m = chk.NumRows()
+            cols = [G.DeviceColumn(self.ctx, t, m) for t in self.types]
+            for src, dst in zip(chk.columns, cols):
+                assert not src.var, "the exchange executors of the distributed plans move fixed-width columns"
+                _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.data, src.data, m * G._es(src.tp)), self.ctx.h)
+                if src.bitmap is not None:
+                    _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.bitmap, src.bitmap, (m + 7) // 8), self.ctx.h)
+                else:
+                    self.ctx.memset(dst.bitmap, 0xFF, (m + 7) // 8)
+            parts.append((cols, m))
+            total += m
+        if len(parts) == 1:
+            return parts[0][0], total
+        out = [G.DeviceColumn(self.ctx, t, max(total, 1) + 64) for t in self.types]
+        at = 0
+        for cols, m in parts:  # batches are multiples of 8 rows except the last one of a child: bitmaps concatenate byte-wise
+            assert at % 8 == 0, "a child handed out a batch that is not a multiple of 8 rows before its last one"
+            for src, dst in zip(cols, out):
+                _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.data + at * G._es(src.tp), src.data, m * G._es(src.tp)), self.ctx.h)
+                _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.bitmap + at // 8, src.bitmap, (m + 7) // 8), self.ctx.h)
+            at += m
+        self.ctx.sync()
+        for cols, _ in parts:
+            for c in cols:
+                c.free()
+        return out, total
+
+
+class GpuBroadcastExec(_Collected):
+    """all-gather of the child's rows: every rank's Next() returns the rows of ALL ranks (one chunk).  The small side of a broadcast
+    join — a filtered dimension table, the result of an earlier join — goes to every GPU once; the big side is never moved."""
+
+    def __init__(self, ctx, comm, child, slot=0):
+        super().__init__(ctx, child)
+        self.comm, self.slot, self.done, self.mine = comm, slot, False, None
+
+    def Open(self):
+        super().Open()
+        self.done = False
+
+    def Next(self):
+        if self.done:
+            return G.EOS
+        self.done = True
+        self.mine, n = self.collect()
+        got, total = self.comm.allgather([c.col(n) for c in self.mine], n, slot=self.slot)
+        self.comm.wait(self.slot)
+        self.wire_bytes = (total - n) * sum(G._es(t) for t in self.types)  # received from the other ranks
+        if total == 0:
+            return G.EOS
+        cols = [G.DeviceColumn(self.ctx, t, total, data=g.data, bitmap=g.null_bitmap) for t, g in zip(self.types, got)]
+        return G.DeviceChunk(cols, total)
+
+    def Close(self):
+        if self.mine:
+            for c in self.mine:
+                c.free()
+            self.mine = None
+        super().Close()
+
+
+class GpuShuffleExec(_Collected):
+    """hash-radix redistribute of the child's rows by rank(key column): shuffleIntermData (executor/aggregate.go:352-356) across GPUs.
+    key_mode 1: group-key equality (partial aggregate rows meet their group's owner), 0: join-key equality."""
+
+    def __init__(self, ctx, comm, child, key_col, key_mode=1, slot=1):
+        super().__init__(ctx, child)
+        self.comm, self.key_col, self.key_mode, self.slot, self.done, self.mine = comm, key_col, key_mode, slot, False, None
+
+    def Open(self):
+        super().Open()
+        self.done = False
+
+    def Next(self):
+        if self.done:
+            return G.EOS
+        self.done = True
+        self.mine, n = self.collect()
+        got, total = self.comm.redistribute([c.col(n) for c in self.mine], self.key_col, self.key_mode, n, slot=self.slot)
+        self.comm.wait(self.slot)
+        self.wire_bytes = n * sum(G._es(t) for t in self.types) * (self.comm.world - 1) // self.comm.world
+        if total == 0:
+            return G.EOS
+        cols = [G.DeviceColumn(self.ctx, t, total, data=g.data, bitmap=g.null_bitmap) for t, g in zip(self.types, got)]
+        return G.DeviceChunk(cols, total)
+
+    def Close(self):
+        if self.mine:
+            for c in self.mine:
+                c.free()
+            self.mine = None
+        super().Close()
+
+
+def dist_q3_plan(ctx, comm, customer_d, orders_d, lineitem_d, seg, day, batch_rows=1 << 24, jit=None):
+    """BASELINE configs[4]: the TPC-H Q3-shaped query over tables ROW-SHARDED across the ranks of `comm` (every rank holds 1 / N of
+    customer, orders and lineitem, in any order).  The plan moves only what is small:
+
+        customer' = Broadcast( Selection(customer_r, c_mktsegment = seg) -> c_custkey )              all-gather: 3e6 x 8 B at SF 100
+        orders'   = Broadcast( Join(Selection(orders_r, o_orderdate < day), customer') -> 3 columns )  all-gather: 1.5e7 x 24 B
+        partial   = HashAgg_partial( Projection( Join(Selection(lineitem_r, l_shipdate > day), orders') ) )   lineitem never moves
+        result    = HashAgg_final( Shuffle(partial, by l_orderkey) )                                   partial groups: <= 3.1e7 x 32 B / N per rank
+
+    — the reference's shapes: a hash join whose build side is complete before the probe starts (executor/join.go:233-239: every
+    worker sees the whole build side), and HashAggExec's partial -> shuffle -> final (executor/aggregate.go:96-133, 352-356).
+    Every rank returns the groups it owns (rank(l_orderkey)); the union over the ranks is the query's result.
+    Returns (root executor, [join executors], [exchange executors])."""
+    from . import expression as E
+    from .executor import AggFuncDesc
+    F, Col, K = E.ScalarFunction, E.Column, E.Constant
+    I, R = abi.I64, abi.F64
+    cust = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, I), K(seg))], jit=jit)
+    cust_all = GpuBroadcastExec(ctx, comm, G.GpuProjectionExec(ctx, cust, [Col(0, I)], jit=jit), slot=0)
+    ords = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, orders_d, batch_rows), [F("lt", Col(2, I), K(day))], jit=jit)
+    # orders_r (probe: o_orderkey, o_custkey, o_orderdate, o_shippriority) JOIN customer' (build: c_custkey)
+    j1 = G.GpuHashJoinExec(ctx, ords, cust_all, [1], [0], abi.JOIN_INNER, 1)
+    ords_all = GpuBroadcastExec(ctx, comm, G.GpuProjectionExec(ctx, j1, [Col(0, I), Col(2, I), Col(3, I)], jit=jit), slot=1)
+    line = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, lineitem_d, batch_rows), [F("gt", Col(1, I), K(day))], jit=jit)
+    # lineitem_r (probe: l_orderkey, l_shipdate, price, disc) JOIN orders' (build: o_orderkey, o_orderdate, o_shippriority)
+    j2 = G.GpuHashJoinExec(ctx, line, ords_all, [0], [0], abi.JOIN_INNER, 1)
+    proj = G.GpuProjectionExec(ctx, j2, [Col(0, I), Col(5, I), Col(6, I), F("mul", Col(2, R), F("minus", K(1.0), Col(3, R)))], jit=jit)
+    P1, FIN = abi.MODE_PARTIAL1, abi.MODE_FINAL
+    partial = G.GpuHashAggExec(ctx, proj, [0, 1, 2], [AggFuncDesc(abi.AGG_FIRSTROW, 0, I, P1), AggFuncDesc(abi.AGG_FIRSTROW, 1, I, P1),
+                                                       AggFuncDesc(abi.AGG_FIRSTROW, 2, I, P1), AggFuncDesc(abi.AGG_SUM, 3, R, P1)])
+    shuffled = GpuShuffleExec(ctx, comm, partial, 0, key_mode=1, slot=2)
+    final = G.GpuHashAggExec(ctx, shuffled, [0, 1, 2], [AggFuncDesc(abi.AGG_FIRSTROW, 0, I, FIN), AggFuncDesc(abi.AGG_FIRSTROW, 1, I, FIN),
+                                                        AggFuncDesc(abi.AGG_FIRSTROW, 2, I, FIN), AggFuncDesc(abi.AGG_SUM, 3, R, FIN)])
+    return final, [j1, j2], [cust_all, ords_all, shuffled]

@@ -81,31 +81,35 @@ static int run_case(const char* name, uint32_t b, uint32_t pb, const std::vector
     return (missing || extra) ? 1 : 0;
 }
 
-int main() {
-    int bad = 0;
-    std::mt19937_64 rng(7);
-    for (int64_t n : {16384LL, 49153LL, 82020LL, 9830477LL}) {
-        for (int hot : {0, 1}) {
-            for (uint32_t b : {20u, 27u, 28u, 30u}) {
-                const uint64_t span = (1ull << b) - 3;
-                std::vector<uint64_t> keys((size_t)n);
-                for (auto& k : keys) k = 1000 + rng() % span;
-                if (hot)
-                    for (int64_t i = 0; i < std::min<int64_t>(n, 40 * 16384); i++)
-                        if (rng() % 10 < 6) keys[(size_t)i] = 1000 + 12345 % span;
-                const uint32_t pb = std::min(11u, b - 10u) < b - (b > 28 ? 20u : 17u) ? b - (b > 28 ? 20u : 17u) : std::min(11u, b - 10u);
-                char name[96];
-                snprintf(name, sizeof name, "n=%lld hot=%d b=%u", (long long)n, hot, b);
-                if (b - pb <= 16) {
-                    bad += run_case<uint16_t, 1>(name, b, pb, keys, nullptr, 1000, span - 1);
-                    bad += run_case<uint16_t, 2>(name, b, pb, keys, nullptr, 1000, span - 1);
-                } else {
-                    bad += run_case<uint32_t, 1>(name, b, pb, keys, nullptr, 1000, span - 1);
-                    bad += run_case<uint32_t, 2>(name, b, pb, keys, nullptr, 1000, span - 1);
-                }
-            }
-        }
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    // usage: partition_check N HOT B VARIANT — one case per process (a fault must not hide the other cases); no arguments: the list
+    if (argc < 5) {
+        for (long long n : {16384LL, 49153LL, 82020LL, 9830477LL})
+            for (int hot : {0, 1})
+                for (unsigned b : {20u, 27u, 28u, 30u})
+                    for (int var : {1, 2}) printf("%lld %d %u %d\n", n, hot, b, var);
+        return 0;
     }
-    printf("%s (%d mismatching runs)\n", bad ? "FAILED" : "ALL OK", bad);
-    return bad ? 1 : 0;
+    const int64_t n = atoll(argv[1]);
+    const int hot = atoi(argv[2]);
+    const uint32_t b = (uint32_t)atoi(argv[3]);
+    const int var = atoi(argv[4]);
+    std::mt19937_64 rng(7 + (uint64_t)n + b);
+    const uint64_t span = (1ull << b) - 3;
+    std::vector<uint64_t> keys((size_t)n);
+    for (auto& k : keys) k = 1000 + rng() % span;
+    if (hot)
+        for (int64_t i = 0; i < std::min<int64_t>(n, 40 * 16384); i++)
+            if (rng() % 10 < 6) keys[(size_t)i] = 1000 + 12345 % span;
+    const uint32_t max_e = b > 28 ? 20u : 17u;
+    uint32_t pb = std::min(11u, b - 10u);
+    if (pb + max_e < b) pb = b - max_e;
+    char name[96];
+    snprintf(name, sizeof name, "n=%lld hot=%d b=%u", (long long)n, hot, b);
+    printf("case %s var %d: pb %u ebits %u\n", name, var, pb, b - pb);
+    int bad;
+    if (b - pb <= 16) bad = var == 1 ? run_case<uint16_t, 1>(name, b, pb, keys, nullptr, 1000, span - 1) : run_case<uint16_t, 2>(name, b, pb, keys, nullptr, 1000, span - 1);
+    else bad = var == 1 ? run_case<uint32_t, 1>(name, b, pb, keys, nullptr, 1000, span - 1) : run_case<uint32_t, 2>(name, b, pb, keys, nullptr, 1000, span - 1);
+    return bad;
 }

@@ -47,10 +47,12 @@ def tables(sf, seed=7, string_segment=False):
     return customer, orders, lineitem
 
 
-def tables_device(ctx, sf, seed=7):
+def tables_device(ctx, sf, seed=7, rank=0, world=1):
     """the same shapes generated in HBM (tsq_gen_column: counter-based splitmix64) — SF 100 is 24 GB of
-    columns that never cross PCIe.  o_orderkey is a bijection of [0, N_orders); prices / discounts are uniform in [0, 1)."""
+    columns that never cross PCIe.  o_orderkey is a bijection of [0, N_orders); prices / discounts are uniform in [0, 1).
+    world > 1: this rank's 1 / world of the rows of every table (rows [rank n / world, (rank + 1) n / world) of the same generators)."""
     nc, no, nl = int(150_000 * sf), int(1_500_000 * sf), int(6_000_000 * sf)
+    share = lambda n: (n * rank // world, n * (rank + 1) // world)  # noqa: E731
 
     def spec(kind, table, col, **kw):
         g = abi.GenSpec()
@@ -59,12 +61,15 @@ def tables_device(ctx, sf, seed=7):
             setattr(g, k, v)
         return g
 
-    def table(n, specs, types):
+    def table(n_all, specs, types):
+        lo, hi = share(n_all)
+        n = hi - lo
         cols = []
         for sp, tp in zip(specs, types):
-            c = G.DeviceColumn(ctx, tp, n)
-            ctx.gen_column(sp, n, c.data)
-            ctx.memset(c.bitmap, 0xFF, (n + 7) // 8)
+            c = G.DeviceColumn(ctx, tp, max(n, 1), with_bitmap=False)  # TPC-H columns are NOT NULL (mysql.NotNullFlag): no null bitmap
+            sp.start = lo
+            if n:
+                ctx.gen_column(sp, n, c.data)
             cols.append(c)
         return G.DeviceChunk(cols, n)
 
@@ -81,24 +86,32 @@ JOINS = []  # the two join operators of the last plan (their route statistics ar
 ROUTES = {0: "direct", 1: "radix, slices through L2", 2: "radix, 64-bit LDS images", 3: "packed keys"}
 
 
-def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 24, jit=None, topn=0, string_segment=False):
+def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 27, jit=None, topn=0, string_segment=False, classic=False):
+    """classic=True: round 3's plan (compacting selections, every join column materialised, 16 Mi-row batches) for comparison.
+    Default (round 4): what the planner's column pruning and TiDB-style inline projection give — the probe-side selections hand their
+    selection flags to the join instead of compacting (Chunk.sel), the joins materialise only the columns their parent reads
+    (tsq_join_set_used_columns), batches of 128 Mi rows, the aggregate is told the expected number of groups."""
     F, Col, K = E.ScalarFunction, E.Column, E.Constant
+    if classic:
+        batch_rows = min(batch_rows, 1 << 24)
+    fuse = not classic
     if string_segment:  # WHERE c_mktsegment = 'BUILDING' on the varchar column; the join below only needs c_custkey (column pruning)
         sel = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, abi.BYTES), K(SEGMENTS[SEG]))], jit=jit)
         cust = G.GpuProjectionExec(ctx, sel, [Col(0, I), Col(0, I)], jit=jit)  # (two columns so that the join's output keeps its column numbers)
     else:
         cust = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, customer_d, batch_rows), [F("eq", Col(1, I), K(SEG))], jit=jit)
-    ords = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, orders_d, batch_rows), [F("lt", Col(2, I), K(D))], jit=jit)
+    ords = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, orders_d, batch_rows), [F("lt", Col(2, I), K(D))], jit=jit, compact=not fuse)
     # orders (probe, left) JOIN customer (build, right) ON o_custkey = c_custkey  ->  o_orderkey,o_custkey,o_orderdate,o_shippriority,c_custkey,c_mktsegment
-    j1 = G.GpuHashJoinExec(ctx, ords, cust, [1], [0], abi.JOIN_INNER, 1)
+    j1 = G.GpuHashJoinExec(ctx, ords, cust, [1], [0], abi.JOIN_INNER, 1, used=None if classic else [0, 2, 3])
     JOINS[:] = [j1]
-    line = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, lineitem_d, batch_rows), [F("gt", Col(1, I), K(D))], jit=jit)
+    line = G.GpuSelectionExec(ctx, G.DeviceTableScan(ctx, lineitem_d, batch_rows), [F("gt", Col(1, I), K(D))], jit=jit, compact=not fuse)
     # lineitem (probe, left) JOIN j1 (build, right) ON l_orderkey = o_orderkey -> l_orderkey,l_shipdate,price,disc | o_orderkey,o_custkey,o_orderdate,o_shippriority,c_*,c_*
-    j2 = G.GpuHashJoinExec(ctx, line, j1, [0], [0], abi.JOIN_INNER, 1)
+    j2 = G.GpuHashJoinExec(ctx, line, j1, [0], [0], abi.JOIN_INNER, 1, used=None if classic else [0, 2, 3, 6, 7])
     JOINS.append(j2)
     proj = G.GpuProjectionExec(ctx, j2, [Col(0, I), Col(6, I), Col(7, I), F("mul", Col(2, R), F("minus", K(1.0), Col(3, R)))], jit=jit)
     aggs = [AggFuncDesc(abi.AGG_FIRSTROW, 0, I), AggFuncDesc(abi.AGG_FIRSTROW, 1, I), AggFuncDesc(abi.AGG_FIRSTROW, 2, I), AggFuncDesc(abi.AGG_SUM, 3, R)]
-    agg = G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs)
+    # est_groups: the planner's cardinality estimate of the GROUP BY (here: the qualifying orders, at most a tenth of the order table)
+    agg = G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs, est_groups=0 if classic else orders_d.NumRows() // 8)
     if not topn:
         return agg
     # ... ORDER BY revenue DESC, o_orderdate LIMIT topn (TopNExec, executor/sort.go:146-318); agg output: orderkey, date, prio, revenue
@@ -147,7 +160,82 @@ class TimedLib:
         return wrapped
 
 
+def main_dist():
+    """q3.py SF --dist [--device-gen]: the distributed plan (tinysql_amd/parallel.py: dist_q3_plan), one process per GPU
+    (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as torch.distributed.run sets them; a single process runs world size 1)."""
+    from tinysql_amd import parallel
+    sys.argv.remove("--dist")
+    on_device = "--device-gen" in sys.argv
+    if on_device:
+        sys.argv.remove("--device-gen")
+    sf = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    real_stdout = os.dup(1)  # (RCCL prints its version on stdout: keep the JSON line alone there)
+    os.dup2(2, 1)
+    with _lib.Context(local) as ctx:
+        comm = parallel.Comm(ctx, rank, world)
+        t0 = time.time()
+        if on_device:
+            dev = list(tables_device(ctx, sf, rank=rank, world=world))
+            full = None
+        else:
+            full = tables(sf)
+            dev = [G.DeviceChunk.from_host(ctx, t.slice(t.NumRows() * rank // world, t.NumRows() * (rank + 1) // world)) for t in full]
+        ctx.sync()
+        gen_s = time.time() - t0
+        try:
+            best, groups, wire = 1e30, 0, []
+            for rep in range(4):
+                exe, joins, xch = parallel.dist_q3_plan(ctx, comm, *dev, seg=SEG, day=D)
+                ctx.sync()
+                comm.barrier()
+                t1 = time.perf_counter()
+                exe.Open()
+                out = []
+                try:
+                    while True:
+                        chk = exe.Next()
+                        if chk.NumRows() == 0:
+                            break
+                        out.append(chk.to_host() if full is not None else chk.NumRows())
+                finally:
+                    wire = [int(getattr(x, "wire_bytes", 0)) for x in xch]
+                    exe.Close()
+                ctx.sync()
+                dt = comm.allreduce_f64([time.perf_counter() - t1], parallel.Comm.MAX)[0]
+                best = min(best, dt)
+                mine = sum(c.NumRows() if full is not None else c for c in out)
+                groups = comm.allreduce_i64([mine])[0]
+            ok = None
+            if full is not None:  # the groups this rank owns are groups of the whole query, with its sums; the ranks' groups add up
+                uk, ud, up, us = reference(*full)
+                want = {int(k): (int(d), int(p), float(v)) for k, d, p, v in zip(uk, ud, up, us)}
+                ok = groups == len(want)
+                for c in out:
+                    k, d, p, v = (col.data for col in c.columns)
+                    for i in range(c.NumRows()):
+                        w = want.get(int(k[i]))
+                        ok = ok and w is not None and w[0] == int(d[i]) and w[1] == int(p[i]) and abs(w[2] - float(v[i])) <= 1e-9 * max(1.0, abs(w[2]))
+            rows_in = int(150_000 * sf) + int(1_500_000 * sf) + int(6_000_000 * sf)
+            line = {"query": "TPC-H Q3-shaped, DISTRIBUTED: tables row-sharded over %d rank(s); broadcast(customer') -> join -> broadcast(orders') -> join -> partial agg -> shuffle -> final agg" % world,
+                    "SF": sf, "n_gpus": world, "input_rows": rows_in, "groups": int(groups), "best_s": best, "input_rows_per_s": rows_in / best,
+                    "verified_against_numpy": ok, "table_gen_s": gen_s,
+                    "wire_bytes_this_rank": {"broadcast_customer": wire[0], "broadcast_orders": wire[1], "shuffle_partial_groups": wire[2]} if len(wire) == 3 else None}
+        finally:
+            for d in dev:
+                d.free()
+            comm.close()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if rank == 0:
+        print(json.dumps(line))
+    if ok is False:
+        sys.exit("q3 --dist: result differs from the numpy restatement")
+
+
 def main():
+    if "--dist" in sys.argv:
+        return main_dist()
     trace = "--trace" in sys.argv
     if trace:
         sys.argv.remove("--trace")
@@ -157,6 +245,9 @@ def main():
     on_device = "--device-gen" in sys.argv
     if on_device:
         sys.argv.remove("--device-gen")
+    classic = "--classic" in sys.argv
+    if classic:
+        sys.argv.remove("--classic")
     strseg = "--string-segment" in sys.argv
     if strseg:
         sys.argv.remove("--string-segment")
@@ -179,7 +270,7 @@ def main():
             for rep in range(4):
                 if trace and rep == 3:
                     ctx.lib = TimedLib(ctx.lib)
-                exe = plan(ctx, *dev, topn=topn, string_segment=strseg)
+                exe = plan(ctx, *dev, topn=topn, string_segment=strseg, classic=classic)
                 ctx.sync()
                 t1 = time.perf_counter()
                 exe.Open()
@@ -205,7 +296,8 @@ def main():
                     print("%-28s %5d calls %9.3f ms" % (k, n, t * 1e3), file=sys.stderr)
                 print("last rep: total %.3f ms, in Next %.3f ms" % (dt * 1e3, t_exec * 1e3), file=sys.stderr)
             rows_in = customer.NumRows() + orders.NumRows() + lineitem.NumRows()
-            print(json.dumps({"query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg" + ("->TopN(10)" if topn else "") + (", c_mktsegment = 'BUILDING' on a varchar column" if strseg else ""), "SF": sf, "input_rows": rows_in,
+            print(json.dumps({"plan": "round 3 (compacting selections, all join columns, 16 Mi-row batches)" if classic else "round 4 (selection flags into the joins, used columns only, 128 Mi-row batches)",
+                              "query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg" + ("->TopN(10)" if topn else "") + (", c_mktsegment = 'BUILDING' on a varchar column" if strseg else ""), "SF": sf, "input_rows": rows_in,
                               "tables": "generated in HBM (tsq_gen_column)" if on_device else "numpy, copied to HBM once",
                               "groups": groups, "best_s": best, "exec_s_result_in_hbm": best_exec, "input_rows_per_s": rows_in / best,
                               "input_rows_per_s_result_in_hbm": rows_in / best_exec, "host_table_gen_s": gen_s,
