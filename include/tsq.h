@@ -107,7 +107,7 @@ tsq_status tsq_ctx_reserve(tsq_ctx* ctx, int64_t bytes);
 #define TSQ_KNOB_DEFAULT INT64_MIN
 enum {
     TSQ_KNOB_PACKED_KEYS = 0,        /* 0: no packed-key routes (join and aggregate) */
-    TSQ_KNOB_DA_MIN_BUILD_ROWS = 1,  /* build rows from which AUTO tries the packed routes (default 4 Mi) */
+    TSQ_KNOB_DA_MIN_BUILD_ROWS = 1,  /* build rows from which AUTO tries the packed routes (default 1 Mi) */
     TSQ_KNOB_DA_PBITS = 2,           /* log2(partitions) of the packed routes (default: min(11, b - 10)) */
     TSQ_KNOB_PACKED_EMIT_PAIRS = 3,  /* 1: AUTO may take the pairs variant of the materialising packed route (K4d) */
     TSQ_KNOB_RADIX_KERNEL_L2 = 4,    /* 1: the 64-bit radix probe keeps round 1's L2 route */
@@ -131,6 +131,7 @@ enum {
                                         serve leaves it to the first probe batch that needs it) */
     TSQ_KNOB_DA_PAIRS_BELOW_PERMILLE = 22, /* AUTO: a probe batch whose sampled hit ratio lies below this (in 1/1000, default 350) takes the pairs
                                         variant of the materialising packed route (K4d) instead of the travelling columns (K5f + K4e) */
+    TSQ_KNOB_AGG_WIDE_KEYS = 23,     /* 0: several integer group-key columns never become one 64-bit composite key (the several-column upsert keeps them) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -144,6 +145,10 @@ tsq_status tsq_copy_h2d(tsq_ctx* ctx, void* dst_dev, const void* src_host, int64
 tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
 /* device to device, queued on the context's stream (not synchronised): an operator's output batch kept beyond its next Next() */
 tsq_status tsq_copy_d2d(tsq_ctx* ctx, void* dst_dev, const void* src_dev, int64_t bytes);
+/* rows [dst_rows, dst_rows + n) of a device null bitmap := the first n bits of src_bitmap (device; NULL: n NOT-NULL bits) — the bit
+ * offset is arbitrary (Column.appendNullBitmap, util/chunk/column.go; chunk.Decoder.decodeColumn's shift-and-or, codec.go:325-343).
+ * Queued on the context's stream.  The destination must hold (dst_rows + n + 7) / 8 + 8 bytes. */
+tsq_status tsq_bitmap_append(tsq_ctx* ctx, uint8_t* dst_bitmap, int64_t dst_rows, const uint8_t* src_bitmap, int64_t n);
 
 /* Timing helper: HIP events recorded on the ctx stream (bench.py's roofline leg). */
 tsq_status tsq_timer_start(tsq_ctx* ctx);

@@ -235,3 +235,88 @@ def test_packed_agg_several_key_columns_too_wide_keeps_the_row_upsert(ctx, orc):
     chk, types, nk = _mk_chunk(rng, 50_000, [(abi.I64, 0, 1 << 20, None), (abi.I64, 0, 1 << 10, None)])
     chk.columns[0] = Column(abi.I64, rng.integers(0, 50, 50_000) * (1 << 14))
     _mk_check(ctx, orc, chk, types, nk, _mk_aggs(nk, types, "sum_count"), want_packed=False)
+
+
+# ---------------------------------------------------------------- several integer key columns as ONE 64-bit composite key (round 4)
+# Key sets wider than the packed route's 23 bits (Q3's l_orderkey, o_orderdate, o_shippriority: 42 bits) used to take the several-column
+# row upsert.  Now the first batch gives every key column a field, the cells of a row become ONE 64-bit number d, and a child aggregate
+# with the single key d does the work (tsq_agg.hip: wide_setup / wide_batch); FIRST_ROW(key column) is decoded from d.  Rows with a
+# cell outside its field stay in the parent's own several-column table (exceptions).  stats.build_partitioned == 2 says the child ran.
+WIDE_SPECS = {
+    # Q3-like: a wide surrogate key, a day number, a tiny code; NULLs in two of them
+    "q3_like": [(abi.I64, 0, 1 << 28, 0.02), (abi.I64, 8000, 10500, None), (abi.I64, 0, 3, 0.05)],
+    # negative and unsigned cells; four columns
+    "four_mixed": [(abi.I64, -(1 << 20), 1 << 20, 0.03), (abi.I64, -5, 5, None), (abi.I64, 10**15, 10**15 + 1000, 0.01), (abi.I64, 0, 2, None)],
+    # two very wide columns: 30 + 30 bits
+    "two_wide": [(abi.I64, -(1 << 29), 1 << 29, None), (abi.I64, 0, 1 << 30, 0.04)],
+}
+
+
+@pytest.mark.parametrize("which", ["sum_count", "ints", "minmax2", "reals", "f32"])
+@pytest.mark.parametrize("spec", sorted(WIDE_SPECS))
+def test_wide_composite_group_key_vs_oracle(ctx, orc, spec, which):
+    rng = np.random.default_rng(len(spec) * 11 + len(which))
+    chk, types, nk = _mk_chunk(rng, 150_001, WIDE_SPECS[spec])
+    # few distinct values per column so that groups repeat (the ranges stay wide: the values are spread)
+    for k in range(nk):
+        c = chk.columns[k]
+        lo, hi = WIDE_SPECS[spec][k][1], WIDE_SPECS[spec][k][2]
+        vals = rng.integers(lo, hi, 40)
+        vals[0], vals[1] = lo, hi - 1
+        chk.columns[k] = Column(c.tp, vals[rng.integers(0, 40, len(c))], c.notnull)
+    st = _mk_check(ctx, orc, chk, types, nk, _mk_aggs(nk, types, which), want_packed=None)
+    assert st.build_partitioned == 2 and st.build_handed_back_rows == 0
+
+
+def test_wide_composite_group_key_later_batches_outside_the_fields_and_other_first_rows(ctx, orc):
+    ctx.set_knob(abi.KNOB_AGG_BATCH_ROWS, 1 << 16)
+    # batch 1 shows a in [0, 2^26), b in [100, 200); batch 2 brings keys far outside both fields (exception rows: this operator's own
+    # several-column table) next to keys inside them; FIRST_ROW of a column that is NOT a key travels through the child like any aggregate
+    rng = np.random.default_rng(77)
+    n1, n2 = 1 << 16, 90_000
+    a1, b1 = rng.integers(0, 1 << 26, 300)[rng.integers(0, 300, n1)], rng.integers(100, 200, n1)
+    a2 = np.where(rng.random(n2) < 0.3, rng.integers(1 << 40, (1 << 40) + 50, n2), a1[rng.integers(0, n1, n2)])
+    b2 = np.where(rng.random(n2) < 0.2, rng.integers(-10**9, -10**9 + 5, n2), rng.integers(100, 200, n2))
+    a, b = np.concatenate([a1, a2]), np.concatenate([b1, b2])
+    n = n1 + n2
+    v = H.random_column(rng, abi.I64, n, 0.1, lo=-1000, hi=1000)
+    chk = Chunk([Column(abi.I64, a, rng.random(n) > 0.02), Column(abi.I64, b), v, Column(abi.I64, a * 3 + b)])  # column 3 depends on the key
+    types = [abi.I64] * 4
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_FIRSTROW, 1, abi.I64), (abi.AGG_FIRSTROW, 3, abi.I64), (abi.AGG_SUM, 2, abi.I64), (abi.AGG_COUNT, -1, abi.I64),
+            (abi.AGG_AVG, 2, abi.I64)]
+    cfg = H.agg_cfg(types, [0, 1], aggs)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    stats = []
+    got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 20, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].build_partitioned == 2 and stats[0].build_handed_back_rows > 10_000
+    # rows with a NULL first key have a NULL a * 3 + b as well?  No: column 3 has no bitmap; FIRST_ROW(col 3) of the NULL-a groups is any
+    # row's value — those groups hold several a values.  Compare everything but that column for groups with a NULL key cell.
+    _match_by_key(got, want, [0, 1], [3, 4, 5], [], {})
+    gd = {(r[0], r[1]): r[2] for r in got.rows()}
+    wd = {(r[0], r[1]): r[2] for r in want.rows()}
+    assert all(gd[k] == wd[k] for k in wd if k[0] is not None)
+
+
+@pytest.mark.parametrize("modes", [(abi.MODE_PARTIAL1, abi.MODE_FINAL)])
+def test_wide_composite_group_key_partial_then_final(ctx, orc, modes):
+    # the distributed plans run HashAgg as partial -> shuffle -> final (parallel.py): both stages take the composite-key route
+    rng = np.random.default_rng(5)
+    n = 120_000
+    k0 = rng.integers(0, 1 << 27, 500)[rng.integers(0, 500, n)]
+    k1, k2 = rng.integers(9000, 9400, n), rng.integers(0, 3, n)
+    v = rng.random(n)
+    chk = Chunk([Column(abi.I64, k0), Column(abi.I64, k1, rng.random(n) > 0.02), Column(abi.I64, k2), Column(abi.F64, v, rng.random(n) > 0.05)])
+    t = [abi.I64, abi.I64, abi.I64, abi.F64]
+    full = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_FIRSTROW, 1, abi.I64), (abi.AGG_FIRSTROW, 2, abi.I64), (abi.AGG_SUM, 3, abi.F64), (abi.AGG_COUNT, 3, abi.F64)]
+    want = orc.hash_agg(H.agg_cfg(t, [0, 1, 2], full), chk, 4, 4)
+    paggs = [(f, c, tp, modes[0]) for f, c, tp in full]
+    stats = []
+    part = G.run_agg(ctx, H.agg_cfg(t, [0, 1, 2], paggs), chk, [abi.I64, abi.I64, abi.I64, abi.F64, abi.I64], chunk_rows=1 << 20, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].build_partitioned == 2
+    pt = [abi.I64, abi.I64, abi.I64, abi.F64, abi.I64]
+    faggs = [(abi.AGG_FIRSTROW, 0, abi.I64, modes[1]), (abi.AGG_FIRSTROW, 1, abi.I64, modes[1]), (abi.AGG_FIRSTROW, 2, abi.I64, modes[1]),
+             (abi.AGG_SUM, 3, abi.F64, modes[1]), (abi.AGG_COUNT, 4, abi.I64, modes[1])]
+    stats = []
+    got = G.run_agg(ctx, H.agg_cfg(pt, [0, 1, 2], faggs), part, [abi.I64, abi.I64, abi.I64, abi.F64, abi.I64], chunk_rows=1 << 20, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].build_partitioned == 2
+    _match_by_key(got, want, [0, 1, 2], [4], [3], _group_tols_multi(chk, [0, 1, 2], full, [3]))

@@ -574,3 +574,48 @@ def test_packed_routes_take_a_selected_vector(ctx, orc, jt, inner, route):
     if jt == abi.JOIN_INNER:
         c = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, selected=sel, count_only=True, radix=FORCE, packing=FORCE)
         assert c == want.NumRows()
+
+
+# ------------------------------------------------------------------ pairs route on BIT cells: a unique build side with a 28..30-bit key range (round 4)
+# The primary-key side of a PK-FK join is unique and its key range is often wider than the 27 bits byte cells + 2-byte entries take
+# (TPC-H SF 100: 1.5e8 order keys).  One bit per cell + popcount ranks give (probe row, build row) pairs with 4-byte entries
+# (tsq_dajoin.h: k_da_build_rows_bits, k_da_emit_pairs_bits); the columns follow through the pairs.
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("span_bits", [28, 29, 30])
+def test_packed_bit_cell_pairs_unique_wide_build_side(ctx, orc, jt, inner, span_bits):
+    rng = np.random.default_rng(span_bits * 3 + jt)
+    span = (1 << span_bits) - 7
+    base = -(1 << 40) + 11
+    bk = base + np.unique(np.concatenate([rng.integers(0, span, 60_000), np.array([0, span - 1])]))
+    rng.shuffle(bk)
+    nb, n = len(bk), 150_001
+    pk = np.where(rng.random(n) < 0.5, bk[rng.integers(0, nb, n)], base + rng.integers(-span // 8, span + span // 8, n))
+    pk[::7] = bk[5]  # a hot probe key: its partition's region overflows (the overflow list emits through the images in HBM)
+    build = Chunk([Column(abi.I64, bk), Column(abi.F64, rng.random(nb), rng.random(nb) > 0.1), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, pk, rng.random(n) > 0.03), Column(abi.I64, rng.integers(-9, 9, n), rng.random(n) > 0.1)])
+    sel = (rng.random(n) > 0.2).astype(np.uint8)
+    left, right = (probe, build) if inner == 1 else (build, probe)
+    cfg = H.join_cfg(left.types(), right.types(), [0], [0], jt, inner)
+    for selected in (None, sel):
+        want = orc.hash_join(cfg, build, probe, selected=selected)
+        stats = []
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, selected=selected, stats_out=stats, radix=FORCE, packing=FORCE)
+        assert stats[0].probe_route == abi.ROUTE_PACKED and stats[0].packed_key_bits == span_bits and stats[0].radix_overflow_rows > 0
+        assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+def test_packed_bit_cell_pairs_need_a_unique_build_side(ctx, orc):
+    # one duplicate among keys that span 28 bits: 4-byte entries against byte cells have no materialising route — the direct route keeps the join
+    rng = np.random.default_rng(8)
+    bk = np.unique(rng.integers(0, (1 << 28) - 1, 50_000))
+    bk = np.concatenate([bk, bk[:1], np.array([(1 << 28) - 2])])
+    pk = np.concatenate([bk[rng.integers(0, len(bk), 40_000)], rng.integers(0, 1 << 28, 40_000)])
+    build = Chunk([Column(abi.I64, bk), Column(abi.I64, np.arange(len(bk)))])
+    probe = Chunk([Column(abi.I64, pk), Column(abi.I64, np.arange(len(pk)))])
+    t = [abi.I64, abi.I64]
+    cfg = H.join_cfg(t, t, [0], [0], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, stats_out=stats, radix=FORCE, packing=FORCE)
+    assert stats[0].probe_route == abi.ROUTE_DIRECT
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)

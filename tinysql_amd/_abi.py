@@ -163,7 +163,7 @@ KNOB_DEFAULT = -(1 << 63)
 (KNOB_PACKED_KEYS, KNOB_DA_MIN_BUILD_ROWS, KNOB_DA_PBITS, KNOB_PACKED_EMIT_PAIRS, KNOB_RADIX_KERNEL_L2, KNOB_LDS_NF_MAX, KNOB_RADIX_PB_MAX,
  KNOB_TABLE_LF_PERMILLE, KNOB_LDS_PROF, KNOB_DA_TRACE, KNOB_BUILD_IMAGES_CAS, KNOB_DAAGG_SIG, KNOB_DAAGG_LOG2C, KNOB_AGG_HEAP_GC_BYTES,
  KNOB_AGG_TAG_BITS, KNOB_AGG_BATCH_ROWS, KNOB_ROWCODEC_LDS_KB, KNOB_ROWCODEC_FAST_LAYOUT, KNOB_ROWCODEC_PIPELINE, KNOB_DA_PARTITION,
- KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE, KNOB_DA_PAIRS_BELOW_PERMILLE) = range(23)
+ KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE, KNOB_DA_PAIRS_BELOW_PERMILLE, KNOB_AGG_WIDE_KEYS) = range(24)
 
 
 # every symbol include/tsq.h declares: name -> (restype, argtypes)
@@ -186,6 +186,7 @@ SIGNATURES = {
     "tsq_copy_h2d": (C.c_int32, [P, P, P, C.c_int64]),
     "tsq_copy_d2h": (C.c_int32, [P, P, P, C.c_int64]),
     "tsq_copy_d2d": (C.c_int32, [P, P, P, C.c_int64]),
+    "tsq_bitmap_append": (C.c_int32, [P, P, C.c_int64, P, C.c_int64]),
     "tsq_timer_start": (C.c_int32, [P]),
     "tsq_timer_stop_ms": (C.c_int32, [P, C.POINTER(C.c_double)]),
     "tsq_gen_column": (C.c_int32, [P, C.POINTER(GenSpec), C.c_int64, P, P, P]),

@@ -835,6 +835,116 @@ __global__ void __launch_bounds__(256) k_heap_gc_move(HeapGcArgs a) {
 }
 
 // ====================================================================== host side
+// ---- several integer key columns wider than the packed route's 23 bits: ONE 64-bit composite key (round 4)
+// GROUP BY l_orderkey, o_orderdate, o_shippriority (Q3: 28 + 12 + 2 bits) used to take the several-column row upsert: a 64-bit TAG of
+// the cells in phase 0, the cells compared in a second launch, four FIRST_ROW state arrays — ~9 random lines per row.  When the
+// fields of the key columns ([kmin_k, kmin_k + 2^w_k), one more code for NULL, found by the first batch and widened while the sum
+// stays <= 63 bits) hold a row's cells, the row's group IS the number d = sum field_k << shift_k — equal d <=> equal cells in every
+// column, NULL = NULL (aggregate.go:359-394 / codec.go:713-746: the group key is the concatenation of the encoded cells) — and the
+// operator hands (d, the argument columns) to a CHILD aggregate with ONE BIGINT UNSIGNED key: the single-key upsert (one launch, the
+// tag is the key), its LDS pre-aggregation when groups repeat, no FIRST_ROW state for the key columns at all (their values are
+// decoded from d when the groups are emitted).  A row with a cell outside its field is an EXCEPTION: it takes the several-column
+// upsert into this operator's own table; a group lives in exactly one of the two tables (its cells decide), so the result is the
+// child's groups followed by the own ones.
+#define TSQ_WIDE_NO_NULL (~0ull)
+struct WideFields {
+    int32_t n;
+    uint64_t kmin[TSQ_MAX_GROUP_KEYS], maxd[TSQ_MAX_GROUP_KEYS], nullcode[TSQ_MAX_GROUP_KEYS];
+    uint32_t shift[TSQ_MAX_GROUP_KEYS], width[TSQ_MAX_GROUP_KEYS];
+};
+struct WideComposeArgs {
+    WideFields f;
+    const uint64_t* col[TSQ_MAX_GROUP_KEYS];
+    const uint8_t* nulls[TSQ_MAX_GROUP_KEYS];
+    int64_t nrows;
+    uint64_t* d;                    // composite per row (exception rows: ~0, never read by the child)
+    unsigned long long* counts;     // [0] += exception rows
+};
+__device__ __forceinline__ uint64_t wide_compose_row(const WideComposeArgs& a, int64_t row, bool* ok) {
+    uint64_t d = 0;
+    bool good = true;
+#pragma unroll
+    for (int k = 0; k < TSQ_MAX_GROUP_KEYS; k++) {
+        if (k < a.f.n) {
+            uint64_t fld;
+            if (tsq_is_null(a.nulls[k], row)) {
+                fld = a.f.nullcode[k];
+                good = good && fld != TSQ_WIDE_NO_NULL;
+            } else {
+                fld = a.col[k][row] - a.f.kmin[k];
+                good = good && fld <= a.f.maxd[k];
+            }
+            d |= fld << a.f.shift[k];
+        }
+    }
+    *ok = good;
+    return good ? d : ~0ull;
+}
+__global__ void __launch_bounds__(256) k_agg_wide_compose(WideComposeArgs a) {
+    uint32_t exc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nrows; i += (int64_t)gridDim.x * 256) {
+        bool ok;
+        a.d[i] = wide_compose_row(a, i, &ok);
+        exc += ok ? 0u : 1u;
+    }
+    block_add_u32(&a.counts[0], exc);
+}
+// the two row lists of a batch that holds exception rows (any order): one device atomic per workgroup and list
+struct WideListArgs {
+    const uint64_t* d;
+    int64_t nrows;
+    uint32_t* ok_rows;
+    uint32_t* exc_rows;
+    unsigned long long* cursors;  // [0] ok, [1] exceptions
+};
+__global__ void __launch_bounds__(256) k_agg_wide_lists(WideListArgs a) {
+    __shared__ uint32_t s_base[2], s_cnt[2];
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < a.nrows; base += (int64_t)gridDim.x * 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool in = i < a.nrows, exc = in && a.d[i] == ~0ull, ok = in && !exc;
+        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t mo = __ballot(ok), me = __ballot(exc);
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t wo = 0, we = 0;
+        if (lane == 0) {
+            wo = atomicAdd(&s_cnt[0], (uint32_t)__popcll(mo));
+            we = atomicAdd(&s_cnt[1], (uint32_t)__popcll(me));
+        }
+        wo = __shfl(wo, 0, 64);
+        we = __shfl(we, 0, 64);
+        __syncthreads();
+        if (threadIdx.x < 2 && s_cnt[threadIdx.x]) s_base[threadIdx.x] = (uint32_t)atomicAdd(&a.cursors[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+        __syncthreads();
+        const uint64_t below = (1ull << lane) - 1ull;
+        if (ok) a.ok_rows[s_base[0] + wo + (uint32_t)__popcll(mo & below)] = (uint32_t)i;
+        if (exc) a.exc_rows[s_base[1] + we + (uint32_t)__popcll(me & below)] = (uint32_t)i;
+        __syncthreads();
+    }
+}
+// the key columns of the child's groups, decoded from their composite
+struct WideDecodeArgs {
+    WideFields f;
+    const uint64_t* d;
+    int64_t n;
+    int32_t n_out;
+    int32_t key_of[TSQ_MAX_AGGS];        // output column -> key column it is FIRST_ROW of
+    uint64_t* out[TSQ_MAX_AGGS];
+    uint8_t* out_nn[TSQ_MAX_AGGS];
+};
+__global__ void __launch_bounds__(256) k_agg_wide_decode(WideDecodeArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t d = a.d[i];
+        for (int o = 0; o < a.n_out; o++) {
+            const int k = a.key_of[o];
+            const uint64_t fld = a.f.width[k] >= 64 ? d : ((d >> a.f.shift[k]) & ((1ull << a.f.width[k]) - 1ull));
+            const bool isnull = a.f.nullcode[k] != TSQ_WIDE_NO_NULL && fld == a.f.nullcode[k];
+            a.out[o][i] = isnull ? 0ull : a.f.kmin[k] + fld;
+            a.out_nn[o][i] = isnull ? 0 : 1;
+        }
+    }
+}
+
 struct AggTableBufs {
     DevBuf tag, gknull;
     DevBuf gkey[TSQ_MAX_GROUP_KEYS];
@@ -900,6 +1010,15 @@ struct tsq_agg {
     int32_t mk_col[TSQ_DAAGG_MAXK] = {0, 0, 0, 0};
     DaAggKeys da_keys{};
     bool da_low = false;
+    // several integer key columns as ONE 64-bit composite key handed to a child aggregate (see k_agg_wide_compose)
+    int wide_state = 0;        // 0: not tried, 1: in use, -1: not usable (this plan, or the fields of the first batch exceed 63 bits)
+    bool wide_ok = false;      // the plan allows it (integer key columns, fixed-width inputs)
+    bool is_wide_child = false;
+    WideFields wide_f{};
+    tsq_agg* wide = nullptr;   // the child: GROUP BY d
+    DevBuf wide_d, wide_okrows, wide_excrows;
+    int32_t wide_child_out[TSQ_MAX_AGGS * 2];  // own output column -> the child's output column, or -1 - k: decoded from d (key column k)
+    int64_t wide_batches = 0, wide_exception_rows = 0;
 };
 
 namespace {
@@ -1465,8 +1584,196 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
 }
 
 // one device-resident batch: LDS pre-aggregation when the plan and the batch allow it, the row upsert otherwise
+// ---- several integer key columns as one 64-bit composite key (k_agg_wide_compose): the fields from the first batch, the child
+tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows);
+tsq_status wide_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    if (a->wide_state) return TSQ_OK;
+    a->wide_state = -1;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    WideFields& f = a->wide_f;
+    memset(&f, 0, sizeof f);
+    f.n = a->plan.n_keys;
+    uint32_t need[TSQ_MAX_GROUP_KEYS], total = 0;
+    uint64_t lo[TSQ_MAX_GROUP_KEYS], range[TSQ_MAX_GROUP_KEYS];
+    bool nullable[TSQ_MAX_GROUP_KEYS];
+    for (int k = 0; k < f.n; k++) {
+        const int c = a->plan.key_col[k];
+        DaMinMaxArgs ma;
+        memset(&ma, 0, sizeof ma);
+        ma.src.data = (const uint64_t*)in.data[c];
+        ma.src.nulls = in.nulls[c];
+        ma.src.nrows = nrows;
+        ma.flip = a->cfg.group_key_type[k] == TSQ_I64 ? 0x8000000000000000ULL : 0ULL;
+        ma.out = (unsigned long long*)(ctx->dscratch + 48);
+        ctx->pinned[48] = ~0ULL;
+        ctx->pinned[49] = 0;
+        ctx->pinned[50] = 0;
+        TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 24, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, ma);
+        TSQ_HIP(h, hipGetLastError());
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        a->st.kernel_launches++;
+        lo[k] = range[k] = 0;
+        if (ctx->pinned[50] != 0) {
+            lo[k] = ctx->pinned[48] ^ ma.flip;
+            range[k] = (ctx->pinned[49] ^ ma.flip) - lo[k];
+        }
+        // NULL gets a code whether or not this batch holds one (a later batch may: GROUP BY makes NULL a group, codec.go:718-719)
+        nullable[k] = true;
+        uint32_t w = 0;
+        while (w < 64 && (range[k] >> w) != 0) w++;
+        need[k] = w + 1;  // the observed range, doubled: room for the NULL code and for somewhat larger keys of later batches
+        total += need[k];
+    }
+    if (total > 63) return TSQ_OK;
+    // widen the fields while the word has room (later batches: order numbers keep growing, dates move on), at most 8 bits each
+    uint32_t spare = 63 - total;
+    for (int round = 0; round < 8 && spare; round++)
+        for (int k = 0; k < f.n && spare; k++) {
+            need[k]++;
+            spare--;
+        }
+    uint32_t at = 0;
+    for (int k = 0; k < f.n; k++) {
+        const uint64_t cells = need[k] >= 64 ? ~0ull : ((1ull << need[k]) - 1ull);  // the last code is NULL's
+        // the window starts a quarter of its slack below the smallest key seen (unless that would wrap around zero of the key's order)
+        const uint64_t slack = (cells - 1 > range[k]) ? (cells - 1 - range[k]) / 4 : 0;
+        const bool is_signed = a->cfg.group_key_type[k] == TSQ_I64;
+        const uint64_t floor_key = is_signed ? 0x8000000000000000ULL : 0ULL;  // the smallest cell of the order, as a 64-bit word
+        const uint64_t room = lo[k] - floor_key;                               // (wrapping subtraction: distance above the floor)
+        f.kmin[k] = lo[k] - (slack < room ? slack : room);
+        f.width[k] = need[k];
+        f.shift[k] = at;
+        f.nullcode[k] = nullable[k] ? cells : TSQ_WIDE_NO_NULL;
+        f.maxd[k] = cells - 1;
+        at += need[k];
+    }
+    // ---- the child: GROUP BY d (one BIGINT UNSIGNED key = input column n_input_cols), the same aggregates minus FIRST_ROW(key column)
+    tsq_agg_cfg cc = a->cfg;
+    if (cc.n_input_cols >= TSQ_MAX_COLS) return TSQ_OK;
+    const int dcol = cc.n_input_cols;
+    cc.input_types[dcol] = TSQ_U64;
+    cc.n_input_cols = dcol + 1;
+    cc.n_group_keys = 1;
+    cc.group_key_col[0] = dcol;
+    cc.group_key_type[0] = TSQ_U64;
+    cc.n_aggs = 0;
+    memset(&cc.aggs[0], 0, sizeof(tsq_agg_func));
+    cc.aggs[0].func = TSQ_AGG_FIRSTROW;
+    cc.aggs[0].mode = TSQ_MODE_COMPLETE;
+    cc.aggs[0].arg_col = dcol;
+    cc.aggs[0].arg_col2 = -1;
+    cc.aggs[0].arg_type = TSQ_U64;
+    cc.n_aggs = 1;
+    int child_oc = 1, own_oc = 0;
+    for (int i = 0; i < a->cfg.n_aggs; i++) {
+        const tsq_agg_func& fn = a->cfg.aggs[i];
+        const bool partial_out = fn.mode == TSQ_MODE_PARTIAL1 || fn.mode == TSQ_MODE_PARTIAL2;
+        const int outs = (fn.func == TSQ_AGG_AVG && partial_out) ? 2 : 1;
+        int key = -1;
+        if (fn.func == TSQ_AGG_FIRSTROW)
+            for (int k = 0; k < f.n; k++)
+                if (fn.arg_col == a->plan.key_col[k]) key = k;
+        if (key >= 0) {
+            a->wide_child_out[own_oc++] = -1 - key;
+            continue;
+        }
+        if (cc.n_aggs >= TSQ_MAX_AGGS) return TSQ_OK;
+        cc.aggs[cc.n_aggs++] = fn;
+        for (int o = 0; o < outs; o++) a->wide_child_out[own_oc++] = child_oc++;
+    }
+    tsq_agg* child = nullptr;
+    const tsq_status cs = tsq_agg_create(ctx, &cc, &child);
+    if (cs != TSQ_OK) return TSQ_OK;  // (a plan the single-key operator refuses: the several-column upsert keeps this aggregate)
+    child->is_wide_child = true;
+    child->fast_mode = a->fast_mode;
+    child->host_mode = false;
+    a->wide = child;
+    a->wide_state = 1;
+    return TSQ_OK;
+}
+
+tsq_status wide_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    TSQ_TRY(a->wide_d.reserve(ctx, h, (size_t)nrows * 8 + 64));
+    WideComposeArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.f = a->wide_f;
+    for (int k = 0; k < ca.f.n; k++) {
+        ca.col[k] = (const uint64_t*)in.data[a->plan.key_col[k]];
+        ca.nulls[k] = in.nulls[a->plan.key_col[k]];
+    }
+    ca.nrows = nrows;
+    ca.d = a->wide_d.as<uint64_t>();
+    ca.counts = (unsigned long long*)(ctx->dscratch + 60);
+    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 60, 0, 24, ctx->stream));
+    hipLaunchKernelGGL(k_agg_wide_compose, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, ca);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 60, ctx->dscratch + 60, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    a->st.kernel_launches++;
+    const int64_t n_exc = (int64_t)ctx->pinned[60];
+    // the child's batch: the caller's columns + d
+    tsq_agg* c = a->wide;
+    tsq_colset cin = in;
+    const int dcol = a->cfg.n_input_cols;
+    cin.n = dcol + 1;
+    cin.data[dcol] = a->wide_d.p;
+    cin.nulls[dcol] = nullptr;
+    cin.type[dcol] = TSQ_U64;
+    cin.offs[dcol] = nullptr;
+    a->wide_batches++;
+    if (n_exc == 0) {
+        TSQ_TRY(agg_batch(c, cin, nrows));
+        if (c->hdr.err.size()) h->err = c->hdr.err;
+        c->in_rows += nrows;
+        return TSQ_OK;
+    }
+    // exception rows (a cell outside its field): they take the several-column upsert into this operator's own table, the others go
+    // to the child as a row list
+    a->wide_exception_rows += n_exc;
+    TSQ_TRY(a->wide_okrows.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(a->wide_excrows.reserve(ctx, h, (size_t)n_exc * 4 + 64));
+    WideListArgs la;
+    memset(&la, 0, sizeof la);
+    la.d = ca.d;
+    la.nrows = nrows;
+    la.ok_rows = a->wide_okrows.as<uint32_t>();
+    la.exc_rows = a->wide_excrows.as<uint32_t>();
+    la.cursors = (unsigned long long*)(ctx->dscratch + 61);
+    hipLaunchKernelGGL(k_agg_wide_lists, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, la);
+    TSQ_HIP(h, hipGetLastError());
+    a->st.kernel_launches++;
+    if (nrows - n_exc > 0) {
+        const tsq_status s = agg_rows(c, cin, nrows - n_exc, la.ok_rows);
+        if (s != TSQ_OK) { h->err = c->hdr.err; return s; }
+    }
+    c->in_rows += nrows - n_exc;
+    return agg_rows(a, in, n_exc, la.exc_rows);
+}
+
 tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     if (nrows == 0) return TSQ_OK;
+    // several integer key columns wider than the packed route takes: one composite key for a single-key child (wide_setup).  The
+    // first batch decides; small first batches (below 64 Ki rows) wait for a bigger one unless the fast paths are FORCEd (tests)
+    if (a->wide_ok && a->wide_state >= 0 && a->fast_mode != TSQ_AGGFAST_OFF && nrows < 0x7fffffffLL) {
+        if (a->wide_state == 0 && a->groups == 0 && a->in_rows == 0 && (nrows >= (1 << 16) || a->fast_mode == TSQ_AGGFAST_FORCE)) {
+            // the packed several-column route (<= 23 bits of fields) is tried first by agg_batch_fast: here only what it cannot take
+            bool packed_fits = false;
+            if (a->fast_ok && a->mk_n > 1 && (nrows >= (1 << 20) || a->fast_mode == TSQ_AGGFAST_FORCE)) {
+                TSQ_TRY(da_agg_setup(a, in, nrows));  // (what agg_batch_fast would do with this batch: idempotent)
+                packed_fits = a->da_state == 1;
+            }
+            if (!packed_fits) TSQ_TRY(wide_setup(a, in, nrows));
+            else a->wide_state = -1;
+        } else if (a->wide_state == 0 && (a->groups > 0 || a->in_rows > 0)) {
+            a->wide_state = -1;  // rows already live in the several-column table: keep one table
+        }
+        if (a->wide_state == 1) return wide_batch(a, in, nrows);
+    }
     const bool want_fast = a->fast_ok && a->fast_mode != TSQ_AGGFAST_OFF && nrows < 0x7fffffffLL &&
                            (a->fast_mode == TSQ_AGGFAST_FORCE || nrows >= (1 << 20));
     if (!want_fast) return agg_rows(a, in, nrows, nullptr);
@@ -1770,7 +2077,12 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
         hipError_t e = hipMemsetAsync(a->counters.p, 0, 64, ctx->stream);
         if (e != hipSuccess) s = tsq_fail(h, TSQ_ERR_HIP, hipGetErrorString(e));
     }
-    uint64_t cap = cfg->n_group_keys == 0 ? 16 : (cfg->est_groups > 0 ? (uint64_t)cfg->est_groups * 2 + 16 : (1u << 16));
+    // several integer key columns, fixed-width inputs: the composite-key child may take this aggregate (wide_setup decides at the first
+    // batch); this operator's own table then only holds exception rows and starts small
+    a->wide_ok = cfg->n_group_keys >= 2 && !has_str && tsq_knob(ctx, TSQ_KNOB_AGG_WIDE_KEYS, 1) != 0;
+    for (int k = 0; k < cfg->n_group_keys && a->wide_ok; k++)
+        if (cfg->group_key_type[k] != TSQ_I64 && cfg->group_key_type[k] != TSQ_U64) a->wide_ok = false;
+    uint64_t cap = cfg->n_group_keys == 0 ? 16 : ((cfg->est_groups > 0 && !a->wide_ok) ? (uint64_t)cfg->est_groups * 2 + 16 : (1u << 16));
     if (s == TSQ_OK) s = alloc_table(a.get(), a->tb, cap);
     if (s == TSQ_OK) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -1855,7 +2167,15 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
         TSQ_HIP(h, hipMemcpy((char*)a->tb.tag.p + (a->tb.cap + 1) * 8, &one, 8, hipMemcpyHostToDevice));
         a->groups = 1;
     }
-    const int64_t g = a->groups;
+    // the groups of the composite-key child come after this operator's own (exception) groups
+    int64_t g_child = 0;
+    if (a->wide_state == 1) {
+        const tsq_status cs = tsq_agg_finish(a->wide);
+        if (cs != TSQ_OK) return tsq_fail(h, cs, a->wide->hdr.err);
+        g_child = a->wide->out_rows;
+    }
+    const int64_t g_own = a->groups;
+    const int64_t g = g_own + g_child;
     a->odata.resize(a->n_out);
     a->onn.resize(a->n_out);
     a->obitmap.resize(a->n_out);
@@ -1876,6 +2196,32 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     hipLaunchKernelGGL(k_agg_finalize, dim3(grid), dim3(256), 0, ctx->stream, fa);
     TSQ_HIP(h, hipGetLastError());
     a->st.kernel_launches++;
+    if (g_child > 0) {  // rows [g_own, g) of every output column: copied from the child, or decoded from its composite key
+        tsq_agg* c = a->wide;
+        WideDecodeArgs da;
+        memset(&da, 0, sizeof da);
+        da.f = a->wide_f;
+        da.d = c->odata[0].as<uint64_t>();
+        da.n = g_child;
+        for (int oc = 0; oc < a->n_out; oc++) {
+            const int32_t src = a->wide_child_out[oc];
+            const size_t es = tsq_elem_size(a->out_types[oc]);
+            if (src < 0) {
+                da.key_of[da.n_out] = -1 - src;
+                da.out[da.n_out] = a->odata[oc].as<uint64_t>() + g_own;
+                da.out_nn[da.n_out] = a->onn[oc].as<uint8_t>() + g_own;
+                da.n_out++;
+            } else {
+                TSQ_HIP(h, hipMemcpyAsync((char*)a->odata[oc].p + (size_t)g_own * es, c->odata[src].p, (size_t)g_child * es, hipMemcpyDeviceToDevice, ctx->stream));
+                TSQ_HIP(h, hipMemcpyAsync(a->onn[oc].as<uint8_t>() + g_own, c->onn[src].p, (size_t)g_child, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        if (da.n_out) {
+            hipLaunchKernelGGL(k_agg_wide_decode, dim3(tsq_grid_for(ctx, g_child, 256)), dim3(256), 0, ctx->stream, da);
+            TSQ_HIP(h, hipGetLastError());
+            a->st.kernel_launches++;
+        }
+    }
     for (int oc = 0; oc < a->n_out; oc++) {
         TSQ_TRY(a->obitmap[oc].reserve(ctx, h, tsq_bitmap_bytes(g) + 16));
         TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a->onn[oc].as<uint8_t>(), a->obitmap[oc].as<uint8_t>(), g));
@@ -1886,7 +2232,7 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     const bool overflow = ctx->pinned[1] != 0;
     if (ctx->pinned[2]) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "aggregate: a string cell longer than 16 MiB - 2 bytes: fall back to the Go operator");
     if (overflow) return tsq_fail(h, TSQ_ERR_OVERFLOW_BIGINT, "BIGINT value is out of range in 'sum/avg' (func_sum.go:133-137)");
-    if (emitted != g) return tsq_fail(h, TSQ_ERR_HIP, "internal: finalize emitted " + std::to_string(emitted) + " groups, expected " + std::to_string(g));
+    if (emitted != g_own) return tsq_fail(h, TSQ_ERR_HIP, "internal: finalize emitted " + std::to_string(emitted) + " groups, expected " + std::to_string(g_own));
     // var-len output columns: references -> offsets + bytes
     a->ooffs.resize(a->n_out);
     a->obytes.resize(a->n_out);
@@ -1963,7 +2309,7 @@ TSQ_API tsq_status tsq_agg_set_fast(tsq_agg* a, int32_t mode) {
 TSQ_API tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out) {
     tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG || !out) return TSQ_ERR_INVALID;
-    *out = a->finished ? a->out_rows : a->groups;
+    *out = a->finished ? a->out_rows : a->groups + (a->wide_state == 1 ? a->wide->groups : 0);
     return TSQ_OK;
 }
 
@@ -2062,6 +2408,7 @@ TSQ_API tsq_status tsq_agg_peek(tsq_agg* a, int64_t cap_rows, int64_t* nrows_out
 TSQ_API tsq_status tsq_agg_cancel(tsq_agg* a) {
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
     a->cancelled.store(1);
+    if (a->wide) a->wide->cancelled.store(1);
     return TSQ_OK;
 }
 
@@ -2073,6 +2420,15 @@ TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
     a->st.radix_batches = a->fast_batches;
     a->st.radix_overflow_rows = a->fast_fallbacks;
     a->st.packed_key_bits = a->packed_batches > 0 ? (int32_t)a->da_dm.b : 0;
+    if (a->wide_state == 1) {  // the composite-key child did the work: its batches / packed range, the rows that stayed here as exceptions
+        tsq_stats cs;
+        if (tsq_agg_stats(a->wide, &cs) == TSQ_OK) {
+            a->st.radix_batches = cs.radix_batches;
+            a->st.packed_key_bits = cs.packed_key_bits;
+        }
+        a->st.build_handed_back_rows = a->wide_exception_rows;
+        a->st.build_partitioned = 2;  // (aggregate: 2 = several key columns composed into one 64-bit key)
+    }
     a->st.heap_bytes = 0;
     for (const ColStore& hs : a->heap)
         if (hs.type == TSQ_BYTES) a->st.heap_bytes = std::max<int64_t>(a->st.heap_bytes, hs.nbytes);
@@ -2086,6 +2442,11 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return;
     (void)hipSetDevice(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->stream);
+    if (a->wide) {
+        tsq_agg_destroy(a->wide);
+        a->wide = nullptr;
+    }
+    for (DevBuf* b : {&a->wide_d, &a->wide_okrows, &a->wide_excrows}) b->release();
     a->tb.release();
     a->counters.release();
     a->retry[0].release();

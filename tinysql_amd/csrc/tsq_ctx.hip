@@ -221,6 +221,16 @@ TSQ_API tsq_status tsq_copy_d2d(tsq_ctx* ctx, void* dst_dev, const void* src_dev
     return TSQ_OK;
 }
 
+// append n rows of a device null bitmap at bit position dst_rows of another one (Column.appendNullBitmap / Decoder.decodeColumn's
+// shift-and-or, util/chunk/codec.go:325-343): chunks whose row counts are not multiples of 8 are concatenated on the device
+TSQ_API tsq_status tsq_bitmap_append(tsq_ctx* ctx, uint8_t* dst_bitmap, int64_t dst_rows, const uint8_t* src_bitmap, int64_t n) {
+    tsq_ctx_lock _api_lock(ctx);
+    if (!ctx || !dst_bitmap || dst_rows < 0 || n < 0) return TSQ_ERR_INVALID;
+    if (n == 0) return TSQ_OK;
+    TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
+    return tsq_launch_append_bits(ctx, &ctx->hdr, dst_bitmap, dst_rows, src_bitmap, n);  // src == NULL: n set bits
+}
+
 TSQ_API tsq_status tsq_timer_start(tsq_ctx* ctx) {
     tsq_ctx_lock _api_lock(ctx);
     if (!ctx) return TSQ_ERR_INVALID;

@@ -784,6 +784,8 @@ struct tsq_join {
     bool shared = false;
     int64_t shared_image_bytes = 0, shared_usable_local = 0;
     double shared_allreduce_ms = 0;
+    int da_bitrows_state = 0;         // bit-cell pairs route (unique build side, 4-byte entries): bit image + coarse popcounts + sorted build rows
+    DevBuf da_bitimg;                 // ... the bit form of byte cells (b <= 28)
     int da_rows_state = 0;            // materialising packed route: build rows sorted by word (CSR over the images)
     DevBuf da_coarse, da_pstart, da_brows;
     DevBuf ridx, rovfidx, rmiss;      // ... probe rows travelling with the entries | of the overflow list | that cannot match (outer joins)
@@ -1142,7 +1144,12 @@ tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st,
     constexpr int NT = 1024, K = 16, T = NT * K;
     const int64_t ntiles = (src.nrows + T - 1) / T;
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, j->ctx->num_cus));
-    if (with_idx && miss) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    if (with_idx && st.ebits > 16) {  // (4-byte entries with row ids: the bit-cell pairs route; 8 keys per thread — the row ids share the LDS)
+        constexpr int K8 = 8, T8 = NT * K8;
+        const dim3 grid8((unsigned)std::min<int64_t>((src.nrows + T8 - 1) / T8, j->ctx->num_cus));
+        if (miss) hipLaunchKernelGGL((k_da_partition<NT, K8, uint32_t, true, true>), grid8, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+        else hipLaunchKernelGGL((k_da_partition<NT, K8, uint32_t, true, false>), grid8, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
+    } else if (with_idx && miss) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, true>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     else if (with_idx) hipLaunchKernelGGL((k_da_partition<NT, K, uint16_t, true, false>), grid, dim3(NT), 0, j->ctx->stream, src, j->da_dm, st);
     else {
         // COUNT(*) routes: two 512-thread workgroups per CU (k_da_partition2: one loads while the other scatters) with non-temporal key
@@ -1291,7 +1298,7 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr) {
     const int64_t nb = j->bcols[kc].rows;
     if (!sc && (nb <= 0 || nb >= 0xffffffffLL)) return TSQ_OK;
     const bool force = j->packing_mode == TSQ_RADIX_FORCE;
-    const int64_t min_build = tsq_knob(ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(4 << 20));  // (experiment knob)
+    const int64_t min_build = tsq_knob(ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(1 << 20));  // (experiment knob)
     if (!sc && !force && nb < min_build) return TSQ_OK;
     if (j->multi) {  // several key columns: one composite column, unsigned, ~0 = cannot match
         bool ok = false;
@@ -1335,7 +1342,8 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr) {
     const int pb_env = (int)tsq_knob(ctx, TSQ_KNOB_DA_PBITS, -1);  // (experiment knob)
     // 29..31 bits: one BIT per cell instead of one byte (k_da_build_bits) — only a build side WITHOUT duplicate keys fits that
     // (the images kernel finds out); COUNT(*) route only.  The arithmetic is host-only: tsq_da_plan (tsq_dapack.h)
-    const DaPlan pl = tsq_da_plan(lo_img ^ ma.flip, hi_img ^ ma.flip, usable, ma.skip_high, j->count_only, force, pb_env);
+    // (bit cells also serve a materialising join of a unique build side: the bit-cell pairs route, da_emit_bits)
+    const DaPlan pl = tsq_da_plan(lo_img ^ ma.flip, hi_img ^ ma.flip, usable, ma.skip_high, true, force, pb_env);
     if (!pl.ok) return TSQ_OK;
     const bool bits_mode = pl.bit_cells != 0;
     j->da_bits = bits_mode;
@@ -1763,6 +1771,223 @@ tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nro
             hipLaunchKernelGGL((k_da_emit_pairs<512, false>), pgrid, dim3(512), lds, ctx->stream, ea);
             TSQ_HIP(h, hipGetLastError());
             hipLaunchKernelGGL(k_da_emit_ovf<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+        }
+        TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+        j->st.kernel_launches += 3;
+        return TSQ_OK;
+    });
+}
+
+// ---- pairs route on BIT cells (tsq_dajoin.h): a UNIQUE build side whose key range needs 4-byte entries (28..30 bits)
+bool da_bits_emit_eligible(const tsq_join* j, int64_t nrows) {
+    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->never_match || j->ordered) return false;
+    if (!j->conds_h.empty() || !j->filters_h.empty()) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_bitrows_state < 0) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (4 << 20);
+}
+tsq_status da_prepare_rows_bits(tsq_join* j) {
+    if (j->da_bitrows_state) return TSQ_OK;
+    j->da_bitrows_state = -1;
+    if (j->da_state != 1 || !j->da_unique || j->da_ebits <= 16 || j->da_ebits > 19) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const int kc = j->ks.bidx[0];
+    const int64_t nb = j->bcols[kc].rows;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nb, 1024 * 8);
+    if (g.nregions * g.cap >= 0xffffffffULL) return TSQ_OK;
+    const size_t nwords = ((size_t)1 << j->da_dm.b) >> 5;
+    DevBuf ent, idx, ctl, vend, ovf, ovfi;
+    auto release_all = [&]() {
+        for (DevBuf* x : {&ent, &idx, &ctl, &vend, &ovf, &ovfi}) x->release();
+    };
+    tsq_status s = ent.reserve(ctx, h, g.ent_bytes);
+    if (s == TSQ_OK) s = idx.reserve(ctx, h, g.nregions * g.cap * 4 + 256);
+    if (s == TSQ_OK) s = ctl.reserve(ctx, h, g.ctl_bytes);
+    if (s == TSQ_OK) s = vend.reserve(ctx, h, g.nregions * 4);
+    if (s == TSQ_OK) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK) s = ovfi.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s == TSQ_OK && !j->da_bits) s = j->da_bitimg.reserve(ctx, h, nwords * 4 + 64);
+    if (s == TSQ_OK) s = j->da_coarse.reserve(ctx, h, nwords * 4 + 64);
+    if (s == TSQ_OK) s = j->da_pstart.reserve(ctx, h, ((size_t)g.P + 1) * 4 + 64);
+    if (s == TSQ_OK) s = j->da_brows.reserve(ctx, h, (size_t)nb * 4 + 64);
+    if (s != TSQ_OK) { release_all(); return s; }
+    DaStore st;
+    memset(&st, 0, sizeof st);
+    st.ent = ent.p;
+    st.idx = idx.as<uint32_t>();
+    st.cursor = ctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.valid_end = vend.as<uint32_t>();
+    st.ovf = ovf.as<uint32_t>();
+    st.ovf_idx = ovfi.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nb;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    DaSrc src;
+    da_build_key(j, src);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess && !j->da_bits) {  // the byte cells of a unique build side are 0 / 1: their bit form
+        hipLaunchKernelGGL(k_da_bytes_to_bits, dim3(tsq_grid_for(ctx, (int64_t)nwords, 256)), dim3(256), 0, ctx->stream, j->da_img.as<uint8_t>(), j->da_bitimg.as<uint32_t>(), nwords);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
+    if (e == hipSuccess) s = da_launch_partition(j, src, st, true, false);
+    if (e == hipSuccess && s == TSQ_OK) {
+        hipLaunchKernelGGL(k_da_part_starts, dim3(1), dim3(1024), 0, ctx->stream, st, j->da_pstart.as<uint32_t>());
+        e = hipGetLastError();
+    }
+    DaRowsBitsArgs ra;
+    memset(&ra, 0, sizeof ra);
+    ra.st = st;
+    ra.bits = j->da_bits ? j->da_img.as<uint32_t>() : j->da_bitimg.as<uint32_t>();
+    ra.coarse = j->da_coarse.as<uint32_t>();
+    ra.pstart = j->da_pstart.as<uint32_t>();
+    ra.brows = j->da_brows.as<uint32_t>();
+    const size_t lds = ((size_t)1 << j->da_ebits) / 4;  // bits + coarse
+    if (e == hipSuccess && s == TSQ_OK) e = hipFuncSetAttribute((const void*)k_da_build_rows_bits<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && s == TSQ_OK) {
+        hipLaunchKernelGGL((k_da_build_rows_bits<1024>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus)), dim3(1024), lds, ctx->stream, ra);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 52, st.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0;
+    if (e == hipSuccess && e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms += ms;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    release_all();
+    j->st.kernel_launches += 4;
+    if (s != TSQ_OK) return s;
+    if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("bit-cell build rows: ") + hipGetErrorString(e));
+    if (((const uint32_t*)(ctx->pinned + 52))[0] != 0) return TSQ_OK;  // skewed build keys: some rows missed their region — the other routes keep this join
+    j->da_bitrows_state = 1;
+    return TSQ_OK;
+}
+
+tsq_status da_emit_bits(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows, const uint8_t* sel) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nrows, 1024 * 8);
+    if (g.nregions * g.cap >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "radix probe batch too large");
+    TSQ_TRY(j->rkeys.reserve(ctx, h, g.ent_bytes));
+    TSQ_TRY(j->ridx.reserve(ctx, h, g.nregions * g.cap * 4 + 256));
+    TSQ_TRY(j->rctl.reserve(ctx, h, g.ctl_bytes));
+    TSQ_TRY(j->rvend.reserve(ctx, h, g.nregions * 4));
+    TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(j->rovfidx.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    if (outer) TSQ_TRY(j->rmiss.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    const size_t n_pc = (size_t)g.P + 1;
+    TSQ_TRY(j->tkcnt.reserve(ctx, h, n_pc * 8 + 64));
+    DaStore st;
+    memset(&st, 0, sizeof st);
+    st.ent = j->rkeys.p;
+    st.idx = j->ridx.as<uint32_t>();
+    st.cursor = j->rctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.miss_count = st.cursor + g.nregions + 1;
+    st.miss = j->rmiss.as<uint32_t>();
+    st.valid_end = j->rvend.as<uint32_t>();
+    st.ovf = j->rovf.as<uint32_t>();
+    st.ovf_idx = j->rovfidx.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nrows;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->tkcnt.p, 0, n_pc * 8, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));
+    hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
+    for (int e = 0; e < 3; e++)
+        if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    DaSrc src;
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src, sel));
+    TSQ_TRY(da_launch_partition(j, src, st, true, outer));
+    TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
+    // ---- sizing pass: output rows per partition (one bit test per entry), their exclusive scan
+    const uint32_t* bits = j->da_bits ? j->da_img.as<uint32_t>() : j->da_bitimg.as<uint32_t>();
+    DaProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.st = st;
+    pa.img = (const uint8_t*)bits;
+    pa.counters = (unsigned long long*)(ctx->dscratch + 52);
+    pa.pcount = j->tkcnt.as<unsigned long long>();
+    const size_t img_lds = ((size_t)1 << j->da_ebits) / 8;
+    const dim3 pgrid(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * (img_lds <= (64u << 10) ? 2u : 1u)));
+    if (outer) {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<1024, uint32_t, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds));
+        hipLaunchKernelGGL((k_da_probe_count<1024, uint32_t, true, true, true>), pgrid, dim3(1024), img_lds, ctx->stream, pa);
+        TSQ_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL((k_da_probe_ovf<true, true>), dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    } else {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_probe_count<1024, uint32_t, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)img_lds));
+        hipLaunchKernelGGL((k_da_probe_count<1024, uint32_t, true, false, true>), pgrid, dim3(1024), img_lds, ctx->stream, pa);
+        TSQ_HIP(h, hipGetLastError());
+        hipLaunchKernelGGL((k_da_probe_ovf<false, true>), dim3(ctx->num_cus), dim3(256), 0, ctx->stream, pa);
+    }
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, pa.pcount, (int)n_pc);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 52, pa.pcount + g.P, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 53, ctx->dscratch + 52, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 54, st.miss_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const int64_t part_rows = (int64_t)ctx->pinned[52], ovf_rows = (int64_t)ctx->pinned[53];
+    const int64_t miss_rows = outer ? (int64_t)((const uint32_t*)(ctx->pinned + 54))[0] : 0;
+    const int64_t out_rows = part_rows + ovf_rows + miss_rows;
+    j->st.kernel_launches += 3;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)st.bits;
+    j->st.probe_route = TSQ_ROUTE_PACKED;
+    j->st.packed_key_bits = (int32_t)j->da_dm.b;
+    if (out_rows == 0) {
+        TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+        TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    return materialise_pairs(j, pcs, a, nrows, out_rows, [&]() -> tsq_status {
+        DaEmitBitsArgs ea;
+        memset(&ea, 0, sizeof ea);
+        ea.st = st;
+        ea.bits = bits;
+        ea.coarse = j->da_coarse.as<uint32_t>();
+        ea.pstart = j->da_pstart.as<uint32_t>();
+        ea.brows = j->da_brows.as<uint32_t>();
+        ea.pbase = pa.pcount;
+        ea.pairs = a.pairs;
+        ea.ovf_cursor = (unsigned long long*)(ctx->dscratch + 53);
+        ctx->pinned[55] = (uint64_t)part_rows;
+        TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 53, ctx->pinned + 55, 8, hipMemcpyHostToDevice, ctx->stream));
+        const size_t lds = ((size_t)1 << j->da_ebits) / 4;
+        const dim3 egrid(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * (lds <= (64u << 10) ? 2u : 1u)));
+        if (outer) {
+            TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_pairs_bits<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_da_emit_pairs_bits<1024, true>), egrid, dim3(1024), lds, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+            hipLaunchKernelGGL(k_da_emit_ovf_bits<true>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+            if (miss_rows) {
+                hipLaunchKernelGGL(k_da_emit_miss, dim3(tsq_grid_for(ctx, miss_rows, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)st.miss, (uint32_t)miss_rows,
+                                   a.pairs + part_rows + ovf_rows);
+                TSQ_HIP(h, hipGetLastError());
+            }
+        } else {
+            TSQ_HIP(h, hipFuncSetAttribute((const void*)k_da_emit_pairs_bits<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_da_emit_pairs_bits<1024, false>), egrid, dim3(1024), lds, ctx->stream, ea);
+            TSQ_HIP(h, hipGetLastError());
+            hipLaunchKernelGGL(k_da_emit_ovf_bits<false>, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, ea);
             TSQ_HIP(h, hipGetLastError());
         }
         TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
@@ -2831,6 +3056,11 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         TSQ_TRY(da_prepare_rows(j));
         if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows, selected_dev);
     }
+    if (da_bits_emit_eligible(j, nrows)) {  // a unique build side whose key range needs 4-byte entries: pairs through bit cells
+        TSQ_TRY(da_prepare(j));
+        TSQ_TRY(da_prepare_rows_bits(j));
+        if (j->da_bitrows_state == 1) return da_emit_bits(j, pcs, a, nrows, selected_dev);
+    }
     TSQ_TRY(need_table());
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
     j->st.probe_route = TSQ_ROUTE_DIRECT;
@@ -3331,7 +3561,7 @@ static bool table_can_wait(const tsq_join* j, int64_t nb) {
     if (tsq_knob(j->ctx, TSQ_KNOB_PACKED_KEYS, 1) == 0 || tsq_knob(j->ctx, TSQ_KNOB_LAZY_TABLE, 1) == 0) return false;
     if (j->multi ? !da_multi_ok(j) : !(is_int_class(j->cfg.build_types[j->ks.bidx[0]]) && is_int_class(j->cfg.probe_types[j->ks.pidx[0]]))) return false;
     if (!j->filters_h.empty() || j->ordered) return false;
-    return j->packing_mode == TSQ_RADIX_FORCE || nb >= tsq_knob(j->ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(4 << 20));
+    return j->packing_mode == TSQ_RADIX_FORCE || nb >= tsq_knob(j->ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(1 << 20));
 }
 
 TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {

@@ -361,33 +361,42 @@ class _Collected(G.GpuExecutor):
         self.child, self.buf, self.n, self.cap = child, None, 0, 0
 
     def collect(self):
+        """-> (owned DeviceColumns of all the child's rows, row count).  A column gets a null bitmap only if some batch brings one
+        (the batches of a NOT NULL column have none); bitmaps are appended at arbitrary bit positions (tsq_bitmap_append): a child's
+        batches need not be multiples of 8 rows"""
         parts, total = [], 0
         while True:
             chk = self.child.Next()
-            if chk.NumRows() == 0:
+            m = chk.NumRows()
+            if m == 0:
                 break
             # the child's buffers are reused by its next Next(): copy the batch (device to device, on the context's stream)
-            m = chk.NumRows()
-            cols = [G.DeviceColumn(self.ctx, t, m) for t in self.types]
-            for src, dst in zip(chk.columns, cols):
+            cols = []
+            for src, t in zip(chk.columns, self.types):
                 assert not src.var, "the exchange executors of the distributed plans move fixed-width columns"
+                dst = G.DeviceColumn(self.ctx, t, m, with_bitmap=src.bitmap is not None)
                 _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.data, src.data, m * G._es(src.tp)), self.ctx.h)
                 if src.bitmap is not None:
                     _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.bitmap, src.bitmap, (m + 7) // 8), self.ctx.h)
-                else:
-                    self.ctx.memset(dst.bitmap, 0xFF, (m + 7) // 8)
+                cols.append(dst)
             parts.append((cols, m))
             total += m
         if len(parts) == 1:
             return parts[0][0], total
-        out = [G.DeviceColumn(self.ctx, t, max(total, 1) + 64) for t in self.types]
-        at = 0
-        for cols, m in parts:  # batches are multiples of 8 rows except the last one of a child: bitmaps concatenate byte-wise
-            assert at % 8 == 0, "a child handed out a batch that is not a multiple of 8 rows before its last one"
-            for src, dst in zip(cols, out):
-                _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.data + at * G._es(src.tp), src.data, m * G._es(src.tp)), self.ctx.h)
-                _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.bitmap + at // 8, src.bitmap, (m + 7) // 8), self.ctx.h)
-            at += m
+        if not parts:
+            return [G.DeviceColumn(self.ctx, t, 1, with_bitmap=False) for t in self.types], 0
+        out = []
+        for i, t in enumerate(self.types):
+            nullable = any(cols[i].bitmap is not None for cols, _ in parts)
+            dst = G.DeviceColumn(self.ctx, t, total + 64, with_bitmap=nullable)
+            at = 0
+            for cols, m in parts:
+                src = cols[i]
+                _lib.check(self.lib.tsq_copy_d2d(self.ctx.h, dst.data + at * G._es(t), src.data, m * G._es(t)), self.ctx.h)
+                if nullable:
+                    _lib.check(self.lib.tsq_bitmap_append(self.ctx.h, dst.bitmap, at, src.bitmap, m), self.ctx.h)
+                at += m
+            out.append(dst)
         self.ctx.sync()
         for cols, _ in parts:
             for c in cols:
