@@ -423,10 +423,13 @@ def main():
                         ("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("wide_keys_31bit_unique_bit_cells", lambda: extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("two_key_columns_count", lambda: extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr)),
+                        ("two_key_columns_count_48bit", lambda: extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, spread=1000003)),
                         ("variants_8d", lambda: extra_variants(ctx, abi, _lib, bk, nb, npr)),
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
                         ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
+                        ("c3_zipf_s1", lambda: extra_c3_variant(ctx, abi, _lib, "zipf")),
+                        ("c3_sparse_keys", lambda: extra_c3_variant(ctx, abi, _lib, "sparse")),
                         ("agg_two_keys_1000x100", lambda: extra_two_keys(ctx, abi, _lib)),
                         ("agg_two_keys_50x20", lambda: extra_two_keys(ctx, abi, _lib, ma=50, mb=20)),
                         ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
@@ -471,6 +474,7 @@ def main():
         comm.close()
     ctx.close()
     sys.stdout.flush()
+    C.CDLL(None).fflush(None)  # C stdio too (RCCL announces itself with printf: on a pipe that text would come out at exit, after the line)
     os.dup2(real_stdout, 1)
     os.close(real_stdout)
     if rank == 0:
@@ -770,7 +774,7 @@ def extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
             "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "packed_images_ms": st.packed_build_ms, "steps": steps}
 
 
-def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3):
+def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3, spread=1):
     """The headline join on TWO key columns: (k div 10000, k mod 10000) on both sides — the same pairs match as in the one-column
     join, every second probe row's second cell is pushed out of its field (a miss).  Packed route (the cells composed into one key
     column per batch) against the direct route (64-bit tag of both cells, cells compared)."""
@@ -780,7 +784,9 @@ def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3):
     hb, hp = np.empty(nb, dtype=np.int64), np.empty(npr, dtype=np.int64)
     ctx.d2h(hb, bk)
     ctx.d2h(hp, pk)
-    cols_h = [hb // 10000, hb % 10000, hp // 10000, hp % 10000 + 20000 * (np.arange(npr, dtype=np.int64) & 1)]
+    # spread > 1: the first key column's cells are multiplied — the same pairs match, but its field is wider (spread = 1000003: 34 + 14 =
+    # 48 bits of fields: beyond the packed composite's 28 bits, the composite-key child join takes the COUNT(*): tsq_join.hip, wide_prepare)
+    cols_h = [hb // 10000 * spread, hb % 10000, hp // 10000 * spread, hp % 10000 + 20000 * (np.arange(npr, dtype=np.int64) & 1)]
     del hb, hp
     want = int(npr - npr // 2)
     dev = [ctx.alloc(len(c) * 8) for c in cols_h]
@@ -789,7 +795,7 @@ def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3):
         for d, c in zip(dev, cols_h):
             ctx.h2d(d, np.ascontiguousarray(c))
         del cols_h
-        for name, mode in (("packed", abi.RADIX_AUTO), ("direct", abi.RADIX_OFF)):
+        for name, mode in ((("packed" if spread == 1 else "composite_key_child_join"), abi.RADIX_AUTO),) + ((("direct", abi.RADIX_OFF),) if spread == 1 else ()):
             cfg = abi.JoinCfg()
             cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 2, 2, 2
             for i in range(2):
@@ -823,7 +829,8 @@ def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3):
     finally:
         for d in dev:
             ctx.free(d)
-    res["workload"] = "1e8 x 1e8 count(*) on TWO BIGINT key columns (k div 10000, k mod 10000), hit ratio 0.5; frac prices 32 B per probe row (two key cells + one 16 B slot)"
+    res["workload"] = ("1e8 x 1e8 count(*) on TWO BIGINT key columns (k div 10000%s, k mod 10000), hit ratio 0.5; frac prices 32 B per probe row (two key cells + one 16 B slot)"
+                       % ("" if spread == 1 else " x %d: %d bits of fields" % (spread, 48)))
     return res
 
 
@@ -1006,6 +1013,115 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
             "frac": algo / ms / 1e6 / 8000.0, "verified": bool(ng.value == groups and check.get("ok")), "check": check, "first_run_ms": runs[0],
             "route": "packed keys: %d-bit key range, 2-byte entries + argument cells, direct-addressed LDS accumulators" % st.packed_key_bits if st.packed_key_bits else "64-bit table words, LDS hash tables",
             "timing": "HIP events around every tsq_agg_push (%d device-resident batches of %.3g rows) + tsq_agg_finish; second of two runs" % ((n + batch - 1) // batch, batch)}
+
+
+def extra_c3_variant(ctx, abi, _lib, keys, n=1_000_000_000, groups=1_000_000, batch=250_000_000):
+    """SURVEY.md 8(d)'s C3 variants: SELECT k, SUM(v), COUNT(*) GROUP BY k over 1e9 rows, v = r mod 1000 (BIGINT: exact), with
+      keys = "zipf"  : skewed keys in [0, 1e6) with the s = 1 harmonic envelope (TSQ_GEN_ZIPF_OCT: key 0 alone is 5 % of the rows)
+      keys = "sparse": 1e6 distinct keys drawn from the whole 64-bit space (splitmix64 of r mod 1e6) — no dense range to pack
+    Verified against numpy: per-key COUNT(*) by np.bincount over host copies of the key batches (zipf) / the exact key set (sparse),
+    sum of the groups' sums = numpy's sum of all values, sum of counts = rows."""
+    import numpy as np
+
+    lib = ctx.lib
+    k, v, t = ctx.alloc(batch * 8), ctx.alloc(batch * 8), ctx.alloc(batch * 8)
+    try:
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 1
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
+        cfg.n_input_cols = 2
+        cfg.input_types[0], cfg.input_types[1] = abi.I64, abi.I64
+        cfg.n_aggs = 3
+        for i, (f, col) in enumerate([(abi.AGG_FIRSTROW, 0), (abi.AGG_SUM, 1), (abi.AGG_COUNT, -1)]):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
+        cfg.est_groups = groups
+
+        def gen(done, m):
+            if keys == "zipf":
+                ctx.gen_column(_spec(abi, abi.GEN_ZIPF_OCT, table=6, col=0, a=20, m=groups, start=done), m, k)
+            else:
+                ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=6, col=0, m=groups, start=done), m, t)
+                ctx.gen_column(_spec(abi, abi.GEN_HASH_OF_COL, table=6, b=0x5EED5EED), m, k, src=t)
+            ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=6, col=1, m=1000, start=done), m, v)
+            ctx.sync()
+
+        runs, want_sum = [], 0
+        want_cnt = np.zeros(groups, dtype=np.int64)
+        for run in range(2):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ms, done = 0.0, 0
+                while done < n:
+                    m = min(batch, n - done)
+                    gen(done, m)
+                    if run == 1:
+                        host = np.empty(m, dtype=np.int64)
+                        ctx.d2h(host, v)
+                        want_sum += int(host.sum(dtype=np.int64))
+                        ctx.d2h(host, t if keys == "sparse" else k)  # (sparse: the key's pre-image r mod 1e6 is what numpy counts)
+                        want_cnt += np.bincount(host, minlength=groups)
+                        del host
+                    ctx.timer_start()
+                    _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m)), 2, m), h)
+                    ms += ctx.timer_stop_ms()
+                    done += m
+                ctx.timer_start()
+                _lib.check(lib.tsq_agg_finish(h), h)
+                ms += ctx.timer_stop_ms()
+                runs.append(ms)
+                ng = C.c_int64(0)
+                _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
+                if run == 1:
+                    cap = max(ng.value, 8)
+                    dbufs = [ctx.alloc(cap * 8) for _ in range(3)]
+                    dbms = [ctx.alloc(cap // 8 + 64) for _ in range(3)]
+                    out = (abi.Col * 3)()
+                    for i in range(3):
+                        out[i].data, out[i].length, out[i].elem_size, out[i].type, out[i].flags = dbufs[i], cap, 8, abi.I64, abi.COL_DEVICE
+                        out[i].null_bitmap = dbms[i]
+                    nn, eos = C.c_int64(0), C.c_int32(0)
+                    _lib.check(lib.tsq_agg_pull(h, out, 3, cap, C.byref(nn), C.byref(eos)), h)
+                    got = [np.empty(nn.value, dtype=np.int64) for _ in range(3)]
+                    for i in range(3):
+                        ctx.d2h(got[i], dbufs[i])
+                    for pbuf in dbufs + dbms:
+                        ctx.free(pbuf)
+                    if keys == "sparse":  # the group of pre-image x carries the key splitmix64(x ^ b): compare the key SETS and the counts through it
+                        pre = np.arange(groups, dtype=np.uint64) ^ np.uint64(0x5EED5EED)
+                        with np.errstate(over="ignore"):
+                            z = pre + np.uint64(0x9E3779B97F4A7C15)
+                            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                            z = z ^ (z >> np.uint64(31))
+                        order = np.argsort(z)
+                        gk = got[0].view(np.uint64)
+                        gorder = np.argsort(gk)
+                        present = want_cnt[order] > 0
+                        keys_ok = bool(len(gk) == int(present.sum()) and (gk[gorder] == z[order][present]).all())
+                        counts_ok = bool(keys_ok and (got[2][gorder] == want_cnt[order][present]).all())
+                    else:
+                        present = want_cnt > 0
+                        inr = (got[0] >= 0) & (got[0] < groups)
+                        keys_ok = bool(inr.all() and len(np.unique(got[0])) == len(got[0]) == int(present.sum()))
+                        counts_ok = bool(keys_ok and (want_cnt[got[0]] == got[2]).all())
+                    check = {"groups_pulled": int(nn.value), "keys_are_the_expected_set": keys_ok, "every_count_equals_numpy_bincount": counts_ok,
+                             "sum_of_sums": int(got[1].sum()), "sum_of_values_numpy": want_sum, "largest_group_rows": int(got[2].max()) if nn.value else 0}
+                    check["ok"] = bool(keys_ok and counts_ok and check["sum_of_sums"] == want_sum and int(got[2].sum()) == n)
+            finally:
+                lib.tsq_agg_destroy(h)
+        ms = runs[-1]
+    finally:
+        for b in (k, v, t):
+            ctx.free(b)
+    return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows, v BIGINT r mod 1000, keys: %s" %
+                        ("Zipf-like (s = 1 envelope per octave) over [0, 1e6)" if keys == "zipf" else "1e6 distinct values spread over the 64-bit space"),
+            "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value, "frac": (16.0 * n + 24.0 * ng.value) / ms / 1e6 / 8000.0, "verified": bool(check.get("ok")),
+            "check": check, "first_run_ms": runs[0],
+            "route": ("packed keys: %d-bit key range" % st.packed_key_bits) if st.packed_key_bits else "64-bit key words, LDS hash tables per partition (H mode)",
+            "timing": "HIP events around every tsq_agg_push + tsq_agg_finish; second of two runs; frac prices 16 B per row + 24 B per group (SURVEY.md 8d)"}
 
 
 def extra_two_keys(ctx, abi, _lib, n=250_000_000, ma=1000, mb=100):

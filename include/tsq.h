@@ -163,7 +163,10 @@ enum {
     TSQ_GEN_AFFINE = 1,     /* v = (a*i + b) mod m : bijection on [0,m) when gcd(a,m)=1, m < 2^31        */
     TSQ_GEN_RAND_MOD = 2,   /* v = r(i,c) mod m                                                           */
     TSQ_GEN_RAND_F64 = 3,   /* v = (r(i,c)>>11) * 2^-53 in [0,1)  (rand.Float64, benchmark_test.go:118)   */
-    TSQ_GEN_HASH_OF_COL = 4 /* v = splitmix64(src[i] ^ b): payload that is a function of another column  */
+    TSQ_GEN_HASH_OF_COL = 4,/* v = splitmix64(src[i] ^ b): payload that is a function of another column  */
+    TSQ_GEN_ZIPF_OCT = 5    /* skewed keys with the s = 1 harmonic envelope, piecewise constant per octave: an octave e is drawn uniformly
+                               from [0, a), then a value uniformly from [2^e, 2^(e+1)); v = (that - 1) mod m.  P(v) ~ 1 / (a 2^floor(log2(v+1))):
+                               key 0 takes 1 / a of the rows (C3 with Zipf s = 1.0 keys)                */
 };
 typedef struct tsq_gen_spec {
     int32_t  kind;

@@ -964,6 +964,12 @@ void orc_gen_column(const tsq_gen_spec* spec, int64_t nrows, void* dst, uint8_t*
                 break;
             }
             case TSQ_GEN_HASH_OF_COL: v = splitmix64(((const uint64_t*)src)[k] ^ s.b); break;
+            case TSQ_GEN_ZIPF_OCT: {  // an octave drawn uniformly, a value drawn uniformly inside it (include/tsq.h)
+                const uint64_t r = gen_r(s, i, (uint64_t)s.col);
+                const uint64_t lo = 1ull << (r % (s.a ? s.a : 1));
+                v = (lo + (splitmix64(r) & (lo - 1)) - 1) % s.m;
+                break;
+            }
         }
         if (isnull) v = 0;  // NULL slot holds zero bytes (column.go:150-158)
         ((uint64_t*)dst)[k] = v;

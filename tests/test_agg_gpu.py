@@ -294,7 +294,9 @@ def test_multi_key_tag_collisions_are_resolved_not_reported(ctx, orc, bits):
     aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_FIRSTROW, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 2, abi.I64), (abi.AGG_MAX, 2, abi.I64)]
     cfg = H.agg_cfg(types, [0, 1], aggs)
     want = orc.hash_agg(cfg, chk, 4, 4)
-    with ctx.knobs(AGG_TAG_BITS=bits):
+    # (AGG_WIDE_KEYS = 0: the several-column upsert itself is under test — since round 4 integer key columns would otherwise become one
+    # composite key for a single-key child aggregate, which has no tags to collide)
+    with ctx.knobs(AGG_TAG_BITS=bits, AGG_WIDE_KEYS=0):
         stats = []
         got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 22, stats_out=stats)
         got2 = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=7000)  # many batches: later rows meet earlier groups

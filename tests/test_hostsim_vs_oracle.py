@@ -186,7 +186,7 @@ def test_first_error_is_first_node_then_first_row(sim, orc):
 
 def test_generator_matches_oracle(sim, orc):
     for kind, extra in [(abi.GEN_SEQ, {}), (abi.GEN_AFFINE, dict(a=48271, b=11, m=100003)), (abi.GEN_RAND_MOD, dict(m=1000)),
-                        (abi.GEN_RAND_F64, {}), (abi.GEN_HASH_OF_COL, dict(b=0x1234))]:
+                        (abi.GEN_RAND_F64, {}), (abi.GEN_HASH_OF_COL, dict(b=0x1234)), (abi.GEN_ZIPF_OCT, dict(a=20, m=1_000_000))]:
         spec = abi.GenSpec()
         spec.kind, spec.table, spec.col, spec.null_pct, spec.seed, spec.start = kind, 3, 1, 7, 42, 1000
         for k, v in extra.items():

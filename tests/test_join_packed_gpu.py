@@ -617,5 +617,39 @@ def test_packed_bit_cell_pairs_need_a_unique_build_side(ctx, orc):
     want = orc.hash_join(cfg, build, probe)
     stats = []
     got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, stats_out=stats, radix=FORCE, packing=FORCE)
-    assert stats[0].probe_route == abi.ROUTE_DIRECT
+    assert stats[0].probe_route != abi.ROUTE_PACKED  # (the 64-bit LDS route or the direct one)
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+# ------------------------------------------------------------------ several integer key columns of 29..63 bits: COUNT(*) through a composite-key child join
+@pytest.mark.parametrize("shape", ["two_wide", "three_mixed", "four"])
+@pytest.mark.parametrize("n_probe", [1, 4097, 150_001])
+def test_wide_several_key_columns_count_vs_oracle(ctx, orc, shape, n_probe):
+    # the fields of the key columns add up to more than the packed route's 28 bits: the composite (exact up to 63 bits) is the ONE key of a
+    # child join, which takes a single-key route (tsq_join.hip: wide_prepare).  NULL cells, probe cells outside the fields, duplicate tuples,
+    # BIGINT UNSIGNED against BIGINT.
+    rng = np.random.default_rng(len(shape) * 100 + n_probe)
+    fields = {"two_wide": [(abi.I64, -(1 << 21), 1 << 21), (abi.I64, 10**12, 10**12 + (1 << 20))],
+              "three_mixed": [(abi.I64, 0, 1 << 24), (abi.U64, 0, 3000), (abi.I64, -100, 100)],
+              "four": [(abi.I64, 0, 1 << 14), (abi.I64, 0, 1 << 14), (abi.I64, -(1 << 13), 1 << 13), (abi.I64, 5, 9)]}[shape]
+    nk = len(fields)
+    build = _mk_side(rng, 40_000, fields, 1)
+    # probe tuples: half drawn from the build side's tuples (so that the join is not empty), half random around the fields
+    wider = [(tp, lo - 3 if tp != abi.U64 else lo, hi + 3) for tp, lo, hi in fields]
+    probe = _mk_side(rng, n_probe, wider, 1)
+    take = rng.integers(0, build.NumRows(), n_probe)
+    use = rng.random(n_probe) < 0.5
+    for k in range(nk):
+        bc, pc = build.columns[k], probe.columns[k]
+        data = np.where(use, bc.data[take], pc.data)
+        nn = np.where(use, bc.notnull[take] if bc.notnull is not None else True, pc.notnull if pc.notnull is not None else True)
+        probe.columns[k] = Column(pc.tp, data.astype(pc.data.dtype), nn.astype(bool))
+    keys = list(range(nk))
+    cfg = H.join_cfg(probe.types(), build.types(), keys, keys, abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    if n_probe > 1:
+        assert want > 0
+    stats_route = _count(ctx, cfg, build, probe)
+    assert stats_route == want
+    assert _count(ctx, cfg, build, probe, packing=OFF) == want
+    assert _count(ctx, cfg, build, probe, chunk_rows=1024) == want

@@ -25,7 +25,7 @@ COL_DEVICE = 1
 COL_BORROW = 2
 
 # generator kinds
-GEN_SEQ, GEN_AFFINE, GEN_RAND_MOD, GEN_RAND_F64, GEN_HASH_OF_COL = 0, 1, 2, 3, 4
+GEN_SEQ, GEN_AFFINE, GEN_RAND_MOD, GEN_RAND_F64, GEN_HASH_OF_COL, GEN_ZIPF_OCT = 0, 1, 2, 3, 4, 5
 
 # join types / agg funcs / modes
 JOIN_INNER, JOIN_LEFT_OUTER, JOIN_RIGHT_OUTER = 0, 1, 2

@@ -2338,7 +2338,7 @@ TSQ_API tsq_status tsq_agg_pull(tsq_agg* a, tsq_col* out_cols, int32_t n_cols, i
                 memcpy(o.data, (const char*)a->hdata[oc].p + so[0], (size_t)(so[n] - so[0]));
                 for (int64_t i = 0; i <= n; i++) o.offsets[i] = so[i] - so[0];
             } else {
-                memcpy(o.data, (const char*)a->hdata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es);
+                tsq_host_copy(o.data, (const char*)a->hdata[oc].p + (size_t)a->out_cursor * es, (size_t)n * es);
             }
             const uint8_t* src = (const uint8_t*)a->hbitmap[oc].p;
             if ((a->out_cursor & 7) == 0) memcpy(o.null_bitmap, src + (a->out_cursor >> 3), tsq_bitmap_bytes(n));

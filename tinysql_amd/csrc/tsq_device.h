@@ -136,6 +136,11 @@ TSQ_HD uint64_t tsq_gen_value(const tsq_gen_spec& s, uint64_t i, uint64_t src) {
             return tsq_f64_bits((double)(tsq_gen_r(s.seed, (uint32_t)s.table, (uint64_t)s.col, i) >> 11) *
                                 (1.0 / 9007199254740992.0));
         case TSQ_GEN_HASH_OF_COL: return tsq_splitmix64(src ^ s.b);
+        case TSQ_GEN_ZIPF_OCT: {
+            const uint64_t r = tsq_gen_r(s.seed, (uint32_t)s.table, (uint64_t)s.col, i);
+            const uint64_t lo = 1ull << (r % (s.a ? s.a : 1));
+            return (lo + (tsq_splitmix64(r) & (lo - 1)) - 1) % s.m;
+        }
     }
     return 0;
 }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -204,6 +205,28 @@ struct PinnedBuf {
         cap = 0;
     }
 };
+
+// host-side copy of a large chunk between the caller's memory and pinned staging: one core moves ~10 GB/s, the link 50+, so a copy of
+// several MB is cut into slices for a few threads (a 1 Mi-row push / pull of the cgo shim; 1024-row chunks stay on the calling thread)
+inline void tsq_host_copy(void* dst, const void* src, size_t n) {
+    constexpr size_t kMin = (size_t)2 << 20;
+    if (n < 2 * kMin) {
+        memcpy(dst, src, n);
+        return;
+    }
+    const size_t parts = std::min<size_t>(8, n / kMin);
+    const size_t per = ((n + parts - 1) / parts + 63) & ~(size_t)63;
+    std::vector<std::thread> th;
+    th.reserve(parts - 1);
+    for (size_t p = 1; p < parts; p++) {
+        const size_t lo = p * per;
+        if (lo >= n) break;
+        const size_t len = std::min(per, n - lo);
+        th.emplace_back([=] { memcpy((char*)dst + lo, (const char*)src + lo, len); });
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (auto& t : th) t.join();
+}
 
 inline int tsq_elem_size(int32_t type) { return type == TSQ_F32 ? 4 : 8; }
 inline size_t tsq_bitmap_bytes(int64_t rows) { return (size_t)((rows + 7) / 8); }

@@ -780,6 +780,8 @@ struct tsq_join {
     // (tsq_join_build_finish_shared): the handle answers COUNT(*) for LOCAL probe rows, no 64-bit table exists
     std::vector<uint8_t> used_out;    // per output column: 0 = the parent never reads it (tsq_join_set_used_columns); empty: all are used
     double last_sampled_hit_ratio = -1.0;  // of the last probe batch whose materialising route was chosen by a sample (k_da_sample)
+    int wide_state = 0;               // several integer key columns of 29..63 bits: COUNT(*) through a single-key child join (wide_prepare)
+    tsq_join* wide = nullptr;
     int64_t div0_packed = 0;          // division-by-zero warnings of conditions evaluated over materialised batches (da_post_conditions)
     bool shared = false;
     int64_t shared_image_bytes = 0, shared_usable_local = 0;
@@ -1222,7 +1224,7 @@ tsq_status da_probe_key(tsq_join* j, const tsq_colset& pcs, int64_t nrows, DaSrc
     return TSQ_OK;
 }
 // the fields of a several-column key from the build side's columns, and the build side's composite column
-tsq_status da_compose_build(tsq_join* j, bool* ok) {
+tsq_status da_compose_build(tsq_join* j, bool* ok, uint32_t max_total_bits = TSQ_DA_MAX_BITS) {
     *ok = false;
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
@@ -1254,15 +1256,15 @@ tsq_status da_compose_build(tsq_join* j, bool* ok) {
         j->st.kernel_launches++;
         if (ctx->pinned[50] == 0) return TSQ_OK;  // no usable cell in this column: nothing can match, the direct route says so
         const uint64_t kmin = ctx->pinned[48] ^ ma.flip, range = (ctx->pinned[49] ^ ma.flip) - kmin;
-        if (range >> TSQ_DA_MAX_BITS) return TSQ_OK;
+        if (max_total_bits < 64 && (range >> max_total_bits)) return TSQ_OK;
         uint32_t w = 0;
-        while ((range >> w) != 0) w++;
+        while (w < 64 && (range >> w) != 0) w++;
         f.kmin[k] = kmin;
         f.maxd[k] = range;
         f.shift[k] = total;
         f.skip_high[k] = ma.skip_high;
         total += w;
-        if (total > TSQ_DA_MAX_BITS) return TSQ_OK;
+        if (total > max_total_bits) return TSQ_OK;
     }
     TSQ_TRY(j->da_ckey.reserve(ctx, h, (size_t)nb * 8 + 64));
     DaComposeArgs ca;
@@ -2151,11 +2153,13 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
         return give_up(s);
     }
     const uint32_t cells = 1u << j->da_ebits;
-    sa.sub_bits = j->da_ebits > 13 ? std::min<uint32_t>(3u, j->da_ebits - 13u) : 0u;
+    // 16 sub-buckets per partition: ~60 KB of LDS per workgroup, two 1024-thread workgroups per CU — the kernel is a chain of dependent
+    // loads (image slice, entry units, cells, write-out) and lives on occupancy; the entries stream 16 times per partition, from L2
+    sa.sub_bits = j->da_ebits > 12 ? std::min<uint32_t>(4u, j->da_ebits - 12u) : 0u;
     const uint32_t scells = cells >> sa.sub_bits;
-    // the staging buffer: twice the expected rows of a sub-bucket (denser sub-buckets take several windows), at most ~100 KB
-    const uint64_t expect = (uint64_t)(n / std::max<int64_t>(1, (int64_t)g.P << sa.sub_bits)) * 2 + 1024;
-    sa.stage_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(expect, 2048), 12288);
+    // the staging buffer: 1.5 x the expected rows of a sub-bucket (denser sub-buckets take several windows)
+    const uint64_t expect = (uint64_t)(n / std::max<int64_t>(1, (int64_t)g.P << sa.sub_bits)) * 3 / 2 + 512;
+    sa.stage_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(expect, 1024), 6144);
     {
         DaCoarseArgs ca;
         memset(&ca, 0, sizeof ca);
@@ -2172,7 +2176,8 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
         const size_t lds = (size_t)2 * scells + (size_t)(scells >> 5) * 4 + (size_t)sa.stage_cap * 9 + 16;
         e = hipFuncSetAttribute((const void*)k_da_sort_partition<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) {
-            const uint32_t grid = (uint32_t)std::max(8, (ctx->num_cus / 8) * 8);
+            const uint32_t per_cu = lds <= (72u << 10) ? 2u : 1u;
+            const uint32_t grid = (uint32_t)std::max(8, (ctx->num_cus * (int)per_cu / 8) * 8);
             hipLaunchKernelGGL((k_da_sort_partition<1024>), dim3(grid), dim3(1024), lds, ctx->stream, sa);
             e = hipGetLastError();
         }
@@ -2946,6 +2951,83 @@ tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, i
     return deliver_batch(j, std::move(rb), may_null_v);
 }
 
+// ---- several integer key columns whose fields need 29..63 bits: COUNT(*) through a single-key CHILD join on the composite (round 4)
+// The packed composite (k_da_compose) is exact for any total width up to 63 bits: equal composites <=> equal cells in every column
+// (codec.go:243-338).  Beyond 28 bits the packed images do not take it, but every SINGLE-key route does: the build side's composite
+// column becomes the one BIGINT UNSIGNED key column of a child join, a probe batch is composed and pushed to the child, and the child
+// picks its route (bit cells, the 64-bit LDS route, ...) as for any 64-bit key.  A row that cannot match (a NULL key cell, a probe cell
+// outside its field) composes to ~0: the child compares BIGINT UNSIGNED with BIGINT, where cells >= 2^63 never match (codec.go:219-224).
+tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev);
+bool wide_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || !j->multi || !da_multi_ok(j) || j->wide_state < 0) return false;
+    if (!j->count_only || j->checksum || j->general_cfg || selected_dev || j->never_match) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (4 << 20) && j->bcols[j->ks.bidx[0]].rows >= (1 << 20);
+}
+tsq_status wide_prepare(tsq_join* j) {
+    if (j->wide_state) return TSQ_OK;
+    j->wide_state = -1;
+    bool ok = false;
+    TSQ_TRY(da_compose_build(j, &ok, 63));
+    if (!ok) { j->da_ckey.release(); return TSQ_OK; }
+    tsq_join_cfg cc;
+    memset(&cc, 0, sizeof cc);
+    cc.join_type = TSQ_JOIN_INNER;
+    cc.build_is_right = 1;
+    cc.n_keys = 1;
+    cc.n_build_cols = cc.n_probe_cols = 1;
+    cc.build_types[0] = TSQ_U64;
+    cc.probe_types[0] = TSQ_I64;  // (mixed signedness on purpose: a composite of ~0 — "cannot match" — is dropped on both sides)
+    cc.max_chunk_size = j->cfg.max_chunk_size;
+    cc.concurrency = j->cfg.concurrency;
+    cc.probe_batch_rows = j->cfg.probe_batch_rows;
+    tsq_join* c = nullptr;
+    tsq_status s = tsq_join_create(j->ctx, &cc, &c);
+    if (s != TSQ_OK) return TSQ_OK;
+    c->radix_mode = j->radix_mode;
+    c->packing_mode = j->packing_mode;
+    tsq_col bc;
+    memset(&bc, 0, sizeof bc);
+    bc.data = j->da_ckey.p;
+    bc.length = j->bcols[j->ks.bidx[0]].rows;
+    bc.elem_size = 8;
+    bc.type = TSQ_U64;
+    bc.flags = TSQ_COL_DEVICE;
+    s = tsq_join_build_push(c, &bc, 1, bc.length);
+    if (s == TSQ_OK) s = tsq_join_build_finish(c);
+    if (s == TSQ_OK) s = tsq_join_set_count_only(c, 1);
+    if (s != TSQ_OK) {
+        tsq_fail(&j->hdr, s, c->hdr.err);
+        tsq_join_destroy(c);
+        return s == TSQ_ERR_UNSUPPORTED ? TSQ_OK : s;
+    }
+    j->wide = c;
+    j->wide_state = 1;
+    return TSQ_OK;
+}
+tsq_status wide_count_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+    DaSrc src;
+    const bool was = j->da_multi;
+    j->da_multi = true;  // (da_probe_key composes the batch with j->da_fields)
+    const tsq_status ks = da_probe_key(j, pcs, nrows, src);
+    j->da_multi = was;
+    TSQ_TRY(ks);
+    tsq_colset cs;
+    memset(&cs, 0, sizeof cs);
+    cs.n = 1;
+    cs.data[0] = src.data;
+    cs.type[0] = TSQ_I64;
+    tsq_join* c = j->wide;
+    const tsq_status s = probe_batch(c, cs, nrows, nullptr);
+    if (s != TSQ_OK) return tsq_fail(&j->hdr, s, c->hdr.err);
+    j->st.probe_route = c->st.probe_route;
+    j->st.packed_key_bits = c->st.packed_key_bits;
+    j->st.radix_bits = c->st.radix_bits;
+    j->st.radix_batches++;
+    return TSQ_OK;
+}
+
 // hit ratio of a probe batch against the packed images, from a strided sample of its keys (k_da_sample): one small kernel + one sync
 tsq_status da_sample_hit_ratio(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* sel, double* rho) {
     tsq_ctx* ctx = j->ctx;
@@ -3013,9 +3095,13 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
             if (radix_eligible(j, nrows, selected_dev)) return radix_probe(j, pcs, nrows);  // (the real table may be chained / too small)
         }
     }
-    if (da_multi_count_eligible(j, nrows, selected_dev)) {  // several integer key columns: the packed route or the direct one
+    if (da_multi_count_eligible(j, nrows, selected_dev)) {  // several integer key columns: the packed route ...
         TSQ_TRY(da_prepare(j));
         if (j->da_state == 1) return da_probe(j, pcs, nrows, selected_dev);
+    }
+    if (wide_count_eligible(j, nrows, selected_dev)) {  // ... or, with fields of 29..63 bits, a single-key child join on the composite
+        TSQ_TRY(wide_prepare(j));
+        if (j->wide_state == 1) return wide_count_batch(j, pcs, nrows);
     }
     // ---- materialising packed routes.  Which one: when most probe rows join, the probe columns travel with the entries (K5f + K4e);
     // a SELECTIVE batch (few rows join: a sample of its keys against the images tells, k_da_sample) is better served by (probe row,
@@ -3774,7 +3860,7 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
                 memcpy(o.data, (const char*)rb->hdata[oc].p + so[0], (size_t)(so[n] - so[0]));
                 for (int64_t i = 0; i <= n; i++) o.offsets[i] = so[i] - so[0];
             } else
-            memcpy(o.data, (const char*)rb->hdata[oc].p + (size_t)rb->cursor * es, (size_t)n * es);
+            tsq_host_copy(o.data, (const char*)rb->hdata[oc].p + (size_t)rb->cursor * es, (size_t)n * es);
             if (o.null_bitmap) {
                 if (!has_bm) memset(o.null_bitmap, 0xff, tsq_bitmap_bytes(n));
                 else if ((rb->cursor & 7) == 0) {
@@ -3870,8 +3956,13 @@ TSQ_API tsq_status tsq_join_count(tsq_join* j, int64_t* rows_out) {
     unsigned long long c[8];
     TSQ_TRY(read_counters(j, c));
     TSQ_TRY(status_from_errword(j, c[3]));
-    *rows_out = (int64_t)c[0];
-    j->st.out_rows = (int64_t)c[0];
+    int64_t child = 0;
+    if (j->wide) {  // the batches that went through the composite-key child
+        const tsq_status ws = tsq_join_count(j->wide, &child);
+        if (ws != TSQ_OK) return tsq_fail(&j->hdr, ws, j->wide->hdr.err);
+    }
+    *rows_out = (int64_t)c[0] + child;
+    j->st.out_rows = *rows_out;
     return TSQ_OK;
 }
 
@@ -3941,6 +4032,10 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return;
     (void)hipSetDevice(j->ctx->device);
     (void)hipStreamSynchronize(j->ctx->stream);  // Close() drains in-flight work (join.go:81-107)
+    if (j->wide) {
+        tsq_join_destroy(j->wide);
+        j->wide = nullptr;
+    }
     for (auto& c : j->bcols) c.release();
     for (auto& c : j->pcols) c.release();
     for (auto& r : j->results) r->release();

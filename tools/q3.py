@@ -10,6 +10,7 @@ TinySQL has int / real / string types only (types/eval_type.go:21-28): dates are
 Plan (what planner/core would produce with hash joins): Selection(customer) -> build;  Selection(orders) probes it;
 that result is the build side for Selection(lineitem);  Projection(revenue);  HashAgg.
 usage: q3.py [SF]   (customer 1.5e5*SF, orders 1.5e6*SF, lineitem 6e6*SF rows)"""
+import ctypes as C
 import json
 import os
 import sys
@@ -226,6 +227,7 @@ def main_dist():
                 d.free()
             comm.close()
     sys.stdout.flush()
+    C.CDLL(None).fflush(None)  # C stdio too (RCCL announces itself with printf: on a pipe that text would come out at exit, after the line)
     os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(line))
