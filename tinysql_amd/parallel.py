@@ -34,6 +34,14 @@ def _launch_start_time():
         import psutil
         return psutil.Process(os.getppid()).create_time()
     except Exception:
+        pass
+    try:  # without psutil: field 22 of /proc/<ppid>/stat = start time in clock ticks since boot, next to the boot time
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/stat") as f:
+            btime = next(int(l.split()[1]) for l in f if l.startswith("btime"))
+        return btime + ticks / float(os.sysconf("SC_CLK_TCK"))
+    except Exception:
         return 0.0
 
 
