@@ -1011,7 +1011,11 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
     return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows / 1e6 int64 groups, v %s, HashAggExec" % ("double in [0, 1)" if double else "BIGINT r mod 1000"),
             "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value,
             "frac": algo / ms / 1e6 / 8000.0, "verified": bool(ng.value == groups and check.get("ok")), "check": check, "first_run_ms": runs[0],
-            "route": "packed keys: %d-bit key range, 2-byte entries + argument cells, direct-addressed LDS accumulators" % st.packed_key_bits if st.packed_key_bits else "64-bit table words, LDS hash tables",
+            "route": ("packed keys: %d-bit key range, 2-byte entries + %d-byte argument cells, direct-addressed LDS accumulators%s"
+                      % (st.packed_key_bits, max(st.table_slice_bits, 8) // 8,
+                         ", folded into a dense partial state in HBM that becomes groups once, at finish" if st.dense_flushes else ", partial groups merged after every batch"))
+                     if st.packed_key_bits else "64-bit table words, LDS hash tables",
+            "argument_cell_bits": st.table_slice_bits, "dense_flushes": st.dense_flushes,
             "timing": "HIP events around every tsq_agg_push (%d device-resident batches of %.3g rows) + tsq_agg_finish; second of two runs" % ((n + batch - 1) // batch, batch)}
 
 
@@ -1120,7 +1124,9 @@ def extra_c3_variant(ctx, abi, _lib, keys, n=1_000_000_000, groups=1_000_000, ba
                         ("Zipf-like (s = 1 envelope per octave) over [0, 1e6)" if keys == "zipf" else "1e6 distinct values spread over the 64-bit space"),
             "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value, "frac": (16.0 * n + 24.0 * ng.value) / ms / 1e6 / 8000.0, "verified": bool(check.get("ok")),
             "check": check, "first_run_ms": runs[0],
-            "route": ("packed keys: %d-bit key range" % st.packed_key_bits) if st.packed_key_bits else "64-bit key words, LDS hash tables per partition (H mode)",
+            "route": ("packed keys: %d-bit key range, %d-byte argument cells%s" % (st.packed_key_bits, max(st.table_slice_bits, 8) // 8,
+                      "; the runs of the hot keys that do not fit their partitions' regions go through the overflow store (k_daagg_ovf)" if keys == "zipf" else ""))
+                     if st.packed_key_bits else "64-bit key words, LDS hash tables per partition (H mode)",
             "timing": "HIP events around every tsq_agg_push + tsq_agg_finish; second of two runs; frac prices 16 B per row + 24 B per group (SURVEY.md 8d)"}
 
 

@@ -132,6 +132,8 @@ enum {
     TSQ_KNOB_DA_PAIRS_BELOW_PERMILLE = 22, /* AUTO: a probe batch whose sampled hit ratio lies below this (in 1/1000, default 350) takes the pairs
                                         variant of the materialising packed route (K4d) instead of the travelling columns (K5f + K4e) */
     TSQ_KNOB_AGG_WIDE_KEYS = 23,     /* 0: several integer group-key columns never become one 64-bit composite key (the several-column upsert keeps them) */
+    TSQ_KNOB_AGG_DENSE = 24,         /* 0: the one-key packed aggregate appends partial groups after every batch instead of folding its LDS tables into the dense state; v > 1 (tests): the state is emptied into the table before more than v rows went into it (default 2^31) */
+    TSQ_KNOB_AGG_NARROW_CELLS = 25,  /* 0: the argument column of the packed aggregate always travels as 8-byte cells */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -789,7 +791,7 @@ typedef struct tsq_stats {
     int32_t build_partitioned;     /* 1: the table was assembled slice by slice in LDS (tsq_buildpart.h), 0: row-at-a-time CAS build */
     int64_t build_handed_back_rows; /* partitioned build: rows inserted row by row afterwards (skewed pass-1 / pass-2 regions);
                                        aggregate: rows of a multi-key GROUP BY whose 64-bit tag belonged to another key (resolved) */
-    int32_t table_slice_bits;      /* log2(slices) of the join table (0: one slice) */
+    int32_t table_slice_bits;      /* join: log2(slices) of the join table (0: one slice); aggregate on the packed route: bits of a travelling argument cell (16 / 32: narrow cells, 64) */
     int32_t build_slice_retries;   /* 1: a slice overflowed (skewed keys) and the table was rebuilt as one slice */
     int32_t probe_route;           /* route of the last probe batch: TSQ_ROUTE_* */
     int32_t packed_key_bits;       /* TSQ_ROUTE_PACKED: bits of the build side's key range (0 otherwise) */
@@ -797,7 +799,7 @@ typedef struct tsq_stats {
     int64_t heap_bytes;            /* aggregate: bytes of var-len input cells the operator holds (largest column heap) */
     int64_t heap_compactions;      /* aggregate: times a string heap was compacted to the strings the groups refer to */
     int32_t shared_build;          /* join: 1 = tsq_join_build_finish_shared replicated the packed images (probe rows never cross xGMI) */
-    int32_t reserved0;
+    int32_t dense_flushes;         /* aggregate: times the dense partial state of the one-key packed route became groups of the table (1 = at finish only; 0 = route not taken) */
     int64_t shared_image_bytes;    /* ... bytes of the images every rank all-reduced, once per build side */
     double  shared_allreduce_ms;   /* ... wall time of that all-reduce on this rank */
     int64_t div_by_zero_warnings;  /* join: division-by-zero warnings the OtherConditions / outer filters raised so far (NULL result + warning,

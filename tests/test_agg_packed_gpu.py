@@ -320,3 +320,88 @@ def test_wide_composite_group_key_partial_then_final(ctx, orc, modes):
     got = G.run_agg(ctx, H.agg_cfg(pt, [0, 1, 2], faggs), part, [abi.I64, abi.I64, abi.I64, abi.F64, abi.I64], chunk_rows=1 << 20, fast=abi.AGGFAST_FORCE, stats_out=stats)
     assert stats[0].build_partitioned == 2
     _match_by_key(got, want, [0, 1, 2], [4], [3], _group_tols_multi(chk, [0, 1, 2], full, [3]))
+
+
+# ---------------------------------------------------------------- round 4: dense partial state + narrow argument cells
+def _dense_case(rng, n, key_hi, vmax, neg_frac=0.0):
+    k = Column(abi.I64, rng.integers(0, key_hi, n), rng.random(n) > 0.01)
+    vv = rng.integers(0, vmax, n)
+    if neg_frac:
+        vv[rng.random(n) < neg_frac] = -5
+    v = Column(abi.I64, vv, rng.random(n) > 0.03)
+    return Chunk([k, v]), [abi.I64, abi.I64]
+
+
+@pytest.mark.parametrize("dense,narrow", [(1, 1), (0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("key_hi,vmax,bits", [(30_000, 60_000, 16), (30_000, 3_000_000_000, 32), (3_000_000, 1000, 16), (3_000_000, 1 << 40, 64)])
+def test_packed_agg_dense_state_and_narrow_cells(ctx, orc, dense, narrow, key_hi, vmax, bits):
+    """30 000 keys: 32 partitions, each split over 8 workgroups (device atomics into the dense state); 3e6 keys: one workgroup per
+    partition (plain read-modify-write).  Several device batches, so that the state accumulates across launches."""
+    rng = np.random.default_rng(key_hi % 97 + bits)
+    n = 700_001
+    chk, types = _dense_case(rng, n, key_hi, vmax)
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_MAX, 1, abi.I64), (abi.AGG_MIN, 1, abi.I64)]
+    with ctx.knobs(AGG_DENSE=dense, AGG_NARROW_CELLS=narrow, AGG_BATCH_ROWS=1 << 18):
+        cfg = H.agg_cfg(types, [0], aggs, est_groups=key_hi)
+        want = orc.hash_agg(cfg, chk, 4, 4)
+        stats = []
+        got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 18, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    st = stats[0]
+    assert st.packed_key_bits > 0 and st.radix_batches >= 3
+    assert st.dense_flushes == (1 if dense else 0)
+    assert st.table_slice_bits == (bits if narrow else 64)  # (one travelling argument column: the four aggregates read the same one)
+    assert H.rows_equal_unordered(got, want)
+
+
+@pytest.mark.parametrize("vmax,bits", [(60_000, 16), (3_000_000_000, 32), (1 << 40, 64)])
+def test_packed_agg_narrow_cells_width_and_values_that_do_not_fit(ctx, orc, vmax, bits):
+    """SUM + COUNT(*) (C3's plan: one travelling argument column).  Batch 1 shows values below vmax; batch 2 brings a few larger and
+    negative ones (exception rows, exact all the same); batch 3 is mostly large: the operator goes back to full cells."""
+    rng = np.random.default_rng(bits)
+    nb = 1 << 17
+    k = rng.integers(0, 200_000, 3 * nb)
+    v = rng.integers(0, vmax, 3 * nb)
+    big = np.int64(1 << 50)
+    sel2 = nb + rng.choice(nb, 300, replace=False)
+    v[sel2[:200]] = big + rng.integers(0, 1000, 200)
+    v[sel2[200:]] = -rng.integers(1, 1000, 100)
+    v[2 * nb:][rng.random(nb) < 0.5] = big
+    chk = Chunk([Column(abi.I64, k, rng.random(3 * nb) > 0.01), Column(abi.I64, v, rng.random(3 * nb) > 0.02)])
+    aggs = AGG_SETS["c3"]
+    with ctx.knobs(AGG_BATCH_ROWS=nb):
+        cfg = H.agg_cfg([abi.I64, abi.I64], [0], aggs, est_groups=200_000)
+        want = orc.hash_agg(cfg, chk, 4, 4)
+        stats = []
+        got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=nb, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    st = stats[0]
+    assert st.packed_key_bits > 0 and st.radix_batches == 3 and st.dense_flushes == 1
+    assert st.table_slice_bits == 64  # (after batch 3; batches 1 and 2 travelled `bits` wide)
+    assert H.rows_equal_unordered(got, want)
+    # the same plan on values that fit all the way keeps its narrow cells
+    chk2 = Chunk([chk.columns[0], Column(abi.I64, rng.integers(0, vmax, 3 * nb), rng.random(3 * nb) > 0.02)])
+    with ctx.knobs(AGG_BATCH_ROWS=nb):
+        want = orc.hash_agg(cfg, chk2, 4, 4)
+        stats = []
+        got = G.run_agg(ctx, cfg, chk2, out_types_for(aggs), chunk_rows=nb, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].table_slice_bits == bits and stats[0].dense_flushes == 1
+    assert H.rows_equal_unordered(got, want)
+
+
+def test_packed_agg_dense_state_emptied_between_batches(ctx, orc):
+    """AGG_DENSE = v > 1: the state becomes groups of the table before more than v rows went into it (product: 2^31 rows, so that a
+    group's lo32 sums cannot wrap) — the groups of earlier flushes and later ones must add up; DOUBLE sums within the group tolerance."""
+    rng = np.random.default_rng(77)
+    n = 600_000
+    chk, types = _chunk(rng, n, 0, 100_000)
+    for name in ("c3", "c3_double", "ints", "minmax2"):
+        aggs = AGG_SETS[name]
+        with ctx.knobs(AGG_DENSE=150_000, AGG_BATCH_ROWS=1 << 16):
+            cfg = H.agg_cfg(types, [0], aggs, est_groups=100_000)
+            want = orc.hash_agg(cfg, chk, 4, 4)
+            stats = []
+            got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 16, fast=abi.AGGFAST_FORCE, stats_out=stats)
+        assert stats[0].dense_flushes >= 4, stats[0].dense_flushes
+        real_cols = [i for i, a in enumerate(aggs) if a[0] in (abi.AGG_SUM, abi.AGG_AVG) and a[2] in (abi.F64, abi.F32)]
+        exact_cols = [i for i in range(len(aggs)) if i not in real_cols]
+        key_out = [i for i, a in enumerate(aggs) if a[0] == abi.AGG_FIRSTROW][0]
+        _match_by_key(got, want, [key_out], exact_cols, real_cols, group_tols(chk, 0, aggs, real_cols))

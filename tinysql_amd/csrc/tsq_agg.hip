@@ -1005,6 +1005,12 @@ struct tsq_agg {
     DaDomain da_dm{};
     uint32_t da_pbits = 0, da_ebits = 0;
     int64_t packed_batches = 0;
+    uint32_t da_paybytes = 8;   // width of the one travelling argument column in the partitioned store (8: as it is)
+    // dense partial state of the one-key packed route (tsq_daagg.h): words [k][u] + touch bits, folded into the table at finish
+    int dense_state = 0;        // 0: not tried, 1: in use, -1: not usable
+    DevBuf dense_w[TSQ_AF_MAXW], dense_touch;
+    int64_t dense_rows = 0;     // rows that went into the state since it was last emptied
+    int64_t dense_flushes = 0;
     // several integer key columns as the fields of one packed word (tsq_daagg.h): mk_n > 1.  da_low: the word fits one LDS table
     int mk_n = 0;
     int32_t mk_col[TSQ_DAAGG_MAXK] = {0, 0, 0, 0};
@@ -1311,24 +1317,46 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     const AfPlan& pl = a->fplan;
     if (env_off || (pl.key_type != TSQ_I64 && pl.key_type != TSQ_U64)) return TSQ_OK;
     if (a->mk_n > 1) return da_agg_setup_multi(a, in, nrows);
-    DaMinMaxArgs ma;
-    memset(&ma, 0, sizeof ma);
-    ma.src.data = (const uint64_t*)in.data[pl.key_col];
-    ma.src.nulls = in.nulls[pl.key_col];
-    ma.src.nrows = nrows;
-    ma.flip = pl.key_type == TSQ_I64 ? 0x8000000000000000ULL : 0ULL;
-    ma.out = (unsigned long long*)(ctx->dscratch + 48);
-    ctx->pinned[48] = ~0ULL;
-    ctx->pinned[49] = 0;
-    ctx->pinned[50] = 0;
-    TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 24, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, ma);
+    // the key range — and, for one integer argument column, its value range — over a sample of the batch (one 256-row block of
+    // every 16 once the batch has 4 Mi rows: 2 GB of keys would take 0.4 ms to read, the sample 0.03): a key or an argument the
+    // sample did not show is an exception row later (tsq_daagg.h), never a wrong result
+    DaAggRangeArgs ra;
+    memset(&ra, 0, sizeof ra);
+    ra.data[0] = (const uint64_t*)in.data[pl.key_col];
+    ra.nulls[0] = in.nulls[pl.key_col];
+    ra.flip[0] = pl.key_type == TSQ_I64 ? 0x8000000000000000ULL : 0ULL;
+    ra.ncols = 1;
+    const bool narrow_try = pl.V == 1 && (pl.vtype[0] == TSQ_I64 || pl.vtype[0] == TSQ_U64) && tsq_knob(ctx, TSQ_KNOB_AGG_NARROW_CELLS, 1) != 0;
+    if (narrow_try) {
+        ra.data[1] = (const uint64_t*)in.data[pl.vcol[0]];
+        ra.nulls[1] = in.nulls[pl.vcol[0]];
+        ra.flip[1] = 0;  // as unsigned numbers: a negative BIGINT is a huge value and keeps the full cell
+        ra.ncols = 2;
+    }
+    ra.nrows = nrows;
+    ra.every = nrows >= (4 << 20) ? 16 : 1;
+    ra.out = (unsigned long long*)(ctx->dscratch + 48);
+    for (int c = 0; c < 2; c++) {
+        ctx->pinned[48 + 3 * c] = ~0ULL;
+        ctx->pinned[49 + 3 * c] = 0;
+        ctx->pinned[50 + 3 * c] = 0;
+    }
+    TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 48, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const int64_t sblocks = ((nrows + 255) / 256 + ra.every - 1) / ra.every;
+        hipLaunchKernelGGL(k_daagg_sample_range, dim3((unsigned)std::min<int64_t>(sblocks, (int64_t)ctx->num_cus * 8)), dim3(256), 0, ctx->stream, ra);
+    }
     TSQ_HIP(h, hipGetLastError());
-    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 48, hipMemcpyDeviceToHost, ctx->stream));
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
     a->st.kernel_launches++;
     if (ctx->pinned[50] == 0) return TSQ_OK;
-    const uint64_t kmin = ctx->pinned[48] ^ ma.flip, kmax = ctx->pinned[49] ^ ma.flip, range = kmax - kmin;
+    const uint64_t kmin = ctx->pinned[48] ^ ra.flip[0], kmax = ctx->pinned[49] ^ ra.flip[0], range = kmax - kmin;
+    a->da_paybytes = 8;
+    if (narrow_try && ctx->pinned[53] != 0) {
+        const uint64_t vmax = ctx->pinned[52];
+        a->da_paybytes = vmax < (1ull << 16) ? 2u : (vmax < (1ull << 32) ? 4u : 8u);
+    }
     const int log2c_env = (int)tsq_knob(a->ctx, TSQ_KNOB_DAAGG_LOG2C, 0);  // (experiment knob: 11 = half-size tables)
     const uint32_t log2c = (log2c_env >= 9 && log2c_env <= 12 && pl.W <= 3) ? (uint32_t)log2c_env : (pl.W <= 3 ? 12u : 11u);
     if (range >> TSQ_DAAGG_MAX_BITS) return TSQ_OK;
@@ -1345,6 +1373,105 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     a->da_dm.skip_high = 0;
     a->da_state = 1;
     return TSQ_OK;
+}
+
+// n_part partial groups (key word + W words each) into the group table: consumeIntermData (aggregate.go:424-427)
+tsq_status merge_partials(tsq_agg* a, const AfPartials& parts, uint32_t n_part) {
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const bool mk = a->mk_n > 1;
+    MergeArgs ma;
+    memset(&ma, 0, sizeof ma);
+    ma.plan = a->fplan;
+    ma.in = parts;
+    ma.counters = a->counters.as<unsigned long long>();
+    if (mk) TSQ_TRY(a->slot_of.reserve(ctx, h, (size_t)n_part * 4 + 16));
+    return upsert_loop(a, (int64_t)n_part, nullptr, [&](const AggTable& t, int64_t n, const uint32_t* retry_in, uint32_t* retry_out) -> tsq_status {
+        ma.t = t;
+        ma.bail_after = std::max<uint64_t>(1024, t.cap / 16);
+        ma.n = n;
+        ma.retry_in = retry_in;
+        ma.retry_out = retry_out;
+        if (mk) {  // several key columns: claim by tag, then compare the cells (two launches, as the row upsert does)
+            if (t.cap + 2 >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "multi-key aggregate: more than 2^32 group slots");
+            MergeMultiArgs mm;
+            memset(&mm, 0, sizeof mm);
+            mm.m = ma;
+            mm.ks = a->da_keys;
+            mm.slot_of = a->slot_of.as<uint32_t>();
+            mm.tag_bits = a->test_tag_bits;
+            for (int phase = 0; phase < 2; phase++) {
+                mm.phase = phase;
+                hipLaunchKernelGGL(k_agg_merge_multi, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, mm);
+                TSQ_HIP(h, hipGetLastError());
+                a->st.kernel_launches++;
+            }
+            return TSQ_OK;
+        }
+        hipLaunchKernelGGL(k_agg_merge, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, ma);
+        TSQ_HIP(h, hipGetLastError());
+        a->st.kernel_launches++;
+        return TSQ_OK;
+    });
+}
+
+// ---- dense partial state of the one-key packed route (tsq_daagg.h, K7f)
+void da_dense_args(tsq_agg* a, DaAggDenseArgs& da) {
+    memset(&da, 0, sizeof da);
+    da.plan = a->fplan;
+    da.dm = a->da_dm;
+    for (int k = 0; k < a->fplan.W; k++) da.dense_w[k] = a->dense_w[k].as<unsigned long long>();
+    da.dense_touch = a->dense_touch.as<uint32_t>();
+    da.ncells = (uint64_t)1 << a->da_dm.b;
+}
+// first use: the accumulators of all 2^b packed words, set to the words' initial values.  Not usable (dense_state = -1) when the
+// memory is not there: the batch then appends partial groups as before.
+tsq_status da_dense_setup(tsq_agg* a) {
+    if (a->dense_state) return TSQ_OK;
+    a->dense_state = -1;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    if (tsq_knob(ctx, TSQ_KNOB_AGG_DENSE, 1) == 0 || a->mk_n > 1 || a->da_ebits < 5) return TSQ_OK;
+    const size_t ncells = (size_t)1 << a->da_dm.b;
+    for (int k = 0; k < a->fplan.W; k++)
+        if (a->dense_w[k].reserve(ctx, h, ncells * 8) != TSQ_OK) return TSQ_OK;
+    if (a->dense_touch.reserve(ctx, h, ncells / 8 + 64) != TSQ_OK) return TSQ_OK;
+    DaAggDenseArgs da;
+    da_dense_args(a, da);
+    da.init_only = 1;
+    hipLaunchKernelGGL(k_daagg_dense_emit, dim3(tsq_grid_for(ctx, (int64_t)ncells, 256)), dim3(256), 0, ctx->stream, da);
+    TSQ_HIP(h, hipGetLastError());
+    a->st.kernel_launches++;
+    a->dense_state = 1;
+    a->dense_rows = 0;
+    return TSQ_OK;
+}
+// the touched cells become partial groups and are merged into the table; the state is empty (initial words) afterwards
+tsq_status da_dense_flush(tsq_agg* a) {
+    if (a->dense_state != 1 || a->dense_rows == 0) return TSQ_OK;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const AfPlan& pl = a->fplan;
+    const size_t ncells = (size_t)1 << a->da_dm.b;
+    TSQ_TRY(a->fkey.reserve(ctx, h, ncells * 8));
+    for (int k = 0; k < pl.W; k++) TSQ_TRY(a->fw[k].reserve(ctx, h, ncells * 8));
+    TSQ_TRY(a->fctl.reserve(ctx, h, 64));
+    TSQ_HIP(h, hipMemsetAsync(a->fctl.p, 0, 64, ctx->stream));
+    DaAggDenseArgs da;
+    da_dense_args(a, da);
+    da.out.key = a->fkey.as<unsigned long long>();
+    for (int k = 0; k < pl.W; k++) da.out.w[k] = a->fw[k].as<unsigned long long>();
+    da.out.count = a->fctl.as<uint32_t>();
+    da.out.cap = (uint32_t)ncells;
+    hipLaunchKernelGGL(k_daagg_dense_emit, dim3(tsq_grid_for(ctx, (int64_t)ncells, 256)), dim3(256), 0, ctx->stream, da);
+    TSQ_HIP(h, hipGetLastError());
+    a->st.kernel_launches++;
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 8, a->fctl.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const uint32_t n_part = ((const uint32_t*)(ctx->pinned + 8))[0];
+    a->dense_rows = 0;
+    a->dense_flushes++;
+    return merge_partials(a, da.out, n_part);
 }
 
 // one batch through LDS pre-aggregation.  *done = false: nothing was merged, the caller runs the row path.
@@ -1374,8 +1501,16 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     uint32_t da_nsplit = 1;
     if (packed && !packed_low)
         while (da_nsplit < 8 && ((uint32_t)1 << a->da_pbits) * da_nsplit < (uint32_t)ctx->num_cus) da_nsplit *= 2;
+    // one key column on the packed route: the LDS tables are folded into the dense state, no partial groups leave the batch
+    bool dense = false;
+    if (packed && !packed_low && !mk) {
+        TSQ_TRY(da_dense_setup(a));
+        dense = a->dense_state == 1;
+        const int64_t dk = tsq_knob(ctx, TSQ_KNOB_AGG_DENSE, 1);
+        if (dense && a->dense_rows + nrows > (dk > 1 ? dk : ((int64_t)1 << 31))) TSQ_TRY(da_dense_flush(a));  // (its lo32 sums must not wrap)
+    }
     const size_t nblocks = (low || packed_low) ? (size_t)ctx->num_cus : (((size_t)1 << (packed ? a->da_pbits : bits)) * da_nsplit);
-    const size_t pcap = std::min<size_t>(nblocks * S + (size_t)nrows / 8 + 4096, 0x7fffffffULL);
+    const size_t pcap = dense ? 4096 : std::min<size_t>(nblocks * S + (size_t)nrows / 8 + 4096, 0x7fffffffULL);
     TSQ_TRY(a->fkey.reserve(ctx, h, pcap * 8));
     for (int k = 0; k < pl.W; k++) TSQ_TRY(a->fw[k].reserve(ctx, h, pcap * 8));
     TSQ_TRY(a->fctl.reserve(ctx, h, 64));
@@ -1428,6 +1563,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         memset(&st, 0, sizeof st);
         st.bits = a->da_pbits;
         st.ebits = a->da_ebits;
+        st.paybytes = (pl.V == 1 && !mk) ? a->da_paybytes : 8u;
         const uint32_t P = 1u << st.bits;
         const int K = pl.V == 0 ? 16 : (pl.V == 1 ? 8 : 4), T = 1024 * K;
         const double tiles = ceil((double)nrows / T);
@@ -1437,13 +1573,22 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         const size_t nregions = (size_t)P * 8, slots = nregions * st.cap;
         if (slots >= 0xffffffffULL) return TSQ_OK;
         TSQ_TRY(a->rkeys.reserve(ctx, h, slots * 2 + 256));
-        for (int v = 0; v < pl.V; v++) TSQ_TRY(a->rpay[v].reserve(ctx, h, slots * 8 + 256));
+        for (int v = 0; v < pl.V; v++) TSQ_TRY(a->rpay[v].reserve(ctx, h, slots * (v == 0 ? st.paybytes : 8u) + 256));
         TSQ_TRY(a->rctl.reserve(ctx, h, nregions * 4 + 64));
         TSQ_TRY(a->rvend.reserve(ctx, h, nregions * 4));
         st.ent = a->rkeys.as<uint16_t>();
         st.cursor = a->rctl.as<uint32_t>();
         st.valid_end = a->rvend.as<uint32_t>();
         for (int v = 0; v < pl.V; v++) st.pay[v] = a->rpay[v].as<uint64_t>();
+        if (dense) {  // skewed keys: the runs that do not fit their regions are aggregated from an overflow store (k_daagg_ovf) — it
+                      // holds a whole batch, so it cannot fill
+            TSQ_TRY(a->rokeys.reserve(ctx, h, (size_t)nrows * 4 + 64));
+            for (int v = 0; v < pl.V; v++) TSQ_TRY(a->ropay[v].reserve(ctx, h, (size_t)nrows * 8 + 64));
+            st.ovf_u = a->rokeys.as<uint32_t>();
+            for (int v = 0; v < pl.V; v++) st.ovf_pay[v] = a->ropay[v].as<uint64_t>();
+            st.ovf_count = st.cursor + nregions;
+            st.ovf_cap = (uint32_t)nrows;
+        }
         TSQ_HIP(h, hipMemsetAsync(a->rctl.p, 0, nregions * 4 + 64, ctx->stream));
         TSQ_HIP(h, hipMemsetAsync(a->rvend.p, 0xff, nregions * 4, ctx->stream));
         DaAggSrc src;
@@ -1466,6 +1611,8 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         if (!mk) ks.n = 1;
         const int pgrid = (int)std::min<int64_t>((nrows + T - 1) / T, ctx->num_cus);
         if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
+        else if (pl.V == 1 && st.paybytes == 4) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 4>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
+        else if (pl.V == 1 && st.paybytes == 2) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
         else if (pl.V == 1) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
         else hipLaunchKernelGGL((k_daagg_partition<1024, 4, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
         TSQ_HIP(h, hipGetLastError());
@@ -1477,9 +1624,32 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         da.st = st;
         da.dm = a->da_dm;
         da.nsplit = da_nsplit;
+        if (dense) {
+            for (int k = 0; k < pl.W; k++) da.dense_w[k] = a->dense_w[k].as<unsigned long long>();
+            da.dense_touch = a->dense_touch.as<uint32_t>();
+            a->dense_rows += nrows;
+        }
         const uint32_t wg_per_cu = (pl.W <= 3 && st.ebits <= 11) ? 2u : 1u;
         const int agrid = (int)std::min<uint32_t>(P * da.nsplit, (uint32_t)ctx->num_cus * wg_per_cu);
         TSQ_TRY(launch_agg_da(a, da, agrid));
+        if (dense) {
+            DaAggOvfArgs oa;
+            memset(&oa, 0, sizeof oa);
+            oa.plan = pl;
+            oa.st = st;
+            for (int k = 0; k < pl.W; k++) oa.dense_w[k] = da.dense_w[k];
+            oa.dense_touch = da.dense_touch;
+            const dim3 ogrid((unsigned)ctx->num_cus);
+            switch (pl.W) {
+                case 1: hipLaunchKernelGGL((k_daagg_ovf<1>), ogrid, dim3(TSQ_AF_NT), 0, ctx->stream, oa); break;
+                case 2: hipLaunchKernelGGL((k_daagg_ovf<2>), ogrid, dim3(TSQ_AF_NT), 0, ctx->stream, oa); break;
+                case 3: hipLaunchKernelGGL((k_daagg_ovf<3>), ogrid, dim3(TSQ_AF_NT), 0, ctx->stream, oa); break;
+                case 4: hipLaunchKernelGGL((k_daagg_ovf<4>), ogrid, dim3(TSQ_AF_NT), 0, ctx->stream, oa); break;
+                default: hipLaunchKernelGGL((k_daagg_ovf<5>), ogrid, dim3(TSQ_AF_NT), 0, ctx->stream, oa); break;
+            }
+            TSQ_HIP(h, hipGetLastError());
+            a->st.kernel_launches++;
+        }
         a->packed_batches++;
     } else {
         RadixStore st;
@@ -1543,41 +1713,10 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         a->fast_fallbacks++;
         return TSQ_OK;
     }
-    MergeArgs ma;
-    memset(&ma, 0, sizeof ma);
-    ma.plan = pl;
-    ma.in = la.out;
-    ma.counters = a->counters.as<unsigned long long>();
-    if (mk) TSQ_TRY(a->slot_of.reserve(ctx, h, (size_t)n_part * 4 + 16));
-    TSQ_TRY(upsert_loop(a, (int64_t)n_part, nullptr, [&](const AggTable& t, int64_t n, const uint32_t* retry_in, uint32_t* retry_out) -> tsq_status {
-        ma.t = t;
-        ma.bail_after = std::max<uint64_t>(1024, t.cap / 16);
-        ma.n = n;
-        ma.retry_in = retry_in;
-        ma.retry_out = retry_out;
-        if (mk) {  // several key columns: claim by tag, then compare the cells (two launches, as the row upsert does)
-            if (t.cap + 2 >= 0xffffffffULL) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "multi-key aggregate: more than 2^32 group slots");
-            MergeMultiArgs mm;
-            memset(&mm, 0, sizeof mm);
-            mm.m = ma;
-            mm.ks = a->da_keys;
-            mm.slot_of = a->slot_of.as<uint32_t>();
-            mm.tag_bits = a->test_tag_bits;
-            for (int phase = 0; phase < 2; phase++) {
-                mm.phase = phase;
-                hipLaunchKernelGGL(k_agg_merge_multi, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, mm);
-                TSQ_HIP(h, hipGetLastError());
-                a->st.kernel_launches++;
-            }
-            return TSQ_OK;
-        }
-        hipLaunchKernelGGL(k_agg_merge, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, ma);
-        TSQ_HIP(h, hipGetLastError());
-        a->st.kernel_launches++;
-        return TSQ_OK;
-    }));
+    TSQ_TRY(merge_partials(a, la.out, n_part));
     if (n_exc) TSQ_TRY(agg_rows(a, in, (int64_t)n_exc, a->fexc.as<uint32_t>()));
-    if (packed && (int64_t)n_exc > nrows / 4) a->da_state = -1;  // the range of the first batch does not describe the input: 64-bit H mode from here on
+    if (packed && a->da_paybytes != 8 && (int64_t)n_exc > nrows / 64) a->da_paybytes = 8;  // the sample did not describe the argument column: full cells from here on
+    else if (packed && (int64_t)n_exc > nrows / 4) a->da_state = -1;  // the range of the first batch does not describe the input: 64-bit H mode from here on
     a->fast_batches++;
     *done = true;
     return TSQ_OK;
@@ -2159,6 +2298,7 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     tsq_handle_hdr* h = &a->hdr;
     TSQ_HIP(h, hipSetDevice(ctx->device));
     TSQ_TRY(agg_flush(a));
+    TSQ_TRY(da_dense_flush(a));
     // empty input without GROUP BY: exactly one row of defaults (aggregate.go:572-574,
     // builder.go:517-539): COUNT -> 0, everything else NULL.  The NULL-group slot (cap+1) is the
     // single group of a key-less aggregate; claim it so that finalize emits it.
@@ -2420,6 +2560,8 @@ TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
     a->st.radix_batches = a->fast_batches;
     a->st.radix_overflow_rows = a->fast_fallbacks;
     a->st.packed_key_bits = a->packed_batches > 0 ? (int32_t)a->da_dm.b : 0;
+    a->st.dense_flushes = (int32_t)a->dense_flushes;
+    a->st.table_slice_bits = (a->packed_batches > 0 && a->mk_n <= 1 && a->fplan.V == 1) ? (int32_t)a->da_paybytes * 8 : 0;
     if (a->wide_state == 1) {  // the composite-key child did the work: its batches / packed range, the rows that stayed here as exceptions
         tsq_stats cs;
         if (tsq_agg_stats(a->wide, &cs) == TSQ_OK) {
@@ -2470,6 +2612,8 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
     a->rkeys.release();
     a->rctl.release();
     a->rvend.release();
+    for (auto& b : a->dense_w) b.release();
+    a->dense_touch.release();
     a->rokeys.release();
     for (auto& b : a->rpay) b.release();
     for (auto& b : a->ropay) b.release();

@@ -10,6 +10,11 @@
 // equal key cells, equal group); the key of a partial group comes back as kmin + unmix(u).
 // Rows outside the range (later batches may bring new keys), NULL keys and NULL argument cells go to the exception list and
 // take the row-at-a-time upsert, exactly like the rows tsq_aggfast.h cannot take.
+// Round 4: (1) NARROW ARGUMENT CELLS — one integer argument column whose sampled values are all in [0, 2^16) or [0, 2^32) travels
+// as 2- or 4-byte cells (DaAggStore.paybytes): 4..6 B per row each way instead of 10; a value that does not fit is an exception.
+// (2) DENSE PARTIAL STATE — one key column: the LDS tables are folded into accumulators [word][u] in HBM (u = the b-bit packed
+// word: 2^b x W x 8 B, 24 MB for C3) instead of being appended as partial groups and merged into the hash table after every batch;
+// the touched cells become partial groups ONCE, when the operator finishes (k_daagg_dense_emit), and take the usual merge then.
 //
 // Replaces (reference): HashAggPartialWorker.updatePartialResult + getGroupKey + getPartialResult
 // (executor/aggregate.go:332-410) with LDS as the partial worker's map; the partial groups are merged by k_agg_merge
@@ -27,10 +32,15 @@ struct DaAggStore {
     uint64_t* pay[TSQ_RADIX_MAXV];  // [P * 8 * cap] argument cells travelling with the entry
     uint32_t* cursor;     // [8][P]
     uint32_t* valid_end;  // [8][P]
-    uint32_t* ovf_row;    // overflow list (runs that did not fit their region): source rows, re-read and handled row by row
+    // overflow store (skewed keys: a tile's run that did not fit its region): the whole words u and the argument cells, appended run
+    // by run (one device atomic per run) and aggregated by k_daagg_ovf into the dense state.  ovf_u == nullptr (no dense state), or
+    // the store is full: those rows go to the exception list instead and are aggregated row by row
+    uint32_t* ovf_u;
+    uint64_t* ovf_pay[TSQ_RADIX_MAXV];
     uint32_t* ovf_count;
     uint32_t ovf_cap;
     uint32_t bits, ebits, cap;
+    uint32_t paybytes;    // width of pay[0]'s cells in the store: 8, or 4 / 2 when V == 1 and the values fit (zero-extended)
 };
 // A group key of SEVERAL integer columns as one word: field i holds key_i - kmin_i (or the NULL code of a nullable column) at bit
 // shift[i]; a cell outside its field's window makes the row an exception, like a key outside [kmin, kmin + 2^b) of the one-column
@@ -96,20 +106,26 @@ __device__ __forceinline__ uint32_t daagg_region_len(const DaAggStore& st, uint3
 // K5e — partition of (packed key entry, argument cells).  The structure of k_da_partition (tsq_dajoin.h) with V payload columns
 // staged through LDS next to the words; a run that does not fit its region sends its ROWS to the exception list (they are
 // aggregated row by row: exact under any skew).
-template <int NT, int K, int V>
+template <int PB> struct da_pay_t { typedef uint64_t type; };
+template <> struct da_pay_t<4> { typedef uint32_t type; };
+template <> struct da_pay_t<2> { typedef uint16_t type; };
+template <int NT, int K, int V, int PB = 8>
 __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain dm, DaAggStore st, DaAggKeys ks) {
     constexpr int T = NT * K;
+    static_assert(PB == 8 || (V == 1 && (PB == 4 || PB == 2)), "narrow cells: one argument column");
+    typedef typename da_pay_t<PB>::type PT;
     constexpr int MAXPER = (TSQ_RADIX_MAX_P + NT - 1) / NT;
     static_assert(T <= 65536 && (K % 2) == 0 && V >= 0 && V <= TSQ_RADIX_MAXV, "tile");
     __shared__ uint32_t s_u[T];
     __shared__ uint32_t s_row[T];
-    __shared__ uint64_t s_pay[V ? V : 1][V ? T : 1];
+    __shared__ PT s_pay[V ? V : 1][V ? T : 1];
     __shared__ uint32_t s_hist[TSQ_RADIX_MAX_P];
     __shared__ uint32_t s_delta[TSQ_RADIX_MAX_P];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_flag;
     const uint32_t tid = threadIdx.x;
     const uint32_t P = 1u << st.bits, ebits = st.ebits, emask = (1u << ebits) - 1u;
+    auto fits = [](uint64_t cell) -> bool { return PB == 8 || (cell >> (PB == 8 ? 0 : 8 * PB)) == 0; };
     const uint32_t r = tsq_xcc_id();
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
     if (tid == 0) s_flag = 0;
@@ -179,6 +195,7 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
             for (int j = 0; j < K; j++) {
                 if (mk) u[j] = dsum[j] == TSQ_DA_NONE ? TSQ_DA_NONE : tsq_da_mix(dsum[j], dm.s, dm.mask);
                 else u[j] = da_word(dm, k[j]);
+                if (PB != 8 && !fits(pay[0][j])) u[j] = TSQ_DA_NONE;
                 if (u[j] == TSQ_DA_NONE) except((uint32_t)base + ((uint32_t)(j >> 1) * NT + tid) * 2 + (j & 1));
             }
         } else {
@@ -200,12 +217,13 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
                             u[j] = da_word(dm, ((const uint64_t*)src.kdata)[base + pos]);
                         }
                     }
-                    if (u[j] == TSQ_DA_NONE) except((uint32_t)base + pos);
-                    else {
+                    if (u[j] != TSQ_DA_NONE) {
 #pragma unroll
                         for (int v = 0; v < V; v++)
                             pay[v][j] = src.vtype[v] == TSQ_F32 ? (uint64_t)((const uint32_t*)src.vdata[v])[base + pos] : ((const uint64_t*)src.vdata[v])[base + pos];
+                        if (PB != 8 && !fits(pay[0][j])) u[j] = TSQ_DA_NONE;
                     }
+                    if (u[j] == TSQ_DA_NONE) except((uint32_t)base + pos);
                 }
             }
         }
@@ -251,39 +269,52 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
             if ((uint32_t)q < per && p0 + q < P) {
                 const uint32_t p = p0 + q, cnt = c[q], offs = run;
                 run += cnt;
-                uint32_t flag = 0;
+                uint32_t flag = 0;  // 2: the run goes to the overflow store, 3: to the exception list
                 if (cnt) {
+                    s_delta[p] = (p * 8u + r) * st.cap + g[q] - offs;
                     if (g[q] + cnt > st.cap) {
-                        flag = 1;
+                        flag = 3;
                         atomicMin(&st.valid_end[r * P + p], g[q]);
                         s_flag = 1;
+                        if (st.ovf_u != nullptr) {
+                            const uint32_t ob = __hip_atomic_fetch_add(st.ovf_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (ob <= st.ovf_cap && cnt <= st.ovf_cap - ob) {
+                                flag = 2;
+                                s_delta[p] = ob - offs;
+                            }
+                        }
                     }
-                    s_delta[p] = (p * 8u + r) * st.cap + g[q] - offs;
                 }
-                s_hist[p] = offs | (flag << 31);
+                s_hist[p] = offs | (flag << 30);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < K; j++)
             if (u[j] != TSQ_DA_NONE) {
-                const uint32_t d = (s_hist[u[j] >> ebits] & 0x7fffffffu) + rk[j];
+                const uint32_t d = (s_hist[u[j] >> ebits] & 0x3fffffffu) + rk[j];
                 s_u[d] = u[j];
                 s_row[d] = (uint32_t)base + (full ? (((uint32_t)(j >> 1) * NT + tid) * 2 + (j & 1)) : ((uint32_t)j * NT + tid));
 #pragma unroll
-                for (int v = 0; v < V; v++) s_pay[v][d] = pay[v][j];
+                for (int v = 0; v < V; v++) s_pay[v][d] = (PT)pay[v][j];
             }
         __syncthreads();
         const bool any_ovf = s_flag != 0;
         for (uint32_t i = tid; i < total; i += NT) {
             const uint32_t w = s_u[i], p = w >> ebits;
-            if (!any_ovf || !(s_hist[p] >> 31)) {
+            const uint32_t how = any_ovf ? (s_hist[p] >> 30) : 0u;
+            if (how == 0) {
                 const uint32_t d = s_delta[p] + i;
                 st.ent[d] = (uint16_t)(w & emask);
 #pragma unroll
-                for (int v = 0; v < V; v++) st.pay[v][d] = s_pay[v][i];
+                for (int v = 0; v < V; v++) reinterpret_cast<PT*>(st.pay[v])[d] = s_pay[v][i];
+            } else if (how == 2) {  // skewed keys: the run did not fit its region — overflow store (k_daagg_ovf)
+                const uint32_t d = s_delta[p] + i;
+                st.ovf_u[d] = w;
+#pragma unroll
+                for (int v = 0; v < V; v++) reinterpret_cast<PT*>(st.ovf_pay[v])[d] = s_pay[v][i];
             } else {
-                except(s_row[i]);  // rare (skewed keys): the run did not fit its region — the row is aggregated row by row
+                except(s_row[i]);  // no overflow store / store full: the row is aggregated row by row
             }
         }
         __syncthreads();
@@ -299,6 +330,10 @@ struct DaAggLdsArgs {
     DaAggStore st;
     DaDomain dm;
     uint32_t nsplit;  // workgroups per partition (1, 2, 4 or 8: each takes every nsplit-th XCC region)
+    // dense partial state (one key column): word k of packed word u accumulates in dense_w[k][u], bit u of dense_touch says the
+    // cell received a row; nullptr: the workgroup appends its touched cells to `out` as partial groups
+    unsigned long long* dense_w[TSQ_AF_MAXW];
+    uint32_t* dense_touch;
 };
 // what one row does to the accumulators of cell e
 // SIG: the two commonest plans with their update descriptors known at compile time — 1: SUM(BIGINT cell 0) + COUNT(*) (words lo32,
@@ -380,6 +415,45 @@ __device__ __forceinline__ void daagg_emit_cells(const AfPlan& plan, const AfPar
         }
     }
 }
+// the workgroup's table folded into the dense accumulators of partition p (cells [p << ebits, (p + 1) << ebits)).  `shared`: other
+// workgroups of this launch fold into the same cells (nsplit > 1) — device atomics; otherwise the cells are this workgroup's alone
+// until the kernel ends and a read-modify-write is enough.  The words stay in their LDS form (a BIGINT sum as lo32 / hi32 sums:
+// the host flushes the state before 2^31 rows went into it, so neither can wrap).
+template <int W, int CELLS>
+__device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const DaAggLdsArgs& a, unsigned long long (*s_w)[CELLS], const uint32_t* s_touch, uint32_t p) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ncell = 1u << a.st.ebits;  // <= CELLS, >= 32 (host)
+    const size_t cbase = (size_t)p << a.st.ebits;
+    const bool shared = a.nsplit > 1;
+    for (uint32_t i = tid; i < ncell; i += TSQ_AF_NT) {
+        if (!((s_touch[i >> 5] >> (i & 31u)) & 1u)) continue;
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            unsigned long long* g = a.dense_w[k] + cbase + i;
+            const unsigned long long v = s_w[k][i];
+            switch (wd[k] & 7u) {
+                case AF_W_ADD_REAL:
+                    if (shared) atomicAdd(reinterpret_cast<double*>(g), tsq_bits_f64(v));
+                    else *g = tsq_f64_bits(tsq_bits_f64(*g) + tsq_bits_f64(v));
+                    break;
+                case AF_W_MAX:
+                    if (shared) atomicMax(g, v);
+                    else if (v > *g) *g = v;
+                    break;
+                case AF_W_MIN:
+                    if (shared) atomicMin(g, v);
+                    else if (v < *g) *g = v;
+                    break;
+                default:  // counts, lo32 / hi32 sums: 64-bit adds
+                    if (shared) atomicAdd(g, v);
+                    else *g += v;
+                    break;
+            }
+        }
+    }
+    for (uint32_t i = tid; i < ncell / 32; i += TSQ_AF_NT)
+        if (s_touch[i]) atomicOr(&a.dense_touch[(cbase >> 5) + i], s_touch[i]);
+}
 template <int W, int CELLS, int SIG = 0>
 __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
     constexpr int U = 4;
@@ -404,29 +478,256 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
         }
         for (uint32_t i = tid; i < (uint32_t)CELLS / 32; i += TSQ_AF_NT) s_touch[i] = 0;
         __syncthreads();
-        for (uint32_t r = r0; r < 8; r += nsplit) {
-            const uint32_t len = daagg_region_len(a.st, P, p, r);
-            const size_t base = (size_t)(p * 8u + r) * a.st.cap;
-            for (uint32_t i0 = tid; i0 < len; i0 += TSQ_AF_NT * U) {
-                uint32_t e[U];
-                uint64_t cells[U][TSQ_RADIX_MAXV];
+        auto regions = [&](auto pb_tag) {  // the width of the travelling argument cells is the same for the whole launch
+            constexpr int PB = decltype(pb_tag)::value;
+            typedef typename da_pay_t<PB>::type PT;
+            for (uint32_t r = r0; r < 8; r += nsplit) {
+                const uint32_t len = daagg_region_len(a.st, P, p, r);
+                const size_t base = (size_t)(p * 8u + r) * a.st.cap;
+                for (uint32_t i0 = tid; i0 < len; i0 += TSQ_AF_NT * U) {
+                    uint32_t e[U];
+                    uint64_t cells[U][TSQ_RADIX_MAXV];
 #pragma unroll
-                for (int x = 0; x < U; x++) {
-                    const uint32_t i = i0 + (uint32_t)x * TSQ_AF_NT;
-                    const uint32_t ic = i < len ? i : 0u;  // (a load that has nothing to fetch reads the region's first slot)
-                    e[x] = a.st.ent[base + ic];
+                    for (int x = 0; x < U; x++) {
+                        const uint32_t i = i0 + (uint32_t)x * TSQ_AF_NT;
+                        const uint32_t ic = i < len ? i : 0u;  // (a load that has nothing to fetch reads the region's first slot)
+                        e[x] = a.st.ent[base + ic];
+                        if (PB != 8) {
+                            cells[x][0] = (uint64_t)reinterpret_cast<const PT*>(a.st.pay[0])[base + ic];
+                            cells[x][1] = 0ull;
+                        } else {
 #pragma unroll
-                    for (int v = 0; v < TSQ_RADIX_MAXV; v++) cells[x][v] = v < a.plan.V ? a.st.pay[v][base + ic] : 0ull;
+                            for (int v = 0; v < TSQ_RADIX_MAXV; v++) cells[x][v] = v < a.plan.V ? a.st.pay[v][base + ic] : 0ull;
+                        }
+                    }
+#pragma unroll
+                    for (int x = 0; x < U; x++)
+                        if (i0 + (uint32_t)x * TSQ_AF_NT < len) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
                 }
-#pragma unroll
-                for (int x = 0; x < U; x++)
-                    if (i0 + (uint32_t)x * TSQ_AF_NT < len) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
             }
-        }
+        };
+        if (a.st.paybytes == 4) regions(std::integral_constant<int, 4>{});
+        else if (a.st.paybytes == 2) regions(std::integral_constant<int, 2>{});
+        else regions(std::integral_constant<int, 8>{});
         __syncthreads();
+        if (a.dense_touch != nullptr) {
+            daagg_fold_dense<W, CELLS>(wd, a, s_w, s_touch, p);
+            continue;
+        }
         daagg_emit_cells<W, CELLS>(a.plan, a.out, s_w, s_touch, &s_base, s_wsum, [&](uint32_t i) -> unsigned long long {
             return a.dm.kmin + (uint64_t)tsq_da_unmix((p << a.st.ebits) | i, a.dm.s, a.dm.mask);
         });
+    }
+}
+
+// K7g — the overflow store of a skewed batch into the dense state.  The rows of a hot key fill the store (its partition's region
+// holds lambda x 1.08 rows; a key with 5 % of the rows brings twenty times that): every workgroup takes a stripe, pre-aggregates in
+// an LDS table HASHED by the word u (the hot keys claim their slots at once, the same one-atomic-per-word updates as k_agg_da), and
+// folds the table into the dense accumulators with device atomics at the end.  A row that finds no slot within 16 steps goes to
+// its dense cell directly: different addresses, so no same-address serialisation (what made the row-at-a-time upsert take 2.9 s
+// on the Zipf variant of C3: 1.7e8 rows behind twenty slots).
+struct DaAggOvfArgs {
+    AfPlan plan;
+    DaAggStore st;
+    unsigned long long* dense_w[TSQ_AF_MAXW];
+    uint32_t* dense_touch;
+};
+template <int W>
+__device__ __forceinline__ void daagg_words_to_dense(const uint32_t (&wd)[W], unsigned long long* const* dense_w, uint32_t* dense_touch, uint32_t u,
+                                                     const unsigned long long (&v)[W]) {
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        unsigned long long* g = dense_w[k] + u;
+        switch (wd[k] & 7u) {
+            case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(g), tsq_bits_f64(v[k])); break;
+            case AF_W_MAX: atomicMax(g, v[k]); break;
+            case AF_W_MIN: atomicMin(g, v[k]); break;
+            default: if (v[k]) atomicAdd(g, v[k]); break;
+        }
+    }
+    atomicOr(&dense_touch[u >> 5], 1u << (u & 31u));
+}
+template <int W>
+__global__ void __launch_bounds__(TSQ_AF_NT) k_daagg_ovf(DaAggOvfArgs a) {
+    constexpr uint32_t S = W <= 3 ? 4096u : 2048u, LOG2S = W <= 3 ? 12u : 11u;
+    constexpr uint32_t EMPTY = 0xffffffffu;
+    uint32_t n = *a.st.ovf_count;
+    n = n < a.st.ovf_cap ? n : a.st.ovf_cap;
+    if (n == 0) return;
+    uint32_t wd[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) wd[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.plan.wdesc[k]);
+    __shared__ uint32_t s_key[S];
+    __shared__ unsigned long long s_w[W][S];
+    __shared__ uint32_t s_touch[S / 32];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < S; i += TSQ_AF_NT) {
+        s_key[i] = EMPTY;
+#pragma unroll
+        for (int k = 0; k < W; k++) s_w[k][i] = a.plan.init[k];
+    }
+    for (uint32_t i = tid; i < S / 32; i += TSQ_AF_NT) s_touch[i] = 0;
+    __syncthreads();
+    auto rows = [&](auto pb_tag) {
+        constexpr int PB = decltype(pb_tag)::value;
+        typedef typename da_pay_t<PB>::type PT;
+        for (uint32_t i = blockIdx.x * TSQ_AF_NT + tid; i < n; i += gridDim.x * TSQ_AF_NT) {
+            const uint32_t u = a.st.ovf_u[i];
+            uint64_t c0 = 0, c1 = 0;
+            if (PB != 8) c0 = (uint64_t)reinterpret_cast<const PT*>(a.st.ovf_pay[0])[i];
+            else {
+                if (a.plan.V > 0) c0 = a.st.ovf_pay[0][i];
+                if (a.plan.V > 1) c1 = a.st.ovf_pay[1][i];
+            }
+            uint32_t slot = (u * 0x9E3779B1u) >> (32u - LOG2S);
+            bool found = false;
+            for (int step = 0; step < 16 && !found; step++) {
+                uint32_t cur = s_key[slot];
+                if (cur == EMPTY) cur = atomicCAS(&s_key[slot], EMPTY, u);
+                if (cur == EMPTY || cur == u) found = true;
+                else slot = (slot + 1) & (S - 1);
+            }
+            if (found) {
+                daagg_apply<W, (int)S, 0>(wd, s_w, s_touch, slot, c0, c1);
+            } else {  // the words of a one-row group, straight into the row's dense cell
+                unsigned long long v[W];
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const uint64_t cell = (wd[k] & 8u) ? c1 : c0;
+                    const int32_t type = (int32_t)(wd[k] >> 4);
+                    switch (wd[k] & 7u) {
+                        case AF_W_ADD1: v[k] = 1ull; break;
+                        case AF_W_ADD_REAL: v[k] = tsq_f64_bits(af_real(cell, type)); break;
+                        case AF_W_ADD_LO32: v[k] = cell & 0xffffffffull; break;
+                        case AF_W_ADD_HI32: v[k] = (unsigned long long)((long long)cell >> 32); break;
+                        default: v[k] = af_ord_image(cell, type); break;
+                    }
+                }
+                daagg_words_to_dense<W>(wd, a.dense_w, a.dense_touch, u, v);
+            }
+        }
+    };
+    if (a.st.paybytes == 4) rows(std::integral_constant<int, 4>{});
+    else if (a.st.paybytes == 2) rows(std::integral_constant<int, 2>{});
+    else rows(std::integral_constant<int, 8>{});
+    __syncthreads();
+    for (uint32_t i = tid; i < S; i += TSQ_AF_NT) {
+        const uint32_t u = s_key[i];
+        if (u == EMPTY) continue;
+        unsigned long long v[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) v[k] = s_w[k][i];
+        daagg_words_to_dense<W>(wd, a.dense_w, a.dense_touch, u, v);
+    }
+}
+
+// K7f — the dense partial state becomes partial groups (once per operator, or before 2^31 rows went into it): every touched cell u
+// leaves as (key = kmin + unmix(u), words in the partial-group form of daagg_emit_cells) and is reset to the words' initial values.
+struct DaAggDenseArgs {
+    AfPlan plan;
+    AfPartials out;
+    DaDomain dm;
+    unsigned long long* dense_w[TSQ_AF_MAXW];
+    uint32_t* dense_touch;
+    uint64_t ncells;
+    int32_t init_only;  // 1: set every cell to the initial words, emit nothing (first use)
+};
+__global__ void __launch_bounds__(256) k_daagg_dense_emit(DaAggDenseArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // (the grid covers whole 64-cell blocks: a wave reads its two touch words together)
+    for (uint64_t u0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) & ~63ull; u0 < a.ncells; u0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t u = u0 + lane;
+        if (a.init_only) {
+            if (u < a.ncells)
+                for (int k = 0; k < a.plan.W; k++) a.dense_w[k][u] = a.plan.init[k];
+            if (lane < 2 && u0 + 32 * lane < a.ncells) a.dense_touch[(u0 >> 5) + lane] = 0;
+            continue;
+        }
+        const bool occ = u < a.ncells && ((a.dense_touch[u >> 5] >> (u & 31u)) & 1u);
+        const unsigned long long m = __ballot(occ);
+        if (m == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = __hip_atomic_fetch_add(a.out.count, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (occ) {
+            const uint32_t o = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            unsigned long long w[TSQ_AF_MAXW];
+            for (int k = 0; k < a.plan.W; k++) {
+                w[k] = a.dense_w[k][u];
+                a.dense_w[k][u] = a.plan.init[k];
+            }
+            for (int q = 0; q < a.plan.n_aggs; q++) {  // split int64 sums -> (lo, hi) of the 128-bit value, as daagg_emit_cells does
+                const AfAgg f = a.plan.f[q];
+                if (f.w < 0 || (f.func != TSQ_AGG_SUM && f.func != TSQ_AGG_AVG) || af_is_real(f.type)) continue;
+                const unsigned long long lo32 = w[f.w], hi32 = w[f.w + 1];
+                const unsigned long long lo = (hi32 << 32) + lo32;
+                w[f.w] = lo;
+                w[f.w + 1] = (unsigned long long)((long long)hi32 >> 32) + (lo < lo32 ? 1ull : 0ull);
+            }
+            if (o < a.out.cap) {
+                a.out.key[o] = a.dm.kmin + (uint64_t)tsq_da_unmix((uint32_t)u, a.dm.s, a.dm.mask);
+                for (int k = 0; k < a.plan.W; k++) a.out.w[k][o] = w[k];
+            }
+        }
+        if (lane < 2 && u0 + 32 * lane < a.ncells) a.dense_touch[(u0 >> 5) + lane] = 0;
+    }
+}
+
+// the value range of up to two columns over a SAMPLE of the batch — of every `every` consecutive 256-row blocks one is read — for the
+// set-up of the packed route: a key or an argument the sample did not show is an exception row later, never a wrong result.
+struct DaAggRangeArgs {
+    const uint64_t* data[2];
+    const uint8_t* nulls[2];
+    uint64_t flip[2];          // order image of the column's type: x ^ flip compares unsigned
+    int32_t ncols;
+    int64_t nrows;
+    int64_t every;
+    unsigned long long* out;   // per column c: [3c] min image (preset ~0), [3c + 1] max image (preset 0), [3c + 2] rows seen
+};
+__global__ void __launch_bounds__(256) k_daagg_sample_range(DaAggRangeArgs a) {
+    uint64_t lo[2] = {~0ull, ~0ull}, hi[2] = {0, 0}, n[2] = {0, 0};
+    const int64_t nblocks = (a.nrows + 255) / 256;
+    for (int64_t sb = blockIdx.x; sb * a.every < nblocks; sb += gridDim.x) {
+        const int64_t row = sb * a.every * 256 + threadIdx.x;
+        if (row >= a.nrows) continue;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c >= a.ncols || tsq_is_null(a.nulls[c], row)) continue;
+            const uint64_t x = a.data[c][row] ^ a.flip[c];
+            lo[c] = x < lo[c] ? x : lo[c];
+            hi[c] = x > hi[c] ? x : hi[c];
+            n[c]++;
+        }
+    }
+    __shared__ uint64_t s_lo[2][4], s_hi[2][4], s_n[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t l2 = __shfl_xor(lo[c], o, 64), h2 = __shfl_xor(hi[c], o, 64);
+            lo[c] = l2 < lo[c] ? l2 : lo[c];
+            hi[c] = h2 > hi[c] ? h2 : hi[c];
+            n[c] += __shfl_xor(n[c], o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_lo[c][threadIdx.x >> 6] = lo[c];
+            s_hi[c][threadIdx.x >> 6] = hi[c];
+            s_n[c][threadIdx.x >> 6] = n[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && (int)threadIdx.x < a.ncols) {
+        const int c = threadIdx.x;
+        uint64_t l = s_lo[c][0], h = s_hi[c][0], m = s_n[c][0];
+        for (int w = 1; w < 4; w++) {
+            l = s_lo[c][w] < l ? s_lo[c][w] : l;
+            h = s_hi[c][w] > h ? s_hi[c][w] : h;
+            m += s_n[c][w];
+        }
+        if (m) {
+            atomicMin(&a.out[3 * c], (unsigned long long)l);
+            atomicMax(&a.out[3 * c + 1], (unsigned long long)h);
+            atomicAdd(&a.out[3 * c + 2], (unsigned long long)m);
+        }
     }
 }
 
