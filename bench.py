@@ -441,21 +441,25 @@ def main():
             except Exception as e:  # reporting only
                 out[key] = {"error": str(e)[:200]}
 
-        # PMC-derived HBM traffic of the extras' kernels (measured offline, committed under profiles/: per launch, KiB; FETCH_SIZE
-        # needs x2 for wide streaming reads on gfx950, per-launch averages mix the shapes a kernel serves — profiles/r03_bench_pmc.txt)
+        # PMC-derived HBM traffic of the extras' kernels (measured offline, committed under profiles/: per launch, KiB, one average per
+        # (kernel, grid size) so the shapes of a run are not mixed; FETCH_SIZE needs x2 for wide streaming reads on gfx950)
         try:
-            tk = json.load(open(os.path.join(ROOT, "profiles", "traffic_r03.json")))["other_kernels_of_the_line_KiB"]
-            which = {"c3_agg_1e9_1e6": ["k_daagg_partition<1024,8,1>", "k_agg_da<3,4096>"], "c3_agg_1e9_1e6_double": ["k_daagg_partition<1024,8,1>", "k_agg_da<3,4096>"],
-                     "agg_two_keys_50x20": ["k_agg_da_low<3,4096>"], "materialising": ["k_da_partition_cols<1024,8,false>", "k_da_emit_cols<512,false,true>"],
-                     "materialising_nullable_left_outer": ["k_da_partition_cols<1024,8,true>", "k_da_emit_cols<512,true,true>"],
-                     "build_warm": ["k_radix_partition<1024,8,4,0,true,true>", "k_radix_subpartition<1024,8>", "k_build_images_cnt<512,8>"],
-                     "wide_keys_64bit_route": ["k_lds_probe_count<1024,false,0>"],
-                     "wide_keys_31bit_unique_bit_cells": ["k_da_build_bits<1024>", "k_da_probe_count<1024,uint32_t,BITS>"],
-                     "two_key_columns_count": ["k_da_compose", "k_probe_count<MULTI>"]}
+            tk = json.load(open(os.path.join(ROOT, "profiles", "traffic_r04.json")))["kernels_KiB_per_launch"]
+            which = {"c3_agg_1e9_1e6": ["void k_daagg_partition<1024, 8, 1", "void k_agg_da<3, 4096, 1>", "k_daagg_dense_emit", "k_agg_merge("],
+                     "c3_agg_1e9_1e6_double": ["void k_daagg_partition<1024, 8, 1>", "void k_agg_da<2, 4096, 2>"],
+                     "c3_zipf_s1": ["void k_daagg_ovf<3>"],
+                     "c3_sparse_keys": ["void k_radix_partition<1024, 8, 4, 1, false, true>", "void k_agg_lds<1, 3>"],
+                     "agg_two_keys_50x20": ["void k_agg_da_low<3, 4096>"],
+                     "materialising": ["void k_da_partition_cols<1024, 8, false>", "void k_da_emit_cols<512, false, true>", "void k_da_sort_partition<1024>"],
+                     "materialising_nullable_left_outer": ["void k_da_partition_cols<1024, 8, true>", "void k_da_emit_cols<512, true, true>"],
+                     "wide_keys_64bit_route": ["void k_lds_probe_count<1024, false, 0>", "void k_radix_partition<1024, 16, 4, 0, false, true>"],
+                     "wide_keys_31bit_unique_bit_cells": ["void k_da_build_bits<1024>", "void k_da_probe_count<1024, unsigned int, false, false, true>",
+                                                          "void k_da_partition<1024, 16, unsigned int, false, false>"],
+                     "two_key_columns_count": ["k_da_compose", "void k_probe_count<true, false, false>"]}
             for key, names in which.items():
                 if key in out and "error" not in out[key]:
-                    out[key]["traffic_KiB_per_launch"] = {n: tk[n] for n in names if n in tk}
-                    out[key]["traffic_source"] = "profiles/traffic_r03.json (rocprofv3 --pmc passes of this command)"
+                    out[key]["traffic_KiB_per_launch"] = {k: v for k, v in tk.items() if any(k.startswith(n) for n in names)}
+                    out[key]["traffic_source"] = "profiles/traffic_r04.json (rocprofv3 --pmc passes of this command; one entry per kernel and grid size)"
         except Exception:
             pass
 

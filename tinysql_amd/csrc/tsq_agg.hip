@@ -1482,7 +1482,8 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     const AfPlan& pl = a->fplan;
     const uint32_t S = af_slots(pl);
     const bool mk = a->mk_n > 1;  // several key columns: the packed route or nothing
-    const bool low = !mk && groups_est <= (int64_t)(S / 2);
+    // (rows in the dense state of the packed route are groups the table has not seen yet: `groups_est` says nothing then)
+    const bool low = !mk && groups_est <= (int64_t)(S / 2) && !(a->da_state == 1 && a->dense_state == 1 && a->dense_rows > 0);
     uint32_t bits = 0;
     if (!low) TSQ_TRY(da_agg_setup(a, in, nrows));
     const bool packed = !low && a->da_state == 1;
@@ -1706,17 +1707,18 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         TSQ_TRY(launch_lds<1>(a, la, (int)P));
         TSQ_TRY(launch_lds<2>(a, la, 8));  // the overflow list of skewed partitions (usually empty)
     }
-    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 8, a->fctl.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 8, a->fctl.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
     const uint32_t n_part = ((const uint32_t*)(ctx->pinned + 8))[0], n_exc = ((const uint32_t*)(ctx->pinned + 8))[1];
+    const uint32_t n_misfit = ((const uint32_t*)(ctx->pinned + 8))[2];  // exception rows whose argument did not fit the narrow cells
     if (n_part > la.out.cap) {  // more partial groups than the buffer holds: nothing was merged yet, redo the batch row by row
         a->fast_fallbacks++;
         return TSQ_OK;
     }
     TSQ_TRY(merge_partials(a, la.out, n_part));
     if (n_exc) TSQ_TRY(agg_rows(a, in, (int64_t)n_exc, a->fexc.as<uint32_t>()));
-    if (packed && a->da_paybytes != 8 && (int64_t)n_exc > nrows / 64) a->da_paybytes = 8;  // the sample did not describe the argument column: full cells from here on
-    else if (packed && (int64_t)n_exc > nrows / 4) a->da_state = -1;  // the range of the first batch does not describe the input: 64-bit H mode from here on
+    if (packed && a->da_paybytes != 8 && (int64_t)n_misfit > nrows / 64) a->da_paybytes = 8;  // the sample did not describe the argument column: full cells from here on
+    if (packed && (int64_t)(n_exc - n_misfit) > nrows / 4) a->da_state = -1;  // the range of the first batch does not describe the input: 64-bit H mode from here on
     a->fast_batches++;
     *done = true;
     return TSQ_OK;

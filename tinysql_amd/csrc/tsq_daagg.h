@@ -66,7 +66,7 @@ struct DaAggSrc {
     int32_t vtype[TSQ_RADIX_MAXV];
     int64_t nrows;
     uint32_t* exc_rows;   // rows the LDS stage cannot take (NULL key / NULL argument / key outside the packed range)
-    uint32_t* exc_count;
+    uint32_t* exc_count;  // [0] the exception rows; [1] those among them whose argument did not fit the narrow cells (DaAggStore.paybytes)
 };
 // the fields of row `row` as one number d, or TSQ_DA_NONE (a cell outside its window, a NULL without a code)
 __device__ __forceinline__ uint32_t daagg_fields(const DaAggKeys& ks, const DaAggSrc& src, int64_t row) {
@@ -122,10 +122,11 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
     __shared__ uint32_t s_hist[TSQ_RADIX_MAX_P];
     __shared__ uint32_t s_delta[TSQ_RADIX_MAX_P];
     __shared__ uint32_t s_wsum[NT / 64];
-    __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_flag, s_obase;
     const uint32_t tid = threadIdx.x;
     const uint32_t P = 1u << st.bits, ebits = st.ebits, emask = (1u << ebits) - 1u;
     auto fits = [](uint64_t cell) -> bool { return PB == 8 || (cell >> (PB == 8 ? 0 : 8 * PB)) == 0; };
+    uint32_t misfits = 0;
     const uint32_t r = tsq_xcc_id();
     const uint32_t per = P >= (uint32_t)NT ? P / NT : 1u;
     if (tid == 0) s_flag = 0;
@@ -195,7 +196,10 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
             for (int j = 0; j < K; j++) {
                 if (mk) u[j] = dsum[j] == TSQ_DA_NONE ? TSQ_DA_NONE : tsq_da_mix(dsum[j], dm.s, dm.mask);
                 else u[j] = da_word(dm, k[j]);
-                if (PB != 8 && !fits(pay[0][j])) u[j] = TSQ_DA_NONE;
+                if (PB != 8 && u[j] != TSQ_DA_NONE && !fits(pay[0][j])) {
+                    u[j] = TSQ_DA_NONE;
+                    misfits++;
+                }
                 if (u[j] == TSQ_DA_NONE) except((uint32_t)base + ((uint32_t)(j >> 1) * NT + tid) * 2 + (j & 1));
             }
         } else {
@@ -221,7 +225,10 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
 #pragma unroll
                         for (int v = 0; v < V; v++)
                             pay[v][j] = src.vtype[v] == TSQ_F32 ? (uint64_t)((const uint32_t*)src.vdata[v])[base + pos] : ((const uint64_t*)src.vdata[v])[base + pos];
-                        if (PB != 8 && !fits(pay[0][j])) u[j] = TSQ_DA_NONE;
+                        if (PB != 8 && !fits(pay[0][j])) {
+                            u[j] = TSQ_DA_NONE;
+                            misfits++;
+                        }
                     }
                     if (u[j] == TSQ_DA_NONE) except((uint32_t)base + pos);
                 }
@@ -264,8 +271,10 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
                 if ((uint32_t)q < per && p0 + q < P && c[q]) g[q] = atomicAdd(&st.cursor[r * P + p0 + q], c[q]);
             }
         }
+        uint32_t oc[MAXPER], ooff[MAXPER];  // this thread's runs that did not fit their regions: rows, offset in the tile
 #pragma unroll
         for (int q = 0; q < MAXPER; q++) {
+            oc[q] = ooff[q] = 0;
             if ((uint32_t)q < per && p0 + q < P) {
                 const uint32_t p = p0 + q, cnt = c[q], offs = run;
                 run += cnt;
@@ -276,19 +285,35 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
                         flag = 3;
                         atomicMin(&st.valid_end[r * P + p], g[q]);
                         s_flag = 1;
-                        if (st.ovf_u != nullptr) {
-                            const uint32_t ob = __hip_atomic_fetch_add(st.ovf_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (ob <= st.ovf_cap && cnt <= st.ovf_cap - ob) {
-                                flag = 2;
-                                s_delta[p] = ob - offs;
-                            }
-                        }
+                        oc[q] = cnt;
+                        ooff[q] = offs;
                     }
                 }
                 s_hist[p] = offs | (flag << 30);
             }
         }
         __syncthreads();
+        // skewed keys: the tile's overflowing runs get consecutive places in the overflow store behind ONE device atomic per tile (a
+        // same-address atomic costs ~11 ns chip-wide: one per run — 6e5 per batch on the Zipf variant of C3 — was 5 ms of the kernel)
+        if (s_flag != 0 && st.ovf_u != nullptr) {
+            uint32_t osum = 0;
+#pragma unroll
+            for (int q = 0; q < MAXPER; q++) osum += oc[q];
+            uint32_t ototal;
+            uint32_t orun = block_excl_scan<NT>(osum, s_wsum, &ototal);
+            if (tid == 0) s_obase = ototal ? __hip_atomic_fetch_add(st.ovf_count, ototal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            __syncthreads();
+            const uint32_t ob = s_obase;
+            if (ototal && ob <= st.ovf_cap && ototal <= st.ovf_cap - ob) {
+#pragma unroll
+                for (int q = 0; q < MAXPER; q++)
+                    if (oc[q]) {
+                        s_delta[p0 + q] = ob + orun - ooff[q];
+                        s_hist[p0 + q] = ooff[q] | (2u << 30);
+                        orun += oc[q];
+                    }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < K; j++)
             if (u[j] != TSQ_DA_NONE) {
@@ -318,6 +343,10 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
             }
         }
         __syncthreads();
+    }
+    if (PB != 8) {  // one device atomic per wave that saw a value too wide for the cells: the host widens the cells when there are many
+        for (int o = 32; o > 0; o >>= 1) misfits += __shfl_xor(misfits, o, 64);
+        if ((tid & 63u) == 0 && misfits) atomicAdd(src.exc_count + 1, misfits);
     }
 }
 

@@ -3771,9 +3771,13 @@ TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t
         // process in slices so an emit batch stays bounded
         // device-resident input: larger emit batches (every batch costs a count pass, two host syncs and its output buffers)
         // (the materialising radix path partitions the whole push at once: its passes are the better the longer the partitions)
-        const int64_t slice = (j->count_only || radix_emit_eligible(j, pcs, nrows, selected) || (da_cols_eligible(j, nrows, selected) && j->da_cols_state >= 0))
-                                  ? nrows : std::max<int64_t>(j->cfg.probe_batch_rows, 32 << 20);
+        // (the packed pairs routes, once an earlier slice has prepared them: every slice costs a count pass, two host syncs and its
+        // output buffers — Q3's lineitem join took 15 slices of a 600 M-row side; 128 Mi rows keep the partition store at 1.5 GB)
+        const bool whole = j->count_only || radix_emit_eligible(j, pcs, nrows, selected) || (da_cols_eligible(j, nrows, selected) && j->da_cols_state >= 0);
+        int64_t slice = 0;
         for (int64_t off = 0; off < nrows; off += slice) {
+            const bool pairs_ready = j->da_state == 1 && j->da_unique && (j->da_rows_state == 1 || j->da_bitrows_state == 1) && j->conds_h.empty() && j->filters_h.empty();  // (unique build side: at most one output row per probe row)
+            slice = whole ? nrows : std::max<int64_t>(j->cfg.probe_batch_rows, pairs_ready ? (128 << 20) : (32 << 20));
             const int64_t n = std::min<int64_t>(slice, nrows - off);
             tsq_colset s;
             tsq_colset_slice(s, pcs, off);  // slices are multiples of 64 rows
