@@ -134,6 +134,7 @@ enum {
     TSQ_KNOB_AGG_WIDE_KEYS = 23,     /* 0: several integer group-key columns never become one 64-bit composite key (the several-column upsert keeps them) */
     TSQ_KNOB_AGG_DENSE = 24,         /* 0: the one-key packed aggregate appends partial groups after every batch instead of folding its LDS tables into the dense state; v > 1 (tests): the state is emptied into the table before more than v rows went into it (default 2^31) */
     TSQ_KNOB_AGG_NARROW_CELLS = 25,  /* 0: the argument column of the packed aggregate always travels as 8-byte cells */
+    TSQ_KNOB_DAAGG_PART2 = 26,       /* partition kernel of the packed aggregate with a dense state: 0 = 1024 threads, one workgroup per CU; 1 = two 512-thread workgroups per CU for narrow argument cells; 2 = for 8-byte cells too (default) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);

@@ -1566,7 +1566,11 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         st.ebits = a->da_ebits;
         st.paybytes = (pl.V == 1 && !mk) ? a->da_paybytes : 8u;
         const uint32_t P = 1u << st.bits;
-        const int K = pl.V == 0 ? 16 : (pl.V == 1 ? 8 : 4), T = 1024 * K;
+        // two 512-thread workgroups per CU (tsq_daagg.h, WITH_ROW = false): one argument column and the overflow store of the dense
+        // state; tiles of 4096 rows; knob 0: the 1024-thread kernel, 1: narrow cells only, 2 (default): 8-byte cells too
+        const int64_t part2_knob = tsq_knob(ctx, TSQ_KNOB_DAAGG_PART2, 2);
+        const bool part2 = dense && pl.V == 1 && part2_knob != 0 && (st.paybytes != 8 || part2_knob >= 2);
+        const int K = part2 ? 8 : (pl.V == 0 ? 16 : (pl.V == 1 ? 8 : 4)), T = (part2 ? 512 : 1024) * K;  // (part2 with 16 rows per lane: 110 spilled VGPRs at the 128 it may use)
         const double tiles = ceil((double)nrows / T);
         const double lam = std::max((double)nrows / ((double)P * 8.0), ceil(tiles / 8.0) * std::min<double>((double)T, (double)nrows) / (double)P);
         st.cap = (uint32_t)(lam * 1.08 + 8.0 * sqrt(lam) + 2.0 * T / 64.0 + 64.0);
@@ -1610,8 +1614,11 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         src.exc_count = la.exc_count;
         DaAggKeys ks = a->da_keys;
         if (!mk) ks.n = 1;
-        const int pgrid = (int)std::min<int64_t>((nrows + T - 1) / T, ctx->num_cus);
-        if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
+        const int pgrid = (int)std::min<int64_t>((nrows + T - 1) / T, (int64_t)ctx->num_cus * (part2 ? 2 : 1));
+        if (part2 && st.paybytes == 2) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 2, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks);
+        else if (part2 && st.paybytes == 4) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 4, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks);
+        else if (part2) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 8, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks);
+        else if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
         else if (pl.V == 1 && st.paybytes == 4) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 4>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
         else if (pl.V == 1 && st.paybytes == 2) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
         else if (pl.V == 1) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
@@ -1711,6 +1718,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
     const uint32_t n_part = ((const uint32_t*)(ctx->pinned + 8))[0], n_exc = ((const uint32_t*)(ctx->pinned + 8))[1];
     const uint32_t n_misfit = ((const uint32_t*)(ctx->pinned + 8))[2];  // exception rows whose argument did not fit the narrow cells
+    if (((const uint32_t*)(ctx->pinned + 8))[3]) return tsq_fail(h, TSQ_ERR_HIP, "internal: the overflow store of the packed aggregate was full");
     if (n_part > la.out.cap) {  // more partial groups than the buffer holds: nothing was merged yet, redo the batch row by row
         a->fast_fallbacks++;
         return TSQ_OK;

@@ -109,15 +109,19 @@ __device__ __forceinline__ uint32_t daagg_region_len(const DaAggStore& st, uint3
 template <int PB> struct da_pay_t { typedef uint64_t type; };
 template <> struct da_pay_t<4> { typedef uint32_t type; };
 template <> struct da_pay_t<2> { typedef uint16_t type; };
-template <int NT, int K, int V, int PB = 8>
-__global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain dm, DaAggStore st, DaAggKeys ks) {
+// WITH_ROW = false (round 4): the tile does not keep its source rows in LDS — only legal with an overflow store that holds a whole
+// batch (then no row of a run ever needs the exception list) — which brings a 512-thread tile of 4096 rows down to 40..64 KB of LDS
+// and 127 VGPRs: TWO workgroups per CU, one loading while the other scatters (what k_da_partition2 did for the join: the
+// 1024-thread version's waves are parked more than half of their cycles).
+template <int NT, int K, int V, int PB = 8, bool WITH_ROW = true>
+__global__ void __launch_bounds__(NT, WITH_ROW ? 1 : 4) k_daagg_partition(DaAggSrc src, DaDomain dm, DaAggStore st, DaAggKeys ks) {
     constexpr int T = NT * K;
     static_assert(PB == 8 || (V == 1 && (PB == 4 || PB == 2)), "narrow cells: one argument column");
     typedef typename da_pay_t<PB>::type PT;
     constexpr int MAXPER = (TSQ_RADIX_MAX_P + NT - 1) / NT;
     static_assert(T <= 65536 && (K % 2) == 0 && V >= 0 && V <= TSQ_RADIX_MAXV, "tile");
     __shared__ uint32_t s_u[T];
-    __shared__ uint32_t s_row[T];
+    __shared__ uint32_t s_row[WITH_ROW ? T : 1];
     __shared__ PT s_pay[V ? V : 1][V ? T : 1];
     __shared__ uint32_t s_hist[TSQ_RADIX_MAX_P];
     __shared__ uint32_t s_delta[TSQ_RADIX_MAX_P];
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
             if (u[j] != TSQ_DA_NONE) {
                 const uint32_t d = (s_hist[u[j] >> ebits] & 0x3fffffffu) + rk[j];
                 s_u[d] = u[j];
-                s_row[d] = (uint32_t)base + (full ? (((uint32_t)(j >> 1) * NT + tid) * 2 + (j & 1)) : ((uint32_t)j * NT + tid));
+                if (WITH_ROW) s_row[d] = (uint32_t)base + (full ? (((uint32_t)(j >> 1) * NT + tid) * 2 + (j & 1)) : ((uint32_t)j * NT + tid));
 #pragma unroll
                 for (int v = 0; v < V; v++) s_pay[v][d] = (PT)pay[v][j];
             }
@@ -338,8 +342,10 @@ __global__ void __launch_bounds__(NT) k_daagg_partition(DaAggSrc src, DaDomain d
                 st.ovf_u[d] = w;
 #pragma unroll
                 for (int v = 0; v < V; v++) reinterpret_cast<PT*>(st.ovf_pay[v])[d] = s_pay[v][i];
-            } else {
+            } else if (WITH_ROW) {
                 except(s_row[i]);  // no overflow store / store full: the row is aggregated row by row
+            } else {
+                atomicOr(src.exc_count + 2, 1u);  // cannot happen (the store holds a whole batch); the host fails the batch if it does
             }
         }
         __syncthreads();

@@ -187,20 +187,63 @@ struct DevBuf {
     T* as() const { return (T*)p; }
 };
 
+// Pinned host memory is expensive to get (hipHostMalloc pins page by page: ~0.3 ms per MB, 100 ms for the 320 MB of result columns of
+// bench.py's pcie_inclusive_1e7) and every join result batch, every staging area asked for its own: released buffers are kept in a
+// process-wide pool (up to 8 GB, best fit within 2x) and handed to the next owner.  A buffer comes back only after its owner has
+// synchronised the stream that wrote it (result batches are released once they were pulled, staging areas at destroy).  The pool is
+// never destroyed (static teardown would run after the HIP runtime's).
+struct tsq_pinned_pool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> free_list;
+    size_t bytes = 0;
+};
+inline tsq_pinned_pool& tsq_pinned() {
+    static tsq_pinned_pool* pool = new tsq_pinned_pool();
+    return *pool;
+}
 struct PinnedBuf {
     void* p = nullptr;
     size_t cap = 0;
     tsq_status reserve(tsq_handle_hdr* h, size_t bytes) {
         if (bytes <= cap) return TSQ_OK;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        TSQ_HIP(h, hipHostMalloc(&p, bytes, hipHostMallocDefault));
-        cap = bytes;
+        release();
+        {
+            tsq_pinned_pool& pool = tsq_pinned();
+            std::lock_guard<std::mutex> g(pool.mu);
+            int best = -1;
+            for (int i = 0; i < (int)pool.free_list.size(); i++) {
+                const size_t c = pool.free_list[i].second;
+                if (c >= bytes && c <= 2 * bytes + (1 << 20) && (best < 0 || c < pool.free_list[best].second)) best = i;
+            }
+            if (best >= 0) {
+                p = pool.free_list[best].first;
+                cap = pool.free_list[best].second;
+                pool.bytes -= cap;
+                pool.free_list.erase(pool.free_list.begin() + best);
+                return TSQ_OK;
+            }
+        }
+        // (sizes rounded up — 64 KB granules below 1 MB, 1 MB granules above — so that the next batch of nearly the same size fits)
+        const size_t gran = bytes >= ((size_t)1 << 20) ? ((size_t)1 << 20) : ((size_t)1 << 16);
+        const size_t want = (bytes + gran - 1) / gran * gran;
+        TSQ_HIP(h, hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
         return TSQ_OK;
     }
     void release() {
-        if (p) (void)hipHostFree(p);
+        if (p) {
+            tsq_pinned_pool& pool = tsq_pinned();
+            bool kept = false;
+            {
+                std::lock_guard<std::mutex> g(pool.mu);
+                if (cap >= ((size_t)1 << 16) && pool.bytes + cap <= ((size_t)8 << 30) && pool.free_list.size() < 512) {
+                    pool.free_list.emplace_back(p, cap);
+                    pool.bytes += cap;
+                    kept = true;
+                }
+            }
+            if (!kept) (void)hipHostFree(p);
+        }
         p = nullptr;
         cap = 0;
     }
