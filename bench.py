@@ -432,6 +432,7 @@ def main():
                         ("c3_sparse_keys", lambda: extra_c3_variant(ctx, abi, _lib, "sparse")),
                         ("agg_two_keys_1000x100", lambda: extra_two_keys(ctx, abi, _lib)),
                         ("agg_two_keys_50x20", lambda: extra_two_keys(ctx, abi, _lib, ma=50, mb=20)),
+                        ("q3_sf100", lambda: extra_q3()),
                         ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
                         ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True))):
             if args.only_extras and key not in args.only_extras.split(","):
@@ -695,6 +696,25 @@ def extra_pcie(ctx, abi, _lib, n=10_000_000):
                                              "probe_rows_per_s_end_to_end": n / t_probe, "verified": rows == n}
     res["workload"] = "1e7 x 1e7 (k, v) x (k, v) inner join, host chunks in (pinned staging -> HBM) and host chunks out (D2H per result batch, then memcpy per pull)"
     return res
+
+
+def extra_q3(sf=100):
+    """BASELINE configs[4] on ONE GPU: the Q3-shaped pipeline of tools/q3.py (Selection -> Join -> Join -> Projection -> HashAgg over
+    tables generated in HBM), run in a process of its own (its own context and arena) while this one idles.  `frac` prices the bytes
+    the query must touch once — the 2 + 4 + 4 eight-byte columns of customer / orders / lineitem and the four result columns — at
+    8 TB/s over the pipeline's execution time with the result in HBM (best of 4 runs)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "q3.py"), str(sf), "--device-gen"], capture_output=True, text=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": (r.stderr or r.stdout)[-200:]}
+    q = json.loads(line[-1])
+    nc, no, nl = int(150_000 * sf), int(1_500_000 * sf), int(6_000_000 * sf)
+    touched = 8.0 * (2 * nc + 4 * no + 4 * nl) + 32.0 * q["groups"]
+    return {"workload": q["query"] + ", SF %g: %d input rows, tables %s" % (sf, q["input_rows"], q["tables"]), "ms": q["exec_s_result_in_hbm"] * 1e3,
+            "input_rows_per_s": q["input_rows_per_s_result_in_hbm"], "groups": q["groups"], "bytes_touched_once": touched,
+            "frac": touched / q["exec_s_result_in_hbm"] / 8e12, "ms_with_result_on_host": q["best_s"] * 1e3, "joins": q["joins"], "plan": q["plan"],
+            "verified": "tests/test_pipeline_gpu.py compares the same plan with the oracle's operator chain at SF 0.01-0.1; profile: profiles/r04_q3_rocprof.txt"}
 
 
 def extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr, steps=5):

@@ -117,7 +117,7 @@ enum {
     TSQ_KNOB_LDS_PROF = 8,           /* 1: per-phase shader cycles of the LDS probe on stderr (synchronises) */
     TSQ_KNOB_DA_TRACE = 9,           /* 1: host time points of the travelling-columns route on stderr */
     TSQ_KNOB_BUILD_IMAGES_CAS = 10,  /* 1: the first (compare-and-swap) slice-image kernel of the partitioned build */
-    TSQ_KNOB_DAAGG_SIG = 11,         /* 0: no plan-specialised instantiations of k_agg_da */
+    TSQ_KNOB_DAAGG_SIG = 11,         /* 0: no plan-specialised instantiations of k_agg_da; 1: SUM + COUNT(*) plans; 2: also count and sum of 2-byte cells in one LDS word */
     TSQ_KNOB_DAAGG_LOG2C = 12,       /* log2(cells per LDS table) of the packed aggregate, 9..12 */
     TSQ_KNOB_AGG_HEAP_GC_BYTES = 13, /* string-heap size from which the aggregate compacts between batches (default 256 MiB) */
     TSQ_KNOB_AGG_TAG_BITS = 14,      /* truncate the 64-bit group tag of a several-column GROUP BY (collision tests) */
@@ -134,7 +134,7 @@ enum {
     TSQ_KNOB_AGG_WIDE_KEYS = 23,     /* 0: several integer group-key columns never become one 64-bit composite key (the several-column upsert keeps them) */
     TSQ_KNOB_AGG_DENSE = 24,         /* 0: the one-key packed aggregate appends partial groups after every batch instead of folding its LDS tables into the dense state; v > 1 (tests): the state is emptied into the table before more than v rows went into it (default 2^31) */
     TSQ_KNOB_AGG_NARROW_CELLS = 25,  /* 0: the argument column of the packed aggregate always travels as 8-byte cells */
-    TSQ_KNOB_DAAGG_PART2 = 26,       /* partition kernel of the packed aggregate with a dense state: 0 = 1024 threads, one workgroup per CU; 1 = two 512-thread workgroups per CU for narrow argument cells; 2 = for 8-byte cells too (default) */
+    TSQ_KNOB_DAAGG_PART2 = 26,       /* partition kernel of the packed aggregate with a dense state: 0 = 1024 threads, one workgroup per CU; 1 = two 512-thread workgroups per CU for narrow argument cells (default); 2 = for 8-byte cells too */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);

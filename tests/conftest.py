@@ -32,6 +32,13 @@ def ctx():
 @pytest.fixture(autouse=True)
 def _knobs_back_to_default(request):
     """a test may turn the context's test knobs (tsq_ctx_set_knob); the session-wide context gets its defaults back afterwards"""
+    # TSQ_TEST_KNOBS="NAME=VALUE,..." (test runs only; the product reads no environment): the whole run with a knob off its default,
+    # e.g. an A/B of a kernel variant over the full parity suite before its default is switched
+    preset = [kv.split("=") for kv in os.environ.get("TSQ_TEST_KNOBS", "").split(",") if "=" in kv]
+    if preset and "ctx" in request.fixturenames:
+        from tinysql_amd import _abi as abi
+        for k, v in preset:
+            request.getfixturevalue("ctx").set_knob(getattr(abi, "KNOB_" + k), int(v))
     yield
     if "ctx" in request.fixturenames:
         request.getfixturevalue("ctx").reset_knobs()

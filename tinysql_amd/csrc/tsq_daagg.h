@@ -26,6 +26,7 @@
 #include "tsq_dajoin.h"
 
 #define TSQ_DAAGG_MAX_BITS 23
+#define TSQ_DAAGG_PACK_SHIFT 40  /* SIG 3 (daagg_apply): count << 40 | sum of 16-bit values */
 
 struct DaAggStore {
     uint16_t* ent;        // [P * 8 * cap] entries
@@ -374,10 +375,17 @@ struct DaAggLdsArgs {
 // SIG: the two commonest plans with their update descriptors known at compile time — 1: SUM(BIGINT cell 0) + COUNT(*) (words lo32,
 // hi32, count), 2: SUM(DOUBLE cell 0) + COUNT(*) — instead of a wave-uniform switch per word and row (scalar compares and
 // branches: k_agg_da<3,4096> issued as many scalar as vector instructions, profiles/r03_bench_sq.txt); 0: any plan.
+// 3 (round 4): plan 1 with 2-BYTE argument cells and a dense state: value < 2^16 and fewer than 2^24 rows per partition and batch
+// (host), so the sum (< 2^40) and the count share ONE LDS word — `count << 40 | sum`, one atomic per row instead of two; the fold
+// into the dense state takes the word apart again (TSQ_DAAGG_PACK_SHIFT).
 template <int W, int CELLS, int SIG = 0>
 __device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1) {
     // (a plain LDS read first: after its first row a cell's bit is set, and a returning-or-not LDS atomic costs more than a read)
     if (!((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
+    if (SIG == 3 && W == 3) {
+        atomicAdd(&s_w[0][e], (1ull << TSQ_DAAGG_PACK_SHIFT) + (unsigned long long)c0);
+        return;
+    }
     if (SIG == 1 && W == 3) {
         atomicAdd(&s_w[0][e], (unsigned long long)(c0 & 0xffffffffull));
         if ((long long)c0 >> 32) atomicAdd(&s_w[1][e], (unsigned long long)((long long)c0 >> 32));
@@ -454,7 +462,7 @@ __device__ __forceinline__ void daagg_emit_cells(const AfPlan& plan, const AfPar
 // workgroups of this launch fold into the same cells (nsplit > 1) — device atomics; otherwise the cells are this workgroup's alone
 // until the kernel ends and a read-modify-write is enough.  The words stay in their LDS form (a BIGINT sum as lo32 / hi32 sums:
 // the host flushes the state before 2^31 rows went into it, so neither can wrap).
-template <int W, int CELLS>
+template <int W, int CELLS, int SIG = 0>
 __device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const DaAggLdsArgs& a, unsigned long long (*s_w)[CELLS], const uint32_t* s_touch, uint32_t p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t ncell = 1u << a.st.ebits;  // <= CELLS, >= 32 (host)
@@ -462,6 +470,20 @@ __device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const 
     const bool shared = a.nsplit > 1;
     for (uint32_t i = tid; i < ncell; i += TSQ_AF_NT) {
         if (!((s_touch[i >> 5] >> (i & 31u)) & 1u)) continue;
+        if (SIG == 3 && W == 3) {  // word 0 = count << 40 | sum: into the dense lo32 sum (word 0) and count (word 2); the hi32 sum stays
+            const unsigned long long v = s_w[0][i];
+            const unsigned long long sum = v & ((1ull << TSQ_DAAGG_PACK_SHIFT) - 1ull), cnt = v >> TSQ_DAAGG_PACK_SHIFT;
+            unsigned long long* g0 = a.dense_w[0] + cbase + i;
+            unsigned long long* g2 = a.dense_w[W - 1] + cbase + i;
+            if (shared) {
+                atomicAdd(g0, sum);
+                atomicAdd(g2, cnt);
+            } else {
+                *g0 += sum;
+                *g2 += cnt;
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < W; k++) {
             unsigned long long* g = a.dense_w[k] + cbase + i;
@@ -546,7 +568,7 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
         else regions(std::integral_constant<int, 8>{});
         __syncthreads();
         if (a.dense_touch != nullptr) {
-            daagg_fold_dense<W, CELLS>(wd, a, s_w, s_touch, p);
+            daagg_fold_dense<W, CELLS, SIG>(wd, a, s_w, s_touch, p);
             continue;
         }
         daagg_emit_cells<W, CELLS>(a.plan, a.out, s_w, s_touch, &s_base, s_wsum, [&](uint32_t i) -> unsigned long long {
