@@ -494,6 +494,8 @@ tsq_status tsq_agg_finish(tsq_agg* a);
 #define TSQ_AGGFAST_OFF     0
 #define TSQ_AGGFAST_FORCE   1
 tsq_status tsq_agg_set_fast(tsq_agg* a, int32_t mode);
+/* After tsq_agg_finish: the number of result rows.  Before: the groups the operator's table holds so far — a LOWER bound (the packed
+ * route keeps the partial state of a one-key GROUP BY outside the table until finish, tsq_stats.dense_flushes). */
 tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out);
 /* HashAggExec.Next (aggregate.go:559-588): output schema = one column per agg func, in cfg
  * order.  COMPLETE/FINAL emit final values; PARTIAL1/PARTIAL2 emit partial columns (AVG emits

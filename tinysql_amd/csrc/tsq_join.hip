@@ -2153,13 +2153,14 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
         return give_up(s);
     }
     const uint32_t cells = 1u << j->da_ebits;
-    // 16 sub-buckets per partition: ~60 KB of LDS per workgroup, two 1024-thread workgroups per CU — the kernel is a chain of dependent
-    // loads (image slice, entry units, cells, write-out) and lives on occupancy; the entries stream 16 times per partition, from L2
-    sa.sub_bits = j->da_ebits > 12 ? std::min<uint32_t>(4u, j->da_ebits - 12u) : 0u;
+    // (16 sub-buckets per partition and two workgroups per CU — ~60 KB of LDS each, the entries streamed 16 times from L2 — were
+    // measured in round 4: 2.88 ms per column and 1e8 rows against 1.67 ms for 8 sub-buckets and one workgroup per CU with a staging
+    // buffer of twice the expected rows: kept)
+    sa.sub_bits = j->da_ebits > 13 ? std::min<uint32_t>(3u, j->da_ebits - 13u) : 0u;
     const uint32_t scells = cells >> sa.sub_bits;
-    // the staging buffer: 1.5 x the expected rows of a sub-bucket (denser sub-buckets take several windows)
-    const uint64_t expect = (uint64_t)(n / std::max<int64_t>(1, (int64_t)g.P << sa.sub_bits)) * 3 / 2 + 512;
-    sa.stage_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(expect, 1024), 6144);
+    // the staging buffer: twice the expected rows of a sub-bucket (denser sub-buckets take several windows), at most ~100 KB
+    const uint64_t expect = (uint64_t)(n / std::max<int64_t>(1, (int64_t)g.P << sa.sub_bits)) * 2 + 1024;
+    sa.stage_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(expect, 2048), 12288);
     {
         DaCoarseArgs ca;
         memset(&ca, 0, sizeof ca);
@@ -2176,8 +2177,7 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
         const size_t lds = (size_t)2 * scells + (size_t)(scells >> 5) * 4 + (size_t)sa.stage_cap * 9 + 16;
         e = hipFuncSetAttribute((const void*)k_da_sort_partition<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) {
-            const uint32_t per_cu = lds <= (72u << 10) ? 2u : 1u;
-            const uint32_t grid = (uint32_t)std::max(8, (ctx->num_cus * (int)per_cu / 8) * 8);
+            const uint32_t grid = (uint32_t)std::max(8, (ctx->num_cus / 8) * 8);
             hipLaunchKernelGGL((k_da_sort_partition<1024>), dim3(grid), dim3(1024), lds, ctx->stream, sa);
             e = hipGetLastError();
         }

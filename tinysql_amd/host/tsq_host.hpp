@@ -625,6 +625,8 @@ public:
         cfg_.n_outer_filters = (int32_t)filter_.size();
         check(tsq_join_create(ctx_->h, &cfg_, &h_), ctx_->h);
         if (ordered_) check(tsq_join_set_ordered(h_, 1), h_);
+        if (!used_.empty()) check(tsq_join_set_used_columns(h_, used_.data(), (int32_t)used_.size()), h_);
+        warnings_ = 0;
         prepared_ = false;
         probeDone_ = false;
     }
@@ -671,8 +673,23 @@ public:
         }
     }
     // Close may race with Next on another thread (join_test.go:172-182, TestJoinLeak): cancel first.
-    void Close() override { destroy(); Executor::Close(); }
+    void Close() override {
+        if (h_) {  // the division-by-zero warnings of OtherConditions / outer filters (expression/errors.go:65-77: handleDivisionByZeroError
+                   // appends one warning per offending row to the statement context; the shim does that with this count)
+            tsq_stats st;
+            if (tsq_join_stats(h_, &st) == TSQ_OK) warnings_ = st.div_by_zero_warnings;
+        }
+        destroy();
+        Executor::Close();
+    }
     void Cancel() { if (h_) tsq_join_cancel(h_); }
+    // Inline projection (planner/core/rule_column_pruning.go): used[c] == 0: the parent never reads output column c (left child's
+    // columns, then the right child's).  The operator may leave such a column unmaterialised; its cells in `req` are unspecified.
+    void SetUsedColumns(std::vector<uint8_t> used) {
+        if (!used.empty() && used.size() != schema().size()) throw Error(TSQ_ERR_INVALID, "SetUsedColumns: one flag per output column");
+        used_ = std::move(used);
+    }
+    int64_t DivisionByZeroWarnings() const { return warnings_; }  // after Close()
 protected:
     bool ordered_ = false;  // MergeJoinExec: outer rows in order, each with its inner matches in order
 private:
@@ -684,6 +701,8 @@ private:
     std::vector<tsq_expr_prog> other_, filter_;
     Executor *build_, *probe_;
     bool buildIsRight_ = true, prepared_ = false, probeDone_ = false;
+    std::vector<uint8_t> used_;
+    int64_t warnings_ = 0;
     tsq_join* h_ = nullptr;
 };
 

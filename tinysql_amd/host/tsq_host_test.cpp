@@ -120,6 +120,19 @@ int main() {
         HashJoinExec j(&ctx, &l, &r, {0}, {0}, InnerJoin, 1, {Func("gt", {Func("plus", {Col(0, TSQ_I64), Col(1, TSQ_I64)}), Int(5)})});
         expect("join_test.go:112-116 other condition a.c1+b.c1>5", render(Drain(&j)), {"3 3", "4 4", "5 5", "6 6", "7 7"});
     }
+    // ---- inline projection (planner/core/rule_column_pruning.go): the parent reads a.k, a.v, b.v only — the join may leave b.k unmaterialised
+    {
+        Chunk a = table_i64(2, {1, 10, 2, 20, 3, 30}), b = table_i64(2, {2, 200, 3, 300, 4, 400});
+        MockDataSource l(&ctx, a), r(&ctx, b);
+        HashJoinExec j(&ctx, &l, &r, {0}, {0}, InnerJoin, 1);
+        j.SetUsedColumns({1, 1, 0, 1});
+        Rows got;
+        for (auto& chk : Drain(&j))
+            for (int64_t i = 0; i < chk.NumRows(); i++) got.push_back(cell(chk.columns[0], i) + " " + cell(chk.columns[1], i) + " " + cell(chk.columns[3], i));
+        std::sort(got.begin(), got.end());
+        expect("used columns {a.k, a.v, b.v} of an inner join", got, {"2 20 200", "3 30 300"});
+        expect_true("no division-by-zero warnings without conditions", j.DivisionByZeroWarnings() == 0);
+    }
     // ---- NULL keys never join (hash_table.go:161-163, join.go:344); the outer side keeps them
     {
         Chunk a = table_i64(2, {NIL, 1, 2, 2, NIL, 3}), b = table_i64(2, {NIL, 10, 2, 20});
