@@ -171,4 +171,57 @@ int32_t sim_shared_projection(int32_t world, int64_t build_rows_per_rank, int64_
     return 0;
 }
 
+// ---- the same plan rank by rank, for a run with REAL processes (tests/dist_shared_worker.py: two processes over gloo).  A process
+// calls sim_shared_rank_plan with the ALL-REDUCED range and row count (the product all-reduces the same three numbers), assembles its
+// image with sim_shared_rank_image, the processes sum their images with an all-reduce (uint8 / int32 elements: the arithmetic of
+// ncclSum), every process checks the population and probes its own rows.
+// plan[]: [0] ok  [1] bit cells  [2] domain bits b  [3] mix shift s  [4] mask  [5] kmin (as int64 bits)  [6] range  [7] image bytes
+int32_t sim_shared_rank_plan(int64_t kmin, int64_t kmax, int64_t usable, int32_t force, int64_t* plan) {
+    const DaPlan pl = tsq_da_plan((uint64_t)kmin, (uint64_t)kmax, (uint64_t)usable, 0, true, force != 0);
+    plan[0] = pl.ok ? 1 : 0;
+    plan[1] = pl.bit_cells;
+    plan[2] = pl.dm.b;
+    plan[3] = pl.dm.s;
+    plan[4] = pl.dm.mask;
+    plan[5] = (int64_t)pl.dm.kmin;
+    plan[6] = (int64_t)pl.dm.range;
+    plan[7] = pl.ok ? (int64_t)tsq_da_image_bytes(pl) : 0;
+    return 0;
+}
+// this rank's build keys into its (zeroed) image; returns 1 when a cell overflowed locally (byte beyond 255 / bit set twice)
+int32_t sim_shared_rank_image(const int64_t* keys, int64_t n, const int64_t* plan, uint8_t* img) {
+    int32_t fail = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t d = (uint64_t)keys[i] - (uint64_t)plan[5];
+        if (d > (uint64_t)plan[6]) return -1;  // outside the merged range: the range all-reduce was wrong
+        const uint32_t u = tsq_da_mix((uint32_t)d, (uint32_t)plan[3], (uint32_t)plan[4]);
+        if (plan[1]) {
+            if (img[u >> 3] & (1u << (u & 7u))) fail = 1;
+            img[u >> 3] |= (uint8_t)(1u << (u & 7u));
+        } else {
+            if (img[u] == 255) fail = 1;
+            img[u]++;
+        }
+    }
+    return fail;
+}
+// the population of a (summed) image: k_da_image_check
+int64_t sim_shared_population(const uint8_t* img, int64_t bytes, int32_t bit_cells) {
+    uint64_t pop = 0;
+    for (int64_t i = 0; i < bytes; i++) pop += bit_cells ? (uint64_t)__builtin_popcount(img[i]) : img[i];
+    return (int64_t)pop;
+}
+int32_t sim_shared_images_ok(int64_t population, int64_t usable) { return tsq_da_shared_images_ok((uint64_t)population, (uint64_t)usable) ? 1 : 0; }
+// this rank's probe keys against the summed image: joined rows
+int64_t sim_shared_rank_probe(const int64_t* keys, int64_t n, const int64_t* plan, const uint8_t* sum) {
+    int64_t got = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t d = (uint64_t)keys[i] - (uint64_t)plan[5];
+        if (d > (uint64_t)plan[6]) continue;
+        const uint32_t u = tsq_da_mix((uint32_t)d, (uint32_t)plan[3], (uint32_t)plan[4]);
+        got += plan[1] ? ((sum[u >> 3] >> (u & 7u)) & 1u) : sum[u];
+    }
+    return got;
+}
+
 }  // extern "C"

@@ -91,3 +91,19 @@ def test_projection_of_the_bench_shape(sim, world, bits, b, img):
     assert out[4] == (0 if world == 1 else 2 * img * (world - 1) // world)
     # a build side WITH duplicate keys beyond 28 bits has no images: the exchange plan
     assert sim.sim_shared_projection(world, 100_000_000, 100_000_000, 0, out) == 0 and out[0] == (1 if b <= 28 else 0)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_real_processes_run_the_shared_plan_over_gloo(world):
+    """tests/dist_shared_worker.py: the range / usable-rows / flag / image all-reduces are real collectives (gloo), the plan and the
+    verdicts are the product's host arithmetic — byte cells with duplicates across ranks, bit cells with a rank that holds no build
+    rows, a key on two ranks that must make EVERY rank drop the plan, a hot key whose byte cell approaches the wrap."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29531 + world), os.path.join(ROOT, "tests", "dist_shared_worker.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "SHARED_OK" in p.stdout

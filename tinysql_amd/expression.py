@@ -309,12 +309,18 @@ class CompiledExpr:
         out.null_bitmap = bm.ctypes.data_as(C.c_void_p)
         out.length, out.elem_size, out.type = n, -1, abi.BYTES
         w, need = C.c_int64(0), C.c_int64(0)
-        st = self.lib.tsq_expr_eval_str(self.h, cols, len(chk.columns), n, sel, C.byref(out), 0, C.byref(need), C.byref(w))
-        if st != abi.OK and not (st == abi.ERR_INVALID and need.value > 0):
-            self.warnings += w.value
-            _lib.check(st, self.h)
-        data = np.zeros(need.value + 8, dtype=np.uint8)
-        if need.value > 0 or st != abi.OK:
+        # ONE evaluation in the common case: a result cell is one of the row's input strings or a constant of the program,
+        # so the bytes of the string input columns (+ a constant per row, guessed at 32 B) bound the result; only when the guess was
+        # too small the operator reports the size (TSQ_ERR_INVALID with bytes_out > 0) and runs again
+        guess = 64 + 32 * n
+        for c in chk.columns:
+            if getattr(c, "offsets", None) is not None and len(c.offsets):
+                guess += int(c.offsets[-1])
+        data = np.zeros(guess + 8, dtype=np.uint8)
+        out.data = data.ctypes.data_as(C.c_void_p)
+        st = self.lib.tsq_expr_eval_str(self.h, cols, len(chk.columns), n, sel, C.byref(out), guess, C.byref(need), C.byref(w))
+        if st == abi.ERR_INVALID and need.value > guess:
+            data = np.zeros(need.value + 8, dtype=np.uint8)
             out.data = data.ctypes.data_as(C.c_void_p)
             st = self.lib.tsq_expr_eval_str(self.h, cols, len(chk.columns), n, sel, C.byref(out), need.value, C.byref(need), C.byref(w))
         self.warnings += w.value
