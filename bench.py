@@ -424,6 +424,7 @@ def main():
                         ("wide_keys_31bit_unique_bit_cells", lambda: extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("two_key_columns_count", lambda: extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr)),
                         ("two_key_columns_count_48bit", lambda: extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, spread=1000003)),
+                        ("two_key_bigint_string_count", lambda: extra_string_key_join(ctx, abi, _lib)),
                         ("variants_8d", lambda: extra_variants(ctx, abi, _lib, bk, nb, npr)),
                         ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
                         ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
@@ -856,6 +857,75 @@ def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3, spread=1):
     res["workload"] = ("1e8 x 1e8 count(*) on TWO BIGINT key columns (k div 10000%s, k mod 10000), hit ratio 0.5; frac prices 32 B per probe row (two key cells + one 16 B slot)"
                        % ("" if spread == 1 else " x %d: %d bits of fields" % (spread, 48)))
     return res
+
+
+def extra_string_key_join(ctx, abi, _lib, n=10_000_000, steps=3):
+    """The reference benchmark's own key shape: keyIdx {0, 1} = (bigint, varstring) (executor/benchmark_test.go:357, 328) — COUNT(*) of a
+    1e7 x 1e7 join ON a.k = b.k AND a.s = b.s, s a 16-byte binary string derived from k.  Build rows: k = 0 .. n-1; probe rows: k uniform
+    in [0, 2n) (hit ratio 0.5, expected count by numpy).  String keys keep the DIRECT several-column route (64-bit tag of both cells,
+    bytes compared on a tag hit): the line is here so that the route's cost is in the driver JSON, not because it is fast."""
+    import numpy as np
+    lib = ctx.lib
+
+    def strings(k):  # 16 bytes per cell: two 64-bit mixes of the bigint, as raw bytes
+        a = (k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(0x1234567)
+        b = (k.astype(np.uint64) + np.uint64(77)) * np.uint64(0xC2B2AE3D27D4EB4F)
+        return np.ascontiguousarray(np.stack([a, b], axis=1)).view(np.uint8).reshape(-1)
+    rng = np.random.default_rng(3)
+    bk = rng.permutation(n).astype(np.int64)
+    pk = rng.integers(0, 2 * n, n)
+    want = int((pk < n).sum())
+    offs = (np.arange(n + 1, dtype=np.int64) * 16)
+    dev = []
+
+    def up(arr):
+        p = ctx.alloc(arr.nbytes + 64)
+        ctx.h2d(p, np.ascontiguousarray(arr))
+        dev.append(p)
+        return p
+
+    def cols(k, sdata, o):
+        c = (abi.Col * 2)()
+        c[0] = _dev_col(abi, k, n)
+        c[1].data, c[1].offsets, c[1].length, c[1].elem_size, c[1].type, c[1].flags = sdata, o, n, -1, abi.BYTES, abi.COL_DEVICE
+        return c
+    try:
+        o = up(offs)
+        bc = cols(up(bk), up(strings(bk)), o)
+        pc = cols(up(pk), up(strings(pk)), o)
+        cfg = abi.JoinCfg()
+        cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 2, 2, 2
+        for i, t in enumerate((abi.I64, abi.BYTES)):
+            cfg.build_types[i] = cfg.probe_types[i] = t
+            cfg.build_key_idx[i] = cfg.probe_key_idx[i] = i
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            t0 = time.perf_counter()
+            _lib.check(lib.tsq_join_build_push(h, bc, 2, n), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            ctx.sync()
+            build_ms = (time.perf_counter() - t0) * 1e3
+            _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+            _lib.check(lib.tsq_join_probe_push(h, pc, 2, n, None), h)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(steps):
+                _lib.check(lib.tsq_join_probe_push(h, pc, 2, n, None), h)
+            ms = ctx.timer_stop_ms() / steps
+            cnt = C.c_int64(0)
+            _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+        finally:
+            lib.tsq_join_destroy(h)
+    finally:
+        for d in dev:
+            ctx.free(d)
+    return {"workload": "1e7 x 1e7 count(*) ON (bigint, 16-byte varstring) key columns (benchmark_test.go's keyIdx {0, 1}), hit ratio 0.5; "
+                        "frac prices 48 B per probe row (8 B + 16 B + 8 B of offsets of the key cells, one 16 B slot)",
+            "ms_per_probe_pass": ms, "rows_per_s": n / ms * 1e3, "frac": 48.0 * n / ms / 1e6 / 8000.0, "build_ms": build_ms,
+            "joined_rows_per_pass": cnt.value // (steps + 1), "expected": want, "verified": cnt.value == (steps + 1) * want, "route": int(st.probe_route)}
 
 
 def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3, nullable_left_outer=False):

@@ -1163,7 +1163,11 @@ tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st,
         const bool two = variant == 0 ? !wide : variant == 2;  // (4-byte entries: the default stays the 1024-thread kernel until the A/B below is in)
         const bool ntl = tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) != 0;
         const dim3 grid2((unsigned)std::min<int64_t>(ntiles, (int64_t)j->ctx->num_cus * 2));
-        if (two && wide) {
+        const bool flags = src.nulls != nullptr || src.sel != nullptr;  // (NULL bitmap / selection flags: the FLAGS instantiations keep the 16-byte-load path)
+        if (two && flags && ntl) {
+            if (wide) hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true, uint32_t, true>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
+            else hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true, uint16_t, true>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
+        } else if (two && wide) {
             if (ntl) hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true, uint32_t>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
             else hipLaunchKernelGGL((k_da_partition2<512, 8, 4, false, uint32_t>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st);
         } else if (two) {
