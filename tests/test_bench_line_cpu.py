@@ -1,0 +1,63 @@
+"""CPU: the bench line committed under profiles/ keeps the driver's contract (the keys bench.py must print, the `roofline` and
+`cpu_baseline` objects of the task's measurement section), every side measurement in it carried a passed check when it was taken,
+and profiles/traffic_r04.json is what tools/make_traffic.py makes of the committed PMC summaries (the file bench.py reads its
+counter traffic from)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line():
+    return json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    d = _line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "int64"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["probe_rows_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 0.02
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] < 1.0 and 0.0 < r["traffic_frac"] < 1.0 and 0.0 < r["step"]["traffic_frac"] < 1.0  # no unlabelled fraction above 1
+    assert "traffic_r04.json" in r["traffic_source"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 5 and set(c["rows_per_s_by_probe_threads"]) >= {"4", "5"}
+
+
+def test_every_side_measurement_of_the_line_was_verified():
+    d = _line()
+    seen = 0
+    for k, v in d.items():
+        if not isinstance(v, dict):
+            continue
+        assert "error" not in v, (k, v.get("error"))
+        if "verified" in v:
+            seen += 1
+            assert v["verified"], k
+        for kk, vv in v.items():
+            if isinstance(vv, dict) and "verified" in vv:
+                seen += 1
+                assert vv["verified"], (k, kk)
+    assert seen >= 20 and d["verified"] is True
+    for k in ("c2_1e8x1e7", "c3_agg_1e9_1e6", "c3_zipf_s1", "c3_sparse_keys", "q3_sf100", "materialising", "two_key_columns_count_48bit",
+              "two_key_bigint_string_count", "variants_8d", "pcie_inclusive_1e7", "wide_keys_64bit_route"):
+        assert k in d, k
+
+
+def test_traffic_file_is_what_the_tool_makes_of_the_committed_pmc_summary(tmp_path):
+    out = tmp_path / "t.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_traffic.py"), os.path.join(ROOT, "profiles", "r04_bench_pmc.txt"), str(out)],
+                   check=True, capture_output=True)
+    made, have = json.load(open(out)), json.load(open(os.path.join(ROOT, "profiles", "traffic_r04.json")))
+    for k in ("k_da_partition2<512,8,4,true>", "k_da_probe_count<512,uint16_t>", "workload", "kernels_KiB_per_launch"):
+        assert made[k] == have[k], k
+    assert _line()["roofline"]["traffic"] == have["k_da_partition2<512,8,4,true>"]["traffic_bytes"]
