@@ -61,3 +61,73 @@ def test_traffic_file_is_what_the_tool_makes_of_the_committed_pmc_summary(tmp_pa
     for k in ("k_da_partition2<512,8,4,true>", "k_da_probe_count<512,uint16_t>", "workload", "kernels_KiB_per_launch"):
         assert made[k] == have[k], k
     assert _line()["roofline"]["traffic"] == have["k_da_partition2<512,8,4,true>"]["traffic_bytes"]
+
+
+# ---------------------------------------------------------------- round 5: the ONE stdout line is small and strict JSON
+def _bench_module():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _strict(text):
+    def bad(c):
+        raise ValueError("non-strict JSON constant " + c)
+    return json.loads(text, parse_constant=bad)
+
+
+def test_the_stdout_line_of_a_full_record_is_under_4_KB_and_strict_json():
+    bench = _bench_module()
+    full = _line()  # round 4's 21 KB record = what main() hands to compact_line()
+    assert len(json.dumps(full)) > 20000
+    text = bench.compact_line(full)
+    assert "\n" not in text and len(text.encode()) < 4096
+    d = _strict(text)
+    for k in bench.CONTRACT_KEYS + ("config", "roofline", "cpu_baseline", "sides", "verified"):
+        assert k in d, k
+    assert d["config"]["workload"].startswith("SELECT count(*)") and d["dtype"] == "int64" and d["n_gpus"] == 1
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac", "kernel", "kernel_ms", "step"):
+        assert k in r, k
+    assert set(r["step"]) == {"ms", "frac", "traffic_frac", "frac_priced_at_24B_per_probe_row"} and "probe_phase" not in r
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    # every side measurement: at most {ms | rows_per_s, frac, ok | error}
+    assert len(d["sides"]) >= 20
+    for k, e in d["sides"].items():
+        assert set(e) <= {"ms", "rows_per_s", "frac", "ok", "error"}, (k, e)
+    for k in ("c2_1e8x1e7", "c3_agg_1e9_1e6", "wide_keys_64bit_route", "materialising", "q3_sf100", "variants_8d.rho_0.1", "pcie_inclusive_1e7.chunks_of_1024_rows"):
+        assert k in d["sides"], k
+
+
+def test_the_stdout_line_stays_under_the_limit_whatever_the_sides_return():
+    bench = _bench_module()
+    full = _line()
+    for i in range(200):  # many more side measurements than fit, each with paragraphs of prose
+        full["side_%03d" % i] = {"ms": 1.0 / 3.0, "frac": 2.0 / 3.0, "verified": i != 7, "workload": "x" * 500, "note": {"a": ["y" * 100] * 10}}
+    full["config"]["parallelism"] = "p" * 3000
+    full["cpu_baseline"]["sample"] = "s" * 3000
+    text = bench.compact_line(full)
+    assert len(text.encode()) < 4096
+    d = _strict(text)
+    assert d["value"] == full["value"] or abs(d["value"] - full["value"]) / full["value"] < 1e-5
+    assert d["sides"] == {"dropped": 223, "all_ok": False} or "side_007" in d["sides"]
+    # NaN / inf never reach the line (strict JSON): compact_line refuses them
+    full2 = _line()
+    full2["ms_per_step"] = float("nan")
+    try:
+        bench.compact_line(full2)
+        raised = False
+    except ValueError:
+        raised = True
+    assert raised
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_its_ranks(tmp_path):
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE in the environment must become the launcher: checked
+    here without a GPU by letting the ranks fail at context creation — each must have been started with its own RANK / WORLD_SIZE."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["TSQ_BENCH_ECHO_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    seen = sorted(l for l in (r.stdout + r.stderr).splitlines() if l.startswith("bench-rank "))
+    assert seen == ["bench-rank 0 of 2 local 0", "bench-rank 1 of 2 local 1"], (r.stdout[-500:], r.stderr[-500:])

@@ -1,0 +1,887 @@
+"""Side measurements of bench.py (N = 1, after the timed region): BASELINE configs[1], [2] and [4], SURVEY.md 8(d)'s workload
+variants, the other probe routes, the materialising joins and the boundary with host chunks.  Every function returns a dict with
+`verified` (a closed form or numpy, never libtsq itself); bench.py keeps {ms, frac, ok} of each in its ONE line and writes the
+whole dicts to gpurun_out/bench_extras.json."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _dev_col(abi, ptr, n, tp=None):
+    c = abi.Col()
+    c.data, c.length, c.elem_size, c.type, c.flags = ptr, n, 8, abi.I64 if tp is None else tp, abi.COL_DEVICE
+    return c
+
+
+def _spec(abi, kind, **kw):
+    s = abi.GenSpec()
+    s.kind, s.seed = kind, 42
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def count_join_fracs(abi, st, npr, ms, key_bytes=8.0):
+    """the two prices of one COUNT(*) probe pass (fractions of 8 TB/s):
+      frac_8d : SURVEY.md 8(d)'s price — the key cells + one 16-byte slot per probe row (the north star's 64-bit design);
+      frac    : the bytes THIS route must move.  Packed route: key cells read + one packed entry written by the partition pass and read
+                again by the probe pass + the direct-address images read once.  The other routes move what 8(d) prices."""
+    f8 = (key_bytes + 16.0) * npr / ms / 1e6 / 8000.0
+    if st.probe_route == abi.ROUTE_PACKED and st.packed_key_bits > 0:
+        esz = 4.0 if st.packed_key_bits - st.radix_bits > 16 else 2.0
+        image = ((1 << st.packed_key_bits) / 8.0) if st.packed_key_bits > 28 else float(1 << st.packed_key_bits)
+        real = ((key_bytes + 2.0 * esz) * npr + image) / ms / 1e6 / 8000.0
+    else:
+        real = f8
+    return {"frac": real, "frac_8d": f8}
+
+
+def extra_c2(ctx, abi, _lib, pk, npr, nb=10_000_000, steps=10):
+    """BASELINE configs[1]: 1e8 probe rows x 1e7 build rows, count(*); probe keys = the bench's keys mod nb (hit ratio 1.0)."""
+    lib = ctx.lib
+    bk, pk2 = ctx.alloc(nb * 8), ctx.alloc(npr * 8)
+    try:
+        ctx.gen_column(_spec(abi, abi.GEN_AFFINE, table=2, a=2654435761, b=12345, m=nb), nb, bk)
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=1, col=0, m=nb), npr, pk2)
+        cfg = abi.JoinCfg()
+        cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 1, 1
+        cfg.build_types[0] = cfg.probe_types[0] = abi.I64
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            _lib.check(lib.tsq_join_build_push(h, (abi.Col * 1)(_dev_col(abi, bk, nb)), 1, nb), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+            pc = (abi.Col * 1)(_dev_col(abi, pk2, npr))
+            for _ in range(2):
+                _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(steps):
+                _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+            ms = ctx.timer_stop_ms() / steps
+            cnt = C.c_int64(0)
+            _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+        finally:
+            lib.tsq_join_destroy(h)
+    finally:
+        ctx.free(bk)
+        ctx.free(pk2)
+    return {"workload": "1e8 x 1e7 int64-key inner hash join, count(*), build side resident", "ms_per_probe_pass": ms, "rows_per_s": npr / ms * 1e3,
+            **count_join_fracs(abi, st, npr, ms), "verified": cnt.value == (steps + 2) * npr, "probe_kernel_ms": st.radix_probe_kernel_ms,
+            "partition_kernel_ms": st.partition_kernel_ms, "build_kernel_ms": st.build_kernel_ms, "steps": steps, "route": st.probe_route,
+            "packed_key_bits": st.packed_key_bits}
+
+
+def extra_variants(ctx, abi, _lib, bk, nb, npr, steps=3):
+    """SURVEY.md 8(d)'s workload variants at the headline size (1e8 x 1e8 count(*)), each with its own check:
+      j_dup_x4     : every build key four times (build keys = a bijection of [0, N_b / 4), walked four times): every probe row joins 4 build rows
+      rho_0.1      : probe keys uniform in [0, 10 N_b): hit ratio 0.1, the expected count from numpy on a host copy of the keys
+      null_keys_1pct: 1 % of the probe keys NULL (never probed, join.go:344): the expected count = the NOT-NULL rows, from numpy on the bitmap"""
+    import numpy as np
+
+    lib = ctx.lib
+    res = {}
+
+    def run(build_key, probe_key, probe_bm, want, label):
+        cfg = abi.JoinCfg()
+        cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 1, 1
+        cfg.build_types[0] = cfg.probe_types[0] = abi.I64
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            _lib.check(lib.tsq_join_build_push(h, (abi.Col * 1)(_dev_col(abi, build_key, nb)), 1, nb), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+            c = _dev_col(abi, probe_key, npr)
+            if probe_bm:
+                c.null_bitmap = probe_bm
+            pc = (abi.Col * 1)(c)
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(steps):
+                _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+            ms = ctx.timer_stop_ms() / steps
+            cnt = C.c_int64(0)
+            _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+        finally:
+            lib.tsq_join_destroy(h)
+        return {"workload": label, "ms_per_probe_pass": ms, "rows_per_s": npr / ms * 1e3, "joined_rows_per_pass": cnt.value // (steps + 1), "expected": want,
+                "verified": cnt.value == (steps + 1) * want, "route": st.probe_route, "packed_key_bits": int(st.packed_key_bits),
+                "partition_kernel_ms": st.partition_kernel_ms, "probe_kernel_ms": st.radix_probe_kernel_ms,
+                **count_join_fracs(abi, st, npr, ms)}
+
+    k2, p2 = ctx.alloc(nb * 8), ctx.alloc(npr * 8)
+    bm = ctx.alloc(npr // 8 + 64)
+    try:
+        m4 = nb // 4
+        ctx.gen_column(_spec(abi, abi.GEN_AFFINE, table=2, a=2654435761, b=12345, m=m4), nb, k2)   # i mod m4 walks [0, m4) four times
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=1, col=7, m=m4), npr, p2)
+        ctx.sync()
+        res["j_dup_x4"] = run(k2, p2, None, 4 * npr, "build keys with multiplicity 4 (2.5e7 distinct), probe keys uniform over them: 4 joined rows per probe row")
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=1, col=8, m=10 * nb), npr, p2)
+        ctx.sync()
+        host = np.empty(npr, dtype=np.int64)
+        ctx.d2h(host, p2)
+        want = int(np.count_nonzero((host >= 0) & (host < nb)))
+        del host
+        res["rho_0.1"] = run(bk, p2, None, want, "the headline build side, probe keys uniform in [0, 10 N_b): hit ratio 0.1 (expected count by numpy)")
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=1, col=9, m=nb, null_pct=1), npr, p2, null_bitmap=bm)
+        ctx.sync()
+        hb = np.empty(npr // 8, dtype=np.uint8)
+        ctx.d2h(hb, bm)
+        want = int(np.unpackbits(hb).sum()) + 0  # NOT-NULL probe rows (npr is a multiple of 8); every one of them joins exactly once
+        res["null_keys_1pct"] = run(bk, p2, bm, want, "the headline join with 1 % NULL probe keys (a NULL key is never probed): expected = the NOT-NULL rows (numpy on the bitmap)")
+    finally:
+        ctx.free(k2)
+        ctx.free(p2)
+        ctx.free(bm)
+    return res
+
+
+def extra_build_warm(ctx, abi, _lib, bk, bv, nb):
+    """`build_ms` of the headline is a COLD build: ~6 GB of first-touch hipMalloc (35 ms per GB).  A second build on the same context
+    finds its buffers in the context's pool — what every join after the first one of a session sees."""
+    lib = ctx.lib
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 2, 2
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    out = []
+    for _ in range(2):
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            t0 = time.perf_counter()
+            _lib.check(lib.tsq_join_build_push(h, (abi.Col * 2)(_dev_col(abi, bk, nb), _dev_col(abi, bv, nb)), 2, nb), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            ctx.sync()
+            out.append((time.perf_counter() - t0) * 1e3)
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+        finally:
+            lib.tsq_join_destroy(h)
+    return {"workload": "tsq_join_build_push + tsq_join_build_finish of 1e8 (k, v) rows, buffers from the context's pool", "build_ms_warm": min(out),
+            "build_kernel_ms": st.build_kernel_ms, "algorithmic_frac_of_kernels": 32.0 * nb / st.build_kernel_ms / 1e6 / 8000.0 if st.build_kernel_ms > 0 else None}
+
+
+def extra_pcie(ctx, abi, _lib, n=10_000_000):
+    """SURVEY.md §8(d) "end-to-end incl. H2D / D2H": a 1e7 x 1e7 (k, v) x (k, v) inner join with HOST chunks in and HOST chunks out, the
+    way the cgo shim drives it: pushes of tidb_max_chunk_size = 1024 rows (copied into pinned staging, flushed in 4 Mi-row batches) and
+    pulls of 1024 rows, against pushes / pulls of 1 Mi rows.  Never `value`: the link (63 GB/s) bounds a 16-byte row at 4e9 rows/s."""
+    import numpy as np
+    lib = ctx.lib
+    rng = np.random.default_rng(1)
+    bk, bv = rng.permutation(n).astype(np.int64), rng.integers(0, 1 << 40, n)
+    pk, pv = rng.integers(0, n, n), np.arange(n, dtype=np.int64)
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 2, 2
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    res = {}
+    for chunk in (1024, 1 << 20):
+        def cols(a, b, lo, hi):
+            arr = (abi.Col * 2)()
+            for i, x in enumerate((a, b)):
+                arr[i].data, arr[i].length, arr[i].elem_size, arr[i].type = x[lo:hi].ctypes.data_as(C.c_void_p), hi - lo, 8, abi.I64
+            return arr
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            t0 = time.perf_counter()
+            for lo in range(0, n, chunk):
+                _lib.check(lib.tsq_join_build_push(h, cols(bk, bv, lo, min(n, lo + chunk)), 2, min(n, lo + chunk) - lo), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            t_build = time.perf_counter() - t0
+            outb = [np.empty(chunk, dtype=np.int64) for _ in range(4)]
+            bms = [np.zeros(chunk // 8 + 16, dtype=np.uint8) for _ in range(4)]
+            oc = (abi.Col * 4)()
+            for i in range(4):
+                oc[i].data, oc[i].null_bitmap, oc[i].length, oc[i].elem_size, oc[i].type = outb[i].ctypes.data_as(C.c_void_p), bms[i].ctypes.data_as(C.c_void_p), chunk, 8, abi.I64
+            rows, t_pull = 0, 0.0
+            nn, eos = C.c_int64(0), C.c_int32(0)
+
+            def drain():
+                nonlocal rows, t_pull
+                while True:
+                    t = time.perf_counter()
+                    _lib.check(lib.tsq_join_pull(h, oc, 4, chunk, C.byref(nn), C.byref(eos)), h)
+                    t_pull += time.perf_counter() - t
+                    if nn.value == 0:
+                        return
+                    rows += nn.value
+            t0 = time.perf_counter()
+            for lo in range(0, n, chunk):
+                _lib.check(lib.tsq_join_probe_push(h, cols(pk, pv, lo, min(n, lo + chunk)), 2, min(n, lo + chunk) - lo, None), h)
+                if (lo // chunk) % 64 == 63 or chunk > 1024:
+                    drain()
+            _lib.check(lib.tsq_join_probe_finish(h), h)
+            drain()
+            t_probe = time.perf_counter() - t0
+        finally:
+            lib.tsq_join_destroy(h)
+        res["chunks_of_%d_rows" % chunk] = {"build_s": t_build, "probe_and_pull_s": t_probe, "of_which_pull_s": t_pull, "joined_rows": rows,
+                                             "probe_rows_per_s_end_to_end": n / t_probe, "verified": rows == n}
+    res["workload"] = "1e7 x 1e7 (k, v) x (k, v) inner join, host chunks in (pinned staging -> HBM) and host chunks out (D2H per result batch, then memcpy per pull)"
+    return res
+
+
+def extra_q3(sf=100):
+    """BASELINE configs[4] on ONE GPU: the Q3-shaped pipeline of tools/q3.py (Selection -> Join -> Join -> Projection -> HashAgg over
+    tables generated in HBM), run in a process of its own (its own context and arena) while this one idles.  `frac` prices the bytes
+    the query must touch once — the 2 + 4 + 4 eight-byte columns of customer / orders / lineitem and the four result columns — at
+    8 TB/s over the pipeline's execution time with the result in HBM (best of 4 runs)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "q3.py"), str(sf), "--device-gen"], capture_output=True, text=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": (r.stderr or r.stdout)[-200:]}
+    q = json.loads(line[-1])
+    nc, no, nl = int(150_000 * sf), int(1_500_000 * sf), int(6_000_000 * sf)
+    touched = 8.0 * (2 * nc + 4 * no + 4 * nl) + 32.0 * q["groups"]
+    return {"workload": q["query"] + ", SF %g: %d input rows, tables %s" % (sf, q["input_rows"], q["tables"]), "ms": q["exec_s_result_in_hbm"] * 1e3,
+            "input_rows_per_s": q["input_rows_per_s_result_in_hbm"], "groups": q["groups"], "bytes_touched_once": touched,
+            "frac": touched / q["exec_s_result_in_hbm"] / 8e12, "ms_with_result_on_host": q["best_s"] * 1e3, "joins": q["joins"], "plan": q["plan"],
+            "verified": "tests/test_pipeline_gpu.py compares the same plan with the oracle's operator chain at SF 0.01-0.1; profile: profiles/r04_q3_rocprof.txt"}
+
+
+def extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
+    """The headline join with key packing switched off: every key travels as a 64-bit table word (round 2's route, the one a build
+    side takes whose keys do not fit 28 bits)."""
+    lib = ctx.lib
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 1, 1
+    cfg.build_types[0] = cfg.probe_types[0] = abi.I64
+    h = C.c_void_p()
+    _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        _lib.check(lib.tsq_join_set_key_packing(h, abi.RADIX_OFF), h)
+        _lib.check(lib.tsq_join_build_push(h, (abi.Col * 1)(_dev_col(abi, bk, nb)), 1, nb), h)
+        _lib.check(lib.tsq_join_build_finish(h), h)
+        _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+        pc = (abi.Col * 1)(_dev_col(abi, pk, npr))
+        for _ in range(2):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(steps):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ms = ctx.timer_stop_ms() / steps
+        cnt = C.c_int64(0)
+        _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+        st = abi.Stats()
+        _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+    finally:
+        lib.tsq_join_destroy(h)
+    return {"workload": "1e8 x 1e8 count(*), key packing off: 64-bit table words (k_radix_partition + k_lds_probe_count)", "ms_per_probe_pass": ms,
+            "rows_per_s": npr / ms * 1e3, **count_join_fracs(abi, st, npr, ms), "verified": cnt.value == (steps + 2) * npr,
+            "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "steps": steps}
+
+
+def extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr, steps=5):
+    """The headline join with its keys SPREAD over 31 bits (key' = 16 key + 3, build side still unique): one byte per cell does not
+    fit (2^31 cells), one BIT per cell does (k_da_build_bits: 256 MB of images, 4-byte entries).  Every second probe key is moved off
+    the grid (+ 1: a miss), so the count is checked against numpy's count of the keys that stayed on it."""
+    import numpy as np
+
+    lib = ctx.lib
+    hb, hp = np.empty(nb, dtype=np.int64), np.empty(npr, dtype=np.int64)
+    ctx.d2h(hb, bk)
+    ctx.d2h(hp, pk)
+    hb = hb * 16 + 3
+    hp = hp * 16 + 3 + (np.arange(npr, dtype=np.int64) & 1)
+    want = int(npr - (npr // 2))  # rows with an even index keep their key
+    bk2, pk2 = ctx.alloc(nb * 8), ctx.alloc(npr * 8)
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 1, 1, 1
+    cfg.build_types[0] = cfg.probe_types[0] = abi.I64
+    h = C.c_void_p()
+    try:
+        ctx.h2d(bk2, hb)
+        ctx.h2d(pk2, hp)
+        del hb, hp
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        _lib.check(lib.tsq_join_build_push(h, (abi.Col * 1)(_dev_col(abi, bk2, nb)), 1, nb), h)
+        _lib.check(lib.tsq_join_build_finish(h), h)
+        _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+        pc = (abi.Col * 1)(_dev_col(abi, pk2, npr))
+        for _ in range(2):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(steps):
+            _lib.check(lib.tsq_join_probe_push(h, pc, 1, npr, None), h)
+        ms = ctx.timer_stop_ms() / steps
+        cnt = C.c_int64(0)
+        _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+        st = abi.Stats()
+        _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+    finally:
+        if h:
+            lib.tsq_join_destroy(h)
+        ctx.free(bk2)
+        ctx.free(pk2)
+    return {"workload": "1e8 x 1e8 count(*), keys spread over 31 bits (16 k + 3), hit ratio 0.5: 4-byte entries against one-BIT cells in LDS", "ms_per_probe_pass": ms,
+            "rows_per_s": npr / ms * 1e3, **count_join_fracs(abi, st, npr, ms), "verified": cnt.value == (steps + 2) * want, "packed_key_bits": int(st.packed_key_bits),
+            "probe_kernel_ms": st.radix_probe_kernel_ms, "partition_kernel_ms": st.partition_kernel_ms, "route": st.probe_route, "packed_images_ms": st.packed_build_ms, "steps": steps}
+
+
+def extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, steps=3, spread=1):
+    """The headline join on TWO key columns: (k div 10000, k mod 10000) on both sides — the same pairs match as in the one-column
+    join, every second probe row's second cell is pushed out of its field (a miss).  Packed route (the cells composed into one key
+    column per batch) against the direct route (64-bit tag of both cells, cells compared)."""
+    import numpy as np
+
+    lib = ctx.lib
+    hb, hp = np.empty(nb, dtype=np.int64), np.empty(npr, dtype=np.int64)
+    ctx.d2h(hb, bk)
+    ctx.d2h(hp, pk)
+    # spread > 1: the first key column's cells are multiplied — the same pairs match, but its field is wider (spread = 1000003: 34 + 14 =
+    # 48 bits of fields: beyond the packed composite's 28 bits, the composite-key child join takes the COUNT(*): tsq_join.hip, wide_prepare)
+    cols_h = [hb // 10000 * spread, hb % 10000, hp // 10000 * spread, hp % 10000 + 20000 * (np.arange(npr, dtype=np.int64) & 1)]
+    del hb, hp
+    want = int(npr - npr // 2)
+    dev = [ctx.alloc(len(c) * 8) for c in cols_h]
+    res = {}
+    try:
+        for d, c in zip(dev, cols_h):
+            ctx.h2d(d, np.ascontiguousarray(c))
+        del cols_h
+        for name, mode in ((("packed" if spread == 1 else "composite_key_child_join"), abi.RADIX_AUTO),) + ((("direct", abi.RADIX_OFF),) if spread == 1 else ()):
+            cfg = abi.JoinCfg()
+            cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 2, 2, 2
+            for i in range(2):
+                cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+                cfg.build_key_idx[i] = cfg.probe_key_idx[i] = i
+            h = C.c_void_p()
+            _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                _lib.check(lib.tsq_join_set_key_packing(h, mode), h)
+                t0 = time.perf_counter()
+                _lib.check(lib.tsq_join_build_push(h, (abi.Col * 2)(_dev_col(abi, dev[0], nb), _dev_col(abi, dev[1], nb)), 2, nb), h)
+                _lib.check(lib.tsq_join_build_finish(h), h)
+                ctx.sync()
+                build_ms = (time.perf_counter() - t0) * 1e3
+                _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+                pc = (abi.Col * 2)(_dev_col(abi, dev[2], npr), _dev_col(abi, dev[3], npr))
+                _lib.check(lib.tsq_join_probe_push(h, pc, 2, npr, None), h)
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(steps):
+                    _lib.check(lib.tsq_join_probe_push(h, pc, 2, npr, None), h)
+                ms = ctx.timer_stop_ms() / steps
+                cnt = C.c_int64(0)
+                _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+                res[name] = {"ms_per_probe_pass": ms, "rows_per_s": npr / ms * 1e3, **count_join_fracs(abi, st, npr, ms, key_bytes=16.0), "build_ms": build_ms,
+                             "verified": cnt.value == (steps + 1) * want, "route": st.probe_route, "packed_key_bits": int(st.packed_key_bits)}
+            finally:
+                lib.tsq_join_destroy(h)
+    finally:
+        for d in dev:
+            ctx.free(d)
+    res["workload"] = ("1e8 x 1e8 count(*) on TWO BIGINT key columns (k div 10000%s, k mod 10000), hit ratio 0.5; frac prices 32 B per probe row (two key cells + one 16 B slot)"
+                       % ("" if spread == 1 else " x %d: %d bits of fields" % (spread, 48)))
+    return res
+
+
+def extra_string_key_join(ctx, abi, _lib, n=10_000_000, steps=3):
+    """The reference benchmark's own key shape: keyIdx {0, 1} = (bigint, varstring) (executor/benchmark_test.go:357, 328) — COUNT(*) of a
+    1e7 x 1e7 join ON a.k = b.k AND a.s = b.s, s a 16-byte binary string derived from k.  Build rows: k = 0 .. n-1; probe rows: k uniform
+    in [0, 2n) (hit ratio 0.5, expected count by numpy).  String keys keep the DIRECT several-column route (64-bit tag of both cells,
+    bytes compared on a tag hit): the line is here so that the route's cost is in the driver JSON, not because it is fast."""
+    import numpy as np
+    lib = ctx.lib
+
+    def strings(k):  # 16 bytes per cell: two 64-bit mixes of the bigint, as raw bytes
+        a = (k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64(0x1234567)
+        b = (k.astype(np.uint64) + np.uint64(77)) * np.uint64(0xC2B2AE3D27D4EB4F)
+        return np.ascontiguousarray(np.stack([a, b], axis=1)).view(np.uint8).reshape(-1)
+    rng = np.random.default_rng(3)
+    bk = rng.permutation(n).astype(np.int64)
+    pk = rng.integers(0, 2 * n, n)
+    want = int((pk < n).sum())
+    offs = (np.arange(n + 1, dtype=np.int64) * 16)
+    dev = []
+
+    def up(arr):
+        p = ctx.alloc(arr.nbytes + 64)
+        ctx.h2d(p, np.ascontiguousarray(arr))
+        dev.append(p)
+        return p
+
+    def cols(k, sdata, o):
+        c = (abi.Col * 2)()
+        c[0] = _dev_col(abi, k, n)
+        c[1].data, c[1].offsets, c[1].length, c[1].elem_size, c[1].type, c[1].flags = sdata, o, n, -1, abi.BYTES, abi.COL_DEVICE
+        return c
+    try:
+        o = up(offs)
+        bc = cols(up(bk), up(strings(bk)), o)
+        pc = cols(up(pk), up(strings(pk)), o)
+        cfg = abi.JoinCfg()
+        cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, 2, 2, 2
+        for i, t in enumerate((abi.I64, abi.BYTES)):
+            cfg.build_types[i] = cfg.probe_types[i] = t
+            cfg.build_key_idx[i] = cfg.probe_key_idx[i] = i
+        h = C.c_void_p()
+        _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+        try:
+            t0 = time.perf_counter()
+            _lib.check(lib.tsq_join_build_push(h, bc, 2, n), h)
+            _lib.check(lib.tsq_join_build_finish(h), h)
+            ctx.sync()
+            build_ms = (time.perf_counter() - t0) * 1e3
+            _lib.check(lib.tsq_join_set_count_only(h, 1), h)
+            _lib.check(lib.tsq_join_probe_push(h, pc, 2, n, None), h)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(steps):
+                _lib.check(lib.tsq_join_probe_push(h, pc, 2, n, None), h)
+            ms = ctx.timer_stop_ms() / steps
+            cnt = C.c_int64(0)
+            _lib.check(lib.tsq_join_count(h, C.byref(cnt)), h)
+            st = abi.Stats()
+            _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+        finally:
+            lib.tsq_join_destroy(h)
+    finally:
+        for d in dev:
+            ctx.free(d)
+    return {"workload": "1e7 x 1e7 count(*) ON (bigint, 16-byte varstring) key columns (benchmark_test.go's keyIdx {0, 1}), hit ratio 0.5; "
+                        "frac prices 48 B per probe row (8 B + 16 B + 8 B of offsets of the key cells, one 16 B slot)",
+            "ms_per_probe_pass": ms, "rows_per_s": n / ms * 1e3, "frac": 48.0 * n / ms / 1e6 / 8000.0, "build_ms": build_ms,
+            "joined_rows_per_pass": cnt.value // (steps + 1), "expected": want, "verified": cnt.value == (steps + 1) * want, "route": int(st.probe_route)}
+
+
+def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3, nullable_left_outer=False):
+    """The bench's join with its four output columns (probe k, v | build k, v) materialised in HBM: HashJoinExec.Next
+    (executor/join.go:125-146, joiner.go:351-378).  Algorithmic bytes: 32 B per probe row + 24 B per joined row.
+    nullable_left_outer: 3 % NULL probe keys, 3 % NULL payload cells on both sides, LEFT OUTER JOIN (joiner.go:220-281: a probe row
+    without a match is padded with NULLs) — every probe row makes exactly one output row (unique build keys, hit ratio 1.0)."""
+    lib = ctx.lib
+    cfg = abi.JoinCfg()
+    cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_LEFT_OUTER if nullable_left_outer else abi.JOIN_INNER, 1, 1, 2, 2
+    for i in range(2):
+        cfg.build_types[i] = cfg.probe_types[i] = abi.I64
+    bms = []
+
+    def col(ptr, n, bm=None):
+        c = _dev_col(abi, ptr, n)
+        if bm:
+            c.null_bitmap = bm
+        return c
+
+    if nullable_left_outer:
+        tmp = ctx.alloc(max(nb, npr) * 8)
+        for n, colid in ((npr, 11), (npr, 12), (nb, 13)):  # bitmaps of: probe key, probe payload, build payload (3 % NULL each)
+            bm = ctx.alloc(n // 8 + 64)
+            ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=4, col=colid, m=7, null_pct=3), n, tmp, null_bitmap=bm)
+            bms.append(bm)
+        ctx.sync()
+        ctx.free(tmp)
+        bcols = (abi.Col * 2)(col(bk, nb), col(bv, nb, bms[2]))
+        pcols = (abi.Col * 2)(col(pk, npr, bms[0]), col(pv, npr, bms[1]))
+    else:
+        bcols = (abi.Col * 2)(col(bk, nb), col(bv, nb))
+        pcols = (abi.Col * 2)(col(pk, npr), col(pv, npr))
+    one_pass, again, build_only = 1e30, 1e30, 1e30
+    rows = 0
+    st = abi.Stats()
+    try:
+        for _ in range(reps):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ctx.sync()
+                t = time.perf_counter()
+                _lib.check(lib.tsq_join_build_push(h, bcols, 2, nb), h)
+                _lib.check(lib.tsq_join_build_finish(h), h)
+                ctx.sync()
+                t_b = time.perf_counter() - t
+                _lib.check(lib.tsq_join_probe_push(h, pcols, 2, npr, None), h)  # HashJoinExec: build once, probe once — everything the route prepares is in here
+                ctx.sync()
+                one_pass = min(one_pass, time.perf_counter() - t)
+                build_only = min(build_only, t_b)
+                t = time.perf_counter()
+                _lib.check(lib.tsq_join_probe_push(h, pcols, 2, npr, None), h)  # a second pass against the prepared build side (a probe side of 2e8 rows)
+                ctx.sync()
+                again = min(again, time.perf_counter() - t)
+                _lib.check(lib.tsq_join_stats(h, C.byref(st)), h)
+                _lib.check(lib.tsq_join_probe_finish(h), h)
+                c = C.c_int64(0)
+                _lib.check(lib.tsq_join_count(h, C.byref(c)), h)
+                rows = c.value // 2
+            finally:
+                lib.tsq_join_destroy(h)
+    finally:
+        for bm in bms:
+            ctx.free(bm)
+    algo_probe = 32.0 * npr + 24.0 * rows
+    algo_all = 32.0 * nb + algo_probe
+    return {"workload": "1e8 x 1e8 (k, v) x (k, v) %s, 4 output columns written to HBM" % ("LEFT OUTER JOIN with 3 % NULL probe keys and 3 % NULL payload cells on both sides"
+                                                                                            if nullable_left_outer else "inner join"),
+            "ms": one_pass * 1e3, "joined_rows": rows, "joined_rows_per_s": rows / one_pass, "frac": algo_all / one_pass / 8e12, "verified": rows == npr,
+            "build_call_ms": build_only * 1e3, "repeated_probe_pass_ms": again * 1e3, "repeated_probe_pass_frac": algo_probe / again / 8e12,
+            "route": {0: "direct (K3 + K4a + gather)", 2: "64-bit LDS route (partition with payload, sizing pass, emit)",
+                      3: "packed keys: probe columns travel with 2-byte entries, build columns sorted by word, K4e writes the rows"}.get(st.probe_route, str(st.probe_route)),
+            "packed_prepare_ms": st.packed_build_ms,
+            "timing": "host clock, best of %d.  `ms` = ONE PASS of the operator: tsq_join_build_push + build_finish + one probe_push of all rows + stream sync — the "
+                      "build, everything the route prepares on the build side (packed_prepare_ms of kernels: images, partitioned + sorted build columns) and the "
+                      "probe; `frac` prices it at 32 B per build row + 32 B per probe row + 24 B per joined row (SURVEY.md 8d).  repeated_probe_pass_ms = a further "
+                      "probe pass against the prepared build side" % reps}
+
+
+def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_000, double=False):
+    """BASELINE configs[2]: SELECT k, SUM(v), COUNT(*) GROUP BY k, 1e9 rows / 1e6 int64 groups; the rows are generated batch by
+    batch on the device (untimed) and pushed device resident, like the chunks of a GPU child operator.  v = r mod 1000 (BIGINT:
+    bit-exact SUM) or, double=True, a double in [0, 1) (BASELINE.md C3's primary shape).  Verified against numpy on host copies of the
+    value batches: sum of the groups' counts = rows, sum of the groups' sums = sum of all values (exact for BIGINT, within the
+    re-ordering bound 2 n 2^-53 sum|v| for doubles), every key in [0, groups) exactly once."""
+    import numpy as np
+
+    lib = ctx.lib
+    vt = abi.F64 if double else abi.I64
+    k, v = ctx.alloc(batch * 8), ctx.alloc(batch * 8)
+    try:
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 1
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
+        cfg.n_input_cols = 2
+        cfg.input_types[0], cfg.input_types[1] = abi.I64, vt
+        cfg.n_aggs = 3
+        for i, (f, col, t) in enumerate([(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, vt), (abi.AGG_COUNT, -1, abi.I64)]):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, t
+        cfg.est_groups = groups
+        runs = []
+        want_sum, want_abs = 0, 0.0
+        check = {}
+        for run in range(2):  # the second run finds its partition / group buffers in the context's pool (hipMalloc costs ~35 ms per GB)
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ms, done = 0.0, 0
+                while done < n:
+                    m = min(batch, n - done)
+                    ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=0, m=groups, start=done), m, k)
+                    if double:
+                        ctx.gen_column(_spec(abi, abi.GEN_RAND_F64, table=3, col=1, start=done), m, v)
+                    else:
+                        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=1, m=1000, start=done), m, v)
+                    ctx.sync()
+                    if run == 1:  # the independent total of the values (numpy on a host copy)
+                        host = np.empty(m, dtype=np.float64 if double else np.int64)
+                        ctx.d2h(host, v)
+                        if double:
+                            want_sum += float(host.sum(dtype=np.float64))
+                            want_abs += float(np.abs(host).sum())
+                        else:
+                            want_sum += int(host.sum(dtype=np.int64))
+                        del host
+                    ctx.timer_start()
+                    _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m, vt)), 2, m), h)
+                    ms += ctx.timer_stop_ms()
+                    done += m
+                ctx.timer_start()
+                _lib.check(lib.tsq_agg_finish(h), h)
+                ms += ctx.timer_stop_ms()
+                ng = C.c_int64(0)
+                _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
+                runs.append(ms)
+                if run == 1:  # pull the groups: (firstrow k, sum, count)
+                    cap = 1 << 20
+                    bufs = [np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float64 if double else np.int64), np.empty(cap, dtype=np.int64)]
+                    dbufs = [ctx.alloc(cap * 8) for _ in range(3)]  # device-resident pushes -> device-resident pulls, then a copy to the host
+                    dbms = [ctx.alloc(cap // 8 + 64) for _ in range(3)]
+                    keys_seen = np.zeros(groups, dtype=np.uint8)
+                    got_rows, got_cnt, got_sum, bad_keys = 0, 0, 0, 0
+                    while True:
+                        out = (abi.Col * 3)()
+                        for i, b in enumerate(bufs):
+                            out[i].data, out[i].length, out[i].elem_size, out[i].type, out[i].flags = dbufs[i], cap, 8, (abi.I64, vt, abi.I64)[i], abi.COL_DEVICE
+                            out[i].null_bitmap = dbms[i]
+                        nn, eos = C.c_int64(0), C.c_int32(0)
+                        _lib.check(lib.tsq_agg_pull(h, out, 3, cap, C.byref(nn), C.byref(eos)), h)
+                        if nn.value == 0:
+                            break
+                        for i, b in enumerate(bufs):
+                            ctx.d2h(b[:nn.value], dbufs[i])
+                        kk = bufs[0][:nn.value]
+                        ok = (kk >= 0) & (kk < groups)
+                        bad_keys += int((~ok).sum())
+                        np.add.at(keys_seen, kk[ok], 1)
+                        got_rows += nn.value
+                        got_cnt += int(bufs[2][:nn.value].sum())
+                        got_sum += float(bufs[1][:nn.value].sum()) if double else int(bufs[1][:nn.value].sum())
+                    for pbuf in dbufs + dbms:
+                        ctx.free(pbuf)
+                    tol = 2.0 * n * 2.0 ** -53 * want_abs * 2 if double else 0
+                    check = {"groups_pulled": got_rows, "sum_of_counts": got_cnt, "sum_of_sums": got_sum, "sum_of_values_numpy": want_sum,
+                             "every_key_once": bool(bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1),
+                             "ok": bool(got_cnt == n and abs(got_sum - want_sum) <= tol and bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1)}
+            finally:
+                lib.tsq_agg_destroy(h)
+        ms = runs[-1]
+    finally:
+        ctx.free(k)
+        ctx.free(v)
+    algo = 16.0 * n + 24.0 * ng.value
+    return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows / 1e6 int64 groups, v %s, HashAggExec" % ("double in [0, 1)" if double else "BIGINT r mod 1000"),
+            "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value,
+            "frac": algo / ms / 1e6 / 8000.0, "verified": bool(ng.value == groups and check.get("ok")), "check": check, "first_run_ms": runs[0],
+            "route": ("packed keys: %d-bit key range, 2-byte entries + %d-byte argument cells, direct-addressed LDS accumulators%s"
+                      % (st.packed_key_bits, max(st.table_slice_bits, 8) // 8,
+                         ", folded into a dense partial state in HBM that becomes groups once, at finish" if st.dense_flushes else ", partial groups merged after every batch"))
+                     if st.packed_key_bits else "64-bit table words, LDS hash tables",
+            "argument_cell_bits": st.table_slice_bits, "dense_flushes": st.dense_flushes,
+            "timing": "HIP events around every tsq_agg_push (%d device-resident batches of %.3g rows) + tsq_agg_finish; second of two runs" % ((n + batch - 1) // batch, batch)}
+
+
+def extra_c3_variant(ctx, abi, _lib, keys, n=1_000_000_000, groups=1_000_000, batch=250_000_000):
+    """SURVEY.md 8(d)'s C3 variants: SELECT k, SUM(v), COUNT(*) GROUP BY k over 1e9 rows, v = r mod 1000 (BIGINT: exact), with
+      keys = "zipf"  : skewed keys in [0, 1e6) with the s = 1 harmonic envelope (TSQ_GEN_ZIPF_OCT: key 0 alone is 5 % of the rows)
+      keys = "sparse": 1e6 distinct keys drawn from the whole 64-bit space (splitmix64 of r mod 1e6) — no dense range to pack
+    Verified against numpy: per-key COUNT(*) by np.bincount over host copies of the key batches (zipf) / the exact key set (sparse),
+    sum of the groups' sums = numpy's sum of all values, sum of counts = rows."""
+    import numpy as np
+
+    lib = ctx.lib
+    k, v, t = ctx.alloc(batch * 8), ctx.alloc(batch * 8), ctx.alloc(batch * 8)
+    try:
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 1
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
+        cfg.n_input_cols = 2
+        cfg.input_types[0], cfg.input_types[1] = abi.I64, abi.I64
+        cfg.n_aggs = 3
+        for i, (f, col) in enumerate([(abi.AGG_FIRSTROW, 0), (abi.AGG_SUM, 1), (abi.AGG_COUNT, -1)]):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
+        cfg.est_groups = groups
+
+        def gen(done, m):
+            if keys == "zipf":
+                ctx.gen_column(_spec(abi, abi.GEN_ZIPF_OCT, table=6, col=0, a=20, m=groups, start=done), m, k)
+            else:
+                ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=6, col=0, m=groups, start=done), m, t)
+                ctx.gen_column(_spec(abi, abi.GEN_HASH_OF_COL, table=6, b=0x5EED5EED), m, k, src=t)
+            ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=6, col=1, m=1000, start=done), m, v)
+            ctx.sync()
+
+        runs, want_sum = [], 0
+        want_cnt = np.zeros(groups, dtype=np.int64)
+        for run in range(2):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ms, done = 0.0, 0
+                while done < n:
+                    m = min(batch, n - done)
+                    gen(done, m)
+                    if run == 1:
+                        host = np.empty(m, dtype=np.int64)
+                        ctx.d2h(host, v)
+                        want_sum += int(host.sum(dtype=np.int64))
+                        ctx.d2h(host, t if keys == "sparse" else k)  # (sparse: the key's pre-image r mod 1e6 is what numpy counts)
+                        want_cnt += np.bincount(host, minlength=groups)
+                        del host
+                    ctx.timer_start()
+                    _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m)), 2, m), h)
+                    ms += ctx.timer_stop_ms()
+                    done += m
+                ctx.timer_start()
+                _lib.check(lib.tsq_agg_finish(h), h)
+                ms += ctx.timer_stop_ms()
+                runs.append(ms)
+                ng = C.c_int64(0)
+                _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
+                if run == 1:
+                    cap = max(ng.value, 8)
+                    dbufs = [ctx.alloc(cap * 8) for _ in range(3)]
+                    dbms = [ctx.alloc(cap // 8 + 64) for _ in range(3)]
+                    out = (abi.Col * 3)()
+                    for i in range(3):
+                        out[i].data, out[i].length, out[i].elem_size, out[i].type, out[i].flags = dbufs[i], cap, 8, abi.I64, abi.COL_DEVICE
+                        out[i].null_bitmap = dbms[i]
+                    nn, eos = C.c_int64(0), C.c_int32(0)
+                    _lib.check(lib.tsq_agg_pull(h, out, 3, cap, C.byref(nn), C.byref(eos)), h)
+                    got = [np.empty(nn.value, dtype=np.int64) for _ in range(3)]
+                    for i in range(3):
+                        ctx.d2h(got[i], dbufs[i])
+                    for pbuf in dbufs + dbms:
+                        ctx.free(pbuf)
+                    if keys == "sparse":  # the group of pre-image x carries the key splitmix64(x ^ b): compare the key SETS and the counts through it
+                        pre = np.arange(groups, dtype=np.uint64) ^ np.uint64(0x5EED5EED)
+                        with np.errstate(over="ignore"):
+                            z = pre + np.uint64(0x9E3779B97F4A7C15)
+                            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+                            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+                            z = z ^ (z >> np.uint64(31))
+                        order = np.argsort(z)
+                        gk = got[0].view(np.uint64)
+                        gorder = np.argsort(gk)
+                        present = want_cnt[order] > 0
+                        keys_ok = bool(len(gk) == int(present.sum()) and (gk[gorder] == z[order][present]).all())
+                        counts_ok = bool(keys_ok and (got[2][gorder] == want_cnt[order][present]).all())
+                    else:
+                        present = want_cnt > 0
+                        inr = (got[0] >= 0) & (got[0] < groups)
+                        keys_ok = bool(inr.all() and len(np.unique(got[0])) == len(got[0]) == int(present.sum()))
+                        counts_ok = bool(keys_ok and (want_cnt[got[0]] == got[2]).all())
+                    check = {"groups_pulled": int(nn.value), "keys_are_the_expected_set": keys_ok, "every_count_equals_numpy_bincount": counts_ok,
+                             "sum_of_sums": int(got[1].sum()), "sum_of_values_numpy": want_sum, "largest_group_rows": int(got[2].max()) if nn.value else 0}
+                    check["ok"] = bool(keys_ok and counts_ok and check["sum_of_sums"] == want_sum and int(got[2].sum()) == n)
+            finally:
+                lib.tsq_agg_destroy(h)
+        ms = runs[-1]
+    finally:
+        for b in (k, v, t):
+            ctx.free(b)
+    return {"workload": "SELECT k, SUM(v), COUNT(*) GROUP BY k: 1e9 rows, v BIGINT r mod 1000, keys: %s" %
+                        ("Zipf-like (s = 1 envelope per octave) over [0, 1e6)" if keys == "zipf" else "1e6 distinct values spread over the 64-bit space"),
+            "ms": ms, "rows_per_s": n / ms * 1e3, "groups": ng.value, "frac": (16.0 * n + 24.0 * ng.value) / ms / 1e6 / 8000.0, "verified": bool(check.get("ok")),
+            "check": check, "first_run_ms": runs[0],
+            "route": ("packed keys: %d-bit key range, %d-byte argument cells%s" % (st.packed_key_bits, max(st.table_slice_bits, 8) // 8,
+                      "; the runs of the hot keys that do not fit their partitions' regions go through the overflow store (k_daagg_ovf)" if keys == "zipf" else ""))
+                     if st.packed_key_bits else "64-bit key words, LDS hash tables per partition (H mode)",
+            "timing": "HIP events around every tsq_agg_push + tsq_agg_finish; second of two runs; frac prices 16 B per row + 24 B per group (SURVEY.md 8d)"}
+
+
+def extra_two_keys(ctx, abi, _lib, n=250_000_000, ma=1000, mb=100):
+    """SELECT a, b, SUM(v), COUNT(*) GROUP BY a, b — two BIGINT key columns (a = r mod ma, b = r' mod mb), v = r'' mod 1000, one
+    device-resident batch: the key cells travel as the fields of one packed word (tsq_daagg.h).  Verified: every (a, b) pair once,
+    sum of counts = rows, sum of sums = numpy's sum of the value column."""
+    import numpy as np
+
+    lib = ctx.lib
+    bufs = [ctx.alloc(n * 8) for _ in range(3)]
+    try:
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 2
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
+        cfg.group_key_col[1], cfg.group_key_type[1] = 1, abi.I64
+        cfg.n_input_cols = 3
+        for c in range(3):
+            cfg.input_types[c] = abi.I64
+        aggs = [(abi.AGG_FIRSTROW, 0), (abi.AGG_FIRSTROW, 1), (abi.AGG_SUM, 2), (abi.AGG_COUNT, -1)]
+        cfg.n_aggs = len(aggs)
+        for i, (f, col) in enumerate(aggs):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
+        cfg.est_groups = ma * mb
+        for c, m in enumerate((ma, mb, 1000)):
+            ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=5, col=c, m=m), n, bufs[c])
+        ctx.sync()
+        host = np.empty(n, dtype=np.int64)
+        ctx.d2h(host, bufs[2])
+        want_sum = int(host.sum(dtype=np.int64))
+        del host
+        runs = []
+        for run in range(2):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ctx.timer_start()
+                _lib.check(lib.tsq_agg_push(h, (abi.Col * 3)(*[_dev_col(abi, b, n) for b in bufs]), 3, n), h)
+                _lib.check(lib.tsq_agg_finish(h), h)
+                runs.append(ctx.timer_stop_ms())
+                ng = C.c_int64(0)
+                _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                st = abi.Stats()
+                _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
+                if run == 1:
+                    cap = ma * mb + 8
+                    dbufs = [ctx.alloc(cap * 8) for _ in range(4)]
+                    dbms = [ctx.alloc(cap // 8 + 64) for _ in range(4)]
+                    out = (abi.Col * 4)()
+                    for i in range(4):
+                        out[i].data, out[i].length, out[i].elem_size, out[i].type, out[i].flags = dbufs[i], cap, 8, abi.I64, abi.COL_DEVICE
+                        out[i].null_bitmap = dbms[i]
+                    nn, eos = C.c_int64(0), C.c_int32(0)
+                    _lib.check(lib.tsq_agg_pull(h, out, 4, cap, C.byref(nn), C.byref(eos)), h)
+                    got = [np.empty(nn.value, dtype=np.int64) for _ in range(4)]
+                    for i in range(4):
+                        ctx.d2h(got[i], dbufs[i])
+                    for pbuf in dbufs + dbms:
+                        ctx.free(pbuf)
+                    pair = got[0] * mb + got[1]
+                    in_range = bool(((got[0] >= 0) & (got[0] < ma) & (got[1] >= 0) & (got[1] < mb)).all())
+                    check = {"groups_pulled": int(nn.value), "every_pair_once": bool(in_range and len(np.unique(pair)) == ma * mb and nn.value == ma * mb),
+                             "sum_of_counts": int(got[3].sum()), "sum_of_sums": int(got[2].sum()), "sum_of_values_numpy": want_sum}
+                    check["ok"] = bool(check["every_pair_once"] and check["sum_of_counts"] == n and check["sum_of_sums"] == want_sum)
+            finally:
+                lib.tsq_agg_destroy(h)
+    finally:
+        for b in bufs:
+            ctx.free(b)
+    ms = runs[-1]
+    return {"workload": "SELECT a, b, SUM(v), COUNT(*) GROUP BY a, b: %.3g rows, %d x %d BIGINT key pairs, HashAggExec" % (n, ma, mb), "ms": ms,
+            "rows_per_s": n / ms * 1e3, "groups": ng.value, "frac": 24.0 * n / ms / 1e6 / 8000.0, "verified": bool(check.get("ok")), "check": check,
+            "first_run_ms": runs[0], "packed_key_bits": int(st.packed_key_bits),
+            "route": ("packed keys: the two key cells are the fields of one %d-bit word" % st.packed_key_bits) if st.packed_key_bits else "row-at-a-time upsert (two-phase tag table)",
+            "timing": "HIP events around tsq_agg_push of one device-resident batch + tsq_agg_finish; second of two runs; frac prices 24 B per row"}
+
+
+def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
+    """(key, thunk) of every side measurement, in the order they run"""
+    return (("build_warm", lambda: extra_build_warm(ctx, abi, _lib, bk, bv, nb)),
+            ("pcie_inclusive_1e7", lambda: extra_pcie(ctx, abi, _lib)),
+            ("wide_keys_64bit_route", lambda: extra_unpacked(ctx, abi, _lib, bk, pk, nb, npr)),
+            ("wide_keys_31bit_unique_bit_cells", lambda: extra_bit_cells(ctx, abi, _lib, bk, pk, nb, npr)),
+            ("two_key_columns_count", lambda: extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr)),
+            ("two_key_columns_count_48bit", lambda: extra_two_key_join(ctx, abi, _lib, bk, pk, nb, npr, spread=1000003)),
+            ("two_key_bigint_string_count", lambda: extra_string_key_join(ctx, abi, _lib)),
+            ("variants_8d", lambda: extra_variants(ctx, abi, _lib, bk, nb, npr)),
+            ("c2_1e8x1e7", lambda: extra_c2(ctx, abi, _lib, pk, npr)),
+            ("c3_agg_1e9_1e6", lambda: extra_c3(ctx, abi, _lib)),
+            ("c3_agg_1e9_1e6_double", lambda: extra_c3(ctx, abi, _lib, double=True)),
+            ("c3_zipf_s1", lambda: extra_c3_variant(ctx, abi, _lib, "zipf")),
+            ("c3_sparse_keys", lambda: extra_c3_variant(ctx, abi, _lib, "sparse")),
+            ("agg_two_keys_1000x100", lambda: extra_two_keys(ctx, abi, _lib)),
+            ("agg_two_keys_50x20", lambda: extra_two_keys(ctx, abi, _lib, ma=50, mb=20)),
+            ("q3_sf100", lambda: extra_q3()),
+            ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
+            ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True)))
+
+
+TRAFFIC_FILE = "traffic_r04.json"
+TRAFFIC_KERNELS = {
+    "c3_agg_1e9_1e6": ["void k_daagg_partition<1024, 8, 1", "void k_agg_da<3, 4096, 1>", "k_daagg_dense_emit", "k_agg_merge("],
+    "c3_agg_1e9_1e6_double": ["void k_daagg_partition<1024, 8, 1>", "void k_agg_da<2, 4096, 2>"],
+    "c3_zipf_s1": ["void k_daagg_ovf<3>"],
+    "c3_sparse_keys": ["void k_radix_partition<1024, 8, 4, 1, false, true>", "void k_agg_lds<1, 3>"],
+    "agg_two_keys_50x20": ["void k_agg_da_low<3, 4096>"],
+    "materialising": ["void k_da_partition_cols<1024, 8, false>", "void k_da_emit_cols<512, false, true>", "void k_da_sort_partition<1024>"],
+    "materialising_nullable_left_outer": ["void k_da_partition_cols<1024, 8, true>", "void k_da_emit_cols<512, true, true>"],
+    "wide_keys_64bit_route": ["void k_lds_probe_count<1024, false, 0>", "void k_radix_partition<1024, 16, 4, 0, false, true>"],
+    "wide_keys_31bit_unique_bit_cells": ["void k_da_build_bits<1024>", "void k_da_probe_count<1024, unsigned int, false, false, true>",
+                                         "void k_da_partition<1024, 16, unsigned int, false, false>"],
+    "two_key_columns_count": ["k_da_compose", "void k_probe_count<true, false, false>"],
+}
+
+
+def attach_counter_traffic(out):
+    """PMC-derived HBM traffic of the side measurements' kernels (measured offline, committed under profiles/: per launch, KiB, one average per
+    (kernel, grid size) so the shapes of a run are not mixed; FETCH_SIZE needs x2 for wide streaming reads on gfx950) — extras file only"""
+    try:
+        tk = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))["kernels_KiB_per_launch"]
+    except Exception:
+        return
+    for key, names in TRAFFIC_KERNELS.items():
+        if key in out and isinstance(out[key], dict) and "error" not in out[key]:
+            out[key]["traffic_KiB_per_launch"] = {k: v for k, v in tk.items() if any(k.startswith(n) for n in names)}
+            out[key]["traffic_source"] = "profiles/%s (rocprofv3 --pmc passes of this command; one entry per kernel and grid size)" % TRAFFIC_FILE
