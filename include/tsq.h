@@ -62,7 +62,8 @@ enum {
 #define TSQ_COL_DEVICE 1u /* data/null_bitmap/offsets are device (HBM) pointers */
 #define TSQ_COL_BORROW 2u /* an OUTPUT column of a device-resident pull (tsq_join_pull): instead of copying into the caller's buffers the
                              operator hands out pointers into its own result batch — data / null_bitmap are SET by the call (null_bitmap =
-                             NULL when the column holds no NULL) and stay valid until the next pull, finish or destroy on the handle.
+                             NULL when the column holds no NULL) and stay valid until the next pull, peek, finish or destroy on the handle (tsq_join_peek
+                             releases fully consumed result batches too).
                              The device-chunk hand-off between GPU operators (Chunk.SwapColumns, util/chunk/chunk.go:231-235, is the
                              same idea: ownership of the buffers moves, no row is copied).  Fixed-width columns only. */
 

@@ -138,7 +138,8 @@ TSQ_HD uint64_t tsq_gen_value(const tsq_gen_spec& s, uint64_t i, uint64_t src) {
         case TSQ_GEN_HASH_OF_COL: return tsq_splitmix64(src ^ s.b);
         case TSQ_GEN_ZIPF_OCT: {
             const uint64_t r = tsq_gen_r(s.seed, (uint32_t)s.table, (uint64_t)s.col, i);
-            const uint64_t lo = 1ull << (r % (s.a ? s.a : 1));
+            const uint64_t oct = s.a ? (s.a < 63 ? s.a : 63) : 1;  // octaves: a shift of 64 or more is undefined
+            const uint64_t lo = 1ull << (r % oct);
             return (lo + (tsq_splitmix64(r) & (lo - 1)) - 1) % s.m;
         }
     }

@@ -790,6 +790,7 @@ struct tsq_join {
     DevBuf da_bitimg;                 // ... the bit form of byte cells (b <= 28)
     int da_rows_state = 0;            // materialising packed route: build rows sorted by word (CSR over the images)
     DevBuf da_coarse, da_pstart, da_brows;
+    DevBuf da_coarse_c, da_pstart_c;  // the travelling-columns route keeps its OWN coarse counts / partition starts: AUTO may prepare both routes in one join, and a give-up of one must not free what the other reads
     DevBuf ridx, rovfidx, rmiss;      // ... probe rows travelling with the entries | of the overflow list | that cannot match (outer joins)
     int da_cols_state = 0;            // travelling-columns route: the build columns sorted by word (+ NOT-NULL bytes)
     DevBuf da_bsorted[TSQ_DA_MAXCOLS], da_bsorted_nn[TSQ_DA_MAXCOLS];
@@ -1291,7 +1292,7 @@ tsq_status da_compose_build(tsq_join* j, bool* ok, uint32_t max_total_bits = TSQ
 // range over all ranks, every rank assembles the images of ITS rows over that range, and the images are summed across the ranks
 // (one all-reduce, once per build side): afterwards every rank holds the images of the WHOLE build side and probes its own probe
 // rows locally.  Every rank takes the same decisions: they depend on the configuration and on all-reduced values only.
-tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr) {
+tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status = TSQ_OK) {
     if (j->da_state) return TSQ_OK;
     j->da_state = -1;
     tsq_ctx* ctx = j->ctx;
@@ -1323,14 +1324,27 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr) {
     ctx->pinned[49] = 0;
     ctx->pinned[50] = 0;
     ctx->pinned[51] = 0;  // [51]: the two flag words of the images kernel
-    bool local_fail = sc && nb >= 0xffffffffLL;  // (a shared build: a rank that cannot take part still joins every collective)
+    // a shared build is a COLLECTIVE: a rank that cannot take part (too many rows, a failure before this call — pre_status —, a HIP
+    // error below) still joins every all-reduce, and every rank returns an error once the flags have been agreed on (a rank
+    // that returned early left the others waiting in RCCL)
+    bool local_fail = sc && (nb >= 0xffffffffLL || pre_status != TSQ_OK);
+    hipError_t e_mm = hipSuccess;
     if (nb > 0 && !local_fail) {
-        TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 32, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nb, 256)), dim3(256), 0, ctx->stream, ma);
-        TSQ_HIP(h, hipGetLastError());
-        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream));
-        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        e_mm = hipMemcpyAsync(ctx->dscratch + 48, ctx->pinned + 48, 32, hipMemcpyHostToDevice, ctx->stream);
+        if (e_mm == hipSuccess) {
+            hipLaunchKernelGGL(k_da_minmax, dim3(tsq_grid_for(ctx, nb, 256)), dim3(256), 0, ctx->stream, ma);
+            e_mm = hipGetLastError();
+        }
+        if (e_mm == hipSuccess) e_mm = hipMemcpyAsync(ctx->pinned + 48, ctx->dscratch + 48, 24, hipMemcpyDeviceToHost, ctx->stream);
+        if (e_mm == hipSuccess) e_mm = hipStreamSynchronize(ctx->stream);
         j->st.kernel_launches++;
+        if (e_mm != hipSuccess) {
+            if (!sc) return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key range: ") + hipGetErrorString(e_mm));
+            local_fail = true;
+            ctx->pinned[48] = ~0ULL;  // (an empty range: this rank adds nothing to the agreed one)
+            ctx->pinned[49] = 0;
+            ctx->pinned[50] = 0;
+        }
     }
     uint64_t lo_img = ctx->pinned[48], hi_img = ctx->pinned[49], usable = ctx->pinned[50];
     const uint64_t usable_local = usable;
@@ -1440,8 +1454,12 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr) {
         if (s == TSQ_OK && e == hipSuccess && cs != TSQ_OK) s = cs;
         if (fl[0] || fl[1] || fl[2]) {
             j->da_img.release();
+            if (pre_status != TSQ_OK) return pre_status;
             if (s != TSQ_OK) return s;
+            if (e_mm != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key range: ") + hipGetErrorString(e_mm));
             if (e != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("packed-key images: ") + hipGetErrorString(e));
+            // a PEER failed: this rank is healthy, but the plan (shared images or the exchange) must stop on every rank together
+            if (fl[0]) return tsq_fail(h, TSQ_ERR_INVALID, "shared build side: another rank failed before its images were ready");
             return TSQ_OK;
         }
         // ---- the images of all ranks, summed: byte cells as bytes, bit cells as 32-bit words (tsq_dapack.h: what the sum can do wrong
@@ -2056,7 +2074,7 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
     };
     auto give_up = [&](tsq_status st) {
         release_all();
-        for (DevBuf* b : {&j->da_coarse, &j->da_pstart}) b->release();
+        for (DevBuf* b : {&j->da_coarse_c, &j->da_pstart_c}) b->release();
         for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
             j->da_bsorted[c].release();
             j->da_bsorted_nn[c].release();
@@ -2071,8 +2089,8 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
     for (int v = 0; v < ncols && s == TSQ_OK; v++) s = pay[v].reserve(ctx, h, slots * 8 + 256);
     if (s == TSQ_OK && any_nulls) s = nnm.reserve(ctx, h, slots + 256);
     if (s == TSQ_OK && !j->da_unique) s = bdup.reserve(ctx, h, slots + 256);
-    if (s == TSQ_OK) s = j->da_pstart.reserve(ctx, h, ((size_t)g.P + 1) * 4 + 64);
-    if (s == TSQ_OK) s = j->da_coarse.reserve(ctx, h, (((size_t)1 << j->da_dm.b) >> 5) * 4 + 64);
+    if (s == TSQ_OK) s = j->da_pstart_c.reserve(ctx, h, ((size_t)g.P + 1) * 4 + 64);
+    if (s == TSQ_OK) s = j->da_coarse_c.reserve(ctx, h, (((size_t)1 << j->da_dm.b) >> 5) * 4 + 64);
     if (s != TSQ_OK) return give_up(s);
     DaColStore cs;
     memset(&cs, 0, sizeof cs);
@@ -2111,11 +2129,11 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_da_part_starts, dim3(1), dim3(1024), 0, ctx->stream, st, j->da_pstart.as<uint32_t>());
+        hipLaunchKernelGGL(k_da_part_starts, dim3(1), dim3(1024), 0, ctx->stream, st, j->da_pstart_c.as<uint32_t>());
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 52, st.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 56, j->da_pstart.as<uint32_t>() + g.P, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 56, j->da_pstart_c.as<uint32_t>() + g.P, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     j->st.kernel_launches += 2;
     auto finish_events = [&]() {
@@ -2139,8 +2157,8 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
     memset(&sa, 0, sizeof sa);
     sa.cs = cs;
     sa.img = j->da_img.as<uint8_t>();
-    sa.coarse = j->da_coarse.as<uint32_t>();
-    sa.pstart = j->da_pstart.as<uint32_t>();
+    sa.coarse = j->da_coarse_c.as<uint32_t>();
+    sa.pstart = j->da_pstart_c.as<uint32_t>();
     sa.bdup = j->da_unique ? nullptr : bdup.as<uint8_t>();
     sa.n_cols = ncols;
     for (int v = 0; v < ncols && s == TSQ_OK; v++) {
@@ -2170,7 +2188,7 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
         memset(&ca, 0, sizeof ca);
         ca.st = st;
         ca.img = sa.img;
-        ca.coarse = j->da_coarse.as<uint32_t>();
+        ca.coarse = j->da_coarse_c.as<uint32_t>();
         e = hipFuncSetAttribute((const void*)k_da_coarse<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cells);
         if (e == hipSuccess) {
             hipLaunchKernelGGL((k_da_coarse<1024>), dim3(std::min<uint32_t>(g.P, (uint32_t)ctx->num_cus * 2)), dim3(1024), cells, ctx->stream, ca);
@@ -2557,8 +2575,8 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
         memset(&pe, 0, sizeof pe);
         pe.st = st;
         pe.img = pa.img;
-        pe.coarse = j->da_coarse.as<uint32_t>();
-        pe.pstart = j->da_pstart.as<uint32_t>();
+        pe.coarse = j->da_coarse_c.as<uint32_t>();
+        pe.pstart = j->da_pstart_c.as<uint32_t>();
         pe.brows = nullptr;  // the pairs name PLACES of the sorted build columns (pstart + rank + k), not build rows
         pe.pairs = j->pairs.as<unsigned long long>();
         pe.ovf_cursor = (unsigned long long*)(ctx->dscratch + 53);  // starts at 0 (cleared above)
@@ -2582,8 +2600,8 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     }
     ea.cs = cs;
     ea.img = pa.img;
-    ea.coarse = j->da_coarse.as<uint32_t>();
-    ea.pstart = j->da_pstart.as<uint32_t>();
+    ea.coarse = j->da_coarse_c.as<uint32_t>();
+    ea.pstart = j->da_pstart_c.as<uint32_t>();
     ea.pbase = pa.pcount;
     ea.row0 = (unsigned long long)exc_rows;
     ea.dm = j->da_dm;
@@ -3681,24 +3699,26 @@ TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
 TSQ_API tsq_status tsq_join_build_finish_shared(tsq_join* j, tsq_comm* c, int32_t* shared_out) {
     tsq_ctx_lock _api_lock(tsq_ctx_of(j, TSQ_MAGIC_JOIN));
     if (!j || j->hdr.magic != TSQ_MAGIC_JOIN) return TSQ_ERR_INVALID;
-    TSQ_TRY(check_cancel(j));
+    const tsq_status cancelled = check_cancel(j);  // (rank-local: carried into the collective below)
     tsq_handle_hdr* h = &j->hdr;
     if (!shared_out) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_join_build_finish_shared: NULL argument");
     *shared_out = 0;
     if (!tsq_comm_usable(c, j->ctx)) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_join_build_finish_shared: the communicator does not belong to the join's context");
     if (j->build_done) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_join_build_finish_shared after build_finish");
-    TSQ_HIP(h, hipSetDevice(j->ctx->device));
-    TSQ_TRY(build_flush(j));
+    // rank-local failures from here on are carried INTO the collective (da_prepare's pre_status) instead of returned before it
+    tsq_status pre = cancelled;
+    if (pre == TSQ_OK && hipSetDevice(j->ctx->device) != hipSuccess) pre = tsq_fail(h, TSQ_ERR_HIP, "tsq_join_build_finish_shared: hipSetDevice failed");
+    if (pre == TSQ_OK) pre = build_flush(j);
     // what the images can answer (the same on every rank: it is the plan): COUNT(*) of an inner equi-join on one integer column
-    if (j->general || j->multi || j->never_match || j->ordered || j->radix_mode == TSQ_RADIX_OFF) return TSQ_OK;
+    if (j->general || j->multi || j->never_match || j->ordered || j->radix_mode == TSQ_RADIX_OFF) return pre;
     const bool was_count_only = j->count_only;
     j->count_only = true;
     j->da_state = 0;
-    const tsq_status s = da_prepare(j, c);
+    const tsq_status s = da_prepare(j, c, pre);
     if (s != TSQ_OK || j->da_state != 1) {  // not packable (or this rank failed): the handle still holds its rows, nothing else
         j->count_only = was_count_only;
         j->da_state = 0;
-        return s;
+        return s != TSQ_OK ? s : pre;
     }
     j->shared = true;
     j->st.build_rows = j->bcols[0].rows;
@@ -4073,7 +4093,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->da_img.release();
     j->da_ckey.release();
     j->rckey.release();
-    for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
+    for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_coarse_c, &j->da_pstart_c, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
         j->da_bsorted[c].release();
         j->da_bsorted_nn[c].release();

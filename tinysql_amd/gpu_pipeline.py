@@ -371,6 +371,8 @@ class GpuHashJoinExec(GpuExecutor):
                 chk = self.build.Next()
                 if chk.NumRows() == 0:
                     break
+                if chk.sel:  # tsq_join_build_push has no `selected`: flags on the build side would be ignored silently
+                    raise ValueError("GpuHashJoinExec: selection flags on the build side: use GpuSelectionExec(compact=True)")
                 _lib.check(self.lib.tsq_join_build_push(self.h, chk.cols(), len(chk.columns), chk.NumRows()), self.h)
             _lib.check(self.lib.tsq_join_build_finish(self.h), self.h)
             self.prepared = True
@@ -399,7 +401,11 @@ class GpuHashJoinExec(GpuExecutor):
             if chk.NumRows() == 0:
                 _lib.check(self.lib.tsq_join_probe_finish(self.h), self.h)
                 continue
-            # a probe-side chunk may carry selection flags (GpuSelectionExec(compact=False)): the join takes them as `selected`
+            # a probe-side chunk may carry selection flags (GpuSelectionExec(compact=False)): the join takes them as `selected`.
+            # Under an OUTER join a row with selected == 0 is emitted NULL-padded (onMissMatch, executor/join.go:344-345), not dropped:
+            # flags are a WHERE filter only below an inner join — anything else must compact first
+            if chk.sel and self.cfg.join_type != abi.JOIN_INNER:
+                raise ValueError("GpuHashJoinExec: selection flags on the probe side of an outer join: use GpuSelectionExec(compact=True)")
             _lib.check(self.lib.tsq_join_probe_push(self.h, chk.cols(), len(chk.columns), chk.NumRows(), C.c_void_p(chk.sel) if chk.sel else None), self.h)
 
     def Close(self):
