@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSQ_ABI_VERSION 5
+#define TSQ_ABI_VERSION 6
 
 /* ---------------------------------------------------------------- status codes */
 typedef int32_t tsq_status;
@@ -136,6 +136,7 @@ enum {
     TSQ_KNOB_AGG_DENSE = 24,         /* 0: the one-key packed aggregate appends partial groups after every batch instead of folding its LDS tables into the dense state; v > 1 (tests): the state is emptied into the table before more than v rows went into it (default 2^31) */
     TSQ_KNOB_AGG_NARROW_CELLS = 25,  /* 0: the argument column of the packed aggregate always travels as 8-byte cells */
     TSQ_KNOB_DAAGG_PART2 = 26,       /* partition kernel of the packed aggregate with a dense state: 0 = 1024 threads, one workgroup per CU; 1 = two 512-thread workgroups per CU for narrow argument cells (default); 2 = for 8-byte cells too */
+    TSQ_KNOB_DAAGG_HOT = 27,         /* 0: the packed aggregate does not sample the batch for hot keys (their rows then travel through the partitioned store and its overflow store) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -495,6 +496,15 @@ tsq_status tsq_agg_finish(tsq_agg* a);
 #define TSQ_AGGFAST_OFF     0
 #define TSQ_AGGFAST_FORCE   1
 tsq_status tsq_agg_set_fast(tsq_agg* a, int32_t mode);
+/* StreamAggExec (BASELINE.json north star; the reference has only the plan name, planner/core/cbo_test.go:200-212 "StreamAgg"): on != 0
+ * before the first row tells the operator that its child delivers rows ORDERED by the group-by items — equal keys are adjacent (NULL
+ * equals NULL, +0.0 equals -0.0: the group key of util/codec/codec.go:713-746).  A group is closed by the first row with another
+ * key; tsq_agg_pull then returns the groups IN INPUT ORDER, and FIRST_ROW is the first row of its group.  Aggregate functions,
+ * modes, NULL / overflow rules, the empty-input default row and the output schema are HashAggExec's (executor/aggregate.go:307-350,
+ * 559-588).  No hash table is probed: a row's group = the groups closed so far + the group heads up to the row (csrc/tsq_streamagg.h);
+ * a key that comes back after another key opens a NEW group (the child's order is the caller's contract, as in the planner's
+ * property enforcement).  Sort an unordered child with tsq_sort_* first (tinysql_amd/executor.py StreamAggExec does). */
+tsq_status tsq_agg_set_stream(tsq_agg* a, int32_t on);
 /* After tsq_agg_finish: the number of result rows.  Before: the groups the operator's table holds so far — a LOWER bound (the packed
  * route keeps the partial state of a one-key GROUP BY outside the table until finish, tsq_stats.dense_flushes). */
 tsq_status tsq_agg_num_groups(tsq_agg* a, int64_t* out);
@@ -532,8 +542,12 @@ tsq_status tsq_chunk_compact(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, 
  * Errors are the reference's, decided by the FIRST offending value in stream order; *nrows_out then holds the complete
  * rows before it (already in out_cols) and *bytes_consumed is 0: TSQ_ERR_INVALID with tsq_last_error =
  * "invalid encoded key" (a row ends early, codec.go:625) | "insufficient bytes to decode value" (number.go:46,122) |
- * "value larger than 64 bits" (number.go:120) | "invalid encoded key flag" (codec.go:683); a bytes / compact-bytes
- * datum (var-len column) -> TSQ_ERR_UNSUPPORTED: decode that response with the Go decoder. */
+ * "value larger than 64 bits" (number.go:120) | "invalid encoded key flag" (codec.go:683).
+ * col_types may contain TSQ_BYTES (ABI 6): a compact-bytes (flag 2, bytes.go:141-160) or memcomparable (flag 1, bytes.go:35-118) datum
+ * becomes a var-len cell — out_cols of such a column need offsets[cap_rows + 1] and a data buffer of n_bytes bytes, as for
+ * tsq_rows_decode_chunks, whose errors apply ("datum kind does not match the column type", DecodeBytes' messages).  A bytes datum has
+ * no bounded length, so the row boundaries of such a stream come from one sequential walk over flags and lengths on the host (a
+ * stream in HBM is copied back for it); the values are decoded on the GPU, 64 rows per piece (csrc/tsq_decode.hip). */
 tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, uint32_t data_flags, int32_t n_cols,
                            const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out,
                            int64_t* bytes_consumed);

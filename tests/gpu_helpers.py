@@ -102,13 +102,15 @@ def run_join(ctx, cfg, build, probe, chunk_rows=1024, selected=None, pull_rows=1
         lib.tsq_join_destroy(h)
 
 
-def run_agg(ctx, cfg, chunk, out_types, chunk_rows=1024, pull_rows=1024, fast=None, stats_out=None):
+def run_agg(ctx, cfg, chunk, out_types, chunk_rows=1024, pull_rows=1024, fast=None, stats_out=None, stream=False):
     lib = ctx.lib
     h = C.c_void_p()
     _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
     try:
         if fast is not None:
             _lib.check(lib.tsq_agg_set_fast(h, fast), h)
+        if stream:  # StreamAggExec: the rows of `chunk` are ordered by the group keys
+            _lib.check(lib.tsq_agg_set_stream(h, 1), h)
         push_chunked(lib.tsq_agg_push, h, chunk, chunk_rows)
         _lib.check(lib.tsq_agg_finish(h), h)
         if stats_out is not None:

@@ -641,3 +641,16 @@ extern "C" void sim_wire_move(int32_t mode, const uint8_t* src, uint8_t* dst, in
     for (int64_t b = 0; b < blocks; b++)
         for (int t = 0; t < 256; t++) tsq_wire_move_lane(mode, src, dst, n, imm, b, t);
 }
+
+// ---- tsq_rows_decode with a var-len column (round 5): the host walk that finds the row boundaries of a stream with bytes datums
+// (tsq_decode_dp.h: tsq_dec_walk_rows) — the product's own function, called here without a GPU
+extern "C" int64_t sim_dec_walk_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, int64_t cap_rows, int64_t per, int64_t* offs_out, int64_t offs_cap,
+                                     int64_t* n_offs_out, int64_t* end_out, int32_t* damaged_out) {
+    std::vector<int64_t> offs;
+    bool damaged = false;
+    const int64_t rows = tsq_dec_walk_rows(data, n_bytes, n_cols, cap_rows, per, offs, end_out, &damaged);
+    *damaged_out = damaged ? 1 : 0;
+    *n_offs_out = (int64_t)offs.size();
+    for (size_t i = 0; i < offs.size() && (int64_t)i < offs_cap; i++) offs_out[i] = offs[i];
+    return rows;
+}

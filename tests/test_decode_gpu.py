@@ -151,7 +151,9 @@ def test_errors_are_the_reference_errors_in_stream_order(ctx, orc):
         st, _, _ = orc.decode_rows(raw, types, 64)
         gs, _, msg = _status_of(ctx, raw, types)
         assert st in MSG and gs == abi.ERR_INVALID and msg == MSG[st], (bytes(raw), st, msg)
-    assert _status_of(ctx, b"\x02\x02ab", [abi.I64])[0] == abi.ERR_UNSUPPORTED          # compact bytes: a var-len column
+    # a bytes datum where the schema says number: the chunk decoder's message (round 5: tsq_rows_decode takes var-len columns itself)
+    gs, _, msg = _status_of(ctx, b"\x02\x02ab", [abi.I64])
+    assert gs == abi.ERR_INVALID and msg == "datum kind does not match the column type"
     # the FIRST offending value decides: a bad flag in row 5000 wins over a cut varint at the very end, and the rows before
     # it are delivered (DecodeOne has appended them by then)
     rng = np.random.default_rng(5)
@@ -227,7 +229,74 @@ def test_decode_argument_contract(ctx, orc):
     assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, tp, out, 8, None, C.byref(used)) == abi.ERR_INVALID
     assert lib.tsq_rows_decode(ctx.h, p, -1, 0, 1, tp, out, 8, C.byref(n), C.byref(used)) == abi.ERR_INVALID
     assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 17, tp, out, 8, C.byref(n), C.byref(used)) == abi.ERR_UNSUPPORTED
-    assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, (C.c_int32 * 1)(4), out, 8, C.byref(n), C.byref(used)) == abi.ERR_UNSUPPORTED
+    assert lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, (C.c_int32 * 1)(4), out, 8, C.byref(n), C.byref(used)) == abi.ERR_INVALID  # a var-len column without offsets
     # and the normal call still works on the same context afterwards
     _lib.check(lib.tsq_rows_decode(ctx.h, p, raw.size, 0, 1, tp, out, 8, C.byref(n), C.byref(used)), ctx.h)
     assert n.value == 3 and used.value == raw.size and bufs[0][0][:3].tolist() == [5, 6, 7]
+
+
+# ---------------------------------------------------------------- round 5: var-len columns in the single-stream decoder (codec.go:670-690)
+def _decode_varlen(ctx, raw, types, cap_rows, device=False):
+    from tinysql_amd.chunk import chunk_from_buffers, out_buffers
+    nbytes = len(raw)
+    raw = np.ascontiguousarray(np.frombuffer(bytes(raw), np.uint8)) if nbytes else np.zeros(1, np.uint8)
+    keep = []
+    out, bufs = out_buffers(types, max(cap_rows, 1), keep, var_bytes=[max(nbytes, 1) if t == abi.BYTES else 0 for t in types])
+    tp = (C.c_int32 * len(types))(*types)
+    n, used = C.c_int64(0), C.c_int64(0)
+    ptr, flags = raw.ctypes.data_as(C.c_void_p), 0
+    dev = None
+    if device:
+        dev = ctx.alloc(raw.size + 64)
+        ctx.h2d(dev, raw)
+        ptr, flags = C.c_void_p(dev), abi.COL_DEVICE
+    try:
+        st = ctx.lib.tsq_rows_decode(ctx.h, ptr, nbytes, flags, len(types), tp, out, cap_rows, C.byref(n), C.byref(used))
+    finally:
+        if dev:
+            ctx.free(dev)
+    return st, chunk_from_buffers(types, bufs, n.value), used.value
+
+
+def _varlen_table(rng, n):
+    from tinysql_amd.chunk import StrColumn
+    words = [None if rng.random() < 0.15 else bytes(rng.integers(0, 256, int(rng.integers(0, 60)), dtype=np.uint8)) for _ in range(n)]
+    notes = [None if rng.random() < 0.1 else (b"" if rng.random() < 0.2 else b"n%d" % i) for i in range(n)]
+    return Chunk([Column(abi.I64, rng.integers(-(1 << 40), 1 << 40, n), rng.random(n) > 0.2), StrColumn(words), Column(abi.F64, rng.standard_normal(n), rng.random(n) > 0.2),
+                  StrColumn(notes), Column(abi.U64, rng.integers(0, 1 << 62, n).astype(np.uint64))])
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 5000])
+def test_single_stream_with_bytes_datums_equals_the_oracle(ctx, orc, n):
+    rng = np.random.default_rng(600 + n)
+    t = _varlen_table(rng, n)
+    raw = bytes(orc.encode_rows(t))  # ONE byte string, no chunk boundaries: compact-bytes datums between the numbers
+    for device in (False, True):
+        st, got, used = _decode_varlen(ctx, raw, t.types(), n + 10, device)
+        assert st == abi.OK and used == len(raw) and got.rows() == t.rows()
+    # the chunk-capacity contract of select_result.go:153: cap_rows rows, the remainder stays with the caller
+    cap = max(1, n // 3)
+    st, got, used = _decode_varlen(ctx, raw, t.types(), cap)
+    assert st == abi.OK and got.rows() == t.slice(0, cap).rows() and used == len(bytes(orc.encode_rows(t.slice(0, cap))))
+    st, rest, used2 = _decode_varlen(ctx, raw[used:], t.types(), n)
+    assert st == abi.OK and rest.rows() == t.slice(cap, n).rows() and used + used2 == len(raw)
+
+
+def test_single_stream_with_bytes_datums_reports_the_first_error_in_stream_order(ctx, orc):
+    rng = np.random.default_rng(601)
+    t = _varlen_table(rng, 300)
+    raw = bytearray(bytes(orc.encode_rows(t)))
+    at = len(bytes(orc.encode_rows(t.slice(0, 200))))
+    raw[at] = 0x7E  # the first flag of row 200: no such flag (codec.go:683)
+    st, got, used = _decode_varlen(ctx, bytes(raw), t.types(), 1000)
+    assert st == abi.ERR_INVALID and _lib.last_error(ctx.h) == "invalid encoded key flag" and used == 0 and got.rows() == t.slice(0, 200).rows()
+    # a string whose declared length runs past the end of the stream (bytes.go:156-158)
+    cut = bytes(orc.encode_rows(t))[:at + 3]
+    st, got, used = _decode_varlen(ctx, cut, t.types(), 1000)
+    assert st == abi.ERR_INVALID and got.NumRows() == 200 and _lib.last_error(ctx.h) in ("insufficient bytes to decode value", "invalid encoded key")
+    # a memcomparable bytes datum (flag 1, the EncodeKey form) decodes too: bytes.go:35-118
+    from tinysql_amd.chunk import StrColumn
+    key = Chunk([StrColumn([b"abcdefgh-long-key", b"", None, b"12345678"]), Column(abi.I64, np.array([1, 2, 3, 4]))])
+    rawk = bytes(orc.encode_rows(key, comparable=True))
+    st, got, used = _decode_varlen(ctx, rawk, key.types(), 10)
+    assert st == abi.OK and got.rows() == key.rows() and used == len(rawk)

@@ -207,3 +207,50 @@ def test_comparable_responses_walk_like_the_oracle(sim, n, per, phase):
     code, rows, got = run_sim(sim, data, offs, t.types(), phase)
     assert st == 0 and code == 0 and rows == n
     assert got.rows() == want.rows() == t.rows()
+
+
+# ---------------------------------------------------------------- round 5: tsq_rows_decode with a var-len column — the host walk that finds the row boundaries
+def _walk(sim, data, n_cols, cap_rows, per):
+    raw = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    offs = np.zeros(len(data) + 4, np.int64)
+    n_offs, end, dmg = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+    sim.sim_dec_walk_rows.restype = C.c_int64
+    sim.sim_dec_walk_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    rows = sim.sim_dec_walk_rows(raw.ctypes.data, len(data), n_cols, cap_rows, per, offs.ctypes.data, offs.size, C.byref(n_offs), C.byref(end), C.byref(dmg))
+    return rows, offs[:n_offs.value].copy(), end.value, bool(dmg.value)
+
+
+@pytest.mark.parametrize("n,per", [(1, 64), (64, 64), (65, 64), (1000, 64), (333, 7)])
+def test_row_walk_finds_the_boundaries_the_encoder_made(sim, n, per):
+    rng = np.random.default_rng(900 + n + per)
+    t = table(rng, n, long_strings=(n == 333))
+    data, offs = response(t, per)  # the oracle's encoder, `per` rows per chunk: ITS boundaries are the truth
+    rows, got, end, dmg = _walk(sim, data, len(t.types()), 1 << 40, per)
+    assert rows == n and not dmg and end == len(data) and (got == offs).all()
+    # cap_rows: the walk stops after that many rows, the consumed prefix ends there (select_result.go:153 keeps the remainder)
+    cap = max(1, n // 3)
+    rows, got, end, dmg = _walk(sim, data, len(t.types()), cap, per)
+    want_end = len(bytes(orc.encode_rows(t.slice(0, cap))))
+    assert rows == cap and not dmg and end == want_end and got[-1] == want_end and got[0] == 0
+    # ... and the pieces decode (through the kernels' own walk, on the CPU) to the first `cap` rows
+    code, nrows, dec = run_sim(sim, data[:end], got, t.types())
+    assert code == 0 and nrows == cap and dec.rows() == t.slice(0, cap).rows()
+
+
+def test_row_walk_hands_a_damaged_remainder_to_the_kernels(sim):
+    rng = np.random.default_rng(77)
+    t = table(rng, 200)
+    data, offs = response(t, 64)
+    bad = bytearray(data)
+    at = int(offs[2]) + 0  # the first flag byte of row 128
+    bad[at] = 0x7E         # not a flag DecodeOne knows (codec.go:683)
+    rows, got, end, dmg = _walk(sim, bytes(bad), len(t.types()), 1 << 40, 64)
+    assert dmg and rows == 128 and end == len(bad) and got[-1] == len(bad) and got[-2] == int(offs[2])
+    code, nrows, dec = run_sim(sim, bytes(bad), got, t.types())
+    assert STATUS[code] == "bad flag" and nrows == 128 and dec.rows() == t.slice(0, 128).rows()
+    # a stream that ends inside a row: the rows before it, then "row cut" / "insufficient" from the kernels' walk
+    cut = data[:int(offs[1]) + 5]
+    rows, got, end, dmg = _walk(sim, cut, len(t.types()), 1 << 40, 64)
+    assert dmg and rows >= 64 and got[-1] == len(cut)
+    # an empty stream
+    assert _walk(sim, b"", 3, 10, 64)[:1] == (0,)

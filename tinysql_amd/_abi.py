@@ -5,7 +5,7 @@ Shared by the product binding (tinysql_amd._lib) and by the test-only oracle bin
 """
 import ctypes as C
 
-TSQ_ABI_VERSION = 5
+TSQ_ABI_VERSION = 6
 RADIX_AUTO, RADIX_OFF, RADIX_FORCE = -1, 0, 1
 AGGFAST_AUTO, AGGFAST_OFF, AGGFAST_FORCE = -1, 0, 1
 JIT_AUTO, JIT_OFF, JIT_FORCE = -1, 0, 1
@@ -163,7 +163,7 @@ KNOB_DEFAULT = -(1 << 63)
 (KNOB_PACKED_KEYS, KNOB_DA_MIN_BUILD_ROWS, KNOB_DA_PBITS, KNOB_PACKED_EMIT_PAIRS, KNOB_RADIX_KERNEL_L2, KNOB_LDS_NF_MAX, KNOB_RADIX_PB_MAX,
  KNOB_TABLE_LF_PERMILLE, KNOB_LDS_PROF, KNOB_DA_TRACE, KNOB_BUILD_IMAGES_CAS, KNOB_DAAGG_SIG, KNOB_DAAGG_LOG2C, KNOB_AGG_HEAP_GC_BYTES,
  KNOB_AGG_TAG_BITS, KNOB_AGG_BATCH_ROWS, KNOB_ROWCODEC_LDS_KB, KNOB_ROWCODEC_FAST_LAYOUT, KNOB_ROWCODEC_PIPELINE, KNOB_DA_PARTITION,
- KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE, KNOB_DA_PAIRS_BELOW_PERMILLE, KNOB_AGG_WIDE_KEYS, KNOB_AGG_DENSE, KNOB_AGG_NARROW_CELLS, KNOB_DAAGG_PART2) = range(27)
+ KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE, KNOB_DA_PAIRS_BELOW_PERMILLE, KNOB_AGG_WIDE_KEYS, KNOB_AGG_DENSE, KNOB_AGG_NARROW_CELLS, KNOB_DAAGG_PART2, KNOB_DAAGG_HOT) = range(28)
 
 
 # every symbol include/tsq.h declares: name -> (restype, argtypes)
@@ -218,6 +218,7 @@ SIGNATURES = {
     "tsq_agg_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),
     "tsq_agg_finish": (C.c_int32, [P]),
     "tsq_agg_set_fast": (C.c_int32, [P, C.c_int32]),
+    "tsq_agg_set_stream": (C.c_int32, [P, C.c_int32]),
     "tsq_agg_num_groups": (C.c_int32, [P, C.POINTER(C.c_int64)]),
     "tsq_agg_pull": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tsq_agg_cancel": (C.c_int32, [P]),

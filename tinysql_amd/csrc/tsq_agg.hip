@@ -407,6 +407,8 @@ __global__ void __launch_bounds__(256) k_agg_update(AggArgs a) {
 }
 
 
+#include "tsq_streamagg.h"
+
 // K7b — merge of LDS partial groups into the HBM group table.  Replaces HashAggFinalWorker.consumeIntermData
 // (executor/aggregate.go:424-427, STUB; intended per courses/proj5-part3) + AggFunc.MergePartialResult
 // (aggfuncs/func_count.go:51-55, func_sum.go:96-111, func_avg.go:86-113, func_max_min.go:60-79): one
@@ -660,6 +662,8 @@ struct FinalArgs {
     void* out_data[2 * TSQ_MAX_AGGS];
     uint8_t* out_notnull[2 * TSQ_MAX_AGGS];
     unsigned long long* counters;  // [3] = output cursor, [4] = overflow flag (BIGINT)
+    uint64_t ordered_groups;       // StreamAggExec: slots [0, ordered_groups) are the groups in input order, group s -> output row s
+    int32_t ordered;
 };
 __device__ __forceinline__ bool sum128_fits(unsigned long long lo, unsigned long long hi) {
     return hi == ((lo >> 63) ? ~0ull : 0ull);  // hi must be the sign extension of lo
@@ -670,7 +674,7 @@ __device__ __forceinline__ bool sum128_fits(unsigned long long lo, unsigned long
 #define TSQ_FINAL_CHUNK 4096
 __global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
     __shared__ unsigned long long s_cnt, s_cur;
-    const uint64_t nslots = a.t.cap + 2;
+    const uint64_t nslots = a.ordered ? a.ordered_groups : a.t.cap + 2;
     const uint64_t nchunks = (nslots + TSQ_FINAL_CHUNK - 1) / TSQ_FINAL_CHUNK;
     const int lane = threadIdx.x & 63;
     for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
@@ -694,7 +698,7 @@ __global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
         if (lane == 0) base = atomicAdd(&s_cur, (unsigned long long)__popcll(m));
         base = __shfl(base, 0, 64);
         if (!occ) continue;
-        const uint64_t pos = base + __popcll(m & ((1ull << lane) - 1));
+        const uint64_t pos = a.ordered ? s : base + __popcll(m & ((1ull << lane) - 1));
         int oc = 0;
         for (int i = 0; i < a.plan.n_aggs; i++) {
             const tsq_agg_func f = a.plan.f[i];
@@ -1025,6 +1029,11 @@ struct tsq_agg {
     DevBuf wide_d, wide_okrows, wide_excrows;
     int32_t wide_child_out[TSQ_MAX_AGGS * 2];  // own output column -> the child's output column, or -1 - k: decoded from d (key column k)
     int64_t wide_batches = 0, wide_exception_rows = 0;
+    // StreamAggExec (tsq_streamagg.h): the input arrives ordered by the group keys, the table is an ARRAY of groups in input order
+    bool stream = false;
+    DevBuf sa_cnt;             // heads per 2048-row chunk of the current batch
+    DevBuf hotkeys;            // packed aggregate: the sampled hot keys of the current batch (tsq_daagg.h DaAggHot)
+    int64_t stream_batches = 0;
 };
 
 namespace {
@@ -1038,7 +1047,7 @@ void fill_agg_table(const tsq_agg* a, const AggTableBufs& b, AggTable& t) {
     memset(&t, 0, sizeof t);
     t.tag = b.tag.as<unsigned long long>();
     for (int k = 0; k < a->plan.n_keys; k++) t.gkey[k] = b.gkey[k].as<unsigned long long>();
-    t.gknull = a->multi ? b.gknull.as<uint8_t>() : nullptr;
+    t.gknull = (a->multi || a->stream) ? b.gknull.as<uint8_t>() : nullptr;
     for (int i = 0; i < a->plan.n_aggs; i++) {
         t.st[i].acc = b.acc[i].as<unsigned long long>();
         t.st[i].aux = b.aux[i].as<unsigned long long>();
@@ -1056,7 +1065,7 @@ tsq_status alloc_table(tsq_agg* a, AggTableBufs& b, uint64_t cap) {
     TSQ_TRY(b.tag.reserve(ctx, h, n * 8));
     TSQ_HIP(h, hipMemsetAsync(b.tag.p, 0x80, n * 8, ctx->stream));
     for (int k = 0; k < a->plan.n_keys; k++) TSQ_TRY(b.gkey[k].reserve(ctx, h, n * 8));
-    if (a->multi) {
+    if (a->multi || a->stream) {
         TSQ_TRY(b.gknull.reserve(ctx, h, n));
         TSQ_HIP(h, hipMemsetAsync(b.gknull.p, 0, n, ctx->stream));
     }
@@ -1618,15 +1627,47 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         src.exc_count = la.exc_count;
         DaAggKeys ks = a->da_keys;
         if (!mk) ks.n = 1;
+        // hot keys of the batch (tsq_daagg.h, round 5): sampled, then aggregated inside the partition kernel — with a dense state
+        // (where their partial groups go) and one integer key column; knob DAAGG_HOT = 0 switches it off (A/B measurements)
+        DaAggHot hot;
+        memset(&hot, 0, sizeof hot);
+        if (dense && !mk && part2 && pl.W <= TSQ_DAAGG_HOT_MAXW && tsq_knob(ctx, TSQ_KNOB_DAAGG_HOT, 1) != 0 && (in.type[pl.key_col] == TSQ_I64 || in.type[pl.key_col] == TSQ_U64)) {
+            TSQ_TRY(a->hotkeys.reserve(ctx, h, (TSQ_DAAGG_HOT_MAX + 16 + 2 * TSQ_DAAGG_HOT_TABLE) * 4));
+            DaAggHotSampleArgs ha;
+            memset(&ha, 0, sizeof ha);
+            ha.kdata = (const uint64_t*)in.data[pl.key_col];
+            ha.knulls = in.nulls[pl.key_col];
+            ha.nrows = nrows;
+            ha.dm = a->da_dm;
+            ha.keys = a->hotkeys.as<uint32_t>();
+            ha.n = ha.keys + TSQ_DAAGG_HOT_MAX;
+            ha.table = ha.keys + TSQ_DAAGG_HOT_MAX + 16;
+            TSQ_HIP(h, hipMemsetAsync(ha.table, 0xff, (size_t)TSQ_DAAGG_HOT_TABLE * 4, ctx->stream));  // words: TSQ_DA_NONE
+            TSQ_HIP(h, hipMemsetAsync(ha.table + TSQ_DAAGG_HOT_TABLE, 0, (size_t)TSQ_DAAGG_HOT_TABLE * 4, ctx->stream));
+            hipLaunchKernelGGL(k_daagg_hot_sample, dim3(TSQ_DAAGG_HOT_SAMPLE / 1024), dim3(1024), 0, ctx->stream, ha);
+            TSQ_HIP(h, hipGetLastError());
+            hipLaunchKernelGGL(k_daagg_hot_list, dim3(1), dim3(1024), 0, ctx->stream, ha);
+            TSQ_HIP(h, hipGetLastError());
+            a->st.kernel_launches += 2;
+            hot.keys = ha.keys;
+            hot.n = ha.n;
+            hot.W = pl.W;
+            for (int k = 0; k < pl.W; k++) {
+                hot.dense_w[k] = a->dense_w[k].as<unsigned long long>();
+                hot.init[k] = pl.init[k];
+                hot.wdesc[k] = pl.wdesc[k];
+            }
+            hot.dense_touch = a->dense_touch.as<uint32_t>();
+        }
         const int pgrid = (int)std::min<int64_t>((nrows + T - 1) / T, (int64_t)ctx->num_cus * (part2 ? 2 : 1));
-        if (part2 && st.paybytes == 2) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 2, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks);
-        else if (part2 && st.paybytes == 4) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 4, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks);
-        else if (part2) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 8, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks);
-        else if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
-        else if (pl.V == 1 && st.paybytes == 4) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 4>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
-        else if (pl.V == 1 && st.paybytes == 2) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
-        else if (pl.V == 1) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
-        else hipLaunchKernelGGL((k_daagg_partition<1024, 4, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks);
+        if (part2 && st.paybytes == 2) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 2, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks, hot);
+        else if (part2 && st.paybytes == 4) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 4, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks, hot);
+        else if (part2) hipLaunchKernelGGL((k_daagg_partition<512, 8, 1, 8, false>), dim3(pgrid), dim3(512), 0, ctx->stream, src, a->da_dm, st, ks, hot);
+        else if (pl.V == 0) hipLaunchKernelGGL((k_daagg_partition<1024, 16, 0>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks, hot);
+        else if (pl.V == 1 && st.paybytes == 4) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 4>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks, hot);
+        else if (pl.V == 1 && st.paybytes == 2) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks, hot);
+        else if (pl.V == 1) hipLaunchKernelGGL((k_daagg_partition<1024, 8, 1>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks, hot);
+        else hipLaunchKernelGGL((k_daagg_partition<1024, 4, 2>), dim3(pgrid), dim3(1024), 0, ctx->stream, src, a->da_dm, st, ks, hot);
         TSQ_HIP(h, hipGetLastError());
         a->st.kernel_launches++;
         DaAggLdsArgs da;
@@ -1739,6 +1780,74 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
 // one device-resident batch: LDS pre-aggregation when the plan and the batch allow it, the row upsert otherwise
 // ---- several integer key columns as one 64-bit composite key (k_agg_wide_compose): the fields from the first batch, the child
 tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows);
+
+// ---------------------------------------------------------------- StreamAggExec (host side; kernels in tsq_streamagg.h)
+// the group array grows by copy: a group's number never changes (no rehash)
+tsq_status stream_grow(tsq_agg* a, uint64_t new_cap) {
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    AggTableBufs nb;
+    tsq_status s = alloc_table(a, nb, new_cap);
+    if (s != TSQ_OK) { nb.release(); return s; }
+    const size_t g = (size_t)a->groups;
+    hipError_t e = hipSuccess;
+    auto cp = [&](DevBuf& to, DevBuf& from, size_t bytes) {
+        if (e == hipSuccess && bytes && to.p && from.p) e = hipMemcpyAsync(to.p, from.p, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+    };
+    cp(nb.tag, a->tb.tag, g * 8);
+    cp(nb.gknull, a->tb.gknull, g);
+    for (int k = 0; k < a->plan.n_keys; k++) cp(nb.gkey[k], a->tb.gkey[k], g * 8);
+    for (int i = 0; i < a->plan.n_aggs; i++) {
+        cp(nb.acc[i], a->tb.acc[i], g * 8);
+        cp(nb.aux[i], a->tb.aux[i], g * 8);
+        cp(nb.cnt[i], a->tb.cnt[i], g * 8);
+        cp(nb.seen[i], a->tb.seen[i], g);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { nb.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("stream aggregate, growing the group array: ") + hipGetErrorString(e)); }
+    a->tb.release();
+    a->tb = nb;  // shallow move of the buffer handles
+    return TSQ_OK;
+}
+
+tsq_status stream_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    if (nrows >= 0x7fffffffLL) return tsq_fail(h, TSQ_ERR_INVALID, "internal: batch too large");
+    const uint32_t nchunks = (uint32_t)((nrows + TSQ_SA_CHUNK - 1) / TSQ_SA_CHUNK);
+    TSQ_TRY(a->sa_cnt.reserve(ctx, h, ((size_t)nchunks + 1) * 4 + 64));
+    StreamAggArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.u.in = in;
+    sa.u.plan = a->plan;
+    sa.u.nrows = nrows;
+    sa.u.row_base = a->in_rows;
+    sa.u.counters = a->counters.as<unsigned long long>();
+    fill_agg_table(a, a->tb, sa.u.t);
+    sa.groups_before = (uint64_t)a->groups;
+    sa.chunk_cnt = a->sa_cnt.as<uint32_t>();
+    sa.nchunks = nchunks;
+    const int grid = (int)std::min<int64_t>(nchunks, (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(k_sa_count, dim3(grid), dim3(TSQ_SA_NT), 0, ctx->stream, sa);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_sa_scan, dim3(1), dim3(1024), 0, ctx->stream, sa.chunk_cnt, nchunks);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned, sa.chunk_cnt + nchunks, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const uint64_t heads = ((const uint32_t*)ctx->pinned)[0];
+    const uint64_t need = (uint64_t)a->groups + heads;
+    if (need > a->tb.cap) {
+        TSQ_TRY(stream_grow(a, std::max<uint64_t>(need, a->tb.cap * 2)));
+        fill_agg_table(a, a->tb, sa.u.t);
+    }
+    hipLaunchKernelGGL(k_sa_update, dim3(grid), dim3(TSQ_SA_NT), 0, ctx->stream, sa);
+    TSQ_HIP(h, hipGetLastError());
+    a->groups = (int64_t)need;
+    a->st.kernel_launches += 3;
+    a->stream_batches++;
+    return TSQ_OK;
+}
+
 tsq_status wide_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     if (a->wide_state) return TSQ_OK;
     a->wide_state = -1;
@@ -1910,6 +2019,7 @@ tsq_status wide_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
 
 tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     if (nrows == 0) return TSQ_OK;
+    if (a->stream) return stream_batch(a, in, nrows);
     // several integer key columns wider than the packed route takes: one composite key for a single-key child (wide_setup).  The
     // first batch decides; small first batches (below 64 Ki rows) wait for a bigger one unless the fast paths are FORCEd (tests)
     if (a->wide_ok && a->wide_state >= 0 && a->fast_mode != TSQ_AGGFAST_OFF && nrows < 0x7fffffffLL) {
@@ -2318,7 +2428,8 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     // single group of a key-less aggregate; claim it so that finalize emits it.
     if (a->plan.n_keys == 0 && a->groups == 0) {
         unsigned long long one = 1;
-        TSQ_HIP(h, hipMemcpy((char*)a->tb.tag.p + (a->tb.cap + 1) * 8, &one, 8, hipMemcpyHostToDevice));
+        // (StreamAggExec: groups live in slots [0, groups) — the default row is group 0)
+        TSQ_HIP(h, hipMemcpy((char*)a->tb.tag.p + (a->stream ? 0 : (a->tb.cap + 1) * 8), &one, 8, hipMemcpyHostToDevice));
         a->groups = 1;
     }
     // the groups of the composite-key child come after this operator's own (exception) groups
@@ -2345,8 +2456,10 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
         fa.out_notnull[oc] = a->onn[oc].as<uint8_t>();
     }
     fa.counters = a->counters.as<unsigned long long>();
+    fa.ordered = a->stream ? 1 : 0;
+    fa.ordered_groups = (uint64_t)g_own;
     TSQ_HIP(h, hipMemsetAsync((char*)a->counters.p + 3 * 8, 0, 16, ctx->stream));
-    int grid = tsq_grid_for(ctx, (int64_t)a->tb.cap + 2, 256, TSQ_FINAL_CHUNK / 256);
+    int grid = tsq_grid_for(ctx, a->stream ? std::max<int64_t>(g_own, 1) : (int64_t)a->tb.cap + 2, 256, TSQ_FINAL_CHUNK / 256);
     hipLaunchKernelGGL(k_agg_finalize, dim3(grid), dim3(256), 0, ctx->stream, fa);
     TSQ_HIP(h, hipGetLastError());
     a->st.kernel_launches++;
@@ -2457,6 +2570,20 @@ TSQ_API tsq_status tsq_agg_set_fast(tsq_agg* a, int32_t mode) {
     if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
     if (mode < TSQ_AGGFAST_AUTO || mode > TSQ_AGGFAST_FORCE) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "mode must be -1 (auto), 0 (off) or 1 (force)");
     a->fast_mode = mode;
+    return TSQ_OK;
+}
+
+TSQ_API tsq_status tsq_agg_set_stream(tsq_agg* a, int32_t on) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(a, TSQ_MAGIC_AGG));
+    if (!a || a->hdr.magic != TSQ_MAGIC_AGG) return TSQ_ERR_INVALID;
+    if (a->in_rows > 0 || a->stage.staged > 0 || a->finished) return tsq_fail(&a->hdr, TSQ_ERR_INVALID, "stream mode must be chosen before the first row");
+    const bool want = on != 0;
+    if (want && !a->multi && !a->tb.gknull.p) {  // the open group's NULL flags: one byte per group (the hash table of a one-key plan has none)
+        TSQ_HIP(&a->hdr, hipSetDevice(a->ctx->device));
+        TSQ_TRY(a->tb.gknull.reserve(a->ctx, &a->hdr, a->tb.cap + 2));
+        TSQ_HIP(&a->hdr, hipMemsetAsync(a->tb.gknull.p, 0, a->tb.cap + 2, a->ctx->stream));
+    }
+    a->stream = want;
     return TSQ_OK;
 }
 
@@ -2608,6 +2735,8 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
     a->retry[0].release();
     a->retry[1].release();
     a->slot_of.release();
+    a->sa_cnt.release();
+    a->hotkeys.release();
     a->stage.release();
     for (auto& c : a->icols) c.release();
     for (auto& c : a->heap) c.release();

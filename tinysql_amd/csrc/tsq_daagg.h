@@ -24,6 +24,7 @@
 
 #include "tsq_aggfast.h"
 #include "tsq_dajoin.h"
+#include "tsq_wavescan.h"
 
 #define TSQ_DAAGG_MAX_BITS 23
 #define TSQ_DAAGG_PACK_SHIFT 40  /* SIG 3 (daagg_apply): count << 40 | sum of 16-bit values */
@@ -104,6 +105,109 @@ __device__ __forceinline__ uint32_t daagg_region_len(const DaAggStore& st, uint3
     return len < st.cap ? len : st.cap;
 }
 
+// Round 5 — HOT KEYS.  A skewed batch (the Zipf variant of C3: ONE key holds 5 % of the rows, fifteen keys 20 %) sends the rows of a hot key
+// to one partition: they overflow its region, travel through the overflow store and meet again in one LDS cell (k_daagg_ovf 4.6 ms +
+// k_agg_da 1.9 instead of 0.4 ms per 2.5e8-row batch).  Those rows need not travel at all: a sample of the batch (k_daagg_hot_sample:
+// 64 Ki rows, every key seen >= TSQ_DAAGG_HOT_MIN times, at most TSQ_DAAGG_HOT_MAX of them) names the hot keys, and the partition kernel
+// accumulates their rows in a small LDS table of its own (the words of the plan, exactly as k_agg_da would) and adds that table to
+// the dense state when it ends — one device atomic per (workgroup, hot key, word).  What is left for the store has no key above
+// ~0.04 % of the rows.  A uniform batch has no hot key: the kernels pay one LDS read of the count.
+#define TSQ_DAAGG_HOT_MAX 256
+#define TSQ_DAAGG_HOT_SLOTS 1024 /* DIRECT-MAPPED LDS table of the hot keys inside the partition kernel: one read per row, no probe loop (the 8 lookups of a
+                                    lane are independent loads); a hot key whose slot is taken stays an ordinary key */
+#define TSQ_DAAGG_HOT_MIN 12     /* occurrences among 65536 sampled rows: 0.018 % of the batch */
+#define TSQ_DAAGG_HOT_MAXW 3     /* words per hot slot: plans with more LDS words per group do not use the feature (3 x 1024 x 8 B of LDS) */
+#define TSQ_DAAGG_HOT_SAMPLE 65536
+struct DaAggHot {
+    uint32_t* keys;   // [TSQ_DAAGG_HOT_MAX] packed words u of the batch's hot keys; nullptr: the feature is off for this launch
+    uint32_t* n;      // [1]
+    unsigned long long* dense_w[TSQ_AF_MAXW];
+    uint32_t* dense_touch;
+    unsigned long long init[TSQ_AF_MAXW];
+    uint32_t wdesc[TSQ_AF_MAXW];
+    int32_t W;
+};
+struct DaAggHotSampleArgs {
+    const uint64_t* kdata;
+    const uint8_t* knulls;
+    int64_t nrows;
+    DaDomain dm;
+    uint32_t* table;  // [2 * TSQ_DAAGG_HOT_TABLE]: words, counts (zeroed / set to TSQ_DA_NONE by the host before the launch)
+    uint32_t* keys;
+    uint32_t* n;
+};
+#define TSQ_DAAGG_HOT_TABLE 16384
+// one sampled row per thread (64 workgroups: the loads are in flight together — one workgroup walking 64 samples per thread took
+// 0.65 ms, as long as half a partition pass), counted in a hash table in HBM
+__global__ void __launch_bounds__(1024) k_daagg_hot_sample(DaAggHotSampleArgs a) {
+    constexpr uint32_t S = TSQ_DAAGG_HOT_TABLE;
+    const int64_t ns = a.nrows < TSQ_DAAGG_HOT_SAMPLE ? a.nrows : (int64_t)TSQ_DAAGG_HOT_SAMPLE;
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i >= ns) return;
+    // workgroup b reads 1024 CONSECUTIVE rows at b / 64 of the batch (coalesced: 64 Ki rows spread one by one over the batch cost
+    // 105 us in TLB and line misses).  Clustered input makes a block see few keys often: such a key is absorbed although it may
+    // not be hot over the whole batch — that costs nothing but its LDS slot.
+    const int64_t nblk = (ns + 1023) / 1024;
+    const int64_t row = (a.nrows / nblk) * (int64_t)blockIdx.x + threadIdx.x;
+    if (row >= a.nrows) return;
+    if (tsq_is_null(a.knulls, row)) return;
+    const uint32_t u = da_word(a.dm, a.kdata[row]);
+    if (u == TSQ_DA_NONE) return;
+    uint32_t* keys = a.table;
+    uint32_t* cnt = a.table + S;
+    uint32_t slot = (u * 0x9E3779B1u) >> 18;
+    // (uniform keys: 64 Ki distinct words meet 16 Ki slots — a row that finds no place within 4 steps is not counted.  A hot key shows up in
+    // the first blocks and owns its slot long before the table fills; 32 steps made the kernel cost 105 us on a uniform batch)
+    for (int step = 0; step < 4; step++) {
+        uint32_t cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == TSQ_DA_NONE) cur = atomicCAS(&keys[slot], TSQ_DA_NONE, u);
+        if (cur == TSQ_DA_NONE || cur == u) { atomicAdd(&cnt[slot], 1u); return; }
+        slot = (slot + 1) & (S - 1);
+    }
+}
+// ... and the keys seen >= TSQ_DAAGG_HOT_MIN times become the batch's hot keys (one workgroup)
+__global__ void __launch_bounds__(1024) k_daagg_hot_list(DaAggHotSampleArgs a) {
+    constexpr uint32_t S = TSQ_DAAGG_HOT_TABLE;
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // the hottest first: when more keys pass the threshold than the list holds, the ones left out are the coolest
+    for (uint32_t lo = TSQ_DAAGG_HOT_MIN * 8u, hi = 0xffffffffu; lo >= TSQ_DAAGG_HOT_MIN; hi = lo, lo >>= 1) {
+        for (uint32_t i = threadIdx.x; i < S; i += 1024) {
+            const uint32_t c = a.table[S + i];
+            if (a.table[i] != TSQ_DA_NONE && c >= lo && c < hi) {
+                const uint32_t o = atomicAdd(&s_n, 1u);
+                if (o < TSQ_DAAGG_HOT_MAX) a.keys[o] = a.table[i];
+            }
+        }
+        __syncthreads();
+        if (s_n >= TSQ_DAAGG_HOT_MAX) break;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *a.n = s_n < TSQ_DAAGG_HOT_MAX ? s_n : (uint32_t)TSQ_DAAGG_HOT_MAX;
+}
+// what one row does to the words of hot slot h (the generic form of daagg_apply: W and the descriptors are run-time values here)
+__device__ __forceinline__ void daagg_hot_apply(const DaAggHot& hot, unsigned long long (*s_hw)[TSQ_DAAGG_HOT_SLOTS], uint32_t h, uint64_t c0, uint64_t c1) {
+#pragma unroll
+    for (int k = 0; k < TSQ_DAAGG_HOT_MAXW; k++) {
+        if (k >= hot.W) break;
+        const uint32_t d = hot.wdesc[k];
+        const uint64_t cell = (d & 8u) ? c1 : c0;
+        const int32_t type = (int32_t)(d >> 4);
+        switch (d & 7u) {
+            case AF_W_ADD1: atomicAdd(&s_hw[k][h], 1ull); break;
+            case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(&s_hw[k][h]), af_real(cell, type)); break;
+            case AF_W_ADD_LO32: atomicAdd(&s_hw[k][h], (unsigned long long)(cell & 0xffffffffull)); break;
+            case AF_W_ADD_HI32:
+                if ((long long)cell >> 32) atomicAdd(&s_hw[k][h], (unsigned long long)((long long)cell >> 32));
+                break;
+            case AF_W_MAX: atomicMax(&s_hw[k][h], (unsigned long long)af_ord_image(cell, type)); break;
+            default: atomicMin(&s_hw[k][h], (unsigned long long)af_ord_image(cell, type)); break;
+        }
+    }
+}
+
 // K5e — partition of (packed key entry, argument cells).  The structure of k_da_partition (tsq_dajoin.h) with V payload columns
 // staged through LDS next to the words; a run that does not fit its region sends its ROWS to the exception list (they are
 // aggregated row by row: exact under any skew).
@@ -115,7 +219,7 @@ template <> struct da_pay_t<2> { typedef uint16_t type; };
 // and 127 VGPRs: TWO workgroups per CU, one loading while the other scatters (what k_da_partition2 did for the join: the
 // 1024-thread version's waves are parked more than half of their cycles).
 template <int NT, int K, int V, int PB = 8, bool WITH_ROW = true>
-__global__ void __launch_bounds__(NT, WITH_ROW ? 1 : 4) k_daagg_partition(DaAggSrc src, DaDomain dm, DaAggStore st, DaAggKeys ks) {
+__global__ void __launch_bounds__(NT, WITH_ROW ? 1 : 4) k_daagg_partition(DaAggSrc src, DaDomain dm, DaAggStore st, DaAggKeys ks, DaAggHot hot) {
     constexpr int T = NT * K;
     static_assert(PB == 8 || (V == 1 && (PB == 4 || PB == 2)), "narrow cells: one argument column");
     typedef typename da_pay_t<PB>::type PT;
@@ -128,7 +232,31 @@ __global__ void __launch_bounds__(NT, WITH_ROW ? 1 : 4) k_daagg_partition(DaAggS
     __shared__ uint32_t s_delta[TSQ_RADIX_MAX_P];
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_flag, s_obase;
+    // hot keys of the batch (round 5): their rows are aggregated here and never reach the store
+    // (only the two-workgroups-per-CU variants have the LDS for it: the 1024-thread tiles fill a CU's 160 KB)
+    constexpr int HS = WITH_ROW ? 32 : TSQ_DAAGG_HOT_SLOTS;
+    __shared__ uint32_t s_hk[HS];
+    __shared__ unsigned long long s_hw[WITH_ROW ? 1 : TSQ_DAAGG_HOT_MAXW][WITH_ROW ? 32 : TSQ_DAAGG_HOT_SLOTS];
+    __shared__ uint32_t s_ht[HS / 32];  // slot received a row
+    __shared__ uint32_t s_hn;
     const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_hn = (!WITH_ROW && hot.keys) ? *hot.n : 0u;
+    __syncthreads();
+    const uint32_t hot_n = WITH_ROW ? 0u : s_hn;
+    if constexpr (!WITH_ROW) if (hot_n) {
+        for (uint32_t i = tid; i < TSQ_DAAGG_HOT_SLOTS; i += NT) {
+            s_hk[i] = TSQ_DA_NONE;
+#pragma unroll
+            for (int k = 0; k < TSQ_DAAGG_HOT_MAXW; k++) s_hw[k][i] = hot.init[k];
+        }
+        if (tid < TSQ_DAAGG_HOT_SLOTS / 32) s_ht[tid] = 0;
+        __syncthreads();
+        if (tid < hot_n) {  // two slots per key (a key that finds both taken is simply not absorbed: 256 keys, 1024 slots)
+            const uint32_t u = hot.keys[tid];
+            if (atomicCAS(&s_hk[(u * 0x9E3779B1u) >> 22], TSQ_DA_NONE, u) != TSQ_DA_NONE) atomicCAS(&s_hk[(u * 0x85EBCA6Bu) >> 22], TSQ_DA_NONE, u);
+        }
+        __syncthreads();
+    }
     const uint32_t P = 1u << st.bits, ebits = st.ebits, emask = (1u << ebits) - 1u;
     auto fits = [](uint64_t cell) -> bool { return PB == 8 || (cell >> (PB == 8 ? 0 : 8 * PB)) == 0; };
     uint32_t misfits = 0;
@@ -237,6 +365,18 @@ __global__ void __launch_bounds__(NT, WITH_ROW ? 1 : 4) k_daagg_partition(DaAggS
                     }
                     if (u[j] == TSQ_DA_NONE) except((uint32_t)base + pos);
                 }
+            }
+        }
+        if constexpr (!WITH_ROW) if (hot_n) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const uint32_t h1 = (u[j] * 0x9E3779B1u) >> 22, h2 = (u[j] * 0x85EBCA6Bu) >> 22;
+                const uint32_t k1 = s_hk[h1], k2 = s_hk[h2];  // (two independent LDS reads: no probe loop)
+                if (u[j] == TSQ_DA_NONE || (k1 != u[j] && k2 != u[j])) continue;
+                const uint32_t hs = k1 == u[j] ? h1 : h2;
+                daagg_hot_apply(hot, s_hw, hs, V > 0 ? pay[0][j] : 0ull, V > 1 ? pay[V > 1 ? 1 : 0][j] : 0ull);
+                if (!((s_ht[hs >> 5] >> (hs & 31u)) & 1u)) atomicOr(&s_ht[hs >> 5], 1u << (hs & 31u));
+                u[j] = TSQ_DA_NONE;  // aggregated: nothing of this row travels
             }
         }
         __syncthreads();
@@ -351,6 +491,26 @@ __global__ void __launch_bounds__(NT, WITH_ROW ? 1 : 4) k_daagg_partition(DaAggS
         }
         __syncthreads();
     }
+    if constexpr (!WITH_ROW) if (hot_n) {  // this workgroup's share of the hot keys' groups -> the dense state (words in their LDS form, like daagg_fold_dense)
+        __syncthreads();
+        for (uint32_t i = tid; i < TSQ_DAAGG_HOT_SLOTS; i += NT) {
+            const uint32_t u = s_hk[i];
+            if (u == TSQ_DA_NONE || !((s_ht[i >> 5] >> (i & 31u)) & 1u)) continue;
+#pragma unroll
+            for (int k = 0; k < TSQ_DAAGG_HOT_MAXW; k++) {
+                if (k >= hot.W) break;
+                const unsigned long long v = s_hw[k][i];
+                unsigned long long* g = hot.dense_w[k] + u;
+                switch (hot.wdesc[k] & 7u) {
+                    case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(g), tsq_bits_f64(v)); break;
+                    case AF_W_MAX: atomicMax(g, v); break;
+                    case AF_W_MIN: atomicMin(g, v); break;
+                    default: if (v) atomicAdd(g, v); break;
+                }
+            }
+            atomicOr(&hot.dense_touch[u >> 5], 1u << (u & 31u));
+        }
+    }
     if (PB != 8) {  // one device atomic per wave that saw a value too wide for the cells: the host widens the cells when there are many
         for (int o = 32; o > 0; o >>= 1) misfits += __shfl_xor(misfits, o, 64);
         if ((tid & 63u) == 0 && misfits) atomicAdd(src.exc_count + 1, misfits);
@@ -411,6 +571,71 @@ __device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned lo
                 break;
             case AF_W_MAX: atomicMax(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
             default: atomicMin(&s_w[k][e], (unsigned long long)af_ord_image(cell, type)); break;
+        }
+    }
+}
+// Round 5 — the same for a WAVE whose lanes hold consecutive rows of the store: runs of lanes with the same cell (a hot key: 5 % of a
+// Zipf batch is ONE key, ~93 % of its partition's rows) are reduced with segmented shuffle scans first and only the last lane of a run
+// touches LDS — 64 same-address LDS atomics are 64 serial operations (k_daagg_ovf spent 4.4 ms per 2.5e8-row Zipf batch in them, the hot
+// partitions of k_agg_da as long again).  Wave-uniform choice: fewer than TSQ_DAAGG_COMBINE_MIN lanes repeating their neighbour's
+// cell -> the plain per-row path (uniform keys pay one ballot).  Every lane of the wave must call; `live` = the lane holds a row.
+#define TSQ_DAAGG_COMBINE_MIN 8
+template <int W, int CELLS, int SIG = 0>
+__device__ __forceinline__ void daagg_apply_wave(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1,
+                                                 bool live) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t eprev = (uint32_t)__shfl_up((int)e, 1, 64);
+    const bool lprev = __shfl_up((int)live, 1, 64) != 0;
+    const bool head = !live || lane == 0 || !lprev || e != eprev;
+    const unsigned long long hm = __ballot(head);
+    if (64 - __popcll(hm) < TSQ_DAAGG_COMBINE_MIN) {
+        if (live) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e, c0, c1);
+        return;
+    }
+    const bool tail = live && (lane == 63 || ((hm >> (lane + 1)) & 1ull));
+    const uint32_t cm = sa_cond_mask(head, lane);
+    if (tail && !((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
+    if (SIG == 3 && W == 3) {
+        const uint64_t v = sa_scan_add(live ? (1ull << TSQ_DAAGG_PACK_SHIFT) + c0 : 0ull, cm);
+        if (tail) atomicAdd(&s_w[0][e], (unsigned long long)v);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        const uint32_t d = wd[k];
+        const uint64_t cell = (d & 8u) ? c1 : c0;
+        const int32_t type = (int32_t)(d >> 4);
+        switch (d & 7u) {
+            case AF_W_ADD1: {
+                const uint64_t v = sa_scan_add(live ? 1ull : 0ull, cm);
+                if (tail) atomicAdd(&s_w[k][e], (unsigned long long)v);
+                break;
+            }
+            case AF_W_ADD_REAL: {
+                const double v = sa_scan_addf(live ? af_real(cell, type) : 0.0, cm);
+                if (tail) atomicAdd(reinterpret_cast<double*>(&s_w[k][e]), v);
+                break;
+            }
+            case AF_W_ADD_LO32: {
+                const uint64_t v = sa_scan_add(live ? (cell & 0xffffffffull) : 0ull, cm);
+                if (tail) atomicAdd(&s_w[k][e], (unsigned long long)v);
+                break;
+            }
+            case AF_W_ADD_HI32: {
+                const uint64_t v = sa_scan_add(live ? (uint64_t)((long long)cell >> 32) : 0ull, cm);
+                if (tail && v) atomicAdd(&s_w[k][e], (unsigned long long)v);
+                break;
+            }
+            case AF_W_MAX: {
+                const uint64_t v = sa_scan_max(live ? af_ord_image(cell, type) : 0ull, cm);
+                if (tail) atomicMax(&s_w[k][e], (unsigned long long)v);
+                break;
+            }
+            default: {
+                const uint64_t v = sa_scan_min(live ? af_ord_image(cell, type) : ~0ull, cm);
+                if (tail) atomicMin(&s_w[k][e], (unsigned long long)v);
+                break;
+            }
         }
     }
 }
@@ -557,9 +782,16 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
                             for (int v = 0; v < TSQ_RADIX_MAXV; v++) cells[x][v] = v < a.plan.V ? a.st.pay[v][base + ic] : 0ull;
                         }
                     }
+                    // (the loop bound is not wave-uniform: lanes past the end of the region fall out of the last iteration, so the wave
+                    // variant — every lane calls — is entered only when the whole wave is still inside the loop; `live` covers the rows
+                    // i0 + x NT that lie past the end)
+                    const bool whole_wave = (i0 - (tid & 63u)) + 63u < len;
 #pragma unroll
-                    for (int x = 0; x < U; x++)
-                        if (i0 + (uint32_t)x * TSQ_AF_NT < len) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
+                    for (int x = 0; x < U; x++) {
+                        const bool live = i0 + (uint32_t)x * TSQ_AF_NT < len;
+                        if (whole_wave) daagg_apply_wave<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1], live);
+                        else if (live) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
+                    }
                 }
             }
         };
@@ -644,9 +876,12 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_daagg_ovf(DaAggOvfArgs a) {
                 if (cur == EMPTY || cur == u) found = true;
                 else slot = (slot + 1) & (S - 1);
             }
-            if (found) {
-                daagg_apply<W, (int)S, 0>(wd, s_w, s_touch, slot, c0, c1);
-            } else {  // the words of a one-row group, straight into the row's dense cell
+            // consecutive rows of the store are a tile's run of ONE partition — mostly one hot key: the wave combines neighbours that
+            // found the same slot before it touches LDS (daagg_apply_wave; the last, partial wave of the stripe goes row by row)
+            const bool whole_wave = (i - (tid & 63u)) + 63u < n;
+            if (whole_wave) daagg_apply_wave<W, (int)S, 0>(wd, s_w, s_touch, slot, c0, c1, found);
+            else if (found) daagg_apply<W, (int)S, 0>(wd, s_w, s_touch, slot, c0, c1);
+            if (!found) {  // the words of a one-row group, straight into the row's dense cell
                 unsigned long long v[W];
 #pragma unroll
                 for (int k = 0; k < W; k++) {

@@ -317,6 +317,46 @@ __global__ void __launch_bounds__(TSQ_DEC_NT) k_dec_emit(DecArgs a) {
 }
 
 // ====================================================================== host side
+// A schema with a var-len column (round 5): bytes datums have no bounded length, so the row boundaries come from one sequential
+// host walk over flags and lengths (tsq_dec_walk_rows, tsq_decode_dp.h) and the values are decoded by the chunk-parallel kernels of
+// tsq_decodec.hip, 64 rows per piece — the size the storage side cuts a response into (cop_handler_dag.go:510-519).  A stream that
+// lives in HBM is copied to the host for the walk (the bytes are read there, nothing is decoded there).
+extern "C" tsq_status tsq_rows_decode_chunks(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, const int64_t* chunk_offsets, int64_t n_chunks,
+                                              uint32_t data_flags, int32_t n_cols, const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows,
+                                              int64_t* nrows_out);
+static tsq_status tsq_rows_decode_varlen(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, uint32_t data_flags, int32_t n_cols, const int32_t* col_types,
+                                         tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_consumed) {
+    tsq_handle_hdr* h = &ctx->hdr;
+    if (n_bytes == 0 || cap_rows == 0) return tsq_rows_decode_chunks(ctx, rows_data, 0, nullptr, 0, data_flags, n_cols, col_types, out_cols, cap_rows, nrows_out);
+    const uint8_t* host = rows_data;
+    std::vector<uint8_t> copy;
+    if (data_flags & TSQ_COL_DEVICE) {
+        TSQ_HIP(h, hipSetDevice(ctx->device));
+        copy.resize((size_t)n_bytes);
+        TSQ_HIP(h, hipMemcpy(copy.data(), rows_data, (size_t)n_bytes, hipMemcpyDeviceToHost));
+        host = copy.data();
+    }
+    std::vector<int64_t> offs;
+    int64_t end = 0;
+    bool damaged = false;
+    (void)tsq_dec_walk_rows(host, n_bytes, n_cols, cap_rows, 64, offs, &end, &damaged);
+    const int64_t* po = offs.data();
+    DevBuf doffs;  // (a stream in HBM: the piece boundaries live next to it — the chunk decoder reads both where the data is)
+    if (data_flags & TSQ_COL_DEVICE) {
+        TSQ_TRY(doffs.reserve(ctx, h, offs.size() * 8 + 64));
+        const hipError_t e = hipMemcpy(doffs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            doffs.release();
+            return tsq_fail(h, TSQ_ERR_HIP, std::string("tsq_rows_decode(piece boundaries): ") + hipGetErrorString(e));
+        }
+        po = doffs.as<int64_t>();
+    }
+    const tsq_status s = tsq_rows_decode_chunks(ctx, rows_data, end, po, (int64_t)offs.size() - 1, data_flags, n_cols, col_types, out_cols, cap_rows, nrows_out);
+    doffs.release();
+    if (s == TSQ_OK) *bytes_consumed = end;
+    return s;
+}
+
 TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64_t n_bytes, uint32_t data_flags, int32_t n_cols,
                                    const int32_t* col_types, tsq_col* out_cols, int64_t cap_rows, int64_t* nrows_out, int64_t* bytes_consumed) {
     tsq_ctx_lock _api_lock(ctx);
@@ -327,8 +367,10 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
     if (!nrows_out || !bytes_consumed || !col_types || !out_cols || n_bytes < 0 || cap_rows < 0 || (n_bytes > 0 && !rows_data))
         return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode: bad arguments");
     if (n_cols < 1 || n_cols > TSQ_MAX_COLS) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "1..16 columns supported");
+    for (int c = 0; c < n_cols; c++)
+        if (col_types[c] == TSQ_BYTES) return tsq_rows_decode_varlen(ctx, rows_data, n_bytes, data_flags, n_cols, col_types, out_cols, cap_rows, nrows_out, bytes_consumed);
     for (int c = 0; c < n_cols; c++) {
-        if (col_types[c] < TSQ_I64 || col_types[c] > TSQ_F64) return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "var-len column: decode it with the Go decoder");
+        if (col_types[c] < TSQ_I64 || col_types[c] > TSQ_F64) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode: unknown column type");
         if (!out_cols[c].data || !out_cols[c].null_bitmap) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode: out columns need data and null_bitmap buffers");
         if (((out_cols[c].flags ^ out_cols[0].flags) & TSQ_COL_DEVICE) != 0) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_decode: mixed host/device outputs");
     }
@@ -455,7 +497,7 @@ TSQ_API tsq_status tsq_rows_decode(tsq_ctx* ctx, const uint8_t* rows_data, int64
         case DEC_ROW_CUT: return tsq_fail(h, TSQ_ERR_INVALID, "invalid encoded key");                          // codec.go:625
         case DEC_INSUFFICIENT: return tsq_fail(h, TSQ_ERR_INVALID, "insufficient bytes to decode value");     // number.go:46,122
         case DEC_OVERFLOW: return tsq_fail(h, TSQ_ERR_INVALID, "value larger than 64 bits");                  // number.go:120
-        case DEC_VARLEN: return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "bytes datum in a fixed-width column: decode this response with the Go decoder");
+        case DEC_VARLEN: return tsq_fail(h, TSQ_ERR_INVALID, "datum kind does not match the column type");  // a bytes datum, a number column (as tsq_rows_decode_chunks)
         default: return tsq_fail(h, TSQ_ERR_INVALID, "invalid encoded key flag");                             // codec.go:683
     }
 }

@@ -6,6 +6,8 @@
 #ifndef TSQ_DECODE_DP_H
 #define TSQ_DECODE_DP_H
 
+#include <vector>
+
 #include "tsq_device.h"
 
 enum { DEC_OK = 0, DEC_ROW_CUT = 1, DEC_INSUFFICIENT = 2, DEC_OVERFLOW = 3, DEC_BAD_FLAG = 4, DEC_VARLEN = 5 };
@@ -210,6 +212,51 @@ TSQ_HD int tsq_decc_membytes(const uint8_t* p, uint64_t avail, tsq_decc_val* v) 
     v->bits = n;
     v->len = at;
     return DEC_OK;
+}
+// HOST: the row boundaries of a RowsData stream that holds bytes datums (round 5; tsq_rows_decode with a TSQ_BYTES column).  A
+// compact-bytes datum is a varint length + that many raw bytes, so where a value starts depends on every value before it and no
+// bounded window can be entered speculatively (what tsq_decode.hip does for the <= 11-byte number datums): the boundaries are found
+// by ONE sequential walk that reads flags and lengths only — selectResult.readRowsData's own loop (distsql/select_result.go:139-155)
+// minus the decoding — and the rows between them are decoded by the chunk-parallel kernels (tsq_decodec.hip), every `per` rows one
+// piece.  offs receives the piece boundaries (first 0).  Stops after cap_rows rows or at the first value DecodeOne would reject; a
+// stream with a damaged value keeps its remainder as the LAST piece, so the kernels meet the damage and report it with the
+// reference's message and the rows before it.  Returns the rows walked; *end = bytes of the walked prefix (bytes_consumed on success).
+inline int64_t tsq_dec_walk_rows(const uint8_t* data, int64_t n_bytes, int32_t n_cols, int64_t cap_rows, int64_t per, std::vector<int64_t>& offs, int64_t* end,
+                                 bool* damaged) {
+    int64_t pos = 0, rows = 0;
+    offs.clear();
+    offs.push_back(0);
+    *damaged = false;
+    while (pos < n_bytes && rows < cap_rows) {
+        int64_t p = pos;
+        bool ok = true;
+        for (int32_t c = 0; c < n_cols && ok; c++) {
+            if (p >= n_bytes) { ok = false; break; }  // the row ends early (codec.go:625)
+            const uint64_t avail = (uint64_t)(n_bytes - p);
+            uint32_t w[3] = {0, 0, 0};
+            for (uint32_t k = 0; k < 12 && k < avail; k++) w[k >> 2] |= (uint32_t)data[p + k] << (8 * (k & 3));
+            tsq_decc_val v;
+            int st = tsq_decc_value(w[0], w[1], w[2], avail, &v);
+            if (st == DEC_VARLEN) st = tsq_decc_membytes(data + p, avail, &v);
+            if (st != DEC_OK) { ok = false; break; }
+            p += (int64_t)v.len;
+        }
+        if (!ok) {
+            *damaged = true;
+            break;
+        }
+        pos = p;
+        rows++;
+        if (rows % per == 0) offs.push_back(pos);
+    }
+    if (*damaged) {  // the remainder travels as one piece (or extends the open one): the kernels find the first offending value
+        offs.push_back(n_bytes);
+        *end = n_bytes;
+    } else {
+        if (offs.back() != pos) offs.push_back(pos);
+        *end = pos;
+    }
+    return rows;
 }
 #define TSQ_DECC_GROUPED (1ll << 62)  // flag in a cell reference: the bytes are grouped (skip one marker byte after every 8)
 // what column type `type` stores for a datum (appendIntToChunk / appendUintToChunk / appendFloatToChunk / AppendBytes,

@@ -284,6 +284,21 @@ class HashAggExec(Executor):
         super().Close()
 
 
+class StreamAggExec(HashAggExec):
+    """GPU StreamAggExec (BASELINE.json north star; the reference has only the plan name "StreamAgg", planner/core/cbo_test.go:200-212):
+    the child delivers rows ordered by the group-by columns, groups come out in that order (tsq_agg_set_stream, csrc/tsq_streamagg.h).
+    `child_is_ordered=False` puts a SortExec on the group-by columns below the operator — the planner's order enforcement."""
+
+    def __init__(self, ctx, child, group_by_cols, agg_funcs, max_chunk_size=1024, child_is_ordered=True):
+        if not child_is_ordered and group_by_cols:
+            child = SortExec(ctx, child, list(group_by_cols), [False] * len(group_by_cols), max_chunk_size)
+        super().__init__(ctx, child, group_by_cols, agg_funcs, max_chunk_size)
+
+    def Open(self):
+        super().Open()
+        _lib.check(self.lib.tsq_agg_set_stream(self.h, 1), self.h)
+
+
 class SelectionExec(Executor):
     """SelectionExec.Next vectorized branch (executor/executor.go:393-409, STUB in the reference):
     VectorizedFilter over the child chunk, keep the selected rows."""
