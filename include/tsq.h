@@ -146,6 +146,12 @@ tsq_status tsq_ctx_arena_stats(tsq_ctx* ctx, int64_t* size_out, int64_t* used_ou
 tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out);
 tsq_status tsq_dev_free(tsq_ctx* ctx, void* p);
 tsq_status tsq_dev_memset(tsq_ctx* ctx, void* p, int32_t byte, int64_t bytes);
+/* Pinned host memory (ABI 6) for the chunks a host pushes or pulls and for tsq_copy_h2d / tsq_copy_d2h: the DMA engines read and write
+ * it directly, a pageable Go / numpy buffer goes through a bounce buffer at a fraction of the link rate (BASELINE north star: "chunk.Column
+ * batches pinned and DMA'd to HBM").  The cgo shim keeps its chunk.Column data in such blocks; freed blocks return to
+ * a process-wide pool. */
+tsq_status tsq_host_alloc(tsq_ctx* ctx, int64_t bytes, void** out);
+tsq_status tsq_host_free(tsq_ctx* ctx, void* p);
 tsq_status tsq_copy_h2d(tsq_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
 tsq_status tsq_copy_d2h(tsq_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
 /* device to device, queued on the context's stream (not synchronised): an operator's output batch kept beyond its next Next() */

@@ -332,8 +332,10 @@ def _dense_case(rng, n, key_hi, vmax, neg_frac=0.0):
     return Chunk([k, v]), [abi.I64, abi.I64]
 
 
-@pytest.mark.parametrize("dense,narrow", [(1, 1), (0, 1), (1, 0), (0, 0)])
-@pytest.mark.parametrize("key_hi,vmax,bits", [(30_000, 60_000, 16), (30_000, 3_000_000_000, 32), (3_000_000, 1000, 16), (3_000_000, 1 << 40, 64)])
+@pytest.mark.parametrize("dense,narrow,key_hi,vmax,bits", [
+    (1, 1, 30_000, 60_000, 16), (1, 1, 30_000, 3_000_000_000, 32), (1, 1, 3_000_000, 1000, 16), (1, 1, 3_000_000, 1 << 40, 64),
+    (0, 1, 30_000, 60_000, 16), (0, 1, 3_000_000, 1 << 40, 64), (1, 0, 30_000, 3_000_000_000, 32), (1, 0, 3_000_000, 1000, 16),
+    (0, 0, 30_000, 60_000, 16), (0, 0, 3_000_000, 1 << 40, 64)])  # (round 5: 10 of the 16 combinations — every (dense, narrow) pair on a small and a large key range)
 def test_packed_agg_dense_state_and_narrow_cells(ctx, orc, dense, narrow, key_hi, vmax, bits):
     """30 000 keys: 32 partitions, each split over 8 workgroups (device atomics into the dense state); 3e6 keys: one workgroup per
     partition (plain read-modify-write).  Several device batches, so that the state accumulates across launches."""
@@ -351,6 +353,30 @@ def test_packed_agg_dense_state_and_narrow_cells(ctx, orc, dense, narrow, key_hi
     assert st.dense_flushes == (1 if dense else 0)
     assert st.table_slice_bits == (bits if narrow else 64)  # (one travelling argument column: the four aggregates read the same one)
     assert H.rows_equal_unordered(got, want)
+
+
+@pytest.mark.parametrize("hot", [1, 0])
+@pytest.mark.parametrize("vmax", [60_000, 3_000_000_000])
+def test_packed_agg_hot_keys_are_absorbed_in_the_partition_kernel(ctx, orc, hot, vmax):
+    """round 5: a skewed batch (six keys hold 45 % of the rows, one of them 20 %) — the sampled hot keys are aggregated inside the partition
+    kernel's LDS and added to the dense state, the other rows travel as before; the same groups either way (knob DAAGG_HOT = 0: the hot
+    rows overflow their regions and take the overflow store).  NULL keys / NULL arguments stay exception rows."""
+    rng = np.random.default_rng(vmax % 1000 + hot)
+    n = 900_001
+    keys = rng.integers(0, 200_000, n)
+    r = rng.random(n)
+    for i, (lo, hi, k) in enumerate([(0.0, 0.20, 7), (0.20, 0.28, 199_999), (0.28, 0.34, 12_345), (0.34, 0.39, 0), (0.39, 0.43, 65_536), (0.43, 0.45, 100_000)]):
+        keys[(r >= lo) & (r < hi)] = k
+    chk = Chunk([Column(abi.I64, keys, rng.random(n) > 0.01), Column(abi.I64, rng.integers(0, vmax, n), rng.random(n) > 0.02)])
+    aggs = AGG_SETS["c3"]
+    with ctx.knobs(AGG_BATCH_ROWS=300_000, DAAGG_HOT=hot):
+        cfg = H.agg_cfg([abi.I64, abi.I64], [0], aggs, est_groups=200_000)
+        want = orc.hash_agg(cfg, chk, 4, 4)
+        stats = []
+        got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=100_000, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    st = stats[0]
+    assert st.packed_key_bits > 0 and st.radix_batches >= 3 and st.dense_flushes == 1
+    assert got.NumRows() == want.NumRows() and H.multiset(got) == H.multiset(want)
 
 
 @pytest.mark.parametrize("vmax,bits", [(60_000, 16), (3_000_000_000, 32), (1 << 40, 64)])

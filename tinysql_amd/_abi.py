@@ -182,6 +182,8 @@ SIGNATURES = {
     "tsq_ctx_arena_stats": (C.c_int32, [P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tsq_dev_alloc": (C.c_int32, [P, C.c_int64, PP]),
     "tsq_dev_free": (C.c_int32, [P, P]),
+    "tsq_host_alloc": (C.c_int32, [P, C.c_int64, PP]),
+    "tsq_host_free": (C.c_int32, [P, P]),
     "tsq_dev_memset": (C.c_int32, [P, P, C.c_int32, C.c_int64]),
     "tsq_copy_h2d": (C.c_int32, [P, P, P, C.c_int64]),
     "tsq_copy_d2h": (C.c_int32, [P, P, P, C.c_int64]),

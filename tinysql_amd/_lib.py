@@ -109,6 +109,24 @@ class Context:
         if ptr:
             check(self.lib.tsq_dev_free(self.h, C.c_void_p(ptr)), self.h)
 
+    def host_array(self, n, dtype):
+        """numpy array of n elements over PINNED host memory (tsq_host_alloc): what a host keeps the chunks in that it pushes or
+        pulls — the DMA engines reach it directly.  Give it back with host_release(arr) (or it goes with the context)."""
+        import numpy as np
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        check(self.lib.tsq_host_alloc(self.h, max(int(n), 1) * dt.itemsize, C.byref(p)), self.h)
+        buf = (C.c_uint8 * (max(int(n), 1) * dt.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt, count=int(n))
+        self._host_blocks = getattr(self, "_host_blocks", {})
+        self._host_blocks[arr.ctypes.data] = p.value
+        return arr
+
+    def host_release(self, arr):
+        p = getattr(self, "_host_blocks", {}).pop(arr.ctypes.data, None)
+        if p:
+            check(self.lib.tsq_host_free(self.h, C.c_void_p(p)), self.h)
+
     def memset(self, ptr, byte, nbytes):
         check(self.lib.tsq_dev_memset(self.h, C.c_void_p(ptr), byte, nbytes), self.h)
 

@@ -72,6 +72,7 @@ struct tsq_ctx {
     std::vector<std::pair<void*, size_t>> pool;
     size_t pool_bytes = 0, pool_cap = (size_t)48 << 30;
     std::unordered_map<void*, size_t> user_allocs;  // live tsq_dev_alloc blocks -> capacity (guarded by pool_mu)
+    std::unordered_map<void*, size_t> host_allocs;  // live tsq_host_alloc blocks (pinned) -> capacity (guarded by pool_mu)
     // ARENA (tsq_ctx_reserve): one slab allocated up front — by the host process when it creates the context, outside any query —
     // that the buffers of every operator are carved from, so that the FIRST build / aggregate of a session does not pay hipMalloc's
     // first touch (35 ms per GB: 310 ms for the 1e8-row build side).  Free ranges by offset, merged with their neighbours on release;

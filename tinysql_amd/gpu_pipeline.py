@@ -79,6 +79,18 @@ class DeviceColumn:
             self.cap_bytes = int(nbytes * 1.25) + 64
             self.data = self.ctx.alloc(self.cap_bytes + 64)
 
+    def to_host_pinned(self, nrows):
+        """fixed-width column -> (data array, bitmap bytes or None) in PINNED host memory (ctx.host_array): one DMA each, no
+        pageable bounce, no unpacking — the form a host operator consumes (util/chunk/column.go:28-34 keeps the bitmap packed too)"""
+        assert not self.var
+        data = self.ctx.host_array(max(nrows, 1), np_dtype(self.tp))
+        self.ctx.d2h(data, self.data)
+        bm = None
+        if self.bitmap is not None:
+            bm = self.ctx.host_array((nrows + 7) // 8 + 1, np.uint8)
+            self.ctx.d2h(bm, self.bitmap)
+        return data, bm
+
     def to_host(self, nrows):
         nn = None
         if self.bitmap is not None:

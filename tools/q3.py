@@ -142,6 +142,56 @@ def reference(customer, orders, lineitem):
     return uk, date_of[uk], prio_of[uk], sums
 
 
+def verify_against_numpy(ctx, customer_d, orders_d, lineitem_d, result):
+    """--verify: the result of the LAST run (host arrays: orderkey, date, priority, revenue per group) against a numpy restatement
+    of the query over host copies of the very tables the GPU read, at any scale factor: lineitem is walked in slices of 2^26 rows
+    (SF 100: 9 slices of 600 M rows), revenue and row counts accumulate per order key (np.bincount), the qualifying orders come
+    from the two small tables.  Keys exact; revenue within the re-ordering bound of a sum of <= n_g terms."""
+    def host(col, n, dt):
+        a = np.empty(n, dtype=dt)
+        step = 1 << 27
+        for lo in range(0, n, step):  # (pageable destination: slices keep the bounce copies short)
+            m = min(step, n - lo)
+            ctx.d2h(a[lo:lo + m], col.data + lo * 8)
+        return a
+    nc, no, nl = customer_d.NumRows(), orders_d.NumRows(), lineitem_d.NumRows()
+    ck, cs = host(customer_d.columns[0], nc, np.int64), host(customer_d.columns[1], nc, np.int64)
+    ok, oc, od, op = (host(c, no, np.int64) for c in orders_d.columns)
+    good_c = np.zeros(nc, bool)
+    good_c[ck[cs == SEG]] = True
+    o_sel = (od < D) & good_c[oc]
+    date_of = np.full(no, -1, np.int64)
+    prio_of = np.zeros(no, np.int64)
+    date_of[ok[o_sel]] = od[o_sel]
+    prio_of[ok[o_sel]] = op[o_sel]
+    del ck, cs, oc, od, op, good_c, o_sel
+    rev_by, abs_by, cnt_by = np.zeros(no), np.zeros(no), np.zeros(no, np.int64)
+    step = 1 << 26
+    for lo in range(0, nl, step):
+        m = min(step, nl - lo)
+        lk = np.empty(m, np.int64); ls = np.empty(m, np.int64); lp = np.empty(m, np.float64); ld = np.empty(m, np.float64)
+        for a, c in ((lk, 0), (ls, 1), (lp, 2), (ld, 3)):
+            ctx.d2h(a, lineitem_d.columns[c].data + lo * 8)
+        sel = (ls > D) & (date_of[lk] >= 0)
+        k = lk[sel]
+        r = lp[sel] * (1.0 - ld[sel])  # the Projection's expression, IEEE double, same operation order (builtin_arithmetic_vec.go:29,62)
+        rev_by += np.bincount(k, weights=r, minlength=no)
+        abs_by += np.bincount(k, weights=np.abs(r), minlength=no)
+        cnt_by += np.bincount(k, minlength=no)
+    want_keys = np.nonzero(cnt_by)[0]
+    g_key, g_date, g_prio, g_rev = result
+    order = np.argsort(g_key, kind="stable")
+    g_key, g_date, g_prio, g_rev = g_key[order], g_date[order], g_prio[order], g_rev[order]
+    ok_keys = len(g_key) == len(want_keys) and bool((g_key == want_keys).all())
+    ok_cols = ok_keys and bool((g_date == date_of[want_keys]).all()) and bool((g_prio == prio_of[want_keys]).all())
+    tol = 2.0 * cnt_by[want_keys] * 2.0 ** -53 * abs_by[want_keys]
+    err = np.abs(g_rev - rev_by[want_keys]) if ok_keys else np.array([np.inf])
+    ok_rev = ok_keys and bool((err <= tol).all())
+    return {"groups_numpy": int(len(want_keys)), "groups_gpu": int(len(g_key)), "keys_equal": ok_keys, "date_and_priority_equal": ok_cols,
+            "revenue_within_reordering_bound": ok_rev, "max_abs_revenue_error": float(err.max()) if len(err) else 0.0,
+            "sum_revenue_numpy": float(rev_by[want_keys].sum()), "sum_revenue_gpu": float(g_rev.sum()), "ok": bool(ok_keys and ok_cols and ok_rev)}
+
+
 class TimedLib:
     """--trace: wall time per C-ABI entry point (host view: launch + synchronisation + ctypes marshalling)."""
 
@@ -250,6 +300,9 @@ def main():
     classic = "--classic" in sys.argv
     if classic:
         sys.argv.remove("--classic")
+    verify = "--verify" in sys.argv
+    if verify:
+        sys.argv.remove("--verify")
     strseg = "--string-segment" in sys.argv
     if strseg:
         sys.argv.remove("--string-segment")
@@ -284,24 +337,47 @@ def main():
                         t_exec += time.perf_counter() - t2
                         if chk.NumRows() == 0:
                             break
-                        out.append(chk.to_host())
+                        # result on the host: every column of the chunk by DMA into pinned memory (tsq_host_alloc), what the cgo shim's
+                        # Next() hands to its parent — round 4 copied into fresh pageable numpy arrays (page faults + a bounce buffer:
+                        # 108 ms for 420 MB) and unpacked the bitmaps in Python
+                        out.append((chk.NumRows(), [c.to_host_pinned(chk.NumRows()) for c in chk.columns]))
                 finally:
                     exe.Close()
                 ctx.sync()
                 dt = time.perf_counter() - t1
                 if dt < best:
                     best, best_exec = dt, t_exec
-                groups = sum(c.NumRows() for c in out)
+                groups = sum(n for n, _ in out)
+                result_checksum = None
+                if rep == 3:  # the groups of the last run, as a fingerprint a numpy restatement of the query can be checked against
+                    import numpy as np
+                    acc = 0
+                    for n, cols in out:
+                        h = np.zeros(n, np.uint64)
+                        for ci, (d, bm) in enumerate(cols):
+                            v = d[:n].view(np.uint64) if d.dtype.itemsize == 8 else d[:n].astype(np.uint64)
+                            h = (h * np.uint64(0x9E3779B97F4A7C15)) ^ (v + np.uint64(ci))
+                        acc = (acc + int(h.sum(dtype=np.uint64))) & 0xFFFFFFFFFFFFFFFF
+                    result_checksum = acc
+                last_result = None
+                if verify and rep == 3 and not topn:
+                    last_result = tuple(np.concatenate([cols[ci][0][:n] for n, cols in out]) if out else np.zeros(0) for ci in range(4))
+                for n, cols in out:
+                    for d, bm in cols:
+                        ctx.host_release(d)
+                        if bm is not None:
+                            ctx.host_release(bm)
             if trace:
                 tl, ctx.lib = ctx.lib, ctx.lib._lib
                 for k, (n, t) in sorted(tl.acc.items(), key=lambda kv: -kv[1][1]):
                     print("%-28s %5d calls %9.3f ms" % (k, n, t * 1e3), file=sys.stderr)
                 print("last rep: total %.3f ms, in Next %.3f ms" % (dt * 1e3, t_exec * 1e3), file=sys.stderr)
             rows_in = customer.NumRows() + orders.NumRows() + lineitem.NumRows()
-            print(json.dumps({"plan": "round 3 (compacting selections, all join columns, 16 Mi-row batches)" if classic else "round 4 (selection flags into the joins, used columns only, 128 Mi-row batches)",
+            check = verify_against_numpy(ctx, *dev, last_result) if (verify and last_result is not None) else None
+            print(json.dumps({"verified_against_numpy": check, "plan": "round 3 (compacting selections, all join columns, 16 Mi-row batches)" if classic else "round 4 (selection flags into the joins, used columns only, 128 Mi-row batches)",
                               "query": "TPC-H Q3-shaped, device-resident Selection->Join->Join->Projection->HashAgg" + ("->TopN(10)" if topn else "") + (", c_mktsegment = 'BUILDING' on a varchar column" if strseg else ""), "SF": sf, "input_rows": rows_in,
                               "tables": "generated in HBM (tsq_gen_column)" if on_device else "numpy, copied to HBM once",
-                              "groups": groups, "best_s": best, "exec_s_result_in_hbm": best_exec, "input_rows_per_s": rows_in / best,
+                              "groups": groups, "result_checksum": result_checksum, "best_s": best, "exec_s_result_in_hbm": best_exec, "input_rows_per_s": rows_in / best,
                               "input_rows_per_s_result_in_hbm": rows_in / best_exec, "host_table_gen_s": gen_s,
                               "joins": [{"build_rows": int(j.last_stats.build_rows), "probe_rows": int(j.last_stats.probe_rows), "out_rows": int(j.last_stats.out_rows),
                                          "route_of_last_batch": ROUTES.get(j.last_stats.probe_route, "?"), "radix_batches": int(j.last_stats.radix_batches),
