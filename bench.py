@@ -365,7 +365,7 @@ def main():
     if rho_check is not None:
         out["rho_0.5"] = rho_check
     traffic = traffic_part = traffic_src = None
-    for tf in ("traffic_r04.json", "traffic_r03.json"):  # PMC-derived HBM bytes per launch: measured offline (rocprofv3 --pmc passes), committed
+    for tf in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json"):  # PMC-derived HBM bytes per launch: measured offline (rocprofv3 --pmc passes), committed
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             w = tj["workload"]

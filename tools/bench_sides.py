@@ -860,6 +860,106 @@ def extra_two_keys(ctx, abi, _lib, n=250_000_000, ma=1000, mb=100):
             "timing": "HIP events around tsq_agg_push of one device-resident batch + tsq_agg_finish; second of two runs; frac prices 24 B per row"}
 
 
+def extra_expr_kernels(ctx, abi, _lib, n=100_000_000):
+    """SURVEY.md 8(a)-D/E on 1e8 device-resident rows (the only roofline evidence of the expression kernels was round 1's):
+      arith  : (a + b) * 3 - a over BIGINT columns, overflow checked at every node (builtin_arithmetic_vec.go:389,308,95) -> 8 B written per row
+      filter : a < b AND c > 0.5 (VectorizedFilter, chunk_executor.go:196-313; LTInt :186, GTReal :187) -> one selected byte per row
+      strcmp : s < 'k050' on a varchar column of 6..12-byte cells (LTString, builtin_compare_vec_generated.go:65), 2e7 rows
+    each hiprtc-specialised (the default for a plan that runs on large batches); `frac` = the bytes the expression must read and write once /
+    time / 8 TB/s; verified against numpy on the first 2^20 rows."""
+    import numpy as np
+    from tinysql_amd import expression as E
+    lib = ctx.lib
+    res = {}
+    a, b, c, out = (ctx.alloc(n * 8) for _ in range(4))
+    bm, sel = ctx.alloc(n // 8 + 64), ctx.alloc(n + 64)
+    m = 1 << 20
+    try:
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=5, col=0, m=1 << 20), n, a)
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=5, col=1, m=1 << 20), n, b)
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_F64, table=5, col=2), n, c)
+        ctx.sync()
+        ha, hb, hc = np.empty(m, np.int64), np.empty(m, np.int64), np.empty(m, np.float64)
+        ctx.d2h(ha, a); ctx.d2h(hb, b); ctx.d2h(hc, c)
+        cols = (abi.Col * 3)(_dev_col(abi, a, n), _dev_col(abi, b, n), _dev_col(abi, c, n, abi.F64))
+
+        def best_of(fn, reps=3):
+            t = 1e30
+            for _ in range(reps):
+                ctx.timer_start()
+                fn()
+                t = min(t, ctx.timer_stop_ms())
+            return t
+        w = C.c_int64(0)
+        e1 = E.ScalarFunction("minus", E.ScalarFunction("mul", E.ScalarFunction("plus", E.Column(0, abi.I64), E.Column(1, abi.I64)), E.Constant(3)), E.Column(0, abi.I64))
+        ce = E.CompiledExpr(ctx, [e1], jit=abi.JIT_FORCE)
+        try:
+            oc = _dev_col(abi, out, n)
+            oc.null_bitmap = bm
+            fn = lambda: _lib.check(lib.tsq_expr_eval(ce.h, cols, 3, n, None, C.byref(oc), C.byref(w)), ce.h)  # noqa: E731
+            fn()
+            ms = best_of(fn)
+            ho = np.empty(m, np.int64)
+            ctx.d2h(ho, out)
+            res["arith_int64"] = {"ms": ms, "rows_per_s": n / ms * 1e3, "frac": 24.0 * n / ms / 1e6 / 8000.0, "verified": bool((ho == (ha + hb) * 3 - ha).all()), "jit_launches": ce.jit_launches()}
+        finally:
+            ce.close()
+        f = [E.ScalarFunction("lt", E.Column(0, abi.I64), E.Column(1, abi.I64)), E.ScalarFunction("gt", E.Column(2, abi.F64), E.Constant(0.5))]
+        cf = E.CompiledExpr(ctx, f, jit=abi.JIT_FORCE)
+        try:
+            fn = lambda: _lib.check(lib.tsq_filter_eval(cf.h, cols, 3, n, None, sel, None, C.byref(w)), cf.h)  # noqa: E731
+            fn()
+            ms = best_of(fn)
+            hs = np.empty(m, np.uint8)
+            ctx.d2h(hs, sel)
+            res["filter_lt_and_gt"] = {"ms": ms, "rows_per_s": n / ms * 1e3, "frac": 25.0 * n / ms / 1e6 / 8000.0, "verified": bool((hs.astype(bool) == ((ha < hb) & (hc > 0.5))).all())}
+        finally:
+            cf.close()
+    finally:
+        for p in (a, b, c, out, bm, sel):
+            ctx.free(p)
+    # a varchar column: 2e7 cells "k%03d" + up to 7 more bytes (host-built once, copied to HBM)
+    ns = 20_000_000
+    rng = np.random.default_rng(3)
+    ids = rng.integers(0, 100, ns)
+    extra = rng.integers(0, 8, ns)
+    lens = 4 + extra
+    offs = np.zeros(ns + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.full(int(offs[-1]), ord("x"), np.uint8)
+    digits = np.char.zfill(ids.astype(str), 3)
+    head = np.frombuffer(("".join("k" + d for d in digits.tolist())).encode(), np.uint8).reshape(ns, 4)
+    for j in range(4):
+        data[offs[:-1] + j] = head[:, j]
+    d_data, d_offs, d_sel = ctx.alloc(data.size + 64), ctx.alloc((ns + 1) * 8 + 64), ctx.alloc(ns + 64)
+    try:
+        ctx.h2d(d_data, data)
+        ctx.h2d(d_offs, offs)
+        sc = abi.Col()
+        sc.data, sc.offsets, sc.length, sc.elem_size, sc.type, sc.flags = d_data, d_offs, ns, -1, abi.BYTES, abi.COL_DEVICE
+        cs = E.CompiledExpr(ctx, [E.ScalarFunction("lt", E.Column(0, abi.BYTES), E.Constant("k050"))], jit=abi.JIT_FORCE)
+        try:
+            w = C.c_int64(0)
+            fn = lambda: _lib.check(lib.tsq_filter_eval(cs.h, (abi.Col * 1)(sc), 1, ns, None, d_sel, None, C.byref(w)), cs.h)  # noqa: E731
+            fn()
+            t = 1e30
+            for _ in range(3):
+                ctx.timer_start()
+                fn()
+                t = min(t, ctx.timer_stop_ms())
+            hs = np.empty(ns, np.uint8)
+            ctx.d2h(hs, d_sel)
+            res["strcmp_lt_const"] = {"ms": t, "rows_per_s": ns / t * 1e3, "frac": (data.size + 8.0 * ns + ns) / t / 1e6 / 8000.0, "rows": ns,
+                                      "verified": bool((hs.astype(bool) == (ids < 50)).all())}
+        finally:
+            cs.close()
+    finally:
+        for p in (d_data, d_offs, d_sel):
+            ctx.free(p)
+    res["workload"] = "vectorized expression kernels on device-resident columns (1e8 rows; the string compare 2e7), hiprtc-specialised; frac = bytes read + written once / time / 8 TB/s"
+    return res
+
+
 def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
     """(key, thunk) of every side measurement, in the order they run"""
     return (("build_warm", lambda: extra_build_warm(ctx, abi, _lib, bk, bv, nb)),
@@ -878,11 +978,12 @@ def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
             ("agg_two_keys_1000x100", lambda: extra_two_keys(ctx, abi, _lib)),
             ("agg_two_keys_50x20", lambda: extra_two_keys(ctx, abi, _lib, ma=50, mb=20)),
             ("q3_sf100", lambda: extra_q3()),
+            ("expr_kernels", lambda: extra_expr_kernels(ctx, abi, _lib)),
             ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
             ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True)))
 
 
-TRAFFIC_FILE = "traffic_r04.json"
+TRAFFIC_FILE = "traffic_r05.json" if os.path.exists(os.path.join(ROOT, "profiles", "traffic_r05.json")) else "traffic_r04.json"
 TRAFFIC_KERNELS = {
     "c3_agg_1e9_1e6": ["void k_daagg_partition<1024, 8, 1", "void k_agg_da<3, 4096, 1>", "k_daagg_dense_emit", "k_agg_merge("],
     "c3_agg_1e9_1e6_double": ["void k_daagg_partition<1024, 8, 1>", "void k_agg_da<2, 4096, 2>"],

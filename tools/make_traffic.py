@@ -32,6 +32,10 @@ def main():
            "workload": {"probe_rows": 100000000, "build_rows": 100000000, "radix_bits": 11}}
     for key, (name, grid) in HEADLINE.items():
         e = kernels.get("%s [grid %d]" % (name, grid))
+        if e is None:  # (a template parameter added since: match the name up to its parameter list)
+            stem = name.split(">(")[0]
+            cand = [v for k, v in kernels.items() if k.startswith(stem) and k.endswith("[grid %d]" % grid)]
+            e = cand[0] if len(cand) == 1 else None
         if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             out[key] = {"FETCH_SIZE_KiB": e["FETCH_SIZE"], "WRITE_SIZE_KiB": e["WRITE_SIZE"], "launches": e["launches"],
                         "traffic_bytes": int(round((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, -3))}
