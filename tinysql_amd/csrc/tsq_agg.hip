@@ -1033,6 +1033,7 @@ struct tsq_agg {
     bool stream = false;
     DevBuf sa_cnt;             // heads per 2048-row chunk of the current batch
     DevBuf hotkeys;            // packed aggregate: the sampled hot keys of the current batch (tsq_daagg.h DaAggHot)
+    int64_t hot_age = 0;       // batches since the operator started: the hot keys are sampled every fourth
     int64_t stream_batches = 0;
 };
 
@@ -1642,13 +1643,18 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
             ha.keys = a->hotkeys.as<uint32_t>();
             ha.n = ha.keys + TSQ_DAAGG_HOT_MAX;
             ha.table = ha.keys + TSQ_DAAGG_HOT_MAX + 16;
-            TSQ_HIP(h, hipMemsetAsync(ha.table, 0xff, (size_t)TSQ_DAAGG_HOT_TABLE * 4, ctx->stream));  // words: TSQ_DA_NONE
-            TSQ_HIP(h, hipMemsetAsync(ha.table + TSQ_DAAGG_HOT_TABLE, 0, (size_t)TSQ_DAAGG_HOT_TABLE * 4, ctx->stream));
-            hipLaunchKernelGGL(k_daagg_hot_sample, dim3(TSQ_DAAGG_HOT_SAMPLE / 1024), dim3(1024), 0, ctx->stream, ha);
-            TSQ_HIP(h, hipGetLastError());
-            hipLaunchKernelGGL(k_daagg_hot_list, dim3(1), dim3(1024), 0, ctx->stream, ha);
-            TSQ_HIP(h, hipGetLastError());
-            a->st.kernel_launches += 2;
+            // the hot set of a batch serves the next three as well (a stale set costs speed, never a result: a key that is no longer
+            // hot is aggregated in the partition kernel all the same, one that became hot travels like any other key)
+            if (a->hot_age % 4 == 0) {
+                TSQ_HIP(h, hipMemsetAsync(ha.table, 0xff, (size_t)TSQ_DAAGG_HOT_TABLE * 4, ctx->stream));  // words: TSQ_DA_NONE
+                TSQ_HIP(h, hipMemsetAsync(ha.table + TSQ_DAAGG_HOT_TABLE, 0, (size_t)TSQ_DAAGG_HOT_TABLE * 4, ctx->stream));
+                hipLaunchKernelGGL(k_daagg_hot_sample, dim3(TSQ_DAAGG_HOT_SAMPLE / 1024), dim3(1024), 0, ctx->stream, ha);
+                TSQ_HIP(h, hipGetLastError());
+                hipLaunchKernelGGL(k_daagg_hot_list, dim3(1), dim3(1024), 0, ctx->stream, ha);
+                TSQ_HIP(h, hipGetLastError());
+                a->st.kernel_launches += 2;
+            }
+            a->hot_age++;
             hot.keys = ha.keys;
             hot.n = ha.n;
             hot.W = pl.W;

@@ -1,0 +1,241 @@
+// tsq_keyrec.h — COUNT(*) of an inner join on SEVERAL key columns and on STRING keys, partitioned (round 5; device code, included by
+// tsq_join.hip).
+//
+// The reference's own join benchmark keys on (bigint, varstring) — `keyIdx: []int{0, 1}`, executor/benchmark_test.go:352-360 — and that
+// shape took the direct route: a hash of the key cells finds a slot of the 64-bit table in HBM, then the build row's cells are fetched
+// and compared (codec.EqualChunkRow, util/codec/codec.go:363-382).  Per probe row that is one random table line and, on a hit, three to
+// four more random lines (row id, offsets, bytes, the integer cell) over hundreds of megabytes: the address translation of random
+// 64-byte reads bounds it at ~7e9 lines/s — 2.9e9 probe rows/s at 1e7 x 1e7, 90 times below the packed integer route.
+//
+// Here no probe ever leaves the chip's caches.  A row's key cells are packed into a KEY RECORD of 32 bytes — per key column its flag
+// byte (8 / 9 / 5: the classes of tsq_key_word; 2 for a string, as codec.go:233-235) followed by the 8-byte word or by a length byte and
+// the string's bytes — so two rows have equal keys iff their records are equal byte for byte (the flag makes a string never equal a
+// number and an UNSIGNED cell above 2^63 never equal a negative one, codec.go:219-224).  Records that do not fit 32 bytes: a build
+// side that has one keeps the direct route; a probe row that has one cannot match any build row.  NULL key cells drop the row on both
+// sides (hash_table.go:161-163, join.go:344).  Then
+//   k_kr_hist     both sides: records -> 64-bit mix -> partition (top bits); an LDS histogram per workgroup (a contiguous chunk of rows)
+//   k_kr_offsets  + k_kr_scan: a partition's records are contiguous, every workgroup's share inside it too
+//   k_kr_scatter  records written to their places: 32 B per row, two 16-byte stores
+//   k_kr_probe    one workgroup per partition: the build records of the partition (<= TSQ_KR_CAP of them, the host sizes P for half of
+//                 that) go to LDS with an open-addressed index over them, the probe records of the partition stream past: slot walk in
+//                 LDS, the four words compared in LDS.  Duplicate build keys are separate entries (the multimap of rowHashMap).
+// Every byte moves in streams: key cells read once per side and pass, 32 B written and 32 B read per row — ~100 B per row pair instead
+// of ~5 random lines.  Algorithmic bytes per probe row (SURVEY.md 8d pricing for this key shape): the key cells + one 16-byte slot.
+// The build side's records are made once per build (first eligible probe batch) and kept.
+#ifndef TSQ_KEYREC_H
+#define TSQ_KEYREC_H
+
+#define TSQ_KR_BYTES 32
+#define TSQ_KR_CAP 2048      // build records per partition the probe kernel holds in LDS (64 KB) ...
+#define TSQ_KR_SLOTS 4096    // ... and the slots of its index
+#define TSQ_KR_NT 256
+#define TSQ_KR_MAXP 16384    // partitions: one LDS counter each in the hist / scatter passes (64 KB)
+#define TSQ_KR_MAXWG 512     // workgroups of the hist / scatter passes = contiguous row chunks
+#define TSQ_KR_FILL 1400     // build records per partition, on average, the host accepts (Poisson: + 5 sigma stays below TSQ_KR_CAP)
+
+struct KrSrc {
+    tsq_colset cs;
+    int32_t n_keys;
+    int32_t col[TSQ_MAX_KEYS];
+    int64_t nrows;
+};
+struct KrArgs {
+    KrSrc src;
+    uint32_t pbits;          // log2(partitions)
+    uint32_t n_wg;           // workgroups of the pass
+    int64_t rows_per_wg;     // rows [wg * rows_per_wg, + rows_per_wg) belong to workgroup wg (a multiple of TSQ_KR_NT)
+    uint32_t* counts;        // [n_wg][P] rows of (workgroup, partition); after k_kr_offsets: the pair's first place INSIDE its partition
+    uint32_t* pstart;        // [P + 1] first record of every partition; [P] = all records (k_kr_offsets: the totals, then scanned)
+    unsigned long long* rec; // scatter: [records][4] in partition order
+    uint32_t* flags;         // [0] |= 1: a row's record does not fit (build side: the route is off)
+};
+
+// byte x at byte position `at` of the record words (no array indexed by a run-time value: those live in scratch memory)
+__device__ __forceinline__ void kr_put(uint64_t (&w)[4], uint32_t at, uint32_t x) {
+    const uint64_t v = (uint64_t)x << (8u * (at & 7u));
+    const uint32_t q = at >> 3;
+    w[0] |= q == 0 ? v : 0ull;
+    w[1] |= q == 1 ? v : 0ull;
+    w[2] |= q == 2 ? v : 0ull;
+    w[3] |= q == 3 ? v : 0ull;
+}
+// the key record of row `row`: false = the row has no key (a NULL cell) or its cells do not fit 32 bytes (*toolong)
+__device__ __forceinline__ bool kr_record(const KrSrc& s, int64_t row, uint64_t (&w)[4], bool* toolong) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    uint32_t at = 0;
+    *toolong = false;
+    for (int k = 0; k < s.n_keys; k++) {
+        const int c = s.col[k];
+        if (tsq_is_null(s.cs.nulls[c], row)) return false;
+        if (s.cs.type[c] == TSQ_BYTES) {
+            const int64_t o = s.cs.offs[c][row], n = s.cs.offs[c][row + 1] - o;
+            if (n > 255 || at + 2 + (uint32_t)n > TSQ_KR_BYTES) { *toolong = true; return false; }
+            kr_put(w, at++, 2u);  // compactBytesFlag (codec.go:233-235)
+            kr_put(w, at++, (uint32_t)n);
+            const uint8_t* p = (const uint8_t*)s.cs.data[c] + o;
+            for (int64_t i = 0; i < n; i++) kr_put(w, at++, p[i]);
+        } else {
+            if (at + 9 > TSQ_KR_BYTES) { *toolong = true; return false; }
+            uint32_t flag;
+            const uint64_t x = tsq_key_word(s.cs.data[c], s.cs.type[c], row, &flag);
+            kr_put(w, at++, flag);
+#pragma unroll
+            for (int i = 0; i < 8; i++) kr_put(w, at++, (uint32_t)(x >> (8 * i)) & 255u);
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ uint64_t kr_hash(const uint64_t (&w)[4]) {
+    uint64_t h = tsq_splitmix64(w[0] ^ 0x6A09E667F3BCC908ULL);
+    h = tsq_splitmix64(h ^ w[1]);
+    h = tsq_splitmix64(h ^ w[2]);
+    return tsq_splitmix64(h ^ w[3]);
+}
+
+// counts[wg][p]: how many rows of workgroup wg's chunk belong to partition p (an LDS histogram, written out coalesced)
+__global__ void __launch_bounds__(TSQ_KR_NT) k_kr_hist(KrArgs a) {
+    extern __shared__ uint32_t s_hist[];
+    const uint32_t wg = blockIdx.x, P = 1u << a.pbits;
+    for (uint32_t i = threadIdx.x; i < P; i += TSQ_KR_NT) s_hist[i] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)wg * a.rows_per_wg, hi = lo + a.rows_per_wg < a.src.nrows ? lo + a.rows_per_wg : a.src.nrows;
+    uint32_t bad = 0;
+    for (int64_t row = lo + threadIdx.x; row < hi; row += TSQ_KR_NT) {
+        uint64_t w[4];
+        bool toolong;
+        if (!kr_record(a.src, row, w, &toolong)) {
+            bad |= toolong ? 1u : 0u;
+            continue;
+        }
+        const uint32_t p = a.pbits ? (uint32_t)(kr_hash(w) >> (64 - a.pbits)) : 0u;
+        atomicAdd(&s_hist[p], 1u);
+    }
+    if (bad) atomicOr(a.flags, 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < P; i += TSQ_KR_NT) a.counts[(size_t)wg * P + i] = s_hist[i];
+}
+// thread p: the prefix of partition p's counts over the workgroups (coalesced across p), its total -> pstart[p]
+__global__ void __launch_bounds__(256) k_kr_offsets(KrArgs a) {
+    const uint32_t P = 1u << a.pbits;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    uint32_t run = 0;
+    for (uint32_t wg = 0; wg < a.n_wg; wg++) {
+        const uint32_t c = a.counts[(size_t)wg * P + p];
+        a.counts[(size_t)wg * P + p] = run;
+        run += c;
+    }
+    a.pstart[p] = run;
+}
+// exclusive scan of pstart[0 .. P) in place, pstart[P] = total; flags[1] = the largest partition (one workgroup of 1024 threads)
+__global__ void __launch_bounds__(1024) k_kr_scan(uint32_t* v, uint32_t n, uint32_t* flags) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_run, s_max;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_run = 0; s_max = 0; }
+    __syncthreads();
+    uint32_t mx = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = i < n ? v[i] : 0u;
+        mx = c > mx ? c : mx;
+        uint32_t x = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t before = s_run;
+        for (uint32_t w = 0; w < wave; w++) before += s_w[w];
+        if (i < n) v[i] = before + x - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = before + x;
+        __syncthreads();
+    }
+    atomicMax(&s_max, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v[n] = s_run;
+        atomicMax(&flags[1], s_max);
+    }
+}
+// the records to their places: pstart[p] + counts[wg][p] + the row's rank among the workgroup's rows of p (an LDS cursor)
+__global__ void __launch_bounds__(TSQ_KR_NT) k_kr_scatter(KrArgs a) {
+    extern __shared__ uint32_t s_cur[];
+    const uint32_t wg = blockIdx.x, P = 1u << a.pbits;
+    for (uint32_t i = threadIdx.x; i < P; i += TSQ_KR_NT) s_cur[i] = a.pstart[i] + a.counts[(size_t)wg * P + i];
+    __syncthreads();
+    const int64_t lo = (int64_t)wg * a.rows_per_wg, hi = lo + a.rows_per_wg < a.src.nrows ? lo + a.rows_per_wg : a.src.nrows;
+    for (int64_t row = lo + threadIdx.x; row < hi; row += TSQ_KR_NT) {
+        uint64_t w[4];
+        bool toolong;
+        if (!kr_record(a.src, row, w, &toolong)) continue;
+        const uint32_t p = a.pbits ? (uint32_t)(kr_hash(w) >> (64 - a.pbits)) : 0u;
+        const uint64_t pos = atomicAdd(&s_cur[p], 1u);
+        ulonglong2* d = reinterpret_cast<ulonglong2*>(a.rec + pos * 4);
+        d[0] = make_ulonglong2(w[0], w[1]);
+        d[1] = make_ulonglong2(w[2], w[3]);
+    }
+}
+
+struct KrProbeArgs {
+    const unsigned long long* brec;  // build records, partition order
+    const uint32_t* bstart;          // [P + 1] first build record of every partition
+    const unsigned long long* prec;
+    const uint32_t* pstart;
+    uint32_t P;
+    unsigned long long* counters;    // [0] += joined rows
+    uint32_t* flags;                 // [0] |= 2: a partition with more than TSQ_KR_CAP build records (cannot happen after the host's check)
+};
+__global__ void __launch_bounds__(TSQ_KR_NT) k_kr_probe(KrProbeArgs a) {
+    __shared__ unsigned long long s_rec[4][TSQ_KR_CAP];
+    __shared__ uint32_t s_tab[TSQ_KR_SLOTS];
+    __shared__ unsigned long long s_cnt;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    unsigned long long mine = 0;
+    for (uint32_t p = blockIdx.x; p < a.P; p += gridDim.x) {
+        const uint64_t b0 = a.bstart[p], b1 = a.bstart[p + 1];
+        const uint64_t p0 = a.pstart[p], p1 = a.pstart[p + 1];
+        if (b1 == b0 || p1 == p0) continue;  // (block-uniform)
+        uint32_t nb = (uint32_t)(b1 - b0);
+        if (nb > TSQ_KR_CAP) {
+            if (tid == 0) atomicOr(a.flags, 2u);
+            nb = TSQ_KR_CAP;
+        }
+        __syncthreads();  // the previous partition's probes are done with the tables
+        for (uint32_t i = tid; i < TSQ_KR_SLOTS; i += TSQ_KR_NT) s_tab[i] = 0xffffffffu;
+        for (uint32_t i = tid; i < nb; i += TSQ_KR_NT) {
+            const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + i) * 4);
+            const ulonglong2 x = s[0], y = s[1];
+            s_rec[0][i] = x.x; s_rec[1][i] = x.y; s_rec[2][i] = y.x; s_rec[3][i] = y.y;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < nb; i += TSQ_KR_NT) {  // the index: row numbers at the slots their records hash to (low bits: the top ones chose the partition)
+            const uint64_t w[4] = {s_rec[0][i], s_rec[1][i], s_rec[2][i], s_rec[3][i]};
+            uint32_t slot = (uint32_t)kr_hash(w) & (TSQ_KR_SLOTS - 1);
+            while (atomicCAS(&s_tab[slot], 0xffffffffu, i) != 0xffffffffu) slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
+        }
+        __syncthreads();
+        for (uint64_t r = p0 + tid; r < p1; r += TSQ_KR_NT) {
+            const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
+            const ulonglong2 x = s[0], y = s[1];
+            const uint64_t w[4] = {x.x, x.y, y.x, y.y};
+            uint32_t slot = (uint32_t)kr_hash(w) & (TSQ_KR_SLOTS - 1);
+            for (;;) {
+                const uint32_t i = s_tab[slot];
+                if (i == 0xffffffffu) break;
+                if (s_rec[0][i] == w[0] && s_rec[1][i] == w[1] && s_rec[2][i] == w[2] && s_rec[3][i] == w[3]) mine++;
+                slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
+            }
+        }
+    }
+    mine = wave_sum_u64(mine);
+    __syncthreads();
+    if ((tid & 63u) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (tid == 0 && s_cnt) atomicAdd(&a.counters[0], s_cnt);
+}
+
+#endif

@@ -9,7 +9,7 @@ import re
 import sys
 
 HEADLINE = {  # bench.py's names of the headline step's kernels -> (kernel name as rocprofv3 prints it, grid)
-    "k_da_partition2<512,8,4,true>": ("void k_da_partition2<512, 8, 4, true, unsigned short>(DaSrc, DaDomain, DaStore)", 262144),
+    "k_da_partition2<512,8,4,true>": ("void k_da_partition2<512, 8, 4, true, unsigned short, false>(DaSrc, DaDomain, DaStore)", 262144),  # (last parameter: rows carry a NULL bitmap)
     "k_da_probe_count<512,uint16_t>": ("void k_da_probe_count<512, unsigned short, false, false, false>(DaProbeArgs)", 262144),
 }
 
@@ -33,8 +33,9 @@ def main():
     for key, (name, grid) in HEADLINE.items():
         e = kernels.get("%s [grid %d]" % (name, grid))
         if e is None:  # (a template parameter added since: match the name up to its parameter list)
-            stem = name.split(">(")[0]
-            cand = [v for k, v in kernels.items() if k.startswith(stem) and k.endswith("[grid %d]" % grid)]
+            # (round 4's summaries print k_da_partition2 without its last template parameter)
+            stem = name.split(">(")[0].rsplit(",", 1)[0]
+            cand = [v for k, v in kernels.items() if k.startswith(stem + ">(") and k.endswith("[grid %d]" % grid)]
             e = cand[0] if len(cand) == 1 else None
         if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             out[key] = {"FETCH_SIZE_KiB": e["FETCH_SIZE"], "WRITE_SIZE_KiB": e["WRITE_SIZE"], "launches": e["launches"],
