@@ -137,6 +137,7 @@ enum {
     TSQ_KNOB_AGG_NARROW_CELLS = 25,  /* 0: the argument column of the packed aggregate always travels as 8-byte cells */
     TSQ_KNOB_DAAGG_PART2 = 26,       /* partition kernel of the packed aggregate with a dense state: 0 = 1024 threads, one workgroup per CU; 1 = two 512-thread workgroups per CU for narrow argument cells (default); 2 = for 8-byte cells too */
     TSQ_KNOB_DAAGG_HOT = 27,         /* 0: the packed aggregate does not sample the batch for hot keys (their rows then travel through the partitioned store and its overflow store) */
+    TSQ_KNOB_KEYREC = 28,            /* 0: COUNT(*) joins on several key columns / string keys never take the key-record route (csrc/tsq_keyrec.h) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -834,6 +835,7 @@ typedef struct tsq_stats {
 #define TSQ_ROUTE_RADIX_L2   1   /* radix partition, table slices through the XCD's L2 */
 #define TSQ_ROUTE_RADIX_LDS  2   /* radix partition, LDS copies of the table slices (64-bit table words) */
 #define TSQ_ROUTE_PACKED     3   /* packed keys: 2-byte entries against direct-address images in LDS */
+#define TSQ_ROUTE_KEYREC     4   /* key records (ABI 6): several key columns / string keys as 32-byte records, hash-partitioned, matched in LDS (csrc/tsq_keyrec.h) */
 tsq_status tsq_join_stats(tsq_join* j, tsq_stats* out);
 tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out);
 

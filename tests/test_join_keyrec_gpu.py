@@ -1,0 +1,139 @@
+"""GPU parity: the KEY-RECORD route (csrc/tsq_keyrec.h, round 5) — COUNT(*) of an inner join on several key columns / string keys,
+partitioned by a mix of a 32-byte record of the key cells and matched in LDS — against the oracle's HashJoinExec restatement (count of
+its joined rows) and against the direct route.  The route is FORCED and asserted through tsq_stats.probe_route;
+key equality is the reference's codec.EqualChunkRow (util/codec/codec.go:363-382): same flag, same bytes, cell by cell — a string
+never equals a number, "a" never equals "a\\0", an UNSIGNED cell above 2^63 never equals a negative BIGINT, float32 1.0 equals double 1.0.
+The key shape of the reference's own join benchmark, keyIdx {0, 1} = (bigint, varstring) (executor/benchmark_test.go:352-360), is the
+first case."""
+import numpy as np
+import pytest
+
+from tinysql_amd import _abi as abi
+from tinysql_amd.chunk import Chunk, Column, StrColumn
+
+from . import gpu_helpers as G
+from . import helpers as H
+
+pytestmark = pytest.mark.gpu
+FORCE, OFF = abi.RADIX_FORCE, abi.RADIX_OFF
+
+
+def _count(ctx, cfg, build, probe, radix=FORCE, chunk_rows=1 << 22, knobs=None):
+    stats = []
+    with ctx.knobs(**(knobs or {})):
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=chunk_rows, count_only=True, radix=radix, stats_out=stats)
+    return got, stats[0]
+
+
+def _strs(rng, n, pool, null_frac=0.03, max_len=12):
+    words = [bytes(rng.integers(97, 123, int(rng.integers(0, max_len + 1)), dtype=np.uint8)) for _ in range(pool)]
+    ids = rng.integers(0, pool, n)
+    return StrColumn([None if rng.random() < null_frac else words[i] for i in ids.tolist()])
+
+
+def test_bigint_and_varstring_keys_the_reference_benchmark_shape(ctx, orc):
+    rng = np.random.default_rng(101)
+    nb, npr = 60_000, 90_000
+    build = Chunk([Column(abi.I64, rng.integers(0, 300, nb), rng.random(nb) > 0.02), _strs(rng, nb, 400, max_len=16), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, rng.integers(0, 330, npr), rng.random(npr) > 0.02), _strs(rng, npr, 440, max_len=16), Column(abi.F64, rng.random(npr))])
+    # the two sides draw their strings from different pools: equal words only by chance of the generator -> reseed the probe pool from the build's
+    words = [w for w in build.columns[1].values() if w is not None]
+    pw = [None if rng.random() < 0.03 else (words[int(i)] if rng.random() < 0.7 else b"zz" + words[int(i)][:10]) for i in rng.integers(0, len(words), npr)]
+    probe = Chunk([probe.columns[0], StrColumn(pw), probe.columns[2]])
+    cfg = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    got, st = _count(ctx, cfg, build, probe)
+    assert st.probe_route == abi.ROUTE_KEYREC and got == want > 1000
+    # the direct route says the same (knob KEYREC = 0)
+    got0, st0 = _count(ctx, cfg, build, probe, knobs={"KEYREC": 0})
+    assert st0.probe_route == abi.ROUTE_DIRECT and got0 == want
+    # ... and so do several probe batches through one handle (the build side's records are made once)
+    cfg3 = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_INNER, 1, probe_batch_rows=25_000)
+    got3, st3 = _count(ctx, cfg3, build, probe, chunk_rows=5_000)
+    assert st3.probe_route == abi.ROUTE_KEYREC and st3.radix_batches >= 3 and got3 == want
+
+
+@pytest.mark.parametrize("shape", ["string", "string,string", "u64,i64", "f32,f64,string"])
+def test_key_shapes_and_the_flag_rules_of_EqualChunkRow(ctx, orc, shape):
+    rng = np.random.default_rng(len(shape))
+    nb, npr = 20_000, 30_000
+
+    def col(kind, n, side):
+        if kind == "string":
+            base = [b"", b"a", b"a\x00", b"ab", b"abcdefgh", b"abcdefghi", b"abcdefgX", b"k" * 12, None]
+            return StrColumn([base[i] for i in rng.integers(0, len(base), n)])
+        if kind == "u64":  # the build side's cells above 2^63 (flag 9) must not meet the probe side's negative BIGINTs with the same bits (flag 8)
+            v = rng.integers(0, 50, n).astype(np.uint64)
+            v[rng.random(n) < 0.3] += np.uint64(1 << 63)
+            return Column(abi.U64, v)
+        if kind == "i64":
+            return Column(abi.I64, rng.integers(-5, 5, n), rng.random(n) > 0.05)
+        if kind == "f32":
+            return Column(abi.F32, rng.integers(0, 6, n).astype(np.float32) * 0.5)
+        return Column(abi.F64, rng.integers(0, 6, n).astype(np.float64) * 0.5)
+    kinds = shape.split(",")
+    build = Chunk([col(k, nb, 0) for k in kinds] + [Column(abi.I64, np.arange(nb))])
+    if shape == "u64,i64":  # probe: the SAME bit patterns as BIGINT (signed) in the first column -> only cells below 2^63 may match
+        pv = build.columns[0].data[rng.integers(0, nb, npr)].view(np.int64)
+        probe = Chunk([Column(abi.I64, pv), col("i64", npr, 1), Column(abi.I64, np.arange(npr))])
+    elif shape == "f32,f64,string":  # float32 1.5 joins double 1.5 (codec.go:288-289: float32 is widened before it is hashed / compared)
+        probe = Chunk([col("f64", npr, 1), col("f32", npr, 1), col("string", npr, 1), Column(abi.I64, np.arange(npr))])
+    else:
+        probe = Chunk([col(k, npr, 1) for k in kinds] + [Column(abi.I64, np.arange(npr))])
+    keys = list(range(len(kinds)))
+    cfg = H.join_cfg(probe.types(), build.types(), keys, keys, abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    got, st = _count(ctx, cfg, build, probe, knobs={"DA_MIN_BUILD_ROWS": 1 << 40})  # (keep the integer shapes away from the packed route: this test is about the records)
+    # few distinct keys with thousands of rows each: a partition may not fit LDS -> another route (the direct one for string shapes), same count
+    if "string" in shape:
+        assert st.probe_route in (abi.ROUTE_KEYREC, abi.ROUTE_DIRECT)
+    assert got == want > 0
+    got0, _ = _count(ctx, cfg, build, probe, knobs={"DA_MIN_BUILD_ROWS": 1 << 40, "KEYREC": 0})
+    assert got0 == want
+
+
+def test_records_that_do_not_fit_and_partitions_that_do_not_fit(ctx, orc):
+    rng = np.random.default_rng(7)
+    nb, npr = 30_000, 40_000
+    ids_b, ids_p = rng.integers(0, 5000, nb), rng.integers(0, 6000, npr)
+    short = lambda i: b"k%05d" % i  # noqa: E731
+    # (1) a PROBE row whose cells need more than 32 bytes cannot equal any build row: dropped, the route stays
+    build = Chunk([Column(abi.I64, ids_b % 7), StrColumn([short(i) for i in ids_b.tolist()]), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, ids_p % 7), StrColumn([short(i) if i % 5 else short(i) * 8 for i in ids_p.tolist()]), Column(abi.I64, np.arange(npr))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    got, st = _count(ctx, cfg, build, probe)
+    assert st.probe_route == abi.ROUTE_KEYREC and got == want > 0
+    # (2) a BUILD row that does not fit: the whole join keeps the direct route
+    build2 = Chunk([build.columns[0], StrColumn([short(i) if i % 1000 else short(i) * 8 for i in ids_b.tolist()]), build.columns[2]])
+    want2 = orc.hash_join(cfg, build2, probe).NumRows()
+    got2, st2 = _count(ctx, cfg, build2, probe)
+    assert st2.probe_route == abi.ROUTE_DIRECT and got2 == want2
+    # (3) one key with 5000 build rows: its partition exceeds the LDS tables -> direct route, exact
+    hot = np.where(rng.random(nb) < 0.17, 4242, ids_b)
+    build3 = Chunk([Column(abi.I64, hot % 7), StrColumn([short(i) for i in hot.tolist()]), build.columns[2]])
+    want3 = orc.hash_join(cfg, build3, probe).NumRows()
+    got3, st3 = _count(ctx, cfg, build3, probe)
+    assert st3.probe_route == abi.ROUTE_DIRECT and got3 == want3
+    # (4) empty sides and all-NULL keys
+    none = Chunk([Column(abi.I64, np.zeros(100, np.int64), np.zeros(100, bool)), StrColumn([b"x"] * 100), Column(abi.I64, np.arange(100))])
+    assert _count(ctx, cfg, none, probe)[0] == 0 and _count(ctx, cfg, build, none)[0] == 0
+
+
+def test_auto_takes_the_route_at_scale_and_counts_like_numpy(ctx):
+    """1e6 x 1.5e6 rows on (bigint, 16-byte varstring), AUTO (no forcing): every build key (k, 's%015d' % k) once, probe keys uniform over twice
+    the build domain -> the joined rows are the probe rows with k < N_b (numpy).  The 1e7 x 1e7 form is bench.py's
+    two_key_bigint_string_count."""
+    rng = np.random.default_rng(5)
+    nb, npr = 1_000_000, 1_500_000
+
+    def table(keys):
+        return Chunk([Column(abi.I64, keys), StrColumn([b"s%015d" % k for k in keys.tolist()]), Column(abi.I64, np.arange(len(keys)))])
+    bk = rng.permutation(nb).astype(np.int64)
+    pk = rng.integers(0, 2 * nb, npr)
+    build, probe = table(bk), table(pk)
+    cfg = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_INNER, 1)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_KEYREC
+    assert got == int(np.count_nonzero(pk < nb))

@@ -22,6 +22,7 @@
 #include "tsq_jointable.h"
 #include "tsq_buildpart.h"
 #include "tsq_ldsprobe.h"
+#include "tsq_keyrec.h"
 #include "tsq_dajoin.h"
 
 #include <chrono>
@@ -782,6 +783,10 @@ struct tsq_join {
     double last_sampled_hit_ratio = -1.0;  // of the last probe batch whose materialising route was chosen by a sample (k_da_sample)
     int wide_state = 0;               // several integer key columns of 29..63 bits: COUNT(*) through a single-key child join (wide_prepare)
     tsq_join* wide = nullptr;
+    // key records (tsq_keyrec.h): COUNT(*) on several key columns / string keys whose cells fit 32 bytes, partitioned
+    int kr_state = 0;                 // 0: not tried, 1: the build side's records are in place, -1: not usable for this build side
+    uint32_t kr_pbits = 0;
+    DevBuf kr_brec, kr_bstart, kr_counts, kr_prec, kr_pstart, kr_flags;
     int64_t div0_packed = 0;          // division-by-zero warnings of conditions evaluated over materialised batches (da_post_conditions)
     bool shared = false;
     int64_t shared_image_bytes = 0, shared_usable_local = 0;
@@ -2980,6 +2985,108 @@ tsq_status materialise_pairs(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, i
 // picks its route (bit cells, the 64-bit LDS route, ...) as for any 64-bit key.  A row that cannot match (a NULL key cell, a probe cell
 // outside its field) composes to ~0: the child compares BIGINT UNSIGNED with BIGINT, where cells >= 2^63 never match (codec.go:219-224).
 tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev);
+// ---------------------------------------------------------------- key-record route (host side; tsq_keyrec.h)
+bool kr_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF || !j->multi || j->kr_state < 0 || tsq_knob(j->ctx, TSQ_KNOB_KEYREC, 1) == 0) return false;
+    if (!j->count_only || j->checksum || j->general_cfg || selected_dev || j->never_match || j->ordered) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
+    const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
+    if (nb <= 0 || nb > (int64_t)TSQ_KR_MAXP * TSQ_KR_FILL) return false;  // (larger build sides: the partitions would not fit the LDS tables)
+    if (j->radix_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (1 << 18) && nb >= (1 << 18);
+}
+// hist -> offsets -> scan [-> check] -> scatter of one side.  `check`: read the flags after the scan (a synchronisation): *ok = every
+// record fits and no partition holds more than TSQ_KR_CAP of them
+tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, int64_t nrows, uint32_t pbits, DevBuf& counts, DevBuf& pstart, DevBuf& rec,
+                   bool check, bool* ok) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const uint32_t P = 1u << pbits;
+    KrArgs a;
+    memset(&a, 0, sizeof a);
+    a.src.cs = cs;
+    a.src.n_keys = j->ks.n_keys;
+    for (int k = 0; k < j->ks.n_keys; k++) a.src.col[k] = key_cols[k];
+    a.src.nrows = nrows;
+    a.pbits = pbits;
+    const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;
+    a.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(TSQ_KR_MAXWG, chunks));
+    a.rows_per_wg = ((chunks + a.n_wg - 1) / a.n_wg) * TSQ_KR_NT;
+    TSQ_TRY(counts.reserve(ctx, h, (size_t)a.n_wg * P * 4 + 64));
+    TSQ_TRY(pstart.reserve(ctx, h, ((size_t)P + 1) * 4 + 64));
+    TSQ_TRY(rec.reserve(ctx, h, (size_t)nrows * TSQ_KR_BYTES + 64));
+    TSQ_TRY(j->kr_flags.reserve(ctx, h, 64));
+    a.counts = counts.as<uint32_t>();
+    a.pstart = pstart.as<uint32_t>();
+    a.rec = rec.as<unsigned long long>();
+    a.flags = j->kr_flags.as<uint32_t>();
+    if (check) TSQ_HIP(h, hipMemsetAsync(a.flags, 0, 16, ctx->stream));
+    const size_t lds = (size_t)P * 4;
+    TSQ_HIP(h, hipFuncSetAttribute((const void*)k_kr_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TSQ_HIP(h, hipFuncSetAttribute((const void*)k_kr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_kr_hist, dim3(a.n_wg), dim3(TSQ_KR_NT), lds, ctx->stream, a);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_kr_offsets, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, a);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_kr_scan, dim3(1), dim3(1024), 0, ctx->stream, a.pstart, P, a.flags);
+    TSQ_HIP(h, hipGetLastError());
+    if (check) {
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 40, a.flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        const uint32_t* f = (const uint32_t*)(ctx->pinned + 40);
+        *ok = (f[0] & 1u) == 0 && f[1] <= TSQ_KR_CAP;
+        if (!*ok) return TSQ_OK;
+    }
+    hipLaunchKernelGGL(k_kr_scatter, dim3(a.n_wg), dim3(TSQ_KR_NT), lds, ctx->stream, a);
+    TSQ_HIP(h, hipGetLastError());
+    j->st.kernel_launches += 4;
+    return TSQ_OK;
+}
+tsq_status kr_prepare(tsq_join* j) {
+    if (j->kr_state) return TSQ_OK;
+    j->kr_state = -1;
+    const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
+    uint32_t pbits = 0;
+    while (((int64_t)1 << pbits) * 1024 < nb && (1u << pbits) < TSQ_KR_MAXP) pbits++;  // ~1024 build records per partition
+    tsq_colset bcs;
+    tsq_fill_colset(bcs, j->bcols);
+    bool ok = false;
+    const tsq_status s = kr_pass(j, bcs, j->ks.bidx, nb, pbits, j->kr_counts, j->kr_bstart, j->kr_brec, true, &ok);
+    if (s != TSQ_OK || !ok) {  // a key that does not fit a record, or a partition too large for LDS (one key with thousands of rows): the other routes keep this join
+        for (DevBuf* b : {&j->kr_counts, &j->kr_bstart, &j->kr_brec}) b->release();
+        return s;
+    }
+    j->kr_pbits = pbits;
+    j->kr_state = 1;
+    return TSQ_OK;
+}
+tsq_status kr_count_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    bool ok = true;
+    TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok));
+    KrProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.brec = j->kr_brec.as<unsigned long long>();
+    pa.bstart = j->kr_bstart.as<uint32_t>();
+    pa.prec = j->kr_prec.as<unsigned long long>();
+    pa.pstart = j->kr_pstart.as<uint32_t>();
+    pa.P = 1u << j->kr_pbits;
+    pa.counters = j->counters.as<unsigned long long>();
+    pa.flags = j->kr_flags.as<uint32_t>();
+    const int grid = (int)std::min<uint32_t>(pa.P, (uint32_t)ctx->num_cus);
+    hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+    j->have_probe_ev = true;
+    j->st.kernel_launches++;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)j->kr_pbits;
+    j->st.probe_route = TSQ_ROUTE_KEYREC;
+    return TSQ_OK;
+}
+
 bool wide_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || !j->multi || !da_multi_ok(j) || j->wide_state < 0) return false;
     if (!j->count_only || j->checksum || j->general_cfg || selected_dev || j->never_match) return false;
@@ -3124,6 +3231,10 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     if (wide_count_eligible(j, nrows, selected_dev)) {  // ... or, with fields of 29..63 bits, a single-key child join on the composite
         TSQ_TRY(wide_prepare(j));
         if (j->wide_state == 1) return wide_count_batch(j, pcs, nrows);
+    }
+    if (kr_count_eligible(j, nrows, selected_dev)) {  // ... or key records: any key columns (strings included) whose cells fit 32 bytes
+        TSQ_TRY(kr_prepare(j));
+        if (j->kr_state == 1) return kr_count_batch(j, pcs, nrows);
     }
     // ---- materialising packed routes.  Which one: when most probe rows join, the probe columns travel with the entries (K5f + K4e);
     // a SELECTIVE batch (few rows join: a sample of its keys against the images tells, k_da_sample) is better served by (probe row,
@@ -4094,6 +4205,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->da_ckey.release();
     j->rckey.release();
     for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_coarse_c, &j->da_pstart_c, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
+    for (DevBuf* b : {&j->kr_brec, &j->kr_bstart, &j->kr_counts, &j->kr_prec, &j->kr_pstart, &j->kr_flags}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
         j->da_bsorted[c].release();
         j->da_bsorted_nn[c].release();

@@ -28,7 +28,8 @@
 #define TSQ_KR_BYTES 32
 #define TSQ_KR_CAP 2048      // build records per partition the probe kernel holds in LDS (64 KB) ...
 #define TSQ_KR_SLOTS 4096    // ... and the slots of its index
-#define TSQ_KR_NT 256
+#define TSQ_KR_NT 1024     // threads of the hist / scatter passes: two workgroups per CU (64 KB of LDS each), 32 waves to hide the offsets -> bytes chain
+#define TSQ_KR_PNT 1024     // threads of the probe kernel: one workgroup per CU (80 KB of LDS), 16 waves to keep the record stream in flight
 #define TSQ_KR_MAXP 16384    // partitions: one LDS counter each in the hist / scatter passes (64 KB)
 #define TSQ_KR_MAXWG 512     // workgroups of the hist / scatter passes = contiguous row chunks
 #define TSQ_KR_FILL 1400     // build records per partition, on average, the host accepts (Poisson: + 5 sigma stays below TSQ_KR_CAP)
@@ -50,14 +51,25 @@ struct KrArgs {
     uint32_t* flags;         // [0] |= 1: a row's record does not fit (build side: the route is off)
 };
 
-// byte x at byte position `at` of the record words (no array indexed by a run-time value: those live in scratch memory)
-__device__ __forceinline__ void kr_put(uint64_t (&w)[4], uint32_t at, uint32_t x) {
-    const uint64_t v = (uint64_t)x << (8u * (at & 7u));
-    const uint32_t q = at >> 3;
-    w[0] |= q == 0 ? v : 0ull;
-    w[1] |= q == 1 ? v : 0ull;
-    w[2] |= q == 2 ? v : 0ull;
-    w[3] |= q == 3 ? v : 0ull;
+// `nb` (1..8) low bytes of x at byte position `at` of the record words (no array indexed by a run-time value: those live in scratch
+// memory; a piece may straddle two words)
+__device__ __forceinline__ void kr_put(uint64_t (&w)[4], uint32_t at, uint64_t x, uint32_t nb) {
+    if (nb < 8) x &= (1ull << (8u * nb)) - 1ull;
+    const uint32_t q = at >> 3, sh = 8u * (at & 7u);
+    const uint64_t lo = x << sh, hi = sh ? x >> (64u - sh) : 0ull;
+    w[0] |= q == 0 ? lo : 0ull;
+    w[1] |= q == 1 ? lo : (q == 0 ? hi : 0ull);
+    w[2] |= q == 2 ? lo : (q == 1 ? hi : 0ull);
+    w[3] |= q == 3 ? lo : (q == 2 ? hi : 0ull);
+}
+// 8 bytes from any address: the two aligned words around it, funnel-shifted (the second word is read only when the bytes reach into it)
+__device__ __forceinline__ uint64_t kr_load8(const uint8_t* p, uint32_t need) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint64_t* q = (const uint64_t*)(a & ~(uintptr_t)7);
+    const uint32_t sh = 8u * (uint32_t)(a & 7u);
+    uint64_t v = q[0] >> sh;
+    if (sh && (a & 7u) + need > 8u) v |= q[1] << (64u - sh);
+    return v;
 }
 // the key record of row `row`: false = the row has no key (a NULL cell) or its cells do not fit 32 bytes (*toolong)
 __device__ __forceinline__ bool kr_record(const KrSrc& s, int64_t row, uint64_t (&w)[4], bool* toolong) {
@@ -70,17 +82,21 @@ __device__ __forceinline__ bool kr_record(const KrSrc& s, int64_t row, uint64_t 
         if (s.cs.type[c] == TSQ_BYTES) {
             const int64_t o = s.cs.offs[c][row], n = s.cs.offs[c][row + 1] - o;
             if (n > 255 || at + 2 + (uint32_t)n > TSQ_KR_BYTES) { *toolong = true; return false; }
-            kr_put(w, at++, 2u);  // compactBytesFlag (codec.go:233-235)
-            kr_put(w, at++, (uint32_t)n);
+            kr_put(w, at, 2ull | ((uint64_t)n << 8), 2);  // compactBytesFlag (codec.go:233-235), then the length
+            at += 2;
             const uint8_t* p = (const uint8_t*)s.cs.data[c] + o;
-            for (int64_t i = 0; i < n; i++) kr_put(w, at++, p[i]);
+            for (uint32_t i = 0; i < (uint32_t)n; i += 8) {
+                const uint32_t m = (uint32_t)n - i < 8u ? (uint32_t)n - i : 8u;
+                kr_put(w, at + i, kr_load8(p + i, m), m);
+            }
+            at += (uint32_t)n;
         } else {
             if (at + 9 > TSQ_KR_BYTES) { *toolong = true; return false; }
             uint32_t flag;
             const uint64_t x = tsq_key_word(s.cs.data[c], s.cs.type[c], row, &flag);
-            kr_put(w, at++, flag);
-#pragma unroll
-            for (int i = 0; i < 8; i++) kr_put(w, at++, (uint32_t)(x >> (8 * i)) & 255u);
+            kr_put(w, at, flag, 1);
+            kr_put(w, at + 1, x, 8);
+            at += 9;
         }
     }
     return true;
@@ -120,10 +136,15 @@ __global__ void __launch_bounds__(256) k_kr_offsets(KrArgs a) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     uint32_t run = 0;
-    for (uint32_t wg = 0; wg < a.n_wg; wg++) {
-        const uint32_t c = a.counts[(size_t)wg * P + p];
-        a.counts[(size_t)wg * P + p] = run;
-        run += c;
+    for (uint32_t w0 = 0; w0 < a.n_wg; w0 += 16) {  // 16 loads in flight: one round trip per 16 workgroups instead of one per workgroup
+        uint32_t c[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[i] = w0 + i < a.n_wg ? a.counts[(size_t)(w0 + i) * P + p] : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (w0 + i < a.n_wg) a.counts[(size_t)(w0 + i) * P + p] = run;
+            run += c[i];
+        }
     }
     a.pstart[p] = run;
 }
@@ -188,7 +209,7 @@ struct KrProbeArgs {
     unsigned long long* counters;    // [0] += joined rows
     uint32_t* flags;                 // [0] |= 2: a partition with more than TSQ_KR_CAP build records (cannot happen after the host's check)
 };
-__global__ void __launch_bounds__(TSQ_KR_NT) k_kr_probe(KrProbeArgs a) {
+__global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
     __shared__ unsigned long long s_rec[4][TSQ_KR_CAP];
     __shared__ uint32_t s_tab[TSQ_KR_SLOTS];
     __shared__ unsigned long long s_cnt;
@@ -205,20 +226,20 @@ __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_probe(KrProbeArgs a) {
             nb = TSQ_KR_CAP;
         }
         __syncthreads();  // the previous partition's probes are done with the tables
-        for (uint32_t i = tid; i < TSQ_KR_SLOTS; i += TSQ_KR_NT) s_tab[i] = 0xffffffffu;
-        for (uint32_t i = tid; i < nb; i += TSQ_KR_NT) {
+        for (uint32_t i = tid; i < TSQ_KR_SLOTS; i += TSQ_KR_PNT) s_tab[i] = 0xffffffffu;
+        for (uint32_t i = tid; i < nb; i += TSQ_KR_PNT) {
             const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + i) * 4);
             const ulonglong2 x = s[0], y = s[1];
             s_rec[0][i] = x.x; s_rec[1][i] = x.y; s_rec[2][i] = y.x; s_rec[3][i] = y.y;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < nb; i += TSQ_KR_NT) {  // the index: row numbers at the slots their records hash to (low bits: the top ones chose the partition)
+        for (uint32_t i = tid; i < nb; i += TSQ_KR_PNT) {  // the index: row numbers at the slots their records hash to (low bits: the top ones chose the partition)
             const uint64_t w[4] = {s_rec[0][i], s_rec[1][i], s_rec[2][i], s_rec[3][i]};
             uint32_t slot = (uint32_t)kr_hash(w) & (TSQ_KR_SLOTS - 1);
             while (atomicCAS(&s_tab[slot], 0xffffffffu, i) != 0xffffffffu) slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
         }
         __syncthreads();
-        for (uint64_t r = p0 + tid; r < p1; r += TSQ_KR_NT) {
+        for (uint64_t r = p0 + tid; r < p1; r += TSQ_KR_PNT) {
             const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
             const ulonglong2 x = s[0], y = s[1];
             const uint64_t w[4] = {x.x, x.y, y.x, y.y};
