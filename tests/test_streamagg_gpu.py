@@ -114,6 +114,54 @@ def test_stream_agg_random_single_key_vs_oracle(ctx, orc, nkeys, chunk_rows):
     _check_stream_vs_oracle(ctx, orc, chk, [0], AGGS_1K, list(range(1, 11)), [11, 12, 13], chunk_rows=chunk_rows)
 
 
+@pytest.mark.parametrize("lanes", [1, 0])
+@pytest.mark.parametrize("aggset", ["sum_count_max", "avg_min_real", "merge_modes"])
+def test_stream_agg_long_and_short_runs_per_lane_accumulators(ctx, orc, aggset, lanes):
+    """plans with <= 4 reducing aggregates keep the open run's partial results in registers, one per lane (k_sa_update_lanes; knob
+    STREAMAGG_LANES = 0: every 64-row step is reduced across the lanes, k_sa_update) — runs from 1 to 9000 rows, so that steps
+    without a head, steps that start with one, steps with several, stripes (4096 rows) that end inside a run and NULL arguments all occur"""
+    rng = np.random.default_rng(len(aggset) + lanes)
+    lens = np.concatenate([rng.integers(1, 4, 3000), rng.integers(50, 200, 300), rng.integers(3000, 9000, 30), rng.integers(1, 70, 2000)])
+    rng.shuffle(lens)
+    keys = np.repeat(np.arange(len(lens), dtype=np.int64) * 7 - 1000, lens)
+    n = len(keys)
+    knn = np.ones(n, bool)
+    knn[:int(lens[0])] = False  # the first run is the NULL group
+    chk = Chunk([Column(abi.I64, keys, knn), H.random_column(rng, abi.I64, n, 0.2, lo=-10**9, hi=10**9), H.random_column(rng, abi.F64, n, 0.1),
+                 Column(abi.I64, np.where(np.arange(n) % 2 == 0, 1 << 60, -(1 << 60)) + rng.integers(-1000, 1000, n))])  # (cells beyond 2^56: the 128-bit scans; alternating signs keep every running sum inside BIGINT)
+    types = chk.types()
+    if aggset == "sum_count_max":
+        aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, 1, abi.I64), (abi.AGG_MAX, 2, abi.F64), (abi.AGG_SUM, 3, abi.I64)]
+        exact, real = [1, 2, 3], []
+    elif aggset == "avg_min_real":
+        aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_AVG, 1, abi.I64), (abi.AGG_MIN, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 2, abi.F64)]
+        exact, real = [1, 2, 3], [4]
+    else:  # Partial1 over the rows, then Final over the partial rows (still ordered by key): COUNT / SUM / AVG merge their partial columns
+        aggs = None
+    with ctx.knobs(STREAMAGG_LANES=lanes, AGG_BATCH_ROWS=100_000):
+        if aggs is not None:
+            cfg = H.agg_cfg(types, [0], aggs)
+            want = orc.hash_agg(cfg, chk, 4, 4)
+            got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), stream=True, chunk_rows=4096)
+            if aggset == "sum_count_max":  # SUM(column 3): the 128-bit path (cells up to 2^62): exact too
+                exact = exact + [4]
+            _match_by_key(got, want, [0], exact, real, group_tols(chk, 0, aggs, real) if real else 0.0)
+            assert [H.canon(r[0]) for r in got.rows()] == [k[0] for k in _first_appearance_order(chk, [0])]
+        else:
+            paggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_COUNT, 1, abi.I64, abi.MODE_PARTIAL1), (abi.AGG_SUM, 1, abi.I64, abi.MODE_PARTIAL1),
+                     (abi.AGG_AVG, 1, abi.I64, abi.MODE_PARTIAL1)]
+            pt = out_types_for(paggs)
+            half = n // 2
+            parts = concat([G.run_agg(ctx, H.agg_cfg(types, [0], paggs), chk.slice(0, half), pt, stream=True),
+                            G.run_agg(ctx, H.agg_cfg(types, [0], paggs), chk.slice(half, n), pt, stream=True)], pt)  # (the run cut at `half` yields two partial rows of one key, adjacent)
+            faggs = [(abi.AGG_FIRSTROW, 0, abi.I64, abi.MODE_FINAL), (abi.AGG_COUNT, 1, abi.I64, abi.MODE_FINAL), (abi.AGG_SUM, 2, abi.I64, abi.MODE_FINAL),
+                     (abi.AGG_AVG, 3, abi.I64, abi.MODE_FINAL, 4)]
+            fin = G.run_agg(ctx, H.agg_cfg(pt, [0], faggs), parts, out_types_for([(a[0], a[1], a[2]) for a in faggs]), stream=True)
+            caggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_COUNT, 1, abi.I64), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_AVG, 1, abi.I64)]
+            comp = orc.hash_agg(H.agg_cfg(types, [0], caggs), chk, 1, 1)
+            assert H.rows_equal_unordered(fin, comp)
+
+
 def test_stream_agg_groups_continue_across_device_batches(ctx, orc):
     """host chunks are aggregated in device batches (knob: 4096 rows here): a group that straddles two batches is ONE group — the
     open group's key cells stay in the table and row 0 of the next batch is compared with them"""

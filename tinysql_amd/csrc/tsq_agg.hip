@@ -1846,7 +1846,48 @@ tsq_status stream_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
         TSQ_TRY(stream_grow(a, std::max<uint64_t>(need, a->tb.cap * 2)));
         fill_agg_table(a, a->tb, sa.u.t);
     }
-    hipLaunchKernelGGL(k_sa_update, dim3(grid), dim3(TSQ_SA_NT), 0, ctx->stream, sa);
+    // plans whose reducing aggregates (COUNT / SUM / AVG / MAX / MIN of fixed-width arguments) number <= 4 keep the open run's partial
+    // results in registers, one per lane (k_sa_update_lanes); the others — MAX / MIN of strings, more aggregates — reduce every step
+    SaRed red;
+    memset(&red, 0, sizeof red);
+    bool lanes_ok = true;
+    for (int i = 0; i < a->plan.n_aggs; i++) {
+        const tsq_agg_func& f = a->plan.f[i];
+        if (f.func == TSQ_AGG_FIRSTROW) continue;
+        if ((f.func == TSQ_AGG_MAX || f.func == TSQ_AGG_MIN) && f.arg_type == TSQ_BYTES) { lanes_ok = false; break; }
+        if (red.n == 4) { lanes_ok = false; break; }
+        red.agg[red.n++] = i;
+    }
+    if (lanes_ok && red.n > 0 && tsq_knob(ctx, TSQ_KNOB_STREAMAGG_LANES, 1) != 0) {
+        uint32_t kinds = 0;  // SA_K_* of the reducing aggregates, 4 bits each: the commonest plans have their own instantiation
+        for (int q = 0; q < red.n; q++) {
+            const tsq_agg_func& f = a->plan.f[red.agg[q]];
+            const bool real = f.arg_type == TSQ_F32 || f.arg_type == TSQ_F64;
+            const uint32_t k = f.func == TSQ_AGG_COUNT ? SA_K_COUNT : (f.func == TSQ_AGG_SUM || f.func == TSQ_AGG_AVG) ? (real ? SA_K_SUMR : SA_K_SUMI)
+                               : f.func == TSQ_AGG_MAX ? SA_K_MAX : SA_K_MIN;
+            kinds |= k << (4 * q);
+        }
+#define TSQ_SA_LAUNCH(NA, K) hipLaunchKernelGGL((k_sa_update_lanes<NA, K>), dim3(grid), dim3(TSQ_SA_NT), 0, ctx->stream, sa, red)
+        switch (red.n * 0x10000u + kinds) {
+            case 0x10001u: TSQ_SA_LAUNCH(1, 0x1u); break;    // COUNT
+            case 0x10002u: TSQ_SA_LAUNCH(1, 0x2u); break;    // SUM / AVG (BIGINT)
+            case 0x10003u: TSQ_SA_LAUNCH(1, 0x3u); break;    // SUM / AVG (DOUBLE)
+            case 0x20012u: TSQ_SA_LAUNCH(2, 0x12u); break;   // SUM(BIGINT), COUNT — the C3 plan
+            case 0x20013u: TSQ_SA_LAUNCH(2, 0x13u); break;   // SUM(DOUBLE), COUNT
+            case 0x30412u: TSQ_SA_LAUNCH(3, 0x412u); break;  // SUM(BIGINT), COUNT, MAX
+            case 0x30413u: TSQ_SA_LAUNCH(3, 0x413u); break;
+            default:
+                switch (red.n) {
+                    case 1: TSQ_SA_LAUNCH(1, 0u); break;
+                    case 2: TSQ_SA_LAUNCH(2, 0u); break;
+                    case 3: TSQ_SA_LAUNCH(3, 0u); break;
+                    default: TSQ_SA_LAUNCH(4, 0u); break;
+                }
+        }
+#undef TSQ_SA_LAUNCH
+    } else {
+        hipLaunchKernelGGL(k_sa_update, dim3(grid), dim3(TSQ_SA_NT), 0, ctx->stream, sa);
+    }
     TSQ_HIP(h, hipGetLastError());
     a->groups = (int64_t)need;
     a->st.kernel_launches += 3;

@@ -820,6 +820,8 @@ public:
         if (n == 0) done_ = true;
     }
     void Close() override { destroy(); Executor::Close(); }
+protected:
+    tsq_agg* h_ = nullptr;
 private:
     static Schema types(const std::vector<AggFuncDesc>& fs) {
         Schema s;
@@ -832,7 +834,19 @@ private:
     tsq_agg_cfg cfg_;
     std::vector<AggFuncDesc> funcs_;
     bool defaultRow_ = false, prepared_ = false, sawInput_ = false, done_ = false;
-    tsq_agg* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- StreamAggExec (the north star names it; the reference has only the
+// plan name, planner/core/cbo_test.go:200-212): the child delivers rows ORDERED by the group-by columns, the groups come out in that
+// order, FIRST_ROW is the first row of its group.  Same aggregate functions, modes and default row as HashAggExec — the same
+// tsq_agg handle with tsq_agg_set_stream (csrc/tsq_streamagg.h).
+class StreamAggExec : public HashAggExec {
+public:
+    using HashAggExec::HashAggExec;
+    void Open() override {
+        HashAggExec::Open();
+        check(tsq_agg_set_stream(h_, 1), h_);
+    }
 };
 
 // ---------------------------------------------------------------- SortExec / TopNExec (executor/sort.go:27-318)

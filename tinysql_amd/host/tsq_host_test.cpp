@@ -40,6 +40,16 @@ static Rows render(const std::vector<Chunk>& chunks) {
     std::sort(out.begin(), out.end());
     return out;
 }
+static Rows render_in_order(const std::vector<Chunk>& chunks) {  // (StreamAggExec / SortExec: the order is part of the contract)
+    Rows out;
+    for (auto& chk : chunks)
+        for (int64_t r = 0; r < chk.NumRows(); r++) {
+            std::string s;
+            for (int c = 0; c < chk.NumCols(); c++) s += (c ? " " : "") + cell(chk.columns[c], r);
+            out.push_back(s);
+        }
+    return out;
+}
 static void expect(const char* name, Rows got, Rows want) {
     std::sort(want.begin(), want.end());
     if (got == want) { g_pass++; printf("PASS %s (%zu rows)\n", name, got.size()); return; }
@@ -184,6 +194,20 @@ int main() {
                                          {TSQ_AGG_MAX, 1, TSQ_I64}, {TSQ_AGG_MIN, 1, TSQ_I64}});
         expect("func_{count,sum,avg,max_min}_test.go: 0..4 -> 5 10 2 4 0; all-NULL group; NULL group", render(Drain(&agg)),
                {"1 5 10 2 4 0", "2 0 <nil> <nil> <nil> <nil>", "<nil> 1 7 7 7 7"});
+    }
+    // ---- StreamAggExec: the same cases on key-ordered input, groups IN INPUT ORDER (NULL group first: the order the child delivers)
+    {
+        Chunk t = table_i64(2, {NIL, 7, 1, 0, 1, 1, 1, 2, 1, 3, 1, 4, 2, NIL, 2, NIL});
+        MockDataSource src(&ctx, t);
+        StreamAggExec agg(&ctx, &src, {0}, {{TSQ_AGG_FIRSTROW, 0, TSQ_I64}, {TSQ_AGG_COUNT, 1, TSQ_I64}, {TSQ_AGG_SUM, 1, TSQ_I64}, {TSQ_AGG_AVG, 1, TSQ_I64},
+                                           {TSQ_AGG_MAX, 1, TSQ_I64}, {TSQ_AGG_MIN, 1, TSQ_I64}});
+        Rows got = render_in_order(Drain(&agg));
+        expect_true("StreamAggExec (planner/core/cbo_test.go:200-212 StreamAgg): func_*_test.go values, groups in input order",
+                    got == Rows{"<nil> 1 7 7 7 7", "1 5 10 2 4 0", "2 0 <nil> <nil> <nil> <nil>"});
+        Chunk e(Schema{TSQ_I64});
+        MockDataSource empty(&ctx, e);
+        StreamAggExec agg0(&ctx, &empty, {}, {{TSQ_AGG_COUNT, -1, TSQ_I64}, {TSQ_AGG_SUM, 0, TSQ_I64}});
+        expect("StreamAggExec: aggregate.go:572-574 default row on empty input", render(Drain(&agg0)), {"0 <nil>"});
     }
     // ---- SUM(int64) overflow is an error, not a wrap (func_sum.go:133-137, types/overflow.go:33-40)
     {

@@ -960,6 +960,97 @@ def extra_expr_kernels(ctx, abi, _lib, n=100_000_000):
     return res
 
 
+def extra_stream_agg(ctx, abi, _lib, n=100_000_000, groups=100_000):
+    """StreamAggExec (round 5, csrc/tsq_streamagg.h): SELECT k, SUM(v), COUNT(*), MAX(v) GROUP BY k over 1e8 rows that arrive ORDERED by k —
+    the child is a SortExec (tsq_sort_* over the device-resident (k, v) columns, untimed here; its own line is tools/bench_sort.py).
+    `ms` = tsq_agg_push of the ordered columns + tsq_agg_finish; `frac` = the bytes the operator must read once (16 B per row) / time /
+    8 TB/s (it reads the key column twice: heads are counted, then scanned).  Verified against numpy: groups in key order, every count
+    and sum exact."""
+    import numpy as np
+    lib = ctx.lib
+    k, v, ks, vs = (ctx.alloc(n * 8) for _ in range(4))
+    try:
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=6, col=0, m=groups), n, k)
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=6, col=1, m=1000), n, v)
+        sc = abi.SortCfg()
+        sc.n_cols, sc.n_keys, sc.limit_offset, sc.limit_count, sc.max_chunk_size = 2, 1, 0, -1, 1024
+        sc.col_types[0] = sc.col_types[1] = abi.I64
+        sc.key_col[0], sc.key_desc[0] = 0, 0
+        sh = C.c_void_p()
+        _lib.check(lib.tsq_sort_create(ctx.h, C.byref(sc), C.byref(sh)), ctx.h)
+        try:
+            _lib.check(lib.tsq_sort_push(sh, (abi.Col * 2)(_dev_col(abi, k, n), _dev_col(abi, v, n)), 2, n), sh)
+            ctx.timer_start()
+            _lib.check(lib.tsq_sort_finish(sh), sh)
+            sort_ms = ctx.timer_stop_ms()
+            out = (abi.Col * 2)(_dev_col(abi, ks, n), _dev_col(abi, vs, n))
+            bm = [ctx.alloc(n // 8 + 64) for _ in range(2)]
+            for i in range(2):
+                out[i].null_bitmap = bm[i]
+            nn, eos = C.c_int64(0), C.c_int32(0)
+            _lib.check(lib.tsq_sort_pull(sh, out, 2, n, C.byref(nn), C.byref(eos)), sh)
+            for b in bm:
+                ctx.free(b)
+            assert nn.value == n
+        finally:
+            lib.tsq_sort_destroy(sh)
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 1
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.I64
+        cfg.n_input_cols = 2
+        cfg.input_types[0] = cfg.input_types[1] = abi.I64
+        cfg.n_aggs = 4
+        for i, (f, col) in enumerate([(abi.AGG_FIRSTROW, 0), (abi.AGG_SUM, 1), (abi.AGG_COUNT, -1), (abi.AGG_MAX, 1)]):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, abi.I64
+        runs = []
+        for run in range(2):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                _lib.check(lib.tsq_agg_set_stream(h, 1), h)
+                ctx.sync()
+                ctx.timer_start()
+                _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, ks, n), _dev_col(abi, vs, n)), 2, n), h)
+                _lib.check(lib.tsq_agg_finish(h), h)
+                runs.append(ctx.timer_stop_ms())
+                if run == 1:
+                    ng = C.c_int64(0)
+                    _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                    g = ng.value
+                    d = [ctx.alloc(max(g, 1) * 8) for _ in range(4)]
+                    dbm = [ctx.alloc(g // 8 + 64) for _ in range(4)]
+                    oc = (abi.Col * 4)()
+                    for i in range(4):
+                        oc[i] = _dev_col(abi, d[i], g)
+                        oc[i].null_bitmap = dbm[i]
+                    gn, eos = C.c_int64(0), C.c_int32(0)
+                    _lib.check(lib.tsq_agg_pull(h, oc, 4, g, C.byref(gn), C.byref(eos)), h)
+                    host = [np.empty(g, np.int64) for _ in range(4)]
+                    for i in range(4):
+                        ctx.d2h(host[i], d[i])
+                    for p in d + dbm:
+                        ctx.free(p)
+            finally:
+                lib.tsq_agg_destroy(h)
+        hk, hv = np.empty(n, np.int64), np.empty(n, np.int64)
+        ctx.d2h(hk, k)
+        ctx.d2h(hv, v)
+        cnt = np.bincount(hk, minlength=groups)
+        sm = np.bincount(hk, weights=hv.astype(np.float64), minlength=groups).astype(np.int64)  # (sums < 2^53: exact in doubles)
+        present = np.nonzero(cnt)[0]
+        ok = bool(g == len(present) and (host[0] == present).all() and (host[2] == cnt[present]).all() and (host[1] == sm[present]).all())
+        order = np.argsort(hk, kind="stable")  # MAX per group from a sorted host copy
+        sk, sv = hk[order], hv[order]
+        starts = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]])
+        ok = ok and bool((host[3] == np.maximum.reduceat(sv, starts)).all())
+    finally:
+        for p in (k, v, ks, vs):
+            ctx.free(p)
+    ms = runs[-1]
+    return {"workload": "SELECT k, SUM(v), COUNT(*), MAX(v) GROUP BY k over 1e8 rows ordered by k (1e5 groups), StreamAggExec; the SortExec below it: %.2f ms, untimed" % sort_ms,
+            "ms": ms, "rows_per_s": n / ms * 1e3, "groups": int(g), "frac": 16.0 * n / ms / 1e6 / 8000.0, "verified": ok, "first_run_ms": runs[0], "sort_ms": sort_ms}
+
+
 def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
     """(key, thunk) of every side measurement, in the order they run"""
     return (("build_warm", lambda: extra_build_warm(ctx, abi, _lib, bk, bv, nb)),
@@ -979,6 +1070,7 @@ def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
             ("agg_two_keys_50x20", lambda: extra_two_keys(ctx, abi, _lib, ma=50, mb=20)),
             ("q3_sf100", lambda: extra_q3()),
             ("expr_kernels", lambda: extra_expr_kernels(ctx, abi, _lib)),
+            ("stream_agg_1e8_ordered", lambda: extra_stream_agg(ctx, abi, _lib)),
             ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
             ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True)))
 
