@@ -109,8 +109,8 @@ def test_records_that_do_not_fit_and_partitions_that_do_not_fit(ctx, orc):
     want2 = orc.hash_join(cfg, build2, probe).NumRows()
     got2, st2 = _count(ctx, cfg, build2, probe)
     assert st2.probe_route == abi.ROUTE_DIRECT and got2 == want2
-    # (3) one key with 5000 build rows: its partition exceeds the LDS tables -> direct route, exact
-    hot = np.where(rng.random(nb) < 0.17, 4242, ids_b)
+    # (3) one key with 18 000 build rows: its partition exceeds the index in LDS (12 288 records) -> direct route, exact
+    hot = np.where(rng.random(nb) < 0.6, 4242, ids_b)
     build3 = Chunk([Column(abi.I64, hot % 7), StrColumn([short(i) for i in hot.tolist()]), build.columns[2]])
     want3 = orc.hash_join(cfg, build3, probe).NumRows()
     got3, st3 = _count(ctx, cfg, build3, probe)

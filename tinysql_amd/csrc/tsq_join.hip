@@ -3047,7 +3047,7 @@ tsq_status kr_prepare(tsq_join* j) {
     j->kr_state = -1;
     const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
     uint32_t pbits = 0;
-    while (((int64_t)1 << pbits) * 1024 < nb && (1u << pbits) < TSQ_KR_MAXP) pbits++;  // ~1024 build records per partition
+    while (((int64_t)1 << pbits) * TSQ_KR_FILL < nb && (1u << pbits) < TSQ_KR_MAXP) pbits++;  // ~8192 build records per partition (half of them at the power of two above)
     tsq_colset bcs;
     tsq_fill_colset(bcs, j->bcols);
     bool ok = false;
@@ -3075,7 +3075,7 @@ tsq_status kr_count_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     pa.P = 1u << j->kr_pbits;
     pa.counters = j->counters.as<unsigned long long>();
     pa.flags = j->kr_flags.as<uint32_t>();
-    const int grid = (int)std::min<uint32_t>(pa.P, (uint32_t)ctx->num_cus);
+    const int grid = (int)std::min<uint32_t>(pa.P, (uint32_t)ctx->num_cus * 2);
     hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));

@@ -7,7 +7,7 @@
 // four more random lines (row id, offsets, bytes, the integer cell) over hundreds of megabytes: the address translation of random
 // 64-byte reads bounds it at ~7e9 lines/s — 2.9e9 probe rows/s at 1e7 x 1e7, 90 times below the packed integer route.
 //
-// Here no probe ever leaves the chip's caches.  A row's key cells are packed into a KEY RECORD of 32 bytes — per key column its flag
+// Here no probe leaves the chip's caches.  A row's key cells are packed into a KEY RECORD of 32 bytes — per key column its flag
 // byte (8 / 9 / 5: the classes of tsq_key_word; 2 for a string, as codec.go:233-235) followed by the 8-byte word or by a length byte and
 // the string's bytes — so two rows have equal keys iff their records are equal byte for byte (the flag makes a string never equal a
 // number and an UNSIGNED cell above 2^63 never equal a negative one, codec.go:219-224).  Records that do not fit 32 bytes: a build
@@ -16,9 +16,9 @@
 //   k_kr_hist     both sides: records -> 64-bit mix -> partition (top bits); an LDS histogram per workgroup (a contiguous chunk of rows)
 //   k_kr_offsets  + k_kr_scan: a partition's records are contiguous, every workgroup's share inside it too
 //   k_kr_scatter  records written to their places: 32 B per row, two 16-byte stores
-//   k_kr_probe    one workgroup per partition: the build records of the partition (<= TSQ_KR_CAP of them, the host sizes P for half of
-//                 that) go to LDS with an open-addressed index over them, the probe records of the partition stream past: slot walk in
-//                 LDS, the four words compared in LDS.  Duplicate build keys are separate entries (the multimap of rowHashMap).
+//   k_kr_probe    one workgroup per partition: an open-addressed index over the partition's build records (<= TSQ_KR_CAP: 18-bit tag +
+//                 record number per entry) in LDS, the records themselves in the XCD's L2; the probe records stream past: slot walk in
+//                 LDS, on a tag match the four words compared.  Duplicate build keys are separate entries (the multimap of rowHashMap).
 // Every byte moves in streams: key cells read once per side and pass, 32 B written and 32 B read per row — ~100 B per row pair instead
 // of ~5 random lines.  Algorithmic bytes per probe row (SURVEY.md 8d pricing for this key shape): the key cells + one 16-byte slot.
 // The build side's records are made once per build (first eligible probe batch) and kept.
@@ -26,13 +26,13 @@
 #define TSQ_KEYREC_H
 
 #define TSQ_KR_BYTES 32
-#define TSQ_KR_CAP 2048      // build records per partition the probe kernel holds in LDS (64 KB) ...
-#define TSQ_KR_SLOTS 4096    // ... and the slots of its index
-#define TSQ_KR_NT 1024     // threads of the hist / scatter passes: two workgroups per CU (64 KB of LDS each), 32 waves to hide the offsets -> bytes chain
-#define TSQ_KR_PNT 1024     // threads of the probe kernel: one workgroup per CU (80 KB of LDS), 16 waves to keep the record stream in flight
+#define TSQ_KR_CAP 12288     // build records of one partition the probe kernel indexes in LDS ...
+#define TSQ_KR_SLOTS 16384   // ... with one 4-byte entry each (18-bit tag | 14-bit record number): 64 KB, two workgroups per CU
+#define TSQ_KR_NT 1024       // threads of the hist / scatter passes
+#define TSQ_KR_PNT 512       // threads of the probe kernel
 #define TSQ_KR_MAXP 16384    // partitions: one LDS counter each in the hist / scatter passes (64 KB)
 #define TSQ_KR_MAXWG 512     // workgroups of the hist / scatter passes = contiguous row chunks
-#define TSQ_KR_FILL 1400     // build records per partition, on average, the host accepts (Poisson: + 5 sigma stays below TSQ_KR_CAP)
+#define TSQ_KR_FILL 8192     // build records per partition, on average (the host picks P for it; + 45 sigma stays below TSQ_KR_CAP)
 
 struct KrSrc {
     tsq_colset cs;
@@ -209,8 +209,12 @@ struct KrProbeArgs {
     unsigned long long* counters;    // [0] += joined rows
     uint32_t* flags;                 // [0] |= 2: a partition with more than TSQ_KR_CAP build records (cannot happen after the host's check)
 };
+// One workgroup per partition.  The build records of the partition stay where the scatter pass put them (a contiguous window of
+// <= 384 KB: it is read once to build the index and then served by the XCD's L2); LDS holds an open-addressed index over them — per
+// record one entry (tag = 18 bits of the mix that neither chose the partition nor the slot, 14-bit record number).  A probe record
+// walks the slots from its home until an empty one; on a tag match the build record's four words are compared (a false tag match
+// costs one more 32-byte read, 2^-18 per slot looked at).  Duplicate build keys are separate entries (the multimap of rowHashMap).
 __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
-    __shared__ unsigned long long s_rec[4][TSQ_KR_CAP];
     __shared__ uint32_t s_tab[TSQ_KR_SLOTS];
     __shared__ unsigned long long s_cnt;
     const uint32_t tid = threadIdx.x;
@@ -225,29 +229,34 @@ __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
             if (tid == 0) atomicOr(a.flags, 2u);
             nb = TSQ_KR_CAP;
         }
-        __syncthreads();  // the previous partition's probes are done with the tables
+        __syncthreads();  // the previous partition's probes are done with the index
         for (uint32_t i = tid; i < TSQ_KR_SLOTS; i += TSQ_KR_PNT) s_tab[i] = 0xffffffffu;
+        __syncthreads();
         for (uint32_t i = tid; i < nb; i += TSQ_KR_PNT) {
             const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + i) * 4);
             const ulonglong2 x = s[0], y = s[1];
-            s_rec[0][i] = x.x; s_rec[1][i] = x.y; s_rec[2][i] = y.x; s_rec[3][i] = y.y;
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < nb; i += TSQ_KR_PNT) {  // the index: row numbers at the slots their records hash to (low bits: the top ones chose the partition)
-            const uint64_t w[4] = {s_rec[0][i], s_rec[1][i], s_rec[2][i], s_rec[3][i]};
-            uint32_t slot = (uint32_t)kr_hash(w) & (TSQ_KR_SLOTS - 1);
-            while (atomicCAS(&s_tab[slot], 0xffffffffu, i) != 0xffffffffu) slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
+            const uint64_t w[4] = {x.x, x.y, y.x, y.y};
+            const uint64_t h = kr_hash(w);
+            const uint32_t entry = (((uint32_t)(h >> 14) & 0x3ffffu) << 14) | i;
+            uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
+            while (atomicCAS(&s_tab[slot], 0xffffffffu, entry) != 0xffffffffu) slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
         }
         __syncthreads();
         for (uint64_t r = p0 + tid; r < p1; r += TSQ_KR_PNT) {
             const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
             const ulonglong2 x = s[0], y = s[1];
             const uint64_t w[4] = {x.x, x.y, y.x, y.y};
-            uint32_t slot = (uint32_t)kr_hash(w) & (TSQ_KR_SLOTS - 1);
+            const uint64_t h = kr_hash(w);
+            const uint32_t tag = (uint32_t)(h >> 14) & 0x3ffffu;
+            uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
             for (;;) {
-                const uint32_t i = s_tab[slot];
-                if (i == 0xffffffffu) break;
-                if (s_rec[0][i] == w[0] && s_rec[1][i] == w[1] && s_rec[2][i] == w[2] && s_rec[3][i] == w[3]) mine++;
+                const uint32_t e = s_tab[slot];
+                if (e == 0xffffffffu) break;
+                if ((e >> 14) == tag) {
+                    const ulonglong2* bq = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + (e & 0x3fffu)) * 4);
+                    const ulonglong2 bx = bq[0], by = bq[1];
+                    if (bx.x == w[0] && bx.y == w[1] && by.x == w[2] && by.y == w[3]) mine++;
+                }
                 slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
             }
         }
