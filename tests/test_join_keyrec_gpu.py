@@ -137,3 +137,34 @@ def test_auto_takes_the_route_at_scale_and_counts_like_numpy(ctx):
     got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, stats_out=stats)
     assert stats[0].probe_route == abi.ROUTE_KEYREC
     assert got == int(np.count_nonzero(pk < nb))
+
+
+def test_materialising_join_on_bigint_and_varstring_keys(ctx, orc):
+    """the same records, joined ROWS: (probe row, build row) pairs out of the LDS index, then the usual column gather — the reference's
+    BenchmarkHashJoinExec materialises its joined chunks too (benchmark_test.go:352-360).  String keys, string payload, NULLs, duplicate
+    build keys; two probe batches through one handle."""
+    rng = np.random.default_rng(202)
+    nb, npr = 8_000, 20_000
+    words = [b"w%03d" % i for i in range(120)] + [b"", b"a", b"a\x00"]
+    bw = [None if rng.random() < 0.03 else words[int(i)] for i in rng.integers(0, len(words), nb)]
+    pw = [None if rng.random() < 0.03 else words[int(i)] for i in rng.integers(0, len(words), npr)]
+    build = Chunk([Column(abi.I64, rng.integers(0, 40, nb), rng.random(nb) > 0.02), StrColumn(bw), Column(abi.F64, rng.random(nb), rng.random(nb) > 0.1),
+                   StrColumn([None if i % 11 == 0 else b"pay%d" % i for i in range(nb)])])
+    probe = Chunk([Column(abi.I64, rng.integers(0, 44, npr), rng.random(npr) > 0.02), StrColumn(pw), Column(abi.I64, np.arange(npr))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_INNER, 1, probe_batch_rows=12_000)
+    want = orc.hash_join(cfg, build, probe)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=4096, pull_rows=4096, radix=FORCE, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_KEYREC and stats[0].radix_batches >= 2
+    assert got.NumRows() == want.NumRows() > 10_000 and H.rows_equal_unordered(got, want)
+    # the build side as the LEFT child (inner_child 0): output = left || right = build || probe columns
+    cfg0 = H.join_cfg(build.types(), probe.types(), [0, 1], [0, 1], abi.JOIN_INNER, 0)
+    want0 = orc.hash_join(cfg0, build, probe)
+    stats = []
+    got0 = G.run_join(ctx, cfg0, build, probe, chunk_rows=1 << 20, radix=FORCE, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_KEYREC and H.rows_equal_unordered(got0, want0)
+    # an outer join keeps the direct route (the records know no miss rows)
+    cfgo = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_LEFT_OUTER, 1)
+    stats = []
+    goto = G.run_join(ctx, cfgo, build, probe, chunk_rows=1 << 20, radix=FORCE, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_DIRECT and H.rows_equal_unordered(goto, orc.hash_join(cfgo, build, probe))

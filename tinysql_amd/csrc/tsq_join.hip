@@ -786,7 +786,7 @@ struct tsq_join {
     // key records (tsq_keyrec.h): COUNT(*) on several key columns / string keys whose cells fit 32 bytes, partitioned
     int kr_state = 0;                 // 0: not tried, 1: the build side's records are in place, -1: not usable for this build side
     uint32_t kr_pbits = 0;
-    DevBuf kr_brec, kr_bstart, kr_counts, kr_prec, kr_pstart, kr_flags;
+    DevBuf kr_brec, kr_bstart, kr_counts, kr_prec, kr_pstart, kr_flags, kr_bids, kr_pids, kr_pcnt;
     int64_t div0_packed = 0;          // division-by-zero warnings of conditions evaluated over materialised batches (da_post_conditions)
     bool shared = false;
     int64_t shared_image_bytes = 0, shared_usable_local = 0;
@@ -2998,7 +2998,7 @@ bool kr_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected
 // hist -> offsets -> scan [-> check] -> scatter of one side.  `check`: read the flags after the scan (a synchronisation): *ok = every
 // record fits and no partition holds more than TSQ_KR_CAP of them
 tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, int64_t nrows, uint32_t pbits, DevBuf& counts, DevBuf& pstart, DevBuf& rec,
-                   bool check, bool* ok) {
+                   bool check, bool* ok, DevBuf* ids = nullptr) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const uint32_t P = 1u << pbits;
@@ -3016,6 +3016,10 @@ tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, i
     TSQ_TRY(pstart.reserve(ctx, h, ((size_t)P + 1) * 4 + 64));
     TSQ_TRY(rec.reserve(ctx, h, (size_t)nrows * TSQ_KR_BYTES + 64));
     TSQ_TRY(j->kr_flags.reserve(ctx, h, 64));
+    if (ids) {
+        TSQ_TRY(ids->reserve(ctx, h, (size_t)nrows * 4 + 64));
+        a.ids = ids->as<uint32_t>();
+    }
     a.counts = counts.as<uint32_t>();
     a.pstart = pstart.as<uint32_t>();
     a.rec = rec.as<unsigned long long>();
@@ -3051,8 +3055,9 @@ tsq_status kr_prepare(tsq_join* j) {
     tsq_colset bcs;
     tsq_fill_colset(bcs, j->bcols);
     bool ok = false;
-    const tsq_status s = kr_pass(j, bcs, j->ks.bidx, nb, pbits, j->kr_counts, j->kr_bstart, j->kr_brec, true, &ok);
-    if (s != TSQ_OK || !ok) {  // a key that does not fit a record, or a partition too large for LDS (one key with thousands of rows): the other routes keep this join
+    const tsq_status s = kr_pass(j, bcs, j->ks.bidx, nb, pbits, j->kr_counts, j->kr_bstart, j->kr_brec, true, &ok, &j->kr_bids);
+    if (s != TSQ_OK || !ok) {
+        j->kr_bids.release();  // a key that does not fit a record, or a partition too large for LDS (one key with thousands of rows): the other routes keep this join
         for (DevBuf* b : {&j->kr_counts, &j->kr_bstart, &j->kr_brec}) b->release();
         return s;
     }
@@ -3085,6 +3090,64 @@ tsq_status kr_count_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     j->st.radix_bits = (int32_t)j->kr_pbits;
     j->st.probe_route = TSQ_ROUTE_KEYREC;
     return TSQ_OK;
+}
+
+// the MATERIALISING form: the joined (probe row, build row) pairs of the records, then the usual column gather (k_gather_cols, var-len
+// columns included) — inner joins without conditions; the reference's BenchmarkHashJoinExec shape (benchmark_test.go:352-360) with its rows
+bool kr_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
+    if (j->radix_mode == TSQ_RADIX_OFF || !j->multi || j->kr_state < 0 || tsq_knob(j->ctx, TSQ_KNOB_KEYREC, 1) == 0) return false;
+    if (j->count_only || j->general_cfg || selected_dev || j->never_match || j->ordered) return false;
+    if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
+    const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
+    if (nb <= 0 || nb > (int64_t)TSQ_KR_MAXP * TSQ_KR_FILL || nb > 0xffffffffLL) return false;
+    if (j->radix_mode == TSQ_RADIX_FORCE) return true;
+    return nrows >= (1 << 18) && nb >= (1 << 18);
+}
+tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    bool ok = true;
+    TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok, &j->kr_pids));
+    KrProbeArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.brec = j->kr_brec.as<unsigned long long>();
+    pa.bstart = j->kr_bstart.as<uint32_t>();
+    pa.prec = j->kr_prec.as<unsigned long long>();
+    pa.pstart = j->kr_pstart.as<uint32_t>();
+    pa.P = 1u << j->kr_pbits;
+    pa.counters = j->counters.as<unsigned long long>();
+    pa.flags = j->kr_flags.as<uint32_t>();
+    pa.bids = j->kr_bids.as<uint32_t>();
+    pa.pids = j->kr_pids.as<uint32_t>();
+    // sizing launch: joined rows per partition; their exclusive scan = every partition's first output row
+    TSQ_TRY(j->kr_pcnt.reserve(ctx, h, ((size_t)pa.P + 1) * 8 + 64));
+    pa.part_cnt = j->kr_pcnt.as<unsigned long long>();
+    TSQ_HIP(h, hipMemsetAsync(pa.part_cnt, 0, ((size_t)pa.P + 1) * 8, ctx->stream));  // (partitions without rows on one side are skipped by the kernel)
+    const int grid = (int)std::min<uint32_t>(pa.P, (uint32_t)ctx->num_cus * 2);
+    hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);  // pairs == nullptr
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_kr_scan64, dim3(1), dim3(1024), 0, ctx->stream, pa.part_cnt, pa.P);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 41, pa.part_cnt + pa.P, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    const int64_t out_rows = (int64_t)ctx->pinned[41];
+    j->st.kernel_launches += 2;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)j->kr_pbits;
+    j->st.probe_route = TSQ_ROUTE_KEYREC;
+    if (out_rows == 0) {
+        TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    return materialise_pairs(j, pcs, a, nrows, out_rows, [&]() -> tsq_status {
+        pa.pairs = a.pairs;
+        hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
+        TSQ_HIP(h, hipGetLastError());
+        j->st.kernel_launches++;
+        return TSQ_OK;
+    });
 }
 
 bool wide_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
@@ -3279,6 +3342,10 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
         TSQ_TRY(da_prepare(j));
         TSQ_TRY(da_prepare_rows_bits(j));
         if (j->da_bitrows_state == 1) return da_emit_bits(j, pcs, a, nrows, selected_dev);
+    }
+    if (kr_emit_eligible(j, nrows, selected_dev)) {  // several key columns / string keys, materialising: pairs out of the key records
+        TSQ_TRY(kr_prepare(j));
+        if (j->kr_state == 1) return kr_emit_batch(j, pcs, a, nrows);
     }
     TSQ_TRY(need_table());
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
@@ -4205,7 +4272,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->da_ckey.release();
     j->rckey.release();
     for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_coarse_c, &j->da_pstart_c, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
-    for (DevBuf* b : {&j->kr_brec, &j->kr_bstart, &j->kr_counts, &j->kr_prec, &j->kr_pstart, &j->kr_flags}) b->release();
+    for (DevBuf* b : {&j->kr_brec, &j->kr_bstart, &j->kr_counts, &j->kr_prec, &j->kr_pstart, &j->kr_flags, &j->kr_bids, &j->kr_pids, &j->kr_pcnt}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
         j->da_bsorted[c].release();
         j->da_bsorted_nn[c].release();
