@@ -674,8 +674,9 @@ tsq_status tsq_rowcodec_decode(tsq_ctx* ctx, const uint8_t* values, int64_t n_by
  * row_offsets (NULL or nrows + 1 entries, same residency as out): row r = out[row_offsets[r], row_offsets[r + 1]) — the response
  * is cut into tipb.Chunks of 64 rows (cop_handler_dag.go:510-519).  *bytes_out = length of the byte string; when it exceeds
  * cap_bytes nothing is written and the call returns TSQ_ERR_INVALID with *bytes_out = the bytes needed (a caller that cannot bound
- * the size — string columns — asks with cap_bytes = 0 first).  TSQ_ENC_COMPARABLE on a var-len column (memcomparable bytes, the
- * EncodeKey form) -> TSQ_ERR_UNSUPPORTED: that response keeps the Go encoder.  256 consecutive rows must encode to < 4 GiB. */
+ * the size — string columns — asks with cap_bytes = 0 first).  TSQ_ENC_COMPARABLE on a var-len column writes the memcomparable
+ * form index keys hold: bytesFlag + groups of 8 bytes, each followed by its marker 0xFF - pad count (codec.go:86-91,
+ * bytes.go:35-67).  256 consecutive rows must encode to < 4 GiB. */
 #define TSQ_ENC_COMPARABLE 1u
 tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_cols, const uint32_t* col_flags, int64_t nrows,
                            uint8_t* out, int64_t cap_bytes, uint32_t out_flags, int64_t* row_offsets, int64_t* bytes_out);

@@ -317,7 +317,8 @@ uint32_t sim_enc_row_len(const tsq_col* cols, int n_cols, uint32_t comparable, i
             const uint8_t* bm = cols[c].null_bitmap;
             const bool nn = bm ? ((bm[r >> 3] >> (r & 7)) & 1) != 0 : true;
             const uint64_t n = (uint64_t)(cols[c].offsets[r + 1] - cols[c].offsets[r]);
-            len += nn ? tsq_enc_str_hdr_len(n) + (uint32_t)n : 1u;
+            if ((comparable >> c) & 1u) len += nn ? (uint32_t)tsq_enc_membytes_len(n) : 1u;
+            else len += nn ? tsq_enc_str_hdr_len(n) + (uint32_t)n : 1u;
             continue;
         }
         bool nn;
@@ -389,6 +390,14 @@ extern "C" int64_t sim_rows_encode(const tsq_col* cols, int32_t n_cols, uint32_t
                         if (!nn) { dst[pos++] = 0; continue; }
                         const int64_t s0 = cols[c].offsets[r];
                         const uint64_t n = (uint64_t)(cols[c].offsets[r + 1] - s0);
+                        if ((comparable >> c) & 1u) {
+                            const uint8_t* src = (const uint8_t*)cols[c].data + s0;
+                            const uint32_t m = (uint32_t)tsq_enc_membytes_len(n) - 1u;
+                            dst[pos++] = 1;
+                            for (uint32_t i = 0; i < m; i++) dst[pos + i] = tsq_enc_membytes_at(src, n, i);
+                            pos += m;
+                            continue;
+                        }
                         const uint32_t hn = tsq_enc_str_hdr(n, &lo, &hi);
                         for (uint32_t i = 0; i < hn; i++) dst[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
                         pos += hn;

@@ -137,3 +137,29 @@ def test_string_columns_as_compact_bytes(sim, n, long_every, phase):
     # the row boundaries cut the byte string into the rows the oracle encodes one by one
     for r in (0, n // 2, n - 1):
         assert bytes(got[offs[r]:offs[r + 1]]) == bytes(orc.encode_rows(chk.slice(r, r + 1)))
+
+
+@pytest.mark.parametrize("n,long_every", [(1, 0), (257, 0), (3000, 0), (700, 50)])
+@pytest.mark.parametrize("phase", [0, 9])
+def test_string_columns_in_the_memcomparable_form(sim, n, long_every, phase):
+    # EncodeKey of a var-len cell = bytesFlag + groups of 8 bytes, each followed by 0xFF - its pad count; a cell whose length is a
+    # multiple of 8 (the empty one too) ends with an all-pad group and 0xF7 (codec.go:86-91, bytes.go:35-67)
+    rng = np.random.default_rng(100 + n + phase)
+    chk = string_chunk(rng, n, long_every)
+    want = orc.encode_rows(chk, comparable=True)
+    total, got, offs = run_sim(sim, chk, 0xF, n_wg=5, phase=phase, cap=len(want) + 64)
+    assert total == len(want) and bytes(got) == bytes(want)
+    for r in (0, n // 2, n - 1):
+        assert bytes(got[offs[r]:offs[r + 1]]) == bytes(orc.encode_rows(chk.slice(r, r + 1), comparable=True))
+
+
+def test_memcomparable_known_answers(sim):
+    # the examples of bytes.go:38-42
+    from tinysql_amd.chunk import StrColumn
+    cells = [b"", bytes([1, 2, 3]), bytes([1, 2, 3, 0]), bytes(range(1, 9))]
+    want = [bytes([0] * 8 + [247]), bytes([1, 2, 3, 0, 0, 0, 0, 0, 250]), bytes([1, 2, 3, 0, 0, 0, 0, 0, 251]),
+            bytes(list(range(1, 9)) + [255] + [0] * 8 + [247])]
+    chk = Chunk([StrColumn(cells)])
+    total, got, offs = run_sim(sim, chk, 1, cap=256)
+    for r, w in enumerate(want):
+        assert bytes(got[offs[r]:offs[r + 1]]) == b"\x01" + w

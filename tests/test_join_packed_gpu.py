@@ -456,14 +456,19 @@ def test_packed_several_key_columns_mixed_signedness_and_too_wide(ctx, orc):
 def test_packed_travelling_columns_outer_join_conditions(ctx, orc, jt, inner, unique):
     # leftOuterJoiner / rightOuterJoiner with OtherConditions (joiner.go:220-344): an outer row whose candidates all fail the
     # conditions is padded with NULLs.  With a UNIQUE build side there is one candidate at most: the packed route materialises the
-    # batch and un-matches the failed rows (k_outer_unmatch); with duplicates the direct route keeps the join
+    # batch and un-matches the failed rows (k_outer_unmatch); with duplicates (round 5) the candidates of an outer row are consecutive
+    # rows of the batch: failed candidates go, and an outer row that lost them all keeps its first row, padded (k_outer_segments) —
+    # also for the rows of a hot probe key, which take the overflow list
     rng = np.random.default_rng(23 + jt + unique)
     nb = 4000
     bk = rng.permutation(6000)[:nb] - 1000 if unique else rng.integers(-900, 1000, nb)
     bside = Chunk([Column(abi.I64, bk, None if unique else rng.random(nb) > 0.03), Column(abi.F64, rng.random(nb), rng.random(nb) > 0.1),
                    Column(abi.I64, rng.integers(0, 100, nb))])
     n = 50_001
-    pside = Chunk([Column(abi.I64, rng.integers(-1200, 5200, n), rng.random(n) > 0.03), Column(abi.F64, rng.random(n), rng.random(n) > 0.2),
+    pk = rng.integers(-1200, 5200, n)
+    if not unique:
+        pk[::3] = bk[11]  # a hot probe key with several build rows: its partition's region overflows
+    pside = Chunk([Column(abi.I64, pk, rng.random(n) > 0.03), Column(abi.F64, rng.random(n), rng.random(n) > 0.2),
                    Column(abi.I64, rng.integers(0, 100, n))])
     left, right = (pside, bside) if inner == 1 else (bside, pside)
     nl = 3
@@ -471,7 +476,7 @@ def test_packed_travelling_columns_outer_join_conditions(ctx, orc, jt, inner, un
     keep = []
     cfg = H.join_cfg(left.types(), right.types(), [0], [0], jt, inner, conds, (), keep)
     want = orc.hash_join(cfg, bside, pside)
-    got = _rows(ctx, cfg, bside, pside, want_route=abi.ROUTE_PACKED if unique else abi.ROUTE_DIRECT)
+    got = _rows(ctx, cfg, bside, pside, want_route=abi.ROUTE_PACKED)
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
     if unique:
         assert got.NumRows() == n
@@ -524,12 +529,15 @@ def test_packed_hot_probe_key_both_partition_kernels(ctx, variant, span_bits, sh
 # warning to the statement context (expression/errors.go:65-77: NULL result + ErrDivisionByZero warning).  The shim needs the COUNT
 # (tsq_stats.div_by_zero_warnings) to call handleDivisionByZeroError that many times.  Expected value: the oracle's VecEvalBool over the
 # oracle's condition-less join of the same tables — one evaluation per candidate pair, as in the reference.
-@pytest.mark.parametrize("route", ["direct", "packed"])
+@pytest.mark.parametrize("route", ["direct", "packed", "packed_duplicate_build_keys"])
 @pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
 def test_division_by_zero_warnings_of_join_conditions_are_counted(ctx, orc, route, jt):
     rng = np.random.default_rng(77)
     nb, npr = 40_000, 90_000
-    bk = rng.permutation(nb).astype(np.int64)  # unique build keys: the packed route takes outer-join conditions too
+    bk = rng.permutation(nb).astype(np.int64)  # unique build keys ...
+    if route == "packed_duplicate_build_keys":  # ... or ~2 rows per key: every candidate of an outer row is evaluated (and warns) once
+        bk = rng.integers(0, nb // 2, nb).astype(np.int64)
+        route = "packed"
     bv = rng.integers(0, 4, nb).astype(np.float64)  # a quarter of the divisors is zero (DIV is real-only, builtin_arithmetic.go:435-444)
     pk = rng.integers(-5000, nb + 5000, npr).astype(np.int64)
     pv = rng.integers(-50, 50, npr).astype(np.float64)
@@ -657,3 +665,53 @@ def test_wide_several_key_columns_count_vs_oracle(ctx, orc, shape, n_probe):
     assert stats_route == want
     assert _count(ctx, cfg, build, probe, packing=OFF) == want
     assert _count(ctx, cfg, build, probe, chunk_rows=1024) == want
+
+
+# ------------------------------------------------------------------ outer-side filters on the packed routes (round 5)
+# join.go:328-345: the outer side's filter is evaluated over the probe chunk (VectorizedFilter -> selected[]); a row that fails it goes
+# to onMissMatch — NULL-padded — without touching the table.  The library evaluates the filter into flags (k_outer_filter_flags) and
+# the packed kernels take them like an external selected[] vector; before round 5 every join with an outer filter took the direct route.
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("route", ["travelling_columns", "pairs"])
+@pytest.mark.parametrize("with_selected", [False, True])
+def test_packed_routes_take_the_outer_side_filter(ctx, orc, jt, inner, route, with_selected):
+    rng = np.random.default_rng(131 + jt + with_selected)
+    nb, npr = 30_000, 70_001
+    bk = rng.integers(0, 25_000, nb).astype(np.int64)  # duplicates
+    pk = rng.integers(-3000, 28_000, npr).astype(np.int64)
+    build = Chunk([Column(abi.I64, bk, rng.random(nb) > 0.03), Column(abi.I64, rng.integers(-9, 9, nb), rng.random(nb) > 0.1)])
+    probe = Chunk([Column(abi.I64, pk, rng.random(npr) > 0.03), Column(abi.F64, rng.random(npr), rng.random(npr) > 0.1), Column(abi.F64, rng.integers(0, 4, npr).astype(np.float64))])
+    sel = (rng.random(npr) > 0.3).astype(np.uint8) if with_selected else None
+    left, right = (probe, build) if inner == 1 else (build, probe)
+    # probe.f > 0.4 AND 10.0 / probe.c > 3.0: NULL cells and divisions by zero fail the filter (VecEvalBool: NULL is false) and warn
+    filters = [E.ScalarFunction("gt", E.Column(1, abi.F64), E.Constant(0.4)),
+               E.ScalarFunction("gt", E.ScalarFunction("div", E.Constant(10.0), E.Column(2, abi.F64)), E.Constant(3.0))]
+    keep = []
+    cfg = H.join_cfg(left.types(), right.types(), [0], [0], jt, inner, (), filters, keep)
+    want = orc.hash_join(cfg, build, probe, selected=sel)
+    with ctx.knobs(PACKED_EMIT_PAIRS=1, DA_PAIRS_BELOW_PERMILLE=(1001 if route == "pairs" else 0)):
+        stats = []
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, selected=sel, stats_out=stats, radix=FORCE, packing=FORCE)
+    assert stats[0].probe_route == abi.ROUTE_PACKED
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    # the same warnings as the direct route counts
+    stats_d = []
+    got_d = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, selected=sel, stats_out=stats_d, radix=abi.RADIX_OFF, packing=abi.RADIX_OFF)
+    assert stats_d[0].probe_route == abi.ROUTE_DIRECT and got_d.NumRows() == want.NumRows()
+    assert stats[0].div_by_zero_warnings == stats_d[0].div_by_zero_warnings > 0
+
+
+def test_an_outer_side_filter_that_raises_an_error_is_the_direct_routes(ctx, orc):
+    # BIGINT overflow in the filter: the error the statement reports depends on the row order -> the batch is the direct route's
+    rng = np.random.default_rng(7)
+    nb, npr = 5000, 20_000
+    build = Chunk([Column(abi.I64, rng.permutation(nb)), Column(abi.I64, np.arange(nb))])
+    pv = rng.integers(0, 100, npr)
+    pv[777] = (1 << 63) - 1
+    probe = Chunk([Column(abi.I64, rng.integers(0, nb, npr)), Column(abi.I64, pv)])
+    filters = [E.ScalarFunction("gt", E.ScalarFunction("plus", E.Column(1, abi.I64), E.Constant(1)), E.Constant(10))]
+    keep = []
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], abi.JOIN_LEFT_OUTER, 1, (), filters, keep)
+    with pytest.raises(Exception) as ei:
+        G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, radix=FORCE, packing=FORCE)
+    assert "overflow" in str(ei.value).lower() or "range" in str(ei.value).lower()

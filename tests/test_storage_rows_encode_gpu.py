@@ -100,8 +100,6 @@ def test_contracts(ctx, orc):
     assert lib.tsq_rows_encode(ctx.h, cols, 1, None, 4, po, 64, 0, None, C.byref(m)) == abi.ERR_INVALID  # column shorter than nrows
     cols[0].type = abi.BYTES
     assert lib.tsq_rows_encode(ctx.h, cols, 1, None, 3, po, 64, 0, None, C.byref(m)) == abi.ERR_INVALID  # a var-len column without offsets
-    cmpf = (C.c_uint32 * 1)(abi.ENC_COMPARABLE)
-    assert lib.tsq_rows_encode(ctx.h, cols, 1, cmpf, 3, po, 64, 0, None, C.byref(m)) == abi.ERR_UNSUPPORTED  # memcomparable bytes (EncodeKey form)
     cols[0].type = abi.I64
     _lib.check(lib.tsq_rows_encode(ctx.h, cols, 1, None, 3, po, 64, 0, None, C.byref(m)), ctx.h)
     assert m.value == 6 and bytes(out[:6]) == b"\x08\x0a\x08\x0c\x08\x0e" and (out[6:] == 0xEE).all()
@@ -174,3 +172,17 @@ def test_string_response_size_can_be_asked_first(ctx, orc):
     out = np.full(m.value + 8, 0xEE, np.uint8)
     _lib.check(ctx.lib.tsq_rows_encode(ctx.h, cols, 4, None, 1000, out.ctypes.data_as(C.c_void_p), m.value, 0, None, C.byref(m)), ctx.h)
     assert bytes(out[:m.value]) == bytes(want) and (out[m.value:] == 0xEE).all()
+
+
+@pytest.mark.parametrize("n,long_every", [(1, 0), (5000, 0), (700, 50)])
+def test_string_columns_in_the_memcomparable_form(ctx, orc, n, long_every):
+    # EncodeKey of a var-len cell = bytesFlag + groups of 8 bytes with their markers (codec.go:86-91, bytes.go:35-67) — what an index
+    # key holds; equals the oracle byte for byte, and the single-stream decoder reads the rows back
+    from .test_hostsim_encode import string_chunk
+    rng = np.random.default_rng(50 + n)
+    chk = string_chunk(rng, n, long_every)
+    want = orc.encode_rows(chk, comparable=True)
+    raw, offs = distsql.encode_rows(ctx, chk, comparable_cols=range(4))
+    assert bytes(raw) == bytes(want) and offs[0] == 0 and offs[-1] == len(want)
+    back = distsql.decode_chunks(ctx, distsql.response_chunks(raw, offs), chk.types())
+    assert back.rows() == chk.rows()

@@ -56,7 +56,8 @@ __device__ __forceinline__ uint32_t enc_row_len(const EncArgs& a, int64_t r) {
             const uint8_t* bm = a.nulls[c];
             const bool nn = bm ? ((bm[r >> 3] >> (r & 7)) & 1) != 0 : true;
             const uint64_t n = (uint64_t)(a.offs[c][r + 1] - a.offs[c][r]);
-            len += nn ? tsq_enc_str_hdr_len(n) + (uint32_t)n : 1u;
+            if ((a.comparable >> c) & 1u) len += nn ? (uint32_t)tsq_enc_membytes_len(n) : 1u;
+            else len += nn ? tsq_enc_str_hdr_len(n) + (uint32_t)n : 1u;
             continue;
         }
         bool nn;
@@ -127,6 +128,14 @@ __global__ void __launch_bounds__(ENC_NT) k_enc_emit(EncArgs a) {
                     if (!nn) { dst[pos++] = 0; continue; }  // NilFlag
                     const int64_t s0 = a.offs[c][r];
                     const uint64_t n = (uint64_t)(a.offs[c][r + 1] - s0);
+                    if ((a.comparable >> c) & 1u) {  // bytesFlag + the groups of 8 bytes with their markers
+                        const uint8_t* src = (const uint8_t*)a.data[c] + s0;
+                        const uint32_t m = (uint32_t)tsq_enc_membytes_len(n) - 1u;
+                        dst[pos++] = 1;
+                        for (uint32_t i = 0; i < m; i++) dst[pos + i] = tsq_enc_membytes_at(src, n, i);
+                        pos += m;
+                        continue;
+                    }
                     const uint32_t hn = tsq_enc_str_hdr(n, &lo, &hi);
                     for (uint32_t i = 0; i < hn; i++) dst[pos + i] = (uint8_t)(i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8)));
                     pos += hn;
@@ -171,8 +180,6 @@ TSQ_API tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
         if (cols[c].type < TSQ_I64 || cols[c].type > TSQ_BYTES) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: unknown column type");
         if (cols[c].length < nrows) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: column shorter than nrows");
         if (cols[c].type == TSQ_BYTES) {
-            if (col_flags && (col_flags[c] & TSQ_ENC_COMPARABLE))
-                return tsq_fail(h, TSQ_ERR_UNSUPPORTED, "EncodeKey form of a var-len column (memcomparable bytes): encode it with the Go encoder");
             if (nrows > 0 && !cols[c].offsets) return tsq_fail(h, TSQ_ERR_INVALID, "tsq_rows_encode: var-len column without offsets");
             if (!(cols[c].flags & TSQ_COL_DEVICE)) any_host_var = true;
         } else if (nrows > 0 && !cols[c].data) {
@@ -217,7 +224,7 @@ TSQ_API tsq_status tsq_rows_encode(tsq_ctx* ctx, const tsq_col* cols, int32_t n_
         if (cmp) a.comparable |= 1u << c;
         const bool var = cols[c].type == TSQ_BYTES;
         any_var = any_var || var;
-        row_max += var ? 32u : ((cols[c].type == TSQ_F32 || cols[c].type == TSQ_F64 || cmp) ? 9u : TSQ_ENC_MAX_VALUE);  // (strings: a guess; tiles that do not fit go direct)
+        row_max += var ? (cmp ? 40u : 32u) : ((cols[c].type == TSQ_F32 || cols[c].type == TSQ_F64 || cmp) ? 9u : TSQ_ENC_MAX_VALUE);  // (strings: a guess; tiles that do not fit go direct)
         if (in_dev) {
             a.data[c] = cols[c].data;
             a.nulls[c] = cols[c].null_bitmap;

@@ -77,6 +77,18 @@ TSQ_HD uint32_t tsq_enc_str_hdr(uint64_t n, uint64_t* lo, uint32_t* hi) {
 }
 TSQ_HD uint32_t tsq_enc_str_hdr_len(uint64_t n) { return tsq_enc_len(TSQ_I64, false, n, true); }
 
+// the EncodeKey form of a var-len cell of `n` bytes: bytesFlag + EncodeBytes = [1] then n / 8 + 1 groups of 8 data bytes (the last one
+// padded with zeros) each followed by a marker byte 0xFF - its pad count (codec.go:86-91, bytes.go:35-67): a cell whose length is a
+// multiple of 8 (the empty one too) ends with a group of 8 pad bytes and the marker 0xF7
+TSQ_HD uint64_t tsq_enc_membytes_len(uint64_t n) { return 1u + (n / 8u + 1u) * 9u; }
+// byte i (0-based, after the flag) of that encoding
+TSQ_HD uint8_t tsq_enc_membytes_at(const uint8_t* src, uint64_t n, uint64_t i) {
+    const uint64_t g = i / 9u, k = i - g * 9u;
+    if (k < 8u) { const uint64_t at = g * 8u + k; return at < n ? src[at] : (uint8_t)0; }
+    const uint64_t remain = n - g * 8u;  // bytes of the cell from this group on (g <= n / 8)
+    return remain >= 8u ? (uint8_t)0xFF : (uint8_t)(0xFFu - (8u - remain));
+}
+
 // How the T bytes of a tile, assembled in LDS at [skew, skew + T), reach out[base, base + T): LDS byte i <-> global byte
 // (out + base - skew) + i with skew = (address of out[base]) & 15, so whole 16-byte vectors are stored aligned; the bytes before the
 // first / after the last whole vector are shared with the neighbouring tiles' vectors and are stored one by one.

@@ -787,6 +787,10 @@ struct tsq_join {
     int kr_state = 0;                 // 0: not tried, 1: the build side's records are in place, -1: not usable for this build side
     uint32_t kr_pbits = 0;
     DevBuf kr_brec, kr_bstart, kr_counts, kr_prec, kr_pstart, kr_flags, kr_bids, kr_pids, kr_pcnt;
+    bool filters_folded = false;      // this batch: the outer-side filters are already in the selected[] flags the packed routes take (fold_outer_filters)
+    DevBuf fflags;                    //   ... those flags
+    DevBuf heads;                     // da_emit_cols: first-candidate flags of a batch (outer join + conditions + duplicate build keys)
+    int64_t direct_batches = 0;       // batches that went through the direct route
     int64_t div0_packed = 0;          // division-by-zero warnings of conditions evaluated over materialised batches (da_post_conditions)
     bool shared = false;
     int64_t shared_image_bytes = 0, shared_usable_local = 0;
@@ -1590,7 +1594,7 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uin
 // no OtherConditions, no selected[], not ordered; any number and type of payload columns, NULLs anywhere.
 bool da_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || (j->multi && !da_multi_ok(j)) || j->never_match || j->ordered) return false;
-    if (!j->conds_h.empty() || !j->filters_h.empty()) return false;  // (selected[]: the packed kernels treat a row with selected == 0 like a NULL key)
+    if (!j->conds_h.empty() || (!j->filters_h.empty() && !j->filters_folded)) return false;  // (selected[]: the packed kernels treat a row with selected == 0 like a NULL key)
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_rows_state < 0) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
     // AUTO: the pairs come out in PARTITION order, so the gather of the probe-side columns is as random as the build side's (the
@@ -1811,7 +1815,7 @@ tsq_status da_emit(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nro
 // ---- pairs route on BIT cells (tsq_dajoin.h): a UNIQUE build side whose key range needs 4-byte entries (28..30 bits)
 bool da_bits_emit_eligible(const tsq_join* j, int64_t nrows) {
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || j->multi || j->never_match || j->ordered) return false;
-    if (!j->conds_h.empty() || !j->filters_h.empty()) return false;
+    if (!j->conds_h.empty() || (!j->filters_h.empty() && !j->filters_folded)) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_bitrows_state < 0) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE || j->packing_mode == TSQ_RADIX_FORCE) return true;
     return nrows >= (4 << 20);
@@ -2032,9 +2036,11 @@ bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_
     if (j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || j->count_only || (j->multi && !da_multi_ok(j)) || j->never_match || j->ordered) return false;
     // OtherConditions of an INNER join are a filter over the joined rows (joiner.go:351-378: innerJoiner.tryToMatch filters the
     // joined chunk): evaluated on the output batch and compacted (da_post_conditions).  An outer join needs "did ANY match of this
-    // outer row pass" — taken here only when no build key repeats (da_unique, known once the images exist: probe_batch checks): an outer row then has
-    // at most one candidate, and a candidate that fails the conditions turns into the NULL-padded row (onMissMatch, joiner.go:274-281)
-    if (!j->filters_h.empty()) return false;  // (selected[]: the packed kernels treat a row with selected == 0 like a NULL key)
+    // outer row pass": with a unique build side an outer row has at most one candidate, and a candidate that fails the conditions
+    // turns into the NULL-padded row (onMissMatch, joiner.go:274-281); with duplicate build keys the candidates of an outer row are
+    // consecutive rows of the batch and a segmented pass decides (k_outer_segments)
+    if (!j->filters_h.empty() && !j->filters_folded) return false;  // (selected[]: the packed kernels treat a row with selected == 0 like a NULL key;
+                                                                   //  outer-side filters reach them as such flags: fold_outer_filters)
     if (nrows <= 0 || nrows > 0x7fffffffLL || j->da_state < 0 || j->da_cols_state < 0) return false;
     if (j->cfg.n_probe_cols > TSQ_DA_MAXCOLS || j->cfg.n_build_cols > TSQ_DA_MAXCOLS) return false;
     for (int c = 0; c < j->cfg.n_probe_cols; c++)
@@ -2219,6 +2225,75 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
     return TSQ_OK;
 }
 
+// The outer-side filter of an outer join (join.go:328-345: a probe row that fails it goes to onMissMatch — NULL-padded — without
+// touching the table) evaluated over the probe batch into one flag byte per row, so that the packed routes take it the way they take
+// an externally evaluated selected[] vector: a row with flag 0 behaves like a row with a NULL key.
+struct FilterFlagArgs {
+    tsq_colset p;
+    const tsq_expr_prog* filters;
+    int32_t n_filters;
+    int64_t n;
+    const uint8_t* selected;  // nullptr or the caller's flags: ANDed in
+    uint8_t* flags;
+    unsigned long long* err;  // err word (preset TSQ_ERRWORD_NONE): an evaluation error leaves the batch to the direct route
+    unsigned long long* div0;
+};
+__global__ void __launch_bounds__(256) k_outer_filter_flags(FilterFlagArgs a) {
+    uint64_t errw = TSQ_ERRWORD_NONE;
+    uint32_t div0 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        bool sel = !a.selected || a.selected[i] != 0;
+        if (sel) {
+            tsq_chunk_src src{&a.p, i};
+            bool isnull = false;
+            int ec = 0, en = 0, d0 = 0;
+            sel = false;
+            const tsq_status s = tsq_filter_row(a.filters, a.n_filters, src, &sel, &isnull, &ec, &en, &d0);
+            div0 += (uint32_t)d0;
+            if (s != TSQ_OK) {
+                const uint64_t w = tsq_errword(ec, en, (uint64_t)i, s);
+                errw = w < errw ? w : errw;
+                sel = false;
+            }
+        }
+        a.flags[i] = sel ? 1 : 0;
+    }
+    if (errw != TSQ_ERRWORD_NONE) atomicMin(a.err, (unsigned long long)errw);
+    const uint64_t d = wave_sum_u64(div0);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(a.div0, (unsigned long long)d);
+}
+// *folded: j->fflags holds the flags and *div0 the warnings the filters raised (added to the statistics by the caller once a packed
+// route has taken the batch: the direct route evaluates — and counts — again)
+tsq_status fold_outer_filters(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev, bool* folded, int64_t* div0) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    *folded = false;
+    *div0 = 0;
+    TSQ_TRY(j->fflags.reserve(ctx, h, (size_t)nrows + 64));
+    FilterFlagArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.p = pcs;
+    fa.filters = j->filters_d.as<tsq_expr_prog>();
+    fa.n_filters = (int32_t)j->filters_h.size();
+    fa.n = nrows;
+    fa.selected = selected_dev;
+    fa.flags = j->fflags.as<uint8_t>();
+    fa.err = (unsigned long long*)(ctx->dscratch + 56);
+    fa.div0 = (unsigned long long*)(ctx->dscratch + 57);
+    ctx->pinned[56] = TSQ_ERRWORD_NONE;
+    ctx->pinned[57] = 0;
+    TSQ_HIP(h, hipMemcpyAsync(ctx->dscratch + 56, ctx->pinned + 56, 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_outer_filter_flags, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, fa);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 56, ctx->dscratch + 56, 16, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    j->st.kernel_launches++;
+    if (ctx->pinned[56] != TSQ_ERRWORD_NONE) return TSQ_OK;  // which error the reference reports depends on the row order: the direct route's business
+    *folded = true;
+    *div0 = (int64_t)ctx->pinned[57];
+    return TSQ_OK;
+}
+
 // OtherConditions over a materialised batch of joined rows: row i of the output columns is (left row, right row) at once.
 struct PostCondArgs {
     tsq_colset L, R;
@@ -2263,6 +2338,7 @@ __global__ void __launch_bounds__(256) k_post_conds(PostCondArgs a) {
 // outer join, unique build side: a joined row whose conditions failed becomes the NULL-padded row — the build side's cells go NULL
 struct OuterUnmatchArgs {
     const uint8_t* keep;
+    int32_t padded_is;  // the value of keep[] that marks a row to pad: 0 (unique build side: the failed candidate itself) or 2 (k_outer_segments)
     int64_t n;
     int32_t n_cols;
     uint8_t* bitmap[TSQ_MAX_COLS];  // the build side's output columns
@@ -2271,14 +2347,26 @@ __global__ void __launch_bounds__(256) k_outer_unmatch(OuterUnmatchArgs a) {
     const int64_t nbytes = (a.n + 7) >> 3;
     for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nbytes; b += (int64_t)gridDim.x * 256) {
         uint32_t m = 0;
-        for (int k = 0; k < 8 && b * 8 + k < a.n; k++) m |= a.keep[b * 8 + k] ? (1u << k) : 0u;
+        for (int k = 0; k < 8 && b * 8 + k < a.n; k++) m |= (int32_t)a.keep[b * 8 + k] != a.padded_is ? (1u << k) : 0u;
         if (m == 0xffu) continue;
         for (int c = 0; c < a.n_cols; c++) a.bitmap[c][b] &= (uint8_t)m;
     }
 }
+// outer join, build side with duplicate keys: the candidates of an outer row are consecutive rows of the batch, head[] marks the first
+// of each.  An outer row none of whose candidates passed the conditions keeps its first row, padded (keep = 2): onMissMatch after
+// tryToMatch found nothing (joiner.go:252-281)
+__global__ void __launch_bounds__(256) k_outer_segments(uint8_t* keep, const uint8_t* head, const uint8_t* matched, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (!head[i] || tsq_is_null(matched, i)) continue;  // (a padded row is a segment of its own and stays)
+        bool any = false;
+        int64_t k = i;
+        do { any = any || keep[k] != 0; k++; } while (k < n && !head[k]);
+        if (!any) keep[i] = 2;
+    }
+}
 // filters the batch in place (new, dense column buffers).  *redo: a condition raised an error — which error the reference reports
 // depends on the probe row order, so the batch is dropped and the caller runs it through the direct route.
-tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bool>& may_null_v, bool* redo) {
+tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bool>& may_null_v, bool* redo, const uint8_t* head = nullptr) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const int np = j->cfg.n_probe_cols, nbc = j->cfg.n_build_cols, nout = np + nbc;
@@ -2339,10 +2427,19 @@ tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bo
         return TSQ_OK;
     }
     j->div0_packed += (int64_t)ctx->pinned[57];
-    if (j->cfg.join_type != TSQ_JOIN_INNER) {  // every outer row keeps its one output row; a failed candidate is un-matched
+    if (j->cfg.join_type != TSQ_JOIN_INNER) {
+        // unique build side: every outer row keeps its one output row, a failed candidate is un-matched.  Duplicates (head != null):
+        // failed candidates go, except the first row of an outer row that lost them all, which is padded; then the batch is compacted
+        if (head) {
+            hipLaunchKernelGGL(k_outer_segments, dim3(tsq_grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, keep.as<uint8_t>(), head, pa.matched, n);
+            hipError_t e4 = hipGetLastError();
+            if (e4 != hipSuccess) { keep.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("outer join conditions: ") + hipGetErrorString(e4)); }
+            j->st.kernel_launches++;
+        }
         OuterUnmatchArgs ua;
         memset(&ua, 0, sizeof ua);
         ua.keep = keep.as<uint8_t>();
+        ua.padded_is = head ? 2 : 0;
         ua.n = n;
         for (int oc = 0; oc < nout; oc++) {
             const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
@@ -2353,10 +2450,12 @@ tsq_status da_post_conditions(tsq_join* j, ResultBatch& rb, const std::vector<bo
         hipLaunchKernelGGL(k_outer_unmatch, dim3(tsq_grid_for(ctx, (n + 7) / 8, 256)), dim3(256), 0, ctx->stream, ua);
         hipError_t e3 = hipGetLastError();
         if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
-        keep.release();
-        if (e3 != hipSuccess) return tsq_fail(h, TSQ_ERR_HIP, std::string("outer join conditions: ") + hipGetErrorString(e3));
+        if (e3 != hipSuccess) { keep.release(); return tsq_fail(h, TSQ_ERR_HIP, std::string("outer join conditions: ") + hipGetErrorString(e3)); }
         j->st.kernel_launches++;
-        return TSQ_OK;
+        if (!head) {
+            keep.release();
+            return TSQ_OK;
+        }
     }
     std::vector<DevBuf> nd((size_t)nout), nbm((size_t)nout);
     tsq_status s = TSQ_OK;
@@ -2573,6 +2672,15 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
             xa.out_build_nn[sc] = of;
         }
     }
+    // outer join + conditions + duplicate build keys: which output rows start an outer row's candidates
+    const bool want_heads = outer && !j->conds_h.empty() && !j->da_unique;
+    DevBuf& head = j->heads;
+    if (want_heads) {
+        tsq_status s = head.reserve(ctx, h, (size_t)out_rows + 64);
+        if (s != TSQ_OK) { rb->release(); return s; }
+        TSQ_HIP(h, hipMemsetAsync(head.p, 1, (size_t)out_rows, ctx->stream));
+        ea.out_head = head.as<uint8_t>();
+    }
     tp("output buffers");
     if (exc_rows > 0) {  // overflow-list rows, then the NULL-padded rows of the miss list, as pairs; their cells through the pairs
         TSQ_TRY(j->pairs.reserve(ctx, h, (size_t)exc_rows * 8 + 64));
@@ -2601,6 +2709,10 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
         xa.n_build = nbc;
         hipLaunchKernelGGL(k_da_gather_exc, dim3(tsq_grid_for(ctx, exc_rows, 256)), dim3(256), 0, ctx->stream, xa);
         TSQ_HIP(h, hipGetLastError());
+        if (want_heads) {
+            hipLaunchKernelGGL(k_da_exc_heads, dim3(tsq_grid_for(ctx, exc_rows, 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)xa.pairs, exc_rows, head.as<uint8_t>());
+            TSQ_HIP(h, hipGetLastError());
+        }
         j->st.kernel_launches += 3;
     }
     ea.cs = cs;
@@ -2627,7 +2739,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     for (int oc = 0; oc < nout; oc++)
         if (may_null_v[oc]) TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, rb->notnull[oc].as<uint8_t>(), rb->bitmap[oc].as<uint8_t>(), out_rows));
     if (!j->conds_h.empty()) {
-        tsq_status ps = da_post_conditions(j, *rb, may_null_v, redo);
+        tsq_status ps = da_post_conditions(j, *rb, may_null_v, redo, want_heads ? head.as<uint8_t>() : nullptr);
         if (ps != TSQ_OK || *redo) {
             rb->release();
             if (*redo) {  // as if this route had not been tried
@@ -3247,8 +3359,34 @@ tsq_status da_sample_hit_ratio(tsq_join* j, const tsq_colset& pcs, int64_t nrows
 }
 
 // run the probe kernels over one device-resident batch described by pcs / selected
+tsq_status probe_batch_routes(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev, const uint8_t* caller_selected);
 tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev) {
     if (nrows == 0) return TSQ_OK;
+    j->filters_folded = false;
+    if (!j->filters_h.empty() && !j->shared && !j->count_only) {
+        // outer-side filters: worth a pass over the batch when a materialising packed route would take the batch without them
+        j->filters_folded = true;
+        const bool packed = da_cols_eligible(j, nrows, selected_dev) || da_emit_eligible(j, nrows, selected_dev) || da_bits_emit_eligible(j, nrows);
+        j->filters_folded = false;
+        if (packed) {
+            bool folded = false;
+            int64_t div0 = 0;
+            TSQ_TRY(fold_outer_filters(j, pcs, nrows, selected_dev, &folded, &div0));
+            if (folded) {
+                j->filters_folded = true;
+                const int64_t direct_before = j->direct_batches;
+                const tsq_status s = probe_batch_routes(j, pcs, nrows, j->fflags.as<uint8_t>(), selected_dev);
+                j->filters_folded = false;
+                if (s == TSQ_OK && j->direct_batches == direct_before) j->div0_packed += div0;  // (the direct route counted its own)
+                return s;
+            }
+        }
+    }
+    return probe_batch_routes(j, pcs, nrows, selected_dev, selected_dev);
+}
+// selected_dev: what the packed routes see (the caller's flags, or those with the outer-side filters folded in); caller_selected: what
+// the direct route sees next to the filters themselves
+tsq_status probe_batch_routes(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* selected_dev, const uint8_t* caller_selected) {
     tsq_ctx* ctx = j->ctx;
     ProbeArgs a;
     memset(&a, 0, sizeof a);
@@ -3257,7 +3395,7 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     a.ks = j->ks;
     fill_table(j, a.t);
     a.nrows = nrows;
-    a.selected = selected_dev;
+    a.selected = caller_selected;
     a.filters = j->filters_d.as<tsq_expr_prog>();
     a.n_filters = (int32_t)j->filters_h.size();
     a.conds = j->conds_d.as<tsq_expr_prog>();
@@ -3320,10 +3458,10 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     }
     if (da_cols_eligible(j, nrows, selected_dev)) {
         TSQ_TRY(da_prepare(j));
-        // conditions of an OUTER join: only with a unique build side (one candidate per outer row, see da_cols_eligible)
-        const bool usable = j->conds_h.empty() || j->cfg.join_type == TSQ_JOIN_INNER || j->da_unique;
-        if (usable) TSQ_TRY(da_prepare_cols_direct(j));
-        if (usable && j->da_cols_state == 1) {
+        // conditions of an OUTER join over a build side with duplicate keys: "did ANY candidate of this outer row pass" is a segmented
+        // reduction over the batch (the candidates of an outer row are consecutive output rows: k_outer_segments)
+        TSQ_TRY(da_prepare_cols_direct(j));
+        if (j->da_cols_state == 1) {
             bool redo = false;
             TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo, selected_dev));
             if (!redo) return TSQ_OK;
@@ -3350,6 +3488,7 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     TSQ_TRY(need_table());
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
     j->st.probe_route = TSQ_ROUTE_DIRECT;
+    j->direct_batches++;
     if (j->count_only) {
         TSQ_TRY(dispatch_count(j, a, j->checksum));
         TSQ_HIP(&j->hdr, hipEventRecord(j->ev[3], ctx->stream));
@@ -4254,6 +4393,8 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->counters.release();
     j->conds_d.release();
     j->filters_d.release();
+    j->fflags.release();
+    j->heads.release();
     j->stage.release();
     for (int i = 0; i < 4; i++)
         if (j->ev[i]) (void)hipEventDestroy(j->ev[i]);

@@ -101,7 +101,9 @@ def encode_rows(ctx, chunk, comparable_cols=()):
     cols = make_cols(chunk.columns, keep)
     flags = (C.c_uint32 * len(chunk.columns))(*[abi.ENC_COMPARABLE if i in comparable_cols else 0 for i in range(len(chunk.columns))])
     # 11 bytes bound every fixed-width datum; a string cell adds its bytes to its (<= 11-byte) header
-    cap = n * len(chunk.columns) * 11 + 16 + sum(int(c.offsets[-1] - c.offsets[0]) for c in chunk.columns if c.tp == abi.BYTES and len(c.offsets))
+    # (the memcomparable form: 9 bytes per 8 + one more group)
+    var = sum(int(c.offsets[-1] - c.offsets[0]) for c in chunk.columns if c.tp == abi.BYTES and len(c.offsets))
+    cap = n * len(chunk.columns) * 11 + 16 + var + (var // 8 + n * len(chunk.columns))
     out = np.zeros(cap, np.uint8)
     offs = np.zeros(n + 1, np.int64)
     got = C.c_int64(0)
