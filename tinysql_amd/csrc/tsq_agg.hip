@@ -27,6 +27,7 @@
 #include "tsq_stage.h"
 #include "tsq_aggfast.h"
 #include "tsq_daagg.h"
+#include "tsq_keydict.h"
 
 #include <memory>
 
@@ -775,6 +776,8 @@ struct RefOutArgs {
     const uint8_t* heap;
     int64_t* out_offs;       // [rows + 1]
     uint8_t* out_data;
+    const uint8_t* heap_child;  // rows [child_from, rows): references into this buffer (the dictionary of group keys, tsq_keydict.h)
+    int64_t child_from;         // (rows: no such rows)
 };
 __global__ void __launch_bounds__(256) k_ref_len(RefOutArgs a) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * blockDim.x)
@@ -786,7 +789,7 @@ __global__ void __launch_bounds__(256) k_ref_copy(RefOutArgs a) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = WAVE ? (t >> 6) : t; r < a.rows; r += WAVE ? (nt >> 6) : nt) {
         if (!a.notnull[r]) continue;
-        const uint8_t* s = a.heap + ref_off(a.refs[r]);
+        const uint8_t* s = (r >= a.child_from ? a.heap_child : a.heap) + ref_off(a.refs[r]);
         uint8_t* d = a.out_data + a.out_offs[r];
         const int64_t n = a.out_offs[r + 1] - a.out_offs[r];
         for (int64_t i = lane; i < n; i += step) d[i] = s[i];
@@ -1029,6 +1032,16 @@ struct tsq_agg {
     DevBuf wide_d, wide_okrows, wide_excrows;
     int32_t wide_child_out[TSQ_MAX_AGGS * 2];  // own output column -> the child's output column, or -1 - k: decoded from d (key column k)
     int64_t wide_batches = 0, wide_exception_rows = 0;
+    // string keys / several key columns through a DICTIONARY of group keys (tsq_keydict.h): the child (`wide`, wide_state, wide_child_out and the
+    // row lists above are shared with the composite-key route) groups by the dense id of a row's key record
+    bool kd_ok = false;        // the plan allows it
+    bool has_str_key = false;  // some group key column is a string
+    bool kd_mode = false;      // the child's key is a dictionary id (wide_state == 1)
+    uint32_t kd_pbits = 0;
+    int32_t kd_npay = 0, kd_paycol[TSQ_KR_MAXPAY] = {0, 0, 0, 0};
+    DevBuf kd_counts, kd_pstart, kd_rec, kd_ids, kd_flags, kd_pay[TSQ_KR_MAXPAY], kd_paynn, kd_paybm[TSQ_KR_MAXPAY], kd_norec, kd_ridx, kd_gid;
+    DevBuf kd_drec, kd_dids, kd_dcount, kd_dloc, kd_ctl;  // the dictionary; kd_ctl: [0] ids handed out, [1] exception rows of the batch, [2] rows without a record, [3..4] list cursors
+    int64_t kd_next_host = 0;  // ids handed out, as of the last batch
     // StreamAggExec (tsq_streamagg.h): the input arrives ordered by the group keys, the table is an ARRAY of groups in input order
     bool stream = false;
     DevBuf sa_cnt;             // heads per 2048-row chunk of the current batch
@@ -2064,6 +2077,218 @@ tsq_status wide_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     return agg_rows(a, in, n_exc, la.exc_rows);
 }
 
+// ---------------------------------------------------------------- GROUP BY through the dictionary of group keys (host side; tsq_keydict.h)
+tsq_status kd_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    (void)in;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    // partitions: at most ~8192 groups each on average (two thirds of a partition's places: + 45 sigma stays below TSQ_KR_CAP); the planner's
+    // estimate, else as many groups as the first batch has rows
+    const int64_t est = a->cfg.est_groups > 0 ? a->cfg.est_groups : nrows;
+    uint32_t pbits = 0;
+    while (((int64_t)TSQ_KR_FILL << pbits) < est && (1u << pbits) < TSQ_KR_MAXP) pbits++;
+    const size_t P = (size_t)1 << pbits;
+    // ---- the child: GROUP BY id (input column 0) over the travelled argument columns (input columns 1 ..)
+    tsq_agg_cfg cc = a->cfg;
+    cc.n_input_cols = 1 + a->kd_npay;
+    cc.input_types[0] = TSQ_U64;
+    for (int v = 0; v < a->kd_npay; v++) cc.input_types[1 + v] = a->cfg.input_types[a->kd_paycol[v]];
+    cc.n_group_keys = 1;
+    cc.group_key_col[0] = 0;
+    cc.group_key_type[0] = TSQ_U64;
+    cc.est_groups = 0;
+    memset(&cc.aggs[0], 0, sizeof(tsq_agg_func));
+    cc.aggs[0].func = TSQ_AGG_FIRSTROW;
+    cc.aggs[0].mode = TSQ_MODE_COMPLETE;
+    cc.aggs[0].arg_col = 0;
+    cc.aggs[0].arg_col2 = -1;
+    cc.aggs[0].arg_type = TSQ_U64;
+    cc.n_aggs = 1;
+    auto child_col = [&](int c) {
+        for (int v = 0; v < a->kd_npay; v++)
+            if (a->kd_paycol[v] == c) return 1 + v;
+        return -1;
+    };
+    int child_oc = 1, own_oc = 0;
+    for (int i = 0; i < a->cfg.n_aggs; i++) {
+        const tsq_agg_func& fn = a->cfg.aggs[i];
+        const bool partial_out = fn.mode == TSQ_MODE_PARTIAL1 || fn.mode == TSQ_MODE_PARTIAL2;
+        const int outs = (fn.func == TSQ_AGG_AVG && partial_out) ? 2 : 1;
+        if (fn.func == TSQ_AGG_FIRSTROW) {
+            int key = -1;
+            for (int k = 0; k < a->plan.n_keys; k++)
+                if (fn.arg_col == a->plan.key_col[k]) key = k;
+            a->wide_child_out[own_oc++] = -1 - key;
+            continue;
+        }
+        if (cc.n_aggs >= TSQ_MAX_AGGS) return TSQ_OK;
+        tsq_agg_func g = fn;
+        g.arg_col = fn.arg_col >= 0 ? child_col(fn.arg_col) : -1;
+        g.arg_col2 = fn.arg_col2 >= 0 ? child_col(fn.arg_col2) : -1;
+        cc.aggs[cc.n_aggs++] = g;
+        for (int o = 0; o < outs; o++) a->wide_child_out[own_oc++] = child_oc++;
+    }
+    TSQ_TRY(a->kd_drec.reserve(ctx, h, P * TSQ_KR_CAP * TSQ_KR_BYTES + 64));
+    TSQ_TRY(a->kd_dids.reserve(ctx, h, P * TSQ_KR_CAP * 4 + 64));
+    TSQ_TRY(a->kd_dcount.reserve(ctx, h, P * 4 + 64));
+    TSQ_TRY(a->kd_ctl.reserve(ctx, h, 64));
+    TSQ_HIP(h, hipMemsetAsync(a->kd_dcount.p, 0, P * 4, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(a->kd_ctl.p, 0, 64, ctx->stream));
+    tsq_agg* child = nullptr;
+    const tsq_status cs = tsq_agg_create(ctx, &cc, &child);
+    if (cs != TSQ_OK) return TSQ_OK;  // (a plan the single-key operator refuses: the several-column upsert keeps this aggregate)
+    child->is_wide_child = true;
+    child->fast_mode = a->fast_mode;
+    child->host_mode = false;
+    a->wide = child;
+    a->wide_state = 1;
+    a->kd_mode = true;
+    a->kd_pbits = pbits;
+    a->kd_next_host = 0;
+    return TSQ_OK;
+}
+
+tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const uint32_t P = 1u << a->kd_pbits;
+    // ---- the rows' key records, partitioned by their hash; the argument cells travel
+    KrArgs ka;
+    memset(&ka, 0, sizeof ka);
+    ka.src.cs = in;
+    ka.src.n_keys = a->plan.n_keys;
+    for (int k = 0; k < a->plan.n_keys; k++) ka.src.col[k] = a->plan.key_col[k];
+    ka.src.keep_nulls = 1;
+    ka.src.nrows = nrows;
+    ka.pbits = a->kd_pbits;
+    const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;
+    ka.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(TSQ_KR_MAXWG, chunks));
+    ka.rows_per_wg = ((chunks + ka.n_wg - 1) / ka.n_wg) * TSQ_KR_NT;
+    TSQ_TRY(a->kd_counts.reserve(ctx, h, (size_t)ka.n_wg * P * 4 + 64));
+    TSQ_TRY(a->kd_pstart.reserve(ctx, h, ((size_t)P + 1) * 4 + 64));
+    TSQ_TRY(a->kd_rec.reserve(ctx, h, (size_t)nrows * TSQ_KR_BYTES + 64));
+    TSQ_TRY(a->kd_ids.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(a->kd_norec.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(a->kd_flags.reserve(ctx, h, 64));
+    bool any_nulls = false;
+    ka.n_pay = a->kd_npay;
+    for (int v = 0; v < a->kd_npay; v++) {
+        TSQ_TRY(a->kd_pay[v].reserve(ctx, h, (size_t)nrows * 8 + 64));
+        ka.pay_src[v] = (const uint64_t*)in.data[a->kd_paycol[v]];
+        ka.pay_nulls[v] = in.nulls[a->kd_paycol[v]];
+        ka.pay_dst[v] = a->kd_pay[v].as<uint64_t>();
+        any_nulls = any_nulls || in.nulls[a->kd_paycol[v]] != nullptr;
+    }
+    if (any_nulls) {
+        TSQ_TRY(a->kd_paynn.reserve(ctx, h, (size_t)nrows + 64));
+        ka.pay_nn = a->kd_paynn.as<uint8_t>();
+    }
+    unsigned long long* ctl = a->kd_ctl.as<unsigned long long>();
+    ka.counts = a->kd_counts.as<uint32_t>();
+    ka.pstart = a->kd_pstart.as<uint32_t>();
+    ka.rec = a->kd_rec.as<unsigned long long>();
+    ka.ids = a->kd_ids.as<uint32_t>();
+    ka.flags = a->kd_flags.as<uint32_t>();
+    ka.norec = a->kd_norec.as<uint32_t>();
+    ka.norec_count = ctl + 2;
+    TSQ_HIP(h, hipMemsetAsync(ka.flags, 0, 16, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(ctl + 1, 0, 32, ctx->stream));  // [1] exception rows, [2] rows without a record, [3..4] list cursors
+    const size_t lds = (size_t)P * 4;
+    TSQ_HIP(h, hipFuncSetAttribute((const void*)k_kr_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    TSQ_HIP(h, hipFuncSetAttribute((const void*)k_kr_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_kr_hist, dim3(ka.n_wg), dim3(TSQ_KR_NT), lds, ctx->stream, ka);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_kr_offsets, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, ka);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_kr_scan, dim3(1), dim3(1024), 0, ctx->stream, ka.pstart, P, ka.flags);
+    TSQ_HIP(h, hipGetLastError());
+    hipLaunchKernelGGL(k_kr_scatter, dim3(ka.n_wg), dim3(TSQ_KR_NT), lds, ctx->stream, ka);
+    TSQ_HIP(h, hipGetLastError());
+    // ---- records -> group ids (new keys enter the dictionary)
+    TSQ_TRY(a->kd_dloc.reserve(ctx, h, (size_t)(a->kd_next_host + nrows) * 4 + 64, true, (size_t)a->kd_next_host * 4));
+    TSQ_TRY(a->kd_ridx.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(a->kd_gid.reserve(ctx, h, (size_t)nrows * 8 + 64));
+    KdArgs da;
+    memset(&da, 0, sizeof da);
+    da.prec = ka.rec;
+    da.pstart = ka.pstart;
+    da.P = P;
+    da.drec = a->kd_drec.as<unsigned long long>();
+    da.dids = a->kd_dids.as<uint32_t>();
+    da.dcount = a->kd_dcount.as<uint32_t>();
+    da.dloc = a->kd_dloc.as<uint32_t>();
+    da.next_id = ctl;
+    da.ridx = a->kd_ridx.as<uint32_t>();
+    da.gid = a->kd_gid.as<uint64_t>();
+    da.counters = ctl + 1;
+    hipLaunchKernelGGL(k_kd_assign, dim3(std::min<uint32_t>(P, (uint32_t)ctx->num_cus * 2)), dim3(TSQ_KD_NT), 0, ctx->stream, da);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 60, ctl, 24, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    a->st.kernel_launches += 5;
+    a->kd_next_host = (int64_t)ctx->pinned[60];
+    const int64_t n_exc = (int64_t)ctx->pinned[61], n_norec = (int64_t)ctx->pinned[62];
+    const int64_t n_rec = nrows - n_norec;
+    // ---- the child's batch: ids + the travelled columns, in partition order
+    tsq_agg* c = a->wide;
+    tsq_colset cin;
+    memset(&cin, 0, sizeof cin);
+    cin.n = 1 + a->kd_npay;
+    cin.data[0] = a->kd_gid.p;
+    cin.type[0] = TSQ_U64;
+    for (int v = 0; v < a->kd_npay; v++) {
+        cin.data[1 + v] = a->kd_pay[v].p;
+        cin.type[1 + v] = a->cfg.input_types[a->kd_paycol[v]];
+        if (in.nulls[a->kd_paycol[v]] && n_rec > 0) {  // the NOT-NULL bits of the column, in partition order
+            TSQ_TRY(a->kd_paybm[v].reserve(ctx, h, tsq_bitmap_bytes(n_rec) + 64));
+            hipLaunchKernelGGL(k_kd_nn_bitmap, dim3(tsq_grid_for(ctx, (n_rec + 7) / 8, 256)), dim3(256), 0, ctx->stream, (const uint8_t*)a->kd_paynn.p, n_rec, (uint32_t)v,
+                               a->kd_paybm[v].as<uint8_t>());
+            TSQ_HIP(h, hipGetLastError());
+            cin.nulls[1 + v] = a->kd_paybm[v].as<uint8_t>();
+            a->st.kernel_launches++;
+        }
+    }
+    a->wide_batches++;
+    c->cfg.est_groups = std::max<int64_t>(1, a->kd_next_host);  // (the child need not learn its cardinality from a prefix of the batch)
+    // ... nor find its table too small in the middle of a merge (a failed merge is a second merge): every id is a group of the child
+    if (!c->multi && c->tb.cap < (uint64_t)a->kd_next_host * 2) {
+        const tsq_status gs = grow_table(c, (uint64_t)a->kd_next_host * 3 + 16);
+        if (gs != TSQ_OK) { h->err = c->hdr.err; return gs; }
+    }
+    if (n_exc == 0) {
+        if (n_rec > 0) {
+            const tsq_status s = agg_batch(c, cin, n_rec);
+            if (s != TSQ_OK) { h->err = c->hdr.err; return s; }
+            c->in_rows += n_rec;
+        }
+    } else {
+        // rows whose partition of the dictionary is full: the several-column upsert into this operator's own table (by source row); the others
+        // go to the child as a list of positions
+        TSQ_TRY(a->wide_okrows.reserve(ctx, h, (size_t)n_rec * 4 + 64));
+        TSQ_TRY(a->wide_excrows.reserve(ctx, h, (size_t)n_exc * 4 + 64));
+        KdListArgs la;
+        memset(&la, 0, sizeof la);
+        la.gid = da.gid;
+        la.ids = ka.ids;
+        la.n = n_rec;
+        la.ok_pos = a->wide_okrows.as<uint32_t>();
+        la.exc_rows = a->wide_excrows.as<uint32_t>();
+        la.cursors = ctl + 3;
+        hipLaunchKernelGGL(k_kd_lists, dim3(tsq_grid_for(ctx, n_rec, 256)), dim3(256), 0, ctx->stream, la);
+        TSQ_HIP(h, hipGetLastError());
+        a->st.kernel_launches++;
+        if (n_rec - n_exc > 0) {
+            const tsq_status s = agg_rows(c, cin, n_rec - n_exc, la.ok_pos);
+            if (s != TSQ_OK) { h->err = c->hdr.err; return s; }
+        }
+        c->in_rows += n_rec - n_exc;
+        TSQ_TRY(agg_rows(a, in, n_exc, la.exc_rows));
+    }
+    a->wide_exception_rows += n_exc + n_norec;
+    if (n_norec > 0) TSQ_TRY(agg_rows(a, in, n_norec, ka.norec));  // key cells that do not fit a record
+    return TSQ_OK;
+}
+
 tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     if (nrows == 0) return TSQ_OK;
     if (a->stream) return stream_batch(a, in, nrows);
@@ -2084,6 +2309,15 @@ tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
         }
         if (a->wide_state == 1) return wide_batch(a, in, nrows);
     }
+    // string keys / key columns the composite word cannot hold: the dictionary of group keys + a child GROUP BY id (kd_setup)
+    // (integer key columns: only what neither the packed several-column route nor the composite word can hold)
+    bool kd_turn = a->kd_ok && a->wide_state <= 0;
+    if (kd_turn && !a->has_str_key) kd_turn = a->wide_ok && a->wide_state == -1 && a->da_state != 1;
+    if (kd_turn && a->fast_mode != TSQ_AGGFAST_OFF && nrows < 0x7fffffffLL) {
+        if (a->groups == 0 && a->in_rows == 0 && (nrows >= (1 << 16) || a->fast_mode == TSQ_AGGFAST_FORCE)) TSQ_TRY(kd_setup(a, in, nrows));
+        a->kd_ok = a->kd_mode;  // (rows already live in the several-column table, or the setup refused: keep one table)
+    }
+    if (a->kd_mode) return kd_batch(a, in, nrows);
     const bool want_fast = a->fast_ok && a->fast_mode != TSQ_AGGFAST_OFF && nrows < 0x7fffffffLL &&
                            (a->fast_mode == TSQ_AGGFAST_FORCE || nrows >= (1 << 20));
     if (!want_fast) return agg_rows(a, in, nrows, nullptr);
@@ -2392,7 +2626,42 @@ TSQ_API tsq_status tsq_agg_create(tsq_ctx* ctx, const tsq_agg_cfg* cfg, tsq_agg*
     a->wide_ok = cfg->n_group_keys >= 2 && !has_str && tsq_knob(ctx, TSQ_KNOB_AGG_WIDE_KEYS, 1) != 0;
     for (int k = 0; k < cfg->n_group_keys && a->wide_ok; k++)
         if (cfg->group_key_type[k] != TSQ_I64 && cfg->group_key_type[k] != TSQ_U64) a->wide_ok = false;
-    uint64_t cap = cfg->n_group_keys == 0 ? 16 : ((cfg->est_groups > 0 && !a->wide_ok) ? (uint64_t)cfg->est_groups * 2 + 16 : (1u << 16));
+    // string keys, or several key columns of integers and strings: the dictionary of group keys may take this aggregate (kd_setup decides
+    // at the first batch, after the composite-key route): key cells that fit a key record, 8-byte argument columns that travel
+    {
+        bool ok = cfg->n_group_keys >= 1 && (cfg->n_group_keys >= 2 || cfg->group_key_type[0] == TSQ_BYTES) && tsq_knob(ctx, TSQ_KNOB_KEYREC, 1) != 0;
+        for (int k = 0; k < cfg->n_group_keys && ok; k++) {
+            const int32_t t = cfg->group_key_type[k];
+            ok = t == TSQ_I64 || t == TSQ_U64 || t == TSQ_BYTES;
+        }
+        a->kd_npay = 0;
+        auto travel = [&](int c) {
+            if (c < 0) return true;
+            const int32_t t = cfg->input_types[c];
+            if (t != TSQ_I64 && t != TSQ_U64 && t != TSQ_F64) return false;
+            for (int v = 0; v < a->kd_npay; v++)
+                if (a->kd_paycol[v] == c) return true;
+            if (a->kd_npay == TSQ_KR_MAXPAY) return false;
+            a->kd_paycol[a->kd_npay++] = c;
+            return true;
+        };
+        for (int i = 0; i < cfg->n_aggs && ok; i++) {
+            const tsq_agg_func& f = cfg->aggs[i];
+            if (f.func == TSQ_AGG_FIRSTROW) {  // only of a group key column: its value comes back from the dictionary
+                bool is_key = false;
+                for (int k = 0; k < cfg->n_group_keys; k++) is_key = is_key || f.arg_col == cfg->group_key_col[k];
+                ok = is_key;
+                continue;
+            }
+            const bool merge = f.mode == TSQ_MODE_FINAL || f.mode == TSQ_MODE_PARTIAL2;
+            ok = travel(f.arg_col) && (!(f.func == TSQ_AGG_AVG && merge) || travel(f.arg_col2));
+        }
+        int fixed_bytes = 0;  // what the cells need at least: 9 bytes per integer cell, flag + length per string cell
+        for (int k = 0; k < cfg->n_group_keys; k++) fixed_bytes += cfg->group_key_type[k] == TSQ_BYTES ? 2 : 9;
+        a->kd_ok = ok && cfg->n_input_cols < TSQ_MAX_COLS && fixed_bytes <= TSQ_KR_BYTES;
+        for (int k = 0; k < cfg->n_group_keys; k++) a->has_str_key = a->has_str_key || cfg->group_key_type[k] == TSQ_BYTES;
+    }
+    uint64_t cap = cfg->n_group_keys == 0 ? 16 : ((cfg->est_groups > 0 && !a->wide_ok && !a->kd_ok) ? (uint64_t)cfg->est_groups * 2 + 16 : (1u << 16));
     if (s == TSQ_OK) s = alloc_table(a.get(), a->tb, cap);
     if (s == TSQ_OK) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -2530,7 +2799,37 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
                 TSQ_HIP(h, hipMemcpyAsync(a->onn[oc].as<uint8_t>() + g_own, c->onn[src].p, (size_t)g_child, hipMemcpyDeviceToDevice, ctx->stream));
             }
         }
-        if (da.n_out) {
+        if (da.n_out && a->kd_mode) {  // the key columns come back from the dictionary records
+            KdDecodeArgs ka;
+            memset(&ka, 0, sizeof ka);
+            ka.id = da.d;
+            ka.n = g_child;
+            ka.dloc = a->kd_dloc.as<uint32_t>();
+            ka.drec = a->kd_drec.as<unsigned long long>();
+            ka.n_keys = a->plan.n_keys;
+            ka.len_bits = TSQ_REF_LEN_BITS;
+            for (int k = 0; k < a->plan.n_keys; k++) ka.key_is_str[k] = a->cfg.group_key_type[k] == TSQ_BYTES ? 1 : 0;
+            // (two FIRST_ROWs of one key column: the decode kernel fills one output per key column, the others are copies)
+            int first_of[TSQ_MAX_GROUP_KEYS];
+            for (int k = 0; k < TSQ_MAX_GROUP_KEYS; k++) first_of[k] = -1;
+            for (int o = 0; o < da.n_out; o++) {
+                const int k = da.key_of[o];
+                if (first_of[k] < 0) {
+                    first_of[k] = o;
+                    ka.out[k] = da.out[o];
+                    ka.out_nn[k] = da.out_nn[o];
+                }
+            }
+            hipLaunchKernelGGL(k_kd_decode, dim3(tsq_grid_for(ctx, g_child, 256)), dim3(256), 0, ctx->stream, ka);
+            TSQ_HIP(h, hipGetLastError());
+            for (int o = 0; o < da.n_out; o++) {
+                const int f0 = first_of[da.key_of[o]];
+                if (f0 == o) continue;
+                TSQ_HIP(h, hipMemcpyAsync(da.out[o], da.out[f0], (size_t)g_child * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                TSQ_HIP(h, hipMemcpyAsync(da.out_nn[o], da.out_nn[f0], (size_t)g_child, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            a->st.kernel_launches++;
+        } else if (da.n_out) {
             hipLaunchKernelGGL(k_agg_wide_decode, dim3(tsq_grid_for(ctx, g_child, 256)), dim3(256), 0, ctx->stream, da);
             TSQ_HIP(h, hipGetLastError());
             a->st.kernel_launches++;
@@ -2562,6 +2861,8 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
         ra.notnull = a->onn[oc].as<uint8_t>();
         ra.rows = g;
         ra.heap = (const uint8_t*)a->heap[a->out_arg_col[oc]].data.p;
+        ra.heap_child = a->kd_mode ? (const uint8_t*)a->kd_drec.p : nullptr;
+        ra.child_from = a->kd_mode ? g_own : g;
         ra.out_offs = a->ooffs[oc].as<int64_t>();
         hipLaunchKernelGGL(k_ref_len, dim3(tsq_grid_for(ctx, g, 256)), dim3(256), 0, ctx->stream, ra);
         TSQ_HIP(h, hipGetLastError());
@@ -2757,7 +3058,7 @@ TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
             a->st.packed_key_bits = cs.packed_key_bits;
         }
         a->st.build_handed_back_rows = a->wide_exception_rows;
-        a->st.build_partitioned = 2;  // (aggregate: 2 = several key columns composed into one 64-bit key)
+        a->st.build_partitioned = a->kd_mode ? 3 : 2;  // (aggregate: 2 = several key columns composed into one 64-bit key, 3 = group keys through the dictionary of key records)
     }
     a->st.heap_bytes = 0;
     for (const ColStore& hs : a->heap)
@@ -2777,6 +3078,11 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
         a->wide = nullptr;
     }
     for (DevBuf* b : {&a->wide_d, &a->wide_okrows, &a->wide_excrows}) b->release();
+    for (DevBuf* b : {&a->kd_counts, &a->kd_pstart, &a->kd_rec, &a->kd_ids, &a->kd_flags, &a->kd_paynn, &a->kd_norec, &a->kd_ridx, &a->kd_gid, &a->kd_drec,
+                      &a->kd_dids, &a->kd_dcount, &a->kd_dloc, &a->kd_ctl})
+        b->release();
+    for (auto& b : a->kd_pay) b.release();
+    for (auto& b : a->kd_paybm) b.release();
     a->tb.release();
     a->counters.release();
     a->retry[0].release();

@@ -1,5 +1,5 @@
 // tsq_keyrec.h — COUNT(*) of an inner join on SEVERAL key columns and on STRING keys, partitioned (round 5; device code, included by
-// tsq_join.hip).
+// tsq_join.hip; the aggregate's dictionary of group keys, tsq_keydict.h, partitions its rows with the same passes).
 //
 // The reference's own join benchmark keys on (bigint, varstring) — `keyIdx: []int{0, 1}`, executor/benchmark_test.go:352-360 — and that
 // shape took the direct route: a hash of the key cells finds a slot of the 64-bit table in HBM, then the build row's cells are fetched
@@ -38,8 +38,10 @@ struct KrSrc {
     tsq_colset cs;
     int32_t n_keys;
     int32_t col[TSQ_MAX_KEYS];
+    int32_t keep_nulls;      // GROUP BY: a NULL cell is a key like any other (one NilFlag byte, codec.go:718-719) — a join drops the row
     int64_t nrows;
 };
+#define TSQ_KR_MAXPAY 4
 struct KrArgs {
     KrSrc src;
     uint32_t pbits;          // log2(partitions)
@@ -50,6 +52,14 @@ struct KrArgs {
     unsigned long long* rec; // scatter: [records][4] in partition order
     uint32_t* ids;           // scatter: the source row of every record (nullptr: not kept — COUNT(*) needs no row numbers)
     uint32_t* flags;         // [0] |= 1: a row's record does not fit (build side: the route is off)
+    // the aggregate (tsq_keydict.h): 8-byte argument cells travel with the records, rows without a record are listed
+    int32_t n_pay;
+    const uint64_t* pay_src[TSQ_KR_MAXPAY];
+    const uint8_t* pay_nulls[TSQ_KR_MAXPAY];
+    uint64_t* pay_dst[TSQ_KR_MAXPAY];
+    uint8_t* pay_nn;         // [records] bit v: travelling cell v is NOT NULL (nullptr: no travelling column is nullable)
+    uint32_t* norec;         // rows whose cells do not fit a record (nullptr: not kept)
+    unsigned long long* norec_count;
 };
 
 // `nb` (1..8) low bytes of x at byte position `at` of the record words (no array indexed by a run-time value: those live in scratch
@@ -79,7 +89,12 @@ __device__ __forceinline__ bool kr_record(const KrSrc& s, int64_t row, uint64_t 
     *toolong = false;
     for (int k = 0; k < s.n_keys; k++) {
         const int c = s.col[k];
-        if (tsq_is_null(s.cs.nulls[c], row)) return false;
+        if (tsq_is_null(s.cs.nulls[c], row)) {
+            if (!s.keep_nulls) return false;
+            if (at + 1 > TSQ_KR_BYTES) { *toolong = true; return false; }
+            at += 1;  // NilFlag = 0: the record's bytes are zero already (every other cell starts with a non-zero flag)
+            continue;
+        }
         if (s.cs.type[c] == TSQ_BYTES) {
             const int64_t o = s.cs.offs[c][row], n = s.cs.offs[c][row + 1] - o;
             if (n > 255 || at + 2 + (uint32_t)n > TSQ_KR_BYTES) { *toolong = true; return false; }
@@ -110,7 +125,7 @@ __device__ __forceinline__ uint64_t kr_hash(const uint64_t (&w)[4]) {
 }
 
 // counts[wg][p]: how many rows of workgroup wg's chunk belong to partition p (an LDS histogram, written out coalesced)
-__global__ void __launch_bounds__(TSQ_KR_NT) k_kr_hist(KrArgs a) {
+static __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_hist(KrArgs a) {
     extern __shared__ uint32_t s_hist[];
     const uint32_t wg = blockIdx.x, P = 1u << a.pbits;
     for (uint32_t i = threadIdx.x; i < P; i += TSQ_KR_NT) s_hist[i] = 0;
@@ -132,7 +147,7 @@ __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_hist(KrArgs a) {
     for (uint32_t i = threadIdx.x; i < P; i += TSQ_KR_NT) a.counts[(size_t)wg * P + i] = s_hist[i];
 }
 // thread p: the prefix of partition p's counts over the workgroups (coalesced across p), its total -> pstart[p]
-__global__ void __launch_bounds__(256) k_kr_offsets(KrArgs a) {
+static __global__ void __launch_bounds__(256) k_kr_offsets(KrArgs a) {
     const uint32_t P = 1u << a.pbits;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
@@ -150,7 +165,7 @@ __global__ void __launch_bounds__(256) k_kr_offsets(KrArgs a) {
     a.pstart[p] = run;
 }
 // exclusive scan of pstart[0 .. P) in place, pstart[P] = total; flags[1] = the largest partition (one workgroup of 1024 threads)
-__global__ void __launch_bounds__(1024) k_kr_scan(uint32_t* v, uint32_t n, uint32_t* flags) {
+static __global__ void __launch_bounds__(1024) k_kr_scan(uint32_t* v, uint32_t n, uint32_t* flags) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_run, s_max;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -183,7 +198,7 @@ __global__ void __launch_bounds__(1024) k_kr_scan(uint32_t* v, uint32_t n, uint3
     }
 }
 // the records to their places: pstart[p] + counts[wg][p] + the row's rank among the workgroup's rows of p (an LDS cursor)
-__global__ void __launch_bounds__(TSQ_KR_NT) k_kr_scatter(KrArgs a) {
+static __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_scatter(KrArgs a) {
     extern __shared__ uint32_t s_cur[];
     const uint32_t wg = blockIdx.x, P = 1u << a.pbits;
     for (uint32_t i = threadIdx.x; i < P; i += TSQ_KR_NT) s_cur[i] = a.pstart[i] + a.counts[(size_t)wg * P + i];
@@ -192,13 +207,26 @@ __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_scatter(KrArgs a) {
     for (int64_t row = lo + threadIdx.x; row < hi; row += TSQ_KR_NT) {
         uint64_t w[4];
         bool toolong;
-        if (!kr_record(a.src, row, w, &toolong)) continue;
+        if (!kr_record(a.src, row, w, &toolong)) {
+            if (toolong && a.norec) a.norec[atomicAdd(a.norec_count, 1ull)] = (uint32_t)row;  // (rare: one device atomic per such row)
+            continue;
+        }
         const uint32_t p = a.pbits ? (uint32_t)(kr_hash(w) >> (64 - a.pbits)) : 0u;
         const uint64_t pos = atomicAdd(&s_cur[p], 1u);
         ulonglong2* d = reinterpret_cast<ulonglong2*>(a.rec + pos * 4);
         d[0] = make_ulonglong2(w[0], w[1]);
         d[1] = make_ulonglong2(w[2], w[3]);
         if (a.ids) a.ids[pos] = (uint32_t)row;
+        if (a.n_pay) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int v = 0; v < TSQ_KR_MAXPAY; v++)
+                if (v < a.n_pay) {
+                    a.pay_dst[v][pos] = a.pay_src[v][row];
+                    m |= tsq_is_null(a.pay_nulls[v], row) ? 0u : (1u << v);
+                }
+            if (a.pay_nn) a.pay_nn[pos] = (uint8_t)m;
+        }
     }
 }
 
@@ -224,7 +252,7 @@ struct KrProbeArgs {
 // record one entry (tag = 18 bits of the mix that neither chose the partition nor the slot, 14-bit record number).  A probe record
 // walks the slots from its home until an empty one; on a tag match the build record's four words are compared (a false tag match
 // costs one more 32-byte read, 2^-18 per slot looked at).  Duplicate build keys are separate entries (the multimap of rowHashMap).
-__global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
+static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
     __shared__ uint32_t s_tab[TSQ_KR_SLOTS];
     __shared__ unsigned long long s_cnt;
     __shared__ unsigned long long s_pcnt;  // joined rows of the current partition (sizing) / its output cursor (emit)
@@ -290,7 +318,7 @@ __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
     if (tid == 0 && s_cnt && !a.part_cnt) atomicAdd(&a.counters[0], s_cnt);
 }
 // exclusive scan of v[0 .. n) in place, v[n] = total (one workgroup of 1024 threads, 64-bit counts)
-__global__ void __launch_bounds__(1024) k_kr_scan64(unsigned long long* v, uint32_t n) {
+static __global__ void __launch_bounds__(1024) k_kr_scan64(unsigned long long* v, uint32_t n) {
     __shared__ unsigned long long s_w[16];
     __shared__ unsigned long long s_run;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;

@@ -1100,8 +1100,8 @@ def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
 
 TRAFFIC_FILE = "traffic_r05.json" if os.path.exists(os.path.join(ROOT, "profiles", "traffic_r05.json")) else "traffic_r04.json"
 TRAFFIC_KERNELS = {
-    "c3_agg_1e9_1e6": ["void k_daagg_partition<1024, 8, 1", "void k_agg_da<3, 4096, 1>", "k_daagg_dense_emit", "k_agg_merge("],
-    "c3_agg_1e9_1e6_double": ["void k_daagg_partition<1024, 8, 1>", "void k_agg_da<2, 4096, 2>"],
+    "c3_agg_1e9_1e6": ["void k_daagg_partition<512, 8, 1, 2, false>", "void k_daagg_partition<1024, 8, 1", "void k_agg_da<3, 4096, 1>", "k_daagg_dense_emit", "k_agg_merge("],
+    "c3_agg_1e9_1e6_double": ["void k_daagg_partition<1024, 8, 1, 8, true>", "void k_daagg_partition<1024, 8, 1>", "void k_agg_da<2, 4096, 2>"],
     "c3_zipf_s1": ["void k_daagg_ovf<3>"],
     "c3_sparse_keys": ["void k_radix_partition<1024, 8, 4, 1, false, true>", "void k_agg_lds<1, 3>"],
     "agg_two_keys_50x20": ["void k_agg_da_low<3, 4096>"],
@@ -1111,6 +1111,8 @@ TRAFFIC_KERNELS = {
     "wide_keys_31bit_unique_bit_cells": ["void k_da_build_bits<1024>", "void k_da_probe_count<1024, unsigned int, false, false, true>",
                                          "void k_da_partition<1024, 16, unsigned int, false, false>"],
     "two_key_columns_count": ["k_da_compose", "void k_probe_count<true, false, false>"],
+    "stream_agg_1e8_ordered": ["void k_sa_update_lanes", "k_sa_count", "k_sa_scan"],
+    "two_key_bigint_string_count": ["k_kr_hist", "k_kr_scatter", "k_kr_probe", "k_kr_offsets"],
 }
 
 
