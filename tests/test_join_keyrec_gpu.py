@@ -163,8 +163,32 @@ def test_materialising_join_on_bigint_and_varstring_keys(ctx, orc):
     stats = []
     got0 = G.run_join(ctx, cfg0, build, probe, chunk_rows=1 << 20, radix=FORCE, stats_out=stats)
     assert stats[0].probe_route == abi.ROUTE_KEYREC and H.rows_equal_unordered(got0, want0)
-    # an outer join keeps the direct route (the records know no miss rows)
-    cfgo = H.join_cfg(probe.types(), build.types(), [0, 1], [0, 1], abi.JOIN_LEFT_OUTER, 1)
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+@pytest.mark.parametrize("with_selected,with_filter", [(False, False), (True, False), (False, True), (True, True)])
+def test_outer_joins_on_key_records(ctx, orc, jt, inner, with_selected, with_filter):
+    """leftOuterJoiner / rightOuterJoiner (joiner.go:220-344) on (bigint, varstring) keys: an outer row without a joined build row comes out
+    once, NULL-padded — a probe record that met no equal build record (a pair with the MISS build row), and the outer rows that have no key
+    record at all: a NULL key cell, cells that do not fit 32 bytes, selected == 0 (join.go:344), an outer-side filter that said no
+    (evaluated into flags by the library, k_outer_filter_flags)."""
+    rng = np.random.default_rng(303 + jt + 2 * with_selected + with_filter)
+    nb, npr = 9_000, 30_001
+    words = [b"w%03d" % i for i in range(150)] + [b"", b"a", b"a\x00", b"L" * 40]
+    bw = [None if rng.random() < 0.03 else words[int(i)] for i in rng.integers(0, len(words), nb)]
+    pw = [None if rng.random() < 0.03 else words[int(i)] for i in rng.integers(0, len(words), npr)]
+    build = Chunk([Column(abi.I64, rng.integers(0, 40, nb), rng.random(nb) > 0.02), StrColumn(bw), Column(abi.F64, rng.random(nb), rng.random(nb) > 0.1)])
+    probe = Chunk([Column(abi.I64, rng.integers(0, 50, npr), rng.random(npr) > 0.02), StrColumn(pw), Column(abi.F64, rng.random(npr), rng.random(npr) > 0.1)])
+    # (a 40-byte word on the BUILD side would switch the route off: the build side keeps short words only)
+    build = Chunk([build.columns[0], StrColumn([None if w is not None and len(w) > 30 else w for w in bw]), build.columns[2]])
+    sel = (rng.random(npr) > 0.3).astype(np.uint8) if with_selected else None
+    left, right = (probe, build) if inner == 1 else (build, probe)
+    from tinysql_amd import expression as E
+    filters = [E.ScalarFunction("gt", E.Column(2, abi.F64), E.Constant(0.25))] if with_filter else ()
+    keep = []
+    cfg = H.join_cfg(left.types(), right.types(), [0, 1], [0, 1], jt, inner, (), filters, keep, probe_batch_rows=16_000)
+    want = orc.hash_join(cfg, build, probe, selected=sel)
     stats = []
-    goto = G.run_join(ctx, cfgo, build, probe, chunk_rows=1 << 20, radix=FORCE, stats_out=stats)
-    assert stats[0].probe_route == abi.ROUTE_DIRECT and H.rows_equal_unordered(goto, orc.hash_join(cfgo, build, probe))
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 20, pull_rows=4096, selected=sel, radix=FORCE, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_KEYREC, stats[0].probe_route
+    assert got.NumRows() == want.NumRows() >= npr and H.rows_equal_unordered(got, want)

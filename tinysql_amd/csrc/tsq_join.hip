@@ -786,7 +786,7 @@ struct tsq_join {
     // key records (tsq_keyrec.h): COUNT(*) on several key columns / string keys whose cells fit 32 bytes, partitioned
     int kr_state = 0;                 // 0: not tried, 1: the build side's records are in place, -1: not usable for this build side
     uint32_t kr_pbits = 0;
-    DevBuf kr_brec, kr_bstart, kr_counts, kr_prec, kr_pstart, kr_flags, kr_bids, kr_pids, kr_pcnt;
+    DevBuf kr_brec, kr_bstart, kr_counts, kr_prec, kr_pstart, kr_flags, kr_bids, kr_pids, kr_pcnt, kr_norec;
     bool filters_folded = false;      // this batch: the outer-side filters are already in the selected[] flags the packed routes take (fold_outer_filters)
     DevBuf fflags;                    //   ... those flags
     DevBuf heads;                     // da_emit_cols: first-candidate flags of a batch (outer join + conditions + duplicate build keys)
@@ -3110,7 +3110,7 @@ bool kr_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected
 // hist -> offsets -> scan [-> check] -> scatter of one side.  `check`: read the flags after the scan (a synchronisation): *ok = every
 // record fits and no partition holds more than TSQ_KR_CAP of them
 tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, int64_t nrows, uint32_t pbits, DevBuf& counts, DevBuf& pstart, DevBuf& rec,
-                   bool check, bool* ok, DevBuf* ids = nullptr) {
+                   bool check, bool* ok, DevBuf* ids = nullptr, const uint8_t* selected = nullptr, bool list_rows_without_key = false) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const uint32_t P = 1u << pbits;
@@ -3120,10 +3120,18 @@ tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, i
     a.src.n_keys = j->ks.n_keys;
     for (int k = 0; k < j->ks.n_keys; k++) a.src.col[k] = key_cols[k];
     a.src.nrows = nrows;
+    a.src.selected = selected;
     a.pbits = pbits;
     const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;
     a.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(TSQ_KR_MAXWG, chunks));
     a.rows_per_wg = ((chunks + a.n_wg - 1) / a.n_wg) * TSQ_KR_NT;
+    if (list_rows_without_key) {  // the outer side of an outer join: rows with a NULL key cell, cells beyond a record, selected == 0
+        TSQ_TRY(j->kr_norec.reserve(ctx, h, (size_t)nrows * 4 + 64));
+        a.norec = j->kr_norec.as<uint32_t>();
+        a.norec_all = 1;
+        a.norec_count = (unsigned long long*)(ctx->dscratch + 58);
+        TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 58, 0, 8, ctx->stream));
+    }
     TSQ_TRY(counts.reserve(ctx, h, (size_t)a.n_wg * P * 4 + 64));
     TSQ_TRY(pstart.reserve(ctx, h, ((size_t)P + 1) * 4 + 64));
     TSQ_TRY(rec.reserve(ctx, h, (size_t)nrows * TSQ_KR_BYTES + 64));
@@ -3208,19 +3216,22 @@ tsq_status kr_count_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
 // columns included) — inner joins without conditions; the reference's BenchmarkHashJoinExec shape (benchmark_test.go:352-360) with its rows
 bool kr_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_dev) {
     if (j->radix_mode == TSQ_RADIX_OFF || !j->multi || j->kr_state < 0 || tsq_knob(j->ctx, TSQ_KNOB_KEYREC, 1) == 0) return false;
-    if (j->count_only || j->general_cfg || selected_dev || j->never_match || j->ordered) return false;
+    // inner and outer joins; outer-side filters arrive as flags (fold_outer_filters), OtherConditions keep the direct route
+    (void)selected_dev;
+    if (j->count_only || !j->conds_h.empty() || (!j->filters_h.empty() && !j->filters_folded) || j->never_match || j->ordered) return false;
     if (nrows <= 0 || nrows > 0x7fffffffLL) return false;
     const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
     if (nb <= 0 || nb > (int64_t)TSQ_KR_MAXP * TSQ_KR_FILL || nb > 0xffffffffLL) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE) return true;
     return nrows >= (1 << 18) && nb >= (1 << 18);
 }
-tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows) {
+tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows, const uint8_t* selected_dev) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     bool ok = true;
-    TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok, &j->kr_pids));
+    const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
+    TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok, &j->kr_pids, selected_dev, outer));
     KrProbeArgs pa;
     memset(&pa, 0, sizeof pa);
     pa.brec = j->kr_brec.as<unsigned long long>();
@@ -3232,6 +3243,7 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     pa.flags = j->kr_flags.as<uint32_t>();
     pa.bids = j->kr_bids.as<uint32_t>();
     pa.pids = j->kr_pids.as<uint32_t>();
+    pa.outer = outer ? 1 : 0;
     // sizing launch: joined rows per partition; their exclusive scan = every partition's first output row
     TSQ_TRY(j->kr_pcnt.reserve(ctx, h, ((size_t)pa.P + 1) * 8 + 64));
     pa.part_cnt = j->kr_pcnt.as<unsigned long long>();
@@ -3242,8 +3254,11 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     hipLaunchKernelGGL(k_kr_scan64, dim3(1), dim3(1024), 0, ctx->stream, pa.part_cnt, pa.P);
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 41, pa.part_cnt + pa.P, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (outer) TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 42, ctx->dscratch + 58, 8, hipMemcpyDeviceToHost, ctx->stream));
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
-    const int64_t out_rows = (int64_t)ctx->pinned[41];
+    const int64_t part_rows = (int64_t)ctx->pinned[41];
+    const int64_t keyless = outer ? (int64_t)ctx->pinned[42] : 0;  // outer rows without a key: one NULL-padded row each, after the partitions' rows
+    const int64_t out_rows = part_rows + keyless;
     j->st.kernel_launches += 2;
     j->st.radix_batches++;
     j->st.radix_bits = (int32_t)j->kr_pbits;
@@ -3258,6 +3273,11 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
         hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
         TSQ_HIP(h, hipGetLastError());
         j->st.kernel_launches++;
+        if (keyless > 0) {
+            hipLaunchKernelGGL(k_kr_miss_pairs, dim3(tsq_grid_for(ctx, keyless, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)j->kr_norec.p, keyless, a.pairs + part_rows);
+            TSQ_HIP(h, hipGetLastError());
+            j->st.kernel_launches++;
+        }
         return TSQ_OK;
     });
 }
@@ -3366,7 +3386,8 @@ tsq_status probe_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const 
     if (!j->filters_h.empty() && !j->shared && !j->count_only) {
         // outer-side filters: worth a pass over the batch when a materialising packed route would take the batch without them
         j->filters_folded = true;
-        const bool packed = da_cols_eligible(j, nrows, selected_dev) || da_emit_eligible(j, nrows, selected_dev) || da_bits_emit_eligible(j, nrows);
+        const bool packed = da_cols_eligible(j, nrows, selected_dev) || da_emit_eligible(j, nrows, selected_dev) || da_bits_emit_eligible(j, nrows) ||
+                            kr_emit_eligible(j, nrows, selected_dev);
         j->filters_folded = false;
         if (packed) {
             bool folded = false;
@@ -3483,7 +3504,7 @@ tsq_status probe_batch_routes(tsq_join* j, const tsq_colset& pcs, int64_t nrows,
     }
     if (kr_emit_eligible(j, nrows, selected_dev)) {  // several key columns / string keys, materialising: pairs out of the key records
         TSQ_TRY(kr_prepare(j));
-        if (j->kr_state == 1) return kr_emit_batch(j, pcs, a, nrows);
+        if (j->kr_state == 1) return kr_emit_batch(j, pcs, a, nrows, selected_dev);
     }
     TSQ_TRY(need_table());
     TSQ_HIP(&j->hdr, hipEventRecord(j->ev[2], ctx->stream));
@@ -4413,7 +4434,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->da_ckey.release();
     j->rckey.release();
     for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_coarse_c, &j->da_pstart_c, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
-    for (DevBuf* b : {&j->kr_brec, &j->kr_bstart, &j->kr_counts, &j->kr_prec, &j->kr_pstart, &j->kr_flags, &j->kr_bids, &j->kr_pids, &j->kr_pcnt}) b->release();
+    for (DevBuf* b : {&j->kr_brec, &j->kr_bstart, &j->kr_counts, &j->kr_prec, &j->kr_pstart, &j->kr_flags, &j->kr_bids, &j->kr_pids, &j->kr_pcnt, &j->kr_norec}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
         j->da_bsorted[c].release();
         j->da_bsorted_nn[c].release();

@@ -39,6 +39,7 @@ struct KrSrc {
     int32_t n_keys;
     int32_t col[TSQ_MAX_KEYS];
     int32_t keep_nulls;      // GROUP BY: a NULL cell is a key like any other (one NilFlag byte, codec.go:718-719) — a join drops the row
+    const uint8_t* selected; // nullptr or one byte per row: 0 = the row has no key (an outer-side filter said no, join.go:344)
     int64_t nrows;
 };
 #define TSQ_KR_MAXPAY 4
@@ -58,7 +59,8 @@ struct KrArgs {
     const uint8_t* pay_nulls[TSQ_KR_MAXPAY];
     uint64_t* pay_dst[TSQ_KR_MAXPAY];
     uint8_t* pay_nn;         // [records] bit v: travelling cell v is NOT NULL (nullptr: no travelling column is nullable)
-    uint32_t* norec;         // rows whose cells do not fit a record (nullptr: not kept)
+    uint32_t* norec;         // rows whose cells do not fit a record (nullptr: not kept) ...
+    int32_t norec_all;       // ... and, for the outer side of an outer join, every other row without a key (NULL cell, selected == 0)
     unsigned long long* norec_count;
 };
 
@@ -87,6 +89,7 @@ __device__ __forceinline__ bool kr_record(const KrSrc& s, int64_t row, uint64_t 
     w[0] = w[1] = w[2] = w[3] = 0;
     uint32_t at = 0;
     *toolong = false;
+    if (s.selected && !s.selected[row]) return false;
     for (int k = 0; k < s.n_keys; k++) {
         const int c = s.col[k];
         if (tsq_is_null(s.cs.nulls[c], row)) {
@@ -208,7 +211,7 @@ static __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_scatter(KrArgs a) {
         uint64_t w[4];
         bool toolong;
         if (!kr_record(a.src, row, w, &toolong)) {
-            if (toolong && a.norec) a.norec[atomicAdd(a.norec_count, 1ull)] = (uint32_t)row;  // (rare: one device atomic per such row)
+            if ((toolong || a.norec_all) && a.norec) a.norec[atomicAdd(a.norec_count, 1ull)] = (uint32_t)row;  // (rare: one device atomic per such row)
             continue;
         }
         const uint32_t p = a.pbits ? (uint32_t)(kr_hash(w) >> (64 - a.pbits)) : 0u;
@@ -246,7 +249,9 @@ struct KrProbeArgs {
                                     // [P] = all of them; emit launch: positions = part_cnt[p] + an LDS cursor (one SHARED device cursor cost ~11 ns per joined
                                     // row chip-wide: 55 ms for 5e6 rows)
     uint32_t* flags;                 // [0] |= 2: a partition with more than TSQ_KR_CAP build records (cannot happen after the host's check)
+    int32_t outer;                   // materialising an outer join: a probe record without a joined build row makes one pair (probe row, TSQ_KR_MISS)
 };
+#define TSQ_KR_MISS 0xffffffffull
 // One workgroup per partition.  The build records of the partition stay where the scatter pass put them (a contiguous window of
 // <= 384 KB: it is read once to build the index and then served by the XCD's L2); LDS holds an open-addressed index over them — per
 // record one entry (tag = 18 bits of the mix that neither chose the partition nor the slot, 14-bit record number).  A probe record
@@ -262,7 +267,7 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
     for (uint32_t p = blockIdx.x; p < a.P; p += gridDim.x) {
         const uint64_t b0 = a.bstart[p], b1 = a.bstart[p + 1];
         const uint64_t p0 = a.pstart[p], p1 = a.pstart[p + 1];
-        if (b1 == b0 || p1 == p0) continue;  // (block-uniform)
+        if (p1 == p0 || (b1 == b0 && !a.outer)) continue;  // (block-uniform)
         uint32_t nb = (uint32_t)(b1 - b0);
         if (nb > TSQ_KR_CAP) {
             if (tid == 0) atomicOr(a.flags, 2u);
@@ -289,6 +294,7 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
             const uint64_t h = kr_hash(w);
             const uint32_t tag = (uint32_t)(h >> 14) & 0x3ffffu;
             uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
+            bool any = false;
             for (;;) {
                 const uint32_t e = s_tab[slot];
                 if (e == 0xffffffffu) break;
@@ -296,6 +302,7 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
                     const ulonglong2* bq = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + (e & 0x3fffu)) * 4);
                     const ulonglong2 bx = bq[0], by = bq[1];
                     if (bx.x == w[0] && bx.y == w[1] && by.x == w[2] && by.y == w[3]) {
+                        any = true;
                         mine++;
                         if (a.part_cnt) {  // materialising: count per partition (sizing), or the pair at the partition's next output row (emit)
                             const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
@@ -304,6 +311,10 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
                     }
                 }
                 slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
+            }
+            if (a.outer && !any) {  // onMissMatch: the outer row once, NULL-padded
+                const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
+                if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)a.pids[r] | (TSQ_KR_MISS << 32);
             }
         }
         if (a.part_cnt && !a.pairs) {
@@ -316,6 +327,10 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
     if ((tid & 63u) == 0 && mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
     if (tid == 0 && s_cnt && !a.part_cnt) atomicAdd(&a.counters[0], s_cnt);
+}
+// outer join: the outer rows that have no key at all (listed by the scatter pass), NULL-padded
+static __global__ void __launch_bounds__(256) k_kr_miss_pairs(const uint32_t* rows, int64_t n, unsigned long long* pairs) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) pairs[i] = (unsigned long long)rows[i] | (TSQ_KR_MISS << 32);
 }
 // exclusive scan of v[0 .. n) in place, v[n] = total (one workgroup of 1024 threads, 64-bit counts)
 static __global__ void __launch_bounds__(1024) k_kr_scan64(unsigned long long* v, uint32_t n) {

@@ -1074,6 +1074,104 @@ def extra_stream_agg(ctx, abi, _lib, n=100_000_000, groups=100_000):
             "ms": ms, "rows_per_s": n / ms * 1e3, "groups": int(g), "frac": 16.0 * n / ms / 1e6 / 8000.0, "verified": ok, "first_run_ms": runs[0], "sort_ms": sort_ms}
 
 
+def extra_agg_string_keys(ctx, abi, _lib, n=10_000_000, groups=100_000):
+    """SELECT s, SUM(v), COUNT(*) GROUP BY s over n device-resident rows, s a 16-byte binary string with `groups` distinct values (round 5:
+    the dictionary of group keys, csrc/tsq_keydict.h — key records hash-partitioned with the argument cell, one workgroup per partition
+    finds or inserts, a child aggregate groups by the dense id).  `ms` = tsq_agg_push + tsq_agg_finish of a fresh operator; `frac` prices
+    32 B per row (8 B of offsets + 16 B of key bytes + the 8-byte argument cell).  `several_column_upsert_ms` = the same with the route
+    off (TSQ_KNOB_KEYREC = 0: round 4's several-column upsert).  Verified per group against numpy (the key bytes decode back to k)."""
+    import numpy as np
+    lib = ctx.lib
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, groups, n)
+    v = rng.integers(0, 1000, n)
+    MUL, XOR = np.uint64(0x9E3779B97F4A7C15), np.uint64(0x1234567)
+    with np.errstate(over="ignore"):
+        a = (k.astype(np.uint64) * MUL) ^ XOR
+        b = (k.astype(np.uint64) + np.uint64(77)) * np.uint64(0xC2B2AE3D27D4EB4F)
+    sdata = np.ascontiguousarray(np.stack([a, b], axis=1)).view(np.uint8).reshape(-1)
+    offs = np.arange(n + 1, dtype=np.int64) * 16
+    dev = []
+
+    def up(arr):
+        p = ctx.alloc(arr.nbytes + 64)
+        ctx.h2d(p, np.ascontiguousarray(arr))
+        dev.append(p)
+        return p
+    try:
+        cols = (abi.Col * 2)()
+        cols[0].data, cols[0].offsets, cols[0].length, cols[0].elem_size, cols[0].type, cols[0].flags = up(sdata), up(offs), n, -1, abi.BYTES, abi.COL_DEVICE
+        cols[1] = _dev_col(abi, up(v), n)
+        cfg = abi.AggCfg()
+        cfg.n_group_keys = 1
+        cfg.group_key_col[0], cfg.group_key_type[0] = 0, abi.BYTES
+        cfg.n_input_cols = 2
+        cfg.input_types[0], cfg.input_types[1] = abi.BYTES, abi.I64
+        cfg.n_aggs = 3
+        for i, (f, col, t) in enumerate([(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_SUM, 1, abi.I64), (abi.AGG_COUNT, -1, abi.I64)]):
+            cfg.aggs[i].func, cfg.aggs[i].mode, cfg.aggs[i].arg_col, cfg.aggs[i].arg_type = f, abi.MODE_COMPLETE, col, t
+
+        def run(check):
+            h = C.c_void_p()
+            _lib.check(lib.tsq_agg_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+            try:
+                ctx.sync()
+                t0 = time.perf_counter()
+                _lib.check(lib.tsq_agg_push(h, cols, 2, n), h)
+                _lib.check(lib.tsq_agg_finish(h), h)
+                ctx.sync()
+                ms = (time.perf_counter() - t0) * 1e3
+                st = abi.Stats()
+                _lib.check(lib.tsq_agg_stats(h, C.byref(st)), h)
+                ok = None
+                if check:
+                    ng = C.c_int64(0)
+                    _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
+                    g = ng.value
+                    dk, do, ds, dc = ctx.alloc(g * 16 + 64), ctx.alloc((g + 1) * 8 + 64), ctx.alloc(g * 8 + 64), ctx.alloc(g * 8 + 64)
+                    bm = [ctx.alloc(g // 8 + 64) for _ in range(3)]
+                    oc = (abi.Col * 3)()
+                    oc[0].data, oc[0].offsets, oc[0].length, oc[0].elem_size, oc[0].type, oc[0].flags = dk, do, g, -1, abi.BYTES, abi.COL_DEVICE
+                    oc[1], oc[2] = _dev_col(abi, ds, g), _dev_col(abi, dc, g)
+                    for i in range(3):
+                        oc[i].null_bitmap = bm[i]
+                    gn, eos = C.c_int64(0), C.c_int32(0)
+                    _lib.check(lib.tsq_agg_pull(h, oc, 3, g, C.byref(gn), C.byref(eos)), h)
+                    hk, hs, hc = np.empty(g * 2, np.uint64), np.empty(g, np.int64), np.empty(g, np.int64)
+                    ctx.d2h(hk, dk)
+                    ctx.d2h(hs, ds)
+                    ctx.d2h(hc, dc)
+                    for p in [dk, do, ds, dc] + bm:
+                        ctx.free(p)
+                    with np.errstate(over="ignore"):
+                        back = ((hk[0::2] ^ XOR) * np.uint64(pow(0x9E3779B97F4A7C15, -1, 1 << 64))).astype(np.int64)  # the key bytes -> k
+                    cnt = np.bincount(k, minlength=groups)
+                    sm = np.bincount(k, weights=v.astype(np.float64), minlength=groups).astype(np.int64)
+                    ok = bool(gn.value == g == int((cnt > 0).sum()) and back.min() >= 0 and back.max() < groups and len(np.unique(back)) == g
+                              and (hc == cnt[back]).all() and (hs == sm[back]).all())
+                return ms, int(st.build_partitioned), ok
+            finally:
+                lib.tsq_agg_destroy(h)
+        run(False)
+        runs = [run(False) for _ in range(2)]
+        ms_v, route, ok = run(True)
+        ms = min(r[0] for r in runs)
+        upsert_ms = None
+        if groups <= 1_000_000:  # (the several-column upsert at 5e6 groups: 60 ms per 1e7 rows)
+            ctx.set_knob(abi.KNOB_KEYREC, 0)
+            try:
+                run(False)
+                upsert_ms = min(run(False)[0] for _ in range(2))
+            finally:
+                ctx.set_knob(abi.KNOB_KEYREC)
+    finally:
+        for d in dev:
+            ctx.free(d)
+    return {"workload": "SELECT s, SUM(v), COUNT(*) GROUP BY s: %.0e rows, %.0e distinct 16-byte string keys, HashAggExec through the dictionary of group keys" % (n, groups),
+            "ms": ms, "rows_per_s": n / ms * 1e3, "frac": 32.0 * n / ms / 1e6 / 8000.0, "verified": ok, "route": route,
+            "several_column_upsert_ms": upsert_ms}
+
+
 def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
     """(key, thunk) of every side measurement, in the order they run"""
     return (("build_warm", lambda: extra_build_warm(ctx, abi, _lib, bk, bv, nb)),
@@ -1094,6 +1192,8 @@ def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
             ("q3_sf100", lambda: extra_q3()),
             ("expr_kernels", lambda: extra_expr_kernels(ctx, abi, _lib)),
             ("stream_agg_1e8_ordered", lambda: extra_stream_agg(ctx, abi, _lib)),
+            ("agg_string_keys_1e7_1e5", lambda: extra_agg_string_keys(ctx, abi, _lib)),
+            ("agg_string_keys_1e7_5e6", lambda: extra_agg_string_keys(ctx, abi, _lib, groups=5_000_000)),
             ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
             ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True)))
 
@@ -1113,6 +1213,7 @@ TRAFFIC_KERNELS = {
     "two_key_columns_count": ["k_da_compose", "void k_probe_count<true, false, false>"],
     "stream_agg_1e8_ordered": ["void k_sa_update_lanes", "k_sa_count", "k_sa_scan"],
     "two_key_bigint_string_count": ["k_kr_hist", "k_kr_scatter", "k_kr_probe", "k_kr_offsets"],
+    "agg_string_keys_1e7_1e5": ["k_kd_assign", "k_kr_scatter", "k_kr_hist"],
 }
 
 
