@@ -138,3 +138,38 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
     seen = sorted(l for l in (r.stdout + r.stderr).splitlines() if l.startswith("bench-rank "))
     assert seen == ["bench-rank 0 of 2 local 0", "bench-rank 1 of 2 local 1"], (r.stdout[-500:], r.stderr[-500:])
+
+
+# ---- round 5: the line the driver's command printed on the GPU box (tools/gpu_r05_final.sh), in the compact form (< 4 KB) it parses
+def _line5():
+    raw = open(os.path.join(ROOT, "profiles", "r05_bench.json")).read().strip().splitlines()
+    assert len(raw) == 1, "stdout of bench.py is ONE line"
+    assert len(raw[0]) < 4096
+    return json.loads(raw[0])
+
+
+def test_round5_line_has_the_contract_keys_roofline_and_cpu_baseline():
+    d = _line5()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 20, 5)  # the driver's command
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "int64" and d["verified"] is True
+    assert "1e+08 x 1e+08" in d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["probe_rows_per_gpu"] / d["ms_per_step"] * 1e3) / d["value"] < 0.02
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.4 < r["frac"] < 1.0 and 0.0 < r["traffic_frac"] < 1.0 and 0.0 < r["step"]["frac"] < 1.0 and r["traffic"] > 5e8
+    assert r["kernel_ms"] < r["step"]["ms"] <= d["ms_per_step"] * 1.05  # the dominant kernel fits its step, the step the wall clock
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 5 and c["unit"] == "rows/s" and 1e6 < c["value"] < 1e8 and c["sample"]
+
+
+def test_round5_every_side_measurement_passed_its_check():
+    s = _line5()["sides"]
+    assert len(s) >= 30
+    for k, e in s.items():
+        assert "error" not in e and e.get("ok", True) is True, k
+    for k in ("c2_1e8x1e7", "c3_agg_1e9_1e6", "c3_zipf_s1", "c3_sparse_keys", "q3_sf100", "materialising", "two_key_bigint_string_count", "two_key_bigint_string_count.rows",
+              "wide_keys_64bit_route", "stream_agg_1e8_ordered", "agg_string_keys_1e7_1e5", "agg_string_keys_1e7_5e6", "expr_kernels.arith_int64",
+              "pcie_inclusive_1e7.native_chunks_of_1024_rows"):
+        assert k in s, k
