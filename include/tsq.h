@@ -139,6 +139,7 @@ enum {
     TSQ_KNOB_DAAGG_HOT = 27,         /* 0: the packed aggregate does not sample the batch for hot keys (their rows then travel through the partitioned store and its overflow store) */
     TSQ_KNOB_KEYREC = 28,            /* 0: COUNT(*) joins on several key columns / string keys never take the key-record route (csrc/tsq_keyrec.h) */
     TSQ_KNOB_STREAMAGG_LANES = 29,   /* 0: StreamAggExec always reduces every 64-row step across the lanes (k_sa_update) instead of keeping per-lane partial results of the open run (k_sa_update_lanes) */
+    TSQ_KNOB_XCD_ATOMICS = 30,       /* 1: the cursors of the per-XCD partition regions (headline partition kernel) are claimed with workgroup-scope atomics — performed in the XCD's own L2 — instead of agent-scope ones (default; measured equal) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
