@@ -816,7 +816,10 @@ typedef struct tsq_stats {
     int64_t radix_batches;         /* join: probe batches through the radix path; agg: batches pre-aggregated in LDS */
     int64_t radix_overflow_rows;   /* rows that did not fit their partition region (skew) in the last batch */
     int32_t radix_bits;            /* log2(partitions) of the last radix batch */
-    int32_t build_partitioned;     /* 1: the table was assembled slice by slice in LDS (tsq_buildpart.h), 0: row-at-a-time CAS build */
+    int32_t build_partitioned;     /* join: 1: the table was assembled slice by slice in LDS (tsq_buildpart.h), 0: row-at-a-time CAS build;
+                                      aggregate: 2: several integer key columns composed into one 64-bit key for a child aggregate, 3: the group
+                                      keys (strings / wide key sets) went through the dictionary of key records (tsq_keydict.h) to a child
+                                      aggregate by group id; build_handed_back_rows then counts the exception rows this operator kept */
     int64_t build_handed_back_rows; /* partitioned build: rows inserted row by row afterwards (skewed pass-1 / pass-2 regions);
                                        aggregate: rows of a multi-key GROUP BY whose 64-bit tag belonged to another key (resolved) */
     int32_t table_slice_bits;      /* join: log2(slices) of the join table (0: one slice); aggregate on the packed route: bits of a travelling argument cell (16 / 32: narrow cells, 64) */
