@@ -232,3 +232,19 @@ def test_integer_key_columns_too_wide_for_the_composite_word(ctx, orc):
         want = orc.hash_agg(cfg, chk, 4, 4)
         got, _ = _run(ctx, cfg, chk, aggs, want_dict=want_dict, chunk_rows=1 << 20, pull_rows=4096)
         assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+# ------------------------------------------------------------------ the reference's own aggregate vectors through the dictionary
+# tests/golden/agg_cases.json "sql" (executor/aggregate_test.go) groups by an integer column; grouping by its decimal text — a string
+# key, NULL staying NULL — makes the same groups, and with the fast paths FORCED that key goes through the dictionary of key records
+@pytest.mark.parametrize("case", [c for c in H.golden("agg_cases.json")["sql"] if c["group_by"]], ids=lambda c: c["ref"][:40])
+def test_golden_aggregate_cases_with_the_group_key_as_a_string(ctx, case):
+    types = [H.TYPES[t] for t in case["types"]]
+    gk = case["group_by"][0]
+    rows = [[(None if v is None else b"%d" % v) if i == gk else v for i, v in enumerate(r)] for r in case["rows"]]
+    stypes = [abi.BYTES if i == gk else t for i, t in enumerate(types)]
+    chk = H.chunk_from_rows(rows, stypes)
+    aggs = [(H.AGG_FUNCS[f], col, abi.BYTES if col == gk else H.TYPES[t]) for f, col, t in case["aggs"]]
+    cfg = H.agg_cfg(stypes, case["group_by"], aggs)
+    got, _ = _run(ctx, cfg, chk, aggs, want_dict=bool(case["rows"]))
+    assert H.rows_equal_unordered(got, [tuple(r) for r in case["expect"]]), case["ref"]

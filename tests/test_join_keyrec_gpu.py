@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from tinysql_amd import _abi as abi
+from tinysql_amd import expression as E
 from tinysql_amd.chunk import Chunk, Column, StrColumn
 
 from . import gpu_helpers as G
@@ -192,3 +193,40 @@ def test_outer_joins_on_key_records(ctx, orc, jt, inner, with_selected, with_fil
     got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 20, pull_rows=4096, selected=sel, radix=FORCE, stats_out=stats)
     assert stats[0].probe_route == abi.ROUTE_KEYREC, stats[0].probe_route
     assert got.NumRows() == want.NumRows() >= npr and H.rows_equal_unordered(got, want)
+
+
+# ------------------------------------------------------------------ the reference's own join vectors on the key-record route
+# tests/golden/join_cases.json (transcribed from executor/join_test.go) joins on ONE integer column.  Joining on (k, k') with k' a copy
+# of k appended to both sides is the same join — the same rows match, a NULL k is a NULL k' — and its key no longer packs into one
+# word, so with the radix routes FORCED the join takes the key records (joins with OtherConditions keep the direct route).
+@pytest.mark.parametrize("case", H.golden("join_cases.json"), ids=lambda c: c["ref"][:48])
+def test_golden_join_cases_on_two_key_columns(ctx, case):
+    from tinysql_amd.chunk import concat
+    keep = []
+    cfg1, left, right, _, _, conds, filt = H.lower_join_case(case, keep)
+    lk, rk = case["left_keys"][0], case["right_keys"][0]
+
+    def widen(chk, kc):
+        c = chk.columns[kc]
+        return Chunk(list(chk.columns) + [Column(c.tp, c.data.copy(), None if c.notnull is None else c.notnull.copy())])
+    left2, right2 = widen(left, lk), widen(right, rk)
+    nl, nr = len(left.columns), len(right.columns)
+    # conditions address the joined row left || right: the right side's columns moved one place to the right
+    def shift(e):
+        if isinstance(e, E.Column):
+            return E.Column(e.index + 1, e.tp) if e.index >= nl else e
+        if isinstance(e, E.ScalarFunction):
+            return E.ScalarFunction(e.name, *[shift(a) for a in e.args])
+        return e
+    inner = case["inner_child"]
+    cfg = H.join_cfg(left2.types(), right2.types(), [lk, nl], [rk, nr], H.JOIN_TYPES[case["type"]], inner, [shift(c) for c in conds], filt, keep)
+    build, probe = (right2, left2) if inner == 1 else (left2, right2)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, radix=FORCE, stats_out=stats)
+    want = []
+    for row in case["expect"]:
+        l, r = list(row[:nl]), list(row[nl:])
+        want.append(tuple(l + [l[lk]] + r + [r[rk]]))
+    assert H.rows_equal_unordered(got, want), case["ref"]
+    if not conds and (len(case["left"]) and len(case["right"])):
+        assert stats[0].probe_route == abi.ROUTE_KEYREC, (case["ref"], stats[0].probe_route)
