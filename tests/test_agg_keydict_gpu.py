@@ -107,7 +107,8 @@ def test_a_full_partition_of_the_dictionary_hands_rows_back(ctx, orc):
     cfg = H.agg_cfg([abi.BYTES, abi.I64], [0], aggs)
     cfg.est_groups = 1
     want = orc.hash_agg(cfg, chk, 4, 4)
-    got, st = _run(ctx, cfg, chk, aggs, chunk_rows=50_000, pull_rows=4096)
+    with ctx.knobs(AGG_BATCH_ROWS=50_000):  # three device batches of 50 000 rows (a first batch of 65 536 rows or more gets 256 partitions at least)
+        got, st = _run(ctx, cfg, chk, aggs, chunk_rows=50_000, pull_rows=4096)
     assert got.NumRows() == want.NumRows() == len(np.unique(ids)) and H.rows_equal_unordered(got, want)
     assert st.build_handed_back_rows > 0
 

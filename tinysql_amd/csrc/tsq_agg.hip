@@ -2087,6 +2087,7 @@ tsq_status kd_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     const int64_t est = a->cfg.est_groups > 0 ? a->cfg.est_groups : nrows;
     uint32_t pbits = 0;
     while (((int64_t)TSQ_KR_FILL << pbits) < est && (1u << pbits) < TSQ_KR_MAXP) pbits++;
+    if (nrows >= (1 << 16) && pbits < 8) pbits = 8;  // (one workgroup works on one partition: later batches may be much larger than the first)
     const size_t P = (size_t)1 << pbits;
     // ---- the child: GROUP BY id (input column 0) over the travelled argument columns (input columns 1 ..)
     tsq_agg_cfg cc = a->cfg;
