@@ -924,24 +924,42 @@ struct DaAggDenseArgs {
     uint64_t ncells;
     int32_t init_only;  // 1: set every cell to the initial words, emit nothing (first use)
 };
+// Output places: a workgroup takes TSQ_DENSE_CHUNK consecutive cells, counts the touched ones (their touch words), reserves its range of
+// the partial-group list with ONE device atomic and hands places out from an LDS cursor.  (One returning device atomic per wave on the
+// list's single counter cost ~11 ns each, chip-wide: 1.5 ms of a 4.9 ms aggregate with 4.3e6 groups over a 2^23-cell state.)
+#define TSQ_DENSE_CHUNK 4096
 __global__ void __launch_bounds__(256) k_daagg_dense_emit(DaAggDenseArgs a) {
+    __shared__ uint32_t s_cnt, s_cur;
     const uint32_t lane = threadIdx.x & 63u;
-    // (the grid covers whole 64-cell blocks: a wave reads its two touch words together)
-    for (uint64_t u0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) & ~63ull; u0 < a.ncells; u0 += (uint64_t)gridDim.x * 256) {
-        const uint64_t u = u0 + lane;
+    const uint64_t nchunks = (a.ncells + TSQ_DENSE_CHUNK - 1) / TSQ_DENSE_CHUNK;
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const uint64_t lo = ch * TSQ_DENSE_CHUNK;
         if (a.init_only) {
-            if (u < a.ncells)
-                for (int k = 0; k < a.plan.W; k++) a.dense_w[k][u] = a.plan.init[k];
-            if (lane < 2 && u0 + 32 * lane < a.ncells) a.dense_touch[(u0 >> 5) + lane] = 0;
+            for (uint32_t i = threadIdx.x; i < TSQ_DENSE_CHUNK; i += 256)
+                if (lo + i < a.ncells)
+                    for (int k = 0; k < a.plan.W; k++) a.dense_w[k][lo + i] = a.plan.init[k];
+            if (threadIdx.x < TSQ_DENSE_CHUNK / 32 && lo + 32ull * threadIdx.x < a.ncells) a.dense_touch[(lo >> 5) + threadIdx.x] = 0;
             continue;
         }
-        const bool occ = u < a.ncells && ((a.dense_touch[u >> 5] >> (u & 31u)) & 1u);
-        const unsigned long long m = __ballot(occ);
-        if (m == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = __hip_atomic_fetch_add(a.out.count, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (occ) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        if (threadIdx.x < TSQ_DENSE_CHUNK / 32 && lo + 32ull * threadIdx.x < a.ncells) {  // (cells beyond ncells have no touch bit set)
+            const uint32_t c = (uint32_t)__popc(a.dense_touch[(lo >> 5) + threadIdx.x]);
+            if (c) atomicAdd(&s_cnt, c);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cur = s_cnt ? __hip_atomic_fetch_add(a.out.count, s_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __syncthreads();
+        if (s_cnt == 0) continue;  // (block-uniform)
+        for (uint32_t i0 = 0; i0 < TSQ_DENSE_CHUNK; i0 += 256) {
+            const uint64_t u = lo + i0 + threadIdx.x;
+            const bool occ = u < a.ncells && ((a.dense_touch[u >> 5] >> (u & 31u)) & 1u);
+            const unsigned long long m = __ballot(occ);
+            if (m == 0) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_cur, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (!occ) continue;
             const uint32_t o = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             unsigned long long w[TSQ_AF_MAXW];
             for (int k = 0; k < a.plan.W; k++) {
@@ -952,16 +970,17 @@ __global__ void __launch_bounds__(256) k_daagg_dense_emit(DaAggDenseArgs a) {
                 const AfAgg f = a.plan.f[q];
                 if (f.w < 0 || (f.func != TSQ_AGG_SUM && f.func != TSQ_AGG_AVG) || af_is_real(f.type)) continue;
                 const unsigned long long lo32 = w[f.w], hi32 = w[f.w + 1];
-                const unsigned long long lo = (hi32 << 32) + lo32;
-                w[f.w] = lo;
-                w[f.w + 1] = (unsigned long long)((long long)hi32 >> 32) + (lo < lo32 ? 1ull : 0ull);
+                const unsigned long long lo64 = (hi32 << 32) + lo32;
+                w[f.w] = lo64;
+                w[f.w + 1] = (unsigned long long)((long long)hi32 >> 32) + (lo64 < lo32 ? 1ull : 0ull);
             }
             if (o < a.out.cap) {
                 a.out.key[o] = a.dm.kmin + (uint64_t)tsq_da_unmix((uint32_t)u, a.dm.s, a.dm.mask);
                 for (int k = 0; k < a.plan.W; k++) a.out.w[k][o] = w[k];
             }
         }
-        if (lane < 2 && u0 + 32 * lane < a.ncells) a.dense_touch[(u0 >> 5) + lane] = 0;
+        __syncthreads();  // every touch bit of the chunk has been read
+        if (threadIdx.x < TSQ_DENSE_CHUNK / 32 && lo + 32ull * threadIdx.x < a.ncells) a.dense_touch[(lo >> 5) + threadIdx.x] = 0;
     }
 }
 
