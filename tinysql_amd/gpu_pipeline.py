@@ -436,7 +436,11 @@ class GpuHashJoinExec(GpuExecutor):
 
 
 class GpuHashAggExec(GpuExecutor):
-    def __init__(self, ctx, child, group_by_cols, agg_funcs, est_groups=0, pull_rows=1 << 22):
+    """HashAggExec on device-resident chunks (tsq_agg_*); stream=True: StreamAggExec — the child delivers its rows ordered by the group
+    keys (a GpuSortExec, an ordered scan) and the groups come out in that order (tsq_agg_set_stream)."""
+
+    def __init__(self, ctx, child, group_by_cols, agg_funcs, est_groups=0, pull_rows=1 << 22, stream=False):
+        self.stream = stream
         types = []
         for f in agg_funcs:
             types += f.out_types()
@@ -462,6 +466,8 @@ class GpuHashAggExec(GpuExecutor):
         super().Open()
         h = C.c_void_p()
         _lib.check(self.lib.tsq_agg_create(self.ctx.h, C.byref(self.cfg), C.byref(h)), self.ctx.h)
+        if self.stream:
+            _lib.check(self.lib.tsq_agg_set_stream(h, 1), h)
         self.h, self.prepared = h, False
         self.out = self._buffers(self.pull_rows)
 

@@ -87,7 +87,7 @@ JOINS = []  # the two join operators of the last plan (their route statistics ar
 ROUTES = {0: "direct", 1: "radix, slices through L2", 2: "radix, 64-bit LDS images", 3: "packed keys"}
 
 
-def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 27, jit=None, topn=0, string_segment=False, classic=False):
+def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 27, jit=None, topn=0, string_segment=False, classic=False, sort_agg=False):
     """classic=True: round 3's plan (compacting selections, every join column materialised, 16 Mi-row batches) for comparison.
     Default (round 4): what the planner's column pruning and TiDB-style inline projection give — the probe-side selections hand their
     selection flags to the join instead of compacting (Chunk.sel), the joins materialise only the columns their parent reads
@@ -112,7 +112,12 @@ def plan(ctx, customer_d, orders_d, lineitem_d, batch_rows=1 << 27, jit=None, to
     proj = G.GpuProjectionExec(ctx, j2, [Col(0, I), Col(6, I), Col(7, I), F("mul", Col(2, R), F("minus", K(1.0), Col(3, R)))], jit=jit)
     aggs = [AggFuncDesc(abi.AGG_FIRSTROW, 0, I), AggFuncDesc(abi.AGG_FIRSTROW, 1, I), AggFuncDesc(abi.AGG_FIRSTROW, 2, I), AggFuncDesc(abi.AGG_SUM, 3, R)]
     # est_groups: the planner's cardinality estimate of the GROUP BY (here: the qualifying orders, at most a tenth of the order table)
-    agg = G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs, est_groups=0 if classic else orders_d.NumRows() // 8)
+    if sort_agg:
+        # --sort-agg: SortExec on l_orderkey + StreamAggExec (the group keys o_orderdate, o_shippriority depend on the order key, so rows of
+        # one group are adjacent once the order keys are): 1.3e7 groups of ~2.4 rows each are a poor fit for a hash table in HBM
+        agg = G.GpuHashAggExec(ctx, G.GpuSortExec(ctx, proj, [0], [False], pull_rows=1 << 25), [0, 1, 2], aggs, stream=True)
+    else:
+        agg = G.GpuHashAggExec(ctx, proj, [0, 1, 2], aggs, est_groups=0 if classic else orders_d.NumRows() // 8)
     if not topn:
         return agg
     # ... ORDER BY revenue DESC, o_orderdate LIMIT topn (TopNExec, executor/sort.go:146-318); agg output: orderkey, date, prio, revenue
@@ -300,6 +305,9 @@ def main():
     classic = "--classic" in sys.argv
     if classic:
         sys.argv.remove("--classic")
+    sort_agg = "--sort-agg" in sys.argv
+    if sort_agg:
+        sys.argv.remove("--sort-agg")
     verify = "--verify" in sys.argv
     if verify:
         sys.argv.remove("--verify")
@@ -325,7 +333,7 @@ def main():
             for rep in range(4):
                 if trace and rep == 3:
                     ctx.lib = TimedLib(ctx.lib)
-                exe = plan(ctx, *dev, topn=topn, string_segment=strseg, classic=classic)
+                exe = plan(ctx, *dev, topn=topn, string_segment=strseg, classic=classic, sort_agg=sort_agg)
                 ctx.sync()
                 t1 = time.perf_counter()
                 exe.Open()
