@@ -663,3 +663,26 @@ extern "C" int64_t sim_dec_walk_rows(const uint8_t* data, int64_t n_bytes, int32
     for (size_t i = 0; i < offs.size() && (int64_t)i < offs_cap; i++) offs_out[i] = offs[i];
     return rows;
 }
+
+// ---- key records (tsq_keyrec_dp.h): the record k_kr_hist / k_kr_scatter / k_kd_assign build for every row, and its 64-bit mix
+#include "../../tinysql_amd/csrc/tsq_keyrec_dp.h"
+// status[r]: 0 = a record, 1 = the row has no key (NULL cell of a join key, selected == 0), 2 = the cells do not fit 32 bytes
+extern "C" void sim_kr_records(const tsq_col* cols, int32_t n_cols, const int32_t* key_cols, int32_t n_keys, int32_t keep_nulls, const uint8_t* selected, int64_t nrows,
+                               uint64_t* rec, uint8_t* status, uint64_t* hash) {
+    KrSrc s;
+    memset(&s, 0, sizeof s);
+    fill(s.cs, cols, n_cols);
+    s.n_keys = n_keys;
+    for (int k = 0; k < n_keys; k++) s.col[k] = key_cols[k];
+    s.keep_nulls = keep_nulls;
+    s.selected = selected;
+    s.nrows = nrows;
+    for (int64_t r = 0; r < nrows; r++) {
+        uint64_t w[4];
+        bool toolong = false;
+        const bool ok = kr_record(s, r, w, &toolong);
+        status[r] = ok ? 0 : (toolong ? 2 : 1);
+        for (int q = 0; q < 4; q++) rec[r * 4 + q] = ok ? w[q] : 0;
+        hash[r] = ok ? kr_hash(w) : 0;
+    }
+}
