@@ -45,6 +45,29 @@ def test_string_group_key_vs_oracle(ctx, orc, n, distinct, chunk_rows):
     assert st.build_handed_back_rows == 0  # every cell fits a record: no exception rows
 
 
+def test_separate_arrays_instead_of_slots(ctx, orc):
+    # the scatter pass writes one 64-byte slot per row (record, travelling cells, source row) when <= 3 columns travel; with FOUR argument
+    # columns — and under TSQ_KNOB_KEYREC = 2 — records, row ids and cells go to separate arrays: the same groups either way
+    rng = np.random.default_rng(77)
+    n = 70_000
+    k = _words(rng, n, 900, hi=14)
+    vs = [H.random_column(rng, abi.I64, n, 0.1, lo=-1000, hi=1000) for _ in range(4)]
+    chk = Chunk([k] + vs)
+    types = [abi.BYTES] + [abi.I64] * 4
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_COUNT, -1, abi.I64)] + [(abi.AGG_SUM, 1 + i, abi.I64) for i in range(4)]
+    cfg = H.agg_cfg(types, [0], aggs)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    got, _ = _run(ctx, cfg, chk, aggs, chunk_rows=1 << 20, pull_rows=4096)
+    assert H.rows_equal_unordered(got, want)
+    aggs3 = aggs[:5]
+    cfg3 = H.agg_cfg(types, [0], aggs3)
+    want3 = orc.hash_agg(cfg3, chk, 4, 4)
+    for knob in (1, 2):
+        with ctx.knobs(KEYREC=knob):
+            got3, _ = _run(ctx, cfg3, chk, aggs3, chunk_rows=1 << 20, pull_rows=4096)
+        assert H.rows_equal_unordered(got3, want3), knob
+
+
 def test_null_and_empty_string_keys_are_different_groups(ctx, orc):
     k = StrColumn([None, b"", b"", None, b"a", b"a\0", b"a", None])  # a trailing NUL byte is part of the value
     chk = Chunk([k, Column(abi.I64, np.arange(8))])

@@ -2167,7 +2167,8 @@ tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     ka.rows_per_wg = ((chunks + ka.n_wg - 1) / ka.n_wg) * TSQ_KR_NT;
     TSQ_TRY(a->kd_counts.reserve(ctx, h, (size_t)ka.n_wg * P * 4 + 64));
     TSQ_TRY(a->kd_pstart.reserve(ctx, h, ((size_t)P + 1) * 4 + 64));
-    TSQ_TRY(a->kd_rec.reserve(ctx, h, (size_t)nrows * TSQ_KR_BYTES + 64));
+    const bool slots = a->kd_npay <= 3 && tsq_knob(ctx, TSQ_KNOB_KEYREC, 1) != 2;  // (knob value 2: separate arrays, for A/B and the tests)
+    TSQ_TRY(a->kd_rec.reserve(ctx, h, (size_t)nrows * (slots ? 64 : TSQ_KR_BYTES) + 64));
     TSQ_TRY(a->kd_ids.reserve(ctx, h, (size_t)nrows * 4 + 64));
     TSQ_TRY(a->kd_norec.reserve(ctx, h, (size_t)nrows * 4 + 64));
     TSQ_TRY(a->kd_flags.reserve(ctx, h, 64));
@@ -2189,6 +2190,7 @@ tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     ka.pstart = a->kd_pstart.as<uint32_t>();
     ka.rec = a->kd_rec.as<unsigned long long>();
     ka.ids = a->kd_ids.as<uint32_t>();
+    if (slots) ka.slot = ka.rec;
     ka.flags = a->kd_flags.as<uint32_t>();
     ka.norec = a->kd_norec.as<uint32_t>();
     ka.norec_count = ctl + 2;
@@ -2212,6 +2214,13 @@ tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     KdArgs da;
     memset(&da, 0, sizeof da);
     da.prec = ka.rec;
+    da.stride = slots ? 8u : 4u;
+    if (slots) {
+        da.n_pay = a->kd_npay;
+        for (int v = 0; v < a->kd_npay; v++) da.pay_dst[v] = a->kd_pay[v].as<uint64_t>();
+        da.pay_nn = any_nulls ? a->kd_paynn.as<uint8_t>() : nullptr;
+        da.ids = ka.ids;
+    }
     da.pstart = ka.pstart;
     da.P = P;
     da.drec = a->kd_drec.as<unsigned long long>();

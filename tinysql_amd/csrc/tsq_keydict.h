@@ -27,7 +27,13 @@
 #define TSQ_KD_RES 0x3fffu          // place code of a reserved slot (places are < TSQ_KR_CAP = 12288)
 
 struct KdArgs {
-    const unsigned long long* prec;  // the batch's records, partition order
+    const unsigned long long* prec;  // the batch's records, partition order: `stride` words each (4: records; 8: the 64-byte slots of
+                                     // k_kr_scatter — record, travelling cells, source row | NOT-NULL bits)
+    uint32_t stride;
+    int32_t n_pay;                   // slots: the travelling cells leave as columns (partition order), with the row ids and the NOT-NULL bytes
+    uint64_t* pay_dst[3];
+    uint8_t* pay_nn;
+    uint32_t* ids;
     const uint32_t* pstart;          // [P + 1]
     uint32_t P;
     unsigned long long* drec;        // dictionary: [P][TSQ_KR_CAP] records ...
@@ -125,7 +131,7 @@ static __global__ void __launch_bounds__(TSQ_KD_NT) k_kd_assign(KdArgs a) {
         // ---- pass 1: find or insert; deferred records look again after a barrier (a thread owns the same records in every sweep)
         uint32_t deferred = 0;
         for (uint64_t r = p0 + tid; r < p1; r += TSQ_KD_NT) {
-            const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
+            const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * a.stride);
             const uint32_t res = kd_find_or_insert(s_tab, &s_draw, drec_p, nd, s[0], s[1]);
             a.ridx[r] = res;
             deferred += res == TSQ_KD_DEFER ? 1u : 0u;
@@ -142,7 +148,7 @@ static __global__ void __launch_bounds__(TSQ_KD_NT) k_kd_assign(KdArgs a) {
                 deferred = 0;
                 for (uint64_t r = p0 + tid; r < p1; r += TSQ_KD_NT) {
                     if (a.ridx[r] != TSQ_KD_DEFER) continue;
-                    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
+                    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * a.stride);
                     const uint32_t res = kd_find_or_insert(s_tab, &s_draw, drec_p, nd, s[0], s[1]);
                     a.ridx[r] = res;
                     deferred += res == TSQ_KD_DEFER ? 1u : 0u;
@@ -171,6 +177,15 @@ static __global__ void __launch_bounds__(TSQ_KD_NT) k_kd_assign(KdArgs a) {
             }
             a.gid[r] = id;
             exc += id == ~0ull ? 1u : 0u;
+            if (a.stride == 8) {  // the slot's second half: the travelling cells become columns (consecutive r: coalesced)
+                const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 8 + 4);
+                const ulonglong2 c01 = s[0], c2t = s[1];
+                if (a.n_pay > 0) a.pay_dst[0][r] = c01.x;
+                if (a.n_pay > 1) a.pay_dst[1][r] = c01.y;
+                if (a.n_pay > 2) a.pay_dst[2][r] = c2t.x;
+                a.ids[r] = (uint32_t)c2t.y;
+                if (a.pay_nn) a.pay_nn[r] = (uint8_t)(c2t.y >> 32);
+            }
         }
     }
     const uint64_t e = wave_sum_u64(exc);

@@ -51,6 +51,10 @@ struct KrArgs {
     const uint8_t* pay_nulls[TSQ_KR_MAXPAY];
     uint64_t* pay_dst[TSQ_KR_MAXPAY];
     uint8_t* pay_nn;         // [records] bit v: travelling cell v is NOT NULL (nullptr: no travelling column is nullable)
+    // ... as ONE 64-byte slot per row instead (the aggregate with <= 3 travelling columns): words 0-3 the record, 4-6 the cells, word 7 =
+    // source row | NOT-NULL bits << 32.  One full 64-byte piece per row instead of three partial lines in three arrays (record 32 B,
+    // row id 4 B, cell 8 B: the counters saw ~145 B written per row)
+    unsigned long long* slot;
     uint32_t* norec;         // rows whose cells do not fit a record (nullptr: not kept) ...
     int32_t norec_all;       // ... and, for the outer side of an outer join, every other row without a key (NULL cell, selected == 0)
     unsigned long long* norec_count;
@@ -145,6 +149,22 @@ static __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_scatter(KrArgs a) {
         }
         const uint32_t p = a.pbits ? (uint32_t)(kr_hash(w) >> (64 - a.pbits)) : 0u;
         const uint64_t pos = atomicAdd(&s_cur[p], 1u);
+        if (a.slot) {
+            uint64_t c[3] = {0, 0, 0};
+            uint32_t m = 0;
+#pragma unroll
+            for (int v = 0; v < 3; v++)
+                if (v < a.n_pay) {
+                    c[v] = a.pay_src[v][row];
+                    m |= tsq_is_null(a.pay_nulls[v], row) ? 0u : (1u << v);
+                }
+            ulonglong2* d = reinterpret_cast<ulonglong2*>(a.slot + pos * 8);
+            d[0] = make_ulonglong2(w[0], w[1]);
+            d[1] = make_ulonglong2(w[2], w[3]);
+            d[2] = make_ulonglong2(c[0], c[1]);
+            d[3] = make_ulonglong2(c[2], (unsigned long long)(uint32_t)row | ((unsigned long long)m << 32));
+            continue;
+        }
         // (measured: NON-TEMPORAL stores of the record, the row id and the travelling cells make this pass 1.8x slower — the scattered pieces
         // of a line do meet in L2 often enough)
         ulonglong2* d = reinterpret_cast<ulonglong2*>(a.rec + pos * 4);

@@ -19,6 +19,8 @@ g = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
 ctx = _lib.Context(0)
 if len(sys.argv) > 3 and sys.argv[3] == "--no-dict":  # the several-column upsert (round 4's route) for comparison
     ctx.set_knob(abi.KNOB_KEYREC, 0)
+if len(sys.argv) > 3 and sys.argv[3] == "--arrays":  # records, row ids and travelling cells in separate arrays instead of 64-byte slots
+    ctx.set_knob(abi.KNOB_KEYREC, 2)
 lib = ctx.lib
 rng = np.random.default_rng(5)
 k = rng.integers(0, g, n)
@@ -62,5 +64,5 @@ for run in range(3):
     _lib.check(lib.tsq_agg_num_groups(h, C.byref(ng)), h)
     lib.tsq_agg_destroy(h)
 st = None
-print(json.dumps({"dict": not (len(sys.argv) > 3 and sys.argv[3] == "--no-dict"), "rows": n, "groups": int(ng.value), "expected_groups": int(len(np.unique(k))), "ms": min(runs), "runs_ms": runs, "rows_per_s": n / min(runs) * 1e3}))
+print(json.dumps({"mode": sys.argv[3] if len(sys.argv) > 3 else "dict", "rows": n, "groups": int(ng.value), "expected_groups": int(len(np.unique(k))), "ms": min(runs), "runs_ms": runs, "rows_per_s": n / min(runs) * 1e3}))
 ctx.close()
