@@ -667,8 +667,9 @@ extern "C" int64_t sim_dec_walk_rows(const uint8_t* data, int64_t n_bytes, int32
 // ---- key records (tsq_keyrec_dp.h): the record k_kr_hist / k_kr_scatter / k_kd_assign build for every row, and its 64-bit mix
 #include "../../tinysql_amd/csrc/tsq_keyrec_dp.h"
 // status[r]: 0 = a record, 1 = the row has no key (NULL cell of a join key, selected == 0), 2 = the cells do not fit 32 bytes
+// generic != 0: run-time positions (kr_record_any) whatever the key columns are — the fixed-position builders must agree with it
 extern "C" void sim_kr_records(const tsq_col* cols, int32_t n_cols, const int32_t* key_cols, int32_t n_keys, int32_t keep_nulls, const uint8_t* selected, int64_t nrows,
-                               uint64_t* rec, uint8_t* status, uint64_t* hash) {
+                               uint64_t* rec, uint8_t* status, uint64_t* hash, int32_t generic) {
     KrSrc s;
     memset(&s, 0, sizeof s);
     fill(s.cs, cols, n_cols);
@@ -677,6 +678,11 @@ extern "C" void sim_kr_records(const tsq_col* cols, int32_t n_cols, const int32_
     s.keep_nulls = keep_nulls;
     s.selected = selected;
     s.nrows = nrows;
+    {
+        int32_t kt[TSQ_MAX_KEYS];
+        for (int k = 0; k < n_keys; k++) kt[k] = cols[key_cols[k]].type;
+        s.layout = generic ? 0 : kr_layout_of(kt, n_keys);
+    }
     for (int64_t r = 0; r < nrows; r++) {
         uint64_t w[4];
         bool toolong = false;

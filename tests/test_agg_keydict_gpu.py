@@ -195,7 +195,7 @@ def test_plans_the_dictionary_does_not_take(ctx, orc):
 
 def _record_tags(keys):
     """the 18-bit index tag k_kd_assign derives from the key record of a single string key (csrc/tsq_keyrec.h kr_record / kr_hash): flag 2,
-    length byte, bytes, zero padding to 32 bytes = four little-endian words through a splitmix64 chain; tag = bits 14..31 of the mix"""
+    length byte, bytes, zero padding to 32 bytes = four little-endian words through kr_hash; tag = bits 14..31 of the mix"""
     rec = np.zeros((len(keys), 32), np.uint8)
     for i, k in enumerate(keys):
         rec[i, 0], rec[i, 1] = 2, len(k)
@@ -203,15 +203,14 @@ def _record_tags(keys):
     w = rec.view("<u8")
     M = np.uint64
 
-    def splitmix(x):
-        z = x + M(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> M(30))) * M(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> M(27))) * M(0x94D049BB133111EB)
-        return z ^ (z >> M(31))
-    with np.errstate(over="ignore"):
-        h = splitmix(w[:, 0] ^ M(0x6A09E667F3BCC908))
-        for c in (1, 2, 3):
-            h = splitmix(h ^ w[:, c])
+    def rotl32(x):
+        return (x << M(32)) | (x >> M(32))
+    with np.errstate(over="ignore"):  # kr_hash: one multiply per word, a multiply-xorshift finish
+        h = (w[:, 0] ^ M(0x6A09E667F3BCC908)) * M(0x9E3779B97F4A7C15)
+        for c, k in ((1, 0xBF58476D1CE4E5B9), (2, 0x94D049BB133111EB), (3, 0xD6E8FEB86659FD93)):
+            h = (w[:, c] ^ rotl32(h)) * M(k)
+        h = (h ^ (h >> M(32))) * M(0xFF51AFD7ED558CCD)
+        h = h ^ (h >> M(29))
     return (h >> M(14)) & M(0x3ffff)
 
 

@@ -23,11 +23,11 @@ def sim():
     lib = C.CDLL(os.path.join(HERE, "hostsim", "hostsim.so"))
     P = C.c_void_p
     lib.sim_kr_records.restype = None
-    lib.sim_kr_records.argtypes = [C.POINTER(abi.Col), C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int64, P, P, P]
+    lib.sim_kr_records.argtypes = [C.POINTER(abi.Col), C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int64, P, P, P, C.c_int32]
     return lib
 
 
-def records(sim, chk, key_cols, keep_nulls, selected=None):
+def records(sim, chk, key_cols, keep_nulls, selected=None, generic=False):
     keep = []
     cols = make_cols(chk.columns, keep)
     n = chk.NumRows()
@@ -37,7 +37,7 @@ def records(sim, chk, key_cols, keep_nulls, selected=None):
     h = np.zeros(n, np.uint64)
     sel = None if selected is None else np.ascontiguousarray(selected, np.uint8)
     sim.sim_kr_records(cols, len(chk.columns), kc.ctypes.data, len(key_cols), 1 if keep_nulls else 0, None if sel is None else sel.ctypes.data, n,
-                       rec.ctypes.data, st.ctypes.data, h.ctypes.data)
+                       rec.ctypes.data, st.ctypes.data, h.ctypes.data, 1 if generic else 0)
     return rec, st, h
 
 
@@ -63,7 +63,8 @@ def test_known_answer_bytes(sim):
     assert bytes(b[1]) == bytes([8] + [255] * 8 + [2, 0]) + bytes(21)
 
 
-@pytest.mark.parametrize("shape", [[abi.BYTES], [abi.I64, abi.BYTES], [abi.BYTES, abi.U64, abi.BYTES], [abi.I64, abi.U64, abi.I64]])
+@pytest.mark.parametrize("shape", [[abi.BYTES], [abi.I64, abi.BYTES], [abi.I64, abi.U64, abi.BYTES], [abi.BYTES, abi.U64, abi.BYTES], [abi.I64], [abi.I64, abi.U64],
+                                   [abi.I64, abi.U64, abi.I64], [abi.BYTES, abi.I64]])
 @pytest.mark.parametrize("keep_nulls", [False, True])
 def test_equal_records_iff_equal_keys(sim, shape, keep_nulls):
     rng = np.random.default_rng(len(shape) * 10 + keep_nulls)
@@ -86,6 +87,9 @@ def test_equal_records_iff_equal_keys(sim, shape, keep_nulls):
         pyvals.append(vals)
     chk = Chunk(cols)
     rec, st, h = records(sim, chk, list(range(len(shape))), keep_nulls)
+    # the builders with compile-time cell positions (keys of 8-byte cells, optionally ending with a string) agree with the general one
+    rec_g, st_g, h_g = records(sim, chk, list(range(len(shape))), keep_nulls, generic=True)
+    assert (rec == rec_g).all() and (st == st_g).all() and (h == h_g).all()
     keys = [tuple(cell_class(shape[c], pyvals[c][r]) for c in range(len(shape))) for r in range(n)]
     by_rec = {}
     for r in range(n):
@@ -132,3 +136,30 @@ def test_the_numpy_restatement_used_by_the_gpu_regression_test(sim):
     _, st, h = records(sim, chk, [0], True)
     assert (st == 0).all()
     assert (((h >> np.uint64(14)) & np.uint64(0x3ffff)) == _record_tags(keys)).all()
+
+
+def test_null_cells_keep_the_room_of_a_value(sim):
+    # GROUP BY (bigint, string): a NULL bigint is nine zero bytes, a NULL string two — the cells after them start where they always do
+    chk = Chunk([Column(abi.I64, np.array([7, 7]), np.array([False, True])), StrColumn([b"ab", None])])
+    rec, st, _ = records(sim, chk, [0, 1], True)
+    b = rec.view(np.uint8).reshape(2, 32)
+    assert st.tolist() == [0, 0]
+    assert bytes(b[0]) == bytes(9) + bytes([2, 2, 97, 98]) + bytes(19)
+    assert bytes(b[1]) == bytes([8, 7, 0, 0, 0, 0, 0, 0, 0]) + bytes(23)
+
+
+def test_the_mix_spreads_sequential_keys(sim):
+    # partition = top bits, LDS slot = low 14 bits, tag = bits 14..31 of the record's mix: keys that differ in a few low bits (order numbers,
+    # "k123" strings) must spread over all three
+    n = 200_000
+    for chk, keys in ((Chunk([Column(abi.I64, np.arange(n)), StrColumn([b"s%d" % (i % 977) for i in range(n)])]), [0, 1]),
+                      (Chunk([StrColumn([b"key-%07d" % i for i in range(n)])]), [0]),
+                      (Chunk([Column(abi.I64, np.arange(n) * 4096), Column(abi.I64, np.arange(n) % 3)]), [0, 1])):
+        _, st, h = records(sim, chk, keys, True)
+        assert (st == 0).all() and len(np.unique(h)) == n
+        top = np.bincount((h >> np.uint64(53)).astype(np.int64), minlength=2048)    # 2048 partitions: ~98 keys each
+        low = np.bincount((h & np.uint64(0x3fff)).astype(np.int64), minlength=16384)  # ~12 per slot
+        assert top.min() > 50 and top.max() < 160, (top.min(), top.max())
+        assert low.max() < 40
+        tags = (h >> np.uint64(14)) & np.uint64(0x3ffff)
+        assert len(np.unique(tags)) > 0.6 * min(n, 1 << 18) * (1 - np.exp(-n / (1 << 18))) / (n / (1 << 18)) * (n / (1 << 18)) * 0.9

@@ -2160,6 +2160,7 @@ tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     ka.src.n_keys = a->plan.n_keys;
     for (int k = 0; k < a->plan.n_keys; k++) ka.src.col[k] = a->plan.key_col[k];
     ka.src.keep_nulls = 1;
+    ka.src.layout = kr_layout_of(a->cfg.group_key_type, a->plan.n_keys);
     ka.src.nrows = nrows;
     ka.pbits = a->kd_pbits;
     const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;

@@ -3122,6 +3122,11 @@ tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, i
     for (int k = 0; k < j->ks.n_keys; k++) a.src.col[k] = key_cols[k];
     a.src.nrows = nrows;
     a.src.selected = selected;
+    {
+        int32_t kt[TSQ_MAX_KEYS];
+        for (int k = 0; k < j->ks.n_keys; k++) kt[k] = cs.type[key_cols[k]];
+        a.src.layout = kr_layout_of(kt, j->ks.n_keys);
+    }
     a.pbits = pbits;
     const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;
     a.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(TSQ_KR_MAXWG, chunks));

@@ -212,9 +212,9 @@ static __global__ void __launch_bounds__(256) k_kd_decode(KdDecodeArgs a) {
         uint32_t at = 0;
         for (int k = 0; k < a.n_keys; k++) {
             const uint32_t flag = rec[at];
-            if (flag == 0) {  // NilFlag
+            if (flag == 0) {  // NilFlag: the cell's fixed part is zero bytes (tsq_keyrec_dp.h)
                 if (a.out[k]) { a.out[k][i] = 0; a.out_nn[k][i] = 0; }
-                at += 1;
+                at += a.key_is_str[k] ? 2 : 9;
             } else if (a.key_is_str[k]) {
                 const uint32_t n = rec[at + 1];
                 if (a.out[k]) {
