@@ -32,7 +32,7 @@
 #define TSQ_KR_NT 1024       // threads of the hist / scatter passes
 #define TSQ_KR_PNT 512       // threads of the probe kernel
 #define TSQ_KR_MAXP 16384    // partitions: one LDS counter each in the hist / scatter passes (64 KB)
-#define TSQ_KR_MAXWG 512     // workgroups of the hist / scatter passes = contiguous row chunks
+#define TSQ_KR_MAXWG 256     // workgroups of the hist / scatter passes = contiguous row chunks
 #define TSQ_KR_FILL 8192     // build records per partition, on average (the host picks P for it; + 45 sigma stays below TSQ_KR_CAP)
 
 struct KrArgs {
