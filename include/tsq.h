@@ -140,6 +140,7 @@ enum {
     TSQ_KNOB_KEYREC = 28,            /* 0: joins on several key columns / string keys never take the key-record route (csrc/tsq_keyrec.h), aggregates never the dictionary of group keys (csrc/tsq_keydict.h); 2: the dictionary's scatter pass writes separate arrays instead of 64-byte slots */
     TSQ_KNOB_STREAMAGG_LANES = 29,   /* 0: StreamAggExec always reduces every 64-row step across the lanes (k_sa_update) instead of keeping per-lane partial results of the open run (k_sa_update_lanes) */
     TSQ_KNOB_XCD_ATOMICS = 30,       /* 1: the cursors of the per-XCD partition regions (headline partition kernel) are claimed with workgroup-scope atomics — performed in the XCD's own L2 — instead of agent-scope ones (default; measured equal) */
+    TSQ_KNOB_DENSE_DIRECT = 31,      /* 0: the packed aggregate's dense state always leaves through partial groups and the hash table, also when the table is empty (k_dense_finalize off) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);

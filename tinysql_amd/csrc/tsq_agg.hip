@@ -766,6 +766,132 @@ __global__ void __launch_bounds__(256) k_agg_finalize(FinalArgs a) {
     }
 }
 
+// K8a' — the rows of an aggregate whose every group lives in the DENSE partial state of the packed route (tsq_daagg.h: one cell per packed
+// key word; no row took the exception path, nothing was merged into the hash table): straight from the cells.  Replaces k_daagg_dense_emit
+// -> k_agg_merge -> k_agg_finalize (every group through a partial-group list and a random upsert before it is read back from the table:
+// 1.2 of 3.3 ms for 4.3e6 groups).  A cell's words are the partial-group words of tsq_aggfast.h: COUNT = the count; SUM / AVG of integers =
+// (sum of the low halves, sum of the high halves[, count]); of reals = (sum[, count]); MAX / MIN = the ordered image.  Every aggregate of
+// a touched cell has seen a value: rows with a NULL argument cell are exception rows, and this kernel only runs when there were none.
+struct DenseFinalArgs {
+    AfPlan fplan;
+    AggPlan plan;
+    DaDomain dm;
+    int32_t key_type;
+    const unsigned long long* dense_w[TSQ_AF_MAXW];
+    const uint32_t* dense_touch;
+    uint64_t ncells;
+    void* out_data[2 * TSQ_MAX_AGGS];
+    uint8_t* out_notnull[2 * TSQ_MAX_AGGS];
+    unsigned long long* counters;  // [3] = output cursor, [4] = overflow flag (BIGINT)
+};
+__global__ void __launch_bounds__(256) k_dense_count(const uint32_t* touch, uint64_t nwords, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * 256) c += (unsigned long long)__popc(touch[i]);
+    c = wave_sum_u64(c);
+    __shared__ unsigned long long s_c;  // one device atomic per workgroup (same-address device atomics cost ~11 ns each, chip-wide)
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_c, c);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_c) atomicAdd(out, s_c);
+}
+__global__ void __launch_bounds__(256) k_dense_finalize(DenseFinalArgs a) {
+    __shared__ uint32_t s_cnt;
+    __shared__ unsigned long long s_cur;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t nchunks = (a.ncells + TSQ_FINAL_CHUNK - 1) / TSQ_FINAL_CHUNK;
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const uint64_t lo = ch * TSQ_FINAL_CHUNK;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        if (threadIdx.x < TSQ_FINAL_CHUNK / 32 && lo + 32ull * threadIdx.x < a.ncells) {
+            const uint32_t c = (uint32_t)__popc(a.dense_touch[(lo >> 5) + threadIdx.x]);
+            if (c) atomicAdd(&s_cnt, c);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_cur = s_cnt ? atomicAdd(&a.counters[3], (unsigned long long)s_cnt) : 0ull;
+        __syncthreads();
+        if (s_cnt == 0) continue;  // (block-uniform)
+        for (uint32_t i0 = 0; i0 < TSQ_FINAL_CHUNK; i0 += 256) {
+            const uint64_t u = lo + i0 + threadIdx.x;
+            const bool occ = u < a.ncells && ((a.dense_touch[u >> 5] >> (u & 31u)) & 1u);
+            const unsigned long long m = __ballot(occ);
+            if (!m) continue;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&s_cur, (unsigned long long)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (!occ) continue;
+            const uint64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            int oc = 0;
+            for (int i = 0; i < a.plan.n_aggs; i++) {
+                const tsq_agg_func f = a.plan.f[i];
+                const AfAgg g = a.fplan.f[i];
+                const bool partial_out = f.mode == TSQ_MODE_PARTIAL1 || f.mode == TSQ_MODE_PARTIAL2;
+                const bool real = is_real_type(f.arg_type);
+                switch (f.func) {
+                    case TSQ_AGG_COUNT:
+                        ((uint64_t*)a.out_data[oc])[pos] = a.dense_w[g.w][u];
+                        if (a.out_notnull[oc]) a.out_notnull[oc][pos] = 1;
+                        oc++;
+                        break;
+                    case TSQ_AGG_SUM:
+                    case TSQ_AGG_AVG: {
+                        unsigned long long sum, cnt = 0;
+                        if (real) {
+                            sum = a.dense_w[g.w][u];
+                            if (f.func == TSQ_AGG_AVG) cnt = a.dense_w[g.w + 1][u];
+                        } else {  // (sum of low halves, sum of high halves) -> the 128-bit sum, as k_daagg_dense_emit splits it
+                            const unsigned long long lo32 = a.dense_w[g.w][u], hi32 = a.dense_w[g.w + 1][u];
+                            sum = (hi32 << 32) + lo32;
+                            const unsigned long long hi = (unsigned long long)((long long)hi32 >> 32) + (sum < lo32 ? 1ull : 0ull);
+                            if (!sum128_fits(sum, hi)) atomicOr(&a.counters[4], 1ull);
+                            if (f.func == TSQ_AGG_AVG) cnt = a.dense_w[g.w + 2][u];
+                        }
+                        if (f.func == TSQ_AGG_SUM) {
+                            ((uint64_t*)a.out_data[oc])[pos] = sum;
+                            a.out_notnull[oc][pos] = 1;
+                            oc++;
+                        } else if (partial_out) {  // (count, sum) columns (descriptor.go:70-81)
+                            ((uint64_t*)a.out_data[oc])[pos] = cnt;
+                            if (a.out_notnull[oc]) a.out_notnull[oc][pos] = 1;
+                            oc++;
+                            ((uint64_t*)a.out_data[oc])[pos] = sum;
+                            if (a.out_notnull[oc]) a.out_notnull[oc][pos] = 1;
+                            oc++;
+                        } else {
+                            uint64_t v = 0;
+                            if (cnt) {
+                                if (real) v = tsq_f64_bits(tsq_bits_f64(sum) / (double)(long long)cnt);  // func_avg.go:154-162
+                                else v = (uint64_t)tsq_godiv((int64_t)sum, (int64_t)cnt);                 // func_avg.go:47-55
+                            }
+                            ((uint64_t*)a.out_data[oc])[pos] = v;
+                            a.out_notnull[oc][pos] = cnt ? 1 : 0;
+                            oc++;
+                        }
+                        break;
+                    }
+                    case TSQ_AGG_MAX:
+                    case TSQ_AGG_MIN: {
+                        const uint64_t v = ord_image_decode(a.dense_w[g.w][u], f.arg_type);
+                        if (f.arg_type == TSQ_F32) ((uint32_t*)a.out_data[oc])[pos] = (uint32_t)v;
+                        else ((uint64_t*)a.out_data[oc])[pos] = v;
+                        a.out_notnull[oc][pos] = 1;
+                        oc++;
+                        break;
+                    }
+                    case TSQ_AGG_FIRSTROW: {  // of the group key: the cell's word back to the key (tsq_da_unmix is the inverse of the packing mix)
+                        const uint64_t key = a.dm.kmin + (uint64_t)tsq_da_unmix((uint32_t)u, a.dm.s, a.dm.mask);
+                        ((uint64_t*)a.out_data[oc])[pos] = group_key_word_decode(key, a.key_type);
+                        a.out_notnull[oc][pos] = 1;
+                        oc++;
+                        break;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // K8b — var-len output columns (AppendFinalResult2Chunk of firstRow4String / maxMin4String: chk.AppendString): the
 // finalize pass left references; their lengths (k_ref_len), the exclusive scan of the lengths = the column's offsets
 // (tsq_launch_scan64), then the bytes out of the heap (k_ref_copy: one row per lane, or per wave for long cells).
@@ -1027,6 +1153,8 @@ struct tsq_agg {
     int wide_state = 0;        // 0: not tried, 1: in use, -1: not usable (this plan, or the fields of the first batch exceed 63 bits)
     bool wide_ok = false;      // the plan allows it (integer key columns, fixed-width inputs)
     bool is_wide_child = false;
+    bool da_hint = false;      // packed route: the key range is given (unsigned keys in [da_hint_min, da_hint_max]) instead of sampled alone
+    uint64_t da_hint_min = 0, da_hint_max = 0;
     WideFields wide_f{};
     tsq_agg* wide = nullptr;   // the child: GROUP BY d
     DevBuf wide_d, wide_okrows, wide_excrows;
@@ -1378,7 +1506,12 @@ tsq_status da_agg_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
     a->st.kernel_launches++;
     if (ctx->pinned[50] == 0) return TSQ_OK;
-    const uint64_t kmin = ctx->pinned[48] ^ ra.flip[0], kmax = ctx->pinned[49] ^ ra.flip[0], range = kmax - kmin;
+    uint64_t kmin = ctx->pinned[48] ^ ra.flip[0], kmax = ctx->pinned[49] ^ ra.flip[0];
+    if (a->da_hint) {  // the caller knows the keys' range (the dictionary's group ids, kd_batch): nothing the sample missed becomes an exception row
+        kmin = a->da_hint_min;
+        kmax = std::max<uint64_t>(kmax, a->da_hint_max);
+    }
+    const uint64_t range = kmax - kmin;
     a->da_paybytes = 8;
     if (narrow_try && ctx->pinned[53] != 0) {
         const uint64_t vmax = ctx->pinned[52];
@@ -2261,6 +2394,9 @@ tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     }
     a->wide_batches++;
     c->cfg.est_groups = std::max<int64_t>(1, a->kd_next_host);  // (the child need not learn its cardinality from a prefix of the batch)
+    c->da_hint = true;  // ... and its keys are the ids 0 .. next - 1 (the packed window is the power of two above)
+    c->da_hint_min = 0;
+    c->da_hint_max = (uint64_t)std::max<int64_t>(1, a->kd_next_host) - 1;
     // ... nor find its table too small in the middle of a merge (a failed merge is a second merge): every id is a group of the child
     if (!c->multi && c->tb.cap < (uint64_t)a->kd_next_host * 2) {
         const tsq_status gs = grow_table(c, (uint64_t)a->kd_next_host * 3 + 16);
@@ -2749,7 +2885,10 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     tsq_handle_hdr* h = &a->hdr;
     TSQ_HIP(h, hipSetDevice(ctx->device));
     TSQ_TRY(agg_flush(a));
-    TSQ_TRY(da_dense_flush(a));
+    // every group in the dense state of the packed route and none in the table: the rows come straight from the cells (k_dense_finalize)
+    const bool dense_direct = a->dense_state == 1 && a->dense_rows > 0 && a->groups == 0 && !a->multi && a->plan.n_keys == 1 && a->mk_n <= 1 &&
+                              a->wide_state != 1 && !a->stream && tsq_knob(ctx, TSQ_KNOB_DENSE_DIRECT, 1) != 0;
+    if (!dense_direct) TSQ_TRY(da_dense_flush(a));
     // empty input without GROUP BY: exactly one row of defaults (aggregate.go:572-574,
     // builder.go:517-539): COUNT -> 0, everything else NULL.  The NULL-group slot (cap+1) is the
     // single group of a key-less aggregate; claim it so that finalize emits it.
@@ -2766,7 +2905,18 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
         if (cs != TSQ_OK) return tsq_fail(h, cs, a->wide->hdr.err);
         g_child = a->wide->out_rows;
     }
-    const int64_t g_own = a->groups;
+    int64_t g_own = a->groups;
+    if (dense_direct) {  // the groups = the touched cells
+        const uint64_t nwords = ((uint64_t)1 << a->da_dm.b) >> 5;
+        TSQ_HIP(h, hipMemsetAsync((char*)a->counters.p + 6 * 8, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_dense_count, dim3(std::min<int>(tsq_grid_for(ctx, (int64_t)nwords, 256), ctx->num_cus)), dim3(256), 0, ctx->stream, a->dense_touch.as<uint32_t>(), nwords,
+                           a->counters.as<unsigned long long>() + 6);
+        TSQ_HIP(h, hipGetLastError());
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 9, (char*)a->counters.p + 6 * 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        g_own = (int64_t)ctx->pinned[9];
+        a->st.kernel_launches++;
+    }
     const int64_t g = g_own + g_child;
     a->odata.resize(a->n_out);
     a->onn.resize(a->n_out);
@@ -2786,8 +2936,27 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     fa.ordered = a->stream ? 1 : 0;
     fa.ordered_groups = (uint64_t)g_own;
     TSQ_HIP(h, hipMemsetAsync((char*)a->counters.p + 3 * 8, 0, 16, ctx->stream));
-    int grid = tsq_grid_for(ctx, a->stream ? std::max<int64_t>(g_own, 1) : (int64_t)a->tb.cap + 2, 256, TSQ_FINAL_CHUNK / 256);
-    hipLaunchKernelGGL(k_agg_finalize, dim3(grid), dim3(256), 0, ctx->stream, fa);
+    if (dense_direct) {
+        DenseFinalArgs da;
+        memset(&da, 0, sizeof da);
+        da.fplan = a->fplan;
+        da.plan = a->plan;
+        da.dm = a->da_dm;
+        da.key_type = a->cfg.group_key_type[0];
+        for (int k = 0; k < a->fplan.W; k++) da.dense_w[k] = a->dense_w[k].as<unsigned long long>();
+        da.dense_touch = a->dense_touch.as<uint32_t>();
+        da.ncells = (uint64_t)1 << a->da_dm.b;
+        for (int oc = 0; oc < a->n_out; oc++) {
+            da.out_data[oc] = fa.out_data[oc];
+            da.out_notnull[oc] = fa.out_notnull[oc];
+        }
+        da.counters = fa.counters;
+        hipLaunchKernelGGL(k_dense_finalize, dim3(tsq_grid_for(ctx, (int64_t)da.ncells, 256, TSQ_FINAL_CHUNK / 256)), dim3(256), 0, ctx->stream, da);
+        a->dense_flushes++;
+    } else {
+        int grid = tsq_grid_for(ctx, a->stream ? std::max<int64_t>(g_own, 1) : (int64_t)a->tb.cap + 2, 256, TSQ_FINAL_CHUNK / 256);
+        hipLaunchKernelGGL(k_agg_finalize, dim3(grid), dim3(256), 0, ctx->stream, fa);
+    }
     TSQ_HIP(h, hipGetLastError());
     a->st.kernel_launches++;
     if (g_child > 0) {  // rows [g_own, g) of every output column: copied from the child, or decoded from its composite key
