@@ -692,3 +692,9 @@ extern "C" void sim_kr_records(const tsq_col* cols, int32_t n_cols, const int32_
         hash[r] = ok ? kr_hash(w) : 0;
     }
 }
+
+// the cells of record `rec` (32 bytes) read back (kr_parse_cell, what k_kd_decode does for the aggregate's output key columns)
+extern "C" void sim_kr_parse(const uint8_t* rec, int32_t n_keys, const int32_t* is_str, uint32_t* flag, uint64_t* word, uint32_t* off, uint32_t* len) {
+    uint32_t at = 0;
+    for (int k = 0; k < n_keys; k++) flag[k] = kr_parse_cell(rec, &at, is_str[k] != 0, &word[k], &off[k], &len[k]);
+}

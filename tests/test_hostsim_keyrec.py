@@ -24,6 +24,8 @@ def sim():
     P = C.c_void_p
     lib.sim_kr_records.restype = None
     lib.sim_kr_records.argtypes = [C.POINTER(abi.Col), C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int64, P, P, P, C.c_int32]
+    lib.sim_kr_parse.restype = None
+    lib.sim_kr_parse.argtypes = [P, C.c_int32, P, P, P, P, P]
     return lib
 
 
@@ -163,3 +165,38 @@ def test_the_mix_spreads_sequential_keys(sim):
         assert low.max() < 40
         tags = (h >> np.uint64(14)) & np.uint64(0x3ffff)
         assert len(np.unique(tags)) > 0.6 * min(n, 1 << 18) * (1 - np.exp(-n / (1 << 18))) / (n / (1 << 18)) * (n / (1 << 18)) * 0.9
+
+
+@pytest.mark.parametrize("shape", [[abi.BYTES], [abi.I64, abi.BYTES], [abi.BYTES, abi.U64, abi.BYTES], [abi.I64, abi.U64, abi.I64], [abi.BYTES, abi.I64]])
+def test_records_read_back_to_their_cells(sim, shape):
+    # the aggregate's output key columns come back from the dictionary records (k_kd_decode -> kr_parse_cell): every cell of a GROUP BY key,
+    # NULL cells included, is what went in
+    rng = np.random.default_rng(len(shape) + 40)
+    n = 600
+    cols, pyvals = [], []
+    for tp in shape:
+        if tp == abi.BYTES:
+            vals = [None if rng.random() < 0.15 else bytes(rng.integers(0, 256, int(rng.integers(0, 6)), dtype=np.uint8)) for _ in range(n)]
+            cols.append(StrColumn(vals))
+        else:
+            data = rng.integers(-(1 << 63), (1 << 63) - 1, n, dtype=np.int64).astype(np.int64 if tp == abi.I64 else np.uint64)
+            nn = rng.random(n) > 0.15
+            cols.append(Column(tp, data, nn))
+            vals = [None if not nn[i] else int(data[i]) for i in range(n)]
+        pyvals.append(vals)
+    rec, st, _ = records(sim, Chunk(cols), list(range(len(shape))), True)
+    assert (st == 0).all()
+    is_str = np.array([1 if t == abi.BYTES else 0 for t in shape], np.int32)
+    k = len(shape)
+    for r in range(n):
+        flag, word, off, ln = np.zeros(k, np.uint32), np.zeros(k, np.uint64), np.zeros(k, np.uint32), np.zeros(k, np.uint32)
+        raw = np.ascontiguousarray(rec[r]).view(np.uint8)
+        sim.sim_kr_parse(raw.ctypes.data, k, is_str.ctypes.data, flag.ctypes.data, word.ctypes.data, off.ctypes.data, ln.ctypes.data)
+        for c in range(k):
+            v = pyvals[c][r]
+            if v is None:
+                assert flag[c] == 0
+            elif shape[c] == abi.BYTES:
+                assert flag[c] == 2 and bytes(raw[off[c]:off[c] + ln[c]]) == v
+            else:
+                assert flag[c] in (8, 9) and int(word[c]) == v & ((1 << 64) - 1)

@@ -211,23 +211,13 @@ static __global__ void __launch_bounds__(256) k_kd_decode(KdDecodeArgs a) {
         const uint8_t* rec = reinterpret_cast<const uint8_t*>(a.drec + loc * 4);
         uint32_t at = 0;
         for (int k = 0; k < a.n_keys; k++) {
-            const uint32_t flag = rec[at];
-            if (flag == 0) {  // NilFlag: the cell's fixed part is zero bytes (tsq_keyrec_dp.h)
-                if (a.out[k]) { a.out[k][i] = 0; a.out_nn[k][i] = 0; }
-                at += a.key_is_str[k] ? 2 : 9;
-            } else if (a.key_is_str[k]) {
-                const uint32_t n = rec[at + 1];
-                if (a.out[k]) {
-                    a.out[k][i] = ((uint64_t)(loc * TSQ_KR_BYTES + at + 2) << a.len_bits) | n;
-                    a.out_nn[k][i] = 1;
-                }
-                at += 2 + n;
-            } else {
-                uint64_t v = 0;
-                for (int b = 0; b < 8; b++) v |= (uint64_t)rec[at + 1 + b] << (8 * b);
-                if (a.out[k]) { a.out[k][i] = v; a.out_nn[k][i] = 1; }
-                at += 9;
-            }
+            uint64_t word;
+            uint32_t off, len;
+            const uint32_t flag = kr_parse_cell(rec, &at, a.key_is_str[k] != 0, &word, &off, &len);
+            if (!a.out[k]) continue;
+            // a string cell: a reference to its bytes inside the dictionary buffer
+            a.out[k][i] = flag == 0 ? 0ull : (a.key_is_str[k] ? (((uint64_t)(loc * TSQ_KR_BYTES + off) << a.len_bits) | len) : word);
+            a.out_nn[k][i] = flag == 0 ? 0 : 1;
         }
     }
 }

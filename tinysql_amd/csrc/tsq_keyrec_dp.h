@@ -155,6 +155,26 @@ TSQ_HD bool kr_record(const KrSrc& s, int64_t row, uint64_t (&w)[4], bool* toolo
         default: return kr_record_any(s, row, w, toolong);
     }
 }
+// the way back (the aggregate's group keys leave the dictionary, k_kd_decode): cell k of a record starts at *at; returns its flag (0: a NULL
+// cell) and moves *at behind the cell.  An 8-byte cell: *word; a string: its bytes are rec[*off .. *off + *len)
+TSQ_HD uint32_t kr_parse_cell(const uint8_t* rec, uint32_t* at, bool is_str, uint64_t* word, uint32_t* off, uint32_t* len) {
+    const uint32_t a = *at, flag = rec[a];
+    *word = 0;
+    *off = *len = 0;
+    if (flag == 0) {  // NilFlag: the cell's fixed part is zero bytes
+        *at = a + (is_str ? 2u : 9u);
+    } else if (is_str) {
+        *len = rec[a + 1];
+        *off = a + 2;
+        *at = a + 2 + *len;
+    } else {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v |= (uint64_t)rec[a + 1 + b] << (8 * b);
+        *word = v;
+        *at = a + 9;
+    }
+    return flag;
+}
 // the 64-bit mix of a record: one multiply per word (the rotation hands the well-mixed high half of a product to the next multiply's
 // low bits) and a multiply-xorshift finish — 5 multiplies where four rounds of splitmix64 took 8; the partition comes from the top bits,
 // the LDS slot from the low 14, the tag from bits 14..31
