@@ -136,6 +136,28 @@ def test_a_full_partition_of_the_dictionary_hands_rows_back(ctx, orc):
     assert st.build_handed_back_rows > 0
 
 
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_partition_fills_up_in_a_batch_with_several_rows_per_key(ctx, orc, seed):
+    # the batch in which the ONE partition (12 288 places, index 3/4 full: long walks) runs out of places brings every key
+    # ~4 times — a reservation that draws no place must not turn back into an empty slot (a key that settled BEHIND it would be looked
+    # for at the empty slot by its later rows: the group would live in the dictionary AND in the parent's table and come out twice).
+    # Every group exactly once, with its exact count and sum, also for the rows of the next batch.
+    rng = np.random.default_rng(seed)
+    n = 120_000
+    ids = rng.integers(0, 14_000, n)
+    k = StrColumn([b"key-%07d" % i for i in ids])
+    v = Column(abi.I64, rng.integers(-9, 9, n))
+    chk = Chunk([k, v])
+    aggs = [(abi.AGG_FIRSTROW, 0, abi.BYTES), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 1, abi.I64)]
+    cfg = H.agg_cfg([abi.BYTES, abi.I64], [0], aggs)
+    cfg.est_groups = 1
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    with ctx.knobs(AGG_BATCH_ROWS=60_000):  # (a first batch of 65 536 rows or more gets 256 partitions at least)
+        got, st = _run(ctx, cfg, chk, aggs, chunk_rows=60_000, pull_rows=4096)
+    assert got.NumRows() == want.NumRows() == len(np.unique(ids)) and H.rows_equal_unordered(got, want)
+    assert st.build_handed_back_rows > 0
+
+
 def test_hot_key_and_many_rows_per_key(ctx, orc):
     # half of the rows carry one key: hundreds of rows bring the same NEW key to a partition at once (each draws a place, one publishes,
     # the others leave tombstones); later batches find it

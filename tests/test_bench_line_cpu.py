@@ -140,7 +140,7 @@ def test_bench_gpus_n_without_a_launcher_spawns_its_ranks(tmp_path):
     assert seen == ["bench-rank 0 of 2 local 0", "bench-rank 1 of 2 local 1"], (r.stdout[-500:], r.stderr[-500:])
 
 
-# ---- round 5: the line the driver's command printed on the GPU box (tools/gpu_r05_final.sh), in the compact form (< 4 KB) it parses
+# ---- round 5: the line the driver's command printed on the GPU box (`tools/gpu.sh bench --gpus 1 --steps 20 --warmup 5`), in the compact form (< 4 KB) it parses
 def _line5():
     raw = open(os.path.join(ROOT, "profiles", "r05_bench.json")).read().strip().splitlines()
     assert len(raw) == 1, "stdout of bench.py is ONE line"

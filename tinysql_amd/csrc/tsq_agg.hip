@@ -2262,15 +2262,23 @@ tsq_status kd_setup(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
         cc.aggs[cc.n_aggs++] = g;
         for (int o = 0; o < outs; o++) a->wide_child_out[own_oc++] = child_oc++;
     }
-    TSQ_TRY(a->kd_drec.reserve(ctx, h, P * TSQ_KR_CAP * TSQ_KR_BYTES + 64));
-    TSQ_TRY(a->kd_dids.reserve(ctx, h, P * TSQ_KR_CAP * 4 + 64));
-    TSQ_TRY(a->kd_dcount.reserve(ctx, h, P * 4 + 64));
-    TSQ_TRY(a->kd_ctl.reserve(ctx, h, 64));
+    // the dictionary: P * 12288 places of 32 + 4 bytes.  No memory for it (a first batch of 1e8 rows without an estimate asks for ~7 GB)
+    // means "route not usable", not a failed aggregate: the several-column upsert keeps the rows
+    auto drop_dictionary = [&]() {
+        for (DevBuf* b : {&a->kd_drec, &a->kd_dids, &a->kd_dcount, &a->kd_ctl}) b->release();
+        h->err.clear();
+        return TSQ_OK;
+    };
+    tsq_status rs = a->kd_drec.reserve(ctx, h, P * TSQ_KR_CAP * TSQ_KR_BYTES + 64);
+    if (rs == TSQ_OK) rs = a->kd_dids.reserve(ctx, h, P * TSQ_KR_CAP * 4 + 64);
+    if (rs == TSQ_OK) rs = a->kd_dcount.reserve(ctx, h, P * 4 + 64);
+    if (rs == TSQ_OK) rs = a->kd_ctl.reserve(ctx, h, 64);
+    if (rs != TSQ_OK) return drop_dictionary();
     TSQ_HIP(h, hipMemsetAsync(a->kd_dcount.p, 0, P * 4, ctx->stream));
     TSQ_HIP(h, hipMemsetAsync(a->kd_ctl.p, 0, 64, ctx->stream));
     tsq_agg* child = nullptr;
     const tsq_status cs = tsq_agg_create(ctx, &cc, &child);
-    if (cs != TSQ_OK) return TSQ_OK;  // (a plan the single-key operator refuses: the several-column upsert keeps this aggregate)
+    if (cs != TSQ_OK) return drop_dictionary();  // (a plan the single-key operator refuses: the several-column upsert keeps this aggregate)
     child->is_wide_child = true;
     child->fast_mode = a->fast_mode;
     child->host_mode = false;

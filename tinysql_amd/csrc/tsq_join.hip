@@ -1546,7 +1546,6 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uin
     st.bits = j->da_pbits;
     st.ebits = j->da_ebits;
     st.cap = g.cap;
-    st.xcd_atomics = tsq_knob(ctx, TSQ_KNOB_XCD_ATOMICS, 0) != 0 ? 1u : 0u;  // (A/B, round 5: 0.282 vs 0.280 ms per 1e8 keys — the cursor atomics are not what bounds the kernel)
     TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
     TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
     hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
@@ -2361,7 +2360,7 @@ __global__ void __launch_bounds__(256) k_outer_segments(uint8_t* keep, const uin
         if (!head[i] || tsq_is_null(matched, i)) continue;  // (a padded row is a segment of its own and stays)
         bool any = false;
         int64_t k = i;
-        do { any = any || keep[k] != 0; k++; } while (k < n && !head[k]);
+        do { any = keep[k] != 0; k++; } while (!any && k < n && !head[k]);  // (stops at the first candidate that passed; the packed route's segments hold <= 255 rows)
         if (!any) keep[i] = 2;
     }
 }

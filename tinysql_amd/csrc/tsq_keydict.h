@@ -25,6 +25,7 @@
 #define TSQ_KD_EXC 0xffffffffu      // ridx: the key is not in the dictionary and found no place
 #define TSQ_KD_DEFER 0xfffffffeu    // ridx: the walk met a reserved slot with this key's tag: look again after the barrier
 #define TSQ_KD_RES 0x3fffu          // place code of a reserved slot (places are < TSQ_KR_CAP = 12288)
+#define TSQ_KD_DEAD 0x3ffeu         // place code of a slot whose reservation drew no place: walks pass it, it never turns EMPTY again
 
 struct KdArgs {
     const unsigned long long* prec;  // the batch's records, partition order: `stride` words each (4: records; 8: the 64-byte slots of
@@ -67,20 +68,28 @@ __device__ __forceinline__ uint32_t kd_tag(uint64_t h) {
 // TSQ_KD_RES: nobody can compare against it yet), draw a place of the partition's dictionary, write the record's bytes there, and only
 // then put the real entry (tag, place) into the slot — whoever sees a place can compare against complete bytes.  A walk that meets a
 // reserved slot with its own tag cannot tell yet whether that is its key: TSQ_KD_DEFER (the caller looks again after a barrier, when
-// every reservation has become an entry).  No place left: the reservation is taken back and the row is an exception row.
+// every reservation has become an entry).
+// No place left: the row is an exception row.  A reservation that drew no place becomes a DEAD slot and never EMPTY again (ADVICE r5:
+// another key may have walked PAST the reserved slot and settled behind it — were the slot emptied, a later row with that key would
+// stop at it, find no place and become an exception row although its key lives in the dictionary: one group in two places).  A walk
+// that ends at an empty slot reads the draw counter first and reserves nothing once the places are gone, so DEAD slots come only from
+// threads already between that check and their draw: fewer than the workgroup's threads, and the index keeps
+// TSQ_KR_SLOTS - TSQ_KR_CAP = 4096 slots beyond the places — a walk always meets an empty slot.
 __device__ __forceinline__ uint32_t kd_find_or_insert(uint32_t* s_tab, uint32_t* s_draw, unsigned long long* drec_p, uint32_t nd, const ulonglong2& x, const ulonglong2& y) {
     const uint64_t w[4] = {x.x, x.y, y.x, y.y};
     const uint64_t h = kr_hash(w);
     const uint32_t tag = kd_tag(h);
     uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
     for (;;) {
-        uint32_t e = __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // acquire: the record bytes behind a published place are read after the place (free at workgroup scope: no cache invalidate)
+        uint32_t e = __hip_atomic_load(&s_tab[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (e == 0xffffffffu) {
+            if (__hip_atomic_load(s_draw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= TSQ_KR_CAP - nd) return TSQ_KD_EXC;  // full (for good)
             e = atomicCAS(&s_tab[slot], 0xffffffffu, (tag << 14) | TSQ_KD_RES);
             if (e == 0xffffffffu) {
                 const uint32_t k = atomicAdd(s_draw, 1u);
-                if (k >= TSQ_KR_CAP - nd) {  // the partition's dictionary is full (for good)
-                    __hip_atomic_store(&s_tab[slot], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (k >= TSQ_KR_CAP - nd) {  // the last places went between the check and the draw
+                    __hip_atomic_store(&s_tab[slot], (tag << 14) | TSQ_KD_DEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     return TSQ_KD_EXC;
                 }
                 const uint32_t place = nd + k;
@@ -93,8 +102,9 @@ __device__ __forceinline__ uint32_t kd_find_or_insert(uint32_t* s_tab, uint32_t*
             }
         }
         if ((e >> 14) == tag) {
-            if ((e & 0x3fffu) == TSQ_KD_RES) return TSQ_KD_DEFER;
-            if (kd_drec_equal(drec_p + (size_t)(e & 0x3fffu) * 4, w)) return e & 0x3fffu;
+            const uint32_t pl = e & 0x3fffu;
+            if (pl == TSQ_KD_RES) return TSQ_KD_DEFER;
+            if (pl != TSQ_KD_DEAD && kd_drec_equal(drec_p + (size_t)pl * 4, w)) return pl;
         }
         slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
     }
