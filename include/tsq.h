@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TSQ_ABI_VERSION 6
+#define TSQ_ABI_VERSION 7
 
 /* ---------------------------------------------------------------- status codes */
 typedef int32_t tsq_status;
@@ -141,6 +141,7 @@ enum {
     TSQ_KNOB_STREAMAGG_LANES = 29,   /* 0: StreamAggExec always reduces every 64-row step across the lanes (k_sa_update) instead of keeping per-lane partial results of the open run (k_sa_update_lanes) */
     TSQ_KNOB_XCD_ATOMICS = 30,       /* retired in round 6 (was: workgroup-scope cursor atomics, an A/B that measured equal); setting it has no effect */
     TSQ_KNOB_DENSE_DIRECT = 31,      /* 0: the packed aggregate's dense state always leaves through partial groups and the hash table, also when the table is empty (k_dense_finalize off) */
+    TSQ_KNOB_DA_LDS_BUILD = 32,      /* 0: the materialising packed join never keeps a partition's build rows in LDS (csrc/tsq_damat.h): unique build sides take the sorted-build-columns variant of round 4 like the others; 2 .. 5 (tests): the second partition level splits 1 / 2 / 4 / 8 ways whatever the build side's size */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -837,6 +838,9 @@ typedef struct tsq_stats {
     int64_t div_by_zero_warnings;  /* join: division-by-zero warnings the OtherConditions / outer filters raised so far (NULL result + warning,
                                       expression/errors.go:65-77): the shim appends that many ErrDivisionByZero warnings to the statement context
                                       (handleDivisionByZeroError via executor/joiner.go:155-167) */
+    int32_t packed_lds_bits;       /* join, ABI 7: log2 of the FINAL partitions of the last materialising packed batch whose build side sat in LDS
+                                      (csrc/tsq_damat.h: two partition levels, ranked payload tables); 0: the batch took another variant */
+    int32_t reserved0;
 } tsq_stats;
 #define TSQ_ROUTE_DIRECT     0   /* k_probe_count / k_probe_emit on the table in HBM */
 #define TSQ_ROUTE_RADIX_L2   1   /* radix partition, table slices through the XCD's L2 */

@@ -361,10 +361,38 @@ __global__ void __launch_bounds__(256) k_pack_bitmap(const uint8_t* __restrict__
     }
 }
 
+// the same, 32 rows per thread: two 16-byte loads of flags -> one 4-byte store (round 6: the byte-per-lane kernel above took 0.27 ms per
+// 1e8 rows — 1.1 of the 4.3 ms of a nullable LEFT OUTER probe pass went into packing four bitmaps).  A flag byte becomes its bit with
+// an OR-fold (any non-zero value counts) and a multiply that gathers the eight low bits of a 64-bit word into one byte.
+__device__ __forceinline__ uint32_t tsq_flags8_to_bits(uint64_t w) {
+    w |= w >> 4;
+    w |= w >> 2;
+    w |= w >> 1;
+    w &= 0x0101010101010101ull;
+    return (uint32_t)((w * 0x0102040810204080ull) >> 56);
+}
+__global__ void __launch_bounds__(256) k_pack_bitmap32(const uint4* __restrict__ flags, uint32_t* __restrict__ bitmap, int64_t nwords) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nwords; k += (int64_t)gridDim.x * 256) {
+        const uint4 a = flags[2 * k], b = flags[2 * k + 1];
+        const uint32_t b0 = tsq_flags8_to_bits((uint64_t)a.x | ((uint64_t)a.y << 32)), b1 = tsq_flags8_to_bits((uint64_t)a.z | ((uint64_t)a.w << 32));
+        const uint32_t b2 = tsq_flags8_to_bits((uint64_t)b.x | ((uint64_t)b.y << 32)), b3 = tsq_flags8_to_bits((uint64_t)b.z | ((uint64_t)b.w << 32));
+        bitmap[k] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+}
+
 tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n) {
     if (n <= 0) return TSQ_OK;
-    int grid = tsq_grid_for(ctx, n, 256);
-    hipLaunchKernelGGL(k_pack_bitmap, dim3(grid), dim3(256), 0, ctx->stream, notnull_bytes, bitmap, n);
+    // whole 32-row words through the wide kernel (buffers of the operators start on 256-byte boundaries), the tail byte by byte
+    int64_t done = 0;
+    if (n >= 4096 && ((uintptr_t)notnull_bytes & 15u) == 0 && ((uintptr_t)bitmap & 3u) == 0) {
+        const int64_t nwords = n / 32;
+        hipLaunchKernelGGL(k_pack_bitmap32, dim3(tsq_grid_for(ctx, nwords, 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(notnull_bytes), reinterpret_cast<uint32_t*>(bitmap), nwords);
+        TSQ_HIP(h, hipGetLastError());
+        done = nwords * 32;
+        if (done == n) return TSQ_OK;
+    }
+    int grid = tsq_grid_for(ctx, n - done, 256);
+    hipLaunchKernelGGL(k_pack_bitmap, dim3(grid), dim3(256), 0, ctx->stream, notnull_bytes + done, bitmap + done / 8, n - done);
     TSQ_HIP(h, hipGetLastError());
     return TSQ_OK;
 }

@@ -24,6 +24,7 @@
 #include "tsq_ldsprobe.h"
 #include "tsq_keyrec.h"
 #include "tsq_dajoin.h"
+#include "tsq_damat.h"
 
 #include <chrono>
 #include <deque>
@@ -804,6 +805,18 @@ struct tsq_join {
     int da_cols_state = 0;            // travelling-columns route: the build columns sorted by word (+ NOT-NULL bytes)
     DevBuf da_bsorted[TSQ_DA_MAXCOLS], da_bsorted_nn[TSQ_DA_MAXCOLS];
     DevBuf rcols[TSQ_DA_MAXCOLS], rnnmask;  // ... the probe columns travelling with the entries, their NOT-NULL bits
+    // materialising packed route with the build side in LDS (round 6, tsq_damat.h): two partition levels, ranked payload tables
+    int dm_state = 0;                 // 0: not tried yet, 1: the build side's final partitions are ready, -1: not usable for this build side
+    uint32_t dm_sbits = 0, dm_tab_rows = 0, dm_cap1_b = 0;
+    int dm_nb = 0, dm_bcol_of[TSQ_DA_MAXCOLS] = {};  // the build columns in the tables (all but the key column)
+    bool dm_bnulls = false;
+    DevBuf dm_bent, dm_bpay[TSQ_DA_MAXCOLS], dm_bnn, dm_boff, dm_bcnt, dm_bitmap;  // build side: final partitions | one bit per word of the domain
+    DevBuf dm_pent, dm_ppay[TSQ_DA_MAXCOLS], dm_pnn, dm_poff, dm_pcnt;             // the probe batch in flight: final partitions
+    // level 1 of the build side WITH its columns, made by da_prepare in place of its key-only partition pass when the join materialises
+    // (the images are assembled from the same entries): dm_prepare_build starts from it — one pass over the build side saved
+    bool dm_l1_ready = false, dm_l1_nulls = false;
+    uint32_t dm_l1_cap = 0;
+    DevBuf dm_l1ent, dm_l1ctl, dm_l1vend, dm_l1nn, dm_l1pay[TSQ_DA_MAXCOLS];
     static constexpr int RING = 32;   // HIP events of the most recent radix batches: [slot][0..2] = start, after partition, end
     hipEvent_t rev[RING][3] = {};
 
@@ -1301,7 +1314,8 @@ tsq_status da_compose_build(tsq_join* j, bool* ok, uint32_t max_total_bits = TSQ
 // range over all ranks, every rank assembles the images of ITS rows over that range, and the images are summed across the ranks
 // (one all-reduce, once per build side): afterwards every rank holds the images of the WHOLE build side and probes its own probe
 // rows locally.  Every rank takes the same decisions: they depend on the configuration and on all-reduced values only.
-tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status = TSQ_OK) {
+bool dm_cols_shape(const tsq_join* j);
+tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status = TSQ_OK, bool want_cols = false) {
     if (j->da_state) return TSQ_OK;
     j->da_state = -1;
     tsq_ctx* ctx = j->ctx;
@@ -1386,10 +1400,24 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status
         if (!sc) return TSQ_OK;
         local_fail = true;
     }
-    DevBuf ent, ctl, vend, ovf;
+    DevBuf ent, ctl, vend, ovf, ovfi, nnm, pay[TSQ_DA_MAXCOLS];
     auto release_all = [&]() {
-        for (DevBuf* x : {&ent, &ctl, &vend, &ovf}) x->release();
+        for (DevBuf* x : {&ent, &ctl, &vend, &ovf, &ovfi, &nnm}) x->release();
+        for (auto& b : pay) b.release();
     };
+    // a materialising join whose build side may go into LDS (tsq_damat.h): the partition pass takes the build COLUMNS along and its
+    // store is kept for dm_prepare_build (k_da_partition_cols in place of k_da_partition2: + 16 B per row here, - 26 B per row there)
+    const bool cols_l1 = want_cols && !sc && !bits_mode && nb > 0 && pl.ebits <= 16 && pl.ebits >= 7 && dm_cols_shape(j);
+    int l1_cols[TSQ_DA_MAXCOLS], l1_n = 0;
+    bool l1_nulls = false;
+    if (cols_l1) {
+        const int kb = j->da_multi ? -1 : kc;
+        for (int c = 0; c < j->cfg.n_build_cols; c++)
+            if (c != kb) {
+                l1_cols[l1_n++] = c;
+                l1_nulls = l1_nulls || j->bcols[c].has_nulls;
+            }
+    }
     tsq_status s = TSQ_OK;
     hipError_t e = hipSuccess;
     if (!local_fail) {
@@ -1398,6 +1426,11 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status
         if (s == TSQ_OK && nb > 0) s = ctl.reserve(ctx, h, g.ctl_bytes);
         if (s == TSQ_OK && nb > 0) s = vend.reserve(ctx, h, g.nregions * 4);
         if (s == TSQ_OK && nb > 0) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
+        if (cols_l1) {
+            if (s == TSQ_OK) s = ovfi.reserve(ctx, h, (size_t)nb * 4 + 64);
+            for (int v = 0; v < l1_n && s == TSQ_OK; v++) s = pay[v].reserve(ctx, h, g.nregions * g.cap * 8 + 256);
+            if (s == TSQ_OK && l1_nulls) s = nnm.reserve(ctx, h, g.nregions * g.cap + 256);
+        }
         if (s != TSQ_OK && !sc) { release_all(); j->da_img.release(); return s; }
     }
     if (!local_fail && s == TSQ_OK && nb == 0) {  // (a rank of a shared build side without rows: its images are zeros)
@@ -1421,7 +1454,28 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
-        if (e == hipSuccess) s = da_launch_partition(j, ma.src, st);
+        if (e == hipSuccess && cols_l1) {
+            DaColStore cs;
+            memset(&cs, 0, sizeof cs);
+            cs.st = st;
+            cs.st.miss_count = st.cursor + g.nregions + 1;
+            cs.st.ovf_idx = ovfi.as<uint32_t>();
+            for (int v = 0; v < l1_n; v++) cs.pay[v] = pay[v].as<uint64_t>();
+            cs.nnmask = l1_nulls ? nnm.as<uint8_t>() : nullptr;
+            DaColSrc src;
+            memset(&src, 0, sizeof src);
+            src.key = ma.src;
+            src.n_cols = l1_n;
+            src.any_nulls = l1_nulls ? 1 : 0;
+            for (int v = 0; v < l1_n; v++) {
+                src.col[v] = j->bcols[l1_cols[v]].data.as<uint64_t>();
+                src.nulls[v] = j->bcols[l1_cols[v]].has_nulls ? j->bcols[l1_cols[v]].nulls.as<uint8_t>() : nullptr;
+            }
+            constexpr int TC = 1024 * 8;
+            hipLaunchKernelGGL((k_da_partition_cols<1024, 8, false>), dim3((unsigned)std::min<int64_t>((nb + TC - 1) / TC, ctx->num_cus)), dim3(1024), 0, ctx->stream, src, j->da_dm, cs);
+            e = hipGetLastError();
+            j->st.kernel_launches++;
+        } else if (e == hipSuccess) s = da_launch_partition(j, ma.src, st);
         DaImageArgs ia;
         memset(&ia, 0, sizeof ia);
         ia.st = st;
@@ -1448,6 +1502,8 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status
         }
         if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned + 51, ctx->dscratch + 51, 8, hipMemcpyDeviceToHost, ctx->stream);
+        ctx->pinned[52] = 0;
+        if (e == hipSuccess && cols_l1) e = hipMemcpyAsync(ctx->pinned + 52, ctl.as<uint32_t>() + g.nregions, 4, hipMemcpyDeviceToHost, ctx->stream);  // rows that missed their region
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         float ms = 0;
         if (e == hipSuccess && e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms = ms;
@@ -1455,8 +1511,24 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status
         if (e1) (void)hipEventDestroy(e1);
         j->st.kernel_launches += 2;
     }
-    release_all();
     uint32_t f_over = ((const uint32_t*)(ctx->pinned + 51))[0], f_dup = ((const uint32_t*)(ctx->pinned + 51))[1];
+    if (cols_l1 && !local_fail && s == TSQ_OK && e == hipSuccess && !f_over && !f_dup && ((const uint32_t*)(ctx->pinned + 52))[0] == 0) {  // a unique build side, every row in its region: this level 1 is dm_prepare_build's
+        auto hand = [](DevBuf& to, DevBuf& from) {
+            to.release();
+            to = from;
+            from.p = nullptr;
+            from.cap = 0;
+        };
+        hand(j->dm_l1ent, ent);
+        hand(j->dm_l1ctl, ctl);
+        hand(j->dm_l1vend, vend);
+        hand(j->dm_l1nn, nnm);
+        for (int v = 0; v < l1_n; v++) hand(j->dm_l1pay[v], pay[v]);
+        j->dm_l1_cap = g.cap;
+        j->dm_l1_nulls = l1_nulls;
+        j->dm_l1_ready = true;
+    }
+    release_all();
     if (sc) {  // one more agreement: did every rank get its images, did any rank's cell overflow / hold a duplicate (bit cells)
         int64_t fl[3] = {(local_fail || s != TSQ_OK || e != hipSuccess) ? 1 : 0, (int64_t)(f_over != 0), (int64_t)(bits_mode && f_dup != 0)};
         const tsq_status cs = tsq_comm_allreduce_host_i64(sc, fl, 3, 1);
@@ -1524,6 +1596,16 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status
     j->da_unique = f_dup == 0;
     j->da_state = 1;
     return TSQ_OK;
+}
+// every column on both sides an 8-byte type, at most TSQ_DA_MAXCOLS per side (what the travelling-columns routes take)
+bool dm_cols_shape(const tsq_join* j) {
+    if (tsq_knob(j->ctx, TSQ_KNOB_DA_LDS_BUILD, 1) == 0 || j->count_only) return false;
+    if (j->cfg.n_probe_cols > TSQ_DA_MAXCOLS || j->cfg.n_build_cols > TSQ_DA_MAXCOLS) return false;
+    for (int c = 0; c < j->cfg.n_probe_cols; c++)
+        if (j->cfg.probe_types[c] == TSQ_F32 || j->cfg.probe_types[c] == TSQ_BYTES) return false;
+    for (int c = 0; c < j->cfg.n_build_cols; c++)
+        if (j->cfg.build_types[c] == TSQ_F32 || j->cfg.build_types[c] == TSQ_BYTES) return false;
+    return true;
 }
 
 tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uint8_t* sel = nullptr) {
@@ -2606,6 +2688,7 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     j->st.radix_bits = (int32_t)st.bits;
     j->st.probe_route = TSQ_ROUTE_PACKED;
     j->st.packed_key_bits = (int32_t)j->da_dm.b;
+    j->st.packed_lds_bits = 0;
     if (out_rows == 0) {
         TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
         TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
@@ -2760,6 +2843,460 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     const tsq_status ds = deliver_batch(j, std::move(rb), may_null_v);
     tp("delivered (stream idle)");
     return ds;
+}
+
+// ---------------------------------------------------------------- materialising packed route, build side in LDS (host side; tsq_damat.h)
+// Eligible on top of da_cols_eligible: a build side WITHOUT duplicate keys (byte cells 0 / 1), 2-byte entries of 7..16 bits.  S (the
+// level-2 fan-out) is the smallest power of two <= 8 that brings the build rows of a final partition into a table of <= 64 KB per
+// workgroup (two workgroups per CU); a build side that does not get there (more than ~5e8 rows, or several wide columns) keeps round
+// 4's variant.  TSQ_KNOB_DA_LDS_BUILD = 0 switches the route off (A/B measurements, tests of the other variant).
+bool dm_eligible(const tsq_join* j) {
+    if (tsq_knob(j->ctx, TSQ_KNOB_DA_LDS_BUILD, 1) == 0) return false;
+    return j->da_state == 1 && !j->da_bits && j->da_unique && j->da_ebits <= 16 && j->da_ebits >= 7 && j->dm_state >= 0;
+}
+// (the state the build side must be in before its final partitions are made)
+static bool dm_eligible_shape(const tsq_join* j) { return j->da_state == 1 && !j->da_bits && j->da_unique && j->da_ebits <= 16 && j->da_ebits >= 7; }
+static size_t dm_split_lds(uint32_t ebits1, bool filter) { return (size_t)512 * 8 * 10 + (filter ? ((size_t)1 << ebits1) / 8 : 0) + 16; }
+// level 2 of one side: src (level 1) -> dst; filter: the probe side of an inner join
+tsq_status dm_launch_split(tsq_join* j, const DaColStore& src, int n_cols, const DmStore& dst, bool filter) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    DmSplitArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = src;
+    a.n_cols = n_cols;
+    a.dst = dst;
+    a.bitmap = filter ? j->dm_bitmap.as<uint32_t>() : nullptr;
+    const size_t lds = dm_split_lds(src.st.ebits, filter);
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (size_t)(150 * 1024) / lds));  // (measured: 3 workgroups per CU 0.42 ms, 2: 0.46, 1: 0.64 per 1e8 rows)
+    const dim3 grid(std::min<uint32_t>(1u << src.st.bits, (uint32_t)ctx->num_cus * per_cu));
+    if (filter) {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_dm_split<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_dm_split<512, true>), grid, dim3(512), lds, ctx->stream, a);
+    } else {
+        TSQ_HIP(h, hipFuncSetAttribute((const void*)k_dm_split<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_dm_split<512, false>), grid, dim3(512), lds, ctx->stream, a);
+    }
+    TSQ_HIP(h, hipGetLastError());
+    j->st.kernel_launches++;
+    return TSQ_OK;
+}
+// the build side, once per build: level 1 with its columns, level 2, the bitmap of the domain; the largest final partition sizes the tables
+tsq_status dm_prepare_build(tsq_join* j) {
+    if (j->dm_state) return TSQ_OK;
+    j->dm_state = -1;
+    struct L1Drop {  // whatever of da_prepare's level-1 store this function does not take over goes back to the pool when it returns
+        tsq_join* j;
+        ~L1Drop() {
+            j->dm_l1_ready = false;
+            for (DevBuf* b : {&j->dm_l1ent, &j->dm_l1ctl, &j->dm_l1vend, &j->dm_l1nn}) b->release();
+            for (auto& b : j->dm_l1pay) b.release();
+        }
+    } l1_drop{j};
+    if (!dm_eligible_shape(j)) return TSQ_OK;
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    const int kb = j->da_multi ? -1 : j->ks.bidx[0];
+    const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
+    constexpr int T = 1024 * 8;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nb, T);
+    if (g.nregions * g.cap >= 0xffffffffULL) return TSQ_OK;
+    const size_t slots = g.nregions * g.cap;
+    int ncols = 0;
+    bool any_nulls = false;
+    for (int c = 0; c < j->cfg.n_build_cols; c++) {
+        if (c == kb) continue;
+        if (ncols == TSQ_DA_MAXCOLS) return TSQ_OK;
+        j->dm_bcol_of[ncols++] = c;
+        any_nulls = any_nulls || j->bcols[c].has_nulls;
+    }
+    if (j->dm_l1_ready && j->dm_l1_nulls != any_nulls) {  // (cannot happen: both look at the same columns)
+        j->dm_l1_ready = false;
+        for (DevBuf* b : {&j->dm_l1ent, &j->dm_l1ctl, &j->dm_l1vend, &j->dm_l1nn}) b->release();
+        for (auto& b : j->dm_l1pay) b.release();
+    }
+    // S: expected build rows of a final partition (+ 25 % and 6 sigma: the mix spreads any key set evenly) against a table of 64 KB
+    const double table_rows = (64.0 * 1024.0) / (8.0 * std::max(1, ncols));
+    uint32_t sbits = 0;
+    auto expect = [&](uint32_t sb) { const double lam = (double)nb / (double)((size_t)1 << (j->da_pbits + sb)); return lam * 1.25 + 6.0 * sqrt(lam) + 32.0; };
+    while (sbits < 3 && j->da_ebits - sbits > 7 && expect(sbits) > table_rows) sbits++;
+    const int64_t forced = tsq_knob(ctx, TSQ_KNOB_DA_LDS_BUILD, 1);  // (tests: 2 .. 5 force S = 1 .. 8 on small build sides)
+    if (forced >= 2) sbits = std::min<uint32_t>((uint32_t)std::min<int64_t>(forced - 2, 3), j->da_ebits - 5);
+    if (expect(sbits) > 2.0 * table_rows) return TSQ_OK;  // (one workgroup per CU would still take 128 KB: beyond that the route is not for this build side)
+    const uint32_t S = 1u << sbits, P1 = g.P, Q = P1 * S;
+    DevBuf ent, ctl, vend, ovf, ovfi, nnm, pay[TSQ_DA_MAXCOLS];
+    const bool have_l1 = j->dm_l1_ready;  // da_prepare partitioned the build side with its columns already
+    j->dm_l1_ready = false;
+    if (have_l1) {
+        auto take = [](DevBuf& to, DevBuf& from) {
+            to = from;
+            from.p = nullptr;
+            from.cap = 0;
+        };
+        take(ent, j->dm_l1ent);
+        take(ctl, j->dm_l1ctl);
+        take(vend, j->dm_l1vend);
+        take(nnm, j->dm_l1nn);
+        for (int v = 0; v < ncols; v++) take(pay[v], j->dm_l1pay[v]);
+    }
+    auto release_tmp = [&]() {
+        for (DevBuf* x : {&ent, &ctl, &vend, &ovf, &ovfi, &nnm}) x->release();
+        for (auto& b : pay) b.release();
+    };
+    auto give_up = [&](tsq_status st) {
+        release_tmp();
+        for (DevBuf* b : {&j->dm_bent, &j->dm_bnn, &j->dm_boff, &j->dm_bcnt, &j->dm_bitmap}) b->release();
+        for (auto& b : j->dm_bpay) b.release();
+        return st;
+    };
+    const uint32_t cap = have_l1 ? j->dm_l1_cap : g.cap;  // (da_prepare sized its regions for 16 Ki-row tiles: a little larger)
+    const uint32_t cap1 = 8u * cap + 8u * S;
+    const size_t slots2 = (size_t)P1 * cap1;
+    if (slots2 >= 0xffffffffULL) return give_up(TSQ_OK);
+    tsq_status s = TSQ_OK;
+    if (!have_l1) {
+        s = ent.reserve(ctx, h, g.ent_bytes);
+        if (s == TSQ_OK) s = ctl.reserve(ctx, h, g.ctl_bytes);
+        if (s == TSQ_OK) s = vend.reserve(ctx, h, g.nregions * 4);
+        if (s == TSQ_OK) s = ovf.reserve(ctx, h, (size_t)nb * 4 + 64);
+        if (s == TSQ_OK) s = ovfi.reserve(ctx, h, (size_t)nb * 4 + 64);
+        for (int v = 0; v < ncols && s == TSQ_OK; v++) s = pay[v].reserve(ctx, h, slots * 8 + 256);
+        if (s == TSQ_OK && any_nulls) s = nnm.reserve(ctx, h, slots + 256);
+    }
+    if (s == TSQ_OK) s = j->dm_bent.reserve(ctx, h, slots2 * 2 + 256);
+    for (int v = 0; v < ncols && s == TSQ_OK; v++) s = j->dm_bpay[v].reserve(ctx, h, slots2 * 8 + 256);
+    if (s == TSQ_OK && any_nulls) s = j->dm_bnn.reserve(ctx, h, slots2 + 256);
+    if (s == TSQ_OK) s = j->dm_boff.reserve(ctx, h, (size_t)Q * 4 + 64);
+    if (s == TSQ_OK) s = j->dm_bcnt.reserve(ctx, h, ((size_t)Q + 1) * 8 + 64);
+    const size_t bit_words = ((size_t)1 << j->da_dm.b) / 32;
+    if (s == TSQ_OK) s = j->dm_bitmap.reserve(ctx, h, bit_words * 4 + 64);
+    if (s != TSQ_OK) {  // no memory for the second copy of the build side: the other variants keep the join
+        h->err.clear();
+        return give_up(TSQ_OK);
+    }
+    DaColStore cs;
+    memset(&cs, 0, sizeof cs);
+    DaStore& st = cs.st;
+    st.ent = ent.p;
+    st.cursor = ctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.miss_count = st.cursor + g.nregions + 1;
+    st.valid_end = vend.as<uint32_t>();
+    st.ovf = ovf.as<uint32_t>();
+    st.ovf_idx = ovfi.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nb;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = cap;
+    for (int v = 0; v < ncols; v++) cs.pay[v] = pay[v].as<uint64_t>();
+    cs.nnmask = any_nulls ? nnm.as<uint8_t>() : nullptr;
+    DaColSrc src;
+    memset(&src, 0, sizeof src);
+    da_build_key(j, src.key);
+    src.n_cols = ncols;
+    src.any_nulls = any_nulls ? 1 : 0;
+    for (int v = 0; v < ncols; v++) {
+        src.col[v] = j->bcols[j->dm_bcol_of[v]].data.as<uint64_t>();
+        src.nulls[v] = j->bcols[j->dm_bcol_of[v]].has_nulls ? j->bcols[j->dm_bcol_of[v]].nulls.as<uint8_t>() : nullptr;
+    }
+    if (have_l1) ctx->pinned[52] = 0;  // (its overflow count was checked by da_prepare)
+    DmStore d2;
+    memset(&d2, 0, sizeof d2);
+    d2.ent = j->dm_bent.as<uint16_t>();
+    for (int v = 0; v < ncols; v++) d2.pay[v] = j->dm_bpay[v].as<uint64_t>();
+    d2.nnmask = any_nulls ? j->dm_bnn.as<uint8_t>() : nullptr;
+    d2.off = j->dm_boff.as<uint32_t>();
+    d2.cnt = j->dm_bcnt.as<unsigned long long>();
+    d2.cap1 = cap1;
+    d2.sbits = sbits;
+    d2.ebits2 = j->da_ebits - sbits;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess && !have_l1) e = hipMemsetAsync(ctl.p, 0, g.ctl_bytes, ctx->stream);
+    if (e == hipSuccess && !have_l1) e = hipMemsetAsync(vend.p, 0xff, g.nregions * 4, ctx->stream);
+    if (e == hipSuccess && !have_l1) {
+        const dim3 grid((unsigned)std::min<int64_t>((nb + T - 1) / T, ctx->num_cus));
+        hipLaunchKernelGGL((k_da_partition_cols<1024, 8, false>), grid, dim3(1024), 0, ctx->stream, src, j->da_dm, cs);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_da_bytes_to_bits, dim3(tsq_grid_for(ctx, (int64_t)bit_words, 256)), dim3(256), 0, ctx->stream, j->da_img.as<uint8_t>(), j->dm_bitmap.as<uint32_t>(), bit_words);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && dm_launch_split(j, cs, ncols, d2, false) != TSQ_OK) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    // the overflow count of level 1 and the rows of every final partition: the host sizes the tables by the largest
+    std::vector<unsigned long long> cnt((size_t)Q);
+    if (e == hipSuccess && !have_l1) e = hipMemcpyAsync(ctx->pinned + 52, st.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cnt.data(), d2.cnt, (size_t)Q * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0;
+    if (e == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) j->da_build_ms += ms;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    j->st.kernel_launches += 2;
+    if (e != hipSuccess) return give_up(tsq_fail(h, TSQ_ERR_HIP, std::string("packed build side in LDS: ") + hipGetErrorString(e)));
+    if (((const uint32_t*)(ctx->pinned + 52))[0] != 0) return give_up(TSQ_OK);  // (rows that missed their level-1 region: cannot happen with unique keys; the other variant copes)
+    unsigned long long bmax = 0;
+    for (unsigned long long c : cnt) bmax = std::max(bmax, c);
+    const uint32_t tab_rows = (uint32_t)((bmax + 31) & ~31ull);
+    if (dm_emit_lds(d2.ebits2, tab_rows, ncols, any_nulls) > (size_t)150 * 1024) return give_up(TSQ_OK);
+    release_tmp();
+    j->dm_sbits = sbits;
+    j->dm_tab_rows = std::max<uint32_t>(tab_rows, 32u);
+    j->dm_cap1_b = cap1;
+    j->dm_nb = ncols;
+    j->dm_bnulls = any_nulls;
+    j->dm_state = 1;
+    return TSQ_OK;
+}
+
+// One probe batch: level 1 (+ the miss list of an outer join), level 2 (an inner join drops the rows without a build row), scan, emit.
+// *fallback: a run of this batch missed its level-1 region (skewed probe keys) — nothing was delivered, the caller takes round 4's variant.
+tsq_status dm_emit_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool* redo, bool* fallback, const uint8_t* sel = nullptr) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    *fallback = false;
+    const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
+    const int np = j->cfg.n_probe_cols, nbc = j->cfg.n_build_cols;
+    constexpr int T = 1024 * 8;
+    const DaGeom g = da_geometry(j->da_pbits, j->da_ebits, nrows, T);
+    if (g.nregions * g.cap >= 0xffffffffULL) { *fallback = true; return TSQ_OK; }
+    const size_t slots = g.nregions * g.cap;
+    const uint32_t sbits = j->dm_sbits, S = 1u << sbits, P1 = g.P, Q = P1 * S;
+    const uint32_t cap1 = 8u * g.cap + 8u * S;
+    const size_t slots2 = (size_t)P1 * cap1;
+    if (slots2 >= 0xffffffffULL) { *fallback = true; return TSQ_OK; }
+    TSQ_TRY(j->rkeys.reserve(ctx, h, g.ent_bytes));
+    TSQ_TRY(j->rctl.reserve(ctx, h, g.ctl_bytes));
+    TSQ_TRY(j->rvend.reserve(ctx, h, g.nregions * 4));
+    TSQ_TRY(j->rovf.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    TSQ_TRY(j->rovfidx.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    if (outer) TSQ_TRY(j->rmiss.reserve(ctx, h, (size_t)nrows * 4 + 64));
+    const int kc = j->da_multi ? -1 : j->ks.pidx[0], kb = j->da_multi ? -1 : j->ks.bidx[0];
+    int trav[TSQ_DA_MAXCOLS], ntrav = 0;
+    for (int c = 0; c < np; c++)
+        if (c != kc) trav[ntrav++] = c;
+    bool any_nulls = false;
+    for (int v = 0; v < ntrav; v++) {
+        TSQ_TRY(j->rcols[v].reserve(ctx, h, slots * 8 + 256));
+        TSQ_TRY(j->dm_ppay[v].reserve(ctx, h, slots2 * 8 + 256));
+        any_nulls = any_nulls || pcs.nulls[trav[v]] != nullptr;
+    }
+    if (any_nulls) {
+        TSQ_TRY(j->rnnmask.reserve(ctx, h, slots + 256));
+        TSQ_TRY(j->dm_pnn.reserve(ctx, h, slots2 + 256));
+    }
+    TSQ_TRY(j->dm_pent.reserve(ctx, h, slots2 * 2 + 256));
+    TSQ_TRY(j->dm_poff.reserve(ctx, h, (size_t)Q * 4 + 64));
+    TSQ_TRY(j->dm_pcnt.reserve(ctx, h, ((size_t)Q + 1) * 8 + 64));
+    DaColStore cs;
+    memset(&cs, 0, sizeof cs);
+    DaStore& st = cs.st;
+    st.ent = j->rkeys.p;
+    st.cursor = j->rctl.as<uint32_t>();
+    st.ovf_count = st.cursor + g.nregions;
+    st.miss_count = st.cursor + g.nregions + 1;
+    st.miss = j->rmiss.as<uint32_t>();
+    st.valid_end = j->rvend.as<uint32_t>();
+    st.ovf = j->rovf.as<uint32_t>();
+    st.ovf_idx = j->rovfidx.as<uint32_t>();
+    st.ovf_cap = (uint32_t)nrows;
+    st.bits = j->da_pbits;
+    st.ebits = j->da_ebits;
+    st.cap = g.cap;
+    for (int v = 0; v < ntrav; v++) cs.pay[v] = j->rcols[v].as<uint64_t>();
+    cs.nnmask = any_nulls ? j->rnnmask.as<uint8_t>() : nullptr;
+    DmStore p2;
+    memset(&p2, 0, sizeof p2);
+    p2.ent = j->dm_pent.as<uint16_t>();
+    for (int v = 0; v < ntrav; v++) p2.pay[v] = j->dm_ppay[v].as<uint64_t>();
+    p2.nnmask = any_nulls ? j->dm_pnn.as<uint8_t>() : nullptr;
+    p2.off = j->dm_poff.as<uint32_t>();
+    p2.cnt = j->dm_pcnt.as<unsigned long long>();
+    p2.cap1 = cap1;
+    p2.sbits = sbits;
+    p2.ebits2 = j->da_ebits - sbits;
+    TSQ_HIP(h, hipMemsetAsync(j->rctl.p, 0, g.ctl_bytes, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(j->rvend.p, 0xff, g.nregions * 4, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(p2.cnt + Q, 0, 8, ctx->stream));
+    DaColSrc src;
+    memset(&src, 0, sizeof src);
+    TSQ_TRY(da_probe_key(j, pcs, nrows, src.key, sel));
+    src.n_cols = ntrav;
+    src.any_nulls = any_nulls ? 1 : 0;
+    for (int v = 0; v < ntrav; v++) {
+        src.col[v] = (const uint64_t*)pcs.data[trav[v]];
+        src.nulls[v] = pcs.nulls[trav[v]];
+    }
+    hipEvent_t* re = j->rev[j->st.radix_batches % tsq_join::RING];
+    for (int e = 0; e < 3; e++)
+        if (!re[e]) TSQ_HIP(h, hipEventCreate(&re[e]));
+    TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
+    {
+        const dim3 grid((unsigned)std::min<int64_t>((nrows + T - 1) / T, ctx->num_cus));
+        if (outer) hipLaunchKernelGGL((k_da_partition_cols<1024, 8, true>), grid, dim3(1024), 0, ctx->stream, src, j->da_dm, cs);
+        else hipLaunchKernelGGL((k_da_partition_cols<1024, 8, false>), grid, dim3(1024), 0, ctx->stream, src, j->da_dm, cs);
+        TSQ_HIP(h, hipGetLastError());
+    }
+    TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
+    TSQ_TRY(dm_launch_split(j, cs, ntrav, p2, !outer));
+    TSQ_HIP(h, hipFuncSetAttribute((const void*)k_dm_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)Q + 1) * 8)));
+    hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), ((size_t)Q + 1) * 8, ctx->stream, p2.cnt, Q + 1);
+    TSQ_HIP(h, hipGetLastError());
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 52, p2.cnt + Q, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 53, st.ovf_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 54, st.miss_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+    j->st.kernel_launches += 2;
+    const int64_t part_rows = (int64_t)ctx->pinned[52];
+    if (((const uint32_t*)(ctx->pinned + 53))[0] != 0) {  // skewed probe keys: a run did not fit its region — round 4's variant has the overflow list
+        *fallback = true;
+        return TSQ_OK;
+    }
+    const int64_t miss_rows = outer ? (int64_t)((const uint32_t*)(ctx->pinned + 54))[0] : 0;
+    const int64_t exc_rows = miss_rows, out_rows = exc_rows + part_rows;
+    j->st.radix_batches++;
+    j->st.radix_bits = (int32_t)st.bits;
+    j->st.probe_route = TSQ_ROUTE_PACKED;
+    j->st.packed_key_bits = (int32_t)j->da_dm.b;
+    j->st.packed_lds_bits = (int32_t)(st.bits + sbits);
+    if (out_rows == 0) {
+        TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+        TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+        j->have_probe_ev = true;
+        return TSQ_OK;
+    }
+    // ---- the output batch: [NULL-padded rows of the miss list | rows of the final partitions]; NULLs as one byte per row, packed at the end
+    const int nout = np + nbc;
+    const bool probe_is_left = j->cfg.build_is_right != 0;
+    const int nl = probe_is_left ? np : nbc;
+    std::unique_ptr<ResultBatch> rb(new ResultBatch());
+    rb->rows = out_rows;
+    rb->data.resize(nout);
+    rb->notnull.resize(nout);
+    rb->bitmap.resize(nout);
+    rb->offs.resize(nout);
+    rb->nbytes.assign(nout, 0);
+    std::vector<bool> may_null_v(nout, false);
+    DmEmitArgs ea;
+    memset(&ea, 0, sizeof ea);
+    DaExcArgs xa;
+    memset(&xa, 0, sizeof xa);
+    auto build_table_col = [&](int sc) {  // build column sc -> its table
+        for (int v = 0; v < j->dm_nb; v++)
+            if (j->dm_bcol_of[v] == sc) return v;
+        return -1;
+    };
+    for (int oc = 0; oc < nout; oc++) {
+        const bool from_probe = probe_is_left ? oc < nl : oc >= nl;
+        const int sc = oc < nl ? oc : oc - nl;
+        const bool may_null = from_probe ? pcs.nulls[sc] != nullptr : (j->bcols[sc].has_nulls || outer);
+        may_null_v[oc] = may_null;
+        tsq_status s = rb->data[oc].reserve(ctx, h, ((size_t)out_rows + 8) * 8 + 16);
+        if (s == TSQ_OK && may_null) s = rb->notnull[oc].reserve(ctx, h, (size_t)out_rows + 64);
+        if (s == TSQ_OK && may_null) s = rb->bitmap[oc].reserve(ctx, h, tsq_bitmap_bytes(out_rows) + 16);
+        if (s != TSQ_OK) { rb->release(); return s; }
+        if (may_null) TSQ_HIP(h, hipMemsetAsync(rb->notnull[oc].p, 1, (size_t)out_rows, ctx->stream));  // the emit kernel stores the NULL cells' flags only
+        uint64_t* od = rb->data[oc].as<uint64_t>();
+        uint8_t* of = may_null ? rb->notnull[oc].as<uint8_t>() : nullptr;
+        if (from_probe) {
+            if (sc == kc) ea.out_pkey = od;  // (a probe key cell of a row that reached a partition is never NULL)
+            else {
+                const int v = (kc < 0 || sc < kc) ? sc : sc - 1;
+                ea.out_probe[v] = od;
+                ea.out_probe_nn[v] = of;
+            }
+            xa.pcol[sc] = (const uint64_t*)pcs.data[sc];
+            xa.pnull[sc] = pcs.nulls[sc];
+            xa.out_probe[sc] = od;
+            xa.out_probe_nn[sc] = of;
+        } else {
+            if (sc == kb) {
+                ea.out_bkey = od;
+                ea.out_bkey_nn = of;
+            } else {
+                const int v = build_table_col(sc);
+                ea.out_build[v] = od;
+                ea.out_build_nn[v] = of;
+            }
+            xa.out_build[sc] = od;
+            xa.out_build_nn[sc] = of;  // (exception rows of this route are the NULL-padded rows only: no build cell is read)
+        }
+    }
+    if (exc_rows > 0) {  // the NULL-padded rows of the probe rows that never reached a partition (NULL key, key outside the build side's range)
+        TSQ_TRY(j->pairs.reserve(ctx, h, (size_t)exc_rows * 8 + 64));
+        hipLaunchKernelGGL(k_da_emit_miss, dim3(tsq_grid_for(ctx, miss_rows, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)st.miss, (uint32_t)miss_rows,
+                           j->pairs.as<unsigned long long>());
+        TSQ_HIP(h, hipGetLastError());
+        xa.pairs = j->pairs.as<unsigned long long>();
+        xa.bkey_col = kb;
+        xa.pkey_col = kc;
+        xa.n = exc_rows;
+        xa.n_probe = np;
+        xa.n_build = nbc;
+        hipLaunchKernelGGL(k_da_gather_exc, dim3(tsq_grid_for(ctx, exc_rows, 256)), dim3(256), 0, ctx->stream, xa);
+        TSQ_HIP(h, hipGetLastError());
+        j->st.kernel_launches += 2;
+    }
+    if (part_rows > 0) {
+        ea.pst = p2;
+        ea.bst.ent = j->dm_bent.as<uint16_t>();
+        for (int v = 0; v < j->dm_nb; v++) ea.bst.pay[v] = j->dm_bpay[v].as<uint64_t>();
+        ea.bst.nnmask = j->dm_bnulls ? j->dm_bnn.as<uint8_t>() : nullptr;
+        ea.bst.off = j->dm_boff.as<uint32_t>();
+        ea.bst.cnt = j->dm_bcnt.as<unsigned long long>();
+        ea.bst.cap1 = j->dm_cap1_b;
+        ea.bst.sbits = sbits;
+        ea.bst.ebits2 = p2.ebits2;
+        ea.dm = j->da_dm;
+        ea.pbits = st.bits + sbits;
+        ea.row0 = (unsigned long long)exc_rows;
+        ea.tab_rows = j->dm_tab_rows;
+        ea.n_probe = ntrav;
+        ea.n_build = j->dm_nb;
+        const size_t lds = dm_emit_lds(p2.ebits2, ea.tab_rows, ea.n_build, j->dm_bnulls);
+        const uint32_t per_cu = lds <= (size_t)76 * 1024 ? 2u : 1u;
+        const dim3 egrid(std::min<uint32_t>(Q, (uint32_t)ctx->num_cus * per_cu));
+        if (per_cu == 2) {  // two 512-thread workgroups per CU: one fills its table while the other streams (measured equal to one of 1024 threads)
+            const void* fn = outer ? (const void*)k_dm_emit<512, true> : (const void*)k_dm_emit<512, false>;
+            TSQ_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (outer) hipLaunchKernelGGL((k_dm_emit<512, true>), egrid, dim3(512), lds, ctx->stream, ea);
+            else hipLaunchKernelGGL((k_dm_emit<512, false>), egrid, dim3(512), lds, ctx->stream, ea);
+        } else {
+            const void* fn = outer ? (const void*)k_dm_emit<1024, true> : (const void*)k_dm_emit<1024, false>;
+            TSQ_HIP(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (outer) hipLaunchKernelGGL((k_dm_emit<1024, true>), egrid, dim3(1024), lds, ctx->stream, ea);
+            else hipLaunchKernelGGL((k_dm_emit<1024, false>), egrid, dim3(1024), lds, ctx->stream, ea);
+        }
+        TSQ_HIP(h, hipGetLastError());
+        j->st.kernel_launches++;
+    }
+    for (int oc = 0; oc < nout; oc++)
+        if (may_null_v[oc]) TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, rb->notnull[oc].as<uint8_t>(), rb->bitmap[oc].as<uint8_t>(), out_rows));
+    if (!j->conds_h.empty()) {
+        tsq_status ps = da_post_conditions(j, *rb, may_null_v, redo, nullptr);
+        if (ps != TSQ_OK || *redo) {
+            rb->release();
+            if (*redo) {  // as if this route had not been tried
+                j->st.radix_batches--;
+                j->st.probe_route = TSQ_ROUTE_DIRECT;
+                j->st.packed_lds_bits = 0;
+            }
+            return ps;
+        }
+    }
+    TSQ_HIP(h, hipEventRecord(re[2], ctx->stream));
+    TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
+    j->have_probe_ev = true;
+    if (rb->rows == 0) {
+        rb->release();
+        return TSQ_OK;
+    }
+    return deliver_batch(j, std::move(rb), may_null_v);
 }
 
 // ---------------------------------------------------------------- materialising radix path (host side)
@@ -3470,7 +4007,7 @@ tsq_status probe_batch_routes(tsq_join* j, const tsq_colset& pcs, int64_t nrows,
     bool prefer_pairs = false;
     const bool pairs_knob_set = ctx->knob[TSQ_KNOB_DA_PAIRS_BELOW_PERMILLE] != TSQ_KNOB_DEFAULT;  // (tests force either variant with it)
     if ((!forced || pairs_knob_set) && !j->count_only && !j->da_multi && da_cols_eligible(j, nrows, selected_dev) && j->conds_h.empty()) {
-        TSQ_TRY(da_prepare(j));
+        TSQ_TRY(da_prepare(j, nullptr, TSQ_OK, true));
         if (j->da_state == 1 && !j->da_bits) {
             double rho = 1.0;
             TSQ_TRY(da_sample_hit_ratio(j, pcs, nrows, selected_dev, &rho));
@@ -3483,14 +4020,26 @@ tsq_status probe_batch_routes(tsq_join* j, const tsq_colset& pcs, int64_t nrows,
         if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows, selected_dev);
     }
     if (da_cols_eligible(j, nrows, selected_dev)) {
-        TSQ_TRY(da_prepare(j));
+        TSQ_TRY(da_prepare(j, nullptr, TSQ_OK, true));
+        // a build side without duplicate keys: its final partitions sit in LDS (tsq_damat.h) — unless this batch's keys are skewed
+        bool lds_redo = false;
+        if (dm_eligible(j)) {
+            TSQ_TRY(dm_prepare_build(j));
+            if (j->dm_state == 1) {
+                bool fallback = false;
+                TSQ_TRY(dm_emit_batch(j, pcs, nrows, &lds_redo, &fallback, selected_dev));
+                if (!fallback && !lds_redo) return TSQ_OK;
+            }
+        }
         // conditions of an OUTER join over a build side with duplicate keys: "did ANY candidate of this outer row pass" is a segmented
         // reduction over the batch (the candidates of an outer row are consecutive output rows: k_outer_segments)
-        TSQ_TRY(da_prepare_cols_direct(j));
-        if (j->da_cols_state == 1) {
-            bool redo = false;
-            TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo, selected_dev));
-            if (!redo) return TSQ_OK;
+        if (!lds_redo) {  // (a condition that raised an error: the direct route reports it in the reference's order)
+            TSQ_TRY(da_prepare_cols_direct(j));
+            if (j->da_cols_state == 1) {
+                bool redo = false;
+                TSQ_TRY(da_emit_cols(j, pcs, nrows, &redo, selected_dev));
+                if (!redo) return TSQ_OK;
+            }
         }
     }
     if (!selected_dev && radix_emit_eligible(j, pcs, nrows, selected_dev)) {
@@ -4440,11 +4989,16 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->rckey.release();
     for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_coarse_c, &j->da_pstart_c, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
     for (DevBuf* b : {&j->kr_brec, &j->kr_bstart, &j->kr_counts, &j->kr_prec, &j->kr_pstart, &j->kr_flags, &j->kr_bids, &j->kr_pids, &j->kr_pcnt, &j->kr_norec}) b->release();
+    for (DevBuf* b : {&j->dm_bent, &j->dm_bnn, &j->dm_boff, &j->dm_bcnt, &j->dm_bitmap, &j->dm_pent, &j->dm_pnn, &j->dm_poff, &j->dm_pcnt}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
         j->da_bsorted[c].release();
         j->da_bsorted_nn[c].release();
         j->rcols[c].release();
+        j->dm_bpay[c].release();
+        j->dm_ppay[c].release();
+        j->dm_l1pay[c].release();
     }
+    for (DevBuf* b : {&j->dm_l1ent, &j->dm_l1ctl, &j->dm_l1vend, &j->dm_l1nn}) b->release();
     for (int v = 0; v < TSQ_LDS_MAXPAY; v++) {
         j->rpay[v].release();
         j->rovfpay[v].release();

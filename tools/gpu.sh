@@ -24,13 +24,22 @@ if [ "$step" != tests ] && [ "$step" != bench ]; then
   shift
   [ "$1" = "--" ] && shift
 fi
+# the profiler runs from /tmp (rocprofv3 writes next to its cwd): arguments that name files of the repo become absolute paths
+abs_args() {
+  ARGS=()
+  for a in "$@"; do
+    if [ -e "$R/$a" ] && [ "${a#/}" = "$a" ]; then ARGS+=("$R/$a"); else ARGS+=("$a"); fi
+  done
+}
 prof() {
+  abs_args "$@"; set -- "${ARGS[@]}"
   ( cd /tmp && timeout ${PROF_TIMEOUT:-900} rocprofv3 --kernel-trace --stats -d "$O/.prof_$name" -o p --output-format csv -- "$@" > "$O/${name}_prof.out" 2> "$O/${name}_prof.err" )
   python3 "$R/tools/summarise_prof.py" stats "$(find "$O/.prof_$name" -name '*kernel_stats.csv' | head -1)" > "$O/${name}_rocprof.txt" 2>&1
   rm -rf "$O/.prof_$name"
   head -${HEAD:-14} "$O/${name}_rocprof.txt" | cut -c1-200
 }
 pmc() {
+  abs_args "$@"; set -- "${ARGS[@]}"
   for c in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && timeout ${PROF_TIMEOUT:-900} rocprofv3 --kernel-trace --pmc $c -d "$O/.pmc_${name}_$c" -o p --output-format csv -- "$@" > "$O/${name}_pmc_$c.out" 2> "$O/${name}_pmc_$c.err" )
   done
@@ -53,6 +62,7 @@ case $step in
   prof) prof "$@" ;;
   pmc) pmc "$@" ;;
   sq)
+    abs_args "$@"; set -- "${ARGS[@]}"
     ( cd /tmp && timeout ${PROF_TIMEOUT:-900} rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU \
         -d "$O/.sq_$name" -o p --output-format csv -- "$@" > "$O/${name}_sq.out" 2> "$O/${name}_sq.err" )
     python3 "$R/tools/summarise_prof.py" pmc-by-grid $(find "$O/.sq_$name" -name '*counter_collection.csv') > "$O/${name}_sq.txt" 2>&1
