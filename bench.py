@@ -274,7 +274,80 @@ def main():
             ok = ok and rho_check["verified"]
         finally:
             ctx.free(pk2)
+    plans = None
     if dj:
+        # ---- N > 1: BOTH distributed plans in the one line.  `value` is the plan --dist-plan chose (shared images when
+        # the build side packs: no probe row on xGMI); the other plan — north_star's hash-radix exchange with the RCCL all-to-all, or the
+        # shared images when the exchange was asked for — runs the same K steps right after, between the same barriers, and is reported
+        # beside it with its split / exchange / probe times.
+        def plan_record(d, ms_step, verified, nsteps):
+            sd = d.stats()
+            rec = {"ms_per_step": ms_step, "rows_per_s": npr * world / (ms_step * 1e-3), "verified": bool(verified),
+                   "local_probe_route": {abi.ROUTE_PACKED: "packed", abi.ROUTE_RADIX_LDS: "64-bit LDS", abi.ROUTE_RADIX_L2: "64-bit L2", abi.ROUTE_DIRECT: "direct"}.get(sd.probe_route, str(sd.probe_route))}
+            if d.shared:
+                rec.update({"wire_bytes_per_probe_row": 0.0, "allreduce_ms_once_per_build": sd.shared_allreduce_ms, "image_bytes": sd.shared_image_bytes})
+            else:
+                rec["wire_bytes_per_probe_row"] = 8.0 * (world - 1) / world
+                if sd.radix_timed_batches > 0 and d.probe_batches > 0:  # local probe kernels of one step (a launch per received piece)
+                    per_step = d.probe_batches / float(nsteps)
+                    rec["t_probe_ms"] = (sd.partition_kernel_ms_sum + sd.radix_probe_kernel_ms_sum) / sd.radix_timed_batches * per_step
+            return rec
+
+        def exchange_times(rec):
+            # t_partition: tsq_radix_split of this rank's probe keys alone; t_exchange: the split + all-to-all pass without probes, minus it
+            try:
+                spl = ctx.alloc(npr * 8)
+                cnts = (C.c_int64 * max(world, 1))()
+                one, dst = (abi.Col * 1)(dev_col(pk, npr)), (abi.Col * 1)(dev_col(spl, npr))
+                _lib.check(lib.tsq_radix_split(ctx.h, one, 1, 0, 0, npr, world, dst, cnts), ctx.h)
+                ctx.timer_start()
+                for _ in range(3):
+                    _lib.check(lib.tsq_radix_split(ctx.h, one, 1, 0, 0, npr, world, dst, cnts), ctx.h)
+                rec["t_partition_ms"] = comm.allreduce_f64([ctx.timer_stop_ms() / 3.0], parallel.Comm.MAX)[0]
+                ctx.free(spl)
+                full_sync()
+                te = time.perf_counter()
+                parallel.redistribute_pieces(comm, pcols1, 0, 0, npr, args.exchange_chunks, lambda got, n: None)
+                full_sync()
+                both = comm.allreduce_f64([time.perf_counter() - te], parallel.Comm.MAX)[0] * 1e3
+                rec["t_split_and_exchange_ms"] = both
+                rec["t_exchange_ms"] = max(0.0, both - rec["t_partition_ms"])
+            except Exception as e:  # reporting only
+                rec["times_error"] = str(e)[:120]
+
+        plans = {}
+        main_key = "shared_images" if dj.shared else "hash_radix_exchange"
+        plans[main_key] = plan_record(dj, elapsed / args.steps * 1e3, ok, args.steps)
+        if not dj.shared:
+            exchange_times(plans[main_key])
+        try:
+            other = parallel.DistHashJoinCount(comm, cfg, radix_mode=radix_mode, packing_mode=abi.RADIX_OFF if args.packing == "off" else None, shared=not dj.shared)
+            other.build([dev_col(bk, nb), dev_col(bv, nb)], 0, nb)
+            okey = "shared_images" if other.shared else "hash_radix_exchange"
+            if okey == main_key:
+                plans["other_plan"] = {"available": False, "why": "the build side does not pack: tsq_join_build_finish_shared declined on every rank"}
+            else:
+                other.probe(pcols1, 0, npr, args.exchange_chunks)  # warm
+                full_sync()
+                c0 = other.count()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    other.probe(pcols1, 0, npr, args.exchange_chunks)
+                full_sync()
+                el2 = comm.allreduce_f64([time.perf_counter() - t1], parallel.Comm.MAX)[0]
+                c1 = other.count()
+                want2 = (expect // (args.steps + args.warmup)) * args.steps
+                plans[okey] = plan_record(other, el2 / args.steps * 1e3, (c1 - c0) == want2, args.steps + 1)
+                if not other.shared:
+                    exchange_times(plans[okey])
+            other.close()
+        except Exception as e:  # reporting only: `value` stands
+            plans["other_plan"] = {"error": str(e)[:160]}
+        try:
+            r_, n_, v_ = comm.info()
+            plans["rccl"] = {"rank": r_, "nranks": n_, "version": v_}
+        except Exception as e:
+            plans["rccl"] = {"error": str(e)[:80]}
         dj.close()
     else:
         lib.tsq_join_destroy(h)
@@ -353,6 +426,8 @@ def main():
             out["shared_images"] = {"image_bytes": st.shared_image_bytes, "allreduce_ms": st.shared_allreduce_ms,
                                     "wire_bytes_per_rank_once_per_build": 2.0 * st.shared_image_bytes * (world - 1) / world,
                                     "cells": "bit" if st.packed_key_bits > 28 else "byte", "key_range_bits": st.packed_key_bits}
+    if plans:
+        out["plans"] = plans
     if exchange_ms is not None:
         out["split_and_exchange_ms"] = exchange_ms  # tsq_redistribute of one step's probe keys (split + RCCL exchange), without the probes
     if packed:
@@ -513,6 +588,10 @@ def compact_line(full, limit=LINE_LIMIT):
             line[k] = _r(full[k])
     if isinstance(full.get("shared_images"), dict):
         line["shared_images"] = {k: _r(v) for k, v in full["shared_images"].items() if k in ("image_bytes", "allreduce_ms", "cells", "key_range_bits")}
+    if isinstance(full.get("plans"), dict):
+        keep = ("ms_per_step", "rows_per_s", "verified", "t_partition_ms", "t_exchange_ms", "t_probe_ms", "wire_bytes_per_probe_row", "allreduce_ms_once_per_build",
+                "available", "error", "rank", "nranks", "version")
+        line["plans"] = {k: {kk: (_r(vv) if not isinstance(vv, str) else vv[:60]) for kk, vv in v.items() if kk in keep} for k, v in full["plans"].items() if isinstance(v, dict)}
     rf = full.get("roofline")
     if isinstance(rf, dict):
         r = {k: _r(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac", "kernel", "kernel_ms") if k in rf}
@@ -526,7 +605,7 @@ def compact_line(full, limit=LINE_LIMIT):
         line["cpu_baseline"] = {k: (_r(v) if not isinstance(v, str) else v[:120]) for k, v in cb.items() if k in ("value", "unit", "cores", "kind", "sample", "error")}
     sides = {}
     for k, v in full.items():
-        if k in ("config", "roofline", "cpu_baseline", "arena", "shared_images") or not isinstance(v, dict):
+        if k in ("config", "roofline", "cpu_baseline", "arena", "shared_images", "plans") or not isinstance(v, dict):
             continue
         subs = {kk: vv for kk, vv in v.items() if isinstance(vv, dict) and ("verified" in vv or "error" in vv)}
         if ("verified" in v or "error" in v or "ms" in v or "build_ms_warm" in v) and not (subs and "ms" not in v and "ms_per_probe_pass" not in v):

@@ -60,6 +60,12 @@ enum {
 
 /* tsq_col.flags */
 #define TSQ_COL_DEVICE 1u /* data/null_bitmap/offsets are device (HBM) pointers */
+#define TSQ_COL_RETAIN 4u /* ABI 7, an INPUT column of tsq_join_build_push: the operator may KEEP this device buffer as its build-side storage
+                           * instead of copying the rows — what the reference does with the chunks it is handed (hash_table.go:146-169 PutChunk ->
+                           * chunk.List.Add keeps the chunk, util/chunk/list.go:96-110).  The caller leaves the buffer (and its null bitmap) unchanged and
+                           * allocated until tsq_join_destroy.  Honoured for the FIRST push of a build side when every column is a fixed-width
+                           * TSQ_COL_DEVICE | TSQ_COL_RETAIN column whose buffers are whole tsq_dev_alloc blocks; otherwise the rows are copied as always
+                           * (later pushes copy the retained rows into the operator's own storage first). */
 #define TSQ_COL_BORROW 2u /* an OUTPUT column of a device-resident pull (tsq_join_pull): instead of copying into the caller's buffers the
                              operator hands out pointers into its own result batch — data / null_bitmap are SET by the call (null_bitmap =
                              NULL when the column holds no NULL) and stay valid until the next pull, peek, finish or destroy on the handle (tsq_join_peek
@@ -778,6 +784,9 @@ void       tsq_comm_destroy(tsq_comm* c);
 tsq_status tsq_comm_allreduce_i64(tsq_comm* c, int64_t* inout, int32_t n, int32_t op);
 tsq_status tsq_comm_allreduce_f64(tsq_comm* c, double* inout, int32_t n, int32_t op);
 tsq_status tsq_comm_barrier(tsq_comm* c);
+/* ABI 7: the communicator as the collective library sees it — ncclCommUserRank, ncclCommCount, ncclGetVersion (-1: the loaded librccl
+ * lacks the call).  bench.py prints them next to a multi-GPU number. */
+tsq_status tsq_comm_info(tsq_comm* c, int32_t* rank_out, int32_t* nranks_out, int32_t* rccl_version_out);
 /* key_mode of tsq_redistribute: 0 / 1 as for tsq_radix_split; TSQ_KEYMODE_BROADCAST = an ALL-GATHER of the columns — every rank
  * receives every rank's rows, in rank order (key_col is ignored): the small side of a broadcast join (a filtered dimension table,
  * the result of an earlier join) goes to every GPU once, and the big side is never moved (tinysql_amd/parallel.py: dist_q3). */

@@ -35,7 +35,7 @@ def test_operators_run_out_of_the_arena(orc):
         st = ctx.arena_stats()
         assert st["used"] == 0 and st["peak"] > (1 << 20), st  # the operators' buffers came from the slab and went back
         p = ctx.alloc(1 << 20)
-        assert ctx.arena_stats()["used"] == 1 << 20
+        assert (1 << 20) <= ctx.arena_stats()["used"] <= (1 << 20) + 4096  # (+ the 64 readable bytes behind every tsq_dev_alloc block, rounded to the slab's granule)
         with pytest.raises(_lib.TsqError):  # live buffers: the slab cannot be given back
             ctx.reserve(0)
         ctx.free(p)

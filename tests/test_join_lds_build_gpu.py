@@ -168,3 +168,58 @@ def test_lds_build_1e7_checksum_every_split(ctx):
             assert stats[0].probe_route == abi.ROUTE_PACKED and stats[0].radix_batches == 3 and stats[0].packed_lds_bits > 0
             assert got.NumRows() == c
             assert orc_b.rows_checksum(got) == (s, x), (jt, knob)
+
+
+@pytest.mark.parametrize("second_push", [False, True])
+def test_retained_build_chunk(ctx, orc, second_push):
+    # TSQ_COL_RETAIN: the first build chunk is kept where it is (hash_table.go:146-169: PutChunk keeps the chunk it is handed,
+    # util/chunk/list.go:96-110) — nullable payload, NULL keys; a second push copies the retained rows into the operator's own storage
+    # first.  Host-pulled rows equal the oracle's either way, and the caller's buffers are unchanged afterwards.
+    import ctypes as C
+    from tinysql_amd import _lib
+    rng = np.random.default_rng(41 + second_push)
+    nb, n = 40_000, 90_000
+    bside = _unique_build(rng, nb, 0, 60_000, 3)
+    pside = _probe(rng, n, -500, 60_500, 2)
+    cfg = H.join_cfg(pside.types(), bside.types(), [0], [0], abi.JOIN_LEFT_OUTER, 1)
+    want = orc.hash_join(cfg, bside, pside)
+    cut = 25_000 if second_push else nb
+    first, rest = bside.slice(0, cut), bside.slice(cut, nb)
+    dcols = [G.to_device(ctx, c) for c in first.columns]
+    before = [d.to_host() for d in dcols]
+    lib = ctx.lib
+    h = C.c_void_p()
+    _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        _lib.check(lib.tsq_join_set_radix(h, FORCE), h)
+        _lib.check(lib.tsq_join_set_key_packing(h, FORCE), h)
+        arr = G.dev_cols(dcols)
+        for c in arr:
+            c.flags = abi.COL_DEVICE | abi.COL_RETAIN
+        _lib.check(lib.tsq_join_build_push(h, arr, len(dcols), cut), h)
+        if second_push:
+            keep = []
+            _lib.check(lib.tsq_join_build_push(h, G.make_cols(rest.columns, keep), len(rest.columns), nb - cut), h)
+        _lib.check(lib.tsq_join_build_finish(h), h)
+        keep = []
+        _lib.check(lib.tsq_join_probe_push(h, G.make_cols(pside.columns, keep), len(pside.columns), n, None), h)
+        _lib.check(lib.tsq_join_probe_finish(h), h)
+        out_types = pside.types() + bside.types()
+        got = []
+        while True:
+            keep = []
+            out, bufs = G.out_buffers(out_types, 8192, keep, None)
+            nr, eos = C.c_int64(0), C.c_int32(0)
+            _lib.check(lib.tsq_join_pull(h, out, len(out_types), 8192, C.byref(nr), C.byref(eos)), h)
+            if nr.value == 0:
+                break
+            got.append(G.chunk_from_buffers(out_types, bufs, nr.value))
+        from tinysql_amd.chunk import concat
+        got = concat(got, out_types)
+        assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+    finally:
+        lib.tsq_join_destroy(h)
+    for d, b in zip(dcols, before):
+        a = d.to_host()
+        assert np.array_equal(a.data, b.data) and ((a.notnull is None) == (b.notnull is None)) and (a.notnull is None or np.array_equal(a.notnull, b.notnull))
+        d.free()

@@ -23,6 +23,7 @@ STATUS_NAMES = {
 I64, U64, F32, F64, BYTES = 0, 1, 2, 3, 4
 COL_DEVICE = 1
 COL_BORROW = 2
+COL_RETAIN = 4
 
 # generator kinds
 GEN_SEQ, GEN_AFFINE, GEN_RAND_MOD, GEN_RAND_F64, GEN_HASH_OF_COL, GEN_ZIPF_OCT = 0, 1, 2, 3, 4, 5
@@ -258,6 +259,7 @@ SIGNATURES = {
     "tsq_comm_destroy": (None, [P]),
     "tsq_comm_allreduce_i64": (C.c_int32, [P, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "tsq_comm_allreduce_f64": (C.c_int32, [P, C.POINTER(C.c_double), C.c_int32, C.c_int32]),
+    "tsq_comm_info": (C.c_int32, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tsq_comm_barrier": (C.c_int32, [P]),
     "tsq_redistribute": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(Col), C.POINTER(C.c_int64)]),
     "tsq_redistribute_wait": (C.c_int32, [P, C.c_int32]),

@@ -40,6 +40,9 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // (the three below are optional: tsq_comm_info reports -1 without them)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     std::string err;
 };
 
@@ -74,6 +77,11 @@ RcclApi* rccl() {
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (ok) {
+            api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+            api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
+            api.GetVersion = (decltype(api.GetVersion))dlsym(api.lib, "ncclGetVersion");
+        }
         if (!ok) {
             dlclose(api.lib);
             api.lib = nullptr;
@@ -269,6 +277,31 @@ TSQ_API tsq_status tsq_comm_barrier(tsq_comm* c) {
     if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
     int64_t one = 1;
     return allreduce8(c, &one, 1, ncclInt64, 0);
+}
+
+// what the communicator itself says it is: ranks and this rank as RCCL counts them (ncclCommCount / ncclCommUserRank), the library's
+// version — the bench line carries them so that a multi-GPU number can be checked against the collective library, not the launcher
+TSQ_API tsq_status tsq_comm_info(tsq_comm* c, int32_t* rank_out, int32_t* nranks_out, int32_t* rccl_version_out) {
+    tsq_ctx_lock _api_lock(tsq_ctx_of(c, TSQ_MAGIC_COMM));
+    if (!c || c->hdr.magic != TSQ_MAGIC_COMM) return TSQ_ERR_INVALID;
+    RcclApi* r = rccl();
+    int v = -1;
+    if (rank_out) {
+        v = -1;
+        if (r->CommUserRank && c->nccl) TSQ_NCCL(&c->hdr, r->CommUserRank(c->nccl, &v));
+        *rank_out = v;
+    }
+    if (nranks_out) {
+        v = -1;
+        if (r->CommCount && c->nccl) TSQ_NCCL(&c->hdr, r->CommCount(c->nccl, &v));
+        *nranks_out = v;
+    }
+    if (rccl_version_out) {
+        v = -1;
+        if (r->GetVersion) TSQ_NCCL(&c->hdr, r->GetVersion(&v));
+        *rccl_version_out = v;
+    }
+    return TSQ_OK;
 }
 
 namespace {

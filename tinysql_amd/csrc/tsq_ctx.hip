@@ -168,7 +168,7 @@ TSQ_API tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out) {
     TSQ_HIP(&ctx->hdr, hipSetDevice(ctx->device));
     *out = nullptr;
     if (bytes == 0) bytes = 8;
-    size_t cap = (size_t)bytes;
+    size_t cap = (size_t)bytes + 64;  // (64 readable bytes behind the last one: what the operators' own column buffers have — a block a join keeps as it is, TSQ_COL_RETAIN, is read with 16-byte loads)
     void* p = tsq_pool_get(ctx, cap, &cap);
     if (!p) TSQ_HIP(&ctx->hdr, hipMalloc(&p, cap));
     {
@@ -177,6 +177,12 @@ TSQ_API tsq_status tsq_dev_alloc(tsq_ctx* ctx, int64_t bytes, void** out) {
     }
     *out = p;
     return TSQ_OK;
+}
+// bytes of the tsq_dev_alloc block that starts at p (0: not such a block)
+size_t tsq_user_alloc_bytes(tsq_ctx* ctx, const void* p) {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    auto it = ctx->user_allocs.find(const_cast<void*>(p));
+    return it == ctx->user_allocs.end() ? 0 : it->second;
 }
 TSQ_API tsq_status tsq_dev_free(tsq_ctx* ctx, void* p) {
     tsq_ctx_lock _api_lock(ctx);

@@ -150,10 +150,12 @@ inline tsq_status tsq_fail(tsq_handle_hdr* h, tsq_status s, const std::string& m
     } while (0)
 
 // growable device buffer (never shrinks); contents are NOT preserved on growth unless keep=true
+size_t tsq_user_alloc_bytes(tsq_ctx* ctx, const void* p);  // tsq_ctx.hip
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     tsq_ctx* owner = nullptr;
+    bool foreign = false;  // p is the CALLER's buffer (TSQ_COL_RETAIN): never freed here; a reserve() beyond cap copies it into an own block
     tsq_status reserve(tsq_ctx* ctx, tsq_handle_hdr* h, size_t bytes, bool keep = false, size_t used = 0) {
         if (bytes <= cap) return TSQ_OK;
         size_t ncap = bytes;
@@ -177,12 +179,19 @@ struct DevBuf {
         return TSQ_OK;
     }
     void release() {
-        if (p) {
+        if (p && !foreign) {
             if (owner) tsq_pool_put(owner, p, cap);
             else (void)hipFree(p);
         }
         p = nullptr;
         cap = 0;
+        foreign = false;
+    }
+    void adopt(void* ptr, size_t bytes) {  // keep the caller's buffer as this column's storage
+        release();
+        p = ptr;
+        cap = bytes;
+        foreign = true;
     }
     template <class T>
     T* as() const { return (T*)p; }

@@ -3200,12 +3200,14 @@ tsq_status dm_emit_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool
         if (s == TSQ_OK && may_null) s = rb->notnull[oc].reserve(ctx, h, (size_t)out_rows + 64);
         if (s == TSQ_OK && may_null) s = rb->bitmap[oc].reserve(ctx, h, tsq_bitmap_bytes(out_rows) + 16);
         if (s != TSQ_OK) { rb->release(); return s; }
-        if (may_null) TSQ_HIP(h, hipMemsetAsync(rb->notnull[oc].p, 1, (size_t)out_rows, ctx->stream));  // the emit kernel stores the NULL cells' flags only
+        // (no preset of the flags: k_dm_emit writes every partition row's flag, k_da_gather_exc every exception row's)
         uint64_t* od = rb->data[oc].as<uint64_t>();
         uint8_t* of = may_null ? rb->notnull[oc].as<uint8_t>() : nullptr;
         if (from_probe) {
-            if (sc == kc) ea.out_pkey = od;  // (a probe key cell of a row that reached a partition is never NULL)
-            else {
+            if (sc == kc) {
+                ea.out_pkey = od;
+                ea.out_pkey_nn = of;  // (a probe key cell of a row that reached a partition is never NULL: the flags are all ones)
+            } else {
                 const int v = (kc < 0 || sc < kc) ? sc : sc - 1;
                 ea.out_probe[v] = od;
                 ea.out_probe_nn[v] = of;
@@ -4016,6 +4018,11 @@ tsq_status probe_batch_routes(tsq_join* j, const tsq_colset& pcs, int64_t nrows,
         }
     }
     if (prefer_pairs) {
+        if (j->dm_l1_ready) {  // (the level-1 store da_prepare kept for the LDS variant: a selective join does not take it)
+            j->dm_l1_ready = false;
+            for (DevBuf* b : {&j->dm_l1ent, &j->dm_l1ctl, &j->dm_l1vend, &j->dm_l1nn}) b->release();
+            for (auto& b : j->dm_l1pay) b.release();
+        }
         TSQ_TRY(da_prepare_rows(j));
         if (j->da_rows_state == 1) return da_emit(j, pcs, a, nrows, selected_dev);
     }
@@ -4416,6 +4423,25 @@ TSQ_API tsq_status tsq_join_build_push(tsq_join* j, const tsq_col* cols, int32_t
         return tsq_fail(&j->hdr, TSQ_ERR_UNSUPPORTED, "build side exceeds 2^32 rows per GPU: partition across GPUs first");
     if (dev) {
         TSQ_TRY(build_flush(j));
+        // the first chunk of a build side handed over with TSQ_COL_RETAIN: kept where it is (hash_table.go:146-169: PutChunk keeps the chunk)
+        bool retain = j->bcols[0].rows == 0;
+        for (int c = 0; c < n_cols && retain; c++) {
+            const size_t need = (size_t)nrows * (size_t)tsq_elem_size(cols[c].type);
+            retain = (cols[c].flags & TSQ_COL_RETAIN) && cols[c].type != TSQ_BYTES && j->bcols[c].rows == 0 && tsq_user_alloc_bytes(j->ctx, cols[c].data) >= need + 64 &&
+                     (!cols[c].null_bitmap || tsq_user_alloc_bytes(j->ctx, cols[c].null_bitmap) >= (size_t)tsq_bitmap_bytes(nrows) + 8);
+        }
+        if (retain) {
+            for (int c = 0; c < n_cols; c++) {
+                ColStore& cs = j->bcols[c];
+                cs.data.adopt(cols[c].data, (size_t)nrows * (size_t)cs.elem() + 64);
+                if (cols[c].null_bitmap) {
+                    cs.nulls.adopt(cols[c].null_bitmap, (size_t)tsq_bitmap_bytes(nrows) + 8);
+                    cs.has_nulls = true;
+                }
+                cs.rows = nrows;
+            }
+            return TSQ_OK;
+        }
         DevBuf tmp, tmp2;
         for (int c = 0; c < n_cols; c++) {
             tsq_status s = cols[c].type == TSQ_BYTES

@@ -126,6 +126,12 @@ class Comm:
     def barrier(self):
         _lib.check(self.lib.tsq_comm_barrier(self.h), self.h)
 
+    def info(self):
+        """(rank, ranks, library version) as RCCL itself reports them (ncclCommUserRank / ncclCommCount / ncclGetVersion)"""
+        r, n, v = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        _lib.check(self.lib.tsq_comm_info(self.h, C.byref(r), C.byref(n), C.byref(v)), self.h)
+        return r.value, n.value, v.value
+
     def redistribute(self, cols, key_col, key_mode, nrows, slot=0):
         """cols: list of abi.Col (device resident).  Returns (received abi.Col array, n_received); call wait(slot) before the
         consumer of the received columns is queued."""
