@@ -329,6 +329,8 @@ tsq_status tsq_filter_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, 
 #define TSQ_JIT_FORCE   1
 tsq_status tsq_expr_set_jit(tsq_expr* e, int32_t mode);
 int64_t    tsq_expr_jit_launches(tsq_expr* e);   /* number of launches served by specialised kernels so far */
+double     tsq_expr_jit_compile_ms(tsq_expr* e); /* ABI 7: what hiprtc + the module load of this handle's programs took (0: not compiled yet, or found
+                                                  * in the context's cache of program sets; a tree is compiled once per context) */
 void       tsq_expr_destroy(tsq_expr* e);
 
 /* ---------------------------------------------------------------- hash join

@@ -200,6 +200,7 @@ SIGNATURES = {
     "tsq_filter_eval": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64, P, P, P, C.POINTER(C.c_int64)]),
     "tsq_expr_set_jit": (C.c_int32, [P, C.c_int32]),
     "tsq_expr_jit_launches": (C.c_int64, [P]),
+    "tsq_expr_jit_compile_ms": (C.c_double, [P]),
     "tsq_expr_destroy": (None, [P]),
     "tsq_join_create": (C.c_int32, [P, C.POINTER(JoinCfg), PP]),
     "tsq_join_build_push": (C.c_int32, [P, C.POINTER(Col), C.c_int32, C.c_int64]),

@@ -53,6 +53,7 @@ struct tsq_ctx {
         hipModule_t mod = nullptr;
         hipFunction_t f_expr = nullptr, f_filter = nullptr;
         std::string log;
+        double compile_ms = 0;  // hiprtc + module load of this program set (once per distinct tree and context)
     };
     std::unordered_map<std::string, JitEntry> jit_cache;
     std::mutex jit_mu;

@@ -255,6 +255,10 @@ class CompiledExpr:
             _lib.check(self.lib.tsq_expr_set_jit(h, jit), h)
         self.warnings = 0  # StmtCtx.AppendWarning(ErrDivisionByZero) count (errors.go:65-77)
 
+    def jit_compile_ms(self):
+        """what hiprtc + the module load of this handle's programs took (0.0: served from the context's cache, or not compiled yet)"""
+        return float(self.lib.tsq_expr_jit_compile_ms(self.h))
+
     def jit_launches(self):
         """launches served by run-time specialised kernels; raises with the hiprtc log when the JIT is unavailable."""
         n = self.lib.tsq_expr_jit_launches(self.h)

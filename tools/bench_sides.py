@@ -933,7 +933,8 @@ def extra_expr_kernels(ctx, abi, _lib, n=100_000_000):
             ms = best_of(fn)
             ho = np.empty(m, np.int64)
             ctx.d2h(ho, out)
-            res["arith_int64"] = {"ms": ms, "rows_per_s": n / ms * 1e3, "frac": 24.0 * n / ms / 1e6 / 8000.0, "verified": bool((ho == (ha + hb) * 3 - ha).all()), "jit_launches": ce.jit_launches()}
+            res["arith_int64"] = {"ms": ms, "rows_per_s": n / ms * 1e3, "frac": 24.0 * n / ms / 1e6 / 8000.0, "verified": bool((ho == (ha + hb) * 3 - ha).all()), "jit_launches": ce.jit_launches(),
+                                  "hiprtc_compile_ms": ce.jit_compile_ms()}
         finally:
             ce.close()
         f = [E.ScalarFunction("lt", E.Column(0, abi.I64), E.Column(1, abi.I64)), E.ScalarFunction("gt", E.Column(2, abi.F64), E.Constant(0.5))]
@@ -944,7 +945,8 @@ def extra_expr_kernels(ctx, abi, _lib, n=100_000_000):
             ms = best_of(fn)
             hs = np.empty(m, np.uint8)
             ctx.d2h(hs, sel)
-            res["filter_lt_and_gt"] = {"ms": ms, "rows_per_s": n / ms * 1e3, "frac": 25.0 * n / ms / 1e6 / 8000.0, "verified": bool((hs.astype(bool) == ((ha < hb) & (hc > 0.5))).all())}
+            res["filter_lt_and_gt"] = {"ms": ms, "rows_per_s": n / ms * 1e3, "frac": 25.0 * n / ms / 1e6 / 8000.0, "verified": bool((hs.astype(bool) == ((ha < hb) & (hc > 0.5))).all()),
+                                       "hiprtc_compile_ms": cf.jit_compile_ms()}
         finally:
             cf.close()
     finally:
