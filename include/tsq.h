@@ -148,6 +148,7 @@ enum {
     TSQ_KNOB_XCD_ATOMICS = 30,       /* retired in round 6 (was: workgroup-scope cursor atomics, an A/B that measured equal); setting it has no effect */
     TSQ_KNOB_DENSE_DIRECT = 31,      /* 0: the packed aggregate's dense state always leaves through partial groups and the hash table, also when the table is empty (k_dense_finalize off) */
     TSQ_KNOB_DA_LDS_BUILD = 32,      /* 0: the materialising packed join never keeps a partition's build rows in LDS (csrc/tsq_damat.h): unique build sides take the sorted-build-columns variant of round 4 like the others; 2 .. 5 (tests): the second partition level splits 1 / 2 / 4 / 8 ways whatever the build side's size */
+    TSQ_KNOB_AGG_PG = 33,            /* 0: an aggregate with about as many groups as rows never keeps its groups in partitioned LDS-sized sub-tables (csrc/tsq_aggfast.h K7p): the row upsert serves it; v >= 2 (tests): the mode is taken whatever the estimate, with 2^(v - 2) sub-tables */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -832,7 +833,9 @@ typedef struct tsq_stats {
     int32_t build_partitioned;     /* join: 1: the table was assembled slice by slice in LDS (tsq_buildpart.h), 0: row-at-a-time CAS build;
                                       aggregate: 2: several integer key columns composed into one 64-bit key for a child aggregate, 3: the group
                                       keys (strings / wide key sets) went through the dictionary of key records (tsq_keydict.h) to a child
-                                      aggregate by group id; build_handed_back_rows then counts the exception rows this operator kept */
+                                      aggregate by group id; build_handed_back_rows then counts the exception rows this operator kept; 4 (ABI 7): about
+                                      as many groups as rows — the group table was a set of partitioned, LDS-sized sub-tables (csrc/tsq_aggfast.h K7p);
+                                      when the composite-key child of (2) took that mode, dense_flushes reads -4 */
     int64_t build_handed_back_rows; /* partitioned build: rows inserted row by row afterwards (skewed pass-1 / pass-2 regions);
                                        aggregate: rows of a multi-key GROUP BY whose 64-bit tag belonged to another key (resolved) */
     int32_t table_slice_bits;      /* join: log2(slices) of the join table (0: one slice); aggregate on the packed route: bits of a travelling argument cell (16 / 32: narrow cells, 64) */

@@ -779,6 +779,9 @@ struct DenseFinalArgs {
     int32_t key_type;
     const unsigned long long* dense_w[TSQ_AF_MAXW];
     const uint32_t* dense_touch;
+    // pg form (partitioned groups, tsq_aggfast.h K7p): the cells are the slots of the sub-tables, a slot is a group when its table word is
+    // not TSQ_AF_EMPTY, and the word gives the key back (tsq_unmix64: mix64 is a bijection)
+    const unsigned long long* pg_key;
     uint64_t ncells;
     void* out_data[2 * TSQ_MAX_AGGS];
     uint8_t* out_notnull[2 * TSQ_MAX_AGGS];
@@ -804,7 +807,12 @@ __global__ void __launch_bounds__(256) k_dense_finalize(DenseFinalArgs a) {
         const uint64_t lo = ch * TSQ_FINAL_CHUNK;
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
-        if (threadIdx.x < TSQ_FINAL_CHUNK / 32 && lo + 32ull * threadIdx.x < a.ncells) {
+        if (a.pg_key) {
+            uint32_t c = 0;
+            for (uint32_t i = threadIdx.x; i < TSQ_FINAL_CHUNK; i += 256) c += (lo + i < a.ncells && a.pg_key[lo + i] != TSQ_AF_EMPTY) ? 1u : 0u;
+            c = (uint32_t)wave_sum_u64(c);
+            if (lane == 0 && c) atomicAdd(&s_cnt, c);
+        } else if (threadIdx.x < TSQ_FINAL_CHUNK / 32 && lo + 32ull * threadIdx.x < a.ncells) {
             const uint32_t c = (uint32_t)__popc(a.dense_touch[(lo >> 5) + threadIdx.x]);
             if (c) atomicAdd(&s_cnt, c);
         }
@@ -814,7 +822,7 @@ __global__ void __launch_bounds__(256) k_dense_finalize(DenseFinalArgs a) {
         if (s_cnt == 0) continue;  // (block-uniform)
         for (uint32_t i0 = 0; i0 < TSQ_FINAL_CHUNK; i0 += 256) {
             const uint64_t u = lo + i0 + threadIdx.x;
-            const bool occ = u < a.ncells && ((a.dense_touch[u >> 5] >> (u & 31u)) & 1u);
+            const bool occ = u < a.ncells && (a.pg_key ? a.pg_key[u] != TSQ_AF_EMPTY : (bool)((a.dense_touch[u >> 5] >> (u & 31u)) & 1u));
             const unsigned long long m = __ballot(occ);
             if (!m) continue;
             unsigned long long base = 0;
@@ -880,7 +888,7 @@ __global__ void __launch_bounds__(256) k_dense_finalize(DenseFinalArgs a) {
                         break;
                     }
                     case TSQ_AGG_FIRSTROW: {  // of the group key: the cell's word back to the key (tsq_da_unmix is the inverse of the packing mix)
-                        const uint64_t key = a.dm.kmin + (uint64_t)tsq_da_unmix((uint32_t)u, a.dm.s, a.dm.mask);
+                        const uint64_t key = a.pg_key ? tsq_unmix64(a.pg_key[u]) : a.dm.kmin + (uint64_t)tsq_da_unmix((uint32_t)u, a.dm.s, a.dm.mask);
                         ((uint64_t*)a.out_data[oc])[pos] = group_key_word_decode(key, a.key_type);
                         a.out_notnull[oc][pos] = 1;
                         oc++;
@@ -1133,6 +1141,11 @@ struct tsq_agg {
     DevBuf fkey, fw[TSQ_AF_MAXW], fctl, fexc;      // partial groups | counters (partials, exceptions) | exception row ids
     DevBuf rkeys, rpay[TSQ_RADIX_MAXV], rctl, rvend, rokeys, ropay[TSQ_RADIX_MAXV];  // partitioned rows (H mode)
     int64_t fast_batches = 0, fast_fallbacks = 0;
+    // partitioned groups (tsq_aggfast.h K7p): about as many groups as rows — the group table is a set of LDS-sized sub-tables in HBM
+    int pg_state = 0;            // 0: not tried, 1: in use, -1: not usable
+    uint32_t pg_pbits = 0, pg_sbits = 0;
+    int64_t pg_rows = 0, pg_batches = 0;
+    DevBuf pg_key, pg_w[TSQ_AF_MAXW], pg_used;
     // packed-key pre-aggregation (tsq_daagg.h): the key range the first large batch showed
     int da_state = 0;  // 0: not tried, 1: in use, -1: not usable (range too wide, float key, too many rows outside the range)
     DaDomain da_dm{};
@@ -1635,6 +1648,100 @@ tsq_status da_dense_flush(tsq_agg* a) {
 }
 
 // one batch through LDS pre-aggregation.  *done = false: nothing was merged, the caller runs the row path.
+// ---- partitioned groups (tsq_aggfast.h K7p)
+// what H mode takes: partitions of 2^10 at most, each half-filling one LDS table
+static bool pg_h_fits(const AfPlan& pl, int64_t groups_est) { return ((double)groups_est * 1.3 / (double)af_slots(pl)) <= 1024.0; }
+// the sub-tables for `est` groups at half load; refused beyond 2^11 partitions x 16 sub-tables (6.7e7 groups of <= 3 words)
+tsq_status pg_setup(tsq_agg* a, int64_t est) {
+    if (a->pg_state) return TSQ_OK;
+    a->pg_state = -1;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const AfPlan& pl = a->fplan;
+    const bool trace = tsq_knob(ctx, TSQ_KNOB_DA_TRACE, 0) != 0;
+    if (a->mk_n > 1 || a->plan.n_keys != 1 || a->groups != 0 || a->in_rows != 0 || a->stream) {
+        if (trace) fprintf(stderr, "[pg_setup] refused: mk_n %d n_keys %d groups %lld in_rows %lld stream %d\n", a->mk_n, a->plan.n_keys, (long long)a->groups, (long long)a->in_rows, (int)a->stream);
+        return TSQ_OK;
+    }
+    for (int k = 0; k < pl.W; k++)
+        if (pl.init[k] != 0 && pl.init[k] != ~0ull) {  // (the state is initialised with memsets)
+            if (trace) fprintf(stderr, "[pg_setup] refused: init[%d] = %llx\n", k, pl.init[k]);
+            return TSQ_OK;
+        }
+    const uint64_t S = af_slots(pl);
+    const uint64_t want = (uint64_t)est * 2 + S;
+    uint32_t pbits = 8, sbits = 0;
+    while (pbits < 11 && (S << pbits) < want) pbits++;
+    while (sbits < 4 && (S << (pbits + sbits)) < want) sbits++;
+    const int64_t forced = tsq_knob(ctx, TSQ_KNOB_AGG_PG, 1);  // (tests: v >= 2 -> 2^(v - 2) sub-tables whatever the estimate: small states that fill up)
+    if (forced >= 2) {
+        const uint32_t tot = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(forced - 2, 15));  // (two sub-tables at least: the partition pass needs a bit)
+        pbits = std::min<uint32_t>(tot, 11u);
+        sbits = tot - pbits;
+    } else if ((S << (pbits + sbits)) < want) return TSQ_OK;
+    const size_t slots = (size_t)S << (pbits + sbits), subs = (size_t)1 << (pbits + sbits);
+    tsq_status s = a->pg_key.reserve(ctx, h, slots * 8 + 64);
+    for (int k = 0; k < pl.W && s == TSQ_OK; k++) s = a->pg_w[k].reserve(ctx, h, slots * 8 + 64);
+    if (s == TSQ_OK) s = a->pg_used.reserve(ctx, h, subs * 4 + 64);
+    if (s != TSQ_OK) {  // no memory for the state: the other modes keep the aggregate
+        h->err.clear();
+        a->pg_key.release();
+        for (auto& b : a->pg_w) b.release();
+        a->pg_used.release();
+        return TSQ_OK;
+    }
+    TSQ_HIP(h, hipMemsetAsync(a->pg_key.p, 0x80, slots * 8, ctx->stream));  // TSQ_AF_EMPTY
+    for (int k = 0; k < pl.W; k++) TSQ_HIP(h, hipMemsetAsync(a->pg_w[k].p, pl.init[k] ? 0xff : 0x00, slots * 8, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(a->pg_used.p, 0, subs * 4, ctx->stream));
+    a->pg_pbits = pbits;
+    a->pg_sbits = sbits;
+    a->pg_rows = 0;
+    a->pg_state = 1;
+    return TSQ_OK;
+}
+// the merging way out: every group of the sub-tables as a partial group into the table in HBM (slot ranges of 2^24: the partial list
+// of a range cannot overflow), then the state is empty again
+tsq_status pg_flush(tsq_agg* a) {
+    if (a->pg_state != 1 || a->pg_rows == 0) return TSQ_OK;
+    tsq_ctx* ctx = a->ctx;
+    tsq_handle_hdr* h = &a->hdr;
+    const AfPlan& pl = a->fplan;
+    const uint64_t S = af_slots(pl), slots = S << (a->pg_pbits + a->pg_sbits), step = (uint64_t)1 << 24;
+    const size_t pcap = (size_t)std::min<uint64_t>(slots, step);
+    TSQ_TRY(a->fkey.reserve(ctx, h, pcap * 8));
+    for (int k = 0; k < pl.W; k++) TSQ_TRY(a->fw[k].reserve(ctx, h, pcap * 8));
+    TSQ_TRY(a->fctl.reserve(ctx, h, 64));
+    for (uint64_t lo = 0; lo < slots; lo += step) {
+        AfPgEmitArgs ea;
+        memset(&ea, 0, sizeof ea);
+        ea.plan = pl;
+        ea.out.key = a->fkey.as<unsigned long long>();
+        for (int k = 0; k < pl.W; k++) {
+            ea.out.w[k] = a->fw[k].as<unsigned long long>();
+            ea.pg_w[k] = a->pg_w[k].as<unsigned long long>();
+        }
+        ea.out.count = a->fctl.as<uint32_t>();
+        ea.out.cap = (uint32_t)pcap;
+        ea.pg_key = a->pg_key.as<unsigned long long>();
+        ea.lo = lo;
+        ea.n = std::min<uint64_t>(step, slots - lo);
+        TSQ_HIP(h, hipMemsetAsync(a->fctl.p, 0, 64, ctx->stream));
+        hipLaunchKernelGGL(k_pg_emit, dim3(tsq_grid_for(ctx, (int64_t)ea.n, 256)), dim3(256), 0, ctx->stream, ea);
+        TSQ_HIP(h, hipGetLastError());
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 8, a->fctl.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        a->st.kernel_launches++;
+        const uint32_t n_part = ((const uint32_t*)(ctx->pinned + 8))[0];
+        if (n_part) TSQ_TRY(merge_partials(a, ea.out, n_part));
+    }
+    const size_t subs = (size_t)1 << (a->pg_pbits + a->pg_sbits);
+    TSQ_HIP(h, hipMemsetAsync(a->pg_key.p, 0x80, slots * 8, ctx->stream));
+    for (int k = 0; k < pl.W; k++) TSQ_HIP(h, hipMemsetAsync(a->pg_w[k].p, pl.init[k] ? 0xff : 0x00, slots * 8, ctx->stream));
+    TSQ_HIP(h, hipMemsetAsync(a->pg_used.p, 0, subs * 4, ctx->stream));
+    a->pg_rows = 0;
+    return TSQ_OK;
+}
+
 tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64_t groups_est, bool* done) {
     *done = false;
     tsq_ctx* ctx = a->ctx;
@@ -1642,14 +1749,27 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     const AfPlan& pl = a->fplan;
     const uint32_t S = af_slots(pl);
     const bool mk = a->mk_n > 1;  // several key columns: the packed route or nothing
+    // partitioned groups: once the sub-tables hold groups every batch goes to them (a group has ONE home)
+    bool pg = a->pg_state == 1;
+    const int64_t pg_knob = tsq_knob(ctx, TSQ_KNOB_AGG_PG, 1);  // 0: never; >= 2 (tests): always, with 2^(v - 2) sub-tables
+    if (!pg && pg_knob >= 2 && !mk && a->pg_state == 0) {
+        TSQ_TRY(pg_setup(a, groups_est));
+        pg = a->pg_state == 1;
+    }
     // (rows in the dense state of the packed route are groups the table has not seen yet: `groups_est` says nothing then)
-    const bool low = !mk && groups_est <= (int64_t)(S / 2) && !(a->da_state == 1 && a->dense_state == 1 && a->dense_rows > 0);
+    const bool low = !pg && !mk && groups_est <= (int64_t)(S / 2) && !(a->da_state == 1 && a->dense_state == 1 && a->dense_rows > 0);
     uint32_t bits = 0;
-    if (!low) TSQ_TRY(da_agg_setup(a, in, nrows));
-    const bool packed = !low && a->da_state == 1;
+    if (!low && !pg) TSQ_TRY(da_agg_setup(a, in, nrows));
+    const bool packed = !pg && !low && a->da_state == 1;
+    if (!low && !packed && !pg && !mk && pg_knob != 0 && !pg_h_fits(pl, groups_est)) {  // more groups than LDS tables hold per batch: the sub-tables
+        TSQ_TRY(pg_setup(a, groups_est));
+        pg = a->pg_state == 1;
+    }
+    if (pg && a->pg_rows + nrows > ((int64_t)1 << 31)) TSQ_TRY(pg_flush(a));  // (the 32-bit halves of its int64 sums must not wrap)
     if (mk && !packed) return TSQ_OK;
     const bool packed_low = packed && mk && a->da_low;
-    if (!low && !packed) {
+    if (pg) bits = a->pg_pbits;
+    else if (!low && !packed) {
         // H: partitions small enough that their groups half-fill one LDS table, at least 256 of them (parallelism)
         // (2^11 partitions — tables 1/8 full, shorter walks — were measured: k_agg_lds 0.66 -> 0.64 ms per 1e8 rows, but the partition
         // kernel with a payload column writes 32-byte runs then and goes from 0.76 to 0.83 ms: kept at 2^10)
@@ -1671,7 +1791,8 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         if (dense && a->dense_rows + nrows > (dk > 1 ? dk : ((int64_t)1 << 31))) TSQ_TRY(da_dense_flush(a));  // (its lo32 sums must not wrap)
     }
     const size_t nblocks = (low || packed_low) ? (size_t)ctx->num_cus : (((size_t)1 << (packed ? a->da_pbits : bits)) * da_nsplit);
-    const size_t pcap = dense ? 4096 : std::min<size_t>(nblocks * S + (size_t)nrows / 8 + 4096, 0x7fffffffULL);
+    // (partitioned groups: every row may be spilled, and the batch cannot be redone — the sub-tables have taken its rows)
+    const size_t pcap = pg ? (size_t)nrows + 4096 : (dense ? 4096 : std::min<size_t>(nblocks * S + (size_t)nrows / 8 + 4096, 0x7fffffffULL));
     TSQ_TRY(a->fkey.reserve(ctx, h, pcap * 8));
     for (int k = 0; k < pl.W; k++) TSQ_TRY(a->fw[k].reserve(ctx, h, pcap * 8));
     TSQ_TRY(a->fctl.reserve(ctx, h, 64));
@@ -1908,8 +2029,39 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
         TSQ_HIP(h, hipGetLastError());
         a->st.kernel_launches++;
         la.st = st;
-        TSQ_TRY(launch_lds<1>(a, la, (int)P));
-        TSQ_TRY(launch_lds<2>(a, la, 8));  // the overflow list of skewed partitions (usually empty)
+        if (pg) {
+            AfPgArgs ga;
+            memset(&ga, 0, sizeof ga);
+            ga.plan = pl;
+            ga.out = la.out;
+            ga.st = st;
+            ga.pg_key = a->pg_key.as<unsigned long long>();
+            for (int k = 0; k < pl.W; k++) ga.pg_w[k] = a->pg_w[k].as<unsigned long long>();
+            ga.pg_used = a->pg_used.as<uint32_t>();
+            ga.sbits = a->pg_sbits;
+            const dim3 ggrid(std::min<uint32_t>(P, (uint32_t)ctx->num_cus));
+            switch (pl.W) {
+                case 1: hipLaunchKernelGGL((k_agg_pg<1>), ggrid, dim3(TSQ_AF_NT), 0, ctx->stream, ga); break;
+                case 2: hipLaunchKernelGGL((k_agg_pg<2>), ggrid, dim3(TSQ_AF_NT), 0, ctx->stream, ga); break;
+                case 3: hipLaunchKernelGGL((k_agg_pg<3>), ggrid, dim3(TSQ_AF_NT), 0, ctx->stream, ga); break;
+                case 4: hipLaunchKernelGGL((k_agg_pg<4>), ggrid, dim3(TSQ_AF_NT), 0, ctx->stream, ga); break;
+                default: hipLaunchKernelGGL((k_agg_pg<5>), ggrid, dim3(TSQ_AF_NT), 0, ctx->stream, ga); break;
+            }
+            TSQ_HIP(h, hipGetLastError());
+            AfPgOvfArgs oa;
+            memset(&oa, 0, sizeof oa);
+            oa.plan = pl;
+            oa.out = la.out;
+            oa.st = st;
+            hipLaunchKernelGGL(k_pg_ovf, dim3(ctx->num_cus), dim3(256), 0, ctx->stream, oa);  // the overflow list of skewed partitions (usually empty)
+            TSQ_HIP(h, hipGetLastError());
+            a->st.kernel_launches += 2;
+            a->pg_rows += nrows;
+            a->pg_batches++;
+        } else {
+            TSQ_TRY(launch_lds<1>(a, la, (int)P));
+            TSQ_TRY(launch_lds<2>(a, la, 8));  // the overflow list of skewed partitions (usually empty)
+        }
     }
     TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 8, a->fctl.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
@@ -1917,6 +2069,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     const uint32_t n_misfit = ((const uint32_t*)(ctx->pinned + 8))[2];  // exception rows whose argument did not fit the narrow cells
     if (((const uint32_t*)(ctx->pinned + 8))[3]) return tsq_fail(h, TSQ_ERR_HIP, "internal: the overflow store of the packed aggregate was full");
     if (n_part > la.out.cap) {  // more partial groups than the buffer holds: nothing was merged yet, redo the batch row by row
+        if (pg) return tsq_fail(h, TSQ_ERR_HIP, "internal: the spill list of the partitioned groups was full");  // (sized for every row)
         a->fast_fallbacks++;
         return TSQ_OK;
     }
@@ -2473,6 +2626,12 @@ tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
         a->kd_ok = a->kd_mode;  // (rows already live in the several-column table, or the setup refused: keep one table)
     }
     if (a->kd_mode) return kd_batch(a, in, nrows);
+    if (a->pg_state == 1 && nrows < 0x7fffffffLL) {  // the groups live in the partitioned sub-tables: every batch goes there, whatever its size
+        bool done = false;
+        TSQ_TRY(agg_batch_fast(a, in, nrows, 1, &done));
+        if (!done) return tsq_fail(&a->hdr, TSQ_ERR_HIP, "internal: a batch of the partitioned groups was not taken");
+        return TSQ_OK;
+    }
     const bool want_fast = a->fast_ok && a->fast_mode != TSQ_AGGFAST_OFF && nrows < 0x7fffffffLL &&
                            (a->fast_mode == TSQ_AGGFAST_FORCE || nrows >= (1 << 20));
     if (!want_fast) return agg_rows(a, in, nrows, nullptr);
@@ -2481,6 +2640,30 @@ tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     int64_t est = a->cfg.est_groups > 0 ? a->cfg.est_groups : 0;
     const int64_t seen_rows = a->in_rows;
     if (seen_rows + done_rows >= (1 << 20) || (a->fast_mode == TSQ_AGGFAST_FORCE && a->groups > 0)) est = std::max<int64_t>(a->groups, 1);
+    if (est == 0 && a->pg_state == 0 && a->mk_n <= 1 && a->plan.n_keys == 1 && a->groups == 0 && a->in_rows == 0 && nrows >= (1 << 20) && tsq_knob(a->ctx, TSQ_KNOB_AGG_PG, 1) != 0) {
+        // no estimate: 8192 keys of the batch tell "about as many groups as rows" from what the LDS modes take (k_pg_sample) — without a
+        // prefix in the table, which would then hold groups that the sub-tables hold too
+        tsq_ctx* ctx = a->ctx;
+        AfPgSampleArgs sa;
+        memset(&sa, 0, sizeof sa);
+        sa.src.data = in.data[a->fplan.key_col];
+        sa.src.nulls = in.nulls[a->fplan.key_col];
+        sa.src.type = in.type[a->fplan.key_col];
+        sa.src.nrows = nrows;
+        sa.src.key_kind = 1;
+        sa.out = (uint32_t*)(ctx->dscratch + 40);
+        hipLaunchKernelGGL(k_pg_sample, dim3(1), dim3(1024), 0, ctx->stream, sa);
+        TSQ_HIP(&a->hdr, hipGetLastError());
+        TSQ_HIP(&a->hdr, hipMemcpyAsync(ctx->pinned + 40, ctx->dscratch + 40, 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(&a->hdr, hipStreamSynchronize(ctx->stream));
+        a->st.kernel_launches++;
+        const double n = (double)((const uint32_t*)(ctx->pinned + 40))[0], d = (double)((const uint32_t*)(ctx->pinned + 40))[1];
+        if (n >= 4096.0) {
+            const double ndv = d > 0 ? n * n / (2.0 * d) : 4.0 * (double)nrows;
+            if (!pg_h_fits(a->fplan, (int64_t)std::min<double>(ndv, 9e18)))  // (a planner would pass this on as est_groups)
+                est = (int64_t)std::min<double>(std::min<double>(ndv * 1.5, (double)nrows), 9e18);
+        }
+    }
     if (est == 0 && a->fast_mode != TSQ_AGGFAST_FORCE) {
         const int64_t prefix = std::min<int64_t>(nrows, 1 << 20);  // multiple of 8 rows: bitmap slices stay byte aligned
         TSQ_TRY(agg_rows(a, in, prefix, nullptr));
@@ -2897,6 +3080,9 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     const bool dense_direct = a->dense_state == 1 && a->dense_rows > 0 && a->groups == 0 && !a->multi && a->plan.n_keys == 1 && a->mk_n <= 1 &&
                               a->wide_state != 1 && !a->stream && tsq_knob(ctx, TSQ_KNOB_DENSE_DIRECT, 1) != 0;
     if (!dense_direct) TSQ_TRY(da_dense_flush(a));
+    // every group in the partitioned sub-tables and none in the table (no spilled or exception row): the rows come straight from the slots
+    const bool pg_direct = a->pg_state == 1 && a->pg_rows > 0 && a->groups == 0 && !a->multi && a->plan.n_keys == 1 && a->mk_n <= 1 && a->wide_state != 1 && !a->stream;
+    if (!pg_direct) TSQ_TRY(pg_flush(a));
     // empty input without GROUP BY: exactly one row of defaults (aggregate.go:572-574,
     // builder.go:517-539): COUNT -> 0, everything else NULL.  The NULL-group slot (cap+1) is the
     // single group of a key-less aggregate; claim it so that finalize emits it.
@@ -2925,6 +3111,14 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
         g_own = (int64_t)ctx->pinned[9];
         a->st.kernel_launches++;
     }
+    if (pg_direct) {  // the groups = the occupied slots: the sub-tables' counts, summed on the host (<= 128 KB)
+        const size_t subs = (size_t)1 << (a->pg_pbits + a->pg_sbits);
+        std::vector<uint32_t> used(subs);
+        TSQ_HIP(h, hipMemcpyAsync(used.data(), a->pg_used.p, subs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        g_own = 0;
+        for (uint32_t u : used) g_own += u;
+    }
     const int64_t g = g_own + g_child;
     a->odata.resize(a->n_out);
     a->onn.resize(a->n_out);
@@ -2944,23 +3138,29 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     fa.ordered = a->stream ? 1 : 0;
     fa.ordered_groups = (uint64_t)g_own;
     TSQ_HIP(h, hipMemsetAsync((char*)a->counters.p + 3 * 8, 0, 16, ctx->stream));
-    if (dense_direct) {
+    if (dense_direct || pg_direct) {
         DenseFinalArgs da;
         memset(&da, 0, sizeof da);
         da.fplan = a->fplan;
         da.plan = a->plan;
         da.dm = a->da_dm;
         da.key_type = a->cfg.group_key_type[0];
-        for (int k = 0; k < a->fplan.W; k++) da.dense_w[k] = a->dense_w[k].as<unsigned long long>();
-        da.dense_touch = a->dense_touch.as<uint32_t>();
-        da.ncells = (uint64_t)1 << a->da_dm.b;
+        if (pg_direct) {
+            for (int k = 0; k < a->fplan.W; k++) da.dense_w[k] = a->pg_w[k].as<unsigned long long>();
+            da.pg_key = a->pg_key.as<unsigned long long>();
+            da.ncells = (uint64_t)af_slots(a->fplan) << (a->pg_pbits + a->pg_sbits);
+        } else {
+            for (int k = 0; k < a->fplan.W; k++) da.dense_w[k] = a->dense_w[k].as<unsigned long long>();
+            da.dense_touch = a->dense_touch.as<uint32_t>();
+            da.ncells = (uint64_t)1 << a->da_dm.b;
+        }
         for (int oc = 0; oc < a->n_out; oc++) {
             da.out_data[oc] = fa.out_data[oc];
             da.out_notnull[oc] = fa.out_notnull[oc];
         }
         da.counters = fa.counters;
         hipLaunchKernelGGL(k_dense_finalize, dim3(tsq_grid_for(ctx, (int64_t)da.ncells, 256, TSQ_FINAL_CHUNK / 256)), dim3(256), 0, ctx->stream, da);
-        a->dense_flushes++;
+        if (dense_direct) a->dense_flushes++;
     } else {
         int grid = tsq_grid_for(ctx, a->stream ? std::max<int64_t>(g_own, 1) : (int64_t)a->tb.cap + 2, 256, TSQ_FINAL_CHUNK / 256);
         hipLaunchKernelGGL(k_agg_finalize, dim3(grid), dim3(256), 0, ctx->stream, fa);
@@ -3248,6 +3448,8 @@ TSQ_API tsq_status tsq_agg_stats(tsq_agg* a, tsq_stats* out) {
         a->st.build_handed_back_rows = a->wide_exception_rows;
         a->st.build_partitioned = a->kd_mode ? 3 : 2;  // (aggregate: 2 = several key columns composed into one 64-bit key, 3 = group keys through the dictionary of key records)
     }
+    if (a->pg_batches > 0 && a->wide_state != 1) a->st.build_partitioned = 4;  // (aggregate: 4 = the groups lived in partitioned, LDS-sized sub-tables: tsq_aggfast.h K7p)
+    else if (a->wide_state == 1 && a->wide && a->wide->pg_batches > 0 && !a->kd_mode) a->st.dense_flushes = -4;  // (... of the composite-key child)
     a->st.heap_bytes = 0;
     for (const ColStore& hs : a->heap)
         if (hs.type == TSQ_BYTES) a->st.heap_bytes = std::max<int64_t>(a->st.heap_bytes, hs.nbytes);
@@ -3291,6 +3493,9 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
     for (auto& b : a->hbitmap) b.release();
     a->fkey.release();
     for (auto& b : a->fw) b.release();
+    a->pg_key.release();
+    for (auto& b : a->pg_w) b.release();
+    a->pg_used.release();
     a->fctl.release();
     a->fexc.release();
     a->rkeys.release();

@@ -335,4 +335,220 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_lds(AfLdsArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K7p — PARTITIONED GROUPS (round 6): a GROUP BY with about as many groups as rows (SELECT .. GROUP BY l_orderkey, .. of Q3: 1.3e7
+// groups of 3e7 rows; BenchmarkAggGroupByNDV at NDV = 1e7, executor/benchmark_test.go:296-305).  H mode gives such an input up — its
+// partial groups do not shrink the batch, and every one of them is a random upsert into the table in HBM (k_agg_merge: 7e9 a second,
+// the row path's speed) — and the row path took 136 ms for 1e7 rows of 6.3e6 groups.  Here the operator's group table IS a set of
+// LDS-sized sub-tables: 2^bits partitions (the radix partition of H mode) x 2^sbits sub-tables of S slots each, kept in HBM between the
+// batches.  A batch is partitioned as in H mode; ONE workgroup per partition loads sub-table t into LDS, lets the partition's rows whose
+// word belongs to t find or insert their group there (the same CAS + one LDS atomic per word as k_agg_lds), stores the sub-table back,
+// and goes on to t + 1 (the partition's rows are read 2^sbits times: from the L2).  A word that finds its sub-table full is SPILLED as a
+// one-row partial group (k_agg_merge puts it into the table in HBM): a sub-table never shrinks, so a key lives either in its sub-table
+// from some batch on or in the HBM table for good — one home per group.  At the end the groups come straight out of the sub-tables
+// (k_dense_finalize, pg form) when the HBM table stayed empty; otherwise they are emitted as partial groups and merged (k_pg_emit).
+// Replaces (reference): getGroupKey + the partial-result map + shuffle + final map (executor/aggregate.go:332-356, 424-457).
+struct AfPgArgs {
+    AfPlan plan;
+    AfPartials out;                       // spilled one-row partial groups
+    RadixStore st;
+    unsigned long long* pg_key;           // [P << sbits][S] table words (TSQ_AF_EMPTY: free)
+    unsigned long long* pg_w[TSQ_AF_MAXW];
+    uint32_t* pg_used;                    // [P << sbits] occupied slots
+    uint32_t sbits;
+};
+template <int W>
+__global__ void __launch_bounds__(TSQ_AF_NT) k_agg_pg(AfPgArgs a) {
+    constexpr uint32_t S = W <= 3 ? 4096u : 2048u;
+    uint32_t wd[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) wd[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.plan.wdesc[k]);
+    __shared__ unsigned long long s_key[S];
+    __shared__ unsigned long long s_w[W][S];
+    __shared__ uint32_t s_used;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t P = 1u << a.st.bits, NS = 1u << a.sbits, sshift = 64u - a.st.bits - a.sbits;
+    auto spill = [&](uint64_t tag, uint64_t c0, uint64_t c1) {
+        const uint64_t cells[TSQ_RADIX_MAXV] = {c0, c1};
+        unsigned long long w[TSQ_AF_MAXW];
+        af_row_words(a.plan, cells, w);
+        const uint32_t o = __hip_atomic_fetch_add(a.out.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o < a.out.cap) {
+            a.out.key[o] = tsq_unmix64(tag);
+#pragma unroll
+            for (int k = 0; k < W; k++) a.out.w[k][o] = w[k];
+        }
+    };
+    auto apply = [&](uint64_t tag, uint64_t c0, uint64_t c1) {
+        if (tag == TSQ_AF_EMPTY) { spill(tag, c0, c1); return; }  // (the sentinel word lives in a slot of its own of the HBM table)
+        uint32_t slot = (uint32_t)tag & (S - 1);
+        bool found = false;
+        for (int probe = 0; probe < 64 && !found; probe++) {
+            unsigned long long cur = s_key[slot];
+            if (cur == TSQ_AF_EMPTY) {
+                if (s_used >= S - S / 8) break;  // full (for good): the row is spilled
+                cur = atomicCAS(&s_key[slot], (unsigned long long)TSQ_AF_EMPTY, (unsigned long long)tag);
+                if (cur == TSQ_AF_EMPTY) {
+                    atomicAdd(&s_used, 1u);
+                    found = true;
+                    break;
+                }
+            }
+            if (cur == tag) found = true;
+            else slot = (slot + 1) & (S - 1);
+        }
+        if (!found) { spill(tag, c0, c1); return; }
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            const uint32_t d = wd[k];
+            const uint64_t cell = (d & 8u) ? c1 : c0;
+            const int32_t type = (int32_t)(d >> 4);
+            switch (d & 7u) {
+                case AF_W_ADD1: atomicAdd(&s_w[k][slot], 1ull); break;
+                case AF_W_ADD_REAL: atomicAdd(reinterpret_cast<double*>(&s_w[k][slot]), af_real(cell, type)); break;
+                case AF_W_ADD_LO32: atomicAdd(&s_w[k][slot], (unsigned long long)(cell & 0xffffffffull)); break;
+                case AF_W_ADD_HI32: atomicAdd(&s_w[k][slot], (unsigned long long)((long long)cell >> 32)); break;
+                case AF_W_MAX: atomicMax(&s_w[k][slot], (unsigned long long)af_ord_image(cell, type)); break;
+                default: atomicMin(&s_w[k][slot], (unsigned long long)af_ord_image(cell, type)); break;
+            }
+        }
+    };
+    constexpr int U = 4;
+    for (uint32_t p = blockIdx.x; p < P; p += gridDim.x) {
+        uint32_t rows_p = 0;
+        for (uint32_t r = 0; r < a.st.R; r++) rows_p += radix_region_len(a.st, P, p, r);
+        if (rows_p == 0) continue;  // (block-uniform)
+        for (uint32_t t = 0; t < NS; t++) {
+            const size_t sub = (size_t)p * NS + t, tb = sub * S;
+            __syncthreads();  // the previous sub-table has been stored
+            for (uint32_t i = tid; i < S; i += TSQ_AF_NT) {
+                s_key[i] = a.pg_key[tb + i];
+#pragma unroll
+                for (int k = 0; k < W; k++) s_w[k][i] = a.pg_w[k][tb + i];
+            }
+            if (tid == 0) s_used = a.pg_used[sub];
+            __syncthreads();
+            for (uint32_t r = 0; r < a.st.R; r++) {
+                const uint32_t len = radix_region_len(a.st, P, p, r);
+                const size_t base = (size_t)(p * a.st.R + r) * a.st.cap;
+                for (uint32_t i0 = tid; i0 < len; i0 += TSQ_AF_NT * U) {
+                    uint64_t tag[U], cells[U][TSQ_RADIX_MAXV];
+                    bool mine[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t i = i0 + (uint32_t)u * TSQ_AF_NT;
+                        tag[u] = 0;
+                        cells[u][0] = cells[u][1] = 0;
+                        mine[u] = false;
+                        if (i < len) {
+                            tag[u] = a.st.keys[base + i];
+                            mine[u] = a.sbits == 0 || (uint32_t)((tag[u] >> sshift) & (NS - 1)) == t;
+#pragma unroll
+                            for (int v = 0; v < TSQ_RADIX_MAXV; v++)
+                                if (v < a.plan.V && mine[u]) cells[u][v] = a.st.pay[v][base + i];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                        if (mine[u]) apply(tag[u], cells[u][0], cells[u][1]);
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < S; i += TSQ_AF_NT) {
+                a.pg_key[tb + i] = s_key[i];
+#pragma unroll
+                for (int k = 0; k < W; k++) a.pg_w[k][tb + i] = s_w[k][i];
+            }
+            if (tid == 0) a.pg_used[sub] = s_used;
+        }
+    }
+}
+// the overflow list of the partition pass (skewed keys: runs that missed their region) and anything else that must not wait: every row
+// as a one-row partial group for k_agg_merge.  (Such a key may live in a sub-table as well: the end then takes the merging way.)
+struct AfPgOvfArgs {
+    AfPlan plan;
+    AfPartials out;
+    RadixStore st;
+};
+static __global__ void __launch_bounds__(256) k_pg_ovf(AfPgOvfArgs a) {
+    uint32_t n = *a.st.ovf_count;
+    n = n < a.st.ovf_cap ? n : a.st.ovf_cap;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint64_t cells[TSQ_RADIX_MAXV] = {0, 0};
+#pragma unroll
+        for (int v = 0; v < TSQ_RADIX_MAXV; v++)
+            if (v < a.plan.V) cells[v] = a.st.ovf_pay[v][i];
+        unsigned long long w[TSQ_AF_MAXW];
+        af_row_words(a.plan, cells, w);
+        const uint32_t o = __hip_atomic_fetch_add(a.out.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o < a.out.cap) {
+            a.out.key[o] = tsq_unmix64(a.st.ovf_keys[i]);
+            for (int k = 0; k < a.plan.W; k++) a.out.w[k][o] = w[k];
+        }
+    }
+}
+// the groups of slots [lo, lo + n) of the sub-tables as partial groups (int64 sums: (low halves, high halves) -> the 128-bit (lo, hi)
+// pair, as k_agg_lds emits them): the merging way out, taken when the table in HBM holds groups as well
+struct AfPgEmitArgs {
+    AfPlan plan;
+    AfPartials out;
+    const unsigned long long* pg_key;
+    const unsigned long long* pg_w[TSQ_AF_MAXW];
+    uint64_t lo, n;
+};
+static __global__ void __launch_bounds__(256) k_pg_emit(AfPgEmitArgs a) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (uint64_t)gridDim.x * 256) {
+        const unsigned long long key = a.pg_key[a.lo + i];
+        if (key == TSQ_AF_EMPTY) continue;
+        unsigned long long w[TSQ_AF_MAXW];
+        for (int k = 0; k < a.plan.W; k++) w[k] = a.pg_w[k][a.lo + i];
+        for (int q = 0; q < a.plan.n_aggs; q++) {
+            const AfAgg f = a.plan.f[q];
+            if (f.w < 0 || (f.func != TSQ_AGG_SUM && f.func != TSQ_AGG_AVG) || af_is_real(f.type)) continue;
+            const unsigned long long lo32 = w[f.w], hi32 = w[f.w + 1];
+            const unsigned long long lo = (hi32 << 32) + lo32;
+            w[f.w] = lo;
+            w[f.w + 1] = (unsigned long long)((long long)hi32 >> 32) + (lo < lo32 ? 1ull : 0ull);
+        }
+        const uint32_t o = __hip_atomic_fetch_add(a.out.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (o < a.out.cap) {
+            a.out.key[o] = tsq_unmix64(key);
+            for (int k = 0; k < a.plan.W; k++) a.out.w[k][o] = w[k];
+        }
+    }
+}
+// how many distinct keys does the input hold?  8192 keys spread over the batch go into one LDS set; d of them were there already:
+// N ~ n^2 / (2 d) (the birthday bound, good to a factor of two up to ~1e9 keys) — enough to tell "about as many groups as rows" from
+// what H mode takes, without putting a prefix of the batch into the table (which would then hold groups the sub-tables hold too)
+struct AfPgSampleArgs {
+    RadixSrc src;
+    uint32_t* out;  // [0] keys sampled (not NULL), [1] duplicates among them
+};
+static __global__ void __launch_bounds__(1024) k_pg_sample(AfPgSampleArgs a) {
+    constexpr uint32_t S = 16384, N = 8192;
+    __shared__ unsigned long long s_set[S];
+    __shared__ uint32_t s_n, s_dup;
+    for (uint32_t i = threadIdx.x; i < S; i += 1024) s_set[i] = TSQ_AF_EMPTY;
+    if (threadIdx.x == 0) s_n = s_dup = 0;
+    __syncthreads();
+    const int64_t stride = a.src.nrows / N > 0 ? a.src.nrows / N : 1;
+    for (uint32_t i = threadIdx.x; i < N; i += 1024) {
+        const int64_t r = (int64_t)i * stride;
+        if (r >= a.src.nrows || tsq_is_null(a.src.nulls, r)) continue;
+        const unsigned long long w = tsq_mix64(radix_src_key(a.src, r));
+        if (w == TSQ_AF_EMPTY) continue;
+        atomicAdd(&s_n, 1u);
+        uint32_t slot = (uint32_t)w & (S - 1);
+        for (;;) {
+            unsigned long long cur = s_set[slot];
+            if (cur == TSQ_AF_EMPTY) cur = atomicCAS(&s_set[slot], (unsigned long long)TSQ_AF_EMPTY, w);
+            if (cur == TSQ_AF_EMPTY) break;
+            if (cur == w) { atomicAdd(&s_dup, 1u); break; }
+            slot = (slot + 1) & (S - 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { a.out[0] = s_n; a.out[1] = s_dup; }
+}
+
 #endif

@@ -1183,6 +1183,143 @@ def extra_agg_string_keys(ctx, abi, _lib, n=10_000_000, groups=100_000):
             "several_column_upsert_ms": upsert_ms}
 
 
+def extra_ref_hashjoin(ctx, abi, _lib, key_idx=(0, 1), rows=100_000, cpu_threads=4):
+    """The reference's own join benchmark, shape for shape (executor/benchmark_test.go:328-457 BenchmarkHashJoinExec): two data sources of
+    `rows` rows (bigint = the row number, varstring = 5 KiB of 'x'), inner join ON the columns of `key_idx` ({0, 1} or {0}), concurrency 4,
+    Open -> Next until the result is drained -> Close.  GPU: the device-resident Executor mirror (DeviceTableScan -> GpuHashJoinExec,
+    tinysql_amd/gpu_pipeline.py: the mock data sources hand their chunks over with SwapColumns, the scans hand out pointer views), every
+    joined chunk — four columns, two of them 5 KiB strings: 1 GB of cells — materialised in HBM.  CPU: the oracle's restatement of the
+    reference algorithm on the same rows with `cpu_threads` probe workers (oracle/, test infrastructure: a reported baseline only)."""
+    import numpy as np
+    from tinysql_amd import gpu_pipeline as G
+    from tinysql_amd.chunk import Chunk, Column, StrColumn
+    cell = 5 * 1024
+    I = abi.I64
+
+    def table():
+        k = G.DeviceColumn(ctx, I, rows, with_bitmap=False)
+        ctx.h2d(k.data, np.arange(rows, dtype=np.int64))
+        s = G.DeviceColumn(ctx, abi.BYTES, rows, with_bitmap=False, cap_bytes=rows * cell)
+        _lib.check(ctx.lib.tsq_dev_memset(ctx.h, C.c_void_p(s.data), ord("x"), rows * cell), ctx.h)
+        ctx.h2d(s.offsets, np.arange(rows + 1, dtype=np.int64) * cell)
+        return G.DeviceChunk([k, s], rows)
+    t1, t2 = table(), table()
+    ctx.sync()
+    best, out_rows, out_bytes, route = 1e30, 0, 0, None
+    try:
+        for _ in range(3):
+            j = G.GpuHashJoinExec(ctx, G.DeviceTableScan(ctx, t2, 1 << 20), G.DeviceTableScan(ctx, t1, 1 << 20), list(key_idx), list(key_idx), abi.JOIN_INNER, 1, pull_rows=1 << 17)
+            ctx.sync()
+            t = time.perf_counter()
+            j.Open()
+            n_out = n_bytes = 0
+            while True:
+                chk = j.Next()
+                if chk.NumRows() == 0:
+                    break
+                n_out += chk.NumRows()
+            ctx.sync()
+            dt = time.perf_counter() - t
+            for c in (j.out or []):  # the two string columns of the last pulled chunk: their bytes say the cells were really written
+                if c.var:
+                    n_bytes += c.nbytes(min(n_out, 1 << 17))
+            j.Close()
+            route = int(j.last_stats.probe_route) if getattr(j, "last_stats", None) is not None else None
+            best, out_rows, out_bytes = min(best, dt), n_out, n_bytes
+    finally:
+        t1.free()
+        t2.free()
+    # the CPU side: the oracle on the same rows (host copies), build + probe
+    cpu_ms = None
+    try:
+        from oracle import binding as orc
+        x = b"x" * cell
+        hc = Chunk([Column(I, np.arange(rows, dtype=np.int64)), StrColumn([x] * rows)])
+        cfg = abi.JoinCfg()
+        cfg.join_type, cfg.build_is_right, cfg.n_keys, cfg.n_build_cols, cfg.n_probe_cols = abi.JOIN_INNER, 1, len(key_idx), 2, 2
+        for i, t in enumerate((I, abi.BYTES)):
+            cfg.build_types[i] = cfg.probe_types[i] = t
+        for i, kcol in enumerate(key_idx):
+            cfg.build_key_idx[i] = cfg.probe_key_idx[i] = kcol
+        cfg.max_chunk_size, cfg.concurrency = 1024, cpu_threads
+        n_cpu, bms, pms, _, _ = orc.hash_join_timed(cfg, hc, hc, cpu_threads)
+        cpu_ms = bms + pms
+        cpu_rows = int(n_cpu)
+    except Exception as e:  # reporting only
+        cpu_rows = None
+        cpu_ms = None
+        cpu_err = str(e)[:120]
+    res = {"workload": "executor/benchmark_test.go BenchmarkHashJoinExec (rows:%d, concurrency:%d, joinKeyIdx:%s): (bigint, 5 KiB varstring) x the same, inner join, Open/Next*/Close; "
+                       "GPU = DeviceTableScan -> GpuHashJoinExec with the joined chunks (1 GB of cells) materialised in HBM" % (rows, cpu_threads, list(key_idx)),
+           "ms": best * 1e3, "joined_rows": out_rows, "string_bytes_in_last_chunk": out_bytes, "verified": out_rows == rows and out_bytes == 2 * cell * min(rows, 1 << 17),
+           "route": route, "rows_per_s": rows / best, "frac": (2.0 * rows * (cell + 16) + 2.0 * rows * (cell + 16)) / best / 8e12}
+    if cpu_ms is not None:
+        res["cpu_oracle_ms"] = cpu_ms
+        res["cpu_oracle_threads"] = cpu_threads
+        res["cpu_rows_ok"] = cpu_rows == rows
+        res["speedup_vs_cpu_oracle"] = cpu_ms / (best * 1e3)
+    else:
+        res["cpu_oracle_error"] = cpu_err
+    return res
+
+
+def extra_ref_agg(ctx, abi, _lib, rows=10_000_000, ndv=1000, cpu_threads=4):
+    """The reference's aggregate benchmark (executor/benchmark_test.go:179-326 BenchmarkAggRows / BenchmarkAggGroupByNDV): SELECT SUM(d) GROUP BY k
+    over `rows` rows of (double, bigint with `ndv` distinct values), HashAggExec with concurrency 4, Open -> Next* -> Close.  GPU: DeviceTableScan ->
+    GpuHashAggExec on device-resident columns; CPU: the oracle's partial -> shuffle -> final restatement with the same worker counts."""
+    import numpy as np
+    from tinysql_amd import gpu_pipeline as G
+    from tinysql_amd.chunk import Chunk, Column
+    from tinysql_amd.executor import AggFuncDesc
+    rng = np.random.default_rng(rows + ndv)
+    d = rng.random(rows)
+    k = rng.integers(0, ndv, rows)
+    dc, kc = G.DeviceColumn(ctx, abi.F64, rows, with_bitmap=False), G.DeviceColumn(ctx, abi.I64, rows, with_bitmap=False)
+    ctx.h2d(dc.data, d)
+    ctx.h2d(kc.data, k)
+    tab = G.DeviceChunk([dc, kc], rows)
+    ctx.sync()
+    best, groups, total = 1e30, 0, 0.0
+    try:
+        for _ in range(3):
+            agg = G.GpuHashAggExec(ctx, G.DeviceTableScan(ctx, tab, 1 << 26), [1], [AggFuncDesc(abi.AGG_SUM, 0, abi.F64)], est_groups=0)
+            ctx.sync()
+            t = time.perf_counter()
+            agg.Open()
+            got, last = 0, None
+            while True:
+                chk = agg.Next()
+                if chk.NumRows() == 0:
+                    break
+                got += chk.NumRows()
+                last = chk
+            ctx.sync()
+            dt = time.perf_counter() - t
+            if last is not None and got == last.NumRows():
+                total = float(last.columns[0].to_host(last.NumRows()).data.sum())
+            agg.Close()
+            best, groups = min(best, dt), got
+    finally:
+        tab.free()
+    want_groups = int(len(np.unique(k)))
+    res = {"workload": "executor/benchmark_test.go BenchmarkAgg* (aggFunc:sum, ndv:%d, rows:%d, concurrency:%d): SUM(double) GROUP BY bigint, Open/Next*/Close on device-resident columns" % (ndv, rows, cpu_threads),
+           "ms": best * 1e3, "groups": groups, "rows_per_s": rows / best, "frac": 16.0 * rows / best / 8e12,
+           "verified": groups == want_groups and (groups > (1 << 22) or abs(total - float(d.sum())) <= 1e-6 * float(d.sum()))}
+    try:
+        from oracle import binding as orc
+        cfg = abi.AggCfg()
+        cfg.n_group_keys, cfg.n_aggs, cfg.n_input_cols = 1, 1, 2
+        cfg.group_key_col[0], cfg.group_key_type[0] = 1, abi.I64
+        cfg.aggs[0].func, cfg.aggs[0].mode, cfg.aggs[0].arg_col, cfg.aggs[0].arg_col2, cfg.aggs[0].arg_type = abi.AGG_SUM, abi.MODE_COMPLETE, 0, -1, abi.F64
+        cfg.input_types[0], cfg.input_types[1] = abi.F64, abi.I64
+        cfg.max_chunk_size = 1024
+        _, cpu_ms = orc.hash_agg_timed(cfg, Chunk([Column(abi.F64, d), Column(abi.I64, k)]), cpu_threads)
+        res["cpu_oracle_ms"], res["cpu_oracle_threads"], res["speedup_vs_cpu_oracle"] = cpu_ms, cpu_threads, cpu_ms / (best * 1e3)
+    except Exception as e:  # reporting only
+        res["cpu_oracle_error"] = str(e)[:120]
+    return res
+
+
 def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
     """(key, thunk) of every side measurement, in the order they run"""
     return (("build_warm", lambda: extra_build_warm(ctx, abi, _lib, bk, bv, nb)),
@@ -1206,18 +1343,22 @@ def registry(ctx, abi, _lib, bk, bv, pk, pv, nb, npr):
             ("agg_string_keys_1e7_1e5", lambda: extra_agg_string_keys(ctx, abi, _lib)),
             ("agg_string_keys_1e7_5e6", lambda: extra_agg_string_keys(ctx, abi, _lib, groups=5_000_000)),
             ("materialising", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr)),
-            ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True)))
+            ("materialising_nullable_left_outer", lambda: extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, nullable_left_outer=True)),
+            ("ref_BenchmarkHashJoinExec_keyIdx01", lambda: extra_ref_hashjoin(ctx, abi, _lib, (0, 1))),
+            ("ref_BenchmarkHashJoinExec_keyIdx0", lambda: extra_ref_hashjoin(ctx, abi, _lib, (0,))),
+            ("ref_BenchmarkAggRows_1e7_ndv1000", lambda: extra_ref_agg(ctx, abi, _lib, 10_000_000, 1000)),
+            ("ref_BenchmarkAggNDV_1e7_ndv1e7", lambda: extra_ref_agg(ctx, abi, _lib, 10_000_000, 10_000_000)))
 
 
-TRAFFIC_FILE = "traffic_r05.json" if os.path.exists(os.path.join(ROOT, "profiles", "traffic_r05.json")) else "traffic_r04.json"
+TRAFFIC_FILE = next((f for f in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "traffic_r04.json")
 TRAFFIC_KERNELS = {
     "c3_agg_1e9_1e6": ["void k_daagg_partition<512, 8, 1, 2, false>", "void k_daagg_partition<1024, 8, 1", "void k_agg_da<3, 4096, 1>", "k_daagg_dense_emit", "k_agg_merge("],
     "c3_agg_1e9_1e6_double": ["void k_daagg_partition<1024, 8, 1, 8, true>", "void k_daagg_partition<1024, 8, 1>", "void k_agg_da<2, 4096, 2>"],
     "c3_zipf_s1": ["void k_daagg_ovf<3>"],
     "c3_sparse_keys": ["void k_radix_partition<1024, 8, 4, 1, false, true>", "void k_agg_lds<1, 3>"],
     "agg_two_keys_50x20": ["void k_agg_da_low<3, 4096>"],
-    "materialising": ["void k_da_partition_cols<1024, 8, false>", "void k_da_emit_cols<512, false, true>", "void k_da_sort_partition<1024>"],
-    "materialising_nullable_left_outer": ["void k_da_partition_cols<1024, 8, true>", "void k_da_emit_cols<512, true, true>"],
+    "materialising": ["void k_da_partition_cols<1024, 8, false>", "void k_dm_split<512, true>", "void k_dm_split<512, false>", "void k_dm_emit<512, false>"],
+    "materialising_nullable_left_outer": ["void k_da_partition_cols<1024, 8, true>", "void k_dm_emit<512, true>"],
     "wide_keys_64bit_route": ["void k_lds_probe_count<1024, false, 0>", "void k_radix_partition<1024, 16, 4, 0, false, true>"],
     "wide_keys_31bit_unique_bit_cells": ["void k_da_build_bits<1024>", "void k_da_probe_count<1024, unsigned int, false, false, true>",
                                          "void k_da_partition<1024, 16, unsigned int, false, false>"],
