@@ -125,6 +125,8 @@ def test_pg_by_the_planners_estimate_and_by_the_key_sample(ctx, orc):
     chk, types = _table(rng, n, n)
     aggs = [(abi.AGG_FIRSTROW, 0, abi.I64), (abi.AGG_COUNT, -1, abi.I64), (abi.AGG_SUM, 1, abi.I64)]
     _check(ctx, orc, chk, aggs, types, est=4_000_000, fast=abi.AGGFAST_AUTO)
+    # batches much smaller than the state wait (every pass rewrites all the sub-tables) and are aggregated together at the end
+    _check(ctx, orc, chk, aggs, types, est=4_000_000, fast=abi.AGGFAST_AUTO, chunk_rows=1 << 20, batch_rows=1 << 20)
     m = 4_500_000  # every key once: the sample finds no duplicate and takes "four times the rows" for the number of keys (H mode holds 3.2e6 groups a batch)
     chk2 = Chunk([Column(abi.I64, rng.permutation(m).astype(np.int64) * 1_000_003 - 7), H.random_column(rng, abi.I64, m, 0.0, lo=-10**9, hi=10**9), H.random_column(rng, abi.F64, m, 0.0)])
     _check(ctx, orc, chk2, aggs, types, est=0, fast=abi.AGGFAST_AUTO, chunk_rows=1 << 23, batch_rows=1 << 23)

@@ -1146,6 +1146,11 @@ struct tsq_agg {
     uint32_t pg_pbits = 0, pg_sbits = 0;
     int64_t pg_rows = 0, pg_batches = 0;
     DevBuf pg_key, pg_w[TSQ_AF_MAXW], pg_used;
+    // every batch rewrites all the sub-tables (load, apply, store): batches much smaller than the state wait in these columns (the key
+    // column and the argument columns, with their null bitmaps) until they are worth a pass — or until the end
+    std::vector<ColStore> pg_pend;
+    int64_t pg_pend_rows = 0;
+    bool pg_in_flush = false;
     // packed-key pre-aggregation (tsq_daagg.h): the key range the first large batch showed
     int da_state = 0;  // 0: not tried, 1: in use, -1: not usable (range too wide, float key, too many rows outside the range)
     DaDomain da_dm{};
@@ -1649,6 +1654,7 @@ tsq_status da_dense_flush(tsq_agg* a) {
 
 // one batch through LDS pre-aggregation.  *done = false: nothing was merged, the caller runs the row path.
 // ---- partitioned groups (tsq_aggfast.h K7p)
+tsq_status pg_pend_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows);
 // what H mode takes: partitions of 2^10 at most, each half-filling one LDS table
 static bool pg_h_fits(const AfPlan& pl, int64_t groups_est) { return ((double)groups_est * 1.3 / (double)af_slots(pl)) <= 1024.0; }
 // the sub-tables for `est` groups at half load; refused beyond 2^11 partitions x 16 sub-tables (6.7e7 groups of <= 3 words)
@@ -1669,7 +1675,7 @@ tsq_status pg_setup(tsq_agg* a, int64_t est) {
             return TSQ_OK;
         }
     const uint64_t S = af_slots(pl);
-    const uint64_t want = (uint64_t)est * 2 + S;
+    const uint64_t want = (uint64_t)((double)est / 0.6) + S;  // (an LDS table takes groups up to 7/8 of its slots; the estimate may be low)
     uint32_t pbits = 8, sbits = 0;
     while (pbits < 11 && (S << pbits) < want) pbits++;
     while (sbits < 4 && (S << (pbits + sbits)) < want) sbits++;
@@ -1764,6 +1770,10 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
     if (!low && !packed && !pg && !mk && pg_knob != 0 && !pg_h_fits(pl, groups_est)) {  // more groups than LDS tables hold per batch: the sub-tables
         TSQ_TRY(pg_setup(a, groups_est));
         pg = a->pg_state == 1;
+    }
+    if (pg && !a->pg_in_flush) {  // (the batch that made the state: it waits like the later ones unless it is worth a pass by itself)
+        *done = true;
+        return pg_pend_batch(a, in, nrows);
     }
     if (pg && a->pg_rows + nrows > ((int64_t)1 << 31)) TSQ_TRY(pg_flush(a));  // (the 32-bit halves of its int64 sums must not wrap)
     if (mk && !packed) return TSQ_OK;
@@ -2039,7 +2049,7 @@ tsq_status agg_batch_fast(tsq_agg* a, const tsq_colset& in, int64_t nrows, int64
             for (int k = 0; k < pl.W; k++) ga.pg_w[k] = a->pg_w[k].as<unsigned long long>();
             ga.pg_used = a->pg_used.as<uint32_t>();
             ga.sbits = a->pg_sbits;
-            const dim3 ggrid(std::min<uint32_t>(P, (uint32_t)ctx->num_cus));
+            const dim3 ggrid(std::min<uint32_t>(P << a->pg_sbits, (uint32_t)ctx->num_cus * (pl.W <= 1 ? 2u : 1u)));
             switch (pl.W) {
                 case 1: hipLaunchKernelGGL((k_agg_pg<1>), ggrid, dim3(TSQ_AF_NT), 0, ctx->stream, ga); break;
                 case 2: hipLaunchKernelGGL((k_agg_pg<2>), ggrid, dim3(TSQ_AF_NT), 0, ctx->stream, ga); break;
@@ -2597,6 +2607,63 @@ tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     return TSQ_OK;
 }
 
+// ---- partitioned groups: small batches wait (every pass rewrites the whole state)
+tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows);
+tsq_status pg_pend_flush(tsq_agg* a) {
+    if (a->pg_pend_rows == 0) return TSQ_OK;
+    tsq_colset in;
+    memset(&in, 0, sizeof in);
+    in.n = a->cfg.n_input_cols;
+    for (int c = 0; c < in.n; c++) {
+        const ColStore& cs = a->pg_pend[c];
+        in.type[c] = a->cfg.input_types[c];
+        in.data[c] = cs.rows ? cs.data.p : nullptr;  // (columns the plan does not read were not kept)
+        in.nulls[c] = (cs.rows && cs.has_nulls) ? cs.nulls.as<uint8_t>() : nullptr;
+    }
+    const int64_t n = a->pg_pend_rows;
+    a->pg_in_flush = true;
+    const tsq_status s = agg_batch(a, in, n);
+    a->pg_in_flush = false;
+    for (auto& cs : a->pg_pend) cs.clear();
+    a->pg_pend_rows = 0;
+    return s;
+}
+tsq_status pg_pend_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
+    tsq_ctx* ctx = a->ctx;
+    const AfPlan& pl = a->fplan;
+    const int64_t slots = (int64_t)af_slots(pl) << (a->pg_pbits + a->pg_sbits);
+    // rows that make a pass over the state worth it (tests that force the mode, knob >= 2, send every batch straight through: the keys of a
+    // batch must meet their groups of the earlier ones)
+    const int64_t worth = tsq_knob(ctx, TSQ_KNOB_AGG_PG, 1) >= 2 ? 0 : std::max<int64_t>(4 << 20, slots / 2);
+    if (a->pg_pend_rows == 0 && nrows >= worth) {  // a big batch: straight through
+        a->pg_in_flush = true;
+        const tsq_status s = agg_batch(a, in, nrows);
+        a->pg_in_flush = false;
+        return s;
+    }
+    if (a->pg_pend_rows + nrows >= ((int64_t)1 << 31)) TSQ_TRY(pg_pend_flush(a));
+    if (a->pg_pend.empty()) {
+        a->pg_pend.resize(a->cfg.n_input_cols);
+        for (int c = 0; c < a->cfg.n_input_cols; c++) a->pg_pend[c].type = a->cfg.input_types[c];
+    }
+    // the columns the plan reads: the key column and the argument columns
+    bool used[TSQ_MAX_COLS] = {};
+    used[pl.key_col] = true;
+    for (int v = 0; v < pl.V; v++) used[pl.vcol[v]] = true;
+    DevBuf tmp;
+    for (int c = 0; c < a->cfg.n_input_cols; c++) {
+        if (!used[c]) continue;
+        ColStore& cs = a->pg_pend[c];
+        if (cs.rows != a->pg_pend_rows) { tmp.release(); return tsq_fail(&a->hdr, TSQ_ERR_HIP, "internal: pending columns out of step"); }
+        const tsq_status s = tsq_col_append(ctx, &a->hdr, cs, in.data[c], in.nulls[c], nrows, true, tmp);
+        if (s != TSQ_OK) { tmp.release(); return s; }
+    }
+    tmp.release();
+    a->pg_pend_rows += nrows;
+    if (a->pg_pend_rows >= worth) return pg_pend_flush(a);
+    return TSQ_OK;
+}
+
 tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     if (nrows == 0) return TSQ_OK;
     if (a->stream) return stream_batch(a, in, nrows);
@@ -2627,6 +2694,7 @@ tsq_status agg_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     }
     if (a->kd_mode) return kd_batch(a, in, nrows);
     if (a->pg_state == 1 && nrows < 0x7fffffffLL) {  // the groups live in the partitioned sub-tables: every batch goes there, whatever its size
+        if (!a->pg_in_flush) return pg_pend_batch(a, in, nrows);
         bool done = false;
         TSQ_TRY(agg_batch_fast(a, in, nrows, 1, &done));
         if (!done) return tsq_fail(&a->hdr, TSQ_ERR_HIP, "internal: a batch of the partitioned groups was not taken");
@@ -3080,6 +3148,7 @@ TSQ_API tsq_status tsq_agg_finish(tsq_agg* a) {
     const bool dense_direct = a->dense_state == 1 && a->dense_rows > 0 && a->groups == 0 && !a->multi && a->plan.n_keys == 1 && a->mk_n <= 1 &&
                               a->wide_state != 1 && !a->stream && tsq_knob(ctx, TSQ_KNOB_DENSE_DIRECT, 1) != 0;
     if (!dense_direct) TSQ_TRY(da_dense_flush(a));
+    TSQ_TRY(pg_pend_flush(a));
     // every group in the partitioned sub-tables and none in the table (no spilled or exception row): the rows come straight from the slots
     const bool pg_direct = a->pg_state == 1 && a->pg_rows > 0 && a->groups == 0 && !a->multi && a->plan.n_keys == 1 && a->mk_n <= 1 && a->wide_state != 1 && !a->stream;
     if (!pg_direct) TSQ_TRY(pg_flush(a));
@@ -3496,6 +3565,7 @@ TSQ_API void tsq_agg_destroy(tsq_agg* a) {
     a->pg_key.release();
     for (auto& b : a->pg_w) b.release();
     a->pg_used.release();
+    for (auto& cs : a->pg_pend) cs.release();
     a->fctl.release();
     a->fexc.release();
     a->rkeys.release();

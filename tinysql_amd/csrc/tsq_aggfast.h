@@ -414,11 +414,14 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_pg(AfPgArgs a) {
         }
     };
     constexpr int U = 4;
-    for (uint32_t p = blockIdx.x; p < P; p += gridDim.x) {
+    // a work item = one sub-table (partition p, part t): two workgroups per CU (W <= 1) load / apply / store at different times, and the
+    // NS parts of a partition run next to each other — its rows come from HBM once and from the L2 for the other parts
+    for (uint32_t item = blockIdx.x; item < P * NS; item += gridDim.x) {
+        const uint32_t p = item / NS, t = item % NS;
         uint32_t rows_p = 0;
         for (uint32_t r = 0; r < a.st.R; r++) rows_p += radix_region_len(a.st, P, p, r);
         if (rows_p == 0) continue;  // (block-uniform)
-        for (uint32_t t = 0; t < NS; t++) {
+        {
             const size_t sub = (size_t)p * NS + t, tb = sub * S;
             __syncthreads();  // the previous sub-table has been stored
             for (uint32_t i = tid; i < S; i += TSQ_AF_NT) {
