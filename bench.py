@@ -394,7 +394,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "SELECT count(*) FROM probe JOIN build ON k: %.0e x %.0e int64-key inner hash join per GPU, "
-                        "J-uniq-shuffled, hit ratio 1.0, build side resident in HBM" % (npr, nb),
+                        "J-uniq-shuffled, hit ratio 1.0, build side resident in HBM%s" % (npr, nb, (
+                            "; build key range %d bits <= 28: packed route (2-byte entries against direct-address images) — keys beyond 28 bits (31 if unique) "
+                            "take the 64-bit route, see general_keys_64bit_route" % st.packed_key_bits) if packed else ""),
             "probe_rows_per_gpu": npr, "build_rows_per_gpu": nb,
             "parallelism": ("single GPU" if not distributed else
                             ("shared packed images x%d: every rank probes its own rows, the images are all-reduced once per build side (tsq_join_build_finish_shared)" % world
@@ -440,7 +442,7 @@ def main():
     if rho_check is not None:
         out["rho_0.5"] = rho_check
     traffic = traffic_part = traffic_src = None
-    for tf in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json"):  # PMC-derived HBM bytes per launch: measured offline (rocprofv3 --pmc passes), committed
+    for tf in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json"):  # PMC-derived HBM bytes per launch: measured offline (rocprofv3 --pmc passes), committed
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             w = tj["workload"]
@@ -583,6 +585,9 @@ def compact_line(full, limit=LINE_LIMIT):
     line = {k: _r(full.get(k), 6) for k in CONTRACT_KEYS}
     line["config"] = full.get("config")
     line["verified"] = full.get("verified")
+    wk = full.get("wide_keys_64bit_route")
+    if isinstance(wk, dict) and wk.get("rows_per_s") is not None:  # the same join with arbitrary int64 keys: never hidden behind the packed headline
+        line["general_keys_64bit_route"] = {"value": _r(wk["rows_per_s"]), "ms_per_step": _r(wk.get("ms_per_probe_pass")), "frac_at_24B_per_row": _r(wk.get("frac"), 3), "ok": wk.get("verified")}
     for k in ("dist_plan", "emulated_world", "wire_bytes_per_probe_row", "split_and_exchange_ms", "build_ms"):
         if full.get(k) is not None:
             line[k] = _r(full[k])

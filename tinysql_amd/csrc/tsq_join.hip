@@ -2134,7 +2134,7 @@ bool da_cols_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_
     // rows and column), big enough next to the build side for that preparation to amortise: a 4 Mi-row probe against 1e8 build rows
     // is better served by the routes that only read the table (the gate used to look at the batch alone)
     if (nrows < (4 << 20)) return false;
-    return j->da_cols_state == 1 || nrows * 4 >= j->bcols[j->ks.bidx[0]].rows;
+    return j->da_cols_state == 1 || j->dm_state == 1 || nrows * 4 >= j->bcols[j->ks.bidx[0]].rows;
 }
 
 // Round 4: the build side of the travelling-columns route in one partition pass + one sort pass (tsq_dajoin.h: k_da_coarse,

@@ -604,8 +604,9 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
     """BASELINE configs[2]: SELECT k, SUM(v), COUNT(*) GROUP BY k, 1e9 rows / 1e6 int64 groups; the rows are generated batch by
     batch on the device (untimed) and pushed device resident, like the chunks of a GPU child operator.  v = r mod 1000 (BIGINT:
     bit-exact SUM) or, double=True, a double in [0, 1) (BASELINE.md C3's primary shape).  Verified against numpy on host copies of the
-    value batches: sum of the groups' counts = rows, sum of the groups' sums = sum of all values (exact for BIGINT, within the
-    re-ordering bound 2 n 2^-53 sum|v| for doubles), every key in [0, groups) exactly once."""
+    key and value batches: EVERY group's count and sum against np.bincount (round 6; counts exact, sums exact for BIGINT and within the
+    re-ordering bound for doubles), sum of the groups' counts = rows, sum of the groups' sums = sum of all values, every key in [0, groups)
+    exactly once."""
     import numpy as np
 
     lib = ctx.lib
@@ -623,6 +624,8 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
         cfg.est_groups = groups
         runs = []
         want_sum, want_abs = 0, 0.0
+        want_cnt_g, want_sum_g = np.zeros(groups, dtype=np.int64), np.zeros(groups, dtype=np.float64)
+        got_cnt_g, got_sum_g = np.zeros(groups, dtype=np.int64), np.zeros(groups, dtype=np.float64)
         check = {}
         for run in range(2):  # the second run finds its partition / group buffers in the context's pool (hipMalloc costs ~35 ms per GB)
             h = C.c_void_p()
@@ -637,15 +640,20 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
                     else:
                         ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=3, col=1, m=1000, start=done), m, v)
                     ctx.sync()
-                    if run == 1:  # the independent total of the values (numpy on a host copy)
+                    if run == 1:  # the independent results (numpy on host copies): the total AND every group's count and sum (a sum
+                                  # credited to the wrong group passed the totals)
                         host = np.empty(m, dtype=np.float64 if double else np.int64)
+                        hk = np.empty(m, dtype=np.int64)
                         ctx.d2h(host, v)
+                        ctx.d2h(hk, k)
                         if double:
                             want_sum += float(host.sum(dtype=np.float64))
                             want_abs += float(np.abs(host).sum())
                         else:
                             want_sum += int(host.sum(dtype=np.int64))
-                        del host
+                        want_cnt_g += np.bincount(hk, minlength=groups)
+                        want_sum_g += np.bincount(hk, weights=host.astype(np.float64), minlength=groups)  # (BIGINT: r mod 1000 summed over <= 2^31 rows is exact in a double)
+                        del host, hk
                     ctx.timer_start()
                     _lib.check(lib.tsq_agg_push(h, (abi.Col * 2)(_dev_col(abi, k, m), _dev_col(abi, v, m, vt)), 2, m), h)
                     ms += ctx.timer_stop_ms()
@@ -680,15 +688,22 @@ def extra_c3(ctx, abi, _lib, n=1_000_000_000, groups=1_000_000, batch=250_000_00
                         ok = (kk >= 0) & (kk < groups)
                         bad_keys += int((~ok).sum())
                         np.add.at(keys_seen, kk[ok], 1)
+                        got_cnt_g[kk[ok]] = bufs[2][:nn.value][ok]
+                        got_sum_g[kk[ok]] = bufs[1][:nn.value][ok].astype(np.float64)
                         got_rows += nn.value
                         got_cnt += int(bufs[2][:nn.value].sum())
                         got_sum += float(bufs[1][:nn.value].sum()) if double else int(bufs[1][:nn.value].sum())
                     for pbuf in dbufs + dbms:
                         ctx.free(pbuf)
                     tol = 2.0 * n * 2.0 ** -53 * want_abs * 2 if double else 0
+                    # per group: counts exact; sums exact (BIGINT) or within the re-ordering bound 2 n_g 2^-53 sum_g|v| (v in [0, 1): sum_g|v| <= n_g)
+                    counts_ok = bool(np.array_equal(got_cnt_g, want_cnt_g))
+                    tol_g = 4.0 * want_cnt_g.astype(np.float64) ** 2 * 2.0 ** -53 if double else np.zeros(groups)
+                    sums_ok = bool((np.abs(got_sum_g - want_sum_g) <= tol_g).all())
                     check = {"groups_pulled": got_rows, "sum_of_counts": got_cnt, "sum_of_sums": got_sum, "sum_of_values_numpy": want_sum,
                              "every_key_once": bool(bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1),
-                             "ok": bool(got_cnt == n and abs(got_sum - want_sum) <= tol and bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1)}
+                             "every_count_equals_numpy_bincount": counts_ok, "every_sum_equals_numpy_bincount": sums_ok,
+                             "ok": bool(got_cnt == n and abs(got_sum - want_sum) <= tol and bad_keys == 0 and int(keys_seen.min()) == 1 and int(keys_seen.max()) == 1 and counts_ok and sums_ok)}
             finally:
                 lib.tsq_agg_destroy(h)
         ms = runs[-1]
