@@ -854,7 +854,8 @@ typedef struct tsq_stats {
                                       (handleDivisionByZeroError via executor/joiner.go:155-167) */
     int32_t packed_lds_bits;       /* join, ABI 7: log2 of the FINAL partitions of the last materialising packed batch whose build side sat in LDS
                                       (csrc/tsq_damat.h: two partition levels, ranked payload tables); 0: the batch took another variant */
-    int32_t reserved0;
+    int32_t keyrec_digests;        /* join, ABI 7: 1 when the key-record route keeps string cells that do not fit a record as (length, 64-bit digest)
+                                      and compares the bytes of every candidate match (long string keys), 0 otherwise */
 } tsq_stats;
 #define TSQ_ROUTE_DIRECT     0   /* k_probe_count / k_probe_emit on the table in HBM */
 #define TSQ_ROUTE_RADIX_L2   1   /* radix partition, table slices through the XCD's L2 */

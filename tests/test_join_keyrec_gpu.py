@@ -105,11 +105,12 @@ def test_records_that_do_not_fit_and_partitions_that_do_not_fit(ctx, orc):
     want = orc.hash_join(cfg, build, probe).NumRows()
     got, st = _count(ctx, cfg, build, probe)
     assert st.probe_route == abi.ROUTE_KEYREC and got == want > 0
-    # (2) a BUILD row that does not fit: the whole join keeps the direct route
+    assert st.keyrec_digests == 0
+    # (2) a BUILD row that does not fit (round 6): the string cells enter the records as (length, digest), every candidate is compared byte for byte
     build2 = Chunk([build.columns[0], StrColumn([short(i) if i % 1000 else short(i) * 8 for i in ids_b.tolist()]), build.columns[2]])
     want2 = orc.hash_join(cfg, build2, probe).NumRows()
     got2, st2 = _count(ctx, cfg, build2, probe)
-    assert st2.probe_route == abi.ROUTE_DIRECT and got2 == want2
+    assert st2.probe_route == abi.ROUTE_KEYREC and st2.keyrec_digests == 1 and got2 == want2 > want
     # (3) one key with 18 000 build rows: its partition exceeds the index in LDS (12 288 records) -> direct route, exact
     hot = np.where(rng.random(nb) < 0.6, 4242, ids_b)
     build3 = Chunk([Column(abi.I64, hot % 7), StrColumn([short(i) for i in hot.tolist()]), build.columns[2]])
@@ -230,3 +231,66 @@ def test_golden_join_cases_on_two_key_columns(ctx, case):
     assert H.rows_equal_unordered(got, want), case["ref"]
     if not conds and (len(case["left"]) and len(case["right"])):
         assert stats[0].probe_route == abi.ROUTE_KEYREC, (case["ref"], stats[0].probe_route)
+
+
+# ------------------------------------------------------------------ long string keys (round 6): digest records + byte-for-byte verification
+def _long_words(rng, pool, lo=40, hi=5000):
+    # lengths 40..5000 (most of them short, one in ten long); families of words that share their length AND all bytes but the last one
+    words = []
+    while len(words) < pool:
+        n = int(rng.integers(lo, 200)) if rng.random() < 0.9 else int(rng.integers(200, hi + 1))
+        w = bytes(rng.integers(97, 123, n, dtype=np.uint8))
+        words.append(w)
+        if rng.random() < 0.2:
+            words.append(w[:-1] + bytes([(w[-1] - 97 + 1) % 26 + 97]))  # the same length, the same first n - 1 bytes
+    return words[:pool]
+
+
+def test_long_string_keys_1e6_rows_vs_oracle(ctx, orc):
+    # the reference's benchmark keys on a 5 KiB varstring (executor/benchmark_test.go:328-360): cells that do not fit a 32-byte record enter it
+    # as (length, digest) and every candidate match is compared byte for byte (codec.EqualChunkRow, codec.go:363-382).  1e6 probe rows x
+    # 2e5 build rows, keys of 40..5000 bytes, (bigint, varstring) and varstring alone; COUNT(*) and the joined rows' checksum
+    rng = np.random.default_rng(1001)
+    nb, npr, pool = 200_000, 1_000_000, 150_000
+    words = _long_words(rng, pool)
+    bw = [None if rng.random() < 0.02 else words[i] for i in rng.integers(0, pool, nb).tolist()]
+    pid = rng.integers(0, int(pool * 1.3), npr)
+    extra = [b"q" + w for w in words[:int(pool * 0.3)]]  # probe-only words: 23 % of the probe rows find no build row
+    allw = words + extra
+    pw = [None if rng.random() < 0.02 else allw[i] for i in pid.tolist()]
+    build = Chunk([Column(abi.I64, rng.integers(0, 3, nb)), StrColumn(bw), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([Column(abi.I64, rng.integers(0, 3, npr)), StrColumn(pw), Column(abi.F64, rng.random(npr))])
+    for keys in ([0, 1], [1]):
+        cfg = H.join_cfg(probe.types(), build.types(), keys, keys, abi.JOIN_INNER, 1)
+        want = orc.hash_join(cfg, build, probe)
+        got, st = _count(ctx, cfg, build, probe)
+        assert st.probe_route == abi.ROUTE_KEYREC and st.keyrec_digests == 1 and got == want.NumRows() > 100_000, (st.probe_route, got, want.NumRows())
+        got0, st0 = _count(ctx, cfg, build, probe, radix=OFF)  # the direct route says the same
+        assert st0.probe_route == abi.ROUTE_DIRECT and got0 == got
+        stats = []
+        rows = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 16, radix=FORCE, stats_out=stats)  # materialised on the key-record route
+        assert stats[0].probe_route == abi.ROUTE_KEYREC and stats[0].keyrec_digests == 1 and rows.NumRows() == want.NumRows()
+        # the fixed-width cells through the oracle's row checksum (the build row's id is one of them); the string cells: a joined row
+        # carries the same word on both sides, and it is the word of that build row
+        fixed = lambda ch: Chunk([c for c in ch.columns if not isinstance(c, StrColumn)])  # noqa: E731
+        assert orc.rows_checksum(fixed(rows)) == orc.rows_checksum(fixed(want))
+        gp, gb = rows.columns[1].values(), rows.columns[4].values()
+        assert gp == gb and gb == [bw[i] for i in rows.columns[5].data.tolist()]
+
+
+@pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
+def test_long_string_keys_rows_small(ctx, orc, jt):
+    # row-for-row at a size Python compares: equal-length words that differ in their last byte only, NULL keys, the empty string, an
+    # outer join's padded rows; several probe batches against one set of build records
+    rng = np.random.default_rng(77 + jt)
+    words = _long_words(rng, 300, lo=33, hi=900) + [b"", b"x" * 33, b"x" * 32 + b"y"]
+    nb, npr = 2_000, 9_000
+    build = Chunk([StrColumn([None if rng.random() < 0.03 else words[i] for i in rng.integers(0, 200, nb).tolist()]), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([StrColumn([None if rng.random() < 0.03 else words[i] for i in rng.integers(0, len(words), npr).tolist()]), Column(abi.I64, np.arange(npr)),
+                   Column(abi.F64, rng.random(npr), rng.random(npr) > 0.1)])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], jt, 1, probe_batch_rows=4_096)
+    want = orc.hash_join(cfg, build, probe)
+    stats = []
+    got = G.run_join(ctx, cfg, build, probe, chunk_rows=4_096, pull_rows=1 << 14, radix=FORCE, stats_out=stats)
+    assert stats[0].probe_route == abi.ROUTE_KEYREC and stats[0].radix_batches >= 3
+    assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)

@@ -150,7 +150,7 @@ class Stats(C.Structure):
         ("heap_bytes", C.c_int64), ("heap_compactions", C.c_int64),
         ("shared_build", C.c_int32), ("dense_flushes", C.c_int32), ("shared_image_bytes", C.c_int64), ("shared_allreduce_ms", C.c_double),
         ("div_by_zero_warnings", C.c_int64),
-        ("packed_lds_bits", C.c_int32), ("reserved0", C.c_int32),
+        ("packed_lds_bits", C.c_int32), ("keyrec_digests", C.c_int32),
     ]
 
 

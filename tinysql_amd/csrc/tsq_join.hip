@@ -788,6 +788,9 @@ struct tsq_join {
     int kr_state = 0;                 // 0: not tried, 1: the build side's records are in place, -1: not usable for this build side
     uint32_t kr_pbits = 0;
     DevBuf kr_brec, kr_bstart, kr_counts, kr_prec, kr_pstart, kr_flags, kr_bids, kr_pids, kr_pcnt, kr_norec;
+    // long string keys (round 6): the string key columns enter the records as (length, digest of the bytes); matches are verified byte for byte
+    bool kr_digest = false;
+    DevBuf kr_bdig[TSQ_MAX_KEYS], kr_pdig[TSQ_MAX_KEYS];
     bool filters_folded = false;      // this batch: the outer-side filters are already in the selected[] flags the packed routes take (fold_outer_filters)
     DevBuf fflags;                    //   ... those flags
     DevBuf heads;                     // da_emit_cols: first-candidate flags of a batch (outer join + conditions + duplicate build keys)
@@ -3644,12 +3647,40 @@ bool kr_count_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected
     const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
     if (nb <= 0 || nb > (int64_t)TSQ_KR_MAXP * TSQ_KR_FILL) return false;  // (larger build sides: the partitions would not fit the LDS tables)
     if (j->radix_mode == TSQ_RADIX_FORCE) return true;
-    return nrows >= (1 << 18) && nb >= (1 << 18);
+    return nrows >= (1 << 16) && nb >= (1 << 16);
 }
 // hist -> offsets -> scan [-> check] -> scatter of one side.  `check`: read the flags after the scan (a synchronisation): *ok = every
 // record fits and no partition holds more than TSQ_KR_CAP of them
+// the digests of the string key columns of one side (digest mode): dig[k] <- k_kr_digest of column key_cols[k]
+tsq_status kr_digests(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, int64_t nrows, DevBuf* dig) {
+    tsq_ctx* ctx = j->ctx;
+    tsq_handle_hdr* h = &j->hdr;
+    for (int k = 0; k < j->ks.n_keys; k++) {
+        const int c = key_cols[k];
+        if (cs.type[c] != TSQ_BYTES) continue;
+        TSQ_TRY(dig[k].reserve(ctx, h, (size_t)nrows * 8 + 64));
+        KrDigestArgs da;
+        memset(&da, 0, sizeof da);
+        da.data = (const uint8_t*)cs.data[c];
+        da.offs = cs.offs[c];
+        da.nulls = cs.nulls[c];
+        da.nrows = nrows;
+        da.out = dig[k].as<uint64_t>();
+        // long cells: a wave per row (the host knows the average length from the offsets' ends)
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 43, cs.offs[c], 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 44, cs.offs[c] + nrows, 8, hipMemcpyDeviceToHost, ctx->stream));
+        TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
+        const int64_t bytes = (int64_t)ctx->pinned[44] - (int64_t)ctx->pinned[43];
+        if (nrows > 0 && bytes / nrows >= 64) hipLaunchKernelGGL(k_kr_digest<true>, dim3(tsq_grid_for(ctx, nrows * 64, 256)), dim3(256), 0, ctx->stream, da);
+        else hipLaunchKernelGGL(k_kr_digest<false>, dim3(tsq_grid_for(ctx, nrows, 256)), dim3(256), 0, ctx->stream, da);
+        TSQ_HIP(h, hipGetLastError());
+        j->st.kernel_launches++;
+    }
+    return TSQ_OK;
+}
 tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, int64_t nrows, uint32_t pbits, DevBuf& counts, DevBuf& pstart, DevBuf& rec,
-                   bool check, bool* ok, DevBuf* ids = nullptr, const uint8_t* selected = nullptr, bool list_rows_without_key = false) {
+                   bool check, bool* ok, DevBuf* ids = nullptr, const uint8_t* selected = nullptr, bool list_rows_without_key = false, const DevBuf* dig = nullptr,
+                   bool* toolong_out = nullptr) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     const uint32_t P = 1u << pbits;
@@ -3664,6 +3695,10 @@ tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, i
         int32_t kt[TSQ_MAX_KEYS];
         for (int k = 0; k < j->ks.n_keys; k++) kt[k] = cs.type[key_cols[k]];
         a.src.layout = kr_layout_of(kt, j->ks.n_keys);
+    }
+    if (dig) {  // digest mode: the string cells as (length, digest); run-time cell positions
+        a.src.layout = 0;
+        for (int k = 0; k < j->ks.n_keys; k++) a.src.digest[k] = cs.type[key_cols[k]] == TSQ_BYTES ? dig[k].as<uint64_t>() : nullptr;
     }
     a.pbits = pbits;
     const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;
@@ -3703,6 +3738,7 @@ tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, i
         TSQ_HIP(h, hipStreamSynchronize(ctx->stream));
         const uint32_t* f = (const uint32_t*)(ctx->pinned + 40);
         *ok = (f[0] & 1u) == 0 && f[1] <= TSQ_KR_CAP;
+        if (toolong_out) *toolong_out = (f[0] & 1u) != 0;
         if (!*ok) return TSQ_OK;
     }
     hipLaunchKernelGGL(k_kr_scatter, dim3(a.n_wg), dim3(TSQ_KR_NT), lds, ctx->stream, a);
@@ -3716,11 +3752,29 @@ tsq_status kr_prepare(tsq_join* j) {
     const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
     uint32_t pbits = 0;
     while (((int64_t)1 << pbits) * TSQ_KR_FILL < nb && (1u << pbits) < TSQ_KR_MAXP) pbits++;  // ~8192 build records per partition (half of them at the power of two above)
+    while (pbits < 9 && ((int64_t)256 << pbits) <= nb) pbits++;  // ... and two workgroups for every CU while a partition keeps 128 records or more (one partition = one workgroup)
     tsq_colset bcs;
     tsq_fill_colset(bcs, j->bcols);
-    bool ok = false;
-    const tsq_status s = kr_pass(j, bcs, j->ks.bidx, nb, pbits, j->kr_counts, j->kr_bstart, j->kr_brec, true, &ok, &j->kr_bids);
+    bool ok = false, toolong = false;
+    tsq_status s = kr_pass(j, bcs, j->ks.bidx, nb, pbits, j->kr_counts, j->kr_bstart, j->kr_brec, true, &ok, &j->kr_bids, nullptr, false, nullptr, &toolong);
+    if (s == TSQ_OK && !ok && toolong) {
+        // a key that does not fit a record: its string cells as (length, digest of the bytes) — 13 bytes each — and the matches verified
+        // byte for byte (the reference's own benchmark joins on a 5 KiB varstring, executor/benchmark_test.go:328-360)
+        bool any_str = false;
+        uint32_t need = 0;
+        for (int k = 0; k < j->ks.n_keys; k++) {
+            const bool str = j->cfg.build_types[j->ks.bidx[k]] == TSQ_BYTES;
+            any_str = any_str || str;
+            need += str ? TSQ_KR_DIGEST_CELL : 9u;
+        }
+        if (any_str && need <= TSQ_KR_BYTES) {
+            s = kr_digests(j, bcs, j->ks.bidx, nb, j->kr_bdig);
+            if (s == TSQ_OK) s = kr_pass(j, bcs, j->ks.bidx, nb, pbits, j->kr_counts, j->kr_bstart, j->kr_brec, true, &ok, &j->kr_bids, nullptr, false, j->kr_bdig);
+            j->kr_digest = s == TSQ_OK && ok;
+        }
+    }
     if (s != TSQ_OK || !ok) {
+        for (auto& b : j->kr_bdig) b.release();
         j->kr_bids.release();  // a key that does not fit a record, or a partition too large for LDS (one key with thousands of rows): the other routes keep this join
         for (DevBuf* b : {&j->kr_counts, &j->kr_bstart, &j->kr_brec}) b->release();
         return s;
@@ -3729,11 +3783,34 @@ tsq_status kr_prepare(tsq_join* j) {
     j->kr_state = 1;
     return TSQ_OK;
 }
+static void kr_launch_probe(tsq_ctx* ctx, uint32_t grid, const KrProbeArgs& pa) {
+    if (pa.n_verify) hipLaunchKernelGGL(k_kr_probe<true>, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
+    else hipLaunchKernelGGL(k_kr_probe<false>, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
+}
+// digest mode: what the probe kernel compares byte for byte — the string key columns of both sides
+void kr_verify_args(tsq_join* j, const tsq_colset& pcs, KrProbeArgs& pa) {
+    if (!j->kr_digest) return;
+    for (int k = 0; k < j->ks.n_keys; k++) {
+        const int bc = j->ks.bidx[k], pc = j->ks.pidx[k];
+        if (j->cfg.build_types[bc] != TSQ_BYTES) continue;
+        const int v = pa.n_verify++;
+        pa.vb_data[v] = j->bcols[bc].data.as<uint8_t>();
+        pa.vb_offs[v] = j->bcols[bc].offs.as<int64_t>();
+        pa.vp_data[v] = (const uint8_t*)pcs.data[pc];
+        pa.vp_offs[v] = pcs.offs[pc];
+    }
+    pa.bids = j->kr_bids.as<uint32_t>();
+    pa.pids = j->kr_pids.as<uint32_t>();
+}
 tsq_status kr_count_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     tsq_ctx* ctx = j->ctx;
     tsq_handle_hdr* h = &j->hdr;
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     bool ok = true;
+    if (j->kr_digest) {
+        TSQ_TRY(kr_digests(j, pcs, j->ks.pidx, nrows, j->kr_pdig));
+        TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok, &j->kr_pids, nullptr, false, j->kr_pdig));
+    } else
     TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok));
     KrProbeArgs pa;
     memset(&pa, 0, sizeof pa);
@@ -3744,14 +3821,16 @@ tsq_status kr_count_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows) {
     pa.P = 1u << j->kr_pbits;
     pa.counters = j->counters.as<unsigned long long>();
     pa.flags = j->kr_flags.as<uint32_t>();
+    kr_verify_args(j, pcs, pa);
     const int grid = (int)std::min<uint32_t>(pa.P, (uint32_t)ctx->num_cus * 2);
-    hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
+    kr_launch_probe(ctx, grid, pa);
     TSQ_HIP(h, hipGetLastError());
     TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
     j->have_probe_ev = true;
     j->st.kernel_launches++;
     j->st.radix_batches++;
     j->st.radix_bits = (int32_t)j->kr_pbits;
+    j->st.keyrec_digests = j->kr_digest ? 1 : 0;
     j->st.probe_route = TSQ_ROUTE_KEYREC;
     return TSQ_OK;
 }
@@ -3767,7 +3846,7 @@ bool kr_emit_eligible(const tsq_join* j, int64_t nrows, const uint8_t* selected_
     const int64_t nb = j->bcols[j->ks.bidx[0]].rows;
     if (nb <= 0 || nb > (int64_t)TSQ_KR_MAXP * TSQ_KR_FILL || nb > 0xffffffffLL) return false;
     if (j->radix_mode == TSQ_RADIX_FORCE) return true;
-    return nrows >= (1 << 18) && nb >= (1 << 18);
+    return nrows >= (1 << 16) && nb >= (1 << 16);
 }
 tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64_t nrows, const uint8_t* selected_dev) {
     tsq_ctx* ctx = j->ctx;
@@ -3775,7 +3854,8 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     bool ok = true;
     const bool outer = j->cfg.join_type != TSQ_JOIN_INNER;
-    TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok, &j->kr_pids, selected_dev, outer));
+    if (j->kr_digest) TSQ_TRY(kr_digests(j, pcs, j->ks.pidx, nrows, j->kr_pdig));
+    TSQ_TRY(kr_pass(j, pcs, j->ks.pidx, nrows, j->kr_pbits, j->kr_counts, j->kr_pstart, j->kr_prec, false, &ok, &j->kr_pids, selected_dev, outer, j->kr_digest ? j->kr_pdig : nullptr));
     KrProbeArgs pa;
     memset(&pa, 0, sizeof pa);
     pa.brec = j->kr_brec.as<unsigned long long>();
@@ -3788,12 +3868,13 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     pa.bids = j->kr_bids.as<uint32_t>();
     pa.pids = j->kr_pids.as<uint32_t>();
     pa.outer = outer ? 1 : 0;
+    kr_verify_args(j, pcs, pa);
     // sizing launch: joined rows per partition; their exclusive scan = every partition's first output row
     TSQ_TRY(j->kr_pcnt.reserve(ctx, h, ((size_t)pa.P + 1) * 8 + 64));
     pa.part_cnt = j->kr_pcnt.as<unsigned long long>();
     TSQ_HIP(h, hipMemsetAsync(pa.part_cnt, 0, ((size_t)pa.P + 1) * 8, ctx->stream));  // (partitions without rows on one side are skipped by the kernel)
     const int grid = (int)std::min<uint32_t>(pa.P, (uint32_t)ctx->num_cus * 2);
-    hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);  // pairs == nullptr
+    kr_launch_probe(ctx, grid, pa);  // pairs == nullptr
     TSQ_HIP(h, hipGetLastError());
     hipLaunchKernelGGL(k_kr_scan64, dim3(1), dim3(1024), 0, ctx->stream, pa.part_cnt, pa.P);
     TSQ_HIP(h, hipGetLastError());
@@ -3806,6 +3887,7 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     j->st.kernel_launches += 2;
     j->st.radix_batches++;
     j->st.radix_bits = (int32_t)j->kr_pbits;
+    j->st.keyrec_digests = j->kr_digest ? 1 : 0;
     j->st.probe_route = TSQ_ROUTE_KEYREC;
     if (out_rows == 0) {
         TSQ_HIP(h, hipEventRecord(j->ev[3], ctx->stream));
@@ -3814,7 +3896,7 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     }
     return materialise_pairs(j, pcs, a, nrows, out_rows, [&]() -> tsq_status {
         pa.pairs = a.pairs;
-        hipLaunchKernelGGL(k_kr_probe, dim3(grid), dim3(TSQ_KR_PNT), 0, ctx->stream, pa);
+        kr_launch_probe(ctx, grid, pa);
         TSQ_HIP(h, hipGetLastError());
         j->st.kernel_launches++;
         if (keyless > 0) {
@@ -5015,6 +5097,10 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     j->rckey.release();
     for (DevBuf* b : {&j->da_coarse, &j->da_pstart, &j->da_coarse_c, &j->da_pstart_c, &j->da_brows, &j->ridx, &j->rovfidx, &j->rmiss, &j->rnnmask}) b->release();
     for (DevBuf* b : {&j->kr_brec, &j->kr_bstart, &j->kr_counts, &j->kr_prec, &j->kr_pstart, &j->kr_flags, &j->kr_bids, &j->kr_pids, &j->kr_pcnt, &j->kr_norec}) b->release();
+    for (int k = 0; k < TSQ_MAX_KEYS; k++) {
+        j->kr_bdig[k].release();
+        j->kr_pdig[k].release();
+    }
     for (DevBuf* b : {&j->dm_bent, &j->dm_bnn, &j->dm_boff, &j->dm_bcnt, &j->dm_bitmap, &j->dm_pent, &j->dm_pnn, &j->dm_poff, &j->dm_pcnt}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {
         j->da_bsorted[c].release();

@@ -60,6 +60,63 @@ struct KrArgs {
     unsigned long long* norec_count;
 };
 
+// the digests of a string column's cells (KrSrc.digest): WAVE = one wave per row (long cells: the lanes take the cell's words in turn,
+// 512 contiguous bytes per step), else one lane per row
+struct KrDigestArgs {
+    const uint8_t* data;
+    const int64_t* offs;
+    const uint8_t* nulls;
+    int64_t nrows;
+    uint64_t* out;
+};
+template <bool WAVE>
+static __global__ void __launch_bounds__(256) k_kr_digest(KrDigestArgs a) {
+    const uint32_t lane = WAVE ? (threadIdx.x & 63u) : 0u, step = WAVE ? 64u : 1u;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+    for (int64_t r = WAVE ? (t >> 6) : t; r < a.nrows; r += WAVE ? (nt >> 6) : nt) {
+        if (tsq_is_null(a.nulls, r)) {
+            if (lane == 0) a.out[r] = 0;
+            continue;
+        }
+        const int64_t o = a.offs[r], n = a.offs[r + 1] - o;
+        const uint8_t* p = a.data + o;
+        const uint32_t nw = (uint32_t)((n + 7) >> 3);
+        uint64_t sum = 0;
+        for (uint32_t i = lane; i < nw; i += step) {
+            const uint32_t m = (uint64_t)n - 8ull * i < 8ull ? (uint32_t)((uint64_t)n - 8ull * i) : 8u;
+            uint64_t v = kr_load8(p + 8ull * i, m);
+            if (m < 8u) v &= (1ull << (8u * m)) - 1ull;
+            sum += kr_digest_word(v, i);
+        }
+        if (WAVE) sum = wave_sum_u64(sum);
+        if (lane == 0) a.out[r] = kr_digest_finish(sum, (uint64_t)n);
+    }
+}
+// are the n bytes at x and y the same?  Asked by a whole wave with the same arguments (the matches of digest records are checked byte for
+// byte — the lengths are equal already): lane l compares words l, l + 64, l + 128, l + 192 of each round of 2 KiB
+__device__ __forceinline__ bool kr_wave_bytes_equal(const uint8_t* x, const uint8_t* y, uint64_t n, uint32_t lane) {
+    const uint64_t nw = (n + 7) >> 3;
+    for (uint64_t i0 = 0; i0 < nw; i0 += 256) {
+        bool diff = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = i0 + 64u * u + lane;
+            if (i < nw) {
+                const uint32_t m = n - 8 * i < 8 ? (uint32_t)(n - 8 * i) : 8u;
+                uint64_t a = kr_load8(x + 8 * i, m), b = kr_load8(y + 8 * i, m);
+                if (m < 8u) {
+                    const uint64_t mask = (1ull << (8u * m)) - 1ull;
+                    a &= mask;
+                    b &= mask;
+                }
+                diff = diff || a != b;
+            }
+        }
+        if (__ballot(diff)) return false;
+    }
+    return true;
+}
+
 // counts[wg][p]: how many rows of workgroup wg's chunk belong to partition p (an LDS histogram, written out coalesced)
 static __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_hist(KrArgs a) {
     extern __shared__ uint32_t s_hist[];
@@ -201,6 +258,13 @@ struct KrProbeArgs {
                                     // row chip-wide: 55 ms for 5e6 rows)
     uint32_t* flags;                 // [0] |= 2: a partition with more than TSQ_KR_CAP build records (cannot happen after the host's check)
     int32_t outer;                   // materialising an outer join: a probe record without a joined build row makes one pair (probe row, TSQ_KR_MISS)
+    // digest records (long string keys): equal records are candidates — the cells of these string columns are compared byte for byte
+    // (build row bids[..], probe row pids[..]: both kept in this mode)
+    int32_t n_verify;
+    const uint8_t* vb_data[TSQ_MAX_KEYS];
+    const int64_t* vb_offs[TSQ_MAX_KEYS];
+    const uint8_t* vp_data[TSQ_MAX_KEYS];
+    const int64_t* vp_offs[TSQ_MAX_KEYS];
 };
 #define TSQ_KR_MISS 0xffffffffull
 // One workgroup per partition.  The build records of the partition stay where the scatter pass put them (a contiguous window of
@@ -208,6 +272,7 @@ struct KrProbeArgs {
 // record one entry (tag = 18 bits of the mix that neither chose the partition nor the slot, 14-bit record number).  A probe record
 // walks the slots from its home until an empty one; on a tag match the build record's four words are compared (a false tag match
 // costs one more 32-byte read, 2^-18 per slot looked at).  Duplicate build keys are separate entries (the multimap of rowHashMap).
+template <bool VERIFY>
 static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
     __shared__ uint32_t s_tab[TSQ_KR_SLOTS];
     __shared__ unsigned long long s_cnt;
@@ -238,34 +303,97 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
             while (atomicCAS(&s_tab[slot], 0xffffffffu, entry) != 0xffffffffu) slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
         }
         __syncthreads();
-        for (uint64_t r = p0 + tid; r < p1; r += TSQ_KR_PNT) {
-            const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
-            const ulonglong2 x = s[0], y = s[1];
-            const uint64_t w[4] = {x.x, x.y, y.x, y.y};
-            const uint64_t h = kr_hash(w);
-            const uint32_t tag = (uint32_t)(h >> 14) & 0x3ffffu;
-            uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
-            bool any = false;
-            for (;;) {
-                const uint32_t e = s_tab[slot];
-                if (e == 0xffffffffu) break;
-                if ((e >> 14) == tag) {
-                    const ulonglong2* bq = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + (e & 0x3fffu)) * 4);
-                    const ulonglong2 bx = bq[0], by = bq[1];
-                    if (bx.x == w[0] && bx.y == w[1] && by.x == w[2] && by.y == w[3]) {
-                        any = true;
-                        mine++;
-                        if (a.part_cnt) {  // materialising: count per partition (sizing), or the pair at the partition's next output row (emit)
-                            const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
-                            if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)a.pids[r] | ((unsigned long long)a.bids[b0 + (e & 0x3fffu)] << 32);
+        if (!VERIFY) {
+            for (uint64_t r = p0 + tid; r < p1; r += TSQ_KR_PNT) {
+                const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
+                const ulonglong2 x = s[0], y = s[1];
+                const uint64_t w[4] = {x.x, x.y, y.x, y.y};
+                const uint64_t h = kr_hash(w);
+                const uint32_t tag = (uint32_t)(h >> 14) & 0x3ffffu;
+                uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
+                bool any = false;
+                for (;;) {
+                    const uint32_t e = s_tab[slot];
+                    if (e == 0xffffffffu) break;
+                    if ((e >> 14) == tag) {
+                        const ulonglong2* bq = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + (e & 0x3fffu)) * 4);
+                        const ulonglong2 bx = bq[0], by = bq[1];
+                        bool same = bx.x == w[0] && bx.y == w[1] && by.x == w[2] && by.y == w[3];
+                        if (same) {
+                            any = true;
+                            mine++;
+                            if (a.part_cnt) {  // materialising: count per partition (sizing), or the pair at the partition's next output row (emit)
+                                const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
+                                if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)a.pids[r] | ((unsigned long long)a.bids[b0 + (e & 0x3fffu)] << 32);
+                            }
                         }
                     }
+                    slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
                 }
-                slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
+                if (a.outer && !any) {  // onMissMatch: the outer row once, NULL-padded
+                    const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
+                    if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)a.pids[r] | (TSQ_KR_MISS << 32);
+                }
             }
-            if (a.outer && !any) {  // onMissMatch: the outer row once, NULL-padded
-                const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
-                if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)a.pids[r] | (TSQ_KR_MISS << 32);
+        } else {
+            // digest records: a record match says "same lengths, same digests" — the bytes are compared by the whole wave, one candidate
+            // at a time (64 lanes x 8 bytes of each side per load: a 5 KiB key is ten loads, not 640 dependent ones of one lane), so
+            // every lane of the wave walks its slots in step with the others
+            const uint32_t lane = tid & 63u;
+            for (uint64_t rb = p0 + (tid & ~63u); rb < p1; rb += TSQ_KR_PNT) {  // (wave-uniform)
+                const uint64_t r = rb + lane;
+                const bool valid = r < p1;
+                uint64_t w[4] = {0, 0, 0, 0};
+                if (valid) {
+                    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(a.prec + r * 4);
+                    const ulonglong2 x = s[0], y = s[1];
+                    w[0] = x.x, w[1] = x.y, w[2] = y.x, w[3] = y.y;
+                }
+                const uint64_t h = kr_hash(w);
+                const uint32_t tag = (uint32_t)(h >> 14) & 0x3ffffu;
+                uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
+                const uint32_t prow = valid ? a.pids[r] : 0u;
+                bool any = false, walking = valid;
+                while (__ballot(walking)) {
+                    bool cand = false;
+                    uint32_t bi = 0, brow = 0;
+                    if (walking) {
+                        const uint32_t e = s_tab[slot];
+                        if (e == 0xffffffffu) {
+                            walking = false;
+                        } else if ((e >> 14) == tag) {
+                            bi = e & 0x3fffu;
+                            const ulonglong2* bq = reinterpret_cast<const ulonglong2*>(a.brec + (b0 + bi) * 4);
+                            const ulonglong2 bx = bq[0], by = bq[1];
+                            cand = bx.x == w[0] && bx.y == w[1] && by.x == w[2] && by.y == w[3];
+                            if (cand) brow = a.bids[b0 + bi];
+                        }
+                    }
+                    bool same = cand;
+                    for (uint64_t need = __ballot(cand); need; need &= need - 1) {
+                        const int L = __builtin_ctzll(need);
+                        const uint64_t vb = (uint32_t)__shfl((int)brow, L), vp = (uint32_t)__shfl((int)prow, L);
+                        bool eq = true;
+                        for (int v = 0; v < a.n_verify && eq; v++) {
+                            const int64_t bo = a.vb_offs[v][vb], po = a.vp_offs[v][vp];
+                            eq = kr_wave_bytes_equal(a.vb_data[v] + bo, a.vp_data[v] + po, (uint64_t)(a.vb_offs[v][vb + 1] - bo), lane);
+                        }
+                        if ((int)lane == L) same = eq;
+                    }
+                    if (same) {
+                        any = true;
+                        mine++;
+                        if (a.part_cnt) {
+                            const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
+                            if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)prow | ((unsigned long long)brow << 32);
+                        }
+                    }
+                    if (walking) slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
+                }
+                if (a.outer && valid && !any) {
+                    const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
+                    if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)prow | (TSQ_KR_MISS << 32);
+                }
             }
         }
         if (a.part_cnt && !a.pairs) {

@@ -18,7 +18,24 @@ struct KrSrc {
     int32_t layout;          // kr_layout_of(): 0 = any key columns; else the cells' byte positions are compile-time constants (kr_record_fixed)
     const uint8_t* selected; // nullptr or one byte per row: 0 = the row has no key (an outer-side filter said no, join.go:344)
     int64_t nrows;
+    // round 6, LONG string keys (the reference's own benchmark joins on a 5 KiB varstring, executor/benchmark_test.go:328-360): digest[k] !=
+    // nullptr -> the cell of string key column k enters the record as flag 3 | length (4 bytes) | 64-bit digest of its bytes (digest[k][row],
+    // k_kr_digest) instead of its bytes — 13 bytes whatever the length.  Equal records then mean "equal lengths and digests": the probe
+    // kernel compares the bytes themselves before it counts a match (KrProbeArgs.n_verify), so the result is exact.
+    const uint64_t* digest[TSQ_MAX_KEYS];
 };
+#define TSQ_KR_DIGEST_CELL 13u
+// the digest of a cell's bytes: the cell as little-endian 8-byte words (the last one zero-padded), word i mixed with its position, the
+// mixes SUMMED (any order: a wave takes a long cell's words lane by lane), the length folded in at the end
+TSQ_HD uint64_t kr_digest_word(uint64_t w, uint32_t i) {
+    uint64_t x = (w ^ ((uint64_t)(i + 1u) * 0x9E3779B97F4A7C15ULL)) * 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 29;
+    return x * 0x94D049BB133111EBULL;
+}
+TSQ_HD uint64_t kr_digest_finish(uint64_t sum, uint64_t len) {
+    uint64_t h = (sum ^ (len * 0xD6E8FEB86659FD93ULL)) * 0xFF51AFD7ED558CCDULL;
+    return h ^ (h >> 32);
+}
 #define TSQ_KR_MAXPAY 4
 // Cell sizes: an 8-byte cell takes 9 bytes (flag + word), a string 2 + its bytes (flag 2, length, bytes).  A NULL cell of a GROUP BY
 // key takes the same room as a value's fixed part — 9 zero bytes, or 2 — so that the cells of a key with at most one string column,
@@ -71,9 +88,18 @@ TSQ_HD bool kr_record_any(const KrSrc& s, int64_t row, uint64_t (&w)[4], bool* t
         const bool str = s.cs.type[c] == TSQ_BYTES;
         if (tsq_is_null(s.cs.nulls[c], row)) {
             if (!s.keep_nulls) return false;
-            const uint32_t room = str ? 2u : 9u;  // NilFlag = 0 and zero bytes: the record's bytes are zero already (every value starts with a non-zero flag)
+            const uint32_t room = str ? (s.digest[k] ? TSQ_KR_DIGEST_CELL : 2u) : 9u;  // NilFlag = 0 and zero bytes: the record's bytes are zero already (every value starts with a non-zero flag)
             if (at + room > TSQ_KR_BYTES) { *toolong = true; return false; }
             at += room;
+            continue;
+        }
+        if (str && s.digest[k]) {  // a long string: flag 3, its length, the digest of its bytes
+            if (at + TSQ_KR_DIGEST_CELL > TSQ_KR_BYTES) { *toolong = true; return false; }
+            const uint64_t n = (uint64_t)(s.cs.offs[c][row + 1] - s.cs.offs[c][row]);
+            if (n >> 32) { *toolong = true; return false; }
+            kr_put(w, at, 3ull | (n << 8), 5);
+            kr_put(w, at + 5, s.digest[k][row], 8);
+            at += TSQ_KR_DIGEST_CELL;
             continue;
         }
         if (str) {
