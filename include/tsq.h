@@ -149,6 +149,7 @@ enum {
     TSQ_KNOB_DENSE_DIRECT = 31,      /* 0: the packed aggregate's dense state always leaves through partial groups and the hash table, also when the table is empty (k_dense_finalize off) */
     TSQ_KNOB_DA_LDS_BUILD = 32,      /* 0: the materialising packed join never keeps a partition's build rows in LDS (csrc/tsq_damat.h): unique build sides take the sorted-build-columns variant of round 4 like the others; 2 .. 5 (tests): the second partition level splits 1 / 2 / 4 / 8 ways whatever the build side's size */
     TSQ_KNOB_AGG_PG = 33,            /* 0: an aggregate with about as many groups as rows never keeps its groups in partitioned LDS-sized sub-tables (csrc/tsq_aggfast.h K7p): the row upsert serves it; v >= 2 (tests): the mode is taken whatever the estimate, with 2^(v - 2) sub-tables */
+    TSQ_KNOB_AGG_OVERLAP = 34,       /* default 0: the packed aggregate with a dense state runs every batch on one stream (partition pass, then k_agg_da); 1: k_agg_da / k_daagg_ovf of a batch run on a side stream beside the partition pass of the next batch (two partitioned stores) for batches of 2^24 rows or more — an A/B that measured SLOWER (C3 7.0 -> 10.1 ms, profiles/r06_ab_measurements.txt); v >= 2 (tests): for batches of v rows or more */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -856,6 +857,9 @@ typedef struct tsq_stats {
                                       (csrc/tsq_damat.h: two partition levels, ranked payload tables); 0: the batch took another variant */
     int32_t keyrec_digests;        /* join, ABI 7: 1 when the key-record route keeps string cells that do not fit a record as (length, 64-bit digest)
                                       and compares the bytes of every candidate match (long string keys), 0 otherwise */
+    int32_t side_stream_batches;   /* aggregate, ABI 7: batches of the packed route whose rows went from the partitioned store into the dense state on the
+                                      operator's side stream, beside the partition pass of the next batch (TSQ_KNOB_AGG_OVERLAP) */
+    int32_t reserved0;
 } tsq_stats;
 #define TSQ_ROUTE_DIRECT     0   /* k_probe_count / k_probe_emit on the table in HBM */
 #define TSQ_ROUTE_RADIX_L2   1   /* radix partition, table slices through the XCD's L2 */

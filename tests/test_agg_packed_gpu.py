@@ -449,3 +449,60 @@ def test_packed_agg_count_and_sum_in_one_lds_word(ctx, orc, key_hi):
         got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 18, fast=abi.AGGFAST_FORCE, stats_out=stats)
     assert stats[0].packed_key_bits > 0 and stats[0].dense_flushes == 1 and stats[0].table_slice_bits == 16
     assert H.rows_equal_unordered(got, want)
+
+
+@pytest.mark.parametrize("name", ["c3", "c3_double", "ints", "minmax2"])
+@pytest.mark.parametrize("key_hi", [30_000, 3_000_000])
+def test_packed_agg_side_stream_beside_the_next_partition_pass(ctx, orc, name, key_hi):
+    """round 6 (TSQ_KNOB_AGG_OVERLAP; tests: v >= 2 = batches of v rows or more): k_agg_da / k_daagg_ovf of batch i run on the operator's side
+    stream while batch i + 1 is partitioned into the second store; the fold into the dense state is made of device atomics then (the
+    partition kernel adds its hot keys to the same cells).  Ten batches — both stores reused four times —, a skewed key (hot in every
+    batch, and overflowing its region where the hot keys are switched off), NULL keys and arguments as exception rows on the first stream:
+    the same groups as the oracle and as the one-stream run."""
+    rng = np.random.default_rng(key_hi % 101 + len(name))
+    n = 1_000_000
+    chk, types = _chunk(rng, n, 0, key_hi)
+    hot_rows = rng.random(n) < 0.15
+    if chk.columns[0].notnull is not None:
+        hot_rows &= chk.columns[0].notnull  # (NULL slots keep their zero bytes)
+    chk.columns[0].data[hot_rows] = 4242
+    aggs = AGG_SETS[name]
+    cfg = H.agg_cfg(types, [0], aggs, est_groups=key_hi)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    real_cols = [i for i, a in enumerate(aggs) if a[0] in (abi.AGG_SUM, abi.AGG_AVG) and a[2] in (abi.F64, abi.F32)]
+    exact_cols = [i for i in range(len(aggs)) if i not in real_cols]
+    key_out = [i for i, a in enumerate(aggs) if a[0] == abi.AGG_FIRSTROW][0]
+    for overlap, hot in ((2, 1), (2, 0), (0, 1)):
+        stats = []
+        with ctx.knobs(AGG_OVERLAP=overlap, DAAGG_HOT=hot, AGG_BATCH_ROWS=100_000):
+            got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=100_000, fast=abi.AGGFAST_FORCE, stats_out=stats)
+        st = stats[0]
+        assert st.packed_key_bits > 0 and st.radix_batches == 10 and st.dense_flushes == 1
+        assert st.side_stream_batches == (10 if overlap else 0), st.side_stream_batches
+        _match_by_key(got, want, [key_out], exact_cols, real_cols, group_tols(chk, 0, aggs, real_cols))
+
+
+def test_packed_agg_side_stream_then_other_modes_and_flushes(ctx, orc):
+    """the side stream is joined wherever the first stream needs what it works on: a dense state emptied every other batch (AGG_DENSE = v),
+    and batches whose keys leave the packed range (the operator goes back to the 64-bit H mode, which reuses the first partitioned store)."""
+    rng = np.random.default_rng(5)
+    n = 800_000
+    chk, types = _chunk(rng, n, 0, 150_000)
+    aggs = AGG_SETS["c3"]
+    cfg = H.agg_cfg(types, [0], aggs, est_groups=150_000)
+    want = orc.hash_agg(cfg, chk, 4, 4)
+    stats = []
+    with ctx.knobs(AGG_OVERLAP=2, AGG_DENSE=150_000, AGG_BATCH_ROWS=1 << 16):
+        got = G.run_agg(ctx, cfg, chk, out_types_for(aggs), chunk_rows=1 << 16, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert stats[0].side_stream_batches >= 12 and stats[0].dense_flushes >= 5
+    assert H.rows_equal_unordered(got, want)
+    # the second half of the input far outside the range the first batches showed
+    k2 = chk.columns[0].data.copy()
+    k2[n // 2:] = rng.integers(1 << 40, (1 << 40) + 10**9, n - n // 2)
+    chk2 = Chunk([Column(abi.I64, k2, chk.columns[0].notnull)] + chk.columns[1:])
+    want2 = orc.hash_agg(cfg, chk2, 4, 4)
+    stats = []
+    with ctx.knobs(AGG_OVERLAP=2, AGG_BATCH_ROWS=100_000):
+        got2 = G.run_agg(ctx, cfg, chk2, out_types_for(aggs), chunk_rows=100_000, fast=abi.AGGFAST_FORCE, stats_out=stats)
+    assert 3 <= stats[0].side_stream_batches <= 5, stats[0].side_stream_batches
+    assert H.rows_equal_unordered(got2, want2)

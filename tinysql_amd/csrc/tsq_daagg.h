@@ -530,6 +530,7 @@ struct DaAggLdsArgs {
     // cell received a row; nullptr: the workgroup appends its touched cells to `out` as partial groups
     unsigned long long* dense_w[TSQ_AF_MAXW];
     uint32_t* dense_touch;
+    uint32_t concurrent;  // the partition kernel of the NEXT batch runs beside this launch (side stream) and adds its hot keys to the dense state: device atomics
 };
 // what one row does to the accumulators of cell e
 // SIG: the two commonest plans with their update descriptors known at compile time — 1: SUM(BIGINT cell 0) + COUNT(*) (words lo32,
@@ -692,7 +693,7 @@ __device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const 
     const uint32_t tid = threadIdx.x;
     const uint32_t ncell = 1u << a.st.ebits;  // <= CELLS, >= 32 (host)
     const size_t cbase = (size_t)p << a.st.ebits;
-    const bool shared = a.nsplit > 1;
+    const bool shared = a.nsplit > 1 || a.concurrent != 0;
     for (uint32_t i = tid; i < ncell; i += TSQ_AF_NT) {
         if (!((s_touch[i >> 5] >> (i & 31u)) & 1u)) continue;
         if (SIG == 3 && W == 3) {  // word 0 = count << 40 | sum: into the dense lo32 sum (word 0) and count (word 2); the hi32 sum stays
