@@ -739,7 +739,6 @@ __device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const 
 }
 template <int W, int CELLS, int SIG = 0>
 __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
-    constexpr int U = 4;
     uint32_t wd[W];
 #pragma unroll
     for (int k = 0; k < W; k++) wd[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.plan.wdesc[k]);
@@ -763,35 +762,63 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
         __syncthreads();
         auto regions = [&](auto pb_tag) {  // the width of the travelling argument cells is the same for the whole launch
             constexpr int PB = decltype(pb_tag)::value;
-            typedef typename da_pay_t<PB>::type PT;
             for (uint32_t r = r0; r < 8; r += nsplit) {
                 const uint32_t len = daagg_region_len(a.st, P, p, r);
                 const size_t base = (size_t)(p * 8u + r) * a.st.cap;
-                for (uint32_t i0 = tid; i0 < len; i0 += TSQ_AF_NT * U) {
-                    uint32_t e[U];
-                    uint64_t cells[U][TSQ_RADIX_MAXV];
+                // Round 6: EIGHT consecutive rows per lane and load — the entries as one 16-byte vector, the argument cells as one (2-byte
+                // cells), two (4-byte) or four per column (8-byte).  The 2-byte loads of round 3 kept 16 KB in flight per CU (16 waves x 4
+                // rows x two 128-byte wave loads): the kernel waited for memory, not for its LDS atomics (one atomic instead of two per
+                // row changed 2 % — profiles/r04_ab_measurements.txt).  The regions start on 128-byte boundaries (cap % 64 == 0) and a
+                // lane's rows on 16-byte ones; the last vector of a region may reach past `len` but not past the region (`live`).
+                for (uint32_t i0 = tid * 8u; i0 < len; i0 += TSQ_AF_NT * 8u) {
+                    const uint4 ev = *reinterpret_cast<const uint4*>(a.st.ent + base + i0);
+                    uint64_t cells[8][TSQ_RADIX_MAXV];
+                    if (PB == 2) {
+                        const uint4 cv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.st.pay[0]) + base + i0);
+                        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
-                    for (int x = 0; x < U; x++) {
-                        const uint32_t i = i0 + (uint32_t)x * TSQ_AF_NT;
-                        const uint32_t ic = i < len ? i : 0u;  // (a load that has nothing to fetch reads the region's first slot)
-                        e[x] = a.st.ent[base + ic];
-                        if (PB != 8) {
-                            cells[x][0] = (uint64_t)reinterpret_cast<const PT*>(a.st.pay[0])[base + ic];
+                        for (int x = 0; x < 8; x++) {
+                            cells[x][0] = (uint64_t)((cw[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
                             cells[x][1] = 0ull;
-                        } else {
+                        }
+                    } else if (PB == 4) {
+                        const uint4* cp = reinterpret_cast<const uint4*>(reinterpret_cast<const uint32_t*>(a.st.pay[0]) + base + i0);
+                        const uint4 c0 = cp[0], c1 = cp[1];
+                        const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-                            for (int v = 0; v < TSQ_RADIX_MAXV; v++) cells[x][v] = v < a.plan.V ? a.st.pay[v][base + ic] : 0ull;
+                        for (int x = 0; x < 8; x++) {
+                            cells[x][0] = (uint64_t)cw[x];
+                            cells[x][1] = 0ull;
+                        }
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < TSQ_RADIX_MAXV; v++) {
+                            if (v < a.plan.V) {
+                                const ulonglong2* cp = reinterpret_cast<const ulonglong2*>(a.st.pay[v] + base + i0);
+#pragma unroll
+                                for (int x = 0; x < 4; x++) {
+                                    const ulonglong2 c = cp[x];
+                                    cells[2 * x][v] = c.x;
+                                    cells[2 * x + 1][v] = c.y;
+                                }
+                            } else {
+#pragma unroll
+                                for (int x = 0; x < 8; x++) cells[x][v] = 0ull;
+                            }
                         }
                     }
+                    const uint32_t ew[4] = {ev.x, ev.y, ev.z, ev.w};
                     // (the loop bound is not wave-uniform: lanes past the end of the region fall out of the last iteration, so the wave
                     // variant — every lane calls — is entered only when the whole wave is still inside the loop; `live` covers the rows
-                    // i0 + x NT that lie past the end)
-                    const bool whole_wave = (i0 - (tid & 63u)) + 63u < len;
+                    // past the end.  The lanes of a wave hold rows 8 apart: a run of one key long enough to be worth combining — the
+                    // rows of a hot key that overflowed — still puts the same cell into neighbouring lanes)
+                    const bool whole_wave = (i0 - (tid & 63u) * 8u) + 63u * 8u < len;
 #pragma unroll
-                    for (int x = 0; x < U; x++) {
-                        const bool live = i0 + (uint32_t)x * TSQ_AF_NT < len;
-                        if (whole_wave) daagg_apply_wave<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1], live);
-                        else if (live) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e[x], cells[x][0], cells[x][1]);
+                    for (int x = 0; x < 8; x++) {
+                        const uint32_t e = (ew[x >> 1] >> ((x & 1) * 16)) & 0xffffu;
+                        const bool live = i0 + (uint32_t)x < len;
+                        if (whole_wave) daagg_apply_wave<W, CELLS, SIG>(wd, s_w, s_touch, e, cells[x][0], cells[x][1], live);
+                        else if (live) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e, cells[x][0], cells[x][1]);
                     }
                 }
             }
