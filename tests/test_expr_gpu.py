@@ -134,3 +134,21 @@ def test_jit_specialised_kernels_match_oracle(ctx, orc):
             assert ce.jit_launches() >= 1
         finally:
             ce.close()
+
+
+@pytest.mark.parametrize("n", [4096, 10_007, 131_073])
+def test_jit_four_rows_per_lane_and_the_bitmap_written_by_the_kernel(ctx, orc, n):
+    # round 6: the specialised kernel evaluates four rows per lane from 16-byte loads and, for batches of 4096 rows or more, writes whole
+    # 32-row words of the result's null bitmap itself (tsq_expr.hip: jit_expr, counters[2]); the rows past the last whole word come
+    # through the flag bytes and the pack pass.  NULL inputs, NULL results, every signature, and an overflow in the middle of a batch
+    # (the reference's first-error row, builtin_arithmetic_vec.go:389-420) at sizes around the word boundaries
+    rng = np.random.default_rng(n)
+    small, full = cols_for(rng, n, True), cols_for(rng, n, False)
+    for i, e in enumerate(all_exprs()):
+        check_same(ctx, orc, e, small if i % 2 == 0 else full, jit=abi.JIT_FORCE)
+    a = rng.integers(-1000, 1000, n)
+    a[n // 2 + 3] = (1 << 63) - 1
+    from tinysql_amd.chunk import Chunk, Column
+    chk = Chunk([Column(abi.I64, a, rng.random(n) > 0.1), Column(abi.I64, np.ones(n, np.int64))])
+    e = E.ScalarFunction("plus", E.Column(0, abi.I64), E.Column(1, abi.I64))
+    check_same(ctx, orc, e, chk, jit=abi.JIT_FORCE)  # row n/2 + 3 overflows (unless it is NULL: then the batch passes) — same status either way

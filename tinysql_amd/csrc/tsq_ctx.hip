@@ -377,8 +377,9 @@ __device__ __forceinline__ uint32_t tsq_flags8_to_bits(uint64_t w) {
     w &= 0x0101010101010101ull;
     return (uint32_t)((w * 0x0102040810204080ull) >> 56);
 }
-__global__ void __launch_bounds__(256) k_pack_bitmap32(const uint4* __restrict__ flags, uint32_t* __restrict__ bitmap, int64_t nwords) {
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nwords; k += (int64_t)gridDim.x * 256) {
+__global__ void __launch_bounds__(256) k_pack_bitmap32(const uint4* __restrict__ flags, uint32_t* __restrict__ bitmap, int64_t nwords, const unsigned long long* first_row) {
+    const int64_t k0 = first_row ? (int64_t)(*first_row >> 5) : 0;  // (words below: written by the kernel that produced the rows)
+    for (int64_t k = k0 + (int64_t)blockIdx.x * 256 + threadIdx.x; k < nwords; k += (int64_t)gridDim.x * 256) {
         const uint4 a = flags[2 * k], b = flags[2 * k + 1];
         const uint32_t b0 = tsq_flags8_to_bits((uint64_t)a.x | ((uint64_t)a.y << 32)), b1 = tsq_flags8_to_bits((uint64_t)a.z | ((uint64_t)a.w << 32));
         const uint32_t b2 = tsq_flags8_to_bits((uint64_t)b.x | ((uint64_t)b.y << 32)), b3 = tsq_flags8_to_bits((uint64_t)b.z | ((uint64_t)b.w << 32));
@@ -386,13 +387,13 @@ __global__ void __launch_bounds__(256) k_pack_bitmap32(const uint4* __restrict__
     }
 }
 
-tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n) {
+tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n, const unsigned long long* first_row) {
     if (n <= 0) return TSQ_OK;
     // whole 32-row words through the wide kernel (buffers of the operators start on 256-byte boundaries), the tail byte by byte
     int64_t done = 0;
     if (n >= 4096 && ((uintptr_t)notnull_bytes & 15u) == 0 && ((uintptr_t)bitmap & 3u) == 0) {
         const int64_t nwords = n / 32;
-        hipLaunchKernelGGL(k_pack_bitmap32, dim3(tsq_grid_for(ctx, nwords, 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(notnull_bytes), reinterpret_cast<uint32_t*>(bitmap), nwords);
+        hipLaunchKernelGGL(k_pack_bitmap32, dim3(tsq_grid_for(ctx, nwords, 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(notnull_bytes), reinterpret_cast<uint32_t*>(bitmap), nwords, first_row);
         TSQ_HIP(h, hipGetLastError());
         done = nwords * 32;
         if (done == n) return TSQ_OK;

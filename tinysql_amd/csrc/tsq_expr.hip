@@ -27,7 +27,8 @@ struct ExprArgs {
     uint8_t* out_notnull;        // projection: 1 byte per row
     uint8_t* out_selected;       // filter: 1 byte per row (Go []bool)
     uint8_t* out_isnull;         // filter: optional
-    unsigned long long* counters;  // [0] = error word (min), [1] = division-by-zero warnings
+    unsigned long long* counters;  // [0] = error word (min), [1] = division-by-zero warnings, [2] = rows whose NOT-NULL bits the kernel wrote into out_bits itself
+    uint32_t* out_bits;          // projection, optional: the result's null bitmap (the specialised kernel writes whole 32-row words of it instead of byte flags)
 };
 
 // The postfix programs are copied into LDS once per workgroup: interpreting them out of global memory made every
@@ -270,7 +271,7 @@ static std::string jit_source(const std::vector<tsq_expr_prog>& progs) {
          "typedef unsigned long size_t;\n";
     o << TSQ_JIT_HDR_ABI << "\n" << TSQ_JIT_HDR_DEV << "\n";
     o << "struct ExprArgs { tsq_colset in; const tsq_expr_prog* progs; int32_t n_progs; int64_t nrows; const int32_t* sel; uint64_t* out_data;\n"
-         "  uint8_t* out_notnull; uint8_t* out_selected; uint8_t* out_isnull; unsigned long long* counters; };\n";
+         "  uint8_t* out_notnull; uint8_t* out_selected; uint8_t* out_isnull; unsigned long long* counters; uint32_t* out_bits; };\n";
     o << "__device__ const tsq_expr_prog P[" << progs.size() << "] = {\n";
     for (const tsq_expr_prog& p : progs) {
         o << " { " << p.n_ops << ", " << p.n_consts << ", " << p.result_type << ", " << p.result_unsigned << ", {";
@@ -333,53 +334,77 @@ __device__ bool jit_pairs_usable(const ExprArgs& a, const void* out, unsigned ou
     }
     return true;
 }
-__device__ __forceinline__ void jit_load_pair(const ExprArgs& a, int64_t p, tsq_pre_src& s0, tsq_pre_src& s1) {
-    s0.cs = s1.cs = &a.in;
-    s0.row = 2 * p;
-    s1.row = 2 * p + 1;
+// rows 4 q .. 4 q + 3 of every column the tree reads: two 16-byte loads per column and lane (a wave takes 2 KB of a column at once), the
+// four NOT-NULL bits = one nibble of the bitmap
+__device__ __forceinline__ void jit_load_quad(const ExprArgs& a, int64_t q, tsq_pre_src (&s)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        s[r].cs = &a.in;
+        s[r].row = 4 * q + r;
+    }
 #pragma unroll
     for (int sl = 0; sl < N_SLOTS; sl++) {
         const int c = SLOT_COL[sl];
-        const jit_v2u64 x = reinterpret_cast<const jit_v2u64*>(a.in.data[c])[p];
-        s0.cell[sl] = x.x;
-        s1.cell[sl] = x.y;
-        s0.isnull[sl] = s1.isnull[sl] = false;
-        if (a.in.nulls[c]) {  // rows 2 p and 2 p + 1: two neighbouring bits of one byte (1 = NOT NULL)
-            const uint32_t b = (uint32_t)a.in.nulls[c][p >> 2] >> ((uint32_t)(p & 3) * 2u);
-            s0.isnull[sl] = !(b & 1u);
-            s1.isnull[sl] = !(b & 2u);
-        }
+        const jit_v2u64* src = reinterpret_cast<const jit_v2u64*>(a.in.data[c]) + 2 * q;
+        const jit_v2u64 x = src[0], y = src[1];
+        s[0].cell[sl] = x.x;
+        s[1].cell[sl] = x.y;
+        s[2].cell[sl] = y.x;
+        s[3].cell[sl] = y.y;
+        uint32_t b = 0xfu;
+        if (a.in.nulls[c]) b = (uint32_t)a.in.nulls[c][q >> 1] >> ((uint32_t)(q & 1) * 4u);
+#pragma unroll
+        for (int r = 0; r < 4; r++) s[r].isnull[sl] = !((b >> r) & 1u);
     }
 }
 extern "C" __global__ void __launch_bounds__(256) jit_expr(ExprArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint64_t errw = TSQ_ERRWORD_NONE;
     uint32_t div0 = 0;
-    int64_t first = 0;  // rows the pairs loop has done
-    if (jit_pairs_usable(a, a.out_data, 16u) && !((unsigned long)a.out_notnull & 1u)) {
-        const int64_t np = a.nrows >> 1;
-        for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += stride) {
-            tsq_pre_src s0, s1;
-            jit_load_pair(a, p, s0, s1);
-            tsq_val v0, v1;
-            int n0 = 0, n1 = 0, d0 = 0;
-            const tsq_status t0 = tsq_eval_row(P[0], s0, &v0, &n0, &d0);
-            const tsq_status t1 = tsq_eval_row(P[0], s1, &v1, &n1, &d0);
+    int64_t first = 0;  // rows the four-row loop has done
+    if (jit_pairs_usable(a, a.out_data, 16u) && !((unsigned long)a.out_notnull & 3u)) {
+        // the NOT-NULL bits of a lane's four rows are a nibble; eight neighbouring lanes make one 32-row word of the result's bitmap and
+        // write it themselves (out_bits: the host's pack pass then starts at row counters[2]) — otherwise four flag bytes per lane
+        const bool bits = a.out_bits != nullptr;
+        const int64_t nq = bits ? (a.nrows >> 5) << 3 : a.nrows >> 2;
+        const uint32_t lane8 = threadIdx.x & 7u;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {  // (nq % 8 == 0 with `bits`: the eight lanes of a word stay together)
+            tsq_pre_src s[4];
+            jit_load_quad(a, q, s);
+            tsq_val v[4];
+            int n[4] = {0, 0, 0, 0}, d0 = 0;
+            tsq_status t[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) t[r] = tsq_eval_row(P[0], s[r], &v[r], &n[r], &d0);
             div0 += (uint32_t)d0;
-            if (t0 == TSQ_OK && t1 == TSQ_OK) {
-                jit_v2u64 y;
-                y.x = (uint64_t)v0.v;
-                y.y = (uint64_t)v1.v;
-                reinterpret_cast<jit_v2u64*>(a.out_data)[p] = y;
-                reinterpret_cast<uint16_t*>(a.out_notnull)[p] = (uint16_t)((v0.null ? 0u : 1u) | (v1.null ? 0u : 0x100u));
+            const bool ok = t[0] == TSQ_OK && t[1] == TSQ_OK && t[2] == TSQ_OK && t[3] == TSQ_OK;
+            if (bits) {
+                uint32_t w = ((v[0].null ? 0u : 1u) | (v[1].null ? 0u : 2u) | (v[2].null ? 0u : 4u) | (v[3].null ? 0u : 8u)) << (4u * lane8);
+                w |= (uint32_t)__shfl_xor((int)w, 1);
+                w |= (uint32_t)__shfl_xor((int)w, 2);
+                w |= (uint32_t)__shfl_xor((int)w, 4);
+                if (lane8 == 0) a.out_bits[q >> 3] = w;  // (a row that raised an error: the whole result is discarded)
+            }
+            if (ok) {
+                jit_v2u64 y0, y1;
+                y0.x = (uint64_t)v[0].v;
+                y0.y = (uint64_t)v[1].v;
+                y1.x = (uint64_t)v[2].v;
+                y1.y = (uint64_t)v[3].v;
+                jit_v2u64* dst = reinterpret_cast<jit_v2u64*>(a.out_data) + 2 * q;
+                dst[0] = y0;
+                dst[1] = y1;
+                if (!bits) reinterpret_cast<uint32_t*>(a.out_notnull)[q] = (v[0].null ? 0u : 1u) | (v[1].null ? 0u : 0x100u) | (v[2].null ? 0u : 0x10000u) | (v[3].null ? 0u : 0x1000000u);
                 continue;
             }
-            if (t0 != TSQ_OK) { const uint64_t w = tsq_errword(0, n0, (uint64_t)(2 * p), t0); errw = w < errw ? w : errw; }
-            else { a.out_data[2 * p] = (uint64_t)v0.v; a.out_notnull[2 * p] = v0.null ? 0 : 1; }
-            if (t1 != TSQ_OK) { const uint64_t w = tsq_errword(0, n1, (uint64_t)(2 * p + 1), t1); errw = w < errw ? w : errw; }
-            else { a.out_data[2 * p + 1] = (uint64_t)v1.v; a.out_notnull[2 * p + 1] = v1.null ? 0 : 1; }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (t[r] != TSQ_OK) { const uint64_t w = tsq_errword(0, n[r], (uint64_t)(4 * q + r), t[r]); errw = w < errw ? w : errw; }
+                else { a.out_data[4 * q + r] = (uint64_t)v[r].v; if (!bits) a.out_notnull[4 * q + r] = v[r].null ? 0 : 1; }
+            }
         }
-        first = np * 2;
+        first = nq * 4;
+        if (bits && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = (unsigned long long)first;
     }
     for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nrows; i += stride) {
         tsq_chunk_src src{&a.in, a.sel ? (int64_t)a.sel[i] : i};
@@ -552,7 +577,8 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
     a.counters = e->counters.as<unsigned long long>();
     ctx->pinned[0] = TSQ_ERRWORD_NONE;
     ctx->pinned[1] = 0;
-    TSQ_HIP(h, hipMemcpyAsync(a.counters, ctx->pinned, 16, hipMemcpyHostToDevice, ctx->stream));
+    ctx->pinned[2] = 0;
+    TSQ_HIP(h, hipMemcpyAsync(a.counters, ctx->pinned, 24, hipMemcpyHostToDevice, ctx->stream));
     const int grid = tsq_grid_for(ctx, nrows, 256);
     if (!filter) {
         const bool odev = out->flags & TSQ_COL_DEVICE;
@@ -567,13 +593,17 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
         TSQ_TRY(e->out_nn.reserve(ctx, h, (size_t)nrows + 16));
         a.out_data = od;
         a.out_notnull = e->out_nn.as<uint8_t>();
-        if (!jit_launch(e, false, a, grid)) hipLaunchKernelGGL(k_expr_eval, dim3(grid), dim3(256), 0, ctx->stream, a);
-        TSQ_HIP(h, hipGetLastError());
         uint8_t* ob = out->null_bitmap;
         if (!odev) {
             TSQ_TRY(e->out_bitmap.reserve(ctx, h, tsq_bitmap_bytes(nrows) + 16));
             ob = e->out_bitmap.as<uint8_t>();
         }
+        // the specialised kernel may write the bitmap's whole words itself (four rows per lane, eight lanes per word) and says in counters[2]
+        // where the pack pass has to start; the interpreter leaves the word at 0 and every row comes from its flag byte
+        const bool bits_ok = !str_root && nrows >= 4096 && ((uintptr_t)ob & 3u) == 0 && ((uintptr_t)a.out_notnull & 15u) == 0;
+        a.out_bits = bits_ok ? reinterpret_cast<uint32_t*>(ob) : nullptr;
+        if (!jit_launch(e, false, a, grid)) hipLaunchKernelGGL(k_expr_eval, dim3(grid), dim3(256), 0, ctx->stream, a);
+        TSQ_HIP(h, hipGetLastError());
         if (str_root) {
             // references -> lengths -> offsets (exclusive scan) -> bytes; the caller's buffers are written only when the bytes fit
             StrRootArgs sa;
@@ -628,7 +658,7 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
             out->type = TSQ_BYTES;
             return TSQ_OK;
         }
-        TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a.out_notnull, ob, nrows));
+        TSQ_TRY(tsq_launch_pack_bitmap(ctx, h, a.out_notnull, ob, nrows, bits_ok ? a.counters + 2 : nullptr));
         if (!odev) {
             TSQ_TRY(e->hout.reserve(h, (size_t)nrows * 8 + tsq_bitmap_bytes(nrows) + 32));
             TSQ_HIP(h, hipMemcpyAsync(e->hout.p, od, (size_t)nrows * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -295,7 +295,8 @@ inline int tsq_grid_for(const tsq_ctx* ctx, int64_t work_items, int block, int i
 }
 
 // kernels defined in tsq_ctx.hip that other units launch through these wrappers
-tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n);
+// first_row (device, optional): rows below *first_row (a multiple of 32) have their bits already — the pass starts there
+tsq_status tsq_launch_pack_bitmap(tsq_ctx* ctx, tsq_handle_hdr* h, const uint8_t* notnull_bytes, uint8_t* bitmap, int64_t n, const unsigned long long* first_row = nullptr);
 
 // tsq_comm.hip, for the COLLECTIVE steps of an operator (tsq_join_build_finish_shared): every rank of the communicator calls them
 // in the same order.  The device all-reduce sums `count` elements of 1 or 4 bytes in place: it waits for the context's stream,
