@@ -591,11 +591,13 @@ def extra_materialising(ctx, abi, _lib, bk, bv, pk, pv, nb, npr, reps=3, nullabl
             "ms": one_pass * 1e3, "ms_with_build_copy": one_pass_copy * 1e3, "joined_rows": rows, "joined_rows_per_s": rows / one_pass, "frac": algo_all / one_pass / 8e12, "verified": rows == npr,
             "build_call_ms": build_only * 1e3, "repeated_probe_pass_ms": again * 1e3, "repeated_probe_pass_frac": algo_probe / again / 8e12,
             "route": {0: "direct (K3 + K4a + gather)", 2: "64-bit LDS route (partition with payload, sizing pass, emit)",
-                      3: "packed keys: probe columns travel with 2-byte entries, build columns sorted by word, K4e writes the rows"}.get(st.probe_route, str(st.probe_route)),
-            "packed_prepare_ms": st.packed_build_ms,
+                      3: ("packed keys, build side in LDS: both sides' columns travel through two partition levels (2^%d final partitions), the build rows of a "
+                          "partition sit in a ranked LDS table, k_dm_emit writes one output row per probe row (csrc/tsq_damat.h)" % st.packed_lds_bits) if st.packed_lds_bits > 0
+                      else "packed keys: probe columns travel with 2-byte entries, build columns sorted by word, K4e writes the rows"}.get(st.probe_route, str(st.probe_route)),
+            "packed_lds_bits": st.packed_lds_bits, "packed_prepare_ms": st.packed_build_ms,
             "timing": "host clock, best of %d.  `ms` = ONE PASS of the operator: tsq_join_build_push (the build chunk handed over with TSQ_COL_RETAIN, as PutChunk keeps its chunk; "
                       "`ms_with_build_copy`: the first, cold repetition, rows copied into the operator) + build_finish + one probe_push of all rows + stream sync — the "
-                      "build, everything the route prepares on the build side (packed_prepare_ms of kernels: images, partitioned + sorted build columns) and the "
+                      "build, everything the route prepares on the build side (packed_prepare_ms of kernels: images, the build columns' two partition levels) and the "
                       "probe; `frac` prices it at 32 B per build row + 32 B per probe row + 24 B per joined row (SURVEY.md 8d).  repeated_probe_pass_ms = a further "
                       "probe pass against the prepared build side" % reps}
 
