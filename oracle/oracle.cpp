@@ -1002,6 +1002,42 @@ int64_t orc_rowhashmap_put_get(const uint64_t* keys, const uint64_t* ptrs, int64
     return (int64_t)got.size();
 }
 
+// tryToMatchInners with OtherConditions (joiner.go:351-378 + filter :155-167): the outer row joined with every candidate inner row in a
+// scratch chunk, VectorizedFilter over it; sel[r] = candidate r passes.  Shared by the hash join and the merge join (merge_join.go:291).
+static tsq_status join_conds_select(const tsq_join_cfg* cfg, const tsq_col* probe_cols, const tsq_col* build_cols, int32_t probe_off, int32_t build_off,
+                                    int64_t prow, const std::vector<int64_t>& matched, std::vector<uint8_t>& sel) {
+    const int32_t nb = cfg->n_build_cols, np = cfg->n_probe_cols;
+    const int64_t m = (int64_t)matched.size();
+    std::vector<std::vector<uint64_t>> data(nb + np, std::vector<uint64_t>(m));
+    std::vector<std::vector<uint8_t>> bm(nb + np, std::vector<uint8_t>((m + 7) / 8, 0));
+    std::vector<tsq_col> jc(nb + np);
+    auto fill = [&](int32_t oc, const tsq_col& src, int64_t srow, int64_t r) {
+        bool isnull = col_is_null(src, srow);
+        data[oc][r] = isnull ? 0 : col_raw64(src, srow);
+        if (!isnull) bm[oc][r >> 3] |= (uint8_t)(1u << (r & 7));
+    };
+    for (int64_t r = 0; r < m; r++) {
+        for (int32_t c = 0; c < np; c++) fill(probe_off + c, probe_cols[c], prow, r);
+        for (int32_t c = 0; c < nb; c++) fill(build_off + c, build_cols[c], matched[r], r);
+    }
+    for (int32_t c = 0; c < nb + np; c++) {
+        int32_t t = (c >= probe_off && c < probe_off + np) ? cfg->probe_types[c - probe_off] : cfg->build_types[c - build_off];
+        jc[c] = tsq_col{};
+        jc[c].length = m;
+        jc[c].type = t;
+        jc[c].elem_size = t == TSQ_F32 ? 4 : 8;
+        jc[c].null_bitmap = bm[c].data();
+        if (t == TSQ_F32) {  // repack 4-byte
+            uint32_t* d32 = (uint32_t*)data[c].data();
+            for (int64_t r = 0; r < m; r++) d32[r] = (uint32_t)data[c][r];
+        }
+        jc[c].data = data[c].data();
+    }
+    std::vector<uint8_t> nl2;
+    int64_t w = 0;
+    return vec_eval_bool(cfg->other_conds, cfg->n_other_conds, jc.data(), nb + np, m, nullptr, sel, nl2, &w);
+}
+
 orc_result* orc_hash_join(const tsq_join_cfg* cfg, const tsq_col* build_cols, int64_t n_build,
                           const tsq_col* probe_cols, int64_t n_probe, const uint8_t* selected_in,
                           tsq_status* status) {
@@ -1059,42 +1095,13 @@ orc_result* orc_hash_join(const tsq_join_cfg* cfg, const tsq_col* build_cols, in
             for (int64_t b : matched) emit(i, b);
             continue;
         }
-        // tryToMatchInners with conditions (joiner.go:351-378 + filter :155-167): build the joined
-        // rows in a scratch chunk, VectorizedFilter, copy the selected ones.
+        // tryToMatchInners with conditions (join_conds_select): the selected candidates are joined
         bool hasMatch = false;
         {
-            const int64_t m = (int64_t)matched.size();
-            std::vector<std::vector<uint64_t>> data(nb + np, std::vector<uint64_t>(m));
-            std::vector<std::vector<uint8_t>> bm(nb + np, std::vector<uint8_t>((m + 7) / 8, 0));
-            std::vector<tsq_col> jc(nb + np);
-            auto fill = [&](int32_t oc, const tsq_col& src, int64_t srow, int64_t r) {
-                bool isnull = col_is_null(src, srow);
-                data[oc][r] = isnull ? 0 : col_raw64(src, srow);
-                if (!isnull) bm[oc][r >> 3] |= (uint8_t)(1u << (r & 7));
-            };
-            for (int64_t r = 0; r < m; r++) {
-                for (int32_t c = 0; c < np; c++) fill(probe_off + c, probe_cols[c], i, r);
-                for (int32_t c = 0; c < nb; c++) fill(build_off + c, build_cols[c], matched[r], r);
-            }
-            for (int32_t c = 0; c < nb + np; c++) {
-                int32_t t = (c >= probe_off && c < probe_off + np) ? cfg->probe_types[c - probe_off]
-                                                                    : cfg->build_types[c - build_off];
-                jc[c] = tsq_col{};
-                jc[c].length = m;
-                jc[c].type = t;
-                jc[c].elem_size = t == TSQ_F32 ? 4 : 8;
-                jc[c].null_bitmap = bm[c].data();
-                if (t == TSQ_F32) {  // repack 4-byte
-                    uint32_t* d32 = (uint32_t*)data[c].data();
-                    for (int64_t r = 0; r < m; r++) d32[r] = (uint32_t)data[c][r];
-                }
-                jc[c].data = data[c].data();
-            }
-            std::vector<uint8_t> sel2, nl2;
-            int64_t w = 0;
-            tsq_status s = vec_eval_bool(cfg->other_conds, cfg->n_other_conds, jc.data(), nb + np, m, nullptr, sel2, nl2, &w);
+            std::vector<uint8_t> sel2;
+            tsq_status s = join_conds_select(cfg, probe_cols, build_cols, probe_off, build_off, i, matched, sel2);
             if (s != TSQ_OK) { *status = s; delete res; return nullptr; }
-            for (int64_t r = 0; r < m; r++)
+            for (size_t r = 0; r < matched.size(); r++)
                 if (sel2[r]) { emit(i, matched[r]); hasMatch = true; }
         }
         if (!hasMatch) on_miss(i);  // join.go:319-321
@@ -1107,11 +1114,11 @@ orc_result* orc_hash_join(const tsq_join_cfg* cfg, const tsq_col* build_cols, in
 // :148-156), joinToChunk (:257-310) compares the outer row with the current inner group: greater -> next group, smaller
 // (or filtered out, or no group left) -> onMissMatch, equal -> the outer row joined with every row of the group in order.
 // `build` plays the inner table, `probe` the outer one (cfg->build_is_right tells which child is which; output is
-// left-child columns || right-child columns, joiner.go:145-150).  OtherConditions are not restated here.
+// left-child columns || right-child columns, joiner.go:145-150).  OtherConditions: tryToMatchInners filters the group's joined rows (:291,
+// joiner.go:351-378); an outer row none of whose candidates passes is a miss (:296-299).
 orc_result* orc_merge_join(const tsq_join_cfg* cfg, const tsq_col* inner_cols, int64_t n_inner, const tsq_col* outer_cols,
                            int64_t n_outer, tsq_status* status) {
     *status = TSQ_OK;
-    if (cfg->n_other_conds > 0) { *status = TSQ_ERR_UNSUPPORTED; return nullptr; }
     const int32_t nb = cfg->n_build_cols, np = cfg->n_probe_cols;
     const bool outerIsRight = !cfg->build_is_right;
     const int32_t probe_off = outerIsRight ? nb : 0, build_off = outerIsRight ? 0 : np;
@@ -1187,7 +1194,18 @@ orc_result* orc_merge_join(const tsq_join_cfg* cfg, const tsq_col* inner_cols, i
         if (selected[o] && g0 < inner.size()) c = cmp_keys(o, inner[g0]);
         if (c > 0) { next_group(); continue; }
         if (c < 0) { on_miss(o); o++; continue; }
-        for (size_t g = g0; g < g1; g++) emit(o, inner[g]);
+        if (cfg->n_other_conds == 0) {
+            for (size_t g = g0; g < g1; g++) emit(o, inner[g]);
+        } else {
+            const std::vector<int64_t> group(inner.begin() + (std::ptrdiff_t)g0, inner.begin() + (std::ptrdiff_t)g1);
+            std::vector<uint8_t> sel2;
+            const tsq_status st = join_conds_select(cfg, outer_cols, inner_cols, probe_off, build_off, o, group, sel2);
+            if (st != TSQ_OK) { *status = st; delete res; return nullptr; }
+            bool hasMatch = false;
+            for (size_t r = 0; r < group.size(); r++)
+                if (sel2[r]) { emit(o, group[r]); hasMatch = true; }
+            if (!hasMatch) on_miss(o);
+        }
         o++;
     }
     return res;

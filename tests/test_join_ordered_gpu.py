@@ -97,3 +97,20 @@ def test_ordered_with_heavily_duplicated_keys(ctx, orc):
     outer = Chunk([Column(abi.I64, ok), Column(abi.I64, np.arange(len(ok)))])
     cfg = H.join_cfg([abi.I64, abi.I64], [abi.I64, abi.I64], [0], [0], abi.JOIN_INNER, 1)
     assert G.run_join(ctx, cfg, innr, outer, chunk_rows=1 << 20, pull_rows=1 << 20, ordered=True).rows() == orc.hash_join(cfg, innr, outer).rows()
+
+
+@pytest.mark.parametrize("jt,inner", [(abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)])
+def test_ordered_with_other_conditions_equals_the_merge_join_restatement(ctx, orc, jt, inner):
+    # round 6: MergeJoinExec's OtherConditions (merge_join.go:291-299: tryToMatchInners filters the outer row's inner group, a row none of
+    # whose candidates passes is a miss) are restated in the oracle — sorted children, the ordered join row for row IN ORDER
+    rng = np.random.default_rng(91 + jt)
+    no, ni = 30_000, 20_000
+    outer = Chunk([Column(abi.I64, np.sort(rng.integers(0, 4000, no))), Column(abi.I64, rng.integers(-50, 50, no), rng.random(no) > 0.05)])
+    innr = Chunk([Column(abi.I64, np.sort(rng.integers(0, 4000, ni))), Column(abi.I64, rng.integers(-50, 50, ni), rng.random(ni) > 0.05)])
+    keep = []
+    conds = [E.ScalarFunction("gt", E.ScalarFunction("plus", E.Column(1, abi.I64), E.Column(3, abi.I64)), E.Constant(0))]
+    t = [abi.I64, abi.I64]
+    cfg = H.join_cfg(t, t, [0], [0], jt, inner, conds, (), keep)
+    want = orc.merge_join(cfg, innr, outer).rows()
+    assert len(want) > 10_000
+    assert G.run_join(ctx, cfg, innr, outer, chunk_rows=4096, pull_rows=4096, ordered=True).rows() == want

@@ -72,3 +72,42 @@ def test_merge_join_order_equals_the_ordered_hash_join_restatement():
     for jt in (abi.JOIN_INNER, abi.JOIN_LEFT_OUTER):
         cfg = _cfg(2, 2, jt, 1)
         assert orc.merge_join(cfg, inner, outer).rows() == orc.hash_join(cfg, inner, outer).rows()
+
+
+def test_other_conditions_filter_the_group_and_a_row_without_a_passing_candidate_is_a_miss():
+    # merge_join.go:291-299: tryToMatchInners runs the joiner's filter (joiner.go:155-167, 351-378) over the outer row joined with its inner
+    # group; hasMatch stays false when no candidate passes -> onMissMatch.  merge_join_test.go holds no ON-condition beyond the outer
+    # filter, so the restatement is pinned on its equality with the hash join's (join_test.go:69-116 are its golden rows) on sorted children
+    outer = _t([(1, 5), (1, -5), (2, 1), (3, 0), (3, 9)])
+    inner = _t([(1, 1), (1, 10), (3, -20), (3, 2)])
+    cond = [E.ScalarFunction("gt", E.ScalarFunction("plus", E.Column(1, abi.I64), E.Column(3, abi.I64)), E.Constant(0))]  # outer.c2 + inner.c2 > 0
+    keep = []
+    cfg = H.join_cfg([abi.I64] * 2, [abi.I64] * 2, [0], [0], abi.JOIN_LEFT_OUTER, 1, cond, (), keep)
+    assert orc.merge_join(cfg, inner, outer).rows() == [(1, 5, 1, 1), (1, 5, 1, 10), (1, -5, 1, 10), (2, 1, None, None), (3, 0, 3, 2), (3, 9, 3, 2)]
+    cfg_in = H.join_cfg([abi.I64] * 2, [abi.I64] * 2, [0], [0], abi.JOIN_INNER, 1, cond, (), keep)
+    assert orc.merge_join(cfg_in, inner, outer).rows() == [(1, 5, 1, 1), (1, 5, 1, 10), (1, -5, 1, 10), (3, 0, 3, 2), (3, 9, 3, 2)]
+    # an outer row whose every candidate fails: NULL-padded once
+    cond2 = [E.ScalarFunction("gt", E.Column(3, abi.I64), E.Constant(100))]
+    cfg2 = H.join_cfg([abi.I64] * 2, [abi.I64] * 2, [0], [0], abi.JOIN_LEFT_OUTER, 1, cond2, (), keep)
+    assert orc.merge_join(cfg2, inner, outer).rows() == [(1, 5, None, None), (1, -5, None, None), (2, 1, None, None), (3, 0, None, None), (3, 9, None, None)]
+    # random sorted children, duplicates on both sides, NULL keys and NULL condition operands: merge join == hash join, row for row in order
+    rng = np.random.default_rng(12)
+    for jt, inner_child in ((abi.JOIN_INNER, 1), (abi.JOIN_LEFT_OUTER, 1), (abi.JOIN_RIGHT_OUTER, 0)):
+        no, ni = 3000, 2500
+        o = Chunk([Column(abi.I64, np.sort(rng.integers(0, 400, no)), rng.random(no) > 0.03), Column(abi.I64, rng.integers(-50, 50, no), rng.random(no) > 0.1)])
+        i = Chunk([Column(abi.I64, np.sort(rng.integers(0, 400, ni)), rng.random(ni) > 0.03), Column(abi.I64, rng.integers(-50, 50, ni), rng.random(ni) > 0.1)])
+        # (NULL keys sort first: put them there, as a sorted child would deliver them)
+        for ch in (o, i):
+            k = ch.columns[0]
+            if k.notnull is not None:
+                order = np.argsort(np.where(k.notnull, k.data, -1), kind="stable")
+                for c in ch.columns:
+                    c.data = c.data[order]
+                    if c.notnull is not None:
+                        c.notnull = c.notnull[order]
+                    c._bitmap = None
+        a, b = (1, 3) if inner_child == 1 else (3, 1)  # the outer child's c2 and the inner child's c2 in the joined schema
+        cond = [E.ScalarFunction("gt", E.ScalarFunction("plus", E.Column(a, abi.I64), E.Column(b, abi.I64)), E.Constant(0))]
+        keep = []
+        cfg = H.join_cfg([abi.I64] * 2, [abi.I64] * 2, [0], [0], jt, inner_child, cond, (), keep)
+        assert orc.merge_join(cfg, i, o).rows() == orc.hash_join(cfg, i, o).rows()
