@@ -83,13 +83,26 @@ TSQ_HD uint64_t tsq_hash_bytes(const uint8_t* p, int64_t n) {
 
 // one var-len cell copied by ONE lane: eight bytes at a time (global loads and stores take any byte address), then the tail
 TSQ_HD void tsq_copy_cell(uint8_t* d, const uint8_t* s, int64_t n) {
-    int64_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t x;
-        memcpy(&x, s + i, 8);
-        memcpy(d + i, &x, 8);
+    // (d and s never overlap: a cell is copied between two buffers.  No byte loop over memory: every byte load behind a byte store may
+    // alias it, so a 7-byte tail was seven dependent round trips — round 6: the tail of a cell of 8 bytes or more is one more 8-byte copy
+    // that overlaps the bytes before it, a shorter cell is gathered into a register first)
+    if (n >= 8) {
+        int64_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t x;
+            memcpy(&x, s + i, 8);
+            memcpy(d + i, &x, 8);
+        }
+        if (i < n) {
+            uint64_t x;
+            memcpy(&x, s + n - 8, 8);
+            memcpy(d + n - 8, &x, 8);
+        }
+        return;
     }
-    for (; i < n; i++) d[i] = s[i];
+    uint64_t x = 0;
+    for (int64_t i = 0; i < n; i++) x |= (uint64_t)s[i] << (8 * i);
+    for (int64_t i = 0; i < n; i++) d[i] = (uint8_t)(x >> (8 * i));
 }
 
 // rank of a key for the multi-GPU radix redistribute (tsq_radix_split)
