@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -236,3 +237,20 @@ def test_round6_sides_carry_the_reference_benchmark_shapes_and_the_targets_met()
               "materialising", "materialising_nullable_left_outer", "q3_sf100", "c3_agg_1e9_1e6", "c3_agg_1e9_1e6_double", "expr_kernels.arith_int64"):
         assert k in s, k
     assert s["materialising"]["ms"] <= 4.5 and s["materialising_nullable_left_outer"]["ms"] <= 7.0  # VERDICT r5 item 1's one-pass targets
+
+
+def test_watchdog_prints_what_is_known_and_leaves_when_the_reporting_part_hangs():
+    # bench.py at N > 1 measures the second distributed plan after `value` is known; a collective that hangs there must not cost the line
+    code = ("import sys, time, json; sys.path.insert(0, %r); import bench\n"
+            "disarm = bench.arm_watchdog(0.3, lambda: (sys.stdout.write(json.dumps({'value': 1.5, 'plans': {'other_plan': {'error': 'deadline'}}}) + '\\n'), sys.stdout.flush()))\n"
+            "time.sleep(30)\nprint('not reached')\n") % ROOT
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
+    assert time.time() - t0 < 20 and r.returncode == 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["value"] == 1.5 and "not reached" not in r.stdout
+    # disarmed in time: nothing is printed, the program goes on
+    code2 = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+             "disarm = bench.arm_watchdog(0.3, lambda: print('late'))\ndisarm()\ntime.sleep(0.8)\nprint('went on')\n") % ROOT
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=25)
+    assert r2.returncode == 0 and "went on" in r2.stdout and "late" not in r2.stdout
