@@ -143,7 +143,7 @@ enum {
     TSQ_KNOB_AGG_NARROW_CELLS = 25,  /* 0: the argument column of the packed aggregate always travels as 8-byte cells */
     TSQ_KNOB_DAAGG_PART2 = 26,       /* partition kernel of the packed aggregate with a dense state: 0 = 1024 threads, one workgroup per CU; 1 = two 512-thread workgroups per CU for narrow argument cells (default); 2 = for 8-byte cells too */
     TSQ_KNOB_DAAGG_HOT = 27,         /* 0: the packed aggregate does not sample the batch for hot keys (their rows then travel through the partitioned store and its overflow store) */
-    TSQ_KNOB_KEYREC = 28,            /* 0: joins on several key columns / string keys never take the key-record route (csrc/tsq_keyrec.h), aggregates never the dictionary of group keys (csrc/tsq_keydict.h); 2: the dictionary's scatter pass writes separate arrays instead of 64-byte slots */
+    TSQ_KNOB_KEYREC = 28,            /* 0: joins on several key columns / string keys never take the key-record route (csrc/tsq_keyrec.h), aggregates never the dictionary of group keys (csrc/tsq_keydict.h); 2: the dictionary's scatter pass writes separate arrays instead of 64-byte slots; 3 (tests): the digest of a long string cell carries its length only, so that every two cells of one length are candidates and the byte comparison decides */
     TSQ_KNOB_STREAMAGG_LANES = 29,   /* 0: StreamAggExec always reduces every 64-row step across the lanes (k_sa_update) instead of keeping per-lane partial results of the open run (k_sa_update_lanes) */
     TSQ_KNOB_XCD_ATOMICS = 30,       /* retired in round 6 (was: workgroup-scope cursor atomics, an A/B that measured equal); setting it has no effect */
     TSQ_KNOB_DENSE_DIRECT = 31,      /* 0: the packed aggregate's dense state always leaves through partial groups and the hash table, also when the table is empty (k_dense_finalize off) */

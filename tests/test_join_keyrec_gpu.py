@@ -294,3 +294,25 @@ def test_long_string_keys_rows_small(ctx, orc, jt):
     got = G.run_join(ctx, cfg, build, probe, chunk_rows=4_096, pull_rows=1 << 14, radix=FORCE, stats_out=stats)
     assert stats[0].probe_route == abi.ROUTE_KEYREC and stats[0].radix_batches >= 3
     assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+
+
+@pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
+def test_long_string_keys_when_every_digest_of_a_length_collides(ctx, orc, jt):
+    # knob KEYREC = 3: a digest that only carries the length — all 40 words of a length are candidates of one another, so the byte comparison
+    # decides nearly every match (and the materialising form's notes say "not every candidate passed": its emit launch compares again).
+    # COUNT(*) and rows, several batches, NULL keys
+    rng = np.random.default_rng(5 + jt)
+    words = [bytes(rng.integers(97, 123, n, dtype=np.uint8)) for n in (40, 41, 64, 200, 1000) for _ in range(40)]
+    nb, npr = 3_000, 12_000
+    build = Chunk([StrColumn([None if rng.random() < 0.03 else words[i] for i in rng.integers(0, 150, nb).tolist()]), Column(abi.I64, np.arange(nb))])
+    probe = Chunk([StrColumn([None if rng.random() < 0.03 else words[i] for i in rng.integers(0, len(words), npr).tolist()]), Column(abi.I64, np.arange(npr))])
+    cfg = H.join_cfg(probe.types(), build.types(), [0], [0], jt, 1, probe_batch_rows=5_000)
+    want = orc.hash_join(cfg, build, probe)
+    with ctx.knobs(KEYREC=3):
+        stats = []
+        got = G.run_join(ctx, cfg, build, probe, chunk_rows=5_000, pull_rows=1 << 14, radix=FORCE, stats_out=stats)
+        assert stats[0].probe_route == abi.ROUTE_KEYREC and stats[0].keyrec_digests == 1 and stats[0].radix_batches >= 3
+        assert got.NumRows() == want.NumRows() and H.rows_equal_unordered(got, want)
+        if jt == abi.JOIN_INNER:
+            c, st = _count(ctx, cfg, build, probe, chunk_rows=5_000)
+            assert st.probe_route == abi.ROUTE_KEYREC and c == want.NumRows()

@@ -791,6 +791,7 @@ struct tsq_join {
     // long string keys (round 6): the string key columns enter the records as (length, digest of the bytes); matches are verified byte for byte
     bool kr_digest = false;
     DevBuf kr_bdig[TSQ_MAX_KEYS], kr_pdig[TSQ_MAX_KEYS];
+    DevBuf kr_vmask;                  // ... the outcomes of the sizing launch's byte comparisons, one word per probe record (k_kr_probe: vmode)
     bool filters_folded = false;      // this batch: the outer-side filters are already in the selected[] flags the packed routes take (fold_outer_filters)
     DevBuf fflags;                    //   ... those flags
     DevBuf heads;                     // da_emit_cols: first-candidate flags of a batch (outer join + conditions + duplicate build keys)
@@ -3666,6 +3667,7 @@ tsq_status kr_digests(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols
         da.nulls = cs.nulls[c];
         da.nrows = nrows;
         da.out = dig[k].as<uint64_t>();
+        da.weak = tsq_knob(ctx, TSQ_KNOB_KEYREC, 1) == 3 ? 1 : 0;
         // long cells: a wave per row (the host knows the average length from the offsets' ends)
         TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 43, cs.offs[c], 8, hipMemcpyDeviceToHost, ctx->stream));
         TSQ_HIP(h, hipMemcpyAsync(ctx->pinned + 44, cs.offs[c] + nrows, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -3869,6 +3871,11 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     pa.pids = j->kr_pids.as<uint32_t>();
     pa.outer = outer ? 1 : 0;
     kr_verify_args(j, pcs, pa);
+    if (j->kr_digest) {  // the emit launch reuses the sizing launch's byte comparisons
+        TSQ_TRY(j->kr_vmask.reserve(ctx, h, (size_t)nrows * 4 + 64));
+        pa.vmask = j->kr_vmask.as<uint32_t>();
+        pa.vmode = 1;
+    }
     // sizing launch: joined rows per partition; their exclusive scan = every partition's first output row
     TSQ_TRY(j->kr_pcnt.reserve(ctx, h, ((size_t)pa.P + 1) * 8 + 64));
     pa.part_cnt = j->kr_pcnt.as<unsigned long long>();
@@ -3896,6 +3903,7 @@ tsq_status kr_emit_batch(tsq_join* j, const tsq_colset& pcs, ProbeArgs& a, int64
     }
     return materialise_pairs(j, pcs, a, nrows, out_rows, [&]() -> tsq_status {
         pa.pairs = a.pairs;
+        if (pa.vmode == 1) pa.vmode = 2;
         kr_launch_probe(ctx, grid, pa);
         TSQ_HIP(h, hipGetLastError());
         j->st.kernel_launches++;
@@ -4665,11 +4673,16 @@ static tsq_status build_table(tsq_join* j) {
 // key column (or several that compose), nothing switched off, and a build side of the size AUTO packs (or packing FORCEd).  The
 // decision only moves WORK: a batch that takes another route builds the table first (probe_batch: need_table).
 static bool table_can_wait(const tsq_join* j, int64_t nb) {
-    if (j->never_match || j->radix_mode == TSQ_RADIX_OFF || j->packing_mode == TSQ_RADIX_OFF || nb <= 0 || nb >= 0xffffffffLL) return false;
-    if (tsq_knob(j->ctx, TSQ_KNOB_PACKED_KEYS, 1) == 0 || tsq_knob(j->ctx, TSQ_KNOB_LAZY_TABLE, 1) == 0) return false;
-    if (j->multi ? !da_multi_ok(j) : !(is_int_class(j->cfg.build_types[j->ks.bidx[0]]) && is_int_class(j->cfg.probe_types[j->ks.pidx[0]]))) return false;
-    if (!j->filters_h.empty() || j->ordered) return false;
-    return j->packing_mode == TSQ_RADIX_FORCE || nb >= tsq_knob(j->ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(1 << 20));
+    if (j->never_match || j->radix_mode == TSQ_RADIX_OFF || nb <= 0 || nb >= 0xffffffffLL) return false;
+    if (tsq_knob(j->ctx, TSQ_KNOB_LAZY_TABLE, 1) == 0 || !j->filters_h.empty() || j->ordered) return false;
+    const bool packable = j->multi ? da_multi_ok(j) : (is_int_class(j->cfg.build_types[j->ks.bidx[0]]) && is_int_class(j->cfg.probe_types[j->ks.pidx[0]]));
+    if (packable && j->packing_mode != TSQ_RADIX_OFF && tsq_knob(j->ctx, TSQ_KNOB_PACKED_KEYS, 1) != 0)
+        return j->packing_mode == TSQ_RADIX_FORCE || nb >= tsq_knob(j->ctx, TSQ_KNOB_DA_MIN_BUILD_ROWS, (int64_t)(1 << 20));
+    // string keys / key columns that do not compose: the key-record route serves the batches it takes (kr_count_eligible, kr_emit_eligible)
+    // without the table — inserting 1e5 build rows keyed by a 5 KiB string hashed every byte of them for nothing (round 6)
+    if (j->multi && !packable && tsq_knob(j->ctx, TSQ_KNOB_KEYREC, 1) != 0 && j->conds_h.empty() && nb <= (int64_t)TSQ_KR_MAXP * TSQ_KR_FILL)
+        return j->radix_mode == TSQ_RADIX_FORCE || nb >= (1 << 16);
+    return false;
 }
 
 TSQ_API tsq_status tsq_join_build_finish(tsq_join* j) {
@@ -5100,6 +5113,7 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     for (int k = 0; k < TSQ_MAX_KEYS; k++) {
         j->kr_bdig[k].release();
         j->kr_pdig[k].release();
+        j->kr_vmask.release();
     }
     for (DevBuf* b : {&j->dm_bent, &j->dm_bnn, &j->dm_boff, &j->dm_bcnt, &j->dm_bitmap, &j->dm_pent, &j->dm_pnn, &j->dm_poff, &j->dm_pcnt}) b->release();
     for (int c = 0; c < TSQ_DA_MAXCOLS; c++) {

@@ -68,6 +68,7 @@ struct KrDigestArgs {
     const uint8_t* nulls;
     int64_t nrows;
     uint64_t* out;
+    int32_t weak;  // tests (TSQ_KNOB_KEYREC = 3): the digest says nothing beyond the length — every two cells of one length collide and the byte comparison decides
 };
 template <bool WAVE>
 static __global__ void __launch_bounds__(256) k_kr_digest(KrDigestArgs a) {
@@ -89,7 +90,7 @@ static __global__ void __launch_bounds__(256) k_kr_digest(KrDigestArgs a) {
             sum += kr_digest_word(v, i);
         }
         if (WAVE) sum = wave_sum_u64(sum);
-        if (lane == 0) a.out[r] = kr_digest_finish(sum, (uint64_t)n);
+        if (lane == 0) a.out[r] = kr_digest_finish(a.weak ? 0ull : sum, (uint64_t)n);
     }
 }
 // are the n bytes at x and y the same?  Asked by a whole wave with the same arguments (the matches of digest records are checked byte for
@@ -135,8 +136,9 @@ static __global__ void __launch_bounds__(TSQ_KR_NT) k_kr_hist(KrArgs a) {
         const uint32_t p = a.pbits ? (uint32_t)(kr_hash(w) >> (64 - a.pbits)) : 0u;
         atomicAdd(&s_hist[p], 1u);
     }
-    if (bad) atomicOr(a.flags, 1u);
-    __syncthreads();
+    // (one atomic per workgroup: with every cell too long for a record — the reference's 5 KiB benchmark key — a lane-by-lane atomicOr was
+    // 1e5 atomics on one word, 1.1 ms of the pass that only finds out that digests are needed)
+    if (__syncthreads_or((int)bad) && threadIdx.x == 0) atomicOr(a.flags, 1u);
     for (uint32_t i = threadIdx.x; i < P; i += TSQ_KR_NT) a.counts[(size_t)wg * P + i] = s_hist[i];
 }
 // thread p: the prefix of partition p's counts over the workgroups (coalesced across p), its total -> pstart[p]
@@ -265,6 +267,12 @@ struct KrProbeArgs {
     const int64_t* vb_offs[TSQ_MAX_KEYS];
     const uint8_t* vp_data[TSQ_MAX_KEYS];
     const int64_t* vp_offs[TSQ_MAX_KEYS];
+    // the materialising form probes twice (sizing launch, emit launch): the sizing launch notes in vmask[record] whether EVERY candidate of
+    // the probe record passed its byte comparison (anything else is a digest collision, 2^-64) — the emit launch then takes the candidates of
+    // such a record as they are, whatever order its index hands them out in, and compares bytes only for the others: a 5 KiB key is read
+    // once, not twice.  vmode 0: compare, 1: compare and note, 2: use the notes
+    uint32_t* vmask;
+    int32_t vmode;
 };
 #define TSQ_KR_MISS 0xffffffffull
 // One workgroup per partition.  The build records of the partition stay where the scatter pass put them (a contiguous window of
@@ -354,6 +362,8 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
                 uint32_t slot = (uint32_t)h & (TSQ_KR_SLOTS - 1);
                 const uint32_t prow = valid ? a.pids[r] : 0u;
                 bool any = false, walking = valid;
+                const bool trusted = a.vmode == 2 && valid && a.vmask[r] != 0u;  // (every candidate of this record passed in the sizing launch)
+                bool all_passed = true;
                 while (__ballot(walking)) {
                     bool cand = false;
                     uint32_t bi = 0, brow = 0;
@@ -370,7 +380,7 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
                         }
                     }
                     bool same = cand;
-                    for (uint64_t need = __ballot(cand); need; need &= need - 1) {
+                    for (uint64_t need = __ballot(cand && !trusted); need; need &= need - 1) {
                         const int L = __builtin_ctzll(need);
                         const uint64_t vb = (uint32_t)__shfl((int)brow, L), vp = (uint32_t)__shfl((int)prow, L);
                         bool eq = true;
@@ -380,6 +390,7 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
                         }
                         if ((int)lane == L) same = eq;
                     }
+                    if (cand && !same) all_passed = false;
                     if (same) {
                         any = true;
                         mine++;
@@ -390,6 +401,7 @@ static __global__ void __launch_bounds__(TSQ_KR_PNT) k_kr_probe(KrProbeArgs a) {
                     }
                     if (walking) slot = (slot + 1) & (TSQ_KR_SLOTS - 1);
                 }
+                if (a.vmode == 1 && valid) a.vmask[r] = all_passed ? 1u : 0u;
                 if (a.outer && valid && !any) {
                     const unsigned long long k = atomicAdd(&s_pcnt, 1ull);
                     if (a.pairs) a.pairs[a.part_cnt[p] + k] = (unsigned long long)prow | (TSQ_KR_MISS << 32);
