@@ -581,8 +581,9 @@ __device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned lo
 // partitions of k_agg_da as long again).  Wave-uniform choice: fewer than TSQ_DAAGG_COMBINE_MIN lanes repeating their neighbour's
 // cell -> the plain per-row path (uniform keys pay one ballot).  Every lane of the wave must call; `live` = the lane holds a row.
 #define TSQ_DAAGG_COMBINE_MIN 8
+// returns: the wave combined (enough lanes repeated their neighbour's cell) — the caller's hint for the rows that follow in the same lanes
 template <int W, int CELLS, int SIG = 0>
-__device__ __forceinline__ void daagg_apply_wave(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1,
+__device__ __forceinline__ bool daagg_apply_wave(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1,
                                                  bool live) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t eprev = (uint32_t)__shfl_up((int)e, 1, 64);
@@ -591,7 +592,7 @@ __device__ __forceinline__ void daagg_apply_wave(const uint32_t (&wd)[W], unsign
     const unsigned long long hm = __ballot(head);
     if (64 - __popcll(hm) < TSQ_DAAGG_COMBINE_MIN) {
         if (live) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e, c0, c1);
-        return;
+        return false;
     }
     const bool tail = live && (lane == 63 || ((hm >> (lane + 1)) & 1ull));
     const uint32_t cm = sa_cond_mask(head, lane);
@@ -599,7 +600,7 @@ __device__ __forceinline__ void daagg_apply_wave(const uint32_t (&wd)[W], unsign
     if (SIG == 3 && W == 3) {
         const uint64_t v = sa_scan_add(live ? (1ull << TSQ_DAAGG_PACK_SHIFT) + c0 : 0ull, cm);
         if (tail) atomicAdd(&s_w[0][e], (unsigned long long)v);
-        return;
+        return true;
     }
 #pragma unroll
     for (int k = 0; k < W; k++) {
@@ -639,6 +640,7 @@ __device__ __forceinline__ void daagg_apply_wave(const uint32_t (&wd)[W], unsign
             }
         }
     }
+    return true;
 }
 // the touched cells of the workgroup's table -> partial groups; key_of(cell) = the 64-bit key word of the record
 template <int W, int CELLS, class KeyOf>
@@ -813,11 +815,14 @@ __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
                     // past the end.  The lanes of a wave hold rows 8 apart: a run of one key long enough to be worth combining — the
                     // rows of a hot key that overflowed — still puts the same cell into neighbouring lanes)
                     const bool whole_wave = (i0 - (tid & 63u) * 8u) + 63u * 8u < len;
+                    // ... and a wave whose first rows did not combine skips the test for its other seven (neighbour shuffles, a ballot and a
+                    // population count per row are a fifth of the instructions of a row whose keys do not repeat; either way is exact)
+                    bool combine = whole_wave;
 #pragma unroll
                     for (int x = 0; x < 8; x++) {
                         const uint32_t e = (ew[x >> 1] >> ((x & 1) * 16)) & 0xffffu;
                         const bool live = i0 + (uint32_t)x < len;
-                        if (whole_wave) daagg_apply_wave<W, CELLS, SIG>(wd, s_w, s_touch, e, cells[x][0], cells[x][1], live);
+                        if (combine) combine = daagg_apply_wave<W, CELLS, SIG>(wd, s_w, s_touch, e, cells[x][0], cells[x][1], live);
                         else if (live) daagg_apply<W, CELLS, SIG>(wd, s_w, s_touch, e, cells[x][0], cells[x][1]);
                     }
                 }
