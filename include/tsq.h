@@ -124,7 +124,7 @@ enum {
     TSQ_KNOB_LDS_PROF = 8,           /* 1: per-phase shader cycles of the LDS probe on stderr (synchronises) */
     TSQ_KNOB_DA_TRACE = 9,           /* 1: host time points of the travelling-columns route on stderr */
     TSQ_KNOB_BUILD_IMAGES_CAS = 10,  /* 1: the first (compare-and-swap) slice-image kernel of the partitioned build */
-    TSQ_KNOB_DAAGG_SIG = 11,         /* 0: no plan-specialised instantiations of k_agg_da; 1: SUM + COUNT(*) plans; 2: also count and sum of 2-byte cells in one LDS word */
+    TSQ_KNOB_DAAGG_SIG = 11,         /* 0: no plan-specialised instantiations of k_agg_da; 1: SUM + COUNT(*) plans; 2 (default since round 6): also count and sum of 2-byte cells in one LDS word */
     TSQ_KNOB_DAAGG_LOG2C = 12,       /* log2(cells per LDS table) of the packed aggregate, 9..12 */
     TSQ_KNOB_AGG_HEAP_GC_BYTES = 13, /* string-heap size from which the aggregate compacts between batches (default 256 MiB) */
     TSQ_KNOB_AGG_TAG_BITS = 14,      /* truncate the 64-bit group tag of a several-column GROUP BY (collision tests) */

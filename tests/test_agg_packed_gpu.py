@@ -433,16 +433,17 @@ def test_packed_agg_dense_state_emptied_between_batches(ctx, orc):
         _match_by_key(got, want, [key_out], exact_cols, real_cols, group_tols(chk, 0, aggs, real_cols))
 
 
+@pytest.mark.parametrize("sig", [2, 1])
 @pytest.mark.parametrize("key_hi", [30_000, 3_000_000])
-def test_packed_agg_count_and_sum_in_one_lds_word(ctx, orc, key_hi):
-    """TSQ_KNOB_DAAGG_SIG = 2 (default off, A/B in profiles/r04_ab_measurements.txt): SUM(BIGINT) + COUNT(*) over 2-byte argument cells
+def test_packed_agg_count_and_sum_in_one_lds_word(ctx, orc, key_hi, sig):
+    """TSQ_KNOB_DAAGG_SIG = 2 (the default since round 6; 1: two words, as before): SUM(BIGINT) + COUNT(*) over 2-byte argument cells
     keeps `count << 40 | sum` in ONE LDS word per cell; the fold into the dense state takes it apart.  Same groups as the oracle, with
     workgroups sharing partitions (30 000 keys: device atomics) and owning them (3e6 keys)."""
     rng = np.random.default_rng(key_hi % 89)
     n = 600_001
     chk, types = _dense_case(rng, n, key_hi, 50_000)
     aggs = AGG_SETS["c3"]
-    with ctx.knobs(DAAGG_SIG=2, AGG_BATCH_ROWS=1 << 18):
+    with ctx.knobs(DAAGG_SIG=sig, AGG_BATCH_ROWS=1 << 18):
         cfg = H.agg_cfg(types, [0], aggs, est_groups=key_hi)
         want = orc.hash_agg(cfg, chk, 4, 4)
         stats = []

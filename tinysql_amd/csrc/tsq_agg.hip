@@ -1415,7 +1415,9 @@ tsq_status launch_agg_da(tsq_agg* a, DaAggLdsArgs& la, int grid, hipStream_t st)
     }
     {   // the two commonest plans: update descriptors as compile-time constants (tsq_daagg.h, SIG)
         const uint32_t* wd = la.plan.wdesc;
-        const int64_t sig_knob = tsq_knob(a->ctx, TSQ_KNOB_DAAGG_SIG, 1);
+        // (default 2 since round 6: k_agg_da is bound by the instructions it issues — one LDS atomic per row instead of two: C3 5.98 -> 5.64 ms,
+        // the Zipf variant 15.0 -> 12.6 ms; round 4 measured 2 % and left it off)
+        const int64_t sig_knob = tsq_knob(a->ctx, TSQ_KNOB_DAAGG_SIG, 2);
         const bool sig_on = sig_knob != 0;
         int sig = 0;
         if (sig_on && la.plan.W == 3 && wd[0] == af_wdesc(AF_W_ADD_LO32, 0, TSQ_I64) && wd[1] == af_wdesc(AF_W_ADD_HI32, 0, TSQ_I64) && wd[2] == af_wdesc(AF_W_ADD1, 0, 0)) sig = 1;

@@ -541,12 +541,12 @@ struct DaAggLdsArgs {
 // into the dense state takes the word apart again (TSQ_DAAGG_PACK_SHIFT).
 template <int W, int CELLS, int SIG = 0>
 __device__ __forceinline__ void daagg_apply(const uint32_t (&wd)[W], unsigned long long (*s_w)[CELLS], uint32_t* s_touch, uint32_t e, uint64_t c0, uint64_t c1) {
-    // (a plain LDS read first: after its first row a cell's bit is set, and a returning-or-not LDS atomic costs more than a read)
-    if (!((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
-    if (SIG == 3 && W == 3) {
+    if (SIG == 3 && W == 3) {  // (no touch bit: the packed word counts its rows — a cell is touched iff its word is not zero, daagg_fold_dense)
         atomicAdd(&s_w[0][e], (1ull << TSQ_DAAGG_PACK_SHIFT) + (unsigned long long)c0);
         return;
     }
+    // (a plain LDS read first: after its first row a cell's bit is set, and a returning-or-not LDS atomic costs more than a read)
+    if (!((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
     if (SIG == 1 && W == 3) {
         atomicAdd(&s_w[0][e], (unsigned long long)(c0 & 0xffffffffull));
         if ((long long)c0 >> 32) atomicAdd(&s_w[1][e], (unsigned long long)((long long)c0 >> 32));
@@ -596,12 +596,12 @@ __device__ __forceinline__ bool daagg_apply_wave(const uint32_t (&wd)[W], unsign
     }
     const bool tail = live && (lane == 63 || ((hm >> (lane + 1)) & 1ull));
     const uint32_t cm = sa_cond_mask(head, lane);
-    if (tail && !((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
     if (SIG == 3 && W == 3) {
         const uint64_t v = sa_scan_add(live ? (1ull << TSQ_DAAGG_PACK_SHIFT) + c0 : 0ull, cm);
         if (tail) atomicAdd(&s_w[0][e], (unsigned long long)v);
         return true;
     }
+    if (tail && !((s_touch[e >> 5] >> (e & 31u)) & 1u)) atomicOr(&s_touch[e >> 5], 1u << (e & 31u));
 #pragma unroll
     for (int k = 0; k < W; k++) {
         const uint32_t d = wd[k];
@@ -697,9 +697,16 @@ __device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const 
     const size_t cbase = (size_t)p << a.st.ebits;
     const bool shared = a.nsplit > 1 || a.concurrent != 0;
     for (uint32_t i = tid; i < ncell; i += TSQ_AF_NT) {
-        if (!((s_touch[i >> 5] >> (i & 31u)) & 1u)) continue;
         if (SIG == 3 && W == 3) {  // word 0 = count << 40 | sum: into the dense lo32 sum (word 0) and count (word 2); the hi32 sum stays
             const unsigned long long v = s_w[0][i];
+            // the touch bits of these 64 cells (ncell is a multiple of 32, i of the wave's first lane one of 64: one or two words)
+            const unsigned long long tm = __ballot(v != 0ull);
+            if ((tid & 63u) == 0) {
+                const size_t wbit = (cbase + i) >> 5;
+                if ((uint32_t)tm) atomicOr(&a.dense_touch[wbit], (uint32_t)tm);
+                if ((uint32_t)(tm >> 32)) atomicOr(&a.dense_touch[wbit + 1], (uint32_t)(tm >> 32));
+            }
+            if (v == 0ull) continue;
             const unsigned long long sum = v & ((1ull << TSQ_DAAGG_PACK_SHIFT) - 1ull), cnt = v >> TSQ_DAAGG_PACK_SHIFT;
             unsigned long long* g0 = a.dense_w[0] + cbase + i;
             unsigned long long* g2 = a.dense_w[W - 1] + cbase + i;
@@ -712,6 +719,7 @@ __device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const 
             }
             continue;
         }
+        if (!((s_touch[i >> 5] >> (i & 31u)) & 1u)) continue;
 #pragma unroll
         for (int k = 0; k < W; k++) {
             unsigned long long* g = a.dense_w[k] + cbase + i;
@@ -736,8 +744,9 @@ __device__ __forceinline__ void daagg_fold_dense(const uint32_t (&wd)[W], const 
             }
         }
     }
-    for (uint32_t i = tid; i < ncell / 32; i += TSQ_AF_NT)
-        if (s_touch[i]) atomicOr(&a.dense_touch[(cbase >> 5) + i], s_touch[i]);
+    if (!(SIG == 3 && W == 3))
+        for (uint32_t i = tid; i < ncell / 32; i += TSQ_AF_NT)
+            if (s_touch[i]) atomicOr(&a.dense_touch[(cbase >> 5) + i], s_touch[i]);
 }
 template <int W, int CELLS, int SIG = 0>
 __global__ void __launch_bounds__(TSQ_AF_NT) k_agg_da(DaAggLdsArgs a) {
