@@ -715,3 +715,38 @@ def test_an_outer_side_filter_that_raises_an_error_is_the_direct_routes(ctx, orc
     with pytest.raises(Exception) as ei:
         G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, pull_rows=1 << 20, radix=FORCE, packing=FORCE)
     assert "overflow" in str(ei.value).lower() or "range" in str(ei.value).lower()
+
+
+@pytest.mark.parametrize("nk,wide", [(2, False), (3, False), (4, False), (2, True)])
+def test_packed_several_key_columns_composed_in_the_partition_kernel(ctx, orc, nk, wide):
+    """round 6: COUNT(*) over several integer key columns WITHOUT NULL bitmaps — k_da_partition2<.., MK> reads the columns itself and makes
+    the composite in registers (no k_da_compose, no composite column in HBM).  Full tiles and a partly filled last one, probe cells outside
+    the build side's fields, BIGINT cells against BIGINT UNSIGNED ones (cells >= 2^63 never match), 2-byte and 4-byte entries (fields of
+    27 bits); the same counts from the oracle, from the kernel that reads a composed column (knob DA_PARTITION = 1) and with packing off,
+    and one kernel launch fewer per batch."""
+    rng = np.random.default_rng(nk * 7 + wide)
+    if wide:
+        fields = [(abi.I64, -5000, 5000), (abi.I64, 10**12, 10**12 + 9000)]  # 14 + 14 bits: entries of 17 bits
+        nb = 200_000
+    else:
+        fields = [(abi.I64, -40, 41), (abi.I64, 10**12, 10**12 + 9), (abi.U64, 0, 5), (abi.I64, -3, 4)][:nk]
+        nb = 5000
+    build = _mk_side(rng, nb, fields, 1, null_key=0.03)
+    n_probe = 16384 * 3 + 77
+    probe = _mk_side(rng, n_probe, [(abi.I64 if tp == abi.U64 else tp, lo - 3, hi + 3) for tp, lo, hi in fields], 1, null_key=0)
+    keys = list(range(nk))
+    cfg = H.join_cfg(probe.types(), build.types(), keys, keys, abi.JOIN_INNER, 1)
+    want = orc.hash_join(cfg, build, probe).NumRows()
+    assert want > 0
+    launches = {}
+    for variant in (0, 1):
+        stats = []
+        with ctx.knobs(DA_PARTITION=variant):
+            got = G.run_join(ctx, cfg, build, probe, chunk_rows=1 << 22, count_only=True, radix=FORCE, packing=FORCE, stats_out=stats)
+        assert stats[0].probe_route == abi.ROUTE_PACKED and got == want, (variant, got, want)
+        launches[variant] = stats[0].kernel_launches
+    assert launches[0] == launches[1] - 1, launches  # (no k_da_compose)
+    assert _count(ctx, cfg, build, probe, packing=OFF) == want
+    # NULL key cells on the probe side: the batch is composed as before (a bitmap is not read by the fused kernel), same count
+    probe2 = _mk_side(rng, n_probe, [(abi.I64 if tp == abi.U64 else tp, lo - 3, hi + 3) for tp, lo, hi in fields], 1, null_key=0.05)
+    assert _count(ctx, cfg, build, probe2, want_route=abi.ROUTE_PACKED) == orc.hash_join(cfg, build, probe2).NumRows()

@@ -1169,10 +1169,18 @@ DaGeom da_geometry(uint32_t pbits, uint32_t ebits, int64_t nrows, int T) {
     g.ctl_bytes = ((g.nregions + 16) * 4 + 511) & ~(size_t)511;
     return g;
 }
-tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st, bool with_idx = false, bool miss = false) {
+tsq_status da_launch_partition(tsq_join* j, const DaSrc& src, const DaStore& st, bool with_idx = false, bool miss = false, const DaMk* mk = nullptr) {
     constexpr int NT = 1024, K = 16, T = NT * K;
     const int64_t ntiles = (src.nrows + T - 1) / T;
     const dim3 grid((unsigned)std::min<int64_t>(ntiles, j->ctx->num_cus));
+    if (mk) {  // several key columns composed inside the kernel (da_mk_usable: COUNT(*), 2-byte entries, no bitmaps / flags)
+        const dim3 grid2((unsigned)std::min<int64_t>(ntiles, (int64_t)j->ctx->num_cus * 2));
+        if (st.ebits > 16) hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true, uint32_t, false, true>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st, *mk);
+        else hipLaunchKernelGGL((k_da_partition2<512, 8, 4, true, uint16_t, false, true>), grid2, dim3(512), 0, j->ctx->stream, src, j->da_dm, st, *mk);
+        TSQ_HIP(&j->hdr, hipGetLastError());
+        j->st.kernel_launches++;
+        return TSQ_OK;
+    }
     if (with_idx && st.ebits > 16) {  // (4-byte entries with row ids: the bit-cell pairs route; 8 keys per thread — the row ids share the LDS)
         constexpr int K8 = 8, T8 = NT * K8;
         const dim3 grid8((unsigned)std::min<int64_t>((src.nrows + T8 - 1) / T8, j->ctx->num_cus));
@@ -1228,6 +1236,20 @@ void da_build_key(const tsq_join* j, DaSrc& src) {
     src.nulls = j->bcols[kc].has_nulls ? j->bcols[kc].nulls.as<uint8_t>() : nullptr;
 }
 // ... and a probe batch's (composed into j->rckey first when the key has several columns)
+// may the partition kernel compose the key columns itself?  The COUNT(*) kernel with two workgroups per CU, columns
+// without NULL bitmaps on 16-byte boundaries, no selection flags; knob DA_PARTITION = 1 (the 1024-thread kernel) keeps k_da_compose
+bool da_mk_usable(const tsq_join* j, const tsq_colset& pcs, const DaStore& st, const uint8_t* sel, DaMk& mk) {
+    (void)st;
+    if (!j->da_multi || sel != nullptr || tsq_knob(j->ctx, TSQ_KNOB_DA_PARTITION, 0) != 0 || tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) == 0) return false;
+    memset(&mk, 0, sizeof mk);
+    mk.f = j->da_fields;
+    for (int k = 0; k < j->ks.n_keys; k++) {
+        const int c = j->ks.pidx[k];
+        if (pcs.nulls[c] != nullptr || ((uintptr_t)pcs.data[c] & 15u)) return false;
+        mk.col[k] = (const uint64_t*)pcs.data[c];
+    }
+    return true;
+}
 tsq_status da_probe_key(tsq_join* j, const tsq_colset& pcs, int64_t nrows, DaSrc& src, const uint8_t* sel = nullptr) {
     memset(&src, 0, sizeof src);
     src.nrows = nrows;
@@ -1640,8 +1662,15 @@ tsq_status da_probe(tsq_join* j, const tsq_colset& pcs, int64_t nrows, const uin
     TSQ_HIP(h, hipEventRecord(j->ev[2], ctx->stream));
     TSQ_HIP(h, hipEventRecord(re[0], ctx->stream));
     DaSrc src;
-    TSQ_TRY(da_probe_key(j, pcs, nrows, src, sel));
-    TSQ_TRY(da_launch_partition(j, src, st));
+    DaMk mk;
+    if (da_mk_usable(j, pcs, st, sel, mk)) {  // several key columns: composed in the partition kernel's registers (no composite column in HBM)
+        memset(&src, 0, sizeof src);
+        src.nrows = nrows;
+        TSQ_TRY(da_launch_partition(j, src, st, false, false, &mk));
+    } else {
+        TSQ_TRY(da_probe_key(j, pcs, nrows, src, sel));
+        TSQ_TRY(da_launch_partition(j, src, st));
+    }
     TSQ_HIP(h, hipEventRecord(re[1], ctx->stream));
     DaProbeArgs pa;
     memset(&pa, 0, sizeof pa);
