@@ -150,6 +150,7 @@ enum {
     TSQ_KNOB_DA_LDS_BUILD = 32,      /* 0: the materialising packed join never keeps a partition's build rows in LDS (csrc/tsq_damat.h): unique build sides take the sorted-build-columns variant of round 4 like the others; 2 .. 5 (tests): the second partition level splits 1 / 2 / 4 / 8 ways whatever the build side's size */
     TSQ_KNOB_AGG_PG = 33,            /* 0: an aggregate with about as many groups as rows never keeps its groups in partitioned LDS-sized sub-tables (csrc/tsq_aggfast.h K7p): the row upsert serves it; v >= 2 (tests): the mode is taken whatever the estimate, with 2^(v - 2) sub-tables */
     TSQ_KNOB_AGG_OVERLAP = 34,       /* default 0: the packed aggregate with a dense state runs every batch on one stream (partition pass, then k_agg_da); 1: k_agg_da / k_daagg_ovf of a batch run on a side stream beside the partition pass of the next batch (two partitioned stores) for batches of 2^24 rows or more — an A/B that measured SLOWER (C3 7.0 -> 10.1 ms, profiles/r06_ab_measurements.txt); v >= 2 (tests): for batches of v rows or more */
+    TSQ_KNOB_JIT_VARIANT = 35,       /* A/B bits of the hiprtc-specialised projection kernel (jit_expr), default 7 (measured 0.525 -> 0.453 ms per 1e8 rows of (a+b)*3-a against 0, profiles/r06_jit_sweep.txt): 1 = non-temporal loads of the input cells, 2 = non-temporal stores of the result, 4 = whole-wave coalesced 16-byte accesses (a lane takes rows 2 l, 2 l + 1 of each 128-row half of a 256-row step instead of four consecutive rows), 8 = two steps' loads in flight; bits 4-6: workgroups per CU = 8 (0), 4, 16, 32, 2 */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);
@@ -322,10 +323,12 @@ tsq_status tsq_expr_eval_str(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols
 tsq_status tsq_filter_eval(tsq_expr* e, const tsq_col* in_cols, int32_t n_cols, int64_t nrows,
                            const int32_t* sel, uint8_t* selected_out, uint8_t* isnull_out,
                            int64_t* div_by_zero_warnings);
-/* Kernel selection.  TSQ_JIT_AUTO (default): once a handle has seen >= 4 Mi rows its programs are compiled into
+/* Kernel selection.  TSQ_JIT_AUTO (default): once a handle has seen >= 256 Ki rows its programs are compiled into
  * specialised kernels with hiprtc (same source as the interpreter, programs as compile-time constants: the node loop
- * unrolls and every opcode switch folds); smaller inputs and any hiprtc failure use the generic interpreter kernels
- * (tsq_last_error(e) after tsq_expr_jit_launches tells why).  Results are identical by construction. */
+ * unrolls and every opcode switch folds) — on a helper thread: no call waits for the compile (~250 ms per distinct tree and
+ * context, cached), the generic interpreter kernels serve the handle until the code object is there, and they keep serving
+ * smaller inputs and any hiprtc failure (tsq_last_error(e) after tsq_expr_jit_launches tells why).  TSQ_JIT_FORCE compiles
+ * inside the first call.  Results are identical by construction. */
 #define TSQ_JIT_AUTO  (-1)
 #define TSQ_JIT_OFF     0
 #define TSQ_JIT_FORCE   1

@@ -152,3 +152,58 @@ def test_jit_four_rows_per_lane_and_the_bitmap_written_by_the_kernel(ctx, orc, n
     chk = Chunk([Column(abi.I64, a, rng.random(n) > 0.1), Column(abi.I64, np.ones(n, np.int64))])
     e = E.ScalarFunction("plus", E.Column(0, abi.I64), E.Column(1, abi.I64))
     check_same(ctx, orc, e, chk, jit=abi.JIT_FORCE)  # row n/2 + 3 overflows (unless it is NULL: then the batch passes) — same status either way
+
+
+@pytest.mark.parametrize("variant", [0, 4, 3, 12, 15, 8 | 16, 4 | 64])
+@pytest.mark.parametrize("n", [4096, 10_007, 131_073])
+def test_jit_variants_agree_with_the_oracle(ctx, orc, n, variant):
+    # TSQ_KNOB_JIT_VARIANT: the A/B forms of jit_expr (non-temporal accesses, the whole-wave coalesced row layout with its own bitmap words,
+    # two steps in flight, other grid sizes) are the same function of the rows — every signature, NULLs in and out, an overflow mid-batch
+    ctx.set_knob(abi.KNOB_JIT_VARIANT, variant)
+    try:
+        rng = np.random.default_rng(n + variant)
+        small, full = cols_for(rng, n, True), cols_for(rng, n, False)
+        for i, e in enumerate(all_exprs()):
+            check_same(ctx, orc, e, small if i % 2 == 0 else full, jit=abi.JIT_FORCE)
+        a = rng.integers(-1000, 1000, n)
+        a[n // 2 + 3] = (1 << 63) - 1
+        from tinysql_amd.chunk import Chunk, Column
+        chk = Chunk([Column(abi.I64, a, rng.random(n) > 0.1), Column(abi.I64, np.ones(n, np.int64))])
+        check_same(ctx, orc, E.ScalarFunction("plus", E.Column(0, abi.I64), E.Column(1, abi.I64)), chk, jit=abi.JIT_FORCE)
+    finally:
+        ctx.set_knob(abi.KNOB_JIT_VARIANT, -1)
+
+
+def test_jit_auto_compiles_on_a_helper_thread_and_never_blocks(ctx, orc):
+    # TSQ_JIT_AUTO (round 6): the hiprtc compile of a plan runs on a helper thread once the handle has seen 256 Ki rows; the calls made
+    # meanwhile are served by the interpreter kernels (same rows), and once the code object is there the specialised kernel takes over
+    import time
+    F = E.ScalarFunction
+    rng = np.random.default_rng(77)
+    n = 300_000
+    chk = cols_for(rng, n, True)
+    e = F("minus", F("mul", F("plus", E.Column(0, abi.I64), E.Column(1, abi.I64)), E.Constant(7)), E.Column(0, abi.I64))
+    ce = E.CompiledExpr(ctx, [e])  # (no jit argument: AUTO)
+    try:
+        want, _ = orc.expr_eval(E.compile_expr(e), chk)
+        wn = want.notnull if want.notnull is not None else np.ones(len(want), bool)
+        t0 = time.time()
+        first_call = None
+        calls = 0
+        while time.time() - t0 < 60:
+            t = time.time()
+            got = ce.VecEval(chk)
+            if first_call is None:
+                first_call = time.time() - t
+            calls += 1
+            gn = got.notnull if got.notnull is not None else np.ones(len(got), bool)
+            assert (gn == wn).all() and (got.data.view(np.uint64)[gn] == want.data.view(np.uint64)[wn]).all()
+            if ce.jit_launches() >= 1:
+                break
+            time.sleep(0.01)
+        assert ce.jit_launches() >= 1, "the helper thread's module never arrived"
+        assert calls >= 2  # the first call could not have waited for the compile ...
+        assert first_call < 0.15  # ... and did not (hiprtc takes ~250 ms)
+        assert ce.jit_compile_ms() > 1.0
+    finally:
+        ce.close()

@@ -97,8 +97,10 @@ TSQ_API void tsq_ctx_destroy(tsq_ctx* ctx) {
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     (void)hipDeviceSynchronize();
     for (hipModule_t m : ctx->retired_modules) (void)hipModuleUnload(m);
-    for (auto& kv : ctx->jit_cache)
+    for (auto& kv : ctx->jit_cache) {
+        if (kv.second.worker.joinable()) kv.second.worker.join();  // (a compile still running on its helper thread)
         if (kv.second.mod) (void)hipModuleUnload(kv.second.mod);
+    }
     for (auto& b : ctx->pool) (void)hipFree(b.first);
     for (auto& b : ctx->user_allocs)  // blocks the caller never handed back (the arena's go with the slab)
         if (!ctx->arena_base || (char*)b.first < ctx->arena_base || (char*)b.first >= ctx->arena_base + ctx->arena.size) (void)hipFree(b.first);

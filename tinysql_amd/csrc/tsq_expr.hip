@@ -146,6 +146,7 @@ struct tsq_expr {
     // loop of tsq_eval_row unrolls and every switch folds — same source, same semantics, ~10x fewer instructions
     int32_t jit_mode = TSQ_JIT_AUTO;
     bool jit_tried = false;
+    std::string jit_src;  // generated once per handle (the plan cache's key)
     hipModule_t jit_mod = nullptr;
     hipFunction_t jit_expr = nullptr, jit_filter = nullptr;
     int64_t rows_seen = 0, jit_launches = 0;
@@ -263,7 +264,7 @@ TSQ_API tsq_status tsq_expr_compile(tsq_ctx* ctx, const tsq_expr_prog* progs, in
 // stack traffic), i.e. a 7-node expression runs at 6 % of the HBM roofline.  For large inputs the SAME source
 // (tsq.h + tsq_device.h, embedded at build time) is compiled once per handle with the programs as a constant
 // table; the compiler unrolls the node loop and folds every opcode switch, leaving straight-line code.
-static std::string jit_source(const std::vector<tsq_expr_prog>& progs) {
+static std::string jit_source(const std::vector<tsq_expr_prog>& progs, int variant) {
     std::ostringstream o;
     o << "#define TSQ_JIT 1\n";
     o << "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
@@ -287,7 +288,7 @@ static std::string jit_source(const std::vector<tsq_expr_prog>& progs) {
         o << "} },\n";
     }
     o << "};\n";
-    o << "#define N_PROGS " << progs.size() << "\n";
+    o << "#define N_PROGS " << progs.size() << "\n#define JIT_VARIANT " << variant << "\n";
     // ---- round 6: TWO rows per lane.  The 8-byte cells of the columns the programs read are loaded beforehand, rows 2 p and 2 p + 1 of a
     // column with ONE 16-byte load (a float4-style stream: the 8-byte-per-lane loop reached 0.38 of the roofline on (a + b) * 3 - a), and
     // the two results leave with one 16-byte store (+ one 2-byte store of their NOT-NULL flags).  SLOT[c] = the register slot of column c.
@@ -335,26 +336,105 @@ __device__ bool jit_pairs_usable(const ExprArgs& a, const void* out, unsigned ou
     return true;
 }
 // rows 4 q .. 4 q + 3 of every column the tree reads: two 16-byte loads per column and lane (a wave takes 2 KB of a column at once), the
-// four NOT-NULL bits = one nibble of the bitmap
+// four NOT-NULL bits = one nibble of the bitmap.  JIT_VARIANT & 4 (A/B): a wave's step of 256 rows as two whole-wave coalesced
+// 16-byte accesses — lane l takes rows 2 l, 2 l + 1 of the first and of the second 128 rows
+#define JIT_COAL ((JIT_VARIANT & 4) != 0)
+__device__ __forceinline__ int64_t jit_row(int64_t q, int r) {
+    if (!JIT_COAL) return 4 * q + r;
+    return ((q >> 6) << 8) + ((r >> 1) << 7) + 2 * (q & 63) + (r & 1);
+}
+__device__ __forceinline__ jit_v2u64 jit_ld16(const jit_v2u64* p) {
+    if (JIT_VARIANT & 1) return __builtin_nontemporal_load(p);
+    return *p;
+}
+__device__ __forceinline__ void jit_st16(jit_v2u64* p, jit_v2u64 v) {
+    if (JIT_VARIANT & 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 __device__ __forceinline__ void jit_load_quad(const ExprArgs& a, int64_t q, tsq_pre_src (&s)[4]) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         s[r].cs = &a.in;
-        s[r].row = 4 * q + r;
+        s[r].row = jit_row(q, r);
     }
+    const int64_t i0 = JIT_COAL ? ((q >> 6) << 7) + (q & 63) : 2 * q, i1 = JIT_COAL ? i0 + 64 : i0 + 1;
 #pragma unroll
     for (int sl = 0; sl < N_SLOTS; sl++) {
         const int c = SLOT_COL[sl];
-        const jit_v2u64* src = reinterpret_cast<const jit_v2u64*>(a.in.data[c]) + 2 * q;
-        const jit_v2u64 x = src[0], y = src[1];
+        const jit_v2u64* src = reinterpret_cast<const jit_v2u64*>(a.in.data[c]);
+        const jit_v2u64 x = jit_ld16(src + i0), y = jit_ld16(src + i1);
         s[0].cell[sl] = x.x;
         s[1].cell[sl] = x.y;
         s[2].cell[sl] = y.x;
         s[3].cell[sl] = y.y;
         uint32_t b = 0xfu;
-        if (a.in.nulls[c]) b = (uint32_t)a.in.nulls[c][q >> 1] >> ((uint32_t)(q & 1) * 4u);
+        if (a.in.nulls[c]) {
+            if (JIT_COAL) {
+                const int64_t by = ((q >> 6) << 5) + ((q & 63) >> 2);
+                const uint32_t sh = 2u * (uint32_t)(q & 3);
+                b = (((uint32_t)a.in.nulls[c][by] >> sh) & 3u) | ((((uint32_t)a.in.nulls[c][by + 16] >> sh) & 3u) << 2);
+            } else b = (uint32_t)a.in.nulls[c][q >> 1] >> ((uint32_t)(q & 1) * 4u);
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) s[r].isnull[sl] = !((b >> r) & 1u);
+    }
+}
+// one lane's four rows of a step: evaluated, stored; the NOT-NULL bits as whole 32-row words of the result's bitmap (bits) or as flag bytes
+__device__ __forceinline__ void jit_quad(const ExprArgs& a, int64_t q, tsq_pre_src (&s)[4], bool bits, uint64_t& errw, uint32_t& div0) {
+    tsq_val v[4];
+    int n[4] = {0, 0, 0, 0}, d0 = 0;
+    tsq_status t[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) t[r] = tsq_eval_row(P[0], s[r], &v[r], &n[r], &d0);
+    div0 += (uint32_t)d0;
+    const bool ok = t[0] == TSQ_OK && t[1] == TSQ_OK && t[2] == TSQ_OK && t[3] == TSQ_OK;
+    if (bits) {  // (a row that raised an error: the whole result is discarded)
+        if (JIT_COAL) {  // sixteen lanes make one word of each half
+            const uint32_t l16 = (uint32_t)q & 15u;
+            uint32_t w0 = ((v[0].null ? 0u : 1u) | (v[1].null ? 0u : 2u)) << (2u * l16), w1 = ((v[2].null ? 0u : 1u) | (v[3].null ? 0u : 2u)) << (2u * l16);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                w0 |= (uint32_t)__shfl_xor((int)w0, o);
+                w1 |= (uint32_t)__shfl_xor((int)w1, o);
+            }
+            if (l16 == 0) {
+                const int64_t wi = ((q >> 6) << 3) + ((q & 63) >> 4);
+                a.out_bits[wi] = w0;
+                a.out_bits[wi + 4] = w1;
+            }
+        } else {  // a lane's four rows are a nibble; eight neighbouring lanes make one word
+            const uint32_t lane8 = (uint32_t)q & 7u;
+            uint32_t w = ((v[0].null ? 0u : 1u) | (v[1].null ? 0u : 2u) | (v[2].null ? 0u : 4u) | (v[3].null ? 0u : 8u)) << (4u * lane8);
+            w |= (uint32_t)__shfl_xor((int)w, 1);
+            w |= (uint32_t)__shfl_xor((int)w, 2);
+            w |= (uint32_t)__shfl_xor((int)w, 4);
+            if (lane8 == 0) a.out_bits[q >> 3] = w;
+        }
+    }
+    if (ok) {
+        jit_v2u64 y0, y1;
+        y0.x = (uint64_t)v[0].v;
+        y0.y = (uint64_t)v[1].v;
+        y1.x = (uint64_t)v[2].v;
+        y1.y = (uint64_t)v[3].v;
+        jit_v2u64* dst = reinterpret_cast<jit_v2u64*>(a.out_data);
+        const int64_t i0 = JIT_COAL ? ((q >> 6) << 7) + (q & 63) : 2 * q, i1 = JIT_COAL ? i0 + 64 : i0 + 1;
+        jit_st16(dst + i0, y0);
+        jit_st16(dst + i1, y1);
+        if (!bits) {
+            if (JIT_COAL) {
+                *reinterpret_cast<unsigned short*>(a.out_notnull + jit_row(q, 0)) = (unsigned short)((v[0].null ? 0u : 1u) | (v[1].null ? 0u : 0x100u));
+                *reinterpret_cast<unsigned short*>(a.out_notnull + jit_row(q, 2)) = (unsigned short)((v[2].null ? 0u : 1u) | (v[3].null ? 0u : 0x100u));
+            } else
+                reinterpret_cast<uint32_t*>(a.out_notnull)[q] = (v[0].null ? 0u : 1u) | (v[1].null ? 0u : 0x100u) | (v[2].null ? 0u : 0x10000u) | (v[3].null ? 0u : 0x1000000u);
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int64_t row = jit_row(q, r);
+        if (t[r] != TSQ_OK) { const uint64_t w = tsq_errword(0, n[r], (uint64_t)row, t[r]); errw = w < errw ? w : errw; }
+        else { a.out_data[row] = (uint64_t)v[r].v; if (!bits) a.out_notnull[row] = v[r].null ? 0 : 1; }
     }
 }
 extern "C" __global__ void __launch_bounds__(256) jit_expr(ExprArgs a) {
@@ -363,45 +443,23 @@ extern "C" __global__ void __launch_bounds__(256) jit_expr(ExprArgs a) {
     uint32_t div0 = 0;
     int64_t first = 0;  // rows the four-row loop has done
     if (jit_pairs_usable(a, a.out_data, 16u) && !((unsigned long)a.out_notnull & 3u)) {
-        // the NOT-NULL bits of a lane's four rows are a nibble; eight neighbouring lanes make one 32-row word of the result's bitmap and
-        // write it themselves (out_bits: the host's pack pass then starts at row counters[2]) — otherwise four flag bytes per lane
+        // whole 32-row words of the result's bitmap are written by the lanes themselves (out_bits: the host's pack pass then starts at row
+        // counters[2]) — otherwise flag bytes
         const bool bits = a.out_bits != nullptr;
-        const int64_t nq = bits ? (a.nrows >> 5) << 3 : a.nrows >> 2;
-        const uint32_t lane8 = threadIdx.x & 7u;
-        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {  // (nq % 8 == 0 with `bits`: the eight lanes of a word stay together)
+        const int64_t nq = JIT_COAL ? (a.nrows >> 8) << 6 : (bits ? (a.nrows >> 5) << 3 : a.nrows >> 2);  // (whole words / whole waves stay together)
+        int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (JIT_VARIANT & 8)
+            for (; q + stride < nq; q += 2 * stride) {  // two steps' loads in flight
+                tsq_pre_src s0[4], s1[4];
+                jit_load_quad(a, q, s0);
+                jit_load_quad(a, q + stride, s1);
+                jit_quad(a, q, s0, bits, errw, div0);
+                jit_quad(a, q + stride, s1, bits, errw, div0);
+            }
+        for (; q < nq; q += stride) {
             tsq_pre_src s[4];
             jit_load_quad(a, q, s);
-            tsq_val v[4];
-            int n[4] = {0, 0, 0, 0}, d0 = 0;
-            tsq_status t[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) t[r] = tsq_eval_row(P[0], s[r], &v[r], &n[r], &d0);
-            div0 += (uint32_t)d0;
-            const bool ok = t[0] == TSQ_OK && t[1] == TSQ_OK && t[2] == TSQ_OK && t[3] == TSQ_OK;
-            if (bits) {
-                uint32_t w = ((v[0].null ? 0u : 1u) | (v[1].null ? 0u : 2u) | (v[2].null ? 0u : 4u) | (v[3].null ? 0u : 8u)) << (4u * lane8);
-                w |= (uint32_t)__shfl_xor((int)w, 1);
-                w |= (uint32_t)__shfl_xor((int)w, 2);
-                w |= (uint32_t)__shfl_xor((int)w, 4);
-                if (lane8 == 0) a.out_bits[q >> 3] = w;  // (a row that raised an error: the whole result is discarded)
-            }
-            if (ok) {
-                jit_v2u64 y0, y1;
-                y0.x = (uint64_t)v[0].v;
-                y0.y = (uint64_t)v[1].v;
-                y1.x = (uint64_t)v[2].v;
-                y1.y = (uint64_t)v[3].v;
-                jit_v2u64* dst = reinterpret_cast<jit_v2u64*>(a.out_data) + 2 * q;
-                dst[0] = y0;
-                dst[1] = y1;
-                if (!bits) reinterpret_cast<uint32_t*>(a.out_notnull)[q] = (v[0].null ? 0u : 1u) | (v[1].null ? 0u : 0x100u) | (v[2].null ? 0u : 0x10000u) | (v[3].null ? 0u : 0x1000000u);
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (t[r] != TSQ_OK) { const uint64_t w = tsq_errword(0, n[r], (uint64_t)(4 * q + r), t[r]); errw = w < errw ? w : errw; }
-                else { a.out_data[4 * q + r] = (uint64_t)v[r].v; if (!bits) a.out_notnull[4 * q + r] = v[r].null ? 0 : 1; }
-            }
+            jit_quad(a, q, s, bits, errw, div0);
         }
         first = nq * 4;
         if (bits && blockIdx.x == 0 && threadIdx.x == 0) a.counters[2] = (unsigned long long)first;
@@ -451,20 +509,16 @@ extern "C" __global__ void __launch_bounds__(256) jit_filter(ExprArgs a) {
     return o.str();
 }
 
-// compiles once per handle; on any failure the generic kernels keep serving (still the GPU, never a CPU path)
-static void jit_compile_inner(tsq_ctx* ctx, const std::string& src, tsq_ctx::JitEntry& out);
-static void jit_compile(tsq_ctx* ctx, const std::string& src, tsq_ctx::JitEntry& out) {
+// compiles once per distinct program set and context; on any failure the generic kernels keep serving (still the GPU, never a CPU path).
+// jit_compile_code: source -> code object (hiprtc only: no device call, so a helper thread may run it); jit_load: code object -> module
+static void jit_compile_code(const std::string& arch_name, const std::string& src, tsq_ctx::JitEntry& out) {
     const auto t0 = std::chrono::steady_clock::now();
-    jit_compile_inner(ctx, src, out);
-    out.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-}
-static void jit_compile_inner(tsq_ctx* ctx, const std::string& src, tsq_ctx::JitEntry& out) {
     hiprtcProgram prog = nullptr;
     if (hiprtcCreateProgram(&prog, src.c_str(), "tsq_expr_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         out.log = "hiprtcCreateProgram failed";
         return;
     }
-    std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
+    std::string arch = std::string("--offload-arch=") + arch_name;
     const char* opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics"};
     const hiprtcResult rc = hiprtcCompileProgram(prog, 5, opts);
     size_t logsz = 0;
@@ -472,52 +526,79 @@ static void jit_compile_inner(tsq_ctx* ctx, const std::string& src, tsq_ctx::Jit
         out.log.resize(logsz);
         (void)hiprtcGetProgramLog(prog, &out.log[0]);
     }
-    if (rc != HIPRTC_SUCCESS) {
-        (void)hiprtcDestroyProgram(&prog);
-        return;
-    }
     size_t codesz = 0;
-    std::vector<char> code;
-    if (hiprtcGetCodeSize(prog, &codesz) == HIPRTC_SUCCESS && codesz) {
-        code.resize(codesz);
-        if (hiprtcGetCode(prog, code.data()) != HIPRTC_SUCCESS) code.clear();
+    if (rc == HIPRTC_SUCCESS && hiprtcGetCodeSize(prog, &codesz) == HIPRTC_SUCCESS && codesz) {
+        out.code.resize(codesz);
+        if (hiprtcGetCode(prog, out.code.data()) != HIPRTC_SUCCESS) out.code.clear();
     }
     (void)hiprtcDestroyProgram(&prog);
-    if (code.empty()) return;
-    if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) {
+    out.compile_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+static void jit_load(tsq_ctx::JitEntry& out) {
+    if (out.code.empty()) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipModuleLoadData(&out.mod, out.code.data()) != hipSuccess) {
         out.mod = nullptr;
         out.log += "\nhipModuleLoadData failed";
-        return;
+    } else {
+        if (hipModuleGetFunction(&out.f_expr, out.mod, "jit_expr") != hipSuccess) out.f_expr = nullptr;
+        if (hipModuleGetFunction(&out.f_filter, out.mod, "jit_filter") != hipSuccess) out.f_filter = nullptr;
     }
-    if (hipModuleGetFunction(&out.f_expr, out.mod, "jit_expr") != hipSuccess) out.f_expr = nullptr;
-    if (hipModuleGetFunction(&out.f_filter, out.mod, "jit_filter") != hipSuccess) out.f_filter = nullptr;
+    std::vector<char>().swap(out.code);
+    out.compile_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// The module belongs to the context's plan cache (tsq_internal.h) and lives until the context is destroyed.
-static void jit_prepare(tsq_expr* e) {
-    if (e->jit_tried) return;
-    e->jit_tried = true;
-    const std::string src = jit_source(e->progs);
+// The module belongs to the context's plan cache (tsq_internal.h) and lives until the context is destroyed.  wait (TSQ_JIT_FORCE): the
+// caller compiles (or waits for the helper thread's compile); otherwise (TSQ_JIT_AUTO, round 6) the compile starts on a helper thread and
+// the call returns at once — the interpreter kernels serve the handle until the code object is there, and no Next call ever waits for
+// hiprtc (~250 ms per distinct tree).  Returns true once the entry is final (loaded or failed).
+static bool jit_prepare(tsq_expr* e, bool wait) {
+    if (e->jit_tried) return true;
     tsq_ctx* ctx = e->ctx;
+    if (e->jit_src.empty()) e->jit_src = jit_source(e->progs, (int)tsq_knob(ctx, TSQ_KNOB_JIT_VARIANT, 7));
     std::lock_guard<std::mutex> g(ctx->jit_mu);
-    auto it = ctx->jit_cache.find(src);
-    if (it == ctx->jit_cache.end()) {
-        tsq_ctx::JitEntry ent;
-        jit_compile(ctx, src, ent);
-        it = ctx->jit_cache.emplace(src, std::move(ent)).first;
+    tsq_ctx::JitEntry& ent = ctx->jit_cache.try_emplace(e->jit_src).first->second;
+    int st = ent.state.load(std::memory_order_acquire);
+    if (st == 0) {
+        if (wait) {
+            jit_compile_code(ctx->prop.gcnArchName, e->jit_src, ent);
+            st = 2;
+        } else {
+            ent.state.store(1, std::memory_order_release);
+            const std::string arch = ctx->prop.gcnArchName;
+            const std::string* src = &ctx->jit_cache.find(e->jit_src)->first;  // (the map's own copy: nodes of an unordered_map never move)
+            ent.worker = std::thread([arch, src, &ent]() {
+                jit_compile_code(arch, *src, ent);
+                ent.state.store(2, std::memory_order_release);
+            });
+            return false;
+        }
     }
-    e->jit_mod = it->second.mod;
-    e->jit_expr = it->second.f_expr;
-    e->jit_filter = it->second.f_filter;
-    e->jit_log = it->second.log;
-    e->jit_compile_ms = it->second.compile_ms;
+    if (st == 1) {
+        if (!wait) return false;
+        if (ent.worker.joinable()) ent.worker.join();
+        st = 2;
+    }
+    if (st == 2) {
+        if (ent.worker.joinable()) ent.worker.join();
+        jit_load(ent);
+        ent.state.store(3, std::memory_order_release);
+    }
+    e->jit_tried = true;
+    e->jit_mod = ent.mod;
+    e->jit_expr = ent.f_expr;
+    e->jit_filter = ent.f_filter;
+    e->jit_log = ent.log;
+    e->jit_compile_ms = ent.compile_ms;
+    return true;
 }
 
 // launches the specialised kernel when policy and availability allow it; returns false -> use the generic kernel
+#define TSQ_JIT_AUTO_ROWS (256 << 10)
 static bool jit_launch(tsq_expr* e, bool filter, ExprArgs& a, int grid) {
     if (e->jit_mode == TSQ_JIT_OFF) return false;
-    if (e->jit_mode == TSQ_JIT_AUTO && e->rows_seen + a.nrows < (4 << 20)) return false;  // a compile costs ~1 s
-    jit_prepare(e);
+    if (e->jit_mode == TSQ_JIT_AUTO && e->rows_seen + a.nrows < TSQ_JIT_AUTO_ROWS) return false;  // (a compile costs ~250 ms of one host thread: not for a point query)
+    if (!jit_prepare(e, e->jit_mode == TSQ_JIT_FORCE)) return false;
     hipFunction_t f = filter ? e->jit_filter : e->jit_expr;
     if (!f) return false;
     void* params[] = {&a};
@@ -579,7 +660,12 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
     ctx->pinned[1] = 0;
     ctx->pinned[2] = 0;
     TSQ_HIP(h, hipMemcpyAsync(a.counters, ctx->pinned, 24, hipMemcpyHostToDevice, ctx->stream));
-    const int grid = tsq_grid_for(ctx, nrows, 256);
+    int grid = tsq_grid_for(ctx, nrows, 256);
+    {
+        static const int per_cu[8] = {8, 4, 16, 32, 2, 8, 8, 8};
+        const int gv = ((int)tsq_knob(ctx, TSQ_KNOB_JIT_VARIANT, 7) >> 4) & 7;
+        if (gv) grid = (int)std::min<int64_t>((nrows + 255) / 256, (int64_t)ctx->num_cus * per_cu[gv]);
+    }
     if (!filter) {
         const bool odev = out->flags & TSQ_COL_DEVICE;
         if (odev != dev) return tsq_fail(h, TSQ_ERR_INVALID, "output placement (host/device) must match the inputs");

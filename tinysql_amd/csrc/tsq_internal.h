@@ -54,6 +54,11 @@ struct tsq_ctx {
         hipFunction_t f_expr = nullptr, f_filter = nullptr;
         std::string log;
         double compile_ms = 0;  // hiprtc + module load of this program set (once per distinct tree and context)
+        // TSQ_JIT_AUTO compiles on a helper thread (the interpreter kernels serve the handle meanwhile): the thread leaves the code object
+        // here and sets `state` to 2; the first launch after that loads the module on the caller's thread (state 3 = loaded or failed for good)
+        std::vector<char> code;
+        std::atomic<int> state{0};  // 0 new, 1 compiling on `worker`, 2 code ready, 3 final
+        std::thread worker;
     };
     std::unordered_map<std::string, JitEntry> jit_cache;
     std::mutex jit_mu;

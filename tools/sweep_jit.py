@@ -1,0 +1,61 @@
+"""A/B sweep of jit_expr's forms (TSQ_KNOB_JIT_VARIANT, include/tsq.h) on (a + b) * 3 - a over 1e8 BIGINT rows: one JSON line per variant
+(kernel + its launch through tsq_expr_eval, best of 5 on the context's HIP-event timer; every row compared with numpy).
+  python tools/sweep_jit.py [variant ...]"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from tinysql_amd import _abi as abi, _lib, expression as E  # noqa: E402
+from tools.bench_sides import _dev_col, _spec  # noqa: E402
+
+
+def main():
+    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 15, 16, 32, 48, 64, 4 | 32, 12 | 32, 8 | 32]
+    n = 100_000_000
+    ctx = _lib.Context(0)
+    lib = ctx.lib
+    a, b, out = (ctx.alloc(n * 8) for _ in range(3))
+    bm = ctx.alloc(n // 8 + 64)
+    ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=5, col=0, m=1 << 20), n, a)
+    ctx.gen_column(_spec(abi, abi.GEN_RAND_MOD, table=5, col=1, m=1 << 20), n, b)
+    ctx.sync()
+    ha, hb = np.empty(n, np.int64), np.empty(n, np.int64)
+    ctx.d2h(ha, a)
+    ctx.d2h(hb, b)
+    want = (ha + hb) * 3 - ha
+    cols = (abi.Col * 2)(_dev_col(abi, a, n), _dev_col(abi, b, n))
+    e1 = E.ScalarFunction("minus", E.ScalarFunction("mul", E.ScalarFunction("plus", E.Column(0, abi.I64), E.Column(1, abi.I64)), E.Constant(3)), E.Column(0, abi.I64))
+    w = C.c_int64(0)
+    for v in variants:
+        ctx.set_knob(abi.KNOB_JIT_VARIANT, v)
+        ce = E.CompiledExpr(ctx, [e1], jit=abi.JIT_FORCE)
+        try:
+            oc = _dev_col(abi, out, n)
+            oc.null_bitmap = bm
+            fn = lambda: _lib.check(lib.tsq_expr_eval(ce.h, cols, 2, n, None, C.byref(oc), C.byref(w)), ce.h)  # noqa: E731
+            fn()
+            ts = []
+            for _ in range(7):
+                ctx.timer_start()
+                fn()
+                ts.append(ctx.timer_stop_ms())
+            ho = np.empty(n, np.int64)
+            ctx.d2h(ho, out)
+            hbm = np.empty(n // 8, np.uint8)
+            ctx.d2h(hbm, bm)
+            ok = bool((ho == want).all() and (hbm == 0xff).all())
+            print(json.dumps({"variant": v, "ms_min": round(min(ts), 4), "ms_med": round(sorted(ts)[3], 4), "frac": round(24.0 * n / min(ts) / 1e6 / 8000.0, 4), "ok": ok,
+                              "jit_launches": ce.jit_launches()}), flush=True)
+            ctx.memset(out, 0, n * 8)
+            ctx.memset(bm, 0, n // 8)
+        finally:
+            ce.close()
+    ctx.set_knob(abi.KNOB_JIT_VARIANT)
+
+
+if __name__ == "__main__":
+    main()
