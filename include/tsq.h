@@ -66,7 +66,8 @@ enum {
                            * allocated until tsq_join_destroy.  Honoured for the FIRST push of a build side when every column is a fixed-width
                            * TSQ_COL_DEVICE | TSQ_COL_RETAIN column whose buffers are whole tsq_dev_alloc blocks; otherwise the rows are copied as always
                            * (later pushes copy the retained rows into the operator's own storage first). */
-#define TSQ_COL_BORROW 2u /* an OUTPUT column of a device-resident pull (tsq_join_pull): instead of copying into the caller's buffers the
+#define TSQ_COL_BORROW 2u /* an OUTPUT column of a pull (tsq_join_pull; device-resident pulls, and since round 6 host pulls too — the pointers then
+                             lead into the operator's PINNED result batch, which the D2H copies filled): instead of copying into the caller's buffers the
                              operator hands out pointers into its own result batch — data / null_bitmap are SET by the call (null_bitmap =
                              NULL when the column holds no NULL) and stay valid until the next pull, peek, finish or destroy on the handle (tsq_join_peek
                              releases fully consumed result batches too).
@@ -151,6 +152,8 @@ enum {
     TSQ_KNOB_AGG_PG = 33,            /* 0: an aggregate with about as many groups as rows never keeps its groups in partitioned LDS-sized sub-tables (csrc/tsq_aggfast.h K7p): the row upsert serves it; v >= 2 (tests): the mode is taken whatever the estimate, with 2^(v - 2) sub-tables */
     TSQ_KNOB_AGG_OVERLAP = 34,       /* default 0: the packed aggregate with a dense state runs every batch on one stream (partition pass, then k_agg_da); 1: k_agg_da / k_daagg_ovf of a batch run on a side stream beside the partition pass of the next batch (two partitioned stores) for batches of 2^24 rows or more — an A/B that measured SLOWER (C3 7.0 -> 10.1 ms, profiles/r06_ab_measurements.txt); v >= 2 (tests): for batches of v rows or more */
     TSQ_KNOB_JIT_VARIANT = 35,       /* A/B bits of the hiprtc-specialised projection kernel (jit_expr), default 7 (measured 0.525 -> 0.453 ms per 1e8 rows of (a+b)*3-a against 0, profiles/r06_jit_sweep.txt): 1 = non-temporal loads of the input cells, 2 = non-temporal stores of the result, 4 = whole-wave coalesced 16-byte accesses (a lane takes rows 2 l, 2 l + 1 of each 128-row half of a 256-row step instead of four consecutive rows), 8 = two steps' loads in flight; bits 4-6: workgroups per CU = 8 (0), 4, 16, 32, 2 */
+    TSQ_KNOB_HOST_OVERLAP = 36,      /* 0: a join fed with host chunks copies every result batch to pinned memory on the context's one stream and waits for it (rounds 1-5); default 1: the D2H copies run on the operator's copy stream beside the staging, H2D and kernels of the next batch, a flush waits for its H2D copies only, and tsq_join_pull answers "no rows yet" while the front batch is still on its way and the probe side is not finished */
+    TSQ_KNOB_HOST_NT_COPY = 37,      /* 0: host chunks enter the pinned staging buffers through memcpy instead of non-temporal stores (process-wide) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);

@@ -299,3 +299,69 @@ def test_join_full_size_1e8_by_1e8_property(ctx):
     # order-independent checksum must equal the closed-form expectation.
     n = 100_000_000
     assert _device_join(ctx, n, n, n) == _expected_device_join(n, n, n)
+
+
+@pytest.mark.parametrize("jt", [abi.JOIN_INNER, abi.JOIN_LEFT_OUTER])
+def test_host_chunks_overlapped_copies_same_rows_as_one_stream(ctx, orc, jt):
+    # round 6 (TSQ_KNOB_HOST_OVERLAP, default 1): the D2H copies of a result batch run on the operator's copy stream beside the next batch,
+    # a flush waits for its H2D copies only, a pull before probe_finish may answer "no rows yet".  Many small batches in flight, ragged
+    # chunk and pull sizes, NULL keys and payloads: the rows are the oracle's, with the knob on and off
+    rng = np.random.default_rng(61)
+    t = [abi.I64, abi.I64]
+    left, right = _rand_table(rng, 60_000, 9000, t), _rand_table(rng, 20_000, 9000, t)
+    cfg = H.join_cfg(t, t, [0], [0], jt, 1, probe_batch_rows=4096)
+    want = orc.hash_join(cfg, right, left)
+    for knob in (1, 0):
+        ctx.set_knob(abi.KNOB_HOST_OVERLAP, knob)
+        try:
+            for cr, pr in ((1024, 1024), (333, 4000), (5000, 100)):
+                assert H.rows_equal_unordered(G.run_join(ctx, cfg, right, left, chunk_rows=cr, pull_rows=pr), want)
+        finally:
+            ctx.set_knob(abi.KNOB_HOST_OVERLAP)
+
+
+def test_host_pull_borrows_the_pinned_result_batch(ctx, orc):
+    # TSQ_COL_BORROW on HOST output columns (round 6): tsq_join_pull sets data / null_bitmap to point into the operator's pinned result batch
+    # (valid until the next pull) instead of copying into the caller's chunk; same rows as the oracle's, NULL payloads included
+    rng = np.random.default_rng(62)
+    t = [abi.I64, abi.I64]
+    left, right = _rand_table(rng, 30_000, 5000, t), _rand_table(rng, 10_000, 5000, t)
+    cfg = H.join_cfg(t, t, [0], [0], abi.JOIN_LEFT_OUTER, 1, probe_batch_rows=8192)
+    want = orc.hash_join(cfg, right, left)
+    lib = ctx.lib
+    h = C.c_void_p()
+    _lib.check(lib.tsq_join_create(ctx.h, C.byref(cfg), C.byref(h)), ctx.h)
+    try:
+        G.push_chunked(lib.tsq_join_build_push, h, right, 1024)
+        _lib.check(lib.tsq_join_build_finish(h), h)
+        got = [[] for _ in range(4)]
+        gotnn = [[] for _ in range(4)]
+
+        def pull_all():
+            while True:
+                oc = (abi.Col * 4)()
+                for i in range(4):
+                    oc[i].flags = abi.COL_BORROW
+                n, eos = C.c_int64(0), C.c_int32(0)
+                _lib.check(lib.tsq_join_pull(h, oc, 4, 1024, C.byref(n), C.byref(eos)), h)
+                if n.value == 0:
+                    return
+                for i in range(4):
+                    assert oc[i].data and oc[i].length == n.value
+                    got[i].append(np.ctypeslib.as_array(C.cast(oc[i].data, C.POINTER(C.c_int64)), (n.value,)).copy())
+                    if oc[i].null_bitmap:
+                        bits = np.ctypeslib.as_array(C.cast(oc[i].null_bitmap, C.POINTER(C.c_uint8)), ((n.value + 7) // 8,)).copy()
+                        gotnn[i].append(np.unpackbits(bits, bitorder="little")[:n.value].astype(bool))
+                    else:
+                        gotnn[i].append(np.ones(n.value, bool))
+        for lo in range(0, left.NumRows(), 1000):
+            part = left.slice(lo, min(left.NumRows(), lo + 1000))
+            keep = []
+            _lib.check(lib.tsq_join_probe_push(h, G.make_cols(part.columns, keep), 2, part.NumRows(), None), h)
+            pull_all()
+        _lib.check(lib.tsq_join_probe_finish(h), h)
+        pull_all()
+        out = Chunk([Column(abi.I64, np.concatenate(got[i]), np.concatenate(gotnn[i])) for i in range(4)])
+        assert H.rows_equal_unordered(out, want)
+    finally:
+        lib.tsq_join_destroy(h)

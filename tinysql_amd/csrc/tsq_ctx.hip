@@ -120,6 +120,7 @@ TSQ_API tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value) {
     if (!ctx || ctx->hdr.magic != TSQ_MAGIC_CTX) return TSQ_ERR_INVALID;
     if (knob < 0 || knob >= TSQ_KNOB_COUNT) return tsq_fail(&ctx->hdr, TSQ_ERR_INVALID, "tsq_ctx_set_knob: unknown knob");
     ctx->knob[knob] = value;
+    if (knob == TSQ_KNOB_HOST_NT_COPY) tsq_host_nt_copy_on.store(value == 0 ? 0 : 1, std::memory_order_relaxed);  // (process-wide: the staging copies have no context at hand)
     return TSQ_OK;
 }
 

@@ -287,6 +287,41 @@ inline void tsq_host_copy(void* dst, const void* src, size_t n) {
     for (auto& t : th) t.join();
 }
 
+// caller's chunk -> pinned staging (HostStage::add, a 1024-row push = 8 KB per column): the staged bytes are next read by a DMA engine,
+// never by this core, so they are written with NON-TEMPORAL stores (SSE2 movntdq through clang's builtin; 64 bytes per step) — a plain
+// memcpy first reads every destination line into the cache to own it, a third of the memory traffic of the copy.  The sfence at the
+// end orders the write-combining buffers before the hipMemcpyAsync that follows.  TSQ_KNOB_HOST_NT_COPY = 0: memcpy.
+inline std::atomic<int> tsq_host_nt_copy_on{1};
+inline void tsq_stage_copy(void* dst, const void* src, size_t n) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    if (n >= 1024 && n < ((size_t)4 << 20) && tsq_host_nt_copy_on.load(std::memory_order_relaxed)) {
+        typedef long long tsq_v2di __attribute__((vector_size(16), aligned(16)));
+        typedef long long tsq_v2di_u __attribute__((vector_size(16), aligned(1)));
+        char* d = (char*)dst;
+        const char* s = (const char*)src;
+        const size_t head = (16 - ((uintptr_t)d & 15)) & 15;
+        if (head) {
+            memcpy(d, s, head);
+            d += head;
+            s += head;
+            n -= head;
+        }
+        size_t i = 0;
+        for (; i + 64 <= n; i += 64) {
+            const tsq_v2di a = *(const tsq_v2di_u*)(s + i), b = *(const tsq_v2di_u*)(s + i + 16), c = *(const tsq_v2di_u*)(s + i + 32), e = *(const tsq_v2di_u*)(s + i + 48);
+            __builtin_nontemporal_store(a, (tsq_v2di*)(d + i));
+            __builtin_nontemporal_store(b, (tsq_v2di*)(d + i + 16));
+            __builtin_nontemporal_store(c, (tsq_v2di*)(d + i + 32));
+            __builtin_nontemporal_store(e, (tsq_v2di*)(d + i + 48));
+        }
+        if (i < n) memcpy(d + i, s + i, n - i);
+        asm volatile("sfence" ::: "memory");
+        return;
+    }
+#endif
+    tsq_host_copy(dst, src, n);
+}
+
 inline int tsq_elem_size(int32_t type) { return type == TSQ_F32 ? 4 : 8; }
 inline size_t tsq_bitmap_bytes(int64_t rows) { return (size_t)((rows + 7) / 8); }
 

@@ -704,7 +704,17 @@ struct ResultBatch {  // one probe batch worth of joined rows
     std::vector<int64_t> nbytes;     // ... and their data bytes
     bool on_host = false;
     std::vector<PinnedBuf> hdata, hbitmap, hoffs;
+    // host pushes (round 6): the D2H copies of the batch run on the operator's copy stream beside the kernels of the next batch; `ready`
+    // is recorded behind them and the device columns are kept until it has fired (settle_batch)
+    hipEvent_t ready = nullptr;
+    bool pending = false;
     void release() {
+        if (ready) {
+            if (pending) (void)hipEventSynchronize(ready);
+            (void)hipEventDestroy(ready);
+            ready = nullptr;
+            pending = false;
+        }
         for (auto& b : data) b.release();
         for (auto& b : notnull) b.release();
         for (auto& b : bitmap) b.release();
@@ -827,6 +837,9 @@ struct tsq_join {
     // stats
     tsq_stats st{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;  // host pushes: result batches leave for pinned memory here (deliver_batch)
+    hipEvent_t ev_emit = nullptr;       // main stream: the columns of the batch being delivered are written
+    hipEvent_t ev_h2d = nullptr;        // main stream: the staged rows of a flush have left pinned memory
     bool have_build_ev = false, have_probe_ev = false;
     double probe_ms_acc = 0;
 };
@@ -937,6 +950,19 @@ tsq_status dispatch_emit(tsq_join* j, ProbeArgs& a) {
 }
 
 
+// the D2H copies of a host-mode batch are done: its device columns go back to the pool (stream order protects pooled buffers on the main
+// stream only, so they were kept until the copy stream was through with them)
+tsq_status settle_batch(tsq_join* j, ResultBatch* rb) {
+    if (!rb->pending) return TSQ_OK;
+    TSQ_HIP(&j->hdr, hipEventSynchronize(rb->ready));
+    rb->pending = false;
+    for (auto& b : rb->data) b.release();
+    for (auto& b : rb->notnull) b.release();
+    for (auto& b : rb->bitmap) b.release();
+    for (auto& b : rb->offs) b.release();
+    return TSQ_OK;
+}
+
 // hand a materialised batch (device columns) to tsq_join_pull: host pushes get it in pinned host memory (pulls are then plain memcpy)
 tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std::vector<bool>& may_null_v) {
     tsq_ctx* ctx = j->ctx;
@@ -945,6 +971,19 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
     const int nl = probe_is_left ? j->cfg.n_probe_cols : j->cfg.n_build_cols;
     const int64_t out_rows = rb->rows;
     if (j->host_mode) {
+        // round 6: the copies run on the operator's copy stream behind an event of the main stream, the call does not wait for them — the
+        // next batch's staging, H2D and kernels run beside them, tsq_join_pull waits for `ready` (TSQ_KNOB_HOST_OVERLAP = 0: one stream
+        // and a wait here, as before)
+        const bool overlap = tsq_knob(ctx, TSQ_KNOB_HOST_OVERLAP, 1) != 0;
+        hipStream_t cs = ctx->stream;
+        if (overlap) {
+            if (!j->copy_stream) TSQ_HIP(&j->hdr, hipStreamCreateWithFlags(&j->copy_stream, hipStreamNonBlocking));
+            if (!j->ev_emit) TSQ_HIP(&j->hdr, hipEventCreateWithFlags(&j->ev_emit, hipEventDisableTiming));
+            TSQ_HIP(&j->hdr, hipEventCreateWithFlags(&rb->ready, hipEventDisableTiming));
+            cs = j->copy_stream;
+            TSQ_HIP(&j->hdr, hipEventRecord(j->ev_emit, ctx->stream));
+            TSQ_HIP(&j->hdr, hipStreamWaitEvent(cs, j->ev_emit, 0));
+        }
         rb->hdata.resize(nout);
         rb->hbitmap.resize(nout);
         rb->hoffs.resize(nout);
@@ -957,24 +996,36 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
             tsq_status s = rb->hdata[oc].reserve(&j->hdr, bytes + 16);
             if (s == TSQ_OK && type == TSQ_BYTES) s = rb->hoffs[oc].reserve(&j->hdr, ((size_t)out_rows + 1) * 8 + 16);
             if (s != TSQ_OK) { rb->release(); return s; }
-            if (bytes) TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (bytes) TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, cs));
             if (type == TSQ_BYTES) {
-                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hoffs[oc].p, rb->offs[oc].p, ((size_t)out_rows + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hoffs[oc].p, rb->offs[oc].p, ((size_t)out_rows + 1) * 8, hipMemcpyDeviceToHost, cs));
                 bytes += ((size_t)out_rows + 1) * 8;
             }
             j->st.d2h_bytes += bytes;
             if (may_null_v[oc]) {
                 s = rb->hbitmap[oc].reserve(&j->hdr, tsq_bitmap_bytes(out_rows) + 16);
                 if (s != TSQ_OK) { rb->release(); return s; }
-                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hbitmap[oc].p, rb->bitmap[oc].p, tsq_bitmap_bytes(out_rows), hipMemcpyDeviceToHost, ctx->stream));
+                TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hbitmap[oc].p, rb->bitmap[oc].p, tsq_bitmap_bytes(out_rows), hipMemcpyDeviceToHost, cs));
             }
         }
+        if (overlap) {
+            TSQ_HIP(&j->hdr, hipEventRecord(rb->ready, cs));
+            rb->pending = true;
+            rb->on_host = true;
+            // at most three batches in flight behind the one being pulled (their device columns are alive until their copies are done)
+            int inflight = 0;
+            for (auto& r : j->results) inflight += r->pending ? 1 : 0;
+            if (inflight >= 3)
+                for (auto& r : j->results)
+                    if (r->pending) { TSQ_TRY(settle_batch(j, r.get())); break; }
+        } else {
         TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
         for (auto& b : rb->data) b.release();
         for (auto& b : rb->notnull) b.release();
         for (auto& b : rb->bitmap) b.release();
         for (auto& b : rb->offs) b.release();
         rb->on_host = true;
+        }
     } else {
         TSQ_HIP(&j->hdr, hipStreamSynchronize(ctx->stream));
         for (auto& b : rb->notnull) b.release();
@@ -4242,11 +4293,18 @@ tsq_status probe_flush(tsq_join* j) {
         if (e != hipSuccess) { tmp.release(); tmp2.release(); return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipMemcpyAsync(sel): ") + hipGetErrorString(e)); }
         sel_dev = j->psel.as<uint8_t>();
     }
+    // staging (pinned) memory is reused by the next pushes: the call waits for the H2D copies — not for the kernels behind them, which run
+    // beside the staging of the next batch (round 6; a materialising batch has read its counters back by then anyway)
+    const bool overlap = tsq_knob(ctx, TSQ_KNOB_HOST_OVERLAP, 1) != 0;
+    if (overlap) {
+        hipError_t ee = j->ev_h2d ? hipSuccess : hipEventCreateWithFlags(&j->ev_h2d, hipEventDisableTiming);
+        if (ee == hipSuccess) ee = hipEventRecord(j->ev_h2d, ctx->stream);
+        if (ee != hipSuccess) { tmp.release(); tmp2.release(); return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipEventRecord(h2d): ") + hipGetErrorString(ee)); }
+    }
     tsq_colset pcs;
     tsq_fill_colset(pcs, j->pcols);
     tsq_status s = probe_batch(j, pcs, sg.staged, sel_dev);
-    // staging (pinned) memory is reused by the next pushes: wait for the H2D copies
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = overlap ? hipEventSynchronize(j->ev_h2d) : hipStreamSynchronize(ctx->stream);
     tmp.release();
     tmp2.release();
     sg.reset();
@@ -4897,6 +4955,12 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
         return TSQ_OK;
     }
     ResultBatch* rb = j->results.front().get();
+    if (rb->pending) {
+        // its copies are still on the way: while the probe side has more to push the caller gets "no rows yet" (it pushes its next chunk, as
+        // after any pull that found nothing) instead of waiting beside an idle staging buffer; after probe_finish the call waits
+        if (!j->probe_done && hipEventQuery(rb->ready) == hipErrorNotReady) return TSQ_OK;
+        TSQ_TRY(settle_batch(j, rb));
+    }
     const int64_t n = std::min<int64_t>(cap_rows, rb->rows - rb->cursor);
     if (n <= 0) return TSQ_OK;
     const bool probe_is_left = j->cfg.build_is_right != 0;
@@ -4913,6 +4977,15 @@ TSQ_API tsq_status tsq_join_pull(tsq_join* j, tsq_col* out_cols, int32_t n_cols,
             if ((rb->cursor & 7) != 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "device pull: cap_rows must keep the cursor a multiple of 8");
             o.data = rb->data[oc].p ? (char*)rb->data[oc].p + (size_t)rb->cursor * es : nullptr;  // (nullptr: a column the parent does not use)
             o.null_bitmap = has_bm ? rb->bitmap[oc].as<uint8_t>() + (rb->cursor >> 3) : nullptr;
+            o.length = n;
+            o.type = type;
+            o.elem_size = es;
+            continue;
+        }
+        if ((o.flags & TSQ_COL_BORROW) && !odev && rb->on_host && type != TSQ_BYTES) {  // round 6: the same for HOST pulls — pointers into the pinned result batch
+            if ((rb->cursor & 7) != 0) return tsq_fail(&j->hdr, TSQ_ERR_INVALID, "borrowed pull: cap_rows must keep the cursor a multiple of 8");
+            o.data = rb->hdata[oc].p ? (char*)rb->hdata[oc].p + (size_t)rb->cursor * es : nullptr;
+            o.null_bitmap = has_bm ? (uint8_t*)rb->hbitmap[oc].p + (rb->cursor >> 3) : nullptr;
             o.length = n;
             o.type = type;
             o.elem_size = es;
@@ -4995,6 +5068,7 @@ TSQ_API tsq_status tsq_join_peek(tsq_join* j, int64_t cap_rows, int64_t* nrows_o
     }
     if (j->results.empty()) return TSQ_OK;
     ResultBatch* rb = j->results.front().get();
+    TSQ_TRY(settle_batch(j, rb));  // (waits: what peek says and what the next pull delivers must be the same batch)
     const int64_t n = std::min<int64_t>(cap_rows, rb->rows - rb->cursor);
     if (n <= 0) return TSQ_OK;
     *nrows_out = n;
@@ -5108,8 +5182,12 @@ TSQ_API void tsq_join_destroy(tsq_join* j) {
     }
     for (auto& c : j->bcols) c.release();
     for (auto& c : j->pcols) c.release();
+    if (j->copy_stream) (void)hipStreamSynchronize(j->copy_stream);
     for (auto& r : j->results) r->release();
     j->results.clear();
+    if (j->copy_stream) (void)hipStreamDestroy(j->copy_stream);
+    if (j->ev_emit) (void)hipEventDestroy(j->ev_emit);
+    if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
     j->tkeys.release();
     j->tvals.release();
     j->tnext.release();

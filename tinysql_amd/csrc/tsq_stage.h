@@ -224,7 +224,7 @@ struct HostStage {
                 nbytes[c] += bytes;
             } else {
                 const int es = tsq_elem_size(types[c]);
-                tsq_host_copy((char*)data[c].p + (size_t)staged * es, (const char*)cols[c].data + (size_t)src_off * es, (size_t)n * es);
+                tsq_stage_copy((char*)data[c].p + (size_t)staged * es, (const char*)cols[c].data + (size_t)src_off * es, (size_t)n * es);
             }
             uint8_t* bm = (uint8_t*)nulls[c].p;
             if (cols[c].null_bitmap && !null_any[c]) {  // first bitmap seen: earlier staged rows are NOT NULL

@@ -3,6 +3,9 @@
 // pulled through tsq_join_pull (Executor.Next, executor/executor.go:146-152) — from C, so that the per-call cost measured is the
 // library's (lock, validation, copy into pinned staging) and not a Python interpreter's (ctypes: ~6 us per call, more than the call
 // itself).  bench.py (tools/bench_sides.py: extra_pcie) calls tsq_boundary_join with the context it already holds.
+// pull_every < 0: the pulls BORROW (TSQ_COL_BORROW on host columns: pointers into the operator's pinned result batch instead of a copy into
+// the caller's chunk — what a shim that wraps the pinned memory as a chunk.Column for the duration of the parent's Next does); every
+// borrowed cell is still read once (a sum per column) so that the number does not hide the parent's first touch of the rows.
 // Build: g++ -shared (host/Makefile) -> tinysql_amd/host/libtsq_boundary.so; links libtsq.so from the package directory.
 #include <chrono>
 #include <cstdint>
@@ -27,6 +30,9 @@ void host_col(tsq_col& c, const int64_t* p, int64_t n) {
 extern "C" __attribute__((visibility("default"))) int32_t tsq_boundary_join(tsq_ctx* ctx, int64_t n_build, int64_t n_probe, int64_t chunk, int64_t pull_every,
                                                                             const int64_t* bk, const int64_t* bv, const int64_t* pk, const int64_t* pv,
                                                                             double* out) {
+    const bool borrow = pull_every < 0;
+    if (borrow) pull_every = -pull_every;
+    uint64_t touched = 0;
     tsq_join_cfg cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.join_type = TSQ_JOIN_INNER;
@@ -65,7 +71,16 @@ extern "C" __attribute__((visibility("default"))) int32_t tsq_boundary_join(tsq_
             int64_t n = 0;
             int32_t eos = 0;
             const double t = now_s();
+            if (borrow)
+                for (int i = 0; i < 4; i++) oc[i].flags = TSQ_COL_BORROW;
             s = tsq_join_pull(j, oc, 4, chunk, &n, &eos);
+            if (borrow && s == TSQ_OK)
+                for (int i = 0; i < 4; i++) {
+                    const uint64_t* p = (const uint64_t*)oc[i].data;
+                    uint64_t a = 0;
+                    for (int64_t r = 0; r < n; r++) a += p[r];
+                    touched += a;
+                }
             t_pull += now_s() - t;
             pulls++;
             if (n == 0) return;
@@ -87,6 +102,7 @@ extern "C" __attribute__((visibility("default"))) int32_t tsq_boundary_join(tsq_
     out[2] = t_pull;
     out[3] = (double)rows;
     out[4] = (double)pulls;
+    memcpy(&out[5], &touched, 8);  // (the 64 bits of the wrapped sum, not a double)
     tsq_join_destroy(j);
     return s;
 }

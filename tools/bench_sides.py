@@ -190,7 +190,7 @@ def extra_pcie(ctx, abi, _lib, n=10_000_000):
     for i in range(2):
         cfg.build_types[i] = cfg.probe_types[i] = abi.I64
     res = {}
-    for chunk in (1024, 1 << 20):
+    for chunk in (1024, 1 << 20, 1 << 20):  # (the 1 Mi-row shape twice, the better run kept: the first one allocates the pinned result batches)
         def cols(a, b, lo, hi):
             arr = (abi.Col * 2)()
             for i, x in enumerate((a, b)):
@@ -231,8 +231,9 @@ def extra_pcie(ctx, abi, _lib, n=10_000_000):
             t_probe = time.perf_counter() - t0
         finally:
             lib.tsq_join_destroy(h)
-        res["chunks_of_%d_rows" % chunk] = {"build_s": t_build, "probe_and_pull_s": t_probe, "of_which_pull_s": t_pull, "joined_rows": rows,
-                                             "probe_rows_per_s_end_to_end": n / t_probe, "verified": rows == n}
+        if "chunks_of_%d_rows" % chunk not in res or t_probe < res["chunks_of_%d_rows" % chunk]["probe_and_pull_s"]:
+            res["chunks_of_%d_rows" % chunk] = {"build_s": t_build, "probe_and_pull_s": t_probe, "of_which_pull_s": t_pull, "joined_rows": rows,
+                                                 "probe_rows_per_s_end_to_end": n / t_probe, "verified": rows == n}
     # the same two shapes driven from C (tinysql_amd/host/tsq_boundary_bench.cpp): what a cgo shim sees — a Python interpreter spends
     # ~6 us in ctypes around every call, more than a 1024-row push costs the library.  These are the figures the line carries.
     try:
@@ -240,7 +241,11 @@ def extra_pcie(ctx, abi, _lib, n=10_000_000):
         nat.tsq_boundary_join.restype = C.c_int32
         nat.tsq_boundary_join.argtypes = [C.c_void_p] + [C.c_int64] * 4 + [C.c_void_p] * 4 + [C.POINTER(C.c_double)]
         bv64, pk64 = np.ascontiguousarray(bv, dtype=np.int64), np.ascontiguousarray(pk, dtype=np.int64)
-        for chunk, every in ((1024, 64), (1 << 20, 1)):
+        bvk = np.empty(n, np.int64)
+        bvk[bk] = bv64
+        with np.errstate(over="ignore"):
+            want_sum = int((2 * pk64.astype(np.uint64).sum(dtype=np.uint64) + pv.astype(np.uint64).sum(dtype=np.uint64) + bvk[pk64].astype(np.uint64).sum(dtype=np.uint64)) & np.uint64(0xffffffffffffffff))
+        for chunk, every in ((1024, 64), (1 << 20, 1), (1024, -64), (1 << 20, -1)):
             best = None
             for _ in range(2):
                 o = (C.c_double * 8)()
@@ -249,12 +254,19 @@ def extra_pcie(ctx, abi, _lib, n=10_000_000):
                     raise RuntimeError("tsq_boundary_join: status %d" % rc)
                 if best is None or o[1] < best[1]:
                     best = list(o)
-            res["native_chunks_of_%d_rows" % chunk] = {"build_s": best[0], "probe_and_pull_s": best[1], "of_which_pull_s": best[2], "joined_rows": int(best[3]),
-                                                       "pull_calls": int(best[4]), "probe_rows_per_s_end_to_end": n / best[1], "verified": int(best[3]) == n}
+            rec = {"build_s": best[0], "probe_and_pull_s": best[1], "of_which_pull_s": best[2], "joined_rows": int(best[3]),
+                   "pull_calls": int(best[4]), "probe_rows_per_s_end_to_end": n / best[1], "verified": int(best[3]) == n}
+            if every < 0:  # borrowed pulls: the C driver read every cell it was lent (a wrapped sum per column)
+                got_sum = int(np.array([best[5]], np.float64).view(np.uint64)[0])
+                rec["borrowed_cells_sum_ok"] = got_sum == want_sum
+                rec["verified"] = rec["verified"] and rec["borrowed_cells_sum_ok"]
+            res["native_%schunks_of_%d_rows" % ("borrowed_pulls_" if every < 0 else "", chunk)] = rec
     except OSError as e:
         res["native"] = {"error": "libtsq_boundary.so not built: %s" % str(e)[:80]}
     res["workload"] = ("1e7 x 1e7 (k, v) x (k, v) inner join, host chunks in (pinned staging -> HBM) and host chunks out (D2H per result batch, then memcpy per pull); "
-                       "chunks_of_*: driven from Python (ctypes), native_chunks_of_*: the same calls from C (host/tsq_boundary_bench.cpp)")
+                       "chunks_of_*: driven from Python (ctypes), native_chunks_of_*: the same calls from C (host/tsq_boundary_bench.cpp), native_borrowed_pulls_*: "
+                       "the pulls hand out pointers into the operator's pinned result batch (TSQ_COL_BORROW) and the driver reads every cell once; round 6: the D2H copies "
+                       "of a result batch run on a copy stream beside the next batch (TSQ_KNOB_HOST_OVERLAP)")
     return res
 
 
