@@ -840,6 +840,7 @@ struct tsq_join {
     hipStream_t copy_stream = nullptr;  // host pushes: result batches leave for pinned memory here (deliver_batch)
     hipEvent_t ev_emit = nullptr;       // main stream: the columns of the batch being delivered are written
     hipEvent_t ev_h2d = nullptr;        // main stream: the staged rows of a flush have left pinned memory
+    int64_t stage_sent = 0;             // probe rows of the staging buffers whose H2D copies are queued already (probe_stage_early)
     bool have_build_ev = false, have_probe_ev = false;
     double probe_ms_acc = 0;
 };
@@ -974,7 +975,7 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
         // round 6: the copies run on the operator's copy stream behind an event of the main stream, the call does not wait for them — the
         // next batch's staging, H2D and kernels run beside them, tsq_join_pull waits for `ready` (TSQ_KNOB_HOST_OVERLAP = 0: one stream
         // and a wait here, as before)
-        const bool overlap = tsq_knob(ctx, TSQ_KNOB_HOST_OVERLAP, 1) != 0;
+        const bool overlap = (tsq_knob(ctx, TSQ_KNOB_HOST_OVERLAP, 3) & 1) != 0;
         hipStream_t cs = ctx->stream;
         if (overlap) {
             if (!j->copy_stream) TSQ_HIP(&j->hdr, hipStreamCreateWithFlags(&j->copy_stream, hipStreamNonBlocking));
@@ -4274,11 +4275,43 @@ tsq_status probe_batch_routes(tsq_join* j, const tsq_colset& pcs, int64_t nrows,
     });
 }
 
+// Host chunks, fixed-width columns: the H2D copies of the rows staged so far are queued while the caller is still pushing (every 256 Ki
+// rows), so that a flush has only the last slice — not the whole batch, 64 MB for 4 Mi (k, v) rows — between it and its kernels.  The
+// device columns of the batch are reserved for a whole batch first (a reserve that grows would move the rows already there); the copies
+// are stream-ordered behind the previous batch's kernels, which read the same columns.
+#define TSQ_STAGE_EARLY_ROWS (256 << 10)
+tsq_status probe_stage_early(tsq_join* j) {
+    HostStage& sg = j->stage;
+    tsq_ctx* ctx = j->ctx;
+    for (size_t c = 0; c < j->pcols.size(); c++)
+        if (j->pcols[c].type == TSQ_BYTES) return TSQ_OK;
+    for (size_t c = 0; c < j->pcols.size(); c++) {
+        ColStore& cs = j->pcols[c];
+        const int es = cs.elem();
+        TSQ_TRY(cs.data.reserve(ctx, &j->hdr, (size_t)sg.cap * es + 64));
+        TSQ_HIP(&j->hdr, hipMemcpyAsync((char*)cs.data.p + (size_t)j->stage_sent * es, (const char*)sg.data[c].p + (size_t)j->stage_sent * es,
+                                         (size_t)(sg.staged - j->stage_sent) * es, hipMemcpyHostToDevice, ctx->stream));
+    }
+    j->stage_sent = sg.staged;
+    return TSQ_OK;
+}
+
 tsq_status probe_flush(tsq_join* j) {
     HostStage& sg = j->stage;
     if (sg.staged == 0) return TSQ_OK;
     tsq_ctx* ctx = j->ctx;
     DevBuf tmp, tmp2;
+    if (j->stage_sent > 0) {  // (fixed-width columns only: the rest of the rows, then the bitmaps of the whole batch)
+        tsq_status s = probe_stage_early(j);
+        for (size_t c = 0; c < j->pcols.size() && s == TSQ_OK; c++) {
+            ColStore& cs = j->pcols[c];
+            cs.clear();
+            s = tsq_col_append_bitmap(ctx, &j->hdr, cs, sg.bitmap((int)c), sg.staged, false, tmp);
+            cs.rows = sg.staged;
+            j->st.h2d_bytes += sg.staged * cs.elem();
+        }
+        if (s != TSQ_OK) { tmp.release(); j->stage_sent = 0; return s; }
+    } else
     for (size_t c = 0; c < j->pcols.size(); c++) {
         j->pcols[c].clear();
         tsq_status s = sg.append_to(ctx, &j->hdr, (int)c, j->pcols[c], tmp, tmp2);
@@ -4295,7 +4328,7 @@ tsq_status probe_flush(tsq_join* j) {
     }
     // staging (pinned) memory is reused by the next pushes: the call waits for the H2D copies — not for the kernels behind them, which run
     // beside the staging of the next batch (round 6; a materialising batch has read its counters back by then anyway)
-    const bool overlap = tsq_knob(ctx, TSQ_KNOB_HOST_OVERLAP, 1) != 0;
+    const bool overlap = (tsq_knob(ctx, TSQ_KNOB_HOST_OVERLAP, 3) & 1) != 0;
     if (overlap) {
         hipError_t ee = j->ev_h2d ? hipSuccess : hipEventCreateWithFlags(&j->ev_h2d, hipEventDisableTiming);
         if (ee == hipSuccess) ee = hipEventRecord(j->ev_h2d, ctx->stream);
@@ -4308,6 +4341,7 @@ tsq_status probe_flush(tsq_join* j) {
     tmp.release();
     tmp2.release();
     sg.reset();
+    j->stage_sent = 0;
     if (s != TSQ_OK) return s;
     if (e != hipSuccess) return tsq_fail(&j->hdr, TSQ_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return TSQ_OK;
@@ -4919,6 +4953,8 @@ TSQ_API tsq_status tsq_join_probe_push(tsq_join* j, const tsq_col* cols, int32_t
         if (j->stage.room() == 0) {
             TSQ_TRY(check_cancel(j));
             TSQ_TRY(probe_flush(j));
+        } else if (j->stage.staged - j->stage_sent >= TSQ_STAGE_EARLY_ROWS && (tsq_knob(j->ctx, TSQ_KNOB_HOST_OVERLAP, 3) & 2) != 0) {
+            TSQ_TRY(probe_stage_early(j));
         }
     }
     return TSQ_OK;
