@@ -154,6 +154,7 @@ enum {
     TSQ_KNOB_JIT_VARIANT = 35,       /* A/B bits of the hiprtc-specialised projection kernel (jit_expr), default 7 (measured 0.525 -> 0.453 ms per 1e8 rows of (a+b)*3-a against 0, profiles/r06_jit_sweep.txt): 1 = non-temporal loads of the input cells, 2 = non-temporal stores of the result, 4 = whole-wave coalesced 16-byte accesses (a lane takes rows 2 l, 2 l + 1 of each 128-row half of a 256-row step instead of four consecutive rows), 8 = two steps' loads in flight; bits 4-6: workgroups per CU = 8 (0), 4, 16, 32, 2 */
     TSQ_KNOB_HOST_OVERLAP = 36,      /* 0: a join fed with host chunks copies every result batch to pinned memory on the context's one stream and waits for it (rounds 1-5); default 1: the D2H copies run on the operator's copy stream beside the staging, H2D and kernels of the next batch, a flush waits for its H2D copies only, and tsq_join_pull answers "no rows yet" while the front batch is still on its way and the probe side is not finished */
     TSQ_KNOB_HOST_NT_COPY = 37,      /* 0: host chunks enter the pinned staging buffers through memcpy instead of non-temporal stores (process-wide) */
+    TSQ_KNOB_KR_WG = 38,             /* workgroups (contiguous row chunks) of the key-record hist / scatter passes, 8..256 (default 256): fewer workgroups keep fewer partition lines open at once (A/B, profiles/r06_keyrec_ab.txt) */
     TSQ_KNOB_COUNT = 48
 };
 tsq_status tsq_ctx_set_knob(tsq_ctx* ctx, int32_t knob, int64_t value);

@@ -165,7 +165,7 @@ KNOB_DEFAULT = -(1 << 63)
 (KNOB_PACKED_KEYS, KNOB_DA_MIN_BUILD_ROWS, KNOB_DA_PBITS, KNOB_PACKED_EMIT_PAIRS, KNOB_RADIX_KERNEL_L2, KNOB_LDS_NF_MAX, KNOB_RADIX_PB_MAX,
  KNOB_TABLE_LF_PERMILLE, KNOB_LDS_PROF, KNOB_DA_TRACE, KNOB_BUILD_IMAGES_CAS, KNOB_DAAGG_SIG, KNOB_DAAGG_LOG2C, KNOB_AGG_HEAP_GC_BYTES,
  KNOB_AGG_TAG_BITS, KNOB_AGG_BATCH_ROWS, KNOB_ROWCODEC_LDS_KB, KNOB_ROWCODEC_FAST_LAYOUT, KNOB_ROWCODEC_PIPELINE, KNOB_DA_PARTITION,
- KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE, KNOB_DA_PAIRS_BELOW_PERMILLE, KNOB_AGG_WIDE_KEYS, KNOB_AGG_DENSE, KNOB_AGG_NARROW_CELLS, KNOB_DAAGG_PART2, KNOB_DAAGG_HOT, KNOB_KEYREC, KNOB_STREAMAGG_LANES, KNOB_XCD_ATOMICS, KNOB_DENSE_DIRECT, KNOB_DA_LDS_BUILD, KNOB_AGG_PG, KNOB_AGG_OVERLAP, KNOB_JIT_VARIANT, KNOB_HOST_OVERLAP, KNOB_HOST_NT_COPY) = range(38)
+ KNOB_DA_NT_LOADS, KNOB_LAZY_TABLE, KNOB_DA_PAIRS_BELOW_PERMILLE, KNOB_AGG_WIDE_KEYS, KNOB_AGG_DENSE, KNOB_AGG_NARROW_CELLS, KNOB_DAAGG_PART2, KNOB_DAAGG_HOT, KNOB_KEYREC, KNOB_STREAMAGG_LANES, KNOB_XCD_ATOMICS, KNOB_DENSE_DIRECT, KNOB_DA_LDS_BUILD, KNOB_AGG_PG, KNOB_AGG_OVERLAP, KNOB_JIT_VARIANT, KNOB_HOST_OVERLAP, KNOB_HOST_NT_COPY, KNOB_KR_WG) = range(39)
 
 
 # every symbol include/tsq.h declares: name -> (restype, argtypes)

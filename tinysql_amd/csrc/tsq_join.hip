@@ -3785,7 +3785,7 @@ tsq_status kr_pass(tsq_join* j, const tsq_colset& cs, const int32_t* key_cols, i
     }
     a.pbits = pbits;
     const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;
-    a.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(TSQ_KR_MAXWG, chunks));
+    a.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(1024, std::max<int64_t>(8, tsq_knob(ctx, TSQ_KNOB_KR_WG, TSQ_KR_MAXWG))), chunks));
     a.rows_per_wg = ((chunks + a.n_wg - 1) / a.n_wg) * TSQ_KR_NT;
     if (list_rows_without_key) {  // the outer side of an outer join: rows with a NULL key cell, cells beyond a record, selected == 0
         TSQ_TRY(j->kr_norec.reserve(ctx, h, (size_t)nrows * 4 + 64));
