@@ -2550,7 +2550,7 @@ tsq_status kd_batch(tsq_agg* a, const tsq_colset& in, int64_t nrows) {
     ka.src.nrows = nrows;
     ka.pbits = a->kd_pbits;
     const int64_t chunks = (nrows + TSQ_KR_NT - 1) / TSQ_KR_NT;
-    ka.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(TSQ_KR_MAXWG, chunks));
+    ka.n_wg = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(1024, std::max<int64_t>(8, tsq_knob(ctx, TSQ_KNOB_KR_WG, TSQ_KR_MAXWG))), chunks));
     ka.rows_per_wg = ((chunks + ka.n_wg - 1) / ka.n_wg) * TSQ_KR_NT;
     TSQ_TRY(a->kd_counts.reserve(ctx, h, (size_t)ka.n_wg * P * 4 + 64));
     TSQ_TRY(a->kd_pstart.reserve(ctx, h, ((size_t)P + 1) * 4 + 64));
