@@ -151,7 +151,7 @@ enum {
     TSQ_KNOB_DA_LDS_BUILD = 32,      /* 0: the materialising packed join never keeps a partition's build rows in LDS (csrc/tsq_damat.h): unique build sides take the sorted-build-columns variant of round 4 like the others; 2 .. 5 (tests): the second partition level splits 1 / 2 / 4 / 8 ways whatever the build side's size */
     TSQ_KNOB_AGG_PG = 33,            /* 0: an aggregate with about as many groups as rows never keeps its groups in partitioned LDS-sized sub-tables (csrc/tsq_aggfast.h K7p): the row upsert serves it; v >= 2 (tests): the mode is taken whatever the estimate, with 2^(v - 2) sub-tables */
     TSQ_KNOB_AGG_OVERLAP = 34,       /* default 0: the packed aggregate with a dense state runs every batch on one stream (partition pass, then k_agg_da); 1: k_agg_da / k_daagg_ovf of a batch run on a side stream beside the partition pass of the next batch (two partitioned stores) for batches of 2^24 rows or more — an A/B that measured SLOWER (C3 7.0 -> 10.1 ms, profiles/r06_ab_measurements.txt); v >= 2 (tests): for batches of v rows or more */
-    TSQ_KNOB_JIT_VARIANT = 35,       /* A/B bits of the hiprtc-specialised projection kernel (jit_expr), default 7 (measured 0.525 -> 0.453 ms per 1e8 rows of (a+b)*3-a against 0, profiles/r06_jit_sweep.txt): 1 = non-temporal loads of the input cells, 2 = non-temporal stores of the result, 4 = whole-wave coalesced 16-byte accesses (a lane takes rows 2 l, 2 l + 1 of each 128-row half of a 256-row step instead of four consecutive rows), 8 = two steps' loads in flight; bits 4-6: workgroups per CU = 8 (0), 4, 16, 32, 2 */
+    TSQ_KNOB_JIT_VARIANT = 35,       /* A/B bits of the hiprtc-specialised projection kernel (jit_expr), default 391 = 7 | 128 | 256 (measured 0.525 -> 0.453 ms per 1e8 rows of (a+b)*3-a against 0, the filter a<b AND c>0.5 0.463 -> 0.429 ms, profiles/r06_jit_sweep.txt): 1 = non-temporal loads of the input cells, 2 = non-temporal stores of the result, 4 = whole-wave coalesced 16-byte accesses (a lane takes rows 2 l, 2 l + 1 of each 128-row half of a 256-row step instead of four consecutive rows), 8 = two steps' loads in flight; bits 4-6: workgroups per CU = 8 (0), 4, 16, 32, 2; 128 = jit_filter reads its 8-byte cells with non-temporal loads, 256 = and writes the selected byte with a non-temporal store */
     TSQ_KNOB_HOST_OVERLAP = 36,      /* bits of the pipelining of a join fed with HOST chunks (default 3; 0 = rounds 1-5: one stream, every result batch copied to pinned memory and waited for): 1 = the D2H copies run on the operator's copy stream beside the staging, H2D and kernels of the next batch, a flush waits for its H2D copies only, and tsq_join_pull answers "no rows yet" while the front batch is still on its way and the probe side is not finished; 2 = the H2D copies of staged probe rows are queued every 256 Ki rows while the caller still pushes (a software prefetch of the next pull's first lines was measured without effect and removed) */
     TSQ_KNOB_HOST_NT_COPY = 37,      /* 0: host chunks enter the pinned staging buffers through memcpy instead of non-temporal stores (process-wide) */
     TSQ_KNOB_KR_WG = 38,             /* workgroups (contiguous row chunks) of the key-record hist / scatter passes, 8..256 (default 256): fewer workgroups keep fewer partition lines open at once (A/B, profiles/r06_keyrec_ab.txt) */

@@ -154,7 +154,7 @@ def test_jit_four_rows_per_lane_and_the_bitmap_written_by_the_kernel(ctx, orc, n
     check_same(ctx, orc, e, chk, jit=abi.JIT_FORCE)  # row n/2 + 3 overflows (unless it is NULL: then the batch passes) — same status either way
 
 
-@pytest.mark.parametrize("variant", [0, 4, 3, 12, 15, 8 | 16, 4 | 64])
+@pytest.mark.parametrize("variant", [0, 4, 3, 7, 12, 15, 8 | 16, 4 | 64])
 @pytest.mark.parametrize("n", [4096, 10_007, 131_073])
 def test_jit_variants_agree_with_the_oracle(ctx, orc, n, variant):
     # TSQ_KNOB_JIT_VARIANT: the A/B forms of jit_expr (non-temporal accesses, the whole-wave coalesced row layout with its own bitmap words,

@@ -264,6 +264,7 @@ TSQ_API tsq_status tsq_expr_compile(tsq_ctx* ctx, const tsq_expr_prog* progs, in
 // stack traffic), i.e. a 7-node expression runs at 6 % of the HBM roofline.  For large inputs the SAME source
 // (tsq.h + tsq_device.h, embedded at build time) is compiled once per handle with the programs as a constant
 // table; the compiler unrolls the node loop and folds every opcode switch, leaving straight-line code.
+#define TSQ_JIT_VARIANT_DEFAULT (7 | 128 | 256)  // coalesced + non-temporal projection, non-temporal filter (profiles/r06_jit_sweep.txt)
 static std::string jit_source(const std::vector<tsq_expr_prog>& progs, int variant) {
     std::ostringstream o;
     o << "#define TSQ_JIT 1\n";
@@ -481,6 +482,23 @@ extern "C" __global__ void __launch_bounds__(256) jit_expr(ExprArgs a) {
     if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[0], (unsigned long long)errw);
     if (div0) atomicAdd(&a.counters[1], (unsigned long long)div0);
 }
+// JIT_VARIANT & 128 (A/B): the filter's 8-byte cells through non-temporal loads (the columns are read once)
+struct tsq_nt_src {
+    const tsq_colset* cs;
+    int64_t row;
+    __device__ tsq_val load_int(int c) const {
+        tsq_val r;
+        r.null = tsq_is_null(cs->nulls[c], row);
+        r.v = __builtin_nontemporal_load((const int64_t*)cs->data[c] + row);
+        return r;
+    }
+    __device__ tsq_val load_real(int c) const {
+        if (cs->type[c] == TSQ_F32) return tsq_cell_real(*cs, c, row);
+        return load_int(c);
+    }
+    __device__ tsq_val load_str(int c, bool* bad) const { tsq_val r; r.v = (int64_t)tsq_cell_str(*cs, c, c, row, &r.null, bad); return r; }
+    __device__ const uint8_t* str_base(uint32_t src) const { return (const uint8_t*)cs->data[src]; }
+};
 extern "C" __global__ void __launch_bounds__(256) jit_filter(ExprArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint64_t errw = TSQ_ERRWORD_NONE;
@@ -489,17 +507,24 @@ extern "C" __global__ void __launch_bounds__(256) jit_filter(ExprArgs a) {
     // failed — loading every column of two rows beforehand, as jit_expr does, measured 0.53 vs 0.47 ms on `a < b AND c > 0.5`, 1e8 rows)
     const int64_t first = 0;
     for (int64_t i = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nrows; i += stride) {
-        tsq_chunk_src src{&a.in, a.sel ? (int64_t)a.sel[i] : i};
         bool selected = false, isnull = false;
         int conj = 0, node = 0, d0 = 0;
-        tsq_status s = tsq_filter_row(P, N_PROGS, src, &selected, &isnull, &conj, &node, &d0);
+        tsq_status s;
+        if (JIT_VARIANT & 128) {
+            tsq_nt_src src{&a.in, a.sel ? (int64_t)a.sel[i] : i};
+            s = tsq_filter_row(P, N_PROGS, src, &selected, &isnull, &conj, &node, &d0);
+        } else {
+            tsq_chunk_src src{&a.in, a.sel ? (int64_t)a.sel[i] : i};
+            s = tsq_filter_row(P, N_PROGS, src, &selected, &isnull, &conj, &node, &d0);
+        }
         div0 += (uint32_t)d0;
         if (s != TSQ_OK) {
             uint64_t w = tsq_errword(conj, node, (uint64_t)i, s);
             errw = w < errw ? w : errw;
             continue;
         }
-        a.out_selected[i] = selected ? 1 : 0;
+        if (JIT_VARIANT & 256) __builtin_nontemporal_store((uint8_t)(selected ? 1 : 0), &a.out_selected[i]);
+        else a.out_selected[i] = selected ? 1 : 0;
         if (a.out_isnull) a.out_isnull[i] = isnull ? 1 : 0;
     }
     if (errw != TSQ_ERRWORD_NONE) atomicMin(&a.counters[0], (unsigned long long)errw);
@@ -555,7 +580,7 @@ static void jit_load(tsq_ctx::JitEntry& out) {
 static bool jit_prepare(tsq_expr* e, bool wait) {
     if (e->jit_tried) return true;
     tsq_ctx* ctx = e->ctx;
-    if (e->jit_src.empty()) e->jit_src = jit_source(e->progs, (int)tsq_knob(ctx, TSQ_KNOB_JIT_VARIANT, 7));
+    if (e->jit_src.empty()) e->jit_src = jit_source(e->progs, (int)tsq_knob(ctx, TSQ_KNOB_JIT_VARIANT, TSQ_JIT_VARIANT_DEFAULT));
     std::lock_guard<std::mutex> g(ctx->jit_mu);
     tsq_ctx::JitEntry& ent = ctx->jit_cache.try_emplace(e->jit_src).first->second;
     int st = ent.state.load(std::memory_order_acquire);
@@ -663,7 +688,7 @@ static tsq_status expr_run(tsq_expr* e, bool filter, const tsq_col* in_cols, int
     int grid = tsq_grid_for(ctx, nrows, 256);
     {
         static const int per_cu[8] = {8, 4, 16, 32, 2, 8, 8, 8};
-        const int gv = ((int)tsq_knob(ctx, TSQ_KNOB_JIT_VARIANT, 7) >> 4) & 7;
+        const int gv = ((int)tsq_knob(ctx, TSQ_KNOB_JIT_VARIANT, TSQ_JIT_VARIANT_DEFAULT) >> 4) & 7;
         if (gv) grid = (int)std::min<int64_t>((nrows + 255) / 256, (int64_t)ctx->num_cus * per_cu[gv]);
     }
     if (!filter) {

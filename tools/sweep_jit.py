@@ -14,7 +14,8 @@ from tools.bench_sides import _dev_col, _spec  # noqa: E402
 
 
 def main():
-    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 15, 16, 32, 48, 64, 4 | 32, 12 | 32, 8 | 32]
+    do_filter = "--filter" in sys.argv
+    variants = [int(v) for v in sys.argv[1:] if v != "--filter"] or [0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 15, 16, 32, 48, 64, 4 | 32, 12 | 32, 8 | 32]
     n = 100_000_000
     ctx = _lib.Context(0)
     lib = ctx.lib
@@ -28,6 +29,36 @@ def main():
     ctx.d2h(hb, b)
     want = (ha + hb) * 3 - ha
     cols = (abi.Col * 2)(_dev_col(abi, a, n), _dev_col(abi, b, n))
+    if do_filter:  # a < b AND c > 0.5 (jit_filter; bits 128 / 256 of the variant: non-temporal loads / store)
+        c, sel = ctx.alloc(n * 8), ctx.alloc(n + 64)
+        ctx.gen_column(_spec(abi, abi.GEN_RAND_F64, table=5, col=2), n, c)
+        ctx.sync()
+        hc = np.empty(n, np.float64)
+        ctx.d2h(hc, c)
+        wantf = (ha < hb) & (hc > 0.5)
+        cols3 = (abi.Col * 3)(_dev_col(abi, a, n), _dev_col(abi, b, n), _dev_col(abi, c, n, abi.F64))
+        f = [E.ScalarFunction("lt", E.Column(0, abi.I64), E.Column(1, abi.I64)), E.ScalarFunction("gt", E.Column(2, abi.F64), E.Constant(0.5))]
+        wf = C.c_int64(0)
+        for v in variants:
+            ctx.set_knob(abi.KNOB_JIT_VARIANT, v)
+            cf = E.CompiledExpr(ctx, f, jit=abi.JIT_FORCE)
+            try:
+                fn = lambda: _lib.check(lib.tsq_filter_eval(cf.h, cols3, 3, n, None, sel, None, C.byref(wf)), cf.h)  # noqa: E731
+                fn()
+                ts = []
+                for _ in range(7):
+                    ctx.timer_start()
+                    fn()
+                    ts.append(ctx.timer_stop_ms())
+                hs = np.empty(n, np.uint8)
+                ctx.d2h(hs, sel)
+                print(json.dumps({"filter_variant": v, "ms_min": round(min(ts), 4), "ms_med": round(sorted(ts)[3], 4), "frac": round(25.0 * n / min(ts) / 1e6 / 8000.0, 4),
+                                  "ok": bool((hs.astype(bool) == wantf).all())}), flush=True)
+                ctx.memset(sel, 0, n)
+            finally:
+                cf.close()
+        ctx.set_knob(abi.KNOB_JIT_VARIANT)
+        return
     e1 = E.ScalarFunction("minus", E.ScalarFunction("mul", E.ScalarFunction("plus", E.Column(0, abi.I64), E.Column(1, abi.I64)), E.Constant(3)), E.Column(0, abi.I64))
     w = C.c_int64(0)
     for v in variants:
