@@ -996,7 +996,7 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
             size_t bytes = type == TSQ_BYTES ? (size_t)rb->nbytes[oc] : (size_t)out_rows * tsq_elem_size(type);
             tsq_status s = rb->hdata[oc].reserve(&j->hdr, bytes + 16);
             if (s == TSQ_OK && type == TSQ_BYTES) s = rb->hoffs[oc].reserve(&j->hdr, ((size_t)out_rows + 1) * 8 + 16);
-            if (s != TSQ_OK) { rb->release(); return s; }
+            if (s != TSQ_OK) { if (overlap) (void)hipStreamSynchronize(cs); rb->release(); return s; }  // (copies of earlier columns may be on their way into the buffers being handed back)
             if (bytes) TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hdata[oc].p, rb->data[oc].p, bytes, hipMemcpyDeviceToHost, cs));
             if (type == TSQ_BYTES) {
                 TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hoffs[oc].p, rb->offs[oc].p, ((size_t)out_rows + 1) * 8, hipMemcpyDeviceToHost, cs));
@@ -1005,7 +1005,7 @@ tsq_status deliver_batch(tsq_join* j, std::unique_ptr<ResultBatch> rb, const std
             j->st.d2h_bytes += bytes;
             if (may_null_v[oc]) {
                 s = rb->hbitmap[oc].reserve(&j->hdr, tsq_bitmap_bytes(out_rows) + 16);
-                if (s != TSQ_OK) { rb->release(); return s; }
+                if (s != TSQ_OK) { if (overlap) (void)hipStreamSynchronize(cs); rb->release(); return s; }  // (copies of earlier columns may be on their way into the buffers being handed back)
                 TSQ_HIP(&j->hdr, hipMemcpyAsync(rb->hbitmap[oc].p, rb->bitmap[oc].p, tsq_bitmap_bytes(out_rows), hipMemcpyDeviceToHost, cs));
             }
         }
