@@ -653,6 +653,8 @@ def compact_line(full, limit=LINE_LIMIT):
         if ("verified" in v or "error" in v or "ms" in v or "build_ms_warm" in v) and not (subs and "ms" not in v and "ms_per_probe_pass" not in v):
             sides[k] = _side_entry(v)
         for kk, vv in subs.items():
+            if "borrowed_pulls" in kk:  # (a variant of the boundary measurement that measured equal: in the extras file, not in the line)
+                continue
             sides["%s.%s" % (k, kk)] = _side_entry(vv)
     if sides:
         line["sides"] = sides
