@@ -15,9 +15,12 @@ from tools.bench_sides import _dev_col, _spec  # noqa: E402
 
 def main():
     do_filter = "--filter" in sys.argv
-    variants = [int(v) for v in sys.argv[1:] if v != "--filter"] or [0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 15, 16, 32, 48, 64, 4 | 32, 12 | 32, 8 | 32]
+    do_arena = "--arena" in sys.argv  # tsq_ctx_reserve(64 GB) first, as bench.py does: the columns then come out of the context's slab
+    variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 15, 16, 32, 48, 64, 4 | 32, 12 | 32, 8 | 32]
     n = 100_000_000
     ctx = _lib.Context(0)
+    if do_arena:
+        ctx.reserve(64 << 30)
     lib = ctx.lib
     a, b, out = (ctx.alloc(n * 8) for _ in range(3))
     bm = ctx.alloc(n // 8 + 64)
