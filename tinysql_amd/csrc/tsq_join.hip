@@ -1542,7 +1542,6 @@ tsq_status da_prepare(tsq_join* j, tsq_comm* sc = nullptr, tsq_status pre_status
             cs.nnmask = l1_nulls ? nnm.as<uint8_t>() : nullptr;
             DaColSrc src;
             memset(&src, 0, sizeof src);
-            src.ntl = (tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) & 2) ? 1 : 0;
             src.key = ma.src;
             src.n_cols = l1_n;
             src.any_nulls = l1_nulls ? 1 : 0;
@@ -2289,7 +2288,6 @@ tsq_status da_prepare_cols_direct(tsq_join* j) {
     cs.nnmask = any_nulls ? nnm.as<uint8_t>() : nullptr;
     DaColSrc src;
     memset(&src, 0, sizeof src);
-    src.ntl = (tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) & 2) ? 1 : 0;
     da_build_key(j, src.key);
     src.n_cols = ncols;
     src.any_nulls = any_nulls ? 1 : 0;
@@ -2718,7 +2716,6 @@ tsq_status da_emit_cols(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool*
     TSQ_HIP(h, hipMemsetAsync(ctx->dscratch + 52, 0, 16, ctx->stream));
     DaColSrc src;
     memset(&src, 0, sizeof src);
-    src.ntl = (tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) & 2) ? 1 : 0;
     TSQ_TRY(da_probe_key(j, pcs, nrows, src.key, sel));
     src.n_cols = ntrav;
     src.any_nulls = any_nulls ? 1 : 0;
@@ -3080,7 +3077,6 @@ tsq_status dm_prepare_build(tsq_join* j) {
     cs.nnmask = any_nulls ? nnm.as<uint8_t>() : nullptr;
     DaColSrc src;
     memset(&src, 0, sizeof src);
-    src.ntl = (tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) & 2) ? 1 : 0;
     da_build_key(j, src.key);
     src.n_cols = ncols;
     src.any_nulls = any_nulls ? 1 : 0;
@@ -3213,7 +3209,6 @@ tsq_status dm_emit_batch(tsq_join* j, const tsq_colset& pcs, int64_t nrows, bool
     TSQ_HIP(h, hipMemsetAsync(p2.cnt + Q, 0, 8, ctx->stream));
     DaColSrc src;
     memset(&src, 0, sizeof src);
-    src.ntl = (tsq_knob(j->ctx, TSQ_KNOB_DA_NT_LOADS, 1) & 2) ? 1 : 0;
     TSQ_TRY(da_probe_key(j, pcs, nrows, src.key, sel));
     src.n_cols = ntrav;
     src.any_nulls = any_nulls ? 1 : 0;
