@@ -207,3 +207,25 @@ def test_jit_auto_compiles_on_a_helper_thread_and_never_blocks(ctx, orc):
         assert ce.jit_compile_ms() > 1.0
     finally:
         ce.close()
+
+
+def test_a_process_may_end_while_the_helper_thread_still_compiles():
+    # a short script: one AUTO evaluation of 300 000 rows starts the background hiprtc compile, then the process ends without closing
+    # anything — the library's atexit hook waits for the compile (hiprtc's teardown under a running compile would crash the exit)
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np\n"
+        "from tinysql_amd import _abi as abi, _lib, expression as E\n"
+        "from tinysql_amd.chunk import Chunk, Column\n"
+        "ctx = _lib.Context(0)\n"
+        "n = 300000\n"
+        "chk = Chunk([Column(abi.I64, np.arange(n)), Column(abi.I64, np.arange(n))])\n"
+        "ce = E.CompiledExpr(ctx, [E.ScalarFunction('plus', E.Column(0, abi.I64), E.Column(1, abi.I64))])\n"
+        "got = ce.VecEval(chk)\n"
+        "assert (got.data == 2 * np.arange(n)).all()\n"
+        "print('evaluated', flush=True)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "evaluated" in r.stdout, (r.returncode, r.stdout[-200:], r.stderr[-400:])

@@ -592,9 +592,21 @@ static bool jit_prepare(tsq_expr* e, bool wait) {
             ent.state.store(1, std::memory_order_release);
             const std::string arch = ctx->prop.gcnArchName;
             const std::string* src = &ctx->jit_cache.find(e->jit_src)->first;  // (the map's own copy: nodes of an unordered_map never move)
+            // a process that ends while a compile is still running (a short script that never destroys its context) waits for it first:
+            // hiprtc's own teardown must not start under a running compile.  Handlers registered later run earlier, so this one runs
+            // before the destructors of the libraries loaded at start-up.
+            static std::atomic<int> workers{0};
+            static std::once_flag at_exit_once;
+            std::call_once(at_exit_once, [] {
+                std::atexit([] {
+                    for (int i = 0; i < 20000 && workers.load(std::memory_order_acquire) > 0; i++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                });
+            });
+            workers.fetch_add(1, std::memory_order_acq_rel);
             ent.worker = std::thread([arch, src, &ent]() {
                 jit_compile_code(arch, *src, ent);
                 ent.state.store(2, std::memory_order_release);
+                workers.fetch_sub(1, std::memory_order_acq_rel);
             });
             return false;
         }
