@@ -28,7 +28,8 @@ def pmc(paths, by_grid=False):
         print("== rocprofv3 --pmc : %s" % path)
         print("%-110s %-24s %6s %16s" % ("kernel", "counter", "calls", "avg_value"))
         for (k, c), d in acc.items():
-            print("%-110s %-24s %6d %16.1f" % (k[:110], c, len(d), sum(d.values()) / len(d)))
+            kk = k if len(k) <= 110 else k[:110 - len(k[k.rindex(" [grid"):])] + k[k.rindex(" [grid"):]  # (a long name keeps its "[grid N]")
+            print("%-110s %-24s %6d %16.1f" % (kk, c, len(d), sum(d.values()) / len(d)))
         print()
 
 
