@@ -365,3 +365,28 @@ def test_host_pull_borrows_the_pinned_result_batch(ctx, orc):
         assert H.rows_equal_unordered(out, want)
     finally:
         lib.tsq_join_destroy(h)
+
+
+def test_outer_join_conditions_over_a_hot_build_key(ctx, orc):
+    # k_outer_segments walked an outer row's whole candidate segment with one lane.  A build key with 20 000 duplicates (the
+    # packed route hands such a side back at 256): outer rows of that key whose condition passes for exactly one candidate — the first, one
+    # in the middle, the very last — or for none (the padded row), next to ordinary short segments.  Lengths around the 32-row hand-over
+    # to the wave and around its 64-row steps too.
+    rng = np.random.default_rng(71)
+    t = [abi.I64, abi.I64]
+    for dup in (20_000, 31, 32, 33, 95, 96, 97, 160):
+        bk = np.concatenate([np.full(dup, 7, np.int64), rng.integers(100, 400, 3000)])
+        bv = np.concatenate([np.arange(dup, dtype=np.int64), rng.integers(0, 50, 3000)])
+        right = Chunk([Column(abi.I64, bk), Column(abi.I64, bv)])
+        # l.v + r.v == dup - 1 ... for key 7: l.v = dup - 1 matches r.v = 0 (first), l.v = 0 matches r.v = dup - 1 (last), l.v = -5 matches none
+        lk = np.concatenate([np.full(6, 7, np.int64), rng.integers(100, 400, 2000)])
+        lv = np.concatenate([np.array([dup - 1, 0, dup // 2, -5, dup + 7, 1], np.int64), rng.integers(0, 50, 2000)])
+        perm = rng.permutation(len(lk))
+        left = Chunk([Column(abi.I64, lk[perm]), Column(abi.I64, lv[perm])])
+        keep = []
+        conds = [E.ScalarFunction("eq", E.ScalarFunction("plus", E.Column(1, abi.I64), E.Column(3, abi.I64)), E.Constant(dup - 1))]
+        for jt in (abi.JOIN_LEFT_OUTER, abi.JOIN_INNER):
+            cfg = H.join_cfg(t, t, [0], [0], jt, 1, conds, (), keep)
+            want = orc.hash_join(cfg, right, left)
+            got = G.run_join(ctx, cfg, right, left)
+            assert H.rows_equal_unordered(got, want), (dup, jt)

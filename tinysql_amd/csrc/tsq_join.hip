@@ -2522,13 +2522,40 @@ __global__ void __launch_bounds__(256) k_outer_unmatch(OuterUnmatchArgs a) {
 // outer join, build side with duplicate keys: the candidates of an outer row are consecutive rows of the batch, head[] marks the first
 // of each.  An outer row none of whose candidates passed the conditions keeps its first row, padded (keep = 2): onMissMatch after
 // tryToMatch found nothing (joiner.go:252-281)
+// A lane walks the first 32 candidates of its outer row itself; a longer segment (a hot build key: 1e5 duplicates walked by one lane while
+// the grid idles — ADVICE r5) is then scanned by the whole wave, 64 candidates per step.
 __global__ void __launch_bounds__(256) k_outer_segments(uint8_t* keep, const uint8_t* head, const uint8_t* matched, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        if (!head[i] || tsq_is_null(matched, i)) continue;  // (a padded row is a segment of its own and stays)
-        bool any = false;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t base = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); base < n; base += stride) {  // (wave-uniform: every lane stays in the loop)
+        const int64_t i = base + lane;
+        const bool mine = i < n && head[i] && !tsq_is_null(matched, i);  // (a padded row is a segment of its own and stays)
+        bool any = false, open = false;
         int64_t k = i;
-        do { any = keep[k] != 0; k++; } while (!any && k < n && !head[k]);  // (stops at the first candidate that passed; the packed route's segments hold <= 255 rows)
-        if (!any) keep[i] = 2;
+        if (mine) {
+            int steps = 0;
+            do { any = keep[k] != 0; k++; steps++; } while (!any && k < n && !head[k] && steps < 32);  // (stops at the first candidate that passed)
+            open = !any && k < n && !head[k];
+        }
+        for (uint64_t todo = __ballot(open); todo; todo &= todo - 1) {  // the long segments of this wave's rows, one after the other
+            const int l = __ffsll((unsigned long long)todo) - 1;
+            int64_t k0 = __shfl(k, l, 64);
+            bool found = false;
+            for (;;) {
+                const int64_t kk = k0 + lane;
+                const bool in = kk < n;
+                const bool hd = in && head[kk];
+                const bool kp = in && keep[kk] != 0;
+                const uint64_t mh = __ballot(hd || !in), mk = __ballot(kp);
+                // candidates of the segment = the lanes before the first head (or the end of the batch)
+                const uint64_t before = mh ? ((mh & (0 - mh)) - 1) : ~0ull;
+                if (mk & before) { found = true; break; }
+                if (mh) break;
+                k0 += 64;
+            }
+            if ((int)lane == l) any = found;
+        }
+        if (mine && !any) keep[i] = 2;
     }
 }
 // filters the batch in place (new, dense column buffers).  *redo: a condition raised an error — which error the reference reports
